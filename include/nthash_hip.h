@@ -1,0 +1,146 @@
+/*
+ * include/nthash_hip.h -- the C-ABI of nthash_amd (libnthash_hip.so).
+ *
+ * This is the drop-in boundary for the ntHash batch hot path on MI355X
+ * (gfx950): plain C, plain pointers and sizes, `int` status codes, no C++ or
+ * torch types.  The reference (bcgsc/ntHash 2.4.0) has no FFI layer of its
+ * own: its boundary is the C++ iterator API of include/nthash/nthash.hpp.
+ * Each entry point below names the reference interface whose per-read
+ * `while (h.roll()) use(h.hashes())` loop it replaces for a whole batch.  The
+ * C++ classes in include/nthash/nthash.hpp (this repo) are implemented on top
+ * of this ABI; INTEGRATION.md shows the binding a maintainer of the reference
+ * would add.
+ *
+ * Conventions
+ *   - every function returns NTHIP_OK (0) or a negative NTHIP_ERR_* code;
+ *     nthip_last_error() returns a thread-local message for the last failure.
+ *     Nothing throws, nothing calls exit().
+ *   - there is NO CPU fallback: without a usable HIP device every entry point
+ *     that touches the device fails with NTHIP_ERR_NODEVICE / NTHIP_ERR_HIP.
+ *   - pointers are DEVICE pointers unless the NTHIP_HOST_* flag for that side
+ *     is given, in which case the library stages through device memory.
+ *   - output order is the reference's: read-major, then emitted position
+ *     ascending, then the hash index (NtHash: m values; SeedNtHash: seed-major
+ *     n_seeds*m2 values, src/seed.cpp:167-172).
+ */
+#ifndef NTHASH_HIP_H
+#define NTHASH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTHIP_OK 0
+#define NTHIP_ERR_ARG (-1)         /* invalid argument (what the reference raise_error()s on) */
+#define NTHIP_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define NTHIP_ERR_NODEVICE (-3)    /* no usable gfx950 device */
+#define NTHIP_ERR_CAPACITY (-4)    /* out.capacity too small; *total holds the need */
+#define NTHIP_ERR_UNSUPPORTED (-5) /* outside the supported domain (e.g. k < 3) */
+
+/* flags */
+#define NTHIP_HOST_INPUT 0x1u   /* reads.seqs / reads.offsets are host memory */
+#define NTHIP_HOST_OUTPUT 0x2u  /* every non-NULL pointer in nthip_out is host memory */
+#define NTHIP_FORCE_GENERAL 0x4u /* skip the fixed-length fast kernels (testing / A-B) */
+
+typedef struct nthip_ctx nthip_ctx;     /* one device + one stream + scratch */
+typedef struct nthip_seeds nthip_seeds; /* parsed spaced-seed set (device tables) */
+
+/* A batch of reads: the `const char* seq, size_t seq_len` pair of
+ * NtHash::NtHash (include/nthash/nthash.hpp:74-78), once per read. */
+typedef struct {
+  const char* seqs;        /* concatenated ASCII bases, no separators */
+  const uint64_t* offsets; /* n_reads+1 byte offsets into seqs; NULL if fixed_len != 0 */
+  uint64_t n_reads;
+  uint32_t fixed_len;      /* != 0: read r is seqs[r*stride, r*stride + fixed_len) */
+  uint32_t stride;         /* bytes between read starts; 0 means fixed_len.  stride <
+                              fixed_len describes overlapping runs of ONE long sequence:
+                              stride = R, fixed_len = R + k - 1 hashes R windows per run */
+} nthip_reads;
+
+/* Where the hash stream goes.  Replaces NtHash::hashes() / get_pos() /
+ * get_forward_hash() / get_reverse_hash() (nthash.hpp:163-194) for every
+ * emitted k-mer of the batch. */
+typedef struct {
+  uint64_t* hashes;  /* required: capacity * hashes_per_kmer values */
+  uint64_t capacity; /* in k-mers */
+  uint64_t* counts;  /* optional: n_reads values, emitted k-mers per read */
+  uint32_t* pos;     /* optional: capacity values, get_pos() of each emitted k-mer */
+  uint64_t* fwd;     /* optional (k-mer hashing only): capacity values */
+  uint64_t* rev;     /* optional (k-mer hashing only): capacity values */
+} nthip_out;
+
+/* ---- library / context -------------------------------------------------- */
+const char* nthip_version(void);
+const char* nthip_last_error(void);
+int nthip_device_count(int* count);
+int nthip_ctx_create(int device, nthip_ctx** ctx);
+int nthip_ctx_destroy(nthip_ctx* ctx);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL
+ * restores the context's own stream */
+int nthip_ctx_set_stream(nthip_ctx* ctx, void* hip_stream);
+int nthip_ctx_synchronize(nthip_ctx* ctx);
+/* when on, every hash call brackets its dominant kernel with HIP events on the
+ * launch stream; nthip_last_kernel_ms reads the last bracket (synchronises) */
+int nthip_ctx_set_profiling(nthip_ctx* ctx, int on);
+int nthip_last_kernel_ms(nthip_ctx* ctx, float* ms, const char** kernel_name);
+
+/* ---- device memory helpers (for callers without their own allocator) ---- */
+int nthip_malloc(nthip_ctx* ctx, size_t bytes, void** dptr);
+int nthip_free(nthip_ctx* ctx, void* dptr);
+int nthip_memcpy_h2d(nthip_ctx* ctx, void* dst, const void* src, size_t bytes);
+int nthip_memcpy_d2h(nthip_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+/* ---- the hot path -------------------------------------------------------- */
+/*
+ * nthip_kmer_hash: for every read r, what
+ *     nthash::NtHash h(seq_r, len_r, m, k);            // src/kmer.cpp:200-226
+ *     while (h.roll()) emit(h.hashes()[0..m));          // src/kmer.cpp:246-264
+ * produces, i.e. the m canonical hashes (src/internal.hpp:104-118) of every
+ * window whose k characters are all in ACGTUacgtu, in position order.  Reads
+ * shorter than k emit nothing (the iterator would raise_error,
+ * src/kmer.cpp:215-219).  *total = number of k-mers emitted.
+ * Supported domain: 3 <= k <= 65535 (the reference is undefined for k < 3,
+ * SURVEY.md App. B Q7), 1 <= m <= 255.
+ */
+int nthip_kmer_hash(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint8_t m,
+                    const nthip_out* out, uint64_t* total, uint32_t flags);
+
+/*
+ * Spaced seeds.  nthip_seeds_create does once what every SeedNtHash constructor
+ * redoes per object (check_seeds + get_blocks, src/seed.cpp:19-104, 466-470).
+ * *asymmetric (optional) is set if any seed is not a palindrome, the condition
+ * the reference warns about (src/seed.cpp:96-102).
+ */
+int nthip_seeds_create(nthip_ctx* ctx, const char* const* seeds, uint32_t n_seeds, uint16_t k,
+                       nthip_seeds** out, int* asymmetric);
+int nthip_seeds_destroy(nthip_seeds* seeds);
+/*
+ * nthip_seed_hash: for every read r, what
+ *     nthash::SeedNtHash h(seq_r, len_r, seeds, m2, k); // src/seed.cpp:449-471
+ *     while (h.roll()) emit(h.hashes()[0..n_seeds*m2)); // src/seed.cpp:518-544
+ * produces, including the reference's position state machine on reads with
+ * non-ACGTU characters.  out->fwd / out->rev must be NULL.
+ */
+int nthip_seed_hash(nthip_ctx* ctx, const nthip_reads* reads, const nthip_seeds* seeds,
+                    uint8_t m2, const nthip_out* out, uint64_t* total, uint32_t flags);
+
+/* ---- measurement helpers (device-resident synthetic data, checksums) ---- */
+/* counter-based reads: read r, 32-base word w ->
+ * splitmix64(seed + r*W + w), 2 bits per base, "ACGT"[..]; writes
+ * n_reads*len bytes at d_dst */
+int nthip_synth_reads(nthip_ctx* ctx, char* d_dst, uint64_t first_read, uint64_t n_reads,
+                      uint32_t len, uint64_t seed);
+/* wrapping sum and XOR of n device-resident u64 values */
+int nthip_checksum(nthip_ctx* ctx, const uint64_t* d_vals, uint64_t n, uint64_t* sum,
+                   uint64_t* xr);
+/* device-to-device copy rate (the achievable-HBM yardstick next to the 8 TB/s spec) */
+int nthip_copy_bench(nthip_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int reps,
+                     float* best_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTHASH_HIP_H */

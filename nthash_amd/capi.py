@@ -1,0 +1,279 @@
+"""ctypes binding of the nthash_amd C-ABI (include/nthash_hip.h).
+
+This is plumbing for the tests and bench.py: it loads nthash_amd/lib/libnthash_hip.so,
+declares every symbol of the header, and offers thin numpy/torch-pointer
+helpers.  It contains no hashing logic and no CPU fallback: if the shared
+library is missing it raises, and if there is no HIP device every call that
+touches the device returns NTHIP_ERR_NODEVICE, which is raised as NtHipError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnthash_hip.so")
+
+NTHIP_OK = 0
+NTHIP_ERR_ARG = -1
+NTHIP_ERR_HIP = -2
+NTHIP_ERR_NODEVICE = -3
+NTHIP_ERR_CAPACITY = -4
+NTHIP_ERR_UNSUPPORTED = -5
+NTHIP_HOST_INPUT = 0x1
+NTHIP_HOST_OUTPUT = 0x2
+NTHIP_FORCE_GENERAL = 0x4
+
+# every exported symbol of include/nthash_hip.h (kept in sync by tests/test_abi.py)
+SYMBOLS = [
+    "nthip_version", "nthip_last_error", "nthip_device_count", "nthip_ctx_create",
+    "nthip_ctx_destroy", "nthip_ctx_set_stream", "nthip_ctx_synchronize",
+    "nthip_ctx_set_profiling", "nthip_last_kernel_ms", "nthip_malloc", "nthip_free",
+    "nthip_memcpy_h2d", "nthip_memcpy_d2h", "nthip_kmer_hash", "nthip_seeds_create",
+    "nthip_seeds_destroy", "nthip_seed_hash", "nthip_synth_reads", "nthip_checksum",
+    "nthip_copy_bench",
+]
+
+
+class NtHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"nthip error {code}: {msg}")
+        self.code = code
+
+
+class Reads(C.Structure):
+    _fields_ = [("seqs", C.c_void_p), ("offsets", C.c_void_p), ("n_reads", C.c_uint64),
+                ("fixed_len", C.c_uint32), ("stride", C.c_uint32)]
+
+
+class Out(C.Structure):
+    _fields_ = [("hashes", C.c_void_p), ("capacity", C.c_uint64), ("counts", C.c_void_p),
+                ("pos", C.c_void_p), ("fwd", C.c_void_p), ("rev", C.c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the C-ABI library; loud failure if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m nthash_amd.build` "
+            "(nthash_amd has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.nthip_version.restype = C.c_char_p
+    L.nthip_last_error.restype = C.c_char_p
+    L.nthip_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.nthip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.nthip_ctx_destroy.argtypes = [vp]
+    L.nthip_ctx_set_stream.argtypes = [vp, vp]
+    L.nthip_ctx_synchronize.argtypes = [vp]
+    L.nthip_ctx_set_profiling.argtypes = [vp, C.c_int]
+    L.nthip_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p)]
+    L.nthip_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.nthip_free.argtypes = [vp, vp]
+    L.nthip_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.nthip_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.nthip_kmer_hash.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, C.POINTER(Out),
+                                  C.POINTER(u64), u32]
+    L.nthip_seeds_create.argtypes = [vp, C.POINTER(C.c_char_p), u32, C.c_uint16, C.POINTER(vp),
+                                     C.POINTER(C.c_int)]
+    L.nthip_seeds_destroy.argtypes = [vp]
+    L.nthip_seed_hash.argtypes = [vp, C.POINTER(Reads), vp, C.c_uint8, C.POINTER(Out),
+                                  C.POINTER(u64), u32]
+    L.nthip_synth_reads.argtypes = [vp, vp, u64, u64, u32, u64]
+    L.nthip_checksum.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.nthip_copy_bench.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("nthip_version", "nthip_last_error"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != NTHIP_OK:
+        raise NtHipError(rc, load().nthip_last_error().decode(errors="replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().nthip_device_count(C.byref(n))
+    return n.value if rc == NTHIP_OK else 0
+
+
+class Seeds:
+    def __init__(self, ctx, seeds, k):
+        self.ctx = ctx
+        self.strings = [s.encode() if isinstance(s, str) else bytes(s) for s in seeds]
+        arr = (C.c_char_p * len(self.strings))(*self.strings)
+        h = C.c_void_p()
+        asym = C.c_int(0)
+        _chk(load().nthip_seeds_create(ctx.h, arr, len(self.strings), k, C.byref(h), C.byref(asym)))
+        self.h = h
+        self.asymmetric = bool(asym.value)
+        self.n = len(self.strings)
+        self.k = k
+
+    def close(self):
+        if self.h:
+            load().nthip_seeds_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One device + one stream.  Raises NtHipError(NTHIP_ERR_NODEVICE) without a GPU."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        _chk(self.L.nthip_ctx_create(device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.nthip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- raw pointer API (device pointers as ints; e.g. torch tensor.data_ptr()) --
+    def set_stream(self, stream_ptr):
+        _chk(self.L.nthip_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        _chk(self.L.nthip_ctx_synchronize(self.h))
+
+    def set_profiling(self, on=True):
+        _chk(self.L.nthip_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        name = C.c_char_p()
+        _chk(self.L.nthip_last_kernel_ms(self.h, C.byref(ms), C.byref(name)))
+        return ms.value, (name.value or b"").decode()
+
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        _chk(self.L.nthip_malloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        _chk(self.L.nthip_free(self.h, C.c_void_p(ptr)))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        _chk(self.L.nthip_memcpy_h2d(self.h, C.c_void_p(dptr), arr.ctypes.data, arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        _chk(self.L.nthip_memcpy_d2h(self.h, arr.ctypes.data, C.c_void_p(dptr), arr.nbytes))
+
+    def kmer_hash_ptr(self, seqs, offsets, n_reads, fixed_len, stride, k, m, hashes, capacity,
+                      counts=0, pos=0, fwd=0, rev=0, flags=0):
+        rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
+        out = Out(hashes, capacity, counts or None, pos or None, fwd or None, rev or None)
+        total = C.c_uint64(0)
+        rc = self.L.nthip_kmer_hash(self.h, C.byref(rd), k, m, C.byref(out), C.byref(total), flags)
+        if rc != NTHIP_OK:
+            err = NtHipError(rc, self.L.nthip_last_error().decode(errors="replace"))
+            err.total = total.value
+            raise err
+        return total.value
+
+    def seed_hash_ptr(self, seqs, offsets, n_reads, fixed_len, stride, seeds, m2, hashes, capacity,
+                      counts=0, pos=0, flags=0):
+        rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
+        out = Out(hashes, capacity, counts or None, pos or None, None, None)
+        total = C.c_uint64(0)
+        rc = self.L.nthip_seed_hash(self.h, C.byref(rd), seeds.h, m2, C.byref(out), C.byref(total), flags)
+        if rc != NTHIP_OK:
+            err = NtHipError(rc, self.L.nthip_last_error().decode(errors="replace"))
+            err.total = total.value
+            raise err
+        return total.value
+
+    def synth_reads_ptr(self, dptr, first_read, n_reads, length, seed=42):
+        _chk(self.L.nthip_synth_reads(self.h, C.c_void_p(dptr), first_read, n_reads, length, seed))
+
+    def checksum_ptr(self, dptr, n):
+        s, x = C.c_uint64(0), C.c_uint64(0)
+        _chk(self.L.nthip_checksum(self.h, C.c_void_p(dptr), n, C.byref(s), C.byref(x)))
+        return s.value, x.value
+
+    def copy_bench_ptr(self, dst, src, nbytes, reps=5):
+        ms = C.c_float(0)
+        _chk(self.L.nthip_copy_bench(self.h, C.c_void_p(dst), C.c_void_p(src), nbytes, reps, C.byref(ms)))
+        return ms.value
+
+    # -- numpy convenience (host buffers, staged by the library) ------------------
+    @staticmethod
+    def _cap(offsets, fixed_len, stride, n_reads, k):
+        if offsets is not None:
+            lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+            return int(np.maximum(lens - k + 1, 0).sum())
+        return int(n_reads * max(fixed_len - k + 1, 0))
+
+    def kmer_hash(self, data, k, m, offsets=None, fixed_len=0, stride=0, n_reads=None,
+                  want_pos=False, want_strands=False, want_counts=True, flags=0):
+        """Hash host reads (staged by the library); returns a dict of numpy arrays."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            n_reads = len(offsets) - 1
+        cap = max(self._cap(offsets, fixed_len, stride, n_reads, k), 1)
+        hashes = np.zeros(cap * m, np.uint64)
+        counts = np.zeros(max(n_reads, 1), np.uint64) if want_counts else None
+        pos = np.zeros(cap, np.uint32) if want_pos else None
+        fwd = np.zeros(cap, np.uint64) if want_strands else None
+        rev = np.zeros(cap, np.uint64) if want_strands else None
+        p = lambda a: a.ctypes.data if a is not None else 0
+        total = self.kmer_hash_ptr(p(data), p(offsets), n_reads, fixed_len, stride, k, m, p(hashes), cap,
+                                   p(counts), p(pos), p(fwd), p(rev),
+                                   flags | NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT)
+        out = {"total": total, "hashes": hashes[: total * m].reshape(total, m)}
+        if want_counts:
+            out["counts"] = counts[:n_reads]
+        if want_pos:
+            out["pos"] = pos[:total]
+        if want_strands:
+            out["fwd"] = fwd[:total]
+            out["rev"] = rev[:total]
+        return out
+
+    def seed_hash(self, data, seeds, k, m2, offsets=None, fixed_len=0, stride=0, n_reads=None,
+                  want_pos=False, want_counts=True, flags=0):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            n_reads = len(offsets) - 1
+        sd = seeds if isinstance(seeds, Seeds) else Seeds(self, seeds, k)
+        per = sd.n * m2
+        cap = max(self._cap(offsets, fixed_len, stride, n_reads, k), 1)
+        hashes = np.zeros(cap * per, np.uint64)
+        counts = np.zeros(max(n_reads, 1), np.uint64) if want_counts else None
+        pos = np.zeros(cap, np.uint32) if want_pos else None
+        p = lambda a: a.ctypes.data if a is not None else 0
+        total = self.seed_hash_ptr(p(data), p(offsets), n_reads, fixed_len, stride, sd, m2, p(hashes), cap,
+                                   p(counts), p(pos), flags | NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT)
+        out = {"total": total, "hashes": hashes[: total * per].reshape(total, per)}
+        if want_counts:
+            out["counts"] = counts[:n_reads]
+        if want_pos:
+            out["pos"] = pos[:total]
+        return out

@@ -1,0 +1,352 @@
+// kmer_kernels.hpp -- CDNA4 (gfx950) kernels for contiguous k-mer hashing.
+//
+// Replaces, for a whole batch of reads, the reference's per-read loop
+//     NtHash h(seq, len, m, k); while (h.roll()) use(h.hashes());
+// (src/kmer.cpp:200-264): next_forward_hash / next_reverse_hash
+// (src/kmer.cpp:84-94, 164-174), canonical() and extend_hashes()
+// (src/internal.hpp:24-29, 104-118).
+//
+// Two kernels:
+//   kmer_fixed_kernel   the hot path.  Fixed-length reads (optionally
+//                       overlapping runs of one long sequence via `stride`),
+//                       one lane rolls one run, state in VGPRs; ASCII is
+//                       staged through LDS as a 2-bit stream, the hash stream
+//                       leaves through an XOR-swizzled LDS tile so that every
+//                       global store is a 16-byte piece of a 128-byte row.
+//   kmer_general_kernel the N-aware path for ragged / dirty batches: one lane
+//                       per read, exact reference emission order, compact
+//                       output through per-read offsets.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "nt_math.hpp"
+
+namespace ntamd {
+
+constexpr int KF_THREADS = 256;              // 4 wavefronts
+constexpr int KF_RUNS_PER_BLOCK = 256;       // one run (read) per lane
+constexpr int KF_ROW_U64 = 16;               // tile row = 16 hashes = 128 B
+constexpr int KF_TILE_U64 = 64 * KF_ROW_U64; // per-wave tile (8 KiB)
+constexpr int KF_MAX_RUNTIME_M = 8;
+
+struct KmerFixedArgs {
+  const uint8_t* seqs;   // device, ASCII
+  uint64_t* hashes;      // device, dense [run][window][m]
+  uint32_t* dirty;       // device flag: set when a non-ACGTU byte is seen
+  uint64_t n_runs;       // number of reads / runs
+  uint32_t len;          // bases per run
+  uint32_t stride;       // bases between run starts (== len for plain reads)
+  uint32_t k, m;
+  uint32_t nwin;         // len - k + 1
+  uint32_t pad_dwords;   // front pad of the LDS bit stream, >= ceil(k/16)+1
+  uint32_t n_tiles;
+  uint32_t reserved;
+  uint64_t f_init, r_init; // strand hashes of k virtual 'A's
+  uint64_t tab[16][2];     // [(in<<2)|out] -> {fwd term, rev term}
+  uint64_t mult[KF_MAX_RUNTIME_M]; // i ^ k*MULTISEED, i = 0..7 (runtime-m variant)
+};
+
+// ---- 2-bit packing of 16 ASCII bytes + validity accumulation -------------
+// code = (c >> 1) & 3.  A byte is a base iff, lower-cased and with 'u' folded
+// onto 't', it equals the canonical letter of its own code.
+__device__ __forceinline__ uint32_t pack4(uint32_t w, uint32_t& bad)
+{
+  const uint32_t t = (w >> 1) & 0x03030303u;
+  uint32_t x = w | 0x20202020u;
+  const uint32_t ubit = (x >> 4) & 0x01010101u; // set for 0x7_ letters (t,u)
+  x = x & ~ubit;                                // 'u'(0x75) -> 't'(0x74)
+  const uint32_t canon = __builtin_amdgcn_perm(0u, 0x67746361u, t); // a,c,t,g by code
+  bad |= x ^ canon;
+  // gather the four 2-bit fields (at bits 0,8,16,24) into one byte
+  const uint32_t lo = (t & 0x00FFFFFFu) * 0x00010410u; // f0<<16 | f1<<18 | f2<<20
+  return ((lo >> 16) & 0x3Fu) | ((t >> 24) << 6);
+}
+
+__device__ __forceinline__ uint32_t pack16(uint4 v, uint32_t& bad)
+{
+  return pack4(v.x, bad) | (pack4(v.y, bad) << 8) | (pack4(v.z, bad) << 16) |
+         (pack4(v.w, bad) << 24);
+}
+
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+  return __builtin_amdgcn_alignbit(hi, lo, sh); // ({hi,lo} >> (sh & 31))[31:0]
+}
+
+// word modes of the per-lane rolling loop
+enum : int { W_NOEMIT = 0, W_EMIT = 1, W_BOUNDARY = 2, W_CHECKED = 3 };
+
+// K_T / M_T: compile-time k and m (0 = read from args)
+template <int K_T, int M_T>
+__global__ __launch_bounds__(KF_THREADS) void kmer_fixed_kernel(const KmerFixedArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  __shared__ __attribute__((aligned(16))) uint64_t tile_all[4 * KF_TILE_U64];
+  __shared__ __attribute__((aligned(16))) uint4 tab[16];
+  uint32_t* bits = lds_dyn;
+
+  const uint32_t k = K_T ? (uint32_t)K_T : a.k;
+  const uint32_t m = M_T ? (uint32_t)M_T : a.m;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  uint64_t* tile = tile_all + wave * KF_TILE_U64;
+
+  if (tid < 16) {
+    tab[tid] = make_uint4((uint32_t)a.tab[tid][0], (uint32_t)(a.tab[tid][0] >> 32),
+                          (uint32_t)a.tab[tid][1], (uint32_t)(a.tab[tid][1] >> 32));
+  }
+  // front pad of the bit stream = virtual 'A's (code 0)
+  for (uint32_t i = tid; i < a.pad_dwords; i += KF_THREADS) bits[i] = 0;
+
+  // swizzled slot of this lane's row: conflict-free 8-byte writes, 16-byte reads
+  const uint32_t sw = ((lane & 7u) << 1) | ((lane >> 3) & 1u);
+  const uint32_t wr_base = lane * KF_ROW_U64 + sw;
+  const uint32_t vpr = a.nwin * m; // values per run in the output stream
+  const uint32_t kmod = (k - 1u) & 15u;
+  const uint32_t jb = (k - 1u) >> 4; // word holding the first emitting step
+  const uint32_t n_full = a.len >> 4; // words with all 16 steps
+  const uint32_t n_words = (a.len + 15u) >> 4;
+  uint32_t bad = 0;
+
+  for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+    const uint64_t run0 = (uint64_t)t * KF_RUNS_PER_BLOCK;
+    const uint64_t left = a.n_runs - run0;
+    const uint32_t runs_here = left < KF_RUNS_PER_BLOCK ? (uint32_t)left : KF_RUNS_PER_BLOCK;
+    // ---- phase 1: slab of ASCII -> 2-bit stream in LDS ---------------------
+    // 16-byte vectors aligned in memory; a vector that holds one valid byte
+    // lies inside that byte's page, so edge vectors are safe to load whole.
+    const uint64_t byte0 = run0 * a.stride;
+    const uint64_t addr0 = (uint64_t)(a.seqs + byte0);
+    const uint32_t shift = (uint32_t)(addr0 & 15u); // foreign bytes in the first vector
+    const uint4* vsrc = (const uint4*)(addr0 - shift);
+    const uint32_t slab_bytes = (runs_here - 1u) * a.stride + a.len;
+    const uint32_t n_vec = (shift + slab_bytes + 15u) >> 4;
+    __syncthreads(); // previous tile consumed; pad/tab visible on the first pass
+    for (uint32_t i = tid; i < n_vec; i += KF_THREADS) {
+      const uint4 v = vsrc[i];
+      uint32_t b = 0;
+      const uint32_t p = pack16(v, b);
+      const int32_t lo_cut = (int32_t)shift - (int32_t)(i << 4);
+      const int32_t hi_cut = (int32_t)(shift + slab_bytes) - (int32_t)(i << 4);
+      if (lo_cut > 0 || hi_cut < 16) {
+        // edge vector: bytes outside the slab are somebody else's, do not judge them
+        uint32_t bx[4] = {0, 0, 0, 0};
+        (void)pack4(v.x, bx[0]);
+        (void)pack4(v.y, bx[1]);
+        (void)pack4(v.z, bx[2]);
+        (void)pack4(v.w, bx[3]);
+        b = 0;
+        for (int q = 0; q < 16; ++q)
+          if (q >= lo_cut && q < hi_cut) b |= (bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+      }
+      bad |= b;
+      bits[a.pad_dwords + i] = p;
+    }
+    if (tid < 2) bits[a.pad_dwords + n_vec + tid] = 0; // funnel reads one word ahead
+    __syncthreads();
+
+    // ---- phase 2: every lane rolls its run --------------------------------
+    const uint32_t lrun = wave * 64u + lane; // run index inside the tile
+    const uint32_t bl = a.pad_dwords * 16u + shift + lrun * a.stride; // first base (stream index)
+    const uint32_t in_d = bl >> 4, in_sh = (bl & 15u) << 1;
+    const uint32_t ob = bl - k; // never negative thanks to the pad
+    const uint32_t out_d = ob >> 4, out_sh = (ob & 15u) << 1;
+    const uint64_t wave_run0 = run0 + wave * 64u;
+
+    uint64_t f = a.f_init, r = a.r_init;
+    uint32_t in_lo = bits[in_d], out_lo = bits[out_d];
+
+    // write one 128-byte row per lane to global memory: 8 x (64 lanes x 16 B)
+    auto flush_row = [&](uint32_t row_v0, uint32_t nvalid) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const uint32_t R = (uint32_t)s * 8u + (lane >> 3);
+        const uint32_t ch = lane & 7u;
+        const uint32_t chp = ch ^ (R & 7u);
+        const uint4 d = *(const uint4*)(tile + R * KF_ROW_U64 + 2u * chp);
+        const uint64_t run = wave_run0 + R;
+        uint64_t* dst = a.hashes + run * vpr + row_v0 + 2u * ch;
+        const uint4 o = (s & 1) ? make_uint4(d.z, d.w, d.x, d.y) : d;
+        if (run < a.n_runs) {
+          if (2u * ch + 1u < nvalid) {
+            *(uint4*)dst = o;
+          } else if (2u * ch < nvalid) {
+            *(uint2*)dst = make_uint2(o.x, o.y);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+
+    auto emit = [&](uint32_t step, uint32_t i) {
+      const uint64_t h0 = f + r;
+      const uint32_t p = step - (k - 1u);           // window index inside the run
+      const uint32_t pi = (i + 16u - kmod) & 15u;   // == p & 15
+      uint64_t tb = 0;
+      if (M_T > 1) tb = h0 * multiplier(k, 0);
+#pragma unroll
+      for (uint32_t jj = 0; jj < (M_T ? (uint32_t)M_T : m); ++jj) {
+        uint64_t val;
+        if (jj == 0) {
+          val = h0;
+        } else if (M_T) {
+          // i ^ B differs from B = k*MULTISEED only in its low bits, so
+          // h0*(i^B) = h0*B + h0*delta with a tiny compile-time delta
+          const int64_t delta = (int64_t)(multiplier(k, jj) - multiplier(k, 0));
+          const uint64_t tv = tb + (uint64_t)delta * h0;
+          val = tv ^ (tv >> MULTISHIFT);
+        } else {
+          val = mix_hash(h0, a.mult[jj & (KF_MAX_RUNTIME_M - 1)]);
+        }
+        const uint32_t slot = (pi * m + jj) & 15u;
+        tile[wr_base ^ slot] = val;
+        if (slot == 15u) flush_row((p * m + jj) & ~15u, 16u);
+      }
+    };
+
+    auto word = [&](auto mode_tag, uint32_t j) {
+      constexpr int MODE = decltype(mode_tag)::value;
+      const uint32_t in_hi = bits[in_d + j + 1];
+      const uint32_t out_hi = bits[out_d + j + 1];
+      const uint32_t w_in = funnel(in_hi, in_lo, in_sh);
+      uint32_t w_out = funnel(out_hi, out_lo, out_sh);
+      in_lo = in_hi;
+      out_lo = out_hi;
+      const uint32_t s0 = j << 4;
+      // steps whose outgoing base lies before the run start see a virtual 'A'
+      if (s0 + 16u <= k) w_out = 0;
+      else if (s0 < k) w_out &= ~0u << ((k - s0) << 1);
+      // nibble streams: u = even steps, v = odd steps; nibble = (in<<2)|out
+      const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
+      const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
+      auto step_fn = [&](uint32_t i) {
+        const uint32_t src = (i & 1u) ? v : u;
+        const uint32_t off = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
+        const uint4 term = *(const uint4*)((const char*)tab + off);
+        f = srol1(f) ^ (((uint64_t)term.y << 32) | term.x);
+        r = sror1(r ^ (((uint64_t)term.w << 32) | term.z));
+      };
+      if constexpr (MODE == W_CHECKED) {
+        const uint32_t steps = (a.len - s0) < 16u ? (a.len - s0) : 16u;
+#pragma unroll 1
+        for (uint32_t i = 0; i < steps; ++i) {
+          step_fn(i);
+          if (s0 + i >= k - 1u) emit(s0 + i, i);
+        }
+      } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i) {
+          step_fn(i);
+          if constexpr (MODE == W_EMIT) emit(s0 + i, i);
+          if constexpr (MODE == W_BOUNDARY) {
+            if (i >= kmod) emit(s0 + i, i);
+          }
+        }
+      }
+    };
+
+    uint32_t j = 0;
+    const uint32_t pre_end = jb < n_full ? jb : n_full;
+    for (; j < pre_end; ++j) word(std::integral_constant<int, W_NOEMIT>{}, j);
+    if (j < n_full) { word(std::integral_constant<int, W_BOUNDARY>{}, j); ++j; }
+#pragma unroll 1
+    for (; j < n_full; ++j) word(std::integral_constant<int, W_EMIT>{}, j);
+    for (; j < n_words; ++j) word(std::integral_constant<int, W_CHECKED>{}, j);
+    if (vpr & 15u) flush_row(vpr & ~15u, vpr & 15u); // last, partial row
+  }
+  // any non-base byte in this block's slabs -> the caller re-runs the general path
+  if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
+}
+
+// --------------------------------------------------------------------------
+// General path: exact NtHash emission order on arbitrary bytes and lengths.
+// --------------------------------------------------------------------------
+struct KmerGeneralArgs {
+  const uint8_t* seqs;
+  const uint64_t* offsets; // n_reads+1, or nullptr with fixed len/stride
+  uint64_t n_reads;
+  uint32_t len, stride;    // used when offsets == nullptr
+  uint32_t k, m;
+  const uint64_t* read_off; // exclusive scan of counts (hash pass only)
+  uint64_t* counts;         // per-read emitted windows (may be nullptr)
+  uint64_t* hashes;
+  uint32_t* pos;
+  uint64_t* fwd;
+  uint64_t* rev;
+  uint64_t capacity;        // k-mers
+  uint64_t sk_fwd[4];       // srol^k(seed[code])
+  uint64_t sk_rc[4];        // srol^k(seed[code^2])
+  uint64_t mult[256];
+};
+
+// One lane per read.  A window is emitted iff its k bytes are all bases -- the
+// net effect of the reference's init()/roll() skipping (src/kmer.cpp:228-264).
+// Non-base bytes contribute nothing on entry and on exit, so the rolled state
+// is exact again as soon as a clean window is reached.
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(256) void kmer_general_kernel(const KmerGeneralArgs* __restrict__ ap)
+{
+  const KmerGeneralArgs& a = *ap;
+  const uint64_t rid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (rid >= a.n_reads) return;
+  uint64_t start, len;
+  if (a.offsets) {
+    start = a.offsets[rid];
+    len = a.offsets[rid + 1] - start;
+  } else {
+    start = rid * a.stride;
+    len = a.len;
+  }
+  const uint8_t* s = a.seqs + start;
+  const uint32_t k = a.k;
+  uint64_t emitted = 0;
+  if (len >= k) {
+    uint64_t f = 0, r = 0;
+    uint64_t run = 0; // consecutive base bytes ending at i
+    const uint64_t base = COUNT_ONLY ? 0 : a.read_off[rid];
+    for (uint64_t i = 0; i < len; ++i) {
+      const uint8_t cin = s[i];
+      const bool vin = is_base(cin);
+      run = vin ? run + 1 : 0;
+      if (!COUNT_ONLY) {
+        const uint32_t ci = code_of(cin);
+        uint64_t tf = vin ? seed_of_code(ci) : 0;
+        uint64_t tr = vin ? a.sk_rc[ci] : 0;
+        if (i >= k) {
+          const uint8_t cout = s[i - k];
+          if (is_base(cout)) {
+            const uint32_t co = code_of(cout);
+            tf ^= a.sk_fwd[co];
+            tr ^= seed_of_code(co ^ 2u);
+          }
+        }
+        f = srol1(f) ^ tf;
+        r = sror1(r ^ tr);
+      }
+      if (run >= k) {
+        if (!COUNT_ONLY) {
+          const uint64_t o = base + emitted;
+          if (o < a.capacity) {
+            const uint64_t h0 = f + r;
+            a.hashes[o * a.m] = h0;
+            for (uint32_t jj = 1; jj < a.m; ++jj) a.hashes[o * a.m + jj] = mix_hash(h0, a.mult[jj]);
+            if (a.pos) a.pos[o] = (uint32_t)(i + 1 - k);
+            if (a.fwd) a.fwd[o] = f;
+            if (a.rev) a.rev[o] = r;
+          }
+        }
+        emitted++;
+      }
+    }
+  }
+  if (a.counts) a.counts[rid] = emitted;
+}
+
+} // namespace ntamd

@@ -1,0 +1,967 @@
+// nthip_capi.hip -- implementation of include/nthash_hip.h (libnthash_hip.so).
+//
+// Host-side orchestration of the gfx950 kernels: argument validation (the
+// conditions the reference raise_error()s on, src/kmer.cpp:212-225,
+// src/seed.cpp:90-95), per-k constant tables, path selection (optimistic dense
+// fixed-length kernel, N-aware general kernels as the device-side fallback),
+// staging for host buffers, and HIP-event timing of the dominant kernel.
+// There is no CPU hashing path in this file or anywhere under nthash_amd/.
+#include "../../include/nthash_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kmer_kernels.hpp"
+#include "nt_math.hpp"
+#include "seed_kernels.hpp"
+#include "util_kernels.hpp"
+
+using namespace ntamd;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(call)                                                                    \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(NTHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                  \
+  } while (0)
+
+#define NTCHK(call)             \
+  do {                          \
+    int rc_ = (call);           \
+    if (rc_ != NTHIP_OK) return rc_; \
+  } while (0)
+
+} // namespace
+
+struct nthip_ctx {
+  int device = 0;
+  int n_cu = 0;
+  size_t lds_max = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // small device scratch: [0] dirty flag (u32), [8] total (u64)
+  uint8_t* d_small = nullptr;
+  uint8_t* h_small = nullptr; // pinned mirror
+  // device copy of the large argument blocks of the general kernels
+  void* d_args = nullptr;
+  size_t d_args_bytes = 0;
+  // scratch for counts / scan
+  uint64_t* d_scratch = nullptr;
+  size_t d_scratch_elems = 0;
+  bool profiling = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
+  const char* last_kernel = "";
+};
+
+struct nthip_seeds {
+  nthip_ctx* ctx = nullptr;
+  uint32_t n_seeds = 0, k = 0, ntab = 0, care_words = 0;
+  bool asymmetric = false;
+  uint4* d_tables = nullptr;      // [seed][ntab][256]
+  uint32_t* d_care = nullptr;     // [seed][care_words]
+  uint32_t* d_blk_start = nullptr;
+  uint32_t* d_blk_count = nullptr;
+  uint32_t* d_blk_pairs = nullptr;
+};
+
+namespace {
+
+int ensure_scratch(nthip_ctx* c, size_t elems)
+{
+  if (c->d_scratch_elems >= elems) return NTHIP_OK;
+  if (c->d_scratch) HIPCHK(hipFree(c->d_scratch));
+  c->d_scratch = nullptr;
+  c->d_scratch_elems = 0;
+  HIPCHK(hipMalloc((void**)&c->d_scratch, elems * sizeof(uint64_t)));
+  c->d_scratch_elems = elems;
+  return NTHIP_OK;
+}
+
+int ensure_args(nthip_ctx* c, size_t bytes)
+{
+  if (c->d_args_bytes >= bytes) return NTHIP_OK;
+  if (c->d_args) HIPCHK(hipFree(c->d_args));
+  c->d_args = nullptr;
+  HIPCHK(hipMalloc(&c->d_args, bytes));
+  c->d_args_bytes = bytes;
+  return NTHIP_OK;
+}
+
+void prof_begin(nthip_ctx* c, const char* name)
+{
+  c->last_kernel = name;
+  if (c->profiling) {
+    (void)hipEventRecord(c->ev0, c->stream);
+    c->ev_valid = false;
+  }
+}
+void prof_end(nthip_ctx* c)
+{
+  if (c->profiling) {
+    (void)hipEventRecord(c->ev1, c->stream);
+    c->ev_valid = true;
+  }
+}
+
+// exclusive scan of n u64 on the device: out[i] = sum(in[0..i)), *d_total = sum
+// scratch: needs ceil(n/1024) (+ recursion) extra u64, taken from `sums`
+int device_exclusive_scan(nthip_ctx* c, const uint64_t* d_in, uint64_t* d_out, uint64_t n,
+                          uint64_t* d_sums, uint64_t* d_total)
+{
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nb == 0) {
+    HIPCHK(hipMemsetAsync(d_total, 0, sizeof(uint64_t), c->stream));
+    return NTHIP_OK;
+  }
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, c->stream, d_in, d_out,
+                     d_sums, n);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, c->stream, d_sums, nb, d_total);
+  hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, c->stream, d_out, d_sums, n);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+struct Staged {
+  // device views of the caller's buffers (staged copies when host flags are set)
+  const uint8_t* seqs = nullptr;
+  const uint64_t* offsets = nullptr;
+  uint64_t* hashes = nullptr;
+  uint64_t* counts = nullptr;
+  uint32_t* pos = nullptr;
+  uint64_t* fwd = nullptr;
+  uint64_t* rev = nullptr;
+  std::vector<void*> owned;
+  ~Staged()
+  {
+    for (void* p : owned) (void)hipFree(p);
+  }
+};
+
+int stage_inputs(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, uint64_t total_bytes, Staged& st)
+{
+  if (flags & NTHIP_HOST_INPUT) {
+    void* d = nullptr;
+    HIPCHK(hipMalloc(&d, total_bytes ? total_bytes : 16));
+    st.owned.push_back(d);
+    if (total_bytes) HIPCHK(hipMemcpyAsync(d, rd->seqs, total_bytes, hipMemcpyHostToDevice, c->stream));
+    st.seqs = (const uint8_t*)d;
+    if (rd->offsets) {
+      void* o = nullptr;
+      HIPCHK(hipMalloc(&o, (rd->n_reads + 1) * sizeof(uint64_t)));
+      st.owned.push_back(o);
+      HIPCHK(hipMemcpyAsync(o, rd->offsets, (rd->n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
+                            c->stream));
+      st.offsets = (const uint64_t*)o;
+    }
+  } else {
+    st.seqs = (const uint8_t*)rd->seqs;
+    st.offsets = rd->offsets;
+  }
+  return NTHIP_OK;
+}
+
+int stage_outputs(nthip_ctx* c, const nthip_out* out, uint32_t flags, uint64_t n_reads, uint32_t per,
+                  Staged& st)
+{
+  (void)c;
+  if (flags & NTHIP_HOST_OUTPUT) {
+    auto alloc = [&](size_t bytes, void** p) -> int {
+      HIPCHK(hipMalloc(p, bytes ? bytes : 16));
+      st.owned.push_back(*p);
+      return NTHIP_OK;
+    };
+    NTCHK(alloc(out->capacity * per * sizeof(uint64_t), (void**)&st.hashes));
+    if (out->counts) NTCHK(alloc(n_reads * sizeof(uint64_t), (void**)&st.counts));
+    if (out->pos) NTCHK(alloc(out->capacity * sizeof(uint32_t), (void**)&st.pos));
+    if (out->fwd) NTCHK(alloc(out->capacity * sizeof(uint64_t), (void**)&st.fwd));
+    if (out->rev) NTCHK(alloc(out->capacity * sizeof(uint64_t), (void**)&st.rev));
+  } else {
+    st.hashes = out->hashes;
+    st.counts = out->counts;
+    st.pos = out->pos;
+    st.fwd = out->fwd;
+    st.rev = out->rev;
+  }
+  return NTHIP_OK;
+}
+
+int unstage_outputs(nthip_ctx* c, const nthip_out* out, uint32_t flags, uint64_t n_reads, uint32_t per,
+                    uint64_t total, const Staged& st)
+{
+  if (!(flags & NTHIP_HOST_OUTPUT)) return NTHIP_OK;
+  if (total) {
+    HIPCHK(hipMemcpyAsync(out->hashes, st.hashes, total * per * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                          c->stream));
+    if (out->pos)
+      HIPCHK(hipMemcpyAsync(out->pos, st.pos, total * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (out->fwd)
+      HIPCHK(hipMemcpyAsync(out->fwd, st.fwd, total * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (out->rev)
+      HIPCHK(hipMemcpyAsync(out->rev, st.rev, total * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  }
+  if (out->counts && n_reads)
+    HIPCHK(hipMemcpyAsync(out->counts, st.counts, n_reads * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                          c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+// total bytes of the read buffer (needs the last offset when offsets are on the device)
+int reads_total_bytes(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, uint64_t* out)
+{
+  if (rd->n_reads == 0) { *out = 0; return NTHIP_OK; }
+  if (rd->offsets) {
+    if (flags & NTHIP_HOST_INPUT) {
+      *out = rd->offsets[rd->n_reads];
+    } else {
+      uint64_t last = 0;
+      HIPCHK(hipMemcpyAsync(&last, rd->offsets + rd->n_reads, sizeof last, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      *out = last;
+    }
+  } else {
+    const uint32_t stride = rd->stride ? rd->stride : rd->fixed_len;
+    *out = (rd->n_reads - 1) * (uint64_t)stride + rd->fixed_len;
+  }
+  return NTHIP_OK;
+}
+
+int check_reads(const nthip_reads* rd)
+{
+  if (!rd) return fail(NTHIP_ERR_ARG, "reads is NULL");
+  if (rd->n_reads && !rd->seqs) return fail(NTHIP_ERR_ARG, "reads->seqs is NULL");
+  if (!rd->offsets && rd->fixed_len == 0 && rd->n_reads)
+    return fail(NTHIP_ERR_ARG, "reads needs either offsets or fixed_len");
+  if (rd->offsets && rd->fixed_len) return fail(NTHIP_ERR_ARG, "reads has both offsets and fixed_len");
+  return NTHIP_OK;
+}
+
+template <typename K>
+int set_max_lds(K kernel, size_t bytes)
+{
+  // static + dynamic LDS beyond the 64 KiB default needs the opt-in attribute
+  if (bytes > 24 * 1024) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  }
+  return NTHIP_OK;
+}
+
+template <typename K>
+int launch_kmer_fixed(nthip_ctx* c, K kernel, const KmerFixedArgs& a, size_t dyn_lds)
+{
+  NTCHK(set_max_lds(kernel, dyn_lds));
+  int per_cu = 0;
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, KF_THREADS, dyn_lds));
+  if (per_cu < 1) per_cu = 1;
+  uint64_t grid = (uint64_t)c->n_cu * per_cu;
+  if (grid > a.n_tiles) grid = a.n_tiles;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(KF_THREADS), dyn_lds, c->stream, a);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+} // namespace
+
+// ==========================================================================
+// library / context
+// ==========================================================================
+extern "C" const char* nthip_version(void) { return "nthash_amd 0.1 (gfx950; ntHash_v2 bit-exact)"; }
+extern "C" const char* nthip_last_error(void) { return g_err.c_str(); }
+
+extern "C" int nthip_device_count(int* count)
+{
+  if (!count) return fail(NTHIP_ERR_ARG, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(NTHIP_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_ctx_create(int device, nthip_ctx** out)
+{
+  if (!out) return fail(NTHIP_ERR_ARG, "ctx out pointer is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(NTHIP_ERR_NODEVICE, "no HIP device available (nthash_amd has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(NTHIP_ERR_ARG, "device %d out of range [0,%d)", device, n);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  nthip_ctx* c = new nthip_ctx();
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount;
+  c->lds_max = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void**)&c->d_small, 64) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_small, 64) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return fail(NTHIP_ERR_HIP, "context resource creation failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_ctx_destroy(nthip_ctx* c)
+{
+  if (!c) return NTHIP_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->d_small) (void)hipFree(c->d_small);
+  if (c->h_small) (void)hipHostFree(c->h_small);
+  if (c->d_args) (void)hipFree(c->d_args);
+  if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_ctx_set_stream(nthip_ctx* c, void* s)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_ctx_synchronize(nthip_ctx* c)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_ctx_set_profiling(nthip_ctx* c, int on)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  c->profiling = on != 0;
+  c->ev_valid = false;
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_last_kernel_ms(nthip_ctx* c, float* ms, const char** name)
+{
+  if (!c || !ms) return fail(NTHIP_ERR_ARG, "ctx/ms is NULL");
+  if (!c->ev_valid) return fail(NTHIP_ERR_ARG, "no profiled kernel recorded (enable profiling first)");
+  HIPCHK(hipEventSynchronize(c->ev1));
+  HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  if (name) *name = c->last_kernel;
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_malloc(nthip_ctx* c, size_t bytes, void** p)
+{
+  if (!c || !p) return fail(NTHIP_ERR_ARG, "ctx/dptr is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMalloc(p, bytes ? bytes : 16));
+  return NTHIP_OK;
+}
+extern "C" int nthip_free(nthip_ctx* c, void* p)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipFree(p));
+  return NTHIP_OK;
+}
+extern "C" int nthip_memcpy_h2d(nthip_ctx* c, void* dst, const void* src, size_t bytes)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+extern "C" int nthip_memcpy_d2h(nthip_ctx* c, void* dst, const void* src, size_t bytes)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+// ==========================================================================
+// k-mer hashing
+// ==========================================================================
+namespace {
+
+void fill_kmer_consts(uint32_t k, uint32_t m, KmerFixedArgs& a)
+{
+  // (in,out) pair terms of the roll (src/kmer.cpp:84-94, 164-174):
+  //   F' = srol(F) ^ S[in] ^ srol^k(S[out]);  R' = sror(R ^ srol^k(S[~in]) ^ S[~out])
+  for (unsigned in = 0; in < 4; ++in)
+    for (unsigned o = 0; o < 4; ++o) {
+      a.tab[(in << 2) | o][0] = seed_of_code(in) ^ srol_n(seed_of_code(o), k);
+      a.tab[(in << 2) | o][1] = srol_n(seed_of_code(in ^ 2u), k) ^ seed_of_code(o ^ 2u);
+    }
+  // strand hashes of a window of k 'A's: the state before the first real base
+  uint64_t f = 0, r = 0;
+  for (uint32_t i = 0; i < k; ++i) {
+    f = srol1(f) ^ SEED_A;
+    r = srol1(r) ^ SEED_T; // all terms equal, so the order of rotation does not matter
+  }
+  a.f_init = f;
+  a.r_init = r;
+  for (uint32_t i = 0; i < (uint32_t)KF_MAX_RUNTIME_M; ++i) a.mult[i] = multiplier(k, i);
+  (void)m;
+}
+
+// Can the fixed-length kernel take this batch?  Returns the dynamic LDS size.
+bool kmer_fixed_eligible(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m,
+                         uint32_t* pad_dwords, size_t* dyn_lds)
+{
+  if (len < k || m > (uint32_t)KF_MAX_RUNTIME_M) return false;
+  if (stride > len) return false; // gaps between reads: general path
+  const uint32_t pad = (k + 15u) / 16u + 1u;
+  const uint64_t slab = 15ull + (uint64_t)(KF_RUNS_PER_BLOCK - 1) * stride + len;
+  const uint64_t n_vec = (slab + 15u) >> 4;
+  const uint64_t dwords = pad + n_vec + 2;
+  const size_t bytes = dwords * 4;
+  const size_t static_lds = 4 * KF_TILE_U64 * 8 + 256;
+  if (bytes + static_lds > c->lds_max || bytes + static_lds > 160 * 1024) return false;
+  *pad_dwords = pad;
+  *dyn_lds = bytes;
+  return true;
+}
+
+int run_kmer_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m,
+                     uint64_t capacity, uint64_t* total)
+{
+  const uint64_t n = rd->n_reads;
+  KmerGeneralArgs h;
+  memset(&h, 0, sizeof h);
+  h.seqs = st.seqs;
+  h.offsets = st.offsets;
+  h.n_reads = n;
+  h.len = rd->fixed_len;
+  h.stride = rd->stride ? rd->stride : rd->fixed_len;
+  h.k = k;
+  h.m = m;
+  for (unsigned cde = 0; cde < 4; ++cde) {
+    h.sk_fwd[cde] = srol_n(seed_of_code(cde), k);
+    h.sk_rc[cde] = srol_n(seed_of_code(cde ^ 2u), k);
+  }
+  for (uint32_t i = 0; i < 256; ++i) h.mult[i] = multiplier(k, i);
+  // scratch: counts[n] | read_off[n] | tile sums
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  NTCHK(ensure_scratch(c, 2 * n + nb + 16));
+  uint64_t* d_counts = st.counts ? st.counts : c->d_scratch;
+  uint64_t* d_off = c->d_scratch + n;
+  uint64_t* d_sums = c->d_scratch + 2 * n;
+  uint64_t* d_total = (uint64_t*)(c->d_small + 8);
+  NTCHK(ensure_args(c, sizeof(KmerGeneralArgs)));
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+
+  // pass 1: per-read counts
+  h.counts = d_counts;
+  HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(kmer_general_kernel<true>, dim3(blocks), dim3(256), 0, c->stream,
+                     (const KmerGeneralArgs*)c->d_args);
+  HIPCHK(hipGetLastError());
+  NTCHK(device_exclusive_scan(c, d_counts, d_off, n, d_sums, d_total));
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream)); // also makes reuse of the stack copy `h` safe
+  memcpy(total, c->h_small + 8, 8);
+  if (*total > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
+                (unsigned long long)capacity, (unsigned long long)*total);
+  // pass 2: hashes at their compact offsets
+  h.counts = nullptr;
+  h.read_off = d_off;
+  h.hashes = st.hashes;
+  h.pos = st.pos;
+  h.fwd = st.fwd;
+  h.rev = st.rev;
+  h.capacity = capacity;
+  HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+  prof_begin(c, "kmer_general_kernel");
+  hipLaunchKernelGGL(kmer_general_kernel<false>, dim3(blocks), dim3(256), 0, c->stream,
+                     (const KmerGeneralArgs*)c->d_args);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+} // namespace
+
+extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8,
+                               const nthip_out* out, uint64_t* total_out, uint32_t flags)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  NTCHK(check_reads(rd));
+  if (!out || !out->hashes) return fail(NTHIP_ERR_ARG, "out->hashes is NULL");
+  const uint32_t k = k16, m = m8;
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0"); // src/kmer.cpp:212-214
+  if (k < 3) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 is undefined in the reference (src/kmer.cpp:47)");
+  if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
+  HIPCHK(hipSetDevice(c->device));
+  uint64_t total = 0;
+  if (total_out) *total_out = 0;
+  if (rd->n_reads == 0) return NTHIP_OK;
+
+  uint64_t total_bytes = 0;
+  NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
+  Staged st;
+  NTCHK(stage_inputs(c, rd, flags, total_bytes, st));
+  NTCHK(stage_outputs(c, out, flags, rd->n_reads, m, st));
+
+  const uint32_t len = rd->fixed_len;
+  const uint32_t stride = rd->stride ? rd->stride : len;
+  uint32_t pad = 0;
+  size_t dyn = 0;
+  bool done = false;
+  const bool want_fast = !rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.pos && !st.fwd && !st.rev &&
+                         kmer_fixed_eligible(c, len, stride, k, m, &pad, &dyn);
+  if (!rd->offsets && len < k) {
+    // every read shorter than k: nothing is emitted
+    if (st.counts) {
+      hipLaunchKernelGGL(fill_u64_kernel, dim3(1024), dim3(256), 0, c->stream, st.counts, rd->n_reads, 0ull);
+      HIPCHK(hipGetLastError());
+    }
+    done = true;
+  } else if (want_fast) {
+    const uint32_t nwin = len - k + 1;
+    const uint64_t dense = rd->n_reads * (uint64_t)nwin;
+    if (dense > out->capacity) {
+      if (total_out) *total_out = dense;
+      return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
+                  (unsigned long long)out->capacity, (unsigned long long)dense);
+    }
+    KmerFixedArgs a;
+    memset(&a, 0, sizeof a);
+    a.seqs = st.seqs;
+    a.hashes = st.hashes;
+    a.dirty = (uint32_t*)c->d_small;
+    a.n_runs = rd->n_reads;
+    a.len = len;
+    a.stride = stride;
+    a.k = k;
+    a.m = m;
+    a.nwin = nwin;
+    a.pad_dwords = pad;
+    const uint64_t n_tiles = (rd->n_reads + KF_RUNS_PER_BLOCK - 1) / KF_RUNS_PER_BLOCK;
+    if (n_tiles > 0xFFFFFFFFull) return fail(NTHIP_ERR_UNSUPPORTED, "too many reads for one call");
+    a.n_tiles = (uint32_t)n_tiles;
+    fill_kmer_consts(k, m, a);
+    HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream));
+    prof_begin(c, "kmer_fixed_kernel");
+    int rc;
+    if (k == 31 && m == 1) rc = launch_kmer_fixed(c, kmer_fixed_kernel<31, 1>, a, dyn);
+    else if (k == 31 && m == 4) rc = launch_kmer_fixed(c, kmer_fixed_kernel<31, 4>, a, dyn);
+    else rc = launch_kmer_fixed(c, kmer_fixed_kernel<0, 0>, a, dyn);
+    prof_end(c);
+    NTCHK(rc);
+    HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint32_t dirty = 0;
+    memcpy(&dirty, c->h_small, 4);
+    if (!dirty) {
+      total = dense;
+      if (st.counts) {
+        hipLaunchKernelGGL(fill_u64_kernel, dim3(1024), dim3(256), 0, c->stream, st.counts, rd->n_reads,
+                           (uint64_t)nwin);
+        HIPCHK(hipGetLastError());
+      }
+      done = true;
+    }
+    // dirty: some byte is not ACGTU -> redo on the N-aware path (device side)
+  }
+  if (!done) NTCHK(run_kmer_general(c, st, rd, k, m, out->capacity, &total));
+  if (total_out) *total_out = total;
+  NTCHK(unstage_outputs(c, out, flags, rd->n_reads, m, total, st));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+// ==========================================================================
+// spaced seeds
+// ==========================================================================
+namespace {
+
+// get_blocks (src/seed.cpp:19-66): runs of care / don't-care positions; a care
+// run ends at a literal '0', a don't-care run at a literal '1'.  Returns the
+// description the reference would use (care runs, or don't-care runs plus the
+// whole-k-mer block pushed last when that is cheaper).
+void seed_blocks(const std::string& s, std::vector<uint32_t>& pairs, std::vector<uint32_t>& monos)
+{
+  const uint32_t k = (uint32_t)s.size();
+  std::vector<uint32_t> cb, ib, cm, im;
+  const char sentinel = s[k - 1] == '1' ? '0' : '1';
+  bool care = s[0] == '1';
+  uint32_t start = 0;
+  for (uint32_t p = 0; p <= k; ++p) {
+    const char ch = p < k ? s[p] : sentinel;
+    if (care && ch == '0') {
+      if (p - start == 1) cm.push_back(start);
+      else { cb.push_back(start); cb.push_back(p); }
+      start = p;
+      care = false;
+    } else if (!care && ch == '1') {
+      if (p - start == 1) im.push_back(start);
+      else { ib.push_back(start); ib.push_back(p); }
+      start = p;
+      care = true;
+    }
+  }
+  const size_t cost_care = cb.size() + cm.size();      // 2 per block + 1 per monomer
+  const size_t cost_ign = ib.size() + im.size() + 2;
+  if (cost_ign < cost_care) {
+    pairs = ib;
+    pairs.push_back(0);
+    pairs.push_back(k);
+    monos = im;
+  } else {
+    pairs = cb;
+    monos = cm;
+  }
+}
+
+} // namespace
+
+extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32_t n_seeds, uint16_t k16,
+                                  nthip_seeds** out, int* asymmetric)
+{
+  if (!c || !out) return fail(NTHIP_ERR_ARG, "ctx/out is NULL");
+  *out = nullptr;
+  if (!seeds || n_seeds == 0) return fail(NTHIP_ERR_ARG, "no seeds given");
+  const uint32_t k = k16;
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
+  HIPCHK(hipSetDevice(c->device));
+  const uint32_t ntab = (k + 3) / 4, cw = (k + 31) / 32;
+  std::vector<uint4> tables((size_t)n_seeds * ntab * 256);
+  std::vector<uint32_t> care((size_t)n_seeds * cw, 0), blk_start(n_seeds), blk_count(n_seeds), blk_pairs;
+  bool asym = false;
+  for (uint32_t s = 0; s < n_seeds; ++s) {
+    if (!seeds[s]) return fail(NTHIP_ERR_ARG, "seed %u is NULL", s);
+    const std::string str(seeds[s]);
+    if (str.size() != k) // src/seed.cpp:90-95
+      return fail(NTHIP_ERR_ARG, "Spaced seed string length (%zu) not equal to k=%u in %s", str.size(), k,
+                  str.c_str());
+    if (!std::equal(str.begin(), str.end(), str.rbegin())) asym = true; // src/seed.cpp:96-102
+    std::vector<uint32_t> pairs, monos;
+    seed_blocks(str, pairs, monos);
+    blk_start[s] = (uint32_t)(blk_pairs.size() / 2);
+    blk_count[s] = (uint32_t)(pairs.size() / 2);
+    blk_pairs.insert(blk_pairs.end(), pairs.begin(), pairs.end());
+    // contributing positions = XOR-coverage of blocks and monomers (src/seed.cpp:149-164)
+    std::vector<uint8_t> par(k, 0);
+    for (size_t b = 0; b + 1 < pairs.size(); b += 2)
+      for (uint32_t p = pairs[b]; p < pairs[b + 1]; ++p) par[p] ^= 1;
+    for (uint32_t p : monos) par[p] ^= 1;
+    for (uint32_t p = 0; p < k; ++p)
+      if (par[p]) care[(size_t)s * cw + (p >> 5)] |= 1u << (p & 31);
+    // byte tables: entry = XOR over the byte's 4 bases of the masked rotated seeds
+    for (uint32_t jt = 0; jt < ntab; ++jt)
+      for (uint32_t byte = 0; byte < 256; ++byte) {
+        uint64_t f = 0, r = 0;
+        for (uint32_t q = 0; q < 4; ++q) {
+          const uint32_t p = 4 * jt + q;
+          if (p >= k || !par[p]) continue;
+          const uint32_t code = (byte >> (2 * q)) & 3u;
+          f ^= srol_n(seed_of_code(code), k - 1 - p);
+          r ^= srol_n(seed_of_code(code ^ 2u), p);
+        }
+        tables[((size_t)s * ntab + jt) * 256 + byte] =
+            make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+      }
+  }
+  if (blk_pairs.empty()) blk_pairs.push_back(0);
+  nthip_seeds* sd = new nthip_seeds();
+  sd->ctx = c;
+  sd->n_seeds = n_seeds;
+  sd->k = k;
+  sd->ntab = ntab;
+  sd->care_words = cw;
+  sd->asymmetric = asym;
+  auto up = [&](const void* src, size_t bytes, void** dst) -> int {
+    HIPCHK(hipMalloc(dst, bytes));
+    HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return NTHIP_OK;
+  };
+  int rc = up(tables.data(), tables.size() * sizeof(uint4), (void**)&sd->d_tables);
+  if (rc == NTHIP_OK) rc = up(care.data(), care.size() * 4, (void**)&sd->d_care);
+  if (rc == NTHIP_OK) rc = up(blk_start.data(), blk_start.size() * 4, (void**)&sd->d_blk_start);
+  if (rc == NTHIP_OK) rc = up(blk_count.data(), blk_count.size() * 4, (void**)&sd->d_blk_count);
+  if (rc == NTHIP_OK) rc = up(blk_pairs.data(), blk_pairs.size() * 4, (void**)&sd->d_blk_pairs);
+  if (rc != NTHIP_OK) {
+    nthip_seeds_destroy(sd);
+    return rc;
+  }
+  if (asymmetric) *asymmetric = asym ? 1 : 0;
+  *out = sd;
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_seeds_destroy(nthip_seeds* sd)
+{
+  if (!sd) return NTHIP_OK;
+  if (sd->ctx) (void)hipSetDevice(sd->ctx->device);
+  if (sd->d_tables) (void)hipFree(sd->d_tables);
+  if (sd->d_care) (void)hipFree(sd->d_care);
+  if (sd->d_blk_start) (void)hipFree(sd->d_blk_start);
+  if (sd->d_blk_count) (void)hipFree(sd->d_blk_count);
+  if (sd->d_blk_pairs) (void)hipFree(sd->d_blk_pairs);
+  delete sd;
+  return NTHIP_OK;
+}
+
+namespace {
+
+int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd,
+                     uint32_t m2, uint64_t capacity, uint64_t* total)
+{
+  const uint64_t n = rd->n_reads;
+  SeedGeneralArgs h;
+  memset(&h, 0, sizeof h);
+  h.seqs = st.seqs;
+  h.offsets = st.offsets;
+  h.n_reads = n;
+  h.len = rd->fixed_len;
+  h.stride = rd->stride ? rd->stride : rd->fixed_len;
+  h.k = sd->k;
+  h.m2 = m2;
+  h.n_seeds = sd->n_seeds;
+  h.care_words = sd->care_words;
+  h.care_bits = sd->d_care;
+  h.blk_start = sd->d_blk_start;
+  h.blk_count = sd->d_blk_count;
+  h.blk_pairs = sd->d_blk_pairs;
+  for (uint32_t i = 0; i < 256; ++i) h.mult[i] = multiplier(sd->k, i);
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  NTCHK(ensure_scratch(c, 2 * n + nb + 16));
+  uint64_t* d_counts = st.counts ? st.counts : c->d_scratch;
+  uint64_t* d_off = c->d_scratch + n;
+  uint64_t* d_sums = c->d_scratch + 2 * n;
+  uint64_t* d_total = (uint64_t*)(c->d_small + 8);
+  NTCHK(ensure_args(c, sizeof(SeedGeneralArgs)));
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  h.counts = d_counts;
+  HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(seed_general_kernel<true>, dim3(blocks), dim3(256), 0, c->stream,
+                     (const SeedGeneralArgs*)c->d_args);
+  HIPCHK(hipGetLastError());
+  NTCHK(device_exclusive_scan(c, d_counts, d_off, n, d_sums, d_total));
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(total, c->h_small + 8, 8);
+  if (*total > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
+                (unsigned long long)capacity, (unsigned long long)*total);
+  h.counts = nullptr;
+  h.read_off = d_off;
+  h.hashes = st.hashes;
+  h.pos = st.pos;
+  h.capacity = capacity;
+  HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+  prof_begin(c, "seed_general_kernel");
+  hipLaunchKernelGGL(seed_general_kernel<false>, dim3(blocks), dim3(256), 0, c->stream,
+                     (const SeedGeneralArgs*)c->d_args);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+template <typename K>
+int launch_seed_fixed(nthip_ctx* c, K kernel, const SeedFixedArgs& a, size_t dyn_lds)
+{
+  NTCHK(set_max_lds(kernel, dyn_lds));
+  int per_cu = 0;
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SF_THREADS, dyn_lds));
+  if (per_cu < 1) per_cu = 1;
+  uint64_t grid = (uint64_t)c->n_cu * per_cu;
+  if (grid > a.n_tiles) grid = a.n_tiles;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(SF_THREADS), dyn_lds, c->stream, a);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+} // namespace
+
+extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, uint8_t m28,
+                               const nthip_out* out, uint64_t* total_out, uint32_t flags)
+{
+  if (!c || !sd) return fail(NTHIP_ERR_ARG, "ctx/seeds is NULL");
+  NTCHK(check_reads(rd));
+  if (!out || !out->hashes) return fail(NTHIP_ERR_ARG, "out->hashes is NULL");
+  if (out->fwd || out->rev) return fail(NTHIP_ERR_ARG, "out->fwd/rev are not produced by seed hashing");
+  const uint32_t m2 = m28, k = sd->k;
+  if (m2 == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes_per_seed must be >= 1");
+  HIPCHK(hipSetDevice(c->device));
+  uint64_t total = 0;
+  if (total_out) *total_out = 0;
+  if (rd->n_reads == 0) return NTHIP_OK;
+  const uint32_t per = sd->n_seeds * m2;
+
+  uint64_t total_bytes = 0;
+  NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
+  Staged st;
+  NTCHK(stage_inputs(c, rd, flags, total_bytes, st));
+  NTCHK(stage_outputs(c, out, flags, rd->n_reads, per, st));
+
+  const uint32_t len = rd->fixed_len;
+  const uint32_t stride = rd->stride ? rd->stride : len;
+  bool done = false;
+  if (!rd->offsets && len < k) {
+    if (st.counts) {
+      hipLaunchKernelGGL(fill_u64_kernel, dim3(1024), dim3(256), 0, c->stream, st.counts, rd->n_reads, 0ull);
+      HIPCHK(hipGetLastError());
+    }
+    done = true;
+  } else if (!rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.pos && m2 <= (uint32_t)SF_MAX_RUNTIME_M &&
+             k <= 64 && stride <= len) {
+    const uint32_t nwin = len - k + 1;
+    const size_t table_bytes = (size_t)sd->n_seeds * sd->ntab * 256 * sizeof(uint4);
+    // tile = as many runs as give a ~16 KiB bit stream (64 Ki bases), at most 256
+    uint32_t rpt = 65536u / stride;
+    if (rpt > 256) rpt = 256;
+    if (rpt < 1) rpt = 1;
+    const uint64_t slab = 15ull + (uint64_t)(rpt - 1) * stride + len;
+    const size_t dyn = table_bytes + (((slab + 15) >> 4) + 8) * 4;
+    const uint64_t dense = rd->n_reads * (uint64_t)nwin;
+    if (dyn <= 150 * 1024 && dyn <= c->lds_max && (uint64_t)rpt * nwin < 0x7FFFFFFFull) {
+      if (dense > out->capacity) {
+        if (total_out) *total_out = dense;
+        return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
+                    (unsigned long long)out->capacity, (unsigned long long)dense);
+      }
+      SeedFixedArgs a;
+      memset(&a, 0, sizeof a);
+      a.seqs = st.seqs;
+      a.hashes = st.hashes;
+      a.dirty = (uint32_t*)c->d_small;
+      a.tables = sd->d_tables;
+      a.n_runs = rd->n_reads;
+      a.len = len;
+      a.stride = stride;
+      a.k = k;
+      a.m2 = m2;
+      a.n_seeds = sd->n_seeds;
+      a.ntab = sd->ntab;
+      a.nwin = nwin;
+      a.runs_per_tile = rpt;
+      const uint64_t n_tiles = (rd->n_reads + rpt - 1) / rpt;
+      if (n_tiles > 0xFFFFFFFFull) return fail(NTHIP_ERR_UNSUPPORTED, "too many reads for one call");
+      a.n_tiles = (uint32_t)n_tiles;
+      a.inv_nwin = (uint32_t)((1ull << 32) / nwin + 1);
+      for (uint32_t i = 0; i < (uint32_t)SF_MAX_RUNTIME_M; ++i) a.mult[i] = multiplier(k, i);
+      HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream));
+      prof_begin(c, "seed_fixed_kernel");
+      int rc;
+      if (k <= 16) rc = launch_seed_fixed(c, seed_fixed_kernel<1>, a, dyn);
+      else if (k <= 32) rc = launch_seed_fixed(c, seed_fixed_kernel<2>, a, dyn);
+      else if (k <= 48) rc = launch_seed_fixed(c, seed_fixed_kernel<3>, a, dyn);
+      else rc = launch_seed_fixed(c, seed_fixed_kernel<4>, a, dyn);
+      prof_end(c);
+      NTCHK(rc);
+      HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      uint32_t dirty = 0;
+      memcpy(&dirty, c->h_small, 4);
+      if (!dirty) {
+        total = dense;
+        if (st.counts) {
+          hipLaunchKernelGGL(fill_u64_kernel, dim3(1024), dim3(256), 0, c->stream, st.counts, rd->n_reads,
+                             (uint64_t)nwin);
+          HIPCHK(hipGetLastError());
+        }
+        done = true;
+      }
+    }
+  }
+  if (!done) NTCHK(run_seed_general(c, st, rd, sd, m2, out->capacity, &total));
+  if (total_out) *total_out = total;
+  NTCHK(unstage_outputs(c, out, flags, rd->n_reads, per, total, st));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+// ==========================================================================
+// measurement helpers
+// ==========================================================================
+extern "C" int nthip_synth_reads(nthip_ctx* c, char* d_dst, uint64_t first_read, uint64_t n_reads,
+                                 uint32_t len, uint64_t seed)
+{
+  if (!c || !d_dst) return fail(NTHIP_ERR_ARG, "ctx/dst is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  if (n_reads == 0 || len == 0) return NTHIP_OK;
+  hipLaunchKernelGGL(synth_reads_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, (uint8_t*)d_dst,
+                     first_read, n_reads, len, seed);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_checksum(nthip_ctx* c, const uint64_t* d_vals, uint64_t n, uint64_t* sum, uint64_t* xr)
+{
+  if (!c || !sum || !xr) return fail(NTHIP_ERR_ARG, "ctx/sum/xor is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  *sum = 0;
+  *xr = 0;
+  if (n == 0) return NTHIP_OK;
+  const unsigned blocks = (unsigned)c->n_cu * 8;
+  NTCHK(ensure_scratch(c, 2 * blocks + 16));
+  hipLaunchKernelGGL(checksum_kernel, dim3(blocks), dim3(256), 0, c->stream, d_vals, n, c->d_scratch);
+  HIPCHK(hipGetLastError());
+  std::vector<uint64_t> part(2 * blocks);
+  HIPCHK(hipMemcpyAsync(part.data(), c->d_scratch, part.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (unsigned b = 0; b < blocks; ++b) {
+    *sum += part[2 * b];
+    *xr ^= part[2 * b + 1];
+  }
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_copy_bench(nthip_ctx* c, void* d_dst, const void* d_src, size_t bytes, int reps,
+                                float* best_ms)
+{
+  if (!c || !d_dst || !d_src || !best_ms) return fail(NTHIP_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  float best = 1e30f;
+  for (int i = 0; i < (reps > 0 ? reps : 1); ++i) {
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(copy_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, (uint4*)d_dst,
+                       (const uint4*)d_src, (uint64_t)(bytes / 16));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (ms < best) best = ms;
+  }
+  c->ev_valid = false;
+  *best_ms = best;
+  return NTHIP_OK;
+}

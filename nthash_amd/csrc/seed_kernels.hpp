@@ -1,0 +1,239 @@
+// seed_kernels.hpp -- CDNA4 (gfx950) kernels for spaced-seed hashing.
+//
+// Replaces, for a whole batch of reads, the reference's per-read loop
+//     SeedNtHash h(seq, len, seeds, m2, k); while (h.roll()) use(h.hashes());
+// (src/seed.cpp:449-544).  The reference rolls a blocks-only state per seed
+// and re-adds the monomers on every window (NTMSM64, src/seed.cpp:177-207);
+// what that evaluates on every window is the masked direct formula
+//     F = XOR_{p in care} srol^{k-1-p}(S[c_p]),  R = XOR_{p in care} srol^{p}(S[comp c_p])
+// (SURVEY.md App. A.4).  On a GPU the masked formula is cheaper to evaluate
+// directly: the 2-bit window is cut into bytes (4 bases) and each byte indexes
+// a per-seed, per-byte-position table in LDS that already holds the XOR of the
+// four masked, rotated seeds for both strands (16 B per entry).  No per-lane
+// state is carried from window to window, so one lane owns one window and the
+// stores are naturally ordered.
+//
+//   seed_fixed_kernel    hot path: fixed-length clean reads.
+//   seed_general_kernel  exact reference position state machine (quirk Q3,
+//                        NUL handling of src/seed.cpp:151) for ragged / dirty
+//                        batches; one lane per read.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kmer_kernels.hpp" // pack16 / funnel
+#include "nt_math.hpp"
+
+namespace ntamd {
+
+constexpr int SF_THREADS = 512;
+constexpr int SF_MAX_RUNTIME_M = 8;
+
+struct SeedFixedArgs {
+  const uint8_t* seqs;
+  uint64_t* hashes;     // dense [run][window][seed][m2]
+  uint32_t* dirty;
+  const uint4* tables;  // global: [seed][byte position][256] {f.lo,f.hi,r.lo,r.hi}
+  uint64_t n_runs;
+  uint32_t len, stride, k, m2;
+  uint32_t n_seeds, ntab; // ntab = ceil(k/4)
+  uint32_t nwin;
+  uint32_t runs_per_tile;
+  uint32_t n_tiles;
+  uint32_t inv_nwin;      // floor(2^32 / nwin) + 1 (for q / nwin)
+  uint64_t mult[SF_MAX_RUNTIME_M];
+};
+
+// NW = 32-bit words of 2-bit window kept in registers: k <= 16*NW
+template <int NW>
+__global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  // layout: [tables: n_seeds*ntab*256 uint4][bit stream]
+  uint4* tabs = (uint4*)lds_dyn;
+  const uint32_t n_entries = a.n_seeds * a.ntab * 256u;
+  uint32_t* bits = lds_dyn + n_entries * 4u;
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  for (uint32_t i = tid; i < n_entries; i += SF_THREADS) tabs[i] = a.tables[i];
+
+  const uint32_t per = a.n_seeds * a.m2; // values per window
+  uint32_t bad = 0;
+
+  for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+    const uint64_t run0 = (uint64_t)t * a.runs_per_tile;
+    const uint64_t left = a.n_runs - run0;
+    const uint32_t runs_here = left < a.runs_per_tile ? (uint32_t)left : a.runs_per_tile;
+    const uint64_t byte0 = run0 * a.stride;
+    const uint64_t addr0 = (uint64_t)(a.seqs + byte0);
+    const uint32_t shift = (uint32_t)(addr0 & 15u);
+    const uint4* vsrc = (const uint4*)(addr0 - shift);
+    const uint32_t slab_bytes = (runs_here - 1u) * a.stride + a.len;
+    const uint32_t n_vec = (shift + slab_bytes + 15u) >> 4;
+    __syncthreads();
+    for (uint32_t i = tid; i < n_vec; i += SF_THREADS) {
+      const uint4 v = vsrc[i];
+      uint32_t b = 0;
+      const uint32_t p = pack16(v, b);
+      const int32_t lo_cut = (int32_t)shift - (int32_t)(i << 4);
+      const int32_t hi_cut = (int32_t)(shift + slab_bytes) - (int32_t)(i << 4);
+      if (lo_cut > 0 || hi_cut < 16) {
+        uint32_t bx[4] = {0, 0, 0, 0};
+        (void)pack4(v.x, bx[0]);
+        (void)pack4(v.y, bx[1]);
+        (void)pack4(v.z, bx[2]);
+        (void)pack4(v.w, bx[3]);
+        b = 0;
+        for (int q = 0; q < 16; ++q)
+          if (q >= lo_cut && q < hi_cut) b |= (bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+      }
+      bad |= b;
+      bits[i] = p;
+    }
+    if (tid < NW + 1) bits[n_vec + tid] = 0;
+    __syncthreads();
+
+    const uint32_t n_win_tile = runs_here * a.nwin;
+    for (uint32_t q = tid; q < n_win_tile; q += SF_THREADS) {
+      // q -> (run, window) with a multiply-high and one fix-up
+      uint32_t lr = a.nwin == 1u ? q : __umulhi(q, a.inv_nwin);
+      if (lr * a.nwin > q) lr--;
+      const uint32_t p = q - lr * a.nwin;
+      const uint32_t b = shift + lr * a.stride + p; // first base of the window (stream index)
+      const uint32_t d = b >> 4, sh = (b & 15u) << 1;
+      uint32_t w[NW];
+      uint32_t lo = bits[d];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const uint32_t hi = bits[d + i + 1];
+        w[i] = funnel(hi, lo, sh);
+        lo = hi;
+      }
+      uint64_t* dst = a.hashes + (run0 * a.nwin + q) * per;
+      for (uint32_t s = 0; s < a.n_seeds; ++s) {
+        uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
+        const uint4* ts = tabs + s * a.ntab * 256u;
+#pragma unroll
+        for (int jt = 0; jt < 4 * NW; ++jt) {
+          if ((uint32_t)jt < a.ntab) {
+            const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+            const uint4 e = ts[(uint32_t)jt * 256u + byte];
+            f0 ^= e.x; f1 ^= e.y; r0 ^= e.z; r1 ^= e.w;
+          }
+        }
+        const uint64_t h0 = (((uint64_t)f1 << 32) | f0) + (((uint64_t)r1 << 32) | r0);
+        dst[s * a.m2] = h0;
+        for (uint32_t jj = 1; jj < a.m2; ++jj)
+          dst[s * a.m2 + jj] = mix_hash(h0, a.mult[jj & (SF_MAX_RUNTIME_M - 1)]);
+      }
+    }
+  }
+  if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
+}
+
+// --------------------------------------------------------------------------
+// General path: the reference's position state machine, one lane per read.
+// --------------------------------------------------------------------------
+struct SeedGeneralArgs {
+  const uint8_t* seqs;
+  const uint64_t* offsets;
+  uint64_t n_reads;
+  uint32_t len, stride;
+  uint32_t k, m2, n_seeds;
+  uint32_t care_words;        // ceil(k/32)
+  const uint32_t* care_bits;  // [seed][care_words]: bit p = position p contributes
+  const uint32_t* blk_start;  // [seed] index into blk_pairs
+  const uint32_t* blk_count;  // [seed]
+  const uint32_t* blk_pairs;  // [start,end) pairs in get_blocks order (src/seed.cpp:19-66)
+  const uint64_t* read_off;
+  uint64_t* counts;
+  uint64_t* hashes;
+  uint32_t* pos;
+  uint64_t capacity;
+  uint64_t mult[256];
+};
+
+// src/seed.cpp:146-158: walking seeds -> blocks -> positions, the first NUL byte
+__device__ inline bool seed_first_nul(const SeedGeneralArgs& a, const uint8_t* win, uint32_t* where)
+{
+  for (uint32_t s = 0; s < a.n_seeds; ++s) {
+    const uint32_t b0 = a.blk_start[s];
+    for (uint32_t b = 0; b < a.blk_count[s]; ++b) {
+      const uint32_t lo = a.blk_pairs[2 * (b0 + b)], hi = a.blk_pairs[2 * (b0 + b) + 1];
+      for (uint32_t p = lo; p < hi; ++p)
+        if (win[p] == 0) { *where = p; return true; }
+    }
+  }
+  return false;
+}
+
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(256) void seed_general_kernel(const SeedGeneralArgs* __restrict__ ap)
+{
+  const SeedGeneralArgs& a = *ap;
+  const uint64_t rid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (rid >= a.n_reads) return;
+  uint64_t start, len;
+  if (a.offsets) {
+    start = a.offsets[rid];
+    len = a.offsets[rid + 1] - start;
+  } else {
+    start = rid * a.stride;
+    len = a.len;
+  }
+  const uint8_t* s = a.seqs + start;
+  const uint32_t k = a.k;
+  const uint32_t per = a.n_seeds * a.m2;
+  uint64_t emitted = 0;
+  if (len >= k) {
+    bool has_nul = false;
+    for (uint64_t i = 0; i < len; ++i) has_nul |= (s[i] == 0);
+    const uint64_t base = COUNT_ONLY ? 0 : a.read_off[rid];
+    uint64_t pos = 0;
+    // SeedNtHash::init (src/seed.cpp:493-516)
+    auto init = [&]() -> bool {
+      uint32_t where = 0;
+      while (pos < len - k + 1 && has_nul && seed_first_nul(a, s + pos, &where)) pos += where + 1;
+      return !(pos > len - k);
+    };
+    bool ok = init();
+    while (ok) {
+      if (!COUNT_ONLY) {
+        const uint64_t o = base + emitted;
+        if (o < a.capacity) {
+          const uint8_t* win = s + pos;
+          for (uint32_t sd = 0; sd < a.n_seeds; ++sd) {
+            const uint32_t* care = a.care_bits + sd * a.care_words;
+            uint64_t fh = 0, rh = 0;
+            for (uint32_t p = 0; p < k; ++p) { // Horner: F = XOR srol^{k-1-p}(S[c_p])
+              const bool c = (care[p >> 5] >> (p & 31u)) & 1u;
+              fh = srol1(fh) ^ (c ? fwd_seed(win[p]) : 0);
+            }
+            for (uint32_t p = k; p-- > 0;) {   // R = XOR srol^{p}(S[c_p & 7])
+              const bool c = (care[p >> 5] >> (p & 31u)) & 1u;
+              rh = srol1(rh) ^ (c ? rc_seed(win[p]) : 0);
+            }
+            const uint64_t h0 = fh + rh;
+            uint64_t* dst = a.hashes + o * per + sd * a.m2;
+            dst[0] = h0;
+            for (uint32_t jj = 1; jj < a.m2; ++jj) dst[jj] = mix_hash(h0, a.mult[jj]);
+          }
+          if (a.pos) a.pos[o] = (uint32_t)pos;
+        }
+      }
+      emitted++;
+      // SeedNtHash::roll (src/seed.cpp:518-544)
+      if (pos >= len - k) break;
+      if (!is_base(s[pos + k])) {
+        pos += k;
+        ok = init();
+      } else {
+        pos++;
+      }
+    }
+  }
+  if (a.counts) a.counts[rid] = emitted;
+}
+
+} // namespace ntamd

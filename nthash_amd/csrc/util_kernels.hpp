@@ -1,0 +1,171 @@
+// util_kernels.hpp -- small device helpers around the hash kernels:
+// exclusive scan of per-read counts (compact output offsets), dense fills,
+// counter-based synthetic reads, stream checksums, and a copy yardstick.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ntamd {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS; // 1024 values per block
+
+__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, uint32_t lane)
+{
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = __shfl_up(v, d, 64);
+    if ((int)lane >= d) v += o;
+  }
+  return v;
+}
+
+// per-tile exclusive scan; tile totals go to block_sums
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(const uint64_t* __restrict__ in,
+                                                                 uint64_t* __restrict__ out,
+                                                                 uint64_t* __restrict__ block_sums,
+                                                                 uint64_t n)
+{
+  __shared__ uint64_t wave_tot[SCAN_THREADS / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)tid * SCAN_ITEMS;
+  uint64_t v[SCAN_ITEMS];
+  uint64_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = (base + i < n) ? in[base + i] : 0;
+    sum += v[i];
+  }
+  const uint64_t incl = wave_incl_scan(sum, lane);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint64_t off = 0;
+  for (uint32_t w = 0; w < wave; ++w) off += wave_tot[w];
+  uint64_t run = off + incl - sum;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    if (base + i < n) out[base + i] = run;
+    run += v[i];
+  }
+  if (tid == SCAN_THREADS - 1) block_sums[blockIdx.x] = run;
+}
+
+// single block: exclusive scan of the tile totals in place, grand total out
+__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(uint64_t* __restrict__ sums, uint64_t n,
+                                                                uint64_t* __restrict__ total)
+{
+  __shared__ uint64_t wave_tot[SCAN_THREADS / 64];
+  __shared__ uint64_t carry_s;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (uint64_t b0 = 0; b0 < n; b0 += SCAN_THREADS) {
+    const uint64_t i = b0 + tid;
+    const uint64_t v = i < n ? sums[i] : 0;
+    const uint64_t incl = wave_incl_scan(v, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint64_t off = carry_s;
+    for (uint32_t w = 0; w < wave; ++w) off += wave_tot[w];
+    if (i < n) sums[i] = off + incl - v;
+    __syncthreads();
+    if (tid == SCAN_THREADS - 1) carry_s = off + incl;
+    __syncthreads();
+  }
+  if (tid == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(uint64_t* __restrict__ out,
+                                                               const uint64_t* __restrict__ sums, uint64_t n)
+{
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  const uint64_t add = sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i)
+    if (base + i < n) out[base + i] += add;
+}
+
+__global__ void fill_u64_kernel(uint64_t* __restrict__ dst, uint64_t n, uint64_t value)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    dst[i] = value;
+}
+
+// pos[r*nwin + p] = p
+__global__ void fill_pos_kernel(uint32_t* __restrict__ dst, uint64_t n, uint32_t nwin)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    dst[i] = (uint32_t)(i % nwin);
+}
+
+__device__ __host__ inline uint64_t splitmix64(uint64_t x)
+{
+  uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+// Counter-based synthetic reads: one thread per (read, 32-base word)
+__global__ void synth_reads_kernel(uint8_t* __restrict__ dst, uint64_t first_read, uint64_t n_reads,
+                                   uint32_t len, uint64_t seed)
+{
+  const uint64_t W = (len + 31u) / 32u;
+  const uint64_t n = n_reads * W;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = i / W, w = i - r * W;
+    const uint64_t x = splitmix64(seed + (first_read + r) * W + w);
+    uint8_t* out = dst + r * (uint64_t)len + w * 32u;
+    const uint32_t cnt = (uint32_t)((w * 32u + 32u <= len) ? 32u : (len - w * 32u));
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t c = (uint32_t)(x >> (2u * j)) & 3u;
+      out[j] = (uint8_t)(c == 0 ? 'A' : c == 1 ? 'C' : c == 2 ? 'G' : 'T');
+    }
+  }
+}
+
+// wrapping sum and xor of a u64 stream; partial[2*block + {0,1}]
+__global__ __launch_bounds__(256) void checksum_kernel(const uint64_t* __restrict__ v, uint64_t n,
+                                                      uint64_t* __restrict__ partial)
+{
+  __shared__ uint64_t ss[4], sx[4];
+  uint64_t s = 0, x = 0;
+  const uint64_t n2 = n / 2;
+  const ulonglong2* v2 = (const ulonglong2*)v;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const ulonglong2 q = v2[i];
+    s += q.x + q.y;
+    x ^= q.x ^ q.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { s += v[n - 1]; x ^= v[n - 1]; }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    s += __shfl_xor(s, d, 64);
+    x ^= __shfl_xor(x, d, 64);
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (lane == 0) { ss[wave] = s; sx[wave] = x; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = ss[0] + ss[1] + ss[2] + ss[3];
+    partial[2 * blockIdx.x + 1] = sx[0] ^ sx[1] ^ sx[2] ^ sx[3];
+  }
+}
+
+// plain 16-byte/lane device copy: the achievable-bandwidth yardstick
+__global__ __launch_bounds__(256) void copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src,
+                                                  uint64_t n16)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+} // namespace ntamd

@@ -1,0 +1,364 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the
+C-ABI (include/nthash_hip.h) and is compared bit-for-bit with
+  * the golden fixtures generated from the real reference (tests/golden),
+  * the oracle (oracle/nthash_oracle.c) on seeded inputs,
+and, at sizes where no oracle run is affordable, through size-independent
+properties (strand symmetry, full-care seed == k-mer hash, fast kernel ==
+general kernel, shard concatenation, checksums of checksums).
+Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle.pyoracle import concat_reads
+
+pytestmark = pytest.mark.gpu
+
+SEED_A = "1010101010101010101010101010101"
+SEED_B = "1101101101101101011011011011011"
+
+
+def h2i(xs):
+    return np.array([int(x, 16) for x in xs], dtype=np.uint64)
+
+
+def rc_bytes(a):
+    tab = np.arange(256, dtype=np.uint8)
+    for x, y in zip(b"ACGTacgt", b"TGCAtgca"):
+        tab[x] = y
+    return tab[a[::-1]]
+
+
+def test_native_library_is_loaded(ctx):
+    """the HIP extension, not a fallback, is what runs"""
+    import nthash_amd
+    assert nthash_amd.device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libnthash_hip.so" in maps
+
+
+# ---------------------------------------------------------------------------
+# golden fixtures (generated from the real reference)
+# ---------------------------------------------------------------------------
+def test_golden_kmer_cases(ctx):
+    for c in load_golden("kmer_cases.json"):
+        d, offs = concat_reads(c["reads"])
+        r = ctx.kmer_hash(d, c["k"], c["m"], offsets=offs, want_pos=True, want_strands=True)
+        assert r["counts"].tolist() == c["counts"], c["reads"]
+        assert r["pos"].tolist() == c["pos"]
+        assert (r["hashes"].ravel() == h2i(c["hashes"])).all()
+        assert (r["fwd"] == h2i(c["fwd"])).all() and (r["rev"] == h2i(c["rev"])).all()
+
+
+def test_golden_seed_cases(ctx):
+    for c in load_golden("seed_cases.json"):
+        d, offs = concat_reads(c["reads"])
+        r = ctx.seed_hash(d, c["seeds"], c["k"], c["m2"], offsets=offs, want_pos=True)
+        assert r["counts"].tolist() == c["counts"], (c["reads"], c["seeds"])
+        assert r["pos"].tolist() == c["pos"]
+        assert (r["hashes"].ravel() == h2i(c["hashes"])).all()
+
+
+def test_golden_synth_checksums_device_resident(ctx, oracle):
+    """BASELINE config 1 (10k x 150 bp, k=31) and friends, inputs generated ON the
+    device by the counter-based generator, full stream compared by checksum and
+    head values with what the real reference produced for the same reads."""
+    for c in load_golden("synth_checksums.json"):
+        n, L, k = c["n_reads"], c["len"], c["k"]
+        d_in = ctx.malloc(n * L)
+        ctx.synth_reads_ptr(d_in, 0, n, L, c["seed"])
+        host = np.zeros(n * L, np.uint8)
+        ctx.d2h(host, d_in)
+        assert (host == oracle.synth_reads(0, n, L, c["seed"])).all()  # generator parity
+        nwin = L - k + 1
+        per = c["m"] if c["kind"] == "kmer" else len(c["seeds"]) * c["m2"]
+        d_out = ctx.malloc(n * nwin * per * 8)
+        if c["kind"] == "kmer":
+            tot = ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, c["m"], d_out, n * nwin)
+        else:
+            import nthash_amd
+            sd = nthash_amd.Seeds(ctx, c["seeds"], k)
+            tot = ctx.seed_hash_ptr(d_in, 0, n, L, 0, sd, c["m2"], d_out, n * nwin)
+        assert tot == c["total"]
+        s, x = ctx.checksum_ptr(d_out, tot * per)
+        assert format(s, "016x") == c["sum"] and format(x, "016x") == c["xor"]
+        head = np.zeros(len(c["head"]), np.uint64)
+        ctx.d2h(head, d_out)
+        assert (head == h2i(c["head"])).all()
+        ctx.free(d_in)
+        ctx.free(d_out)
+
+
+# ---------------------------------------------------------------------------
+# oracle on seeded inputs: fixed-length fast kernels
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,L,k,m", [
+    (10000, 150, 31, 1),   # BASELINE config 1 shape: full bit-exact compare
+    (3000, 150, 31, 4),    # multi-hash (config 3 shape)
+    (1000, 150, 31, 2), (777, 150, 31, 8),
+    (513, 100, 64, 3),     # examples/benchmark.cpp shape (k > 32: d mod 31/33 wrap)
+    (300, 151, 21, 3), (257, 97, 17, 5), (255, 64, 33, 1), (100, 31, 31, 1), (64, 40, 3, 2),
+    (1, 150, 31, 1), (3, 250, 16, 1), (1000, 250, 47, 1), (2, 500, 32, 7),
+])
+def test_kmer_fixed_vs_oracle(ctx, oracle, n, L, k, m):
+    data = oracle.synth_reads(5, n, L, 1234 + L)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    got = ctx.kmer_hash(data, k, m, fixed_len=L, n_reads=n)
+    assert got["total"] == want["total"] == n * (L - k + 1)
+    assert (got["hashes"] == want["hashes"]).all()
+    assert (got["counts"] == want["counts"]).all()
+    # the N-aware general kernel must give the same stream
+    gen = ctx.kmer_hash(data, k, m, fixed_len=L, n_reads=n, flags=4, want_pos=True, want_strands=True)
+    assert (gen["hashes"] == want["hashes"]).all()
+
+
+def test_kmer_fixed_unaligned_base_pointer(ctx, oracle):
+    """device buffer that does not start on a 16-byte boundary (edge vectors)"""
+    n, L, k = 700, 150, 31
+    data = oracle.synth_reads(0, n, L, 9)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, 1, want_pos=False)["hashes"]
+    for shift in (1, 7, 13):
+        d_in = ctx.malloc(n * L + 64)
+        ctx.h2d(d_in + shift, data)
+        d_out = ctx.malloc(n * (L - k + 1) * 8)
+        tot = ctx.kmer_hash_ptr(d_in + shift, 0, n, L, 0, k, 1, d_out, n * (L - k + 1))
+        got = np.zeros(tot, np.uint64)
+        ctx.d2h(got, d_out)
+        assert (got == want.ravel()).all()
+        ctx.free(d_in)
+        ctx.free(d_out)
+
+
+def test_kmer_lowercase_and_rna(ctx, oracle):
+    n, L, k = 500, 150, 31
+    data = oracle.synth_reads(0, n, L, 3)
+    lower = data | 0x20
+    rna = data.copy()
+    rna[rna == ord("T")] = ord("U")
+    a = ctx.kmer_hash(data, k, 2, fixed_len=L, n_reads=n)["hashes"]
+    assert (ctx.kmer_hash(lower, k, 2, fixed_len=L, n_reads=n)["hashes"] == a).all()
+    assert (ctx.kmer_hash(rna, k, 2, fixed_len=L, n_reads=n)["hashes"] == a).all()
+
+
+def test_kmer_dirty_fixed_len_falls_back_exactly(ctx, oracle):
+    """fixed-length batch with N / IUPAC bytes: optimistic kernel must notice and
+    the device-side N-aware path must reproduce the reference's skipping"""
+    rng = np.random.default_rng(3)
+    n, L, k = 2000, 150, 31
+    data = oracle.synth_reads(0, n, L, 77).copy()
+    bad = rng.choice(n * L, 60, replace=False)
+    data[bad] = np.frombuffer(b"NnRY-*", dtype=np.uint8)[rng.integers(0, 6, 60)]
+    data[0] = ord("N")
+    data[-1] = ord("N")
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, 3)
+    got = ctx.kmer_hash(data, k, 3, fixed_len=L, n_reads=n, want_pos=True)
+    assert got["total"] == want["total"] < n * (L - k + 1)
+    assert (got["counts"] == want["counts"]).all()
+    assert (got["pos"] == want["pos"]).all()
+    assert (got["hashes"] == want["hashes"]).all()
+    # without pos the optimistic fixed-length kernel runs first, sees the dirt, and falls back
+    got = ctx.kmer_hash(data, k, 3, fixed_len=L, n_reads=n)
+    assert got["total"] == want["total"] and (got["hashes"] == want["hashes"]).all()
+    assert (got["counts"] == want["counts"]).all()
+
+
+def test_kmer_ragged_reads_vs_oracle(ctx, oracle):
+    rng = np.random.default_rng(21)
+    alph = np.frombuffer(b"ACGTacgtUuNnRYKM-*", dtype=np.uint8)
+    for k, m in [(31, 1), (5, 3), (64, 2), (17, 4)]:
+        reads = []
+        for _ in range(400):
+            L = int(rng.integers(0, 300))
+            if rng.random() < 0.5:
+                idx = rng.integers(0, 4, L)
+            else:
+                idx = np.where(rng.random(L) < 0.95, rng.integers(0, 10, L), rng.integers(10, len(alph), L))
+            reads.append(alph[idx].tobytes())
+        reads += [b"", b"A", b"ACGT" * 100, b"N" * 50]
+        d, offs = concat_reads(reads)
+        want = oracle.kmer_batch(d, offs, k, m, want_strands=True)
+        got = ctx.kmer_hash(d, k, m, offsets=offs, want_pos=True, want_strands=True)
+        assert got["total"] == want["total"]
+        for key in ("counts", "pos", "hashes", "fwd", "rev"):
+            assert (got[key] == want[key]).all(), (k, m, key)
+
+
+def test_kmer_long_sequence_as_overlapping_runs(ctx, oracle):
+    """one long sequence hashed as runs of R windows overlapping by k-1 bases
+    (stride < fixed_len) == the sequence hashed as a single read"""
+    rng = np.random.default_rng(8)
+    k, R = 31, 120
+    n_runs = 1500
+    N = n_runs * R + k - 1
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, N)]
+    offs = np.array([0, N], dtype=np.uint64)
+    want = oracle.kmer_batch(seq, offs, k, 1, want_pos=False)["hashes"]
+    got = ctx.kmer_hash(seq, k, 1, fixed_len=R + k - 1, stride=R, n_reads=n_runs)
+    assert got["total"] == n_runs * R == len(want)
+    assert (got["hashes"] == want).all()
+
+
+def test_kmer_argument_errors(ctx):
+    import nthash_amd
+    from nthash_amd import capi
+    data = np.frombuffer(b"ACGTACGTAC", dtype=np.uint8)
+    with pytest.raises(nthash_amd.NtHipError) as e:
+        ctx.kmer_hash(data, 0, 1, fixed_len=10, n_reads=1)  # k == 0: src/kmer.cpp:212
+    assert e.value.code == capi.NTHIP_ERR_ARG
+    with pytest.raises(nthash_amd.NtHipError) as e:
+        ctx.kmer_hash(data, 2, 1, fixed_len=10, n_reads=1)
+    assert e.value.code == capi.NTHIP_ERR_UNSUPPORTED
+    # reads shorter than k emit nothing (the iterator would exit(1), src/kmer.cpp:215)
+    r = ctx.kmer_hash(data, 11, 1, fixed_len=10, n_reads=1)
+    assert r["total"] == 0 and r["counts"].tolist() == [0]
+    # capacity too small: error code + required size
+    d_in = ctx.malloc(1000)
+    d_out = ctx.malloc(8 * 10)
+    ctx.h2d(d_in, np.frombuffer(b"ACGT" * 250, dtype=np.uint8))
+    with pytest.raises(nthash_amd.NtHipError) as e:
+        ctx.kmer_hash_ptr(d_in, 0, 10, 100, 0, 31, 1, d_out, 10)
+    assert e.value.code == capi.NTHIP_ERR_CAPACITY and e.value.total == 10 * 70
+    ctx.free(d_in)
+    ctx.free(d_out)
+    # seed length != k: src/seed.cpp:90-95
+    with pytest.raises(nthash_amd.NtHipError) as e:
+        nthash_amd.Seeds(ctx, ["110011"], 5)
+    assert e.value.code == capi.NTHIP_ERR_ARG
+
+
+# ---------------------------------------------------------------------------
+# spaced seeds
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,L,seeds,m2", [
+    (4000, 250, [SEED_A, SEED_B], 3),      # BASELINE config 4 shape
+    (1000, 150, [SEED_A], 1),
+    (600, 100, ["11100111"], 3),
+    (500, 120, ["111110000000011111", "111111100001111111"], 2),
+    (300, 150, ["1" * 31], 4),
+    (300, 130, ["1111111111111110111111111111111"], 2),   # ignore-path description
+    (200, 200, [("1101" * 8) + ("1101" * 8)[::-1]], 2),          # k = 64 (NW = 4)
+    (129, 90, ["10" * 24 + "01" * 24], 1),     # k = 96 > 64: general kernel
+])
+def test_seed_fixed_vs_oracle(ctx, oracle, n, L, seeds, m2):
+    k = len(seeds[0])
+    data = oracle.synth_reads(11, n, L, 99 + L)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.seed_batch(data, offs, seeds, k, m2, want_pos=False)
+    got = ctx.seed_hash(data, seeds, k, m2, fixed_len=L, n_reads=n)
+    assert got["total"] == want["total"] == n * (L - k + 1)
+    assert (got["hashes"] == want["hashes"]).all()
+    gen = ctx.seed_hash(data, seeds, k, m2, fixed_len=L, n_reads=n, flags=4, want_pos=True)
+    assert (gen["hashes"] == want["hashes"]).all()
+
+
+def test_seed_dirty_and_ragged_vs_oracle(ctx, oracle):
+    rng = np.random.default_rng(33)
+    alph = np.frombuffer(b"ACGTacgtUuNnRYKMSW-*\x00", dtype=np.uint8)
+    for seeds, m2 in [([SEED_A, SEED_B], 3), (["110011"], 2), (["1111111111111110111111111111111"], 2),
+                      (["10101", "11011", "01110"], 1)]:
+        k = len(seeds[0])
+        reads = []
+        for _ in range(300):
+            L = int(rng.integers(0, 260))
+            p = rng.random()
+            if p < 0.4:
+                idx = rng.integers(0, 4, L)
+            elif p < 0.9:
+                idx = np.where(rng.random(L) < 0.95, rng.integers(0, 10, L), rng.integers(10, len(alph) - 1, L))
+            else:
+                idx = np.where(rng.random(L) < 0.9, rng.integers(0, 10, L), rng.integers(10, len(alph), L))
+            reads.append(alph[idx].tobytes())
+        d, offs = concat_reads(reads)
+        want = oracle.seed_batch(d, offs, seeds, k, m2)
+        got = ctx.seed_hash(d, seeds, k, m2, offsets=offs, want_pos=True)
+        assert got["total"] == want["total"]
+        for key in ("counts", "pos", "hashes"):
+            assert (got[key] == want[key]).all(), (seeds, key)
+    # fixed-length but dirty: optimistic kernel -> exact fallback
+    n, L = 1500, 250
+    data = oracle.synth_reads(0, n, L, 5).copy()
+    data[rng.choice(n * L, 40, replace=False)] = ord("N")
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.seed_batch(data, offs, [SEED_A, SEED_B], 31, 3)
+    got = ctx.seed_hash(data, [SEED_A, SEED_B], 31, 3, fixed_len=L, n_reads=n, want_pos=True)
+    assert got["total"] == want["total"]
+    assert (got["pos"] == want["pos"]).all() and (got["hashes"] == want["hashes"]).all()
+
+
+def test_seed_asymmetric_flag(ctx):
+    import nthash_amd
+    assert nthash_amd.Seeds(ctx, ["1101"], 4).asymmetric       # src/seed.cpp:96-102 warns
+    assert not nthash_amd.Seeds(ctx, ["1001"], 4).asymmetric
+
+
+# ---------------------------------------------------------------------------
+# properties at sizes the oracle does not cover
+# ---------------------------------------------------------------------------
+def test_properties_at_scale(ctx, oracle):
+    """4M x 150 bp on the device (480M k-mers; not the 100M-read config, but big
+    enough to cross every tile/grid-stride boundary many times)."""
+    import nthash_amd
+    n, L, k = 4_000_000, 150, 31
+    nwin = L - k + 1
+    d_in = ctx.malloc(n * L)
+    ctx.synth_reads_ptr(d_in, 0, n, L, 42)
+    d_out = ctx.malloc(n * nwin * 8)
+    assert ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, 1, d_out, n * nwin) == n * nwin
+    s_all, x_all = ctx.checksum_ptr(d_out, n * nwin)
+    # (1) shard property: hashing [0,n/2) and [n/2,n) separately gives the same stream
+    half = n // 2
+    d_o2 = ctx.malloc(half * nwin * 8)
+    s2 = x2 = 0
+    for part in range(2):
+        assert ctx.kmer_hash_ptr(d_in + part * half * L, 0, half, L, 0, k, 1, d_o2, half * nwin) == half * nwin
+        s, x = ctx.checksum_ptr(d_o2, half * nwin)
+        s2 = (s2 + s) & (2**64 - 1)
+        x2 ^= x
+    assert (s2, x2) == (s_all, x_all)
+    # (2) spot-check reads against the oracle (first, last, tile edges)
+    for r0 in (0, 255, 256, 257, 1_000_003, n - 1):
+        got = np.zeros(nwin, np.uint64)
+        ctx.d2h(got, d_out + r0 * nwin * 8)
+        data = oracle.synth_reads(r0, 1, L, 42)
+        want = oracle.kmer_batch(data, np.array([0, L], dtype=np.uint64), k, 1, want_pos=False)["hashes"].ravel()
+        assert (got == want).all(), r0
+    # (3) full-care spaced seed == k-mer hash (tests/tests.cpp:447-463) on 1M reads
+    n3 = 1_000_000
+    sd = nthash_amd.Seeds(ctx, ["1" * k], k)
+    assert ctx.seed_hash_ptr(d_in, 0, n3, L, 0, sd, 1, d_o2, n3 * nwin) == n3 * nwin
+    s3, x3 = ctx.checksum_ptr(d_o2, n3 * nwin)
+    assert (s3, x3) == ctx.checksum_ptr(d_out, n3 * nwin)
+    # (4) multi-hash: h[0] of the m=4 stream is the m=1 stream
+    n4 = 200_000
+    d_o4 = ctx.malloc(n4 * nwin * 4 * 8)
+    assert ctx.kmer_hash_ptr(d_in, 0, n4, L, 0, k, 4, d_o4, n4 * nwin) == n4 * nwin
+    a = np.zeros(n4 * nwin * 4, np.uint64)
+    ctx.d2h(a, d_o4)
+    b = np.zeros(n4 * nwin, np.uint64)
+    ctx.d2h(b, d_out)
+    a = a.reshape(-1, 4)
+    assert (a[:, 0] == b).all()
+    mult = [(i ^ (31 * 0x90b45d39fb6da1fa)) & (2**64 - 1) for i in range(4)]
+    for i in (1, 2, 3):
+        t = b * np.uint64(mult[i])
+        assert (a[:, i] == (t ^ (t >> np.uint64(27)))).all()
+    for p in (d_in, d_out, d_o2, d_o4):
+        ctx.free(p)
+
+
+def test_strand_symmetry_on_device(ctx, oracle):
+    """canonical hashing (tests/tests.cpp:119-133): a read and its reverse
+    complement give mirrored streams"""
+    n, L, k = 2000, 150, 31
+    data = oracle.synth_reads(0, n, L, 17).reshape(n, L)
+    rcd = np.stack([rc_bytes(r) for r in data])
+    a = ctx.kmer_hash(data.ravel(), k, 3, fixed_len=L, n_reads=n)["hashes"].reshape(n, L - k + 1, 3)
+    b = ctx.kmer_hash(rcd.ravel(), k, 3, fixed_len=L, n_reads=n)["hashes"].reshape(n, L - k + 1, 3)
+    assert (a == b[:, ::-1, :]).all()
+    sa = ctx.seed_hash(data.ravel(), [SEED_A, SEED_B], k, 2, fixed_len=L, n_reads=n)["hashes"]
+    sb = ctx.seed_hash(rcd.ravel(), [SEED_A, SEED_B], k, 2, fixed_len=L, n_reads=n)["hashes"]
+    assert (sa.reshape(n, L - k + 1, 4) == sb.reshape(n, L - k + 1, 4)[:, ::-1, :]).all()
