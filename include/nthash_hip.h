@@ -44,6 +44,7 @@ extern "C" {
 #define NTHIP_HOST_INPUT 0x1u   /* reads.seqs / reads.offsets are host memory */
 #define NTHIP_HOST_OUTPUT 0x2u  /* every non-NULL pointer in nthip_out is host memory */
 #define NTHIP_FORCE_GENERAL 0x4u /* skip the fixed-length fast kernels (testing / A-B) */
+#define NTHIP_FORCE_ROWS 0x8u    /* use the row-per-read fixed-length kernel (testing / A-B) */
 
 typedef struct nthip_ctx nthip_ctx;     /* one device + one stream + scratch */
 typedef struct nthip_seeds nthip_seeds; /* parsed spaced-seed set (device tables) */

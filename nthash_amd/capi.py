@@ -23,6 +23,7 @@ NTHIP_ERR_UNSUPPORTED = -5
 NTHIP_HOST_INPUT = 0x1
 NTHIP_HOST_OUTPUT = 0x2
 NTHIP_FORCE_GENERAL = 0x4
+NTHIP_FORCE_ROWS = 0x8
 
 # every exported symbol of include/nthash_hip.h (kept in sync by tests/test_abi.py)
 SYMBOLS = [

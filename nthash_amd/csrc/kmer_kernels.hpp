@@ -76,6 +76,25 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh
   return __builtin_amdgcn_alignbit(hi, lo, sh); // ({hi,lo} >> (sh & 31))[31:0]
 }
 
+// Split rotates on a (lo, hi) register pair, 5 VALU ops each (the generic
+// 64-bit C++ in nt_math.hpp compiles to ~10 ops with 64-bit shifts).
+//   srol: bits 63..33 rotate left as a 31-bit word, bits 32..0 as a 33-bit word
+__device__ __forceinline__ void srol_pair(uint32_t& lo, uint32_t& hi)
+{
+  const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 31); // (hi << 1) | (lo >> 31)
+  const uint32_t nlo = (lo << 1) | (hi & 1u);               // bit 32 -> bit 0
+  hi = (t & ~2u) | ((hi >> 30) & 2u);                       // bit 63 -> bit 33
+  lo = nlo;
+}
+//   sror: the inverse
+__device__ __forceinline__ void sror_pair(uint32_t& lo, uint32_t& hi)
+{
+  const uint32_t nlo = __builtin_amdgcn_alignbit(hi, lo, 1); // bits 32..1 -> 31..0
+  const uint32_t x = (hi << 30) | (lo & 1u);                 // bit 33 -> bit 63, bit 0 -> bit 32
+  hi = ((hi >> 1) & 0x7FFFFFFEu) | (x & 0x80000001u);
+  lo = nlo;
+}
+
 // word modes of the per-lane rolling loop
 enum : int { W_NOEMIT = 0, W_EMIT = 1, W_BOUNDARY = 2, W_CHECKED = 3 };
 
@@ -157,27 +176,43 @@ __global__ __launch_bounds__(KF_THREADS) void kmer_fixed_kernel(const KmerFixedA
     const uint32_t out_d = ob >> 4, out_sh = (ob & 15u) << 1;
     const uint64_t wave_run0 = run0 + wave * 64u;
 
-    uint64_t f = a.f_init, r = a.r_init;
+    uint32_t f_lo = (uint32_t)a.f_init, f_hi = (uint32_t)(a.f_init >> 32);
+    uint32_t r_lo = (uint32_t)a.r_init, r_hi = (uint32_t)(a.r_init >> 32);
     uint32_t in_lo = bits[in_d], out_lo = bits[out_d];
+    const bool wave_full = wave_run0 + 64u <= a.n_runs;
+    // this lane's slice of the wave's output rows: row R = 8*s + (lane >> 3), 16-byte chunk lane & 7
+    uint64_t* const out_lane = a.hashes + (wave_run0 + (lane >> 3)) * vpr + 2u * (lane & 7u);
+    const uint32_t rd_R = lane >> 3, rd_ch = lane & 7u;
 
-    // write one 128-byte row per lane to global memory: 8 x (64 lanes x 16 B)
+    // write one 128-byte row per lane to global memory: 8 x (64 lanes x 16 B).
+    // All eight LDS reads are issued before the first store so that their
+    // latencies overlap; full waves take the unpredicated path.
     auto flush_row = [&](uint32_t row_v0, uint32_t nvalid) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      uint4 d[8];
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const uint32_t R = (uint32_t)s * 8u + (lane >> 3);
-        const uint32_t ch = lane & 7u;
-        const uint32_t chp = ch ^ (R & 7u);
-        const uint4 d = *(const uint4*)(tile + R * KF_ROW_U64 + 2u * chp);
-        const uint64_t run = wave_run0 + R;
-        uint64_t* dst = a.hashes + run * vpr + row_v0 + 2u * ch;
-        const uint4 o = (s & 1) ? make_uint4(d.z, d.w, d.x, d.y) : d;
-        if (run < a.n_runs) {
-          if (2u * ch + 1u < nvalid) {
-            *(uint4*)dst = o;
-          } else if (2u * ch < nvalid) {
-            *(uint2*)dst = make_uint2(o.x, o.y);
+        const uint32_t R = (uint32_t)s * 8u + rd_R;
+        const uint32_t chp = rd_ch ^ (R & 7u);
+        const uint4 q = *(const uint4*)(tile + R * KF_ROW_U64 + 2u * chp);
+        d[s] = (s & 1) ? make_uint4(q.z, q.w, q.x, q.y) : q;
+      }
+      uint64_t* const dst0 = out_lane + row_v0;
+      if (wave_full && nvalid == 16u) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) *(uint4*)(dst0 + (uint64_t)s * 8u * vpr) = d[s];
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const uint64_t run = wave_run0 + (uint32_t)s * 8u + rd_R;
+          uint64_t* dst = dst0 + (uint64_t)s * 8u * vpr;
+          if (run < a.n_runs) {
+            if (2u * rd_ch + 1u < nvalid) {
+              *(uint4*)dst = d[s];
+            } else if (2u * rd_ch < nvalid) {
+              *(uint2*)dst = make_uint2(d[s].x, d[s].y);
+            }
           }
         }
       }
@@ -186,7 +221,7 @@ __global__ __launch_bounds__(KF_THREADS) void kmer_fixed_kernel(const KmerFixedA
     };
 
     auto emit = [&](uint32_t step, uint32_t i) {
-      const uint64_t h0 = f + r;
+      const uint64_t h0 = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
       const uint32_t p = step - (k - 1u);           // window index inside the run
       const uint32_t pi = (i + 16u - kmod) & 15u;   // == p & 15
       uint64_t tb = 0;
@@ -226,24 +261,35 @@ __global__ __launch_bounds__(KF_THREADS) void kmer_fixed_kernel(const KmerFixedA
       // nibble streams: u = even steps, v = odd steps; nibble = (in<<2)|out
       const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
       const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
-      auto step_fn = [&](uint32_t i) {
+      auto lookup = [&](uint32_t i) -> uint4 {
         const uint32_t src = (i & 1u) ? v : u;
         const uint32_t off = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
-        const uint4 term = *(const uint4*)((const char*)tab + off);
-        f = srol1(f) ^ (((uint64_t)term.y << 32) | term.x);
-        r = sror1(r ^ (((uint64_t)term.w << 32) | term.z));
+        return *(const uint4*)((const char*)tab + off);
+      };
+      auto roll = [&](const uint4 term) {
+        srol_pair(f_lo, f_hi);
+        f_lo ^= term.x;
+        f_hi ^= term.y;
+        r_lo ^= term.z;
+        r_hi ^= term.w;
+        sror_pair(r_lo, r_hi);
       };
       if constexpr (MODE == W_CHECKED) {
         const uint32_t steps = (a.len - s0) < 16u ? (a.len - s0) : 16u;
 #pragma unroll 1
         for (uint32_t i = 0; i < steps; ++i) {
-          step_fn(i);
+          roll(lookup(i));
           if (s0 + i >= k - 1u) emit(s0 + i, i);
         }
       } else {
+        // the 16 table terms do not depend on the hash state: fetch them all
+        // first so their LDS latencies overlap, then run the dependent chain
+        uint4 terms[16];
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i) terms[i] = lookup(i);
 #pragma unroll
         for (uint32_t i = 0; i < 16; ++i) {
-          step_fn(i);
+          roll(terms[i]);
           if constexpr (MODE == W_EMIT) emit(s0 + i, i);
           if constexpr (MODE == W_BOUNDARY) {
             if (i >= kmod) emit(s0 + i, i);

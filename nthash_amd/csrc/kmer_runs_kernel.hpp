@@ -1,0 +1,389 @@
+// kmer_runs_kernel.hpp -- the headline kernel: contiguous k-mer hashing of
+// fixed-length reads with a fully contiguous hash-stream write-out.
+//
+// Why this shape (measured on MI355X, profiles/r01_notes.md): HBM write
+// bandwidth depends on how much contiguous memory one wave writes at a time.
+// 128-byte pieces at a 960-byte stride (one row per read, the first design,
+// kept as kmer_fixed_kernel) reach ~2.9 TB/s; a wave that writes >= 1 KiB
+// contiguous per store instruction reaches ~6 TB/s.  So the unit of work here
+// is a RUN of C consecutive windows inside one read, C | (len-k+1): the 64
+// lanes of a wave own 64 consecutive runs, i.e. 64*C consecutive k-mers of the
+// output stream (7.5 KiB for C=15), staged in a wave-private LDS tile and
+// copied out as one contiguous block.
+//
+// Per lane: the first window of its run is hashed directly with byte-indexed
+// LDS tables (4 bases per lookup, both strands in one 16-byte entry -- the
+// same tables the spaced-seed kernel uses with an all-care mask; this replaces
+// base_forward_hash/base_reverse_hash, src/kmer.cpp:43-73,123-152); the other
+// C-1 windows are rolled (next_forward_hash/next_reverse_hash,
+// src/kmer.cpp:84-94,164-174) with one 16-entry (in,out) pair-table lookup per
+// step.  Waves never synchronise with each other after the tables are loaded:
+// each wave stages its own ~1.2 KB slab of ASCII as a private 2-bit stream,
+// and the loads of the NEXT slab are issued before the current tile is hashed
+// and consumed after its stores have been issued with a counted s_waitcnt
+// (vmcnt is in-order on gfx950: an ordinary load after the stores would make
+// the wave wait for its own stores to be acknowledged).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kmer_kernels.hpp"
+
+namespace ntamd {
+
+constexpr int KR_MAX_THREADS = 1024;
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+struct KmerRunsArgs {
+  const uint8_t* seqs;
+  uint64_t* hashes;      // dense [read][window][m]
+  uint32_t* dirty;
+  const uint4* init_tab; // global [ntab][256] {f.lo,f.hi,r.lo,r.hi}, all-care mask
+  uint64_t n_reads;
+  uint64_t n_runs;       // n_reads * rpr
+  uint64_t n_wtiles;     // ceil(n_runs / 64)
+  uint32_t len, stride, k, m;
+  uint32_t nwin;
+  uint32_t C;            // windows per run, C | nwin
+  uint32_t rpr;          // runs per read = nwin / C
+  uint32_t ntab;         // ceil(k/4)
+  uint32_t waves;        // waves per block
+  uint32_t bits_dwords;  // per-wave bit-stream capacity
+  uint32_t tile_u64;     // per-wave tile capacity (64*C)
+  uint32_t inv_rpr;      // floor(65536 / rpr) + 1
+  uint32_t dword_tail;   // every slab is <= 1280 bytes: tail staged as one dword per lane
+  uint32_t pad0;
+  uint64_t tab[16][2];
+  uint64_t mult[KF_MAX_RUNTIME_M];
+};
+
+// C_T: compile-time run length (0 = runtime); NW: window words, k <= 16*NW;
+// DT: every slab is <= 1280 bytes, so its tail is staged as one dword per lane
+template <int K_T, int M_T, int C_T, int NW, bool DT>
+__global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRunsArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t k = K_T ? (uint32_t)K_T : a.k;
+  const uint32_t m = M_T ? (uint32_t)M_T : a.m;
+  const uint32_t C = C_T ? (uint32_t)C_T : a.C;
+  const uint32_t ntab = K_T ? (uint32_t)((K_T + 3) / 4) : a.ntab;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+
+  // LDS layout: init tables | pair table | multipliers | per-wave {tile, bits}
+  uint4* itab = (uint4*)lds_dyn;
+  uint4* ptab = itab + ntab * 256u;
+  uint64_t* mults = (uint64_t*)(ptab + 16);
+  uint32_t* wave_base = (uint32_t*)(mults + KF_MAX_RUNTIME_M) + wave * (a.tile_u64 * 2u + a.bits_dwords);
+  uint64_t* tile = (uint64_t*)wave_base;
+  uint32_t* bits = wave_base + a.tile_u64 * 2u;
+
+  for (uint32_t i = tid; i < ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
+  if (tid < 16)
+    ptab[tid] = make_uint4((uint32_t)a.tab[tid][0], (uint32_t)(a.tab[tid][0] >> 32),
+                           (uint32_t)a.tab[tid][1], (uint32_t)(a.tab[tid][1] >> 32));
+  if (tid < KF_MAX_RUNTIME_M) mults[tid] = a.mult[tid];
+  __syncthreads(); // the only block-wide barrier
+
+  const uint32_t vals_per_run = C * m;
+  uint32_t bad = 0;
+  // Tile bookkeeping without a 64-bit division per tile: (r_first, rem0) =
+  // divmod(64*wt, rpr) is advanced by the constant divmod(64*wstride, rpr).
+  const uint64_t wstride = (uint64_t)gridDim.x * a.waves;
+  uint64_t wt = (uint64_t)blockIdx.x * a.waves + wave;
+  uint64_t r_first = (wt * 64u) / a.rpr;
+  uint32_t rem0 = (uint32_t)(wt * 64u - r_first * a.rpr);
+  const uint64_t step_q = (wstride * 64u) / a.rpr;
+  const uint32_t step_r = (uint32_t)(wstride * 64u - step_q * a.rpr);
+
+  // slab geometry of the tile whose first run lives in read rf (run rm of it)
+  struct Slab {
+    uint64_t byte0; // offset of the first 16-byte vector from a.seqs (wraps below 0 by < 16)
+    uint32_t shift, slab_bytes, n_vec, runs_here;
+    uint32_t edge; // slab touches the first or the last byte of the caller's buffer
+  };
+  auto slab_of = [&](uint64_t g0, uint64_t rf, uint32_t rm) -> Slab {
+    Slab sl;
+    const uint64_t runs_left = a.n_runs - g0;
+    sl.runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
+    const uint32_t n_slab_reads = (rm + sl.runs_here - 1u) / a.rpr + 1u;
+    const uint64_t off = rf * a.stride;
+    sl.shift = (uint32_t)(((uint64_t)a.seqs + off) & 15u);
+    sl.byte0 = off - sl.shift;
+    sl.slab_bytes = (n_slab_reads - 1u) * a.stride + a.len;
+    sl.n_vec = (sl.shift + sl.slab_bytes + 15u) >> 4;
+    sl.edge = (rf == 0 || rf + n_slab_reads >= a.n_reads) ? 1u : 0u;
+    return sl;
+  };
+  // Pack one 16-byte vector of the slab into the bit stream and judge its bytes.
+  // Bytes of neighbouring reads inside an edge vector are judged too: they are
+  // bytes of this batch, so a non-base there makes the batch dirty anyway.  Only
+  // bytes outside the caller's buffer (before the first read / after the last)
+  // must not be judged; that can only happen in the first and last slab.
+  auto pack_vec = [&](const Slab& sl, uint32_t i, const uint4 v) {
+    uint32_t b = 0;
+    const uint32_t p = pack16(v, b);
+    if (sl.edge) {
+      const int32_t lo_cut = (int32_t)sl.shift - (int32_t)(i << 4);
+      const int32_t hi_cut = (int32_t)(sl.shift + sl.slab_bytes) - (int32_t)(i << 4);
+      if (lo_cut > 0 || hi_cut < 16) {
+        uint32_t bx[4] = {0, 0, 0, 0};
+        (void)pack4(v.x, bx[0]);
+        (void)pack4(v.y, bx[1]);
+        (void)pack4(v.z, bx[2]);
+        (void)pack4(v.w, bx[3]);
+        b = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (q >= lo_cut && q < hi_cut) b |= (bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+      }
+    }
+    bad |= b;
+    bits[i] = p;
+  };
+  // the same for one dword (4 bases -> one byte of the stream): the tail of a slab
+  auto pack_dword = [&](const Slab& sl, uint32_t j, const uint32_t wv) {
+    uint32_t b = 0;
+    const uint32_t p = pack4(wv, b);
+    if (sl.edge) {
+      const int32_t hi_cut = (int32_t)(sl.shift + sl.slab_bytes) - (int32_t)(1024u + (j << 2));
+      uint32_t keep = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < hi_cut) keep |= 0xFFu << (q * 8);
+      b &= keep;
+    }
+    bad |= b;
+    ((uint8_t*)bits)[256u + j] = (uint8_t)p;
+  };
+  // stage vectors [first, n_vec) of a slab with ordinary loads
+  auto stage = [&](const Slab& sl, uint32_t first) {
+    for (uint32_t i = first + lane; i < sl.n_vec; i += 64u)
+      pack_vec(sl, i, *(const uint4*)(a.seqs + sl.byte0 + ((uint64_t)i << 4)));
+    if (lane < (uint32_t)NW + 3u) bits[sl.n_vec + lane] = 0; // funnels read a little ahead
+  };
+  auto lds_sync = [&]() { // LDS is in-order per wave: only the compiler must not reorder
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+
+  Slab cur;
+  cur.byte0 = 0;
+  cur.shift = cur.slab_bytes = cur.n_vec = cur.runs_here = 0;
+  cur.edge = 1u;
+  if (wt < a.n_wtiles) {
+    cur = slab_of(wt * 64u, r_first, rem0);
+    stage(cur, 0u);
+  }
+  for (; wt < a.n_wtiles; wt += wstride) {
+    lds_sync();
+    const uint64_t g0 = wt * 64u;
+    const uint32_t shift = cur.shift, runs_here = cur.runs_here;
+    const uint32_t my_rem0 = rem0;
+    // ---- issue the loads of the NEXT tile's slab (two vectors per lane) --------
+    r_first += step_q;
+    rem0 += step_r;
+    if (rem0 >= a.rpr) { rem0 -= a.rpr; r_first += 1; }
+    const uint64_t nwt = wt + wstride;
+    const bool have_next = nwt < a.n_wtiles;
+    Slab nxt = cur;
+    if (have_next) nxt = slab_of(nwt * 64u, r_first, rem0);
+    // vector `lane` of the slab, plus its tail: slabs of at most 1280 bytes
+    // (a.dword_tail, the common case) finish with ONE DWORD per lane -- a second
+    // 16-byte round would leave most lanes idle --, longer slabs with a second vector
+    v4u pv0, pv1;
+    uint32_t pw;
+    {
+      // lanes without an item re-read item 0 so that every lane issues both loads
+      const uint32_t i0 = lane < nxt.n_vec ? lane : 0u;
+      const uint8_t* p0 = a.seqs + nxt.byte0 + ((uint64_t)i0 << 4);
+      if constexpr (DT) {
+        const uint32_t n_dw = (nxt.shift + nxt.slab_bytes + 3u) >> 2; // dwords in the slab
+        const uint32_t j = 256u + lane < n_dw ? 256u + lane : 0u;
+        const uint8_t* p1 = a.seqs + nxt.byte0 + ((uint64_t)j << 2);
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dword %1, %3, off"
+                     : "=&v"(pv0), "=&v"(pw)
+                     : "v"(p0), "v"(p1)
+                     : "memory");
+      } else {
+        const uint32_t i1 = lane + 64u < nxt.n_vec ? lane + 64u : 0u;
+        const uint8_t* p1 = a.seqs + nxt.byte0 + ((uint64_t)i1 << 4);
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"
+                     : "=&v"(pv0), "=&v"(pv1)
+                     : "v"(p0), "v"(p1)
+                     : "memory");
+      }
+    }
+
+    // ---- this lane's run ----------------------------------------------------
+    const bool live = lane < runs_here;
+    const uint32_t gl = live ? my_rem0 + lane : my_rem0; // run index relative to r_first's run 0
+    const uint32_t lr = (gl * a.inv_rpr) >> 16;           // gl / rpr (gl < 64 + rpr: exact)
+    const uint32_t q = gl - lr * a.rpr;                   // run inside the read
+    const uint32_t b0 = shift + lr * a.stride + q * C;    // first base of the first window
+    const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
+    uint32_t w[NW];
+    {
+      uint32_t lo = bits[d0];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const uint32_t hi = bits[d0 + i + 1];
+        w[i] = funnel(hi, lo, sh0);
+        lo = hi;
+      }
+    }
+    // first window: XOR of per-byte table entries (4 bases per lookup)
+    uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
+#pragma unroll
+    for (int jt = 0; jt < 4 * NW; ++jt) {
+      if ((uint32_t)jt < ntab) {
+        const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+        const uint4 e = itab[(uint32_t)jt * 256u + byte];
+        f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
+      }
+    }
+    uint64_t* my_row = tile + lane * C;
+    my_row[0] = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+
+    // remaining C-1 windows: roll.  step t (1..C-1): in = base b0+k-1+t, out = base b0+t-1
+    const uint32_t bi = b0 + k;
+    const uint32_t di = bi >> 4, shi = (bi & 15u) << 1;
+    auto roll_word = [&](uint32_t jw, auto n_tag) {
+      const uint32_t w_in = funnel(bits[di + jw + 1], bits[di + jw], shi);
+      const uint32_t w_out = funnel(bits[d0 + jw + 1], bits[d0 + jw], sh0);
+      const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
+      const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
+      auto lookup = [&](uint32_t i) -> uint4 {
+        const uint32_t src = (i & 1u) ? v : u;
+        const uint32_t off = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
+        return *(const uint4*)((const char*)ptab + off);
+      };
+      auto roll = [&](const uint4 term) {
+        srol_pair(f_lo, f_hi);
+        f_lo ^= term.x;
+        f_hi ^= term.y;
+        r_lo ^= term.z;
+        r_hi ^= term.w;
+        sror_pair(r_lo, r_hi);
+      };
+      constexpr uint32_t NS = decltype(n_tag)::value; // 0 = runtime count
+      if constexpr (NS != 0) {
+        // table terms do not depend on the hash state: fetch them in batches
+        // ahead of the dependent chain so their LDS latencies overlap
+        constexpr uint32_t B = 8;
+#pragma unroll
+        for (uint32_t i0 = 0; i0 < NS; i0 += B) {
+          uint4 terms[B];
+#pragma unroll
+          for (uint32_t i = 0; i < B; ++i)
+            if (i0 + i < NS) terms[i] = lookup(i0 + i);
+#pragma unroll
+          for (uint32_t i = 0; i < B; ++i) {
+            if (i0 + i < NS) {
+              roll(terms[i]);
+              my_row[jw * 16u + i0 + i + 1u] =
+                  (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+            }
+          }
+        }
+      } else {
+        const uint32_t left = C - 1u - jw * 16u;
+        const uint32_t ns = left < 16u ? left : 16u;
+#pragma unroll 1
+        for (uint32_t i = 0; i < ns; ++i) {
+          roll(lookup(i));
+          my_row[jw * 16u + i + 1u] =
+              (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+        }
+      }
+    };
+    if constexpr (C_T != 0 && C_T <= 17) {
+      if constexpr (C_T > 1) roll_word(0u, std::integral_constant<uint32_t, (uint32_t)(C_T - 1)>{});
+    } else {
+      for (uint32_t jw = 0; jw * 16u + 1u < C; ++jw) roll_word(jw, std::integral_constant<uint32_t, 0u>{});
+    }
+
+    // ---- copy the tile out: 64*C*m consecutive values of the hash stream ------
+    lds_sync();
+    uint64_t* const out0 = a.hashes + g0 * vals_per_run;
+    const uint32_t n_vals = runs_here * vals_per_run;
+    const uint32_t n_pairs = (n_vals + 1u) >> 1;
+    constexpr uint32_t NP = 32u * (uint32_t)(C_T ? C_T : 1); // 16-byte pieces of a full m=1 tile
+    constexpr uint32_t NFULL = NP / 64u, REM = NP % 64u;
+    constexpr uint32_t NST = NFULL + (REM ? 1u : 0u);        // store instructions of a full tile
+    bool counted = false;
+    if (m == 1) {
+      if (C_T != 0 && runs_here == 64u) {
+        // full tile, compile-time shape: all LDS reads first, then the stores
+        // (named registers, not an array: hipcc sends a partially predicated
+        // uint4 array to scratch, whose traffic would also break the counted wait)
+        static_assert(NST <= 8, "flush is written for at most 8 store instructions");
+        const uint4* src = (const uint4*)tile + lane;
+        uint4* dst = (uint4*)out0 + lane;
+        uint4 d0, d1, d2, d3, d4, d5, d6, d7;
+#define KR_LD(n, var) \
+        if constexpr (n < NFULL) var = src[n * 64u]; \
+        else if constexpr (n == NFULL && REM != 0) { if (lane < REM) var = src[n * 64u]; }
+#define KR_ST(n, var) \
+        if constexpr (n < NFULL) dst[n * 64u] = var; \
+        else if constexpr (n == NFULL && REM != 0) { if (lane < REM) dst[n * 64u] = var; }
+        KR_LD(0, d0) KR_LD(1, d1) KR_LD(2, d2) KR_LD(3, d3) KR_LD(4, d4) KR_LD(5, d5) KR_LD(6, d6) KR_LD(7, d7)
+        KR_ST(0, d0) KR_ST(1, d1) KR_ST(2, d2) KR_ST(3, d3) KR_ST(4, d4) KR_ST(5, d5) KR_ST(6, d6) KR_ST(7, d7)
+#undef KR_LD
+#undef KR_ST
+        counted = true;
+      } else {
+        for (uint32_t pi = lane; pi < n_pairs; pi += 64u) {
+          const uint4 dv = *(const uint4*)(tile + 2u * pi);
+          if (2u * pi + 1u < n_vals) *(uint4*)(out0 + 2u * pi) = dv;
+          else *(uint2*)(out0 + 2u * pi) = make_uint2(dv.x, dv.y);
+        }
+      }
+    } else {
+      // multi-hash expansion (extend_hashes, src/internal.hpp:104-118) fused into the
+      // copy-out: the tile holds h[0] only; value v of the stream is h[v % m] of k-mer v / m
+      for (uint32_t pi = lane; pi < n_pairs; pi += 64u) {
+        uint64_t o[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t vi = 2u * pi + (uint32_t)h;
+          const uint32_t e = vi / m, jj = vi - e * m;
+          const uint64_t h0 = tile[e < runs_here * C ? e : 0];
+          o[h] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
+        }
+        if (2u * pi + 1u < n_vals) *(uint4*)(out0 + 2u * pi) =
+            make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
+        else *(uint2*)(out0 + 2u * pi) = make_uint2((uint32_t)o[0], (uint32_t)(o[0] >> 32));
+      }
+    }
+    lds_sync(); // tile and bits are free again
+
+    // ---- consume the prefetched slab ---------------------------------------------
+    // After a counted full tile the only VMEM operations younger than the two
+    // loads are its NST stores: wait until at most NST operations are in flight.
+    if constexpr (DT) {
+      if (counted && NST == 8u) asm volatile("s_waitcnt vmcnt(8)" : "+v"(pv0), "+v"(pw)::"memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv0), "+v"(pw)::"memory");
+    } else {
+      if (counted && NST == 8u) asm volatile("s_waitcnt vmcnt(8)" : "+v"(pv0), "+v"(pv1)::"memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv0), "+v"(pv1)::"memory");
+    }
+    if (have_next) {
+      cur = nxt;
+      if (lane < cur.n_vec) pack_vec(cur, lane, make_uint4(pv0.x, pv0.y, pv0.z, pv0.w));
+      if constexpr (DT) {
+        const uint32_t n_dw = (cur.shift + cur.slab_bytes + 3u) >> 2;
+        if (256u + lane < n_dw) pack_dword(cur, lane, pw);
+        if (lane < (uint32_t)NW + 3u) bits[cur.n_vec + lane] = 0;
+      } else {
+        if (lane + 64u < cur.n_vec) pack_vec(cur, lane + 64u, make_uint4(pv1.x, pv1.y, pv1.z, pv1.w));
+        stage(cur, 128u); // slabs longer than 128 vectors: the rest with ordinary loads
+      }
+    }
+  }
+  if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
+}
+
+} // namespace ntamd

@@ -12,11 +12,14 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
 #include "kmer_kernels.hpp"
+#include "kmer_runs_kernel.hpp"
 #include "nt_math.hpp"
 #include "seed_kernels.hpp"
 #include "util_kernels.hpp"
@@ -73,6 +76,10 @@ struct nthip_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
   const char* last_kernel = "";
+  // blocks per CU of (kernel, dynamic LDS) pairs already configured
+  std::map<std::pair<const void*, size_t>, int> occ_cache;
+  // all-care byte tables for the first window of a run, per k (device memory)
+  std::map<uint32_t, uint4*> init_tabs;
 };
 
 struct nthip_seeds {
@@ -269,16 +276,34 @@ int set_max_lds(K kernel, size_t bytes)
   return NTHIP_OK;
 }
 
+// blocks per CU for a persistent-style grid; the LDS opt-in and the occupancy
+// query are host calls worth ~1 ms, so they are cached per (kernel, LDS size)
+template <typename K>
+int blocks_per_cu(nthip_ctx* c, K kernel, int threads, size_t dyn_lds, int* out)
+{
+  const auto key = std::make_pair(reinterpret_cast<const void*>(kernel), dyn_lds);
+  auto it = c->occ_cache.find(key);
+  if (it == c->occ_cache.end()) {
+    NTCHK(set_max_lds(kernel, dyn_lds));
+    int per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, dyn_lds));
+    if (per_cu < 1) per_cu = 1;
+    it = c->occ_cache.emplace(key, per_cu).first;
+  }
+  *out = it->second;
+  return NTHIP_OK;
+}
+
 template <typename K>
 int launch_kmer_fixed(nthip_ctx* c, K kernel, const KmerFixedArgs& a, size_t dyn_lds)
 {
-  NTCHK(set_max_lds(kernel, dyn_lds));
-  int per_cu = 0;
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, KF_THREADS, dyn_lds));
-  if (per_cu < 1) per_cu = 1;
+  int per_cu = 1;
+  NTCHK(blocks_per_cu(c, kernel, KF_THREADS, dyn_lds, &per_cu));
   uint64_t grid = (uint64_t)c->n_cu * per_cu;
   if (grid > a.n_tiles) grid = a.n_tiles;
+  prof_begin(c, "kmer_fixed_kernel");
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(KF_THREADS), dyn_lds, c->stream, a);
+  prof_end(c);
   HIPCHK(hipGetLastError());
   return NTHIP_OK;
 }
@@ -340,6 +365,7 @@ extern "C" int nthip_ctx_destroy(nthip_ctx* c)
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->d_args) (void)hipFree(c->d_args);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
+  for (auto& kv : c->init_tabs) (void)hipFree(kv.second);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -453,6 +479,96 @@ bool kmer_fixed_eligible(const nthip_ctx* c, uint32_t len, uint32_t stride, uint
   *pad_dwords = pad;
   *dyn_lds = bytes;
   return true;
+}
+
+// byte tables: entry [jt][byte] = XOR over the byte's 4 bases of the rotated seeds
+// of window positions 4jt..4jt+3 (care[p] == 0 drops position p), both strands
+void build_byte_tables(uint32_t k, const uint8_t* care, uint4* out)
+{
+  const uint32_t ntab = (k + 3) / 4;
+  for (uint32_t jt = 0; jt < ntab; ++jt)
+    for (uint32_t byte = 0; byte < 256; ++byte) {
+      uint64_t f = 0, r = 0;
+      for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t p = 4 * jt + q;
+        if (p >= k || (care && !care[p])) continue;
+        const uint32_t code = (byte >> (2 * q)) & 3u;
+        f ^= srol_n(seed_of_code(code), k - 1 - p);
+        r ^= srol_n(seed_of_code(code ^ 2u), p);
+      }
+      out[(size_t)jt * 256 + byte] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+    }
+}
+
+int get_init_tab(nthip_ctx* c, uint32_t k, const uint4** out)
+{
+  auto it = c->init_tabs.find(k);
+  if (it == c->init_tabs.end()) {
+    const uint32_t ntab = (k + 3) / 4;
+    std::vector<uint4> h((size_t)ntab * 256);
+    build_byte_tables(k, nullptr, h.data());
+    uint4* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, h.size() * sizeof(uint4)));
+    HIPCHK(hipMemcpy(d, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    it = c->init_tabs.emplace(k, d).first;
+  }
+  *out = it->second;
+  return NTHIP_OK;
+}
+
+// Plan for the run-split kernel: run length C | nwin, waves per block, LDS bytes.
+struct RunsPlan {
+  uint32_t C = 0, rpr = 0, waves = 0, bits_dwords = 0, tile_u64 = 0, nw = 0, dword_tail = 0;
+  size_t lds = 0;
+};
+
+bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, RunsPlan* p)
+{
+  if (len < k || k > 64 || m > (uint32_t)KF_MAX_RUNTIME_M || stride > len || stride == 0) return false;
+  const uint32_t nwin = len - k + 1;
+  uint32_t best = 0;
+  for (uint32_t d = 16; d >= 4; --d)
+    if (nwin % d == 0) { best = d; break; }
+  if (best < 6)
+    for (uint32_t d = 17; d <= 32; ++d)
+      if (nwin % d == 0) { best = d; break; }
+  if (best == 0) return false;
+  p->C = best;
+  p->rpr = nwin / best;
+  p->nw = (k + 15) / 16;
+  p->tile_u64 = 64 * best;
+  const uint32_t slab_reads = (p->rpr - 1 + 63) / p->rpr + 1;
+  const uint64_t slab_bytes = (uint64_t)(slab_reads - 1) * stride + len;
+  uint32_t bd = (uint32_t)((15 + slab_bytes + 15) >> 4) + p->nw + 4;
+  bd = (bd + 3u) & ~3u;
+  p->bits_dwords = bd;
+  p->dword_tail = (15 + slab_bytes <= 1280) ? 1u : 0u;
+  const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
+  const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4;
+  const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
+  for (uint32_t w = 16; w >= 4; w >>= 1) {
+    if (fixed + per_wave * w <= cap) {
+      p->waves = w;
+      p->lds = fixed + per_wave * w;
+      return true;
+    }
+  }
+  return false;
+}
+
+template <typename K>
+int launch_kmer_runs(nthip_ctx* c, K kernel, const KmerRunsArgs& a, size_t dyn_lds)
+{
+  int per_cu = 1;
+  NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
+  const uint64_t need = (a.n_wtiles + a.waves - 1) / a.waves;
+  uint64_t grid = (uint64_t)c->n_cu * per_cu;
+  if (grid > need) grid = need;
+  prof_begin(c, "kmer_runs_kernel");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
 }
 
 int run_kmer_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m,
@@ -576,12 +692,51 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
     a.n_tiles = (uint32_t)n_tiles;
     fill_kmer_consts(k, m, a);
     HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream));
-    prof_begin(c, "kmer_fixed_kernel");
     int rc;
-    if (k == 31 && m == 1) rc = launch_kmer_fixed(c, kmer_fixed_kernel<31, 1>, a, dyn);
+    RunsPlan plan;
+    const bool rows_only = (flags & NTHIP_FORCE_ROWS) != 0;
+    if (!rows_only && kmer_runs_plan(c, len, stride, k, m, &plan)) {
+      // run-split kernel: contiguous write-out (see kmer_runs_kernel.hpp)
+      KmerRunsArgs ra;
+      memset(&ra, 0, sizeof ra);
+      ra.seqs = st.seqs;
+      ra.hashes = st.hashes;
+      ra.dirty = (uint32_t*)c->d_small;
+      NTCHK(get_init_tab(c, k, &ra.init_tab));
+      ra.n_reads = rd->n_reads;
+      ra.n_runs = rd->n_reads * plan.rpr;
+      ra.n_wtiles = (ra.n_runs + 63) / 64;
+      ra.len = len;
+      ra.stride = stride;
+      ra.k = k;
+      ra.m = m;
+      ra.nwin = nwin;
+      ra.C = plan.C;
+      ra.rpr = plan.rpr;
+      ra.ntab = (k + 3) / 4;
+      ra.waves = plan.waves;
+      ra.bits_dwords = plan.bits_dwords;
+      ra.tile_u64 = plan.tile_u64;
+      ra.inv_rpr = 65536u / plan.rpr + 1u;
+      ra.dword_tail = plan.dword_tail;
+      memcpy(ra.tab, a.tab, sizeof ra.tab);
+      memcpy(ra.mult, a.mult, sizeof ra.mult);
+      // NTHIP_TUNE_NO_DWORD_TAIL=1: A/B switch for the slab-tail staging variant (tools/ablate.py)
+      const char* tune = getenv("NTHIP_TUNE_NO_DWORD_TAIL");
+      const bool dt = plan.dword_tail != 0 && !(tune && tune[0] == '1');
+#define NT_RUNS(KT, MT, CT, NWT) \
+  (dt ? launch_kmer_runs(c, kmer_runs_kernel<KT, MT, CT, NWT, true>, ra, plan.lds) \
+      : launch_kmer_runs(c, kmer_runs_kernel<KT, MT, CT, NWT, false>, ra, plan.lds))
+      if (k == 31 && m == 1 && plan.C == 15) rc = NT_RUNS(31, 1, 15, 2);
+      else if (k == 31 && plan.C == 15) rc = NT_RUNS(31, 0, 15, 2);
+      else if (plan.nw == 1) rc = NT_RUNS(0, 0, 0, 1);
+      else if (plan.nw == 2) rc = NT_RUNS(0, 0, 0, 2);
+      else if (plan.nw == 3) rc = NT_RUNS(0, 0, 0, 3);
+      else rc = NT_RUNS(0, 0, 0, 4);
+#undef NT_RUNS
+    } else if (k == 31 && m == 1) rc = launch_kmer_fixed(c, kmer_fixed_kernel<31, 1>, a, dyn);
     else if (k == 31 && m == 4) rc = launch_kmer_fixed(c, kmer_fixed_kernel<31, 4>, a, dyn);
     else rc = launch_kmer_fixed(c, kmer_fixed_kernel<0, 0>, a, dyn);
-    prof_end(c);
     NTCHK(rc);
     HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -683,19 +838,7 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
     for (uint32_t p = 0; p < k; ++p)
       if (par[p]) care[(size_t)s * cw + (p >> 5)] |= 1u << (p & 31);
     // byte tables: entry = XOR over the byte's 4 bases of the masked rotated seeds
-    for (uint32_t jt = 0; jt < ntab; ++jt)
-      for (uint32_t byte = 0; byte < 256; ++byte) {
-        uint64_t f = 0, r = 0;
-        for (uint32_t q = 0; q < 4; ++q) {
-          const uint32_t p = 4 * jt + q;
-          if (p >= k || !par[p]) continue;
-          const uint32_t code = (byte >> (2 * q)) & 3u;
-          f ^= srol_n(seed_of_code(code), k - 1 - p);
-          r ^= srol_n(seed_of_code(code ^ 2u), p);
-        }
-        tables[((size_t)s * ntab + jt) * 256 + byte] =
-            make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
-      }
+    build_byte_tables(k, par.data(), tables.data() + (size_t)s * ntab * 256);
   }
   if (blk_pairs.empty()) blk_pairs.push_back(0);
   nthip_seeds* sd = new nthip_seeds();
@@ -797,13 +940,13 @@ int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, cons
 template <typename K>
 int launch_seed_fixed(nthip_ctx* c, K kernel, const SeedFixedArgs& a, size_t dyn_lds)
 {
-  NTCHK(set_max_lds(kernel, dyn_lds));
-  int per_cu = 0;
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SF_THREADS, dyn_lds));
-  if (per_cu < 1) per_cu = 1;
+  int per_cu = 1;
+  NTCHK(blocks_per_cu(c, kernel, SF_THREADS, dyn_lds, &per_cu));
   uint64_t grid = (uint64_t)c->n_cu * per_cu;
   if (grid > a.n_tiles) grid = a.n_tiles;
+  prof_begin(c, "seed_fixed_kernel");
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(SF_THREADS), dyn_lds, c->stream, a);
+  prof_end(c);
   HIPCHK(hipGetLastError());
   return NTHIP_OK;
 }
@@ -878,13 +1021,11 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
       a.inv_nwin = (uint32_t)((1ull << 32) / nwin + 1);
       for (uint32_t i = 0; i < (uint32_t)SF_MAX_RUNTIME_M; ++i) a.mult[i] = multiplier(k, i);
       HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream));
-      prof_begin(c, "seed_fixed_kernel");
       int rc;
       if (k <= 16) rc = launch_seed_fixed(c, seed_fixed_kernel<1>, a, dyn);
       else if (k <= 32) rc = launch_seed_fixed(c, seed_fixed_kernel<2>, a, dyn);
       else if (k <= 48) rc = launch_seed_fixed(c, seed_fixed_kernel<3>, a, dyn);
       else rc = launch_seed_fixed(c, seed_fixed_kernel<4>, a, dyn);
-      prof_end(c);
       NTCHK(rc);
       HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));

@@ -109,9 +109,11 @@ def test_kmer_fixed_vs_oracle(ctx, oracle, n, L, k, m):
     assert got["total"] == want["total"] == n * (L - k + 1)
     assert (got["hashes"] == want["hashes"]).all()
     assert (got["counts"] == want["counts"]).all()
-    # the N-aware general kernel must give the same stream
+    # the N-aware general kernel and the row-per-read kernel must give the same stream
     gen = ctx.kmer_hash(data, k, m, fixed_len=L, n_reads=n, flags=4, want_pos=True, want_strands=True)
     assert (gen["hashes"] == want["hashes"]).all()
+    rows = ctx.kmer_hash(data, k, m, fixed_len=L, n_reads=n, flags=8)
+    assert (rows["hashes"] == want["hashes"]).all()
 
 
 def test_kmer_fixed_unaligned_base_pointer(ctx, oracle):
@@ -241,7 +243,7 @@ def test_kmer_argument_errors(ctx):
     (300, 150, ["1" * 31], 4),
     (300, 130, ["1111111111111110111111111111111"], 2),   # ignore-path description
     (200, 200, [("1101" * 8) + ("1101" * 8)[::-1]], 2),          # k = 64 (NW = 4)
-    (129, 90, ["10" * 24 + "01" * 24], 1),     # k = 96 > 64: general kernel
+    (129, 150, ["10" * 24 + "01" * 24], 1),    # k = 96 > 64: general kernel
 ])
 def test_seed_fixed_vs_oracle(ctx, oracle, n, L, seeds, m2):
     k = len(seeds[0])

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Within-process interleaved A/B timing of kernel variants (HIP-event kernel time).
+
+    python tools/ablate.py [reads] [variant,variant,...] [rounds]
+variants: runs (default kernel), runs_vec (NTHIP_TUNE_NO_DWORD_TAIL=1), rows (flag 8), general (flag 4)
+"""
+import os, sys, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import nthash_amd
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
+variants = (sys.argv[2] if len(sys.argv) > 2 else "runs,runs_vec,rows").split(",")
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+L, k, m = 150, 31, 1
+nwin = L - k + 1
+ctx = nthash_amd.Context(0)
+d_in = ctx.malloc(n * L); d_out = ctx.malloc(n * nwin * m * 8)
+ctx.synth_reads_ptr(d_in, 0, n, L, 42)
+ctx.set_profiling(True)
+gb = n * nwin * (8 * m + L / nwin) / 1e9
+res = {v: [] for v in variants}
+for rnd in range(rounds):
+    for v in variants:
+        os.environ["NTHIP_TUNE_NO_DWORD_TAIL"] = "1" if v == "runs_vec" else "0"
+        flags = 8 if v == "rows" else 4 if v == "general" else 0
+        ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin, flags=flags)
+        ms, name = ctx.last_kernel_ms()
+        res[v].append(ms)
+for v in variants:
+    t = res[v][2:] or res[v]
+    med, mn = statistics.median(t), min(t)
+    print(f"{v:9s} median {med:.3f} ms ({gb/med:.0f} GB/s alg, {n*nwin/med/1e6:.1f} Gkmer/s)  min {mn:.3f} ms ({gb/mn:.0f} GB/s)")

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Workload for rocprofv3 --pmc passes: one calibration copy of known size
+(so FETCH_SIZE / WRITE_SIZE can be calibrated as MI355X_MICROARCH.md asks) and
+then the hot kernels on a reduced batch.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python tools/pmc_probe.py [c2|c3|c4] [reads]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import nthash_amd  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000_000
+SEEDS = ["1010101010101010101010101010101", "1101101101101101011011011011011"]
+L, k, m, seeds = {"c2": (150, 31, 1, None), "c3": (150, 31, 4, None), "c4": (250, 31, 3, SEEDS)}[cfg]
+per = m if seeds is None else len(seeds) * m
+nwin = L - k + 1
+ctx = nthash_amd.Context(0)
+COPY = 4 << 30
+a = ctx.malloc(COPY)
+b = ctx.malloc(COPY)
+ctx.synth_reads_ptr(a, 0, COPY // 128, 128, 1)
+print("copy 4GiB ms:", ctx.copy_bench_ptr(b, a, COPY, 2))
+ctx.free(a)
+ctx.free(b)
+d_in = ctx.malloc(n * L)
+d_out = ctx.malloc(n * nwin * per * 8)
+ctx.synth_reads_ptr(d_in, 0, n, L, 42)
+ctx.set_profiling(True)
+sd = nthash_amd.Seeds(ctx, seeds, k) if seeds else None
+for _ in range(3):
+    if sd is None:
+        ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin)
+    else:
+        ctx.seed_hash_ptr(d_in, 0, n, L, 0, sd, m, d_out, n * nwin)
+    print("kernel ms:", ctx.last_kernel_ms(), "algorithmic GB:", n * nwin * (8 * per + L / nwin) / 1e9)
