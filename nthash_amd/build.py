@@ -42,8 +42,8 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
               "-Wno-pass-failed", f"-I{os.path.join(ROOT, 'include')}"]
-    hip_deps = _sources("nthip_capi.hip", "kmer_kernels.hpp", "seed_kernels.hpp", "util_kernels.hpp",
-                        "nt_math.hpp") + [os.path.join(ROOT, "include", "nthash_hip.h")]
+    hip_deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))] + \
+        [os.path.join(ROOT, "include", "nthash_hip.h")]
     if force or _newer(HIP_SO, hip_deps):
         cmd = common + [os.path.join(CSRC, "nthip_capi.hip"), "-o", HIP_SO]
         if verbose:

@@ -60,9 +60,9 @@ __device__ __forceinline__ uint32_t pack4(uint32_t w, uint32_t& bad)
   x = x & ~ubit;                                // 'u'(0x75) -> 't'(0x74)
   const uint32_t canon = __builtin_amdgcn_perm(0u, 0x67746361u, t); // a,c,t,g by code
   bad |= x ^ canon;
-  // gather the four 2-bit fields (at bits 0,8,16,24) into one byte
-  const uint32_t lo = (t & 0x00FFFFFFu) * 0x00010410u; // f0<<16 | f1<<18 | f2<<20
-  return ((lo >> 16) & 0x3Fu) | ((t >> 24) << 6);
+  // gather the four 2-bit fields (one per byte of t) into one byte:
+  // f0 + 4*f1 + 16*f2 + 64*f3 is a single 4-way byte dot product
+  return __builtin_amdgcn_udot4(t, 0x40100401u, 0u, false);
 }
 
 __device__ __forceinline__ uint32_t pack16(uint4 v, uint32_t& bad)

@@ -52,7 +52,7 @@ struct KmerRunsArgs {
   uint32_t tile_u64;     // per-wave tile capacity (64*C)
   uint32_t inv_rpr;      // floor(65536 / rpr) + 1
   uint32_t dword_tail;   // every slab is <= 1280 bytes: tail staged as one dword per lane
-  uint32_t pad0;
+  uint32_t tile_map;     // number of wave groups of the tile -> wave mapping (see the kernel)
   uint64_t tab[16][2];
   uint64_t mult[KF_MAX_RUNTIME_M];
 };
@@ -90,8 +90,27 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
   uint32_t bad = 0;
   // Tile bookkeeping without a 64-bit division per tile: (r_first, rem0) =
   // divmod(64*wt, rpr) is advanced by the constant divmod(64*wstride, rpr).
-  const uint64_t wstride = (uint64_t)gridDim.x * a.waves;
-  uint64_t wt = (uint64_t)blockIdx.x * a.waves + wave;
+  // tile -> wave mapping: the waves of the grid are split into a.tile_map groups
+  // of consecutive waves; every group owns one contiguous range of tiles and its
+  // waves interleave inside it (0/1 = one group = plain grid stride; one group
+  // per block measured best: each CU then streams through its own region)
+  uint64_t wt, wstride, wt_end;
+  {
+    const uint64_t n_waves_total = (uint64_t)gridDim.x * a.waves;
+    const uint64_t gw = (uint64_t)blockIdx.x * a.waves + wave;
+    uint64_t groups = a.tile_map ? a.tile_map : 1u;
+    if (groups > n_waves_total) groups = n_waves_total;
+    const uint64_t wpg = n_waves_total / groups;           // waves per group (last group may be larger)
+    uint64_t g = gw / wpg;
+    if (g >= groups) g = groups - 1;
+    const uint64_t w_in_g = gw - g * wpg;
+    const uint64_t g_waves = g == groups - 1 ? n_waves_total - g * wpg : wpg;
+    const uint64_t per = (a.n_wtiles + groups - 1) / groups; // tiles per group
+    const uint64_t t0 = g * per;
+    wt = t0 + w_in_g;
+    wstride = g_waves;
+    wt_end = t0 + per < a.n_wtiles ? t0 + per : a.n_wtiles;
+  }
   uint64_t r_first = (wt * 64u) / a.rpr;
   uint32_t rem0 = (uint32_t)(wt * 64u - r_first * a.rpr);
   const uint64_t step_q = (wstride * 64u) / a.rpr;
@@ -173,11 +192,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
   cur.byte0 = 0;
   cur.shift = cur.slab_bytes = cur.n_vec = cur.runs_here = 0;
   cur.edge = 1u;
-  if (wt < a.n_wtiles) {
+  if (wt < wt_end) {
     cur = slab_of(wt * 64u, r_first, rem0);
     stage(cur, 0u);
   }
-  for (; wt < a.n_wtiles; wt += wstride) {
+  for (; wt < wt_end; wt += wstride) {
     lds_sync();
     const uint64_t g0 = wt * 64u;
     const uint32_t shift = cur.shift, runs_here = cur.runs_here;
@@ -187,7 +206,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
     rem0 += step_r;
     if (rem0 >= a.rpr) { rem0 -= a.rpr; r_first += 1; }
     const uint64_t nwt = wt + wstride;
-    const bool have_next = nwt < a.n_wtiles;
+    const bool have_next = nwt < wt_end;
     Slab nxt = cur;
     if (have_next) nxt = slab_of(nwt * 64u, r_first, rem0);
     // vector `lane` of the slab, plus its tail: slabs of at most 1280 bytes

@@ -537,7 +537,8 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
   p->rpr = nwin / best;
   p->nw = (k + 15) / 16;
   p->tile_u64 = 64 * best;
-  const uint32_t slab_reads = (p->rpr - 1 + 63) / p->rpr + 1;
+  // reads touched by one wave tile (64 consecutive runs)
+  const uint32_t slab_reads = (64 % p->rpr == 0) ? 64 / p->rpr : (p->rpr - 1 + 63) / p->rpr + 1;
   const uint64_t slab_bytes = (uint64_t)(slab_reads - 1) * stride + len;
   uint32_t bd = (uint32_t)((15 + slab_bytes + 15) >> 4) + p->nw + 4;
   bd = (bd + 3u) & ~3u;
@@ -557,13 +558,14 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
 }
 
 template <typename K>
-int launch_kmer_runs(nthip_ctx* c, K kernel, const KmerRunsArgs& a, size_t dyn_lds)
+int launch_kmer_runs(nthip_ctx* c, K kernel, KmerRunsArgs a, size_t dyn_lds)
 {
   int per_cu = 1;
   NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
   const uint64_t need = (a.n_wtiles + a.waves - 1) / a.waves;
   uint64_t grid = (uint64_t)c->n_cu * per_cu;
   if (grid > need) grid = need;
+  if (a.tile_map == 0xFFFFFFFFu) a.tile_map = (uint32_t)grid; // every block streams its own range
   prof_begin(c, "kmer_runs_kernel");
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
   prof_end(c);
@@ -719,6 +721,8 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
       ra.tile_u64 = plan.tile_u64;
       ra.inv_rpr = 65536u / plan.rpr + 1u;
       ra.dword_tail = plan.dword_tail;
+      // one tile group per block (set in launch_kmer_runs); NTHIP_TUNE_TILE_MAP overrides for A/B runs
+      { const char* t2 = getenv("NTHIP_TUNE_TILE_MAP"); ra.tile_map = t2 ? (uint32_t)atoi(t2) : 0xFFFFFFFFu; }
       memcpy(ra.tab, a.tab, sizeof ra.tab);
       memcpy(ra.mult, a.mult, sizeof ra.mult);
       // NTHIP_TUNE_NO_DWORD_TAIL=1: A/B switch for the slab-tail staging variant (tools/ablate.py)

@@ -22,6 +22,10 @@ res = {v: [] for v in variants}
 for rnd in range(rounds):
     for v in variants:
         os.environ["NTHIP_TUNE_NO_DWORD_TAIL"] = "1" if v == "runs_vec" else "0"
+        if v.startswith("map"):
+            os.environ["NTHIP_TUNE_TILE_MAP"] = v[3:]
+        else:
+            os.environ.pop("NTHIP_TUNE_TILE_MAP", None)
         flags = 8 if v == "rows" else 4 if v == "general" else 0
         ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin, flags=flags)
         ms, name = ctx.last_kernel_ms()
