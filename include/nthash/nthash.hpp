@@ -1,0 +1,262 @@
+// include/nthash/nthash.hpp -- nthash_amd's C++ host API.
+//
+// Drop-in for the public header of bcgsc/ntHash 2.4.0
+// (reference: include/nthash/nthash.hpp): the same namespace, class names,
+// constructor and method signatures, argument meaning, return values and error
+// behaviour (misuse prints "[ntHash::<Class>] ERROR: ..." and exits with status
+// 1, reference src/internal.hpp:16-22), so code written against the reference --
+// including its own tests/tests.cpp and examples/*.cpp -- compiles against this
+// header unchanged and links with libnthash.so (nthash_amd/lib).
+//
+// What is different is underneath.  NtHash::roll() and SeedNtHash::roll() do
+// not roll a scalar state on the CPU: the first roll() hashes the WHOLE sequence
+// on the MI355X through the C-ABI (include/nthash_hip.h: nthip_kmer_hash /
+// nthip_seed_hash) and every roll() then steps through that device-computed
+// stream.  There is no CPU fallback for this path: without a HIP device the
+// first roll() reports the error and exits, like any other misuse.  The calls
+// that cannot be batched -- roll_back(), the peek*() family and the Blind*
+// classes, which hash ONE caller-chosen base per call -- evaluate the O(1)
+// recurrence on the host (reference src/kmer.cpp:84-194, src/seed.cpp:177-425).
+//
+// For throughput use the batch C-ABI directly (one call per read set, device
+// pointers in and out); this iterator API is the compatibility boundary.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <string>
+#include <sys/types.h>
+#include <vector>
+
+namespace nthash {
+
+// reference: include/nthash/nthash.hpp:18
+static const char* const NTHASH_FN_NAME = "ntHash_v2";
+
+// reference: include/nthash/nthash.hpp:24-29
+namespace typedefs {
+using NUM_HASHES_TYPE = uint8_t;
+using K_TYPE = uint16_t;
+using SpacedSeedBlocks = std::vector<std::array<unsigned, 2>>;
+using SpacedSeedMonomers = std::vector<unsigned>;
+} // namespace typedefs
+
+class NtHash;
+class BlindNtHash;
+class SeedNtHash;
+class BlindSeedNtHash;
+
+// Seed patterns -> lists of don't-care positions (reference nthash.hpp:59-60)
+std::vector<std::vector<unsigned>>
+parse_seeds(const std::vector<std::string>& seed_strings);
+
+namespace detail {
+struct KmerStream; // device-computed hash stream of one sequence (opaque)
+struct SeedStream;
+struct SeedSet;    // parsed seeds: blocks, monomers, masks (host) + device tables
+} // namespace detail
+
+// ---------------------------------------------------------------------------
+// Contiguous k-mer hashing (reference nthash.hpp:62-211, src/kmer.cpp:200-336)
+// ---------------------------------------------------------------------------
+class NtHash
+{
+public:
+  NtHash(const char* seq,
+         size_t seq_len,
+         typedefs::NUM_HASHES_TYPE num_hashes,
+         typedefs::K_TYPE k,
+         size_t pos = 0);
+  NtHash(const std::string& seq,
+         typedefs::NUM_HASHES_TYPE num_hashes,
+         typedefs::K_TYPE k,
+         size_t pos = 0)
+    : NtHash(seq.data(), seq.size(), num_hashes, k, pos)
+  {
+  }
+  NtHash(const NtHash& obj);
+  NtHash(NtHash&&) noexcept;
+  ~NtHash();
+
+  bool roll();
+  bool roll_back();
+  bool peek();
+  bool peek_back();
+  bool peek(char char_in);
+  bool peek_back(char char_in);
+
+  const uint64_t* hashes() const { return hash_arr_.get(); }
+  size_t get_pos() const { return pos_; }
+  typedefs::NUM_HASHES_TYPE get_hash_num() const { return num_hashes_; }
+  typedefs::K_TYPE get_k() const { return k_; }
+  uint64_t get_forward_hash() const { return fwd_; }
+  uint64_t get_reverse_hash() const { return rev_; }
+
+private:
+  const char* seq_;
+  size_t len_;
+  typedefs::NUM_HASHES_TYPE num_hashes_;
+  typedefs::K_TYPE k_;
+  size_t pos_;
+  bool initialized_;
+  uint64_t fwd_ = 0;
+  uint64_t rev_ = 0;
+  std::unique_ptr<uint64_t[]> hash_arr_;
+  std::shared_ptr<detail::KmerStream> stream_; // shared by copies, immutable once built
+  size_t cursor_ = 0;                          // last stream entry used (search hint)
+
+  bool init();
+  bool load_from_stream();
+};
+
+// ---------------------------------------------------------------------------
+// Caller-fed k-mer hashing (reference nthash.hpp:213-311, src/kmer.cpp:338-393)
+// ---------------------------------------------------------------------------
+class BlindNtHash
+{
+public:
+  BlindNtHash(const char* seq,
+              typedefs::NUM_HASHES_TYPE num_hashes,
+              typedefs::K_TYPE k,
+              ssize_t pos = 0);
+  BlindNtHash(const BlindNtHash& obj);
+  BlindNtHash(BlindNtHash&&) = default;
+
+  void roll(char char_in);
+  void roll_back(char char_in);
+  void peek(char char_in);
+  void peek_back(char char_in);
+
+  const uint64_t* hashes() const { return hash_arr_.get(); }
+  ssize_t get_pos() const { return pos_; }
+  typedefs::NUM_HASHES_TYPE get_hash_num() const { return num_hashes_; }
+  typedefs::K_TYPE get_k() const { return (typedefs::K_TYPE)window_.size(); }
+  uint64_t get_forward_hash() const { return fwd_; }
+  uint64_t get_reverse_hash() const { return rev_; }
+
+private:
+  std::deque<char> window_;
+  typedefs::NUM_HASHES_TYPE num_hashes_;
+  ssize_t pos_;
+  uint64_t fwd_ = 0;
+  uint64_t rev_ = 0;
+  std::unique_ptr<uint64_t[]> hash_arr_;
+};
+
+// ---------------------------------------------------------------------------
+// Spaced-seed hashing (reference nthash.hpp:313-521, src/seed.cpp:449-667)
+// ---------------------------------------------------------------------------
+class SeedNtHash
+{
+public:
+  SeedNtHash(const char* seq,
+             size_t seq_len,
+             const std::vector<std::string>& seeds,
+             typedefs::NUM_HASHES_TYPE num_hashes_per_seed,
+             typedefs::K_TYPE k,
+             size_t pos = 0);
+  SeedNtHash(const std::string& seq,
+             const std::vector<std::string>& seeds,
+             typedefs::NUM_HASHES_TYPE num_hashes_per_seed,
+             typedefs::K_TYPE k,
+             size_t pos = 0)
+    : SeedNtHash(seq.data(), seq.size(), seeds, num_hashes_per_seed, k, pos)
+  {
+  }
+  SeedNtHash(const char* seq,
+             size_t seq_len,
+             const std::vector<std::vector<unsigned>>& seeds,
+             typedefs::NUM_HASHES_TYPE num_hashes_per_seed,
+             typedefs::K_TYPE k,
+             size_t pos = 0);
+  SeedNtHash(const std::string& seq,
+             const std::vector<std::vector<unsigned>>& seeds,
+             typedefs::NUM_HASHES_TYPE num_hashes_per_seed,
+             typedefs::K_TYPE k,
+             size_t pos = 0)
+    : SeedNtHash(seq.data(), seq.size(), seeds, num_hashes_per_seed, k, pos)
+  {
+  }
+  SeedNtHash(const SeedNtHash& obj);
+  SeedNtHash(SeedNtHash&&) noexcept;
+  ~SeedNtHash();
+
+  bool roll();
+  bool roll_back();
+  bool peek();
+  bool peek_back();
+  bool peek(char char_in);
+  bool peek_back(char char_in);
+
+  const uint64_t* hashes() const { return hash_arr_.get(); }
+  size_t get_pos() const { return pos_; }
+  unsigned get_hash_num() const { return num_hashes_per_seed_ * n_seeds_; }
+  typedefs::NUM_HASHES_TYPE get_hash_num_per_seed() const { return num_hashes_per_seed_; }
+  typedefs::K_TYPE get_k() const { return k_; }
+  uint64_t* get_forward_hash() const { return fwd_.get(); }
+  uint64_t* get_reverse_hash() const { return rev_.get(); }
+
+private:
+  const char* seq_;
+  size_t len_;
+  typedefs::NUM_HASHES_TYPE num_hashes_per_seed_;
+  typedefs::K_TYPE k_;
+  size_t pos_;
+  size_t pos0_; // where the device stream starts (constructor's pos)
+  bool initialized_;
+  unsigned n_seeds_;
+  std::shared_ptr<detail::SeedSet> seeds_;
+  std::unique_ptr<uint64_t[]> fwd_;
+  std::unique_ptr<uint64_t[]> rev_;
+  std::unique_ptr<uint64_t[]> hash_arr_;
+  std::shared_ptr<detail::SeedStream> stream_;
+  size_t cursor_ = 0;
+
+  bool init(bool from_roll);
+  void set_window(const char* win, bool try_stream);
+  void hash_backward(bool commit);
+};
+
+// ---------------------------------------------------------------------------
+// Caller-fed spaced-seed hashing (reference nthash.hpp:523-646, src/seed.cpp:669-737)
+// ---------------------------------------------------------------------------
+class BlindSeedNtHash
+{
+public:
+  BlindSeedNtHash(const char* seq,
+                  const std::vector<std::string>& seeds,
+                  typedefs::NUM_HASHES_TYPE num_hashes_per_seed,
+                  typedefs::K_TYPE k,
+                  ssize_t pos = 0);
+  BlindSeedNtHash(const BlindSeedNtHash& seed_nthash);
+  BlindSeedNtHash(BlindSeedNtHash&&) = default;
+
+  void roll(char char_in);
+  void roll_back(char char_in);
+
+  const uint64_t* hashes() const { return hash_arr_.get(); }
+  ssize_t get_pos() const { return pos_; }
+  unsigned get_hash_num() const { return num_hashes_per_seed_ * n_seeds_; }
+  typedefs::NUM_HASHES_TYPE get_hash_num_per_seed() const { return num_hashes_per_seed_; }
+  typedefs::K_TYPE get_k() const { return k_; }
+  uint64_t* get_forward_hash() const { return fwd_.get(); }
+  uint64_t* get_reverse_hash() const { return rev_.get(); }
+
+private:
+  std::deque<char> window_;
+  typedefs::NUM_HASHES_TYPE num_hashes_per_seed_;
+  typedefs::K_TYPE k_;
+  ssize_t pos_;
+  unsigned n_seeds_;
+  std::shared_ptr<detail::SeedSet> seeds_;
+  std::unique_ptr<uint64_t[]> fwd_;
+  std::unique_ptr<uint64_t[]> rev_;
+  std::unique_ptr<uint64_t[]> hash_arr_;
+
+  void rehash();
+};
+
+} // namespace nthash

@@ -69,8 +69,9 @@ typedef struct {
   uint64_t capacity; /* in k-mers */
   uint64_t* counts;  /* optional: n_reads values, emitted k-mers per read */
   uint32_t* pos;     /* optional: capacity values, get_pos() of each emitted k-mer */
-  uint64_t* fwd;     /* optional (k-mer hashing only): capacity values */
-  uint64_t* rev;     /* optional (k-mer hashing only): capacity values */
+  uint64_t* fwd;     /* optional: forward-strand hash(es) of each emitted k-mer: capacity values
+                        (k-mer hashing) or capacity * n_seeds values, seed-minor (seed hashing) */
+  uint64_t* rev;     /* optional: reverse-strand hash(es), same layout */
 } nthip_out;
 
 /* ---- library / context -------------------------------------------------- */
@@ -123,7 +124,8 @@ int nthip_seeds_destroy(nthip_seeds* seeds);
  *     nthash::SeedNtHash h(seq_r, len_r, seeds, m2, k); // src/seed.cpp:449-471
  *     while (h.roll()) emit(h.hashes()[0..n_seeds*m2)); // src/seed.cpp:518-544
  * produces, including the reference's position state machine on reads with
- * non-ACGTU characters.  out->fwd / out->rev must be NULL.
+ * non-ACGTU characters.  out->fwd / out->rev (optional)
+ * receive SeedNtHash::get_forward_hash() / get_reverse_hash(): n_seeds values per k-mer.
  */
 int nthip_seed_hash(nthip_ctx* ctx, const nthip_reads* reads, const nthip_seeds* seeds,
                     uint8_t m2, const nthip_out* out, uint64_t* total, uint32_t flags);

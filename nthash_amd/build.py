@@ -49,17 +49,19 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    # the C++ host facade is plain host C++17 on top of the C-ABI
     facade_src = os.path.join(CSRC, "nthash_facade.cpp")
-    if os.path.exists(facade_src):
-        deps = [facade_src, os.path.join(CSRC, "nt_math.hpp"),
-                os.path.join(ROOT, "include", "nthash", "nthash.hpp"), HIP_SO]
-        if force or _newer(FACADE_SO, deps):
-            cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "c++",
-                   f"-I{os.path.join(ROOT, 'include')}", facade_src, "-o", FACADE_SO,
-                   f"-L{LIB}", "-lnthash_hip", "-Wl,-rpath,$ORIGIN"]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+    deps = [facade_src, os.path.join(CSRC, "nt_math.hpp"), os.path.join(CSRC, "seed_parse.hpp"),
+            os.path.join(ROOT, "include", "nthash", "nthash.hpp"),
+            os.path.join(ROOT, "include", "nthash_hip.h"), HIP_SO]
+    if force or _newer(FACADE_SO, deps):
+        cxx = shutil.which("g++") or shutil.which("c++") or hipcc
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+               f"-I{os.path.join(ROOT, 'include')}", facade_src, "-o", FACADE_SO,
+               f"-L{LIB}", "-lnthash_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
     return HIP_SO
 
 

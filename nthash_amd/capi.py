@@ -198,9 +198,9 @@ class Context:
         return total.value
 
     def seed_hash_ptr(self, seqs, offsets, n_reads, fixed_len, stride, seeds, m2, hashes, capacity,
-                      counts=0, pos=0, flags=0):
+                      counts=0, pos=0, flags=0, fwd=0, rev=0):
         rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
-        out = Out(hashes, capacity, counts or None, pos or None, None, None)
+        out = Out(hashes, capacity, counts or None, pos or None, fwd or None, rev or None)
         total = C.c_uint64(0)
         rc = self.L.nthip_seed_hash(self.h, C.byref(rd), seeds.h, m2, C.byref(out), C.byref(total), flags)
         if rc != NTHIP_OK:
@@ -258,7 +258,7 @@ class Context:
         return out
 
     def seed_hash(self, data, seeds, k, m2, offsets=None, fixed_len=0, stride=0, n_reads=None,
-                  want_pos=False, want_counts=True, flags=0):
+                  want_pos=False, want_counts=True, want_strands=False, flags=0):
         data = np.ascontiguousarray(data, dtype=np.uint8)
         if offsets is not None:
             offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -269,10 +269,16 @@ class Context:
         hashes = np.zeros(cap * per, np.uint64)
         counts = np.zeros(max(n_reads, 1), np.uint64) if want_counts else None
         pos = np.zeros(cap, np.uint32) if want_pos else None
+        fwd = np.zeros(cap * sd.n, np.uint64) if want_strands else None
+        rev = np.zeros(cap * sd.n, np.uint64) if want_strands else None
         p = lambda a: a.ctypes.data if a is not None else 0
         total = self.seed_hash_ptr(p(data), p(offsets), n_reads, fixed_len, stride, sd, m2, p(hashes), cap,
-                                   p(counts), p(pos), flags | NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT)
+                                   p(counts), p(pos), flags | NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT,
+                                   p(fwd), p(rev))
         out = {"total": total, "hashes": hashes[: total * per].reshape(total, per)}
+        if want_strands:
+            out["fwd"] = fwd[: total * sd.n].reshape(total, sd.n)
+            out["rev"] = rev[: total * sd.n].reshape(total, sd.n)
         if want_counts:
             out["counts"] = counts[:n_reads]
         if want_pos:

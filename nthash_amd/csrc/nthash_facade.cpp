@@ -1,0 +1,738 @@
+// nthash_facade.cpp -- libnthash.so: the C++ iterator classes of
+// include/nthash/nthash.hpp on top of the C-ABI (include/nthash_hip.h).
+//
+// Position logic (which window comes next, what is skipped) follows the
+// reference's state machines exactly and runs on the host, because it only
+// inspects characters.  Hash VALUES for roll() come from the device: the first
+// roll() hashes the whole sequence with one nthip_*_hash call and roll() then
+// steps through that stream.  roll_back()/peek*() and the Blind* classes hash a
+// single caller-chosen base per call and evaluate the recurrence on the host
+// with the shared arithmetic of nt_math.hpp.
+#include "nthash/nthash.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <mutex>
+
+#include "nt_math.hpp"
+#include "nthash_hip.h"
+#include "seed_parse.hpp"
+
+namespace nthash {
+
+using namespace ntamd;
+
+namespace {
+
+// reference: raise_warning / raise_error, src/internal.hpp:9-22
+void raise_warning(const std::string& cls, const std::string& msg)
+{
+  std::cerr << "[ntHash::" << cls << "] \33[33mWARNING: \33[0m" << msg << std::endl;
+}
+[[noreturn]] void raise_error(const std::string& cls, const std::string& msg)
+{
+  std::cerr << "[ntHash::" << cls << "] \33[31mERROR: \33[0m" << msg << std::endl;
+  std::exit(1);
+}
+
+std::mutex g_dev_mutex; // one context, serialised calls
+
+nthip_ctx* device_ctx(const char* cls)
+{
+  static nthip_ctx* ctx = nullptr;
+  if (!ctx) {
+    int dev = 0;
+    if (const char* e = std::getenv("NTHASH_AMD_DEVICE")) dev = std::atoi(e);
+    if (nthip_ctx_create(dev, &ctx) != NTHIP_OK)
+      raise_error(cls, std::string("GPU hashing unavailable: ") + nthip_last_error());
+  }
+  return ctx;
+}
+
+inline bool valid_base(char c) { return is_base((unsigned char)c); }
+
+// the O(1) recurrences (reference src/kmer.cpp:84-114, 164-194)
+inline uint64_t next_fwd(uint64_t f, unsigned k, unsigned char out, unsigned char in)
+{
+  return srol1(f) ^ fwd_seed(in) ^ srol_n(fwd_seed(out), k);
+}
+inline uint64_t next_rev(uint64_t r, unsigned k, unsigned char out, unsigned char in)
+{
+  return sror1(r ^ srol_n(rc_seed(in), k) ^ rc_seed(out));
+}
+inline uint64_t prev_fwd(uint64_t f, unsigned k, unsigned char out, unsigned char in)
+{
+  return sror1(f ^ srol_n(fwd_seed(in), k) ^ fwd_seed(out));
+}
+inline uint64_t prev_rev(uint64_t r, unsigned k, unsigned char out, unsigned char in)
+{
+  return srol1(r) ^ rc_seed(in) ^ srol_n(rc_seed(out), k);
+}
+
+// reference: extend_hashes, src/internal.hpp:104-118
+inline void extend(uint64_t f, uint64_t r, unsigned k, unsigned m, uint64_t* h)
+{
+  h[0] = f + r;
+  for (unsigned i = 1; i < m; ++i) h[i] = mix_hash(h[0], multiplier(k, i));
+}
+
+} // namespace
+
+// ===========================================================================
+// device-computed streams
+// ===========================================================================
+namespace detail {
+
+struct KmerStream {
+  std::vector<uint32_t> pos;
+  std::vector<uint64_t> fwd, rev, hashes; // hashes: m per entry
+  unsigned m = 0;
+  // index of the entry at position p, or npos
+  size_t find(size_t p, size_t hint) const
+  {
+    if (hint < pos.size() && pos[hint] == p) return hint;
+    if (hint + 1 < pos.size() && pos[hint + 1] == p) return hint + 1;
+    auto it = std::lower_bound(pos.begin(), pos.end(), (uint32_t)p);
+    return (it != pos.end() && *it == p) ? (size_t)(it - pos.begin()) : (size_t)-1;
+  }
+};
+
+struct SeedSet {
+  std::vector<std::string> strings;
+  std::vector<SeedShape> shapes;
+  unsigned k = 0;
+  nthip_seeds* dev = nullptr;
+  ~SeedSet()
+  {
+    if (dev) nthip_seeds_destroy(dev);
+  }
+};
+
+struct SeedStream {
+  std::vector<uint32_t> pos;
+  std::vector<uint64_t> fwd, rev, hashes; // fwd/rev: n_seeds per entry; hashes: n_seeds*m2
+  size_t find(size_t p, size_t hint) const
+  {
+    if (hint < pos.size() && pos[hint] == p) return hint;
+    if (hint + 1 < pos.size() && pos[hint + 1] == p) return hint + 1;
+    auto it = std::lower_bound(pos.begin(), pos.end(), (uint32_t)p);
+    return (it != pos.end() && *it == p) ? (size_t)(it - pos.begin()) : (size_t)-1;
+  }
+};
+
+} // namespace detail
+
+namespace {
+
+std::shared_ptr<detail::KmerStream> build_kmer_stream(const char* seq, size_t len, unsigned k, unsigned m)
+{
+  auto st = std::make_shared<detail::KmerStream>();
+  st->m = m;
+  const size_t cap = len - k + 1;
+  st->pos.resize(cap);
+  st->fwd.resize(cap);
+  st->rev.resize(cap);
+  st->hashes.resize(cap * m);
+  std::lock_guard<std::mutex> lock(g_dev_mutex);
+  nthip_ctx* ctx = device_ctx("NtHash");
+  const uint64_t offsets[2] = { 0, (uint64_t)len };
+  nthip_reads rd = { seq, offsets, 1, 0, 0 };
+  nthip_out out = { st->hashes.data(), cap, nullptr, st->pos.data(), st->fwd.data(), st->rev.data() };
+  uint64_t total = 0;
+  if (nthip_kmer_hash(ctx, &rd, (uint16_t)k, (uint8_t)m, &out, &total, NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT) !=
+      NTHIP_OK)
+    raise_error("NtHash", std::string("GPU hashing failed: ") + nthip_last_error());
+  st->pos.resize(total);
+  st->fwd.resize(total);
+  st->rev.resize(total);
+  st->hashes.resize(total * m);
+  return st;
+}
+
+std::shared_ptr<detail::SeedStream> build_seed_stream(const char* seq, size_t len, size_t pos0,
+                                                      detail::SeedSet& seeds, unsigned m2)
+{
+  auto st = std::make_shared<detail::SeedStream>();
+  const unsigned k = seeds.k, ns = (unsigned)seeds.strings.size();
+  const size_t sub = len - pos0;
+  const size_t cap = sub - k + 1;
+  st->pos.resize(cap);
+  st->fwd.resize(cap * ns);
+  st->rev.resize(cap * ns);
+  st->hashes.resize(cap * ns * m2);
+  std::lock_guard<std::mutex> lock(g_dev_mutex);
+  nthip_ctx* ctx = device_ctx("SeedNtHash");
+  if (!seeds.dev) {
+    std::vector<const char*> ptrs;
+    for (const auto& s : seeds.strings) ptrs.push_back(s.c_str());
+    if (nthip_seeds_create(ctx, ptrs.data(), ns, (uint16_t)k, &seeds.dev, nullptr) != NTHIP_OK)
+      raise_error("SeedNtHash", std::string("GPU seed set-up failed: ") + nthip_last_error());
+  }
+  const uint64_t offsets[2] = { 0, (uint64_t)sub };
+  nthip_reads rd = { seq + pos0, offsets, 1, 0, 0 };
+  nthip_out out = { st->hashes.data(), cap, nullptr, st->pos.data(), st->fwd.data(), st->rev.data() };
+  uint64_t total = 0;
+  if (nthip_seed_hash(ctx, &rd, seeds.dev, (uint8_t)m2, &out, &total, NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT) !=
+      NTHIP_OK)
+    raise_error("SeedNtHash", std::string("GPU hashing failed: ") + nthip_last_error());
+  st->pos.resize(total);
+  for (auto& p : st->pos) p += (uint32_t)pos0;
+  st->fwd.resize(total * ns);
+  st->rev.resize(total * ns);
+  st->hashes.resize(total * ns * m2);
+  return st;
+}
+
+// Hash of one window for one seed (reference src/seed.cpp:130-207).  The
+// reference keeps a blocks-only state and adds the monomers on every call, and
+// its backward / peek flavours read the two parts from DIFFERENT windows (see
+// the callers), so the block-covered positions and the monomer positions take
+// their characters from two accessors.  With blk_at == mono_at this is the
+// masked direct formula F = XOR_{p in care} srol^{k-1-p}(S[c_p]).
+template <typename BlkAt, typename MonoAt>
+void seed_window_hash(const SeedShape& sh, unsigned k, BlkAt blk_at, MonoAt mono_at, uint64_t* f, uint64_t* r)
+{
+  auto fterm = [&](unsigned p) {
+    return (sh.blk_parity[p] ? fwd_seed((unsigned char)blk_at(p)) : 0) ^
+           (sh.is_mono[p] ? fwd_seed((unsigned char)mono_at(p)) : 0);
+  };
+  auto rterm = [&](unsigned p) {
+    return (sh.blk_parity[p] ? rc_seed((unsigned char)blk_at(p)) : 0) ^
+           (sh.is_mono[p] ? rc_seed((unsigned char)mono_at(p)) : 0);
+  };
+  uint64_t fh = 0, rh = 0;
+  for (unsigned p = 0; p < k; ++p) fh = srol1(fh) ^ fterm(p);
+  for (unsigned p = k; p-- > 0;) rh = srol1(rh) ^ rterm(p);
+  *f = fh;
+  *r = rh;
+}
+
+std::shared_ptr<detail::SeedSet> make_seed_set(const std::vector<std::string>& seeds, unsigned k)
+{
+  auto ss = std::make_shared<detail::SeedSet>();
+  ss->k = k;
+  ss->strings = seeds;
+  for (const auto& s : seeds) ss->shapes.push_back(parse_seed_shape(s));
+  return ss;
+}
+
+// reference: check_seeds, src/seed.cpp:85-104
+void check_seeds(const std::vector<std::string>& seeds, unsigned k)
+{
+  for (const auto& seed : seeds) {
+    if (seed.length() != k)
+      raise_error("SeedNtHash", "Spaced seed string length (" + std::to_string(seed.length()) +
+                                  ") not equal to k=" + std::to_string(k) + " in " + seed);
+    if (!seed_is_symmetric(seed))
+      raise_warning("SeedNtHash",
+                    "Seed " + seed + " is not symmetric, reverse-complement hashing will be inconsistent");
+  }
+}
+
+} // namespace
+
+// reference: parse_seeds, src/seed.cpp:431-447
+std::vector<std::vector<unsigned>>
+parse_seeds(const std::vector<std::string>& seed_strings)
+{
+  std::vector<std::vector<unsigned>> out;
+  for (const auto& s : seed_strings) {
+    std::vector<unsigned> dont_care;
+    for (unsigned p = 0; p < s.size(); ++p)
+      if (s[p] != '1') dont_care.push_back(p);
+    out.push_back(dont_care);
+  }
+  return out;
+}
+
+// ===========================================================================
+// NtHash
+// ===========================================================================
+NtHash::NtHash(const char* seq, size_t seq_len, typedefs::NUM_HASHES_TYPE num_hashes, typedefs::K_TYPE k,
+               size_t pos)
+  : seq_(seq)
+  , len_(seq_len)
+  , num_hashes_(num_hashes)
+  , k_(k)
+  , pos_(pos)
+  , initialized_(false)
+  , hash_arr_(new uint64_t[num_hashes ? num_hashes : 1]())
+{
+  // reference: src/kmer.cpp:212-225
+  if (k == 0) raise_error("NtHash", "k must be greater than 0");
+  if (len_ < k)
+    raise_error("NtHash", "sequence length (" + std::to_string(len_) + ") is smaller than k (" +
+                            std::to_string(k) + ")");
+  if (pos > len_ - k)
+    raise_error("NtHash", "passed position (" + std::to_string(pos) + ") is larger than sequence length (" +
+                            std::to_string(len_) + ")");
+}
+
+NtHash::NtHash(const NtHash& o)
+  : seq_(o.seq_)
+  , len_(o.len_)
+  , num_hashes_(o.num_hashes_)
+  , k_(o.k_)
+  , pos_(o.pos_)
+  , initialized_(o.initialized_)
+  , fwd_(o.fwd_)
+  , rev_(o.rev_)
+  , hash_arr_(new uint64_t[o.num_hashes_ ? o.num_hashes_ : 1])
+  , stream_(o.stream_)
+  , cursor_(o.cursor_)
+{
+  std::memcpy(hash_arr_.get(), o.hash_arr_.get(), (num_hashes_ ? num_hashes_ : 1) * sizeof(uint64_t));
+}
+
+NtHash::NtHash(NtHash&&) noexcept = default;
+NtHash::~NtHash() = default;
+
+// take fwd/rev/hashes of the window at pos_ from the device stream
+bool NtHash::load_from_stream()
+{
+  if (!stream_) stream_ = build_kmer_stream(seq_, len_, k_, num_hashes_);
+  const size_t i = stream_->find(pos_, cursor_);
+  if (i == (size_t)-1) return false;
+  cursor_ = i;
+  fwd_ = stream_->fwd[i];
+  rev_ = stream_->rev[i];
+  std::memcpy(hash_arr_.get(), stream_->hashes.data() + i * num_hashes_, num_hashes_ * sizeof(uint64_t));
+  return true;
+}
+
+// reference: NtHash::init, src/kmer.cpp:228-244.  The skip loop only looks at
+// characters; index len_ (one past the view, which the reference may read) is
+// treated as a terminator, i.e. not a base.
+bool NtHash::init()
+{
+  auto window_invalid = [&](size_t at, size_t& bad) {
+    for (size_t i = k_; i-- > 0;) {
+      const size_t idx = at + i;
+      if (idx >= len_ || !valid_base(seq_[idx])) {
+        bad = i;
+        return true;
+      }
+    }
+    return false;
+  };
+  size_t bad = 0;
+  while (pos_ <= len_ - k_ + 1 && window_invalid(pos_, bad)) pos_ += bad + 1;
+  if (pos_ > len_ - k_) return false;
+  if (!load_from_stream())
+    raise_error("NtHash", "internal error: valid window missing from the device stream");
+  initialized_ = true;
+  return true;
+}
+
+// reference: NtHash::roll, src/kmer.cpp:246-264
+bool NtHash::roll()
+{
+  if (!initialized_) return init();
+  if (pos_ >= len_ - k_) return false;
+  if (!valid_base(seq_[pos_ + k_])) {
+    pos_ += k_;
+    return init();
+  }
+  ++pos_;
+  if (!load_from_stream())
+    raise_error("NtHash", "internal error: valid window missing from the device stream");
+  return true;
+}
+
+// reference: NtHash::roll_back, src/kmer.cpp:266-287
+bool NtHash::roll_back()
+{
+  if (!initialized_) return init();
+  if (pos_ == 0) return false;
+  const char in = seq_[pos_ - 1];
+  if (!valid_base(in) && pos_ >= k_) {
+    pos_ -= k_;
+    return init();
+  }
+  if (!valid_base(in)) return false;
+  const unsigned char out = (unsigned char)seq_[pos_ + k_ - 1];
+  fwd_ = prev_fwd(fwd_, k_, out, (unsigned char)in);
+  rev_ = prev_rev(rev_, k_, out, (unsigned char)in);
+  extend(fwd_, rev_, k_, num_hashes_, hash_arr_.get());
+  --pos_;
+  return true;
+}
+
+// reference: NtHash::peek*, src/kmer.cpp:289-336
+bool NtHash::peek()
+{
+  if (pos_ >= len_ - k_) return false;
+  return peek(seq_[pos_ + k_]);
+}
+
+bool NtHash::peek(char char_in)
+{
+  if (!initialized_) return init();
+  if (!valid_base(char_in)) return false;
+  const unsigned char out = (unsigned char)seq_[pos_];
+  extend(next_fwd(fwd_, k_, out, (unsigned char)char_in), next_rev(rev_, k_, out, (unsigned char)char_in), k_,
+         num_hashes_, hash_arr_.get());
+  return true;
+}
+
+bool NtHash::peek_back()
+{
+  if (pos_ == 0) return false;
+  return peek_back(seq_[pos_ - 1]);
+}
+
+bool NtHash::peek_back(char char_in)
+{
+  if (!initialized_) return init();
+  if (!valid_base(char_in)) return false;
+  const unsigned char out = (unsigned char)seq_[pos_ + k_ - 1];
+  extend(prev_fwd(fwd_, k_, out, (unsigned char)char_in), prev_rev(rev_, k_, out, (unsigned char)char_in), k_,
+         num_hashes_, hash_arr_.get());
+  return true;
+}
+
+// ===========================================================================
+// BlindNtHash (reference src/kmer.cpp:338-393): one caller-chosen base per call
+// ===========================================================================
+BlindNtHash::BlindNtHash(const char* seq, typedefs::NUM_HASHES_TYPE num_hashes, typedefs::K_TYPE k, ssize_t pos)
+  : window_(seq + pos, seq + pos + k)
+  , num_hashes_(num_hashes)
+  , pos_(pos)
+  , hash_arr_(new uint64_t[num_hashes ? num_hashes : 1]())
+{
+  if (k == 0) raise_error("BlindNtHash", "k must be greater than 0");
+  // the reference hashes seq[0..k) while its window holds seq[pos..pos+k)
+  // (src/kmer.cpp:342 vs :350-351) -- reproduced
+  fwd_ = direct_fwd(seq, k);
+  rev_ = direct_rev(seq, k);
+  extend(fwd_, rev_, k, num_hashes_, hash_arr_.get());
+}
+
+BlindNtHash::BlindNtHash(const BlindNtHash& o)
+  : window_(o.window_)
+  , num_hashes_(o.num_hashes_)
+  , pos_(o.pos_)
+  , fwd_(o.fwd_)
+  , rev_(o.rev_)
+  , hash_arr_(new uint64_t[o.num_hashes_ ? o.num_hashes_ : 1])
+{
+  std::memcpy(hash_arr_.get(), o.hash_arr_.get(), (num_hashes_ ? num_hashes_ : 1) * sizeof(uint64_t));
+}
+
+void BlindNtHash::roll(char char_in)
+{
+  const unsigned k = (unsigned)window_.size();
+  fwd_ = next_fwd(fwd_, k, (unsigned char)window_.front(), (unsigned char)char_in);
+  rev_ = next_rev(rev_, k, (unsigned char)window_.front(), (unsigned char)char_in);
+  extend(fwd_, rev_, k, num_hashes_, hash_arr_.get());
+  window_.pop_front();
+  window_.push_back(char_in);
+  ++pos_;
+}
+
+void BlindNtHash::roll_back(char char_in)
+{
+  const unsigned k = (unsigned)window_.size();
+  fwd_ = prev_fwd(fwd_, k, (unsigned char)window_.back(), (unsigned char)char_in);
+  rev_ = prev_rev(rev_, k, (unsigned char)window_.back(), (unsigned char)char_in);
+  extend(fwd_, rev_, k, num_hashes_, hash_arr_.get());
+  window_.pop_back();
+  window_.push_front(char_in);
+  --pos_;
+}
+
+void BlindNtHash::peek(char char_in)
+{
+  const unsigned k = (unsigned)window_.size();
+  extend(next_fwd(fwd_, k, (unsigned char)window_.front(), (unsigned char)char_in),
+         next_rev(rev_, k, (unsigned char)window_.front(), (unsigned char)char_in), k, num_hashes_,
+         hash_arr_.get());
+}
+
+void BlindNtHash::peek_back(char char_in)
+{
+  const unsigned k = (unsigned)window_.size();
+  extend(prev_fwd(fwd_, k, (unsigned char)window_.back(), (unsigned char)char_in),
+         prev_rev(rev_, k, (unsigned char)window_.back(), (unsigned char)char_in), k, num_hashes_,
+         hash_arr_.get());
+}
+
+// ===========================================================================
+// SeedNtHash
+// ===========================================================================
+SeedNtHash::SeedNtHash(const char* seq, size_t seq_len, const std::vector<std::string>& seeds,
+                       typedefs::NUM_HASHES_TYPE num_hashes_per_seed, typedefs::K_TYPE k, size_t pos)
+  : seq_(seq)
+  , len_(seq_len)
+  , num_hashes_per_seed_(num_hashes_per_seed)
+  , k_(k)
+  , pos_(pos)
+  , pos0_(pos)
+  , initialized_(false)
+  , n_seeds_((unsigned)seeds.size())
+  , fwd_(new uint64_t[seeds.size() ? seeds.size() : 1]())
+  , rev_(new uint64_t[seeds.size() ? seeds.size() : 1]())
+  , hash_arr_(new uint64_t[std::max<size_t>(1, (size_t)num_hashes_per_seed * seeds.size())]())
+{
+  // reference: src/seed.cpp:466-470
+  check_seeds(seeds, k);
+  if (seeds.empty() || seeds[0].size() != k)
+    raise_error("SeedNtHash", "k should be equal to seed string lengths");
+  seeds_ = make_seed_set(seeds, k);
+}
+
+SeedNtHash::SeedNtHash(const char* seq, size_t seq_len, const std::vector<std::vector<unsigned>>& seeds,
+                       typedefs::NUM_HASHES_TYPE num_hashes_per_seed, typedefs::K_TYPE k, size_t pos)
+  : seq_(seq)
+  , len_(seq_len)
+  , num_hashes_per_seed_(num_hashes_per_seed)
+  , k_(k)
+  , pos_(pos)
+  , pos0_(pos)
+  , initialized_(false)
+  , n_seeds_((unsigned)seeds.size())
+  , fwd_(new uint64_t[seeds.size() ? seeds.size() : 1]())
+  , rev_(new uint64_t[seeds.size() ? seeds.size() : 1]())
+  , hash_arr_(new uint64_t[std::max<size_t>(1, (size_t)num_hashes_per_seed * seeds.size())]())
+{
+  // reference: parsed_seeds_to_blocks, src/seed.cpp:68-83 (no check_seeds on this path)
+  std::vector<std::string> strings;
+  for (const auto& dont_care : seeds) {
+    std::string s(k, '1');
+    for (unsigned p : dont_care) s[p] = '0';
+    strings.push_back(s);
+  }
+  seeds_ = make_seed_set(strings, k);
+}
+
+SeedNtHash::SeedNtHash(const SeedNtHash& o)
+  : seq_(o.seq_)
+  , len_(o.len_)
+  , num_hashes_per_seed_(o.num_hashes_per_seed_)
+  , k_(o.k_)
+  , pos_(o.pos_)
+  , pos0_(o.pos0_)
+  , initialized_(o.initialized_)
+  , n_seeds_(o.n_seeds_)
+  , seeds_(o.seeds_)
+  , fwd_(new uint64_t[o.n_seeds_ ? o.n_seeds_ : 1])
+  , rev_(new uint64_t[o.n_seeds_ ? o.n_seeds_ : 1])
+  , hash_arr_(new uint64_t[o.get_hash_num() ? o.get_hash_num() : 1])
+  , stream_(o.stream_)
+  , cursor_(o.cursor_)
+{
+  std::memcpy(fwd_.get(), o.fwd_.get(), n_seeds_ * sizeof(uint64_t));
+  std::memcpy(rev_.get(), o.rev_.get(), n_seeds_ * sizeof(uint64_t));
+  std::memcpy(hash_arr_.get(), o.hash_arr_.get(), get_hash_num() * sizeof(uint64_t));
+}
+
+SeedNtHash::SeedNtHash(SeedNtHash&&) noexcept = default;
+SeedNtHash::~SeedNtHash() = default;
+
+// hashes of the window `win` (k characters).  A window of the sequence itself
+// is taken from the device stream when the stream holds it.
+void SeedNtHash::set_window(const char* win, bool try_stream)
+{
+  if (try_stream && win >= seq_ && win + k_ <= seq_ + len_) {
+    if (!stream_) stream_ = build_seed_stream(seq_, len_, pos0_, *seeds_, num_hashes_per_seed_);
+    const size_t p = (size_t)(win - seq_);
+    const size_t i = stream_->find(p, cursor_);
+    if (i != (size_t)-1) {
+      cursor_ = i;
+      std::memcpy(fwd_.get(), stream_->fwd.data() + i * n_seeds_, n_seeds_ * sizeof(uint64_t));
+      std::memcpy(rev_.get(), stream_->rev.data() + i * n_seeds_, n_seeds_ * sizeof(uint64_t));
+      std::memcpy(hash_arr_.get(), stream_->hashes.data() + i * get_hash_num(),
+                  get_hash_num() * sizeof(uint64_t));
+      return;
+    }
+  }
+  for (unsigned s = 0; s < n_seeds_; ++s) {
+    auto at = [&](unsigned i) { return win[i]; };
+    seed_window_hash(seeds_->shapes[s], k_, at, at, &fwd_[s], &rev_[s]);
+    extend(fwd_[s], rev_[s], k_, num_hashes_per_seed_, hash_arr_.get() + (size_t)s * num_hashes_per_seed_);
+  }
+}
+
+// reference: SeedNtHash::init, src/seed.cpp:493-516 -- the first-window routine
+// fails on the first NUL met while walking seeds -> blocks -> positions
+bool SeedNtHash::init(bool from_roll)
+{
+  auto first_nul = [&](const char* win, unsigned& where) {
+    for (const auto& sh : seeds_->shapes)
+      for (size_t b = 0; b + 1 < sh.block_pairs.size(); b += 2)
+        for (uint32_t p = sh.block_pairs[b]; p < sh.block_pairs[b + 1]; ++p)
+          if (win[p] == 0) {
+            where = p;
+            return true;
+          }
+    return false;
+  };
+  unsigned where = 0;
+  while (pos_ < len_ - k_ + 1 && first_nul(seq_ + pos_, where)) pos_ += where + 1;
+  if (pos_ > len_ - k_) return false;
+  set_window(seq_ + pos_, from_roll);
+  initialized_ = true;
+  return true;
+}
+
+// reference: SeedNtHash::roll, src/seed.cpp:518-544
+bool SeedNtHash::roll()
+{
+  if (!initialized_) return init(true);
+  if (pos_ >= len_ - k_) return false;
+  if (!valid_base(seq_[pos_ + k_])) {
+    pos_ += k_;
+    return init(true);
+  }
+  ++pos_;
+  set_window(seq_ + pos_, true);
+  return true;
+}
+
+// reference: SeedNtHash::roll_back, src/seed.cpp:546-575
+bool SeedNtHash::roll_back()
+{
+  if (!initialized_) return init(false);
+  if (pos_ == 0) return false;
+  if (!valid_base(seq_[pos_ - 1]) && pos_ >= k_) {
+    pos_ -= k_;
+    return init(false);
+  }
+  if (!valid_base(seq_[pos_ - 1])) return false;
+  --pos_;
+  hash_backward(true);
+  return true;
+}
+
+// The reference's backward flavour (ntmsm64l, src/seed.cpp:293-333) rolls the
+// blocks-only state back correctly but then adds the monomers with the forward
+// macro's index `kmer_seq[pos + 1]` (src/seed.cpp:195-198), i.e. from the window
+// it came FROM.  Block-covered positions therefore see the window at pos_,
+// monomer positions the window at pos_ + 1.  Reproduced bit for bit.
+void SeedNtHash::hash_backward(bool commit)
+{
+  const char* nw = seq_ + pos_;
+  for (unsigned s = 0; s < n_seeds_; ++s) {
+    uint64_t f, r;
+    seed_window_hash(seeds_->shapes[s], k_, [&](unsigned i) { return nw[i]; },
+                     [&](unsigned i) { return nw[i + 1]; }, &f, &r);
+    if (commit) {
+      fwd_[s] = f;
+      rev_[s] = r;
+    }
+    extend(f, r, k_, num_hashes_per_seed_, hash_arr_.get() + (size_t)s * num_hashes_per_seed_);
+  }
+}
+
+// reference: SeedNtHash::peek*, src/seed.cpp:577-667 (state is not advanced;
+// unlike NtHash::peek(char), the character is not validated)
+bool SeedNtHash::peek()
+{
+  if (pos_ >= len_ - k_) return false;
+  return peek(seq_[pos_ + k_]);
+}
+
+// Forward peek (src/seed.cpp:356-379): blocks take char_in at the new last
+// position; monomers are read from the sequence itself (`kmer_seq[pos + 1]`),
+// so a monomer at position k-1 sees seq[pos+k], not char_in.
+bool SeedNtHash::peek(char char_in)
+{
+  if (!initialized_) return init(false);
+  const char* nw = seq_ + pos_ + 1;
+  for (unsigned s = 0; s < n_seeds_; ++s) {
+    uint64_t f, r;
+    seed_window_hash(
+      seeds_->shapes[s], k_, [&](unsigned i) { return i + 1 < k_ ? nw[i] : char_in; },
+      [&](unsigned i) { return pos_ + 1 + i < len_ ? nw[i] : '\0'; }, &f, &r);
+    extend(f, r, k_, num_hashes_per_seed_, hash_arr_.get() + (size_t)s * num_hashes_per_seed_);
+  }
+  return true;
+}
+
+bool SeedNtHash::peek_back()
+{
+  if (pos_ == 0) return false;
+  return peek_back(seq_[pos_ - 1]);
+}
+
+// Backward peek (src/seed.cpp:402-425): the guard `i_in > k - 1` copied from the
+// forward flavour never fires for i_in = block[0], so char_in is not used at
+// all: the result is that of roll_back() on the sequence, state untouched.
+bool SeedNtHash::peek_back(char /*char_in*/)
+{
+  if (!initialized_) return init(false);
+  --pos_;
+  hash_backward(false);
+  ++pos_;
+  return true;
+}
+
+// ===========================================================================
+// BlindSeedNtHash (reference src/seed.cpp:669-737)
+// ===========================================================================
+BlindSeedNtHash::BlindSeedNtHash(const char* seq, const std::vector<std::string>& seeds,
+                                 typedefs::NUM_HASHES_TYPE num_hashes_per_seed, typedefs::K_TYPE k, ssize_t pos)
+  : window_(seq + pos, seq + pos + k)
+  , num_hashes_per_seed_(num_hashes_per_seed)
+  , k_(k)
+  , pos_(pos)
+  , n_seeds_((unsigned)seeds.size())
+  , fwd_(new uint64_t[seeds.size() ? seeds.size() : 1]())
+  , rev_(new uint64_t[seeds.size() ? seeds.size() : 1]())
+  , hash_arr_(new uint64_t[std::max<size_t>(1, (size_t)num_hashes_per_seed * seeds.size())]())
+{
+  check_seeds(seeds, k);
+  seeds_ = make_seed_set(seeds, k);
+  rehash();
+}
+
+BlindSeedNtHash::BlindSeedNtHash(const BlindSeedNtHash& o)
+  : window_(o.window_)
+  , num_hashes_per_seed_(o.num_hashes_per_seed_)
+  , k_(o.k_)
+  , pos_(o.pos_)
+  , n_seeds_(o.n_seeds_)
+  , seeds_(o.seeds_)
+  , fwd_(new uint64_t[o.n_seeds_ ? o.n_seeds_ : 1])
+  , rev_(new uint64_t[o.n_seeds_ ? o.n_seeds_ : 1])
+  , hash_arr_(new uint64_t[o.get_hash_num() ? o.get_hash_num() : 1])
+{
+  std::memcpy(fwd_.get(), o.fwd_.get(), n_seeds_ * sizeof(uint64_t));
+  std::memcpy(rev_.get(), o.rev_.get(), n_seeds_ * sizeof(uint64_t));
+  std::memcpy(hash_arr_.get(), o.hash_arr_.get(), get_hash_num() * sizeof(uint64_t));
+}
+
+// hashes of the current window_ (its first k_ characters)
+void BlindSeedNtHash::rehash()
+{
+  for (unsigned s = 0; s < n_seeds_; ++s) {
+    auto at = [&](unsigned i) { return window_[i]; };
+    seed_window_hash(seeds_->shapes[s], k_, at, at, &fwd_[s], &rev_[s]);
+    extend(fwd_[s], rev_[s], k_, num_hashes_per_seed_, hash_arr_.get() + (size_t)s * num_hashes_per_seed_);
+  }
+}
+
+void BlindSeedNtHash::roll(char char_in)
+{
+  window_.push_back(char_in);
+  window_.pop_front();
+  rehash();
+  ++pos_;
+}
+
+// backward flavour: monomers from the window being left (see SeedNtHash::hash_backward)
+void BlindSeedNtHash::roll_back(char char_in)
+{
+  window_.push_front(char_in); // k+1 characters: [0,k) new window, [1,k] old window
+  for (unsigned s = 0; s < n_seeds_; ++s) {
+    seed_window_hash(seeds_->shapes[s], k_, [&](unsigned i) { return window_[i]; },
+                     [&](unsigned i) { return window_[i + 1]; }, &fwd_[s], &rev_[s]);
+    extend(fwd_[s], rev_[s], k_, num_hashes_per_seed_, hash_arr_.get() + (size_t)s * num_hashes_per_seed_);
+  }
+  window_.pop_back();
+  --pos_;
+}
+
+} // namespace nthash

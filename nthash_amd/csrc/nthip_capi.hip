@@ -22,6 +22,7 @@
 #include "kmer_runs_kernel.hpp"
 #include "nt_math.hpp"
 #include "seed_kernels.hpp"
+#include "seed_parse.hpp"
 #include "util_kernels.hpp"
 
 using namespace ntamd;
@@ -190,7 +191,7 @@ int stage_inputs(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, uint64_t t
 }
 
 int stage_outputs(nthip_ctx* c, const nthip_out* out, uint32_t flags, uint64_t n_reads, uint32_t per,
-                  Staged& st)
+                  Staged& st, uint32_t strands_per = 1)
 {
   (void)c;
   if (flags & NTHIP_HOST_OUTPUT) {
@@ -202,8 +203,8 @@ int stage_outputs(nthip_ctx* c, const nthip_out* out, uint32_t flags, uint64_t n
     NTCHK(alloc(out->capacity * per * sizeof(uint64_t), (void**)&st.hashes));
     if (out->counts) NTCHK(alloc(n_reads * sizeof(uint64_t), (void**)&st.counts));
     if (out->pos) NTCHK(alloc(out->capacity * sizeof(uint32_t), (void**)&st.pos));
-    if (out->fwd) NTCHK(alloc(out->capacity * sizeof(uint64_t), (void**)&st.fwd));
-    if (out->rev) NTCHK(alloc(out->capacity * sizeof(uint64_t), (void**)&st.rev));
+    if (out->fwd) NTCHK(alloc(out->capacity * strands_per * sizeof(uint64_t), (void**)&st.fwd));
+    if (out->rev) NTCHK(alloc(out->capacity * strands_per * sizeof(uint64_t), (void**)&st.rev));
   } else {
     st.hashes = out->hashes;
     st.counts = out->counts;
@@ -215,7 +216,7 @@ int stage_outputs(nthip_ctx* c, const nthip_out* out, uint32_t flags, uint64_t n
 }
 
 int unstage_outputs(nthip_ctx* c, const nthip_out* out, uint32_t flags, uint64_t n_reads, uint32_t per,
-                    uint64_t total, const Staged& st)
+                    uint64_t total, const Staged& st, uint32_t strands_per = 1)
 {
   if (!(flags & NTHIP_HOST_OUTPUT)) return NTHIP_OK;
   if (total) {
@@ -224,9 +225,11 @@ int unstage_outputs(nthip_ctx* c, const nthip_out* out, uint32_t flags, uint64_t
     if (out->pos)
       HIPCHK(hipMemcpyAsync(out->pos, st.pos, total * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     if (out->fwd)
-      HIPCHK(hipMemcpyAsync(out->fwd, st.fwd, total * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(out->fwd, st.fwd, total * strands_per * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                            c->stream));
     if (out->rev)
-      HIPCHK(hipMemcpyAsync(out->rev, st.rev, total * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(out->rev, st.rev, total * strands_per * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                            c->stream));
   }
   if (out->counts && n_reads)
     HIPCHK(hipMemcpyAsync(out->counts, st.counts, n_reads * sizeof(uint64_t), hipMemcpyDeviceToHost,
@@ -769,44 +772,6 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
 // ==========================================================================
 namespace {
 
-// get_blocks (src/seed.cpp:19-66): runs of care / don't-care positions; a care
-// run ends at a literal '0', a don't-care run at a literal '1'.  Returns the
-// description the reference would use (care runs, or don't-care runs plus the
-// whole-k-mer block pushed last when that is cheaper).
-void seed_blocks(const std::string& s, std::vector<uint32_t>& pairs, std::vector<uint32_t>& monos)
-{
-  const uint32_t k = (uint32_t)s.size();
-  std::vector<uint32_t> cb, ib, cm, im;
-  const char sentinel = s[k - 1] == '1' ? '0' : '1';
-  bool care = s[0] == '1';
-  uint32_t start = 0;
-  for (uint32_t p = 0; p <= k; ++p) {
-    const char ch = p < k ? s[p] : sentinel;
-    if (care && ch == '0') {
-      if (p - start == 1) cm.push_back(start);
-      else { cb.push_back(start); cb.push_back(p); }
-      start = p;
-      care = false;
-    } else if (!care && ch == '1') {
-      if (p - start == 1) im.push_back(start);
-      else { ib.push_back(start); ib.push_back(p); }
-      start = p;
-      care = true;
-    }
-  }
-  const size_t cost_care = cb.size() + cm.size();      // 2 per block + 1 per monomer
-  const size_t cost_ign = ib.size() + im.size() + 2;
-  if (cost_ign < cost_care) {
-    pairs = ib;
-    pairs.push_back(0);
-    pairs.push_back(k);
-    monos = im;
-  } else {
-    pairs = cb;
-    monos = cm;
-  }
-}
-
 } // namespace
 
 extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32_t n_seeds, uint16_t k16,
@@ -828,17 +793,13 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
     if (str.size() != k) // src/seed.cpp:90-95
       return fail(NTHIP_ERR_ARG, "Spaced seed string length (%zu) not equal to k=%u in %s", str.size(), k,
                   str.c_str());
-    if (!std::equal(str.begin(), str.end(), str.rbegin())) asym = true; // src/seed.cpp:96-102
-    std::vector<uint32_t> pairs, monos;
-    seed_blocks(str, pairs, monos);
+    if (!seed_is_symmetric(str)) asym = true; // src/seed.cpp:96-102
+    const SeedShape shape = parse_seed_shape(str);
+    const std::vector<uint32_t>& pairs = shape.block_pairs;
+    const std::vector<uint8_t>& par = shape.care;
     blk_start[s] = (uint32_t)(blk_pairs.size() / 2);
     blk_count[s] = (uint32_t)(pairs.size() / 2);
     blk_pairs.insert(blk_pairs.end(), pairs.begin(), pairs.end());
-    // contributing positions = XOR-coverage of blocks and monomers (src/seed.cpp:149-164)
-    std::vector<uint8_t> par(k, 0);
-    for (size_t b = 0; b + 1 < pairs.size(); b += 2)
-      for (uint32_t p = pairs[b]; p < pairs[b + 1]; ++p) par[p] ^= 1;
-    for (uint32_t p : monos) par[p] ^= 1;
     for (uint32_t p = 0; p < k; ++p)
       if (par[p]) care[(size_t)s * cw + (p >> 5)] |= 1u << (p & 31);
     // byte tables: entry = XOR over the byte's 4 bases of the masked rotated seeds
@@ -930,6 +891,8 @@ int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, cons
   h.read_off = d_off;
   h.hashes = st.hashes;
   h.pos = st.pos;
+  h.fwd = st.fwd;
+  h.rev = st.rev;
   h.capacity = capacity;
   HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
   prof_begin(c, "seed_general_kernel");
@@ -963,7 +926,6 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
   if (!c || !sd) return fail(NTHIP_ERR_ARG, "ctx/seeds is NULL");
   NTCHK(check_reads(rd));
   if (!out || !out->hashes) return fail(NTHIP_ERR_ARG, "out->hashes is NULL");
-  if (out->fwd || out->rev) return fail(NTHIP_ERR_ARG, "out->fwd/rev are not produced by seed hashing");
   const uint32_t m2 = m28, k = sd->k;
   if (m2 == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes_per_seed must be >= 1");
   HIPCHK(hipSetDevice(c->device));
@@ -976,7 +938,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
   NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
   Staged st;
   NTCHK(stage_inputs(c, rd, flags, total_bytes, st));
-  NTCHK(stage_outputs(c, out, flags, rd->n_reads, per, st));
+  NTCHK(stage_outputs(c, out, flags, rd->n_reads, per, st, sd->n_seeds));
 
   const uint32_t len = rd->fixed_len;
   const uint32_t stride = rd->stride ? rd->stride : len;
@@ -987,7 +949,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
       HIPCHK(hipGetLastError());
     }
     done = true;
-  } else if (!rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.pos && m2 <= (uint32_t)SF_MAX_RUNTIME_M &&
+  } else if (!rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.pos && !st.fwd && !st.rev && m2 <= (uint32_t)SF_MAX_RUNTIME_M &&
              k <= 64 && stride <= len) {
     const uint32_t nwin = len - k + 1;
     const size_t table_bytes = (size_t)sd->n_seeds * sd->ntab * 256 * sizeof(uint4);
@@ -1048,7 +1010,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
   }
   if (!done) NTCHK(run_seed_general(c, st, rd, sd, m2, out->capacity, &total));
   if (total_out) *total_out = total;
-  NTCHK(unstage_outputs(c, out, flags, rd->n_reads, per, total, st));
+  NTCHK(unstage_outputs(c, out, flags, rd->n_reads, per, total, st, sd->n_seeds));
   HIPCHK(hipStreamSynchronize(c->stream));
   return NTHIP_OK;
 }

@@ -150,6 +150,8 @@ struct SeedGeneralArgs {
   uint64_t* counts;
   uint64_t* hashes;
   uint32_t* pos;
+  uint64_t* fwd;              // optional: [k-mer][seed] forward-strand hashes
+  uint64_t* rev;              // optional: [k-mer][seed] reverse-strand hashes
   uint64_t capacity;
   uint64_t mult[256];
 };
@@ -215,6 +217,8 @@ __global__ __launch_bounds__(256) void seed_general_kernel(const SeedGeneralArgs
               rh = srol1(rh) ^ (c ? rc_seed(win[p]) : 0);
             }
             const uint64_t h0 = fh + rh;
+            if (a.fwd) a.fwd[o * a.n_seeds + sd] = fh;
+            if (a.rev) a.rev[o * a.n_seeds + sd] = rh;
             uint64_t* dst = a.hashes + o * per + sd * a.m2;
             dst[0] = h0;
             for (uint32_t jj = 1; jj < a.m2; ++jj) dst[jj] = mix_hash(h0, a.mult[jj]);

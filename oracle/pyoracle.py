@@ -256,11 +256,14 @@ class Reference(Oracle):
         build()
         return os.path.exists(_REF_SO)
 
-    def __init__(self):
+    def __init__(self, so_path=None):
+        """so_path: another library exporting the ref_* driver symbols (tests build
+        oracle/ref_shim.cpp against nthash_amd's own header to drive its C++ facade)"""
         super().__init__()
-        if not os.path.exists(_REF_SO):
-            raise FileNotFoundError(_REF_SO)
-        R = C.CDLL(_REF_SO)
+        so_path = so_path or _REF_SO
+        if not os.path.exists(so_path):
+            raise FileNotFoundError(so_path)
+        R = C.CDLL(so_path)
         self.R = R
         R.ref_fn_name.restype = C.c_char_p
         R.ref_kmer_batch.restype = C.c_uint64
