@@ -336,8 +336,16 @@ bool NtHash::roll()
     return init();
   }
   ++pos_;
-  if (!load_from_stream())
-    raise_error("NtHash", "internal error: valid window missing from the device stream");
+  if (!load_from_stream()) {
+    // Only reachable when the object was driven outside the reference's contract
+    // (e.g. roll_back() after a failed roll() left pos past the last window, where
+    // the reference itself reads out of bounds): the window at pos_ then holds a
+    // non-base, so it is not in the stream.  Do what the reference does: roll.
+    const unsigned char out = (unsigned char)seq_[pos_ - 1], in = (unsigned char)seq_[pos_ + k_ - 1];
+    fwd_ = next_fwd(fwd_, k_, out, in);
+    rev_ = next_rev(rev_, k_, out, in);
+    extend(fwd_, rev_, k_, num_hashes_, hash_arr_.get());
+  }
   return true;
 }
 
