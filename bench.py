@@ -106,6 +106,7 @@ def main():
     import torch.distributed as dist
 
     import nthash_amd
+    from nthash_amd.sharding import weak_shard
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -135,7 +136,8 @@ def main():
     d_in = torch.empty(n_reads * L, dtype=torch.uint8, device=dev)
     d_out = torch.empty(chunk * nwin * per, dtype=torch.int64, device=dev)
     # this rank's shard of the global read set [rank*n_reads, (rank+1)*n_reads)
-    ctx.synth_reads_ptr(d_in.data_ptr(), rank * n_reads, n_reads, L, 42)
+    first_read, _ = weak_shard(rank, n_reads)
+    ctx.synth_reads_ptr(d_in.data_ptr(), first_read, n_reads, L, 42)
     seeds = nthash_amd.Seeds(ctx, cfg["seeds"], k) if cfg["seeds"] else None
     torch.cuda.synchronize(dev)
 
@@ -188,7 +190,7 @@ def main():
         last_r0 = (n_chunks - 1) * chunk  # d_out holds the last chunk
         nv = min(2000, n_reads - last_r0)
         host = d_out[: nv * nwin * per].cpu().numpy().view(np.uint64).reshape(-1, per)
-        data = orc.synth_reads(rank * n_reads + last_r0, nv, L, 42)
+        data = orc.synth_reads(first_read + last_r0, nv, L, 42)
         offs = np.arange(nv + 1, dtype=np.uint64) * L
         if seeds is None:
             want = orc.kmer_batch(data, offs, k, m, want_pos=False)["hashes"]
