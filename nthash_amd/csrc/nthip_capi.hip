@@ -953,14 +953,15 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
              k <= 64 && stride <= len) {
     const uint32_t nwin = len - k + 1;
     const size_t table_bytes = (size_t)sd->n_seeds * sd->ntab * 256 * sizeof(uint4);
-    // tile = as many runs as give a ~16 KiB bit stream (64 Ki bases), at most 256
-    uint32_t rpt = 65536u / stride;
+    // tile = as many runs as give a ~8 KiB bit stream (32 Ki bases), at most 256
+    uint32_t rpt = 32768u / stride;
     if (rpt > 256) rpt = 256;
     if (rpt < 1) rpt = 1;
     const uint64_t slab = 15ull + (uint64_t)(rpt - 1) * stride + len;
-    const size_t dyn = table_bytes + (((slab + 15) >> 4) + 8) * 4;
+    const uint32_t bits_dwords = (uint32_t)((((slab + 15) >> 4) + 8 + 3) & ~3ull);
+    const size_t dyn = table_bytes + (size_t)bits_dwords * 4 + (size_t)(SF_THREADS / 64) * 64 * per * 8;
     const uint64_t dense = rd->n_reads * (uint64_t)nwin;
-    if (dyn <= 150 * 1024 && dyn <= c->lds_max && (uint64_t)rpt * nwin < 0x7FFFFFFFull) {
+    if (dyn <= 158 * 1024 && dyn <= c->lds_max && (uint64_t)rpt * nwin < 0x7FFFFFFFull) {
       if (dense > out->capacity) {
         if (total_out) *total_out = dense;
         return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
@@ -985,6 +986,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
       if (n_tiles > 0xFFFFFFFFull) return fail(NTHIP_ERR_UNSUPPORTED, "too many reads for one call");
       a.n_tiles = (uint32_t)n_tiles;
       a.inv_nwin = (uint32_t)((1ull << 32) / nwin + 1);
+      a.bits_dwords = bits_dwords;
       for (uint32_t i = 0; i < (uint32_t)SF_MAX_RUNTIME_M; ++i) a.mult[i] = multiplier(k, i);
       HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream));
       int rc;

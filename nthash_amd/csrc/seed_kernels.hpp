@@ -26,7 +26,7 @@
 
 namespace ntamd {
 
-constexpr int SF_THREADS = 512;
+constexpr int SF_THREADS = 1024; // 16 waves: one block per CU shares the byte tables
 constexpr int SF_MAX_RUNTIME_M = 8;
 
 struct SeedFixedArgs {
@@ -41,6 +41,7 @@ struct SeedFixedArgs {
   uint32_t runs_per_tile;
   uint32_t n_tiles;
   uint32_t inv_nwin;      // floor(2^32 / nwin) + 1 (for q / nwin)
+  uint32_t bits_dwords;   // LDS dwords reserved for the slab's bit stream
   uint64_t mult[SF_MAX_RUNTIME_M];
 };
 
@@ -50,15 +51,18 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   // layout: [tables: n_seeds*ntab*256 uint4][bit stream]
+  // layout: [tables: n_seeds*ntab*256 uint4][bit stream][per-wave output tiles: 64*per u64]
   uint4* tabs = (uint4*)lds_dyn;
   const uint32_t n_entries = a.n_seeds * a.ntab * 256u;
   uint32_t* bits = lds_dyn + n_entries * 4u;
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
   for (uint32_t i = tid; i < n_entries; i += SF_THREADS) tabs[i] = a.tables[i];
 
   const uint32_t per = a.n_seeds * a.m2; // values per window
+  uint64_t* otile = (uint64_t*)(bits + a.bits_dwords) + wave * 64u * per;
   uint32_t bad = 0;
 
   for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
@@ -94,12 +98,18 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
     if (tid < NW + 1) bits[n_vec + tid] = 0;
     __syncthreads();
 
+    // Every wave takes 64 consecutive windows at a time: their per*8-byte records are
+    // contiguous in the output stream, so they are collected in a wave-private LDS
+    // tile and written out as one contiguous block, 16 bytes per lane per store.
     const uint32_t n_win_tile = runs_here * a.nwin;
-    for (uint32_t q = tid; q < n_win_tile; q += SF_THREADS) {
-      // q -> (run, window) with a multiply-high and one fix-up
-      uint32_t lr = a.nwin == 1u ? q : __umulhi(q, a.inv_nwin);
-      if (lr * a.nwin > q) lr--;
-      const uint32_t p = q - lr * a.nwin;
+    for (uint32_t q0 = wave * 64u; q0 < n_win_tile; q0 += (SF_THREADS / 64u) * 64u) {
+      const uint32_t q = q0 + lane;
+      const bool live = q < n_win_tile;
+      const uint32_t qq = live ? q : q0;
+      // qq -> (run, window) with a multiply-high and one fix-up
+      uint32_t lr = a.nwin == 1u ? qq : __umulhi(qq, a.inv_nwin);
+      if (lr * a.nwin > qq) lr--;
+      const uint32_t p = qq - lr * a.nwin;
       const uint32_t b = shift + lr * a.stride + p; // first base of the window (stream index)
       const uint32_t d = b >> 4, sh = (b & 15u) << 1;
       uint32_t w[NW];
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
         w[i] = funnel(hi, lo, sh);
         lo = hi;
       }
-      uint64_t* dst = a.hashes + (run0 * a.nwin + q) * per;
+      uint64_t* mine = otile + lane * per;
       for (uint32_t s = 0; s < a.n_seeds; ++s) {
         uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
         const uint4* ts = tabs + s * a.ntab * 256u;
@@ -123,10 +133,23 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
           }
         }
         const uint64_t h0 = (((uint64_t)f1 << 32) | f0) + (((uint64_t)r1 << 32) | r0);
-        dst[s * a.m2] = h0;
+        mine[s * a.m2] = h0;
         for (uint32_t jj = 1; jj < a.m2; ++jj)
-          dst[s * a.m2 + jj] = mix_hash(h0, a.mult[jj & (SF_MAX_RUNTIME_M - 1)]);
+          mine[s * a.m2 + jj] = mix_hash(h0, a.mult[jj & (SF_MAX_RUNTIME_M - 1)]);
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+      const uint32_t n_here = (n_win_tile - q0) < 64u ? (n_win_tile - q0) : 64u;
+      const uint32_t n_vals = n_here * per;
+      uint64_t* dst = a.hashes + (run0 * a.nwin + q0) * per;
+      for (uint32_t pi = lane; 2u * pi < n_vals; pi += 64u) {
+        const uint4 dv = *(const uint4*)(otile + 2u * pi);
+        if (2u * pi + 1u < n_vals) *(uint4*)(dst + 2u * pi) = dv;
+        else *(uint2*)(dst + 2u * pi) = make_uint2(dv.x, dv.y);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
     }
   }
   if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
