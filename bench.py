@@ -207,6 +207,16 @@ def main():
         avg_ms = sum(ms_list) / len(ms_list)
         kmers_per_launch = sum(x[2] for x in kernel_ms) / len(kernel_ms)
         achieved = kmers_per_launch * b_per_kmer / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2
+        # gfx950 correction + WRITE_SIZE, collected in separate rocprofv3 --pmc runs on the same
+        # kernel); counters cannot be read inside this process, so null when no summary exists
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if args.config in tj:
+                traffic = tj[args.config]["bytes_per_kmer_measured"] * kmers_per_launch
+        except Exception:
+            traffic = None
         res = {
             "metric": "k-mers hashed/sec (canonical, k=31, %dbp reads)" % L,
             "value": total_kmers / dt,
@@ -226,7 +236,7 @@ def main():
                        "launches_per_step": n_chunks, "input": "ASCII, device-resident",
                        "parallelism": "reads sharded by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": kernel_ms[0][1], "kernel_avg_ms": avg_ms,
                          "bytes_per_kmer": b_per_kmer, "kmers_per_launch": kmers_per_launch},
             "verified_vs_oracle": verified,
