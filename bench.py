@@ -110,11 +110,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # NTHASH_BENCH_SHARE_GPU=1 (testing only): all ranks on GPU 0 with a gloo group, so that the
+    # multi-rank control flow can be exercised on a 1-GPU box; real runs use one GPU per rank + RCCL
+    share = os.environ.get("NTHASH_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     L, k, m = cfg["L"], cfg["k"], cfg["m"]
     nwin = L - k + 1
@@ -175,7 +183,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert kmers == args.steps * n_reads * nwin, (kmers, args.steps * n_reads * nwin)
