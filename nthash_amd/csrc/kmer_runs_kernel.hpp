@@ -318,8 +318,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
         }
       }
     };
-    if constexpr (C_T != 0 && C_T <= 17) {
-      if constexpr (C_T > 1) roll_word(0u, std::integral_constant<uint32_t, (uint32_t)(C_T - 1)>{});
+    if constexpr (C_T != 0 && C_T <= 33) {
+      constexpr uint32_t NROLL = (uint32_t)(C_T - 1);
+      if constexpr (NROLL > 0) roll_word(0u, std::integral_constant<uint32_t, (NROLL < 16u ? NROLL : 16u)>{});
+      if constexpr (NROLL > 16) roll_word(1u, std::integral_constant<uint32_t, NROLL - 16u>{});
     } else {
       for (uint32_t jw = 0; jw * 16u + 1u < C; ++jw) roll_word(jw, std::integral_constant<uint32_t, 0u>{});
     }
@@ -335,21 +337,27 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
     bool counted = false;
     if (m == 1) {
       if (C_T != 0 && runs_here == 64u) {
-        // full tile, compile-time shape: all LDS reads first, then the stores
+        // full tile, compile-time shape: LDS reads first, then the stores, in groups of 8
         // (named registers, not an array: hipcc sends a partially predicated
         // uint4 array to scratch, whose traffic would also break the counted wait)
-        static_assert(NST <= 8, "flush is written for at most 8 store instructions");
+        static_assert(NST <= 16, "flush is written for at most 16 store instructions");
         const uint4* src = (const uint4*)tile + lane;
         uint4* dst = (uint4*)out0 + lane;
         uint4 d0, d1, d2, d3, d4, d5, d6, d7;
 #define KR_LD(n, var) \
-        if constexpr (n < NFULL) var = src[n * 64u]; \
-        else if constexpr (n == NFULL && REM != 0) { if (lane < REM) var = src[n * 64u]; }
+        if constexpr ((n) < NFULL) var = src[(n) * 64u]; \
+        else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) var = src[(n) * 64u]; }
 #define KR_ST(n, var) \
-        if constexpr (n < NFULL) dst[n * 64u] = var; \
-        else if constexpr (n == NFULL && REM != 0) { if (lane < REM) dst[n * 64u] = var; }
-        KR_LD(0, d0) KR_LD(1, d1) KR_LD(2, d2) KR_LD(3, d3) KR_LD(4, d4) KR_LD(5, d5) KR_LD(6, d6) KR_LD(7, d7)
-        KR_ST(0, d0) KR_ST(1, d1) KR_ST(2, d2) KR_ST(3, d3) KR_ST(4, d4) KR_ST(5, d5) KR_ST(6, d6) KR_ST(7, d7)
+        if constexpr ((n) < NFULL) dst[(n) * 64u] = var; \
+        else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) dst[(n) * 64u] = var; }
+#define KR_GROUP(b) \
+        KR_LD(b + 0, d0) KR_LD(b + 1, d1) KR_LD(b + 2, d2) KR_LD(b + 3, d3) \
+        KR_LD(b + 4, d4) KR_LD(b + 5, d5) KR_LD(b + 6, d6) KR_LD(b + 7, d7) \
+        KR_ST(b + 0, d0) KR_ST(b + 1, d1) KR_ST(b + 2, d2) KR_ST(b + 3, d3) \
+        KR_ST(b + 4, d4) KR_ST(b + 5, d5) KR_ST(b + 6, d6) KR_ST(b + 7, d7)
+        KR_GROUP(0)
+        if constexpr (NST > 8) { KR_GROUP(8) }
+#undef KR_GROUP
 #undef KR_LD
 #undef KR_ST
         counted = true;
@@ -382,13 +390,16 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
     // ---- consume the prefetched slab ---------------------------------------------
     // After a counted full tile the only VMEM operations younger than the two
     // loads are its NST stores: wait until at most NST operations are in flight.
-    if constexpr (DT) {
-      if (counted && NST == 8u) asm volatile("s_waitcnt vmcnt(8)" : "+v"(pv0), "+v"(pw)::"memory");
-      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv0), "+v"(pw)::"memory");
-    } else {
-      if (counted && NST == 8u) asm volatile("s_waitcnt vmcnt(8)" : "+v"(pv0), "+v"(pv1)::"memory");
-      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv0), "+v"(pv1)::"memory");
-    }
+    // (NST is 8 for C=15 and 15 for C=30)
+#define KR_WAIT(...) \
+    do { \
+      if (counted && NST == 8u) asm volatile("s_waitcnt vmcnt(8)" : __VA_ARGS__::"memory"); \
+      else if (counted && NST == 15u) asm volatile("s_waitcnt vmcnt(15)" : __VA_ARGS__::"memory"); \
+      else asm volatile("s_waitcnt vmcnt(0)" : __VA_ARGS__::"memory"); \
+    } while (0)
+    if constexpr (DT) KR_WAIT("+v"(pv0), "+v"(pw));
+    else KR_WAIT("+v"(pv0), "+v"(pv1));
+#undef KR_WAIT
     if (have_next) {
       cur = nxt;
       if (lane < cur.n_vec) pack_vec(cur, lane, make_uint4(pv0.x, pv0.y, pv0.z, pv0.w));

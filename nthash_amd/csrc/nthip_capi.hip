@@ -535,6 +535,11 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
   if (best < 6)
     for (uint32_t d = 17; d <= 32; ++d)
       if (nwin % d == 0) { best = d; break; }
+  // NTHIP_TUNE_RUN_LEN: A/B override of the run length (must divide the window count)
+  if (const char* t = getenv("NTHIP_TUNE_RUN_LEN")) {
+    const uint32_t d = (uint32_t)atoi(t);
+    if (d >= 2 && d <= 64 && nwin % d == 0) best = d;
+  }
   if (best == 0) return false;
   p->C = best;
   p->rpr = nwin / best;
@@ -550,7 +555,13 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
   const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
   const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
-  for (uint32_t w = 16; w >= 4; w >>= 1) {
+  // 8 waves per CU measured 1.5-2 % faster than 16 on the HBM-bound C2 shape (profiles/r01_notes.md)
+  uint32_t w_max = 8;
+  if (const char* t = getenv("NTHIP_TUNE_WAVES")) {
+    const uint32_t w = (uint32_t)atoi(t);
+    if (w >= 1 && w <= 16) w_max = w;
+  }
+  for (uint32_t w = w_max; w >= 1; --w) {
     if (fixed + per_wave * w <= cap) {
       p->waves = w;
       p->lds = fixed + per_wave * w;
@@ -735,6 +746,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
   (dt ? launch_kmer_runs(c, kmer_runs_kernel<KT, MT, CT, NWT, true>, ra, plan.lds) \
       : launch_kmer_runs(c, kmer_runs_kernel<KT, MT, CT, NWT, false>, ra, plan.lds))
       if (k == 31 && m == 1 && plan.C == 15) rc = NT_RUNS(31, 1, 15, 2);
+      else if (k == 31 && m == 1 && plan.C == 30) rc = NT_RUNS(31, 1, 30, 2);
       else if (k == 31 && plan.C == 15) rc = NT_RUNS(31, 0, 15, 2);
       else if (plan.nw == 1) rc = NT_RUNS(0, 0, 0, 1);
       else if (plan.nw == 2) rc = NT_RUNS(0, 0, 0, 2);

@@ -22,6 +22,13 @@ res = {v: [] for v in variants}
 for rnd in range(rounds):
     for v in variants:
         os.environ["NTHIP_TUNE_NO_DWORD_TAIL"] = "1" if v == "runs_vec" else "0"
+        os.environ.pop("NTHIP_TUNE_RUN_LEN", None)
+        os.environ.pop("NTHIP_TUNE_WAVES", None)
+        if v.startswith("C"):      # e.g. C20 or C20w12
+            c, _, w = v[1:].partition("w")
+            os.environ["NTHIP_TUNE_RUN_LEN"] = c
+            if w:
+                os.environ["NTHIP_TUNE_WAVES"] = w
         if v.startswith("map"):
             os.environ["NTHIP_TUNE_TILE_MAP"] = v[3:]
         else:
