@@ -1,0 +1,231 @@
+// kmer_runs_na_kernel.hpp -- the N-aware sibling of kmer_runs_kernel: fixed-length
+// reads that contain non-ACGTU bytes, hashed at (nearly) the clean-path rate with
+// the reference's emission rule and a COMPACT output stream.
+//
+// NtHash emits exactly the windows whose k bytes are all bases (the net effect
+// of init()/roll(), src/kmer.cpp:228-264).  That is a
+// parallel predicate, so the run-split decomposition still works:
+//   pass 1 (MODE_COUNT)  per wave tile (64 runs of C windows): a validity bit
+//                        per base, OR-ed over every window by doubling, popcount
+//                        -> valid windows per tile (and per read, on request);
+//   host                 exclusive scan of the tile counts -> tile offsets;
+//   pass 2 (MODE_HASH)   the same tiles are hashed as in kmer_runs_kernel (a
+//                        non-base keeps a garbage 2-bit code; it enters and
+//                        leaves the rolled state with the same code, so every
+//                        all-base window is exact), each lane drops its valid
+//                        hashes at its compacted slot of the wave's LDS tile
+//                        (wave-level exclusive scan of the per-lane counts), and
+//                        the tile is copied out contiguously at its offset.
+// Optional get_pos() stream through a second LDS tile.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kmer_runs_kernel.hpp"
+
+namespace ntamd {
+
+enum : int { NA_MODE_COUNT = 1, NA_MODE_HASH = 2 };
+
+struct KmerRunsNaArgs {
+  const uint8_t* seqs;
+  uint64_t* hashes;          // compact [emitted k-mer][m]
+  uint32_t* pos;             // optional: position of every emitted k-mer in its read
+  uint64_t* counts;          // optional (count pass, zeroed by the host): per-read emitted windows
+  uint64_t* tile_counts;     // count pass out: valid windows per wave tile
+  const uint64_t* tile_off;  // hash pass in: exclusive scan of tile_counts
+  const uint4* init_tab;
+  uint64_t n_reads, n_runs, n_wtiles;
+  uint32_t len, stride, k, m;
+  uint32_t nwin, C, rpr, ntab;
+  uint32_t waves, bits_dwords, vbits_dwords, tile_u64;
+  uint32_t inv_rpr, pad0;
+  uint64_t tab[16][2];
+  uint64_t mult[KF_MAX_RUNTIME_M];
+};
+
+// 4 ASCII bytes -> 4 x 2-bit codes (one byte) and a 4-bit mask of the non-bases
+__device__ __forceinline__ uint32_t pack4v(uint32_t w, uint32_t& inv4)
+{
+  const uint32_t t = (w >> 1) & 0x03030303u;
+  uint32_t x = w | 0x20202020u;
+  const uint32_t ubit = (x >> 4) & 0x01010101u;
+  x = x & ~ubit;
+  const uint32_t canon = __builtin_amdgcn_perm(0u, 0x67746361u, t);
+  const uint32_t d = x ^ canon;                                   // byte != 0 <=> not a base
+  const uint32_t nz = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;
+  inv4 = __builtin_amdgcn_udot4(nz >> 7, 0x08040201u, 0u, false); // gather the four flags
+  return __builtin_amdgcn_udot4(t, 0x40100401u, 0u, false);
+}
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_na_kernel(const KmerRunsNaArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t k = a.k, m = a.m, C = a.C;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+
+  // LDS: init tables | pair table | multipliers | per wave {hash tile, pos tile, bits, validity bits}
+  uint4* itab = (uint4*)lds_dyn;
+  uint4* ptab = itab + a.ntab * 256u;
+  uint64_t* mults = (uint64_t*)(ptab + 16);
+  const uint32_t per_wave = a.tile_u64 * 2u + a.tile_u64 + a.bits_dwords + a.vbits_dwords;
+  uint32_t* wave_base = (uint32_t*)(mults + KF_MAX_RUNTIME_M) + wave * per_wave;
+  uint64_t* tile = (uint64_t*)wave_base;
+  uint32_t* ptile = wave_base + a.tile_u64 * 2u;
+  uint32_t* bits = ptile + a.tile_u64;
+  uint16_t* vbits = (uint16_t*)(bits + a.bits_dwords);
+
+  if (MODE == NA_MODE_HASH) {
+    for (uint32_t i = tid; i < a.ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
+    if (tid < 16)
+      ptab[tid] = make_uint4((uint32_t)a.tab[tid][0], (uint32_t)(a.tab[tid][0] >> 32),
+                             (uint32_t)a.tab[tid][1], (uint32_t)(a.tab[tid][1] >> 32));
+    if (tid < KF_MAX_RUNTIME_M) mults[tid] = a.mult[tid];
+  }
+  __syncthreads();
+
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+
+  const uint64_t wstride = (uint64_t)gridDim.x * a.waves;
+  for (uint64_t wt = (uint64_t)blockIdx.x * a.waves + wave; wt < a.n_wtiles; wt += wstride) {
+    const uint64_t g0 = wt * 64u;
+    const uint64_t r_first = g0 / a.rpr;
+    const uint32_t rem0 = (uint32_t)(g0 - r_first * a.rpr);
+    const uint64_t runs_left = a.n_runs - g0;
+    const uint32_t runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
+    const uint32_t n_slab_reads = (rem0 + runs_here - 1u) / a.rpr + 1u;
+    const uint64_t off = r_first * a.stride;
+    const uint32_t shift = (uint32_t)(((uint64_t)a.seqs + off) & 15u);
+    const uint32_t slab_bytes = (n_slab_reads - 1u) * a.stride + a.len;
+    const uint32_t n_vec = (shift + slab_bytes + 15u) >> 4;
+    lds_sync();
+    // ---- stage: codes + one validity bit per base (bytes outside the slab are
+    // never part of a window of this tile, so they need no special treatment)
+    for (uint32_t i = lane; i < n_vec; i += 64u) {
+      const uint4 v = *(const uint4*)(a.seqs + (off - shift) + ((uint64_t)i << 4));
+      uint32_t i0, i1, i2, i3;
+      const uint32_t c0 = pack4v(v.x, i0), c1 = pack4v(v.y, i1), c2 = pack4v(v.z, i2), c3 = pack4v(v.w, i3);
+      bits[i] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+      vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+    }
+    if (lane < (uint32_t)NW + 3u) bits[n_vec + lane] = 0;
+    if (lane < 6u) vbits[n_vec + lane] = 0xFFFFu; // beyond the slab: not a base
+    lds_sync();
+
+    // ---- this lane's run and the validity of its C windows ----------------------
+    const bool live = lane < runs_here;
+    const uint32_t gl = live ? rem0 + lane : rem0;
+    const uint32_t lr = (gl * a.inv_rpr) >> 16;
+    const uint32_t q = gl - lr * a.rpr;
+    const uint32_t b0 = shift + lr * a.stride + q * C;
+    uint32_t valid;
+    {
+      // 64 validity bits from base b0 on (the run touches C + k - 1 <= 64 bases)
+      const uint32_t* vw = (const uint32_t*)vbits;
+      const uint32_t dw = b0 >> 5, sh = b0 & 31u;
+      const uint32_t x0 = vw[dw], x1 = vw[dw + 1], x2 = vw[dw + 2];
+      uint64_t r = ((uint64_t)funnel(x2, x1, sh) << 32) | funnel(x1, x0, sh);
+      // bit j of r := OR of bits j .. j+k-1 (doubling, then one shift for the remainder)
+      uint32_t span = 1;
+      while (2u * span <= k) {
+        r |= r >> span;
+        span *= 2u;
+      }
+      if (k > span) r |= r >> (k - span);
+      valid = live ? (~(uint32_t)r) & (C >= 32u ? 0xFFFFFFFFu : ((1u << C) - 1u)) : 0u;
+    }
+    const uint32_t cnt = __builtin_popcount(valid);
+    // wave exclusive scan of the per-lane counts
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if ((int)lane >= d) incl += o;
+    }
+    const uint32_t lane_off = incl - cnt;
+    const uint32_t total = __shfl(incl, 63, 64);
+
+    if (MODE == NA_MODE_COUNT) {
+      if (lane == 0) a.tile_counts[wt] = total;
+      if (a.counts && live && cnt) atomicAdd((unsigned long long*)&a.counts[r_first + lr], (unsigned long long)cnt);
+      continue;
+    }
+
+    // ---- hash the run (as kmer_runs_kernel) and drop valid hashes at their slots --
+    const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
+    uint32_t w[NW];
+    {
+      uint32_t lo = bits[d0];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const uint32_t hi = bits[d0 + i + 1];
+        w[i] = funnel(hi, lo, sh0);
+        lo = hi;
+      }
+    }
+    uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
+#pragma unroll
+    for (int jt = 0; jt < 4 * NW; ++jt) {
+      if ((uint32_t)jt < a.ntab) {
+        const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+        const uint4 e = itab[(uint32_t)jt * 256u + byte];
+        f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
+      }
+    }
+    uint32_t slot = lane_off;
+    auto emit = [&](uint32_t j) {
+      if ((valid >> j) & 1u) {
+        tile[slot] = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+        ptile[slot] = q * C + j;
+        ++slot;
+      }
+    };
+    emit(0u);
+    const uint32_t bi = b0 + k;
+    const uint32_t di = bi >> 4, shi = (bi & 15u) << 1;
+    for (uint32_t jw = 0; jw * 16u + 1u < C; ++jw) {
+      const uint32_t w_in = funnel(bits[di + jw + 1], bits[di + jw], shi);
+      const uint32_t w_out = funnel(bits[d0 + jw + 1], bits[d0 + jw], sh0);
+      const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
+      const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
+      const uint32_t left = C - 1u - jw * 16u;
+      const uint32_t ns = left < 16u ? left : 16u;
+#pragma unroll 2
+      for (uint32_t i = 0; i < ns; ++i) {
+        const uint32_t src = (i & 1u) ? v : u;
+        const uint32_t toff = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
+        const uint4 term = *(const uint4*)((const char*)ptab + toff);
+        srol_pair(f_lo, f_hi);
+        f_lo ^= term.x;
+        f_hi ^= term.y;
+        r_lo ^= term.z;
+        r_hi ^= term.w;
+        sror_pair(r_lo, r_hi);
+        emit(jw * 16u + i + 1u);
+      }
+    }
+    lds_sync();
+    // ---- copy out `total` k-mers (x m values) at this tile's offset -----------------
+    const uint64_t o0 = a.tile_off[wt];
+    uint64_t* out0 = a.hashes + o0 * m;
+    if (m == 1) {
+      for (uint32_t e = lane; e < total; e += 64u) out0[e] = tile[e];
+    } else {
+      const uint32_t nv = total * m;
+      for (uint32_t vi = lane; vi < nv; vi += 64u) {
+        const uint32_t e = vi / m, jj = vi - e * m;
+        const uint64_t h0 = tile[e];
+        out0[vi] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
+      }
+    }
+    if (a.pos)
+      for (uint32_t e = lane; e < total; e += 64u) a.pos[o0 + e] = ptile[e];
+  }
+}
+
+} // namespace ntamd

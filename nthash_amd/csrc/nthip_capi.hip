@@ -20,6 +20,7 @@
 
 #include "kmer_kernels.hpp"
 #include "kmer_runs_kernel.hpp"
+#include "kmer_runs_na_kernel.hpp"
 #include "nt_math.hpp"
 #include "seed_kernels.hpp"
 #include "seed_parse.hpp"
@@ -587,6 +588,107 @@ int launch_kmer_runs(nthip_ctx* c, K kernel, KmerRunsArgs a, size_t dyn_lds)
   return NTHIP_OK;
 }
 
+// N-aware run-split path for fixed-length reads: count pass -> scan -> compact hash pass
+// (kmer_runs_na_kernel.hpp).  `plan` comes from kmer_runs_plan; needs C + k - 1 <= 64.
+template <int NW>
+int launch_kmer_na(nthip_ctx* c, int mode, const KmerRunsNaArgs& a, size_t dyn_lds)
+{
+  auto kernel = mode == NA_MODE_COUNT ? kmer_runs_na_kernel<NA_MODE_COUNT, NW> : kmer_runs_na_kernel<NA_MODE_HASH, NW>;
+  int per_cu = 1;
+  NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
+  const uint64_t need = (a.n_wtiles + a.waves - 1) / a.waves;
+  uint64_t grid = (uint64_t)c->n_cu * per_cu;
+  if (grid > need) grid = need;
+  if (mode == NA_MODE_HASH) prof_begin(c, "kmer_runs_na_kernel");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
+  if (mode == NA_MODE_HASH) prof_end(c);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+int launch_kmer_na_nw(nthip_ctx* c, int mode, const KmerRunsNaArgs& a, size_t dyn_lds, uint32_t nw)
+{
+  switch (nw) {
+    case 1: return launch_kmer_na<1>(c, mode, a, dyn_lds);
+    case 2: return launch_kmer_na<2>(c, mode, a, dyn_lds);
+    case 3: return launch_kmer_na<3>(c, mode, a, dyn_lds);
+    default: return launch_kmer_na<4>(c, mode, a, dyn_lds);
+  }
+}
+
+bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, RunsPlan* p,
+                  uint32_t* vbits_dwords)
+{
+  if (!kmer_runs_plan(c, len, stride, k, m, p)) return false;
+  if (p->C + k - 1 > 64 || p->C > 32) return false;
+  const uint32_t slab_reads = (64 % p->rpr == 0) ? 64 / p->rpr : (p->rpr - 1 + 63) / p->rpr + 1;
+  const uint64_t slab_bytes = (uint64_t)(slab_reads - 1) * stride + len;
+  const uint32_t n_vec = (uint32_t)((15 + slab_bytes + 15) >> 4);
+  *vbits_dwords = (((n_vec + 8) / 2 + 3) + 3u) & ~3u;
+  const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
+  const size_t per_wave = (size_t)p->tile_u64 * 12 + (size_t)p->bits_dwords * 4 + (size_t)*vbits_dwords * 4;
+  const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
+  for (uint32_t w = 8; w >= 1; --w)
+    if (fixed + per_wave * w <= cap) {
+      p->waves = w;
+      p->lds = fixed + per_wave * w;
+      return true;
+    }
+  return false;
+}
+
+int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m,
+                const RunsPlan& plan, uint32_t vbits_dwords, const KmerFixedArgs& consts, uint64_t capacity,
+                uint64_t* total)
+{
+  KmerRunsNaArgs a;
+  memset(&a, 0, sizeof a);
+  a.seqs = st.seqs;
+  a.hashes = st.hashes;
+  a.pos = st.pos;
+  a.counts = st.counts;
+  NTCHK(get_init_tab(c, k, &a.init_tab));
+  a.n_reads = rd->n_reads;
+  a.n_runs = rd->n_reads * plan.rpr;
+  a.n_wtiles = (a.n_runs + 63) / 64;
+  a.len = rd->fixed_len;
+  a.stride = rd->stride ? rd->stride : rd->fixed_len;
+  a.k = k;
+  a.m = m;
+  a.nwin = a.len - k + 1;
+  a.C = plan.C;
+  a.rpr = plan.rpr;
+  a.ntab = (k + 3) / 4;
+  a.waves = plan.waves;
+  a.bits_dwords = plan.bits_dwords;
+  a.vbits_dwords = vbits_dwords;
+  a.tile_u64 = plan.tile_u64;
+  a.inv_rpr = 65536u / plan.rpr + 1u;
+  memcpy(a.tab, consts.tab, sizeof a.tab);
+  memcpy(a.mult, consts.mult, sizeof a.mult);
+  const uint64_t nt = a.n_wtiles;
+  const uint64_t nb = (nt + SCAN_TILE - 1) / SCAN_TILE;
+  NTCHK(ensure_scratch(c, 2 * nt + nb + 16));
+  a.tile_counts = c->d_scratch;
+  uint64_t* d_off = c->d_scratch + nt;
+  uint64_t* d_sums = c->d_scratch + 2 * nt;
+  uint64_t* d_total = (uint64_t*)(c->d_small + 8);
+  a.tile_off = d_off;
+  if (st.counts) HIPCHK(hipMemsetAsync(st.counts, 0, rd->n_reads * sizeof(uint64_t), c->stream));
+  NTCHK(launch_kmer_na_nw(c, NA_MODE_COUNT, a, plan.lds, plan.nw));
+  NTCHK(device_exclusive_scan(c, a.tile_counts, d_off, nt, d_sums, d_total));
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(total, c->h_small + 8, 8);
+  if (*total > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
+                (unsigned long long)capacity, (unsigned long long)*total);
+  a.counts = nullptr;
+  NTCHK(launch_kmer_na_nw(c, NA_MODE_HASH, a, plan.lds, plan.nw));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
 int run_kmer_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m,
                      uint64_t capacity, uint64_t* total)
 {
@@ -676,6 +778,11 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
   bool done = false;
   const bool want_fast = !rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.pos && !st.fwd && !st.rev &&
                          kmer_fixed_eligible(c, len, stride, k, m, &pad, &dyn);
+  // fixed-length reads that are (or may be) dirty, or whose positions are wanted: N-aware run-split path
+  RunsPlan na_plan;
+  uint32_t na_vbits = 0;
+  const bool na_ok = !rd->offsets && !(flags & (NTHIP_FORCE_GENERAL | NTHIP_FORCE_ROWS)) && !st.fwd && !st.rev &&
+                     len >= k && kmer_na_plan(c, len, stride, k, m, &na_plan, &na_vbits);
   if (!rd->offsets && len < k) {
     // every read shorter than k: nothing is emitted
     if (st.counts) {
@@ -770,7 +877,16 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
       }
       done = true;
     }
-    // dirty: some byte is not ACGTU -> redo on the N-aware path (device side)
+    // dirty: some byte is not ACGTU -> redo on an N-aware path (device side)
+  }
+  if (!done && na_ok) {
+    KmerFixedArgs consts;
+    memset(&consts, 0, sizeof consts);
+    fill_kmer_consts(k, m, consts);
+    int rc = run_kmer_na(c, st, rd, k, m, na_plan, na_vbits, consts, out->capacity, &total);
+    if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
+    NTCHK(rc);
+    done = true;
   }
   if (!done) NTCHK(run_kmer_general(c, st, rd, k, m, out->capacity, &total));
   if (total_out) *total_out = total;

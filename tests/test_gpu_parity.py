@@ -168,6 +168,35 @@ def test_kmer_dirty_fixed_len_falls_back_exactly(ctx, oracle):
     assert (got["counts"] == want["counts"]).all()
 
 
+@pytest.mark.parametrize("n,L,k,m,frac", [
+    (5000, 150, 31, 1, 0.002), (3000, 150, 31, 4, 0.01), (2000, 150, 31, 1, 0.2),
+    (1500, 100, 21, 2, 0.01), (1000, 250, 31, 3, 0.005), (700, 151, 25, 1, 0.01), (513, 64, 33, 1, 0.02),
+    (400, 120, 64, 2, 0.003),
+])
+def test_kmer_na_runs_path_vs_oracle(ctx, oracle, n, L, k, m, frac):
+    """fixed-length reads sprinkled with non-bases: count pass -> scan -> compact hash pass
+    (kmer_runs_na_kernel) must reproduce the reference's emitted set, order, positions and counts"""
+    rng = np.random.default_rng(n + L)
+    data = oracle.synth_reads(3, n, L, 7 * L + k).copy()
+    nbad = max(1, int(frac * n * L))
+    where = rng.choice(n * L, nbad, replace=False)
+    data[where] = np.frombuffer(b"NnRYKM-*.", dtype=np.uint8)[rng.integers(0, 9, nbad)]
+    data[:3] = ord("N")            # first window of the batch
+    data[-2:] = ord("n")           # last window of the batch
+    data[L * 7:L * 8] = ord("N")   # a read with no valid window at all
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m)
+    got = ctx.kmer_hash(data, k, m, fixed_len=L, n_reads=n, want_pos=True)
+    assert got["total"] == want["total"]
+    assert (got["counts"] == want["counts"]).all()
+    assert (got["pos"] == want["pos"]).all()
+    assert (got["hashes"] == want["hashes"]).all()
+    got2 = ctx.kmer_hash(data, k, m, fixed_len=L, n_reads=n)  # optimistic dense kernel first, then N-aware
+    assert got2["total"] == want["total"] and (got2["hashes"] == want["hashes"]).all()
+    gen = ctx.kmer_hash(data, k, m, fixed_len=L, n_reads=n, flags=4, want_pos=True)
+    assert (gen["hashes"] == want["hashes"]).all() and (gen["pos"] == want["pos"]).all()
+
+
 def test_kmer_ragged_reads_vs_oracle(ctx, oracle):
     rng = np.random.default_rng(21)
     alph = np.frombuffer(b"ACGTacgtUuNnRYKM-*", dtype=np.uint8)
