@@ -381,6 +381,53 @@ def test_properties_at_scale(ctx, oracle):
         ctx.free(p)
 
 
+def test_full_size_config2_properties(ctx, oracle):
+    """BASELINE.json configs[1] at FULL size (100 M x 150 bp, k=31, m=1: 15 GB in, 96 GB out):
+    no oracle run is affordable, so parity rests on size-independent properties --
+    (1) hashing the two halves separately gives the same checksum-of-checksums as the
+    whole batch, (2) reads sampled across the batch (tile, block-range and batch edges)
+    are bit-exact against the oracle, (3) the m=4 stream's h[0] column is the m=1 stream."""
+    n, L, k = 100_000_000, 150, 31
+    nwin = L - k + 1
+    try:
+        d_in = ctx.malloc(n * L)
+        d_out = ctx.malloc(n * nwin * 8)
+    except Exception as e:  # a smaller GPU: the 4 M-read test above still runs
+        pytest.skip(f"not enough device memory for the full-size config: {e}")
+    ctx.synth_reads_ptr(d_in, 0, n, L, 42)
+    assert ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, 1, d_out, n * nwin) == n * nwin
+    s_all, x_all = ctx.checksum_ptr(d_out, n * nwin)
+    rng = np.random.default_rng(0)
+    sample = [0, 1, 255, 256, 4095, 4096, n // 2 - 1, n // 2, n - 2, n - 1] + \
+        [int(x) for x in rng.integers(0, n, 40)]
+    for r0 in sample:
+        got = np.zeros(nwin, np.uint64)
+        ctx.d2h(got, d_out + r0 * nwin * 8)
+        data = oracle.synth_reads(r0, 1, L, 42)
+        want = oracle.kmer_batch(data, np.array([0, L], dtype=np.uint64), k, 1, want_pos=False)["hashes"].ravel()
+        assert (got == want).all(), r0
+    half = n // 2
+    s2 = x2 = 0
+    for part in range(2):  # reuse the first half of d_out as the destination
+        assert ctx.kmer_hash_ptr(d_in + part * half * L, 0, half, L, 0, k, 1, d_out, half * nwin) == half * nwin
+        s, x = ctx.checksum_ptr(d_out, half * nwin)
+        s2 = (s2 + s) & (2**64 - 1)
+        x2 ^= x
+    assert (s2, x2) == (s_all, x_all)
+    # d_out now holds the m=1 stream of the second half; hash its first 12.5 M reads with m=4
+    n4 = 12_500_000
+    d_o4 = ctx.malloc(n4 * nwin * 4 * 8)
+    assert ctx.kmer_hash_ptr(d_in + half * L, 0, n4, L, 0, k, 4, d_o4, n4 * nwin) == n4 * nwin
+    a = np.zeros(1_000_000 * 4, np.uint64)
+    b = np.zeros(1_000_000, np.uint64)
+    off = (n4 * nwin - 1_000_000)
+    ctx.d2h(a, d_o4 + off * 32)
+    ctx.d2h(b, d_out + off * 8)
+    assert (a.reshape(-1, 4)[:, 0] == b).all()
+    for p_ in (d_in, d_out, d_o4):
+        ctx.free(p_)
+
+
 def test_strand_symmetry_on_device(ctx, oracle):
     """canonical hashing (tests/tests.cpp:119-133): a read and its reverse
     complement give mirrored streams"""
