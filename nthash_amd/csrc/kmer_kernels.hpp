@@ -314,14 +314,20 @@ __global__ __launch_bounds__(KF_THREADS) void kmer_fixed_kernel(const KmerFixedA
 // --------------------------------------------------------------------------
 // General path: exact NtHash emission order on arbitrary bytes and lengths.
 // --------------------------------------------------------------------------
+constexpr uint32_t KG_SEG_WINDOWS = 1024; // long reads are cut into segments of this many windows
+
 struct KmerGeneralArgs {
   const uint8_t* seqs;
   const uint64_t* offsets; // n_reads+1, or nullptr with fixed len/stride
   uint64_t n_reads;
   uint32_t len, stride;    // used when offsets == nullptr
   uint32_t k, m;
-  const uint64_t* read_off; // exclusive scan of counts (hash pass only)
-  uint64_t* counts;         // per-read emitted windows (may be nullptr)
+  // segmented mode (seg_base != nullptr): work item = one segment of a read;
+  // seg_base[r] = index of read r's first segment (exclusive scan), n_items segments
+  const uint64_t* seg_base;
+  uint64_t n_items;
+  const uint64_t* item_off; // exclusive scan of the per-item counts (hash pass only)
+  uint64_t* counts;         // per-item emitted windows (count pass)
   uint64_t* hashes;
   uint32_t* pos;
   uint64_t* fwd;
@@ -332,16 +338,56 @@ struct KmerGeneralArgs {
   uint64_t mult[256];
 };
 
-// One lane per read.  A window is emitted iff its k bytes are all bases -- the
-// net effect of the reference's init()/roll() skipping (src/kmer.cpp:228-264).
-// Non-base bytes contribute nothing on entry and on exit, so the rolled state
-// is exact again as soon as a clean window is reached.
+// segments per read: ceil(windows / KG_SEG_WINDOWS)
+__global__ __launch_bounds__(256) void kmer_seg_count_kernel(const uint64_t* __restrict__ offsets, uint64_t n_reads,
+                                                            uint32_t len, uint32_t k, uint64_t* __restrict__ segs)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const uint64_t l = offsets ? offsets[r + 1] - offsets[r] : len;
+  segs[r] = l >= k ? (l - k + 1 + KG_SEG_WINDOWS - 1) / KG_SEG_WINDOWS : 0;
+}
+
+// per-read counts from per-item offsets: counts[r] = item_off[seg_base[r+1]] - item_off[seg_base[r]]
+__global__ __launch_bounds__(256) void kmer_seg_read_counts_kernel(const uint64_t* __restrict__ seg_base,
+                                                                  const uint64_t* __restrict__ item_off,
+                                                                  uint64_t n_reads, uint64_t n_items, uint64_t total,
+                                                                  uint64_t* __restrict__ counts)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const uint64_t a = seg_base[r], b = r + 1 < n_reads ? seg_base[r + 1] : n_items;
+  const uint64_t oa = a < n_items ? item_off[a] : total, ob = b < n_items ? item_off[b] : total;
+  counts[r] = ob - oa;
+}
+
+// One lane per read (or per segment of a read).  A window is emitted iff its k
+// bytes are all bases -- the net effect of the reference's init()/roll() skipping
+// (src/kmer.cpp:228-264).  Non-base bytes contribute nothing on entry and on
+// exit, so the rolled state is exact again as soon as a clean window is reached.
+// A segment starts its roll k-1 bytes before its first window's last byte, i.e.
+// from scratch at its first window: no state crosses segments.
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256) void kmer_general_kernel(const KmerGeneralArgs* __restrict__ ap)
 {
   const KmerGeneralArgs& a = *ap;
-  const uint64_t rid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (rid >= a.n_reads) return;
+  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k = a.k;
+  uint64_t rid = id, w0 = 0, w1 = ~0ull; // read, first window, one past the last window of this item
+  if (a.seg_base) {
+    if (id >= a.n_items) return;
+    // the read whose segment range contains id: last r with seg_base[r] <= id
+    uint64_t lo = 0, hi = a.n_reads;
+    while (hi - lo > 1) {
+      const uint64_t mid = lo + (hi - lo) / 2;
+      if (a.seg_base[mid] <= id) lo = mid; else hi = mid;
+    }
+    rid = lo;
+    w0 = (id - a.seg_base[rid]) * KG_SEG_WINDOWS;
+    w1 = w0 + KG_SEG_WINDOWS;
+  } else if (id >= a.n_reads) {
+    return;
+  }
   uint64_t start, len;
   if (a.offsets) {
     start = a.offsets[rid];
@@ -351,13 +397,15 @@ __global__ __launch_bounds__(256) void kmer_general_kernel(const KmerGeneralArgs
     len = a.len;
   }
   const uint8_t* s = a.seqs + start;
-  const uint32_t k = a.k;
   uint64_t emitted = 0;
   if (len >= k) {
+    const uint64_t nwin = len - k + 1;
+    if (w1 > nwin) w1 = nwin;
     uint64_t f = 0, r = 0;
     uint64_t run = 0; // consecutive base bytes ending at i
-    const uint64_t base = COUNT_ONLY ? 0 : a.read_off[rid];
-    for (uint64_t i = 0; i < len; ++i) {
+    const uint64_t base = COUNT_ONLY ? 0 : a.item_off[id];
+    const uint64_t i_end = w1 + k - 1; // bytes [w0, i_end) cover windows [w0, w1)
+    for (uint64_t i = w0; i < i_end; ++i) {
       const uint8_t cin = s[i];
       const bool vin = is_base(cin);
       run = vin ? run + 1 : 0;
@@ -365,7 +413,7 @@ __global__ __launch_bounds__(256) void kmer_general_kernel(const KmerGeneralArgs
         const uint32_t ci = code_of(cin);
         uint64_t tf = vin ? seed_of_code(ci) : 0;
         uint64_t tr = vin ? a.sk_rc[ci] : 0;
-        if (i >= k) {
+        if (i >= w0 + k) {
           const uint8_t cout = s[i - k];
           if (is_base(cout)) {
             const uint32_t co = code_of(cout);
@@ -392,7 +440,7 @@ __global__ __launch_bounds__(256) void kmer_general_kernel(const KmerGeneralArgs
       }
     }
   }
-  if (a.counts) a.counts[rid] = emitted;
+  if (a.counts) a.counts[id] = emitted;
 }
 
 } // namespace ntamd

@@ -218,6 +218,28 @@ def test_kmer_ragged_reads_vs_oracle(ctx, oracle):
             assert (got[key] == want[key]).all(), (k, m, key)
 
 
+def test_kmer_long_reads_are_segmented(ctx, oracle):
+    """reads far longer than a segment (1024 windows) next to short and empty ones: the general
+    kernel cuts them into segments that restart the roll; stream, positions and counts must not change"""
+    rng = np.random.default_rng(5)
+    alph = np.frombuffer(b"ACGTACGTACGTNacgtn", dtype=np.uint8)
+    reads = [alph[rng.integers(0, len(alph), L)].tobytes()
+             for L in (300_000, 40, 0, 5000, 1023 + 30, 1024 + 30, 1025 + 30, 150, 70_001)]
+    reads.append(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 200_000)].tobytes())
+    d, offs = concat_reads(reads)
+    for k, m in ((31, 2), (64, 1), (5, 1)):
+        want = oracle.kmer_batch(d, offs, k, m, want_strands=True)
+        got = ctx.kmer_hash(d, k, m, offsets=offs, want_pos=True, want_strands=True)
+        assert got["total"] == want["total"]
+        for key in ("counts", "pos", "hashes", "fwd", "rev"):
+            assert (got[key] == want[key]).all(), (k, m, key)
+    # one long fixed-length "read" (no offsets) goes the same way
+    one = np.frombuffer(reads[-1], dtype=np.uint8)
+    want = oracle.kmer_batch(one, np.array([0, len(one)], dtype=np.uint64), 31, 1)
+    got = ctx.kmer_hash(one, 31, 1, fixed_len=len(one), n_reads=1, want_pos=True, want_strands=True)
+    assert (got["hashes"] == want["hashes"]).all() and (got["pos"] == want["pos"]).all()
+
+
 def test_kmer_long_sequence_as_overlapping_runs(ctx, oracle):
     """one long sequence hashed as runs of R windows overlapping by k-1 bases
     (stride < fixed_len) == the sequence hashed as a single read"""
