@@ -214,6 +214,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
     // 16-byte round would leave most lanes idle --, longer slabs with a second vector
     v4u pv0, pv1;
     uint32_t pw;
+    uint32_t dirty_seen; // the batch-wide dirty flag, read along with the next slab
     {
       // lanes without an item re-read item 0 so that every lane issues both loads
       const uint32_t i0 = lane < nxt.n_vec ? lane : 0u;
@@ -222,16 +223,18 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
         const uint32_t n_dw = (nxt.shift + nxt.slab_bytes + 3u) >> 2; // dwords in the slab
         const uint32_t j = 256u + lane < n_dw ? 256u + lane : 0u;
         const uint8_t* p1 = a.seqs + nxt.byte0 + ((uint64_t)j << 2);
-        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dword %1, %3, off"
-                     : "=&v"(pv0), "=&v"(pw)
-                     : "v"(p0), "v"(p1)
+        asm volatile("global_load_dword %2, %5, off sc1\n\tglobal_load_dwordx4 %0, %3, off\n\t"
+                     "global_load_dword %1, %4, off"
+                     : "=&v"(pv0), "=&v"(pw), "=&v"(dirty_seen)
+                     : "v"(p0), "v"(p1), "v"(a.dirty)
                      : "memory");
       } else {
         const uint32_t i1 = lane + 64u < nxt.n_vec ? lane + 64u : 0u;
         const uint8_t* p1 = a.seqs + nxt.byte0 + ((uint64_t)i1 << 4);
-        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"
-                     : "=&v"(pv0), "=&v"(pv1)
-                     : "v"(p0), "v"(p1)
+        asm volatile("global_load_dword %2, %5, off sc1\n\tglobal_load_dwordx4 %0, %3, off\n\t"
+                     "global_load_dwordx4 %1, %4, off"
+                     : "=&v"(pv0), "=&v"(pv1), "=&v"(dirty_seen)
+                     : "v"(p0), "v"(p1), "v"(a.dirty)
                      : "memory");
       }
     }
@@ -397,9 +400,12 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
       else if (counted && NST == 15u) asm volatile("s_waitcnt vmcnt(15)" : __VA_ARGS__::"memory"); \
       else asm volatile("s_waitcnt vmcnt(0)" : __VA_ARGS__::"memory"); \
     } while (0)
-    if constexpr (DT) KR_WAIT("+v"(pv0), "+v"(pw));
-    else KR_WAIT("+v"(pv0), "+v"(pv1));
+    if constexpr (DT) KR_WAIT("+v"(pv0), "+v"(pw), "+v"(dirty_seen));
+    else KR_WAIT("+v"(pv0), "+v"(pv1), "+v"(dirty_seen));
 #undef KR_WAIT
+    // some wave already found a non-base byte: the caller will redo the batch on the
+    // N-aware path, so stop producing a dense stream nobody will read
+    if (__builtin_amdgcn_readfirstlane(dirty_seen) != 0u) break;
     if (have_next) {
       cur = nxt;
       if (lane < cur.n_vec) pack_vec(cur, lane, make_uint4(pv0.x, pv0.y, pv0.z, pv0.w));
@@ -410,6 +416,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
       } else {
         if (lane + 64u < cur.n_vec) pack_vec(cur, lane + 64u, make_uint4(pv1.x, pv1.y, pv1.z, pv1.w));
         stage(cur, 128u); // slabs longer than 128 vectors: the rest with ordinary loads
+      }
+      if (__ballot(bad != 0) != 0) { // publish at once so that every wave can stop early
+        if (lane == 0) atomicOr(a.dirty, 1u);
+        break;
       }
     }
   }
