@@ -58,11 +58,12 @@ __device__ __forceinline__ uint32_t pack4v(uint32_t w, uint32_t& inv4)
   return __builtin_amdgcn_udot4(t, 0x40100401u, 0u, false);
 }
 
-template <int MODE, int NW>
+// C_T: compile-time run length (0 = runtime) -- unrolls the roll and prefetches its table terms
+template <int MODE, int NW, int C_T>
 __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_na_kernel(const KmerRunsNaArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
-  const uint32_t k = a.k, m = a.m, C = a.C;
+  const uint32_t k = a.k, m = a.m, C = C_T ? (uint32_t)C_T : a.C;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
   // LDS: init tables | pair table | multipliers | per wave {hash tile, pos tile, bits, validity bits}
@@ -193,20 +194,43 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_na_kernel(const Kmer
       const uint32_t w_out = funnel(bits[d0 + jw + 1], bits[d0 + jw], sh0);
       const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
       const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
-      const uint32_t left = C - 1u - jw * 16u;
-      const uint32_t ns = left < 16u ? left : 16u;
-#pragma unroll 2
-      for (uint32_t i = 0; i < ns; ++i) {
+      auto lookup = [&](uint32_t i) -> uint4 {
         const uint32_t src = (i & 1u) ? v : u;
         const uint32_t toff = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
-        const uint4 term = *(const uint4*)((const char*)ptab + toff);
+        return *(const uint4*)((const char*)ptab + toff);
+      };
+      auto roll = [&](const uint4 term) {
         srol_pair(f_lo, f_hi);
         f_lo ^= term.x;
         f_hi ^= term.y;
         r_lo ^= term.z;
         r_hi ^= term.w;
         sror_pair(r_lo, r_hi);
-        emit(jw * 16u + i + 1u);
+      };
+      if constexpr (C_T != 0 && C_T <= 17) {
+        constexpr uint32_t NS = (uint32_t)(C_T - 1);
+        constexpr uint32_t B = 8;
+#pragma unroll
+        for (uint32_t i0 = 0; i0 < NS; i0 += B) {
+          uint4 terms[B];
+#pragma unroll
+          for (uint32_t i = 0; i < B; ++i)
+            if (i0 + i < NS) terms[i] = lookup(i0 + i);
+#pragma unroll
+          for (uint32_t i = 0; i < B; ++i)
+            if (i0 + i < NS) {
+              roll(terms[i]);
+              emit(i0 + i + 1u);
+            }
+        }
+      } else {
+        const uint32_t left = C - 1u - jw * 16u;
+        const uint32_t ns = left < 16u ? left : 16u;
+#pragma unroll 2
+        for (uint32_t i = 0; i < ns; ++i) {
+          roll(lookup(i));
+          emit(jw * 16u + i + 1u);
+        }
       }
     }
     lds_sync();
@@ -214,7 +238,16 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_na_kernel(const Kmer
     const uint64_t o0 = a.tile_off[wt];
     uint64_t* out0 = a.hashes + o0 * m;
     if (m == 1) {
-      for (uint32_t e = lane; e < total; e += 64u) out0[e] = tile[e];
+      // 16-byte pieces where the (arbitrary) tile offset allows: a possibly odd first
+      // element, then pairs, then a possibly odd last one
+      const uint32_t head = (uint32_t)(o0 & 1u) < total ? (uint32_t)(o0 & 1u) : total;
+      if (lane == 0 && head) out0[0] = tile[0];
+      const uint32_t n_pairs = (total - head) >> 1;
+      for (uint32_t pi = lane; pi < n_pairs; pi += 64u) {
+        const uint64_t x = tile[head + 2u * pi], y = tile[head + 2u * pi + 1u];
+        *(uint4*)(out0 + head + 2u * pi) = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32));
+      }
+      if (lane == 0 && ((total - head) & 1u)) out0[total - 1u] = tile[total - 1u];
     } else {
       const uint32_t nv = total * m;
       for (uint32_t vi = lane; vi < nv; vi += 64u) {

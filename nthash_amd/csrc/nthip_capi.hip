@@ -590,10 +590,11 @@ int launch_kmer_runs(nthip_ctx* c, K kernel, KmerRunsArgs a, size_t dyn_lds)
 
 // N-aware run-split path for fixed-length reads: count pass -> scan -> compact hash pass
 // (kmer_runs_na_kernel.hpp).  `plan` comes from kmer_runs_plan; needs C + k - 1 <= 64.
-template <int NW>
+template <int NW, int C_T>
 int launch_kmer_na(nthip_ctx* c, int mode, const KmerRunsNaArgs& a, size_t dyn_lds)
 {
-  auto kernel = mode == NA_MODE_COUNT ? kmer_runs_na_kernel<NA_MODE_COUNT, NW> : kmer_runs_na_kernel<NA_MODE_HASH, NW>;
+  auto kernel = mode == NA_MODE_COUNT ? kmer_runs_na_kernel<NA_MODE_COUNT, NW, C_T>
+                                      : kmer_runs_na_kernel<NA_MODE_HASH, NW, C_T>;
   int per_cu = 1;
   NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
   const uint64_t need = (a.n_wtiles + a.waves - 1) / a.waves;
@@ -608,11 +609,12 @@ int launch_kmer_na(nthip_ctx* c, int mode, const KmerRunsNaArgs& a, size_t dyn_l
 
 int launch_kmer_na_nw(nthip_ctx* c, int mode, const KmerRunsNaArgs& a, size_t dyn_lds, uint32_t nw)
 {
+  if (nw == 2 && a.C == 15) return launch_kmer_na<2, 15>(c, mode, a, dyn_lds);
   switch (nw) {
-    case 1: return launch_kmer_na<1>(c, mode, a, dyn_lds);
-    case 2: return launch_kmer_na<2>(c, mode, a, dyn_lds);
-    case 3: return launch_kmer_na<3>(c, mode, a, dyn_lds);
-    default: return launch_kmer_na<4>(c, mode, a, dyn_lds);
+    case 1: return launch_kmer_na<1, 0>(c, mode, a, dyn_lds);
+    case 2: return launch_kmer_na<2, 0>(c, mode, a, dyn_lds);
+    case 3: return launch_kmer_na<3, 0>(c, mode, a, dyn_lds);
+    default: return launch_kmer_na<4, 0>(c, mode, a, dyn_lds);
   }
 }
 
