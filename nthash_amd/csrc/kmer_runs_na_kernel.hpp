@@ -92,8 +92,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_na_kernel(const Kmer
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   };
 
-  const uint64_t wstride = (uint64_t)gridDim.x * a.waves;
-  for (uint64_t wt = (uint64_t)blockIdx.x * a.waves + wave; wt < a.n_wtiles; wt += wstride) {
+  // every block streams through its own contiguous range of tiles (as kmer_runs_kernel)
+  const uint64_t per_block = (a.n_wtiles + gridDim.x - 1) / gridDim.x;
+  const uint64_t t_begin = (uint64_t)blockIdx.x * per_block;
+  const uint64_t t_end = t_begin + per_block < a.n_wtiles ? t_begin + per_block : a.n_wtiles;
+  for (uint64_t wt = t_begin + wave; wt < t_end; wt += a.waves) {
     const uint64_t g0 = wt * 64u;
     const uint64_t r_first = g0 / a.rpr;
     const uint32_t rem0 = (uint32_t)(g0 - r_first * a.rpr);
@@ -179,10 +182,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_na_kernel(const Kmer
       }
     }
     uint32_t slot = lane_off;
+    const bool want_pos = a.pos != nullptr;
     auto emit = [&](uint32_t j) {
       if ((valid >> j) & 1u) {
         tile[slot] = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
-        ptile[slot] = q * C + j;
+        if (want_pos) ptile[slot] = q * C + j;
         ++slot;
       }
     };
