@@ -462,3 +462,69 @@ def test_strand_symmetry_on_device(ctx, oracle):
     sa = ctx.seed_hash(data.ravel(), [SEED_A, SEED_B], k, 2, fixed_len=L, n_reads=n)["hashes"]
     sb = ctx.seed_hash(rcd.ravel(), [SEED_A, SEED_B], k, 2, fixed_len=L, n_reads=n)["hashes"]
     assert (sa.reshape(n, L - k + 1, 4) == sb.reshape(n, L - k + 1, 4)[:, ::-1, :]).all()
+
+
+# ---------------------------------------------------------------------------
+# randomised shapes: every dispatch corner (run-split / row / N-aware / general
+# kernels, odd strides, unaligned bases, tiny and prime window counts)
+# ---------------------------------------------------------------------------
+def test_fuzz_fixed_length_shapes(ctx, oracle):
+    rng = np.random.default_rng(2026)
+    for it in range(120):
+        k = int(rng.choice([3, 4, 5, 8, 15, 16, 17, 21, 31, 32, 33, 48, 63, 64, 65, 100]))
+        L = int(k + rng.choice([0, 1, 2, 3, 6, 11, 14, 15, 29, 30, 59, 60, 96, 119, 120, 127, 219]))
+        n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 1537]))
+        m = int(rng.choice([1, 1, 2, 3, 4, 8]))
+        dirty = rng.random() < 0.4
+        data = oracle.synth_reads(int(rng.integers(0, 1000)), n, L, int(rng.integers(0, 1 << 30))).copy()
+        if dirty:
+            nb = max(1, (n * L) // 300)
+            data[rng.choice(n * L, nb, replace=False)] = ord("N")
+        offs = np.arange(n + 1, dtype=np.uint64) * L
+        want = oracle.kmer_batch(data, offs, k, m)
+        shift = int(rng.choice([0, 0, 1, 5, 8, 15]))
+        d_in = ctx.malloc(n * L + 32)
+        ctx.h2d(d_in + shift, data)
+        cap = n * (L - k + 1)
+        d_out = ctx.malloc(cap * m * 8 + 16)
+        d_cnt = ctx.malloc(n * 8)
+        d_pos = ctx.malloc(cap * 4 + 16)
+        want_pos = rng.random() < 0.3
+        tot = ctx.kmer_hash_ptr(d_in + shift, 0, n, L, 0, k, m, d_out, cap, counts=d_cnt,
+                                pos=d_pos if want_pos else 0)
+        assert tot == want["total"], (it, n, L, k, m, dirty)
+        got = np.zeros(tot * m, np.uint64)
+        cnt = np.zeros(n, np.uint64)
+        ctx.d2h(got, d_out)
+        ctx.d2h(cnt, d_cnt)
+        assert (got == want["hashes"].ravel()).all(), (it, n, L, k, m, dirty, shift)
+        assert (cnt == want["counts"]).all(), (it, n, L, k, m, dirty)
+        if want_pos:
+            pos = np.zeros(tot, np.uint32)
+            ctx.d2h(pos, d_pos)
+            assert (pos == want["pos"]).all(), (it, n, L, k, m, dirty)
+        for p_ in (d_in, d_out, d_cnt, d_pos):
+            ctx.free(p_)
+
+
+def test_fuzz_seed_shapes(ctx, oracle):
+    import nthash_amd
+    rng = np.random.default_rng(77)
+    for it in range(60):
+        k = int(rng.choice([4, 8, 16, 17, 31, 32, 33, 48, 64, 65, 80]))
+        L = int(k + rng.choice([0, 1, 7, 30, 64, 119, 219]))
+        n = int(rng.choice([1, 3, 64, 129, 500]))
+        m2 = int(rng.choice([1, 2, 3, 5]))
+        seeds = []
+        for _ in range(int(rng.integers(1, 4))):
+            half = "".join("1" if rng.random() < 0.6 else "0" for _ in range((k + 1) // 2))
+            seeds.append(half + half[: k // 2][::-1])
+        data = oracle.synth_reads(0, n, L, int(rng.integers(0, 1 << 30))).copy()
+        if rng.random() < 0.3:
+            data[rng.choice(n * L, max(1, n * L // 400), replace=False)] = ord("N")
+        offs = np.arange(n + 1, dtype=np.uint64) * L
+        want = oracle.seed_batch(data, offs, seeds, k, m2)
+        got = ctx.seed_hash(data, seeds, k, m2, fixed_len=L, n_reads=n, want_pos=bool(rng.random() < 0.3))
+        assert got["total"] == want["total"], (it, n, L, k, m2, seeds)
+        assert (got["hashes"] == want["hashes"]).all(), (it, n, L, k, m2, seeds)
+        assert (got["counts"] == want["counts"]).all()
