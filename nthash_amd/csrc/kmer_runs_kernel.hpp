@@ -311,10 +311,23 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
           }
         }
       } else {
+        // runtime step count: full batches of 8 (terms prefetched), then the remainder
         const uint32_t left = C - 1u - jw * 16u;
         const uint32_t ns = left < 16u ? left : 16u;
+        uint32_t i0 = 0;
+        for (; i0 + 8u <= ns; i0 += 8u) {
+          uint4 terms[8];
+#pragma unroll
+          for (uint32_t i = 0; i < 8; ++i) terms[i] = lookup(i0 + i);
+#pragma unroll
+          for (uint32_t i = 0; i < 8; ++i) {
+            roll(terms[i]);
+            my_row[jw * 16u + i0 + i + 1u] =
+                (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+          }
+        }
 #pragma unroll 1
-        for (uint32_t i = 0; i < ns; ++i) {
+        for (uint32_t i = i0; i < ns; ++i) {
           roll(lookup(i));
           my_row[jw * 16u + i + 1u] =
               (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);

@@ -534,7 +534,7 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
   for (uint32_t d = 16; d >= 4; --d)
     if (nwin % d == 0) { best = d; break; }
   if (best < 6)
-    for (uint32_t d = 17; d <= 32; ++d)
+    for (uint32_t d = 17; d <= 64; ++d) // e.g. a prime window count: the whole read is one run
       if (nwin % d == 0) { best = d; break; }
   // NTHIP_TUNE_RUN_LEN: A/B override of the run length (must divide the window count)
   if (const char* t = getenv("NTHIP_TUNE_RUN_LEN")) {
