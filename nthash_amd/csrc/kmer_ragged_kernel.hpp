@@ -1,0 +1,325 @@
+// kmer_ragged_kernel.hpp -- run-split k-mer hashing of VARIABLE-LENGTH reads
+// (n_reads+1 offsets) with N-aware compaction: the path real FASTQ batches take.
+//
+// Same decomposition as kmer_runs_na_kernel (runs of up to C windows, 64 runs per
+// wave tile, count pass -> scan -> compact hash pass), but a read contributes
+// ceil(windows / C) runs and the last one may be short.  A device pre-pass
+// (ragged_* kernels below) lists the reads that have at least one window, scans
+// their run counts and tells every tile which listed read its first run belongs
+// to.  A tile then touches at most 64 listed reads; each of them stages exactly
+// the bytes its runs in this tile need, packed back to back (16-base aligned per
+// read) in the wave's LDS stream, so reads without windows, and the parts of a
+// long read that belong to other tiles, cost nothing.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kmer_runs_na_kernel.hpp"
+
+namespace ntamd {
+
+// ---- pre-pass ---------------------------------------------------------------
+// runs per read and a 0/1 flag "has a window"
+__global__ __launch_bounds__(256) void ragged_runs_kernel(const uint64_t* __restrict__ offsets, uint64_t n_reads,
+                                                         uint32_t k, uint32_t C, uint64_t* __restrict__ rc,
+                                                         uint64_t* __restrict__ flag)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const uint64_t len = offsets[r + 1] - offsets[r];
+  const uint64_t runs = len >= k ? (len - k + 1 + C - 1) / C : 0;
+  rc[r] = runs;
+  flag[r] = runs ? 1 : 0;
+}
+
+// compact list of the reads that have runs: nz_read[j], nz_rc[j]
+__global__ __launch_bounds__(256) void ragged_scatter_kernel(const uint64_t* __restrict__ rc,
+                                                            const uint64_t* __restrict__ nz_idx, uint64_t n_reads,
+                                                            uint64_t* __restrict__ nz_read,
+                                                            uint64_t* __restrict__ nz_rc)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads || rc[r] == 0) return;
+  const uint64_t j = nz_idx[r];
+  nz_read[j] = r;
+  nz_rc[j] = rc[r];
+}
+
+// per tile: the listed read that holds run 64*t, and how many of its runs precede it
+__global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t* __restrict__ nz_run_base, uint64_t n_nz,
+                                                          uint64_t n_tiles, uint64_t* __restrict__ tile_j0,
+                                                          uint64_t* __restrict__ tile_rem0)
+{
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tiles) return;
+  const uint64_t g0 = t * 64u;
+  uint64_t lo = 0, hi = n_nz; // last j with nz_run_base[j] <= g0
+  while (hi - lo > 1) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    if (nz_run_base[mid] <= g0) lo = mid; else hi = mid;
+  }
+  tile_j0[t] = lo;
+  tile_rem0[t] = g0 - nz_run_base[lo];
+}
+
+// ---- main kernel --------------------------------------------------------------
+struct KmerRaggedArgs {
+  const uint8_t* seqs;
+  const uint64_t* offsets;
+  uint64_t total_bytes;      // offsets[n_reads]
+  uint64_t* hashes;
+  uint32_t* pos;
+  uint64_t* counts;          // optional (count pass, zeroed by the host): per-read emitted windows
+  uint64_t* tile_counts;
+  const uint64_t* tile_off;
+  const uint64_t* nz_read;
+  const uint64_t* nz_rc;
+  const uint64_t* tile_j0;
+  const uint64_t* tile_rem0;
+  const uint4* init_tab;
+  uint64_t n_nz, total_runs, n_wtiles;
+  uint32_t k, m, C, ntab;
+  uint32_t waves, bits_dwords, vbits_dwords, tile_u64;
+  uint64_t tab[16][2];
+  uint64_t mult[KF_MAX_RUNTIME_M];
+};
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerRaggedArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t k = a.k, m = a.m, C = a.C;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+
+  // LDS: tables | pair table | multipliers | per wave {hash tile, pos tile, bits, vbits, read table}
+  uint4* itab = (uint4*)lds_dyn;
+  uint4* ptab = itab + a.ntab * 256u;
+  uint64_t* mults = (uint64_t*)(ptab + 16);
+  constexpr uint32_t RT_DWORDS = 64 * 8; // per listed read: run begin, vector begin, q_lo, windows, read lo/hi, spare
+  const uint32_t per_wave = a.tile_u64 * 3u + a.bits_dwords + a.vbits_dwords + RT_DWORDS;
+  uint32_t* wave_base = (uint32_t*)(mults + KF_MAX_RUNTIME_M) + wave * per_wave;
+  uint64_t* tile = (uint64_t*)wave_base;
+  uint32_t* ptile = wave_base + a.tile_u64 * 2u;
+  uint32_t* bits = ptile + a.tile_u64;
+  uint16_t* vbits = (uint16_t*)(bits + a.bits_dwords);
+  uint32_t* rt_begin = bits + a.bits_dwords + a.vbits_dwords; // first run (tile-relative) of listed read j
+  uint32_t* rt_vbeg = rt_begin + 64;                          // first staged vector of read j
+  uint32_t* rt_qlo = rt_vbeg + 64;                            // first run of read j in this tile
+  uint32_t* rt_nwin = rt_qlo + 64;                            // windows of read j (saturated to 2^32-1)
+  uint64_t* rt_read = (uint64_t*)(rt_nwin + 64);              // read index
+  uint64_t* rt_addr = rt_read + 64;                           // byte offset of the first staged byte
+
+  if (MODE == NA_MODE_HASH) {
+    for (uint32_t i = tid; i < a.ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
+    if (tid < 16)
+      ptab[tid] = make_uint4((uint32_t)a.tab[tid][0], (uint32_t)(a.tab[tid][0] >> 32),
+                             (uint32_t)a.tab[tid][1], (uint32_t)(a.tab[tid][1] >> 32));
+    if (tid < KF_MAX_RUNTIME_M) mults[tid] = a.mult[tid];
+  }
+  __syncthreads();
+
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+  auto wave_incl_scan32 = [&](uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(v, d, 64);
+      if ((int)lane >= d) v += o;
+    }
+    return v;
+  };
+  // last j in [0,64) with arr[j] <= x (arr non-decreasing, arr[0] <= x)
+  auto search64 = [&](const uint32_t* arr, uint32_t x) {
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = 32; step > 0; step >>= 1)
+      if (lo + step < 64u && arr[lo + step] <= x) lo += step;
+    return lo;
+  };
+
+  const uint64_t per_block = (a.n_wtiles + gridDim.x - 1) / gridDim.x;
+  const uint64_t t_begin = (uint64_t)blockIdx.x * per_block;
+  const uint64_t t_end = t_begin + per_block < a.n_wtiles ? t_begin + per_block : a.n_wtiles;
+  for (uint64_t wt = t_begin + wave; wt < t_end; wt += a.waves) {
+    const uint64_t g0 = wt * 64u;
+    const uint64_t runs_left = a.total_runs - g0;
+    const uint32_t runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
+    const uint64_t j0 = a.tile_j0[wt];
+    const uint32_t rem0 = (uint32_t)a.tile_rem0[wt];
+    lds_sync();
+    // ---- the (at most 64) listed reads of this tile: one per lane ------------------
+    uint32_t take = 0, q_lo = 0, nv = 0, nwin32 = 0;
+    uint64_t rd = 0, byte0 = 0;
+    {
+      const uint64_t jj = j0 + lane;
+      uint64_t avail = 0, rcj = 0, len = 0, start = 0;
+      if (jj < a.n_nz) {
+        rd = a.nz_read[jj];
+        rcj = a.nz_rc[jj];
+        start = a.offsets[rd];
+        len = a.offsets[rd + 1] - start;
+        q_lo = lane == 0 ? rem0 : 0u;
+        avail = rcj - q_lo;
+      }
+      const uint32_t av32 = avail > 64u ? 64u : (uint32_t)avail; // a tile never takes more than 64 runs
+      const uint32_t end = wave_incl_scan32(av32);
+      const uint32_t begin = end - av32;
+      take = begin < runs_here ? (runs_here - begin < av32 ? runs_here - begin : av32) : 0u;
+      const uint64_t nwin = len >= k ? len - k + 1 : 0;
+      nwin32 = nwin > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nwin;
+      if (take) {
+        const uint64_t first_b = (uint64_t)q_lo * C;
+        uint64_t last_b = (uint64_t)(q_lo + take) * C + k - 1; // one past the last needed byte
+        if (last_b > len) last_b = len;
+        nv = (uint32_t)((last_b - first_b + 15u) >> 4);
+        byte0 = start + first_b;
+      }
+      const uint32_t vend = wave_incl_scan32(nv);
+      rt_begin[lane] = take ? begin : 0xFFFFFFFFu; // reads past the tile never match a search
+      rt_vbeg[lane] = take ? vend - nv : 0xFFFFFFFFu;
+      rt_qlo[lane] = q_lo;
+      rt_nwin[lane] = nwin32;
+      rt_read[lane] = rd;
+      rt_addr[lane] = byte0;
+    }
+    const uint32_t v_total = __shfl(wave_incl_scan32(nv), 63, 64);
+    lds_sync();
+    // ---- stage the needed bytes of every listed read, packed back to back ------------
+    for (uint32_t v = lane; v < v_total; v += 64u) {
+      const uint32_t j = search64(rt_vbeg, v);
+      const uint64_t off = rt_addr[j] + ((uint64_t)(v - rt_vbeg[j]) << 4);
+      uint4 x;
+      if (off + 16u <= a.total_bytes) {
+        __builtin_memcpy(&x, a.seqs + off, 16); // unaligned 16-byte load (one global_load_dwordx4)
+      } else { // the very end of the caller's buffer: never read past it
+        uint32_t wv[4] = {0, 0, 0, 0};
+        for (uint32_t b = 0; b < 16u && off + b < a.total_bytes; ++b)
+          wv[b >> 2] |= (uint32_t)a.seqs[off + b] << ((b & 3u) * 8u);
+        x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      }
+      uint32_t i0, i1, i2, i3;
+      const uint32_t c0 = pack4v(x.x, i0), c1 = pack4v(x.y, i1), c2 = pack4v(x.z, i2), c3 = pack4v(x.w, i3);
+      bits[v] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+      vbits[v] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+    }
+    if (lane < (uint32_t)NW + 3u) bits[v_total + lane] = 0;
+    if (lane < 6u) vbits[v_total + lane] = 0xFFFFu;
+    lds_sync();
+
+    // ---- this lane's run -------------------------------------------------------------
+    const bool live = lane < runs_here;
+    const uint32_t j = search64(rt_begin, live ? lane : 0u);
+    const uint32_t q = rt_qlo[j] + ((live ? lane : 0u) - rt_begin[j]);
+    const uint32_t nwin_j = rt_nwin[j];
+    const uint64_t w_first = (uint64_t)q * C;
+    const uint32_t c_run = !live ? 0u : (nwin_j - w_first < C ? (uint32_t)(nwin_j - w_first) : C);
+    const uint32_t b0 = (rt_vbeg[j] << 4) + (q - rt_qlo[j]) * C;
+    uint32_t valid;
+    {
+      const uint32_t* vw = (const uint32_t*)vbits;
+      const uint32_t dw = b0 >> 5, sh = b0 & 31u;
+      const uint32_t x0 = vw[dw], x1 = vw[dw + 1], x2 = vw[dw + 2];
+      uint64_t r = ((uint64_t)funnel(x2, x1, sh) << 32) | funnel(x1, x0, sh);
+      uint32_t span = 1;
+      while (2u * span <= k) {
+        r |= r >> span;
+        span *= 2u;
+      }
+      if (k > span) r |= r >> (k - span);
+      valid = (~(uint32_t)r) & (c_run >= 32u ? 0xFFFFFFFFu : ((1u << c_run) - 1u));
+    }
+    const uint32_t cnt = __builtin_popcount(valid);
+    const uint32_t incl = wave_incl_scan32(cnt);
+    const uint32_t lane_off = incl - cnt;
+    const uint32_t total = __shfl(incl, 63, 64);
+
+    if (MODE == NA_MODE_COUNT) {
+      if (lane == 0) a.tile_counts[wt] = total;
+      if (a.counts && cnt) atomicAdd((unsigned long long*)&a.counts[rt_read[j]], (unsigned long long)cnt);
+      continue;
+    }
+
+    // ---- hash the run, drop valid hashes at their compacted slots ------------------------
+    const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
+    uint32_t w[NW];
+    {
+      uint32_t lo = bits[d0];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const uint32_t hi = bits[d0 + i + 1];
+        w[i] = funnel(hi, lo, sh0);
+        lo = hi;
+      }
+    }
+    uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
+#pragma unroll
+    for (int jt = 0; jt < 4 * NW; ++jt) {
+      if ((uint32_t)jt < a.ntab) {
+        const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+        const uint4 e = itab[(uint32_t)jt * 256u + byte];
+        f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
+      }
+    }
+    uint32_t slot = lane_off;
+    const bool want_pos = a.pos != nullptr;
+    const uint32_t p_first = (uint32_t)w_first;
+    auto emit = [&](uint32_t jw) {
+      if ((valid >> jw) & 1u) {
+        tile[slot] = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+        if (want_pos) ptile[slot] = p_first + jw;
+        ++slot;
+      }
+    };
+    emit(0u);
+    const uint32_t bi = b0 + k;
+    const uint32_t di = bi >> 4, shi = (bi & 15u) << 1;
+    for (uint32_t jw = 0; jw * 16u + 1u < C; ++jw) {
+      const uint32_t w_in = funnel(bits[di + jw + 1], bits[di + jw], shi);
+      const uint32_t w_out = funnel(bits[d0 + jw + 1], bits[d0 + jw], sh0);
+      const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
+      const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
+      const uint32_t left = C - 1u - jw * 16u;
+      const uint32_t ns = left < 16u ? left : 16u;
+#pragma unroll 2
+      for (uint32_t i = 0; i < ns; ++i) {
+        const uint32_t src = (i & 1u) ? v : u;
+        const uint32_t toff = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
+        const uint4 term = *(const uint4*)((const char*)ptab + toff);
+        srol_pair(f_lo, f_hi);
+        f_lo ^= term.x;
+        f_hi ^= term.y;
+        r_lo ^= term.z;
+        r_hi ^= term.w;
+        sror_pair(r_lo, r_hi);
+        emit(jw * 16u + i + 1u);
+      }
+    }
+    lds_sync();
+    const uint64_t o0 = a.tile_off[wt];
+    uint64_t* out0 = a.hashes + o0 * m;
+    if (m == 1) {
+      const uint32_t head = (uint32_t)(o0 & 1u) < total ? (uint32_t)(o0 & 1u) : total;
+      if (lane == 0 && head) out0[0] = tile[0];
+      const uint32_t n_pairs = (total - head) >> 1;
+      for (uint32_t pi = lane; pi < n_pairs; pi += 64u) {
+        const uint64_t x = tile[head + 2u * pi], y = tile[head + 2u * pi + 1u];
+        *(uint4*)(out0 + head + 2u * pi) = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32));
+      }
+      if (lane == 0 && ((total - head) & 1u)) out0[total - 1u] = tile[total - 1u];
+    } else {
+      const uint32_t nvals = total * m;
+      for (uint32_t vi = lane; vi < nvals; vi += 64u) {
+        const uint32_t e = vi / m, jj = vi - e * m;
+        const uint64_t h0 = tile[e];
+        out0[vi] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
+      }
+    }
+    if (want_pos)
+      for (uint32_t e = lane; e < total; e += 64u) a.pos[o0 + e] = ptile[e];
+  }
+}
+
+} // namespace ntamd

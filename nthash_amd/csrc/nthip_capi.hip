@@ -21,6 +21,7 @@
 #include "kmer_kernels.hpp"
 #include "kmer_runs_kernel.hpp"
 #include "kmer_runs_na_kernel.hpp"
+#include "kmer_ragged_kernel.hpp"
 #include "nt_math.hpp"
 #include "seed_kernels.hpp"
 #include "seed_parse.hpp"
@@ -74,6 +75,8 @@ struct nthip_ctx {
   // scratch for counts / scan
   uint64_t* d_scratch = nullptr;
   size_t d_scratch_elems = 0;
+  uint64_t* d_scratch2 = nullptr; // second area (tile-level arrays next to read-level ones)
+  size_t d_scratch2_elems = 0;
   bool profiling = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
@@ -105,6 +108,17 @@ int ensure_scratch(nthip_ctx* c, size_t elems)
   c->d_scratch_elems = 0;
   HIPCHK(hipMalloc((void**)&c->d_scratch, elems * sizeof(uint64_t)));
   c->d_scratch_elems = elems;
+  return NTHIP_OK;
+}
+
+int ensure_scratch2(nthip_ctx* c, size_t elems)
+{
+  if (c->d_scratch2_elems >= elems) return NTHIP_OK;
+  if (c->d_scratch2) HIPCHK(hipFree(c->d_scratch2));
+  c->d_scratch2 = nullptr;
+  c->d_scratch2_elems = 0;
+  HIPCHK(hipMalloc((void**)&c->d_scratch2, elems * sizeof(uint64_t)));
+  c->d_scratch2_elems = elems;
   return NTHIP_OK;
 }
 
@@ -369,6 +383,7 @@ extern "C" int nthip_ctx_destroy(nthip_ctx* c)
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->d_args) (void)hipFree(c->d_args);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->d_scratch2) (void)hipFree(c->d_scratch2);
   for (auto& kv : c->init_tabs) (void)hipFree(kv.second);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -691,6 +706,143 @@ int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t 
   return NTHIP_OK;
 }
 
+// Variable-length reads: pre-pass (runs per read, list of reads with windows, tile table) ->
+// count pass -> scan -> compact hash pass (kmer_ragged_kernel.hpp).  *handled = false when the
+// shape is outside this path (k, m, LDS), the caller then uses the general kernel.
+template <int NW>
+int launch_kmer_ragged(nthip_ctx* c, int mode, const KmerRaggedArgs& a, size_t dyn_lds)
+{
+  auto kernel = mode == NA_MODE_COUNT ? kmer_ragged_kernel<NA_MODE_COUNT, NW> : kmer_ragged_kernel<NA_MODE_HASH, NW>;
+  int per_cu = 1;
+  NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
+  const uint64_t need = (a.n_wtiles + a.waves - 1) / a.waves;
+  uint64_t grid = (uint64_t)c->n_cu * per_cu;
+  if (grid > need) grid = need;
+  if (mode == NA_MODE_HASH) prof_begin(c, "kmer_ragged_kernel");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
+  if (mode == NA_MODE_HASH) prof_end(c);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+int run_kmer_ragged(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint64_t total_bytes, uint32_t k,
+                    uint32_t m, uint64_t capacity, uint64_t* total, bool* handled)
+{
+  *handled = false;
+  const uint32_t C = 15; // run length; the last run of a read may be shorter
+  if (k > 64 || C + k - 1 > 64 || m > (uint32_t)KF_MAX_RUNTIME_M || st.fwd || st.rev) return NTHIP_OK;
+  const uint64_t n = rd->n_reads;
+  const uint32_t nw = (k + 15) / 16;
+  // per-wave LDS: a tile touches <= 64 listed reads, each staging its runs' bytes rounded up to 16
+  const uint32_t max_vec = (64 * C + 64 * (k - 1 + 15 + 15)) / 16 + 64;
+  const uint32_t bits_dwords = (max_vec + nw + 8 + 3u) & ~3u;
+  const uint32_t vbits_dwords = ((max_vec + 8) / 2 + 3 + 3u) & ~3u;
+  const uint32_t tile_u64 = 64 * C;
+  const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
+  const size_t per_wave = (size_t)tile_u64 * 12 + (size_t)bits_dwords * 4 + (size_t)vbits_dwords * 4 + 512 * 4;
+  const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
+  uint32_t waves = 0;
+  for (uint32_t w = 8; w >= 1; --w)
+    if (fixed + per_wave * w <= cap) { waves = w; break; }
+  if (!waves) return NTHIP_OK;
+  *handled = true;
+
+  // ---- pre-pass over reads ----------------------------------------------------------------
+  const uint64_t nb_r = (n + SCAN_TILE - 1) / SCAN_TILE;
+  NTCHK(ensure_scratch(c, 5 * n + nb_r + 16));
+  uint64_t* d_rc = c->d_scratch;
+  uint64_t* d_flag = c->d_scratch + n;      // flag, then (scanned) nz index
+  uint64_t* d_nz_read = c->d_scratch + 2 * n;
+  uint64_t* d_nz_rc = c->d_scratch + 3 * n;
+  uint64_t* d_run_base = c->d_scratch + 4 * n;
+  uint64_t* d_sums = c->d_scratch + 5 * n;
+  uint64_t* d_total = (uint64_t*)(c->d_small + 8);
+  const unsigned rblocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(ragged_runs_kernel, dim3(rblocks), dim3(256), 0, c->stream, st.offsets, n, k, C, d_rc, d_flag);
+  NTCHK(device_exclusive_scan(c, d_flag, d_flag, n, d_sums, d_total));
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t n_nz = 0;
+  memcpy(&n_nz, c->h_small + 8, 8);
+  *total = 0;
+  if (n_nz == 0) { // no read has a window
+    if (st.counts) HIPCHK(hipMemsetAsync(st.counts, 0, n * sizeof(uint64_t), c->stream));
+    return NTHIP_OK;
+  }
+  hipLaunchKernelGGL(ragged_scatter_kernel, dim3(rblocks), dim3(256), 0, c->stream, d_rc, d_flag, n, d_nz_read,
+                     d_nz_rc);
+  NTCHK(device_exclusive_scan(c, d_nz_rc, d_run_base, n_nz, d_sums, d_total));
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t total_runs = 0;
+  memcpy(&total_runs, c->h_small + 8, 8);
+  const uint64_t nt = (total_runs + 63) / 64;
+  const uint64_t nb_t = (nt + SCAN_TILE - 1) / SCAN_TILE;
+  NTCHK(ensure_scratch2(c, 4 * nt + nb_t + 16));
+  uint64_t* d_tile_j0 = c->d_scratch2;
+  uint64_t* d_tile_rem0 = c->d_scratch2 + nt;
+  uint64_t* d_tile_cnt = c->d_scratch2 + 2 * nt;
+  uint64_t* d_tile_off = c->d_scratch2 + 3 * nt;
+  uint64_t* d_sums2 = c->d_scratch2 + 4 * nt;
+  hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, d_run_base,
+                     n_nz, nt, d_tile_j0, d_tile_rem0);
+  HIPCHK(hipGetLastError());
+
+  KmerRaggedArgs a;
+  memset(&a, 0, sizeof a);
+  KmerFixedArgs consts;
+  memset(&consts, 0, sizeof consts);
+  fill_kmer_consts(k, m, consts);
+  a.seqs = st.seqs;
+  a.offsets = st.offsets;
+  a.total_bytes = total_bytes;
+  a.hashes = st.hashes;
+  a.pos = st.pos;
+  a.counts = st.counts;
+  a.tile_counts = d_tile_cnt;
+  a.tile_off = d_tile_off;
+  a.nz_read = d_nz_read;
+  a.nz_rc = d_nz_rc;
+  a.tile_j0 = d_tile_j0;
+  a.tile_rem0 = d_tile_rem0;
+  NTCHK(get_init_tab(c, k, &a.init_tab));
+  a.n_nz = n_nz;
+  a.total_runs = total_runs;
+  a.n_wtiles = nt;
+  a.k = k;
+  a.m = m;
+  a.C = C;
+  a.ntab = (k + 3) / 4;
+  a.waves = waves;
+  a.bits_dwords = bits_dwords;
+  a.vbits_dwords = vbits_dwords;
+  a.tile_u64 = tile_u64;
+  memcpy(a.tab, consts.tab, sizeof a.tab);
+  memcpy(a.mult, consts.mult, sizeof a.mult);
+  const size_t lds = fixed + per_wave * waves;
+  auto launch = [&](int mode) -> int {
+    switch (nw) {
+      case 1: return launch_kmer_ragged<1>(c, mode, a, lds);
+      case 2: return launch_kmer_ragged<2>(c, mode, a, lds);
+      case 3: return launch_kmer_ragged<3>(c, mode, a, lds);
+      default: return launch_kmer_ragged<4>(c, mode, a, lds);
+    }
+  };
+  if (st.counts) HIPCHK(hipMemsetAsync(st.counts, 0, n * sizeof(uint64_t), c->stream));
+  NTCHK(launch(NA_MODE_COUNT));
+  NTCHK(device_exclusive_scan(c, d_tile_cnt, d_tile_off, nt, d_sums2, d_total));
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(total, c->h_small + 8, 8);
+  if (*total > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
+                (unsigned long long)capacity, (unsigned long long)*total);
+  a.counts = nullptr;
+  NTCHK(launch(NA_MODE_HASH));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
 int run_kmer_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m,
                      uint64_t capacity, uint64_t* total)
 {
@@ -931,6 +1083,13 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
     if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
     NTCHK(rc);
     done = true;
+  }
+  if (!done && rd->offsets && !(flags & NTHIP_FORCE_GENERAL)) {
+    bool handled = false;
+    int rc = run_kmer_ragged(c, st, rd, total_bytes, k, m, out->capacity, &total, &handled);
+    if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
+    NTCHK(rc);
+    done = handled;
   }
   if (!done) NTCHK(run_kmer_general(c, st, rd, k, m, out->capacity, &total));
   if (total_out) *total_out = total;

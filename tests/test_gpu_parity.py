@@ -218,6 +218,43 @@ def test_kmer_ragged_reads_vs_oracle(ctx, oracle):
             assert (got[key] == want[key]).all(), (k, m, key)
 
 
+def test_kmer_ragged_fast_path_vs_oracle(ctx, oracle):
+    """variable-length reads through the run-split ragged kernel (no strand outputs requested):
+    reads shorter than k, empty reads, long reads spanning many tiles, bursts of tiny reads between
+    real ones, non-bases everywhere -- stream, positions and per-read counts must be the reference's"""
+    rng = np.random.default_rng(314)
+    alph = np.frombuffer(b"ACGTacgtUuNnRYKM-*", dtype=np.uint8)
+    for k, m in [(31, 1), (31, 4), (5, 2), (21, 1), (50, 1), (17, 3)]:
+        reads = []
+        for _ in range(600):
+            p = rng.random()
+            L = int(rng.integers(0, 40)) if p < 0.15 else int(rng.integers(40, 400)) if p < 0.97 else int(rng.integers(3000, 20000))
+            if rng.random() < 0.5:
+                idx = rng.integers(0, 4, L)
+            else:
+                idx = np.where(rng.random(L) < 0.97, rng.integers(0, 10, L), rng.integers(10, len(alph), L))
+            reads.append(alph[idx].tobytes())
+        reads[5:5] = [b"AC"] * 300            # a burst of reads without any window
+        reads += [b"", b"A" * k, b"ACGT" * 2000, b"N" * 200, b"ACGTN" * 50]
+        d, offs = concat_reads(reads)
+        want = oracle.kmer_batch(d, offs, k, m)
+        got = ctx.kmer_hash(d, k, m, offsets=offs, want_pos=True)
+        assert got["total"] == want["total"], (k, m)
+        for key in ("counts", "pos", "hashes"):
+            assert (got[key] == want[key]).all(), (k, m, key)
+        got = ctx.kmer_hash(d, k, m, offsets=offs)          # without positions
+        assert (got["hashes"] == want["hashes"]).all() and (got["counts"] == want["counts"]).all()
+        gen = ctx.kmer_hash(d, k, m, offsets=offs, flags=4)  # the lane-per-read kernel agrees
+        assert (gen["hashes"] == want["hashes"]).all()
+    # degenerate batches
+    for reads in ([b""], [b"AC", b"A"], [b"ACGTACGTAC"] * 3, [b"N" * 100]):
+        d, offs = concat_reads(reads)
+        want = oracle.kmer_batch(d, offs, 5, 2)
+        got = ctx.kmer_hash(d, 5, 2, offsets=offs, want_pos=True)
+        assert got["total"] == want["total"] and (got["counts"] == want["counts"]).all()
+        assert (got["hashes"] == want["hashes"]).all()
+
+
 def test_kmer_long_reads_are_segmented(ctx, oracle):
     """reads far longer than a segment (1024 windows) next to short and empty ones: the general
     kernel cuts them into segments that restart the roll; stream, positions and counts must not change"""
