@@ -48,3 +48,20 @@ def ctx(built_lib):
     c = nthash_amd.Context(0)  # raises NtHipError(NODEVICE) without a GPU: gpu tests only
     yield c
     c.close()
+
+
+@pytest.fixture(scope="session")
+def facade(built_lib):
+    """oracle/ref_shim.cpp (the driver that also runs the REAL reference when fixtures are
+    generated) compiled against nthash_amd's own header + libnthash.so: drives our C++ facade."""
+    import subprocess
+
+    from oracle.pyoracle import Reference
+    lib = os.path.join(ROOT, "nthash_amd", "lib")
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libfacade_shim.so")
+    src = os.path.join(ROOT, "oracle", "ref_shim.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", f"-I{os.path.join(ROOT, 'include')}",
+                           src, "-o", so, f"-L{lib}", "-lnthash", "-lnthash_hip", f"-Wl,-rpath,{lib}"])
+    return Reference(so_path=so)

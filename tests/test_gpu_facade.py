@@ -23,19 +23,6 @@ def h2i(xs):
     return np.array([int(x, 16) for x in xs], dtype=np.uint64)
 
 
-@pytest.fixture(scope="session")
-def facade(built_lib):
-    from oracle.pyoracle import Reference
-    lib = os.path.join(ROOT, "nthash_amd", "lib")
-    out_dir = os.path.join(ROOT, "tests", "_build")
-    os.makedirs(out_dir, exist_ok=True)
-    so = os.path.join(out_dir, "libfacade_shim.so")
-    src = os.path.join(ROOT, "oracle", "ref_shim.cpp")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", f"-I{os.path.join(ROOT, 'include')}",
-                           src, "-o", so, f"-L{lib}", "-lnthash", "-lnthash_hip", f"-Wl,-rpath,{lib}"])
-    return Reference(so_path=so)
-
-
 def test_facade_is_ours(facade):
     assert facade.fn_name() == "ntHash_v2"
     maps = open("/proc/self/maps").read()
