@@ -130,6 +130,20 @@ int nthip_seeds_destroy(nthip_seeds* seeds);
 int nthip_seed_hash(nthip_ctx* ctx, const nthip_reads* reads, const nthip_seeds* seeds,
                     uint8_t m2, const nthip_out* out, uint64_t* total, uint32_t flags);
 
+/*
+ * nthip_kmer_extend: the batched form of the de Bruijn graph query BlindNtHash exists
+ * for (include/nthash/nthash.hpp:36-41): for each of n k-mers (n*k ASCII bytes, no
+ * separators) the hashes of its 4 possible successors and/or predecessors, i.e. what
+ *     nthash::BlindNtHash h(kmer, m, k);                  // src/kmer.cpp:338-353
+ *     h.peek("ACGT"[b]);  / h.peek_back("ACGT"[b]);       // src/kmer.cpp:377-393
+ * leave in h.hashes().  Layout: next[(i*4 + b)*m + j], prev[(i*4 + b)*m + j], self[i*m + j]
+ * (the k-mer's own hashes); any of the three may be NULL.  Like BlindNtHash, bytes are not
+ * validated; k-mers must consist of bases (ACGTU, either case) -- for other bytes the
+ * reference's constructor reads its tetramer tables out of contract (src/kmer.cpp:50-54).
+ */
+int nthip_kmer_extend(nthip_ctx* ctx, const char* kmers, uint64_t n_kmers, uint16_t k, uint8_t m,
+                      uint64_t* self, uint64_t* next, uint64_t* prev, uint32_t flags);
+
 /* ---- measurement helpers (device-resident synthetic data, checksums) ---- */
 /* counter-based reads: read r, 32-base word w ->
  * splitmix64(seed + r*W + w), 2 bits per base, "ACGT"[..]; writes

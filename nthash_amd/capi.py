@@ -31,7 +31,7 @@ SYMBOLS = [
     "nthip_ctx_destroy", "nthip_ctx_set_stream", "nthip_ctx_synchronize",
     "nthip_ctx_set_profiling", "nthip_last_kernel_ms", "nthip_malloc", "nthip_free",
     "nthip_memcpy_h2d", "nthip_memcpy_d2h", "nthip_kmer_hash", "nthip_seeds_create",
-    "nthip_seeds_destroy", "nthip_seed_hash", "nthip_synth_reads", "nthip_checksum",
+    "nthip_seeds_destroy", "nthip_seed_hash", "nthip_kmer_extend", "nthip_synth_reads", "nthip_checksum",
     "nthip_copy_bench",
 ]
 
@@ -86,6 +86,7 @@ def load():
     L.nthip_seeds_destroy.argtypes = [vp]
     L.nthip_seed_hash.argtypes = [vp, C.POINTER(Reads), vp, C.c_uint8, C.POINTER(Out),
                                   C.POINTER(u64), u32]
+    L.nthip_kmer_extend.argtypes = [vp, vp, u64, C.c_uint16, C.c_uint8, vp, vp, vp, u32]
     L.nthip_synth_reads.argtypes = [vp, vp, u64, u64, u32, u64]
     L.nthip_checksum.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
     L.nthip_copy_bench.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
@@ -208,6 +209,25 @@ class Context:
             err.total = total.value
             raise err
         return total.value
+
+    def kmer_extend(self, kmers, k, m, want_self=True, want_next=True, want_prev=True):
+        """host k-mers (n*k bytes) -> dict of self [n,m], next [n,4,m], prev [n,4,m] (base order ACGT)"""
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint8)
+        n = kmers.size // k
+        se = np.zeros(n * m, np.uint64) if want_self else None
+        nx = np.zeros(n * 4 * m, np.uint64) if want_next else None
+        pv = np.zeros(n * 4 * m, np.uint64) if want_prev else None
+        p = lambda a: a.ctypes.data if a is not None else None
+        _chk(self.L.nthip_kmer_extend(self.h, kmers.ctypes.data, n, k, m, p(se), p(nx), p(pv),
+                                      NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT))
+        out = {}
+        if want_self:
+            out["self"] = se.reshape(n, m)
+        if want_next:
+            out["next"] = nx.reshape(n, 4, m)
+        if want_prev:
+            out["prev"] = pv.reshape(n, 4, m)
+        return out
 
     def synth_reads_ptr(self, dptr, first_read, n_reads, length, seed=42):
         _chk(self.L.nthip_synth_reads(self.h, C.c_void_p(dptr), first_read, n_reads, length, seed))

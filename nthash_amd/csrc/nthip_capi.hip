@@ -1349,6 +1349,59 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
 }
 
 // ==========================================================================
+// batched graph-extension query
+// ==========================================================================
+extern "C" int nthip_kmer_extend(nthip_ctx* c, const char* kmers, uint64_t n, uint16_t k16, uint8_t m8,
+                                 uint64_t* self, uint64_t* next, uint64_t* prev, uint32_t flags)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  const uint32_t k = k16, m = m8;
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0"); // src/kmer.cpp:347-349
+  if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
+  if (n && !kmers) return fail(NTHIP_ERR_ARG, "kmers is NULL");
+  if (!self && !next && !prev) return fail(NTHIP_ERR_ARG, "no output requested");
+  HIPCHK(hipSetDevice(c->device));
+  if (n == 0) return NTHIP_OK;
+  std::vector<void*> owned;
+  auto cleanup = [&]() { for (void* p : owned) (void)hipFree(p); };
+  const uint8_t* d_in = (const uint8_t*)kmers;
+  uint64_t *d_self = self, *d_next = next, *d_prev = prev;
+  int rc = NTHIP_OK;
+  auto dev_alloc = [&](size_t bytes, void** p) -> int {
+    HIPCHK(hipMalloc(p, bytes));
+    owned.push_back(*p);
+    return NTHIP_OK;
+  };
+  if (flags & NTHIP_HOST_INPUT) {
+    void* p = nullptr;
+    rc = dev_alloc(n * k, &p);
+    if (rc == NTHIP_OK && hipMemcpyAsync(p, kmers, n * k, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+      rc = fail(NTHIP_ERR_HIP, "H2D copy failed");
+    d_in = (const uint8_t*)p;
+  }
+  if (rc == NTHIP_OK && (flags & NTHIP_HOST_OUTPUT)) {
+    if (self) rc = dev_alloc(n * m * 8, (void**)&d_self);
+    if (rc == NTHIP_OK && next) rc = dev_alloc(n * 4 * m * 8, (void**)&d_next);
+    if (rc == NTHIP_OK && prev) rc = dev_alloc(n * 4 * m * 8, (void**)&d_prev);
+  }
+  if (rc != NTHIP_OK) { cleanup(); return rc; }
+  prof_begin(c, "kmer_extend_kernel");
+  hipLaunchKernelGGL(kmer_extend_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, k, m,
+                     d_self, d_next, d_prev);
+  prof_end(c);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && (flags & NTHIP_HOST_OUTPUT)) {
+    if (self) e = hipMemcpyAsync(self, d_self, n * m * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && next) e = hipMemcpyAsync(next, d_next, n * 4 * m * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && prev) e = hipMemcpyAsync(prev, d_prev, n * 4 * m * 8, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  cleanup();
+  if (e != hipSuccess) return fail(NTHIP_ERR_HIP, "kmer_extend failed: %s", hipGetErrorString(e));
+  return NTHIP_OK;
+}
+
+// ==========================================================================
 // measurement helpers
 // ==========================================================================
 extern "C" int nthip_synth_reads(nthip_ctx* c, char* d_dst, uint64_t first_read, uint64_t n_reads,

@@ -7,6 +7,8 @@
 
 #include <cstdint>
 
+#include "nt_math.hpp"
+
 namespace ntamd {
 
 constexpr int SCAN_THREADS = 256;
@@ -156,6 +158,40 @@ __global__ __launch_bounds__(256) void checksum_kernel(const uint64_t* __restric
   if (threadIdx.x == 0) {
     partial[2 * blockIdx.x] = ss[0] + ss[1] + ss[2] + ss[3];
     partial[2 * blockIdx.x + 1] = sx[0] ^ sx[1] ^ sx[2] ^ sx[3];
+  }
+}
+
+// Batched BlindNtHash::peek / peek_back (src/kmer.cpp:377-393): one lane per k-mer.
+// The k-mer (bases only, not validated -- like BlindNtHash) is hashed directly, then the
+// 4 successors / predecessors follow from one roll step each.
+__global__ __launch_bounds__(256) void kmer_extend_kernel(const uint8_t* __restrict__ kmers, uint64_t n, uint32_t k,
+                                                         uint32_t m, uint64_t* __restrict__ self,
+                                                         uint64_t* __restrict__ next, uint64_t* __restrict__ prev)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* s = kmers + i * k;
+  const uint64_t f = direct_fwd((const char*)s, k), r = direct_rev((const char*)s, k);
+  const uint64_t base = (uint64_t)k * MULTISEED;
+  auto emit = [&](uint64_t* dst, uint64_t ff, uint64_t rr) {
+    const uint64_t h0 = ff + rr;
+    dst[0] = h0;
+    for (uint32_t j = 1; j < m; ++j) dst[j] = mix_hash(h0, (uint64_t)j ^ base);
+  };
+  if (self) emit(self + i * m, f, r);
+  const uint8_t first = s[0], last = s[k - 1];
+  const uint64_t out_f_next = srol_n(fwd_seed(first), k), out_r_next = rc_seed(first);
+  const uint64_t out_f_prev = fwd_seed(last), out_r_prev = srol_n(rc_seed(last), k);
+  const uint64_t sk_in_rc[4] = {srol_n(SEED_T, k), srol_n(SEED_G, k), srol_n(SEED_C, k), srol_n(SEED_A, k)};
+  const uint64_t sk_in_fw[4] = {srol_n(SEED_A, k), srol_n(SEED_C, k), srol_n(SEED_G, k), srol_n(SEED_T, k)};
+  const uint64_t in_fw[4] = {SEED_A, SEED_C, SEED_G, SEED_T}; // "ACGT"[b]
+  const uint64_t in_rc[4] = {SEED_T, SEED_G, SEED_C, SEED_A};
+#pragma unroll
+  for (uint32_t b = 0; b < 4; ++b) {
+    if (next) // next_forward_hash / next_reverse_hash, src/kmer.cpp:84-94,164-174
+      emit(next + (i * 4 + b) * m, srol1(f) ^ in_fw[b] ^ out_f_next, sror1(r ^ sk_in_rc[b] ^ out_r_next));
+    if (prev) // prev_forward_hash / prev_reverse_hash, src/kmer.cpp:104-114,184-194
+      emit(prev + (i * 4 + b) * m, sror1(f ^ sk_in_fw[b] ^ out_f_prev), srol1(r) ^ in_rc[b] ^ out_r_prev);
   }
 }
 

@@ -216,6 +216,19 @@ def main():
     for s in [SEED_A, SEED_B, "11100111", "101101", "110011", "1111", "0110", "1x01", "11111111111111101111111111"]:
         ps.append({"seed": s, "dont_care": ref.parse_seeds(s)})
     json.dump(ps, open(os.path.join(OUT, "parse_seeds.json"), "w"), indent=0)
+    # ---- 6. batched graph-extension query: BlindNtHash::peek / peek_back per base -------
+    ext = []
+    for _ in range(40):
+        k = int(rng.choice([3, 5, 16, 21, 31, 32, 33, 64, 100]))
+        m = int(rng.integers(1, 5))
+        # bases only (any case, U allowed): for other bytes the reference's constructor indexes its
+        # tetramer tables with CONVERT_TAB = 255 (src/kmer.cpp:50-54), which is not a defined hash
+        kmer = "".join("ACGTacgtUu"[i] for i in rng.integers(0, 10, k))
+        res = ref.blind_script(kmer, m, k, 0, "PAPCPGPTQAQCQGQT")
+        ext.append({"kmer": kmer, "k": k, "m": m, "self": hx(res[0][3]),
+                    "next": [hx(res[1 + b][3]) for b in range(4)],
+                    "prev": [hx(res[5 + b][3]) for b in range(4)]})
+    json.dump(ext, open(os.path.join(OUT, "extend_cases.json"), "w"), indent=0)
     print("fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

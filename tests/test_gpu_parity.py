@@ -565,3 +565,32 @@ def test_fuzz_seed_shapes(ctx, oracle):
         assert got["total"] == want["total"], (it, n, L, k, m2, seeds)
         assert (got["hashes"] == want["hashes"]).all(), (it, n, L, k, m2, seeds)
         assert (got["counts"] == want["counts"]).all()
+
+
+# ---------------------------------------------------------------------------
+# batched graph-extension query (BlindNtHash::peek / peek_back for all 4 bases)
+# ---------------------------------------------------------------------------
+def test_kmer_extend_golden(ctx):
+    for c in load_golden("extend_cases.json"):
+        kmer = np.frombuffer(c["kmer"].encode("latin-1"), dtype=np.uint8)
+        r = ctx.kmer_extend(kmer, c["k"], c["m"])
+        assert (r["self"][0] == h2i(c["self"])).all(), c["kmer"]
+        for b in range(4):
+            assert (r["next"][0, b] == h2i(c["next"][b])).all(), (c["kmer"], "next", b)
+            assert (r["prev"][0, b] == h2i(c["prev"][b])).all(), (c["kmer"], "prev", b)
+
+
+def test_kmer_extend_batch_consistency(ctx, oracle):
+    """a batch: successor b of k-mer i == the hash stream entry of (kmer[1:] + b); self == k-mer hash"""
+    rng = np.random.default_rng(12)
+    n, k, m = 5000, 31, 3
+    kmers = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (n, k))]
+    r = ctx.kmer_extend(kmers.ravel(), k, m)
+    offs = np.arange(n + 1, dtype=np.uint64) * k
+    want_self = oracle.kmer_batch(kmers.ravel(), offs, k, m, want_pos=False)["hashes"]
+    assert (r["self"] == want_self).all()
+    for b, ch in enumerate(b"ACGT"):
+        nxt = np.concatenate([kmers[:, 1:], np.full((n, 1), ch, np.uint8)], axis=1)
+        prv = np.concatenate([np.full((n, 1), ch, np.uint8), kmers[:, :-1]], axis=1)
+        assert (r["next"][:, b] == oracle.kmer_batch(nxt.ravel(), offs, k, m, want_pos=False)["hashes"]).all()
+        assert (r["prev"][:, b] == oracle.kmer_batch(prv.ravel(), offs, k, m, want_pos=False)["hashes"]).all()
