@@ -206,7 +206,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
       vbits[v] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
     }
     if (lane < (uint32_t)NW + 3u) bits[v_total + lane] = 0;
-    if (lane < 6u) vbits[v_total + lane] = 0xFFFFu;
+    if (lane < 10u) vbits[v_total + lane] = 0xFFFFu;
     lds_sync();
 
     // ---- this lane's run -------------------------------------------------------------
@@ -217,20 +217,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
     const uint64_t w_first = (uint64_t)q * C;
     const uint32_t c_run = !live ? 0u : (nwin_j - w_first < C ? (uint32_t)(nwin_j - w_first) : C);
     const uint32_t b0 = (rt_vbeg[j] << 4) + (q - rt_qlo[j]) * C;
-    uint32_t valid;
-    {
-      const uint32_t* vw = (const uint32_t*)vbits;
-      const uint32_t dw = b0 >> 5, sh = b0 & 31u;
-      const uint32_t x0 = vw[dw], x1 = vw[dw + 1], x2 = vw[dw + 2];
-      uint64_t r = ((uint64_t)funnel(x2, x1, sh) << 32) | funnel(x1, x0, sh);
-      uint32_t span = 1;
-      while (2u * span <= k) {
-        r |= r >> span;
-        span *= 2u;
-      }
-      if (k > span) r |= r >> (k - span);
-      valid = (~(uint32_t)r) & (c_run >= 32u ? 0xFFFFFFFFu : ((1u << c_run) - 1u));
-    }
+    const uint32_t valid = ~windows_with_non_base((const uint32_t*)vbits, b0, k) & ((1u << c_run) - 1u); // C <= 16
     const uint32_t cnt = __builtin_popcount(valid);
     const uint32_t incl = wave_incl_scan32(cnt);
     const uint32_t lane_off = incl - cnt;

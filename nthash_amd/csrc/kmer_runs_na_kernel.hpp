@@ -5,9 +5,11 @@
 // NtHash emits exactly the windows whose k bytes are all bases (the net effect
 // of init()/roll(), src/kmer.cpp:228-264).  That is a
 // parallel predicate, so the run-split decomposition still works:
-//   pass 1 (MODE_COUNT)  per wave tile (64 runs of C windows): a validity bit
-//                        per base, OR-ed over every window by doubling, popcount
-//                        -> valid windows per tile (and per read, on request);
+//   pass 1 (MODE_COUNT)  per wave tile (64 runs of up to C windows, geometry of
+//                        kmer_runs_gen_kernel.hpp but with DISJOINT runs: the last
+//                        run of a read is short): a validity bit per base, OR-ed
+//                        over every window by doubling, popcount -> valid windows
+//                        per tile (and per read, on request);
 //   host                 exclusive scan of the tile counts -> tile offsets;
 //   pass 2 (MODE_HASH)   the same tiles are hashed as in kmer_runs_kernel (a
 //                        non-base keeps a garbage 2-bit code; it enters and
@@ -37,9 +39,9 @@ struct KmerRunsNaArgs {
   const uint4* init_tab;
   uint64_t n_reads, n_runs, n_wtiles;
   uint32_t len, stride, k, m;
-  uint32_t nwin, C, rpr, ntab;
+  uint32_t nwin, C, rpr, ntab;   // rpr = ceil(nwin / C)
   uint32_t waves, bits_dwords, vbits_dwords, tile_u64;
-  uint32_t inv_rpr, pad0;
+  uint32_t inv_rpr, last_cnt;    // last_cnt = nwin - (rpr - 1) * C: windows of a read's last run
   uint64_t tab[16][2];
   uint64_t mult[KF_MAX_RUNTIME_M];
 };
@@ -58,12 +60,33 @@ __device__ __forceinline__ uint32_t pack4v(uint32_t w, uint32_t& inv4)
   return __builtin_amdgcn_udot4(t, 0x40100401u, 0u, false);
 }
 
-// C_T: compile-time run length (0 = runtime) -- unrolls the roll and prefetches its table terms
-template <int MODE, int NW, int C_T>
+// Which of the (up to 32) windows starting at bases b0, b0+1, ... hold a non-base.
+// vw: validity bit stream (1 = not a base); reads 128 bits from the dword of b0 on.
+// OR over k <= 64 consecutive bits by doubling, on a 96-bit register pair.
+__device__ __forceinline__ uint32_t windows_with_non_base(const uint32_t* vw, uint32_t b0, uint32_t k)
+{
+  const uint32_t dw = b0 >> 5, sh = b0 & 31u;
+  const uint32_t x0 = vw[dw], x1 = vw[dw + 1], x2 = vw[dw + 2], x3 = vw[dw + 3];
+  uint64_t lo = ((uint64_t)funnel(x2, x1, sh) << 32) | funnel(x1, x0, sh);
+  uint64_t hi = funnel(x3, x2, sh); // bits 64..95
+  auto fold = [&](uint32_t s) {     // bit j |= bit j + s, 1 <= s <= 32
+    lo |= (lo >> s) | (hi << (64u - s));
+    hi |= hi >> s;
+  };
+  uint32_t span = 1;
+  while (2u * span <= k) {
+    fold(span);
+    span *= 2u;
+  }
+  if (k > span) fold(k - span);
+  return (uint32_t)lo; // bit j exact for j + k - 1 <= 95
+}
+
+template <int MODE, int NW>
 __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_na_kernel(const KmerRunsNaArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
-  const uint32_t k = a.k, m = a.m, C = C_T ? (uint32_t)C_T : a.C;
+  const uint32_t k = a.k, m = a.m, C = a.C, rpr = a.rpr;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
   // LDS: init tables | pair table | multipliers | per wave {hash tile, pos tile, bits, validity bits}
@@ -98,14 +121,21 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_na_kernel(const Kmer
   const uint64_t t_end = t_begin + per_block < a.n_wtiles ? t_begin + per_block : a.n_wtiles;
   for (uint64_t wt = t_begin + wave; wt < t_end; wt += a.waves) {
     const uint64_t g0 = wt * 64u;
-    const uint64_t r_first = g0 / a.rpr;
-    const uint32_t rem0 = (uint32_t)(g0 - r_first * a.rpr);
+    const uint64_t r_first = g0 / rpr;
+    const uint32_t rem0 = (uint32_t)(g0 - r_first * rpr);
     const uint64_t runs_left = a.n_runs - g0;
     const uint32_t runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
-    const uint32_t n_slab_reads = (rem0 + runs_here - 1u) / a.rpr + 1u;
-    const uint64_t off = r_first * a.stride;
+    // gl = run index counted from run 0 of read r_first (gl < 64 + rpr) -> read, run in read
+    auto split = [&](uint32_t gl, uint32_t& lr_, uint32_t& q_) {
+      lr_ = rpr > 64u ? (gl >= rpr ? 1u : 0u) : (gl * a.inv_rpr) >> 16;
+      q_ = gl - lr_ * rpr;
+    };
+    // the slab: first base of the first run .. last base of the last run's last window
+    uint32_t lre, qe;
+    split(rem0 + runs_here - 1u, lre, qe);
+    const uint64_t off = r_first * a.stride + (uint64_t)rem0 * C;
     const uint32_t shift = (uint32_t)(((uint64_t)a.seqs + off) & 15u);
-    const uint32_t slab_bytes = (n_slab_reads - 1u) * a.stride + a.len;
+    const uint32_t slab_bytes = lre * a.stride + qe * C + (qe == rpr - 1u ? a.last_cnt : C) + k - 1u - rem0 * C;
     const uint32_t n_vec = (shift + slab_bytes + 15u) >> 4;
     lds_sync();
     // ---- stage: codes + one validity bit per base (bytes outside the slab are
@@ -118,31 +148,16 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_na_kernel(const Kmer
       vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
     }
     if (lane < (uint32_t)NW + 3u) bits[n_vec + lane] = 0;
-    if (lane < 6u) vbits[n_vec + lane] = 0xFFFFu; // beyond the slab: not a base
+    if (lane < 10u) vbits[n_vec + lane] = 0xFFFFu; // beyond the slab: not a base
     lds_sync();
 
     // ---- this lane's run and the validity of its C windows ----------------------
     const bool live = lane < runs_here;
-    const uint32_t gl = live ? rem0 + lane : rem0;
-    const uint32_t lr = (gl * a.inv_rpr) >> 16;
-    const uint32_t q = gl - lr * a.rpr;
-    const uint32_t b0 = shift + lr * a.stride + q * C;
-    uint32_t valid;
-    {
-      // 64 validity bits from base b0 on (the run touches C + k - 1 <= 64 bases)
-      const uint32_t* vw = (const uint32_t*)vbits;
-      const uint32_t dw = b0 >> 5, sh = b0 & 31u;
-      const uint32_t x0 = vw[dw], x1 = vw[dw + 1], x2 = vw[dw + 2];
-      uint64_t r = ((uint64_t)funnel(x2, x1, sh) << 32) | funnel(x1, x0, sh);
-      // bit j of r := OR of bits j .. j+k-1 (doubling, then one shift for the remainder)
-      uint32_t span = 1;
-      while (2u * span <= k) {
-        r |= r >> span;
-        span *= 2u;
-      }
-      if (k > span) r |= r >> (k - span);
-      valid = live ? (~(uint32_t)r) & (C >= 32u ? 0xFFFFFFFFu : ((1u << C) - 1u)) : 0u;
-    }
+    uint32_t lr, q;
+    split(live ? rem0 + lane : rem0, lr, q);
+    const uint32_t b0 = shift + lr * a.stride + q * C - rem0 * C;
+    const uint32_t c_run = live ? (q == rpr - 1u ? a.last_cnt : C) : 0u; // C <= 16
+    const uint32_t valid = ~windows_with_non_base((const uint32_t*)vbits, b0, k) & ((1u << c_run) - 1u);
     const uint32_t cnt = __builtin_popcount(valid);
     // wave exclusive scan of the per-lane counts
     uint32_t incl = cnt;
@@ -211,30 +226,31 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_na_kernel(const Kmer
         r_hi ^= term.w;
         sror_pair(r_lo, r_hi);
       };
-      if constexpr (C_T != 0 && C_T <= 17) {
-        constexpr uint32_t NS = (uint32_t)(C_T - 1);
-        constexpr uint32_t B = 8;
+      // table terms do not depend on the hash state: fetch a batch ahead of the dependent chain
+      auto batch = [&](uint32_t i0, auto n_tag) {
+        constexpr uint32_t N = decltype(n_tag)::value;
+        uint4 terms[N];
 #pragma unroll
-        for (uint32_t i0 = 0; i0 < NS; i0 += B) {
-          uint4 terms[B];
+        for (uint32_t i = 0; i < N; ++i) terms[i] = lookup(i0 + i);
 #pragma unroll
-          for (uint32_t i = 0; i < B; ++i)
-            if (i0 + i < NS) terms[i] = lookup(i0 + i);
-#pragma unroll
-          for (uint32_t i = 0; i < B; ++i)
-            if (i0 + i < NS) {
-              roll(terms[i]);
-              emit(i0 + i + 1u);
-            }
+        for (uint32_t i = 0; i < N; ++i) {
+          roll(terms[i]);
+          emit(jw * 16u + i0 + i + 1u);
         }
-      } else {
-        const uint32_t left = C - 1u - jw * 16u;
-        const uint32_t ns = left < 16u ? left : 16u;
-#pragma unroll 2
-        for (uint32_t i = 0; i < ns; ++i) {
-          roll(lookup(i));
-          emit(jw * 16u + i + 1u);
-        }
+      };
+      const uint32_t left = C - 1u - jw * 16u;
+      const uint32_t ns = left < 16u ? left : 16u;
+      uint32_t i0 = 0;
+      for (; i0 + 8u <= ns; i0 += 8u) batch(i0, std::integral_constant<uint32_t, 8u>{});
+      switch (ns - i0) {
+        case 1: batch(i0, std::integral_constant<uint32_t, 1u>{}); break;
+        case 2: batch(i0, std::integral_constant<uint32_t, 2u>{}); break;
+        case 3: batch(i0, std::integral_constant<uint32_t, 3u>{}); break;
+        case 4: batch(i0, std::integral_constant<uint32_t, 4u>{}); break;
+        case 5: batch(i0, std::integral_constant<uint32_t, 5u>{}); break;
+        case 6: batch(i0, std::integral_constant<uint32_t, 6u>{}); break;
+        case 7: batch(i0, std::integral_constant<uint32_t, 7u>{}); break;
+        default: break;
       }
     }
     lds_sync();

@@ -20,6 +20,7 @@
 
 #include "kmer_kernels.hpp"
 #include "kmer_runs_kernel.hpp"
+#include "kmer_runs_gen_kernel.hpp"
 #include "kmer_runs_na_kernel.hpp"
 #include "kmer_ragged_kernel.hpp"
 #include "nt_math.hpp"
@@ -603,47 +604,137 @@ int launch_kmer_runs(nthip_ctx* c, K kernel, KmerRunsArgs a, size_t dyn_lds)
   return NTHIP_OK;
 }
 
-// N-aware run-split path for fixed-length reads: count pass -> scan -> compact hash pass
-// (kmer_runs_na_kernel.hpp).  `plan` comes from kmer_runs_plan; needs C + k - 1 <= 64.
-template <int NW, int C_T>
-int launch_kmer_na(nthip_ctx* c, int mode, const KmerRunsNaArgs& a, size_t dyn_lds)
+// Geometry of the general run-split kernel (kmer_runs_gen_kernel.hpp): any window count.
+// The run length minimises lane work per k-mer: one first-window evaluation (about
+// 2 + ntab/2 roll steps' worth) plus C-1 rolls per run, the windows a read's last run recomputes included.
+struct GenPlan {
+  uint32_t C = 0, rpr = 0, last_start = 0, waves = 0, bits_dwords = 0, tile_u64 = 0, nw = 0, dword_tail = 0;
+  size_t lds = 0;
+};
+
+bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, GenPlan* p)
 {
-  auto kernel = mode == NA_MODE_COUNT ? kmer_runs_na_kernel<NA_MODE_COUNT, NW, C_T>
-                                      : kmer_runs_na_kernel<NA_MODE_HASH, NW, C_T>;
+  if (len < k || k > 64 || m > (uint32_t)KF_MAX_RUNTIME_M || stride > len || len >= (1u << 30)) return false;
+  const uint32_t nwin = len - k + 1;
+  if (stride < nwin) return false; // reads overlapping by more than k-1 bases: other paths
+  const uint32_t ntab = (k + 3) / 4;
+  uint32_t best = 0;
+  double best_cost = 1e30;
+  const uint32_t c_hi = nwin < 16 ? nwin : 16;
+  for (uint32_t C = c_hi; C >= 1; --C) {
+    const uint32_t rpr = (nwin + C - 1) / C;
+    // the 64 rows of a tile are C*8 bytes apart: an even C puts several lanes of a ds_write_b64 on the
+    // same LDS banks (16-way for C = 16), an odd C none
+    uint32_t g = 2 * C, ways = 1;
+    while (ways < 32 && (g & 1) == 0) { g >>= 1; ways <<= 1; }
+    ways = ways > 2 ? ways / 2 : 1;
+    const double cost = (double)rpr * (2.0 + 0.5 * ntab + (C - 1) * (1.0 + 0.05 * (ways - 1))) / nwin;
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = C; }
+  }
+  if (const char* t = getenv("NTHIP_TUNE_RUN_LEN")) { // A/B override
+    const uint32_t d = (uint32_t)atoi(t);
+    if (d >= 1 && d <= 16 && d <= nwin) best = d;
+  }
+  if (best == 0) return false;
+  p->C = best;
+  p->rpr = (nwin + best - 1) / best;
+  p->last_start = nwin - best;
+  p->nw = (k + 15) / 16;
+  p->tile_u64 = 64 * best + 128;
+  // longest slab: 63 run-to-run steps of at most C bases, C + stride - nwin across a read boundary, plus
+  // the last run
+  const uint64_t crossings = (63 + p->rpr - 1) / p->rpr;
+  const uint64_t slab_bytes = 64ull * best + k - 1 + crossings * (uint64_t)(stride - nwin);
+  uint32_t bd = (uint32_t)((15 + slab_bytes + 15) >> 4) + p->nw + 6;
+  bd = (bd + 3u) & ~3u;
+  p->bits_dwords = bd;
+  p->dword_tail = (15 + slab_bytes <= 1280) ? 1u : 0u;
+  const size_t fixed = (size_t)ntab * 4096 + 256 + 64;
+  const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4;
+  const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
+  uint32_t w_max = 8;
+  if (const char* t = getenv("NTHIP_TUNE_WAVES")) {
+    const uint32_t w = (uint32_t)atoi(t);
+    if (w >= 1 && w <= 16) w_max = w;
+  }
+  for (uint32_t w = w_max; w >= 1; --w)
+    if (fixed + per_wave * w <= cap) {
+      p->waves = w;
+      p->lds = fixed + per_wave * w;
+      return true;
+    }
+  return false;
+}
+
+template <typename K>
+int launch_kmer_runs_gen(nthip_ctx* c, K kernel, KmerRunsGenArgs a, size_t dyn_lds)
+{
   int per_cu = 1;
   NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
   const uint64_t need = (a.n_wtiles + a.waves - 1) / a.waves;
   uint64_t grid = (uint64_t)c->n_cu * per_cu;
   if (grid > need) grid = need;
-  if (mode == NA_MODE_HASH) prof_begin(c, "kmer_runs_na_kernel");
+  if (a.tile_map == 0xFFFFFFFFu) a.tile_map = (uint32_t)grid;
+  prof_begin(c, "kmer_runs_gen_kernel");
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
-  if (mode == NA_MODE_HASH) prof_end(c);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+// N-aware run-split path for fixed-length reads: count pass -> scan -> compact hash pass
+// (kmer_runs_na_kernel.hpp).  Geometry as the general run-split kernel, with disjoint runs.
+template <int MODE, int NW>
+int launch_kmer_na(nthip_ctx* c, const KmerRunsNaArgs& a, size_t dyn_lds)
+{
+  auto kernel = kmer_runs_na_kernel<MODE, NW>;
+  int per_cu = 1;
+  NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
+  const uint64_t need = (a.n_wtiles + a.waves - 1) / a.waves;
+  uint64_t grid = (uint64_t)c->n_cu * per_cu;
+  if (grid > need) grid = need;
+  if (MODE == NA_MODE_HASH) prof_begin(c, "kmer_runs_na_kernel");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
+  if (MODE == NA_MODE_HASH) prof_end(c);
   HIPCHK(hipGetLastError());
   return NTHIP_OK;
 }
 
 int launch_kmer_na_nw(nthip_ctx* c, int mode, const KmerRunsNaArgs& a, size_t dyn_lds, uint32_t nw)
 {
-  if (nw == 2 && a.C == 15) return launch_kmer_na<2, 15>(c, mode, a, dyn_lds);
+  if (mode == NA_MODE_COUNT) return launch_kmer_na<NA_MODE_COUNT, 1>(c, a, dyn_lds); // no hashing: NW unused
   switch (nw) {
-    case 1: return launch_kmer_na<1, 0>(c, mode, a, dyn_lds);
-    case 2: return launch_kmer_na<2, 0>(c, mode, a, dyn_lds);
-    case 3: return launch_kmer_na<3, 0>(c, mode, a, dyn_lds);
-    default: return launch_kmer_na<4, 0>(c, mode, a, dyn_lds);
+    case 1: return launch_kmer_na<NA_MODE_HASH, 1>(c, a, dyn_lds);
+    case 2: return launch_kmer_na<NA_MODE_HASH, 2>(c, a, dyn_lds);
+    case 3: return launch_kmer_na<NA_MODE_HASH, 3>(c, a, dyn_lds);
+    default: return launch_kmer_na<NA_MODE_HASH, 4>(c, a, dyn_lds);
   }
 }
 
-bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, RunsPlan* p,
-                  uint32_t* vbits_dwords)
+struct NaPlan {
+  uint32_t C = 0, rpr = 0, last_cnt = 0, waves = 0, bits_dwords = 0, vbits_dwords = 0, tile_u64 = 0, nw = 0;
+  size_t lds = 0;
+};
+
+bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, NaPlan* p)
 {
-  if (!kmer_runs_plan(c, len, stride, k, m, p)) return false;
-  if (p->C + k - 1 > 64 || p->C > 32) return false;
-  const uint32_t slab_reads = (64 % p->rpr == 0) ? 64 / p->rpr : (p->rpr - 1 + 63) / p->rpr + 1;
-  const uint64_t slab_bytes = (uint64_t)(slab_reads - 1) * stride + len;
+  GenPlan g;
+  if (!kmer_gen_plan(c, len, stride, k, m, &g)) return false;
+  const uint32_t nwin = len - k + 1;
+  p->C = g.C;
+  p->rpr = g.rpr;
+  p->last_cnt = nwin - (g.rpr - 1) * g.C;
+  p->nw = g.nw;
+  p->tile_u64 = 64 * g.C;
+  // longest slab: 63 run-to-run steps (C bases; stride - (rpr-1)*C across a read boundary) + the last run
+  const int64_t x = (int64_t)stride - (int64_t)g.rpr * g.C;
+  const uint64_t crossings = (63 + g.rpr - 1) / g.rpr;
+  const uint64_t slab_bytes = 64ull * g.C + k - 1 + (x > 0 ? crossings * (uint64_t)x : 0);
   const uint32_t n_vec = (uint32_t)((15 + slab_bytes + 15) >> 4);
-  *vbits_dwords = (((n_vec + 8) / 2 + 3) + 3u) & ~3u;
+  p->bits_dwords = (n_vec + g.nw + 6 + 3u) & ~3u;
+  p->vbits_dwords = ((n_vec + 12) / 2 + 2 + 3u) & ~3u;
   const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
-  const size_t per_wave = (size_t)p->tile_u64 * 12 + (size_t)p->bits_dwords * 4 + (size_t)*vbits_dwords * 4;
+  const size_t per_wave = (size_t)p->tile_u64 * 12 + (size_t)p->bits_dwords * 4 + (size_t)p->vbits_dwords * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
   for (uint32_t w = 8; w >= 1; --w)
     if (fixed + per_wave * w <= cap) {
@@ -655,8 +746,7 @@ bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k,
 }
 
 int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m,
-                const RunsPlan& plan, uint32_t vbits_dwords, const KmerFixedArgs& consts, uint64_t capacity,
-                uint64_t* total)
+                const NaPlan& plan, const KmerFixedArgs& consts, uint64_t capacity, uint64_t* total)
 {
   KmerRunsNaArgs a;
   memset(&a, 0, sizeof a);
@@ -678,9 +768,10 @@ int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t 
   a.ntab = (k + 3) / 4;
   a.waves = plan.waves;
   a.bits_dwords = plan.bits_dwords;
-  a.vbits_dwords = vbits_dwords;
+  a.vbits_dwords = plan.vbits_dwords;
   a.tile_u64 = plan.tile_u64;
   a.inv_rpr = 65536u / plan.rpr + 1u;
+  a.last_cnt = plan.last_cnt;
   memcpy(a.tab, consts.tab, sizeof a.tab);
   memcpy(a.mult, consts.mult, sizeof a.mult);
   const uint64_t nt = a.n_wtiles;
@@ -730,13 +821,13 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint6
 {
   *handled = false;
   const uint32_t C = 15; // run length; the last run of a read may be shorter
-  if (k > 64 || C + k - 1 > 64 || m > (uint32_t)KF_MAX_RUNTIME_M || st.fwd || st.rev) return NTHIP_OK;
+  if (k > 64 || m > (uint32_t)KF_MAX_RUNTIME_M || st.fwd || st.rev) return NTHIP_OK;
   const uint64_t n = rd->n_reads;
   const uint32_t nw = (k + 15) / 16;
   // per-wave LDS: a tile touches <= 64 listed reads, each staging its runs' bytes rounded up to 16
   const uint32_t max_vec = (64 * C + 64 * (k - 1 + 15 + 15)) / 16 + 64;
   const uint32_t bits_dwords = (max_vec + nw + 8 + 3u) & ~3u;
-  const uint32_t vbits_dwords = ((max_vec + 8) / 2 + 3 + 3u) & ~3u;
+  const uint32_t vbits_dwords = ((max_vec + 12) / 2 + 2 + 3u) & ~3u;
   const uint32_t tile_u64 = 64 * C;
   const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
   const size_t per_wave = (size_t)tile_u64 * 12 + (size_t)bits_dwords * 4 + (size_t)vbits_dwords * 4 + 512 * 4;
@@ -972,13 +1063,15 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
   uint32_t pad = 0;
   size_t dyn = 0;
   bool done = false;
+  // optimistic dense pass: wanted when the dense stream fits the caller's capacity (a batch with non-bases
+  // may still fit when the dense stream does not: the counting paths below decide that)
+  const bool rows_ok = !rd->offsets && kmer_fixed_eligible(c, len, stride, k, m, &pad, &dyn);
   const bool want_fast = !rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.pos && !st.fwd && !st.rev &&
-                         kmer_fixed_eligible(c, len, stride, k, m, &pad, &dyn);
+                         len >= k && rd->n_reads * (uint64_t)(len - k + 1) <= out->capacity;
   // fixed-length reads that are (or may be) dirty, or whose positions are wanted: N-aware run-split path
-  RunsPlan na_plan;
-  uint32_t na_vbits = 0;
+  NaPlan na_plan;
   const bool na_ok = !rd->offsets && !(flags & (NTHIP_FORCE_GENERAL | NTHIP_FORCE_ROWS)) && !st.fwd && !st.rev &&
-                     len >= k && kmer_na_plan(c, len, stride, k, m, &na_plan, &na_vbits);
+                     len >= k && kmer_na_plan(c, len, stride, k, m, &na_plan);
   if (!rd->offsets && len < k) {
     // every read shorter than k: nothing is emitted
     if (st.counts) {
@@ -989,11 +1082,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
   } else if (want_fast) {
     const uint32_t nwin = len - k + 1;
     const uint64_t dense = rd->n_reads * (uint64_t)nwin;
-    if (dense > out->capacity) {
-      if (total_out) *total_out = dense;
-      return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
-                  (unsigned long long)out->capacity, (unsigned long long)dense);
-    }
+    bool fast_ran = true;
     KmerFixedArgs a;
     memset(&a, 0, sizeof a);
     a.seqs = st.seqs;
@@ -1014,7 +1103,13 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
     int rc;
     RunsPlan plan;
     const bool rows_only = (flags & NTHIP_FORCE_ROWS) != 0;
-    if (!rows_only && kmer_runs_plan(c, len, stride, k, m, &plan)) {
+    GenPlan gplan;
+    // the specialised k=31 instantiations (run length 15 / 30 dividing the window count); everything
+    // else goes to the general run-split kernel
+    const char* no_special = getenv("NTHIP_TUNE_NO_SPECIAL"); // A/B: general kernel on the k=31 shapes too
+    const bool special = !rows_only && k == 31 && kmer_runs_plan(c, len, stride, k, m, &plan) &&
+                         (plan.C == 15 || (plan.C == 30 && m == 1)) && !(no_special && no_special[0] == '1');
+    if (special) {
       // run-split kernel: contiguous write-out (see kmer_runs_kernel.hpp)
       KmerRunsArgs ra;
       memset(&ra, 0, sizeof ra);
@@ -1050,20 +1145,58 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
       : launch_kmer_runs(c, kmer_runs_kernel<KT, MT, CT, NWT, false>, ra, plan.lds))
       if (k == 31 && m == 1 && plan.C == 15) rc = NT_RUNS(31, 1, 15, 2);
       else if (k == 31 && m == 1 && plan.C == 30) rc = NT_RUNS(31, 1, 30, 2);
-      else if (k == 31 && plan.C == 15) rc = NT_RUNS(31, 0, 15, 2);
-      else if (plan.nw == 1) rc = NT_RUNS(0, 0, 0, 1);
-      else if (plan.nw == 2) rc = NT_RUNS(0, 0, 0, 2);
-      else if (plan.nw == 3) rc = NT_RUNS(0, 0, 0, 3);
-      else rc = NT_RUNS(0, 0, 0, 4);
+      else rc = NT_RUNS(31, 0, 15, 2);
 #undef NT_RUNS
+    } else if (!rows_only && kmer_gen_plan(c, len, stride, k, m, &gplan)) {
+      // any other shape: general run-split kernel (kmer_runs_gen_kernel.hpp)
+      KmerRunsGenArgs ga;
+      memset(&ga, 0, sizeof ga);
+      ga.seqs = st.seqs;
+      ga.hashes = st.hashes;
+      ga.dirty = (uint32_t*)c->d_small;
+      NTCHK(get_init_tab(c, k, &ga.init_tab));
+      ga.n_reads = rd->n_reads;
+      ga.n_runs = rd->n_reads * gplan.rpr;
+      ga.n_wtiles = (ga.n_runs + 63) / 64;
+      ga.total_bytes = (rd->n_reads - 1) * (uint64_t)stride + len;
+      ga.len = len;
+      ga.stride = stride;
+      ga.k = k;
+      ga.m = m;
+      ga.nwin = nwin;
+      ga.C = gplan.C;
+      ga.rpr = gplan.rpr;
+      ga.last_start = gplan.last_start;
+      ga.ntab = (k + 3) / 4;
+      ga.waves = gplan.waves;
+      ga.bits_dwords = gplan.bits_dwords;
+      ga.tile_u64 = gplan.tile_u64;
+      ga.inv_rpr = 65536u / gplan.rpr + 1u;
+      { const char* t2 = getenv("NTHIP_TUNE_TILE_MAP"); ga.tile_map = t2 ? (uint32_t)atoi(t2) : 0xFFFFFFFFu; }
+      memcpy(ga.tab, a.tab, sizeof ga.tab);
+      memcpy(ga.mult, a.mult, sizeof ga.mult);
+      const bool dt = gplan.dword_tail != 0;
+#define NT_GEN(NWT) \
+  (dt ? launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, true>, ga, gplan.lds) \
+      : launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, false>, ga, gplan.lds))
+      if (gplan.nw == 1) rc = NT_GEN(1);
+      else if (gplan.nw == 2) rc = NT_GEN(2);
+      else if (gplan.nw == 3) rc = NT_GEN(3);
+      else rc = NT_GEN(4);
+#undef NT_GEN
+    } else if (!rows_ok) {
+      rc = NTHIP_OK;
+      fast_ran = false;
     } else if (k == 31 && m == 1) rc = launch_kmer_fixed(c, kmer_fixed_kernel<31, 1>, a, dyn);
     else if (k == 31 && m == 4) rc = launch_kmer_fixed(c, kmer_fixed_kernel<31, 4>, a, dyn);
     else rc = launch_kmer_fixed(c, kmer_fixed_kernel<0, 0>, a, dyn);
     NTCHK(rc);
-    HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    uint32_t dirty = 0;
-    memcpy(&dirty, c->h_small, 4);
+    uint32_t dirty = 1;
+    if (fast_ran) {
+      HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      memcpy(&dirty, c->h_small, 4);
+    }
     if (!dirty) {
       total = dense;
       if (st.counts) {
@@ -1079,7 +1212,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
     KmerFixedArgs consts;
     memset(&consts, 0, sizeof consts);
     fill_kmer_consts(k, m, consts);
-    int rc = run_kmer_na(c, st, rd, k, m, na_plan, na_vbits, consts, out->capacity, &total);
+    int rc = run_kmer_na(c, st, rd, k, m, na_plan, consts, out->capacity, &total);
     if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
     NTCHK(rc);
     done = true;

@@ -116,6 +116,75 @@ def test_kmer_fixed_vs_oracle(ctx, oracle, n, L, k, m):
     assert (rows["hashes"] == want["hashes"]).all()
 
 
+@pytest.mark.parametrize("n,L,k,m", [
+    (4097, 101, 31, 1),    # 71 windows (prime): ragged last run
+    (1000, 151, 25, 2),    # 127 windows (prime), odd value offsets with m = 2
+    (999, 100, 64, 3),     # 37 windows, k = 64 (examples/benchmark.cpp shape)
+    (333, 251, 31, 1), (777, 149, 31, 1), (500, 76, 31, 1), (1001, 36, 21, 1), (129, 53, 50, 5),
+    (65, 1000, 31, 1), (7, 10000, 31, 1), (3, 10007, 64, 2), (1, 5003, 17, 1), (2, 70001, 31, 3),
+    (5000, 33, 31, 1), (5000, 31, 31, 8), (63, 47, 40, 7), (64, 48, 40, 1), (200, 150, 32, 1),
+])
+def test_kmer_general_run_split_shapes_vs_oracle(ctx, oracle, n, L, k, m):
+    """shapes whose window count has no convenient divisor, very long reads, odd
+    stream offsets: the general run-split kernel (kmer_runs_gen_kernel.hpp)"""
+    data = oracle.synth_reads(11, n, L, 4321 + L + k)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    ctx.set_profiling(True)
+    got = ctx.kmer_hash(data, k, m, fixed_len=L, n_reads=n)
+    name = ctx.last_kernel_ms()[1]
+    ctx.set_profiling(False)
+    assert name in ("kmer_runs_gen_kernel", "kmer_runs_kernel"), name
+    assert got["total"] == want["total"] == n * (L - k + 1)
+    assert (got["hashes"] == want["hashes"]).all()
+    assert (got["counts"] == want["counts"]).all()
+
+
+def test_kmer_general_run_split_unaligned_and_overlapping(ctx, oracle):
+    """base pointer off the 16-byte grid; stride < len (a long sequence cut into
+    overlapping runs) -- both with a ragged run split"""
+    n, L, k = 301, 101, 31
+    data = oracle.synth_reads(0, n, L, 19)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, 1, want_pos=False)["hashes"].ravel()
+    for shift in (1, 5, 15):
+        d_in = ctx.malloc(n * L + 64)
+        ctx.h2d(d_in + shift, data)
+        d_out = ctx.malloc(n * (L - k + 1) * 8)
+        tot = ctx.kmer_hash_ptr(d_in + shift, 0, n, L, 0, k, 1, d_out, n * (L - k + 1))
+        got = np.zeros(tot, np.uint64)
+        ctx.d2h(got, d_out)
+        assert (got == want).all()
+        ctx.free(d_in)
+        ctx.free(d_out)
+    # one 50 kb sequence as runs of R = 997 windows: stride R, len R + k - 1
+    R, k, m = 997, 25, 2
+    n_runs = 50
+    seq = oracle.synth_reads(0, 1, R * n_runs + k - 1, 5)
+    one = oracle.kmer_batch(seq, np.array([0, seq.size], np.uint64), k, m, want_pos=False)["hashes"]
+    got = ctx.kmer_hash(seq, k, m, fixed_len=R + k - 1, n_reads=n_runs, stride=R)
+    assert got["total"] == R * n_runs and (got["hashes"] == one).all()
+
+
+def test_kmer_general_run_split_detects_every_non_base(ctx, oracle):
+    """a single non-base byte anywhere (first / last byte of the batch, a read's short
+    last run, the last read) must send the batch to the N-aware paths"""
+    n, L, k, m = 193, 101, 31, 1
+    clean = oracle.synth_reads(0, n, L, 23)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    rng = np.random.default_rng(5)
+    spots = [0, 1, 15, 16, L - 1, L, n * L - 1, n * L - 2, (n - 1) * L, 70 + 17 * L, 100 + 64 * L]
+    spots += [int(x) for x in rng.integers(0, n * L, 24)]
+    for sp in spots:
+        data = clean.copy()
+        data[sp] = ord("N")
+        want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+        got = ctx.kmer_hash(data, k, m, fixed_len=L, n_reads=n)
+        assert got["total"] == want["total"] < n * (L - k + 1), sp
+        assert (got["hashes"] == want["hashes"]).all(), sp
+        assert (got["counts"] == want["counts"]).all(), sp
+
+
 def test_kmer_fixed_unaligned_base_pointer(ctx, oracle):
     """device buffer that does not start on a 16-byte boundary (edge vectors)"""
     n, L, k = 700, 150, 31
@@ -172,6 +241,9 @@ def test_kmer_dirty_fixed_len_falls_back_exactly(ctx, oracle):
     (5000, 150, 31, 1, 0.002), (3000, 150, 31, 4, 0.01), (2000, 150, 31, 1, 0.2),
     (1500, 100, 21, 2, 0.01), (1000, 250, 31, 3, 0.005), (700, 151, 25, 1, 0.01), (513, 64, 33, 1, 0.02),
     (400, 120, 64, 2, 0.003),
+    # any shape: prime window counts, k > 50 (validity over more than 64 bases), long reads
+    (2000, 101, 31, 1, 0.004), (900, 151, 25, 2, 0.01), (1500, 100, 64, 3, 0.002), (600, 150, 63, 1, 0.003),
+    (40, 5003, 31, 1, 0.001), (5, 40001, 57, 2, 0.0005), (3000, 36, 21, 1, 0.01), (700, 33, 31, 1, 0.01),
 ])
 def test_kmer_na_runs_path_vs_oracle(ctx, oracle, n, L, k, m, frac):
     """fixed-length reads sprinkled with non-bases: count pass -> scan -> compact hash pass
@@ -224,7 +296,7 @@ def test_kmer_ragged_fast_path_vs_oracle(ctx, oracle):
     real ones, non-bases everywhere -- stream, positions and per-read counts must be the reference's"""
     rng = np.random.default_rng(314)
     alph = np.frombuffer(b"ACGTacgtUuNnRYKM-*", dtype=np.uint8)
-    for k, m in [(31, 1), (31, 4), (5, 2), (21, 1), (50, 1), (17, 3)]:
+    for k, m in [(31, 1), (31, 4), (5, 2), (21, 1), (50, 1), (17, 3), (64, 1), (57, 2)]:
         reads = []
         for _ in range(600):
             p = rng.random()

@@ -2,7 +2,7 @@
 """Within-process interleaved A/B timing of kernel variants (HIP-event kernel time).
 
     python tools/ablate.py [reads] [variant,variant,...] [rounds]
-variants: runs (default kernel), runs_vec (NTHIP_TUNE_NO_DWORD_TAIL=1), rows (flag 8), general (flag 4)
+variants: runs (default kernel), gen / genC<n> (general run-split kernel, run length n), runs_vec (NTHIP_TUNE_NO_DWORD_TAIL=1), rows (flag 8), general (flag 4)
 """
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ import nthash_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 variants = (sys.argv[2] if len(sys.argv) > 2 else "runs,runs_vec,rows").split(",")
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-L, k, m = 150, 31, 1
+L, k, m = (int(x) for x in os.environ.get("ABLATE_SHAPE", "150,31,1").split(","))
 nwin = L - k + 1
 ctx = nthash_amd.Context(0)
 d_in = ctx.malloc(n * L); d_out = ctx.malloc(n * nwin * m * 8)
@@ -33,6 +33,9 @@ for rnd in range(rounds):
             os.environ["NTHIP_TUNE_TILE_MAP"] = v[3:]
         else:
             os.environ.pop("NTHIP_TUNE_TILE_MAP", None)
+        os.environ["NTHIP_TUNE_NO_SPECIAL"] = "1" if v.startswith("gen") else "0"
+        if v.startswith("genC"):
+            os.environ["NTHIP_TUNE_RUN_LEN"] = v[4:]
         flags = 8 if v == "rows" else 4 if v == "general" else 0
         ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin, flags=flags)
         ms, name = ctx.last_kernel_ms()
