@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnthash_hip.so")
+# NTHASH_AMD_LIB: A/B builds of the same C-ABI (tools/ab_build.sh); default is the in-tree library
+LIB_PATH = os.environ.get("NTHASH_AMD_LIB") or os.path.join(_HERE, "lib", "libnthash_hip.so")
 
 NTHIP_OK = 0
 NTHIP_ERR_ARG = -1

@@ -14,9 +14,11 @@
 
 #include <hip/hip_runtime.h>
 
-#include "kmer_runs_na_kernel.hpp"
+#include "kmer_runs_gen_kernel.hpp"
 
 namespace ntamd {
+
+enum : int { NA_MODE_COUNT = 1, NA_MODE_HASH = 2 };
 
 // ---- pre-pass ---------------------------------------------------------------
 // runs per read and a 0/1 flag "has a window"

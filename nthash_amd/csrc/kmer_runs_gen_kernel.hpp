@@ -1,10 +1,13 @@
-// kmer_runs_gen_kernel.hpp -- the run-split kernel for ANY fixed read shape.
+// kmer_runs_gen_kernel.hpp -- the run-split kernels for ANY fixed read shape:
+//   kmer_runs_gen_kernel<NW, DT, false>  dense stream (optimistic pass: every byte a base)
+//   kmer_runs_gen_kernel<NW, DT, true>   N-aware hash pass: compact stream at scanned tile offsets
+//   kmer_runs_count_kernel               N-aware count pass: valid windows per tile / per read
 //
 // kmer_runs_kernel.hpp needs the run length C to divide the window count and
 // stages whole reads; that leaves cliffs (a prime window count, reads of 10 kb).
-// This kernel keeps its structure -- 64 lanes own 64 consecutive runs, wave-private
+// These kernels keep its structure -- 64 lanes own 64 consecutive runs, wave-private
 // 2-bit slab + output tile, prefetch of the next slab with a counted s_waitcnt --
-// and generalises the geometry:
+// and generalise the geometry:
 //   * runs per read rpr = ceil(nwin / C); every run has C windows, and the LAST run
 //     of a read starts at window nwin - C, i.e. it overlaps its predecessor and
 //     recomputes a few windows (same values to the same addresses) instead of being
@@ -15,8 +18,18 @@
 //     as aligned 16-byte stores with an 8-byte head / tail.
 //   * the slab is the byte range the 64 runs really touch (first base of the first
 //     run .. last base of the last run), not whole reads.
-// Hash arithmetic is the same as in kmer_runs_kernel.hpp (first window from the byte
-// tables, src/kmer.cpp:43-73,123-152; the rest rolled, src/kmer.cpp:84-94,164-174).
+//
+// N-aware (NtHash emits exactly the windows whose k bytes are all bases: the net
+// effect of init()/roll(), src/kmer.cpp:228-264).  That is a
+// parallel predicate: one validity bit per base, OR-ed over every window by
+// doubling.  A run's recomputed windows are masked out, so every window counts
+// once.  Count pass -> device scan of the tile counts -> hash pass; a non-base keeps
+// a garbage 2-bit code that enters and leaves the rolled state with the same code,
+// so every all-base window is exact.  Tiles without any non-base (almost all of
+// them in real data) take the same unpredicated code path as the dense kernel.
+//
+// Hash arithmetic as in kmer_runs_kernel.hpp (first window from the byte tables,
+// src/kmer.cpp:43-73,123-152; the rest rolled, src/kmer.cpp:84-94,164-174).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -25,24 +38,34 @@
 
 namespace ntamd {
 
+constexpr uint32_t KRG_ALIGN_U64 = 128; // the output tile is aligned to 1 KiB of the stream
+constexpr uint32_t KRG_SLACK_U64 = 16;  // N-aware: room below the tile for a first run's recomputed windows
+
 struct KmerRunsGenArgs {
   const uint8_t* seqs;
-  uint64_t* hashes;      // dense [read][window][m]
-  uint32_t* dirty;
-  const uint4* init_tab; // global [ntab][256] {f.lo,f.hi,r.lo,r.hi}
+  uint64_t* hashes;          // dense [read][window][m]  /  N-aware: compact [emitted k-mer][m]
+  uint32_t* dirty;           // dense: set when a non-base is seen
+  const uint4* init_tab;     // global [ntab][256] {f.lo,f.hi,r.lo,r.hi}
+  uint32_t* pos;             // N-aware, optional: position of every emitted k-mer in its read
+  uint64_t* counts;          // count pass, optional (zeroed by the host): per-read emitted windows
+  uint64_t* tile_counts;     // count pass out: valid windows per wave tile
+  const uint64_t* tile_off;  // N-aware hash pass in: exclusive scan of tile_counts
   uint64_t n_reads;
   uint64_t n_runs;       // n_reads * rpr
   uint64_t n_wtiles;     // ceil(n_runs / 64)
   uint64_t total_bytes;  // (n_reads - 1) * stride + len
   uint32_t len, stride, k, m;
   uint32_t nwin;
-  uint32_t C;            // windows per full run
+  uint32_t C;            // windows per run
   uint32_t rpr;          // runs per read = ceil(nwin / C)
   uint32_t last_start;   // first window of a read's last run = nwin - C
+  uint32_t last_dup;     // windows the last run recomputes = rpr * C - nwin
   uint32_t ntab;         // ceil(k/4)
   uint32_t waves;        // waves per block
   uint32_t bits_dwords;  // per-wave bit-stream capacity
-  uint32_t tile_u64;     // per-wave tile capacity (64*C + 128)
+  uint32_t vbits_dwords; // per-wave validity-bit capacity (N-aware)
+  uint32_t ptile_dwords; // per-wave position tile (N-aware with pos), else 0
+  uint32_t tile_u64;     // per-wave tile capacity
   uint32_t inv_rpr;      // floor(65536 / rpr) + 1 (used when rpr <= 64)
   uint32_t tile_map;     // wave groups of the tile -> wave mapping (as in kmer_runs_kernel)
   uint64_t tab[16][2];
@@ -62,22 +85,135 @@ __device__ __forceinline__ void wait_vmcnt_upto15(uint32_t n)
 }
 #undef KRG_WAITCASE
 
-// NW: window words, k <= 16*NW; DT: every slab is <= 1280 bytes (tail = one dword per lane)
-template <int NW, bool DT>
+// 4 ASCII bytes -> 4 x 2-bit codes (one byte) and a 4-bit mask of the non-bases
+__device__ __forceinline__ uint32_t pack4v(uint32_t w, uint32_t& inv4)
+{
+  const uint32_t t = (w >> 1) & 0x03030303u;
+  uint32_t x = w | 0x20202020u;
+  const uint32_t ubit = (x >> 4) & 0x01010101u;
+  x = x & ~ubit;
+  const uint32_t canon = __builtin_amdgcn_perm(0u, 0x67746361u, t);
+  const uint32_t d = x ^ canon;                                   // byte != 0 <=> not a base
+  const uint32_t nz = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;
+  inv4 = __builtin_amdgcn_udot4(nz >> 7, 0x08040201u, 0u, false); // gather the four flags
+  return __builtin_amdgcn_udot4(t, 0x40100401u, 0u, false);
+}
+
+// Which of the (up to 32) windows starting at bases b0, b0+1, ... hold a non-base.
+// vw: validity bit stream (1 = not a base); reads 128 bits from the dword of b0 on.
+// OR over k <= 64 consecutive bits by doubling, on a 96-bit register pair.
+__device__ __forceinline__ uint32_t windows_with_non_base(const uint32_t* vw, uint32_t b0, uint32_t k)
+{
+  const uint32_t dw = b0 >> 5, sh = b0 & 31u;
+  const uint32_t x0 = vw[dw], x1 = vw[dw + 1], x2 = vw[dw + 2], x3 = vw[dw + 3];
+  uint64_t lo = ((uint64_t)funnel(x2, x1, sh) << 32) | funnel(x1, x0, sh);
+  uint64_t hi = funnel(x3, x2, sh); // bits 64..95
+  auto fold = [&](uint32_t s) {     // bit j |= bit j + s, 1 <= s <= 32
+    lo |= (lo >> s) | (hi << (64u - s));
+    hi |= hi >> s;
+  };
+  uint32_t span = 1;
+  while (2u * span <= k) {
+    fold(span);
+    span *= 2u;
+  }
+  if (k > span) fold(k - span);
+  return (uint32_t)lo; // bit j exact for j + k - 1 <= 95
+}
+
+// ---- geometry shared by the three kernels (wave-uniform integers only) ---------------
+struct RunShape {
+  uint32_t C, rpr, inv_rpr, last_start, last_dup, stride, nwin, k;
+};
+// gl = run index counted from run 0 of a tile's first read, gl < 64 + rpr:
+// read (relative), first window of the run inside it, and whether it is a read's last run
+__device__ __forceinline__ void run_split(const RunShape& s, uint32_t gl, uint32_t& lr, uint32_t& w0, bool& last)
+{
+  lr = s.rpr > 64u ? (gl >= s.rpr ? 1u : 0u) : (gl * s.inv_rpr) >> 16;
+  const uint32_t q = gl - lr * s.rpr;
+  last = q == s.rpr - 1u;
+  w0 = last ? s.last_start : q * s.C;
+}
+struct TileGeo {
+  uint64_t byte0;   // offset of the first 16-byte vector from seqs (wraps below 0 by < 16)
+  uint64_t out0;    // dense stream index of the tile's first k-mer
+  uint32_t shift, slab_bytes, n_vec, runs_here;
+  uint32_t n_kmers; // k-mers of the dense tile
+  uint32_t w_first; // first window (inside its read) of the tile's first run
+  uint32_t edge;    // the vectors of the slab reach outside the caller's buffer
+};
+// the tile whose first run is run rm of read rf (g0 = its global run index)
+__device__ __forceinline__ TileGeo tile_geo(const RunShape& s, uint64_t seqs_addr, uint64_t n_runs,
+                                            uint64_t total_bytes, uint64_t g0, uint64_t rf, uint32_t rm)
+{
+  TileGeo g;
+  const uint64_t runs_left = n_runs - g0;
+  g.runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
+  uint32_t lre, we;
+  bool laste;
+  run_split(s, rm + g.runs_here - 1u, lre, we, laste);
+  const uint32_t w_first = rm == s.rpr - 1u ? s.last_start : rm * s.C;
+  const uint64_t start = rf * s.stride + w_first;
+  g.w_first = w_first;
+  g.slab_bytes = lre * s.stride + we + s.C + s.k - 1u - w_first;
+  g.n_kmers = lre * s.nwin + we + s.C - w_first;
+  g.out0 = rf * s.nwin + w_first;
+  g.shift = (uint32_t)((seqs_addr + start) & 15u);
+  g.byte0 = start - g.shift;
+  g.n_vec = (g.shift + g.slab_bytes + 15u) >> 4;
+  g.edge = (start < g.shift || g.byte0 + ((uint64_t)g.n_vec << 4) > total_bytes) ? 1u : 0u;
+  return g;
+}
+// the waves of the grid are split into tile_map groups of consecutive waves; every group owns one
+// contiguous range of tiles and its waves interleave inside it (see kmer_runs_kernel.hpp)
+__device__ __forceinline__ void tile_range(uint32_t tile_map, uint32_t waves, uint32_t wave, uint64_t n_wtiles,
+                                           uint64_t& wt, uint64_t& wstride, uint64_t& wt_end)
+{
+  const uint64_t n_waves_total = (uint64_t)gridDim.x * waves;
+  const uint64_t gw = (uint64_t)blockIdx.x * waves + wave;
+  uint64_t groups = tile_map ? tile_map : 1u;
+  if (groups > n_waves_total) groups = n_waves_total;
+  const uint64_t wpg = n_waves_total / groups;
+  uint64_t g = gw / wpg;
+  if (g >= groups) g = groups - 1;
+  const uint64_t w_in_g = gw - g * wpg;
+  const uint64_t g_waves = g == groups - 1 ? n_waves_total - g * wpg : wpg;
+  const uint64_t per = (n_wtiles + groups - 1) / groups;
+  const uint64_t t0 = g * per;
+  wt = t0 + w_in_g;
+  wstride = g_waves;
+  wt_end = t0 + per < n_wtiles ? t0 + per : n_wtiles;
+}
+
+// NW: window words, k <= 16*NW; DT: every slab is <= 1280 bytes (tail = one dword per lane);
+// NA: N-aware hash pass (compact output at a.tile_off) instead of the dense optimistic pass
+template <int NW, bool DT, bool NA>
 __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const KmerRunsGenArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t k = a.k, m = a.m, C = a.C, ntab = a.ntab, rpr = a.rpr;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
+#ifndef KRG_UNIFORM_WAVE
+#define KRG_UNIFORM_WAVE 1
+#endif
+#if KRG_UNIFORM_WAVE
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile geometry runs on the scalar unit
+#else
   const uint32_t wave = tid >> 6;
+#endif
+  const RunShape shape = {C, rpr, a.inv_rpr, a.last_start, a.last_dup, a.stride, a.nwin, k};
 
+  // LDS: init tables | pair table | multipliers | per wave {tile, [pos tile], bits, [validity bits]}
   uint4* itab = (uint4*)lds_dyn;
   uint4* ptab = itab + ntab * 256u;
   uint64_t* mults = (uint64_t*)(ptab + 16);
-  uint32_t* wave_base = (uint32_t*)(mults + KF_MAX_RUNTIME_M) + wave * (a.tile_u64 * 2u + a.bits_dwords);
-  uint64_t* tile = (uint64_t*)wave_base;
-  uint32_t* bits = wave_base + a.tile_u64 * 2u;
+  const uint32_t per_wave = a.tile_u64 * 2u + a.ptile_dwords + a.bits_dwords + a.vbits_dwords;
+  uint32_t* wave_base = (uint32_t*)(mults + KF_MAX_RUNTIME_M) + wave * per_wave;
+  uint64_t* tile = (uint64_t*)wave_base + (NA ? KRG_SLACK_U64 : 0u);
+  uint32_t* ptile = wave_base + a.tile_u64 * 2u + KRG_SLACK_U64;
+  uint32_t* bits = wave_base + a.tile_u64 * 2u + a.ptile_dwords;
+  uint16_t* vbits = (uint16_t*)(bits + a.bits_dwords);
 
   for (uint32_t i = tid; i < ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
   if (tid < 16)
@@ -88,101 +224,71 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
 
   uint32_t bad = 0;
   uint64_t wt, wstride, wt_end;
-  {
-    const uint64_t n_waves_total = (uint64_t)gridDim.x * a.waves;
-    const uint64_t gw = (uint64_t)blockIdx.x * a.waves + wave;
-    uint64_t groups = a.tile_map ? a.tile_map : 1u;
-    if (groups > n_waves_total) groups = n_waves_total;
-    const uint64_t wpg = n_waves_total / groups;
-    uint64_t g = gw / wpg;
-    if (g >= groups) g = groups - 1;
-    const uint64_t w_in_g = gw - g * wpg;
-    const uint64_t g_waves = g == groups - 1 ? n_waves_total - g * wpg : wpg;
-    const uint64_t per = (a.n_wtiles + groups - 1) / groups;
-    const uint64_t t0 = g * per;
-    wt = t0 + w_in_g;
-    wstride = g_waves;
-    wt_end = t0 + per < a.n_wtiles ? t0 + per : a.n_wtiles;
-  }
+  tile_range(a.tile_map, a.waves, wave, a.n_wtiles, wt, wstride, wt_end);
   uint64_t r_first = (wt * 64u) / rpr;
   uint32_t rem0 = (uint32_t)(wt * 64u - r_first * rpr);
   const uint64_t step_q = (wstride * 64u) / rpr;
   const uint32_t step_r = (uint32_t)(wstride * 64u - step_q * rpr);
 
-  // gl = run index counted from run 0 of read r_first, gl < 64 + rpr:
-  // read (relative) and first window of the run inside it
-  auto split = [&](uint32_t gl, uint32_t& lr, uint32_t& w0) {
-    lr = rpr > 64u ? (gl >= rpr ? 1u : 0u) : (gl * a.inv_rpr) >> 16;
-    const uint32_t q = gl - lr * rpr;
-    w0 = q == rpr - 1u ? a.last_start : q * C;
-  };
-
-  // geometry of the tile whose first run is run rm of read rf
-  struct Geo {
-    uint64_t byte0;  // offset of the first 16-byte vector from a.seqs (wraps below 0 by < 16)
-    uint64_t out0;   // index of the tile's first k-mer in the dense stream
-    uint32_t shift, slab_bytes, n_vec, runs_here;
-    uint32_t n_kmers; // k-mers of this tile
-    uint32_t w_first; // first window (inside its read) of the tile's first run
-    uint32_t edge;    // the vectors of the slab reach outside the caller's buffer
-  };
-  auto geo_of = [&](uint64_t g0, uint64_t rf, uint32_t rm) -> Geo {
-    Geo g;
-    const uint64_t runs_left = a.n_runs - g0;
-    g.runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
-    uint32_t lre, we;
-    split(rm + g.runs_here - 1u, lre, we);
-    const uint32_t w_first = rm == rpr - 1u ? a.last_start : rm * C;
-    const uint64_t start = rf * a.stride + w_first;
-    g.w_first = w_first;
-    g.slab_bytes = lre * a.stride + we + C + k - 1u - w_first;
-    g.n_kmers = lre * a.nwin + we + C - w_first;
-    g.out0 = rf * a.nwin + w_first;
-    g.shift = (uint32_t)(((uint64_t)a.seqs + start) & 15u);
-    g.byte0 = start - g.shift;
-    g.n_vec = (g.shift + g.slab_bytes + 15u) >> 4;
-    g.edge = (start < g.shift || g.byte0 + ((uint64_t)g.n_vec << 4) > a.total_bytes) ? 1u : 0u;
-    return g;
-  };
-  // Bytes of the batch next to the slab inside its first / last vector are judged
-  // too (a non-base there makes the batch dirty anyway); bytes outside the caller's
-  // buffer are not: they exist only in the slabs flagged `edge`.
-  auto pack_vec = [&](const Geo& sl, uint32_t i, const uint4 v) {
-    uint32_t b = 0;
-    const uint32_t p = pack16(v, b);
-    if (sl.edge) {
-      const int32_t lo_cut = (int32_t)sl.shift - (int32_t)(i << 4);
-      const int32_t hi_cut = (int32_t)(sl.shift + sl.slab_bytes) - (int32_t)(i << 4);
-      if (lo_cut > 0 || hi_cut < 16) {
-        uint32_t bx[4] = {0, 0, 0, 0};
-        (void)pack4(v.x, bx[0]);
-        (void)pack4(v.y, bx[1]);
-        (void)pack4(v.z, bx[2]);
-        (void)pack4(v.w, bx[3]);
-        b = 0;
+  // Dense pass: bytes of the batch next to the slab inside its first / last vector are
+  // judged too (a non-base there makes the batch dirty anyway); bytes outside the
+  // caller's buffer are not: they exist only in the slabs flagged `edge`.
+  // N-aware pass: no judging, a validity bit per base instead (bits outside the slab
+  // never reach an emitted window).
+  auto pack_vec = [&](const TileGeo& sl, uint32_t i, const uint4 v) {
+    if constexpr (NA) {
+      uint32_t i0, i1, i2, i3;
+      const uint32_t c0 = pack4v(v.x, i0), c1 = pack4v(v.y, i1), c2 = pack4v(v.z, i2), c3 = pack4v(v.w, i3);
+      bits[i] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+      vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+    } else {
+      uint32_t b = 0;
+      const uint32_t p = pack16(v, b);
+      if (sl.edge) {
+        const int32_t lo_cut = (int32_t)sl.shift - (int32_t)(i << 4);
+        const int32_t hi_cut = (int32_t)(sl.shift + sl.slab_bytes) - (int32_t)(i << 4);
+        if (lo_cut > 0 || hi_cut < 16) {
+          uint32_t bx[4] = {0, 0, 0, 0};
+          (void)pack4(v.x, bx[0]);
+          (void)pack4(v.y, bx[1]);
+          (void)pack4(v.z, bx[2]);
+          (void)pack4(v.w, bx[3]);
+          b = 0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-          if (q >= lo_cut && q < hi_cut) b |= (bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+          for (int q = 0; q < 16; ++q)
+            if (q >= lo_cut && q < hi_cut) b |= (bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+        }
       }
+      bad |= b;
+      bits[i] = p;
     }
-    bad |= b;
-    bits[i] = p;
   };
-  auto pack_dword = [&](const Geo& sl, uint32_t j, const uint32_t wv) {
-    uint32_t b = 0;
-    const uint32_t p = pack4(wv, b);
-    if (sl.edge) {
-      const int32_t hi_cut = (int32_t)(sl.shift + sl.slab_bytes) - (int32_t)(1024u + (j << 2));
-      uint32_t keep = 0;
+  // the tail of a short slab: dword 256 + lane (4 bases -> one byte of the stream), all lanes call
+  auto pack_tail = [&](const TileGeo& sl, const uint32_t wv) {
+    const uint32_t n_dw = (sl.shift + sl.slab_bytes + 3u) >> 2;
+    const bool mine = 256u + lane < n_dw;
+    if constexpr (NA) {
+      uint32_t nib;
+      const uint32_t p = pack4v(wv, nib);
+      const uint32_t pair = nib | (__shfl_down(nib, 1, 64) << 4); // two lanes share a validity byte
+      if (mine) ((uint8_t*)bits)[256u + lane] = (uint8_t)p;
+      if (mine && (lane & 1u) == 0u) ((uint8_t*)vbits)[128u + (lane >> 1)] = (uint8_t)pair;
+    } else if (mine) {
+      uint32_t b = 0;
+      const uint32_t p = pack4(wv, b);
+      if (sl.edge) {
+        const int32_t hi_cut = (int32_t)(sl.shift + sl.slab_bytes) - (int32_t)(1024u + (lane << 2));
+        uint32_t keep = 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (q < hi_cut) keep |= 0xFFu << (q * 8);
-      b &= keep;
+        for (int q = 0; q < 4; ++q)
+          if (q < hi_cut) keep |= 0xFFu << (q * 8);
+        b &= keep;
+      }
+      bad |= b;
+      ((uint8_t*)bits)[256u + lane] = (uint8_t)p;
     }
-    bad |= b;
-    ((uint8_t*)bits)[256u + j] = (uint8_t)p;
   };
-  auto stage = [&](const Geo& sl, uint32_t first) {
+  auto stage = [&](const TileGeo& sl, uint32_t first) {
     for (uint32_t i = first + lane; i < sl.n_vec; i += 64u)
       pack_vec(sl, i, *(const uint4*)(a.seqs + sl.byte0 + ((uint64_t)i << 4)));
     if (lane < (uint32_t)NW + 5u) bits[sl.n_vec + lane] = 0; // funnels read a little ahead
@@ -193,12 +299,14 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   };
 
-  Geo cur;
+  TileGeo cur;
   cur.byte0 = cur.out0 = 0;
   cur.shift = cur.slab_bytes = cur.n_vec = cur.runs_here = cur.n_kmers = cur.w_first = 0;
   cur.edge = 1u;
+  uint64_t cur_off = 0; // N-aware: compact stream index of the tile's first emitted k-mer
   if (wt < wt_end) {
-    cur = geo_of(wt * 64u, r_first, rem0);
+    cur = tile_geo(shape, (uint64_t)a.seqs, a.n_runs, a.total_bytes, wt * 64u, r_first, rem0);
+    if constexpr (NA) cur_off = a.tile_off[wt];
     stage(cur, 0u);
   }
   for (; wt < wt_end; wt += wstride) {
@@ -211,8 +319,12 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     if (rem0 >= rpr) { rem0 -= rpr; r_first += 1; }
     const uint64_t nwt = wt + wstride;
     const bool have_next = nwt < wt_end;
-    Geo nxt = cur;
-    if (have_next) nxt = geo_of(nwt * 64u, r_first, rem0);
+    TileGeo nxt = cur;
+    uint64_t nxt_off = cur_off;
+    if (have_next) {
+      nxt = tile_geo(shape, (uint64_t)a.seqs, a.n_runs, a.total_bytes, nwt * 64u, r_first, rem0);
+      if constexpr (NA) nxt_off = a.tile_off[nwt];
+    }
     v4u pv0, pv1;
     uint32_t pw;
     uint32_t dirty_seen;
@@ -241,14 +353,44 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
 
     // ---- this lane's run ----------------------------------------------------------
     // lanes past the end of the last tile redo the tile's first run (same values, same addresses)
+    const bool live = lane < runs_here;
     uint32_t lr, w0;
-    split(lane < runs_here ? my_rem0 + lane : my_rem0, lr, w0);
+    bool last_run;
+    run_split(shape, live ? my_rem0 + lane : my_rem0, lr, w0, last_run);
     const uint32_t b0 = shift + lr * a.stride + w0 - cur.w_first; // first base of the first window
+
+    // N-aware: which of the C windows are emitted, and where in the tile they go
+    uint32_t valid = 0, lane_off = 0, n_emit = cur.n_kmers;
+    bool all_valid = true;
+    if constexpr (NA) {
+      const uint32_t dup = live && last_run ? a.last_dup : 0u; // windows the run before already covers
+      const uint32_t run_mask = live ? ((1u << C) - 1u) & ~((1u << dup) - 1u) : 0u;
+      valid = ~windows_with_non_base((const uint32_t*)vbits, b0, k) & run_mask;
+      const uint32_t cnt = __builtin_popcount(valid);
+      uint32_t incl = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += o;
+      }
+      lane_off = incl - cnt;
+      n_emit = __shfl(incl, 63, 64);
+      all_valid = __ballot(valid != run_mask) == 0;
+      // clean tile: window j of the run goes to lane_off + j - dup (a recomputed
+      // window lands on the slot the previous run gives the same value)
+      if (all_valid) lane_off -= dup;
+    }
     // the tile is built shifted by the position of its first stream element inside a
     // 1 KiB block of the output (m == 1): every store instruction of the copy-out then
     // covers one aligned KiB, instead of every wave splitting cache lines with its neighbours
-    const uint32_t tpar = m == 1u ? (uint32_t)(cur.out0 & 127u) : 0u;
-    uint64_t* my_row = tile + tpar + (lr * a.nwin + w0 - cur.w_first);
+    const uint64_t out0 = NA ? cur_off : cur.out0;
+    const uint32_t tpar = m == 1u ? (uint32_t)(out0 & (KRG_ALIGN_U64 - 1u)) : 0u;
+    // (signed: a clean tile's first run may start up to KRG_SLACK_U64 slots below the tile)
+    uint64_t* my_row = tile + (int32_t)(tpar + (NA ? lane_off : lr * a.nwin + w0 - cur.w_first));
+    uint32_t* my_pos = ptile + (int32_t)lane_off;
+    const bool want_pos = NA && a.pos != nullptr;
+    uint32_t slot = 0; // N-aware, tile with non-bases: next free slot of this lane
+
     const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
     uint32_t w[NW];
     {
@@ -269,69 +411,84 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
         f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
       }
     }
-    my_row[0] = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
-
-    // remaining C-1 windows: roll.  step t: in = base b0+k-1+t, out = base b0+t-1
-    const uint32_t bi = b0 + k;
-    const uint32_t di = bi >> 4, shi = (bi & 15u) << 1;
-    for (uint32_t jw = 0; jw * 16u + 1u < C; ++jw) {
-      const uint32_t w_in = funnel(bits[di + jw + 1], bits[di + jw], shi);
-      const uint32_t w_out = funnel(bits[d0 + jw + 1], bits[d0 + jw], sh0);
-      const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
-      const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
-      auto lookup = [&](uint32_t i) -> uint4 {
-        const uint32_t src = (i & 1u) ? v : u;
-        const uint32_t off = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
-        return *(const uint4*)((const char*)ptab + off);
-      };
-      auto roll = [&](const uint4 term) {
-        srol_pair(f_lo, f_hi);
-        f_lo ^= term.x;
-        f_hi ^= term.y;
-        r_lo ^= term.z;
-        r_hi ^= term.w;
-        sror_pair(r_lo, r_hi);
-      };
-      // table terms do not depend on the hash state: fetch a batch of them ahead of the
-      // dependent chain so that their LDS latencies overlap
-      auto batch = [&](uint32_t i0, auto n_tag) {
-        constexpr uint32_t N = decltype(n_tag)::value;
-        uint4 terms[N];
-#pragma unroll
-        for (uint32_t i = 0; i < N; ++i) terms[i] = lookup(i0 + i);
-#pragma unroll
-        for (uint32_t i = 0; i < N; ++i) {
-          roll(terms[i]);
-          my_row[jw * 16u + i0 + i + 1u] = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
-        }
-      };
-      const uint32_t left = C - 1u - jw * 16u;
-      const uint32_t ns = left < 16u ? left : 16u;
-      uint32_t i0 = 0;
-      for (; i0 + 8u <= ns; i0 += 8u) batch(i0, std::integral_constant<uint32_t, 8u>{});
-      switch (ns - i0) {
-        case 1: batch(i0, std::integral_constant<uint32_t, 1u>{}); break;
-        case 2: batch(i0, std::integral_constant<uint32_t, 2u>{}); break;
-        case 3: batch(i0, std::integral_constant<uint32_t, 3u>{}); break;
-        case 4: batch(i0, std::integral_constant<uint32_t, 4u>{}); break;
-        case 5: batch(i0, std::integral_constant<uint32_t, 5u>{}); break;
-        case 6: batch(i0, std::integral_constant<uint32_t, 6u>{}); break;
-        case 7: batch(i0, std::integral_constant<uint32_t, 7u>{}); break;
-        default: break;
+    // window j of the run has just been hashed
+    auto emit = [&](uint32_t j, auto clean_tag) {
+      const uint64_t h = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+      if constexpr (decltype(clean_tag)::value) {
+        my_row[j] = h;
+        if (want_pos) my_pos[j] = w0 + j;
+      } else if ((valid >> j) & 1u) {
+        my_row[slot] = h;
+        if (want_pos) my_pos[slot] = w0 + j;
+        ++slot;
       }
-    }
+    };
+    // remaining C-1 windows: roll.  step t: in = base b0+k-1+t, out = base b0+t-1
+    auto hash_run = [&](auto clean_tag) {
+      emit(0u, clean_tag);
+      const uint32_t bi = b0 + k;
+      const uint32_t di = bi >> 4, shi = (bi & 15u) << 1;
+      for (uint32_t jw = 0; jw * 16u + 1u < C; ++jw) {
+        const uint32_t w_in = funnel(bits[di + jw + 1], bits[di + jw], shi);
+        const uint32_t w_out = funnel(bits[d0 + jw + 1], bits[d0 + jw], sh0);
+        const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
+        const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
+        auto lookup = [&](uint32_t i) -> uint4 {
+          const uint32_t src = (i & 1u) ? v : u;
+          const uint32_t off = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
+          return *(const uint4*)((const char*)ptab + off);
+        };
+        auto roll = [&](const uint4 term) {
+          srol_pair(f_lo, f_hi);
+          f_lo ^= term.x;
+          f_hi ^= term.y;
+          r_lo ^= term.z;
+          r_hi ^= term.w;
+          sror_pair(r_lo, r_hi);
+        };
+        // table terms do not depend on the hash state: fetch a batch of them ahead of the
+        // dependent chain so that their LDS latencies overlap
+        auto batch = [&](uint32_t i0, auto n_tag) {
+          constexpr uint32_t N = decltype(n_tag)::value;
+          uint4 terms[N];
+#pragma unroll
+          for (uint32_t i = 0; i < N; ++i) terms[i] = lookup(i0 + i);
+#pragma unroll
+          for (uint32_t i = 0; i < N; ++i) {
+            roll(terms[i]);
+            emit(jw * 16u + i0 + i + 1u, clean_tag);
+          }
+        };
+        const uint32_t left = C - 1u - jw * 16u;
+        const uint32_t ns = left < 16u ? left : 16u;
+        uint32_t i0 = 0;
+        for (; i0 + 8u <= ns; i0 += 8u) batch(i0, std::integral_constant<uint32_t, 8u>{});
+        switch (ns - i0) {
+          case 1: batch(i0, std::integral_constant<uint32_t, 1u>{}); break;
+          case 2: batch(i0, std::integral_constant<uint32_t, 2u>{}); break;
+          case 3: batch(i0, std::integral_constant<uint32_t, 3u>{}); break;
+          case 4: batch(i0, std::integral_constant<uint32_t, 4u>{}); break;
+          case 5: batch(i0, std::integral_constant<uint32_t, 5u>{}); break;
+          case 6: batch(i0, std::integral_constant<uint32_t, 6u>{}); break;
+          case 7: batch(i0, std::integral_constant<uint32_t, 7u>{}); break;
+          default: break;
+        }
+      }
+    };
+    if (!NA || all_valid) hash_run(std::true_type{});
+    else hash_run(std::false_type{});
 
-    // ---- copy the tile out: n_kmers * m consecutive values of the hash stream -----
+    // ---- copy the tile out: n_emit * m consecutive values of the hash stream -------
     lds_sync();
     uint32_t n_counted; // store instructions surely issued after the prefetch loads
     if (m == 1u) {
-      const uint32_t span = tpar + cur.n_kmers;
+      const uint32_t span = tpar + n_emit;
       const uint32_t pieces = (span + 1u) >> 1;
-      const uint32_t first = tpar >> 1;                    // first piece that holds a value
-      uint64_t* const base = a.hashes + (cur.out0 - tpar); // 1 KiB aligned
+      const uint32_t first = tpar >> 1;               // first piece that holds a value
+      uint64_t* const base = a.hashes + (out0 - tpar); // 1 KiB aligned
       for (uint32_t pi = lane; pi < pieces; pi += 64u) {
         const uint4 dv = *(const uint4*)(tile + 2u * pi);
-        const bool lo_ok = 2u * pi >= tpar;
+        const bool lo_ok = 2u * pi >= tpar && 2u * pi < span;
         const bool hi_ok = 2u * pi + 1u >= tpar && 2u * pi + 1u < span;
         if (lo_ok && hi_ok) *(uint4*)(base + 2u * pi) = dv;
         else if (lo_ok) *(uint2*)(base + 2u * pi) = make_uint2(dv.x, dv.y);
@@ -343,9 +500,9 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     } else {
       // multi-hash expansion (extend_hashes, src/internal.hpp:104-118) fused into the
       // copy-out: stream value v is h[v % m] of k-mer v / m
-      const uint64_t v0 = cur.out0 * m;
+      const uint64_t v0 = out0 * m;
       const uint32_t vpar = (uint32_t)(v0 & 1u);
-      const uint32_t n_vals = cur.n_kmers * m;
+      const uint32_t n_vals = n_emit * m;
       const uint32_t span = vpar + n_vals;
       const uint32_t pieces = (span + 1u) >> 1;
       uint64_t* const base = a.hashes + (v0 - vpar);
@@ -368,6 +525,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
       }
       n_counted = pieces >> 6;
     }
+    if (want_pos)
+      for (uint32_t e = lane; e < n_emit; e += 64u) a.pos[out0 + e] = ptile[e];
     lds_sync(); // tile and bits are free again
 
     // ---- consume the prefetched slab ------------------------------------------------
@@ -377,25 +536,77 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     wait_vmcnt_upto15(n_counted < 15u ? n_counted : 15u);
     if constexpr (DT) asm volatile("" : "+v"(pv0), "+v"(pw), "+v"(dirty_seen)::"memory");
     else asm volatile("" : "+v"(pv0), "+v"(pv1), "+v"(dirty_seen)::"memory");
-    if (__builtin_amdgcn_readfirstlane(dirty_seen) != 0u) break;
+    // dense pass: some wave already found a non-base byte -- the caller will redo the batch
+    // on the N-aware path, so stop producing a dense stream nobody will read
+    if (!NA && __builtin_amdgcn_readfirstlane(dirty_seen) != 0u) break;
     if (have_next) {
       cur = nxt;
+      cur_off = nxt_off;
       if (lane < cur.n_vec) pack_vec(cur, lane, make_uint4(pv0.x, pv0.y, pv0.z, pv0.w));
       if constexpr (DT) {
-        const uint32_t n_dw = (cur.shift + cur.slab_bytes + 3u) >> 2;
-        if (256u + lane < n_dw) pack_dword(cur, lane, pw);
+        pack_tail(cur, pw);
         if (lane < (uint32_t)NW + 5u) bits[cur.n_vec + lane] = 0;
       } else {
         if (lane + 64u < cur.n_vec) pack_vec(cur, lane + 64u, make_uint4(pv1.x, pv1.y, pv1.z, pv1.w));
         stage(cur, 128u);
       }
-      if (__ballot(bad != 0) != 0) {
+      if (!NA && __ballot(bad != 0) != 0) { // publish at once so that every wave can stop early
         if (lane == 0) atomicOr(a.dirty, 1u);
         break;
       }
     }
   }
-  if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
+  if (!NA && __ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
+}
+
+// Count pass of the N-aware path: validity bits only, no tables, no tile -- a few
+// hundred bytes of LDS per wave, so the CU runs at full occupancy and the pass
+// streams the reads at close to HBM read rate.  Same geometry and the same window
+// masks as the hash pass.
+__global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_count_kernel(const KmerRunsGenArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t k = a.k, C = a.C, rpr = a.rpr;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const RunShape shape = {C, rpr, a.inv_rpr, a.last_start, a.last_dup, a.stride, a.nwin, k};
+  uint16_t* vbits = (uint16_t*)(lds_dyn + wave * a.vbits_dwords);
+  const uint64_t n_waves_total = (uint64_t)gridDim.x * a.waves;
+  for (uint64_t wt = (uint64_t)blockIdx.x * a.waves + wave; wt < a.n_wtiles; wt += n_waves_total) {
+    const uint64_t g0 = wt * 64u;
+    const uint64_t rf = g0 / rpr;
+    const uint32_t rm = (uint32_t)(g0 - rf * rpr);
+    const TileGeo g = tile_geo(shape, (uint64_t)a.seqs, a.n_runs, a.total_bytes, g0, rf, rm);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < g.n_vec; i += 64u) {
+      const uint4 v = *(const uint4*)(a.seqs + g.byte0 + ((uint64_t)i << 4));
+      uint32_t i0, i1, i2, i3;
+      (void)pack4v(v.x, i0);
+      (void)pack4v(v.y, i1);
+      (void)pack4v(v.z, i2);
+      (void)pack4v(v.w, i3);
+      vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    const bool live = lane < g.runs_here;
+    uint32_t lr, w0;
+    bool last_run;
+    run_split(shape, live ? rm + lane : rm, lr, w0, last_run);
+    const uint32_t b0 = g.shift + lr * a.stride + w0 - g.w_first;
+    const uint32_t dup = last_run ? a.last_dup : 0u;
+    const uint32_t run_mask = live ? ((1u << C) - 1u) & ~((1u << dup) - 1u) : 0u;
+    const uint32_t valid = ~windows_with_non_base((const uint32_t*)vbits, b0, k) & run_mask;
+    const uint32_t cnt = __builtin_popcount(valid);
+    uint32_t sum = cnt;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane == 0) a.tile_counts[wt] = sum;
+    if (a.counts && cnt) atomicAdd((unsigned long long*)&a.counts[rf + lr], (unsigned long long)cnt);
+  }
 }
 
 } // namespace ntamd

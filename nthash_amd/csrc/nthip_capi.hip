@@ -21,7 +21,6 @@
 #include "kmer_kernels.hpp"
 #include "kmer_runs_kernel.hpp"
 #include "kmer_runs_gen_kernel.hpp"
-#include "kmer_runs_na_kernel.hpp"
 #include "kmer_ragged_kernel.hpp"
 #include "nt_math.hpp"
 #include "seed_kernels.hpp"
@@ -667,7 +666,7 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
 }
 
 template <typename K>
-int launch_kmer_runs_gen(nthip_ctx* c, K kernel, KmerRunsGenArgs a, size_t dyn_lds)
+int launch_kmer_runs_gen(nthip_ctx* c, K kernel, KmerRunsGenArgs a, size_t dyn_lds, const char* label)
 {
   int per_cu = 1;
   NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
@@ -675,7 +674,7 @@ int launch_kmer_runs_gen(nthip_ctx* c, K kernel, KmerRunsGenArgs a, size_t dyn_l
   uint64_t grid = (uint64_t)c->n_cu * per_cu;
   if (grid > need) grid = need;
   if (a.tile_map == 0xFFFFFFFFu) a.tile_map = (uint32_t)grid;
-  prof_begin(c, "kmer_runs_gen_kernel");
+  prof_begin(c, label);
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
   prof_end(c);
   HIPCHK(hipGetLastError());
@@ -683,58 +682,23 @@ int launch_kmer_runs_gen(nthip_ctx* c, K kernel, KmerRunsGenArgs a, size_t dyn_l
 }
 
 // N-aware run-split path for fixed-length reads: count pass -> scan -> compact hash pass
-// (kmer_runs_na_kernel.hpp).  Geometry as the general run-split kernel, with disjoint runs.
-template <int MODE, int NW>
-int launch_kmer_na(nthip_ctx* c, const KmerRunsNaArgs& a, size_t dyn_lds)
-{
-  auto kernel = kmer_runs_na_kernel<MODE, NW>;
-  int per_cu = 1;
-  NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
-  const uint64_t need = (a.n_wtiles + a.waves - 1) / a.waves;
-  uint64_t grid = (uint64_t)c->n_cu * per_cu;
-  if (grid > need) grid = need;
-  if (MODE == NA_MODE_HASH) prof_begin(c, "kmer_runs_na_kernel");
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
-  if (MODE == NA_MODE_HASH) prof_end(c);
-  HIPCHK(hipGetLastError());
-  return NTHIP_OK;
-}
-
-int launch_kmer_na_nw(nthip_ctx* c, int mode, const KmerRunsNaArgs& a, size_t dyn_lds, uint32_t nw)
-{
-  if (mode == NA_MODE_COUNT) return launch_kmer_na<NA_MODE_COUNT, 1>(c, a, dyn_lds); // no hashing: NW unused
-  switch (nw) {
-    case 1: return launch_kmer_na<NA_MODE_HASH, 1>(c, a, dyn_lds);
-    case 2: return launch_kmer_na<NA_MODE_HASH, 2>(c, a, dyn_lds);
-    case 3: return launch_kmer_na<NA_MODE_HASH, 3>(c, a, dyn_lds);
-    default: return launch_kmer_na<NA_MODE_HASH, 4>(c, a, dyn_lds);
-  }
-}
-
+// (kmer_runs_gen_kernel.hpp, NA = true).  Same geometry as the dense general kernel.
 struct NaPlan {
-  uint32_t C = 0, rpr = 0, last_cnt = 0, waves = 0, bits_dwords = 0, vbits_dwords = 0, tile_u64 = 0, nw = 0;
+  GenPlan g;
+  uint32_t vbits_dwords = 0, ptile_dwords = 0, waves = 0, tile_u64 = 0;
   size_t lds = 0;
 };
 
-bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, NaPlan* p)
+bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, bool want_pos,
+                  NaPlan* p)
 {
-  GenPlan g;
-  if (!kmer_gen_plan(c, len, stride, k, m, &g)) return false;
-  const uint32_t nwin = len - k + 1;
-  p->C = g.C;
-  p->rpr = g.rpr;
-  p->last_cnt = nwin - (g.rpr - 1) * g.C;
-  p->nw = g.nw;
-  p->tile_u64 = 64 * g.C;
-  // longest slab: 63 run-to-run steps (C bases; stride - (rpr-1)*C across a read boundary) + the last run
-  const int64_t x = (int64_t)stride - (int64_t)g.rpr * g.C;
-  const uint64_t crossings = (63 + g.rpr - 1) / g.rpr;
-  const uint64_t slab_bytes = 64ull * g.C + k - 1 + (x > 0 ? crossings * (uint64_t)x : 0);
-  const uint32_t n_vec = (uint32_t)((15 + slab_bytes + 15) >> 4);
-  p->bits_dwords = (n_vec + g.nw + 6 + 3u) & ~3u;
-  p->vbits_dwords = ((n_vec + 12) / 2 + 2 + 3u) & ~3u;
+  if (!kmer_gen_plan(c, len, stride, k, m, &p->g)) return false;
+  const GenPlan& g = p->g;
+  p->tile_u64 = 64 * g.C + KRG_ALIGN_U64 + KRG_SLACK_U64;
+  p->ptile_dwords = want_pos ? (64 * g.C + KRG_SLACK_U64 + 3u) & ~3u : 0u;
+  p->vbits_dwords = (g.bits_dwords / 2 + 8 + 3u) & ~3u; // 16 validity bits per 32 stream bits, read 4 dwords ahead
   const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
-  const size_t per_wave = (size_t)p->tile_u64 * 12 + (size_t)p->bits_dwords * 4 + (size_t)p->vbits_dwords * 4;
+  const size_t per_wave = (size_t)p->tile_u64 * 8 + ((size_t)p->ptile_dwords + g.bits_dwords + p->vbits_dwords) * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
   for (uint32_t w = 8; w >= 1; --w)
     if (fixed + per_wave * w <= cap) {
@@ -745,35 +709,64 @@ bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k,
   return false;
 }
 
+void fill_gen_args(KmerRunsGenArgs& ga, nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k,
+                   uint32_t m, const GenPlan& g, const KmerFixedArgs& consts)
+{
+  memset(&ga, 0, sizeof ga);
+  const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
+  ga.seqs = st.seqs;
+  ga.hashes = st.hashes;
+  ga.dirty = (uint32_t*)c->d_small;
+  ga.n_reads = rd->n_reads;
+  ga.n_runs = rd->n_reads * g.rpr;
+  ga.n_wtiles = (ga.n_runs + 63) / 64;
+  ga.total_bytes = (rd->n_reads - 1) * (uint64_t)stride + len;
+  ga.len = len;
+  ga.stride = stride;
+  ga.k = k;
+  ga.m = m;
+  ga.nwin = len - k + 1;
+  ga.C = g.C;
+  ga.rpr = g.rpr;
+  ga.last_start = g.last_start;
+  ga.last_dup = g.rpr * g.C - ga.nwin;
+  ga.ntab = (k + 3) / 4;
+  ga.waves = g.waves;
+  ga.bits_dwords = g.bits_dwords;
+  ga.tile_u64 = g.tile_u64;
+  ga.inv_rpr = 65536u / g.rpr + 1u;
+  { const char* t2 = getenv("NTHIP_TUNE_TILE_MAP"); ga.tile_map = t2 ? (uint32_t)atoi(t2) : 0xFFFFFFFFu; }
+  memcpy(ga.tab, consts.tab, sizeof ga.tab);
+  memcpy(ga.mult, consts.mult, sizeof ga.mult);
+}
+
+template <bool NA>
+int launch_kmer_runs_gen_nw(nthip_ctx* c, const KmerRunsGenArgs& ga, size_t lds, uint32_t nw, bool dt)
+{
+  const char* label = NA ? "kmer_runs_gen_kernel(N-aware)" : "kmer_runs_gen_kernel";
+#define NT_GEN(NWT) \
+  (dt ? launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, true, NA>, ga, lds, label) \
+      : launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, false, NA>, ga, lds, label))
+  switch (nw) {
+    case 1: return NT_GEN(1);
+    case 2: return NT_GEN(2);
+    case 3: return NT_GEN(3);
+    default: return NT_GEN(4);
+  }
+#undef NT_GEN
+}
+
 int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m,
                 const NaPlan& plan, const KmerFixedArgs& consts, uint64_t capacity, uint64_t* total)
 {
-  KmerRunsNaArgs a;
-  memset(&a, 0, sizeof a);
-  a.seqs = st.seqs;
-  a.hashes = st.hashes;
+  KmerRunsGenArgs a;
+  fill_gen_args(a, c, st, rd, k, m, plan.g, consts);
+  NTCHK(get_init_tab(c, k, &a.init_tab));
   a.pos = st.pos;
   a.counts = st.counts;
-  NTCHK(get_init_tab(c, k, &a.init_tab));
-  a.n_reads = rd->n_reads;
-  a.n_runs = rd->n_reads * plan.rpr;
-  a.n_wtiles = (a.n_runs + 63) / 64;
-  a.len = rd->fixed_len;
-  a.stride = rd->stride ? rd->stride : rd->fixed_len;
-  a.k = k;
-  a.m = m;
-  a.nwin = a.len - k + 1;
-  a.C = plan.C;
-  a.rpr = plan.rpr;
-  a.ntab = (k + 3) / 4;
-  a.waves = plan.waves;
-  a.bits_dwords = plan.bits_dwords;
   a.vbits_dwords = plan.vbits_dwords;
+  a.ptile_dwords = plan.ptile_dwords;
   a.tile_u64 = plan.tile_u64;
-  a.inv_rpr = 65536u / plan.rpr + 1u;
-  a.last_cnt = plan.last_cnt;
-  memcpy(a.tab, consts.tab, sizeof a.tab);
-  memcpy(a.mult, consts.mult, sizeof a.mult);
   const uint64_t nt = a.n_wtiles;
   const uint64_t nb = (nt + SCAN_TILE - 1) / SCAN_TILE;
   NTCHK(ensure_scratch(c, 2 * nt + nb + 16));
@@ -783,7 +776,19 @@ int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t 
   uint64_t* d_total = (uint64_t*)(c->d_small + 8);
   a.tile_off = d_off;
   if (st.counts) HIPCHK(hipMemsetAsync(st.counts, 0, rd->n_reads * sizeof(uint64_t), c->stream));
-  NTCHK(launch_kmer_na_nw(c, NA_MODE_COUNT, a, plan.lds, plan.nw));
+  {
+    // count pass: 16 waves per block, validity bits only
+    KmerRunsGenArgs ca = a;
+    ca.waves = 16;
+    const size_t lds = (size_t)ca.waves * ca.vbits_dwords * 4 + 64;
+    int per_cu = 1;
+    NTCHK(blocks_per_cu(c, kmer_runs_count_kernel, (int)ca.waves * 64, lds, &per_cu));
+    const uint64_t need = (ca.n_wtiles + ca.waves - 1) / ca.waves;
+    uint64_t grid = (uint64_t)c->n_cu * per_cu;
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL(kmer_runs_count_kernel, dim3((unsigned)grid), dim3(ca.waves * 64), lds, c->stream, ca);
+    HIPCHK(hipGetLastError());
+  }
   NTCHK(device_exclusive_scan(c, a.tile_counts, d_off, nt, d_sums, d_total));
   HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -792,7 +797,8 @@ int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t 
     return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
                 (unsigned long long)capacity, (unsigned long long)*total);
   a.counts = nullptr;
-  NTCHK(launch_kmer_na_nw(c, NA_MODE_HASH, a, plan.lds, plan.nw));
+  a.waves = plan.waves;
+  NTCHK(launch_kmer_runs_gen_nw<true>(c, a, plan.lds, plan.g.nw, plan.g.dword_tail != 0));
   HIPCHK(hipStreamSynchronize(c->stream));
   return NTHIP_OK;
 }
@@ -1071,7 +1077,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
   // fixed-length reads that are (or may be) dirty, or whose positions are wanted: N-aware run-split path
   NaPlan na_plan;
   const bool na_ok = !rd->offsets && !(flags & (NTHIP_FORCE_GENERAL | NTHIP_FORCE_ROWS)) && !st.fwd && !st.rev &&
-                     len >= k && kmer_na_plan(c, len, stride, k, m, &na_plan);
+                     len >= k && kmer_na_plan(c, len, stride, k, m, st.pos != nullptr, &na_plan);
   if (!rd->offsets && len < k) {
     // every read shorter than k: nothing is emitted
     if (st.counts) {
@@ -1150,40 +1156,9 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
     } else if (!rows_only && kmer_gen_plan(c, len, stride, k, m, &gplan)) {
       // any other shape: general run-split kernel (kmer_runs_gen_kernel.hpp)
       KmerRunsGenArgs ga;
-      memset(&ga, 0, sizeof ga);
-      ga.seqs = st.seqs;
-      ga.hashes = st.hashes;
-      ga.dirty = (uint32_t*)c->d_small;
+      fill_gen_args(ga, c, st, rd, k, m, gplan, a);
       NTCHK(get_init_tab(c, k, &ga.init_tab));
-      ga.n_reads = rd->n_reads;
-      ga.n_runs = rd->n_reads * gplan.rpr;
-      ga.n_wtiles = (ga.n_runs + 63) / 64;
-      ga.total_bytes = (rd->n_reads - 1) * (uint64_t)stride + len;
-      ga.len = len;
-      ga.stride = stride;
-      ga.k = k;
-      ga.m = m;
-      ga.nwin = nwin;
-      ga.C = gplan.C;
-      ga.rpr = gplan.rpr;
-      ga.last_start = gplan.last_start;
-      ga.ntab = (k + 3) / 4;
-      ga.waves = gplan.waves;
-      ga.bits_dwords = gplan.bits_dwords;
-      ga.tile_u64 = gplan.tile_u64;
-      ga.inv_rpr = 65536u / gplan.rpr + 1u;
-      { const char* t2 = getenv("NTHIP_TUNE_TILE_MAP"); ga.tile_map = t2 ? (uint32_t)atoi(t2) : 0xFFFFFFFFu; }
-      memcpy(ga.tab, a.tab, sizeof ga.tab);
-      memcpy(ga.mult, a.mult, sizeof ga.mult);
-      const bool dt = gplan.dword_tail != 0;
-#define NT_GEN(NWT) \
-  (dt ? launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, true>, ga, gplan.lds) \
-      : launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, false>, ga, gplan.lds))
-      if (gplan.nw == 1) rc = NT_GEN(1);
-      else if (gplan.nw == 2) rc = NT_GEN(2);
-      else if (gplan.nw == 3) rc = NT_GEN(3);
-      else rc = NT_GEN(4);
-#undef NT_GEN
+      rc = launch_kmer_runs_gen_nw<false>(c, ga, gplan.lds, gplan.nw, gplan.dword_tail != 0);
     } else if (!rows_ok) {
       rc = NTHIP_OK;
       fast_ran = false;
