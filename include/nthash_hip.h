@@ -94,6 +94,7 @@ int nthip_malloc(nthip_ctx* ctx, size_t bytes, void** dptr);
 int nthip_free(nthip_ctx* ctx, void* dptr);
 int nthip_memcpy_h2d(nthip_ctx* ctx, void* dst, const void* src, size_t bytes);
 int nthip_memcpy_d2h(nthip_ctx* ctx, void* dst, const void* src, size_t bytes);
+int nthip_memset(nthip_ctx* ctx, void* d_dst, int byte_value, size_t bytes);
 
 /* ---- the hot path -------------------------------------------------------- */
 /*
@@ -143,6 +144,32 @@ int nthip_seed_hash(nthip_ctx* ctx, const nthip_reads* reads, const nthip_seeds*
  */
 int nthip_kmer_extend(nthip_ctx* ctx, const char* kmers, uint64_t n_kmers, uint16_t k, uint8_t m,
                       uint64_t* self, uint64_t* next, uint64_t* prev, uint32_t flags);
+
+/*
+ * Fused consumers of the k-mer hash stream: what ntHash's callers do with
+ * hashes() -- Bloom filter insert / membership (the reference points at btllib's Bloom filters,
+ * include/nthash/nthash.hpp:14-17,56-57) -- done inside the hashing kernel, so the 8*m bytes per
+ * k-mer that bound nthip_kmer_hash are never written.  For every k-mer NtHash would emit for read r
+ * (same emission rule as nthip_kmer_hash) and every i < m, bit  hashes()[i] mod n_bits  of the
+ * filter is set (insert) or tested (query).  Filter layout: bit p = bit (p & 7) of byte p >> 3
+ * (a plain byte array as in btllib::BloomFilter); DEVICE memory, 4-byte aligned, ceil(n_bits/32)*4
+ * bytes, persistent across calls -- build it with several insert calls, test with query.
+ *
+ * insert: *total (optional) = k-mers consumed.
+ * query : hits[r] (optional; host memory with NTHIP_HOST_OUTPUT) = k-mers of read r whose m bits
+ *         are all set; *total = k-mers tested, *total_hits = sum of hits.
+ * Fixed-length reads (reads->offsets == NULL), k <= 64, m <= 8; otherwise NTHIP_ERR_UNSUPPORTED
+ * (hash to a stream with nthip_kmer_hash and consume that).
+ */
+int nthip_kmer_bloom_insert(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint8_t m,
+                            uint8_t* d_filter, uint64_t n_bits, uint64_t* total, uint32_t flags);
+int nthip_kmer_bloom_query(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint8_t m,
+                           const uint8_t* d_filter, uint64_t n_bits, uint64_t* hits, uint64_t* total,
+                           uint64_t* total_hits, uint32_t flags);
+/* the same two operations on an already materialised stream of n_kmers*m hashes (device memory):
+ * the unfused baseline, and the consumer for shapes the fused kernels do not take */
+int nthip_stream_bloom_insert(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t n_values,
+                              uint8_t* d_filter, uint64_t n_bits);
 
 /* ---- measurement helpers (device-resident synthetic data, checksums) ---- */
 /* counter-based reads: read r, 32-base word w ->

@@ -31,8 +31,9 @@ SYMBOLS = [
     "nthip_version", "nthip_last_error", "nthip_device_count", "nthip_ctx_create",
     "nthip_ctx_destroy", "nthip_ctx_set_stream", "nthip_ctx_synchronize",
     "nthip_ctx_set_profiling", "nthip_last_kernel_ms", "nthip_malloc", "nthip_free",
-    "nthip_memcpy_h2d", "nthip_memcpy_d2h", "nthip_kmer_hash", "nthip_seeds_create",
-    "nthip_seeds_destroy", "nthip_seed_hash", "nthip_kmer_extend", "nthip_synth_reads", "nthip_checksum",
+    "nthip_memcpy_h2d", "nthip_memcpy_d2h", "nthip_memset", "nthip_kmer_hash", "nthip_seeds_create",
+    "nthip_seeds_destroy", "nthip_seed_hash", "nthip_kmer_extend", "nthip_kmer_bloom_insert",
+    "nthip_kmer_bloom_query", "nthip_stream_bloom_insert", "nthip_synth_reads", "nthip_checksum",
     "nthip_copy_bench",
 ]
 
@@ -80,6 +81,7 @@ def load():
     L.nthip_free.argtypes = [vp, vp]
     L.nthip_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     L.nthip_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.nthip_memset.argtypes = [vp, vp, C.c_int, C.c_size_t]
     L.nthip_kmer_hash.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, C.POINTER(Out),
                                   C.POINTER(u64), u32]
     L.nthip_seeds_create.argtypes = [vp, C.POINTER(C.c_char_p), u32, C.c_uint16, C.POINTER(vp),
@@ -88,6 +90,10 @@ def load():
     L.nthip_seed_hash.argtypes = [vp, C.POINTER(Reads), vp, C.c_uint8, C.POINTER(Out),
                                   C.POINTER(u64), u32]
     L.nthip_kmer_extend.argtypes = [vp, vp, u64, C.c_uint16, C.c_uint8, vp, vp, vp, u32]
+    L.nthip_kmer_bloom_insert.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, u64, C.POINTER(u64), u32]
+    L.nthip_kmer_bloom_query.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, u64, vp,
+                                         C.POINTER(u64), C.POINTER(u64), u32]
+    L.nthip_stream_bloom_insert.argtypes = [vp, vp, u64, vp, u64]
     L.nthip_synth_reads.argtypes = [vp, vp, u64, u64, u32, u64]
     L.nthip_checksum.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
     L.nthip_copy_bench.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
@@ -187,6 +193,9 @@ class Context:
         assert arr.flags["C_CONTIGUOUS"]
         _chk(self.L.nthip_memcpy_d2h(self.h, arr.ctypes.data, C.c_void_p(dptr), arr.nbytes))
 
+    def memset(self, dptr, value, nbytes):
+        _chk(self.L.nthip_memset(self.h, C.c_void_p(dptr), value, nbytes))
+
     def kmer_hash_ptr(self, seqs, offsets, n_reads, fixed_len, stride, k, m, hashes, capacity,
                       counts=0, pos=0, fwd=0, rev=0, flags=0):
         rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
@@ -229,6 +238,45 @@ class Context:
         if want_prev:
             out["prev"] = pv.reshape(n, 4, m)
         return out
+
+    # -- fused Bloom-filter consumers (filter: device memory, ceil(n_bits/32)*4 bytes) ---------
+    def bloom_insert_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_filter, n_bits, flags=0):
+        rd = Reads(seqs, None, n_reads, fixed_len, stride)
+        total = C.c_uint64(0)
+        _chk(self.L.nthip_kmer_bloom_insert(self.h, C.byref(rd), k, m, C.c_void_p(d_filter), n_bits,
+                                            C.byref(total), flags))
+        return total.value
+
+    def bloom_query_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_filter, n_bits, hits=0, flags=0):
+        rd = Reads(seqs, None, n_reads, fixed_len, stride)
+        total, found = C.c_uint64(0), C.c_uint64(0)
+        _chk(self.L.nthip_kmer_bloom_query(self.h, C.byref(rd), k, m, C.c_void_p(d_filter), n_bits,
+                                           C.c_void_p(hits) if hits else None, C.byref(total), C.byref(found),
+                                           flags))
+        return total.value, found.value
+
+    def stream_bloom_insert_ptr(self, d_hashes, n_values, d_filter, n_bits):
+        _chk(self.L.nthip_stream_bloom_insert(self.h, C.c_void_p(d_hashes), n_values, C.c_void_p(d_filter), n_bits))
+
+    def bloom_new(self, n_bits):
+        """zeroed device filter of n_bits bits; returns (device pointer, bytes)"""
+        nbytes = (n_bits + 31) // 32 * 4
+        d = self.malloc(nbytes)
+        self.memset(d, 0, nbytes)
+        return d, nbytes
+
+    def bloom_insert(self, data, k, m, fixed_len, n_reads, d_filter, n_bits, stride=0):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        return self.bloom_insert_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, d_filter, n_bits,
+                                     flags=NTHIP_HOST_INPUT)
+
+    def bloom_query(self, data, k, m, fixed_len, n_reads, d_filter, n_bits, stride=0):
+        """-> (hits per read, k-mers tested, k-mers found)"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        hits = np.zeros(n_reads, np.uint64)
+        total, found = self.bloom_query_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, d_filter, n_bits,
+                                            hits=hits.ctypes.data, flags=NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT)
+        return hits, total, found
 
     def synth_reads_ptr(self, dptr, first_read, n_reads, length, seed=42):
         _chk(self.L.nthip_synth_reads(self.h, C.c_void_p(dptr), first_read, n_reads, length, seed))

