@@ -171,6 +171,64 @@ int nthip_kmer_bloom_query(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k,
 int nthip_stream_bloom_insert(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t n_values,
                               uint8_t* d_filter, uint64_t n_bits);
 
+/*
+ * FASTQ / FASTA -> device batches, done the GPU way: the raw file bytes are
+ * uploaded as they are, record boundaries are found on the device, and the k-mer kernels read the
+ * sequence lines where they lie -- no host parser, no packing copy.
+ *
+ * nthip_kmer_hash_spans: nthip_kmer_hash for reads given as spans [d_starts[r], d_ends[r]) of one
+ * device buffer of buf_bytes bytes (sequence lines inside a raw FASTQ chunk; spans may be separated
+ * by anything).  Same emission rule, order and outputs (out->hashes/counts/pos; fwd/rev must be NULL)
+ * as nthip_kmer_hash with offsets.  All pointers are device pointers unless NTHIP_HOST_OUTPUT is set
+ * for the outputs.  k <= 64, m <= 8.
+ */
+int nthip_kmer_hash_spans(nthip_ctx* ctx, const char* d_buf, uint64_t buf_bytes, const uint64_t* d_starts,
+                          const uint64_t* d_ends, uint64_t n_reads, uint16_t k, uint8_t m,
+                          const nthip_out* out, uint64_t* total, uint32_t flags);
+
+#define NTHIP_FASTQ 4u  /* 4-line records: @header / sequence / + / quality            */
+#define NTHIP_FASTA 2u  /* 2-line records: >header / sequence (one line per sequence)   */
+/*
+ * nthip_fastx_index: d_buf[0..n_bytes) is a piece of a FASTQ / single-line FASTA file that begins
+ * at a record start.  For every COMPLETE record r in it (all of its lines end with '\n' inside the
+ * piece) writes the span of its sequence line to d_starts[r], d_ends[r] (a trailing '\r' is dropped).
+ * *n_records = complete records, *consumed = one past the last byte of the last complete record
+ * (the bytes after it are the beginning of the next piece), *malformed != 0 when a record does not
+ * begin with '@' / '>' or a FASTQ record's third line does not begin with '+'.
+ * NTHIP_ERR_CAPACITY (with *n_records set) when there are more than `capacity` records.
+ */
+int nthip_fastx_index(nthip_ctx* ctx, const char* d_buf, uint64_t n_bytes, uint32_t format,
+                      uint64_t* d_starts, uint64_t* d_ends, uint64_t capacity, uint64_t* n_records,
+                      uint64_t* consumed, int* malformed);
+
+/* one batch of a streamed file: every pointer is DEVICE memory owned by the driver, valid during the callback */
+typedef struct nthip_fastx_batch {
+  uint64_t n_reads;          /* records of this batch, in file order                              */
+  uint64_t n_kmers;          /* k-mers emitted for them                                           */
+  const uint64_t* hashes;    /* n_kmers * m, order as nthip_kmer_hash                             */
+  const uint64_t* counts;    /* n_reads: k-mers per read                                          */
+  const char* raw;           /* the raw bytes the spans refer to                                  */
+  const uint64_t* starts;    /* n_reads: sequence line of read r = raw[starts[r] .. ends[r])      */
+  const uint64_t* ends;
+  uint64_t first_read;       /* index of the batch's first record in the file                     */
+} nthip_fastx_batch;
+typedef int (*nthip_fastx_fn)(void* user, const nthip_fastx_batch* batch); /* non-zero return stops the stream */
+typedef struct nthip_fastx_stats {
+  uint64_t file_bytes, reads, kmers, batches;
+  double seconds;            /* wall time of the whole call                                        */
+  double read_seconds;       /* time the reader threads spent in pread (overlapped)                */
+  double gpu_seconds;        /* index + hash + callback time (overlapped with reads and uploads)   */
+} nthip_fastx_stats;
+/*
+ * nthip_fastx_kmer_hash_file: stream a FASTQ / single-line FASTA file through the hash path.
+ * Reader threads pread() pieces of chunk_bytes into pinned buffers; each piece is uploaded on a copy
+ * stream while the previous one is indexed and hashed; `fn` sees every batch once, in file order.
+ * chunk_bytes == 0 picks 256 MiB.  Records longer than 16 MiB are not supported by the driver
+ * (hash such sequences with nthip_kmer_hash directly).
+ */
+int nthip_fastx_kmer_hash_file(nthip_ctx* ctx, const char* path, uint32_t format, uint16_t k, uint8_t m,
+                               uint64_t chunk_bytes, nthip_fastx_fn fn, void* user, nthip_fastx_stats* stats);
+
 /* ---- measurement helpers (device-resident synthetic data, checksums) ---- */
 /* counter-based reads: read r, 32-base word w ->
  * splitmix64(seed + r*W + w), 2 bits per base, "ACGT"[..]; writes

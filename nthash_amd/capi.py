@@ -33,7 +33,8 @@ SYMBOLS = [
     "nthip_ctx_set_profiling", "nthip_last_kernel_ms", "nthip_malloc", "nthip_free",
     "nthip_memcpy_h2d", "nthip_memcpy_d2h", "nthip_memset", "nthip_kmer_hash", "nthip_seeds_create",
     "nthip_seeds_destroy", "nthip_seed_hash", "nthip_kmer_extend", "nthip_kmer_bloom_insert",
-    "nthip_kmer_bloom_query", "nthip_stream_bloom_insert", "nthip_synth_reads", "nthip_checksum",
+    "nthip_kmer_bloom_query", "nthip_stream_bloom_insert", "nthip_kmer_hash_spans", "nthip_fastx_index",
+    "nthip_fastx_kmer_hash_file", "nthip_synth_reads", "nthip_checksum",
     "nthip_copy_bench",
 ]
 
@@ -53,6 +54,19 @@ class Out(C.Structure):
     _fields_ = [("hashes", C.c_void_p), ("capacity", C.c_uint64), ("counts", C.c_void_p),
                 ("pos", C.c_void_p), ("fwd", C.c_void_p), ("rev", C.c_void_p)]
 
+
+class FastxBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_kmers", C.c_uint64), ("hashes", C.c_void_p), ("counts", C.c_void_p),
+                ("raw", C.c_void_p), ("starts", C.c_void_p), ("ends", C.c_void_p), ("first_read", C.c_uint64)]
+
+
+class FastxStats(C.Structure):
+    _fields_ = [("file_bytes", C.c_uint64), ("reads", C.c_uint64), ("kmers", C.c_uint64), ("batches", C.c_uint64),
+                ("seconds", C.c_double), ("read_seconds", C.c_double), ("gpu_seconds", C.c_double)]
+
+
+FASTX_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(FastxBatch))
+NTHIP_FASTQ, NTHIP_FASTA = 4, 2
 
 _lib = None
 
@@ -94,6 +108,12 @@ def load():
     L.nthip_kmer_bloom_query.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, u64, vp,
                                          C.POINTER(u64), C.POINTER(u64), u32]
     L.nthip_stream_bloom_insert.argtypes = [vp, vp, u64, vp, u64]
+    L.nthip_kmer_hash_spans.argtypes = [vp, vp, u64, vp, vp, u64, C.c_uint16, C.c_uint8, C.POINTER(Out),
+                                        C.POINTER(u64), u32]
+    L.nthip_fastx_index.argtypes = [vp, vp, u64, u32, vp, vp, u64, C.POINTER(u64), C.POINTER(u64),
+                                    C.POINTER(C.c_int)]
+    L.nthip_fastx_kmer_hash_file.argtypes = [vp, C.c_char_p, u32, C.c_uint16, C.c_uint8, u64, FASTX_FN, vp,
+                                             C.POINTER(FastxStats)]
     L.nthip_synth_reads.argtypes = [vp, vp, u64, u64, u32, u64]
     L.nthip_checksum.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
     L.nthip_copy_bench.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
@@ -277,6 +297,47 @@ class Context:
         total, found = self.bloom_query_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, d_filter, n_bits,
                                             hits=hits.ctypes.data, flags=NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT)
         return hits, total, found
+
+    # -- FASTQ / FASTA: device indexer, spans, file streaming ------------------------------------
+    def fastx_index_ptr(self, d_buf, n_bytes, fmt, d_starts, d_ends, capacity):
+        """-> (records, consumed bytes, malformed flag)"""
+        n, cons, bad = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+        _chk(self.L.nthip_fastx_index(self.h, C.c_void_p(d_buf), n_bytes, fmt, C.c_void_p(d_starts),
+                                      C.c_void_p(d_ends), capacity, C.byref(n), C.byref(cons), C.byref(bad)))
+        return n.value, cons.value, bad.value
+
+    def kmer_hash_spans_ptr(self, d_buf, buf_bytes, d_starts, d_ends, n_reads, k, m, hashes, capacity,
+                            counts=0, pos=0, flags=0):
+        out = Out(hashes, capacity, counts or None, pos or None, None, None)
+        total = C.c_uint64(0)
+        rc = self.L.nthip_kmer_hash_spans(self.h, C.c_void_p(d_buf), buf_bytes, C.c_void_p(d_starts),
+                                          C.c_void_p(d_ends), n_reads, k, m, C.byref(out), C.byref(total), flags)
+        if rc != NTHIP_OK:
+            err = NtHipError(rc, self.L.nthip_last_error().decode(errors="replace"))
+            err.total = total.value
+            raise err
+        return total.value
+
+    def fastx_kmer_hash_file(self, path, fmt, k, m, chunk_bytes=0, on_batch=None):
+        """stream a file; on_batch(FastxBatch) is called per batch (device pointers).  -> FastxStats"""
+        stats = FastxStats()
+        err = []
+
+        def tramp(_user, bp):
+            try:
+                if on_batch is not None:
+                    on_batch(bp.contents)
+                return 0
+            except Exception as e:  # noqa: BLE001 -- must not unwind through the C frame
+                err.append(e)
+                return 1
+        cb = FASTX_FN(tramp)
+        rc = self.L.nthip_fastx_kmer_hash_file(self.h, os.fsencode(path), fmt, k, m, chunk_bytes, cb, None,
+                                               C.byref(stats))
+        if err:
+            raise err[0]
+        _chk(rc)
+        return stats
 
     def synth_reads_ptr(self, dptr, first_read, n_reads, length, seed=42):
         _chk(self.L.nthip_synth_reads(self.h, C.c_void_p(dptr), first_read, n_reads, length, seed))

@@ -1,0 +1,313 @@
+// fastx_stream.hpp -- host side of the FASTQ/FASTA path (included by nthip_capi.hip):
+// nthip_kmer_hash_spans, nthip_fastx_index and the streaming driver
+// nthip_fastx_kmer_hash_file (reader threads -> pinned buffers -> copy stream -> index + hash).
+#pragma once
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+#include "fastx_kernels.hpp"
+
+extern "C" int nthip_kmer_hash_spans(nthip_ctx* c, const char* d_buf, uint64_t buf_bytes, const uint64_t* d_starts,
+                                     const uint64_t* d_ends, uint64_t n_reads, uint16_t k16, uint8_t m8,
+                                     const nthip_out* out, uint64_t* total_out, uint32_t flags)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  if (!out || !out->hashes) return fail(NTHIP_ERR_ARG, "out->hashes is NULL");
+  if (n_reads && (!d_buf || !d_starts || !d_ends)) return fail(NTHIP_ERR_ARG, "buffer / spans are NULL");
+  if (flags & NTHIP_HOST_INPUT) return fail(NTHIP_ERR_UNSUPPORTED, "spans are device pointers");
+  if (out->fwd || out->rev) return fail(NTHIP_ERR_UNSUPPORTED, "strand outputs are not available for spans");
+  const uint32_t k = k16, m = m8;
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
+  if (k < 3) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 is undefined in the reference (src/kmer.cpp:47)");
+  if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
+  if (k > 64 || m > (uint32_t)KF_MAX_RUNTIME_M)
+    return fail(NTHIP_ERR_UNSUPPORTED, "spans take k <= 64 and m <= %d", KF_MAX_RUNTIME_M);
+  HIPCHK(hipSetDevice(c->device));
+  if (total_out) *total_out = 0;
+  if (n_reads == 0) return NTHIP_OK;
+  Staged st;
+  st.seqs = (const uint8_t*)d_buf;
+  NTCHK(stage_outputs(c, out, flags, n_reads, m, st));
+  uint64_t total = 0;
+  bool handled = false;
+  int rc = run_kmer_ragged(c, st, d_starts, d_ends, n_reads, buf_bytes, k, m, out->capacity, &total, &handled);
+  if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
+  NTCHK(rc);
+  if (!handled) return fail(NTHIP_ERR_UNSUPPORTED, "shape outside the run-split ragged kernel");
+  if (total_out) *total_out = total;
+  NTCHK(unstage_outputs(c, out, flags, n_reads, m, total, st));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_fastx_index(nthip_ctx* c, const char* d_buf, uint64_t n_bytes, uint32_t format,
+                                 uint64_t* d_starts, uint64_t* d_ends, uint64_t capacity, uint64_t* n_records,
+                                 uint64_t* consumed, int* malformed)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  if (format != NTHIP_FASTQ && format != NTHIP_FASTA) return fail(NTHIP_ERR_ARG, "format must be NTHIP_FASTQ or NTHIP_FASTA");
+  if (n_bytes && (!d_buf || !d_starts || !d_ends)) return fail(NTHIP_ERR_ARG, "buffer / span arrays are NULL");
+  HIPCHK(hipSetDevice(c->device));
+  if (n_records) *n_records = 0;
+  if (consumed) *consumed = 0;
+  if (malformed) *malformed = 0;
+  if (n_bytes == 0) return NTHIP_OK;
+  const uint64_t nb = (n_bytes + FX_BLOCK_BYTES - 1) / FX_BLOCK_BYTES;
+  const uint64_t nbs = (nb + SCAN_TILE - 1) / SCAN_TILE;
+  NTCHK(ensure_scratch(c, 2 * nb + nbs + 16));
+  uint64_t* d_cnt = c->d_scratch;
+  uint64_t* d_base = c->d_scratch + nb;
+  uint64_t* d_sums = c->d_scratch + 2 * nb;
+  uint64_t* d_total = (uint64_t*)(c->d_small + 8);
+  FastxIndexOut* d_out = (FastxIndexOut*)(c->d_small + 32);
+  HIPCHK(hipMemsetAsync(d_out, 0, sizeof(FastxIndexOut), c->stream));
+  hipLaunchKernelGGL(fastx_count_kernel, dim3((unsigned)nb), dim3(FX_THREADS), 0, c->stream, (const uint8_t*)d_buf,
+                     n_bytes, d_cnt);
+  NTCHK(device_exclusive_scan(c, d_cnt, d_base, nb, d_sums, d_total));
+  prof_begin(c, "fastx_index_kernel");
+  hipLaunchKernelGGL(fastx_index_kernel, dim3((unsigned)nb), dim3(FX_THREADS), 0, c->stream, (const uint8_t*)d_buf,
+                     n_bytes, d_base, d_total, format, (uint8_t)(format == NTHIP_FASTQ ? '@' : '>'), d_starts, d_ends,
+                     capacity, d_out);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_small + 32, d_out, sizeof(FastxIndexOut), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t newlines = 0;
+  FastxIndexOut ho;
+  memcpy(&newlines, c->h_small + 8, 8);
+  memcpy(&ho, c->h_small + 32, sizeof ho);
+  const uint64_t nrec = newlines / format;
+  if (n_records) *n_records = nrec;
+  if (consumed) *consumed = ho.consumed;
+  if (malformed) *malformed = (int)ho.malformed;
+  if (nrec > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "span capacity %llu records < %llu in the chunk", (unsigned long long)capacity,
+                (unsigned long long)nrec);
+  return NTHIP_OK;
+}
+
+namespace {
+
+constexpr uint64_t FXS_HEAD = 16ull << 20; // room in front of a chunk for the carried-over tail of the previous one
+
+struct FxReader {
+  // the reader thread fills pinned[j & 1] with file bytes [j*S, (j+1)*S) for j = 0, 1, ...
+  int fd = -1;
+  uint64_t file_size = 0, chunk = 0, n_chunks = 0;
+  uint8_t* pinned[2] = {nullptr, nullptr};
+  uint64_t filled[2] = {0, 0};
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t next_ready = 0;  // chunks [0, next_ready) have been read
+  uint64_t next_free = 2;   // chunks [0, next_free) may be read (their buffer is free)
+  bool failed = false, stop = false;
+  double read_seconds = 0;
+  std::thread th;
+
+  void run()
+  {
+    const unsigned n_thr = 8;
+    for (uint64_t j = 0; j < n_chunks; ++j) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || j < next_free; });
+        if (stop) return;
+      }
+      const uint64_t off = j * chunk;
+      const uint64_t len = off + chunk <= file_size ? chunk : file_size - off;
+      const auto t0 = std::chrono::steady_clock::now();
+      // several preads at once: one thread does not reach the page-cache copy rate PCIe can take
+      std::atomic<bool> ok{true};
+      std::vector<std::thread> ws;
+      const uint64_t part = (len + n_thr - 1) / n_thr;
+      for (unsigned t = 0; t < n_thr; ++t) {
+        const uint64_t a = (uint64_t)t * part, b = a + part < len ? a + part : len;
+        if (a >= b) break;
+        ws.emplace_back([&, a, b] {
+          uint64_t done = a;
+          while (done < b) {
+            const ssize_t r = pread(fd, pinned[j & 1] + done, b - done, (off_t)(off + done));
+            if (r <= 0) { ok = false; return; }
+            done += (uint64_t)r;
+          }
+        });
+      }
+      for (auto& w : ws) w.join();
+      read_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        filled[j & 1] = len;
+        if (!ok) failed = true;
+        next_ready = j + 1;
+      }
+      cv.notify_all();
+      if (!ok) return;
+    }
+  }
+};
+
+} // namespace
+
+extern "C" int nthip_fastx_kmer_hash_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t k, uint8_t m,
+                                          uint64_t chunk_bytes, nthip_fastx_fn fn, void* user,
+                                          nthip_fastx_stats* stats)
+{
+  if (!c || !path) return fail(NTHIP_ERR_ARG, "ctx/path is NULL");
+  if (format != NTHIP_FASTQ && format != NTHIP_FASTA) return fail(NTHIP_ERR_ARG, "format must be NTHIP_FASTQ or NTHIP_FASTA");
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
+  if (k < 3 || k > 64 || m == 0 || m > KF_MAX_RUNTIME_M)
+    return fail(NTHIP_ERR_UNSUPPORTED, "the file driver takes 3 <= k <= 64 and 1 <= m <= %d", KF_MAX_RUNTIME_M);
+  HIPCHK(hipSetDevice(c->device));
+  const auto t_begin = std::chrono::steady_clock::now();
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (chunk_bytes == 0) chunk_bytes = 256ull << 20;
+  if (chunk_bytes < (1ull << 16)) chunk_bytes = 1ull << 16;
+  chunk_bytes = (chunk_bytes + 4095) & ~4095ull;
+
+  FxReader rd;
+  rd.fd = open(path, O_RDONLY);
+  if (rd.fd < 0) return fail(NTHIP_ERR_ARG, "cannot open %s", path);
+  struct stat sb;
+  if (fstat(rd.fd, &sb) != 0) { close(rd.fd); return fail(NTHIP_ERR_ARG, "cannot stat %s", path); }
+  rd.file_size = (uint64_t)sb.st_size;
+  rd.chunk = chunk_bytes;
+  rd.n_chunks = (rd.file_size + chunk_bytes - 1) / chunk_bytes;
+  if (stats) stats->file_bytes = rd.file_size;
+  if (rd.file_size == 0) { close(rd.fd); return NTHIP_OK; }
+
+  // worst cases inside one piece (head room + chunk + a final newline): an 8-byte record, half of the bytes bases
+  const uint64_t piece_max = FXS_HEAD + chunk_bytes + 16;
+  const uint64_t cap_reads = piece_max / 8 + 1;
+  const uint64_t cap_kmers = piece_max / 2 + 1;
+  uint8_t* d_raw[2] = {nullptr, nullptr};
+  uint64_t *d_starts = nullptr, *d_ends = nullptr, *d_hashes = nullptr, *d_counts = nullptr;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+  int rc = NTHIP_OK;
+  auto cleanup = [&]() {
+    {
+      std::lock_guard<std::mutex> lk(rd.mu);
+      rd.stop = true;
+    }
+    rd.cv.notify_all();
+    if (rd.th.joinable()) rd.th.join();
+    (void)hipStreamSynchronize(c->stream);
+    if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+    for (int i = 0; i < 2; ++i) {
+      if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]);
+      if (rd.pinned[i]) (void)hipHostFree(rd.pinned[i]);
+      if (d_raw[i]) (void)hipFree(d_raw[i]);
+    }
+    if (d_starts) (void)hipFree(d_starts);
+    if (d_ends) (void)hipFree(d_ends);
+    if (d_hashes) (void)hipFree(d_hashes);
+    if (d_counts) (void)hipFree(d_counts);
+    close(rd.fd);
+  };
+#define FX_TRY(expr) \
+  do { \
+    hipError_t e_ = (expr); \
+    if (e_ != hipSuccess) { rc = fail(NTHIP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } \
+  } while (0)
+  FX_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    FX_TRY(hipEventCreateWithFlags(&ev_h2d[i], hipEventDisableTiming));
+    FX_TRY(hipHostMalloc((void**)&rd.pinned[i], chunk_bytes + 16, hipHostMallocDefault));
+    FX_TRY(hipMalloc((void**)&d_raw[i], piece_max + 64));
+  }
+  FX_TRY(hipMalloc((void**)&d_starts, cap_reads * sizeof(uint64_t)));
+  FX_TRY(hipMalloc((void**)&d_ends, cap_reads * sizeof(uint64_t)));
+  FX_TRY(hipMalloc((void**)&d_counts, cap_reads * sizeof(uint64_t)));
+  FX_TRY(hipMalloc((void**)&d_hashes, cap_kmers * (uint64_t)m * sizeof(uint64_t)));
+  rd.th = std::thread([&rd] { rd.run(); });
+
+  uint64_t tail = 0;       // bytes of the piece before chunk j that belong to its first (incomplete) record
+  uint64_t first_read = 0;
+  double gpu_seconds = 0;
+  // piece j = [tail of piece j-1][chunk j]; it lives at d_raw[j & 1] + FXS_HEAD - tail
+  auto process = [&](uint64_t j, uint64_t len, bool last) -> int {
+    uint8_t* piece = d_raw[j & 1] + FXS_HEAD - tail;
+    uint64_t n_bytes = tail + len;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t n_rec = 0, consumed = 0;
+    int malformed = 0;
+    NTCHK(nthip_fastx_index(c, (const char*)piece, n_bytes, format, d_starts, d_ends, cap_reads, &n_rec, &consumed,
+                            &malformed));
+    if (malformed) return fail(NTHIP_ERR_ARG, "%s: malformed record near byte %llu", path,
+                               (unsigned long long)(j * chunk_bytes));
+    uint64_t n_kmers = 0;
+    if (n_rec) {
+      nthip_out out = {d_hashes, cap_kmers, d_counts, nullptr, nullptr, nullptr};
+      NTCHK(nthip_kmer_hash_spans(c, (const char*)piece, n_bytes, d_starts, d_ends, n_rec, k, m, &out, &n_kmers, 0));
+    }
+    if (fn && n_rec) {
+      nthip_fastx_batch b = {n_rec, n_kmers, d_hashes, d_counts, (const char*)piece, d_starts, d_ends, first_read};
+      if (fn(user, &b) != 0) return fail(NTHIP_ERR_ARG, "stopped by the callback");
+    }
+    if (stats) { stats->reads += n_rec; stats->kmers += n_kmers; stats->batches += 1; }
+    first_read += n_rec;
+    const uint64_t rest = n_bytes - consumed;
+    if (last) {
+      if (rest != 0) return fail(NTHIP_ERR_ARG, "%s: truncated record at the end of the file", path);
+    } else {
+      if (rest > FXS_HEAD) return fail(NTHIP_ERR_UNSUPPORTED, "%s: record longer than %llu bytes", path,
+                                       (unsigned long long)FXS_HEAD);
+      // carry the incomplete record in front of the next chunk (its upload writes from FXS_HEAD on)
+      if (rest) HIPCHK(hipMemcpyAsync(d_raw[(j + 1) & 1] + FXS_HEAD - rest, piece + consumed, rest,
+                                      hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    tail = rest;
+    gpu_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return NTHIP_OK;
+  };
+
+  uint64_t lens[2] = {0, 0};
+  for (uint64_t j = 0; j <= rd.n_chunks && rc == NTHIP_OK; ++j) {
+    if (j < rd.n_chunks) {
+      {
+        std::unique_lock<std::mutex> lk(rd.mu);
+        rd.cv.wait(lk, [&] { return rd.failed || rd.next_ready > j; });
+        if (rd.failed) { rc = fail(NTHIP_ERR_ARG, "read error on %s", path); break; }
+      }
+      uint64_t len = rd.filled[j & 1];
+      if (j + 1 == rd.n_chunks && len && rd.pinned[j & 1][len - 1] != '\n') rd.pinned[j & 1][len++] = '\n';
+      lens[j & 1] = len;
+      // d_raw[j & 1] was last read by piece j-2, processed synchronously two iterations ago
+      if (hipMemcpyAsync(d_raw[j & 1] + FXS_HEAD, rd.pinned[j & 1], len, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+          hipEventRecord(ev_h2d[j & 1], copy_stream) != hipSuccess) {
+        rc = fail(NTHIP_ERR_HIP, "upload failed");
+        break;
+      }
+    }
+    if (j > 0) {
+      // piece j-1: its upload was issued one iteration ago and ran under piece j-2's kernels
+      if (hipEventSynchronize(ev_h2d[(j - 1) & 1]) != hipSuccess) { rc = fail(NTHIP_ERR_HIP, "upload failed"); break; }
+      {
+        // its pinned buffer is free again: the reader may fetch chunk j+1 into it
+        std::lock_guard<std::mutex> lk(rd.mu);
+        rd.next_free = j + 2;
+      }
+      rd.cv.notify_all();
+      rc = process(j - 1, lens[(j - 1) & 1], j == rd.n_chunks);
+    }
+  }
+#undef FX_TRY
+  const double read_s = rd.read_seconds;
+  cleanup();
+  if (stats) {
+    stats->read_seconds = read_s;
+    stats->gpu_seconds = gpu_seconds;
+    stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return rc;
+}

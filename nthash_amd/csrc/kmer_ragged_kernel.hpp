@@ -1,5 +1,8 @@
 // kmer_ragged_kernel.hpp -- run-split k-mer hashing of VARIABLE-LENGTH reads
-// (n_reads+1 offsets) with N-aware compaction: the path real FASTQ batches take.
+// with N-aware compaction: the path real FASTQ batches take.  A read is a span
+// [starts[r], ends[r]) of one device buffer -- n_reads+1 offsets of concatenated reads
+// (starts = offsets, ends = offsets + 1) or the sequence lines of a raw FASTQ chunk
+// indexed on the device (fastx_kernels.hpp).
 //
 // Same decomposition as kmer_runs_na_kernel (runs of up to C windows, 64 runs per
 // wave tile, count pass -> scan -> compact hash pass), but a read contributes
@@ -22,13 +25,14 @@ enum : int { NA_MODE_COUNT = 1, NA_MODE_HASH = 2 };
 
 // ---- pre-pass ---------------------------------------------------------------
 // runs per read and a 0/1 flag "has a window"
-__global__ __launch_bounds__(256) void ragged_runs_kernel(const uint64_t* __restrict__ offsets, uint64_t n_reads,
+__global__ __launch_bounds__(256) void ragged_runs_kernel(const uint64_t* __restrict__ starts,
+                                                         const uint64_t* __restrict__ ends, uint64_t n_reads,
                                                          uint32_t k, uint32_t C, uint64_t* __restrict__ rc,
                                                          uint64_t* __restrict__ flag)
 {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_reads) return;
-  const uint64_t len = offsets[r + 1] - offsets[r];
+  const uint64_t len = ends[r] > starts[r] ? ends[r] - starts[r] : 0;
   const uint64_t runs = len >= k ? (len - k + 1 + C - 1) / C : 0;
   rc[r] = runs;
   flag[r] = runs ? 1 : 0;
@@ -67,8 +71,9 @@ __global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t* __res
 // ---- main kernel --------------------------------------------------------------
 struct KmerRaggedArgs {
   const uint8_t* seqs;
-  const uint64_t* offsets;
-  uint64_t total_bytes;      // offsets[n_reads]
+  const uint64_t* starts;    // read r = bytes [starts[r], ends[r]) of seqs
+  const uint64_t* ends;
+  uint64_t total_bytes;      // size of the seqs buffer (no load goes past it)
   uint64_t* hashes;
   uint32_t* pos;
   uint64_t* counts;          // optional (count pass, zeroed by the host): per-read emitted windows
@@ -161,8 +166,9 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
       if (jj < a.n_nz) {
         rd = a.nz_read[jj];
         rcj = a.nz_rc[jj];
-        start = a.offsets[rd];
-        len = a.offsets[rd + 1] - start;
+        start = a.starts[rd];
+        const uint64_t end = a.ends[rd];
+        len = end > start ? end - start : 0;
         q_lo = lane == 0 ? rem0 : 0u;
         avail = rcj - q_lo;
       }

@@ -834,13 +834,14 @@ int launch_kmer_ragged(nthip_ctx* c, int mode, const KmerRaggedArgs& a, size_t d
   return NTHIP_OK;
 }
 
-int run_kmer_ragged(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint64_t total_bytes, uint32_t k,
-                    uint32_t m, uint64_t capacity, uint64_t* total, bool* handled)
+// reads = spans [starts[r], ends[r]) of the device buffer st.seqs (total_bytes long)
+int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
+                    uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled)
 {
   *handled = false;
   const uint32_t C = 15; // run length; the last run of a read may be shorter
   if (k > 64 || m > (uint32_t)KF_MAX_RUNTIME_M || st.fwd || st.rev) return NTHIP_OK;
-  const uint64_t n = rd->n_reads;
+  const uint64_t n = n_reads;
   const uint32_t nw = (k + 15) / 16;
   // per-wave LDS: a tile touches <= 64 listed reads, each staging its runs' bytes rounded up to 16
   const uint32_t max_vec = (64 * C + 64 * (k - 1 + 15 + 15)) / 16 + 64;
@@ -867,7 +868,7 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint6
   uint64_t* d_sums = c->d_scratch + 5 * n;
   uint64_t* d_total = (uint64_t*)(c->d_small + 8);
   const unsigned rblocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(ragged_runs_kernel, dim3(rblocks), dim3(256), 0, c->stream, st.offsets, n, k, C, d_rc, d_flag);
+  hipLaunchKernelGGL(ragged_runs_kernel, dim3(rblocks), dim3(256), 0, c->stream, d_starts, d_ends, n, k, C, d_rc, d_flag);
   NTCHK(device_exclusive_scan(c, d_flag, d_flag, n, d_sums, d_total));
   HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -903,7 +904,8 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint6
   memset(&consts, 0, sizeof consts);
   fill_kmer_consts(k, m, consts);
   a.seqs = st.seqs;
-  a.offsets = st.offsets;
+  a.starts = d_starts;
+  a.ends = d_ends;
   a.total_bytes = total_bytes;
   a.hashes = st.hashes;
   a.pos = st.pos;
@@ -1206,7 +1208,8 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
   }
   if (!done && rd->offsets && !(flags & NTHIP_FORCE_GENERAL)) {
     bool handled = false;
-    int rc = run_kmer_ragged(c, st, rd, total_bytes, k, m, out->capacity, &total, &handled);
+    int rc = run_kmer_ragged(c, st, st.offsets, st.offsets + 1, rd->n_reads, total_bytes, k, m, out->capacity,
+                             &total, &handled);
     if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
     NTCHK(rc);
     done = handled;
@@ -1632,6 +1635,11 @@ extern "C" int nthip_stream_bloom_insert(nthip_ctx* c, const uint64_t* d_hashes,
   HIPCHK(hipStreamSynchronize(c->stream));
   return NTHIP_OK;
 }
+
+// ==========================================================================
+// FASTQ / FASTA -> device batches: spans entry point, device indexer, streaming driver
+// ==========================================================================
+#include "fastx_stream.hpp"
 
 // ==========================================================================
 // measurement helpers

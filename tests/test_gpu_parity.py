@@ -768,3 +768,138 @@ def test_bloom_argument_errors(ctx):
         ctx.bloom_insert(data, 0, 1, 200, 1, d_f, 1024)            # k == 0
     assert ctx.bloom_insert(data, 31, 1, 20, 10, d_f, 1024) == 0    # reads shorter than k: nothing consumed
     ctx.free(d_f)
+
+
+# ---------------------------------------------------------------------------
+# FASTQ / FASTA -> device batches: device indexer, spans, file streaming
+# ---------------------------------------------------------------------------
+def _make_fastx(rng, n, fmt, crlf=False, lo=0, hi=320, bad_frac=0.01):
+    """(file bytes, list of sequences) -- variable-length reads, some shorter than k, some with N"""
+    alph = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+    nl = b"\r\n" if crlf else b"\n"
+    parts, seqs = [], []
+    for i in range(n):
+        L = int(rng.integers(lo, hi))
+        idx = np.where(rng.random(L) < bad_frac, 8, rng.integers(0, 8, L))
+        sq = alph[idx].tobytes()
+        seqs.append(sq)
+        if fmt == 4:
+            qual = bytes(rng.integers(33, 74, L, dtype=np.uint8))   # may start with '@' or '+'
+            parts.append(b"@r%d some text" % i + nl + sq + nl + b"+" + nl + qual + nl)
+        else:
+            parts.append(b">s%d" % i + nl + sq + nl)
+    return b"".join(parts), seqs
+
+
+def _py_spans(buf, fmt):
+    """reference parser: spans of the sequence lines of the complete records, consumed bytes"""
+    starts, ends, pos, consumed = [], [], 0, 0
+    while True:
+        lines = []
+        p = pos
+        for _ in range(fmt):
+            q = buf.find(b"\n", p)
+            if q < 0:
+                lines = None
+                break
+            lines.append((p, q))
+            p = q + 1
+        if lines is None:
+            break
+        s, e = lines[1]
+        if e > s and buf[e - 1:e] == b"\r":
+            e -= 1
+        starts.append(s)
+        ends.append(e)
+        pos = consumed = p
+    return np.array(starts, np.uint64), np.array(ends, np.uint64), consumed
+
+
+@pytest.mark.parametrize("fmt,crlf,cut", [(4, False, 0), (4, True, 0), (2, False, 0), (4, False, 777), (2, True, 5)])
+def test_fastx_index_and_spans_vs_python_parser(ctx, oracle, fmt, crlf, cut):
+    rng = np.random.default_rng(fmt * 10 + cut)
+    buf, seqs = _make_fastx(rng, 3000, fmt, crlf)
+    if cut:
+        buf = buf[: len(buf) - cut]           # the chunk ends inside a record
+    raw = np.frombuffer(buf, dtype=np.uint8)
+    w_starts, w_ends, w_consumed = _py_spans(buf, fmt)
+    d_buf = ctx.malloc(raw.size + 64)
+    ctx.h2d(d_buf + 3, raw)                    # not even 4-byte aligned
+    cap = w_starts.size + 5
+    d_s, d_e = ctx.malloc(cap * 8), ctx.malloc(cap * 8)
+    n_rec, consumed, bad = ctx.fastx_index_ptr(d_buf + 3, raw.size, fmt, d_s, d_e, cap)
+    assert (n_rec, consumed, bad) == (w_starts.size, w_consumed, 0)
+    g_s, g_e = np.zeros(n_rec, np.uint64), np.zeros(n_rec, np.uint64)
+    ctx.d2h(g_s, d_s)
+    ctx.d2h(g_e, d_e)
+    assert (g_s == w_starts).all() and (g_e == w_ends).all()
+    # hash the sequence lines where they lie; oracle on the parsed reads
+    data, offs = concat_reads(seqs[:n_rec])
+    for k, m in ((31, 2), (64, 1), (5, 3)):
+        want = oracle.kmer_batch(data, offs, k, m)
+        capk = max(int(want["total"]), 1)
+        d_h, d_c, d_p = ctx.malloc(capk * m * 8), ctx.malloc(n_rec * 8), ctx.malloc(capk * 4)
+        tot = ctx.kmer_hash_spans_ptr(d_buf + 3, raw.size, d_s, d_e, n_rec, k, m, d_h, capk, counts=d_c, pos=d_p)
+        assert tot == want["total"]
+        h, cnt, pos = np.zeros(tot * m, np.uint64), np.zeros(n_rec, np.uint64), np.zeros(tot, np.uint32)
+        ctx.d2h(h, d_h); ctx.d2h(cnt, d_c); ctx.d2h(pos, d_p)
+        assert (h == want["hashes"].ravel()).all() and (cnt == want["counts"]).all() and (pos == want["pos"]).all()
+        for d in (d_h, d_c, d_p):
+            ctx.free(d)
+    for d in (d_buf, d_s, d_e):
+        ctx.free(d)
+
+
+def test_fastx_index_flags_malformed_input(ctx):
+    for buf, fmt in ((b"@a\nACGT\n-\nIIII\n", 4), (b"a\nACGT\n+\nIIII\n", 4), (b"@a\nAC\n+\nII\nxx\nAC\n+\nII\n", 4),
+                     (b">a\nACGT\nACGT\n>b\nAC\n", 2)):
+        raw = np.frombuffer(buf, dtype=np.uint8)
+        d_buf, d_s, d_e = ctx.malloc(raw.size + 16), ctx.malloc(64), ctx.malloc(64)
+        ctx.h2d(d_buf, raw)
+        _n, _c, bad = ctx.fastx_index_ptr(d_buf, raw.size, fmt, d_s, d_e, 8)
+        assert bad != 0, buf
+        for d in (d_buf, d_s, d_e):
+            ctx.free(d)
+
+
+@pytest.mark.parametrize("fmt,chunk,final_newline", [(4, 1 << 16, True), (4, 100_000, False), (2, 1 << 16, True),
+                                                     (4, 1 << 22, True)])
+def test_fastx_file_stream_vs_oracle(ctx, oracle, tmp_path, fmt, chunk, final_newline):
+    """a file far larger than the chunk size: many batches, records straddling every chunk boundary"""
+    rng = np.random.default_rng(chunk % 1000 + fmt)
+    buf, seqs = _make_fastx(rng, 6000, fmt, lo=20, hi=400)
+    if not final_newline:
+        buf = buf[:-1]
+    path = tmp_path / ("reads.fq" if fmt == 4 else "reads.fa")
+    path.write_bytes(buf)
+    k, m = 31, 2
+    data, offs = concat_reads(seqs)
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    got_h, got_c, firsts = [], [], []
+
+    def on_batch(b):
+        h, cnt = np.zeros(b.n_kmers * m, np.uint64), np.zeros(b.n_reads, np.uint64)
+        if h.size:
+            ctx.d2h(h, b.hashes)
+        ctx.d2h(cnt, b.counts)
+        got_h.append(h); got_c.append(cnt); firsts.append(b.first_read)
+
+    st = ctx.fastx_kmer_hash_file(path, fmt, k, m, chunk_bytes=chunk, on_batch=on_batch)
+    assert st.reads == len(seqs) and st.kmers == want["total"] and st.file_bytes == len(buf)
+    if chunk < len(buf) // 4:
+        assert st.batches > 4
+    assert firsts == list(np.cumsum([0] + [c.size for c in got_c[:-1]]))
+    assert (np.concatenate(got_c) == want["counts"]).all()
+    assert (np.concatenate(got_h) == want["hashes"].ravel()).all()
+
+
+def test_fastx_file_errors(ctx, tmp_path):
+    import nthash_amd
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.fastx_kmer_hash_file(tmp_path / "missing.fq", 4, 31, 1)
+    p = tmp_path / "bad.fq"
+    p.write_bytes(b"@a\nACGT\n+\nIIII\n@b\nACGT\n+\n")       # truncated last record
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.fastx_kmer_hash_file(p, 4, 3, 1)
+    p.write_bytes(b"")
+    assert ctx.fastx_kmer_hash_file(p, 4, 31, 1).reads == 0

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""End-to-end FASTQ file -> k-mer hashes on the device (nthip_fastx_kmer_hash_file).
+
+    python tools/fastq_bench.py [reads] [chunk_MiB] [m]
+Writes a synthetic FASTQ (150 bp reads, 321-byte records) to $TMPDIR, streams it twice (page cache warm),
+prints file GB/s, reads/s, k-mers/s and the stage times the driver reports.
+"""
+import os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import nthash_amd
+from nthash_amd.capi import NTHIP_FASTQ
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+chunk = (int(sys.argv[2]) if len(sys.argv) > 2 else 256) << 20
+m = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+L, k = 150, 31
+ctx = nthash_amd.Context(0)
+d_in = ctx.malloc(n * L)
+ctx.synth_reads_ptr(d_in, 0, n, L, 42)
+seqs = np.zeros(n * L, np.uint8)
+ctx.d2h(seqs, d_in)
+ctx.free(d_in)
+rec = np.empty((n, 17 + L + 1 + 2 + L + 1), np.uint8)
+rec[:, 0] = ord("@")
+ids = np.arange(n, dtype=np.uint64)
+for d in range(15):
+    rec[:, 15 - d] = (ids // np.uint64(10 ** d) % np.uint64(10)).astype(np.uint8) + ord("0")
+rec[:, 16] = ord("\n")
+rec[:, 17:17 + L] = seqs.reshape(n, L)
+rec[:, 17 + L] = ord("\n")
+rec[:, 18 + L] = ord("+")
+rec[:, 19 + L] = ord("\n")
+rec[:, 20 + L:20 + 2 * L] = ord("I")
+rec[:, 20 + 2 * L] = ord("\n")
+path = os.path.join(tempfile.gettempdir(), "nthash_bench.fq")
+t0 = time.perf_counter()
+rec.tofile(path)
+print(f"wrote {rec.nbytes/1e9:.2f} GB in {time.perf_counter()-t0:.1f} s -> {path}", flush=True)
+del rec, seqs
+for it in range(3):
+    st = ctx.fastx_kmer_hash_file(path, NTHIP_FASTQ, k, m, chunk_bytes=chunk)
+    print(f"run {it}: {st.seconds*1e3:8.1f} ms  {st.file_bytes/st.seconds/1e9:6.2f} GB/s of file  "
+          f"{st.reads/st.seconds/1e6:7.1f} M reads/s  {st.kmers/st.seconds/1e9:6.2f} G k-mers/s  "
+          f"(batches {st.batches}, pread {st.read_seconds*1e3:.0f} ms, index+hash {st.gpu_seconds*1e3:.0f} ms)", flush=True)
+os.remove(path)
