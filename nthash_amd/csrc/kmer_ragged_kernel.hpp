@@ -38,16 +38,31 @@ __global__ __launch_bounds__(256) void ragged_runs_kernel(const uint64_t* __rest
   flag[r] = runs ? 1 : 0;
 }
 
-// compact list of the reads that have runs: nz_read[j], nz_rc[j]
+// everything a tile needs to know about a listed read, in one 32-byte record (one load level)
+struct __attribute__((aligned(32))) NzMeta {
+  uint64_t read;  // index in the caller's batch
+  uint64_t rc;    // runs
+  uint64_t start; // first byte in the buffer
+  uint64_t len;   // bytes
+};
+
+// compact list of the reads that have runs: nz_meta[j], and nz_rc[j] on its own for the scan
 __global__ __launch_bounds__(256) void ragged_scatter_kernel(const uint64_t* __restrict__ rc,
-                                                            const uint64_t* __restrict__ nz_idx, uint64_t n_reads,
-                                                            uint64_t* __restrict__ nz_read,
+                                                            const uint64_t* __restrict__ nz_idx,
+                                                            const uint64_t* __restrict__ starts,
+                                                            const uint64_t* __restrict__ ends, uint64_t n_reads,
+                                                            NzMeta* __restrict__ nz_meta,
                                                             uint64_t* __restrict__ nz_rc)
 {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_reads || rc[r] == 0) return;
   const uint64_t j = nz_idx[r];
-  nz_read[j] = r;
+  NzMeta mm;
+  mm.read = r;
+  mm.rc = rc[r];
+  mm.start = starts[r];
+  mm.len = ends[r] - starts[r];
+  nz_meta[j] = mm;
   nz_rc[j] = rc[r];
 }
 
@@ -79,14 +94,14 @@ struct KmerRaggedArgs {
   uint64_t* counts;          // optional (count pass, zeroed by the host): per-read emitted windows
   uint64_t* tile_counts;
   const uint64_t* tile_off;
-  const uint64_t* nz_read;
-  const uint64_t* nz_rc;
+  const NzMeta* nz_meta;
   const uint64_t* tile_j0;
   const uint64_t* tile_rem0;
   const uint4* init_tab;
   uint64_t n_nz, total_runs, n_wtiles;
   uint32_t k, m, C, ntab;
-  uint32_t waves, bits_dwords, vbits_dwords, tile_u64;
+  uint32_t waves, bits_dwords, vbits_dwords, tile_u64; // count pass: tile_u64 = bits_dwords = 0 (validity only)
+  uint32_t ptile_dwords, pad0;                         // position tile, 0 unless pos is wanted
   uint64_t tab[16][2];
   uint64_t mult[KF_MAX_RUNTIME_M];
 };
@@ -96,18 +111,20 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t k = a.k, m = a.m, C = a.C;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile bookkeeping on the scalar unit
 
   // LDS: tables | pair table | multipliers | per wave {hash tile, pos tile, bits, vbits, read table}
   uint4* itab = (uint4*)lds_dyn;
   uint4* ptab = itab + a.ntab * 256u;
   uint64_t* mults = (uint64_t*)(ptab + 16);
   constexpr uint32_t RT_DWORDS = 64 * 8; // per listed read: run begin, vector begin, q_lo, windows, read lo/hi, spare
-  const uint32_t per_wave = a.tile_u64 * 3u + a.bits_dwords + a.vbits_dwords + RT_DWORDS;
-  uint32_t* wave_base = (uint32_t*)(mults + KF_MAX_RUNTIME_M) + wave * per_wave;
+  const uint32_t per_wave = a.tile_u64 * 2u + a.ptile_dwords + a.bits_dwords + a.vbits_dwords + RT_DWORDS;
+  // the count pass keeps no tables, tile or code stream: a few KB per wave, so it runs at full occupancy
+  uint32_t* wave_base = (MODE == NA_MODE_HASH ? (uint32_t*)(mults + KF_MAX_RUNTIME_M) : lds_dyn) + wave * per_wave;
   uint64_t* tile = (uint64_t*)wave_base;
   uint32_t* ptile = wave_base + a.tile_u64 * 2u;
-  uint32_t* bits = ptile + a.tile_u64;
+  uint32_t* bits = ptile + a.ptile_dwords;
   uint16_t* vbits = (uint16_t*)(bits + a.bits_dwords);
   uint32_t* rt_begin = bits + a.bits_dwords + a.vbits_dwords; // first run (tile-relative) of listed read j
   uint32_t* rt_vbeg = rt_begin + 64;                          // first staged vector of read j
@@ -150,12 +167,38 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
   const uint64_t per_block = (a.n_wtiles + gridDim.x - 1) / gridDim.x;
   const uint64_t t_begin = (uint64_t)blockIdx.x * per_block;
   const uint64_t t_end = t_begin + per_block < a.n_wtiles ? t_begin + per_block : a.n_wtiles;
-  for (uint64_t wt = t_begin + wave; wt < t_end; wt += a.waves) {
+  // A tile's metadata sits behind two dependent loads (tile -> first listed read -> that read's
+  // record); both are fetched ahead -- the tile record two tiles ahead, the read records one tile
+  // ahead -- so only the staging loads of the bytes themselves are waited for.
+  auto load_meta = [&](uint64_t j0_) -> NzMeta {
+    NzMeta mm;
+    mm.read = mm.rc = mm.start = mm.len = 0;
+    const uint64_t jj = j0_ + lane;
+    if (jj < a.n_nz) mm = a.nz_meta[jj];
+    return mm;
+  };
+  const uint64_t wstride = a.waves;
+  uint64_t wt = t_begin + wave;
+  uint64_t j0_cur = 0, j0_nxt = 0;
+  uint32_t rem0_cur = 0, rem0_nxt = 0;
+  if (wt < t_end) { j0_cur = a.tile_j0[wt]; rem0_cur = (uint32_t)a.tile_rem0[wt]; }
+  if (wt + wstride < t_end) { j0_nxt = a.tile_j0[wt + wstride]; rem0_nxt = (uint32_t)a.tile_rem0[wt + wstride]; }
+  NzMeta meta_cur = load_meta(j0_cur);
+  for (; wt < t_end; wt += wstride) {
     const uint64_t g0 = wt * 64u;
     const uint64_t runs_left = a.total_runs - g0;
     const uint32_t runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
-    const uint64_t j0 = a.tile_j0[wt];
-    const uint32_t rem0 = (uint32_t)a.tile_rem0[wt];
+    const uint64_t j0 = j0_cur;
+    const uint32_t rem0 = rem0_cur;
+    const NzMeta meta = meta_cur;
+    {
+      uint64_t j0_n2 = 0;
+      uint32_t rem0_n2 = 0;
+      if (wt + 2u * wstride < t_end) { j0_n2 = a.tile_j0[wt + 2u * wstride]; rem0_n2 = (uint32_t)a.tile_rem0[wt + 2u * wstride]; }
+      if (wt + wstride < t_end) meta_cur = load_meta(j0_nxt);
+      j0_cur = j0_nxt; rem0_cur = rem0_nxt;
+      j0_nxt = j0_n2; rem0_nxt = rem0_n2;
+    }
     lds_sync();
     // ---- the (at most 64) listed reads of this tile: one per lane ------------------
     uint32_t take = 0, q_lo = 0, nv = 0, nwin32 = 0;
@@ -164,11 +207,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
       const uint64_t jj = j0 + lane;
       uint64_t avail = 0, rcj = 0, len = 0, start = 0;
       if (jj < a.n_nz) {
-        rd = a.nz_read[jj];
-        rcj = a.nz_rc[jj];
-        start = a.starts[rd];
-        const uint64_t end = a.ends[rd];
-        len = end > start ? end - start : 0;
+        rd = meta.read;
+        rcj = meta.rc;
+        start = meta.start;
+        len = meta.len;
         q_lo = lane == 0 ? rem0 : 0u;
         avail = rcj - q_lo;
       }
@@ -210,10 +252,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
       }
       uint32_t i0, i1, i2, i3;
       const uint32_t c0 = pack4v(x.x, i0), c1 = pack4v(x.y, i1), c2 = pack4v(x.z, i2), c3 = pack4v(x.w, i3);
-      bits[v] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+      if (MODE == NA_MODE_HASH) bits[v] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
       vbits[v] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
     }
-    if (lane < (uint32_t)NW + 3u) bits[v_total + lane] = 0;
+    if (MODE == NA_MODE_HASH && lane < (uint32_t)NW + 3u) bits[v_total + lane] = 0;
     if (lane < 10u) vbits[v_total + lane] = 0xFFFFu;
     lds_sync();
 
@@ -261,9 +303,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
     uint32_t slot = lane_off;
     const bool want_pos = a.pos != nullptr;
     const uint32_t p_first = (uint32_t)w_first;
+    const uint64_t o0 = a.tile_off[wt];
+    const uint32_t tpar = m == 1u ? (uint32_t)(o0 & (KRG_ALIGN_U64 - 1u)) : 0u;
     auto emit = [&](uint32_t jw) {
       if ((valid >> jw) & 1u) {
-        tile[slot] = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+        tile[tpar + slot] = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
         if (want_pos) ptile[slot] = p_first + jw;
         ++slot;
       }
@@ -293,23 +337,43 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
       }
     }
     lds_sync();
-    const uint64_t o0 = a.tile_off[wt];
-    uint64_t* out0 = a.hashes + o0 * m;
+    // copy-out as in kmer_runs_gen_kernel.hpp: the tile was built shifted by tpar = o0 mod 128, every store
+    // instruction covers one aligned KiB of the stream
     if (m == 1) {
-      const uint32_t head = (uint32_t)(o0 & 1u) < total ? (uint32_t)(o0 & 1u) : total;
-      if (lane == 0 && head) out0[0] = tile[0];
-      const uint32_t n_pairs = (total - head) >> 1;
-      for (uint32_t pi = lane; pi < n_pairs; pi += 64u) {
-        const uint64_t x = tile[head + 2u * pi], y = tile[head + 2u * pi + 1u];
-        *(uint4*)(out0 + head + 2u * pi) = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32));
+      const uint32_t span = tpar + total;
+      const uint32_t pieces = (span + 1u) >> 1;
+      uint64_t* const base = a.hashes + (o0 - tpar);
+      for (uint32_t pi = lane; pi < pieces; pi += 64u) {
+        const uint4 dv = *(const uint4*)(tile + 2u * pi);
+        const bool lo_ok = 2u * pi >= tpar && 2u * pi < span;
+        const bool hi_ok = 2u * pi + 1u >= tpar && 2u * pi + 1u < span;
+        if (lo_ok && hi_ok) *(uint4*)(base + 2u * pi) = dv;
+        else if (lo_ok) *(uint2*)(base + 2u * pi) = make_uint2(dv.x, dv.y);
+        else if (hi_ok) *(uint2*)(base + 2u * pi + 1u) = make_uint2(dv.z, dv.w);
       }
-      if (lane == 0 && ((total - head) & 1u)) out0[total - 1u] = tile[total - 1u];
     } else {
-      const uint32_t nvals = total * m;
-      for (uint32_t vi = lane; vi < nvals; vi += 64u) {
-        const uint32_t e = vi / m, jj = vi - e * m;
-        const uint64_t h0 = tile[e];
-        out0[vi] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
+      const uint64_t v0 = o0 * m;
+      const uint32_t vpar = (uint32_t)(v0 & 1u);
+      const uint32_t n_vals = total * m;
+      const uint32_t span = vpar + n_vals;
+      const uint32_t pieces = (span + 1u) >> 1;
+      uint64_t* const base = a.hashes + (v0 - vpar);
+      for (uint32_t pi = lane; pi < pieces; pi += 64u) {
+        uint64_t o[2];
+        bool ok[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t sv = 2u * pi + (uint32_t)h - vpar;
+          ok[h] = sv < n_vals;
+          const uint32_t e = ok[h] ? sv / m : 0u, jj = ok[h] ? sv - e * m : 0u;
+          const uint64_t h0 = tile[e];
+          o[h] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
+        }
+        if (ok[0] && ok[1])
+          *(uint4*)(base + 2u * pi) =
+              make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
+        else if (ok[0]) *(uint2*)(base + 2u * pi) = make_uint2((uint32_t)o[0], (uint32_t)(o[0] >> 32));
+        else if (ok[1]) *(uint2*)(base + 2u * pi + 1u) = make_uint2((uint32_t)o[1], (uint32_t)(o[1] >> 32));
       }
     }
     if (want_pos)

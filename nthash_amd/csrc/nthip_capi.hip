@@ -847,9 +847,10 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
   const uint32_t max_vec = (64 * C + 64 * (k - 1 + 15 + 15)) / 16 + 64;
   const uint32_t bits_dwords = (max_vec + nw + 8 + 3u) & ~3u;
   const uint32_t vbits_dwords = ((max_vec + 12) / 2 + 2 + 3u) & ~3u;
-  const uint32_t tile_u64 = 64 * C;
+  const uint32_t tile_u64 = 64 * C + KRG_ALIGN_U64;
+  const uint32_t ptile_dwords = st.pos ? 64 * C : 0;
   const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
-  const size_t per_wave = (size_t)tile_u64 * 12 + (size_t)bits_dwords * 4 + (size_t)vbits_dwords * 4 + 512 * 4;
+  const size_t per_wave = (size_t)tile_u64 * 8 + ((size_t)ptile_dwords + bits_dwords + vbits_dwords + 512) * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
   uint32_t waves = 0;
   for (uint32_t w = 8; w >= 1; --w)
@@ -859,13 +860,13 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
 
   // ---- pre-pass over reads ----------------------------------------------------------------
   const uint64_t nb_r = (n + SCAN_TILE - 1) / SCAN_TILE;
-  NTCHK(ensure_scratch(c, 5 * n + nb_r + 16));
+  NTCHK(ensure_scratch(c, 8 * n + nb_r + 16));
   uint64_t* d_rc = c->d_scratch;
   uint64_t* d_flag = c->d_scratch + n;      // flag, then (scanned) nz index
-  uint64_t* d_nz_read = c->d_scratch + 2 * n;
-  uint64_t* d_nz_rc = c->d_scratch + 3 * n;
-  uint64_t* d_run_base = c->d_scratch + 4 * n;
-  uint64_t* d_sums = c->d_scratch + 5 * n;
+  uint64_t* d_nz_rc = c->d_scratch + 2 * n;
+  NzMeta* d_nz_meta = (NzMeta*)(c->d_scratch + 4 * n); // 32-byte records (d_scratch comes from hipMalloc: aligned)
+  uint64_t* d_run_base = c->d_scratch + 3 * n;
+  uint64_t* d_sums = c->d_scratch + 8 * n;
   uint64_t* d_total = (uint64_t*)(c->d_small + 8);
   const unsigned rblocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(ragged_runs_kernel, dim3(rblocks), dim3(256), 0, c->stream, d_starts, d_ends, n, k, C, d_rc, d_flag);
@@ -879,8 +880,8 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
     if (st.counts) HIPCHK(hipMemsetAsync(st.counts, 0, n * sizeof(uint64_t), c->stream));
     return NTHIP_OK;
   }
-  hipLaunchKernelGGL(ragged_scatter_kernel, dim3(rblocks), dim3(256), 0, c->stream, d_rc, d_flag, n, d_nz_read,
-                     d_nz_rc);
+  hipLaunchKernelGGL(ragged_scatter_kernel, dim3(rblocks), dim3(256), 0, c->stream, d_rc, d_flag, d_starts, d_ends, n,
+                     d_nz_meta, d_nz_rc);
   NTCHK(device_exclusive_scan(c, d_nz_rc, d_run_base, n_nz, d_sums, d_total));
   HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -912,8 +913,7 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
   a.counts = st.counts;
   a.tile_counts = d_tile_cnt;
   a.tile_off = d_tile_off;
-  a.nz_read = d_nz_read;
-  a.nz_rc = d_nz_rc;
+  a.nz_meta = d_nz_meta;
   a.tile_j0 = d_tile_j0;
   a.tile_rem0 = d_tile_rem0;
   NTCHK(get_init_tab(c, k, &a.init_tab));
@@ -928,6 +928,7 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
   a.bits_dwords = bits_dwords;
   a.vbits_dwords = vbits_dwords;
   a.tile_u64 = tile_u64;
+  a.ptile_dwords = ptile_dwords;
   memcpy(a.tab, consts.tab, sizeof a.tab);
   memcpy(a.mult, consts.mult, sizeof a.mult);
   const size_t lds = fixed + per_wave * waves;
@@ -940,7 +941,16 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
     }
   };
   if (st.counts) HIPCHK(hipMemsetAsync(st.counts, 0, n * sizeof(uint64_t), c->stream));
-  NTCHK(launch(NA_MODE_COUNT));
+  {
+    // count pass: validity bits and the read table only, 16 waves per block
+    KmerRaggedArgs ca = a;
+    ca.tile_u64 = 0;
+    ca.ptile_dwords = 0;
+    ca.bits_dwords = 0;
+    ca.waves = 16;
+    const size_t clds = ((size_t)ca.vbits_dwords + 512) * 4 * ca.waves + 64;
+    NTCHK(launch_kmer_ragged<1>(c, NA_MODE_COUNT, ca, clds));
+  }
   NTCHK(device_exclusive_scan(c, d_tile_cnt, d_tile_off, nt, d_sums2, d_total));
   HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
