@@ -201,6 +201,18 @@ int nthip_fastx_index(nthip_ctx* ctx, const char* d_buf, uint64_t n_bytes, uint3
                       uint64_t* d_starts, uint64_t* d_ends, uint64_t capacity, uint64_t* n_records,
                       uint64_t* consumed, int* malformed);
 
+/*
+ * nthip_fasta_compact: multi-line FASTA on the device.  d_raw[0..n_bytes) is a whole FASTA text that
+ * begins with '>' (records may span any number of lines; CR, LF and blank lines are dropped).
+ * d_seqs (>= n_bytes bytes) receives the sequences back to back, d_offsets[0..*n_records] their
+ * offsets -- the layout nthip_kmer_hash takes (reads->seqs / reads->offsets, device pointers).
+ * *seq_bytes = d_offsets[*n_records].  NTHIP_ERR_CAPACITY (with *n_records set) when the text has
+ * more than `capacity` records (d_offsets must hold capacity + 1 values).
+ */
+int nthip_fasta_compact(nthip_ctx* ctx, const char* d_raw, uint64_t n_bytes, char* d_seqs,
+                        uint64_t* d_offsets, uint64_t capacity, uint64_t* n_records, uint64_t* seq_bytes);
+
+#define NTHIP_FASTA_MULTILINE 1u /* file driver: FASTA whose sequences span lines; the whole file is one batch */
 /* one batch of a streamed file: every pointer is DEVICE memory owned by the driver, valid during the callback */
 typedef struct nthip_fastx_batch {
   uint64_t n_reads;          /* records of this batch, in file order                              */
@@ -223,8 +235,10 @@ typedef struct nthip_fastx_stats {
  * nthip_fastx_kmer_hash_file: stream a FASTQ / single-line FASTA file through the hash path.
  * Reader threads pread() pieces of chunk_bytes into pinned buffers; each piece is uploaded on a copy
  * stream while the previous one is indexed and hashed; `fn` sees every batch once, in file order.
- * chunk_bytes == 0 picks 256 MiB.  Records longer than 16 MiB are not supported by the driver
- * (hash such sequences with nthip_kmer_hash directly).
+ * chunk_bytes == 0 picks 256 MiB.  Records longer than 16 MiB are not supported by the streaming
+ * formats; NTHIP_FASTA_MULTILINE (genomes: few, long sequences) loads the whole file into HBM,
+ * compacts it with nthip_fasta_compact and calls `fn` once (raw = the compacted sequences,
+ * starts/ends = their offsets).
  */
 int nthip_fastx_kmer_hash_file(nthip_ctx* ctx, const char* path, uint32_t format, uint16_t k, uint8_t m,
                                uint64_t chunk_bytes, nthip_fastx_fn fn, void* user, nthip_fastx_stats* stats);

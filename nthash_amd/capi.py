@@ -34,7 +34,7 @@ SYMBOLS = [
     "nthip_memcpy_h2d", "nthip_memcpy_d2h", "nthip_memset", "nthip_kmer_hash", "nthip_seeds_create",
     "nthip_seeds_destroy", "nthip_seed_hash", "nthip_kmer_extend", "nthip_kmer_bloom_insert",
     "nthip_kmer_bloom_query", "nthip_stream_bloom_insert", "nthip_kmer_hash_spans", "nthip_fastx_index",
-    "nthip_fastx_kmer_hash_file", "nthip_synth_reads", "nthip_checksum",
+    "nthip_fastx_kmer_hash_file", "nthip_fasta_compact", "nthip_synth_reads", "nthip_checksum",
     "nthip_copy_bench",
 ]
 
@@ -66,7 +66,7 @@ class FastxStats(C.Structure):
 
 
 FASTX_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(FastxBatch))
-NTHIP_FASTQ, NTHIP_FASTA = 4, 2
+NTHIP_FASTQ, NTHIP_FASTA, NTHIP_FASTA_MULTILINE = 4, 2, 1
 
 _lib = None
 
@@ -112,6 +112,7 @@ def load():
                                         C.POINTER(u64), u32]
     L.nthip_fastx_index.argtypes = [vp, vp, u64, u32, vp, vp, u64, C.POINTER(u64), C.POINTER(u64),
                                     C.POINTER(C.c_int)]
+    L.nthip_fasta_compact.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
     L.nthip_fastx_kmer_hash_file.argtypes = [vp, C.c_char_p, u32, C.c_uint16, C.c_uint8, u64, FASTX_FN, vp,
                                              C.POINTER(FastxStats)]
     L.nthip_synth_reads.argtypes = [vp, vp, u64, u64, u32, u64]
@@ -305,6 +306,17 @@ class Context:
         _chk(self.L.nthip_fastx_index(self.h, C.c_void_p(d_buf), n_bytes, fmt, C.c_void_p(d_starts),
                                       C.c_void_p(d_ends), capacity, C.byref(n), C.byref(cons), C.byref(bad)))
         return n.value, cons.value, bad.value
+
+    def fasta_compact_ptr(self, d_raw, n_bytes, d_seqs, d_offsets, capacity):
+        """-> (records, sequence bytes)"""
+        n, sb = C.c_uint64(0), C.c_uint64(0)
+        rc = self.L.nthip_fasta_compact(self.h, C.c_void_p(d_raw), n_bytes, C.c_void_p(d_seqs), C.c_void_p(d_offsets),
+                                        capacity, C.byref(n), C.byref(sb))
+        if rc != NTHIP_OK:
+            err = NtHipError(rc, self.L.nthip_last_error().decode(errors="replace"))
+            err.n_records = n.value
+            raise err
+        return n.value, sb.value
 
     def kmer_hash_spans_ptr(self, d_buf, buf_bytes, d_starts, d_ends, n_reads, k, m, hashes, capacity,
                             counts=0, pos=0, flags=0):

@@ -126,3 +126,217 @@ __global__ __launch_bounds__(FX_THREADS) void fastx_index_kernel(const uint8_t* 
 }
 
 } // namespace ntamd
+
+// ==========================================================================
+// multi-line FASTA: strip header lines and line ends, sequences back to back
+// ==========================================================================
+// Two kinds of events decide whether a byte belongs to a header line: a '>' at a line
+// start (byte 0, or right after '\n') opens one, the next '\n' closes it.  Both are
+// visible locally (one byte of look-behind), so "is byte i inside a header" is the kind
+// of the LAST event at or before i: a scan with the operator "right operand unless it
+// is empty".  Pass 1 gives every 16 KiB block its last event, one small kernel carries
+// that across blocks, pass 2 counts kept bytes / headers per block (sum scans give the
+// output position of every block), pass 3 writes the bytes and the record offsets.
+namespace ntamd {
+
+enum : uint32_t { FA_EV_NONE = 0, FA_EV_HEADER = 1, FA_EV_NEWLINE = 2 };
+
+struct FaChunk {
+  uint64_t nl, hs, keep_if_seq; // newline bits, header-start bits, bytes kept when no header is open
+  uint32_t valid;               // bytes of this chunk inside the buffer
+};
+
+// masks of one thread's 64 bytes (nl from thread_newlines)
+__device__ __forceinline__ FaChunk fasta_chunk(const uint8_t* __restrict__ buf, uint64_t n_bytes, uint64_t base)
+{
+  FaChunk ch;
+  ch.nl = ch.hs = ch.keep_if_seq = 0;
+  ch.valid = 0;
+  if (base >= n_bytes) return ch;
+  ch.valid = n_bytes - base < 64u ? (uint32_t)(n_bytes - base) : 64u;
+  ch.nl = thread_newlines(buf, n_bytes, base);
+  uint64_t gt = 0, cr = 0;
+  for (uint32_t b = 0; b < ch.valid; ++b) {
+    const uint8_t c = buf[base + b];
+    if (c == '>') gt |= 1ull << b;
+    if (c == '\r') cr |= 1ull << b;
+  }
+  const uint64_t prev_nl = base == 0 ? 1ull : (buf[base - 1] == '\n' ? 1ull : 0ull);
+  const uint64_t line_start = (ch.nl << 1) | prev_nl;
+  ch.hs = gt & line_start;
+  const uint64_t in_range = ch.valid == 64u ? ~0ull : ((1ull << ch.valid) - 1ull);
+  ch.keep_if_seq = in_range & ~ch.nl & ~cr;
+  return ch;
+}
+
+// bit i set <=> byte i of the chunk lies in a header line (carry: a header is open at the chunk's start)
+__device__ __forceinline__ uint64_t fasta_header_mask(const FaChunk& ch, bool carry)
+{
+  // walk the events in order; few per 64 bytes
+  uint64_t mask = 0;
+  uint64_t ev = ch.nl | ch.hs;
+  bool open = carry;
+  uint32_t from = 0;
+  while (ev) {
+    const uint32_t b = (uint32_t)__builtin_ctzll(ev);
+    ev &= ev - 1;
+    if (open && b > from) mask |= ((b >= 64u ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << from) - 1ull));
+    if ((ch.hs >> b) & 1ull) { open = true; from = b; }
+    else { if (open) mask |= 1ull << b; open = false; from = b + 1u; } // the closing '\n' is dropped anyway
+  }
+  if (open && from < 64u) mask |= ~((1ull << from) - 1ull);
+  return mask;
+}
+
+__device__ __forceinline__ uint32_t fasta_last_event(const FaChunk& ch)
+{
+  const uint64_t ev = ch.nl | ch.hs;
+  if (!ev) return FA_EV_NONE;
+  const uint32_t b = 63u - (uint32_t)__builtin_clzll(ev);
+  return ((ch.hs >> b) & 1ull) ? FA_EV_HEADER : FA_EV_NEWLINE;
+}
+
+// "right unless empty" inclusive scan over the 256 threads of a block; returns the EXCLUSIVE value
+__device__ __forceinline__ uint32_t fasta_block_carry(uint32_t mine, uint32_t* ws /*[4]*/, uint32_t& block_last)
+{
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if ((int)lane >= d && incl == FA_EV_NONE) incl = o;
+  }
+  uint32_t excl = __shfl_up(incl, 1, 64);
+  if (lane == 0) excl = FA_EV_NONE;
+  if (lane == 63) ws[wave] = incl;
+  __syncthreads();
+  uint32_t before = FA_EV_NONE; // last event of the waves before this one
+  for (uint32_t w = 0; w < wave; ++w)
+    if (ws[w] != FA_EV_NONE) before = ws[w];
+  if (excl == FA_EV_NONE) excl = before;
+  block_last = FA_EV_NONE;
+  for (uint32_t w = 0; w < FX_THREADS / 64; ++w)
+    if (ws[w] != FA_EV_NONE) block_last = ws[w];
+  return excl;
+}
+
+// pass 1: last event of every block
+__global__ __launch_bounds__(FX_THREADS) void fasta_events_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
+                                                                 uint32_t* __restrict__ block_last)
+{
+  __shared__ uint32_t ws[FX_THREADS / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * FX_BLOCK_BYTES + (uint64_t)threadIdx.x * FX_BYTES_PER_THREAD;
+  const FaChunk ch = fasta_chunk(buf, n_bytes, base);
+  uint32_t bl;
+  (void)fasta_block_carry(fasta_last_event(ch), ws, bl);
+  if (threadIdx.x == 0) block_last[blockIdx.x] = bl;
+}
+
+// carry across blocks: block_carry[b] = last event of blocks [0, b) (one block, sequential over tiles of 1024)
+__global__ __launch_bounds__(1024) void fasta_carry_kernel(const uint32_t* __restrict__ block_last, uint64_t nb,
+                                                          uint32_t* __restrict__ block_carry)
+{
+  __shared__ uint32_t ws[16];
+  __shared__ uint32_t running;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) running = FA_EV_NONE;
+  __syncthreads();
+  for (uint64_t b0 = 0; b0 < nb; b0 += 1024) {
+    const uint64_t b = b0 + tid;
+    const uint32_t mine = b < nb ? block_last[b] : FA_EV_NONE;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if ((int)lane >= d && incl == FA_EV_NONE) incl = o;
+    }
+    uint32_t excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = FA_EV_NONE;
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    uint32_t before = running;
+    for (uint32_t w = 0; w < wave; ++w)
+      if (ws[w] != FA_EV_NONE) before = ws[w];
+    if (excl == FA_EV_NONE) excl = before;
+    if (b < nb) block_carry[b] = excl;
+    __syncthreads();
+    if (tid == 1023) running = incl != FA_EV_NONE ? incl : before;
+    __syncthreads();
+  }
+}
+
+// pass 2: kept bytes and header starts per block
+__global__ __launch_bounds__(FX_THREADS) void fasta_count_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
+                                                                const uint32_t* __restrict__ block_carry,
+                                                                uint64_t* __restrict__ block_kept,
+                                                                uint64_t* __restrict__ block_hdrs)
+{
+  __shared__ uint32_t ws[FX_THREADS / 64];
+  __shared__ uint32_t sk[FX_THREADS / 64], sh[FX_THREADS / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * FX_BLOCK_BYTES + (uint64_t)threadIdx.x * FX_BYTES_PER_THREAD;
+  const FaChunk ch = fasta_chunk(buf, n_bytes, base);
+  uint32_t bl;
+  uint32_t carry = fasta_block_carry(fasta_last_event(ch), ws, bl);
+  if (carry == FA_EV_NONE) carry = block_carry[blockIdx.x];
+  const uint64_t hdr = fasta_header_mask(ch, carry == FA_EV_HEADER);
+  uint32_t kept = (uint32_t)__builtin_popcountll(ch.keep_if_seq & ~hdr);
+  uint32_t hs = (uint32_t)__builtin_popcountll(ch.hs);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    kept += __shfl_xor(kept, d, 64);
+    hs += __shfl_xor(hs, d, 64);
+  }
+  if ((threadIdx.x & 63u) == 0) { sk[threadIdx.x >> 6] = kept; sh[threadIdx.x >> 6] = hs; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    block_kept[blockIdx.x] = (uint64_t)sk[0] + sk[1] + sk[2] + sk[3];
+    block_hdrs[blockIdx.x] = (uint64_t)sh[0] + sh[1] + sh[2] + sh[3];
+  }
+}
+
+// pass 3: write the kept bytes at their output positions and the offset of every record
+__global__ __launch_bounds__(FX_THREADS) void fasta_scatter_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
+                                                                  const uint32_t* __restrict__ block_carry,
+                                                                  const uint64_t* __restrict__ kept_base,
+                                                                  const uint64_t* __restrict__ hdr_base,
+                                                                  uint8_t* __restrict__ seqs,
+                                                                  uint64_t* __restrict__ offsets, uint64_t capacity)
+{
+  __shared__ uint32_t ws[FX_THREADS / 64];
+  __shared__ uint32_t sk[FX_THREADS / 64], sh[FX_THREADS / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint64_t base = (uint64_t)blockIdx.x * FX_BLOCK_BYTES + (uint64_t)tid * FX_BYTES_PER_THREAD;
+  const FaChunk ch = fasta_chunk(buf, n_bytes, base);
+  uint32_t bl;
+  uint32_t carry = fasta_block_carry(fasta_last_event(ch), ws, bl);
+  if (carry == FA_EV_NONE) carry = block_carry[blockIdx.x];
+  const uint64_t hdr = fasta_header_mask(ch, carry == FA_EV_HEADER);
+  uint64_t keep = ch.keep_if_seq & ~hdr;
+  const uint32_t kept = (uint32_t)__builtin_popcountll(keep);
+  const uint32_t hs = (uint32_t)__builtin_popcountll(ch.hs);
+  uint32_t ik = kept, ih = hs;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t ok = __shfl_up(ik, d, 64), oh = __shfl_up(ih, d, 64);
+    if ((int)lane >= d) { ik += ok; ih += oh; }
+  }
+  if (lane == 63) { sk[wave] = ik; sh[wave] = ih; }
+  __syncthreads();
+  uint64_t out = kept_base[blockIdx.x] + (ik - kept);
+  uint64_t rec = hdr_base[blockIdx.x] + (ih - hs);
+  for (uint32_t w = 0; w < wave; ++w) { out += sk[w]; rec += sh[w]; }
+  // walk the chunk: kept bytes go out in order, a header start records the current output position
+  uint64_t ev = keep | ch.hs;
+  while (ev) {
+    const uint32_t b = (uint32_t)__builtin_ctzll(ev);
+    ev &= ev - 1;
+    if ((ch.hs >> b) & 1ull) {
+      if (rec < capacity) offsets[rec] = out;
+      ++rec;
+    } else {
+      seqs[out++] = buf[base + b];
+    }
+  }
+}
+
+} // namespace ntamd

@@ -95,6 +95,59 @@ extern "C" int nthip_fastx_index(nthip_ctx* c, const char* d_buf, uint64_t n_byt
   return NTHIP_OK;
 }
 
+extern "C" int nthip_fasta_compact(nthip_ctx* c, const char* d_raw, uint64_t n_bytes, char* d_seqs,
+                                   uint64_t* d_offsets, uint64_t capacity, uint64_t* n_records, uint64_t* seq_bytes)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  if (n_bytes && (!d_raw || !d_seqs || !d_offsets)) return fail(NTHIP_ERR_ARG, "buffers are NULL");
+  HIPCHK(hipSetDevice(c->device));
+  if (n_records) *n_records = 0;
+  if (seq_bytes) *seq_bytes = 0;
+  if (n_bytes == 0) return NTHIP_OK;
+  char first = 0;
+  HIPCHK(hipMemcpyAsync(&first, d_raw, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (first != '>') return fail(NTHIP_ERR_ARG, "FASTA text does not begin with '>'");
+  const uint64_t nb = (n_bytes + FX_BLOCK_BYTES - 1) / FX_BLOCK_BYTES;
+  const uint64_t nbs = (nb + SCAN_TILE - 1) / SCAN_TILE;
+  NTCHK(ensure_scratch(c, 5 * nb + nbs + 32));
+  uint64_t* d_kept = c->d_scratch;
+  uint64_t* d_hdrs = c->d_scratch + nb;
+  uint64_t* d_kept_base = c->d_scratch + 2 * nb;
+  uint64_t* d_hdr_base = c->d_scratch + 3 * nb;
+  uint32_t* d_last = (uint32_t*)(c->d_scratch + 4 * nb);
+  uint32_t* d_carry = d_last + nb;
+  uint64_t* d_sums = c->d_scratch + 5 * nb + 8;
+  uint64_t* d_total = (uint64_t*)(c->d_small + 8);
+  const uint8_t* raw = (const uint8_t*)d_raw;
+  hipLaunchKernelGGL(fasta_events_kernel, dim3((unsigned)nb), dim3(FX_THREADS), 0, c->stream, raw, n_bytes, d_last);
+  hipLaunchKernelGGL(fasta_carry_kernel, dim3(1), dim3(1024), 0, c->stream, d_last, nb, d_carry);
+  hipLaunchKernelGGL(fasta_count_kernel, dim3((unsigned)nb), dim3(FX_THREADS), 0, c->stream, raw, n_bytes, d_carry,
+                     d_kept, d_hdrs);
+  HIPCHK(hipGetLastError());
+  NTCHK(device_exclusive_scan(c, d_kept, d_kept_base, nb, d_sums, d_total));
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  NTCHK(device_exclusive_scan(c, d_hdrs, d_hdr_base, nb, d_sums, d_total));
+  HIPCHK(hipMemcpyAsync(c->h_small + 40, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t kept = 0, nrec = 0;
+  memcpy(&kept, c->h_small + 8, 8);
+  memcpy(&nrec, c->h_small + 40, 8);
+  if (n_records) *n_records = nrec;
+  if (seq_bytes) *seq_bytes = kept;
+  if (nrec > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "offset capacity %llu records < %llu in the text", (unsigned long long)capacity,
+                (unsigned long long)nrec);
+  prof_begin(c, "fasta_scatter_kernel");
+  hipLaunchKernelGGL(fasta_scatter_kernel, dim3((unsigned)nb), dim3(FX_THREADS), 0, c->stream, raw, n_bytes, d_carry,
+                     d_kept_base, d_hdr_base, (uint8_t*)d_seqs, d_offsets, capacity);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(d_offsets + nrec, &kept, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
 namespace {
 
 constexpr uint64_t FXS_HEAD = 16ull << 20; // room in front of a chunk for the carried-over tail of the previous one
@@ -155,6 +208,118 @@ struct FxReader {
   }
 };
 
+// multi-line FASTA (genomes): whole file -> HBM -> compact -> one hash call -> one callback
+int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, nthip_fastx_fn fn, void* user,
+                         nthip_fastx_stats* stats)
+{
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
+  if (k < 3 || k > 64 || m == 0 || m > KF_MAX_RUNTIME_M)
+    return fail(NTHIP_ERR_UNSUPPORTED, "the file driver takes 3 <= k <= 64 and 1 <= m <= %d", KF_MAX_RUNTIME_M);
+  HIPCHK(hipSetDevice(c->device));
+  const auto t_begin = std::chrono::steady_clock::now();
+  if (stats) memset(stats, 0, sizeof *stats);
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return fail(NTHIP_ERR_ARG, "cannot open %s", path);
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); return fail(NTHIP_ERR_ARG, "cannot stat %s", path); }
+  const uint64_t size = (uint64_t)sb.st_size;
+  if (stats) stats->file_bytes = size;
+  if (size == 0) { close(fd); return NTHIP_OK; }
+  const uint64_t piece = 64ull << 20;
+  uint8_t* pinned[2] = {nullptr, nullptr};
+  uint8_t *d_raw = nullptr, *d_seqs = nullptr;
+  uint64_t *d_offsets = nullptr, *d_hashes = nullptr, *d_counts = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int rc = NTHIP_OK;
+  double read_s = 0, gpu_s = 0;
+  auto cleanup = [&]() {
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 2; ++i) {
+      if (pinned[i]) (void)hipHostFree(pinned[i]);
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    for (void* p : {(void*)d_raw, (void*)d_seqs, (void*)d_offsets, (void*)d_hashes, (void*)d_counts})
+      if (p) (void)hipFree(p);
+    close(fd);
+  };
+#define FA_TRY(expr) \
+  do { \
+    hipError_t e_ = (expr); \
+    if (e_ != hipSuccess) { rc = fail(NTHIP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } \
+  } while (0)
+  FA_TRY(hipMalloc((void**)&d_raw, size + 64));
+  for (int i = 0; i < 2; ++i) {
+    FA_TRY(hipHostMalloc((void**)&pinned[i], piece, hipHostMallocDefault));
+    FA_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+  }
+  uint64_t n_bytes = size;
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    uint8_t last_byte = 0;
+    uint64_t i = 0;
+    for (uint64_t off = 0; off < size; off += piece, ++i) {
+      const uint64_t len = off + piece <= size ? piece : size - off;
+      if (i >= 2) FA_TRY(hipEventSynchronize(ev[i & 1])); // the upload that used this pinned buffer
+      uint64_t done = 0;
+      while (done < len) {
+        const ssize_t r = pread(fd, pinned[i & 1] + done, len - done, (off_t)(off + done));
+        if (r <= 0) { rc = fail(NTHIP_ERR_ARG, "read error on %s", path); cleanup(); return rc; }
+        done += (uint64_t)r;
+      }
+      last_byte = pinned[i & 1][len - 1];
+      FA_TRY(hipMemcpyAsync(d_raw + off, pinned[i & 1], len, hipMemcpyHostToDevice, c->stream));
+      FA_TRY(hipEventRecord(ev[i & 1], c->stream));
+    }
+    if (last_byte != '\n') { // close the last line
+      const char nl = '\n';
+      FA_TRY(hipMemcpyAsync(d_raw + size, &nl, 1, hipMemcpyHostToDevice, c->stream));
+      n_bytes = size + 1;
+    }
+    FA_TRY(hipStreamSynchronize(c->stream));
+    read_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  // records: at most one per 2 bytes (">\n"); count them first with a zero-capacity probe
+  uint64_t n_rec = 0, seq_bytes = 0;
+  FA_TRY(hipMalloc((void**)&d_seqs, n_bytes + 64));
+  FA_TRY(hipMalloc((void**)&d_offsets, 16));
+  rc = nthip_fasta_compact(c, (const char*)d_raw, n_bytes, (char*)d_seqs, d_offsets, 0, &n_rec, &seq_bytes);
+  if (rc != NTHIP_OK && rc != NTHIP_ERR_CAPACITY) { cleanup(); return rc; }
+  (void)hipFree(d_offsets);
+  d_offsets = nullptr;
+  FA_TRY(hipMalloc((void**)&d_offsets, (n_rec + 1) * sizeof(uint64_t)));
+  rc = nthip_fasta_compact(c, (const char*)d_raw, n_bytes, (char*)d_seqs, d_offsets, n_rec, &n_rec, &seq_bytes);
+  if (rc != NTHIP_OK) { cleanup(); return rc; }
+  (void)hipFree(d_raw);
+  d_raw = nullptr;
+  uint64_t n_kmers = 0;
+  if (n_rec) {
+    const uint64_t cap = seq_bytes ? seq_bytes : 1;
+    FA_TRY(hipMalloc((void**)&d_hashes, cap * (uint64_t)m * sizeof(uint64_t)));
+    FA_TRY(hipMalloc((void**)&d_counts, n_rec * sizeof(uint64_t)));
+    nthip_reads rdx = {(const char*)d_seqs, d_offsets, n_rec, 0, 0};
+    nthip_out out = {d_hashes, cap, d_counts, nullptr, nullptr, nullptr};
+    rc = nthip_kmer_hash(c, &rdx, k, m, &out, &n_kmers, 0);
+    if (rc != NTHIP_OK) { cleanup(); return rc; }
+    if (fn) {
+      nthip_fastx_batch b = {n_rec, n_kmers, d_hashes, d_counts, (const char*)d_seqs, d_offsets, d_offsets + 1, 0};
+      if (fn(user, &b) != 0) { rc = fail(NTHIP_ERR_ARG, "stopped by the callback"); cleanup(); return rc; }
+    }
+  }
+#undef FA_TRY
+  gpu_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+  cleanup();
+  if (stats) {
+    stats->reads = n_rec;
+    stats->kmers = n_kmers;
+    stats->batches = n_rec ? 1 : 0;
+    stats->read_seconds = read_s;
+    stats->gpu_seconds = gpu_s;
+    stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return NTHIP_OK;
+}
+
 } // namespace
 
 extern "C" int nthip_fastx_kmer_hash_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t k, uint8_t m,
@@ -162,6 +327,7 @@ extern "C" int nthip_fastx_kmer_hash_file(nthip_ctx* c, const char* path, uint32
                                           nthip_fastx_stats* stats)
 {
   if (!c || !path) return fail(NTHIP_ERR_ARG, "ctx/path is NULL");
+  if (format == NTHIP_FASTA_MULTILINE) return fasta_multiline_file(c, path, k, m, fn, user, stats);
   if (format != NTHIP_FASTQ && format != NTHIP_FASTA) return fail(NTHIP_ERR_ARG, "format must be NTHIP_FASTQ or NTHIP_FASTA");
   if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
   if (k < 3 || k > 64 || m == 0 || m > KF_MAX_RUNTIME_M)

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
   if (wt < t_end) { j0_cur = a.tile_j0[wt]; rem0_cur = (uint32_t)a.tile_rem0[wt]; }
   if (wt + wstride < t_end) { j0_nxt = a.tile_j0[wt + wstride]; rem0_nxt = (uint32_t)a.tile_rem0[wt + wstride]; }
   NzMeta meta_cur = load_meta(j0_cur);
+  uint64_t acc_read = ~0ull, acc_cnt = 0; // count pass: running per-read count of this wave
   for (; wt < t_end; wt += wstride) {
     const uint64_t g0 = wt * 64u;
     const uint64_t runs_left = a.total_runs - g0;
@@ -275,7 +276,25 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
 
     if (MODE == NA_MODE_COUNT) {
       if (lane == 0) a.tile_counts[wt] = total;
-      if (a.counts && cnt) atomicAdd((unsigned long long*)&a.counts[rt_read[j]], (unsigned long long)cnt);
+      if (a.counts) {
+        // Per-read counts.  A long read owns thousands of consecutive tiles: adding every lane's count to
+        // its one address serialises the whole pass (1 s for a 3 Gbp genome).  A wave keeps the count of
+        // the read it is in and adds it once, when the read changes; tiles that mix reads (short reads,
+        // distinct addresses) add per lane.
+        const uint64_t my_read = rt_read[j];
+        const uint64_t r0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(my_read >> 32)) << 32) |
+                            __builtin_amdgcn_readfirstlane((uint32_t)my_read);
+        if (__ballot(live && my_read != r0) == 0) {
+          if (r0 != acc_read) {
+            if (acc_cnt && lane == 0) atomicAdd((unsigned long long*)&a.counts[acc_read], (unsigned long long)acc_cnt);
+            acc_read = r0;
+            acc_cnt = 0;
+          }
+          acc_cnt += total;
+        } else if (cnt) {
+          atomicAdd((unsigned long long*)&a.counts[my_read], (unsigned long long)cnt);
+        }
+      }
       continue;
     }
 
@@ -379,6 +398,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
     if (want_pos)
       for (uint32_t e = lane; e < total; e += 64u) a.pos[o0 + e] = ptile[e];
   }
+  if (MODE == NA_MODE_COUNT && a.counts && acc_cnt && lane == 0)
+    atomicAdd((unsigned long long*)&a.counts[acc_read], (unsigned long long)acc_cnt);
 }
 
 } // namespace ntamd

@@ -756,7 +756,20 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_count_kernel(const K
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
     if (lane == 0) a.tile_counts[wt] = sum;
-    if (a.counts && cnt) atomicAdd((unsigned long long*)&a.counts[rf + lr], (unsigned long long)cnt);
+    if (a.counts) {
+      if (rpr > 64u) {
+        // long reads: a tile touches at most two of them -- one add each instead of one per lane
+        uint32_t s0 = lr == 0u ? cnt : 0u;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) s0 += __shfl_xor(s0, d, 64);
+        if (lane == 0) {
+          if (s0) atomicAdd((unsigned long long*)&a.counts[rf], (unsigned long long)s0);
+          if (sum - s0) atomicAdd((unsigned long long*)&a.counts[rf + 1u], (unsigned long long)(sum - s0));
+        }
+      } else if (cnt) {
+        atomicAdd((unsigned long long*)&a.counts[rf + lr], (unsigned long long)cnt);
+      }
+    }
   }
 }
 

@@ -903,3 +903,72 @@ def test_fastx_file_errors(ctx, tmp_path):
         ctx.fastx_kmer_hash_file(p, 4, 3, 1)
     p.write_bytes(b"")
     assert ctx.fastx_kmer_hash_file(p, 4, 31, 1).reads == 0
+
+
+def _make_multiline_fasta(rng, n_rec, crlf=False, max_len=5000, blank_lines=True):
+    alph = np.frombuffer(b"ACGTacgtNn", dtype=np.uint8)
+    nl = b"\r\n" if crlf else b"\n"
+    parts, seqs = [], []
+    for i in range(n_rec):
+        L = int(rng.integers(0, max_len)) if rng.random() < 0.9 else 0
+        sq = alph[np.where(rng.random(L) < 0.01, rng.integers(8, 10, L), rng.integers(0, 8, L))].tobytes()
+        seqs.append(sq)
+        width = int(rng.choice([1, 7, 60, 61, 63, 64, 65, 80, 127, 128, 129, 1000]))
+        parts.append(b">chr%d some > text with \t tabs" % i + nl)
+        for p in range(0, L, width):
+            parts.append(sq[p:p + width] + nl)
+            if blank_lines and rng.random() < 0.02:
+                parts.append(nl)
+    return b"".join(parts), seqs
+
+
+@pytest.mark.parametrize("n_rec,crlf,max_len", [(300, False, 5000), (200, True, 3000), (3, False, 400_000), (1, False, 70),
+                                                (2000, False, 40)])
+def test_fasta_multiline_compaction_vs_python(ctx, oracle, n_rec, crlf, max_len):
+    rng = np.random.default_rng(n_rec + max_len)
+    buf, seqs = _make_multiline_fasta(rng, n_rec, crlf, max_len)
+    raw = np.frombuffer(buf, dtype=np.uint8)
+    d_raw = ctx.malloc(raw.size + 64)
+    ctx.h2d(d_raw + 1, raw)                                   # odd base address
+    d_seqs, d_offs = ctx.malloc(raw.size + 64), ctx.malloc((n_rec + 1) * 8)
+    import nthash_amd
+    with pytest.raises(nthash_amd.NtHipError) as ei:           # too small an offsets array: count is reported
+        ctx.fasta_compact_ptr(d_raw + 1, raw.size, d_seqs, d_offs, n_rec - 1 if n_rec > 1 else 0)
+    assert ei.value.n_records == n_rec
+    got_n, got_bytes = ctx.fasta_compact_ptr(d_raw + 1, raw.size, d_seqs, d_offs, n_rec)
+    data, offs = concat_reads(seqs)
+    assert got_n == n_rec and got_bytes == data.size
+    g_offs = np.zeros(n_rec + 1, np.uint64)
+    ctx.d2h(g_offs, d_offs)
+    assert (g_offs == offs).all()
+    if data.size:
+        g_data = np.zeros(data.size, np.uint8)
+        ctx.d2h(g_data, d_seqs)
+        assert (g_data == data).all()
+    for d in (d_raw, d_seqs, d_offs):
+        ctx.free(d)
+
+
+def test_fasta_multiline_file_vs_oracle(ctx, oracle, tmp_path):
+    from nthash_amd.capi import NTHIP_FASTA_MULTILINE
+    rng = np.random.default_rng(77)
+    buf, seqs = _make_multiline_fasta(rng, 40, max_len=60_000)
+    path = tmp_path / "genome.fa"
+    path.write_bytes(buf[:-1])                                  # no newline at the end of the file
+    k, m = 31, 2
+    data, offs = concat_reads(seqs)
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    got = {}
+
+    def on_batch(b):
+        h, cnt = np.zeros(b.n_kmers * m, np.uint64), np.zeros(b.n_reads, np.uint64)
+        ctx.d2h(h, b.hashes); ctx.d2h(cnt, b.counts)
+        got["h"], got["c"] = h, cnt
+
+    st = ctx.fastx_kmer_hash_file(path, NTHIP_FASTA_MULTILINE, k, m, on_batch=on_batch)
+    assert st.reads == len(seqs) and st.kmers == want["total"] and st.batches == 1
+    assert (got["c"] == want["counts"]).all() and (got["h"] == want["hashes"].ravel()).all()
+    import nthash_amd
+    (tmp_path / "bad.fa").write_bytes(b"ACGT\n>x\nAC\n")
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.fastx_kmer_hash_file(tmp_path / "bad.fa", NTHIP_FASTA_MULTILINE, k, m)
