@@ -111,6 +111,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t k = a.k, m = a.m, C = a.C;
+  const uint32_t inv_m = 0xFFFFFFFFu / m + 1u; // v / m == umulhi(v, inv_m) for v < 2^29
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile bookkeeping on the scalar unit
 
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
         for (int h = 0; h < 2; ++h) {
           const uint32_t sv = 2u * pi + (uint32_t)h - vpar;
           ok[h] = sv < n_vals;
-          const uint32_t e = ok[h] ? sv / m : 0u, jj = ok[h] ? sv - e * m : 0u;
+          const uint32_t e = ok[h] ? __umulhi(sv, inv_m) : 0u, jj = ok[h] ? sv - e * m : 0u;
           const uint64_t h0 = tile[e];
           o[h] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
         }

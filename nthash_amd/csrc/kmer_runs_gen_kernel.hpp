@@ -224,6 +224,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
   const uint32_t wave = tid >> 6;
 #endif
   const RunShape shape = {C, rpr, a.inv_rpr, a.last_start, a.last_dup, a.stride, a.nwin, k};
+  const uint32_t inv_m = 0xFFFFFFFFu / m + 1u; // v / m == umulhi(v, inv_m) for v < 2^29
 
   // LDS: init tables | pair table | multipliers | per wave {tile, [pos tile], bits, [validity bits]}
   uint4* itab = (uint4*)lds_dyn;
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
         for (int h = 0; h < 2; ++h) {
           const uint32_t sv = 2u * pi + (uint32_t)h - vpar; // wraps for the skipped head half
           ok[h] = sv < n_vals;
-          const uint32_t e = ok[h] ? sv / m : 0u, jj = ok[h] ? sv - e * m : 0u;
+          const uint32_t e = ok[h] ? __umulhi(sv, inv_m) : 0u, jj = ok[h] ? sv - e * m : 0u;
           const uint64_t h0 = tile[e];
           o[h] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
         }

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
   __syncthreads(); // the only block-wide barrier
 
   const uint32_t vals_per_run = C * m;
+  const uint32_t inv_m = 0xFFFFFFFFu / m + 1u; // v / m == umulhi(v, inv_m) for v < 2^29 (runtime m)
   uint32_t bad = 0;
   // Tile bookkeeping without a 64-bit division per tile: (r_first, rem0) =
   // divmod(64*wt, rpr) is advanced by the constant divmod(64*wstride, rpr).
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const uint32_t vi = 2u * pi + (uint32_t)h;
-          const uint32_t e = vi / m, jj = vi - e * m;
+          const uint32_t e = M_T ? vi / m : __umulhi(vi, inv_m), jj = vi - e * m;
           const uint64_t h0 = tile[e < runs_here * C ? e : 0];
           o[h] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
         }

@@ -580,8 +580,9 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
   const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
   const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
-  // 8 waves per CU measured 1.5-2 % faster than 16 on the HBM-bound C2 shape (profiles/r01_notes.md)
-  uint32_t w_max = 8;
+  // 8 waves per CU measured 1.5-2 % faster than 16 on the HBM-bound C2 shape; with m > 1 the copy-out does the
+  // multi-hash expansion and more waves hide it: 16 waves +6 % (m=4), +9 % (m=8)  (profiles/r01_notes.md)
+  uint32_t w_max = m == 1 ? 8 : 16;
   if (const char* t = getenv("NTHIP_TUNE_WAVES")) {
     const uint32_t w = (uint32_t)atoi(t);
     if (w >= 1 && w <= 16) w_max = w;
@@ -660,7 +661,7 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
   const size_t fixed = (size_t)ntab * 4096 + 256 + 64;
   const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
-  uint32_t w_max = 8;
+  uint32_t w_max = m == 1 ? 8 : 16;
   if (const char* t = getenv("NTHIP_TUNE_WAVES")) {
     const uint32_t w = (uint32_t)atoi(t);
     if (w >= 1 && w <= 16) w_max = w;
@@ -1175,6 +1176,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
       : launch_kmer_runs(c, kmer_runs_kernel<KT, MT, CT, NWT, false>, ra, plan.lds))
       if (k == 31 && m == 1 && plan.C == 15) rc = NT_RUNS(31, 1, 15, 2);
       else if (k == 31 && m == 1 && plan.C == 30) rc = NT_RUNS(31, 1, 30, 2);
+      else if (m == 4 && !getenv("NTHIP_TUNE_NO_M4")) rc = NT_RUNS(31, 4, 15, 2); // BASELINE config 3
       else rc = NT_RUNS(31, 0, 15, 2);
 #undef NT_RUNS
     } else if (!rows_only && kmer_gen_plan(c, len, stride, k, m, &gplan)) {

@@ -36,6 +36,10 @@ for rnd in range(rounds):
         os.environ["NTHIP_TUNE_NO_SPECIAL"] = "1" if v.startswith("gen") else "0"
         if v.startswith("genC"):
             os.environ["NTHIP_TUNE_RUN_LEN"] = v[4:]
+        if v.endswith("nom4"):
+            os.environ["NTHIP_TUNE_NO_M4"] = "1"
+        else:
+            os.environ.pop("NTHIP_TUNE_NO_M4", None)
         flags = 8 if v == "rows" else 4 if v == "general" else 0
         ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin, flags=flags)
         ms, name = ctx.last_kernel_ms()
