@@ -115,24 +115,26 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile bookkeeping on the scalar unit
 
-  // LDS: tables | pair table | multipliers | per wave {hash tile, pos tile, bits, vbits, read table}
+  // LDS: tables | pair table | multipliers | per wave {hash tile, pos tile, bits, vbits, 2 read tables}
   uint4* itab = (uint4*)lds_dyn;
   uint4* ptab = itab + a.ntab * 256u;
   uint64_t* mults = (uint64_t*)(ptab + 16);
-  constexpr uint32_t RT_DWORDS = 64 * 8; // per listed read: run begin, vector begin, q_lo, windows, read lo/hi, spare
-  const uint32_t per_wave = a.tile_u64 * 2u + a.ptile_dwords + a.bits_dwords + a.vbits_dwords + RT_DWORDS;
+  // per listed read: run begin, vector begin, q_lo, windows, read index (u64), first staged byte (u64)
+  constexpr uint32_t RT_DWORDS = 64 * 8;
+  const uint32_t per_wave = a.tile_u64 * 2u + a.ptile_dwords + a.bits_dwords + a.vbits_dwords + 2u * RT_DWORDS;
   // the count pass keeps no tables, tile or code stream: a few KB per wave, so it runs at full occupancy
   uint32_t* wave_base = (MODE == NA_MODE_HASH ? (uint32_t*)(mults + KF_MAX_RUNTIME_M) : lds_dyn) + wave * per_wave;
   uint64_t* tile = (uint64_t*)wave_base;
   uint32_t* ptile = wave_base + a.tile_u64 * 2u;
   uint32_t* bits = ptile + a.ptile_dwords;
   uint16_t* vbits = (uint16_t*)(bits + a.bits_dwords);
-  uint32_t* rt_begin = bits + a.bits_dwords + a.vbits_dwords; // first run (tile-relative) of listed read j
-  uint32_t* rt_vbeg = rt_begin + 64;                          // first staged vector of read j
-  uint32_t* rt_qlo = rt_vbeg + 64;                            // first run of read j in this tile
-  uint32_t* rt_nwin = rt_qlo + 64;                            // windows of read j (saturated to 2^32-1)
-  uint64_t* rt_read = (uint64_t*)(rt_nwin + 64);              // read index
-  uint64_t* rt_addr = rt_read + 64;                           // byte offset of the first staged byte
+  uint32_t* rt_base = bits + a.bits_dwords + a.vbits_dwords; // two tables: this tile's and the next one's
+#define RT_BEGIN(sel) (rt_base + (sel) * RT_DWORDS)                     /* first run (tile-relative) of listed read j */
+#define RT_VBEG(sel) (rt_base + (sel) * RT_DWORDS + 64)                 /* first staged vector of read j */
+#define RT_QLO(sel) (rt_base + (sel) * RT_DWORDS + 128)                 /* first run of read j in this tile */
+#define RT_NWIN(sel) (rt_base + (sel) * RT_DWORDS + 192)                /* windows of read j (saturated) */
+#define RT_READ(sel) ((uint64_t*)(rt_base + (sel) * RT_DWORDS + 256))   /* read index */
+#define RT_ADDR(sel) ((uint64_t*)(rt_base + (sel) * RT_DWORDS + 384))   /* byte offset of the first staged byte */
 
   if (MODE == NA_MODE_HASH) {
     for (uint32_t i = tid; i < a.ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
@@ -168,107 +170,172 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
   const uint64_t per_block = (a.n_wtiles + gridDim.x - 1) / gridDim.x;
   const uint64_t t_begin = (uint64_t)blockIdx.x * per_block;
   const uint64_t t_end = t_begin + per_block < a.n_wtiles ? t_begin + per_block : a.n_wtiles;
-  // A tile's metadata sits behind two dependent loads (tile -> first listed read -> that read's
-  // record); both are fetched ahead -- the tile record two tiles ahead, the read records one tile
-  // ahead -- so only the staging loads of the bytes themselves are waited for.
-  auto load_meta = [&](uint64_t j0_) -> NzMeta {
-    NzMeta mm;
-    mm.read = mm.rc = mm.start = mm.len = 0;
-    const uint64_t jj = j0_ + lane;
-    if (jj < a.n_nz) mm = a.nz_meta[jj];
-    return mm;
-  };
   const uint64_t wstride = a.waves;
   uint64_t wt = t_begin + wave;
-  uint64_t j0_cur = 0, j0_nxt = 0;
-  uint32_t rem0_cur = 0, rem0_nxt = 0;
-  if (wt < t_end) { j0_cur = a.tile_j0[wt]; rem0_cur = (uint32_t)a.tile_rem0[wt]; }
-  if (wt + wstride < t_end) { j0_nxt = a.tile_j0[wt + wstride]; rem0_nxt = (uint32_t)a.tile_rem0[wt + wstride]; }
-  NzMeta meta_cur = load_meta(j0_cur);
-  uint64_t acc_read = ~0ull, acc_cnt = 0; // count pass: running per-read count of this wave
-  for (; wt < t_end; wt += wstride) {
-    const uint64_t g0 = wt * 64u;
-    const uint64_t runs_left = a.total_runs - g0;
-    const uint32_t runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
-    const uint64_t j0 = j0_cur;
-    const uint32_t rem0 = rem0_cur;
-    const NzMeta meta = meta_cur;
-    {
-      uint64_t j0_n2 = 0;
-      uint32_t rem0_n2 = 0;
-      if (wt + 2u * wstride < t_end) { j0_n2 = a.tile_j0[wt + 2u * wstride]; rem0_n2 = (uint32_t)a.tile_rem0[wt + 2u * wstride]; }
-      if (wt + wstride < t_end) meta_cur = load_meta(j0_nxt);
-      j0_cur = j0_nxt; rem0_cur = rem0_nxt;
-      j0_nxt = j0_n2; rem0_nxt = rem0_n2;
-    }
-    lds_sync();
-    // ---- the (at most 64) listed reads of this tile: one per lane ------------------
+  if (wt >= t_end) return;
+
+  // Software pipeline (the wave is alone with its latencies: 8 waves per CU).  A tile's bytes sit
+  // behind three dependent loads: tile -> first listed read (scalar loads, two tiles ahead), that
+  // read's 32-byte record (one tile ahead), the bytes themselves (issued for the NEXT tile before
+  // this one is hashed).  Record and byte loads are inline asm consumed after this tile's stores
+  // with a counted s_waitcnt, as in kmer_runs_kernel.hpp (vmcnt retires in order).
+  v4u meta_lo, meta_hi;        // NzMeta of the tile whose table is built next
+  v4u st0, st1, st2;           // staged vectors lane, lane+64, lane+128 of the current tile
+  uint32_t st_unsafe = 0;      // bit i: vector i was not loaded (16 bytes would cross the end of the buffer)
+  auto issue_meta = [&](uint64_t j0_) {
+    uint64_t jj = j0_ + lane;
+    if (jj >= a.n_nz) jj = a.n_nz - 1;
+    const NzMeta* p = a.nz_meta + jj;
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                 : "=&v"(meta_lo), "=&v"(meta_hi)
+                 : "v"(p)
+                 : "memory");
+  };
+  auto runs_of = [&](uint64_t t) -> uint32_t {
+    const uint64_t left = a.total_runs - t * 64u;
+    return left < 64u ? (uint32_t)left : 64u;
+  };
+  // read table of a tile from the records in meta_lo/meta_hi; returns the number of staged vectors
+  auto build_table = [&](uint32_t sel, uint64_t j0, uint32_t rem0, uint32_t runs_here) -> uint32_t {
     uint32_t take = 0, q_lo = 0, nv = 0, nwin32 = 0;
     uint64_t rd = 0, byte0 = 0;
-    {
-      const uint64_t jj = j0 + lane;
-      uint64_t avail = 0, rcj = 0, len = 0, start = 0;
-      if (jj < a.n_nz) {
-        rd = meta.read;
-        rcj = meta.rc;
-        start = meta.start;
-        len = meta.len;
-        q_lo = lane == 0 ? rem0 : 0u;
-        avail = rcj - q_lo;
-      }
-      const uint32_t av32 = avail > 64u ? 64u : (uint32_t)avail; // a tile never takes more than 64 runs
-      const uint32_t end = wave_incl_scan32(av32);
-      const uint32_t begin = end - av32;
-      take = begin < runs_here ? (runs_here - begin < av32 ? runs_here - begin : av32) : 0u;
-      const uint64_t nwin = len >= k ? len - k + 1 : 0;
-      nwin32 = nwin > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nwin;
-      if (take) {
-        const uint64_t first_b = (uint64_t)q_lo * C;
-        uint64_t last_b = (uint64_t)(q_lo + take) * C + k - 1; // one past the last needed byte
-        if (last_b > len) last_b = len;
-        nv = (uint32_t)((last_b - first_b + 15u) >> 4);
-        byte0 = start + first_b;
-      }
-      const uint32_t vend = wave_incl_scan32(nv);
-      rt_begin[lane] = take ? begin : 0xFFFFFFFFu; // reads past the tile never match a search
-      rt_vbeg[lane] = take ? vend - nv : 0xFFFFFFFFu;
-      rt_qlo[lane] = q_lo;
-      rt_nwin[lane] = nwin32;
-      rt_read[lane] = rd;
-      rt_addr[lane] = byte0;
+    uint64_t avail = 0, len = 0, start = 0;
+    if (j0 + lane < a.n_nz) {
+      rd = ((uint64_t)meta_lo.y << 32) | meta_lo.x;
+      const uint64_t rcj = ((uint64_t)meta_lo.w << 32) | meta_lo.z;
+      start = ((uint64_t)meta_hi.y << 32) | meta_hi.x;
+      len = ((uint64_t)meta_hi.w << 32) | meta_hi.z;
+      q_lo = lane == 0 ? rem0 : 0u;
+      avail = rcj - q_lo;
     }
-    const uint32_t v_total = __shfl(wave_incl_scan32(nv), 63, 64);
-    lds_sync();
-    // ---- stage the needed bytes of every listed read, packed back to back ------------
-    for (uint32_t v = lane; v < v_total; v += 64u) {
-      const uint32_t j = search64(rt_vbeg, v);
-      const uint64_t off = rt_addr[j] + ((uint64_t)(v - rt_vbeg[j]) << 4);
-      uint4 x;
-      if (off + 16u <= a.total_bytes) {
-        __builtin_memcpy(&x, a.seqs + off, 16); // unaligned 16-byte load (one global_load_dwordx4)
-      } else { // the very end of the caller's buffer: never read past it
-        uint32_t wv[4] = {0, 0, 0, 0};
-        for (uint32_t b = 0; b < 16u && off + b < a.total_bytes; ++b)
-          wv[b >> 2] |= (uint32_t)a.seqs[off + b] << ((b & 3u) * 8u);
-        x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    const uint32_t av32 = avail > 64u ? 64u : (uint32_t)avail; // a tile never takes more than 64 runs
+    const uint32_t end = wave_incl_scan32(av32);
+    const uint32_t begin = end - av32;
+    take = begin < runs_here ? (runs_here - begin < av32 ? runs_here - begin : av32) : 0u;
+    const uint64_t nwin = len >= k ? len - k + 1 : 0;
+    nwin32 = nwin > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nwin;
+    if (take) {
+      const uint64_t first_b = (uint64_t)q_lo * C;
+      uint64_t last_b = (uint64_t)(q_lo + take) * C + k - 1; // one past the last needed byte
+      if (last_b > len) last_b = len;
+      nv = (uint32_t)((last_b - first_b + 15u) >> 4);
+      byte0 = start + first_b;
+    }
+    const uint32_t vend = wave_incl_scan32(nv);
+    RT_BEGIN(sel)[lane] = take ? begin : 0xFFFFFFFFu; // reads past the tile never match a search
+    RT_VBEG(sel)[lane] = take ? vend - nv : 0xFFFFFFFFu;
+    RT_QLO(sel)[lane] = q_lo;
+    RT_NWIN(sel)[lane] = nwin32;
+    RT_READ(sel)[lane] = rd;
+    RT_ADDR(sel)[lane] = byte0;
+    return __shfl(vend, 63, 64);
+  };
+  // byte offset of staged vector v of the tile whose table is `sel`
+  auto vec_offset = [&](uint32_t sel, uint32_t v) -> uint64_t {
+    const uint32_t j = search64(RT_VBEG(sel), v);
+    return RT_ADDR(sel)[j] + ((uint64_t)(v - RT_VBEG(sel)[j]) << 4);
+  };
+  auto issue_stage = [&](uint32_t sel, uint32_t v_total) {
+    const uint8_t* p[3];
+    st_unsafe = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 3; ++i) {
+      const uint32_t v = lane + 64u * i;
+      uint64_t off = 0;
+      if (v < v_total) {
+        off = vec_offset(sel, v);
+        if (off + 16u > a.total_bytes) { // the very end of the buffer: load nothing there, redo bytewise
+          st_unsafe |= 1u << i;
+          off = 0;
+        }
       }
-      uint32_t i0, i1, i2, i3;
-      const uint32_t c0 = pack4v(x.x, i0), c1 = pack4v(x.y, i1), c2 = pack4v(x.z, i2), c3 = pack4v(x.w, i3);
-      if (MODE == NA_MODE_HASH) bits[v] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-      vbits[v] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+      p[i] = a.seqs + off;
+    }
+    // (a batch shorter than 16 bytes never gets here with a safe vector; offset 0 of such a batch is
+    // read as the aligned 16 bytes around seqs, which stay inside its page)
+    if (a.total_bytes < 16u) {
+#pragma unroll
+      for (uint32_t i = 0; i < 3; ++i) p[i] = (const uint8_t*)((uintptr_t)a.seqs & ~(uintptr_t)15);
+    }
+    asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off\n\t"
+                 "global_load_dwordx4 %2, %5, off"
+                 : "=&v"(st0), "=&v"(st1), "=&v"(st2)
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2])
+                 : "memory");
+  };
+  auto pack_one = [&](uint32_t v, uint4 x) {
+    uint32_t i0, i1, i2, i3;
+    const uint32_t c0 = pack4v(x.x, i0), c1 = pack4v(x.y, i1), c2 = pack4v(x.z, i2), c3 = pack4v(x.w, i3);
+    if (MODE == NA_MODE_HASH) bits[v] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+    vbits[v] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+  };
+  auto load_plain = [&](uint32_t sel, uint32_t v) -> uint4 {
+    const uint64_t off = vec_offset(sel, v);
+    uint4 x;
+    if (off + 16u <= a.total_bytes) {
+      __builtin_memcpy(&x, a.seqs + off, 16); // unaligned 16-byte load (one global_load_dwordx4)
+    } else { // never read past the caller's buffer
+      uint32_t wv[4] = {0, 0, 0, 0};
+      for (uint32_t b = 0; b < 16u && off + b < a.total_bytes; ++b)
+        wv[b >> 2] |= (uint32_t)a.seqs[off + b] << ((b & 3u) * 8u);
+      x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    }
+    return x;
+  };
+
+  // ---- prologue: tile records of the first two tiles, first table, first staging loads ----
+  uint64_t j0_cur = a.tile_j0[wt], j0_nxt = 0;
+  uint32_t rem0_cur = (uint32_t)a.tile_rem0[wt], rem0_nxt = 0;
+  if (wt + wstride < t_end) { j0_nxt = a.tile_j0[wt + wstride]; rem0_nxt = (uint32_t)a.tile_rem0[wt + wstride]; }
+  uint32_t cur = 0;
+  issue_meta(j0_cur);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(meta_lo), "+v"(meta_hi)::"memory");
+  uint32_t v_total = build_table(cur, j0_cur, rem0_cur, runs_of(wt));
+  lds_sync();
+  issue_stage(cur, v_total);
+  if (wt + wstride < t_end) issue_meta(j0_nxt);
+  uint32_t n_counted = 0;                  // stores surely issued after the loads in flight
+  uint64_t acc_read = ~0ull, acc_cnt = 0;  // count pass: running per-read count of this wave
+
+  for (; wt < t_end; wt += wstride) {
+    const uint32_t runs_here = runs_of(wt);
+    const bool have_next = wt + wstride < t_end;
+    // ---- the staged vectors of this tile (and the records of the next) have landed ------------
+    wait_vmcnt_upto15(n_counted < 15u ? n_counted : 15u);
+    asm volatile("" : "+v"(st0), "+v"(st1), "+v"(st2), "+v"(meta_lo), "+v"(meta_hi)::"memory");
+    {
+      const uint4 x0 = make_uint4(st0.x, st0.y, st0.z, st0.w), x1 = make_uint4(st1.x, st1.y, st1.z, st1.w),
+                  x2 = make_uint4(st2.x, st2.y, st2.z, st2.w);
+      if (lane < v_total) pack_one(lane, (st_unsafe & 1u) ? load_plain(cur, lane) : x0);
+      if (lane + 64u < v_total) pack_one(lane + 64u, (st_unsafe & 2u) ? load_plain(cur, lane + 64u) : x1);
+      if (lane + 128u < v_total) pack_one(lane + 128u, (st_unsafe & 4u) ? load_plain(cur, lane + 128u) : x2);
+      for (uint32_t v = lane + 192u; v < v_total; v += 64u) pack_one(v, load_plain(cur, v)); // long k only
     }
     if (MODE == NA_MODE_HASH && lane < (uint32_t)NW + 3u) bits[v_total + lane] = 0;
     if (lane < 10u) vbits[v_total + lane] = 0xFFFFu;
+    // ---- next tile: table, staging loads, and the records of the tile after it ------------------
+    uint32_t v_total_nxt = 0;
+    if (have_next) v_total_nxt = build_table(cur ^ 1u, j0_nxt, rem0_nxt, runs_of(wt + wstride));
     lds_sync();
+    uint64_t j0_n2 = 0;
+    uint32_t rem0_n2 = 0;
+    if (have_next) {
+      issue_stage(cur ^ 1u, v_total_nxt);
+      if (wt + 2u * wstride < t_end) {
+        j0_n2 = a.tile_j0[wt + 2u * wstride];
+        rem0_n2 = (uint32_t)a.tile_rem0[wt + 2u * wstride];
+        issue_meta(j0_n2);
+      }
+    }
 
     // ---- this lane's run -------------------------------------------------------------
     const bool live = lane < runs_here;
-    const uint32_t j = search64(rt_begin, live ? lane : 0u);
-    const uint32_t q = rt_qlo[j] + ((live ? lane : 0u) - rt_begin[j]);
-    const uint32_t nwin_j = rt_nwin[j];
+    const uint32_t j = search64(RT_BEGIN(cur), live ? lane : 0u);
+    const uint32_t q = RT_QLO(cur)[j] + ((live ? lane : 0u) - RT_BEGIN(cur)[j]);
+    const uint32_t nwin_j = RT_NWIN(cur)[j];
     const uint64_t w_first = (uint64_t)q * C;
     const uint32_t c_run = !live ? 0u : (nwin_j - w_first < C ? (uint32_t)(nwin_j - w_first) : C);
-    const uint32_t b0 = (rt_vbeg[j] << 4) + (q - rt_qlo[j]) * C;
+    const uint32_t b0 = (RT_VBEG(cur)[j] << 4) + (q - RT_QLO(cur)[j]) * C;
     const uint32_t valid = ~windows_with_non_base((const uint32_t*)vbits, b0, k) & ((1u << c_run) - 1u); // C <= 16
     const uint32_t cnt = __builtin_popcount(valid);
     const uint32_t incl = wave_incl_scan32(cnt);
@@ -282,7 +349,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
         // its one address serialises the whole pass (1 s for a 3 Gbp genome).  A wave keeps the count of
         // the read it is in and adds it once, when the read changes; tiles that mix reads (short reads,
         // distinct addresses) add per lane.
-        const uint64_t my_read = rt_read[j];
+        const uint64_t my_read = RT_READ(cur)[j];
         const uint64_t r0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(my_read >> 32)) << 32) |
                             __builtin_amdgcn_readfirstlane((uint32_t)my_read);
         if (__ballot(live && my_read != r0) == 0) {
@@ -296,111 +363,150 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
           atomicAdd((unsigned long long*)&a.counts[my_read], (unsigned long long)cnt);
         }
       }
-      continue;
-    }
-
-    // ---- hash the run, drop valid hashes at their compacted slots ------------------------
-    const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
-    uint32_t w[NW];
-    {
-      uint32_t lo = bits[d0];
-#pragma unroll
-      for (int i = 0; i < NW; ++i) {
-        const uint32_t hi = bits[d0 + i + 1];
-        w[i] = funnel(hi, lo, sh0);
-        lo = hi;
-      }
-    }
-    uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
-#pragma unroll
-    for (int jt = 0; jt < 4 * NW; ++jt) {
-      if ((uint32_t)jt < a.ntab) {
-        const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
-        const uint4 e = itab[(uint32_t)jt * 256u + byte];
-        f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
-      }
-    }
-    uint32_t slot = lane_off;
-    const bool want_pos = a.pos != nullptr;
-    const uint32_t p_first = (uint32_t)w_first;
-    const uint64_t o0 = a.tile_off[wt];
-    const uint32_t tpar = m == 1u ? (uint32_t)(o0 & (KRG_ALIGN_U64 - 1u)) : 0u;
-    auto emit = [&](uint32_t jw) {
-      if ((valid >> jw) & 1u) {
-        tile[tpar + slot] = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
-        if (want_pos) ptile[slot] = p_first + jw;
-        ++slot;
-      }
-    };
-    emit(0u);
-    const uint32_t bi = b0 + k;
-    const uint32_t di = bi >> 4, shi = (bi & 15u) << 1;
-    for (uint32_t jw = 0; jw * 16u + 1u < C; ++jw) {
-      const uint32_t w_in = funnel(bits[di + jw + 1], bits[di + jw], shi);
-      const uint32_t w_out = funnel(bits[d0 + jw + 1], bits[d0 + jw], sh0);
-      const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
-      const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
-      const uint32_t left = C - 1u - jw * 16u;
-      const uint32_t ns = left < 16u ? left : 16u;
-#pragma unroll 2
-      for (uint32_t i = 0; i < ns; ++i) {
-        const uint32_t src = (i & 1u) ? v : u;
-        const uint32_t toff = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
-        const uint4 term = *(const uint4*)((const char*)ptab + toff);
-        srol_pair(f_lo, f_hi);
-        f_lo ^= term.x;
-        f_hi ^= term.y;
-        r_lo ^= term.z;
-        r_hi ^= term.w;
-        sror_pair(r_lo, r_hi);
-        emit(jw * 16u + i + 1u);
-      }
-    }
-    lds_sync();
-    // copy-out as in kmer_runs_gen_kernel.hpp: the tile was built shifted by tpar = o0 mod 128, every store
-    // instruction covers one aligned KiB of the stream
-    if (m == 1) {
-      const uint32_t span = tpar + total;
-      const uint32_t pieces = (span + 1u) >> 1;
-      uint64_t* const base = a.hashes + (o0 - tpar);
-      for (uint32_t pi = lane; pi < pieces; pi += 64u) {
-        const uint4 dv = *(const uint4*)(tile + 2u * pi);
-        const bool lo_ok = 2u * pi >= tpar && 2u * pi < span;
-        const bool hi_ok = 2u * pi + 1u >= tpar && 2u * pi + 1u < span;
-        if (lo_ok && hi_ok) *(uint4*)(base + 2u * pi) = dv;
-        else if (lo_ok) *(uint2*)(base + 2u * pi) = make_uint2(dv.x, dv.y);
-        else if (hi_ok) *(uint2*)(base + 2u * pi + 1u) = make_uint2(dv.z, dv.w);
-      }
+      n_counted = 0;
     } else {
-      const uint64_t v0 = o0 * m;
-      const uint32_t vpar = (uint32_t)(v0 & 1u);
-      const uint32_t n_vals = total * m;
-      const uint32_t span = vpar + n_vals;
-      const uint32_t pieces = (span + 1u) >> 1;
-      uint64_t* const base = a.hashes + (v0 - vpar);
-      for (uint32_t pi = lane; pi < pieces; pi += 64u) {
-        uint64_t o[2];
-        bool ok[2];
+      // ---- hash the run, drop valid hashes at their compacted slots ------------------------
+      const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
+      uint32_t w[NW];
+      {
+        uint32_t lo = bits[d0];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const uint32_t sv = 2u * pi + (uint32_t)h - vpar;
-          ok[h] = sv < n_vals;
-          const uint32_t e = ok[h] ? __umulhi(sv, inv_m) : 0u, jj = ok[h] ? sv - e * m : 0u;
-          const uint64_t h0 = tile[e];
-          o[h] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
+        for (int i = 0; i < NW; ++i) {
+          const uint32_t hi = bits[d0 + i + 1];
+          w[i] = funnel(hi, lo, sh0);
+          lo = hi;
         }
-        if (ok[0] && ok[1])
-          *(uint4*)(base + 2u * pi) =
-              make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
-        else if (ok[0]) *(uint2*)(base + 2u * pi) = make_uint2((uint32_t)o[0], (uint32_t)(o[0] >> 32));
-        else if (ok[1]) *(uint2*)(base + 2u * pi + 1u) = make_uint2((uint32_t)o[1], (uint32_t)(o[1] >> 32));
       }
+      uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
+#pragma unroll
+      for (int jt = 0; jt < 4 * NW; ++jt) {
+        if ((uint32_t)jt < a.ntab) {
+          const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+          const uint4 e = itab[(uint32_t)jt * 256u + byte];
+          f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
+        }
+      }
+      uint32_t slot = lane_off;
+      const bool want_pos = a.pos != nullptr;
+      const uint32_t p_first = (uint32_t)w_first;
+      const uint64_t o0 = a.tile_off[wt];
+      const uint32_t tpar = m == 1u ? (uint32_t)(o0 & (KRG_ALIGN_U64 - 1u)) : 0u;
+      auto emit = [&](uint32_t jw) {
+        if ((valid >> jw) & 1u) {
+          tile[tpar + slot] = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+          if (want_pos) ptile[slot] = p_first + jw;
+          ++slot;
+        }
+      };
+      emit(0u);
+      const uint32_t bi = b0 + k;
+      const uint32_t di = bi >> 4, shi = (bi & 15u) << 1;
+      for (uint32_t jw = 0; jw * 16u + 1u < C; ++jw) {
+        const uint32_t w_in = funnel(bits[di + jw + 1], bits[di + jw], shi);
+        const uint32_t w_out = funnel(bits[d0 + jw + 1], bits[d0 + jw], sh0);
+        const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
+        const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
+        auto lookup = [&](uint32_t i) -> uint4 {
+          const uint32_t src = (i & 1u) ? v : u;
+          const uint32_t toff = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
+          return *(const uint4*)((const char*)ptab + toff);
+        };
+        auto roll = [&](const uint4 term) {
+          srol_pair(f_lo, f_hi);
+          f_lo ^= term.x;
+          f_hi ^= term.y;
+          r_lo ^= term.z;
+          r_hi ^= term.w;
+          sror_pair(r_lo, r_hi);
+        };
+        // table terms do not depend on the hash state: fetch a batch ahead of the dependent chain
+        auto batch = [&](uint32_t i0, auto n_tag) {
+          constexpr uint32_t N = decltype(n_tag)::value;
+          uint4 terms[N];
+#pragma unroll
+          for (uint32_t i = 0; i < N; ++i) terms[i] = lookup(i0 + i);
+#pragma unroll
+          for (uint32_t i = 0; i < N; ++i) {
+            roll(terms[i]);
+            emit(jw * 16u + i0 + i + 1u);
+          }
+        };
+        const uint32_t left = C - 1u - jw * 16u;
+        const uint32_t ns = left < 16u ? left : 16u;
+        uint32_t i0 = 0;
+        for (; i0 + 8u <= ns; i0 += 8u) batch(i0, std::integral_constant<uint32_t, 8u>{});
+        switch (ns - i0) {
+          case 1: batch(i0, std::integral_constant<uint32_t, 1u>{}); break;
+          case 2: batch(i0, std::integral_constant<uint32_t, 2u>{}); break;
+          case 3: batch(i0, std::integral_constant<uint32_t, 3u>{}); break;
+          case 4: batch(i0, std::integral_constant<uint32_t, 4u>{}); break;
+          case 5: batch(i0, std::integral_constant<uint32_t, 5u>{}); break;
+          case 6: batch(i0, std::integral_constant<uint32_t, 6u>{}); break;
+          case 7: batch(i0, std::integral_constant<uint32_t, 7u>{}); break;
+          default: break;
+        }
+      }
+      lds_sync();
+      // copy-out as in kmer_runs_gen_kernel.hpp: the tile was built shifted by tpar = o0 mod 128, every store
+      // instruction covers one aligned KiB of the stream
+      if (m == 1) {
+        const uint32_t span = tpar + total;
+        const uint32_t pieces = (span + 1u) >> 1;
+        uint64_t* const base = a.hashes + (o0 - tpar);
+        for (uint32_t pi = lane; pi < pieces; pi += 64u) {
+          const uint4 dv = *(const uint4*)(tile + 2u * pi);
+          const bool lo_ok = 2u * pi >= tpar && 2u * pi < span;
+          const bool hi_ok = 2u * pi + 1u >= tpar && 2u * pi + 1u < span;
+          if (lo_ok && hi_ok) *(uint4*)(base + 2u * pi) = dv;
+          else if (lo_ok) *(uint2*)(base + 2u * pi) = make_uint2(dv.x, dv.y);
+          else if (hi_ok) *(uint2*)(base + 2u * pi + 1u) = make_uint2(dv.z, dv.w);
+        }
+        const uint32_t it_lo = ((tpar >> 1) + 64u) >> 6, it_hi = pieces >> 6;
+        n_counted = it_hi > it_lo ? it_hi - it_lo : 0u;
+      } else {
+        const uint64_t v0 = o0 * m;
+        const uint32_t vpar = (uint32_t)(v0 & 1u);
+        const uint32_t n_vals = total * m;
+        const uint32_t span = vpar + n_vals;
+        const uint32_t pieces = (span + 1u) >> 1;
+        uint64_t* const base = a.hashes + (v0 - vpar);
+        for (uint32_t pi = lane; pi < pieces; pi += 64u) {
+          uint64_t o[2];
+          bool ok[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t sv = 2u * pi + (uint32_t)h - vpar;
+            ok[h] = sv < n_vals;
+            const uint32_t e = ok[h] ? __umulhi(sv, inv_m) : 0u, jj = ok[h] ? sv - e * m : 0u;
+            const uint64_t h0 = tile[e];
+            o[h] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
+          }
+          if (ok[0] && ok[1])
+            *(uint4*)(base + 2u * pi) =
+                make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
+          else if (ok[0]) *(uint2*)(base + 2u * pi) = make_uint2((uint32_t)o[0], (uint32_t)(o[0] >> 32));
+          else if (ok[1]) *(uint2*)(base + 2u * pi + 1u) = make_uint2((uint32_t)o[1], (uint32_t)(o[1] >> 32));
+        }
+        n_counted = pieces >> 6;
+      }
+      if (want_pos)
+        for (uint32_t e = lane; e < total; e += 64u) a.pos[o0 + e] = ptile[e];
+      lds_sync(); // tile, bits and this tile's table are free again
     }
-    if (want_pos)
-      for (uint32_t e = lane; e < total; e += 64u) a.pos[o0 + e] = ptile[e];
+    // ---- rotate the pipeline -----------------------------------------------------------------
+    cur ^= 1u;
+    v_total = v_total_nxt;
+    j0_cur = j0_nxt; rem0_cur = rem0_nxt;
+    j0_nxt = j0_n2; rem0_nxt = rem0_n2;
   }
   if (MODE == NA_MODE_COUNT && a.counts && acc_cnt && lane == 0)
     atomicAdd((unsigned long long*)&a.counts[acc_read], (unsigned long long)acc_cnt);
+#undef RT_BEGIN
+#undef RT_VBEG
+#undef RT_QLO
+#undef RT_NWIN
+#undef RT_READ
+#undef RT_ADDR
 }
 
 } // namespace ntamd

@@ -851,7 +851,7 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
   const uint32_t tile_u64 = 64 * C + KRG_ALIGN_U64;
   const uint32_t ptile_dwords = st.pos ? 64 * C : 0;
   const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
-  const size_t per_wave = (size_t)tile_u64 * 8 + ((size_t)ptile_dwords + bits_dwords + vbits_dwords + 512) * 4;
+  const size_t per_wave = (size_t)tile_u64 * 8 + ((size_t)ptile_dwords + bits_dwords + vbits_dwords + 2 * 512) * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
   uint32_t waves = 0;
   for (uint32_t w = 8; w >= 1; --w)
@@ -949,7 +949,7 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
     ca.ptile_dwords = 0;
     ca.bits_dwords = 0;
     ca.waves = 16;
-    const size_t clds = ((size_t)ca.vbits_dwords + 512) * 4 * ca.waves + 64;
+    const size_t clds = ((size_t)ca.vbits_dwords + 2 * 512) * 4 * ca.waves + 64;
     NTCHK(launch_kmer_ragged<1>(c, NA_MODE_COUNT, ca, clds));
   }
   NTCHK(device_exclusive_scan(c, d_tile_cnt, d_tile_off, nt, d_sums2, d_total));
