@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the fast paths against the lane-per-read general kernel (both on the GPU):
+fixed-length shapes (dense general run-split kernel / N-aware pass), overlapping runs, ragged reads.
+
+    python tools/stress_shapes.py [iterations] [seed]
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import nthash_amd
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = nthash_amd.Context(0)
+alph = np.frombuffer(b"ACGTacgtUu", dtype=np.uint8)
+bad_alph = np.frombuffer(b"NnRYKM-*.\x00", dtype=np.uint8)
+fails = 0
+for it in range(iters):
+    k = int(rng.integers(3, 65))
+    m = int(rng.integers(1, 9))
+    kind = rng.integers(0, 3)
+    if kind < 2:   # fixed length
+        L = int(k + rng.integers(0, 40)) if rng.random() < 0.3 else int(rng.integers(k, 4000))
+        n = max(1, int(rng.integers(1, 3_000_000 // L + 2)))
+        stride = 0
+        total = n * L
+        if kind == 1 and L > k:  # overlapping runs of one sequence
+            stride = L - k + 1
+            total = (n - 1) * stride + L
+        data = alph[rng.integers(0, len(alph), total)]
+        if rng.random() < 0.5:
+            nb = int(rng.integers(1, max(2, total // 2000)))
+            data[rng.integers(0, total, nb)] = bad_alph[rng.integers(0, len(bad_alph) - 1, nb)]
+        want_pos = bool(rng.random() < 0.3)
+        a = ctx.kmer_hash(data, k, m, fixed_len=L, stride=stride, n_reads=n, want_pos=want_pos)
+        b = ctx.kmer_hash(data, k, m, fixed_len=L, stride=stride, n_reads=n, want_pos=want_pos, flags=4)
+        desc = f"fixed n={n} L={L} k={k} m={m} stride={stride} pos={want_pos}"
+    else:
+        n = int(rng.integers(1, 4000))
+        lens = np.where(rng.random(n) < 0.1, rng.integers(0, k + 2, n), rng.integers(0, 600, n))
+        if rng.random() < 0.2:
+            lens[rng.integers(0, n)] = int(rng.integers(5000, 200000))
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        total = int(offs[-1])
+        data = alph[rng.integers(0, len(alph), max(total, 1))]
+        if total and rng.random() < 0.6:
+            nb = int(rng.integers(1, max(2, total // 1000)))
+            data[rng.integers(0, total, nb)] = bad_alph[rng.integers(0, len(bad_alph), nb)]
+        want_pos = bool(rng.random() < 0.5)
+        a = ctx.kmer_hash(data, k, m, offsets=offs, want_pos=want_pos)
+        b = ctx.kmer_hash(data, k, m, offsets=offs, want_pos=want_pos, flags=4)
+        desc = f"ragged n={n} bytes={total} k={k} m={m} pos={want_pos}"
+    ok = a["total"] == b["total"] and (a["hashes"] == b["hashes"]).all() and (a["counts"] == b["counts"]).all()
+    if want_pos:
+        ok = ok and (a["pos"] == b["pos"]).all()
+    if not ok:
+        fails += 1
+        print("MISMATCH", desc, a["total"], b["total"], flush=True)
+    elif it % 25 == 0:
+        print("ok", it, desc, "kmers", a["total"], flush=True)
+print("done:", iters, "cases,", fails, "mismatches")
+sys.exit(1 if fails else 0)
