@@ -186,6 +186,11 @@ int nthip_kmer_hash_spans(nthip_ctx* ctx, const char* d_buf, uint64_t buf_bytes,
                           const uint64_t* d_ends, uint64_t n_reads, uint16_t k, uint8_t m,
                           const nthip_out* out, uint64_t* total, uint32_t flags);
 
+/* nthip_seed_hash over spans: as nthip_seed_hash (the reference's position state machine, App. B Q3) */
+int nthip_seed_hash_spans(nthip_ctx* ctx, const char* d_buf, uint64_t buf_bytes, const uint64_t* d_starts,
+                          const uint64_t* d_ends, uint64_t n_reads, const nthip_seeds* seeds, uint8_t m2,
+                          const nthip_out* out, uint64_t* total, uint32_t flags);
+
 #define NTHIP_FASTQ 4u  /* 4-line records: @header / sequence / + / quality            */
 #define NTHIP_FASTA 2u  /* 2-line records: >header / sequence (one line per sequence)   */
 /*
@@ -242,6 +247,10 @@ typedef struct nthip_fastx_stats {
  */
 int nthip_fastx_kmer_hash_file(nthip_ctx* ctx, const char* path, uint32_t format, uint16_t k, uint8_t m,
                                uint64_t chunk_bytes, nthip_fastx_fn fn, void* user, nthip_fastx_stats* stats);
+/* the same stream through SeedNtHash: batch->hashes holds n_seeds*m2 values per k-mer (NTHIP_FASTQ / NTHIP_FASTA) */
+int nthip_fastx_seed_hash_file(nthip_ctx* ctx, const char* path, uint32_t format, const nthip_seeds* seeds,
+                               uint8_t m2, uint64_t chunk_bytes, nthip_fastx_fn fn, void* user,
+                               nthip_fastx_stats* stats);
 
 /* ---- measurement helpers (device-resident synthetic data, checksums) ---- */
 /* counter-based reads: read r, 32-base word w ->

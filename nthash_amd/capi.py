@@ -34,7 +34,7 @@ SYMBOLS = [
     "nthip_memcpy_h2d", "nthip_memcpy_d2h", "nthip_memset", "nthip_kmer_hash", "nthip_seeds_create",
     "nthip_seeds_destroy", "nthip_seed_hash", "nthip_kmer_extend", "nthip_kmer_bloom_insert",
     "nthip_kmer_bloom_query", "nthip_stream_bloom_insert", "nthip_kmer_hash_spans", "nthip_fastx_index",
-    "nthip_fastx_kmer_hash_file", "nthip_fasta_compact", "nthip_synth_reads", "nthip_checksum",
+    "nthip_fastx_kmer_hash_file", "nthip_fastx_seed_hash_file", "nthip_seed_hash_spans", "nthip_fasta_compact", "nthip_synth_reads", "nthip_checksum",
     "nthip_copy_bench",
 ]
 
@@ -112,6 +112,9 @@ def load():
                                         C.POINTER(u64), u32]
     L.nthip_fastx_index.argtypes = [vp, vp, u64, u32, vp, vp, u64, C.POINTER(u64), C.POINTER(u64),
                                     C.POINTER(C.c_int)]
+    L.nthip_seed_hash_spans.argtypes = [vp, vp, u64, vp, vp, u64, vp, C.c_uint8, C.POINTER(Out), C.POINTER(u64), u32]
+    L.nthip_fastx_seed_hash_file.argtypes = [vp, C.c_char_p, u32, vp, C.c_uint8, u64, FASTX_FN, vp,
+                                             C.POINTER(FastxStats)]
     L.nthip_fasta_compact.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
     L.nthip_fastx_kmer_hash_file.argtypes = [vp, C.c_char_p, u32, C.c_uint16, C.c_uint8, u64, FASTX_FN, vp,
                                              C.POINTER(FastxStats)]
@@ -330,8 +333,17 @@ class Context:
             raise err
         return total.value
 
-    def fastx_kmer_hash_file(self, path, fmt, k, m, chunk_bytes=0, on_batch=None):
-        """stream a file; on_batch(FastxBatch) is called per batch (device pointers).  -> FastxStats"""
+    def seed_hash_spans_ptr(self, d_buf, buf_bytes, d_starts, d_ends, n_reads, seeds, m2, hashes, capacity,
+                            counts=0, pos=0, flags=0):
+        out = Out(hashes, capacity, counts or None, pos or None, None, None)
+        total = C.c_uint64(0)
+        _chk(self.L.nthip_seed_hash_spans(self.h, C.c_void_p(d_buf), buf_bytes, C.c_void_p(d_starts),
+                                          C.c_void_p(d_ends), n_reads, seeds.h, m2, C.byref(out), C.byref(total), flags))
+        return total.value
+
+    def fastx_kmer_hash_file(self, path, fmt, k, m, chunk_bytes=0, on_batch=None, seeds=None):
+        """stream a file; on_batch(FastxBatch) is called per batch (device pointers).  -> FastxStats
+        seeds: a Seeds object -> SeedNtHash with m hashes per seed (k is the seeds' k)"""
         stats = FastxStats()
         err = []
 
@@ -344,8 +356,12 @@ class Context:
                 err.append(e)
                 return 1
         cb = FASTX_FN(tramp)
-        rc = self.L.nthip_fastx_kmer_hash_file(self.h, os.fsencode(path), fmt, k, m, chunk_bytes, cb, None,
-                                               C.byref(stats))
+        if seeds is not None:
+            rc = self.L.nthip_fastx_seed_hash_file(self.h, os.fsencode(path), fmt, seeds.h, m, chunk_bytes, cb, None,
+                                                   C.byref(stats))
+        else:
+            rc = self.L.nthip_fastx_kmer_hash_file(self.h, os.fsencode(path), fmt, k, m, chunk_bytes, cb, None,
+                                                   C.byref(stats))
         if err:
             raise err[0]
         _chk(rc)

@@ -48,6 +48,36 @@ extern "C" int nthip_kmer_hash_spans(nthip_ctx* c, const char* d_buf, uint64_t b
   return NTHIP_OK;
 }
 
+extern "C" int nthip_seed_hash_spans(nthip_ctx* c, const char* d_buf, uint64_t buf_bytes, const uint64_t* d_starts,
+                                     const uint64_t* d_ends, uint64_t n_reads, const nthip_seeds* sd, uint8_t m28,
+                                     const nthip_out* out, uint64_t* total_out, uint32_t flags)
+{
+  (void)buf_bytes;
+  if (!c || !sd) return fail(NTHIP_ERR_ARG, "ctx/seeds is NULL");
+  if (!out || !out->hashes) return fail(NTHIP_ERR_ARG, "out->hashes is NULL");
+  if (n_reads && (!d_buf || !d_starts || !d_ends)) return fail(NTHIP_ERR_ARG, "buffer / spans are NULL");
+  if (flags & NTHIP_HOST_INPUT) return fail(NTHIP_ERR_UNSUPPORTED, "spans are device pointers");
+  const uint32_t m2 = m28;
+  if (m2 == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes_per_seed must be >= 1");
+  HIPCHK(hipSetDevice(c->device));
+  if (total_out) *total_out = 0;
+  if (n_reads == 0) return NTHIP_OK;
+  const uint32_t per = sd->n_seeds * m2;
+  Staged st;
+  st.seqs = (const uint8_t*)d_buf;
+  st.offsets = d_starts;
+  NTCHK(stage_outputs(c, out, flags, n_reads, per, st, sd->n_seeds));
+  nthip_reads rd = {d_buf, d_starts, n_reads, 0, 0};
+  uint64_t total = 0;
+  int rc = run_seed_general(c, st, &rd, sd, m2, out->capacity, &total, d_ends);
+  if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
+  NTCHK(rc);
+  if (total_out) *total_out = total;
+  NTCHK(unstage_outputs(c, out, flags, n_reads, per, total, st, sd->n_seeds));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
 extern "C" int nthip_fastx_index(nthip_ctx* c, const char* d_buf, uint64_t n_bytes, uint32_t format,
                                  uint64_t* d_starts, uint64_t* d_ends, uint64_t capacity, uint64_t* n_records,
                                  uint64_t* consumed, int* malformed)
@@ -322,16 +352,39 @@ int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, 
 
 } // namespace
 
+namespace {
+// seeds == nullptr: NtHash(k, m); else SeedNtHash(seeds, m = hashes per seed)
+int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t k, uint8_t m, const nthip_seeds* seeds,
+                      uint64_t chunk_bytes, nthip_fastx_fn fn, void* user, nthip_fastx_stats* stats);
+} // namespace
+
 extern "C" int nthip_fastx_kmer_hash_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t k, uint8_t m,
                                           uint64_t chunk_bytes, nthip_fastx_fn fn, void* user,
                                           nthip_fastx_stats* stats)
 {
   if (!c || !path) return fail(NTHIP_ERR_ARG, "ctx/path is NULL");
   if (format == NTHIP_FASTA_MULTILINE) return fasta_multiline_file(c, path, k, m, fn, user, stats);
-  if (format != NTHIP_FASTQ && format != NTHIP_FASTA) return fail(NTHIP_ERR_ARG, "format must be NTHIP_FASTQ or NTHIP_FASTA");
   if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
   if (k < 3 || k > 64 || m == 0 || m > KF_MAX_RUNTIME_M)
     return fail(NTHIP_ERR_UNSUPPORTED, "the file driver takes 3 <= k <= 64 and 1 <= m <= %d", KF_MAX_RUNTIME_M);
+  return fastx_stream_file(c, path, format, k, m, nullptr, chunk_bytes, fn, user, stats);
+}
+
+extern "C" int nthip_fastx_seed_hash_file(nthip_ctx* c, const char* path, uint32_t format, const nthip_seeds* seeds,
+                                          uint8_t m2, uint64_t chunk_bytes, nthip_fastx_fn fn, void* user,
+                                          nthip_fastx_stats* stats)
+{
+  if (!c || !path || !seeds) return fail(NTHIP_ERR_ARG, "ctx/path/seeds is NULL");
+  if (m2 == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes_per_seed must be >= 1");
+  return fastx_stream_file(c, path, format, (uint16_t)seeds->k, m2, seeds, chunk_bytes, fn, user, stats);
+}
+
+namespace {
+int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t k, uint8_t m, const nthip_seeds* seeds,
+                      uint64_t chunk_bytes, nthip_fastx_fn fn, void* user, nthip_fastx_stats* stats)
+{
+  if (format != NTHIP_FASTQ && format != NTHIP_FASTA) return fail(NTHIP_ERR_ARG, "format must be NTHIP_FASTQ or NTHIP_FASTA");
+  const uint64_t per = seeds ? (uint64_t)seeds->n_seeds * m : (uint64_t)m;
   HIPCHK(hipSetDevice(c->device));
   const auto t_begin = std::chrono::steady_clock::now();
   if (stats) memset(stats, 0, sizeof *stats);
@@ -353,7 +406,7 @@ extern "C" int nthip_fastx_kmer_hash_file(nthip_ctx* c, const char* path, uint32
   // worst cases inside one piece (head room + chunk + a final newline): an 8-byte record, half of the bytes bases
   const uint64_t piece_max = FXS_HEAD + chunk_bytes + 16;
   const uint64_t cap_reads = piece_max / 8 + 1;
-  const uint64_t cap_kmers = piece_max / 2 + 1;
+  const uint64_t cap_kmers = format == NTHIP_FASTQ ? piece_max / 2 + 1 : piece_max; // FASTQ: as many quality bytes as bases
   uint8_t* d_raw[2] = {nullptr, nullptr};
   uint64_t *d_starts = nullptr, *d_ends = nullptr, *d_hashes = nullptr, *d_counts = nullptr;
   hipStream_t copy_stream = nullptr;
@@ -393,7 +446,7 @@ extern "C" int nthip_fastx_kmer_hash_file(nthip_ctx* c, const char* path, uint32
   FX_TRY(hipMalloc((void**)&d_starts, cap_reads * sizeof(uint64_t)));
   FX_TRY(hipMalloc((void**)&d_ends, cap_reads * sizeof(uint64_t)));
   FX_TRY(hipMalloc((void**)&d_counts, cap_reads * sizeof(uint64_t)));
-  FX_TRY(hipMalloc((void**)&d_hashes, cap_kmers * (uint64_t)m * sizeof(uint64_t)));
+  FX_TRY(hipMalloc((void**)&d_hashes, cap_kmers * per * sizeof(uint64_t)));
   rd.th = std::thread([&rd] { rd.run(); });
 
   uint64_t tail = 0;       // bytes of the piece before chunk j that belong to its first (incomplete) record
@@ -413,7 +466,8 @@ extern "C" int nthip_fastx_kmer_hash_file(nthip_ctx* c, const char* path, uint32
     uint64_t n_kmers = 0;
     if (n_rec) {
       nthip_out out = {d_hashes, cap_kmers, d_counts, nullptr, nullptr, nullptr};
-      NTCHK(nthip_kmer_hash_spans(c, (const char*)piece, n_bytes, d_starts, d_ends, n_rec, k, m, &out, &n_kmers, 0));
+      if (seeds) NTCHK(nthip_seed_hash_spans(c, (const char*)piece, n_bytes, d_starts, d_ends, n_rec, seeds, m, &out, &n_kmers, 0));
+      else NTCHK(nthip_kmer_hash_spans(c, (const char*)piece, n_bytes, d_starts, d_ends, n_rec, k, m, &out, &n_kmers, 0));
     }
     if (fn && n_rec) {
       nthip_fastx_batch b = {n_rec, n_kmers, d_hashes, d_counts, (const char*)piece, d_starts, d_ends, first_read};
@@ -477,3 +531,4 @@ extern "C" int nthip_fastx_kmer_hash_file(nthip_ctx* c, const char* path, uint32
   }
   return rc;
 }
+} // namespace

@@ -1314,13 +1314,14 @@ extern "C" int nthip_seeds_destroy(nthip_seeds* sd)
 namespace {
 
 int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd,
-                     uint32_t m2, uint64_t capacity, uint64_t* total)
+                     uint32_t m2, uint64_t capacity, uint64_t* total, const uint64_t* d_ends = nullptr)
 {
   const uint64_t n = rd->n_reads;
   SeedGeneralArgs h;
   memset(&h, 0, sizeof h);
   h.seqs = st.seqs;
   h.offsets = st.offsets;
+  h.ends = d_ends; // spans: st.offsets holds the starts
   h.n_reads = n;
   h.len = rd->fixed_len;
   h.stride = rd->stride ? rd->stride : rd->fixed_len;

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
 // --------------------------------------------------------------------------
 struct SeedGeneralArgs {
   const uint8_t* seqs;
-  const uint64_t* offsets;
+  const uint64_t* offsets;    // n_reads+1 offsets, or (with ends) the first byte of every read
+  const uint64_t* ends;       // optional: read r = [offsets[r], ends[r]) -- spans of one buffer
   uint64_t n_reads;
   uint32_t len, stride;
   uint32_t k, m2, n_seeds;
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(256) void seed_general_kernel(const SeedGeneralArgs
   uint64_t start, len;
   if (a.offsets) {
     start = a.offsets[rid];
-    len = a.offsets[rid + 1] - start;
+    const uint64_t end = a.ends ? a.ends[rid] : a.offsets[rid + 1];
+    len = end > start ? end - start : 0;
   } else {
     start = rid * a.stride;
     len = a.len;

@@ -972,3 +972,52 @@ def test_fasta_multiline_file_vs_oracle(ctx, oracle, tmp_path):
     (tmp_path / "bad.fa").write_bytes(b"ACGT\n>x\nAC\n")
     with pytest.raises(nthash_amd.NtHipError):
         ctx.fastx_kmer_hash_file(tmp_path / "bad.fa", NTHIP_FASTA_MULTILINE, k, m)
+
+
+def test_fastx_seed_stream_vs_oracle(ctx, oracle, tmp_path):
+    """SeedNtHash over a streamed FASTQ (spans + the reference's position state machine on reads with N)"""
+    import nthash_amd
+    rng = np.random.default_rng(91)
+    buf, seqs = _make_fastx(rng, 2500, 4, lo=10, hi=300, bad_frac=0.004)
+    path = tmp_path / "reads.fq"
+    path.write_bytes(buf)
+    seeds = ["1010101010101010101010101010101", "1101101101101101011011011011011"]
+    k, m2 = 31, 2
+    data, offs = concat_reads(seqs)
+    want = oracle.seed_batch(data, offs, seeds, k, m2, want_pos=False)
+    sd = nthash_amd.Seeds(ctx, seeds, k)
+    per = len(seeds) * m2
+    got_h, got_c = [], []
+
+    def on_batch(b):
+        h, cnt = np.zeros(b.n_kmers * per, np.uint64), np.zeros(b.n_reads, np.uint64)
+        if h.size:
+            ctx.d2h(h, b.hashes)
+        ctx.d2h(cnt, b.counts)
+        got_h.append(h); got_c.append(cnt)
+
+    st = ctx.fastx_kmer_hash_file(path, 4, k, m2, chunk_bytes=1 << 17, on_batch=on_batch, seeds=sd)
+    assert st.reads == len(seqs) and st.kmers == want["total"] and st.batches > 3
+    assert (np.concatenate(got_c) == want["counts"]).all()
+    assert (np.concatenate(got_h) == want["hashes"].ravel()).all()
+
+
+def test_fastx_single_line_fasta_long_sequences(ctx, oracle, tmp_path):
+    """2-line FASTA whose sequence lines are almost the whole chunk (capacity: one k-mer per byte)"""
+    rng = np.random.default_rng(5)
+    buf, seqs = _make_fastx(rng, 40, 2, lo=20_000, hi=60_000)
+    path = tmp_path / "contigs.fa"
+    path.write_bytes(buf)
+    data, offs = concat_reads(seqs)
+    want = oracle.kmer_batch(data, offs, 31, 1, want_pos=False)
+    got = []
+    st = ctx.fastx_kmer_hash_file(path, 2, 31, 1, chunk_bytes=1 << 18,
+                                  on_batch=lambda b: got.append(_d2h_u64(ctx, b.hashes, b.n_kmers)))
+    assert st.kmers == want["total"] and (np.concatenate(got) == want["hashes"].ravel()).all()
+
+
+def _d2h_u64(ctx, dptr, n):
+    out = np.zeros(n, np.uint64)
+    if n:
+        ctx.d2h(out, dptr)
+    return out
