@@ -119,6 +119,9 @@ def main():
     share = os.environ.get("NTHASH_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    # a launcher that pins one GPU per rank (HIP_VISIBLE_DEVICES) leaves every rank with device 0 only
+    if local_rank >= torch.cuda.device_count():
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
