@@ -158,8 +158,8 @@ int nthip_kmer_extend(nthip_ctx* ctx, const char* kmers, uint64_t n_kmers, uint1
  * insert: *total (optional) = k-mers consumed.
  * query : hits[r] (optional; host memory with NTHIP_HOST_OUTPUT) = k-mers of read r whose m bits
  *         are all set; *total = k-mers tested, *total_hits = sum of hits.
- * Fixed-length reads (reads->offsets == NULL), k <= 64, m <= 8; otherwise NTHIP_ERR_UNSUPPORTED
- * (hash to a stream with nthip_kmer_hash and consume that).
+ * Fixed-length reads (reads->offsets == NULL), any k >= 3 and m >= 1; otherwise NTHIP_ERR_UNSUPPORTED
+ * (hash to a stream with nthip_kmer_hash and consume that with nthip_stream_bloom_insert).
  */
 int nthip_kmer_bloom_insert(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint8_t m,
                             uint8_t* d_filter, uint64_t n_bits, uint64_t* total, uint32_t flags);
@@ -180,7 +180,7 @@ int nthip_stream_bloom_insert(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t
  * device buffer of buf_bytes bytes (sequence lines inside a raw FASTQ chunk; spans may be separated
  * by anything).  Same emission rule, order and outputs (out->hashes/counts/pos; fwd/rev must be NULL)
  * as nthip_kmer_hash with offsets.  All pointers are device pointers unless NTHIP_HOST_OUTPUT is set
- * for the outputs.  k <= 64, m <= 8.
+ * for the outputs.  Any k >= 3, m >= 1.
  */
 int nthip_kmer_hash_spans(nthip_ctx* ctx, const char* d_buf, uint64_t buf_bytes, const uint64_t* d_starts,
                           const uint64_t* d_ends, uint64_t n_reads, uint16_t k, uint8_t m,

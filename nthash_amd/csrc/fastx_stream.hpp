@@ -28,8 +28,6 @@ extern "C" int nthip_kmer_hash_spans(nthip_ctx* c, const char* d_buf, uint64_t b
   if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
   if (k < 3) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 is undefined in the reference (src/kmer.cpp:47)");
   if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
-  if (k > 64 || m > (uint32_t)KF_MAX_RUNTIME_M)
-    return fail(NTHIP_ERR_UNSUPPORTED, "spans take k <= 64 and m <= %d", KF_MAX_RUNTIME_M);
   HIPCHK(hipSetDevice(c->device));
   if (total_out) *total_out = 0;
   if (n_reads == 0) return NTHIP_OK;
@@ -243,8 +241,7 @@ int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, 
                          nthip_fastx_stats* stats)
 {
   if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
-  if (k < 3 || k > 64 || m == 0 || m > KF_MAX_RUNTIME_M)
-    return fail(NTHIP_ERR_UNSUPPORTED, "the file driver takes 3 <= k <= 64 and 1 <= m <= %d", KF_MAX_RUNTIME_M);
+  if (k < 3 || m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 / m == 0 are undefined in the reference");
   HIPCHK(hipSetDevice(c->device));
   const auto t_begin = std::chrono::steady_clock::now();
   if (stats) memset(stats, 0, sizeof *stats);
@@ -365,8 +362,7 @@ extern "C" int nthip_fastx_kmer_hash_file(nthip_ctx* c, const char* path, uint32
   if (!c || !path) return fail(NTHIP_ERR_ARG, "ctx/path is NULL");
   if (format == NTHIP_FASTA_MULTILINE) return fasta_multiline_file(c, path, k, m, fn, user, stats);
   if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
-  if (k < 3 || k > 64 || m == 0 || m > KF_MAX_RUNTIME_M)
-    return fail(NTHIP_ERR_UNSUPPORTED, "the file driver takes 3 <= k <= 64 and 1 <= m <= %d", KF_MAX_RUNTIME_M);
+  if (k < 3 || m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 / m == 0 are undefined in the reference");
   return fastx_stream_file(c, path, format, k, m, nullptr, chunk_bytes, fn, user, stats);
 }
 

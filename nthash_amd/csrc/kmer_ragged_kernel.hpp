@@ -112,6 +112,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t k = a.k, m = a.m, C = a.C;
   const uint32_t inv_m = 0xFFFFFFFFu / m + 1u; // v / m == umulhi(v, inv_m) for v < 2^29
+  const uint64_t kmul = (uint64_t)k * MULTISEED; // h[i] = mix(h[0] * (i ^ k*MULTISEED)), any m
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform: tile bookkeeping on the scalar unit
 
@@ -336,7 +337,9 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
     const uint64_t w_first = (uint64_t)q * C;
     const uint32_t c_run = !live ? 0u : (nwin_j - w_first < C ? (uint32_t)(nwin_j - w_first) : C);
     const uint32_t b0 = (RT_VBEG(cur)[j] << 4) + (q - RT_QLO(cur)[j]) * C;
-    const uint32_t valid = ~windows_with_non_base((const uint32_t*)vbits, b0, k) & ((1u << c_run) - 1u); // C <= 16
+    const uint32_t valid = ~(k <= 64u ? windows_with_non_base((const uint32_t*)vbits, b0, k)
+                                      : windows_with_non_base_long((const uint32_t*)vbits, b0, k, C)) &
+                           ((1u << c_run) - 1u); // C <= 16
     const uint32_t cnt = __builtin_popcount(valid);
     const uint32_t incl = wave_incl_scan32(cnt);
     const uint32_t lane_off = incl - cnt;
@@ -367,8 +370,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
     } else {
       // ---- hash the run, drop valid hashes at their compacted slots ------------------------
       const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
-      uint32_t w[NW];
-      {
+      uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
+      if constexpr (NW == 0) { // any k: Horner first window (kmer_runs_gen_kernel.hpp)
+        horner_first_window(bits, itab, b0, k, f_lo, f_hi, r_lo, r_hi);
+      } else {
+        uint32_t w[NW];
         uint32_t lo = bits[d0];
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
@@ -376,14 +382,13 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
           w[i] = funnel(hi, lo, sh0);
           lo = hi;
         }
-      }
-      uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
 #pragma unroll
-      for (int jt = 0; jt < 4 * NW; ++jt) {
-        if ((uint32_t)jt < a.ntab) {
-          const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
-          const uint4 e = itab[(uint32_t)jt * 256u + byte];
-          f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
+        for (int jt = 0; jt < 4 * NW; ++jt) {
+          if ((uint32_t)jt < a.ntab) {
+            const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+            const uint4 e = itab[(uint32_t)jt * 256u + byte];
+            f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
+          }
         }
       }
       uint32_t slot = lane_off;
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
             ok[h] = sv < n_vals;
             const uint32_t e = ok[h] ? __umulhi(sv, inv_m) : 0u, jj = ok[h] ? sv - e * m : 0u;
             const uint64_t h0 = tile[e];
-            o[h] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
+            o[h] = jj == 0 ? h0 : mix_hash(h0, ((uint64_t)jj ^ kmul));
           }
           if (ok[0] && ok[1])
             *(uint4*)(base + 2u * pi) =

@@ -141,6 +141,106 @@ __device__ __forceinline__ uint32_t windows_with_non_base(const uint32_t* vw, ui
   return (uint32_t)lo; // bit j exact for j + k - 1 <= 95
 }
 
+// The same for ANY k: walk the non-bases of [b0, b0 + C + k - 1) and knock out the windows they hit.
+__device__ __forceinline__ uint32_t windows_with_non_base_long(const uint32_t* vw, uint32_t b0, uint32_t k,
+                                                               uint32_t C)
+{
+  uint32_t inv = 0;
+  const uint32_t end = b0 + C + k - 1u; // one past the last base a window of the run touches
+  uint32_t w = b0 >> 5;
+  uint32_t word = vw[w] & (~0u << (b0 & 31u));
+  for (;;) {
+    while (word) {
+      const uint32_t pos = (w << 5) + (uint32_t)__builtin_ctz(word);
+      word &= word - 1u;
+      if (pos >= end) return inv;
+      // windows j with b0 + j <= pos < b0 + j + k
+      const int32_t hi = (int32_t)(pos - b0), lo = hi - (int32_t)k + 1;
+      const int32_t lo_c = lo > 0 ? lo : 0, hi_c = hi < (int32_t)C - 1 ? hi : (int32_t)C - 1;
+      if (lo_c <= hi_c) inv |= ((2u << hi_c) - 1u) & ~((1u << lo_c) - 1u);
+    }
+    ++w;
+    if ((w << 5) >= end) break;
+    word = vw[w];
+  }
+  return inv;
+}
+
+// split rotate by N (2..16) on the {lo, hi} halves (see srol_pair)
+template <int N>
+__device__ __forceinline__ void srol_pair_n(uint32_t& lo, uint32_t& hi)
+{
+  static_assert(N >= 2 && N <= 16, "");
+  const uint32_t h31 = hi >> 1;
+  const uint32_t nb32 = (lo >> (32 - N)) & 1u;
+  const uint32_t nlo = (lo << N) | ((hi & 1u) << (N - 1)) | (lo >> (33 - N));
+  const uint32_t nh31 = ((h31 << N) | (h31 >> (31 - N))) & 0x7FFFFFFFu;
+  lo = nlo;
+  hi = (nh31 << 1) | nb32;
+}
+
+// First window of a run for ANY k (the NW == 0 instantiations): Horner over the window, 4 bases per step
+// with one k-independent byte table -- the position-specific tables of the NW > 0 path would need
+// ceil(k/4) * 4 KB of LDS -- the k % 4 leftover bases one at a time.  F runs forward from the first
+// base, R backward from the last.  tab[0..255] = byte table of a 4-mer, tab[256..259] = of a 1-mer
+// (build_byte_tables with k = 4 / k = 1).  Same values as base_forward_hash / base_reverse_hash,
+// src/kmer.cpp:43-73,123-152.
+__device__ __forceinline__ void horner_first_window(const uint32_t* bits, const uint4* tab, uint32_t b0, uint32_t k,
+                                                    uint32_t& f_lo, uint32_t& f_hi, uint32_t& r_lo, uint32_t& r_hi)
+{
+  const uint4* t4 = tab;
+  const uint4* t1 = tab + 256;
+  const uint32_t nbytes = k >> 2, rem = k & 3u;
+  auto word_at = [&](uint32_t pos) { return funnel(bits[(pos >> 4) + 1u], bits[pos >> 4], (pos & 15u) << 1); };
+  f_lo = f_hi = r_lo = r_hi = 0;
+  // forward strand: full bytes from the first base, then the leftover bases
+  for (uint32_t w = 0; 4u * w < nbytes; ++w) {
+    const uint32_t word = word_at(b0 + 16u * w);
+    const uint32_t nb = nbytes - 4u * w < 4u ? nbytes - 4u * w : 4u;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+      if (q < nb) {
+        const uint4 e = t4[(word >> (8u * q)) & 0xFFu];
+        srol_pair_n<4>(f_lo, f_hi);
+        f_lo ^= e.x;
+        f_hi ^= e.y;
+      }
+    }
+  }
+  if (rem) {
+    const uint32_t word = word_at(b0 + 4u * nbytes);
+    for (uint32_t i = 0; i < rem; ++i) {
+      const uint4 e = t1[(word >> (2u * i)) & 3u];
+      srol_pair(f_lo, f_hi);
+      f_lo ^= e.x;
+      f_hi ^= e.y;
+    }
+  }
+  // reverse strand: full bytes backward from the last base (they start at base `rem`), then bases rem-1 .. 0
+  for (uint32_t w = (nbytes + 3u) >> 2; w-- > 0;) {
+    const uint32_t word = word_at(b0 + rem + 16u * w);
+    const uint32_t nb = nbytes - 4u * w < 4u ? nbytes - 4u * w : 4u;
+#pragma unroll
+    for (int q = 3; q >= 0; --q) {
+      if ((uint32_t)q < nb) {
+        const uint4 e = t4[(word >> (8u * q)) & 0xFFu];
+        srol_pair_n<4>(r_lo, r_hi);
+        r_lo ^= e.z;
+        r_hi ^= e.w;
+      }
+    }
+  }
+  if (rem) {
+    const uint32_t word = word_at(b0);
+    for (uint32_t i = rem; i-- > 0;) {
+      const uint4 e = t1[(word >> (2u * i)) & 3u];
+      srol_pair(r_lo, r_hi);
+      r_lo ^= e.z;
+      r_hi ^= e.w;
+    }
+  }
+}
+
 // ---- geometry shared by the three kernels (wave-uniform integers only) ---------------
 struct RunShape {
   uint32_t C, rpr, inv_rpr, last_start, last_dup, stride, nwin, k;
@@ -205,7 +305,8 @@ __device__ __forceinline__ void tile_range(uint32_t tile_map, uint32_t waves, ui
   wt_end = t0 + per < n_wtiles ? t0 + per : n_wtiles;
 }
 
-// NW: window words, k <= 16*NW; DT: every slab is <= 1280 bytes (tail = one dword per lane);
+// NW: window words, k <= 16*NW (0: any k, Horner first window); DT: every slab is <= 1280 bytes (tail = one
+// dword per lane);
 // NA: N-aware hash pass (compact output at a.tile_off) instead of the dense optimistic pass;
 // SINK (needs NA): consume the tile's hashes instead of writing them out
 template <int NW, bool DT, bool NA, int SINK = SINK_NONE>
@@ -225,6 +326,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
 #endif
   const RunShape shape = {C, rpr, a.inv_rpr, a.last_start, a.last_dup, a.stride, a.nwin, k};
   const uint32_t inv_m = 0xFFFFFFFFu / m + 1u; // v / m == umulhi(v, inv_m) for v < 2^29
+  const uint64_t kmul = (uint64_t)k * MULTISEED; // h[i] = mix(h[0] * (i ^ k*MULTISEED)), any m (src/internal.hpp:104-118)
 
   // LDS: init tables | pair table | multipliers | per wave {tile, [pos tile], bits, [validity bits]}
   uint4* itab = (uint4*)lds_dyn;
@@ -392,7 +494,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     if constexpr (NA) {
       const uint32_t dup = live && last_run ? a.last_dup : 0u; // windows the run before already covers
       const uint32_t run_mask = live ? ((1u << C) - 1u) & ~((1u << dup) - 1u) : 0u;
-      valid = ~windows_with_non_base((const uint32_t*)vbits, b0, k) & run_mask;
+      valid = ~(k <= 64u ? windows_with_non_base((const uint32_t*)vbits, b0, k)
+                         : windows_with_non_base_long((const uint32_t*)vbits, b0, k, C)) & run_mask;
       const uint32_t cnt = __builtin_popcount(valid);
       uint32_t incl = cnt;
 #pragma unroll
@@ -420,8 +523,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     uint32_t slot = 0; // N-aware, tile with non-bases: next free slot of this lane
 
     const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
-    uint32_t w[NW];
-    {
+    uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
+    if constexpr (NW == 0) {
+      horner_first_window(bits, itab, b0, k, f_lo, f_hi, r_lo, r_hi);
+    } else {
+      uint32_t w[NW];
       uint32_t lo = bits[d0];
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
@@ -429,14 +535,13 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
         w[i] = funnel(hi, lo, sh0);
         lo = hi;
       }
-    }
-    uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
 #pragma unroll
-    for (int jt = 0; jt < 4 * NW; ++jt) {
-      if ((uint32_t)jt < ntab) {
-        const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
-        const uint4 e = itab[(uint32_t)jt * 256u + byte];
-        f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
+      for (int jt = 0; jt < 4 * NW; ++jt) {
+        if ((uint32_t)jt < ntab) {
+          const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+          const uint4 e = itab[(uint32_t)jt * 256u + byte];
+          f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
+        }
       }
     }
     // window j of the run has just been hashed
@@ -532,7 +637,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
             uint32_t word[U];
 #pragma unroll
             for (uint32_t u = 0; u < U; ++u) {
-              const uint64_t h = i == 0 ? h0[u] : mix_hash(h0[u], mults[i & (KF_MAX_RUNTIME_M - 1)]);
+              const uint64_t h = i == 0 ? h0[u] : mix_hash(h0[u], ((uint64_t)i ^ kmul));
               p[u] = mod_invariant(h, a.n_bits, a.bloom_magic);
               word[u] = a.bloom[p[u] >> 5];
             }
@@ -555,7 +660,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
         for (uint32_t e = lane; e < n_emit; e += 64u) {
           const uint64_t h0 = tile[e];
           for (uint32_t i = 0; i < m; ++i) {
-            const uint64_t h = i == 0 ? h0 : mix_hash(h0, mults[i & (KF_MAX_RUNTIME_M - 1)]);
+            const uint64_t h = i == 0 ? h0 : mix_hash(h0, ((uint64_t)i ^ kmul));
             const uint64_t p = mod_invariant(h, a.n_bits, a.bloom_magic);
             atomicOr(&a.bloom[p >> 5], 1u << ((uint32_t)p & 31u)); // no return value: counted like a store
           }
@@ -587,7 +692,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
           uint32_t word[U];
 #pragma unroll
           for (uint32_t u = 0; u < U; ++u) {
-            const uint64_t h = i == 0 ? h0[u] : mix_hash(h0[u], mults[i & (KF_MAX_RUNTIME_M - 1)]);
+            const uint64_t h = i == 0 ? h0[u] : mix_hash(h0[u], ((uint64_t)i ^ kmul));
             p[u] = mod_invariant(h, a.n_bits, a.bloom_magic);
             word[u] = a.bloom[p[u] >> 5];
           }
@@ -652,7 +757,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
           ok[h] = sv < n_vals;
           const uint32_t e = ok[h] ? __umulhi(sv, inv_m) : 0u, jj = ok[h] ? sv - e * m : 0u;
           const uint64_t h0 = tile[e];
-          o[h] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
+          o[h] = jj == 0 ? h0 : mix_hash(h0, ((uint64_t)jj ^ kmul));
         }
         if (ok[0] && ok[1])
           *(uint4*)(base + 2u * pi) =
@@ -751,7 +856,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_count_kernel(const K
     const uint32_t b0 = g.shift + lr * a.stride + w0 - g.w_first;
     const uint32_t dup = last_run ? a.last_dup : 0u;
     const uint32_t run_mask = live ? ((1u << C) - 1u) & ~((1u << dup) - 1u) : 0u;
-    const uint32_t valid = ~windows_with_non_base((const uint32_t*)vbits, b0, k) & run_mask;
+    const uint32_t valid = ~(k <= 64u ? windows_with_non_base((const uint32_t*)vbits, b0, k)
+                                      : windows_with_non_base_long((const uint32_t*)vbits, b0, k, C)) & run_mask;
     const uint32_t cnt = __builtin_popcount(valid);
     uint32_t sum = cnt;
 #pragma unroll

@@ -544,6 +544,29 @@ int get_init_tab(nthip_ctx* c, uint32_t k, const uint4** out)
   return NTHIP_OK;
 }
 
+// k > 64: the run-split kernels hash a run's first window by Horner with ONE k-independent byte table
+// (a 4-mer's) plus a 1-mer's for the k % 4 leftover bases -- [0..255] and [256..511] of the same array
+constexpr uint32_t KMER_TABLE_K_MAX = 64; // beyond: Horner
+int get_kmer_tab(nthip_ctx* c, uint32_t k, const uint4** out)
+{
+  if (k <= KMER_TABLE_K_MAX) return get_init_tab(c, k, out);
+  const uint32_t key = 0xFFFF0004u;
+  auto it = c->init_tabs.find(key);
+  if (it == c->init_tabs.end()) {
+    std::vector<uint4> h(512);
+    build_byte_tables(4, nullptr, h.data());
+    build_byte_tables(1, nullptr, h.data() + 256);
+    uint4* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, h.size() * sizeof(uint4)));
+    HIPCHK(hipMemcpy(d, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    it = c->init_tabs.emplace(key, d).first;
+  }
+  *out = it->second;
+  return NTHIP_OK;
+}
+inline uint32_t kmer_ntab(uint32_t k) { return k <= KMER_TABLE_K_MAX ? (k + 3) / 4 : 2u; }
+inline uint32_t kmer_nw(uint32_t k) { return k <= KMER_TABLE_K_MAX ? (k + 15) / 16 : 0u; }
+
 // Plan for the run-split kernel: run length C | nwin, waves per block, LDS bytes.
 struct RunsPlan {
   uint32_t C = 0, rpr = 0, waves = 0, bits_dwords = 0, tile_u64 = 0, nw = 0, dword_tail = 0;
@@ -623,10 +646,10 @@ struct GenPlan {
 
 bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, GenPlan* p)
 {
-  if (len < k || k > 64 || m > (uint32_t)KF_MAX_RUNTIME_M || stride > len || len >= (1u << 30)) return false;
+  if (len < k || m == 0 || stride > len || len >= (1u << 30)) return false;
   const uint32_t nwin = len - k + 1;
   if (stride < nwin) return false; // reads overlapping by more than k-1 bases: other paths
-  const uint32_t ntab = (k + 3) / 4;
+  const uint32_t ntab = (k + 3) / 4; // first-window cost in the model (table lookups or Horner steps)
   uint32_t best = 0;
   double best_cost = 1e30;
   const uint32_t c_hi = nwin < 16 ? nwin : 16;
@@ -648,7 +671,7 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
   p->C = best;
   p->rpr = (nwin + best - 1) / best;
   p->last_start = nwin - best;
-  p->nw = (k + 15) / 16;
+  p->nw = kmer_nw(k);
   p->tile_u64 = 64 * best + 128;
   // longest slab: 63 run-to-run steps of at most C bases, C + stride - nwin across a read boundary, plus
   // the last run
@@ -658,7 +681,7 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
   bd = (bd + 3u) & ~3u;
   p->bits_dwords = bd;
   p->dword_tail = (15 + slab_bytes <= 1280) ? 1u : 0u;
-  const size_t fixed = (size_t)ntab * 4096 + 256 + 64;
+  const size_t fixed = (size_t)kmer_ntab(k) * 4096 + 256 + 64;
   const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
   uint32_t w_max = m == 1 ? 8 : 16;
@@ -707,7 +730,7 @@ bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k,
   p->tile_u64 = 64 * g.C + KRG_ALIGN_U64 + KRG_SLACK_U64;
   p->ptile_dwords = want_pos ? (64 * g.C + KRG_SLACK_U64 + 3u) & ~3u : 0u;
   p->vbits_dwords = (g.bits_dwords / 2 + 8 + 3u) & ~3u; // 16 validity bits per 32 stream bits, read 4 dwords ahead
-  const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
+  const size_t fixed = (size_t)kmer_ntab(k) * 4096 + 256 + 64;
   const size_t per_wave = (size_t)p->tile_u64 * 8 + ((size_t)p->ptile_dwords + g.bits_dwords + p->vbits_dwords) * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
   for (uint32_t w = 8; w >= 1; --w)
@@ -740,7 +763,7 @@ void fill_gen_args(KmerRunsGenArgs& ga, nthip_ctx* c, const Staged& st, const nt
   ga.rpr = g.rpr;
   ga.last_start = g.last_start;
   ga.last_dup = g.rpr * g.C - ga.nwin;
-  ga.ntab = (k + 3) / 4;
+  ga.ntab = kmer_ntab(k);
   ga.waves = g.waves;
   ga.bits_dwords = g.bits_dwords;
   ga.tile_u64 = g.tile_u64;
@@ -761,6 +784,7 @@ int launch_kmer_runs_gen_nw(nthip_ctx* c, const KmerRunsGenArgs& ga, size_t lds,
   (dt ? launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, true, NA, SINK>, ga, lds, label) \
       : launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, false, NA, SINK>, ga, lds, label))
   switch (nw) {
+    case 0: return NT_GEN(0); // any k
     case 1: return NT_GEN(1);
     case 2: return NT_GEN(2);
     case 3: return NT_GEN(3);
@@ -774,7 +798,7 @@ int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t 
 {
   KmerRunsGenArgs a;
   fill_gen_args(a, c, st, rd, k, m, plan.g, consts);
-  NTCHK(get_init_tab(c, k, &a.init_tab));
+  NTCHK(get_kmer_tab(c, k, &a.init_tab));
   a.pos = st.pos;
   a.counts = st.counts;
   a.vbits_dwords = plan.vbits_dwords;
@@ -793,6 +817,7 @@ int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t 
     // count pass: 16 waves per block, validity bits only
     KmerRunsGenArgs ca = a;
     ca.waves = 16;
+    while (ca.waves > 1 && (size_t)ca.waves * ca.vbits_dwords * 4 + 64 > 150 * 1024) ca.waves /= 2; // long k
     const size_t lds = (size_t)ca.waves * ca.vbits_dwords * 4 + 64;
     int per_cu = 1;
     NTCHK(blocks_per_cu(c, kmer_runs_count_kernel, (int)ca.waves * 64, lds, &per_cu));
@@ -841,16 +866,16 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
 {
   *handled = false;
   const uint32_t C = 15; // run length; the last run of a read may be shorter
-  if (k > 64 || m > (uint32_t)KF_MAX_RUNTIME_M || st.fwd || st.rev) return NTHIP_OK;
+  if (st.fwd || st.rev) return NTHIP_OK;
   const uint64_t n = n_reads;
-  const uint32_t nw = (k + 15) / 16;
+  const uint32_t nw = kmer_nw(k);
   // per-wave LDS: a tile touches <= 64 listed reads, each staging its runs' bytes rounded up to 16
   const uint32_t max_vec = (64 * C + 64 * (k - 1 + 15 + 15)) / 16 + 64;
   const uint32_t bits_dwords = (max_vec + nw + 8 + 3u) & ~3u;
   const uint32_t vbits_dwords = ((max_vec + 12) / 2 + 2 + 3u) & ~3u;
   const uint32_t tile_u64 = 64 * C + KRG_ALIGN_U64;
   const uint32_t ptile_dwords = st.pos ? 64 * C : 0;
-  const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
+  const size_t fixed = (size_t)kmer_ntab(k) * 4096 + 256 + 64;
   const size_t per_wave = (size_t)tile_u64 * 8 + ((size_t)ptile_dwords + bits_dwords + vbits_dwords + 2 * 512) * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
   uint32_t waves = 0;
@@ -917,14 +942,14 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
   a.nz_meta = d_nz_meta;
   a.tile_j0 = d_tile_j0;
   a.tile_rem0 = d_tile_rem0;
-  NTCHK(get_init_tab(c, k, &a.init_tab));
+  NTCHK(get_kmer_tab(c, k, &a.init_tab));
   a.n_nz = n_nz;
   a.total_runs = total_runs;
   a.n_wtiles = nt;
   a.k = k;
   a.m = m;
   a.C = C;
-  a.ntab = (k + 3) / 4;
+  a.ntab = kmer_ntab(k);
   a.waves = waves;
   a.bits_dwords = bits_dwords;
   a.vbits_dwords = vbits_dwords;
@@ -935,6 +960,7 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
   const size_t lds = fixed + per_wave * waves;
   auto launch = [&](int mode) -> int {
     switch (nw) {
+      case 0: return launch_kmer_ragged<0>(c, mode, a, lds); // any k
       case 1: return launch_kmer_ragged<1>(c, mode, a, lds);
       case 2: return launch_kmer_ragged<2>(c, mode, a, lds);
       case 3: return launch_kmer_ragged<3>(c, mode, a, lds);
@@ -949,6 +975,7 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
     ca.ptile_dwords = 0;
     ca.bits_dwords = 0;
     ca.waves = 16;
+    while (ca.waves > 1 && ((size_t)ca.vbits_dwords + 2 * 512) * 4 * ca.waves + 64 > cap) ca.waves /= 2; // long k
     const size_t clds = ((size_t)ca.vbits_dwords + 2 * 512) * 4 * ca.waves + 64;
     NTCHK(launch_kmer_ragged<1>(c, NA_MODE_COUNT, ca, clds));
   }
@@ -1183,7 +1210,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
       // any other shape: general run-split kernel (kmer_runs_gen_kernel.hpp)
       KmerRunsGenArgs ga;
       fill_gen_args(ga, c, st, rd, k, m, gplan, a);
-      NTCHK(get_init_tab(c, k, &ga.init_tab));
+      NTCHK(get_kmer_tab(c, k, &ga.init_tab));
       rc = launch_kmer_runs_gen_nw<false>(c, ga, gplan.lds, gplan.nw, gplan.dword_tail != 0);
     } else if (!rows_ok) {
       rc = NTHIP_OK;
@@ -1592,7 +1619,7 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
   fill_kmer_consts(k, m, consts);
   KmerRunsGenArgs a;
   fill_gen_args(a, c, st, rd, k, m, plan.g, consts);
-  NTCHK(get_init_tab(c, k, &a.init_tab));
+  NTCHK(get_kmer_tab(c, k, &a.init_tab));
   a.hashes = nullptr;
   a.vbits_dwords = plan.vbits_dwords;
   a.ptile_dwords = plan.ptile_dwords;

@@ -1021,3 +1021,59 @@ def _d2h_u64(ctx, dptr, n):
     if n:
         ctx.d2h(out, dptr)
     return out
+
+
+# ---------------------------------------------------------------------------
+# any k, any m: k > 64 hashes a run's first window by Horner, m > 8 computes its multipliers
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,L,k,m", [
+    (500, 300, 65, 1), (300, 250, 96, 2), (200, 400, 128, 3), (150, 401, 127, 1), (100, 1000, 255, 1),
+    (40, 3000, 1000, 2), (6, 9000, 4099, 1), (800, 150, 31, 12), (300, 150, 31, 255), (64, 200, 100, 9),
+    (700, 130, 66, 1), (33, 150, 150, 4),
+])
+def test_kmer_any_k_any_m_vs_oracle(ctx, oracle, n, L, k, m):
+    rng = np.random.default_rng(n + k)
+    clean = oracle.synth_reads(4, n, L, 31 * k + m)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(clean, offs, k, m, want_pos=False)
+    ctx.set_profiling(True)
+    got = ctx.kmer_hash(clean, k, m, fixed_len=L, n_reads=n)                     # dense pass
+    name = ctx.last_kernel_ms()[1]
+    ctx.set_profiling(False)
+    assert name.startswith("kmer_runs_gen_kernel"), name
+    assert got["total"] == want["total"] == n * (L - k + 1)
+    assert (got["hashes"] == want["hashes"]).all()
+    dirty = clean.copy()
+    bad = rng.choice(n * L, max(4, n * L // 3000), replace=False)
+    dirty[bad] = np.frombuffer(b"NnRY*", dtype=np.uint8)[rng.integers(0, 5, bad.size)]
+    dirty[0] = ord("N"); dirty[-1] = ord("N")
+    want = oracle.kmer_batch(dirty, offs, k, m)
+    got = ctx.kmer_hash(dirty, k, m, fixed_len=L, n_reads=n, want_pos=True)      # N-aware pass
+    assert got["total"] == want["total"]
+    for key in ("counts", "pos", "hashes"):
+        assert (got[key] == want[key]).all(), key
+    # the same reads as a ragged batch (trimmed to random lengths): the run-split ragged kernel
+    lens = rng.integers(0, L + 1, n)
+    reads = [dirty[i * L:i * L + int(lens[i])].tobytes() for i in range(n)]
+    d, o = concat_reads(reads)
+    want = oracle.kmer_batch(d, o, k, m)
+    got = ctx.kmer_hash(d, k, m, offsets=o, want_pos=True)
+    assert got["total"] == want["total"]
+    for key in ("counts", "pos", "hashes"):
+        assert (got[key] == want[key]).all(), ("ragged", key)
+
+
+def test_bloom_long_k_many_hashes(ctx, oracle):
+    n, L, k, m, n_bits = 300, 400, 101, 11, 3_000_017
+    data = oracle.synth_reads(1, n, L, 8).copy()
+    data[5::997] = ord("N")
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    d_f, nbytes = ctx.bloom_new(n_bits)
+    assert ctx.bloom_insert(data, k, m, L, n, d_f, n_bits) == want["total"]
+    got = np.zeros(nbytes, np.uint8)
+    ctx.d2h(got, d_f)
+    assert (got == _bloom_expected(want["hashes"], n_bits)).all()
+    hits, total, found = ctx.bloom_query(data, k, m, L, n, d_f, n_bits)
+    assert total == found == want["total"] and (hits == want["counts"]).all()
+    ctx.free(d_f)
