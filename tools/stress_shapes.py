@@ -16,8 +16,8 @@ alph = np.frombuffer(b"ACGTacgtUu", dtype=np.uint8)
 bad_alph = np.frombuffer(b"NnRYKM-*.\x00", dtype=np.uint8)
 fails = 0
 for it in range(iters):
-    k = int(rng.integers(3, 65))
-    m = int(rng.integers(1, 9))
+    k = int(rng.integers(3, 65)) if rng.random() < 0.6 else int(rng.integers(65, 400))
+    m = int(rng.integers(1, 9)) if rng.random() < 0.8 else int(rng.integers(9, 40))
     kind = rng.integers(0, 3)
     if kind < 2:   # fixed length
         L = int(k + rng.integers(0, 40)) if rng.random() < 0.3 else int(rng.integers(k, 4000))
@@ -37,7 +37,7 @@ for it in range(iters):
         desc = f"fixed n={n} L={L} k={k} m={m} stride={stride} pos={want_pos}"
     else:
         n = int(rng.integers(1, 4000))
-        lens = np.where(rng.random(n) < 0.1, rng.integers(0, k + 2, n), rng.integers(0, 600, n))
+        lens = np.where(rng.random(n) < 0.1, rng.integers(0, k + 2, n), rng.integers(0, 600 + 2 * k, n))
         if rng.random() < 0.2:
             lens[rng.integers(0, n)] = int(rng.integers(5000, 200000))
         offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
