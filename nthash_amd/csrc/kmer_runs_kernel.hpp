@@ -69,7 +69,14 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
   const uint32_t ntab = K_T ? (uint32_t)((K_T + 3) / 4) : a.ntab;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
+#ifndef KR_UNIFORM_WAVE
+#define KR_UNIFORM_WAVE 0
+#endif
+#if KR_UNIFORM_WAVE
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6); // tile bookkeeping on the scalar unit
+#else
   const uint32_t wave = tid >> 6;
+#endif
 
   // LDS layout: init tables | pair table | multipliers | per-wave {tile, bits}
   uint4* itab = (uint4*)lds_dyn;

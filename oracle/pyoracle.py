@@ -29,6 +29,14 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF_SO)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    # the reference's own test program linked with OUR facade library (run on the GPU box by
+    # tests/test_gpu_facade.py); rebuilt whenever the facade library is newer
+    facade = os.path.join(os.path.dirname(_HERE), "nthash_amd", "lib", "libnthash.so")
+    exe = os.path.join(_HERE, "_ref", "ref_tests_on_facade")
+    if os.path.isfile("/root/reference/tests/tests.cpp") and os.path.exists(facade) and (
+        force or not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(facade)
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "ref_tests"], stdout=subprocess.DEVNULL)
 
 
 def _ptr(a, t):

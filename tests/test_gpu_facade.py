@@ -123,3 +123,15 @@ def test_facade_vs_oracle_scripts_random(facade, oracle):
             seen_true |= bool(y[0])
             if seen_true:  # hashes()/strands are undefined before the first success
                 assert x[2] == y[2] and x[3] == y[3] and (x[4] == y[4]).all(), (seq, k, ops)
+
+
+def test_reference_own_test_program_passes_on_our_library():
+    """the reference's tests/tests.cpp, unchanged, compiled against include/nthash/nthash.hpp and linked
+    with libnthash.so (oracle/Makefile target ref_tests; the binary travels, the source does not):
+    every block of it must pass with the hashes coming from the MI355X"""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_tests_on_facade")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_tests_on_facade not built (needs the reference tree at build time)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
