@@ -86,6 +86,24 @@ __device__ __forceinline__ void srol_pair(uint32_t& lo, uint32_t& hi)
   hi = (t & ~2u) | ((hi >> 30) & 2u);                       // bit 63 -> bit 33
   lo = nlo;
 }
+// canonical hash f + r (mod 2^64) from the 32-bit halves as ONE carry chain: the 64-bit C++ form
+// (((u64)f_hi << 32) | f_lo) + ... compiles to two v_lshl_add_u64 plus moves and ors on gfx950
+#ifndef NT_CANON_ASM
+#define NT_CANON_ASM 1
+#endif
+__device__ __forceinline__ uint64_t canon_pair(uint32_t f_lo, uint32_t f_hi, uint32_t r_lo, uint32_t r_hi)
+{
+#if NT_CANON_ASM
+  uint32_t lo, hi;
+  asm("v_add_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, %4, %5, vcc"
+      : "=&v"(lo), "=v"(hi)
+      : "v"(f_lo), "v"(r_lo), "v"(f_hi), "v"(r_hi)
+      : "vcc");
+  return ((uint64_t)hi << 32) | lo;
+#else
+  return (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+#endif
+}
 //   sror: the inverse
 __device__ __forceinline__ void sror_pair(uint32_t& lo, uint32_t& hi)
 {
@@ -221,7 +239,7 @@ __global__ __launch_bounds__(KF_THREADS) void kmer_fixed_kernel(const KmerFixedA
     };
 
     auto emit = [&](uint32_t step, uint32_t i) {
-      const uint64_t h0 = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+      const uint64_t h0 = canon_pair(f_lo, f_hi, r_lo, r_hi);
       const uint32_t p = step - (k - 1u);           // window index inside the run
       const uint32_t pi = (i + 16u - kmod) & 15u;   // == p & 15
       uint64_t tb = 0;

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
       const uint32_t tpar = m == 1u ? (uint32_t)(o0 & (KRG_ALIGN_U64 - 1u)) : 0u;
       auto emit = [&](uint32_t jw) {
         if ((valid >> jw) & 1u) {
-          tile[tpar + slot] = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+          tile[tpar + slot] = canon_pair(f_lo, f_hi, r_lo, r_hi);
           if (want_pos) ptile[slot] = p_first + jw;
           ++slot;
         }

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     }
     // window j of the run has just been hashed
     auto emit = [&](uint32_t j, auto clean_tag) {
-      const uint64_t h = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+      const uint64_t h = canon_pair(f_lo, f_hi, r_lo, r_hi);
       if constexpr (decltype(clean_tag)::value) {
         my_row[j] = h;
         if (want_pos) my_pos[j] = w0 + j;

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
       }
     }
     uint64_t* my_row = tile + lane * C;
-    my_row[0] = (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+    my_row[0] = canon_pair(f_lo, f_hi, r_lo, r_hi);
 
     // remaining C-1 windows: roll.  step t (1..C-1): in = base b0+k-1+t, out = base b0+t-1
     const uint32_t bi = b0 + k;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
             if (i0 + i < NS) {
               roll(terms[i]);
               my_row[jw * 16u + i0 + i + 1u] =
-                  (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+                  canon_pair(f_lo, f_hi, r_lo, r_hi);
             }
           }
         }
@@ -331,14 +331,14 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
           for (uint32_t i = 0; i < 8; ++i) {
             roll(terms[i]);
             my_row[jw * 16u + i0 + i + 1u] =
-                (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+                canon_pair(f_lo, f_hi, r_lo, r_hi);
           }
         }
 #pragma unroll 1
         for (uint32_t i = i0; i < ns; ++i) {
           roll(lookup(i));
           my_row[jw * 16u + i + 1u] =
-              (((uint64_t)f_hi << 32) | f_lo) + (((uint64_t)r_hi << 32) | r_lo);
+              canon_pair(f_lo, f_hi, r_lo, r_hi);
         }
       }
     };

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""A/B two builds of the C-ABI library INSIDE ONE PROCESS (process-to-process spread on a box is ~5 %,
+in-process repeatability ~0.5 %): the in-tree library against nthash_amd/lib/ab/libnthash_hip_<tag>.so.
+
+    tools/ab_build.sh x -DSOME_FLAG=1 && python tools/ab_libs.py x [reads] [rounds]   (ABLATE_SHAPE=L,k,m)
+"""
+import importlib.util, os, statistics, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+tag = sys.argv[1]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000_000
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+L, k, m = (int(x) for x in os.environ.get("ABLATE_SHAPE", "150,31,1").split(","))
+nwin = L - k + 1
+
+
+def load(path, name):
+    if path:
+        os.environ["NTHASH_AMD_LIB"] = path
+    else:
+        os.environ.pop("NTHASH_AMD_LIB", None)
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "nthash_amd", "capi.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.load()
+    return mod
+
+
+A = load(None, "capi_a")
+B = load(os.path.join(ROOT, "nthash_amd", "lib", "ab", f"libnthash_hip_{tag}.so"), "capi_b")
+ca, cb = A.Context(0), B.Context(0)
+d_in = ca.malloc(n * L); d_out = ca.malloc(n * nwin * m * 8)
+ca.synth_reads_ptr(d_in, 0, n, L, 42)
+res = {"base": [], tag: []}
+for c in (ca, cb):
+    c.set_profiling(True)
+for r in range(rounds):
+    for name, c in (("base", ca), (tag, cb)):
+        c.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin)
+        res[name].append(c.last_kernel_ms()[0])
+for name in res:
+    t = res[name][2:]
+    print(f"{name:8s} median {statistics.median(t):.3f} ms  min {min(t):.3f}  ({n*nwin/statistics.median(t)/1e6:.1f} Gkmer/s)  {c.last_kernel_ms()[1]}")
+print(f"ratio {tag}/base = {statistics.median(res[tag][2:]) / statistics.median(res['base'][2:]):.4f}")
