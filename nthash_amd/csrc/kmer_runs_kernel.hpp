@@ -266,6 +266,23 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
     }
     // first window: XOR of per-byte table entries (4 bases per lookup)
     uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
+#ifndef KR_BATCH_INIT
+#define KR_BATCH_INIT 1
+#endif
+#if KR_BATCH_INIT
+    {
+      // all lookups in flight before the first XOR (the wave is one of two on its SIMD: registers are plentiful)
+      uint4 e[4 * NW];
+#pragma unroll
+      for (int jt = 0; jt < 4 * NW; ++jt) {
+        const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+        e[jt] = (uint32_t)jt < ntab ? itab[(uint32_t)jt * 256u + byte] : make_uint4(0, 0, 0, 0);
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int jt = 0; jt < 4 * NW; ++jt) { f_lo ^= e[jt].x; f_hi ^= e[jt].y; r_lo ^= e[jt].z; r_hi ^= e[jt].w; }
+    }
+#else
 #pragma unroll
     for (int jt = 0; jt < 4 * NW; ++jt) {
       if ((uint32_t)jt < ntab) {
@@ -274,6 +291,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
         f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
       }
     }
+#endif
     uint64_t* my_row = tile + lane * C;
     my_row[0] = canon_pair(f_lo, f_hi, r_lo, r_hi);
 

@@ -124,6 +124,27 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
       for (uint32_t s = 0; s < a.n_seeds; ++s) {
         uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
         const uint4* ts = tabs + s * a.ntab * 256u;
+#ifndef SF_BATCH_LOOKUPS
+#define SF_BATCH_LOOKUPS 0
+#endif
+#if SF_BATCH_LOOKUPS
+        {
+          // all lookups of the seed in flight, then XOR them two at a time (v_bitop3: a ^ b ^ c is one instruction)
+          uint4 e[4 * NW];
+#pragma unroll
+          for (int jt = 0; jt < 4 * NW; ++jt) {
+            const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+            e[jt] = (uint32_t)jt < a.ntab ? ts[(uint32_t)jt * 256u + byte] : make_uint4(0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int jt = 0; jt < 4 * NW; jt += 2) {
+            f0 = f0 ^ e[jt].x ^ e[jt + 1].x;
+            f1 = f1 ^ e[jt].y ^ e[jt + 1].y;
+            r0 = r0 ^ e[jt].z ^ e[jt + 1].z;
+            r1 = r1 ^ e[jt].w ^ e[jt + 1].w;
+          }
+        }
+#else
 #pragma unroll
         for (int jt = 0; jt < 4 * NW; ++jt) {
           if ((uint32_t)jt < a.ntab) {
@@ -132,6 +153,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
             f0 ^= e.x; f1 ^= e.y; r0 ^= e.z; r1 ^= e.w;
           }
         }
+#endif
         const uint64_t h0 = (((uint64_t)f1 << 32) | f0) + (((uint64_t)r1 << 32) | r0);
         mine[s * a.m2] = h0;
         for (uint32_t jj = 1; jj < a.m2; ++jj)

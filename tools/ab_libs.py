@@ -29,14 +29,21 @@ def load(path, name):
 A = load(None, "capi_a")
 B = load(os.path.join(ROOT, "nthash_amd", "lib", "ab", f"libnthash_hip_{tag}.so"), "capi_b")
 ca, cb = A.Context(0), B.Context(0)
-d_in = ca.malloc(n * L); d_out = ca.malloc(n * nwin * m * 8)
+SEEDS = ["1010101010101010101010101010101", "1101101101101101011011011011011"] if os.environ.get("ABLATE_SEEDS") else None
+per = m * (len(SEEDS) if SEEDS else 1)
+sa = A.Seeds(ca, SEEDS, k) if SEEDS else None
+sb = B.Seeds(cb, SEEDS, k) if SEEDS else None
+d_in = ca.malloc(n * L); d_out = ca.malloc(n * nwin * per * 8)
 ca.synth_reads_ptr(d_in, 0, n, L, 42)
 res = {"base": [], tag: []}
 for c in (ca, cb):
     c.set_profiling(True)
 for r in range(rounds):
     for name, c in (("base", ca), (tag, cb)):
-        c.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin)
+        if SEEDS:
+            c.seed_hash_ptr(d_in, 0, n, L, 0, sa if c is ca else sb, m, d_out, n * nwin)
+        else:
+            c.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin)
         res[name].append(c.last_kernel_ms()[0])
 for name in res:
     t = res[name][2:]
