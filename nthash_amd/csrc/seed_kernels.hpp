@@ -121,6 +121,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
         lo = hi;
       }
       uint64_t* mine = otile + lane * per;
+      uint64_t held = 0;
       for (uint32_t s = 0; s < a.n_seeds; ++s) {
         uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
         const uint4* ts = tabs + s * a.ntab * 256u;
@@ -154,11 +155,27 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
           }
         }
 #endif
-        const uint64_t h0 = (((uint64_t)f1 << 32) | f0) + (((uint64_t)r1 << 32) | r0);
+        const uint64_t h0 = canon_pair(f0, f1, r0, r1);
+#ifndef SF_PAIR_STORES
+#define SF_PAIR_STORES 0
+#endif
+#if SF_PAIR_STORES
+        // the record's values go to the tile two at a time (16-byte LDS writes; lane records are 16-byte aligned
+        // when `per` is even, which the launcher checks)
+        for (uint32_t jj = 0; jj < a.m2; ++jj) {
+          const uint64_t v = jj == 0 ? h0 : mix_hash(h0, a.mult[jj & (SF_MAX_RUNTIME_M - 1)]);
+          const uint32_t idx = s * a.m2 + jj;
+          if ((per & 1u) != 0u) mine[idx] = v; // odd records: lanes are only 8-byte aligned
+          else if (idx & 1u) *(ulonglong2*)(mine + idx - 1u) = make_ulonglong2(held, v);
+          else held = v;
+        }
+#else
         mine[s * a.m2] = h0;
         for (uint32_t jj = 1; jj < a.m2; ++jj)
           mine[s * a.m2 + jj] = mix_hash(h0, a.mult[jj & (SF_MAX_RUNTIME_M - 1)]);
+#endif
       }
+
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
