@@ -47,6 +47,17 @@ CONFIGS = {
 }
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,7 +92,7 @@ def cpu_baseline(cfg, sample_reads):
     out = {"value": nk / t1, "unit": "kmers/s", "cores": 1, "kind": impl.kind,
            "sample": f"{sample_reads} x {L}bp synthetic reads (same generator, seed 42), "
                      f"{nk} k-mers in {t1:.2f}s, iterator per read, every hash consumed",
-           "host_cpus": os.cpu_count()}
+           "host_cpus": os.cpu_count(), "cpu_model": _cpu_model()}
     if impl.kind == "reference":
         # the reference has no threaded path; this is OUR OpenMP parallel-for over reads
         nt = impl.max_threads()
