@@ -1501,6 +1501,87 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
           HIPCHK(hipGetLastError());
         }
         done = true;
+      } else if (dyn + (size_t)rpt * 8 <= 158 * 1024 && dyn + (size_t)rpt * 8 <= c->lds_max) {
+        // Batch with non-bases.  SeedNtHash's position state machine (App. B Q3) only matters for the reads
+        // that HAVE a non-base: those (usually a fraction of a percent) go through seed_general_kernel, every
+        // other read emits all its windows and stays on the fast kernel, writing at its place in the compact
+        // stream (per-read counts -> scan -> offsets).
+        const uint64_t n = rd->n_reads;
+        const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+        NTCHK(ensure_scratch(c, 5 * n + nb + 16));
+        uint64_t* d_flags = c->d_scratch;
+        uint64_t* d_idx = c->d_scratch + n;
+        uint64_t* d_list = c->d_scratch + 2 * n;
+        uint64_t* d_cnt = st.counts ? st.counts : c->d_scratch + 3 * n;
+        uint64_t* d_roff = c->d_scratch + 4 * n;
+        uint64_t* d_sums = c->d_scratch + 5 * n;
+        uint64_t* d_total = (uint64_t*)(c->d_small + 8);
+        const unsigned rblocks = (unsigned)((n + 255) / 256);
+        HIPCHK(hipMemsetAsync(d_flags, 0, n * sizeof(uint64_t), c->stream));
+        hipLaunchKernelGGL(seed_mark_dirty_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, st.seqs, total_bytes, len,
+                           stride, n, d_flags);
+        NTCHK(device_exclusive_scan(c, d_flags, d_idx, n, d_sums, d_total));
+        HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+        hipLaunchKernelGGL(seed_list_kernel, dim3(rblocks), dim3(256), 0, c->stream, d_flags, d_idx, n, d_list);
+        hipLaunchKernelGGL(fill_u64_kernel, dim3(1024), dim3(256), 0, c->stream, d_cnt, n, (uint64_t)nwin);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        uint64_t n_dirty = 0;
+        memcpy(&n_dirty, c->h_small + 8, 8);
+        SeedGeneralArgs h;
+        memset(&h, 0, sizeof h);
+        h.seqs = st.seqs;
+        h.read_list = d_list;
+        h.n_reads = n_dirty;
+        h.len = len;
+        h.stride = stride;
+        h.k = k;
+        h.m2 = m2;
+        h.n_seeds = sd->n_seeds;
+        h.care_words = sd->care_words;
+        h.care_bits = sd->d_care;
+        h.blk_start = sd->d_blk_start;
+        h.blk_count = sd->d_blk_count;
+        h.blk_pairs = sd->d_blk_pairs;
+        for (uint32_t i = 0; i < 256; ++i) h.mult[i] = multiplier(k, i);
+        NTCHK(ensure_args(c, sizeof(SeedGeneralArgs)));
+        const unsigned lblocks = (unsigned)((n_dirty + 255) / 256);
+        if (n_dirty) {
+          h.counts = d_cnt;
+          HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+          hipLaunchKernelGGL(seed_general_kernel<true>, dim3(lblocks), dim3(256), 0, c->stream,
+                             (const SeedGeneralArgs*)c->d_args);
+          HIPCHK(hipGetLastError());
+        }
+        NTCHK(device_exclusive_scan(c, d_cnt, d_roff, n, d_sums, d_total));
+        HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(&total, c->h_small + 8, 8);
+        if (total > out->capacity) {
+          if (total_out) *total_out = total;
+          return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
+                      (unsigned long long)out->capacity, (unsigned long long)total);
+        }
+        a.read_dirty = d_flags;
+        a.read_off = d_roff;
+        const size_t dyn2 = dyn + (size_t)rpt * 8;
+        if (k <= 16) rc = launch_seed_fixed(c, seed_fixed_kernel<1, true>, a, dyn2);
+        else if (k <= 32) rc = launch_seed_fixed(c, seed_fixed_kernel<2, true>, a, dyn2);
+        else if (k <= 48) rc = launch_seed_fixed(c, seed_fixed_kernel<3, true>, a, dyn2);
+        else rc = launch_seed_fixed(c, seed_fixed_kernel<4, true>, a, dyn2);
+        NTCHK(rc);
+        if (n_dirty) {
+          h.counts = nullptr;
+          h.read_off = d_roff;
+          h.hashes = st.hashes;
+          h.capacity = out->capacity;
+          HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+          hipLaunchKernelGGL(seed_general_kernel<false>, dim3(lblocks), dim3(256), 0, c->stream,
+                             (const SeedGeneralArgs*)c->d_args);
+          HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        done = true;
       }
     }
   }

@@ -43,10 +43,63 @@ struct SeedFixedArgs {
   uint32_t inv_nwin;      // floor(2^32 / nwin) + 1 (for q / nwin)
   uint32_t bits_dwords;   // LDS dwords reserved for the slab's bit stream
   uint64_t mult[SF_MAX_RUNTIME_M];
+  // SPLIT instantiation (batches with non-bases): reads flagged dirty are left to seed_general_kernel, the
+  // records of a clean read go to its own place in the compact stream
+  const uint64_t* read_dirty; // [run] != 0: the read has a byte that is not ACGTU
+  const uint64_t* read_off;   // [run] index of the read's first k-mer in the compact stream
 };
 
+// Which fixed-length reads contain a byte that is not a base?  One 16-byte vector per thread; a byte
+// belongs to every read whose [r*stride, r*stride + len) covers it (overlapping reads when stride < len).
+__global__ __launch_bounds__(256) void seed_mark_dirty_kernel(const uint8_t* __restrict__ seqs, uint64_t total_bytes,
+                                                             uint32_t len, uint32_t stride, uint64_t n_reads,
+                                                             uint64_t* __restrict__ flags)
+{
+  const uint64_t n_vec = (total_bytes + 15) >> 4;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t off = i << 4;
+    uint32_t badmask = 0; // bit b: byte off + b is not a base
+    if (off + 16 <= total_bytes) {
+      uint4 v;
+      __builtin_memcpy(&v, seqs + off, 16);
+      uint32_t bx[4] = {0, 0, 0, 0};
+      (void)pack4(v.x, bx[0]);
+      (void)pack4(v.y, bx[1]);
+      (void)pack4(v.z, bx[2]);
+      (void)pack4(v.w, bx[3]);
+      if ((bx[0] | bx[1] | bx[2] | bx[3]) == 0) continue;
+      for (int q = 0; q < 16; ++q)
+        if ((bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu) badmask |= 1u << q;
+    } else {
+      for (uint32_t b = 0; off + b < total_bytes; ++b)
+        if (!is_base(seqs[off + b])) badmask |= 1u << b;
+    }
+    while (badmask) {
+      const uint32_t b = (uint32_t)__builtin_ctz(badmask);
+      badmask &= badmask - 1;
+      const uint64_t pos = off + b;
+      uint64_t r_hi = pos / stride;
+      if (r_hi >= n_reads) r_hi = n_reads - 1;
+      for (uint64_t r = r_hi;; --r) { // every read that covers the byte
+        if (pos >= r * stride + len) break;
+        flags[r] = 1;
+        if (r == 0) break;
+      }
+    }
+  }
+}
+
+// list[idx[r]] = r for the flagged reads (idx = exclusive scan of the flags)
+__global__ __launch_bounds__(256) void seed_list_kernel(const uint64_t* __restrict__ flags, const uint64_t* __restrict__ idx,
+                                                       uint64_t n_reads, uint64_t* __restrict__ list)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_reads && flags[r]) list[idx[r]] = r;
+}
+
 // NW = 32-bit words of 2-bit window kept in registers: k <= 16*NW
-template <int NW>
+// SPLIT: skip the reads flagged in a.read_dirty, write every other read at a.read_off (compact stream)
+template <int NW, bool SPLIT = false>
 __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
@@ -63,6 +116,9 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
 
   const uint32_t per = a.n_seeds * a.m2; // values per window
   uint64_t* otile = (uint64_t*)(bits + a.bits_dwords) + wave * 64u * per;
+  // SPLIT: the tile's reads -- offset in the compact stream, or ~0 for a read left to the general kernel
+  uint64_t* roff = (uint64_t*)(bits + a.bits_dwords) + (SF_THREADS / 64u) * 64u * per;
+  const uint32_t inv_per = 0xFFFFFFFFu / per + 1u; // v / per == umulhi(v, inv_per) for v < 2^29
   uint32_t bad = 0;
 
   for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
@@ -96,6 +152,16 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
       bits[i] = p;
     }
     if (tid < NW + 1) bits[n_vec + tid] = 0;
+    if (!SPLIT) {
+      // optimistic pass: publish a non-base at once and stop producing a dense stream nobody will read
+      // (some block already found one: the caller redoes the batch on the split path)
+      if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
+      if (__hip_atomic_load(a.dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+    }
+    if (SPLIT) {
+      for (uint32_t i = tid; i < runs_here; i += SF_THREADS)
+        roff[i] = a.read_dirty[run0 + i] ? ~0ull : a.read_off[run0 + i];
+    }
     __syncthreads();
 
     // Every wave takes 64 consecutive windows at a time: their per*8-byte records are
@@ -181,11 +247,28 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
       const uint32_t n_here = (n_win_tile - q0) < 64u ? (n_win_tile - q0) : 64u;
       const uint32_t n_vals = n_here * per;
-      uint64_t* dst = a.hashes + (run0 * a.nwin + q0) * per;
-      for (uint32_t pi = lane; 2u * pi < n_vals; pi += 64u) {
-        const uint4 dv = *(const uint4*)(otile + 2u * pi);
-        if (2u * pi + 1u < n_vals) *(uint4*)(dst + 2u * pi) = dv;
-        else *(uint2*)(dst + 2u * pi) = make_uint2(dv.x, dv.y);
+      if (SPLIT) {
+        // every value finds its read's place in the compact stream (16 bytes at a time when records are even)
+        const uint32_t step = (per & 1u) ? 1u : 2u;
+        for (uint32_t v = lane * step; v < n_vals; v += 64u * step) {
+          const uint32_t wv = per == 1u ? v : __umulhi(v, inv_per); // window inside the group (inv_per wraps for per = 1)
+          const uint32_t vi = v - wv * per;                          // value inside the record
+          const uint32_t wq = q0 + wv;
+          uint32_t lr2 = a.nwin == 1u ? wq : __umulhi(wq, a.inv_nwin);
+          if (lr2 * a.nwin > wq) lr2--;
+          const uint64_t ro = roff[lr2];
+          if (ro == ~0ull) continue;
+          uint64_t* d = a.hashes + (ro + (wq - lr2 * a.nwin)) * per + vi;
+          if (step == 2u) *(uint4*)d = *(const uint4*)(otile + v);
+          else *d = otile[v];
+        }
+      } else {
+        uint64_t* dst = a.hashes + (run0 * a.nwin + q0) * per;
+        for (uint32_t pi = lane; 2u * pi < n_vals; pi += 64u) {
+          const uint4 dv = *(const uint4*)(otile + 2u * pi);
+          if (2u * pi + 1u < n_vals) *(uint4*)(dst + 2u * pi) = dv;
+          else *(uint2*)(dst + 2u * pi) = make_uint2(dv.x, dv.y);
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
@@ -199,6 +282,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
 // --------------------------------------------------------------------------
 struct SeedGeneralArgs {
   const uint8_t* seqs;
+  const uint64_t* read_list;  // optional: only these reads (n_reads = length of the list)
   const uint64_t* offsets;    // n_reads+1 offsets, or (with ends) the first byte of every read
   const uint64_t* ends;       // optional: read r = [offsets[r], ends[r]) -- spans of one buffer
   uint64_t n_reads;
@@ -237,8 +321,9 @@ template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256) void seed_general_kernel(const SeedGeneralArgs* __restrict__ ap)
 {
   const SeedGeneralArgs& a = *ap;
-  const uint64_t rid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (rid >= a.n_reads) return;
+  const uint64_t item = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= a.n_reads) return;
+  const uint64_t rid = a.read_list ? a.read_list[item] : item;
   uint64_t start, len;
   if (a.offsets) {
     start = a.offsets[rid];

@@ -1077,3 +1077,34 @@ def test_bloom_long_k_many_hashes(ctx, oracle):
     hits, total, found = ctx.bloom_query(data, k, m, L, n, d_f, n_bits)
     assert total == found == want["total"] and (hits == want["counts"]).all()
     ctx.free(d_f)
+
+
+@pytest.mark.parametrize("n,L,seeds,m2,stride", [
+    (3000, 250, [SEED_A, SEED_B], 3, 0),          # BASELINE config 4 shape with N's
+    (2000, 150, [SEED_A], 1, 0),                   # one seed, one hash: odd record size
+    (1500, 100, ["110011", "101101", "111111"], 1, 0), (800, 64, ["1111111111111110111111111111111"], 2, 0),
+    (500, 250, [SEED_A, SEED_B], 2, 220),          # overlapping runs: a bad byte lies in two reads
+    (70, 40, ["10101", "11011"], 4, 0),
+])
+def test_seed_dirty_fixed_length_split_path(ctx, oracle, n, L, seeds, m2, stride):
+    """fixed-length batch with non-bases (N, IUPAC, NUL): the reads that have one go through the reference's
+    position state machine, the others stay on the fast kernel, writing into one compact stream"""
+    rng = np.random.default_rng(n + L)
+    k = len(seeds[0])
+    total_bytes = n * L if not stride else (n - 1) * stride + L
+    data = oracle.synth_reads(0, 1, total_bytes, 5).copy()
+    nbad = max(5, total_bytes // 4000)
+    data[rng.choice(total_bytes, nbad, replace=False)] = np.frombuffer(b"NnRYKMSW-\x00", dtype=np.uint8)[rng.integers(0, 10, nbad)]
+    data[0] = ord("N"); data[-1] = ord("n")
+    st_ = stride or L
+    reads = [data[i * st_: i * st_ + L].tobytes() for i in range(n)]
+    d, offs = concat_reads(reads)
+    want = oracle.seed_batch(d, offs, seeds, k, m2, want_pos=False)
+    ctx.set_profiling(True)
+    got = ctx.seed_hash(data, seeds, k, m2, fixed_len=L, stride=stride, n_reads=n)
+    name = ctx.last_kernel_ms()[1]
+    ctx.set_profiling(False)
+    assert name == "seed_fixed_kernel", name          # not the all-reads general fallback
+    assert got["total"] == want["total"]
+    assert (got["counts"] == want["counts"]).all()
+    assert (got["hashes"] == want["hashes"]).all()
