@@ -1360,6 +1360,8 @@ int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, cons
   h.blk_start = sd->d_blk_start;
   h.blk_count = sd->d_blk_count;
   h.blk_pairs = sd->d_blk_pairs;
+  h.tables = sd->d_tables;
+  h.ntab = sd->ntab;
   for (uint32_t i = 0; i < 256; ++i) h.mult[i] = multiplier(sd->k, i);
   const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   NTCHK(ensure_scratch(c, 2 * n + nb + 16));
@@ -1543,6 +1545,8 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
         h.blk_start = sd->d_blk_start;
         h.blk_count = sd->d_blk_count;
         h.blk_pairs = sd->d_blk_pairs;
+        h.tables = sd->d_tables;
+        h.ntab = sd->ntab;
         for (uint32_t i = 0; i < 256; ++i) h.mult[i] = multiplier(k, i);
         NTCHK(ensure_args(c, sizeof(SeedGeneralArgs)));
         const unsigned lblocks = (unsigned)((n_dirty + 255) / 256);

@@ -293,6 +293,8 @@ struct SeedGeneralArgs {
   const uint32_t* blk_start;  // [seed] index into blk_pairs
   const uint32_t* blk_count;  // [seed]
   const uint32_t* blk_pairs;  // [start,end) pairs in get_blocks order (src/seed.cpp:19-66)
+  const uint4* tables;        // optional: [seed][ntab][256] byte tables (windows made of bases only)
+  uint32_t ntab, pad1;
   const uint64_t* read_off;
   uint64_t* counts;
   uint64_t* hashes;
@@ -354,16 +356,31 @@ __global__ __launch_bounds__(256) void seed_general_kernel(const SeedGeneralArgs
         const uint64_t o = base + emitted;
         if (o < a.capacity) {
           const uint8_t* win = s + pos;
+          // a window of bases only (almost all of them) is hashed from the byte tables, 4 bases per lookup;
+          // one with a non-base needs the per-character seed values (SEED_TAB), position by position
+          bool all_bases = a.tables != nullptr;
+          for (uint32_t p = 0; p < k && all_bases; ++p) all_bases = is_base(win[p]);
           for (uint32_t sd = 0; sd < a.n_seeds; ++sd) {
             const uint32_t* care = a.care_bits + sd * a.care_words;
             uint64_t fh = 0, rh = 0;
-            for (uint32_t p = 0; p < k; ++p) { // Horner: F = XOR srol^{k-1-p}(S[c_p])
-              const bool c = (care[p >> 5] >> (p & 31u)) & 1u;
-              fh = srol1(fh) ^ (c ? fwd_seed(win[p]) : 0);
-            }
-            for (uint32_t p = k; p-- > 0;) {   // R = XOR srol^{p}(S[c_p & 7])
-              const bool c = (care[p >> 5] >> (p & 31u)) & 1u;
-              rh = srol1(rh) ^ (c ? rc_seed(win[p]) : 0);
+            if (all_bases) {
+              const uint4* ts = a.tables + (size_t)sd * a.ntab * 256u;
+              for (uint32_t jt = 0; jt < a.ntab; ++jt) {
+                uint32_t byte = 0;
+                for (uint32_t q = 0; q < 4u && 4u * jt + q < k; ++q) byte |= ((win[4u * jt + q] >> 1) & 3u) << (2u * q);
+                const uint4 e = ts[jt * 256u + byte];
+                fh ^= ((uint64_t)e.y << 32) | e.x;
+                rh ^= ((uint64_t)e.w << 32) | e.z;
+              }
+            } else {
+              for (uint32_t p = 0; p < k; ++p) { // Horner: F = XOR srol^{k-1-p}(S[c_p])
+                const bool c = (care[p >> 5] >> (p & 31u)) & 1u;
+                fh = srol1(fh) ^ (c ? fwd_seed(win[p]) : 0);
+              }
+              for (uint32_t p = k; p-- > 0;) {   // R = XOR srol^{p}(S[c_p & 7])
+                const bool c = (care[p >> 5] >> (p & 31u)) & 1u;
+                rh = srol1(rh) ^ (c ? rc_seed(win[p]) : 0);
+              }
             }
             const uint64_t h0 = fh + rh;
             if (a.fwd) a.fwd[o * a.n_seeds + sd] = fh;
