@@ -1340,6 +1340,54 @@ extern "C" int nthip_seeds_destroy(nthip_seeds* sd)
 
 namespace {
 
+// seed_wave_kernel (one wave per read): reads of at most SEED_WAVE_LMAX bytes, k <= 64, no strand outputs.
+constexpr uint32_t SEED_WAVE_LMAX = 2048;
+struct SeedWavePlan {
+  uint32_t nw = 0, waves_count = 0, waves_hash = 0;
+  size_t lds_count = 0, lds_hash = 0;
+};
+bool seed_wave_plan(const nthip_ctx* c, const nthip_seeds* sd, uint32_t m2, SeedWavePlan* p)
+{
+  if (sd->k > 64 || sd->k < 2) return false;
+  const uint32_t per = sd->n_seeds * m2, lmax = SEED_WAVE_LMAX;
+  const uint32_t raw_dw = (lmax + 64u) >> 2, code_dw = (lmax >> 4) + 8u, bit_dw = (lmax >> 5) + 8u;
+  const size_t pw_count = (size_t)((raw_dw + code_dw + 2u * bit_dw + 3u) & ~3u) * 4;
+  const size_t pw_hash = (size_t)((raw_dw + code_dw + 2u * bit_dw + 64u * per * 2u + 3u) & ~3u) * 4;
+  const size_t tables = (size_t)sd->n_seeds * sd->ntab * 256 * sizeof(uint4);
+  const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
+  p->nw = (sd->k + 15) / 16;
+  for (uint32_t w = 16; w >= 1; --w)
+    if (pw_count * w <= cap) { p->waves_count = w; p->lds_count = pw_count * w; break; }
+  for (uint32_t w = 16; w >= 2; --w)
+    if (tables + pw_hash * w <= cap) { p->waves_hash = w; p->lds_hash = tables + pw_hash * w; break; }
+  return p->waves_count && p->waves_hash;
+}
+template <bool COUNT_ONLY>
+int launch_seed_wave(nthip_ctx* c, const SeedWavePlan& plan, uint64_t n_items, bool record = true)
+{
+  const uint32_t waves = COUNT_ONLY ? plan.waves_count : plan.waves_hash;
+  const size_t lds = COUNT_ONLY ? plan.lds_count : plan.lds_hash;
+  auto go = [&](auto kernel) -> int {
+    int per_cu = 1;
+    NTCHK(blocks_per_cu(c, kernel, (int)waves * 64, lds, &per_cu));
+    const uint64_t need = (n_items + waves - 1) / waves;
+    uint64_t grid = (uint64_t)c->n_cu * per_cu;
+    if (grid > need) grid = need;
+    if (!COUNT_ONLY && record) prof_begin(c, "seed_wave_kernel");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream,
+                       (const SeedGeneralArgs*)c->d_args);
+    if (!COUNT_ONLY && record) prof_end(c);
+    HIPCHK(hipGetLastError());
+    return NTHIP_OK;
+  };
+  switch (plan.nw) {
+    case 1: return go(seed_wave_kernel<COUNT_ONLY, 1>);
+    case 2: return go(seed_wave_kernel<COUNT_ONLY, 2>);
+    case 3: return go(seed_wave_kernel<COUNT_ONLY, 3>);
+    default: return go(seed_wave_kernel<COUNT_ONLY, 4>);
+  }
+}
+
 int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd,
                      uint32_t m2, uint64_t capacity, uint64_t* total, const uint64_t* d_ends = nullptr)
 {
@@ -1371,11 +1419,34 @@ int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, cons
   uint64_t* d_total = (uint64_t*)(c->d_small + 8);
   NTCHK(ensure_args(c, sizeof(SeedGeneralArgs)));
   const unsigned blocks = (unsigned)((n + 255) / 256);
+  // one wave per read (seed_wave_kernel) when every read fits its LDS staging and no strand output is wanted;
+  // the lane-per-read kernel otherwise
+  SeedWavePlan wplan;
+  bool use_wave = !st.fwd && !st.rev && !getenv("NTHIP_TUNE_NO_SEED_WAVE") && seed_wave_plan(c, sd, m2, &wplan);
+  if (use_wave) {
+    uint64_t max_len = h.len;
+    if (st.offsets) {
+      unsigned long long* d_max = (unsigned long long*)(c->d_small + 48);
+      HIPCHK(hipMemsetAsync(d_max, 0, 8, c->stream));
+      hipLaunchKernelGGL(max_len_kernel, dim3(c->n_cu * 4), dim3(256), 0, c->stream, st.offsets, d_ends, n, d_max);
+      HIPCHK(hipMemcpyAsync(c->h_small + 48, d_max, 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      memcpy(&max_len, c->h_small + 48, 8);
+    }
+    use_wave = max_len <= SEED_WAVE_LMAX;
+  }
+  h.wave_lmax = SEED_WAVE_LMAX;
   h.counts = d_counts;
-  HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(seed_general_kernel<true>, dim3(blocks), dim3(256), 0, c->stream,
-                     (const SeedGeneralArgs*)c->d_args);
-  HIPCHK(hipGetLastError());
+  if (use_wave) {
+    h.wave_waves = wplan.waves_count;
+    HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    NTCHK(launch_seed_wave<true>(c, wplan, n));
+  } else {
+    HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(seed_general_kernel<true>, dim3(blocks), dim3(256), 0, c->stream,
+                       (const SeedGeneralArgs*)c->d_args);
+    HIPCHK(hipGetLastError());
+  }
   NTCHK(device_exclusive_scan(c, d_counts, d_off, n, d_sums, d_total));
   HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1390,12 +1461,18 @@ int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, cons
   h.fwd = st.fwd;
   h.rev = st.rev;
   h.capacity = capacity;
-  HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
-  prof_begin(c, "seed_general_kernel");
-  hipLaunchKernelGGL(seed_general_kernel<false>, dim3(blocks), dim3(256), 0, c->stream,
-                     (const SeedGeneralArgs*)c->d_args);
-  prof_end(c);
-  HIPCHK(hipGetLastError());
+  if (use_wave) {
+    h.wave_waves = wplan.waves_hash;
+    HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    NTCHK(launch_seed_wave<false>(c, wplan, n));
+  } else {
+    HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    prof_begin(c, "seed_general_kernel");
+    hipLaunchKernelGGL(seed_general_kernel<false>, dim3(blocks), dim3(256), 0, c->stream,
+                       (const SeedGeneralArgs*)c->d_args);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   return NTHIP_OK;
 }
@@ -1550,12 +1627,20 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
         for (uint32_t i = 0; i < 256; ++i) h.mult[i] = multiplier(k, i);
         NTCHK(ensure_args(c, sizeof(SeedGeneralArgs)));
         const unsigned lblocks = (unsigned)((n_dirty + 255) / 256);
+        SeedWavePlan wplan;
+        const bool list_wave = len <= SEED_WAVE_LMAX && !getenv("NTHIP_TUNE_NO_SEED_WAVE") && seed_wave_plan(c, sd, m2, &wplan);
+        h.wave_lmax = SEED_WAVE_LMAX;
         if (n_dirty) {
           h.counts = d_cnt;
+          h.wave_waves = wplan.waves_count;
           HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
-          hipLaunchKernelGGL(seed_general_kernel<true>, dim3(lblocks), dim3(256), 0, c->stream,
-                             (const SeedGeneralArgs*)c->d_args);
-          HIPCHK(hipGetLastError());
+          if (list_wave) {
+            NTCHK(launch_seed_wave<true>(c, wplan, n_dirty));
+          } else {
+            hipLaunchKernelGGL(seed_general_kernel<true>, dim3(lblocks), dim3(256), 0, c->stream,
+                               (const SeedGeneralArgs*)c->d_args);
+            HIPCHK(hipGetLastError());
+          }
         }
         NTCHK(device_exclusive_scan(c, d_cnt, d_roff, n, d_sums, d_total));
         HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1579,10 +1664,15 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
           h.read_off = d_roff;
           h.hashes = st.hashes;
           h.capacity = out->capacity;
+          h.wave_waves = wplan.waves_hash;
           HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
-          hipLaunchKernelGGL(seed_general_kernel<false>, dim3(lblocks), dim3(256), 0, c->stream,
-                             (const SeedGeneralArgs*)c->d_args);
-          HIPCHK(hipGetLastError());
+          if (list_wave) {
+            NTCHK(launch_seed_wave<false>(c, wplan, n_dirty, /*record*/ false)); // kernel of record: seed_fixed_kernel
+          } else {
+            hipLaunchKernelGGL(seed_general_kernel<false>, dim3(lblocks), dim3(256), 0, c->stream,
+                               (const SeedGeneralArgs*)c->d_args);
+            HIPCHK(hipGetLastError());
+          }
         }
         HIPCHK(hipStreamSynchronize(c->stream));
         done = true;

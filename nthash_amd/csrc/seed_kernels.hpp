@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kmer_kernels.hpp" // pack16 / funnel
+#include "kmer_runs_gen_kernel.hpp" // pack4v, windows_with_non_base
 #include "nt_math.hpp"
 
 namespace ntamd {
@@ -295,6 +296,7 @@ struct SeedGeneralArgs {
   const uint32_t* blk_pairs;  // [start,end) pairs in get_blocks order (src/seed.cpp:19-66)
   const uint4* tables;        // optional: [seed][ntab][256] byte tables (windows made of bases only)
   uint32_t ntab, pad1;
+  uint32_t wave_lmax, wave_waves; // seed_wave_kernel: longest read it stages, waves per block
   const uint64_t* read_off;
   uint64_t* counts;
   uint64_t* hashes;
@@ -404,6 +406,218 @@ __global__ __launch_bounds__(256) void seed_general_kernel(const SeedGeneralArgs
     }
   }
   if (a.counts) a.counts[rid] = emitted;
+}
+
+
+// --------------------------------------------------------------------------
+// seed_wave_kernel: one WAVE per read, one lane per window -- SeedNtHash on reads of any (bounded) length,
+// given as offsets, spans or fixed length, with or without non-bases.  The exact semantics of the reference
+// without its sequential walk:
+//   * the emitted positions.  SeedNtHash::roll() only looks at the INCOMING character (src/seed.cpp:518-544):
+//     a non-base at q makes it jump to the window that starts AT q, but only if position q-k was visited,
+//     i.e. q >= (previous jump target) + k, the first one q >= k.  These "triggers" are found by one pass
+//     over the read's non-bases (usually none); window p is emitted iff no trigger lies in (p, p+k).
+//     (Reads containing NUL follow init()'s extra rule, src/seed.cpp:146-158,493-516: lane 0 walks those.)
+//   * the values.  A window of bases only is hashed from the per-seed byte tables as in seed_fixed_kernel;
+//     a window holding a non-base (emitted all the same) needs the per-character seed values of
+//     SEED_TAB: Horner over its k raw bytes (rare, divergent).
+// Emitted records are compacted per 64 windows through a wave-private LDS tile and written contiguously at
+// the read's scanned offset.  COUNT_ONLY: just the emitted count per read.
+// --------------------------------------------------------------------------
+template <bool COUNT_ONLY, int NW>
+__global__ __launch_bounds__(1024) void seed_wave_kernel(const SeedGeneralArgs* __restrict__ ap)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const SeedGeneralArgs& a = *ap;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t k = a.k, per = a.n_seeds * a.m2, lmax = a.wave_lmax;
+  // LDS: [tables] | per wave { raw bytes | codes | validity | triggers / emission | record tile }
+  uint4* tabs = (uint4*)lds_dyn;
+  const uint32_t n_entries = COUNT_ONLY ? 0u : a.n_seeds * a.ntab * 256u;
+  const uint32_t raw_dw = (lmax + 64u) >> 2, code_dw = (lmax >> 4) + 8u, bit_dw = (lmax >> 5) + 8u;
+  const uint32_t tile_dw = COUNT_ONLY ? 0u : 64u * per * 2u;
+  const uint32_t per_wave = (raw_dw + code_dw + 2u * bit_dw + tile_dw + 3u) & ~3u;
+  uint32_t* wb = lds_dyn + n_entries * 4u + wave * per_wave;
+  uint8_t* raw = (uint8_t*)wb;
+  uint32_t* bits = wb + raw_dw;
+  uint32_t* vbits = bits + code_dw;
+  uint32_t* tbits = vbits + bit_dw;
+  uint64_t* otile = (uint64_t*)(wb + ((raw_dw + code_dw + 2u * bit_dw + 3u) & ~3u));
+  if (!COUNT_ONLY) {
+    for (uint32_t i = tid; i < n_entries; i += blockDim.x) tabs[i] = a.tables[i];
+  }
+  __syncthreads();
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+  const uint64_t per_block = (a.n_reads + gridDim.x - 1) / gridDim.x;
+  const uint64_t i_begin = (uint64_t)blockIdx.x * per_block;
+  const uint64_t i_end = i_begin + per_block < a.n_reads ? i_begin + per_block : a.n_reads;
+  for (uint64_t item = i_begin + wave; item < i_end; item += a.wave_waves) {
+    const uint64_t rid = a.read_list ? a.read_list[item] : item;
+    uint64_t start, len64;
+    if (a.offsets) {
+      start = a.offsets[rid];
+      const uint64_t end = a.ends ? a.ends[rid] : a.offsets[rid + 1];
+      len64 = end > start ? end - start : 0;
+    } else {
+      start = rid * a.stride;
+      len64 = a.len;
+    }
+    const uint32_t len = (uint32_t)len64; // the launcher guarantees len <= wave_lmax
+    if (len < k) {
+      if (COUNT_ONLY && lane == 0) a.counts[rid] = 0;
+      continue;
+    }
+    const uint32_t nwin = len - k + 1u;
+    const uint8_t* s = a.seqs + start;
+    lds_sync();
+    // ---- stage the read: raw bytes, 2-bit codes, validity bits -------------------------------------
+    uint32_t f_bad = 0, f_nul = 0;
+    const uint32_t n_vec = (len + 15u) >> 4;
+    for (uint32_t i = lane; i < n_vec; i += 64u) {
+      uint4 x;
+      if (16u * i + 16u <= len) {
+        __builtin_memcpy(&x, s + 16u * i, 16);
+      } else {
+        uint32_t wv[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u}; // 'A' padding past the read
+        for (uint32_t b = 0; 16u * i + b < len; ++b) {
+          wv[b >> 2] &= ~(0xFFu << ((b & 3u) * 8u));
+          wv[b >> 2] |= (uint32_t)s[16u * i + b] << ((b & 3u) * 8u);
+        }
+        x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      }
+      *(uint4*)(raw + 16u * i) = x;
+      uint32_t i0, i1, i2, i3;
+      const uint32_t c0 = pack4v(x.x, i0), c1 = pack4v(x.y, i1), c2 = pack4v(x.z, i2), c3 = pack4v(x.w, i3);
+      bits[i] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+      const uint32_t inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
+      ((uint16_t*)vbits)[i] = (uint16_t)inv16;
+      f_bad |= inv16;
+      auto has_zero = [](uint32_t w) { return ((w - 0x01010101u) & ~w & 0x80808080u) != 0u; };
+      if (inv16 && (has_zero(x.x) || has_zero(x.y) || has_zero(x.z) || has_zero(x.w))) f_nul = 1;
+    }
+    if (lane < 12u) { bits[n_vec + (lane & 7u)] = 0; ((uint16_t*)vbits)[n_vec + lane] = 0; }
+    for (uint32_t i = lane; i < ((len + 31u) >> 5) + 6u; i += 64u) tbits[i] = 0;
+    const bool any_bad = __ballot(f_bad != 0) != 0;
+    const bool any_nul = __ballot(f_nul != 0) != 0;
+    lds_sync();
+    if (any_nul) {
+      // init()'s NUL rule makes the walk sequential: lane 0 runs the reference's state machine over
+      // positions only and marks the emitted ones in tbits
+      if (lane == 0) {
+        uint32_t pos = 0;
+        auto init = [&]() -> bool {
+          uint32_t where = 0;
+          while (pos < nwin && seed_first_nul(a, raw + pos, &where)) pos += where + 1;
+          return !(pos > len - k);
+        };
+        bool ok = init();
+        while (ok) {
+          tbits[pos >> 5] |= 1u << (pos & 31u);
+          if (pos >= len - k) break;
+          if (!is_base(raw[pos + k])) { pos += k; ok = init(); }
+          else pos++;
+        }
+      }
+    } else if (any_bad) {
+      // triggers: a non-base q with q >= (previous trigger, 0 at the start) + k
+      if (lane == 0) {
+        uint32_t last = 0;
+        for (uint32_t w = 0; 32u * w < len; ++w) {
+          uint32_t word = vbits[w];
+          while (word) {
+            const uint32_t q = 32u * w + (uint32_t)__builtin_ctz(word);
+            word &= word - 1u;
+            if (q >= len) break;
+            if (q >= last + k) { last = q; tbits[q >> 5] |= 1u << (q & 31u); }
+          }
+        }
+      }
+    }
+    lds_sync();
+    // ---- the windows, 64 at a time ---------------------------------------------------------------------
+    uint64_t emitted_before = 0;
+    const uint64_t obase = COUNT_ONLY ? 0 : a.read_off[rid];
+    for (uint32_t w0 = 0; w0 < nwin; w0 += 64u) {
+      const uint32_t p = w0 + lane;
+      const bool in = p < nwin;
+      const uint32_t pc = in ? p : 0u;
+      bool emit;
+      if (any_nul) emit = in && ((tbits[pc >> 5] >> (pc & 31u)) & 1u);
+      else emit = in && (!any_bad || (windows_with_non_base(tbits, pc + 1u, k - 1u) & 1u) == 0u);
+      const uint64_t eb = __ballot(emit);
+      const uint32_t n_e = (uint32_t)__builtin_popcountll(eb);
+      if (COUNT_ONLY) { emitted_before += n_e; continue; }
+      if (n_e == 0) continue;
+      const uint32_t slot = (uint32_t)__builtin_popcountll(eb & ((1ull << lane) - 1ull));
+      if (emit) {
+        const bool dirty_win = any_bad && (windows_with_non_base(vbits, pc, k) & 1u);
+        uint64_t* mine = otile + slot * per;
+        uint32_t wwords[NW];
+        if (!dirty_win) {
+          const uint32_t d = pc >> 4, sh = (pc & 15u) << 1;
+          uint32_t lo = bits[d];
+#pragma unroll
+          for (int i = 0; i < NW; ++i) {
+            const uint32_t hi = bits[d + i + 1];
+            wwords[i] = funnel(hi, lo, sh);
+            lo = hi;
+          }
+        }
+        for (uint32_t sdx = 0; sdx < a.n_seeds; ++sdx) {
+          uint64_t fh = 0, rh = 0;
+          if (!dirty_win) {
+            const uint4* ts = tabs + sdx * a.ntab * 256u;
+            uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
+#pragma unroll
+            for (int jt = 0; jt < 4 * NW; ++jt) {
+              if ((uint32_t)jt < a.ntab) {
+                const uint32_t byte = (wwords[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+                const uint4 e = ts[(uint32_t)jt * 256u + byte];
+                f0 ^= e.x; f1 ^= e.y; r0 ^= e.z; r1 ^= e.w;
+              }
+            }
+            fh = ((uint64_t)f1 << 32) | f0;
+            rh = ((uint64_t)r1 << 32) | r0;
+          } else {
+            const uint32_t* care = a.care_bits + sdx * a.care_words;
+            const uint8_t* win = raw + pc;
+            for (uint32_t q = 0; q < k; ++q) {
+              const bool c = (care[q >> 5] >> (q & 31u)) & 1u;
+              fh = srol1(fh) ^ (c ? fwd_seed(win[q]) : 0);
+            }
+            for (uint32_t q = k; q-- > 0;) {
+              const bool c = (care[q >> 5] >> (q & 31u)) & 1u;
+              rh = srol1(rh) ^ (c ? rc_seed(win[q]) : 0);
+            }
+          }
+          const uint64_t h0 = fh + rh;
+          mine[sdx * a.m2] = h0;
+          for (uint32_t jj = 1; jj < a.m2; ++jj) mine[sdx * a.m2 + jj] = mix_hash(h0, a.mult[jj]);
+        }
+        if (a.pos) a.pos[obase + emitted_before + slot] = pc;
+      }
+      lds_sync();
+      const uint32_t n_vals = n_e * per;
+      uint64_t* dst = a.hashes + (obase + emitted_before) * per;
+      if ((((uint64_t)(uintptr_t)dst) & 15u) == 0u) {
+        for (uint32_t pi = lane; 2u * pi < n_vals; pi += 64u) {
+          const uint4 dv = *(const uint4*)(otile + 2u * pi);
+          if (2u * pi + 1u < n_vals) *(uint4*)(dst + 2u * pi) = dv;
+          else *(uint2*)(dst + 2u * pi) = make_uint2(dv.x, dv.y);
+        }
+      } else {
+        for (uint32_t v = lane; v < n_vals; v += 64u) dst[v] = otile[v];
+      }
+      emitted_before += n_e;
+      lds_sync();
+    }
+    if (COUNT_ONLY && lane == 0) a.counts[rid] = emitted_before;
+  }
 }
 
 } // namespace ntamd
