@@ -14,6 +14,7 @@ from nthash_amd.capi import NTHIP_FASTQ
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 chunk = (int(sys.argv[2]) if len(sys.argv) > 2 else 256) << 20
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+use_seeds = len(sys.argv) > 4 and sys.argv[4] == "seeds"   # SeedNtHash, BASELINE config 4 seeds, m hashes per seed
 L, k = 150, 31
 ctx = nthash_amd.Context(0)
 d_in = ctx.malloc(n * L)
@@ -38,8 +39,9 @@ t0 = time.perf_counter()
 rec.tofile(path)
 print(f"wrote {rec.nbytes/1e9:.2f} GB in {time.perf_counter()-t0:.1f} s -> {path}", flush=True)
 del rec, seqs
+sd = nthash_amd.Seeds(ctx, ["1010101010101010101010101010101", "1101101101101101011011011011011"], k) if use_seeds else None
 for it in range(3):
-    st = ctx.fastx_kmer_hash_file(path, NTHIP_FASTQ, k, m, chunk_bytes=chunk)
+    st = ctx.fastx_kmer_hash_file(path, NTHIP_FASTQ, k, m, chunk_bytes=chunk, seeds=sd)
     print(f"run {it}: {st.seconds*1e3:8.1f} ms  {st.file_bytes/st.seconds/1e9:6.2f} GB/s of file  "
           f"{st.reads/st.seconds/1e6:7.1f} M reads/s  {st.kmers/st.seconds/1e9:6.2f} G k-mers/s  "
           f"(batches {st.batches}, pread {st.read_seconds*1e3:.0f} ms, index+hash {st.gpu_seconds*1e3:.0f} ms)", flush=True)
