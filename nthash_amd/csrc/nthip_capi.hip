@@ -1723,10 +1723,32 @@ extern "C" int nthip_kmer_extend(nthip_ctx* c, const char* kmers, uint64_t n, ui
     if (rc == NTHIP_OK && prev) rc = dev_alloc(n * 4 * m * 8, (void**)&d_prev);
   }
   if (rc != NTHIP_OK) { cleanup(); return rc; }
-  prof_begin(c, "kmer_extend_kernel");
-  hipLaunchKernelGGL(kmer_extend_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, k, m,
-                     d_self, d_next, d_prev);
-  prof_end(c);
+  const bool aligned16 = (!d_next || ((uintptr_t)d_next & 15u) == 0) && (!d_prev || ((uintptr_t)d_prev & 15u) == 0);
+  if (k <= 64 && aligned16) {
+    // byte tables in LDS, 16-byte neighbour stores
+    const uint4* tab = nullptr;
+    if (get_init_tab(c, k, &tab) != NTHIP_OK) { cleanup(); return NTHIP_ERR_HIP; }
+    const uint32_t ntab = (k + 3) / 4;
+    const size_t lds = (size_t)ntab * 4096;
+    uint64_t blocks = (n + 1023) / 1024;
+    if (blocks > (uint64_t)c->n_cu * 2) blocks = (uint64_t)c->n_cu * 2;
+    auto go = [&](auto kernel) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      prof_begin(c, "kmer_extend_tab_kernel");
+      hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(1024), lds, c->stream, d_in, n, k, m, tab, ntab, d_self,
+                         d_next, d_prev);
+      prof_end(c);
+    };
+    if (k <= 16) go(kmer_extend_tab_kernel<1>);
+    else if (k <= 32) go(kmer_extend_tab_kernel<2>);
+    else if (k <= 48) go(kmer_extend_tab_kernel<3>);
+    else go(kmer_extend_tab_kernel<4>);
+  } else {
+    prof_begin(c, "kmer_extend_kernel");
+    hipLaunchKernelGGL(kmer_extend_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, k, m,
+                       d_self, d_next, d_prev);
+    prof_end(c);
+  }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && (flags & NTHIP_HOST_OUTPUT)) {
     if (self) e = hipMemcpyAsync(self, d_self, n * m * 8, hipMemcpyDeviceToHost, c->stream);

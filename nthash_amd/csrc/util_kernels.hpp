@@ -195,6 +195,95 @@ __global__ __launch_bounds__(256) void kmer_extend_kernel(const uint8_t* __restr
   }
 }
 
+// The same for k <= 64 with the first-window byte tables in LDS (4 bases per lookup instead of 2k Horner
+// steps) and, for m == 1, the four neighbours of a k-mer written as two 16-byte stores (32 contiguous bytes
+// per lane: the wave writes 2 KiB contiguous).  tab = build_byte_tables(k): [ceil(k/4)][256].
+template <int NW>
+__global__ __launch_bounds__(1024) void kmer_extend_tab_kernel(const uint8_t* __restrict__ kmers, uint64_t n, uint32_t k,
+                                                              uint32_t m, const uint4* __restrict__ tab, uint32_t ntab,
+                                                              uint64_t* __restrict__ self, uint64_t* __restrict__ next,
+                                                              uint64_t* __restrict__ prev)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_ext[];
+  uint4* itab = (uint4*)lds_ext;
+  for (uint32_t i = threadIdx.x; i < ntab * 256u; i += blockDim.x) itab[i] = tab[i];
+  __syncthreads();
+  const uint64_t base = (uint64_t)k * MULTISEED;
+  const uint64_t total_bytes = n * (uint64_t)k;
+  // srol^k of the four seeds, forward and complement (code order A C T G of (c >> 1) & 3)
+  uint64_t sk[4], skc[4];
+#pragma unroll
+  for (uint32_t c = 0; c < 4; ++c) {
+    sk[c] = srol_n(seed_of_code(c), k);
+    skc[c] = srol_n(seed_of_code(c ^ 2u), k);
+  }
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t off = i * k;
+    uint32_t w[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      uint4 v = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+      const uint64_t o = off + 16u * q;
+      if (o + 16u <= total_bytes) {
+        __builtin_memcpy(&v, kmers + o, 16);
+      } else {
+        uint32_t wv[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+        for (uint32_t b = 0; o + b < total_bytes && b < 16u; ++b) {
+          wv[b >> 2] &= ~(0xFFu << ((b & 3u) * 8u));
+          wv[b >> 2] |= (uint32_t)kmers[o + b] << ((b & 3u) * 8u);
+        }
+        v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      }
+      // 16 bases -> 16 two-bit codes ((c >> 1) & 3, no validation: like BlindNtHash)
+      auto p4 = [](uint32_t x) { return __builtin_amdgcn_udot4((x >> 1) & 0x03030303u, 0x40100401u, 0u, false); };
+      w[q] = p4(v.x) | (p4(v.y) << 8) | (p4(v.z) << 16) | (p4(v.w) << 24);
+    }
+    uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
+#pragma unroll
+    for (int jt = 0; jt < 4 * NW; ++jt) {
+      if ((uint32_t)jt < ntab) {
+        const uint4 e = itab[(uint32_t)jt * 256u + ((w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu)];
+        f0 ^= e.x; f1 ^= e.y; r0 ^= e.z; r1 ^= e.w;
+      }
+    }
+    const uint64_t f = ((uint64_t)f1 << 32) | f0, r = ((uint64_t)r1 << 32) | r0;
+    const uint32_t c_first = w[0] & 3u, c_last = (w[(k - 1u) >> 4] >> (((k - 1u) & 15u) * 2u)) & 3u;
+    auto emit = [&](uint64_t* dst, uint64_t h0) {
+      dst[0] = h0;
+      for (uint32_t j = 1; j < m; ++j) dst[j] = mix_hash(h0, (uint64_t)j ^ base);
+    };
+    if (self) emit(self + i * m, f + r);
+    // base order "ACGT" = codes 0, 1, 3, 2
+    uint64_t hn[4], hp[4];
+#pragma unroll
+    for (uint32_t b = 0; b < 4; ++b) {
+      const uint32_t c = b == 2u ? 3u : b == 3u ? 2u : b;
+      // next_forward_hash / next_reverse_hash, src/kmer.cpp:84-94,164-174
+      hn[b] = (srol1(f) ^ seed_of_code(c) ^ sk[c_first]) + sror1(r ^ skc[c] ^ seed_of_code(c_first ^ 2u));
+      // prev_forward_hash / prev_reverse_hash, src/kmer.cpp:104-114,184-194
+      hp[b] = sror1(f ^ sk[c] ^ seed_of_code(c_last)) + (srol1(r) ^ seed_of_code(c ^ 2u) ^ skc[c_last]);
+    }
+    if (m == 1u) {
+      if (next) {
+        ulonglong2* d = (ulonglong2*)(next + i * 4u);
+        d[0] = make_ulonglong2(hn[0], hn[1]);
+        d[1] = make_ulonglong2(hn[2], hn[3]);
+      }
+      if (prev) {
+        ulonglong2* d = (ulonglong2*)(prev + i * 4u);
+        d[0] = make_ulonglong2(hp[0], hp[1]);
+        d[1] = make_ulonglong2(hp[2], hp[3]);
+      }
+    } else {
+#pragma unroll
+      for (uint32_t b = 0; b < 4; ++b) {
+        if (next) emit(next + (i * 4u + b) * m, hn[b]);
+        if (prev) emit(prev + (i * 4u + b) * m, hp[b]);
+      }
+    }
+  }
+}
+
 // longest read of a batch given as spans / offsets (ends == nullptr: offsets[r+1])
 __global__ __launch_bounds__(256) void max_len_kernel(const uint64_t* __restrict__ starts,
                                                      const uint64_t* __restrict__ ends, uint64_t n,
