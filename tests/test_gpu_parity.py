@@ -652,10 +652,12 @@ def test_kmer_extend_golden(ctx):
             assert (r["prev"][0, b] == h2i(c["prev"][b])).all(), (c["kmer"], "prev", b)
 
 
-def test_kmer_extend_batch_consistency(ctx, oracle):
-    """a batch: successor b of k-mer i == the hash stream entry of (kmer[1:] + b); self == k-mer hash"""
-    rng = np.random.default_rng(12)
-    n, k, m = 5000, 31, 3
+@pytest.mark.parametrize("n,k,m", [(5000, 31, 3), (3001, 31, 1), (777, 17, 1), (500, 64, 2), (300, 65, 1), (200, 100, 2),
+                                   (64, 4, 1), (1, 48, 1)])
+def test_kmer_extend_batch_consistency(ctx, oracle, n, k, m):
+    """a batch: successor b of k-mer i == the hash stream entry of (kmer[1:] + b); self == k-mer hash
+    (k <= 64: table kernel with 16-byte neighbour stores for m = 1; k > 64: Horner kernel)"""
+    rng = np.random.default_rng(12 + k)
     kmers = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (n, k))]
     r = ctx.kmer_extend(kmers.ravel(), k, m)
     offs = np.arange(n + 1, dtype=np.uint64) * k
