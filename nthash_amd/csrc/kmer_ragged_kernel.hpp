@@ -101,7 +101,8 @@ struct KmerRaggedArgs {
   uint64_t n_nz, total_runs, n_wtiles;
   uint32_t k, m, C, ntab;
   uint32_t waves, bits_dwords, vbits_dwords, tile_u64; // count pass: tile_u64 = bits_dwords = 0 (validity only)
-  uint32_t ptile_dwords, pad0;                         // position tile, 0 unless pos is wanted
+  uint32_t ptile_dwords;                               // position tile, 0 unless pos is wanted
+  uint32_t value_sel;                                  // 0: canonical hash (+ mixes), 1: forward, 2: reverse strand (m == 1)
   uint64_t tab[16][2];
   uint64_t mult[KF_MAX_RUNTIME_M];
 };
@@ -398,7 +399,9 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
       const uint32_t tpar = m == 1u ? (uint32_t)(o0 & (KRG_ALIGN_U64 - 1u)) : 0u;
       auto emit = [&](uint32_t jw) {
         if ((valid >> jw) & 1u) {
-          tile[tpar + slot] = canon_pair(f_lo, f_hi, r_lo, r_hi);
+          tile[tpar + slot] = a.value_sel == 0u   ? canon_pair(f_lo, f_hi, r_lo, r_hi)
+                              : a.value_sel == 1u ? (((uint64_t)f_hi << 32) | f_lo)
+                                                  : (((uint64_t)r_hi << 32) | r_lo);
           if (want_pos) ptile[slot] = p_first + jw;
           ++slot;
         }

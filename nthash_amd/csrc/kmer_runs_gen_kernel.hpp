@@ -80,6 +80,9 @@ struct KmerRunsGenArgs {
   uint64_t bloom_magic;      // floor((2^64 - 1) / n_bits), 0 when n_bits is a power of two
   uint64_t* hits;            // query, optional: per-read k-mers found
   uint64_t* sink_totals;     // [0] += k-mers consumed, [1] += k-mers found (query)
+  // N-aware pass: what a k-mer's value is -- 0: the canonical hash (+ m-1 mixes), 1: the forward-strand hash,
+  // 2: the reverse-strand hash (NtHash::get_forward_hash / get_reverse_hash; one value per k-mer, m must be 1)
+  uint32_t value_sel, pad2;
 };
 
 // h mod d for an invariant d (magic = floor((2^64 - 1) / d): the quotient estimate is at most 2 short)
@@ -546,7 +549,9 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     }
     // window j of the run has just been hashed
     auto emit = [&](uint32_t j, auto clean_tag) {
-      const uint64_t h = canon_pair(f_lo, f_hi, r_lo, r_hi);
+      uint64_t h = canon_pair(f_lo, f_hi, r_lo, r_hi);
+      if (NA && SINK == SINK_NONE && a.value_sel != 0u)
+        h = a.value_sel == 1u ? (((uint64_t)f_hi << 32) | f_lo) : (((uint64_t)r_hi << 32) | r_lo);
       if constexpr (decltype(clean_tag)::value) {
         my_row[j] = h;
         if (want_pos) my_pos[j] = w0 + j;

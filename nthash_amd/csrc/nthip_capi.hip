@@ -837,6 +837,18 @@ int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t 
   a.counts = nullptr;
   a.waves = plan.waves;
   NTCHK(launch_kmer_runs_gen_nw<true>(c, a, plan.lds, plan.g.nw, plan.g.dword_tail != 0));
+  // strand hashes (get_forward_hash / get_reverse_hash): the same pass again with another value selected,
+  // one value per k-mer at the same compact offsets
+  for (uint32_t sel = 1; sel <= 2; ++sel) {
+    uint64_t* dst = sel == 1 ? st.fwd : st.rev;
+    if (!dst) continue;
+    KmerRunsGenArgs b = a;
+    b.hashes = dst;
+    b.pos = nullptr;
+    b.m = 1;
+    b.value_sel = sel;
+    NTCHK(launch_kmer_runs_gen_nw<true>(c, b, plan.lds, plan.g.nw, plan.g.dword_tail != 0));
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   return NTHIP_OK;
 }
@@ -866,7 +878,6 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
 {
   *handled = false;
   const uint32_t C = 15; // run length; the last run of a read may be shorter
-  if (st.fwd || st.rev) return NTHIP_OK;
   const uint64_t n = n_reads;
   const uint32_t nw = kmer_nw(k);
   // per-wave LDS: a tile touches <= 64 listed reads, each staging its runs' bytes rounded up to 16
@@ -988,6 +999,15 @@ int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, co
                 (unsigned long long)capacity, (unsigned long long)*total);
   a.counts = nullptr;
   NTCHK(launch(NA_MODE_HASH));
+  for (uint32_t sel = 1; sel <= 2; ++sel) { // strand hashes: the hash pass again with another value selected
+    uint64_t* dst = sel == 1 ? st.fwd : st.rev;
+    if (!dst) continue;
+    a.hashes = dst;
+    a.pos = nullptr;
+    a.m = 1;
+    a.value_sel = sel;
+    NTCHK(launch(NA_MODE_HASH));
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   return NTHIP_OK;
 }
@@ -1128,7 +1148,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
                          len >= k && rd->n_reads * (uint64_t)(len - k + 1) <= out->capacity;
   // fixed-length reads that are (or may be) dirty, or whose positions are wanted: N-aware run-split path
   NaPlan na_plan;
-  const bool na_ok = !rd->offsets && !(flags & (NTHIP_FORCE_GENERAL | NTHIP_FORCE_ROWS)) && !st.fwd && !st.rev &&
+  const bool na_ok = !rd->offsets && !(flags & (NTHIP_FORCE_GENERAL | NTHIP_FORCE_ROWS)) &&
                      len >= k && kmer_na_plan(c, len, stride, k, m, st.pos != nullptr, &na_plan);
   if (!rd->offsets && len < k) {
     // every read shorter than k: nothing is emitted

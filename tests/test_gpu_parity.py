@@ -267,6 +267,12 @@ def test_kmer_na_runs_path_vs_oracle(ctx, oracle, n, L, k, m, frac):
     assert got2["total"] == want["total"] and (got2["hashes"] == want["hashes"]).all()
     gen = ctx.kmer_hash(data, k, m, fixed_len=L, n_reads=n, flags=4, want_pos=True)
     assert (gen["hashes"] == want["hashes"]).all() and (gen["pos"] == want["pos"]).all()
+    # strand hashes (get_forward_hash / get_reverse_hash) from the run-split pass: value selector
+    ws = oracle.kmer_batch(data, offs, k, m, want_strands=True)
+    gs = ctx.kmer_hash(data, k, m, fixed_len=L, n_reads=n, want_pos=True, want_strands=True)
+    assert gs["total"] == ws["total"]
+    for key in ("hashes", "pos", "fwd", "rev"):
+        assert (gs[key] == ws[key]).all(), key
 
 
 def test_kmer_ragged_reads_vs_oracle(ctx, oracle):
