@@ -32,8 +32,9 @@ for it in range(iters):
             nb = int(rng.integers(1, max(2, total // 2000)))
             data[rng.integers(0, total, nb)] = bad_alph[rng.integers(0, len(bad_alph) - 1, nb)]
         want_pos = bool(rng.random() < 0.3)
-        a = ctx.kmer_hash(data, k, m, fixed_len=L, stride=stride, n_reads=n, want_pos=want_pos)
-        b = ctx.kmer_hash(data, k, m, fixed_len=L, stride=stride, n_reads=n, want_pos=want_pos, flags=4)
+        want_str = bool(rng.random() < 0.25)
+        a = ctx.kmer_hash(data, k, m, fixed_len=L, stride=stride, n_reads=n, want_pos=want_pos, want_strands=want_str)
+        b = ctx.kmer_hash(data, k, m, fixed_len=L, stride=stride, n_reads=n, want_pos=want_pos, want_strands=want_str, flags=4)
         desc = f"fixed n={n} L={L} k={k} m={m} stride={stride} pos={want_pos}"
     else:
         n = int(rng.integers(1, 4000))
@@ -47,12 +48,15 @@ for it in range(iters):
             nb = int(rng.integers(1, max(2, total // 1000)))
             data[rng.integers(0, total, nb)] = bad_alph[rng.integers(0, len(bad_alph), nb)]
         want_pos = bool(rng.random() < 0.5)
-        a = ctx.kmer_hash(data, k, m, offsets=offs, want_pos=want_pos)
-        b = ctx.kmer_hash(data, k, m, offsets=offs, want_pos=want_pos, flags=4)
+        want_str = bool(rng.random() < 0.25)
+        a = ctx.kmer_hash(data, k, m, offsets=offs, want_pos=want_pos, want_strands=want_str)
+        b = ctx.kmer_hash(data, k, m, offsets=offs, want_pos=want_pos, want_strands=want_str, flags=4)
         desc = f"ragged n={n} bytes={total} k={k} m={m} pos={want_pos}"
     ok = a["total"] == b["total"] and (a["hashes"] == b["hashes"]).all() and (a["counts"] == b["counts"]).all()
     if want_pos:
         ok = ok and (a["pos"] == b["pos"]).all()
+    if want_str:
+        ok = ok and (a["fwd"] == b["fwd"]).all() and (a["rev"] == b["rev"]).all()
     if not ok:
         fails += 1
         print("MISMATCH", desc, a["total"], b["total"], flush=True)
