@@ -259,8 +259,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
 #pragma unroll
       for (uint32_t i = 0; i < 3; ++i) p[i] = (const uint8_t*)((uintptr_t)a.seqs & ~(uintptr_t)15);
     }
-    asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off\n\t"
-                 "global_load_dwordx4 %2, %5, off"
+    asm volatile("global_load_dwordx4 %0, %3, off" KRG_LOAD_NT "\n\tglobal_load_dwordx4 %1, %4, off" KRG_LOAD_NT "\n\t"
+                 "global_load_dwordx4 %2, %5, off" KRG_LOAD_NT
                  : "=&v"(st0), "=&v"(st1), "=&v"(st2)
                  : "v"(p[0]), "v"(p[1]), "v"(p[2])
                  : "memory");

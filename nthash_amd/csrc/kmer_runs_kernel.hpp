@@ -231,8 +231,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
         const uint32_t n_dw = (nxt.shift + nxt.slab_bytes + 3u) >> 2; // dwords in the slab
         const uint32_t j = 256u + lane < n_dw ? 256u + lane : 0u;
         const uint8_t* p1 = a.seqs + nxt.byte0 + ((uint64_t)j << 2);
-        asm volatile("global_load_dword %2, %5, off sc1\n\tglobal_load_dwordx4 %0, %3, off\n\t"
-                     "global_load_dword %1, %4, off"
+#ifndef KR_LOAD_NT
+#define KR_LOAD_NT " nt"
+#endif
+        asm volatile("global_load_dword %2, %5, off sc1\n\tglobal_load_dwordx4 %0, %3, off" KR_LOAD_NT "\n\t"
+                     "global_load_dword %1, %4, off" KR_LOAD_NT
                      : "=&v"(pv0), "=&v"(pw), "=&v"(dirty_seen)
                      : "v"(p0), "v"(p1), "v"(a.dirty)
                      : "memory");
@@ -389,9 +392,17 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
 #define KR_LD(n, var) \
         if constexpr ((n) < NFULL) var = src[(n) * 64u]; \
         else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) var = src[(n) * 64u]; }
+#ifndef KR_STORE_NT
+#define KR_STORE_NT 0
+#endif
+#if KR_STORE_NT
+#define KR_ST1(p, var) __builtin_nontemporal_store((v4u){var.x, var.y, var.z, var.w}, (v4u*)(p))
+#else
+#define KR_ST1(p, var) *(p) = var
+#endif
 #define KR_ST(n, var) \
-        if constexpr ((n) < NFULL) dst[(n) * 64u] = var; \
-        else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) dst[(n) * 64u] = var; }
+        if constexpr ((n) < NFULL) KR_ST1(dst + (n) * 64u, var); \
+        else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) KR_ST1(dst + (n) * 64u, var); }
 #define KR_GROUP(b) \
         KR_LD(b + 0, d0) KR_LD(b + 1, d1) KR_LD(b + 2, d2) KR_LD(b + 3, d3) \
         KR_LD(b + 4, d4) KR_LD(b + 5, d5) KR_LD(b + 6, d6) KR_LD(b + 7, d7) \
@@ -402,6 +413,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
 #undef KR_GROUP
 #undef KR_LD
 #undef KR_ST
+#undef KR_ST1
         counted = true;
       } else {
         for (uint32_t pi = lane; pi < n_pairs; pi += 64u) {
