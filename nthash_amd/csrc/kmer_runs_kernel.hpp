@@ -234,7 +234,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
 #ifndef KR_LOAD_NT
 #define KR_LOAD_NT " nt"
 #endif
-        asm volatile("global_load_dword %2, %5, off sc1\n\tglobal_load_dwordx4 %0, %3, off" KR_LOAD_NT "\n\t"
+#ifndef KR_FLAG_SC
+#define KR_FLAG_SC " sc1"
+#endif
+        asm volatile("global_load_dword %2, %5, off" KR_FLAG_SC "\n\tglobal_load_dwordx4 %0, %3, off" KR_LOAD_NT "\n\t"
                      "global_load_dword %1, %4, off" KR_LOAD_NT
                      : "=&v"(pv0), "=&v"(pw), "=&v"(dirty_seen)
                      : "v"(p0), "v"(p1), "v"(a.dirty)
