@@ -1360,7 +1360,7 @@ extern "C" int nthip_seeds_destroy(nthip_seeds* sd)
 
 namespace {
 
-// seed_wave_kernel (one wave per read): reads of at most SEED_WAVE_LMAX bytes, k <= 64, no strand outputs.
+// seed_wave_kernel (one wave per read, staged in segments of SEED_WAVE_LMAX bytes): k <= 64, no strand outputs.
 constexpr uint32_t SEED_WAVE_LMAX = 2048;
 struct SeedWavePlan {
   uint32_t nw = 0, waves_count = 0, waves_hash = 0;
@@ -1443,18 +1443,6 @@ int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, cons
   // the lane-per-read kernel otherwise
   SeedWavePlan wplan;
   bool use_wave = !st.fwd && !st.rev && !getenv("NTHIP_TUNE_NO_SEED_WAVE") && seed_wave_plan(c, sd, m2, &wplan);
-  if (use_wave) {
-    uint64_t max_len = h.len;
-    if (st.offsets) {
-      unsigned long long* d_max = (unsigned long long*)(c->d_small + 48);
-      HIPCHK(hipMemsetAsync(d_max, 0, 8, c->stream));
-      hipLaunchKernelGGL(max_len_kernel, dim3(c->n_cu * 4), dim3(256), 0, c->stream, st.offsets, d_ends, n, d_max);
-      HIPCHK(hipMemcpyAsync(c->h_small + 48, d_max, 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-      memcpy(&max_len, c->h_small + 48, 8);
-    }
-    use_wave = max_len <= SEED_WAVE_LMAX;
-  }
   h.wave_lmax = SEED_WAVE_LMAX;
   h.counts = d_counts;
   if (use_wave) {
@@ -1648,7 +1636,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
         NTCHK(ensure_args(c, sizeof(SeedGeneralArgs)));
         const unsigned lblocks = (unsigned)((n_dirty + 255) / 256);
         SeedWavePlan wplan;
-        const bool list_wave = len <= SEED_WAVE_LMAX && !getenv("NTHIP_TUNE_NO_SEED_WAVE") && seed_wave_plan(c, sd, m2, &wplan);
+        const bool list_wave = !getenv("NTHIP_TUNE_NO_SEED_WAVE") && seed_wave_plan(c, sd, m2, &wplan);
         h.wave_lmax = SEED_WAVE_LMAX;
         if (n_dirty) {
           h.counts = d_cnt;

@@ -467,154 +467,184 @@ __global__ __launch_bounds__(1024) void seed_wave_kernel(const SeedGeneralArgs* 
       start = rid * a.stride;
       len64 = a.len;
     }
-    const uint32_t len = (uint32_t)len64; // the launcher guarantees len <= wave_lmax
+    // reads longer than the staging buffers go through it in segments of seg_w windows; the state of the
+    // reference's walk between two segments is (last init position, next position that may be emitted,
+    // "that position still needs init()'s NUL check")
+    const uint64_t len = len64;
     if (len < k) {
       if (COUNT_ONLY && lane == 0) a.counts[rid] = 0;
       continue;
     }
-    const uint32_t nwin = len - k + 1u;
-    const uint8_t* s = a.seqs + start;
-    lds_sync();
-    // ---- stage the read: raw bytes, 2-bit codes, validity bits -------------------------------------
-    uint32_t f_bad = 0, f_nul = 0;
-    const uint32_t n_vec = (len + 15u) >> 4;
-    for (uint32_t i = lane; i < n_vec; i += 64u) {
-      uint4 x;
-      if (16u * i + 16u <= len) {
-        __builtin_memcpy(&x, s + 16u * i, 16);
-      } else {
-        uint32_t wv[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u}; // 'A' padding past the read
-        for (uint32_t b = 0; 16u * i + b < len; ++b) {
-          wv[b >> 2] &= ~(0xFFu << ((b & 3u) * 8u));
-          wv[b >> 2] |= (uint32_t)s[16u * i + b] << ((b & 3u) * 8u);
-        }
-        x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-      }
-      *(uint4*)(raw + 16u * i) = x;
-      uint32_t i0, i1, i2, i3;
-      const uint32_t c0 = pack4v(x.x, i0), c1 = pack4v(x.y, i1), c2 = pack4v(x.z, i2), c3 = pack4v(x.w, i3);
-      bits[i] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-      const uint32_t inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
-      ((uint16_t*)vbits)[i] = (uint16_t)inv16;
-      f_bad |= inv16;
-      auto has_zero = [](uint32_t w) { return ((w - 0x01010101u) & ~w & 0x80808080u) != 0u; };
-      if (inv16 && (has_zero(x.x) || has_zero(x.y) || has_zero(x.z) || has_zero(x.w))) f_nul = 1;
-    }
-    if (lane < 12u) { bits[n_vec + (lane & 7u)] = 0; ((uint16_t*)vbits)[n_vec + lane] = 0; }
-    for (uint32_t i = lane; i < ((len + 31u) >> 5) + 6u; i += 64u) tbits[i] = 0;
-    const bool any_bad = __ballot(f_bad != 0) != 0;
-    const bool any_nul = __ballot(f_nul != 0) != 0;
-    lds_sync();
-    if (any_nul) {
-      // init()'s NUL rule makes the walk sequential: lane 0 runs the reference's state machine over
-      // positions only and marks the emitted ones in tbits
-      if (lane == 0) {
-        uint32_t pos = 0;
-        auto init = [&]() -> bool {
-          uint32_t where = 0;
-          while (pos < nwin && seed_first_nul(a, raw + pos, &where)) pos += where + 1;
-          return !(pos > len - k);
-        };
-        bool ok = init();
-        while (ok) {
-          tbits[pos >> 5] |= 1u << (pos & 31u);
-          if (pos >= len - k) break;
-          if (!is_base(raw[pos + k])) { pos += k; ok = init(); }
-          else pos++;
-        }
-      }
-    } else if (any_bad) {
-      // triggers: a non-base q with q >= (previous trigger, 0 at the start) + k
-      if (lane == 0) {
-        uint32_t last = 0;
-        for (uint32_t w = 0; 32u * w < len; ++w) {
-          uint32_t word = vbits[w];
-          while (word) {
-            const uint32_t q = 32u * w + (uint32_t)__builtin_ctz(word);
-            word &= word - 1u;
-            if (q >= len) break;
-            if (q >= last + k) { last = q; tbits[q >> 5] |= 1u << (q & 31u); }
-          }
-        }
-      }
-    }
-    lds_sync();
-    // ---- the windows, 64 at a time ---------------------------------------------------------------------
+    const uint64_t nwin = len - k + 1u;
+    const uint32_t seg_w = lmax - k;
+    uint64_t last_init = 0, next_pos = 0;
+    uint32_t need_init = 1;
     uint64_t emitted_before = 0;
     const uint64_t obase = COUNT_ONLY ? 0 : a.read_off[rid];
-    for (uint32_t w0 = 0; w0 < nwin; w0 += 64u) {
-      const uint32_t p = w0 + lane;
-      const bool in = p < nwin;
-      const uint32_t pc = in ? p : 0u;
-      bool emit;
-      if (any_nul) emit = in && ((tbits[pc >> 5] >> (pc & 31u)) & 1u);
-      else emit = in && (!any_bad || (windows_with_non_base(tbits, pc + 1u, k - 1u) & 1u) == 0u);
-      const uint64_t eb = __ballot(emit);
-      const uint32_t n_e = (uint32_t)__builtin_popcountll(eb);
-      if (COUNT_ONLY) { emitted_before += n_e; continue; }
-      if (n_e == 0) continue;
-      const uint32_t slot = (uint32_t)__builtin_popcountll(eb & ((1ull << lane) - 1ull));
-      if (emit) {
-        const bool dirty_win = any_bad && (windows_with_non_base(vbits, pc, k) & 1u);
-        uint64_t* mine = otile + slot * per;
-        uint32_t wwords[NW];
-        if (!dirty_win) {
-          const uint32_t d = pc >> 4, sh = (pc & 15u) << 1;
-          uint32_t lo = bits[d];
-#pragma unroll
-          for (int i = 0; i < NW; ++i) {
-            const uint32_t hi = bits[d + i + 1];
-            wwords[i] = funnel(hi, lo, sh);
-            lo = hi;
+    for (uint64_t ws = 0; ws < nwin; ws += seg_w) {
+      const uint64_t we = ws + seg_w < nwin ? ws + seg_w : nwin;
+      // staged bases: [ws, we + k) -- the k bases of the last window and the character that comes in after it
+      const uint32_t nb = (uint32_t)(len - ws < we - ws + k ? len - ws : we - ws + k);
+      const uint32_t seg_win = (uint32_t)(we - ws);
+      const uint8_t* s = a.seqs + start + ws;
+      lds_sync();
+      // ---- stage the segment: raw bytes, 2-bit codes, validity bits ------------------------------------
+      uint32_t f_bad = 0, f_nul = 0;
+      const uint32_t n_vec = (nb + 15u) >> 4;
+      for (uint32_t i = lane; i < n_vec; i += 64u) {
+        uint4 x;
+        if (16u * i + 16u <= nb) {
+          __builtin_memcpy(&x, s + 16u * i, 16);
+        } else {
+          uint32_t wv[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u}; // 'A' padding past the segment
+          for (uint32_t b = 0; 16u * i + b < nb; ++b) {
+            wv[b >> 2] &= ~(0xFFu << ((b & 3u) * 8u));
+            wv[b >> 2] |= (uint32_t)s[16u * i + b] << ((b & 3u) * 8u);
           }
+          x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
         }
-        for (uint32_t sdx = 0; sdx < a.n_seeds; ++sdx) {
-          uint64_t fh = 0, rh = 0;
-          if (!dirty_win) {
-            const uint4* ts = tabs + sdx * a.ntab * 256u;
-            uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
-#pragma unroll
-            for (int jt = 0; jt < 4 * NW; ++jt) {
-              if ((uint32_t)jt < a.ntab) {
-                const uint32_t byte = (wwords[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
-                const uint4 e = ts[(uint32_t)jt * 256u + byte];
-                f0 ^= e.x; f1 ^= e.y; r0 ^= e.z; r1 ^= e.w;
+        *(uint4*)(raw + 16u * i) = x;
+        uint32_t i0, i1, i2, i3;
+        const uint32_t c0 = pack4v(x.x, i0), c1 = pack4v(x.y, i1), c2 = pack4v(x.z, i2), c3 = pack4v(x.w, i3);
+        bits[i] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+        const uint32_t inv16 = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
+        ((uint16_t*)vbits)[i] = (uint16_t)inv16;
+        f_bad |= inv16;
+        auto has_zero = [](uint32_t w) { return ((w - 0x01010101u) & ~w & 0x80808080u) != 0u; };
+        if (inv16 && (has_zero(x.x) || has_zero(x.y) || has_zero(x.z) || has_zero(x.w))) f_nul = 1;
+      }
+      if (lane < 12u) { bits[n_vec + (lane & 7u)] = 0; ((uint16_t*)vbits)[n_vec + lane] = 0; }
+      for (uint32_t i = lane; i < ((nb + 31u) >> 5) + 6u; i += 64u) tbits[i] = 0;
+      const bool any_bad = __ballot(f_bad != 0) != 0;
+      const bool any_nul = __ballot(f_nul != 0) != 0;
+      lds_sync();
+      const uint64_t next_pos_in = next_pos;
+      if (lane == 0) {
+        if (any_nul) {
+          // init()'s NUL rule makes the walk sequential: the reference's state machine over positions only,
+          // emitted windows marked in tbits (relative to ws)
+          uint64_t pos = next_pos > ws ? next_pos : ws;
+          while (pos < we) {
+            if (need_init) {
+              uint32_t where = 0;
+              while (pos < nwin && pos < we && seed_first_nul(a, raw + (pos - ws), &where)) pos += where + 1;
+              if (pos >= we || pos >= nwin) break; // init() continues in the next segment / the read is over
+              last_init = pos;
+              need_init = 0;
+            }
+            tbits[(pos - ws) >> 5] |= 1u << ((pos - ws) & 31u);
+            if (pos >= len - k) { pos = nwin; break; }
+            if (!is_base(raw[pos + k - ws])) { pos += k; need_init = 1; }
+            else pos++;
+          }
+          next_pos = pos;
+        } else {
+          if (need_init) { last_init = next_pos > ws ? next_pos : ws; need_init = 0; } // no NUL here: init() passes
+          if (any_bad) {
+            // triggers: a non-base q decides when position q-k is visited (q >= ws + k: not an earlier segment's),
+            // and jumps iff q >= last init + k
+            uint64_t last_trigger = 0;
+            bool have = false;
+            for (uint32_t w = 0; 32u * w < nb; ++w) {
+              uint32_t word = vbits[w];
+              while (word) {
+                const uint32_t qr = 32u * w + (uint32_t)__builtin_ctz(word);
+                word &= word - 1u;
+                if (qr >= nb) break;
+                const uint64_t q = ws + qr;
+                if (q >= ws + k && q >= last_init + k) {
+                  last_init = q;
+                  last_trigger = q;
+                  have = true;
+                  tbits[qr >> 5] |= 1u << (qr & 31u);
+                }
               }
             }
-            fh = ((uint64_t)f1 << 32) | f0;
-            rh = ((uint64_t)r1 << 32) | r0;
-          } else {
-            const uint32_t* care = a.care_bits + sdx * a.care_words;
-            const uint8_t* win = raw + pc;
-            for (uint32_t q = 0; q < k; ++q) {
-              const bool c = (care[q >> 5] >> (q & 31u)) & 1u;
-              fh = srol1(fh) ^ (c ? fwd_seed(win[q]) : 0);
-            }
-            for (uint32_t q = k; q-- > 0;) {
-              const bool c = (care[q >> 5] >> (q & 31u)) & 1u;
-              rh = srol1(rh) ^ (c ? rc_seed(win[q]) : 0);
+            if (have && last_trigger > next_pos) next_pos = last_trigger;
+            if (have && last_trigger >= we) need_init = 1; // its window reaches into the next segment
+          }
+        }
+      }
+      last_init = ((uint64_t)__shfl((uint32_t)(last_init >> 32), 0, 64) << 32) | __shfl((uint32_t)last_init, 0, 64);
+      next_pos = ((uint64_t)__shfl((uint32_t)(next_pos >> 32), 0, 64) << 32) | __shfl((uint32_t)next_pos, 0, 64);
+      need_init = __shfl(need_init, 0, 64);
+      lds_sync();
+      // ---- the windows of the segment, 64 at a time ----------------------------------------------------
+      for (uint32_t w0 = 0; w0 < seg_win; w0 += 64u) {
+        const uint32_t p = w0 + lane;
+        const bool in = p < seg_win;
+        const uint32_t pc = in ? p : 0u;
+        bool emit;
+        if (any_nul) emit = in && ((tbits[pc >> 5] >> (pc & 31u)) & 1u);
+        else emit = in && ws + pc >= next_pos_in &&
+                    (!any_bad || (windows_with_non_base(tbits, pc + 1u, k - 1u) & 1u) == 0u);
+        const uint64_t eb = __ballot(emit);
+        const uint32_t n_e = (uint32_t)__builtin_popcountll(eb);
+        if (COUNT_ONLY) { emitted_before += n_e; continue; }
+        if (n_e == 0) continue;
+        const uint32_t slot = (uint32_t)__builtin_popcountll(eb & ((1ull << lane) - 1ull));
+        if (emit) {
+          const bool dirty_win = any_bad && (windows_with_non_base(vbits, pc, k) & 1u);
+          uint64_t* mine = otile + slot * per;
+          uint32_t wwords[NW];
+          if (!dirty_win) {
+            const uint32_t d = pc >> 4, sh = (pc & 15u) << 1;
+            uint32_t lo = bits[d];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+              const uint32_t hi = bits[d + i + 1];
+              wwords[i] = funnel(hi, lo, sh);
+              lo = hi;
             }
           }
-          const uint64_t h0 = fh + rh;
-          mine[sdx * a.m2] = h0;
-          for (uint32_t jj = 1; jj < a.m2; ++jj) mine[sdx * a.m2 + jj] = mix_hash(h0, a.mult[jj]);
+          for (uint32_t sdx = 0; sdx < a.n_seeds; ++sdx) {
+            uint64_t fh = 0, rh = 0;
+            if (!dirty_win) {
+              const uint4* ts = tabs + sdx * a.ntab * 256u;
+              uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
+#pragma unroll
+              for (int jt = 0; jt < 4 * NW; ++jt) {
+                if ((uint32_t)jt < a.ntab) {
+                  const uint32_t byte = (wwords[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+                  const uint4 e = ts[(uint32_t)jt * 256u + byte];
+                  f0 ^= e.x; f1 ^= e.y; r0 ^= e.z; r1 ^= e.w;
+                }
+              }
+              fh = ((uint64_t)f1 << 32) | f0;
+              rh = ((uint64_t)r1 << 32) | r0;
+            } else {
+              const uint32_t* care = a.care_bits + sdx * a.care_words;
+              const uint8_t* win = raw + pc;
+              for (uint32_t q = 0; q < k; ++q) {
+                const bool c = (care[q >> 5] >> (q & 31u)) & 1u;
+                fh = srol1(fh) ^ (c ? fwd_seed(win[q]) : 0);
+              }
+              for (uint32_t q = k; q-- > 0;) {
+                const bool c = (care[q >> 5] >> (q & 31u)) & 1u;
+                rh = srol1(rh) ^ (c ? rc_seed(win[q]) : 0);
+              }
+            }
+            const uint64_t h0 = fh + rh;
+            mine[sdx * a.m2] = h0;
+            for (uint32_t jj = 1; jj < a.m2; ++jj) mine[sdx * a.m2 + jj] = mix_hash(h0, a.mult[jj]);
+          }
+          if (a.pos) a.pos[obase + emitted_before + slot] = (uint32_t)(ws + pc);
         }
-        if (a.pos) a.pos[obase + emitted_before + slot] = pc;
-      }
-      lds_sync();
-      const uint32_t n_vals = n_e * per;
-      uint64_t* dst = a.hashes + (obase + emitted_before) * per;
-      if ((((uint64_t)(uintptr_t)dst) & 15u) == 0u) {
-        for (uint32_t pi = lane; 2u * pi < n_vals; pi += 64u) {
-          const uint4 dv = *(const uint4*)(otile + 2u * pi);
-          if (2u * pi + 1u < n_vals) *(uint4*)(dst + 2u * pi) = dv;
-          else *(uint2*)(dst + 2u * pi) = make_uint2(dv.x, dv.y);
+        lds_sync();
+        const uint32_t n_vals = n_e * per;
+        uint64_t* dst = a.hashes + (obase + emitted_before) * per;
+        if ((((uint64_t)(uintptr_t)dst) & 15u) == 0u) {
+          for (uint32_t pi = lane; 2u * pi < n_vals; pi += 64u) {
+            const uint4 dv = *(const uint4*)(otile + 2u * pi);
+            if (2u * pi + 1u < n_vals) *(uint4*)(dst + 2u * pi) = dv;
+            else *(uint2*)(dst + 2u * pi) = make_uint2(dv.x, dv.y);
+          }
+        } else {
+          for (uint32_t v = lane; v < n_vals; v += 64u) dst[v] = otile[v];
         }
-      } else {
-        for (uint32_t v = lane; v < n_vals; v += 64u) dst[v] = otile[v];
+        emitted_before += n_e;
+        lds_sync();
       }
-      emitted_before += n_e;
-      lds_sync();
     }
     if (COUNT_ONLY && lane == 0) a.counts[rid] = emitted_before;
   }

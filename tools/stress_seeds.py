@@ -37,8 +37,9 @@ for it in range(iters):
     else:
         n = int(rng.integers(1, 1500))
         lens = np.where(rng.random(n) < 0.1, rng.integers(0, k + 2, n), rng.integers(0, 500, n))
-        if rng.random() < 0.15:
-            lens[rng.integers(0, n)] = int(rng.integers(2049, 6000))   # longer than the wave kernel stages
+        if rng.random() < 0.4:
+            for _ in range(int(rng.integers(1, 4))):
+                lens[rng.integers(0, n)] = int(rng.choice([1984, 2047, 2048, 2049, 4031, 4032, 6000, 20000]))  # segment edges
         offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
         total = int(offs[-1])
         data = alph[rng.integers(0, len(alph), max(total, 1))]
