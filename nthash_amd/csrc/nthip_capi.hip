@@ -1439,10 +1439,9 @@ int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, cons
   uint64_t* d_total = (uint64_t*)(c->d_small + 8);
   NTCHK(ensure_args(c, sizeof(SeedGeneralArgs)));
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  // one wave per read (seed_wave_kernel) when every read fits its LDS staging and no strand output is wanted;
-  // the lane-per-read kernel otherwise
+  // one wave per read (seed_wave_kernel), k <= 64; the lane-per-read kernel otherwise
   SeedWavePlan wplan;
-  bool use_wave = !st.fwd && !st.rev && !getenv("NTHIP_TUNE_NO_SEED_WAVE") && seed_wave_plan(c, sd, m2, &wplan);
+  bool use_wave = !getenv("NTHIP_TUNE_NO_SEED_WAVE") && seed_wave_plan(c, sd, m2, &wplan);
   h.wave_lmax = SEED_WAVE_LMAX;
   h.counts = d_counts;
   if (use_wave) {

@@ -627,6 +627,9 @@ __global__ __launch_bounds__(1024) void seed_wave_kernel(const SeedGeneralArgs* 
             const uint64_t h0 = fh + rh;
             mine[sdx * a.m2] = h0;
             for (uint32_t jj = 1; jj < a.m2; ++jj) mine[sdx * a.m2 + jj] = mix_hash(h0, a.mult[jj]);
+            // SeedNtHash::get_forward_hash / get_reverse_hash: one value per seed and k-mer
+            if (a.fwd) a.fwd[(obase + emitted_before + slot) * a.n_seeds + sdx] = fh;
+            if (a.rev) a.rev[(obase + emitted_before + slot) * a.n_seeds + sdx] = rh;
           }
           if (a.pos) a.pos[obase + emitted_before + slot] = (uint32_t)(ws + pc);
         }

@@ -49,13 +49,16 @@ for it in range(iters):
         kw = dict(offsets=offs)
         desc = f"ragged n={n} bytes={total}"
     want_pos = bool(rng.random() < 0.4)
+    want_str = bool(rng.random() < 0.3)
     os.environ.pop("NTHIP_TUNE_NO_SEED_WAVE", None)
-    a = ctx.seed_hash(data, seeds, k, m2, want_pos=want_pos, **kw)
+    a = ctx.seed_hash(data, seeds, k, m2, want_pos=want_pos, want_strands=want_str, **kw)
     os.environ["NTHIP_TUNE_NO_SEED_WAVE"] = "1"
-    b = ctx.seed_hash(data, seeds, k, m2, want_pos=want_pos, flags=4, **kw)
+    b = ctx.seed_hash(data, seeds, k, m2, want_pos=want_pos, want_strands=want_str, flags=4, **kw)
     ok = a["total"] == b["total"] and (a["hashes"] == b["hashes"]).all() and (a["counts"] == b["counts"]).all()
     if want_pos:
         ok = ok and (a["pos"] == b["pos"]).all()
+    if want_str:
+        ok = ok and (a["fwd"] == b["fwd"]).all() and (a["rev"] == b["rev"]).all()
     if not ok:
         fails += 1
         print("MISMATCH", desc, k, m2, seeds, bad_rate, a["total"], b["total"], flush=True)
