@@ -395,14 +395,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
 #define KR_LD(n, var) \
         if constexpr ((n) < NFULL) var = src[(n) * 64u]; \
         else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) var = src[(n) * 64u]; }
-#ifndef KR_STORE_NT
-#define KR_STORE_NT 0
-#endif
-#if KR_STORE_NT
-#define KR_ST1(p, var) __builtin_nontemporal_store((v4u){var.x, var.y, var.z, var.w}, (v4u*)(p))
-#else
-#define KR_ST1(p, var) *(p) = var
-#endif
+#define KR_ST1(p, var) stream_store16((p), var)
 #define KR_ST(n, var) \
         if constexpr ((n) < NFULL) KR_ST1(dst + (n) * 64u, var); \
         else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) KR_ST1(dst + (n) * 64u, var); }
