@@ -45,6 +45,13 @@ extern "C" {
 #define NTHIP_HOST_OUTPUT 0x2u  /* every non-NULL pointer in nthip_out is host memory */
 #define NTHIP_FORCE_GENERAL 0x4u /* skip the fixed-length fast kernels (testing / A-B) */
 #define NTHIP_FORCE_ROWS 0x8u    /* use the row-per-read fixed-length kernel (testing / A-B) */
+#define NTHIP_ASYNC 0x10u        /* nthip_kmer_hash on device-resident fixed-length reads: launch the dense pass and
+                                    return without synchronising (many small batches back to back: the call costs a
+                                    kernel launch, not a round trip).  The stream is only valid if no batch since the
+                                    last nthip_ctx_take_dirty() held a non-base: call it when the results are needed
+                                    (it synchronises) and redo the batches without this flag if it reports one.
+                                    NTHIP_ERR_UNSUPPORTED when the call is not a plain dense one (offsets, host
+                                    buffers, pos / strand outputs, capacity below n_reads * windows). */
 
 typedef struct nthip_ctx nthip_ctx;     /* one device + one stream + scratch */
 typedef struct nthip_seeds nthip_seeds; /* parsed spaced-seed set (device tables) */
@@ -84,6 +91,8 @@ int nthip_ctx_destroy(nthip_ctx* ctx);
  * restores the context's own stream */
 int nthip_ctx_set_stream(nthip_ctx* ctx, void* hip_stream);
 int nthip_ctx_synchronize(nthip_ctx* ctx);
+/* synchronise, report (and clear) whether any NTHIP_ASYNC call since the last one met a byte that is not ACGTU */
+int nthip_ctx_take_dirty(nthip_ctx* ctx, int* dirty);
 /* when on, every hash call brackets its dominant kernel with HIP events on the
  * launch stream; nthip_last_kernel_ms reads the last bracket (synchronises) */
 int nthip_ctx_set_profiling(nthip_ctx* ctx, int on);

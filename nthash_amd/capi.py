@@ -23,13 +23,14 @@ NTHIP_ERR_CAPACITY = -4
 NTHIP_ERR_UNSUPPORTED = -5
 NTHIP_HOST_INPUT = 0x1
 NTHIP_HOST_OUTPUT = 0x2
+NTHIP_ASYNC = 0x10
 NTHIP_FORCE_GENERAL = 0x4
 NTHIP_FORCE_ROWS = 0x8
 
 # every exported symbol of include/nthash_hip.h (kept in sync by tests/test_abi.py)
 SYMBOLS = [
     "nthip_version", "nthip_last_error", "nthip_device_count", "nthip_ctx_create",
-    "nthip_ctx_destroy", "nthip_ctx_set_stream", "nthip_ctx_synchronize",
+    "nthip_ctx_destroy", "nthip_ctx_set_stream", "nthip_ctx_synchronize", "nthip_ctx_take_dirty",
     "nthip_ctx_set_profiling", "nthip_last_kernel_ms", "nthip_malloc", "nthip_free",
     "nthip_memcpy_h2d", "nthip_memcpy_d2h", "nthip_memset", "nthip_kmer_hash", "nthip_seeds_create",
     "nthip_seeds_destroy", "nthip_seed_hash", "nthip_kmer_extend", "nthip_kmer_bloom_insert",
@@ -89,6 +90,7 @@ def load():
     L.nthip_ctx_destroy.argtypes = [vp]
     L.nthip_ctx_set_stream.argtypes = [vp, vp]
     L.nthip_ctx_synchronize.argtypes = [vp]
+    L.nthip_ctx_take_dirty.argtypes = [vp, C.POINTER(C.c_int)]
     L.nthip_ctx_set_profiling.argtypes = [vp, C.c_int]
     L.nthip_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p)]
     L.nthip_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -216,6 +218,12 @@ class Context:
     def d2h(self, arr, dptr):
         assert arr.flags["C_CONTIGUOUS"]
         _chk(self.L.nthip_memcpy_d2h(self.h, arr.ctypes.data, C.c_void_p(dptr), arr.nbytes))
+
+    def take_dirty(self):
+        """synchronise; True if an NTHIP_ASYNC batch since the last call met a non-base (its stream is invalid)"""
+        d = C.c_int(0)
+        _chk(self.L.nthip_ctx_take_dirty(self.h, C.byref(d)))
+        return bool(d.value)
 
     def memset(self, dptr, value, nbytes):
         _chk(self.L.nthip_memset(self.h, C.c_void_p(dptr), value, nbytes))

@@ -81,6 +81,7 @@ struct nthip_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
   const char* last_kernel = "";
+  bool async_pending = false; // NTHIP_ASYNC launches since the last nthip_ctx_take_dirty: d_small[0] accumulates
   // blocks per CU of (kernel, dynamic LDS) pairs already configured
   std::map<std::pair<const void*, size_t>, int> occ_cache;
   // all-care byte tables for the first window of a run, per k (device memory)
@@ -404,6 +405,23 @@ extern "C" int nthip_ctx_synchronize(nthip_ctx* c)
   if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_ctx_take_dirty(nthip_ctx* c, int* dirty)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  uint32_t d = 0;
+  if (c->async_pending) {
+    HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(&d, c->h_small, 4);
+    c->async_pending = false;
+  } else {
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  if (dirty) *dirty = d ? 1 : 0;
   return NTHIP_OK;
 }
 
@@ -1158,6 +1176,8 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
     }
     done = true;
   } else if (want_fast) {
+    if ((flags & NTHIP_ASYNC) && (flags & (NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT)))
+      return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_ASYNC takes device-resident buffers");
     const uint32_t nwin = len - k + 1;
     const uint64_t dense = rd->n_reads * (uint64_t)nwin;
     bool fast_ran = true;
@@ -1177,7 +1197,10 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
     if (n_tiles > 0xFFFFFFFFull) return fail(NTHIP_ERR_UNSUPPORTED, "too many reads for one call");
     a.n_tiles = (uint32_t)n_tiles;
     fill_kmer_consts(k, m, a);
-    HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream));
+    const bool async = (flags & NTHIP_ASYNC) != 0;
+    if (!async && c->async_pending)
+      return fail(NTHIP_ERR_ARG, "NTHIP_ASYNC batches are pending: call nthip_ctx_take_dirty first");
+    if (!c->async_pending) HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream));
     int rc;
     RunsPlan plan;
     const bool rows_only = (flags & NTHIP_FORCE_ROWS) != 0;
@@ -1239,6 +1262,17 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
     else if (k == 31 && m == 4) rc = launch_kmer_fixed(c, kmer_fixed_kernel<31, 4>, a, dyn);
     else rc = launch_kmer_fixed(c, kmer_fixed_kernel<0, 0>, a, dyn);
     NTCHK(rc);
+    if (async) {
+      if (!fast_ran) return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_ASYNC: no dense kernel takes this shape");
+      c->async_pending = true;
+      if (st.counts) {
+        hipLaunchKernelGGL(fill_u64_kernel, dim3(1024), dim3(256), 0, c->stream, st.counts, rd->n_reads,
+                           (uint64_t)nwin);
+        HIPCHK(hipGetLastError());
+      }
+      if (total_out) *total_out = dense;
+      return NTHIP_OK;
+    }
     uint32_t dirty = 1;
     if (fast_ran) {
       HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1256,6 +1290,8 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
     }
     // dirty: some byte is not ACGTU -> redo on an N-aware path (device side)
   }
+  if (!done && (flags & NTHIP_ASYNC))
+    return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_ASYNC: not a plain dense call (offsets, pos / strand outputs, capacity)");
   if (!done && na_ok) {
     KmerFixedArgs consts;
     memset(&consts, 0, sizeof consts);
@@ -1508,6 +1544,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
   if (!out || !out->hashes) return fail(NTHIP_ERR_ARG, "out->hashes is NULL");
   const uint32_t m2 = m28, k = sd->k;
   if (m2 == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes_per_seed must be >= 1");
+  if (c->async_pending) return fail(NTHIP_ERR_ARG, "NTHIP_ASYNC batches are pending: call nthip_ctx_take_dirty first");
   HIPCHK(hipSetDevice(c->device));
   uint64_t total = 0;
   if (total_out) *total_out = 0;

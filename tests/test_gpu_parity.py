@@ -1116,3 +1116,40 @@ def test_seed_dirty_fixed_length_split_path(ctx, oracle, n, L, seeds, m2, stride
     assert got["total"] == want["total"]
     assert (got["counts"] == want["counts"]).all()
     assert (got["hashes"] == want["hashes"]).all()
+
+
+def test_async_dense_batches(ctx, oracle):
+    """NTHIP_ASYNC: many small device-resident batches back to back without a round trip per call;
+    nthip_ctx_take_dirty tells afterwards whether every stream is valid"""
+    import nthash_amd
+    from nthash_amd.capi import NTHIP_ASYNC
+    n, L, k, m, nb = 500, 150, 31, 2, 12
+    nwin = L - k + 1
+    d_in, d_out = ctx.malloc(nb * n * L), ctx.malloc(nb * n * nwin * m * 8)
+    ctx.synth_reads_ptr(d_in, 0, nb * n, L, 77)
+    for b in range(nb):
+        tot = ctx.kmer_hash_ptr(d_in + b * n * L, 0, n, L, 0, k, m, d_out + b * n * nwin * m * 8, n * nwin, flags=NTHIP_ASYNC)
+        assert tot == n * nwin
+    assert ctx.take_dirty() is False
+    got = np.zeros(nb * n * nwin * m, np.uint64)
+    ctx.d2h(got, d_out)
+    data = oracle.synth_reads(0, nb * n, L, 77)
+    want = oracle.kmer_batch(data, np.arange(nb * n + 1, dtype=np.uint64) * L, k, m, want_pos=False)["hashes"]
+    assert (got == want.ravel()).all()
+    # a batch with a non-base: reported, and synchronous calls are refused until it has been taken
+    ctx.h2d(d_in + 5 * n * L + 77, np.frombuffer(b"N", np.uint8))
+    for b in range(nb):
+        ctx.kmer_hash_ptr(d_in + b * n * L, 0, n, L, 0, k, m, d_out + b * n * nwin * m * 8, n * nwin, flags=NTHIP_ASYNC)
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin)
+    assert ctx.take_dirty() is True
+    assert ctx.take_dirty() is False
+    # not a plain dense call
+    d_offs = ctx.malloc(16)
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.kmer_hash_ptr(d_in, d_offs, 1, 0, 0, k, m, d_out, n * nwin, flags=NTHIP_ASYNC)
+    # and the ordinary path still works
+    tot = ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin)
+    assert tot == n * nwin
+    for d in (d_in, d_out, d_offs):
+        ctx.free(d)

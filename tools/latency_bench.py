@@ -16,5 +16,10 @@ for n in (1, 100, 10_000, 100_000, 1_000_000):
     for _ in range(reps):
         ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin)
     dt = (time.perf_counter() - t0) / reps
-    print(f"n_reads={n:8d}  {dt*1e6:8.1f} us/call  {n*nwin/dt/1e9:8.2f} Gkmer/s")
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin, flags=nthash_amd.capi.NTHIP_ASYNC)
+    assert ctx.take_dirty() is False
+    da = (time.perf_counter() - t0) / reps
+    print(f"n_reads={n:8d}  {dt*1e6:8.1f} us/call  {n*nwin/dt/1e9:8.2f} Gkmer/s   |  NTHIP_ASYNC {da*1e6:7.1f} us/call  {n*nwin/da/1e9:8.2f} Gkmer/s")
     ctx.free(d_in); ctx.free(d_out)
