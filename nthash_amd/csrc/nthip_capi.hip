@@ -1404,14 +1404,14 @@ struct SeedWavePlan {
 };
 bool seed_wave_plan(const nthip_ctx* c, const nthip_seeds* sd, uint32_t m2, SeedWavePlan* p)
 {
-  if (sd->k > 64 || sd->k < 2) return false;
+  if (sd->k + 64u > SEED_WAVE_LMAX || sd->k < 2) return false; // a segment must hold some windows
   const uint32_t per = sd->n_seeds * m2, lmax = SEED_WAVE_LMAX;
   const uint32_t raw_dw = (lmax + 64u) >> 2, code_dw = (lmax >> 4) + 8u, bit_dw = (lmax >> 5) + 8u;
   const size_t pw_count = (size_t)((raw_dw + code_dw + 2u * bit_dw + 3u) & ~3u) * 4;
   const size_t pw_hash = (size_t)((raw_dw + code_dw + 2u * bit_dw + 64u * per * 2u + 3u) & ~3u) * 4;
-  const size_t tables = (size_t)sd->n_seeds * sd->ntab * 256 * sizeof(uint4);
+  const size_t tables = sd->k <= 64 ? (size_t)sd->n_seeds * sd->ntab * 256 * sizeof(uint4) : 0; // k > 64: Horner, no tables
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
-  p->nw = (sd->k + 15) / 16;
+  p->nw = sd->k <= 64 ? (sd->k + 15) / 16 : 0;
   for (uint32_t w = 16; w >= 1; --w)
     if (pw_count * w <= cap) { p->waves_count = w; p->lds_count = pw_count * w; break; }
   for (uint32_t w = 16; w >= 2; --w)
@@ -1437,6 +1437,7 @@ int launch_seed_wave(nthip_ctx* c, const SeedWavePlan& plan, uint64_t n_items, b
     return NTHIP_OK;
   };
   switch (plan.nw) {
+    case 0: return go(seed_wave_kernel<COUNT_ONLY, 0>); // k > 64
     case 1: return go(seed_wave_kernel<COUNT_ONLY, 1>);
     case 2: return go(seed_wave_kernel<COUNT_ONLY, 2>);
     case 3: return go(seed_wave_kernel<COUNT_ONLY, 3>);

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(1024) void seed_wave_kernel(const SeedGeneralArgs* 
   const uint32_t k = a.k, per = a.n_seeds * a.m2, lmax = a.wave_lmax;
   // LDS: [tables] | per wave { raw bytes | codes | validity | triggers / emission | record tile }
   uint4* tabs = (uint4*)lds_dyn;
-  const uint32_t n_entries = COUNT_ONLY ? 0u : a.n_seeds * a.ntab * 256u;
+  const uint32_t n_entries = (COUNT_ONLY || NW == 0) ? 0u : a.n_seeds * a.ntab * 256u;
   const uint32_t raw_dw = (lmax + 64u) >> 2, code_dw = (lmax >> 4) + 8u, bit_dw = (lmax >> 5) + 8u;
   const uint32_t tile_dw = COUNT_ONLY ? 0u : 64u * per * 2u;
   const uint32_t per_wave = (raw_dw + code_dw + 2u * bit_dw + tile_dw + 3u) & ~3u;
@@ -577,16 +577,18 @@ __global__ __launch_bounds__(1024) void seed_wave_kernel(const SeedGeneralArgs* 
         bool emit;
         if (any_nul) emit = in && ((tbits[pc >> 5] >> (pc & 31u)) & 1u);
         else emit = in && ws + pc >= next_pos_in &&
-                    (!any_bad || (windows_with_non_base(tbits, pc + 1u, k - 1u) & 1u) == 0u);
+                    (!any_bad || ((k <= 65u ? windows_with_non_base(tbits, pc + 1u, k - 1u)
+                                            : windows_with_non_base_long(tbits, pc + 1u, k - 1u, 1u)) & 1u) == 0u);
         const uint64_t eb = __ballot(emit);
         const uint32_t n_e = (uint32_t)__builtin_popcountll(eb);
         if (COUNT_ONLY) { emitted_before += n_e; continue; }
         if (n_e == 0) continue;
         const uint32_t slot = (uint32_t)__builtin_popcountll(eb & ((1ull << lane) - 1ull));
         if (emit) {
-          const bool dirty_win = any_bad && (windows_with_non_base(vbits, pc, k) & 1u);
+          // NW == 0 (k > 64): every window by Horner over its raw bytes, no tables
+          const bool dirty_win = NW == 0 || (any_bad && (windows_with_non_base(vbits, pc, k) & 1u));
           uint64_t* mine = otile + slot * per;
-          uint32_t wwords[NW];
+          uint32_t wwords[NW ? NW : 1];
           if (!dirty_win) {
             const uint32_t d = pc >> 4, sh = (pc & 15u) << 1;
             uint32_t lo = bits[d];

@@ -13,7 +13,7 @@ alph = np.frombuffer(b"ACGTacgtUu", dtype=np.uint8)
 bad_alph = np.frombuffer(b"NnRYKMSWBDHV-*.\x00\x01\x07", dtype=np.uint8)
 fails = 0
 for it in range(iters):
-    k = int(rng.choice([3, 4, 5, 8, 15, 16, 17, 25, 31, 32, 33, 47, 48, 49, 63, 64]))
+    k = int(rng.choice([3, 4, 5, 8, 15, 16, 17, 25, 31, 32, 33, 47, 48, 49, 63, 64, 65, 66, 80, 100, 127, 128, 200]))
     m2 = int(rng.integers(1, 6))
     seeds = []
     for _ in range(int(rng.integers(1, 4))):
