@@ -150,6 +150,38 @@ def test_oracle_vs_reference_random(oracle, reference):
             assert (a[key] == b[key]).all(), (it, key, seeds)
 
 
+def test_oracle_vs_reference_long_k_many_hashes(oracle, reference):
+    """the restatement against the REAL reference beyond k = 64 and m = 8 (the GPU's Horner first window, computed
+    multipliers and long-k validity are checked against this oracle): k up to 1100 crosses the 1023 period of the
+    split rotate, m up to 255, spaced seeds up to k = 200, with non-bases"""
+    rng = np.random.default_rng(12)
+    alph = np.frombuffer(b"ACGTacgtUuNnRY-", dtype=np.uint8)
+    for it, (k, m) in enumerate([(65, 1), (96, 2), (100, 12), (127, 3), (128, 1), (200, 9), (255, 2), (300, 40),
+                                 (1000, 1), (1023, 2), (1024, 1), (1100, 3), (31, 255), (64, 100)]):
+        reads = []
+        for _ in range(4):
+            L = int(rng.integers(0, k + 400))
+            idx = np.where(rng.random(L) < 0.995, rng.integers(0, 10, L), rng.integers(10, len(alph), L))
+            reads.append(alph[idx].tobytes())
+        d, offs = concat_reads(reads)
+        a = oracle.kmer_batch(d, offs, k, m, want_strands=True)
+        b = reference.kmer_batch(d, offs, k, m, want_strands=True)
+        assert a["total"] == b["total"], (k, m)
+        for key in ("hashes", "pos", "fwd", "rev", "counts"):
+            assert (a[key] == b[key]).all(), (k, m, key)
+        if k <= 200:
+            seeds = []
+            for _s in range(2):
+                half = "".join("1" if rng.random() < 0.6 else "0" for _ in range((k + 1) // 2))
+                seeds.append(half + half[: k // 2][::-1])
+            m2 = min(m, 5)
+            a = oracle.seed_batch(d, offs, seeds, k, m2)
+            b = reference.seed_batch(d, offs, seeds, k, m2)
+            assert a["total"] == b["total"], (k, "seeds")
+            for key in ("hashes", "pos", "counts"):
+                assert (a[key] == b[key]).all(), (k, key, "seeds")
+
+
 def test_properties_canonical_and_full_care_seed(oracle):
     rng = np.random.default_rng(5)
     for _ in range(50):
