@@ -175,6 +175,16 @@ int nthip_kmer_bloom_insert(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k
 int nthip_kmer_bloom_query(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint8_t m,
                            const uint8_t* d_filter, uint64_t n_bits, uint64_t* hits, uint64_t* total,
                            uint64_t* total_hits, uint32_t flags);
+/*
+ * nthip_kmer_minhash: per-read MinHash signatures, the other thing callers do with m hashes per k-mer
+ * (sketching: one minimum per hash function).  signatures[r*m + i] = the minimum of hashes()[i] over the
+ * k-mers NtHash emits for read r (src/kmer.cpp:228-264 for the emission rule, src/internal.hpp:104-118
+ * for hashes()[i]); UINT64_MAX for a read without a valid k-mer.  The hashes stay in registers: the
+ * kernel reads the bases and writes 8*m bytes per READ.  signatures: device memory, or host memory with
+ * NTHIP_HOST_OUTPUT.  *total (optional) = k-mers consumed.  Fixed-length reads, any k >= 3, m >= 1.
+ */
+int nthip_kmer_minhash(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint8_t m,
+                       uint64_t* signatures, uint64_t* total, uint32_t flags);
 /* the same two operations on an already materialised stream of n_kmers*m hashes (device memory):
  * the unfused baseline, and the consumer for shapes the fused kernels do not take */
 int nthip_stream_bloom_insert(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t n_values,

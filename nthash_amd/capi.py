@@ -34,7 +34,7 @@ SYMBOLS = [
     "nthip_ctx_set_profiling", "nthip_last_kernel_ms", "nthip_malloc", "nthip_free",
     "nthip_memcpy_h2d", "nthip_memcpy_d2h", "nthip_memset", "nthip_kmer_hash", "nthip_seeds_create",
     "nthip_seeds_destroy", "nthip_seed_hash", "nthip_kmer_extend", "nthip_kmer_bloom_insert",
-    "nthip_kmer_bloom_query", "nthip_stream_bloom_insert", "nthip_kmer_hash_spans", "nthip_fastx_index",
+    "nthip_kmer_bloom_query", "nthip_kmer_minhash", "nthip_stream_bloom_insert", "nthip_kmer_hash_spans", "nthip_fastx_index",
     "nthip_fastx_kmer_hash_file", "nthip_fastx_seed_hash_file", "nthip_seed_hash_spans", "nthip_fasta_compact", "nthip_synth_reads", "nthip_checksum",
     "nthip_copy_bench",
 ]
@@ -109,6 +109,7 @@ def load():
     L.nthip_kmer_bloom_insert.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, u64, C.POINTER(u64), u32]
     L.nthip_kmer_bloom_query.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, u64, vp,
                                          C.POINTER(u64), C.POINTER(u64), u32]
+    L.nthip_kmer_minhash.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, C.POINTER(u64), u32]
     L.nthip_stream_bloom_insert.argtypes = [vp, vp, u64, vp, u64]
     L.nthip_kmer_hash_spans.argtypes = [vp, vp, u64, vp, vp, u64, C.c_uint16, C.c_uint8, C.POINTER(Out),
                                         C.POINTER(u64), u32]
@@ -286,6 +287,21 @@ class Context:
                                            C.c_void_p(hits) if hits else None, C.byref(total), C.byref(found),
                                            flags))
         return total.value, found.value
+
+    def minhash_ptr(self, seqs, n_reads, fixed_len, stride, k, m, sig, flags=0):
+        """per-read MinHash signatures into sig[n_reads * m]; -> k-mers consumed"""
+        rd = Reads(seqs, None, n_reads, fixed_len, stride)
+        total = C.c_uint64(0)
+        _chk(self.L.nthip_kmer_minhash(self.h, C.byref(rd), k, m, C.c_void_p(sig), C.byref(total), flags))
+        return total.value
+
+    def minhash(self, data, k, m, fixed_len, n_reads, stride=0):
+        """-> (signatures [n_reads, m], k-mers consumed)"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        sig = np.zeros((n_reads, m), np.uint64)
+        total = self.minhash_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, sig.ctypes.data,
+                                 flags=NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT)
+        return sig, total
 
     def stream_bloom_insert_ptr(self, d_hashes, n_values, d_filter, n_bits):
         _chk(self.L.nthip_stream_bloom_insert(self.h, C.c_void_p(d_hashes), n_values, C.c_void_p(d_filter), n_bits))

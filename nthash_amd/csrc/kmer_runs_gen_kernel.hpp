@@ -2,9 +2,10 @@
 //   kmer_runs_gen_kernel<NW, DT, false>  dense stream (optimistic pass: every byte a base)
 //   kmer_runs_gen_kernel<NW, DT, true>   N-aware hash pass: compact stream at scanned tile offsets
 //   kmer_runs_count_kernel               N-aware count pass: valid windows per tile / per read
-//   kmer_runs_gen_kernel<NW, DT, true, SINK_BLOOM_INSERT / SINK_BLOOM_QUERY>
+//   kmer_runs_gen_kernel<NW, DT, true, SINK_BLOOM_INSERT / SINK_BLOOM_QUERY / SINK_MINHASH>
 //                                        fused consumers: the hashes of a tile go from LDS straight
-//                                        into a Bloom filter (set / test bits), never to HBM
+//                                        into a Bloom filter (set / test bits), or from registers
+//                                        into per-read MinHash signatures -- never to HBM
 //
 // kmer_runs_kernel.hpp needs the run length C to divide the window count and
 // stages whole reads; that leaves cliffs (a prime window count, reads of 10 kb).
@@ -48,7 +49,10 @@ namespace ntamd {
 #endif
 constexpr uint32_t KRG_ALIGN_U64 = 128; // the output tile is aligned to 1 KiB of the stream
 constexpr uint32_t KRG_SLACK_U64 = 16;  // N-aware: room below the tile for a first run's recomputed windows
-enum : int { SINK_NONE = 0, SINK_BLOOM_INSERT = 1, SINK_BLOOM_QUERY = 2 };
+enum : int { SINK_NONE = 0, SINK_BLOOM_INSERT = 1, SINK_BLOOM_QUERY = 2, SINK_MINHASH = 3, SINK_MINHASH1 = 4 };
+// (SINK_MINHASH1: the signature is the minimum canonical hash alone -- one register pair, no multiplies)
+constexpr uint32_t KRG_SIG_MAX = 8;     // MinHash: signature entries one launch keeps in registers
+constexpr uint32_t KRG_TILE_READS = 66; // reads a tile of 64 runs can touch, rounded up
 
 struct KmerRunsGenArgs {
   const uint8_t* seqs;
@@ -85,6 +89,10 @@ struct KmerRunsGenArgs {
   uint64_t bloom_magic;      // floor((2^64 - 1) / n_bits), 0 when n_bits is a power of two
   uint64_t* hits;            // query, optional: per-read k-mers found
   uint64_t* sink_totals;     // [0] += k-mers consumed, [1] += k-mers found (query)
+  // MinHash: sig[r * m + i] = min over read r's k-mers of hashes()[i], for sig_first <= i < sig_first + sig_n
+  // (sig_n <= KRG_SIG_MAX; preset to all ones by the host)
+  uint64_t* sig;
+  uint32_t sig_first, sig_n;
   // N-aware pass: what a k-mer's value is -- 0: the canonical hash (+ m-1 mixes), 1: the forward-strand hash,
   // 2: the reverse-strand hash (NtHash::get_forward_hash / get_reverse_hash; one value per k-mer, m must be 1)
   uint32_t value_sel, pad2;
@@ -436,6 +444,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
   cur.shift = cur.slab_bytes = cur.n_vec = cur.runs_here = cur.n_kmers = cur.w_first = 0;
   cur.edge = 1u;
   static_assert(SINK == SINK_NONE || NA, "consumers run on the N-aware pass");
+  constexpr bool MINH = SINK == SINK_MINHASH || SINK == SINK_MINHASH1;
+  constexpr uint32_t N_MN = SINK == SINK_MINHASH ? KRG_SIG_MAX : 1u;
   uint64_t cur_off = 0; // N-aware: compact stream index of the tile's first emitted k-mer
   uint64_t sum_emit = 0, sum_hits = 0; // consumers: k-mers consumed / found by this wave
   bool test_first = true;              // Bloom insert: look at the bit before the atomic (see below)
@@ -502,8 +512,9 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     if constexpr (NA) {
       const uint32_t dup = live && last_run ? a.last_dup : 0u; // windows the run before already covers
       const uint32_t run_mask = live ? ((1u << C) - 1u) & ~((1u << dup) - 1u) : 0u;
-      valid = ~(k <= 64u ? windows_with_non_base((const uint32_t*)vbits, b0, k)
-                         : windows_with_non_base_long((const uint32_t*)vbits, b0, k, C)) & run_mask;
+      const uint32_t with_non_base = k <= 64u ? windows_with_non_base((const uint32_t*)vbits, b0, k)
+                                              : windows_with_non_base_long((const uint32_t*)vbits, b0, k, C);
+      valid = ~with_non_base & run_mask;
       const uint32_t cnt = __builtin_popcount(valid);
       uint32_t incl = cnt;
 #pragma unroll
@@ -514,7 +525,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
       lane_off = incl - cnt;
       n_emit = __shfl(incl, 63, 64);
       // (consumers always compact: slots 0 .. n_emit-1 of the tile, no alignment shift)
-      all_valid = SINK == SINK_NONE && __ballot(valid != run_mask) == 0;
+      // (MinHash folds every window of a clean tile, the recomputed ones too: those must be valid as well --
+      // the run they repeat may sit in another wave's tile)
+      all_valid = MINH ? __ballot(live && (with_non_base & ((1u << C) - 1u)) != 0u) == 0
+                       : SINK == SINK_NONE && __ballot(valid != run_mask) == 0;
       // clean tile: window j of the run goes to lane_off + j - dup (a recomputed
       // window lands on the slot the previous run gives the same value)
       if (all_valid) lane_off -= dup;
@@ -529,6 +543,9 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     uint32_t* my_pos = ptile + (int32_t)lane_off;
     const bool want_pos = NA && (SINK == SINK_BLOOM_QUERY || a.pos != nullptr); // query: the k-mer's read
     uint32_t slot = 0; // N-aware, tile with non-bases: next free slot of this lane
+    uint64_t mn[N_MN]; // MinHash: this run's minima
+#pragma unroll
+    for (uint32_t i = 0; i < N_MN; ++i) mn[i] = ~0ull;
 
     const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
     uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
@@ -555,6 +572,23 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     // window j of the run has just been hashed
     auto emit = [&](uint32_t j, auto clean_tag) {
       uint64_t h = canon_pair(f_lo, f_hi, r_lo, r_hi);
+      if constexpr (MINH) {
+        // the consumer lives in registers: nothing of the k-mer is written anywhere.  (Clean tile: a
+        // recomputed window repeats a value the minimum has already seen.)
+        const bool on = decltype(clean_tag)::value || ((valid >> j) & 1u);
+        if constexpr (SINK == SINK_MINHASH1) {
+          mn[0] = on && h < mn[0] ? h : mn[0];
+        } else {
+#pragma unroll
+          for (uint32_t i = 0; i < N_MN; ++i)
+            if (i < a.sig_n) {
+              const uint32_t hi_idx = a.sig_first + i;
+              const uint64_t hv = hi_idx == 0u ? h : mix_hash(h, ((uint64_t)hi_idx ^ kmul));
+              mn[i] = on && hv < mn[i] ? hv : mn[i];
+            }
+        }
+        return;
+      }
       if (NA && SINK == SINK_NONE && a.value_sel != 0u)
         h = a.value_sel == 1u ? (((uint64_t)f_hi << 32) | f_lo) : (((uint64_t)r_hi << 32) | r_lo);
       if constexpr (decltype(clean_tag)::value) {
@@ -731,6 +765,26 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
       sum_hits += mine;
+      sum_emit += n_emit;
+      n_counted = 0;
+    } else if constexpr (MINH) {
+      // runs of one read sit in neighbouring lanes: fold them in LDS (the tile is not used by this
+      // consumer), then one global atomic per read and signature entry the tile touched
+      uint64_t* rmin = tile;
+      const uint32_t n_slots = KRG_TILE_READS * a.sig_n;
+      for (uint32_t i = lane; i < n_slots; i += 64u) rmin[i] = ~0ull;
+      lds_sync();
+#pragma unroll
+      for (uint32_t i = 0; i < N_MN; ++i)
+        if (i < a.sig_n && mn[i] != ~0ull) atomicMin((unsigned long long*)&rmin[lr * a.sig_n + i], (unsigned long long)mn[i]);
+      lds_sync();
+      for (uint32_t i = lane; i < n_slots; i += 64u) {
+        const uint64_t v = rmin[i];
+        if (v != ~0ull) {
+          const uint32_t rr = i / a.sig_n, ii = i - rr * a.sig_n;
+          atomicMin((unsigned long long*)&a.sig[(my_rf + rr) * m + a.sig_first + ii], (unsigned long long)v);
+        }
+      }
       sum_emit += n_emit;
       n_counted = 0;
     } else if (m == 1u) {

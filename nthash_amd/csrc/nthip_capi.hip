@@ -662,9 +662,13 @@ struct GenPlan {
   size_t lds = 0;
 };
 
-bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, GenPlan* p)
+// gaps_ok: rows may be padded (stride > len).  The padding travels through the slab like any other byte, so
+// the dense pass -- which flags every non-base it stages -- does not take such batches; the N-aware passes do
+// (no window reaches into the padding).
+bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, GenPlan* p,
+                   bool gaps_ok = false)
 {
-  if (len < k || m == 0 || stride > len || len >= (1u << 30)) return false;
+  if (len < k || m == 0 || (stride > len && !gaps_ok) || len >= (1u << 30) || stride >= (1u << 30)) return false;
   const uint32_t nwin = len - k + 1;
   if (stride < nwin) return false; // reads overlapping by more than k-1 bases: other paths
   const uint32_t ntab = (k + 3) / 4; // first-window cost in the model (table lookups or Horner steps)
@@ -741,17 +745,24 @@ struct NaPlan {
 };
 
 bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, bool want_pos,
-                  NaPlan* p)
+                  NaPlan* p, uint32_t register_sink_u64 = 0)
 {
-  if (!kmer_gen_plan(c, len, stride, k, m, &p->g)) return false;
+  if (!kmer_gen_plan(c, len, stride, k, m, &p->g, /*gaps_ok*/ true)) return false;
   const GenPlan& g = p->g;
   p->tile_u64 = 64 * g.C + KRG_ALIGN_U64 + KRG_SLACK_U64;
+  // a consumer that keeps the hashes in registers (MinHash) needs no tile, only its fold area
+  if (register_sink_u64) p->tile_u64 = (register_sink_u64 + 1u) & ~1u;
   p->ptile_dwords = want_pos ? (64 * g.C + KRG_SLACK_U64 + 3u) & ~3u : 0u;
   p->vbits_dwords = (g.bits_dwords / 2 + 8 + 3u) & ~3u; // 16 validity bits per 32 stream bits, read 4 dwords ahead
   const size_t fixed = (size_t)kmer_ntab(k) * 4096 + 256 + 64;
   const size_t per_wave = (size_t)p->tile_u64 * 8 + ((size_t)p->ptile_dwords + g.bits_dwords + p->vbits_dwords) * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
-  for (uint32_t w = 8; w >= 1; --w)
+  uint32_t w_max = register_sink_u64 ? 16 : 8;
+  if (const char* t = getenv("NTHIP_TUNE_NA_WAVES")) {
+    const uint32_t w = (uint32_t)atoi(t);
+    if (w >= 1 && w <= 16) w_max = w;
+  }
+  for (uint32_t w = w_max; w >= 1; --w)
     if (fixed + per_wave * w <= cap) {
       p->waves = w;
       p->lds = fixed + per_wave * w;
@@ -795,6 +806,8 @@ template <bool NA, int SINK = SINK_NONE>
 int launch_kmer_runs_gen_nw(nthip_ctx* c, const KmerRunsGenArgs& ga, size_t lds, uint32_t nw, bool dt)
 {
   const char* label = SINK == SINK_BLOOM_INSERT  ? "kmer_runs_gen_kernel(bloom insert)"
+                      : SINK == SINK_MINHASH     ? "kmer_runs_gen_kernel(minhash)"
+                      : SINK == SINK_MINHASH1    ? "kmer_runs_gen_kernel(minhash, m = 1)"
                       : SINK == SINK_BLOOM_QUERY ? "kmer_runs_gen_kernel(bloom query)"
                       : NA                       ? "kmer_runs_gen_kernel(N-aware)"
                                                  : "kmer_runs_gen_kernel";
@@ -1885,6 +1898,76 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
   return NTHIP_OK;
 }
 
+// per-read MinHash signatures: the k-mer hashes never leave the registers (kmer_runs_gen_kernel, SINK_MINHASH)
+int run_kmer_minhash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8, uint64_t* sig, uint64_t* total_out,
+                     uint32_t flags)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  NTCHK(check_reads(rd));
+  const uint32_t k = k16, m = m8;
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
+  if (k < 3) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 is undefined in the reference (src/kmer.cpp:47)");
+  if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
+  if (rd->n_reads && !sig) return fail(NTHIP_ERR_ARG, "signatures is NULL");
+  if (rd->offsets) return fail(NTHIP_ERR_UNSUPPORTED, "fused consumers take fixed-length reads (offsets == NULL)");
+  HIPCHK(hipSetDevice(c->device));
+  if (total_out) *total_out = 0;
+  if (rd->n_reads == 0) return NTHIP_OK;
+  const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
+  const bool host_sig = (flags & NTHIP_HOST_OUTPUT) != 0;
+  const size_t sig_bytes = rd->n_reads * (size_t)m * sizeof(uint64_t);
+  if (len < k) { // no read has a k-mer
+    if (host_sig) memset(sig, 0xFF, sig_bytes);
+    else {
+      HIPCHK(hipMemsetAsync(sig, 0xFF, sig_bytes, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return NTHIP_OK;
+  }
+  const uint32_t per_launch = m < KRG_SIG_MAX ? m : KRG_SIG_MAX;
+  NaPlan plan;
+  if (!kmer_na_plan(c, len, stride, k, m, false, &plan, KRG_TILE_READS * per_launch))
+    return fail(NTHIP_ERR_UNSUPPORTED, "shape outside the fused consumer kernels (stride >= windows)");
+  uint64_t total_bytes = 0;
+  NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
+  Staged st;
+  NTCHK(stage_inputs(c, rd, flags, total_bytes, st));
+  uint64_t* d_sig = sig;
+  if (host_sig) {
+    HIPCHK(hipMalloc((void**)&d_sig, sig_bytes));
+    st.owned.push_back(d_sig);
+  }
+  HIPCHK(hipMemsetAsync(d_sig, 0xFF, sig_bytes, c->stream));
+  KmerFixedArgs consts;
+  memset(&consts, 0, sizeof consts);
+  fill_kmer_consts(k, m, consts);
+  KmerRunsGenArgs a;
+  fill_gen_args(a, c, st, rd, k, m, plan.g, consts);
+  NTCHK(get_kmer_tab(c, k, &a.init_tab));
+  a.hashes = nullptr;
+  a.vbits_dwords = plan.vbits_dwords;
+  a.ptile_dwords = plan.ptile_dwords;
+  a.tile_u64 = plan.tile_u64;
+  a.waves = plan.waves;
+  a.sig = d_sig;
+  a.sink_totals = (uint64_t*)(c->d_small + 16);
+  HIPCHK(hipMemsetAsync(c->d_small + 16, 0, 16, c->stream));
+  uint32_t launches = 0;
+  for (uint32_t first = 0; first < m; first += KRG_SIG_MAX, ++launches) { // KRG_SIG_MAX entries per pass
+    a.sig_first = first;
+    a.sig_n = m - first < KRG_SIG_MAX ? m - first : KRG_SIG_MAX;
+    if (m == 1) NTCHK((launch_kmer_runs_gen_nw<true, SINK_MINHASH1>(c, a, plan.lds, plan.g.nw, plan.g.dword_tail != 0)));
+    else NTCHK((launch_kmer_runs_gen_nw<true, SINK_MINHASH>(c, a, plan.lds, plan.g.nw, plan.g.dword_tail != 0)));
+  }
+  HIPCHK(hipMemcpyAsync(c->h_small + 16, c->d_small + 16, 16, hipMemcpyDeviceToHost, c->stream));
+  if (host_sig) HIPCHK(hipMemcpyAsync(sig, d_sig, sig_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t tot = 0;
+  memcpy(&tot, c->h_small + 16, 8);
+  if (total_out) *total_out = tot / launches; // every pass consumes every k-mer
+  return NTHIP_OK;
+}
+
 } // namespace
 
 extern "C" int nthip_kmer_bloom_insert(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m, uint8_t* d_filter,
@@ -1898,6 +1981,12 @@ extern "C" int nthip_kmer_bloom_query(nthip_ctx* c, const nthip_reads* rd, uint1
                                       uint64_t* total_hits, uint32_t flags)
 {
   return run_kmer_bloom(c, rd, k, m, (uint32_t*)d_filter, n_bits, hits, total, total_hits, flags, true);
+}
+
+extern "C" int nthip_kmer_minhash(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m, uint64_t* signatures,
+                                  uint64_t* total, uint32_t flags)
+{
+  return run_kmer_minhash(c, rd, k, m, signatures, total, flags);
 }
 
 extern "C" int nthip_stream_bloom_insert(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, uint8_t* d_filter,

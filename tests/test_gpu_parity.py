@@ -778,6 +778,81 @@ def test_bloom_argument_errors(ctx):
     ctx.free(d_f)
 
 
+def _minhash_expected(want, n, m):
+    """per-read minimum of every hash column of the oracle's stream; all ones for a read without k-mers"""
+    hs = np.ascontiguousarray(want["hashes"]).reshape(-1, m)
+    counts = want["counts"].astype(np.int64)
+    sig = np.full((n, m), np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64)
+    start = np.concatenate(([0], np.cumsum(counts)))[:-1]
+    has = counts > 0
+    if has.any():
+        sig[has] = np.minimum.reduceat(hs, start[has], axis=0)
+    return sig
+
+
+@pytest.mark.parametrize("n,L,k,m,bad_every", [
+    (3000, 150, 31, 1, 0), (3000, 150, 31, 1, 211), (2500, 150, 31, 4, 0), (1500, 151, 31, 3, 97),
+    (1000, 100, 64, 3, 401), (700, 250, 21, 8, 53), (500, 149, 31, 12, 307), (60, 5003, 31, 2, 1009),
+    (300, 400, 101, 9, 997), (4000, 35, 31, 2, 41), (129, 31, 31, 5, 7), (900, 64, 5, 1, 3),
+])
+def test_minhash_signatures_match_oracle_stream(ctx, oracle, n, L, k, m, bad_every):
+    """fused consumer: signatures[r][i] == min over the oracle's k-mers of read r of hash i (bit-exact;
+    min is order-free); reads without a valid k-mer keep UINT64_MAX"""
+    data = oracle.synth_reads(4, n, L, 1234 + L).copy()
+    if bad_every:
+        data[bad_every // 2::bad_every] = ord("N")
+        data[L * (n // 3): L * (n // 3 + 1)] = ord("n")     # one read without any k-mer
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    sig, total = ctx.minhash(data, k, m, L, n)
+    assert total == want["total"]
+    expect = _minhash_expected(want, n, m)
+    assert (sig == expect).all()
+
+
+@pytest.mark.parametrize("n,L,k,m,stride", [(13529, 92, 55, 3, 38), (20000, 151, 31, 2, 0), (9000, 100, 64, 1, 37)])
+def test_minhash_sparse_non_bases_across_tile_boundaries(ctx, oracle, n, L, k, m, stride):
+    """a read whose runs sit in two wave tiles, with a non-base only in the part the second tile recomputes:
+    the recomputed windows must not enter the minimum (found by tools/stress_shapes.py)"""
+    rng = np.random.default_rng(n)
+    total = n * L if stride == 0 else (n - 1) * stride + L
+    data = np.frombuffer(b"ACGTacgtUu", dtype=np.uint8)[rng.integers(0, 10, total)]
+    data[rng.integers(0, total, total // 2500)] = ord("N")
+    step = stride if stride else L
+    reads = np.lib.stride_tricks.as_strided(data, (n, L), (step, 1)).copy()
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(reads.ravel(), offs, k, m, want_pos=False)
+    sig, total_k = ctx.minhash(data, k, m, L, n, stride=stride)
+    assert total_k == want["total"]
+    assert (sig == _minhash_expected(want, n, m)).all()
+
+
+def test_minhash_device_io_stride_and_errors(ctx, oracle):
+    import nthash_amd
+    from nthash_amd.capi import NTHIP_HOST_INPUT
+    n, L, stride, k, m = 800, 120, 128, 25, 3
+    rows = oracle.synth_reads(9, n, L, 77).reshape(n, L)
+    padded = np.full((n, stride), ord("N"), np.uint8)
+    padded[:, :L] = rows
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(rows.ravel(), offs, k, m, want_pos=False)
+    d_in = ctx.malloc(padded.size)
+    ctx.h2d(d_in, padded.ravel())
+    d_sig = ctx.malloc(n * m * 8)
+    total = ctx.minhash_ptr(d_in, n, L, stride, k, m, d_sig)
+    got = np.zeros((n, m), np.uint64)
+    ctx.d2h(got, d_sig)
+    assert total == want["total"] and (got == _minhash_expected(want, n, m)).all()
+    ctx.free(d_in)
+    ctx.free(d_sig)
+    short, tot = ctx.minhash(rows.ravel()[: 10 * 20], 31, 2, 20, 10)          # reads shorter than k
+    assert tot == 0 and (short == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.minhash(rows.ravel(), 0, 1, L, n)
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.minhash_ptr(rows.ctypes.data, n, L, 0, k, m, 0, flags=NTHIP_HOST_INPUT)    # NULL signatures
+
+
 # ---------------------------------------------------------------------------
 # FASTQ / FASTA -> device batches (SURVEY 8f rank 2): device indexer, spans, file streaming
 # ---------------------------------------------------------------------------

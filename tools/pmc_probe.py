@@ -3,7 +3,7 @@
 (so FETCH_SIZE / WRITE_SIZE can be calibrated as MI355X_MICROARCH.md asks) and
 then the hot kernels on a reduced batch.
 
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python tools/pmc_probe.py [c2|c3|c4] [reads]
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python tools/pmc_probe.py [c2|c3|c4|mh|gen] [reads]
 """
 import os
 import sys
@@ -15,7 +15,10 @@ import nthash_amd  # noqa: E402
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000_000
 SEEDS = ["1010101010101010101010101010101", "1101101101101101011011011011011"]
-L, k, m, seeds = {"c2": (150, 31, 1, None), "c3": (150, 31, 4, None), "c4": (250, 31, 3, SEEDS)}[cfg]
+L, k, m, seeds = {"c2": (150, 31, 1, None), "c3": (150, 31, 4, None), "c4": (250, 31, 3, SEEDS),
+                  "mh": (150, 31, 1, None), "gen": (150, 31, 1, None)}[cfg]   # mh: fused MinHash; gen: general kernel
+if cfg == "gen":
+    os.environ["NTHIP_TUNE_NO_SPECIAL"] = "1"
 per = m if seeds is None else len(seeds) * m
 nwin = L - k + 1
 ctx = nthash_amd.Context(0)
@@ -32,7 +35,9 @@ ctx.synth_reads_ptr(d_in, 0, n, L, 42)
 ctx.set_profiling(True)
 sd = nthash_amd.Seeds(ctx, seeds, k) if seeds else None
 for _ in range(3):
-    if sd is None:
+    if cfg == "mh":
+        ctx.minhash_ptr(d_in, n, L, 0, k, m, d_out)
+    elif sd is None:
         ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin)
     else:
         ctx.seed_hash_ptr(d_in, 0, n, L, 0, sd, m, d_out, n * nwin)

@@ -27,7 +27,15 @@ for it in range(iters):
         if kind == 1 and L > k:  # overlapping runs of one sequence
             stride = L - k + 1
             total = (n - 1) * stride + L
+        padded = kind == 0 and rng.random() < 0.3   # rows with padding between the reads (any bytes)
+        if padded:
+            stride = L + int(rng.integers(1, 200))
+            total = (n - 1) * stride + L
         data = alph[rng.integers(0, len(alph), total)]
+        if padded:
+            if n > 1:
+                np.lib.stride_tricks.as_strided(data[L:], (n - 1, stride - L), (stride, 1), writeable=True)[:] = \
+                    (bad_alph if rng.random() < 0.5 else alph)[rng.integers(0, 9, (n - 1, stride - L))]
         if rng.random() < 0.5:
             nb = int(rng.integers(1, max(2, total // 2000)))
             data[rng.integers(0, total, nb)] = bad_alph[rng.integers(0, len(bad_alph) - 1, nb)]
@@ -36,6 +44,19 @@ for it in range(iters):
         a = ctx.kmer_hash(data, k, m, fixed_len=L, stride=stride, n_reads=n, want_pos=want_pos, want_strands=want_str)
         b = ctx.kmer_hash(data, k, m, fixed_len=L, stride=stride, n_reads=n, want_pos=want_pos, want_strands=want_str, flags=4)
         desc = f"fixed n={n} L={L} k={k} m={m} stride={stride} pos={want_pos}"
+        if (stride == 0 or stride >= L - k + 1) and rng.random() < 0.5:   # the fused MinHash consumer on the same batch
+            sig, tot = ctx.minhash(data, k, m, L, n, stride=stride)
+            hs = b["hashes"].reshape(-1, m)
+            cnt = b["counts"].astype(np.int64)
+            exp = np.full((n, m), np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64)
+            st0 = np.concatenate(([0], np.cumsum(cnt)))[:-1]
+            if (cnt > 0).any():
+                exp[cnt > 0] = np.minimum.reduceat(hs, st0[cnt > 0], axis=0)
+            if tot != b["total"] or not (sig == exp).all():
+                fails += 1
+                badix = np.argwhere(sig != exp)
+                print("MISMATCH minhash", desc, tot, b["total"], "entries", len(badix), badix[:6].tolist(),
+                      [(hex(int(sig[r, c])), hex(int(exp[r, c])), int(cnt[r])) for r, c in badix[:3]], flush=True)
     else:
         n = int(rng.integers(1, 4000))
         lens = np.where(rng.random(n) < 0.1, rng.integers(0, k + 2, n), rng.integers(0, 600 + 2 * k, n))
