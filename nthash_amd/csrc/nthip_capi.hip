@@ -1583,14 +1583,28 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
   } else if (!rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.pos && !st.fwd && !st.rev && m2 <= (uint32_t)SF_MAX_RUNTIME_M &&
              k <= 64 && stride <= len) {
     const uint32_t nwin = len - k + 1;
-    const size_t table_bytes = (size_t)sd->n_seeds * sd->ntab * 256 * sizeof(uint4);
+    const uint32_t nh = (k + 7) / 8; // 16-bit halves of the window; 2*nh byte tables per seed in LDS (zero-padded)
+    const size_t table_bytes = (size_t)sd->n_seeds * 2 * nh * 256 * sizeof(uint4);
     // tile = as many runs as give a ~8 KiB bit stream (32 Ki bases), at most 256
     uint32_t rpt = 32768u / stride;
     if (rpt > 256) rpt = 256;
     if (rpt < 1) rpt = 1;
+    {
+      // a tile's records are one contiguous piece of the stream: make every tile start on a KiB of it (or the
+      // largest power of two below that the read count allows), so that no store splits lines with another block's
+      const uint64_t tile_unit = (uint64_t)nwin * per * 8;
+      uint32_t mult_of = 1;
+      while (mult_of < 128 && ((tile_unit * mult_of) & 1023u) != 0) mult_of <<= 1;
+      while (mult_of > 1 && mult_of > rpt) mult_of >>= 1;
+      rpt -= rpt % mult_of;
+      if (const char* t = getenv("NTHIP_TUNE_SEED_RPT")) { // A/B override
+        const uint32_t v = (uint32_t)atoi(t);
+        if (v >= 1 && v <= 256) rpt = v;
+      }
+    }
     const uint64_t slab = 15ull + (uint64_t)(rpt - 1) * stride + len;
     const uint32_t bits_dwords = (uint32_t)((((slab + 15) >> 4) + 8 + 3) & ~3ull);
-    const size_t dyn = table_bytes + (size_t)bits_dwords * 4 + (size_t)(SF_THREADS / 64) * 64 * per * 8;
+    const size_t dyn = table_bytes + (size_t)bits_dwords * 4 + (size_t)(SF_THREADS / 64) * (64 * per + 2) * 8;
     const uint64_t dense = rd->n_reads * (uint64_t)nwin;
     if (dyn <= 158 * 1024 && dyn <= c->lds_max && (uint64_t)rpt * nwin < 0x7FFFFFFFull) {
       if (dense > out->capacity) {
@@ -1621,10 +1635,16 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
       for (uint32_t i = 0; i < (uint32_t)SF_MAX_RUNTIME_M; ++i) a.mult[i] = multiplier(k, i);
       HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream));
       int rc;
-      if (k <= 16) rc = launch_seed_fixed(c, seed_fixed_kernel<1>, a, dyn);
-      else if (k <= 32) rc = launch_seed_fixed(c, seed_fixed_kernel<2>, a, dyn);
-      else if (k <= 48) rc = launch_seed_fixed(c, seed_fixed_kernel<3>, a, dyn);
-      else rc = launch_seed_fixed(c, seed_fixed_kernel<4>, a, dyn);
+#define NT_SEED_FIXED(SPLIT_T, DYN) \
+  (nh == 1   ? launch_seed_fixed(c, seed_fixed_kernel<1, SPLIT_T>, a, DYN) \
+   : nh == 2 ? launch_seed_fixed(c, seed_fixed_kernel<2, SPLIT_T>, a, DYN) \
+   : nh == 3 ? launch_seed_fixed(c, seed_fixed_kernel<3, SPLIT_T>, a, DYN) \
+   : nh == 4 ? launch_seed_fixed(c, seed_fixed_kernel<4, SPLIT_T>, a, DYN) \
+   : nh == 5 ? launch_seed_fixed(c, seed_fixed_kernel<5, SPLIT_T>, a, DYN) \
+   : nh == 6 ? launch_seed_fixed(c, seed_fixed_kernel<6, SPLIT_T>, a, DYN) \
+   : nh == 7 ? launch_seed_fixed(c, seed_fixed_kernel<7, SPLIT_T>, a, DYN) \
+             : launch_seed_fixed(c, seed_fixed_kernel<8, SPLIT_T>, a, DYN))
+      rc = NT_SEED_FIXED(false, dyn);
       NTCHK(rc);
       HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
@@ -1712,10 +1732,8 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
         a.read_dirty = d_flags;
         a.read_off = d_roff;
         const size_t dyn2 = dyn + (size_t)rpt * 8;
-        if (k <= 16) rc = launch_seed_fixed(c, seed_fixed_kernel<1, true>, a, dyn2);
-        else if (k <= 32) rc = launch_seed_fixed(c, seed_fixed_kernel<2, true>, a, dyn2);
-        else if (k <= 48) rc = launch_seed_fixed(c, seed_fixed_kernel<3, true>, a, dyn2);
-        else rc = launch_seed_fixed(c, seed_fixed_kernel<4, true>, a, dyn2);
+        rc = NT_SEED_FIXED(true, dyn2);
+#undef NT_SEED_FIXED
         NTCHK(rc);
         if (n_dirty) {
           h.counts = nullptr;

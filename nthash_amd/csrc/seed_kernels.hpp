@@ -98,27 +98,35 @@ __global__ __launch_bounds__(256) void seed_list_kernel(const uint64_t* __restri
   if (r < n_reads && flags[r]) list[idx[r]] = r;
 }
 
-// NW = 32-bit words of 2-bit window kept in registers: k <= 16*NW
+// NH = 16-bit halves of the 2-bit window (8 bases each): k <= 8*NH.  Every seed has NT = 2*NH byte tables in LDS
+// (the ones past ceil(k/4) are zero), so the lookups of a window are unconditional and all in flight at once --
+// with a uniform branch around each one (a runtime table count) the compiler waits for every ds_read before it
+// issues the next: 16 serial LDS round trips per window for two k=31 seeds.
 // SPLIT: skip the reads flagged in a.read_dirty, write every other read at a.read_off (compact stream)
-template <int NW, bool SPLIT = false>
+template <int NH, bool SPLIT = false>
 __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedArgs a)
 {
+  constexpr int NW = (NH + 1) / 2; // 32-bit words of window kept in registers
+  constexpr uint32_t NT = 2u * NH; // byte tables per seed in LDS
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
-  // layout: [tables: n_seeds*ntab*256 uint4][bit stream]
-  // layout: [tables: n_seeds*ntab*256 uint4][bit stream][per-wave output tiles: 64*per u64]
+  // layout: [tables: n_seeds*NT*256 uint4][bit stream][per-wave output tiles: 64*per u64][SPLIT: read offsets]
   uint4* tabs = (uint4*)lds_dyn;
-  const uint32_t n_entries = a.n_seeds * a.ntab * 256u;
+  const uint32_t n_entries = a.n_seeds * NT * 256u;
   uint32_t* bits = lds_dyn + n_entries * 4u;
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = tid >> 6;
-  for (uint32_t i = tid; i < n_entries; i += SF_THREADS) tabs[i] = a.tables[i];
+  for (uint32_t i = tid; i < n_entries; i += SF_THREADS) {
+    const uint32_t tb = i >> 8, sd = tb / NT, jt = tb - sd * NT;
+    tabs[i] = jt < a.ntab ? a.tables[((size_t)sd * a.ntab + jt) * 256u + (i & 255u)] : make_uint4(0, 0, 0, 0);
+  }
 
   const uint32_t per = a.n_seeds * a.m2; // values per window
-  uint64_t* otile = (uint64_t*)(bits + a.bits_dwords) + wave * 64u * per;
+  const uint32_t otile_u64 = 64u * per + 2u; // + room to build the tile shifted by one value (see the copy-out)
+  uint64_t* otile = (uint64_t*)(bits + a.bits_dwords) + wave * otile_u64;
   // SPLIT: the tile's reads -- offset in the compact stream, or ~0 for a read left to the general kernel
-  uint64_t* roff = (uint64_t*)(bits + a.bits_dwords) + (SF_THREADS / 64u) * 64u * per;
+  uint64_t* roff = (uint64_t*)(bits + a.bits_dwords) + (SF_THREADS / 64u) * otile_u64;
   const uint32_t inv_per = 0xFFFFFFFFu / per + 1u; // v / per == umulhi(v, inv_per) for v < 2^29
   uint32_t bad = 0;
 
@@ -187,60 +195,37 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
         w[i] = funnel(hi, lo, sh);
         lo = hi;
       }
-      uint64_t* mine = otile + lane * per;
-      uint64_t held = 0;
+      // the 64 records are built shifted by the parity of their place in the output stream, so that both the
+      // LDS reads and the global stores of the copy-out are 16-byte aligned
+      uint64_t* const dst = a.hashes + (run0 * a.nwin + q0) * per;
+      const uint32_t par = SPLIT ? 0u : (uint32_t)(((uintptr_t)dst >> 3) & 1u);
+      uint64_t* mine = otile + par + lane * per;
       for (uint32_t s = 0; s < a.n_seeds; ++s) {
-        uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
-        const uint4* ts = tabs + s * a.ntab * 256u;
-#ifndef SF_BATCH_LOOKUPS
-#define SF_BATCH_LOOKUPS 0
-#endif
-#if SF_BATCH_LOOKUPS
-        {
-          // all lookups of the seed in flight, then XOR them two at a time (v_bitop3: a ^ b ^ c is one instruction)
-          uint4 e[4 * NW];
+        const uint4* ts = tabs + s * NT * 256u;
+        // all lookups of the seed in flight, then XOR them up
+        uint4 e[NT];
 #pragma unroll
-          for (int jt = 0; jt < 4 * NW; ++jt) {
-            const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
-            e[jt] = (uint32_t)jt < a.ntab ? ts[(uint32_t)jt * 256u + byte] : make_uint4(0, 0, 0, 0);
-          }
-#pragma unroll
-          for (int jt = 0; jt < 4 * NW; jt += 2) {
-            f0 = f0 ^ e[jt].x ^ e[jt + 1].x;
-            f1 = f1 ^ e[jt].y ^ e[jt + 1].y;
-            r0 = r0 ^ e[jt].z ^ e[jt + 1].z;
-            r1 = r1 ^ e[jt].w ^ e[jt + 1].w;
-          }
+        for (uint32_t jt = 0; jt < NT; ++jt) {
+          const uint32_t byte = (w[jt >> 2] >> ((jt & 3u) * 8u)) & 0xFFu;
+          e[jt] = ts[jt * 256u + byte];
         }
+        uint32_t f0 = e[0].x ^ e[1].x, f1 = e[0].y ^ e[1].y, r0 = e[0].z ^ e[1].z, r1 = e[0].w ^ e[1].w;
+#pragma unroll
+        for (uint32_t jt = 2; jt < NT; jt += 2) { // NT is even; a ^ b ^ c is one v_bitop3_b32
+#ifdef SF_NO_XOR3
+          f0 ^= e[jt].x ^ e[jt + 1].x; f1 ^= e[jt].y ^ e[jt + 1].y; r0 ^= e[jt].z ^ e[jt + 1].z; r1 ^= e[jt].w ^ e[jt + 1].w;
 #else
-#pragma unroll
-        for (int jt = 0; jt < 4 * NW; ++jt) {
-          if ((uint32_t)jt < a.ntab) {
-            const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
-            const uint4 e = ts[(uint32_t)jt * 256u + byte];
-            f0 ^= e.x; f1 ^= e.y; r0 ^= e.z; r1 ^= e.w;
-          }
-        }
+          f0 = __builtin_amdgcn_bitop3_b32(f0, e[jt].x, e[jt + 1].x, 0x96);
+          f1 = __builtin_amdgcn_bitop3_b32(f1, e[jt].y, e[jt + 1].y, 0x96);
+          r0 = __builtin_amdgcn_bitop3_b32(r0, e[jt].z, e[jt + 1].z, 0x96);
+          r1 = __builtin_amdgcn_bitop3_b32(r1, e[jt].w, e[jt + 1].w, 0x96);
 #endif
+        }
         const uint64_t h0 = canon_pair(f0, f1, r0, r1);
-#ifndef SF_PAIR_STORES
-#define SF_PAIR_STORES 0
-#endif
-#if SF_PAIR_STORES
-        // the record's values go to the tile two at a time (16-byte LDS writes; lane records are 16-byte aligned
-        // when `per` is even, which the launcher checks)
-        for (uint32_t jj = 0; jj < a.m2; ++jj) {
-          const uint64_t v = jj == 0 ? h0 : mix_hash(h0, a.mult[jj & (SF_MAX_RUNTIME_M - 1)]);
-          const uint32_t idx = s * a.m2 + jj;
-          if ((per & 1u) != 0u) mine[idx] = v; // odd records: lanes are only 8-byte aligned
-          else if (idx & 1u) *(ulonglong2*)(mine + idx - 1u) = make_ulonglong2(held, v);
-          else held = v;
-        }
-#else
         mine[s * a.m2] = h0;
-        for (uint32_t jj = 1; jj < a.m2; ++jj)
-          mine[s * a.m2 + jj] = mix_hash(h0, a.mult[jj & (SF_MAX_RUNTIME_M - 1)]);
-#endif
+#pragma unroll
+        for (uint32_t jj = 1; jj < (uint32_t)SF_MAX_RUNTIME_M; ++jj)
+          if (jj < a.m2) mine[s * a.m2 + jj] = mix_hash(h0, a.mult[jj]);
       }
 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -264,12 +249,17 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
           else *d = otile[v];
         }
       } else {
-        uint64_t* dst = a.hashes + (run0 * a.nwin + q0) * per;
-        for (uint32_t pi = lane; 2u * pi < n_vals; pi += 64u) {
-          const uint4 dv = *(const uint4*)(otile + 2u * pi);
-          if (2u * pi + 1u < n_vals) *(uint4*)(dst + 2u * pi) = dv;
-          else *(uint2*)(dst + 2u * pi) = make_uint2(dv.x, dv.y);
+        uint64_t* const base = dst - par; // 16-byte aligned; value i of the shifted tile goes to base[i]
+        const uint32_t span = par + n_vals;
+        for (uint32_t pi = par + lane; pi < (span >> 1); pi += 64u) { // whole 16-byte pieces
+#ifdef SF_STORE_PLAIN
+          *(nt_v4u*)(base + 2u * pi) = *(const nt_v4u*)(otile + 2u * pi);
+#else     // written once, never read back by this kernel: streaming stores (+1.1 % on BASELINE config 4)
+          __builtin_nontemporal_store(*(const nt_v4u*)(otile + 2u * pi), (nt_v4u*)(base + 2u * pi));
+#endif
         }
+        if (lane == 0u && par != 0u) base[1] = otile[1];                         // head
+        if (lane == 1u && (span & 1u) != 0u && span > 2u * par) base[span - 1u] = otile[span - 1u]; // tail
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
