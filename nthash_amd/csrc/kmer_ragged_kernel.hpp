@@ -384,12 +384,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
           lo = hi;
         }
 #pragma unroll
-        for (int jt = 0; jt < 4 * NW; ++jt) {
-          if ((uint32_t)jt < a.ntab) {
-            const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
-            const uint4 e = itab[(uint32_t)jt * 256u + byte];
-            f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
-          }
+        for (int jt = 0; jt < 4 * NW; ++jt) { // a.ntab == 4 * NW (zero tables past ceil(k/4)): no branch, lookups in flight together
+          const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+          const uint4 e = itab[(uint32_t)jt * 256u + byte];
+          f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
         }
       }
       uint32_t slot = lane_off;

@@ -73,7 +73,7 @@ struct KmerRunsGenArgs {
   uint32_t rpr;          // runs per read = ceil(nwin / C)
   uint32_t last_start;   // first window of a read's last run = nwin - C
   uint32_t last_dup;     // windows the last run recomputes = rpr * C - nwin
-  uint32_t ntab;         // ceil(k/4)
+  uint32_t ntab;         // byte tables in LDS: 4 * NW (zero past ceil(k/4)); 2 for the Horner path
   uint32_t waves;        // waves per block
   uint32_t bits_dwords;  // per-wave bit-stream capacity
   uint32_t vbits_dwords; // per-wave validity-bit capacity (N-aware)
@@ -560,13 +560,19 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
         w[i] = funnel(hi, lo, sh0);
         lo = hi;
       }
+      // ntab == 4 * NW: the host pads the tables with zero ones past ceil(k/4), so no lookup sits behind a
+      // (uniform) branch and the compiler keeps them all in flight -- with the branch it waits for each
+      // ds_read_b128 before issuing the next
+      uint4 e[4 * NW];
 #pragma unroll
-      for (int jt = 0; jt < 4 * NW; ++jt) {
-        if ((uint32_t)jt < ntab) {
-          const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
-          const uint4 e = itab[(uint32_t)jt * 256u + byte];
-          f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
-        }
+      for (int jt = 0; jt < 4 * NW; ++jt) e[jt] = itab[(uint32_t)jt * 256u + ((w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu)];
+      f_lo = e[0].x ^ e[1].x; f_hi = e[0].y ^ e[1].y; r_lo = e[0].z ^ e[1].z; r_hi = e[0].w ^ e[1].w;
+#pragma unroll
+      for (int jt = 2; jt < 4 * NW; jt += 2) { // a ^ b ^ c: one v_bitop3_b32
+        f_lo = __builtin_amdgcn_bitop3_b32(f_lo, e[jt].x, e[jt + 1].x, 0x96);
+        f_hi = __builtin_amdgcn_bitop3_b32(f_hi, e[jt].y, e[jt + 1].y, 0x96);
+        r_lo = __builtin_amdgcn_bitop3_b32(r_lo, e[jt].z, e[jt + 1].z, 0x96);
+        r_hi = __builtin_amdgcn_bitop3_b32(r_hi, e[jt].w, e[jt + 1].w, 0x96);
       }
     }
     // window j of the run has just been hashed

@@ -550,8 +550,8 @@ int get_init_tab(nthip_ctx* c, uint32_t k, const uint4** out)
 {
   auto it = c->init_tabs.find(k);
   if (it == c->init_tabs.end()) {
-    const uint32_t ntab = (k + 3) / 4;
-    std::vector<uint4> h((size_t)ntab * 256);
+    const uint32_t ntab = 4u * ((k + 15) / 16); // zero tables past ceil(k/4)
+    std::vector<uint4> h((size_t)ntab * 256, make_uint4(0, 0, 0, 0));
     build_byte_tables(k, nullptr, h.data());
     uint4* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, h.size() * sizeof(uint4)));
@@ -582,7 +582,9 @@ int get_kmer_tab(nthip_ctx* c, uint32_t k, const uint4** out)
   *out = it->second;
   return NTHIP_OK;
 }
-inline uint32_t kmer_ntab(uint32_t k) { return k <= KMER_TABLE_K_MAX ? (k + 3) / 4 : 2u; }
+// byte tables a kernel instantiated for NW = ceil(k/16) window words looks up: 4 per word, the ones past
+// ceil(k/4) all zero (so that no lookup needs a branch); k > 64: the two Horner tables
+inline uint32_t kmer_ntab(uint32_t k) { return k <= KMER_TABLE_K_MAX ? 4u * ((k + 15) / 16) : 2u; }
 inline uint32_t kmer_nw(uint32_t k) { return k <= KMER_TABLE_K_MAX ? (k + 15) / 16 : 0u; }
 
 // Plan for the run-split kernel: run length C | nwin, waves per block, LDS bytes.
@@ -1345,8 +1347,9 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
   const uint32_t k = k16;
   if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
   HIPCHK(hipSetDevice(c->device));
-  const uint32_t ntab = (k + 3) / 4, cw = (k + 31) / 32;
-  std::vector<uint4> tables((size_t)n_seeds * ntab * 256);
+  // byte tables per seed: 4 per 16-base window word for k <= 64 (zero past ceil(k/4): the kernels look all of them up)
+  const uint32_t ntab = k <= 64 ? 4u * ((k + 15) / 16) : (k + 3) / 4, cw = (k + 31) / 32;
+  std::vector<uint4> tables((size_t)n_seeds * ntab * 256, make_uint4(0, 0, 0, 0));
   std::vector<uint32_t> care((size_t)n_seeds * cw, 0), blk_start(n_seeds), blk_count(n_seeds), blk_pairs;
   bool asym = false;
   for (uint32_t s = 0; s < n_seeds; ++s) {
@@ -1804,7 +1807,7 @@ extern "C" int nthip_kmer_extend(nthip_ctx* c, const char* kmers, uint64_t n, ui
     // byte tables in LDS, 16-byte neighbour stores
     const uint4* tab = nullptr;
     if (get_init_tab(c, k, &tab) != NTHIP_OK) { cleanup(); return NTHIP_ERR_HIP; }
-    const uint32_t ntab = (k + 3) / 4;
+    const uint32_t ntab = kmer_ntab(k);
     const size_t lds = (size_t)ntab * 4096;
     uint64_t blocks = (n + 1023) / 1024;
     if (blocks > (uint64_t)c->n_cu * 2) blocks = (uint64_t)c->n_cu * 2;

@@ -595,12 +595,10 @@ __global__ __launch_bounds__(1024) void seed_wave_kernel(const SeedGeneralArgs* 
               const uint4* ts = tabs + sdx * a.ntab * 256u;
               uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
 #pragma unroll
-              for (int jt = 0; jt < 4 * NW; ++jt) {
-                if ((uint32_t)jt < a.ntab) {
-                  const uint32_t byte = (wwords[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
-                  const uint4 e = ts[(uint32_t)jt * 256u + byte];
-                  f0 ^= e.x; f1 ^= e.y; r0 ^= e.z; r1 ^= e.w;
-                }
+              for (int jt = 0; jt < 4 * NW; ++jt) { // a.ntab == 4 * NW (zero tables past ceil(k/4))
+                const uint32_t byte = (wwords[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+                const uint4 e = ts[(uint32_t)jt * 256u + byte];
+                f0 ^= e.x; f1 ^= e.y; r0 ^= e.z; r1 ^= e.w;
               }
               fh = ((uint64_t)f1 << 32) | f0;
               rh = ((uint64_t)r1 << 32) | r0;

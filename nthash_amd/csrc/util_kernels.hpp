@@ -240,11 +240,9 @@ __global__ __launch_bounds__(1024) void kmer_extend_tab_kernel(const uint8_t* __
     }
     uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
 #pragma unroll
-    for (int jt = 0; jt < 4 * NW; ++jt) {
-      if ((uint32_t)jt < ntab) {
-        const uint4 e = itab[(uint32_t)jt * 256u + ((w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu)];
-        f0 ^= e.x; f1 ^= e.y; r0 ^= e.z; r1 ^= e.w;
-      }
+    for (int jt = 0; jt < 4 * NW; ++jt) { // ntab == 4 * NW (zero tables past ceil(k/4))
+      const uint4 e = itab[(uint32_t)jt * 256u + ((w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu)];
+      f0 ^= e.x; f1 ^= e.y; r0 ^= e.z; r1 ^= e.w;
     }
     const uint64_t f = ((uint64_t)f1 << 32) | f0, r = ((uint64_t)r1 << 32) | r0;
     const uint32_t c_first = w[0] & 3u, c_last = (w[(k - 1u) >> 4] >> (((k - 1u) & 15u) * 2u)) & 3u;
