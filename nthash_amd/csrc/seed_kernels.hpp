@@ -27,7 +27,10 @@
 
 namespace ntamd {
 
-constexpr int SF_THREADS = 1024; // 16 waves: one block per CU shares the byte tables
+#ifndef SF_THREADS_N
+#define SF_THREADS_N 1024
+#endif
+constexpr int SF_THREADS = SF_THREADS_N; // 16 waves: one block per CU shares the byte tables
 constexpr int SF_MAX_RUNTIME_M = 8;
 
 struct SeedFixedArgs {

@@ -282,25 +282,6 @@ __global__ __launch_bounds__(1024) void kmer_extend_tab_kernel(const uint8_t* __
   }
 }
 
-// longest read of a batch given as spans / offsets (ends == nullptr: offsets[r+1])
-__global__ __launch_bounds__(256) void max_len_kernel(const uint64_t* __restrict__ starts,
-                                                     const uint64_t* __restrict__ ends, uint64_t n,
-                                                     unsigned long long* __restrict__ out)
-{
-  unsigned long long m = 0;
-  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t e = ends ? ends[r] : starts[r + 1];
-    const uint64_t l = e > starts[r] ? e - starts[r] : 0;
-    m = l > m ? l : m;
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    const unsigned long long o = __shfl_xor(m, d, 64);
-    m = o > m ? o : m;
-  }
-  if ((threadIdx.x & 63u) == 0 && m) atomicMax(out, m);
-}
-
 // plain 16-byte/lane device copy: the achievable-bandwidth yardstick
 __global__ __launch_bounds__(256) void copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src,
                                                   uint64_t n16)
