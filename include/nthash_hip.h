@@ -87,6 +87,9 @@ const char* nthip_last_error(void);
 int nthip_device_count(int* count);
 int nthip_ctx_create(int device, nthip_ctx** ctx);
 int nthip_ctx_destroy(nthip_ctx* ctx);
+/* release what the context keeps between calls to make them cheap: the pinned and device buffers of the
+ * FASTQ / FASTA streaming driver (2 x chunk_bytes pinned + about 6 x chunk_bytes of HBM) and the scan scratch */
+int nthip_ctx_trim(nthip_ctx* ctx);
 /* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL
  * restores the context's own stream */
 int nthip_ctx_set_stream(nthip_ctx* ctx, void* hip_stream);

@@ -196,7 +196,11 @@ struct FxReader {
 
   void run()
   {
-    const unsigned n_thr = 8;
+    unsigned n_thr = 8;
+    if (const char* t = getenv("NTHIP_TUNE_READ_THREADS")) { // A/B knob
+      const int v = atoi(t);
+      if (v >= 1 && v <= 64) n_thr = (unsigned)v;
+    }
     for (uint64_t j = 0; j < n_chunks; ++j) {
       {
         std::unique_lock<std::mutex> lk(mu);
@@ -403,10 +407,8 @@ int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t 
   const uint64_t piece_max = FXS_HEAD + chunk_bytes + 16;
   const uint64_t cap_reads = piece_max / 8 + 1;
   const uint64_t cap_kmers = format == NTHIP_FASTQ ? piece_max / 2 + 1 : piece_max; // FASTQ: as many quality bytes as bases
-  uint8_t* d_raw[2] = {nullptr, nullptr};
-  uint64_t *d_starts = nullptr, *d_ends = nullptr, *d_hashes = nullptr, *d_counts = nullptr;
-  hipStream_t copy_stream = nullptr;
-  hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+  // the buffers live in the context and are reused by later calls that fit them
+  auto& fx = c->fx;
   int rc = NTHIP_OK;
   auto cleanup = [&]() {
     {
@@ -416,33 +418,44 @@ int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t 
     rd.cv.notify_all();
     if (rd.th.joinable()) rd.th.join();
     (void)hipStreamSynchronize(c->stream);
-    if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
-    for (int i = 0; i < 2; ++i) {
-      if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]);
-      if (rd.pinned[i]) (void)hipHostFree(rd.pinned[i]);
-      if (d_raw[i]) (void)hipFree(d_raw[i]);
-    }
-    if (d_starts) (void)hipFree(d_starts);
-    if (d_ends) (void)hipFree(d_ends);
-    if (d_hashes) (void)hipFree(d_hashes);
-    if (d_counts) (void)hipFree(d_counts);
+    if (fx.copy_stream) (void)hipStreamSynchronize(fx.copy_stream);
     close(rd.fd);
   };
 #define FX_TRY(expr) \
   do { \
     hipError_t e_ = (expr); \
-    if (e_ != hipSuccess) { rc = fail(NTHIP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } \
+    if (e_ != hipSuccess) { \
+      rc = fail(NTHIP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+      cleanup(); \
+      fastx_buffers_release(c); \
+      return rc; \
+    } \
   } while (0)
-  FX_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-  for (int i = 0; i < 2; ++i) {
-    FX_TRY(hipEventCreateWithFlags(&ev_h2d[i], hipEventDisableTiming));
-    FX_TRY(hipHostMalloc((void**)&rd.pinned[i], chunk_bytes + 16, hipHostMallocDefault));
-    FX_TRY(hipMalloc((void**)&d_raw[i], piece_max + 64));
+  if (fx.pinned_bytes < chunk_bytes + 16 || fx.raw_bytes < piece_max + 64 || fx.reads_cap < cap_reads ||
+      fx.hashes_cap < cap_kmers * per) {
+    FX_TRY(hipStreamSynchronize(c->stream));
+    fastx_buffers_release(c);
+    FX_TRY(hipStreamCreateWithFlags(&fx.copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      FX_TRY(hipEventCreateWithFlags(&fx.ev_h2d[i], hipEventDisableTiming));
+      FX_TRY(hipHostMalloc((void**)&fx.pinned[i], chunk_bytes + 16, hipHostMallocDefault));
+      FX_TRY(hipMalloc((void**)&fx.d_raw[i], piece_max + 64));
+    }
+    FX_TRY(hipMalloc((void**)&fx.d_starts, cap_reads * sizeof(uint64_t)));
+    FX_TRY(hipMalloc((void**)&fx.d_ends, cap_reads * sizeof(uint64_t)));
+    FX_TRY(hipMalloc((void**)&fx.d_counts, cap_reads * sizeof(uint64_t)));
+    FX_TRY(hipMalloc((void**)&fx.d_hashes, cap_kmers * per * sizeof(uint64_t)));
+    fx.pinned_bytes = chunk_bytes + 16;
+    fx.raw_bytes = piece_max + 64;
+    fx.reads_cap = cap_reads;
+    fx.hashes_cap = cap_kmers * per;
   }
-  FX_TRY(hipMalloc((void**)&d_starts, cap_reads * sizeof(uint64_t)));
-  FX_TRY(hipMalloc((void**)&d_ends, cap_reads * sizeof(uint64_t)));
-  FX_TRY(hipMalloc((void**)&d_counts, cap_reads * sizeof(uint64_t)));
-  FX_TRY(hipMalloc((void**)&d_hashes, cap_kmers * per * sizeof(uint64_t)));
+  rd.pinned[0] = fx.pinned[0];
+  rd.pinned[1] = fx.pinned[1];
+  uint8_t* const* d_raw = fx.d_raw;
+  uint64_t *const d_starts = fx.d_starts, *const d_ends = fx.d_ends, *const d_hashes = fx.d_hashes, *const d_counts = fx.d_counts;
+  hipStream_t const copy_stream = fx.copy_stream;
+  hipEvent_t const* ev_h2d = fx.ev_h2d;
   rd.th = std::thread([&rd] { rd.run(); });
 
   uint64_t tail = 0;       // bytes of the piece before chunk j that belong to its first (incomplete) record

@@ -86,7 +86,36 @@ struct nthip_ctx {
   std::map<std::pair<const void*, size_t>, int> occ_cache;
   // all-care byte tables for the first window of a run, per k (device memory)
   std::map<uint32_t, uint4*> init_tabs;
+  // buffers of the FASTQ / FASTA streaming driver, kept between calls (pinning and mapping half a GiB costs more
+  // than streaming a few GB through it); released by nthip_ctx_trim / nthip_ctx_destroy
+  struct FastxBuffers {
+    uint8_t* pinned[2] = {nullptr, nullptr};
+    uint8_t* d_raw[2] = {nullptr, nullptr};
+    uint64_t *d_starts = nullptr, *d_ends = nullptr, *d_counts = nullptr, *d_hashes = nullptr;
+    uint64_t pinned_bytes = 0, raw_bytes = 0, reads_cap = 0, hashes_cap = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+  } fx;
 };
+
+namespace {
+void fastx_buffers_release(nthip_ctx* c)
+{
+  auto& b = c->fx;
+  if (b.copy_stream) (void)hipStreamSynchronize(b.copy_stream);
+  for (int i = 0; i < 2; ++i) {
+    if (b.pinned[i]) (void)hipHostFree(b.pinned[i]);
+    if (b.d_raw[i]) (void)hipFree(b.d_raw[i]);
+    if (b.ev_h2d[i]) (void)hipEventDestroy(b.ev_h2d[i]);
+  }
+  if (b.d_starts) (void)hipFree(b.d_starts);
+  if (b.d_ends) (void)hipFree(b.d_ends);
+  if (b.d_counts) (void)hipFree(b.d_counts);
+  if (b.d_hashes) (void)hipFree(b.d_hashes);
+  if (b.copy_stream) (void)hipStreamDestroy(b.copy_stream);
+  b = nthip_ctx::FastxBuffers();
+}
+} // namespace
 
 struct nthip_seeds {
   nthip_ctx* ctx = nullptr;
@@ -386,10 +415,24 @@ extern "C" int nthip_ctx_destroy(nthip_ctx* c)
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->d_scratch2) (void)hipFree(c->d_scratch2);
   for (auto& kv : c->init_tabs) (void)hipFree(kv.second);
+  fastx_buffers_release(c);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_ctx_trim(nthip_ctx* c)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  fastx_buffers_release(c);
+  if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->d_scratch2) (void)hipFree(c->d_scratch2);
+  c->d_scratch = c->d_scratch2 = nullptr;
+  c->d_scratch_elems = c->d_scratch2_elems = 0;
   return NTHIP_OK;
 }
 

@@ -976,6 +976,36 @@ def test_fastx_file_stream_vs_oracle(ctx, oracle, tmp_path, fmt, chunk, final_ne
     assert (np.concatenate(got_h) == want["hashes"].ravel()).all()
 
 
+def test_fastx_file_stream_reuses_and_trims_context_buffers(ctx, oracle, tmp_path):
+    """the streaming buffers live in the context: same file again (reuse), bigger chunks (regrow), after
+    nthip_ctx_trim (fresh) and with more hashes per k-mer (regrow of the hash buffer) -- same stream every time"""
+    rng = np.random.default_rng(77)
+    buf, seqs = _make_fastx(rng, 3000, 4, lo=20, hi=300)
+    path = tmp_path / "again.fq"
+    path.write_bytes(buf)
+    data, offs = concat_reads(seqs)
+    for m, chunk, trim in ((1, 1 << 16, False), (1, 1 << 16, False), (1, 1 << 20, False), (1, 1 << 16, True),
+                           (3, 1 << 16, False), (1, 1 << 18, True)):
+        if trim:
+            ctx.trim()
+        want = oracle.kmer_batch(data, offs, 31, m, want_pos=False)
+        got = []
+
+        def on_batch(b, m=m, got=got):
+            h = np.zeros(b.n_kmers * m, np.uint64)
+            if h.size:
+                ctx.d2h(h, b.hashes)
+            got.append(h)
+
+        st = ctx.fastx_kmer_hash_file(path, 4, 31, m, chunk_bytes=chunk, on_batch=on_batch)
+        assert st.reads == len(seqs) and st.kmers == want["total"]
+        assert (np.concatenate(got) == want["hashes"].ravel()).all()
+    # the batch paths still work after a trim (their scratch is reallocated on demand)
+    ctx.trim()
+    one = ctx.kmer_hash(data, 31, 1, offsets=offs)
+    assert one["total"] == oracle.kmer_batch(data, offs, 31, 1, want_pos=False)["total"]
+
+
 def test_fastx_file_errors(ctx, tmp_path):
     import nthash_amd
     with pytest.raises(nthash_amd.NtHipError):
