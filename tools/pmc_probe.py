@@ -16,7 +16,8 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000_000
 SEEDS = ["1010101010101010101010101010101", "1101101101101101011011011011011"]
 L, k, m, seeds = {"c2": (150, 31, 1, None), "c3": (150, 31, 4, None), "c4": (250, 31, 3, SEEDS),
-                  "mh": (150, 31, 1, None), "gen": (150, 31, 1, None)}[cfg]   # mh: fused MinHash; gen: general kernel
+                  "mh": (150, 31, 1, None), "gen": (150, 31, 1, None),      # mh: fused MinHash; gen: general kernel
+                  "rag": (150, 31, 1, None)}[cfg]                           # rag: variable-length reads (100..150 bp)
 if cfg == "gen":
     os.environ["NTHIP_TUNE_NO_SPECIAL"] = "1"
 per = m if seeds is None else len(seeds) * m
@@ -32,10 +33,17 @@ ctx.free(b)
 d_in = ctx.malloc(n * L)
 d_out = ctx.malloc(n * nwin * per * 8)
 ctx.synth_reads_ptr(d_in, 0, n, L, 42)
+if cfg == "rag":
+    import numpy as np
+    lens = np.random.default_rng(1).integers(100, 151, n).astype(np.uint64)
+    offs = np.zeros(n + 1, np.uint64); offs[1:] = np.cumsum(lens)
+    d_offs = ctx.malloc((n + 1) * 8); ctx.h2d(d_offs, offs)
 ctx.set_profiling(True)
 sd = nthash_amd.Seeds(ctx, seeds, k) if seeds else None
 for _ in range(3):
-    if cfg == "mh":
+    if cfg == "rag":
+        ctx.kmer_hash_ptr(d_in, d_offs, n, 0, 0, k, m, d_out, n * nwin)
+    elif cfg == "mh":
         ctx.minhash_ptr(d_in, n, L, 0, k, m, d_out)
     elif sd is None:
         ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin)
