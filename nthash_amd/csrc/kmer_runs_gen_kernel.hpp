@@ -515,23 +515,29 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
       const uint32_t with_non_base = k <= 64u ? windows_with_non_base((const uint32_t*)vbits, b0, k)
                                               : windows_with_non_base_long((const uint32_t*)vbits, b0, k, C);
       valid = ~with_non_base & run_mask;
-      const uint32_t cnt = __builtin_popcount(valid);
-      uint32_t incl = cnt;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        if ((int)lane >= d) incl += o;
-      }
-      lane_off = incl - cnt;
-      n_emit = __shfl(incl, 63, 64);
       // (consumers always compact: slots 0 .. n_emit-1 of the tile, no alignment shift)
       // (MinHash folds every window of a clean tile, the recomputed ones too: those must be valid as well --
       // the run they repeat may sit in another wave's tile)
       all_valid = MINH ? __ballot(live && (with_non_base & ((1u << C) - 1u)) != 0u) == 0
                        : SINK == SINK_NONE && __ballot(valid != run_mask) == 0;
-      // clean tile: window j of the run goes to lane_off + j - dup (a recomputed
-      // window lands on the slot the previous run gives the same value)
-      if (all_valid) lane_off -= dup;
+      if (all_valid) {
+        // clean tile (almost all of them): the dense geometry, no scan.  Window j of a run goes to its dense
+        // slot; a recomputed window lands on the slot the run before gives the same value -- only the tile's
+        // FIRST run has its recomputed windows in another tile: they fall below slot 0 (KRG_SLACK_U64)
+        const uint32_t d0 = my_rem0 == rpr - 1u ? a.last_dup : 0u;
+        lane_off = lr * a.nwin + w0 - cur.w_first - d0;
+        n_emit = cur.n_kmers - d0;
+      } else {
+        const uint32_t cnt = __builtin_popcount(valid);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t o = __shfl_up(incl, d, 64);
+          if ((int)lane >= d) incl += o;
+        }
+        lane_off = incl - cnt;
+        n_emit = __shfl(incl, 63, 64);
+      }
     }
     // the tile is built shifted by the position of its first stream element inside a
     // 1 KiB block of the output (m == 1): every store instruction of the copy-out then
