@@ -17,7 +17,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000_000
 SEEDS = ["1010101010101010101010101010101", "1101101101101101011011011011011"]
 L, k, m, seeds = {"c2": (150, 31, 1, None), "c3": (150, 31, 4, None), "c4": (250, 31, 3, SEEDS),
                   "mh": (150, 31, 1, None), "gen": (150, 31, 1, None),      # mh: fused MinHash; gen: general kernel
-                  "rag": (150, 31, 1, None)}[cfg]                           # rag: variable-length reads (100..150 bp)
+                  "rag": (150, 31, 1, None),                                # rag: variable-length reads (100..150 bp)
+                  "na": (150, 31, 1, None)}[cfg]                            # na: fixed-length batch with N's (N-aware pass)
 if cfg == "gen":
     os.environ["NTHIP_TUNE_NO_SPECIAL"] = "1"
 per = m if seeds is None else len(seeds) * m
@@ -33,6 +34,10 @@ ctx.free(b)
 d_in = ctx.malloc(n * L)
 d_out = ctx.malloc(n * nwin * per * 8)
 ctx.synth_reads_ptr(d_in, 0, n, L, 42)
+if cfg == "na":
+    import numpy as np
+    for i in range(0, n * L, 187_507):
+        ctx.h2d(d_in + i, np.frombuffer(b"N", np.uint8))
 if cfg == "rag":
     import numpy as np
     lens = np.random.default_rng(1).integers(100, 151, n).astype(np.uint64)
