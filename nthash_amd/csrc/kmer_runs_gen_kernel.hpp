@@ -121,6 +121,16 @@ __device__ __forceinline__ void wait_vmcnt_upto15(uint32_t n)
 }
 #undef KRG_WAITCASE
 
+// 4 ASCII bytes: a byte of the result is non-zero <=> that byte is not a base (the test of pack4 alone)
+__device__ __forceinline__ uint32_t non_base4(uint32_t w)
+{
+  const uint32_t t = (w >> 1) & 0x03030303u;
+  uint32_t x = w | 0x20202020u;
+  const uint32_t ubit = (x >> 4) & 0x01010101u;
+  x = x & ~ubit;
+  return x ^ __builtin_amdgcn_perm(0u, 0x67746361u, t);
+}
+
 // 4 ASCII bytes -> 4 x 2-bit codes (one byte) and a 4-bit mask of the non-bases
 __device__ __forceinline__ uint32_t pack4v(uint32_t w, uint32_t& inv4)
 {
@@ -911,29 +921,41 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_count_kernel(const K
     const uint64_t rf = g0 / rpr;
     const uint32_t rm = (uint32_t)(g0 - rf * rpr);
     const TileGeo g = tile_geo(shape, (uint64_t)a.seqs, a.n_runs, a.total_bytes, g0, rf, rm);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < g.n_vec; i += 64u) {
-      const uint4 v = *(const uint4*)(a.seqs + g.byte0 + ((uint64_t)i << 4));
-      uint32_t i0, i1, i2, i3;
-      (void)pack4v(v.x, i0);
-      (void)pack4v(v.y, i1);
-      (void)pack4v(v.z, i2);
-      (void)pack4v(v.w, i3);
-      vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     const bool live = lane < g.runs_here;
     uint32_t lr, w0;
     bool last_run;
     run_split(shape, live ? rm + lane : rm, lr, w0, last_run);
-    const uint32_t b0 = g.shift + lr * a.stride + w0 - g.w_first;
     const uint32_t dup = last_run ? a.last_dup : 0u;
     const uint32_t run_mask = live ? ((1u << C) - 1u) & ~((1u << dup) - 1u) : 0u;
-    const uint32_t valid = ~(k <= 64u ? windows_with_non_base((const uint32_t*)vbits, b0, k)
-                                      : windows_with_non_base_long((const uint32_t*)vbits, b0, k, C)) & run_mask;
+    // almost every tile holds bases only: look for a non-base first (no validity bits, no LDS) ...
+    uint32_t any_bad = 0;
+    for (uint32_t i = lane; i < g.n_vec; i += 64u) {
+      const uint4 v = *(const uint4*)(a.seqs + g.byte0 + ((uint64_t)i << 4));
+      any_bad |= non_base4(v.x) | non_base4(v.y) | non_base4(v.z) | non_base4(v.w);
+    }
+    uint32_t valid = run_mask;
+    if (__ballot(any_bad != 0u) != 0ull) {
+      // ... and only then build the validity bits (the slab comes from L2 this time) and test every window
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t i = lane; i < g.n_vec; i += 64u) {
+        const uint4 v = *(const uint4*)(a.seqs + g.byte0 + ((uint64_t)i << 4));
+        uint32_t i0, i1, i2, i3;
+        (void)pack4v(v.x, i0);
+        (void)pack4v(v.y, i1);
+        (void)pack4v(v.z, i2);
+        (void)pack4v(v.w, i3);
+        vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+      const uint32_t b0 = g.shift + lr * a.stride + w0 - g.w_first;
+      valid = ~(k <= 64u ? windows_with_non_base((const uint32_t*)vbits, b0, k)
+                         : windows_with_non_base_long((const uint32_t*)vbits, b0, k, C)) & run_mask;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+    }
     const uint32_t cnt = __builtin_popcount(valid);
     uint32_t sum = cnt;
 #pragma unroll
