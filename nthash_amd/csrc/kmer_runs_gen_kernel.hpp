@@ -387,10 +387,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
   // never reach an emitted window).
   auto pack_vec = [&](const TileGeo& sl, uint32_t i, const uint4 v) {
     if constexpr (NA) {
-      uint32_t i0, i1, i2, i3;
-      const uint32_t c0 = pack4v(v.x, i0), c1 = pack4v(v.y, i1), c2 = pack4v(v.z, i2), c3 = pack4v(v.w, i3);
-      bits[i] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-      vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+      // validity bits are only built for the slabs that hold a non-base (validity_bits() below): `bad`
+      // collects the test for the tile being staged (bytes next to the slab included: harmless)
+      uint32_t b = 0;
+      bits[i] = pack16(v, b);
+      bad |= b;
     } else {
       uint32_t b = 0;
       const uint32_t p = pack16(v, b);
@@ -418,11 +419,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     const uint32_t n_dw = (sl.shift + sl.slab_bytes + 3u) >> 2;
     const bool mine = 256u + lane < n_dw;
     if constexpr (NA) {
-      uint32_t nib;
-      const uint32_t p = pack4v(wv, nib);
-      const uint32_t pair = nib | (__shfl_down(nib, 1, 64) << 4); // two lanes share a validity byte
-      if (mine) ((uint8_t*)bits)[256u + lane] = (uint8_t)p;
-      if (mine && (lane & 1u) == 0u) ((uint8_t*)vbits)[128u + (lane >> 1)] = (uint8_t)pair;
+      if (mine) {
+        uint32_t b = 0;
+        ((uint8_t*)bits)[256u + lane] = (uint8_t)pack4(wv, b);
+        bad |= b;
+      }
     } else if (mine) {
       uint32_t b = 0;
       const uint32_t p = pack4(wv, b);
@@ -443,6 +444,19 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
       pack_vec(sl, i, *(const uint4*)(a.seqs + sl.byte0 + ((uint64_t)i << 4)));
     if (lane < (uint32_t)NW + 5u) bits[sl.n_vec + lane] = 0; // funnels read a little ahead
   };
+  // N-aware pass, slab with a non-base (rare): one validity bit per base of the slab, 16 per vector, from
+  // the bytes themselves (L2-hot: they were staged a moment ago)
+  auto validity_bits = [&](const TileGeo& sl) {
+    for (uint32_t i = lane; i < sl.n_vec; i += 64u) {
+      const uint4 v = *(const uint4*)(a.seqs + sl.byte0 + ((uint64_t)i << 4));
+      uint32_t i0, i1, i2, i3;
+      (void)pack4v(v.x, i0);
+      (void)pack4v(v.y, i1);
+      (void)pack4v(v.z, i2);
+      (void)pack4v(v.w, i3);
+      vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+    }
+  };
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
@@ -457,6 +471,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
   constexpr bool MINH = SINK == SINK_MINHASH || SINK == SINK_MINHASH1;
   constexpr uint32_t N_MN = SINK == SINK_MINHASH ? KRG_SIG_MAX : 1u;
   uint64_t cur_off = 0; // N-aware: compact stream index of the tile's first emitted k-mer
+  bool cur_dirty = false; // N-aware: the staged slab holds a non-base (validity bits are built)
   uint64_t sum_emit = 0, sum_hits = 0; // consumers: k-mers consumed / found by this wave
   bool test_first = true;              // Bloom insert: look at the bit before the atomic (see below)
   uint32_t probe_wait = 0;
@@ -464,6 +479,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     cur = tile_geo(shape, (uint64_t)a.seqs, a.n_runs, a.total_bytes, wt * 64u, r_first, rem0);
     if constexpr (NA && SINK == SINK_NONE) cur_off = a.tile_off[wt];
     stage(cur, 0u);
+    if constexpr (NA) {
+      cur_dirty = __ballot(bad != 0u) != 0ull;
+      if (cur_dirty) validity_bits(cur);
+    }
   }
   for (; wt < wt_end; wt += wstride) {
     lds_sync();
@@ -522,8 +541,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     if constexpr (NA) {
       const uint32_t dup = live && last_run ? a.last_dup : 0u; // windows the run before already covers
       const uint32_t run_mask = live ? ((1u << C) - 1u) & ~((1u << dup) - 1u) : 0u;
-      const uint32_t with_non_base = k <= 64u ? windows_with_non_base((const uint32_t*)vbits, b0, k)
-                                              : windows_with_non_base_long((const uint32_t*)vbits, b0, k, C);
+      uint32_t with_non_base = 0; // a slab of bases only: every window is valid
+      if (cur_dirty)
+        with_non_base = k <= 64u ? windows_with_non_base((const uint32_t*)vbits, b0, k)
+                                 : windows_with_non_base_long((const uint32_t*)vbits, b0, k, C);
       valid = ~with_non_base & run_mask;
       // (consumers always compact: slots 0 .. n_emit-1 of the tile, no alignment shift)
       // (MinHash folds every window of a clean tile, the recomputed ones too: those must be valid as well --
@@ -870,6 +891,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     if (have_next) {
       cur = nxt;
       cur_off = nxt_off;
+      if constexpr (NA) bad = 0;
       if (lane < cur.n_vec) pack_vec(cur, lane, make_uint4(pv0.x, pv0.y, pv0.z, pv0.w));
       if constexpr (DT) {
         pack_tail(cur, pw);
@@ -877,6 +899,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
       } else {
         if (lane + 64u < cur.n_vec) pack_vec(cur, lane + 64u, make_uint4(pv1.x, pv1.y, pv1.z, pv1.w));
         stage(cur, 128u);
+      }
+      if constexpr (NA) {
+        cur_dirty = __ballot(bad != 0u) != 0ull;
+        if (cur_dirty) validity_bits(cur);
       }
       if (!NA && __ballot(bad != 0) != 0) { // publish at once so that every wave can stop early
         if (lane == 0) atomicOr(a.dirty, 1u);

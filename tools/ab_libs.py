@@ -2,7 +2,8 @@
 """A/B two builds of the C-ABI library INSIDE ONE PROCESS (process-to-process spread on a box is ~5 %,
 in-process repeatability ~0.5 %): the in-tree library against nthash_amd/lib/ab/libnthash_hip_<tag>.so.
 
-    tools/ab_build.sh x -DSOME_FLAG=1 && python tools/ab_libs.py x [reads] [rounds]   (ABLATE_SHAPE=L,k,m)
+    tools/ab_build.sh x -DSOME_FLAG=1 && python tools/ab_libs.py x [reads] [rounds]   (ABLATE_SHAPE=L,k,m; ABLATE_SEEDS=1;
+    ABLATE_DIRTY=1: reads with N's)
 """
 import importlib.util, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,6 +36,10 @@ sa = A.Seeds(ca, SEEDS, k) if SEEDS else None
 sb = B.Seeds(cb, SEEDS, k) if SEEDS else None
 d_in = ca.malloc(n * L); d_out = ca.malloc(n * nwin * per * 8)
 ca.synth_reads_ptr(d_in, 0, n, L, 42)
+if os.environ.get("ABLATE_DIRTY"):   # one N per ~190 kB: the batch takes the N-aware path
+    import numpy as np
+    for i in range(0, n * L, 187_507):
+        ca.h2d(d_in + i, np.frombuffer(b"N", np.uint8))
 res = {"base": [], tag: []}
 for c in (ca, cb):
     c.set_profiling(True)
