@@ -1851,7 +1851,7 @@ extern "C" int nthip_kmer_extend(nthip_ctx* c, const char* kmers, uint64_t n, ui
     const uint4* tab = nullptr;
     if (get_init_tab(c, k, &tab) != NTHIP_OK) { cleanup(); return NTHIP_ERR_HIP; }
     const uint32_t ntab = kmer_ntab(k);
-    const size_t lds = (size_t)ntab * 4096;
+    const size_t lds = (size_t)ntab * 4096 + 16 * 2048; // tables + a 2 KiB exchange tile per wave
     uint64_t blocks = (n + 1023) / 1024;
     if (blocks > (uint64_t)c->n_cu * 2) blocks = (uint64_t)c->n_cu * 2;
     auto go = [&](auto kernel) {

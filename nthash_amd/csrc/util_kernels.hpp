@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void kmer_extend_kernel(const uint8_t* __restr
 }
 
 // The same for k <= 64 with the first-window byte tables in LDS (4 bases per lookup instead of 2k Horner
-// steps) and, for m == 1, the four neighbours of a k-mer written as two 16-byte stores (32 contiguous bytes
-// per lane: the wave writes 2 KiB contiguous).  tab = build_byte_tables(k): [ceil(k/4)][256].
+// steps) and, for m == 1, the four neighbours of the wave's 64 k-mers (2 KiB contiguous) exchanged through LDS
+// so that each store instruction writes one contiguous KiB.  tab = build_byte_tables(k), zero-padded to ntab.
 template <int NW>
 __global__ __launch_bounds__(1024) void kmer_extend_tab_kernel(const uint8_t* __restrict__ kmers, uint64_t n, uint32_t k,
                                                               uint32_t m, const uint4* __restrict__ tab, uint32_t ntab,
@@ -262,16 +262,34 @@ __global__ __launch_bounds__(1024) void kmer_extend_tab_kernel(const uint8_t* __
       hp[b] = sror1(f ^ sk[c] ^ seed_of_code(c_last)) + (srol1(r) ^ seed_of_code(c ^ 2u) ^ skc[c_last]);
     }
     if (m == 1u) {
-      if (next) {
-        ulonglong2* d = (ulonglong2*)(next + i * 4u);
-        d[0] = make_ulonglong2(hn[0], hn[1]);
-        d[1] = make_ulonglong2(hn[2], hn[3]);
-      }
-      if (prev) {
-        ulonglong2* d = (ulonglong2*)(prev + i * 4u);
-        d[0] = make_ulonglong2(hp[0], hp[1]);
-        d[1] = make_ulonglong2(hp[2], hp[3]);
-      }
+      // a wave's 64 k-mers own 2 KiB of next[] (and of prev[]): through a wave-private LDS tile, so that each of
+      // the two store instructions writes one contiguous KiB instead of 16-byte pieces 32 bytes apart
+      const uint32_t lane = threadIdx.x & 63u;
+      const uint64_t i_wave = i - lane;
+      const bool whole_wave = i_wave + 64u <= n; // uniform: lanes of a wave hold consecutive k-mers
+      ulonglong2* xt = (ulonglong2*)(itab + ntab * 256u) + (threadIdx.x >> 6) * 128u;
+      auto out4 = [&](uint64_t* arr, const uint64_t* h) {
+        if (!arr) return;
+        if (whole_wave) {
+          xt[2u * lane] = make_ulonglong2(h[0], h[1]);
+          xt[2u * lane + 1u] = make_ulonglong2(h[2], h[3]);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+          ulonglong2* d = (ulonglong2*)(arr + i_wave * 4u);
+          const ulonglong2 a0 = xt[lane], a1 = xt[64u + lane];
+          d[lane] = a0;
+          d[64u + lane] = a1;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+          __builtin_amdgcn_wave_barrier();
+        } else {
+          ulonglong2* d = (ulonglong2*)(arr + i * 4u);
+          d[0] = make_ulonglong2(h[0], h[1]);
+          d[1] = make_ulonglong2(h[2], h[3]);
+        }
+      };
+      out4(next, hn);
+      out4(prev, hp);
     } else {
 #pragma unroll
       for (uint32_t b = 0; b < 4; ++b) {
