@@ -250,7 +250,6 @@ __global__ __launch_bounds__(1024) void kmer_extend_tab_kernel(const uint8_t* __
       dst[0] = h0;
       for (uint32_t j = 1; j < m; ++j) dst[j] = mix_hash(h0, (uint64_t)j ^ base);
     };
-    if (self) emit(self + i * m, f + r);
     // base order "ACGT" = codes 0, 1, 3, 2
     uint64_t hn[4], hp[4];
 #pragma unroll
@@ -262,6 +261,7 @@ __global__ __launch_bounds__(1024) void kmer_extend_tab_kernel(const uint8_t* __
       hp[b] = sror1(f ^ sk[c] ^ seed_of_code(c_last)) + (srol1(r) ^ seed_of_code(c ^ 2u) ^ skc[c_last]);
     }
     if (m == 1u) {
+      if (self) self[i] = f + r;
       // a wave's 64 k-mers own 2 KiB of next[] (and of prev[]): through a wave-private LDS tile, so that each of
       // the two store instructions writes one contiguous KiB instead of 16-byte pieces 32 bytes apart
       const uint32_t lane = threadIdx.x & 63u;
@@ -291,11 +291,53 @@ __global__ __launch_bounds__(1024) void kmer_extend_tab_kernel(const uint8_t* __
       out4(next, hn);
       out4(prev, hp);
     } else {
+      // m > 1: the wave's 64 * 4 * m values of next[] (and prev[]) are 2*m KiB contiguous.  The 256 base hashes go
+      // to the exchange tile; then lane t produces values 2t, 2t+1 (+128, +256, ...) of the block -- value v is
+      // hash v % m of base hash v / m -- and stores them as 16 bytes: every store instruction one contiguous KiB
+      const uint32_t lane = threadIdx.x & 63u;
+      const uint64_t i_wave = i - lane;
+      const bool whole_wave = i_wave + 64u <= n;
+      uint64_t* xt = (uint64_t*)(itab + ntab * 256u) + (threadIdx.x >> 6) * 256u;
+      const uint32_t inv_m = 0xFFFFFFFFu / m + 1u; // v / m == umulhi(v, inv_m) for v < 2^29
+      // the n_base base hashes in the exchange tile -> n_base * m values at dst, 16 bytes per lane and store
+      auto expand = [&](uint64_t* dst, uint32_t n_base) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        for (uint32_t v2 = 2u * lane; v2 < n_base * m; v2 += 128u) {
+          uint64_t o[2];
 #pragma unroll
-      for (uint32_t b = 0; b < 4; ++b) {
-        if (next) emit(next + (i * 4u + b) * m, hn[b]);
-        if (prev) emit(prev + (i * 4u + b) * m, hp[b]);
+          for (uint32_t q = 0; q < 2; ++q) {
+            const uint32_t v = v2 + q, e = __umulhi(v, inv_m), j = v - e * m;
+            const uint64_t hb = xt[e];
+            o[q] = j == 0u ? hb : mix_hash(hb, (uint64_t)j ^ base);
+          }
+          *(ulonglong2*)(dst + v2) = make_ulonglong2(o[0], o[1]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+      };
+      auto out4m = [&](uint64_t* arr, const uint64_t* h) {
+        if (!arr) return;
+        if (!whole_wave) {
+#pragma unroll
+          for (uint32_t b = 0; b < 4; ++b) emit(arr + (i * 4u + b) * m, h[b]);
+          return;
+        }
+        ((ulonglong2*)xt)[2u * lane] = make_ulonglong2(h[0], h[1]);
+        ((ulonglong2*)xt)[2u * lane + 1u] = make_ulonglong2(h[2], h[3]);
+        expand(arr + i_wave * 4u * m, 256u);
+      };
+      if (self) {
+        if (whole_wave) {
+          xt[lane] = f + r;
+          expand(self + i_wave * m, 64u);
+        } else {
+          emit(self + i * m, f + r);
+        }
       }
+      out4m(next, hn);
+      out4m(prev, hp);
     }
   }
 }
