@@ -1846,22 +1846,29 @@ extern "C" int nthip_kmer_extend(nthip_ctx* c, const char* kmers, uint64_t n, ui
   }
   if (rc != NTHIP_OK) { cleanup(); return rc; }
   const bool aligned16 = (!d_next || ((uintptr_t)d_next & 15u) == 0) && (!d_prev || ((uintptr_t)d_prev & 15u) == 0);
-  if (k <= 64 && aligned16) {
-    // byte tables in LDS, 16-byte neighbour stores
+  // byte tables in LDS (k > 64: the two Horner tables + a 2-bit stream of the wave's k-mers), 16-byte stores
+  const uint32_t ntab = kmer_ntab(k);
+  const size_t wave_bits = k > 64 ? ((((size_t)64 * k + 30) >> 4) + 4) * 4 : 0;
+  const size_t lds_fixed = (size_t)ntab * 4096 + 16 * 2048; // tables + a 2 KiB exchange tile per wave
+  const size_t lds_cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
+  uint32_t waves = 16;
+  while (waves > 1 && lds_fixed + wave_bits * waves > lds_cap) waves /= 2;
+  if (aligned16 && lds_fixed + wave_bits * waves <= lds_cap) {
     const uint4* tab = nullptr;
-    if (get_init_tab(c, k, &tab) != NTHIP_OK) { cleanup(); return NTHIP_ERR_HIP; }
-    const uint32_t ntab = kmer_ntab(k);
-    const size_t lds = (size_t)ntab * 4096 + 16 * 2048; // tables + a 2 KiB exchange tile per wave
-    uint64_t blocks = (n + 1023) / 1024;
+    if (get_kmer_tab(c, k, &tab) != NTHIP_OK) { cleanup(); return NTHIP_ERR_HIP; }
+    const size_t lds = lds_fixed + wave_bits * waves;
+    const uint32_t threads = waves * 64;
+    uint64_t blocks = (n + threads - 1) / threads;
     if (blocks > (uint64_t)c->n_cu * 2) blocks = (uint64_t)c->n_cu * 2;
     auto go = [&](auto kernel) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       prof_begin(c, "kmer_extend_tab_kernel");
-      hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(1024), lds, c->stream, d_in, n, k, m, tab, ntab, d_self,
+      hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), lds, c->stream, d_in, n, k, m, tab, ntab, d_self,
                          d_next, d_prev);
       prof_end(c);
     };
-    if (k <= 16) go(kmer_extend_tab_kernel<1>);
+    if (k > 64) go(kmer_extend_tab_kernel<0>);
+    else if (k <= 16) go(kmer_extend_tab_kernel<1>);
     else if (k <= 32) go(kmer_extend_tab_kernel<2>);
     else if (k <= 48) go(kmer_extend_tab_kernel<3>);
     else go(kmer_extend_tab_kernel<4>);

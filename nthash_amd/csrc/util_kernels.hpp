@@ -7,6 +7,7 @@
 
 #include <cstdint>
 
+#include "kmer_runs_gen_kernel.hpp" // horner_first_window, pack16
 #include "nt_math.hpp"
 
 namespace ntamd {
@@ -217,9 +218,44 @@ __global__ __launch_bounds__(1024) void kmer_extend_tab_kernel(const uint8_t* __
     sk[c] = srol_n(seed_of_code(c), k);
     skc[c] = srol_n(seed_of_code(c ^ 2u), k);
   }
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+  // NW == 0 (k > 64): per-wave 2-bit stream of the wave's 64 k-mers after the exchange tiles
+  const uint32_t wbits_dw = NW == 0 ? ((64u * k + 30u) >> 4) + 4u : 0u;
+  uint32_t* wbits = (uint32_t*)(itab + ntab * 256u) + 16u * 512u + (threadIdx.x >> 6) * wbits_dw;
+  // (the trip count is uniform inside a wave: the lanes past the end idle through the last iteration)
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i - (threadIdx.x & 63u) < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t off = i * k;
-    uint32_t w[NW];
+    uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0, c_first = 0, c_last = 0;
+    if constexpr (NW == 0) {
+      // stage the wave's k-mers (64 * k contiguous bytes) as a 2-bit stream, then Horner over 4-base table
+      // entries per lane (the tables of kmer_runs_gen_kernel's NW = 0 path: a 4-mer's and a 1-mer's)
+      const uint32_t lane0 = threadIdx.x & 63u;
+      const uint64_t i_w = i - lane0;
+      const uint64_t cnt = n - i_w < 64u ? n - i_w : 64u;
+      const uint64_t addr = (uint64_t)(kmers + i_w * k);
+      const uint32_t shift = (uint32_t)(addr & 15u);
+      const uint32_t n_vec = (uint32_t)((shift + cnt * k + 15u) >> 4);
+      // (aligned 16-byte blocks that hold at least one byte of the batch: never cross into another page)
+      for (uint32_t v = lane0; v < n_vec; v += 64u) {
+        uint32_t b = 0;
+        wbits[v] = pack16(*(const uint4*)(addr - shift + ((uint64_t)v << 4)), b);
+      }
+      if (lane0 < 3u) wbits[n_vec + lane0] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+      if (i < n) {
+        const uint32_t b0 = shift + lane0 * k;
+        horner_first_window(wbits, itab, b0, k, f0, f1, r0, r1);
+        c_first = (wbits[b0 >> 4] >> ((b0 & 15u) * 2u)) & 3u;
+        const uint32_t bl = b0 + k - 1u;
+        c_last = (wbits[bl >> 4] >> ((bl & 15u) * 2u)) & 3u;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (i >= n) continue;
+    uint32_t w[NW ? NW : 1];
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
       uint4 v = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
@@ -238,14 +274,16 @@ __global__ __launch_bounds__(1024) void kmer_extend_tab_kernel(const uint8_t* __
       auto p4 = [](uint32_t x) { return __builtin_amdgcn_udot4((x >> 1) & 0x03030303u, 0x40100401u, 0u, false); };
       w[q] = p4(v.x) | (p4(v.y) << 8) | (p4(v.z) << 16) | (p4(v.w) << 24);
     }
-    uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
 #pragma unroll
     for (int jt = 0; jt < 4 * NW; ++jt) { // ntab == 4 * NW (zero tables past ceil(k/4))
       const uint4 e = itab[(uint32_t)jt * 256u + ((w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu)];
       f0 ^= e.x; f1 ^= e.y; r0 ^= e.z; r1 ^= e.w;
     }
     const uint64_t f = ((uint64_t)f1 << 32) | f0, r = ((uint64_t)r1 << 32) | r0;
-    const uint32_t c_first = w[0] & 3u, c_last = (w[(k - 1u) >> 4] >> (((k - 1u) & 15u) * 2u)) & 3u;
+    if constexpr (NW != 0) {
+      c_first = w[0] & 3u;
+      c_last = (w[(k - 1u) >> 4] >> (((k - 1u) & 15u) * 2u)) & 3u;
+    }
     auto emit = [&](uint64_t* dst, uint64_t h0) {
       dst[0] = h0;
       for (uint32_t j = 1; j < m; ++j) dst[j] = mix_hash(h0, (uint64_t)j ^ base);

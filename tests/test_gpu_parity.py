@@ -659,10 +659,11 @@ def test_kmer_extend_golden(ctx):
 
 
 @pytest.mark.parametrize("n,k,m", [(5000, 31, 3), (3001, 31, 1), (777, 17, 1), (500, 64, 2), (300, 65, 1), (200, 100, 2),
-                                   (64, 4, 1), (1, 48, 1), (600033, 31, 1), (70, 33, 1), (4001, 31, 8), (1000, 21, 5), (300000, 25, 2)])
+                                   (64, 4, 1), (1, 48, 1), (600033, 31, 1), (70, 33, 1), (4001, 31, 8), (1000, 21, 5), (300000, 25, 2),
+                                   (5003, 96, 1), (700, 200, 3), (131, 1000, 2), (70, 2500, 1), (3, 9000, 1)])
 def test_kmer_extend_batch_consistency(ctx, oracle, n, k, m):
     """a batch: successor b of k-mer i == the hash stream entry of (kmer[1:] + b); self == k-mer hash
-    (k <= 64: table kernel with 16-byte neighbour stores for m = 1; k > 64: Horner kernel)"""
+    (k <= 64: byte tables; k > 64: Horner over a staged 2-bit stream; very long k: the lane-per-k-mer kernel)"""
     rng = np.random.default_rng(12 + k)
     kmers = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (n, k))]
     r = ctx.kmer_extend(kmers.ravel(), k, m)

@@ -5,8 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import nthash_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
-k = 31
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 31
 ctx = nthash_amd.Context(0)
 d_in = ctx.malloc(n * k)
 ctx.synth_reads_ptr(d_in, 0, n, k, 3)
@@ -20,4 +20,4 @@ for _ in range(4):
     assert rc == 0
 ms, name = ctx.last_kernel_ms()
 gb = n * (k + 9 * m * 8) / 1e9
-print(f"{name} m={m}: {ms:.3f} ms for {n} k-mers = {n/ms/1e6:.1f} G k-mers/s ({9*m*n/ms/1e6:.0f} G hashes/s, {gb/ms:.2f} TB/s)")
+print(f"{name} k={k} m={m}: {ms:.3f} ms for {n} k-mers = {n/ms/1e6:.1f} G k-mers/s ({9*m*n/ms/1e6:.0f} G hashes/s, {gb/ms:.2f} TB/s)")
