@@ -65,7 +65,9 @@ typedef struct {
   uint32_t fixed_len;      /* != 0: read r is seqs[r*stride, r*stride + fixed_len) */
   uint32_t stride;         /* bytes between read starts; 0 means fixed_len.  stride <
                               fixed_len describes overlapping runs of ONE long sequence:
-                              stride = R, fixed_len = R + k - 1 hashes R windows per run */
+                              stride = R, fixed_len = R + k - 1 hashes R windows per run;
+                              stride > fixed_len: padded rows (one read per line of a text
+                              file: stride = fixed_len + 1), the padding bytes are never hashed */
 } nthip_reads;
 
 /* Where the hash stream goes.  Replaces NtHash::hashes() / get_pos() /
