@@ -645,6 +645,30 @@ def test_fuzz_seed_shapes(ctx, oracle):
         assert (got["counts"] == want["counts"]).all()
 
 
+@pytest.mark.parametrize("n,L,gap,k,m,dirty,pad", [
+    (3000, 120, 1, 31, 1, False, b"\n"), (3000, 120, 1, 31, 1, True, b"\n"), (1500, 151, 5, 25, 3, True, b"ACGTN"),
+    (900, 100, 28, 64, 2, False, b"A"), (40, 5003, 117, 31, 1, True, b"\r\n"), (2000, 64, 64, 21, 1, False, b"#"),
+])
+def test_kmer_padded_rows_vs_oracle(ctx, oracle, n, L, gap, k, m, dirty, pad):
+    """rows with padding between the reads (stride > fixed_len; e.g. one read per line of a text file):
+    the padding -- bases, newlines, anything -- is never hashed; positions and per-read counts as for packed reads"""
+    rng = np.random.default_rng(n + gap)
+    reads = oracle.synth_reads(6, n, L, 31 + gap).reshape(n, L).copy()
+    if dirty:
+        reads.ravel()[rng.integers(0, n * L, max(2, n * L // 3000))] = ord("N")
+    rows = np.empty((n, L + gap), np.uint8)
+    rows[:, :L] = reads
+    rows[:, L:] = np.frombuffer(pad, np.uint8)[rng.integers(0, len(pad), (n, gap))]
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(reads.ravel(), offs, k, m, want_pos=True)
+    flat = rows.ravel()[: (n - 1) * (L + gap) + L]           # the batch ends with the last read, not its padding
+    got = ctx.kmer_hash(flat, k, m, fixed_len=L, stride=L + gap, n_reads=n, want_pos=True)
+    assert got["total"] == want["total"]
+    assert (got["counts"] == want["counts"]).all()
+    assert (got["hashes"] == want["hashes"]).all()
+    assert (got["pos"] == want["pos"]).all()
+
+
 # ---------------------------------------------------------------------------
 # batched graph-extension query (BlindNtHash::peek / peek_back for all 4 bases)
 # ---------------------------------------------------------------------------
