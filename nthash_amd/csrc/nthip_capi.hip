@@ -1626,7 +1626,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
       HIPCHK(hipGetLastError());
     }
     done = true;
-  } else if (!rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.pos && !st.fwd && !st.rev && m2 <= (uint32_t)SF_MAX_RUNTIME_M &&
+  } else if (!rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.fwd && !st.rev && m2 <= (uint32_t)SF_MAX_RUNTIME_M &&
              k <= 64 && stride <= len) {
     const uint32_t nwin = len - k + 1;
     const uint32_t nh = (k + 7) / 8; // 16-bit halves of the window; 2*nh byte tables per seed in LDS (zero-padded)
@@ -1701,6 +1701,11 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
         if (st.counts) {
           hipLaunchKernelGGL(fill_u64_kernel, dim3(1024), dim3(256), 0, c->stream, st.counts, rd->n_reads,
                              (uint64_t)nwin);
+          HIPCHK(hipGetLastError());
+        }
+        if (st.pos) { // every read emits every window: get_pos() is the window index
+          hipLaunchKernelGGL(seed_fill_pos_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, st.pos, rd->n_reads, nwin,
+                             (const uint64_t*)nullptr, (const uint64_t*)nullptr);
           HIPCHK(hipGetLastError());
         }
         done = true;
@@ -1781,10 +1786,16 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
         rc = NT_SEED_FIXED(true, dyn2);
 #undef NT_SEED_FIXED
         NTCHK(rc);
+        if (st.pos) {
+          hipLaunchKernelGGL(seed_fill_pos_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, st.pos, n, nwin,
+                             (const uint64_t*)d_flags, (const uint64_t*)d_roff);
+          HIPCHK(hipGetLastError());
+        }
         if (n_dirty) {
           h.counts = nullptr;
           h.read_off = d_roff;
           h.hashes = st.hashes;
+          h.pos = st.pos;
           h.capacity = out->capacity;
           h.wave_waves = wplan.waves_hash;
           HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));

@@ -1237,15 +1237,28 @@ def test_seed_dirty_fixed_length_split_path(ctx, oracle, n, L, seeds, m2, stride
     st_ = stride or L
     reads = [data[i * st_: i * st_ + L].tobytes() for i in range(n)]
     d, offs = concat_reads(reads)
-    want = oracle.seed_batch(d, offs, seeds, k, m2, want_pos=False)
+    want = oracle.seed_batch(d, offs, seeds, k, m2, want_pos=True)
+    for want_pos in (False, True):   # positions: window indices for the clean reads, the state machine's for the others
+        ctx.set_profiling(True)
+        got = ctx.seed_hash(data, seeds, k, m2, fixed_len=L, stride=stride, n_reads=n, want_pos=want_pos)
+        name = ctx.last_kernel_ms()[1]
+        ctx.set_profiling(False)
+        assert name == "seed_fixed_kernel", name          # not the all-reads general fallback
+        assert got["total"] == want["total"]
+        assert (got["counts"] == want["counts"]).all()
+        assert (got["hashes"] == want["hashes"]).all()
+        if want_pos:
+            assert (got["pos"] == want["pos"]).all()
+    # a clean batch with positions stays on the dense kernel too
+    clean = oracle.synth_reads(3, n, L, 9)
+    offs_c = np.arange(n + 1, dtype=np.uint64) * L
+    want_c = oracle.seed_batch(clean, offs_c, seeds, k, m2, want_pos=True)
     ctx.set_profiling(True)
-    got = ctx.seed_hash(data, seeds, k, m2, fixed_len=L, stride=stride, n_reads=n)
+    got_c = ctx.seed_hash(clean, seeds, k, m2, fixed_len=L, n_reads=n, want_pos=True)
     name = ctx.last_kernel_ms()[1]
     ctx.set_profiling(False)
-    assert name == "seed_fixed_kernel", name          # not the all-reads general fallback
-    assert got["total"] == want["total"]
-    assert (got["counts"] == want["counts"]).all()
-    assert (got["hashes"] == want["hashes"]).all()
+    assert name == "seed_fixed_kernel", name
+    assert (got_c["hashes"] == want_c["hashes"]).all() and (got_c["pos"] == want_c["pos"]).all()
 
 
 def test_async_dense_batches(ctx, oracle):
