@@ -1862,7 +1862,7 @@ extern "C" int nthip_kmer_extend(nthip_ctx* c, const char* kmers, uint64_t n, ui
   const size_t wave_bits = k > 64 ? ((((size_t)64 * k + 30) >> 4) + 4) * 4 : 0;
   const size_t lds_fixed = (size_t)ntab * 4096 + 16 * 2048; // tables + a 2 KiB exchange tile per wave
   const size_t lds_cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
-  uint32_t waves = 16;
+  uint32_t waves = k > 32 && k <= 64 ? KX_WIDE_THREADS / 64 : 16;
   while (waves > 1 && lds_fixed + wave_bits * waves > lds_cap) waves /= 2;
   if (aligned16 && lds_fixed + wave_bits * waves <= lds_cap) {
     const uint4* tab = nullptr;

@@ -199,8 +199,11 @@ __global__ __launch_bounds__(256) void kmer_extend_kernel(const uint8_t* __restr
 // The same for k <= 64 with the first-window byte tables in LDS (4 bases per lookup instead of 2k Horner
 // steps) and, for m == 1, the four neighbours of the wave's 64 k-mers (2 KiB contiguous) exchanged through LDS
 // so that each store instruction writes one contiguous KiB.  tab = build_byte_tables(k), zero-padded to ntab.
+#ifndef KX_WIDE_THREADS
+#define KX_WIDE_THREADS 512 // NW >= 3 (k > 32): 16 lookups in flight need more than the 128 VGPRs a 1024-thread block gets
+#endif
 template <int NW>
-__global__ __launch_bounds__(1024) void kmer_extend_tab_kernel(const uint8_t* __restrict__ kmers, uint64_t n, uint32_t k,
+__global__ __launch_bounds__(NW >= 3 ? KX_WIDE_THREADS : 1024) void kmer_extend_tab_kernel(const uint8_t* __restrict__ kmers, uint64_t n, uint32_t k,
                                                               uint32_t m, const uint4* __restrict__ tab, uint32_t ntab,
                                                               uint64_t* __restrict__ self, uint64_t* __restrict__ next,
                                                               uint64_t* __restrict__ prev)
