@@ -1220,7 +1220,9 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
   // optimistic dense pass: wanted when the dense stream fits the caller's capacity (a batch with non-bases
   // may still fit when the dense stream does not: the counting paths below decide that)
   const bool rows_ok = !rd->offsets && kmer_fixed_eligible(c, len, stride, k, m, &pad, &dyn);
-  const bool want_fast = !rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.pos && !st.fwd && !st.rev &&
+  // (positions do not need the N-aware pass when the batch turns out clean: every window is emitted)
+  const bool want_fast = !rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.fwd && !st.rev &&
+                         !(st.pos && (flags & NTHIP_ASYNC)) &&
                          len >= k && rd->n_reads * (uint64_t)(len - k + 1) <= out->capacity;
   // fixed-length reads that are (or may be) dirty, or whose positions are wanted: N-aware run-split path
   NaPlan na_plan;
@@ -1342,6 +1344,11 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
       if (st.counts) {
         hipLaunchKernelGGL(fill_u64_kernel, dim3(1024), dim3(256), 0, c->stream, st.counts, rd->n_reads,
                            (uint64_t)nwin);
+        HIPCHK(hipGetLastError());
+      }
+      if (st.pos) { // get_pos() of a read of bases only: the window index
+        hipLaunchKernelGGL(fill_window_pos_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, st.pos, rd->n_reads, nwin,
+                           (const uint64_t*)nullptr, (const uint64_t*)nullptr);
         HIPCHK(hipGetLastError());
       }
       done = true;
@@ -1704,7 +1711,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
           HIPCHK(hipGetLastError());
         }
         if (st.pos) { // every read emits every window: get_pos() is the window index
-          hipLaunchKernelGGL(seed_fill_pos_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, st.pos, rd->n_reads, nwin,
+          hipLaunchKernelGGL(fill_window_pos_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, st.pos, rd->n_reads, nwin,
                              (const uint64_t*)nullptr, (const uint64_t*)nullptr);
           HIPCHK(hipGetLastError());
         }
@@ -1787,7 +1794,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
 #undef NT_SEED_FIXED
         NTCHK(rc);
         if (st.pos) {
-          hipLaunchKernelGGL(seed_fill_pos_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, st.pos, n, nwin,
+          hipLaunchKernelGGL(fill_window_pos_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, st.pos, n, nwin,
                              (const uint64_t*)d_flags, (const uint64_t*)d_roff);
           HIPCHK(hipGetLastError());
         }

@@ -93,22 +93,6 @@ __global__ __launch_bounds__(256) void seed_mark_dirty_kernel(const uint8_t* __r
   }
 }
 
-// get_pos() of the k-mers the dense seed kernel writes: a read of bases only emits every window, 0 .. nwin-1, at
-// its place in the stream (read_off[r], or r * nwin for a clean batch); flagged reads are left to seed_wave_kernel.
-// One wave per read at a time: nwin * 4 contiguous bytes.
-__global__ __launch_bounds__(256) void seed_fill_pos_kernel(uint32_t* __restrict__ pos, uint64_t n_reads, uint32_t nwin,
-                                                           const uint64_t* __restrict__ read_dirty,
-                                                           const uint64_t* __restrict__ read_off)
-{
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-  for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < n_reads; r += n_waves) {
-    if (read_dirty && read_dirty[r]) continue;
-    uint32_t* dst = pos + (read_off ? read_off[r] : r * nwin);
-    for (uint32_t p = lane; p < nwin; p += 64u) dst[p] = p;
-  }
-}
-
 // list[idx[r]] = r for the flagged reads (idx = exclusive scan of the flags)
 __global__ __launch_bounds__(256) void seed_list_kernel(const uint64_t* __restrict__ flags, const uint64_t* __restrict__ idx,
                                                        uint64_t n_reads, uint64_t* __restrict__ list)

@@ -383,6 +383,22 @@ __global__ __launch_bounds__(NW >= 3 ? KX_WIDE_THREADS : 1024) void kmer_extend_
   }
 }
 
+// get_pos() of the k-mers the dense kernels write: a read of bases only emits every window, 0 .. nwin-1, at its
+// place in the stream (read_off[r], or r * nwin for a clean batch); flagged reads are left to the N-aware kernels.
+// One wave per read at a time: nwin * 4 contiguous bytes.
+__global__ __launch_bounds__(256) void fill_window_pos_kernel(uint32_t* __restrict__ pos, uint64_t n_reads, uint32_t nwin,
+                                                           const uint64_t* __restrict__ read_dirty,
+                                                           const uint64_t* __restrict__ read_off)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < n_reads; r += n_waves) {
+    if (read_dirty && read_dirty[r]) continue;
+    uint32_t* dst = pos + (read_off ? read_off[r] : r * nwin);
+    for (uint32_t p = lane; p < nwin; p += 64u) dst[p] = p;
+  }
+}
+
 // plain 16-byte/lane device copy: the achievable-bandwidth yardstick
 __global__ __launch_bounds__(256) void copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src,
                                                   uint64_t n16)
