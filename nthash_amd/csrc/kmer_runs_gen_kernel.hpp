@@ -48,7 +48,7 @@ namespace ntamd {
 #define KRG_LOAD_NT " nt"
 #endif
 constexpr uint32_t KRG_ALIGN_U64 = 128; // the output tile is aligned to 1 KiB of the stream
-constexpr uint32_t KRG_SLACK_U64 = 16;  // N-aware: room below the tile for a first run's recomputed windows
+constexpr uint32_t KRG_SLACK_U64 = 32;  // N-aware: room below the tile for a first run's recomputed windows (< C <= 31)
 enum : int { SINK_NONE = 0, SINK_BLOOM_INSERT = 1, SINK_BLOOM_QUERY = 2, SINK_MINHASH = 3, SINK_MINHASH1 = 4 };
 // (SINK_MINHASH1: the signature is the minimum canonical hash alone -- one register pair, no multiplies)
 constexpr uint32_t KRG_SIG_MAX = 8;     // MinHash: signature entries one launch keeps in registers

@@ -719,20 +719,31 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
   const uint32_t ntab = (k + 3) / 4; // first-window cost in the model (table lookups or Horner steps)
   uint32_t best = 0;
   double best_cost = 1e30;
-  const uint32_t c_hi = nwin < 16 ? nwin : 16;
+  // The kernels take runs of up to 31 windows (the window masks of the N-aware pass are 32 bits wide), but the
+  // model stops at 16: it does not see what a larger tile costs in waves per CU.  In-process A/B over 24 shapes
+  // (profiles/r01_notes.md): longer runs win 3-8 % where they cut the runs per read sharply (100 bp/k64: 13 -> 19,
+  // 1 kb reads, k <= 15) and lose 5-28 % elsewhere (k = 63/64 at 150 bp: -27 %).
+  uint32_t c_cap = 16;
+  if (const char* t = getenv("NTHIP_TUNE_RUN_MAX")) { // A/B knob: longest run the model may pick
+    const uint32_t d = (uint32_t)atoi(t);
+    if (d >= 1 && d <= 31) c_cap = d;
+  }
+  const uint32_t c_hi = nwin < c_cap ? nwin : c_cap;
   for (uint32_t C = c_hi; C >= 1; --C) {
     const uint32_t rpr = (nwin + C - 1) / C;
     // the 64 rows of a tile are C*8 bytes apart: an even C puts several lanes of a ds_write_b64 on the
-    // same LDS banks (16-way for C = 16), an odd C none
+    // same LDS banks (16-way for C = 16), an odd C none.  Measured: 2-way is nearly free (C = 18 on 101 bp
+    // +7 % over C = 15), 4-way is not (C = 20 on 50 bp -12 % against two runs of 10)
     uint32_t g = 2 * C, ways = 1;
     while (ways < 32 && (g & 1) == 0) { g >>= 1; ways <<= 1; }
     ways = ways > 2 ? ways / 2 : 1;
-    const double cost = (double)rpr * (2.0 + 0.5 * ntab + (C - 1) * (1.0 + 0.05 * (ways - 1))) / nwin;
+    const double conflict = ways <= 1 ? 0.0 : ways == 2 ? 0.05 : ways == 4 ? 0.45 : 1.0;
+    const double cost = (double)rpr * (2.0 + 0.5 * ntab + (C - 1) * (1.0 + conflict)) / nwin;
     if (cost < best_cost - 1e-9) { best_cost = cost; best = C; }
   }
   if (const char* t = getenv("NTHIP_TUNE_RUN_LEN")) { // A/B override
     const uint32_t d = (uint32_t)atoi(t);
-    if (d >= 1 && d <= 16 && d <= nwin) best = d;
+    if (d >= 1 && d <= 31 && d <= nwin) best = d; // (the model itself stays at <= 16)
   }
   if (best == 0) return false;
   p->C = best;
