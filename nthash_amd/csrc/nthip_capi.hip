@@ -86,6 +86,11 @@ struct nthip_ctx {
   std::map<std::pair<const void*, size_t>, int> occ_cache;
   // all-care byte tables for the first window of a run, per k (device memory)
   std::map<uint32_t, uint4*> init_tabs;
+  // staging arena of the NTHIP_HOST_INPUT / NTHIP_HOST_OUTPUT calls: small host-buffer calls (the C++ facade makes
+  // one per object) carve their device copies out of it instead of paying five hipMalloc / hipFree pairs each.
+  // Grow-only up to STAGE_ARENA_MAX; calls that need more allocate as before.
+  uint8_t* stage_buf = nullptr;
+  size_t stage_cap = 0, stage_used = 0, stage_want = 0;
   // buffers of the FASTQ / FASTA streaming driver, kept between calls (pinning and mapping half a GiB costs more
   // than streaming a few GB through it); released by nthip_ctx_trim / nthip_ctx_destroy
   struct FastxBuffers {
@@ -212,18 +217,51 @@ struct Staged {
   }
 };
 
+constexpr size_t STAGE_ARENA_MAX = 64u << 20;
+
+// a call that stages host buffers starts here (stage_inputs is its first staging step): the arena is free again
+// (staged calls end synchronised), and grows to what the previous call would have liked
+int stage_begin(nthip_ctx* c)
+{
+  if (c->stage_want > c->stage_cap && c->stage_want <= STAGE_ARENA_MAX) {
+    if (c->stage_buf) HIPCHK(hipFree(c->stage_buf));
+    c->stage_buf = nullptr;
+    c->stage_cap = 0;
+    size_t cap = c->stage_want + c->stage_want / 4 + 4096;
+    if (cap > STAGE_ARENA_MAX) cap = STAGE_ARENA_MAX;
+    HIPCHK(hipMalloc((void**)&c->stage_buf, cap));
+    c->stage_cap = cap;
+  }
+  c->stage_used = c->stage_want = 0;
+  return NTHIP_OK;
+}
+
+// device memory for one staged buffer of this call: from the arena when it fits, its own allocation otherwise
+int stage_alloc(nthip_ctx* c, Staged& st, size_t bytes, void** p)
+{
+  const size_t need = ((bytes ? bytes : 16) + 255) & ~(size_t)255;
+  c->stage_want += need;
+  if (c->stage_buf && c->stage_used + need <= c->stage_cap) {
+    *p = c->stage_buf + c->stage_used;
+    c->stage_used += need;
+    return NTHIP_OK;
+  }
+  HIPCHK(hipMalloc(p, need));
+  st.owned.push_back(*p);
+  return NTHIP_OK;
+}
+
 int stage_inputs(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, uint64_t total_bytes, Staged& st)
 {
+  if (flags & (NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT)) NTCHK(stage_begin(c));
   if (flags & NTHIP_HOST_INPUT) {
     void* d = nullptr;
-    HIPCHK(hipMalloc(&d, total_bytes ? total_bytes : 16));
-    st.owned.push_back(d);
+    NTCHK(stage_alloc(c, st, total_bytes, &d));
     if (total_bytes) HIPCHK(hipMemcpyAsync(d, rd->seqs, total_bytes, hipMemcpyHostToDevice, c->stream));
     st.seqs = (const uint8_t*)d;
     if (rd->offsets) {
       void* o = nullptr;
-      HIPCHK(hipMalloc(&o, (rd->n_reads + 1) * sizeof(uint64_t)));
-      st.owned.push_back(o);
+      NTCHK(stage_alloc(c, st, (rd->n_reads + 1) * sizeof(uint64_t), &o));
       HIPCHK(hipMemcpyAsync(o, rd->offsets, (rd->n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
                             c->stream));
       st.offsets = (const uint64_t*)o;
@@ -238,13 +276,8 @@ int stage_inputs(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, uint64_t t
 int stage_outputs(nthip_ctx* c, const nthip_out* out, uint32_t flags, uint64_t n_reads, uint32_t per,
                   Staged& st, uint32_t strands_per = 1)
 {
-  (void)c;
   if (flags & NTHIP_HOST_OUTPUT) {
-    auto alloc = [&](size_t bytes, void** p) -> int {
-      HIPCHK(hipMalloc(p, bytes ? bytes : 16));
-      st.owned.push_back(*p);
-      return NTHIP_OK;
-    };
+    auto alloc = [&](size_t bytes, void** p) -> int { return stage_alloc(c, st, bytes, p); };
     NTCHK(alloc(out->capacity * per * sizeof(uint64_t), (void**)&st.hashes));
     if (out->counts) NTCHK(alloc(n_reads * sizeof(uint64_t), (void**)&st.counts));
     if (out->pos) NTCHK(alloc(out->capacity * sizeof(uint32_t), (void**)&st.pos));
@@ -416,6 +449,7 @@ extern "C" int nthip_ctx_destroy(nthip_ctx* c)
   if (c->d_scratch2) (void)hipFree(c->d_scratch2);
   for (auto& kv : c->init_tabs) (void)hipFree(kv.second);
   fastx_buffers_release(c);
+  if (c->stage_buf) (void)hipFree(c->stage_buf);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -429,6 +463,9 @@ extern "C" int nthip_ctx_trim(nthip_ctx* c)
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
   fastx_buffers_release(c);
+  if (c->stage_buf) (void)hipFree(c->stage_buf);
+  c->stage_buf = nullptr;
+  c->stage_cap = c->stage_used = c->stage_want = 0;
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->d_scratch2) (void)hipFree(c->d_scratch2);
   c->d_scratch = c->d_scratch2 = nullptr;
