@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <map>
 #include <string>
 #include <vector>
@@ -86,6 +87,9 @@ struct nthip_ctx {
   std::map<std::pair<const void*, size_t>, int> occ_cache;
   // all-care byte tables for the first window of a run, per k (device memory)
   std::map<uint32_t, uint4*> init_tabs;
+  // run length of the general dense kernel per (len, stride, k, m), measured on the first big batch of that shape
+  // (the cost model does not see what a longer run costs in waves per CU or LDS conflicts: +-10 % either way)
+  std::map<std::array<uint32_t, 4>, uint32_t> run_len_cache;
   // staging arena of the NTHIP_HOST_INPUT / NTHIP_HOST_OUTPUT calls: small host-buffer calls (the C++ facade makes
   // one per object) carve their device copies out of it instead of paying five hipMalloc / hipFree pairs each.
   // Grow-only up to STAGE_ARENA_MAX; calls that need more allocate as before.
@@ -747,8 +751,9 @@ struct GenPlan {
 // gaps_ok: rows may be padded (stride > len).  The padding travels through the slab like any other byte, so
 // the dense pass -- which flags every non-base it stages -- does not take such batches; the N-aware passes do
 // (no window reaches into the padding).
+// force_c: run length to use (0: the model's choice); model_cap: longest run the model may pick (0: its default)
 bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, GenPlan* p,
-                   bool gaps_ok = false)
+                   bool gaps_ok = false, uint32_t force_c = 0, uint32_t model_cap = 0)
 {
   if (len < k || m == 0 || (stride > len && !gaps_ok) || len >= (1u << 30) || stride >= (1u << 30)) return false;
   const uint32_t nwin = len - k + 1;
@@ -760,7 +765,7 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
   // model stops at 16: it does not see what a larger tile costs in waves per CU.  In-process A/B over 24 shapes
   // (profiles/r01_notes.md): longer runs win 3-8 % where they cut the runs per read sharply (100 bp/k64: 13 -> 19,
   // 1 kb reads, k <= 15) and lose 5-28 % elsewhere (k = 63/64 at 150 bp: -27 %).
-  uint32_t c_cap = 16;
+  uint32_t c_cap = model_cap ? model_cap : 16;
   if (const char* t = getenv("NTHIP_TUNE_RUN_MAX")) { // A/B knob: longest run the model may pick
     const uint32_t d = (uint32_t)atoi(t);
     if (d >= 1 && d <= 31) c_cap = d;
@@ -778,6 +783,7 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
     const double cost = (double)rpr * (2.0 + 0.5 * ntab + (C - 1) * (1.0 + conflict)) / nwin;
     if (cost < best_cost - 1e-9) { best_cost = cost; best = C; }
   }
+  if (force_c >= 1 && force_c <= 31 && force_c <= nwin) best = force_c;
   if (const char* t = getenv("NTHIP_TUNE_RUN_LEN")) { // A/B override
     const uint32_t d = (uint32_t)atoi(t);
     if (d >= 1 && d <= 31 && d <= nwin) best = d; // (the model itself stays at <= 16)
@@ -1360,8 +1366,71 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
     } else if (!rows_only && kmer_gen_plan(c, len, stride, k, m, &gplan)) {
       // any other shape: general run-split kernel (kmer_runs_gen_kernel.hpp)
       KmerRunsGenArgs ga;
+      const uint4* gen_tab = nullptr;
+      NTCHK(get_kmer_tab(c, k, &gen_tab));
+      // big batch of a shape not seen before: time the model's run length against the longer ones it may not pick
+      // on a slice of the batch (a few launches of ~1 ms), keep the fastest for this context
+      const std::array<uint32_t, 4> shape_key = {len, stride, k, m};
+      auto tuned = c->run_len_cache.find(shape_key);
+      if (tuned == c->run_len_cache.end() && dense >= (1ull << 30) && !async && !getenv("NTHIP_TUNE_RUN_LEN") &&
+          !getenv("NTHIP_TUNE_RUN_MAX") && !getenv("NTHIP_TUNE_NO_AUTOTUNE")) {
+        uint32_t cand[4] = {gplan.C, 0, 0, 0};
+        const uint32_t caps[3] = {19, 23, 31};
+        uint32_t n_cand = 1;
+        for (uint32_t cap : caps) {
+          GenPlan q;
+          if (!kmer_gen_plan(c, len, stride, k, m, &q, false, 0, cap)) continue;
+          bool seen = false;
+          for (uint32_t i = 0; i < n_cand; ++i) seen = seen || cand[i] == q.C;
+          if (!seen) cand[n_cand++] = q.C;
+        }
+        uint32_t best_c = gplan.C;
+        if (n_cand > 1) {
+          nthip_reads slice = *rd;
+          const uint64_t want = (128ull << 20) / nwin + 1; // ~128 M k-mers (a quarter of a millisecond) per trial
+          slice.n_reads = rd->n_reads < want ? rd->n_reads : want;
+          hipEvent_t e0 = nullptr, e1 = nullptr;
+          HIPCHK(hipEventCreate(&e0));
+          HIPCHK(hipEventCreate(&e1));
+          float best_ms = 1e30f;
+          bool clean = true;
+          for (uint32_t i = 0; i < n_cand && clean; ++i) {
+            GenPlan q;
+            if (!kmer_gen_plan(c, len, stride, k, m, &q, false, cand[i])) continue;
+            fill_gen_args(ga, c, st, &slice, k, m, q, a);
+            ga.init_tab = gen_tab;
+            float ms = 1e30f;
+            for (int rep = 0; rep < 2 && clean; ++rep) { // the first launch warms the tables and the clocks
+              HIPCHK(hipEventRecord(e0, c->stream));
+              const bool prof = c->profiling;
+              c->profiling = false;
+              const int trc = launch_kmer_runs_gen_nw<false>(c, ga, q.lds, q.nw, q.dword_tail != 0);
+              c->profiling = prof;
+              NTCHK(trc);
+              HIPCHK(hipEventRecord(e1, c->stream));
+              HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
+              HIPCHK(hipStreamSynchronize(c->stream));
+              uint32_t d = 0;
+              memcpy(&d, c->h_small, 4);
+              if (d) clean = false; // a non-base: the dense kernel stopped early, the times mean nothing
+              HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            }
+            // (the model's choice is the first candidate: another one has to beat it by 3 % to replace it)
+            if (clean && ms < (i == 0 ? best_ms : 0.97f * best_ms)) { best_ms = ms; best_c = cand[i]; }
+          }
+          (void)hipEventDestroy(e0);
+          (void)hipEventDestroy(e1);
+          if (clean) tuned = c->run_len_cache.emplace(shape_key, best_c).first;
+          else HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream)); // the real pass below finds it again
+        } else {
+          tuned = c->run_len_cache.emplace(shape_key, gplan.C).first;
+        }
+      }
+      if (tuned != c->run_len_cache.end() && tuned->second != gplan.C &&
+          !kmer_gen_plan(c, len, stride, k, m, &gplan, false, tuned->second))
+        return fail(NTHIP_ERR_HIP, "run-split plan failed for a tuned run length");
       fill_gen_args(ga, c, st, rd, k, m, gplan, a);
-      NTCHK(get_kmer_tab(c, k, &ga.init_tab));
+      ga.init_tab = gen_tab;
       rc = launch_kmer_runs_gen_nw<false>(c, ga, gplan.lds, gplan.nw, gplan.dword_tail != 0);
     } else if (!rows_ok) {
       rc = NTHIP_OK;

@@ -1261,6 +1261,36 @@ def test_seed_dirty_fixed_length_split_path(ctx, oracle, n, L, seeds, m2, stride
     assert (got_c["hashes"] == want_c["hashes"]).all() and (got_c["pos"] == want_c["pos"]).all()
 
 
+@pytest.mark.parametrize("L,k,m", [(151, 31, 1), (125, 31, 1), (96, 64, 1), (76, 31, 2)])
+def test_autotuned_run_length_gives_the_same_stream(oracle, L, k, m, monkeypatch):
+    """a batch of >= 2^30 k-mers of a shape the context has not seen: the general dense kernel times a few run
+    lengths on a slice and keeps the fastest -- whatever it picks, the stream is the one the model's choice gives
+    (checksums of the whole stream + the first reads against the oracle)"""
+    import nthash_amd
+    nwin = L - k + 1
+    n = (1 << 30) // nwin + 1000
+    tuned, plain = nthash_amd.Context(0), nthash_amd.Context(0)
+    d_in = tuned.malloc(n * L)
+    d_out = tuned.malloc(n * nwin * m * 8)
+    tuned.synth_reads_ptr(d_in, 0, n, L, 11)
+    monkeypatch.delenv("NTHIP_TUNE_NO_AUTOTUNE", raising=False)
+    assert tuned.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin) == n * nwin
+    sums_tuned = tuned.checksum_ptr(d_out, n * nwin * m)
+    head = np.zeros(2000 * nwin * m, np.uint64)
+    tuned.d2h(head, d_out)
+    monkeypatch.setenv("NTHIP_TUNE_NO_AUTOTUNE", "1")
+    assert plain.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin) == n * nwin
+    assert plain.checksum_ptr(d_out, n * nwin * m) == sums_tuned
+    reads = oracle.synth_reads(0, 2000, L, 11)
+    want = oracle.kmer_batch(reads, np.arange(2001, dtype=np.uint64) * L, k, m, want_pos=False)
+    assert (head == want["hashes"].ravel()).all()
+    # the second call of the tuned context reuses its choice
+    assert tuned.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin) == n * nwin
+    assert tuned.checksum_ptr(d_out, n * nwin * m) == sums_tuned
+    tuned.free(d_in)
+    tuned.free(d_out)
+
+
 def test_async_dense_batches(ctx, oracle):
     """NTHIP_ASYNC: many small device-resident batches back to back without a round trip per call;
     nthip_ctx_take_dirty tells afterwards whether every stream is valid"""

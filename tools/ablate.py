@@ -7,6 +7,7 @@ variants: runs (default kernel), gen / genC<n> (general run-split kernel, run le
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("NTHIP_TUNE_NO_AUTOTUNE", "1")  # A/B hygiene: the same run length on both sides
 import nthash_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 variants = (sys.argv[2] if len(sys.argv) > 2 else "runs,runs_vec,rows").split(",")
