@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <array>
+#include <chrono>
 #include <map>
 #include <string>
 #include <vector>
@@ -844,9 +845,9 @@ struct NaPlan {
 };
 
 bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, bool want_pos,
-                  NaPlan* p, uint32_t register_sink_u64 = 0)
+                  NaPlan* p, uint32_t register_sink_u64 = 0, uint32_t force_c = 0, uint32_t model_cap = 0)
 {
-  if (!kmer_gen_plan(c, len, stride, k, m, &p->g, /*gaps_ok*/ true)) return false;
+  if (!kmer_gen_plan(c, len, stride, k, m, &p->g, /*gaps_ok*/ true, force_c, model_cap)) return false;
   const GenPlan& g = p->g;
   p->tile_u64 = 64 * g.C + KRG_ALIGN_U64 + KRG_SLACK_U64;
   // a consumer that keeps the hashes in registers (MinHash) needs no tile, only its fold area
@@ -1478,6 +1479,50 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
     KmerFixedArgs consts;
     memset(&consts, 0, sizeof consts);
     fill_kmer_consts(k, m, consts);
+    // the run length of the N-aware passes, measured like the dense kernel's (see there): the first big batch of a
+    // shape runs count -> scan -> hash on a slice for every candidate
+    const uint64_t na_dense = rd->n_reads * (uint64_t)(len - k + 1);
+    const std::array<uint32_t, 4> na_key = {len, stride | 0x80000000u, k, m | (st.pos ? 0x100u : 0u)};
+    auto na_tuned = c->run_len_cache.find(na_key);
+    if (na_tuned == c->run_len_cache.end() && na_dense >= (1ull << 30) && !st.fwd && !st.rev &&
+        !getenv("NTHIP_TUNE_RUN_LEN") && !getenv("NTHIP_TUNE_RUN_MAX") && !getenv("NTHIP_TUNE_NO_AUTOTUNE")) {
+      uint32_t cand[4] = {na_plan.g.C, 0, 0, 0}, n_cand = 1;
+      for (uint32_t cap : {19u, 23u, 31u}) {
+        NaPlan q;
+        if (!kmer_na_plan(c, len, stride, k, m, st.pos != nullptr, &q, 0, 0, cap)) continue;
+        bool seen = false;
+        for (uint32_t i = 0; i < n_cand; ++i) seen = seen || cand[i] == q.g.C;
+        if (!seen) cand[n_cand++] = q.g.C;
+      }
+      uint32_t best_c = na_plan.g.C;
+      if (n_cand > 1) {
+        nthip_reads slice = *rd;
+        const uint64_t want = (256ull << 20) / (len - k + 1) + 1; // wall-clock timing (host round trips inside): longer trials
+        slice.n_reads = rd->n_reads < want ? rd->n_reads : want;
+        double best_s = 1e30;
+        const bool prof = c->profiling;
+        c->profiling = false;
+        for (uint32_t i = 0; i < n_cand; ++i) {
+          NaPlan q;
+          if (!kmer_na_plan(c, len, stride, k, m, st.pos != nullptr, &q, 0, cand[i])) continue;
+          double sec = 1e30;
+          int trc = NTHIP_OK;
+          for (int rep = 0; rep < 2 && trc == NTHIP_OK; ++rep) {
+            uint64_t tt = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            trc = run_kmer_na(c, st, &slice, k, m, q, consts, out->capacity, &tt);
+            sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          }
+          if (trc != NTHIP_OK) { c->profiling = prof; return trc; }
+          if (sec < (i == 0 ? best_s : 0.96 * best_s)) { best_s = sec; best_c = cand[i]; }
+        }
+        c->profiling = prof;
+      }
+      na_tuned = c->run_len_cache.emplace(na_key, best_c).first;
+    }
+    if (na_tuned != c->run_len_cache.end() && na_tuned->second != na_plan.g.C &&
+        !kmer_na_plan(c, len, stride, k, m, st.pos != nullptr, &na_plan, 0, na_tuned->second))
+      return fail(NTHIP_ERR_HIP, "N-aware plan failed for a tuned run length");
     int rc = run_kmer_na(c, st, rd, k, m, na_plan, consts, out->capacity, &total);
     if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
     NTCHK(rc);

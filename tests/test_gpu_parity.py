@@ -1287,8 +1287,27 @@ def test_autotuned_run_length_gives_the_same_stream(oracle, L, k, m, monkeypatch
     # the second call of the tuned context reuses its choice
     assert tuned.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin) == n * nwin
     assert tuned.checksum_ptr(d_out, n * nwin * m) == sums_tuned
-    tuned.free(d_in)
-    tuned.free(d_out)
+    # the same with N's: the N-aware passes tune their own run length (count -> scan -> hash on a slice)
+    for i in range(0, n * L, 150_001):
+        tuned.h2d(d_in + i, np.frombuffer(b"N", np.uint8))
+    d_cnt = tuned.malloc(n * 8)
+    monkeypatch.delenv("NTHIP_TUNE_NO_AUTOTUNE", raising=False)
+    tot_t = tuned.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin, counts=d_cnt)
+    res_t = (tuned.checksum_ptr(d_out, tot_t * m), tuned.checksum_ptr(d_cnt, n))
+    monkeypatch.setenv("NTHIP_TUNE_NO_AUTOTUNE", "1")
+    tot_p = plain.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin, counts=d_cnt)
+    assert tot_p == tot_t < n * nwin
+    assert (plain.checksum_ptr(d_out, tot_p * m), plain.checksum_ptr(d_cnt, n)) == res_t
+    raw = np.zeros(3000 * L, np.uint8)
+    tuned.d2h(raw, d_in)
+    want_d = oracle.kmer_batch(raw, np.arange(3001, dtype=np.uint64) * L, k, m, want_pos=False)
+    head_d = np.zeros(want_d["total"] * m, np.uint64)
+    monkeypatch.delenv("NTHIP_TUNE_NO_AUTOTUNE", raising=False)
+    assert tuned.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin, counts=d_cnt) == tot_t
+    tuned.d2h(head_d, d_out)
+    assert (head_d == want_d["hashes"].ravel()).all()
+    for d in (d_in, d_out, d_cnt):
+        tuned.free(d)
 
 
 def test_async_dense_batches(ctx, oracle):
