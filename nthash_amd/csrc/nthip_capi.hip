@@ -753,8 +753,11 @@ struct GenPlan {
 // the dense pass -- which flags every non-base it stages -- does not take such batches; the N-aware passes do
 // (no window reaches into the padding).
 // force_c: run length to use (0: the model's choice); model_cap: longest run the model may pick (0: its default)
+// no_tile: a consumer that keeps the hashes in registers (MinHash) -- a longer run then costs neither LDS nor
+// bank conflicts, only fewer first windows: the model may go to 31 (measured: 150 bp m=1 798 -> 853-868 G k-mers/s,
+// m=2 +16 %, m=4 +12 %)
 bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, GenPlan* p,
-                   bool gaps_ok = false, uint32_t force_c = 0, uint32_t model_cap = 0)
+                   bool gaps_ok = false, uint32_t force_c = 0, uint32_t model_cap = 0, bool no_tile = false)
 {
   if (len < k || m == 0 || (stride > len && !gaps_ok) || len >= (1u << 30) || stride >= (1u << 30)) return false;
   const uint32_t nwin = len - k + 1;
@@ -766,7 +769,7 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
   // model stops at 16: it does not see what a larger tile costs in waves per CU.  In-process A/B over 24 shapes
   // (profiles/r01_notes.md): longer runs win 3-8 % where they cut the runs per read sharply (100 bp/k64: 13 -> 19,
   // 1 kb reads, k <= 15) and lose 5-28 % elsewhere (k = 63/64 at 150 bp: -27 %).
-  uint32_t c_cap = model_cap ? model_cap : 16;
+  uint32_t c_cap = model_cap ? model_cap : no_tile ? 31 : 16;
   if (const char* t = getenv("NTHIP_TUNE_RUN_MAX")) { // A/B knob: longest run the model may pick
     const uint32_t d = (uint32_t)atoi(t);
     if (d >= 1 && d <= 31) c_cap = d;
@@ -780,7 +783,7 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
     uint32_t g = 2 * C, ways = 1;
     while (ways < 32 && (g & 1) == 0) { g >>= 1; ways <<= 1; }
     ways = ways > 2 ? ways / 2 : 1;
-    const double conflict = ways <= 1 ? 0.0 : ways == 2 ? 0.05 : ways == 4 ? 0.45 : 1.0;
+    const double conflict = no_tile || ways <= 1 ? 0.0 : ways == 2 ? 0.05 : ways == 4 ? 0.45 : 1.0;
     const double cost = (double)rpr * (2.0 + 0.5 * ntab + (C - 1) * (1.0 + conflict)) / nwin;
     if (cost < best_cost - 1e-9) { best_cost = cost; best = C; }
   }
@@ -847,7 +850,8 @@ struct NaPlan {
 bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, bool want_pos,
                   NaPlan* p, uint32_t register_sink_u64 = 0, uint32_t force_c = 0, uint32_t model_cap = 0)
 {
-  if (!kmer_gen_plan(c, len, stride, k, m, &p->g, /*gaps_ok*/ true, force_c, model_cap)) return false;
+  if (!kmer_gen_plan(c, len, stride, k, m, &p->g, /*gaps_ok*/ true, force_c, model_cap, register_sink_u64 != 0))
+    return false;
   const GenPlan& g = p->g;
   p->tile_u64 = 64 * g.C + KRG_ALIGN_U64 + KRG_SLACK_U64;
   // a consumer that keeps the hashes in registers (MinHash) needs no tile, only its fold area
