@@ -463,7 +463,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
           const uint4 dv = *(const uint4*)(tile + 2u * pi);
           const bool lo_ok = 2u * pi >= tpar && 2u * pi < span;
           const bool hi_ok = 2u * pi + 1u >= tpar && 2u * pi + 1u < span;
+#if defined(KRR_ST_PLAIN)
           if (lo_ok && hi_ok) *(uint4*)(base + 2u * pi) = dv;
+#else     // streaming stores for the whole pieces, as in the general kernel
+          if (lo_ok && hi_ok) __builtin_nontemporal_store(*(const nt_v4u*)&dv, (nt_v4u*)(base + 2u * pi));
+#endif
           else if (lo_ok) *(uint2*)(base + 2u * pi) = make_uint2(dv.x, dv.y);
           else if (hi_ok) *(uint2*)(base + 2u * pi + 1u) = make_uint2(dv.z, dv.w);
         }
