@@ -102,6 +102,9 @@ int nthip_ctx_take_dirty(nthip_ctx* ctx, int* dirty);
  * launch stream; nthip_last_kernel_ms reads the last bracket (synchronises) */
 int nthip_ctx_set_profiling(nthip_ctx* ctx, int on);
 int nthip_last_kernel_ms(nthip_ctx* ctx, float* ms, const char** kernel_name);
+/* the NTHIP_TUNE_* environment knobs of the measurement tools are read once, when the context is created;
+ * this reads them again (A/B runs that change them between variants) and forgets the measured run lengths */
+int nthip_ctx_reload_tuning(nthip_ctx* ctx);
 
 /* ---- device memory helpers (for callers without their own allocator) ---- */
 int nthip_malloc(nthip_ctx* ctx, size_t bytes, void** dptr);
@@ -288,6 +291,8 @@ int nthip_checksum(nthip_ctx* ctx, const uint64_t* d_vals, uint64_t n, uint64_t*
 /* device-to-device copy rate (the achievable-HBM yardstick next to the 8 TB/s spec) */
 int nthip_copy_bench(nthip_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int reps,
                      float* best_ms);
+/* write-only rate: every wave instruction stores one contiguous KiB (the ceiling of a write-bound hash stream) */
+int nthip_fill_bench(nthip_ctx* ctx, void* d_dst, size_t bytes, int reps, float* best_ms);
 
 #ifdef __cplusplus
 }

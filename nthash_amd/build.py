@@ -1,11 +1,17 @@
 """Build the nthash_amd native libraries in-tree with hipcc (gfx950 only).
 
-    python -m nthash_amd.build            # builds nthash_amd/lib/*.so
+    python -m nthash_amd.build [--force] [--tag T --flags "-DX=1 ..."]
 
-libnthash_hip.so  the C-ABI (include/nthash_hip.h): HIP kernels + launch logic
+libnthash_hip.so  the C-ABI (include/nthash_hip.h): HIP kernels + launch logic, one object per
+                  csrc/capi_*.hip, compiled in parallel and rebuilt only when a file it includes changed
 libnthash.so      the C++ host facade (include/nthash/nthash.hpp) on top of it
+
+--tag T builds a second copy of the C-ABI library with extra compiler flags for in-process A/B timing
+(nthash_amd/lib/ab/libnthash_hip_T.so; use it with NTHASH_AMD_LIB=...).
 """
+import concurrent.futures
 import os
+import shlex
 import shutil
 import subprocess
 import sys
@@ -14,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
+OBJ = os.path.join(HERE, "build")
 HIP_SO = os.path.join(LIB, "libnthash_hip.so")
 FACADE_SO = os.path.join(LIB, "libnthash.so")
 ARCH = "gfx950"
@@ -30,33 +37,67 @@ def _newer(target, sources):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
 
 
-def _sources(*names):
-    return [os.path.join(CSRC, n) for n in names]
+def _deps_of(depfile):
+    """Files named by a make-style dependency file written by -MD."""
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return None
+    text = text.replace("\\\n", " ")
+    _, _, rhs = text.partition(":")
+    return [p for p in rhs.split() if p]
+
+
+def hip_units():
+    return sorted(f for f in os.listdir(CSRC) if f.startswith("capi_") and f.endswith(".hip"))
+
+
+def _compile_unit(hipcc, unit, objdir, extra, force, verbose):
+    src = os.path.join(CSRC, unit)
+    obj = os.path.join(objdir, unit[:-4] + ".o")
+    dep = obj + ".d"
+    deps = _deps_of(dep)
+    if not force and deps is not None and not _newer(obj, deps + [src]) and all(os.path.exists(d) for d in deps):
+        return obj, False
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed",
+           f"-I{os.path.join(ROOT, 'include')}", "-MD", "-MF", dep] + list(extra) + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return obj, True
+
+
+def build_hip(out_so=HIP_SO, objdir=OBJ, extra=(), force=False, verbose=False):
+    os.makedirs(os.path.dirname(out_so), exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    units = hip_units()
+    jobs = min(len(units), max(1, (os.cpu_count() or 2)))
+    with concurrent.futures.ThreadPoolExecutor(jobs) as pool:
+        res = list(pool.map(lambda u: _compile_unit(hipcc, u, objdir, extra, force, verbose), units))
+    objs = [o for o, _ in res]
+    if any(ch for _, ch in res) or _newer(out_so, objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", out_so, "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return out_so
 
 
 def build(force=False, verbose=False):
     os.makedirs(LIB, exist_ok=True)
-    hipcc = _hipcc()
-    common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-Wno-pass-failed", f"-I{os.path.join(ROOT, 'include')}"]
-    hip_deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))] + \
-        [os.path.join(ROOT, "include", "nthash_hip.h")]
-    if force or _newer(HIP_SO, hip_deps):
-        cmd = common + [os.path.join(CSRC, "nthip_capi.hip"), "-o", HIP_SO]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+    build_hip(force=force, verbose=verbose)
     # the C++ host facade is plain host C++17 on top of the C-ABI
     facade_src = os.path.join(CSRC, "nthash_facade.cpp")
     deps = [facade_src, os.path.join(CSRC, "nt_math.hpp"), os.path.join(CSRC, "seed_parse.hpp"),
             os.path.join(ROOT, "include", "nthash", "nthash.hpp"),
             os.path.join(ROOT, "include", "nthash_hip.h"), HIP_SO]
     if force or _newer(FACADE_SO, deps):
-        cxx = shutil.which("g++") or shutil.which("c++") or hipcc
-        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+        cxx = shutil.which("g++") or shutil.which("c++") or _hipcc()
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-pthread",
                f"-I{os.path.join(ROOT, 'include')}", facade_src, "-o", FACADE_SO,
                f"-L{LIB}", "-lnthash_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
@@ -65,6 +106,18 @@ def build(force=False, verbose=False):
     return HIP_SO
 
 
+def build_variant(tag, flags, force=False, verbose=False):
+    out = os.path.join(LIB, "ab", f"libnthash_hip_{tag}.so")
+    return build_hip(out_so=out, objdir=os.path.join(OBJ, "ab_" + tag), extra=flags, force=force, verbose=verbose)
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
-    print(HIP_SO)
+    argv = sys.argv[1:]
+    force = "--force" in argv
+    if "--tag" in argv:
+        tag = argv[argv.index("--tag") + 1]
+        flags = shlex.split(argv[argv.index("--flags") + 1]) if "--flags" in argv else []
+        print(build_variant(tag, flags, force=force, verbose=True))
+    else:
+        build(force=force, verbose=True)
+        print(HIP_SO)

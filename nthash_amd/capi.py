@@ -36,7 +36,7 @@ SYMBOLS = [
     "nthip_seeds_destroy", "nthip_seed_hash", "nthip_kmer_extend", "nthip_kmer_bloom_insert",
     "nthip_kmer_bloom_query", "nthip_kmer_minhash", "nthip_stream_bloom_insert", "nthip_kmer_hash_spans", "nthip_fastx_index",
     "nthip_fastx_kmer_hash_file", "nthip_fastx_seed_hash_file", "nthip_seed_hash_spans", "nthip_fasta_compact", "nthip_synth_reads", "nthip_checksum",
-    "nthip_copy_bench",
+    "nthip_copy_bench", "nthip_fill_bench", "nthip_ctx_reload_tuning",
 ]
 
 
@@ -125,6 +125,8 @@ def load():
     L.nthip_synth_reads.argtypes = [vp, vp, u64, u64, u32, u64]
     L.nthip_checksum.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
     L.nthip_copy_bench.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
+    L.nthip_fill_bench.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
+    L.nthip_ctx_reload_tuning.argtypes = [vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("nthip_version", "nthip_last_error"):
@@ -408,6 +410,15 @@ class Context:
         ms = C.c_float(0)
         _chk(self.L.nthip_copy_bench(self.h, C.c_void_p(dst), C.c_void_p(src), nbytes, reps, C.byref(ms)))
         return ms.value
+
+    def fill_bench_ptr(self, dst, nbytes, reps=5):
+        ms = C.c_float(0)
+        _chk(self.L.nthip_fill_bench(self.h, C.c_void_p(dst), nbytes, reps, C.byref(ms)))
+        return ms.value
+
+    def reload_tuning(self):
+        """Re-read the NTHIP_TUNE_* environment knobs (they are read once, when the context is created)."""
+        _chk(self.L.nthip_ctx_reload_tuning(self.h))
 
     # -- numpy convenience (host buffers, staged by the library) ------------------
     @staticmethod

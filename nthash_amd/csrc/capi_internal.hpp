@@ -1,0 +1,327 @@
+// capi_internal.hpp -- what the translation units of libnthash_hip.so share.
+//
+// The C-ABI (include/nthash_hip.h) is implemented by one .hip file per path:
+//   capi_ctx.hip           context, error string, staging of host buffers, memory helpers, tuning knobs
+//   capi_util.hip          device scan, synthetic reads, checksums, copy / fill yardsticks, nthip_kmer_extend
+//   capi_kmer_plan.hip     per-k constants and tables, geometry plans of the run-split kernels (host only)
+//   capi_kmer.hip          nthip_kmer_hash: path selection
+//   capi_kmer_runs.hip     kmer_runs_kernel instantiations (headline shapes)
+//   capi_kmer_gen.hip      kmer_runs_gen_kernel, dense
+//   capi_kmer_na.hip       kmer_runs_gen_kernel, N-aware: count -> scan -> hash
+//   capi_kmer_ragged.hip   kmer_ragged_kernel (offsets / spans)
+//   capi_kmer_general.hip  lane-per-read kernels (correctness paths) and the row-per-read kernel
+//   capi_seed.hip          spaced seeds
+//   capi_sink_bloom.hip / capi_sink_minhash.hip   fused consumers
+//   capi_fastx.hip         FASTQ / FASTA indexing and the file streaming driver
+// Kernels live in the *_kernel(s).hpp headers; every TU instantiates only the ones it launches.
+// There is no CPU hashing path in any of them.
+#pragma once
+
+#include "../../include/nthash_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <array>
+#include <chrono>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kmer_kernels.hpp"
+#include "kmer_runs_kernel.hpp"
+#include "kmer_runs_gen_kernel.hpp"
+#include "nt_math.hpp"
+
+namespace ntamd {
+namespace host {
+
+// sets the thread-local error string returned by nthip_last_error() and returns `code`
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+} // namespace host
+} // namespace ntamd
+
+#define HIPCHK(call)                                                                                 \
+  do {                                                                                               \
+    hipError_t e_ = (call);                                                                          \
+    if (e_ != hipSuccess)                                                                            \
+      return ::ntamd::host::fail(NTHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                 __FILE__, __LINE__);                                                \
+  } while (0)
+
+#define NTCHK(call)                  \
+  do {                               \
+    int rc_ = (call);                \
+    if (rc_ != NTHIP_OK) return rc_; \
+  } while (0)
+
+// A/B knobs (NTHIP_TUNE_* environment variables), read ONCE per context at nthip_ctx_create -- not on the hot
+// calls -- and again by nthip_ctx_reload_tuning (the measurement tools change them between variants).
+struct nthip_tune {
+  uint32_t run_len = 0;     // NTHIP_TUNE_RUN_LEN: run length override (0 = the plan's choice)
+  uint32_t run_max = 0;     // NTHIP_TUNE_RUN_MAX: longest run the cost model may pick
+  uint32_t waves = 0;       // NTHIP_TUNE_WAVES: waves per block of the dense run-split kernels
+  uint32_t na_waves = 0;    // NTHIP_TUNE_NA_WAVES: ... of the N-aware pass
+  uint32_t seed_rpt = 0;    // NTHIP_TUNE_SEED_RPT: reads per tile of seed_fixed_kernel
+  uint32_t read_threads = 0; // NTHIP_TUNE_READ_THREADS: pread threads of the file driver
+  bool has_tile_map = false;
+  uint32_t tile_map = 0;    // NTHIP_TUNE_TILE_MAP
+  bool no_special = false;  // NTHIP_TUNE_NO_SPECIAL=1: general kernel on the k=31 shapes too
+  bool no_dword_tail = false; // NTHIP_TUNE_NO_DWORD_TAIL=1
+  bool no_m4 = false;       // NTHIP_TUNE_NO_M4 (set): runtime-m instantiation for m = 4
+  bool no_autotune = false; // NTHIP_TUNE_NO_AUTOTUNE (set)
+  bool no_seed_wave = false; // NTHIP_TUNE_NO_SEED_WAVE (set)
+};
+
+struct nthip_ctx {
+  int device = 0;
+  int n_cu = 0;
+  size_t lds_max = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // small device scratch: [0] dirty flag (u32), [8] total (u64), [16..32) sink totals
+  uint8_t* d_small = nullptr;
+  uint8_t* h_small = nullptr; // pinned mirror
+  // device copy of the large argument blocks of the general kernels
+  void* d_args = nullptr;
+  size_t d_args_bytes = 0;
+  // scratch for counts / scan
+  uint64_t* d_scratch = nullptr;
+  size_t d_scratch_elems = 0;
+  uint64_t* d_scratch2 = nullptr; // second area (tile-level arrays next to read-level ones)
+  size_t d_scratch2_elems = 0;
+  bool profiling = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
+  const char* last_kernel = "";
+  bool async_pending = false; // NTHIP_ASYNC launches since the last nthip_ctx_take_dirty: d_small[0] accumulates
+  nthip_tune tune;
+  // blocks per CU of (kernel, dynamic LDS) pairs already configured
+  std::map<std::pair<const void*, size_t>, int> occ_cache;
+  // all-care byte tables for the first window of a run, per k (device memory)
+  std::map<uint32_t, uint4*> init_tabs;
+  // run length of the general dense kernel per (len, stride, k, m), measured on the first big batch of that shape
+  // (the cost model does not see what a longer run costs in waves per CU or LDS conflicts: +-10 % either way)
+  std::map<std::array<uint32_t, 4>, uint32_t> run_len_cache;
+  // staging arena of the NTHIP_HOST_INPUT / NTHIP_HOST_OUTPUT calls: small host-buffer calls (the C++ facade makes
+  // one per object) carve their device copies out of it instead of paying five hipMalloc / hipFree pairs each.
+  // Grow-only up to STAGE_ARENA_MAX; calls that need more allocate as before.
+  uint8_t* stage_buf = nullptr;
+  size_t stage_cap = 0, stage_used = 0, stage_want = 0;
+  // buffers of the FASTQ / FASTA streaming driver, kept between calls (pinning and mapping half a GiB costs more
+  // than streaming a few GB through it); released by nthip_ctx_trim / nthip_ctx_destroy
+  struct FastxBuffers {
+    uint8_t* pinned[2] = {nullptr, nullptr};
+    uint8_t* d_raw[2] = {nullptr, nullptr};
+    uint64_t *d_starts = nullptr, *d_ends = nullptr, *d_counts = nullptr, *d_hashes = nullptr;
+    uint64_t pinned_bytes = 0, raw_bytes = 0, reads_cap = 0, hashes_cap = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+  } fx;
+};
+
+struct nthip_seeds {
+  nthip_ctx* ctx = nullptr;
+  uint32_t n_seeds = 0, k = 0, ntab = 0, care_words = 0;
+  bool asymmetric = false;
+  uint4* d_tables = nullptr;      // [seed][ntab][256]
+  uint32_t* d_care = nullptr;     // [seed][care_words]
+  uint32_t* d_blk_start = nullptr;
+  uint32_t* d_blk_count = nullptr;
+  uint32_t* d_blk_pairs = nullptr;
+};
+
+namespace ntamd {
+namespace host {
+
+// ---- capi_ctx.hip -------------------------------------------------------------------------------------------
+int ensure_scratch(nthip_ctx* c, size_t elems);
+int ensure_scratch2(nthip_ctx* c, size_t elems);
+int ensure_args(nthip_ctx* c, size_t bytes);
+void fastx_buffers_release(nthip_ctx* c); // the file driver's pinned / device buffers
+
+inline void prof_begin(nthip_ctx* c, const char* name)
+{
+  c->last_kernel = name;
+  if (c->profiling) {
+    (void)hipEventRecord(c->ev0, c->stream);
+    c->ev_valid = false;
+  }
+}
+inline void prof_end(nthip_ctx* c)
+{
+  if (c->profiling) {
+    (void)hipEventRecord(c->ev1, c->stream);
+    c->ev_valid = true;
+  }
+}
+
+struct Staged {
+  // device views of the caller's buffers (staged copies when host flags are set)
+  const uint8_t* seqs = nullptr;
+  const uint64_t* offsets = nullptr;
+  uint64_t* hashes = nullptr;
+  uint64_t* counts = nullptr;
+  uint32_t* pos = nullptr;
+  uint64_t* fwd = nullptr;
+  uint64_t* rev = nullptr;
+  std::vector<void*> owned;
+  ~Staged()
+  {
+    for (void* p : owned) (void)hipFree(p);
+  }
+};
+
+int stage_alloc(nthip_ctx* c, Staged& st, size_t bytes, void** p);
+int stage_inputs(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, uint64_t total_bytes, Staged& st);
+int stage_outputs(nthip_ctx* c, const nthip_out* out, uint32_t flags, uint64_t n_reads, uint32_t per, Staged& st,
+                  uint32_t strands_per = 1);
+int unstage_outputs(nthip_ctx* c, const nthip_out* out, uint32_t flags, uint64_t n_reads, uint32_t per,
+                    uint64_t total, const Staged& st, uint32_t strands_per = 1);
+// total bytes of the read buffer (needs the last offset when offsets are on the device)
+int reads_total_bytes(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, uint64_t* out);
+int check_reads(const nthip_reads* rd);
+// offsets / spans sanity on the device (non-decreasing, inside the buffer): NTHIP_ERR_ARG instead of a wild read
+int check_offsets_device(nthip_ctx* c, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
+                         uint64_t buf_bytes, bool contiguous);
+inline size_t lds_cap_of(const nthip_ctx* c) { return (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512; }
+
+// ---- capi_util.hip ------------------------------------------------------------------------------------------
+// exclusive scan of n u64 on the device: out[i] = sum(in[0..i)), *d_total = sum; d_sums: ceil(n/1024) + 16 u64
+// (in-place is allowed: d_out == d_in)
+int device_exclusive_scan(nthip_ctx* c, const uint64_t* d_in, uint64_t* d_out, uint64_t n, uint64_t* d_sums,
+                          uint64_t* d_total);
+int launch_fill_u64(nthip_ctx* c, uint64_t* d_dst, uint64_t n, uint64_t value);
+// get_pos() of reads that emit every window (flags/offsets: only the reads with flags[r] == 0, at offsets[r])
+int launch_fill_window_pos(nthip_ctx* c, uint32_t* d_pos, uint64_t n_reads, uint32_t nwin, const uint64_t* d_flags,
+                           const uint64_t* d_offsets);
+
+// ---- capi_kmer_plan.hip (host only) ---------------------------------------------------------------------------
+constexpr uint32_t KMER_TABLE_K_MAX = 64; // beyond: Horner first window
+inline uint32_t kmer_ntab(uint32_t k) { return k <= KMER_TABLE_K_MAX ? 4u * ((k + 15) / 16) : 2u; }
+inline uint32_t kmer_nw(uint32_t k) { return k <= KMER_TABLE_K_MAX ? (k + 15) / 16 : 0u; }
+
+void fill_kmer_consts(uint32_t k, uint32_t m, KmerFixedArgs& a);
+bool kmer_fixed_eligible(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m,
+                         uint32_t* pad_dwords, size_t* dyn_lds);
+void build_byte_tables(uint32_t k, const uint8_t* care, uint4* out);
+int get_init_tab(nthip_ctx* c, uint32_t k, const uint4** out);
+int get_kmer_tab(nthip_ctx* c, uint32_t k, const uint4** out);
+
+// Plan for the headline run-split kernel: run length C | nwin, waves per block, LDS bytes.
+struct RunsPlan {
+  uint32_t C = 0, rpr = 0, waves = 0, bits_dwords = 0, tile_u64 = 0, nw = 0, dword_tail = 0;
+  size_t lds = 0;
+};
+bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, RunsPlan* p);
+
+struct GenPlan {
+  uint32_t C = 0, rpr = 0, last_start = 0, waves = 0, bits_dwords = 0, tile_u64 = 0, nw = 0, dword_tail = 0;
+  size_t lds = 0;
+};
+bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, GenPlan* p,
+                   bool gaps_ok = false, uint32_t force_c = 0, uint32_t model_cap = 0, bool no_tile = false);
+
+struct NaPlan {
+  GenPlan g;
+  uint32_t vbits_dwords = 0, ptile_dwords = 0, waves = 0, tile_u64 = 0;
+  size_t lds = 0;
+};
+bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, bool want_pos,
+                  NaPlan* p, uint32_t register_sink_u64 = 0, uint32_t force_c = 0, uint32_t model_cap = 0);
+void fill_gen_args(KmerRunsGenArgs& ga, nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k,
+                   uint32_t m, const GenPlan& g, const KmerFixedArgs& consts);
+
+// ---- kernel launchers, one TU each ----------------------------------------------------------------------------
+// capi_kmer_runs.hip: the k = 31 instantiations of kmer_runs_kernel (C = 15 | nwin, or 30 for m = 1)
+int launch_kmer_runs_special(nthip_ctx* c, const KmerRunsArgs& ra, const RunsPlan& plan, bool dword_tail);
+// capi_kmer_gen.hip: kmer_runs_gen_kernel<NW, DT, false>
+int launch_kmer_gen_dense(nthip_ctx* c, const KmerRunsGenArgs& ga, size_t lds, uint32_t nw, bool dt);
+// capi_kmer_na.hip
+int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m, const NaPlan& plan,
+                const KmerFixedArgs& consts, uint64_t capacity, uint64_t* total);
+// capi_kmer_ragged.hip: reads = spans [starts[r], ends[r]) of the device buffer st.seqs (total_bytes long)
+int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
+                    uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled);
+// capi_kmer_general.hip
+int run_kmer_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m,
+                     uint64_t capacity, uint64_t* total);
+int launch_kmer_rows(nthip_ctx* c, const KmerFixedArgs& a, size_t dyn_lds);
+// capi_seed.hip
+int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd, uint32_t m2,
+                     uint64_t capacity, uint64_t* total, const uint64_t* d_ends = nullptr);
+
+// ---- templates every launching TU uses --------------------------------------------------------------------------
+template <typename K>
+int set_max_lds(K kernel, size_t bytes)
+{
+  // static + dynamic LDS beyond the 64 KiB default needs the opt-in attribute
+  if (bytes > 24 * 1024) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  }
+  return NTHIP_OK;
+}
+
+// blocks per CU for a persistent-style grid; the LDS opt-in and the occupancy
+// query are host calls worth ~1 ms, so they are cached per (kernel, LDS size)
+template <typename K>
+int blocks_per_cu(nthip_ctx* c, K kernel, int threads, size_t dyn_lds, int* out)
+{
+  const auto key = std::make_pair(reinterpret_cast<const void*>(kernel), dyn_lds);
+  auto it = c->occ_cache.find(key);
+  if (it == c->occ_cache.end()) {
+    NTCHK(set_max_lds(kernel, dyn_lds));
+    int per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, dyn_lds));
+    if (per_cu < 1) per_cu = 1;
+    it = c->occ_cache.emplace(key, per_cu).first;
+  }
+  *out = it->second;
+  return NTHIP_OK;
+}
+
+template <typename K>
+int launch_kmer_runs_gen(nthip_ctx* c, K kernel, KmerRunsGenArgs a, size_t dyn_lds, const char* label)
+{
+  int per_cu = 1;
+  NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
+  const uint64_t need = (a.n_wtiles + a.waves - 1) / a.waves;
+  uint64_t grid = (uint64_t)c->n_cu * per_cu;
+  if (grid > need) grid = need;
+  if (a.tile_map == 0xFFFFFFFFu) a.tile_map = (uint32_t)grid;
+  prof_begin(c, label);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+template <bool NA, int SINK = SINK_NONE>
+int launch_kmer_runs_gen_nw(nthip_ctx* c, const KmerRunsGenArgs& ga, size_t lds, uint32_t nw, bool dt)
+{
+  const char* label = SINK == SINK_BLOOM_INSERT  ? "kmer_runs_gen_kernel(bloom insert)"
+                      : SINK == SINK_MINHASH     ? "kmer_runs_gen_kernel(minhash)"
+                      : SINK == SINK_MINHASH1    ? "kmer_runs_gen_kernel(minhash, m = 1)"
+                      : SINK == SINK_BLOOM_QUERY ? "kmer_runs_gen_kernel(bloom query)"
+                      : NA                       ? "kmer_runs_gen_kernel(N-aware)"
+                                                 : "kmer_runs_gen_kernel";
+#define NT_GEN(NWT) \
+  (dt ? launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, true, NA, SINK>, ga, lds, label) \
+      : launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, false, NA, SINK>, ga, lds, label))
+  switch (nw) {
+    case 0: return NT_GEN(0); // any k
+    case 1: return NT_GEN(1);
+    case 2: return NT_GEN(2);
+    case 3: return NT_GEN(3);
+    default: return NT_GEN(4);
+  }
+#undef NT_GEN
+}
+
+} // namespace host
+} // namespace ntamd

@@ -1,0 +1,277 @@
+// capi_kmer_plan.hip -- per-k constants and tables, geometry plans of the run-split kernels (host code only)
+// Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
+#include "capi_internal.hpp"
+
+using namespace ntamd;
+using namespace ntamd::host;
+
+namespace ntamd {
+namespace host {
+
+void fill_kmer_consts(uint32_t k, uint32_t m, KmerFixedArgs& a)
+{
+  // (in,out) pair terms of the roll (src/kmer.cpp:84-94, 164-174):
+  //   F' = srol(F) ^ S[in] ^ srol^k(S[out]);  R' = sror(R ^ srol^k(S[~in]) ^ S[~out])
+  for (unsigned in = 0; in < 4; ++in)
+    for (unsigned o = 0; o < 4; ++o) {
+      a.tab[(in << 2) | o][0] = seed_of_code(in) ^ srol_n(seed_of_code(o), k);
+      a.tab[(in << 2) | o][1] = srol_n(seed_of_code(in ^ 2u), k) ^ seed_of_code(o ^ 2u);
+    }
+  // strand hashes of a window of k 'A's: the state before the first real base
+  uint64_t f = 0, r = 0;
+  for (uint32_t i = 0; i < k; ++i) {
+    f = srol1(f) ^ SEED_A;
+    r = srol1(r) ^ SEED_T; // all terms equal, so the order of rotation does not matter
+  }
+  a.f_init = f;
+  a.r_init = r;
+  for (uint32_t i = 0; i < (uint32_t)KF_MAX_RUNTIME_M; ++i) a.mult[i] = multiplier(k, i);
+  (void)m;
+}
+
+// Can the fixed-length kernel take this batch?  Returns the dynamic LDS size.
+bool kmer_fixed_eligible(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m,
+                         uint32_t* pad_dwords, size_t* dyn_lds)
+{
+  if (len < k || m > (uint32_t)KF_MAX_RUNTIME_M) return false;
+  if (stride > len) return false; // gaps between reads: general path
+  const uint32_t pad = (k + 15u) / 16u + 1u;
+  const uint64_t slab = 15ull + (uint64_t)(KF_RUNS_PER_BLOCK - 1) * stride + len;
+  const uint64_t n_vec = (slab + 15u) >> 4;
+  const uint64_t dwords = pad + n_vec + 2;
+  const size_t bytes = dwords * 4;
+  const size_t static_lds = 4 * KF_TILE_U64 * 8 + 256;
+  if (bytes + static_lds > c->lds_max || bytes + static_lds > 160 * 1024) return false;
+  *pad_dwords = pad;
+  *dyn_lds = bytes;
+  return true;
+}
+
+// byte tables: entry [jt][byte] = XOR over the byte's 4 bases of the rotated seeds
+// of window positions 4jt..4jt+3 (care[p] == 0 drops position p), both strands
+void build_byte_tables(uint32_t k, const uint8_t* care, uint4* out)
+{
+  const uint32_t ntab = (k + 3) / 4;
+  for (uint32_t jt = 0; jt < ntab; ++jt)
+    for (uint32_t byte = 0; byte < 256; ++byte) {
+      uint64_t f = 0, r = 0;
+      for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t p = 4 * jt + q;
+        if (p >= k || (care && !care[p])) continue;
+        const uint32_t code = (byte >> (2 * q)) & 3u;
+        f ^= srol_n(seed_of_code(code), k - 1 - p);
+        r ^= srol_n(seed_of_code(code ^ 2u), p);
+      }
+      out[(size_t)jt * 256 + byte] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+    }
+}
+
+int get_init_tab(nthip_ctx* c, uint32_t k, const uint4** out)
+{
+  auto it = c->init_tabs.find(k);
+  if (it == c->init_tabs.end()) {
+    const uint32_t ntab = 4u * ((k + 15) / 16); // zero tables past ceil(k/4)
+    std::vector<uint4> h((size_t)ntab * 256, make_uint4(0, 0, 0, 0));
+    build_byte_tables(k, nullptr, h.data());
+    uint4* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, h.size() * sizeof(uint4)));
+    HIPCHK(hipMemcpy(d, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    it = c->init_tabs.emplace(k, d).first;
+  }
+  *out = it->second;
+  return NTHIP_OK;
+}
+
+// k > 64: the run-split kernels hash a run's first window by Horner with ONE k-independent byte table
+// (a 4-mer's) plus a 1-mer's for the k % 4 leftover bases -- [0..255] and [256..511] of the same array
+int get_kmer_tab(nthip_ctx* c, uint32_t k, const uint4** out)
+{
+  if (k <= KMER_TABLE_K_MAX) return get_init_tab(c, k, out);
+  const uint32_t key = 0xFFFF0004u;
+  auto it = c->init_tabs.find(key);
+  if (it == c->init_tabs.end()) {
+    std::vector<uint4> h(512);
+    build_byte_tables(4, nullptr, h.data());
+    build_byte_tables(1, nullptr, h.data() + 256);
+    uint4* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, h.size() * sizeof(uint4)));
+    HIPCHK(hipMemcpy(d, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    it = c->init_tabs.emplace(key, d).first;
+  }
+  *out = it->second;
+  return NTHIP_OK;
+}
+// byte tables a kernel instantiated for NW = ceil(k/16) window words looks up: 4 per word, the ones past
+// ceil(k/4) all zero (so that no lookup needs a branch); k > 64: the two Horner tables
+
+bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, RunsPlan* p)
+{
+  if (len < k || k > 64 || m > (uint32_t)KF_MAX_RUNTIME_M || stride > len || stride == 0) return false;
+  const uint32_t nwin = len - k + 1;
+  uint32_t best = 0;
+  for (uint32_t d = 16; d >= 4; --d)
+    if (nwin % d == 0) { best = d; break; }
+  if (best < 6)
+    for (uint32_t d = 17; d <= 64; ++d) // e.g. a prime window count: the whole read is one run
+      if (nwin % d == 0) { best = d; break; }
+  // NTHIP_TUNE_RUN_LEN: A/B override of the run length (must divide the window count)
+  if (const uint32_t d = c->tune.run_len) // A/B override of the run length (must divide the window count)
+    if (d >= 2 && d <= 64 && nwin % d == 0) best = d;
+  if (best == 0) return false;
+  p->C = best;
+  p->rpr = nwin / best;
+  p->nw = (k + 15) / 16;
+  p->tile_u64 = 64 * best;
+  // reads touched by one wave tile (64 consecutive runs)
+  const uint32_t slab_reads = (64 % p->rpr == 0) ? 64 / p->rpr : (p->rpr - 1 + 63) / p->rpr + 1;
+  const uint64_t slab_bytes = (uint64_t)(slab_reads - 1) * stride + len;
+  uint32_t bd = (uint32_t)((15 + slab_bytes + 15) >> 4) + p->nw + 4;
+  bd = (bd + 3u) & ~3u;
+  p->bits_dwords = bd;
+  p->dword_tail = (15 + slab_bytes <= 1280) ? 1u : 0u;
+  const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
+  const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4;
+  const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
+  // 8 waves per CU measured 1.5-2 % faster than 16 on the HBM-bound C2 shape; with m > 1 the copy-out does the
+  // multi-hash expansion and more waves hide it: 16 waves +6 % (m=4), +9 % (m=8)  (profiles/r01_notes.md)
+  uint32_t w_max = m == 1 ? 8 : 16;
+  if (c->tune.waves) w_max = c->tune.waves;
+  for (uint32_t w = w_max; w >= 1; --w) {
+    if (fixed + per_wave * w <= cap) {
+      p->waves = w;
+      p->lds = fixed + per_wave * w;
+      return true;
+    }
+  }
+  return false;
+}
+
+// Geometry of the general run-split kernel (kmer_runs_gen_kernel.hpp): any window count.
+// The run length minimises lane work per k-mer: one first-window evaluation (about
+// 2 + ntab/2 roll steps' worth) plus C-1 rolls per run, the windows a read's last run recomputes included.
+// gaps_ok: rows may be padded (stride > len).  The padding travels through the slab like any other byte, so
+// the dense pass -- which flags every non-base it stages -- does not take such batches; the N-aware passes do
+// (no window reaches into the padding).
+// force_c: run length to use (0: the model's choice); model_cap: longest run the model may pick (0: its default)
+// no_tile: a consumer that keeps the hashes in registers (MinHash) -- a longer run then costs neither LDS nor
+// bank conflicts, only fewer first windows: the model may go to 31 (measured: 150 bp m=1 798 -> 853-868 G k-mers/s,
+// m=2 +16 %, m=4 +12 %)
+bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, GenPlan* p,
+                   bool gaps_ok, uint32_t force_c, uint32_t model_cap, bool no_tile)
+{
+  if (len < k || m == 0 || (stride > len && !gaps_ok) || len >= (1u << 30) || stride >= (1u << 30)) return false;
+  const uint32_t nwin = len - k + 1;
+  if (stride < nwin) return false; // reads overlapping by more than k-1 bases: other paths
+  const uint32_t ntab = (k + 3) / 4; // first-window cost in the model (table lookups or Horner steps)
+  uint32_t best = 0;
+  double best_cost = 1e30;
+  // The kernels take runs of up to 31 windows (the window masks of the N-aware pass are 32 bits wide), but the
+  // model stops at 16: it does not see what a larger tile costs in waves per CU.  In-process A/B over 24 shapes
+  // (profiles/r01_notes.md): longer runs win 3-8 % where they cut the runs per read sharply (100 bp/k64: 13 -> 19,
+  // 1 kb reads, k <= 15) and lose 5-28 % elsewhere (k = 63/64 at 150 bp: -27 %).
+  uint32_t c_cap = model_cap ? model_cap : no_tile ? 31 : 16;
+  if (c->tune.run_max) c_cap = c->tune.run_max; // A/B knob: longest run the model may pick
+  const uint32_t c_hi = nwin < c_cap ? nwin : c_cap;
+  for (uint32_t C = c_hi; C >= 1; --C) {
+    const uint32_t rpr = (nwin + C - 1) / C;
+    // the 64 rows of a tile are C*8 bytes apart: an even C puts several lanes of a ds_write_b64 on the
+    // same LDS banks (16-way for C = 16), an odd C none.  Measured: 2-way is nearly free (C = 18 on 101 bp
+    // +7 % over C = 15), 4-way is not (C = 20 on 50 bp -12 % against two runs of 10)
+    uint32_t g = 2 * C, ways = 1;
+    while (ways < 32 && (g & 1) == 0) { g >>= 1; ways <<= 1; }
+    ways = ways > 2 ? ways / 2 : 1;
+    const double conflict = no_tile || ways <= 1 ? 0.0 : ways == 2 ? 0.05 : ways == 4 ? 0.45 : 1.0;
+    const double cost = (double)rpr * (2.0 + 0.5 * ntab + (C - 1) * (1.0 + conflict)) / nwin;
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = C; }
+  }
+  if (force_c >= 1 && force_c <= 31 && force_c <= nwin) best = force_c;
+  if (const uint32_t d = c->tune.run_len) // A/B override
+    if (d >= 1 && d <= 31 && d <= nwin) best = d; // (the model itself stays at <= 16)
+  if (best == 0) return false;
+  p->C = best;
+  p->rpr = (nwin + best - 1) / best;
+  p->last_start = nwin - best;
+  p->nw = kmer_nw(k);
+  p->tile_u64 = 64 * best + 128;
+  // longest slab: 63 run-to-run steps of at most C bases, C + stride - nwin across a read boundary, plus
+  // the last run
+  const uint64_t crossings = (63 + p->rpr - 1) / p->rpr;
+  const uint64_t slab_bytes = 64ull * best + k - 1 + crossings * (uint64_t)(stride - nwin);
+  uint32_t bd = (uint32_t)((15 + slab_bytes + 15) >> 4) + p->nw + 6;
+  bd = (bd + 3u) & ~3u;
+  p->bits_dwords = bd;
+  p->dword_tail = (15 + slab_bytes <= 1280) ? 1u : 0u;
+  const size_t fixed = (size_t)kmer_ntab(k) * 4096 + 256 + 64;
+  const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4;
+  const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
+  uint32_t w_max = m == 1 ? 8 : 16;
+  if (c->tune.waves) w_max = c->tune.waves;
+  for (uint32_t w = w_max; w >= 1; --w)
+    if (fixed + per_wave * w <= cap) {
+      p->waves = w;
+      p->lds = fixed + per_wave * w;
+      return true;
+    }
+  return false;
+}
+
+// N-aware run-split path for fixed-length reads: count pass -> scan -> compact hash pass
+// (kmer_runs_gen_kernel.hpp, NA = true).  Same geometry as the dense general kernel.
+bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, bool want_pos,
+                  NaPlan* p, uint32_t register_sink_u64, uint32_t force_c, uint32_t model_cap)
+{
+  if (!kmer_gen_plan(c, len, stride, k, m, &p->g, /*gaps_ok*/ true, force_c, model_cap, register_sink_u64 != 0))
+    return false;
+  const GenPlan& g = p->g;
+  p->tile_u64 = 64 * g.C + KRG_ALIGN_U64 + KRG_SLACK_U64;
+  // a consumer that keeps the hashes in registers (MinHash) needs no tile, only its fold area
+  if (register_sink_u64) p->tile_u64 = (register_sink_u64 + 1u) & ~1u;
+  p->ptile_dwords = want_pos ? (64 * g.C + KRG_SLACK_U64 + 3u) & ~3u : 0u;
+  p->vbits_dwords = (g.bits_dwords / 2 + 8 + 3u) & ~3u; // 16 validity bits per 32 stream bits, read 4 dwords ahead
+  const size_t fixed = (size_t)kmer_ntab(k) * 4096 + 256 + 64;
+  const size_t per_wave = (size_t)p->tile_u64 * 8 + ((size_t)p->ptile_dwords + g.bits_dwords + p->vbits_dwords) * 4;
+  const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
+  uint32_t w_max = register_sink_u64 ? 16 : 8;
+  if (c->tune.na_waves) w_max = c->tune.na_waves;
+  for (uint32_t w = w_max; w >= 1; --w)
+    if (fixed + per_wave * w <= cap) {
+      p->waves = w;
+      p->lds = fixed + per_wave * w;
+      return true;
+    }
+  return false;
+}
+
+void fill_gen_args(KmerRunsGenArgs& ga, nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k,
+                   uint32_t m, const GenPlan& g, const KmerFixedArgs& consts)
+{
+  memset(&ga, 0, sizeof ga);
+  const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
+  ga.seqs = st.seqs;
+  ga.hashes = st.hashes;
+  ga.dirty = (uint32_t*)c->d_small;
+  ga.n_reads = rd->n_reads;
+  ga.n_runs = rd->n_reads * g.rpr;
+  ga.n_wtiles = (ga.n_runs + 63) / 64;
+  ga.total_bytes = (rd->n_reads - 1) * (uint64_t)stride + len;
+  ga.len = len;
+  ga.stride = stride;
+  ga.k = k;
+  ga.m = m;
+  ga.nwin = len - k + 1;
+  ga.C = g.C;
+  ga.rpr = g.rpr;
+  ga.last_start = g.last_start;
+  ga.last_dup = g.rpr * g.C - ga.nwin;
+  ga.ntab = kmer_ntab(k);
+  ga.waves = g.waves;
+  ga.bits_dwords = g.bits_dwords;
+  ga.tile_u64 = g.tile_u64;
+  ga.inv_rpr = 65536u / g.rpr + 1u;
+  ga.tile_map = c->tune.has_tile_map ? c->tune.tile_map : 0xFFFFFFFFu;
+  memcpy(ga.tab, consts.tab, sizeof ga.tab);
+  memcpy(ga.mult, consts.mult, sizeof ga.mult);
+}
+
+} // namespace host
+} // namespace ntamd

@@ -1,0 +1,448 @@
+// capi_seed.hip -- spaced seeds: nthip_seeds_*, nthip_seed_hash
+// Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
+#include "capi_internal.hpp"
+#include "seed_kernels.hpp"
+#include "seed_parse.hpp"
+#include "util_kernels.hpp"
+
+using namespace ntamd;
+using namespace ntamd::host;
+
+extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32_t n_seeds, uint16_t k16,
+                                  nthip_seeds** out, int* asymmetric)
+{
+  if (!c || !out) return fail(NTHIP_ERR_ARG, "ctx/out is NULL");
+  *out = nullptr;
+  if (!seeds || n_seeds == 0) return fail(NTHIP_ERR_ARG, "no seeds given");
+  const uint32_t k = k16;
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
+  HIPCHK(hipSetDevice(c->device));
+  // byte tables per seed: 4 per 16-base window word for k <= 64 (zero past ceil(k/4): the kernels look all of them up)
+  const uint32_t ntab = k <= 64 ? 4u * ((k + 15) / 16) : (k + 3) / 4, cw = (k + 31) / 32;
+  std::vector<uint4> tables((size_t)n_seeds * ntab * 256, make_uint4(0, 0, 0, 0));
+  std::vector<uint32_t> care((size_t)n_seeds * cw, 0), blk_start(n_seeds), blk_count(n_seeds), blk_pairs;
+  bool asym = false;
+  for (uint32_t s = 0; s < n_seeds; ++s) {
+    if (!seeds[s]) return fail(NTHIP_ERR_ARG, "seed %u is NULL", s);
+    const std::string str(seeds[s]);
+    if (str.size() != k) // src/seed.cpp:90-95
+      return fail(NTHIP_ERR_ARG, "Spaced seed string length (%zu) not equal to k=%u in %s", str.size(), k,
+                  str.c_str());
+    if (!seed_is_symmetric(str)) asym = true; // src/seed.cpp:96-102
+    const SeedShape shape = parse_seed_shape(str);
+    const std::vector<uint32_t>& pairs = shape.block_pairs;
+    const std::vector<uint8_t>& par = shape.care;
+    blk_start[s] = (uint32_t)(blk_pairs.size() / 2);
+    blk_count[s] = (uint32_t)(pairs.size() / 2);
+    blk_pairs.insert(blk_pairs.end(), pairs.begin(), pairs.end());
+    for (uint32_t p = 0; p < k; ++p)
+      if (par[p]) care[(size_t)s * cw + (p >> 5)] |= 1u << (p & 31);
+    // byte tables: entry = XOR over the byte's 4 bases of the masked rotated seeds
+    build_byte_tables(k, par.data(), tables.data() + (size_t)s * ntab * 256);
+  }
+  if (blk_pairs.empty()) blk_pairs.push_back(0);
+  nthip_seeds* sd = new nthip_seeds();
+  sd->ctx = c;
+  sd->n_seeds = n_seeds;
+  sd->k = k;
+  sd->ntab = ntab;
+  sd->care_words = cw;
+  sd->asymmetric = asym;
+  auto up = [&](const void* src, size_t bytes, void** dst) -> int {
+    HIPCHK(hipMalloc(dst, bytes));
+    HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return NTHIP_OK;
+  };
+  int rc = up(tables.data(), tables.size() * sizeof(uint4), (void**)&sd->d_tables);
+  if (rc == NTHIP_OK) rc = up(care.data(), care.size() * 4, (void**)&sd->d_care);
+  if (rc == NTHIP_OK) rc = up(blk_start.data(), blk_start.size() * 4, (void**)&sd->d_blk_start);
+  if (rc == NTHIP_OK) rc = up(blk_count.data(), blk_count.size() * 4, (void**)&sd->d_blk_count);
+  if (rc == NTHIP_OK) rc = up(blk_pairs.data(), blk_pairs.size() * 4, (void**)&sd->d_blk_pairs);
+  if (rc != NTHIP_OK) {
+    nthip_seeds_destroy(sd);
+    return rc;
+  }
+  if (asymmetric) *asymmetric = asym ? 1 : 0;
+  *out = sd;
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_seeds_destroy(nthip_seeds* sd)
+{
+  if (!sd) return NTHIP_OK;
+  if (sd->ctx) (void)hipSetDevice(sd->ctx->device);
+  if (sd->d_tables) (void)hipFree(sd->d_tables);
+  if (sd->d_care) (void)hipFree(sd->d_care);
+  if (sd->d_blk_start) (void)hipFree(sd->d_blk_start);
+  if (sd->d_blk_count) (void)hipFree(sd->d_blk_count);
+  if (sd->d_blk_pairs) (void)hipFree(sd->d_blk_pairs);
+  delete sd;
+  return NTHIP_OK;
+}
+
+namespace {
+
+// seed_wave_kernel (one wave per read, staged in segments of SEED_WAVE_LMAX bytes): k <= 64, no strand outputs.
+constexpr uint32_t SEED_WAVE_LMAX = 2048;
+struct SeedWavePlan {
+  uint32_t nw = 0, waves_count = 0, waves_hash = 0;
+  size_t lds_count = 0, lds_hash = 0;
+};
+bool seed_wave_plan(const nthip_ctx* c, const nthip_seeds* sd, uint32_t m2, SeedWavePlan* p)
+{
+  if (sd->k + 64u > SEED_WAVE_LMAX || sd->k < 2) return false; // a segment must hold some windows
+  const uint32_t per = sd->n_seeds * m2, lmax = SEED_WAVE_LMAX;
+  const uint32_t raw_dw = (lmax + 64u) >> 2, code_dw = (lmax >> 4) + 8u, bit_dw = (lmax >> 5) + 8u;
+  const size_t pw_count = (size_t)((raw_dw + code_dw + 2u * bit_dw + 3u) & ~3u) * 4;
+  const size_t pw_hash = (size_t)((raw_dw + code_dw + 2u * bit_dw + 64u * per * 2u + 3u) & ~3u) * 4;
+  const size_t tables = sd->k <= 64 ? (size_t)sd->n_seeds * sd->ntab * 256 * sizeof(uint4) : 0; // k > 64: Horner, no tables
+  const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
+  p->nw = sd->k <= 64 ? (sd->k + 15) / 16 : 0;
+  for (uint32_t w = 16; w >= 1; --w)
+    if (pw_count * w <= cap) { p->waves_count = w; p->lds_count = pw_count * w; break; }
+  for (uint32_t w = 16; w >= 2; --w)
+    if (tables + pw_hash * w <= cap) { p->waves_hash = w; p->lds_hash = tables + pw_hash * w; break; }
+  return p->waves_count && p->waves_hash;
+}
+template <bool COUNT_ONLY>
+int launch_seed_wave(nthip_ctx* c, const SeedWavePlan& plan, uint64_t n_items, bool record = true)
+{
+  const uint32_t waves = COUNT_ONLY ? plan.waves_count : plan.waves_hash;
+  const size_t lds = COUNT_ONLY ? plan.lds_count : plan.lds_hash;
+  auto go = [&](auto kernel) -> int {
+    int per_cu = 1;
+    NTCHK(blocks_per_cu(c, kernel, (int)waves * 64, lds, &per_cu));
+    const uint64_t need = (n_items + waves - 1) / waves;
+    uint64_t grid = (uint64_t)c->n_cu * per_cu;
+    if (grid > need) grid = need;
+    if (!COUNT_ONLY && record) prof_begin(c, "seed_wave_kernel");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream,
+                       (const SeedGeneralArgs*)c->d_args);
+    if (!COUNT_ONLY && record) prof_end(c);
+    HIPCHK(hipGetLastError());
+    return NTHIP_OK;
+  };
+  switch (plan.nw) {
+    case 0: return go(seed_wave_kernel<COUNT_ONLY, 0>); // k > 64
+    case 1: return go(seed_wave_kernel<COUNT_ONLY, 1>);
+    case 2: return go(seed_wave_kernel<COUNT_ONLY, 2>);
+    case 3: return go(seed_wave_kernel<COUNT_ONLY, 3>);
+    default: return go(seed_wave_kernel<COUNT_ONLY, 4>);
+  }
+}
+
+} // namespace
+
+int ntamd::host::run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd,
+                     uint32_t m2, uint64_t capacity, uint64_t* total, const uint64_t* d_ends)
+{
+  const uint64_t n = rd->n_reads;
+  SeedGeneralArgs h;
+  memset(&h, 0, sizeof h);
+  h.seqs = st.seqs;
+  h.offsets = st.offsets;
+  h.ends = d_ends; // spans: st.offsets holds the starts
+  h.n_reads = n;
+  h.len = rd->fixed_len;
+  h.stride = rd->stride ? rd->stride : rd->fixed_len;
+  h.k = sd->k;
+  h.m2 = m2;
+  h.n_seeds = sd->n_seeds;
+  h.care_words = sd->care_words;
+  h.care_bits = sd->d_care;
+  h.blk_start = sd->d_blk_start;
+  h.blk_count = sd->d_blk_count;
+  h.blk_pairs = sd->d_blk_pairs;
+  h.tables = sd->d_tables;
+  h.ntab = sd->ntab;
+  for (uint32_t i = 0; i < 256; ++i) h.mult[i] = multiplier(sd->k, i);
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  NTCHK(ensure_scratch(c, 2 * n + nb + 16));
+  uint64_t* d_counts = st.counts ? st.counts : c->d_scratch;
+  uint64_t* d_off = c->d_scratch + n;
+  uint64_t* d_sums = c->d_scratch + 2 * n;
+  uint64_t* d_total = (uint64_t*)(c->d_small + 8);
+  NTCHK(ensure_args(c, sizeof(SeedGeneralArgs)));
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  // one wave per read (seed_wave_kernel), k <= 64; the lane-per-read kernel otherwise
+  SeedWavePlan wplan;
+  bool use_wave = !c->tune.no_seed_wave && seed_wave_plan(c, sd, m2, &wplan);
+  h.wave_lmax = SEED_WAVE_LMAX;
+  h.counts = d_counts;
+  if (use_wave) {
+    h.wave_waves = wplan.waves_count;
+    HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    NTCHK(launch_seed_wave<true>(c, wplan, n));
+  } else {
+    HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(seed_general_kernel<true>, dim3(blocks), dim3(256), 0, c->stream,
+                       (const SeedGeneralArgs*)c->d_args);
+    HIPCHK(hipGetLastError());
+  }
+  NTCHK(device_exclusive_scan(c, d_counts, d_off, n, d_sums, d_total));
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(total, c->h_small + 8, 8);
+  if (*total > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
+                (unsigned long long)capacity, (unsigned long long)*total);
+  h.counts = nullptr;
+  h.read_off = d_off;
+  h.hashes = st.hashes;
+  h.pos = st.pos;
+  h.fwd = st.fwd;
+  h.rev = st.rev;
+  h.capacity = capacity;
+  if (use_wave) {
+    h.wave_waves = wplan.waves_hash;
+    HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    NTCHK(launch_seed_wave<false>(c, wplan, n));
+  } else {
+    HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    prof_begin(c, "seed_general_kernel");
+    hipLaunchKernelGGL(seed_general_kernel<false>, dim3(blocks), dim3(256), 0, c->stream,
+                       (const SeedGeneralArgs*)c->d_args);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+namespace {
+
+template <typename K>
+int launch_seed_fixed(nthip_ctx* c, K kernel, const SeedFixedArgs& a, size_t dyn_lds)
+{
+  int per_cu = 1;
+  NTCHK(blocks_per_cu(c, kernel, SF_THREADS, dyn_lds, &per_cu));
+  uint64_t grid = (uint64_t)c->n_cu * per_cu;
+  if (grid > a.n_tiles) grid = a.n_tiles;
+  prof_begin(c, "seed_fixed_kernel");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(SF_THREADS), dyn_lds, c->stream, a);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+} // namespace
+
+extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, uint8_t m28,
+                               const nthip_out* out, uint64_t* total_out, uint32_t flags)
+{
+  if (!c || !sd) return fail(NTHIP_ERR_ARG, "ctx/seeds is NULL");
+  NTCHK(check_reads(rd));
+  if (!out || !out->hashes) return fail(NTHIP_ERR_ARG, "out->hashes is NULL");
+  const uint32_t m2 = m28, k = sd->k;
+  if (m2 == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes_per_seed must be >= 1");
+  if (c->async_pending) return fail(NTHIP_ERR_ARG, "NTHIP_ASYNC batches are pending: call nthip_ctx_take_dirty first");
+  HIPCHK(hipSetDevice(c->device));
+  uint64_t total = 0;
+  if (total_out) *total_out = 0;
+  if (rd->n_reads == 0) return NTHIP_OK;
+  const uint32_t per = sd->n_seeds * m2;
+
+  uint64_t total_bytes = 0;
+  NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
+  Staged st;
+  NTCHK(stage_inputs(c, rd, flags, total_bytes, st));
+  NTCHK(stage_outputs(c, out, flags, rd->n_reads, per, st, sd->n_seeds));
+
+  const uint32_t len = rd->fixed_len;
+  const uint32_t stride = rd->stride ? rd->stride : len;
+  bool done = false;
+  if (!rd->offsets && len < k) {
+    if (st.counts) {
+      hipLaunchKernelGGL(fill_u64_kernel, dim3(1024), dim3(256), 0, c->stream, st.counts, rd->n_reads, 0ull);
+      HIPCHK(hipGetLastError());
+    }
+    done = true;
+  } else if (!rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.fwd && !st.rev && m2 <= (uint32_t)SF_MAX_RUNTIME_M &&
+             k <= 64 && stride <= len) {
+    const uint32_t nwin = len - k + 1;
+    const uint32_t nh = (k + 7) / 8; // 16-bit halves of the window; 2*nh byte tables per seed in LDS (zero-padded)
+    const size_t table_bytes = (size_t)sd->n_seeds * 2 * nh * 256 * sizeof(uint4);
+    // tile = as many runs as give a ~8 KiB bit stream (32 Ki bases), at most 256
+    uint32_t rpt = 32768u / stride;
+    if (rpt > 256) rpt = 256;
+    if (rpt < 1) rpt = 1;
+    {
+      // a tile's records are one contiguous piece of the stream: make every tile start on a KiB of it (or the
+      // largest power of two below that the read count allows), so that no store splits lines with another block's
+      const uint64_t tile_unit = (uint64_t)nwin * per * 8;
+      uint32_t mult_of = 1;
+      while (mult_of < 128 && ((tile_unit * mult_of) & 1023u) != 0) mult_of <<= 1;
+      while (mult_of > 1 && mult_of > rpt) mult_of >>= 1;
+      rpt -= rpt % mult_of;
+      if (c->tune.seed_rpt) rpt = c->tune.seed_rpt; // A/B override
+    }
+    const uint64_t slab = 15ull + (uint64_t)(rpt - 1) * stride + len;
+    const uint32_t bits_dwords = (uint32_t)((((slab + 15) >> 4) + 8 + 3) & ~3ull);
+    const size_t dyn = table_bytes + (size_t)bits_dwords * 4 + (size_t)(SF_THREADS / 64) * (64 * per + 2) * 8;
+    const uint64_t dense = rd->n_reads * (uint64_t)nwin;
+    if (dyn <= 158 * 1024 && dyn <= c->lds_max && (uint64_t)rpt * nwin < 0x7FFFFFFFull) {
+      if (dense > out->capacity) {
+        if (total_out) *total_out = dense;
+        return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
+                    (unsigned long long)out->capacity, (unsigned long long)dense);
+      }
+      SeedFixedArgs a;
+      memset(&a, 0, sizeof a);
+      a.seqs = st.seqs;
+      a.hashes = st.hashes;
+      a.dirty = (uint32_t*)c->d_small;
+      a.tables = sd->d_tables;
+      a.n_runs = rd->n_reads;
+      a.len = len;
+      a.stride = stride;
+      a.k = k;
+      a.m2 = m2;
+      a.n_seeds = sd->n_seeds;
+      a.ntab = sd->ntab;
+      a.nwin = nwin;
+      a.runs_per_tile = rpt;
+      const uint64_t n_tiles = (rd->n_reads + rpt - 1) / rpt;
+      if (n_tiles > 0xFFFFFFFFull) return fail(NTHIP_ERR_UNSUPPORTED, "too many reads for one call");
+      a.n_tiles = (uint32_t)n_tiles;
+      a.inv_nwin = (uint32_t)((1ull << 32) / nwin + 1);
+      a.bits_dwords = bits_dwords;
+      for (uint32_t i = 0; i < (uint32_t)SF_MAX_RUNTIME_M; ++i) a.mult[i] = multiplier(k, i);
+      HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream));
+      int rc;
+#define NT_SEED_FIXED(SPLIT_T, DYN) \
+  (nh == 1   ? launch_seed_fixed(c, seed_fixed_kernel<1, SPLIT_T>, a, DYN) \
+   : nh == 2 ? launch_seed_fixed(c, seed_fixed_kernel<2, SPLIT_T>, a, DYN) \
+   : nh == 3 ? launch_seed_fixed(c, seed_fixed_kernel<3, SPLIT_T>, a, DYN) \
+   : nh == 4 ? launch_seed_fixed(c, seed_fixed_kernel<4, SPLIT_T>, a, DYN) \
+   : nh == 5 ? launch_seed_fixed(c, seed_fixed_kernel<5, SPLIT_T>, a, DYN) \
+   : nh == 6 ? launch_seed_fixed(c, seed_fixed_kernel<6, SPLIT_T>, a, DYN) \
+   : nh == 7 ? launch_seed_fixed(c, seed_fixed_kernel<7, SPLIT_T>, a, DYN) \
+             : launch_seed_fixed(c, seed_fixed_kernel<8, SPLIT_T>, a, DYN))
+      rc = NT_SEED_FIXED(false, dyn);
+      NTCHK(rc);
+      HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      uint32_t dirty = 0;
+      memcpy(&dirty, c->h_small, 4);
+      if (!dirty) {
+        total = dense;
+        if (st.counts) {
+          hipLaunchKernelGGL(fill_u64_kernel, dim3(1024), dim3(256), 0, c->stream, st.counts, rd->n_reads,
+                             (uint64_t)nwin);
+          HIPCHK(hipGetLastError());
+        }
+        if (st.pos) { // every read emits every window: get_pos() is the window index
+          hipLaunchKernelGGL(fill_window_pos_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, st.pos, rd->n_reads, nwin,
+                             (const uint64_t*)nullptr, (const uint64_t*)nullptr);
+          HIPCHK(hipGetLastError());
+        }
+        done = true;
+      } else if (dyn + (size_t)rpt * 8 <= 158 * 1024 && dyn + (size_t)rpt * 8 <= c->lds_max) {
+        // Batch with non-bases.  SeedNtHash's position state machine (App. B Q3) only matters for the reads
+        // that HAVE a non-base: those (usually a fraction of a percent) go through seed_general_kernel, every
+        // other read emits all its windows and stays on the fast kernel, writing at its place in the compact
+        // stream (per-read counts -> scan -> offsets).
+        const uint64_t n = rd->n_reads;
+        const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+        NTCHK(ensure_scratch(c, 5 * n + nb + 16));
+        uint64_t* d_flags = c->d_scratch;
+        uint64_t* d_idx = c->d_scratch + n;
+        uint64_t* d_list = c->d_scratch + 2 * n;
+        uint64_t* d_cnt = st.counts ? st.counts : c->d_scratch + 3 * n;
+        uint64_t* d_roff = c->d_scratch + 4 * n;
+        uint64_t* d_sums = c->d_scratch + 5 * n;
+        uint64_t* d_total = (uint64_t*)(c->d_small + 8);
+        const unsigned rblocks = (unsigned)((n + 255) / 256);
+        HIPCHK(hipMemsetAsync(d_flags, 0, n * sizeof(uint64_t), c->stream));
+        hipLaunchKernelGGL(seed_mark_dirty_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, st.seqs, total_bytes, len,
+                           stride, n, d_flags);
+        NTCHK(device_exclusive_scan(c, d_flags, d_idx, n, d_sums, d_total));
+        HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+        hipLaunchKernelGGL(seed_list_kernel, dim3(rblocks), dim3(256), 0, c->stream, d_flags, d_idx, n, d_list);
+        hipLaunchKernelGGL(fill_u64_kernel, dim3(1024), dim3(256), 0, c->stream, d_cnt, n, (uint64_t)nwin);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        uint64_t n_dirty = 0;
+        memcpy(&n_dirty, c->h_small + 8, 8);
+        SeedGeneralArgs h;
+        memset(&h, 0, sizeof h);
+        h.seqs = st.seqs;
+        h.read_list = d_list;
+        h.n_reads = n_dirty;
+        h.len = len;
+        h.stride = stride;
+        h.k = k;
+        h.m2 = m2;
+        h.n_seeds = sd->n_seeds;
+        h.care_words = sd->care_words;
+        h.care_bits = sd->d_care;
+        h.blk_start = sd->d_blk_start;
+        h.blk_count = sd->d_blk_count;
+        h.blk_pairs = sd->d_blk_pairs;
+        h.tables = sd->d_tables;
+        h.ntab = sd->ntab;
+        for (uint32_t i = 0; i < 256; ++i) h.mult[i] = multiplier(k, i);
+        NTCHK(ensure_args(c, sizeof(SeedGeneralArgs)));
+        const unsigned lblocks = (unsigned)((n_dirty + 255) / 256);
+        SeedWavePlan wplan;
+        const bool list_wave = !c->tune.no_seed_wave && seed_wave_plan(c, sd, m2, &wplan);
+        h.wave_lmax = SEED_WAVE_LMAX;
+        if (n_dirty) {
+          h.counts = d_cnt;
+          h.wave_waves = wplan.waves_count;
+          HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+          if (list_wave) {
+            NTCHK(launch_seed_wave<true>(c, wplan, n_dirty));
+          } else {
+            hipLaunchKernelGGL(seed_general_kernel<true>, dim3(lblocks), dim3(256), 0, c->stream,
+                               (const SeedGeneralArgs*)c->d_args);
+            HIPCHK(hipGetLastError());
+          }
+        }
+        NTCHK(device_exclusive_scan(c, d_cnt, d_roff, n, d_sums, d_total));
+        HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(&total, c->h_small + 8, 8);
+        if (total > out->capacity) {
+          if (total_out) *total_out = total;
+          return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
+                      (unsigned long long)out->capacity, (unsigned long long)total);
+        }
+        a.read_dirty = d_flags;
+        a.read_off = d_roff;
+        const size_t dyn2 = dyn + (size_t)rpt * 8;
+        rc = NT_SEED_FIXED(true, dyn2);
+#undef NT_SEED_FIXED
+        NTCHK(rc);
+        if (st.pos) {
+          hipLaunchKernelGGL(fill_window_pos_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, st.pos, n, nwin,
+                             (const uint64_t*)d_flags, (const uint64_t*)d_roff);
+          HIPCHK(hipGetLastError());
+        }
+        if (n_dirty) {
+          h.counts = nullptr;
+          h.read_off = d_roff;
+          h.hashes = st.hashes;
+          h.pos = st.pos;
+          h.capacity = out->capacity;
+          h.wave_waves = wplan.waves_hash;
+          HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+          if (list_wave) {
+            NTCHK(launch_seed_wave<false>(c, wplan, n_dirty, /*record*/ false)); // kernel of record: seed_fixed_kernel
+          } else {
+            hipLaunchKernelGGL(seed_general_kernel<false>, dim3(lblocks), dim3(256), 0, c->stream,
+                               (const SeedGeneralArgs*)c->d_args);
+            HIPCHK(hipGetLastError());
+          }
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        done = true;
+      }
+    }
+  }
+  if (!done) NTCHK(run_seed_general(c, st, rd, sd, m2, out->capacity, &total));
+  if (total_out) *total_out = total;
+  NTCHK(unstage_outputs(c, out, flags, rd->n_reads, per, total, st, sd->n_seeds));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}

@@ -1,0 +1,229 @@
+// capi_util.hip -- device scan, graph-extension query, measurement helpers
+// Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
+#include "capi_internal.hpp"
+#include "util_kernels.hpp"
+
+using namespace ntamd;
+using namespace ntamd::host;
+
+namespace ntamd {
+namespace host {
+
+// exclusive scan of n u64 on the device: out[i] = sum(in[0..i)), *d_total = sum
+// scratch: needs ceil(n/1024) (+ recursion) extra u64, taken from `sums`
+int device_exclusive_scan(nthip_ctx* c, const uint64_t* d_in, uint64_t* d_out, uint64_t n,
+                          uint64_t* d_sums, uint64_t* d_total)
+{
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nb == 0) {
+    HIPCHK(hipMemsetAsync(d_total, 0, sizeof(uint64_t), c->stream));
+    return NTHIP_OK;
+  }
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, c->stream, d_in, d_out,
+                     d_sums, n);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, c->stream, d_sums, nb, d_total);
+  hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, c->stream, d_out, d_sums, n);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+int launch_fill_u64(nthip_ctx* c, uint64_t* d_dst, uint64_t n, uint64_t value)
+{
+  hipLaunchKernelGGL(fill_u64_kernel, dim3(1024), dim3(256), 0, c->stream, d_dst, n, value);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+int launch_fill_window_pos(nthip_ctx* c, uint32_t* d_pos, uint64_t n_reads, uint32_t nwin, const uint64_t* d_flags,
+                           const uint64_t* d_offsets)
+{
+  hipLaunchKernelGGL(fill_window_pos_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, d_pos, n_reads, nwin, d_flags,
+                     d_offsets);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+// One pass over the offsets / spans before a kernel trusts them (a decreasing pair would underflow a length and
+// read far outside the buffer): costs one round trip, only on the paths that take caller-made offsets.
+int check_offsets_device(nthip_ctx* c, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
+                         uint64_t buf_bytes, bool contiguous)
+{
+  (void)contiguous;
+  if (n_reads == 0) return NTHIP_OK;
+  uint32_t* d_bad = (uint32_t*)(c->d_small + 32);
+  HIPCHK(hipMemsetAsync(d_bad, 0, 4, c->stream));
+  uint64_t blocks = (n_reads + 255) / 256;
+  if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
+  hipLaunchKernelGGL(check_spans_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n_reads,
+                     buf_bytes, d_bad);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_small + 32, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint32_t bad = 0;
+  memcpy(&bad, c->h_small + 32, 4);
+  if (bad) return fail(NTHIP_ERR_ARG, "offsets / spans are not non-decreasing or reach outside the read buffer");
+  return NTHIP_OK;
+}
+
+} // namespace host
+} // namespace ntamd
+
+// ==========================================================================
+// batched graph-extension query
+// ==========================================================================
+extern "C" int nthip_kmer_extend(nthip_ctx* c, const char* kmers, uint64_t n, uint16_t k16, uint8_t m8,
+                                 uint64_t* self, uint64_t* next, uint64_t* prev, uint32_t flags)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  const uint32_t k = k16, m = m8;
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0"); // src/kmer.cpp:347-349
+  if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
+  if (n && !kmers) return fail(NTHIP_ERR_ARG, "kmers is NULL");
+  if (!self && !next && !prev) return fail(NTHIP_ERR_ARG, "no output requested");
+  HIPCHK(hipSetDevice(c->device));
+  if (n == 0) return NTHIP_OK;
+  std::vector<void*> owned;
+  auto cleanup = [&]() { for (void* p : owned) (void)hipFree(p); };
+  const uint8_t* d_in = (const uint8_t*)kmers;
+  uint64_t *d_self = self, *d_next = next, *d_prev = prev;
+  int rc = NTHIP_OK;
+  auto dev_alloc = [&](size_t bytes, void** p) -> int {
+    HIPCHK(hipMalloc(p, bytes));
+    owned.push_back(*p);
+    return NTHIP_OK;
+  };
+  if (flags & NTHIP_HOST_INPUT) {
+    void* p = nullptr;
+    rc = dev_alloc(n * k, &p);
+    if (rc == NTHIP_OK && hipMemcpyAsync(p, kmers, n * k, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+      rc = fail(NTHIP_ERR_HIP, "H2D copy failed");
+    d_in = (const uint8_t*)p;
+  }
+  if (rc == NTHIP_OK && (flags & NTHIP_HOST_OUTPUT)) {
+    if (self) rc = dev_alloc(n * m * 8, (void**)&d_self);
+    if (rc == NTHIP_OK && next) rc = dev_alloc(n * 4 * m * 8, (void**)&d_next);
+    if (rc == NTHIP_OK && prev) rc = dev_alloc(n * 4 * m * 8, (void**)&d_prev);
+  }
+  if (rc != NTHIP_OK) { cleanup(); return rc; }
+  const bool aligned16 = (!d_next || ((uintptr_t)d_next & 15u) == 0) && (!d_prev || ((uintptr_t)d_prev & 15u) == 0);
+  // byte tables in LDS (k > 64: the two Horner tables + a 2-bit stream of the wave's k-mers), 16-byte stores
+  const uint32_t ntab = kmer_ntab(k);
+  const size_t wave_bits = k > 64 ? ((((size_t)64 * k + 30) >> 4) + 4) * 4 : 0;
+  const size_t lds_fixed = (size_t)ntab * 4096 + 16 * 2048; // tables + a 2 KiB exchange tile per wave
+  const size_t lds_cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
+  uint32_t waves = k > 32 && k <= 64 ? KX_WIDE_THREADS / 64 : 16;
+  while (waves > 1 && lds_fixed + wave_bits * waves > lds_cap) waves /= 2;
+  if (aligned16 && lds_fixed + wave_bits * waves <= lds_cap) {
+    const uint4* tab = nullptr;
+    if (get_kmer_tab(c, k, &tab) != NTHIP_OK) { cleanup(); return NTHIP_ERR_HIP; }
+    const size_t lds = lds_fixed + wave_bits * waves;
+    const uint32_t threads = waves * 64;
+    uint64_t blocks = (n + threads - 1) / threads;
+    if (blocks > (uint64_t)c->n_cu * 2) blocks = (uint64_t)c->n_cu * 2;
+    auto go = [&](auto kernel) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      prof_begin(c, "kmer_extend_tab_kernel");
+      hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), lds, c->stream, d_in, n, k, m, tab, ntab, d_self,
+                         d_next, d_prev);
+      prof_end(c);
+    };
+    if (k > 64) go(kmer_extend_tab_kernel<0>);
+    else if (k <= 16) go(kmer_extend_tab_kernel<1>);
+    else if (k <= 32) go(kmer_extend_tab_kernel<2>);
+    else if (k <= 48) go(kmer_extend_tab_kernel<3>);
+    else go(kmer_extend_tab_kernel<4>);
+  } else {
+    prof_begin(c, "kmer_extend_kernel");
+    hipLaunchKernelGGL(kmer_extend_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, k, m,
+                       d_self, d_next, d_prev);
+    prof_end(c);
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && (flags & NTHIP_HOST_OUTPUT)) {
+    if (self) e = hipMemcpyAsync(self, d_self, n * m * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && next) e = hipMemcpyAsync(next, d_next, n * 4 * m * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && prev) e = hipMemcpyAsync(prev, d_prev, n * 4 * m * 8, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  cleanup();
+  if (e != hipSuccess) return fail(NTHIP_ERR_HIP, "kmer_extend failed: %s", hipGetErrorString(e));
+  return NTHIP_OK;
+}
+
+// ==========================================================================
+// measurement helpers
+// ==========================================================================
+extern "C" int nthip_synth_reads(nthip_ctx* c, char* d_dst, uint64_t first_read, uint64_t n_reads,
+                                 uint32_t len, uint64_t seed)
+{
+  if (!c || !d_dst) return fail(NTHIP_ERR_ARG, "ctx/dst is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  if (n_reads == 0 || len == 0) return NTHIP_OK;
+  hipLaunchKernelGGL(synth_reads_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, (uint8_t*)d_dst,
+                     first_read, n_reads, len, seed);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_checksum(nthip_ctx* c, const uint64_t* d_vals, uint64_t n, uint64_t* sum, uint64_t* xr)
+{
+  if (!c || !sum || !xr) return fail(NTHIP_ERR_ARG, "ctx/sum/xor is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  *sum = 0;
+  *xr = 0;
+  if (n == 0) return NTHIP_OK;
+  const unsigned blocks = (unsigned)c->n_cu * 8;
+  NTCHK(ensure_scratch(c, 2 * blocks + 16));
+  hipLaunchKernelGGL(checksum_kernel, dim3(blocks), dim3(256), 0, c->stream, d_vals, n, c->d_scratch);
+  HIPCHK(hipGetLastError());
+  std::vector<uint64_t> part(2 * blocks);
+  HIPCHK(hipMemcpyAsync(part.data(), c->d_scratch, part.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (unsigned b = 0; b < blocks; ++b) {
+    *sum += part[2 * b];
+    *xr ^= part[2 * b + 1];
+  }
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_copy_bench(nthip_ctx* c, void* d_dst, const void* d_src, size_t bytes, int reps,
+                                float* best_ms)
+{
+  if (!c || !d_dst || !d_src || !best_ms) return fail(NTHIP_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  float best = 1e30f;
+  for (int i = 0; i < (reps > 0 ? reps : 1); ++i) {
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(copy_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, (uint4*)d_dst,
+                       (const uint4*)d_src, (uint64_t)(bytes / 16));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (ms < best) best = ms;
+  }
+  c->ev_valid = false;
+  *best_ms = best;
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_fill_bench(nthip_ctx* c, void* d_dst, size_t bytes, int reps, float* best_ms)
+{
+  if (!c || !d_dst || !best_ms) return fail(NTHIP_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  float best = 1e30f;
+  for (int i = 0; i < (reps > 0 ? reps : 1); ++i) {
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(fill16_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, (uint4*)d_dst,
+                       (uint64_t)(bytes / 16), (uint32_t)i);
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (ms < best) best = ms;
+  }
+  c->ev_valid = false;
+  *best_ms = best;
+  return NTHIP_OK;
+}

@@ -63,7 +63,7 @@ __device__ __forceinline__ uint64_t thread_newlines(const uint8_t* __restrict__ 
   return mask;
 }
 
-__global__ __launch_bounds__(FX_THREADS) void fastx_count_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
+static __global__ __launch_bounds__(FX_THREADS) void fastx_count_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
                                                                 uint64_t* __restrict__ block_counts)
 {
   __shared__ uint32_t ws[FX_THREADS / 64];
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(FX_THREADS) void fastx_count_kernel(const uint8_t* 
 
 // block_base: exclusive scan of block_counts; total_newlines: their sum (device memory).
 // marker: '@' (FASTQ) or '>' (FASTA).  Records >= capacity are counted but not written.
-__global__ __launch_bounds__(FX_THREADS) void fastx_index_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
+static __global__ __launch_bounds__(FX_THREADS) void fastx_index_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
                                                                 const uint64_t* __restrict__ block_base,
                                                                 const uint64_t* __restrict__ total_newlines,
                                                                 uint32_t lpr, uint8_t marker,
@@ -221,7 +221,7 @@ __device__ __forceinline__ uint32_t fasta_block_carry(uint32_t mine, uint32_t* w
 }
 
 // pass 1: last event of every block
-__global__ __launch_bounds__(FX_THREADS) void fasta_events_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
+static __global__ __launch_bounds__(FX_THREADS) void fasta_events_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
                                                                  uint32_t* __restrict__ block_last)
 {
   __shared__ uint32_t ws[FX_THREADS / 64];
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(FX_THREADS) void fasta_events_kernel(const uint8_t*
 }
 
 // carry across blocks: block_carry[b] = last event of blocks [0, b) (one block, sequential over tiles of 1024)
-__global__ __launch_bounds__(1024) void fasta_carry_kernel(const uint32_t* __restrict__ block_last, uint64_t nb,
+static __global__ __launch_bounds__(1024) void fasta_carry_kernel(const uint32_t* __restrict__ block_last, uint64_t nb,
                                                           uint32_t* __restrict__ block_carry)
 {
   __shared__ uint32_t ws[16];
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(1024) void fasta_carry_kernel(const uint32_t* __res
 }
 
 // pass 2: kept bytes and header starts per block
-__global__ __launch_bounds__(FX_THREADS) void fasta_count_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
+static __global__ __launch_bounds__(FX_THREADS) void fasta_count_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
                                                                 const uint32_t* __restrict__ block_carry,
                                                                 uint64_t* __restrict__ block_kept,
                                                                 uint64_t* __restrict__ block_hdrs)
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(FX_THREADS) void fasta_count_kernel(const uint8_t* 
 }
 
 // pass 3: write the kept bytes at their output positions and the offset of every record
-__global__ __launch_bounds__(FX_THREADS) void fasta_scatter_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
+static __global__ __launch_bounds__(FX_THREADS) void fasta_scatter_kernel(const uint8_t* __restrict__ buf, uint64_t n_bytes,
                                                                   const uint32_t* __restrict__ block_carry,
                                                                   const uint64_t* __restrict__ kept_base,
                                                                   const uint64_t* __restrict__ hdr_base,

@@ -1,4 +1,4 @@
-// fastx_stream.hpp -- host side of the FASTQ/FASTA path (included by nthip_capi.hip):
+// fastx_stream.hpp -- host side of the FASTQ/FASTA path (included by capi_fastx.hip):
 // nthip_kmer_hash_spans, nthip_fastx_index and the streaming driver
 // nthip_fastx_kmer_hash_file (reader threads -> pinned buffers -> copy stream -> index + hash).
 #pragma once
@@ -192,15 +192,12 @@ struct FxReader {
   uint64_t next_free = 2;   // chunks [0, next_free) may be read (their buffer is free)
   bool failed = false, stop = false;
   double read_seconds = 0;
+  unsigned n_threads = 0;
   std::thread th;
 
   void run()
   {
-    unsigned n_thr = 8;
-    if (const char* t = getenv("NTHIP_TUNE_READ_THREADS")) { // A/B knob
-      const int v = atoi(t);
-      if (v >= 1 && v <= 64) n_thr = (unsigned)v;
-    }
+    const unsigned n_thr = n_threads ? n_threads : 8u; // (NTHIP_TUNE_READ_THREADS: A/B knob)
     for (uint64_t j = 0; j < n_chunks; ++j) {
       {
         std::unique_lock<std::mutex> lk(mu);
@@ -393,6 +390,7 @@ int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t 
   chunk_bytes = (chunk_bytes + 4095) & ~4095ull;
 
   FxReader rd;
+  rd.n_threads = c->tune.read_threads;
   rd.fd = open(path, O_RDONLY);
   if (rd.fd < 0) return fail(NTHIP_ERR_ARG, "cannot open %s", path);
   struct stat sb;

@@ -371,7 +371,7 @@ struct KmerGeneralArgs {
 };
 
 // segments per read: ceil(windows / KG_SEG_WINDOWS)
-__global__ __launch_bounds__(256) void kmer_seg_count_kernel(const uint64_t* __restrict__ offsets, uint64_t n_reads,
+static __global__ __launch_bounds__(256) void kmer_seg_count_kernel(const uint64_t* __restrict__ offsets, uint64_t n_reads,
                                                             uint32_t len, uint32_t k, uint64_t* __restrict__ segs)
 {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void kmer_seg_count_kernel(const uint64_t* __r
 }
 
 // per-read counts from per-item offsets: counts[r] = item_off[seg_base[r+1]] - item_off[seg_base[r]]
-__global__ __launch_bounds__(256) void kmer_seg_read_counts_kernel(const uint64_t* __restrict__ seg_base,
+static __global__ __launch_bounds__(256) void kmer_seg_read_counts_kernel(const uint64_t* __restrict__ seg_base,
                                                                   const uint64_t* __restrict__ item_off,
                                                                   uint64_t n_reads, uint64_t n_items, uint64_t total,
                                                                   uint64_t* __restrict__ counts)

@@ -25,7 +25,7 @@ enum : int { NA_MODE_COUNT = 1, NA_MODE_HASH = 2 };
 
 // ---- pre-pass ---------------------------------------------------------------
 // runs per read and a 0/1 flag "has a window"
-__global__ __launch_bounds__(256) void ragged_runs_kernel(const uint64_t* __restrict__ starts,
+static __global__ __launch_bounds__(256) void ragged_runs_kernel(const uint64_t* __restrict__ starts,
                                                          const uint64_t* __restrict__ ends, uint64_t n_reads,
                                                          uint32_t k, uint32_t C, uint64_t* __restrict__ rc,
                                                          uint64_t* __restrict__ flag)
@@ -47,7 +47,7 @@ struct __attribute__((aligned(32))) NzMeta {
 };
 
 // compact list of the reads that have runs: nz_meta[j], and nz_rc[j] on its own for the scan
-__global__ __launch_bounds__(256) void ragged_scatter_kernel(const uint64_t* __restrict__ rc,
+static __global__ __launch_bounds__(256) void ragged_scatter_kernel(const uint64_t* __restrict__ rc,
                                                             const uint64_t* __restrict__ nz_idx,
                                                             const uint64_t* __restrict__ starts,
                                                             const uint64_t* __restrict__ ends, uint64_t n_reads,
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void ragged_scatter_kernel(const uint64_t* __r
 }
 
 // per tile: the listed read that holds run 64*t, and how many of its runs precede it
-__global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t* __restrict__ nz_run_base, uint64_t n_nz,
+static __global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t* __restrict__ nz_run_base, uint64_t n_nz,
                                                           uint64_t n_tiles, uint64_t* __restrict__ tile_j0,
                                                           uint64_t* __restrict__ tile_rem0)
 {

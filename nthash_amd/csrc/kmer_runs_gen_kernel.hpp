@@ -924,7 +924,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
 }
 
 // the unfused consumer: set the bits of an already materialised hash stream
-__global__ __launch_bounds__(256) void stream_bloom_insert_kernel(const uint64_t* __restrict__ hashes, uint64_t n,
+static __global__ __launch_bounds__(256) void stream_bloom_insert_kernel(const uint64_t* __restrict__ hashes, uint64_t n,
                                                                  uint32_t* __restrict__ bloom, uint64_t n_bits,
                                                                  uint64_t magic)
 {
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(256) void stream_bloom_insert_kernel(const uint64_t
 // hundred bytes of LDS per wave, so the CU runs at full occupancy and the pass
 // streams the reads at close to HBM read rate.  Same geometry and the same window
 // masks as the hash pass.
-__global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_count_kernel(const KmerRunsGenArgs a)
+static __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_count_kernel(const KmerRunsGenArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t k = a.k, C = a.C, rpr = a.rpr;

@@ -55,7 +55,7 @@ struct SeedFixedArgs {
 
 // Which fixed-length reads contain a byte that is not a base?  One 16-byte vector per thread; a byte
 // belongs to every read whose [r*stride, r*stride + len) covers it (overlapping reads when stride < len).
-__global__ __launch_bounds__(256) void seed_mark_dirty_kernel(const uint8_t* __restrict__ seqs, uint64_t total_bytes,
+static __global__ __launch_bounds__(256) void seed_mark_dirty_kernel(const uint8_t* __restrict__ seqs, uint64_t total_bytes,
                                                              uint32_t len, uint32_t stride, uint64_t n_reads,
                                                              uint64_t* __restrict__ flags)
 {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void seed_mark_dirty_kernel(const uint8_t* __r
 }
 
 // list[idx[r]] = r for the flagged reads (idx = exclusive scan of the flags)
-__global__ __launch_bounds__(256) void seed_list_kernel(const uint64_t* __restrict__ flags, const uint64_t* __restrict__ idx,
+static __global__ __launch_bounds__(256) void seed_list_kernel(const uint64_t* __restrict__ flags, const uint64_t* __restrict__ idx,
                                                        uint64_t n_reads, uint64_t* __restrict__ list)
 {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -27,8 +27,8 @@ __device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, uint32_t lane)
 }
 
 // per-tile exclusive scan; tile totals go to block_sums
-__global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(const uint64_t* __restrict__ in,
-                                                                 uint64_t* __restrict__ out,
+static __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(const uint64_t* in,
+                                                                 uint64_t* out,
                                                                  uint64_t* __restrict__ block_sums,
                                                                  uint64_t n)
 {
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(const uint64_t
 }
 
 // single block: exclusive scan of the tile totals in place, grand total out
-__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(uint64_t* __restrict__ sums, uint64_t n,
+static __global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(uint64_t* __restrict__ sums, uint64_t n,
                                                                 uint64_t* __restrict__ total)
 {
   __shared__ uint64_t wave_tot[SCAN_THREADS / 64];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(uint64_t* __res
   if (tid == 0) *total = carry_s;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(uint64_t* __restrict__ out,
+static __global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(uint64_t* __restrict__ out,
                                                                const uint64_t* __restrict__ sums, uint64_t n)
 {
   const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(uint64_t* __rest
     if (base + i < n) out[base + i] += add;
 }
 
-__global__ void fill_u64_kernel(uint64_t* __restrict__ dst, uint64_t n, uint64_t value)
+static __global__ void fill_u64_kernel(uint64_t* __restrict__ dst, uint64_t n, uint64_t value)
 {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * blockDim.x)
@@ -99,7 +99,7 @@ __global__ void fill_u64_kernel(uint64_t* __restrict__ dst, uint64_t n, uint64_t
 }
 
 // pos[r*nwin + p] = p
-__global__ void fill_pos_kernel(uint32_t* __restrict__ dst, uint64_t n, uint32_t nwin)
+static __global__ void fill_pos_kernel(uint32_t* __restrict__ dst, uint64_t n, uint32_t nwin)
 {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * blockDim.x)
@@ -115,7 +115,7 @@ __device__ __host__ inline uint64_t splitmix64(uint64_t x)
 }
 
 // Counter-based synthetic reads: one thread per (read, 32-base word)
-__global__ void synth_reads_kernel(uint8_t* __restrict__ dst, uint64_t first_read, uint64_t n_reads,
+static __global__ void synth_reads_kernel(uint8_t* __restrict__ dst, uint64_t first_read, uint64_t n_reads,
                                    uint32_t len, uint64_t seed)
 {
   const uint64_t W = (len + 31u) / 32u;
@@ -134,7 +134,7 @@ __global__ void synth_reads_kernel(uint8_t* __restrict__ dst, uint64_t first_rea
 }
 
 // wrapping sum and xor of a u64 stream; partial[2*block + {0,1}]
-__global__ __launch_bounds__(256) void checksum_kernel(const uint64_t* __restrict__ v, uint64_t n,
+static __global__ __launch_bounds__(256) void checksum_kernel(const uint64_t* __restrict__ v, uint64_t n,
                                                       uint64_t* __restrict__ partial)
 {
   __shared__ uint64_t ss[4], sx[4];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void checksum_kernel(const uint64_t* __restric
 // Batched BlindNtHash::peek / peek_back (src/kmer.cpp:377-393): one lane per k-mer.
 // The k-mer (bases only, not validated -- like BlindNtHash) is hashed directly, then the
 // 4 successors / predecessors follow from one roll step each.
-__global__ __launch_bounds__(256) void kmer_extend_kernel(const uint8_t* __restrict__ kmers, uint64_t n, uint32_t k,
+static __global__ __launch_bounds__(256) void kmer_extend_kernel(const uint8_t* __restrict__ kmers, uint64_t n, uint32_t k,
                                                          uint32_t m, uint64_t* __restrict__ self,
                                                          uint64_t* __restrict__ next, uint64_t* __restrict__ prev)
 {
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(NW >= 3 ? KX_WIDE_THREADS : 1024) void kmer_extend_
 // get_pos() of the k-mers the dense kernels write: a read of bases only emits every window, 0 .. nwin-1, at its
 // place in the stream (read_off[r], or r * nwin for a clean batch); flagged reads are left to the N-aware kernels.
 // One wave per read at a time: nwin * 4 contiguous bytes.
-__global__ __launch_bounds__(256) void fill_window_pos_kernel(uint32_t* __restrict__ pos, uint64_t n_reads, uint32_t nwin,
+static __global__ __launch_bounds__(256) void fill_window_pos_kernel(uint32_t* __restrict__ pos, uint64_t n_reads, uint32_t nwin,
                                                            const uint64_t* __restrict__ read_dirty,
                                                            const uint64_t* __restrict__ read_off)
 {
@@ -400,12 +400,34 @@ __global__ __launch_bounds__(256) void fill_window_pos_kernel(uint32_t* __restri
 }
 
 // plain 16-byte/lane device copy: the achievable-bandwidth yardstick
-__global__ __launch_bounds__(256) void copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src,
+static __global__ __launch_bounds__(256) void copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src,
                                                   uint64_t n16)
 {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
        i += (uint64_t)gridDim.x * blockDim.x)
     dst[i] = src[i];
+}
+
+// write-only yardstick: every wave instruction stores one contiguous KiB
+static __global__ __launch_bounds__(256) void fill16_kernel(uint4* __restrict__ dst, uint64_t n16, uint32_t value)
+{
+  const v4u v = {value, value ^ 0x55555555u, ~value, value ^ 0xAAAAAAAAu};
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    __builtin_nontemporal_store(v, (v4u*)dst + i);
+}
+
+// spans / offsets sanity (the kernels trust them): every read must satisfy starts[r] <= ends[r] <= buf_bytes
+static __global__ __launch_bounds__(256) void check_spans_kernel(const uint64_t* __restrict__ starts,
+                                                                 const uint64_t* __restrict__ ends, uint64_t n,
+                                                                 uint64_t buf_bytes, uint32_t* __restrict__ bad)
+{
+  uint32_t b = 0;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t s0 = starts[r], e0 = ends[r];
+    if (s0 > e0 || e0 > buf_bytes) b = 1u;
+  }
+  if (__ballot(b != 0) != 0 && (threadIdx.x & 63u) == 0) atomicOr(bad, 1u);
 }
 
 } // namespace ntamd

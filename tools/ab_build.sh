@@ -5,7 +5,4 @@
 set -e
 cd "$(dirname "$0")/.."
 tag=$1; shift
-mkdir -p nthash_amd/lib/ab
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -Iinclude "$@" \
-  nthash_amd/csrc/nthip_capi.hip -o nthash_amd/lib/ab/libnthash_hip_$tag.so
-echo nthash_amd/lib/ab/libnthash_hip_$tag.so
+python -m nthash_amd.build --tag "$tag" --flags "$*" | tail -1

@@ -41,6 +41,7 @@ for rnd in range(rounds):
             os.environ["NTHIP_TUNE_NO_M4"] = "1"
         else:
             os.environ.pop("NTHIP_TUNE_NO_M4", None)
+        ctx.reload_tuning()  # the knobs are read once per context
         flags = 8 if v == "rows" else 4 if v == "general" else 0
         ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin, flags=flags)
         ms, name = ctx.last_kernel_ms()

@@ -23,6 +23,7 @@ cap = int((lens - k + 1).sum())
 d_out = ctx.malloc(cap * 6 * 8)
 for name, env in (("seed_wave_kernel", None), ("lane-per-read kernel", "1")):
     if env: os.environ["NTHIP_TUNE_NO_SEED_WAVE"] = env
+    ctx.reload_tuning()
     ts = []
     for _ in range(3 if not env else 1):
         t0 = time.perf_counter(); tot = ctx.seed_hash_ptr(d_in, d_offs, n, 0, 0, sd, m2, d_out, cap); ts.append(time.perf_counter() - t0)

@@ -51,8 +51,10 @@ for it in range(iters):
     want_pos = bool(rng.random() < 0.4)
     want_str = bool(rng.random() < 0.3)
     os.environ.pop("NTHIP_TUNE_NO_SEED_WAVE", None)
+    ctx.reload_tuning()
     a = ctx.seed_hash(data, seeds, k, m2, want_pos=want_pos, want_strands=want_str, **kw)
     os.environ["NTHIP_TUNE_NO_SEED_WAVE"] = "1"
+    ctx.reload_tuning()
     b = ctx.seed_hash(data, seeds, k, m2, want_pos=want_pos, want_strands=want_str, flags=4, **kw)
     ok = a["total"] == b["total"] and (a["hashes"] == b["hashes"]).all() and (a["counts"] == b["counts"]).all()
     if want_pos:
