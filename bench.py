@@ -1,26 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- k-mers hashed/sec of the ntHash hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4] [--reads R]
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|ref] [--reads R]
 
-One "step" = one pass of the hot path (nthip_kmer_hash / nthip_seed_hash through
-the C-ABI) over the rank's device-resident batch of synthetic reads.  Default
-workload = BASELINE.json configs[1]: NtHash k=31 canonical, 1 hash/k-mer,
-100M x 150 bp reads on one MI355X (15 GB in, 96 GB of hashes out, both resident
-in HBM).  With N > 1 (launched by torch.distributed.run, one rank per GPU) every
-rank hashes its own shard of N*R reads -- reads are independent, so there is no
-data-path collective ("weak" scaling); torch.distributed is used only for the
-barrier and the max-over-ranks time.
+One "step" = one pass of the hot path (nthip_kmer_hash / nthip_seed_hash through the C-ABI) over the rank's
+device-resident batch of synthetic reads.
+
+N = 1: BASELINE.json configs[1] -- NtHash k=31 canonical, 1 hash/k-mer, 100 M x 150 bp reads on one MI355X
+(15 GB in, 96 GB of hashes out, both resident in HBM).
+N > 1: BASELINE.json configs[4] -- the 1 G x 150 bp job in shards of 125 M reads per GPU; rank r hashes reads
+[r*125 M, (r+1)*125 M).  Reads are independent (include/nthash/nthash.hpp:196-204 of the reference: all state is
+per object), so there is NO data-path collective ("weak" scaling); torch.distributed (RCCL) carries the barrier, the
+max-over-ranks time and the per-rank results.  `python bench.py --gpus N` launches its own N ranks (one process per
+GPU under torch.distributed.run); under an external launcher (WORLD_SIZE set) it just runs its rank.
 
 Rank 0 prints ONE JSON line: BASELINE.json's metric plus
-  roofline      algorithmic HBM bytes per launch / HIP-event duration of the
-                dominant kernel, against the 8 TB/s spec peak,
-  cpu_baseline  the reference CPU library (oracle/_ref, kind "reference") or the
-                C restatement (kind "port") timed on this host on a bounded sample.
+  roofline      algorithmic HBM bytes per launch / HIP-event duration of the dominant kernel, against the 8 TB/s
+                spec peak AND against the write / copy rates measured on this box in the same process,
+  verify        the on-device checksum of the WHOLE hash stream against the reference's
+                (tests/golden/bench_checksums.json, made by the real reference library),
+  secondary     (N = 1) the other single-GPU configs of BASELINE.json, same clock, 3 steps each,
+  cpu_baseline  the reference CPU library (oracle/_ref, kind "reference") or the C restatement (kind "port")
+                timed on this host on a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -30,10 +36,12 @@ if ROOT not in sys.path:
 
 SEED_A = "1010101010101010101010101010101"
 SEED_B = "1101101101101101011011011011011"
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+SHARD_READS_MULTI = 125_000_000  # BASELINE config 5: 1 G reads over 8 GPUs
+TRAFFIC_FILE = "profiles/r02_traffic.json"
 
 CONFIGS = {
-    # name: (description, read_len, k, hashes/k-mer kind, default reads per GPU)
+    # name: description, read length, k, hashes per k-mer (m, or m per seed), default reads per GPU
     "c2": dict(desc="NtHash k=31 canonical, 1 hash/k-mer, 100M x 150bp", L=150, k=31, m=1, seeds=None,
                reads=100_000_000),
     "c3": dict(desc="NtHash k=31, m=4 hashes/k-mer (multi-hash), 100M x 150bp", L=150, k=31, m=4,
@@ -47,6 +55,49 @@ CONFIGS = {
 }
 
 
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the config's size)")
+    ap.add_argument("--chunk-reads", type=int, default=0,
+                    help="reads per launch (outputs of c3/c4 exceed HBM: a ring buffer is reused)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the c3 / c4 / ref lines at N = 1")
+    ap.add_argument("--no-peak", action="store_true", help="skip the measured fill / copy ceiling")
+    ap.add_argument("--cpu-sample-reads", type=int, default=0)
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# launching: `python bench.py --gpus N` becomes N ranks
+# ---------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """Re-exec under torch.distributed.run with one process per GPU (never returns)."""
+    share = os.environ.get("NTHASH_BENCH_SHARE_GPU") == "1"
+    if not share:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible -- refusing to report "
+                             f"a {args.gpus}-GPU number from fewer GPUs")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------------------
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -58,64 +109,210 @@ def _cpu_model():
     return "unknown"
 
 
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the config's size)")
-    ap.add_argument("--chunk-reads", type=int, default=0,
-                    help="reads per launch (outputs of c3/c4 exceed HBM: a ring buffer is reused)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-reads", type=int, default=0)
-    return ap.parse_args()
+def _cgroup_cpu_max():
+    for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            return open(p).read().strip()
+        except OSError:
+            continue
+    return None
 
 
 def cpu_baseline(cfg, sample_reads):
-    """Time the reference CPU library on a bounded sample of the same workload."""
-    import numpy as np  # noqa: F401
+    """Time the reference CPU library on a bounded sample of the same workload (same reads, same k / m)."""
+    import numpy as np
 
     from oracle.pyoracle import Oracle, Reference
-    impl = Reference() if Reference.available() else Oracle()
-    L, k, m = cfg["L"], cfg["k"], cfg["m"]
+    L, k, m, seeds = cfg["L"], cfg["k"], cfg["m"], cfg["seeds"]
+    usable = len(os.sched_getaffinity(0))
+    host = {"host_cpus": os.cpu_count(), "usable_cpus": usable, "cgroup_cpu_max": _cgroup_cpu_max(),
+            "cpu_model": _cpu_model()}
+    ref = Reference() if Reference.available() else None
+    if ref is not None and ref.has_synth:
+        sec, nk, _ = ref.bench_synth(0, sample_reads, L, k, m, seeds=seeds, threads=1)
+        out = {"value": nk / sec, "unit": "kmers/s", "cores": 1, "kind": "reference",
+               "sample": f"{sample_reads} x {L}bp synthetic reads (same generator, seed 42), {nk} k-mers in "
+                         f"{sec:.2f}s, one iterator per read, every hash consumed, timed inside the library"}
+        out.update(host)
+        # the reference has no threaded path: this is OUR OpenMP parallel-for over reads around it.  One thread
+        # per usable CPU, reads first-touched by the thread that hashes them, pool warm, sample >= 3 s.
+        nt = max(1, min(usable, ref.max_threads()))
+        if nt > 1:
+            n_mt = min(cfg["reads"], max(sample_reads, 250_000 * nt))
+            sec1, nk1, used = ref.bench_synth(0, n_mt, L, k, m, seeds=seeds, threads=nt)  # calibration pass
+            reps = max(1, min(64, int(3.5 / max(sec1, 1e-3)) + 1))
+            sec2, nk2, used = ref.bench_synth(0, n_mt, L, k, m, seeds=seeds, threads=nt, repeats=reps)
+            out["openmp"] = {"value": nk2 / sec2, "unit": "kmers/s", "cores": used,
+                             "speedup_vs_1_thread": (nk2 / sec2) / out["value"],
+                             "sample": f"{n_mt} reads x {reps} passes, {nk2} k-mers in {sec2:.2f}s",
+                             "note": "OpenMP parallel-for over reads added by the harness; threads = usable CPUs "
+                                     "(SMT siblings included)"}
+        return out
+    impl = ref if ref is not None else Oracle()
     data = impl.synth_reads(0, sample_reads, L, 42)
     t0 = time.perf_counter()
-    if cfg["seeds"] is None:
+    if seeds is None:
         _acc, nk = impl.bench_kmer(data, sample_reads, L, k, m, threads=1)
     elif impl.kind == "reference":
-        _acc, nk = impl.bench_seed(data, sample_reads, L, cfg["seeds"], k, m, threads=1)
+        _acc, nk = impl.bench_seed(data, sample_reads, L, seeds, k, m, threads=1)
     else:
         offs = np.arange(sample_reads + 1, dtype=np.uint64) * L
-        nk = impl.seed_batch(data, offs, cfg["seeds"], k, m, want_pos=False)["total"]
+        nk = impl.seed_batch(data, offs, seeds, k, m, want_pos=False)["total"]
     t1 = time.perf_counter() - t0
     out = {"value": nk / t1, "unit": "kmers/s", "cores": 1, "kind": impl.kind,
-           "sample": f"{sample_reads} x {L}bp synthetic reads (same generator, seed 42), "
-                     f"{nk} k-mers in {t1:.2f}s, iterator per read, every hash consumed",
-           "host_cpus": os.cpu_count(), "cpu_model": _cpu_model()}
-    if impl.kind == "reference":
-        # the reference has no threaded path; this is OUR OpenMP parallel-for over reads
-        nt = impl.max_threads()
-        if nt > 1:
-            t0 = time.perf_counter()
-            if cfg["seeds"] is None:
-                _acc, nk2 = impl.bench_kmer(data, sample_reads, L, k, m, threads=nt)
-            else:
-                _acc, nk2 = impl.bench_seed(data, sample_reads, L, cfg["seeds"], k, m, threads=nt)
-            t2 = time.perf_counter() - t0
-            out["openmp"] = {"value": nk2 / t2, "unit": "kmers/s", "cores": nt,
-                             "note": "OpenMP parallel-for over reads added by the harness"}
+           "sample": f"{sample_reads} x {L}bp synthetic reads (same generator, seed 42), {nk} k-mers in {t1:.2f}s, "
+                     f"iterator per read, every hash consumed"}
+    out.update(host)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# one workload on one rank
+# ---------------------------------------------------------------------------------------------------------
+_CHECKSUMS = None
+
+
+def reference_checksum(name, first_read, n_reads):
+    """The reference's (sum, xor, total) for this shard, from the committed fixture; None when it holds none."""
+    global _CHECKSUMS
+    if _CHECKSUMS is None:
+        try:
+            _CHECKSUMS = {(e["workload"], e["first_read"], e["n_reads"]): e
+                          for e in json.load(open(os.path.join(ROOT, "tests", "golden", "bench_checksums.json")))}
+        except (OSError, ValueError):
+            _CHECKSUMS = {}
+    return _CHECKSUMS.get((name, first_read, n_reads))
+
+
+class Workload:
+    """Device-resident reads + output ring of one config on one rank."""
+
+    def __init__(self, torch, ctx, dev, name, cfg, n_reads, first_read, chunk_reads=0):
+        import nthash_amd
+        self.torch, self.ctx, self.dev, self.name, self.cfg = torch, ctx, dev, name, cfg
+        self.n_reads, self.first_read = n_reads, first_read
+        L, k, m = cfg["L"], cfg["k"], cfg["m"]
+        self.L, self.k, self.m = L, k, m
+        self.nwin = L - k + 1
+        self.per = m if cfg["seeds"] is None else len(cfg["seeds"]) * m
+        # launches per step: outputs larger than the free memory are produced chunk by chunk into one buffer
+        free_b, _tot_b = torch.cuda.mem_get_info(dev)
+        out_bytes_per_read = self.nwin * self.per * 8
+        budget = int(free_b * 0.85) - n_reads * L
+        chunk = chunk_reads or min(n_reads, max(1, budget // out_bytes_per_read))
+        chunk = min(chunk, n_reads)
+        if chunk < n_reads:  # keep chunks a multiple of the kernels' read tiles
+            chunk = max(256, chunk // 256 * 256)
+        self.chunk = chunk
+        self.n_chunks = (n_reads + chunk - 1) // chunk
+        self.d_in = torch.empty(n_reads * L, dtype=torch.uint8, device=dev)
+        self.d_out = torch.empty(chunk * self.nwin * self.per, dtype=torch.int64, device=dev)
+        ctx.synth_reads_ptr(self.d_in.data_ptr(), first_read, n_reads, L, 42)
+        self.seeds = nthash_amd.Seeds(ctx, cfg["seeds"], k) if cfg["seeds"] else None
+        torch.cuda.synchronize(dev)
+        self.kernel_ms = []
+
+    def launch(self, c):
+        r0 = c * self.chunk
+        nr = min(self.chunk, self.n_reads - r0)
+        if self.seeds is None:
+            return self.ctx.kmer_hash_ptr(self.d_in.data_ptr() + r0 * self.L, 0, nr, self.L, 0, self.k, self.m,
+                                          self.d_out.data_ptr(), self.chunk * self.nwin)
+        return self.ctx.seed_hash_ptr(self.d_in.data_ptr() + r0 * self.L, 0, nr, self.L, 0, self.seeds, self.m,
+                                      self.d_out.data_ptr(), self.chunk * self.nwin)
+
+    def step(self, record):
+        done = 0
+        for c in range(self.n_chunks):
+            tot = self.launch(c)
+            if record:
+                ms, name = self.ctx.last_kernel_ms()
+                self.kernel_ms.append((ms, name, tot))
+            done += tot
+        return done
+
+    def verify(self):
+        """Outside the timed region: one more pass, the WHOLE stream checksummed on the device and compared with the
+        reference's checksum of the same reads; plus a full compare of the last chunk's first reads with the oracle."""
+        import numpy as np
+        out = {"method": "on-device wrapping sum + XOR of every hash of the stream vs the reference library's "
+                         "(tests/golden/bench_checksums.json)", "ok": None}
+        s = x = tot = 0
+        for c in range(self.n_chunks):
+            t = self.launch(c)
+            cs, cx = self.ctx.checksum_ptr(self.d_out.data_ptr(), t * self.per)
+            s = (s + cs) & 0xFFFFFFFFFFFFFFFF
+            x ^= cx
+            tot += t
+        out.update(sum=format(s, "016x"), xor=format(x, "016x"), total=tot)
+        want = reference_checksum(self.name, self.first_read, self.n_reads)
+        if want is not None:
+            out["ok"] = bool(want["sum"] == out["sum"] and want["xor"] == out["xor"] and want["total"] == tot)
+            out["reference"] = {"sum": want["sum"], "xor": want["xor"], "total": want["total"]}
+        else:
+            out["note"] = "no committed reference checksum for this (workload, shard): spot check only"
+        spot = None
+        try:
+            from oracle.pyoracle import Oracle
+            orc = Oracle()
+            last_r0 = (self.n_chunks - 1) * self.chunk  # d_out holds the last chunk
+            nv = min(2000, self.n_reads - last_r0)
+            host = self.d_out[: nv * self.nwin * self.per].cpu().numpy().view(np.uint64).reshape(-1, self.per)
+            data = orc.synth_reads(self.first_read + last_r0, nv, self.L, 42)
+            offs = np.arange(nv + 1, dtype=np.uint64) * self.L
+            if self.seeds is None:
+                w = orc.kmer_batch(data, offs, self.k, self.m, want_pos=False)["hashes"]
+            else:
+                w = orc.seed_batch(data, offs, self.cfg["seeds"], self.k, self.m, want_pos=False)["hashes"]
+            spot = bool((host == w).all())
+        except Exception as e:  # the oracle is a checker, not a dependency of the measurement
+            spot = f"not checked: {e}"
+        out["spot_vs_oracle"] = spot
+        return out
+
+    def roofline(self):
+        b_per_kmer = 8.0 * self.per + self.L / self.nwin  # SURVEY 8(d): 8*H + b_in*L/(L-k+1), ASCII input
+        ms_list = [q[0] for q in self.kernel_ms]
+        avg_ms = sum(ms_list) / len(ms_list)
+        kmers_per_launch = sum(q[2] for q in self.kernel_ms) / len(self.kernel_ms)
+        achieved = kmers_per_launch * b_per_kmer / (avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": self.kernel_ms[0][1],
+                "kernel_avg_ms": avg_ms, "bytes_per_kmer": b_per_kmer, "kmers_per_launch": kmers_per_launch}
+
+    def free(self):
+        if self.seeds is not None:
+            self.seeds.close()
+        self.d_in = self.d_out = None
+        self.torch.cuda.empty_cache()
+
+
+def measured_peak(torch, ctx, dev):
+    """Write-only and copy rates of this box, same process, same clock: the achievable ceiling next to the spec."""
+    nbytes = 8 << 30
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    fill_ms = ctx.fill_bench_ptr(a.data_ptr(), nbytes, 6)
+    copy_ms = ctx.copy_bench_ptr(b.data_ptr(), a.data_ptr(), nbytes, 6)
+    del a, b
+    torch.cuda.empty_cache()
+    fill = nbytes / (fill_ms * 1e-3) / 1e9
+    copy = 2 * nbytes / (copy_ms * 1e-3) / 1e9
+    return {"fill_GBps": fill, "copy_GBps": copy, "best_GBps": max(fill, copy),
+            "how": "nthip_fill_bench / nthip_copy_bench, 8 GiB, best of 6, in this process"}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     cfg = dict(CONFIGS[args.config])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(or run `python bench.py --gpus {args.gpus}` and let it launch them)")
 
     import torch
     import torch.distributed as dist
@@ -128,11 +325,13 @@ def main():
     # NTHASH_BENCH_SHARE_GPU=1 (testing only): all ranks on GPU 0 with a gloo group, so that the
     # multi-rank control flow can be exercised on a 1-GPU box; real runs use one GPU per rank + RCCL
     share = os.environ.get("NTHASH_BENCH_SHARE_GPU") == "1"
+    n_dev = torch.cuda.device_count()
     if share:
         local_rank = 0
-    # a launcher that pins one GPU per rank (HIP_VISIBLE_DEVICES) leaves every rank with device 0 only
-    if local_rank >= torch.cuda.device_count():
-        local_rank = local_rank % torch.cuda.device_count()
+    elif n_dev == 1 and world > 1 and os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES")):
+        local_rank = 0  # a launcher that pins one GPU per rank leaves every rank with device 0 only
+    elif local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {n_dev} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -141,50 +340,15 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
+    cpu_group_dev = "cpu" if share else dev
 
-    L, k, m = cfg["L"], cfg["k"], cfg["m"]
-    nwin = L - k + 1
-    n_reads = args.reads or cfg["reads"]
-    per = m if cfg["seeds"] is None else len(cfg["seeds"]) * m
-    # launches per step: outputs larger than ~100 GB are produced chunk by chunk into one buffer
-    free_b, _tot_b = torch.cuda.mem_get_info(dev)
-    out_bytes_per_read = nwin * per * 8
-    budget = int(free_b * 0.85) - n_reads * L
-    chunk = args.chunk_reads or min(n_reads, max(1, budget // out_bytes_per_read))
-    chunk = min(chunk, n_reads)
-    if chunk < n_reads:  # keep chunks a multiple of the kernel's 256-read tile
-        chunk = max(256, chunk // 256 * 256)
-    n_chunks = (n_reads + chunk - 1) // chunk
-
+    n_reads = args.reads or (SHARD_READS_MULTI if (world > 1 and args.config == "c2") else cfg["reads"])
     ctx = nthash_amd.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     ctx.set_profiling(True)
-    d_in = torch.empty(n_reads * L, dtype=torch.uint8, device=dev)
-    d_out = torch.empty(chunk * nwin * per, dtype=torch.int64, device=dev)
     # this rank's shard of the global read set [rank*n_reads, (rank+1)*n_reads)
     first_read, _ = weak_shard(rank, n_reads)
-    ctx.synth_reads_ptr(d_in.data_ptr(), first_read, n_reads, L, 42)
-    seeds = nthash_amd.Seeds(ctx, cfg["seeds"], k) if cfg["seeds"] else None
-    torch.cuda.synchronize(dev)
-
-    kernel_ms = []
-
-    def step(record):
-        done = 0
-        for c in range(n_chunks):
-            r0 = c * chunk
-            nr = min(chunk, n_reads - r0)
-            if seeds is None:
-                tot = ctx.kmer_hash_ptr(d_in.data_ptr() + r0 * L, 0, nr, L, 0, k, m, d_out.data_ptr(),
-                                        chunk * nwin)
-            else:
-                tot = ctx.seed_hash_ptr(d_in.data_ptr() + r0 * L, 0, nr, L, 0, seeds, m,
-                                        d_out.data_ptr(), chunk * nwin)
-            if record:
-                ms, name = ctx.last_kernel_ms()
-                kernel_ms.append((ms, name, tot))
-            done += tot
-        return done
+    wl = Workload(torch, ctx, dev, args.config, cfg, n_reads, first_read, args.chunk_reads)
 
     def barrier():
         if world > 1:
@@ -192,57 +356,54 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        step(False)
+        wl.step(False)
     barrier()
     t0 = time.perf_counter()
     kmers = 0
     for _ in range(args.steps):
-        kmers += step(True)
+        kmers += wl.step(True)
+    torch.cuda.synchronize(dev)
+    my_dt = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    assert kmers == args.steps * n_reads * wl.nwin, (kmers, args.steps * n_reads * wl.nwin)
+
+    verify = wl.verify()
+    ok_local = (verify["ok"] is not False) and (verify["spot_vs_oracle"] is True)
+    per_rank = [kmers / my_dt]
+    all_ok = ok_local
+    checked_full = verify["ok"] is True
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cpu_group_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert kmers == args.steps * n_reads * nwin, (kmers, args.steps * n_reads * nwin)
-
-    # ---- post-run verification (outside the timed region) -------------------
-    verified = None
-    try:
-        import numpy as np
-
-        from oracle.pyoracle import Oracle
-        orc = Oracle()
-        last_r0 = (n_chunks - 1) * chunk  # d_out holds the last chunk
-        nv = min(2000, n_reads - last_r0)
-        host = d_out[: nv * nwin * per].cpu().numpy().view(np.uint64).reshape(-1, per)
-        data = orc.synth_reads(first_read + last_r0, nv, L, 42)
-        offs = np.arange(nv + 1, dtype=np.uint64) * L
-        if seeds is None:
-            want = orc.kmer_batch(data, offs, k, m, want_pos=False)["hashes"]
-        else:
-            want = orc.seed_batch(data, offs, cfg["seeds"], k, m, want_pos=False)["hashes"]
-        verified = bool((host == want).all())
-    except Exception as e:  # the oracle is a checker, not a dependency of the measurement
-        verified = f"not checked: {e}"
+        g = [torch.zeros(3, dtype=torch.float64, device=cpu_group_dev) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([kmers / my_dt, 1.0 if ok_local else 0.0, 1.0 if checked_full else 0.0],
+                                        dtype=torch.float64, device=cpu_group_dev))
+        per_rank = [float(q[0]) for q in g]
+        all_ok = all(float(q[1]) == 1.0 for q in g)
+        checked_full = all(float(q[2]) == 1.0 for q in g)
 
     if rank == 0:
+        L, k = cfg["L"], cfg["k"]
         total_kmers = kmers * world
-        b_per_kmer = 8.0 * per + L / nwin  # 8*H + b_in*L/(L-k+1), ASCII input
-        ms_list = [x[0] for x in kernel_ms]
-        avg_ms = sum(ms_list) / len(ms_list)
-        kmers_per_launch = sum(x[2] for x in kernel_ms) / len(kernel_ms)
-        achieved = kmers_per_launch * b_per_kmer / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2
-        # gfx950 correction + WRITE_SIZE, collected in separate rocprofv3 --pmc runs on the same
-        # kernel); counters cannot be read inside this process, so null when no summary exists
-        traffic = None
+        roof = wl.roofline()
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 gfx950 correction +
+        # WRITE_SIZE, separate rocprofv3 --pmc runs of the same kernel); counters cannot be read inside this process
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
             if args.config in tj:
-                traffic = tj[args.config]["bytes_per_kmer_measured"] * kmers_per_launch
+                roof["traffic"] = tj[args.config]["bytes_per_kmer_measured"] * roof["kmers_per_launch"]
+                roof["traffic_source"] = TRAFFIC_FILE + " (offline rocprofv3 --pmc passes of this kernel, scaled by " \
+                                                        "k-mers per launch; not measured in this run)"
         except Exception:
-            traffic = None
+            roof["traffic"] = None
+        workload = cfg["desc"]
+        if world > 1 and args.config == "c2" and n_reads == SHARD_READS_MULTI:
+            workload = (f"NtHash k=31 canonical, 1 hash/k-mer, {world} x 125M x 150bp shards of the 1B-read job "
+                        f"(BASELINE config 5)")
+        elif n_reads != cfg["reads"]:
+            workload = cfg["desc"] + f" [REDUCED to {n_reads} reads/GPU]"
         res = {
             "metric": "k-mers hashed/sec (canonical, k=%d, %dbp reads)" % (k, L),
             "value": total_kmers / dt,
@@ -256,25 +417,62 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": cfg["desc"] if n_reads == cfg["reads"] else
-                       cfg["desc"] + f" [REDUCED to {n_reads} reads/GPU]",
-                       "reads_per_gpu": n_reads, "read_len": L, "k": k, "hashes_per_kmer": per,
-                       "launches_per_step": n_chunks, "input": "ASCII, device-resident",
-                       "parallelism": "reads sharded by rank, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": kernel_ms[0][1], "kernel_avg_ms": avg_ms,
-                         "bytes_per_kmer": b_per_kmer, "kmers_per_launch": kmers_per_launch},
-            "verified_vs_oracle": verified,
+            "config": {"workload": workload, "reads_per_gpu": n_reads, "read_len": L, "k": k,
+                       "hashes_per_kmer": wl.per, "launches_per_step": wl.n_chunks, "input": "ASCII, device-resident",
+                       "parallelism": "reads sharded by rank, no data-path collective"},
+            "roofline": roof,
+            "verify": verify,
+            "verified_vs_oracle": bool(all_ok),
+            "verified_full_stream_all_ranks": bool(checked_full),
+            "per_rank_kmers_per_s": per_rank,
         }
-        if world == 1 and not args.no_cpu_baseline:
+    # ---- N = 1 extras: measured ceiling, the other single-GPU configs, the CPU beside it ----------------------
+    if world == 1:
+        wl.free()
+        if not args.no_peak:
             try:
-                sample = args.cpu_sample_reads or (12_000_000 if cfg["seeds"] is None and m == 1 else
+                pk = measured_peak(torch, ctx, dev)
+                res["roofline"]["peak_measured"] = pk["best_GBps"]
+                res["roofline"]["frac_of_measured"] = res["roofline"]["achieved"] / pk["best_GBps"]
+                res["roofline"]["peak_measured_detail"] = pk
+            except Exception as e:
+                res["roofline"]["peak_measured"] = None
+                res["roofline"]["peak_measured_error"] = str(e)
+        if not args.no_secondary and args.config == "c2" and not args.reads:
+            sec = {}
+            for name in ("c3", "c4", "ref"):
+                try:
+                    c2 = dict(CONFIGS[name])
+                    w2 = Workload(torch, ctx, dev, name, c2, c2["reads"], 0)
+                    w2.step(False)
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    km = 0
+                    for _ in range(3):
+                        km += w2.step(True)
+                    torch.cuda.synchronize(dev)
+                    d2 = time.perf_counter() - t0
+                    r2 = w2.roofline()
+                    v2 = w2.verify()
+                    sec[name] = {"workload": c2["desc"], "value": km / d2, "unit": "kmers/s", "steps": 3,
+                                 "ms_per_step": d2 / 3 * 1e3, "launches_per_step": w2.n_chunks,
+                                 "kernel": r2["kernel"], "kernel_ms_per_step": r2["kernel_avg_ms"] * w2.n_chunks,
+                                 "bytes_per_kmer": r2["bytes_per_kmer"], "achieved_GBps": r2["achieved"],
+                                 "frac": r2["frac"], "verify_ok": v2["ok"], "spot_vs_oracle": v2["spot_vs_oracle"],
+                                 "sum": v2["sum"], "xor": v2["xor"]}
+                    w2.free()
+                except Exception as e:
+                    sec[name] = {"error": str(e)}
+            res["secondary"] = sec
+        if not args.no_cpu_baseline:
+            try:
+                sample = args.cpu_sample_reads or (12_000_000 if cfg["seeds"] is None and cfg["m"] == 1 else
                                                    6_000_000 if cfg["seeds"] is None else 600_000)
                 sample = min(sample, n_reads)
                 res["cpu_baseline"] = cpu_baseline(cfg, sample)
             except Exception as e:
                 res["cpu_baseline"] = {"value": None, "error": str(e)}
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,6 +1,6 @@
 """Build the nthash_amd native libraries in-tree with hipcc (gfx950 only).
 
-    python -m nthash_amd.build [--force] [--tag T --flags "-DX=1 ..."]
+    python -m nthash_amd.build [--force] [--tag T --flags "-DX=1 ..." [--units capi_kmer_runs,...]]
 
 libnthash_hip.so  the C-ABI (include/nthash_hip.h): HIP kernels + launch logic, one object per
                   csrc/capi_*.hip, compiled in parallel and rebuilt only when a file it includes changed
@@ -70,14 +70,20 @@ def _compile_unit(hipcc, unit, objdir, extra, force, verbose):
     return obj, True
 
 
-def build_hip(out_so=HIP_SO, objdir=OBJ, extra=(), force=False, verbose=False):
+def build_hip(out_so=HIP_SO, objdir=OBJ, extra=(), force=False, verbose=False, only_units=None):
+    """only_units: compile just these units with `extra` into objdir and take every other object from the
+    base build (a variant of one kernel does not need the other eleven units rebuilt)."""
     os.makedirs(os.path.dirname(out_so), exist_ok=True)
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     units = hip_units()
-    jobs = min(len(units), max(1, (os.cpu_count() or 2)))
+    mine = [u for u in units if only_units is None or u[:-4] in only_units]
+    jobs = min(len(mine), max(1, (os.cpu_count() or 2)))
     with concurrent.futures.ThreadPoolExecutor(jobs) as pool:
-        res = list(pool.map(lambda u: _compile_unit(hipcc, u, objdir, extra, force, verbose), units))
+        res = list(pool.map(lambda u: _compile_unit(hipcc, u, objdir, extra, force, verbose), mine))
+    if only_units is not None:
+        build_hip(verbose=verbose)  # the base objects
+        res += [(os.path.join(OBJ, u[:-4] + ".o"), False) for u in units if u not in mine]
     objs = [o for o, _ in res]
     if any(ch for _, ch in res) or _newer(out_so, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", out_so, "-lpthread"]
@@ -106,9 +112,10 @@ def build(force=False, verbose=False):
     return HIP_SO
 
 
-def build_variant(tag, flags, force=False, verbose=False):
+def build_variant(tag, flags, force=False, verbose=False, only_units=None):
     out = os.path.join(LIB, "ab", f"libnthash_hip_{tag}.so")
-    return build_hip(out_so=out, objdir=os.path.join(OBJ, "ab_" + tag), extra=flags, force=force, verbose=verbose)
+    return build_hip(out_so=out, objdir=os.path.join(OBJ, "ab_" + tag), extra=flags, force=force, verbose=verbose,
+                     only_units=only_units)
 
 
 if __name__ == "__main__":
@@ -117,7 +124,8 @@ if __name__ == "__main__":
     if "--tag" in argv:
         tag = argv[argv.index("--tag") + 1]
         flags = shlex.split(argv[argv.index("--flags") + 1]) if "--flags" in argv else []
-        print(build_variant(tag, flags, force=force, verbose=True))
+        units = argv[argv.index("--units") + 1].split(",") if "--units" in argv else None
+        print(build_variant(tag, flags, force=force, verbose=True, only_units=units))
     else:
         build(force=force, verbose=True)
         print(HIP_SO)

@@ -301,6 +301,16 @@ class Reference(Oracle):
         R.ref_bench_seed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint, C.POINTER(C.c_char_p),
                                      C.c_uint, C.c_uint, C.c_uint, C.c_int, _u64p]
         R.ref_max_threads.restype = C.c_int
+        # older prebuilt _ref libraries lack the synthetic-workload helpers
+        self.has_synth = hasattr(R, "ref_synth_checksum") and hasattr(R, "ref_bench_synth")
+        if self.has_synth:
+            R.ref_synth_checksum.restype = None
+            R.ref_synth_checksum.argtypes = [C.c_uint64, C.c_uint64, C.c_uint, C.c_uint64, C.POINTER(C.c_char_p),
+                                             C.c_uint, C.c_uint, C.c_uint, C.c_int, _u64p, _u64p, _u64p]
+            R.ref_bench_synth.restype = C.c_double
+            R.ref_bench_synth.argtypes = [C.c_uint64, C.c_uint64, C.c_uint, C.c_uint64, C.POINTER(C.c_char_p),
+                                          C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_int, _u64p, _u64p,
+                                          C.POINTER(C.c_int)]
 
     def fn_name(self):
         return self.R.ref_fn_name().decode()
@@ -412,3 +422,23 @@ class Reference(Oracle):
 
     def max_threads(self):
         return self.R.ref_max_threads()
+
+    def synth_checksum(self, first_read, n_reads, length, k, m, seeds=None, seed=42, threads=0):
+        """(sum, xor, total) over EVERY hash of the synthetic reads [first_read, first_read + n_reads):
+        NtHash(k, m), or SeedNtHash(seeds, m per seed).  OpenMP over reads, no read buffer."""
+        sa = _SeedArr(seeds or [])
+        s_, x_, t_ = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self.R.ref_synth_checksum(first_read, n_reads, length, seed, sa.arr if sa.n else None, sa.n, k, m, threads,
+                                  C.byref(s_), C.byref(x_), C.byref(t_))
+        return s_.value, x_.value, t_.value
+
+    def bench_synth(self, first_read, n_reads, length, k, m, seeds=None, seed=42, threads=1, repeats=1):
+        """Seconds the reference needs for the reads (timed inside the library: warm thread pool, reads first
+        touched by the thread that hashes them); returns (seconds, k-mers, threads used)."""
+        sa = _SeedArr(seeds or [])
+        nk, acc, used = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+        sec = self.R.ref_bench_synth(first_read, n_reads, length, seed, sa.arr if sa.n else None, sa.n, k, m, threads,
+                                     repeats, C.byref(nk), C.byref(acc), C.byref(used))
+        if sec < 0:
+            raise MemoryError("ref_bench_synth: allocation failed")
+        return sec, nk.value, used.value

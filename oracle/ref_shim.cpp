@@ -10,7 +10,9 @@
 //   (c) bench.py can time the true reference as the CPU baseline.
 #include <nthash/nthash.hpp>
 
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -257,6 +259,131 @@ uint64_t ref_bench_seed(const char* seqs, uint64_t n_reads, unsigned len,
   }
   *n_kmers = cnt;
   return acc;
+}
+
+// ---- whole-workload helpers on the counter-based synthetic reads (read r, 32-base word w ->
+// splitmix64(seed + r*W + w), 2 bits per base).  The generator is ours; every hash comes from the reference.
+static inline uint64_t shim_splitmix64(uint64_t x)
+{
+  uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static inline void shim_synth_read(char* out, uint64_t r, unsigned len, uint64_t seed)
+{
+  static const char ACGT[4] = { 'A', 'C', 'G', 'T' };
+  const uint64_t W = (len + 31) / 32;
+  for (uint64_t w = 0; w < W; w++) {
+    const uint64_t x = shim_splitmix64(seed + r * W + w);
+    for (unsigned j = 0; j < 32 && w * 32 + j < len; j++) out[w * 32 + j] = ACGT[(x >> (2 * j)) & 3];
+  }
+}
+
+// wrapping sum and XOR of EVERY hash the reference emits for reads [first_read, first_read + n_reads) of the
+// synthetic workload; seeds == NULL: NtHash(k, m), else SeedNtHash(seeds, m per seed).  Reads are generated by
+// the thread that hashes them (no 15 GB buffer), OpenMP over reads.
+void ref_synth_checksum(uint64_t first_read, uint64_t n_reads, unsigned len, uint64_t seed,
+                        const char* const* seeds, unsigned n_seeds, unsigned k, unsigned m, int threads,
+                        uint64_t* sum_out, uint64_t* xor_out, uint64_t* total_out)
+{
+  std::vector<std::string> sv;
+  for (unsigned i = 0; i < n_seeds; i++) sv.emplace_back(seeds[i]);
+  const unsigned per = n_seeds ? n_seeds * m : m;
+  uint64_t sum = 0, xr = 0, cnt = 0;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel reduction(+ : sum, cnt) reduction(^ : xr)
+#endif
+  {
+    std::vector<char> buf(len + 1);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int64_t i = 0; i < (int64_t)n_reads; i++) {
+      shim_synth_read(buf.data(), first_read + (uint64_t)i, len, seed);
+      if (n_seeds) {
+        nthash::SeedNtHash h(buf.data(), len, sv, (uint8_t)m, (uint16_t)k);
+        while (h.roll()) {
+          const uint64_t* hv = h.hashes();
+          for (unsigned j = 0; j < per; j++) { sum += hv[j]; xr ^= hv[j]; }
+          cnt++;
+        }
+      } else {
+        nthash::NtHash h(buf.data(), len, (uint8_t)m, (uint16_t)k);
+        while (h.roll()) {
+          const uint64_t* hv = h.hashes();
+          for (unsigned j = 0; j < per; j++) { sum += hv[j]; xr ^= hv[j]; }
+          cnt++;
+        }
+      }
+    }
+  }
+  *sum_out = sum;
+  *xor_out = xr;
+  *total_out = cnt;
+}
+
+// CPU baseline, timed inside: the reads are generated (untimed) by the threads that will hash them -- first touch
+// on their own NUMA node, thread pool warm -- then the same static partition is hashed the way
+// examples/benchmark.cpp uses the library (iterator per read, every hash consumed).  Returns seconds.
+double ref_bench_synth(uint64_t first_read, uint64_t n_reads, unsigned len, uint64_t seed,
+                       const char* const* seeds, unsigned n_seeds, unsigned k, unsigned m, int threads,
+                       int repeats, uint64_t* n_kmers, uint64_t* acc_out, int* threads_used)
+{
+  std::vector<std::string> sv;
+  for (unsigned i = 0; i < n_seeds; i++) sv.emplace_back(seeds[i]);
+  const unsigned per = n_seeds ? n_seeds * m : m;
+  char* data = (char*)malloc((size_t)n_reads * len + 64); // untouched pages: placed by the first writer
+  if (!data) return -1.0;
+  uint64_t acc = 0, cnt = 0;
+  int used = 1;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+  {
+#pragma omp single
+    used = omp_get_num_threads();
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n_reads; i++) shim_synth_read(data + (uint64_t)i * len, first_read + (uint64_t)i, len, seed);
+  }
+  const double t0 = omp_get_wtime();
+#else
+  for (uint64_t i = 0; i < n_reads; i++) shim_synth_read(data + i * len, first_read + i, len, seed);
+  const auto c0 = std::chrono::steady_clock::now();
+#endif
+  for (int rep = 0; rep < (repeats > 0 ? repeats : 1); rep++) { // the same reads again: a longer, steadier sample
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(+ : acc, cnt)
+#endif
+  for (int64_t r = 0; r < (int64_t)n_reads; r++) {
+    if (n_seeds) {
+      nthash::SeedNtHash h(data + (uint64_t)r * len, len, sv, (uint8_t)m, (uint16_t)k);
+      while (h.roll()) {
+        const uint64_t* hv = h.hashes();
+        for (unsigned j = 0; j < per; j++) acc += hv[j];
+        cnt++;
+      }
+    } else {
+      nthash::NtHash h(data + (uint64_t)r * len, len, (uint8_t)m, (uint16_t)k);
+      while (h.roll()) {
+        const uint64_t* hv = h.hashes();
+        for (unsigned j = 0; j < per; j++) acc += hv[j];
+        cnt++;
+      }
+    }
+  }
+  }
+#ifdef _OPENMP
+  const double sec = omp_get_wtime() - t0;
+#else
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+#endif
+  free(data);
+  *n_kmers = cnt;
+  *acc_out = acc;
+  *threads_used = used;
+  return sec;
 }
 
 int ref_max_threads()

@@ -1,0 +1,114 @@
+"""GPU tests of bench.py itself and of the full-size workloads (run with -m gpu on an MI355X).
+
+* `python bench.py --gpus 2` must really run two ranks (it launches them itself); on a 1-GPU box the two ranks
+  share the GPU over a gloo group (NTHASH_BENCH_SHARE_GPU=1) -- the control flow, the sharding, the max-over-ranks
+  time and the all-rank verification are the ones an 8-GPU run uses.
+* BASELINE config 5's per-GPU shard (125 M x 150 bp) and the chunked full-size configs 3 / 4 are checked through the
+  on-device checksum of the whole hash stream against the checksums the REAL reference produced for the same reads
+  (tests/golden/bench_checksums.json, tests/golden/gen_bench_checksums.py).
+Nothing here reads /root/reference.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*argv, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], cwd=ROOT, env=e, capture_output=True,
+                       text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_self_launch():
+    """--gpus 2 without a launcher: two ranks, each its own shard, whole-job value, every rank verified"""
+    res = run_bench("--gpus", "2", "--reads", "2000000", "--steps", "2", "--warmup", "1",
+                    env={"NTHASH_BENCH_SHARE_GPU": "1"})
+    assert res["n_gpus"] == 2
+    assert res["scaling"] == "weak"
+    assert res["verified_vs_oracle"] is True
+    assert len(res["per_rank_kmers_per_s"]) == 2 and all(v > 0 for v in res["per_rank_kmers_per_s"])
+    # whole-job value = both ranks' k-mers over the max-over-ranks time
+    kmers = 2 * 2 * 2_000_000 * 120
+    assert abs(res["value"] - kmers / (res["ms_per_step"] * 2 * 1e-3)) / res["value"] < 1e-6
+    assert res["roofline"]["frac"] > 0 and res["roofline"]["kernel"] == "kmer_runs_kernel"
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import torch
+    have = torch.cuda.device_count()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1), "--reads", "1000"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "n_gpus" not in p.stdout
+    assert "refusing" in (p.stdout + p.stderr)
+
+
+def test_bench_rejects_world_size_mismatch():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--reads", "1000"], cwd=ROOT,
+                       env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0 and "n_gpus" not in p.stdout
+
+
+def _entry(name, first, n):
+    for e in load_golden("bench_checksums.json"):
+        if (e["workload"], e["first_read"], e["n_reads"]) == (name, first, n):
+            return e
+    raise KeyError((name, first, n))
+
+
+@pytest.mark.parametrize("rank", [0, 5])
+def test_config5_shard_full_size_checksum(ctx, rank):
+    """125 M x 150 bp -- one GPU's share of the 1 G-read job -- hashed in one call; checksum of all 15 G hashes
+    against the reference's for reads [rank*125 M, (rank+1)*125 M)"""
+    n, L, k = 125_000_000, 150, 31
+    want = _entry("c2", rank * n, n)
+    nwin = L - k + 1
+    d_in = ctx.malloc(n * L)
+    d_out = ctx.malloc(n * nwin * 8)
+    try:
+        ctx.synth_reads_ptr(d_in, rank * n, n, L, 42)
+        tot = ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, 1, d_out, n * nwin)
+        assert tot == want["total"] == n * nwin
+        s, x = ctx.checksum_ptr(d_out, tot)
+        assert (format(s, "016x"), format(x, "016x")) == (want["sum"], want["xor"])
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+
+
+@pytest.mark.parametrize("config", ["c3", "c4", "ref"])
+def test_full_size_chunked_configs_checksum(config):
+    """configs 3 / 4 (outputs of 384 / 528 GB: produced chunk by chunk into a ring) and the reference's own
+    benchmark shape at full size, through bench.py's code path: whole stream == the reference's checksum"""
+    res = run_bench("--config", config, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-peak")
+    assert res["verify"]["ok"] is True, res["verify"]
+    assert res["verify"]["spot_vs_oracle"] is True
+    assert res["config"]["launches_per_step"] >= (2 if config in ("c3", "c4") else 1)
+    assert "REDUCED" not in res["config"]["workload"]
+
+
+def test_bench_default_line_has_all_parts():
+    """the default run at a reduced size: every object the contract names is there"""
+    res = run_bench("--reads", "4000000", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "200000")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in res, key
+    r = res["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["peak_measured"] and 2000 < r["peak_measured"] < 8000
+    assert res["cpu_baseline"]["value"] > 0 and res["cpu_baseline"]["cores"] == 1
+    assert "REDUCED" in res["config"]["workload"]
+    assert res["verified_vs_oracle"] is True

@@ -206,3 +206,34 @@ def test_get_blocks_examples(oracle):
         [(0, 31)], [2, 5, 8, 11, 14, 16, 19, 22, 25, 28])
     assert oracle.get_blocks("11100111") == ([(0, 3), (5, 8)], [])
     assert oracle.get_blocks("101101") == ([(2, 4)], [0, 5])
+
+
+def test_bench_checksum_fixture_small_entries_vs_oracle(oracle):
+    """tests/golden/bench_checksums.json (made by the REAL reference, gen_bench_checksums.py) is what bench.py
+    verifies the full-size streams against; its small entries pin the file's format and the shard layout
+    (first_read = rank * 125 M) against the C restatement."""
+    for e in load_golden("bench_checksums.json"):
+        if e["n_reads"] > 50_000:
+            assert e["total"] == e["n_reads"] * (e["len"] - e["k"] + 1)
+            continue
+        data = oracle.synth_reads(e["first_read"], e["n_reads"], e["len"], e["seed"])
+        offs = np.arange(e["n_reads"] + 1, dtype=np.uint64) * e["len"]
+        if e["seeds"]:
+            r = oracle.seed_batch(data, offs, e["seeds"], e["k"], e["m"], want_pos=False)
+        else:
+            r = oracle.kmer_batch(data, offs, e["k"], e["m"], want_pos=False)
+        s, x = oracle.checksum(r["hashes"])
+        assert (int(r["total"]), format(s, "016x"), format(x, "016x")) == (e["total"], e["sum"], e["xor"])
+
+
+def test_reference_synth_checksum_matches_batch_checksum(oracle, reference):
+    """the OpenMP on-the-fly checksum helper of the reference shim == checksum of its batch output"""
+    if not reference.has_synth:
+        pytest.skip("prebuilt oracle/_ref without the synthetic-workload helpers")
+    for (first, n, L, k, m, seeds) in [(7, 3000, 150, 31, 2, None), (10**9, 500, 250, 31, 3, ["1" * 15 + "0" + "1" * 15])]:
+        data = reference.synth_reads(first, n, L, 42)
+        offs = np.arange(n + 1, dtype=np.uint64) * L
+        r = (reference.seed_batch(data, offs, seeds, k, m, want_pos=False) if seeds
+             else reference.kmer_batch(data, offs, k, m, want_pos=False))
+        s, x = reference.checksum(r["hashes"])
+        assert reference.synth_checksum(first, n, L, k, m, seeds=seeds, threads=3) == (s, x, int(r["total"]))
