@@ -32,6 +32,19 @@
 namespace ntamd {
 
 constexpr int KR_MAX_THREADS = 1024;
+// Ablation builds (tools/ab_build.sh, WRONG results by design): where does the time of the headline kernel go?
+//   KR_ABL_NOHASH   no first window, no rolls: staging + LDS copy-out + the memory streams only
+//   KR_ABL_NOSTORE  the hash stream is not written (everything else as usual)
+//   KR_ABL_NOLOAD   the next slab is not read (the first one is hashed again and again)
+#ifndef KR_ABL_NOHASH
+#define KR_ABL_NOHASH 0
+#endif
+#ifndef KR_ABL_NOSTORE
+#define KR_ABL_NOSTORE 0
+#endif
+#ifndef KR_ABL_NOLOAD
+#define KR_ABL_NOLOAD 0
+#endif
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
 struct KmerRunsArgs {
@@ -227,6 +240,14 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
       // lanes without an item re-read item 0 so that every lane issues both loads
       const uint32_t i0 = lane < nxt.n_vec ? lane : 0u;
       const uint8_t* p0 = a.seqs + nxt.byte0 + ((uint64_t)i0 << 4);
+#if KR_ABL_NOLOAD
+      (void)p0;
+      pv0 = v4u{0x41414141u, 0x43434343u, 0x47474747u, 0x54545454u};
+      pv1 = pv0;
+      pw = 0x41434754u;
+      dirty_seen = 0;
+      asm volatile("" : "+v"(pv0), "+v"(pv1), "+v"(pw), "+v"(dirty_seen));
+#else
       if constexpr (DT) {
         const uint32_t n_dw = (nxt.shift + nxt.slab_bytes + 3u) >> 2; // dwords in the slab
         const uint32_t j = 256u + lane < n_dw ? 256u + lane : 0u;
@@ -251,6 +272,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
                      : "v"(p0), "v"(p1), "v"(a.dirty)
                      : "memory");
       }
+#endif
     }
 
     // ---- this lane's run ----------------------------------------------------
@@ -260,6 +282,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
     const uint32_t q = gl - lr * a.rpr;                   // run inside the read
     const uint32_t b0 = shift + lr * a.stride + q * C;    // first base of the first window
     const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
+#if KR_ABL_NOHASH
+    (void)d0; (void)sh0;
+    tile[lane] = (uint64_t)b0; // (keeps the geometry alive)
+#else
     uint32_t w[NW];
     {
       uint32_t lo = bits[d0];
@@ -374,6 +400,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
       for (uint32_t jw = 0; jw * 16u + 1u < C; ++jw) roll_word(jw, std::integral_constant<uint32_t, 0u>{});
     }
 
+#endif // KR_ABL_NOHASH
+
     // ---- copy the tile out: 64*C*m consecutive values of the hash stream ------
     lds_sync();
     uint64_t* const out0 = a.hashes + g0 * vals_per_run;
@@ -395,7 +423,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
 #define KR_LD(n, var) \
         if constexpr ((n) < NFULL) var = src[(n) * 64u]; \
         else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) var = src[(n) * 64u]; }
+#if KR_ABL_NOSTORE
+#define KR_ST1(p, var) asm volatile("" ::"v"((p)), "v"((var).x), "v"((var).y), "v"((var).z), "v"((var).w))
+#else
 #define KR_ST1(p, var) stream_store16((p), var)
+#endif
 #define KR_ST(n, var) \
         if constexpr ((n) < NFULL) KR_ST1(dst + (n) * 64u, var); \
         else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) KR_ST1(dst + (n) * 64u, var); }
@@ -410,7 +442,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
 #undef KR_LD
 #undef KR_ST
 #undef KR_ST1
-        counted = true;
+        counted = !KR_ABL_NOSTORE;
       } else {
         for (uint32_t pi = lane; pi < n_pairs; pi += 64u) {
           const uint4 dv = *(const uint4*)(tile + 2u * pi);

@@ -408,13 +408,33 @@ static __global__ __launch_bounds__(256) void copy_kernel(uint4* __restrict__ ds
     dst[i] = src[i];
 }
 
-// write-only yardstick: every wave instruction stores one contiguous KiB
-static __global__ __launch_bounds__(256) void fill16_kernel(uint4* __restrict__ dst, uint64_t n16, uint32_t value)
+// write-only yardstick, shaped like the hash kernels' copy-out: one block per CU streams through its own
+// contiguous range, every wave writes whole tiles of FILL_TILE_KIB contiguous KiB, one KiB per store instruction
+#ifndef FILL_TILE_KIB
+#define FILL_TILE_KIB 8
+#endif
+#ifndef FILL_STORE_POLICY
+#define FILL_STORE_POLICY ""
+#endif
+static __global__ __launch_bounds__(1024) void fill16_kernel(uint4* __restrict__ dst, uint64_t n16, uint32_t value)
 {
-  const v4u v = {value, value ^ 0x55555555u, ~value, value ^ 0xAAAAAAAAu};
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const v4u v = {value, value ^ 0x55555555u, ~value, lane};
+  constexpr uint64_t TILE = (uint64_t)FILL_TILE_KIB * 64u; // uint4 per tile
+  const uint64_t n_tiles = n16 / TILE;
+  const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const uint64_t t0 = (uint64_t)blockIdx.x * per;
+  const uint64_t t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+  for (uint64_t t = t0 + wave; t < t1; t += n_waves) {
+    uint4* p = dst + t * TILE + lane;
+#pragma unroll
+    for (uint32_t j = 0; j < (uint32_t)FILL_TILE_KIB; ++j)
+      asm volatile("global_store_dwordx4 %0, %1, off" FILL_STORE_POLICY "\n\ts_nop 1" ::"v"(p + j * 64u), "v"(v) : "memory");
+  }
+  // the tail that is not a whole tile
+  for (uint64_t i = n_tiles * TILE + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
        i += (uint64_t)gridDim.x * blockDim.x)
-    __builtin_nontemporal_store(v, (v4u*)dst + i);
+    *((v4u*)dst + i) = v;
 }
 
 // spans / offsets sanity (the kernels trust them): every read must satisfy starts[r] <= ends[r] <= buf_bytes
