@@ -136,7 +136,15 @@ def cpu_baseline(cfg, sample_reads):
         out.update(host)
         # the reference has no threaded path: this is OUR OpenMP parallel-for over reads around it.  One thread
         # per usable CPU, reads first-touched by the thread that hashes them, pool warm, sample >= 3 s.
-        nt = max(1, min(usable, ref.max_threads()))
+        # (threads the cgroup quota grants, not the CPUs the OS shows: a 16-CPU lease on a 256-CPU host)
+        quota = usable
+        try:
+            q, per = (_cgroup_cpu_max() or "max").split()[:2]
+            if q != "max":
+                quota = max(1, int(q) // int(per))
+        except Exception:
+            pass
+        nt = max(1, min(usable, quota))
         if nt > 1:
             n_mt = min(cfg["reads"], max(sample_reads, 250_000 * nt))
             sec1, nk1, used = ref.bench_synth(0, n_mt, L, k, m, seeds=seeds, threads=nt)  # calibration pass
@@ -145,8 +153,8 @@ def cpu_baseline(cfg, sample_reads):
             out["openmp"] = {"value": nk2 / sec2, "unit": "kmers/s", "cores": used,
                              "speedup_vs_1_thread": (nk2 / sec2) / out["value"],
                              "sample": f"{n_mt} reads x {reps} passes, {nk2} k-mers in {sec2:.2f}s",
-                             "note": "OpenMP parallel-for over reads added by the harness; threads = usable CPUs "
-                                     "(SMT siblings included)"}
+                             "note": "OpenMP parallel-for over reads added by the harness; threads = CPUs the "
+                                     "cgroup quota grants (cpu.max) out of the usable ones"}
         return out
     impl = ref if ref is not None else Oracle()
     data = impl.synth_reads(0, sample_reads, L, 42)

@@ -242,6 +242,11 @@ void load_tuning(nthip_tune& t)
   t.no_m4 = is_set("NTHIP_TUNE_NO_M4");
   t.no_autotune = is_set("NTHIP_TUNE_NO_AUTOTUNE");
   t.no_seed_wave = is_set("NTHIP_TUNE_NO_SEED_WAVE");
+  t.no_phases = is_one("NTHIP_TUNE_NO_PHASES");
+  t.pacing = is_one("NTHIP_TUNE_PACING");
+  t.ph_tiles = num("NTHIP_TUNE_PH_TILES", 1, 64);
+  t.ph_period = num("NTHIP_TUNE_PH_PERIOD", 1, 10000000);
+  t.ph_read = num("NTHIP_TUNE_PH_READ", 1, 10000000);
 }
 } // namespace
 
@@ -282,8 +287,8 @@ extern "C" int nthip_ctx_create(int device, nthip_ctx** out)
   c->n_cu = prop.multiProcessorCount;
   c->lds_max = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&c->d_small, 64) != hipSuccess ||
-      hipHostMalloc((void**)&c->h_small, 64) != hipSuccess ||
+      hipMalloc((void**)&c->d_small, 256) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_small, 256) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return fail(NTHIP_ERR_HIP, "context resource creation failed: %s", hipGetErrorString(hipGetLastError()));

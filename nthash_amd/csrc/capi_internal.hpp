@@ -75,6 +75,12 @@ struct nthip_tune {
   bool no_m4 = false;       // NTHIP_TUNE_NO_M4 (set): runtime-m instantiation for m = 4
   bool no_autotune = false; // NTHIP_TUNE_NO_AUTOTUNE (set)
   bool no_seed_wave = false; // NTHIP_TUNE_NO_SEED_WAVE (set)
+  // phased headline kernel (kmer_runs_kernel.hpp): tiles per wave and period, period / read window in 10 ns ticks
+  bool no_phases = false;   // NTHIP_TUNE_NO_PHASES=1: the static loop (one tile ahead) instead of dynamic chunks
+  bool pacing = false;      // NTHIP_TUNE_PACING=1: chunk loads in chip-wide windows of the 100 MHz clock
+  uint32_t ph_tiles = 0;    // NTHIP_TUNE_PH_TILES
+  uint32_t ph_period = 0;   // NTHIP_TUNE_PH_PERIOD
+  uint32_t ph_read = 0;     // NTHIP_TUNE_PH_READ
 };
 
 struct nthip_ctx {
@@ -214,7 +220,7 @@ int get_kmer_tab(nthip_ctx* c, uint32_t k, const uint4** out);
 
 // Plan for the headline run-split kernel: run length C | nwin, waves per block, LDS bytes.
 struct RunsPlan {
-  uint32_t C = 0, rpr = 0, waves = 0, bits_dwords = 0, tile_u64 = 0, nw = 0, dword_tail = 0;
+  uint32_t C = 0, rpr = 0, waves = 0, bits_dwords = 0, tile_u64 = 0, nw = 0, dword_tail = 0, ph_tiles = 0;
   size_t lds = 0;
 };
 bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, RunsPlan* p);
@@ -239,6 +245,8 @@ void fill_gen_args(KmerRunsGenArgs& ga, nthip_ctx* c, const Staged& st, const nt
 // ---- kernel launchers, one TU each ----------------------------------------------------------------------------
 // capi_kmer_runs.hip: the k = 31 instantiations of kmer_runs_kernel (C = 15 | nwin, or 30 for m = 1)
 int launch_kmer_runs_special(nthip_ctx* c, const KmerRunsArgs& ra, const RunsPlan& plan, bool dword_tail);
+// whether that unit was built with the chunked path (KR_CHUNKED; an A/B build of the unit may differ from the plan's)
+bool kmer_runs_chunked_compiled();
 // capi_kmer_gen.hip: kmer_runs_gen_kernel<NW, DT, false>
 int launch_kmer_gen_dense(nthip_ctx* c, const KmerRunsGenArgs& ga, size_t lds, uint32_t nw, bool dt);
 // capi_kmer_na.hip

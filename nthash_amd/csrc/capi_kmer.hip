@@ -108,12 +108,13 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16
       ra.tile_u64 = plan.tile_u64;
       ra.inv_rpr = 65536u / plan.rpr + 1u;
       ra.dword_tail = plan.dword_tail;
+      ra.ph_tiles = plan.ph_tiles;
       // one tile group per block (set in launch_kmer_runs); NTHIP_TUNE_TILE_MAP overrides for A/B runs
       ra.tile_map = c->tune.has_tile_map ? c->tune.tile_map : 0xFFFFFFFFu;
       memcpy(ra.tab, a.tab, sizeof ra.tab);
       memcpy(ra.mult, a.mult, sizeof ra.mult);
       // NTHIP_TUNE_NO_DWORD_TAIL=1: A/B switch for the slab-tail staging variant (tools/ablate.py)
-      const bool dt = plan.dword_tail != 0 && !c->tune.no_dword_tail;
+      const bool dt = plan.dword_tail != 0;
       rc = launch_kmer_runs_special(c, ra, plan, dt);
     } else if (!rows_only && kmer_gen_plan(c, len, stride, k, m, &gplan)) {
       // any other shape: general run-split kernel (kmer_runs_gen_kernel.hpp)

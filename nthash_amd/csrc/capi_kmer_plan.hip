@@ -125,17 +125,23 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
   // reads touched by one wave tile (64 consecutive runs)
   const uint32_t slab_reads = (64 % p->rpr == 0) ? 64 / p->rpr : (p->rpr - 1 + 63) / p->rpr + 1;
   const uint64_t slab_bytes = (uint64_t)(slab_reads - 1) * stride + len;
-  uint32_t bd = (uint32_t)((15 + slab_bytes + 15) >> 4) + p->nw + 4;
+  constexpr uint32_t AL = KR_SLAB_ALIGN - 1; // a slab starts on an aligned address at or below its first byte
+  uint32_t bd = (uint32_t)((AL + slab_bytes + 15) >> 4) + p->nw + 4;
   bd = (bd + 3u) & ~3u;
   p->bits_dwords = bd;
-  p->dword_tail = (15 + slab_bytes <= 1280) ? 1u : 0u;
+  p->dword_tail = (AL + slab_bytes <= 1280 && !c->tune.no_dword_tail) ? 1u : 0u;
   const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
-  const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4;
+  // chunked path (kmer_runs_kernel.hpp, only when compiled in): every wave keeps the bit streams of a chunk's tiles
+  // in LDS and is limited to 8 waves per CU
+  const bool chunked = kmer_runs_chunked_compiled() && p->dword_tail && !c->tune.no_phases && (m == 1 || c->tune.ph_tiles);
+  p->ph_tiles = chunked ? (c->tune.ph_tiles ? (c->tune.ph_tiles < 16u ? c->tune.ph_tiles : 16u) : 16u) : 0u;
+  const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4 * (p->ph_tiles ? p->ph_tiles : 1u);
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
-  // 8 waves per CU measured 1.5-2 % faster than 16 on the HBM-bound C2 shape; with m > 1 the copy-out does the
-  // multi-hash expansion and more waves hide it: 16 waves +6 % (m=4), +9 % (m=8)  (profiles/r01_notes.md)
-  uint32_t w_max = m == 1 ? 8 : 16;
+  // m = 1: 16 waves per CU measured 1.3-2.9 % faster than 8 once the tile geometry runs on the scalar unit (round 1:
+  // 8 were 2 % ahead); m > 1: the copy-out does the multi-hash expansion and more waves hide it (+6 % m=4, +9 % m=8)
+  uint32_t w_max = 16;
   if (c->tune.waves) w_max = c->tune.waves;
+  if (chunked && m == 1 && w_max > 8) w_max = 8; // (launch bounds of the chunked build's m = 1 kernels)
   for (uint32_t w = w_max; w >= 1; --w) {
     if (fixed + per_wave * w <= cap) {
       p->waves = w;

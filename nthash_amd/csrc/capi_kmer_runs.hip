@@ -16,15 +16,52 @@ int launch_kmer_runs(nthip_ctx* c, K kernel, KmerRunsArgs a, size_t dyn_lds)
   uint64_t grid = (uint64_t)c->n_cu * per_cu;
   if (grid > need) grid = need;
   if (a.tile_map == 0xFFFFFFFFu) a.tile_map = (uint32_t)grid; // every block streams its own range
+  if (a.ph_tiles) {
+    // chunks of ph_tiles tiles are handed out through a counter: enough blocks to fill the chip, however few tiles
+    a.chunk_counter = (uint32_t*)(c->d_small + 192);
+    HIPCHK(hipMemsetAsync(a.chunk_counter, 0, 4, c->stream));
+    const uint64_t n_chunks = (a.n_wtiles + a.ph_tiles - 1) / a.ph_tiles;
+    if (n_chunks > 0xFFFF0000ull) return fail(NTHIP_ERR_UNSUPPORTED, "too many reads for one call");
+    const uint64_t need2 = (n_chunks + a.waves - 1) / a.waves;
+    grid = (uint64_t)c->n_cu * per_cu;
+    if (grid > need2) grid = need2;
+  }
+  if (a.ph_tiles && c->tune.pacing) {
+    // period of the phased path = the time HBM needs for what the chip reads and writes in one period, apart:
+    // reads at ~6.0 TB/s, write-through stores at ~6.8 TB/s (measured with the hash switched off), in ticks of 10 ns
+    const double kmers = (double)grid * a.waves * a.ph_tiles * 64.0 * a.C;
+    const double t_r = kmers * a.len / a.nwin / 6.0e12, t_w = kmers * 8.0 * a.m / 6.8e12;
+    a.ph_read = c->tune.ph_read ? c->tune.ph_read : (uint32_t)((t_r + 1.5e-6) * 1e8);
+    a.ph_period = c->tune.ph_period ? c->tune.ph_period : (uint32_t)((t_r + t_w + 1.0e-6) * 1e8);
+    if (a.ph_read >= a.ph_period) a.ph_read = a.ph_period / 4;
+  }
+#if KR_DEBUG_TIMES
+  HIPCHK(hipMemsetAsync(c->d_small + 64, 0, 64, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_small + 64 + 48, 0xFF, 8, c->stream));
+#endif
   prof_begin(c, "kmer_runs_kernel");
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
   prof_end(c);
   HIPCHK(hipGetLastError());
+#if KR_DEBUG_TIMES
+  {
+    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(t, c->d_small + 64, 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const double nw = (double)grid * a.waves;
+    fprintf(stderr, "[kmer_runs phased] per wave, us: store drain %.0f  wait read window %.0f  load+pack %.0f  wait write window %.0f  "
+                    "hash+write %.0f  | wave elapsed min %.0f avg %.0f max %.0f  (period %u read %u ticks, P %u)\n",
+            t[0] / nw / 100.0, t[1] / nw / 100.0, t[2] / nw / 100.0, t[3] / nw / 100.0, t[4] / nw / 100.0, t[6] / 100.0,
+            t[7] / nw / 100.0, t[5] / 100.0, a.ph_period, a.ph_read, a.ph_tiles);
+  }
+#endif
   return NTHIP_OK;
 }
 
 } // namespace
 
+
+bool ntamd::host::kmer_runs_chunked_compiled() { return KR_CHUNKED != 0; }
 
 // ra.m selects the instantiation: m = 1 (configs 2 / 5; run length 15 or 30), m = 4 compile-time (config 3),
 // any other m at run time

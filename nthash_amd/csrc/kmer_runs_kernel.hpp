@@ -18,11 +18,10 @@
 // C-1 windows are rolled (next_forward_hash/next_reverse_hash,
 // src/kmer.cpp:84-94,164-174) with one 16-entry (in,out) pair-table lookup per
 // step.  Waves never synchronise with each other after the tables are loaded:
-// each wave stages its own ~1.2 KB slab of ASCII as a private 2-bit stream,
-// and the loads of the NEXT slab are issued before the current tile is hashed
-// and consumed after its stores have been issued with a counted s_waitcnt
-// (vmcnt is in-order on gfx950: an ordinary load after the stores would make
-// the wave wait for its own stores to be acknowledged).
+// each wave stages its own ~1.2 KB slab of ASCII as a private 2-bit stream.
+//
+// Round 2 (profiles/r02_notes.md): the kernel sits on the rate HBM gives a MIX of its two streams (13 % reads,
+// 87 % writes); apart, the streams run 10 % faster -- hence the phased path at the end of the kernel.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -32,6 +31,19 @@
 namespace ntamd {
 
 constexpr int KR_MAX_THREADS = 1024;
+// KR_CHUNKED=1 compiles the chunked path in (dynamic chunks of 16 tiles, the next chunk's 16 slabs in flight in 80
+// registers, optional chip-wide read windows: see the end of the kernel and profiles/r02_notes.md).  It needs the
+// m = 1 instantiations limited to 8 waves per CU (256 registers per lane); measured equal to or slower than the static
+// loop at 16 waves on every box tried, so it is off -- kept because it is the only structure in which HBM served the
+// two streams apart (17.3 ms against 18.8 ms per 100 M reads with the hash switched off).
+#ifndef KR_CHUNKED
+#define KR_CHUNKED 0
+#endif
+constexpr int KR_M1_THREADS = KR_CHUNKED ? 512 : 1024;
+// a slab starts at the read's first byte rounded down to this many bytes (16: one vector; 64 / 128: whole lines)
+#ifndef KR_SLAB_ALIGN
+#define KR_SLAB_ALIGN 16
+#endif
 // Ablation builds (tools/ab_build.sh, WRONG results by design): where does the time of the headline kernel go?
 //   KR_ABL_NOHASH   no first window, no rolls: staging + LDS copy-out + the memory streams only
 //   KR_ABL_NOSTORE  the hash stream is not written (everything else as usual)
@@ -45,7 +57,21 @@ constexpr int KR_MAX_THREADS = 1024;
 #ifndef KR_ABL_NOLOAD
 #define KR_ABL_NOLOAD 0
 #endif
+
+// KR_DEBUG_TIMES=1 (measurement builds): every wave of the phased path adds the ticks it spent waiting for its own
+// stores, waiting for the read window, loading + packing, waiting for the write window, and hashing + writing to five
+// counters behind the dirty flag (bytes 64..104 of the context's scratch), printed by the launcher
+#ifndef KR_DEBUG_TIMES
+#define KR_DEBUG_TIMES 0
+#endif
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+// counted wait: at most N vector-memory operations of this wave stay in flight
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 struct KmerRunsArgs {
   const uint8_t* seqs;
@@ -66,6 +92,11 @@ struct KmerRunsArgs {
   uint32_t inv_rpr;      // floor(65536 / rpr) + 1
   uint32_t dword_tail;   // every slab is <= 1280 bytes: tail staged as one dword per lane
   uint32_t tile_map;     // number of wave groups of the tile -> wave mapping (see the kernel)
+  // chunked path (DT shapes): tiles per chunk (0 = the static loop; every wave has that many bit streams in LDS),
+  // optional pacing (period and read window in ticks of the constant 100 MHz clock, 0 = none), the chunk counter
+  // (zeroed before the launch)
+  uint32_t ph_tiles, ph_period, ph_read;
+  uint32_t* chunk_counter;
   uint64_t tab[16][2];
   uint64_t mult[KF_MAX_RUNTIME_M];
 };
@@ -73,7 +104,7 @@ struct KmerRunsArgs {
 // C_T: compile-time run length (0 = runtime); NW: window words, k <= 16*NW;
 // DT: every slab is <= 1280 bytes, so its tail is staged as one dword per lane
 template <int K_T, int M_T, int C_T, int NW, bool DT>
-__global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRunsArgs a)
+__global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kmer_runs_kernel(const KmerRunsArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t k = K_T ? (uint32_t)K_T : a.k;
@@ -83,7 +114,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
 #ifndef KR_UNIFORM_WAVE
-#define KR_UNIFORM_WAVE 0
+#define KR_UNIFORM_WAVE 1 // (+1.5 % on C2: the tile geometry moves to the scalar unit)
 #endif
 #if KR_UNIFORM_WAVE
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6); // tile bookkeeping on the scalar unit
@@ -95,9 +126,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
   uint4* itab = (uint4*)lds_dyn;
   uint4* ptab = itab + ntab * 256u;
   uint64_t* mults = (uint64_t*)(ptab + 16);
-  uint32_t* wave_base = (uint32_t*)(mults + KF_MAX_RUNTIME_M) + wave * (a.tile_u64 * 2u + a.bits_dwords);
+  uint32_t* wave_base =
+      (uint32_t*)(mults + KF_MAX_RUNTIME_M) + wave * (a.tile_u64 * 2u + a.bits_dwords * (a.ph_tiles ? a.ph_tiles : 1u));
   uint64_t* tile = (uint64_t*)wave_base;
-  uint32_t* bits = wave_base + a.tile_u64 * 2u;
+  uint32_t* bits = wave_base + a.tile_u64 * 2u; // the bit stream being packed / hashed (ph_tiles of them when phased)
 
   for (uint32_t i = tid; i < ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
   if (tid < 16)
@@ -149,7 +181,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
     sl.runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
     const uint32_t n_slab_reads = (rm + sl.runs_here - 1u) / a.rpr + 1u;
     const uint64_t off = rf * a.stride;
-    sl.shift = (uint32_t)(((uint64_t)a.seqs + off) & 15u);
+    sl.shift = (uint32_t)(((uint64_t)a.seqs + off) & (uint32_t)(KR_SLAB_ALIGN - 1));
     sl.byte0 = off - sl.shift;
     sl.slab_bytes = (n_slab_reads - 1u) * a.stride + a.len;
     sl.n_vec = (sl.shift + sl.slab_bytes + 15u) >> 4;
@@ -209,299 +241,511 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_kernel(const KmerRun
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   };
 
-  Slab cur;
-  cur.byte0 = 0;
-  cur.shift = cur.slab_bytes = cur.n_vec = cur.runs_here = 0;
-  cur.edge = 1u;
-  if (wt < wt_end) {
-    cur = slab_of(wt * 64u, r_first, rem0);
-    stage(cur, 0u);
-  }
-  for (; wt < wt_end; wt += wstride) {
-    lds_sync();
-    const uint64_t g0 = wt * 64u;
-    const uint32_t shift = cur.shift, runs_here = cur.runs_here;
-    const uint32_t my_rem0 = rem0;
-    // ---- issue the loads of the NEXT tile's slab (two vectors per lane) --------
-    r_first += step_q;
-    rem0 += step_r;
-    if (rem0 >= a.rpr) { rem0 -= a.rpr; r_first += 1; }
-    const uint64_t nwt = wt + wstride;
-    const bool have_next = nwt < wt_end;
-    Slab nxt = cur;
-    if (have_next) nxt = slab_of(nwt * 64u, r_first, rem0);
-    // vector `lane` of the slab, plus its tail: slabs of at most 1280 bytes
-    // (a.dword_tail, the common case) finish with ONE DWORD per lane -- a second
-    // 16-byte round would leave most lanes idle --, longer slabs with a second vector
-    v4u pv0, pv1;
-    uint32_t pw;
-    uint32_t dirty_seen; // the batch-wide dirty flag, read along with the next slab
-    {
-      // lanes without an item re-read item 0 so that every lane issues both loads
-      const uint32_t i0 = lane < nxt.n_vec ? lane : 0u;
-      const uint8_t* p0 = a.seqs + nxt.byte0 + ((uint64_t)i0 << 4);
-#if KR_ABL_NOLOAD
-      (void)p0;
-      pv0 = v4u{0x41414141u, 0x43434343u, 0x47474747u, 0x54545454u};
-      pv1 = pv0;
-      pw = 0x41434754u;
-      dirty_seen = 0;
-      asm volatile("" : "+v"(pv0), "+v"(pv1), "+v"(pw), "+v"(dirty_seen));
-#else
-      if constexpr (DT) {
-        const uint32_t n_dw = (nxt.shift + nxt.slab_bytes + 3u) >> 2; // dwords in the slab
-        const uint32_t j = 256u + lane < n_dw ? 256u + lane : 0u;
-        const uint8_t* p1 = a.seqs + nxt.byte0 + ((uint64_t)j << 2);
-#ifndef KR_LOAD_NT
-#define KR_LOAD_NT " nt"
-#endif
-#ifndef KR_FLAG_SC
-#define KR_FLAG_SC " sc1"
-#endif
-        asm volatile("global_load_dword %2, %5, off" KR_FLAG_SC "\n\tglobal_load_dwordx4 %0, %3, off" KR_LOAD_NT "\n\t"
-                     "global_load_dword %1, %4, off" KR_LOAD_NT
-                     : "=&v"(pv0), "=&v"(pw), "=&v"(dirty_seen)
-                     : "v"(p0), "v"(p1), "v"(a.dirty)
-                     : "memory");
-      } else {
-        const uint32_t i1 = lane + 64u < nxt.n_vec ? lane + 64u : 0u;
-        const uint8_t* p1 = a.seqs + nxt.byte0 + ((uint64_t)i1 << 4);
-        asm volatile("global_load_dword %2, %5, off sc1\n\tglobal_load_dwordx4 %0, %3, off\n\t"
-                     "global_load_dwordx4 %1, %4, off"
-                     : "=&v"(pv0), "=&v"(pv1), "=&v"(dirty_seen)
-                     : "v"(p0), "v"(p1), "v"(a.dirty)
-                     : "memory");
-      }
-#endif
-    }
+  constexpr uint32_t NP = 32u * (uint32_t)(C_T ? C_T : 1); // 16-byte pieces of a full m=1 tile
+  constexpr uint32_t NFULL = NP / 64u, REM = NP % 64u;
+  constexpr uint32_t NST = NFULL + (REM ? 1u : 0u);        // store instructions of a full tile
 
-    // ---- this lane's run ----------------------------------------------------
-    const bool live = lane < runs_here;
-    const uint32_t gl = live ? my_rem0 + lane : my_rem0; // run index relative to r_first's run 0
-    const uint32_t lr = (gl * a.inv_rpr) >> 16;           // gl / rpr (gl < 64 + rpr: exact)
-    const uint32_t q = gl - lr * a.rpr;                   // run inside the read
-    const uint32_t b0 = shift + lr * a.stride + q * C;    // first base of the first window
-    const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
+  // ---- one tile: every lane hashes its run into the wave's LDS tile -----------------------------------
+  auto hash_tile = [&](const uint32_t shift, const uint32_t runs_here, const uint32_t my_rem0) {
+      const bool live = lane < runs_here;
+      const uint32_t gl = live ? my_rem0 + lane : my_rem0; // run index relative to r_first's run 0
+      const uint32_t lr = (gl * a.inv_rpr) >> 16;           // gl / rpr (gl < 64 + rpr: exact)
+      const uint32_t q = gl - lr * a.rpr;                   // run inside the read
+      const uint32_t b0 = shift + lr * a.stride + q * C;    // first base of the first window
+      const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
 #if KR_ABL_NOHASH
-    (void)d0; (void)sh0;
-    tile[lane] = (uint64_t)b0; // (keeps the geometry alive)
+      (void)d0; (void)sh0;
+      tile[lane] = (uint64_t)b0; // (keeps the geometry alive)
 #else
-    uint32_t w[NW];
-    {
-      uint32_t lo = bits[d0];
+      uint32_t w[NW];
+      {
+        uint32_t lo = bits[d0];
 #pragma unroll
-      for (int i = 0; i < NW; ++i) {
-        const uint32_t hi = bits[d0 + i + 1];
-        w[i] = funnel(hi, lo, sh0);
-        lo = hi;
+        for (int i = 0; i < NW; ++i) {
+          const uint32_t hi = bits[d0 + i + 1];
+          w[i] = funnel(hi, lo, sh0);
+          lo = hi;
+        }
       }
-    }
-    // first window: XOR of per-byte table entries (4 bases per lookup)
-    uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
+      // first window: XOR of per-byte table entries (4 bases per lookup)
+      uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
 #ifndef KR_BATCH_INIT
 #define KR_BATCH_INIT 1
 #endif
 #if KR_BATCH_INIT
-    {
-      // all lookups in flight before the first XOR (the wave is one of two on its SIMD: registers are plentiful)
-      uint4 e[4 * NW];
+      {
+        // all lookups in flight before the first XOR (the wave is one of two on its SIMD: registers are plentiful)
+        uint4 e[4 * NW];
 #pragma unroll
-      for (int jt = 0; jt < 4 * NW; ++jt) {
-        const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
-        e[jt] = (uint32_t)jt < ntab ? itab[(uint32_t)jt * 256u + byte] : make_uint4(0, 0, 0, 0);
+        for (int jt = 0; jt < 4 * NW; ++jt) {
+          const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+          e[jt] = (uint32_t)jt < ntab ? itab[(uint32_t)jt * 256u + byte] : make_uint4(0, 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int jt = 0; jt < 4 * NW; ++jt) { f_lo ^= e[jt].x; f_hi ^= e[jt].y; r_lo ^= e[jt].z; r_hi ^= e[jt].w; }
       }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int jt = 0; jt < 4 * NW; ++jt) { f_lo ^= e[jt].x; f_hi ^= e[jt].y; r_lo ^= e[jt].z; r_hi ^= e[jt].w; }
-    }
 #else
 #pragma unroll
-    for (int jt = 0; jt < 4 * NW; ++jt) {
-      if ((uint32_t)jt < ntab) {
-        const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
-        const uint4 e = itab[(uint32_t)jt * 256u + byte];
-        f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
+      for (int jt = 0; jt < 4 * NW; ++jt) {
+        if ((uint32_t)jt < ntab) {
+          const uint32_t byte = (w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu;
+          const uint4 e = itab[(uint32_t)jt * 256u + byte];
+          f_lo ^= e.x; f_hi ^= e.y; r_lo ^= e.z; r_hi ^= e.w;
+        }
       }
-    }
 #endif
-    uint64_t* my_row = tile + lane * C;
-    my_row[0] = canon_pair(f_lo, f_hi, r_lo, r_hi);
+      uint64_t* my_row = tile + lane * C;
+      my_row[0] = canon_pair(f_lo, f_hi, r_lo, r_hi);
 
-    // remaining C-1 windows: roll.  step t (1..C-1): in = base b0+k-1+t, out = base b0+t-1
-    const uint32_t bi = b0 + k;
-    const uint32_t di = bi >> 4, shi = (bi & 15u) << 1;
-    auto roll_word = [&](uint32_t jw, auto n_tag) {
-      const uint32_t w_in = funnel(bits[di + jw + 1], bits[di + jw], shi);
-      const uint32_t w_out = funnel(bits[d0 + jw + 1], bits[d0 + jw], sh0);
-      const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
-      const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
-      auto lookup = [&](uint32_t i) -> uint4 {
-        const uint32_t src = (i & 1u) ? v : u;
-        const uint32_t off = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
-        return *(const uint4*)((const char*)ptab + off);
-      };
-      auto roll = [&](const uint4 term) {
-        srol_pair(f_lo, f_hi);
-        f_lo ^= term.x;
-        f_hi ^= term.y;
-        r_lo ^= term.z;
-        r_hi ^= term.w;
-        sror_pair(r_lo, r_hi);
-      };
-      constexpr uint32_t NS = decltype(n_tag)::value; // 0 = runtime count
-      if constexpr (NS != 0) {
-        // table terms do not depend on the hash state: fetch them in batches
-        // ahead of the dependent chain so their LDS latencies overlap
-        constexpr uint32_t B = 8;
+      // remaining C-1 windows: roll.  step t (1..C-1): in = base b0+k-1+t, out = base b0+t-1
+      const uint32_t bi = b0 + k;
+      const uint32_t di = bi >> 4, shi = (bi & 15u) << 1;
+      auto roll_word = [&](uint32_t jw, auto n_tag) {
+        const uint32_t w_in = funnel(bits[di + jw + 1], bits[di + jw], shi);
+        const uint32_t w_out = funnel(bits[d0 + jw + 1], bits[d0 + jw], sh0);
+        const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
+        const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
+        auto lookup = [&](uint32_t i) -> uint4 {
+          const uint32_t src = (i & 1u) ? v : u;
+          const uint32_t off = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
+          return *(const uint4*)((const char*)ptab + off);
+        };
+        auto roll = [&](const uint4 term) {
+          srol_pair(f_lo, f_hi);
+          f_lo ^= term.x;
+          f_hi ^= term.y;
+          r_lo ^= term.z;
+          r_hi ^= term.w;
+          sror_pair(r_lo, r_hi);
+        };
+        constexpr uint32_t NS = decltype(n_tag)::value; // 0 = runtime count
+        if constexpr (NS != 0) {
+          // table terms do not depend on the hash state: fetch them in batches
+          // ahead of the dependent chain so their LDS latencies overlap
+          constexpr uint32_t B = 8;
 #pragma unroll
-        for (uint32_t i0 = 0; i0 < NS; i0 += B) {
-          uint4 terms[B];
+          for (uint32_t i0 = 0; i0 < NS; i0 += B) {
+            uint4 terms[B];
 #pragma unroll
-          for (uint32_t i = 0; i < B; ++i)
-            if (i0 + i < NS) terms[i] = lookup(i0 + i);
+            for (uint32_t i = 0; i < B; ++i)
+              if (i0 + i < NS) terms[i] = lookup(i0 + i);
 #pragma unroll
-          for (uint32_t i = 0; i < B; ++i) {
-            if (i0 + i < NS) {
+            for (uint32_t i = 0; i < B; ++i) {
+              if (i0 + i < NS) {
+                roll(terms[i]);
+                my_row[jw * 16u + i0 + i + 1u] =
+                    canon_pair(f_lo, f_hi, r_lo, r_hi);
+              }
+            }
+          }
+        } else {
+          // runtime step count: full batches of 8 (terms prefetched), then the remainder
+          const uint32_t left = C - 1u - jw * 16u;
+          const uint32_t ns = left < 16u ? left : 16u;
+          uint32_t i0 = 0;
+          for (; i0 + 8u <= ns; i0 += 8u) {
+            uint4 terms[8];
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i) terms[i] = lookup(i0 + i);
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i) {
               roll(terms[i]);
               my_row[jw * 16u + i0 + i + 1u] =
                   canon_pair(f_lo, f_hi, r_lo, r_hi);
             }
           }
-        }
-      } else {
-        // runtime step count: full batches of 8 (terms prefetched), then the remainder
-        const uint32_t left = C - 1u - jw * 16u;
-        const uint32_t ns = left < 16u ? left : 16u;
-        uint32_t i0 = 0;
-        for (; i0 + 8u <= ns; i0 += 8u) {
-          uint4 terms[8];
-#pragma unroll
-          for (uint32_t i = 0; i < 8; ++i) terms[i] = lookup(i0 + i);
-#pragma unroll
-          for (uint32_t i = 0; i < 8; ++i) {
-            roll(terms[i]);
-            my_row[jw * 16u + i0 + i + 1u] =
+#pragma unroll 1
+          for (uint32_t i = i0; i < ns; ++i) {
+            roll(lookup(i));
+            my_row[jw * 16u + i + 1u] =
                 canon_pair(f_lo, f_hi, r_lo, r_hi);
           }
         }
-#pragma unroll 1
-        for (uint32_t i = i0; i < ns; ++i) {
-          roll(lookup(i));
-          my_row[jw * 16u + i + 1u] =
-              canon_pair(f_lo, f_hi, r_lo, r_hi);
-        }
+      };
+      if constexpr (C_T != 0 && C_T <= 33) {
+        constexpr uint32_t NROLL = (uint32_t)(C_T - 1);
+        if constexpr (NROLL > 0) roll_word(0u, std::integral_constant<uint32_t, (NROLL < 16u ? NROLL : 16u)>{});
+        if constexpr (NROLL > 16) roll_word(1u, std::integral_constant<uint32_t, NROLL - 16u>{});
+      } else {
+        for (uint32_t jw = 0; jw * 16u + 1u < C; ++jw) roll_word(jw, std::integral_constant<uint32_t, 0u>{});
       }
-    };
-    if constexpr (C_T != 0 && C_T <= 33) {
-      constexpr uint32_t NROLL = (uint32_t)(C_T - 1);
-      if constexpr (NROLL > 0) roll_word(0u, std::integral_constant<uint32_t, (NROLL < 16u ? NROLL : 16u)>{});
-      if constexpr (NROLL > 16) roll_word(1u, std::integral_constant<uint32_t, NROLL - 16u>{});
-    } else {
-      for (uint32_t jw = 0; jw * 16u + 1u < C; ++jw) roll_word(jw, std::integral_constant<uint32_t, 0u>{});
-    }
 
 #endif // KR_ABL_NOHASH
 
-    // ---- copy the tile out: 64*C*m consecutive values of the hash stream ------
+  };
+
+  // ---- copy the tile out: 64*C*m consecutive values of the hash stream; true = a full tile left as exactly
+  // NST store instructions (what the counted waits below rely on) ---------------------------------------
+  auto copy_out = [&](const uint64_t g0, const uint32_t runs_here) -> bool {
     lds_sync();
-    uint64_t* const out0 = a.hashes + g0 * vals_per_run;
-    const uint32_t n_vals = runs_here * vals_per_run;
-    const uint32_t n_pairs = (n_vals + 1u) >> 1;
-    constexpr uint32_t NP = 32u * (uint32_t)(C_T ? C_T : 1); // 16-byte pieces of a full m=1 tile
-    constexpr uint32_t NFULL = NP / 64u, REM = NP % 64u;
-    constexpr uint32_t NST = NFULL + (REM ? 1u : 0u);        // store instructions of a full tile
-    bool counted = false;
-    if (m == 1) {
-      if (C_T != 0 && runs_here == 64u) {
-        // full tile, compile-time shape: LDS reads first, then the stores, in groups of 8
-        // (named registers, not an array: hipcc sends a partially predicated
-        // uint4 array to scratch, whose traffic would also break the counted wait)
-        static_assert(NST <= 16, "flush is written for at most 16 store instructions");
-        const uint4* src = (const uint4*)tile + lane;
-        uint4* dst = (uint4*)out0 + lane;
-        uint4 d0, d1, d2, d3, d4, d5, d6, d7;
+      uint64_t* const out0 = a.hashes + g0 * vals_per_run;
+      const uint32_t n_vals = runs_here * vals_per_run;
+      const uint32_t n_pairs = (n_vals + 1u) >> 1;
+      bool counted = false;
+      if (m == 1) {
+        if (C_T != 0 && runs_here == 64u) {
+          // full tile, compile-time shape: LDS reads first, then the stores, in groups of 8
+          // (named registers, not an array: hipcc sends a partially predicated
+          // uint4 array to scratch, whose traffic would also break the counted wait)
+          static_assert(NST <= 16, "flush is written for at most 16 store instructions");
+          const uint4* src = (const uint4*)tile + lane;
+          uint4* dst = (uint4*)out0 + lane;
+          uint4 d0, d1, d2, d3, d4, d5, d6, d7;
 #define KR_LD(n, var) \
-        if constexpr ((n) < NFULL) var = src[(n) * 64u]; \
-        else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) var = src[(n) * 64u]; }
+          if constexpr ((n) < NFULL) var = src[(n) * 64u]; \
+          else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) var = src[(n) * 64u]; }
 #if KR_ABL_NOSTORE
 #define KR_ST1(p, var) asm volatile("" ::"v"((p)), "v"((var).x), "v"((var).y), "v"((var).z), "v"((var).w))
 #else
 #define KR_ST1(p, var) stream_store16((p), var)
 #endif
 #define KR_ST(n, var) \
-        if constexpr ((n) < NFULL) KR_ST1(dst + (n) * 64u, var); \
-        else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) KR_ST1(dst + (n) * 64u, var); }
+          if constexpr ((n) < NFULL) KR_ST1(dst + (n) * 64u, var); \
+          else if constexpr ((n) == NFULL && REM != 0) { if (lane < REM) KR_ST1(dst + (n) * 64u, var); }
 #define KR_GROUP(b) \
-        KR_LD(b + 0, d0) KR_LD(b + 1, d1) KR_LD(b + 2, d2) KR_LD(b + 3, d3) \
-        KR_LD(b + 4, d4) KR_LD(b + 5, d5) KR_LD(b + 6, d6) KR_LD(b + 7, d7) \
-        KR_ST(b + 0, d0) KR_ST(b + 1, d1) KR_ST(b + 2, d2) KR_ST(b + 3, d3) \
-        KR_ST(b + 4, d4) KR_ST(b + 5, d5) KR_ST(b + 6, d6) KR_ST(b + 7, d7)
-        KR_GROUP(0)
-        if constexpr (NST > 8) { KR_GROUP(8) }
+          KR_LD(b + 0, d0) KR_LD(b + 1, d1) KR_LD(b + 2, d2) KR_LD(b + 3, d3) \
+          KR_LD(b + 4, d4) KR_LD(b + 5, d5) KR_LD(b + 6, d6) KR_LD(b + 7, d7) \
+          KR_ST(b + 0, d0) KR_ST(b + 1, d1) KR_ST(b + 2, d2) KR_ST(b + 3, d3) \
+          KR_ST(b + 4, d4) KR_ST(b + 5, d5) KR_ST(b + 6, d6) KR_ST(b + 7, d7)
+          KR_GROUP(0)
+          if constexpr (NST > 8) { KR_GROUP(8) }
 #undef KR_GROUP
 #undef KR_LD
 #undef KR_ST
 #undef KR_ST1
-        counted = !KR_ABL_NOSTORE;
+          counted = !KR_ABL_NOSTORE;
+        } else {
+          for (uint32_t pi = lane; pi < n_pairs; pi += 64u) {
+            const uint4 dv = *(const uint4*)(tile + 2u * pi);
+            if (2u * pi + 1u < n_vals) *(uint4*)(out0 + 2u * pi) = dv;
+            else *(uint2*)(out0 + 2u * pi) = make_uint2(dv.x, dv.y);
+          }
+        }
       } else {
+        // multi-hash expansion (extend_hashes, src/internal.hpp:104-118) fused into the
+        // copy-out: the tile holds h[0] only; value v of the stream is h[v % m] of k-mer v / m
         for (uint32_t pi = lane; pi < n_pairs; pi += 64u) {
-          const uint4 dv = *(const uint4*)(tile + 2u * pi);
-          if (2u * pi + 1u < n_vals) *(uint4*)(out0 + 2u * pi) = dv;
-          else *(uint2*)(out0 + 2u * pi) = make_uint2(dv.x, dv.y);
-        }
-      }
-    } else {
-      // multi-hash expansion (extend_hashes, src/internal.hpp:104-118) fused into the
-      // copy-out: the tile holds h[0] only; value v of the stream is h[v % m] of k-mer v / m
-      for (uint32_t pi = lane; pi < n_pairs; pi += 64u) {
-        uint64_t o[2];
+          uint64_t o[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const uint32_t vi = 2u * pi + (uint32_t)h;
-          const uint32_t e = M_T ? vi / m : __umulhi(vi, inv_m), jj = vi - e * m;
-          const uint64_t h0 = tile[e < runs_here * C ? e : 0];
-          o[h] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t vi = 2u * pi + (uint32_t)h;
+            const uint32_t e = M_T ? vi / m : __umulhi(vi, inv_m), jj = vi - e * m;
+            const uint64_t h0 = tile[e < runs_here * C ? e : 0];
+            o[h] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
+          }
+          if (2u * pi + 1u < n_vals) *(uint4*)(out0 + 2u * pi) =
+              make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
+          else *(uint2*)(out0 + 2u * pi) = make_uint2((uint32_t)o[0], (uint32_t)(o[0] >> 32));
         }
-        if (2u * pi + 1u < n_vals) *(uint4*)(out0 + 2u * pi) =
-            make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
-        else *(uint2*)(out0 + 2u * pi) = make_uint2((uint32_t)o[0], (uint32_t)(o[0] >> 32));
       }
-    }
-    lds_sync(); // tile and bits are free again
+    return counted;
+  };
 
-    // ---- consume the prefetched slab ---------------------------------------------
-    // After a counted full tile the only VMEM operations younger than the two
-    // loads are its NST stores: wait until at most NST operations are in flight.
-    // (NST is 8 for C=15 and 15 for C=30)
-#define KR_WAIT(...) \
-    do { \
-      if (counted && NST == 8u) asm volatile("s_waitcnt vmcnt(8)" : __VA_ARGS__::"memory"); \
-      else if (counted && NST == 15u) asm volatile("s_waitcnt vmcnt(15)" : __VA_ARGS__::"memory"); \
-      else asm volatile("s_waitcnt vmcnt(0)" : __VA_ARGS__::"memory"); \
-    } while (0)
-    if constexpr (DT) KR_WAIT("+v"(pv0), "+v"(pw), "+v"(dirty_seen));
-    else KR_WAIT("+v"(pv0), "+v"(pv1), "+v"(dirty_seen));
-#undef KR_WAIT
-    // some wave already found a non-base byte: the caller will redo the batch on the
-    // N-aware path, so stop producing a dense stream nobody will read
-    if (__builtin_amdgcn_readfirstlane(dirty_seen) != 0u) break;
-    if (have_next) {
-      cur = nxt;
-      if (lane < cur.n_vec) pack_vec(cur, lane, make_uint4(pv0.x, pv0.y, pv0.z, pv0.w));
-      if constexpr (DT) {
-        const uint32_t n_dw = (cur.shift + cur.slab_bytes + 3u) >> 2;
-        if (256u + lane < n_dw) pack_dword(cur, lane, pw);
-        if (lane < (uint32_t)NW + 3u) bits[cur.n_vec + lane] = 0;
-      } else {
-        if (lane + 64u < cur.n_vec) pack_vec(cur, lane + 64u, make_uint4(pv1.x, pv1.y, pv1.z, pv1.w));
-        stage(cur, 128u); // slabs longer than 128 vectors: the rest with ordinary loads
+  if (!KR_CHUNKED || !DT || a.ph_tiles == 0u) {
+    Slab cur;
+    cur.byte0 = 0;
+    cur.shift = cur.slab_bytes = cur.n_vec = cur.runs_here = 0;
+    cur.edge = 1u;
+    if (wt < wt_end) {
+      cur = slab_of(wt * 64u, r_first, rem0);
+      stage(cur, 0u);
+    }
+    for (; wt < wt_end; wt += wstride) {
+      lds_sync();
+      const uint64_t g0 = wt * 64u;
+      const uint32_t shift = cur.shift, runs_here = cur.runs_here;
+      const uint32_t my_rem0 = rem0;
+      // ---- issue the loads of the NEXT tile's slab (two vectors per lane) --------
+      r_first += step_q;
+      rem0 += step_r;
+      if (rem0 >= a.rpr) { rem0 -= a.rpr; r_first += 1; }
+      const uint64_t nwt = wt + wstride;
+      const bool have_next = nwt < wt_end;
+      Slab nxt = cur;
+      if (have_next) nxt = slab_of(nwt * 64u, r_first, rem0);
+      // vector `lane` of the slab, plus its tail: slabs of at most 1280 bytes
+      // (a.dword_tail, the common case) finish with ONE DWORD per lane -- a second
+      // 16-byte round would leave most lanes idle --, longer slabs with a second vector
+      v4u pv0, pv1;
+      uint32_t pw;
+      uint32_t dirty_seen; // the batch-wide dirty flag, read along with the next slab
+      {
+        // lanes without an item re-read item 0 so that every lane issues both loads
+        const uint32_t i0 = lane < nxt.n_vec ? lane : 0u;
+        const uint8_t* p0 = a.seqs + nxt.byte0 + ((uint64_t)i0 << 4);
+#if KR_ABL_NOLOAD
+        (void)p0;
+        pv0 = v4u{0x41414141u, 0x43434343u, 0x47474747u, 0x54545454u};
+        pv1 = pv0;
+        pw = 0x41434754u;
+        dirty_seen = 0;
+        asm volatile("" : "+v"(pv0), "+v"(pv1), "+v"(pw), "+v"(dirty_seen));
+#else
+        if constexpr (DT) {
+          const uint32_t n_dw = (nxt.shift + nxt.slab_bytes + 3u) >> 2; // dwords in the slab
+          const uint32_t j = 256u + lane < n_dw ? 256u + lane : 0u;
+          const uint8_t* p1 = a.seqs + nxt.byte0 + ((uint64_t)j << 2);
+#ifndef KR_LOAD_NT
+#define KR_LOAD_NT " sc1 nt"
+#endif
+#ifndef KR_FLAG_SC
+#define KR_FLAG_SC " sc1"
+#endif
+          asm volatile("global_load_dword %2, %5, off" KR_FLAG_SC "\n\tglobal_load_dwordx4 %0, %3, off" KR_LOAD_NT "\n\t"
+                       "global_load_dword %1, %4, off" KR_LOAD_NT
+                       : "=&v"(pv0), "=&v"(pw), "=&v"(dirty_seen)
+                       : "v"(p0), "v"(p1), "v"(a.dirty)
+                       : "memory");
+        } else {
+          const uint32_t i1 = lane + 64u < nxt.n_vec ? lane + 64u : 0u;
+          const uint8_t* p1 = a.seqs + nxt.byte0 + ((uint64_t)i1 << 4);
+          asm volatile("global_load_dword %2, %5, off sc1\n\tglobal_load_dwordx4 %0, %3, off\n\t"
+                       "global_load_dwordx4 %1, %4, off"
+                       : "=&v"(pv0), "=&v"(pv1), "=&v"(dirty_seen)
+                       : "v"(p0), "v"(p1), "v"(a.dirty)
+                       : "memory");
+        }
+#endif
       }
-      if (__ballot(bad != 0) != 0) { // publish at once so that every wave can stop early
-        if (lane == 0) atomicOr(a.dirty, 1u);
-        break;
+
+      hash_tile(shift, runs_here, my_rem0);
+      const bool counted = copy_out(g0, runs_here);
+      lds_sync(); // tile and bits are free again
+
+      // ---- consume the prefetched slab ---------------------------------------------
+      // After a counted full tile the only VMEM operations younger than the two
+      // loads are its NST stores: wait until at most NST operations are in flight.
+      // (NST is 8 for C=15 and 15 for C=30)
+#define KR_WAIT(...) \
+      do { \
+        if (counted && NST == 8u) asm volatile("s_waitcnt vmcnt(8)" : __VA_ARGS__::"memory"); \
+        else if (counted && NST == 15u) asm volatile("s_waitcnt vmcnt(15)" : __VA_ARGS__::"memory"); \
+        else asm volatile("s_waitcnt vmcnt(0)" : __VA_ARGS__::"memory"); \
+      } while (0)
+      if constexpr (DT) KR_WAIT("+v"(pv0), "+v"(pw), "+v"(dirty_seen));
+      else KR_WAIT("+v"(pv0), "+v"(pv1), "+v"(dirty_seen));
+#undef KR_WAIT
+      // some wave already found a non-base byte: the caller will redo the batch on the
+      // N-aware path, so stop producing a dense stream nobody will read
+      if (__builtin_amdgcn_readfirstlane(dirty_seen) != 0u) break;
+      if (have_next) {
+        cur = nxt;
+        if (lane < cur.n_vec) pack_vec(cur, lane, make_uint4(pv0.x, pv0.y, pv0.z, pv0.w));
+        if constexpr (DT) {
+          const uint32_t n_dw = (cur.shift + cur.slab_bytes + 3u) >> 2;
+          if (256u + lane < n_dw) pack_dword(cur, lane, pw);
+          if (lane < (uint32_t)NW + 3u) bits[cur.n_vec + lane] = 0;
+        } else {
+          if (lane + 64u < cur.n_vec) pack_vec(cur, lane + 64u, make_uint4(pv1.x, pv1.y, pv1.z, pv1.w));
+          stage(cur, 128u); // slabs longer than 128 vectors: the rest with ordinary loads
+        }
+        if (__ballot(bad != 0) != 0) { // publish at once so that every wave can stop early
+          if (lane == 0) atomicOr(a.dirty, 1u);
+          break;
+        }
       }
     }
   }
+#if KR_CHUNKED
+  else {
+    // ---- chunked path (DT shapes): a wave works through CHUNKS of P consecutive tiles that it takes from a global
+    // counter, one after the other.
+    // * Dynamic, because the waves of a launch are far from equally fast: with the static split (every block an equal
+    //   range) the first wave finished after 15.2 ms and the last after 19.6 ms of the same launch (profiles/
+    //   r02_notes.md) -- a fifth of the chip idles towards the end.  A chunk is 120 KiB of contiguous output.
+    // * The slabs of the NEXT chunk (P times ~1.2 KB) are loaded while this chunk is hashed: 16 slabs per lane in
+    //   flight in 80 registers, so no wave ever waits for a slab it asked for one tile ago.
+    // * Optional pacing (a.ph_period != 0): all waves of the chip issue those loads in the same window of the constant
+    //   100 MHz clock (s_memrealtime; period n starts at tick n * T, the stores of a chunk's first tile wait until
+    //   R ticks into it), so that HBM sees its reads and writes apart.  With the hash switched off the two streams
+    //   take 17.3 ms apart against 18.8 ms mixed; what the full kernel gains depends on the box, hence a knob.
+    const uint32_t P = a.ph_tiles;
+    uint32_t* const bits0 = bits;
+    struct Coord { uint64_t rf; uint32_t rm; }; // (first read, run inside it) of a tile's first run
+    const uint32_t t_q = 64u / a.rpr, t_r = 64u - t_q * a.rpr; // consecutive tiles: 64 runs further
+    auto advance = [&](Coord& c) {
+      c.rf += t_q;
+      c.rm += t_r;
+      if (c.rm >= a.rpr) { c.rm -= a.rpr; c.rf += 1; }
+    };
+    auto coord_of = [&](const uint64_t t) -> Coord {
+      const uint64_t rf = (t * 64u) / a.rpr;
+      return Coord{rf, (uint32_t)(t * 64u - rf * a.rpr)};
+    };
+    auto spin_until = [&](const uint64_t tick) {
+      while (__builtin_amdgcn_s_memrealtime() < tick) __builtin_amdgcn_s_sleep(1);
+    };
+    const uint64_t n_chunks = (a.n_wtiles + P - 1u) / P;
+    auto next_chunk = [&]() -> uint64_t { // wave-uniform
+      uint32_t c = 0;
+      if (lane == 0) c = atomicAdd(a.chunk_counter, 1u);
+      return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(c);
+    };
+    auto chunk_tiles = [&](const uint64_t chunk) -> uint32_t {
+      if (chunk >= n_chunks) return 0u;
+      const uint64_t left = a.n_wtiles - chunk * P;
+      return left < P ? (uint32_t)left : P;
+    };
+    const uint64_t T = a.ph_period, R = a.ph_read;
+    uint64_t t_read = 0;
+    if (T) t_read = (__builtin_amdgcn_s_memrealtime() / T + 1u) * T;
+    constexpr uint32_t RND = 16; // slabs a lane has in flight (5 registers each); P <= RND
+#if KR_DEBUG_TIMES
+    uint64_t dbg[5] = {0, 0, 0, 0, 0}, dbg_t = __builtin_amdgcn_s_memrealtime();
+    const uint64_t dbg_start = dbg_t;
+#define KR_DBG(i) do { const uint64_t n_ = __builtin_amdgcn_s_memrealtime(); dbg[i] += n_ - dbg_t; dbg_t = n_; } while (0)
+#else
+#define KR_DBG(i) do { } while (0)
+#endif
+#ifndef KR_LOAD_NT
+#define KR_LOAD_NT " sc1 nt"
+#endif
+    v4u v[RND];
+    uint32_t w4[RND];
+    uint32_t meta[RND]; // per slab: shift | n_vec << 8 | n_dw << 16 | edge << 31 (wave-uniform: scalar registers)
+    // Every lane issues the loads of a chunk's slabs back to back, without a branch in between (behind a branch hipcc
+    // waits for the previous load before it issues the next: 16 memory latencies in a row); a chunk of fewer tiles
+    // loads its last slab again.  t_first: the chunk's first tile.
+    auto issue_chunk = [&](const uint64_t t_first, const uint32_t n) {
+      Coord c = coord_of(t_first);
+#pragma unroll
+      for (uint32_t i = 0; i < RND; ++i) {
+        const Slab sl = slab_of((t_first + (i < n ? i : n - 1u)) * 64u, c.rf, c.rm);
+        Coord nx = c;
+        advance(nx);
+        const bool more = i + 1u < n;
+        c.rf = more ? nx.rf : c.rf;
+        c.rm = more ? nx.rm : c.rm;
+        const uint32_t n_dw = (sl.shift + sl.slab_bytes + 3u) >> 2;
+        meta[i] = (uint32_t)__builtin_amdgcn_readfirstlane(sl.shift | (sl.n_vec << 8) | (n_dw << 16) | (sl.edge << 31));
+        const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sl.byte0) |
+                              ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sl.byte0 >> 32)) << 32);
+        const uint32_t i0 = lane < sl.n_vec ? lane : 0u;
+        const uint32_t jd = 256u + lane < n_dw ? 256u + lane : 0u;
+#if KR_ABL_NOLOAD
+        v[i] = v4u{0x41414141u, 0x43434343u, 0x47474747u, 0x54545454u};
+        w4[i] = 0x41434754u;
+        (void)i0; (void)jd; (void)base;
+#else
+        // hidden from hipcc on purpose: it would wait for these loads by counting down vmcnt where they are used, a
+        // chunk later, behind the chunk's 128 stores -- i.e. for the store acknowledgements.  See loads_landed()
+        // for why no wait is needed at all.  (scalar base + 32-bit lane offset: no 64-bit vector arithmetic)
+        const uint8_t* sbase = a.seqs + base;
+        asm volatile("global_load_dwordx4 %0, %2, %4" KR_LOAD_NT "\n\tglobal_load_dword %1, %3, %4" KR_LOAD_NT
+                     : "=&v"(v[i]), "=&v"(w4[i])
+                     : "v"(i0 << 4), "v"(jd << 2), "s"(sbase)
+                     : "memory");
+#endif
+      }
+    };
+    // ... and packs them into the chunk's bit streams (bits0 + q * bits_dwords)
+    auto pack_chunk = [&](const uint64_t t_first, const uint32_t n) {
+#pragma unroll
+      for (uint32_t i = 0; i < RND; ++i) {
+        if (i < n) {
+          Slab sl;
+          sl.shift = meta[i] & 0xFFu;
+          sl.n_vec = (meta[i] >> 8) & 0xFFu;
+          sl.edge = 0u;
+          sl.slab_bytes = 0u; // (only the edge path looks at it)
+          sl.byte0 = 0;
+          sl.runs_here = 0;
+          const uint32_t n_dw = (meta[i] >> 16) & 0x7FFFu;
+          if (meta[i] >> 31) { // first / last slab of the buffer
+            const Coord c = coord_of(t_first + i);
+            sl = slab_of((t_first + i) * 64u, c.rf, c.rm);
+          }
+          bits = bits0 + i * a.bits_dwords;
+          if (lane < sl.n_vec) pack_vec(sl, lane, make_uint4(v[i].x, v[i].y, v[i].z, v[i].w));
+          if (256u + lane < n_dw) pack_dword(sl, lane, w4[i]);
+          if (lane < (uint32_t)NW + 3u) bits[sl.n_vec + lane] = 0;
+        }
+      }
+    };
+    // The slab registers are read a chunk after their loads were issued.  vmcnt retires in order and never holds
+    // more than 63 operations, so once this wave has ISSUED 64 younger vector-memory operations (8 full tiles of
+    // stores) the loads have landed; a shorter chunk waits for everything.  The empty statements name every
+    // destination register, which keeps hipcc from touching them before this point.
+    auto loads_landed = [&](const uint32_t younger_ops) {
+      if (younger_ops < 64u) wait_vmcnt<0>();
+      asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                        "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])::"memory");
+      asm volatile("" : "+v"(w4[0]), "+v"(w4[1]), "+v"(w4[2]), "+v"(w4[3]), "+v"(w4[4]), "+v"(w4[5]), "+v"(w4[6]), "+v"(w4[7]),
+                        "+v"(w4[8]), "+v"(w4[9]), "+v"(w4[10]), "+v"(w4[11]), "+v"(w4[12]), "+v"(w4[13]), "+v"(w4[14]), "+v"(w4[15])::"memory");
+    };
+    // prologue: the first chunk, loaded and packed at once
+    uint64_t chunk = next_chunk();
+    uint32_t n_here = chunk_tiles(chunk);
+    if (n_here) {
+      issue_chunk(chunk * P, n_here);
+      loads_landed(0u);
+      pack_chunk(chunk * P, n_here);
+    }
+    while (n_here) {
+      // a non-base anywhere in the batch (found here or by another wave): the caller redoes the batch on the
+      // N-aware path, so stop producing a dense stream nobody will read
+      if (__ballot(bad != 0) != 0) {
+        if (lane == 0) atomicOr(a.dirty, 1u);
+        break;
+      }
+      if (__hip_atomic_load(a.dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+      if (T) {
+        wait_vmcnt<0>(); // paced: this wave's stores have reached memory before it reads
+        KR_DBG(0);
+        const uint64_t now = __builtin_amdgcn_s_memrealtime();
+        if (now >= t_read + T) t_read = (now / T) * T; // more than a period late: rejoin the grid, no waiting
+        spin_until(t_read);
+        KR_DBG(1);
+      }
+      // ---- the loads of the NEXT chunk go out; they are consumed when this chunk has been hashed ----
+      const uint64_t chunk_next = next_chunk();
+      const uint32_t n_next = chunk_tiles(chunk_next);
+      if (n_next) issue_chunk(chunk_next * P, n_next);
+      KR_DBG(2);
+      // ---- this chunk: hash and write ----
+      Coord cw = coord_of(chunk * P);
+      for (uint32_t q = 0; q < n_here; ++q) {
+        const uint64_t g0 = (chunk * P + q) * 64u;
+        const uint64_t runs_left = a.n_runs - g0;
+        const uint32_t runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
+        const uint32_t shift = (uint32_t)(((uint64_t)a.seqs + cw.rf * a.stride) & (uint32_t)(KR_SLAB_ALIGN - 1));
+        bits = bits0 + q * a.bits_dwords;
+        lds_sync();
+        hash_tile(shift, runs_here, cw.rm);
+        if (q == 0u && T) {
+          KR_DBG(4);
+          spin_until(t_read + R); // (paced: the first tile's stores wait for the end of the read window)
+          KR_DBG(3);
+        }
+        (void)copy_out(g0, runs_here);
+        lds_sync(); // the tile is free again
+        advance(cw);
+      }
+      KR_DBG(4);
+      // ---- the next chunk's slabs arrived long ago: pack them (every bit stream of this chunk has been hashed) ----
+      if (n_next) {
+        loads_landed(m == 1u && C_T != 0 ? NST * n_here : 0u); // (only the m = 1 copy-out has a fixed store count)
+        pack_chunk(chunk_next * P, n_next);
+      }
+      KR_DBG(2);
+      chunk = chunk_next;
+      n_here = n_next;
+      t_read += T;
+    }
+#if KR_DEBUG_TIMES
+    if (lane == 0) {
+      for (int i = 0; i < 5; ++i) atomicAdd((unsigned long long*)(a.dirty + 16) + i, (unsigned long long)dbg[i]);
+      const unsigned long long el = __builtin_amdgcn_s_memrealtime() - dbg_start;
+      atomicMax((unsigned long long*)(a.dirty + 16) + 5, el);
+      atomicMin((unsigned long long*)(a.dirty + 16) + 6, el);
+      atomicAdd((unsigned long long*)(a.dirty + 16) + 7, el);
+    }
+#endif
+#undef KR_DBG
+  }
+#endif // KR_CHUNKED
+
   if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
 }
 

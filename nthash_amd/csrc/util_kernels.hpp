@@ -408,19 +408,15 @@ static __global__ __launch_bounds__(256) void copy_kernel(uint4* __restrict__ ds
     dst[i] = src[i];
 }
 
-// write-only yardstick, shaped like the hash kernels' copy-out: one block per CU streams through its own
-// contiguous range, every wave writes whole tiles of FILL_TILE_KIB contiguous KiB, one KiB per store instruction
-#ifndef FILL_TILE_KIB
-#define FILL_TILE_KIB 8
-#endif
-#ifndef FILL_STORE_POLICY
-#define FILL_STORE_POLICY ""
-#endif
-static __global__ __launch_bounds__(1024) void fill16_kernel(uint4* __restrict__ dst, uint64_t n16, uint32_t value)
+// write-only yardstick, shaped like the headline kernel's copy-out (which writes 6.7-7.0 TB/s with its hashing and
+// slab loads switched off): one block of 8 waves per CU streams through its own contiguous range, every wave writes
+// whole tiles of 7.5 KiB -- one contiguous KiB per write-through store instruction -- and lets at most one tile's
+// stores stay in flight while it issues the next (an unthrottled fill of 16 waves reaches only 5.7 TB/s)
+static __global__ __launch_bounds__(512) void fill16_kernel(uint4* __restrict__ dst, uint64_t n16, uint32_t value)
 {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   const v4u v = {value, value ^ 0x55555555u, ~value, lane};
-  constexpr uint64_t TILE = (uint64_t)FILL_TILE_KIB * 64u; // uint4 per tile
+  constexpr uint64_t TILE = 480u; // uint4 per tile: 7.5 KiB
   const uint64_t n_tiles = n16 / TILE;
   const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
   const uint64_t t0 = (uint64_t)blockIdx.x * per;
@@ -428,8 +424,10 @@ static __global__ __launch_bounds__(1024) void fill16_kernel(uint4* __restrict__
   for (uint64_t t = t0 + wave; t < t1; t += n_waves) {
     uint4* p = dst + t * TILE + lane;
 #pragma unroll
-    for (uint32_t j = 0; j < (uint32_t)FILL_TILE_KIB; ++j)
-      asm volatile("global_store_dwordx4 %0, %1, off" FILL_STORE_POLICY "\n\ts_nop 1" ::"v"(p + j * 64u), "v"(v) : "memory");
+    for (uint32_t j = 0; j < 7u; ++j)
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p + j * 64u), "v"(v) : "memory");
+    if (lane < 32u) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p + 448u), "v"(v) : "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   }
   // the tail that is not a whole tile
   for (uint64_t i = n_tiles * TILE + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
