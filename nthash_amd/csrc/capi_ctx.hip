@@ -242,6 +242,7 @@ void load_tuning(nthip_tune& t)
   t.no_m4 = is_set("NTHIP_TUNE_NO_M4");
   t.no_autotune = is_set("NTHIP_TUNE_NO_AUTOTUNE");
   t.no_seed_wave = is_set("NTHIP_TUNE_NO_SEED_WAVE");
+  t.no_seed_wtile = is_one("NTHIP_TUNE_NO_SEED_WTILE");
   t.no_phases = is_one("NTHIP_TUNE_NO_PHASES");
   t.pacing = is_one("NTHIP_TUNE_PACING");
   t.ph_tiles = num("NTHIP_TUNE_PH_TILES", 1, 64);

@@ -75,6 +75,7 @@ struct nthip_tune {
   bool no_m4 = false;       // NTHIP_TUNE_NO_M4 (set): runtime-m instantiation for m = 4
   bool no_autotune = false; // NTHIP_TUNE_NO_AUTOTUNE (set)
   bool no_seed_wave = false; // NTHIP_TUNE_NO_SEED_WAVE (set)
+  bool no_seed_wtile = false; // NTHIP_TUNE_NO_SEED_WTILE=1: the block-tile dense seed kernel instead of the wave-tile one
   // phased headline kernel (kmer_runs_kernel.hpp): tiles per wave and period, period / read window in 10 ns ticks
   bool no_phases = false;   // NTHIP_TUNE_NO_PHASES=1: the static loop (one tile ahead) instead of dynamic chunks
   bool pacing = false;      // NTHIP_TUNE_PACING=1: chunk loads in chip-wide windows of the 100 MHz clock

@@ -211,6 +211,83 @@ int ntamd::host::run_seed_general(nthip_ctx* c, const Staged& st, const nthip_re
 
 namespace {
 
+// seed_wtile_kernel: plan (reads per wave tile, LDS) + launch; *ran = false when the shape is outside it
+int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, uint32_t nh, bool* ran)
+{
+  *ran = false;
+  if (c->tune.no_seed_wtile) return NTHIP_OK;
+  const uint32_t per = f.n_seeds * f.m2;
+  const uint64_t rec_bytes = (uint64_t)f.nwin * per * 8; // a read's records
+  // reads per tile: ~4 KB of reads, rounded up so that a tile's records are a whole number of KiB when the
+  // slab stays under 8 KiB (SW_MAX_VEC_ROUNDS x 64 vectors)
+  uint32_t R = 4096u / f.stride;
+  if (R < 1) R = 1;
+  {
+    uint64_t g = rec_bytes, h = 1024;
+    while (h) { const uint64_t t2 = g % h; g = h; h = t2; } // gcd(rec_bytes, 1024)
+    const uint32_t unit = (uint32_t)(1024 / g);
+    const uint32_t Ra = (R + unit - 1) / unit * unit;
+    if (15ull + (uint64_t)(Ra - 1) * f.stride + f.len <= SW_MAX_VEC_ROUNDS * 1024ull) R = Ra;
+  }
+  const uint64_t slab = 15ull + (uint64_t)(R - 1) * f.stride + f.len;
+  if (slab > SW_MAX_VEC_ROUNDS * 1024ull || (uint64_t)R * f.nwin >= 0x7FFFFFFFull) return NTHIP_OK;
+  const uint32_t bits_dwords = (uint32_t)((((slab + 15) >> 4) + 8 + 3) & ~3ull);
+  const size_t table_bytes = (size_t)f.n_seeds * 2 * nh * 256 * sizeof(uint4);
+  const size_t per_wave = (size_t)(64 * per + 2) * 8 + (size_t)bits_dwords * 4;
+  const size_t cap = lds_cap_of(c);
+  uint32_t waves = 0;
+  for (uint32_t w = 16; w >= 4; w -= 4)
+    if (table_bytes + per_wave * w <= cap) { waves = w; break; }
+  if (!waves) return NTHIP_OK;
+  SeedWtileArgs a;
+  memset(&a, 0, sizeof a);
+  a.seqs = f.seqs;
+  a.hashes = f.hashes;
+  a.dirty = f.dirty;
+  a.tables = f.tables;
+  a.n_reads = f.n_runs;
+  a.n_tiles = (f.n_runs + R - 1) / R;
+  a.len = f.len;
+  a.stride = f.stride;
+  a.k = f.k;
+  a.m2 = f.m2;
+  a.n_seeds = f.n_seeds;
+  a.ntab = f.ntab;
+  a.nwin = f.nwin;
+  a.reads_per_tile = R;
+  a.inv_nwin = f.inv_nwin;
+  a.bits_dwords = bits_dwords;
+  a.waves = waves;
+  memcpy(a.mult, f.mult, sizeof a.mult);
+  const size_t lds = table_bytes + per_wave * waves;
+  auto go = [&](auto kernel) -> int {
+    int per_cu = 1;
+    NTCHK(blocks_per_cu(c, kernel, (int)waves * 64, lds, &per_cu));
+    const uint64_t need = (a.n_tiles + waves - 1) / waves;
+    uint64_t grid = (uint64_t)c->n_cu * per_cu;
+    if (grid > need) grid = need;
+    prof_begin(c, "seed_wtile_kernel");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream, a);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    return NTHIP_OK;
+  };
+  int rc;
+  switch (nh) {
+    case 1: rc = go(seed_wtile_kernel<1>); break;
+    case 2: rc = go(seed_wtile_kernel<2>); break;
+    case 3: rc = go(seed_wtile_kernel<3>); break;
+    case 4: rc = go(seed_wtile_kernel<4>); break;
+    case 5: rc = go(seed_wtile_kernel<5>); break;
+    case 6: rc = go(seed_wtile_kernel<6>); break;
+    case 7: rc = go(seed_wtile_kernel<7>); break;
+    default: rc = go(seed_wtile_kernel<8>); break;
+  }
+  NTCHK(rc);
+  *ran = true;
+  return NTHIP_OK;
+}
+
 template <typename K>
 int launch_seed_fixed(nthip_ctx* c, K kernel, const SeedFixedArgs& a, size_t dyn_lds)
 {
@@ -318,8 +395,14 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
    : nh == 6 ? launch_seed_fixed(c, seed_fixed_kernel<6, SPLIT_T>, a, DYN) \
    : nh == 7 ? launch_seed_fixed(c, seed_fixed_kernel<7, SPLIT_T>, a, DYN) \
              : launch_seed_fixed(c, seed_fixed_kernel<8, SPLIT_T>, a, DYN))
-      rc = NT_SEED_FIXED(false, dyn);
-      NTCHK(rc);
+      // clean batches (the optimistic pass): one wave per tile of reads, no block barriers (seed_wtile_kernel);
+      // shapes outside it (slabs of more than 8 KiB per tile, LDS) keep the block-tile kernel
+      bool wtile_ran = false;
+      NTCHK(launch_seed_wtile(c, a, sd, nh, &wtile_ran));
+      if (!wtile_ran) {
+        rc = NT_SEED_FIXED(false, dyn);
+        NTCHK(rc);
+      }
       HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       uint32_t dirty = 0;

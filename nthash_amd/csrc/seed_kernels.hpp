@@ -31,6 +31,22 @@ namespace ntamd {
 #define SF_THREADS_N 1024
 #endif
 constexpr int SF_THREADS = SF_THREADS_N; // 16 waves: one block per CU shares the byte tables
+// ablation / A-B switches of seed_fixed_kernel (measurement builds)
+#ifndef SF_ABL_NOHASH
+#define SF_ABL_NOHASH 0 // no table lookups: staging + copy-out + the memory streams only (WRONG results)
+#endif
+#ifndef SF_ABL_NOSTORE
+#define SF_ABL_NOSTORE 0 // the hash stream is not written
+#endif
+#ifndef SF_STORE_POLICY
+#define SF_STORE_POLICY " nt"
+#endif
+#ifndef SW_STORE_POLICY
+#define SW_STORE_POLICY " sc0 sc1" // seed_wtile_kernel: whole aligned lines of a contiguous block -> write-through
+#endif
+#ifndef SF_BLOCK_RANGES
+#define SF_BLOCK_RANGES 0 // 1: every block streams through its own contiguous range of tiles (0: grid stride)
+#endif
 constexpr int SF_MAX_RUNTIME_M = 8;
 
 struct SeedFixedArgs {
@@ -133,7 +149,14 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
   const uint32_t inv_per = 0xFFFFFFFFu / per + 1u; // v / per == umulhi(v, inv_per) for v < 2^29
   uint32_t bad = 0;
 
+#if SF_BLOCK_RANGES
+  const uint32_t tiles_per_block = (a.n_tiles + gridDim.x - 1u) / gridDim.x;
+  const uint32_t t_begin = blockIdx.x * tiles_per_block;
+  const uint32_t t_end = t_begin + tiles_per_block < a.n_tiles ? t_begin + tiles_per_block : a.n_tiles;
+  for (uint32_t t = t_begin; t < t_end; ++t) {
+#else
   for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+#endif
     const uint64_t run0 = (uint64_t)t * a.runs_per_tile;
     const uint64_t left = a.n_runs - run0;
     const uint32_t runs_here = left < a.runs_per_tile ? (uint32_t)left : a.runs_per_tile;
@@ -203,6 +226,9 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
       uint64_t* const dst = a.hashes + (run0 * a.nwin + q0) * per;
       const uint32_t par = SPLIT ? 0u : (uint32_t)(((uintptr_t)dst >> 3) & 1u);
       uint64_t* mine = otile + par + lane * per;
+#if SF_ABL_NOHASH
+      for (uint32_t s = 0; s < per; ++s) mine[s] = w[0] + s;
+#else
       for (uint32_t s = 0; s < a.n_seeds; ++s) {
         const uint4* ts = tabs + s * NT * 256u;
         // all lookups of the seed in flight, then XOR them up
@@ -230,6 +256,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
         for (uint32_t jj = 1; jj < (uint32_t)SF_MAX_RUNTIME_M; ++jj)
           if (jj < a.m2) mine[s * a.m2 + jj] = mix_hash(h0, a.mult[jj]);
       }
+#endif
 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
@@ -255,10 +282,13 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
         uint64_t* const base = dst - par; // 16-byte aligned; value i of the shifted tile goes to base[i]
         const uint32_t span = par + n_vals;
         for (uint32_t pi = par + lane; pi < (span >> 1); pi += 64u) { // whole 16-byte pieces
-#ifdef SF_STORE_PLAIN
-          *(nt_v4u*)(base + 2u * pi) = *(const nt_v4u*)(otile + 2u * pi);
-#else     // written once, never read back by this kernel: streaming stores (+1.1 % on BASELINE config 4)
-          __builtin_nontemporal_store(*(const nt_v4u*)(otile + 2u * pi), (nt_v4u*)(base + 2u * pi));
+#if SF_ABL_NOSTORE
+          asm volatile("" ::"v"(*(const nt_v4u*)(otile + 2u * pi)));
+#else     // written once, never read back by this kernel, whole aligned 16-byte pieces of a contiguous 3 KiB: SF_STORE_POLICY
+          {
+            const nt_v4u sv = *(const nt_v4u*)(otile + 2u * pi);
+            asm volatile("global_store_dwordx4 %0, %1, off" SF_STORE_POLICY "\n\ts_nop 1" ::"v"(base + 2u * pi), "v"(sv) : "memory");
+          }
 #endif
         }
         if (lane == 0u && par != 0u) base[1] = otile[1];                         // head
@@ -266,6 +296,237 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
+}
+
+// --------------------------------------------------------------------------
+// seed_wtile_kernel -- the dense spaced-seed path, one WAVE per tile (round 2).
+//
+// seed_fixed_kernel stages the reads of a tile block-wide: two __syncthreads() per tile, each of them draining the
+// wave's stores (hipcc waits vmcnt(0) in front of a barrier) and lining the 16 waves up, so that they hash together
+// and write together: hashing alone took 26.5 ms per 16 M reads, the stores alone 26.2 ms, both 31.9 ms
+// (profiles/r02_notes.md).  Here a wave owns its tile: R consecutive reads (R chosen so that a tile's records are a
+// multiple of 1 KiB of the stream: 16 reads of 250 bp = 165 KiB), staged as a wave-private bit stream; the next tile's
+// slab is loaded while this one is hashed; no block barrier after the tables are in LDS.  Every group of 64 consecutive
+// windows leaves as one contiguous, KiB-aligned block (3 KiB for two seeds x three hashes) of write-through stores.
+// Blocks stream through contiguous ranges of tiles.
+// --------------------------------------------------------------------------
+struct SeedWtileArgs {
+  const uint8_t* seqs;
+  uint64_t* hashes;      // dense [read][window][seed][m2]
+  uint32_t* dirty;
+  const uint4* tables;   // global: [seed][ntab][256] {f.lo,f.hi,r.lo,r.hi}
+  uint64_t n_reads;
+  uint64_t n_tiles;      // wave tiles of reads_per_tile reads
+  uint32_t len, stride, k, m2;
+  uint32_t n_seeds, ntab;
+  uint32_t nwin;
+  uint32_t reads_per_tile;
+  uint32_t inv_nwin;     // floor(2^32 / nwin) + 1
+  uint32_t bits_dwords;  // per wave
+  uint32_t waves;        // per block
+  uint64_t mult[SF_MAX_RUNTIME_M];
+};
+
+constexpr uint32_t SW_MAX_VEC_ROUNDS = 8; // a tile's slab: at most 8 x 64 vectors of 16 bytes (8 KiB of reads)
+
+template <int NH>
+__global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileArgs a)
+{
+  constexpr int NW = (NH + 1) / 2; // 32-bit words of window kept in registers
+  constexpr uint32_t NT = 2u * NH; // byte tables per seed in LDS
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // layout: [tables: n_seeds*NT*256 uint4][per wave: output tile 64*per+2 u64 | bit stream]
+  uint4* tabs = (uint4*)lds_dyn;
+  const uint32_t n_entries = a.n_seeds * NT * 256u;
+  const uint32_t per = a.n_seeds * a.m2; // values per window
+  const uint32_t otile_u64 = 64u * per + 2u;
+  uint32_t* wbase = lds_dyn + n_entries * 4u + wave * (otile_u64 * 2u + a.bits_dwords);
+  uint64_t* otile = (uint64_t*)wbase;
+  uint32_t* bits = wbase + otile_u64 * 2u;
+  for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
+    const uint32_t tb = i >> 8, sd = tb / NT, jt = tb - sd * NT;
+    tabs[i] = jt < a.ntab ? a.tables[((size_t)sd * a.ntab + jt) * 256u + (i & 255u)] : make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads(); // the only block-wide barrier
+
+  // this block's contiguous range of tiles, its waves interleaved inside it
+  const uint64_t per_block = (a.n_tiles + gridDim.x - 1u) / gridDim.x;
+  const uint64_t t_begin = (uint64_t)blockIdx.x * per_block;
+  const uint64_t t_end = t_begin + per_block < a.n_tiles ? t_begin + per_block : a.n_tiles;
+  const uint32_t R = a.reads_per_tile;
+  uint32_t bad = 0;
+
+  struct Slab {
+    uint64_t byte0; // offset of the first 16-byte vector from a.seqs (wraps below 0 by < 16)
+    uint32_t shift, slab_bytes, n_vec, reads_here, edge;
+  };
+  auto slab_of = [&](const uint64_t t) -> Slab {
+    Slab sl;
+    const uint64_t r0 = t * R;
+    const uint64_t left = a.n_reads - r0;
+    sl.reads_here = left < R ? (uint32_t)left : R;
+    const uint64_t off = r0 * a.stride;
+    sl.shift = (uint32_t)(((uint64_t)a.seqs + off) & 15u);
+    sl.byte0 = off - sl.shift;
+    sl.slab_bytes = (sl.reads_here - 1u) * a.stride + a.len;
+    sl.n_vec = (sl.shift + sl.slab_bytes + 15u) >> 4;
+    sl.edge = (r0 == 0 || r0 + sl.reads_here >= a.n_reads) ? 1u : 0u;
+    return sl;
+  };
+  // one vector of the slab into the bit stream; bytes of this batch are judged (a non-base anywhere makes the batch
+  // dirty), bytes outside the caller's buffer (first / last slab only) are not
+  auto pack_vec = [&](const Slab& sl, const uint32_t i, const uint4 v) {
+    uint32_t b = 0;
+    const uint32_t p = pack16(v, b);
+    if (sl.edge) {
+      const int32_t lo_cut = (int32_t)sl.shift - (int32_t)(i << 4);
+      const int32_t hi_cut = (int32_t)(sl.shift + sl.slab_bytes) - (int32_t)(i << 4);
+      if (lo_cut > 0 || hi_cut < 16) {
+        uint32_t bx[4] = {0, 0, 0, 0};
+        (void)pack4(v.x, bx[0]);
+        (void)pack4(v.y, bx[1]);
+        (void)pack4(v.z, bx[2]);
+        (void)pack4(v.w, bx[3]);
+        b = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (q >= lo_cut && q < hi_cut) b |= (bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+      }
+    }
+    bad |= b;
+    bits[i] = p;
+  };
+  auto lds_sync = [&]() { // LDS is in-order per wave: only the compiler must not reorder
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+
+  uint64_t t = t_begin + wave;
+  if (t >= t_end) return;
+  Slab cur = slab_of(t);
+  for (uint32_t i = lane; i < cur.n_vec; i += 64u)
+    pack_vec(cur, i, *(const uint4*)(a.seqs + cur.byte0 + ((uint64_t)i << 4)));
+  if (lane < (uint32_t)NW + 1u) bits[cur.n_vec + lane] = 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  for (; t < t_end; t += a.waves) {
+    lds_sync();
+    // ---- the NEXT tile's slab: loads now, consumed after this tile's stores have been issued.  Hidden from hipcc
+    // (it would wait for them behind the tile's stores, i.e. for the store acknowledgements); vmcnt retires in order
+    // and holds at most 63 operations, so after 64 younger operations have been issued they have landed. ----
+    const uint64_t tn = t + a.waves;
+    const bool have_next = tn < t_end;
+    const Slab nxt = have_next ? slab_of(tn) : cur;
+    nt_v4u pv[SW_MAX_VEC_ROUNDS];
+    uint32_t dirty_seen;
+    {
+      const uint64_t b0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)nxt.byte0) |
+                          ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(nxt.byte0 >> 32)) << 32);
+      const uint8_t* sbase = a.seqs + b0; // (wave-uniform: scalar base + 32-bit lane offset)
+#pragma unroll
+      for (uint32_t rd = 0; rd < SW_MAX_VEC_ROUNDS; ++rd) {
+        const uint32_t i = rd * 64u + lane;
+        const uint32_t off = (i < nxt.n_vec ? i : 0u) << 4; // lanes past the slab re-read its start
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(pv[rd]) : "v"(off), "s"(sbase) : "memory");
+      }
+      asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(dirty_seen) : "v"(a.dirty) : "memory");
+    }
+
+    // ---- this tile: groups of 64 consecutive windows ----
+    const uint32_t n_win_tile = cur.reads_here * a.nwin;
+    const uint64_t rec0 = t * R * (uint64_t)a.nwin; // first window of the tile in the stream
+    uint32_t n_stores = 0;
+    for (uint32_t q0 = 0; q0 < n_win_tile; q0 += 64u) {
+      const uint32_t q = q0 + lane;
+      const bool live = q < n_win_tile;
+      const uint32_t qq = live ? q : q0;
+      uint32_t lr = a.nwin == 1u ? qq : __umulhi(qq, a.inv_nwin); // qq -> (read, window)
+      if (lr * a.nwin > qq) lr--;
+      const uint32_t p = qq - lr * a.nwin;
+      const uint32_t b = cur.shift + lr * a.stride + p; // first base of the window (stream index)
+      const uint32_t d = b >> 4, sh = (b & 15u) << 1;
+      uint32_t w[NW];
+      uint32_t lo = bits[d];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const uint32_t hi = bits[d + i + 1];
+        w[i] = funnel(hi, lo, sh);
+        lo = hi;
+      }
+      // the 64 records are built shifted by the parity of their place in the stream: 16-byte aligned LDS reads and stores
+      uint64_t* const dst = a.hashes + (rec0 + q0) * per;
+      const uint32_t par = (uint32_t)(((uintptr_t)dst >> 3) & 1u);
+      uint64_t* mine = otile + par + lane * per;
+#if SF_ABL_NOHASH
+      for (uint32_t s = 0; s < per; ++s) mine[s] = w[0] + s;
+#else
+      for (uint32_t s = 0; s < a.n_seeds; ++s) {
+        const uint4* ts = tabs + s * NT * 256u;
+        uint4 e[NT]; // all lookups of the seed in flight, then XOR them up
+#pragma unroll
+        for (uint32_t jt = 0; jt < NT; ++jt) {
+          const uint32_t byte = (w[jt >> 2] >> ((jt & 3u) * 8u)) & 0xFFu;
+          e[jt] = ts[jt * 256u + byte];
+        }
+        uint32_t f0 = e[0].x ^ e[1].x, f1 = e[0].y ^ e[1].y, r0 = e[0].z ^ e[1].z, r1 = e[0].w ^ e[1].w;
+#pragma unroll
+        for (uint32_t jt = 2; jt < NT; jt += 2) { // NT is even; a ^ b ^ c is one v_bitop3_b32
+          f0 = __builtin_amdgcn_bitop3_b32(f0, e[jt].x, e[jt + 1].x, 0x96);
+          f1 = __builtin_amdgcn_bitop3_b32(f1, e[jt].y, e[jt + 1].y, 0x96);
+          r0 = __builtin_amdgcn_bitop3_b32(r0, e[jt].z, e[jt + 1].z, 0x96);
+          r1 = __builtin_amdgcn_bitop3_b32(r1, e[jt].w, e[jt + 1].w, 0x96);
+        }
+        const uint64_t h0 = canon_pair(f0, f1, r0, r1);
+        mine[s * a.m2] = h0;
+#pragma unroll
+        for (uint32_t jj = 1; jj < (uint32_t)SF_MAX_RUNTIME_M; ++jj)
+          if (jj < a.m2) mine[s * a.m2 + jj] = mix_hash(h0, a.mult[jj]);
+      }
+#endif
+      lds_sync();
+      const uint32_t n_here = (n_win_tile - q0) < 64u ? (n_win_tile - q0) : 64u;
+      const uint32_t n_vals = n_here * per;
+      uint64_t* const base = dst - par; // 16-byte aligned; value i of the shifted tile goes to base[i]
+      const uint32_t span = par + n_vals;
+      for (uint32_t pi = par + lane; pi < (span >> 1); pi += 64u) { // whole 16-byte pieces
+#if SF_ABL_NOSTORE
+        asm volatile("" ::"v"(*(const nt_v4u*)(otile + 2u * pi)));
+#else
+        const nt_v4u sv = *(const nt_v4u*)(otile + 2u * pi);
+        asm volatile("global_store_dwordx4 %0, %1, off" SW_STORE_POLICY "\n\ts_nop 1" ::"v"(base + 2u * pi), "v"(sv) : "memory");
+#endif
+      }
+      n_stores += ((span >> 1) - par + 63u) >> 6;
+      if (lane == 0u && par != 0u) base[1] = otile[1];                                              // head
+      if (lane == 1u && (span & 1u) != 0u && span > 2u * par) base[span - 1u] = otile[span - 1u]; // tail
+      lds_sync(); // the output tile is free again
+    }
+
+    // ---- consume the next slab ----
+    if (n_stores < 64u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]),
+                      "+v"(pv[7]), "+v"(dirty_seen)::"memory");
+    // some wave already found a non-base: the caller redoes the batch on the split path
+    if (__builtin_amdgcn_readfirstlane(dirty_seen) != 0u) break;
+    if (have_next) {
+      cur = nxt;
+#pragma unroll
+      for (uint32_t rd = 0; rd < SW_MAX_VEC_ROUNDS; ++rd) {
+        const uint32_t i = rd * 64u + lane;
+        if (i < cur.n_vec) pack_vec(cur, i, make_uint4(pv[rd].x, pv[rd].y, pv[rd].z, pv[rd].w));
+      }
+      if (lane < (uint32_t)NW + 1u) bits[cur.n_vec + lane] = 0;
+      if (__ballot(bad != 0) != 0) { // publish at once so that every wave can stop early
+        if (lane == 0) atomicOr(a.dirty, 1u);
+        break;
+      }
     }
   }
   if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);

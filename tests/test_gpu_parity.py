@@ -423,6 +423,47 @@ def test_seed_fixed_vs_oracle(ctx, oracle, n, L, seeds, m2):
     assert (gen["hashes"] == want["hashes"]).all()
 
 
+def test_seed_wave_tile_kernel_shapes_vs_oracle(ctx, oracle):
+    """the dense spaced-seed kernel (one wave per tile of reads, seed_wtile_kernel): read counts that are no multiple
+    of its tile, strides below the read length (overlapping rows), unaligned buffers, short and long k, one to
+    three seeds, and the same stream from the block-tile kernel it replaced"""
+    import os
+    import nthash_amd
+    rng = np.random.default_rng(4242)
+    for (n, L, stride, seeds, m2) in [(1, 250, 0, [SEED_A, SEED_B], 3), (17, 250, 0, [SEED_A, SEED_B], 3),
+                                      (1000, 250, 0, [SEED_A, SEED_B], 3), (4099, 100, 0, ["1101011"], 2),
+                                      (3001, 151, 0, ["1" * 20 + "0" * 9 + "1" * 20], 1),
+                                      (777, 64, 0, ["1" * 64], 4), (513, 300, 41, ["10101", "11011", "01110"], 2),
+                                      (2500, 1000, 0, ["110" * 10 + "1"], 1), (300, 5000, 0, [SEED_A], 2)]:
+        k = len(seeds[0])
+        st_ = stride or L
+        total = (n - 1) * st_ + L
+        raw = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, total + 3)]
+        for shift in (0, 3):    # unaligned start of the buffer
+            data = raw[shift: shift + total]
+            reads = [data[i * st_: i * st_ + L].tobytes() for i in range(n)]
+            d, offs = concat_reads(reads)
+            want = oracle.seed_batch(d, offs, seeds, k, m2, want_pos=False)
+            d_in = ctx.malloc(total + 16)
+            d_out = ctx.malloc(max(1, want["total"]) * len(seeds) * m2 * 8)
+            try:
+                ctx.h2d(d_in + shift, np.ascontiguousarray(data))
+                sd = nthash_amd.Seeds(ctx, seeds, k)
+                ctx.set_profiling(True)
+                tot = ctx.seed_hash_ptr(d_in + shift, 0, n, L, stride, sd, m2, d_out, want["total"])
+                name = ctx.last_kernel_ms()[1]
+                ctx.set_profiling(False)
+                assert tot == want["total"]
+                got = np.zeros(want["hashes"].size, np.uint64)
+                ctx.d2h(got, d_out)
+                assert (got.reshape(want["hashes"].shape) == want["hashes"]).all(), (n, L, stride, seeds, m2, shift, name)
+                if L == 250:
+                    assert name == "seed_wtile_kernel", (name, n, L)
+            finally:
+                ctx.free(d_in)
+                ctx.free(d_out)
+
+
 def test_seed_dirty_and_ragged_vs_oracle(ctx, oracle):
     rng = np.random.default_rng(33)
     alph = np.frombuffer(b"ACGTacgtUuNnRYKMSW-*\x00", dtype=np.uint8)
@@ -1257,7 +1298,7 @@ def test_seed_dirty_fixed_length_split_path(ctx, oracle, n, L, seeds, m2, stride
     got_c = ctx.seed_hash(clean, seeds, k, m2, fixed_len=L, n_reads=n, want_pos=True)
     name = ctx.last_kernel_ms()[1]
     ctx.set_profiling(False)
-    assert name == "seed_fixed_kernel", name
+    assert name in ("seed_fixed_kernel", "seed_wtile_kernel"), name   # (clean: the wave-tile dense kernel)
     assert (got_c["hashes"] == want_c["hashes"]).all() and (got_c["pos"] == want_c["pos"]).all()
 
 
