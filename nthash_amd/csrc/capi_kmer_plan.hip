@@ -210,7 +210,8 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
   const size_t fixed = (size_t)kmer_ntab(k) * 4096 + 256 + 64;
   const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
-  uint32_t w_max = m == 1 ? 8 : 16;
+  // m = 1: 12 waves per CU (3 per SIMD) measured +3 ... +9 % over 8 on 150 / 151 bp, 16 no better (round 2)
+  uint32_t w_max = m == 1 ? 12 : 16;
   if (c->tune.waves) w_max = c->tune.waves;
   for (uint32_t w = w_max; w >= 1; --w)
     if (fixed + per_wave * w <= cap) {

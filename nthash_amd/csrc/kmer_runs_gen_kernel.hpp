@@ -339,7 +339,11 @@ template <int NW, bool DT, bool NA, int SINK = SINK_NONE>
 __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const KmerRunsGenArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+#ifdef KRG_FORCE_C // experiment: what a compile-time run length is worth
+  const uint32_t k = a.k, m = a.m, C = KRG_FORCE_C, ntab = a.ntab, rpr = a.rpr;
+#else
   const uint32_t k = a.k, m = a.m, C = a.C, ntab = a.ntab, rpr = a.rpr;
+#endif
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
 #ifndef KRG_UNIFORM_WAVE

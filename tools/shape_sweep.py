@@ -15,7 +15,9 @@ SHAPES = [  # (L, k, m)
     (100, 64, 3), (100, 64, 1), (150, 31, 2), (150, 31, 4), (150, 31, 8), (151, 25, 2), (1000, 31, 1),
     (10000, 31, 1), (36, 21, 1), (50, 31, 1), (150, 15, 1), (150, 11, 1), (125, 31, 1), (149, 31, 1),
 ]
-OUT_BUDGET = 6 << 30  # bytes of hashes per shape
+OUT_BUDGET = int(os.environ.get("SWEEP_GIB", "6")) << 30  # bytes of hashes per shape
+if os.environ.get("SWEEP_SHAPES"):  # "151,31,1;101,31,1"
+    SHAPES = [tuple(int(x) for x in t.split(",")) for t in os.environ["SWEEP_SHAPES"].split(";")]
 
 ctx = nthash_amd.Context(0)
 ctx.set_profiling(True)
