@@ -54,7 +54,8 @@ std::vector<std::vector<unsigned>>
 parse_seeds(const std::vector<std::string>& seed_strings);
 
 namespace detail {
-struct KmerStream; // device-computed hash stream of one sequence (opaque)
+struct KmerStream; // device-computed hash stream of one window of a sequence (opaque)
+struct RollTables; // per k: what a byte adds when it enters / leaves a window (host recurrences)
 struct SeedStream;
 struct SeedSet;    // parsed seeds: blocks, monomers, masks (host) + device tables
 } // namespace detail
@@ -105,6 +106,7 @@ private:
   uint64_t fwd_ = 0;
   uint64_t rev_ = 0;
   std::unique_ptr<uint64_t[]> hash_arr_;
+  const detail::RollTables* rt_ = nullptr;     // process-wide, immutable
   std::shared_ptr<detail::KmerStream> stream_; // shared by copies, immutable once built
   size_t cursor_ = 0;                          // last stream entry used (search hint)
 
@@ -144,6 +146,7 @@ private:
   uint64_t fwd_ = 0;
   uint64_t rev_ = 0;
   std::unique_ptr<uint64_t[]> hash_arr_;
+  const detail::RollTables* rt_ = nullptr;
 };
 
 // ---------------------------------------------------------------------------
@@ -257,6 +260,46 @@ private:
   std::unique_ptr<uint64_t[]> hash_arr_;
 
   void rehash();
+};
+
+// ---------------------------------------------------------------------------
+// BatchNtHash -- an ADDITION to the reference's API (nothing like it exists there): the loop every caller of the
+// library writes,
+//     for (read : reads) { NtHash h(read, m, k); while (h.roll()) use(h.get_pos(), h.hashes()); }
+// (examples/benchmark.cpp:34-39 of the reference), as ONE device call for all the reads added so far.  The k-mers of
+// read i come back in roll() order: count(i) of them, hashes(i)[j * num_hashes + h], positions(i)[j]; a read
+// shorter than k simply has none (where the iterator's constructor would exit).  Use it where throughput matters:
+// one object per read costs a device round trip each (or, for short reads, runs on the host).
+// ---------------------------------------------------------------------------
+class BatchNtHash
+{
+public:
+  BatchNtHash(typedefs::NUM_HASHES_TYPE num_hashes, typedefs::K_TYPE k);
+  ~BatchNtHash();
+  BatchNtHash(const BatchNtHash&) = delete;
+  BatchNtHash& operator=(const BatchNtHash&) = delete;
+
+  void add(const char* seq, size_t seq_len); // the bytes are copied
+  void add(const std::string& seq) { add(seq.data(), seq.size()); }
+  size_t size() const { return offsets_.size() - 1; }
+  void run();   // hashes every read added since the last clear(); results stay valid until the next add()/clear()
+  void clear();
+
+  size_t count(size_t read) const { return (size_t)counts_[read]; }
+  const uint64_t* hashes(size_t read) const { return hashes_.data() + first_[read] * num_hashes_; }
+  const uint32_t* positions(size_t read) const { return pos_.data() + first_[read]; }
+  uint64_t total() const { return total_; }
+  typedefs::NUM_HASHES_TYPE get_hash_num() const { return num_hashes_; }
+  typedefs::K_TYPE get_k() const { return k_; }
+
+private:
+  typedefs::NUM_HASHES_TYPE num_hashes_;
+  typedefs::K_TYPE k_;
+  std::vector<char> seqs_;
+  std::vector<uint64_t> offsets_; // size() + 1
+  std::vector<uint64_t> counts_, first_, hashes_;
+  std::vector<uint32_t> pos_;
+  uint64_t total_ = 0;
 };
 
 } // namespace nthash

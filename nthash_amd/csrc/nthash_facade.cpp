@@ -3,17 +3,30 @@
 //
 // Position logic (which window comes next, what is skipped) follows the
 // reference's state machines exactly and runs on the host, because it only
-// inspects characters.  Hash VALUES for roll() come from the device: the first
-// roll() hashes the whole sequence with one nthip_*_hash call and roll() then
-// steps through that stream.  roll_back()/peek*() and the Blind* classes hash a
-// single caller-chosen base per call and evaluate the recurrence on the host
-// with the shared arithmetic of nt_math.hpp.
+// inspects characters.  Hash VALUES for roll() come from the device, one WINDOW
+// of the sequence at a time (NTHASH_AMD_WINDOW positions, default 8 Mi: a
+// chromosome-sized NtHash needs a few hundred MB of host memory, not 28+8m
+// bytes per base of the whole sequence); roll() steps through the window's
+// stream and asks for the next window when it runs out.  Every thread has its
+// own device context (no lock).
+// roll_back()/peek*() and the Blind* classes hash a single caller-chosen base
+// per call and evaluate the O(1) recurrence on the host with the shared
+// arithmetic of nt_math.hpp.  The same recurrences serve roll() on sequences of
+// at most NTHASH_AMD_HOST_ROLL_MAX bases (default 32768): one object per short
+// read is the reference's own usage pattern (examples/benchmark.cpp:34-39), and a
+// device round trip per object costs 0.2 ms where rolling 100 bases costs under
+// a microsecond.  That is a latency decision, not a fallback: the library still
+// refuses to construct a hashing object without a HIP device
+// (NTHASH_AMD_FORCE_DEVICE=1 sends every sequence to the device; the GPU tests set it),
+// and throughput work belongs on nthash::BatchNtHash / the C-ABI, which hash
+// many reads per call.
 #include "nthash/nthash.hpp"
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <map>
 #include <mutex>
 
 #include "nt_math.hpp"
@@ -37,38 +50,104 @@ void raise_warning(const std::string& cls, const std::string& msg)
   std::exit(1);
 }
 
-std::mutex g_dev_mutex; // one context, serialised calls
+// One device context per thread: objects used from several threads do not serialise on a lock, and a context's
+// stream / staging arena are never shared.  Destroyed when the thread ends.
+struct ThreadCtx {
+  nthip_ctx* ctx = nullptr;
+  ~ThreadCtx()
+  {
+    if (ctx) nthip_ctx_destroy(ctx);
+  }
+};
 
 nthip_ctx* device_ctx(const char* cls)
 {
-  static nthip_ctx* ctx = nullptr;
-  if (!ctx) {
+  static thread_local ThreadCtx tc;
+  if (!tc.ctx) {
     int dev = 0;
     if (const char* e = std::getenv("NTHASH_AMD_DEVICE")) dev = std::atoi(e);
-    if (nthip_ctx_create(dev, &ctx) != NTHIP_OK)
+    if (nthip_ctx_create(dev, &tc.ctx) != NTHIP_OK)
       raise_error(cls, std::string("GPU hashing unavailable: ") + nthip_last_error());
   }
-  return ctx;
+  return tc.ctx;
+}
+
+size_t env_size(const char* name, size_t dflt)
+{
+  const char* e = std::getenv(name);
+  if (!e || !*e) return dflt;
+  const unsigned long long v = std::strtoull(e, nullptr, 10);
+  return v ? (size_t)v : dflt;
+}
+// positions per device call of a long sequence
+size_t window_positions()
+{
+  static const size_t w = env_size("NTHASH_AMD_WINDOW", (size_t)8 << 20);
+  return w < 1024 ? 1024 : (w > ((size_t)1 << 30) ? ((size_t)1 << 30) : w);
+}
+// sequences of at most this many bases are rolled on the host (see the file comment); 0 with NTHASH_AMD_FORCE_DEVICE=1
+size_t host_roll_max()
+{
+  static const size_t v = [] {
+    const char* f = std::getenv("NTHASH_AMD_FORCE_DEVICE");
+    if (f && f[0] == '1') return (size_t)0;
+    return env_size("NTHASH_AMD_HOST_ROLL_MAX", 32768);
+  }();
+  return v;
 }
 
 inline bool valid_base(char c) { return is_base((unsigned char)c); }
 
-// the O(1) recurrences (reference src/kmer.cpp:84-114, 164-194)
-inline uint64_t next_fwd(uint64_t f, unsigned k, unsigned char out, unsigned char in)
+// The O(1) recurrences (reference src/kmer.cpp:84-114, 164-194).  What a byte adds when it enters or leaves a window
+// of k bases is tabulated per k (the reference's SEED_TAB and MS_TAB, src/internal.hpp:121-348, play this role); every
+// thread keeps the tables of the last two values of k it used.
+} // namespace
+namespace detail {
+struct RollTables {
+  unsigned k = 0;
+  uint64_t f_in[256], f_out[256], r_in[256], r_out[256];
+};
+} // namespace detail
+namespace {
+using detail::RollTables;
+// one immutable table set per k for the life of the process (8 KB each); objects keep the pointer
+const RollTables* roll_tables(unsigned k)
 {
-  return srol1(f) ^ fwd_seed(in) ^ srol_n(fwd_seed(out), k);
+  static thread_local const RollTables* last = nullptr;
+  if (last && last->k == k) return last;
+  static std::mutex mu;
+  static std::map<unsigned, std::unique_ptr<RollTables>> all;
+  std::lock_guard<std::mutex> lock(mu);
+  auto& slot = all[k];
+  if (!slot) {
+    slot.reset(new RollTables());
+    RollTables& t = *slot;
+    t.k = k;
+    for (unsigned c = 0; c < 256; ++c) {
+      t.f_in[c] = fwd_seed((unsigned char)c);
+      t.f_out[c] = srol_n(t.f_in[c], k);
+      t.r_out[c] = rc_seed((unsigned char)c);
+      t.r_in[c] = srol_n(t.r_out[c], k);
+    }
+  }
+  last = slot.get();
+  return last;
 }
-inline uint64_t next_rev(uint64_t r, unsigned k, unsigned char out, unsigned char in)
+inline uint64_t next_fwd(uint64_t f, const RollTables& t, unsigned char out, unsigned char in)
 {
-  return sror1(r ^ srol_n(rc_seed(in), k) ^ rc_seed(out));
+  return srol1(f) ^ t.f_in[in] ^ t.f_out[out];
 }
-inline uint64_t prev_fwd(uint64_t f, unsigned k, unsigned char out, unsigned char in)
+inline uint64_t next_rev(uint64_t r, const RollTables& t, unsigned char out, unsigned char in)
 {
-  return sror1(f ^ srol_n(fwd_seed(in), k) ^ fwd_seed(out));
+  return sror1(r ^ t.r_in[in] ^ t.r_out[out]);
 }
-inline uint64_t prev_rev(uint64_t r, unsigned k, unsigned char out, unsigned char in)
+inline uint64_t prev_fwd(uint64_t f, const RollTables& t, unsigned char out, unsigned char in)
 {
-  return srol1(r) ^ rc_seed(in) ^ srol_n(rc_seed(out), k);
+  return sror1(f ^ t.f_out[in] ^ t.f_in[out]);
+}
+inline uint64_t prev_rev(uint64_t r, const RollTables& t, unsigned char out, unsigned char in)
+{
+  return srol1(r) ^ t.r_out[in] ^ t.r_in[out];
 }
 
 // reference: extend_hashes, src/internal.hpp:104-118
@@ -85,17 +164,21 @@ inline void extend(uint64_t f, uint64_t r, unsigned k, unsigned m, uint64_t* h)
 // ===========================================================================
 namespace detail {
 
+// hashes of the windows [w_begin, w_end) of a sequence, as the device returned them
 struct KmerStream {
-  std::vector<uint32_t> pos;
+  size_t w_begin = 0, w_end = 0;
+  std::vector<uint32_t> pos;              // relative to w_begin, ascending
   std::vector<uint64_t> fwd, rev, hashes; // hashes: m per entry
   unsigned m = 0;
-  // index of the entry at position p, or npos
+  bool covers(size_t p) const { return p >= w_begin && p < w_end; }
+  // index of the entry at (absolute) position p, or npos
   size_t find(size_t p, size_t hint) const
   {
-    if (hint < pos.size() && pos[hint] == p) return hint;
-    if (hint + 1 < pos.size() && pos[hint + 1] == p) return hint + 1;
-    auto it = std::lower_bound(pos.begin(), pos.end(), (uint32_t)p);
-    return (it != pos.end() && *it == p) ? (size_t)(it - pos.begin()) : (size_t)-1;
+    const uint32_t q = (uint32_t)(p - w_begin);
+    if (hint < pos.size() && pos[hint] == q) return hint;
+    if (hint + 1 < pos.size() && pos[hint + 1] == q) return hint + 1;
+    auto it = std::lower_bound(pos.begin(), pos.end(), q);
+    return (it != pos.end() && *it == q) ? (size_t)(it - pos.begin()) : (size_t)-1;
   }
 };
 
@@ -104,6 +187,7 @@ struct SeedSet {
   std::vector<SeedShape> shapes;
   unsigned k = 0;
   nthip_seeds* dev = nullptr;
+  void* dev_ctx = nullptr; // the context `dev` lives in
   ~SeedSet()
   {
     if (dev) nthip_seeds_destroy(dev);
@@ -111,14 +195,17 @@ struct SeedSet {
 };
 
 struct SeedStream {
-  std::vector<uint32_t> pos;
+  size_t w_begin = 0, w_end = 0;
+  std::vector<uint32_t> pos;              // relative to w_begin
   std::vector<uint64_t> fwd, rev, hashes; // fwd/rev: n_seeds per entry; hashes: n_seeds*m2
+  bool covers(size_t p) const { return p >= w_begin && p < w_end; }
   size_t find(size_t p, size_t hint) const
   {
-    if (hint < pos.size() && pos[hint] == p) return hint;
-    if (hint + 1 < pos.size() && pos[hint + 1] == p) return hint + 1;
-    auto it = std::lower_bound(pos.begin(), pos.end(), (uint32_t)p);
-    return (it != pos.end() && *it == p) ? (size_t)(it - pos.begin()) : (size_t)-1;
+    const uint32_t q = (uint32_t)(p - w_begin);
+    if (hint < pos.size() && pos[hint] == q) return hint;
+    if (hint + 1 < pos.size() && pos[hint + 1] == q) return hint + 1;
+    auto it = std::lower_bound(pos.begin(), pos.end(), q);
+    return (it != pos.end() && *it == q) ? (size_t)(it - pos.begin()) : (size_t)-1;
   }
 };
 
@@ -126,19 +213,22 @@ struct SeedStream {
 
 namespace {
 
-std::shared_ptr<detail::KmerStream> build_kmer_stream(const char* seq, size_t len, unsigned k, unsigned m)
+// the windows [from, from + window_positions()) of the sequence, hashed by one device call on that slice
+std::shared_ptr<detail::KmerStream> build_kmer_stream(const char* seq, size_t len, unsigned k, unsigned m, size_t from)
 {
   auto st = std::make_shared<detail::KmerStream>();
   st->m = m;
-  const size_t cap = len - k + 1;
+  const size_t n_pos = len - k + 1;
+  st->w_begin = from;
+  st->w_end = std::min(n_pos, from + window_positions());
+  const size_t cap = st->w_end - st->w_begin;
   st->pos.resize(cap);
   st->fwd.resize(cap);
   st->rev.resize(cap);
   st->hashes.resize(cap * m);
-  std::lock_guard<std::mutex> lock(g_dev_mutex);
   nthip_ctx* ctx = device_ctx("NtHash");
-  const uint64_t offsets[2] = { 0, (uint64_t)len };
-  nthip_reads rd = { seq, offsets, 1, 0, 0 };
+  const uint64_t offsets[2] = { 0, (uint64_t)(cap + k - 1) };
+  nthip_reads rd = { seq + from, offsets, 1, 0, 0 };
   nthip_out out = { st->hashes.data(), cap, nullptr, st->pos.data(), st->fwd.data(), st->rev.data() };
   uint64_t total = 0;
   if (nthip_kmer_hash(ctx, &rd, (uint16_t)k, (uint8_t)m, &out, &total, NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT) !=
@@ -151,34 +241,42 @@ std::shared_ptr<detail::KmerStream> build_kmer_stream(const char* seq, size_t le
   return st;
 }
 
-std::shared_ptr<detail::SeedStream> build_seed_stream(const char* seq, size_t len, size_t pos0,
+// SeedNtHash's emission depends on where the walk started (App. B Q3: a non-base is only acted on when it is the
+// INCOMING character of a roll), so a window of the stream is only valid for the walk that reaches its first
+// position by rolling.  The device call therefore hashes the slice [from, ...) as a sequence of its own -- exactly
+// what the host object does when it (re)initialises at `from` -- and the caller only asks for a window at a position
+// where it is about to init() or has just rolled to: see SeedNtHash::set_window.
+std::shared_ptr<detail::SeedStream> build_seed_stream(const char* seq, size_t len, size_t from,
                                                       detail::SeedSet& seeds, unsigned m2)
 {
   auto st = std::make_shared<detail::SeedStream>();
   const unsigned k = seeds.k, ns = (unsigned)seeds.strings.size();
-  const size_t sub = len - pos0;
-  const size_t cap = sub - k + 1;
+  const size_t n_pos = len - k + 1;
+  st->w_begin = from;
+  st->w_end = std::min(n_pos, from + window_positions());
+  const size_t cap = st->w_end - st->w_begin;
   st->pos.resize(cap);
   st->fwd.resize(cap * ns);
   st->rev.resize(cap * ns);
   st->hashes.resize(cap * ns * m2);
-  std::lock_guard<std::mutex> lock(g_dev_mutex);
   nthip_ctx* ctx = device_ctx("SeedNtHash");
-  if (!seeds.dev) {
+  if (!seeds.dev || seeds.dev_ctx != ctx) { // (the device tables belong to the thread's context)
+    if (seeds.dev) nthip_seeds_destroy(seeds.dev);
+    seeds.dev = nullptr;
     std::vector<const char*> ptrs;
     for (const auto& s : seeds.strings) ptrs.push_back(s.c_str());
     if (nthip_seeds_create(ctx, ptrs.data(), ns, (uint16_t)k, &seeds.dev, nullptr) != NTHIP_OK)
       raise_error("SeedNtHash", std::string("GPU seed set-up failed: ") + nthip_last_error());
+    seeds.dev_ctx = ctx;
   }
-  const uint64_t offsets[2] = { 0, (uint64_t)sub };
-  nthip_reads rd = { seq + pos0, offsets, 1, 0, 0 };
+  const uint64_t offsets[2] = { 0, (uint64_t)(cap + k - 1) };
+  nthip_reads rd = { seq + from, offsets, 1, 0, 0 };
   nthip_out out = { st->hashes.data(), cap, nullptr, st->pos.data(), st->fwd.data(), st->rev.data() };
   uint64_t total = 0;
   if (nthip_seed_hash(ctx, &rd, seeds.dev, (uint8_t)m2, &out, &total, NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT) !=
       NTHIP_OK)
     raise_error("SeedNtHash", std::string("GPU hashing failed: ") + nthip_last_error());
   st->pos.resize(total);
-  for (auto& p : st->pos) p += (uint32_t)pos0;
   st->fwd.resize(total * ns);
   st->rev.resize(total * ns);
   st->hashes.resize(total * ns * m2);
@@ -259,6 +357,7 @@ NtHash::NtHash(const char* seq, size_t seq_len, typedefs::NUM_HASHES_TYPE num_ha
   , pos_(pos)
   , initialized_(false)
   , hash_arr_(new uint64_t[num_hashes ? num_hashes : 1]())
+  , rt_(roll_tables(k))
 {
   // reference: src/kmer.cpp:212-225
   if (k == 0) raise_error("NtHash", "k must be greater than 0");
@@ -280,6 +379,7 @@ NtHash::NtHash(const NtHash& o)
   , fwd_(o.fwd_)
   , rev_(o.rev_)
   , hash_arr_(new uint64_t[o.num_hashes_ ? o.num_hashes_ : 1])
+  , rt_(o.rt_)
   , stream_(o.stream_)
   , cursor_(o.cursor_)
 {
@@ -289,10 +389,30 @@ NtHash::NtHash(const NtHash& o)
 NtHash::NtHash(NtHash&&) noexcept = default;
 NtHash::~NtHash() = default;
 
-// take fwd/rev/hashes of the window at pos_ from the device stream
+// take fwd/rev/hashes of the window at pos_ from the device stream (a short sequence: straight from the bases)
 bool NtHash::load_from_stream()
 {
-  if (!stream_) stream_ = build_kmer_stream(seq_, len_, k_, num_hashes_);
+  if (len_ <= host_roll_max()) {
+    (void)device_ctx("NtHash"); // no HIP device, no hashing object: this is a latency path, not a fallback
+    // F = XOR_i srol^{k-1-i}(S[s_i]), R = XOR_i srol^{i}(S[comp s_i]) (src/kmer.cpp:43-73, 123-152), by Horner from the
+    // per-byte seed tables; a byte whose seed is 0 is not a base
+    const unsigned char* w = (const unsigned char*)seq_ + pos_;
+    uint64_t f = 0, r = 0;
+    for (size_t i = 0; i < k_; ++i) {
+      const uint64_t v = rt_->f_in[w[i]];
+      if (!v) return false;
+      f = srol1(f) ^ v;
+    }
+    for (size_t i = k_; i-- > 0;) r = srol1(r) ^ rt_->r_out[w[i]];
+    fwd_ = f;
+    rev_ = r;
+    extend(fwd_, rev_, k_, num_hashes_, hash_arr_.get());
+    return true;
+  }
+  if (!stream_ || !stream_->covers(pos_)) {
+    stream_ = build_kmer_stream(seq_, len_, k_, num_hashes_, pos_);
+    cursor_ = 0;
+  }
   const size_t i = stream_->find(pos_, cursor_);
   if (i == (size_t)-1) return false;
   cursor_ = i;
@@ -310,7 +430,7 @@ bool NtHash::init()
   auto window_invalid = [&](size_t at, size_t& bad) {
     for (size_t i = k_; i-- > 0;) {
       const size_t idx = at + i;
-      if (idx >= len_ || !valid_base(seq_[idx])) {
+      if (idx >= len_ || rt_->f_in[(unsigned char)seq_[idx]] == 0) { // (seed 0 <=> not ACGTU)
         bad = i;
         return true;
       }
@@ -336,14 +456,21 @@ bool NtHash::roll()
     return init();
   }
   ++pos_;
+  if (len_ <= host_roll_max()) { // short sequence: the recurrence (src/kmer.cpp:84-94, 164-174) on the host
+    const unsigned char out = (unsigned char)seq_[pos_ - 1], in = (unsigned char)seq_[pos_ + k_ - 1];
+    fwd_ = next_fwd(fwd_, *rt_, out, in);
+    rev_ = next_rev(rev_, *rt_, out, in);
+    extend(fwd_, rev_, k_, num_hashes_, hash_arr_.get());
+    return true;
+  }
   if (!load_from_stream()) {
     // Only reachable when the object was driven outside the reference's contract
     // (e.g. roll_back() after a failed roll() left pos past the last window, where
     // the reference itself reads out of bounds): the window at pos_ then holds a
     // non-base, so it is not in the stream.  Do what the reference does: roll.
     const unsigned char out = (unsigned char)seq_[pos_ - 1], in = (unsigned char)seq_[pos_ + k_ - 1];
-    fwd_ = next_fwd(fwd_, k_, out, in);
-    rev_ = next_rev(rev_, k_, out, in);
+    fwd_ = next_fwd(fwd_, *rt_, out, in);
+    rev_ = next_rev(rev_, *rt_, out, in);
     extend(fwd_, rev_, k_, num_hashes_, hash_arr_.get());
   }
   return true;
@@ -361,8 +488,8 @@ bool NtHash::roll_back()
   }
   if (!valid_base(in)) return false;
   const unsigned char out = (unsigned char)seq_[pos_ + k_ - 1];
-  fwd_ = prev_fwd(fwd_, k_, out, (unsigned char)in);
-  rev_ = prev_rev(rev_, k_, out, (unsigned char)in);
+  fwd_ = prev_fwd(fwd_, *rt_, out, (unsigned char)in);
+  rev_ = prev_rev(rev_, *rt_, out, (unsigned char)in);
   extend(fwd_, rev_, k_, num_hashes_, hash_arr_.get());
   --pos_;
   return true;
@@ -380,7 +507,7 @@ bool NtHash::peek(char char_in)
   if (!initialized_) return init();
   if (!valid_base(char_in)) return false;
   const unsigned char out = (unsigned char)seq_[pos_];
-  extend(next_fwd(fwd_, k_, out, (unsigned char)char_in), next_rev(rev_, k_, out, (unsigned char)char_in), k_,
+  extend(next_fwd(fwd_, *rt_, out, (unsigned char)char_in), next_rev(rev_, *rt_, out, (unsigned char)char_in), k_,
          num_hashes_, hash_arr_.get());
   return true;
 }
@@ -396,7 +523,7 @@ bool NtHash::peek_back(char char_in)
   if (!initialized_) return init();
   if (!valid_base(char_in)) return false;
   const unsigned char out = (unsigned char)seq_[pos_ + k_ - 1];
-  extend(prev_fwd(fwd_, k_, out, (unsigned char)char_in), prev_rev(rev_, k_, out, (unsigned char)char_in), k_,
+  extend(prev_fwd(fwd_, *rt_, out, (unsigned char)char_in), prev_rev(rev_, *rt_, out, (unsigned char)char_in), k_,
          num_hashes_, hash_arr_.get());
   return true;
 }
@@ -409,6 +536,7 @@ BlindNtHash::BlindNtHash(const char* seq, typedefs::NUM_HASHES_TYPE num_hashes, 
   , num_hashes_(num_hashes)
   , pos_(pos)
   , hash_arr_(new uint64_t[num_hashes ? num_hashes : 1]())
+  , rt_(roll_tables(k))
 {
   if (k == 0) raise_error("BlindNtHash", "k must be greater than 0");
   // the reference hashes seq[0..k) while its window holds seq[pos..pos+k)
@@ -425,6 +553,7 @@ BlindNtHash::BlindNtHash(const BlindNtHash& o)
   , fwd_(o.fwd_)
   , rev_(o.rev_)
   , hash_arr_(new uint64_t[o.num_hashes_ ? o.num_hashes_ : 1])
+  , rt_(o.rt_)
 {
   std::memcpy(hash_arr_.get(), o.hash_arr_.get(), (num_hashes_ ? num_hashes_ : 1) * sizeof(uint64_t));
 }
@@ -432,8 +561,8 @@ BlindNtHash::BlindNtHash(const BlindNtHash& o)
 void BlindNtHash::roll(char char_in)
 {
   const unsigned k = (unsigned)window_.size();
-  fwd_ = next_fwd(fwd_, k, (unsigned char)window_.front(), (unsigned char)char_in);
-  rev_ = next_rev(rev_, k, (unsigned char)window_.front(), (unsigned char)char_in);
+  fwd_ = next_fwd(fwd_, *rt_, (unsigned char)window_.front(), (unsigned char)char_in);
+  rev_ = next_rev(rev_, *rt_, (unsigned char)window_.front(), (unsigned char)char_in);
   extend(fwd_, rev_, k, num_hashes_, hash_arr_.get());
   window_.pop_front();
   window_.push_back(char_in);
@@ -443,8 +572,8 @@ void BlindNtHash::roll(char char_in)
 void BlindNtHash::roll_back(char char_in)
 {
   const unsigned k = (unsigned)window_.size();
-  fwd_ = prev_fwd(fwd_, k, (unsigned char)window_.back(), (unsigned char)char_in);
-  rev_ = prev_rev(rev_, k, (unsigned char)window_.back(), (unsigned char)char_in);
+  fwd_ = prev_fwd(fwd_, *rt_, (unsigned char)window_.back(), (unsigned char)char_in);
+  rev_ = prev_rev(rev_, *rt_, (unsigned char)window_.back(), (unsigned char)char_in);
   extend(fwd_, rev_, k, num_hashes_, hash_arr_.get());
   window_.pop_back();
   window_.push_front(char_in);
@@ -454,16 +583,16 @@ void BlindNtHash::roll_back(char char_in)
 void BlindNtHash::peek(char char_in)
 {
   const unsigned k = (unsigned)window_.size();
-  extend(next_fwd(fwd_, k, (unsigned char)window_.front(), (unsigned char)char_in),
-         next_rev(rev_, k, (unsigned char)window_.front(), (unsigned char)char_in), k, num_hashes_,
+  extend(next_fwd(fwd_, *rt_, (unsigned char)window_.front(), (unsigned char)char_in),
+         next_rev(rev_, *rt_, (unsigned char)window_.front(), (unsigned char)char_in), k, num_hashes_,
          hash_arr_.get());
 }
 
 void BlindNtHash::peek_back(char char_in)
 {
   const unsigned k = (unsigned)window_.size();
-  extend(prev_fwd(fwd_, k, (unsigned char)window_.back(), (unsigned char)char_in),
-         prev_rev(rev_, k, (unsigned char)window_.back(), (unsigned char)char_in), k, num_hashes_,
+  extend(prev_fwd(fwd_, *rt_, (unsigned char)window_.back(), (unsigned char)char_in),
+         prev_rev(rev_, *rt_, (unsigned char)window_.back(), (unsigned char)char_in), k, num_hashes_,
          hash_arr_.get());
 }
 
@@ -543,10 +672,19 @@ SeedNtHash::~SeedNtHash() = default;
 // is taken from the device stream when the stream holds it.
 void SeedNtHash::set_window(const char* win, bool try_stream)
 {
+  if (try_stream && len_ <= host_roll_max()) {
+    (void)device_ctx("SeedNtHash"); // no HIP device, no hashing object (a latency path, not a fallback)
+    try_stream = false;
+  }
   if (try_stream && win >= seq_ && win + k_ <= seq_ + len_) {
-    if (!stream_) stream_ = build_seed_stream(seq_, len_, pos0_, *seeds_, num_hashes_per_seed_);
     const size_t p = (size_t)(win - seq_);
-    const size_t i = stream_->find(p, cursor_);
+    // a window of the device stream starts where this walk is (first use: at pos0_): the device then walks the slice
+    // the way this object does from here on, and a position its walk does not visit is hashed below
+    if (!stream_ || !stream_->covers(p)) {
+      stream_ = build_seed_stream(seq_, len_, stream_ ? p : std::min(p, pos0_), *seeds_, num_hashes_per_seed_);
+      cursor_ = 0;
+    }
+    const size_t i = stream_->covers(p) ? stream_->find(p, cursor_) : (size_t)-1;
     if (i != (size_t)-1) {
       cursor_ = i;
       std::memcpy(fwd_.get(), stream_->fwd.data() + i * n_seeds_, n_seeds_ * sizeof(uint64_t));
@@ -741,6 +879,68 @@ void BlindSeedNtHash::roll_back(char char_in)
   }
   window_.pop_back();
   --pos_;
+}
+
+// ===========================================================================
+// BatchNtHash: many reads, one device call (nthip_kmer_hash with offsets, counts and positions)
+// ===========================================================================
+BatchNtHash::BatchNtHash(typedefs::NUM_HASHES_TYPE num_hashes, typedefs::K_TYPE k)
+  : num_hashes_(num_hashes)
+  , k_(k)
+  , offsets_(1, 0)
+{
+  if (k == 0) raise_error("BatchNtHash", "k must be greater than 0");
+  if (num_hashes == 0) raise_error("BatchNtHash", "num_hashes must be greater than 0");
+}
+
+BatchNtHash::~BatchNtHash() = default;
+
+void BatchNtHash::add(const char* seq, size_t seq_len)
+{
+  seqs_.insert(seqs_.end(), seq, seq + seq_len);
+  offsets_.push_back(seqs_.size());
+}
+
+void BatchNtHash::clear()
+{
+  seqs_.clear();
+  offsets_.assign(1, 0);
+  counts_.clear();
+  first_.clear();
+  hashes_.clear();
+  pos_.clear();
+  total_ = 0;
+}
+
+void BatchNtHash::run()
+{
+  const size_t n = size();
+  counts_.assign(n, 0);
+  first_.assign(n, 0);
+  total_ = 0;
+  size_t cap = 0;
+  for (size_t r = 0; r < n; ++r) {
+    const size_t len = (size_t)(offsets_[r + 1] - offsets_[r]);
+    if (len >= k_) cap += len - k_ + 1;
+  }
+  hashes_.resize(cap * num_hashes_);
+  pos_.resize(cap);
+  if (n == 0 || cap == 0) return;
+  nthip_ctx* ctx = device_ctx("BatchNtHash");
+  nthip_reads rd = { seqs_.data(), offsets_.data(), (uint64_t)n, 0, 0 };
+  nthip_out out = { hashes_.data(), (uint64_t)cap, counts_.data(), pos_.data(), nullptr, nullptr };
+  uint64_t total = 0;
+  if (nthip_kmer_hash(ctx, &rd, (uint16_t)k_, (uint8_t)num_hashes_, &out, &total,
+                      NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT) != NTHIP_OK)
+    raise_error("BatchNtHash", std::string("GPU hashing failed: ") + nthip_last_error());
+  total_ = total;
+  uint64_t acc = 0;
+  for (size_t r = 0; r < n; ++r) {
+    first_[r] = acc;
+    acc += counts_[r];
+  }
+  hashes_.resize((size_t)total * num_hashes_);
+  pos_.resize((size_t)total);
 }
 
 } // namespace nthash

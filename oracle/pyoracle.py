@@ -27,7 +27,10 @@ def build(force=False):
         os.path.getmtime(_ORACLE_SO) < os.path.getmtime(os.path.join(_HERE, "nthash_oracle.c"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF_SO)):
+    if os.path.isdir("/root/reference/src") and (
+        force or not os.path.exists(_REF_SO)
+        or os.path.getmtime(_REF_SO) < os.path.getmtime(os.path.join(_HERE, "ref_shim.cpp"))
+    ):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     # the reference's own test program linked with OUR facade library (run on the GPU box by
     # tests/test_gpu_facade.py); rebuilt whenever the facade library is newer
@@ -37,6 +40,11 @@ def build(force=False):
         force or not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(facade)
     ):
         subprocess.check_call(["make", "-C", _HERE, "ref_tests"], stdout=subprocess.DEVNULL)
+    bexe = os.path.join(_HERE, "_ref", "ref_benchmark_on_facade")
+    if os.path.isfile("/root/reference/examples/benchmark.cpp") and os.path.exists(facade) and (
+        force or not os.path.exists(bexe) or os.path.getmtime(bexe) < os.path.getmtime(facade)
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "ref_bench"], stdout=subprocess.DEVNULL)
 
 
 def _ptr(a, t):

@@ -8,6 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The C++ facade rolls sequences of up to 32768 bases on the host (a device round trip per object would cost more than
+# the hashing); the GPU tests are about the device path, so they send every sequence there.  One test re-runs the
+# facade suite in the default mode (tests/test_gpu_facade.py::test_facade_suite_again_*).
+os.environ.setdefault("NTHASH_AMD_FORCE_DEVICE", "1")
 
 
 def pytest_configure(config):

@@ -135,3 +135,137 @@ def test_reference_own_test_program_passes_on_our_library():
         pytest.skip("oracle/_ref/ref_tests_on_facade not built (needs the reference tree at build time)")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_long_sequence_streams_in_windows(facade, oracle):
+    """NtHash / SeedNtHash over a 30 kbase sequence with non-bases: the facade fetches the device stream window by
+    window (NTHASH_AMD_WINDOW; the re-run below uses 1024 positions, i.e. ~30 window changes) -- every roll() must
+    agree with the oracle's iterator"""
+    rng = np.random.default_rng(2024)
+    L, k = 30_000, 31
+    alph = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seq = alph[rng.integers(0, 4, L)].copy()
+    seq[rng.choice(L, 40, replace=False)] = ord("N")
+    seq[12_000:12_050] = ord("N")           # a stretch longer than k
+    s = seq.tobytes().decode()
+    ops = "r" * (L - k + 40)
+    a = facade.nthash_script(s, 2, k, 0, ops)
+    b = oracle.nthash_script(s, 2, k, 0, ops)
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x[0] == y[0] and x[1] == y[1]
+        if y[0]:
+            assert x[2] == y[2] and x[3] == y[3] and (x[4] == y[4]).all()
+    # roll back across a window boundary and forward again
+    ops2 = "r" * 2100 + "b" * 1500 + "r" * 3000
+    a = facade.nthash_script(s, 1, k, 500, ops2)
+    b = oracle.nthash_script(s, 1, k, 500, ops2)
+    for x, y in zip(a, b):
+        assert x[0] == y[0] and x[1] == y[1] and (not y[0] or (x[2] == y[2] and (x[4] == y[4]).all()))
+    # spaced seeds: against the batch oracle (positions and hashes of every emitted window)
+    seeds = ["1101101101101101011011011011011", "1010101010101010101010101010101"]
+    res = facade.seed_script(s, seeds, 2, k, 0, "r" * (L - k + 10))
+    want = oracle.seed_batch(seq, np.array([0, L], dtype=np.uint64), seeds, k, 2, want_pos=True)
+    got_pos = [r_[1] for r_ in res if r_[0]]
+    assert got_pos == [int(p) for p in want["pos"]]
+    got_h = np.array([r_[4] for r_ in res if r_[0]], dtype=np.uint64).reshape(-1, 4)
+    assert (got_h == want["hashes"].reshape(-1, 4)).all()
+
+
+def _rerun_suite(env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([os.sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_facade.py"), "-m", "gpu",
+                        "-q", "-x", "-k", "not again and not benchmark"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_facade_suite_again_in_host_roll_mode():
+    """the default mode: sequences of up to 32768 bases never go to the device (host recurrences); everything above
+    must give the same answers"""
+    _rerun_suite({"NTHASH_AMD_FORCE_DEVICE": "0"})
+
+
+def test_facade_suite_again_with_tiny_windows():
+    """every sequence on the device, in windows of 1024 positions"""
+    _rerun_suite({"NTHASH_AMD_FORCE_DEVICE": "1", "NTHASH_AMD_WINDOW": "1024"})
+
+
+BATCH_DRIVER = r"""
+#include <nthash/nthash.hpp>
+#include <cstdio>
+#include <iostream>
+#include <string>
+int main(int argc, char** argv) {
+  const unsigned m = std::stoi(argv[1]), k = std::stoi(argv[2]);
+  nthash::BatchNtHash b(m, k);
+  std::string line;
+  while (std::getline(std::cin, line)) b.add(line);
+  b.run();
+  std::printf("%zu %llu\n", b.size(), (unsigned long long)b.total());
+  for (size_t r = 0; r < b.size(); ++r) {
+    std::printf("%zu", b.count(r));
+    for (size_t j = 0; j < b.count(r); ++j) {
+      std::printf(" %u", b.positions(r)[j]);
+      for (unsigned h = 0; h < m; ++h) std::printf(" %016llx", (unsigned long long)b.hashes(r)[j * m + h]);
+    }
+    std::printf("\n");
+  }
+  b.clear();
+  b.add("ACGTACGTACGTACGTACGTACGTACGTACGTACGTAC");
+  b.run();
+  std::printf("%zu %llu\n", b.size(), (unsigned long long)b.total());
+  return 0;
+}
+"""
+
+
+def test_batch_nthash_helper(built_lib, oracle, tmp_path):
+    """nthash::BatchNtHash (our addition to the header): many reads, one device call, results in roll() order"""
+    lib = os.path.join(ROOT, "nthash_amd", "lib")
+    src = tmp_path / "batch.cpp"
+    src.write_text(BATCH_DRIVER)
+    exe = tmp_path / "batch"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe),
+                           f"-L{lib}", "-lnthash", "-lnthash_hip", f"-Wl,-rpath,{lib}"])
+    rng = np.random.default_rng(7)
+    alph = "ACGTACGTACGTNacgtu"
+    reads = ["".join(alph[i] for i in rng.integers(0, len(alph), int(rng.integers(0, 300)))) for _ in range(400)]
+    reads[3] = ""            # (an empty line is an empty read)
+    m, k = 3, 21
+    r = subprocess.run([str(exe), str(m), str(k)], input="\n".join(reads) + "\n", capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().split("\n")
+    d, offs = concat_reads([x.encode() for x in reads])
+    want = oracle.kmer_batch(d, offs, k, m, want_pos=True)
+    n, total = (int(x) for x in lines[0].split())
+    assert n == len(reads) and total == want["total"]
+    first = 0
+    for i in range(n):
+        f = lines[1 + i].split()
+        cnt = int(f[0])
+        assert cnt == int(want["counts"][i])
+        for j in range(cnt):
+            base = 1 + j * (1 + m)
+            assert int(f[base]) == int(want["pos"][first + j])
+            assert [int(x, 16) for x in f[base + 1: base + 1 + m]] == [int(x) for x in want["hashes"][first + j]]
+        first += cnt
+    assert lines[1 + n].split() == ["1", str(38 - k + 1)]
+
+
+def test_reference_benchmark_program_runs_fast_on_our_library():
+    """the reference's examples/benchmark.cpp (1 M objects of 100 bp, NtHash(seq, 3, 64)), unchanged, on our
+    library in its default mode: one object per short read must not cost a device round trip each"""
+    import time
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_benchmark_on_facade")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_benchmark_on_facade not built (needs the reference tree at build time)")
+    env = dict(os.environ)
+    env["NTHASH_AMD_FORCE_DEVICE"] = "0"
+    t0 = time.time()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    dt = time.time() - t0
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    elapsed = float(r.stdout.split()[0])   # the program prints the seconds of its hashing loop, then its checksum
+    assert elapsed < 2.0, (elapsed, dt)
