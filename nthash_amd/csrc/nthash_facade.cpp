@@ -762,8 +762,10 @@ void SeedNtHash::hash_backward(bool commit)
   const char* nw = seq_ + pos_;
   for (unsigned s = 0; s < n_seeds_; ++s) {
     uint64_t f, r;
-    seed_window_hash(seeds_->shapes[s], k_, [&](unsigned i) { return nw[i]; },
-                     [&](unsigned i) { return nw[i + 1]; }, &f, &r);
+    // (an object driven past its last window -- roll_back() after a roll() that failed while skipping -- would read
+    // beyond the sequence here, as the reference does: found by the sanitizer job; such bytes read as NUL)
+    seed_window_hash(seeds_->shapes[s], k_, [&](unsigned i) { return pos_ + i < len_ ? nw[i] : '\0'; },
+                     [&](unsigned i) { return pos_ + i + 1 < len_ ? nw[i + 1] : '\0'; }, &f, &r);
     if (commit) {
       fwd_[s] = f;
       rev_[s] = r;
