@@ -203,6 +203,9 @@ inline size_t lds_cap_of(const nthip_ctx* c) { return (c->lds_max < 160 * 1024 ?
 int device_exclusive_scan(nthip_ctx* c, const uint64_t* d_in, uint64_t* d_out, uint64_t n, uint64_t* d_sums,
                           uint64_t* d_total);
 int launch_fill_u64(nthip_ctx* c, uint64_t* d_dst, uint64_t n, uint64_t value);
+// do the n reads of a device offsets array all have one length (offsets[r + 1] - offsets[r] == offsets[1] - offsets[0])?
+int offsets_uniform_device(nthip_ctx* c, const uint64_t* d_offsets, uint64_t n_reads, uint64_t* off0, uint64_t* len0,
+                           bool* uniform);
 // get_pos() of reads that emit every window (flags/offsets: only the reads with flags[r] == 0, at offsets[r])
 int launch_fill_window_pos(nthip_ctx* c, uint32_t* d_pos, uint64_t n_reads, uint32_t nwin, const uint64_t* d_flags,
                            const uint64_t* d_offsets);

@@ -43,6 +43,26 @@ int launch_fill_window_pos(nthip_ctx* c, uint32_t* d_pos, uint64_t n_reads, uint
   return NTHIP_OK;
 }
 
+int offsets_uniform_device(nthip_ctx* c, const uint64_t* d_offsets, uint64_t n_reads, uint64_t* off0, uint64_t* len0,
+                           bool* uniform)
+{
+  *uniform = false;
+  uint64_t* d_res = (uint64_t*)(c->d_small + 208); // [0] offsets[0], [1] offsets[1], [2] "differs" flag
+  HIPCHK(hipMemsetAsync(d_res, 0, 24, c->stream));
+  uint64_t blocks = (n_reads + 255) / 256;
+  if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
+  hipLaunchKernelGGL(offsets_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_offsets, n_reads, d_res);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_small + 208, d_res, 24, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t res[3];
+  memcpy(res, c->h_small + 208, 24);
+  *off0 = res[0];
+  *len0 = res[1] >= res[0] ? res[1] - res[0] : 0;
+  *uniform = res[2] == 0 && res[1] >= res[0];
+  return NTHIP_OK;
+}
+
 // One pass over the offsets / spans before a kernel trusts them (a decreasing pair would underflow a length and
 // read far outside the buffer): costs one round trip, only on the paths that take caller-made offsets.
 int check_offsets_device(nthip_ctx* c, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,

@@ -31,6 +31,7 @@ extern "C" int nthip_kmer_hash_spans(nthip_ctx* c, const char* d_buf, uint64_t b
   HIPCHK(hipSetDevice(c->device));
   if (total_out) *total_out = 0;
   if (n_reads == 0) return NTHIP_OK;
+  NTCHK(check_offsets_device(c, d_starts, d_ends, n_reads, buf_bytes, false)); // spans inside the buffer, start <= end
   Staged st;
   st.seqs = (const uint8_t*)d_buf;
   NTCHK(stage_outputs(c, out, flags, n_reads, m, st));
@@ -50,7 +51,6 @@ extern "C" int nthip_seed_hash_spans(nthip_ctx* c, const char* d_buf, uint64_t b
                                      const uint64_t* d_ends, uint64_t n_reads, const nthip_seeds* sd, uint8_t m28,
                                      const nthip_out* out, uint64_t* total_out, uint32_t flags)
 {
-  (void)buf_bytes;
   if (!c || !sd) return fail(NTHIP_ERR_ARG, "ctx/seeds is NULL");
   if (!out || !out->hashes) return fail(NTHIP_ERR_ARG, "out->hashes is NULL");
   if (n_reads && (!d_buf || !d_starts || !d_ends)) return fail(NTHIP_ERR_ARG, "buffer / spans are NULL");
@@ -61,6 +61,7 @@ extern "C" int nthip_seed_hash_spans(nthip_ctx* c, const char* d_buf, uint64_t b
   if (total_out) *total_out = 0;
   if (n_reads == 0) return NTHIP_OK;
   const uint32_t per = sd->n_seeds * m2;
+  NTCHK(check_offsets_device(c, d_starts, d_ends, n_reads, buf_bytes, false)); // spans inside the buffer, start <= end
   Staged st;
   st.seqs = (const uint8_t*)d_buf;
   st.offsets = d_starts;

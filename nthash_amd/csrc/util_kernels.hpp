@@ -435,6 +435,19 @@ static __global__ __launch_bounds__(512) void fill16_kernel(uint4* __restrict__ 
     *((v4u*)dst + i) = v;
 }
 
+// res[0] = offsets[0], res[1] = offsets[1], res[2] != 0 iff some read's length differs from the first one's
+static __global__ __launch_bounds__(256) void offsets_uniform_kernel(const uint64_t* __restrict__ offsets, uint64_t n,
+                                                                     uint64_t* __restrict__ res)
+{
+  const uint64_t o0 = offsets[0], o1 = offsets[1];
+  const uint64_t len0 = o1 - o0;
+  uint32_t differs = o1 < o0 ? 1u : 0u;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x)
+    if (offsets[r + 1] - offsets[r] != len0) differs = 1u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { res[0] = o0; res[1] = o1; }
+  if (__ballot(differs != 0) != 0 && (threadIdx.x & 63u) == 0) atomicOr((unsigned long long*)&res[2], 1ull);
+}
+
 // spans / offsets sanity (the kernels trust them): every read must satisfy starts[r] <= ends[r] <= buf_bytes
 static __global__ __launch_bounds__(256) void check_spans_kernel(const uint64_t* __restrict__ starts,
                                                                  const uint64_t* __restrict__ ends, uint64_t n,

@@ -1386,3 +1386,61 @@ def test_async_dense_batches(ctx, oracle):
     assert tot == n * nwin
     for d in (d_in, d_out, d_offs):
         ctx.free(d)
+
+
+def test_uniform_offsets_take_the_fixed_length_kernels(ctx, oracle):
+    """offsets of equal-length, back-to-back reads (what nthash::BatchNtHash sends for Illumina reads) are recognised
+    and hashed by the fixed-stride kernels; one odd read anywhere keeps the variable-length path; same stream either way"""
+    rng = np.random.default_rng(5)
+    n, L, k, m = 5000, 150, 31, 2
+    data = oracle.synth_reads(17, n, L, 3)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=True)
+    for host in (True, False):
+        ctx.set_profiling(True)
+        if host:
+            got = ctx.kmer_hash(data, k, m, offsets=offs, want_pos=True)
+        else:
+            d_in = ctx.malloc(data.size + 64); d_off = ctx.malloc(offs.nbytes); d_out = ctx.malloc(want["total"] * m * 8)
+            ctx.h2d(d_in + 5, data); ctx.h2d(d_off, offs + np.uint64(5))   # offsets need not start at 0
+            tot = ctx.kmer_hash_ptr(d_in, d_off, n, 0, 0, k, m, d_out, want["total"])
+            h = np.zeros(want["hashes"].size, np.uint64); ctx.d2h(h, d_out)
+            got = {"total": tot, "hashes": h.reshape(want["hashes"].shape)}
+            ctx.free(d_in); ctx.free(d_off); ctx.free(d_out)
+        name = ctx.last_kernel_ms()[1]
+        ctx.set_profiling(False)
+        assert name.startswith("kmer_runs"), name
+        assert got["total"] == want["total"] and (got["hashes"] == want["hashes"]).all()
+        if host:
+            assert (got["pos"] == want["pos"]).all() and (got["counts"] == want["counts"]).all()
+    # one read one base shorter: not uniform
+    lens = np.full(n, L); lens[n // 2] = L - 1
+    offs2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    d2 = data[: int(offs2[-1])]
+    want2 = oracle.kmer_batch(d2, offs2, k, m, want_pos=False)
+    ctx.set_profiling(True)
+    got2 = ctx.kmer_hash(d2, k, m, offsets=offs2)
+    name = ctx.last_kernel_ms()[1]
+    ctx.set_profiling(False)
+    assert name == "kmer_ragged_kernel", name
+    assert got2["total"] == want2["total"] and (got2["hashes"] == want2["hashes"]).all()
+
+
+def test_bad_offsets_are_refused(ctx):
+    """a decreasing pair of offsets must come back as NTHIP_ERR_ARG, not as a wild read (the last offset IS the
+    buffer size in this layout, so it cannot be checked against anything; spans are checked against buf_bytes)"""
+    import nthash_amd
+    n, L = 2000, 100
+    data = np.frombuffer(b"ACGT" * (n * L // 4), dtype=np.uint8)
+    for bad_at, bad_val in ((700, 10), (1500, 0)):
+        offs = np.arange(n + 1, dtype=np.uint64) * L
+        offs[1] = L - 1           # (not uniform: the offsets are really used)
+        offs[bad_at] = bad_val
+        d_in = ctx.malloc(data.size); d_off = ctx.malloc(offs.nbytes); d_out = ctx.malloc(n * L * 8)
+        try:
+            ctx.h2d(d_in, data); ctx.h2d(d_off, offs)
+            with pytest.raises(nthash_amd.NtHipError) as e:
+                ctx.kmer_hash_ptr(d_in, d_off, n, 0, 0, 31, 1, d_out, n * L)
+            assert e.value.code == nthash_amd.capi.NTHIP_ERR_ARG
+        finally:
+            ctx.free(d_in); ctx.free(d_off); ctx.free(d_out)
