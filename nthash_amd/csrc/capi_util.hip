@@ -235,7 +235,10 @@ extern "C" int nthip_fill_bench(nthip_ctx* c, void* d_dst, size_t bytes, int rep
   float best = 1e30f;
   for (int i = 0; i < (reps > 0 ? reps : 1); ++i) {
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(fill16_kernel, dim3(c->n_cu), dim3(512), 0, c->stream, (uint4*)d_dst,
+    #ifndef FILL_WAVES
+#define FILL_WAVES 8
+#endif
+    hipLaunchKernelGGL(fill16_kernel, dim3(c->n_cu), dim3(FILL_WAVES * 64), 0, c->stream, (uint4*)d_dst,
                        (uint64_t)(bytes / 16), (uint32_t)i);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));

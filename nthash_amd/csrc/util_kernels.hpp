@@ -428,6 +428,9 @@ static __global__ __launch_bounds__(512) void fill16_kernel(uint4* __restrict__ 
       asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p + j * 64u), "v"(v) : "memory");
     if (lane < 32u) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p + 448u), "v"(v) : "memory");
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#ifdef FILL_SLEEP
+    __builtin_amdgcn_s_sleep(FILL_SLEEP);
+#endif
   }
   // the tail that is not a whole tile
   for (uint64_t i = n_tiles * TILE + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;

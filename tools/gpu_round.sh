@@ -1,4 +1,2 @@
-set -x
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -6
-python tools/ragged_bench.py 2>&1 | tail -4
+python tools/fill_probe.py fs8,fs32,fs64,fw4,fw2,fw4s16 24

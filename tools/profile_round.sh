@@ -12,10 +12,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o kt -- py
 find "$OUT/trace" -name "*stats*.csv" | head
 for f in $(find "$OUT/trace" -name "*kernel_stats.csv"); do cp "$f" "$OUT/kernel_stats.csv"; done
 cat "$OUT/kernel_stats.csv" 2>/dev/null | head -8
-python bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"; tail -c 1200 "$OUT/bench_c3.json"
-python bench.py --config c4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"; tail -c 1200 "$OUT/bench_c4.json"
+# (c3 / c4 / ref ride in the "secondary" object of the default line since round 2)
 bash tools/run_pmc.sh "$OUT/pmc_c2" c2 20000000 > "$OUT/pmc_c2.log" 2>&1
-cat "$OUT/pmc_c2/summary.txt" | grep -v "^copy" 
+cat "$OUT/pmc_c2/summary.txt" | grep -v "^copy"
+bash tools/run_pmc.sh "$OUT/pmc_c4" c4 8000000 > "$OUT/pmc_c4.log" 2>&1
+cat "$OUT/pmc_c4/summary.txt" | grep -v "^copy"
+find "$OUT/pmc_c4" -name "*kernel_trace.csv" -delete
 # keep only small summaries in the merge-back
 find "$OUT" -name "*.db" -delete; find "$OUT/pmc_c2" -name "*kernel_trace.csv" -delete
 du -sh "$OUT"
