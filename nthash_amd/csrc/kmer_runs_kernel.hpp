@@ -691,7 +691,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
       }
       if (__hip_atomic_load(a.dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
       if (T) {
-        wait_vmcnt<0>(); // paced: this wave's stores have reached memory before it reads
+        if (R > 1u) wait_vmcnt<0>(); // paced with a read window: this wave's stores have reached memory before it reads
         KR_DBG(0);
         const uint64_t now = __builtin_amdgcn_s_memrealtime();
         if (now >= t_read + T) t_read = (now / T) * T; // more than a period late: rejoin the grid, no waiting

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Throughput on a FASTQ-like batch: variable-length reads (100..150 bp) with occasional N, device-resident."""
+"""Throughput on a FASTQ-like batch: variable-length reads (100..150 bp) with occasional N, device-resident.
+RAGGED_MOSTLY=150: all reads that long except one in a thousand (trimmed to 100..149) -- an Illumina run as it comes."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,6 +10,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 k, m = 31, 1
 rng = np.random.default_rng(1)
 lens = rng.integers(100, 151, n).astype(np.uint64)
+if os.environ.get("RAGGED_MOSTLY"):
+    full = int(os.environ["RAGGED_MOSTLY"])
+    lens = np.where(rng.random(n) < 0.001, rng.integers(100, full, n), full).astype(np.uint64)
 offs = np.zeros(n + 1, np.uint64); offs[1:] = np.cumsum(lens)
 total_bytes = int(offs[-1])
 ctx = nthash_amd.Context(0)
