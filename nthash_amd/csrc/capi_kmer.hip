@@ -170,9 +170,17 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
           nthip_reads slice = *rd;
           const uint64_t want = (128ull << 20) / nwin + 1; // ~128 M k-mers (a quarter of a millisecond) per trial
           slice.n_reads = rd->n_reads < want ? rd->n_reads : want;
-          hipEvent_t e0 = nullptr, e1 = nullptr;
-          HIPCHK(hipEventCreate(&e0));
-          HIPCHK(hipEventCreate(&e1));
+          struct EventPair { // destroyed on every way out of the trials
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            ~EventPair()
+            {
+              if (e0) (void)hipEventDestroy(e0);
+              if (e1) (void)hipEventDestroy(e1);
+            }
+          } ev;
+          HIPCHK(hipEventCreate(&ev.e0));
+          HIPCHK(hipEventCreate(&ev.e1));
+          hipEvent_t e0 = ev.e0, e1 = ev.e1;
           float best_ms = 1e30f;
           bool clean = true;
           for (uint32_t i = 0; i < n_cand && clean; ++i) {
@@ -199,8 +207,6 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
             // (the model's choice is the first candidate: another one has to beat it by 3 % to replace it)
             if (clean && ms < (i == 0 ? best_ms : 0.97f * best_ms)) { best_ms = ms; best_c = cand[i]; }
           }
-          (void)hipEventDestroy(e0);
-          (void)hipEventDestroy(e1);
           if (clean) tuned = c->run_len_cache.emplace(shape_key, best_c).first;
           else HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream)); // the real pass below finds it again
         } else {
@@ -291,7 +297,10 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
             trc = run_kmer_na(c, st, &slice, k, m, q, consts, out->capacity, &tt);
             sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
           }
-          if (trc != NTHIP_OK) { c->profiling = prof; return trc; }
+          if (trc != NTHIP_OK) { // (capacity included: the real pass below reports it, with *total set) no tuning
+            best_c = na_plan.g.C;
+            break;
+          }
           if (sec < (i == 0 ? best_s : 0.96 * best_s)) { best_s = sec; best_c = cand[i]; }
         }
         c->profiling = prof;
