@@ -244,7 +244,7 @@ void load_tuning(nthip_tune& t)
   t.no_seed_wave = is_set("NTHIP_TUNE_NO_SEED_WAVE");
   t.no_seed_wtile = is_one("NTHIP_TUNE_NO_SEED_WTILE");
   t.no_phases = is_one("NTHIP_TUNE_NO_PHASES");
-  t.pacing = is_one("NTHIP_TUNE_PACING");
+  t.no_pacing = is_one("NTHIP_TUNE_NO_PACING");
   t.ph_tiles = num("NTHIP_TUNE_PH_TILES", 1, 64);
   t.ph_period = num("NTHIP_TUNE_PH_PERIOD", 1, 10000000);
   t.ph_read = num("NTHIP_TUNE_PH_READ", 1, 10000000);

@@ -78,7 +78,7 @@ struct nthip_tune {
   bool no_seed_wtile = false; // NTHIP_TUNE_NO_SEED_WTILE=1: the block-tile dense seed kernel instead of the wave-tile one
   // phased headline kernel (kmer_runs_kernel.hpp): tiles per wave and period, period / read window in 10 ns ticks
   bool no_phases = false;   // NTHIP_TUNE_NO_PHASES=1: the static loop (one tile ahead) instead of dynamic chunks
-  bool pacing = false;      // NTHIP_TUNE_PACING=1: chunk loads in chip-wide windows of the 100 MHz clock
+  bool no_pacing = false;   // NTHIP_TUNE_NO_PACING=1 (windowed builds): groups of tiles, but no waiting for the clock
   uint32_t ph_tiles = 0;    // NTHIP_TUNE_PH_TILES
   uint32_t ph_period = 0;   // NTHIP_TUNE_PH_PERIOD
   uint32_t ph_read = 0;     // NTHIP_TUNE_PH_READ

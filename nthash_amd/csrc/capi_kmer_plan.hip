@@ -133,7 +133,8 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
   const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
   // chunked path (kmer_runs_kernel.hpp, only when compiled in): every wave keeps the bit streams of a chunk's tiles
   // in LDS and is limited to 8 waves per CU
-  const bool chunked = kmer_runs_chunked_compiled() && p->dword_tail && !c->tune.no_phases && (m == 1 || c->tune.ph_tiles);
+  const bool chunked = kmer_runs_chunked_compiled() && p->dword_tail && !c->tune.no_phases && m == 1 &&
+                       64 % p->rpr == 0 && stride == len; // (tiles are whole reads)
   p->ph_tiles = chunked ? (c->tune.ph_tiles ? (c->tune.ph_tiles < 16u ? c->tune.ph_tiles : 16u) : 16u) : 0u;
   const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4 * (p->ph_tiles ? p->ph_tiles : 1u);
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
@@ -141,7 +142,7 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
   // 8 were 2 % ahead); m > 1: the copy-out does the multi-hash expansion and more waves hide it (+6 % m=4, +9 % m=8)
   uint32_t w_max = 16;
   if (c->tune.waves) w_max = c->tune.waves;
-  if (chunked && m == 1 && w_max > 8) w_max = 8; // (launch bounds of the chunked build's m = 1 kernels)
+  if (kmer_runs_chunked_compiled() && m == 1 && w_max > 8) w_max = 8; // (launch bounds of a windowed build's m = 1 kernels)
   for (uint32_t w = w_max; w >= 1; --w) {
     if (fixed + per_wave * w <= cap) {
       p->waves = w;

@@ -16,17 +16,7 @@ int launch_kmer_runs(nthip_ctx* c, K kernel, KmerRunsArgs a, size_t dyn_lds)
   uint64_t grid = (uint64_t)c->n_cu * per_cu;
   if (grid > need) grid = need;
   if (a.tile_map == 0xFFFFFFFFu) a.tile_map = (uint32_t)grid; // every block streams its own range
-  if (a.ph_tiles) {
-    // chunks of ph_tiles tiles are handed out through a counter: enough blocks to fill the chip, however few tiles
-    a.chunk_counter = (uint32_t*)(c->d_small + 192);
-    HIPCHK(hipMemsetAsync(a.chunk_counter, 0, 4, c->stream));
-    const uint64_t n_chunks = (a.n_wtiles + a.ph_tiles - 1) / a.ph_tiles;
-    if (n_chunks > 0xFFFF0000ull) return fail(NTHIP_ERR_UNSUPPORTED, "too many reads for one call");
-    const uint64_t need2 = (n_chunks + a.waves - 1) / a.waves;
-    grid = (uint64_t)c->n_cu * per_cu;
-    if (grid > need2) grid = need2;
-  }
-  if (a.ph_tiles && c->tune.pacing) {
+  if (a.ph_tiles && !c->tune.no_pacing) {
     // period of the phased path = the time HBM needs for what the chip reads and writes in one period, apart:
     // reads at ~6.0 TB/s, write-through stores at ~6.8 TB/s (measured with the hash switched off), in ticks of 10 ns
     const double kmers = (double)grid * a.waves * a.ph_tiles * 64.0 * a.C;

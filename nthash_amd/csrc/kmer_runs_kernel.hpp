@@ -31,11 +31,12 @@
 namespace ntamd {
 
 constexpr int KR_MAX_THREADS = 1024;
-// KR_CHUNKED=1 compiles the chunked path in (dynamic chunks of 16 tiles, the next chunk's 16 slabs in flight in 80
-// registers, optional chip-wide read windows: see the end of the kernel and profiles/r02_notes.md).  It needs the
-// m = 1 instantiations limited to 8 waves per CU (256 registers per lane); measured equal to or slower than the static
-// loop at 16 waves on every box tried, so it is off -- kept because it is the only structure in which HBM served the
-// two streams apart (17.3 ms against 18.8 ms per 100 M reads with the hash switched off).
+// KR_CHUNKED=1 compiles the windowed path in (the end of the kernel; profiles/r02_notes.md): every wave of the chip loads
+// the slabs of its next 16 tiles inside a common window of the constant 100 MHz clock and hashes / writes outside it.
+// It is the only structure in which HBM served the two streams apart -- 17.1-17.9 ms against 18.5-18.9 ms per 100 M
+// reads with the hash switched off -- but with the hash on a period holds 5 us of loads + 6 us of packing + 34 us of
+// hashing at the 8 waves per CU its 80 slab registers allow, which is the period HBM needs: 19.9-20.6 ms against
+// 19.3-19.6 for the static loop at 16 waves on the same boxes.  Off; parity-tested (tests run it through NTHASH_AMD_LIB).
 #ifndef KR_CHUNKED
 #define KR_CHUNKED 0
 #endif
@@ -92,11 +93,9 @@ struct KmerRunsArgs {
   uint32_t inv_rpr;      // floor(65536 / rpr) + 1
   uint32_t dword_tail;   // every slab is <= 1280 bytes: tail staged as one dword per lane
   uint32_t tile_map;     // number of wave groups of the tile -> wave mapping (see the kernel)
-  // chunked path (DT shapes): tiles per chunk (0 = the static loop; every wave has that many bit streams in LDS),
-  // optional pacing (period and read window in ticks of the constant 100 MHz clock, 0 = none), the chunk counter
-  // (zeroed before the launch)
+  // windowed path (KR_CHUNKED builds): tiles per period (0 = the static loop; every wave has that many bit streams in
+  // LDS), period and read window in ticks of the constant 100 MHz clock (period 0 = groups without pacing)
   uint32_t ph_tiles, ph_period, ph_read;
-  uint32_t* chunk_counter;
   uint64_t tab[16][2];
   uint64_t mult[KF_MAX_RUNTIME_M];
 };
@@ -549,43 +548,22 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
   }
 #if KR_CHUNKED
   else {
-    // ---- chunked path (DT shapes): a wave works through CHUNKS of P consecutive tiles that it takes from a global
-    // counter, one after the other.
-    // * Dynamic, because the waves of a launch are far from equally fast: with the static split (every block an equal
-    //   range) the first wave finished after 15.2 ms and the last after 19.6 ms of the same launch (profiles/
-    //   r02_notes.md) -- a fifth of the chip idles towards the end.  A chunk is 120 KiB of contiguous output.
-    // * The slabs of the NEXT chunk (P times ~1.2 KB) are loaded while this chunk is hashed: 16 slabs per lane in
-    //   flight in 80 registers, so no wave ever waits for a slab it asked for one tile ago.
-    // * Optional pacing (a.ph_period != 0): all waves of the chip issue those loads in the same window of the constant
-    //   100 MHz clock (s_memrealtime; period n starts at tick n * T, the stores of a chunk's first tile wait until
-    //   R ticks into it), so that HBM sees its reads and writes apart.  With the hash switched off the two streams
-    //   take 17.3 ms apart against 18.8 ms mixed; what the full kernel gains depends on the box, hence a knob.
+    // ---- windowed path (DT shapes whose tiles are whole reads: 64 % rpr == 0, stride == len) --------------------------
+    // HBM serves this kernel's two streams far better apart than mixed (profiles/r02_notes.md: with the hash switched
+    // off, 18.6 ms per 100 M reads mixed, 17.3 ms or less in phases).  So every wave of the chip READS in the same time
+    // window and writes outside it.  The windows are defined on the constant 100 MHz clock every CU sees
+    // (s_memrealtime): period n starts at tick n * T on all of them, nothing is exchanged to keep the waves in step.
+    //   [0, ~R)   the slabs of the wave's next P tiles: 2 P loads in flight in 5 P registers, packed into P bit streams in LDS
+    //   [~R, T)   the P tiles hashed and written, one after the other
+    // A wave that falls more than a period behind stops waiting (the streams then simply mix, as in the static loop).
+    // T comes from the host (bytes per period over the rates measured apart; NTHIP_TUNE_PH_PERIOD), 0 = no pacing.
     const uint32_t P = a.ph_tiles;
     uint32_t* const bits0 = bits;
-    struct Coord { uint64_t rf; uint32_t rm; }; // (first read, run inside it) of a tile's first run
-    const uint32_t t_q = 64u / a.rpr, t_r = 64u - t_q * a.rpr; // consecutive tiles: 64 runs further
-    auto advance = [&](Coord& c) {
-      c.rf += t_q;
-      c.rm += t_r;
-      if (c.rm >= a.rpr) { c.rm -= a.rpr; c.rf += 1; }
-    };
-    auto coord_of = [&](const uint64_t t) -> Coord {
-      const uint64_t rf = (t * 64u) / a.rpr;
-      return Coord{rf, (uint32_t)(t * 64u - rf * a.rpr)};
-    };
+    const uint32_t reads_per_tile = 64u / a.rpr;
+    const uint64_t tile_bytes = (uint64_t)reads_per_tile * a.stride; // consecutive tiles: this many bytes further
+    const uint32_t slab_bytes = (reads_per_tile - 1u) * a.stride + a.len;
     auto spin_until = [&](const uint64_t tick) {
       while (__builtin_amdgcn_s_memrealtime() < tick) __builtin_amdgcn_s_sleep(1);
-    };
-    const uint64_t n_chunks = (a.n_wtiles + P - 1u) / P;
-    auto next_chunk = [&]() -> uint64_t { // wave-uniform
-      uint32_t c = 0;
-      if (lane == 0) c = atomicAdd(a.chunk_counter, 1u);
-      return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(c);
-    };
-    auto chunk_tiles = [&](const uint64_t chunk) -> uint32_t {
-      if (chunk >= n_chunks) return 0u;
-      const uint64_t left = a.n_wtiles - chunk * P;
-      return left < P ? (uint32_t)left : P;
     };
     const uint64_t T = a.ph_period, R = a.ph_read;
     uint64_t t_read = 0;
@@ -601,88 +579,74 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
 #ifndef KR_LOAD_NT
 #define KR_LOAD_NT " sc1 nt"
 #endif
-    v4u v[RND];
-    uint32_t w4[RND];
-    uint32_t meta[RND]; // per slab: shift | n_vec << 8 | n_dw << 16 | edge << 31 (wave-uniform: scalar registers)
-    // Every lane issues the loads of a chunk's slabs back to back, without a branch in between (behind a branch hipcc
-    // waits for the previous load before it issues the next: 16 memory latencies in a row); a chunk of fewer tiles
-    // loads its last slab again.  t_first: the chunk's first tile.
-    auto issue_chunk = [&](const uint64_t t_first, const uint32_t n) {
-      Coord c = coord_of(t_first);
+    while (wt < wt_end) {
+      const uint64_t left = (wt_end - wt + wstride - 1u) / wstride;
+      const uint32_t n_here = left < P ? (uint32_t)left : P;
+      KR_DBG(4);
+      if (T) {
+        const uint64_t now = __builtin_amdgcn_s_memrealtime();
+        if (now >= t_read + T) t_read = (now / T) * T; // more than a period late: rejoin the grid, no waiting
+        spin_until(t_read);
+      }
+      KR_DBG(1);
+      // ---- read window: every load of the group back to back (no branch in between: behind one hipcc waits for the
+      // previous load before it issues the next), one wait, then the packing ----
+      v4u v[RND];
+      uint32_t w4[RND];
+      uint32_t shifts[RND];
+      const uint64_t base_addr = (uint64_t)a.seqs;
 #pragma unroll
       for (uint32_t i = 0; i < RND; ++i) {
-        const Slab sl = slab_of((t_first + (i < n ? i : n - 1u)) * 64u, c.rf, c.rm);
-        Coord nx = c;
-        advance(nx);
-        const bool more = i + 1u < n;
-        c.rf = more ? nx.rf : c.rf;
-        c.rm = more ? nx.rm : c.rm;
-        const uint32_t n_dw = (sl.shift + sl.slab_bytes + 3u) >> 2;
-        meta[i] = (uint32_t)__builtin_amdgcn_readfirstlane(sl.shift | (sl.n_vec << 8) | (n_dw << 16) | (sl.edge << 31));
-        const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sl.byte0) |
-                              ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sl.byte0 >> 32)) << 32);
-        const uint32_t i0 = lane < sl.n_vec ? lane : 0u;
+        const uint64_t t = wt + (uint64_t)(i < n_here ? i : n_here - 1u) * wstride; // (a short group loads its last slab again)
+        const uint64_t off = t * tile_bytes;
+        const uint32_t shift = (uint32_t)((base_addr + off) & 15u);
+        shifts[i] = shift;
+        const uint64_t b0 = off - shift;
+        const uint32_t n_vec = (shift + slab_bytes + 15u) >> 4;
+        const uint32_t n_dw = (shift + slab_bytes + 3u) >> 2;
+        const uint32_t i0 = lane < n_vec ? lane : 0u;
         const uint32_t jd = 256u + lane < n_dw ? 256u + lane : 0u;
 #if KR_ABL_NOLOAD
         v[i] = v4u{0x41414141u, 0x43434343u, 0x47474747u, 0x54545454u};
         w4[i] = 0x41434754u;
-        (void)i0; (void)jd; (void)base;
+        (void)i0; (void)jd; (void)b0;
 #else
-        // hidden from hipcc on purpose: it would wait for these loads by counting down vmcnt where they are used, a
-        // chunk later, behind the chunk's 128 stores -- i.e. for the store acknowledgements.  See loads_landed()
-        // for why no wait is needed at all.  (scalar base + 32-bit lane offset: no 64-bit vector arithmetic)
-        const uint8_t* sbase = a.seqs + base;
+        const uint64_t sb = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b0) |
+                            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b0 >> 32)) << 32);
+        const uint8_t* sbase = a.seqs + sb; // scalar base + 32-bit lane offset
         asm volatile("global_load_dwordx4 %0, %2, %4" KR_LOAD_NT "\n\tglobal_load_dword %1, %3, %4" KR_LOAD_NT
                      : "=&v"(v[i]), "=&v"(w4[i])
                      : "v"(i0 << 4), "v"(jd << 2), "s"(sbase)
                      : "memory");
 #endif
       }
-    };
-    // ... and packs them into the chunk's bit streams (bits0 + q * bits_dwords)
-    auto pack_chunk = [&](const uint64_t t_first, const uint32_t n) {
+      // everything this wave has in flight: the loads above and, older, the stores of its previous group
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                     "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                   :: "memory");
+      asm volatile("" : "+v"(w4[0]), "+v"(w4[1]), "+v"(w4[2]), "+v"(w4[3]), "+v"(w4[4]), "+v"(w4[5]), "+v"(w4[6]), "+v"(w4[7]),
+                        "+v"(w4[8]), "+v"(w4[9]), "+v"(w4[10]), "+v"(w4[11]), "+v"(w4[12]), "+v"(w4[13]), "+v"(w4[14]), "+v"(w4[15])::"memory");
+      KR_DBG(0);
 #pragma unroll
       for (uint32_t i = 0; i < RND; ++i) {
-        if (i < n) {
+        if (i < n_here) {
+          const uint64_t t = wt + (uint64_t)i * wstride;
           Slab sl;
-          sl.shift = meta[i] & 0xFFu;
-          sl.n_vec = (meta[i] >> 8) & 0xFFu;
-          sl.edge = 0u;
-          sl.slab_bytes = 0u; // (only the edge path looks at it)
+          sl.shift = shifts[i];
+          sl.slab_bytes = slab_bytes;
+          sl.n_vec = (shifts[i] + slab_bytes + 15u) >> 4;
           sl.byte0 = 0;
-          sl.runs_here = 0;
-          const uint32_t n_dw = (meta[i] >> 16) & 0x7FFFu;
-          if (meta[i] >> 31) { // first / last slab of the buffer
-            const Coord c = coord_of(t_first + i);
-            sl = slab_of((t_first + i) * 64u, c.rf, c.rm);
-          }
+          sl.runs_here = 64u;
+          sl.edge = (t == 0u || (t + 1u) * reads_per_tile >= a.n_reads) ? 1u : 0u; // first / last slab of the buffer
           bits = bits0 + i * a.bits_dwords;
           if (lane < sl.n_vec) pack_vec(sl, lane, make_uint4(v[i].x, v[i].y, v[i].z, v[i].w));
+          const uint32_t n_dw = (sl.shift + slab_bytes + 3u) >> 2;
           if (256u + lane < n_dw) pack_dword(sl, lane, w4[i]);
           if (lane < (uint32_t)NW + 3u) bits[sl.n_vec + lane] = 0;
         }
       }
-    };
-    // The slab registers are read a chunk after their loads were issued.  vmcnt retires in order and never holds
-    // more than 63 operations, so once this wave has ISSUED 64 younger vector-memory operations (8 full tiles of
-    // stores) the loads have landed; a shorter chunk waits for everything.  The empty statements name every
-    // destination register, which keeps hipcc from touching them before this point.
-    auto loads_landed = [&](const uint32_t younger_ops) {
-      if (younger_ops < 64u) wait_vmcnt<0>();
-      asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                        "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])::"memory");
-      asm volatile("" : "+v"(w4[0]), "+v"(w4[1]), "+v"(w4[2]), "+v"(w4[3]), "+v"(w4[4]), "+v"(w4[5]), "+v"(w4[6]), "+v"(w4[7]),
-                        "+v"(w4[8]), "+v"(w4[9]), "+v"(w4[10]), "+v"(w4[11]), "+v"(w4[12]), "+v"(w4[13]), "+v"(w4[14]), "+v"(w4[15])::"memory");
-    };
-    // prologue: the first chunk, loaded and packed at once
-    uint64_t chunk = next_chunk();
-    uint32_t n_here = chunk_tiles(chunk);
-    if (n_here) {
-      issue_chunk(chunk * P, n_here);
-      loads_landed(0u);
-      pack_chunk(chunk * P, n_here);
-    }
-    while (n_here) {
+      KR_DBG(2);
       // a non-base anywhere in the batch (found here or by another wave): the caller redoes the batch on the
       // N-aware path, so stop producing a dense stream nobody will read
       if (__ballot(bad != 0) != 0) {
@@ -690,50 +654,26 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
         break;
       }
       if (__hip_atomic_load(a.dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-      if (T) {
-        if (R > 1u) wait_vmcnt<0>(); // paced with a read window: this wave's stores have reached memory before it reads
-        KR_DBG(0);
-        const uint64_t now = __builtin_amdgcn_s_memrealtime();
-        if (now >= t_read + T) t_read = (now / T) * T; // more than a period late: rejoin the grid, no waiting
-        spin_until(t_read);
-        KR_DBG(1);
-      }
-      // ---- the loads of the NEXT chunk go out; they are consumed when this chunk has been hashed ----
-      const uint64_t chunk_next = next_chunk();
-      const uint32_t n_next = chunk_tiles(chunk_next);
-      if (n_next) issue_chunk(chunk_next * P, n_next);
-      KR_DBG(2);
-      // ---- this chunk: hash and write ----
-      Coord cw = coord_of(chunk * P);
+      // ---- write window ----
+      if (T && R) spin_until(t_read + R);
+      KR_DBG(3);
       for (uint32_t q = 0; q < n_here; ++q) {
-        const uint64_t g0 = (chunk * P + q) * 64u;
+        const uint64_t t = wt + (uint64_t)q * wstride;
+        const uint64_t g0 = t * 64u;
         const uint64_t runs_left = a.n_runs - g0;
         const uint32_t runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
-        const uint32_t shift = (uint32_t)(((uint64_t)a.seqs + cw.rf * a.stride) & (uint32_t)(KR_SLAB_ALIGN - 1));
+        const uint32_t shift = (uint32_t)((base_addr + t * tile_bytes) & 15u);
         bits = bits0 + q * a.bits_dwords;
         lds_sync();
-        hash_tile(shift, runs_here, cw.rm);
-        if (q == 0u && T) {
-          KR_DBG(4);
-          spin_until(t_read + R); // (paced: the first tile's stores wait for the end of the read window)
-          KR_DBG(3);
-        }
+        hash_tile(shift, runs_here, 0u);
         (void)copy_out(g0, runs_here);
         lds_sync(); // the tile is free again
-        advance(cw);
       }
-      KR_DBG(4);
-      // ---- the next chunk's slabs arrived long ago: pack them (every bit stream of this chunk has been hashed) ----
-      if (n_next) {
-        loads_landed(m == 1u && C_T != 0 ? NST * n_here : 0u); // (only the m = 1 copy-out has a fixed store count)
-        pack_chunk(chunk_next * P, n_next);
-      }
-      KR_DBG(2);
-      chunk = chunk_next;
-      n_here = n_next;
+      wt += (uint64_t)n_here * wstride;
       t_read += T;
     }
 #if KR_DEBUG_TIMES
+    KR_DBG(4);
     if (lane == 0) {
       for (int i = 0; i < 5; ++i) atomicAdd((unsigned long long*)(a.dirty + 16) + i, (unsigned long long)dbg[i]);
       const unsigned long long el = __builtin_amdgcn_s_memrealtime() - dbg_start;
