@@ -1444,3 +1444,21 @@ def test_bad_offsets_are_refused(ctx):
             assert e.value.code == nthash_amd.capi.NTHIP_ERR_ARG
         finally:
             ctx.free(d_in); ctx.free(d_off); ctx.free(d_out)
+
+
+def test_windowed_build_of_the_headline_kernel_is_bit_exact():
+    """-DKR_CHUNKED=1 (kmer_runs_kernel.hpp: chip-wide read windows paced by the 100 MHz clock; off by default because
+    it is not faster) must stay bit-exact: this file's k-mer tests again, through that build of the library"""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    subprocess.check_call([sys.executable, "-m", "nthash_amd.build", "--tag", "win", "--flags", "-DKR_CHUNKED=1", "--units",
+                           "capi_kmer_runs"], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lib = os.path.join(ROOT, "nthash_amd", "lib", "ab", "libnthash_hip_win.so")
+    env = dict(os.environ, NTHASH_AMD_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "kmer and not windowed and not native_library"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
