@@ -279,6 +279,27 @@ int nthip_fastx_seed_hash_file(nthip_ctx* ctx, const char* path, uint32_t format
                                uint8_t m2, uint64_t chunk_bytes, nthip_fastx_fn fn, void* user,
                                nthip_fastx_stats* stats);
 
+/* ---- one node, several GPUs --------------------------------
+ * Reads are hashed independently of each other (reference include/nthash/nthash.hpp:196-204: all state is per
+ * object), so a HOST-resident batch is cut into contiguous shards of reads, one per device, hashed concurrently by one
+ * host thread and one context per device; nothing is exchanged.  The result is exactly what ONE nthip_kmer_hash /
+ * nthip_seed_hash call returns for the whole batch (read order, N-skipping, counts, positions).  out->capacity must
+ * hold every window of the batch (sum over reads of max(len - k + 1, 0)): shards write in place and only move when
+ * reads with non-bases left gaps.  devices == NULL: every visible device; a device may be listed more than once
+ * (that is how the path is tested on a one-GPU box). */
+typedef struct nthip_multi nthip_multi;
+typedef struct nthip_multi_seeds nthip_multi_seeds;
+int nthip_multi_create(const int* devices, int n_devices, nthip_multi** out);
+int nthip_multi_destroy(nthip_multi* multi);
+int nthip_multi_device_count(const nthip_multi* multi, int* n);
+int nthip_multi_kmer_hash(nthip_multi* multi, const nthip_reads* reads, uint16_t k, uint8_t m, const nthip_out* out,
+                          uint64_t* total);
+int nthip_multi_seeds_create(nthip_multi* multi, const char* const* seeds, uint32_t n_seeds, uint16_t k,
+                             nthip_multi_seeds** out, int* asymmetric);
+int nthip_multi_seeds_destroy(nthip_multi_seeds* seeds);
+int nthip_multi_seed_hash(nthip_multi* multi, const nthip_reads* reads, const nthip_multi_seeds* seeds, uint8_t m2,
+                          const nthip_out* out, uint64_t* total);
+
 /* ---- measurement helpers (device-resident synthetic data, checksums) ---- */
 /* counter-based reads: read r, 32-base word w ->
  * splitmix64(seed + r*W + w), 2 bits per base, "ACGT"[..]; writes

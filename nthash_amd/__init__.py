@@ -7,6 +7,6 @@ The product is the C-ABI shared library nthash_amd/lib/libnthash_hip.so
 tests and bench.py; importing it never falls back to a CPU implementation.
 """
 from . import capi  # noqa: F401
-from .capi import Context, NtHipError, Seeds, device_count, load  # noqa: F401
+from .capi import Context, Multi, NtHipError, Seeds, device_count, load  # noqa: F401
 
-__all__ = ["capi", "Context", "NtHipError", "Seeds", "device_count", "load"]
+__all__ = ["capi", "Context", "Multi", "NtHipError", "Seeds", "device_count", "load"]

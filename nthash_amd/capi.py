@@ -37,6 +37,8 @@ SYMBOLS = [
     "nthip_kmer_bloom_query", "nthip_kmer_minhash", "nthip_stream_bloom_insert", "nthip_kmer_hash_spans", "nthip_fastx_index",
     "nthip_fastx_kmer_hash_file", "nthip_fastx_seed_hash_file", "nthip_seed_hash_spans", "nthip_fasta_compact", "nthip_synth_reads", "nthip_checksum",
     "nthip_copy_bench", "nthip_fill_bench", "nthip_ctx_reload_tuning",
+    "nthip_multi_create", "nthip_multi_destroy", "nthip_multi_device_count", "nthip_multi_kmer_hash",
+    "nthip_multi_seeds_create", "nthip_multi_seeds_destroy", "nthip_multi_seed_hash",
 ]
 
 
@@ -127,6 +129,13 @@ def load():
     L.nthip_copy_bench.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
     L.nthip_fill_bench.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
     L.nthip_ctx_reload_tuning.argtypes = [vp]
+    L.nthip_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.nthip_multi_destroy.argtypes = [vp]
+    L.nthip_multi_device_count.argtypes = [vp, C.POINTER(C.c_int)]
+    L.nthip_multi_kmer_hash.argtypes = [vp, vp, C.c_uint16, C.c_uint8, vp, C.POINTER(u64)]
+    L.nthip_multi_seeds_create.argtypes = [vp, C.POINTER(C.c_char_p), u32, C.c_uint16, C.POINTER(vp), C.POINTER(C.c_int)]
+    L.nthip_multi_seeds_destroy.argtypes = [vp]
+    L.nthip_multi_seed_hash.argtypes = [vp, vp, vp, C.c_uint8, vp, C.POINTER(u64)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("nthip_version", "nthip_last_error"):
@@ -482,3 +491,79 @@ class Context:
         if want_pos:
             out["pos"] = pos[:total]
         return out
+
+
+class Multi:
+    """Several devices of one node (nthip_multi_*): host-resident batches, cut into contiguous shards of reads, one per
+    device, hashed concurrently.  devices=None: every visible device; a device may be listed more than once."""
+
+    def __init__(self, devices=None):
+        self.L = load()
+        self.h = C.c_void_p()
+        if devices is None:
+            _chk(self.L.nthip_multi_create(None, 0, C.byref(self.h)))
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            _chk(self.L.nthip_multi_create(arr, len(devices), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.nthip_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_count(self):
+        n = C.c_int(0)
+        _chk(self.L.nthip_multi_device_count(self.h, C.byref(n)))
+        return n.value
+
+    def kmer_hash(self, data, k, m, offsets=None, fixed_len=0, stride=0, n_reads=None, want_pos=False):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            n_reads = len(offsets) - 1
+        cap = max(Context._cap(offsets, fixed_len, stride, n_reads, k), 1)
+        hashes = np.zeros(cap * m, np.uint64)
+        counts = np.zeros(max(n_reads, 1), np.uint64)
+        pos = np.zeros(cap, np.uint32) if want_pos else None
+        p = lambda a: a.ctypes.data if a is not None else 0
+        rd = Reads(p(data), p(offsets) or None, n_reads, fixed_len, stride)
+        out = Out(p(hashes), cap, p(counts), p(pos) or None, None, None)
+        total = C.c_uint64(0)
+        _chk(self.L.nthip_multi_kmer_hash(self.h, C.byref(rd), k, m, C.byref(out), C.byref(total)))
+        res = {"total": total.value, "hashes": hashes[: total.value * m].reshape(total.value, m), "counts": counts[:n_reads]}
+        if want_pos:
+            res["pos"] = pos[: total.value]
+        return res
+
+    def seed_hash(self, data, seeds, k, m2, offsets=None, fixed_len=0, stride=0, n_reads=None, want_pos=False):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            n_reads = len(offsets) - 1
+        bs = [s_.encode("latin-1") for s_ in seeds]
+        arr = (C.c_char_p * len(bs))(*bs)
+        ms = C.c_void_p()
+        _chk(self.L.nthip_multi_seeds_create(self.h, arr, len(bs), k, C.byref(ms), None))
+        try:
+            per = len(bs) * m2
+            cap = max(Context._cap(offsets, fixed_len, stride, n_reads, k), 1)
+            hashes = np.zeros(cap * per, np.uint64)
+            counts = np.zeros(max(n_reads, 1), np.uint64)
+            pos = np.zeros(cap, np.uint32) if want_pos else None
+            p = lambda a: a.ctypes.data if a is not None else 0
+            rd = Reads(p(data), p(offsets) or None, n_reads, fixed_len, stride)
+            out = Out(p(hashes), cap, p(counts), p(pos) or None, None, None)
+            total = C.c_uint64(0)
+            _chk(self.L.nthip_multi_seed_hash(self.h, C.byref(rd), ms, m2, C.byref(out), C.byref(total)))
+        finally:
+            self.L.nthip_multi_seeds_destroy(ms)
+        res = {"total": total.value, "hashes": hashes[: total.value * per].reshape(total.value, per), "counts": counts[:n_reads]}
+        if want_pos:
+            res["pos"] = pos[: total.value]
+        return res

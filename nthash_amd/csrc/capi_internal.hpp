@@ -13,6 +13,7 @@
 //   capi_seed.hip          spaced seeds
 //   capi_sink_bloom.hip / capi_sink_minhash.hip   fused consumers
 //   capi_fastx.hip         FASTQ / FASTA indexing and the file streaming driver
+//   capi_multi.hip         several devices of one node: shards of a host batch, one thread + context per device
 // Kernels live in the *_kernel(s).hpp headers; every TU instantiates only the ones it launches.
 // There is no CPU hashing path in any of them.
 #pragma once

@@ -72,6 +72,41 @@ nthip_ctx* device_ctx(const char* cls)
   return tc.ctx;
 }
 
+// NTHASH_AMD_DEVICES="all" or "0,1,2,...": nthash::BatchNtHash cuts its batch over these devices (nthip_multi_*).
+// Unset: one device (NTHASH_AMD_DEVICE).  One multi-device handle per thread, like the context above.
+struct ThreadMulti {
+  nthip_multi* m = nullptr;
+  bool looked = false;
+  ~ThreadMulti()
+  {
+    if (m) nthip_multi_destroy(m);
+  }
+};
+
+nthip_multi* device_multi(const char* cls)
+{
+  static thread_local ThreadMulti tm;
+  if (tm.looked) return tm.m;
+  tm.looked = true;
+  const char* e = std::getenv("NTHASH_AMD_DEVICES");
+  if (!e || !*e) return nullptr;
+  std::vector<int> devs;
+  if (std::string(e) != "all") {
+    const char* p = e;
+    while (*p) {
+      char* end = nullptr;
+      const long d = std::strtol(p, &end, 10);
+      if (end == p || d < 0) raise_error(cls, std::string("NTHASH_AMD_DEVICES is not \"all\" or a list of device numbers: ") + e);
+      devs.push_back((int)d);
+      p = (*end == ',') ? end + 1 : end;
+      if (*end && *end != ',') raise_error(cls, std::string("NTHASH_AMD_DEVICES is not \"all\" or a list of device numbers: ") + e);
+    }
+  }
+  if (nthip_multi_create(devs.empty() ? nullptr : devs.data(), (int)devs.size(), &tm.m) != NTHIP_OK)
+    raise_error(cls, std::string("GPU hashing unavailable: ") + nthip_last_error());
+  return tm.m;
+}
+
 size_t env_size(const char* name, size_t dflt)
 {
   const char* e = std::getenv(name);
@@ -928,13 +963,16 @@ void BatchNtHash::run()
   hashes_.resize(cap * num_hashes_);
   pos_.resize(cap);
   if (n == 0 || cap == 0) return;
-  nthip_ctx* ctx = device_ctx("BatchNtHash");
   nthip_reads rd = { seqs_.data(), offsets_.data(), (uint64_t)n, 0, 0 };
   nthip_out out = { hashes_.data(), (uint64_t)cap, counts_.data(), pos_.data(), nullptr, nullptr };
   uint64_t total = 0;
-  if (nthip_kmer_hash(ctx, &rd, (uint16_t)k_, (uint8_t)num_hashes_, &out, &total,
-                      NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT) != NTHIP_OK)
-    raise_error("BatchNtHash", std::string("GPU hashing failed: ") + nthip_last_error());
+  int rc;
+  if (nthip_multi* multi = device_multi("BatchNtHash"))
+    rc = nthip_multi_kmer_hash(multi, &rd, (uint16_t)k_, (uint8_t)num_hashes_, &out, &total);
+  else
+    rc = nthip_kmer_hash(device_ctx("BatchNtHash"), &rd, (uint16_t)k_, (uint8_t)num_hashes_, &out, &total,
+                         NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT);
+  if (rc != NTHIP_OK) raise_error("BatchNtHash", std::string("GPU hashing failed: ") + nthip_last_error());
   total_ = total;
   uint64_t acc = 0;
   for (size_t r = 0; r < n; ++r) {

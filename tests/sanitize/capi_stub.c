@@ -31,3 +31,11 @@ int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, 
   if (total) *total = 0;
   return NTHIP_ERR_NODEVICE;
 }
+int nthip_multi_create(const int* devices, int n, nthip_multi** out) { (void)devices; (void)n; *out = NULL; return NTHIP_ERR_NODEVICE; }
+int nthip_multi_destroy(nthip_multi* m) { (void)m; return NTHIP_OK; }
+int nthip_multi_kmer_hash(nthip_multi* m, const nthip_reads* rd, uint16_t k, uint8_t mh, const nthip_out* out, uint64_t* total)
+{
+  (void)m; (void)rd; (void)k; (void)mh; (void)out;
+  if (total) *total = 0;
+  return NTHIP_ERR_NODEVICE;
+}

@@ -221,8 +221,14 @@ int main(int argc, char** argv) {
 """
 
 
-def test_batch_nthash_helper(built_lib, oracle, tmp_path):
-    """nthash::BatchNtHash (our addition to the header): many reads, one device call, results in roll() order"""
+@pytest.mark.parametrize("devices", [None, "0,0,0", "all"])
+def test_batch_nthash_helper(built_lib, oracle, tmp_path, devices):
+    """nthash::BatchNtHash (our addition to the header): many reads, one device call, results in roll() order; with
+    NTHASH_AMD_DEVICES the batch is cut over several devices (nthip_multi_*; here the one GPU several times)"""
+    env = dict(os.environ)
+    env.pop("NTHASH_AMD_DEVICES", None)
+    if devices:
+        env["NTHASH_AMD_DEVICES"] = devices
     lib = os.path.join(ROOT, "nthash_amd", "lib")
     src = tmp_path / "batch.cpp"
     src.write_text(BATCH_DRIVER)
@@ -234,7 +240,8 @@ def test_batch_nthash_helper(built_lib, oracle, tmp_path):
     reads = ["".join(alph[i] for i in rng.integers(0, len(alph), int(rng.integers(0, 300)))) for _ in range(400)]
     reads[3] = ""            # (an empty line is an empty read)
     m, k = 3, 21
-    r = subprocess.run([str(exe), str(m), str(k)], input="\n".join(reads) + "\n", capture_output=True, text=True, timeout=300)
+    r = subprocess.run([str(exe), str(m), str(k)], input="\n".join(reads) + "\n", capture_output=True, text=True, timeout=300,
+                       env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.strip().split("\n")
     d, offs = concat_reads([x.encode() for x in reads])

@@ -1462,3 +1462,36 @@ def test_windowed_build_of_the_headline_kernel_is_bit_exact():
                         "-k", "kmer and not windowed and not native_library"], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0]])
+def test_multi_device_shards_give_the_single_call_stream(oracle, devices):
+    """nthip_multi_*: a host batch cut into one shard of reads per device (here the box's GPU listed several times: one
+    context and one host thread each), hashed concurrently, stitched back -- must be exactly the oracle's stream,
+    N-skipping, counts and positions included, for fixed-length and variable-length reads and for spaced seeds"""
+    import nthash_amd
+    mu = nthash_amd.Multi(devices)
+    assert mu.device_count() == len(devices)
+    rng = np.random.default_rng(len(devices))
+    n, L, k, m = 3001, 120, 25, 2
+    data = oracle.synth_reads(5, n, L, 77).copy()
+    data[rng.choice(n * L, 40, replace=False)] = ord("N")       # gaps in the dense layout: shards must move down
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=True)
+    got = mu.kmer_hash(data, k, m, fixed_len=L, n_reads=n, want_pos=True)
+    assert got["total"] == want["total"] and (got["counts"] == want["counts"]).all()
+    assert (got["hashes"] == want["hashes"]).all() and (got["pos"] == want["pos"]).all()
+    # variable lengths (shards balanced by bytes), reads shorter than k, an empty read
+    lens = rng.integers(0, 200, 2000)
+    alph = np.frombuffer(b"ACGTACGTN", dtype=np.uint8)
+    reads = [alph[rng.integers(0, len(alph), int(x))].tobytes() for x in lens]
+    d, o = concat_reads(reads)
+    want = oracle.kmer_batch(d, o, 21, 1, want_pos=True)
+    got = mu.kmer_hash(d, 21, 1, offsets=o, want_pos=True)
+    assert got["total"] == want["total"] and (got["counts"] == want["counts"]).all()
+    assert (got["hashes"] == want["hashes"]).all() and (got["pos"] == want["pos"]).all()
+    # spaced seeds
+    wants = oracle.seed_batch(data, offs, [SEED_A[:25], SEED_B[3:28]], 25, 2, want_pos=True)
+    gots = mu.seed_hash(data, [SEED_A[:25], SEED_B[3:28]], 25, 2, fixed_len=L, n_reads=n, want_pos=True)
+    assert gots["total"] == wants["total"] and (gots["hashes"] == wants["hashes"]).all() and (gots["pos"] == wants["pos"]).all()
+    mu.close()
