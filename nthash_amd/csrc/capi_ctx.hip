@@ -232,6 +232,7 @@ void load_tuning(nthip_tune& t)
   t.waves = num("NTHIP_TUNE_WAVES", 1, 16);
   t.na_waves = num("NTHIP_TUNE_NA_WAVES", 1, 16);
   t.seed_rpt = num("NTHIP_TUNE_SEED_RPT", 1, 256);
+  t.seed_waves = num("NTHIP_TUNE_SEED_WAVES", 4, 16);
   t.read_threads = num("NTHIP_TUNE_READ_THREADS", 1, 64);
   if (const char* v = getenv("NTHIP_TUNE_TILE_MAP")) {
     t.has_tile_map = true;
@@ -243,6 +244,7 @@ void load_tuning(nthip_tune& t)
   t.no_autotune = is_set("NTHIP_TUNE_NO_AUTOTUNE");
   t.no_seed_wave = is_set("NTHIP_TUNE_NO_SEED_WAVE");
   t.no_seed_wtile = is_one("NTHIP_TUNE_NO_SEED_WTILE");
+  t.no_seed_rot = is_one("NTHIP_TUNE_NO_SEED_ROT");
   t.no_phases = is_one("NTHIP_TUNE_NO_PHASES");
   t.no_pacing = is_one("NTHIP_TUNE_NO_PACING");
   t.ph_tiles = num("NTHIP_TUNE_PH_TILES", 1, 64);

@@ -67,7 +67,8 @@ struct nthip_tune {
   uint32_t run_max = 0;     // NTHIP_TUNE_RUN_MAX: longest run the cost model may pick
   uint32_t waves = 0;       // NTHIP_TUNE_WAVES: waves per block of the dense run-split kernels
   uint32_t na_waves = 0;    // NTHIP_TUNE_NA_WAVES: ... of the N-aware pass
-  uint32_t seed_rpt = 0;    // NTHIP_TUNE_SEED_RPT: reads per tile of seed_fixed_kernel
+  uint32_t seed_rpt = 0;    // NTHIP_TUNE_SEED_RPT: reads per tile of seed_fixed_kernel / seed_wtile_kernel
+  uint32_t seed_waves = 0;  // NTHIP_TUNE_SEED_WAVES: waves per block of seed_wtile_kernel (4, 8, 12, 16)
   uint32_t read_threads = 0; // NTHIP_TUNE_READ_THREADS: pread threads of the file driver
   bool has_tile_map = false;
   uint32_t tile_map = 0;    // NTHIP_TUNE_TILE_MAP
@@ -77,6 +78,7 @@ struct nthip_tune {
   bool no_autotune = false; // NTHIP_TUNE_NO_AUTOTUNE (set)
   bool no_seed_wave = false; // NTHIP_TUNE_NO_SEED_WAVE (set)
   bool no_seed_wtile = false; // NTHIP_TUNE_NO_SEED_WTILE=1: the block-tile dense seed kernel instead of the wave-tile one
+  bool no_seed_rot = false;   // NTHIP_TUNE_NO_SEED_ROT=1: the plain [table][entry] layout of the byte tables in LDS
   // phased headline kernel (kmer_runs_kernel.hpp): tiles per wave and period, period / read window in 10 ns ticks
   bool no_phases = false;   // NTHIP_TUNE_NO_PHASES=1: the static loop (one tile ahead) instead of dynamic chunks
   bool no_pacing = false;   // NTHIP_TUNE_NO_PACING=1 (windowed builds): groups of tiles, but no waiting for the clock

@@ -222,7 +222,9 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
   // slab stays under 8 KiB (SW_MAX_VEC_ROUNDS x 64 vectors)
   uint32_t R = 4096u / f.stride;
   if (R < 1) R = 1;
-  {
+  if (c->tune.seed_rpt) {
+    R = c->tune.seed_rpt; // A/B override
+  } else {
     uint64_t g = rec_bytes, h = 1024;
     while (h) { const uint64_t t2 = g % h; g = h; h = t2; } // gcd(rec_bytes, 1024)
     const uint32_t unit = (uint32_t)(1024 / g);
@@ -232,11 +234,13 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
   const uint64_t slab = 15ull + (uint64_t)(R - 1) * f.stride + f.len;
   if (slab > SW_MAX_VEC_ROUNDS * 1024ull || (uint64_t)R * f.nwin >= 0x7FFFFFFFull) return NTHIP_OK;
   const uint32_t bits_dwords = (uint32_t)((((slab + 15) >> 4) + 8 + 3) & ~3ull);
-  const size_t table_bytes = (size_t)f.n_seeds * 2 * nh * 256 * sizeof(uint4);
+  // one or two seeds of k <= 32 bases, few hashes per seed: the rotated-slot table layout (no LDS bank conflicts)
+  const bool rot = !c->tune.no_seed_rot && f.n_seeds <= 2 && f.k <= 32 && f.m2 <= 4;
+  const size_t table_bytes = rot ? 65536 : (size_t)f.n_seeds * 2 * nh * 256 * sizeof(uint4);
   const size_t per_wave = (size_t)(64 * per + 2) * 8 + (size_t)bits_dwords * 4;
   const size_t cap = lds_cap_of(c);
   uint32_t waves = 0;
-  for (uint32_t w = 16; w >= 4; w -= 4)
+  for (uint32_t w = c->tune.seed_waves ? c->tune.seed_waves & ~3u : 16u; w >= 4; w -= 4)
     if (table_bytes + per_wave * w <= cap) { waves = w; break; }
   if (!waves) return NTHIP_OK;
   SeedWtileArgs a;
@@ -273,6 +277,21 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
     return NTHIP_OK;
   };
   int rc;
+  if (rot) {
+    switch (f.n_seeds * 8 + f.m2) {
+      case 8 + 1: rc = go(seed_wtile_kernel<4, 1, 1>); break;
+      case 8 + 2: rc = go(seed_wtile_kernel<4, 1, 2>); break;
+      case 8 + 3: rc = go(seed_wtile_kernel<4, 1, 3>); break;
+      case 8 + 4: rc = go(seed_wtile_kernel<4, 1, 4>); break;
+      case 16 + 1: rc = go(seed_wtile_kernel<4, 2, 1>); break;
+      case 16 + 2: rc = go(seed_wtile_kernel<4, 2, 2>); break;
+      case 16 + 3: rc = go(seed_wtile_kernel<4, 2, 3>); break;
+      default: rc = go(seed_wtile_kernel<4, 2, 4>); break;
+    }
+    NTCHK(rc);
+    *ran = true;
+    return NTHIP_OK;
+  }
   switch (nh) {
     case 1: rc = go(seed_wtile_kernel<1>); break;
     case 2: rc = go(seed_wtile_kernel<2>); break;

@@ -38,6 +38,9 @@ constexpr int SF_THREADS = SF_THREADS_N; // 16 waves: one block per CU shares th
 #ifndef SF_ABL_NOSTORE
 #define SF_ABL_NOSTORE 0 // the hash stream is not written
 #endif
+#ifndef SF_ABL_NOCONFLICT
+#define SF_ABL_NOCONFLICT 0 // table entries picked so that no lookup has a bank conflict (WRONG results): the LDS ceiling
+#endif
 #ifndef SF_STORE_POLICY
 #define SF_STORE_POLICY " nt"
 #endif
@@ -332,28 +335,63 @@ struct SeedWtileArgs {
 
 constexpr uint32_t SW_MAX_VEC_ROUNDS = 8; // a tile's slab: at most 8 x 64 vectors of 16 bytes (8 KiB of reads)
 
-template <int NH>
+//
+// RNS > 0 (k <= 32, one or two seeds, RM2 <= 4 hashes per seed, all compile-time): the ROTATED-SLOT table layout.
+// A ds_read_b128 is served in four groups of 16 lanes, each lane's 16 bytes = one of the 16 four-bank "slots" of the
+// 256-byte bank row; random entries of one table put ~3 lanes of a group on the same slot (58 % of the LDS cycles of
+// the plain layout were conflicts).  Here the 16 byte tables of the two seeds are interleaved ENTRY-major --
+// entry e of table v at e*256 + v*16, so a table owns one slot -- and at step s lane l looks up byte position
+// (l + s) & 7 of the seed-half (l >> 3) & 1 (the other half in the second round): every 16-lane group holds each
+// residue l & 15 once, so its 16 lanes read 16 different tables = 16 different slots, whatever the entries.  XOR is
+// commutative, so the order in which a lane meets its eight tables does not matter.  One seed: both halves hold it.
+template <int NH, int RNS = 0, int RM2 = 0>
 __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileArgs a)
 {
+  constexpr bool ROT = RNS > 0;
+  static_assert(!ROT || (NH == 4 && RNS <= 2 && RM2 >= 1 && RM2 <= 4), "rotated-slot layout: k <= 32, <= 2 seeds");
   constexpr int NW = (NH + 1) / 2; // 32-bit words of window kept in registers
   constexpr uint32_t NT = 2u * NH; // byte tables per seed in LDS
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  extern __shared__ __attribute__((aligned(256))) uint32_t lds_dyn[];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // layout: [tables: n_seeds*NT*256 uint4][per wave: output tile 64*per+2 u64 | bit stream]
+  // layout: [tables: n_seeds*NT*256 uint4 (ROT: 16*256)][per wave: output tile 64*per+2 u64 | bit stream]
   uint4* tabs = (uint4*)lds_dyn;
-  const uint32_t n_entries = a.n_seeds * NT * 256u;
-  const uint32_t per = a.n_seeds * a.m2; // values per window
+  const uint32_t n_entries = ROT ? 4096u : a.n_seeds * NT * 256u;
+  const uint32_t per = ROT ? (uint32_t)(RNS * RM2) : a.n_seeds * a.m2; // values per window
   const uint32_t otile_u64 = 64u * per + 2u;
   uint32_t* wbase = lds_dyn + n_entries * 4u + wave * (otile_u64 * 2u + a.bits_dwords);
   uint64_t* otile = (uint64_t*)wbase;
   uint32_t* bits = wbase + otile_u64 * 2u;
-  for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
-    const uint32_t tb = i >> 8, sd = tb / NT, jt = tb - sd * NT;
-    tabs[i] = jt < a.ntab ? a.tables[((size_t)sd * a.ntab + jt) * 256u + (i & 255u)] : make_uint4(0, 0, 0, 0);
+  if constexpr (ROT) {
+    for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
+      const uint32_t e = i >> 4, v = i & 15u, jt = v & 7u, sd = (v >> 3) < (uint32_t)RNS ? (v >> 3) : (uint32_t)RNS - 1u;
+      tabs[i] = jt < a.ntab ? a.tables[((size_t)sd * a.ntab + jt) * 256u + e] : make_uint4(0, 0, 0, 0);
+    }
+  } else {
+    for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
+      const uint32_t tb = i >> 8, sd = tb / NT, jt = tb - sd * NT;
+      tabs[i] = jt < a.ntab ? a.tables[((size_t)sd * a.ntab + jt) * 256u + (i & 255u)] : make_uint4(0, 0, 0, 0);
+    }
   }
   __syncthreads(); // the only block-wide barrier
+  // ROT: what lane l needs at step s -- the v_perm selector that puts byte (l + s) & 7 of the window at bits 8..15
+  // (= entry * 256) and the LDS address of its slot in the first round; the second round is 128 bytes up or down
+  typedef __attribute__((address_space(3))) const nt_v4u lds_v4u;
+  uint32_t rsel[8], roff[8];
+  uint32_t rdelta = 0, rb3 = 0;
+  if constexpr (ROT) {
+    rb3 = (lane >> 3) & 1u;
+    const uint32_t tb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds_dyn;
+#pragma unroll
+    for (uint32_t st = 0; st < 8; ++st) {
+      const uint32_t cpos = (lane + st) & 7u;
+      rsel[st] = 0x0c0c000cu | (cpos << 8);
+      roff[st] = tb + (((rb3 << 3) + cpos) << 4);
+      asm volatile("" : "+v"(rsel[st]), "+v"(roff[st])); // kept in registers, not recomputed per window
+    }
+    rdelta = rb3 ? (uint32_t)-128 : 128u;
+  }
 
   // this block's contiguous range of tiles, its waves interleaved inside it
   const uint64_t per_block = (a.n_tiles + gridDim.x - 1u) / gridDim.x;
@@ -465,14 +503,51 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
       const uint32_t par = (uint32_t)(((uintptr_t)dst >> 3) & 1u);
       uint64_t* mine = otile + par + lane * per;
 #if SF_ABL_NOHASH
+#ifdef SF_ABL_SPIN // pure-VALU stand-in for the hashing (SF_ABL_SPIN dependent operations per group, no LDS)
+      {
+        uint32_t x = w[0];
+#pragma unroll 8
+        for (int it = 0; it < SF_ABL_SPIN; ++it) asm volatile("v_mad_u32_u24 %0, %0, %0, %1" : "+v"(x) : "v"(lane));
+        w[0] = x;
+      }
+#endif
       for (uint32_t s = 0; s < per; ++s) mine[s] = w[0] + s;
 #else
+      if constexpr (ROT) {
+        uint32_t ad[8];
+#pragma unroll
+        for (uint32_t st = 0; st < 8; ++st) ad[st] = __builtin_amdgcn_perm(w[1], w[0], rsel[st]) + roff[st];
+#pragma unroll
+        for (int half = 0; half < RNS; ++half) {
+          nt_v4u e[8];
+#pragma unroll
+          for (uint32_t st = 0; st < 8; ++st) e[st] = *(lds_v4u*)(uintptr_t)(half == 0 ? ad[st] : ad[st] + rdelta);
+          uint32_t f0 = e[0].x ^ e[1].x, f1 = e[0].y ^ e[1].y, r0 = e[0].z ^ e[1].z, r1 = e[0].w ^ e[1].w;
+#pragma unroll
+          for (uint32_t st = 2; st < 8; st += 2) {
+            f0 = __builtin_amdgcn_bitop3_b32(f0, e[st].x, e[st + 1].x, 0x96);
+            f1 = __builtin_amdgcn_bitop3_b32(f1, e[st].y, e[st + 1].y, 0x96);
+            r0 = __builtin_amdgcn_bitop3_b32(r0, e[st].z, e[st + 1].z, 0x96);
+            r1 = __builtin_amdgcn_bitop3_b32(r1, e[st].w, e[st + 1].w, 0x96);
+          }
+          const uint64_t h0 = canon_pair(f0, f1, r0, r1);
+          // the seed this lane has just hashed: its half in the first round, the other one in the second
+          uint64_t* const rec = mine + (RNS == 2 ? ((uint32_t)half ^ rb3) * (uint32_t)RM2 : 0u);
+          rec[0] = h0;
+#pragma unroll
+          for (uint32_t jj = 1; jj < (uint32_t)RM2; ++jj) rec[jj] = mix_hash(h0, a.mult[jj]);
+        }
+      } else
       for (uint32_t s = 0; s < a.n_seeds; ++s) {
         const uint4* ts = tabs + s * NT * 256u;
         uint4 e[NT]; // all lookups of the seed in flight, then XOR them up
 #pragma unroll
         for (uint32_t jt = 0; jt < NT; ++jt) {
+#if SF_ABL_NOCONFLICT
+          const uint32_t byte = ((w[jt >> 2] >> ((jt & 3u) * 8u)) & 0xF0u) | (lane & 15u);
+#else
           const uint32_t byte = (w[jt >> 2] >> ((jt & 3u) * 8u)) & 0xFFu;
+#endif
           e[jt] = ts[jt * 256u + byte];
         }
         uint32_t f0 = e[0].x ^ e[1].x, f1 = e[0].y ^ e[1].y, r0 = e[0].z ^ e[1].z, r1 = e[0].w ^ e[1].w;

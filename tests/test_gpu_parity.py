@@ -464,6 +464,50 @@ def test_seed_wave_tile_kernel_shapes_vs_oracle(ctx, oracle):
                 ctx.free(d_out)
 
 
+def test_seed_rotated_slot_tables_vs_oracle(oracle):
+    """the rotated-slot layout of the byte tables in LDS (seed_wtile_kernel<4, seeds, m2>: one or two seeds, k <= 32,
+    m2 <= 4): every (seeds, m2) instantiation, k from 4 to 32 (tables past ceil(k/4) are zero), read counts that
+    leave a ragged last tile and a ragged last 64-window group -- against the oracle and against the plain
+    [table][entry] layout (NTHIP_TUNE_NO_SEED_ROT=1), which also covers m2 = 5 and three seeds staying on it"""
+    import os
+    import nthash_amd
+    rng = np.random.default_rng(777)
+    plain_env = "NTHIP_TUNE_NO_SEED_ROT"
+    os.environ.pop(plain_env, None)
+    rot = nthash_amd.Context(0)
+    os.environ[plain_env] = "1"
+    try:
+        plain = nthash_amd.Context(0)
+    finally:
+        os.environ.pop(plain_env, None)
+
+    def mask(k, density):
+        m = (rng.random(k) < density).astype(int)
+        m[0] = m[-1] = 1
+        return "".join(str(int(x)) for x in m)
+
+    cases = []
+    for k in (4, 7, 8, 9, 16, 17, 24, 25, 31, 32):
+        for n_seeds in (1, 2):
+            cases.append((int(rng.integers(1, 400)), int(rng.integers(k, 300)), [mask(k, 0.6) for _ in range(n_seeds)],
+                          int(rng.integers(1, 5))))
+    for m2 in (1, 2, 3, 4, 5):
+        cases.append((1237, 250, [SEED_A, SEED_B], m2))
+        cases.append((641, 150, [SEED_B], m2))
+    cases.append((500, 250, [SEED_A, SEED_B, SEED_A[::-1]], 2))
+    for (n, L, seeds, m2) in cases:
+        k = len(seeds[0])
+        data = np.frombuffer(b"ACGTacgtUu", dtype=np.uint8)[rng.integers(0, 10, n * L)]
+        offs = np.arange(n + 1, dtype=np.uint64) * L
+        want = oracle.seed_batch(data, offs, seeds, k, m2, want_pos=False)
+        for c in (rot, plain):
+            got = c.seed_hash(data, seeds, k, m2, fixed_len=L, n_reads=n)
+            assert got["total"] == want["total"] == n * (L - k + 1)
+            assert (got["hashes"] == want["hashes"]).all(), (n, L, seeds, m2, c is rot)
+    rot.close()
+    plain.close()
+
+
 def test_seed_dirty_and_ragged_vs_oracle(ctx, oracle):
     rng = np.random.default_rng(33)
     alph = np.frombuffer(b"ACGTacgtUuNnRYKMSW-*\x00", dtype=np.uint8)
