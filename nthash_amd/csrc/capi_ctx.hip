@@ -245,6 +245,10 @@ void load_tuning(nthip_tune& t)
   t.no_seed_wave = is_set("NTHIP_TUNE_NO_SEED_WAVE");
   t.no_seed_wtile = is_one("NTHIP_TUNE_NO_SEED_WTILE");
   t.no_seed_rot = is_one("NTHIP_TUNE_NO_SEED_ROT");
+  t.no_kmer_reads = is_one("NTHIP_TUNE_NO_KMER_READS");
+  t.reads_run_len = num("NTHIP_TUNE_READS_RUN_LEN", 2, 16);
+  t.reads_per_tile = num("NTHIP_TUNE_READS_PER_TILE", 1, 64);
+  t.reads_waves = num("NTHIP_TUNE_READS_WAVES", 1, 16);
   t.no_phases = is_one("NTHIP_TUNE_NO_PHASES");
   t.no_pacing = is_one("NTHIP_TUNE_NO_PACING");
   t.ph_tiles = num("NTHIP_TUNE_PH_TILES", 1, 64);

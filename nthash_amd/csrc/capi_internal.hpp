@@ -78,6 +78,8 @@ struct nthip_tune {
   bool no_autotune = false; // NTHIP_TUNE_NO_AUTOTUNE (set)
   bool no_seed_wave = false; // NTHIP_TUNE_NO_SEED_WAVE (set)
   bool no_seed_wtile = false; // NTHIP_TUNE_NO_SEED_WTILE=1: the block-tile dense seed kernel instead of the wave-tile one
+  bool no_kmer_reads = false; // NTHIP_TUNE_NO_KMER_READS=1: variable-length reads on kmer_ragged_kernel only
+  uint32_t reads_run_len = 0, reads_per_tile = 0, reads_waves = 0; // NTHIP_TUNE_READS_RUN_LEN / _PER_TILE / _WAVES (kmer_reads_kernel)
   bool no_seed_rot = false;   // NTHIP_TUNE_NO_SEED_ROT=1: the plain [table][entry] layout of the byte tables in LDS
   // phased headline kernel (kmer_runs_kernel.hpp): tiles per wave and period, period / read window in 10 ns ticks
   bool no_phases = false;   // NTHIP_TUNE_NO_PHASES=1: the static loop (one tile ahead) instead of dynamic chunks
@@ -260,6 +262,8 @@ int launch_kmer_gen_dense(nthip_ctx* c, const KmerRunsGenArgs& ga, size_t lds, u
 int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m, const NaPlan& plan,
                 const KmerFixedArgs& consts, uint64_t capacity, uint64_t* total);
 // capi_kmer_ragged.hip: reads = spans [starts[r], ends[r]) of the device buffer st.seqs (total_bytes long)
+int run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
+                   uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled);
 int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
                     uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled);
 // capi_kmer_general.hip

@@ -35,6 +35,9 @@ int ntamd::host::run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t*
                     uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled)
 {
   *handled = false;
+  // short reads in order (every offsets batch, the sequence lines of a FASTQ chunk): tiles of whole reads
+  NTCHK(run_kmer_reads(c, st, d_starts, d_ends, n_reads, total_bytes, k, m, capacity, total, handled));
+  if (*handled) return NTHIP_OK;
   const uint32_t C = 15; // run length; the last run of a read may be shorter
   const uint64_t n = n_reads;
   const uint32_t nw = kmer_nw(k);

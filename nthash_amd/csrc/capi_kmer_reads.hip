@@ -1,0 +1,193 @@
+// capi_kmer_reads.hip -- variable-length SHORT reads (offsets / sorted spans): tiles of whole reads, clean reads on the
+// run-split kernel, reads with a non-base on a lane-per-read kernel (kmer_reads_kernel.hpp).
+// Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
+#include "capi_internal.hpp"
+#include "kmer_reads_kernel.hpp"
+#include "util_kernels.hpp"
+
+using namespace ntamd;
+using namespace ntamd::host;
+
+namespace {
+
+template <int NW>
+int launch_kmer_reads(nthip_ctx* c, int mode, const KmerReadsArgs& a, size_t dyn_lds)
+{
+  auto kernel = mode == RD_MODE_MARK ? kmer_reads_kernel<RD_MODE_MARK, NW> : kmer_reads_kernel<RD_MODE_HASH, NW>;
+  int per_cu = 1;
+  NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
+  const uint64_t need = (a.n_tiles + a.waves - 1) / a.waves;
+  uint64_t grid = (uint64_t)c->n_cu * per_cu;
+  if (grid > need) grid = need;
+  if (mode == RD_MODE_HASH) prof_begin(c, "kmer_reads_kernel");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
+  if (mode == RD_MODE_HASH) prof_end(c);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+} // namespace
+
+// *handled = false: the batch is outside this path (long reads, spans out of order, LDS); nothing was written
+int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends,
+                                uint64_t n_reads, uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity,
+                                uint64_t* total, bool* handled)
+{
+  *handled = false;
+  (void)total_bytes;
+  if (c->tune.no_kmer_reads || n_reads == 0) return NTHIP_OK;
+  const uint64_t n = n_reads;
+  // ---- shape of the batch: longest read, largest distance between starts, order ----
+  unsigned long long* d_res = (unsigned long long*)(c->d_small + 96); // [0] max length [1] max pitch [2] out of order
+  unsigned long long* d_ndirty = (unsigned long long*)(c->d_small + 128);
+  HIPCHK(hipMemsetAsync(c->d_small + 96, 0, 48, c->stream));
+  {
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
+    hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n, d_res);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipMemcpyAsync(c->h_small + 96, d_res, 24, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t res[3];
+  memcpy(res, c->h_small + 96, 24);
+  const uint64_t max_len = res[0], max_pitch = res[1] > res[0] ? res[1] : res[0];
+  if (res[2] || max_len > RD_MAX_LEN) return NTHIP_OK; // long reads: kmer_ragged_kernel spreads them over tiles
+  if (max_len < k) { // no read has a window
+    *handled = true;
+    *total = 0;
+    if (st.counts) HIPCHK(hipMemsetAsync(st.counts, 0, n * sizeof(uint64_t), c->stream));
+    return NTHIP_OK;
+  }
+  // ---- tile geometry ----
+  const uint32_t C = c->tune.reads_run_len ? c->tune.reads_run_len : 8; // <= 16 (one word of roll steps + the first window)
+  const uint32_t nw = kmer_nw(k);
+  const uint64_t slab_cap = 16384; // bytes of reads (and what lies between them) a tile stages
+  uint32_t R = c->tune.reads_per_tile ? c->tune.reads_per_tile : 32;
+  if (R > 64) R = 64;
+  while (R > 1 && (uint64_t)(R - 1) * max_pitch + max_len + 16 > slab_cap) --R;
+  if ((uint64_t)(R - 1) * max_pitch + max_len + 16 > slab_cap) return NTHIP_OK;
+  const uint32_t max_vec = (uint32_t)(((uint64_t)(R - 1) * max_pitch + max_len + 15 + 15) / 16 + 1);
+  const uint32_t bits_dwords = (max_vec + nw + 8 + 3u) & ~3u;
+  // (a listed read inside a pass leaves a hole; what does not fit the tile waits for the next pass)
+  const uint32_t tile_u64 = (64 * C + RD_ALIGN_U64 + 48 + 1u) & ~1u;
+  const uint32_t ptile_dwords = st.pos ? tile_u64 : 0;
+  const uint32_t max_runs = R * (uint32_t)((max_len - k + 1 + C - 1) / C);
+  const uint32_t rmap_dwords = ((max_runs + 64 + 3) / 4 + 3u) & ~3u;
+  const size_t fixed = (size_t)kmer_ntab(k) * 4096 + 256 + 64;
+  const size_t per_wave = (size_t)tile_u64 * 8 + ((size_t)ptile_dwords + bits_dwords + 256 + rmap_dwords) * 4;
+  const size_t cap = lds_cap_of(c);
+  uint32_t waves = 0;
+  for (uint32_t w = c->tune.reads_waves ? c->tune.reads_waves : 16; w >= 1; --w)
+    if (fixed + per_wave * w <= cap) { waves = w; break; }
+  if (!waves) return NTHIP_OK;
+  *handled = true;
+
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  NTCHK(ensure_scratch(c, 3 * n + nb + n / 8 + 64));
+  uint64_t* d_cnt = st.counts ? st.counts : c->d_scratch;
+  uint64_t* d_off = c->d_scratch + n;
+  uint64_t* d_list = c->d_scratch + 2 * n;
+  uint64_t* d_sums = c->d_scratch + 3 * n;
+  uint8_t* d_flags = (uint8_t*)(c->d_scratch + 3 * n + nb + 8);
+  uint64_t* d_total = (uint64_t*)(c->d_small + 8);
+
+  KmerReadsArgs a;
+  memset(&a, 0, sizeof a);
+  KmerFixedArgs consts;
+  memset(&consts, 0, sizeof consts);
+  fill_kmer_consts(k, m, consts);
+  a.seqs = st.seqs;
+  a.starts = d_starts;
+  a.ends = d_ends;
+  a.n_reads = n;
+  a.R = R;
+  a.n_tiles = (n + R - 1) / R;
+  a.cnt = d_cnt;
+  a.flags = d_flags;
+  a.dirty_list = d_list;
+  a.dirty_count = d_ndirty;
+  a.read_off = d_off;
+  a.hashes = st.hashes;
+  a.pos = st.pos;
+  NTCHK(get_kmer_tab(c, k, &a.init_tab));
+  a.k = k;
+  a.m = m;
+  a.C = C;
+  a.ntab = kmer_ntab(k);
+  a.waves = waves;
+  a.bits_dwords = bits_dwords;
+  a.tile_u64 = tile_u64;
+  a.ptile_dwords = ptile_dwords;
+  a.rmap_dwords = rmap_dwords;
+  memcpy(a.tab, consts.tab, sizeof a.tab);
+  memcpy(a.mult, consts.mult, sizeof a.mult);
+  const size_t lds = fixed + per_wave * waves;
+  auto launch = [&](int mode, const KmerReadsArgs& args, size_t bytes) -> int {
+    switch (nw) {
+      case 0: return launch_kmer_reads<0>(c, mode, args, bytes); // any k
+      case 1: return launch_kmer_reads<1>(c, mode, args, bytes);
+      case 2: return launch_kmer_reads<2>(c, mode, args, bytes);
+      case 3: return launch_kmer_reads<3>(c, mode, args, bytes);
+      default: return launch_kmer_reads<4>(c, mode, args, bytes);
+    }
+  };
+  // ---- mark: which reads have a non-base; counts of the others ----
+  {
+    KmerReadsArgs ma = a;
+    ma.tile_u64 = 0;
+    ma.ptile_dwords = 0;
+    ma.rmap_dwords = 0;
+    ma.bits_dwords = ((max_vec + 4) / 2 + 3u) & ~3u; // 16 validity bits per vector
+    ma.waves = 16;
+    const size_t mlds = ((size_t)ma.bits_dwords + 256) * 4 * ma.waves + 64;
+    NTCHK(launch_kmer_reads<1>(c, RD_MODE_MARK, ma, mlds));
+  }
+  // ---- exact counts of the listed reads, offsets of all ----
+  KmerDirtyReadsArgs da;
+  memset(&da, 0, sizeof da);
+  da.seqs = st.seqs;
+  da.starts = d_starts;
+  da.ends = d_ends;
+  da.list = d_list;
+  da.n_list = d_ndirty;
+  da.k = k;
+  da.m = m;
+  da.cnt = d_cnt;
+  da.read_off = d_off;
+  da.hashes = st.hashes;
+  da.pos = st.pos;
+  da.fwd = st.fwd;
+  da.rev = st.rev;
+  for (uint32_t cde = 0; cde < 4; ++cde) {
+    da.sk_fwd[cde] = srol_n(seed_of_code(cde), k);
+    da.sk_rc[cde] = srol_n(seed_of_code(cde ^ 2u), k);
+  }
+  const unsigned dblocks = (unsigned)c->n_cu * 4;
+  hipLaunchKernelGGL(kmer_dirty_reads_kernel<true>, dim3(dblocks), dim3(256), 0, c->stream, da);
+  HIPCHK(hipGetLastError());
+  NTCHK(device_exclusive_scan(c, d_cnt, d_off, n, d_sums, d_total));
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(total, c->h_small + 8, 8);
+  if (*total > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed", (unsigned long long)capacity,
+                (unsigned long long)*total);
+  // ---- hash: the clean reads, then the listed ones into the holes they left ----
+  NTCHK(launch(RD_MODE_HASH, a, lds));
+  for (uint32_t sel = 1; sel <= 2; ++sel) { // strand hashes: the hash pass again with another value selected
+    uint64_t* dst = sel == 1 ? st.fwd : st.rev;
+    if (!dst) continue;
+    KmerReadsArgs sa = a;
+    sa.hashes = dst;
+    sa.pos = nullptr;
+    sa.ptile_dwords = a.ptile_dwords; // (same LDS layout)
+    sa.m = 1;
+    sa.value_sel = sel;
+    NTCHK(launch(RD_MODE_HASH, sa, lds));
+  }
+  hipLaunchKernelGGL(kmer_dirty_reads_kernel<false>, dim3(dblocks), dim3(256), 0, c->stream, da);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}

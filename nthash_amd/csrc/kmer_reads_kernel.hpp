@@ -1,0 +1,469 @@
+// kmer_reads_kernel.hpp -- run-split k-mer hashing of VARIABLE-LENGTH short reads, tiles of WHOLE reads (round 2).
+//
+// Replaces, for a batch of reads of any lengths, the reference's per-read loop
+//     NtHash h(seq, len, m, k); while (h.roll()) use(h.hashes());      (src/kmer.cpp:196-264)
+// kmer_ragged_kernel (round 1) cuts the run sequence of the batch into tiles of exactly 64 runs, wherever in a read
+// that falls: every tile needs a search structure (listed reads, first read of the tile, staged vectors scattered
+// over up to 64 reads) and a count pass with the same machinery, and the hash pass carries N-awareness for every
+// window although one read in hundreds has an N.  Here
+//   * a wave's tile is R CONSECUTIVE WHOLE reads (R <= 64): its bytes are ONE contiguous slab (the reads of an
+//     offsets batch lie back to back; the sequence lines of a FASTQ chunk have the header / quality lines between
+//     them, staged and never looked at), its k-mers ONE contiguous piece of the stream;
+//   * a MARK pass stages the slabs once and looks only for non-bases: a read without one emits every window
+//     (count = len - k + 1), a read WITH one is put on a list and left to kmer_dirty_reads_kernel (one lane per
+//     read, the reference's skipping rule, exact counts first);
+//   * the HASH pass therefore rolls clean reads only: no validity stream, no predicated compaction, slots from the
+//     geometry.  A lane is a run of C windows of one read, 64 consecutive runs per pass, the pass's hashes go
+//     through a wave-private LDS tile to whole aligned pieces of the stream as in kmer_runs_gen_kernel.hpp.  The
+//     last run of a read starts C windows before the read's last window (it overlaps the run before it and writes
+//     the same values to the same slots), so every run has exactly C windows and nothing in the roll is predicated;
+//     only a read with fewer than C windows has a short run (those passes take the predicated code).  The
+//     k-mers of a listed read inside a pass are a hole in the tile (written as is, the dirty-read kernel runs
+//     afterwards on the same stream and fills it).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kmer_runs_gen_kernel.hpp"
+
+namespace ntamd {
+
+enum : int { RD_MODE_MARK = 1, RD_MODE_HASH = 2 };
+constexpr uint32_t RD_ALIGN_U64 = 16; // the output tile is aligned to a 128-byte line of the stream
+
+struct KmerReadsArgs {
+  const uint8_t* seqs;
+  const uint64_t* starts;    // read r = bytes [starts[r], ends[r]) of seqs, starts non-decreasing, no overlap
+  const uint64_t* ends;
+  uint64_t n_reads, n_tiles;
+  uint32_t R;                // reads per tile
+  // MARK
+  uint64_t* cnt;             // [n_reads] windows of a clean read; 0 for a listed one (kmer_dirty_reads_kernel counts it)
+  uint8_t* flags;            // [n_reads] 1 = listed
+  uint64_t* dirty_list;      // reads with a non-base and at least k bytes
+  unsigned long long* dirty_count;
+  // HASH
+  const uint64_t* read_off;  // exclusive scan of cnt
+  uint64_t* hashes;
+  uint32_t* pos;
+  const uint4* init_tab;
+  uint32_t k, m, C, ntab;
+  uint32_t waves, bits_dwords, tile_u64, ptile_dwords, rmap_dwords;
+  uint32_t value_sel;        // 0: canonical hash (+ mixes), 1: forward, 2: reverse strand (m == 1)
+  uint64_t tab[16][2];
+  uint64_t mult[KF_MAX_RUNTIME_M];
+};
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerReadsArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t k = a.k, m = a.m, C = a.C;
+  const uint32_t inv_m = 0xFFFFFFFFu / m + 1u;
+  const uint64_t kmul = (uint64_t)k * MULTISEED;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // LDS: [HASH: first-window tables | pair table] | per wave {hash tile, pos tile, bit stream, read table 4 x 64}
+  uint4* itab = (uint4*)lds_dyn;
+  uint4* ptab = itab + a.ntab * 256u;
+  const uint32_t per_wave = a.tile_u64 * 2u + a.ptile_dwords + a.bits_dwords + 256u + a.rmap_dwords;
+  uint32_t* wave_base = (MODE == RD_MODE_HASH ? (uint32_t*)(ptab + 16) : lds_dyn) + wave * per_wave;
+  uint64_t* tile = (uint64_t*)wave_base;
+  uint32_t* ptile = wave_base + a.tile_u64 * 2u;
+  uint32_t* bits = ptile + a.ptile_dwords; // HASH: 2-bit codes, 16 per dword; MARK: 1 bit per byte, set = not a base
+  uint32_t* rt_beg = bits + a.bits_dwords; // first run of read j in the tile (0xFFFFFFFF past the tile's reads)
+  uint32_t* rt_sb = rt_beg + 64;           // stream index of the read's first base
+  uint32_t* rt_nw = rt_sb + 64;            // windows (0: shorter than k, or listed)
+  uint32_t* rt_out = rt_nw + 64;           // first k-mer of the read, relative to the tile's first
+  uint8_t* rmap = (uint8_t*)(rt_out + 64); // run of the tile -> its read
+  if (MODE == RD_MODE_HASH) {
+    for (uint32_t i = tid; i < a.ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
+    if (tid < 16)
+      ptab[tid] = make_uint4((uint32_t)a.tab[tid][0], (uint32_t)(a.tab[tid][0] >> 32),
+                             (uint32_t)a.tab[tid][1], (uint32_t)(a.tab[tid][1] >> 32));
+  }
+  __syncthreads();
+
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+  auto wave_incl_scan32 = [&](uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(v, d, 64);
+      if ((int)lane >= d) v += o;
+    }
+    return v;
+  };
+  auto bcast64 = [&](uint64_t v, uint32_t src) -> uint64_t {
+    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src, 64) << 32) |
+           (uint32_t)__shfl((int)(uint32_t)v, (int)src, 64);
+  };
+
+  const uint64_t per_block = (a.n_tiles + gridDim.x - 1) / gridDim.x;
+  const uint64_t t_begin = (uint64_t)blockIdx.x * per_block;
+  const uint64_t t_end = t_begin + per_block < a.n_tiles ? t_begin + per_block : a.n_tiles;
+
+  for (uint64_t t = t_begin + wave; t < t_end; t += a.waves) {
+    const uint64_t r0 = t * a.R;
+    const uint32_t nr = a.n_reads - r0 < a.R ? (uint32_t)(a.n_reads - r0) : a.R;
+    // ---- this tile's reads: one per lane ----
+    const bool has = lane < nr;
+    const uint64_t rj = r0 + (has ? lane : 0u);
+    const uint64_t s_j = a.starts[rj], e_j = a.ends[rj];
+    const uint64_t len_j = has && e_j > s_j ? e_j - s_j : 0;
+    bool listed = false;
+    uint64_t ro_j = 0;
+    if (MODE == RD_MODE_HASH) {
+      listed = a.flags[rj] != 0;
+      ro_j = a.read_off[rj];
+    }
+    const uint64_t slab0 = bcast64(s_j, 0);
+    const uint64_t slab_end = bcast64(e_j, nr - 1u);
+    const uint64_t ro_0 = bcast64(ro_j, 0);
+    const uint32_t shift = (uint32_t)(((uintptr_t)a.seqs + slab0) & 15u);
+    const uint8_t* vbase = a.seqs + slab0 - shift; // 16-byte aligned: a vector never crosses a page
+    const uint32_t n_vec = slab_end > slab0 ? (uint32_t)((shift + (slab_end - slab0) + 15u) >> 4) : 0u;
+    const uint32_t nwin_raw = len_j >= k ? (uint32_t)(len_j - k + 1u) : 0u;
+    const uint32_t sb_j = shift + (uint32_t)(s_j - slab0);
+
+    if (MODE == RD_MODE_MARK) {
+      // ---- stage: one validity bit per byte ----
+      for (uint32_t i = lane; i < n_vec; i += 64u) {
+        const uint4 x = *(const uint4*)(vbase + ((uint64_t)i << 4));
+        uint32_t i0, i1, i2, i3;
+        (void)pack4v(x.x, i0);
+        (void)pack4v(x.y, i1);
+        (void)pack4v(x.z, i2);
+        (void)pack4v(x.w, i3);
+        ((uint16_t*)bits)[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+      }
+      if (lane < 4u) ((uint16_t*)bits)[n_vec + lane] = 0;
+      lds_sync();
+      // ---- any non-base inside [sb_j, sb_j + len_j) ? ----
+      uint32_t any = 0;
+      if (len_j) {
+        const uint32_t b_end = sb_j + (uint32_t)len_j; // one past the last byte
+        const uint32_t w_lo = sb_j >> 5, w_hi = (b_end - 1u) >> 5;
+        for (uint32_t w = w_lo; w <= w_hi; ++w) {
+          uint32_t word = bits[w];
+          if (w == w_lo) word &= ~0u << (sb_j & 31u);
+          if (w == w_hi && (b_end & 31u)) word &= ~0u >> (32u - (b_end & 31u));
+          any |= word;
+        }
+      }
+      if (has) {
+        const bool dirty = any != 0 && nwin_raw != 0;
+        a.cnt[rj] = dirty ? 0 : nwin_raw;
+        a.flags[rj] = dirty ? 1 : 0;
+        if (dirty) a.dirty_list[atomicAdd(a.dirty_count, 1ull)] = rj;
+      }
+      lds_sync(); // the bit stream is free again
+      continue;
+    }
+
+    // ---- HASH: stage the slab as 2-bit codes ----
+    for (uint32_t i = lane; i < n_vec; i += 64u) {
+      const uint4 x = *(const uint4*)(vbase + ((uint64_t)i << 4));
+      uint32_t bad = 0;
+      bits[i] = pack16(x, bad);
+    }
+    if (lane < (uint32_t)NW + 3u) bits[n_vec + lane] = 0;
+    // ---- read table ----
+    const uint32_t nwin_j = listed ? 0u : nwin_raw;
+    const uint32_t rc_j = (nwin_j + C - 1u) / C;
+    const uint32_t rend = wave_incl_scan32(rc_j);
+    rt_beg[lane] = has ? rend - rc_j : 0xFFFFFFFFu;
+    rt_sb[lane] = sb_j;
+    rt_nw[lane] = nwin_j;
+    rt_out[lane] = (uint32_t)(ro_j - ro_0);
+    const uint32_t total_runs = (uint32_t)__shfl((int)rend, 63, 64);
+    for (uint32_t i = 0; i < rc_j; ++i) rmap[rend - rc_j + i] = (uint8_t)lane;
+    const bool short_reads = __ballot(nwin_j != 0u && nwin_j < C) != 0; // a read with fewer than C windows in the tile
+    lds_sync();
+
+    // ---- passes of up to 64 consecutive runs ----
+    for (uint32_t g0 = 0; g0 < total_runs;) {
+      const uint32_t g = g0 + lane;
+      const bool live = g < total_runs;
+      const uint32_t j = rmap[live ? g : g0];
+      const uint32_t q = (live ? g : g0) - rt_beg[j];
+      const uint32_t nwin_r = rt_nw[j];
+      // the read's last run is moved back so that it has C windows too (nwin_r >= C; else one short run)
+      const uint32_t w_first = nwin_r >= C ? (q * C + C <= nwin_r ? q * C : nwin_r - C) : 0u;
+      const uint32_t c_run = live ? (nwin_r < C ? nwin_r : C) : 0u;
+      const uint32_t b0 = rt_sb[j] + w_first;
+      const uint32_t oslot = rt_out[j] + w_first; // place in the tile's piece of the stream
+      const uint32_t pass_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)oslot);
+      const uint64_t o0 = ro_0 + pass_base; // the pass's first k-mer in the stream
+      const uint32_t tpar = m == 1u ? (uint32_t)(o0 & (RD_ALIGN_U64 - 1u)) : 0u;
+      const uint32_t slot = oslot - pass_base;
+      // runs that fit the tile (a listed read inside the pass leaves a hole and may push later runs out)
+      const bool fits = live && tpar + slot + c_run <= a.tile_u64;
+      const uint32_t nl = (uint32_t)__builtin_popcountll(__ballot(fits));
+      const bool act = lane < nl;
+      const uint32_t span = (uint32_t)__shfl((int)(slot + c_run), (int)(nl - 1u), 64);
+
+      auto hash_run = [&](auto pred_tag) {
+        constexpr bool PRED = decltype(pred_tag)::value; // a read shorter than C windows somewhere in the tile
+        const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
+        uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
+        if constexpr (NW == 0) {
+          horner_first_window(bits, itab, b0, k, f_lo, f_hi, r_lo, r_hi);
+        } else {
+          uint32_t w[NW];
+          uint32_t lo = bits[d0];
+#pragma unroll
+          for (int i = 0; i < NW; ++i) {
+            const uint32_t hi = bits[d0 + i + 1];
+            w[i] = funnel(hi, lo, sh0);
+            lo = hi;
+          }
+          uint4 e[4 * NW];
+#pragma unroll
+          for (int jt = 0; jt < 4 * NW; ++jt) e[jt] = itab[(uint32_t)jt * 256u + ((w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu)];
+#pragma unroll
+          for (int jt = 0; jt < 4 * NW; ++jt) {
+            f_lo ^= e[jt].x; f_hi ^= e[jt].y; r_lo ^= e[jt].z; r_hi ^= e[jt].w;
+          }
+        }
+        uint64_t* const mine = tile + tpar + slot;
+        uint32_t* const pmine = ptile + slot;
+        const bool want_pos = a.pos != nullptr;
+        auto emit = [&](uint32_t jw) {
+          if (!PRED || jw < c_run) {
+            mine[jw] = a.value_sel == 0u   ? canon_pair(f_lo, f_hi, r_lo, r_hi)
+                       : a.value_sel == 1u ? (((uint64_t)f_hi << 32) | f_lo)
+                                           : (((uint64_t)r_hi << 32) | r_lo);
+            if (want_pos) pmine[jw] = w_first + jw;
+          }
+        };
+        emit(0u);
+        const uint32_t bi = b0 + k;
+        const uint32_t di = bi >> 4, shi = (bi & 15u) << 1;
+        for (uint32_t jw = 0; jw * 16u + 1u < C; ++jw) {
+          const uint32_t w_in = funnel(bits[di + jw + 1], bits[di + jw], shi);
+          const uint32_t w_out = funnel(bits[d0 + jw + 1], bits[d0 + jw], sh0);
+          const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
+          const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
+          auto lookup = [&](uint32_t i) -> uint4 {
+            const uint32_t src = (i & 1u) ? v : u;
+            const uint32_t toff = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
+            return *(const uint4*)((const char*)ptab + toff);
+          };
+          auto roll = [&](const uint4 term) {
+            srol_pair(f_lo, f_hi);
+            f_lo ^= term.x;
+            f_hi ^= term.y;
+            r_lo ^= term.z;
+            r_hi ^= term.w;
+            sror_pair(r_lo, r_hi);
+          };
+          auto batch = [&](uint32_t i0, auto n_tag) {
+            constexpr uint32_t N = decltype(n_tag)::value;
+            uint4 terms[N];
+#pragma unroll
+            for (uint32_t i = 0; i < N; ++i) terms[i] = lookup(i0 + i);
+#pragma unroll
+            for (uint32_t i = 0; i < N; ++i) {
+              roll(terms[i]);
+              emit(jw * 16u + i0 + i + 1u);
+            }
+          };
+          const uint32_t left = C - 1u - jw * 16u;
+          const uint32_t ns = left < 16u ? left : 16u;
+          uint32_t i0 = 0;
+          for (; i0 + 8u <= ns; i0 += 8u) batch(i0, std::integral_constant<uint32_t, 8u>{});
+          switch (ns - i0) {
+            case 1: batch(i0, std::integral_constant<uint32_t, 1u>{}); break;
+            case 2: batch(i0, std::integral_constant<uint32_t, 2u>{}); break;
+            case 3: batch(i0, std::integral_constant<uint32_t, 3u>{}); break;
+            case 4: batch(i0, std::integral_constant<uint32_t, 4u>{}); break;
+            case 5: batch(i0, std::integral_constant<uint32_t, 5u>{}); break;
+            case 6: batch(i0, std::integral_constant<uint32_t, 6u>{}); break;
+            case 7: batch(i0, std::integral_constant<uint32_t, 7u>{}); break;
+            default: break;
+          }
+        }
+      };
+      if (act) {
+        if (short_reads) hash_run(std::true_type{});
+        else hash_run(std::false_type{});
+      }
+      lds_sync();
+      // ---- copy-out: the tile was built shifted by tpar = o0 mod 16: every 16-byte piece is aligned, a wave
+      // instruction covers whole 128-byte lines of the stream ----
+      if (m == 1) {
+        const uint32_t sp = tpar + span;
+        const uint32_t pieces = (sp + 1u) >> 1;
+        uint64_t* const base = a.hashes + (o0 - tpar);
+        for (uint32_t pi = lane; pi < pieces; pi += 64u) {
+          const uint4 dv = *(const uint4*)(tile + 2u * pi);
+          const bool lo_ok = 2u * pi >= tpar && 2u * pi < sp;
+          const bool hi_ok = 2u * pi + 1u >= tpar && 2u * pi + 1u < sp;
+          if (lo_ok && hi_ok) __builtin_nontemporal_store(*(const nt_v4u*)&dv, (nt_v4u*)(base + 2u * pi));
+          else if (lo_ok) *(uint2*)(base + 2u * pi) = make_uint2(dv.x, dv.y);
+          else if (hi_ok) *(uint2*)(base + 2u * pi + 1u) = make_uint2(dv.z, dv.w);
+        }
+      } else {
+        const uint64_t v0 = o0 * m;
+        const uint32_t vpar = (uint32_t)(v0 & 1u);
+        const uint32_t n_vals = span * m;
+        const uint32_t sp = vpar + n_vals;
+        const uint32_t pieces = (sp + 1u) >> 1;
+        uint64_t* const base = a.hashes + (v0 - vpar);
+        for (uint32_t pi = lane; pi < pieces; pi += 64u) {
+          uint64_t o[2];
+          bool ok[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t sv = 2u * pi + (uint32_t)h - vpar;
+            ok[h] = sv < n_vals;
+            const uint32_t e = ok[h] ? __umulhi(sv, inv_m) : 0u, jj = ok[h] ? sv - e * m : 0u;
+            const uint64_t h0 = tile[e];
+            o[h] = jj == 0 ? h0 : mix_hash(h0, ((uint64_t)jj ^ kmul));
+          }
+          if (ok[0] && ok[1])
+            *(uint4*)(base + 2u * pi) =
+                make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
+          else if (ok[0]) *(uint2*)(base + 2u * pi) = make_uint2((uint32_t)o[0], (uint32_t)(o[0] >> 32));
+          else if (ok[1]) *(uint2*)(base + 2u * pi + 1u) = make_uint2((uint32_t)o[1], (uint32_t)(o[1] >> 32));
+        }
+      }
+      if (a.pos)
+        for (uint32_t e = lane; e < span; e += 64u) a.pos[o0 + e] = ptile[e];
+      lds_sync(); // the tile is free again
+      g0 += nl;
+    }
+    lds_sync(); // bit stream and read table are free again
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// The listed reads (a byte that is not ACGTU somewhere): one lane per read, the reference's rule -- a window is
+// emitted iff its k bytes are all bases (NtHash::init / roll skipping, src/kmer.cpp:228-264) -- with the O(1)
+// recurrences between consecutive valid windows and the direct formula after every skip.
+// --------------------------------------------------------------------------------------------------------------
+struct KmerDirtyReadsArgs {
+  const uint8_t* seqs;
+  const uint64_t* starts;
+  const uint64_t* ends;
+  const uint64_t* list;
+  const unsigned long long* n_list;
+  uint32_t k, m;
+  uint64_t* cnt;             // count pass: exact windows of the read
+  const uint64_t* read_off;  // hash pass
+  uint64_t* hashes;
+  uint32_t* pos;
+  uint64_t* fwd;
+  uint64_t* rev;
+  uint64_t sk_fwd[4];        // srol^k(seed[code])
+  uint64_t sk_rc[4];         // srol^k(seed[code ^ 2])
+};
+
+constexpr uint32_t RD_MAX_LEN = 2048; // longest read this path takes (the host checks)
+
+// One WAVE per listed read: the read's bytes in LDS, for every byte the place of the last non-base at or before
+// it (a wave-wide running maximum), then 64 window starts at a time: a window is emitted iff no non-base lies in
+// it, its place in the read's output is the running count of emitted windows (ballot + mbcnt), its hash the
+// direct formula (Horner over its k bytes: F forward from the first base, R backward from the last).
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyReadsArgs a)
+{
+  __shared__ uint8_t raw_all[4][RD_MAX_LEN + 64];
+  __shared__ uint16_t lb_all[4][RD_MAX_LEN + 64]; // 1 + index of the last non-base in [0, p], 0 if none
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint8_t* raw = raw_all[wave];
+  uint16_t* lb = lb_all[wave];
+  const uint64_t n = *a.n_list;
+  const uint32_t k = a.k, m = a.m;
+  const uint64_t kmul = (uint64_t)k * MULTISEED;
+  for (uint64_t i = (uint64_t)blockIdx.x * 4u + wave; i < n; i += (uint64_t)gridDim.x * 4u) {
+    const uint64_t r = a.list[i];
+    const uint8_t* s = a.seqs + a.starts[r];
+    const uint32_t len = (uint32_t)(a.ends[r] - a.starts[r]);
+    uint32_t carry = 0;
+    for (uint32_t p0 = 0; p0 < len; p0 += 64u) {
+      const uint32_t p = p0 + lane;
+      const uint8_t c = p < len ? s[p] : (uint8_t)'A';
+      uint32_t v = (p < len && !is_base(c)) ? p + 1u : 0u;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if ((int)lane >= d && o > v) v = o;
+      }
+      if (carry > v) v = carry;
+      raw[p] = c;
+      lb[p] = (uint16_t)v;
+      carry = (uint32_t)__shfl((int)v, 63, 64);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    const uint32_t nwin = len >= k ? len - k + 1u : 0u;
+    const uint64_t base = COUNT_ONLY ? 0 : a.read_off[r];
+    uint32_t emitted = 0;
+    for (uint32_t w0 = 0; w0 < nwin; w0 += 64u) {
+      const uint32_t w = w0 + lane;
+      const bool valid = w < nwin && lb[w + k - 1u] <= w; // no non-base in [w, w + k)
+      const uint64_t mask = __ballot(valid);
+      if (!COUNT_ONLY && valid) {
+        const uint32_t slot = emitted + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        uint64_t fh = 0, rh = 0;
+        for (uint32_t x = 0; x < k; ++x) fh = srol1(fh) ^ fwd_seed(raw[w + x]);
+        for (uint32_t x = k; x-- > 0;) rh = srol1(rh) ^ rc_seed(raw[w + x]);
+        const uint64_t o = base + slot;
+        const uint64_t h0 = fh + rh;
+        a.hashes[o * m] = h0;
+        for (uint32_t jj = 1; jj < m; ++jj) a.hashes[o * m + jj] = mix_hash(h0, (uint64_t)jj ^ kmul);
+        if (a.pos) a.pos[o] = w;
+        if (a.fwd) a.fwd[o] = fh;
+        if (a.rev) a.rev[o] = rh;
+      }
+      emitted += (uint32_t)__builtin_popcountll(mask);
+    }
+    if (COUNT_ONLY && lane == 0) a.cnt[r] = emitted;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// max length, max distance between consecutive starts, order: what the host needs to size the tiles
+static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* __restrict__ starts,
+                                                                const uint64_t* __restrict__ ends, uint64_t n,
+                                                                unsigned long long* __restrict__ res)
+{
+  uint64_t mlen = 0, mpitch = 0;
+  uint32_t bad = 0;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t s0 = starts[r], e0 = ends[r];
+    if (e0 < s0) { bad = 1; continue; }
+    if (e0 - s0 > mlen) mlen = e0 - s0;
+    if (r + 1 < n) {
+      const uint64_t s1 = starts[r + 1];
+      if (s1 < e0) bad = 1; // not in order, or overlapping
+      else if (s1 - s0 > mpitch) mpitch = s1 - s0;
+    }
+  }
+  // wave-level reduction, then one atomic per wave
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint64_t ol = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(mlen >> 32), d, 64) << 32) |
+                        (uint32_t)__shfl_down((int)(uint32_t)mlen, d, 64);
+    const uint64_t op = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(mpitch >> 32), d, 64) << 32) |
+                        (uint32_t)__shfl_down((int)(uint32_t)mpitch, d, 64);
+    if (ol > mlen) mlen = ol;
+    if (op > mpitch) mpitch = op;
+  }
+  // (thousands of waves hammering one address serialise in L2: look first, the maximum is reached early)
+  if ((threadIdx.x & 63u) == 0) {
+    if (mlen > __atomic_load_n(&res[0], __ATOMIC_RELAXED)) atomicMax(&res[0], (unsigned long long)mlen);
+    if (mpitch > __atomic_load_n(&res[1], __ATOMIC_RELAXED)) atomicMax(&res[1], (unsigned long long)mpitch);
+  }
+  if (__ballot(bad != 0) != 0 && (threadIdx.x & 63u) == 0 && __atomic_load_n(&res[2], __ATOMIC_RELAXED) == 0)
+    atomicOr(&res[2], 1ull);
+}
+
+} // namespace ntamd

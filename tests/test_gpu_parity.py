@@ -1466,7 +1466,7 @@ def test_uniform_offsets_take_the_fixed_length_kernels(ctx, oracle):
     got2 = ctx.kmer_hash(d2, k, m, offsets=offs2)
     name = ctx.last_kernel_ms()[1]
     ctx.set_profiling(False)
-    assert name == "kmer_ragged_kernel", name
+    assert name in ("kmer_reads_kernel", "kmer_ragged_kernel"), name
     assert got2["total"] == want2["total"] and (got2["hashes"] == want2["hashes"]).all()
 
 

@@ -41,7 +41,10 @@ for name, mod, env in mods:
     ctxs.append((name, mod, mod.Context(0)))  # the knobs are read when the context is created
     for key in env:
         os.environ.pop(key, None)
-SEEDS = ["1010101010101010101010101010101", "1101101101101101011011011011011"] if os.environ.get("ABLATE_SEEDS") else None
+SEEDS = None
+if os.environ.get("ABLATE_SEEDS"):  # "1": the two bench seeds; otherwise a comma-separated list of masks
+    SEEDS = (["1010101010101010101010101010101", "1101101101101101011011011011011"] if os.environ["ABLATE_SEEDS"] == "1"
+             else os.environ["ABLATE_SEEDS"].split(","))
 per = m * (len(SEEDS) if SEEDS else 1)
 seeds = {name: (mod.Seeds(c, SEEDS, k) if SEEDS else None) for name, mod, c in ctxs}
 c0 = ctxs[0][2]
