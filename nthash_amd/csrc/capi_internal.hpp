@@ -209,8 +209,15 @@ int device_exclusive_scan(nthip_ctx* c, const uint64_t* d_in, uint64_t* d_out, u
                           uint64_t* d_total);
 int launch_fill_u64(nthip_ctx* c, uint64_t* d_dst, uint64_t n, uint64_t value);
 // do the n reads of a device offsets array all have one length (offsets[r + 1] - offsets[r] == offsets[1] - offsets[0])?
-int offsets_uniform_device(nthip_ctx* c, const uint64_t* d_offsets, uint64_t n_reads, uint64_t* off0, uint64_t* len0,
-                           bool* uniform);
+struct OffsetsSurvey {
+  uint64_t off0 = 0, len0 = 0, max_len = 0;
+  bool uniform = false, bad = false;
+};
+int offsets_survey_device(nthip_ctx* c, const uint64_t* d_offsets, uint64_t n_reads, uint64_t buf_bytes, OffsetsSurvey* sv);
+// longest read / largest distance between starts of a batch, when the caller already knows them
+struct ReadsShape {
+  uint64_t max_len = 0, max_pitch = 0;
+};
 // get_pos() of reads that emit every window (flags/offsets: only the reads with flags[r] == 0, at offsets[r])
 int launch_fill_window_pos(nthip_ctx* c, uint32_t* d_pos, uint64_t n_reads, uint32_t nwin, const uint64_t* d_flags,
                            const uint64_t* d_offsets);
@@ -263,9 +270,11 @@ int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t 
                 const KmerFixedArgs& consts, uint64_t capacity, uint64_t* total);
 // capi_kmer_ragged.hip: reads = spans [starts[r], ends[r]) of the device buffer st.seqs (total_bytes long)
 int run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
-                   uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled);
+                   uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled,
+                   const ReadsShape* shape);
 int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
-                    uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled);
+                    uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled,
+                    const ReadsShape* shape = nullptr);
 // capi_kmer_general.hip
 int run_kmer_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m,
                      uint64_t capacity, uint64_t* total);

@@ -29,29 +29,26 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
   NTCHK(stage_inputs(c, rd, flags, total_bytes, st));
   NTCHK(stage_outputs(c, out, flags, rd->n_reads, m, st));
 
-  // Offsets whose reads all have one length and lie back to back (Illumina reads through the offsets API, what
-  // nthash::BatchNtHash sends) ARE a fixed-length batch: the fixed-stride kernels hash them 3x faster than the
-  // variable-length path.  One pass over the offsets (on the host when they are there) + one round trip; batches
-  // too small to pay for it keep the general route.
-  if (st.offsets && !(flags & (NTHIP_FORCE_GENERAL | NTHIP_ASYNC)) && rd->n_reads >= 1024) {
-    uint64_t off0 = 0, len0 = 0;
-    bool uniform = false;
-    if (flags & NTHIP_HOST_INPUT) {
-      const uint64_t* o = rd_in->offsets;
-      off0 = o[0];
-      len0 = o[1] >= o[0] ? o[1] - o[0] : 0;
-      uniform = true;
-      for (uint64_t r = 1; r < rd->n_reads && uniform; ++r) uniform = o[r + 1] >= o[r] && o[r + 1] - o[r] == len0;
-    } else {
-      NTCHK(offsets_uniform_device(c, st.offsets, rd->n_reads, &off0, &len0, &uniform));
-    }
-    if (uniform && len0 >= 1 && len0 < (1ull << 30) && off0 + rd->n_reads * len0 <= total_bytes) {
-      st.seqs += off0;
+  // Offsets: one pass over them on the device (+ one round trip) before anything trusts them -- are they in order
+  // and inside the buffer (a decreasing pair would underflow a length), how long is the longest read, and do all
+  // reads have one length?  Reads of one length lying back to back (Illumina reads through the offsets API, what
+  // nthash::BatchNtHash sends) ARE a fixed-length batch: the fixed-stride kernels hash them 2x faster.
+  ReadsShape shape;
+  bool have_shape = false;
+  if (st.offsets) {
+    OffsetsSurvey sv;
+    NTCHK(offsets_survey_device(c, st.offsets, rd->n_reads, total_bytes, &sv));
+    if (sv.bad) return fail(NTHIP_ERR_ARG, "offsets / spans are not non-decreasing or reach outside the read buffer");
+    shape.max_len = shape.max_pitch = sv.max_len;
+    have_shape = true;
+    if (sv.uniform && !(flags & (NTHIP_FORCE_GENERAL | NTHIP_ASYNC)) && rd->n_reads >= 1024 && sv.len0 >= 1 &&
+        sv.len0 < (1ull << 30) && sv.off0 + rd->n_reads * sv.len0 <= total_bytes) {
+      st.seqs += sv.off0;
       st.offsets = nullptr;
       eff.offsets = nullptr;
-      eff.fixed_len = (uint32_t)len0;
+      eff.fixed_len = (uint32_t)sv.len0;
       eff.stride = 0;
-      total_bytes = rd->n_reads * len0;
+      total_bytes = rd->n_reads * sv.len0;
     }
   }
 
@@ -315,12 +312,10 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
     NTCHK(rc);
     done = true;
   }
-  // caller-made offsets are trusted by the kernels below (a decreasing pair would underflow a length): one pass first
-  if (!done && rd->offsets) NTCHK(check_offsets_device(c, st.offsets, st.offsets + 1, rd->n_reads, total_bytes, true));
   if (!done && rd->offsets && !(flags & NTHIP_FORCE_GENERAL)) {
     bool handled = false;
     int rc = run_kmer_ragged(c, st, st.offsets, st.offsets + 1, rd->n_reads, total_bytes, k, m, out->capacity,
-                             &total, &handled);
+                             &total, &handled, have_shape ? &shape : nullptr);
     if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
     NTCHK(rc);
     done = handled;

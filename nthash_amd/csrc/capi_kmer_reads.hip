@@ -13,7 +13,9 @@ namespace {
 template <int NW>
 int launch_kmer_reads(nthip_ctx* c, int mode, const KmerReadsArgs& a, size_t dyn_lds)
 {
-  auto kernel = mode == RD_MODE_MARK ? kmer_reads_kernel<RD_MODE_MARK, NW> : kmer_reads_kernel<RD_MODE_HASH, NW>;
+  auto kernel = mode == RD_MODE_MARK ? kmer_reads_kernel<RD_MODE_MARK, NW, false>
+                : a.pos            ? kmer_reads_kernel<RD_MODE_HASH, NW, true>
+                                   : kmer_reads_kernel<RD_MODE_HASH, NW, false>;
   int per_cu = 1;
   NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
   const uint64_t need = (a.n_tiles + a.waves - 1) / a.waves;
@@ -31,7 +33,7 @@ int launch_kmer_reads(nthip_ctx* c, int mode, const KmerReadsArgs& a, size_t dyn
 // *handled = false: the batch is outside this path (long reads, spans out of order, LDS); nothing was written
 int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends,
                                 uint64_t n_reads, uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity,
-                                uint64_t* total, bool* handled)
+                                uint64_t* total, bool* handled, const ReadsShape* shape)
 {
   *handled = false;
   (void)total_bytes;
@@ -41,16 +43,19 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   unsigned long long* d_res = (unsigned long long*)(c->d_small + 96); // [0] max length [1] max pitch [2] out of order
   unsigned long long* d_ndirty = (unsigned long long*)(c->d_small + 128);
   HIPCHK(hipMemsetAsync(c->d_small + 96, 0, 48, c->stream));
-  {
+  uint64_t res[3] = {0, 0, 0};
+  if (shape) { // back-to-back reads already surveyed by the caller
+    res[0] = shape->max_len;
+    res[1] = shape->max_pitch;
+  } else {
     uint64_t blocks = (n + 255) / 256;
     if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
     hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n, d_res);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_small + 96, d_res, 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(res, c->h_small + 96, 24);
   }
-  HIPCHK(hipMemcpyAsync(c->h_small + 96, d_res, 24, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  uint64_t res[3];
-  memcpy(res, c->h_small + 96, 24);
   const uint64_t max_len = res[0], max_pitch = res[1] > res[0] ? res[1] : res[0];
   if (res[2] || max_len > RD_MAX_LEN) return NTHIP_OK; // long reads: kmer_ragged_kernel spreads them over tiles
   if (max_len < k) { // no read has a window
@@ -83,13 +88,15 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   if (!waves) return NTHIP_OK;
   *handled = true;
 
-  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-  NTCHK(ensure_scratch(c, 3 * n + nb + n / 8 + 64));
+  const uint64_t n_tiles = (n + R - 1) / R;
+  const uint64_t nb = (n_tiles + SCAN_TILE - 1) / SCAN_TILE;
+  NTCHK(ensure_scratch(c, 2 * n + 2 * n_tiles + nb + n / 8 + 64));
   uint64_t* d_cnt = st.counts ? st.counts : c->d_scratch;
-  uint64_t* d_off = c->d_scratch + n;
-  uint64_t* d_list = c->d_scratch + 2 * n;
-  uint64_t* d_sums = c->d_scratch + 3 * n;
-  uint8_t* d_flags = (uint8_t*)(c->d_scratch + 3 * n + nb + 8);
+  uint64_t* d_list = c->d_scratch + n;
+  uint64_t* d_tsum = c->d_scratch + 2 * n;
+  uint64_t* d_toff = d_tsum + n_tiles;
+  uint64_t* d_sums = d_toff + n_tiles;
+  uint8_t* d_flags = (uint8_t*)(d_sums + nb + 8);
   uint64_t* d_total = (uint64_t*)(c->d_small + 8);
 
   KmerReadsArgs a;
@@ -102,12 +109,13 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   a.ends = d_ends;
   a.n_reads = n;
   a.R = R;
-  a.n_tiles = (n + R - 1) / R;
+  a.n_tiles = n_tiles;
   a.cnt = d_cnt;
   a.flags = d_flags;
   a.dirty_list = d_list;
   a.dirty_count = d_ndirty;
-  a.read_off = d_off;
+  a.tile_sum = d_tsum;
+  a.tile_off = d_toff;
   a.hashes = st.hashes;
   a.pos = st.pos;
   NTCHK(get_kmer_tab(c, k, &a.init_tab));
@@ -154,7 +162,9 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   da.k = k;
   da.m = m;
   da.cnt = d_cnt;
-  da.read_off = d_off;
+  da.tile_sum = d_tsum;
+  da.tile_off = d_toff;
+  da.R = R;
   da.hashes = st.hashes;
   da.pos = st.pos;
   da.fwd = st.fwd;
@@ -166,7 +176,7 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   const unsigned dblocks = (unsigned)c->n_cu * 4;
   hipLaunchKernelGGL(kmer_dirty_reads_kernel<true>, dim3(dblocks), dim3(256), 0, c->stream, da);
   HIPCHK(hipGetLastError());
-  NTCHK(device_exclusive_scan(c, d_cnt, d_off, n, d_sums, d_total));
+  NTCHK(device_exclusive_scan(c, d_tsum, d_toff, n_tiles, d_sums, d_total));
   HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   memcpy(total, c->h_small + 8, 8);

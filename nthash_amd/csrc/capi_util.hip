@@ -43,23 +43,24 @@ int launch_fill_window_pos(nthip_ctx* c, uint32_t* d_pos, uint64_t n_reads, uint
   return NTHIP_OK;
 }
 
-int offsets_uniform_device(nthip_ctx* c, const uint64_t* d_offsets, uint64_t n_reads, uint64_t* off0, uint64_t* len0,
-                           bool* uniform)
+int offsets_survey_device(nthip_ctx* c, const uint64_t* d_offsets, uint64_t n_reads, uint64_t buf_bytes, OffsetsSurvey* sv)
 {
-  *uniform = false;
-  uint64_t* d_res = (uint64_t*)(c->d_small + 208); // [0] offsets[0], [1] offsets[1], [2] "differs" flag
-  HIPCHK(hipMemsetAsync(d_res, 0, 24, c->stream));
+  unsigned long long* d_res = (unsigned long long*)(c->d_small + 160); // see offsets_survey_kernel
+  HIPCHK(hipMemsetAsync(d_res, 0, 40, c->stream));
   uint64_t blocks = (n_reads + 255) / 256;
   if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
-  hipLaunchKernelGGL(offsets_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_offsets, n_reads, d_res);
+  hipLaunchKernelGGL(offsets_survey_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_offsets, n_reads, buf_bytes,
+                     d_res);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(c->h_small + 208, d_res, 24, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_small + 160, d_res, 40, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  uint64_t res[3];
-  memcpy(res, c->h_small + 208, 24);
-  *off0 = res[0];
-  *len0 = res[1] >= res[0] ? res[1] - res[0] : 0;
-  *uniform = res[2] == 0 && res[1] >= res[0];
+  uint64_t res[5];
+  memcpy(res, c->h_small + 160, 40);
+  sv->off0 = res[0];
+  sv->len0 = res[1] >= res[0] ? res[1] - res[0] : 0;
+  sv->bad = res[3] != 0;
+  sv->uniform = !sv->bad && res[2] == 0;
+  sv->max_len = res[4];
   return NTHIP_OK;
 }
 

@@ -42,8 +42,9 @@ struct KmerReadsArgs {
   uint8_t* flags;            // [n_reads] 1 = listed
   uint64_t* dirty_list;      // reads with a non-base and at least k bytes
   unsigned long long* dirty_count;
+  uint64_t* tile_sum;        // [n_tiles] k-mers of the tile's clean reads (kmer_dirty_reads_kernel adds the listed ones)
   // HASH
-  const uint64_t* read_off;  // exclusive scan of cnt
+  const uint64_t* tile_off;  // exclusive scan of tile_sum: the tile's first k-mer in the stream
   uint64_t* hashes;
   uint32_t* pos;
   const uint4* init_tab;
@@ -54,10 +55,12 @@ struct KmerReadsArgs {
   uint64_t mult[KF_MAX_RUNTIME_M];
 };
 
-template <int MODE, int NW>
+// POS: window positions wanted.  value_sel 1 / 2 (one strand's hash instead of the canonical one) needs no code in the
+// roll: with the other strand's table terms zeroed its state stays 0 and forward + reverse IS the wanted strand.
+template <int MODE, int NW, bool POS = false>
 __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerReadsArgs a)
 {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  extern __shared__ __attribute__((aligned(256))) uint32_t lds_dyn[];
   const uint32_t k = a.k, m = a.m, C = a.C;
   const uint32_t inv_m = 0xFFFFFFFFu / m + 1u;
   const uint64_t kmul = (uint64_t)k * MULTISEED;
@@ -78,24 +81,32 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
   uint32_t* rt_out = rt_nw + 64;           // first k-mer of the read, relative to the tile's first
   uint8_t* rmap = (uint8_t*)(rt_out + 64); // run of the tile -> its read
   if (MODE == RD_MODE_HASH) {
-    for (uint32_t i = tid; i < a.ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
+    const uint32_t keep_f = a.value_sel == 2u ? 0u : ~0u, keep_r = a.value_sel == 1u ? 0u : ~0u;
+    for (uint32_t i = tid; i < a.ntab * 256u; i += blockDim.x) {
+      const uint4 e = a.init_tab[i];
+      itab[i] = make_uint4(e.x & keep_f, e.y & keep_f, e.z & keep_r, e.w & keep_r);
+    }
     if (tid < 16)
-      ptab[tid] = make_uint4((uint32_t)a.tab[tid][0], (uint32_t)(a.tab[tid][0] >> 32),
-                             (uint32_t)a.tab[tid][1], (uint32_t)(a.tab[tid][1] >> 32));
+      ptab[tid] = make_uint4((uint32_t)a.tab[tid][0] & keep_f, (uint32_t)(a.tab[tid][0] >> 32) & keep_f,
+                             (uint32_t)a.tab[tid][1] & keep_r, (uint32_t)(a.tab[tid][1] >> 32) & keep_r);
   }
   __syncthreads();
 
+  const uint32_t ptab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)ptab;
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   };
+  // inclusive prefix sum over the 64 lanes on the DPP network (no LDS round trips, unlike __shfl_up = ds_bpermute):
+  // row_shr 1, 2, 4, 8 scan each row of 16 lanes, row_bcast15 / row_bcast31 carry the row totals across
   auto wave_incl_scan32 = [&](uint32_t v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(v, d, 64);
-      if ((int)lane >= d) v += o;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
     return v;
   };
   auto bcast64 = [&](uint64_t v, uint32_t src) -> uint64_t {
@@ -117,13 +128,16 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
     const uint64_t len_j = has && e_j > s_j ? e_j - s_j : 0;
     bool listed = false;
     uint64_t ro_j = 0;
+    uint64_t ro_0 = 0;
     if (MODE == RD_MODE_HASH) {
       listed = a.flags[rj] != 0;
-      ro_j = a.read_off[rj];
+      // the read's first k-mer = the tile's + the k-mers of the reads before it in the tile (a tile has < 2^32)
+      const uint32_t cnt_j = has ? (uint32_t)a.cnt[rj] : 0u;
+      ro_0 = a.tile_off[t];
+      ro_j = ro_0 + (wave_incl_scan32(cnt_j) - cnt_j);
     }
     const uint64_t slab0 = bcast64(s_j, 0);
     const uint64_t slab_end = bcast64(e_j, nr - 1u);
-    const uint64_t ro_0 = bcast64(ro_j, 0);
     const uint32_t shift = (uint32_t)(((uintptr_t)a.seqs + slab0) & 15u);
     const uint8_t* vbase = a.seqs + slab0 - shift; // 16-byte aligned: a vector never crosses a page
     const uint32_t n_vec = slab_end > slab0 ? (uint32_t)((shift + (slab_end - slab0) + 15u) >> 4) : 0u;
@@ -155,12 +169,14 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
           any |= word;
         }
       }
+      const bool dirty = has && any != 0 && nwin_raw != 0;
       if (has) {
-        const bool dirty = any != 0 && nwin_raw != 0;
         a.cnt[rj] = dirty ? 0 : nwin_raw;
         a.flags[rj] = dirty ? 1 : 0;
         if (dirty) a.dirty_list[atomicAdd(a.dirty_count, 1ull)] = rj;
       }
+      const uint32_t tsum = wave_incl_scan32(dirty || !has ? 0u : nwin_raw);
+      if (lane == 63u) a.tile_sum[t] = tsum;
       lds_sync(); // the bit stream is free again
       continue;
     }
@@ -225,20 +241,21 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
           uint4 e[4 * NW];
 #pragma unroll
           for (int jt = 0; jt < 4 * NW; ++jt) e[jt] = itab[(uint32_t)jt * 256u + ((w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu)];
+          f_lo = e[0].x ^ e[1].x; f_hi = e[0].y ^ e[1].y; r_lo = e[0].z ^ e[1].z; r_hi = e[0].w ^ e[1].w;
 #pragma unroll
-          for (int jt = 0; jt < 4 * NW; ++jt) {
-            f_lo ^= e[jt].x; f_hi ^= e[jt].y; r_lo ^= e[jt].z; r_hi ^= e[jt].w;
+          for (int jt = 2; jt < 4 * NW; jt += 2) { // a ^ b ^ c is one v_bitop3_b32
+            f_lo = __builtin_amdgcn_bitop3_b32(f_lo, e[jt].x, e[jt + 1].x, 0x96);
+            f_hi = __builtin_amdgcn_bitop3_b32(f_hi, e[jt].y, e[jt + 1].y, 0x96);
+            r_lo = __builtin_amdgcn_bitop3_b32(r_lo, e[jt].z, e[jt + 1].z, 0x96);
+            r_hi = __builtin_amdgcn_bitop3_b32(r_hi, e[jt].w, e[jt + 1].w, 0x96);
           }
         }
         uint64_t* const mine = tile + tpar + slot;
         uint32_t* const pmine = ptile + slot;
-        const bool want_pos = a.pos != nullptr;
         auto emit = [&](uint32_t jw) {
           if (!PRED || jw < c_run) {
-            mine[jw] = a.value_sel == 0u   ? canon_pair(f_lo, f_hi, r_lo, r_hi)
-                       : a.value_sel == 1u ? (((uint64_t)f_hi << 32) | f_lo)
-                                           : (((uint64_t)r_hi << 32) | r_lo);
-            if (want_pos) pmine[jw] = w_first + jw;
+            mine[jw] = canon_pair(f_lo, f_hi, r_lo, r_hi);
+            if (POS) pmine[jw] = w_first + jw;
           }
         };
         emit(0u);
@@ -249,10 +266,12 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
           const uint32_t w_out = funnel(bits[d0 + jw + 1], bits[d0 + jw], sh0);
           const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
           const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
-          auto lookup = [&](uint32_t i) -> uint4 {
+          auto lookup = [&](uint32_t i) -> uint4 { // nibble i of the step stream -> its 16-byte entry (the table is 256-aligned)
             const uint32_t src = (i & 1u) ? v : u;
-            const uint32_t toff = ((src >> ((i >> 1) * 4u)) & 0xFu) << 4;
-            return *(const uint4*)((const char*)ptab + toff);
+            const uint32_t sh = (i >> 1) * 4u;
+            const uint32_t ad = ((sh == 0u ? src << 4 : src >> (sh - 4u)) & 0xF0u) | ptab_addr;
+            const nt_v4u e = *(__attribute__((address_space(3))) const nt_v4u*)(uintptr_t)ad;
+            return make_uint4(e.x, e.y, e.z, e.w);
           };
           auto roll = [&](const uint4 term) {
             srol_pair(f_lo, f_hi);
@@ -300,14 +319,16 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
         const uint32_t sp = tpar + span;
         const uint32_t pieces = (sp + 1u) >> 1;
         uint64_t* const base = a.hashes + (o0 - tpar);
-        for (uint32_t pi = lane; pi < pieces; pi += 64u) {
-          const uint4 dv = *(const uint4*)(tile + 2u * pi);
-          const bool lo_ok = 2u * pi >= tpar && 2u * pi < sp;
-          const bool hi_ok = 2u * pi + 1u >= tpar && 2u * pi + 1u < sp;
-          if (lo_ok && hi_ok) __builtin_nontemporal_store(*(const nt_v4u*)&dv, (nt_v4u*)(base + 2u * pi));
-          else if (lo_ok) *(uint2*)(base + 2u * pi) = make_uint2(dv.x, dv.y);
-          else if (hi_ok) *(uint2*)(base + 2u * pi + 1u) = make_uint2(dv.z, dv.w);
+        const uint32_t pf = (tpar + 1u) >> 1, pl = sp >> 1; // whole 16-byte pieces: [pf, pl)
+        for (uint32_t pi = lane; pi < pl; pi += 64u) {
+          if (pi >= pf) {
+            const uint4 dv = *(const uint4*)(tile + 2u * pi);
+            __builtin_nontemporal_store(*(const nt_v4u*)&dv, (nt_v4u*)(base + 2u * pi));
+          }
         }
+        if (lane == 0u && (tpar & 1u)) base[tpar] = tile[tpar];                   // head
+        if (lane == 1u && (sp & 1u) && sp - 1u >= pf * 2u) base[sp - 1u] = tile[sp - 1u]; // tail
+        (void)pieces;
       } else {
         const uint64_t v0 = o0 * m;
         const uint32_t vpar = (uint32_t)(v0 & 1u);
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
           else if (ok[1]) *(uint2*)(base + 2u * pi + 1u) = make_uint2((uint32_t)o[1], (uint32_t)(o[1] >> 32));
         }
       }
-      if (a.pos)
+      if (POS)
         for (uint32_t e = lane; e < span; e += 64u) a.pos[o0 + e] = ptile[e];
       lds_sync(); // the tile is free again
       g0 += nl;
@@ -354,8 +375,10 @@ struct KmerDirtyReadsArgs {
   const uint64_t* list;
   const unsigned long long* n_list;
   uint32_t k, m;
-  uint64_t* cnt;             // count pass: exact windows of the read
-  const uint64_t* read_off;  // hash pass
+  uint64_t* cnt;             // count pass: exact windows of the read (written), hash pass: of every read (read)
+  uint64_t* tile_sum;        // count pass: += the read's windows
+  const uint64_t* tile_off;  // hash pass
+  uint32_t R;                // reads per tile
   uint64_t* hashes;
   uint32_t* pos;
   uint64_t* fwd;
@@ -404,7 +427,14 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     const uint32_t nwin = len >= k ? len - k + 1u : 0u;
-    const uint64_t base = COUNT_ONLY ? 0 : a.read_off[r];
+    uint64_t base = 0;
+    if (!COUNT_ONLY) { // the tile's first k-mer + the k-mers of the reads before this one in its tile
+      const uint64_t r0 = r / a.R * a.R;
+      uint32_t before = r0 + lane < r ? (uint32_t)a.cnt[r0 + lane] : 0u;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
+      base = a.tile_off[r / a.R] + before;
+    }
     uint32_t emitted = 0;
     for (uint32_t w0 = 0; w0 < nwin; w0 += 64u) {
       const uint32_t w = w0 + lane;
@@ -425,7 +455,10 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
       }
       emitted += (uint32_t)__builtin_popcountll(mask);
     }
-    if (COUNT_ONLY && lane == 0) a.cnt[r] = emitted;
+    if (COUNT_ONLY && lane == 0) {
+      a.cnt[r] = emitted;
+      atomicAdd((unsigned long long*)&a.tile_sum[r / a.R], (unsigned long long)emitted);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
   }

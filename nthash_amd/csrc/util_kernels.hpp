@@ -438,17 +438,48 @@ static __global__ __launch_bounds__(512) void fill16_kernel(uint4* __restrict__ 
     *((v4u*)dst + i) = v;
 }
 
-// res[0] = offsets[0], res[1] = offsets[1], res[2] != 0 iff some read's length differs from the first one's
-static __global__ __launch_bounds__(256) void offsets_uniform_kernel(const uint64_t* __restrict__ offsets, uint64_t n,
-                                                                     uint64_t* __restrict__ res)
+// One pass over n+1 offsets of back-to-back reads: are they in order and inside the buffer, do all reads have one
+// length, how long is the longest.  res: [0] offsets[0] [1] offsets[1] [2] lengths differ [3] bad [4] max length.
+// (Thousands of waves hammering one address serialise in L2: look first, a flag is set / the maximum reached early.)
+static __global__ __launch_bounds__(256) void offsets_survey_kernel(const uint64_t* __restrict__ offsets, uint64_t n,
+                                                                    uint64_t buf_bytes, unsigned long long* __restrict__ res)
 {
   const uint64_t o0 = offsets[0], o1 = offsets[1];
   const uint64_t len0 = o1 - o0;
-  uint32_t differs = o1 < o0 ? 1u : 0u;
-  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x)
-    if (offsets[r + 1] - offsets[r] != len0) differs = 1u;
+  uint32_t differs = 0, bad = 0;
+  uint64_t mlen = 0;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t a0 = offsets[r], a1 = offsets[r + 1];
+    if (a1 < a0 || a1 > buf_bytes) { bad = 1u; continue; }
+    if (a1 - a0 != len0) differs = 1u;
+    if (a1 - a0 > mlen) mlen = a1 - a0;
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint64_t ol = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(mlen >> 32), d, 64) << 32) |
+                        (uint32_t)__shfl_down((int)(uint32_t)mlen, d, 64);
+    if (ol > mlen) mlen = ol;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) { res[0] = o0; res[1] = o1; }
-  if (__ballot(differs != 0) != 0 && (threadIdx.x & 63u) == 0) atomicOr((unsigned long long*)&res[2], 1ull);
+  // per block: one thread speaks for its four waves
+  __shared__ uint64_t w_mlen[4];
+  __shared__ uint32_t w_flags[4];
+  const bool any_differs = __ballot(differs != 0) != 0, any_bad = __ballot(bad != 0) != 0;
+  if ((threadIdx.x & 63u) == 0) {
+    w_mlen[threadIdx.x >> 6] = mlen;
+    w_flags[threadIdx.x >> 6] = (any_differs ? 1u : 0u) | (any_bad ? 2u : 0u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t bl = 0;
+    uint32_t bf = 0;
+    for (int w = 0; w < 4; ++w) {
+      bl = w_mlen[w] > bl ? w_mlen[w] : bl;
+      bf |= w_flags[w];
+    }
+    if ((bf & 1u) && __atomic_load_n(&res[2], __ATOMIC_RELAXED) == 0) atomicOr(&res[2], 1ull);
+    if ((bf & 2u) && __atomic_load_n(&res[3], __ATOMIC_RELAXED) == 0) atomicOr(&res[3], 1ull);
+    if (bl > __atomic_load_n(&res[4], __ATOMIC_RELAXED)) atomicMax(&res[4], (unsigned long long)bl);
+  }
 }
 
 // spans / offsets sanity (the kernels trust them): every read must satisfy starts[r] <= ends[r] <= buf_bytes
