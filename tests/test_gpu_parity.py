@@ -333,6 +333,95 @@ def test_kmer_ragged_fast_path_vs_oracle(ctx, oracle):
         assert (got["hashes"] == want["hashes"]).all()
 
 
+def test_kmer_whole_read_tiles_vs_oracle(oracle):
+    """variable-length SHORT reads on kmer_reads_kernel (tiles of whole reads; clean reads rolled with an overlapping
+    last run, reads with a non-base on the wave-per-read kernel that fills the holes they leave): read counts around
+    the tile size, reads with fewer windows than a run, whole neighbourhoods of reads with N's (holes larger than the
+    output tile's slack), every table width and the any-k Horner start, positions, strands, several hashes per
+    k-mer -- against the oracle and against round 1's kmer_ragged_kernel (NTHIP_TUNE_NO_KMER_READS=1), and the spans
+    entry (sequence lines with other bytes between them)"""
+    import os
+    import nthash_amd
+    rng = np.random.default_rng(2024)
+    new = nthash_amd.Context(0)
+    os.environ["NTHIP_TUNE_NO_KMER_READS"] = "1"
+    try:
+        old = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_NO_KMER_READS", None)
+    alph = np.frombuffer(b"ACGTacgtUuNnRYKM-*", dtype=np.uint8)
+
+    def make_reads(n, lo, hi, p_dirty, cluster=False):
+        reads = []
+        for i in range(n):
+            L = int(rng.integers(lo, hi + 1))
+            dirty = (rng.random() < p_dirty) or (cluster and 40 <= i < 75)
+            idx = np.where(rng.random(L) < 0.96, rng.integers(0, 10, L), rng.integers(10, len(alph), L)) if dirty \
+                else rng.integers(0, 10, L)
+            reads.append(alph[idx].tobytes())
+        return reads
+
+    cases = []
+    for n in (1, 2, 31, 32, 33, 63, 64, 65, 1000):
+        cases.append((n, 60, 151, 0.02, False, 31, 1))
+    cases += [(700, 0, 60, 0.1, False, 31, 1),        # most reads have fewer windows than a run, or none
+              (700, 100, 150, 0.0, True, 31, 1),      # 35 consecutive reads with non-bases: holes beyond the tile's slack
+              (500, 100, 150, 0.3, False, 31, 2),
+              (600, 20, 300, 0.05, False, 3, 1), (600, 20, 300, 0.05, False, 16, 3), (600, 20, 300, 0.05, False, 17, 1),
+              (600, 40, 300, 0.05, False, 32, 4), (600, 40, 300, 0.05, False, 33, 1), (400, 70, 400, 0.05, False, 64, 2),
+              (300, 120, 500, 0.05, False, 100, 1),   # any-k start (NW = 0)
+              (200, 1500, 2048, 0.02, False, 31, 1)]  # the longest reads this path takes
+    for (n, lo, hi, p_dirty, cluster, k, m) in cases:
+        reads = make_reads(n, lo, hi, p_dirty, cluster)
+        d, offs = concat_reads(reads)
+        want = oracle.kmer_batch(d, offs, k, m, want_strands=True)
+        new.set_profiling(True)
+        got = new.kmer_hash(d, k, m, offsets=offs, want_pos=True)
+        name = new.last_kernel_ms()[1]
+        new.set_profiling(False)
+        if want["total"] and max(len(r) for r in reads) >= k:
+            assert name == "kmer_reads_kernel", (name, n, k)
+        assert got["total"] == want["total"], (n, lo, hi, k, m)
+        for key in ("counts", "pos", "hashes"):
+            assert (got[key] == want[key]).all(), (n, lo, hi, k, m, key)
+        got = new.kmer_hash(d, k, m, offsets=offs, want_strands=True)            # no positions; strands
+        for key in ("counts", "hashes", "fwd", "rev"):
+            assert (got[key] == want[key]).all(), (n, lo, hi, k, m, key)
+        ref = old.kmer_hash(d, k, m, offsets=offs, want_pos=True)               # round 1's kernel agrees
+        assert (ref["hashes"] == want["hashes"]).all() and (ref["pos"] == want["pos"]).all()
+    # spans: reads with other bytes between them (what the FASTQ indexer produces), device-resident
+    reads = make_reads(777, 50, 151, 0.03)
+    buf = bytearray(b"@")
+    starts, ends = [], []
+    for r in reads:
+        buf += b"hdr " + bytes(rng.integers(33, 127, int(rng.integers(0, 40))).astype(np.uint8)) + b"\n"
+        starts.append(len(buf)); buf += r; ends.append(len(buf))
+        buf += b"\n+\n" + bytes(rng.integers(33, 127, len(r)).astype(np.uint8)) + b"\n@"
+    raw = np.frombuffer(bytes(buf), dtype=np.uint8)
+    d, offs = concat_reads(reads)
+    for k, m in ((31, 1), (21, 2)):
+        want = oracle.kmer_batch(d, offs, k, m)
+        cap = max(1, want["total"])
+        d_buf = new.malloc(raw.size + 16); d_s = new.malloc(8 * len(reads)); d_e = new.malloc(8 * len(reads))
+        d_h = new.malloc(cap * m * 8); d_c = new.malloc(8 * len(reads)); d_p = new.malloc(4 * cap)
+        try:
+            new.h2d(d_buf, raw); new.h2d(d_s, np.array(starts, np.uint64)); new.h2d(d_e, np.array(ends, np.uint64))
+            new.set_profiling(True)
+            tot = new.kmer_hash_spans_ptr(d_buf, raw.size, d_s, d_e, len(reads), k, m, d_h, cap, counts=d_c, pos=d_p)
+            name = new.last_kernel_ms()[1]
+            new.set_profiling(False)
+            assert name == "kmer_reads_kernel" and tot == want["total"]
+            h = np.zeros(cap * m, np.uint64); cts = np.zeros(len(reads), np.uint64); ps = np.zeros(cap, np.uint32)
+            new.d2h(h, d_h); new.d2h(cts, d_c); new.d2h(ps, d_p)
+            assert (h[: tot * m].reshape(-1, m) == want["hashes"]).all() and (cts == want["counts"]).all()
+            assert (ps[:tot] == want["pos"]).all()
+        finally:
+            for ptr in (d_buf, d_s, d_e, d_h, d_c, d_p):
+                new.free(ptr)
+    new.close()
+    old.close()
+
+
 def test_kmer_long_reads_are_segmented(ctx, oracle):
     """reads far longer than a segment (1024 windows) next to short and empty ones: the general
     kernel cuts them into segments that restart the roll; stream, positions and counts must not change"""
