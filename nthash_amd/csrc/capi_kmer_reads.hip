@@ -65,7 +65,8 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
     return NTHIP_OK;
   }
   // ---- tile geometry ----
-  const uint32_t C = c->tune.reads_run_len ? c->tune.reads_run_len : 8; // <= 16 (one word of roll steps + the first window)
+  // odd: the tile writes of a wave (8-byte entries, C entries apart) then fall on 16 different bank pairs
+  const uint32_t C = c->tune.reads_run_len ? c->tune.reads_run_len : 9; // <= 16 (one word of roll steps + the first window)
   const uint32_t nw = kmer_nw(k);
   const uint64_t slab_cap = 16384; // bytes of reads (and what lies between them) a tile stages
   uint32_t R = c->tune.reads_per_tile ? c->tune.reads_per_tile : 32;

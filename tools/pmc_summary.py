@@ -12,7 +12,8 @@ for f in sorted(glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv
     for row in csv.DictReader(open(f)):
         name = row.get("Kernel_Name", "")
         short = "copy" if "copy_kernel" in name else "ragged_hash" if "kmer_ragged_kernel<2" in name else \
-            "ragged_count" if "kmer_ragged_kernel<1" in name else "kmer_runs_gen" if "kmer_runs_gen" in name else \
+            "ragged_count" if "kmer_ragged_kernel<1" in name else "reads_hash" if "kmer_reads_kernel<2" in name else \
+            "reads_mark" if "kmer_reads_kernel<1" in name else "reads_dirty" if "kmer_dirty_reads" in name else "kmer_runs_gen" if "kmer_runs_gen" in name else \
             "kmer_runs" if "kmer_runs" in name else "kmer_fixed" if "kmer_fixed" in name else \
             "seed_fixed" if "seed_fixed" in name else "seed_wtile" if "seed_wtile" in name else None
         if short is None:

@@ -18,6 +18,9 @@ cat "$OUT/pmc_c2/summary.txt" | grep -v "^copy"
 bash tools/run_pmc.sh "$OUT/pmc_c4" c4 8000000 > "$OUT/pmc_c4.log" 2>&1
 cat "$OUT/pmc_c4/summary.txt" | grep -v "^copy"
 find "$OUT/pmc_c4" -name "*kernel_trace.csv" -delete
+PMC_SQ_ONLY=1 bash tools/run_pmc.sh "$OUT/pmc_rag" rag 10000000 > "$OUT/pmc_rag.log" 2>&1
+cat "$OUT/pmc_rag/summary.txt" | grep -v "^copy"
+find "$OUT/pmc_rag" -name "*kernel_trace.csv" -delete
 # keep only small summaries in the merge-back
 find "$OUT" -name "*.db" -delete; find "$OUT/pmc_c2" -name "*kernel_trace.csv" -delete
 du -sh "$OUT"
