@@ -8,7 +8,8 @@
 //   capi_kmer_runs.hip     kmer_runs_kernel instantiations (headline shapes)
 //   capi_kmer_gen.hip      kmer_runs_gen_kernel, dense
 //   capi_kmer_na.hip       kmer_runs_gen_kernel, N-aware: count -> scan -> hash
-//   capi_kmer_ragged.hip   kmer_ragged_kernel (offsets / spans)
+//   capi_kmer_reads.hip    kmer_reads_kernel (offsets / spans in order, short reads): tiles of whole reads
+//   capi_kmer_ragged.hip   kmer_ragged_kernel (offsets / spans, any lengths)
 //   capi_kmer_general.hip  lane-per-read kernels (correctness paths) and the row-per-read kernel
 //   capi_seed.hip          spaced seeds
 //   capi_sink_bloom.hip / capi_sink_minhash.hip   fused consumers
