@@ -79,6 +79,7 @@ struct nthip_tune {
   bool no_autotune = false; // NTHIP_TUNE_NO_AUTOTUNE (set)
   bool no_seed_wave = false; // NTHIP_TUNE_NO_SEED_WAVE (set)
   bool no_seed_wtile = false; // NTHIP_TUNE_NO_SEED_WTILE=1: the block-tile dense seed kernel instead of the wave-tile one
+  bool no_any_k_runs = false; // NTHIP_TUNE_NO_ANY_K_RUNS=1: only the k = 31 / run length 15, 30 instantiations of kmer_runs_kernel
   bool no_kmer_reads = false; // NTHIP_TUNE_NO_KMER_READS=1: variable-length reads on kmer_ragged_kernel only
   uint32_t reads_run_len = 0, reads_per_tile = 0, reads_waves = 0; // NTHIP_TUNE_READS_RUN_LEN / _PER_TILE / _WAVES (kmer_reads_kernel)
   bool no_seed_rot = false;   // NTHIP_TUNE_NO_SEED_ROT=1: the plain [table][entry] layout of the byte tables in LDS
@@ -261,6 +262,7 @@ void fill_gen_args(KmerRunsGenArgs& ga, nthip_ctx* c, const Staged& st, const nt
 
 // ---- kernel launchers, one TU each ----------------------------------------------------------------------------
 // capi_kmer_runs.hip: the k = 31 instantiations of kmer_runs_kernel (C = 15 | nwin, or 30 for m = 1)
+bool kmer_runs_any_k_compiled(uint32_t k, uint32_t m, uint32_t C);
 int launch_kmer_runs_special(nthip_ctx* c, const KmerRunsArgs& ra, const RunsPlan& plan, bool dword_tail);
 // whether that unit was built with the chunked path (KR_CHUNKED; an A/B build of the unit may differ from the plan's)
 bool kmer_runs_chunked_compiled();

@@ -107,8 +107,12 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
     GenPlan gplan;
     // the specialised k=31 instantiations (run length 15 / 30 dividing the window count); everything
     // else goes to the general run-split kernel
-    const bool special = !rows_only && k == 31 && kmer_runs_plan(c, len, stride, k, m, &plan) &&
-                         (plan.C == 15 || (plan.C == 30 && m == 1)) && !c->tune.no_special; // (A/B: general kernel on these too)
+    const bool planned = !rows_only && !c->tune.no_special && kmer_runs_plan(c, len, stride, k, m, &plan);
+    const bool special31 = planned && k == 31 && (plan.C == 15 || (plan.C == 30 && m == 1));
+    // (runs per read <= 128: the kernel's division of a run index by it, one multiply and a shift, is exact there)
+    const bool any_k = planned && !special31 && !c->tune.no_any_k_runs && plan.rpr <= 128 &&
+                       kmer_runs_any_k_compiled(k, m, plan.C);
+    const bool special = special31 || any_k; // (NTHIP_TUNE_NO_SPECIAL: A/B, the general kernel on these too)
     if (special) {
       // run-split kernel: contiguous write-out (see kmer_runs_kernel.hpp)
       KmerRunsArgs ra;
@@ -116,7 +120,8 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
       ra.seqs = st.seqs;
       ra.hashes = st.hashes;
       ra.dirty = (uint32_t*)c->d_small;
-      NTCHK(get_init_tab(c, k, &ra.init_tab));
+      if (any_k) NTCHK(get_kmer_tab(c, k, &ra.init_tab)); // 4 tables per window word, zero ones past ceil(k/4)
+      else NTCHK(get_init_tab(c, k, &ra.init_tab));
       ra.n_reads = rd->n_reads;
       ra.n_runs = rd->n_reads * plan.rpr;
       ra.n_wtiles = (ra.n_runs + 63) / 64;
@@ -127,7 +132,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
       ra.nwin = nwin;
       ra.C = plan.C;
       ra.rpr = plan.rpr;
-      ra.ntab = (k + 3) / 4;
+      ra.ntab = any_k ? kmer_ntab(k) : (k + 3) / 4;
       ra.waves = plan.waves;
       ra.bits_dwords = plan.bits_dwords;
       ra.tile_u64 = plan.tile_u64;

@@ -130,7 +130,7 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
   bd = (bd + 3u) & ~3u;
   p->bits_dwords = bd;
   p->dword_tail = (AL + slab_bytes <= 1280 && !c->tune.no_dword_tail) ? 1u : 0u;
-  const size_t fixed = (size_t)((k + 3) / 4) * 4096 + 256 + 64;
+  const size_t fixed = (size_t)(4 * p->nw) * 4096 + 256 + 64; // (room for the padded tables of the runtime-k instantiations)
   // chunked path (kmer_runs_kernel.hpp, only when compiled in): every wave keeps the bit streams of a chunk's tiles
   // in LDS and is limited to 8 waves per CU
   const bool chunked = kmer_runs_chunked_compiled() && p->dword_tail && !c->tune.no_phases && m == 1 &&

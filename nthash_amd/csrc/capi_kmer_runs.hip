@@ -55,11 +55,39 @@ bool ntamd::host::kmer_runs_chunked_compiled() { return KR_CHUNKED != 0; }
 
 // ra.m selects the instantiation: m = 1 (configs 2 / 5; run length 15 or 30), m = 4 compile-time (config 3),
 // any other m at run time
+// shapes launch_kmer_runs_special has a runtime-k instantiation for
+bool ntamd::host::kmer_runs_any_k_compiled(uint32_t k, uint32_t m, uint32_t C)
+{
+  if (m != 1 || k < 17 || k > 32) return false;
+  switch (C) {
+    case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 19: case 20: case 22: case 23: case 25: return true;
+    default: return false;
+  }
+}
+
 int ntamd::host::launch_kmer_runs_special(nthip_ctx* c, const KmerRunsArgs& ra, const RunsPlan& plan, bool dt)
 {
 #define NT_RUNS(KT, MT, CT, NWT) \
   (dt ? launch_kmer_runs(c, kmer_runs_kernel<KT, MT, CT, NWT, true>, ra, plan.lds) \
       : launch_kmer_runs(c, kmer_runs_kernel<KT, MT, CT, NWT, false>, ra, plan.lds))
+  // m = 1, 17 <= k <= 32, a run length that divides the window count: k at run time, run length compile-time
+  // (151 bp / k31: 11, 100 bp: 14, 76 bp: 23, 250 bp: 11, 125 bp: 19, 150 bp / k21: 13, ...)
+  if (ra.m == 1 && !(ra.k == 31 && (plan.C == 15 || plan.C == 30)) && kmer_runs_any_k_compiled(ra.k, 1, plan.C)) {
+    switch (plan.C) {
+      case 10: return NT_RUNS(0, 1, 10, 2);
+      case 11: return NT_RUNS(0, 1, 11, 2);
+      case 12: return NT_RUNS(0, 1, 12, 2);
+      case 13: return NT_RUNS(0, 1, 13, 2);
+      case 14: return NT_RUNS(0, 1, 14, 2);
+      case 15: return NT_RUNS(0, 1, 15, 2);
+      case 16: return NT_RUNS(0, 1, 16, 2);
+      case 19: return NT_RUNS(0, 1, 19, 2);
+      case 20: return NT_RUNS(0, 1, 20, 2);
+      case 22: return NT_RUNS(0, 1, 22, 2);
+      case 23: return NT_RUNS(0, 1, 23, 2);
+      default: return NT_RUNS(0, 1, 25, 2);
+    }
+  }
   if (ra.k != 31 || !(plan.C == 15 || (plan.C == 30 && ra.m == 1)))
     return fail(NTHIP_ERR_HIP, "no specialised run-split kernel for k=%u, run length %u", ra.k, plan.C);
   if (ra.m == 1 && plan.C == 15) return NT_RUNS(31, 1, 15, 2);

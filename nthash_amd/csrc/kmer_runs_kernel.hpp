@@ -109,7 +109,9 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
   const uint32_t k = K_T ? (uint32_t)K_T : a.k;
   const uint32_t m = M_T ? (uint32_t)M_T : a.m;
   const uint32_t C = C_T ? (uint32_t)C_T : a.C;
-  const uint32_t ntab = K_T ? (uint32_t)((K_T + 3) / 4) : a.ntab;
+  // K_T == 0 (k at run time): the host pads the first-window tables to 4 per window word with zero tables
+  // (kmer_ntab / get_kmer_tab), so that the lookups below stay unconditional
+  const uint32_t ntab = K_T ? (uint32_t)((K_T + 3) / 4) : 4u * (uint32_t)NW;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
 #ifndef KR_UNIFORM_WAVE

@@ -140,6 +140,54 @@ def test_kmer_general_run_split_shapes_vs_oracle(ctx, oracle, n, L, k, m):
     assert (got["counts"] == want["counts"]).all()
 
 
+def test_kmer_headline_kernel_any_k_instantiations_vs_oracle(ctx, oracle):
+    """kmer_runs_kernel with k at run time and a compile-time run length (m = 1, 17 <= k <= 32, run length dividing the
+    window count): every compiled run length, k at both ends of the table width, short and long slabs (dword tail on
+    and off), an unaligned buffer, and a batch with an N (dense pass gives way to the N-aware one)"""
+    rng = np.random.default_rng(99)
+    for C in (10, 11, 12, 13, 14, 15, 16, 19, 20, 22, 23, 25):
+        for k in (17, 21, 25, 31, 32):
+            for rpr in (1, 3, 7):
+                if k == 31 and C == 15:
+                    continue                       # (the k = 31 instantiation)
+                L = rpr * C + k - 1
+                n = int(rng.integers(65, 400))
+                data = oracle.synth_reads(int(rng.integers(0, 100)), n, L, int(rng.integers(0, 1 << 30)))
+                offs = np.arange(n + 1, dtype=np.uint64) * L
+                want = oracle.kmer_batch(data, offs, k, 1, want_pos=False)
+                ctx.set_profiling(True)
+                got = ctx.kmer_hash(data, k, 1, fixed_len=L, n_reads=n)
+                name = ctx.last_kernel_ms()[1]
+                ctx.set_profiling(False)
+                # (the plan takes the largest divisor <= 16 of the window count: rpr * C may have a larger one than C)
+                assert name in ("kmer_runs_kernel", "kmer_runs_gen_kernel"), name
+                if rpr == 1:
+                    assert name == "kmer_runs_kernel", (name, C, k)
+                assert got["total"] == want["total"] and (got["hashes"] == want["hashes"]).all(), (C, k, rpr, name)
+    n, L, k = 3000, 151, 31                        # 121 windows = 11 x 11
+    data = oracle.synth_reads(1, n, L, 5).copy()
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    d_in = ctx.malloc(n * L + 16)
+    d_out = ctx.malloc(n * 121 * 8)
+    try:
+        for shift in (0, 5):
+            ctx.h2d(d_in + shift, data)
+            ctx.set_profiling(True)
+            tot = ctx.kmer_hash_ptr(d_in + shift, 0, n, L, 0, k, 1, d_out, n * 121)
+            assert ctx.last_kernel_ms()[1] == "kmer_runs_kernel"
+            ctx.set_profiling(False)
+            got = np.zeros(n * 121, np.uint64)
+            ctx.d2h(got, d_out)
+            assert tot == n * 121 and (got.reshape(-1, 1) == oracle.kmer_batch(data, offs, k, 1, want_pos=False)["hashes"]).all()
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+    data[7 * L + 40] = ord("N")
+    want = oracle.kmer_batch(data, offs, k, 1, want_pos=False)
+    got = ctx.kmer_hash(data, k, 1, fixed_len=L, n_reads=n)
+    assert got["total"] == want["total"] == n * 121 - 31 and (got["hashes"] == want["hashes"]).all()
+
+
 def test_kmer_general_run_split_unaligned_and_overlapping(ctx, oracle):
     """base pointer off the 16-byte grid; stride < len (a long sequence cut into
     overlapping runs) -- both with a ragged run split"""
