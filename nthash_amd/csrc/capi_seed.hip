@@ -2,6 +2,7 @@
 // Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
 #include "capi_internal.hpp"
 #include "seed_kernels.hpp"
+#include "kmer_reads_kernel.hpp" // the mark pass (reads with a non-base) is shared with the k-mer path
 #include "seed_parse.hpp"
 #include "util_kernels.hpp"
 
@@ -133,6 +134,206 @@ int launch_seed_wave(nthip_ctx* c, const SeedWavePlan& plan, uint64_t n_items, b
 
 } // namespace
 
+namespace {
+
+// Variable-length short reads in order (offsets, or the sequence lines of a FASTQ chunk): the reads without a non-base
+// on seed_rtile_kernel (tiles of whole reads), the others -- SeedNtHash's position state machine -- on seed_wave_kernel
+// from a list, into the holes they left.  *handled = false: outside this path, nothing written.
+int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n,
+                   const nthip_seeds* sd, uint32_t m2, uint64_t capacity, uint64_t* total, bool* handled,
+                   SeedGeneralArgs& h, const SeedWavePlan& wplan)
+{
+  *handled = false;
+  const uint32_t k = sd->k;
+  if (c->tune.no_seed_reads || n == 0 || st.fwd || st.rev || k > 64 || m2 > (uint32_t)SF_MAX_RUNTIME_M) return NTHIP_OK;
+  unsigned long long* d_res = (unsigned long long*)(c->d_small + 96);
+  unsigned long long* d_ndirty = (unsigned long long*)(c->d_small + 128);
+  HIPCHK(hipMemsetAsync(c->d_small + 96, 0, 48, c->stream));
+  {
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
+    hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n, d_res);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipMemcpyAsync(c->h_small + 96, d_res, 24, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t res[3];
+  memcpy(res, c->h_small + 96, 24);
+  const uint64_t max_len = res[0], max_pitch = res[1] > res[0] ? res[1] : res[0];
+  if (res[2] || max_len > RD_MAX_LEN || max_len < k) return NTHIP_OK;
+  // ---- geometry ----
+  const bool rot = !c->tune.no_seed_rot && sd->n_seeds <= 2 && k <= 32 && m2 <= 4;
+  const uint32_t nh = rot ? 4u : (k + 7) / 8;
+  const uint32_t per = sd->n_seeds * m2;
+  uint32_t R = 16;
+  const uint64_t slab_cap = 8192;
+  while (R > 1 && (uint64_t)(R - 1) * max_pitch + max_len + 16 > slab_cap) --R;
+  if ((uint64_t)(R - 1) * max_pitch + max_len + 16 > slab_cap) return NTHIP_OK;
+  const uint32_t max_vec = (uint32_t)(((uint64_t)(R - 1) * max_pitch + max_len + 15 + 15) / 16 + 1);
+  const uint32_t bits_dwords = (max_vec + (nh + 1) / 2 + 8 + 3u) & ~3u;
+  const uint32_t otile_recs = 64 + 16;
+  const uint32_t max_win = R * (uint32_t)(max_len - k + 1);
+  const uint32_t wmap_dwords = ((max_win / 16 + 8 + 3) / 4 + 3u) & ~3u;
+  const size_t table_bytes = rot ? 65536 : (size_t)sd->n_seeds * 2 * nh * 256 * sizeof(uint4);
+  const size_t per_wave = ((size_t)(otile_recs * per + 2) * 2 + bits_dwords + 256 + wmap_dwords) * 4;
+  const size_t cap = lds_cap_of(c);
+  uint32_t waves = 0;
+  for (uint32_t w = 16; w >= 4; w -= 4)
+    if (table_bytes + per_wave * w <= cap) { waves = w; break; }
+  if (!waves) return NTHIP_OK;
+  *handled = true;
+
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  const uint64_t n_tiles = (n + R - 1) / R;
+  NTCHK(ensure_scratch(c, 3 * n + n_tiles + nb + n / 8 + 64));
+  uint64_t* d_cnt = st.counts ? st.counts : c->d_scratch;
+  uint64_t* d_off = c->d_scratch + n;
+  uint64_t* d_list = c->d_scratch + 2 * n;
+  uint64_t* d_tsum = c->d_scratch + 3 * n; // (the mark pass writes per-tile sums; this path scans per-read counts)
+  uint64_t* d_sums = d_tsum + n_tiles;
+  uint8_t* d_flags = (uint8_t*)(d_sums + nb + 8);
+  uint64_t* d_total = (uint64_t*)(c->d_small + 8);
+  // ---- mark: reads with a non-base -> list; windows of the others ----
+  {
+    KmerReadsArgs ma;
+    memset(&ma, 0, sizeof ma);
+    ma.seqs = st.seqs;
+    ma.starts = d_starts;
+    ma.ends = d_ends;
+    ma.n_reads = n;
+    ma.R = R;
+    ma.n_tiles = n_tiles;
+    ma.cnt = d_cnt;
+    ma.flags = d_flags;
+    ma.dirty_list = d_list;
+    ma.dirty_count = d_ndirty;
+    ma.tile_sum = d_tsum;
+    ma.k = k;
+    ma.m = 1;
+    ma.C = 8;
+    ma.bits_dwords = ((max_vec + 4) / 2 + 3u) & ~3u;
+    ma.waves = 16;
+    const size_t mlds = ((size_t)ma.bits_dwords + 256) * 4 * ma.waves + 64;
+    auto kernel = kmer_reads_kernel<RD_MODE_MARK, 1, false>;
+    int per_cu = 1;
+    NTCHK(blocks_per_cu(c, kernel, (int)ma.waves * 64, mlds, &per_cu));
+    uint64_t grid = (uint64_t)c->n_cu * per_cu;
+    const uint64_t need = (n_tiles + ma.waves - 1) / ma.waves;
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(ma.waves * 64), mlds, c->stream, ma);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipMemcpyAsync(c->h_small + 128, d_ndirty, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t n_dirty = 0;
+  memcpy(&n_dirty, c->h_small + 128, 8);
+  // ---- the listed reads: exact counts (the reference's state machine) ----
+  h.read_list = d_list;
+  h.n_reads = n_dirty;
+  h.counts = d_cnt;
+  NTCHK(ensure_args(c, sizeof(SeedGeneralArgs)));
+  const unsigned lblocks = (unsigned)((n_dirty + 255) / 256);
+  const bool list_wave = wplan.waves_count != 0;
+  if (n_dirty) {
+    h.wave_waves = wplan.waves_count;
+    HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    if (list_wave) {
+      NTCHK(launch_seed_wave<true>(c, wplan, n_dirty));
+    } else {
+      hipLaunchKernelGGL(seed_general_kernel<true>, dim3(lblocks), dim3(256), 0, c->stream, (const SeedGeneralArgs*)c->d_args);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  NTCHK(device_exclusive_scan(c, d_cnt, d_off, n, d_sums, d_total));
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(total, c->h_small + 8, 8);
+  if (*total > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed", (unsigned long long)capacity,
+                (unsigned long long)*total);
+  // ---- the clean reads ----
+  SeedRtileArgs ra;
+  memset(&ra, 0, sizeof ra);
+  ra.seqs = st.seqs;
+  ra.starts = d_starts;
+  ra.ends = d_ends;
+  ra.flags = d_flags;
+  ra.read_off = d_off;
+  ra.hashes = st.hashes;
+  ra.pos = st.pos;
+  ra.tables = sd->d_tables;
+  ra.n_reads = n;
+  ra.n_tiles = n_tiles;
+  ra.R = R;
+  ra.k = k;
+  ra.m2 = m2;
+  ra.n_seeds = sd->n_seeds;
+  ra.ntab = sd->ntab;
+  ra.bits_dwords = bits_dwords;
+  ra.otile_recs = otile_recs;
+  ra.wmap_dwords = wmap_dwords;
+  ra.waves = waves;
+  for (uint32_t i = 0; i < (uint32_t)SF_MAX_RUNTIME_M; ++i) ra.mult[i] = multiplier(k, i);
+  const size_t lds = table_bytes + per_wave * waves;
+  auto go = [&](auto kernel) -> int {
+    int per_cu = 1;
+    NTCHK(blocks_per_cu(c, kernel, (int)waves * 64, lds, &per_cu));
+    const uint64_t need = (n_tiles + waves - 1) / waves;
+    uint64_t grid = (uint64_t)c->n_cu * per_cu;
+    if (grid > need) grid = need;
+    prof_begin(c, "seed_rtile_kernel");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream, ra);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    return NTHIP_OK;
+  };
+  int rc;
+  if (rot) {
+    switch (sd->n_seeds * 8 + m2) {
+      case 8 + 1: rc = go(seed_rtile_kernel<4, 1, 1>); break;
+      case 8 + 2: rc = go(seed_rtile_kernel<4, 1, 2>); break;
+      case 8 + 3: rc = go(seed_rtile_kernel<4, 1, 3>); break;
+      case 8 + 4: rc = go(seed_rtile_kernel<4, 1, 4>); break;
+      case 16 + 1: rc = go(seed_rtile_kernel<4, 2, 1>); break;
+      case 16 + 2: rc = go(seed_rtile_kernel<4, 2, 2>); break;
+      case 16 + 3: rc = go(seed_rtile_kernel<4, 2, 3>); break;
+      default: rc = go(seed_rtile_kernel<4, 2, 4>); break;
+    }
+  } else {
+    switch (nh) {
+      case 1: rc = go(seed_rtile_kernel<1>); break;
+      case 2: rc = go(seed_rtile_kernel<2>); break;
+      case 3: rc = go(seed_rtile_kernel<3>); break;
+      case 4: rc = go(seed_rtile_kernel<4>); break;
+      case 5: rc = go(seed_rtile_kernel<5>); break;
+      case 6: rc = go(seed_rtile_kernel<6>); break;
+      case 7: rc = go(seed_rtile_kernel<7>); break;
+      default: rc = go(seed_rtile_kernel<8>); break;
+    }
+  }
+  NTCHK(rc);
+  // ---- the listed reads, into their holes ----
+  if (n_dirty) {
+    h.counts = nullptr;
+    h.read_off = d_off;
+    h.hashes = st.hashes;
+    h.pos = st.pos;
+    h.capacity = capacity;
+    h.wave_waves = wplan.waves_hash;
+    HIPCHK(hipMemcpyAsync(c->d_args, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    if (list_wave) {
+      NTCHK(launch_seed_wave<false>(c, wplan, n_dirty, /*record*/ false));
+    } else {
+      hipLaunchKernelGGL(seed_general_kernel<false>, dim3(lblocks), dim3(256), 0, c->stream, (const SeedGeneralArgs*)c->d_args);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+} // namespace
+
 int ntamd::host::run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd,
                      uint32_t m2, uint64_t capacity, uint64_t* total, const uint64_t* d_ends)
 {
@@ -168,6 +369,15 @@ int ntamd::host::run_seed_general(nthip_ctx* c, const Staged& st, const nthip_re
   SeedWavePlan wplan;
   bool use_wave = !c->tune.no_seed_wave && seed_wave_plan(c, sd, m2, &wplan);
   h.wave_lmax = SEED_WAVE_LMAX;
+  if (st.offsets && !c->tune.no_seed_wave) { // variable-length reads: the short-read path first (NTHIP_TUNE_NO_SEED_WAVE=1
+                                             // keeps the lane-per-read kernel alone: the reference of the stress tools)
+    bool handled = false;
+    SeedGeneralArgs hl = h;
+    SeedWavePlan lp = wplan;
+    if (!use_wave) lp.waves_count = 0;
+    NTCHK(run_seed_reads(c, st, st.offsets, d_ends ? d_ends : st.offsets + 1, n, sd, m2, capacity, total, &handled, hl, lp));
+    if (handled) return NTHIP_OK;
+  }
   h.counts = d_counts;
   if (use_wave) {
     h.wave_waves = wplan.waves_count;

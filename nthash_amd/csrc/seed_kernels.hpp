@@ -607,6 +607,229 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
   if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
 }
 
+// --------------------------------------------------------------------------------------------------------------
+// seed_rtile_kernel -- spaced seeds on VARIABLE-LENGTH short reads without a non-base (round 2): the counterpart of
+// kmer_reads_kernel.hpp.  A wave's tile is R consecutive whole reads (one contiguous slab), its windows are numbered
+// densely over the tile's clean reads; a lane is a window, 64 consecutive windows per group, hashed by the masked
+// direct formula exactly as in seed_wtile_kernel (rotated-slot tables when RNS > 0), the records collected in a
+// wave-private LDS tile and written as aligned 16-byte pieces.  Reads flagged by the mark pass (a non-base: the
+// reference's position state machine applies) keep their place in the stream as a hole and are hashed afterwards by
+// seed_wave_kernel from the list.
+// --------------------------------------------------------------------------------------------------------------
+struct SeedRtileArgs {
+  const uint8_t* seqs;
+  const uint64_t* starts;   // read r = bytes [starts[r], ends[r])
+  const uint64_t* ends;
+  const uint8_t* flags;     // 1 = listed (not hashed here)
+  const uint64_t* read_off; // first k-mer of read r in the stream
+  uint64_t* hashes;
+  uint32_t* pos;            // optional
+  const uint4* tables;      // global: [seed][ntab][256]
+  uint64_t n_reads, n_tiles;
+  uint32_t R, k, m2, n_seeds, ntab;
+  uint32_t bits_dwords, otile_recs, wmap_dwords, waves;
+  uint64_t mult[SF_MAX_RUNTIME_M];
+};
+
+template <int NH, int RNS = 0, int RM2 = 0>
+__global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileArgs a)
+{
+  constexpr bool ROT = RNS > 0;
+  static_assert(!ROT || (NH == 4 && RNS <= 2 && RM2 >= 1 && RM2 <= 4), "rotated-slot layout: k <= 32, <= 2 seeds");
+  constexpr int NW = (NH + 1) / 2;
+  constexpr uint32_t NT = 2u * NH;
+  extern __shared__ __attribute__((aligned(256))) uint32_t lds_dyn[];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint4* tabs = (uint4*)lds_dyn;
+  const uint32_t n_entries = ROT ? 4096u : a.n_seeds * NT * 256u;
+  const uint32_t per = ROT ? (uint32_t)(RNS * RM2) : a.n_seeds * a.m2;
+  const uint32_t otile_u64 = a.otile_recs * per + 2u;
+  // per wave: record tile | bit stream | read table (first window, last window + 1, first base, first record) | window map
+  const uint32_t per_wave = otile_u64 * 2u + a.bits_dwords + 256u + a.wmap_dwords;
+  uint32_t* wbase = lds_dyn + n_entries * 4u + wave * per_wave;
+  uint64_t* otile = (uint64_t*)wbase;
+  uint32_t* bits = wbase + otile_u64 * 2u;
+  uint32_t* rt_wbeg = bits + a.bits_dwords;
+  uint32_t* rt_wend = rt_wbeg + 64;
+  uint32_t* rt_sb = rt_wend + 64;
+  uint32_t* rt_out = rt_sb + 64;
+  uint8_t* wmap = (uint8_t*)(rt_out + 64); // windows [16c, 16c + 16) of the tile: the read that holds window 16c
+  if constexpr (ROT) {
+    for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
+      const uint32_t e = i >> 4, v = i & 15u, jt = v & 7u, sd = (v >> 3) < (uint32_t)RNS ? (v >> 3) : (uint32_t)RNS - 1u;
+      tabs[i] = jt < a.ntab ? a.tables[((size_t)sd * a.ntab + jt) * 256u + e] : make_uint4(0, 0, 0, 0);
+    }
+  } else {
+    for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
+      const uint32_t tb = i >> 8, sd = tb / NT, jt = tb - sd * NT;
+      tabs[i] = jt < a.ntab ? a.tables[((size_t)sd * a.ntab + jt) * 256u + (i & 255u)] : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  typedef __attribute__((address_space(3))) const nt_v4u lds_v4u;
+  uint32_t rsel[8], roff[8];
+  uint32_t rdelta = 0, rb3 = 0;
+  if constexpr (ROT) {
+    rb3 = (lane >> 3) & 1u;
+    const uint32_t tb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds_dyn;
+#pragma unroll
+    for (uint32_t st = 0; st < 8; ++st) {
+      const uint32_t cpos = (lane + st) & 7u;
+      rsel[st] = 0x0c0c000cu | (cpos << 8);
+      roff[st] = tb + (((rb3 << 3) + cpos) << 4);
+      asm volatile("" : "+v"(rsel[st]), "+v"(roff[st]));
+    }
+    rdelta = rb3 ? (uint32_t)-128 : 128u;
+  }
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+  auto wave_incl_scan32 = [&](uint32_t v) { // DPP prefix sum (see kmer_reads_kernel.hpp)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+  };
+  auto bcast64 = [&](uint64_t v, uint32_t src) -> uint64_t {
+    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src, 64) << 32) |
+           (uint32_t)__shfl((int)(uint32_t)v, (int)src, 64);
+  };
+  const uint32_t k = a.k;
+  const uint64_t per_block = (a.n_tiles + gridDim.x - 1) / gridDim.x;
+  const uint64_t t_begin = (uint64_t)blockIdx.x * per_block;
+  const uint64_t t_end = t_begin + per_block < a.n_tiles ? t_begin + per_block : a.n_tiles;
+
+  for (uint64_t t = t_begin + wave; t < t_end; t += a.waves) {
+    const uint64_t r0 = t * a.R;
+    const uint32_t nr = a.n_reads - r0 < a.R ? (uint32_t)(a.n_reads - r0) : a.R;
+    const bool has = lane < nr;
+    const uint64_t rj = r0 + (has ? lane : 0u);
+    const uint64_t s_j = a.starts[rj], e_j = a.ends[rj];
+    const uint64_t len_j = has && e_j > s_j ? e_j - s_j : 0;
+    const bool listed = a.flags[rj] != 0;
+    const uint64_t ro_j = a.read_off[rj];
+    const uint64_t slab0 = bcast64(s_j, 0), slab_end = bcast64(e_j, nr - 1u), ro_0 = bcast64(ro_j, 0);
+    const uint32_t shift = (uint32_t)(((uintptr_t)a.seqs + slab0) & 15u);
+    const uint8_t* vbase = a.seqs + slab0 - shift;
+    const uint32_t n_vec = slab_end > slab0 ? (uint32_t)((shift + (slab_end - slab0) + 15u) >> 4) : 0u;
+    for (uint32_t i = lane; i < n_vec; i += 64u) {
+      const uint4 x = *(const uint4*)(vbase + ((uint64_t)i << 4));
+      uint32_t bad = 0;
+      bits[i] = pack16(x, bad);
+    }
+    if (lane < (uint32_t)NW + 3u) bits[n_vec + lane] = 0;
+    const uint32_t nwin_j = (!listed && len_j >= k) ? (uint32_t)(len_j - k + 1u) : 0u;
+    const uint32_t wend = wave_incl_scan32(nwin_j), wbeg = wend - nwin_j;
+    rt_wbeg[lane] = wbeg;
+    rt_wend[lane] = has ? wend : 0xFFFFFFFFu; // (the walk below stops at the latest on the entry after the tile's reads)
+    rt_sb[lane] = shift + (uint32_t)(s_j - slab0);
+    rt_out[lane] = (uint32_t)(ro_j - ro_0);
+    const uint32_t W = (uint32_t)__shfl((int)wend, 63, 64);
+    for (uint32_t c = (wbeg + 15u) >> 4; (c << 4) < wend; ++c) wmap[c] = (uint8_t)lane; // (nothing for a read without windows)
+    lds_sync();
+
+    for (uint32_t q0 = 0; q0 < W;) {
+      const uint32_t q = q0 + lane;
+      const bool live = q < W;
+      const uint32_t qq = live ? q : q0;
+      uint32_t j = wmap[qq >> 4];
+      while (qq >= rt_wend[j]) ++j; // reads that start inside this chunk of 16 windows
+      const uint32_t p = qq - rt_wbeg[j];
+      const uint32_t b = rt_sb[j] + p;
+      const uint32_t oslot = rt_out[j] + p;
+      const uint32_t gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)oslot);
+      const uint32_t slot = oslot - gbase;
+      // (a listed read between two clean ones leaves a hole; windows past the tile's capacity wait for the next group)
+      const bool fits = live && slot < a.otile_recs;
+      const uint32_t nl = (uint32_t)__builtin_popcountll(__ballot(fits));
+      const bool act = lane < nl;
+      const uint32_t span = (uint32_t)__shfl((int)slot, (int)(nl - 1u), 64) + 1u;
+      uint64_t* const dst = a.hashes + (ro_0 + gbase) * per;
+      const uint32_t par = (uint32_t)(((uintptr_t)dst >> 3) & 1u);
+      if (act) {
+        const uint32_t d = b >> 4, sh = (b & 15u) << 1;
+        uint32_t w[NW];
+        uint32_t lo = bits[d];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+          const uint32_t hi = bits[d + i + 1];
+          w[i] = funnel(hi, lo, sh);
+          lo = hi;
+        }
+        uint64_t* mine = otile + par + slot * per;
+        if constexpr (ROT) {
+          uint32_t ad[8];
+#pragma unroll
+          for (uint32_t st = 0; st < 8; ++st) ad[st] = __builtin_amdgcn_perm(w[1], w[0], rsel[st]) + roff[st];
+#pragma unroll
+          for (int half = 0; half < RNS; ++half) {
+            nt_v4u e[8];
+#pragma unroll
+            for (uint32_t st = 0; st < 8; ++st) e[st] = *(lds_v4u*)(uintptr_t)(half == 0 ? ad[st] : ad[st] + rdelta);
+            uint32_t f0 = e[0].x ^ e[1].x, f1 = e[0].y ^ e[1].y, r0 = e[0].z ^ e[1].z, r1 = e[0].w ^ e[1].w;
+#pragma unroll
+            for (uint32_t st = 2; st < 8; st += 2) {
+              f0 = __builtin_amdgcn_bitop3_b32(f0, e[st].x, e[st + 1].x, 0x96);
+              f1 = __builtin_amdgcn_bitop3_b32(f1, e[st].y, e[st + 1].y, 0x96);
+              r0 = __builtin_amdgcn_bitop3_b32(r0, e[st].z, e[st + 1].z, 0x96);
+              r1 = __builtin_amdgcn_bitop3_b32(r1, e[st].w, e[st + 1].w, 0x96);
+            }
+            const uint64_t h0 = canon_pair(f0, f1, r0, r1);
+            uint64_t* const rec = mine + (RNS == 2 ? ((uint32_t)half ^ rb3) * (uint32_t)RM2 : 0u);
+            rec[0] = h0;
+#pragma unroll
+            for (uint32_t jj = 1; jj < (uint32_t)RM2; ++jj) rec[jj] = mix_hash(h0, a.mult[jj]);
+          }
+        } else {
+          for (uint32_t s = 0; s < a.n_seeds; ++s) {
+            const uint4* ts = tabs + s * NT * 256u;
+            uint4 e[NT];
+#pragma unroll
+            for (uint32_t jt = 0; jt < NT; ++jt) e[jt] = ts[jt * 256u + ((w[jt >> 2] >> ((jt & 3u) * 8u)) & 0xFFu)];
+            uint32_t f0 = e[0].x ^ e[1].x, f1 = e[0].y ^ e[1].y, r0 = e[0].z ^ e[1].z, r1 = e[0].w ^ e[1].w;
+#pragma unroll
+            for (uint32_t jt = 2; jt < NT; jt += 2) {
+              f0 = __builtin_amdgcn_bitop3_b32(f0, e[jt].x, e[jt + 1].x, 0x96);
+              f1 = __builtin_amdgcn_bitop3_b32(f1, e[jt].y, e[jt + 1].y, 0x96);
+              r0 = __builtin_amdgcn_bitop3_b32(r0, e[jt].z, e[jt + 1].z, 0x96);
+              r1 = __builtin_amdgcn_bitop3_b32(r1, e[jt].w, e[jt + 1].w, 0x96);
+            }
+            const uint64_t h0 = canon_pair(f0, f1, r0, r1);
+            mine[s * a.m2] = h0;
+#pragma unroll
+            for (uint32_t jj = 1; jj < (uint32_t)SF_MAX_RUNTIME_M; ++jj)
+              if (jj < a.m2) mine[s * a.m2 + jj] = mix_hash(h0, a.mult[jj]);
+          }
+        }
+        if (a.pos) a.pos[ro_0 + gbase + slot] = p; // SeedNtHash::get_pos() of a clean read's window
+      }
+      lds_sync();
+      // ---- the group's records (holes included) as aligned 16-byte pieces ----
+      const uint32_t n_vals = span * per;
+      uint64_t* const base = dst - par;
+      const uint32_t sp = par + n_vals;
+      const uint32_t pf = par, pl = sp >> 1; // whole pieces [pf, pl) (par is 0 or 1: piece 0 is whole iff par == 0)
+      for (uint32_t pi = lane; pi < pl; pi += 64u) {
+        if (pi >= pf) {
+          const nt_v4u sv = *(const nt_v4u*)(otile + 2u * pi);
+          asm volatile("global_store_dwordx4 %0, %1, off" SW_STORE_POLICY "\n\ts_nop 1" ::"v"(base + 2u * pi), "v"(sv) : "memory");
+        }
+      }
+      if (lane == 0u && par != 0u) base[1] = otile[1];                              // head
+      if (lane == 1u && (sp & 1u) != 0u && sp > 2u * par) base[sp - 1u] = otile[sp - 1u]; // tail
+      lds_sync();
+      q0 += nl;
+    }
+    lds_sync(); // bit stream, read table and window map are free again
+  }
+}
+
 // --------------------------------------------------------------------------
 // General path: the reference's position state machine, one lane per read.
 // --------------------------------------------------------------------------

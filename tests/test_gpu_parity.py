@@ -679,6 +679,81 @@ def test_seed_dirty_and_ragged_vs_oracle(ctx, oracle):
     assert (got["pos"] == want["pos"]).all() and (got["hashes"] == want["hashes"]).all()
 
 
+def test_seed_whole_read_tiles_vs_oracle(ctx, oracle):
+    """SeedNtHash on variable-length short reads: clean reads on seed_rtile_kernel (tiles of whole reads, rotated-slot
+    or plain tables), reads with a non-base on the wave-per-read kernel into the holes they leave -- read counts around
+    the tile size, tiny reads, neighbourhoods of dirty reads, one to three seeds, k up to 64, positions, and the spans
+    entry; against the oracle's reference state machine"""
+    import nthash_amd
+    rng = np.random.default_rng(555)
+    alph = np.frombuffer(b"ACGTacgtUuNnRYKM-*\x00", dtype=np.uint8)
+
+    def mask(k, density):
+        m_ = (rng.random(k) < density).astype(int)
+        m_[0] = m_[-1] = 1
+        return "".join(str(int(x)) for x in m_)
+
+    def make_reads(n, lo, hi, p_dirty, cluster=False):
+        reads = []
+        for i in range(n):
+            L = int(rng.integers(lo, hi + 1))
+            dirty = (rng.random() < p_dirty) or (cluster and 20 <= i < 45)
+            idx = np.where(rng.random(L) < 0.96, rng.integers(0, 10, L), rng.integers(10, len(alph), L)) if dirty \
+                else rng.integers(0, 10, L)
+            reads.append(alph[idx].tobytes())
+        return reads
+
+    cases = [(n, 60, 151, 0.03, False, [SEED_A, SEED_B], 3) for n in (1, 15, 16, 17, 33, 500)]
+    cases += [(400, 0, 50, 0.1, False, [SEED_A], 2), (400, 100, 150, 0.0, True, [SEED_A, SEED_B], 3),
+              (300, 100, 250, 0.3, False, [SEED_B], 4), (300, 20, 300, 0.05, False, [mask(5, 0.7)], 1),
+              (300, 20, 300, 0.05, False, [mask(17, 0.6), mask(17, 0.8), mask(17, 0.5)], 2),
+              (300, 40, 300, 0.05, False, [mask(32, 0.6), mask(32, 0.9)], 5),
+              (200, 70, 400, 0.05, False, [mask(47, 0.6)], 2), (200, 70, 400, 0.05, False, [mask(64, 0.7), mask(64, 0.4)], 1),
+              (100, 1000, 2048, 0.02, False, [SEED_A, SEED_B], 3)]
+    for (n, lo, hi, p_dirty, cluster, seeds, m2) in cases:
+        k = len(seeds[0])
+        reads = make_reads(n, lo, hi, p_dirty, cluster)
+        d, offs = concat_reads(reads)
+        want = oracle.seed_batch(d, offs, seeds, k, m2)
+        ctx.set_profiling(True)
+        got = ctx.seed_hash(d, seeds, k, m2, offsets=offs, want_pos=True)
+        name = ctx.last_kernel_ms()[1]
+        ctx.set_profiling(False)
+        if max(len(r) for r in reads) >= k:
+            assert name == "seed_rtile_kernel", (name, n, k)
+        assert got["total"] == want["total"], (n, lo, hi, seeds, m2)
+        for key in ("counts", "pos", "hashes"):
+            assert (got[key] == want[key]).all(), (n, lo, hi, seeds, m2, key)
+        got = ctx.seed_hash(d, seeds, k, m2, offsets=offs)
+        assert (got["hashes"] == want["hashes"]).all() and (got["counts"] == want["counts"]).all()
+    # spans with other bytes between the reads
+    reads = make_reads(333, 50, 151, 0.03)
+    buf = bytearray(b"@")
+    starts, ends = [], []
+    for r in reads:
+        buf += b"hdr\n"; starts.append(len(buf)); buf += r; ends.append(len(buf))
+        buf += b"\n+\n" + bytes(rng.integers(33, 127, len(r)).astype(np.uint8)) + b"\n@"
+    raw = np.frombuffer(bytes(buf), dtype=np.uint8)
+    d, offs = concat_reads(reads)
+    want = oracle.seed_batch(d, offs, [SEED_A, SEED_B], 31, 3)
+    cap = max(1, want["total"])
+    sd = nthash_amd.Seeds(ctx, [SEED_A, SEED_B], 31)
+    d_buf = ctx.malloc(raw.size + 16); d_s = ctx.malloc(8 * len(reads)); d_e = ctx.malloc(8 * len(reads))
+    d_h = ctx.malloc(cap * 6 * 8); d_c = ctx.malloc(8 * len(reads)); d_p = ctx.malloc(4 * cap)
+    try:
+        ctx.h2d(d_buf, raw); ctx.h2d(d_s, np.array(starts, np.uint64)); ctx.h2d(d_e, np.array(ends, np.uint64))
+        tot = ctx.seed_hash_spans_ptr(d_buf, raw.size, d_s, d_e, len(reads), sd, 3, d_h, cap, counts=d_c, pos=d_p)
+        assert tot == want["total"]
+        h = np.zeros(cap * 6, np.uint64); cts = np.zeros(len(reads), np.uint64); ps = np.zeros(cap, np.uint32)
+        ctx.d2h(h, d_h); ctx.d2h(cts, d_c); ctx.d2h(ps, d_p)
+        assert (h[: tot * 6].reshape(-1, 6) == want["hashes"]).all() and (cts == want["counts"]).all()
+        assert (ps[:tot] == want["pos"]).all()
+    finally:
+        for ptr in (d_buf, d_s, d_e, d_h, d_c, d_p):
+            ctx.free(ptr)
+        sd.close()
+
+
 def test_seed_asymmetric_flag(ctx):
     import nthash_amd
     assert nthash_amd.Seeds(ctx, ["1101"], 4).asymmetric       # src/seed.cpp:96-102 warns
