@@ -165,7 +165,7 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
   const bool rot = !c->tune.no_seed_rot && sd->n_seeds <= 2 && k <= 32 && m2 <= 4;
   const uint32_t nh = rot ? 4u : (k + 7) / 8;
   const uint32_t per = sd->n_seeds * m2;
-  uint32_t R = 16;
+  uint32_t R = c->tune.seed_rpt ? (c->tune.seed_rpt < 64u ? c->tune.seed_rpt : 64u) : 16;
   const uint64_t slab_cap = 8192;
   while (R > 1 && (uint64_t)(R - 1) * max_pitch + max_len + 16 > slab_cap) --R;
   if ((uint64_t)(R - 1) * max_pitch + max_len + 16 > slab_cap) return NTHIP_OK;
@@ -175,7 +175,8 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
   const uint32_t max_win = R * (uint32_t)(max_len - k + 1);
   const uint32_t wmap_dwords = ((max_win / 16 + 8 + 3) / 4 + 3u) & ~3u;
   const size_t table_bytes = rot ? 65536 : (size_t)sd->n_seeds * 2 * nh * 256 * sizeof(uint4);
-  const size_t per_wave = ((size_t)(otile_recs * per + 2) * 2 + bits_dwords + 256 + wmap_dwords) * 4;
+  const uint32_t rt_n = R <= 16 ? 16 : R <= 32 ? 32 : 64;
+  const size_t per_wave = ((size_t)(otile_recs * per + 2) * 2 + bits_dwords + 4 * rt_n + wmap_dwords) * 4;
   const size_t cap = lds_cap_of(c);
   uint32_t waves = 0;
   for (uint32_t w = 16; w >= 4; w -= 4)

@@ -646,15 +646,16 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
   const uint32_t per = ROT ? (uint32_t)(RNS * RM2) : a.n_seeds * a.m2;
   const uint32_t otile_u64 = a.otile_recs * per + 2u;
   // per wave: record tile | bit stream | read table (first window, last window + 1, first base, first record) | window map
-  const uint32_t per_wave = otile_u64 * 2u + a.bits_dwords + 256u + a.wmap_dwords;
+  const uint32_t RT = a.R <= 16u ? 16u : a.R <= 32u ? 32u : 64u; // entries of the read table
+  const uint32_t per_wave = otile_u64 * 2u + a.bits_dwords + 4u * RT + a.wmap_dwords;
   uint32_t* wbase = lds_dyn + n_entries * 4u + wave * per_wave;
   uint64_t* otile = (uint64_t*)wbase;
   uint32_t* bits = wbase + otile_u64 * 2u;
   uint32_t* rt_wbeg = bits + a.bits_dwords;
-  uint32_t* rt_wend = rt_wbeg + 64;
-  uint32_t* rt_sb = rt_wend + 64;
-  uint32_t* rt_out = rt_sb + 64;
-  uint8_t* wmap = (uint8_t*)(rt_out + 64); // windows [16c, 16c + 16) of the tile: the read that holds window 16c
+  uint32_t* rt_wend = rt_wbeg + RT;
+  uint32_t* rt_sb = rt_wend + RT;
+  uint32_t* rt_out = rt_sb + RT;
+  uint8_t* wmap = (uint8_t*)(rt_out + RT); // windows [16c, 16c + 16) of the tile: the read that holds window 16c
   if constexpr (ROT) {
     for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
       const uint32_t e = i >> 4, v = i & 15u, jt = v & 7u, sd = (v >> 3) < (uint32_t)RNS ? (v >> 3) : (uint32_t)RNS - 1u;
@@ -726,10 +727,12 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
     if (lane < (uint32_t)NW + 3u) bits[n_vec + lane] = 0;
     const uint32_t nwin_j = (!listed && len_j >= k) ? (uint32_t)(len_j - k + 1u) : 0u;
     const uint32_t wend = wave_incl_scan32(nwin_j), wbeg = wend - nwin_j;
-    rt_wbeg[lane] = wbeg;
-    rt_wend[lane] = has ? wend : 0xFFFFFFFFu; // (the walk below stops at the latest on the entry after the tile's reads)
-    rt_sb[lane] = shift + (uint32_t)(s_j - slab0);
-    rt_out[lane] = (uint32_t)(ro_j - ro_0);
+    if (lane < RT) {
+      rt_wbeg[lane] = wbeg;
+      rt_wend[lane] = has ? wend : 0xFFFFFFFFu; // (the walk below stops at the latest on the entry after the tile's reads)
+      rt_sb[lane] = shift + (uint32_t)(s_j - slab0);
+      rt_out[lane] = (uint32_t)(ro_j - ro_0);
+    }
     const uint32_t W = (uint32_t)__shfl((int)wend, 63, 64);
     for (uint32_t c = (wbeg + 15u) >> 4; (c << 4) < wend; ++c) wmap[c] = (uint8_t)lane; // (nothing for a read without windows)
     lds_sync();

@@ -21,7 +21,7 @@ for i in np.arange(0, total_bytes, 600_011, dtype=np.int64)[:20000]:
     ctx.h2d(d_in + int(i), np.frombuffer(b"N", np.uint8))
 cap = int((lens - k + 1).sum())
 d_out = ctx.malloc(cap * 6 * 8)
-for name, env in (("seed_wave_kernel", None), ("lane-per-read kernel", "1")):
+for name, env in (("rtile + wave kernels", None), ("lane-per-read kernel", "1")):
     if env: os.environ["NTHIP_TUNE_NO_SEED_WAVE"] = env
     ctx.reload_tuning()
     ts = []
