@@ -19,7 +19,7 @@ Rank 0 prints ONE JSON line: BASELINE.json's metric plus
                 spec peak AND against the write / copy rates measured on this box in the same process,
   verify        the on-device checksum of the WHOLE hash stream against the reference's
                 (tests/golden/bench_checksums.json, made by the real reference library),
-  secondary     (N = 1) the other single-GPU configs of BASELINE.json, same clock, 3 steps each,
+  secondary     (N = 1) the other single-GPU configs of BASELINE.json and a variable-length batch, same clock, 3 steps each,
   cpu_baseline  the reference CPU library (oracle/_ref, kind "reference") or the C restatement (kind "port")
                 timed on this host on a bounded sample.
 """
@@ -52,6 +52,10 @@ CONFIGS = {
     # scaled from its 1 M reads to a batch that fills the GPU
     "ref": dict(desc="NtHash k=64, m=3, 100bp reads (examples/benchmark.cpp shape), 100M reads", L=100, k=64,
                 m=3, seeds=None, reads=100_000_000),
+    # what a FASTQ batch looks like: reads of different lengths (spans of one buffer), one in ~1000 with an N --
+    # the whole call (mark pass, scan, hash pass, reads with an N) is on the clock, not only the hash kernel
+    "var": dict(desc="NtHash k=31, 1 hash/k-mer, 20M variable-length reads of 100-150 bp (spans), an N in 1 read of ~1000",
+                L=150, lmin=100, k=31, m=1, seeds=None, reads=20_000_000),
 }
 
 
@@ -192,6 +196,28 @@ def reference_checksum(name, first_read, n_reads):
     return _CHECKSUMS.get((name, first_read, n_reads))
 
 
+def _splitmix64(x):
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def var_reads(first_read, n_reads, len_min, len_max, seed=42):
+    """Shape of the variable-length workload (the rule tests/golden/gen_bench_checksums.py's reference run follows,
+    oracle/ref_shim.cpp ref_synth_var_checksum): read r = the first len_r bytes of synthetic read r of length len_max,
+    len_r = len_min + x % (len_max - len_min + 1), x = splitmix64(seed + 0xABCDEF + r); if (x >> 32) % 997 == 0 its byte
+    (x >> 16) % len_r is an 'N'."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        r = np.arange(first_read, first_read + n_reads, dtype=np.uint64)
+        x = _splitmix64(np.uint64(seed) + np.uint64(0xABCDEF) + r)
+    lens = np.uint64(len_min) + x % np.uint64(len_max - len_min + 1)
+    return lens, (x >> np.uint64(32)) % np.uint64(997) == 0, (x >> np.uint64(16)) % lens
+
+
 class Workload:
     """Device-resident reads + output ring of one config on one rank."""
 
@@ -203,6 +229,10 @@ class Workload:
         self.L, self.k, self.m = L, k, m
         self.nwin = L - k + 1
         self.per = m if cfg["seeds"] is None else len(cfg["seeds"]) * m
+        self.var = None
+        if cfg.get("lmin"):  # variable-length reads: spans [r*L, r*L + len_r) of the fixed-length buffer
+            self._init_var(torch, ctx, dev, n_reads, first_read)
+            return
         # launches per step: outputs larger than the free memory are produced chunk by chunk into one buffer
         free_b, _tot_b = torch.cuda.mem_get_info(dev)
         out_bytes_per_read = self.nwin * self.per * 8
@@ -220,7 +250,32 @@ class Workload:
         torch.cuda.synchronize(dev)
         self.kernel_ms = []
 
+    def _init_var(self, torch, ctx, dev, n_reads, first_read):
+        import numpy as np
+        L, k = self.L, self.k
+        lens, has_n, n_pos = var_reads(first_read, n_reads, self.cfg["lmin"], L)
+        starts = np.arange(n_reads, dtype=np.int64) * L
+        ends = starts + lens.astype(np.int64)
+        self.total_kmers = int(np.maximum(lens.astype(np.int64) - k + 1, 0).sum())
+        self.total_bases = int(lens.sum())
+        self.chunk, self.n_chunks = n_reads, 1
+        self.d_in = torch.empty(n_reads * L, dtype=torch.uint8, device=dev)
+        ctx.synth_reads_ptr(self.d_in.data_ptr(), first_read, n_reads, L, 42)
+        idx = torch.from_numpy((starts + n_pos.astype(np.int64))[has_n]).to(dev)
+        self.d_in[idx] = ord("N")
+        self.d_starts = torch.from_numpy(starts).to(dev)
+        self.d_ends = torch.from_numpy(ends).to(dev)
+        self.d_out = torch.empty(self.total_kmers * self.per, dtype=torch.int64, device=dev)
+        self.var = dict(lens=lens, has_n=has_n, n_pos=n_pos)
+        self.seeds = None
+        torch.cuda.synchronize(dev)
+        self.kernel_ms = []
+
     def launch(self, c):
+        if self.var is not None:
+            return self.ctx.kmer_hash_spans_ptr(self.d_in.data_ptr(), self.n_reads * self.L, self.d_starts.data_ptr(),
+                                                self.d_ends.data_ptr(), self.n_reads, self.k, self.m,
+                                                self.d_out.data_ptr(), self.total_kmers)
         r0 = c * self.chunk
         nr = min(self.chunk, self.n_reads - r0)
         if self.seeds is None:
@@ -263,6 +318,17 @@ class Workload:
         try:
             from oracle.pyoracle import Oracle
             orc = Oracle()
+            if self.var is not None:
+                from oracle.pyoracle import concat_reads
+                nv = min(2000, self.n_reads)
+                full = orc.synth_reads(self.first_read, nv, self.L, 42).reshape(nv, self.L).copy()
+                for r in np.nonzero(self.var["has_n"][:nv])[0]:
+                    full[r, int(self.var["n_pos"][r])] = ord("N")
+                d, offs = concat_reads([full[r, : int(self.var["lens"][r])].tobytes() for r in range(nv)])
+                w = orc.kmer_batch(d, offs, self.k, self.m, want_pos=False)
+                host = self.d_out[: w["total"] * self.per].cpu().numpy().view(np.uint64).reshape(-1, self.per)
+                out["spot_vs_oracle"] = bool((host == w["hashes"]).all())
+                return out
             last_r0 = (self.n_chunks - 1) * self.chunk  # d_out holds the last chunk
             nv = min(2000, self.n_reads - last_r0)
             host = self.d_out[: nv * self.nwin * self.per].cpu().numpy().view(np.uint64).reshape(-1, self.per)
@@ -280,6 +346,8 @@ class Workload:
 
     def roofline(self):
         b_per_kmer = 8.0 * self.per + self.L / self.nwin  # 8*H + b_in*L/(L-k+1), ASCII input
+        if self.var is not None:  # the bases of the reads, once, and the hashes (the hash kernel; the mark pass reads them again)
+            b_per_kmer = 8.0 * self.per + self.total_bases / self.total_kmers
         ms_list = [q[0] for q in self.kernel_ms]
         avg_ms = sum(ms_list) / len(ms_list)
         kmers_per_launch = sum(q[2] for q in self.kernel_ms) / len(self.kernel_ms)
@@ -291,7 +359,7 @@ class Workload:
     def free(self):
         if self.seeds is not None:
             self.seeds.close()
-        self.d_in = self.d_out = None
+        self.d_in = self.d_out = self.d_starts = self.d_ends = None
         self.torch.cuda.empty_cache()
 
 
@@ -451,7 +519,7 @@ def main():
                 res["roofline"]["peak_measured_error"] = str(e)
         if not args.no_secondary and args.config == "c2" and not args.reads:
             sec = {}
-            for name in ("c3", "c4", "ref"):
+            for name in ("c3", "c4", "ref", "var"):
                 try:
                     c2 = dict(CONFIGS[name])
                     w2 = Workload(torch, ctx, dev, name, c2, c2["reads"], 0)
@@ -471,6 +539,9 @@ def main():
                                  "bytes_per_kmer": r2["bytes_per_kmer"], "achieved_GBps": r2["achieved"],
                                  "frac": r2["frac"], "verify_ok": v2["ok"], "spot_vs_oracle": v2["spot_vs_oracle"],
                                  "sum": v2["sum"], "xor": v2["xor"]}
+                    if name == "var":
+                        sec[name]["note"] = ("value = whole call (survey of the spans, mark pass, scan, hash pass, reads "
+                                             "with an N); kernel / frac = the hash pass alone")
                     w2.free()
                 except Exception as e:
                     sec[name] = {"error": str(e)}

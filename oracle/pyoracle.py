@@ -312,6 +312,11 @@ class Reference(Oracle):
         # older prebuilt _ref libraries lack the synthetic-workload helpers
         self.has_synth = hasattr(R, "ref_synth_checksum") and hasattr(R, "ref_bench_synth")
         if self.has_synth:
+            if hasattr(R, "ref_synth_var_checksum"):
+                R.ref_synth_var_checksum.restype = None
+                R.ref_synth_var_checksum.argtypes = [C.c_uint64, C.c_uint64, C.c_uint, C.c_uint, C.c_uint64, C.c_uint, C.c_uint,
+                                                     C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                                     C.POINTER(C.c_uint64)]
             R.ref_synth_checksum.restype = None
             R.ref_synth_checksum.argtypes = [C.c_uint64, C.c_uint64, C.c_uint, C.c_uint64, C.POINTER(C.c_char_p),
                                              C.c_uint, C.c_uint, C.c_uint, C.c_int, _u64p, _u64p, _u64p]
@@ -440,6 +445,14 @@ class Reference(Oracle):
                                   C.byref(s_), C.byref(x_), C.byref(t_))
         return s_.value, x_.value, t_.value
 
+    def synth_var_checksum(self, first_read, n_reads, len_min, len_max, k, m, seed=42, threads=0):
+        """(sum, xor, total) over every NtHash(k, m) hash of the variable-length synthetic reads (ref_shim.cpp:
+        ref_synth_var_checksum states the rule; var_reads() below is its numpy twin)"""
+        s_, x_, t_ = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self.R.ref_synth_var_checksum(C.c_uint64(first_read), C.c_uint64(n_reads), len_min, len_max, C.c_uint64(seed),
+                                      k, m, threads, C.byref(s_), C.byref(x_), C.byref(t_))
+        return s_.value, x_.value, t_.value
+
     def bench_synth(self, first_read, n_reads, length, k, m, seeds=None, seed=42, threads=1, repeats=1):
         """Seconds the reference needs for the reads (timed inside the library: warm thread pool, reads first
         touched by the thread that hashes them); returns (seconds, k-mers, threads used)."""
@@ -450,3 +463,25 @@ class Reference(Oracle):
         if sec < 0:
             raise MemoryError("ref_bench_synth: allocation failed")
         return sec, nk.value, used.value
+
+
+def _splitmix64(x):
+    """numpy uint64 splitmix64 (wrapping arithmetic), the generator of the synthetic workloads"""
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def var_reads(first_read, n_reads, len_min, len_max, seed=42):
+    """The variable-length synthetic workload's shape: (lengths, has_n, n_pos) of reads [first_read, +n_reads) --
+    read r = the first lengths[r] bytes of synthetic read r of length len_max, byte n_pos[r] replaced by 'N' where
+    has_n[r] (oracle/ref_shim.cpp: ref_synth_var_checksum)."""
+    with np.errstate(over="ignore"):
+        r = np.arange(first_read, first_read + n_reads, dtype=np.uint64)
+        x = _splitmix64(np.uint64(seed) + np.uint64(0xABCDEF) + r)
+    lens = np.uint64(len_min) + x % np.uint64(len_max - len_min + 1)
+    has_n = (x >> np.uint64(32)) % np.uint64(997) == 0
+    n_pos = (x >> np.uint64(16)) % lens
+    return lens, has_n, n_pos

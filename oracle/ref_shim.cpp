@@ -324,6 +324,43 @@ void ref_synth_checksum(uint64_t first_read, uint64_t n_reads, unsigned len, uin
   *total_out = cnt;
 }
 
+// Variable-length version of the synthetic workload (bench.py's "var" line): read r is the first len_r bytes of the
+// synthetic read r of length len_max, len_r = len_min + x % (len_max - len_min + 1) with x = splitmix64(seed + 0xABCDEF + r);
+// one read in ~997 ((x >> 32) % 997 == 0) has its byte (x >> 16) % len_r replaced by 'N'.  Every hash from the reference.
+void ref_synth_var_checksum(uint64_t first_read, uint64_t n_reads, unsigned len_min, unsigned len_max, uint64_t seed,
+                            unsigned k, unsigned m, int threads, uint64_t* sum_out, uint64_t* xor_out,
+                            uint64_t* total_out)
+{
+  uint64_t sum = 0, xr = 0, cnt = 0;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel reduction(+ : sum, cnt) reduction(^ : xr)
+#endif
+  {
+    std::vector<char> buf(len_max + 1);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int64_t i = 0; i < (int64_t)n_reads; i++) {
+      const uint64_t r = first_read + (uint64_t)i;
+      shim_synth_read(buf.data(), r, len_max, seed);
+      const uint64_t x = shim_splitmix64(seed + 0xABCDEFULL + r);
+      const unsigned len = len_min + (unsigned)(x % (uint64_t)(len_max - len_min + 1));
+      if ((x >> 32) % 997 == 0) buf[(x >> 16) % len] = 'N';
+      if (len < k) continue; // (the reference refuses sequences shorter than k)
+      nthash::NtHash h(buf.data(), len, (uint8_t)m, (uint16_t)k);
+      while (h.roll()) {
+        const uint64_t* hv = h.hashes();
+        for (unsigned j = 0; j < m; j++) { sum += hv[j]; xr ^= hv[j]; }
+        cnt++;
+      }
+    }
+  }
+  *sum_out = sum;
+  *xor_out = xr;
+  *total_out = cnt;
+}
+
 // CPU baseline, timed inside: the reads are generated (untimed) by the threads that will hash them -- first touch
 // on their own NUMA node, thread pool warm -- then the same static partition is hashed the way
 // examples/benchmark.cpp uses the library (iterator per read, every hash consumed).  Returns seconds.

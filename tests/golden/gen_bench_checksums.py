@@ -31,6 +31,10 @@ JOBS += [("c2", 0, 20_000, 150, 31, 1, None), ("c2", 125_000_000, 20_000, 150, 3
          ("c4", 0, 5_000, 250, 31, 3, [SEED_A, SEED_B])]
 
 
+# variable-length reads (bench.py's "var" line): (name, first_read, n_reads, len_min, len_max, k, m)
+VAR_JOBS = [("var", 0, 20_000_000, 100, 150, 31, 1), ("var", 0, 20_000, 100, 150, 31, 1)]
+
+
 def main():
     ref = Reference()
     assert ref.has_synth
@@ -45,6 +49,19 @@ def main():
         s, x, tot = ref.synth_checksum(first, n, L, k, m, seeds=seeds)
         done[(name, first, n)] = {"workload": name, "first_read": first, "n_reads": n, "len": L, "k": k, "m": m,
                                   "seeds": seeds, "seed": 42, "total": tot, "sum": format(s, "016x"),
+                                  "xor": format(x, "016x"), "source": ref.fn_name() + " (oracle/_ref)"}
+        print(name, first, n, format(s, "016x"), format(x, "016x"), tot, "%.1fs" % (time.time() - t0), flush=True)
+        json.dump(sorted(done.values(), key=lambda e: (e["workload"], e["n_reads"], e["first_read"])),
+                  open(OUT, "w"), indent=0)
+
+
+    for (name, first, n, lmin, lmax, k, m) in VAR_JOBS:
+        if (name, first, n) in done:
+            continue
+        t0 = time.time()
+        s, x, tot = ref.synth_var_checksum(first, n, lmin, lmax, k, m)
+        done[(name, first, n)] = {"workload": name, "first_read": first, "n_reads": n, "len_min": lmin, "len": lmax, "k": k,
+                                  "m": m, "seeds": None, "seed": 42, "total": tot, "sum": format(s, "016x"),
                                   "xor": format(x, "016x"), "source": ref.fn_name() + " (oracle/_ref)"}
         print(name, first, n, format(s, "016x"), format(x, "016x"), tot, "%.1fs" % (time.time() - t0), flush=True)
         json.dump(sorted(done.values(), key=lambda e: (e["workload"], e["n_reads"], e["first_read"])),
