@@ -445,7 +445,8 @@ def main():
     my_dt = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
-    assert kmers == args.steps * n_reads * wl.nwin, (kmers, args.steps * n_reads * wl.nwin)
+    if wl.var is None:  # (a variable-length batch emits what its reads hold: checked against the reference's total below)
+        assert kmers == args.steps * n_reads * wl.nwin, (kmers, args.steps * n_reads * wl.nwin)
 
     verify = wl.verify()
     ok_local = (verify["ok"] is not False) and (verify["spot_vs_oracle"] is True)
