@@ -111,6 +111,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
     const bool special31 = planned && k == 31 && (plan.C == 15 || (plan.C == 30 && m == 1));
     // (runs per read <= 128: the kernel's division of a run index by it, one multiply and a shift, is exact there)
     const bool any_k = planned && !special31 && !c->tune.no_any_k_runs && plan.rpr <= 128 &&
+                       !kmer_runs_chunked_compiled() && // (the windowed experiment build keeps to the k = 31 shapes)
                        kmer_runs_any_k_compiled(k, m, plan.C);
     const bool special = special31 || any_k; // (NTHIP_TUNE_NO_SPECIAL: A/B, the general kernel on these too)
     if (special) {
