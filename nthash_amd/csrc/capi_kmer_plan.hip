@@ -109,8 +109,14 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
   if (len < k || k > 64 || m > (uint32_t)KF_MAX_RUNTIME_M || stride > len || stride == 0) return false;
   const uint32_t nwin = len - k + 1;
   uint32_t best = 0;
-  for (uint32_t d = 16; d >= 4; --d)
+  // An ODD run length first: a lane's tile row is C 8-byte entries, and the 16 lanes of a ds_write_b64 group then fall
+  // on 16 different bank pairs; C = 16 is a 16-way conflict on every tile write, 12 and 20 are 4-way, 10 / 14 / 22 2-way.
+  static const uint32_t pref[] = {15, 13, 11, 17, 19, 21, 23, 25, 9, 14, 10, 22};
+  for (uint32_t d : pref)
     if (nwin % d == 0) { best = d; break; }
+  if (best == 0)
+    for (uint32_t d = 16; d >= 4; --d)
+      if (nwin % d == 0) { best = d; break; }
   if (best < 6)
     for (uint32_t d = 17; d <= 64; ++d) // e.g. a prime window count: the whole read is one run
       if (nwin % d == 0) { best = d; break; }

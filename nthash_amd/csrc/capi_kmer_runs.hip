@@ -60,7 +60,8 @@ bool ntamd::host::kmer_runs_any_k_compiled(uint32_t k, uint32_t m, uint32_t C)
 {
   if (m != 1 || k < 17 || k > 32) return false;
   switch (C) {
-    case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 19: case 20: case 22: case 23: case 25: return true;
+    case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 19: case 20: case 21: case 22: case 23:
+    case 25: return true;
     default: return false;
   }
 }
@@ -74,6 +75,9 @@ int ntamd::host::launch_kmer_runs_special(nthip_ctx* c, const KmerRunsArgs& ra, 
   // (151 bp / k31: 11, 100 bp: 14, 76 bp: 23, 250 bp: 11, 125 bp: 19, 150 bp / k21: 13, ...)
   if (ra.m == 1 && !(ra.k == 31 && (plan.C == 15 || plan.C == 30)) && kmer_runs_any_k_compiled(ra.k, 1, plan.C)) {
     switch (plan.C) {
+      case 9: return NT_RUNS(0, 1, 9, 2);
+      case 17: return NT_RUNS(0, 1, 17, 2);
+      case 21: return NT_RUNS(0, 1, 21, 2);
       case 10: return NT_RUNS(0, 1, 10, 2);
       case 11: return NT_RUNS(0, 1, 11, 2);
       case 12: return NT_RUNS(0, 1, 12, 2);
