@@ -226,7 +226,10 @@ int launch_fill_window_pos(nthip_ctx* c, uint32_t* d_pos, uint64_t n_reads, uint
                            const uint64_t* d_offsets);
 
 // ---- capi_kmer_plan.hip (host only) ---------------------------------------------------------------------------
-constexpr uint32_t KMER_TABLE_K_MAX = 64; // beyond: Horner first window
+#ifndef KMER_TABLE_K_MAX_N
+#define KMER_TABLE_K_MAX_N 64
+#endif
+constexpr uint32_t KMER_TABLE_K_MAX = KMER_TABLE_K_MAX_N; // beyond: Horner first window
 inline uint32_t kmer_ntab(uint32_t k) { return k <= KMER_TABLE_K_MAX ? 4u * ((k + 15) / 16) : 2u; }
 inline uint32_t kmer_nw(uint32_t k) { return k <= KMER_TABLE_K_MAX ? (k + 15) / 16 : 0u; }
 

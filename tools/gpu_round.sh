@@ -1,7 +1,6 @@
 #!/bin/bash
-# scratch script for one gpurun call
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r02
-timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -5
-timeout 300 python tools/soak.py 200 99 2>&1 | tail -2
-timeout 200 python tools/stress_seeds.py 300 77 2>&1 | tail -1
-timeout 200 python tools/stress_shapes.py 2>&1 | tail -1
+echo "=== 100,64,3"; ABLATE_SHAPE=100,64,3 python tools/ab_multi.py "h32,h32:NTHIP_TUNE_RUN_LEN=10,:NTHIP_TUNE_RUN_LEN=10" 40000000 8 | cut -c1-130
+echo "=== 100,64,1"; ABLATE_SHAPE=100,64,1 python tools/ab_multi.py "h32" 40000000 8 | cut -c1-130
+echo "=== 150,51,1"; ABLATE_SHAPE=150,51,1 python tools/ab_multi.py "h32,h48" 40000000 8 | cut -c1-130
+echo "=== 150,40,1"; ABLATE_SHAPE=150,40,1 python tools/ab_multi.py "h32" 40000000 8 | cut -c1-130
