@@ -465,6 +465,19 @@ def test_kmer_whole_read_tiles_vs_oracle(oracle):
             new.d2h(h, d_h); new.d2h(cts, d_c); new.d2h(ps, d_p)
             assert (h[: tot * m].reshape(-1, m) == want["hashes"]).all() and (cts == want["counts"]).all()
             assert (ps[:tot] == want["pos"]).all()
+            # the same spans in REVERSE order: not this path's (tiles are contiguous slabs) -- the round-1 kernel takes them
+            rev = list(range(len(reads)))[::-1]
+            d2, offs2 = concat_reads([reads[i] for i in rev])
+            want2 = oracle.kmer_batch(d2, offs2, k, m)
+            new.h2d(d_s, np.array([starts[i] for i in rev], np.uint64)); new.h2d(d_e, np.array([ends[i] for i in rev], np.uint64))
+            new.set_profiling(True)
+            tot2 = new.kmer_hash_spans_ptr(d_buf, raw.size, d_s, d_e, len(reads), k, m, d_h, cap, counts=d_c, pos=d_p)
+            assert new.last_kernel_ms()[1] == "kmer_ragged_kernel"
+            new.set_profiling(False)
+            new.d2h(h, d_h); new.d2h(cts, d_c)
+            assert tot2 == want2["total"] and (h[: tot2 * m].reshape(-1, m) == want2["hashes"]).all()
+            assert (cts == want2["counts"]).all()
+            new.h2d(d_s, np.array(starts, np.uint64)); new.h2d(d_e, np.array(ends, np.uint64))
         finally:
             for ptr in (d_buf, d_s, d_e, d_h, d_c, d_p):
                 new.free(ptr)
