@@ -77,7 +77,8 @@ typedef struct {
   uint64_t* hashes;  /* required: capacity * hashes_per_kmer values */
   uint64_t capacity; /* in k-mers */
   uint64_t* counts;  /* optional: n_reads values, emitted k-mers per read */
-  uint32_t* pos;     /* optional: capacity values, get_pos() of each emitted k-mer */
+  uint32_t* pos;     /* optional: capacity values, get_pos() of each emitted k-mer (32 bits: with offsets, a read of
+                        2^32 bases or more is refused with NTHIP_ERR_UNSUPPORTED when positions are asked for) */
   uint64_t* fwd;     /* optional: forward-strand hash(es) of each emitted k-mer: capacity values
                         (k-mer hashing) or capacity * n_seeds values, seed-minor (seed hashing) */
   uint64_t* rev;     /* optional: reverse-strand hash(es), same layout */

@@ -39,6 +39,9 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
     OffsetsSurvey sv;
     NTCHK(offsets_survey_device(c, st.offsets, rd->n_reads, total_bytes, &sv));
     if (sv.bad) return fail(NTHIP_ERR_ARG, "offsets / spans are not non-decreasing or reach outside the read buffer");
+    if (st.pos && sv.max_len > 0xFFFFFFFFull) // (the façade never gets here: it hashes long sequences window by window)
+      return fail(NTHIP_ERR_UNSUPPORTED, "out->pos is 32 bits wide: a read of %llu bases cannot report its positions",
+                  (unsigned long long)sv.max_len);
     shape.max_len = shape.max_pitch = sv.max_len;
     have_shape = true;
     if (sv.uniform && !(flags & (NTHIP_FORCE_GENERAL | NTHIP_ASYNC)) && rd->n_reads >= 1024 && sv.len0 >= 1 &&
