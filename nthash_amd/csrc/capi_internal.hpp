@@ -219,7 +219,7 @@ struct OffsetsSurvey {
 int offsets_survey_device(nthip_ctx* c, const uint64_t* d_offsets, uint64_t n_reads, uint64_t buf_bytes, OffsetsSurvey* sv);
 // longest read / largest distance between starts of a batch, when the caller already knows them
 struct ReadsShape {
-  uint64_t max_len = 0, max_pitch = 0;
+  uint64_t max_len = 0, max_pitch = 0, sum_len = 0;
 };
 // get_pos() of reads that emit every window (flags/offsets: only the reads with flags[r] == 0, at offsets[r])
 int launch_fill_window_pos(nthip_ctx* c, uint32_t* d_pos, uint64_t n_reads, uint32_t nwin, const uint64_t* d_flags,

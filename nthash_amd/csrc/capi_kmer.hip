@@ -43,6 +43,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
       return fail(NTHIP_ERR_UNSUPPORTED, "out->pos is 32 bits wide: a read of %llu bases cannot report its positions",
                   (unsigned long long)sv.max_len);
     shape.max_len = shape.max_pitch = sv.max_len;
+    shape.sum_len = total_bytes >= sv.off0 ? total_bytes - sv.off0 : 0;
     have_shape = true;
     if (sv.uniform && !(flags & (NTHIP_FORCE_GENERAL | NTHIP_ASYNC)) && rd->n_reads >= 1024 && sv.len0 >= 1 &&
         sv.len0 < (1ull << 30) && sv.off0 + rd->n_reads * sv.len0 <= total_bytes) {

@@ -43,18 +43,19 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   unsigned long long* d_res = (unsigned long long*)(c->d_small + 96); // [0] max length [1] max pitch [2] out of order
   unsigned long long* d_ndirty = (unsigned long long*)(c->d_small + 128);
   HIPCHK(hipMemsetAsync(c->d_small + 96, 0, 48, c->stream));
-  uint64_t res[3] = {0, 0, 0};
+  uint64_t res[4] = {0, 0, 0, 0};
   if (shape) { // back-to-back reads already surveyed by the caller
     res[0] = shape->max_len;
     res[1] = shape->max_pitch;
+    res[3] = shape->sum_len;
   } else {
     uint64_t blocks = (n + 255) / 256;
     if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
     hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n, d_res);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_small + 96, d_res, 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_small + 96, d_res, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    memcpy(res, c->h_small + 96, 24);
+    memcpy(res, c->h_small + 96, 32);
   }
   const uint64_t max_len = res[0], max_pitch = res[1] > res[0] ? res[1] : res[0];
   if (res[2] || max_len > RD_MAX_LEN) return NTHIP_OK; // long reads: kmer_ragged_kernel spreads them over tiles
@@ -65,8 +66,21 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
     return NTHIP_OK;
   }
   // ---- tile geometry ----
-  // odd: the tile writes of a wave (8-byte entries, C entries apart) then fall on 16 different bank pairs
-  const uint32_t C = c->tune.reads_run_len ? c->tune.reads_run_len : 9; // <= 16 (one word of roll steps + the first window)
+  // Run length, odd (the tile writes of a wave -- 8-byte entries, C entries apart -- then fall on 16 different bank
+  // pairs).  Mixed lengths: 9 (in-process A/B on 100-150 bp: 11 -3 %, 15 -6 %: a longer run wastes more of a read's
+  // overlapping last run and costs waves).  Reads (nearly) all of one length -- a sequencer's output before or after a
+  // light trim: what minimises the lane work of a full-length read, runs x (C + ~8 for the first window and the run's
+  // set-up: 151 bp measured 15 > 9 > 11); 150 bp: 15 (+4 % against 9)
+  uint32_t C = 9;
+  if (res[3] >= (uint64_t)(0.95 * (double)max_len * (double)n) && max_len >= k) {
+    const uint32_t W = (uint32_t)(max_len - k + 1);
+    uint32_t best_cost = ~0u;
+    for (uint32_t cand : {15u, 13u, 11u, 9u}) {
+      const uint32_t cost = ((W + cand - 1) / cand) * (cand + 8);
+      if (cost < best_cost) { best_cost = cost; C = cand; }
+    }
+  }
+  if (c->tune.reads_run_len) C = c->tune.reads_run_len; // <= 16 (one word of roll steps + the first window)
   const uint32_t nw = kmer_nw(k);
   const uint64_t slab_cap = 16384; // bytes of reads (and what lies between them) a tile stages
   uint32_t R = c->tune.reads_per_tile ? c->tune.reads_per_tile : 32;

@@ -544,17 +544,18 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
   }
 }
 
-// max length, max distance between consecutive starts, order: what the host needs to size the tiles
+// max length, max distance between consecutive starts, order, total length: what the host needs to size the tiles
 static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* __restrict__ starts,
                                                                 const uint64_t* __restrict__ ends, uint64_t n,
                                                                 unsigned long long* __restrict__ res)
 {
-  uint64_t mlen = 0, mpitch = 0;
+  uint64_t mlen = 0, mpitch = 0, slen = 0;
   uint32_t bad = 0;
   for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t s0 = starts[r], e0 = ends[r];
     if (e0 < s0) { bad = 1; continue; }
     if (e0 - s0 > mlen) mlen = e0 - s0;
+    slen += e0 - s0;
     if (r + 1 < n) {
       const uint64_t s1 = starts[r + 1];
       if (s1 < e0) bad = 1; // not in order, or overlapping
@@ -567,9 +568,18 @@ static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* 
                         (uint32_t)__shfl_down((int)(uint32_t)mlen, d, 64);
     const uint64_t op = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(mpitch >> 32), d, 64) << 32) |
                         (uint32_t)__shfl_down((int)(uint32_t)mpitch, d, 64);
+    const uint64_t os = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(slen >> 32), d, 64) << 32) |
+                        (uint32_t)__shfl_down((int)(uint32_t)slen, d, 64);
     if (ol > mlen) mlen = ol;
     if (op > mpitch) mpitch = op;
+    slen += os;
   }
+  __shared__ unsigned long long block_sum; // total length of the reads: one atomic per block
+  if (threadIdx.x == 0) block_sum = 0;
+  __syncthreads();
+  if ((threadIdx.x & 63u) == 0) atomicAdd(&block_sum, (unsigned long long)slen);
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&res[3], block_sum);
   // (thousands of waves hammering one address serialise in L2: look first, the maximum is reached early)
   if ((threadIdx.x & 63u) == 0) {
     if (mlen > __atomic_load_n(&res[0], __ATOMIC_RELAXED)) atomicMax(&res[0], (unsigned long long)mlen);
