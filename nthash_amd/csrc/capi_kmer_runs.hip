@@ -15,7 +15,11 @@ int launch_kmer_runs(nthip_ctx* c, K kernel, KmerRunsArgs a, size_t dyn_lds)
   const uint64_t need = (a.n_wtiles + a.waves - 1) / a.waves;
   uint64_t grid = (uint64_t)c->n_cu * per_cu;
   if (grid > need) grid = need;
-  if (a.tile_map == 0xFFFFFFFFu) a.tile_map = (uint32_t)grid; // every block streams its own range
+  // 32 groups of 8 blocks, each group streaming through its own range of tiles with its waves interleaved.  Round 1 had
+  // one group per block; in-process over fresh allocations (tools/alloc_ab.py) 16-128 groups are 0-0.9 % faster on the
+  // 150 bp shape (nothing on a box where the allocation is slow anyway), 2 % on 151 bp / run length 11; 1 group
+  // (plain grid stride) is 4-5 % slower on a good allocation and 2-4 % faster on a bad one; m > 1: no difference
+  if (a.tile_map == 0xFFFFFFFFu) a.tile_map = grid >= 64 ? 32u : (uint32_t)grid;
   if (a.ph_tiles && !c->tune.no_pacing) {
     // period of the phased path = the time HBM needs for what the chip reads and writes in one period, apart:
     // reads at ~6.0 TB/s, write-through stores at ~6.8 TB/s (measured with the hash switched off), in ticks of 10 ns
