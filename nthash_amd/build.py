@@ -10,7 +10,9 @@ libnthash.so      the C++ host facade (include/nthash/nthash.hpp) on top of it
 (nthash_amd/lib/ab/libnthash_hip_T.so; use it with NTHASH_AMD_LIB=...).
 """
 import concurrent.futures
+import json
 import os
+import re
 import shlex
 import shutil
 import subprocess
@@ -63,11 +65,51 @@ def _compile_unit(hipcc, unit, objdir, extra, force, verbose):
     if not force and deps is not None and not _newer(obj, deps + [src]) and all(os.path.exists(d) for d in deps):
         return obj, False
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed",
+           "-Rpass-analysis=kernel-resource-usage",
            f"-I{os.path.join(ROOT, 'include')}", "-MD", "-MF", dep] + list(extra) + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    kernels = _resource_usage(r.stderr)
+    rest = "\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and not _REMARK_ECHO.match(l))
+    if rest.strip():
+        print(rest, file=sys.stderr)
+    if r.returncode != 0:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
+    json.dump(kernels, open(obj + ".res.json", "w"), indent=0)
+    # No kernel may spill.  Several of them keep loads in flight behind inline asm that hipcc cannot see (the next
+    # tile's slab): a register of such a load that is spilled is saved before the load has landed -- wrong hashes,
+    # found on seed_wtile_kernel<8> (k = 64 seeds) in round 2.  Scratch traffic would also break the counted waits.
+    spilling = [k_ for k_ in kernels if k_.get("scratch", 0) or k_.get("vgpr_spill", 0)]
+    if spilling and not os.environ.get("NTHASH_AMD_ALLOW_SPILLS"):
+        os.remove(obj)
+        raise RuntimeError(f"{unit}: kernels spill registers (scratch bytes per lane): " +
+                           ", ".join(f"{k_['name']}={k_.get('scratch', 0)}" for k_ in spilling))
     return obj, True
+
+
+_REMARK_ECHO = re.compile(r"^\s*(\d+ \||\||\^)")  # the source line / caret clang prints under every remark
+
+
+def _resource_usage(text):
+    """[{name, vgprs, sgprs, scratch, vgpr_spill, occupancy, lds}] from -Rpass-analysis=kernel-resource-usage remarks."""
+    out, cur = [], None
+    for line in text.splitlines():
+        m = re.search(r"remark:\s+(.*?) \[-Rpass-analysis=kernel-resource-usage\]", line)
+        if not m:
+            continue
+        key, _, val = m.group(1).partition(":")
+        key, val = key.strip(), val.strip()
+        if key == "Function Name":
+            cur = {"name": val}
+            out.append(cur)
+        elif cur is not None:
+            field = {"VGPRs": "vgprs", "TotalSGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch",
+                     "VGPRs Spill": "vgpr_spill", "Occupancy [waves/SIMD]": "occupancy",
+                     "LDS Size [bytes/block]": "lds"}.get(key)
+            if field and val.lstrip("-").isdigit():
+                cur[field] = int(val)
+    return out
 
 
 def build_hip(out_so=HIP_SO, objdir=OBJ, extra=(), force=False, verbose=False, only_units=None):

@@ -143,6 +143,7 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   a.tile_u64 = tile_u64;
   a.ptile_dwords = ptile_dwords;
   a.rmap_dwords = rmap_dwords;
+  a.groups = c->tune.has_tile_map ? c->tune.tile_map : 32u; // (in process: 32 / 64 groups 0.2-0.7 % ahead of one range per block)
   memcpy(a.tab, consts.tab, sizeof a.tab);
   memcpy(a.mult, consts.mult, sizeof a.mult);
   const size_t lds = fixed + per_wave * waves;

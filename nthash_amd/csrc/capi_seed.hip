@@ -473,6 +473,7 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
   a.inv_nwin = f.inv_nwin;
   a.bits_dwords = bits_dwords;
   a.waves = waves;
+  a.groups = c->tune.has_tile_map ? c->tune.tile_map : 32u; // (in process: 32 / 64 groups 0.2-0.4 % ahead of one range per block)
   memcpy(a.mult, f.mult, sizeof a.mult);
   const size_t lds = table_bytes + per_wave * waves;
   auto go = [&](auto kernel) -> int {

@@ -127,6 +127,30 @@ __device__ __forceinline__ void sror_pair(uint32_t& lo, uint32_t& hi)
   lo = nlo;
 }
 
+// Tiles -> waves for the kernels whose waves own whole tiles: the blocks of the grid are split into `groups` groups of
+// consecutive blocks, every group streams through its own contiguous range of tiles with all its waves interleaved in
+// it (groups = 0 or >= blocks: one range per block).  Fewer, wider streams touch fewer pages at any moment.
+struct TileRange {
+  uint64_t first, end, step;
+};
+__device__ __forceinline__ TileRange tile_range(uint64_t n_tiles, uint32_t waves, uint32_t wave, uint32_t groups)
+{
+  const uint32_t nb = gridDim.x;
+  const uint32_t G = groups != 0u && groups < nb ? groups : nb;
+  const uint32_t bpg = nb / G; // blocks per group (the last group takes the remainder)
+  uint32_t g = blockIdx.x / bpg;
+  if (g >= G) g = G - 1u;
+  const uint32_t b_in_g = blockIdx.x - g * bpg;
+  const uint32_t g_blocks = g == G - 1u ? nb - g * bpg : bpg;
+  const uint64_t per = (n_tiles + G - 1u) / G;
+  const uint64_t t0 = (uint64_t)g * per;
+  TileRange r;
+  r.first = t0 + (uint64_t)b_in_g * waves + wave;
+  r.end = t0 + per < n_tiles ? t0 + per : n_tiles;
+  r.step = (uint64_t)g_blocks * waves;
+  return r;
+}
+
 // word modes of the per-lane rolling loop
 enum : int { W_NOEMIT = 0, W_EMIT = 1, W_BOUNDARY = 2, W_CHECKED = 3 };
 

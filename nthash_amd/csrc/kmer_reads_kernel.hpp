@@ -50,6 +50,7 @@ struct KmerReadsArgs {
   const uint4* init_tab;
   uint32_t k, m, C, ntab;
   uint32_t waves, bits_dwords, tile_u64, ptile_dwords, rmap_dwords;
+  uint32_t groups;           // tile_range(): groups of blocks sharing a range of tiles (0: one range per block)
   uint32_t value_sel;        // 0: canonical hash (+ mixes), 1: forward, 2: reverse strand (m == 1)
   uint64_t tab[16][2];
   uint64_t mult[KF_MAX_RUNTIME_M];
@@ -114,9 +115,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
            (uint32_t)__shfl((int)(uint32_t)v, (int)src, 64);
   };
 
-  const uint64_t per_block = (a.n_tiles + gridDim.x - 1) / gridDim.x;
-  const uint64_t t_begin = (uint64_t)blockIdx.x * per_block;
-  const uint64_t t_end = t_begin + per_block < a.n_tiles ? t_begin + per_block : a.n_tiles;
+  const TileRange tr = tile_range(a.n_tiles, a.waves, wave, a.groups);
+  const uint64_t t_end = tr.end, t_step = tr.step;
 
   // Software pipeline of the HASH pass (a wave is alone with its latencies): a tile's bytes sit behind two dependent
   // loads -- the reads' spans, then the slab they delimit.  The spans / flags / counts of tile t + 2 and the first
@@ -168,15 +168,15 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
   Meta m_cur, m_nxt;
   Geom g_cur;
   {
-    const uint64_t t0 = t_begin + wave;
+    const uint64_t t0 = tr.first;
     if (t0 >= t_end) return;
     m_cur = load_meta(t0);
     g_cur = geom_of(m_cur, t0);
     if (MODE == RD_MODE_HASH) issue_slab(g_cur);
-    m_nxt = t0 + a.waves < t_end ? load_meta(t0 + a.waves) : m_cur;
+    m_nxt = t0 + t_step < t_end ? load_meta(t0 + t_step) : m_cur;
   }
 
-  for (uint64_t t = t_begin + wave; t < t_end; t += a.waves) {
+  for (uint64_t t = tr.first; t < t_end; t += t_step) {
     const uint64_t r0 = t * a.R;
     const uint32_t nr = a.n_reads - r0 < a.R ? (uint32_t)(a.n_reads - r0) : a.R;
     // ---- this tile's reads: one per lane ----
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
     const uint32_t n_vec = g_cur.n_vec;
     const uint32_t nwin_raw = len_j >= k ? (uint32_t)(len_j - k + 1u) : 0u;
     const uint32_t sb_j = shift + (uint32_t)(s_j - slab0);
-    const bool have_next = t + a.waves < t_end;
+    const bool have_next = t + t_step < t_end;
 
     if (MODE == RD_MODE_MARK) {
       // ---- stage: one validity bit per byte ----
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
       lds_sync(); // the bit stream is free again
       if (have_next) {
         m_cur = m_nxt;
-        g_cur = geom_of(m_cur, t + a.waves);
-        if (t + 2u * a.waves < t_end) m_nxt = load_meta(t + 2u * a.waves);
+        g_cur = geom_of(m_cur, t + t_step);
+        if (t + 2u * t_step < t_end) m_nxt = load_meta(t + 2u * t_step);
       }
       continue;
     }
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
     Meta m_n2 = m_nxt;
     Geom g_nxt = g_cur;
     if (have_next) {
-      g_nxt = geom_of(m_nxt, t + a.waves);
+      g_nxt = geom_of(m_nxt, t + t_step);
       issue_slab(g_nxt);
-      if (t + 2u * a.waves < t_end) m_n2 = load_meta(t + 2u * a.waves);
+      if (t + 2u * t_step < t_end) m_n2 = load_meta(t + 2u * t_step);
     }
     // ---- read table ----
     const uint32_t nwin_j = listed ? 0u : nwin_raw;

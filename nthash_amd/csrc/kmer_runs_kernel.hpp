@@ -443,7 +443,9 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
     return counted;
   };
 
-  if (!KR_CHUNKED || !DT || a.ph_tiles == 0u) {
+  // (the windowed path exists in the m = 1 instantiations of a KR_CHUNKED build only: 512 threads, 256 VGPRs)
+  constexpr bool KR_WINDOWED = KR_CHUNKED && DT && M_T == 1;
+  if (!KR_WINDOWED || a.ph_tiles == 0u) {
     Slab cur;
     cur.byte0 = 0;
     cur.shift = cur.slab_bytes = cur.n_vec = cur.runs_here = 0;
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
     }
   }
 #if KR_CHUNKED
-  else {
+  else if constexpr (KR_WINDOWED) {
     // ---- windowed path (DT shapes whose tiles are whole reads: 64 % rpr == 0, stride == len) --------------------------
     // HBM serves this kernel's two streams far better apart than mixed (profiles/r02_notes.md: with the hash switched
     // off, 18.6 ms per 100 M reads mixed, 17.3 ms or less in phases).  So every wave of the chip READS in the same time

@@ -330,6 +330,7 @@ struct SeedWtileArgs {
   uint32_t inv_nwin;     // floor(2^32 / nwin) + 1
   uint32_t bits_dwords;  // per wave
   uint32_t waves;        // per block
+  uint32_t groups;       // tile_range(): groups of blocks sharing a range of tiles (0: one range per block)
   uint64_t mult[SF_MAX_RUNTIME_M];
 };
 
@@ -349,6 +350,10 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
 {
   constexpr bool ROT = RNS > 0;
   static_assert(!ROT || (NH == 4 && RNS <= 2 && RM2 >= 1 && RM2 <= 4), "rotated-slot layout: k <= 32, <= 2 seeds");
+  // PF: the next tile's slab travels in registers behind hidden loads.  Only while the kernel does not spill: a spilled
+  // register of a load hipcc cannot see is saved before the load has landed (k > 32: 2 * NH lookups of 16 bytes in flight
+  // take the registers; nthash_amd/build.py refuses a build in which a kernel with hidden loads spills)
+  constexpr bool PF = NH <= 4;
   constexpr int NW = (NH + 1) / 2; // 32-bit words of window kept in registers
   constexpr uint32_t NT = 2u * NH; // byte tables per seed in LDS
   extern __shared__ __attribute__((aligned(256))) uint32_t lds_dyn[];
@@ -394,9 +399,8 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
   }
 
   // this block's contiguous range of tiles, its waves interleaved inside it
-  const uint64_t per_block = (a.n_tiles + gridDim.x - 1u) / gridDim.x;
-  const uint64_t t_begin = (uint64_t)blockIdx.x * per_block;
-  const uint64_t t_end = t_begin + per_block < a.n_tiles ? t_begin + per_block : a.n_tiles;
+  const TileRange tr = tile_range(a.n_tiles, a.waves, wave, a.groups);
+  const uint64_t t_end = tr.end, t_step = tr.step;
   const uint32_t R = a.reads_per_tile;
   uint32_t bad = 0;
 
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   };
 
-  uint64_t t = t_begin + wave;
+  uint64_t t = tr.first;
   if (t >= t_end) return;
   Slab cur = slab_of(t);
   for (uint32_t i = lane; i < cur.n_vec; i += 64u)
@@ -454,17 +458,17 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
   if (lane < (uint32_t)NW + 1u) bits[cur.n_vec + lane] = 0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  for (; t < t_end; t += a.waves) {
+  for (; t < t_end; t += t_step) {
     lds_sync();
     // ---- the NEXT tile's slab: loads now, consumed after this tile's stores have been issued.  Hidden from hipcc
     // (it would wait for them behind the tile's stores, i.e. for the store acknowledgements); vmcnt retires in order
     // and holds at most 63 operations, so after 64 younger operations have been issued they have landed. ----
-    const uint64_t tn = t + a.waves;
+    const uint64_t tn = t + t_step;
     const bool have_next = tn < t_end;
     const Slab nxt = have_next ? slab_of(tn) : cur;
     nt_v4u pv[SW_MAX_VEC_ROUNDS];
-    uint32_t dirty_seen;
-    {
+    uint32_t dirty_seen = 0;
+    if constexpr (PF) {
       const uint64_t b0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)nxt.byte0) |
                           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(nxt.byte0 >> 32)) << 32);
       const uint8_t* sbase = a.seqs + b0; // (wave-uniform: scalar base + 32-bit lane offset)
@@ -585,17 +589,26 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
     }
 
     // ---- consume the next slab ----
-    if (n_stores < 64u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]),
-                      "+v"(pv[7]), "+v"(dirty_seen)::"memory");
+    if constexpr (PF) {
+      if (n_stores < 64u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]),
+                        "+v"(pv[7]), "+v"(dirty_seen)::"memory");
+    } else {
+      dirty_seen = __atomic_load_n(a.dirty, __ATOMIC_RELAXED);
+    }
     // some wave already found a non-base: the caller redoes the batch on the split path
     if (__builtin_amdgcn_readfirstlane(dirty_seen) != 0u) break;
     if (have_next) {
       cur = nxt;
+      if constexpr (PF) {
 #pragma unroll
-      for (uint32_t rd = 0; rd < SW_MAX_VEC_ROUNDS; ++rd) {
-        const uint32_t i = rd * 64u + lane;
-        if (i < cur.n_vec) pack_vec(cur, i, make_uint4(pv[rd].x, pv[rd].y, pv[rd].z, pv[rd].w));
+        for (uint32_t rd = 0; rd < SW_MAX_VEC_ROUNDS; ++rd) {
+          const uint32_t i = rd * 64u + lane;
+          if (i < cur.n_vec) pack_vec(cur, i, make_uint4(pv[rd].x, pv[rd].y, pv[rd].z, pv[rd].w));
+        }
+      } else { // long k: the lookups of a window need the registers, the slab is loaded when it is needed
+        for (uint32_t i = lane; i < cur.n_vec; i += 64u)
+          pack_vec(cur, i, *(const uint4*)(a.seqs + cur.byte0 + ((uint64_t)i << 4)));
       }
       if (lane < (uint32_t)NW + 1u) bits[cur.n_vec + lane] = 0;
       if (__ballot(bad != 0) != 0) { // publish at once so that every wave can stop early

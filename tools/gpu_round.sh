@@ -1,5 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-echo "=== 150,31,4"; ABLATE_SHAPE=150,31,4 python tools/ab_multi.py ":NTHIP_TUNE_TILE_MAP=32,:NTHIP_TUNE_TILE_MAP=16,:NTHIP_TUNE_TILE_MAP=64" 30000000 8 | cut -c1-125
-echo "=== 151,31,1"; ABLATE_SHAPE=151,31,1 python tools/ab_multi.py ":NTHIP_TUNE_TILE_MAP=32,:NTHIP_TUNE_TILE_MAP=16" 60000000 8 | cut -c1-125
-echo "=== 150,31,1"; ABLATE_SHAPE=150,31,1 python tools/ab_multi.py ":NTHIP_TUNE_TILE_MAP=32,:NTHIP_TUNE_TILE_MAP=24,:NTHIP_TUNE_TILE_MAP=48" 100000000 8 | cut -c1-125
+timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -5
+timeout 200 python tools/stress_seeds.py 300 123 2>&1 | tail -1
