@@ -101,6 +101,8 @@ int ntamd::host::launch_kmer_runs_special(nthip_ctx* c, const KmerRunsArgs& ra, 
   if (ra.m == 1 && plan.C == 15) return NT_RUNS(31, 1, 15, 2);
   if (ra.m == 1 && plan.C == 30) return NT_RUNS(31, 1, 30, 2);
   if (ra.m == 4 && !c->tune.no_m4) return NT_RUNS(31, 4, 15, 2); // BASELINE config 3
+  if (ra.m == 2 && !c->tune.no_m4) return NT_RUNS(31, 2, 15, 2); // (compile-time m: the copy-out's division and
+  if (ra.m == 3 && !c->tune.no_m4) return NT_RUNS(31, 3, 15, 2); //  multiplier fetch fold into constants)
   return NT_RUNS(31, 0, 15, 2);
 #undef NT_RUNS
 }

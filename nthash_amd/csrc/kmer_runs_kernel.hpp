@@ -435,9 +435,23 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
             const uint64_t h0 = tile[e < runs_here * C ? e : 0];
             o[h] = jj == 0 ? h0 : mix_hash(h0, mults[jj & (KF_MAX_RUNTIME_M - 1)]);
           }
-          if (2u * pi + 1u < n_vals) *(uint4*)(out0 + 2u * pi) =
-              make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
-          else *(uint2*)(out0 + 2u * pi) = make_uint2((uint32_t)o[0], (uint32_t)(o[0] >> 32));
+#if KR_ABL_NOSTORE
+          asm volatile("" ::"v"((uint32_t)o[0]), "v"((uint32_t)(o[0] >> 32)), "v"((uint32_t)o[1]), "v"((uint32_t)(o[1] >> 32)));
+#else
+#ifndef KR_MH_STORE
+#define KR_MH_STORE 1 // 1: write-through (sc0 sc1) as the m = 1 copy-out (a tile's values are whole, aligned lines), 0: plain
+#endif
+          if (2u * pi + 1u < n_vals) {
+            const uint4 ov = make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
+#if KR_MH_STORE
+            stream_store16(out0 + 2u * pi, ov);
+#else
+            *(uint4*)(out0 + 2u * pi) = ov;
+#endif
+          } else {
+            *(uint2*)(out0 + 2u * pi) = make_uint2((uint32_t)o[0], (uint32_t)(o[0] >> 32));
+          }
+#endif
         }
       }
     return counted;
