@@ -876,9 +876,14 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
           const uint64_t h0 = tile[e];
           o[h] = jj == 0 ? h0 : mix_hash(h0, ((uint64_t)jj ^ kmul));
         }
-        if (ok[0] && ok[1])
-          *(uint4*)(base + 2u * pi) =
-              make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
+        if (ok[0] && ok[1]) {
+          const uint4 ov = make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
+#if defined(KRG_MH_PLAIN)
+          *(uint4*)(base + 2u * pi) = ov;
+#else     // streaming stores for the whole pieces, as in the m = 1 copy-out
+          __builtin_nontemporal_store(*(const nt_v4u*)&ov, (nt_v4u*)(base + 2u * pi));
+#endif
+        }
         else if (ok[0]) *(uint2*)(base + 2u * pi) = make_uint2((uint32_t)o[0], (uint32_t)(o[0] >> 32));
         else if (ok[1]) *(uint2*)(base + 2u * pi + 1u) = make_uint2((uint32_t)o[1], (uint32_t)(o[1] >> 32));
       }
