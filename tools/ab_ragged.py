@@ -8,7 +8,7 @@ import numpy as np
 tags = [t for t in sys.argv[1].split(",") if t]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 12
-k, m = 31, 1
+k, m = 31, int(os.environ.get("RAGGED_M", "1"))
 
 
 def load(path, name):

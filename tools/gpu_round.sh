@@ -1,3 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "fixed or run_split or fuzz or golden or na_runs or dirty or padded or any_k or long" 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "whole_read or ragged" 2>&1 | tail -2
+RAGGED_M=3 python tools/ab_ragged.py rdp 8000000 10
+RAGGED_M=2 python tools/ab_ragged.py rdp 8000000 10
