@@ -400,7 +400,13 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
         for (uint32_t pi = lane; pi < pl; pi += 64u) {
           if (pi >= pf) {
             const uint4 dv = *(const uint4*)(tile + 2u * pi);
+#if defined(RD_ST_PLAIN)
+            *(uint4*)(base + 2u * pi) = dv;
+#elif defined(RD_ST_WT)
+            stream_store16(base + 2u * pi, dv);
+#else
             __builtin_nontemporal_store(*(const nt_v4u*)&dv, (nt_v4u*)(base + 2u * pi));
+#endif
           }
         }
         if (lane == 0u && (tpar & 1u)) base[tpar] = tile[tpar];                   // head
