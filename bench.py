@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the c3 / c4 / ref lines at N = 1")
     ap.add_argument("--no-peak", action="store_true", help="skip the measured fill / copy ceiling")
+    ap.add_argument("--no-placement", action="store_true",
+                    help="plain allocations instead of the library's placement-aware allocator (nthip_malloc_probed)")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
     return ap.parse_args()
 
@@ -218,8 +220,27 @@ def var_reads(first_read, n_reads, len_min, len_max, seed=42):
     return lens, (x >> np.uint64(32)) % np.uint64(997) == 0, (x >> np.uint64(16)) % lens
 
 
+PLACE_CANDIDATES = 3  # nthip_malloc_probed: allocations measured per big buffer (1: plain allocation; --no-placement)
+
+
+class _DevView:
+    """__cuda_array_interface__ over a raw device pointer, so that torch can slice / copy a buffer the library allocated"""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
 class Workload:
     """Device-resident reads + output ring of one config on one rank."""
+
+    def _alloc(self, what, nbytes):
+        """The big buffers come from the library's placement-aware allocator: which pages hipMalloc hands out moves the
+        headline kernel by up to 15 % on this GPU (profiles/r02_notes.md 11); a pipeline would allocate its ring this way."""
+        ptr, gbps, tried = self.ctx.malloc_probed(nbytes, PLACE_CANDIDATES)
+        self.placement.append({"buffer": what, "GiB": round(nbytes / 2**30, 2), "fill_GBps": round(gbps, 1),
+                               "candidates_measured": tried})
+        self._owned.append(ptr)
+        return ptr
 
     def __init__(self, torch, ctx, dev, name, cfg, n_reads, first_read, chunk_reads=0):
         import nthash_amd
@@ -230,21 +251,24 @@ class Workload:
         self.nwin = L - k + 1
         self.per = m if cfg["seeds"] is None else len(cfg["seeds"]) * m
         self.var = None
+        self.placement, self._owned = [], []
         if cfg.get("lmin"):  # variable-length reads: spans [r*L, r*L + len_r) of the fixed-length buffer
             self._init_var(torch, ctx, dev, n_reads, first_read)
             return
         # launches per step: outputs larger than the free memory are produced chunk by chunk into one buffer
         free_b, _tot_b = torch.cuda.mem_get_info(dev)
         out_bytes_per_read = self.nwin * self.per * 8
-        budget = int(free_b * 0.85) - n_reads * L
+        # (with the placement probe two candidates of the ring must fit next to each other)
+        budget = int(free_b * (0.42 if PLACE_CANDIDATES > 1 else 0.85)) - n_reads * L
         chunk = chunk_reads or min(n_reads, max(1, budget // out_bytes_per_read))
         chunk = min(chunk, n_reads)
         if chunk < n_reads:  # keep chunks a multiple of the kernels' read tiles
             chunk = max(256, chunk // 256 * 256)
         self.chunk = chunk
         self.n_chunks = (n_reads + chunk - 1) // chunk
-        self.d_in = torch.empty(n_reads * L, dtype=torch.uint8, device=dev)
-        self.d_out = torch.empty(chunk * self.nwin * self.per, dtype=torch.int64, device=dev)
+        self.d_in = torch.as_tensor(_DevView(self._alloc("reads", n_reads * L), n_reads * L, "|u1"), device=dev)
+        n_out = chunk * self.nwin * self.per
+        self.d_out = torch.as_tensor(_DevView(self._alloc("hashes", n_out * 8), n_out, "<i8"), device=dev)
         ctx.synth_reads_ptr(self.d_in.data_ptr(), first_read, n_reads, L, 42)
         self.seeds = nthash_amd.Seeds(ctx, cfg["seeds"], k) if cfg["seeds"] else None
         torch.cuda.synchronize(dev)
@@ -259,13 +283,14 @@ class Workload:
         self.total_kmers = int(np.maximum(lens.astype(np.int64) - k + 1, 0).sum())
         self.total_bases = int(lens.sum())
         self.chunk, self.n_chunks = n_reads, 1
-        self.d_in = torch.empty(n_reads * L, dtype=torch.uint8, device=dev)
+        self.d_in = torch.as_tensor(_DevView(self._alloc("reads", n_reads * L), n_reads * L, "|u1"), device=dev)
         ctx.synth_reads_ptr(self.d_in.data_ptr(), first_read, n_reads, L, 42)
         idx = torch.from_numpy((starts + n_pos.astype(np.int64))[has_n]).to(dev)
         self.d_in[idx] = ord("N")
         self.d_starts = torch.from_numpy(starts).to(dev)
         self.d_ends = torch.from_numpy(ends).to(dev)
-        self.d_out = torch.empty(self.total_kmers * self.per, dtype=torch.int64, device=dev)
+        n_out = self.total_kmers * self.per
+        self.d_out = torch.as_tensor(_DevView(self._alloc("hashes", n_out * 8), n_out, "<i8"), device=dev)
         self.var = dict(lens=lens, has_n=has_n, n_pos=n_pos)
         self.seeds = None
         torch.cuda.synchronize(dev)
@@ -360,6 +385,10 @@ class Workload:
         if self.seeds is not None:
             self.seeds.close()
         self.d_in = self.d_out = self.d_starts = self.d_ends = None
+        self.torch.cuda.synchronize(self.dev)
+        for ptr in self._owned:
+            self.ctx.free(ptr)
+        self._owned = []
         self.torch.cuda.empty_cache()
 
 
@@ -367,22 +396,26 @@ def measured_peak(torch, ctx, dev):
     """Write-only and copy rates of this box, same process, same clock: the achievable ceilings next to the spec.
     (32 GiB per launch: an 8 GiB fill lasts 1.2 ms and measures 5.6 TB/s on a box whose 24 GiB fill runs at 7.0.)"""
     nbytes = 32 << 30
-    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    fill_ms = ctx.fill_bench_ptr(a.data_ptr(), nbytes, 5)
-    half = nbytes // 2
-    copy_ms = ctx.copy_bench_ptr(a.data_ptr() + half, a.data_ptr(), half, 5)
-    del a
-    torch.cuda.empty_cache()
+    ptr, _g, tried = ctx.malloc_probed(nbytes, PLACE_CANDIDATES)  # (the same allocator as the workload's buffers)
+    try:
+        fill_ms = ctx.fill_bench_ptr(ptr, nbytes, 5)
+        half = nbytes // 2
+        copy_ms = ctx.copy_bench_ptr(ptr + half, ptr, half, 5)
+    finally:
+        ctx.free(ptr)
     fill = nbytes / (fill_ms * 1e-3) / 1e9
     copy = 2 * half / (copy_ms * 1e-3) / 1e9
-    return {"fill_GBps": fill, "copy_GBps": copy, "best_GBps": max(fill, copy),
+    return {"fill_GBps": fill, "copy_GBps": copy, "best_GBps": max(fill, copy), "allocations_measured": tried,
             "how": "nthip_fill_bench (write-only, the kernels' copy-out pattern) on 32 GiB / nthip_copy_bench "
-                   "(50 % reads) on 16 GiB, best of 5, in this process; this kernel's own mix (13.5 % reads) with its "
-                   "hashing switched off reaches 5.8-5.9 TB/s (profiles/r02_notes.md)"}
+                   "(50 % reads) on 16 GiB, best of 5, in this process, on the fastest of the allocations measured; this "
+                   "kernel's own mix (13.5 % reads) with its hashing switched off reaches 5.8-5.9 TB/s (profiles/r02_notes.md)"}
 
 
 def main():
     args = parse()
+    global PLACE_CANDIDATES
+    if args.no_placement:
+        PLACE_CANDIDATES = 1
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     cfg = dict(CONFIGS[args.config])
@@ -499,7 +532,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "reads_per_gpu": n_reads, "read_len": L, "k": k,
                        "hashes_per_kmer": wl.per, "launches_per_step": wl.n_chunks, "input": "ASCII, device-resident",
-                       "parallelism": "reads sharded by rank, no data-path collective"},
+                       "parallelism": "reads sharded by rank, no data-path collective",
+                       "placement": {"allocator": "nthip_malloc_probed: up to %d allocations per buffer measured with the "
+                                                  "library's write-only fill, the fastest kept (rank 0's buffers shown)"
+                                                  % PLACE_CANDIDATES if PLACE_CANDIDATES > 1 else "plain hipMalloc",
+                                     "buffers": wl.placement}},
             "roofline": roof,
             "verify": verify,
             "verified_vs_oracle": bool(all_ok),
@@ -539,7 +576,8 @@ def main():
                                  "kernel": r2["kernel"], "kernel_ms_per_step": r2["kernel_avg_ms"] * w2.n_chunks,
                                  "bytes_per_kmer": r2["bytes_per_kmer"], "achieved_GBps": r2["achieved"],
                                  "frac": r2["frac"], "verify_ok": v2["ok"], "spot_vs_oracle": v2["spot_vs_oracle"],
-                                 "sum": v2["sum"], "xor": v2["xor"]}
+                                 "sum": v2["sum"], "xor": v2["xor"],
+                                 "placement_fill_GBps": [b["fill_GBps"] for b in w2.placement]}
                     if name == "var":
                         sec[name]["note"] = ("value = whole call (survey of the spans, mark pass, scan, hash pass, reads "
                                              "with an N); kernel / frac = the hash pass alone")

@@ -315,6 +315,12 @@ int nthip_copy_bench(nthip_ctx* ctx, void* d_dst, const void* d_src, size_t byte
                      float* best_ms);
 /* write-only rate: every wave instruction stores one contiguous KiB (the ceiling of a write-bound hash stream) */
 int nthip_fill_bench(nthip_ctx* ctx, void* d_dst, size_t bytes, int reps, float* best_ms);
+/* Placement-aware allocation for long-lived device buffers (a pipeline's hash stream): which pages hipMalloc hands out
+ * decides how fast a buffer streams on MI355X (the same fill: 5.6-7.1 TB/s over fresh allocations; the hash kernels follow
+ * it).  Up to `candidates` allocations are made and measured with nthip_fill_bench's write-only pattern, the fastest is
+ * returned (free it with nthip_free), the others are released.  *gbps (optional): its fill rate, *tried (optional): how
+ * many were measured.  The buffer's content is undefined.  Buffers under 64 MiB are allocated without a probe. */
+int nthip_malloc_probed(nthip_ctx* ctx, size_t bytes, int candidates, void** dptr, double* gbps, int* tried);
 
 #ifdef __cplusplus
 }

@@ -72,7 +72,7 @@ def _compile_unit(hipcc, unit, objdir, extra, force, verbose):
     r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
     kernels = _resource_usage(r.stderr)
     rest = "\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and not _REMARK_ECHO.match(l))
-    if rest.strip():
+    if r.returncode != 0 or "warning:" in rest or "error:" in rest:  # (include chains of the remarks alone are noise)
         print(rest, file=sys.stderr)
     if r.returncode != 0:
         raise subprocess.CalledProcessError(r.returncode, cmd)

@@ -36,7 +36,7 @@ SYMBOLS = [
     "nthip_seeds_destroy", "nthip_seed_hash", "nthip_kmer_extend", "nthip_kmer_bloom_insert",
     "nthip_kmer_bloom_query", "nthip_kmer_minhash", "nthip_stream_bloom_insert", "nthip_kmer_hash_spans", "nthip_fastx_index",
     "nthip_fastx_kmer_hash_file", "nthip_fastx_seed_hash_file", "nthip_seed_hash_spans", "nthip_fasta_compact", "nthip_synth_reads", "nthip_checksum",
-    "nthip_copy_bench", "nthip_fill_bench", "nthip_ctx_reload_tuning",
+    "nthip_copy_bench", "nthip_fill_bench", "nthip_malloc_probed", "nthip_ctx_reload_tuning",
     "nthip_multi_create", "nthip_multi_destroy", "nthip_multi_device_count", "nthip_multi_kmer_hash",
     "nthip_multi_seeds_create", "nthip_multi_seeds_destroy", "nthip_multi_seed_hash",
 ]
@@ -129,6 +129,7 @@ def load():
     L.nthip_copy_bench.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
     L.nthip_fill_bench.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
     L.nthip_ctx_reload_tuning.argtypes = [vp]
+    L.nthip_malloc_probed.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(vp), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.nthip_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.nthip_multi_destroy.argtypes = [vp]
     L.nthip_multi_device_count.argtypes = [vp, C.POINTER(C.c_int)]
@@ -424,6 +425,12 @@ class Context:
         ms = C.c_float(0)
         _chk(self.L.nthip_fill_bench(self.h, C.c_void_p(dst), nbytes, reps, C.byref(ms)))
         return ms.value
+
+    def malloc_probed(self, nbytes, candidates=3):
+        """placement-aware allocation (nthip_malloc_probed): -> (device pointer, fill rate in GB/s, candidates measured)"""
+        p, g, t = C.c_void_p(), C.c_double(0), C.c_int(0)
+        _chk(self.L.nthip_malloc_probed(self.h, nbytes, candidates, C.byref(p), C.byref(g), C.byref(t)))
+        return p.value, g.value, t.value
 
     def reload_tuning(self):
         """Re-read the NTHIP_TUNE_* environment knobs (they are read once, when the context is created)."""

@@ -1,6 +1,8 @@
 // capi_util.hip -- device scan, graph-extension query, measurement helpers
 // Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
 #include "capi_internal.hpp"
+
+#include <vector>
 #include "util_kernels.hpp"
 
 using namespace ntamd;
@@ -249,5 +251,60 @@ extern "C" int nthip_fill_bench(nthip_ctx* c, void* d_dst, size_t bytes, int rep
   }
   c->ev_valid = false;
   *best_ms = best;
+  return NTHIP_OK;
+}
+
+// Placement-aware allocation.  On MI355X the page set hipMalloc hands out decides how fast a buffer streams: the same
+// write-only fill runs at 5.6-7.1 TB/s over fresh allocations of one size in one process, the hash kernels follow it
+// (532-632 G k-mers/s on the headline shape), offsets inside an allocation and physically contiguous allocations do
+// not change it (profiles/r02_notes.md 11).  For a long-lived buffer -- the hash stream of a pipeline -- it pays to
+// look: up to `candidates` allocations are made (as many at a time as the free memory holds), each is filled once or
+// twice with the write-only yardstick, the fastest is kept and the others are freed.  The buffer's content is garbage.
+extern "C" int nthip_malloc_probed(nthip_ctx* c, size_t bytes, int candidates, void** out, double* gbps, int* tried)
+{
+  if (!c || !out) return fail(NTHIP_ERR_ARG, "ctx/dptr is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  *out = nullptr;
+  if (gbps) *gbps = 0;
+  if (tried) *tried = 0;
+  if (bytes < (size_t)(64u << 20) || candidates <= 1) { // nothing to measure on a small buffer
+    HIPCHK(hipMalloc(out, bytes ? bytes : 16));
+    if (tried) *tried = 1;
+    return NTHIP_OK;
+  }
+  void* best = nullptr;
+  float best_ms = 1e30f;
+  std::vector<void*> held; // candidates are kept until the end so that the next one gets other pages
+  int n = 0;
+  for (; n < candidates; ++n) {
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    if (free_b < bytes + ((size_t)2 << 30)) {
+      if (n == 0) return fail(NTHIP_ERR_HIP, "not enough device memory for %zu bytes", bytes);
+      // no room for another candidate next to the ones held: give the slower ones back and try once more
+      bool freed = false;
+      for (void*& p : held)
+        if (p && p != best) { (void)hipFree(p); p = nullptr; freed = true; }
+      if (!freed) break;
+      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      if (free_b < bytes + ((size_t)2 << 30)) break;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    held.push_back(p);
+    float ms = 0;
+    const int rc = nthip_fill_bench(c, p, bytes, 2, &ms);
+    if (rc != NTHIP_OK) {
+      for (void* q : held) if (q) (void)hipFree(q);
+      return rc;
+    }
+    if (ms < best_ms) { best_ms = ms; best = p; }
+  }
+  for (void* p : held)
+    if (p && p != best) (void)hipFree(p);
+  if (!best) return fail(NTHIP_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
+  *out = best;
+  if (gbps) *gbps = (double)bytes / (best_ms * 1e-3) / 1e9;
+  if (tried) *tried = n;
   return NTHIP_OK;
 }

@@ -1766,3 +1766,25 @@ def test_multi_device_shards_give_the_single_call_stream(oracle, devices):
     gots = mu.seed_hash(data, [SEED_A[:25], SEED_B[3:28]], 25, 2, fixed_len=L, n_reads=n, want_pos=True)
     assert gots["total"] == wants["total"] and (gots["hashes"] == wants["hashes"]).all() and (gots["pos"] == wants["pos"]).all()
     mu.close()
+
+
+def test_placement_aware_allocation(ctx):
+    """nthip_malloc_probed: several candidate allocations measured with the write-only fill, the fastest returned --
+    a usable buffer (hashing into it gives the usual stream), the rate reported, small buffers allocated without a probe"""
+    p, gbps, tried = ctx.malloc_probed(512 << 20, 3)
+    try:
+        assert p and tried >= 1 and 500 < gbps < 8000, (gbps, tried)
+        n, L, k = 2000, 150, 31
+        d_in = ctx.malloc(n * L)
+        ctx.synth_reads_ptr(d_in, 0, n, L, 42)
+        tot = ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, 1, p, n * 120)
+        s1 = ctx.checksum_ptr(p, tot)
+        q = ctx.malloc(n * 120 * 8)
+        ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, 1, q, n * 120)
+        assert tot == n * 120 and ctx.checksum_ptr(q, tot) == s1
+        ctx.free(q); ctx.free(d_in)
+    finally:
+        ctx.free(p)
+    p, gbps, tried = ctx.malloc_probed(1 << 20, 3)
+    assert p and tried == 1 and gbps == 0
+    ctx.free(p)
