@@ -236,7 +236,8 @@ class Workload:
     def _alloc(self, what, nbytes):
         """The big buffers come from the library's placement-aware allocator: which pages hipMalloc hands out moves the
         headline kernel by up to 15 % on this GPU (profiles/r02_notes.md 11); a pipeline would allocate its ring this way."""
-        ptr, gbps, tried = self.ctx.malloc_probed(nbytes, PLACE_CANDIDATES)
+        cands = PLACE_CANDIDATES if nbytes >= (48 << 30) or PLACE_CANDIDATES <= 1 else PLACE_CANDIDATES + 2
+        ptr, gbps, tried = self.ctx.malloc_probed(nbytes, cands)  # (small buffers: two more candidates cost a few ms)
         self.placement.append({"buffer": what, "GiB": round(nbytes / 2**30, 2), "fill_GBps": round(gbps, 1),
                                "candidates_measured": tried})
         self._owned.append(ptr)
@@ -396,7 +397,7 @@ def measured_peak(torch, ctx, dev):
     """Write-only and copy rates of this box, same process, same clock: the achievable ceilings next to the spec.
     (32 GiB per launch: an 8 GiB fill lasts 1.2 ms and measures 5.6 TB/s on a box whose 24 GiB fill runs at 7.0.)"""
     nbytes = 32 << 30
-    ptr, _g, tried = ctx.malloc_probed(nbytes, PLACE_CANDIDATES)  # (the same allocator as the workload's buffers)
+    ptr, _g, tried = ctx.malloc_probed(nbytes, PLACE_CANDIDATES + 2 if PLACE_CANDIDATES > 1 else 1)  # (as the workload's buffers)
     try:
         fill_ms = ctx.fill_bench_ptr(ptr, nbytes, 5)
         half = nbytes // 2
@@ -533,7 +534,7 @@ def main():
             "config": {"workload": workload, "reads_per_gpu": n_reads, "read_len": L, "k": k,
                        "hashes_per_kmer": wl.per, "launches_per_step": wl.n_chunks, "input": "ASCII, device-resident",
                        "parallelism": "reads sharded by rank, no data-path collective",
-                       "placement": {"allocator": "nthip_malloc_probed: up to %d allocations per buffer measured with the "
+                       "placement": {"allocator": "nthip_malloc_probed: up to %d allocations per buffer (two more under 48 GiB) measured with the "
                                                   "library's write-only fill, the fastest kept (rank 0's buffers shown)"
                                                   % PLACE_CANDIDATES if PLACE_CANDIDATES > 1 else "plain hipMalloc",
                                      "buffers": wl.placement}},
