@@ -279,8 +279,7 @@ extern "C" int nthip_malloc_probed(nthip_ctx* c, size_t bytes, int candidates, v
   for (; n < candidates; ++n) {
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    if (free_b < bytes + ((size_t)2 << 30)) {
-      if (n == 0) return fail(NTHIP_ERR_HIP, "not enough device memory for %zu bytes", bytes);
+    if (n > 0 && free_b < bytes + ((size_t)2 << 30)) {
       // no room for another candidate next to the ones held: give the slower ones back and try once more
       bool freed = false;
       for (void*& p : held)
@@ -290,7 +289,11 @@ extern "C" int nthip_malloc_probed(nthip_ctx* c, size_t bytes, int candidates, v
       if (free_b < bytes + ((size_t)2 << 30)) break;
     }
     void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      if (n == 0) return fail(NTHIP_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
+      break;
+    }
     held.push_back(p);
     float ms = 0;
     const int rc = nthip_fill_bench(c, p, bytes, 2, &ms);
