@@ -48,8 +48,13 @@ if os.environ.get("ABLATE_SEEDS"):  # "1": the two bench seeds; otherwise a comm
 per = m * (len(SEEDS) if SEEDS else 1)
 seeds = {name: (mod.Seeds(c, SEEDS, k) if SEEDS else None) for name, mod, c in ctxs}
 c0 = ctxs[0][2]
-d_in = c0.malloc(n * L)
-d_out = c0.malloc(n * nwin * per * 8)
+if os.environ.get("AB_PROBED"):  # buffers from the placement-aware allocator (fast page sets)
+    d_in, g_in, _ = c0.malloc_probed(n * L, 5)
+    d_out, g_out, _ = c0.malloc_probed(n * nwin * per * 8, 3)
+    print(f"probed buffers: reads {g_in:.0f} GB/s fill, hashes {g_out:.0f} GB/s fill", flush=True)
+else:
+    d_in = c0.malloc(n * L)
+    d_out = c0.malloc(n * nwin * per * 8)
 c0.synth_reads_ptr(d_in, 0, n, L, 42)
 res = {name: [] for name, _, _ in ctxs}
 kern = {}
