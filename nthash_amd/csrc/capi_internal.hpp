@@ -281,7 +281,7 @@ int run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
                    const ReadsShape* shape);
 int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
                     uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled,
-                    const ReadsShape* shape = nullptr);
+                    const ReadsShape* shape = nullptr, bool checked = true);
 // capi_kmer_general.hip
 int run_kmer_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m,
                      uint64_t capacity, uint64_t* total);

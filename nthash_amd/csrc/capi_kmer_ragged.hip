@@ -33,12 +33,14 @@ int launch_kmer_ragged(nthip_ctx* c, int mode, const KmerRaggedArgs& a, size_t d
 // reads = spans [starts[r], ends[r]) of the device buffer st.seqs (total_bytes long)
 int ntamd::host::run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
                     uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled,
-                    const ReadsShape* shape)
+                    const ReadsShape* shape, bool checked)
 {
   *handled = false;
   // short reads in order (every offsets batch, the sequence lines of a FASTQ chunk): tiles of whole reads
   NTCHK(run_kmer_reads(c, st, d_starts, d_ends, n_reads, total_bytes, k, m, capacity, total, handled, shape));
   if (*handled) return NTHIP_OK;
+  // (the short-read path validates the spans in its own survey pass; this one trusts them: one pass first, unless the caller did)
+  if (!checked) NTCHK(check_offsets_device(c, d_starts, d_ends, n_reads, total_bytes, false));
   const uint32_t C = 15; // run length; the last run of a read may be shorter
   const uint64_t n = n_reads;
   const uint32_t nw = kmer_nw(k);

@@ -36,7 +36,6 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
                                 uint64_t* total, bool* handled, const ReadsShape* shape)
 {
   *handled = false;
-  (void)total_bytes;
   if (c->tune.no_kmer_reads || n_reads == 0) return NTHIP_OK;
   const uint64_t n = n_reads;
   // ---- shape of the batch: longest read, largest distance between starts, order ----
@@ -51,7 +50,7 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   } else {
     uint64_t blocks = (n + 255) / 256;
     if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
-    hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n, d_res);
+    hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n, total_bytes, d_res);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_small + 96, d_res, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -31,13 +31,14 @@ extern "C" int nthip_kmer_hash_spans(nthip_ctx* c, const char* d_buf, uint64_t b
   HIPCHK(hipSetDevice(c->device));
   if (total_out) *total_out = 0;
   if (n_reads == 0) return NTHIP_OK;
-  NTCHK(check_offsets_device(c, d_starts, d_ends, n_reads, buf_bytes, false)); // spans inside the buffer, start <= end
   Staged st;
   st.seqs = (const uint8_t*)d_buf;
   NTCHK(stage_outputs(c, out, flags, n_reads, m, st));
   uint64_t total = 0;
   bool handled = false;
-  int rc = run_kmer_ragged(c, st, d_starts, d_ends, n_reads, buf_bytes, k, m, out->capacity, &total, &handled);
+  // (spans inside the buffer, start <= end: checked by the path that takes them, before anything is read through them)
+  int rc = run_kmer_ragged(c, st, d_starts, d_ends, n_reads, buf_bytes, k, m, out->capacity, &total, &handled, nullptr,
+                           /*checked*/ false);
   if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
   NTCHK(rc);
   if (!handled) return fail(NTHIP_ERR_UNSUPPORTED, "shape outside the run-split ragged kernel");

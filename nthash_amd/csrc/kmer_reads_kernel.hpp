@@ -553,13 +553,13 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
 // max length, max distance between consecutive starts, order, total length: what the host needs to size the tiles
 static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* __restrict__ starts,
                                                                 const uint64_t* __restrict__ ends, uint64_t n,
-                                                                unsigned long long* __restrict__ res)
+                                                                uint64_t buf_bytes, unsigned long long* __restrict__ res)
 {
   uint64_t mlen = 0, mpitch = 0, slen = 0;
   uint32_t bad = 0;
   for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t s0 = starts[r], e0 = ends[r];
-    if (e0 < s0) { bad = 1; continue; }
+    if (e0 < s0 || e0 > buf_bytes) { bad = 1; continue; } // (also what check_spans_kernel looks for)
     if (e0 - s0 > mlen) mlen = e0 - s0;
     slen += e0 - s0;
     if (r + 1 < n) {

@@ -1,5 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "golden_synth or fixed_vs_oracle or properties" 2>&1 | tail -2
-NTHIP_TUNE_L2PF_TILES=8 timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "golden_synth or fixed_vs_oracle or properties" 2>&1 | tail -2
-AB_PROBED=1 ABLATE_SHAPE=150,31,1 python tools/ab_multi.py ":NTHIP_TUNE_L2PF_TILES=4,:NTHIP_TUNE_L2PF_TILES=8,:NTHIP_TUNE_L2PF_TILES=16,:NTHIP_TUNE_L2PF_TILES=32,nohash,nohash:NTHIP_TUNE_L2PF_TILES=8,nohash:NTHIP_TUNE_L2PF_TILES=16" 100000000 8 | cut -c1-125
+timeout 900 python -m pytest tests -q -m gpu -x -k "bad_offsets or spans or fastx or fastq or whole_read or seed_whole" 2>&1 | tail -3
+python bench.py --config var --steps 10 --warmup 3 --no-cpu-baseline --no-peak 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e9,1), d['ms_per_step'], d['verify']['ok'])"
