@@ -237,8 +237,11 @@ class Workload:
         """The big buffers come from the library's placement-aware allocator: which pages hipMalloc hands out moves the
         headline kernel by up to 15 % on this GPU (profiles/r02_notes.md 11); a pipeline would allocate its ring this way."""
         cands = PLACE_CANDIDATES if nbytes >= (48 << 30) or PLACE_CANDIDATES <= 1 else PLACE_CANDIDATES + 2
+        free_b, _tot = self.torch.cuda.mem_get_info(self.dev)
+        if nbytes > 0.45 * free_b:
+            cands = 1  # no room for a second candidate
         ptr, gbps, tried = self.ctx.malloc_probed(nbytes, cands)  # (small buffers: two more candidates cost a few ms)
-        self.placement.append({"buffer": what, "GiB": round(nbytes / 2**30, 2), "fill_GBps": round(gbps, 1),
+        self.placement.append({"buffer": what, "GiB": round(nbytes / 2**30, 2), "fill_GBps": round(gbps, 1) if gbps else None,
                                "candidates_measured": tried})
         self._owned.append(ptr)
         return ptr
@@ -259,8 +262,8 @@ class Workload:
         # launches per step: outputs larger than the free memory are produced chunk by chunk into one buffer
         free_b, _tot_b = torch.cuda.mem_get_info(dev)
         out_bytes_per_read = self.nwin * self.per * 8
-        # (with the placement probe two candidates of the ring must fit next to each other)
-        budget = int(free_b * (0.42 if PLACE_CANDIDATES > 1 else 0.85)) - n_reads * L
+        # (a ring that takes most of the memory cannot be probed -- and need not be: it contains every page set there is)
+        budget = int(free_b * 0.85) - n_reads * L
         chunk = chunk_reads or min(n_reads, max(1, budget // out_bytes_per_read))
         chunk = min(chunk, n_reads)
         if chunk < n_reads:  # keep chunks a multiple of the kernels' read tiles
