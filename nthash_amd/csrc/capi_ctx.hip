@@ -247,6 +247,7 @@ void load_tuning(nthip_tune& t)
   t.no_seed_rot = is_one("NTHIP_TUNE_NO_SEED_ROT");
   t.no_kmer_reads = is_one("NTHIP_TUNE_NO_KMER_READS");
   t.no_seed_reads = is_one("NTHIP_TUNE_NO_SEED_READS");
+  t.no_seed_align = is_one("NTHIP_TUNE_NO_SEED_ALIGN");
   t.no_any_k_runs = is_one("NTHIP_TUNE_NO_ANY_K_RUNS");
   t.reads_run_len = num("NTHIP_TUNE_READS_RUN_LEN", 2, 16);
   t.reads_per_tile = num("NTHIP_TUNE_READS_PER_TILE", 1, 64);

@@ -80,6 +80,7 @@ struct nthip_tune {
   bool no_seed_wave = false; // NTHIP_TUNE_NO_SEED_WAVE (set)
   bool no_seed_wtile = false; // NTHIP_TUNE_NO_SEED_WTILE=1: the block-tile dense seed kernel instead of the wave-tile one
   bool no_any_k_runs = false; // NTHIP_TUNE_NO_ANY_K_RUNS=1: only the k = 31 / run length 15, 30 instantiations of kmer_runs_kernel
+  bool no_seed_align = false; // NTHIP_TUNE_NO_SEED_ALIGN=1: seed_rtile_kernel's groups end anywhere (A/B)
   bool no_seed_reads = false; // NTHIP_TUNE_NO_SEED_READS=1: variable-length reads of SeedNtHash on seed_wave_kernel only
   bool no_kmer_reads = false; // NTHIP_TUNE_NO_KMER_READS=1: variable-length reads on kmer_ragged_kernel only
   uint32_t reads_run_len = 0, reads_per_tile = 0, reads_waves = 0; // NTHIP_TUNE_READS_RUN_LEN / _PER_TILE / _WAVES (kmer_reads_kernel)

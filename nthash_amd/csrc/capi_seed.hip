@@ -274,6 +274,11 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
   ra.otile_recs = otile_recs;
   ra.wmap_dwords = wmap_dwords;
   ra.waves = waves;
+  {
+    uint32_t g = per, h = 16;
+    while (h) { const uint32_t t2 = g % h; g = h; h = t2; } // gcd(per, 16)
+    ra.align_recs = c->tune.no_seed_align ? 1u : 16u / g;
+  }
   for (uint32_t i = 0; i < (uint32_t)SF_MAX_RUNTIME_M; ++i) ra.mult[i] = multiplier(k, i);
   const size_t lds = table_bytes + per_wave * waves;
   auto go = [&](auto kernel) -> int {

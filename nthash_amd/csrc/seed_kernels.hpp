@@ -641,6 +641,7 @@ struct SeedRtileArgs {
   uint64_t n_reads, n_tiles;
   uint32_t R, k, m2, n_seeds, ntab;
   uint32_t bits_dwords, otile_recs, wmap_dwords, waves;
+  uint32_t align_recs;      // records after which the stream is on a 128-byte line again: 16 / gcd(values per record, 16)
   uint64_t mult[SF_MAX_RUNTIME_M];
 };
 
@@ -664,11 +665,9 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
   uint32_t* wbase = lds_dyn + n_entries * 4u + wave * per_wave;
   uint64_t* otile = (uint64_t*)wbase;
   uint32_t* bits = wbase + otile_u64 * 2u;
-  uint32_t* rt_wbeg = bits + a.bits_dwords;
-  uint32_t* rt_wend = rt_wbeg + RT;
-  uint32_t* rt_sb = rt_wend + RT;
-  uint32_t* rt_out = rt_sb + RT;
-  uint8_t* wmap = (uint8_t*)(rt_out + RT); // windows [16c, 16c + 16) of the tile: the read that holds window 16c
+  // read table: one 16-byte entry per read {first window, last window + 1, first base, first record} -- one LDS read
+  uint4* rt = (uint4*)(bits + a.bits_dwords);
+  uint8_t* wmap = (uint8_t*)(rt + RT); // windows [16c, 16c + 16) of the tile: the read that holds window 16c
   if constexpr (ROT) {
     for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
       const uint32_t e = i >> 4, v = i & 15u, jt = v & 7u, sd = (v >> 3) < (uint32_t)RNS ? (v >> 3) : (uint32_t)RNS - 1u;
@@ -741,10 +740,8 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
     const uint32_t nwin_j = (!listed && len_j >= k) ? (uint32_t)(len_j - k + 1u) : 0u;
     const uint32_t wend = wave_incl_scan32(nwin_j), wbeg = wend - nwin_j;
     if (lane < RT) {
-      rt_wbeg[lane] = wbeg;
-      rt_wend[lane] = has ? wend : 0xFFFFFFFFu; // (the walk below stops at the latest on the entry after the tile's reads)
-      rt_sb[lane] = shift + (uint32_t)(s_j - slab0);
-      rt_out[lane] = (uint32_t)(ro_j - ro_0);
+      // (y = ~0 past the tile's reads: the walk below stops there at the latest)
+      rt[lane] = make_uint4(wbeg, has ? wend : 0xFFFFFFFFu, shift + (uint32_t)(s_j - slab0), (uint32_t)(ro_j - ro_0));
     }
     const uint32_t W = (uint32_t)__shfl((int)wend, 63, 64);
     for (uint32_t c = (wbeg + 15u) >> 4; (c << 4) < wend; ++c) wmap[c] = (uint8_t)lane; // (nothing for a read without windows)
@@ -755,14 +752,24 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
       const bool live = q < W;
       const uint32_t qq = live ? q : q0;
       uint32_t j = wmap[qq >> 4];
-      while (qq >= rt_wend[j]) ++j; // reads that start inside this chunk of 16 windows
-      const uint32_t p = qq - rt_wbeg[j];
-      const uint32_t b = rt_sb[j] + p;
-      const uint32_t oslot = rt_out[j] + p;
+      // the chunk's first read or, usually at most, the one after it: both entries in flight at once
+      uint4 ent = rt[j];
+      {
+        const uint4 ent1 = rt[j + 1u < RT ? j + 1u : j];
+        if (qq >= ent.y) { ent = ent1; ++j; }
+      }
+      while (qq >= ent.y) ent = rt[++j]; // (several short reads inside one chunk of 16 windows)
+      const uint32_t p = qq - ent.x;
+      const uint32_t b = ent.z + p;
+      const uint32_t oslot = ent.w + p;
       const uint32_t gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)oslot);
       const uint32_t slot = oslot - gbase;
       // (a listed read between two clean ones leaves a hole; windows past the tile's capacity wait for the next group)
-      const bool fits = live && slot < a.otile_recs;
+      // A group ends where a 128-byte line of the stream ends (every `align_recs` records: 8 for 48-byte records), so that
+      // the groups after the tile's first start on a line: their write-through stores then cover whole lines only
+      const uint64_t g_first = ro_0 + gbase;
+      const uint32_t cut = (uint32_t)(((g_first + 64u) / a.align_recs) * a.align_recs - g_first); // in (64 - align, 64]
+      const bool fits = live && slot < a.otile_recs && slot < cut;
       const uint32_t nl = (uint32_t)__builtin_popcountll(__ballot(fits));
       const bool act = lane < nl;
       const uint32_t span = (uint32_t)__shfl((int)slot, (int)(nl - 1u), 64) + 1u;
