@@ -1,4 +1,4 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"
-python tools/ragged_seed_bench.py 2>&1 | tail -2
-timeout 200 python tools/stress_seeds.py 400 555 2>&1 | tail -1
+# scratch script for one gpurun call
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r02
+timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -4
