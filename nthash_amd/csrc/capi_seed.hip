@@ -479,6 +479,11 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
   a.bits_dwords = bits_dwords;
   a.waves = waves;
   a.groups = c->tune.has_tile_map ? c->tune.tile_map : 32u; // (in process: 32 / 64 groups 0.2-0.4 % ahead of one range per block)
+  {
+    uint32_t g = per, h = 16;
+    while (h) { const uint32_t t2 = g % h; g = h; h = t2; } // gcd(per, 16)
+    a.align_recs = c->tune.no_seed_align ? 1u : 16u / g;
+  }
   memcpy(a.mult, f.mult, sizeof a.mult);
   const size_t lds = table_bytes + per_wave * waves;
   auto go = [&](auto kernel) -> int {

@@ -331,6 +331,7 @@ struct SeedWtileArgs {
   uint32_t bits_dwords;  // per wave
   uint32_t waves;        // per block
   uint32_t groups;       // tile_range(): groups of blocks sharing a range of tiles (0: one range per block)
+  uint32_t align_recs;   // records after which the stream is on a 128-byte line again: 16 / gcd(values per record, 16)
   uint64_t mult[SF_MAX_RUNTIME_M];
 };
 
@@ -485,9 +486,13 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
     const uint32_t n_win_tile = cur.reads_here * a.nwin;
     const uint64_t rec0 = t * R * (uint64_t)a.nwin; // first window of the tile in the stream
     uint32_t n_stores = 0;
-    for (uint32_t q0 = 0; q0 < n_win_tile; q0 += 64u) {
+    // a tile whose first record does not start a 128-byte line of the stream (window counts the tile geometry could not
+    // make whole KiB of): its first group ends where a line ends, so that the other groups' write-through stores cover
+    // whole lines (seed_rtile_kernel does the same; partial lines cost that policy a third of its rate)
+    uint32_t g_size = (uint32_t)(((rec0 + 64u) / a.align_recs) * a.align_recs - rec0); // in (64 - align, 64]
+    for (uint32_t q0 = 0; q0 < n_win_tile; q0 += g_size, g_size = 64u) {
       const uint32_t q = q0 + lane;
-      const bool live = q < n_win_tile;
+      const bool live = q < n_win_tile && lane < g_size;
       const uint32_t qq = live ? q : q0;
       uint32_t lr = a.nwin == 1u ? qq : __umulhi(qq, a.inv_nwin); // qq -> (read, window)
       if (lr * a.nwin > qq) lr--;
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
       }
 #endif
       lds_sync();
-      const uint32_t n_here = (n_win_tile - q0) < 64u ? (n_win_tile - q0) : 64u;
+      const uint32_t n_here = (n_win_tile - q0) < g_size ? (n_win_tile - q0) : g_size;
       const uint32_t n_vals = n_here * per;
       uint64_t* const base = dst - par; // 16-byte aligned; value i of the shifted tile goes to base[i]
       const uint32_t span = par + n_vals;
