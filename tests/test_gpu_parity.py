@@ -583,6 +583,8 @@ def test_seed_wave_tile_kernel_shapes_vs_oracle(ctx, oracle):
     import nthash_amd
     rng = np.random.default_rng(4242)
     for (n, L, stride, seeds, m2) in [(1, 250, 0, [SEED_A, SEED_B], 3), (17, 250, 0, [SEED_A, SEED_B], 3),
+                                      (5003, 151, 0, [SEED_A, SEED_B], 3),   # 121 windows: tiles that start between lines
+                                      (2501, 101, 0, [SEED_B], 3), (1999, 77, 0, [SEED_A[:21]], 1),
                                       (1000, 250, 0, [SEED_A, SEED_B], 3), (4099, 100, 0, ["1101011"], 2),
                                       (3001, 151, 0, ["1" * 20 + "0" * 9 + "1" * 20], 1),
                                       (777, 64, 0, ["1" * 64], 4), (513, 300, 41, ["10101", "11011", "01110"], 2),
