@@ -545,11 +545,13 @@ int launch_seed_fixed(nthip_ctx* c, K kernel, const SeedFixedArgs& a, size_t dyn
 
 } // namespace
 
-extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, uint8_t m28,
+extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nthip_seeds* sd, uint8_t m28,
                                const nthip_out* out, uint64_t* total_out, uint32_t flags)
 {
   if (!c || !sd) return fail(NTHIP_ERR_ARG, "ctx/seeds is NULL");
-  NTCHK(check_reads(rd));
+  NTCHK(check_reads(rd_in));
+  nthip_reads eff = *rd_in; // what the paths below see: offsets of equal-length, back-to-back reads become a fixed length
+  const nthip_reads* rd = &eff;
   if (!out || !out->hashes) return fail(NTHIP_ERR_ARG, "out->hashes is NULL");
   const uint32_t m2 = m28, k = sd->k;
   if (m2 == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes_per_seed must be >= 1");
@@ -565,6 +567,23 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd, const nthip_
   Staged st;
   NTCHK(stage_inputs(c, rd, flags, total_bytes, st));
   NTCHK(stage_outputs(c, out, flags, rd->n_reads, per, st, sd->n_seeds));
+
+  // offsets: one pass over them before anything trusts them (order, bounds), and reads that all have one length and
+  // lie back to back are a fixed-length batch (as in nthip_kmer_hash): the dense kernel instead of the variable-length path
+  if (st.offsets) {
+    OffsetsSurvey sv;
+    NTCHK(offsets_survey_device(c, st.offsets, rd->n_reads, total_bytes, &sv));
+    if (sv.bad) return fail(NTHIP_ERR_ARG, "offsets / spans are not non-decreasing or reach outside the read buffer");
+    if (sv.uniform && !(flags & NTHIP_FORCE_GENERAL) && rd->n_reads >= 1024 && sv.len0 >= 1 && sv.len0 < (1ull << 30) &&
+        sv.off0 + rd->n_reads * sv.len0 <= total_bytes) {
+      st.seqs += sv.off0;
+      st.offsets = nullptr;
+      eff.offsets = nullptr;
+      eff.fixed_len = (uint32_t)sv.len0;
+      eff.stride = 0;
+      total_bytes = rd->n_reads * sv.len0;
+    }
+  }
 
   const uint32_t len = rd->fixed_len;
   const uint32_t stride = rd->stride ? rd->stride : len;

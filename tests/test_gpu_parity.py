@@ -1790,3 +1790,25 @@ def test_placement_aware_allocation(ctx):
     p, gbps, tried = ctx.malloc_probed(1 << 20, 3)
     assert p and tried == 1 and gbps == 0
     ctx.free(p)
+
+
+def test_seed_offsets_are_surveyed(ctx, oracle):
+    """nthip_seed_hash with offsets: reads that all have one length and lie back to back take the dense kernel (as in
+    nthip_kmer_hash), offsets that decrease are refused instead of being read through"""
+    import nthash_amd
+    n, L, k, m2 = 3000, 150, 31, 3
+    data = oracle.synth_reads(2, n, L, 7)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.seed_batch(data, offs, [SEED_A, SEED_B], k, m2)
+    ctx.set_profiling(True)
+    got = ctx.seed_hash(data, [SEED_A, SEED_B], k, m2, offsets=offs, want_pos=True)
+    name = ctx.last_kernel_ms()[1]
+    ctx.set_profiling(False)
+    assert name == "seed_wtile_kernel", name
+    assert got["total"] == want["total"] and (got["hashes"] == want["hashes"]).all()
+    assert (got["pos"] == want["pos"]).all() and (got["counts"] == want["counts"]).all()
+    bad = offs.copy()
+    bad[1500] = 10
+    with pytest.raises(nthash_amd.NtHipError) as e:
+        ctx.seed_hash(data, [SEED_A, SEED_B], k, m2, offsets=bad)
+    assert e.value.code == nthash_amd.capi.NTHIP_ERR_ARG
