@@ -1812,3 +1812,23 @@ def test_seed_offsets_are_surveyed(ctx, oracle):
     with pytest.raises(nthash_amd.NtHipError) as e:
         ctx.seed_hash(data, [SEED_A, SEED_B], k, m2, offsets=bad)
     assert e.value.code == nthash_amd.capi.NTHIP_ERR_ARG
+
+
+def test_kmer_whole_read_tiles_many_hashes(ctx, oracle):
+    """the whole-read-tile path with more hashes per k-mer than the multiplier table of the fixed kernels holds (m = 20,
+    m = 255: the multipliers are computed), positions included"""
+    rng = np.random.default_rng(9)
+    alph = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+    for k, m in ((31, 20), (17, 255), (40, 9)):
+        reads = [alph[rng.integers(0, len(alph) - (0 if rng.random() < 0.1 else 1), int(rng.integers(0, 200)))].tobytes()
+                 for _ in range(300)]
+        d, offs = concat_reads(reads)
+        want = oracle.kmer_batch(d, offs, k, m)
+        ctx.set_profiling(True)
+        got = ctx.kmer_hash(d, k, m, offsets=offs, want_pos=True)
+        name = ctx.last_kernel_ms()[1]
+        ctx.set_profiling(False)
+        assert name == "kmer_reads_kernel", name
+        assert got["total"] == want["total"]
+        for key in ("counts", "pos", "hashes"):
+            assert (got[key] == want[key]).all(), (k, m, key)

@@ -1,4 +1,3 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests -q -m gpu -x -k "seed or fastx or fastq" 2>&1 | tail -3
-timeout 200 python tools/stress_seeds.py 300 8 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "many_hashes" 2>&1 | tail -8
