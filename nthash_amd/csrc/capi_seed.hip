@@ -450,28 +450,50 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
   const uint64_t slab = 15ull + (uint64_t)(R - 1) * f.stride + f.len;
   if (slab > SW_MAX_VEC_ROUNDS * 1024ull || (uint64_t)R * f.nwin >= 0x7FFFFFFFull) return NTHIP_OK;
   const uint32_t bits_dwords = (uint32_t)((((slab + 15) >> 4) + 8 + 3) & ~3ull);
-  // one or two seeds of k <= 32 bases, few hashes per seed: the rotated-slot table layout (no LDS bank conflicts)
-  const bool rot = !c->tune.no_seed_rot && f.n_seeds <= 2 && f.k <= 32 && f.m2 <= 4;
-  const size_t table_bytes = rot ? 65536 : (size_t)f.n_seeds * 2 * nh * 256 * sizeof(uint4);
-  const size_t per_wave = (size_t)(64 * per + 2) * 8 + (size_t)bits_dwords * 4;
   const size_t cap = lds_cap_of(c);
-  uint32_t waves = 0;
-  for (uint32_t w = c->tune.seed_waves ? c->tune.seed_waves & ~3u : 16u; w >= 4; w -= 4)
-    if (table_bytes + per_wave * w <= cap) { waves = w; break; }
+  // ---- passes.  The byte tables of a pass live in LDS: 8 KiB x nh per seed in the plain layout, 64 KiB for one or two
+  // seeds of k <= 32 bases in the rotated-slot layout (no LDS bank conflicts; few hashes per seed).  A seed set that
+  // fits whole, even with only 4 waves beside it, is ONE pass writing whole records; a larger one is hashed a few seeds
+  // at a time, every pass writing its part of each record -- 8-byte pieces with gaps, which HBM takes at 0.9-1.4 TB/s
+  // against 2.6-5 TB/s for whole records (tools/seed_sweep.py; 4 seeds x 2 hashes, k = 31: 40.7 G k-mers/s in one pass of
+  // 4 waves, 21.4 G as two rotated-slot passes), so as few passes as possible. ----
+  const bool rot_ok = !c->tune.no_seed_rot && f.k <= 32 && f.m2 <= 4;
+  auto per_wave_of = [&](uint32_t seeds_here) { return (size_t)(64 * seeds_here * f.m2 + 2) * 8 + (size_t)bits_dwords * 4; };
+  auto plain_bytes = [&](uint32_t seeds_here) { return (size_t)seeds_here * 2 * nh * 256 * sizeof(uint4); };
+  auto waves_for = [&](size_t table_bytes, uint32_t seeds_here) -> uint32_t {
+    for (uint32_t w = c->tune.seed_waves ? c->tune.seed_waves & ~3u : 16u; w >= 4; w -= 4)
+      if (table_bytes + per_wave_of(seeds_here) * w <= cap) return w;
+    return 0;
+  };
+  uint32_t pass_seeds; // seeds per pass
+  bool rot;
+  if (c->tune.seed_pass) {
+    pass_seeds = c->tune.seed_pass < f.n_seeds ? c->tune.seed_pass : f.n_seeds;
+    rot = rot_ok && pass_seeds <= 2;
+  } else if (rot_ok && f.n_seeds <= 2) {
+    pass_seeds = f.n_seeds;
+    rot = true;
+  } else {
+    rot = false;
+    uint32_t most = f.n_seeds; // the most seeds whose tables fit beside 4 waves
+    while (most > 1 && waves_for(plain_bytes(most), most) == 0) --most;
+    const uint32_t passes = (f.n_seeds + most - 1) / most;
+    pass_seeds = (f.n_seeds + passes - 1) / passes;
+  }
+  const size_t table_bytes = rot ? 65536 : (size_t)pass_seeds * 2 * nh * 256 * sizeof(uint4);
+  const uint32_t waves = waves_for(table_bytes, pass_seeds);
   if (!waves) return NTHIP_OK;
   SeedWtileArgs a;
   memset(&a, 0, sizeof a);
   a.seqs = f.seqs;
   a.hashes = f.hashes;
   a.dirty = f.dirty;
-  a.tables = f.tables;
   a.n_reads = f.n_runs;
   a.n_tiles = (f.n_runs + R - 1) / R;
   a.len = f.len;
   a.stride = f.stride;
   a.k = f.k;
   a.m2 = f.m2;
-  a.n_seeds = f.n_seeds;
   a.ntab = f.ntab;
   a.nwin = f.nwin;
   a.reads_per_tile = R;
@@ -479,52 +501,63 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
   a.bits_dwords = bits_dwords;
   a.waves = waves;
   a.groups = c->tune.has_tile_map ? c->tune.tile_map : 32u; // (in process: 32 / 64 groups 0.2-0.4 % ahead of one range per block)
-  {
-    uint32_t g = per, h = 16;
-    while (h) { const uint32_t t2 = g % h; g = h; h = t2; } // gcd(per, 16)
-    a.align_recs = c->tune.no_seed_align ? 1u : 16u / g;
-  }
   memcpy(a.mult, f.mult, sizeof a.mult);
-  const size_t lds = table_bytes + per_wave * waves;
-  auto go = [&](auto kernel) -> int {
-    int per_cu = 1;
-    NTCHK(blocks_per_cu(c, kernel, (int)waves * 64, lds, &per_cu));
-    const uint64_t need = (a.n_tiles + waves - 1) / waves;
-    uint64_t grid = (uint64_t)c->n_cu * per_cu;
-    if (grid > need) grid = need;
-    prof_begin(c, "seed_wtile_kernel");
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream, a);
-    prof_end(c);
-    HIPCHK(hipGetLastError());
-    return NTHIP_OK;
-  };
-  int rc;
-  if (rot) {
-    switch (f.n_seeds * 8 + f.m2) {
-      case 8 + 1: rc = go(seed_wtile_kernel<4, 1, 1>); break;
-      case 8 + 2: rc = go(seed_wtile_kernel<4, 1, 2>); break;
-      case 8 + 3: rc = go(seed_wtile_kernel<4, 1, 3>); break;
-      case 8 + 4: rc = go(seed_wtile_kernel<4, 1, 4>); break;
-      case 16 + 1: rc = go(seed_wtile_kernel<4, 2, 1>); break;
-      case 16 + 2: rc = go(seed_wtile_kernel<4, 2, 2>); break;
-      case 16 + 3: rc = go(seed_wtile_kernel<4, 2, 3>); break;
-      default: rc = go(seed_wtile_kernel<4, 2, 4>); break;
+  for (uint32_t s0 = 0; s0 < f.n_seeds; s0 += pass_seeds) {
+    const uint32_t ns = f.n_seeds - s0 < pass_seeds ? f.n_seeds - s0 : pass_seeds;
+    const uint32_t per_here = ns * f.m2;
+    a.n_seeds = ns;
+    a.tables = f.tables + (size_t)s0 * f.ntab * 256;
+    if (ns == f.n_seeds) { // whole records
+      a.rec_stride = 0;
+      a.rec_off = 0;
+      uint32_t g = per_here, h = 16;
+      while (h) { const uint32_t t2 = g % h; g = h; h = t2; } // gcd(per, 16)
+      a.align_recs = c->tune.no_seed_align ? 1u : 16u / g;
+    } else {
+      a.rec_stride = per;
+      a.rec_off = s0 * f.m2;
+      a.align_recs = 1;
+    }
+    a.inv_per = 65536u / per_here + 1u;
+    const size_t lds = table_bytes + per_wave_of(ns) * waves;
+    auto go = [&](auto kernel) -> int {
+      int per_cu = 1;
+      NTCHK(blocks_per_cu(c, kernel, (int)waves * 64, lds, &per_cu));
+      const uint64_t need = (a.n_tiles + waves - 1) / waves;
+      uint64_t grid = (uint64_t)c->n_cu * per_cu;
+      if (grid > need) grid = need;
+      if (s0 == 0) prof_begin(c, "seed_wtile_kernel"); // (all passes in one measurement)
+      hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream, a);
+      prof_end(c);
+      HIPCHK(hipGetLastError());
+      return NTHIP_OK;
+    };
+    int rc;
+    if (rot) {
+      switch (ns * 8 + f.m2) {
+        case 8 + 1: rc = go(seed_wtile_kernel<4, 1, 1>); break;
+        case 8 + 2: rc = go(seed_wtile_kernel<4, 1, 2>); break;
+        case 8 + 3: rc = go(seed_wtile_kernel<4, 1, 3>); break;
+        case 8 + 4: rc = go(seed_wtile_kernel<4, 1, 4>); break;
+        case 16 + 1: rc = go(seed_wtile_kernel<4, 2, 1>); break;
+        case 16 + 2: rc = go(seed_wtile_kernel<4, 2, 2>); break;
+        case 16 + 3: rc = go(seed_wtile_kernel<4, 2, 3>); break;
+        default: rc = go(seed_wtile_kernel<4, 2, 4>); break;
+      }
+    } else {
+      switch (nh) {
+        case 1: rc = go(seed_wtile_kernel<1>); break;
+        case 2: rc = go(seed_wtile_kernel<2>); break;
+        case 3: rc = go(seed_wtile_kernel<3>); break;
+        case 4: rc = go(seed_wtile_kernel<4>); break;
+        case 5: rc = go(seed_wtile_kernel<5>); break;
+        case 6: rc = go(seed_wtile_kernel<6>); break;
+        case 7: rc = go(seed_wtile_kernel<7>); break;
+        default: rc = go(seed_wtile_kernel<8>); break;
+      }
     }
     NTCHK(rc);
-    *ran = true;
-    return NTHIP_OK;
   }
-  switch (nh) {
-    case 1: rc = go(seed_wtile_kernel<1>); break;
-    case 2: rc = go(seed_wtile_kernel<2>); break;
-    case 3: rc = go(seed_wtile_kernel<3>); break;
-    case 4: rc = go(seed_wtile_kernel<4>); break;
-    case 5: rc = go(seed_wtile_kernel<5>); break;
-    case 6: rc = go(seed_wtile_kernel<6>); break;
-    case 7: rc = go(seed_wtile_kernel<7>); break;
-    default: rc = go(seed_wtile_kernel<8>); break;
-  }
-  NTCHK(rc);
   *ran = true;
   return NTHIP_OK;
 }
@@ -617,7 +650,9 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
     const uint32_t bits_dwords = (uint32_t)((((slab + 15) >> 4) + 8 + 3) & ~3ull);
     const size_t dyn = table_bytes + (size_t)bits_dwords * 4 + (size_t)(SF_THREADS / 64) * (64 * per + 2) * 8;
     const uint64_t dense = rd->n_reads * (uint64_t)nwin;
-    if (dyn <= 158 * 1024 && dyn <= c->lds_max && (uint64_t)rpt * nwin < 0x7FFFFFFFull) {
+    // (the block-tile kernel needs its 16 waves' tiles beside ALL the tables; the wave-tile kernel plans its own LDS)
+    const bool block_fits = dyn <= 158 * 1024 && dyn <= c->lds_max;
+    if ((uint64_t)rpt * nwin < 0x7FFFFFFFull) {
       if (dense > out->capacity) {
         if (total_out) *total_out = dense;
         return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
@@ -659,14 +694,16 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
       // shapes outside it (slabs of more than 8 KiB per tile, LDS) keep the block-tile kernel
       bool wtile_ran = false;
       NTCHK(launch_seed_wtile(c, a, sd, nh, &wtile_ran));
-      if (!wtile_ran) {
+      if (!wtile_ran && block_fits) {
         rc = NT_SEED_FIXED(false, dyn);
         NTCHK(rc);
       }
-      HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-      uint32_t dirty = 0;
-      memcpy(&dirty, c->h_small, 4);
+      uint32_t dirty = 1; // (no dense kernel for the shape: the general path below)
+      if (wtile_ran || block_fits) {
+        HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(&dirty, c->h_small, 4);
+      }
       if (!dirty) {
         total = dense;
         if (st.counts) {
@@ -680,7 +717,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
           HIPCHK(hipGetLastError());
         }
         done = true;
-      } else if (dyn + (size_t)rpt * 8 <= 158 * 1024 && dyn + (size_t)rpt * 8 <= c->lds_max) {
+      } else if (block_fits && dyn + (size_t)rpt * 8 <= 158 * 1024 && dyn + (size_t)rpt * 8 <= c->lds_max) {
         // Batch with non-bases.  SeedNtHash's position state machine (App. B Q3) only matters for the reads
         // that HAVE a non-base: those (usually a fraction of a percent) go through seed_general_kernel, every
         // other read emits all its windows and stays on the fast kernel, writing at its place in the compact

@@ -332,6 +332,10 @@ struct SeedWtileArgs {
   uint32_t waves;        // per block
   uint32_t groups;       // tile_range(): groups of blocks sharing a range of tiles (0: one range per block)
   uint32_t align_recs;   // records after which the stream is on a 128-byte line again: 16 / gcd(values per record, 16)
+  // a pass over SOME of the seeds (seed sets whose byte tables do not fit in LDS together, or more than two seeds on the
+  // rotated-slot layout): n_seeds / tables are this pass's seeds, the records keep the stream's layout --
+  // rec_stride values per window (0: the pass writes whole records), this pass's values from rec_off on
+  uint32_t rec_stride, rec_off, inv_per; // inv_per = 65536 / (n_seeds * m2) + 1
   uint64_t mult[SF_MAX_RUNTIME_M];
 };
 
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
       }
       // the 64 records are built shifted by the parity of their place in the stream: 16-byte aligned LDS reads and stores
       uint64_t* const dst = a.hashes + (rec0 + q0) * per;
-      const uint32_t par = (uint32_t)(((uintptr_t)dst >> 3) & 1u);
+      const uint32_t par = a.rec_stride ? 0u : (uint32_t)(((uintptr_t)dst >> 3) & 1u);
       uint64_t* mine = otile + par + lane * per;
 #if SF_ABL_NOHASH
 #ifdef SF_ABL_SPIN // pure-VALU stand-in for the hashing (SF_ABL_SPIN dependent operations per group, no LDS)
@@ -577,6 +581,20 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
       lds_sync();
       const uint32_t n_here = (n_win_tile - q0) < g_size ? (n_win_tile - q0) : g_size;
       const uint32_t n_vals = n_here * per;
+      if (a.rec_stride) {
+        // some of the record's values: 8-byte stores, per values in a row then a gap (ordinary stores: the other passes'
+        // pieces of a line meet them in L2 when they come soon enough)
+        uint64_t* const o = a.hashes + (rec0 + q0) * a.rec_stride + a.rec_off;
+        for (uint32_t v = lane; v < n_vals; v += 64u) {
+          const uint32_t wi = (v * a.inv_per) >> 16, j = v - wi * per; // v < 64 * per <= 1024: exact
+#if !SF_ABL_NOSTORE
+          o[(uint64_t)wi * a.rec_stride + j] = otile[v];
+#endif
+        }
+        n_stores += (n_vals + 63u) >> 6;
+        lds_sync();
+        continue;
+      }
       uint64_t* const base = dst - par; // 16-byte aligned; value i of the shifted tile goes to base[i]
       const uint32_t span = par + n_vals;
       for (uint32_t pi = par + lane; pi < (span >> 1); pi += 64u) { // whole 16-byte pieces

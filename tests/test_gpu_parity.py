@@ -1832,3 +1832,47 @@ def test_kmer_whole_read_tiles_many_hashes(ctx, oracle):
         assert got["total"] == want["total"]
         for key in ("counts", "pos", "hashes"):
             assert (got[key] == want[key]).all(), (k, m, key)
+
+
+def test_seed_passes_vs_oracle(oracle):
+    """seed sets hashed a few seeds per pass of seed_wtile_kernel (every pass writes its part of each record): more than
+    two seeds of k <= 32 on the rotated-slot layout, seed sets whose byte tables do not fit in LDS together (k = 64:
+    three seeds), many seeds; the same batches with one seed per pass forced (NTHIP_TUNE_SEED_PASS=1) and with an 'N'
+    in one read (the batch leaves the dense kernel)"""
+    import os
+    import nthash_amd
+    rng = np.random.default_rng(4242)
+    planned = nthash_amd.Context(0)
+    os.environ["NTHIP_TUNE_SEED_PASS"] = "1"
+    try:
+        single = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_SEED_PASS", None)
+
+    def mask(k, density):
+        m = (rng.random(k) < density).astype(int)
+        m[0] = m[-1] = 1
+        return "".join(str(int(x)) for x in m)
+
+    shapes = [(31, 3, 1), (31, 3, 3), (31, 4, 2), (31, 6, 1), (20, 5, 4), (32, 7, 2), (48, 3, 2), (48, 5, 1), (64, 2, 3),
+              (64, 3, 1), (57, 4, 5), (31, 2, 3), (12, 9, 1)]
+    for (k, n_seeds, m2) in shapes:
+        seeds = [mask(k, 0.65) for _ in range(n_seeds)]
+        n, L = int(rng.integers(100, 900)), int(rng.integers(k, 260))
+        data = np.frombuffer(b"ACGTacgt", dtype=np.uint8)[rng.integers(0, 8, n * L)].copy()
+        offs = np.arange(n + 1, dtype=np.uint64) * L
+        for dirty in (False, True):
+            if dirty:
+                data[(n // 2) * L + L // 2] = ord("N")
+            want = oracle.seed_batch(data, offs, seeds, k, m2, want_pos=False)
+            for c in (planned, single):
+                c.set_profiling(True)
+                got = c.seed_hash(data, seeds, k, m2, fixed_len=L, n_reads=n)
+                name = c.last_kernel_ms()[1]
+                c.set_profiling(False)
+                assert got["total"] == want["total"], (k, n_seeds, m2, dirty)
+                assert (got["hashes"] == want["hashes"]).all(), (k, n_seeds, m2, dirty, c is planned)
+                if not dirty:
+                    assert name == "seed_wtile_kernel", (name, k, n_seeds, m2)
+    planned.close()
+    single.close()

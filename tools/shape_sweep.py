@@ -21,12 +21,14 @@ if os.environ.get("SWEEP_SHAPES"):  # "151,31,1;101,31,1"
 
 ctx = nthash_amd.Context(0)
 ctx.set_profiling(True)
+# buffers from the placement-aware allocator (SWEEP_PROBED=0: plain allocations)
+alloc = (lambda nb: ctx.malloc_probed(nb, 3)[0]) if os.environ.get("SWEEP_PROBED", "1") != "0" else ctx.malloc
 rows = []
 for (L, k, m) in SHAPES:
     nwin = L - k + 1
     n = max(1, int(OUT_BUDGET // (nwin * m * 8)))
-    d_in = ctx.malloc(n * L)
-    d_out = ctx.malloc(n * nwin * m * 8)
+    d_in = alloc(n * L)
+    d_out = alloc(n * nwin * m * 8)
     ctx.synth_reads_ptr(d_in, 0, n, L, 7)
     ts = []
     name = "?"
