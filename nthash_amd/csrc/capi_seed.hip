@@ -162,25 +162,49 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
   const uint64_t max_len = res[0], max_pitch = res[1] > res[0] ? res[1] : res[0];
   if (res[2] || max_len > RD_MAX_LEN || max_len < k) return NTHIP_OK;
   // ---- geometry ----
-  const bool rot = !c->tune.no_seed_rot && sd->n_seeds <= 2 && k <= 32 && m2 <= 4;
-  const uint32_t nh = rot ? 4u : (k + 7) / 8;
+  const bool rot_ok = !c->tune.no_seed_rot && k <= 32 && m2 <= 4;
+  const uint32_t nh_plain = (k + 7) / 8;
   const uint32_t per = sd->n_seeds * m2;
   uint32_t R = c->tune.seed_rpt ? (c->tune.seed_rpt < 64u ? c->tune.seed_rpt : 64u) : 16;
   const uint64_t slab_cap = 8192;
   while (R > 1 && (uint64_t)(R - 1) * max_pitch + max_len + 16 > slab_cap) --R;
   if ((uint64_t)(R - 1) * max_pitch + max_len + 16 > slab_cap) return NTHIP_OK;
   const uint32_t max_vec = (uint32_t)(((uint64_t)(R - 1) * max_pitch + max_len + 15 + 15) / 16 + 1);
-  const uint32_t bits_dwords = (max_vec + (nh + 1) / 2 + 8 + 3u) & ~3u;
+  const uint32_t bits_dwords = (max_vec + (nh_plain + 1) / 2 + 8 + 3u) & ~3u;
   const uint32_t otile_recs = 64 + 16;
   const uint32_t max_win = R * (uint32_t)(max_len - k + 1);
   const uint32_t wmap_dwords = ((max_win / 16 + 8 + 3) / 4 + 3u) & ~3u;
-  const size_t table_bytes = rot ? 65536 : (size_t)sd->n_seeds * 2 * nh * 256 * sizeof(uint4);
   const uint32_t rt_n = R <= 16 ? 16 : R <= 32 ? 32 : 64;
-  const size_t per_wave = ((size_t)(otile_recs * per + 2) * 2 + bits_dwords + 4 * rt_n + wmap_dwords) * 4;
   const size_t cap = lds_cap_of(c);
-  uint32_t waves = 0;
-  for (uint32_t w = 16; w >= 4; w -= 4)
-    if (table_bytes + per_wave * w <= cap) { waves = w; break; }
+  // passes over the seeds, planned as in launch_seed_wtile: one pass writing whole records when the tables of all the
+  // seeds fit in LDS beside 4 waves, otherwise as few passes as possible, each writing its part of every record
+  auto per_wave_of = [&](uint32_t seeds_here) {
+    return ((size_t)(otile_recs * seeds_here * m2 + 2) * 2 + bits_dwords + 4 * rt_n + wmap_dwords) * 4;
+  };
+  auto plain_bytes = [&](uint32_t seeds_here) { return (size_t)seeds_here * 2 * nh_plain * 256 * sizeof(uint4); };
+  auto waves_for = [&](size_t tb, uint32_t seeds_here) -> uint32_t {
+    for (uint32_t w = 16; w >= 4; w -= 4)
+      if (tb + per_wave_of(seeds_here) * w <= cap) return w;
+    return 0;
+  };
+  uint32_t pass_seeds;
+  bool rot;
+  if (c->tune.seed_pass) {
+    pass_seeds = c->tune.seed_pass < sd->n_seeds ? c->tune.seed_pass : sd->n_seeds;
+    rot = rot_ok && pass_seeds <= 2;
+  } else if (rot_ok && sd->n_seeds <= 2) {
+    pass_seeds = sd->n_seeds;
+    rot = true;
+  } else {
+    rot = false;
+    uint32_t most = sd->n_seeds;
+    while (most > 1 && waves_for(plain_bytes(most), most) == 0) --most;
+    const uint32_t passes = (sd->n_seeds + most - 1) / most;
+    pass_seeds = (sd->n_seeds + passes - 1) / passes;
+  }
+  const uint32_t nh = rot ? 4u : nh_plain;
+  const size_t table_bytes = rot ? 65536 : plain_bytes(pass_seeds);
+  const uint32_t waves = waves_for(table_bytes, pass_seeds);
   if (!waves) return NTHIP_OK;
   *handled = true;
 
@@ -268,53 +292,65 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
   ra.R = R;
   ra.k = k;
   ra.m2 = m2;
-  ra.n_seeds = sd->n_seeds;
   ra.ntab = sd->ntab;
   ra.bits_dwords = bits_dwords;
   ra.otile_recs = otile_recs;
   ra.wmap_dwords = wmap_dwords;
   ra.waves = waves;
-  {
-    uint32_t g = per, h = 16;
-    while (h) { const uint32_t t2 = g % h; g = h; h = t2; } // gcd(per, 16)
-    ra.align_recs = c->tune.no_seed_align ? 1u : 16u / g;
-  }
   for (uint32_t i = 0; i < (uint32_t)SF_MAX_RUNTIME_M; ++i) ra.mult[i] = multiplier(k, i);
-  const size_t lds = table_bytes + per_wave * waves;
-  auto go = [&](auto kernel) -> int {
-    int per_cu = 1;
-    NTCHK(blocks_per_cu(c, kernel, (int)waves * 64, lds, &per_cu));
-    const uint64_t need = (n_tiles + waves - 1) / waves;
-    uint64_t grid = (uint64_t)c->n_cu * per_cu;
-    if (grid > need) grid = need;
-    prof_begin(c, "seed_rtile_kernel");
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream, ra);
-    prof_end(c);
-    HIPCHK(hipGetLastError());
-    return NTHIP_OK;
-  };
-  int rc;
-  if (rot) {
-    switch (sd->n_seeds * 8 + m2) {
-      case 8 + 1: rc = go(seed_rtile_kernel<4, 1, 1>); break;
-      case 8 + 2: rc = go(seed_rtile_kernel<4, 1, 2>); break;
-      case 8 + 3: rc = go(seed_rtile_kernel<4, 1, 3>); break;
-      case 8 + 4: rc = go(seed_rtile_kernel<4, 1, 4>); break;
-      case 16 + 1: rc = go(seed_rtile_kernel<4, 2, 1>); break;
-      case 16 + 2: rc = go(seed_rtile_kernel<4, 2, 2>); break;
-      case 16 + 3: rc = go(seed_rtile_kernel<4, 2, 3>); break;
-      default: rc = go(seed_rtile_kernel<4, 2, 4>); break;
+  int rc = NTHIP_OK;
+  for (uint32_t s0 = 0; s0 < sd->n_seeds && rc == NTHIP_OK; s0 += pass_seeds) {
+    const uint32_t ns = sd->n_seeds - s0 < pass_seeds ? sd->n_seeds - s0 : pass_seeds;
+    const uint32_t per_here = ns * m2;
+    ra.n_seeds = ns;
+    ra.tables = sd->d_tables + (size_t)s0 * sd->ntab * 256;
+    ra.pos = s0 == 0 ? st.pos : nullptr;
+    if (ns == sd->n_seeds) {
+      uint32_t g = per_here, h2 = 16;
+      while (h2) { const uint32_t t2 = g % h2; g = h2; h2 = t2; } // gcd(per, 16)
+      ra.align_recs = c->tune.no_seed_align ? 1u : 16u / g;
+      ra.rec_stride = 0;
+      ra.rec_off = 0;
+    } else {
+      ra.align_recs = 1;
+      ra.rec_stride = per;
+      ra.rec_off = s0 * m2;
     }
-  } else {
-    switch (nh) {
-      case 1: rc = go(seed_rtile_kernel<1>); break;
-      case 2: rc = go(seed_rtile_kernel<2>); break;
-      case 3: rc = go(seed_rtile_kernel<3>); break;
-      case 4: rc = go(seed_rtile_kernel<4>); break;
-      case 5: rc = go(seed_rtile_kernel<5>); break;
-      case 6: rc = go(seed_rtile_kernel<6>); break;
-      case 7: rc = go(seed_rtile_kernel<7>); break;
-      default: rc = go(seed_rtile_kernel<8>); break;
+    const size_t lds = table_bytes + per_wave_of(ns) * waves;
+    auto go = [&](auto kernel) -> int {
+      int per_cu = 1;
+      NTCHK(blocks_per_cu(c, kernel, (int)waves * 64, lds, &per_cu));
+      const uint64_t need = (n_tiles + waves - 1) / waves;
+      uint64_t grid = (uint64_t)c->n_cu * per_cu;
+      if (grid > need) grid = need;
+      if (s0 == 0) prof_begin(c, "seed_rtile_kernel"); // (all passes in one measurement)
+      hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream, ra);
+      prof_end(c);
+      HIPCHK(hipGetLastError());
+      return NTHIP_OK;
+    };
+    if (rot) {
+      switch (ns * 8 + m2) {
+        case 8 + 1: rc = go(seed_rtile_kernel<4, 1, 1>); break;
+        case 8 + 2: rc = go(seed_rtile_kernel<4, 1, 2>); break;
+        case 8 + 3: rc = go(seed_rtile_kernel<4, 1, 3>); break;
+        case 8 + 4: rc = go(seed_rtile_kernel<4, 1, 4>); break;
+        case 16 + 1: rc = go(seed_rtile_kernel<4, 2, 1>); break;
+        case 16 + 2: rc = go(seed_rtile_kernel<4, 2, 2>); break;
+        case 16 + 3: rc = go(seed_rtile_kernel<4, 2, 3>); break;
+        default: rc = go(seed_rtile_kernel<4, 2, 4>); break;
+      }
+    } else {
+      switch (nh) {
+        case 1: rc = go(seed_rtile_kernel<1>); break;
+        case 2: rc = go(seed_rtile_kernel<2>); break;
+        case 3: rc = go(seed_rtile_kernel<3>); break;
+        case 4: rc = go(seed_rtile_kernel<4>); break;
+        case 5: rc = go(seed_rtile_kernel<5>); break;
+        case 6: rc = go(seed_rtile_kernel<6>); break;
+        case 7: rc = go(seed_rtile_kernel<7>); break;
+        default: rc = go(seed_rtile_kernel<8>); break;
+      }
     }
   }
   NTCHK(rc);
@@ -518,7 +554,6 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
       a.rec_off = s0 * f.m2;
       a.align_recs = 1;
     }
-    a.inv_per = 65536u / per_here + 1u;
     const size_t lds = table_bytes + per_wave_of(ns) * waves;
     auto go = [&](auto kernel) -> int {
       int per_cu = 1;
@@ -533,29 +568,32 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
       return NTHIP_OK;
     };
     int rc;
+    const bool sub = a.rec_stride != 0;
+#define NT_SW(...) (sub ? go(seed_wtile_kernel<__VA_ARGS__, true>) : go(seed_wtile_kernel<__VA_ARGS__, false>))
     if (rot) {
       switch (ns * 8 + f.m2) {
-        case 8 + 1: rc = go(seed_wtile_kernel<4, 1, 1>); break;
-        case 8 + 2: rc = go(seed_wtile_kernel<4, 1, 2>); break;
-        case 8 + 3: rc = go(seed_wtile_kernel<4, 1, 3>); break;
-        case 8 + 4: rc = go(seed_wtile_kernel<4, 1, 4>); break;
-        case 16 + 1: rc = go(seed_wtile_kernel<4, 2, 1>); break;
-        case 16 + 2: rc = go(seed_wtile_kernel<4, 2, 2>); break;
-        case 16 + 3: rc = go(seed_wtile_kernel<4, 2, 3>); break;
-        default: rc = go(seed_wtile_kernel<4, 2, 4>); break;
+        case 8 + 1: rc = NT_SW(4, 1, 1); break;
+        case 8 + 2: rc = NT_SW(4, 1, 2); break;
+        case 8 + 3: rc = NT_SW(4, 1, 3); break;
+        case 8 + 4: rc = NT_SW(4, 1, 4); break;
+        case 16 + 1: rc = NT_SW(4, 2, 1); break;
+        case 16 + 2: rc = NT_SW(4, 2, 2); break;
+        case 16 + 3: rc = NT_SW(4, 2, 3); break;
+        default: rc = NT_SW(4, 2, 4); break;
       }
     } else {
       switch (nh) {
-        case 1: rc = go(seed_wtile_kernel<1>); break;
-        case 2: rc = go(seed_wtile_kernel<2>); break;
-        case 3: rc = go(seed_wtile_kernel<3>); break;
-        case 4: rc = go(seed_wtile_kernel<4>); break;
-        case 5: rc = go(seed_wtile_kernel<5>); break;
-        case 6: rc = go(seed_wtile_kernel<6>); break;
-        case 7: rc = go(seed_wtile_kernel<7>); break;
-        default: rc = go(seed_wtile_kernel<8>); break;
+        case 1: rc = NT_SW(1, 0, 0); break;
+        case 2: rc = NT_SW(2, 0, 0); break;
+        case 3: rc = NT_SW(3, 0, 0); break;
+        case 4: rc = NT_SW(4, 0, 0); break;
+        case 5: rc = NT_SW(5, 0, 0); break;
+        case 6: rc = NT_SW(6, 0, 0); break;
+        case 7: rc = NT_SW(7, 0, 0); break;
+        default: rc = NT_SW(8, 0, 0); break;
       }
     }
+#undef NT_SW
     NTCHK(rc);
   }
   *ran = true;

@@ -335,7 +335,7 @@ struct SeedWtileArgs {
   // a pass over SOME of the seeds (seed sets whose byte tables do not fit in LDS together, or more than two seeds on the
   // rotated-slot layout): n_seeds / tables are this pass's seeds, the records keep the stream's layout --
   // rec_stride values per window (0: the pass writes whole records), this pass's values from rec_off on
-  uint32_t rec_stride, rec_off, inv_per; // inv_per = 65536 / (n_seeds * m2) + 1
+  uint32_t rec_stride, rec_off;
   uint64_t mult[SF_MAX_RUNTIME_M];
 };
 
@@ -350,15 +350,17 @@ constexpr uint32_t SW_MAX_VEC_ROUNDS = 8; // a tile's slab: at most 8 x 64 vecto
 // (l + s) & 7 of the seed-half (l >> 3) & 1 (the other half in the second round): every 16-lane group holds each
 // residue l & 15 once, so its 16 lanes read 16 different tables = 16 different slots, whatever the entries.  XOR is
 // commutative, so the order in which a lane meets its eight tables does not matter.  One seed: both halves hold it.
-template <int NH, int RNS = 0, int RM2 = 0>
+template <int NH, int RNS = 0, int RM2 = 0, bool SUB = false>
 __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileArgs a)
 {
+  // SUB: a pass over some of the seeds (a.rec_stride != 0), its own instantiation so that the whole-record kernels keep
+  // their register budget
   constexpr bool ROT = RNS > 0;
   static_assert(!ROT || (NH == 4 && RNS <= 2 && RM2 >= 1 && RM2 <= 4), "rotated-slot layout: k <= 32, <= 2 seeds");
   // PF: the next tile's slab travels in registers behind hidden loads.  Only while the kernel does not spill: a spilled
   // register of a load hipcc cannot see is saved before the load has landed (k > 32: 2 * NH lookups of 16 bytes in flight
   // take the registers; nthash_amd/build.py refuses a build in which a kernel with hidden loads spills)
-  constexpr bool PF = NH <= 4;
+  constexpr bool PF = NH <= 4 && !SUB;
   constexpr int NW = (NH + 1) / 2; // 32-bit words of window kept in registers
   constexpr uint32_t NT = 2u * NH; // byte tables per seed in LDS
   extern __shared__ __attribute__((aligned(256))) uint32_t lds_dyn[];
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
       }
       // the 64 records are built shifted by the parity of their place in the stream: 16-byte aligned LDS reads and stores
       uint64_t* const dst = a.hashes + (rec0 + q0) * per;
-      const uint32_t par = a.rec_stride ? 0u : (uint32_t)(((uintptr_t)dst >> 3) & 1u);
+      const uint32_t par = SUB ? 0u : (uint32_t)(((uintptr_t)dst >> 3) & 1u);
       uint64_t* mine = otile + par + lane * per;
 #if SF_ABL_NOHASH
 #ifdef SF_ABL_SPIN // pure-VALU stand-in for the hashing (SF_ABL_SPIN dependent operations per group, no LDS)
@@ -581,17 +583,13 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
       lds_sync();
       const uint32_t n_here = (n_win_tile - q0) < g_size ? (n_win_tile - q0) : g_size;
       const uint32_t n_vals = n_here * per;
-      if (a.rec_stride) {
+      if constexpr (SUB) {
         // some of the record's values: 8-byte stores, per values in a row then a gap (ordinary stores: the other passes'
         // pieces of a line meet them in L2 when they come soon enough)
         uint64_t* const o = a.hashes + (rec0 + q0) * a.rec_stride + a.rec_off;
-        for (uint32_t v = lane; v < n_vals; v += 64u) {
-          const uint32_t wi = (v * a.inv_per) >> 16, j = v - wi * per; // v < 64 * per <= 1024: exact
-#if !SF_ABL_NOSTORE
-          o[(uint64_t)wi * a.rec_stride + j] = otile[v];
-#endif
-        }
-        n_stores += (n_vals + 63u) >> 6;
+        for (uint32_t j = 0; j < per; ++j)
+          if (lane < n_here) o[lane * a.rec_stride + j] = otile[lane * per + j];
+        n_stores += per;
         lds_sync();
         continue;
       }
@@ -665,6 +663,7 @@ struct SeedRtileArgs {
   uint32_t R, k, m2, n_seeds, ntab;
   uint32_t bits_dwords, otile_recs, wmap_dwords, waves;
   uint32_t align_recs;      // records after which the stream is on a 128-byte line again: 16 / gcd(values per record, 16)
+  uint32_t rec_stride, rec_off; // a pass over some of the seeds: as in SeedWtileArgs
   uint64_t mult[SF_MAX_RUNTIME_M];
 };
 
@@ -797,7 +796,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
       const bool act = lane < nl;
       const uint32_t span = (uint32_t)__shfl((int)slot, (int)(nl - 1u), 64) + 1u;
       uint64_t* const dst = a.hashes + (ro_0 + gbase) * per;
-      const uint32_t par = (uint32_t)(((uintptr_t)dst >> 3) & 1u);
+      const uint32_t par = a.rec_stride ? 0u : (uint32_t)(((uintptr_t)dst >> 3) & 1u);
       if (act) {
         const uint32_t d = b >> 4, sh = (b & 15u) << 1;
         uint32_t w[NW];
@@ -858,6 +857,14 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
       lds_sync();
       // ---- the group's records (holes included) as aligned 16-byte pieces ----
       const uint32_t n_vals = span * per;
+      if (a.rec_stride) { // this pass's part of each record: 8-byte pieces
+        uint64_t* const o = a.hashes + (ro_0 + gbase) * a.rec_stride + a.rec_off;
+        for (uint32_t wi = lane; wi < span; wi += 64u)
+          for (uint32_t jv = 0; jv < per; ++jv) o[wi * a.rec_stride + jv] = otile[wi * per + jv];
+        lds_sync();
+        q0 += nl;
+        continue;
+      }
       uint64_t* const base = dst - par;
       const uint32_t sp = par + n_vals;
       const uint32_t pf = par, pl = sp >> 1; // whole pieces [pf, pl) (par is 0 or 1: piece 0 is whole iff par == 0)

@@ -1874,5 +1874,20 @@ def test_seed_passes_vs_oracle(oracle):
                 assert (got["hashes"] == want["hashes"]).all(), (k, n_seeds, m2, dirty, c is planned)
                 if not dirty:
                     assert name == "seed_wtile_kernel", (name, k, n_seeds, m2)
+        # reads of several lengths (tiles of whole reads, seed_rtile_kernel), one of them with an 'N'
+        alph = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
+        reads = [alph[rng.integers(0, 8, int(rng.integers(max(1, k - 3), 200)))].tobytes() for _ in range(700)]
+        reads[350] = reads[350][: len(reads[350]) // 2] + b"N" + reads[350][len(reads[350]) // 2 + 1:]
+        d, roffs = concat_reads(reads)
+        want = oracle.seed_batch(d, roffs, seeds, k, m2)
+        for c in (planned, single):
+            c.set_profiling(True)
+            got = c.seed_hash(d, seeds, k, m2, offsets=roffs, want_pos=True)
+            name = c.last_kernel_ms()[1]
+            c.set_profiling(False)
+            assert name == "seed_rtile_kernel", (name, k, n_seeds, m2)
+            assert got["total"] == want["total"]
+            for key in ("counts", "pos", "hashes"):
+                assert (got[key] == want[key]).all(), (k, n_seeds, m2, key, c is planned)
     planned.close()
     single.close()
