@@ -290,7 +290,7 @@ int run_kmer_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint
 int launch_kmer_rows(nthip_ctx* c, const KmerFixedArgs& a, size_t dyn_lds);
 // capi_seed.hip
 int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd, uint32_t m2,
-                     uint64_t capacity, uint64_t* total, const uint64_t* d_ends = nullptr);
+                     uint64_t capacity, uint64_t* total, const uint64_t* d_ends = nullptr, bool fixed_as_spans = false);
 
 // ---- templates every launching TU uses --------------------------------------------------------------------------
 template <typename K>

@@ -377,7 +377,7 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
 } // namespace
 
 int ntamd::host::run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd,
-                     uint32_t m2, uint64_t capacity, uint64_t* total, const uint64_t* d_ends)
+                     uint32_t m2, uint64_t capacity, uint64_t* total, const uint64_t* d_ends, bool fixed_as_spans)
 {
   const uint64_t n = rd->n_reads;
   SeedGeneralArgs h;
@@ -418,6 +418,22 @@ int ntamd::host::run_seed_general(nthip_ctx* c, const Staged& st, const nthip_re
     SeedWavePlan lp = wplan;
     if (!use_wave) lp.waves_count = 0;
     NTCHK(run_seed_reads(c, st, st.offsets, d_ends ? d_ends : st.offsets + 1, n, sd, m2, capacity, total, &handled, hl, lp));
+    if (handled) return NTHIP_OK;
+  } else if (fixed_as_spans && !st.offsets && !c->tune.no_seed_wave && h.stride >= h.len && n != 0) {
+    // reads of one length that left the dense kernel (a non-base somewhere in the batch and a shape the block-tile
+    // kernel's split pass has no room for): the same path over spans made here -- the clean reads stay on tiles of whole
+    // reads, only the reads with a non-base go one by one
+    NTCHK(ensure_scratch2(c, 2 * n));
+    uint64_t* d_s = c->d_scratch2;
+    uint64_t* d_e = c->d_scratch2 + n;
+    hipLaunchKernelGGL(fill_spans_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, d_s, d_e, n, (uint64_t)h.stride,
+                       (uint64_t)h.len);
+    HIPCHK(hipGetLastError());
+    bool handled = false;
+    SeedGeneralArgs hl = h;
+    SeedWavePlan lp = wplan;
+    if (!use_wave) lp.waves_count = 0;
+    NTCHK(run_seed_reads(c, st, d_s, d_e, n, sd, m2, capacity, total, &handled, hl, lp));
     if (handled) return NTHIP_OK;
   }
   h.counts = d_counts;
@@ -858,7 +874,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
       }
     }
   }
-  if (!done) NTCHK(run_seed_general(c, st, rd, sd, m2, out->capacity, &total));
+  if (!done) NTCHK(run_seed_general(c, st, rd, sd, m2, out->capacity, &total, nullptr, !(flags & NTHIP_FORCE_GENERAL)));
   if (total_out) *total_out = total;
   NTCHK(unstage_outputs(c, out, flags, rd->n_reads, per, total, st, sd->n_seeds));
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -91,6 +91,16 @@ static __global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(uint64_t*
     if (base + i < n) out[base + i] += add;
 }
 
+// reads of one length at one stride as spans: [r * stride, r * stride + len)
+static __global__ void fill_spans_kernel(uint64_t* __restrict__ starts, uint64_t* __restrict__ ends, uint64_t n, uint64_t stride,
+                                         uint64_t len)
+{
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+    starts[r] = r * stride;
+    ends[r] = r * stride + len;
+  }
+}
+
 static __global__ void fill_u64_kernel(uint64_t* __restrict__ dst, uint64_t n, uint64_t value)
 {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;

@@ -1872,8 +1872,10 @@ def test_seed_passes_vs_oracle(oracle):
                 c.set_profiling(False)
                 assert got["total"] == want["total"], (k, n_seeds, m2, dirty)
                 assert (got["hashes"] == want["hashes"]).all(), (k, n_seeds, m2, dirty, c is planned)
-                if not dirty:
-                    assert name == "seed_wtile_kernel", (name, k, n_seeds, m2)
+                # (an 'N' in the batch: the split pass of the block-tile kernel when its LDS plan has room, otherwise tiles of
+                #  whole reads over spans made on the device -- never the lane-per-read kernel for the whole batch)
+                assert name == ("seed_wtile_kernel" if not dirty else name), (name, k, n_seeds, m2)
+                assert name != "seed_general_kernel", (name, k, n_seeds, m2, dirty)
         # reads of several lengths (tiles of whole reads, seed_rtile_kernel), one of them with an 'N'
         alph = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
         reads = [alph[rng.integers(0, 8, int(rng.integers(max(1, k - 3), 200)))].tobytes() for _ in range(700)]

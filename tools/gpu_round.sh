@@ -1,8 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "seed" 2>&1 | tail -4
-for sh in 31,2,3 31,3,3 31,4,2 31,6,1 48,3,2 64,2,3 64,3,1; do
-echo "== $sh"; RSB_SHAPE=$sh timeout 300 python tools/ragged_seed_bench.py 2000000 2>&1 | tail -1
-done | tee gpurun_out/ragged_seed_shapes.txt
-SWEEP_GIB=16 SWEEP_SHAPES="250,31,2,3;250,31,6,1;100,64,3,1;250,31,4,2" timeout 900 python tools/seed_sweep.py 2>&1
+timeout 1500 python tools/stress_seeds.py 1500 11 2>&1 | tail -3
+NTHIP_TUNE_SEED_PASS=1 timeout 900 python tools/stress_seeds.py 500 12 2>&1 | tail -2

@@ -14,9 +14,9 @@ bad_alph = np.frombuffer(b"NnRYKMSWBDHV-*.\x00\x01\x07", dtype=np.uint8)
 fails = 0
 for it in range(iters):
     k = int(rng.choice([3, 4, 5, 8, 15, 16, 17, 25, 31, 32, 33, 47, 48, 49, 63, 64, 65, 66, 80, 100, 127, 128, 200]))
-    m2 = int(rng.integers(1, 6))
+    m2 = int(rng.integers(1, 9)) if rng.random() < 0.2 else int(rng.integers(1, 6))
     seeds = []
-    for _ in range(int(rng.integers(1, 4))):
+    for _ in range(int(rng.integers(1, 8)) if rng.random() < 0.35 else int(rng.integers(1, 4))):  # (many seeds: several passes)
         dens = rng.choice([0.3, 0.6, 0.9])
         sd = "".join("1" if rng.random() < dens else "0" for _ in range(k))
         if "1" not in sd:
