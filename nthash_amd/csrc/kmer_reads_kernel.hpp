@@ -125,7 +125,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
 #define RD_PF_ROUNDS_N 3 // 3 KiB of slab in registers (in-process A/B, 10 M reads: 100-150 bp +5 % against none, 5 rounds
                          // +7 %; nearly all reads 150 bp: -0.7 % / -4.7 %)
 #endif
-  constexpr uint32_t RD_PF_ROUNDS = RD_PF_ROUNDS_N;
+  // (the MARK pass does next to nothing per tile and has the registers: its whole next slab, up to 5 KiB, travels ahead)
+#ifndef RD_PF_MARK_ROUNDS_N
+#define RD_PF_MARK_ROUNDS_N 5
+#endif
+  constexpr uint32_t RD_PF_ROUNDS = MODE == RD_MODE_MARK ? RD_PF_MARK_ROUNDS_N : RD_PF_ROUNDS_N;
   struct Meta {
     uint64_t s, e;
     uint32_t cnt, listed;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
     if (t0 >= t_end) return;
     m_cur = load_meta(t0);
     g_cur = geom_of(m_cur, t0);
-    if (MODE == RD_MODE_HASH) issue_slab(g_cur);
+    issue_slab(g_cur);
     m_nxt = t0 + t_step < t_end ? load_meta(t0 + t_step) : m_cur;
   }
 
@@ -203,18 +207,30 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
     const bool have_next = t + t_step < t_end;
 
     if (MODE == RD_MODE_MARK) {
-      // ---- stage: one validity bit per byte ----
-      for (uint32_t i = lane; i < n_vec; i += 64u) {
-        const uint4 x = *(const uint4*)(vbase + ((uint64_t)i << 4));
+      // ---- stage: one validity bit per byte (the first vectors are in registers already) ----
+      auto mark_vec = [&](const uint32_t i, const uint4 x) {
         uint32_t i0, i1, i2, i3;
         (void)pack4v(x.x, i0);
         (void)pack4v(x.y, i1);
         (void)pack4v(x.z, i2);
         (void)pack4v(x.w, i3);
         ((uint16_t*)bits)[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+      };
+#pragma unroll
+      for (uint32_t rd = 0; rd < RD_PF_ROUNDS; ++rd) {
+        const uint32_t i = rd * 64u + lane;
+        if (i < n_vec) mark_vec(i, pv[rd]);
       }
+      for (uint32_t i = RD_PF_ROUNDS * 64u + lane; i < n_vec; i += 64u) mark_vec(i, *(const uint4*)(vbase + ((uint64_t)i << 4)));
       if (lane < 4u) ((uint16_t*)bits)[n_vec + lane] = 0;
       lds_sync();
+      // ---- the next tile's slab and the spans of the tile after it: in flight during the rest of this tile ----
+      if (have_next) {
+        m_cur = m_nxt;
+        g_cur = geom_of(m_cur, t + t_step);
+        issue_slab(g_cur);
+        if (t + 2u * t_step < t_end) m_nxt = load_meta(t + 2u * t_step);
+      }
       // ---- any non-base inside [sb_j, sb_j + len_j) ? ----
       uint32_t any = 0;
       if (len_j) {
@@ -236,11 +252,6 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerRe
       const uint32_t tsum = wave_incl_scan32(dirty || !has ? 0u : nwin_raw);
       if (lane == 63u) a.tile_sum[t] = tsum;
       lds_sync(); // the bit stream is free again
-      if (have_next) {
-        m_cur = m_nxt;
-        g_cur = geom_of(m_cur, t + t_step);
-        if (t + 2u * t_step < t_end) m_nxt = load_meta(t + 2u * t_step);
-      }
       continue;
     }
 

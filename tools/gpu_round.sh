@@ -1,4 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out
-SWEEP_GIB=4 SWEEP_PROBED=0 SWEEP_SHAPES="250,80,2,2;300,128,1,1;250,31,2,12;250,31,1,9;10000,31,2,3;100000,31,2,3;5000000,31,2,3;31,31,2,3;40,31,2,3;3000,48,3,2;1000,31,4,2" timeout 1200 python tools/seed_sweep.py 2>&1 | tee gpurun_out/seed_sweep_edges.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "whole_read or ragged or seed_passes or fastx or spans" 2>&1 | tail -3
+timeout 600 python tools/ab_ragged.py mk0,mk3 10000000 12 2>&1 | tail -6
+RAGGED_MOSTLY=150 timeout 600 python tools/ab_ragged.py mk0,mk3 10000000 12 2>&1 | tail -4
