@@ -318,8 +318,12 @@ int nthip_fill_bench(nthip_ctx* ctx, void* d_dst, size_t bytes, int reps, float*
 /* Placement-aware allocation for long-lived device buffers (a pipeline's hash stream): which pages hipMalloc hands out
  * decides how fast a buffer streams on MI355X (the same fill: 5.6-7.1 TB/s over fresh allocations; the hash kernels follow
  * it).  Up to `candidates` allocations are made and measured with nthip_fill_bench's write-only pattern, the fastest is
- * returned (free it with nthip_free), the others are released.  *gbps (optional): its fill rate, *tried (optional): how
- * many were measured.  The buffer's content is undefined.  Buffers under 64 MiB are allocated without a probe. */
+ * returned, the others are released.  The first candidate is a plain hipMalloc; the others are one virtual range mapped
+ * from physical pieces of 8-32 MiB (hipMemCreate / hipMemMap): one big physical allocation is the usual way into the slow
+ * class, many small ones almost never are -- so the pointer MUST be released with nthip_free of the same context (which
+ * knows both kinds), not with hipFree.  It is an ordinary device pointer for kernels and copies of this process.
+ * *gbps (optional): its fill rate, *tried (optional): how many were measured.  The buffer's content is undefined.  Buffers
+ * under 64 MiB are allocated without a probe. */
 int nthip_malloc_probed(nthip_ctx* ctx, size_t bytes, int candidates, void** dptr, double* gbps, int* tried);
 
 #ifdef __cplusplus

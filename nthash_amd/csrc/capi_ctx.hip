@@ -246,6 +246,7 @@ void load_tuning(nthip_tune& t)
   t.no_seed_wtile = is_one("NTHIP_TUNE_NO_SEED_WTILE");
   t.no_seed_rot = is_one("NTHIP_TUNE_NO_SEED_ROT");
   t.seed_pass = num("NTHIP_TUNE_SEED_PASS", 1, 255);
+  t.no_scattered = is_one("NTHIP_TUNE_NO_SCATTERED");
   t.no_kmer_reads = is_one("NTHIP_TUNE_NO_KMER_READS");
   t.no_seed_reads = is_one("NTHIP_TUNE_NO_SEED_READS");
   t.no_seed_align = is_one("NTHIP_TUNE_NO_SEED_ALIGN");
@@ -321,6 +322,7 @@ extern "C" int nthip_ctx_destroy(nthip_ctx* c)
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->d_scratch2) (void)hipFree(c->d_scratch2);
   for (auto& kv : c->init_tabs) (void)hipFree(kv.second);
+  while (!c->scattered.empty()) (void)scattered_free(c, c->scattered.begin()->first);
   fastx_buffers_release(c);
   if (c->stage_buf) (void)hipFree(c->stage_buf);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -407,6 +409,7 @@ extern "C" int nthip_free(nthip_ctx* c, void* p)
 {
   if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
   HIPCHK(hipSetDevice(c->device));
+  if (scattered_free(c, p)) return NTHIP_OK;
   HIPCHK(hipFree(p));
   return NTHIP_OK;
 }

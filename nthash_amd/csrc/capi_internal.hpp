@@ -84,6 +84,7 @@ struct nthip_tune {
   bool no_seed_reads = false; // NTHIP_TUNE_NO_SEED_READS=1: variable-length reads of SeedNtHash on seed_wave_kernel only
   bool no_kmer_reads = false; // NTHIP_TUNE_NO_KMER_READS=1: variable-length reads on kmer_ragged_kernel only
   uint32_t reads_run_len = 0, reads_per_tile = 0, reads_waves = 0; // NTHIP_TUNE_READS_RUN_LEN / _PER_TILE / _WAVES (kmer_reads_kernel)
+  bool no_scattered = false;  // NTHIP_TUNE_NO_SCATTERED=1: nthip_malloc_probed tries plain hipMalloc candidates only
   uint32_t seed_pass = 0;     // NTHIP_TUNE_SEED_PASS=n: seed_wtile_kernel hashes n seeds per pass (A/B; 0: planned)
   bool no_seed_rot = false;   // NTHIP_TUNE_NO_SEED_ROT=1: the plain [table][entry] layout of the byte tables in LDS
   // phased headline kernel (kmer_runs_kernel.hpp): tiles per wave and period, period / read window in 10 ns ticks
@@ -121,6 +122,12 @@ struct nthip_ctx {
   std::map<std::pair<const void*, size_t>, int> occ_cache;
   // all-care byte tables for the first window of a run, per k (device memory)
   std::map<uint32_t, uint4*> init_tabs;
+  // buffers nthip_malloc_probed mapped from many small physical pieces (capi_util.hip): base -> pieces, for nthip_free
+  struct ScatteredAlloc {
+    size_t bytes = 0;
+    std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> pieces;
+  };
+  std::map<void*, ScatteredAlloc> scattered;
   // run length of the general dense kernel per (len, stride, k, m), measured on the first big batch of that shape
   // (the cost model does not see what a longer run costs in waves per CU or LDS conflicts: +-10 % either way)
   std::map<std::array<uint32_t, 4>, uint32_t> run_len_cache;
@@ -160,6 +167,10 @@ int ensure_scratch(nthip_ctx* c, size_t elems);
 int ensure_scratch2(nthip_ctx* c, size_t elems);
 int ensure_args(nthip_ctx* c, size_t bytes);
 void fastx_buffers_release(nthip_ctx* c); // the file driver's pinned / device buffers
+// capi_util.hip: a buffer of `bytes` mapped from physical pieces of `piece` bytes (see nthip_malloc_probed); false + *out =
+// nullptr when the virtual-memory API refuses; scattered_free() returns false for a pointer it does not own
+bool scattered_alloc(nthip_ctx* c, size_t bytes, size_t piece, void** out);
+bool scattered_free(nthip_ctx* c, void* p);
 
 inline void prof_begin(nthip_ctx* c, const char* name)
 {

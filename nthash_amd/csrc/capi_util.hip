@@ -275,6 +275,9 @@ extern "C" int nthip_malloc_probed(nthip_ctx* c, size_t bytes, int candidates, v
   void* best = nullptr;
   float best_ms = 1e30f;
   std::vector<void*> held; // candidates are kept until the end so that the next one gets other pages
+  auto give_back = [&](void* p) {
+    if (p && !scattered_free(c, p)) (void)hipFree(p);
+  };
   int n = 0;
   for (; n < candidates; ++n) {
     size_t free_b = 0, total_b = 0;
@@ -283,31 +286,109 @@ extern "C" int nthip_malloc_probed(nthip_ctx* c, size_t bytes, int candidates, v
       // no room for another candidate next to the ones held: give the slower ones back and try once more
       bool freed = false;
       for (void*& p : held)
-        if (p && p != best) { (void)hipFree(p); p = nullptr; freed = true; }
+        if (p && p != best) { give_back(p); p = nullptr; freed = true; }
       if (!freed) break;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
       if (free_b < bytes + ((size_t)2 << 30)) break;
     }
+    // the first candidate is a plain hipMalloc; the others are mapped from 32 / 8 MiB physical pieces: one big physical
+    // allocation is the usual way into the slow class (tools/bench_micro/vmm_alloc.hip: 32 GiB from hipMalloc 5.05-5.16
+    // TB/s in 15 of 15 allocations on one box, from pieces of 2-64 MiB 5.99-6.33 in 8 of 8)
     void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      if (n == 0) return fail(NTHIP_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
-      break;
+    if (n == 0 || c->tune.no_scattered || !scattered_alloc(c, bytes, (size_t)(n & 1 ? 32 : 8) << 20, &p)) {
+      if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (n == 0) return fail(NTHIP_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
+        break;
+      }
     }
     held.push_back(p);
     float ms = 0;
     const int rc = nthip_fill_bench(c, p, bytes, 2, &ms);
     if (rc != NTHIP_OK) {
-      for (void* q : held) if (q) (void)hipFree(q);
+      for (void* q : held) give_back(q);
       return rc;
     }
     if (ms < best_ms) { best_ms = ms; best = p; }
   }
   for (void* p : held)
-    if (p && p != best) (void)hipFree(p);
+    if (p && p != best) give_back(p);
   if (!best) return fail(NTHIP_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
   *out = best;
   if (gbps) *gbps = (double)bytes / (best_ms * 1e-3) / 1e9;
   if (tried) *tried = n;
   return NTHIP_OK;
+}
+
+// A buffer whose virtual range is mapped from many small physical allocations (HIP's virtual-memory API).
+bool ntamd::host::scattered_alloc(nthip_ctx* c, size_t bytes, size_t piece, void** out)
+{
+  *out = nullptr;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = c->device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) {
+    (void)hipGetLastError();
+    return false;
+  }
+  const size_t unit = gran > ((size_t)2 << 20) ? gran : ((size_t)2 << 20);
+  const size_t total = (bytes + unit - 1) / unit * unit;
+  piece = (piece + unit - 1) / unit * unit;
+  void* va = nullptr;
+  if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  nthip_ctx::ScatteredAlloc rec;
+  rec.bytes = total;
+  bool ok = true;
+  for (size_t off = 0; off < total && ok; off += piece) {
+    const size_t sz = total - off < piece ? total - off : piece;
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, sz, &prop, 0) != hipSuccess) { ok = false; break; }
+    if (hipMemMap((char*)va + off, sz, 0, h, 0) != hipSuccess) {
+      (void)hipMemRelease(h);
+      ok = false;
+      break;
+    }
+    rec.pieces.emplace_back(h, sz);
+  }
+  if (ok) {
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    ok = hipMemSetAccess(va, total, &acc, 1) == hipSuccess;
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    size_t off = 0;
+    for (auto& pc : rec.pieces) {
+      (void)hipMemUnmap((char*)va + off, pc.second);
+      (void)hipMemRelease(pc.first);
+      off += pc.second;
+    }
+    (void)hipMemAddressFree(va, total);
+    return false;
+  }
+  c->scattered[va] = std::move(rec);
+  *out = va;
+  return true;
+}
+
+bool ntamd::host::scattered_free(nthip_ctx* c, void* p)
+{
+  auto it = c->scattered.find(p);
+  if (it == c->scattered.end()) return false;
+  (void)hipDeviceSynchronize();
+  size_t off = 0;
+  for (auto& pc : it->second.pieces) {
+    (void)hipMemUnmap((char*)p + off, pc.second);
+    (void)hipMemRelease(pc.first);
+    off += pc.second;
+  }
+  (void)hipMemAddressFree(p, it->second.bytes);
+  c->scattered.erase(it);
+  return true;
 }

@@ -1790,6 +1790,23 @@ def test_placement_aware_allocation(ctx):
     p, gbps, tried = ctx.malloc_probed(1 << 20, 3)
     assert p and tried == 1 and gbps == 0
     ctx.free(p)
+    # candidates after the first are mapped from small physical pieces (virtual-memory API): an odd size, copies both
+    # ways over the whole range, many allocations and frees in a row, a context closed with one still alive
+    import nthash_amd
+    nb = (300 << 20) + 12345
+    for it in range(6):
+        p, gbps, tried = ctx.malloc_probed(nb, 4)
+        assert p and tried >= 2
+        src = np.random.default_rng(it).integers(0, 256, nb, dtype=np.uint8)
+        ctx.h2d(p, src)
+        back = np.empty(nb, np.uint8)
+        ctx.d2h(back, p)
+        assert (back == src).all()
+        ctx.free(p)
+    other = nthash_amd.Context(0)
+    p, _, _ = other.malloc_probed(256 << 20, 3)
+    assert p
+    other.close()
 
 
 def test_seed_offsets_are_surveyed(ctx, oracle):
