@@ -1,6 +1,7 @@
 // capi_seed.hip -- spaced seeds: nthip_seeds_*, nthip_seed_hash
 // Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
 #include "capi_internal.hpp"
+#include "seed_long_kernels.hpp"
 #include "seed_kernels.hpp"
 #include "kmer_reads_kernel.hpp" // the mark pass (reads with a non-base) is shared with the k-mer path
 #include "seed_parse.hpp"
@@ -632,6 +633,119 @@ int launch_seed_fixed(nthip_ctx* c, K kernel, const SeedFixedArgs& a, size_t dyn
 
 } // namespace
 
+// Long reads (seed_long_kernels.hpp): the batch's reads are cut into independent pieces of about SEED_LONG_S windows at
+// positions with 2k bases around them, the pieces go through the span path (a wave per piece instead of a wave per
+// read), counts and positions are folded back per read.  *handled = false: nothing done.
+namespace {
+constexpr uint64_t SEED_LONG_MIN = 16384; // reads from this length on are worth cutting
+struct DevTemp { // device temporaries of one call
+  std::vector<void*> ptrs;
+  ~DevTemp() { for (void* p : ptrs) (void)hipFree(p); }
+  template <typename T> int get(T** out, size_t n)
+  {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+    ptrs.push_back(p);
+    *out = (T*)p;
+    return NTHIP_OK;
+  }
+};
+int run_seed_long(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd, uint32_t m2,
+                  uint64_t capacity, uint64_t* total, bool* handled)
+{
+  *handled = false;
+  const uint64_t n = rd->n_reads;
+  if (n == 0 || c->tune.no_seed_long || c->tune.no_seed_wave) return NTHIP_OK;
+  SeedLongArgs a;
+  memset(&a, 0, sizeof a);
+  a.seqs = st.seqs;
+  a.offsets = st.offsets;
+  a.n_reads = n;
+  a.len = rd->fixed_len;
+  a.stride = rd->stride ? rd->stride : rd->fixed_len;
+  a.k = sd->k;
+  a.S = sd->k * 4u > 1280u ? sd->k * 4u : 1280u;
+  DevTemp tmp;
+  const unsigned gblocks = (unsigned)c->n_cu * 8;
+  uint64_t* d_tot = nullptr;
+  NTCHK(tmp.get(&d_tot, 2));
+  uint64_t P = 0;
+  if (st.offsets) {
+    uint64_t *d_pieces = nullptr, *d_pbase = nullptr, *d_sums = nullptr;
+    NTCHK(tmp.get(&d_pieces, n));
+    NTCHK(tmp.get(&d_pbase, n + 1));
+    NTCHK(tmp.get(&d_sums, (n + SCAN_TILE - 1) / SCAN_TILE + 16));
+    hipLaunchKernelGGL(seed_long_count_kernel, dim3(gblocks), dim3(256), 0, c->stream, a, d_pieces);
+    HIPCHK(hipGetLastError());
+    NTCHK(device_exclusive_scan(c, d_pieces, d_pbase, n, d_sums, d_tot));
+    HIPCHK(hipMemcpyAsync(d_pbase + n, d_tot, 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_small + 8, d_tot, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(&P, c->h_small + 8, 8);
+    a.pbase = d_pbase;
+  } else {
+    a.pieces_per_read = a.len < a.k ? 1 : (a.len - a.k + 1 + a.S - 1) / a.S;
+    P = n * a.pieces_per_read;
+  }
+  a.n_pieces = P;
+  if (P <= n) return NTHIP_OK; // no read is longer than a piece
+  uint64_t *d_valid = nullptr, *d_cut = nullptr, *d_idx = nullptr, *d_sums2 = nullptr;
+  NTCHK(tmp.get(&d_valid, P));
+  NTCHK(tmp.get(&d_cut, P));
+  NTCHK(tmp.get(&d_idx, P));
+  NTCHK(tmp.get(&d_sums2, (P + SCAN_TILE - 1) / SCAN_TILE + 16));
+  hipLaunchKernelGGL(seed_long_cut_kernel, dim3(gblocks), dim3(256), 0, c->stream, a, d_valid, d_cut);
+  HIPCHK(hipGetLastError());
+  NTCHK(device_exclusive_scan(c, d_valid, d_idx, P, d_sums2, d_tot));
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_tot, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t m = 0;
+  memcpy(&m, c->h_small + 8, 8);
+  uint64_t *d_ss = nullptr, *d_se = nullptr, *d_sr = nullptr, *d_rel = nullptr, *d_cnt = nullptr;
+  NTCHK(tmp.get(&d_ss, m));
+  NTCHK(tmp.get(&d_se, m));
+  NTCHK(tmp.get(&d_sr, m));
+  NTCHK(tmp.get(&d_rel, m));
+  NTCHK(tmp.get(&d_cnt, m));
+  hipLaunchKernelGGL(seed_long_spans_kernel, dim3(gblocks), dim3(256), 0, c->stream, a, d_valid, d_idx, d_cut, d_ss, d_se,
+                     d_sr, d_rel);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(d_cnt, 0, m * 8, c->stream));
+  // ---- the pieces as a batch of spans ----
+  Staged st2;
+  st2.seqs = st.seqs;
+  st2.offsets = d_ss;
+  st2.hashes = st.hashes;
+  st2.counts = d_cnt;
+  st2.pos = st.pos;
+  st2.fwd = st.fwd;
+  st2.rev = st.rev;
+  nthip_reads rd2 = *rd;
+  rd2.n_reads = m;
+  rd2.offsets = d_ss; // (a device pointer: only its being non-NULL matters from here on)
+  rd2.fixed_len = 0;
+  rd2.stride = 0;
+  NTCHK(run_seed_general(c, st2, &rd2, sd, m2, capacity, total, d_se, false));
+  // ---- back to the caller's reads ----
+  if (st.counts) {
+    HIPCHK(hipMemsetAsync(st.counts, 0, n * 8, c->stream));
+    hipLaunchKernelGGL(seed_long_fold_counts_kernel, dim3(gblocks), dim3(256), 0, c->stream, d_cnt, d_sr, m, st.counts);
+    HIPCHK(hipGetLastError());
+  }
+  if (st.pos) {
+    uint64_t *d_off = nullptr, *d_sums3 = nullptr;
+    NTCHK(tmp.get(&d_off, m));
+    NTCHK(tmp.get(&d_sums3, (m + SCAN_TILE - 1) / SCAN_TILE + 16));
+    NTCHK(device_exclusive_scan(c, d_cnt, d_off, m, d_sums3, d_tot));
+    hipLaunchKernelGGL(seed_long_fold_pos_kernel, dim3(gblocks), dim3(256), 0, c->stream, d_cnt, d_off, d_rel, m, st.pos);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *handled = true;
+  return NTHIP_OK;
+}
+} // namespace
+
 extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nthip_seeds* sd, uint8_t m28,
                                const nthip_out* out, uint64_t* total_out, uint32_t flags)
 {
@@ -657,10 +771,12 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
 
   // offsets: one pass over them before anything trusts them (order, bounds), and reads that all have one length and
   // lie back to back are a fixed-length batch (as in nthip_kmer_hash): the dense kernel instead of the variable-length path
+  uint64_t max_len = rd->fixed_len; // the longest read of the batch
   if (st.offsets) {
     OffsetsSurvey sv;
     NTCHK(offsets_survey_device(c, st.offsets, rd->n_reads, total_bytes, &sv));
     if (sv.bad) return fail(NTHIP_ERR_ARG, "offsets / spans are not non-decreasing or reach outside the read buffer");
+    max_len = sv.max_len;
     if (sv.uniform && !(flags & NTHIP_FORCE_GENERAL) && rd->n_reads >= 1024 && sv.len0 >= 1 && sv.len0 < (1ull << 30) &&
         sv.off0 + rd->n_reads * sv.len0 <= total_bytes) {
       st.seqs += sv.off0;
@@ -771,7 +887,8 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
           HIPCHK(hipGetLastError());
         }
         done = true;
-      } else if (block_fits && dyn + (size_t)rpt * 8 <= 158 * 1024 && dyn + (size_t)rpt * 8 <= c->lds_max) {
+      } else if (block_fits && dyn + (size_t)rpt * 8 <= 158 * 1024 && dyn + (size_t)rpt * 8 <= c->lds_max &&
+                 (len < SEED_LONG_MIN || c->tune.no_seed_long)) { // (long reads with a non-base: cut into pieces below)
         // Batch with non-bases.  SeedNtHash's position state machine (App. B Q3) only matters for the reads
         // that HAVE a non-base: those (usually a fraction of a percent) go through seed_general_kernel, every
         // other read emits all its windows and stays on the fast kernel, writing at its place in the compact
@@ -873,6 +990,12 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
         done = true;
       }
     }
+  }
+  if (!done && max_len >= SEED_LONG_MIN && !(flags & NTHIP_FORCE_GENERAL)) {
+    // chromosomes / contigs: one wave per read would leave the chip idle; independent pieces instead
+    bool handled = false;
+    NTCHK(run_seed_long(c, st, rd, sd, m2, out->capacity, &total, &handled));
+    done = handled;
   }
   if (!done) NTCHK(run_seed_general(c, st, rd, sd, m2, out->capacity, &total, nullptr, !(flags & NTHIP_FORCE_GENERAL)));
   if (total_out) *total_out = total;

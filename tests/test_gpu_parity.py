@@ -1910,3 +1910,87 @@ def test_seed_passes_vs_oracle(oracle):
                 assert (got[key] == want[key]).all(), (k, n_seeds, m2, key, c is planned)
     planned.close()
     single.close()
+
+
+def test_seed_long_reads_cut_into_pieces(ctx, oracle):
+    """SeedNtHash on long reads (nthip_seed_hash, offsets and fixed length): the reads are cut into independent pieces at
+    positions with 2k bases around them (seed_long_kernels.hpp) -- counts, positions and hashes against the oracle's
+    sequential walk; non-bases single, in runs of k - 1 / k / k + 1 / thousands, right at the nominal cuts, NUL bytes,
+    a clean read, a read of non-bases only, k up to 100"""
+    import os
+    import nthash_amd
+    rng = np.random.default_rng(20260929)
+    alph = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
+
+    def mask(k, density):
+        m = (rng.random(k) < density).astype(int)
+        m[0] = m[-1] = 1
+        return "".join(str(int(x)) for x in m)
+
+    def long_read(n, k, kind):
+        d = alph[rng.integers(0, 8, n)].copy()
+        if kind == "clean":
+            return d
+        if kind == "all_n":
+            d[:] = ord("N")
+            return d
+        S = max(1280, 4 * k)
+        for _ in range(int(rng.integers(3, 40))):  # runs of non-bases of telling lengths
+            ln = int(rng.choice([1, 1, 2, k - 1, k, k + 1, 2 * k, 3 * k + 5, 700, 5000]))
+            at = int(rng.integers(0, max(1, n - ln)))
+            d[at:at + ln] = ord("N")
+        for j in range(1, n // S):  # and right around the nominal cuts
+            if rng.random() < 0.3:
+                at = j * S + int(rng.integers(-2 * k - 2, S // 2 + 2 * k))
+                if 0 <= at < n:
+                    d[at] = rng.choice(np.frombuffer(b"NnRY-\x00", dtype=np.uint8))
+        return d
+
+    cases = [(31, 2, 2, [(60_000, "dirty"), (200_000, "dirty"), (300, "dirty"), (20_000, "clean"), (17_000, "all_n"), (0, "clean")]),
+             (64, 1, 3, [(150_000, "dirty"), (16_384, "dirty")]),
+             (100, 2, 1, [(90_000, "dirty")]),
+             (17, 3, 1, [(120_000, "dirty"), (40_000, "dirty"), (90, "clean")])]
+    for (k, n_seeds, m2, reads) in cases:
+        seeds = [mask(k, 0.7) for _ in range(n_seeds)]
+        parts = [long_read(n, k, kind) for (n, kind) in reads]
+        d = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+        offs = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+        want = oracle.seed_batch(d, offs, seeds, k, m2)
+        ctx.set_profiling(True)
+        got = ctx.seed_hash(d, seeds, k, m2, offsets=offs, want_pos=True)
+        name = ctx.last_kernel_ms()[1]
+        ctx.set_profiling(False)
+        assert name in ("seed_wave_kernel", "seed_rtile_kernel"), name
+        assert got["total"] == want["total"], (k, n_seeds, m2)
+        for key in ("counts", "pos", "hashes"):
+            assert (got[key] == want[key]).all(), (k, n_seeds, m2, key)
+    # fixed length: four reads of 100 kbase with non-bases; one clean read of 1 Mbase (beyond the block-tile kernel's LDS)
+    k, m2, seeds = 31, 3, [SEED_A, SEED_B]
+    L = 100_000
+    d = np.concatenate([long_read(L, k, "dirty") for _ in range(4)])
+    offs = np.arange(5, dtype=np.uint64) * L
+    want = oracle.seed_batch(d, offs, seeds, k, m2)
+    got = ctx.seed_hash(d, seeds, k, m2, fixed_len=L, n_reads=4, want_pos=True)
+    assert got["total"] == want["total"]
+    for key in ("counts", "pos", "hashes"):
+        assert (got[key] == want[key]).all(), key
+    d = long_read(1_000_000, k, "clean")
+    offs = np.array([0, len(d)], dtype=np.uint64)
+    want = oracle.seed_batch(d, offs, seeds, k, m2, want_pos=False)
+    got = ctx.seed_hash(d, seeds, k, m2, fixed_len=len(d), n_reads=1)
+    assert got["total"] == want["total"] == len(d) - k + 1
+    assert (got["hashes"] == want["hashes"]).all()
+    # the pieces against one wave per read (NTHIP_TUNE_NO_SEED_LONG=1), a read with many cuts refused
+    os.environ["NTHIP_TUNE_NO_SEED_LONG"] = "1"
+    try:
+        whole = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_NO_SEED_LONG", None)
+    d = long_read(400_000, k, "dirty")
+    offs = np.array([0, len(d)], dtype=np.uint64)
+    g1 = ctx.seed_hash(d, seeds, k, m2, offsets=offs, want_pos=True)
+    g2 = whole.seed_hash(d, seeds, k, m2, offsets=offs, want_pos=True)
+    assert g1["total"] == g2["total"]
+    for key in ("counts", "pos", "hashes"):
+        assert (g1[key] == g2[key]).all(), key
+    whole.close()
