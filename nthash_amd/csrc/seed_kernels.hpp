@@ -1150,20 +1150,23 @@ __global__ __launch_bounds__(1024) void seed_wave_kernel(const SeedGeneralArgs* 
             // and jumps iff q >= last init + k
             uint64_t last_trigger = 0;
             bool have = false;
-            for (uint32_t w = 0; 32u * w < nb; ++w) {
-              uint32_t word = vbits[w];
-              while (word) {
-                const uint32_t qr = 32u * w + (uint32_t)__builtin_ctz(word);
-                word &= word - 1u;
-                if (qr >= nb) break;
-                const uint64_t q = ws + qr;
-                if (q >= ws + k && q >= last_init + k) {
-                  last_init = q;
-                  last_trigger = q;
-                  have = true;
-                  tbits[qr >> 5] |= 1u << (qr & 31u);
-                }
-              }
+            // from trigger to trigger: the next one is the first non-base at or after (last init + k), so a run of
+            // thousands of non-bases costs one step per k of them, not one per character
+            uint64_t from = last_init + k > ws + k ? last_init + k : ws + k;
+            while (from < ws + nb) {
+              uint32_t qr = (uint32_t)(from - ws);
+              uint32_t w = qr >> 5;
+              uint32_t word = vbits[w] & (~0u << (qr & 31u));
+              while (!word && 32u * (w + 1u) < nb) word = vbits[++w];
+              if (!word) break;
+              qr = 32u * w + (uint32_t)__builtin_ctz(word);
+              if (qr >= nb) break;
+              const uint64_t q = ws + qr;
+              last_init = q;
+              last_trigger = q;
+              have = true;
+              tbits[qr >> 5] |= 1u << (qr & 31u);
+              from = q + k;
             }
             if (have && last_trigger > next_pos) next_pos = last_trigger;
             if (have && last_trigger >= we) need_init = 1; // its window reaches into the next segment
@@ -1192,6 +1195,19 @@ __global__ __launch_bounds__(1024) void seed_wave_kernel(const SeedGeneralArgs* 
         if (emit) {
           // NW == 0 (k > 64): every window by Horner over its raw bytes, no tables
           const bool dirty_win = NW == 0 || (any_bad && (windows_with_non_base(vbits, pc, k) & 1u));
+          // a window inside a run of 'N' (the emitted one of every k there): nothing to add up.  Only for the letter N /
+          // n itself -- bytes 1, 3, 4, 5, 7 are non-bases that still carry a value on the reverse strand (SEED_TAB)
+          bool blank_win = false;
+          if (NW != 0 && dirty_win) {
+            blank_win = true;
+            for (uint32_t q = 0; q < k && blank_win; q += 4u) {
+              uint32_t w4;
+              __builtin_memcpy(&w4, raw + pc + q, 4); // (raw holds 64 bytes past the segment)
+              w4 |= 0x20202020u;                        // lower case
+              const uint32_t keep = k - q >= 4u ? 0xFFFFFFFFu : (1u << (8u * (k - q))) - 1u;
+              blank_win = ((w4 ^ 0x6E6E6E6Eu) & keep) == 0u;
+            }
+          }
           uint64_t* mine = otile + slot * per;
           uint32_t wwords[NW ? NW : 1];
           if (!dirty_win) {
@@ -1206,7 +1222,9 @@ __global__ __launch_bounds__(1024) void seed_wave_kernel(const SeedGeneralArgs* 
           }
           for (uint32_t sdx = 0; sdx < a.n_seeds; ++sdx) {
             uint64_t fh = 0, rh = 0;
-            if (!dirty_win) {
+            if (blank_win) {
+              // (every character a non-base other than the table's odd entries: all seed values are 0)
+            } else if (!dirty_win) {
               const uint4* ts = tabs + sdx * a.ntab * 256u;
               uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
 #pragma unroll
@@ -1218,14 +1236,20 @@ __global__ __launch_bounds__(1024) void seed_wave_kernel(const SeedGeneralArgs* 
               fh = ((uint64_t)f1 << 32) | f0;
               rh = ((uint64_t)r1 << 32) | r0;
             } else {
+              // (the care word in a register: one global load per 32 positions, not one per position -- a segment
+              //  inside a long run of N took a millisecond with the latter)
               const uint32_t* care = a.care_bits + sdx * a.care_words;
               const uint8_t* win = raw + pc;
+              uint32_t cw = 0;
               for (uint32_t q = 0; q < k; ++q) {
-                const bool c = (care[q >> 5] >> (q & 31u)) & 1u;
+                if ((q & 31u) == 0u) cw = care[q >> 5];
+                const bool c = (cw >> (q & 31u)) & 1u;
                 fh = srol1(fh) ^ (c ? fwd_seed(win[q]) : 0);
               }
+              cw = care[(k - 1u) >> 5];
               for (uint32_t q = k; q-- > 0;) {
-                const bool c = (care[q >> 5] >> (q & 31u)) & 1u;
+                if ((q & 31u) == 31u) cw = care[q >> 5];
+                const bool c = (cw >> (q & 31u)) & 1u;
                 rh = srol1(rh) ^ (c ? rc_seed(win[q]) : 0);
               }
             }

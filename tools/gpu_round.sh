@@ -1,6 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -4
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 2400 bash tools/profile_round.sh r02f 2>&1 | tail -60
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_facade.py -q -m gpu -x -k "seed or Seed" 2>&1 | tail -3
+timeout 900 python tools/stress_seeds.py 400 21 2>&1 | tail -1
+for r in 1000 50000 1,10,100,1000,50000; do echo "runs of $r"; LSB_RUNS=$r timeout 600 python tools/long_seed_bench.py 50 1 2>&1 | head -2; done

@@ -26,7 +26,9 @@ for name, env in (("pieces", None), ("one wave per read", "1")):
     # runs of N: one in ~200 kbase, 1 .. 50 000 long, the same for both contexts
     r2 = np.random.default_rng(5)
     for at in r2.integers(0, n * L - 60_000, n * L // 200_000):
-        ln = int(r2.choice([1, 10, 100, 1000, 50_000]))
+        ln = int(r2.choice([int(x) for x in os.environ.get("LSB_RUNS", "1,10,100,1000,50000").split(",")]))
+        if ln == 0:
+            continue
         ctx.h2d(d_in + int(at), np.full(ln, ord("N"), np.uint8))
     d_offs = ctx.malloc((n + 1) * 8)
     ctx.h2d(d_offs, offs)
