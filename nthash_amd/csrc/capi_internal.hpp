@@ -11,7 +11,8 @@
 //   capi_kmer_reads.hip    kmer_reads_kernel (offsets / spans in order, short reads): tiles of whole reads
 //   capi_kmer_ragged.hip   kmer_ragged_kernel (offsets / spans, any lengths)
 //   capi_kmer_general.hip  lane-per-read kernels (correctness paths) and the row-per-read kernel
-//   capi_seed.hip          spaced seeds
+//   capi_seed.hip          spaced seeds: dense (seed_wtile / seed_fixed), variable-length (seed_rtile), one wave per read
+//                          (seed_wave), long reads cut into pieces (seed_long_kernels.hpp), lane per read (seed_general)
 //   capi_sink_bloom.hip / capi_sink_minhash.hip   fused consumers
 //   capi_fastx.hip         FASTQ / FASTA indexing and the file streaming driver
 //   capi_multi.hip         several devices of one node: shards of a host batch, one thread + context per device
