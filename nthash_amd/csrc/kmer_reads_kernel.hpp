@@ -564,8 +564,11 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
 // max length, max distance between consecutive starts, order, total length: what the host needs to size the tiles
 static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* __restrict__ starts,
                                                                 const uint64_t* __restrict__ ends, uint64_t n,
-                                                                uint64_t buf_bytes, unsigned long long* __restrict__ res)
+                                                                uint64_t buf_bytes, unsigned long long* __restrict__ res,
+                                                                uint32_t allow_overlap = 0)
 {
+  // allow_overlap: consecutive reads may share bytes as long as starts and ends both go up (the pieces of a long read
+  // overlap by k - 1: seed_rtile_kernel only needs a tile's reads inside one slab that ends with the last read)
   uint64_t mlen = 0, mpitch = 0, slen = 0;
   uint32_t bad = 0;
   for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
@@ -575,7 +578,7 @@ static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* 
     slen += e0 - s0;
     if (r + 1 < n) {
       const uint64_t s1 = starts[r + 1];
-      if (s1 < e0) bad = 1; // not in order, or overlapping
+      if (s1 < e0 && !(allow_overlap && s1 >= s0 && ends[r + 1] >= e0)) bad = 1; // not in order, or overlapping
       else if (s1 - s0 > mpitch) mpitch = s1 - s0;
     }
   }

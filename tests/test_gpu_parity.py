@@ -1960,6 +1960,8 @@ def test_seed_long_reads_cut_into_pieces(ctx, oracle):
         got = ctx.seed_hash(d, seeds, k, m2, offsets=offs, want_pos=True)
         name = ctx.last_kernel_ms()[1]
         ctx.set_profiling(False)
+        # (the pieces are spans in order that overlap by k - 1: tiles of whole pieces unless one of them -- a long run of
+        #  non-bases has no cut -- is longer than a tile's slab, then a wave per piece)
         assert name in ("seed_wave_kernel", "seed_rtile_kernel"), name
         assert got["total"] == want["total"], (k, n_seeds, m2)
         for key in ("counts", "pos", "hashes"):

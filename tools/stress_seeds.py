@@ -22,7 +22,7 @@ for it in range(iters):
         if "1" not in sd:
             sd = "1" + sd[1:]
         seeds.append(sd)
-    kind = rng.integers(0, 2)
+    kind = rng.integers(0, 2) if rng.random() < 0.85 else 2
     bad_rate = rng.choice([0.0, 0.0005, 0.005, 0.05])
     if kind == 0:
         L = int(k + rng.integers(0, 300))
@@ -34,6 +34,24 @@ for it in range(iters):
             data[rng.integers(0, total, nb)] = bad_alph[rng.integers(0, len(bad_alph), nb)]
         kw = dict(fixed_len=L, n_reads=n)
         desc = f"fixed n={n} L={L}"
+    elif kind == 2:  # a few long reads (cut into independent pieces): runs of non-bases of every length, some at the cuts
+        n = int(rng.integers(1, 5))
+        fixed = bool(rng.random() < 0.4)
+        lens = np.full(n, int(rng.integers(16_384, 120_000))) if fixed else rng.integers(10_000, 250_000, n)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        total = int(offs[-1])
+        data = alph[rng.integers(0, len(alph), total)]
+        for _ in range(int(rng.integers(0, 60))):
+            ln = int(rng.choice([1, 1, 2, max(1, k - 1), k, k + 1, 3 * k, 500, 3000, 20000]))
+            ln = min(ln, total)
+            at = int(rng.integers(0, max(1, total - ln)))
+            data[at:at + ln] = bad_alph[rng.integers(0, len(bad_alph))] if rng.random() < 0.7 else bad_alph[rng.integers(0, len(bad_alph), ln)]
+        S = max(1280, 4 * k)
+        for j in range(1, total // S):
+            if rng.random() < 0.1:
+                data[min(total - 1, j * S + int(rng.integers(0, S)))] = bad_alph[rng.integers(0, len(bad_alph))]
+        kw = dict(fixed_len=int(lens[0]), n_reads=n) if fixed else dict(offsets=offs)
+        desc = f"long n={n} bytes={total} fixed={fixed}"
     else:
         n = int(rng.integers(1, 1500))
         lens = np.where(rng.random(n) < 0.1, rng.integers(0, k + 2, n), rng.integers(0, 500, n))
