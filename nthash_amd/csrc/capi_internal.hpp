@@ -305,6 +305,10 @@ int launch_kmer_rows(nthip_ctx* c, const KmerFixedArgs& a, size_t dyn_lds);
 int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd, uint32_t m2,
                      uint64_t capacity, uint64_t* total, const uint64_t* d_ends = nullptr, bool fixed_as_spans = false);
 
+// reads of >= 16 384 bases cut into independent pieces (seed_long_kernels.hpp); *handled = false: no such read, nothing done
+int run_seed_long(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd, uint32_t m2, uint64_t capacity,
+                  uint64_t* total, bool* handled, const uint64_t* d_ends = nullptr);
+
 // ---- templates every launching TU uses --------------------------------------------------------------------------
 template <typename K>
 int set_max_lds(K kernel, size_t bytes)

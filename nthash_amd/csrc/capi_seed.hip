@@ -650,8 +650,9 @@ struct DevTemp { // device temporaries of one call
     return NTHIP_OK;
   }
 };
-int run_seed_long(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd, uint32_t m2,
-                  uint64_t capacity, uint64_t* total, bool* handled)
+} // namespace
+int ntamd::host::run_seed_long(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd, uint32_t m2,
+                               uint64_t capacity, uint64_t* total, bool* handled, const uint64_t* d_ends)
 {
   *handled = false;
   const uint64_t n = rd->n_reads;
@@ -660,6 +661,7 @@ int run_seed_long(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const n
   memset(&a, 0, sizeof a);
   a.seqs = st.seqs;
   a.offsets = st.offsets;
+  a.ends = d_ends;
   a.n_reads = n;
   a.len = rd->fixed_len;
   a.stride = rd->stride ? rd->stride : rd->fixed_len;
@@ -744,7 +746,6 @@ int run_seed_long(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const n
   *handled = true;
   return NTHIP_OK;
 }
-} // namespace
 
 extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nthip_seeds* sd, uint8_t m28,
                                const nthip_out* out, uint64_t* total_out, uint32_t flags)

@@ -69,7 +69,10 @@ extern "C" int nthip_seed_hash_spans(nthip_ctx* c, const char* d_buf, uint64_t b
   NTCHK(stage_outputs(c, out, flags, n_reads, per, st, sd->n_seeds));
   nthip_reads rd = {d_buf, d_starts, n_reads, 0, 0};
   uint64_t total = 0;
-  int rc = run_seed_general(c, st, &rd, sd, m2, out->capacity, &total, d_ends);
+  int rc = NTHIP_OK;
+  bool long_done = false;
+  if (!(flags & NTHIP_FORCE_GENERAL)) rc = run_seed_long(c, st, &rd, sd, m2, out->capacity, &total, &long_done, d_ends);
+  if (rc == NTHIP_OK && !long_done) rc = run_seed_general(c, st, &rd, sd, m2, out->capacity, &total, d_ends);
   if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
   NTCHK(rc);
   if (total_out) *total_out = total;

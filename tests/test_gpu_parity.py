@@ -1996,3 +1996,47 @@ def test_seed_long_reads_cut_into_pieces(ctx, oracle):
     for key in ("counts", "pos", "hashes"):
         assert (g1[key] == g2[key]).all(), key
     whole.close()
+
+
+def test_seed_long_reads_as_spans(ctx, oracle):
+    """nthip_seed_hash_spans (what the FASTA / FASTQ driver calls) with contig-sized records between header lines: the
+    long ones are cut into pieces as in nthip_seed_hash; counts, positions, hashes against the oracle"""
+    import nthash_amd
+    rng = np.random.default_rng(31337)
+    alph = np.frombuffer(b"ACGT", dtype=np.uint8)
+    k, m2, seeds = 31, 2, [SEED_A, SEED_B]
+    reads = []
+    for n in (70_000, 150, 33_000, 0, 16_384, 2_500):
+        d = alph[rng.integers(0, 4, n)].copy()
+        for _ in range(n // 9000):
+            ln = int(rng.choice([1, k, 400, 3000]))
+            at = int(rng.integers(0, max(1, n - ln)))
+            d[at:at + ln] = ord("N")
+        reads.append(d.tobytes())
+    buf = bytearray()
+    starts, ends = [], []
+    for i, r in enumerate(reads):
+        buf += b">contig%d some text\n" % i
+        starts.append(len(buf)); buf += r; ends.append(len(buf))
+        buf += b"\n"
+    raw = np.frombuffer(bytes(buf), dtype=np.uint8)
+    d, offs = concat_reads(reads)
+    want = oracle.seed_batch(d, offs, seeds, k, m2)
+    cap = max(1, want["total"])
+    per = len(seeds) * m2
+    sd = nthash_amd.Seeds(ctx, seeds, k)
+    d_buf = ctx.malloc(raw.size + 16); d_s = ctx.malloc(8 * len(reads)); d_e = ctx.malloc(8 * len(reads))
+    d_h = ctx.malloc(cap * per * 8); d_c = ctx.malloc(8 * len(reads)); d_p = ctx.malloc(4 * cap)
+    try:
+        ctx.h2d(d_buf, raw); ctx.h2d(d_s, np.array(starts, np.uint64)); ctx.h2d(d_e, np.array(ends, np.uint64))
+        tot = ctx.seed_hash_spans_ptr(d_buf, raw.size, d_s, d_e, len(reads), sd, m2, d_h, cap, counts=d_c, pos=d_p)
+        assert tot == want["total"]
+        h = np.zeros(cap * per, np.uint64); cts = np.zeros(len(reads), np.uint64); ps = np.zeros(cap, np.uint32)
+        ctx.d2h(h, d_h); ctx.d2h(cts, d_c); ctx.d2h(ps, d_p)
+        assert (cts == want["counts"]).all()
+        assert (ps[:tot] == want["pos"]).all()
+        assert (h[: tot * per].reshape(-1, per) == want["hashes"]).all()
+    finally:
+        for ptr in (d_buf, d_s, d_e, d_h, d_c, d_p):
+            ctx.free(ptr)
+        sd.close()
