@@ -696,7 +696,8 @@ int ntamd::host::run_seed_long(nthip_ctx* c, const Staged& st, const nthip_reads
   NTCHK(tmp.get(&d_cut, P));
   NTCHK(tmp.get(&d_idx, P));
   NTCHK(tmp.get(&d_sums2, (P + SCAN_TILE - 1) / SCAN_TILE + 16));
-  hipLaunchKernelGGL(seed_long_cut_kernel, dim3(gblocks), dim3(256), 0, c->stream, a, d_valid, d_cut);
+  hipLaunchKernelGGL(seed_long_lastbase_kernel, dim3(gblocks), dim3(256), 0, c->stream, a, d_idx); // (d_idx: free until the scan)
+  hipLaunchKernelGGL(seed_long_cut_kernel, dim3(gblocks), dim3(256), 0, c->stream, a, (const uint64_t*)d_idx, d_valid, d_cut);
   HIPCHK(hipGetLastError());
   NTCHK(device_exclusive_scan(c, d_valid, d_idx, P, d_sums2, d_tot));
   HIPCHK(hipMemcpyAsync(c->h_small + 8, d_tot, 8, hipMemcpyDeviceToHost, c->stream));

@@ -76,10 +76,40 @@ __device__ __forceinline__ void seed_long_piece(const SeedLongArgs& a, uint64_t 
   j = p - a.pbase[lo];
 }
 
+// One lane per nominal piece: the last character of its S bytes [j S, (j + 1) S) that is not the letter N / n
+// (~0: there is none) -- what the cut kernel needs to find where a long run of N began.
+static __global__ __launch_bounds__(256) void seed_long_lastbase_kernel(const SeedLongArgs a, uint64_t* __restrict__ last_not_n)
+{
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.n_pieces; p += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t r, j;
+    seed_long_piece(a, p, r, j);
+    uint64_t start, len;
+    seed_long_read_of(a, r, start, len);
+    const uint64_t lo = j * (uint64_t)a.S;
+    uint64_t hi = lo + a.S;
+    if (hi > len) hi = len;
+    const uint8_t* s = a.seqs + start;
+    uint64_t found = ~0ull;
+    for (uint64_t x = hi; x-- > lo;)
+      if ((s[x] | 0x20u) != 'n') {
+        found = x;
+        break;
+      }
+    last_not_n[p] = found;
+  }
+}
+
 // One lane per nominal piece: the cut that starts it.  Piece 0 of a read starts at 0; piece j > 0 at the first
 // c in [j S, j S + S / 2) with [c - k, c + k) all bases, if there is one (valid = 0 otherwise: the piece before it grows).
-static __global__ __launch_bounds__(256) void seed_long_cut_kernel(const SeedLongArgs a, uint64_t* __restrict__ valid,
-                                                                   uint64_t* __restrict__ cut)
+//
+// Inside a long run of the letter N there is no such c, but there is another kind of exact cut: a position where the
+// walk RESTARTS.  If the run begins at r0 >= k behind k bases, its first N restarts the walk (no earlier restart lies
+// within k), and so does every k-th N after it; a run that begins before position k restarts at k, 2k, ...
+// (src/seed.cpp:518-544).  A piece that starts AT a restart c is an independent read: the reference calls init() at c
+// there too (NUL check included), the characters c + 1 .. c + k - 1 cannot restart anything in either walk, and the
+// windows before c only look at characters before c + k - 1.
+static __global__ __launch_bounds__(256) void seed_long_cut_kernel(const SeedLongArgs a, const uint64_t* __restrict__ last_not_n,
+                                                                   uint64_t* __restrict__ valid, uint64_t* __restrict__ cut)
 {
   for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.n_pieces; p += (uint64_t)gridDim.x * blockDim.x) {
     uint64_t r, j;
@@ -105,7 +135,40 @@ static __global__ __launch_bounds__(256) void seed_long_cut_kernel(const SeedLon
         break;
       }
     }
-    valid[p] = found != ~0ull && found < c_hi ? 1 : 0;
+    bool ok = found != ~0ull && found < c_hi;
+    if (!ok && c0 < len && (s[c0] | 0x20u) == 'n' && (s[c0 - 1] | 0x20u) == 'n') {
+      // ---- a run of N around c0: where did it begin? (the pieces before this one know their last other character)
+      uint64_t r0 = 0; // first N of the run
+      for (uint64_t q = p; q-- > p - j;) {
+        const uint64_t l = last_not_n[q];
+        if (l != ~0ull) {
+          r0 = l + 1;
+          break;
+        }
+      }
+      uint64_t q0 = ~0ull; // the run's first restart
+      if (r0 < a.k) {
+        // (c0 >= S >= 4k: position k is inside the run.  The characters before the run must be bases: a NUL among them
+        //  would move the read's first init(), src/seed.cpp:493-516)
+        bool bases = true;
+        for (uint64_t x = 0; x < r0 && bases; ++x) bases = is_base(s[x]);
+        if (bases) q0 = a.k;
+      } else {
+        bool bases = true;
+        for (uint64_t x = r0 - a.k; x < r0 && bases; ++x) bases = is_base(s[x]);
+        if (bases) q0 = r0;
+      }
+      if (q0 != ~0ull) {
+        const uint64_t c = q0 + (c0 - q0 + a.k - 1) / a.k * a.k; // the first restart at or after c0
+        bool run = c < c_hi;
+        for (uint64_t x = c0; x <= c && run; ++x) run = (s[x] | 0x20u) == 'n';
+        if (run) {
+          ok = true;
+          found = c;
+        }
+      }
+    }
+    valid[p] = ok ? 1 : 0;
     cut[p] = found;
   }
 }

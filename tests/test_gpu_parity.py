@@ -1966,6 +1966,36 @@ def test_seed_long_reads_cut_into_pieces(ctx, oracle):
         assert got["total"] == want["total"], (k, n_seeds, m2)
         for key in ("counts", "pos", "hashes"):
             assert (got[key] == want[key]).all(), (k, n_seeds, m2, key)
+    # long runs of the letter N (cuts at the positions where the walk restarts): beginning at the read's start, before
+    # position k, behind bases, behind another non-base / a NUL (no cut there), upper and lower case, another character
+    # inside the run, two runs k - 1 bases apart, a run that reaches the read's end
+    k, m2, seeds = 31, 2, [SEED_A, SEED_B]
+
+    def with_runs(n, runs):
+        d = alph[rng.integers(0, 8, n)].copy()
+        for (at, ln, ch, before) in runs:
+            d[at:at + ln] = np.frombuffer(ch, np.uint8)[np.arange(ln) % len(ch)]
+            if before is not None and at > 0:
+                d[at - 1] = before
+        return d
+
+    crafted = [with_runs(40_000, [(0, 30_000, b"N", None)]),
+               with_runs(40_000, [(7, 30_000, b"N", None)]),
+               with_runs(40_000, [(30, 30_000, b"n", None)]),
+               with_runs(60_000, [(5_000, 40_000, b"Nn", None)]),
+               with_runs(60_000, [(5_000, 40_000, b"N", ord("R"))]),
+               with_runs(60_000, [(5_000, 40_000, b"N", 0)]),
+               with_runs(60_000, [(5_000, 20_000, b"N", None), (25_000, 1, b"-", None), (25_001, 20_000, b"N", None)]),
+               with_runs(60_000, [(5_000, 20_000, b"N", None), (25_000 + k - 1, 20_000, b"N", None)]),
+               with_runs(50_000, [(20_000, 30_000, b"N", None)]),
+               with_runs(50_000, [(3, 49_997, b"N", None)])]
+    d = np.concatenate(crafted)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in crafted])]).astype(np.uint64)
+    want = oracle.seed_batch(d, offs, seeds, k, m2)
+    got = ctx.seed_hash(d, seeds, k, m2, offsets=offs, want_pos=True)
+    assert got["total"] == want["total"]
+    for key in ("counts", "pos", "hashes"):
+        assert (got[key] == want[key]).all(), ("runs of N", key)
     # fixed length: four reads of 100 kbase with non-bases; one clean read of 1 Mbase (beyond the block-tile kernel's LDS)
     k, m2, seeds = 31, 3, [SEED_A, SEED_B]
     L = 100_000
