@@ -526,6 +526,14 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
   } else if (rot_ok && f.n_seeds <= 2) {
     pass_seeds = f.n_seeds;
     rot = true;
+  } else if (rot_ok && f.n_seeds <= 4 && waves_for(2 * 65536, f.n_seeds) != 0 &&
+             (f.m2 == 1 || waves_for(plain_bytes(f.n_seeds), f.n_seeds) < 8)) {
+    // three or four seeds: two table sets of 64 KiB (seeds {0, 1} and {2, 3}), 4 waves beside them.  Pays where the
+    // plain layout is LDS-bound (one hash per seed: 3 seeds 111 -> 144 G k-mers/s, 4 seeds 80 -> 117) or has no more
+    // waves itself (4 seeds x 2: 42 -> 60 G); with 8+ waves beside plain tables and several hashes per seed the plain
+    // layout is ahead (3 x 3: 64 against 62 G; 3 x 2, k = 24: 93 against 81)
+    pass_seeds = f.n_seeds;
+    rot = true;
   } else {
     rot = false;
     uint32_t most = f.n_seeds; // the most seeds whose tables fit beside 4 waves
@@ -533,7 +541,7 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
     const uint32_t passes = (f.n_seeds + most - 1) / most;
     pass_seeds = (f.n_seeds + passes - 1) / passes;
   }
-  const size_t table_bytes = rot ? 65536 : (size_t)pass_seeds * 2 * nh * 256 * sizeof(uint4);
+  const size_t table_bytes = rot ? (size_t)65536 * ((pass_seeds + 1) / 2) : (size_t)pass_seeds * 2 * nh * 256 * sizeof(uint4);
   const uint32_t waves = waves_for(table_bytes, pass_seeds);
   if (!waves) return NTHIP_OK;
   SeedWtileArgs a;
@@ -596,7 +604,15 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
         case 16 + 1: rc = NT_SW(4, 2, 1); break;
         case 16 + 2: rc = NT_SW(4, 2, 2); break;
         case 16 + 3: rc = NT_SW(4, 2, 3); break;
-        default: rc = NT_SW(4, 2, 4); break;
+        case 16 + 4: rc = NT_SW(4, 2, 4); break;
+        case 24 + 1: rc = go(seed_wtile_kernel<4, 3, 1>); break; // (three / four seeds: always the whole seed set)
+        case 24 + 2: rc = go(seed_wtile_kernel<4, 3, 2>); break;
+        case 24 + 3: rc = go(seed_wtile_kernel<4, 3, 3>); break;
+        case 24 + 4: rc = go(seed_wtile_kernel<4, 3, 4>); break;
+        case 32 + 1: rc = go(seed_wtile_kernel<4, 4, 1>); break;
+        case 32 + 2: rc = go(seed_wtile_kernel<4, 4, 2>); break;
+        case 32 + 3: rc = go(seed_wtile_kernel<4, 4, 3>); break;
+        default: rc = go(seed_wtile_kernel<4, 4, 4>); break;
       }
     } else {
       switch (nh) {

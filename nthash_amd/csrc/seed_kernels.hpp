@@ -356,7 +356,8 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
   // SUB: a pass over some of the seeds (a.rec_stride != 0), its own instantiation so that the whole-record kernels keep
   // their register budget
   constexpr bool ROT = RNS > 0;
-  static_assert(!ROT || (NH == 4 && RNS <= 2 && RM2 >= 1 && RM2 <= 4), "rotated-slot layout: k <= 32, <= 2 seeds");
+  static_assert(!ROT || (NH == 4 && RNS <= 4 && RM2 >= 1 && RM2 <= 4), "rotated-slot layout: k <= 32, <= 4 seeds");
+  constexpr uint32_t NSETS = ROT ? (uint32_t)(RNS + 1) / 2u : 0u; // table sets of 64 KiB: seeds {0, 1}, {2, 3}
   // PF: the next tile's slab travels in registers behind hidden loads.  Only while the kernel does not spill: a spilled
   // register of a load hipcc cannot see is saved before the load has landed (k > 32: 2 * NH lookups of 16 bytes in flight
   // take the registers; nthash_amd/build.py refuses a build in which a kernel with hidden loads spills)
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // layout: [tables: n_seeds*NT*256 uint4 (ROT: 16*256)][per wave: output tile 64*per+2 u64 | bit stream]
   uint4* tabs = (uint4*)lds_dyn;
-  const uint32_t n_entries = ROT ? 4096u : a.n_seeds * NT * 256u;
+  const uint32_t n_entries = ROT ? 4096u * NSETS : a.n_seeds * NT * 256u;
   const uint32_t per = ROT ? (uint32_t)(RNS * RM2) : a.n_seeds * a.m2; // values per window
   const uint32_t otile_u64 = 64u * per + 2u;
   uint32_t* wbase = lds_dyn + n_entries * 4u + wave * (otile_u64 * 2u + a.bits_dwords);
@@ -377,7 +378,9 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
   uint32_t* bits = wbase + otile_u64 * 2u;
   if constexpr (ROT) {
     for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
-      const uint32_t e = i >> 4, v = i & 15u, jt = v & 7u, sd = (v >> 3) < (uint32_t)RNS ? (v >> 3) : (uint32_t)RNS - 1u;
+      const uint32_t set = i >> 12, ii = i & 4095u;
+      const uint32_t in_set = (uint32_t)RNS - 2u * set < 2u ? (uint32_t)RNS - 2u * set : 2u; // seeds of this set
+      const uint32_t e = ii >> 4, v = ii & 15u, jt = v & 7u, sd = 2u * set + ((v >> 3) < in_set ? (v >> 3) : in_set - 1u);
       tabs[i] = jt < a.ntab ? a.tables[((size_t)sd * a.ntab + jt) * 256u + e] : make_uint4(0, 0, 0, 0);
     }
   } else {
@@ -533,10 +536,15 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
 #pragma unroll
         for (uint32_t st = 0; st < 8; ++st) ad[st] = __builtin_amdgcn_perm(w[1], w[0], rsel[st]) + roff[st];
 #pragma unroll
-        for (int half = 0; half < RNS; ++half) {
+        for (int round = 0; round < RNS; ++round) {
+          // rounds 0, 1: the table set of seeds {0, 1}; rounds 2, 3: of seeds {2, 3}, 64 KiB further (a set with one
+          // seed holds it in both halves and takes one round)
+          const int set = round >> 1, half = round & 1;
+          const bool pair = RNS - 2 * set >= 2; // this set holds two seeds
+          const uint32_t sbase = (uint32_t)set * 65536u;
           nt_v4u e[8];
 #pragma unroll
-          for (uint32_t st = 0; st < 8; ++st) e[st] = *(lds_v4u*)(uintptr_t)(half == 0 ? ad[st] : ad[st] + rdelta);
+          for (uint32_t st = 0; st < 8; ++st) e[st] = *(lds_v4u*)(uintptr_t)((half == 0 ? ad[st] : ad[st] + rdelta) + sbase);
           uint32_t f0 = e[0].x ^ e[1].x, f1 = e[0].y ^ e[1].y, r0 = e[0].z ^ e[1].z, r1 = e[0].w ^ e[1].w;
 #pragma unroll
           for (uint32_t st = 2; st < 8; st += 2) {
@@ -546,8 +554,8 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
             r1 = __builtin_amdgcn_bitop3_b32(r1, e[st].w, e[st + 1].w, 0x96);
           }
           const uint64_t h0 = canon_pair(f0, f1, r0, r1);
-          // the seed this lane has just hashed: its half in the first round, the other one in the second
-          uint64_t* const rec = mine + (RNS == 2 ? ((uint32_t)half ^ rb3) * (uint32_t)RM2 : 0u);
+          // the seed this lane has just hashed: its half in the first round of a pair, the other one in the second
+          uint64_t* const rec = mine + (2u * (uint32_t)set + (pair ? ((uint32_t)half ^ rb3) : 0u)) * (uint32_t)RM2;
           rec[0] = h0;
 #pragma unroll
           for (uint32_t jj = 1; jj < (uint32_t)RM2; ++jj) rec[jj] = mix_hash(h0, a.mult[jj]);
