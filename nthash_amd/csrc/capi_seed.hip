@@ -196,6 +196,10 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
   } else if (rot_ok && sd->n_seeds <= 2) {
     pass_seeds = sd->n_seeds;
     rot = true;
+  } else if (rot_ok && sd->n_seeds <= 4 && waves_for(2 * 65536, sd->n_seeds) != 0 &&
+             (m2 == 1 || waves_for(plain_bytes(sd->n_seeds), sd->n_seeds) < 8)) {
+    pass_seeds = sd->n_seeds; // (as in launch_seed_wtile: two table sets)
+    rot = true;
   } else {
     rot = false;
     uint32_t most = sd->n_seeds;
@@ -204,7 +208,7 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
     pass_seeds = (sd->n_seeds + passes - 1) / passes;
   }
   const uint32_t nh = rot ? 4u : nh_plain;
-  const size_t table_bytes = rot ? 65536 : plain_bytes(pass_seeds);
+  const size_t table_bytes = rot ? (size_t)65536 * ((pass_seeds + 1) / 2) : plain_bytes(pass_seeds);
   const uint32_t waves = waves_for(table_bytes, pass_seeds);
   if (!waves) return NTHIP_OK;
   *handled = true;
@@ -339,7 +343,15 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
         case 16 + 1: rc = go(seed_rtile_kernel<4, 2, 1>); break;
         case 16 + 2: rc = go(seed_rtile_kernel<4, 2, 2>); break;
         case 16 + 3: rc = go(seed_rtile_kernel<4, 2, 3>); break;
-        default: rc = go(seed_rtile_kernel<4, 2, 4>); break;
+        case 16 + 4: rc = go(seed_rtile_kernel<4, 2, 4>); break;
+        case 24 + 1: rc = go(seed_rtile_kernel<4, 3, 1>); break;
+        case 24 + 2: rc = go(seed_rtile_kernel<4, 3, 2>); break;
+        case 24 + 3: rc = go(seed_rtile_kernel<4, 3, 3>); break;
+        case 24 + 4: rc = go(seed_rtile_kernel<4, 3, 4>); break;
+        case 32 + 1: rc = go(seed_rtile_kernel<4, 4, 1>); break;
+        case 32 + 2: rc = go(seed_rtile_kernel<4, 4, 2>); break;
+        case 32 + 3: rc = go(seed_rtile_kernel<4, 4, 3>); break;
+        default: rc = go(seed_rtile_kernel<4, 4, 4>); break;
       }
     } else {
       switch (nh) {

@@ -679,14 +679,15 @@ template <int NH, int RNS = 0, int RM2 = 0>
 __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileArgs a)
 {
   constexpr bool ROT = RNS > 0;
-  static_assert(!ROT || (NH == 4 && RNS <= 2 && RM2 >= 1 && RM2 <= 4), "rotated-slot layout: k <= 32, <= 2 seeds");
+  static_assert(!ROT || (NH == 4 && RNS <= 4 && RM2 >= 1 && RM2 <= 4), "rotated-slot layout: k <= 32, <= 4 seeds");
+  constexpr uint32_t NSETS = ROT ? (uint32_t)(RNS + 1) / 2u : 0u; // table sets of 64 KiB: seeds {0, 1}, {2, 3}
   constexpr int NW = (NH + 1) / 2;
   constexpr uint32_t NT = 2u * NH;
   extern __shared__ __attribute__((aligned(256))) uint32_t lds_dyn[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint4* tabs = (uint4*)lds_dyn;
-  const uint32_t n_entries = ROT ? 4096u : a.n_seeds * NT * 256u;
+  const uint32_t n_entries = ROT ? 4096u * NSETS : a.n_seeds * NT * 256u;
   const uint32_t per = ROT ? (uint32_t)(RNS * RM2) : a.n_seeds * a.m2;
   const uint32_t otile_u64 = a.otile_recs * per + 2u;
   // per wave: record tile | bit stream | read table (first window, last window + 1, first base, first record) | window map
@@ -700,7 +701,9 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
   uint8_t* wmap = (uint8_t*)(rt + RT); // windows [16c, 16c + 16) of the tile: the read that holds window 16c
   if constexpr (ROT) {
     for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
-      const uint32_t e = i >> 4, v = i & 15u, jt = v & 7u, sd = (v >> 3) < (uint32_t)RNS ? (v >> 3) : (uint32_t)RNS - 1u;
+      const uint32_t set = i >> 12, ii = i & 4095u;
+      const uint32_t in_set = (uint32_t)RNS - 2u * set < 2u ? (uint32_t)RNS - 2u * set : 2u;
+      const uint32_t e = ii >> 4, v = ii & 15u, jt = v & 7u, sd = 2u * set + ((v >> 3) < in_set ? (v >> 3) : in_set - 1u);
       tabs[i] = jt < a.ntab ? a.tables[((size_t)sd * a.ntab + jt) * 256u + e] : make_uint4(0, 0, 0, 0);
     }
   } else {
@@ -821,10 +824,13 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
 #pragma unroll
           for (uint32_t st = 0; st < 8; ++st) ad[st] = __builtin_amdgcn_perm(w[1], w[0], rsel[st]) + roff[st];
 #pragma unroll
-          for (int half = 0; half < RNS; ++half) {
+          for (int round = 0; round < RNS; ++round) { // (rounds and table sets as in seed_wtile_kernel)
+            const int set = round >> 1, half = round & 1;
+            const bool pair = RNS - 2 * set >= 2;
+            const uint32_t sbase = (uint32_t)set * 65536u;
             nt_v4u e[8];
 #pragma unroll
-            for (uint32_t st = 0; st < 8; ++st) e[st] = *(lds_v4u*)(uintptr_t)(half == 0 ? ad[st] : ad[st] + rdelta);
+            for (uint32_t st = 0; st < 8; ++st) e[st] = *(lds_v4u*)(uintptr_t)((half == 0 ? ad[st] : ad[st] + rdelta) + sbase);
             uint32_t f0 = e[0].x ^ e[1].x, f1 = e[0].y ^ e[1].y, r0 = e[0].z ^ e[1].z, r1 = e[0].w ^ e[1].w;
 #pragma unroll
             for (uint32_t st = 2; st < 8; st += 2) {
@@ -834,7 +840,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
               r1 = __builtin_amdgcn_bitop3_b32(r1, e[st].w, e[st + 1].w, 0x96);
             }
             const uint64_t h0 = canon_pair(f0, f1, r0, r1);
-            uint64_t* const rec = mine + (RNS == 2 ? ((uint32_t)half ^ rb3) * (uint32_t)RM2 : 0u);
+            uint64_t* const rec = mine + (2u * (uint32_t)set + (pair ? ((uint32_t)half ^ rb3) : 0u)) * (uint32_t)RM2;
             rec[0] = h0;
 #pragma unroll
             for (uint32_t jj = 1; jj < (uint32_t)RM2; ++jj) rec[jj] = mix_hash(h0, a.mult[jj]);
