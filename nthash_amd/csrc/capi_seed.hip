@@ -183,8 +183,8 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
     return ((size_t)(otile_recs * seeds_here * m2 + 2) * 2 + bits_dwords + 4 * rt_n + wmap_dwords) * 4;
   };
   auto plain_bytes = [&](uint32_t seeds_here) { return (size_t)seeds_here * 2 * nh_plain * 256 * sizeof(uint4); };
-  auto waves_for = [&](size_t tb, uint32_t seeds_here) -> uint32_t {
-    for (uint32_t w = 16; w >= 4; w -= 4)
+  auto waves_for = [&](size_t tb, uint32_t seeds_here) -> uint32_t { // (as in launch_seed_wtile)
+    for (uint32_t w = 16; w >= 4; w -= (w > 8 ? 4 : 1))
       if (tb + per_wave_of(seeds_here) * w <= cap) return w;
     return 0;
   };
@@ -526,8 +526,12 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
   auto per_wave_of = [&](uint32_t seeds_here) { return (size_t)(64 * seeds_here * f.m2 + 2) * 8 + (size_t)bits_dwords * 4; };
   auto plain_bytes = [&](uint32_t seeds_here) { return (size_t)seeds_here * 2 * nh * 256 * sizeof(uint4); };
   auto waves_for = [&](size_t table_bytes, uint32_t seeds_here) -> uint32_t {
-    for (uint32_t w = c->tune.seed_waves ? c->tune.seed_waves & ~3u : 16u; w >= 4; w -= 4)
+    // 16 / 12 / 8 waves, below that as many as fit (in process, 128 KiB of tables: 4 -> 5 -> 6 -> 7 waves 48.9 -> 53.6 ->
+    // 61.4 -> 63.0 G k-mers/s at k = 64, 2 seeds x 3; between 8 and 12 the count does not matter).  The knob: any count (A/B)
+    for (uint32_t w = c->tune.seed_waves ? c->tune.seed_waves : 16u; w >= 4; w -= (w > 8 ? 4 : 1)) {
       if (table_bytes + per_wave_of(seeds_here) * w <= cap) return w;
+      if (c->tune.no_seed_w6 && w <= 8 && w > 4) w = 5; // (A/B: straight from 8 to 4)
+    }
     return 0;
   };
   uint32_t pass_seeds; // seeds per pass
