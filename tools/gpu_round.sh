@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "seed" 2>&1 | tail -3
-SWEEP_GIB=16 timeout 900 python tools/seed_sweep.py gpurun_out/seed_sweep.json 2>&1 | tee gpurun_out/seed_sweep.txt
-for sh in 31,2,3 31,3,3 31,4,2 31,6,1 48,3,2 64,2,3 64,3,1; do echo -n "== $sh "; RSB_SHAPE=$sh timeout 300 python tools/ragged_seed_bench.py 2000000 2>&1 | tail -1; done | tee gpurun_out/ragged_seed_shapes.txt
+timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+python bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/bench_final.err | tee gpurun_out/bench_final.json | cut -c1-400
