@@ -1,7 +1,7 @@
 // Does the way device memory is obtained decide the "page class" (profiles/r02_notes.md sections 11, 18, 25)?
 // Write-only fill rate of a buffer from: hipMalloc; the virtual-memory API with one physical handle; with handles of
 // 2 MiB ... 1 GiB mapped back to back; virtual addresses aligned to 2 MiB / 1 GiB.
-//   hipcc --offload-arch=gfx950 -O3 tools/bench_micro/vmm_alloc.hip -o /tmp/vmm_alloc && /tmp/vmm_alloc [GiB]
+//   hipcc --offload-arch=gfx950 -O3 tools/bench_micro/vmm_alloc.hip -o tools/bench_micro/vmm_alloc_bin && tools/bench_micro/vmm_alloc_bin [GiB]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
