@@ -255,6 +255,7 @@ bool kmer_fixed_eligible(const nthip_ctx* c, uint32_t len, uint32_t stride, uint
 void build_byte_tables(uint32_t k, const uint8_t* care, uint4* out);
 int get_init_tab(nthip_ctx* c, uint32_t k, const uint4** out);
 int get_kmer_tab(nthip_ctx* c, uint32_t k, const uint4** out);
+int get_horner_tab(nthip_ctx* c, const uint4** out); // the k-independent pair: a 4-mer's byte table [0..255], a 1-mer's [256..259]
 
 // Plan for the headline run-split kernel: run length C | nwin, waves per block, LDS bytes.
 struct RunsPlan {

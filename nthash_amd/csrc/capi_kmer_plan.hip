@@ -87,6 +87,10 @@ int get_init_tab(nthip_ctx* c, uint32_t k, const uint4** out)
 int get_kmer_tab(nthip_ctx* c, uint32_t k, const uint4** out)
 {
   if (k <= KMER_TABLE_K_MAX) return get_init_tab(c, k, out);
+  return get_horner_tab(c, out);
+}
+int get_horner_tab(nthip_ctx* c, const uint4** out)
+{
   const uint32_t key = 0xFFFF0004u;
   auto it = c->init_tabs.find(key);
   if (it == c->init_tabs.end()) {

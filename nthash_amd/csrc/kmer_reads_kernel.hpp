@@ -480,6 +480,7 @@ struct KmerDirtyReadsArgs {
   uint32_t* pos;
   uint64_t* fwd;
   uint64_t* rev;
+  const uint4* horner_tab;   // hash pass: byte table of a 4-mer [0..255], of a 1-mer [256..259] (get_horner_tab)
   uint64_t sk_fwd[4];        // srol^k(seed[code])
   uint64_t sk_rc[4];         // srol^k(seed[code ^ 2])
 };
@@ -495,9 +496,18 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
 {
   __shared__ uint8_t raw_all[4][RD_MAX_LEN + 64];
   __shared__ uint16_t lb_all[4][RD_MAX_LEN + 64]; // 1 + index of the last non-base in [0, p], 0 if none
+  // hash pass: the read as 2-bit codes too, and the k-independent tables of horner_first_window (4 bases per step:
+  // a window is 2 * ceil(k / 4) table steps instead of 2k character steps)
+  __shared__ uint32_t bits_all[COUNT_ONLY ? 1 : 4][COUNT_ONLY ? 1 : RD_MAX_LEN / 16 + 8];
+  __shared__ uint4 htab[COUNT_ONLY ? 1 : 512];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint8_t* raw = raw_all[wave];
   uint16_t* lb = lb_all[wave];
+  uint32_t* bits = bits_all[COUNT_ONLY ? 0 : wave];
+  if (!COUNT_ONLY) {
+    for (uint32_t i = threadIdx.x; i < 512u; i += blockDim.x) htab[i] = a.horner_tab[i];
+    __syncthreads();
+  }
   const uint64_t n = *a.n_list;
   const uint32_t k = a.k, m = a.m;
   const uint64_t kmul = (uint64_t)k * MULTISEED;
@@ -505,10 +515,16 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
     const uint64_t r = a.list[i];
     const uint8_t* s = a.seqs + a.starts[r];
     const uint32_t len = (uint32_t)(a.ends[r] - a.starts[r]);
+    if (!COUNT_ONLY) {
+      for (uint32_t j = lane; j < (len >> 4) + 8u; j += 64u) bits[j] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+    }
     uint32_t carry = 0;
     for (uint32_t p0 = 0; p0 < len; p0 += 64u) {
       const uint32_t p = p0 + lane;
       const uint8_t c = p < len ? s[p] : (uint8_t)'A';
+      if (!COUNT_ONLY && p < len && is_base(c)) atomicOr(&bits[p >> 4], code_of(c) << ((p & 15u) << 1));
       uint32_t v = (p < len && !is_base(c)) ? p + 1u : 0u;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -539,9 +555,9 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
       const uint64_t mask = __ballot(valid);
       if (!COUNT_ONLY && valid) {
         const uint32_t slot = emitted + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        uint64_t fh = 0, rh = 0;
-        for (uint32_t x = 0; x < k; ++x) fh = srol1(fh) ^ fwd_seed(raw[w + x]);
-        for (uint32_t x = k; x-- > 0;) rh = srol1(rh) ^ rc_seed(raw[w + x]);
+        uint32_t f_lo, f_hi, r_lo, r_hi; // (a valid window holds bases only: its 2-bit codes are all it takes)
+        horner_first_window(bits, htab, w, k, f_lo, f_hi, r_lo, r_hi);
+        const uint64_t fh = ((uint64_t)f_hi << 32) | f_lo, rh = ((uint64_t)r_hi << 32) | r_lo;
         const uint64_t o = base + slot;
         const uint64_t h0 = fh + rh;
         a.hashes[o * m] = h0;
