@@ -58,8 +58,11 @@ struct KmerReadsArgs {
 
 // POS: window positions wanted.  value_sel 1 / 2 (one strand's hash instead of the canonical one) needs no code in the
 // roll: with the other strand's table terms zeroed its state stays 0 and forward + reverse IS the wanted strand.
+// (the MARK pass waits for memory and nothing else: 8 waves per SIMD -- two blocks of 16 waves per CU -- instead of the
+//  4 the register count of the common body would give it)
 template <int MODE, int NW, bool POS = false>
-__global__ __launch_bounds__(KR_MAX_THREADS) void kmer_reads_kernel(const KmerReadsArgs a)
+__global__ __launch_bounds__(KR_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == RD_MODE_MARK ? 8 : 1)))
+void kmer_reads_kernel(const KmerReadsArgs a)
 {
   extern __shared__ __attribute__((aligned(256))) uint32_t lds_dyn[];
   const uint32_t k = a.k, m = a.m, C = a.C;
