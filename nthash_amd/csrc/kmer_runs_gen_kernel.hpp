@@ -878,7 +878,9 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
         }
         if (ok[0] && ok[1]) {
           const uint4 ov = make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
-#if defined(KRG_MH_PLAIN)
+#if defined(KRG_ABL_NOSTORE) // ablation (WRONG results): everything but the stores of the several-hashes copy-out
+          asm volatile("" ::"v"(ov.x), "v"(ov.y), "v"(ov.z), "v"(ov.w));
+#elif defined(KRG_MH_PLAIN)
           *(uint4*)(base + 2u * pi) = ov;
 #else     // streaming stores for the whole pieces, as in the m = 1 copy-out
           __builtin_nontemporal_store(*(const nt_v4u*)&ov, (nt_v4u*)(base + 2u * pi));
