@@ -1,7 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-ABLATE_SHAPE=100,64,3 timeout 600 python tools/ab_multi.py old 30000000 10 2>&1 | tail -2
-ABLATE_SHAPE=151,31,2 timeout 600 python tools/ab_multi.py old 20000000 10 2>&1 | tail -2
-ABLATE_SHAPE=101,31,4 timeout 600 python tools/ab_multi.py old 20000000 10 2>&1 | tail -2
-ABLATE_SHAPE=151,31,5 timeout 600 python tools/ab_multi.py old 20000000 10 2>&1 | tail -2
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "any_m or any_k or multi or general or shapes" 2>&1 | tail -3
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 900 python tools/stress_shapes.py 400 17 2>&1 | tail -1
+timeout 900 python tools/stress_seeds.py 400 18 2>&1 | tail -1
+python bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/bench_final.err | tee gpurun_out/bench_final.json | cut -c1-200
