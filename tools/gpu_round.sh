@@ -1,8 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -3
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 900 python tools/stress_shapes.py 400 17 2>&1 | tail -1
-timeout 900 python tools/stress_seeds.py 400 18 2>&1 | tail -1
-python bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/bench_final.err | tee gpurun_out/bench_final.json | cut -c1-200
+for mb in -1 16 64 160; do echo "SEED_CHUNK_MB=$mb"; NTHIP_TUNE_SEED_CHUNK_MB=$mb SWEEP_GIB=8 SWEEP_SHAPES="250,31,6,1;100,64,3,1;150,48,3,2;250,31,5,4" timeout 900 python tools/seed_sweep.py 2>&1; done
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "seed_passes" 2>&1 | tail -3

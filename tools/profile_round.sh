@@ -6,9 +6,9 @@ TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-python bench.py --steps 5 --warmup 2 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
+python bench.py --steps 20 --warmup 5 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
 tail -c 2500 "$OUT/bench_c2.json"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o kt -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_c2_under_rocprof.json" 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_c2_under_rocprof.json" 2> "$OUT/trace.err"
 find "$OUT/trace" -name "*stats*.csv" | head
 for f in $(find "$OUT/trace" -name "*kernel_stats.csv"); do cp "$f" "$OUT/kernel_stats.csv"; done
 cat "$OUT/kernel_stats.csv" 2>/dev/null | head -8
