@@ -249,7 +249,6 @@ void load_tuning(nthip_tune& t)
   t.no_scattered = is_one("NTHIP_TUNE_NO_SCATTERED");
   t.no_seed_long = is_one("NTHIP_TUNE_NO_SEED_LONG");
   t.no_seed_w6 = is_one("NTHIP_TUNE_NO_SEED_W6");
-  if (const char* v = getenv("NTHIP_TUNE_SEED_CHUNK_MB")) t.seed_chunk_mb = atoi(v) < 0 ? 0xFFFFFFFFu : (uint32_t)atoi(v);
   t.no_kmer_reads = is_one("NTHIP_TUNE_NO_KMER_READS");
   t.no_seed_reads = is_one("NTHIP_TUNE_NO_SEED_READS");
   t.no_seed_align = is_one("NTHIP_TUNE_NO_SEED_ALIGN");

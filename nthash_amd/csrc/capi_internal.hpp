@@ -85,7 +85,6 @@ struct nthip_tune {
   bool no_seed_reads = false; // NTHIP_TUNE_NO_SEED_READS=1: variable-length reads of SeedNtHash on seed_wave_kernel only
   bool no_kmer_reads = false; // NTHIP_TUNE_NO_KMER_READS=1: variable-length reads on kmer_ragged_kernel only
   uint32_t reads_run_len = 0, reads_per_tile = 0, reads_waves = 0; // NTHIP_TUNE_READS_RUN_LEN / _PER_TILE / _WAVES (kmer_reads_kernel)
-  uint32_t seed_chunk_mb = 0; // NTHIP_TUNE_SEED_CHUNK_MB: records per chunk of a several-pass seed launch (0: 64; -1: one chunk)
   bool no_seed_w6 = false;    // NTHIP_TUNE_NO_SEED_W6=1: seed_wtile_kernel with 4 waves where 6 would fit (A/B)
   bool no_seed_long = false;  // NTHIP_TUNE_NO_SEED_LONG=1: long reads of SeedNtHash stay on one wave per read
   bool no_scattered = false;  // NTHIP_TUNE_NO_SCATTERED=1: nthip_malloc_probed tries plain hipMalloc candidates only

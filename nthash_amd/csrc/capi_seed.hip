@@ -579,20 +579,6 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
   a.waves = waves;
   a.groups = c->tune.has_tile_map ? c->tune.tile_map : 32u; // (in process: 32 / 64 groups 0.2-0.4 % ahead of one range per block)
   memcpy(a.mult, f.mult, sizeof a.mult);
-  // Several passes: chunks of reads whose records fit the die's last-level cache, all passes over a chunk before the next
-  // chunk -- the parts of a 128-byte line that the passes write then meet on the die instead of going to HBM one by one
-  uint64_t chunk_reads = f.n_runs;
-  if (pass_seeds < f.n_seeds && c->tune.seed_chunk_mb != 0xFFFFFFFFu) {
-    const uint64_t chunk_bytes = (uint64_t)(c->tune.seed_chunk_mb ? c->tune.seed_chunk_mb : 64u) << 20;
-    chunk_reads = chunk_bytes / ((uint64_t)f.nwin * per * 8);
-    chunk_reads = chunk_reads / R * R; // whole tiles
-    if (chunk_reads < R) chunk_reads = R;
-  }
-  for (uint64_t r_first = 0; r_first < f.n_runs; r_first += chunk_reads) {
-  a.seqs = f.seqs + r_first * f.stride;
-  a.hashes = f.hashes + r_first * f.nwin * per;
-  a.n_reads = f.n_runs - r_first < chunk_reads ? f.n_runs - r_first : chunk_reads;
-  a.n_tiles = (a.n_reads + R - 1) / R;
   for (uint32_t s0 = 0; s0 < f.n_seeds; s0 += pass_seeds) {
     const uint32_t ns = f.n_seeds - s0 < pass_seeds ? f.n_seeds - s0 : pass_seeds;
     const uint32_t per_here = ns * f.m2;
@@ -616,7 +602,7 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
       const uint64_t need = (a.n_tiles + waves - 1) / waves;
       uint64_t grid = (uint64_t)c->n_cu * per_cu;
       if (grid > need) grid = need;
-      if (s0 == 0 && r_first == 0) prof_begin(c, "seed_wtile_kernel"); // (all passes in one measurement)
+      if (s0 == 0) prof_begin(c, "seed_wtile_kernel"); // (all passes in one measurement)
       hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream, a);
       prof_end(c);
       HIPCHK(hipGetLastError());
@@ -658,7 +644,6 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
     }
 #undef NT_SW
     NTCHK(rc);
-  }
   }
   *ran = true;
   return NTHIP_OK;
