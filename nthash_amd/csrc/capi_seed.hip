@@ -639,7 +639,11 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
         case 5: rc = NT_SW(5, 0, 0); break;
         case 6: rc = NT_SW(6, 0, 0); break;
         case 7: rc = NT_SW(7, 0, 0); break;
-        default: rc = NT_SW(8, 0, 0); break;
+        case 8: rc = NT_SW(8, 0, 0); break;
+        case 10: rc = NT_SW(10, 0, 0); break; // seeds of 65..128 bases
+        case 12: rc = NT_SW(12, 0, 0); break;
+        case 14: rc = NT_SW(14, 0, 0); break;
+        default: rc = NT_SW(16, 0, 0); break;
       }
     }
 #undef NT_SW
@@ -832,9 +836,11 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
     }
     done = true;
   } else if (!rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.fwd && !st.rev && m2 <= (uint32_t)SF_MAX_RUNTIME_M &&
-             k <= 64 && stride <= len) {
+             k <= 128 && stride <= len) {
     const uint32_t nwin = len - k + 1;
-    const uint32_t nh = (k + 7) / 8; // 16-bit halves of the window; 2*nh byte tables per seed in LDS (zero-padded)
+    // 16-bit halves of the window; 2*nh byte tables per seed in LDS (zero-padded).  Seeds of 65..128 bases: the wave-tile
+    // kernel only (instantiated for nh = 10, 12, 14, 16), one seed of up to 128 KiB of tables per pass
+    const uint32_t nh = k <= 64 ? (k + 7) / 8 : ((k + 15) / 16) * 2;
     const size_t table_bytes = (size_t)sd->n_seeds * 2 * nh * 256 * sizeof(uint4);
     // tile = as many runs as give a ~8 KiB bit stream (32 Ki bases), at most 256
     uint32_t rpt = 32768u / stride;
@@ -855,7 +861,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
     const size_t dyn = table_bytes + (size_t)bits_dwords * 4 + (size_t)(SF_THREADS / 64) * (64 * per + 2) * 8;
     const uint64_t dense = rd->n_reads * (uint64_t)nwin;
     // (the block-tile kernel needs its 16 waves' tiles beside ALL the tables; the wave-tile kernel plans its own LDS)
-    const bool block_fits = dyn <= 158 * 1024 && dyn <= c->lds_max;
+    const bool block_fits = nh <= 8 && dyn <= 158 * 1024 && dyn <= c->lds_max;
     if ((uint64_t)rpt * nwin < 0x7FFFFFFFull) {
       if (dense > out->capacity) {
         if (total_out) *total_out = dense;

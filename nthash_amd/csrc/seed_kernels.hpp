@@ -563,23 +563,29 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
       } else
       for (uint32_t s = 0; s < a.n_seeds; ++s) {
         const uint4* ts = tabs + s * NT * 256u;
-        uint4 e[NT]; // all lookups of the seed in flight, then XOR them up
+        uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
+        // the lookups of the seed in flight -- all of them up to 64 bases, 8 at a time beyond (NH > 8) -- then XORed up
+        constexpr uint32_t CH = NT <= 16u ? NT : 8u;
 #pragma unroll
-        for (uint32_t jt = 0; jt < NT; ++jt) {
+        for (uint32_t j0 = 0; j0 < NT; j0 += CH) {
+          uint4 e[CH];
+#pragma unroll
+          for (uint32_t jt = 0; jt < CH; ++jt) {
 #if SF_ABL_NOCONFLICT
-          const uint32_t byte = ((w[jt >> 2] >> ((jt & 3u) * 8u)) & 0xF0u) | (lane & 15u);
+            const uint32_t byte = ((w[(j0 + jt) >> 2] >> (((j0 + jt) & 3u) * 8u)) & 0xF0u) | (lane & 15u);
 #else
-          const uint32_t byte = (w[jt >> 2] >> ((jt & 3u) * 8u)) & 0xFFu;
+            const uint32_t byte = (w[(j0 + jt < NT ? j0 + jt : 0u) >> 2] >> (((j0 + jt) & 3u) * 8u)) & 0xFFu;
 #endif
-          e[jt] = ts[jt * 256u + byte];
-        }
-        uint32_t f0 = e[0].x ^ e[1].x, f1 = e[0].y ^ e[1].y, r0 = e[0].z ^ e[1].z, r1 = e[0].w ^ e[1].w;
+            e[jt] = j0 + jt < NT ? ts[(j0 + jt) * 256u + byte] : make_uint4(0, 0, 0, 0); // (NT = 20, 28: the last batch is half full)
+          }
 #pragma unroll
-        for (uint32_t jt = 2; jt < NT; jt += 2) { // NT is even; a ^ b ^ c is one v_bitop3_b32
-          f0 = __builtin_amdgcn_bitop3_b32(f0, e[jt].x, e[jt + 1].x, 0x96);
-          f1 = __builtin_amdgcn_bitop3_b32(f1, e[jt].y, e[jt + 1].y, 0x96);
-          r0 = __builtin_amdgcn_bitop3_b32(r0, e[jt].z, e[jt + 1].z, 0x96);
-          r1 = __builtin_amdgcn_bitop3_b32(r1, e[jt].w, e[jt + 1].w, 0x96);
+          for (uint32_t jt = 0; jt < CH; jt += 2) { // CH is even; a ^ b ^ c is one v_bitop3_b32
+            f0 = __builtin_amdgcn_bitop3_b32(f0, e[jt].x, e[jt + 1].x, 0x96);
+            f1 = __builtin_amdgcn_bitop3_b32(f1, e[jt].y, e[jt + 1].y, 0x96);
+            r0 = __builtin_amdgcn_bitop3_b32(r0, e[jt].z, e[jt + 1].z, 0x96);
+            r1 = __builtin_amdgcn_bitop3_b32(r1, e[jt].w, e[jt + 1].w, 0x96);
+          }
+          if constexpr (NT > 16u) asm volatile("" : "+v"(f0), "+v"(f1), "+v"(r0), "+v"(r1)); // (one batch of lookups at a time)
         }
         const uint64_t h0 = canon_pair(f0, f1, r0, r1);
         mine[s * a.m2] = h0;

@@ -1872,7 +1872,8 @@ def test_seed_passes_vs_oracle(oracle):
         return "".join(str(int(x)) for x in m)
 
     shapes = [(31, 3, 1), (31, 3, 3), (31, 4, 2), (31, 6, 1), (20, 5, 4), (32, 7, 2), (48, 3, 2), (48, 5, 1), (64, 2, 3),
-              (64, 3, 1), (57, 4, 5), (31, 2, 3), (12, 9, 1)]
+              (64, 3, 1), (57, 4, 5), (31, 2, 3), (12, 9, 1),
+              (65, 1, 1), (80, 2, 2), (96, 3, 1), (100, 1, 3), (113, 2, 1), (127, 1, 2), (128, 2, 2)]  # (long seeds: 8 lookups at a time)
     for (k, n_seeds, m2) in shapes:
         seeds = [mask(k, 0.65) for _ in range(n_seeds)]
         n, L = int(rng.integers(100, 900)), int(rng.integers(k, 260))
@@ -1895,7 +1896,7 @@ def test_seed_passes_vs_oracle(oracle):
                 assert name != "seed_general_kernel", (name, k, n_seeds, m2, dirty)
         # reads of several lengths (tiles of whole reads, seed_rtile_kernel), one of them with an 'N'
         alph = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
-        reads = [alph[rng.integers(0, 8, int(rng.integers(max(1, k - 3), 200)))].tobytes() for _ in range(700)]
+        reads = [alph[rng.integers(0, 8, int(rng.integers(max(1, k - 3), max(200, 2 * k))))].tobytes() for _ in range(700)]
         reads[350] = reads[350][: len(reads[350]) // 2] + b"N" + reads[350][len(reads[350]) // 2 + 1:]
         d, roffs = concat_reads(reads)
         want = oracle.seed_batch(d, roffs, seeds, k, m2)
@@ -1904,7 +1905,7 @@ def test_seed_passes_vs_oracle(oracle):
             got = c.seed_hash(d, seeds, k, m2, offsets=roffs, want_pos=True)
             name = c.last_kernel_ms()[1]
             c.set_profiling(False)
-            assert name == "seed_rtile_kernel", (name, k, n_seeds, m2)
+            assert name == ("seed_rtile_kernel" if k <= 64 else "seed_wave_kernel"), (name, k, n_seeds, m2)
             assert got["total"] == want["total"]
             for key in ("counts", "pos", "hashes"):
                 assert (got[key] == want[key]).all(), (k, n_seeds, m2, key, c is planned)
