@@ -1,5 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_facade.py -q -m gpu -x -k "seed or Seed" 2>&1 | tail -4
-SWEEP_GIB=8 SWEEP_SHAPES="250,80,2,2;300,128,1,1;250,100,1,3;250,65,2,3;150,64,2,3;250,31,2,3;150,48,2,3" timeout 900 python tools/seed_sweep.py 2>&1 | tail -8
-timeout 600 python tools/stress_seeds.py 300 555 2>&1 | tail -1
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+SWEEP_GIB=16 timeout 900 python tools/seed_sweep.py gpurun_out/seed_sweep.json 2>&1 | tee gpurun_out/seed_sweep.txt | tail -16
+python bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/bench_final.err | tee gpurun_out/bench_final.json | cut -c1-200
