@@ -674,6 +674,7 @@ int launch_seed_fixed(nthip_ctx* c, K kernel, const SeedFixedArgs& a, size_t dyn
 // read), counts and positions are folded back per read.  *handled = false: nothing done.
 namespace {
 constexpr uint64_t SEED_LONG_MIN = 16384; // reads from this length on are worth cutting
+constexpr uint64_t SEED_LONG_DENSE_MAX = 131072; // fixed-length reads from this length on skip the dense kernels
 struct DevTemp { // device temporaries of one call
   std::vector<void*> ptrs;
   ~DevTemp() { for (void* p : ptrs) (void)hipFree(p); }
@@ -836,7 +837,10 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
     }
     done = true;
   } else if (!rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.fwd && !st.rev && m2 <= (uint32_t)SF_MAX_RUNTIME_M &&
-             k <= 128 && stride <= len) {
+             k <= 128 && stride <= len && (len < SEED_LONG_DENSE_MAX || k > 64 || c->tune.no_seed_long)) {
+    // (reads of 128 Ki bases and more go to the pieces below even when clean: the block-tile kernel keeps the whole read's
+    //  bit stream in LDS and stops fitting near 400 kbase.  Whole calls, 4 GiB of records, tools/seed_long_wholecall.py:
+    //  40 kbase dense 83 G k-mers/s / pieces 77 G; 100 kbase 79 / 81; 300 kbase 7.6 (one wave per read) / 79)
     const uint32_t nwin = len - k + 1;
     // 16-bit halves of the window; 2*nh byte tables per seed in LDS (zero-padded).  Seeds of 65..128 bases: the wave-tile
     // kernel only (instantiated for nh = 10, 12, 14, 16), one seed of up to 128 KiB of tables per pass
