@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--no-peak", action="store_true", help="skip the measured fill / copy ceiling")
     ap.add_argument("--no-placement", action="store_true",
                     help="plain allocations instead of the library's placement-aware allocator (nthip_malloc_probed)")
+    ap.add_argument("--no-plain-pass", action="store_true",
+                    help="skip the extra pass on plain hipMalloc buffers (roofline.frac_plain_alloc)")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
     return ap.parse_args()
 
@@ -237,6 +239,8 @@ class Workload:
         """The big buffers come from the library's placement-aware allocator: which pages hipMalloc hands out moves the
         headline kernel by up to 15 % on this GPU (profiles/r02_notes.md 11); a pipeline would allocate its ring this way."""
         cands = PLACE_CANDIDATES if nbytes >= (48 << 30) or PLACE_CANDIDATES <= 1 else PLACE_CANDIDATES + 2
+        if self.plain:
+            cands = 1  # one plain hipMalloc, unmeasured: what a caller who brings their own buffers gets
         free_b, _tot = self.torch.cuda.mem_get_info(self.dev)
         if nbytes > 0.45 * free_b:
             cands = 1  # no room for a second candidate
@@ -246,9 +250,10 @@ class Workload:
         self._owned.append(ptr)
         return ptr
 
-    def __init__(self, torch, ctx, dev, name, cfg, n_reads, first_read, chunk_reads=0):
+    def __init__(self, torch, ctx, dev, name, cfg, n_reads, first_read, chunk_reads=0, plain=False):
         import nthash_amd
         self.torch, self.ctx, self.dev, self.name, self.cfg = torch, ctx, dev, name, cfg
+        self.plain = plain
         self.n_reads, self.first_read = n_reads, first_read
         L, k, m = cfg["L"], cfg["k"], cfg["m"]
         self.L, self.k, self.m = L, k, m
@@ -450,12 +455,21 @@ def main():
         raise SystemExit(f"rank {rank}: local rank {local_rank} but only {n_dev} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # NTHASH_BENCH_FORCE_DIST=1: the process group is made at world size 1 as well (RCCL unless the GPU is shared), so that
+    # the branch an N-GPU run takes -- init, barrier, MAX all-reduce, all-gather -- also runs on a one-GPU box
+    use_dist = world > 1 or os.environ.get("NTHASH_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if share:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
     cpu_group_dev = "cpu" if share else dev
 
     n_reads = args.reads or (SHARD_READS_MULTI if (world > 1 and args.config == "c2") else cfg["reads"])
@@ -467,7 +481,7 @@ def main():
     wl = Workload(torch, ctx, dev, args.config, cfg, n_reads, first_read, args.chunk_reads)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -487,10 +501,27 @@ def main():
 
     verify = wl.verify()
     ok_local = (verify["ok"] is not False) and (verify["spot_vs_oracle"] is True)
+    # the same workload once more on PLAIN hipMalloc buffers (no placement probe): the rate callers who bring their
+    # own buffers see (torch tensors, a pipeline's ring).  Outside the timed region, 1 warm-up + 3 steps, kernel time.
+    roof = wl.roofline()
+    placement = wl.placement
+    wl.free()
+    plain_roof = None
+    if PLACE_CANDIDATES > 1 and not args.no_plain_pass:
+        try:
+            wp = Workload(torch, ctx, dev, args.config, cfg, n_reads, first_read, args.chunk_reads, plain=True)
+            wp.step(False)
+            for _ in range(3):
+                wp.step(True)
+            torch.cuda.synchronize(dev)
+            plain_roof = wp.roofline()
+            wp.free()
+        except Exception as e:
+            plain_roof = {"error": str(e)}
     per_rank = [kmers / my_dt]
     all_ok = ok_local
     checked_full = verify["ok"] is True
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=cpu_group_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -504,7 +535,12 @@ def main():
     if rank == 0:
         L, k = cfg["L"], cfg["k"]
         total_kmers = kmers * world
-        roof = wl.roofline()
+        if plain_roof is not None:
+            roof["frac_plain_alloc"] = plain_roof.get("frac")
+            roof["plain_alloc"] = ({"achieved": plain_roof["achieved"], "kernel_avg_ms": plain_roof["kernel_avg_ms"],
+                                    "how": "the same workload on one plain hipMalloc per buffer (no placement probe), "
+                                           "1 warm-up + 3 steps after the timed region, HIP-event kernel time"}
+                                   if "frac" in plain_roof else plain_roof)
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 gfx950 correction +
         # WRITE_SIZE, separate rocprofv3 --pmc runs of the same kernel); counters cannot be read inside this process
         try:
@@ -540,16 +576,19 @@ def main():
                        "placement": {"allocator": "nthip_malloc_probed: up to %d allocations per buffer (two more under 48 GiB) measured with the "
                                                   "library's write-only fill, the fastest kept (rank 0's buffers shown)"
                                                   % PLACE_CANDIDATES if PLACE_CANDIDATES > 1 else "plain hipMalloc",
-                                     "buffers": wl.placement}},
+                                     "buffers": placement}},
             "roofline": roof,
             "verify": verify,
             "verified_vs_oracle": bool(all_ok),
             "verified_full_stream_all_ranks": bool(checked_full),
             "per_rank_kmers_per_s": per_rank,
+            "dist": {"process_group": ("gloo (ranks share one GPU: test mode)" if share else "nccl (RCCL)") if use_dist else None,
+                     "collectives": "barrier, all_reduce(MAX) of the step time, all_gather of per-rank rate / verdicts"
+                                    if use_dist else None,
+                     "forced_at_world_1": bool(use_dist and world == 1)},
         }
     # ---- N = 1 extras: measured ceiling, the other single-GPU configs, the CPU beside it ----------------------
     if world == 1:
-        wl.free()
         if not args.no_peak:
             try:
                 pk = measured_peak(torch, ctx, dev)
@@ -599,7 +638,7 @@ def main():
                 res["cpu_baseline"] = {"value": None, "error": str(e)}
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

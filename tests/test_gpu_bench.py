@@ -69,7 +69,18 @@ def _entry(name, first, n):
     raise KeyError((name, first, n))
 
 
-@pytest.mark.parametrize("rank", [0, 5])
+def test_bench_rccl_process_group_at_world_size_one():
+    """NTHASH_BENCH_FORCE_DIST=1: the branch an N-GPU run takes -- init_process_group(backend="nccl") = RCCL, barrier,
+    all_reduce(MAX) of the step time, all_gather of the per-rank rates and verdicts -- runs on this box's one GPU"""
+    res = run_bench("--reads", "2000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-peak",
+                    "--no-secondary", env={"NTHASH_BENCH_FORCE_DIST": "1"})
+    assert res["n_gpus"] == 1
+    assert res["dist"]["process_group"] == "nccl (RCCL)" and res["dist"]["forced_at_world_1"] is True
+    assert res["verified_vs_oracle"] is True and len(res["per_rank_kmers_per_s"]) == 1
+    assert abs(res["per_rank_kmers_per_s"][0] - res["value"]) / res["value"] < 0.2  # (value: max-reduced wall time)
+
+
+@pytest.mark.parametrize("rank", list(range(8)))
 def test_config5_shard_full_size_checksum(ctx, rank):
     """125 M x 150 bp -- one GPU's share of the 1 G-read job -- hashed in one call; checksum of all 15 G hashes
     against the reference's for reads [rank*125 M, (rank+1)*125 M)"""
@@ -110,6 +121,7 @@ def test_bench_default_line_has_all_parts():
     r = res["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["peak_measured"] and 2000 < r["peak_measured"] < 8000
+    assert 0 < r["frac_plain_alloc"] < 1 and r["plain_alloc"]["kernel_avg_ms"] > 0
     assert res["cpu_baseline"]["value"] > 0 and res["cpu_baseline"]["cores"] == 1
     assert "REDUCED" in res["config"]["workload"]
     assert res["verified_vs_oracle"] is True
