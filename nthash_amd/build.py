@@ -57,12 +57,31 @@ def hip_units():
     return sorted(f for f in os.listdir(CSRC) if f.startswith("capi_") and f.endswith(".hip"))
 
 
+def _lint_unit(hipcc, unit, objdir, extra, verbose):
+    """Device assembly of the unit (hipcc -S --cuda-device-only, the flags of the object) through the ISA lint
+    (nthash_amd/isa_lint.py): the hidden-load sites of the kernels must be what the source says they are."""
+    from nthash_amd import isa_lint
+    src = os.path.join(CSRC, unit)
+    asm = os.path.join(objdir, unit[:-4] + ".lint.s")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-Wno-unused-command-line-argument",
+           f"-I{os.path.join(ROOT, 'include')}"] + list(extra) + ["-S", "--cuda-device-only", src, "-o", asm]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    rep = isa_lint.lint_file(asm)
+    os.remove(asm)
+    rep["unit"] = unit
+    return rep
+
+
 def _compile_unit(hipcc, unit, objdir, extra, force, verbose):
     src = os.path.join(CSRC, unit)
     obj = os.path.join(objdir, unit[:-4] + ".o")
     dep = obj + ".d"
+    lint_json = obj + ".lint.json"
     deps = _deps_of(dep)
-    if not force and deps is not None and not _newer(obj, deps + [src]) and all(os.path.exists(d) for d in deps):
+    if not force and deps is not None and not _newer(obj, deps + [src]) and all(os.path.exists(d) for d in deps) and \
+            os.path.exists(lint_json) and not _newer(lint_json, [obj, os.path.join(HERE, "isa_lint.py")]):
         return obj, False
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed",
            "-Rpass-analysis=kernel-resource-usage",
@@ -85,6 +104,13 @@ def _compile_unit(hipcc, unit, objdir, extra, force, verbose):
         os.remove(obj)
         raise RuntimeError(f"{unit}: kernels spill registers (scratch bytes per lane): " +
                            ", ".join(f"{k_['name']}={k_.get('scratch', 0)}" for k_ in spilling))
+    # ... and what the spill check cannot see: a copy or a use of such a register before its counted wait
+    rep = _lint_unit(hipcc, unit, objdir, extra, verbose)
+    json.dump(rep, open(lint_json, "w"), indent=0)
+    if rep["violations"] and not os.environ.get("NTHASH_AMD_ALLOW_LINT_FAIL"):
+        os.remove(obj)
+        raise RuntimeError(f"{unit}: ISA lint of the hidden-load sites failed ({len(rep['violations'])} violations):\n  " +
+                           "\n  ".join(rep["violations"][:12]))
     return obj, True
 
 

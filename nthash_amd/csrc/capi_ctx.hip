@@ -2,6 +2,8 @@
 // Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
 #include "capi_internal.hpp"
 
+#include <mutex>
+
 using namespace ntamd;
 using namespace ntamd::host;
 
@@ -22,6 +24,19 @@ int ntamd::host::fail(int code, const char* fmt, ...)
 
 namespace ntamd {
 namespace host {
+// hipFuncAttributeMaxDynamicSharedMemorySize is one value per (device, function) for the process: raise-only, locked
+int raise_max_dynamic_lds(int device, const void* kernel, size_t bytes)
+{
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> set;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = set[std::make_pair(device, kernel)];
+  if (bytes <= have) return NTHIP_OK;
+  HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have = bytes;
+  return NTHIP_OK;
+}
+
 void fastx_buffers_release(nthip_ctx* c)
 {
   auto& b = c->fx;

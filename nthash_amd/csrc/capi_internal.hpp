@@ -152,7 +152,8 @@ struct nthip_ctx {
 };
 
 struct nthip_seeds {
-  nthip_ctx* ctx = nullptr;
+  nthip_ctx* ctx = nullptr; // the creating context: only compared, never dereferenced after creation (it may be gone)
+  int device = 0;           // where the tables live (nthip_seeds_destroy frees them there)
   uint32_t n_seeds = 0, k = 0, ntab = 0, care_words = 0;
   bool asymmetric = false;
   uint4* d_tables = nullptr;      // [seed][ntab][256]
@@ -217,8 +218,9 @@ int unstage_outputs(nthip_ctx* c, const nthip_out* out, uint32_t flags, uint64_t
 int reads_total_bytes(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, uint64_t* out);
 int check_reads(const nthip_reads* rd);
 // offsets / spans sanity on the device (non-decreasing, inside the buffer): NTHIP_ERR_ARG instead of a wild read
+// *max_len (optional): the longest span
 int check_offsets_device(nthip_ctx* c, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
-                         uint64_t buf_bytes, bool contiguous);
+                         uint64_t buf_bytes, bool contiguous, uint64_t* max_len = nullptr);
 inline size_t lds_cap_of(const nthip_ctx* c) { return (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512; }
 
 // ---- capi_util.hip ------------------------------------------------------------------------------------------
@@ -310,17 +312,21 @@ int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, cons
 // reads of >= 16 384 bases cut into independent pieces (seed_long_kernels.hpp); *handled = false: no such read, nothing done
 int run_seed_long(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd, uint32_t m2, uint64_t capacity,
                   uint64_t* total, bool* handled, const uint64_t* d_ends = nullptr);
+constexpr uint64_t SEED_LONG_MIN = 16384; // reads from this length on are worth cutting into pieces
 
 // ---- templates every launching TU uses --------------------------------------------------------------------------
+// Dynamic LDS beyond the default needs hipFuncAttributeMaxDynamicSharedMemorySize, and that attribute is ONE value per
+// (device, function) for the whole process -- not per context, not per launch size.  So it is only ever RAISED, under a
+// process-wide lock: a context that configures 100 KiB after another configured 150 KiB must not lower it under the
+// other's (cached) launches (several contexts per device are normal: one per facade thread, nthip_multi listing a
+// device twice).  capi_ctx.hip owns the table.
+int raise_max_dynamic_lds(int device, const void* kernel, size_t bytes);
+
 template <typename K>
-int set_max_lds(K kernel, size_t bytes)
+int set_max_lds(const nthip_ctx* c, K kernel, size_t bytes)
 {
-  // static + dynamic LDS beyond the 64 KiB default needs the opt-in attribute
-  if (bytes > 24 * 1024) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  }
-  return NTHIP_OK;
+  if (bytes <= 24 * 1024) return NTHIP_OK;
+  return raise_max_dynamic_lds(c->device, reinterpret_cast<const void*>(kernel), bytes);
 }
 
 // blocks per CU for a persistent-style grid; the LDS opt-in and the occupancy
@@ -331,7 +337,7 @@ int blocks_per_cu(nthip_ctx* c, K kernel, int threads, size_t dyn_lds, int* out)
   const auto key = std::make_pair(reinterpret_cast<const void*>(kernel), dyn_lds);
   auto it = c->occ_cache.find(key);
   if (it == c->occ_cache.end()) {
-    NTCHK(set_max_lds(kernel, dyn_lds));
+    NTCHK(set_max_lds(c, kernel, dyn_lds));
     int per_cu = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, dyn_lds));
     if (per_cu < 1) per_cu = 1;

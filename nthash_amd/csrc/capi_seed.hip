@@ -45,6 +45,7 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
   if (blk_pairs.empty()) blk_pairs.push_back(0);
   nthip_seeds* sd = new nthip_seeds();
   sd->ctx = c;
+  sd->device = c->device;
   sd->n_seeds = n_seeds;
   sd->k = k;
   sd->ntab = ntab;
@@ -72,7 +73,7 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
 extern "C" int nthip_seeds_destroy(nthip_seeds* sd)
 {
   if (!sd) return NTHIP_OK;
-  if (sd->ctx) (void)hipSetDevice(sd->ctx->device);
+  (void)hipSetDevice(sd->device); // (not sd->ctx->device: a seed set may outlive the context that made it)
   if (sd->d_tables) (void)hipFree(sd->d_tables);
   if (sd->d_care) (void)hipFree(sd->d_care);
   if (sd->d_blk_start) (void)hipFree(sd->d_blk_start);
@@ -673,7 +674,6 @@ int launch_seed_fixed(nthip_ctx* c, K kernel, const SeedFixedArgs& a, size_t dyn
 // positions with 2k bases around them, the pieces go through the span path (a wave per piece instead of a wave per
 // read), counts and positions are folded back per read.  *handled = false: nothing done.
 namespace {
-constexpr uint64_t SEED_LONG_MIN = 16384; // reads from this length on are worth cutting
 constexpr uint64_t SEED_LONG_DENSE_MAX = 131072; // fixed-length reads from this length on skip the dense kernels
 struct DevTemp { // device temporaries of one call
   std::vector<void*> ptrs;
@@ -816,6 +816,9 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
     NTCHK(offsets_survey_device(c, st.offsets, rd->n_reads, total_bytes, &sv));
     if (sv.bad) return fail(NTHIP_ERR_ARG, "offsets / spans are not non-decreasing or reach outside the read buffer");
     max_len = sv.max_len;
+    if (st.pos && sv.max_len > 0xFFFFFFFFull) // (as nthip_kmer_hash: the façade hashes long sequences window by window)
+      return fail(NTHIP_ERR_UNSUPPORTED, "out->pos is 32 bits wide: a read of %llu bases cannot report its positions",
+                  (unsigned long long)sv.max_len);
     if (sv.uniform && !(flags & NTHIP_FORCE_GENERAL) && rd->n_reads >= 1024 && sv.len0 >= 1 && sv.len0 < (1ull << 30) &&
         sv.off0 + rd->n_reads * sv.len0 <= total_bytes) {
       st.seqs += sv.off0;
@@ -1038,10 +1041,16 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
   if (!done && max_len >= SEED_LONG_MIN && !(flags & NTHIP_FORCE_GENERAL)) {
     // chromosomes / contigs: one wave per read would leave the chip idle; independent pieces instead
     bool handled = false;
-    NTCHK(run_seed_long(c, st, rd, sd, m2, out->capacity, &total, &handled));
+    const int rc = run_seed_long(c, st, rd, sd, m2, out->capacity, &total, &handled);
+    if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total; // (the need, as the dense and k-mer paths report it)
+    NTCHK(rc);
     done = handled;
   }
-  if (!done) NTCHK(run_seed_general(c, st, rd, sd, m2, out->capacity, &total, nullptr, !(flags & NTHIP_FORCE_GENERAL)));
+  if (!done) {
+    const int rc = run_seed_general(c, st, rd, sd, m2, out->capacity, &total, nullptr, !(flags & NTHIP_FORCE_GENERAL));
+    if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
+    NTCHK(rc);
+  }
   if (total_out) *total_out = total;
   NTCHK(unstage_outputs(c, out, flags, rd->n_reads, per, total, st, sd->n_seeds));
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -69,21 +69,23 @@ int offsets_survey_device(nthip_ctx* c, const uint64_t* d_offsets, uint64_t n_re
 // One pass over the offsets / spans before a kernel trusts them (a decreasing pair would underflow a length and
 // read far outside the buffer): costs one round trip, only on the paths that take caller-made offsets.
 int check_offsets_device(nthip_ctx* c, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
-                         uint64_t buf_bytes, bool contiguous)
+                         uint64_t buf_bytes, bool contiguous, uint64_t* max_len)
 {
   (void)contiguous;
+  if (max_len) *max_len = 0;
   if (n_reads == 0) return NTHIP_OK;
-  uint32_t* d_bad = (uint32_t*)(c->d_small + 32);
-  HIPCHK(hipMemsetAsync(d_bad, 0, 4, c->stream));
+  uint32_t* d_bad = (uint32_t*)(c->d_small + 32); // [32] bad flag (u32), [40] longest span (u64)
+  HIPCHK(hipMemsetAsync(d_bad, 0, 16, c->stream));
   uint64_t blocks = (n_reads + 255) / 256;
   if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
   hipLaunchKernelGGL(check_spans_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n_reads,
-                     buf_bytes, d_bad);
+                     buf_bytes, d_bad, (unsigned long long*)(c->d_small + 40));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(c->h_small + 32, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_small + 32, d_bad, 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   uint32_t bad = 0;
   memcpy(&bad, c->h_small + 32, 4);
+  if (max_len) memcpy(max_len, c->h_small + 40, 8);
   if (bad) return fail(NTHIP_ERR_ARG, "offsets / spans are not non-decreasing or reach outside the read buffer");
   return NTHIP_OK;
 }
@@ -144,7 +146,7 @@ extern "C" int nthip_kmer_extend(nthip_ctx* c, const char* kmers, uint64_t n, ui
     uint64_t blocks = (n + threads - 1) / threads;
     if (blocks > (uint64_t)c->n_cu * 2) blocks = (uint64_t)c->n_cu * 2;
     auto go = [&](auto kernel) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)raise_max_dynamic_lds(c->device, reinterpret_cast<const void*>(kernel), lds);
       prof_begin(c, "kmer_extend_tab_kernel");
       hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), lds, c->stream, d_in, n, k, m, tab, ntab, d_self,
                          d_next, d_prev);

@@ -62,7 +62,11 @@ extern "C" int nthip_seed_hash_spans(nthip_ctx* c, const char* d_buf, uint64_t b
   if (total_out) *total_out = 0;
   if (n_reads == 0) return NTHIP_OK;
   const uint32_t per = sd->n_seeds * m2;
-  NTCHK(check_offsets_device(c, d_starts, d_ends, n_reads, buf_bytes, false)); // spans inside the buffer, start <= end
+  uint64_t max_len = 0; // spans inside the buffer, start <= end; and how long the longest one is
+  NTCHK(check_offsets_device(c, d_starts, d_ends, n_reads, buf_bytes, false, &max_len));
+  if (out->pos && max_len > 0xFFFFFFFFull)
+    return fail(NTHIP_ERR_UNSUPPORTED, "out->pos is 32 bits wide: a read of %llu bases cannot report its positions",
+                (unsigned long long)max_len);
   Staged st;
   st.seqs = (const uint8_t*)d_buf;
   st.offsets = d_starts;
@@ -71,7 +75,9 @@ extern "C" int nthip_seed_hash_spans(nthip_ctx* c, const char* d_buf, uint64_t b
   uint64_t total = 0;
   int rc = NTHIP_OK;
   bool long_done = false;
-  if (!(flags & NTHIP_FORCE_GENERAL)) rc = run_seed_long(c, st, &rd, sd, m2, out->capacity, &total, &long_done, d_ends);
+  // (the pieces only pay for chromosome-sized reads: a FASTQ chunk of short reads goes straight to the variable-length path)
+  if (!(flags & NTHIP_FORCE_GENERAL) && max_len >= SEED_LONG_MIN)
+    rc = run_seed_long(c, st, &rd, sd, m2, out->capacity, &total, &long_done, d_ends);
   if (rc == NTHIP_OK && !long_done) rc = run_seed_general(c, st, &rd, sd, m2, out->capacity, &total, d_ends);
   if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
   NTCHK(rc);

@@ -151,6 +151,27 @@ __device__ __forceinline__ TileRange tile_range(uint64_t n_tiles, uint32_t waves
   return r;
 }
 
+// ---- hidden loads and the ISA lint (nthash_amd/isa_lint.py, run by build.py on every unit) ----------------------------
+// Several kernels issue the NEXT tile's global loads in inline asm and consume them after this tile's stores behind a
+// counted s_waitcnt (vmcnt retires in order; an ordinary load there would make every wave wait for its own store
+// acknowledgements).  hipcc believes the destination registers are ready at the asm statement: any copy, spill or use it
+// inserts before the wait reads stale data (it happened once, round 2).  So every such site ends in a marker
+//     asm volatile("; NTLINT_CONSUME %0 %1 ..." : "+v"(regs) ...)
+// right behind its wait.  The marker is only a comment in the emitted ISA, but it names the registers hipcc holds the
+// values in AT THE WAIT; the lint disassembles every kernel and refuses the build unless, on every path from a hidden
+// load to the marker that consumes it, (1) no instruction reads or writes the load's destination registers, (2) the
+// marker names exactly those registers (no copy in between) and (3) the marker sits behind an inline s_waitcnt vmcnt.
+// -DNT_LINT_SELFTEST=1 breaks rule (1) on purpose in every kernel that has such a site (tests/test_isa_lint.py).
+#ifndef NT_LINT_SELFTEST
+#define NT_LINT_SELFTEST 0
+#endif
+#if NT_LINT_SELFTEST
+#define NT_LINT_SELFTEST_TOUCH(reg32) \
+  do { uint32_t lint_tmp_; asm volatile("v_mov_b32 %0, %1" : "=v"(lint_tmp_) : "v"(reg32)); asm volatile("" ::"v"(lint_tmp_)); } while (0)
+#else
+#define NT_LINT_SELFTEST_TOUCH(reg32) do { } while (0)
+#endif
+
 // word modes of the per-lane rolling loop
 enum : int { W_NOEMIT = 0, W_EMIT = 1, W_BOUNDARY = 2, W_CHECKED = 3 };
 

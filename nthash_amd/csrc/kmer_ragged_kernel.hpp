@@ -291,7 +291,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
   if (wt + wstride < t_end) { j0_nxt = a.tile_j0[wt + wstride]; rem0_nxt = (uint32_t)a.tile_rem0[wt + wstride]; }
   uint32_t cur = 0;
   issue_meta(j0_cur);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(meta_lo), "+v"(meta_hi)::"memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("; NTLINT_CONSUME %0 %1" : "+v"(meta_lo), "+v"(meta_hi)::"memory");
   uint32_t v_total = build_table(cur, j0_cur, rem0_cur, runs_of(wt));
   lds_sync();
   issue_stage(cur, v_total);
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
     const bool have_next = wt + wstride < t_end;
     // ---- the staged vectors of this tile (and the records of the next) have landed ------------
     wait_vmcnt_upto15(n_counted < 15u ? n_counted : 15u);
-    asm volatile("" : "+v"(st0), "+v"(st1), "+v"(st2), "+v"(meta_lo), "+v"(meta_hi)::"memory");
+    asm volatile("; NTLINT_CONSUME %0 %1 %2 %3 %4" : "+v"(st0), "+v"(st1), "+v"(st2), "+v"(meta_lo), "+v"(meta_hi)::"memory");
     {
       const uint4 x0 = make_uint4(st0.x, st0.y, st0.z, st0.w), x1 = make_uint4(st1.x, st1.y, st1.z, st1.w),
                   x2 = make_uint4(st2.x, st2.y, st2.z, st2.w);
@@ -509,6 +510,9 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
     j0_cur = j0_nxt; rem0_cur = rem0_nxt;
     j0_nxt = j0_n2; rem0_nxt = rem0_n2;
   }
+  // (no hidden load is in flight here -- the last iteration issues none -- but that is a property of the loop's
+  //  conditions, not of the flow graph: the registers are reused below, so say it in a way the ISA lint can see)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (MODE == NA_MODE_COUNT && a.counts && acc_cnt && lane == 0)
     atomicAdd((unsigned long long*)&a.counts[acc_read], (unsigned long long)acc_cnt);
 #undef RT_BEGIN

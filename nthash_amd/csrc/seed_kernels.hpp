@@ -489,6 +489,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
         asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(pv[rd]) : "v"(off), "s"(sbase) : "memory");
       }
       asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(dirty_seen) : "v"(a.dirty) : "memory");
+      NT_LINT_SELFTEST_TOUCH(dirty_seen);
     }
 
     // ---- this tile: groups of 64 consecutive windows ----
@@ -625,9 +626,13 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
 
     // ---- consume the next slab ----
     if constexpr (PF) {
+      // vmcnt counts in order and holds at most 63: once 64 younger operations have been issued the loads have landed,
+      // and "at most 63 in flight" is the wait that says so (unconditional: every path into the marker passes an
+      // inline wait, lint rule R3); fewer stores than that: everything
+      asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
       if (n_stores < 64u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]),
-                        "+v"(pv[7]), "+v"(dirty_seen)::"memory");
+      asm volatile("; NTLINT_CONSUME %0 %1 %2 %3 %4 %5 %6 %7 %8" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]),
+                   "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]), "+v"(dirty_seen)::"memory");
     } else {
       dirty_seen = __atomic_load_n(a.dirty, __ATOMIC_RELAXED);
     }

@@ -495,14 +495,23 @@ static __global__ __launch_bounds__(256) void offsets_survey_kernel(const uint64
 // spans / offsets sanity (the kernels trust them): every read must satisfy starts[r] <= ends[r] <= buf_bytes
 static __global__ __launch_bounds__(256) void check_spans_kernel(const uint64_t* __restrict__ starts,
                                                                  const uint64_t* __restrict__ ends, uint64_t n,
-                                                                 uint64_t buf_bytes, uint32_t* __restrict__ bad)
+                                                                 uint64_t buf_bytes, uint32_t* __restrict__ bad,
+                                                                 unsigned long long* __restrict__ max_len)
 {
   uint32_t b = 0;
+  uint64_t longest = 0; // (of the well-formed spans; a malformed one fails the call anyway)
   for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t s0 = starts[r], e0 = ends[r];
     if (s0 > e0 || e0 > buf_bytes) b = 1u;
+    else if (e0 - s0 > longest) longest = e0 - s0;
   }
   if (__ballot(b != 0) != 0 && (threadIdx.x & 63u) == 0) atomicOr(bad, 1u);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint64_t o = __shfl_xor(longest, d, 64);
+    longest = o > longest ? o : longest;
+  }
+  if ((threadIdx.x & 63u) == 0 && longest) atomicMax(max_len, (unsigned long long)longest);
 }
 
 } // namespace ntamd
