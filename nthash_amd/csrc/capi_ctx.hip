@@ -24,6 +24,7 @@ int ntamd::host::fail(int code, const char* fmt, ...)
 
 namespace ntamd {
 namespace host {
+uint32_t g_kmer_table_k_max = KMER_TABLE_K_MAX_N;
 // hipFuncAttributeMaxDynamicSharedMemorySize is one value per (device, function) for the process: raise-only, locked
 int raise_max_dynamic_lds(int device, const void* kernel, size_t bytes)
 {
@@ -276,6 +277,9 @@ void load_tuning(nthip_tune& t)
   t.ph_tiles = num("NTHIP_TUNE_PH_TILES", 1, 64);
   t.ph_period = num("NTHIP_TUNE_PH_PERIOD", 1, 10000000);
   t.ph_read = num("NTHIP_TUNE_PH_READ", 1, 10000000);
+  t.fw = num("NTHIP_TUNE_FW", 1, 2);
+  const uint32_t tk = num("NTHIP_TUNE_TABLE_K_MAX", 16, 64);
+  ntamd::host::g_kmer_table_k_max = tk ? tk : (uint32_t)KMER_TABLE_K_MAX_N;
 }
 } // namespace
 

@@ -96,6 +96,7 @@ struct nthip_tune {
   uint32_t ph_tiles = 0;    // NTHIP_TUNE_PH_TILES
   uint32_t ph_period = 0;   // NTHIP_TUNE_PH_PERIOD
   uint32_t ph_read = 0;     // NTHIP_TUNE_PH_READ
+  uint32_t fw = 0;          // NTHIP_TUNE_FW: first window beyond the position tables -- 1 grouped, 2 prefix scan (0: cost model)
 };
 
 struct nthip_ctx {
@@ -247,8 +248,12 @@ int launch_fill_window_pos(nthip_ctx* c, uint32_t* d_pos, uint64_t n_reads, uint
 #ifndef KMER_TABLE_K_MAX_N
 #define KMER_TABLE_K_MAX_N 64
 #endif
-constexpr uint32_t KMER_TABLE_K_MAX = KMER_TABLE_K_MAX_N; // beyond: Horner first window
-inline uint32_t kmer_ntab(uint32_t k) { return k <= KMER_TABLE_K_MAX ? 4u * ((k + 15) / 16) : 2u; }
+// largest k whose first window comes from position-specific byte tables (4 KiB per 4 bases of k in LDS); beyond it the
+// k-independent first window of first_window.hpp.  A process-wide value: 64 unless NTHIP_TUNE_TABLE_K_MAX (16..64) says
+// otherwise when a context is created (A/B: the k-independent forms on k <= 64 shapes)
+extern uint32_t g_kmer_table_k_max;
+#define KMER_TABLE_K_MAX (::ntamd::host::g_kmer_table_k_max)
+inline uint32_t kmer_ntab(uint32_t k) { return k <= KMER_TABLE_K_MAX ? 4u * ((k + 15) / 16) : FW_ENTRIES / 256u; }
 inline uint32_t kmer_nw(uint32_t k) { return k <= KMER_TABLE_K_MAX ? (k + 15) / 16 : 0u; }
 
 void fill_kmer_consts(uint32_t k, uint32_t m, KmerFixedArgs& a);
@@ -257,7 +262,7 @@ bool kmer_fixed_eligible(const nthip_ctx* c, uint32_t len, uint32_t stride, uint
 void build_byte_tables(uint32_t k, const uint8_t* care, uint4* out);
 int get_init_tab(nthip_ctx* c, uint32_t k, const uint4** out);
 int get_kmer_tab(nthip_ctx* c, uint32_t k, const uint4** out);
-int get_horner_tab(nthip_ctx* c, const uint4** out); // the k-independent pair: a 4-mer's byte table [0..255], a 1-mer's [256..259]
+int get_fw_tab(nthip_ctx* c, const uint4** out); // the k-independent first-window tables (first_window.hpp), FW_ENTRIES entries
 
 // Plan for the headline run-split kernel: run length C | nwin, waves per block, LDS bytes.
 struct RunsPlan {
@@ -268,6 +273,7 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
 
 struct GenPlan {
   uint32_t C = 0, rpr = 0, last_start = 0, waves = 0, bits_dwords = 0, tile_u64 = 0, nw = 0, dword_tail = 0;
+  uint32_t fw_scan = 0, uw_dwords = 0; // nw == 0: the prefix-scan first window and its per-wave LDS (first_window.hpp)
   size_t lds = 0;
 };
 bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, GenPlan* p,

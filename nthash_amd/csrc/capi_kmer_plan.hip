@@ -82,21 +82,20 @@ int get_init_tab(nthip_ctx* c, uint32_t k, const uint4** out)
   return NTHIP_OK;
 }
 
-// k > 64: the run-split kernels hash a run's first window by Horner with ONE k-independent byte table
-// (a 4-mer's) plus a 1-mer's for the k % 4 leftover bases -- [0..255] and [256..511] of the same array
+// k > 64: the first window of a run comes from the k-independent fw tables (first_window.hpp: 16 bases per step, or the
+// prefix-scan form) -- FW_ENTRIES entries, five 4 KiB tables' worth of LDS whatever k is
 int get_kmer_tab(nthip_ctx* c, uint32_t k, const uint4** out)
 {
   if (k <= KMER_TABLE_K_MAX) return get_init_tab(c, k, out);
-  return get_horner_tab(c, out);
+  return get_fw_tab(c, out);
 }
-int get_horner_tab(nthip_ctx* c, const uint4** out)
+int get_fw_tab(nthip_ctx* c, const uint4** out)
 {
-  const uint32_t key = 0xFFFF0004u;
+  const uint32_t key = 0xFFFF0010u;
   auto it = c->init_tabs.find(key);
   if (it == c->init_tabs.end()) {
-    std::vector<uint4> h(512);
-    build_byte_tables(4, nullptr, h.data());
-    build_byte_tables(1, nullptr, h.data() + 256);
+    std::vector<uint4> h(FW_ENTRIES);
+    build_fw_tables(h.data());
     uint4* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, h.size() * sizeof(uint4)));
     HIPCHK(hipMemcpy(d, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice));
@@ -110,7 +109,7 @@ int get_horner_tab(nthip_ctx* c, const uint4** out)
 
 bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, RunsPlan* p)
 {
-  if (len < k || k > 64 || m > (uint32_t)KF_MAX_RUNTIME_M || stride > len || stride == 0) return false;
+  if (len < k || k > KMER_TABLE_K_MAX || m > (uint32_t)KF_MAX_RUNTIME_M || stride > len || stride == 0) return false;
   const uint32_t nwin = len - k + 1;
   uint32_t best = 0;
   // An ODD run length first: a lane's tile row is C 8-byte entries, and the 16 lanes of a ds_write_b64 group then fall
@@ -179,16 +178,37 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
   if (len < k || m == 0 || (stride > len && !gaps_ok) || len >= (1u << 30) || stride >= (1u << 30)) return false;
   const uint32_t nwin = len - k + 1;
   if (stride < nwin) return false; // reads overlapping by more than k-1 bases: other paths
-  const uint32_t ntab = (k + 3) / 4; // first-window cost in the model (table lookups or Horner steps)
+  const uint32_t ntab = (k + 3) / 4; // first-window cost in the model: table lookups (k within the position tables)
+  const bool any_k = kmer_nw(k) == 0;
   uint32_t best = 0;
   double best_cost = 1e30;
   // The kernels take runs of up to 31 windows (the window masks of the N-aware pass are 32 bits wide), but the
   // model stops at 16: it does not see what a larger tile costs in waves per CU.  In-process A/B over 24 shapes
   // (profiles/r01_notes.md): longer runs win 3-8 % where they cut the runs per read sharply (100 bp/k64: 13 -> 19,
-  // 1 kb reads, k <= 15) and lose 5-28 % elsewhere (k = 63/64 at 150 bp: -27 %).
-  uint32_t c_cap = model_cap ? model_cap : no_tile ? 31 : 16;
+  // 1 kb reads, k <= 15) and lose 5-28 % elsewhere (k = 63/64 at 150 bp: -27 %).  Beyond the position tables the
+  // tables are 20 KB whatever k is and the first window is dearer: the model may go to 19 there when a read has few windows
+  // (in-process A/B, profiles/r03_notes.md: 19 wins on 150 bp / k = 65, 17 on the 51-window shapes -- no recomputed
+  // windows --, 15 on 1 kb / k = 500; 23 and more lose 8-25 % everywhere).
+  uint32_t c_cap = model_cap ? model_cap : no_tile ? 31 : any_k && nwin <= 128 ? 19 : 16;
   if (c->tune.run_max) c_cap = c->tune.run_max; // A/B knob: longest run the model may pick
   const uint32_t c_hi = nwin < c_cap ? nwin : c_cap;
+  // slab of a tile of 64 runs of C windows, in dwords of the 2-bit stream: 63 run-to-run steps of at most C bases,
+  // C + stride - nwin across a read boundary, plus the last run
+  auto slab_bytes_of = [&](uint32_t C) -> uint64_t {
+    const uint32_t rpr = (nwin + C - 1) / C;
+    const uint64_t crossings = (63 + rpr - 1) / rpr;
+    return 64ull * C + k - 1 + crossings * (uint64_t)(stride - nwin);
+  };
+  auto slab_dwords = [&](uint32_t C) -> uint64_t { return (15 + slab_bytes_of(C) + 15) >> 4; };
+  // first window of a run beyond the position tables, in VALU instructions (counted on the ISA, fitted to in-process
+  // A/B on seven shapes, profiles/r03_notes.md): grouped ~43 per 16 bases of k + 13; prefix scan ~230 + 60 per word of
+  // the slab a lane takes, whatever k is
+  auto fw_cost = [&](uint32_t C, bool* scan) -> double {
+    const double grouped = 43.0 * (k / 16 + 1) + 13.0;
+    const double sc = 230.0 + 60.0 * (double)((slab_dwords(C) + 1 + 63) / 64);
+    *scan = c->tune.fw ? c->tune.fw == 2 : sc < grouped;
+    return *scan ? sc : grouped;
+  };
   for (uint32_t C = c_hi; C >= 1; --C) {
     const uint32_t rpr = (nwin + C - 1) / C;
     // the 64 rows of a tile are C*8 bytes apart: an even C puts several lanes of a ds_write_b64 on the
@@ -198,7 +218,9 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
     while (ways < 32 && (g & 1) == 0) { g >>= 1; ways <<= 1; }
     ways = ways > 2 ? ways / 2 : 1;
     const double conflict = no_tile || ways <= 1 ? 0.0 : ways == 2 ? 0.05 : ways == 4 ? 0.45 : 1.0;
-    const double cost = (double)rpr * (2.0 + 0.5 * ntab + (C - 1) * (1.0 + conflict)) / nwin;
+    bool scan = false;
+    const double first = any_k ? fw_cost(C, &scan) / 35.0 : 2.0 + 0.5 * ntab; // in roll steps (35 instructions each)
+    const double cost = (double)rpr * (first + (C - 1) * (1.0 + conflict)) / nwin;
     if (cost < best_cost - 1e-9) { best_cost = cost; best = C; }
   }
   if (force_c >= 1 && force_c <= 31 && force_c <= nwin) best = force_c;
@@ -210,16 +232,22 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
   p->last_start = nwin - best;
   p->nw = kmer_nw(k);
   p->tile_u64 = 64 * best + 128;
-  // longest slab: 63 run-to-run steps of at most C bases, C + stride - nwin across a read boundary, plus
-  // the last run
-  const uint64_t crossings = (63 + p->rpr - 1) / p->rpr;
-  const uint64_t slab_bytes = 64ull * best + k - 1 + crossings * (uint64_t)(stride - nwin);
-  uint32_t bd = (uint32_t)((15 + slab_bytes + 15) >> 4) + p->nw + 6;
+  const uint64_t slab_vecs = slab_dwords(best);
+  uint32_t bd = (uint32_t)slab_vecs + p->nw + 6;
   bd = (bd + 3u) & ~3u;
   p->bits_dwords = bd;
-  p->dword_tail = (15 + slab_bytes <= 1280) ? 1u : 0u;
+  p->dword_tail = (15 + slab_bytes_of(best) <= 1280) ? 1u : 0u;
+  // k beyond the position tables: which first window (first_window.hpp), and the scan's {U, V} per word of the slab
+  p->fw_scan = p->uw_dwords = 0;
+  if (any_k) {
+    bool scan = false;
+    (void)fw_cost(best, &scan);
+    if (bd >= 65536u) scan = false; // (positions of the scan are folded below 2^20)
+    p->fw_scan = scan ? 1u : 0u;
+    if (scan) p->uw_dwords = 4u * bd;
+  }
   const size_t fixed = (size_t)kmer_ntab(k) * 4096 + 256 + 64;
-  const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4;
+  const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4 + (size_t)p->uw_dwords * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
   // m = 1: 12 waves per CU (3 per SIMD) measured +3 ... +9 % over 8 on 150 / 151 bp, 16 no better (round 2)
   uint32_t w_max = m == 1 ? 12 : 16;
@@ -247,7 +275,7 @@ bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k,
   p->ptile_dwords = want_pos ? (64 * g.C + KRG_SLACK_U64 + 3u) & ~3u : 0u;
   p->vbits_dwords = (g.bits_dwords / 2 + 8 + 3u) & ~3u; // 16 validity bits per 32 stream bits, read 4 dwords ahead
   const size_t fixed = (size_t)kmer_ntab(k) * 4096 + 256 + 64;
-  const size_t per_wave = (size_t)p->tile_u64 * 8 + ((size_t)p->ptile_dwords + g.bits_dwords + p->vbits_dwords) * 4;
+  const size_t per_wave = (size_t)p->tile_u64 * 8 + ((size_t)p->ptile_dwords + g.bits_dwords + p->vbits_dwords + g.uw_dwords) * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
   uint32_t w_max = register_sink_u64 ? 16 : 8;
   if (c->tune.na_waves) w_max = c->tune.na_waves;
@@ -287,6 +315,8 @@ void fill_gen_args(KmerRunsGenArgs& ga, nthip_ctx* c, const Staged& st, const nt
   ga.tile_u64 = g.tile_u64;
   ga.inv_rpr = 65536u / g.rpr + 1u;
   ga.tile_map = c->tune.has_tile_map ? c->tune.tile_map : 0xFFFFFFFFu;
+  ga.fw_scan = g.fw_scan;
+  ga.uw_dwords = g.uw_dwords;
   memcpy(ga.tab, consts.tab, sizeof ga.tab);
   memcpy(ga.mult, consts.mult, sizeof ga.mult);
 }

@@ -188,7 +188,7 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
     da.sk_fwd[cde] = srol_n(seed_of_code(cde), k);
     da.sk_rc[cde] = srol_n(seed_of_code(cde ^ 2u), k);
   }
-  NTCHK(get_horner_tab(c, &da.horner_tab));
+  NTCHK(get_fw_tab(c, &da.horner_tab));
   const unsigned dblocks = (unsigned)c->n_cu * 4;
   hipLaunchKernelGGL(kmer_dirty_reads_kernel<true>, dim3(dblocks), dim3(256), 0, c->stream, da);
   HIPCHK(hipGetLastError());

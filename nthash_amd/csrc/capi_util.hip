@@ -131,12 +131,13 @@ extern "C" int nthip_kmer_extend(nthip_ctx* c, const char* kmers, uint64_t n, ui
   }
   if (rc != NTHIP_OK) { cleanup(); return rc; }
   const bool aligned16 = (!d_next || ((uintptr_t)d_next & 15u) == 0) && (!d_prev || ((uintptr_t)d_prev & 15u) == 0);
-  // byte tables in LDS (k > 64: the two Horner tables + a 2-bit stream of the wave's k-mers), 16-byte stores
+  // byte tables in LDS (beyond the position tables: the fw tables + a 2-bit stream of the wave's k-mers), 16-byte stores
   const uint32_t ntab = kmer_ntab(k);
-  const size_t wave_bits = k > 64 ? ((((size_t)64 * k + 30) >> 4) + 4) * 4 : 0;
+  const bool any_k = kmer_nw(k) == 0;
+  const size_t wave_bits = any_k ? ((((size_t)64 * k + 30) >> 4) + 4) * 4 : 0;
   const size_t lds_fixed = (size_t)ntab * 4096 + 16 * 2048; // tables + a 2 KiB exchange tile per wave
   const size_t lds_cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
-  uint32_t waves = k > 32 && k <= 64 ? KX_WIDE_THREADS / 64 : 16;
+  uint32_t waves = k > 32 && !any_k ? KX_WIDE_THREADS / 64 : 16;
   while (waves > 1 && lds_fixed + wave_bits * waves > lds_cap) waves /= 2;
   if (aligned16 && lds_fixed + wave_bits * waves <= lds_cap) {
     const uint4* tab = nullptr;
@@ -152,7 +153,7 @@ extern "C" int nthip_kmer_extend(nthip_ctx* c, const char* kmers, uint64_t n, ui
                          d_next, d_prev);
       prof_end(c);
     };
-    if (k > 64) go(kmer_extend_tab_kernel<0>);
+    if (any_k) go(kmer_extend_tab_kernel<0>);
     else if (k <= 16) go(kmer_extend_tab_kernel<1>);
     else if (k <= 32) go(kmer_extend_tab_kernel<2>);
     else if (k <= 48) go(kmer_extend_tab_kernel<3>);

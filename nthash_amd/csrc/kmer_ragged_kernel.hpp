@@ -374,7 +374,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
       const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
       uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
       if constexpr (NW == 0) { // any k: Horner first window (kmer_runs_gen_kernel.hpp)
-        horner_first_window(bits, itab, b0, k, f_lo, f_hi, r_lo, r_hi);
+        any_k_first_window(bits, itab, b0, k, f_lo, f_hi, r_lo, r_hi);
       } else {
         uint32_t w[NW];
         uint32_t lo = bits[d0];

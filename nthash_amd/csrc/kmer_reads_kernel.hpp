@@ -319,7 +319,7 @@ void kmer_reads_kernel(const KmerReadsArgs a)
         const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
         uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
         if constexpr (NW == 0) {
-          horner_first_window(bits, itab, b0, k, f_lo, f_hi, r_lo, r_hi);
+          any_k_first_window(bits, itab, b0, k, f_lo, f_hi, r_lo, r_hi);
         } else {
           uint32_t w[NW];
           uint32_t lo = bits[d0];
@@ -483,7 +483,7 @@ struct KmerDirtyReadsArgs {
   uint32_t* pos;
   uint64_t* fwd;
   uint64_t* rev;
-  const uint4* horner_tab;   // hash pass: byte table of a 4-mer [0..255], of a 1-mer [256..259] (get_horner_tab)
+  const uint4* horner_tab;   // hash pass: the k-independent fw tables (first_window.hpp; get_fw_tab), FW_ENTRIES entries
   uint64_t sk_fwd[4];        // srol^k(seed[code])
   uint64_t sk_rc[4];         // srol^k(seed[code ^ 2])
 };
@@ -502,13 +502,13 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
   // hash pass: the read as 2-bit codes too, and the k-independent tables of horner_first_window (4 bases per step:
   // a window is 2 * ceil(k / 4) table steps instead of 2k character steps)
   __shared__ uint32_t bits_all[COUNT_ONLY ? 1 : 4][COUNT_ONLY ? 1 : RD_MAX_LEN / 16 + 8];
-  __shared__ uint4 htab[COUNT_ONLY ? 1 : 512];
+  __shared__ uint4 htab[COUNT_ONLY ? 1 : FW_ENTRIES];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint8_t* raw = raw_all[wave];
   uint16_t* lb = lb_all[wave];
   uint32_t* bits = bits_all[COUNT_ONLY ? 0 : wave];
   if (!COUNT_ONLY) {
-    for (uint32_t i = threadIdx.x; i < 512u; i += blockDim.x) htab[i] = a.horner_tab[i];
+    for (uint32_t i = threadIdx.x; i < FW_ENTRIES; i += blockDim.x) htab[i] = a.horner_tab[i];
     __syncthreads();
   }
   const uint64_t n = *a.n_list;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
       if (!COUNT_ONLY && valid) {
         const uint32_t slot = emitted + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         uint32_t f_lo, f_hi, r_lo, r_hi; // (a valid window holds bases only: its 2-bit codes are all it takes)
-        horner_first_window(bits, htab, w, k, f_lo, f_hi, r_lo, r_hi);
+        any_k_first_window(bits, htab, w, k, f_lo, f_hi, r_lo, r_hi);
         const uint64_t fh = ((uint64_t)f_hi << 32) | f_lo, rh = ((uint64_t)r_hi << 32) | r_lo;
         const uint64_t o = base + slot;
         const uint64_t h0 = fh + rh;

@@ -38,6 +38,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "first_window.hpp"
 #include "kmer_runs_kernel.hpp"
 
 namespace ntamd {
@@ -95,7 +96,11 @@ struct KmerRunsGenArgs {
   uint32_t sig_first, sig_n;
   // N-aware pass: what a k-mer's value is -- 0: the canonical hash (+ m-1 mixes), 1: the forward-strand hash,
   // 2: the reverse-strand hash (NtHash::get_forward_hash / get_reverse_hash; one value per k-mer, m must be 1)
-  uint32_t value_sel, pad2;
+  uint32_t value_sel;
+  // NW == 0 (k beyond the position tables): 0 = the grouped first window, 1 = the prefix-scan form (first_window.hpp);
+  // the scan keeps {U, V} at every word boundary of the slab in uw_dwords dwords of LDS per wave (4 per word)
+  uint32_t fw_scan;
+  uint32_t uw_dwords, pad3;
 };
 
 // h mod d for an invariant d (magic = floor((2^64 - 1) / d): the quotient estimate is at most 2 short)
@@ -192,79 +197,27 @@ __device__ __forceinline__ uint32_t windows_with_non_base_long(const uint32_t* v
   return inv;
 }
 
-// split rotate by N (2..16) on the {lo, hi} halves (see srol_pair)
-template <int N>
-__device__ __forceinline__ void srol_pair_n(uint32_t& lo, uint32_t& hi)
+// First window of a run for ANY k (the NW == 0 instantiations and every other kernel's k > 64 path): the grouped form of
+// first_window.hpp -- 16 bases per step from the k-independent fw tables (get_fw_tab; kmer_ntab(k) = 5 tables' worth of
+// LDS), constant rotates by 16 between the steps.  Same values as base_forward_hash / base_reverse_hash,
+// src/kmer.cpp:43-73,123-152.  (Round 2 walked the window 4 bases at a time, both strands apart: 2 x k/4 dependent steps.)
+__device__ __forceinline__ void any_k_first_window(const uint32_t* bits, const uint4* tab, uint32_t b0, uint32_t k,
+                                                   uint32_t& f_lo, uint32_t& f_hi, uint32_t& r_lo, uint32_t& r_hi)
 {
-  static_assert(N >= 2 && N <= 16, "");
-  const uint32_t h31 = hi >> 1;
-  const uint32_t nb32 = (lo >> (32 - N)) & 1u;
-  const uint32_t nlo = (lo << N) | ((hi & 1u) << (N - 1)) | (lo >> (33 - N));
-  const uint32_t nh31 = ((h31 << N) | (h31 >> (31 - N))) & 0x7FFFFFFFu;
-  lo = nlo;
-  hi = (nh31 << 1) | nb32;
+  grouped_first_window(bits, tab, b0, k, k % 31u, k % 33u, f_lo, f_hi, r_lo, r_hi);
 }
 
-// First window of a run for ANY k (the NW == 0 instantiations): Horner over the window, 4 bases per step
-// with one k-independent byte table -- the position-specific tables of the NW > 0 path would need
-// ceil(k/4) * 4 KB of LDS -- the k % 4 leftover bases one at a time.  F runs forward from the first
-// base, R backward from the last.  tab[0..255] = byte table of a 4-mer, tab[256..259] = of a 1-mer
-// (build_byte_tables with k = 4 / k = 1).  Same values as base_forward_hash / base_reverse_hash,
-// src/kmer.cpp:43-73,123-152.
-__device__ __forceinline__ void horner_first_window(const uint32_t* bits, const uint4* tab, uint32_t b0, uint32_t k,
-                                                    uint32_t& f_lo, uint32_t& f_hi, uint32_t& r_lo, uint32_t& r_hi)
+// inclusive XOR scan over the 64 lanes on the DPP network: row_shr 1, 2, 4, 8 inside each row of 16 lanes, row_bcast15 /
+// row_bcast31 carry the row totals across (the prefix sums of kmer_reads_kernel.hpp with ^ for +)
+__device__ __forceinline__ uint32_t wave_incl_xor32(uint32_t v)
 {
-  const uint4* t4 = tab;
-  const uint4* t1 = tab + 256;
-  const uint32_t nbytes = k >> 2, rem = k & 3u;
-  auto word_at = [&](uint32_t pos) { return funnel(bits[(pos >> 4) + 1u], bits[pos >> 4], (pos & 15u) << 1); };
-  f_lo = f_hi = r_lo = r_hi = 0;
-  // forward strand: full bytes from the first base, then the leftover bases
-  for (uint32_t w = 0; 4u * w < nbytes; ++w) {
-    const uint32_t word = word_at(b0 + 16u * w);
-    const uint32_t nb = nbytes - 4u * w < 4u ? nbytes - 4u * w : 4u;
-#pragma unroll
-    for (uint32_t q = 0; q < 4; ++q) {
-      if (q < nb) {
-        const uint4 e = t4[(word >> (8u * q)) & 0xFFu];
-        srol_pair_n<4>(f_lo, f_hi);
-        f_lo ^= e.x;
-        f_hi ^= e.y;
-      }
-    }
-  }
-  if (rem) {
-    const uint32_t word = word_at(b0 + 4u * nbytes);
-    for (uint32_t i = 0; i < rem; ++i) {
-      const uint4 e = t1[(word >> (2u * i)) & 3u];
-      srol_pair(f_lo, f_hi);
-      f_lo ^= e.x;
-      f_hi ^= e.y;
-    }
-  }
-  // reverse strand: full bytes backward from the last base (they start at base `rem`), then bases rem-1 .. 0
-  for (uint32_t w = (nbytes + 3u) >> 2; w-- > 0;) {
-    const uint32_t word = word_at(b0 + rem + 16u * w);
-    const uint32_t nb = nbytes - 4u * w < 4u ? nbytes - 4u * w : 4u;
-#pragma unroll
-    for (int q = 3; q >= 0; --q) {
-      if ((uint32_t)q < nb) {
-        const uint4 e = t4[(word >> (8u * q)) & 0xFFu];
-        srol_pair_n<4>(r_lo, r_hi);
-        r_lo ^= e.z;
-        r_hi ^= e.w;
-      }
-    }
-  }
-  if (rem) {
-    const uint32_t word = word_at(b0);
-    for (uint32_t i = rem; i-- > 0;) {
-      const uint4 e = t1[(word >> (2u * i)) & 3u];
-      srol_pair(r_lo, r_hi);
-      r_lo ^= e.z;
-      r_hi ^= e.w;
-    }
-  }
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+  return v;
 }
 
 // ---- geometry shared by the three kernels (wave-uniform integers only) ---------------
@@ -362,12 +315,13 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
   uint4* itab = (uint4*)lds_dyn;
   uint4* ptab = itab + ntab * 256u;
   uint64_t* mults = (uint64_t*)(ptab + 16);
-  const uint32_t per_wave = a.tile_u64 * 2u + a.ptile_dwords + a.bits_dwords + a.vbits_dwords;
+  const uint32_t per_wave = a.tile_u64 * 2u + a.ptile_dwords + a.bits_dwords + a.vbits_dwords + a.uw_dwords;
   uint32_t* wave_base = (uint32_t*)(mults + KF_MAX_RUNTIME_M) + wave * per_wave;
   uint64_t* tile = (uint64_t*)wave_base + (NA ? KRG_SLACK_U64 : 0u);
   uint32_t* ptile = wave_base + a.tile_u64 * 2u + KRG_SLACK_U64;
   uint32_t* bits = wave_base + a.tile_u64 * 2u + a.ptile_dwords;
   uint16_t* vbits = (uint16_t*)(bits + a.bits_dwords);
+  uint4* uw = (uint4*)(bits + a.bits_dwords + a.vbits_dwords); // scan form: {U, V} at the slab's word boundaries
 
   for (uint32_t i = tid; i < ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
   if (tid < 16)
@@ -591,7 +545,36 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
     uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
     if constexpr (NW == 0) {
-      horner_first_window(bits, itab, b0, k, f_lo, f_hi, r_lo, r_hi);
+      if (a.fw_scan) {
+        // Prefix over the whole slab, k-independent (first_window.hpp): lane l takes Wl consecutive words of the 2-bit
+        // stream, leaves the running XOR of their absolute-frame terms at each word's boundary, the lane totals are
+        // XOR-scanned over the wave and folded back in; then a window is a difference of two prefixes.
+        const uint32_t n_words = cur.n_vec + 1u; // boundaries 0 .. n_vec (the word past the slab is zeroed slack)
+        const uint32_t Wl = (n_words + 63u) >> 6;
+        uint4 run = make_uint4(0, 0, 0, 0);
+        for (uint32_t w = 0; w < Wl; ++w) {
+          const uint32_t wi = lane * Wl + w;
+          if (wi < n_words) {
+            uw[wi] = run;
+            const uint4 e = fw_scan_word(itab, bits[wi], wi);
+            run.x ^= e.x; run.y ^= e.y; run.z ^= e.z; run.w ^= e.w;
+          }
+        }
+        const uint4 excl = make_uint4(wave_incl_xor32(run.x) ^ run.x, wave_incl_xor32(run.y) ^ run.y,
+                                      wave_incl_xor32(run.z) ^ run.z, wave_incl_xor32(run.w) ^ run.w);
+        for (uint32_t w = 0; w < Wl; ++w) {
+          const uint32_t wi = lane * Wl + w;
+          if (wi < n_words) {
+            uint4 u = uw[wi];
+            u.x ^= excl.x; u.y ^= excl.y; u.z ^= excl.z; u.w ^= excl.w;
+            uw[wi] = u;
+          }
+        }
+        lds_sync();
+        scan_first_window(bits, itab, uw, b0, k, k % 1023u, k % 31u, k % 33u, f_lo, f_hi, r_lo, r_hi);
+      } else {
+        any_k_first_window(bits, itab, b0, k, f_lo, f_hi, r_lo, r_hi);
+      }
     } else {
       uint32_t w[NW];
       uint32_t lo = bits[d0];
@@ -859,7 +842,9 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
       n_counted = it_hi > it_lo ? it_hi - it_lo : 0u;
     } else {
       // multi-hash expansion (extend_hashes, src/internal.hpp:104-118) fused into the
-      // copy-out: stream value v is h[v % m] of k-mer v / m
+      // copy-out: stream value v is h[v % m] of k-mer v / m.  (Round 3, negative: one K-MER per lane -- m - 1 multiplies,
+      // no division, the values through a wave-private staging area back into stream order -- lost 15 % on 100 bp /
+      // k = 64 / m = 3 and 7 % at m = 2: three dependent LDS round trips per 64 k-mers against independent iterations here.)
       const uint64_t v0 = out0 * m;
       const uint32_t vpar = (uint32_t)(v0 & 1u);
       const uint32_t n_vals = n_emit * m;

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NW >= 3 ? KX_WIDE_THREADS : 1024) void kmer_extend_
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
       if (i < n) {
         const uint32_t b0 = shift + lane0 * k;
-        horner_first_window(wbits, itab, b0, k, f0, f1, r0, r1);
+        any_k_first_window(wbits, itab, b0, k, f0, f1, r0, r1);
         c_first = (wbits[b0 >> 4] >> ((b0 & 15u) * 2u)) & 3u;
         const uint32_t bl = b0 + k - 1u;
         c_last = (wbits[bl >> 4] >> ((bl & 15u) * 2u)) & 3u;

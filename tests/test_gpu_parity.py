@@ -1515,6 +1515,64 @@ def test_kmer_any_k_any_m_vs_oracle(ctx, oracle, n, L, k, m):
         assert (got[key] == want[key]).all(), ("ragged", key)
 
 
+@pytest.mark.parametrize("fw,table_k_max", [("1", None), ("2", None), ("1", "16"), ("2", "16")])
+def test_kmer_first_window_forms_vs_oracle(oracle, fw, table_k_max):
+    """first_window.hpp: the grouped (16 bases per step) and the prefix-scan (k-independent) first window of a run, each
+    forced with NTHIP_TUNE_FW on every shape -- k across 31 / 33 / 64 / 65 / 1023 (the period of the split rotate) and
+    beyond, short and long reads, read lengths that put a slab's end on and off a word boundary -- through the dense
+    pass, the N-aware pass (positions, counts), MinHash, Bloom insert and the batched extension query; with
+    NTHIP_TUNE_TABLE_K_MAX=16 the k <= 64 shapes take the k-independent forms too"""
+    import os
+    import nthash_amd
+    os.environ["NTHIP_TUNE_FW"] = fw
+    if table_k_max:
+        os.environ["NTHIP_TUNE_TABLE_K_MAX"] = table_k_max
+    try:
+        c = nthash_amd.Context(0)
+        shapes = [(400, 150, 65, 1), (300, 150, 100, 2), (200, 250, 200, 1), (60, 1000, 500, 1), (40, 1500, 1023, 1),
+                  (20, 3000, 1024, 3), (12, 6000, 2047, 1), (3, 70000, 300, 1), (300, 160, 65, 1), (257, 177, 129, 1)]
+        if table_k_max:
+            shapes = [(600, 150, 31, 1), (500, 150, 33, 2), (500, 100, 64, 3), (400, 151, 17, 1), (300, 250, 48, 1)]
+        for n, L, k, m in shapes:
+            rng = np.random.default_rng(7 * n + k)
+            clean = oracle.synth_reads(9, n, L, 5 * k + m)
+            offs = np.arange(n + 1, dtype=np.uint64) * L
+            want = oracle.kmer_batch(clean, offs, k, m, want_pos=False)
+            c.set_profiling(True)
+            got = c.kmer_hash(clean, k, m, fixed_len=L, n_reads=n)
+            name = c.last_kernel_ms()[1]
+            c.set_profiling(False)
+            assert name.startswith("kmer_runs_gen_kernel"), (name, n, L, k, m)
+            assert got["total"] == want["total"] == n * (L - k + 1)
+            assert (got["hashes"] == want["hashes"]).all(), ("dense", n, L, k, m)
+            dirty = clean.copy()
+            bad = rng.choice(n * L, max(3, n * L // 4000), replace=False)
+            dirty[bad] = np.frombuffer(b"NnRY*", dtype=np.uint8)[rng.integers(0, 5, bad.size)]
+            want = oracle.kmer_batch(dirty, offs, k, m)
+            got = c.kmer_hash(dirty, k, m, fixed_len=L, n_reads=n, want_pos=True)
+            assert got["total"] == want["total"]
+            for key in ("counts", "pos", "hashes"):
+                assert (got[key] == want[key]).all(), (key, n, L, k, m)
+            sig, _consumed = c.minhash(dirty, k, m, L, n)
+            o = want["counts"].cumsum() - want["counts"]
+            for r in (0, n // 2, n - 1):
+                h = want["hashes"].reshape(-1, m)[int(o[r]):int(o[r] + want["counts"][r])]
+                exp = h.min(axis=0) if len(h) else np.full(m, 2**64 - 1, np.uint64)
+                assert (sig.reshape(n, m)[r] == exp).all(), ("minhash", n, L, k, m, r)
+        # the batched extension query (BlindNtHash::peek / peek_back) hashes each k-mer with the grouped form
+        for k, m in ((31, 1), (64, 2)) if table_k_max else ((65, 1), (129, 2), (1023, 1)):
+            n = 300
+            kmers = oracle.synth_reads(3, n, k, k)
+            got = c.kmer_extend(kmers, k, m)
+            offs = np.arange(n + 1, dtype=np.uint64) * k
+            assert (got["self"].reshape(-1) == oracle.kmer_batch(kmers, offs, k, m, want_pos=False)["hashes"].reshape(-1)).all()
+        c.close()
+    finally:
+        os.environ.pop("NTHIP_TUNE_FW", None)
+        os.environ.pop("NTHIP_TUNE_TABLE_K_MAX", None)
+        nthash_amd.Context(0).close()  # (the table limit is process-wide: a fresh context restores the default)
+
+
 def test_bloom_long_k_many_hashes(ctx, oracle):
     n, L, k, m, n_bits = 300, 400, 101, 11, 3_000_017
     data = oracle.synth_reads(1, n, L, 8).copy()

@@ -15,7 +15,12 @@ import nthash_amd  # noqa: E402
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000_000
 SEEDS = ["1010101010101010101010101010101", "1101101101101101011011011011011"]
-L, k, m, seeds = {"c2": (150, 31, 1, None), "c3": (150, 31, 4, None), "c4": (250, 31, 3, SEEDS),
+if cfg.startswith("shape:"):  # shape:L,k,m -- any fixed-length NtHash shape
+    _L, _k, _m = (int(x) for x in cfg[6:].split(","))
+    SHAPE = {cfg: (_L, _k, _m, None)}
+else:
+    SHAPE = {}
+L, k, m, seeds = SHAPE[cfg] if cfg in SHAPE else {"c2": (150, 31, 1, None), "c3": (150, 31, 4, None), "c4": (250, 31, 3, SEEDS),
                   "mh": (150, 31, 1, None), "gen": (150, 31, 1, None),      # mh: fused MinHash; gen: general kernel
                   "rag": (150, 31, 1, None),                                # rag: variable-length reads (100..150 bp)
                   "na": (150, 31, 1, None)}[cfg]                            # na: fixed-length batch with N's (N-aware pass)
