@@ -48,6 +48,10 @@ CONFIGS = {
                seeds=None, reads=100_000_000),
     "c4": dict(desc="SeedNtHash 2 spaced seeds k=31, m=3, 50M x 250bp", L=250, k=31, m=3,
                seeds=[SEED_A, SEED_B], reads=50_000_000),
+    # the same reads as c2, packed once (2 bits per base + a validity stream: nthip_pack_reads) and hashed from the packed
+    # buffer: SURVEY 8(d)'s 8.3125 B per k-mer.  The pack pass is timed apart (pack_ms): it is paid once per batch, not per k
+    "c2_packed": dict(desc="NtHash k=31 canonical, 1 hash/k-mer, 100M x 150bp, 2-bit packed input (nthip_pack_reads once)",
+                      L=150, k=31, m=1, seeds=None, reads=100_000_000, packed=True, checksum_as="c2"),
     # the reference's own harness shape (examples/benchmark.cpp:9-39: 100 bp reads, NtHash(seq, 3, 64)),
     # scaled from its 1 M reads to a batch that fills the GPU
     "ref": dict(desc="NtHash k=64, m=3, 100bp reads (examples/benchmark.cpp shape), 100M reads", L=100, k=64,
@@ -64,7 +68,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))  # (c2_packed: see CONFIGS)
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the config's size)")
     ap.add_argument("--chunk-reads", type=int, default=0,
                     help="reads per launch (outputs of c3/c4 exceed HBM: a ring buffer is reused)")
@@ -260,6 +264,7 @@ class Workload:
         self.nwin = L - k + 1
         self.per = m if cfg["seeds"] is None else len(cfg["seeds"]) * m
         self.var = None
+        self.d_packed, self.pack = 0, None
         self.placement, self._owned = [], []
         if cfg.get("lmin"):  # variable-length reads: spans [r*L, r*L + len_r) of the fixed-length buffer
             self._init_var(torch, ctx, dev, n_reads, first_read)
@@ -281,6 +286,17 @@ class Workload:
         ctx.synth_reads_ptr(self.d_in.data_ptr(), first_read, n_reads, L, 42)
         self.seeds = nthash_amd.Seeds(ctx, cfg["seeds"], k) if cfg["seeds"] else None
         torch.cuda.synchronize(dev)
+        if cfg.get("packed"):
+            tot, _off = ctx.packed_size(n_reads * L)
+            self.d_packed = self._alloc("packed reads", tot)
+            ctx.set_profiling(True)
+            t0 = time.perf_counter()
+            bad = ctx.pack_reads_ptr(self.d_in.data_ptr(), 0, n_reads, L, 0, self.d_packed)
+            wall = (time.perf_counter() - t0) * 1e3
+            ms, _name = ctx.last_kernel_ms()
+            self.pack = {"pack_kernel_ms": ms, "pack_call_ms": wall, "invalid_bytes": bad, "packed_GiB": round(tot / 2**30, 2),
+                         "pack_GBps_in": n_reads * L / (ms * 1e-3) / 1e9}
+            assert bad == 0
         self.kernel_ms = []
 
     def _init_var(self, torch, ctx, dev, n_reads, first_read):
@@ -312,6 +328,11 @@ class Workload:
                                                 self.d_out.data_ptr(), self.total_kmers)
         r0 = c * self.chunk
         nr = min(self.chunk, self.n_reads - r0)
+        if self.d_packed:
+            import nthash_amd.capi as capi
+            assert self.n_chunks == 1
+            return self.ctx.kmer_hash_ptr(self.d_packed, 0, nr, self.L, 0, self.k, self.m, self.d_out.data_ptr(),
+                                          self.chunk * self.nwin, flags=capi.NTHIP_PACKED_INPUT | capi.NTHIP_PACKED_CLEAN)
         if self.seeds is None:
             return self.ctx.kmer_hash_ptr(self.d_in.data_ptr() + r0 * self.L, 0, nr, self.L, 0, self.k, self.m,
                                           self.d_out.data_ptr(), self.chunk * self.nwin)
@@ -342,7 +363,7 @@ class Workload:
             x ^= cx
             tot += t
         out.update(sum=format(s, "016x"), xor=format(x, "016x"), total=tot)
-        want = reference_checksum(self.name, self.first_read, self.n_reads)
+        want = reference_checksum(self.cfg.get("checksum_as", self.name), self.first_read, self.n_reads)
         if want is not None:
             out["ok"] = bool(want["sum"] == out["sum"] and want["xor"] == out["xor"] and want["total"] == tot)
             out["reference"] = {"sum": want["sum"], "xor": want["xor"], "total": want["total"]}
@@ -379,7 +400,8 @@ class Workload:
         return out
 
     def roofline(self):
-        b_per_kmer = 8.0 * self.per + self.L / self.nwin  # 8*H + b_in*L/(L-k+1), ASCII input
+        b_in = 0.25 if self.d_packed else 1.0               # bytes per base read: ASCII, or 2-bit packed
+        b_per_kmer = 8.0 * self.per + b_in * self.L / self.nwin  # 8*H + b_in*L/(L-k+1)
         if self.var is not None:  # the bases of the reads, once, and the hashes (the hash kernel; the mark pass reads them again)
             b_per_kmer = 8.0 * self.per + self.total_bases / self.total_kmers
         ms_list = [q[0] for q in self.kernel_ms]
@@ -600,7 +622,7 @@ def main():
                 res["roofline"]["peak_measured_error"] = str(e)
         if not args.no_secondary and args.config == "c2" and not args.reads:
             sec = {}
-            for name in ("c3", "c4", "ref", "var"):
+            for name in ("c2_packed", "c3", "c4", "ref", "var"):
                 try:
                     c2 = dict(CONFIGS[name])
                     w2 = Workload(torch, ctx, dev, name, c2, c2["reads"], 0)
@@ -621,6 +643,8 @@ def main():
                                  "frac": r2["frac"], "verify_ok": v2["ok"], "spot_vs_oracle": v2["spot_vs_oracle"],
                                  "sum": v2["sum"], "xor": v2["xor"],
                                  "placement_fill_GBps": [b["fill_GBps"] for b in w2.placement]}
+                    if w2.pack:
+                        sec[name]["pack"] = w2.pack
                     if name == "var":
                         sec[name]["note"] = ("value = whole call (survey of the spans, mark pass, scan, hash pass, reads "
                                              "with an N); kernel / frac = the hash pass alone")

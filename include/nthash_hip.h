@@ -53,6 +53,11 @@ extern "C" {
                                     NTHIP_ERR_UNSUPPORTED when the call is not a plain dense one (offsets, host
                                     buffers, pos / strand outputs, capacity below n_reads * windows). */
 
+#define NTHIP_PACKED_INPUT 0x20u  /* nthip_kmer_hash: reads.seqs is the packed buffer nthip_pack_reads made (device memory,
+                                    fixed-length reads: fixed_len / stride in bases as before, offsets NULL) */
+#define NTHIP_PACKED_CLEAN 0x40u  /* with NTHIP_PACKED_INPUT: nthip_pack_reads reported no invalid byte (or none inside any
+                                    read), every window is emitted and the validity stream is not read at all */
+
 typedef struct nthip_ctx nthip_ctx;     /* one device + one stream + scratch */
 typedef struct nthip_seeds nthip_seeds; /* parsed spaced-seed set (device tables) */
 
@@ -128,6 +133,22 @@ int nthip_memset(nthip_ctx* ctx, void* d_dst, int byte_value, size_t bytes);
  */
 int nthip_kmer_hash(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint8_t m,
                     const nthip_out* out, uint64_t* total, uint32_t flags);
+
+/*
+ * Packed input.  The reference turns bases into 2-bit codes on every call (CONVERT_TAB / RC_CONVERT_TAB,
+ * src/internal.hpp:350-418, index its di- / tri- / tetramer tables, src/kmer.cpp:43-73); a pipeline that hashes the
+ * same reads at several k (ntCard, multi-k assembly) repeats that per k, and on the GPU the ASCII bytes are 13.5 % of the
+ * k = 31 kernel's HBM traffic.  nthip_pack_reads does the step once: the bytes of the batch -- [0, total bytes) of
+ * reads->seqs, whatever the read layout -- become a 2-bit code stream (0.25 bytes per base; code = (c >> 1) & 3, base i
+ * at bits 2i, 2i + 1) followed by a validity stream (1 bit per base, set = not one of ACGTUacgtu).  d_packed: device
+ * memory, 16-byte aligned, nthip_packed_size(total bytes) bytes.  *n_invalid = bytes of the batch that are not bases.
+ * nthip_kmer_hash(..., NTHIP_PACKED_INPUT [| NTHIP_PACKED_CLEAN]) then takes reads->seqs = d_packed for the same
+ * fixed-length reads (reads->offsets == NULL) and returns exactly what it returns for the ASCII batch (hashes, counts,
+ * pos; no strand outputs), for any k and m: clean batches read 0.25 B per base instead of 1, batches with non-bases take
+ * the N-aware passes with the validity stream in place of the byte test.
+ */
+int nthip_packed_size(uint64_t n_bases, size_t* total_bytes, size_t* invalid_offset /* optional */);
+int nthip_pack_reads(nthip_ctx* ctx, const nthip_reads* reads, void* d_packed, uint64_t* n_invalid, uint32_t flags);
 
 /*
  * Spaced seeds.  nthip_seeds_create does once what every SeedNtHash constructor

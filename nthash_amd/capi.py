@@ -24,6 +24,8 @@ NTHIP_ERR_UNSUPPORTED = -5
 NTHIP_HOST_INPUT = 0x1
 NTHIP_HOST_OUTPUT = 0x2
 NTHIP_ASYNC = 0x10
+NTHIP_PACKED_INPUT = 0x20
+NTHIP_PACKED_CLEAN = 0x40
 NTHIP_FORCE_GENERAL = 0x4
 NTHIP_FORCE_ROWS = 0x8
 
@@ -39,6 +41,7 @@ SYMBOLS = [
     "nthip_copy_bench", "nthip_fill_bench", "nthip_malloc_probed", "nthip_ctx_reload_tuning",
     "nthip_multi_create", "nthip_multi_destroy", "nthip_multi_device_count", "nthip_multi_kmer_hash",
     "nthip_multi_seeds_create", "nthip_multi_seeds_destroy", "nthip_multi_seed_hash",
+    "nthip_packed_size", "nthip_pack_reads",
 ]
 
 
@@ -253,6 +256,48 @@ class Context:
             err.total = total.value
             raise err
         return total.value
+
+    # -- packed input: 2 bits per base + a validity stream, made once, hashed at any number of k ----------------
+    def packed_size(self, n_bases):
+        """bytes of the packed buffer for a batch of n_bases bytes -> (total, offset of the validity stream)"""
+        tot, off = C.c_size_t(0), C.c_size_t(0)
+        _chk(self.L.nthip_packed_size(C.c_uint64(n_bases), C.byref(tot), C.byref(off)))
+        return tot.value, off.value
+
+    def pack_reads_ptr(self, seqs, offsets, n_reads, fixed_len, stride, d_packed, flags=0):
+        """device (or, with NTHIP_HOST_INPUT, host) reads -> the packed buffer at d_packed; -> bytes that are not bases"""
+        rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
+        bad = C.c_uint64(0)
+        _chk(self.L.nthip_pack_reads(self.h, C.byref(rd), C.c_void_p(d_packed), C.byref(bad), flags))
+        return bad.value
+
+    def pack_reads(self, data, fixed_len, n_reads, stride=0):
+        """host reads -> (device pointer of the packed buffer [free it with .free()], invalid bytes)"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n_bases = (n_reads - 1) * (stride or fixed_len) + fixed_len if n_reads else 0
+        tot, _ = self.packed_size(n_bases)
+        d = self.malloc(tot)
+        try:
+            bad = self.pack_reads_ptr(data.ctypes.data, 0, n_reads, fixed_len, stride, d, flags=NTHIP_HOST_INPUT)
+        except Exception:
+            self.free(d)
+            raise
+        return d, bad
+
+    def kmer_hash_packed(self, d_packed, k, m, fixed_len, n_reads, stride=0, clean=False, want_pos=False, capacity=None):
+        """nthip_kmer_hash on a packed buffer (device pointer); results to the host like kmer_hash()"""
+        nwin = max(fixed_len - k + 1, 0)
+        cap = n_reads * nwin if capacity is None else capacity
+        hashes = np.zeros(max(cap, 1) * m, np.uint64)
+        counts = np.zeros(n_reads, np.uint64)
+        pos = np.zeros(max(cap, 1), np.uint32) if want_pos else None
+        flags = NTHIP_PACKED_INPUT | NTHIP_HOST_OUTPUT | (NTHIP_PACKED_CLEAN if clean else 0)
+        total = self.kmer_hash_ptr(d_packed, 0, n_reads, fixed_len, stride, k, m, hashes.ctypes.data, cap,
+                                   counts=counts.ctypes.data, pos=pos.ctypes.data if want_pos else 0, flags=flags)
+        out = {"total": total, "hashes": hashes[: total * m].reshape(-1, m), "counts": counts}
+        if want_pos:
+            out["pos"] = pos[:total]
+        return out
 
     def seed_hash_ptr(self, seqs, offsets, n_reads, fixed_len, stride, seeds, m2, hashes, capacity,
                       counts=0, pos=0, flags=0, fwd=0, rev=0):

@@ -15,6 +15,7 @@
 //                          (seed_wave), long reads cut into pieces (seed_long_kernels.hpp), lane per read (seed_general)
 //   capi_sink_bloom.hip / capi_sink_minhash.hip   fused consumers
 //   capi_fastx.hip         FASTQ / FASTA indexing and the file streaming driver
+//   capi_packed.hip        2-bit packed input: nthip_pack_reads, nthip_kmer_hash with NTHIP_PACKED_INPUT
 //   capi_multi.hip         several devices of one node: shards of a host batch, one thread + context per device
 // Kernels live in the *_kernel(s).hpp headers; every TU instantiates only the ones it launches.
 // There is no CPU hashing path in any of them.
@@ -293,13 +294,19 @@ void fill_gen_args(KmerRunsGenArgs& ga, nthip_ctx* c, const Staged& st, const nt
 // capi_kmer_runs.hip: the k = 31 instantiations of kmer_runs_kernel (C = 15 | nwin, or 30 for m = 1)
 bool kmer_runs_any_k_compiled(uint32_t k, uint32_t m, uint32_t C);
 int launch_kmer_runs_special(nthip_ctx* c, const KmerRunsArgs& ra, const RunsPlan& plan, bool dword_tail);
+// the packed-input instantiation of the headline shape (k = 31, m = 1, run length 15, dword-tail slabs)
+int launch_kmer_runs_packed(nthip_ctx* c, const KmerRunsArgs& ra, const RunsPlan& plan);
 // whether that unit was built with the chunked path (KR_CHUNKED; an A/B build of the unit may differ from the plan's)
 bool kmer_runs_chunked_compiled();
 // capi_kmer_gen.hip: kmer_runs_gen_kernel<NW, DT, false>
-int launch_kmer_gen_dense(nthip_ctx* c, const KmerRunsGenArgs& ga, size_t lds, uint32_t nw, bool dt);
+int launch_kmer_gen_dense(nthip_ctx* c, const KmerRunsGenArgs& ga, size_t lds, uint32_t nw, bool dt, bool packed = false);
 // capi_kmer_na.hip
+// invalid != nullptr: packed input (st.seqs = the code stream, invalid = its validity stream)
 int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m, const NaPlan& plan,
-                const KmerFixedArgs& consts, uint64_t capacity, uint64_t* total);
+                const KmerFixedArgs& consts, uint64_t capacity, uint64_t* total, const uint16_t* invalid = nullptr);
+// capi_packed.hip: nthip_kmer_hash with NTHIP_PACKED_INPUT (st: the staged outputs)
+int run_kmer_packed(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t m, const nthip_out* out, const Staged& st,
+                    uint32_t flags, uint64_t* total);
 // capi_kmer_ragged.hip: reads = spans [starts[r], ends[r]) of the device buffer st.seqs (total_bytes long)
 int run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
                    uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled,
@@ -369,18 +376,19 @@ int launch_kmer_runs_gen(nthip_ctx* c, K kernel, KmerRunsGenArgs a, size_t dyn_l
   return NTHIP_OK;
 }
 
-template <bool NA, int SINK = SINK_NONE>
+template <bool NA, int SINK = SINK_NONE, bool PK = false>
 int launch_kmer_runs_gen_nw(nthip_ctx* c, const KmerRunsGenArgs& ga, size_t lds, uint32_t nw, bool dt)
 {
   const char* label = SINK == SINK_BLOOM_INSERT  ? "kmer_runs_gen_kernel(bloom insert)"
                       : SINK == SINK_MINHASH     ? "kmer_runs_gen_kernel(minhash)"
                       : SINK == SINK_MINHASH1    ? "kmer_runs_gen_kernel(minhash, m = 1)"
                       : SINK == SINK_BLOOM_QUERY ? "kmer_runs_gen_kernel(bloom query)"
-                      : NA                       ? "kmer_runs_gen_kernel(N-aware)"
+                      : NA                       ? (PK ? "kmer_runs_gen_kernel(N-aware, packed input)" : "kmer_runs_gen_kernel(N-aware)")
+                      : PK                       ? "kmer_runs_gen_kernel(packed input)"
                                                  : "kmer_runs_gen_kernel";
 #define NT_GEN(NWT) \
-  (dt ? launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, true, NA, SINK>, ga, lds, label) \
-      : launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, false, NA, SINK>, ga, lds, label))
+  (dt ? launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, true, NA, SINK, PK>, ga, lds, label) \
+      : launch_kmer_runs_gen(c, kmer_runs_gen_kernel<NWT, false, NA, SINK, PK>, ga, lds, label))
   switch (nw) {
     case 0: return NT_GEN(0); // any k
     case 1: return NT_GEN(1);

@@ -23,6 +23,17 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
   if (total_out) *total_out = 0;
   if (rd->n_reads == 0) return NTHIP_OK;
 
+  if (flags & NTHIP_PACKED_INPUT) { // reads->seqs is what nthip_pack_reads made (capi_packed.hip)
+    Staged pst;
+    NTCHK(stage_outputs(c, out, flags, rd->n_reads, m, pst));
+    const int rc = run_kmer_packed(c, rd, k, m, out, pst, flags, &total);
+    if (total_out) *total_out = total;
+    NTCHK(rc);
+    NTCHK(unstage_outputs(c, out, flags, rd->n_reads, m, total, pst));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTHIP_OK;
+  }
+
   uint64_t total_bytes = 0;
   NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
   Staged st;

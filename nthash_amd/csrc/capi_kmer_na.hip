@@ -7,10 +7,12 @@ using namespace ntamd;
 using namespace ntamd::host;
 
 int ntamd::host::run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m,
-                const NaPlan& plan, const KmerFixedArgs& consts, uint64_t capacity, uint64_t* total)
+                const NaPlan& plan, const KmerFixedArgs& consts, uint64_t capacity, uint64_t* total, const uint16_t* invalid)
 {
+  const bool packed = invalid != nullptr;
   KmerRunsGenArgs a;
   fill_gen_args(a, c, st, rd, k, m, plan.g, consts);
+  a.invalid = invalid;
   NTCHK(get_kmer_tab(c, k, &a.init_tab));
   a.pos = st.pos;
   a.counts = st.counts;
@@ -33,11 +35,12 @@ int ntamd::host::run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* 
     while (ca.waves > 1 && (size_t)ca.waves * ca.vbits_dwords * 4 + 64 > 150 * 1024) ca.waves /= 2; // long k
     const size_t lds = (size_t)ca.waves * ca.vbits_dwords * 4 + 64;
     int per_cu = 1;
-    NTCHK(blocks_per_cu(c, kmer_runs_count_kernel, (int)ca.waves * 64, lds, &per_cu));
+    auto count_kernel = packed ? kmer_runs_count_kernel<true> : kmer_runs_count_kernel<false>;
+    NTCHK(blocks_per_cu(c, count_kernel, (int)ca.waves * 64, lds, &per_cu));
     const uint64_t need = (ca.n_wtiles + ca.waves - 1) / ca.waves;
     uint64_t grid = (uint64_t)c->n_cu * per_cu;
     if (grid > need) grid = need;
-    hipLaunchKernelGGL(kmer_runs_count_kernel, dim3((unsigned)grid), dim3(ca.waves * 64), lds, c->stream, ca);
+    hipLaunchKernelGGL(count_kernel, dim3((unsigned)grid), dim3(ca.waves * 64), lds, c->stream, ca);
     HIPCHK(hipGetLastError());
   }
   NTCHK(device_exclusive_scan(c, a.tile_counts, d_off, nt, d_sums, d_total));
@@ -49,6 +52,11 @@ int ntamd::host::run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* 
                 (unsigned long long)capacity, (unsigned long long)*total);
   a.counts = nullptr;
   a.waves = plan.waves;
+  if (packed) {
+    NTCHK((launch_kmer_runs_gen_nw<true, SINK_NONE, true>(c, a, plan.lds, plan.g.nw, plan.g.dword_tail != 0)));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTHIP_OK; // (no strand outputs with packed input)
+  }
   NTCHK(launch_kmer_runs_gen_nw<true>(c, a, plan.lds, plan.g.nw, plan.g.dword_tail != 0));
   // strand hashes (get_forward_hash / get_reverse_hash): the same pass again with another value selected,
   // one value per k-mer at the same compact offsets

@@ -106,3 +106,13 @@ int ntamd::host::launch_kmer_runs_special(nthip_ctx* c, const KmerRunsArgs& ra, 
   return NT_RUNS(31, 0, 15, 2);
 #undef NT_RUNS
 }
+
+int ntamd::host::launch_kmer_runs_packed(nthip_ctx* c, const KmerRunsArgs& ra, const RunsPlan& plan)
+{
+#if KR_CHUNKED
+  (void)c; (void)ra; (void)plan;
+  return fail(NTHIP_ERR_UNSUPPORTED, "packed input: not in a windowed (KR_CHUNKED) build");
+#else
+  return launch_kmer_runs(c, kmer_runs_kernel<31, 1, 15, 2, true, true>, ra, plan.lds);
+#endif
+}

@@ -101,6 +101,9 @@ struct KmerRunsGenArgs {
   // the scan keeps {U, V} at every word boundary of the slab in uw_dwords dwords of LDS per wave (4 per word)
   uint32_t fw_scan;
   uint32_t uw_dwords, pad3;
+  // packed input (PK instantiations; NTHIP_PACKED_INPUT): seqs is the 2-bit code stream of nthip_pack_reads, positions
+  // are bases of it; invalid = its companion stream, one bit per base (1 = not a base), read by the N-aware passes only
+  const uint16_t* invalid;
 };
 
 // h mod d for an invariant d (magic = floor((2^64 - 1) / d): the quotient estimate is at most 2 short)
@@ -284,13 +287,17 @@ __device__ __forceinline__ void tile_range(uint32_t tile_map, uint32_t waves, ui
   wt_end = t0 + per < n_wtiles ? t0 + per : n_wtiles;
 }
 
-// NW: window words, k <= 16*NW (0: any k, Horner first window); DT: every slab is <= 1280 bytes (tail = one
+// NW: window words, k <= 16*NW (0: any k, the k-independent first window); DT: every slab is <= 1280 bytes (tail = one
 // dword per lane);
 // NA: N-aware hash pass (compact output at a.tile_off) instead of the dense optimistic pass;
-// SINK (needs NA): consume the tile's hashes instead of writing them out
-template <int NW, bool DT, bool NA, int SINK = SINK_NONE>
+// SINK (needs NA): consume the tile's hashes instead of writing them out;
+// PK: packed input -- a.seqs is the 2-bit code stream (16 bases per dword, the format of the LDS bit stream: a slab is
+//     staged with one dword load per 16 bases), a.invalid the validity stream the N-aware pass reads instead of judging bytes
+template <int NW, bool DT, bool NA, int SINK = SINK_NONE, bool PK = false>
 __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const KmerRunsGenArgs a)
 {
+  static_assert(!PK || SINK == SINK_NONE, "packed input: the hash-stream passes");
+  const uint64_t seqs_addr = PK ? 0ull : (uint64_t)a.seqs; // (packed: positions are bases of a 16-byte aligned stream)
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
 #ifdef KRG_FORCE_C // experiment: what a compile-time run length is worth
   const uint32_t k = a.k, m = a.m, C = KRG_FORCE_C, ntab = a.ntab, rpr = a.rpr;
@@ -398,13 +405,29 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     }
   };
   auto stage = [&](const TileGeo& sl, uint32_t first) {
-    for (uint32_t i = first + lane; i < sl.n_vec; i += 64u)
-      pack_vec(sl, i, *(const uint4*)(a.seqs + sl.byte0 + ((uint64_t)i << 4)));
+    if constexpr (PK) {
+      const uint32_t* codes = (const uint32_t*)a.seqs + (sl.byte0 >> 4); // dword i = bases [byte0 + 16 i, ...)
+      for (uint32_t i = first + lane; i < sl.n_vec; i += 64u) bits[i] = codes[i];
+    } else {
+      for (uint32_t i = first + lane; i < sl.n_vec; i += 64u)
+        pack_vec(sl, i, *(const uint4*)(a.seqs + sl.byte0 + ((uint64_t)i << 4)));
+    }
     if (lane < (uint32_t)NW + 5u) bits[sl.n_vec + lane] = 0; // funnels read a little ahead
+  };
+  // packed N-aware pass: the validity bits of the slab come from the companion stream (16 per vector, as vbits holds
+  // them); `bad` says whether the tile holds a non-base at all
+  auto packed_validity = [&](const TileGeo& sl) {
+    const uint16_t* inv = a.invalid + (sl.byte0 >> 4);
+    for (uint32_t i = lane; i < sl.n_vec; i += 64u) {
+      const uint16_t w = inv[i];
+      vbits[i] = w;
+      bad |= w;
+    }
   };
   // N-aware pass, slab with a non-base (rare): one validity bit per base of the slab, 16 per vector, from
   // the bytes themselves (L2-hot: they were staged a moment ago)
   auto validity_bits = [&](const TileGeo& sl) {
+    if constexpr (PK) return; // (packed_validity has already written them)
     for (uint32_t i = lane; i < sl.n_vec; i += 64u) {
       const uint4 v = *(const uint4*)(a.seqs + sl.byte0 + ((uint64_t)i << 4));
       uint32_t i0, i1, i2, i3;
@@ -434,9 +457,10 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
   bool test_first = true;              // Bloom insert: look at the bit before the atomic (see below)
   uint32_t probe_wait = 0;
   if (wt < wt_end) {
-    cur = tile_geo(shape, (uint64_t)a.seqs, a.n_runs, a.total_bytes, wt * 64u, r_first, rem0);
+    cur = tile_geo(shape, seqs_addr, a.n_runs, a.total_bytes, wt * 64u, r_first, rem0);
     if constexpr (NA && SINK == SINK_NONE) cur_off = a.tile_off[wt];
     stage(cur, 0u);
+    if constexpr (NA && PK) packed_validity(cur);
     if constexpr (NA) {
       cur_dirty = __ballot(bad != 0u) != 0ull;
       if (cur_dirty) validity_bits(cur);
@@ -456,7 +480,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     TileGeo nxt = cur;
     uint64_t nxt_off = cur_off;
     if (have_next) {
-      nxt = tile_geo(shape, (uint64_t)a.seqs, a.n_runs, a.total_bytes, nwt * 64u, r_first, rem0);
+      nxt = tile_geo(shape, seqs_addr, a.n_runs, a.total_bytes, nwt * 64u, r_first, rem0);
       if constexpr (NA && SINK == SINK_NONE) nxt_off = a.tile_off[nwt];
     }
     v4u pv0, pv1;
@@ -465,7 +489,17 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     {
       const uint32_t i0 = lane < nxt.n_vec ? lane : 0u;
       const uint8_t* p0 = a.seqs + nxt.byte0 + ((uint64_t)i0 << 4);
-      if constexpr (DT) {
+      if constexpr (PK) {
+        // dwords lane and 64 + lane of the slab's code stream (the rest of a longer slab: stage(cur, 128) below)
+        const uint32_t* codes = (const uint32_t*)a.seqs + (nxt.byte0 >> 4);
+        const uint32_t* q0 = codes + i0;
+        const uint32_t* q1 = codes + (64u + lane < nxt.n_vec ? 64u + lane : 0u);
+        asm volatile("global_load_dword %0, %2, off nt\n\tglobal_load_dword %1, %3, off nt"
+                     : "=&v"(pw), "=&v"(dirty_seen)
+                     : "v"(q0), "v"(q1)
+                     : "memory");
+        (void)p0;
+      } else if constexpr (DT) {
         const uint32_t n_dw = (nxt.shift + nxt.slab_bytes + 3u) >> 2;
         const uint32_t j = 256u + lane < n_dw ? 256u + lane : 0u;
         const uint8_t* p1 = a.seqs + nxt.byte0 + ((uint64_t)j << 2);
@@ -886,8 +920,24 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     // three loads issued before those stores have landed (never count a store that
     // might not have been issued: an iteration with all 64 lanes active always is)
     wait_vmcnt_upto15(n_counted < 15u ? n_counted : 15u);
-    if constexpr (DT) asm volatile("; NTLINT_CONSUME %0 %1 %2" : "+v"(pv0), "+v"(pw), "+v"(dirty_seen)::"memory");
+    if constexpr (PK) asm volatile("; NTLINT_CONSUME %0 %1" : "+v"(pw), "+v"(dirty_seen)::"memory");
+    else if constexpr (DT) asm volatile("; NTLINT_CONSUME %0 %1 %2" : "+v"(pv0), "+v"(pw), "+v"(dirty_seen)::"memory");
     else asm volatile("; NTLINT_CONSUME %0 %1 %2" : "+v"(pv0), "+v"(pv1), "+v"(dirty_seen)::"memory");
+    if constexpr (PK) { // (dirty_seen holds the slab's second dword here: a packed batch is not judged while it is staged)
+      if (have_next) {
+        cur = nxt;
+        cur_off = nxt_off;
+        if (lane < cur.n_vec) bits[lane] = pw;
+        if (64u + lane < cur.n_vec) bits[64u + lane] = dirty_seen;
+        stage(cur, 128u);
+        if constexpr (NA) {
+          bad = 0;
+          packed_validity(cur);
+          cur_dirty = __ballot(bad != 0u) != 0ull;
+        }
+      }
+      continue;
+    }
     // dense pass: some wave already found a non-base byte -- the caller will redo the batch
     // on the N-aware path, so stop producing a dense stream nobody will read
     if (!NA && __builtin_amdgcn_readfirstlane(dirty_seen) != 0u) break;
@@ -935,6 +985,7 @@ static __global__ __launch_bounds__(256) void stream_bloom_insert_kernel(const u
 // hundred bytes of LDS per wave, so the CU runs at full occupancy and the pass
 // streams the reads at close to HBM read rate.  Same geometry and the same window
 // masks as the hash pass.
+template <bool PK = false> // PK: packed input -- the validity stream is read as it is, the bases not at all
 static __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_count_kernel(const KmerRunsGenArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
@@ -949,7 +1000,7 @@ static __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_count_kernel(
     const uint64_t g0 = wt * 64u;
     const uint64_t rf = g0 / rpr;
     const uint32_t rm = (uint32_t)(g0 - rf * rpr);
-    const TileGeo g = tile_geo(shape, (uint64_t)a.seqs, a.n_runs, a.total_bytes, g0, rf, rm);
+    const TileGeo g = tile_geo(shape, PK ? 0ull : (uint64_t)a.seqs, a.n_runs, a.total_bytes, g0, rf, rm);
     const bool live = lane < g.runs_here;
     uint32_t lr, w0;
     bool last_run;
@@ -958,9 +1009,13 @@ static __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_count_kernel(
     const uint32_t run_mask = live ? ((1u << C) - 1u) & ~((1u << dup) - 1u) : 0u;
     // almost every tile holds bases only: look for a non-base first (no validity bits, no LDS) ...
     uint32_t any_bad = 0;
-    for (uint32_t i = lane; i < g.n_vec; i += 64u) {
-      const uint4 v = *(const uint4*)(a.seqs + g.byte0 + ((uint64_t)i << 4));
-      any_bad |= non_base4(v.x) | non_base4(v.y) | non_base4(v.z) | non_base4(v.w);
+    if constexpr (PK) {
+      for (uint32_t i = lane; i < g.n_vec; i += 64u) any_bad |= a.invalid[(g.byte0 >> 4) + i];
+    } else {
+      for (uint32_t i = lane; i < g.n_vec; i += 64u) {
+        const uint4 v = *(const uint4*)(a.seqs + g.byte0 + ((uint64_t)i << 4));
+        any_bad |= non_base4(v.x) | non_base4(v.y) | non_base4(v.z) | non_base4(v.w);
+      }
     }
     uint32_t valid = run_mask;
     if (__ballot(any_bad != 0u) != 0ull) {
@@ -968,13 +1023,17 @@ static __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_count_kernel(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
       for (uint32_t i = lane; i < g.n_vec; i += 64u) {
-        const uint4 v = *(const uint4*)(a.seqs + g.byte0 + ((uint64_t)i << 4));
-        uint32_t i0, i1, i2, i3;
-        (void)pack4v(v.x, i0);
-        (void)pack4v(v.y, i1);
-        (void)pack4v(v.z, i2);
-        (void)pack4v(v.w, i3);
-        vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+        if constexpr (PK) {
+          vbits[i] = a.invalid[(g.byte0 >> 4) + i];
+        } else {
+          const uint4 v = *(const uint4*)(a.seqs + g.byte0 + ((uint64_t)i << 4));
+          uint32_t i0, i1, i2, i3;
+          (void)pack4v(v.x, i0);
+          (void)pack4v(v.y, i1);
+          (void)pack4v(v.z, i2);
+          (void)pack4v(v.w, i3);
+          vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();

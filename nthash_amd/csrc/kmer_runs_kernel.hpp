@@ -101,10 +101,14 @@ struct KmerRunsArgs {
 };
 
 // C_T: compile-time run length (0 = runtime); NW: window words, k <= 16*NW;
-// DT: every slab is <= 1280 bytes, so its tail is staged as one dword per lane
-template <int K_T, int M_T, int C_T, int NW, bool DT>
+// DT: every slab is <= 1280 bytes, so its tail is staged as one dword per lane;
+// PK: a.seqs is the 2-bit code stream nthip_pack_reads made (NTHIP_PACKED_INPUT: base i of the buffer at bits 2i, 2i + 1;
+//     16 bases per dword -- the very format of the LDS bit stream, so a slab is staged with one dword load per 16 bases
+//     and nothing is packed or judged; a.stride / a.len / offsets stay in bases).  DT shapes only (<= 128 dwords per slab).
+template <int K_T, int M_T, int C_T, int NW, bool DT, bool PK = false>
 __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kmer_runs_kernel(const KmerRunsArgs a)
 {
+  static_assert(!PK || (DT && !KR_CHUNKED), "packed input: the dword-tail shapes of the static loop");
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t k = K_T ? (uint32_t)K_T : a.k;
   const uint32_t m = M_T ? (uint32_t)M_T : a.m;
@@ -182,7 +186,8 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
     sl.runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
     const uint32_t n_slab_reads = (rm + sl.runs_here - 1u) / a.rpr + 1u;
     const uint64_t off = rf * a.stride;
-    sl.shift = (uint32_t)(((uint64_t)a.seqs + off) & (uint32_t)(KR_SLAB_ALIGN - 1));
+    // (packed: positions are bases of the code stream, which starts on a 16-byte boundary; byte0 counts bases as well)
+    sl.shift = PK ? (uint32_t)(off & 15u) : (uint32_t)(((uint64_t)a.seqs + off) & (uint32_t)(KR_SLAB_ALIGN - 1));
     sl.byte0 = off - sl.shift;
     sl.slab_bytes = (n_slab_reads - 1u) * a.stride + a.len;
     sl.n_vec = (sl.shift + sl.slab_bytes + 15u) >> 4;
@@ -232,8 +237,13 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
   };
   // stage vectors [first, n_vec) of a slab with ordinary loads
   auto stage = [&](const Slab& sl, uint32_t first) {
-    for (uint32_t i = first + lane; i < sl.n_vec; i += 64u)
-      pack_vec(sl, i, *(const uint4*)(a.seqs + sl.byte0 + ((uint64_t)i << 4)));
+    if constexpr (PK) {
+      const uint32_t* codes = (const uint32_t*)a.seqs + (sl.byte0 >> 4); // dword i = bases [byte0 + 16 i, ...)
+      for (uint32_t i = first + lane; i < sl.n_vec; i += 64u) bits[i] = codes[i];
+    } else {
+      for (uint32_t i = first + lane; i < sl.n_vec; i += 64u)
+        pack_vec(sl, i, *(const uint4*)(a.seqs + sl.byte0 + ((uint64_t)i << 4)));
+    }
     if (lane < (uint32_t)NW + 3u) bits[sl.n_vec + lane] = 0; // funnels read a little ahead
   };
   auto lds_sync = [&]() { // LDS is in-order per wave: only the compiler must not reorder
@@ -499,7 +509,17 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
         dirty_seen = 0;
         asm volatile("" : "+v"(pv0), "+v"(pv1), "+v"(pw), "+v"(dirty_seen));
 #else
-        if constexpr (DT) {
+        if constexpr (PK) {
+          // the slab's dwords lane and 64 + lane of the code stream (a DT slab has at most 80)
+          const uint32_t* codes = (const uint32_t*)a.seqs + (nxt.byte0 >> 4);
+          const uint32_t* q0 = codes + (lane < nxt.n_vec ? lane : 0u);
+          const uint32_t* q1 = codes + (64u + lane < nxt.n_vec ? 64u + lane : 0u);
+          asm volatile("global_load_dword %0, %2, off nt\n\tglobal_load_dword %1, %3, off nt"
+                       : "=&v"(pw), "=&v"(dirty_seen)
+                       : "v"(q0), "v"(q1)
+                       : "memory");
+          (void)p0;
+        } else if constexpr (DT) {
           const uint32_t n_dw = (nxt.shift + nxt.slab_bytes + 3u) >> 2; // dwords in the slab
           const uint32_t j = 256u + lane < n_dw ? 256u + lane : 0u;
           const uint8_t* p1 = a.seqs + nxt.byte0 + ((uint64_t)j << 2);
@@ -543,8 +563,18 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
       else if constexpr (NST == 15u) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if constexpr (DT) asm volatile("; NTLINT_CONSUME %0 %1 %2" : "+v"(pv0), "+v"(pw), "+v"(dirty_seen)::"memory");
+      if constexpr (PK) asm volatile("; NTLINT_CONSUME %0 %1" : "+v"(pw), "+v"(dirty_seen)::"memory");
+      else if constexpr (DT) asm volatile("; NTLINT_CONSUME %0 %1 %2" : "+v"(pv0), "+v"(pw), "+v"(dirty_seen)::"memory");
       else asm volatile("; NTLINT_CONSUME %0 %1 %2" : "+v"(pv0), "+v"(pv1), "+v"(dirty_seen)::"memory");
+      if constexpr (PK) { // (dirty_seen holds the slab's second dword here: a packed batch has no non-bases to find)
+        if (have_next) {
+          cur = nxt;
+          if (lane < cur.n_vec) bits[lane] = pw;
+          if (64u + lane < cur.n_vec) bits[64u + lane] = dirty_seen;
+          if (lane < (uint32_t)NW + 3u) bits[cur.n_vec + lane] = 0;
+        }
+        continue;
+      }
       // some wave already found a non-base byte: the caller will redo the batch on the
       // N-aware path, so stop producing a dense stream nobody will read
       if (__builtin_amdgcn_readfirstlane(dirty_seen) != 0u) break;

@@ -100,11 +100,11 @@ def test_config5_shard_full_size_checksum(ctx, rank):
         ctx.free(d_out)
 
 
-@pytest.mark.parametrize("config", ["c3", "c4", "ref", "var"])
+@pytest.mark.parametrize("config", ["c3", "c4", "ref", "var", "c2_packed"])
 def test_full_size_chunked_configs_checksum(config):
     """configs 3 / 4 (outputs of 384 / 528 GB: produced chunk by chunk into a ring), the reference's own
-    benchmark shape at full size and the variable-length batch (20 M reads of 100-150 bp as spans, reads with an N),
-    through bench.py's code path: whole stream == the reference's checksum"""
+    benchmark shape at full size, the variable-length batch (20 M reads of 100-150 bp as spans, reads with an N) and
+    config 2 from 2-bit packed input, through bench.py's code path: whole stream == the reference's checksum"""
     res = run_bench("--config", config, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-peak")
     assert res["verify"]["ok"] is True, res["verify"]
     assert res["verify"]["spot_vs_oracle"] is True

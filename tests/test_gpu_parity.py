@@ -1573,6 +1573,96 @@ def test_kmer_first_window_forms_vs_oracle(oracle, fw, table_k_max):
         nthash_amd.Context(0).close()  # (the table limit is process-wide: a fresh context restores the default)
 
 
+@pytest.mark.parametrize("n,L,stride", [(3000, 150, 0), (777, 151, 0), (500, 100, 0), (64, 31, 0), (300, 250, 220), (400, 150, 160),
+                                        (40, 3000, 0), (5, 70000, 0)])
+def test_kmer_packed_input_vs_oracle(ctx, oracle, n, L, stride):
+    """nthip_pack_reads + NTHIP_PACKED_INPUT: the batch as a 2-bit code stream and a validity stream, made once, hashed at
+    several k and m -- clean batches (NTHIP_PACKED_CLEAN: the headline instantiation for k = 31 / 150 bp, the general
+    run-split kernel elsewhere, the k-independent first window beyond k = 64) and batches with non-bases (N-aware passes
+    fed by the validity stream: counts, positions), overlapping runs and padded rows included -- against the oracle on
+    the ASCII reads"""
+    import nthash_amd
+    rng = np.random.default_rng(n * 31 + L)
+    st = stride or L
+    total_bytes = (n - 1) * st + L
+    clean = oracle.synth_reads(11, 1, total_bytes, n + L).copy()
+    if st > L:  # padded rows: the padding is never hashed, whatever it holds
+        for r in range(n):
+            clean[r * st + L:(r + 1) * st] = ord("\n")
+    offs_s = np.arange(n, dtype=np.uint64) * st
+    reads = lambda buf: concat_reads([buf[int(o):int(o) + L].tobytes() for o in offs_s])
+    d_pk, bad = ctx.pack_reads(clean, L, n, stride=stride)
+    assert bad == (n - 1) * (st - L if st > L else 0)
+    try:
+        ks = [(31, 1), (21, 2), (64, 3), (17, 1)] + ([(100, 1), (129, 2)] if L >= 150 else []) + ([(1023, 1)] if L >= 3000 else [])
+        for k, m in ks:
+            if k > L:
+                continue
+            if st < L - k + 1:  # reads overlapping by more than k - 1 bases: not a packed shape
+                with pytest.raises(nthash_amd.NtHipError) as ei:
+                    ctx.kmer_hash_packed(d_pk, k, m, L, n, stride=stride, clean=True)
+                assert ei.value.code == nthash_amd.capi.NTHIP_ERR_UNSUPPORTED
+                continue
+            d, o = reads(clean)
+            want = oracle.kmer_batch(d, o, k, m)
+            ctx.set_profiling(True)
+            got = ctx.kmer_hash_packed(d_pk, k, m, L, n, stride=stride, clean=True, want_pos=True)
+            name = ctx.last_kernel_ms()[1]
+            ctx.set_profiling(False)
+            if (L, k, m, stride) == (150, 31, 1, 0):
+                assert name == "kmer_runs_kernel", name
+            assert got["total"] == want["total"] == n * (L - k + 1)
+            for key in ("hashes", "counts", "pos"):
+                assert (got[key] == want[key]).all(), (key, k, m)
+            # without the promise the same buffer goes through the N-aware passes: same answer
+            got = ctx.kmer_hash_packed(d_pk, k, m, L, n, stride=stride, clean=False, want_pos=True)
+            assert got["total"] == want["total"]
+            for key in ("hashes", "counts", "pos"):
+                assert (got[key] == want[key]).all(), ("unpromised", key, k, m)
+    finally:
+        ctx.free(d_pk)
+    dirty = clean.copy()
+    where = rng.choice(total_bytes, max(5, total_bytes // 2500), replace=False)
+    dirty[where] = np.frombuffer(b"NnRY*\x00", dtype=np.uint8)[rng.integers(0, 6, where.size)]
+    dirty[0] = ord("N"); dirty[-1] = ord("n")
+    d_pk, bad = ctx.pack_reads(dirty, L, n, stride=stride)
+    assert bad == int((~np.isin(dirty, np.frombuffer(b"ACGTUacgtu", dtype=np.uint8))).sum())
+    try:
+        for k, m in [(31, 1), (25, 3), (64, 1)] + ([(96, 2)] if L >= 150 else []):
+            if k > L or st < L - k + 1:
+                continue
+            d, o = reads(dirty)
+            want = oracle.kmer_batch(d, o, k, m)
+            got = ctx.kmer_hash_packed(d_pk, k, m, L, n, stride=stride, clean=False, want_pos=True)
+            assert got["total"] == want["total"]
+            for key in ("hashes", "counts", "pos"):
+                assert (got[key] == want[key]).all(), ("dirty", key, k, m)
+            with pytest.raises(nthash_amd.NtHipError) as ei:  # too small an output: the need is reported
+                ctx.kmer_hash_packed(d_pk, k, m, L, n, stride=stride, capacity=want["total"] - 1)
+            assert ei.value.code == nthash_amd.capi.NTHIP_ERR_CAPACITY and ei.value.total == want["total"]
+    finally:
+        ctx.free(d_pk)
+
+
+def test_kmer_packed_input_refusals(ctx, oracle):
+    import nthash_amd
+    data = oracle.synth_reads(0, 10, 100, 1)
+    d_pk, _ = ctx.pack_reads(data, 100, 10)
+    try:
+        offs = np.arange(11, dtype=np.uint64) * 100
+        d_offs = ctx.malloc(offs.nbytes); ctx.h2d(d_offs, offs)
+        d_out = ctx.malloc(10 * 70 * 8)
+        with pytest.raises(nthash_amd.NtHipError) as ei:   # variable-length reads are not a packed shape (yet)
+            ctx.kmer_hash_ptr(d_pk, d_offs, 10, 0, 0, 31, 1, d_out, 700, flags=nthash_amd.capi.NTHIP_PACKED_INPUT)
+        assert ei.value.code == nthash_amd.capi.NTHIP_ERR_UNSUPPORTED
+        with pytest.raises(nthash_amd.NtHipError) as ei:   # a misaligned buffer is refused, not misread
+            ctx.kmer_hash_ptr(d_pk + 4, 0, 10, 100, 0, 31, 1, d_out, 700, flags=nthash_amd.capi.NTHIP_PACKED_INPUT)
+        assert ei.value.code == nthash_amd.capi.NTHIP_ERR_ARG
+        ctx.free(d_offs); ctx.free(d_out)
+    finally:
+        ctx.free(d_pk)
+
+
 def test_bloom_long_k_many_hashes(ctx, oracle):
     n, L, k, m, n_bits = 300, 400, 101, 11, 3_000_017
     data = oracle.synth_reads(1, n, L, 8).copy()
