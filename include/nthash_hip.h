@@ -277,6 +277,9 @@ typedef struct nthip_fastx_batch {
   const uint64_t* starts;    /* n_reads: sequence line of read r = raw[starts[r] .. ends[r])      */
   const uint64_t* ends;
   uint64_t first_read;       /* index of the batch's first record in the file                     */
+  int32_t device;            /* the HIP device the pointers above live on (nthip_multi_fastx_*: batches of one file
+                                come from several devices, in file order)                          */
+  uint32_t reserved;
 } nthip_fastx_batch;
 typedef int (*nthip_fastx_fn)(void* user, const nthip_fastx_batch* batch); /* non-zero return stops the stream */
 typedef struct nthip_fastx_stats {
@@ -321,6 +324,19 @@ int nthip_multi_seeds_create(nthip_multi* multi, const char* const* seeds, uint3
 int nthip_multi_seeds_destroy(nthip_multi_seeds* seeds);
 int nthip_multi_seed_hash(nthip_multi* multi, const nthip_reads* reads, const nthip_multi_seeds* seeds, uint8_t m2,
                           const nthip_out* out, uint64_t* total);
+
+/*
+ * nthip_multi_fastx_kmer_hash_file: nthip_fastx_kmer_hash_file over the devices of `multi` -- the device-resident
+ * multi-GPU path (8 PCIe roots stream 8 x what one does; nthip_multi_kmer_hash above is bound by the hashes coming BACK
+ * over PCIe).  The file is cut into pieces of about chunk_bytes that begin and end on record boundaries (found on the
+ * host from the line structure), piece j goes to device j mod N; every device runs the single-device pipeline -- its own
+ * reader threads, pinned ring, copy stream and context -- on its pieces, nothing is exchanged.  `fn` still sees every
+ * batch exactly once and IN FILE ORDER (batch->first_read counts through the file), one call at a time; batch->device
+ * says where its pointers live (the callback runs on the worker thread of that device, with that device current).
+ * NTHIP_FASTQ / NTHIP_FASTA only.
+ */
+int nthip_multi_fastx_kmer_hash_file(nthip_multi* multi, const char* path, uint32_t format, uint16_t k, uint8_t m,
+                                     uint64_t chunk_bytes, nthip_fastx_fn fn, void* user, nthip_fastx_stats* stats);
 
 /* ---- measurement helpers (device-resident synthetic data, checksums) ---- */
 /* counter-based reads: read r, 32-base word w ->

@@ -41,7 +41,7 @@ SYMBOLS = [
     "nthip_copy_bench", "nthip_fill_bench", "nthip_malloc_probed", "nthip_ctx_reload_tuning",
     "nthip_multi_create", "nthip_multi_destroy", "nthip_multi_device_count", "nthip_multi_kmer_hash",
     "nthip_multi_seeds_create", "nthip_multi_seeds_destroy", "nthip_multi_seed_hash",
-    "nthip_packed_size", "nthip_pack_reads",
+    "nthip_packed_size", "nthip_pack_reads", "nthip_multi_fastx_kmer_hash_file",
 ]
 
 
@@ -63,7 +63,8 @@ class Out(C.Structure):
 
 class FastxBatch(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_kmers", C.c_uint64), ("hashes", C.c_void_p), ("counts", C.c_void_p),
-                ("raw", C.c_void_p), ("starts", C.c_void_p), ("ends", C.c_void_p), ("first_read", C.c_uint64)]
+                ("raw", C.c_void_p), ("starts", C.c_void_p), ("ends", C.c_void_p), ("first_read", C.c_uint64),
+                ("device", C.c_int32), ("reserved", C.c_uint32)]
 
 
 class FastxStats(C.Structure):
@@ -573,6 +574,28 @@ class Multi:
         n = C.c_int(0)
         _chk(self.L.nthip_multi_device_count(self.h, C.byref(n)))
         return n.value
+
+    def fastx_kmer_hash_file(self, path, fmt, k, m, chunk_bytes=0, on_batch=None):
+        """stream a FASTQ / single-line FASTA file over the devices; on_batch(FastxBatch) sees every batch once, in file
+        order (device pointers on batch.device, that device current on the calling thread).  -> FastxStats"""
+        stats = FastxStats()
+        err = []
+
+        def tramp(_user, bp):
+            try:
+                if on_batch is not None:
+                    on_batch(bp.contents)
+                return 0
+            except Exception as e:  # noqa: BLE001 -- must not unwind through the C frame
+                err.append(e)
+                return 1
+        cb = FASTX_FN(tramp)
+        rc = self.L.nthip_multi_fastx_kmer_hash_file(self.h, os.fsencode(path), fmt, k, m, chunk_bytes, cb, None,
+                                                     C.byref(stats))
+        if err:
+            raise err[0]
+        _chk(rc)
+        return stats
 
     def kmer_hash(self, data, k, m, offsets=None, fixed_len=0, stride=0, n_reads=None, want_pos=False):
         data = np.ascontiguousarray(data, dtype=np.uint8)

@@ -31,6 +31,7 @@
 #include <cstring>
 #include <array>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -326,6 +327,17 @@ int run_seed_general(nthip_ctx* c, const Staged& st, const nthip_reads* rd, cons
 int run_seed_long(nthip_ctx* c, const Staged& st, const nthip_reads* rd, const nthip_seeds* sd, uint32_t m2, uint64_t capacity,
                   uint64_t* total, bool* handled, const uint64_t* d_ends = nullptr);
 constexpr uint64_t SEED_LONG_MIN = 16384; // reads from this length on are worth cutting into pieces
+
+// ---- capi_fastx.hip (fastx_stream.hpp): the streaming pipeline of ONE context over caller-chosen pieces of a file ----
+struct FastxRange {
+  uint64_t off, len; // bytes [off, off + len): begins at a record start, ends where a record ends
+};
+// called with the index of the piece in the list and its batch (device pointers of the context; also for an empty piece)
+typedef std::function<int(uint64_t, nthip_fastx_batch&)> FastxDeliver;
+int fastx_stream_ranges(nthip_ctx* c, const char* path, uint32_t format, uint16_t k, uint8_t m, const nthip_seeds* seeds,
+                        uint64_t chunk_bytes, const std::vector<FastxRange>& ranges, const FastxDeliver& deliver,
+                        nthip_fastx_stats* stats);
+int64_t fastx_find_record_start(int fd, uint64_t file_size, uint64_t pos, uint32_t format);
 
 // ---- templates every launching TU uses --------------------------------------------------------------------------
 // Dynamic LDS beyond the default needs hipFuncAttributeMaxDynamicSharedMemorySize, and that attribute is ONE value per

@@ -226,3 +226,113 @@ extern "C" int nthip_multi_seed_hash(nthip_multi* m, const nthip_reads* rd, cons
                                               NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT);
                      });
 }
+
+// ---- the file driver over several devices (device-resident: the hashes stay on the device that made them) --------
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <condition_variable>
+#include <mutex>
+
+extern "C" int nthip_multi_fastx_kmer_hash_file(nthip_multi* mm, const char* path, uint32_t format, uint16_t k, uint8_t m,
+                                                uint64_t chunk_bytes, nthip_fastx_fn fn, void* user,
+                                                nthip_fastx_stats* stats)
+{
+  if (!mm || !path) return fail(NTHIP_ERR_ARG, "multi / path is NULL");
+  if (format != NTHIP_FASTQ && format != NTHIP_FASTA) return fail(NTHIP_ERR_ARG, "format must be NTHIP_FASTQ or NTHIP_FASTA");
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
+  if (k < 3 || m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 / m == 0 are undefined in the reference");
+  const auto t_begin = std::chrono::steady_clock::now();
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (chunk_bytes == 0) chunk_bytes = 256ull << 20;
+  if (chunk_bytes < (1ull << 16)) chunk_bytes = 1ull << 16;
+  const size_t G = mm->ctx.size();
+  // ---- pieces: about chunk_bytes each, cut where a record starts (host: a window of the file per boundary) ----
+  std::vector<FastxRange> pieces;
+  uint64_t file_size = 0;
+  {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(NTHIP_ERR_ARG, "cannot open %s", path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); return fail(NTHIP_ERR_ARG, "cannot stat %s", path); }
+    file_size = (uint64_t)sb.st_size;
+    uint64_t begin = 0;
+    while (begin < file_size) {
+      int64_t end = (int64_t)file_size;
+      if (begin + chunk_bytes < file_size) {
+        end = fastx_find_record_start(fd, file_size, begin + chunk_bytes, format);
+        if (end < 0) { close(fd); return fail(NTHIP_ERR_ARG, "read error on %s", path); }
+      }
+      if ((uint64_t)end <= begin) end = (int64_t)file_size; // (cannot happen for pos > begin; never loop)
+      pieces.push_back({begin, (uint64_t)end - begin});
+      begin = (uint64_t)end;
+    }
+    close(fd);
+  }
+  if (stats) stats->file_bytes = file_size;
+  if (pieces.empty()) return NTHIP_OK;
+  // ---- one worker per device: its pieces through its own pipeline; the callback in file order ----
+  struct Order {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t next = 0, first_read = 0;
+    bool stop = false;
+  } order;
+  std::vector<std::vector<FastxRange>> mine(G);
+  std::vector<std::vector<uint64_t>> index(G);
+  for (size_t j = 0; j < pieces.size(); ++j) {
+    mine[j % G].push_back(pieces[j]);
+    index[j % G].push_back(j);
+  }
+  std::vector<int> rcs(G, NTHIP_OK);
+  std::vector<std::string> errs(G);
+  std::vector<nthip_fastx_stats> st(G);
+  std::vector<std::thread> workers;
+  for (size_t g = 0; g < G; ++g) {
+    workers.emplace_back([&, g]() {
+      if (mine[g].empty()) return;
+      FastxDeliver deliver = [&, g](uint64_t local, nthip_fastx_batch& b) -> int {
+        const uint64_t ticket = index[g][local];
+        std::unique_lock<std::mutex> lk(order.mu);
+        order.cv.wait(lk, [&] { return order.stop || order.next == ticket; });
+        if (order.stop) return fail(NTHIP_ERR_ARG, "stopped: another device failed or the callback asked to stop");
+        b.first_read = order.first_read;
+        int rc = NTHIP_OK;
+        if (fn && b.n_reads && fn(user, &b) != 0) rc = fail(NTHIP_ERR_ARG, "stopped by the callback");
+        order.first_read += b.n_reads;
+        order.next = ticket + 1;
+        if (rc != NTHIP_OK) order.stop = true;
+        lk.unlock();
+        order.cv.notify_all();
+        return rc;
+      };
+      rcs[g] = fastx_stream_ranges(mm->ctx[g], path, format, k, m, nullptr, chunk_bytes, mine[g], deliver, &st[g]);
+      if (rcs[g] != NTHIP_OK) {
+        errs[g] = nthip_last_error(); // (thread-local: carry it to the caller's thread)
+        {
+          std::lock_guard<std::mutex> lk(order.mu);
+          order.stop = true;
+        }
+        order.cv.notify_all();
+      }
+    });
+  }
+  for (auto& w : workers) w.join();
+  for (size_t g = 0; g < G; ++g)
+    if (rcs[g] != NTHIP_OK && errs[g].find("stopped: another device") == std::string::npos)
+      return fail(rcs[g], "device %d: %s", mm->ctx[g]->device, errs[g].c_str());
+  for (size_t g = 0; g < G; ++g)
+    if (rcs[g] != NTHIP_OK) return fail(rcs[g], "device %d: %s", mm->ctx[g]->device, errs[g].c_str());
+  if (stats) {
+    for (size_t g = 0; g < G; ++g) {
+      stats->reads += st[g].reads;
+      stats->kmers += st[g].kmers;
+      stats->batches += st[g].batches;
+      stats->read_seconds += st[g].read_seconds;
+      stats->gpu_seconds += st[g].gpu_seconds;
+    }
+    stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return NTHIP_OK;
+}

@@ -192,9 +192,11 @@ namespace {
 constexpr uint64_t FXS_HEAD = 16ull << 20; // room in front of a chunk for the carried-over tail of the previous one
 
 struct FxReader {
-  // the reader thread fills pinned[j & 1] with file bytes [j*S, (j+1)*S) for j = 0, 1, ...
+  // the reader thread fills pinned[j & 1] with file bytes [j*S, (j+1)*S) for j = 0, 1, ... (or with the j-th of
+  // `ranges`: record-aligned pieces chosen by the caller -- the multi-device driver)
   int fd = -1;
   uint64_t file_size = 0, chunk = 0, n_chunks = 0;
+  const std::vector<FastxRange>* ranges = nullptr;
   uint8_t* pinned[2] = {nullptr, nullptr};
   uint64_t filled[2] = {0, 0};
   std::mutex mu;
@@ -215,8 +217,8 @@ struct FxReader {
         cv.wait(lk, [&] { return stop || j < next_free; });
         if (stop) return;
       }
-      const uint64_t off = j * chunk;
-      const uint64_t len = off + chunk <= file_size ? chunk : file_size - off;
+      const uint64_t off = ranges ? (*ranges)[j].off : j * chunk;
+      const uint64_t len = ranges ? (*ranges)[j].len : off + chunk <= file_size ? chunk : file_size - off;
       const auto t0 = std::chrono::steady_clock::now();
       // several preads at once: one thread does not reach the page-cache copy rate PCIe can take
       std::atomic<bool> ok{true};
@@ -341,7 +343,7 @@ int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, 
     rc = nthip_kmer_hash(c, &rdx, k, m, &out, &n_kmers, 0);
     if (rc != NTHIP_OK) { cleanup(); return rc; }
     if (fn) {
-      nthip_fastx_batch b = {n_rec, n_kmers, d_hashes, d_counts, (const char*)d_seqs, d_offsets, d_offsets + 1, 0};
+      nthip_fastx_batch b = {n_rec, n_kmers, d_hashes, d_counts, (const char*)d_seqs, d_offsets, d_offsets + 1, 0, c->device, 0};
       if (fn(user, &b) != 0) { rc = fail(NTHIP_ERR_ARG, "stopped by the callback"); cleanup(); return rc; }
     }
   }
@@ -362,10 +364,74 @@ int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, 
 } // namespace
 
 namespace {
-// seeds == nullptr: NtHash(k, m); else SeedNtHash(seeds, m = hashes per seed)
+// seeds == nullptr: NtHash(k, m); else SeedNtHash(seeds, m = hashes per seed).
+// ranges / deliver (the multi-device driver): hash exactly these record-aligned pieces of the file, in this order, and
+// hand every batch -- also an empty one -- to deliver(j, batch) instead of fn
 int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t k, uint8_t m, const nthip_seeds* seeds,
-                      uint64_t chunk_bytes, nthip_fastx_fn fn, void* user, nthip_fastx_stats* stats);
+                      uint64_t chunk_bytes, nthip_fastx_fn fn, void* user, nthip_fastx_stats* stats,
+                      const std::vector<FastxRange>* ranges = nullptr, const FastxDeliver* deliver = nullptr);
 } // namespace
+
+int ntamd::host::fastx_stream_ranges(nthip_ctx* c, const char* path, uint32_t format, uint16_t k, uint8_t m,
+                                     const nthip_seeds* seeds, uint64_t chunk_bytes, const std::vector<FastxRange>& ranges,
+                                     const FastxDeliver& deliver, nthip_fastx_stats* stats)
+{
+  return fastx_stream_file(c, path, format, k, m, seeds, chunk_bytes, nullptr, nullptr, stats, &ranges, &deliver);
+}
+
+// First record start at or after byte `pos` of a FASTQ / single-line FASTA file (pos > 0), found on the host from the
+// line structure alone: FASTA -- a line that begins with '>'; FASTQ -- a line that begins with '@' whose third line
+// begins with '+' and whose second and fourth lines are equally long ('@' and '+' are legal quality characters, so the
+// first character alone does not say).  file_size when no record starts after pos.  < 0: read error.
+int64_t ntamd::host::fastx_find_record_start(int fd, uint64_t file_size, uint64_t pos, uint32_t format)
+{
+  if (pos == 0) return 0;
+  if (pos >= file_size) return (int64_t)file_size;
+  std::vector<uint8_t> buf;
+  for (uint64_t window = 1ull << 20; ; window *= 4) {
+    const uint64_t from = pos - 1;
+    const uint64_t want = from + window <= file_size ? window : file_size - from;
+    buf.resize(want);
+    uint64_t done = 0;
+    while (done < want) {
+      const ssize_t r = pread(fd, buf.data() + done, want - done, (off_t)(from + done));
+      if (r <= 0) return -1;
+      done += (uint64_t)r;
+    }
+    const bool to_eof = from + want == file_size;
+    // line starts inside the window: after every '\n' at or behind `from`
+    std::vector<uint64_t> ls;
+    for (uint64_t i = 0; i < want; ++i)
+      if (buf[i] == '\n' && i + 1 < want) ls.push_back(i + 1);
+    auto line_len = [&](size_t li) -> int64_t { // without '\n' and a trailing '\r'; -1: the line's end is not in the window
+      const uint64_t b = ls[li];
+      uint64_t e;
+      if (li + 1 < ls.size()) e = ls[li + 1] - 1;
+      else if (to_eof) e = buf[want - 1] == '\n' ? want - 1 : want;
+      else return -1;
+      if (e > b && buf[e - 1] == '\r') --e;
+      return (int64_t)(e - b);
+    };
+    bool undecided = false;
+    for (size_t li = 0; li < ls.size(); ++li) {
+      const uint8_t ch = buf[ls[li]];
+      if (format == NTHIP_FASTA) {
+        if (ch == '>') return (int64_t)(from + ls[li]);
+        continue;
+      }
+      if (ch != '@') continue;
+      if (li + 3 >= ls.size() && !to_eof) { undecided = true; break; }
+      if (li + 3 >= ls.size()) continue; // fewer than four lines left in the file: not a record
+      if (buf[ls[li + 2]] != '+') continue;
+      const int64_t l1 = line_len(li + 1), l3 = line_len(li + 3);
+      if (l3 < 0) { undecided = true; break; }
+      if (l1 == l3) return (int64_t)(from + ls[li]);
+    }
+    if (to_eof && !undecided) return (int64_t)file_size;
+    if (to_eof) return (int64_t)file_size;
+    if (window >= (1ull << 30)) return (int64_t)file_size; // a "record" of a gigabyte: give up on this boundary
+  }
+}
 
 extern "C" int nthip_fastx_kmer_hash_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t k, uint8_t m,
                                           uint64_t chunk_bytes, nthip_fastx_fn fn, void* user,
@@ -389,7 +455,8 @@ extern "C" int nthip_fastx_seed_hash_file(nthip_ctx* c, const char* path, uint32
 
 namespace {
 int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t k, uint8_t m, const nthip_seeds* seeds,
-                      uint64_t chunk_bytes, nthip_fastx_fn fn, void* user, nthip_fastx_stats* stats)
+                      uint64_t chunk_bytes, nthip_fastx_fn fn, void* user, nthip_fastx_stats* stats,
+                      const std::vector<FastxRange>* ranges, const FastxDeliver* deliver)
 {
   if (format != NTHIP_FASTQ && format != NTHIP_FASTA) return fail(NTHIP_ERR_ARG, "format must be NTHIP_FASTQ or NTHIP_FASTA");
   const uint64_t per = seeds ? (uint64_t)seeds->n_seeds * m : (uint64_t)m;
@@ -409,8 +476,16 @@ int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t 
   rd.file_size = (uint64_t)sb.st_size;
   rd.chunk = chunk_bytes;
   rd.n_chunks = (rd.file_size + chunk_bytes - 1) / chunk_bytes;
+  if (ranges) { // record-aligned pieces: whole records, so a piece may be longer than a chunk by up to one record
+    rd.ranges = ranges;
+    rd.n_chunks = ranges->size();
+    for (const FastxRange& r : *ranges) {
+      if (r.off + r.len > rd.file_size) { close(rd.fd); return fail(NTHIP_ERR_ARG, "range outside %s", path); }
+      if (r.len > chunk_bytes) chunk_bytes = (r.len + 4095) & ~4095ull;
+    }
+  }
   if (stats) stats->file_bytes = rd.file_size;
-  if (rd.file_size == 0) { close(rd.fd); return NTHIP_OK; }
+  if (rd.file_size == 0 || rd.n_chunks == 0) { close(rd.fd); return NTHIP_OK; }
 
   // worst cases inside one piece (head room + chunk + a final newline): an 8-byte record, half of the bytes bases
   const uint64_t piece_max = FXS_HEAD + chunk_bytes + 16;
@@ -487,14 +562,21 @@ int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t 
       if (seeds) NTCHK(nthip_seed_hash_spans(c, (const char*)piece, n_bytes, d_starts, d_ends, n_rec, seeds, m, &out, &n_kmers, 0));
       else NTCHK(nthip_kmer_hash_spans(c, (const char*)piece, n_bytes, d_starts, d_ends, n_rec, k, m, &out, &n_kmers, 0));
     }
-    if (fn && n_rec) {
-      nthip_fastx_batch b = {n_rec, n_kmers, d_hashes, d_counts, (const char*)piece, d_starts, d_ends, first_read};
+    if (deliver) {
+      nthip_fastx_batch b = {n_rec, n_kmers, d_hashes, d_counts, (const char*)piece, d_starts, d_ends, first_read, c->device, 0};
+      NTCHK((*deliver)(j, b));
+    } else if (fn && n_rec) {
+      nthip_fastx_batch b = {n_rec, n_kmers, d_hashes, d_counts, (const char*)piece, d_starts, d_ends, first_read, c->device, 0};
       if (fn(user, &b) != 0) return fail(NTHIP_ERR_ARG, "stopped by the callback");
     }
     if (stats) { stats->reads += n_rec; stats->kmers += n_kmers; stats->batches += 1; }
     first_read += n_rec;
     const uint64_t rest = n_bytes - consumed;
-    if (last) {
+    if (ranges) { // (every piece ends where a record ends)
+      if (rest != 0) return fail(NTHIP_ERR_ARG, "%s: a piece does not end on a record boundary near byte %llu", path,
+                                 (unsigned long long)((*ranges)[j].off + (*ranges)[j].len));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    } else if (last) {
       if (rest != 0) return fail(NTHIP_ERR_ARG, "%s: truncated record at the end of the file", path);
     } else {
       if (rest > FXS_HEAD) return fail(NTHIP_ERR_UNSUPPORTED, "%s: record longer than %llu bytes", path,
@@ -518,7 +600,8 @@ int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t 
         if (rd.failed) { rc = fail(NTHIP_ERR_ARG, "read error on %s", path); break; }
       }
       uint64_t len = rd.filled[j & 1];
-      if (j + 1 == rd.n_chunks && len && rd.pinned[j & 1][len - 1] != '\n') rd.pinned[j & 1][len++] = '\n';
+      const bool file_end = ranges ? (*ranges)[j].off + (*ranges)[j].len == rd.file_size : j + 1 == rd.n_chunks;
+      if (file_end && len && rd.pinned[j & 1][len - 1] != '\n') rd.pinned[j & 1][len++] = '\n';
       lens[j & 1] = len;
       // d_raw[j & 1] was last read by piece j-2, processed synchronously two iterations ago
       if (hipMemcpyAsync(d_raw[j & 1] + FXS_HEAD, rd.pinned[j & 1], len, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||

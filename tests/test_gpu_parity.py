@@ -1315,6 +1315,72 @@ def test_fastx_file_stream_vs_oracle(ctx, oracle, tmp_path, fmt, chunk, final_ne
     assert (np.concatenate(got_h) == want["hashes"].ravel()).all()
 
 
+@pytest.mark.parametrize("fmt,crlf,chunk,final_newline,devices", [
+    (4, False, 1 << 16, True, [0, 0, 0]), (4, True, 70_000, False, [0, 0]), (2, False, 1 << 16, True, [0, 0, 0, 0]),
+    (4, False, 1 << 22, True, [0, 0, 0]), (4, False, 1 << 16, True, None)])
+def test_multi_device_fastx_file_vs_oracle(ctx, oracle, tmp_path, fmt, crlf, chunk, final_newline, devices):
+    """nthip_multi_fastx_kmer_hash_file: the file cut into record-aligned pieces on the host (quality lines that begin
+    with '@' or '+' must not fool the cut), piece j on device j mod N -- the box's one GPU listed several times: separate
+    contexts, reader threads and pinned rings, the code an 8-GPU node runs --, every batch delivered once, in file order,
+    with first_read counting through the file; hashes and counts == the oracle on the parsed reads"""
+    import nthash_amd
+    rng = np.random.default_rng(chunk % 977 + fmt + (len(devices) if devices else 9))
+    buf, seqs = _make_fastx(rng, 7000, fmt, crlf, lo=20, hi=400)
+    if not final_newline:
+        buf = buf[:-2] if crlf else buf[:-1]
+    path = tmp_path / ("reads.fq" if fmt == 4 else "reads.fa")
+    path.write_bytes(buf)
+    k, m = 31, 2
+    data, offs = concat_reads(seqs)
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    got_h, got_c, firsts, devs = [], [], [], []
+
+    def on_batch(b):
+        h, cnt = np.zeros(b.n_kmers * m, np.uint64), np.zeros(b.n_reads, np.uint64)
+        if h.size:
+            ctx.d2h(h, b.hashes)
+        ctx.d2h(cnt, b.counts)
+        got_h.append(h); got_c.append(cnt); firsts.append(b.first_read); devs.append(b.device)
+
+    mg = nthash_amd.Multi(devices)
+    try:
+        st = mg.fastx_kmer_hash_file(path, fmt, k, m, chunk_bytes=chunk, on_batch=on_batch)
+    finally:
+        mg.close()
+    assert st.reads == len(seqs) and st.kmers == want["total"] and st.file_bytes == len(buf)
+    if chunk < len(buf) // 8:
+        assert st.batches >= 8
+    assert firsts == list(np.cumsum([0] + [c.size for c in got_c[:-1]]))
+    assert set(devs) == {0}
+    assert (np.concatenate(got_c) == want["counts"]).all()
+    assert (np.concatenate(got_h) == want["hashes"].ravel()).all()
+
+
+def test_multi_device_fastx_file_errors(ctx, tmp_path):
+    import nthash_amd
+    mg = nthash_amd.Multi([0, 0])
+    try:
+        with pytest.raises(nthash_amd.NtHipError):
+            mg.fastx_kmer_hash_file(tmp_path / "nope.fq", 4, 31, 1)
+        bad = tmp_path / "bad.fq"
+        bad.write_bytes(b"@a\nACGT\n+\nIIII\n" * 3000 + b"@b\nACGT\n-\nIIII\n" + b"@a\nACGT\n+\nIIII\n" * 3000)
+        with pytest.raises(nthash_amd.NtHipError):
+            mg.fastx_kmer_hash_file(bad, 4, 31, 1, chunk_bytes=1 << 16)
+        seen = []
+
+        def stop_after_two(b):
+            seen.append(b.first_read)
+            if len(seen) == 2:
+                raise RuntimeError("enough")
+        ok = tmp_path / "ok.fq"
+        ok.write_bytes(b"@a\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n" * 20000)
+        with pytest.raises(RuntimeError):
+            mg.fastx_kmer_hash_file(ok, 4, 31, 1, chunk_bytes=1 << 16, on_batch=stop_after_two)
+        assert len(seen) == 2
+    finally:
+        mg.close()
+
+
 def test_fastx_file_stream_reuses_and_trims_context_buffers(ctx, oracle, tmp_path):
     """the streaming buffers live in the context: same file again (reuse), bigger chunks (regrow), after
     nthip_ctx_trim (fresh) and with more hashes per k-mer (regrow of the hash buffer) -- same stream every time"""
