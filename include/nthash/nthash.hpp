@@ -93,8 +93,8 @@ public:
   size_t get_pos() const { return pos_; }
   typedefs::NUM_HASHES_TYPE get_hash_num() const { return num_hashes_; }
   typedefs::K_TYPE get_k() const { return k_; }
-  uint64_t get_forward_hash() const { return fwd_; }
-  uint64_t get_reverse_hash() const { return rev_; }
+  uint64_t get_forward_hash() const { if (strands_stale_) sync_strands(); return fwd_; }
+  uint64_t get_reverse_hash() const { if (strands_stale_) sync_strands(); return rev_; }
 
 private:
   const char* seq_;
@@ -103,8 +103,15 @@ private:
   typedefs::K_TYPE k_;
   size_t pos_;
   bool initialized_;
-  uint64_t fwd_ = 0;
-  uint64_t rev_ = 0;
+  // The strand hashes are not part of what the device sends back (hashes() is: 8 m bytes per k-mer instead of
+  // 16 + 8 m, and two device passes fewer): a window taken from the device stream leaves them stale, the first call that
+  // needs them -- these getters, roll_back(), peek*() -- hashes the current window's strands on the host (k steps), and
+  // from then on roll() keeps them current with the O(1) recurrence.
+  mutable uint64_t fwd_ = 0;
+  mutable uint64_t rev_ = 0;
+  mutable bool strands_stale_ = false;
+  mutable bool strands_wanted_ = false;
+  void sync_strands() const;
   std::unique_ptr<uint64_t[]> hash_arr_;
   const detail::RollTables* rt_ = nullptr;     // process-wide, immutable
   std::shared_ptr<detail::KmerStream> stream_; // shared by copies, immutable once built
@@ -199,8 +206,8 @@ public:
   unsigned get_hash_num() const { return num_hashes_per_seed_ * n_seeds_; }
   typedefs::NUM_HASHES_TYPE get_hash_num_per_seed() const { return num_hashes_per_seed_; }
   typedefs::K_TYPE get_k() const { return k_; }
-  uint64_t* get_forward_hash() const { return fwd_.get(); }
-  uint64_t* get_reverse_hash() const { return rev_.get(); }
+  uint64_t* get_forward_hash() const { if (strands_stale_) sync_strands(); return fwd_.get(); }
+  uint64_t* get_reverse_hash() const { if (strands_stale_) sync_strands(); return rev_.get(); }
 
 private:
   const char* seq_;
@@ -209,6 +216,10 @@ private:
   typedefs::K_TYPE k_;
   size_t pos_;
   size_t pos0_; // where the device stream starts (constructor's pos)
+  // (as in NtHash: the device stream carries hashes() only; the per-seed strand hashes of the current window are
+  //  computed on the host when a getter asks for them)
+  mutable bool strands_stale_ = false;
+  void sync_strands() const;
   bool initialized_;
   unsigned n_seeds_;
   std::shared_ptr<detail::SeedSet> seeds_;

@@ -203,7 +203,7 @@ namespace detail {
 struct KmerStream {
   size_t w_begin = 0, w_end = 0;
   std::vector<uint32_t> pos;              // relative to w_begin, ascending
-  std::vector<uint64_t> fwd, rev, hashes; // hashes: m per entry
+  std::vector<uint64_t> hashes;           // m per entry (the strand hashes stay behind: NtHash::sync_strands)
   unsigned m = 0;
   bool covers(size_t p) const { return p >= w_begin && p < w_end; }
   // index of the entry at (absolute) position p, or npos
@@ -232,7 +232,7 @@ struct SeedSet {
 struct SeedStream {
   size_t w_begin = 0, w_end = 0;
   std::vector<uint32_t> pos;              // relative to w_begin
-  std::vector<uint64_t> fwd, rev, hashes; // fwd/rev: n_seeds per entry; hashes: n_seeds*m2
+  std::vector<uint64_t> hashes;           // n_seeds*m2 per entry (strand hashes: SeedNtHash::sync_strands)
   bool covers(size_t p) const { return p >= w_begin && p < w_end; }
   size_t find(size_t p, size_t hint) const
   {
@@ -258,20 +258,16 @@ std::shared_ptr<detail::KmerStream> build_kmer_stream(const char* seq, size_t le
   st->w_end = std::min(n_pos, from + window_positions());
   const size_t cap = st->w_end - st->w_begin;
   st->pos.resize(cap);
-  st->fwd.resize(cap);
-  st->rev.resize(cap);
   st->hashes.resize(cap * m);
   nthip_ctx* ctx = device_ctx("NtHash");
   const uint64_t offsets[2] = { 0, (uint64_t)(cap + k - 1) };
   nthip_reads rd = { seq + from, offsets, 1, 0, 0 };
-  nthip_out out = { st->hashes.data(), cap, nullptr, st->pos.data(), st->fwd.data(), st->rev.data() };
+  nthip_out out = { st->hashes.data(), cap, nullptr, st->pos.data(), nullptr, nullptr };
   uint64_t total = 0;
   if (nthip_kmer_hash(ctx, &rd, (uint16_t)k, (uint8_t)m, &out, &total, NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT) !=
       NTHIP_OK)
     raise_error("NtHash", std::string("GPU hashing failed: ") + nthip_last_error());
   st->pos.resize(total);
-  st->fwd.resize(total);
-  st->rev.resize(total);
   st->hashes.resize(total * m);
   return st;
 }
@@ -291,8 +287,6 @@ std::shared_ptr<detail::SeedStream> build_seed_stream(const char* seq, size_t le
   st->w_end = std::min(n_pos, from + window_positions());
   const size_t cap = st->w_end - st->w_begin;
   st->pos.resize(cap);
-  st->fwd.resize(cap * ns);
-  st->rev.resize(cap * ns);
   st->hashes.resize(cap * ns * m2);
   nthip_ctx* ctx = device_ctx("SeedNtHash");
   if (!seeds.dev || seeds.dev_ctx != ctx) { // (the device tables belong to the thread's context)
@@ -306,14 +300,12 @@ std::shared_ptr<detail::SeedStream> build_seed_stream(const char* seq, size_t le
   }
   const uint64_t offsets[2] = { 0, (uint64_t)(cap + k - 1) };
   nthip_reads rd = { seq + from, offsets, 1, 0, 0 };
-  nthip_out out = { st->hashes.data(), cap, nullptr, st->pos.data(), st->fwd.data(), st->rev.data() };
+  nthip_out out = { st->hashes.data(), cap, nullptr, st->pos.data(), nullptr, nullptr };
   uint64_t total = 0;
   if (nthip_seed_hash(ctx, &rd, seeds.dev, (uint8_t)m2, &out, &total, NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT) !=
       NTHIP_OK)
     raise_error("SeedNtHash", std::string("GPU hashing failed: ") + nthip_last_error());
   st->pos.resize(total);
-  st->fwd.resize(total * ns);
-  st->rev.resize(total * ns);
   st->hashes.resize(total * ns * m2);
   return st;
 }
@@ -413,6 +405,8 @@ NtHash::NtHash(const NtHash& o)
   , initialized_(o.initialized_)
   , fwd_(o.fwd_)
   , rev_(o.rev_)
+  , strands_stale_(o.strands_stale_)
+  , strands_wanted_(o.strands_wanted_)
   , hash_arr_(new uint64_t[o.num_hashes_ ? o.num_hashes_ : 1])
   , rt_(o.rt_)
   , stream_(o.stream_)
@@ -441,6 +435,7 @@ bool NtHash::load_from_stream()
     for (size_t i = k_; i-- > 0;) r = srol1(r) ^ rt_->r_out[w[i]];
     fwd_ = f;
     rev_ = r;
+    strands_stale_ = false;
     extend(fwd_, rev_, k_, num_hashes_, hash_arr_.get());
     return true;
   }
@@ -451,10 +446,23 @@ bool NtHash::load_from_stream()
   const size_t i = stream_->find(pos_, cursor_);
   if (i == (size_t)-1) return false;
   cursor_ = i;
-  fwd_ = stream_->fwd[i];
-  rev_ = stream_->rev[i];
+  strands_stale_ = true; // (the caller may make them current again: roll())
   std::memcpy(hash_arr_.get(), stream_->hashes.data() + i * num_hashes_, num_hashes_ * sizeof(uint64_t));
   return true;
+}
+
+// the strand hashes of the window at pos_, straight from its bases (src/kmer.cpp:43-73, 123-152): what
+// get_forward_hash() / get_reverse_hash(), roll_back() and peek*() need and the device stream does not carry
+void NtHash::sync_strands() const
+{
+  const unsigned char* w = (const unsigned char*)seq_ + pos_;
+  uint64_t f = 0, r = 0;
+  for (size_t i = 0; i < k_; ++i) f = srol1(f) ^ rt_->f_in[w[i]];
+  for (size_t i = k_; i-- > 0;) r = srol1(r) ^ rt_->r_out[w[i]];
+  fwd_ = f;
+  rev_ = r;
+  strands_stale_ = false;
+  strands_wanted_ = true;
 }
 
 // reference: NtHash::init, src/kmer.cpp:228-244.  The skip loop only looks at
@@ -498,15 +506,29 @@ bool NtHash::roll()
     extend(fwd_, rev_, k_, num_hashes_, hash_arr_.get());
     return true;
   }
+  const bool strands_were_current = !strands_stale_;
+  const uint64_t f_before = fwd_, r_before = rev_;
   if (!load_from_stream()) {
     // Only reachable when the object was driven outside the reference's contract
     // (e.g. roll_back() after a failed roll() left pos past the last window, where
     // the reference itself reads out of bounds): the window at pos_ then holds a
     // non-base, so it is not in the stream.  Do what the reference does: roll.
     const unsigned char out = (unsigned char)seq_[pos_ - 1], in = (unsigned char)seq_[pos_ + k_ - 1];
+    if (!strands_were_current) { // (the strands of the window we come from)
+      --pos_;
+      sync_strands();
+      ++pos_;
+    }
     fwd_ = next_fwd(fwd_, *rt_, out, in);
     rev_ = next_rev(rev_, *rt_, out, in);
+    strands_stale_ = false;
     extend(fwd_, rev_, k_, num_hashes_, hash_arr_.get());
+  } else if (strands_wanted_ && strands_were_current) {
+    // somebody asked for the strand hashes before: keep them current with the O(1) recurrence
+    const unsigned char out = (unsigned char)seq_[pos_ - 1], in = (unsigned char)seq_[pos_ + k_ - 1];
+    fwd_ = next_fwd(f_before, *rt_, out, in);
+    rev_ = next_rev(r_before, *rt_, out, in);
+    strands_stale_ = false;
   }
   return true;
 }
@@ -522,6 +544,7 @@ bool NtHash::roll_back()
     return init();
   }
   if (!valid_base(in)) return false;
+  if (strands_stale_) sync_strands();
   const unsigned char out = (unsigned char)seq_[pos_ + k_ - 1];
   fwd_ = prev_fwd(fwd_, *rt_, out, (unsigned char)in);
   rev_ = prev_rev(rev_, *rt_, out, (unsigned char)in);
@@ -541,6 +564,7 @@ bool NtHash::peek(char char_in)
 {
   if (!initialized_) return init();
   if (!valid_base(char_in)) return false;
+  if (strands_stale_) sync_strands();
   const unsigned char out = (unsigned char)seq_[pos_];
   extend(next_fwd(fwd_, *rt_, out, (unsigned char)char_in), next_rev(rev_, *rt_, out, (unsigned char)char_in), k_,
          num_hashes_, hash_arr_.get());
@@ -557,6 +581,7 @@ bool NtHash::peek_back(char char_in)
 {
   if (!initialized_) return init();
   if (!valid_base(char_in)) return false;
+  if (strands_stale_) sync_strands();
   const unsigned char out = (unsigned char)seq_[pos_ + k_ - 1];
   extend(prev_fwd(fwd_, *rt_, out, (unsigned char)char_in), prev_rev(rev_, *rt_, out, (unsigned char)char_in), k_,
          num_hashes_, hash_arr_.get());
@@ -686,6 +711,7 @@ SeedNtHash::SeedNtHash(const SeedNtHash& o)
   , k_(o.k_)
   , pos_(o.pos_)
   , pos0_(o.pos0_)
+  , strands_stale_(o.strands_stale_)
   , initialized_(o.initialized_)
   , n_seeds_(o.n_seeds_)
   , seeds_(o.seeds_)
@@ -722,8 +748,7 @@ void SeedNtHash::set_window(const char* win, bool try_stream)
     const size_t i = stream_->covers(p) ? stream_->find(p, cursor_) : (size_t)-1;
     if (i != (size_t)-1) {
       cursor_ = i;
-      std::memcpy(fwd_.get(), stream_->fwd.data() + i * n_seeds_, n_seeds_ * sizeof(uint64_t));
-      std::memcpy(rev_.get(), stream_->rev.data() + i * n_seeds_, n_seeds_ * sizeof(uint64_t));
+      strands_stale_ = true; // (win == seq_ + pos_ here: sync_strands hashes that window when a getter asks)
       std::memcpy(hash_arr_.get(), stream_->hashes.data() + i * get_hash_num(),
                   get_hash_num() * sizeof(uint64_t));
       return;
@@ -734,6 +759,19 @@ void SeedNtHash::set_window(const char* win, bool try_stream)
     seed_window_hash(seeds_->shapes[s], k_, at, at, &fwd_[s], &rev_[s]);
     extend(fwd_[s], rev_[s], k_, num_hashes_per_seed_, hash_arr_.get() + (size_t)s * num_hashes_per_seed_);
   }
+  strands_stale_ = false;
+}
+
+// the per-seed strand hashes of the window at pos_ (what set_window's host branch computes; the device stream carries
+// hashes() only)
+void SeedNtHash::sync_strands() const
+{
+  const char* win = seq_ + pos_;
+  for (unsigned s = 0; s < n_seeds_; ++s) {
+    auto at = [&](unsigned i) { return win[i]; };
+    seed_window_hash(seeds_->shapes[s], k_, at, at, &fwd_[s], &rev_[s]);
+  }
+  strands_stale_ = false;
 }
 
 // reference: SeedNtHash::init, src/seed.cpp:493-516 -- the first-window routine
@@ -804,6 +842,7 @@ void SeedNtHash::hash_backward(bool commit)
     if (commit) {
       fwd_[s] = f;
       rev_[s] = r;
+      strands_stale_ = false;
     }
     extend(f, r, k_, num_hashes_per_seed_, hash_arr_.get() + (size_t)s * num_hashes_per_seed_);
   }

@@ -1675,7 +1675,7 @@ def test_kmer_packed_input_vs_oracle(ctx, oracle, n, L, stride):
             got = ctx.kmer_hash_packed(d_pk, k, m, L, n, stride=stride, clean=True, want_pos=True)
             name = ctx.last_kernel_ms()[1]
             ctx.set_profiling(False)
-            if (L, k, m, stride) == (150, 31, 1, 0):
+            if (L, k, m, stride) == (150, 31, 1, 0) and not os.environ.get("NTHASH_AMD_LIB"):  # (A/B builds may differ)
                 assert name == "kmer_runs_kernel", name
             assert got["total"] == want["total"] == n * (L - k + 1)
             for key in ("hashes", "counts", "pos"):
