@@ -145,6 +145,13 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
   const bool chunked = kmer_runs_chunked_compiled() && p->dword_tail && !c->tune.no_phases && m == 1 &&
                        64 % p->rpr == 0 && stride == len; // (tiles are whole reads)
   p->ph_tiles = chunked ? (c->tune.ph_tiles ? (c->tune.ph_tiles < 16u ? c->tune.ph_tiles : 16u) : 16u) : 0u;
+  // burst path (kmer_runs_kernel.hpp, round 3): pieces of KR_BURST consecutive tiles per wave -- run length 15 (8 store
+  // instructions per tile), tiles of whole reads, dword-tail slabs; NTHIP_TUNE_NO_PHASES=1 keeps the static loop (A/B)
+  // (m = 1 only: in-process A/B, 60 M reads, +3.0 % on 150 bp / k = 31; with four hashes per k-mer the copy-out's
+  //  arithmetic needs the 16 waves the longer LDS streams do not leave: -3 %)
+  if (!kmer_runs_chunked_compiled() && p->dword_tail && !c->tune.no_phases && best == 15 && 64 % p->rpr == 0 && stride == len &&
+      k >= 17 && m == 1) // (the instantiations with a compile-time run length: k = 31 and the runtime-k ones)
+    p->ph_tiles = KR_BURST;
   const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4 * (p->ph_tiles ? p->ph_tiles : 1u);
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
   // m = 1: 16 waves per CU measured 1.3-2.9 % faster than 8 once the tile geometry runs on the scalar unit (round 1:

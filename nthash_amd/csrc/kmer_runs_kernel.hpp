@@ -153,6 +153,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
   // waves interleave inside it (0/1 = one group = plain grid stride; one group
   // per block measured best: each CU then streams through its own region)
   uint64_t wt, wstride, wt_end;
+  uint64_t grp_t0 = 0, grp_w = 0; // first tile of the wave's group and the wave's index in it (KR_CONSEC)
   {
     const uint64_t n_waves_total = (uint64_t)gridDim.x * a.waves;
     const uint64_t gw = (uint64_t)blockIdx.x * a.waves + wave;
@@ -168,6 +169,8 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
     wt = t0 + w_in_g;
     wstride = g_waves;
     wt_end = t0 + per < a.n_wtiles ? t0 + per : a.n_wtiles;
+    grp_t0 = t0;
+    grp_w = w_in_g;
   }
   uint64_t r_first = (wt * 64u) / a.rpr;
   uint32_t rem0 = (uint32_t)(wt * 64u - r_first * a.rpr);
@@ -469,6 +472,137 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
 
   // (the windowed path exists in the m = 1 instantiations of a KR_CHUNKED build only: 512 threads, 256 VGPRs)
   constexpr bool KR_WINDOWED = KR_CHUNKED && DT && M_T == 1;
+  // ---- burst path (round 3; DT shapes whose tiles are whole reads: 64 % rpr == 0, stride == len; a.ph_tiles == KR_BURST) --
+  // What the reads of this kernel cost HBM is how OFTEN they come, not how many bytes they are: with the hash switched
+  // off the static loop below takes 18.6 ms per 100 M reads whether it reads ASCII or 2-bit packed input (a quarter of
+  // the bytes), the write stream alone 13.7.  Read in bursts -- the slabs of 16 tiles per wave at a time -- the same
+  // memory-only loop takes 17.0-17.3 ms (profiles/r03_notes.md).  So a wave takes PIECES of KR_BURST consecutive tiles:
+  // one contiguous read of KR_BURST slabs (9.4 KiB), packed into KR_BURST bit streams in LDS, then KR_BURST tiles hashed
+  // and written as one contiguous 60 KiB of the stream.  The next piece's loads are issued before the first tile is
+  // hashed and consumed after the last tile's stores: 8 x 8 = 64 younger stores, and an in-order counter that holds at
+  // most 63 operations proves they have landed (the seed kernel's argument) -- no pacing, no block barrier, any number
+  // of waves.  The waves of a group take the pieces of its tile range in turn.
+#ifndef KR_BURST
+#define KR_BURST 8
+#endif
+  constexpr bool KR_BURST_OK = !KR_CHUNKED && DT && !PK && C_T != 0 && NST == 8u;
+  if constexpr (KR_BURST_OK) {
+    if (a.ph_tiles == (uint32_t)KR_BURST) {
+      constexpr uint32_t P = KR_BURST;
+      static_assert(P * NST >= 64u, "the counted wait of the burst path needs 64 stores per piece");
+      uint32_t* const bits0 = bits;
+      const uint32_t reads_per_tile = 64u / a.rpr;
+      const uint64_t tile_bytes = (uint64_t)reads_per_tile * a.stride;
+      const uint64_t base_addr = (uint64_t)a.seqs;
+      // bytes of tile t's slab (the batch's last tile may hold fewer reads: nothing past the buffer is read or judged)
+      auto slab_bytes_of = [&](const uint64_t t) -> uint32_t {
+        const uint64_t reads_left = a.n_reads - t * reads_per_tile;
+        const uint32_t nr = reads_left < reads_per_tile ? (uint32_t)reads_left : reads_per_tile;
+        return (nr - 1u) * a.stride + a.len;
+      };
+      uint64_t sgrp = grp_w;
+      uint64_t pt = grp_t0 + sgrp * P; // first tile of the wave's current piece
+      v4u v[P];
+      uint32_t w4[P];
+      uint32_t dirty_seen = 0;
+      // loads of the P slabs of the piece that starts at tile t0 (tiles past the range reload the range's last slab)
+      auto issue_piece = [&](const uint64_t t0) {
+#pragma unroll
+        for (uint32_t i = 0; i < P; ++i) {
+          uint64_t t = t0 + i;
+          if (t >= wt_end) t = wt_end - 1u;
+          const uint64_t off = t * tile_bytes;
+          const uint32_t shift = (uint32_t)((base_addr + off) & 15u);
+          const uint64_t b0 = off - shift;
+          const uint32_t slab_bytes = slab_bytes_of(t);
+          const uint32_t n_vec = (shift + slab_bytes + 15u) >> 4;
+          const uint32_t n_dw = (shift + slab_bytes + 3u) >> 2;
+          const uint32_t i0 = lane < n_vec ? lane : 0u;
+          const uint32_t jd = 256u + lane < n_dw ? 256u + lane : 0u;
+          const uint64_t sb = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b0) |
+                              ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b0 >> 32)) << 32);
+          const uint8_t* sbase = a.seqs + sb; // scalar base + 32-bit lane offset
+          asm volatile("global_load_dwordx4 %0, %2, %4 sc1 nt\n\tglobal_load_dword %1, %3, %4 sc1 nt"
+                       : "=&v"(v[i]), "=&v"(w4[i])
+                       : "v"(i0 << 4), "v"(jd << 2), "s"(sbase)
+                       : "memory");
+        }
+        asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(dirty_seen) : "v"(a.dirty) : "memory");
+      };
+      auto pack_piece = [&](const uint64_t t0) {
+#pragma unroll
+        for (uint32_t i = 0; i < P; ++i) {
+          const uint64_t t = t0 + i;
+          if (t < wt_end) {
+            Slab sl;
+            const uint32_t slab_bytes = slab_bytes_of(t);
+            sl.shift = (uint32_t)((base_addr + t * tile_bytes) & 15u);
+            sl.slab_bytes = slab_bytes;
+            sl.n_vec = (sl.shift + slab_bytes + 15u) >> 4;
+            sl.byte0 = 0;
+            sl.runs_here = 64u;
+            sl.edge = (t == 0u || (t + 1u) * reads_per_tile >= a.n_reads) ? 1u : 0u; // first / last slab of the buffer
+            bits = bits0 + i * a.bits_dwords;
+            if (lane < sl.n_vec) pack_vec(sl, lane, make_uint4(v[i].x, v[i].y, v[i].z, v[i].w));
+            const uint32_t n_dw = (sl.shift + slab_bytes + 3u) >> 2;
+            if (256u + lane < n_dw) pack_dword(sl, lane, w4[i]);
+            if (lane < (uint32_t)NW + 3u) bits[sl.n_vec + lane] = 0;
+          }
+        }
+      };
+#define KR_BURST_MARK() \
+      asm volatile("; NTLINT_CONSUME %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11 %12 %13 %14 %15 %16" \
+                   : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), \
+                     "+v"(w4[0]), "+v"(w4[1]), "+v"(w4[2]), "+v"(w4[3]), "+v"(w4[4]), "+v"(w4[5]), "+v"(w4[6]), "+v"(w4[7]), \
+                     "+v"(dirty_seen)::"memory")
+      static_assert(P == 8u, "the marker above lists 8 slabs");
+      if (pt < wt_end) {
+        issue_piece(pt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KR_BURST_MARK();
+        pack_piece(pt);
+      }
+      while (pt < wt_end) {
+        const uint64_t left = wt_end - pt;
+        const uint32_t n_here = left < P ? (uint32_t)left : P;
+        const uint64_t npt = grp_t0 + (sgrp + wstride) * P;
+        const bool have_next = npt < wt_end;
+        // a non-base in the piece just packed (or anywhere in the batch, as of the last look): the caller redoes the
+        // batch on the N-aware path, so stop producing a dense stream nobody will read
+        if (__ballot(bad != 0) != 0) {
+          if (lane == 0) atomicOr(a.dirty, 1u);
+          break;
+        }
+        if (__builtin_amdgcn_readfirstlane(dirty_seen) != 0u) break;
+        issue_piece(have_next ? npt : pt);
+        bool all_full = n_here == P; // (a full tile leaves as >= 8 store instructions, whatever m is)
+        for (uint32_t q = 0; q < n_here; ++q) {
+          const uint64_t t = pt + q;
+          const uint64_t g0 = t * 64u;
+          const uint64_t runs_left = a.n_runs - g0;
+          const uint32_t runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
+          const uint32_t shift = (uint32_t)((base_addr + t * tile_bytes) & 15u);
+          bits = bits0 + q * a.bits_dwords;
+          lds_sync();
+          hash_tile(shift, runs_here, 0u);
+          NT_LINT_SELFTEST_TOUCH(dirty_seen);
+          (void)copy_out(g0, runs_here);
+          all_full = all_full && runs_here == 64u;
+          lds_sync(); // the tile is free again
+        }
+        // P full tiles = at least 64 store instructions issued behind the 17 loads: "at most 63 in flight" says they have landed
+        asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        if (!all_full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KR_BURST_MARK();
+        sgrp += wstride;
+        pt = npt;
+        if (have_next) pack_piece(pt);
+      }
+#undef KR_BURST_MARK
+      if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
+      return;
+    }
+  }
   if (!KR_WINDOWED || a.ph_tiles == 0u) {
     Slab cur;
     cur.byte0 = 0;
@@ -629,8 +763,26 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
 #ifndef KR_LOAD_NT
 #define KR_LOAD_NT " sc1 nt"
 #endif
+    // KR_CONSEC=1 (round 3 experiment): the P tiles of a group are CONSECUTIVE in memory -- the wave reads one contiguous
+    // piece of P slabs and writes one contiguous piece of P tiles, waves of a group take such pieces in turn -- instead
+    // of P tiles wstride apart.  What the reads cost HBM is their number of bursts, not their bytes (2-bit packed input,
+    // a quarter of the bytes, has the same memory-only floor): fewer, longer read bursts per channel.
+#ifndef KR_CONSEC
+#define KR_CONSEC 0
+#endif
+#if KR_CONSEC
+    uint64_t sgrp = grp_w; // index of the wave's current piece of P tiles inside its group
+    wt = grp_t0 + sgrp * P;
+    auto tile_of = [&](uint32_t i) -> uint64_t { return wt + i; };
+#else
+    auto tile_of = [&](uint32_t i) -> uint64_t { return wt + (uint64_t)i * wstride; };
+#endif
     while (wt < wt_end) {
+#if KR_CONSEC
+      const uint64_t left = wt_end - wt;
+#else
       const uint64_t left = (wt_end - wt + wstride - 1u) / wstride;
+#endif
       const uint32_t n_here = left < P ? (uint32_t)left : P;
       KR_DBG(4);
       if (T) {
@@ -647,7 +799,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
       const uint64_t base_addr = (uint64_t)a.seqs;
 #pragma unroll
       for (uint32_t i = 0; i < RND; ++i) {
-        const uint64_t t = wt + (uint64_t)(i < n_here ? i : n_here - 1u) * wstride; // (a short group loads its last slab again)
+        const uint64_t t = tile_of(i < n_here ? i : n_here - 1u); // (a short group loads its last slab again)
         const uint64_t off = t * tile_bytes;
         const uint32_t shift = (uint32_t)((base_addr + off) & 15u);
         shifts[i] = shift;
@@ -681,7 +833,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
 #pragma unroll
       for (uint32_t i = 0; i < RND; ++i) {
         if (i < n_here) {
-          const uint64_t t = wt + (uint64_t)i * wstride;
+          const uint64_t t = tile_of(i);
           Slab sl;
           sl.shift = shifts[i];
           sl.slab_bytes = slab_bytes;
@@ -708,7 +860,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
       if (T && R) spin_until(t_read + R);
       KR_DBG(3);
       for (uint32_t q = 0; q < n_here; ++q) {
-        const uint64_t t = wt + (uint64_t)q * wstride;
+        const uint64_t t = tile_of(q);
         const uint64_t g0 = t * 64u;
         const uint64_t runs_left = a.n_runs - g0;
         const uint32_t runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
@@ -719,7 +871,12 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
         (void)copy_out(g0, runs_here);
         lds_sync(); // the tile is free again
       }
+#if KR_CONSEC
+      sgrp += wstride;
+      wt = grp_t0 + sgrp * P;
+#else
       wt += (uint64_t)n_here * wstride;
+#endif
       t_read += T;
     }
 #if KR_DEBUG_TIMES
