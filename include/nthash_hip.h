@@ -58,6 +58,16 @@ extern "C" {
 #define NTHIP_PACKED_CLEAN 0x40u  /* with NTHIP_PACKED_INPUT: nthip_pack_reads reported no invalid byte (or none inside any
                                     read), every window is emitted and the validity stream is not read at all */
 
+#define NTHIP_OUT_READ_SLOTS 0x80u /* nthip_kmer_hash with offsets, nthip_kmer_hash_spans (short reads in order): a ONE-PASS
+                                    output contract.  Read r's k-mers start at slot_off[r] = sum over the reads before it of
+                                    max(len - k + 1, 0) -- a place that depends on the read LENGTHS alone, so nothing has to be
+                                    counted before anything is written (no pass that marks the reads with non-bases, no
+                                    compaction) -- out->counts[r] (required) says how many of the slot's entries are k-mers:
+                                    they come first, in the reference's order; the rest of the slot is zero.  *total = the
+                                    extent of the slot array (every window of every read), which out->capacity must hold.
+                                    Reads without non-bases -- nearly all of them -- fill their slots: the stream is the
+                                    compact one exactly when every count equals its window count. */
+
 typedef struct nthip_ctx nthip_ctx;     /* one device + one stream + scratch */
 typedef struct nthip_seeds nthip_seeds; /* parsed spaced-seed set (device tables) */
 

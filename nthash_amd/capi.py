@@ -26,6 +26,7 @@ NTHIP_HOST_OUTPUT = 0x2
 NTHIP_ASYNC = 0x10
 NTHIP_PACKED_INPUT = 0x20
 NTHIP_PACKED_CLEAN = 0x40
+NTHIP_OUT_READ_SLOTS = 0x80
 NTHIP_FORCE_GENERAL = 0x4
 NTHIP_FORCE_ROWS = 0x8
 

@@ -311,7 +311,7 @@ int run_kmer_packed(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t m,
 // capi_kmer_ragged.hip: reads = spans [starts[r], ends[r]) of the device buffer st.seqs (total_bytes long)
 int run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
                    uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled,
-                   const ReadsShape* shape);
+                   const ReadsShape* shape, bool slots = false);
 int run_kmer_ragged(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends, uint64_t n_reads,
                     uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity, uint64_t* total, bool* handled,
                     const ReadsShape* shape = nullptr, bool checked = true);

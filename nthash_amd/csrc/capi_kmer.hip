@@ -40,6 +40,22 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
   NTCHK(stage_inputs(c, rd, flags, total_bytes, st));
   NTCHK(stage_outputs(c, out, flags, rd->n_reads, m, st));
 
+  if (flags & NTHIP_OUT_READ_SLOTS) { // one pass: read r's k-mers at the slot its length implies (capi_kmer_reads.hip)
+    if (!st.offsets) return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_OUT_READ_SLOTS takes reads given by offsets (or spans)");
+    if (flags & (NTHIP_ASYNC | NTHIP_FORCE_GENERAL | NTHIP_FORCE_ROWS))
+      return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_OUT_READ_SLOTS: a plain synchronous call");
+    bool handled = false;
+    const int rc = run_kmer_reads(c, st, st.offsets, st.offsets + 1, rd->n_reads, total_bytes, k, m, out->capacity, &total,
+                                  &handled, nullptr, /*slots*/ true);
+    if (total_out) *total_out = total;
+    NTCHK(rc);
+    if (!handled)
+      return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_OUT_READ_SLOTS: short reads (<= 2048 bases) in order only");
+    NTCHK(unstage_outputs(c, out, flags, rd->n_reads, m, total, st));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTHIP_OK;
+  }
+
   // Offsets: one pass over them on the device (+ one round trip) before anything trusts them -- are they in order
   // and inside the buffer (a decreasing pair would underflow a length), how long is the longest read, and do all
   // reads have one length?  Reads of one length lying back to back (Illumina reads through the offsets API, what

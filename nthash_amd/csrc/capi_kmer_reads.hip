@@ -5,6 +5,8 @@
 #include "kmer_reads_kernel.hpp"
 #include "util_kernels.hpp"
 
+#include <algorithm>
+
 using namespace ntamd;
 using namespace ntamd::host;
 
@@ -13,17 +15,18 @@ namespace {
 template <int NW>
 int launch_kmer_reads(nthip_ctx* c, int mode, const KmerReadsArgs& a, size_t dyn_lds)
 {
-  auto kernel = mode == RD_MODE_MARK ? kmer_reads_kernel<RD_MODE_MARK, NW, false>
-                : a.pos            ? kmer_reads_kernel<RD_MODE_HASH, NW, true>
-                                   : kmer_reads_kernel<RD_MODE_HASH, NW, false>;
+  auto kernel = mode == RD_MODE_MARK    ? kmer_reads_kernel<RD_MODE_MARK, NW, false>
+                : mode == RD_MODE_SLOTS ? (a.pos ? kmer_reads_kernel<RD_MODE_SLOTS, NW, true> : kmer_reads_kernel<RD_MODE_SLOTS, NW, false>)
+                : a.pos                 ? kmer_reads_kernel<RD_MODE_HASH, NW, true>
+                                        : kmer_reads_kernel<RD_MODE_HASH, NW, false>;
   int per_cu = 1;
   NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
   const uint64_t need = (a.n_tiles + a.waves - 1) / a.waves;
   uint64_t grid = (uint64_t)c->n_cu * per_cu;
   if (grid > need) grid = need;
-  if (mode == RD_MODE_HASH) prof_begin(c, "kmer_reads_kernel");
+  if (mode != RD_MODE_MARK) prof_begin(c, mode == RD_MODE_SLOTS ? "kmer_reads_kernel(read slots)" : "kmer_reads_kernel");
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
-  if (mode == RD_MODE_HASH) prof_end(c);
+  if (mode != RD_MODE_MARK) prof_end(c);
   HIPCHK(hipGetLastError());
   return NTHIP_OK;
 }
@@ -33,7 +36,7 @@ int launch_kmer_reads(nthip_ctx* c, int mode, const KmerReadsArgs& a, size_t dyn
 // *handled = false: the batch is outside this path (long reads, spans out of order, LDS); nothing was written
 int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, const uint64_t* d_ends,
                                 uint64_t n_reads, uint64_t total_bytes, uint32_t k, uint32_t m, uint64_t capacity,
-                                uint64_t* total, bool* handled, const ReadsShape* shape)
+                                uint64_t* total, bool* handled, const ReadsShape* shape, bool slots)
 {
   *handled = false;
   if (c->tune.no_kmer_reads || n_reads == 0) return NTHIP_OK;
@@ -43,6 +46,10 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   unsigned long long* d_ndirty = (unsigned long long*)(c->d_small + 128);
   HIPCHK(hipMemsetAsync(c->d_small + 96, 0, 48, c->stream));
   uint64_t res[4] = {0, 0, 0, 0};
+  // NTHIP_OUT_READ_SLOTS: the survey also sums the windows of every tile, for the usual tile of 32 reads (decided below:
+  // a batch whose slabs would not fit gets fewer reads per tile and its sums from a pass of their own)
+  const uint32_t R_guess = c->tune.reads_per_tile ? (c->tune.reads_per_tile > 64 ? 64 : c->tune.reads_per_tile) : 32;
+  unsigned long long* d_guess = nullptr;
   if (shape) { // back-to-back reads already surveyed by the caller
     res[0] = shape->max_len;
     res[1] = shape->max_pitch;
@@ -50,7 +57,14 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   } else {
     uint64_t blocks = (n + 255) / 256;
     if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
-    hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n, total_bytes, d_res);
+    if (slots) {
+      const uint64_t nt_guess = (n + R_guess - 1) / R_guess;
+      NTCHK(ensure_scratch2(c, nt_guess + 16));
+      d_guess = (unsigned long long*)c->d_scratch2;
+      HIPCHK(hipMemsetAsync(d_guess, 0, nt_guess * sizeof(uint64_t), c->stream));
+    }
+    hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n, total_bytes, d_res,
+                       0u, R_guess, k, d_guess);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_small + 96, d_res, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -97,7 +111,9 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   const size_t per_wave = (size_t)tile_u64 * 8 + ((size_t)ptile_dwords + bits_dwords + 256 + rmap_dwords) * 4;
   const size_t cap = lds_cap_of(c);
   uint32_t waves = 0;
-  for (uint32_t w = c->tune.reads_waves ? c->tune.reads_waves : 16; w >= 1; --w)
+  uint32_t w_top = c->tune.reads_waves ? c->tune.reads_waves : 16;
+  if (slots && nw >= 4 && w_top > 12) w_top = 12; // (launch bounds of that instantiation: rd_max_threads)
+  for (uint32_t w = w_top; w >= 1; --w)
     if (fixed + per_wave * w <= cap) { waves = w; break; }
   if (!waves) return NTHIP_OK;
   *handled = true;
@@ -146,6 +162,58 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   memcpy(a.tab, consts.tab, sizeof a.tab);
   memcpy(a.mult, consts.mult, sizeof a.mult);
   const size_t lds = fixed + per_wave * waves;
+  // NTHIP_OUT_READ_SLOTS: one pass over the bases -- slots from the spans alone, then hash; the reads the pass lists
+  // (a non-base inside) are redone in their slots afterwards
+  if (slots) {
+    if (!st.counts || st.fwd || st.rev) return fail(NTHIP_ERR_ARG, "NTHIP_OUT_READ_SLOTS needs out->counts and has no strand outputs");
+    const uint64_t* tile_windows = d_tsum;
+    if (d_guess && R == R_guess) {
+      tile_windows = (const uint64_t*)d_guess; // (the survey summed them)
+    } else {
+      const unsigned tblocks = (unsigned)std::min<uint64_t>((n_tiles + 255) / 256, (uint64_t)c->n_cu * 8);
+      hipLaunchKernelGGL(reads_tile_windows_kernel, dim3(tblocks), dim3(256), 0, c->stream, d_starts, d_ends, n, R, k, n_tiles, d_tsum);
+      HIPCHK(hipGetLastError());
+    }
+    NTCHK(device_exclusive_scan(c, tile_windows, d_toff, n_tiles, d_sums, d_total));
+    HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(total, c->h_small + 8, 8); // the extent of the slot array: every window of every read
+    if (*total > capacity)
+      return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu slots needed", (unsigned long long)capacity,
+                  (unsigned long long)*total);
+    KmerReadsArgs sa = a;
+    auto launch_slots = [&]() -> int {
+      switch (nw) {
+        case 0: return launch_kmer_reads<0>(c, RD_MODE_SLOTS, sa, lds);
+        case 1: return launch_kmer_reads<1>(c, RD_MODE_SLOTS, sa, lds);
+        case 2: return launch_kmer_reads<2>(c, RD_MODE_SLOTS, sa, lds);
+        case 3: return launch_kmer_reads<3>(c, RD_MODE_SLOTS, sa, lds);
+        default: return launch_kmer_reads<4>(c, RD_MODE_SLOTS, sa, lds);
+      }
+    };
+    NTCHK(launch_slots());
+    KmerDirtyReadsArgs da;
+    memset(&da, 0, sizeof da);
+    da.seqs = st.seqs;
+    da.starts = d_starts;
+    da.ends = d_ends;
+    da.list = d_list;
+    da.n_list = d_ndirty;
+    da.k = k;
+    da.m = m;
+    da.cnt = d_cnt;
+    da.tile_sum = d_tsum;
+    da.tile_off = d_toff;
+    da.R = R;
+    da.hashes = st.hashes;
+    da.pos = st.pos;
+    da.slots = 1;
+    NTCHK(get_fw_tab(c, &da.horner_tab));
+    hipLaunchKernelGGL(kmer_dirty_reads_kernel<false>, dim3((unsigned)c->n_cu * 4), dim3(256), 0, c->stream, da);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTHIP_OK;
+  }
   auto launch = [&](int mode, const KmerReadsArgs& args, size_t bytes) -> int {
     switch (nw) {
       case 0: return launch_kmer_reads<0>(c, mode, args, bytes); // any k

@@ -37,8 +37,15 @@ extern "C" int nthip_kmer_hash_spans(nthip_ctx* c, const char* d_buf, uint64_t b
   uint64_t total = 0;
   bool handled = false;
   // (spans inside the buffer, start <= end: checked by the path that takes them, before anything is read through them)
-  int rc = run_kmer_ragged(c, st, d_starts, d_ends, n_reads, buf_bytes, k, m, out->capacity, &total, &handled, nullptr,
-                           /*checked*/ false);
+  int rc;
+  if (flags & NTHIP_OUT_READ_SLOTS) { // one pass: read r's k-mers at the slot its length implies (capi_kmer_reads.hip)
+    rc = run_kmer_reads(c, st, d_starts, d_ends, n_reads, buf_bytes, k, m, out->capacity, &total, &handled, nullptr, true);
+    if (rc == NTHIP_OK && !handled)
+      rc = fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_OUT_READ_SLOTS: short reads (<= 2048 bases) in order only");
+  } else {
+    rc = run_kmer_ragged(c, st, d_starts, d_ends, n_reads, buf_bytes, k, m, out->capacity, &total, &handled, nullptr,
+                         /*checked*/ false);
+  }
   if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
   NTCHK(rc);
   if (!handled) return fail(NTHIP_ERR_UNSUPPORTED, "shape outside the run-split ragged kernel");

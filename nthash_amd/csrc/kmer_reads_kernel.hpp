@@ -28,7 +28,13 @@
 
 namespace ntamd {
 
-enum : int { RD_MODE_MARK = 1, RD_MODE_HASH = 2 };
+// RD_MODE_SLOTS (round 3, the NTHIP_OUT_READ_SLOTS contract): ONE pass over the bases.  Read r's k-mers go to the slot its
+// LENGTH implies -- slot_off[r] = sum over the reads before it of max(len - k + 1, 0), a scan of the spans alone -- so
+// nothing has to be counted before anything is written: no mark pass, no compaction.  The pass hashes every read as if
+// clean and looks for non-bases while it packs (free); in the rare tile that has one the wave finds the reads concerned
+// (validity bits of the slab, L2-hot), lists them and leaves their slots to kmer_dirty_reads_kernel, which writes the
+// windows the reference emits at the front of the slot, the exact count into counts[r] and zeros behind.
+enum : int { RD_MODE_MARK = 1, RD_MODE_HASH = 2, RD_MODE_SLOTS = 3 };
 constexpr uint32_t RD_ALIGN_U64 = 16; // the output tile is aligned to a 128-byte line of the stream
 
 struct KmerReadsArgs {
@@ -60,8 +66,10 @@ struct KmerReadsArgs {
 // roll: with the other strand's table terms zeroed its state stays 0 and forward + reverse IS the wanted strand.
 // (the MARK pass waits for memory and nothing else: 8 waves per SIMD -- two blocks of 16 waves per CU -- instead of the
 //  4 the register count of the common body would give it)
+// (SLOTS with four window words needs a few registers more than the 128 that 16 waves leave: at most 12 waves there)
+constexpr int rd_max_threads(int mode, int nw) { return mode == RD_MODE_SLOTS && nw >= 4 ? 768 : KR_MAX_THREADS; }
 template <int MODE, int NW, bool POS = false>
-__global__ __launch_bounds__(KR_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == RD_MODE_MARK ? 8 : 1)))
+__global__ __launch_bounds__(rd_max_threads(MODE, NW)) __attribute__((amdgpu_waves_per_eu(MODE == RD_MODE_MARK ? 8 : 1)))
 void kmer_reads_kernel(const KmerReadsArgs a)
 {
   extern __shared__ __attribute__((aligned(256))) uint32_t lds_dyn[];
@@ -72,10 +80,11 @@ void kmer_reads_kernel(const KmerReadsArgs a)
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // LDS: [HASH: first-window tables | pair table] | per wave {hash tile, pos tile, bit stream, read table 4 x 64}
+  constexpr bool HASHING = MODE == RD_MODE_HASH || MODE == RD_MODE_SLOTS;
   uint4* itab = (uint4*)lds_dyn;
   uint4* ptab = itab + a.ntab * 256u;
   const uint32_t per_wave = a.tile_u64 * 2u + a.ptile_dwords + a.bits_dwords + 256u + a.rmap_dwords;
-  uint32_t* wave_base = (MODE == RD_MODE_HASH ? (uint32_t*)(ptab + 16) : lds_dyn) + wave * per_wave;
+  uint32_t* wave_base = (HASHING ? (uint32_t*)(ptab + 16) : lds_dyn) + wave * per_wave;
   uint64_t* tile = (uint64_t*)wave_base;
   uint32_t* ptile = wave_base + a.tile_u64 * 2u;
   uint32_t* bits = ptile + a.ptile_dwords; // HASH: 2-bit codes, 16 per dword; MARK: 1 bit per byte, set = not a base
@@ -84,7 +93,7 @@ void kmer_reads_kernel(const KmerReadsArgs a)
   uint32_t* rt_nw = rt_sb + 64;            // windows (0: shorter than k, or listed)
   uint32_t* rt_out = rt_nw + 64;           // first k-mer of the read, relative to the tile's first
   uint8_t* rmap = (uint8_t*)(rt_out + 64); // run of the tile -> its read
-  if (MODE == RD_MODE_HASH) {
+  if (HASHING) {
     const uint32_t keep_f = a.value_sel == 2u ? 0u : ~0u, keep_r = a.value_sel == 1u ? 0u : ~0u;
     for (uint32_t i = tid; i < a.ntab * 256u; i += blockDim.x) {
       const uint4 e = a.init_tab[i];
@@ -144,8 +153,8 @@ void kmer_reads_kernel(const KmerReadsArgs a)
     Meta mm;
     mm.s = a.starts[rr];
     mm.e = a.ends[rr];
-    mm.cnt = MODE == RD_MODE_HASH ? (uint32_t)a.cnt[rr] : 0u;
-    mm.listed = MODE == RD_MODE_HASH ? (uint32_t)a.flags[rr] : 0u;
+    mm.cnt = MODE == RD_MODE_HASH ? (uint32_t)a.cnt[rr] : 0u;       // (SLOTS: from the length, below)
+    mm.listed = MODE == RD_MODE_HASH ? (uint32_t)a.flags[rr] : 0u;  // (SLOTS: found while packing)
     return mm;
   };
   struct Geom {
@@ -194,10 +203,12 @@ void kmer_reads_kernel(const KmerReadsArgs a)
     bool listed = false;
     uint64_t ro_j = 0;
     uint64_t ro_0 = 0;
-    if (MODE == RD_MODE_HASH) {
+    const uint32_t nwin_raw = len_j >= k ? (uint32_t)(len_j - k + 1u) : 0u;
+    if (HASHING) {
       listed = m_cur.listed != 0;
-      // the read's first k-mer = the tile's + the k-mers of the reads before it in the tile (a tile has < 2^32)
-      const uint32_t cnt_j = has ? m_cur.cnt : 0u;
+      // the read's first k-mer = the tile's + the k-mers of the reads before it in the tile (a tile has < 2^32);
+      // SLOTS: + the WINDOWS of the reads before it -- a read's place does not depend on what its neighbours hold
+      const uint32_t cnt_j = MODE == RD_MODE_SLOTS ? nwin_raw : has ? m_cur.cnt : 0u;
       ro_0 = a.tile_off[t];
       ro_j = ro_0 + (wave_incl_scan32(cnt_j) - cnt_j);
     }
@@ -205,7 +216,6 @@ void kmer_reads_kernel(const KmerReadsArgs a)
     const uint32_t shift = g_cur.shift;
     const uint8_t* vbase = g_cur.vbase;
     const uint32_t n_vec = g_cur.n_vec;
-    const uint32_t nwin_raw = len_j >= k ? (uint32_t)(len_j - k + 1u) : 0u;
     const uint32_t sb_j = shift + (uint32_t)(s_j - slab0);
     const bool have_next = t + t_step < t_end;
 
@@ -259,18 +269,56 @@ void kmer_reads_kernel(const KmerReadsArgs a)
     }
 
     // ---- HASH: stage the slab as 2-bit codes (the first vectors are in registers already) ----
+    uint32_t slab_bad = 0; // SLOTS: a byte of the slab (reads and whatever lies between them) is not a base
 #pragma unroll
     for (uint32_t rd = 0; rd < RD_PF_ROUNDS; ++rd) {
       const uint32_t i = rd * 64u + lane;
       uint32_t bad = 0;
       if (i < n_vec) bits[i] = pack16(pv[rd], bad);
+      slab_bad |= i < n_vec ? bad : 0u;
     }
     for (uint32_t i = RD_PF_ROUNDS * 64u + lane; i < n_vec; i += 64u) {
       const uint4 x = *(const uint4*)(vbase + ((uint64_t)i << 4));
       uint32_t bad = 0;
       bits[i] = pack16(x, bad);
+      slab_bad |= bad;
     }
     if (lane < (uint32_t)NW + 3u) bits[n_vec + lane] = 0;
+    if constexpr (MODE == RD_MODE_SLOTS) {
+      // which reads hold a non-base?  Almost always none does -- but the bytes BETWEEN the reads of a FASTQ chunk
+      // (headers, quality lines) are never bases, so the question is asked per read, from validity bits built in the
+      // (still unused) hash tile: one bit per byte of the slab, as the MARK pass does
+      if (__ballot(slab_bad != 0u) != 0ull) {
+        uint16_t* vb = (uint16_t*)tile;
+        for (uint32_t i = lane; i < n_vec; i += 64u) {
+          const uint4 x = *(const uint4*)(vbase + ((uint64_t)i << 4));
+          uint32_t i0, i1, i2, i3;
+          (void)pack4v(x.x, i0);
+          (void)pack4v(x.y, i1);
+          (void)pack4v(x.z, i2);
+          (void)pack4v(x.w, i3);
+          vb[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+        }
+        if (lane < 4u) vb[n_vec + lane] = 0;
+        lds_sync();
+        uint32_t any = 0;
+        if (len_j) {
+          const uint32_t* vw = (const uint32_t*)tile;
+          const uint32_t b_end = sb_j + (uint32_t)len_j; // one past the last byte
+          const uint32_t w_lo = sb_j >> 5, w_hi = (b_end - 1u) >> 5;
+          for (uint32_t w = w_lo; w <= w_hi; ++w) {
+            uint32_t word = vw[w];
+            if (w == w_lo) word &= ~0u << (sb_j & 31u);
+            if (w == w_hi && (b_end & 31u)) word &= ~0u >> (32u - (b_end & 31u));
+            any |= word;
+          }
+        }
+        listed = has && any != 0 && nwin_raw != 0;
+        if (listed) a.dirty_list[atomicAdd(a.dirty_count, 1ull)] = rj;
+        lds_sync(); // the tile area is the hash tile again
+      }
+      if (has && !listed) a.cnt[rj] = nwin_raw; // (a listed read's count comes from kmer_dirty_reads_kernel)
+    }
     // ---- the next tile's slab and the spans of the tile after it: in flight during this tile's passes ----
     Meta m_n2 = m_nxt;
     Geom g_nxt = g_cur;
@@ -486,6 +534,9 @@ struct KmerDirtyReadsArgs {
   const uint4* horner_tab;   // hash pass: the k-independent fw tables (first_window.hpp; get_fw_tab), FW_ENTRIES entries
   uint64_t sk_fwd[4];        // srol^k(seed[code])
   uint64_t sk_rc[4];         // srol^k(seed[code ^ 2])
+  // NTHIP_OUT_READ_SLOTS (hash pass only, no count pass before it): the read's k-mers go to the front of the slot its
+  // length implies (tile_off = scan of the tiles' WINDOW counts), cnt[r] = how many, zeros behind them
+  uint32_t slots, pad;
 };
 
 constexpr uint32_t RD_MAX_LEN = 2048; // longest read this path takes (the host checks)
@@ -546,7 +597,15 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
     uint64_t base = 0;
     if (!COUNT_ONLY) { // the tile's first k-mer + the k-mers of the reads before this one in its tile
       const uint64_t r0 = r / a.R * a.R;
-      uint32_t before = r0 + lane < r ? (uint32_t)a.cnt[r0 + lane] : 0u;
+      uint32_t before = 0;
+      if (r0 + lane < r) {
+        if (a.slots) { // windows, not emitted k-mers: a slot's place depends on lengths alone
+          const uint64_t l2 = a.ends[r0 + lane] - a.starts[r0 + lane];
+          before = l2 >= k ? (uint32_t)(l2 - k + 1u) : 0u;
+        } else {
+          before = (uint32_t)a.cnt[r0 + lane];
+        }
+      }
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
       base = a.tile_off[r / a.R] + before;
@@ -575,30 +634,84 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
       a.cnt[r] = emitted;
       atomicAdd((unsigned long long*)&a.tile_sum[r / a.R], (unsigned long long)emitted);
     }
+    if (!COUNT_ONLY && a.slots) { // the rest of the slot: zeros (a whole-array checksum then equals the stream's), the count
+      for (uint32_t w = emitted + lane; w < nwin; w += 64u) {
+        for (uint32_t jj = 0; jj < m; ++jj) a.hashes[(base + w) * m + jj] = 0;
+        if (a.pos) a.pos[base + w] = 0;
+      }
+      if (lane == 0) a.cnt[r] = emitted;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
   }
 }
 
+// NTHIP_OUT_READ_SLOTS: windows of every tile of R reads (one lane per tile): their scan places the tiles' slots
+static __global__ __launch_bounds__(256) void reads_tile_windows_kernel(const uint64_t* __restrict__ starts,
+                                                                        const uint64_t* __restrict__ ends, uint64_t n,
+                                                                        uint32_t R, uint32_t k, uint64_t n_tiles,
+                                                                        uint64_t* __restrict__ tile_sum)
+{
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r0 = t * R, r1 = r0 + R < n ? r0 + R : n;
+    uint64_t sum = 0;
+    for (uint64_t r = r0; r < r1; ++r) {
+      const uint64_t l = ends[r] - starts[r];
+      sum += l >= k ? l - k + 1u : 0u;
+    }
+    tile_sum[t] = sum;
+  }
+}
+
 // max length, max distance between consecutive starts, order, total length: what the host needs to size the tiles
+// tile_sum != nullptr (NTHIP_OUT_READ_SLOTS): also the windows of every tile of R reads -- (len - k + 1 where len >= k),
+// summed per tile with a wave-level segmented scan and at most a few atomics per wave (tile_sum zeroed by the host)
 static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* __restrict__ starts,
                                                                 const uint64_t* __restrict__ ends, uint64_t n,
                                                                 uint64_t buf_bytes, unsigned long long* __restrict__ res,
-                                                                uint32_t allow_overlap = 0)
+                                                                uint32_t allow_overlap = 0, uint32_t R = 0, uint32_t k = 0,
+                                                                unsigned long long* __restrict__ tile_sum = nullptr)
 {
   // allow_overlap: consecutive reads may share bytes as long as starts and ends both go up (the pieces of a long read
   // overlap by k - 1: seed_rtile_kernel only needs a tile's reads inside one slab that ends with the last read)
   uint64_t mlen = 0, mpitch = 0, slen = 0;
   uint32_t bad = 0;
-  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t s0 = starts[r], e0 = ends[r];
-    if (e0 < s0 || e0 > buf_bytes) { bad = 1; continue; } // (also what check_spans_kernel looks for)
-    if (e0 - s0 > mlen) mlen = e0 - s0;
-    slen += e0 - s0;
-    if (r + 1 < n) {
-      const uint64_t s1 = starts[r + 1];
-      if (s1 < e0 && !(allow_overlap && s1 >= s0 && ends[r + 1] >= e0)) bad = 1; // not in order, or overlapping
-      else if (s1 - s0 > mpitch) mpitch = s1 - s0;
+  const uint32_t lane = threadIdx.x & 63u;
+  // (whole waves iterate together: the segmented scan below needs every lane of a wave in the loop)
+  for (uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); r0 < n; r0 += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = r0 + lane;
+    uint64_t nwin = 0;
+    if (r < n) {
+      const uint64_t s0 = starts[r], e0 = ends[r];
+      if (e0 < s0 || e0 > buf_bytes) {
+        bad = 1; // (also what check_spans_kernel looks for)
+      } else {
+        if (e0 - s0 > mlen) mlen = e0 - s0;
+        slen += e0 - s0;
+        nwin = e0 - s0 >= k ? e0 - s0 - k + 1u : 0u;
+        if (r + 1 < n) {
+          const uint64_t s1 = starts[r + 1];
+          if (s1 < e0 && !(allow_overlap && s1 >= s0 && ends[r + 1] >= e0)) bad = 1; // not in order, or overlapping
+          else if (s1 - s0 > mpitch) mpitch = s1 - s0;
+        }
+      }
+    }
+    if (tile_sum) {
+      uint64_t incl = nwin;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), d, 64) << 32) |
+                           (uint32_t)__shfl_up((int)(uint32_t)incl, d, 64);
+        if ((int)lane >= d) incl += o;
+      }
+      const uint32_t in_tile = (uint32_t)(r % R);                     // place of the read in its tile
+      const uint32_t seg0 = in_tile <= lane ? lane - in_tile : 0u;     // first lane of the tile's part in this wave
+      const uint32_t src = seg0 ? seg0 - 1u : 0u;
+      const uint64_t before_all = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(incl >> 32), (int)src, 64) << 32) |
+                                  (uint32_t)__shfl((int)(uint32_t)incl, (int)src, 64);
+      const uint64_t before = seg0 ? before_all : 0;
+      const bool last = r < n && (in_tile == R - 1u || lane == 63u || r == n - 1u);
+      if (last && incl != before) atomicAdd(&tile_sum[r / R], (unsigned long long)(incl - before));
     }
   }
   // wave-level reduction, then one atomic per wave

@@ -1272,6 +1272,68 @@ def test_fastx_index_and_spans_vs_python_parser(ctx, oracle, fmt, crlf, cut):
         ctx.free(d)
 
 
+@pytest.mark.parametrize("k,m,n,lo,hi,bad_frac", [(31, 1, 5000, 20, 400, 0.002), (31, 2, 3000, 100, 151, 0.0), (21, 1, 4000, 1, 90, 0.01),
+                                                   (64, 3, 1500, 60, 300, 0.001), (100, 1, 800, 90, 500, 0.002), (25, 1, 64, 150, 151, 0.05)])
+def test_kmer_read_slots_contract_vs_oracle(ctx, oracle, k, m, n, lo, hi, bad_frac):
+    """NTHIP_OUT_READ_SLOTS: one pass over the bases -- read r's k-mers at the front of the slot its LENGTH implies, the
+    exact count in counts[r], zeros behind, *total = every window of every read -- through the offsets entry (reads back
+    to back) and the spans entry (sequence lines of a FASTQ text: headers and qualities between the reads, never bases);
+    reads with non-bases, reads shorter than k, empty reads; positions"""
+    import nthash_amd
+    from nthash_amd.capi import NTHIP_OUT_READ_SLOTS
+    rng = np.random.default_rng(k * 7 + n)
+    buf, seqs = _make_fastx(rng, n, 4, False, lo=lo, hi=hi, bad_frac=bad_frac)
+    seqs[n // 3] = b""
+    data, offs = concat_reads(seqs)
+    want = oracle.kmer_batch(data, offs, k, m)
+    lens = np.diff(offs.astype(np.int64))
+    nwin = np.maximum(lens - k + 1, 0)
+    slot = np.concatenate([[0], np.cumsum(nwin)])
+    w_off = np.concatenate([[0], np.cumsum(want["counts"].astype(np.int64))])
+
+    def check(got_h, got_c, got_p, total):
+        assert total == slot[-1]
+        assert (got_c == want["counts"]).all()
+        got_h = got_h.reshape(-1, m)
+        for r in range(n):
+            c = int(want["counts"][r])
+            a = int(slot[r])
+            assert (got_h[a:a + c] == want["hashes"][w_off[r]:w_off[r] + c]).all(), r
+            assert (got_p[a:a + c] == want["pos"][w_off[r]:w_off[r] + c]).all(), r
+            assert (got_h[a + c:int(slot[r + 1])] == 0).all(), r
+
+    cap = int(slot[-1])
+    h, c_, p_ = np.zeros(max(cap, 1) * m, np.uint64), np.zeros(n, np.uint64), np.zeros(max(cap, 1), np.uint32)
+    flags = nthash_amd.capi.NTHIP_HOST_INPUT | nthash_amd.capi.NTHIP_HOST_OUTPUT | NTHIP_OUT_READ_SLOTS
+    total = ctx.kmer_hash_ptr(data.ctypes.data, offs.ctypes.data, n, 0, 0, k, m, h.ctypes.data, cap, counts=c_.ctypes.data,
+                              pos=p_.ctypes.data, flags=flags)
+    check(h, c_, p_, total)
+    with pytest.raises(nthash_amd.NtHipError) as ei:   # the slot array must fit
+        ctx.kmer_hash_ptr(data.ctypes.data, offs.ctypes.data, n, 0, 0, k, m, h.ctypes.data, cap - 1, counts=c_.ctypes.data, flags=flags)
+    assert ei.value.code == nthash_amd.capi.NTHIP_ERR_CAPACITY and ei.value.total == cap
+    # the same reads where they lie in the FASTQ text
+    st2 = np.zeros(n, np.uint64)
+    en2 = np.zeros(n, np.uint64)
+    at = 0
+    for r, sq in enumerate(seqs):
+        at = buf.index(b"\n", at) + 1          # past the header line
+        st2[r], en2[r] = at, at + len(sq)
+        if r == n // 3:                          # (the record whose sequence we emptied: an empty span inside its line)
+            en2[r] = at
+        for _ in range(3):
+            at = buf.index(b"\n", at) + 1
+    raw = np.frombuffer(buf, dtype=np.uint8)
+    d_buf, d_s, d_e = ctx.malloc(raw.size + 64), ctx.malloc(n * 8), ctx.malloc(n * 8)
+    d_h, d_c, d_p = ctx.malloc(max(cap, 1) * m * 8), ctx.malloc(n * 8), ctx.malloc(max(cap, 1) * 4)
+    ctx.h2d(d_buf, raw); ctx.h2d(d_s, st2); ctx.h2d(d_e, en2)
+    total = ctx.kmer_hash_spans_ptr(d_buf, raw.size, d_s, d_e, n, k, m, d_h, cap, counts=d_c, pos=d_p, flags=NTHIP_OUT_READ_SLOTS)
+    h2, c2, p2 = np.zeros(max(cap, 1) * m, np.uint64), np.zeros(n, np.uint64), np.zeros(max(cap, 1), np.uint32)
+    ctx.d2h(h2, d_h); ctx.d2h(c2, d_c); ctx.d2h(p2, d_p)
+    check(h2, c2, p2, total)
+    for d in (d_buf, d_s, d_e, d_h, d_c, d_p):
+        ctx.free(d)
+
+
 def test_fastx_index_flags_malformed_input(ctx):
     for buf, fmt in ((b"@a\nACGT\n-\nIIII\n", 4), (b"a\nACGT\n+\nIIII\n", 4), (b"@a\nAC\n+\nII\nxx\nAC\n+\nII\n", 4),
                      (b">a\nACGT\nACGT\n>b\nAC\n", 2)):
