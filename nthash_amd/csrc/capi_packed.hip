@@ -158,6 +158,7 @@ int ntamd::host::run_kmer_packed(nthip_ctx* c, const nthip_reads* rd, uint32_t k
       ra.tile_u64 = plan.tile_u64;
       ra.inv_rpr = 65536u / plan.rpr + 1u;
       ra.dword_tail = 1;
+      ra.ph_tiles = plan.ph_tiles; // (burst path: pieces of 8 consecutive tiles, one contiguous run of the code stream)
       ra.tile_map = c->tune.has_tile_map ? c->tune.tile_map : 0xFFFFFFFFu;
       memcpy(ra.tab, consts.tab, sizeof ra.tab);
       memcpy(ra.mult, consts.mult, sizeof ra.mult);

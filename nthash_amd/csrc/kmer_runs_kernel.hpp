@@ -485,11 +485,88 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
 #ifndef KR_BURST
 #define KR_BURST 8
 #endif
-  constexpr bool KR_BURST_OK = !KR_CHUNKED && DT && !PK && C_T != 0 && NST == 8u;
+  constexpr bool KR_BURST_OK = !KR_CHUNKED && DT && C_T != 0 && NST == 8u;
   if constexpr (KR_BURST_OK) {
     if (a.ph_tiles == (uint32_t)KR_BURST) {
       constexpr uint32_t P = KR_BURST;
       static_assert(P * NST >= 64u, "the counted wait of the burst path needs 64 stores per piece");
+      if constexpr (PK) {
+        // packed input: the piece's P slabs are ONE contiguous run of the code stream (P x 1200 bases = 601 dwords for
+        // config 2), loaded with PKR dword loads per lane and kept as ONE bit stream in LDS -- tile q of the piece
+        // starts q tiles' worth of bases further into it; nothing is packed or judged
+        constexpr uint32_t PKR = 12; // dwords per lane: 768 x 16 bases >= a piece of 8 dword-tail slabs (8 x 1280 + 15 bases)
+        const uint32_t reads_per_tile = 64u / a.rpr;
+        const uint64_t tile_bases = (uint64_t)reads_per_tile * a.stride;
+        uint64_t sgrp = grp_w;
+        uint64_t pt = grp_t0 + sgrp * P;
+        uint32_t pk[PKR];
+        auto piece_dwords = [&](const uint64_t t0) -> uint32_t { // dwords of the piece's stream (bases of its tiles' reads)
+          const uint64_t t_last = t0 + P <= wt_end ? t0 + P - 1u : wt_end - 1u;
+          const uint64_t reads_end = (t_last + 1u) * reads_per_tile < a.n_reads ? (t_last + 1u) * reads_per_tile : a.n_reads;
+          const uint64_t first_base = t0 * tile_bases, end_base = (reads_end - 1u) * a.stride + a.len;
+          return (uint32_t)(((first_base & 15u) + (end_base - first_base) + 15u) >> 4);
+        };
+        auto issue_piece = [&](const uint64_t t0) {
+          const uint64_t first_base = t0 * tile_bases;
+          const uint32_t* codes = (const uint32_t*)a.seqs + (first_base >> 4);
+          const uint32_t n_dw = piece_dwords(t0);
+#pragma unroll
+          for (uint32_t r = 0; r < PKR; ++r) {
+            const uint32_t i = r * 64u + lane;
+            const uint32_t* q = codes + (i < n_dw ? i : 0u);
+            asm volatile("global_load_dword %0, %1, off nt" : "=&v"(pk[r]) : "v"(q) : "memory");
+          }
+        };
+        auto store_piece = [&](const uint64_t t0) {
+          const uint32_t n_dw = piece_dwords(t0);
+#pragma unroll
+          for (uint32_t r = 0; r < PKR; ++r) {
+            const uint32_t i = r * 64u + lane;
+            if (i < n_dw) bits[i] = pk[r];
+          }
+          if (lane < (uint32_t)NW + 3u) bits[n_dw + lane] = 0;
+        };
+#define KR_PK_MARK() \
+        asm volatile("; NTLINT_CONSUME %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11" \
+                     : "+v"(pk[0]), "+v"(pk[1]), "+v"(pk[2]), "+v"(pk[3]), "+v"(pk[4]), "+v"(pk[5]), "+v"(pk[6]), "+v"(pk[7]), \
+                       "+v"(pk[8]), "+v"(pk[9]), "+v"(pk[10]), "+v"(pk[11])::"memory")
+        static_assert(PKR == 12u, "the marker above lists 12 registers");
+        if (pt < wt_end) {
+          issue_piece(pt);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          KR_PK_MARK();
+          store_piece(pt);
+        }
+        while (pt < wt_end) {
+          const uint64_t left = wt_end - pt;
+          const uint32_t n_here = left < P ? (uint32_t)left : P;
+          const uint64_t npt = grp_t0 + (sgrp + wstride) * P;
+          const bool have_next = npt < wt_end;
+          issue_piece(have_next ? npt : pt);
+          bool all_full = n_here == P;
+          const uint32_t shift0 = (uint32_t)((pt * tile_bases) & 15u);
+          for (uint32_t q = 0; q < n_here; ++q) {
+            const uint64_t t = pt + q;
+            const uint64_t g0 = t * 64u;
+            const uint64_t runs_left = a.n_runs - g0;
+            const uint32_t runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
+            lds_sync();
+            hash_tile(shift0 + q * (uint32_t)tile_bases, runs_here, 0u);
+            NT_LINT_SELFTEST_TOUCH(pk[0]);
+            (void)copy_out(g0, runs_here);
+            all_full = all_full && runs_here == 64u;
+            lds_sync(); // the tile is free again
+          }
+          asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+          if (!all_full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          KR_PK_MARK();
+          sgrp += wstride;
+          pt = npt;
+          if (have_next) store_piece(pt);
+        }
+#undef KR_PK_MARK
+        return;
+      }
       uint32_t* const bits0 = bits;
       const uint32_t reads_per_tile = 64u / a.rpr;
       const uint64_t tile_bytes = (uint64_t)reads_per_tile * a.stride;
