@@ -281,7 +281,9 @@ class Workload:
         budget = int(free_b * 0.85) - n_reads * L
         chunk = chunk_reads or min(n_reads, max(1, budget // out_bytes_per_read))
         chunk = min(chunk, n_reads)
-        if chunk < n_reads:  # keep chunks a multiple of the kernels' read tiles
+        if chunk < n_reads and (n_reads % chunk or not chunk_reads):
+            # keep chunks a multiple of the kernels' read tiles -- unless the caller named an exact divisor of the job
+            # (equal launches: what a per-kernel profile of one config wants, see tools/profile_round.sh)
             chunk = max(256, chunk // 256 * 256)
         self.chunk = chunk
         self.n_chunks = (n_reads + chunk - 1) // chunk

@@ -227,7 +227,7 @@ int check_reads(const nthip_reads* rd)
 // ==========================================================================
 // library / context
 // ==========================================================================
-extern "C" const char* nthip_version(void) { return "nthash_amd 0.2 (gfx950; ntHash_v2 bit-exact)"; }
+extern "C" const char* nthip_version(void) { return "nthash_amd 0.3 (gfx950; ntHash_v2 bit-exact)"; }
 extern "C" const char* nthip_last_error(void) { return g_err.c_str(); }
 
 namespace {
@@ -278,6 +278,7 @@ void load_tuning(nthip_tune& t)
   t.ph_period = num("NTHIP_TUNE_PH_PERIOD", 1, 10000000);
   t.ph_read = num("NTHIP_TUNE_PH_READ", 1, 10000000);
   t.fw = num("NTHIP_TUNE_FW", 1, 2);
+  t.seed_any = num("NTHIP_TUNE_SEED_ANY", 1, 2);
   const uint32_t tk = num("NTHIP_TUNE_TABLE_K_MAX", 16, 64);
   ntamd::host::g_kmer_table_k_max = tk ? tk : (uint32_t)KMER_TABLE_K_MAX_N;
 }

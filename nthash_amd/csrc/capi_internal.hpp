@@ -98,6 +98,7 @@ struct nthip_tune {
   uint32_t ph_tiles = 0;    // NTHIP_TUNE_PH_TILES
   uint32_t ph_period = 0;   // NTHIP_TUNE_PH_PERIOD
   uint32_t ph_read = 0;     // NTHIP_TUNE_PH_READ
+  uint32_t seed_any = 0;    // NTHIP_TUNE_SEED_ANY=1: dense seed batches on the any-seed form whatever the seed set, 2: none of k <= 128 (A/B, tests)
   uint32_t fw = 0;          // NTHIP_TUNE_FW: first window beyond the position tables -- 1 grouped, 2 prefix scan (0: cost model)
 };
 
@@ -164,6 +165,11 @@ struct nthip_seeds {
   uint32_t* d_blk_start = nullptr;
   uint32_t* d_blk_count = nullptr;
   uint32_t* d_blk_pairs = nullptr;
+  // the any-seed form of seed_wtile_kernel (NH == 0): per seed and 16-base group of the window, the care positions as a
+  // 2-bit-per-base mask and the code-0 contribution of the others (first_window.hpp's tables)
+  uint32_t any_groups = 0;
+  uint32_t* d_any_mask = nullptr;
+  uint4* d_any_acorr = nullptr;
 };
 
 namespace ntamd {

@@ -43,6 +43,27 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
     build_byte_tables(k, par.data(), tables.data() + (size_t)s * ntab * 256);
   }
   if (blk_pairs.empty()) blk_pairs.push_back(0);
+  // the any-seed form: care masks and code-0 corrections per 16-base group (first_window.hpp: position u of a word
+  // contributes sror^{u+1}(S[c]) / srol^{u}(S[~c]))
+  const uint32_t G = (k + 15) / 16;
+  std::vector<uint32_t> any_mask((size_t)n_seeds * G, 0);
+  std::vector<uint4> any_acorr((size_t)n_seeds * G, make_uint4(0, 0, 0, 0));
+  for (uint32_t s = 0; s < n_seeds; ++s)
+    for (uint32_t g = 0; g < G; ++g) {
+      uint64_t f = 0, r = 0;
+      uint32_t mask = 0;
+      for (uint32_t u = 0; u < 16; ++u) {
+        const uint32_t p = 16 * g + u;
+        if (p < k && ((care[(size_t)s * cw + (p >> 5)] >> (p & 31)) & 1u)) {
+          mask |= 3u << (2 * u);
+        } else {
+          f ^= srol_n(seed_of_code(0), 1023u - (u + 1u));
+          r ^= srol_n(seed_of_code(2), u);
+        }
+      }
+      any_mask[(size_t)s * G + g] = mask;
+      any_acorr[(size_t)s * G + g] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+    }
   nthip_seeds* sd = new nthip_seeds();
   sd->ctx = c;
   sd->device = c->device;
@@ -61,6 +82,9 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
   if (rc == NTHIP_OK) rc = up(blk_start.data(), blk_start.size() * 4, (void**)&sd->d_blk_start);
   if (rc == NTHIP_OK) rc = up(blk_count.data(), blk_count.size() * 4, (void**)&sd->d_blk_count);
   if (rc == NTHIP_OK) rc = up(blk_pairs.data(), blk_pairs.size() * 4, (void**)&sd->d_blk_pairs);
+  sd->any_groups = G;
+  if (rc == NTHIP_OK) rc = up(any_mask.data(), any_mask.size() * 4, (void**)&sd->d_any_mask);
+  if (rc == NTHIP_OK) rc = up(any_acorr.data(), any_acorr.size() * sizeof(uint4), (void**)&sd->d_any_acorr);
   if (rc != NTHIP_OK) {
     nthip_seeds_destroy(sd);
     return rc;
@@ -79,6 +103,8 @@ extern "C" int nthip_seeds_destroy(nthip_seeds* sd)
   if (sd->d_blk_start) (void)hipFree(sd->d_blk_start);
   if (sd->d_blk_count) (void)hipFree(sd->d_blk_count);
   if (sd->d_blk_pairs) (void)hipFree(sd->d_blk_pairs);
+  if (sd->d_any_mask) (void)hipFree(sd->d_any_mask);
+  if (sd->d_any_acorr) (void)hipFree(sd->d_any_acorr);
   delete sd;
   return NTHIP_OK;
 }
@@ -494,7 +520,8 @@ int ntamd::host::run_seed_general(nthip_ctx* c, const Staged& st, const nthip_re
 namespace {
 
 // seed_wtile_kernel: plan (reads per wave tile, LDS) + launch; *ran = false when the shape is outside it
-int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, uint32_t nh, bool* ran)
+int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, uint32_t nh, bool* ran,
+                      bool* prefer_any = nullptr)
 {
   *ran = false;
   if (c->tune.no_seed_wtile) return NTHIP_OK;
@@ -557,6 +584,22 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
     while (most > 1 && waves_for(plain_bytes(most), most) == 0) --most;
     const uint32_t passes = (f.n_seeds + most - 1) / most;
     pass_seeds = (f.n_seeds + passes - 1) / passes;
+    // a seed set that needs several passes here is ONE pass in the any-seed form (whole records; k / 16 table words per
+    // seed and window instead of one table byte per 8 bases).  Picoseconds per k-mer, fitted on tools/seed_sweep.py
+    // (profiles/r03_seed_any_sweep.txt, 14 multi-pass shapes, every one within 15 %): the passes are bound by their
+    // partial-record writes (1.25 TB/s: 6.4 ps per hash) or their table lookups (0.85 ps per seed and table), the any
+    // form by its arithmetic (2.1 ps per seed and group of 16 bases).  6 seeds of 31: 25.6 -> 38.1 G k-mers/s; 5 x 2: 15.1
+    // -> 37.6; 2 x 2 of 80 bases: 38.2 -> 46.7; 4 seeds of 64 and 2 of 100 stay on the passes (37.2 / 30.5, 51.1 / 40.4)
+    if (passes > 1 && prefer_any) {
+      const double per_h = (double)f.n_seeds * f.m2;
+      const double t_lookups = 0.85 * f.n_seeds * ((f.k + 7) / 8);
+      const double t_pass = 6.4 * per_h > t_lookups ? 6.4 * per_h : t_lookups;
+      const double t_any = 2.1 * f.n_seeds * ((f.k + 15) / 16) + 0.5 * per_h;
+      if (t_any < t_pass) {
+        *prefer_any = true;
+        return NTHIP_OK;
+      }
+    }
   }
   const size_t table_bytes = rot ? (size_t)65536 * ((pass_seeds + 1) / 2) : (size_t)pass_seeds * 2 * nh * 256 * sizeof(uint4);
   const uint32_t waves = waves_for(table_bytes, pass_seeds);
@@ -650,6 +693,68 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
 #undef NT_SW
     NTCHK(rc);
   }
+  *ran = true;
+  return NTHIP_OK;
+}
+
+// the any-seed form (seed_wtile_kernel<0>): ONE pass over all the seeds whatever their number and length
+int launch_seed_any(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, bool* ran)
+{
+  *ran = false;
+  const uint32_t per = f.n_seeds * f.m2;
+  uint32_t R = 4096u / f.stride;
+  if (R < 1) R = 1;
+  const uint64_t slab = 15ull + (uint64_t)(R - 1) * f.stride + f.len;
+  if (slab > SW_MAX_VEC_ROUNDS * 1024ull || (uint64_t)R * f.nwin >= 0x7FFFFFFFull) return NTHIP_OK;
+  const uint32_t bits_dwords = (uint32_t)((((slab + 15) >> 4) + 8 + 3) & ~3ull);
+  const uint32_t n_grp = f.n_seeds * sd->any_groups;
+  const size_t table_bytes = ((size_t)FW_AC + 16 + n_grp + ((n_grp + 3) >> 2)) * sizeof(uint4);
+  const size_t per_wave = (size_t)(64 * per + 2) * 8 + (size_t)bits_dwords * 4;
+  const size_t cap = lds_cap_of(c);
+  uint32_t waves = 0;
+  for (uint32_t w = 16; w >= 1; --w)
+    if (table_bytes + per_wave * w <= cap) { waves = w; break; }
+  if (!waves) return NTHIP_OK;
+  const uint4* fw = nullptr;
+  NTCHK(get_fw_tab(c, &fw));
+  SeedWtileArgs a;
+  memset(&a, 0, sizeof a);
+  a.seqs = f.seqs;
+  a.hashes = f.hashes;
+  a.dirty = f.dirty;
+  a.tables = fw;
+  a.n_reads = f.n_runs;
+  a.n_tiles = (f.n_runs + R - 1) / R;
+  a.len = f.len;
+  a.stride = f.stride;
+  a.k = f.k;
+  a.m2 = f.m2;
+  a.n_seeds = f.n_seeds;
+  a.ntab = f.ntab;
+  a.nwin = f.nwin;
+  a.reads_per_tile = R;
+  a.inv_nwin = f.inv_nwin;
+  a.bits_dwords = bits_dwords;
+  a.waves = waves;
+  a.groups = c->tune.has_tile_map ? c->tune.tile_map : 32u;
+  uint32_t g = per, h = 16;
+  while (h) { const uint32_t t2 = g % h; g = h; h = t2; } // gcd(per, 16)
+  a.align_recs = c->tune.no_seed_align ? 1u : 16u / g;
+  a.any_mask = sd->d_any_mask;
+  a.any_acorr = sd->d_any_acorr;
+  a.any_groups = sd->any_groups;
+  memcpy(a.mult, f.mult, sizeof a.mult);
+  const size_t lds = table_bytes + per_wave * waves;
+  auto kernel = seed_wtile_kernel<0, 0, 0, false>;
+  int per_cu = 1;
+  NTCHK(blocks_per_cu(c, kernel, (int)waves * 64, lds, &per_cu));
+  const uint64_t need = (a.n_tiles + waves - 1) / waves;
+  uint64_t grid = (uint64_t)c->n_cu * per_cu;
+  if (grid > need) grid = need;
+  prof_begin(c, "seed_wtile_kernel(any seed set)");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream, a);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
   *ran = true;
   return NTHIP_OK;
 }
@@ -840,7 +945,7 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
     }
     done = true;
   } else if (!rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.fwd && !st.rev && m2 <= (uint32_t)SF_MAX_RUNTIME_M &&
-             k <= 128 && stride <= len && (len < SEED_LONG_DENSE_MAX || k > 64 || c->tune.no_seed_long)) {
+             stride <= len && (len < SEED_LONG_DENSE_MAX || k > 64 || c->tune.no_seed_long)) {
     // (reads of 128 Ki bases and more go to the pieces below even when clean: the block-tile kernel keeps the whole read's
     //  bit stream in LDS and stops fitting near 400 kbase.  Whole calls, 4 GiB of records, tools/seed_long_wholecall.py:
     //  40 kbase dense 83 G k-mers/s / pieces 77 G; 100 kbase 79 / 81; 300 kbase 7.6 (one wave per read) / 79)
@@ -909,8 +1014,17 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
              : launch_seed_fixed(c, seed_fixed_kernel<8, SPLIT_T>, a, DYN))
       // clean batches (the optimistic pass): one wave per tile of reads, no block barriers (seed_wtile_kernel);
       // shapes outside it (slabs of more than 8 KiB per tile, LDS) keep the block-tile kernel
+      // seeds beyond 128 bases have no position tables at all: the any-seed form (k-independent tables, one pass);
+      // NTHIP_TUNE_SEED_ANY=1 sends every dense batch there, =2 none of k <= 128 (A/B, tests)
       bool wtile_ran = false;
-      NTCHK(launch_seed_wtile(c, a, sd, nh, &wtile_ran));
+      bool prefer_any = false;
+      if (k > 128 || c->tune.seed_any == 1) NTCHK(launch_seed_any(c, a, sd, &wtile_ran));
+      if (!wtile_ran && k <= 128)
+        NTCHK(launch_seed_wtile(c, a, sd, nh, &wtile_ran, c->tune.seed_any == 2 ? nullptr : &prefer_any));
+      if (!wtile_ran && prefer_any) { // (a seed set of several position-table passes)
+        NTCHK(launch_seed_any(c, a, sd, &wtile_ran));
+        if (!wtile_ran) NTCHK(launch_seed_wtile(c, a, sd, nh, &wtile_ran));
+      }
       if (!wtile_ran && block_fits) {
         rc = NT_SEED_FIXED(false, dyn);
         NTCHK(rc);

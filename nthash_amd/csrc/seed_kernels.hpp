@@ -337,6 +337,12 @@ struct SeedWtileArgs {
   // rec_stride values per window (0: the pass writes whole records), this pass's values from rec_off on
   uint32_t rec_stride, rec_off;
   uint64_t mult[SF_MAX_RUNTIME_M];
+  // NH == 0 (any seed set, any k; round 3): tables = the k-independent fw tables of first_window.hpp; per seed and
+  // 16-base group of the window: the care positions as a 2-bit-per-base mask, and what the OTHER positions of the group
+  // contribute when they read as code 0 (XOR-ed off again)
+  const uint32_t* any_mask;  // [n_seeds][any_groups]
+  const uint4* any_acorr;    // [n_seeds][any_groups]
+  uint32_t any_groups, pad_any;
 };
 
 constexpr uint32_t SW_MAX_VEC_ROUNDS = 8; // a tile's slab: at most 8 x 64 vectors of 16 bytes (8 KiB of reads)
@@ -358,11 +364,19 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
   constexpr bool ROT = RNS > 0;
   static_assert(!ROT || (NH == 4 && RNS <= 4 && RM2 >= 1 && RM2 <= 4), "rotated-slot layout: k <= 32, <= 4 seeds");
   constexpr uint32_t NSETS = ROT ? (uint32_t)(RNS + 1) / 2u : 0u; // table sets of 64 KiB: seeds {0, 1}, {2, 3}
+  // ANY (NH == 0; round 3): any seed set of any k from the k-independent fw tables (first_window.hpp, 16 KiB whatever the
+  // seeds are): a window's g-th 16-base group is one funnel-shifted word of the bit stream AND-ed with the seed's care
+  // mask -- the positions masked out then read as code 0, whose contribution is a per-(seed, group) constant XOR-ed off
+  // again --, its masked 16-mer hash four lookups, the groups chained with constant rotates by 16 as in the grouped first
+  // window.  ~46 VALU per seed and 16 bases of k against ~12 on the position tables -- but ONE pass writing whole records
+  // however many seeds there are, 16 waves, and no limit on k.
+  constexpr bool ANY = NH == 0;
+  static_assert(!ANY || (!ROT && !SUB), "the any-seed form is one pass over all the seeds");
   // PF: the next tile's slab travels in registers behind hidden loads.  Only while the kernel does not spill: a spilled
   // register of a load hipcc cannot see is saved before the load has landed (k > 32: 2 * NH lookups of 16 bytes in flight
   // take the registers; nthash_amd/build.py refuses a build in which a kernel with hidden loads spills)
   constexpr bool PF = NH <= 4 && !SUB;
-  constexpr int NW = (NH + 1) / 2; // 32-bit words of window kept in registers
+  constexpr int NW = ANY ? 1 : (NH + 1) / 2; // 32-bit words of window kept in registers
   constexpr uint32_t NT = 2u * NH; // byte tables per seed in LDS
   extern __shared__ __attribute__((aligned(256))) uint32_t lds_dyn[];
   const uint32_t tid = threadIdx.x;
@@ -370,13 +384,23 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // layout: [tables: n_seeds*NT*256 uint4 (ROT: 16*256)][per wave: output tile 64*per+2 u64 | bit stream]
   uint4* tabs = (uint4*)lds_dyn;
-  const uint32_t n_entries = ROT ? 4096u * NSETS : a.n_seeds * NT * 256u;
+  // (ANY: the fw tables up to the AC entries, then the seeds' group constants, then their masks)
+  const uint32_t n_grp = ANY ? a.n_seeds * a.any_groups : 0u;
+  const uint32_t n_entries = ANY ? FW_AC + 16u + n_grp + ((n_grp + 3u) >> 2) : ROT ? 4096u * NSETS : a.n_seeds * NT * 256u;
+  const uint4* g_acorr = tabs + FW_AC + 16u;
+  const uint32_t* g_mask = (const uint32_t*)(g_acorr + n_grp);
   const uint32_t per = ROT ? (uint32_t)(RNS * RM2) : a.n_seeds * a.m2; // values per window
   const uint32_t otile_u64 = 64u * per + 2u;
   uint32_t* wbase = lds_dyn + n_entries * 4u + wave * (otile_u64 * 2u + a.bits_dwords);
   uint64_t* otile = (uint64_t*)wbase;
   uint32_t* bits = wbase + otile_u64 * 2u;
-  if constexpr (ROT) {
+  if constexpr (ANY) {
+    for (uint32_t i = tid; i < FW_AC + 16u; i += blockDim.x) tabs[i] = a.tables[i];
+    for (uint32_t i = tid; i < n_grp; i += blockDim.x) {
+      tabs[FW_AC + 16u + i] = a.any_acorr[i];
+      ((uint32_t*)(tabs + FW_AC + 16u + n_grp))[i] = a.any_mask[i];
+    }
+  } else if constexpr (ROT) {
     for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
       const uint32_t set = i >> 12, ii = i & 4095u;
       const uint32_t in_set = (uint32_t)RNS - 2u * set < 2u ? (uint32_t)RNS - 2u * set : 2u; // seeds of this set
@@ -510,12 +534,16 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
       const uint32_t b = cur.shift + lr * a.stride + p; // first base of the window (stream index)
       const uint32_t d = b >> 4, sh = (b & 15u) << 1;
       uint32_t w[NW];
-      uint32_t lo = bits[d];
+      if constexpr (!ANY) {
+        uint32_t lo = bits[d];
 #pragma unroll
-      for (int i = 0; i < NW; ++i) {
-        const uint32_t hi = bits[d + i + 1];
-        w[i] = funnel(hi, lo, sh);
-        lo = hi;
+        for (int i = 0; i < NW; ++i) {
+          const uint32_t hi = bits[d + i + 1];
+          w[i] = funnel(hi, lo, sh);
+          lo = hi;
+        }
+      } else {
+        w[0] = 0;
       }
       // the 64 records are built shifted by the parity of their place in the stream: 16-byte aligned LDS reads and stores
       uint64_t* const dst = a.hashes + (rec0 + q0) * per;
@@ -532,7 +560,25 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
 #endif
       for (uint32_t s = 0; s < per; ++s) mine[s] = w[0] + s;
 #else
-      if constexpr (ROT) {
+      if constexpr (ANY) {
+        const uint32_t G = a.any_groups, k31 = a.k % 31u, k33 = a.k % 33u;
+        for (uint32_t s = 0; s < a.n_seeds; ++s) {
+          uint4 acc = make_uint4(0, 0, 0, 0);
+          for (uint32_t g = G; g-- > 0;) {
+            const uint32_t word = funnel(bits[d + g + 1u], bits[d + g], sh) & g_mask[s * G + g];
+            const uint4 e = fw_word16(tabs, word), ac = g_acorr[s * G + g];
+            sror_var(acc.x, acc.y, 16u, 16u);
+            srol_var(acc.z, acc.w, 16u, 16u);
+            acc.x ^= e.x ^ ac.x; acc.y ^= e.y ^ ac.y; acc.z ^= e.z ^ ac.z; acc.w ^= e.w ^ ac.w;
+          }
+          srol_var(acc.x, acc.y, k31, k33);
+          const uint64_t h0 = canon_pair(acc.x, acc.y, acc.z, acc.w);
+          mine[s * a.m2] = h0;
+#pragma unroll
+          for (uint32_t jj = 1; jj < (uint32_t)SF_MAX_RUNTIME_M; ++jj)
+            if (jj < a.m2) mine[s * a.m2 + jj] = mix_hash(h0, a.mult[jj]);
+        }
+      } else if constexpr (ROT) {
         uint32_t ad[8];
 #pragma unroll
         for (uint32_t st = 0; st < 8; ++st) ad[st] = __builtin_amdgcn_perm(w[1], w[0], rsel[st]) + roff[st];
