@@ -55,6 +55,7 @@ parse_seeds(const std::vector<std::string>& seed_strings);
 
 namespace detail {
 struct KmerStream; // device-computed hash stream of one window of a sequence (opaque)
+struct KmerAhead;  // the NEXT window's stream, being computed on the thread's helper while this one is walked
 struct RollTables; // per k: what a byte adds when it enters / leaves a window (host recurrences)
 struct SeedStream;
 struct SeedSet;    // parsed seeds: blocks, monomers, masks (host) + device tables
@@ -82,7 +83,24 @@ public:
   NtHash(NtHash&&) noexcept;
   ~NtHash();
 
-  bool roll();
+  bool roll()
+  {
+    // The walk through a device-computed window, inline: when the stream's next entry IS the next position, that window
+    // holds bases only (the stream holds nothing else: reference NtHash::roll, src/kmer.cpp:246-264, would roll into it)
+    // and its hashes are the entry's.  Everything else -- the first call, a skip, the end of a window, an object whose
+    // strand hashes somebody reads -- takes the general routine.
+    const size_t i = cursor_ + 1;
+    if (sp_ != nullptr && i < sn_ && sp_[i] == pos_ + 1 - sbegin_ && !strands_wanted_) {
+      cursor_ = i;
+      ++pos_;
+      const uint64_t* h = sh_ + i * num_hashes_;
+      uint64_t* out = hash_arr_.get();
+      for (unsigned j = 0; j < num_hashes_; ++j) out[j] = h[j];
+      strands_stale_ = true;
+      return true;
+    }
+    return roll_general();
+  }
   bool roll_back();
   bool peek();
   bool peek_back();
@@ -116,9 +134,16 @@ private:
   const detail::RollTables* rt_ = nullptr;     // process-wide, immutable
   std::shared_ptr<detail::KmerStream> stream_; // shared by copies, immutable once built
   size_t cursor_ = 0;                          // last stream entry used (search hint)
+  std::shared_ptr<detail::KmerAhead> ahead_;   // (not copied: a copy starts its own)
+  // views into *stream_ for the inline walk of roll(): positions (relative to sbegin_), hashes, entries
+  const uint32_t* sp_ = nullptr;
+  const uint64_t* sh_ = nullptr;
+  size_t sn_ = 0, sbegin_ = 0;
 
   bool init();
+  bool roll_general();
   bool load_from_stream();
+  void next_stream();
 };
 
 // ---------------------------------------------------------------------------

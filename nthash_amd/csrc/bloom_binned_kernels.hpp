@@ -1,0 +1,260 @@
+// bloom_binned_kernels.hpp -- Bloom-filter insert that is not bound by device atomics.
+//
+// What the reference's callers do with hashes() (btllib Bloom filters, include/nthash/nthash.hpp:14-17, 56-57 of the
+// reference): every value sets bit `h mod n_bits`.  Scattered 4-byte atomics retire at ~27 G/s on MI355X whatever the
+// scope or the filter size (tools/bench_micro/atomics.hip) -- 4 % of the rate the hashes are produced at.  Here the
+// values of a batch are brought to the filter region by region instead:
+//
+//   region   2^20 bits of the filter = 128 KiB: what one workgroup keeps in LDS
+//   bin      128 consecutive regions = 2^27 bits
+//
+//   hist     one pass over the values: how many fall in every region (LDS counters, one flush per block)
+//   scan     region bases (exclusive scan), bin bases = every 128th of them; cursors start there
+//   part 1   values -> 27-bit offsets, bin by bin          (tiles of 8192 values sorted by bin in LDS, whole runs out)
+//   part 2   bin by bin: offsets -> 20-bit offsets, region by region   (the same kernel on 4-byte input)
+//   apply    a workgroup per region: its offsets into a zeroed 128 KiB of LDS (ds_or), then the lines of the filter
+//            that got a bit are read, OR-ed and written back -- plain loads and stores, the region has one owner
+//
+// Every byte moves in whole runs: 8 + (8 + 4) + (4 + 4) + 4 B per value plus one read-modify-write of the touched
+// filter lines per batch.  Exact counts: no capacity guesses, no overflow path, repeated values (low-complexity
+// sequence) only make one region's list longer.  Filters of at most 2^35 bits (32768 regions: the histogram's LDS);
+// larger ones and batches too small to amortise the filter pass keep the atomic kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "bloom_math.hpp"
+
+namespace ntamd {
+
+typedef uint32_t bb_v4u __attribute__((ext_vector_type(4)));
+typedef uint64_t bb_v2ul __attribute__((ext_vector_type(2)));
+
+constexpr uint32_t BB_REGION_SHIFT = 20;            // bits of the filter per region: 2^20 = 128 KiB
+constexpr uint32_t BB_BIN_SHIFT = 27;               // ... per bin: 128 regions
+constexpr uint32_t BB_REGIONS_PER_BIN = 1u << (BB_BIN_SHIFT - BB_REGION_SHIFT);
+constexpr uint32_t BB_MAX_REGIONS = 32768;          // 2^35 bits
+constexpr uint32_t BB_MAX_BINS = 256;
+constexpr uint32_t BB_PART_THREADS = 512;
+constexpr uint32_t BB_PART_ITEMS = 16;              // values per thread and tile
+constexpr uint32_t BB_TILE = BB_PART_THREADS * BB_PART_ITEMS;
+constexpr uint32_t BB_APPLY_THREADS = 1024;
+constexpr uint32_t BB_REGION_DWORDS = 1u << (BB_REGION_SHIFT - 5);
+
+// ---- hist: values per region ---------------------------------------------------------------------------------------
+// dynamic LDS: n_regions counters.  counts[r] += ...; every block flushes the counters it touched.
+static __global__ __launch_bounds__(1024) void bloom_hist_kernel(const uint64_t* __restrict__ hashes, uint64_t n, uint64_t n_bits,
+                                                                 uint64_t magic, uint32_t n_regions,
+                                                                 uint32_t* __restrict__ counts)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t bb_lds[];
+  for (uint32_t i = threadIdx.x; i < n_regions; i += blockDim.x) bb_lds[i] = 0;
+  __syncthreads();
+  // two values per load, from the first 16-byte boundary on
+  const uint64_t head = (((uintptr_t)hashes & 8u) && n) ? 1u : 0u;
+  const uint64_t n2 = (n - head) >> 1;
+  const bb_v2ul* h2 = (const bb_v2ul*)(hashes + head);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * blockDim.x) {
+    const bb_v2ul v = __builtin_nontemporal_load(h2 + i);
+    atomicAdd(&bb_lds[(uint32_t)(mod_invariant(v.x, n_bits, magic) >> BB_REGION_SHIFT)], 1u);
+    atomicAdd(&bb_lds[(uint32_t)(mod_invariant(v.y, n_bits, magic) >> BB_REGION_SHIFT)], 1u);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (head) atomicAdd(&bb_lds[(uint32_t)(mod_invariant(hashes[0], n_bits, magic) >> BB_REGION_SHIFT)], 1u);
+    if ((n - head) & 1u) atomicAdd(&bb_lds[(uint32_t)(mod_invariant(hashes[n - 1], n_bits, magic) >> BB_REGION_SHIFT)], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n_regions; i += blockDim.x) {
+    const uint32_t v = bb_lds[i];
+    if (v) atomicAdd(&counts[i], v);
+  }
+}
+
+// ---- scan: one block.  region_base[0 .. n_regions] = exclusive scan of counts; cursors = copies of the bases ----------
+static __global__ __launch_bounds__(1024) void bloom_scan_kernel(const uint32_t* __restrict__ counts, uint32_t n_regions,
+                                                                 uint32_t* __restrict__ region_base,
+                                                                 uint32_t* __restrict__ region_cursor,
+                                                                 uint32_t* __restrict__ bin_cursor)
+{
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (n_regions + 1023u) / 1024u; // <= 32
+  const uint32_t r0 = threadIdx.x * per;
+  uint32_t sum = 0;
+  for (uint32_t i = 0; i < per; ++i)
+    if (r0 + i < n_regions) sum += counts[r0 + i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) { // Hillis-Steele over the 1024 partial sums
+    const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - sum;
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint32_t r = r0 + i;
+    if (r < n_regions) {
+      region_base[r] = run;
+      region_cursor[r] = run;
+      if ((r & (BB_REGIONS_PER_BIN - 1u)) == 0) bin_cursor[r >> (BB_BIN_SHIFT - BB_REGION_SHIFT)] = run;
+      run += counts[r];
+    }
+  }
+  if (threadIdx.x == 1023) region_base[n_regions] = part[1023];
+}
+
+// ---- part: one level of the partition --------------------------------------------------------------------------------
+// IN64: the values themselves (bit position = h mod n_bits), one segment = the whole input; otherwise 4-byte offsets,
+// segment s = bin s of the level before: [seg_base[s * seg_step], seg_base[(s + 1) * seg_step]).
+// A value's bucket is (position >> shift) inside its segment, what is written is position & mask, at the bucket's cursor.
+struct BloomPartArgs {
+  const void* in;
+  uint32_t* out;
+  const uint32_t* seg_base; // !IN64: region_base (bin s = regions [128 s, 128 s + 128))
+  uint32_t* cursor;         // per bucket, all segments: bucket b of segment s = cursor[s * buckets_per_seg + b]
+  uint64_t n;               // IN64: values
+  uint64_t n_bits, magic;
+  uint32_t n_regions;
+  uint32_t shift, mask;
+  uint32_t buckets_per_seg; // IN64: the number of buckets; !IN64: 128 (the last segment may own fewer regions)
+};
+
+template <bool IN64>
+static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(const BloomPartArgs a)
+{
+  __shared__ uint32_t hist[BB_MAX_BINS];
+  __shared__ uint32_t off[BB_MAX_BINS];
+  __shared__ uint32_t gbase[BB_MAX_BINS];
+  __shared__ uint32_t sorted[BB_TILE];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t seg = blockIdx.y;
+  uint64_t s0, s1;
+  uint32_t n_buckets;
+  if constexpr (IN64) {
+    s0 = 0;
+    s1 = a.n;
+    n_buckets = a.buckets_per_seg;
+  } else {
+    const uint32_t r0 = seg * a.buckets_per_seg;
+    const uint32_t r1 = r0 + a.buckets_per_seg < a.n_regions ? r0 + a.buckets_per_seg : a.n_regions;
+    s0 = a.seg_base[r0];
+    s1 = a.seg_base[r1];
+    n_buckets = r1 - r0;
+  }
+  uint32_t* const cursor = a.cursor + (size_t)seg * a.buckets_per_seg;
+  const uint64_t n_tiles = (s1 - s0 + BB_TILE - 1) / BB_TILE;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    if (tid < BB_MAX_BINS) hist[tid] = 0;
+    __syncthreads();
+    const uint64_t t0 = s0 + tile * BB_TILE;
+    uint32_t val[BB_PART_ITEMS], where[BB_PART_ITEMS]; // where = bucket << 16 | rank inside the tile's bucket
+#pragma unroll
+    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+      const uint64_t idx = t0 + (uint64_t)j * BB_PART_THREADS + tid;
+      where[j] = ~0u;
+      val[j] = 0;
+      if (idx < s1) {
+        uint64_t p;
+        if constexpr (IN64) p = mod_invariant(__builtin_nontemporal_load((const uint64_t*)a.in + idx), a.n_bits, a.magic);
+        else p = __builtin_nontemporal_load((const uint32_t*)a.in + idx);
+        const uint32_t b = (uint32_t)(p >> a.shift);
+        val[j] = (uint32_t)p & a.mask;
+        where[j] = (b << 16) | atomicAdd(&hist[b], 1u); // (a tile has 8192 values: the rank fits 16 bits)
+      }
+    }
+    __syncthreads();
+    if (wave == 0) { // exclusive scan of the (at most 256) bucket counts: 4 per lane
+      uint32_t c[4], s = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) {
+        c[i] = hist[lane * 4u + i];
+        s += c[i];
+      }
+      uint32_t incl = s;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += o;
+      }
+      uint32_t run = incl - s;
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) {
+        off[lane * 4u + i] = run;
+        run += c[i];
+      }
+    }
+    if (tid < n_buckets) {
+      const uint32_t c = hist[tid];
+      gbase[tid] = c ? atomicAdd(&cursor[tid], c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j)
+      if (where[j] != ~0u) sorted[off[where[j] >> 16] + (where[j] & 0xFFFFu)] = val[j];
+    __syncthreads();
+    for (uint32_t b = wave; b < n_buckets; b += BB_PART_THREADS / 64u) {
+      const uint32_t c = hist[b], o = off[b];
+      uint32_t* const dst = a.out + gbase[b];
+      for (uint32_t j = lane; j < c; j += 64u) dst[j] = sorted[o + j];
+    }
+    __syncthreads();
+  }
+}
+
+// ---- apply: a workgroup per region -----------------------------------------------------------------------------------
+// dynamic LDS: 128 KiB.  entries = 20-bit offsets of the region's values.
+static __global__ __launch_bounds__(BB_APPLY_THREADS) void bloom_apply_kernel(const uint32_t* __restrict__ entries,
+                                                                              const uint32_t* __restrict__ region_base,
+                                                                              uint32_t n_regions, uint32_t* __restrict__ filter,
+                                                                              uint64_t filter_dwords)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t bb_lds[];
+  uint4* const l4 = (uint4*)bb_lds;
+  for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+    const uint32_t e0 = region_base[r], e1 = region_base[r + 1];
+    if (e0 == e1) continue; // (uniform over the block)
+    for (uint32_t i = threadIdx.x; i < BB_REGION_DWORDS / 4u; i += BB_APPLY_THREADS) l4[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    // entries: vectors of 4 where aligned, singles at the two ends
+    const uint32_t up = (e0 + 3u) & ~3u;
+    const uint32_t a0 = up < e1 ? up : e1, a1 = e1 & ~3u;
+    auto put = [&](uint32_t e) { atomicOr(&bb_lds[e >> 5], 1u << (e & 31u)); };
+    if (threadIdx.x < a0 - e0) put(entries[e0 + threadIdx.x]);
+    if (a1 > a0) {
+      const bb_v4u* v = (const bb_v4u*)(entries + a0);
+      const uint32_t nv = (a1 - a0) >> 2;
+      for (uint32_t i = threadIdx.x; i < nv; i += BB_APPLY_THREADS) {
+        const bb_v4u q = __builtin_nontemporal_load(v + i);
+        put(q.x);
+        put(q.y);
+        put(q.z);
+        put(q.w);
+      }
+    }
+    if (a1 >= a0 && threadIdx.x < e1 - a1) put(entries[a1 + threadIdx.x]);
+    __syncthreads();
+    // the filter lines that got a bit
+    const uint64_t d0 = (uint64_t)r * BB_REGION_DWORDS;
+    const uint64_t left = filter_dwords - d0;
+    const uint32_t here = left < BB_REGION_DWORDS ? (uint32_t)left : BB_REGION_DWORDS;
+    uint4* const f4 = (uint4*)(filter + d0); // (regions start on 128 KiB of a 16-byte aligned filter -- see the host side)
+    for (uint32_t i = threadIdx.x; i < here / 4u; i += BB_APPLY_THREADS) {
+      const uint4 v = l4[i];
+      if (v.x | v.y | v.z | v.w) {
+        uint4 g = f4[i];
+        g.x |= v.x;
+        g.y |= v.y;
+        g.z |= v.z;
+        g.w |= v.w;
+        f4[i] = g;
+      }
+    }
+    for (uint32_t i = (here & ~3u) + threadIdx.x; i < here; i += BB_APPLY_THREADS) // (a filter that does not end on 16 bytes)
+      if (bb_lds[i]) filter[d0 + i] |= bb_lds[i];
+    __syncthreads();
+  }
+}
+
+} // namespace ntamd

@@ -279,6 +279,7 @@ void load_tuning(nthip_tune& t)
   t.ph_read = num("NTHIP_TUNE_PH_READ", 1, 10000000);
   t.fw = num("NTHIP_TUNE_FW", 1, 2);
   t.seed_any = num("NTHIP_TUNE_SEED_ANY", 1, 2);
+  t.bloom_binned = num("NTHIP_TUNE_BLOOM_BINNED", 1, 2);
   const uint32_t tk = num("NTHIP_TUNE_TABLE_K_MAX", 16, 64);
   ntamd::host::g_kmer_table_k_max = tk ? tk : (uint32_t)KMER_TABLE_K_MAX_N;
 }
@@ -343,6 +344,7 @@ extern "C" int nthip_ctx_destroy(nthip_ctx* c)
   if (c->d_args) (void)hipFree(c->d_args);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->d_scratch2) (void)hipFree(c->d_scratch2);
+  if (c->bloom_tmp) (void)hipFree(c->bloom_tmp);
   for (auto& kv : c->init_tabs) (void)hipFree(kv.second);
   while (!c->scattered.empty()) (void)scattered_free(c, c->scattered.begin()->first);
   fastx_buffers_release(c);
@@ -367,6 +369,9 @@ extern "C" int nthip_ctx_trim(nthip_ctx* c)
   if (c->d_scratch2) (void)hipFree(c->d_scratch2);
   c->d_scratch = c->d_scratch2 = nullptr;
   c->d_scratch_elems = c->d_scratch2_elems = 0;
+  if (c->bloom_tmp) (void)hipFree(c->bloom_tmp);
+  c->bloom_tmp = nullptr;
+  c->bloom_tmp_bytes = 0;
   return NTHIP_OK;
 }
 

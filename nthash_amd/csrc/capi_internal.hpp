@@ -98,6 +98,7 @@ struct nthip_tune {
   uint32_t ph_tiles = 0;    // NTHIP_TUNE_PH_TILES
   uint32_t ph_period = 0;   // NTHIP_TUNE_PH_PERIOD
   uint32_t ph_read = 0;     // NTHIP_TUNE_PH_READ
+  uint32_t bloom_binned = 0; // NTHIP_TUNE_BLOOM_BINNED=1: the binned insert whenever the filter allows it, 2: never (A/B, tests)
   uint32_t seed_any = 0;    // NTHIP_TUNE_SEED_ANY=1: dense seed batches on the any-seed form whatever the seed set, 2: none of k <= 128 (A/B, tests)
   uint32_t fw = 0;          // NTHIP_TUNE_FW: first window beyond the position tables -- 1 grouped, 2 prefix scan (0: cost model)
 };
@@ -119,6 +120,9 @@ struct nthip_ctx {
   size_t d_scratch_elems = 0;
   uint64_t* d_scratch2 = nullptr; // second area (tile-level arrays next to read-level ones)
   size_t d_scratch2_elems = 0;
+  // the binned Bloom insert's lists (capi_sink_bloom.hip): grow-only, released by nthip_ctx_trim / nthip_ctx_destroy
+  uint8_t* bloom_tmp = nullptr;
+  size_t bloom_tmp_bytes = 0;
   bool profiling = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;

@@ -1,6 +1,7 @@
 // capi_sink_bloom.hip -- fused consumers of the hash stream: Bloom filter insert / query
 // Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
 #include "capi_internal.hpp"
+#include "bloom_binned_kernels.hpp"
 
 using namespace ntamd;
 using namespace ntamd::host;
@@ -10,6 +11,158 @@ namespace {
 uint64_t bloom_magic_of(uint64_t n_bits)
 {
   return (n_bits & (n_bits - 1)) == 0 ? 0ull : ~0ull / n_bits;
+}
+
+// ---- the binned insert (bloom_binned_kernels.hpp) -------------------------------------------------------------------
+constexpr uint64_t BB_ROUND_MAX = 1ull << 31; // values per round: the lists are indexed with 32 bits
+
+// Does a batch of n values into this filter go through the lists?  The filter must fit the histogram (2^35 bits) and
+// sit on 16 bytes; the round's fixed costs -- one read-modify-write of the touched filter lines, five launches --
+// must be small next to what the atomics would cost: ~37 ps per value against ~8 ps per value + ~0.4 ps per filter byte.
+bool bloom_binned_ok(const nthip_ctx* c, const void* d_filter, uint64_t n_bits, uint64_t n_values)
+{
+  if (c->tune.bloom_binned == 2) return false;
+  if (n_bits > ((uint64_t)BB_MAX_REGIONS << BB_REGION_SHIFT) || ((uintptr_t)d_filter & 15u)) return false;
+  if (c->lds_max < (size_t)BB_REGION_DWORDS * 4 + 1024) return false;
+  if (c->tune.bloom_binned == 1) return n_values != 0;
+  const uint64_t filter_bytes = (n_bits + 7) / 8;
+  return n_values >= (1ull << 22) && n_values >= filter_bytes / 64;
+}
+
+struct BloomLists {
+  uint32_t *counts = nullptr, *region_base = nullptr, *region_cursor = nullptr, *bin_cursor = nullptr;
+  uint32_t *list1 = nullptr, *list2 = nullptr;
+  uint64_t* hashes = nullptr; // the round's hash stream (the reads entry)
+};
+
+// lists for rounds of at most `round` values (+ a hash stream of that many values when with_stream)
+int bloom_lists(nthip_ctx* c, uint64_t round, bool with_stream, BloomLists* t)
+{
+  const size_t head = ((size_t)BB_MAX_REGIONS * 3 + 1 + BB_MAX_BINS + 64) * sizeof(uint32_t);
+  const size_t head_al = (head + 255) & ~(size_t)255;
+  const size_t list_bytes = (((size_t)round * 4) + 255) & ~(size_t)255;
+  const size_t need = head_al + 2 * list_bytes + (with_stream ? (size_t)round * 8 : 0);
+  if (c->bloom_tmp_bytes < need) {
+    if (c->bloom_tmp) HIPCHK(hipFree(c->bloom_tmp));
+    c->bloom_tmp = nullptr;
+    c->bloom_tmp_bytes = 0;
+    HIPCHK(hipMalloc((void**)&c->bloom_tmp, need));
+    c->bloom_tmp_bytes = need;
+  }
+  uint32_t* p = (uint32_t*)c->bloom_tmp;
+  t->counts = p;
+  t->region_base = p + BB_MAX_REGIONS;
+  t->region_cursor = t->region_base + BB_MAX_REGIONS + 1;
+  t->bin_cursor = t->region_cursor + BB_MAX_REGIONS;
+  t->list1 = (uint32_t*)(c->bloom_tmp + head_al);
+  t->list2 = (uint32_t*)(c->bloom_tmp + head_al + list_bytes);
+  t->hashes = with_stream ? (uint64_t*)(c->bloom_tmp + head_al + 2 * list_bytes) : nullptr;
+  return NTHIP_OK;
+}
+
+// values per round: what the free memory allows (16 B per value with the hash stream, 8 without), at most BB_ROUND_MAX
+uint64_t bloom_round_values(const nthip_ctx* c, uint64_t n_values, bool with_stream)
+{
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+  free_b += c->bloom_tmp_bytes; // (what the context already holds is ours to reuse)
+  const uint64_t per = with_stream ? 16 : 8;
+  uint64_t round = (uint64_t)(free_b / 2) / per;
+  if (round > BB_ROUND_MAX) round = BB_ROUND_MAX;
+  if (round > n_values) round = n_values;
+  if (round < (1u << 20)) round = 1u << 20;
+  return round;
+}
+
+// one round: n <= BB_ROUND_MAX values of a device-resident stream into the filter (launches only, no synchronisation)
+int bloom_binned_round(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n, uint32_t* d_filter, uint64_t n_bits,
+                       const BloomLists& t)
+{
+  const uint32_t n_regions = (uint32_t)((n_bits + (1ull << BB_REGION_SHIFT) - 1) >> BB_REGION_SHIFT);
+  const uint32_t n_bins = (n_regions + BB_REGIONS_PER_BIN - 1) / BB_REGIONS_PER_BIN;
+  const uint64_t magic = bloom_magic_of(n_bits);
+  const uint64_t filter_dwords = (n_bits + 31) / 32;
+  HIPCHK(hipMemsetAsync(t.counts, 0, (size_t)n_regions * sizeof(uint32_t), c->stream));
+  const size_t hist_lds = (size_t)(n_regions < 128u ? 128u : n_regions) * sizeof(uint32_t);
+  NTCHK(set_max_lds(c, bloom_hist_kernel, hist_lds));
+  prof_begin(c, "bloom binned insert (hist, scan, part, apply)");
+  hipLaunchKernelGGL(bloom_hist_kernel, dim3(c->n_cu), dim3(1024), hist_lds, c->stream, d_hashes, n, n_bits, magic, n_regions,
+                     t.counts);
+  hipLaunchKernelGGL(bloom_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)t.counts, n_regions, t.region_base,
+                     t.region_cursor, t.bin_cursor);
+  BloomPartArgs a;
+  memset(&a, 0, sizeof a);
+  a.n = n;
+  a.n_bits = n_bits;
+  a.magic = magic;
+  a.n_regions = n_regions;
+  a.seg_base = t.region_base;
+  const uint32_t* entries;
+  if (n_bins == 1) { // a filter of at most 2^27 bits: straight to the regions
+    a.in = d_hashes;
+    a.out = t.list2;
+    a.cursor = t.region_cursor;
+    a.shift = BB_REGION_SHIFT;
+    a.mask = (1u << BB_REGION_SHIFT) - 1u;
+    a.buckets_per_seg = n_regions;
+    hipLaunchKernelGGL(bloom_part_kernel<true>, dim3(c->n_cu * 4), dim3(BB_PART_THREADS), 0, c->stream, a);
+  } else {
+    a.in = d_hashes;
+    a.out = t.list1;
+    a.cursor = t.bin_cursor;
+    a.shift = BB_BIN_SHIFT;
+    a.mask = (1u << BB_BIN_SHIFT) - 1u;
+    a.buckets_per_seg = n_bins;
+    hipLaunchKernelGGL(bloom_part_kernel<true>, dim3(c->n_cu * 4), dim3(BB_PART_THREADS), 0, c->stream, a);
+    a.in = t.list1;
+    a.out = t.list2;
+    a.cursor = t.region_cursor;
+    a.shift = BB_REGION_SHIFT;
+    a.mask = (1u << BB_REGION_SHIFT) - 1u;
+    a.buckets_per_seg = BB_REGIONS_PER_BIN;
+    const uint32_t per_bin = (uint32_t)c->n_cu * 4u / n_bins + 1u;
+    hipLaunchKernelGGL(bloom_part_kernel<false>, dim3(per_bin, n_bins), dim3(BB_PART_THREADS), 0, c->stream, a);
+  }
+  entries = t.list2;
+  const size_t apply_lds = (size_t)BB_REGION_DWORDS * sizeof(uint32_t);
+  NTCHK(set_max_lds(c, bloom_apply_kernel, apply_lds));
+  const uint32_t grid = n_regions < (uint32_t)c->n_cu ? n_regions : (uint32_t)c->n_cu;
+  hipLaunchKernelGGL(bloom_apply_kernel, dim3(grid), dim3(BB_APPLY_THREADS), apply_lds, c->stream, entries,
+                     (const uint32_t*)t.region_base, n_regions, d_filter, filter_dwords);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+// the reads entry on the binned insert: rounds of reads hashed to a stream in the context's lists, every round binned
+int run_kmer_bloom_binned(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m, uint32_t* d_filter, uint64_t n_bits,
+                          uint64_t* total_out, uint32_t flags)
+{
+  const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
+  const uint64_t per_read = (uint64_t)(len - k + 1) * m;
+  const uint64_t round = bloom_round_values(c, rd->n_reads * per_read, true);
+  uint64_t reads_per_round = round / per_read;
+  if (reads_per_round == 0) return fail(NTHIP_ERR_UNSUPPORTED, "reads too long for the binned Bloom insert");
+  BloomLists t;
+  NTCHK(bloom_lists(c, reads_per_round * per_read, true, &t));
+  uint64_t sum = 0;
+  for (uint64_t r0 = 0; r0 < rd->n_reads; r0 += reads_per_round) {
+    const uint64_t nr = rd->n_reads - r0 < reads_per_round ? rd->n_reads - r0 : reads_per_round;
+    nthip_reads part = *rd;
+    part.seqs = rd->seqs + r0 * stride;
+    part.n_reads = nr;
+    nthip_out out;
+    memset(&out, 0, sizeof out);
+    out.hashes = t.hashes;
+    out.capacity = nr * (uint64_t)(len - k + 1);
+    uint64_t total = 0;
+    NTCHK(nthip_kmer_hash(c, &part, k, m, &out, &total, flags & NTHIP_HOST_INPUT));
+    sum += total;
+    if (total) NTCHK(bloom_binned_round(c, t.hashes, total * m, d_filter, n_bits, t));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (total_out) *total_out = sum;
+  return NTHIP_OK;
 }
 
 // shared body: SINK_BLOOM_INSERT or SINK_BLOOM_QUERY over fixed-length reads
@@ -39,6 +192,9 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
     }
     return NTHIP_OK;
   }
+  // a batch that is large next to the filter: hash stream + binned insert, no device atomics
+  if (!query && stride >= len && bloom_binned_ok(c, d_filter, n_bits, rd->n_reads * (uint64_t)(len - k + 1) * m))
+    return run_kmer_bloom_binned(c, rd, k16, m8, d_filter, n_bits, total_out, flags);
   NaPlan plan;
   if (!kmer_na_plan(c, len, stride, k, m, /*want_pos (the k-mer's read)*/ query, &plan))
     return fail(NTHIP_ERR_UNSUPPORTED, "shape outside the fused consumer kernels (k <= 64, m <= 8, stride >= windows)");
@@ -105,6 +261,15 @@ extern "C" int nthip_stream_bloom_insert(nthip_ctx* c, const uint64_t* d_hashes,
   if (n_values && !d_hashes) return fail(NTHIP_ERR_ARG, "hashes is NULL");
   HIPCHK(hipSetDevice(c->device));
   if (n_values == 0) return NTHIP_OK;
+  if (bloom_binned_ok(c, d_filter, n_bits, n_values)) {
+    const uint64_t round = bloom_round_values(c, n_values, false);
+    BloomLists t;
+    NTCHK(bloom_lists(c, round, false, &t));
+    for (uint64_t v0 = 0; v0 < n_values; v0 += round)
+      NTCHK(bloom_binned_round(c, d_hashes + v0, n_values - v0 < round ? n_values - v0 : round, (uint32_t*)d_filter, n_bits, t));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTHIP_OK;
+  }
   prof_begin(c, "stream_bloom_insert_kernel");
   hipLaunchKernelGGL(stream_bloom_insert_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, d_hashes, n_values,
                      (uint32_t*)d_filter, n_bits, bloom_magic_of(n_bits));

@@ -35,6 +35,7 @@
 // Hash arithmetic as in kmer_runs_kernel.hpp (first window from the byte tables,
 // src/kmer.cpp:43-73,123-152; the rest rolled, src/kmer.cpp:84-94,164-174).
 #pragma once
+#include "bloom_math.hpp" // (mod_invariant)
 
 #include <hip/hip_runtime.h>
 
@@ -105,16 +106,6 @@ struct KmerRunsGenArgs {
   // are bases of it; invalid = its companion stream, one bit per base (1 = not a base), read by the N-aware passes only
   const uint16_t* invalid;
 };
-
-// h mod d for an invariant d (magic = floor((2^64 - 1) / d): the quotient estimate is at most 2 short)
-__device__ __forceinline__ uint64_t mod_invariant(uint64_t h, uint64_t d, uint64_t magic)
-{
-  if (magic == 0) return h & (d - 1);
-  uint64_t r = h - __umul64hi(h, magic) * d;
-  if (r >= d) r -= d;
-  if (r >= d) r -= d;
-  return r;
-}
 
 // s_waitcnt needs an immediate: wait until at most n (0..15) vector-memory operations are in flight.  A ladder, not a
 // switch: the weakest wait is unconditional and every smaller count adds a stronger one, so EVERY path through this

@@ -23,11 +23,17 @@
 #include "nthash/nthash.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
+#include <functional>
+#include <future>
 #include <iostream>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "nt_math.hpp"
 #include "nthash_hip.h"
@@ -60,16 +66,84 @@ struct ThreadCtx {
   }
 };
 
-nthip_ctx* device_ctx(const char* cls)
+// (err: where a thread that must not exit the process -- the helper below -- gets the message instead)
+nthip_ctx* device_ctx(const char* cls, std::string* err = nullptr)
 {
   static thread_local ThreadCtx tc;
   if (!tc.ctx) {
     int dev = 0;
     if (const char* e = std::getenv("NTHASH_AMD_DEVICE")) dev = std::atoi(e);
-    if (nthip_ctx_create(dev, &tc.ctx) != NTHIP_OK)
-      raise_error(cls, std::string("GPU hashing unavailable: ") + nthip_last_error());
+    if (nthip_ctx_create(dev, &tc.ctx) != NTHIP_OK) {
+      const std::string msg = std::string("GPU hashing unavailable: ") + nthip_last_error();
+      if (!err) raise_error(cls, msg);
+      *err = msg;
+      return nullptr;
+    }
   }
   return tc.ctx;
+}
+
+// One helper thread per user thread (started by the first long sequence, joined when the user thread ends): it hashes
+// window w + 1 of a sequence -- on its own device context and stream -- while the user thread walks window w.
+class Helper {
+public:
+  Helper() : th_([this] { run(); }) {}
+  ~Helper()
+  {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    th_.join();
+  }
+  template <typename F>
+  auto submit(F f) -> std::future<decltype(f())>
+  {
+    auto task = std::make_shared<std::packaged_task<decltype(f())()>>(std::move(f));
+    auto fut = task->get_future();
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      jobs_.emplace_back([task] { (*task)(); });
+    }
+    cv_.notify_one();
+    return fut;
+  }
+
+private:
+  void run()
+  {
+    for (;;) {
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [&] { return quit_ || !jobs_.empty(); });
+        if (jobs_.empty()) return;
+        job = std::move(jobs_.front());
+        jobs_.pop_front();
+      }
+      job();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> jobs_;
+  bool quit_ = false;
+  std::thread th_; // (last: the thread starts with everything above in place)
+};
+Helper& helper()
+{
+  static thread_local Helper h;
+  return h;
+}
+// NTHASH_AMD_PREFETCH=0: windows one after the other on the user thread (A/B, debugging)
+bool prefetch_enabled()
+{
+  static const bool on = [] {
+    const char* e = std::getenv("NTHASH_AMD_PREFETCH");
+    return !(e && e[0] == '0');
+  }();
+  return on;
 }
 
 // NTHASH_AMD_DEVICES="all" or "0,1,2,...": nthash::BatchNtHash cuts its batch over these devices (nthip_multi_*).
@@ -217,6 +291,16 @@ struct KmerStream {
   }
 };
 
+struct KmerAhead {
+  size_t from = 0;
+  std::future<std::shared_ptr<KmerStream>> fut;
+  std::shared_ptr<std::string> err; // what went wrong on the helper thread (the user thread raises it)
+  ~KmerAhead()
+  {
+    if (fut.valid()) fut.wait(); // the helper reads the caller's sequence: never outlive the object that borrowed it
+  }
+};
+
 struct SeedSet {
   std::vector<std::string> strings;
   std::vector<SeedShape> shapes;
@@ -249,7 +333,9 @@ struct SeedStream {
 namespace {
 
 // the windows [from, from + window_positions()) of the sequence, hashed by one device call on that slice
-std::shared_ptr<detail::KmerStream> build_kmer_stream(const char* seq, size_t len, unsigned k, unsigned m, size_t from)
+// (err: failures are reported there instead of ending the process -- the helper thread's calls)
+std::shared_ptr<detail::KmerStream> build_kmer_stream(const char* seq, size_t len, unsigned k, unsigned m, size_t from,
+                                                      std::string* err = nullptr)
 {
   auto st = std::make_shared<detail::KmerStream>();
   st->m = m;
@@ -259,14 +345,19 @@ std::shared_ptr<detail::KmerStream> build_kmer_stream(const char* seq, size_t le
   const size_t cap = st->w_end - st->w_begin;
   st->pos.resize(cap);
   st->hashes.resize(cap * m);
-  nthip_ctx* ctx = device_ctx("NtHash");
+  nthip_ctx* ctx = device_ctx("NtHash", err);
+  if (!ctx) return nullptr;
   const uint64_t offsets[2] = { 0, (uint64_t)(cap + k - 1) };
   nthip_reads rd = { seq + from, offsets, 1, 0, 0 };
   nthip_out out = { st->hashes.data(), cap, nullptr, st->pos.data(), nullptr, nullptr };
   uint64_t total = 0;
   if (nthip_kmer_hash(ctx, &rd, (uint16_t)k, (uint8_t)m, &out, &total, NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT) !=
-      NTHIP_OK)
-    raise_error("NtHash", std::string("GPU hashing failed: ") + nthip_last_error());
+      NTHIP_OK) {
+    const std::string msg = std::string("GPU hashing failed: ") + nthip_last_error();
+    if (!err) raise_error("NtHash", msg);
+    *err = msg;
+    return nullptr;
+  }
   st->pos.resize(total);
   st->hashes.resize(total * m);
   return st;
@@ -411,6 +502,10 @@ NtHash::NtHash(const NtHash& o)
   , rt_(o.rt_)
   , stream_(o.stream_)
   , cursor_(o.cursor_)
+  , sp_(o.sp_)
+  , sh_(o.sh_)
+  , sn_(o.sn_)
+  , sbegin_(o.sbegin_)
 {
   std::memcpy(hash_arr_.get(), o.hash_arr_.get(), (num_hashes_ ? num_hashes_ : 1) * sizeof(uint64_t));
 }
@@ -439,16 +534,56 @@ bool NtHash::load_from_stream()
     extend(fwd_, rev_, k_, num_hashes_, hash_arr_.get());
     return true;
   }
-  if (!stream_ || !stream_->covers(pos_)) {
-    stream_ = build_kmer_stream(seq_, len_, k_, num_hashes_, pos_);
-    cursor_ = 0;
-  }
+  if (!stream_ || !stream_->covers(pos_)) next_stream();
   const size_t i = stream_->find(pos_, cursor_);
   if (i == (size_t)-1) return false;
   cursor_ = i;
   strands_stale_ = true; // (the caller may make them current again: roll())
   std::memcpy(hash_arr_.get(), stream_->hashes.data() + i * num_hashes_, num_hashes_ * sizeof(uint64_t));
   return true;
+}
+
+// stream_ := the device stream of the window that holds pos_ -- the one the helper thread has been hashing if the walk
+// arrived where it was expected (the end of the previous window, or a skip that stays inside the next one), a call of
+// its own otherwise -- and the window after it is put on the helper
+void NtHash::next_stream()
+{
+  // NTHASH_AMD_TRACE=1: what every window change cost the user thread (stderr)
+  static const bool trace = [] { const char* e = std::getenv("NTHASH_AMD_TRACE"); return e && e[0] == '1'; }();
+  const auto t0 = std::chrono::steady_clock::now();
+  bool from_helper = false;
+  std::shared_ptr<detail::KmerStream> st;
+  if (ahead_) {
+    std::shared_ptr<detail::KmerAhead> a = std::move(ahead_);
+    ahead_.reset();
+    std::shared_ptr<detail::KmerStream> got = a->fut.get();
+    if (!got) raise_error("NtHash", *a->err);
+    if (got->covers(pos_)) {
+      st = std::move(got);
+      from_helper = true;
+    }
+  }
+  if (!st) st = build_kmer_stream(seq_, len_, k_, num_hashes_, pos_);
+  if (trace)
+    std::fprintf(stderr, "[nthash_amd] window at %zu: %s, %.3f ms\n", pos_, from_helper ? "from the helper thread" : "hashed here",
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  stream_ = std::move(st);
+  cursor_ = 0;
+  sp_ = stream_->pos.data();
+  sh_ = stream_->hashes.data();
+  sn_ = stream_->pos.size();
+  sbegin_ = stream_->w_begin;
+  if (prefetch_enabled() && stream_->w_end < len_ - k_ + 1) {
+    auto a = std::make_shared<detail::KmerAhead>();
+    a->from = stream_->w_end;
+    a->err = std::make_shared<std::string>();
+    const char* seq = seq_;
+    const size_t len = len_, from = a->from;
+    const unsigned k = k_, m = num_hashes_;
+    std::shared_ptr<std::string> err = a->err;
+    a->fut = helper().submit([seq, len, k, m, from, err] { return build_kmer_stream(seq, len, k, m, from, err.get()); });
+    ahead_ = std::move(a);
+  }
 }
 
 // the strand hashes of the window at pos_, straight from its bases (src/kmer.cpp:43-73, 123-152): what
@@ -489,8 +624,13 @@ bool NtHash::init()
   return true;
 }
 
-// reference: NtHash::roll, src/kmer.cpp:246-264
-bool NtHash::roll()
+// (the library still exports NtHash::roll(): the reference's library does, src/kmer.cpp:246)
+namespace {
+__attribute__((used)) bool (NtHash::*const export_nthash_roll)() = &NtHash::roll;
+}
+
+// reference: NtHash::roll, src/kmer.cpp:246-264 (the header's inline roll() is this routine's common case)
+bool NtHash::roll_general()
 {
   if (!initialized_) return init();
   if (pos_ >= len_ - k_) return false;

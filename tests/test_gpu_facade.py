@@ -192,6 +192,12 @@ def test_facade_suite_again_with_tiny_windows():
     _rerun_suite({"NTHASH_AMD_FORCE_DEVICE": "1", "NTHASH_AMD_WINDOW": "1024"})
 
 
+def test_facade_suite_again_without_the_prefetch_thread():
+    """windows of 1024 positions fetched one after the other on the user thread (NTHASH_AMD_PREFETCH=0); the run above has
+    the helper thread hash window w + 1 while w is walked"""
+    _rerun_suite({"NTHASH_AMD_FORCE_DEVICE": "1", "NTHASH_AMD_WINDOW": "1024", "NTHASH_AMD_PREFETCH": "0"})
+
+
 BATCH_DRIVER = r"""
 #include <nthash/nthash.hpp>
 #include <cstdio>

@@ -1069,6 +1069,73 @@ def test_bloom_insert_matches_oracle_hash_stream(ctx, oracle, n, L, k, m, n_bits
     ctx.free(d_f2)
 
 
+@pytest.mark.parametrize("n,L,k,m,n_bits,dirty", [
+    (3000, 150, 31, 1, 1 << 22, False),              # 4 regions, one bin: straight to the regions
+    (3000, 150, 31, 4, 4_000_037, True),             # prime size: invariant modulo, a partial last region; reads with N
+    (700, 100, 64, 3, (1 << 20) + 32, False),        # a second region of 32 bits
+    (1, 150, 31, 8, 64, False), (300, 36, 21, 1, 33, False),   # filters smaller than a vector
+    (4000, 150, 31, 2, (1 << 28) + 12_345, False),   # 3 bins (the last one partial): both partition levels
+    (2500, 250, 31, 1, 1 << 30, True),               # 8 bins
+    (1200, 150, 31, 3, (1 << 33) - 1_234_567, False),  # 64 bins, the last one partial
+])
+def test_bloom_binned_insert_matches_oracle_hash_stream(oracle, n, L, k, m, n_bits, dirty):
+    """the binned insert (histogram -> region lists -> one workgroup per 128 KiB region, no device atomics;
+    NTHIP_TUNE_BLOOM_BINNED=1 takes it whatever the batch size) builds the filter the CPU builds from the oracle's hash
+    stream -- from reads and from a materialised stream, on a filter that already holds bits, with repeated k-mers"""
+    import os
+    import nthash_amd
+    os.environ["NTHIP_TUNE_BLOOM_BINNED"] = "1"
+    try:
+        ctx = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_BLOOM_BINNED", None)
+    rng = np.random.default_rng(n + L + m)
+    data = oracle.synth_reads(2, n, L, 99 + k).copy()
+    data[: 3 * L] = ord("A")                      # low-complexity reads: one value many times
+    if n > 10:
+        data[5 * L: 6 * L] = data[4 * L: 5 * L]   # a duplicated read
+    if dirty:
+        bad = rng.choice(n * L, max(3, n * L // 500), replace=False)
+        data[bad] = np.frombuffer(b"NnRY-", dtype=np.uint8)[rng.integers(0, 5, bad.size)]
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    nbytes = (n_bits + 31) // 32 * 4
+
+    def expect_words(prior=None):
+        pos = (want["hashes"].ravel() % np.uint64(n_bits)).astype(np.int64)
+        words = np.zeros(nbytes // 4, np.uint32) if prior is None else prior.copy()
+        np.bitwise_or.at(words, pos >> 5, (np.uint32(1) << (pos & 31).astype(np.uint32)))
+        return words
+
+    d_f, _ = ctx.bloom_new(n_bits)
+    ctx.set_profiling(True)
+    total = ctx.bloom_insert(data, k, m, L, n, d_f, n_bits)
+    name = ctx.last_kernel_ms()[1]
+    ctx.set_profiling(False)
+    assert name.startswith("bloom binned insert"), name
+    assert total == want["total"]
+    got = np.zeros(nbytes // 4, np.uint32)
+    ctx.d2h(got, d_f)
+    exp = expect_words()
+    assert (got == exp).all(), (int((got != exp).sum()), "words differ")
+    # a filter that already holds bits (every 7th word all ones) keeps them; the stream entry, in two uneven calls
+    prior = np.zeros(nbytes // 4, np.uint32)
+    prior[::7] = 0xFFFFFFFF
+    ctx.h2d(d_f, prior)
+    hs = np.ascontiguousarray(want["hashes"]).ravel()
+    d_h = ctx.malloc(max(8, hs.size * 8))
+    ctx.h2d(d_h, hs)
+    cut = hs.size // 3 | 1
+    ctx.stream_bloom_insert_ptr(d_h, cut, d_f, n_bits)
+    ctx.stream_bloom_insert_ptr(d_h + 8 * cut, hs.size - cut, d_f, n_bits)
+    ctx.d2h(got, d_f)
+    exp = expect_words(prior)
+    assert (got == exp).all(), (int((got != exp).sum()), "words differ")
+    ctx.free(d_h)
+    ctx.free(d_f)
+    ctx.close()
+
+
 @pytest.mark.parametrize("n,L,k,m,n_bits", [
     (2000, 150, 31, 1, 1 << 20), (2000, 150, 31, 3, 3_000_017), (1200, 101, 25, 2, 700_001), (40, 5003, 31, 2, 1 << 21),
     (900, 100, 64, 1, 1 << 19),
