@@ -128,6 +128,11 @@ int nthip_free(nthip_ctx* ctx, void* dptr);
 int nthip_memcpy_h2d(nthip_ctx* ctx, void* dst, const void* src, size_t bytes);
 int nthip_memcpy_d2h(nthip_ctx* ctx, void* dst, const void* src, size_t bytes);
 int nthip_memset(nthip_ctx* ctx, void* d_dst, int byte_value, size_t bytes);
+/* Page-locked host memory: buffers handed to the NTHIP_HOST_INPUT / NTHIP_HOST_OUTPUT calls are copied by DMA at PCIe
+ * rate when they come from here, through the runtime's pageable path (a third of that, and a CPU core) otherwise.
+ * No context: any thread, any device.  The C++ facade's stream windows live in such buffers. */
+int nthip_host_alloc(size_t bytes, void** hptr);
+int nthip_host_free(void* hptr);
 
 /* ---- the hot path -------------------------------------------------------- */
 /*

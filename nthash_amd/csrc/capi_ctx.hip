@@ -457,6 +457,21 @@ extern "C" int nthip_memcpy_d2h(nthip_ctx* c, void* dst, const void* src, size_t
   return NTHIP_OK;
 }
 
+extern "C" int nthip_host_alloc(size_t bytes, void** hptr)
+{
+  if (!hptr) return fail(NTHIP_ERR_ARG, "hptr is NULL");
+  *hptr = nullptr;
+  if (bytes == 0) return NTHIP_OK;
+  HIPCHK(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_host_free(void* hptr)
+{
+  if (hptr) HIPCHK(hipHostFree(hptr));
+  return NTHIP_OK;
+}
+
 extern "C" int nthip_memset(nthip_ctx* c, void* d_dst, int byte_value, size_t bytes)
 {
   if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");

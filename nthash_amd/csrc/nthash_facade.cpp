@@ -271,13 +271,99 @@ inline void extend(uint64_t f, uint64_t r, unsigned k, unsigned m, uint64_t* h)
 // ===========================================================================
 // device-computed streams
 // ===========================================================================
+namespace {
+// Page-locked host buffers for the windows of the device streams (nthip_host_alloc): the device writes a window's
+// positions and hashes there by DMA, nothing is zero-filled or paged in first.  A window's buffer goes back to the pool
+// when the last object that walks it lets go; a few are kept for the next window / object / thread, the rest freed.
+// (The pool itself is never destroyed: nothing of it may run after the HIP runtime has shut down.)
+class PinnedPool {
+public:
+  void* acquire(size_t bytes, size_t* got, std::string* err)
+  {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      size_t best = free_.size();
+      for (size_t i = 0; i < free_.size(); ++i)
+        if (free_[i].second >= bytes && free_[i].second <= 2 * bytes + (1u << 20) &&
+            (best == free_.size() || free_[i].second < free_[best].second))
+          best = i;
+      if (best != free_.size()) {
+        void* p = free_[best].first;
+        *got = free_[best].second;
+        free_.erase(free_.begin() + (std::ptrdiff_t)best);
+        return p;
+      }
+    }
+    void* p = nullptr;
+    if (nthip_host_alloc(bytes, &p) != NTHIP_OK) {
+      *err = std::string("page-locked host memory: ") + nthip_last_error();
+      return nullptr;
+    }
+    *got = bytes;
+    return p;
+  }
+  void release(void* p, size_t bytes)
+  {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      if (free_.size() < 4) {
+        free_.emplace_back(p, bytes);
+        return;
+      }
+    }
+    (void)nthip_host_free(p);
+  }
+
+private:
+  std::mutex mu_;
+  std::vector<std::pair<void*, size_t>> free_;
+};
+PinnedPool& pinned_pool()
+{
+  static PinnedPool* pool = new PinnedPool();
+  return *pool;
+}
+struct PinnedBlock {
+  void* p = nullptr;
+  size_t bytes = 0;
+  PinnedBlock() = default;
+  PinnedBlock(const PinnedBlock&) = delete;
+  PinnedBlock& operator=(const PinnedBlock&) = delete;
+  ~PinnedBlock()
+  {
+    if (p) pinned_pool().release(p, bytes);
+  }
+  // room for n_hashes 64-bit values followed by n_pos 32-bit ones
+  bool get(size_t n_hashes, size_t n_pos, uint64_t** hashes, uint32_t** pos, std::string* err)
+  {
+    const size_t need = n_hashes * sizeof(uint64_t) + n_pos * sizeof(uint32_t) + 64;
+    p = pinned_pool().acquire(need, &bytes, err);
+    if (!p) return false;
+    *hashes = (uint64_t*)p;
+    *pos = (uint32_t*)((char*)p + n_hashes * sizeof(uint64_t));
+    return true;
+  }
+};
+template <typename T>
+struct View { // what a stream needs of std::vector, over memory it does not own
+  T* p = nullptr;
+  size_t n = 0;
+  T* data() const { return p; }
+  size_t size() const { return n; }
+  T* begin() const { return p; }
+  T* end() const { return p + n; }
+  T& operator[](size_t i) const { return p[i]; }
+};
+} // namespace
+
 namespace detail {
 
 // hashes of the windows [w_begin, w_end) of a sequence, as the device returned them
 struct KmerStream {
   size_t w_begin = 0, w_end = 0;
-  std::vector<uint32_t> pos;              // relative to w_begin, ascending
-  std::vector<uint64_t> hashes;           // m per entry (the strand hashes stay behind: NtHash::sync_strands)
+  PinnedBlock block;
+  View<uint32_t> pos;              // relative to w_begin, ascending
+  View<uint64_t> hashes;           // m per entry (the strand hashes stay behind: NtHash::sync_strands)
   unsigned m = 0;
   bool covers(size_t p) const { return p >= w_begin && p < w_end; }
   // index of the entry at (absolute) position p, or npos
@@ -315,8 +401,9 @@ struct SeedSet {
 
 struct SeedStream {
   size_t w_begin = 0, w_end = 0;
-  std::vector<uint32_t> pos;              // relative to w_begin
-  std::vector<uint64_t> hashes;           // n_seeds*m2 per entry (strand hashes: SeedNtHash::sync_strands)
+  PinnedBlock block;
+  View<uint32_t> pos;              // relative to w_begin
+  View<uint64_t> hashes;           // n_seeds*m2 per entry (strand hashes: SeedNtHash::sync_strands)
   bool covers(size_t p) const { return p >= w_begin && p < w_end; }
   size_t find(size_t p, size_t hint) const
   {
@@ -343,8 +430,11 @@ std::shared_ptr<detail::KmerStream> build_kmer_stream(const char* seq, size_t le
   st->w_begin = from;
   st->w_end = std::min(n_pos, from + window_positions());
   const size_t cap = st->w_end - st->w_begin;
-  st->pos.resize(cap);
-  st->hashes.resize(cap * m);
+  std::string local_err;
+  if (!st->block.get(cap * m, cap, &st->hashes.p, &st->pos.p, err ? err : &local_err)) {
+    if (!err) raise_error("NtHash", local_err);
+    return nullptr;
+  }
   nthip_ctx* ctx = device_ctx("NtHash", err);
   if (!ctx) return nullptr;
   const uint64_t offsets[2] = { 0, (uint64_t)(cap + k - 1) };
@@ -358,8 +448,8 @@ std::shared_ptr<detail::KmerStream> build_kmer_stream(const char* seq, size_t le
     *err = msg;
     return nullptr;
   }
-  st->pos.resize(total);
-  st->hashes.resize(total * m);
+  st->pos.n = total;
+  st->hashes.n = total * m;
   return st;
 }
 
@@ -377,8 +467,8 @@ std::shared_ptr<detail::SeedStream> build_seed_stream(const char* seq, size_t le
   st->w_begin = from;
   st->w_end = std::min(n_pos, from + window_positions());
   const size_t cap = st->w_end - st->w_begin;
-  st->pos.resize(cap);
-  st->hashes.resize(cap * ns * m2);
+  std::string block_err;
+  if (!st->block.get(cap * ns * m2, cap, &st->hashes.p, &st->pos.p, &block_err)) raise_error("SeedNtHash", block_err);
   nthip_ctx* ctx = device_ctx("SeedNtHash");
   if (!seeds.dev || seeds.dev_ctx != ctx) { // (the device tables belong to the thread's context)
     if (seeds.dev) nthip_seeds_destroy(seeds.dev);
@@ -396,8 +486,8 @@ std::shared_ptr<detail::SeedStream> build_seed_stream(const char* seq, size_t le
   if (nthip_seed_hash(ctx, &rd, seeds.dev, (uint8_t)m2, &out, &total, NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT) !=
       NTHIP_OK)
     raise_error("SeedNtHash", std::string("GPU hashing failed: ") + nthip_last_error());
-  st->pos.resize(total);
-  st->hashes.resize(total * ns * m2);
+  st->pos.n = total;
+  st->hashes.n = total * ns * m2;
   return st;
 }
 
