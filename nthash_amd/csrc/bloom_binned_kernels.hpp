@@ -37,11 +37,31 @@ constexpr uint32_t BB_BIN_SHIFT = 27;               // ... per bin: 128 regions
 constexpr uint32_t BB_REGIONS_PER_BIN = 1u << (BB_BIN_SHIFT - BB_REGION_SHIFT);
 constexpr uint32_t BB_MAX_REGIONS = 32768;          // 2^35 bits
 constexpr uint32_t BB_MAX_BINS = 256;
-constexpr uint32_t BB_PART_THREADS = 512;
-constexpr uint32_t BB_PART_ITEMS = 16;              // values per thread and tile
-constexpr uint32_t BB_TILE = BB_PART_THREADS * BB_PART_ITEMS;
+#ifndef BB_ABL
+#define BB_ABL 0
+#endif
+#ifndef BB_COPY_SLOT
+#define BB_COPY_SLOT 0
+#endif
+#ifndef BB_PART_ITEMS_N
+#define BB_PART_ITEMS_N 16
+#endif
+constexpr uint32_t BB_PART_ITEMS = BB_PART_ITEMS_N; // values per thread and tile
+// threads per block of the two partition levels: a tile is 16 values per thread.  From the values to the bins, tiles of
+// 16 Ki (runs of 64 offsets per bin: 256-byte pieces) -- in-process rocprofv3, 2^31 values: 11.0 -> 7.1 ms against tiles
+// of 8 Ki; from a bin to its 128 regions the smaller tile already makes such runs and leaves four blocks per CU (8.0 ms;
+// 16 Ki: 8.2).  Without its stores the first level takes 4.9 ms: what is left is what HBM makes of 4-byte-granular runs.
+#ifndef BB_L1_THREADS
+#define BB_L1_THREADS 1024
+#endif
+#ifndef BB_L2_THREADS
+#define BB_L2_THREADS 512
+#endif
 constexpr uint32_t BB_APPLY_THREADS = 1024;
 constexpr uint32_t BB_REGION_DWORDS = 1u << (BB_REGION_SHIFT - 5);
+#ifndef BB_CURSOR_STRIDE
+#define BB_CURSOR_STRIDE 32u // dwords between two cursors: one cache line each (tiles of every block hit the same few
+#endif                       // hundred cursors; neighbours in one line serialise in L2 -- profiles/r03_notes.md)
 
 // ---- hist: values per region ---------------------------------------------------------------------------------------
 // dynamic LDS: n_regions counters.  counts[r] += ...; every block flushes the counters it touched.
@@ -97,8 +117,8 @@ static __global__ __launch_bounds__(1024) void bloom_scan_kernel(const uint32_t*
     const uint32_t r = r0 + i;
     if (r < n_regions) {
       region_base[r] = run;
-      region_cursor[r] = run;
-      if ((r & (BB_REGIONS_PER_BIN - 1u)) == 0) bin_cursor[r >> (BB_BIN_SHIFT - BB_REGION_SHIFT)] = run;
+      region_cursor[(size_t)r * BB_CURSOR_STRIDE] = run;
+      if ((r & (BB_REGIONS_PER_BIN - 1u)) == 0) bin_cursor[(size_t)(r >> (BB_BIN_SHIFT - BB_REGION_SHIFT)) * BB_CURSOR_STRIDE] = run;
       run += counts[r];
     }
   }
@@ -121,13 +141,15 @@ struct BloomPartArgs {
   uint32_t buckets_per_seg; // IN64: the number of buckets; !IN64: 128 (the last segment may own fewer regions)
 };
 
-template <bool IN64>
+template <bool IN64, uint32_t BB_PART_THREADS>
 static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(const BloomPartArgs a)
 {
+  constexpr uint32_t BB_TILE = BB_PART_THREADS * BB_PART_ITEMS;
   __shared__ uint32_t hist[BB_MAX_BINS];
   __shared__ uint32_t off[BB_MAX_BINS];
   __shared__ uint32_t gbase[BB_MAX_BINS];
-  __shared__ uint32_t sorted[BB_TILE];
+  extern __shared__ __attribute__((aligned(16))) uint32_t bb_lds[];
+  uint32_t* const sorted = bb_lds; // BB_TILE entries (dynamic: tiles of 16 Ki values and more pass the static limit)
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t seg = blockIdx.y;
   uint64_t s0, s1;
@@ -143,7 +165,7 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
     s1 = a.seg_base[r1];
     n_buckets = r1 - r0;
   }
-  uint32_t* const cursor = a.cursor + (size_t)seg * a.buckets_per_seg;
+  uint32_t* const cursor = a.cursor + (size_t)seg * a.buckets_per_seg * BB_CURSOR_STRIDE;
   const uint64_t n_tiles = (s1 - s0 + BB_TILE - 1) / BB_TILE;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     if (tid < BB_MAX_BINS) hist[tid] = 0;
@@ -187,9 +209,33 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
     }
     if (tid < n_buckets) {
       const uint32_t c = hist[tid];
-      gbase[tid] = c ? atomicAdd(&cursor[tid], c) : 0u;
+#if BB_ABL == 2 // ablation (WRONG results): no cursor atomics, the tile's runs go out back to back
+      gbase[tid] = (uint32_t)(t0 - s0) + off[tid] + (IN64 ? 0u : (uint32_t)s0);
+      (void)cursor;
+#else
+      gbase[tid] = c ? atomicAdd(&cursor[(size_t)tid * BB_CURSOR_STRIDE], c) : 0u;
+#endif
     }
     __syncthreads();
+#if BB_COPY_SLOT
+    // copy-out a slot per lane: slot i of the sorted tile goes to its bucket's run (the bucket of a slot: one byte each)
+    uint8_t* const sbin = (uint8_t*)(sorted + BB_TILE);
+#pragma unroll
+    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j)
+      if (where[j] != ~0u) {
+        const uint32_t slot = off[where[j] >> 16] + (where[j] & 0xFFFFu);
+        sorted[slot] = val[j];
+        sbin[slot] = (uint8_t)(where[j] >> 16);
+      }
+    __syncthreads();
+    const uint64_t left = s1 - t0;
+    const uint32_t n_here = left < BB_TILE ? (uint32_t)left : BB_TILE;
+    for (uint32_t i = tid; i < n_here; i += BB_PART_THREADS) {
+      const uint32_t b = sbin[i];
+      a.out[gbase[b] + (i - off[b])] = sorted[i];
+    }
+    __syncthreads();
+#else
 #pragma unroll
     for (uint32_t j = 0; j < BB_PART_ITEMS; ++j)
       if (where[j] != ~0u) sorted[off[where[j] >> 16] + (where[j] & 0xFFFFu)] = val[j];
@@ -197,9 +243,14 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
     for (uint32_t b = wave; b < n_buckets; b += BB_PART_THREADS / 64u) {
       const uint32_t c = hist[b], o = off[b];
       uint32_t* const dst = a.out + gbase[b];
+#if BB_ABL == 1 // ablation (WRONG results): everything but the stores
+      for (uint32_t j = lane; j < c; j += 64u) asm volatile("" ::"v"(sorted[o + j]), "v"(dst));
+#else
       for (uint32_t j = lane; j < c; j += 64u) dst[j] = sorted[o + j];
+#endif
     }
     __syncthreads();
+#endif
   }
 }
 

@@ -38,7 +38,7 @@ struct BloomLists {
 // lists for rounds of at most `round` values (+ a hash stream of that many values when with_stream)
 int bloom_lists(nthip_ctx* c, uint64_t round, bool with_stream, BloomLists* t)
 {
-  const size_t head = ((size_t)BB_MAX_REGIONS * 3 + 1 + BB_MAX_BINS + 64) * sizeof(uint32_t);
+  const size_t head = ((size_t)BB_MAX_REGIONS * (2 + BB_CURSOR_STRIDE) + 1 + (size_t)BB_MAX_BINS * BB_CURSOR_STRIDE + 64) * sizeof(uint32_t);
   const size_t head_al = (head + 255) & ~(size_t)255;
   const size_t list_bytes = (((size_t)round * 4) + 255) & ~(size_t)255;
   const size_t need = head_al + 2 * list_bytes + (with_stream ? (size_t)round * 8 : 0);
@@ -53,7 +53,7 @@ int bloom_lists(nthip_ctx* c, uint64_t round, bool with_stream, BloomLists* t)
   t->counts = p;
   t->region_base = p + BB_MAX_REGIONS;
   t->region_cursor = t->region_base + BB_MAX_REGIONS + 1;
-  t->bin_cursor = t->region_cursor + BB_MAX_REGIONS;
+  t->bin_cursor = t->region_cursor + (size_t)BB_MAX_REGIONS * BB_CURSOR_STRIDE;
   t->list1 = (uint32_t*)(c->bloom_tmp + head_al);
   t->list2 = (uint32_t*)(c->bloom_tmp + head_al + list_bytes);
   t->hashes = with_stream ? (uint64_t*)(c->bloom_tmp + head_al + 2 * list_bytes) : nullptr;
@@ -90,6 +90,10 @@ int bloom_binned_round(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n, uint3
                      t.counts);
   hipLaunchKernelGGL(bloom_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)t.counts, n_regions, t.region_base,
                      t.region_cursor, t.bin_cursor);
+  auto part_lds = [](uint32_t threads) { return (size_t)threads * BB_PART_ITEMS * (sizeof(uint32_t) + (BB_COPY_SLOT ? 1 : 0)); };
+  auto part_blocks = [&](uint32_t threads) { return (uint32_t)c->n_cu * (part_lds(threads) > 48 * 1024 ? 2u : 4u); };
+  NTCHK(set_max_lds(c, bloom_part_kernel<true, BB_L1_THREADS>, part_lds(BB_L1_THREADS)));
+  NTCHK(set_max_lds(c, bloom_part_kernel<false, BB_L2_THREADS>, part_lds(BB_L2_THREADS)));
   BloomPartArgs a;
   memset(&a, 0, sizeof a);
   a.n = n;
@@ -98,30 +102,32 @@ int bloom_binned_round(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n, uint3
   a.n_regions = n_regions;
   a.seg_base = t.region_base;
   const uint32_t* entries;
+  a.in = d_hashes;
   if (n_bins == 1) { // a filter of at most 2^27 bits: straight to the regions
-    a.in = d_hashes;
     a.out = t.list2;
     a.cursor = t.region_cursor;
     a.shift = BB_REGION_SHIFT;
     a.mask = (1u << BB_REGION_SHIFT) - 1u;
     a.buckets_per_seg = n_regions;
-    hipLaunchKernelGGL(bloom_part_kernel<true>, dim3(c->n_cu * 4), dim3(BB_PART_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL((bloom_part_kernel<true, BB_L1_THREADS>), dim3(part_blocks(BB_L1_THREADS)), dim3(BB_L1_THREADS),
+                       part_lds(BB_L1_THREADS), c->stream, a);
   } else {
-    a.in = d_hashes;
     a.out = t.list1;
     a.cursor = t.bin_cursor;
     a.shift = BB_BIN_SHIFT;
     a.mask = (1u << BB_BIN_SHIFT) - 1u;
     a.buckets_per_seg = n_bins;
-    hipLaunchKernelGGL(bloom_part_kernel<true>, dim3(c->n_cu * 4), dim3(BB_PART_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL((bloom_part_kernel<true, BB_L1_THREADS>), dim3(part_blocks(BB_L1_THREADS)), dim3(BB_L1_THREADS),
+                       part_lds(BB_L1_THREADS), c->stream, a);
     a.in = t.list1;
     a.out = t.list2;
     a.cursor = t.region_cursor;
     a.shift = BB_REGION_SHIFT;
     a.mask = (1u << BB_REGION_SHIFT) - 1u;
     a.buckets_per_seg = BB_REGIONS_PER_BIN;
-    const uint32_t per_bin = (uint32_t)c->n_cu * 4u / n_bins + 1u;
-    hipLaunchKernelGGL(bloom_part_kernel<false>, dim3(per_bin, n_bins), dim3(BB_PART_THREADS), 0, c->stream, a);
+    const uint32_t per_bin = part_blocks(BB_L2_THREADS) / n_bins + 1u;
+    hipLaunchKernelGGL((bloom_part_kernel<false, BB_L2_THREADS>), dim3(per_bin, n_bins), dim3(BB_L2_THREADS),
+                       part_lds(BB_L2_THREADS), c->stream, a);
   }
   entries = t.list2;
   const size_t apply_lds = (size_t)BB_REGION_DWORDS * sizeof(uint32_t);
