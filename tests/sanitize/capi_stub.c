@@ -2,6 +2,7 @@
  * the HOST logic of the C++ facade -- position state machines, the tabulated recurrences behind roll_back()/peek()/
  * Blind* and behind roll() on short sequences, seed parsing, copies and moves -- can run under ASan/UBSan in the CPU
  * test tier.  It hashes nothing: a context "exists", every hashing entry point fails with NTHIP_ERR_NODEVICE. */
+#include <stdlib.h>
 #include "nthash_hip.h"
 #include <stddef.h>
 
@@ -10,6 +11,8 @@ const char* nthip_version(void) { return "stub (no device): sanitizer job only";
 const char* nthip_last_error(void) { return "stub C-ABI: no device (sanitizer job)"; }
 int nthip_ctx_create(int device, nthip_ctx** out) { (void)device; *out = (nthip_ctx*)&g_ctx_storage; return NTHIP_OK; }
 int nthip_ctx_destroy(nthip_ctx* c) { (void)c; return NTHIP_OK; }
+int nthip_host_alloc(size_t bytes, void** p) { *p = malloc(bytes ? bytes : 1); return *p ? NTHIP_OK : NTHIP_ERR_HIP; }
+int nthip_host_free(void* p) { free(p); return NTHIP_OK; }
 int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m, const nthip_out* out, uint64_t* total,
                     uint32_t flags)
 {
