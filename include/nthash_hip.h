@@ -235,6 +235,19 @@ int nthip_kmer_minhash(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uin
 int nthip_stream_bloom_insert(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t n_values,
                               uint8_t* d_filter, uint64_t n_bits);
 
+/* k-mer counting sketch (count-min, one-byte counters): every hash value of the batch -- m per k-mer NtHash emits -- adds
+ * one to counter (h mod n_counters), saturating at 255; nthip_stream_count_query gives a k-mer's estimate, the smallest
+ * of its m counters (hashes: m per k-mer, as nthip_kmer_hash writes them; d_estimates: one byte per k-mer).  The sketch
+ * is a plain byte array on the device, 4-byte aligned, n_counters a multiple of 4.  What the reference's callers do with
+ * hashes() next to Bloom filters (reference include/nthash/nthash.hpp:14-17, 56-57); the layout is ours.  Fixed-length
+ * reads for the reads entry (as the other consumers); NTHIP_HOST_INPUT is honoured. */
+int nthip_kmer_count_insert(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint8_t m, uint8_t* d_counters,
+                            uint64_t n_counters, uint64_t* total, uint32_t flags);
+int nthip_stream_count_insert(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t n_values, uint8_t* d_counters,
+                              uint64_t n_counters);
+int nthip_stream_count_query(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t n_kmers, uint8_t m,
+                             const uint8_t* d_counters, uint64_t n_counters, uint8_t* d_estimates);
+
 /*
  * FASTQ / FASTA -> device batches, done the GPU way: the raw file bytes are
  * uploaded as they are, record boundaries are found on the device, and the k-mer kernels read the

@@ -43,6 +43,7 @@ SYMBOLS = [
     "nthip_multi_create", "nthip_multi_destroy", "nthip_multi_device_count", "nthip_multi_kmer_hash",
     "nthip_multi_seeds_create", "nthip_multi_seeds_destroy", "nthip_multi_seed_hash",
     "nthip_packed_size", "nthip_pack_reads", "nthip_multi_fastx_kmer_hash_file", "nthip_host_alloc", "nthip_host_free",
+    "nthip_kmer_count_insert", "nthip_stream_count_insert", "nthip_stream_count_query",
 ]
 
 
@@ -119,6 +120,11 @@ def load():
                                          C.POINTER(u64), C.POINTER(u64), u32]
     L.nthip_kmer_minhash.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, C.POINTER(u64), u32]
     L.nthip_stream_bloom_insert.argtypes = [vp, vp, u64, vp, u64]
+    L.nthip_kmer_count_insert.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, u64, C.POINTER(u64), u32]
+    L.nthip_stream_count_insert.argtypes = [vp, vp, u64, vp, u64]
+    L.nthip_stream_count_query.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp]
+    L.nthip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.nthip_host_free.argtypes = [vp]
     L.nthip_kmer_hash_spans.argtypes = [vp, vp, u64, vp, vp, u64, C.c_uint16, C.c_uint8, C.POINTER(Out),
                                         C.POINTER(u64), u32]
     L.nthip_fastx_index.argtypes = [vp, vp, u64, u32, vp, vp, u64, C.POINTER(u64), C.POINTER(u64),
@@ -369,6 +375,27 @@ class Context:
 
     def stream_bloom_insert_ptr(self, d_hashes, n_values, d_filter, n_bits):
         _chk(self.L.nthip_stream_bloom_insert(self.h, C.c_void_p(d_hashes), n_values, C.c_void_p(d_filter), n_bits))
+
+    # -- counting sketch (count-min, one-byte saturating counters) ---------------------------------
+    def count_insert_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_counters, n_counters, flags=0):
+        rd = Reads(seqs, None, n_reads, fixed_len, stride)
+        total = C.c_uint64(0)
+        _chk(self.L.nthip_kmer_count_insert(self.h, C.byref(rd), k, m, C.c_void_p(d_counters), C.c_uint64(n_counters),
+                                            C.byref(total), flags))
+        return total.value
+
+    def count_insert(self, data, k, m, fixed_len, n_reads, d_counters, n_counters, stride=0):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        return self.count_insert_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, d_counters, n_counters,
+                                     flags=NTHIP_HOST_INPUT)
+
+    def stream_count_insert_ptr(self, d_hashes, n_values, d_counters, n_counters):
+        _chk(self.L.nthip_stream_count_insert(self.h, C.c_void_p(d_hashes), C.c_uint64(n_values), C.c_void_p(d_counters),
+                                              C.c_uint64(n_counters)))
+
+    def stream_count_query_ptr(self, d_hashes, n_kmers, m, d_counters, n_counters, d_estimates):
+        _chk(self.L.nthip_stream_count_query(self.h, C.c_void_p(d_hashes), C.c_uint64(n_kmers), C.c_uint8(m),
+                                             C.c_void_p(d_counters), C.c_uint64(n_counters), C.c_void_p(d_estimates)))
 
     def bloom_new(self, n_bits):
         """zeroed device filter of n_bits bits; returns (device pointer, bytes)"""

@@ -65,9 +65,10 @@ constexpr uint32_t BB_REGION_DWORDS = 1u << (BB_REGION_SHIFT - 5);
 
 // ---- hist: values per region ---------------------------------------------------------------------------------------
 // dynamic LDS: n_regions counters.  counts[r] += ...; every block flushes the counters it touched.
+// (region_shift: log2 of the table slots per region -- 20 for a filter's bits, 15 for a sketch's counters)
 static __global__ __launch_bounds__(1024) void bloom_hist_kernel(const uint64_t* __restrict__ hashes, uint64_t n, uint64_t n_bits,
                                                                  uint64_t magic, uint32_t n_regions,
-                                                                 uint32_t* __restrict__ counts)
+                                                                 uint32_t* __restrict__ counts, uint32_t region_shift)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t bb_lds[];
   for (uint32_t i = threadIdx.x; i < n_regions; i += blockDim.x) bb_lds[i] = 0;
@@ -78,12 +79,12 @@ static __global__ __launch_bounds__(1024) void bloom_hist_kernel(const uint64_t*
   const bb_v2ul* h2 = (const bb_v2ul*)(hashes + head);
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * blockDim.x) {
     const bb_v2ul v = __builtin_nontemporal_load(h2 + i);
-    atomicAdd(&bb_lds[(uint32_t)(mod_invariant(v.x, n_bits, magic) >> BB_REGION_SHIFT)], 1u);
-    atomicAdd(&bb_lds[(uint32_t)(mod_invariant(v.y, n_bits, magic) >> BB_REGION_SHIFT)], 1u);
+    atomicAdd(&bb_lds[(uint32_t)(mod_invariant(v.x, n_bits, magic) >> region_shift)], 1u);
+    atomicAdd(&bb_lds[(uint32_t)(mod_invariant(v.y, n_bits, magic) >> region_shift)], 1u);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (head) atomicAdd(&bb_lds[(uint32_t)(mod_invariant(hashes[0], n_bits, magic) >> BB_REGION_SHIFT)], 1u);
-    if ((n - head) & 1u) atomicAdd(&bb_lds[(uint32_t)(mod_invariant(hashes[n - 1], n_bits, magic) >> BB_REGION_SHIFT)], 1u);
+    if (head) atomicAdd(&bb_lds[(uint32_t)(mod_invariant(hashes[0], n_bits, magic) >> region_shift)], 1u);
+    if ((n - head) & 1u) atomicAdd(&bb_lds[(uint32_t)(mod_invariant(hashes[n - 1], n_bits, magic) >> region_shift)], 1u);
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < n_regions; i += blockDim.x) {
@@ -305,6 +306,93 @@ static __global__ __launch_bounds__(BB_APPLY_THREADS) void bloom_apply_kernel(co
     for (uint32_t i = (here & ~3u) + threadIdx.x; i < here; i += BB_APPLY_THREADS) // (a filter that does not end on 16 bytes)
       if (bb_lds[i]) filter[d0 + i] |= bb_lds[i];
     __syncthreads();
+  }
+}
+
+// ---- the counting sketch's apply: a workgroup per region of 2^15 one-byte counters -------------------------------------
+// (count-min sketch: every value adds one to counter `h mod n_counters`, saturating at 255.)  dynamic LDS: 128 KiB =
+// 32-bit tallies of the region's counters; entries = 15-bit offsets.  Then every 4 counters that got something are read
+// (one dword of the sketch), added to byte by byte with saturation, and written back.
+constexpr uint32_t CS_REGION_SHIFT = 15;
+constexpr uint32_t CS_BIN_SHIFT = CS_REGION_SHIFT + 7; // 128 regions per bin, as the filter's
+__device__ __forceinline__ uint32_t sat_add_bytes(uint32_t word, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3)
+{
+  const uint32_t b0 = (word & 0xFFu) + a0, b1 = ((word >> 8) & 0xFFu) + a1, b2 = ((word >> 16) & 0xFFu) + a2, b3 = (word >> 24) + a3;
+  // (a tally can be anything up to 2^31: compare before the sum can wrap)
+  const uint32_t c0 = a0 > 255u || b0 > 255u ? 255u : b0, c1 = a1 > 255u || b1 > 255u ? 255u : b1;
+  const uint32_t c2 = a2 > 255u || b2 > 255u ? 255u : b2, c3 = a3 > 255u || b3 > 255u ? 255u : b3;
+  return c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+}
+static __global__ __launch_bounds__(BB_APPLY_THREADS) void count_apply_kernel(const uint32_t* __restrict__ entries,
+                                                                              const uint32_t* __restrict__ region_base,
+                                                                              uint32_t n_regions, uint32_t* __restrict__ sketch,
+                                                                              uint64_t sketch_dwords)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t bb_lds[];
+  uint4* const l4 = (uint4*)bb_lds;
+  constexpr uint32_t SLOTS = 1u << CS_REGION_SHIFT; // counters per region = LDS tallies
+  for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+    const uint32_t e0 = region_base[r], e1 = region_base[r + 1];
+    if (e0 == e1) continue; // (uniform over the block)
+    for (uint32_t i = threadIdx.x; i < SLOTS / 4u; i += BB_APPLY_THREADS) l4[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t up = (e0 + 3u) & ~3u;
+    const uint32_t a0 = up < e1 ? up : e1, a1 = e1 & ~3u;
+    auto put = [&](uint32_t e) { atomicAdd(&bb_lds[e], 1u); };
+    if (threadIdx.x < a0 - e0) put(entries[e0 + threadIdx.x]);
+    if (a1 > a0) {
+      const bb_v4u* v = (const bb_v4u*)(entries + a0);
+      const uint32_t nv = (a1 - a0) >> 2;
+      for (uint32_t i = threadIdx.x; i < nv; i += BB_APPLY_THREADS) {
+        const bb_v4u q = __builtin_nontemporal_load(v + i);
+        put(q.x);
+        put(q.y);
+        put(q.z);
+        put(q.w);
+      }
+    }
+    if (a1 >= a0 && threadIdx.x < e1 - a1) put(entries[a1 + threadIdx.x]);
+    __syncthreads();
+    const uint64_t d0 = (uint64_t)r * (SLOTS / 4u); // the region's first dword of the sketch
+    const uint64_t left = sketch_dwords - d0;
+    const uint32_t here = left < SLOTS / 4u ? (uint32_t)left : SLOTS / 4u;
+    for (uint32_t i = threadIdx.x; i < here; i += BB_APPLY_THREADS) {
+      const uint4 t = l4[i];
+      if (t.x | t.y | t.z | t.w) sketch[d0 + i] = sat_add_bytes(sketch[d0 + i], t.x, t.y, t.z, t.w);
+    }
+    __syncthreads();
+  }
+}
+
+// small batches / sketches beyond the lists' reach: one compare-and-swap loop per value
+static __global__ __launch_bounds__(256) void count_atomic_kernel(const uint64_t* __restrict__ hashes, uint64_t n,
+                                                                  uint32_t* __restrict__ sketch, uint64_t n_counters, uint64_t magic)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p = mod_invariant(hashes[i], n_counters, magic);
+    uint32_t* const w = sketch + (p >> 2);
+    const uint32_t sh = ((uint32_t)p & 3u) * 8u;
+    uint32_t old = *w;
+    while (((old >> sh) & 0xFFu) != 0xFFu) {
+      const uint32_t seen = atomicCAS(w, old, old + (1u << sh));
+      if (seen == old) break;
+      old = seen;
+    }
+  }
+}
+
+// estimate of a k-mer: the smallest of its m counters (values: m per k-mer, as nthip_kmer_hash writes them)
+static __global__ __launch_bounds__(256) void count_query_kernel(const uint64_t* __restrict__ hashes, uint64_t n_kmers, uint32_t m,
+                                                                 const uint8_t* __restrict__ sketch, uint64_t n_counters,
+                                                                 uint64_t magic, uint8_t* __restrict__ out)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_kmers; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t lo = 255u;
+    for (uint32_t j = 0; j < m; ++j) {
+      const uint32_t v = sketch[mod_invariant(hashes[i * m + j], n_counters, magic)];
+      lo = v < lo ? v : lo;
+    }
+    out[i] = (uint8_t)lo;
   }
 }
 

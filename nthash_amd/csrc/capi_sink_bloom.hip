@@ -19,13 +19,15 @@ constexpr uint64_t BB_ROUND_MAX = 1ull << 31; // values per round: the lists are
 // Does a batch of n values into this filter go through the lists?  The filter must fit the histogram (2^35 bits) and
 // sit on 16 bytes; the round's fixed costs -- one read-modify-write of the touched filter lines, five launches --
 // must be small next to what the atomics would cost: ~37 ps per value against ~8 ps per value + ~0.4 ps per filter byte.
-bool bloom_binned_ok(const nthip_ctx* c, const void* d_filter, uint64_t n_bits, uint64_t n_values)
+// (counters: the counting sketch -- one-byte slots, 2^15 per region -- instead of a filter's bits, 2^20 per region)
+bool bloom_binned_ok(const nthip_ctx* c, const void* d_filter, uint64_t n_bits, uint64_t n_values, bool counters = false)
 {
   if (c->tune.bloom_binned == 2) return false;
-  if (n_bits > ((uint64_t)BB_MAX_REGIONS << BB_REGION_SHIFT) || ((uintptr_t)d_filter & 15u)) return false;
+  const uint32_t region_shift = counters ? CS_REGION_SHIFT : BB_REGION_SHIFT;
+  if (n_bits > ((uint64_t)BB_MAX_REGIONS << region_shift) || ((uintptr_t)d_filter & 15u)) return false;
   if (c->lds_max < (size_t)BB_REGION_DWORDS * 4 + 1024) return false;
   if (c->tune.bloom_binned == 1) return n_values != 0;
-  const uint64_t filter_bytes = (n_bits + 7) / 8;
+  const uint64_t filter_bytes = counters ? n_bits : (n_bits + 7) / 8;
   return n_values >= (1ull << 22) && n_values >= filter_bytes / 64;
 }
 
@@ -76,18 +78,19 @@ uint64_t bloom_round_values(const nthip_ctx* c, uint64_t n_values, bool with_str
 
 // one round: n <= BB_ROUND_MAX values of a device-resident stream into the filter (launches only, no synchronisation)
 int bloom_binned_round(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n, uint32_t* d_filter, uint64_t n_bits,
-                       const BloomLists& t)
+                       const BloomLists& t, bool counters = false)
 {
-  const uint32_t n_regions = (uint32_t)((n_bits + (1ull << BB_REGION_SHIFT) - 1) >> BB_REGION_SHIFT);
+  const uint32_t region_shift = counters ? CS_REGION_SHIFT : BB_REGION_SHIFT, bin_shift = region_shift + 7u;
+  const uint32_t n_regions = (uint32_t)((n_bits + (1ull << region_shift) - 1) >> region_shift);
   const uint32_t n_bins = (n_regions + BB_REGIONS_PER_BIN - 1) / BB_REGIONS_PER_BIN;
   const uint64_t magic = bloom_magic_of(n_bits);
-  const uint64_t filter_dwords = (n_bits + 31) / 32;
+  const uint64_t filter_dwords = counters ? (n_bits + 3) / 4 : (n_bits + 31) / 32;
   HIPCHK(hipMemsetAsync(t.counts, 0, (size_t)n_regions * sizeof(uint32_t), c->stream));
   const size_t hist_lds = (size_t)(n_regions < 128u ? 128u : n_regions) * sizeof(uint32_t);
   NTCHK(set_max_lds(c, bloom_hist_kernel, hist_lds));
-  prof_begin(c, "bloom binned insert (hist, scan, part, apply)");
+  prof_begin(c, counters ? "count binned insert (hist, scan, part, apply)" : "bloom binned insert (hist, scan, part, apply)");
   hipLaunchKernelGGL(bloom_hist_kernel, dim3(c->n_cu), dim3(1024), hist_lds, c->stream, d_hashes, n, n_bits, magic, n_regions,
-                     t.counts);
+                     t.counts, region_shift);
   hipLaunchKernelGGL(bloom_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)t.counts, n_regions, t.region_base,
                      t.region_cursor, t.bin_cursor);
   auto part_lds = [](uint32_t threads) { return (size_t)threads * BB_PART_ITEMS * (sizeof(uint32_t) + (BB_COPY_SLOT ? 1 : 0)); };
@@ -106,24 +109,24 @@ int bloom_binned_round(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n, uint3
   if (n_bins == 1) { // a filter of at most 2^27 bits: straight to the regions
     a.out = t.list2;
     a.cursor = t.region_cursor;
-    a.shift = BB_REGION_SHIFT;
-    a.mask = (1u << BB_REGION_SHIFT) - 1u;
+    a.shift = region_shift;
+    a.mask = (1u << region_shift) - 1u;
     a.buckets_per_seg = n_regions;
     hipLaunchKernelGGL((bloom_part_kernel<true, BB_L1_THREADS>), dim3(part_blocks(BB_L1_THREADS)), dim3(BB_L1_THREADS),
                        part_lds(BB_L1_THREADS), c->stream, a);
   } else {
     a.out = t.list1;
     a.cursor = t.bin_cursor;
-    a.shift = BB_BIN_SHIFT;
-    a.mask = (1u << BB_BIN_SHIFT) - 1u;
+    a.shift = bin_shift;
+    a.mask = (1u << bin_shift) - 1u;
     a.buckets_per_seg = n_bins;
     hipLaunchKernelGGL((bloom_part_kernel<true, BB_L1_THREADS>), dim3(part_blocks(BB_L1_THREADS)), dim3(BB_L1_THREADS),
                        part_lds(BB_L1_THREADS), c->stream, a);
     a.in = t.list1;
     a.out = t.list2;
     a.cursor = t.region_cursor;
-    a.shift = BB_REGION_SHIFT;
-    a.mask = (1u << BB_REGION_SHIFT) - 1u;
+    a.shift = region_shift;
+    a.mask = (1u << region_shift) - 1u;
     a.buckets_per_seg = BB_REGIONS_PER_BIN;
     const uint32_t per_bin = part_blocks(BB_L2_THREADS) / n_bins + 1u;
     hipLaunchKernelGGL((bloom_part_kernel<false, BB_L2_THREADS>), dim3(per_bin, n_bins), dim3(BB_L2_THREADS),
@@ -131,10 +134,16 @@ int bloom_binned_round(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n, uint3
   }
   entries = t.list2;
   const size_t apply_lds = (size_t)BB_REGION_DWORDS * sizeof(uint32_t);
-  NTCHK(set_max_lds(c, bloom_apply_kernel, apply_lds));
   const uint32_t grid = n_regions < (uint32_t)c->n_cu ? n_regions : (uint32_t)c->n_cu;
-  hipLaunchKernelGGL(bloom_apply_kernel, dim3(grid), dim3(BB_APPLY_THREADS), apply_lds, c->stream, entries,
-                     (const uint32_t*)t.region_base, n_regions, d_filter, filter_dwords);
+  if (counters) {
+    NTCHK(set_max_lds(c, count_apply_kernel, apply_lds));
+    hipLaunchKernelGGL(count_apply_kernel, dim3(grid), dim3(BB_APPLY_THREADS), apply_lds, c->stream, entries,
+                       (const uint32_t*)t.region_base, n_regions, d_filter, filter_dwords);
+  } else {
+    NTCHK(set_max_lds(c, bloom_apply_kernel, apply_lds));
+    hipLaunchKernelGGL(bloom_apply_kernel, dim3(grid), dim3(BB_APPLY_THREADS), apply_lds, c->stream, entries,
+                       (const uint32_t*)t.region_base, n_regions, d_filter, filter_dwords);
+  }
   prof_end(c);
   HIPCHK(hipGetLastError());
   return NTHIP_OK;
@@ -279,6 +288,117 @@ extern "C" int nthip_stream_bloom_insert(nthip_ctx* c, const uint64_t* d_hashes,
   prof_begin(c, "stream_bloom_insert_kernel");
   hipLaunchKernelGGL(stream_bloom_insert_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, d_hashes, n_values,
                      (uint32_t*)d_filter, n_bits, bloom_magic_of(n_bits));
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+// ---- k-mer counting sketch ("k-mer counting sketch") -------------------------------------------------
+// A count-min sketch of one-byte counters: every hash value adds one to counter `h mod n_counters`, saturating at 255; the
+// estimate of a k-mer is the smallest of its m counters.  Plain count-min (not the order-dependent "increment the
+// minimum" variant): the result does not depend on the order of the values, so it is compared byte for byte with the
+// table built on the CPU from the oracle's stream.  Large batches go through the lists of the binned Bloom insert
+// (regions of 2^15 counters, 32-bit tallies in LDS, one saturating read-modify-write of the touched dwords); small ones
+// and sketches of more than 2^30 counters take a compare-and-swap per value.
+namespace {
+int count_insert_stream(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, uint32_t* d_counters, uint64_t n_counters,
+                        const BloomLists* have)
+{
+  if (n_values == 0) return NTHIP_OK;
+  if (bloom_binned_ok(c, d_counters, n_counters, n_values, true)) {
+    BloomLists t;
+    uint64_t round = n_values;
+    if (have) {
+      t = *have; // (the reads entry: its round already fits the lists)
+    } else {
+      round = bloom_round_values(c, n_values, false);
+      NTCHK(bloom_lists(c, round, false, &t));
+    }
+    for (uint64_t v0 = 0; v0 < n_values; v0 += round)
+      NTCHK(bloom_binned_round(c, d_hashes + v0, n_values - v0 < round ? n_values - v0 : round, d_counters, n_counters, t, true));
+    return NTHIP_OK;
+  }
+  prof_begin(c, "count_atomic_kernel");
+  hipLaunchKernelGGL(count_atomic_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, d_hashes, n_values, d_counters, n_counters,
+                     bloom_magic_of(n_counters));
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+int check_sketch(const void* d_counters, uint64_t n_counters)
+{
+  if (!d_counters || n_counters == 0) return fail(NTHIP_ERR_ARG, "sketch is NULL / n_counters is 0");
+  if ((uintptr_t)d_counters & 3u) return fail(NTHIP_ERR_ARG, "sketch must be 4-byte aligned");
+  if (n_counters & 3u) return fail(NTHIP_ERR_ARG, "n_counters must be a multiple of 4 (the counters are updated a dword at a time)");
+  return NTHIP_OK;
+}
+} // namespace
+
+extern "C" int nthip_stream_count_insert(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, uint8_t* d_counters,
+                                         uint64_t n_counters)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  NTCHK(check_sketch(d_counters, n_counters));
+  if (n_values && !d_hashes) return fail(NTHIP_ERR_ARG, "hashes is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  NTCHK(count_insert_stream(c, d_hashes, n_values, (uint32_t*)d_counters, n_counters, nullptr));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_kmer_count_insert(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m, uint8_t* d_counters,
+                                       uint64_t n_counters, uint64_t* total_out, uint32_t flags)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  NTCHK(check_reads(rd));
+  NTCHK(check_sketch(d_counters, n_counters));
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
+  if (k < 3) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 is undefined in the reference (src/kmer.cpp:47)");
+  if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
+  if (rd->offsets) return fail(NTHIP_ERR_UNSUPPORTED, "the consumers take fixed-length reads (offsets == NULL)");
+  HIPCHK(hipSetDevice(c->device));
+  if (total_out) *total_out = 0;
+  const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
+  if (rd->n_reads == 0 || len < k) return NTHIP_OK;
+  const uint64_t per_read = (uint64_t)(len - k + 1) * m;
+  const uint64_t round = bloom_round_values(c, rd->n_reads * per_read, true);
+  const uint64_t reads_per_round = round / per_read;
+  if (reads_per_round == 0) return fail(NTHIP_ERR_UNSUPPORTED, "reads too long for the counting sketch's rounds");
+  BloomLists t;
+  NTCHK(bloom_lists(c, reads_per_round * per_read, true, &t));
+  uint64_t sum = 0;
+  for (uint64_t r0 = 0; r0 < rd->n_reads; r0 += reads_per_round) {
+    const uint64_t nr = rd->n_reads - r0 < reads_per_round ? rd->n_reads - r0 : reads_per_round;
+    nthip_reads part = *rd;
+    part.seqs = rd->seqs + r0 * stride;
+    part.n_reads = nr;
+    nthip_out out;
+    memset(&out, 0, sizeof out);
+    out.hashes = t.hashes;
+    out.capacity = nr * (uint64_t)(len - k + 1);
+    uint64_t total = 0;
+    NTCHK(nthip_kmer_hash(c, &part, k, m, &out, &total, flags & NTHIP_HOST_INPUT));
+    sum += total;
+    NTCHK(count_insert_stream(c, t.hashes, total * m, (uint32_t*)d_counters, n_counters, &t));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (total_out) *total_out = sum;
+  return NTHIP_OK;
+}
+
+extern "C" int nthip_stream_count_query(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_kmers, uint8_t m,
+                                        const uint8_t* d_counters, uint64_t n_counters, uint8_t* d_estimates)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  NTCHK(check_sketch(d_counters, n_counters));
+  if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
+  if (n_kmers && (!d_hashes || !d_estimates)) return fail(NTHIP_ERR_ARG, "hashes / estimates is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  if (n_kmers == 0) return NTHIP_OK;
+  prof_begin(c, "count_query_kernel");
+  hipLaunchKernelGGL(count_query_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, d_hashes, n_kmers, (uint32_t)m, d_counters,
+                     n_counters, bloom_magic_of(n_counters), d_estimates);
   prof_end(c);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -1136,6 +1136,92 @@ def test_bloom_binned_insert_matches_oracle_hash_stream(oracle, n, L, k, m, n_bi
     ctx.close()
 
 
+@pytest.mark.parametrize("n,L,k,m,n_counters,dirty,binned", [
+    (3000, 150, 31, 1, 1 << 16, False, True),            # 2 regions: counters pile up (saturation at 255 matters)
+    (3000, 150, 31, 4, 4_000_036, True, True),           # not a power of two, a partial last region; reads with N
+    (1, 150, 31, 8, 64, False, True), (300, 36, 21, 1, 36, False, True),
+    (4000, 150, 31, 2, (1 << 23) + 12_344, False, True), # 3 bins: both partition levels
+    (2500, 250, 31, 1, 1 << 26, True, True),             # 16 bins
+    (3000, 150, 31, 3, 1 << 14, False, False), (2000, 101, 25, 2, 999_984, True, False),   # the compare-and-swap kernel
+])
+def test_count_sketch_insert_and_query_match_oracle_hash_stream(oracle, n, L, k, m, n_counters, dirty, binned):
+    """k-mer counting sketch (count-min, one-byte saturating counters): the table after nthip_kmer_count_insert /
+    nthip_stream_count_insert == min(255, prior + number of stream values with h mod n_counters == slot), built on the
+    CPU from the oracle's hash stream; nthip_stream_count_query == the smallest of each k-mer's m counters.  Both insert
+    paths: the lists of the binned insert (NTHIP_TUNE_BLOOM_BINNED=1) and the compare-and-swap kernel (=2)"""
+    import os
+    import nthash_amd
+    os.environ["NTHIP_TUNE_BLOOM_BINNED"] = "1" if binned else "2"
+    try:
+        ctx = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_BLOOM_BINNED", None)
+    rng = np.random.default_rng(n + L + m)
+    data = oracle.synth_reads(2, n, L, 77 + k).copy()
+    data[: 4 * L] = ord("A")                       # one k-mer ~500 times: its counters saturate
+    if dirty:
+        bad = rng.choice(n * L, max(3, n * L // 500), replace=False)
+        data[bad] = np.frombuffer(b"NnRY-", dtype=np.uint8)[rng.integers(0, 5, bad.size)]
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    hs = np.ascontiguousarray(want["hashes"]).ravel()
+    slots = (hs % np.uint64(n_counters)).astype(np.int64)
+    tally = np.bincount(slots, minlength=n_counters).astype(np.int64)
+
+    d_c = ctx.malloc(n_counters)
+    ctx.memset(d_c, 0, n_counters)
+    ctx.set_profiling(True)
+    total = ctx.count_insert(data, k, m, L, n, d_c, n_counters)
+    name = ctx.last_kernel_ms()[1]
+    ctx.set_profiling(False)
+    assert name.startswith("count binned insert" if binned else "count_atomic_kernel"), name
+    assert total == want["total"]
+    got = np.zeros(n_counters, np.uint8)
+    ctx.d2h(got, d_c)
+    exp = np.minimum(255, tally).astype(np.uint8)
+    assert (got == exp).all(), (int((got != exp).sum()), "counters differ")
+    assert n < 1000 or exp.max() == 255           # (the saturating case is really exercised)
+    # on a sketch that already holds counts (some near the top), from a materialised stream in two uneven calls
+    prior = rng.integers(0, 256, n_counters, dtype=np.int64)
+    prior[::5] = 250
+    ctx.h2d(d_c, prior.astype(np.uint8))
+    d_h = ctx.malloc(max(8, hs.size * 8))
+    ctx.h2d(d_h, hs)
+    cut = hs.size // 3 | 1
+    ctx.stream_count_insert_ptr(d_h, cut, d_c, n_counters)
+    ctx.stream_count_insert_ptr(d_h + 8 * cut, hs.size - cut, d_c, n_counters)
+    ctx.d2h(got, d_c)
+    exp2 = np.minimum(255, prior + tally).astype(np.uint8)
+    assert (got == exp2).all(), (int((got != exp2).sum()), "counters differ")
+    # estimates: the smallest of a k-mer's m counters
+    n_kmers = hs.size // m
+    d_e = ctx.malloc(max(4, n_kmers))
+    ctx.stream_count_query_ptr(d_h, n_kmers, m, d_c, n_counters, d_e)
+    est = np.zeros(n_kmers, np.uint8)
+    if n_kmers:
+        ctx.d2h(est, d_e)
+    assert (est == exp2[slots.reshape(n_kmers, m)].min(axis=1)).all()
+    for p in (d_e, d_h, d_c):
+        ctx.free(p)
+    ctx.close()
+
+
+def test_count_sketch_argument_errors(ctx):
+    d_c = ctx.malloc(1024)
+    data = np.frombuffer(b"ACGT" * 50, dtype=np.uint8)
+    import nthash_amd
+    for bad in (lambda: ctx.count_insert(data, 31, 1, 200, 1, 0, 1024),          # NULL sketch
+                lambda: ctx.count_insert(data, 31, 1, 200, 1, d_c + 1, 1024),    # unaligned
+                lambda: ctx.count_insert(data, 31, 1, 200, 1, d_c, 1022),        # not a multiple of 4
+                lambda: ctx.count_insert(data, 31, 1, 200, 1, d_c, 0),
+                lambda: ctx.count_insert(data, 0, 1, 200, 1, d_c, 1024),
+                lambda: ctx.count_insert(data, 31, 0, 200, 1, d_c, 1024)):
+        with pytest.raises(nthash_amd.NtHipError):
+            bad()
+    assert ctx.count_insert(data, 31, 1, 20, 10, d_c, 1024) == 0    # reads shorter than k: nothing counted
+    ctx.free(d_c)
+
+
 @pytest.mark.parametrize("n,L,k,m,n_bits", [
     (2000, 150, 31, 1, 1 << 20), (2000, 150, 31, 3, 3_000_017), (1200, 101, 25, 2, 700_001), (40, 5003, 31, 2, 1 << 21),
     (900, 100, 64, 1, 1 << 19),
