@@ -164,6 +164,21 @@ int launch_seed_wave(nthip_ctx* c, const SeedWavePlan& plan, uint64_t n_items, b
 
 namespace {
 
+// A seed set that needs several passes over the position tables is ONE pass in the any-seed form (whole records; k / 16
+// table words per seed and window instead of one table byte per 8 bases).  Picoseconds per k-mer, fitted on
+// tools/seed_sweep.py (profiles/r03_seed_any_sweep.txt, 14 multi-pass shapes, every one within 15 %): the passes are bound by
+// their partial-record writes (1.25 TB/s: 6.4 ps per hash) or their table lookups (0.85 ps per seed and table), the any form
+// by its arithmetic (2.1 ps per seed and group of 16 bases).  6 seeds of 31: 25.6 -> 38.1 G k-mers/s; 5 x 2: 15.1 -> 37.6;
+// 2 x 2 of 80 bases: 38.2 -> 46.7; 4 seeds of 64 and 2 of 100 stay on the passes (37.2 / 30.5, 51.1 / 40.4)
+bool seed_any_cheaper(uint32_t n_seeds, uint32_t m2, uint32_t k)
+{
+  const double per_h = (double)n_seeds * m2;
+  const double t_lookups = 0.85 * n_seeds * ((k + 7) / 8);
+  const double t_pass = 6.4 * per_h > t_lookups ? 6.4 * per_h : t_lookups;
+  const double t_any = 2.1 * n_seeds * ((k + 15) / 16) + 0.5 * per_h;
+  return t_any < t_pass;
+}
+
 // Variable-length short reads in order (offsets, or the sequence lines of a FASTQ chunk): the reads without a non-base
 // on seed_rtile_kernel (tiles of whole reads), the others -- SeedNtHash's position state machine -- on seed_wave_kernel
 // from a list, into the holes they left.  *handled = false: outside this path, nothing written.
@@ -173,7 +188,8 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
 {
   *handled = false;
   const uint32_t k = sd->k;
-  if (c->tune.no_seed_reads || n == 0 || st.fwd || st.rev || k > 64 || m2 > (uint32_t)SF_MAX_RUNTIME_M) return NTHIP_OK;
+  if (c->tune.no_seed_reads || n == 0 || st.fwd || st.rev || m2 > (uint32_t)SF_MAX_RUNTIME_M) return NTHIP_OK;
+  if (k > 64 && c->tune.seed_any == 2) return NTHIP_OK; // (A/B: the position tables end at 64 bases here)
   unsigned long long* d_res = (unsigned long long*)(c->d_small + 96);
   unsigned long long* d_ndirty = (unsigned long long*)(c->d_small + 128);
   HIPCHK(hipMemsetAsync(c->d_small + 96, 0, 48, c->stream));
@@ -234,9 +250,24 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
     const uint32_t passes = (sd->n_seeds + most - 1) / most;
     pass_seeds = (sd->n_seeds + passes - 1) / passes;
   }
-  const uint32_t nh = rot ? 4u : nh_plain;
-  const size_t table_bytes = rot ? (size_t)65536 * ((pass_seeds + 1) / 2) : plain_bytes(pass_seeds);
-  const uint32_t waves = waves_for(table_bytes, pass_seeds);
+  // the any-seed form (seed_rtile_kernel<0>): seeds beyond 64 bases, and seed sets of several table passes where the cost
+  // model of launch_seed_wtile puts one pass of it ahead
+  bool use_any = k > 64 || c->tune.seed_any == 1;
+  if (!use_any && !rot && pass_seeds < sd->n_seeds && c->tune.seed_any != 2 && !c->tune.seed_pass)
+    use_any = seed_any_cheaper(sd->n_seeds, m2, k);
+  size_t any_bytes = 0;
+  if (use_any) {
+    const uint32_t n_grp = sd->n_seeds * sd->any_groups;
+    any_bytes = ((size_t)FW_AC + 16 + n_grp + ((n_grp + 3) >> 2)) * sizeof(uint4);
+    pass_seeds = sd->n_seeds;
+    rot = false;
+  }
+  const uint32_t nh = use_any ? 0u : rot ? 4u : nh_plain;
+  const size_t table_bytes = use_any ? any_bytes : rot ? (size_t)65536 * ((pass_seeds + 1) / 2) : plain_bytes(pass_seeds);
+  uint32_t waves = waves_for(table_bytes, pass_seeds);
+  if (use_any && !waves) // (many hashes per window: fewer than 4 waves still beat one wave per read)
+    for (uint32_t w = 3; w >= 1 && !waves; --w)
+      if (table_bytes + per_wave_of(pass_seeds) * w <= cap) waves = w;
   if (!waves) return NTHIP_OK;
   *handled = true;
 
@@ -330,12 +361,19 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
   ra.wmap_dwords = wmap_dwords;
   ra.waves = waves;
   for (uint32_t i = 0; i < (uint32_t)SF_MAX_RUNTIME_M; ++i) ra.mult[i] = multiplier(k, i);
+  const uint4* fw_tab = nullptr;
+  if (use_any) {
+    NTCHK(get_fw_tab(c, &fw_tab));
+    ra.any_mask = sd->d_any_mask;
+    ra.any_acorr = sd->d_any_acorr;
+    ra.any_groups = sd->any_groups;
+  }
   int rc = NTHIP_OK;
   for (uint32_t s0 = 0; s0 < sd->n_seeds && rc == NTHIP_OK; s0 += pass_seeds) {
     const uint32_t ns = sd->n_seeds - s0 < pass_seeds ? sd->n_seeds - s0 : pass_seeds;
     const uint32_t per_here = ns * m2;
     ra.n_seeds = ns;
-    ra.tables = sd->d_tables + (size_t)s0 * sd->ntab * 256;
+    ra.tables = use_any ? fw_tab : sd->d_tables + (size_t)s0 * sd->ntab * 256;
     ra.pos = s0 == 0 ? st.pos : nullptr;
     if (ns == sd->n_seeds) {
       uint32_t g = per_here, h2 = 16;
@@ -355,7 +393,7 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
       const uint64_t need = (n_tiles + waves - 1) / waves;
       uint64_t grid = (uint64_t)c->n_cu * per_cu;
       if (grid > need) grid = need;
-      if (s0 == 0) prof_begin(c, "seed_rtile_kernel"); // (all passes in one measurement)
+      if (s0 == 0) prof_begin(c, use_any ? "seed_rtile_kernel(any seed set)" : "seed_rtile_kernel"); // (all passes in one measurement)
       hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream, ra);
       prof_end(c);
       HIPCHK(hipGetLastError());
@@ -382,6 +420,7 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
       }
     } else {
       switch (nh) {
+        case 0: rc = go(seed_rtile_kernel<0>); break; // the any-seed form
         case 1: rc = go(seed_rtile_kernel<1>); break;
         case 2: rc = go(seed_rtile_kernel<2>); break;
         case 3: rc = go(seed_rtile_kernel<3>); break;
@@ -584,21 +623,9 @@ int launch_seed_wtile(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* s
     while (most > 1 && waves_for(plain_bytes(most), most) == 0) --most;
     const uint32_t passes = (f.n_seeds + most - 1) / most;
     pass_seeds = (f.n_seeds + passes - 1) / passes;
-    // a seed set that needs several passes here is ONE pass in the any-seed form (whole records; k / 16 table words per
-    // seed and window instead of one table byte per 8 bases).  Picoseconds per k-mer, fitted on tools/seed_sweep.py
-    // (profiles/r03_seed_any_sweep.txt, 14 multi-pass shapes, every one within 15 %): the passes are bound by their
-    // partial-record writes (1.25 TB/s: 6.4 ps per hash) or their table lookups (0.85 ps per seed and table), the any
-    // form by its arithmetic (2.1 ps per seed and group of 16 bases).  6 seeds of 31: 25.6 -> 38.1 G k-mers/s; 5 x 2: 15.1
-    // -> 37.6; 2 x 2 of 80 bases: 38.2 -> 46.7; 4 seeds of 64 and 2 of 100 stay on the passes (37.2 / 30.5, 51.1 / 40.4)
-    if (passes > 1 && prefer_any) {
-      const double per_h = (double)f.n_seeds * f.m2;
-      const double t_lookups = 0.85 * f.n_seeds * ((f.k + 7) / 8);
-      const double t_pass = 6.4 * per_h > t_lookups ? 6.4 * per_h : t_lookups;
-      const double t_any = 2.1 * f.n_seeds * ((f.k + 15) / 16) + 0.5 * per_h;
-      if (t_any < t_pass) {
-        *prefer_any = true;
-        return NTHIP_OK;
-      }
+    if (passes > 1 && prefer_any && seed_any_cheaper(f.n_seeds, f.m2, f.k)) { // (one pass of the any-seed form instead)
+      *prefer_any = true;
+      return NTHIP_OK;
     }
   }
   const size_t table_bytes = rot ? (size_t)65536 * ((pass_seeds + 1) / 2) : (size_t)pass_seeds * 2 * nh * 256 * sizeof(uint4);

@@ -729,6 +729,10 @@ struct SeedRtileArgs {
   uint32_t bits_dwords, otile_recs, wmap_dwords, waves;
   uint32_t align_recs;      // records after which the stream is on a 128-byte line again: 16 / gcd(values per record, 16)
   uint32_t rec_stride, rec_off; // a pass over some of the seeds: as in SeedWtileArgs
+  // NH == 0, the any-seed form (see seed_wtile_kernel): tables = the fw tables, per (seed, group) mask and constant
+  const uint32_t* any_mask;
+  const uint4* any_acorr;
+  uint32_t any_groups, pad0;
   uint64_t mult[SF_MAX_RUNTIME_M];
 };
 
@@ -738,13 +742,20 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
   constexpr bool ROT = RNS > 0;
   static_assert(!ROT || (NH == 4 && RNS <= 4 && RM2 >= 1 && RM2 <= 4), "rotated-slot layout: k <= 32, <= 4 seeds");
   constexpr uint32_t NSETS = ROT ? (uint32_t)(RNS + 1) / 2u : 0u; // table sets of 64 KiB: seeds {0, 1}, {2, 3}
-  constexpr int NW = (NH + 1) / 2;
+  // ANY (NH == 0, round 3): any seed set of any k in ONE pass from the k-independent fw tables, exactly as in
+  // seed_wtile_kernel -- seeds of more than 64 bases and seed sets of several table passes on variable-length reads
+  constexpr bool ANY = NH == 0;
+  static_assert(!ANY || !ROT, "the any-seed form has its own tables");
+  constexpr int NW = ANY ? 1 : (NH + 1) / 2;
   constexpr uint32_t NT = 2u * NH;
   extern __shared__ __attribute__((aligned(256))) uint32_t lds_dyn[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint4* tabs = (uint4*)lds_dyn;
-  const uint32_t n_entries = ROT ? 4096u * NSETS : a.n_seeds * NT * 256u;
+  const uint32_t n_grp = ANY ? a.n_seeds * a.any_groups : 0u;
+  const uint32_t n_entries = ANY ? FW_AC + 16u + n_grp + ((n_grp + 3u) >> 2) : ROT ? 4096u * NSETS : a.n_seeds * NT * 256u;
+  const uint4* g_acorr = tabs + FW_AC + 16u;
+  const uint32_t* g_mask = (const uint32_t*)(g_acorr + n_grp);
   const uint32_t per = ROT ? (uint32_t)(RNS * RM2) : a.n_seeds * a.m2;
   const uint32_t otile_u64 = a.otile_recs * per + 2u;
   // per wave: record tile | bit stream | read table (first window, last window + 1, first base, first record) | window map
@@ -756,7 +767,13 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
   // read table: one 16-byte entry per read {first window, last window + 1, first base, first record} -- one LDS read
   uint4* rt = (uint4*)(bits + a.bits_dwords);
   uint8_t* wmap = (uint8_t*)(rt + RT); // windows [16c, 16c + 16) of the tile: the read that holds window 16c
-  if constexpr (ROT) {
+  if constexpr (ANY) {
+    for (uint32_t i = tid; i < FW_AC + 16u; i += blockDim.x) tabs[i] = a.tables[i];
+    for (uint32_t i = tid; i < n_grp; i += blockDim.x) {
+      tabs[FW_AC + 16u + i] = a.any_acorr[i];
+      ((uint32_t*)(tabs + FW_AC + 16u + n_grp))[i] = a.any_mask[i];
+    }
+  } else if constexpr (ROT) {
     for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
       const uint32_t set = i >> 12, ii = i & 4095u;
       const uint32_t in_set = (uint32_t)RNS - 2u * set < 2u ? (uint32_t)RNS - 2u * set : 2u;
@@ -868,15 +885,37 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
       if (act) {
         const uint32_t d = b >> 4, sh = (b & 15u) << 1;
         uint32_t w[NW];
-        uint32_t lo = bits[d];
+        if constexpr (!ANY) {
+          uint32_t lo = bits[d];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-          const uint32_t hi = bits[d + i + 1];
-          w[i] = funnel(hi, lo, sh);
-          lo = hi;
+          for (int i = 0; i < NW; ++i) {
+            const uint32_t hi = bits[d + i + 1];
+            w[i] = funnel(hi, lo, sh);
+            lo = hi;
+          }
+        } else {
+          w[0] = 0;
         }
         uint64_t* mine = otile + par + slot * per;
-        if constexpr (ROT) {
+        if constexpr (ANY) {
+          const uint32_t G = a.any_groups, k31 = a.k % 31u, k33 = a.k % 33u;
+          for (uint32_t s = 0; s < a.n_seeds; ++s) {
+            uint4 acc = make_uint4(0, 0, 0, 0);
+            for (uint32_t g = G; g-- > 0;) {
+              const uint32_t word = funnel(bits[d + g + 1u], bits[d + g], sh) & g_mask[s * G + g];
+              const uint4 e = fw_word16(tabs, word), ac = g_acorr[s * G + g];
+              sror_var(acc.x, acc.y, 16u, 16u);
+              srol_var(acc.z, acc.w, 16u, 16u);
+              acc.x ^= e.x ^ ac.x; acc.y ^= e.y ^ ac.y; acc.z ^= e.z ^ ac.z; acc.w ^= e.w ^ ac.w;
+            }
+            srol_var(acc.x, acc.y, k31, k33);
+            const uint64_t h0 = canon_pair(acc.x, acc.y, acc.z, acc.w);
+            mine[s * a.m2] = h0;
+#pragma unroll
+            for (uint32_t jj = 1; jj < (uint32_t)SF_MAX_RUNTIME_M; ++jj)
+              if (jj < a.m2) mine[s * a.m2 + jj] = mix_hash(h0, a.mult[jj]);
+          }
+        } else if constexpr (ROT) {
           uint32_t ad[8];
 #pragma unroll
           for (uint32_t st = 0; st < 8; ++st) ad[st] = __builtin_amdgcn_perm(w[1], w[0], rsel[st]) + roff[st];

@@ -1982,13 +1982,35 @@ def test_seed_any_form_vs_oracle(oracle, forced):
         assert name == "seed_wtile_kernel(any seed set)", (name, k, ns)
         assert got["total"] == want["total"] == n * (L - k + 1)
         assert (got["hashes"] == want["hashes"]).all(), (k, ns, m2)
+        # a batch with non-bases: the clean reads on tiles of whole reads (seed_rtile_kernel<0>, the same form), the
+        # others one by one -- not one wave per read for the whole batch (round 2: seeds beyond 64 bases)
         dirty = data.copy()
         dirty[rng.choice(n * L, 3, replace=False)] = ord("N")
         want = oracle.seed_batch(dirty, offs, seeds, k, m2)
+        c.set_profiling(True)
         got = c.seed_hash(dirty, seeds, k, m2, fixed_len=L, n_reads=n, want_pos=True)
+        name = c.last_kernel_ms()[1]
+        c.set_profiling(False)
+        if k > 64:
+            assert name == "seed_rtile_kernel(any seed set)", (name, k, ns)
         assert got["total"] == want["total"]
         for key in ("counts", "pos", "hashes"):
             assert (got[key] == want[key]).all(), (key, k, ns)
+        # variable-length reads (some shorter than k, one with an N)
+        lens = rng.integers(max(1, k - 5), L + 1, 300)
+        reads = [np.frombuffer(b"ACGTacgt", dtype=np.uint8)[rng.integers(0, 8, int(x))].tobytes() for x in lens]
+        reads[150] = reads[150][: len(reads[150]) // 2] + b"N" + reads[150][len(reads[150]) // 2 + 1:]
+        d, roffs = concat_reads(reads)
+        want = oracle.seed_batch(d, roffs, seeds, k, m2)
+        c.set_profiling(True)
+        got = c.seed_hash(d, seeds, k, m2, offsets=roffs, want_pos=True)
+        name = c.last_kernel_ms()[1]
+        c.set_profiling(False)
+        if k > 64 or forced:
+            assert name == "seed_rtile_kernel(any seed set)", (name, k, ns)
+        assert got["total"] == want["total"]
+        for key in ("counts", "pos", "hashes"):
+            assert (got[key] == want[key]).all(), (key, k, ns, "variable-length")
     c.close()
 
 
@@ -2385,7 +2407,9 @@ def test_seed_passes_vs_oracle(oracle):
             got = c.seed_hash(d, seeds, k, m2, offsets=roffs, want_pos=True)
             name = c.last_kernel_ms()[1]
             c.set_profiling(False)
-            assert name == ("seed_rtile_kernel" if k <= 64 else "seed_wave_kernel"), (name, k, n_seeds, m2)
+            # (seeds beyond 64 bases, and -- on the planned context -- seed sets of several passes: the any-seed form)
+            assert name in (("seed_rtile_kernel", "seed_rtile_kernel(any seed set)") if k <= 64 and c is planned else
+                            ("seed_rtile_kernel",) if k <= 64 else ("seed_rtile_kernel(any seed set)",)), (name, k, n_seeds, m2)
             assert got["total"] == want["total"]
             for key in ("counts", "pos", "hashes"):
                 assert (got[key] == want[key]).all(), (k, n_seeds, m2, key, c is planned)
