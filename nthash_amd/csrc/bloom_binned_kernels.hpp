@@ -213,6 +213,9 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
 #if BB_ABL == 2 // ablation (WRONG results): no cursor atomics, the tile's runs go out back to back
       gbase[tid] = (uint32_t)(t0 - s0) + off[tid] + (IN64 ? 0u : (uint32_t)s0);
       (void)cursor;
+#elif BB_ABL == 3 // ablation (WRONG results): every run starts on a 64-byte piece and is whole pieces long
+      gbase[tid] = c ? (atomicAdd(&cursor[(size_t)tid * BB_CURSOR_STRIDE], c) & ~15u) : 0u;
+      hist[tid] = c & ~15u;
 #else
       gbase[tid] = c ? atomicAdd(&cursor[(size_t)tid * BB_CURSOR_STRIDE], c) : 0u;
 #endif

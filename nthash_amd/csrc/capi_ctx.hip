@@ -280,6 +280,7 @@ void load_tuning(nthip_tune& t)
   t.fw = num("NTHIP_TUNE_FW", 1, 2);
   t.seed_any = num("NTHIP_TUNE_SEED_ANY", 1, 2);
   t.bloom_binned = num("NTHIP_TUNE_BLOOM_BINNED", 1, 2);
+  t.bloom_round = num("NTHIP_TUNE_BLOOM_ROUND", 1024, 0x7FFFFFFF);
   const uint32_t tk = num("NTHIP_TUNE_TABLE_K_MAX", 16, 64);
   ntamd::host::g_kmer_table_k_max = tk ? tk : (uint32_t)KMER_TABLE_K_MAX_N;
 }

@@ -98,6 +98,7 @@ struct nthip_tune {
   uint32_t ph_tiles = 0;    // NTHIP_TUNE_PH_TILES
   uint32_t ph_period = 0;   // NTHIP_TUNE_PH_PERIOD
   uint32_t ph_read = 0;     // NTHIP_TUNE_PH_READ
+  uint32_t bloom_round = 0;  // NTHIP_TUNE_BLOOM_ROUND=<values>: rounds of the binned consumers no longer than this (tests: several rounds on a small batch)
   uint32_t bloom_binned = 0; // NTHIP_TUNE_BLOOM_BINNED=1: the binned insert whenever the filter allows it, 2: never (A/B, tests)
   uint32_t seed_any = 0;    // NTHIP_TUNE_SEED_ANY=1: dense seed batches on the any-seed form whatever the seed set, 2: none of k <= 128 (A/B, tests)
   uint32_t fw = 0;          // NTHIP_TUNE_FW: first window beyond the position tables -- 1 grouped, 2 prefix scan (0: cost model)

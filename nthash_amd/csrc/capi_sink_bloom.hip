@@ -73,6 +73,7 @@ uint64_t bloom_round_values(const nthip_ctx* c, uint64_t n_values, bool with_str
   if (round > BB_ROUND_MAX) round = BB_ROUND_MAX;
   if (round > n_values) round = n_values;
   if (round < (1u << 20)) round = 1u << 20;
+  if (c->tune.bloom_round) round = c->tune.bloom_round;
   return round;
 }
 

@@ -1077,6 +1077,7 @@ def test_bloom_insert_matches_oracle_hash_stream(ctx, oracle, n, L, k, m, n_bits
     (4000, 150, 31, 2, (1 << 28) + 12_345, False),   # 3 bins (the last one partial): both partition levels
     (2500, 250, 31, 1, 1 << 30, True),               # 8 bins
     (1200, 150, 31, 3, (1 << 33) - 1_234_567, False),  # 64 bins, the last one partial
+    (9000, 150, 31, 2, (1 << 28) + 77, True),        # several rounds (NTHIP_TUNE_BLOOM_ROUND below: 300 000 values each)
 ])
 def test_bloom_binned_insert_matches_oracle_hash_stream(oracle, n, L, k, m, n_bits, dirty):
     """the binned insert (histogram -> region lists -> one workgroup per 128 KiB region, no device atomics;
@@ -1085,10 +1086,13 @@ def test_bloom_binned_insert_matches_oracle_hash_stream(oracle, n, L, k, m, n_bi
     import os
     import nthash_amd
     os.environ["NTHIP_TUNE_BLOOM_BINNED"] = "1"
+    if n == 9000:
+        os.environ["NTHIP_TUNE_BLOOM_ROUND"] = "300000"
     try:
         ctx = nthash_amd.Context(0)
     finally:
         os.environ.pop("NTHIP_TUNE_BLOOM_BINNED", None)
+        os.environ.pop("NTHIP_TUNE_BLOOM_ROUND", None)
     rng = np.random.default_rng(n + L + m)
     data = oracle.synth_reads(2, n, L, 99 + k).copy()
     data[: 3 * L] = ord("A")                      # low-complexity reads: one value many times
