@@ -43,7 +43,7 @@ SYMBOLS = [
     "nthip_multi_create", "nthip_multi_destroy", "nthip_multi_device_count", "nthip_multi_kmer_hash",
     "nthip_multi_seeds_create", "nthip_multi_seeds_destroy", "nthip_multi_seed_hash",
     "nthip_packed_size", "nthip_pack_reads", "nthip_multi_fastx_kmer_hash_file", "nthip_host_alloc", "nthip_host_free",
-    "nthip_kmer_count_insert", "nthip_stream_count_insert", "nthip_stream_count_query",
+    "nthip_kmer_count_insert", "nthip_stream_count_insert", "nthip_stream_count_query", "nthip_kmer_minimizers",
 ]
 
 
@@ -123,6 +123,7 @@ def load():
     L.nthip_kmer_count_insert.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, u64, C.POINTER(u64), u32]
     L.nthip_stream_count_insert.argtypes = [vp, vp, u64, vp, u64]
     L.nthip_stream_count_query.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp]
+    L.nthip_kmer_minimizers.argtypes = [vp, C.POINTER(Reads), C.c_uint16, u32, vp, vp, vp, u64, C.POINTER(u64), u32]
     L.nthip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.nthip_host_free.argtypes = [vp]
     L.nthip_kmer_hash_spans.argtypes = [vp, vp, u64, vp, vp, u64, C.c_uint16, C.c_uint8, C.POINTER(Out),
@@ -375,6 +376,39 @@ class Context:
 
     def stream_bloom_insert_ptr(self, d_hashes, n_values, d_filter, n_bits):
         _chk(self.L.nthip_stream_bloom_insert(self.h, C.c_void_p(d_hashes), n_values, C.c_void_p(d_filter), n_bits))
+
+    # -- per-read (w, k)-minimizers ---------------------------------------------------------------
+    def minimizers_ptr(self, seqs, n_reads, fixed_len, stride, k, w, d_hashes, d_pos, d_offsets, capacity, flags=0):
+        """-> number of minimizers (NtHipError with .total set when capacity is too small)"""
+        rd = Reads(seqs, None, n_reads, fixed_len, stride)
+        total = C.c_uint64(0)
+        rc = self.L.nthip_kmer_minimizers(self.h, C.byref(rd), k, w, C.c_void_p(d_hashes), C.c_void_p(d_pos) if d_pos else None,
+                                          C.c_void_p(d_offsets), C.c_uint64(capacity), C.byref(total), flags)
+        if rc != NTHIP_OK:
+            err = NtHipError(rc, self.L.nthip_last_error().decode(errors="replace"))
+            err.total = total.value
+            raise err
+        return total.value
+
+    def minimizers(self, data, k, w, fixed_len, n_reads, stride=0, capacity=None):
+        """host convenience: -> dict(offsets [n_reads + 1], pos, hashes)"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        nwin = max(fixed_len - k + 1, 0)
+        cap = n_reads * nwin if capacity is None else capacity
+        d_h, d_p, d_o = self.malloc(max(8, cap * 8)), self.malloc(max(4, cap * 4)), self.malloc((n_reads + 1) * 8)
+        try:
+            total = self.minimizers_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, w, d_h, d_p, d_o, cap,
+                                        flags=NTHIP_HOST_INPUT)
+            offs = np.zeros(n_reads + 1, np.uint64)
+            self.d2h(offs, d_o)
+            hs, ps = np.zeros(total, np.uint64), np.zeros(total, np.uint32)
+            if total:
+                self.d2h(hs, d_h)
+                self.d2h(ps, d_p)
+            return dict(total=total, offsets=offs, pos=ps, hashes=hs)
+        finally:
+            for p in (d_h, d_p, d_o):
+                self.free(p)
 
     # -- counting sketch (count-min, one-byte saturating counters) ---------------------------------
     def count_insert_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_counters, n_counters, flags=0):

@@ -1,0 +1,134 @@
+// capi_sink_minimizer.hip -- per-read (w, k)-minimizers: nthip_kmer_minimizers
+// Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
+#include "capi_internal.hpp"
+#include "minimizer_kernels.hpp"
+#include "util_kernels.hpp"
+
+using namespace ntamd;
+using namespace ntamd::host;
+
+extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint32_t w, uint64_t* d_min_hashes,
+                                     uint32_t* d_min_pos, uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out,
+                                     uint32_t flags)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  NTCHK(check_reads(rd));
+  const uint32_t k = k16;
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
+  if (k < 3) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 is undefined in the reference (src/kmer.cpp:47)");
+  if (w == 0) return fail(NTHIP_ERR_ARG, "w must be greater than 0");
+  if (rd->offsets) return fail(NTHIP_ERR_UNSUPPORTED, "the consumers take fixed-length reads (offsets == NULL)");
+  if (!d_min_offsets || (capacity && !d_min_hashes)) return fail(NTHIP_ERR_ARG, "min_offsets / min_hashes is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  if (total_out) *total_out = 0;
+  const uint64_t n = rd->n_reads;
+  const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
+  if (n == 0 || len < k) {
+    HIPCHK(hipMemsetAsync(d_min_offsets, 0, (n + 1) * sizeof(uint64_t), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTHIP_OK;
+  }
+  const uint32_t nwin = len - k + 1;
+  // rounds of reads: the emitted stream of a round (hash 8, position 4 -- only written for a round that has a read with a
+  // non-base --, flag 1 byte per k-mer; three 8-byte values per read) in the context's consumer scratch
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
+  free_b += c->bloom_tmp_bytes;
+  uint64_t round_kmers = (uint64_t)(free_b / 2) / 13;
+  if (round_kmers > (1ull << 32)) round_kmers = 1ull << 32;
+  if (c->tune.bloom_round) round_kmers = c->tune.bloom_round; // (tests: several rounds on a small batch)
+  uint64_t reads_per_round = round_kmers / nwin;
+  if (reads_per_round == 0) return fail(NTHIP_ERR_UNSUPPORTED, "reads too long for the minimizer rounds");
+  if (reads_per_round > n) reads_per_round = n;
+  const uint64_t cap_round = reads_per_round * nwin;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const uint32_t chunks = (nwin + 63u) / 64u;
+  const size_t b_h = al(cap_round * 8), b_pos = al(cap_round * 4), b_fl = al(reads_per_round * chunks * 8), b_rd = al(reads_per_round * 8);
+  const size_t b_sums = al((reads_per_round / SCAN_TILE + 64) * 8);
+  const size_t need = b_h + b_pos + b_fl + 4 * b_rd + b_sums + 256;
+  if (c->bloom_tmp_bytes < need) {
+    if (c->bloom_tmp) HIPCHK(hipFree(c->bloom_tmp));
+    c->bloom_tmp = nullptr;
+    c->bloom_tmp_bytes = 0;
+    HIPCHK(hipMalloc((void**)&c->bloom_tmp, need));
+    c->bloom_tmp_bytes = need;
+  }
+  uint8_t* p = c->bloom_tmp;
+  uint64_t* d_h = (uint64_t*)p; p += b_h;
+  uint32_t* d_pos = (uint32_t*)p; p += b_pos;
+  uint64_t* d_masks = (uint64_t*)p; p += b_fl;
+  uint64_t* d_counts = (uint64_t*)p; p += b_rd;
+  uint64_t* d_roff = (uint64_t*)p; p += b_rd;
+  uint64_t* d_picked = (uint64_t*)p; p += b_rd;
+  uint64_t* d_ooff = (uint64_t*)p; p += b_rd;
+  uint64_t* d_sums = (uint64_t*)p; p += b_sums;
+  uint64_t* d_tot = (uint64_t*)p;
+  uint64_t base = 0;
+  bool overflow = false;
+  for (uint64_t r0 = 0; r0 < n; r0 += reads_per_round) {
+    const uint64_t nr = n - r0 < reads_per_round ? n - r0 : reads_per_round;
+    nthip_reads part = *rd;
+    part.seqs = rd->seqs + r0 * stride;
+    part.n_reads = nr;
+    nthip_out out;
+    memset(&out, 0, sizeof out);
+    out.hashes = d_h;
+    out.capacity = nr * (uint64_t)nwin;
+    uint64_t n_kmers = 0;
+    // optimistic: no read of the round has a non-base -- every read emits every window, positions are indices
+    NTCHK(nthip_kmer_hash(c, &part, k16, 1, &out, &n_kmers, flags & NTHIP_HOST_INPUT));
+    const bool dense = n_kmers == nr * (uint64_t)nwin;
+    if (!dense) { // (rare: again, with the positions and the per-read counts)
+      out.counts = d_counts;
+      out.pos = d_pos;
+      NTCHK(nthip_kmer_hash(c, &part, k16, 1, &out, &n_kmers, flags & NTHIP_HOST_INPUT));
+      NTCHK(device_exclusive_scan(c, d_counts, d_roff, nr, d_sums, d_tot));
+    }
+    MinimizerArgs a;
+    memset(&a, 0, sizeof a);
+    a.hashes = d_h;
+    a.pos = dense ? nullptr : d_pos;
+    a.roff = dense ? nullptr : d_roff;
+    a.n_reads = nr;
+    a.n_kmers = n_kmers;
+    a.nwin = nwin;
+    a.w = w;
+    a.masks = d_masks;
+    a.chunks = chunks;
+    a.picked = d_picked;
+    a.out_off = d_ooff;
+    a.base = base;
+    a.capacity = capacity;
+    a.out_hashes = d_min_hashes;
+    a.out_pos = d_min_pos;
+    a.out_offsets = d_min_offsets + r0;
+    const unsigned grid = (unsigned)(c->n_cu * 16);
+    if (nwin > MZ_LDS_POS) HIPCHK(hipMemsetAsync(d_masks, 0, nr * (size_t)chunks * 8, c->stream)); // (the walks OR bits in)
+    prof_begin(c, "minimizer_flag_kernel");
+    if (nwin <= 256) {
+      if (dense) hipLaunchKernelGGL((minimizer_flag_kernel<true, 256>), dim3(grid * 2), dim3(64 * MZ_WAVES), 0, c->stream, a);
+      else hipLaunchKernelGGL((minimizer_flag_kernel<false, 256>), dim3(grid * 2), dim3(64 * MZ_WAVES), 0, c->stream, a);
+    } else {
+      if (dense) hipLaunchKernelGGL((minimizer_flag_kernel<true>), dim3(grid), dim3(64 * MZ_WAVES), 0, c->stream, a);
+      else hipLaunchKernelGGL((minimizer_flag_kernel<false>), dim3(grid), dim3(64 * MZ_WAVES), 0, c->stream, a);
+    }
+    prof_end(c);
+    NTCHK(device_exclusive_scan(c, d_picked, d_ooff, nr, d_sums, d_tot + 1));
+    if (dense) hipLaunchKernelGGL(minimizer_write_kernel<true>, dim3(grid), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(minimizer_write_kernel<false>, dim3(grid), dim3(256), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_small + 8, d_tot + 1, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint64_t round_total = 0;
+    memcpy(&round_total, c->h_small + 8, 8);
+    if (base + round_total > capacity) overflow = true;
+    base += round_total;
+  }
+  HIPCHK(hipMemcpyAsync(d_min_offsets + n, &base, sizeof base, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (total_out) *total_out = base;
+  if (overflow)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu minimizers < %llu needed", (unsigned long long)capacity,
+                (unsigned long long)base);
+  return NTHIP_OK;
+}

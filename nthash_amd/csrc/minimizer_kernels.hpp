@@ -1,0 +1,223 @@
+// minimizer_kernels.hpp -- per-read (w, k)-minimizers of the canonical ntHash values (a consumer of the hash stream).
+//
+// What sketching tools built on ntHash keep of a read: of every w consecutive k-mers the one with the smallest hash
+// (here: the canonical hashes()[0] of NtHash, reference src/kmer.cpp:246-264 for which windows are emitted; ties go to
+// the leftmost).  Works on the emitted stream of a batch -- per read its k-mers in order with their window positions --
+// so a k-mer that holds a non-base simply is not there: a window of w positions picks among the k-mers emitted inside
+// it, and picks nothing when there is none.  Reads with fewer than w windows count as one window.
+//
+// k-mer j (position P, hash h) of a read with `nwin` window positions is picked by the window starting at s iff
+//   s <= P <= s + w - 1,   0 <= s <= nwin - w,
+//   no emitted k-mer at a position in [s, P) has a hash <= h   (an equal one to the left wins the tie),
+//   no emitted k-mer at a position in (P, s + w) has a hash < h.
+// With PL = position of the nearest k-mer on the left with hash <= h (none: -1) and PR = of the nearest on the right with
+// hash < h (none: +inf), such an s exists iff  max(PL + 1, P - w + 1, 0) <= min(P, PR - w, nwin - w).
+// That walk (at most w - 1 positions to either side) is what reads of more than MZ_LDS_POS window positions take.  A
+// shorter read -- every short read -- is laid out by position in the wave's LDS (a k-mer that is not there: the largest
+// value) and every window asks a sparse table for its leftmost minimum: M_j[i] = argmin of [i, i + 2^j) by doubling
+// (log2 w uniform passes over the read, no lane waits for another's walk), window [s, s + w) = the better of
+// M_J[s] and M_J[s + w - 2^J].  The picked positions are bits of a per-read mask (position-indexed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ntamd {
+
+struct MinimizerArgs {
+  const uint64_t* hashes; // the batch's emitted k-mers, read by read (one value per k-mer)
+  const uint32_t* pos;    // their window positions inside the read; NULL: every read emits every window (position = index)
+  const uint64_t* roff;   // [n_reads]: first k-mer of read r in the stream (exclusive scan of the counts); NULL with pos == NULL
+  uint64_t n_reads, n_kmers;
+  uint32_t nwin;          // window positions of a read (fixed-length reads: len - k + 1)
+  uint32_t w;
+  uint64_t* masks;        // [n_reads * chunks] bit l of word (r, c): the k-mer at window position 64 c + l of read r is a minimizer
+  uint32_t chunks;        // ceil(nwin / 64)
+  uint32_t pad0;
+  uint64_t* picked;       // [n_reads] minimizers of the read
+  // second pass
+  const uint64_t* out_off; // [n_reads] exclusive scan of picked
+  uint64_t base, capacity;
+  uint64_t* out_hashes;
+  uint32_t* out_pos;       // may be NULL
+  uint64_t* out_offsets;   // [n_reads] = base + out_off
+};
+
+// pass 1 -- one wave per read at a time: the mask of picked positions, their number.  masks must be zero on entry for the
+// reads that take the walk (the host clears the array).
+// (POSN: window positions a wave's LDS holds -- 256 for short reads: 2.6 KiB per wave, the CU's 32 wave slots fill and
+// the chain of LDS round trips a read is hides behind the other waves; 1024: 10 KiB per wave, 12 waves per CU)
+constexpr uint32_t MZ_LDS_POS = 1024;
+constexpr uint32_t MZ_WAVES = 4; // per block
+template <bool DENSE, uint32_t POSN = MZ_LDS_POS>
+static __global__ __launch_bounds__(64 * MZ_WAVES) void minimizer_flag_kernel(const MinimizerArgs a)
+{
+  static_assert(POSN >= 128 && POSN <= MZ_LDS_POS, "a wave's window positions");
+  __shared__ uint64_t lds_h[MZ_WAVES][POSN];
+  __shared__ uint16_t lds_m[MZ_WAVES][POSN];
+  __shared__ uint32_t lds_k[MZ_WAVES][POSN / 32];
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  const uint32_t nwin = a.nwin;
+  const uint32_t w = a.w < nwin ? a.w : nwin; // (a read with fewer windows than w: one window)
+  const uint32_t n_starts = nwin - w + 1;
+  uint32_t J = 0;
+  while ((2u << J) <= w) ++J; // 2^J <= w < 2^(J+1)
+  uint64_t* const A = lds_h[wv];
+  uint16_t* const M = lds_m[wv];
+  uint32_t* const K = lds_k[wv];
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+  // (a wave is alone with its latencies: the first 128 hashes of its NEXT read travel in registers while this one is done)
+  uint64_t pf0 = 0, pf1 = 0;
+  auto prefetch = [&](uint64_t rr) {
+    if (DENSE && rr < a.n_reads) {
+      const uint64_t b = rr * nwin;
+      pf0 = lane < nwin ? a.hashes[b + lane] : 0;
+      pf1 = lane + 64u < nwin ? a.hashes[b + 64u + lane] : 0;
+    }
+  };
+  prefetch(wave);
+  for (uint64_t r = wave; r < a.n_reads; r += n_waves) {
+    const uint64_t i0 = DENSE ? r * nwin : a.roff[r];
+    const uint64_t i1 = DENSE ? i0 + nwin : (r + 1 < a.n_reads ? a.roff[r + 1] : a.n_kmers);
+    uint64_t* const mrow = a.masks + r * a.chunks;
+    uint32_t n_picked = 0;
+    if (nwin <= POSN) {
+      // ---- the read by position ----
+      if (DENSE) {
+        if (lane < nwin) A[lane] = pf0;
+        if (lane + 64u < nwin) A[lane + 64u] = pf1;
+        for (uint32_t p = 128u + lane; p < nwin; p += 64u) A[p] = a.hashes[i0 + p];
+        prefetch(r + n_waves);
+      }
+      for (uint32_t p = lane; p < nwin; p += 64u) {
+        if (!DENSE) A[p] = ~0ull;
+        M[p] = (uint16_t)p;
+      }
+      if (lane < 2u * a.chunks) K[lane] = 0; // (chunks <= MZ_LDS_POS / 64 = 16)
+      if (!DENSE) {
+        wave_sync();
+        for (uint64_t i = i0 + lane; i < i1; i += 64u) A[a.pos[i]] = a.hashes[i];
+      }
+      wave_sync();
+      // ---- A[i], M[i] := the smallest value of [i, i + 2^j) and the leftmost place it stands at; in place, ascending (a
+      // step reads only what has not been written yet), 128 positions per step: one LDS round trip of 8 independent reads ----
+      for (uint32_t j = 0; j < J; ++j) {
+        const uint32_t off = 1u << j;
+        for (uint32_t p0 = 0; p0 < nwin; p0 += 128u) {
+          uint64_t hv[2];
+          uint32_t mv[2];
+#pragma unroll
+          for (uint32_t u = 0; u < 2; ++u) {
+            const uint32_t p = p0 + u * 64u + lane;
+            const uint32_t pc = p < nwin ? p : nwin - 1u;
+            const uint32_t q = pc + off < nwin ? pc + off : nwin - 1u;
+            const uint64_t hp = A[pc], hq = A[q];
+            const uint32_t mp = M[pc], mq = M[q];
+            hv[u] = hq < hp ? hq : hp; // (an equal value on the left stays)
+            mv[u] = hq < hp ? mq : mp;
+          }
+          wave_sync();
+#pragma unroll
+          for (uint32_t u = 0; u < 2; ++u) {
+            const uint32_t p = p0 + u * 64u + lane;
+            if (p < nwin) {
+              A[p] = hv[u];
+              M[p] = (uint16_t)mv[u];
+            }
+          }
+          wave_sync();
+        }
+      }
+      // ---- every window picks ----
+      const uint32_t tail = w - (1u << J);
+      for (uint32_t s0 = 0; s0 < n_starts; s0 += 64u) {
+        const uint32_t st = s0 + lane;
+        if (st < n_starts) {
+          const uint64_t hx = A[st], hy = A[st + tail];
+          const uint32_t x = M[st], y = M[st + tail];
+          const uint32_t best = hy < hx ? y : hx < hy ? x : (x < y ? x : y);
+          if ((hy < hx ? hy : hx) != ~0ull) atomicOr(&K[best >> 5], 1u << (best & 31u)); // (a window without a k-mer: nothing)
+        }
+      }
+      wave_sync();
+      if (lane < a.chunks) {
+        const uint64_t m = (uint64_t)K[2u * lane] | ((uint64_t)K[2u * lane + 1u] << 32);
+        mrow[lane] = m;
+        n_picked = (uint32_t)__builtin_popcountll(m);
+      }
+      for (int d = 32; d > 0; d >>= 1) n_picked += (uint32_t)__shfl_xor((int)n_picked, d, 64);
+      wave_sync(); // (the next read's staging waits for this one's reads)
+    } else {
+      // ---- a long read: the walks, in global memory ----
+      const int64_t wl = w, last_s = (int64_t)nwin - wl;
+      for (uint64_t c0 = i0; c0 < i1; c0 += 64u) {
+        const uint64_t i = c0 + lane;
+        bool pick = false;
+        int64_t P = 0;
+        if (i < i1) {
+          const uint64_t h = a.hashes[i];
+          P = DENSE ? (int64_t)(i - i0) : (int64_t)a.pos[i];
+          int64_t lo = P - wl + 1 > 0 ? P - wl + 1 : 0; // smallest window start not yet excluded
+          for (uint64_t j = i; j > i0;) {
+            --j;
+            const int64_t q = DENSE ? (int64_t)(j - i0) : (int64_t)a.pos[j];
+            if (q < lo) break;
+            if (a.hashes[j] <= h) { lo = q + 1; break; }
+          }
+          int64_t hi = P < last_s ? P : last_s;       // largest window start
+          for (uint64_t j = i + 1; j < i1; ++j) {
+            const int64_t q = DENSE ? (int64_t)(j - i0) : (int64_t)a.pos[j];
+            if (q > hi + wl - 1) break;
+            if (a.hashes[j] < h) { hi = q - wl < hi ? q - wl : hi; break; }
+          }
+          pick = lo <= hi;
+        }
+        if (pick) atomicOr((unsigned long long*)&mrow[P >> 6], 1ull << (P & 63));
+        n_picked += (uint32_t)__builtin_popcountll(__ballot(pick));
+      }
+    }
+    if (lane == 0) a.picked[r] = n_picked;
+  }
+}
+
+// pass 2 -- the picked k-mers of read r to [base + out_off[r], ...), left to right; the read's offset
+template <bool DENSE>
+static __global__ __launch_bounds__(256) void minimizer_write_kernel(const MinimizerArgs a)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t r = wave; r < a.n_reads; r += n_waves) {
+    const uint64_t i0 = DENSE ? r * a.nwin : a.roff[r];
+    const uint64_t i1 = DENSE ? i0 + a.nwin : (r + 1 < a.n_reads ? a.roff[r + 1] : a.n_kmers);
+    uint64_t o = a.base + a.out_off[r];
+    if (lane == 0) a.out_offsets[r] = o;
+    const uint64_t* const mrow = a.masks + r * a.chunks;
+    for (uint64_t c0 = i0; c0 < i1; c0 += 64u) {
+      const uint64_t i = c0 + lane;
+      bool pick = false;
+      if (i < i1) {
+        const uint32_t P = DENSE ? (uint32_t)(i - i0) : a.pos[i];
+        pick = (mrow[P >> 6] >> (P & 63u)) & 1ull;
+      }
+      const uint64_t m = __ballot(pick);
+      if (pick) {
+        const uint64_t at = o + (uint64_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (at < a.capacity) {
+          a.out_hashes[at] = a.hashes[i];
+          if (a.out_pos) a.out_pos[at] = DENSE ? (uint32_t)(i - i0) : a.pos[i];
+        }
+      }
+      o += (uint64_t)__builtin_popcountll(m);
+    }
+  }
+}
+
+} // namespace ntamd

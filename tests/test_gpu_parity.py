@@ -1140,6 +1140,80 @@ def test_bloom_binned_insert_matches_oracle_hash_stream(oracle, n, L, k, m, n_bi
     ctx.close()
 
 
+def _minimizers_brute(pos, hashes, nwin, w):
+    """positions picked by the windows of w positions of one read (its emitted k-mers: pos ascending, one hash each)"""
+    w = min(w, nwin)
+    picked = set()
+    for s in range(0, nwin - w + 1):
+        lo, hi = np.searchsorted(pos, s), np.searchsorted(pos, s + w)
+        if hi > lo:
+            picked.add(int(pos[lo + int(np.argmin(hashes[lo:hi]))]))   # (argmin: the first of equal values)
+    return sorted(picked)
+
+
+@pytest.mark.parametrize("n,L,k,w,dirty,rounds", [
+    (300, 150, 31, 10, False, False), (300, 150, 31, 10, True, False), (200, 100, 21, 1, True, False),
+    (150, 120, 31, 64, True, False),     # windows wider than most stretches between non-bases
+    (100, 60, 31, 50, False, False),     # fewer windows than w: the read is one window
+    (64, 700, 64, 19, True, False), (40, 1500, 101, 25, True, False),
+    (2500, 150, 31, 12, True, True),     # several rounds of reads (NTHIP_TUNE_BLOOM_ROUND)
+])
+def test_minimizers_match_brute_force_on_oracle_stream(oracle, n, L, k, w, dirty, rounds):
+    """nthip_kmer_minimizers: per read, of every w consecutive window positions the emitted k-mer with the smallest
+    canonical hash (ties: the leftmost) -- against a brute force over the oracle's stream (positions + hashes per read),
+    reads with non-bases, low-complexity reads (runs of equal hashes), reads shorter than k"""
+    import os
+    import nthash_amd
+    if rounds:
+        os.environ["NTHIP_TUNE_BLOOM_ROUND"] = "60000"
+    try:
+        ctx = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_BLOOM_ROUND", None)
+    rng = np.random.default_rng(n + L + w)
+    data = oracle.synth_reads(3, n, L, 5 + k).copy()
+    data[2 * L: 3 * L] = ord("A")                                                   # every hash of the read is the same
+    data[3 * L: 4 * L] = np.frombuffer(b"AC" * L, dtype=np.uint8)[:L]               # period 2: two values alternate
+    if dirty:
+        bad = rng.choice(n * L, max(3, n * L // 300), replace=False)
+        data[bad] = np.frombuffer(b"NnRY-", dtype=np.uint8)[rng.integers(0, 5, bad.size)]
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, 1, want_pos=True)
+    nwin = L - k + 1
+    exp_off, exp_pos, exp_h = [0], [], []
+    o = 0
+    for r in range(n):
+        c = int(want["counts"][r])
+        p, h = want["pos"][o:o + c].astype(np.int64), want["hashes"][o:o + c].ravel()
+        picked = _minimizers_brute(p, h, nwin, w)
+        look = dict(zip(p.tolist(), h.tolist()))
+        exp_pos += picked
+        exp_h += [look[q] for q in picked]
+        exp_off.append(len(exp_pos))
+        o += c
+    got = ctx.minimizers(data, k, w, L, n)
+    assert got["total"] == len(exp_pos)
+    assert (got["offsets"] == np.array(exp_off, np.uint64)).all()
+    assert (got["pos"] == np.array(exp_pos, np.uint32)).all()
+    assert (got["hashes"] == np.array(exp_h, np.uint64)).all()
+    if got["total"] > 1:   # too small a capacity: the need is reported
+        with pytest.raises(nthash_amd.NtHipError) as ei:
+            ctx.minimizers(data, k, w, L, n, capacity=got["total"] - 1)
+        assert ei.value.code == nthash_amd.capi.NTHIP_ERR_CAPACITY and ei.value.total == got["total"]
+    ctx.close()
+
+
+def test_minimizers_argument_errors_and_short_reads(ctx):
+    import nthash_amd
+    data = np.frombuffer(b"ACGT" * 50, dtype=np.uint8)
+    got = ctx.minimizers(data, 31, 5, 20, 10)          # reads shorter than k: no minimizers, offsets all zero
+    assert got["total"] == 0 and (got["offsets"] == 0).all()
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.minimizers(data, 31, 0, 200, 1)            # w == 0
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.minimizers(data, 0, 5, 200, 1)             # k == 0
+
+
 @pytest.mark.parametrize("n,L,k,m,n_counters,dirty,binned", [
     (3000, 150, 31, 1, 1 << 16, False, True),            # 2 regions: counters pile up (saturation at 255 matters)
     (3000, 150, 31, 4, 4_000_036, True, True),           # not a power of two, a partial last region; reads with N
