@@ -697,19 +697,22 @@ static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* 
       }
     }
     if (tile_sum) {
-      uint64_t incl = nwin;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t o = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), d, 64) << 32) |
-                           (uint32_t)__shfl_up((int)(uint32_t)incl, d, 64);
-        if ((int)lane >= d) incl += o;
-      }
+      // inclusive prefix sum of the wave's window counts on the DPP network (a read has < 2^32 windows and so have 64
+      // of them here: reads of this path are at most RD_MAX_LEN bytes -- longer ones make the sums meaningless, and the
+      // caller drops them when it sees the maximum length); six LDS round trips of a 64-bit __shfl_up scan cost the
+      // kernel two thirds of its time
+      uint32_t incl = nwin < 0x3FFFFFFull ? (uint32_t)nwin : 0x3FFFFFFu;
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
       const uint32_t in_tile = (uint32_t)(r % R);                     // place of the read in its tile
       const uint32_t seg0 = in_tile <= lane ? lane - in_tile : 0u;     // first lane of the tile's part in this wave
       const uint32_t src = seg0 ? seg0 - 1u : 0u;
-      const uint64_t before_all = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(incl >> 32), (int)src, 64) << 32) |
-                                  (uint32_t)__shfl((int)(uint32_t)incl, (int)src, 64);
-      const uint64_t before = seg0 ? before_all : 0;
+      const uint32_t before_all = (uint32_t)__shfl((int)incl, (int)src, 64);
+      const uint32_t before = seg0 ? before_all : 0u;
       const bool last = r < n && (in_tile == R - 1u || lane == 63u || r == n - 1u);
       if (last && incl != before) atomicAdd(&tile_sum[r / R], (unsigned long long)(incl - before));
     }
