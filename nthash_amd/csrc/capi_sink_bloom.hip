@@ -37,19 +37,29 @@ struct BloomLists {
   uint64_t* hashes = nullptr; // the round's hash stream (the reads entry)
 };
 
-// lists for rounds of at most `round` values (+ a hash stream of that many values when with_stream)
-int bloom_lists(nthip_ctx* c, uint64_t round, bool with_stream, BloomLists* t)
+// lists for rounds of at most *round values (+ a hash stream of that many values when with_stream).  When the device does
+// not have the memory, *round is halved until it has; returns 1 (not an error: the caller takes the atomic kernels) when
+// not even a round of 2^20 values fits.
+int bloom_lists(nthip_ctx* c, uint64_t* round, bool with_stream, BloomLists* t)
 {
   const size_t head = ((size_t)BB_MAX_REGIONS * (2 + BB_CURSOR_STRIDE) + 1 + (size_t)BB_MAX_BINS * BB_CURSOR_STRIDE + 64) * sizeof(uint32_t);
   const size_t head_al = (head + 255) & ~(size_t)255;
-  const size_t list_bytes = (((size_t)round * 4) + 255) & ~(size_t)255;
-  const size_t need = head_al + 2 * list_bytes + (with_stream ? (size_t)round * 8 : 0);
-  if (c->bloom_tmp_bytes < need) {
+  size_t list_bytes = 0;
+  for (;;) {
+    list_bytes = (((size_t)*round * 4) + 255) & ~(size_t)255;
+    const size_t need = head_al + 2 * list_bytes + (with_stream ? (size_t)*round * 8 : 0);
+    if (c->bloom_tmp_bytes >= need) break;
     if (c->bloom_tmp) HIPCHK(hipFree(c->bloom_tmp));
     c->bloom_tmp = nullptr;
     c->bloom_tmp_bytes = 0;
-    HIPCHK(hipMalloc((void**)&c->bloom_tmp, need));
-    c->bloom_tmp_bytes = need;
+    if (hipMalloc((void**)&c->bloom_tmp, need) == hipSuccess) {
+      c->bloom_tmp_bytes = need;
+      break;
+    }
+    (void)hipGetLastError(); // (out of memory is an answer here, not a sticky error)
+    c->bloom_tmp = nullptr;
+    if (*round <= (1u << 20)) return 1;
+    *round = *round / 2 < (1u << 20) ? (1u << 20) : *round / 2;
   }
   uint32_t* p = (uint32_t*)c->bloom_tmp;
   t->counts = p;
@@ -156,11 +166,16 @@ int run_kmer_bloom_binned(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8
 {
   const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
   const uint64_t per_read = (uint64_t)(len - k + 1) * m;
-  const uint64_t round = bloom_round_values(c, rd->n_reads * per_read, true);
-  uint64_t reads_per_round = round / per_read;
-  if (reads_per_round == 0) return fail(NTHIP_ERR_UNSUPPORTED, "reads too long for the binned Bloom insert");
+  uint64_t round = bloom_round_values(c, rd->n_reads * per_read, true);
+  if (round < per_read) return 1; // (reads of more values than a round: the fused kernel)
+  round = round / per_read * per_read;
   BloomLists t;
-  NTCHK(bloom_lists(c, reads_per_round * per_read, true, &t));
+  {
+    const int rc = bloom_lists(c, &round, true, &t);
+    if (rc) return rc; // (1: no memory for the lists -- the caller takes the fused kernel)
+  }
+  const uint64_t reads_per_round = round / per_read;
+  if (reads_per_round == 0) return 1;
   uint64_t sum = 0;
   for (uint64_t r0 = 0; r0 < rd->n_reads; r0 += reads_per_round) {
     const uint64_t nr = rd->n_reads - r0 < reads_per_round ? rd->n_reads - r0 : reads_per_round;
@@ -209,8 +224,10 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
     return NTHIP_OK;
   }
   // a batch that is large next to the filter: hash stream + binned insert, no device atomics
-  if (!query && stride >= len && bloom_binned_ok(c, d_filter, n_bits, rd->n_reads * (uint64_t)(len - k + 1) * m))
-    return run_kmer_bloom_binned(c, rd, k16, m8, d_filter, n_bits, total_out, flags);
+  if (!query && stride >= len && bloom_binned_ok(c, d_filter, n_bits, rd->n_reads * (uint64_t)(len - k + 1) * m)) {
+    const int rc = run_kmer_bloom_binned(c, rd, k16, m8, d_filter, n_bits, total_out, flags);
+    if (rc != 1) return rc; // (1: the lists do not fit the device right now)
+  }
   NaPlan plan;
   if (!kmer_na_plan(c, len, stride, k, m, /*want_pos (the k-mer's read)*/ query, &plan))
     return fail(NTHIP_ERR_UNSUPPORTED, "shape outside the fused consumer kernels (k <= 64, m <= 8, stride >= windows)");
@@ -278,13 +295,16 @@ extern "C" int nthip_stream_bloom_insert(nthip_ctx* c, const uint64_t* d_hashes,
   HIPCHK(hipSetDevice(c->device));
   if (n_values == 0) return NTHIP_OK;
   if (bloom_binned_ok(c, d_filter, n_bits, n_values)) {
-    const uint64_t round = bloom_round_values(c, n_values, false);
+    uint64_t round = bloom_round_values(c, n_values, false);
     BloomLists t;
-    NTCHK(bloom_lists(c, round, false, &t));
-    for (uint64_t v0 = 0; v0 < n_values; v0 += round)
-      NTCHK(bloom_binned_round(c, d_hashes + v0, n_values - v0 < round ? n_values - v0 : round, (uint32_t*)d_filter, n_bits, t));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return NTHIP_OK;
+    const int lrc = bloom_lists(c, &round, false, &t);
+    if (lrc < 0) return lrc;
+    if (lrc == 0) {
+      for (uint64_t v0 = 0; v0 < n_values; v0 += round)
+        NTCHK(bloom_binned_round(c, d_hashes + v0, n_values - v0 < round ? n_values - v0 : round, (uint32_t*)d_filter, n_bits, t));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      return NTHIP_OK;
+    } // (1: no memory for the lists: the atomic kernel below)
   }
   prof_begin(c, "stream_bloom_insert_kernel");
   hipLaunchKernelGGL(stream_bloom_insert_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, d_hashes, n_values,
@@ -310,15 +330,19 @@ int count_insert_stream(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_value
   if (bloom_binned_ok(c, d_counters, n_counters, n_values, true)) {
     BloomLists t;
     uint64_t round = n_values;
+    int lrc = 0;
     if (have) {
       t = *have; // (the reads entry: its round already fits the lists)
     } else {
       round = bloom_round_values(c, n_values, false);
-      NTCHK(bloom_lists(c, round, false, &t));
+      lrc = bloom_lists(c, &round, false, &t);
+      if (lrc < 0) return lrc;
     }
-    for (uint64_t v0 = 0; v0 < n_values; v0 += round)
-      NTCHK(bloom_binned_round(c, d_hashes + v0, n_values - v0 < round ? n_values - v0 : round, d_counters, n_counters, t, true));
-    return NTHIP_OK;
+    if (lrc == 0) {
+      for (uint64_t v0 = 0; v0 < n_values; v0 += round)
+        NTCHK(bloom_binned_round(c, d_hashes + v0, n_values - v0 < round ? n_values - v0 : round, d_counters, n_counters, t, true));
+      return NTHIP_OK;
+    } // (1: no memory for the lists: one compare-and-swap per value below)
   }
   prof_begin(c, "count_atomic_kernel");
   hipLaunchKernelGGL(count_atomic_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, d_hashes, n_values, d_counters, n_counters,
@@ -363,11 +387,17 @@ extern "C" int nthip_kmer_count_insert(nthip_ctx* c, const nthip_reads* rd, uint
   const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
   if (rd->n_reads == 0 || len < k) return NTHIP_OK;
   const uint64_t per_read = (uint64_t)(len - k + 1) * m;
-  const uint64_t round = bloom_round_values(c, rd->n_reads * per_read, true);
+  uint64_t round = bloom_round_values(c, rd->n_reads * per_read, true);
+  if (round < per_read) round = per_read;
+  round = round / per_read * per_read;
+  BloomLists t;
+  {
+    const int rc = bloom_lists(c, &round, true, &t);
+    if (rc < 0) return rc;
+    if (rc == 1) return fail(NTHIP_ERR_HIP, "no device memory for a round of the counting sketch (%llu values)", (unsigned long long)round);
+  }
   const uint64_t reads_per_round = round / per_read;
   if (reads_per_round == 0) return fail(NTHIP_ERR_UNSUPPORTED, "reads too long for the counting sketch's rounds");
-  BloomLists t;
-  NTCHK(bloom_lists(c, reads_per_round * per_read, true, &t));
   uint64_t sum = 0;
   for (uint64_t r0 = 0; r0 < rd->n_reads; r0 += reads_per_round) {
     const uint64_t nr = rd->n_reads - r0 < reads_per_round ? rd->n_reads - r0 : reads_per_round;

@@ -600,7 +600,32 @@ NtHash::NtHash(const NtHash& o)
   std::memcpy(hash_arr_.get(), o.hash_arr_.get(), (num_hashes_ ? num_hashes_ : 1) * sizeof(uint64_t));
 }
 
-NtHash::NtHash(NtHash&&) noexcept = default;
+// (a moved-from object keeps no view into the stream that went with the move: its inline roll() takes the general routine)
+NtHash::NtHash(NtHash&& o) noexcept
+  : seq_(o.seq_)
+  , len_(o.len_)
+  , num_hashes_(o.num_hashes_)
+  , k_(o.k_)
+  , pos_(o.pos_)
+  , initialized_(o.initialized_)
+  , fwd_(o.fwd_)
+  , rev_(o.rev_)
+  , strands_stale_(o.strands_stale_)
+  , strands_wanted_(o.strands_wanted_)
+  , hash_arr_(std::move(o.hash_arr_))
+  , rt_(o.rt_)
+  , stream_(std::move(o.stream_))
+  , cursor_(o.cursor_)
+  , ahead_(std::move(o.ahead_))
+  , sp_(o.sp_)
+  , sh_(o.sh_)
+  , sn_(o.sn_)
+  , sbegin_(o.sbegin_)
+{
+  o.sp_ = nullptr;
+  o.sh_ = nullptr;
+  o.sn_ = 0;
+}
 NtHash::~NtHash() = default;
 
 // take fwd/rev/hashes of the window at pos_ from the device stream (a short sequence: straight from the bases)
