@@ -281,6 +281,9 @@ void load_tuning(nthip_tune& t)
   t.seed_any = num("NTHIP_TUNE_SEED_ANY", 1, 2);
   t.bloom_binned = num("NTHIP_TUNE_BLOOM_BINNED", 1, 2);
   t.bloom_round = num("NTHIP_TUNE_BLOOM_ROUND", 1024, 0x7FFFFFFF);
+  t.pf_gbps = num("NTHIP_TUNE_PF_GBPS", 1, 100000);
+  t.pf_lead_kb = num("NTHIP_TUNE_PF_LEAD_KB", 1, 1 << 22);
+  t.pf_chunk_kb = num("NTHIP_TUNE_PF_CHUNK_KB", 1, 1 << 20);
   const uint32_t tk = num("NTHIP_TUNE_TABLE_K_MAX", 16, 64);
   ntamd::host::g_kmer_table_k_max = tk ? tk : (uint32_t)KMER_TABLE_K_MAX_N;
 }
@@ -352,6 +355,8 @@ extern "C" int nthip_ctx_destroy(nthip_ctx* c)
   if (c->stage_buf) (void)hipFree(c->stage_buf);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->aux_done) (void)hipEventDestroy(c->aux_done);
+  if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return NTHIP_OK;

@@ -98,6 +98,10 @@ struct nthip_tune {
   uint32_t ph_tiles = 0;    // NTHIP_TUNE_PH_TILES
   uint32_t ph_period = 0;   // NTHIP_TUNE_PH_PERIOD
   uint32_t ph_read = 0;     // NTHIP_TUNE_PH_READ
+  // experiment (profiles/r03_notes.md 16): a second kernel reads the headline kernel's input ahead of it, in large sequential
+  // chunks per tile group, paced by the clock -- NTHIP_TUNE_PF_GBPS = the input rate the main kernel is expected to consume
+  // (GB/s; 0: off), NTHIP_TUNE_PF_LEAD_KB = how far ahead per group, NTHIP_TUNE_PF_CHUNK_KB = bytes per burst
+  uint32_t pf_gbps = 0, pf_lead_kb = 0, pf_chunk_kb = 0;
   uint32_t bloom_round = 0;  // NTHIP_TUNE_BLOOM_ROUND=<values>: rounds of the binned consumers no longer than this (tests: several rounds on a small batch)
   uint32_t bloom_binned = 0; // NTHIP_TUNE_BLOOM_BINNED=1: the binned insert whenever the filter allows it, 2: never (A/B, tests)
   uint32_t seed_any = 0;    // NTHIP_TUNE_SEED_ANY=1: dense seed batches on the any-seed form whatever the seed set, 2: none of k <= 128 (A/B, tests)
@@ -109,6 +113,8 @@ struct nthip_ctx {
   int n_cu = 0;
   size_t lds_max = 0;
   hipStream_t own_stream = nullptr;
+  hipStream_t aux_stream = nullptr; // (the input-prefetch experiment)
+  hipEvent_t aux_done = nullptr;
   hipStream_t stream = nullptr;
   // small device scratch: [0] dirty flag (u32), [8] total (u64), [16..32) sink totals
   uint8_t* d_small = nullptr;

@@ -7,6 +7,32 @@ using namespace ntamd::host;
 
 namespace {
 
+// EXPERIMENT (NTHIP_TUNE_PF_GBPS; off by default): one block per tile group reads the group's input range ahead of the
+// hashing waves, a chunk at a time, at the pace the main kernel is expected to consume it -- large sequential reads
+// instead of thousands of 9 KiB pieces, to see whether HBM / the Infinity Cache take the read share of the mix better
+// that way.  Loads only; the data is dropped.
+__global__ __launch_bounds__(256) void input_prefetch_kernel(const uint8_t* base, uint64_t total_bytes, uint64_t group_bytes,
+                                                              uint32_t chunk_bytes, uint64_t lead_bytes, double ticks_per_byte,
+                                                              uint32_t* sink)
+{
+  const uint64_t g0 = (uint64_t)blockIdx.x * group_bytes;
+  if (g0 >= total_bytes) return;
+  const uint64_t g1 = g0 + group_bytes < total_bytes ? g0 + group_bytes : total_bytes;
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
+  uint32_t acc = 0;
+  for (uint64_t off = g0; off < g1; off += chunk_bytes) {
+    const uint64_t done = off - g0;
+    const uint64_t due = done > lead_bytes ? t0 + (uint64_t)((double)(done - lead_bytes) * ticks_per_byte) : t0;
+    while (__builtin_amdgcn_s_memrealtime() < due) __builtin_amdgcn_s_sleep(32);
+    const uint64_t end = off + chunk_bytes < g1 ? off + chunk_bytes : g1;
+    for (uint64_t p = (off & ~15ull) + (uint64_t)threadIdx.x * 16u; p + 16u <= end; p += 256u * 16u) {
+      const uint4 v = *(const uint4*)(base + p);
+      acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+  }
+  if (acc == 0x9E3779B9u) sink[0] = acc; // (keeps the loads)
+}
+
 template <typename K>
 int launch_kmer_runs(nthip_ctx* c, K kernel, KmerRunsArgs a, size_t dyn_lds)
 {
@@ -33,10 +59,31 @@ int launch_kmer_runs(nthip_ctx* c, K kernel, KmerRunsArgs a, size_t dyn_lds)
   HIPCHK(hipMemsetAsync(c->d_small + 64, 0, 64, c->stream));
   HIPCHK(hipMemsetAsync(c->d_small + 64 + 48, 0xFF, 8, c->stream));
 #endif
+  bool prefetching = false;
+  if (c->tune.pf_gbps && a.ph_tiles == (uint32_t)KR_BURST && a.tile_map && ((uintptr_t)a.seqs & 15u) == 0) {
+    if (!c->aux_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&c->aux_done, hipEventDisableTiming));
+    }
+    const uint64_t tile_bytes = (uint64_t)(64u / a.rpr) * a.stride;
+    const uint64_t per = (a.n_wtiles + a.tile_map - 1) / a.tile_map; // tiles per group (tile_range)
+    const uint64_t group_bytes = per * tile_bytes, total_bytes = a.n_reads * (uint64_t)a.stride;
+    const uint32_t chunk = (c->tune.pf_chunk_kb ? c->tune.pf_chunk_kb : 256u) << 10;
+    const uint64_t lead = (uint64_t)(c->tune.pf_lead_kb ? c->tune.pf_lead_kb : 2048u) << 10;
+    // bytes per second of ONE group = rate / groups; ticks of 10 ns per byte
+    const double ticks_per_byte = 1e8 * (double)a.tile_map / ((double)c->tune.pf_gbps * 1e9);
+    hipLaunchKernelGGL(input_prefetch_kernel, dim3(a.tile_map), dim3(256), 0, c->aux_stream, (const uint8_t*)a.seqs, total_bytes,
+                       group_bytes, chunk, lead, ticks_per_byte, (uint32_t*)(c->d_small + 200));
+    prefetching = true;
+  }
   prof_begin(c, "kmer_runs_kernel");
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), dyn_lds, c->stream, a);
   prof_end(c);
   HIPCHK(hipGetLastError());
+  if (prefetching) { // (what follows on the context's stream follows the reader too)
+    HIPCHK(hipEventRecord(c->aux_done, c->aux_stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->aux_done, 0));
+  }
 #if KR_DEBUG_TIMES
   {
     uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -482,6 +482,9 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
   // hashed and consumed after the last tile's stores: 8 x 8 = 64 younger stores, and an in-order counter that holds at
   // most 63 operations proves they have landed (the seed kernel's argument) -- no pacing, no block barrier, any number
   // of waves.  The waves of a group take the pieces of its tile range in turn.
+#ifndef KR_BURST_PLAIN_LOADS
+#define KR_BURST_PLAIN_LOADS 0
+#endif
 #ifndef KR_BURST
 #define KR_BURST 8
 #endif
@@ -599,7 +602,12 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
           const uint64_t sb = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b0) |
                               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b0 >> 32)) << 32);
           const uint8_t* sbase = a.seqs + sb; // scalar base + 32-bit lane offset
-          asm volatile("global_load_dwordx4 %0, %2, %4 sc1 nt\n\tglobal_load_dword %1, %3, %4 sc1 nt"
+#if KR_BURST_PLAIN_LOADS // (experiment: default cache policy on the slab loads, for the input-prefetch experiment)
+#define KR_BURST_POLICY ""
+#else
+#define KR_BURST_POLICY " sc1 nt"
+#endif
+          asm volatile("global_load_dwordx4 %0, %2, %4" KR_BURST_POLICY "\n\tglobal_load_dword %1, %3, %4" KR_BURST_POLICY
                        : "=&v"(v[i]), "=&v"(w4[i])
                        : "v"(i0 << 4), "v"(jd << 2), "s"(sbase)
                        : "memory");
