@@ -82,6 +82,7 @@ struct nthip_tune {
   bool no_autotune = false; // NTHIP_TUNE_NO_AUTOTUNE (set)
   bool no_seed_wave = false; // NTHIP_TUNE_NO_SEED_WAVE (set)
   bool no_seed_wtile = false; // NTHIP_TUNE_NO_SEED_WTILE=1: the block-tile dense seed kernel instead of the wave-tile one
+  bool no_fh = false;         // NTHIP_TUNE_NO_FH=1: full position tables for k = 49 ... 64 (A/B)
   bool no_any_k_runs = false; // NTHIP_TUNE_NO_ANY_K_RUNS=1: only the k = 31 / run length 15, 30 instantiations of kmer_runs_kernel
   bool no_seed_align = false; // NTHIP_TUNE_NO_SEED_ALIGN=1: seed_rtile_kernel's groups end anywhere (A/B)
   bool no_seed_reads = false; // NTHIP_TUNE_NO_SEED_READS=1: variable-length reads of SeedNtHash on seed_wave_kernel only
@@ -293,6 +294,7 @@ bool kmer_runs_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t 
 struct GenPlan {
   uint32_t C = 0, rpr = 0, last_start = 0, waves = 0, bits_dwords = 0, tile_u64 = 0, nw = 0, dword_tail = 0;
   uint32_t fw_scan = 0, uw_dwords = 0; // nw == 0: the prefix-scan first window and its per-wave LDS (first_window.hpp)
+  uint32_t fh = 0;                     // the forward-half tables of the dense pass (k = 49 ... 64: kmer_runs_gen_kernel FH)
   size_t lds = 0;
 };
 bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k, uint32_t m, GenPlan* p,

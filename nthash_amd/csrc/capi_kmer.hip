@@ -202,7 +202,9 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
         uint32_t best_c = gplan.C;
         if (n_cand > 1) {
           nthip_reads slice = *rd;
-          const uint64_t want = (128ull << 20) / nwin + 1; // ~128 M k-mers (a quarter of a millisecond) per trial
+          // ~512 M k-mers (about a millisecond) per trial: on a quarter of that the candidates' times differed by less
+          // than their launch-to-launch spread and a shape could land 10-16 % off its best run length (round 3)
+          const uint64_t want = (512ull << 20) / nwin + 1;
           slice.n_reads = rd->n_reads < want ? rd->n_reads : want;
           struct EventPair { // destroyed on every way out of the trials
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -223,7 +225,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
             fill_gen_args(ga, c, st, &slice, k, m, q, a);
             ga.init_tab = gen_tab;
             float ms = 1e30f;
-            for (int rep = 0; rep < 2 && clean; ++rep) { // the first launch warms the tables and the clocks
+            for (int rep = 0; rep < 3 && clean; ++rep) { // the first launch warms the tables and the clocks; then the better of two
               HIPCHK(hipEventRecord(e0, c->stream));
               const bool prof = c->profiling;
               c->profiling = false;
@@ -236,7 +238,9 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
               uint32_t d = 0;
               memcpy(&d, c->h_small, 4);
               if (d) clean = false; // a non-base: the dense kernel stopped early, the times mean nothing
-              HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+              float t = 1e30f;
+              HIPCHK(hipEventElapsedTime(&t, e0, e1));
+              if (rep > 0 && t < ms) ms = t;
             }
             // (the model's choice is the first candidate: another one has to beat it by 3 % to replace it)
             if (clean && ms < (i == 0 ? best_ms : 0.97f * best_ms)) { best_ms = ms; best_c = cand[i]; }

@@ -253,7 +253,13 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
     p->fw_scan = scan ? 1u : 0u;
     if (scan) p->uw_dwords = 4u * bd;
   }
-  const size_t fixed = (size_t)kmer_ntab(k) * 4096 + 256 + 64;
+  // forward-half tables (kmer_runs_gen_kernel FH): the dense pass of k = 49 ... 64, and of every k within the position
+  // tables when there are several hashes per k-mer (16 waves wanted).  Half the table bytes -- and, several hashes per
+  // k-mer, no alignment slack in the tile (the copy-out shifts nothing there) -- are 12 waves per CU instead of 8 on the
+  // reference's benchmark shape (100 bp, k = 64, m = 3) and 16 instead of 13 at k = 31
+  p->fh = (!gaps_ok && !no_tile && !any_k && (p->nw == 4 || m > 1) && !c->tune.no_fh) ? 1u : 0u;
+  if (p->fh && m > 1) p->tile_u64 = 64 * best + 2;
+  const size_t fixed = (size_t)kmer_ntab(k) * (p->fh ? 2048 : 4096) + 256 + 64;
   const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4 + (size_t)p->uw_dwords * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
   // m = 1: 12 waves per CU (3 per SIMD) measured +3 ... +9 % over 8 on 150 / 151 bp, 16 no better (round 2)
@@ -324,6 +330,7 @@ void fill_gen_args(KmerRunsGenArgs& ga, nthip_ctx* c, const Staged& st, const nt
   ga.tile_map = c->tune.has_tile_map ? c->tune.tile_map : 0xFFFFFFFFu;
   ga.fw_scan = g.fw_scan;
   ga.uw_dwords = g.uw_dwords;
+  ga.fh = g.fh;
   memcpy(ga.tab, consts.tab, sizeof ga.tab);
   memcpy(ga.mult, consts.mult, sizeof ga.mult);
 }

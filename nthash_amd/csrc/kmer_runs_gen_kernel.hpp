@@ -101,7 +101,10 @@ struct KmerRunsGenArgs {
   // NW == 0 (k beyond the position tables): 0 = the grouped first window, 1 = the prefix-scan form (first_window.hpp);
   // the scan keeps {U, V} at every word boundary of the slab in uw_dwords dwords of LDS per wave (4 per word)
   uint32_t fw_scan;
-  uint32_t uw_dwords, pad3;
+  uint32_t uw_dwords;
+  // FH instantiations: the position tables hold the forward halves only (8 bytes per entry: half the LDS); the reverse
+  // strand's terms are the forward terms of the window's reverse complement
+  uint32_t fh;
   // packed input (PK instantiations; NTHIP_PACKED_INPUT): seqs is the 2-bit code stream of nthip_pack_reads, positions
   // are bases of it; invalid = its companion stream, one bit per base (1 = not a base), read by the N-aware passes only
   const uint16_t* invalid;
@@ -284,10 +287,15 @@ __device__ __forceinline__ void tile_range(uint32_t tile_map, uint32_t waves, ui
 // SINK (needs NA): consume the tile's hashes instead of writing them out;
 // PK: packed input -- a.seqs is the 2-bit code stream (16 bases per dword, the format of the LDS bit stream: a slab is
 //     staged with one dword load per 16 bases), a.invalid the validity stream the N-aware pass reads instead of judging bytes
-template <int NW, bool DT, bool NA, int SINK = SINK_NONE, bool PK = false>
+template <int NW, bool DT, bool NA, int SINK = SINK_NONE, bool PK = false, bool FH = false>
 __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const KmerRunsGenArgs a)
 {
   static_assert(!PK || SINK == SINK_NONE, "packed input: the hash-stream passes");
+  // FH (round 3; k = 49 ... 64, dense pass): R(window) = F(reverse complement of the window), so the first window needs
+  // the forward halves of the position tables only -- 32 KiB instead of 64 at k = 64, i.e. 12 waves per CU instead of 8
+  // for the reference's own benchmark shape -- at the price of 2 x 16 lookups of 8 bytes instead of 16 of 16 and ~20
+  // instructions that reverse-complement the window's four words
+  static_assert(!FH || (NW >= 1 && !NA && !PK), "forward-half tables: the dense pass, k within the position tables");
   const uint64_t seqs_addr = PK ? 0ull : (uint64_t)a.seqs; // (packed: positions are bases of a 16-byte aligned stream)
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
 #ifdef KRG_FORCE_C // experiment: what a compile-time run length is worth
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
 
   // LDS: init tables | pair table | multipliers | per wave {tile, [pos tile], bits, [validity bits]}
   uint4* itab = (uint4*)lds_dyn;
-  uint4* ptab = itab + ntab * 256u;
+  uint4* ptab = FH ? (uint4*)((uint2*)lds_dyn + ntab * 256u) : itab + ntab * 256u;
   uint64_t* mults = (uint64_t*)(ptab + 16);
   const uint32_t per_wave = a.tile_u64 * 2u + a.ptile_dwords + a.bits_dwords + a.vbits_dwords + a.uw_dwords;
   uint32_t* wave_base = (uint32_t*)(mults + KF_MAX_RUNTIME_M) + wave * per_wave;
@@ -321,7 +329,14 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
   uint16_t* vbits = (uint16_t*)(bits + a.bits_dwords);
   uint4* uw = (uint4*)(bits + a.bits_dwords + a.vbits_dwords); // scan form: {U, V} at the slab's word boundaries
 
-  for (uint32_t i = tid; i < ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
+  if constexpr (FH) {
+    for (uint32_t i = tid; i < ntab * 256u; i += blockDim.x) {
+      const uint4 e = a.init_tab[i];
+      ((uint2*)lds_dyn)[i] = make_uint2(e.x, e.y);
+    }
+  } else {
+    for (uint32_t i = tid; i < ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
+  }
   if (tid < 16)
     ptab[tid] = make_uint4((uint32_t)a.tab[tid][0], (uint32_t)(a.tab[tid][0] >> 32),
                            (uint32_t)a.tab[tid][1], (uint32_t)(a.tab[tid][1] >> 32));
@@ -599,6 +614,44 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
         scan_first_window(bits, itab, uw, b0, k, k % 1023u, k % 31u, k % 33u, f_lo, f_hi, r_lo, r_hi);
       } else {
         any_k_first_window(bits, itab, b0, k, f_lo, f_hi, r_lo, r_hi);
+      }
+    } else if constexpr (FH) {
+      const uint2* const ftab = (const uint2*)lds_dyn;
+      uint32_t w[NW];
+      uint32_t lo = bits[d0];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const uint32_t hi = bits[d0 + i + 1];
+        w[i] = funnel(hi, lo, sh0);
+        lo = hi;
+      }
+      // the window's reverse complement: words in reverse order, each with its 16 bases reversed (bit reverse, then the two
+      // bits of every base swapped back) and complemented (code ^ 2: A <-> T, C <-> G), the 16 NW - k bases of padding
+      // shifted out (fewer than 16: k > 16 (NW - 1))
+      uint32_t rw[NW];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const uint32_t r = __builtin_bitreverse32(w[NW - 1 - i]);
+        rw[i] = (((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1)) ^ 0xAAAAAAAAu;
+      }
+      const uint32_t sft = 2u * (16u * (uint32_t)NW - k);
+      uint32_t rs[NW];
+#pragma unroll
+      for (int i = 0; i + 1 < NW; ++i) rs[i] = funnel(rw[i + 1], rw[i], sft);
+      rs[NW - 1] = rw[NW - 1] >> sft;
+      uint2 ef[4 * NW], er[4 * NW];
+#pragma unroll
+      for (int jt = 0; jt < 4 * NW; ++jt) {
+        ef[jt] = ftab[(uint32_t)jt * 256u + ((w[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu)];
+        er[jt] = ftab[(uint32_t)jt * 256u + ((rs[jt >> 2] >> ((jt & 3) * 8)) & 0xFFu)];
+      }
+      f_lo = ef[0].x ^ ef[1].x; f_hi = ef[0].y ^ ef[1].y; r_lo = er[0].x ^ er[1].x; r_hi = er[0].y ^ er[1].y;
+#pragma unroll
+      for (int jt = 2; jt < 4 * NW; jt += 2) {
+        f_lo = __builtin_amdgcn_bitop3_b32(f_lo, ef[jt].x, ef[jt + 1].x, 0x96);
+        f_hi = __builtin_amdgcn_bitop3_b32(f_hi, ef[jt].y, ef[jt + 1].y, 0x96);
+        r_lo = __builtin_amdgcn_bitop3_b32(r_lo, er[jt].x, er[jt + 1].x, 0x96);
+        r_hi = __builtin_amdgcn_bitop3_b32(r_hi, er[jt].y, er[jt + 1].y, 0x96);
       }
     } else {
       uint32_t w[NW];
