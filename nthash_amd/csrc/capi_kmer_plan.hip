@@ -258,7 +258,7 @@ bool kmer_gen_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k
   // k-mer, no alignment slack in the tile (the copy-out shifts nothing there) -- are 12 waves per CU instead of 8 on the
   // reference's benchmark shape (100 bp, k = 64, m = 3) and 16 instead of 13 at k = 31
   p->fh = (!gaps_ok && !no_tile && !any_k && (p->nw == 4 || m > 1) && !c->tune.no_fh) ? 1u : 0u;
-  if (p->fh && m > 1) p->tile_u64 = 64 * best + 2;
+  if (m > 1 && !gaps_ok && !no_tile) p->tile_u64 = 64 * best + 2; // (the dense copy-out shifts the tile only for m = 1)
   const size_t fixed = (size_t)kmer_ntab(k) * (p->fh ? 2048 : 4096) + 256 + 64;
   const size_t per_wave = (size_t)p->tile_u64 * 8 + (size_t)bd * 4 + (size_t)p->uw_dwords * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
