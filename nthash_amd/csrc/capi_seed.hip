@@ -258,7 +258,7 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
   size_t any_bytes = 0;
   if (use_any) {
     const uint32_t n_grp = sd->n_seeds * sd->any_groups;
-    any_bytes = ((size_t)FW_AC + 16 + n_grp + ((n_grp + 3) >> 2)) * sizeof(uint4);
+    any_bytes = ((size_t)SA_TAB_ENTRIES + n_grp + ((n_grp + 3) >> 2)) * sizeof(uint4);
     pass_seeds = sd->n_seeds;
     rot = false;
   }
@@ -735,7 +735,7 @@ int launch_seed_any(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd,
   if (slab > SW_MAX_VEC_ROUNDS * 1024ull || (uint64_t)R * f.nwin >= 0x7FFFFFFFull) return NTHIP_OK;
   const uint32_t bits_dwords = (uint32_t)((((slab + 15) >> 4) + 8 + 3) & ~3ull);
   const uint32_t n_grp = f.n_seeds * sd->any_groups;
-  const size_t table_bytes = ((size_t)FW_AC + 16 + n_grp + ((n_grp + 3) >> 2)) * sizeof(uint4);
+  const size_t table_bytes = ((size_t)SA_TAB_ENTRIES + n_grp + ((n_grp + 3) >> 2)) * sizeof(uint4);
   const size_t per_wave = (size_t)(64 * per + 2) * 8 + (size_t)bits_dwords * 4;
   const size_t cap = lds_cap_of(c);
   uint32_t waves = 0;

@@ -316,6 +316,58 @@ __global__ __launch_bounds__(SF_THREADS) void seed_fixed_kernel(const SeedFixedA
 // windows leaves as one contiguous, KiB-aligned block (3 KiB for two seeds x three hashes) of write-through stores.
 // Blocks stream through contiguous ranges of tiles.
 // --------------------------------------------------------------------------
+// ---- the any-seed form (seed_wtile_kernel<0>, seed_rtile_kernel<0>): shared pieces ------------------------------------
+// LDS: FOUR copies of the four 16-mer byte tables of first_window.hpp, copy q pre-rotated by 16 q bases ({F, R} terms:
+// sror^{16 q} / srol^{16 q}), so that four consecutive 16-base groups of a window are XOR-ed up WITHOUT rotating anything
+// and the Horner step -- one pair of split rotates, by 64 bases -- comes once per four groups instead of once per group
+// (the rotates were half of the ~50 instructions a group cost); then per (seed, group) the correction word, rotated the
+// same way, and the care mask.
+constexpr uint32_t SA_SETS = 4;
+constexpr uint32_t SA_TAB_ENTRIES = SA_SETS * 1024u; // uint4
+__device__ __forceinline__ uint4 sa_rotate(uint4 e, uint32_t q)
+{
+  const uint32_t a = (16u * q) % 31u, b = (16u * q) % 33u;
+  sror_var(e.x, e.y, a, b);
+  srol_var(e.z, e.w, a, b);
+  return e;
+}
+// block-wide: fill the LDS area (no barrier here)
+__device__ __forceinline__ void sa_load(uint4* tabs, const uint4* fw, const uint4* acorr, const uint32_t* mask, uint32_t n_grp,
+                                        uint32_t G, uint32_t tid, uint32_t n_threads)
+{
+  for (uint32_t i = tid; i < SA_TAB_ENTRIES; i += n_threads) tabs[i] = sa_rotate(fw[i & 1023u], i >> 10);
+  uint4* const g_acorr = tabs + SA_TAB_ENTRIES;
+  uint32_t* const g_mask = (uint32_t*)(g_acorr + n_grp);
+  for (uint32_t i = tid; i < n_grp; i += n_threads) {
+    g_acorr[i] = sa_rotate(acorr[i], (i % G) & 3u);
+    g_mask[i] = mask[i];
+  }
+}
+// canonical hash of the window that starts at stream position (d, sh) under seed s
+__device__ __forceinline__ uint64_t sa_hash(const uint4* tabs, const uint4* g_acorr, const uint32_t* g_mask, const uint32_t* bits,
+                                            uint32_t d, uint32_t sh, uint32_t s, uint32_t G, uint32_t k31, uint32_t k33)
+{
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  const uint32_t chunks = (G + 3u) >> 2;
+  for (uint32_t c = chunks; c-- > 0;) {
+    uint4 x = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+      const uint32_t g = 4u * c + q;
+      if (g < G) { // (uniform)
+        const uint32_t word = funnel(bits[d + g + 1u], bits[d + g], sh) & g_mask[s * G + g];
+        const uint4 e = fw_word16(tabs + q * 1024u, word), ac = g_acorr[s * G + g];
+        x.x ^= e.x ^ ac.x; x.y ^= e.y ^ ac.y; x.z ^= e.z ^ ac.z; x.w ^= e.w ^ ac.w;
+      }
+    }
+    sror_var(acc.x, acc.y, 2u, 31u); // 64 bases: 64 mod 31, 64 mod 33
+    srol_var(acc.z, acc.w, 2u, 31u);
+    acc.x ^= x.x; acc.y ^= x.y; acc.z ^= x.z; acc.w ^= x.w;
+  }
+  srol_var(acc.x, acc.y, k31, k33);
+  return canon_pair(acc.x, acc.y, acc.z, acc.w);
+}
+
 struct SeedWtileArgs {
   const uint8_t* seqs;
   uint64_t* hashes;      // dense [read][window][seed][m2]
@@ -386,8 +438,8 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
   uint4* tabs = (uint4*)lds_dyn;
   // (ANY: the fw tables up to the AC entries, then the seeds' group constants, then their masks)
   const uint32_t n_grp = ANY ? a.n_seeds * a.any_groups : 0u;
-  const uint32_t n_entries = ANY ? FW_AC + 16u + n_grp + ((n_grp + 3u) >> 2) : ROT ? 4096u * NSETS : a.n_seeds * NT * 256u;
-  const uint4* g_acorr = tabs + FW_AC + 16u;
+  const uint32_t n_entries = ANY ? SA_TAB_ENTRIES + n_grp + ((n_grp + 3u) >> 2) : ROT ? 4096u * NSETS : a.n_seeds * NT * 256u;
+  const uint4* g_acorr = tabs + SA_TAB_ENTRIES;
   const uint32_t* g_mask = (const uint32_t*)(g_acorr + n_grp);
   const uint32_t per = ROT ? (uint32_t)(RNS * RM2) : a.n_seeds * a.m2; // values per window
   const uint32_t otile_u64 = 64u * per + 2u;
@@ -395,11 +447,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
   uint64_t* otile = (uint64_t*)wbase;
   uint32_t* bits = wbase + otile_u64 * 2u;
   if constexpr (ANY) {
-    for (uint32_t i = tid; i < FW_AC + 16u; i += blockDim.x) tabs[i] = a.tables[i];
-    for (uint32_t i = tid; i < n_grp; i += blockDim.x) {
-      tabs[FW_AC + 16u + i] = a.any_acorr[i];
-      ((uint32_t*)(tabs + FW_AC + 16u + n_grp))[i] = a.any_mask[i];
-    }
+    sa_load(tabs, a.tables, a.any_acorr, a.any_mask, n_grp, a.any_groups, tid, blockDim.x);
   } else if constexpr (ROT) {
     for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
       const uint32_t set = i >> 12, ii = i & 4095u;
@@ -563,16 +611,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_wtile_kernel(const SeedWtileA
       if constexpr (ANY) {
         const uint32_t G = a.any_groups, k31 = a.k % 31u, k33 = a.k % 33u;
         for (uint32_t s = 0; s < a.n_seeds; ++s) {
-          uint4 acc = make_uint4(0, 0, 0, 0);
-          for (uint32_t g = G; g-- > 0;) {
-            const uint32_t word = funnel(bits[d + g + 1u], bits[d + g], sh) & g_mask[s * G + g];
-            const uint4 e = fw_word16(tabs, word), ac = g_acorr[s * G + g];
-            sror_var(acc.x, acc.y, 16u, 16u);
-            srol_var(acc.z, acc.w, 16u, 16u);
-            acc.x ^= e.x ^ ac.x; acc.y ^= e.y ^ ac.y; acc.z ^= e.z ^ ac.z; acc.w ^= e.w ^ ac.w;
-          }
-          srol_var(acc.x, acc.y, k31, k33);
-          const uint64_t h0 = canon_pair(acc.x, acc.y, acc.z, acc.w);
+          const uint64_t h0 = sa_hash(tabs, g_acorr, g_mask, bits, d, sh, s, G, k31, k33);
           mine[s * a.m2] = h0;
 #pragma unroll
           for (uint32_t jj = 1; jj < (uint32_t)SF_MAX_RUNTIME_M; ++jj)
@@ -753,8 +792,8 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint4* tabs = (uint4*)lds_dyn;
   const uint32_t n_grp = ANY ? a.n_seeds * a.any_groups : 0u;
-  const uint32_t n_entries = ANY ? FW_AC + 16u + n_grp + ((n_grp + 3u) >> 2) : ROT ? 4096u * NSETS : a.n_seeds * NT * 256u;
-  const uint4* g_acorr = tabs + FW_AC + 16u;
+  const uint32_t n_entries = ANY ? SA_TAB_ENTRIES + n_grp + ((n_grp + 3u) >> 2) : ROT ? 4096u * NSETS : a.n_seeds * NT * 256u;
+  const uint4* g_acorr = tabs + SA_TAB_ENTRIES;
   const uint32_t* g_mask = (const uint32_t*)(g_acorr + n_grp);
   const uint32_t per = ROT ? (uint32_t)(RNS * RM2) : a.n_seeds * a.m2;
   const uint32_t otile_u64 = a.otile_recs * per + 2u;
@@ -768,11 +807,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
   uint4* rt = (uint4*)(bits + a.bits_dwords);
   uint8_t* wmap = (uint8_t*)(rt + RT); // windows [16c, 16c + 16) of the tile: the read that holds window 16c
   if constexpr (ANY) {
-    for (uint32_t i = tid; i < FW_AC + 16u; i += blockDim.x) tabs[i] = a.tables[i];
-    for (uint32_t i = tid; i < n_grp; i += blockDim.x) {
-      tabs[FW_AC + 16u + i] = a.any_acorr[i];
-      ((uint32_t*)(tabs + FW_AC + 16u + n_grp))[i] = a.any_mask[i];
-    }
+    sa_load(tabs, a.tables, a.any_acorr, a.any_mask, n_grp, a.any_groups, tid, blockDim.x);
   } else if constexpr (ROT) {
     for (uint32_t i = tid; i < n_entries; i += blockDim.x) {
       const uint32_t set = i >> 12, ii = i & 4095u;
@@ -900,16 +935,7 @@ __global__ __launch_bounds__(SF_THREADS) void seed_rtile_kernel(const SeedRtileA
         if constexpr (ANY) {
           const uint32_t G = a.any_groups, k31 = a.k % 31u, k33 = a.k % 33u;
           for (uint32_t s = 0; s < a.n_seeds; ++s) {
-            uint4 acc = make_uint4(0, 0, 0, 0);
-            for (uint32_t g = G; g-- > 0;) {
-              const uint32_t word = funnel(bits[d + g + 1u], bits[d + g], sh) & g_mask[s * G + g];
-              const uint4 e = fw_word16(tabs, word), ac = g_acorr[s * G + g];
-              sror_var(acc.x, acc.y, 16u, 16u);
-              srol_var(acc.z, acc.w, 16u, 16u);
-              acc.x ^= e.x ^ ac.x; acc.y ^= e.y ^ ac.y; acc.z ^= e.z ^ ac.z; acc.w ^= e.w ^ ac.w;
-            }
-            srol_var(acc.x, acc.y, k31, k33);
-            const uint64_t h0 = canon_pair(acc.x, acc.y, acc.z, acc.w);
+            const uint64_t h0 = sa_hash(tabs, g_acorr, g_mask, bits, d, sh, s, G, k31, k33);
             mine[s * a.m2] = h0;
 #pragma unroll
             for (uint32_t jj = 1; jj < (uint32_t)SF_MAX_RUNTIME_M; ++jj)
