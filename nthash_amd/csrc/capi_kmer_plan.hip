@@ -290,7 +290,9 @@ bool kmer_na_plan(const nthip_ctx* c, uint32_t len, uint32_t stride, uint32_t k,
   const size_t fixed = (size_t)kmer_ntab(k) * 4096 + 256 + 64;
   const size_t per_wave = (size_t)p->tile_u64 * 8 + ((size_t)p->ptile_dwords + g.bits_dwords + p->vbits_dwords + g.uw_dwords) * 4;
   const size_t cap = (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512;
-  uint32_t w_max = register_sink_u64 ? 16 : 8;
+  // (tools/na_waves.sh, batches with an N in one read of 1000: 12 waves per CU are 13-14 % ahead of 8 on 150 / 151 bp, k = 31,
+  //  one hash; with several hashes per k-mer or longer k-mers 8 stay level or ahead)
+  uint32_t w_max = register_sink_u64 ? 16 : (m == 1 && k <= 32) ? 12 : 8;
   if (c->tune.na_waves) w_max = c->tune.na_waves;
   for (uint32_t w = w_max; w >= 1; --w)
     if (fixed + per_wave * w <= cap) {

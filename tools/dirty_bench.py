@@ -6,13 +6,13 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import nthash_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
-L, k, m = 150, 31, 1
+L, k, m = (int(x) for x in os.environ.get("DIRTY_SHAPE", "150,31,1").split(","))
 nwin = L - k + 1
 ctx = nthash_amd.Context(0)
 d_in = ctx.malloc(n * L); d_out = ctx.malloc(n * nwin * m * 8)
 ctx.synth_reads_ptr(d_in, 0, n, L, 42)
 # one N every ~1000 reads
-idx = np.arange(0, n * L, 150_017, dtype=np.int64)
+idx = np.arange(0, n * L, 1000 * L + 17, dtype=np.int64)
 for i in idx[:20000]:
     ctx.h2d(d_in + int(i), np.frombuffer(b"N", np.uint8))
 for name, flags in (("optimistic+na", 0), ("general", 4)):
