@@ -219,7 +219,24 @@ public:
   SeedNtHash(SeedNtHash&&) noexcept;
   ~SeedNtHash();
 
-  bool roll();
+  bool roll()
+  {
+    // the walk through a device-computed window, inline (as NtHash::roll): when the stream's next entry IS the next position
+    // the reference's roll() goes there too (src/seed.cpp:518-544: the incoming character is a base -- otherwise it would
+    // jump k positions, which is the next position only for k = 1) and the entry holds its hashes
+    const size_t i = cursor_ + 1;
+    if (sp_ != nullptr && i < sn_ && sp_[i] == pos_ + 1 - sbegin_ && k_ > 1) {
+      cursor_ = i;
+      ++pos_;
+      const unsigned n = get_hash_num();
+      const uint64_t* h = sh_ + i * n;
+      uint64_t* out = hash_arr_.get();
+      for (unsigned j = 0; j < n; ++j) out[j] = h[j];
+      strands_stale_ = true;
+      return true;
+    }
+    return roll_general();
+  }
   bool roll_back();
   bool peek();
   bool peek_back();
@@ -253,7 +270,12 @@ private:
   std::unique_ptr<uint64_t[]> hash_arr_;
   std::shared_ptr<detail::SeedStream> stream_;
   size_t cursor_ = 0;
+  // views into *stream_ for the inline walk of roll(): positions (relative to sbegin_), hashes, entries
+  const uint32_t* sp_ = nullptr;
+  const uint64_t* sh_ = nullptr;
+  size_t sn_ = 0, sbegin_ = 0;
 
+  bool roll_general();
   bool init(bool from_roll);
   void set_window(const char* win, bool try_stream);
   void hash_backward(bool commit);

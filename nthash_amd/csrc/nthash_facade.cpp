@@ -975,13 +975,42 @@ SeedNtHash::SeedNtHash(const SeedNtHash& o)
   , hash_arr_(new uint64_t[o.get_hash_num() ? o.get_hash_num() : 1])
   , stream_(o.stream_)
   , cursor_(o.cursor_)
+  , sp_(o.sp_)
+  , sh_(o.sh_)
+  , sn_(o.sn_)
+  , sbegin_(o.sbegin_)
 {
   std::memcpy(fwd_.get(), o.fwd_.get(), n_seeds_ * sizeof(uint64_t));
   std::memcpy(rev_.get(), o.rev_.get(), n_seeds_ * sizeof(uint64_t));
   std::memcpy(hash_arr_.get(), o.hash_arr_.get(), get_hash_num() * sizeof(uint64_t));
 }
 
-SeedNtHash::SeedNtHash(SeedNtHash&&) noexcept = default;
+// (a moved-from object keeps no view into the stream that went with the move)
+SeedNtHash::SeedNtHash(SeedNtHash&& o) noexcept
+  : seq_(o.seq_)
+  , len_(o.len_)
+  , num_hashes_per_seed_(o.num_hashes_per_seed_)
+  , k_(o.k_)
+  , pos_(o.pos_)
+  , pos0_(o.pos0_)
+  , strands_stale_(o.strands_stale_)
+  , initialized_(o.initialized_)
+  , n_seeds_(o.n_seeds_)
+  , seeds_(std::move(o.seeds_))
+  , fwd_(std::move(o.fwd_))
+  , rev_(std::move(o.rev_))
+  , hash_arr_(std::move(o.hash_arr_))
+  , stream_(std::move(o.stream_))
+  , cursor_(o.cursor_)
+  , sp_(o.sp_)
+  , sh_(o.sh_)
+  , sn_(o.sn_)
+  , sbegin_(o.sbegin_)
+{
+  o.sp_ = nullptr;
+  o.sh_ = nullptr;
+  o.sn_ = 0;
+}
 SeedNtHash::~SeedNtHash() = default;
 
 // hashes of the window `win` (k characters).  A window of the sequence itself
@@ -999,6 +1028,10 @@ void SeedNtHash::set_window(const char* win, bool try_stream)
     if (!stream_ || !stream_->covers(p)) {
       stream_ = build_seed_stream(seq_, len_, stream_ ? p : std::min(p, pos0_), *seeds_, num_hashes_per_seed_);
       cursor_ = 0;
+      sp_ = stream_->pos.data();
+      sh_ = stream_->hashes.data();
+      sn_ = stream_->pos.size();
+      sbegin_ = stream_->w_begin;
     }
     const size_t i = stream_->covers(p) ? stream_->find(p, cursor_) : (size_t)-1;
     if (i != (size_t)-1) {
@@ -1051,8 +1084,13 @@ bool SeedNtHash::init(bool from_roll)
   return true;
 }
 
-// reference: SeedNtHash::roll, src/seed.cpp:518-544
-bool SeedNtHash::roll()
+// (the library still exports SeedNtHash::roll(): the reference's library does, src/seed.cpp:518)
+namespace {
+__attribute__((used)) bool (SeedNtHash::*const export_seednthash_roll)() = &SeedNtHash::roll;
+}
+
+// reference: SeedNtHash::roll, src/seed.cpp:518-544 (the header's inline roll() is this routine's common case)
+bool SeedNtHash::roll_general()
 {
   if (!initialized_) return init(true);
   if (pos_ >= len_ - k_) return false;

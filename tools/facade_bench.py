@@ -17,6 +17,20 @@ int main(int argc, char** argv) {
   std::string s(n, 'A');
   unsigned long long x = 88172645463325252ull;
   for (size_t i = 0; i < n; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; s[i] = "ACGT"[x & 3]; }
+  if (argc > 4) { // spaced seeds: two seeds of k bases (every other position / two of three), m hashes each
+    std::string s1(k, '1'), s2(k, '1');
+    for (unsigned i = 1; i + 1 < k; i += 2) s1[i] = '0';
+    for (unsigned i = 2; i + 1 < k && k - 1 - i > 1; i += 3) { s2[i] = '0'; s2[k - 1 - i] = '0'; }
+    for (int rep = 0; rep < 3; ++rep) {
+      const auto t0 = std::chrono::steady_clock::now();
+      nthash::SeedNtHash h(s, {s1, s2}, m, k);
+      unsigned long long sum = 0, cnt = 0;
+      while (h.roll()) { sum += h.hashes()[0]; ++cnt; }
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      std::printf("SeedNtHash rep %d: %llu k-mers, %.3f s, %.1f M k-mers/s, sum %016llx\n", rep, cnt, dt, cnt / dt / 1e6, sum);
+    }
+    return 0;
+  }
   for (int rep = 0; rep < 3; ++rep) {
     const auto t0 = std::chrono::steady_clock::now();
     nthash::NtHash h(s, m, k);
@@ -38,6 +52,9 @@ with tempfile.TemporaryDirectory() as d:
         env = dict(os.environ, NTHASH_AMD_PREFETCH=pf)
         print("NTHASH_AMD_PREFETCH=" + pf, flush=True)
         subprocess.run([exe, mb, k, m], env=env)
+    if os.environ.get("FACADE_SEEDS") == "1":
+        print("SeedNtHash, 2 seeds x m", flush=True)
+        subprocess.run([exe, str(min(int(mb), 64)), k, m, "seeds"])
     if os.environ.get("FACADE_TRACE") == "1":
         for pf in ("0", "1"):
             print("trace, NTHASH_AMD_PREFETCH=" + pf, flush=True)
