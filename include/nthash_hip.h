@@ -66,7 +66,11 @@ extern "C" {
                                     they come first, in the reference's order; the rest of the slot is zero.  *total = the
                                     extent of the slot array (every window of every read), which out->capacity must hold.
                                     Reads without non-bases -- nearly all of them -- fill their slots: the stream is the
-                                    compact one exactly when every count equals its window count. */
+                                    compact one exactly when every count equals its window count.
+                                    Fixed-length reads too (offsets == NULL, stride == length <= 2048): slot r is
+                                    r * (len - k + 1); the dense kernels run as if the batch were clean and the reads with a
+                                    non-base are redone in their slots -- a batch with an N here and there at the speed of
+                                    a clean one. */
 
 typedef struct nthip_ctx nthip_ctx;     /* one device + one stream + scratch */
 typedef struct nthip_seeds nthip_seeds; /* parsed spaced-seed set (device tables) */

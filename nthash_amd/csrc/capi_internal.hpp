@@ -283,6 +283,19 @@ void build_byte_tables(uint32_t k, const uint8_t* care, uint4* out);
 int get_init_tab(nthip_ctx* c, uint32_t k, const uint4** out);
 int get_kmer_tab(nthip_ctx* c, uint32_t k, const uint4** out);
 int get_fw_tab(nthip_ctx* c, const uint4** out); // the k-independent first-window tables (first_window.hpp), FW_ENTRIES entries
+// NTHIP_OUT_READ_SLOTS on fixed-length reads (capi_kmer_reads.hip): the dense pass marks the 16-byte vectors that hold a
+// non-base in a bit map instead of giving up; afterwards the reads those vectors touch are redone in their slots.
+struct FixedSlots {
+  uint32_t* d_vecmap = nullptr; // what the dense kernels get (KmerRunsArgs::vecmap / KmerRunsGenArgs::vecmap)
+  uint32_t* d_readmap = nullptr;
+  uint64_t* d_list = nullptr;
+  unsigned long long* d_count = nullptr;
+  uint64_t n_words = 0;
+};
+bool kmer_fixed_slots_len_ok(uint32_t len);
+int kmer_fixed_slots_begin(nthip_ctx* c, uint64_t n_reads, uint64_t total_bytes, FixedSlots* fs);
+int kmer_fixed_slots_finish(nthip_ctx* c, const Staged& st, const FixedSlots& fs, uint64_t n_reads, uint32_t len, uint32_t stride,
+                            uint32_t k, uint32_t m, uint64_t total_bytes, uint64_t* n_redone);
 
 // Plan for the headline run-split kernel: run length C | nwin, waves per block, LDS bytes.
 struct RunsPlan {

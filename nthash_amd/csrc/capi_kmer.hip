@@ -40,8 +40,24 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
   NTCHK(stage_inputs(c, rd, flags, total_bytes, st));
   NTCHK(stage_outputs(c, out, flags, rd->n_reads, m, st));
 
-  if (flags & NTHIP_OUT_READ_SLOTS) { // one pass: read r's k-mers at the slot its length implies (capi_kmer_reads.hip)
-    if (!st.offsets) return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_OUT_READ_SLOTS takes reads given by offsets (or spans)");
+  // NTHIP_OUT_READ_SLOTS on fixed-length reads (round 3): slot r = r * (len - k + 1).  The dense pass runs as if the batch
+  // were clean, marking the 16-byte vectors that hold a non-base; the reads those touch are redone afterwards
+  // (kmer_fixed_slots_finish).  A batch with an N in one read of a thousand then costs what a clean one does.
+  const bool fslots = (flags & NTHIP_OUT_READ_SLOTS) && !st.offsets;
+  if (fslots) {
+    const uint32_t flen = rd->fixed_len, fstride = rd->stride ? rd->stride : flen;
+    if (flags & (NTHIP_ASYNC | NTHIP_FORCE_GENERAL | NTHIP_FORCE_ROWS | NTHIP_PACKED_INPUT))
+      return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_OUT_READ_SLOTS: a plain synchronous call on ASCII reads");
+    if (!st.counts || st.fwd || st.rev) return fail(NTHIP_ERR_ARG, "NTHIP_OUT_READ_SLOTS needs out->counts and has no strand outputs");
+    if (fstride != flen || !kmer_fixed_slots_len_ok(flen) || kmer_runs_chunked_compiled())
+      return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_OUT_READ_SLOTS on fixed-length reads: reads back to back (stride == length) of at most 2048 bases");
+    if (flen >= k && rd->n_reads * (uint64_t)(flen - k + 1) > out->capacity) {
+      if (total_out) *total_out = rd->n_reads * (uint64_t)(flen - k + 1);
+      return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed (the slot array)", (unsigned long long)out->capacity,
+                  (unsigned long long)(rd->n_reads * (uint64_t)(flen - k + 1)));
+    }
+  }
+  if ((flags & NTHIP_OUT_READ_SLOTS) && !fslots) { // one pass: read r's k-mers at the slot its length implies (capi_kmer_reads.hip)
     if (flags & (NTHIP_ASYNC | NTHIP_FORCE_GENERAL | NTHIP_FORCE_ROWS))
       return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_OUT_READ_SLOTS: a plain synchronous call");
     bool handled = false;
@@ -132,6 +148,8 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
     if (!async && c->async_pending)
       return fail(NTHIP_ERR_ARG, "NTHIP_ASYNC batches are pending: call nthip_ctx_take_dirty first");
     if (!c->async_pending) HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream));
+    FixedSlots fs;
+    if (fslots) NTCHK(kmer_fixed_slots_begin(c, rd->n_reads, total_bytes, &fs));
     int rc;
     RunsPlan plan;
     const bool rows_only = (flags & NTHIP_FORCE_ROWS) != 0;
@@ -152,6 +170,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
       ra.seqs = st.seqs;
       ra.hashes = st.hashes;
       ra.dirty = (uint32_t*)c->d_small;
+      ra.vecmap = fs.d_vecmap;
       if (any_k) NTCHK(get_kmer_tab(c, k, &ra.init_tab)); // 4 tables per window word, zero ones past ceil(k/4)
       else NTCHK(get_init_tab(c, k, &ra.init_tab));
       ra.n_reads = rd->n_reads;
@@ -224,6 +243,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
             if (!kmer_gen_plan(c, len, stride, k, m, &q, false, cand[i])) continue;
             fill_gen_args(ga, c, st, &slice, k, m, q, a);
             ga.init_tab = gen_tab;
+            ga.vecmap = fs.d_vecmap;
             float ms = 1e30f;
             for (int rep = 0; rep < 3 && clean; ++rep) { // the first launch warms the tables and the clocks; then the better of two
               HIPCHK(hipEventRecord(e0, c->stream));
@@ -256,12 +276,14 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
         return fail(NTHIP_ERR_HIP, "run-split plan failed for a tuned run length");
       fill_gen_args(ga, c, st, rd, k, m, gplan, a);
       ga.init_tab = gen_tab;
+      ga.vecmap = fs.d_vecmap;
       rc = launch_kmer_gen_dense(c, ga, gplan.lds, gplan.nw, gplan.dword_tail != 0);
-    } else if (!rows_ok) {
+    } else if (!rows_ok || fslots) { // (the row-per-read kernel has no read-slots bookkeeping)
       rc = NTHIP_OK;
       fast_ran = false;
     } else rc = launch_kmer_rows(c, a, dyn);
     NTCHK(rc);
+    if (fslots && !fast_ran) return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_OUT_READ_SLOTS: no run-split kernel takes this shape");
     if (async) {
       if (!fast_ran) return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_ASYNC: no dense kernel takes this shape");
       c->async_pending = true;
@@ -291,6 +313,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
                            (const uint64_t*)nullptr, (const uint64_t*)nullptr);
         HIPCHK(hipGetLastError());
       }
+      if (fslots) NTCHK(kmer_fixed_slots_finish(c, st, fs, rd->n_reads, len, stride, k, m, total_bytes, nullptr));
       done = true;
     }
     // dirty: some byte is not ACGTU -> redo on an N-aware path (device side)

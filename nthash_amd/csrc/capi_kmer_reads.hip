@@ -285,3 +285,62 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   HIPCHK(hipStreamSynchronize(c->stream));
   return NTHIP_OK;
 }
+
+// ---- NTHIP_OUT_READ_SLOTS on fixed-length reads ------------------------------------------------------------------------
+bool ntamd::host::kmer_fixed_slots_len_ok(uint32_t len) { return len <= RD_MAX_LEN; }
+
+int ntamd::host::kmer_fixed_slots_begin(nthip_ctx* c, uint64_t n_reads, uint64_t total_bytes, FixedSlots* fs)
+{
+  const uint64_t n_vec = (total_bytes >> 4) + 4;           // vectors of the batch (from the reads' first byte rounded down to 16)
+  const uint64_t vwords = (n_vec + 31) / 32, rwords = (n_reads + 31) / 32;
+  const uint64_t elems = (vwords + rwords + 1) / 2 + n_reads + 8;
+  NTCHK(ensure_scratch2(c, elems));
+  fs->d_vecmap = (uint32_t*)c->d_scratch2;
+  fs->d_readmap = fs->d_vecmap + vwords;
+  fs->d_list = c->d_scratch2 + (vwords + rwords + 1) / 2;
+  fs->d_count = (unsigned long long*)(fs->d_list + n_reads);
+  fs->n_words = vwords;
+  HIPCHK(hipMemsetAsync(fs->d_vecmap, 0, (vwords + rwords) * sizeof(uint32_t), c->stream));
+  HIPCHK(hipMemsetAsync(fs->d_count, 0, sizeof(unsigned long long), c->stream));
+  return NTHIP_OK;
+}
+
+// after the dense pass (counts = windows and, when wanted, positions = window indices already filled for every read):
+// list the reads a marked vector touches, redo them -- the windows the reference emits at the front of the slot, the exact
+// count, zeros behind
+int ntamd::host::kmer_fixed_slots_finish(nthip_ctx* c, const Staged& st, const FixedSlots& fs, uint64_t n_reads, uint32_t len,
+                                         uint32_t stride, uint32_t k, uint32_t m, uint64_t total_bytes, uint64_t* n_redone)
+{
+  uint64_t blocks = (fs.n_words + 255) / 256;
+  if (blocks > (uint64_t)c->n_cu * 16) blocks = (uint64_t)c->n_cu * 16;
+  hipLaunchKernelGGL(slots_list_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const uint32_t*)fs.d_vecmap, fs.n_words,
+                     (uint32_t)((uintptr_t)st.seqs & 15u), stride, n_reads, total_bytes, fs.d_readmap, fs.d_list, fs.d_count);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_small + 128, fs.d_count, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t n_list = 0;
+  memcpy(&n_list, c->h_small + 128, 8);
+  if (n_redone) *n_redone = n_list;
+  if (n_list == 0) return NTHIP_OK;
+  KmerDirtyReadsArgs da;
+  memset(&da, 0, sizeof da);
+  da.seqs = st.seqs;
+  da.list = fs.d_list;
+  da.n_list = fs.d_count;
+  da.k = k;
+  da.m = m;
+  da.cnt = st.counts;
+  da.hashes = st.hashes;
+  da.pos = st.pos;
+  da.slots = 1;
+  da.R = 1;
+  da.fixed_len = len;
+  da.fixed_stride = stride;
+  NTCHK(get_fw_tab(c, &da.horner_tab));
+  prof_begin(c, "kmer_dirty_reads_kernel(read slots, fixed length)");
+  hipLaunchKernelGGL(kmer_dirty_reads_kernel<false>, dim3((unsigned)c->n_cu * 4), dim3(256), 0, c->stream, da);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+

@@ -537,7 +537,59 @@ struct KmerDirtyReadsArgs {
   // NTHIP_OUT_READ_SLOTS (hash pass only, no count pass before it): the read's k-mers go to the front of the slot its
   // length implies (tile_off = scan of the tiles' WINDOW counts), cnt[r] = how many, zeros behind them
   uint32_t slots, pad;
+  // fixed-length reads (starts == NULL; NTHIP_OUT_READ_SLOTS): read r = bytes [r * fixed_stride, + fixed_len), slot r * windows
+  uint32_t fixed_len, fixed_stride;
 };
+
+// NTHIP_OUT_READ_SLOTS on fixed-length reads: the dense pass set a bit per 16-byte vector that holds a non-base
+// (KmerRunsArgs::vecmap).  A thread per word of that map: every read a marked vector touches goes on the list, once
+// (readmap: a bit per read).  mis = address of the reads' first byte mod 16 (vector v = bytes [16 v - mis, 16 v - mis + 16)).
+static __global__ __launch_bounds__(256) void slots_list_kernel(const uint32_t* __restrict__ vecmap, uint64_t n_words, uint32_t mis,
+                                                                uint32_t stride, uint64_t n_reads, uint64_t total_bytes,
+                                                                uint32_t* __restrict__ readmap, uint64_t* __restrict__ list,
+                                                                unsigned long long* __restrict__ n_list)
+{
+  // (the reads found go through a block-local list: one atomic on the shared counter per block and flush, not one per
+  //  read -- 20 000 atomics on one address took 0.27 ms)
+  constexpr uint32_t CAP = 1024;
+  __shared__ uint64_t found[CAP];
+  __shared__ uint32_t n_found;
+  __shared__ unsigned long long out_base;
+  if (threadIdx.x == 0) n_found = 0;
+  __syncthreads();
+  const uint64_t per_round = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t w0 = (uint64_t)blockIdx.x * blockDim.x; w0 < n_words; w0 += per_round) { // (block-uniform trip count)
+    const uint64_t w = w0 + threadIdx.x;
+    uint32_t bitsw = w < n_words ? vecmap[w] : 0u;
+    while (bitsw) {
+      const uint32_t b = (uint32_t)__builtin_ctz(bitsw);
+      bitsw &= bitsw - 1u;
+      const uint64_t v = w * 32u + b;
+      const uint64_t lo = (v << 4) >= mis ? (v << 4) - mis : 0u;
+      uint64_t hi = (v << 4) + 15u - mis;
+      if (hi >= total_bytes) hi = total_bytes - 1u;
+      if (lo >= total_bytes) continue;
+      for (uint64_t r = lo / stride; r <= hi / stride && r < n_reads; ++r) {
+        const uint32_t bit = 1u << (r & 31u);
+        if (!(atomicOr(&readmap[r >> 5], bit) & bit)) {
+          const uint32_t at = atomicAdd(&n_found, 1u);
+          if (at < CAP) found[at] = r;
+          else list[atomicAdd(n_list, 1ull)] = r; // (a block with more than CAP reads in one round: straight out)
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t nf = n_found < CAP ? n_found : CAP;
+    if (nf >= CAP / 2 || w0 + per_round >= n_words) { // flush: half full, or the last round
+      if (threadIdx.x == 0) out_base = nf ? atomicAdd(n_list, (unsigned long long)nf) : 0ull;
+      __syncthreads();
+      for (uint32_t x = threadIdx.x; x < nf; x += blockDim.x) list[out_base + x] = found[x];
+      __syncthreads();
+      if (threadIdx.x == 0) n_found = 0;
+    }
+    __syncthreads();
+  }
+}
 
 constexpr uint32_t RD_MAX_LEN = 2048; // longest read this path takes (the host checks)
 
@@ -567,8 +619,9 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
   const uint64_t kmul = (uint64_t)k * MULTISEED;
   for (uint64_t i = (uint64_t)blockIdx.x * 4u + wave; i < n; i += (uint64_t)gridDim.x * 4u) {
     const uint64_t r = a.list[i];
-    const uint8_t* s = a.seqs + a.starts[r];
-    const uint32_t len = (uint32_t)(a.ends[r] - a.starts[r]);
+    const bool fixed = a.starts == nullptr;
+    const uint8_t* s = a.seqs + (fixed ? r * a.fixed_stride : a.starts[r]);
+    const uint32_t len = fixed ? a.fixed_len : (uint32_t)(a.ends[r] - a.starts[r]);
     if (!COUNT_ONLY) {
       for (uint32_t j = lane; j < (len >> 4) + 8u; j += 64u) bits[j] = 0;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -595,7 +648,9 @@ __global__ __launch_bounds__(256) void kmer_dirty_reads_kernel(const KmerDirtyRe
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     const uint32_t nwin = len >= k ? len - k + 1u : 0u;
     uint64_t base = 0;
-    if (!COUNT_ONLY) { // the tile's first k-mer + the k-mers of the reads before this one in its tile
+    if (!COUNT_ONLY && fixed) {
+      base = r * (uint64_t)nwin; // (every slot has the fixed window count)
+    } else if (!COUNT_ONLY) { // the tile's first k-mer + the k-mers of the reads before this one in its tile
       const uint64_t r0 = r / a.R * a.R;
       uint32_t before = 0;
       if (r0 + lane < r) {

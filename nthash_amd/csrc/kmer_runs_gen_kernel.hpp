@@ -60,6 +60,7 @@ struct KmerRunsGenArgs {
   const uint8_t* seqs;
   uint64_t* hashes;          // dense [read][window][m]  /  N-aware: compact [emitted k-mer][m]
   uint32_t* dirty;           // dense: set when a non-base is seen
+  uint32_t* vecmap;          // dense, NTHIP_OUT_READ_SLOTS on fixed-length reads: see KmerRunsArgs::vecmap (NULL: the plain pass)
   const uint4* init_tab;     // global [ntab][256] {f.lo,f.hi,r.lo,r.hi}
   uint32_t* pos;             // N-aware, optional: position of every emitted k-mer in its read
   uint64_t* counts;          // count pass, optional (zeroed by the host): per-read emitted windows
@@ -381,6 +382,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
             if (q >= lo_cut && q < hi_cut) b |= (bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
         }
       }
+      if (b != 0u && a.vecmap != nullptr) { // (rare) read slots: remember the vector, keep going
+        const uint64_t av = ((seqs_addr + sl.byte0) >> 4) - (seqs_addr >> 4) + i;
+        atomicOr(&a.vecmap[av >> 5], 1u << (av & 31u));
+        b = 0;
+      }
       bad |= b;
       bits[i] = p;
     }
@@ -405,6 +411,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
         for (int q = 0; q < 4; ++q)
           if (q < hi_cut) keep |= 0xFFu << (q * 8);
         b &= keep;
+      }
+      if (b != 0u && a.vecmap != nullptr) {
+        const uint64_t av = ((seqs_addr + sl.byte0) >> 4) - (seqs_addr >> 4) + 64u + (lane >> 2);
+        atomicOr(&a.vecmap[av >> 5], 1u << (av & 31u));
+        b = 0;
       }
       bad |= b;
       ((uint8_t*)bits)[256u + lane] = (uint8_t)p;

@@ -78,6 +78,10 @@ struct KmerRunsArgs {
   const uint8_t* seqs;
   uint64_t* hashes;      // dense [read][window][m]
   uint32_t* dirty;
+  // NTHIP_OUT_READ_SLOTS on fixed-length reads (round 3): a bit per 16-byte vector of the batch (vector index relative to
+  // a.seqs rounded down to 16) -- set where a vector holds a non-base INSTEAD of flagging the batch dirty: the pass goes on
+  // as if the batch were clean, the reads those vectors touch are redone in their slots afterwards.  NULL: the plain pass.
+  uint32_t* vecmap;
   const uint4* init_tab; // global [ntab][256] {f.lo,f.hi,r.lo,r.hi}, all-care mask
   uint64_t n_reads;
   uint64_t n_runs;       // n_reads * rpr
@@ -220,6 +224,11 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
           if (q >= lo_cut && q < hi_cut) b |= (bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
       }
     }
+    if (b != 0u && a.vecmap != nullptr) { // (rare) read slots: remember the vector, keep going
+      const uint64_t av = (((uint64_t)a.seqs + sl.byte0) >> 4) - ((uint64_t)a.seqs >> 4) + i;
+      atomicOr(&a.vecmap[av >> 5], 1u << (av & 31u));
+      b = 0;
+    }
     bad |= b;
     bits[i] = p;
   };
@@ -234,6 +243,11 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
       for (int q = 0; q < 4; ++q)
         if (q < hi_cut) keep |= 0xFFu << (q * 8);
       b &= keep;
+    }
+    if (b != 0u && a.vecmap != nullptr) {
+      const uint64_t av = (((uint64_t)a.seqs + sl.byte0) >> 4) - ((uint64_t)a.seqs >> 4) + 64u + (j >> 2);
+      atomicOr(&a.vecmap[av >> 5], 1u << (av & 31u));
+      b = 0;
     }
     bad |= b;
     ((uint8_t*)bits)[256u + j] = (uint8_t)p;
@@ -624,7 +638,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
             sl.shift = (uint32_t)((base_addr + t * tile_bytes) & 15u);
             sl.slab_bytes = slab_bytes;
             sl.n_vec = (sl.shift + slab_bytes + 15u) >> 4;
-            sl.byte0 = 0;
+            sl.byte0 = t * tile_bytes - sl.shift; // (only the read-slots bookkeeping of pack_vec looks at it here)
             sl.runs_here = 64u;
             sl.edge = (t == 0u || (t + 1u) * reads_per_tile >= a.n_reads) ? 1u : 0u; // first / last slab of the buffer
             bits = bits0 + i * a.bits_dwords;

@@ -1565,6 +1565,65 @@ def test_kmer_read_slots_contract_vs_oracle(ctx, oracle, k, m, n, lo, hi, bad_fr
         ctx.free(d)
 
 
+@pytest.mark.parametrize("n,L,k,m,bad_every", [
+    (4000, 150, 31, 1, 997),      # the headline kernel (burst path: pieces of 8 tiles = 64 reads)
+    (4000, 150, 31, 4, 500),      # compile-time m = 4
+    (3000, 151, 31, 1, 400),      # the run-length-11 instantiation of the headline kernel
+    (3000, 100, 64, 3, 300),      # general kernel, forward-half tables
+    (2500, 250, 21, 2, 700), (1500, 150, 100, 1, 200), (900, 301, 200, 2, 150),   # general kernel; k beyond the position tables
+    (700, 36, 21, 1, 50), (64, 2048, 31, 1, 5),
+    (3000, 150, 31, 1, 0),        # a clean batch: nothing is redone
+    (2000, 150, 31, 1, 3),        # a non-base in most reads
+])
+def test_kmer_read_slots_fixed_length_vs_oracle(ctx, oracle, n, L, k, m, bad_every):
+    """NTHIP_OUT_READ_SLOTS on fixed-length reads (offsets == NULL): slot r = r * (L - k + 1) holds the k-mers NtHash emits
+    for read r at its front, counts[r] says how many, zeros behind; *total = n * (L - k + 1).  The dense kernels run as if
+    the batch were clean and mark the 16-byte vectors that hold a non-base; the reads those touch are redone afterwards.
+    Non-bases at read ends, in neighbouring reads, in the first and the last read, several per read; positions"""
+    import nthash_amd
+    from nthash_amd.capi import NTHIP_OUT_READ_SLOTS, NTHIP_HOST_INPUT, NTHIP_HOST_OUTPUT
+    rng = np.random.default_rng(n + L + k)
+    data = oracle.synth_reads(4, n, L, 11 + k).copy()
+    if bad_every:
+        n_bad = max(4, n * L // (bad_every * L))
+        where = rng.choice(n * L, n_bad, replace=False)
+        data[where] = np.frombuffer(b"NnRY-.", dtype=np.uint8)[rng.integers(0, 6, n_bad)]
+        data[0] = ord("N")                      # the first byte of the batch
+        data[n * L - 1] = ord("N")              # the last one
+        data[5 * L - 1] = ord("N")              # the last base of a read ...
+        data[5 * L] = ord("N")                  # ... and the first of the next
+        data[(n // 2) * L + k - 1] = ord("N")
+        data[(n // 2) * L + k + 3] = ord("n")   # two in one read
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m)
+    nwin = L - k + 1
+    cap = n * nwin
+    h, c_, p_ = np.full(cap * m, 0xAB, np.uint64), np.zeros(n, np.uint64), np.full(cap, 7, np.uint32)
+    flags = NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT | NTHIP_OUT_READ_SLOTS
+    total = ctx.kmer_hash_ptr(data.ctypes.data, 0, n, L, 0, k, m, h.ctypes.data, cap, counts=c_.ctypes.data, pos=p_.ctypes.data,
+                              flags=flags)
+    assert total == cap
+    assert (c_ == want["counts"]).all()
+    hh = h.reshape(n, nwin, m)
+    pp = p_.reshape(n, nwin)
+    w_off = np.concatenate([[0], np.cumsum(want["counts"].astype(np.int64))])
+    wh = want["hashes"].reshape(-1, m)
+    for r in range(n):
+        c = int(want["counts"][r])
+        assert (hh[r, :c] == wh[w_off[r]:w_off[r] + c]).all(), r
+        assert (pp[r, :c] == want["pos"][w_off[r]:w_off[r] + c]).all(), r
+        assert (hh[r, c:] == 0).all(), r
+    # without positions; the slot array must fit
+    h2, c2 = np.zeros(cap * m, np.uint64), np.zeros(n, np.uint64)
+    assert ctx.kmer_hash_ptr(data.ctypes.data, 0, n, L, 0, k, m, h2.ctypes.data, cap, counts=c2.ctypes.data, flags=flags) == cap
+    assert (h2 == h).all() and (c2 == c_).all()
+    with pytest.raises(nthash_amd.NtHipError) as ei:
+        ctx.kmer_hash_ptr(data.ctypes.data, 0, n, L, 0, k, m, h2.ctypes.data, cap - 1, counts=c2.ctypes.data, flags=flags)
+    assert ei.value.code == nthash_amd.capi.NTHIP_ERR_CAPACITY and ei.value.total == cap
+    with pytest.raises(nthash_amd.NtHipError):   # counts are part of the contract
+        ctx.kmer_hash_ptr(data.ctypes.data, 0, n, L, 0, k, m, h2.ctypes.data, cap, flags=flags)
+
+
 def test_fastx_index_flags_malformed_input(ctx):
     for buf, fmt in ((b"@a\nACGT\n-\nIIII\n", 4), (b"a\nACGT\n+\nIIII\n", 4), (b"@a\nAC\n+\nII\nxx\nAC\n+\nII\n", 4),
                      (b">a\nACGT\nACGT\n>b\nAC\n", 2)):
@@ -2310,7 +2369,7 @@ def test_windowed_build_of_the_headline_kernel_is_bit_exact():
                                "capi_kmer_runs"], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     env = dict(os.environ, NTHASH_AMD_LIB=lib)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x",
-                        "-k", "kmer and not windowed and not native_library"], cwd=ROOT, env=env, capture_output=True,
+                        "-k", "kmer and not windowed and not native_library and not read_slots_fixed"], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 

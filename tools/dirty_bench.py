@@ -15,11 +15,12 @@ ctx.synth_reads_ptr(d_in, 0, n, L, 42)
 idx = np.arange(0, n * L, 1000 * L + 17, dtype=np.int64)
 for i in idx[:20000]:
     ctx.h2d(d_in + int(i), np.frombuffer(b"N", np.uint8))
-for name, flags in (("optimistic+na", 0), ("general", 4)):
+d_cnt = ctx.malloc(n * 8)
+for name, flags in (("optimistic+na", 0), ("read slots", nthash_amd.capi.NTHIP_OUT_READ_SLOTS), ("general", 4)):
     ts = []
     for _ in range(4):
         t0 = time.perf_counter()
-        tot = ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin, flags=flags)
+        tot = ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin, flags=flags, counts=d_cnt if name == "read slots" else 0)
         ts.append(time.perf_counter() - t0)
     t = min(ts)
     print(f"{name:14s} total={tot} ({n*nwin-tot} skipped)  {t*1e3:.2f} ms  {tot/t/1e9:.1f} Gkmer/s (wall, whole call)")
