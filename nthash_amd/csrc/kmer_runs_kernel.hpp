@@ -224,11 +224,13 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
           if (q >= lo_cut && q < hi_cut) b |= (bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
       }
     }
+#if !KR_NO_VECMAP // (A/B: the pass without the read-slots bookkeeping)
     if (b != 0u && a.vecmap != nullptr) { // (rare) read slots: remember the vector, keep going
       const uint64_t av = (((uint64_t)a.seqs + sl.byte0) >> 4) - ((uint64_t)a.seqs >> 4) + i;
       atomicOr(&a.vecmap[av >> 5], 1u << (av & 31u));
       b = 0;
     }
+#endif
     bad |= b;
     bits[i] = p;
   };
@@ -244,11 +246,13 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
         if (q < hi_cut) keep |= 0xFFu << (q * 8);
       b &= keep;
     }
+#if !KR_NO_VECMAP
     if (b != 0u && a.vecmap != nullptr) {
       const uint64_t av = (((uint64_t)a.seqs + sl.byte0) >> 4) - ((uint64_t)a.seqs >> 4) + 64u + (j >> 2);
       atomicOr(&a.vecmap[av >> 5], 1u << (av & 31u));
       b = 0;
     }
+#endif
     bad |= b;
     ((uint8_t*)bits)[256u + j] = (uint8_t)p;
   };
@@ -496,6 +500,9 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
   // hashed and consumed after the last tile's stores: 8 x 8 = 64 younger stores, and an in-order counter that holds at
   // most 63 operations proves they have landed (the seed kernel's argument) -- no pacing, no block barrier, any number
   // of waves.  The waves of a group take the pieces of its tile range in turn.
+#ifndef KR_NO_VECMAP
+#define KR_NO_VECMAP 0
+#endif
 #ifndef KR_BURST_PLAIN_LOADS
 #define KR_BURST_PLAIN_LOADS 0
 #endif
