@@ -65,6 +65,14 @@ CONFIGS = {
     "var_slots": dict(desc="NtHash k=31, 1 hash/k-mer, 20M variable-length reads of 100-150 bp (spans), an N in 1 read of ~1000, "
                            "one-pass read-slots output (NTHIP_OUT_READ_SLOTS)",
                       L=150, lmin=100, k=31, m=1, seeds=None, reads=20_000_000, slots=True, checksum_as="var"),
+    # fixed-length reads as a sequencer writes them: config 2's shape with an N in one read of ~1000 (the rule of "var" with
+    # one length).  Compact stream: the optimistic dense pass gives up at the first N, then count -> scan -> hash;
+    # read slots: ONE dense pass that marks the vectors holding a non-base, the reads they touch redone in their slots
+    "c2_dirty": dict(desc="NtHash k=31, 1 hash/k-mer, 20M x 150bp fixed-length reads, an N in 1 read of ~1000 (compact stream)",
+                     L=150, lmin=150, k=31, m=1, seeds=None, reads=20_000_000, fixed=True),
+    "c2_dirty_slots": dict(desc="NtHash k=31, 1 hash/k-mer, 20M x 150bp fixed-length reads, an N in 1 read of ~1000, read-slots "
+                                "output (NTHIP_OUT_READ_SLOTS): one dense pass + the reads with an N redone",
+                           L=150, lmin=150, k=31, m=1, seeds=None, reads=20_000_000, fixed=True, slots=True, checksum_as="c2_dirty"),
 }
 
 
@@ -330,6 +338,13 @@ class Workload:
         self.kernel_ms = []
 
     def launch(self, c):
+        if self.var is not None and self.cfg.get("fixed"):  # the same batch through the fixed-length entry
+            import nthash_amd.capi as capi
+            if self.cfg.get("slots"):
+                return self.ctx.kmer_hash_ptr(self.d_in.data_ptr(), 0, self.n_reads, self.L, 0, self.k, self.m, self.d_out.data_ptr(),
+                                              self.total_kmers, counts=self.d_counts.data_ptr(), flags=capi.NTHIP_OUT_READ_SLOTS)
+            return self.ctx.kmer_hash_ptr(self.d_in.data_ptr(), 0, self.n_reads, self.L, 0, self.k, self.m, self.d_out.data_ptr(),
+                                          self.total_kmers)
         if self.var is not None and self.cfg.get("slots"):
             import nthash_amd.capi as capi
             # (total_kmers = every window of every read: the extent of the slot array)
@@ -650,7 +665,7 @@ def main():
                 res["roofline"]["peak_measured_error"] = str(e)
         if not args.no_secondary and args.config == "c2" and not args.reads:
             sec = {}
-            for name in ("c2_packed", "c3", "c4", "ref", "var", "var_slots"):
+            for name in ("c2_packed", "c3", "c4", "ref", "var", "var_slots", "c2_dirty", "c2_dirty_slots"):
                 try:
                     c2 = dict(CONFIGS[name])
                     w2 = Workload(torch, ctx, dev, name, c2, c2["reads"], 0)
@@ -680,6 +695,13 @@ def main():
                     if name == "var":
                         sec[name]["note"] = ("value = whole call (survey of the spans, mark pass, scan, hash pass, reads "
                                              "with an N); kernel / frac = the hash pass alone")
+                    if name == "c2_dirty":
+                        sec[name]["note"] = ("value = whole call (the dense pass that gives up at the first N, count pass, scan, "
+                                             "N-aware hash pass); kernel / frac = the hash pass alone")
+                    if name == "c2_dirty_slots":
+                        sec[name]["note"] = ("value = whole call (the dense pass marking the vectors with a non-base, the list of "
+                                             "the reads they touch, those reads redone in their slots); k-mers counted = slots "
+                                             "(every window); kernel / frac = the dense pass alone")
                     w2.free()
                 except Exception as e:
                     sec[name] = {"error": str(e)}

@@ -337,9 +337,8 @@ int ntamd::host::kmer_fixed_slots_finish(nthip_ctx* c, const Staged& st, const F
   da.fixed_len = len;
   da.fixed_stride = stride;
   NTCHK(get_fw_tab(c, &da.horner_tab));
-  prof_begin(c, "kmer_dirty_reads_kernel(read slots, fixed length)");
+  // (not the kernel of record: nthip_last_kernel_ms keeps the dense pass)
   hipLaunchKernelGGL(kmer_dirty_reads_kernel<false>, dim3((unsigned)c->n_cu * 4), dim3(256), 0, c->stream, da);
-  prof_end(c);
   HIPCHK(hipGetLastError());
   return NTHIP_OK;
 }

@@ -33,6 +33,8 @@ JOBS += [("c2", 0, 20_000, 150, 31, 1, None), ("c2", 125_000_000, 20_000, 150, 3
 
 # variable-length reads (bench.py's "var" line): (name, first_read, n_reads, len_min, len_max, k, m)
 VAR_JOBS = [("var", 0, 20_000_000, 100, 150, 31, 1), ("var", 0, 20_000, 100, 150, 31, 1)]
+# the same rule with one length (bench.py's "c2_dirty" lines: fixed-length reads, an N in one read of ~1000)
+VAR_JOBS += [("c2_dirty", 0, 20_000_000, 150, 150, 31, 1), ("c2_dirty", 0, 20_000, 150, 150, 31, 1)]
 
 
 def main():

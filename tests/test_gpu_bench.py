@@ -100,7 +100,7 @@ def test_config5_shard_full_size_checksum(ctx, rank):
         ctx.free(d_out)
 
 
-@pytest.mark.parametrize("config", ["c3", "c4", "ref", "var", "c2_packed", "var_slots"])
+@pytest.mark.parametrize("config", ["c3", "c4", "ref", "var", "c2_packed", "var_slots", "c2_dirty", "c2_dirty_slots"])
 def test_full_size_chunked_configs_checksum(config):
     """configs 3 / 4 (outputs of 384 / 528 GB: produced chunk by chunk into a ring), the reference's own
     benchmark shape at full size, the variable-length batch (20 M reads of 100-150 bp as spans, reads with an N) and

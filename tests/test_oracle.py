@@ -214,7 +214,7 @@ def test_bench_checksum_fixture_small_entries_vs_oracle(oracle):
     (first_read = rank * 125 M) against the C restatement."""
     from oracle.pyoracle import var_reads
     for e in load_golden("bench_checksums.json"):
-        if e["workload"] == "var":  # variable-length reads: the rule of ref_synth_var_checksum, restated in numpy
+        if e.get("len_min"):  # the rule of ref_synth_var_checksum (variable lengths; or one length: "c2_dirty"), restated in numpy
             if e["n_reads"] > 50_000:
                 continue
             n = e["n_reads"]
