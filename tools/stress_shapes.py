@@ -44,6 +44,23 @@ for it in range(iters):
         a = ctx.kmer_hash(data, k, m, fixed_len=L, stride=stride, n_reads=n, want_pos=want_pos, want_strands=want_str)
         b = ctx.kmer_hash(data, k, m, fixed_len=L, stride=stride, n_reads=n, want_pos=want_pos, want_strands=want_str, flags=4)
         desc = f"fixed n={n} L={L} k={k} m={m} stride={stride} pos={want_pos}"
+        if stride == 0 and L <= 2048 and L >= k and m <= 8 and rng.random() < 0.6:
+            # NTHIP_OUT_READ_SLOTS on the same batch: read r's k-mers at the front of slot r * (L - k + 1), zeros behind, counts
+            import nthash_amd.capi as capi
+            nwin = L - k + 1
+            hs, cs, ps = np.full(n * nwin * m, 0x5A, np.uint64), np.zeros(n, np.uint64), np.zeros(n * nwin, np.uint32)
+            fl = capi.NTHIP_HOST_INPUT | capi.NTHIP_HOST_OUTPUT | capi.NTHIP_OUT_READ_SLOTS
+            tot = ctx.kmer_hash_ptr(data.ctypes.data, 0, n, L, 0, k, m, hs.ctypes.data, n * nwin, counts=cs.ctypes.data,
+                                    pos=ps.ctypes.data, flags=fl)
+            hs = hs.reshape(n, nwin, m)
+            bh = b["hashes"].reshape(-1, m)
+            cnt = b["counts"].astype(np.int64)
+            o = np.concatenate(([0], np.cumsum(cnt)))
+            keep = np.arange(nwin)[None, :] < cnt[:, None]
+            good = tot == n * nwin and (cs == b["counts"]).all() and (hs[keep] == bh).all() and (hs[~keep] == 0).all()
+            if not good:
+                fails += 1
+                print("MISMATCH read slots", desc, tot, n * nwin, int((cs != b["counts"]).sum()), flush=True)
         if (stride == 0 or stride >= L - k + 1) and rng.random() < 0.5:   # the fused MinHash consumer on the same batch
             sig, tot = ctx.minhash(data, k, m, L, n, stride=stride)
             hs = b["hashes"].reshape(-1, m)
