@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--no-plain-pass", action="store_true",
                     help="skip the extra pass on plain hipMalloc buffers (roofline.frac_plain_alloc)")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
+    ap.add_argument("--consumers-reads", type=int, default=0,
+                    help="only the `consumers` object (Bloom / counting sketch / minimizers / MinHash) on this many reads")
     return ap.parse_args()
 
 
@@ -466,6 +468,91 @@ class Workload:
         self.torch.cuda.empty_cache()
 
 
+def consumers(torch, ctx, dev, n_reads=20_000_000):
+    """What the reference's callers do with hashes(), on the device: whole-call rates on 20 M x 150 bp
+    (k = 31), each with a cheap exact or necessary check.  Not part of `value`; N = 1 only."""
+    L, k = 150, 31
+    nwin = L - k + 1
+    kmers = n_reads * nwin
+    out = {"reads": n_reads, "len": L, "k": k, "kmers": kmers, "unit": "kmers/s (whole call, device-resident reads)"}
+    d_in = ctx.malloc(n_reads * L)
+    owned = [d_in]
+    try:
+        ctx.synth_reads_ptr(d_in, 0, n_reads, L, 42)
+
+        def best(f, reps=3):
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                r = f()
+                ts.append(time.perf_counter() - t0)
+            return min(ts), r
+        # Bloom filter: a fresh 4 GiB filter per repetition, one hash per k-mer; every inserted k-mer must then be found
+        n_bits = 1 << 35
+        d_f = ctx.malloc(n_bits // 8)
+        owned.append(d_f)
+
+        def ins():
+            ctx.memset(d_f, 0, n_bits // 8)
+            t0 = time.perf_counter()
+            tot = ctx.bloom_insert_ptr(d_in, n_reads, L, 0, k, 1, d_f, n_bits)
+            return time.perf_counter() - t0, tot
+        t_ins, tot = min(ins() for _ in range(3))
+        t_q, (tq, found) = best(lambda: ctx.bloom_query_ptr(d_in, n_reads, L, 0, k, 1, d_f, n_bits))
+        out["bloom_insert_fresh_4GiB"] = {"value": tot / t_ins, "ms": t_ins * 1e3, "check": "every inserted k-mer is found",
+                                          "ok": bool(tot == kmers and tq == kmers and found == kmers)}
+        out["bloom_query_4GiB"] = {"value": tq / t_q, "ms": t_q * 1e3}
+        ctx.free(d_f)
+        owned.remove(d_f)
+        # counting sketch: 1 Gi one-byte counters, fresh; no counter saturates here, so the bytes add up to the k-mers
+        n_cnt = 1 << 30
+        d_c = ctx.malloc(n_cnt)
+        owned.append(d_c)
+
+        def cins():
+            ctx.memset(d_c, 0, n_cnt)
+            t0 = time.perf_counter()
+            tot = ctx.count_insert_ptr(d_in, n_reads, L, 0, k, 1, d_c, n_cnt)
+            return time.perf_counter() - t0, tot
+        t_c, totc = min(cins() for _ in range(3))
+        view = torch.as_tensor(_DevView(d_c, n_cnt, "|u1"), device=dev)
+        s_bytes = int(view.sum(dtype=torch.int64).item())
+        top = int(view.max().item())
+        del view
+        out["count_insert_fresh_1Gi_counters"] = {"value": totc / t_c, "ms": t_c * 1e3,
+                                                  "check": "sum of the counters == k-mers inserted (largest counter %d)" % top,
+                                                  "ok": bool(totc == kmers and (s_bytes == kmers or top == 255))}
+        ctx.free(d_c)
+        owned.remove(d_c)
+        # (w, k)-minimizers, w = 10: density close to 2 / (w + 1) on random reads, offsets ascending
+        w = 10
+        cap = n_reads * (2 * nwin // (w + 1) + 4)
+        d_h, d_p, d_o = ctx.malloc(cap * 8), ctx.malloc(cap * 4), ctx.malloc((n_reads + 1) * 8)
+        owned += [d_h, d_p, d_o]
+        t_m, totm = best(lambda: ctx.minimizers_ptr(d_in, n_reads, L, 0, k, w, d_h, d_p, d_o, cap))
+        offs = torch.as_tensor(_DevView(d_o, n_reads + 1, "<i8"), device=dev)
+        mono = bool((offs[1:] >= offs[:-1]).all().item()) and int(offs[-1].item()) == totm
+        del offs
+        dens = totm / kmers
+        out["minimizers_w10"] = {"value": kmers / t_m, "ms": t_m * 1e3, "minimizers": totm, "density": dens,
+                                 "check": "density within 10 % of 2 / (w + 1); offsets ascending, last == total",
+                                 "ok": bool(mono and abs(dens - 2 / (w + 1)) < 0.1 * 2 / (w + 1))}
+        for p in (d_h, d_p, d_o):
+            ctx.free(p)
+            owned.remove(p)
+        # per-read MinHash, 4 hashes per k-mer (fused: no stream is written)
+        d_s = ctx.malloc(n_reads * 4 * 8)
+        owned.append(d_s)
+        t_s, tots = best(lambda: ctx.minhash_ptr(d_in, n_reads, L, 0, k, 4, d_s))
+        out["minhash_m4"] = {"value": tots / t_s, "ms": t_s * 1e3, "ok": bool(tots == kmers)}
+    finally:
+        torch.cuda.synchronize(dev)
+        for p in owned:
+            ctx.free(p)
+    return out
+
+
 def measured_peak(torch, ctx, dev):
     """Write-only and copy rates of this box, same process, same clock: the achievable ceilings next to the spec.
     (32 GiB per launch: an 8 GiB fill lasts 1.2 ms and measures 5.6 TB/s on a box whose 24 GiB fill runs at 7.0.)"""
@@ -490,6 +577,15 @@ def main():
     global PLACE_CANDIDATES
     if args.no_placement:
         PLACE_CANDIDATES = 1
+    if args.consumers_reads:  # (tests: the consumers object alone, at a reduced size)
+        import torch
+        import nthash_amd
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        ctx = nthash_amd.Context(0)
+        print(json.dumps({"consumers": consumers(torch, ctx, dev, args.consumers_reads)}), flush=True)
+        ctx.close()
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     cfg = dict(CONFIGS[args.config])
@@ -706,6 +802,10 @@ def main():
                 except Exception as e:
                     sec[name] = {"error": str(e)}
             res["secondary"] = sec
+            try:
+                res["consumers"] = consumers(torch, ctx, dev)
+            except Exception as e:
+                res["consumers"] = {"error": str(e)}
         if not args.no_cpu_baseline:
             try:
                 sample = args.cpu_sample_reads or (12_000_000 if cfg["seeds"] is None and cfg["m"] == 1 else

@@ -125,3 +125,12 @@ def test_bench_default_line_has_all_parts():
     assert res["cpu_baseline"]["value"] > 0 and res["cpu_baseline"]["cores"] == 1
     assert "REDUCED" in res["config"]["workload"]
     assert res["verified_vs_oracle"] is True
+
+
+def test_bench_consumers_section():
+    """bench.py's `consumers` object (Bloom insert / query, counting sketch, minimizers, MinHash on device-resident reads),
+    at a tenth of its size: every check it carries holds"""
+    res = run_bench("--consumers-reads", "2000000")["consumers"]
+    for key in ("bloom_insert_fresh_4GiB", "count_insert_fresh_1Gi_counters", "minimizers_w10", "minhash_m4"):
+        assert res[key]["ok"] is True and res[key]["value"] > 0, (key, res[key])
+    assert res["bloom_query_4GiB"]["value"] > 0
