@@ -469,7 +469,7 @@ extern "C" int nthip_host_alloc(size_t bytes, void** hptr)
   if (!hptr) return fail(NTHIP_ERR_ARG, "hptr is NULL");
   *hptr = nullptr;
   if (bytes == 0) return NTHIP_OK;
-  HIPCHK(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(hptr, bytes, hipHostMallocPortable)); // (any device of the process copies to / from it)
   return NTHIP_OK;
 }
 
