@@ -257,7 +257,8 @@ int nthip_stream_count_query(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t 
  * without candidates picks nothing, a read with fewer than w windows is one window.  Output, on the device: the picked
  * k-mers read by read and left to right -- min_hashes[j], min_pos[j] (window position inside the read; may be NULL) --
  * and min_offsets[n_reads + 1], read r's minimizers being [min_offsets[r], min_offsets[r + 1]).  *total = their number;
- * NTHIP_ERR_CAPACITY (with *total set) when capacity is smaller.  Fixed-length reads; NTHIP_HOST_INPUT is honoured.
+ * NTHIP_ERR_CAPACITY (with *total set) when capacity is smaller.  Fixed-length reads (any batch size, in rounds) or reads
+ * given by offsets (one round: the batch's emitted stream must fit the device's free memory); NTHIP_HOST_INPUT is honoured.
  * What sketching tools on ntHash keep of a read (the reference's hashes() is their input: src/kmer.cpp:246-264). */
 int nthip_kmer_minimizers(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint32_t w, uint64_t* d_min_hashes,
                           uint32_t* d_min_pos, uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total, uint32_t flags);

@@ -378,9 +378,9 @@ class Context:
         _chk(self.L.nthip_stream_bloom_insert(self.h, C.c_void_p(d_hashes), n_values, C.c_void_p(d_filter), n_bits))
 
     # -- per-read (w, k)-minimizers ---------------------------------------------------------------
-    def minimizers_ptr(self, seqs, n_reads, fixed_len, stride, k, w, d_hashes, d_pos, d_offsets, capacity, flags=0):
+    def minimizers_ptr(self, seqs, n_reads, fixed_len, stride, k, w, d_hashes, d_pos, d_offsets, capacity, flags=0, offsets=0):
         """-> number of minimizers (NtHipError with .total set when capacity is too small)"""
-        rd = Reads(seqs, None, n_reads, fixed_len, stride)
+        rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
         total = C.c_uint64(0)
         rc = self.L.nthip_kmer_minimizers(self.h, C.byref(rd), k, w, C.c_void_p(d_hashes), C.c_void_p(d_pos) if d_pos else None,
                                           C.c_void_p(d_offsets), C.c_uint64(capacity), C.byref(total), flags)
@@ -390,15 +390,17 @@ class Context:
             raise err
         return total.value
 
-    def minimizers(self, data, k, w, fixed_len, n_reads, stride=0, capacity=None):
-        """host convenience: -> dict(offsets [n_reads + 1], pos, hashes)"""
+    def minimizers(self, data, k, w, fixed_len, n_reads, stride=0, capacity=None, offsets=None):
+        """host convenience: -> dict(offsets [n_reads + 1], pos, hashes); offsets: reads of any lengths instead of fixed_len"""
         data = np.ascontiguousarray(data, dtype=np.uint8)
         nwin = max(fixed_len - k + 1, 0)
-        cap = n_reads * nwin if capacity is None else capacity
+        cap = (n_reads * nwin if offsets is None else int(data.size)) if capacity is None else capacity
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         d_h, d_p, d_o = self.malloc(max(8, cap * 8)), self.malloc(max(4, cap * 4)), self.malloc((n_reads + 1) * 8)
         try:
             total = self.minimizers_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, w, d_h, d_p, d_o, cap,
-                                        flags=NTHIP_HOST_INPUT)
+                                        flags=NTHIP_HOST_INPUT, offsets=offsets.ctypes.data if offsets is not None else 0)
             offs = np.zeros(n_reads + 1, np.uint64)
             self.d2h(offs, d_o)
             hs, ps = np.zeros(total, np.uint64), np.zeros(total, np.uint32)

@@ -7,6 +7,121 @@
 using namespace ntamd;
 using namespace ntamd::host;
 
+namespace {
+
+// reads of any lengths (offsets): ONE round -- the emitted stream of the whole batch (at most one k-mer per base) in the
+// context's scratch; the kernels take every read's window count from its length
+int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint32_t w, uint64_t* d_min_hashes, uint32_t* d_min_pos,
+                          uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out, uint32_t flags)
+{
+  const uint32_t k = k16;
+  const uint64_t n = rd->n_reads;
+  if (n == 0) {
+    HIPCHK(hipMemsetAsync(d_min_offsets, 0, sizeof(uint64_t), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTHIP_OK;
+  }
+  uint64_t total_bytes = 0;
+  NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
+  Staged st;
+  NTCHK(stage_inputs(c, rd, flags & NTHIP_HOST_INPUT, total_bytes, st));
+  OffsetsSurvey sv;
+  NTCHK(offsets_survey_device(c, st.offsets, n, total_bytes, &sv));
+  if (sv.bad) return fail(NTHIP_ERR_ARG, "offsets are not non-decreasing or reach outside the read buffer");
+  const uint64_t max_nwin64 = sv.max_len >= k ? sv.max_len - k + 1 : 0;
+  if (max_nwin64 > 0xFFFFFFFFull) return fail(NTHIP_ERR_UNSUPPORTED, "a read of %llu bases: window positions are 32 bits wide", (unsigned long long)sv.max_len);
+  const uint32_t max_nwin = (uint32_t)max_nwin64;
+  if (max_nwin == 0) { // no read has a window
+    HIPCHK(hipMemsetAsync(d_min_offsets, 0, (n + 1) * sizeof(uint64_t), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTHIP_OK;
+  }
+  const uint64_t cap_kmers = total_bytes; // (a k-mer starts at a base)
+  const uint32_t chunks = (max_nwin + 63u) / 64u;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t b_h = al(cap_kmers * 8), b_pos = al(cap_kmers * 4), b_fl = al(n * (size_t)chunks * 8), b_rd = al(n * 8);
+  const size_t b_sums = al((n / SCAN_TILE + cap_kmers / SCAN_TILE + 64) * 8);
+  const size_t need = b_h + b_pos + b_fl + 4 * b_rd + b_sums + 256;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  if (c->bloom_tmp_bytes < need) {
+    if (need > free_b + c->bloom_tmp_bytes)
+      return fail(NTHIP_ERR_UNSUPPORTED, "minimizers of reads given by offsets: the batch needs %llu MB of scratch in one round; split it",
+                  (unsigned long long)(need >> 20));
+    if (c->bloom_tmp) HIPCHK(hipFree(c->bloom_tmp));
+    c->bloom_tmp = nullptr;
+    c->bloom_tmp_bytes = 0;
+    HIPCHK(hipMalloc((void**)&c->bloom_tmp, need));
+    c->bloom_tmp_bytes = need;
+  }
+  uint8_t* p = c->bloom_tmp;
+  uint64_t* d_h = (uint64_t*)p; p += b_h;
+  uint32_t* d_pos = (uint32_t*)p; p += b_pos;
+  uint64_t* d_masks = (uint64_t*)p; p += b_fl;
+  uint64_t* d_counts = (uint64_t*)p; p += b_rd;
+  uint64_t* d_roff = (uint64_t*)p; p += b_rd;
+  uint64_t* d_picked = (uint64_t*)p; p += b_rd;
+  uint64_t* d_ooff = (uint64_t*)p; p += b_rd;
+  uint64_t* d_sums = (uint64_t*)p; p += b_sums;
+  uint64_t* d_tot = (uint64_t*)p;
+  nthip_reads dr;
+  memset(&dr, 0, sizeof dr);
+  dr.seqs = (const char*)st.seqs;
+  dr.offsets = st.offsets;
+  dr.n_reads = n;
+  nthip_out out;
+  memset(&out, 0, sizeof out);
+  out.hashes = d_h;
+  out.capacity = cap_kmers;
+  out.counts = d_counts;
+  out.pos = d_pos;
+  uint64_t n_kmers = 0;
+  NTCHK(nthip_kmer_hash(c, &dr, k16, 1, &out, &n_kmers, 0));
+  NTCHK(device_exclusive_scan(c, d_counts, d_roff, n, d_sums, d_tot));
+  MinimizerArgs a;
+  memset(&a, 0, sizeof a);
+  a.hashes = d_h;
+  a.pos = d_pos;
+  a.roff = d_roff;
+  a.n_reads = n;
+  a.n_kmers = n_kmers;
+  a.nwin = max_nwin;
+  a.w = w;
+  a.offsets = st.offsets;
+  a.k = k;
+  a.masks = d_masks;
+  a.chunks = chunks;
+  a.picked = d_picked;
+  a.out_off = d_ooff;
+  a.base = 0;
+  a.capacity = capacity;
+  a.out_hashes = d_min_hashes;
+  a.out_pos = d_min_pos;
+  a.out_offsets = d_min_offsets;
+  const unsigned grid = (unsigned)(c->n_cu * 16);
+  if (max_nwin > 256) HIPCHK(hipMemsetAsync(d_masks, 0, n * (size_t)chunks * 8, c->stream)); // (reads that take the walk OR bits in)
+  prof_begin(c, "minimizer_flag_kernel");
+  if (max_nwin <= 256) hipLaunchKernelGGL((minimizer_flag_kernel<false, 256>), dim3(grid * 2), dim3(64 * MZ_WAVES), 0, c->stream, a);
+  else hipLaunchKernelGGL((minimizer_flag_kernel<false>), dim3(grid), dim3(64 * MZ_WAVES), 0, c->stream, a);
+  prof_end(c);
+  NTCHK(device_exclusive_scan(c, d_picked, d_ooff, n, d_sums, d_tot + 1));
+  hipLaunchKernelGGL(minimizer_write_kernel<false>, dim3(grid), dim3(256), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_tot + 1, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t total = 0;
+  memcpy(&total, c->h_small + 8, 8);
+  HIPCHK(hipMemcpyAsync(d_min_offsets + n, &total, sizeof total, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (total_out) *total_out = total;
+  if (total > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu minimizers < %llu needed", (unsigned long long)capacity,
+                (unsigned long long)total);
+  return NTHIP_OK;
+}
+
+} // namespace
+
 extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint32_t w, uint64_t* d_min_hashes,
                                      uint32_t* d_min_pos, uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out,
                                      uint32_t flags)
@@ -17,10 +132,10 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
   if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
   if (k < 3) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 is undefined in the reference (src/kmer.cpp:47)");
   if (w == 0) return fail(NTHIP_ERR_ARG, "w must be greater than 0");
-  if (rd->offsets) return fail(NTHIP_ERR_UNSUPPORTED, "the consumers take fixed-length reads (offsets == NULL)");
   if (!d_min_offsets || (capacity && !d_min_hashes)) return fail(NTHIP_ERR_ARG, "min_offsets / min_hashes is NULL");
   HIPCHK(hipSetDevice(c->device));
   if (total_out) *total_out = 0;
+  if (rd->offsets) return minimizers_of_offsets(c, rd, k16, w, d_min_hashes, d_min_pos, d_min_offsets, capacity, total_out, flags);
   const uint64_t n = rd->n_reads;
   const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
   if (n == 0 || len < k) {

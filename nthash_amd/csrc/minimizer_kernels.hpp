@@ -30,8 +30,10 @@ struct MinimizerArgs {
   const uint32_t* pos;    // their window positions inside the read; NULL: every read emits every window (position = index)
   const uint64_t* roff;   // [n_reads]: first k-mer of read r in the stream (exclusive scan of the counts); NULL with pos == NULL
   uint64_t n_reads, n_kmers;
-  uint32_t nwin;          // window positions of a read (fixed-length reads: len - k + 1)
+  uint32_t nwin;          // window positions of a read (fixed-length reads: len - k + 1; with offsets: of the longest read)
   uint32_t w;
+  const uint64_t* offsets; // reads of any lengths (read r = [offsets[r], offsets[r + 1])): the window positions come from here; else NULL
+  uint32_t k, pad1;
   uint64_t* masks;        // [n_reads * chunks] bit l of word (r, c): the k-mer at window position 64 c + l of read r is a minimizer
   uint32_t chunks;        // ceil(nwin / 64)
   uint32_t pad0;
@@ -60,11 +62,6 @@ static __global__ __launch_bounds__(64 * MZ_WAVES) void minimizer_flag_kernel(co
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  const uint32_t nwin = a.nwin;
-  const uint32_t w = a.w < nwin ? a.w : nwin; // (a read with fewer windows than w: one window)
-  const uint32_t n_starts = nwin - w + 1;
-  uint32_t J = 0;
-  while ((2u << J) <= w) ++J; // 2^J <= w < 2^(J+1)
   uint64_t* const A = lds_h[wv];
   uint16_t* const M = lds_m[wv];
   uint32_t* const K = lds_k[wv];
@@ -77,13 +74,27 @@ static __global__ __launch_bounds__(64 * MZ_WAVES) void minimizer_flag_kernel(co
   uint64_t pf0 = 0, pf1 = 0;
   auto prefetch = [&](uint64_t rr) {
     if (DENSE && rr < a.n_reads) {
-      const uint64_t b = rr * nwin;
-      pf0 = lane < nwin ? a.hashes[b + lane] : 0;
-      pf1 = lane + 64u < nwin ? a.hashes[b + 64u + lane] : 0;
+      const uint64_t b = rr * a.nwin;
+      pf0 = lane < a.nwin ? a.hashes[b + lane] : 0;
+      pf1 = lane + 64u < a.nwin ? a.hashes[b + 64u + lane] : 0;
     }
   };
   prefetch(wave);
   for (uint64_t r = wave; r < a.n_reads; r += n_waves) {
+    uint32_t nwin = a.nwin;
+    if (!DENSE && a.offsets != nullptr) { // reads of any lengths
+      const uint64_t l = a.offsets[r + 1] - a.offsets[r];
+      nwin = l >= a.k ? (l - a.k + 1u < 0xFFFFFFFFull ? (uint32_t)(l - a.k + 1u) : 0xFFFFFFFFu) : 0u;
+    }
+    if (nwin == 0u) { // (shorter than k: no k-mer, nothing picked)
+      if (lane == 0) a.picked[r] = 0;
+      continue;
+    }
+    const uint32_t w = a.w < nwin ? a.w : nwin; // (a read with fewer windows than w: one window)
+    const uint32_t n_starts = nwin - w + 1;
+    uint32_t J = 0;
+    while ((2u << J) <= w) ++J; // 2^J <= w < 2^(J+1)
+    const uint32_t chunks_r = (nwin + 63u) >> 6; // mask words of this read (<= a.chunks)
     const uint64_t i0 = DENSE ? r * nwin : a.roff[r];
     const uint64_t i1 = DENSE ? i0 + nwin : (r + 1 < a.n_reads ? a.roff[r + 1] : a.n_kmers);
     uint64_t* const mrow = a.masks + r * a.chunks;
@@ -100,7 +111,7 @@ static __global__ __launch_bounds__(64 * MZ_WAVES) void minimizer_flag_kernel(co
         if (!DENSE) A[p] = ~0ull;
         M[p] = (uint16_t)p;
       }
-      if (lane < 2u * a.chunks) K[lane] = 0; // (chunks <= MZ_LDS_POS / 64 = 16)
+      if (lane < 2u * chunks_r) K[lane] = 0; // (chunks_r <= POSN / 64 <= 16)
       if (!DENSE) {
         wave_sync();
         for (uint64_t i = i0 + lane; i < i1; i += 64u) A[a.pos[i]] = a.hashes[i];
@@ -147,7 +158,7 @@ static __global__ __launch_bounds__(64 * MZ_WAVES) void minimizer_flag_kernel(co
         }
       }
       wave_sync();
-      if (lane < a.chunks) {
+      if (lane < chunks_r) {
         const uint64_t m = (uint64_t)K[2u * lane] | ((uint64_t)K[2u * lane + 1u] << 32);
         mrow[lane] = m;
         n_picked = (uint32_t)__builtin_popcountll(m);

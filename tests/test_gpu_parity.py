@@ -1203,6 +1203,43 @@ def test_minimizers_match_brute_force_on_oracle_stream(oracle, n, L, k, w, dirty
     ctx.close()
 
 
+@pytest.mark.parametrize("n,lmax,k,w,dirty", [
+    (400, 300, 31, 10, True), (300, 180, 21, 300, False),     # w beyond every read: one minimizer per read
+    (60, 3000, 31, 19, True),                                  # reads on both sides of the 1024-window limit of the wave tables
+    (500, 90, 25, 4, False),
+])
+def test_minimizers_of_reads_given_by_offsets(oracle, ctx, n, lmax, k, w, dirty):
+    """the same brute force, reads of any lengths (offsets): empty reads, reads shorter than k, reads of exactly k bases"""
+    rng = np.random.default_rng(n + lmax + w)
+    lens = rng.integers(0, lmax + 1, n).astype(np.uint64)
+    lens[:4] = [0, k - 1, k, k + w - 1]
+    lens[4] = lmax
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total = int(offs[-1])
+    data = oracle.synth_reads(3, 1, total, 9 + k).copy()
+    if dirty:
+        bad = rng.choice(total, max(3, total // 300), replace=False)
+        data[bad] = np.frombuffer(b"NnRY-", dtype=np.uint8)[rng.integers(0, 5, bad.size)]
+    want = oracle.kmer_batch(data, offs, k, 1, want_pos=True)
+    exp_off, exp_pos, exp_h = [0], [], []
+    o = 0
+    for r in range(n):
+        c = int(want["counts"][r])
+        p, h = want["pos"][o:o + c].astype(np.int64), want["hashes"][o:o + c].ravel()
+        nwin = max(int(lens[r]) - k + 1, 0)
+        picked = _minimizers_brute(p, h, nwin, w) if nwin else []
+        look = dict(zip(p.tolist(), h.tolist()))
+        exp_pos += picked
+        exp_h += [look[q] for q in picked]
+        exp_off.append(len(exp_pos))
+        o += c
+    got = ctx.minimizers(data, k, w, 0, n, offsets=offs)
+    assert got["total"] == len(exp_pos)
+    assert (got["offsets"] == np.array(exp_off, np.uint64)).all()
+    assert (got["pos"] == np.array(exp_pos, np.uint32)).all()
+    assert (got["hashes"] == np.array(exp_h, np.uint64)).all()
+
+
 def test_minimizers_argument_errors_and_short_reads(ctx):
     import nthash_amd
     data = np.frombuffer(b"ACGT" * 50, dtype=np.uint8)
