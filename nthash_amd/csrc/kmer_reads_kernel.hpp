@@ -475,29 +475,7 @@ void kmer_reads_kernel(const KmerReadsArgs a)
         if (lane == 1u && (sp & 1u) && sp - 1u >= pf * 2u) base[sp - 1u] = tile[sp - 1u]; // tail
         (void)pieces;
       } else {
-        const uint64_t v0 = o0 * m;
-        const uint32_t vpar = (uint32_t)(v0 & 1u);
-        const uint32_t n_vals = span * m;
-        const uint32_t sp = vpar + n_vals;
-        const uint32_t pieces = (sp + 1u) >> 1;
-        uint64_t* const base = a.hashes + (v0 - vpar);
-        for (uint32_t pi = lane; pi < pieces; pi += 64u) {
-          uint64_t o[2];
-          bool ok[2];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const uint32_t sv = 2u * pi + (uint32_t)h - vpar;
-            ok[h] = sv < n_vals;
-            const uint32_t e = ok[h] ? __umulhi(sv, inv_m) : 0u, jj = ok[h] ? sv - e * m : 0u;
-            const uint64_t h0 = tile[e];
-            o[h] = jj == 0 ? h0 : mix_hash(h0, ((uint64_t)jj ^ kmul));
-          }
-          if (ok[0] && ok[1])
-            *(uint4*)(base + 2u * pi) =
-                make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
-          else if (ok[0]) *(uint2*)(base + 2u * pi) = make_uint2((uint32_t)o[0], (uint32_t)(o[0] >> 32));
-          else if (ok[1]) *(uint2*)(base + 2u * pi + 1u) = make_uint2((uint32_t)o[1], (uint32_t)(o[1] >> 32));
-        }
+        (void)multi_hash_copy_out<false>(tile, a.hashes, o0, span, m, inv_m, kmul, lane);
       }
       if (POS)
         for (uint32_t e = lane; e < span; e += 64u) a.pos[o0 + e] = ptile[e];

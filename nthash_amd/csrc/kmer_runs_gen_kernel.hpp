@@ -44,6 +44,66 @@
 
 namespace ntamd {
 
+// Several hashes per k-mer (extend_hashes, reference src/internal.hpp:104-118), fused into the copy-out of a wave's tile:
+// the tile holds h[0] of n_emit consecutive k-mers, the first of them k-mer o0 of the stream; stream value v is
+// h[v % m] of k-mer v / m.  A lane writes one aligned 16-byte piece (two values) per instruction, the wave whole lines.
+// No division in the loop: a lane's values advance by 128 per iteration -- k-mer += 128 / m, hash index += 128 % m with
+// a carry -- and the first value of the piece follows from the second (round 3: the loop before took a multiply-high and
+// a multiply per value for v / m and v % m, with the three of the 64-bit product five quarter-rate instructions a value).
+// The half pieces at either end (the tile starts / ends on an odd value) are single 8-byte stores of two lanes.  The
+// lane -> piece map starts at a LINE of the stream, not at the tile's first value: every store instruction of the wave
+// covers whole aligned 128-byte lines (the lanes before the tile's first value sit out the first one).
+// NT: streaming stores.  -> the number of store instructions every lane of the wave surely issued (counted waits).
+#ifndef MH_ALIGN_U64
+#define MH_ALIGN_U64 16 // values (a 128-byte line of the stream): lane 0's piece of every store starts a line
+#endif
+template <bool NT>
+__device__ __forceinline__ uint32_t multi_hash_copy_out(const uint64_t* __restrict__ tile, uint64_t* __restrict__ hashes, uint64_t o0,
+                                                        uint32_t n_emit, uint32_t m, uint32_t inv_m, uint64_t kmul, uint32_t lane)
+{
+  const uint64_t v0 = o0 * m;
+  const uint32_t vpar = (uint32_t)(v0 & (uint64_t)(MH_ALIGN_U64 - 1));
+  const uint32_t n_vals = n_emit * m;
+  const uint32_t span = vpar + n_vals;
+  const uint32_t p_first = (vpar + 1u) >> 1, p_end = span >> 1; // pieces [p_first, p_end) hold two values
+  uint64_t* const base = hashes + (v0 - vpar);
+  const uint32_t step_e = 128u / m, step_j = 128u - step_e * m; // (uniform: scalar unit)
+  // the piece's second value, sv1 = 2 lane + 1 - vpar = e1 m + j1 (floor division; negative in the lanes before the
+  // tile's first value, whose first iteration is idle): divide sv1 + 128 and take one step back
+  const uint32_t sv1p = 2u * lane + 129u - vpar;
+  uint32_t e1 = __umulhi(sv1p, inv_m), j1 = sv1p - e1 * m;
+  j1 += m - step_j;
+  e1 -= step_e + 1u;
+  if (j1 >= m) {
+    j1 -= m;
+    ++e1;
+  }
+  for (uint32_t pi = lane; pi < p_end; pi += 64u) {
+    const bool wrap = j1 == 0u; // the first value is the last hash of the k-mer before
+    const uint32_t j0 = wrap ? m - 1u : j1 - 1u;
+    const uint32_t e0 = wrap ? e1 - 1u : e1;
+    if (pi >= p_first) {
+      const uint64_t ha = tile[e0], hb = tile[e1];
+      const uint64_t ma = mix_hash(ha, (uint64_t)j0 ^ kmul), mb = mix_hash(hb, (uint64_t)j1 ^ kmul);
+      const uint64_t oa = j0 == 0u ? ha : ma, ob = wrap ? hb : mb;
+      const nt_v4u ov = {(uint32_t)oa, (uint32_t)(oa >> 32), (uint32_t)ob, (uint32_t)(ob >> 32)};
+      if (NT) __builtin_nontemporal_store(ov, (nt_v4u*)(base + 2u * pi));
+      else *(nt_v4u*)(base + 2u * pi) = ov;
+    }
+    j1 += step_j;
+    e1 += step_e;
+    if (j1 >= m) {
+      j1 -= m;
+      ++e1;
+    }
+  }
+  if (n_vals != 0u) {
+    if ((vpar & 1u) != 0u && lane == 0u) base[vpar] = tile[0]; // value 0 = h[0] of the first k-mer (the second half of its piece)
+    if ((span & 1u) != 0u && lane == 1u) base[span - 1u] = mix_hash(tile[n_emit - 1u], (uint64_t)(m - 1u) ^ kmul);
+  }
+  return p_end >> 6;
+}
+
 // the reads are streamed once: non-temporal loads keep them from displacing the output lines being
 // assembled in L2 (+1.9 % on the headline kernel, in-process A/B)
 #ifndef KRG_LOAD_NT
@@ -934,37 +994,11 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
       // copy-out: stream value v is h[v % m] of k-mer v / m.  (Round 3, negative: one K-MER per lane -- m - 1 multiplies,
       // no division, the values through a wave-private staging area back into stream order -- lost 15 % on 100 bp /
       // k = 64 / m = 3 and 7 % at m = 2: three dependent LDS round trips per 64 k-mers against independent iterations here.)
-      const uint64_t v0 = out0 * m;
-      const uint32_t vpar = (uint32_t)(v0 & 1u);
-      const uint32_t n_vals = n_emit * m;
-      const uint32_t span = vpar + n_vals;
-      const uint32_t pieces = (span + 1u) >> 1;
-      uint64_t* const base = a.hashes + (v0 - vpar);
-      for (uint32_t pi = lane; pi < pieces; pi += 64u) {
-        uint64_t o[2];
-        bool ok[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const uint32_t sv = 2u * pi + (uint32_t)h - vpar; // wraps for the skipped head half
-          ok[h] = sv < n_vals;
-          const uint32_t e = ok[h] ? __umulhi(sv, inv_m) : 0u, jj = ok[h] ? sv - e * m : 0u;
-          const uint64_t h0 = tile[e];
-          o[h] = jj == 0 ? h0 : mix_hash(h0, ((uint64_t)jj ^ kmul));
-        }
-        if (ok[0] && ok[1]) {
-          const uint4 ov = make_uint4((uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32));
-#if defined(KRG_ABL_NOSTORE) // ablation (WRONG results): everything but the stores of the several-hashes copy-out
-          asm volatile("" ::"v"(ov.x), "v"(ov.y), "v"(ov.z), "v"(ov.w));
-#elif defined(KRG_MH_PLAIN)
-          *(uint4*)(base + 2u * pi) = ov;
-#else     // streaming stores for the whole pieces, as in the m = 1 copy-out
-          __builtin_nontemporal_store(*(const nt_v4u*)&ov, (nt_v4u*)(base + 2u * pi));
+#if defined(KRG_MH_PLAIN)
+      n_counted = multi_hash_copy_out<false>(tile, a.hashes, out0, n_emit, m, inv_m, kmul, lane);
+#else // streaming stores for the whole pieces, as in the m = 1 copy-out
+      n_counted = multi_hash_copy_out<true>(tile, a.hashes, out0, n_emit, m, inv_m, kmul, lane);
 #endif
-        }
-        else if (ok[0]) *(uint2*)(base + 2u * pi) = make_uint2((uint32_t)o[0], (uint32_t)(o[0] >> 32));
-        else if (ok[1]) *(uint2*)(base + 2u * pi + 1u) = make_uint2((uint32_t)o[1], (uint32_t)(o[1] >> 32));
-      }
-      n_counted = pieces >> 6;
     }
     if (SINK == SINK_NONE && want_pos)
       for (uint32_t e = lane; e < n_emit; e += 64u) a.pos[out0 + e] = ptile[e];
