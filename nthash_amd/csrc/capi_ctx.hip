@@ -270,6 +270,7 @@ void load_tuning(nthip_tune& t)
   t.no_seed_align = is_one("NTHIP_TUNE_NO_SEED_ALIGN");
   t.no_any_k_runs = is_one("NTHIP_TUNE_NO_ANY_K_RUNS");
   t.no_fh = is_one("NTHIP_TUNE_NO_FH");
+  t.mz_table = is_one("NTHIP_TUNE_MZ_TABLE");
   t.reads_run_len = num("NTHIP_TUNE_READS_RUN_LEN", 2, 16);
   t.reads_per_tile = num("NTHIP_TUNE_READS_PER_TILE", 1, 64);
   t.reads_waves = num("NTHIP_TUNE_READS_WAVES", 1, 16);

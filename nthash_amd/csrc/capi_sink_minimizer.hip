@@ -199,6 +199,43 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
       NTCHK(nthip_kmer_hash(c, &part, k16, 1, &out, &n_kmers, flags & NTHIP_HOST_INPUT));
       NTCHK(device_exclusive_scan(c, d_counts, d_roff, nr, d_sums, d_tot));
     }
+    if (dense && nwin <= MZ_REG_POS && !c->tune.mz_table) {
+      // clean short reads: the table in registers, the picks compacted in place chunk by chunk, then gathered
+      const unsigned grid = (unsigned)(c->n_cu * 8);
+      const uint64_t waves = (uint64_t)grid * 4;
+      uint64_t rb = nr / (waves * 4);
+      rb = rb < 1 ? 1 : rb > 256 ? 256 : rb;
+      const uint64_t n_chunks = (nr + rb - 1) / rb;
+      MinimizerDenseArgs da;
+      memset(&da, 0, sizeof da);
+      da.hashes = d_h;
+      da.tpos = d_pos;
+      da.n_reads = nr;
+      da.nwin = nwin;
+      da.w = w;
+      da.rb = (uint32_t)rb;
+      da.lpre = d_picked;
+      da.ctot = d_counts;
+      da.coff = d_roff;
+      da.base = base;
+      da.capacity = capacity;
+      da.out_hashes = d_min_hashes;
+      da.out_pos = d_min_pos;
+      da.out_offsets = d_min_offsets + r0;
+      prof_begin(c, "minimizer_dense_kernel");
+      hipLaunchKernelGGL(minimizer_dense_kernel, dim3(grid), dim3(256), 0, c->stream, da);
+      prof_end(c);
+      NTCHK(device_exclusive_scan(c, d_counts, d_roff, n_chunks, d_sums, d_tot + 1));
+      hipLaunchKernelGGL(minimizer_gather_kernel, dim3(grid), dim3(256), 0, c->stream, da);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(c->h_small + 8, d_tot + 1, 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      uint64_t round_total = 0;
+      memcpy(&round_total, c->h_small + 8, 8);
+      if (base + round_total > capacity) overflow = true;
+      base += round_total;
+      continue;
+    }
     MinimizerArgs a;
     memset(&a, 0, sizeof a);
     a.hashes = d_h;

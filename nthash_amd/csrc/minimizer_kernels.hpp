@@ -231,4 +231,131 @@ static __global__ __launch_bounds__(256) void minimizer_write_kernel(const Minim
   }
 }
 
+
+// ---- clean fixed-length short reads (every read emits every window, at most MZ_REG_POS of them): the table in REGISTERS ----
+// The usual batch (150 bp reads without a non-base).  Position i of the read lives in lane i (and lane i - 64 of a second
+// register set); a doubling step M[i] = better(M[i], M[i + d]) is a rotation of the wave by d lanes (ds_bpermute: the LDS
+// crossbar, no LDS memory) and a compare, the window query better(M_J[s], M_J[s + w - 2^J]) one more such step.  The hash
+// travels with its position, so when the windows' picks p(s) are known -- non-decreasing in s: a new minimizer wherever
+// p(s) != p(s - 1) -- the wave has (hash, position) of every pick in registers and writes them out at once.  No masks,
+// no second pass over the stream: a wave takes CHUNKS of consecutive reads and compacts each chunk's picks IN PLACE to the
+// front of the chunk's own piece of the stream (a read's picks never pass the end of the read; the next read's hashes are
+// in registers before this read's picks are stored), a scan over the chunks' totals, and minimizer_gather_kernel moves the
+// compacted runs to their place in the output -- 17 % of the stream (w = 10) instead of all of it a second time.
+// (LDS-table version above, 20 M x 150 bp: flag pass 13.5 ms -- its LDS pipe saturated, ~60 LDS operations a read -- and
+//  8.5 ms for the write pass that reads the whole stream again.)
+constexpr uint32_t MZ_REG_POS = 128;
+struct MinimizerDenseArgs {
+  uint64_t* hashes;    // in: the stream, nwin hashes per read; out, in place: the picks of chunk c from k-mer c * rb * nwin on
+  uint32_t* tpos;      // the picks' window positions, same indexing
+  uint64_t n_reads;
+  uint32_t nwin, w, rb, pad0; // rb: reads per chunk (rb * nwin < 2^31)
+  uint64_t* lpre;      // [n_reads] picks of the chunk's reads before read r
+  uint64_t* ctot;      // [n_chunks] picks of the chunk
+  // gather
+  const uint64_t* coff; // exclusive scan of ctot
+  uint64_t base, capacity;
+  uint64_t* out_hashes;
+  uint32_t* out_pos;     // may be NULL
+  uint64_t* out_offsets; // [n_reads]
+};
+
+static __global__ __launch_bounds__(256) void minimizer_dense_kernel(const MinimizerDenseArgs a)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  const uint32_t nwin = a.nwin;
+  const uint32_t w = a.w < nwin ? a.w : nwin; // (a read with fewer windows than w: one window)
+  const uint32_t n_starts = nwin - w + 1u;
+  uint32_t J = 0;
+  while ((2u << J) <= w) ++J; // 2^J <= w < 2^(J+1)
+  const uint32_t q = w - (1u << J);
+  const uint64_t n_chunks = (a.n_reads + a.rb - 1u) / a.rb;
+  const bool in0 = lane < nwin, in1 = lane + 64u < nwin;
+  const bool v0 = lane < n_starts, v1 = lane + 64u < n_starts;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const int idx_prev = (int)(((lane + 63u) & 63u) << 2);
+  for (uint64_t c = wave; c < n_chunks; c += n_waves) {
+    const uint64_t r0 = c * a.rb;
+    const uint64_t r1 = r0 + a.rb < a.n_reads ? r0 + a.rb : a.n_reads;
+    const uint64_t k0 = r0 * nwin;
+    uint32_t cursor = 0;
+    uint64_t pf0 = in0 ? a.hashes[k0 + lane] : ~0ull;
+    uint64_t pf1 = in1 ? a.hashes[k0 + 64u + lane] : ~0ull;
+    for (uint64_t r = r0; r < r1; ++r) {
+      uint32_t h0l = (uint32_t)pf0, h0h = (uint32_t)(pf0 >> 32), h1l = (uint32_t)pf1, h1h = (uint32_t)(pf1 >> 32);
+      uint32_t p0 = lane, p1 = lane + 64u;
+      if (r + 1u < r1) {
+        const uint64_t b = (r + 1u) * nwin;
+        pf0 = in0 ? a.hashes[b + lane] : ~0ull;
+        pf1 = in1 ? a.hashes[b + 64u + lane] : ~0ull;
+      }
+      // M[i] = better(M[i], M[i + d]): the left one wins a tie.  (Positions past the read hold anything: no window of the
+      // read looks at a range that reaches them.)
+      auto step = [&](const uint32_t d) {
+        const int idx = (int)(((lane + d) & 63u) << 2);
+        const bool low = lane + d < 64u; // position lane + d is in set 0
+        const uint32_t a0l = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h0l), a0h = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h0h);
+        const uint32_t a0p = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)p0);
+        const uint32_t a1l = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h1l), a1h = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h1h);
+        const uint32_t a1p = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)p1);
+        const uint32_t n0l = low ? a0l : a1l, n0h = low ? a0h : a1h, n0p = low ? a0p : a1p;
+        const bool t0 = (((uint64_t)n0h << 32) | n0l) < (((uint64_t)h0h << 32) | h0l);
+        const bool t1 = (((uint64_t)a1h << 32) | a1l) < (((uint64_t)h1h << 32) | h1l);
+        h0l = t0 ? n0l : h0l; h0h = t0 ? n0h : h0h; p0 = t0 ? n0p : p0;
+        h1l = t1 ? a1l : h1l; h1h = t1 ? a1h : h1h; p1 = t1 ? a1p : p1;
+      };
+      for (uint32_t j = 0; j < J; ++j) step(1u << j);
+      if (q != 0u) step(q);
+      // p(s) is non-decreasing: a new minimizer wherever it moves
+      const uint32_t pr0 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx_prev, (int)p0);
+      uint32_t pr1 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx_prev, (int)p1);
+      const uint32_t last0 = (uint32_t)__builtin_amdgcn_readlane((int)p0, 63);
+      pr1 = lane == 0u ? last0 : pr1;
+      const bool new0 = v0 && (lane == 0u || p0 != pr0);
+      const bool new1 = v1 && p1 != pr1;
+      const uint64_t b0 = __ballot(new0), b1 = __ballot(new1);
+      const uint32_t c0 = (uint32_t)__builtin_popcountll(b0), c1 = (uint32_t)__builtin_popcountll(b1);
+      if (new0) {
+        const uint64_t at = k0 + cursor + (uint32_t)__builtin_popcountll(b0 & lt_mask);
+        a.hashes[at] = ((uint64_t)h0h << 32) | h0l;
+        a.tpos[at] = p0;
+      }
+      if (new1) {
+        const uint64_t at = k0 + cursor + c0 + (uint32_t)__builtin_popcountll(b1 & lt_mask);
+        a.hashes[at] = ((uint64_t)h1h << 32) | h1l;
+        a.tpos[at] = p1;
+      }
+      if (lane == 0u) a.lpre[r] = cursor;
+      cursor += c0 + c1;
+    }
+    if (lane == 0u) a.ctot[c] = cursor;
+  }
+}
+
+// the chunks' compacted picks to [base + coff[c], ...) of the output; every read's offset
+static __global__ __launch_bounds__(256) void minimizer_gather_kernel(const MinimizerDenseArgs a)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  const uint64_t n_chunks = (a.n_reads + a.rb - 1u) / a.rb;
+  for (uint64_t c = wave; c < n_chunks; c += n_waves) {
+    const uint64_t r0 = c * a.rb;
+    const uint64_t r1 = r0 + a.rb < a.n_reads ? r0 + a.rb : a.n_reads;
+    const uint64_t k0 = r0 * a.nwin;
+    const uint64_t o0 = a.base + a.coff[c];
+    const uint32_t n = (uint32_t)a.ctot[c];
+    for (uint32_t i = lane; i < n; i += 64u) {
+      const uint64_t at = o0 + i;
+      if (at < a.capacity) {
+        a.out_hashes[at] = a.hashes[k0 + i];
+        if (a.out_pos) a.out_pos[at] = a.tpos[k0 + i];
+      }
+    }
+    for (uint64_t r = r0 + lane; r < r1; r += 64u) a.out_offsets[r] = o0 + a.lpre[r];
+  }
+}
+
 } // namespace ntamd

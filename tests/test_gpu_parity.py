@@ -1203,6 +1203,67 @@ def test_minimizers_match_brute_force_on_oracle_stream(oracle, n, L, k, w, dirty
     ctx.close()
 
 
+@pytest.mark.parametrize("n,L,k,w", [
+    (700, 150, 31, 10), (700, 150, 31, 1), (300, 150, 31, 5), (300, 150, 31, 19), (300, 150, 31, 64), (200, 150, 31, 120),
+    (200, 150, 31, 119), (200, 150, 31, 500), (300, 158, 31, 33),   # 128 windows: the two register sets full
+    (300, 94, 31, 16), (300, 95, 31, 17), (300, 93, 31, 63),        # 64 / 65 / 63 windows
+    (500, 31, 31, 4), (400, 32, 31, 2), (300, 100, 64, 37), (300, 250, 160, 12),
+    (70000, 36, 21, 7),                                             # chunks of several reads per wave
+])
+@pytest.mark.parametrize("table", [False, True])
+def test_minimizers_of_clean_short_reads(oracle, n, L, k, w, table):
+    """clean fixed-length reads of at most 128 windows take the register tables (minimizer_dense_kernel: chunks compacted
+    in place + gather); NTHIP_TUNE_MZ_TABLE=1 sends the same batch through the LDS tables: both against the brute force.
+    Reads of one repeated base / period 2 (ties: the leftmost), a too small capacity, several rounds"""
+    import os
+    import nthash_amd
+    if table:
+        os.environ["NTHIP_TUNE_MZ_TABLE"] = "1"
+    if n == 700:
+        os.environ["NTHIP_TUNE_BLOOM_ROUND"] = "30000"   # rounds of 250 reads
+    try:
+        ctx = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_MZ_TABLE", None)
+        os.environ.pop("NTHIP_TUNE_BLOOM_ROUND", None)
+    data = oracle.synth_reads(11, n, L, 3 + k + w).copy()
+    data[2 * L: 3 * L] = ord("A")
+    data[3 * L: 4 * L] = np.frombuffer(b"AC" * L, dtype=np.uint8)[:L]
+    data[5 * L: 6 * L] = np.frombuffer(b"ACG" * L, dtype=np.uint8)[:L]
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, 1, want_pos=False)
+    nwin = L - k + 1
+    hs = want["hashes"].ravel().reshape(n, nwin)
+    weff = min(w, nwin)
+    if n > 5000:    # vectorised brute force: window s picks the first argmin of hs[:, s:s+w]
+        from numpy.lib.stride_tricks import sliding_window_view
+        arg = sliding_window_view(hs, weff, axis=1).argmin(axis=2) + np.arange(nwin - weff + 1)[None, :]
+        pick = np.zeros((n, nwin), dtype=bool)
+        np.put_along_axis(pick, arg, True, axis=1)
+        exp_off = np.concatenate([[0], np.cumsum(pick.sum(axis=1))]).astype(np.uint64)
+        rr, pp = np.nonzero(pick)
+        exp_pos, exp_h = pp.astype(np.uint32), hs[rr, pp]
+    else:
+        eo, ep, eh = [0], [], []
+        pos = np.arange(nwin, dtype=np.int64)
+        for r in range(n):
+            picked = _minimizers_brute(pos, hs[r], nwin, w)
+            ep += picked
+            eh += [hs[r][q] for q in picked]
+            eo.append(len(ep))
+        exp_off, exp_pos, exp_h = np.array(eo, np.uint64), np.array(ep, np.uint32), np.array(eh, np.uint64)
+    got = ctx.minimizers(data, k, w, L, n)
+    assert got["total"] == len(exp_pos)
+    assert (got["offsets"] == exp_off).all()
+    assert (got["pos"] == exp_pos).all()
+    assert (got["hashes"] == exp_h).all()
+    if got["total"] > 1 and n <= 700:
+        with pytest.raises(nthash_amd.NtHipError) as ei:
+            ctx.minimizers(data, k, w, L, n, capacity=got["total"] - 1)
+        assert ei.value.code == nthash_amd.capi.NTHIP_ERR_CAPACITY and ei.value.total == got["total"]
+    ctx.close()
+
+
 @pytest.mark.parametrize("n,lmax,k,w,dirty", [
     (400, 300, 31, 10, True), (300, 180, 21, 300, False),     # w beyond every read: one minimizer per read
     (60, 3000, 31, 19, True),                                  # reads on both sides of the 1024-window limit of the wave tables
