@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 namespace ntamd {
 
@@ -260,11 +261,29 @@ struct MinimizerDenseArgs {
   uint64_t* out_offsets; // [n_reads]
 };
 
+#ifndef MZ_DPP_ROT
+#define MZ_DPP_ROT 1
+#endif
+constexpr uint32_t MZ_BUF = 256; // picks a wave collects in LDS before it writes them out (>= 2 x 128: a read always fits)
 static __global__ __launch_bounds__(256) void minimizer_dense_kernel(const MinimizerDenseArgs a)
 {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  // per wave: the picks of the last few reads (hash, position) and those reads' offsets -- written out together, whole
+  // 512-byte pieces at a time, and -- the point -- not after every read: the wave's memory counter is in order and counts
+  // stores as well, a read's loads could only be waited for together with the stores of the read before
+  __shared__ uint64_t lds_h[4][MZ_BUF];
+  __shared__ uint32_t lds_l[4][64];
+  __shared__ uint8_t lds_p[4][MZ_BUF];
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  uint64_t* const hb = lds_h[wv];
+  uint32_t* const lb = lds_l[wv];
+  uint8_t* const pb = lds_p[wv];
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
   const uint32_t nwin = a.nwin;
   const uint32_t w = a.w < nwin ? a.w : nwin; // (a read with fewer windows than w: one window)
   const uint32_t n_starts = nwin - w + 1u;
@@ -272,65 +291,115 @@ static __global__ __launch_bounds__(256) void minimizer_dense_kernel(const Minim
   while ((2u << J) <= w) ++J; // 2^J <= w < 2^(J+1)
   const uint32_t q = w - (1u << J);
   const uint64_t n_chunks = (a.n_reads + a.rb - 1u) / a.rb;
-  const bool in0 = lane < nwin, in1 = lane + 64u < nwin;
   const bool v0 = lane < n_starts, v1 = lane + 64u < n_starts;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  const int idx_prev = (int)(((lane + 63u) & 63u) << 2);
   for (uint64_t c = wave; c < n_chunks; c += n_waves) {
     const uint64_t r0 = c * a.rb;
-    const uint64_t r1 = r0 + a.rb < a.n_reads ? r0 + a.rb : a.n_reads;
-    const uint64_t k0 = r0 * nwin;
-    uint32_t cursor = 0;
-    uint64_t pf0 = in0 ? a.hashes[k0 + lane] : ~0ull;
-    uint64_t pf1 = in1 ? a.hashes[k0 + 64u + lane] : ~0ull;
-    for (uint64_t r = r0; r < r1; ++r) {
+    const uint32_t nr = (uint32_t)(r0 + a.rb < a.n_reads ? a.rb : a.n_reads - r0);
+    uint64_t* const hc = a.hashes + r0 * nwin; // the chunk's piece of the stream; its picks, compacted, from the front
+    uint32_t* const pc = a.tpos + r0 * nwin;
+    uint64_t* const lc = a.lpre + r0;
+    uint32_t done = 0;  // picks of the chunk already written out
+    uint32_t nbuf = 0;  // picks in the buffer
+    uint32_t rbuf = 0;  // reads in the buffer, the first of them read rfirst of the chunk
+    uint32_t rfirst = 0;
+    auto flush = [&]() {
+      wave_sync();
+      for (uint32_t i = lane; i < nbuf; i += 64u) {
+        hc[done + i] = hb[i];
+        pc[done + i] = pb[i];
+      }
+      if (lane < rbuf) lc[rfirst + lane] = lb[lane];
+      done += nbuf;
+      rfirst += rbuf;
+      nbuf = 0;
+      rbuf = 0;
+      wave_sync();
+    };
+    // the hashes of reads r + 1 and r + 2 are in flight while read r is worked on (one read ahead: 960 bytes a wave in
+    // flight, 3.2 TB/s); unconditional loads -- a lane past the read's last window loads that window again, past the
+    // chunk's last read that read again -- so that the waits can be counted
+    const uint32_t l0 = lane < nwin ? lane : nwin - 1u, l1 = lane + 64u < nwin ? lane + 64u : nwin - 1u;
+    uint64_t pf0 = hc[l0], pf1 = hc[l1];
+    const uint32_t bn = (nr > 1u ? 1u : 0u) * nwin;
+    uint64_t pg0 = hc[bn + l0], pg1 = hc[bn + l1];
+    for (uint32_t r = 0; r < nr; ++r) {
       uint32_t h0l = (uint32_t)pf0, h0h = (uint32_t)(pf0 >> 32), h1l = (uint32_t)pf1, h1h = (uint32_t)(pf1 >> 32);
       uint32_t p0 = lane, p1 = lane + 64u;
-      if (r + 1u < r1) {
-        const uint64_t b = (r + 1u) * nwin;
-        pf0 = in0 ? a.hashes[b + lane] : ~0ull;
-        pf1 = in1 ? a.hashes[b + 64u + lane] : ~0ull;
+      pf0 = pg0;
+      pf1 = pg1;
+      {
+        const uint32_t b = (r + 2u < nr ? r + 2u : nr - 1u) * nwin;
+        pg0 = hc[b + l0];
+        pg1 = hc[b + l1];
       }
+      // (the buffered picks belong to reads before r: their place in the stream is below read r's hashes)
+      if (nbuf + n_starts > MZ_BUF || rbuf == 64u) flush();
       // M[i] = better(M[i], M[i + d]): the left one wins a tie.  (Positions past the read hold anything: no window of the
       // read looks at a range that reaches them.)
-      auto step = [&](const uint32_t d) {
-        const int idx = (int)(((lane + d) & 63u) << 2);
+      // The rotation by d lanes: ds_bpermute (the LDS crossbar: six of them a step are what this kernel waits for) -- or,
+      // for d = 1 and 2, the whole-wave rotate of the DPP network (wave_rol:1, lane i reads lane i + 1 mod 64: VALU moves).
+      auto better = [&](const uint32_t d, const uint32_t a0l, const uint32_t a0h, const uint32_t a0p, const uint32_t a1l,
+                        const uint32_t a1h, const uint32_t a1p) {
         const bool low = lane + d < 64u; // position lane + d is in set 0
-        const uint32_t a0l = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h0l), a0h = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h0h);
-        const uint32_t a0p = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)p0);
-        const uint32_t a1l = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h1l), a1h = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h1h);
-        const uint32_t a1p = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)p1);
         const uint32_t n0l = low ? a0l : a1l, n0h = low ? a0h : a1h, n0p = low ? a0p : a1p;
         const bool t0 = (((uint64_t)n0h << 32) | n0l) < (((uint64_t)h0h << 32) | h0l);
         const bool t1 = (((uint64_t)a1h << 32) | a1l) < (((uint64_t)h1h << 32) | h1l);
         h0l = t0 ? n0l : h0l; h0h = t0 ? n0h : h0h; p0 = t0 ? n0p : p0;
         h1l = t1 ? a1l : h1l; h1h = t1 ? a1h : h1h; p1 = t1 ? a1p : p1;
       };
-      for (uint32_t j = 0; j < J; ++j) step(1u << j);
-      if (q != 0u) step(q);
+      auto step = [&](const uint32_t d) {
+        const int idx = (int)(((lane + d) & 63u) << 2);
+        const uint32_t a0l = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h0l), a0h = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h0h);
+        const uint32_t a0p = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)p0);
+        const uint32_t a1l = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h1l), a1h = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h1h);
+        const uint32_t a1p = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)p1);
+        better(d, a0l, a0h, a0p, a1l, a1h, a1p);
+      };
+      auto rol1 = [](const uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x134, 0xf, 0xf, false); };
+      auto step_rol = [&](auto d_tag) {
+        constexpr uint32_t D = decltype(d_tag)::value; // 1 or 2
+        uint32_t a0l = rol1(h0l), a0h = rol1(h0h), a0p = rol1(p0), a1l = rol1(h1l), a1h = rol1(h1h), a1p = rol1(p1);
+        if constexpr (D == 2u) {
+          a0l = rol1(a0l); a0h = rol1(a0h); a0p = rol1(a0p); a1l = rol1(a1l); a1h = rol1(a1h); a1p = rol1(a1p);
+        }
+        better(D, a0l, a0h, a0p, a1l, a1h, a1p);
+      };
+      auto step_any = [&](const uint32_t d) {
+#if MZ_DPP_ROT
+        if (d == 1u) step_rol(std::integral_constant<uint32_t, 1u>{});
+        else if (d == 2u) step_rol(std::integral_constant<uint32_t, 2u>{});
+        else
+#endif
+          step(d);
+      };
+      for (uint32_t j = 0; j < J; ++j) step_any(1u << j);
+      if (q != 0u) step_any(q);
       // p(s) is non-decreasing: a new minimizer wherever it moves
-      const uint32_t pr0 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx_prev, (int)p0);
-      uint32_t pr1 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx_prev, (int)p1);
-      const uint32_t last0 = (uint32_t)__builtin_amdgcn_readlane((int)p0, 63);
-      pr1 = lane == 0u ? last0 : pr1;
+      // (wave_ror:1: lane i reads lane i - 1 mod 64 -- lane 0 of the second set wants lane 63 of the first)
+      const uint32_t pr0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p0, 0x13C, 0xf, 0xf, false);
+      uint32_t pr1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p1, 0x13C, 0xf, 0xf, false);
+      pr1 = lane == 0u ? pr0 : pr1;
       const bool new0 = v0 && (lane == 0u || p0 != pr0);
       const bool new1 = v1 && p1 != pr1;
       const uint64_t b0 = __ballot(new0), b1 = __ballot(new1);
       const uint32_t c0 = (uint32_t)__builtin_popcountll(b0), c1 = (uint32_t)__builtin_popcountll(b1);
       if (new0) {
-        const uint64_t at = k0 + cursor + (uint32_t)__builtin_popcountll(b0 & lt_mask);
-        a.hashes[at] = ((uint64_t)h0h << 32) | h0l;
-        a.tpos[at] = p0;
+        const uint32_t at = nbuf + (uint32_t)__builtin_popcountll(b0 & lt_mask);
+        hb[at] = ((uint64_t)h0h << 32) | h0l;
+        pb[at] = (uint8_t)p0;
       }
       if (new1) {
-        const uint64_t at = k0 + cursor + c0 + (uint32_t)__builtin_popcountll(b1 & lt_mask);
-        a.hashes[at] = ((uint64_t)h1h << 32) | h1l;
-        a.tpos[at] = p1;
+        const uint32_t at = nbuf + c0 + (uint32_t)__builtin_popcountll(b1 & lt_mask);
+        hb[at] = ((uint64_t)h1h << 32) | h1l;
+        pb[at] = (uint8_t)p1;
       }
-      if (lane == 0u) a.lpre[r] = cursor;
-      cursor += c0 + c1;
+      if (lane == 0u) lb[rbuf] = done + nbuf;
+      nbuf += c0 + c1;
+      ++rbuf;
     }
-    if (lane == 0u) a.ctot[c] = cursor;
+    flush();
+    if (lane == 0u) a.ctot[c] = done;
   }
 }
 
