@@ -9,6 +9,51 @@ using namespace ntamd::host;
 
 namespace {
 
+// one round of reads of at most MZ_REG_POS windows through minimizer_reg_kernel + minimizer_gather_kernel
+// d_roff == NULL: every read emits every one of its nwin windows (positions = indices); d_lpre / d_ctot / d_coff: n_reads u64 each
+int minimizers_reg_round(nthip_ctx* c, uint64_t* d_h, uint32_t* d_pos, const uint64_t* d_roff, uint64_t n_kmers, const uint64_t* d_offsets,
+                         uint32_t k, uint64_t nr, uint32_t nwin, uint32_t w, uint64_t* d_lpre, uint64_t* d_ctot, uint64_t* d_coff,
+                         uint64_t* d_sums, uint64_t* d_tot, uint64_t base, uint64_t capacity, uint64_t* d_min_hashes,
+                         uint32_t* d_min_pos, uint64_t* d_min_offsets, uint64_t* round_total)
+{
+  const unsigned grid = (unsigned)(c->n_cu * 8);
+  const uint64_t waves = (uint64_t)grid * 4;
+  uint64_t rb = nr / (waves * 4);
+  rb = rb < 1 ? 1 : rb > 256 ? 256 : rb;
+  const uint64_t n_chunks = (nr + rb - 1) / rb;
+  MinimizerDenseArgs da;
+  memset(&da, 0, sizeof da);
+  da.hashes = d_h;
+  da.tpos = d_pos;
+  da.n_reads = nr;
+  da.nwin = nwin;
+  da.w = w;
+  da.rb = (uint32_t)rb;
+  da.roff = d_roff;
+  da.n_kmers = n_kmers;
+  da.offsets = d_offsets;
+  da.k = k;
+  da.lpre = d_lpre;
+  da.ctot = d_ctot;
+  da.coff = d_coff;
+  da.base = base;
+  da.capacity = capacity;
+  da.out_hashes = d_min_hashes;
+  da.out_pos = d_min_pos;
+  da.out_offsets = d_min_offsets;
+  prof_begin(c, "minimizer_reg_kernel");
+  if (d_roff) hipLaunchKernelGGL(minimizer_reg_kernel<true>, dim3(grid), dim3(256), 0, c->stream, da);
+  else hipLaunchKernelGGL(minimizer_reg_kernel<false>, dim3(grid), dim3(256), 0, c->stream, da);
+  prof_end(c);
+  NTCHK(device_exclusive_scan(c, d_ctot, d_coff, n_chunks, d_sums, d_tot));
+  hipLaunchKernelGGL(minimizer_gather_kernel, dim3(grid), dim3(256), 0, c->stream, da);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_tot, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(round_total, c->h_small + 8, 8);
+  return NTHIP_OK;
+}
+
 // reads of any lengths (offsets): ONE round -- the emitted stream of the whole batch (at most one k-mer per base) in the
 // context's scratch; the kernels take every read's window count from its length
 int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint32_t w, uint64_t* d_min_hashes, uint32_t* d_min_pos,
@@ -78,6 +123,18 @@ int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uin
   uint64_t n_kmers = 0;
   NTCHK(nthip_kmer_hash(c, &dr, k16, 1, &out, &n_kmers, 0));
   NTCHK(device_exclusive_scan(c, d_counts, d_roff, n, d_sums, d_tot));
+  if (max_nwin <= MZ_REG_POS && !c->tune.mz_table) { // short reads (a FASTQ batch): the tables in registers
+    uint64_t total = 0;
+    NTCHK(minimizers_reg_round(c, d_h, d_pos, d_roff, n_kmers, st.offsets, k, n, max_nwin, w, d_picked, d_counts, d_ooff, d_sums,
+                               d_tot + 1, 0, capacity, d_min_hashes, d_min_pos, d_min_offsets, &total));
+    HIPCHK(hipMemcpyAsync(d_min_offsets + n, &total, sizeof total, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (total_out) *total_out = total;
+    if (total > capacity)
+      return fail(NTHIP_ERR_CAPACITY, "output capacity %llu minimizers < %llu needed", (unsigned long long)capacity,
+                  (unsigned long long)total);
+    return NTHIP_OK;
+  }
   MinimizerArgs a;
   memset(&a, 0, sizeof a);
   a.hashes = d_h;
@@ -199,39 +256,11 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
       NTCHK(nthip_kmer_hash(c, &part, k16, 1, &out, &n_kmers, flags & NTHIP_HOST_INPUT));
       NTCHK(device_exclusive_scan(c, d_counts, d_roff, nr, d_sums, d_tot));
     }
-    if (dense && nwin <= MZ_REG_POS && !c->tune.mz_table) {
-      // clean short reads: the table in registers, the picks compacted in place chunk by chunk, then gathered
-      const unsigned grid = (unsigned)(c->n_cu * 8);
-      const uint64_t waves = (uint64_t)grid * 4;
-      uint64_t rb = nr / (waves * 4);
-      rb = rb < 1 ? 1 : rb > 256 ? 256 : rb;
-      const uint64_t n_chunks = (nr + rb - 1) / rb;
-      MinimizerDenseArgs da;
-      memset(&da, 0, sizeof da);
-      da.hashes = d_h;
-      da.tpos = d_pos;
-      da.n_reads = nr;
-      da.nwin = nwin;
-      da.w = w;
-      da.rb = (uint32_t)rb;
-      da.lpre = d_picked;
-      da.ctot = d_counts;
-      da.coff = d_roff;
-      da.base = base;
-      da.capacity = capacity;
-      da.out_hashes = d_min_hashes;
-      da.out_pos = d_min_pos;
-      da.out_offsets = d_min_offsets + r0;
-      prof_begin(c, "minimizer_dense_kernel");
-      hipLaunchKernelGGL(minimizer_dense_kernel, dim3(grid), dim3(256), 0, c->stream, da);
-      prof_end(c);
-      NTCHK(device_exclusive_scan(c, d_counts, d_roff, n_chunks, d_sums, d_tot + 1));
-      hipLaunchKernelGGL(minimizer_gather_kernel, dim3(grid), dim3(256), 0, c->stream, da);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(c->h_small + 8, d_tot + 1, 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
+    if (nwin <= MZ_REG_POS && !c->tune.mz_table) {
+      // short reads: the table in registers, the picks compacted in place chunk by chunk, then gathered
       uint64_t round_total = 0;
-      memcpy(&round_total, c->h_small + 8, 8);
+      NTCHK(minimizers_reg_round(c, d_h, d_pos, dense ? nullptr : d_roff, n_kmers, nullptr, k, nr, nwin, w, d_picked, d_counts, d_ooff,
+                                 d_sums, d_tot + 1, base, capacity, d_min_hashes, d_min_pos, d_min_offsets + r0, &round_total));
       if (base + round_total > capacity) overflow = true;
       base += round_total;
       continue;

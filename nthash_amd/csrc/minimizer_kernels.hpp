@@ -247,10 +247,15 @@ static __global__ __launch_bounds__(256) void minimizer_write_kernel(const Minim
 //  8.5 ms for the write pass that reads the whole stream again.)
 constexpr uint32_t MZ_REG_POS = 128;
 struct MinimizerDenseArgs {
-  uint64_t* hashes;    // in: the stream, nwin hashes per read; out, in place: the picks of chunk c from k-mer c * rb * nwin on
-  uint32_t* tpos;      // the picks' window positions, same indexing
+  uint64_t* hashes;    // in: the stream; out, in place: the picks of chunk c from the chunk's first k-mer on
+  uint32_t* tpos;      // the picks' window positions, same indexing (SPARSE: in as well -- the k-mers' positions)
   uint64_t n_reads;
-  uint32_t nwin, w, rb, pad0; // rb: reads per chunk (rb * nwin < 2^31)
+  uint32_t nwin, w, rb, pad0; // nwin: of a fixed-length read (with offsets: unused); rb: reads per chunk (rb * 128 < 2^31)
+  // SPARSE -- reads with non-bases and / or reads given by offsets: the emitted k-mers of read r are roff[r] ... roff[r + 1]
+  const uint64_t* roff;    // [n_reads] (exclusive scan of the reads' counts)
+  uint64_t n_kmers;
+  const uint64_t* offsets; // reads of any lengths: read r = [offsets[r], offsets[r + 1]); NULL: fixed-length reads
+  uint32_t k, pad1;
   uint64_t* lpre;      // [n_reads] picks of the chunk's reads before read r
   uint64_t* ctot;      // [n_chunks] picks of the chunk
   // gather
@@ -265,18 +270,23 @@ struct MinimizerDenseArgs {
 #define MZ_DPP_ROT 1
 #endif
 constexpr uint32_t MZ_BUF = 256; // picks a wave collects in LDS before it writes them out (>= 2 x 128: a read always fits)
-static __global__ __launch_bounds__(256) void minimizer_dense_kernel(const MinimizerDenseArgs a)
+// SPARSE (reads with a non-base somewhere, reads of any lengths -- at most MZ_REG_POS windows each): the read's k-mers
+// are laid out by position through 1 KiB of the wave's LDS first (a k-mer that is not there: the largest value; a window
+// without a k-mer picks nothing), the window count may differ from read to read; everything after that is the same.
+template <bool SPARSE>
+static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const MinimizerDenseArgs a)
 {
   // per wave: the picks of the last few reads (hash, position) and those reads' offsets -- written out together, whole
-  // 512-byte pieces at a time, and -- the point -- not after every read: the wave's memory counter is in order and counts
-  // stores as well, a read's loads could only be waited for together with the stores of the read before
+  // 512-byte pieces at a time, not after every read
   __shared__ uint64_t lds_h[4][MZ_BUF];
+  __shared__ uint64_t lds_a[SPARSE ? 4 : 1][SPARSE ? MZ_REG_POS : 1];
   __shared__ uint32_t lds_l[4][64];
   __shared__ uint8_t lds_p[4][MZ_BUF];
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
   uint64_t* const hb = lds_h[wv];
+  uint64_t* const A = lds_a[SPARSE ? wv : 0];
   uint32_t* const lb = lds_l[wv];
   uint8_t* const pb = lds_p[wv];
   auto wave_sync = [&]() {
@@ -284,20 +294,22 @@ static __global__ __launch_bounds__(256) void minimizer_dense_kernel(const Minim
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   };
-  const uint32_t nwin = a.nwin;
-  const uint32_t w = a.w < nwin ? a.w : nwin; // (a read with fewer windows than w: one window)
-  const uint32_t n_starts = nwin - w + 1u;
+  // fixed-length reads: one geometry for all
+  uint32_t nwin = a.nwin;
+  uint32_t w = a.w < nwin ? a.w : nwin; // (a read with fewer windows than w: one window)
+  uint32_t n_starts = nwin - w + 1u;
   uint32_t J = 0;
   while ((2u << J) <= w) ++J; // 2^J <= w < 2^(J+1)
-  const uint32_t q = w - (1u << J);
+  uint32_t q = w - (1u << J);
   const uint64_t n_chunks = (a.n_reads + a.rb - 1u) / a.rb;
-  const bool v0 = lane < n_starts, v1 = lane + 64u < n_starts;
+  bool v0 = lane < n_starts, v1 = lane + 64u < n_starts;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   for (uint64_t c = wave; c < n_chunks; c += n_waves) {
     const uint64_t r0 = c * a.rb;
     const uint32_t nr = (uint32_t)(r0 + a.rb < a.n_reads ? a.rb : a.n_reads - r0);
-    uint64_t* const hc = a.hashes + r0 * nwin; // the chunk's piece of the stream; its picks, compacted, from the front
-    uint32_t* const pc = a.tpos + r0 * nwin;
+    const uint64_t kb = SPARSE ? a.roff[r0] : r0 * nwin; // the chunk's first k-mer
+    uint64_t* const hc = a.hashes + kb; // the chunk's piece of the stream; its picks, compacted, from the front
+    uint32_t* const pc = a.tpos + kb;
     uint64_t* const lc = a.lpre + r0;
     uint32_t done = 0;  // picks of the chunk already written out
     uint32_t nbuf = 0;  // picks in the buffer
@@ -316,19 +328,77 @@ static __global__ __launch_bounds__(256) void minimizer_dense_kernel(const Minim
       rbuf = 0;
       wave_sync();
     };
-    // the hashes of reads r + 1 and r + 2 are in flight while read r is worked on (one read ahead: 960 bytes a wave in
-    // flight, 3.2 TB/s); unconditional loads -- a lane past the read's last window loads that window again, past the
-    // chunk's last read that read again -- so that the waits can be counted
+    // dense: the hashes of reads r + 1 and r + 2 are in flight while read r is worked on (one read ahead: 960 bytes a
+    // wave in flight, 3.2 TB/s); unconditional loads -- a lane past the read's last window loads that window again, past
+    // the chunk's last read that read again -- so that the waits can be counted
     const uint32_t l0 = lane < nwin ? lane : nwin - 1u, l1 = lane + 64u < nwin ? lane + 64u : nwin - 1u;
-    uint64_t pf0 = hc[l0], pf1 = hc[l1];
-    const uint32_t bn = (nr > 1u ? 1u : 0u) * nwin;
-    uint64_t pg0 = hc[bn + l0], pg1 = hc[bn + l1];
+    uint64_t pf0 = 0, pf1 = 0, pg0 = 0, pg1 = 0;
+    // sparse: the k-mers (hash, position) of read r + 1 are in flight; i_cur / i_nxt: first k-mer of read r / r + 1
+    // relative to the chunk's
+    uint32_t pp0 = 0, pp1 = 0, i_cur = 0, i_nxt = 0;
+    auto rel = [&](const uint32_t rr) -> uint32_t { // first k-mer of read rr of the chunk (rr <= nr)
+      const uint64_t g = r0 + rr;
+      return (uint32_t)((g < a.n_reads ? a.roff[g] : a.n_kmers) - kb);
+    };
+    auto load_sparse = [&](const uint32_t i0, const uint32_t i1) {
+      if (i1 > i0) { // (wave-uniform)
+        const uint32_t e0 = i0 + lane < i1 ? i0 + lane : i1 - 1u, e1 = i0 + 64u + lane < i1 ? i0 + 64u + lane : i1 - 1u;
+        pf0 = hc[e0];
+        pp0 = pc[e0];
+        pf1 = hc[e1];
+        pp1 = pc[e1];
+      }
+    };
+    if constexpr (SPARSE) {
+      i_cur = 0;
+      i_nxt = rel(1u);
+      load_sparse(i_cur, i_nxt);
+    } else {
+      pf0 = hc[l0];
+      pf1 = hc[l1];
+      const uint32_t bn = (nr > 1u ? 1u : 0u) * nwin;
+      pg0 = hc[bn + l0];
+      pg1 = hc[bn + l1];
+    }
     for (uint32_t r = 0; r < nr; ++r) {
-      uint32_t h0l = (uint32_t)pf0, h0h = (uint32_t)(pf0 >> 32), h1l = (uint32_t)pf1, h1h = (uint32_t)(pf1 >> 32);
+      uint32_t h0l, h0h, h1l, h1h;
       uint32_t p0 = lane, p1 = lane + 64u;
-      pf0 = pg0;
-      pf1 = pg1;
-      {
+      if constexpr (SPARSE) {
+        const uint32_t cnt = i_nxt - i_cur; // k-mers of the read (<= its windows)
+        if (a.offsets != nullptr) {         // this read's windows
+          const uint64_t l = a.offsets[r0 + r + 1u] - a.offsets[r0 + r];
+          nwin = l >= a.k ? (uint32_t)(l - a.k + 1u) : 0u;
+          w = a.w < nwin ? a.w : nwin;
+          n_starts = nwin - w + 1u;
+          J = 0;
+          while ((2u << J) <= w) ++J;
+          q = w - (1u << J);
+          v0 = lane < n_starts;
+          v1 = lane + 64u < n_starts;
+        }
+        if (cnt != 0u) {
+          A[lane] = ~0ull;
+          A[lane + 64u] = ~0ull;
+          wave_sync();
+          if (lane < cnt) A[pp0] = pf0;
+          if (lane + 64u < cnt) A[pp1] = pf1;
+          wave_sync();
+        }
+        const uint64_t x0 = cnt != 0u ? A[lane] : ~0ull, x1 = cnt != 0u ? A[lane + 64u] : ~0ull;
+        h0l = (uint32_t)x0; h0h = (uint32_t)(x0 >> 32); h1l = (uint32_t)x1; h1h = (uint32_t)(x1 >> 32);
+        i_cur = i_nxt;
+        i_nxt = rel(r + 2u);
+        if (r + 1u < nr) load_sparse(i_cur, i_nxt);
+        if (cnt == 0u) { // no k-mer, no pick (a read shorter than k, a read of non-bases)
+          if (rbuf == 64u) flush();
+          if (lane == 0u) lb[rbuf] = done + nbuf;
+          ++rbuf;
+          continue;
+        }
+      } else {
+        h0l = (uint32_t)pf0; h0h = (uint32_t)(pf0 >> 32); h1l = (uint32_t)pf1; h1h = (uint32_t)(pf1 >> 32);
+        pf0 = pg0;
+        pf1 = pg1;
         const uint32_t b = (r + 2u < nr ? r + 2u : nr - 1u) * nwin;
         pg0 = hc[b + l0];
         pg1 = hc[b + l1];
@@ -380,8 +450,12 @@ static __global__ __launch_bounds__(256) void minimizer_dense_kernel(const Minim
       const uint32_t pr0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p0, 0x13C, 0xf, 0xf, false);
       uint32_t pr1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p1, 0x13C, 0xf, 0xf, false);
       pr1 = lane == 0u ? pr0 : pr1;
-      const bool new0 = v0 && (lane == 0u || p0 != pr0);
-      const bool new1 = v1 && p1 != pr1;
+      bool new0 = v0 && (lane == 0u || p0 != pr0);
+      bool new1 = v1 && p1 != pr1;
+      if constexpr (SPARSE) { // a window without a k-mer picks nothing
+        new0 = new0 && (h0l & h0h) != ~0u;
+        new1 = new1 && (h1l & h1h) != ~0u;
+      }
       const uint64_t b0 = __ballot(new0), b1 = __ballot(new1);
       const uint32_t c0 = (uint32_t)__builtin_popcountll(b0), c1 = (uint32_t)__builtin_popcountll(b1);
       if (new0) {
@@ -413,7 +487,7 @@ static __global__ __launch_bounds__(256) void minimizer_gather_kernel(const Mini
   for (uint64_t c = wave; c < n_chunks; c += n_waves) {
     const uint64_t r0 = c * a.rb;
     const uint64_t r1 = r0 + a.rb < a.n_reads ? r0 + a.rb : a.n_reads;
-    const uint64_t k0 = r0 * a.nwin;
+    const uint64_t k0 = a.roff ? a.roff[r0] : r0 * a.nwin;
     const uint64_t o0 = a.base + a.coff[c];
     const uint32_t n = (uint32_t)a.ctot[c];
     for (uint32_t i = lane; i < n; i += 64u) {

@@ -1268,6 +1268,7 @@ def test_minimizers_of_clean_short_reads(oracle, n, L, k, w, table):
     (400, 300, 31, 10, True), (300, 180, 21, 300, False),     # w beyond every read: one minimizer per read
     (60, 3000, 31, 19, True),                                  # reads on both sides of the 1024-window limit of the wave tables
     (500, 90, 25, 4, False),
+    (600, 150, 31, 10, True), (600, 158, 31, 1, True), (300, 120, 31, 200, True),   # at most 128 windows: the register tables
 ])
 def test_minimizers_of_reads_given_by_offsets(oracle, ctx, n, lmax, k, w, dirty):
     """the same brute force, reads of any lengths (offsets): empty reads, reads shorter than k, reads of exactly k bases"""
