@@ -390,17 +390,27 @@ class Context:
             raise err
         return total.value
 
-    def minimizers(self, data, k, w, fixed_len, n_reads, stride=0, capacity=None, offsets=None):
-        """host convenience: -> dict(offsets [n_reads + 1], pos, hashes); offsets: reads of any lengths instead of fixed_len"""
+    def minimizers(self, data, k, w, fixed_len, n_reads, stride=0, capacity=None, offsets=None, device_input=False):
+        """host convenience: -> dict(offsets [n_reads + 1], pos, hashes); offsets: reads of any lengths instead of fixed_len;
+        device_input: the reads (and offsets) are copied to the device first and handed over as device-resident buffers"""
         data = np.ascontiguousarray(data, dtype=np.uint8)
         nwin = max(fixed_len - k + 1, 0)
         cap = (n_reads * nwin if offsets is None else int(data.size)) if capacity is None else capacity
         if offsets is not None:
             offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         d_h, d_p, d_o = self.malloc(max(8, cap * 8)), self.malloc(max(4, cap * 4)), self.malloc((n_reads + 1) * 8)
+        d_in = d_of = 0
         try:
-            total = self.minimizers_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, w, d_h, d_p, d_o, cap,
-                                        flags=NTHIP_HOST_INPUT, offsets=offsets.ctypes.data if offsets is not None else 0)
+            if device_input:
+                d_in = self.malloc(max(16, data.size + 16))
+                self.h2d(d_in, data)
+                if offsets is not None:
+                    d_of = self.malloc(offsets.nbytes)
+                    self.h2d(d_of, offsets)
+                total = self.minimizers_ptr(d_in, n_reads, fixed_len, stride, k, w, d_h, d_p, d_o, cap, flags=0, offsets=d_of)
+            else:
+                total = self.minimizers_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, w, d_h, d_p, d_o, cap,
+                                            flags=NTHIP_HOST_INPUT, offsets=offsets.ctypes.data if offsets is not None else 0)
             offs = np.zeros(n_reads + 1, np.uint64)
             self.d2h(offs, d_o)
             hs, ps = np.zeros(total, np.uint64), np.zeros(total, np.uint32)
@@ -409,8 +419,9 @@ class Context:
                 self.d2h(ps, d_p)
             return dict(total=total, offsets=offs, pos=ps, hashes=hs)
         finally:
-            for p in (d_h, d_p, d_o):
-                self.free(p)
+            for p in (d_h, d_p, d_o, d_in, d_of):
+                if p:
+                    self.free(p)
 
     # -- counting sketch (count-min, one-byte saturating counters) ---------------------------------
     def count_insert_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_counters, n_counters, flags=0):

@@ -10,8 +10,8 @@ using namespace ntamd::host;
 namespace {
 
 // one round of reads of at most MZ_REG_POS windows through minimizer_reg_kernel + minimizer_gather_kernel
-// d_roff == NULL: every read emits every one of its nwin windows (positions = indices); d_lpre / d_ctot / d_coff: n_reads u64 each
-int minimizers_reg_round(nthip_ctx* c, uint64_t* d_h, uint32_t* d_pos, const uint64_t* d_roff, uint64_t n_kmers, const uint64_t* d_offsets,
+// d_slot_counts: the read-slots form (read r's k-mers at r * nwin); else d_roff; both NULL: every read emits every one of its nwin windows (positions = indices); d_lpre / d_ctot / d_coff: n_reads u64 each
+int minimizers_reg_round(nthip_ctx* c, uint64_t* d_h, uint32_t* d_pos, const uint64_t* d_roff, const uint64_t* d_slot_counts, uint64_t n_kmers, const uint64_t* d_offsets,
                          uint32_t k, uint64_t nr, uint32_t nwin, uint32_t w, uint64_t* d_lpre, uint64_t* d_ctot, uint64_t* d_coff,
                          uint64_t* d_sums, uint64_t* d_tot, uint64_t base, uint64_t capacity, uint64_t* d_min_hashes,
                          uint32_t* d_min_pos, uint64_t* d_min_offsets, uint64_t* round_total)
@@ -30,6 +30,7 @@ int minimizers_reg_round(nthip_ctx* c, uint64_t* d_h, uint32_t* d_pos, const uin
   da.w = w;
   da.rb = (uint32_t)rb;
   da.roff = d_roff;
+  da.counts = d_slot_counts;
   da.n_kmers = n_kmers;
   da.offsets = d_offsets;
   da.k = k;
@@ -42,7 +43,7 @@ int minimizers_reg_round(nthip_ctx* c, uint64_t* d_h, uint32_t* d_pos, const uin
   da.out_pos = d_min_pos;
   da.out_offsets = d_min_offsets;
   prof_begin(c, "minimizer_reg_kernel");
-  if (d_roff) hipLaunchKernelGGL(minimizer_reg_kernel<true>, dim3(grid), dim3(256), 0, c->stream, da);
+  if (d_roff || d_slot_counts) hipLaunchKernelGGL(minimizer_reg_kernel<true>, dim3(grid), dim3(256), 0, c->stream, da);
   else hipLaunchKernelGGL(minimizer_reg_kernel<false>, dim3(grid), dim3(256), 0, c->stream, da);
   prof_end(c);
   NTCHK(device_exclusive_scan(c, d_ctot, d_coff, n_chunks, d_sums, d_tot));
@@ -125,7 +126,7 @@ int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uin
   NTCHK(device_exclusive_scan(c, d_counts, d_roff, n, d_sums, d_tot));
   if (max_nwin <= MZ_REG_POS && !c->tune.mz_table) { // short reads (a FASTQ batch): the tables in registers
     uint64_t total = 0;
-    NTCHK(minimizers_reg_round(c, d_h, d_pos, d_roff, n_kmers, st.offsets, k, n, max_nwin, w, d_picked, d_counts, d_ooff, d_sums,
+    NTCHK(minimizers_reg_round(c, d_h, d_pos, d_roff, nullptr, n_kmers, st.offsets, k, n, max_nwin, w, d_picked, d_counts, d_ooff, d_sums,
                                d_tot + 1, 0, capacity, d_min_hashes, d_min_pos, d_min_offsets, &total));
     HIPCHK(hipMemcpyAsync(d_min_offsets + n, &total, sizeof total, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -189,6 +190,7 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
   if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
   if (k < 3) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 is undefined in the reference (src/kmer.cpp:47)");
   if (w == 0) return fail(NTHIP_ERR_ARG, "w must be greater than 0");
+  if (c->async_pending) return fail(NTHIP_ERR_ARG, "NTHIP_ASYNC batches are pending: call nthip_ctx_take_dirty first");
   if (!d_min_offsets || (capacity && !d_min_hashes)) return fail(NTHIP_ERR_ARG, "min_offsets / min_hashes is NULL");
   HIPCHK(hipSetDevice(c->device));
   if (total_out) *total_out = 0;
@@ -247,20 +249,49 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
     out.hashes = d_h;
     out.capacity = nr * (uint64_t)nwin;
     uint64_t n_kmers = 0;
-    // optimistic: no read of the round has a non-base -- every read emits every window, positions are indices
-    NTCHK(nthip_kmer_hash(c, &part, k16, 1, &out, &n_kmers, flags & NTHIP_HOST_INPUT));
-    const bool dense = n_kmers == nr * (uint64_t)nwin;
-    if (!dense) { // (rare: again, with the positions and the per-read counts)
-      out.counts = d_counts;
-      out.pos = d_pos;
+    bool dense = false, slots = false, settled = false;
+    if (!(flags & NTHIP_HOST_INPUT) && nwin <= MZ_REG_POS && !c->tune.mz_table) {
+      // the dense pass alone, as if no read of the round had a non-base (NTHIP_ASYNC: nothing is redone), then the context's
+      // flag; a round with a non-base: once more under the read-slots contract (the dense pass + the reads concerned redone
+      // in their slots, with positions) -- not the count -> scan -> hash of the compact stream
+      int rc = nthip_kmer_hash(c, &part, k16, 1, &out, &n_kmers, NTHIP_ASYNC);
+      if (rc == NTHIP_OK) {
+        int dirty = 0;
+        NTCHK(nthip_ctx_take_dirty(c, &dirty));
+        if (!dirty) {
+          dense = settled = true;
+          n_kmers = nr * (uint64_t)nwin;
+        } else {
+          out.counts = d_counts;
+          out.pos = d_pos;
+          rc = nthip_kmer_hash(c, &part, k16, 1, &out, &n_kmers, NTHIP_OUT_READ_SLOTS);
+          if (rc == NTHIP_OK) slots = settled = true;
+          else if (rc != NTHIP_ERR_UNSUPPORTED) return rc;
+          out.counts = nullptr;
+          out.pos = nullptr;
+        }
+      } else if (rc != NTHIP_ERR_UNSUPPORTED) {
+        return rc;
+      }
+    }
+    if (!settled) {
+      // optimistic: no read of the round has a non-base -- every read emits every window, positions are indices
       NTCHK(nthip_kmer_hash(c, &part, k16, 1, &out, &n_kmers, flags & NTHIP_HOST_INPUT));
-      NTCHK(device_exclusive_scan(c, d_counts, d_roff, nr, d_sums, d_tot));
+      dense = n_kmers == nr * (uint64_t)nwin;
+      if (!dense) { // (rare: again, with the positions and the per-read counts)
+        out.counts = d_counts;
+        out.pos = d_pos;
+        NTCHK(nthip_kmer_hash(c, &part, k16, 1, &out, &n_kmers, flags & NTHIP_HOST_INPUT));
+        NTCHK(device_exclusive_scan(c, d_counts, d_roff, nr, d_sums, d_tot));
+      }
     }
     if (nwin <= MZ_REG_POS && !c->tune.mz_table) {
       // short reads: the table in registers, the picks compacted in place chunk by chunk, then gathered
       uint64_t round_total = 0;
-      NTCHK(minimizers_reg_round(c, d_h, d_pos, dense ? nullptr : d_roff, n_kmers, nullptr, k, nr, nwin, w, d_picked, d_counts, d_ooff,
-                                 d_sums, d_tot + 1, base, capacity, d_min_hashes, d_min_pos, d_min_offsets + r0, &round_total));
+      // (read-slots form: the counts are an input, the chunks' totals go where the compact form's read offsets would be)
+      NTCHK(minimizers_reg_round(c, d_h, d_pos, dense || slots ? nullptr : d_roff, slots ? d_counts : nullptr, n_kmers, nullptr, k, nr, nwin,
+                                 w, d_picked, slots ? d_roff : d_counts, d_ooff, d_sums, d_tot + 1, base, capacity, d_min_hashes,
+                                 d_min_pos, d_min_offsets + r0, &round_total));
       if (base + round_total > capacity) overflow = true;
       base += round_total;
       continue;

@@ -252,7 +252,8 @@ struct MinimizerDenseArgs {
   uint64_t n_reads;
   uint32_t nwin, w, rb, pad0; // nwin: of a fixed-length read (with offsets: unused); rb: reads per chunk (rb * 128 < 2^31)
   // SPARSE -- reads with non-bases and / or reads given by offsets: the emitted k-mers of read r are roff[r] ... roff[r + 1]
-  const uint64_t* roff;    // [n_reads] (exclusive scan of the reads' counts)
+  const uint64_t* roff;    // [n_reads] (exclusive scan of the reads' counts); NULL with counts
+  const uint64_t* counts;  // the read-slots form (fixed-length reads): read r's counts[r] k-mers stand at r * nwin; else NULL
   uint64_t n_kmers;
   const uint64_t* offsets; // reads of any lengths: read r = [offsets[r], offsets[r + 1]); NULL: fixed-length reads
   uint32_t k, pad1;
@@ -307,7 +308,7 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
   for (uint64_t c = wave; c < n_chunks; c += n_waves) {
     const uint64_t r0 = c * a.rb;
     const uint32_t nr = (uint32_t)(r0 + a.rb < a.n_reads ? a.rb : a.n_reads - r0);
-    const uint64_t kb = SPARSE ? a.roff[r0] : r0 * nwin; // the chunk's first k-mer
+    const uint64_t kb = SPARSE && a.counts == nullptr ? a.roff[r0] : r0 * nwin; // the chunk's first k-mer
     uint64_t* const hc = a.hashes + kb; // the chunk's piece of the stream; its picks, compacted, from the front
     uint32_t* const pc = a.tpos + kb;
     uint64_t* const lc = a.lpre + r0;
@@ -333,15 +334,26 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
     // the chunk's last read that read again -- so that the waits can be counted
     const uint32_t l0 = lane < nwin ? lane : nwin - 1u, l1 = lane + 64u < nwin ? lane + 64u : nwin - 1u;
     uint64_t pf0 = 0, pf1 = 0, pg0 = 0, pg1 = 0;
-    // sparse: the k-mers (hash, position) of read r + 1 are in flight; i_cur / i_nxt: first k-mer of read r / r + 1
-    // relative to the chunk's
-    uint32_t pp0 = 0, pp1 = 0, i_cur = 0, i_nxt = 0;
-    auto rel = [&](const uint32_t rr) -> uint32_t { // first k-mer of read rr of the chunk (rr <= nr)
+    // sparse: the k-mers (hash, position) of read r + 1 are in flight; s_* / c_*: first k-mer (relative to the chunk's)
+    // and number of k-mers of read r (cur) / r + 1 (nxt)
+    uint32_t pp0 = 0, pp1 = 0, s_cur = 0, c_cur = 0, s_nxt = 0, c_nxt = 0;
+    auto geom = [&](const uint32_t rr, uint32_t& st, uint32_t& cn) { // read rr of the chunk
       const uint64_t g = r0 + rr;
-      return (uint32_t)((g < a.n_reads ? a.roff[g] : a.n_kmers) - kb);
+      if (g >= a.n_reads) {
+        st = 0;
+        cn = 0;
+      } else if (a.counts != nullptr) {
+        st = rr * a.nwin;
+        cn = (uint32_t)a.counts[g];
+      } else {
+        const uint64_t b = a.roff[g], e = g + 1u < a.n_reads ? a.roff[g + 1u] : a.n_kmers;
+        st = (uint32_t)(b - kb);
+        cn = (uint32_t)(e - b);
+      }
     };
-    auto load_sparse = [&](const uint32_t i0, const uint32_t i1) {
-      if (i1 > i0) { // (wave-uniform)
+    auto load_sparse = [&](const uint32_t i0, const uint32_t cn) {
+      const uint32_t i1 = i0 + cn;
+      if (cn != 0u) { // (wave-uniform)
         const uint32_t e0 = i0 + lane < i1 ? i0 + lane : i1 - 1u, e1 = i0 + 64u + lane < i1 ? i0 + 64u + lane : i1 - 1u;
         pf0 = hc[e0];
         pp0 = pc[e0];
@@ -350,9 +362,9 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
       }
     };
     if constexpr (SPARSE) {
-      i_cur = 0;
-      i_nxt = rel(1u);
-      load_sparse(i_cur, i_nxt);
+      geom(0u, s_cur, c_cur);
+      geom(1u, s_nxt, c_nxt);
+      load_sparse(s_cur, c_cur);
     } else {
       pf0 = hc[l0];
       pf1 = hc[l1];
@@ -364,7 +376,7 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
       uint32_t h0l, h0h, h1l, h1h;
       uint32_t p0 = lane, p1 = lane + 64u;
       if constexpr (SPARSE) {
-        const uint32_t cnt = i_nxt - i_cur; // k-mers of the read (<= its windows)
+        const uint32_t cnt = c_cur; // k-mers of the read (<= its windows)
         if (a.offsets != nullptr) {         // this read's windows
           const uint64_t l = a.offsets[r0 + r + 1u] - a.offsets[r0 + r];
           nwin = l >= a.k ? (uint32_t)(l - a.k + 1u) : 0u;
@@ -386,9 +398,10 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
         }
         const uint64_t x0 = cnt != 0u ? A[lane] : ~0ull, x1 = cnt != 0u ? A[lane + 64u] : ~0ull;
         h0l = (uint32_t)x0; h0h = (uint32_t)(x0 >> 32); h1l = (uint32_t)x1; h1h = (uint32_t)(x1 >> 32);
-        i_cur = i_nxt;
-        i_nxt = rel(r + 2u);
-        if (r + 1u < nr) load_sparse(i_cur, i_nxt);
+        s_cur = s_nxt;
+        c_cur = c_nxt;
+        geom(r + 2u, s_nxt, c_nxt);
+        if (r + 1u < nr) load_sparse(s_cur, c_cur);
         if (cnt == 0u) { // no k-mer, no pick (a read shorter than k, a read of non-bases)
           if (rbuf == 64u) flush();
           if (lane == 0u) lb[rbuf] = done + nbuf;

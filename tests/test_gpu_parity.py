@@ -1157,6 +1157,7 @@ def _minimizers_brute(pos, hashes, nwin, w):
     (100, 60, 31, 50, False, False),     # fewer windows than w: the read is one window
     (64, 700, 64, 19, True, False), (40, 1500, 101, 25, True, False),
     (2500, 150, 31, 12, True, True),     # several rounds of reads (NTHIP_TUNE_BLOOM_ROUND)
+    (5000, 150, 31, 10, True, False), (3000, 101, 21, 5, True, False), (2000, 158, 31, 128, True, False),
 ])
 def test_minimizers_match_brute_force_on_oracle_stream(oracle, n, L, k, w, dirty, rounds):
     """nthip_kmer_minimizers: per read, of every w consecutive window positions the emitted k-mer with the smallest
@@ -1196,6 +1197,10 @@ def test_minimizers_match_brute_force_on_oracle_stream(oracle, n, L, k, w, dirty
     assert (got["offsets"] == np.array(exp_off, np.uint64)).all()
     assert (got["pos"] == np.array(exp_pos, np.uint32)).all()
     assert (got["hashes"] == np.array(exp_h, np.uint64)).all()
+    # device-resident reads: the dense pass alone first, a round with a non-base once more under the read-slots contract
+    dev = ctx.minimizers(data, k, w, L, n, device_input=True)
+    assert dev["total"] == got["total"] and (dev["offsets"] == got["offsets"]).all()
+    assert (dev["pos"] == got["pos"]).all() and (dev["hashes"] == got["hashes"]).all()
     if got["total"] > 1:   # too small a capacity: the need is reported
         with pytest.raises(nthash_amd.NtHipError) as ei:
             ctx.minimizers(data, k, w, L, n, capacity=got["total"] - 1)
@@ -1257,6 +1262,9 @@ def test_minimizers_of_clean_short_reads(oracle, n, L, k, w, table):
     assert (got["offsets"] == exp_off).all()
     assert (got["pos"] == exp_pos).all()
     assert (got["hashes"] == exp_h).all()
+    dev = ctx.minimizers(data, k, w, L, n, device_input=True)
+    assert dev["total"] == got["total"] and (dev["offsets"] == got["offsets"]).all()
+    assert (dev["pos"] == got["pos"]).all() and (dev["hashes"] == got["hashes"]).all()
     if got["total"] > 1 and n <= 700:
         with pytest.raises(nthash_amd.NtHipError) as ei:
             ctx.minimizers(data, k, w, L, n, capacity=got["total"] - 1)
@@ -1295,7 +1303,7 @@ def test_minimizers_of_reads_given_by_offsets(oracle, ctx, n, lmax, k, w, dirty)
         exp_h += [look[q] for q in picked]
         exp_off.append(len(exp_pos))
         o += c
-    got = ctx.minimizers(data, k, w, 0, n, offsets=offs)
+    got = ctx.minimizers(data, k, w, 0, n, offsets=offs, device_input=(n % 200 == 0))
     assert got["total"] == len(exp_pos)
     assert (got["offsets"] == np.array(exp_off, np.uint64)).all()
     assert (got["pos"] == np.array(exp_pos, np.uint32)).all()
