@@ -216,8 +216,10 @@ int nthip_kmer_extend(nthip_ctx* ctx, const char* kmers, uint64_t n_kmers, uint1
  * insert: *total (optional) = k-mers consumed.
  * query : hits[r] (optional; host memory with NTHIP_HOST_OUTPUT) = k-mers of read r whose m bits
  *         are all set; *total = k-mers tested, *total_hits = sum of hits.
- * Fixed-length reads (reads->offsets == NULL), any k >= 3 and m >= 1; otherwise NTHIP_ERR_UNSUPPORTED
- * (hash to a stream with nthip_kmer_hash and consume that with nthip_stream_bloom_insert).
+ * Any k >= 3 and m >= 1.  Fixed-length reads (reads->offsets == NULL): fused, any batch size.  Reads of any lengths
+ * (reads->offsets: a FASTQ batch): the batch's compact hash stream is produced in ONE round in device scratch and the
+ * stream forms consume it -- NTHIP_ERR_UNSUPPORTED when that stream (8 m bytes per base at most) does not fit the
+ * device: split the batch.
  */
 int nthip_kmer_bloom_insert(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint8_t m,
                             uint8_t* d_filter, uint64_t n_bits, uint64_t* total, uint32_t flags);
@@ -230,7 +232,8 @@ int nthip_kmer_bloom_query(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k,
  * k-mers NtHash emits for read r (src/kmer.cpp:228-264 for the emission rule, src/internal.hpp:104-118
  * for hashes()[i]); UINT64_MAX for a read without a valid k-mer.  The hashes stay in registers: the
  * kernel reads the bases and writes 8*m bytes per READ.  signatures: device memory, or host memory with
- * NTHIP_HOST_OUTPUT.  *total (optional) = k-mers consumed.  Fixed-length reads, any k >= 3, m >= 1.
+ * NTHIP_HOST_OUTPUT.  *total (optional) = k-mers consumed.  Any k >= 3, m >= 1; fixed-length reads, or reads of any
+ * lengths (offsets) through h[0] of the batch's compact stream in one round, as the Bloom entries.
  */
 int nthip_kmer_minhash(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint8_t m,
                        uint64_t* signatures, uint64_t* total, uint32_t flags);
@@ -243,8 +246,9 @@ int nthip_stream_bloom_insert(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t
  * one to counter (h mod n_counters), saturating at 255; nthip_stream_count_query gives a k-mer's estimate, the smallest
  * of its m counters (hashes: m per k-mer, as nthip_kmer_hash writes them; d_estimates: one byte per k-mer).  The sketch
  * is a plain byte array on the device, 4-byte aligned, n_counters a multiple of 4.  What the reference's callers do with
- * hashes() next to Bloom filters (reference include/nthash/nthash.hpp:14-17, 56-57); the layout is ours.  Fixed-length
- * reads for the reads entry (as the other consumers); NTHIP_HOST_INPUT is honoured. */
+ * hashes() next to Bloom filters (reference include/nthash/nthash.hpp:14-17, 56-57); the layout is ours.  The reads entry
+ * takes fixed-length reads in rounds or reads of any lengths (offsets) in one round, as the other consumers;
+ * NTHIP_HOST_INPUT is honoured. */
 int nthip_kmer_count_insert(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint8_t m, uint8_t* d_counters,
                             uint64_t n_counters, uint64_t* total, uint32_t flags);
 int nthip_stream_count_insert(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t n_values, uint8_t* d_counters,

@@ -340,15 +340,15 @@ class Context:
         return out
 
     # -- fused Bloom-filter consumers (filter: device memory, ceil(n_bits/32)*4 bytes) ---------
-    def bloom_insert_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_filter, n_bits, flags=0):
-        rd = Reads(seqs, None, n_reads, fixed_len, stride)
+    def bloom_insert_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_filter, n_bits, flags=0, offsets=0):
+        rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
         total = C.c_uint64(0)
         _chk(self.L.nthip_kmer_bloom_insert(self.h, C.byref(rd), k, m, C.c_void_p(d_filter), n_bits,
                                             C.byref(total), flags))
         return total.value
 
-    def bloom_query_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_filter, n_bits, hits=0, flags=0):
-        rd = Reads(seqs, None, n_reads, fixed_len, stride)
+    def bloom_query_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_filter, n_bits, hits=0, flags=0, offsets=0):
+        rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
         total, found = C.c_uint64(0), C.c_uint64(0)
         _chk(self.L.nthip_kmer_bloom_query(self.h, C.byref(rd), k, m, C.c_void_p(d_filter), n_bits,
                                            C.c_void_p(hits) if hits else None, C.byref(total), C.byref(found),
@@ -359,19 +359,22 @@ class Context:
         """release the buffers the context caches between calls (streaming driver, scan scratch)"""
         _chk(self.L.nthip_ctx_trim(self.h))
 
-    def minhash_ptr(self, seqs, n_reads, fixed_len, stride, k, m, sig, flags=0):
+    def minhash_ptr(self, seqs, n_reads, fixed_len, stride, k, m, sig, flags=0, offsets=0):
         """per-read MinHash signatures into sig[n_reads * m]; -> k-mers consumed"""
-        rd = Reads(seqs, None, n_reads, fixed_len, stride)
+        rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
         total = C.c_uint64(0)
         _chk(self.L.nthip_kmer_minhash(self.h, C.byref(rd), k, m, C.c_void_p(sig), C.byref(total), flags))
         return total.value
 
-    def minhash(self, data, k, m, fixed_len, n_reads, stride=0):
+    def minhash(self, data, k, m, fixed_len, n_reads, stride=0, offsets=None):
         """-> (signatures [n_reads, m], k-mers consumed)"""
         data = np.ascontiguousarray(data, dtype=np.uint8)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         sig = np.zeros((n_reads, m), np.uint64)
         total = self.minhash_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, sig.ctypes.data,
-                                 flags=NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT)
+                                 flags=NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT,
+                                 offsets=offsets.ctypes.data if offsets is not None else 0)
         return sig, total
 
     def stream_bloom_insert_ptr(self, d_hashes, n_values, d_filter, n_bits):
@@ -424,17 +427,19 @@ class Context:
                     self.free(p)
 
     # -- counting sketch (count-min, one-byte saturating counters) ---------------------------------
-    def count_insert_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_counters, n_counters, flags=0):
-        rd = Reads(seqs, None, n_reads, fixed_len, stride)
+    def count_insert_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_counters, n_counters, flags=0, offsets=0):
+        rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
         total = C.c_uint64(0)
         _chk(self.L.nthip_kmer_count_insert(self.h, C.byref(rd), k, m, C.c_void_p(d_counters), C.c_uint64(n_counters),
                                             C.byref(total), flags))
         return total.value
 
-    def count_insert(self, data, k, m, fixed_len, n_reads, d_counters, n_counters, stride=0):
+    def count_insert(self, data, k, m, fixed_len, n_reads, d_counters, n_counters, stride=0, offsets=None):
         data = np.ascontiguousarray(data, dtype=np.uint8)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         return self.count_insert_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, d_counters, n_counters,
-                                     flags=NTHIP_HOST_INPUT)
+                                     flags=NTHIP_HOST_INPUT, offsets=offsets.ctypes.data if offsets is not None else 0)
 
     def stream_count_insert_ptr(self, d_hashes, n_values, d_counters, n_counters):
         _chk(self.L.nthip_stream_count_insert(self.h, C.c_void_p(d_hashes), C.c_uint64(n_values), C.c_void_p(d_counters),
@@ -451,17 +456,22 @@ class Context:
         self.memset(d, 0, nbytes)
         return d, nbytes
 
-    def bloom_insert(self, data, k, m, fixed_len, n_reads, d_filter, n_bits, stride=0):
+    def bloom_insert(self, data, k, m, fixed_len, n_reads, d_filter, n_bits, stride=0, offsets=None):
         data = np.ascontiguousarray(data, dtype=np.uint8)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         return self.bloom_insert_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, d_filter, n_bits,
-                                     flags=NTHIP_HOST_INPUT)
+                                     flags=NTHIP_HOST_INPUT, offsets=offsets.ctypes.data if offsets is not None else 0)
 
-    def bloom_query(self, data, k, m, fixed_len, n_reads, d_filter, n_bits, stride=0):
+    def bloom_query(self, data, k, m, fixed_len, n_reads, d_filter, n_bits, stride=0, offsets=None):
         """-> (hits per read, k-mers tested, k-mers found)"""
         data = np.ascontiguousarray(data, dtype=np.uint8)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         hits = np.zeros(n_reads, np.uint64)
         total, found = self.bloom_query_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, d_filter, n_bits,
-                                            hits=hits.ctypes.data, flags=NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT)
+                                            hits=hits.ctypes.data, flags=NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT,
+                                            offsets=offsets.ctypes.data if offsets is not None else 0)
         return hits, total, found
 
     # -- FASTQ / FASTA: device indexer, spans, file streaming ------------------------------------

@@ -399,4 +399,48 @@ static __global__ __launch_bounds__(256) void count_query_kernel(const uint64_t*
   }
 }
 
+
+// Bloom membership of the k-mers of a hash stream, per READ (reads of any lengths: the stream's read r is k-mers
+// roff[r] ... roff[r + 1], m values each): hits[r] = number of its k-mers whose m bits are all set.  One wave per read
+// at a time; the loads of the filter are what it waits for (four k-mers per lane in flight).
+static __global__ __launch_bounds__(256) void stream_bloom_query_kernel(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ roff,
+                                                                        uint64_t n_reads, uint64_t n_kmers, uint32_t m,
+                                                                        const uint32_t* __restrict__ bloom, uint64_t n_bits, uint64_t magic,
+                                                                        uint64_t* __restrict__ hits, unsigned long long* __restrict__ total_hits)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  uint64_t mine = 0;
+  for (uint64_t r = wave; r < n_reads; r += n_waves) {
+    const uint64_t i0 = roff[r], i1 = r + 1 < n_reads ? roff[r + 1] : n_kmers;
+    uint32_t found = 0;
+    constexpr uint32_t U = 4;
+    for (uint64_t c0 = i0; c0 < i1; c0 += 64u * U) {
+      bool hit[U];
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) hit[u] = c0 + u * 64u + lane < i1;
+      for (uint32_t j = 0; j < m; ++j) {
+        uint64_t p[U];
+        uint32_t word[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+          const uint64_t i = c0 + u * 64u + lane;
+          p[u] = mod_invariant(hashes[(i < i1 ? i : i0) * m + j], n_bits, magic);
+          word[u] = bloom[p[u] >> 5];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) hit[u] = hit[u] && ((word[u] >> ((uint32_t)p[u] & 31u)) & 1u);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) found += (uint32_t)__builtin_popcountll(__ballot(hit[u]));
+    }
+    if (lane == 0) {
+      if (hits) hits[r] = found;
+      mine += found;
+    }
+  }
+  if (lane == 0 && mine) atomicAdd(total_hits, (unsigned long long)mine);
+}
+
 } // namespace ntamd

@@ -245,6 +245,14 @@ int check_offsets_device(nthip_ctx* c, const uint64_t* d_starts, const uint64_t*
                          uint64_t buf_bytes, bool contiguous, uint64_t* max_len = nullptr);
 inline size_t lds_cap_of(const nthip_ctx* c) { return (c->lds_max < 160 * 1024 ? c->lds_max : 160 * 1024) - 512; }
 
+// ---- capi_sink_bloom.hip: consumers on reads of any lengths ----
+// device memory that `keep` frees (not the staging arena, which starts over in every staged call)
+int own_alloc(Staged& keep, size_t bytes, void** p);
+// the compact hash stream (m values per k-mer) of a batch given by offsets, hashed in ONE round into memory `keep` owns;
+// d_counts (optional): per-read counts.  NTHIP_ERR_UNSUPPORTED when the stream does not fit the device
+int stream_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m, uint32_t flags, Staged& keep, uint64_t** d_h,
+                      uint64_t** d_counts, uint64_t* n_kmers);
+
 // ---- capi_util.hip ------------------------------------------------------------------------------------------
 // exclusive scan of n u64 on the device: out[i] = sum(in[0..i)), *d_total = sum; d_sums: ceil(n/1024) + 16 u64
 // (in-place is allowed: d_out == d_in)

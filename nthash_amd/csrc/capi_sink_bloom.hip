@@ -2,9 +2,40 @@
 // Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
 #include "capi_internal.hpp"
 #include "bloom_binned_kernels.hpp"
+#include "util_kernels.hpp" // (SCAN_TILE)
 
 using namespace ntamd;
 using namespace ntamd::host;
+
+// (not stage_alloc: the arena it hands out of starts over in every staged call, and nthip_kmer_hash below may be one)
+int ntamd::host::own_alloc(Staged& keep, size_t bytes, void** p)
+{
+  HIPCHK(hipMalloc(p, bytes ? bytes : 16));
+  keep.owned.push_back(*p);
+  return NTHIP_OK;
+}
+
+int ntamd::host::stream_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m, uint32_t flags, Staged& keep, uint64_t** d_h,
+                      uint64_t** d_counts, uint64_t* n_kmers)
+{
+  uint64_t total_bytes = 0;
+  NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
+  const uint64_t cap = total_bytes > 0 ? total_bytes : 1;
+  const size_t need = (size_t)cap * m * 8 + (d_counts ? (size_t)rd->n_reads * 16 + 4096 : 0);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  if (need > free_b / 10 * 9)
+    return fail(NTHIP_ERR_UNSUPPORTED, "reads given by offsets: the batch's hash stream (%llu MB) does not fit the device in one round; split the batch",
+                (unsigned long long)(need >> 20));
+  NTCHK(own_alloc(keep, (size_t)cap * m * 8, (void**)d_h));
+  if (d_counts) NTCHK(own_alloc(keep, (size_t)(rd->n_reads + 1) * 8, (void**)d_counts));
+  nthip_out out;
+  memset(&out, 0, sizeof out);
+  out.hashes = *d_h;
+  out.capacity = cap;
+  out.counts = d_counts ? *d_counts : nullptr;
+  return nthip_kmer_hash(c, rd, k, m, &out, n_kmers, flags & NTHIP_HOST_INPUT);
+}
 
 namespace {
 
@@ -161,6 +192,9 @@ int bloom_binned_round(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n, uint3
 }
 
 // the reads entry on the binned insert: rounds of reads hashed to a stream in the context's lists, every round binned
+// Reads of any lengths (offsets != NULL) reach the consumers through their compact hash stream: the whole batch hashed in
+// ONE round into a scratch buffer that `keep` owns (a k-mer starts at a base: at most total_bytes k-mers), then the
+// stream forms of the consumers.  NTHIP_ERR_UNSUPPORTED when the stream does not fit the device: split the batch.
 int run_kmer_bloom_binned(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m, uint32_t* d_filter, uint64_t n_bits,
                           uint64_t* total_out, uint32_t flags)
 {
@@ -208,10 +242,34 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
   if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
   if (!d_filter || n_bits == 0) return fail(NTHIP_ERR_ARG, "filter is NULL / n_bits is 0");
   if ((uintptr_t)d_filter & 3u) return fail(NTHIP_ERR_ARG, "filter must be 4-byte aligned");
-  if (rd->offsets) return fail(NTHIP_ERR_UNSUPPORTED, "fused consumers take fixed-length reads (offsets == NULL)");
   HIPCHK(hipSetDevice(c->device));
   if (total_out) *total_out = 0;
   if (total_hits) *total_hits = 0;
+  if (rd->offsets) { // reads of any lengths: the batch's compact stream, then the stream forms
+    if (rd->n_reads == 0) return NTHIP_OK;
+    Staged keep;
+    uint64_t *d_h = nullptr, *d_counts = nullptr, n_kmers = 0;
+    NTCHK(stream_of_offsets(c, rd, k16, m8, flags, keep, &d_h, query ? &d_counts : nullptr, &n_kmers));
+    if (total_out) *total_out = n_kmers;
+    if (!query) return nthip_stream_bloom_insert(c, d_h, n_kmers * m, (uint8_t*)d_filter, n_bits);
+    const bool host = hits && (flags & NTHIP_HOST_OUTPUT);
+    uint64_t* d_hits = hits;
+    if (host) NTCHK(own_alloc(keep, (size_t)rd->n_reads * 8, (void**)&d_hits));
+    uint64_t *d_roff = nullptr, *d_sums = nullptr;
+    NTCHK(own_alloc(keep, (size_t)(rd->n_reads + 1) * 8, (void**)&d_roff));
+    NTCHK(own_alloc(keep, (size_t)(rd->n_reads / SCAN_TILE + 64) * 8, (void**)&d_sums));
+    NTCHK(device_exclusive_scan(c, d_counts, d_roff, rd->n_reads, d_sums, (uint64_t*)(c->d_small + 16)));
+    HIPCHK(hipMemsetAsync(c->d_small + 24, 0, 8, c->stream));
+    const unsigned grid = (unsigned)(c->n_cu * 8);
+    hipLaunchKernelGGL(stream_bloom_query_kernel, dim3(grid), dim3(256), 0, c->stream, d_h, d_roff, rd->n_reads, n_kmers, m, d_filter, n_bits,
+                       bloom_magic_of(n_bits), d_hits, (unsigned long long*)(c->d_small + 24));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_small + 24, c->d_small + 24, 8, hipMemcpyDeviceToHost, c->stream));
+    if (host) HIPCHK(hipMemcpyAsync(hits, d_hits, rd->n_reads * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (total_hits) memcpy(total_hits, c->h_small + 24, 8);
+    return NTHIP_OK;
+  }
   const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
   const bool host_hits = query && hits && (flags & NTHIP_HOST_OUTPUT);
   if (rd->n_reads == 0) return NTHIP_OK;
@@ -381,9 +439,16 @@ extern "C" int nthip_kmer_count_insert(nthip_ctx* c, const nthip_reads* rd, uint
   if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
   if (k < 3) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 is undefined in the reference (src/kmer.cpp:47)");
   if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
-  if (rd->offsets) return fail(NTHIP_ERR_UNSUPPORTED, "the consumers take fixed-length reads (offsets == NULL)");
   HIPCHK(hipSetDevice(c->device));
   if (total_out) *total_out = 0;
+  if (rd->offsets) { // reads of any lengths: the batch's compact stream, then the stream form
+    if (rd->n_reads == 0) return NTHIP_OK;
+    Staged keep;
+    uint64_t *d_h = nullptr, n_kmers = 0;
+    NTCHK(stream_of_offsets(c, rd, k, m, flags, keep, &d_h, nullptr, &n_kmers));
+    if (total_out) *total_out = n_kmers;
+    return nthip_stream_count_insert(c, d_h, n_kmers * m, d_counters, n_counters);
+  }
   const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
   if (rd->n_reads == 0 || len < k) return NTHIP_OK;
   const uint64_t per_read = (uint64_t)(len - k + 1) * m;

@@ -1,6 +1,8 @@
 // capi_sink_minhash.hip -- fused consumer of the hash stream: per-read MinHash signatures
 // Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
 #include "capi_internal.hpp"
+#include "minimizer_kernels.hpp" // (stream_minhash_kernel)
+#include "util_kernels.hpp"      // (SCAN_TILE)
 
 using namespace ntamd;
 using namespace ntamd::host;
@@ -18,10 +20,28 @@ int run_kmer_minhash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t 
   if (k < 3) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 is undefined in the reference (src/kmer.cpp:47)");
   if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
   if (rd->n_reads && !sig) return fail(NTHIP_ERR_ARG, "signatures is NULL");
-  if (rd->offsets) return fail(NTHIP_ERR_UNSUPPORTED, "fused consumers take fixed-length reads (offsets == NULL)");
   HIPCHK(hipSetDevice(c->device));
   if (total_out) *total_out = 0;
   if (rd->n_reads == 0) return NTHIP_OK;
+  if (rd->offsets) { // reads of any lengths: h[0] of the batch's compact stream in one round, the signatures from the stream
+    Staged keep;
+    uint64_t *d_h = nullptr, *d_counts = nullptr, *d_roff = nullptr, *d_sums = nullptr, n_kmers = 0;
+    NTCHK(stream_of_offsets(c, rd, k16, 1, flags, keep, &d_h, &d_counts, &n_kmers));
+    if (total_out) *total_out = n_kmers;
+    const size_t sb = rd->n_reads * (size_t)m * sizeof(uint64_t);
+    const bool host = (flags & NTHIP_HOST_OUTPUT) != 0;
+    uint64_t* d_sig = sig;
+    if (host) NTCHK(own_alloc(keep, sb, (void**)&d_sig));
+    NTCHK(own_alloc(keep, (size_t)(rd->n_reads + 1) * 8, (void**)&d_roff));
+    NTCHK(own_alloc(keep, (size_t)(rd->n_reads / SCAN_TILE + 64) * 8, (void**)&d_sums));
+    NTCHK(device_exclusive_scan(c, d_counts, d_roff, rd->n_reads, d_sums, (uint64_t*)(c->d_small + 16)));
+    hipLaunchKernelGGL(stream_minhash_kernel, dim3((unsigned)(c->n_cu * 8)), dim3(256), 0, c->stream, d_h, d_roff, rd->n_reads, n_kmers, m,
+                       (uint64_t)k * MULTISEED, d_sig);
+    HIPCHK(hipGetLastError());
+    if (host) HIPCHK(hipMemcpyAsync(sig, d_sig, sb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTHIP_OK;
+  }
   const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
   const bool host_sig = (flags & NTHIP_HOST_OUTPUT) != 0;
   const size_t sig_bytes = rd->n_reads * (size_t)m * sizeof(uint64_t);

@@ -21,6 +21,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "nt_math.hpp"
+
 #include <cstdint>
 #include <type_traits>
 
@@ -511,6 +513,42 @@ static __global__ __launch_bounds__(256) void minimizer_gather_kernel(const Mini
       }
     }
     for (uint64_t r = r0 + lane; r < r1; r += 64u) a.out_offsets[r] = o0 + a.lpre[r];
+  }
+}
+
+// per-read MinHash signatures from a hash stream (reads of any lengths: read r = k-mers roff[r] ... roff[r + 1], ONE value
+// -- h[0] -- per k-mer): sig[r][j] = min over the read's k-mers of h[j] (extend_hashes, reference src/internal.hpp:104-118,
+// recomputed here from h[0]); all ones for a read without a k-mer.  One wave per read at a time.
+static __global__ __launch_bounds__(256) void stream_minhash_kernel(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ roff,
+                                                                    uint64_t n_reads, uint64_t n_kmers, uint32_t m, uint64_t kmul,
+                                                                    uint64_t* __restrict__ sig)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t r = wave; r < n_reads; r += n_waves) {
+    const uint64_t i0 = roff[r], i1 = r + 1 < n_reads ? roff[r + 1] : n_kmers;
+    for (uint32_t j0 = 0; j0 < m; j0 += 4u) {
+      uint64_t mn[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+      for (uint64_t e = i0 + lane; e < i1; e += 64u) {
+        const uint64_t h0 = hashes[e];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+          const uint32_t j = j0 + u;
+          const uint64_t v = j == 0u ? h0 : mix_hash(h0, (uint64_t)j ^ kmul);
+          mn[u] = v < mn[u] ? v : mn[u];
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        uint64_t v = mn[u];
+        for (int d = 32; d > 0; d >>= 1) {
+          const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
+          v = o < v ? o : v;
+        }
+        if (lane == 0 && j0 + u < m) sig[r * m + j0 + u] = v;
+      }
+    }
   }
 }
 

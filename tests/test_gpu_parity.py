@@ -1439,6 +1439,78 @@ def test_bloom_query_hits_per_read(ctx, oracle, n, L, k, m, n_bits):
     ctx.free(d_f)
 
 
+@pytest.mark.parametrize("n,lmax,k,m,n_bits,device_input", [
+    (1500, 250, 31, 1, 1 << 22, False), (1200, 180, 25, 3, 3_000_017, True), (600, 400, 64, 2, (1 << 23) + 5, False),
+    (40, 6000, 31, 2, 1 << 21, True),
+])
+def test_consumers_take_reads_given_by_offsets(ctx, oracle, n, lmax, k, m, n_bits, device_input):
+    """Bloom insert / query and the counting sketch on reads of any lengths (offsets): the batch's compact stream in one
+    round, then the stream consumers -- filter, per-read hits and counters against the oracle's stream (empty reads, reads
+    shorter than k, reads with non-bases)"""
+    from nthash_amd.capi import NTHIP_HOST_OUTPUT
+    rng = np.random.default_rng(n + lmax + m)
+    lens = rng.integers(0, lmax + 1, n).astype(np.uint64)
+    lens[:3] = [0, k - 1, k]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total_b = int(offs[-1])
+    a = oracle.synth_reads(5, 1, total_b, 3 + k).copy()
+    b = a.copy()                                    # the query batch: the second half is other sequence, some N
+    half = int(offs[n // 2])
+    b[half:] = oracle.synth_reads(6, 1, total_b, 4 + k)[half:]
+    bad = rng.choice(total_b, max(3, total_b // 700), replace=False)
+    a[bad[::2]] = ord("N")
+    b[bad[1::2]] = ord("n")
+    ha = oracle.kmer_batch(a, offs, k, m, want_pos=False)
+    hb = oracle.kmer_batch(b, offs, k, m, want_pos=False)
+    filt = _bloom_expected(ha["hashes"], n_bits)
+    d_f, nbytes = ctx.bloom_new(n_bits)
+
+    def dev(arr):
+        d = ctx.malloc(max(16, arr.nbytes + 16))
+        ctx.h2d(d, arr)
+        return d
+    if device_input:
+        d_a, d_b, d_o = dev(a), dev(b), dev(offs)
+        assert ctx.bloom_insert_ptr(d_a, n, 0, 0, k, m, d_f, n_bits, offsets=d_o) == ha["total"]
+    else:
+        assert ctx.bloom_insert(a, k, m, 0, n, d_f, n_bits, offsets=offs) == ha["total"]
+    got = np.zeros(nbytes, np.uint8)
+    ctx.d2h(got, d_f)
+    assert (got == filt).all()
+    bits = np.unpackbits(filt, bitorder="little")
+    present = bits[(hb["hashes"] % np.uint64(n_bits)).astype(np.int64)].reshape(-1, m).all(axis=1)
+    read_of = np.repeat(np.arange(n), hb["counts"].astype(np.int64))
+    want_hits = np.bincount(read_of[present], minlength=n).astype(np.uint64)
+    if device_input:
+        d_hits = ctx.malloc(n * 8)
+        total, found = ctx.bloom_query_ptr(d_b, n, 0, 0, k, m, d_f, n_bits, hits=d_hits, offsets=d_o)
+        hits = np.zeros(n, np.uint64)
+        ctx.d2h(hits, d_hits)
+        ctx.free(d_hits)
+    else:
+        hits, total, found = ctx.bloom_query(b, k, m, 0, n, d_f, n_bits, offsets=offs)
+    assert total == hb["total"] and found == int(want_hits.sum())
+    assert (hits == want_hits).all()
+    # counting sketch
+    n_counters = 1 << 18
+    d_c = ctx.malloc(n_counters)
+    ctx.memset(d_c, 0, n_counters)
+    if device_input:
+        assert ctx.count_insert_ptr(d_a, n, 0, 0, k, m, d_c, n_counters, offsets=d_o) == ha["total"]
+    else:
+        assert ctx.count_insert(a, k, m, 0, n, d_c, n_counters, offsets=offs) == ha["total"]
+    tally = np.bincount((np.ascontiguousarray(ha["hashes"]).ravel() % np.uint64(n_counters)).astype(np.int64), minlength=n_counters)
+    cnt = np.zeros(n_counters, np.uint8)
+    ctx.d2h(cnt, d_c)
+    assert (cnt == np.minimum(tally, 255).astype(np.uint8)).all()
+    # per-read MinHash signatures
+    sig, tot = ctx.minhash(a, k, m, 0, n, offsets=offs)
+    assert tot == ha["total"]
+    assert (sig == _minhash_expected(ha, n, m)).all()
+    for d in ([d_a, d_b, d_o] if device_input else []) + [d_f, d_c]:
+        ctx.free(d)
+
+
 def test_bloom_argument_errors(ctx):
     import nthash_amd
     d_f, _ = ctx.bloom_new(1024)
