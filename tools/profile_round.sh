@@ -21,6 +21,12 @@ for cfg in c2 c3 c4 ref var var_slots c2_packed; do
   for f in $(find "$OUT/trace_$cfg" -name "*kernel_stats.csv"); do cp "$f" "$OUT/kernel_stats_$cfg.csv"; done
   echo "== $cfg"; head -4 "$OUT/kernel_stats_$cfg.csv" 2>/dev/null
 done
+# a consumer: per-read minimizers (w = 10) of 20 M clean reads, of the same reads with an N here and there, and given by offsets
+for shape in clean dirty var; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mz_$shape" -o kt -- python tools/minimizer_bench.py 20000000 10 $shape > "$OUT/minimizer_${shape}_under_rocprof.txt" 2> "$OUT/trace_mz_$shape.err"
+  for f in $(find "$OUT/trace_mz_$shape" -name "*kernel_stats.csv"); do cp "$f" "$OUT/kernel_stats_minimizers_$shape.csv"; done
+  cat "$OUT/minimizer_${shape}_under_rocprof.txt"; head -6 "$OUT/kernel_stats_minimizers_$shape.csv" 2>/dev/null
+done
 bash tools/run_pmc.sh "$OUT/pmc_c2" c2 20000000 > "$OUT/pmc_c2.log" 2>&1
 grep -v "^copy" "$OUT/pmc_c2/summary.txt"
 bash tools/run_pmc.sh "$OUT/pmc_c4" c4 8000000 > "$OUT/pmc_c4.log" 2>&1
