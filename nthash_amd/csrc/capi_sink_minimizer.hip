@@ -43,8 +43,11 @@ int minimizers_reg_round(nthip_ctx* c, uint64_t* d_h, uint32_t* d_pos, const uin
   da.out_pos = d_min_pos;
   da.out_offsets = d_min_offsets;
   prof_begin(c, "minimizer_reg_kernel");
-  if (d_roff || d_slot_counts) hipLaunchKernelGGL(minimizer_reg_kernel<true>, dim3(grid), dim3(256), 0, c->stream, da);
-  else hipLaunchKernelGGL(minimizer_reg_kernel<false>, dim3(grid), dim3(256), 0, c->stream, da);
+  const bool sparse = d_roff || d_slot_counts, one = nwin <= 64; // (nwin: of the longest read)
+  if (sparse && one) hipLaunchKernelGGL((minimizer_reg_kernel<true, true>), dim3(grid), dim3(256), 0, c->stream, da);
+  else if (sparse) hipLaunchKernelGGL((minimizer_reg_kernel<true, false>), dim3(grid), dim3(256), 0, c->stream, da);
+  else if (one) hipLaunchKernelGGL((minimizer_reg_kernel<false, true>), dim3(grid), dim3(256), 0, c->stream, da);
+  else hipLaunchKernelGGL((minimizer_reg_kernel<false, false>), dim3(grid), dim3(256), 0, c->stream, da);
   prof_end(c);
   NTCHK(device_exclusive_scan(c, d_ctot, d_coff, n_chunks, d_sums, d_tot));
   hipLaunchKernelGGL(minimizer_gather_kernel, dim3(grid), dim3(256), 0, c->stream, da);

@@ -276,7 +276,8 @@ constexpr uint32_t MZ_BUF = 256; // picks a wave collects in LDS before it write
 // SPARSE (reads with a non-base somewhere, reads of any lengths -- at most MZ_REG_POS windows each): the read's k-mers
 // are laid out by position through 1 KiB of the wave's LDS first (a k-mer that is not there: the largest value; a window
 // without a k-mer picks nothing), the window count may differ from read to read; everything after that is the same.
-template <bool SPARSE>
+// ONE: no read of the batch has more than 64 windows -- the second register set and everything done to it drop out
+template <bool SPARSE, bool ONE = false>
 static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const MinimizerDenseArgs a)
 {
   // per wave: the picks of the last few reads (hash, position) and those reads' offsets -- written out together, whole
@@ -359,8 +360,10 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
         const uint32_t e0 = i0 + lane < i1 ? i0 + lane : i1 - 1u, e1 = i0 + 64u + lane < i1 ? i0 + 64u + lane : i1 - 1u;
         pf0 = hc[e0];
         pp0 = pc[e0];
-        pf1 = hc[e1];
-        pp1 = pc[e1];
+        if constexpr (!ONE) {
+          pf1 = hc[e1];
+          pp1 = pc[e1];
+        }
       }
     };
     if constexpr (SPARSE) {
@@ -369,10 +372,10 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
       load_sparse(s_cur, c_cur);
     } else {
       pf0 = hc[l0];
-      pf1 = hc[l1];
+      if constexpr (!ONE) pf1 = hc[l1];
       const uint32_t bn = (nr > 1u ? 1u : 0u) * nwin;
       pg0 = hc[bn + l0];
-      pg1 = hc[bn + l1];
+      if constexpr (!ONE) pg1 = hc[bn + l1];
     }
     for (uint32_t r = 0; r < nr; ++r) {
       uint32_t h0l, h0h, h1l, h1h;
@@ -392,13 +395,14 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
         }
         if (cnt != 0u) {
           A[lane] = ~0ull;
-          A[lane + 64u] = ~0ull;
+          if constexpr (!ONE) A[lane + 64u] = ~0ull;
           wave_sync();
           if (lane < cnt) A[pp0] = pf0;
-          if (lane + 64u < cnt) A[pp1] = pf1;
+          if constexpr (!ONE)
+            if (lane + 64u < cnt) A[pp1] = pf1;
           wave_sync();
         }
-        const uint64_t x0 = cnt != 0u ? A[lane] : ~0ull, x1 = cnt != 0u ? A[lane + 64u] : ~0ull;
+        const uint64_t x0 = cnt != 0u ? A[lane] : ~0ull, x1 = !ONE && cnt != 0u ? A[lane + 64u] : ~0ull;
         h0l = (uint32_t)x0; h0h = (uint32_t)(x0 >> 32); h1l = (uint32_t)x1; h1h = (uint32_t)(x1 >> 32);
         s_cur = s_nxt;
         c_cur = c_nxt;
@@ -416,7 +420,7 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
         pf1 = pg1;
         const uint32_t b = (r + 2u < nr ? r + 2u : nr - 1u) * nwin;
         pg0 = hc[b + l0];
-        pg1 = hc[b + l1];
+        if constexpr (!ONE) pg1 = hc[b + l1];
       }
       // (the buffered picks belong to reads before r: their place in the stream is below read r's hashes)
       if (nbuf + n_starts > MZ_BUF || rbuf == 64u) flush();
@@ -426,27 +430,39 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
       // for d = 1 and 2, the whole-wave rotate of the DPP network (wave_rol:1, lane i reads lane i + 1 mod 64: VALU moves).
       auto better = [&](const uint32_t d, const uint32_t a0l, const uint32_t a0h, const uint32_t a0p, const uint32_t a1l,
                         const uint32_t a1h, const uint32_t a1p) {
-        const bool low = lane + d < 64u; // position lane + d is in set 0
+        const bool low = ONE || lane + d < 64u; // position lane + d is in set 0
         const uint32_t n0l = low ? a0l : a1l, n0h = low ? a0h : a1h, n0p = low ? a0p : a1p;
         const bool t0 = (((uint64_t)n0h << 32) | n0l) < (((uint64_t)h0h << 32) | h0l);
-        const bool t1 = (((uint64_t)a1h << 32) | a1l) < (((uint64_t)h1h << 32) | h1l);
         h0l = t0 ? n0l : h0l; h0h = t0 ? n0h : h0h; p0 = t0 ? n0p : p0;
-        h1l = t1 ? a1l : h1l; h1h = t1 ? a1h : h1h; p1 = t1 ? a1p : p1;
+        if constexpr (!ONE) {
+          const bool t1 = (((uint64_t)a1h << 32) | a1l) < (((uint64_t)h1h << 32) | h1l);
+          h1l = t1 ? a1l : h1l; h1h = t1 ? a1h : h1h; p1 = t1 ? a1p : p1;
+        }
       };
       auto step = [&](const uint32_t d) {
         const int idx = (int)(((lane + d) & 63u) << 2);
         const uint32_t a0l = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h0l), a0h = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h0h);
         const uint32_t a0p = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)p0);
-        const uint32_t a1l = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h1l), a1h = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h1h);
-        const uint32_t a1p = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)p1);
+        uint32_t a1l = 0, a1h = 0, a1p = 0;
+        if constexpr (!ONE) {
+          a1l = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h1l);
+          a1h = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)h1h);
+          a1p = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)p1);
+        }
         better(d, a0l, a0h, a0p, a1l, a1h, a1p);
       };
       auto rol1 = [](const uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x134, 0xf, 0xf, false); };
       auto step_rol = [&](auto d_tag) {
         constexpr uint32_t D = decltype(d_tag)::value; // 1 or 2
-        uint32_t a0l = rol1(h0l), a0h = rol1(h0h), a0p = rol1(p0), a1l = rol1(h1l), a1h = rol1(h1h), a1p = rol1(p1);
+        uint32_t a0l = rol1(h0l), a0h = rol1(h0h), a0p = rol1(p0), a1l = 0, a1h = 0, a1p = 0;
+        if constexpr (!ONE) {
+          a1l = rol1(h1l); a1h = rol1(h1h); a1p = rol1(p1);
+        }
         if constexpr (D == 2u) {
-          a0l = rol1(a0l); a0h = rol1(a0h); a0p = rol1(a0p); a1l = rol1(a1l); a1h = rol1(a1h); a1p = rol1(a1p);
+          a0l = rol1(a0l); a0h = rol1(a0h); a0p = rol1(a0p);
+          if constexpr (!ONE) {
+            a1l = rol1(a1l); a1h = rol1(a1h); a1p = rol1(a1p);
+          }
         }
         better(D, a0l, a0h, a0p, a1l, a1h, a1p);
       };
@@ -463,10 +479,10 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
       // p(s) is non-decreasing: a new minimizer wherever it moves
       // (wave_ror:1: lane i reads lane i - 1 mod 64 -- lane 0 of the second set wants lane 63 of the first)
       const uint32_t pr0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p0, 0x13C, 0xf, 0xf, false);
-      uint32_t pr1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p1, 0x13C, 0xf, 0xf, false);
+      uint32_t pr1 = ONE ? 0u : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p1, 0x13C, 0xf, 0xf, false);
       pr1 = lane == 0u ? pr0 : pr1;
       bool new0 = v0 && (lane == 0u || p0 != pr0);
-      bool new1 = v1 && p1 != pr1;
+      bool new1 = !ONE && v1 && p1 != pr1;
       if constexpr (SPARSE) { // a window without a k-mer picks nothing
         new0 = new0 && (h0l & h0h) != ~0u;
         new1 = new1 && (h1l & h1h) != ~0u;

@@ -12,7 +12,7 @@ import numpy as np
 import nthash_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 shape = sys.argv[3] if len(sys.argv) > 3 else "clean"
-L, k = 150, 31
+L, k = int(os.environ.get("MZ_L", "150")), 31
 nwin = L - k + 1
 ctx = nthash_amd.Context(0)
 ctx.set_profiling(True)
