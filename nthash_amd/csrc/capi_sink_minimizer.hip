@@ -44,6 +44,10 @@ int minimizers_reg_round(nthip_ctx* c, uint64_t* d_h, uint32_t* d_pos, const uin
   da.out_offsets = d_min_offsets;
   prof_begin(c, "minimizer_reg_kernel");
   const bool sparse = d_roff || d_slot_counts, one = nwin <= 64; // (nwin: of the longest read)
+  if (nwin > MZ_REG_POS) { // up to 256 windows: four register sets
+    if (sparse) hipLaunchKernelGGL((minimizer_regn_kernel<true, 4>), dim3(grid), dim3(256), 0, c->stream, da);
+    else hipLaunchKernelGGL((minimizer_regn_kernel<false, 4>), dim3(grid), dim3(256), 0, c->stream, da);
+  } else
   if (sparse && one) hipLaunchKernelGGL((minimizer_reg_kernel<true, true>), dim3(grid), dim3(256), 0, c->stream, da);
   else if (sparse) hipLaunchKernelGGL((minimizer_reg_kernel<true, false>), dim3(grid), dim3(256), 0, c->stream, da);
   else if (one) hipLaunchKernelGGL((minimizer_reg_kernel<false, true>), dim3(grid), dim3(256), 0, c->stream, da);
@@ -127,7 +131,7 @@ int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uin
   uint64_t n_kmers = 0;
   NTCHK(nthip_kmer_hash(c, &dr, k16, 1, &out, &n_kmers, 0));
   NTCHK(device_exclusive_scan(c, d_counts, d_roff, n, d_sums, d_tot));
-  if (max_nwin <= MZ_REG_POS && !c->tune.mz_table) { // short reads (a FASTQ batch): the tables in registers
+  if (max_nwin <= MZ_REGN_POS && !c->tune.mz_table) { // short reads (a FASTQ batch): the tables in registers
     uint64_t total = 0;
     NTCHK(minimizers_reg_round(c, d_h, d_pos, d_roff, nullptr, n_kmers, st.offsets, k, n, max_nwin, w, d_picked, d_counts, d_ooff, d_sums,
                                d_tot + 1, 0, capacity, d_min_hashes, d_min_pos, d_min_offsets, &total));
@@ -253,7 +257,7 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
     out.capacity = nr * (uint64_t)nwin;
     uint64_t n_kmers = 0;
     bool dense = false, slots = false, settled = false;
-    if (!(flags & NTHIP_HOST_INPUT) && nwin <= MZ_REG_POS && !c->tune.mz_table) {
+    if (!(flags & NTHIP_HOST_INPUT) && nwin <= MZ_REGN_POS && !c->tune.mz_table) {
       // the dense pass alone, as if no read of the round had a non-base (NTHIP_ASYNC: nothing is redone), then the context's
       // flag; a round with a non-base: once more under the read-slots contract (the dense pass + the reads concerned redone
       // in their slots, with positions) -- not the count -> scan -> hash of the compact stream
@@ -288,7 +292,7 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
         NTCHK(device_exclusive_scan(c, d_counts, d_roff, nr, d_sums, d_tot));
       }
     }
-    if (nwin <= MZ_REG_POS && !c->tune.mz_table) {
+    if (nwin <= MZ_REGN_POS && !c->tune.mz_table) {
       // short reads: the table in registers, the picks compacted in place chunk by chunk, then gathered
       uint64_t round_total = 0;
       // (read-slots form: the counts are an input, the chunks' totals go where the compact form's read offsets would be)

@@ -247,7 +247,8 @@ static __global__ __launch_bounds__(256) void minimizer_write_kernel(const Minim
 // compacted runs to their place in the output -- 17 % of the stream (w = 10) instead of all of it a second time.
 // (LDS-table version above, 20 M x 150 bp: flag pass 13.5 ms -- its LDS pipe saturated, ~60 LDS operations a read -- and
 //  8.5 ms for the write pass that reads the whole stream again.)
-constexpr uint32_t MZ_REG_POS = 128;
+constexpr uint32_t MZ_REG_POS = 128;  // minimizer_reg_kernel
+constexpr uint32_t MZ_REGN_POS = 256; // minimizer_regn_kernel<.., 4>
 struct MinimizerDenseArgs {
   uint64_t* hashes;    // in: the stream; out, in place: the picks of chunk c from the chunk's first k-mer on
   uint32_t* tpos;      // the picks' window positions, same indexing (SPARSE: in as well -- the k-mers' positions)
@@ -501,6 +502,223 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
       }
       if (lane == 0u) lb[rbuf] = done + nbuf;
       nbuf += c0 + c1;
+      ++rbuf;
+    }
+    flush();
+    if (lane == 0u) a.ctot[c] = done;
+  }
+}
+
+// The same for reads of up to 64 NS windows (NS register sets; instantiated for NS = 4: 250 bp reads).  Written over arrays
+// of NS sets; a step by d = 64 ds + dl lanes is a rotation by dl (none for the powers of two from 64 on) and a choice of
+// sets.  One read of hashes in flight.
+template <bool SPARSE, uint32_t NS>
+static __global__ __launch_bounds__(256) void minimizer_regn_kernel(const MinimizerDenseArgs a)
+{
+  constexpr uint32_t BUF = 128u * NS; // (a read's picks always fit behind what the buffer holds: n_starts <= 64 NS)
+  __shared__ uint64_t lds_h[4][BUF];
+  __shared__ uint64_t lds_a[SPARSE ? 4 : 1][SPARSE ? 64u * NS : 1];
+  __shared__ uint32_t lds_l[4][64];
+  __shared__ uint8_t lds_p[4][BUF];
+  static_assert(64u * NS <= 256u, "positions are bytes in the buffer");
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  uint64_t* const hb = lds_h[wv];
+  uint64_t* const A = lds_a[SPARSE ? wv : 0];
+  uint32_t* const lb = lds_l[wv];
+  uint8_t* const pb = lds_p[wv];
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+  uint32_t nwin = a.nwin;
+  uint32_t w = a.w < nwin ? a.w : nwin;
+  uint32_t n_starts = nwin - w + 1u;
+  uint32_t J = 0;
+  while ((2u << J) <= w) ++J;
+  uint32_t q = w - (1u << J);
+  const uint64_t n_chunks = (a.n_reads + a.rb - 1u) / a.rb;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (uint64_t c = wave; c < n_chunks; c += n_waves) {
+    const uint64_t r0 = c * a.rb;
+    const uint32_t nr = (uint32_t)(r0 + a.rb < a.n_reads ? a.rb : a.n_reads - r0);
+    const uint64_t kb = SPARSE && a.counts == nullptr ? a.roff[r0] : r0 * nwin;
+    uint64_t* const hc = a.hashes + kb;
+    uint32_t* const pc = a.tpos + kb;
+    uint64_t* const lc = a.lpre + r0;
+    uint32_t done = 0, nbuf = 0, rbuf = 0, rfirst = 0;
+    auto flush = [&]() {
+      wave_sync();
+      for (uint32_t i = lane; i < nbuf; i += 64u) {
+        hc[done + i] = hb[i];
+        pc[done + i] = pb[i];
+      }
+      if (lane < rbuf) lc[rfirst + lane] = lb[lane];
+      done += nbuf;
+      rfirst += rbuf;
+      nbuf = 0;
+      rbuf = 0;
+      wave_sync();
+    };
+    uint64_t pf[NS];
+    uint32_t pp[NS];
+    uint32_t s_cur = 0, c_cur = 0, s_nxt = 0, c_nxt = 0;
+    auto geom = [&](const uint32_t rr, uint32_t& st, uint32_t& cn) {
+      const uint64_t g = r0 + rr;
+      if (g >= a.n_reads) {
+        st = 0;
+        cn = 0;
+      } else if (a.counts != nullptr) {
+        st = rr * a.nwin;
+        cn = (uint32_t)a.counts[g];
+      } else {
+        const uint64_t b = a.roff[g], e = g + 1u < a.n_reads ? a.roff[g + 1u] : a.n_kmers;
+        st = (uint32_t)(b - kb);
+        cn = (uint32_t)(e - b);
+      }
+    };
+    auto load_read = [&](const uint32_t i0, const uint32_t cn) { // the read's k-mers (dense: its windows), a lane past the last one loads it again
+      if (cn != 0u) {
+#pragma unroll
+        for (uint32_t s_ = 0; s_ < NS; ++s_) {
+          const uint32_t e = i0 + (s_ * 64u + lane < cn ? s_ * 64u + lane : cn - 1u);
+          pf[s_] = hc[e];
+          if constexpr (SPARSE) pp[s_] = pc[e];
+        }
+      }
+    };
+#pragma unroll
+    for (uint32_t s_ = 0; s_ < NS; ++s_) {
+      pf[s_] = 0;
+      pp[s_] = 0;
+    }
+    if constexpr (SPARSE) {
+      geom(0u, s_cur, c_cur);
+      geom(1u, s_nxt, c_nxt);
+    } else {
+      s_cur = 0;
+      c_cur = nwin;
+      s_nxt = nwin;
+      c_nxt = nwin;
+    }
+    load_read(s_cur, c_cur);
+    for (uint32_t r = 0; r < nr; ++r) {
+      uint32_t hl[NS], hh[NS], p[NS];
+      const uint32_t cnt = c_cur;
+      if constexpr (SPARSE) {
+        if (a.offsets != nullptr) {
+          const uint64_t l = a.offsets[r0 + r + 1u] - a.offsets[r0 + r];
+          nwin = l >= a.k ? (uint32_t)(l - a.k + 1u) : 0u;
+          w = a.w < nwin ? a.w : nwin;
+          n_starts = nwin - w + 1u;
+          J = 0;
+          while ((2u << J) <= w) ++J;
+          q = w - (1u << J);
+        }
+        if (cnt != 0u) {
+#pragma unroll
+          for (uint32_t s_ = 0; s_ < NS; ++s_) A[s_ * 64u + lane] = ~0ull;
+          wave_sync();
+#pragma unroll
+          for (uint32_t s_ = 0; s_ < NS; ++s_)
+            if (s_ * 64u + lane < cnt) A[pp[s_]] = pf[s_];
+          wave_sync();
+        }
+#pragma unroll
+        for (uint32_t s_ = 0; s_ < NS; ++s_) {
+          const uint64_t x = cnt != 0u ? A[s_ * 64u + lane] : ~0ull;
+          hl[s_] = (uint32_t)x;
+          hh[s_] = (uint32_t)(x >> 32);
+        }
+      } else {
+#pragma unroll
+        for (uint32_t s_ = 0; s_ < NS; ++s_) {
+          hl[s_] = (uint32_t)pf[s_];
+          hh[s_] = (uint32_t)(pf[s_] >> 32);
+        }
+      }
+#pragma unroll
+      for (uint32_t s_ = 0; s_ < NS; ++s_) p[s_] = s_ * 64u + lane;
+      // the next read's k-mers on their way
+      s_cur = s_nxt;
+      c_cur = c_nxt;
+      if constexpr (SPARSE) geom(r + 2u, s_nxt, c_nxt);
+      else s_nxt += nwin;
+      if (r + 1u < nr) load_read(s_cur, c_cur);
+      if (SPARSE && cnt == 0u) {
+        if (rbuf == 64u) flush();
+        if (lane == 0u) lb[rbuf] = done + nbuf;
+        ++rbuf;
+        continue;
+      }
+      if (nbuf + n_starts > BUF || rbuf == 64u) flush();
+      // M[i] = better(M[i], M[i + d]), d = 64 ds + dl
+      auto step = [&](const uint32_t d) {
+        const uint32_t dl = d & 63u, ds = d >> 6;
+        uint32_t al[NS], ah[NS], ap[NS];
+        if (dl == 0u) {
+#pragma unroll
+          for (uint32_t s_ = 0; s_ < NS; ++s_) {
+            al[s_] = hl[s_];
+            ah[s_] = hh[s_];
+            ap[s_] = p[s_];
+          }
+        } else {
+          const int idx = (int)(((lane + dl) & 63u) << 2);
+#pragma unroll
+          for (uint32_t s_ = 0; s_ < NS; ++s_) {
+            al[s_] = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)hl[s_]);
+            ah[s_] = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)hh[s_]);
+            ap[s_] = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)p[s_]);
+          }
+        }
+        const bool low = lane + dl < 64u;
+        auto apply = [&](auto ds_tag) {
+          constexpr uint32_t DS = decltype(ds_tag)::value;
+#pragma unroll
+          for (uint32_t s_ = 0; s_ < NS; ++s_) {
+            const uint32_t i0 = s_ + DS, i1 = s_ + DS + 1u;
+            if (i0 < NS) { // (else: no such position)
+              const uint32_t j1 = i1 < NS ? i1 : i0;
+              const uint32_t nl = low ? al[i0] : al[j1], nh = low ? ah[i0] : ah[j1], np = low ? ap[i0] : ap[j1];
+              const bool t = (((uint64_t)nh << 32) | nl) < (((uint64_t)hh[s_] << 32) | hl[s_]);
+              hl[s_] = t ? nl : hl[s_];
+              hh[s_] = t ? nh : hh[s_];
+              p[s_] = t ? np : p[s_];
+            }
+          }
+        };
+        switch (ds) {
+          case 0: apply(std::integral_constant<uint32_t, 0u>{}); break;
+          case 1: apply(std::integral_constant<uint32_t, 1u>{}); break;
+          case 2: apply(std::integral_constant<uint32_t, 2u>{}); break;
+          default: apply(std::integral_constant<uint32_t, 3u>{}); break;
+        }
+      };
+      for (uint32_t j = 0; j < J; ++j) step(1u << j);
+      if (q != 0u) step(q);
+      // p(s) is non-decreasing: a new minimizer wherever it moves
+      uint32_t off = nbuf;
+      uint32_t prev_ror = 0;
+#pragma unroll
+      for (uint32_t s_ = 0; s_ < NS; ++s_) {
+        const uint32_t ror = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p[s_], 0x13C, 0xf, 0xf, false); // lane i reads lane i - 1 mod 64
+        const uint32_t pr = lane == 0u ? prev_ror : ror; // (lane 0: lane 63 of the set before)
+        prev_ror = ror;
+        bool nw_ = s_ * 64u + lane < n_starts && ((s_ == 0u && lane == 0u) || p[s_] != pr);
+        if constexpr (SPARSE) nw_ = nw_ && (hl[s_] & hh[s_]) != ~0u;
+        const uint64_t b = __ballot(nw_);
+        if (nw_) {
+          const uint32_t at = off + (uint32_t)__builtin_popcountll(b & lt_mask);
+          hb[at] = ((uint64_t)hh[s_] << 32) | hl[s_];
+          pb[at] = (uint8_t)p[s_];
+        }
+        off += (uint32_t)__builtin_popcountll(b);
+      }
+      if (lane == 0u) lb[rbuf] = done + nbuf;
+      nbuf = off;
       ++rbuf;
     }
     flush();

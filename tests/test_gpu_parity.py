@@ -1158,6 +1158,7 @@ def _minimizers_brute(pos, hashes, nwin, w):
     (64, 700, 64, 19, True, False), (40, 1500, 101, 25, True, False),
     (2500, 150, 31, 12, True, True),     # several rounds of reads (NTHIP_TUNE_BLOOM_ROUND)
     (5000, 150, 31, 10, True, False), (3000, 101, 21, 5, True, False), (2000, 158, 31, 128, True, False),
+    (3000, 250, 31, 10, True, False), (1500, 286, 31, 200, True, False), (1000, 200, 21, 65, True, False),   # four register sets
 ])
 def test_minimizers_match_brute_force_on_oracle_stream(oracle, n, L, k, w, dirty, rounds):
     """nthip_kmer_minimizers: per read, of every w consecutive window positions the emitted k-mer with the smallest
@@ -1214,6 +1215,8 @@ def test_minimizers_match_brute_force_on_oracle_stream(oracle, n, L, k, w, dirty
     (300, 94, 31, 16), (300, 95, 31, 17), (300, 93, 31, 63),        # 64 / 65 / 63 windows
     (500, 31, 31, 4), (400, 32, 31, 2), (300, 100, 64, 37), (300, 250, 160, 12),
     (70000, 36, 21, 7),                                             # chunks of several reads per wave
+    (600, 250, 31, 10), (300, 250, 31, 1), (300, 250, 31, 64), (300, 250, 31, 129), (200, 250, 31, 220), (200, 250, 31, 900),
+    (300, 286, 31, 100), (300, 159, 31, 17), (300, 222, 31, 128), (20000, 250, 31, 19),   # 129 ... 256 windows: four register sets
 ])
 @pytest.mark.parametrize("table", [False, True])
 def test_minimizers_of_clean_short_reads(oracle, n, L, k, w, table):
@@ -1277,6 +1280,7 @@ def test_minimizers_of_clean_short_reads(oracle, n, L, k, w, table):
     (60, 3000, 31, 19, True),                                  # reads on both sides of the 1024-window limit of the wave tables
     (500, 90, 25, 4, False),
     (600, 150, 31, 10, True), (600, 158, 31, 1, True), (300, 120, 31, 200, True),   # at most 128 windows: the register tables
+    (600, 280, 31, 10, True), (400, 286, 31, 130, False), (400, 250, 25, 1, True),      # at most 256: four register sets
 ])
 def test_minimizers_of_reads_given_by_offsets(oracle, ctx, n, lmax, k, w, dirty):
     """the same brute force, reads of any lengths (offsets): empty reads, reads shorter than k, reads of exactly k bases"""

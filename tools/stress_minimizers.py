@@ -22,7 +22,7 @@ for it in range(iters):
     k = int(rng.integers(3, 65)) if rng.random() < 0.8 else int(rng.integers(65, 200))
     w = int(rng.integers(1, 40)) if rng.random() < 0.8 else int(rng.integers(40, 300))
     var = rng.random() < 0.4
-    nwin_max = int(rng.integers(1, 129))
+    nwin_max = int(rng.integers(1, 129)) if rng.random() < 0.6 else int(rng.integers(129, 257))
     L = k + nwin_max - 1
     n = int(rng.integers(1, 200_000 // L + 2)) if rng.random() < 0.8 else int(rng.integers(50_000, 200_000))
     if var:
