@@ -241,6 +241,10 @@ int nthip_kmer_minhash(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uin
  * the unfused baseline, and the consumer for shapes the fused kernels do not take */
 int nthip_stream_bloom_insert(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t n_values,
                               uint8_t* d_filter, uint64_t n_bits);
+/* membership of every k-mer of a stream (m values per k-mer, as nthip_kmer_hash writes them): d_flags[i] = 1 when all m bits
+ * of k-mer i are set (btllib's contains()), else 0; *found (optional) = the number of ones.  Device memory throughout. */
+int nthip_stream_bloom_query(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t n_kmers, uint8_t m,
+                             const uint8_t* d_filter, uint64_t n_bits, uint8_t* d_flags, uint64_t* found);
 
 /* k-mer counting sketch (count-min, one-byte counters): every hash value of the batch -- m per k-mer NtHash emits -- adds
  * one to counter (h mod n_counters), saturating at 255; nthip_stream_count_query gives a k-mer's estimate, the smallest

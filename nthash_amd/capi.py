@@ -44,6 +44,7 @@ SYMBOLS = [
     "nthip_multi_seeds_create", "nthip_multi_seeds_destroy", "nthip_multi_seed_hash",
     "nthip_packed_size", "nthip_pack_reads", "nthip_multi_fastx_kmer_hash_file", "nthip_host_alloc", "nthip_host_free",
     "nthip_kmer_count_insert", "nthip_stream_count_insert", "nthip_stream_count_query", "nthip_kmer_minimizers",
+    "nthip_stream_bloom_query",
 ]
 
 
@@ -122,6 +123,7 @@ def load():
     L.nthip_stream_bloom_insert.argtypes = [vp, vp, u64, vp, u64]
     L.nthip_kmer_count_insert.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, u64, C.POINTER(u64), u32]
     L.nthip_stream_count_insert.argtypes = [vp, vp, u64, vp, u64]
+    L.nthip_stream_bloom_query.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp, C.POINTER(u64)]
     L.nthip_stream_count_query.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp]
     L.nthip_kmer_minimizers.argtypes = [vp, C.POINTER(Reads), C.c_uint16, u32, vp, vp, vp, u64, C.POINTER(u64), u32]
     L.nthip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
@@ -440,6 +442,13 @@ class Context:
             offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         return self.count_insert_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, d_counters, n_counters,
                                      flags=NTHIP_HOST_INPUT, offsets=offsets.ctypes.data if offsets is not None else 0)
+
+    def stream_bloom_query_ptr(self, d_hashes, n_kmers, m, d_filter, n_bits, d_flags):
+        """d_flags[i] = 1 when all m bits of k-mer i are set; -> the number of such k-mers"""
+        found = C.c_uint64(0)
+        _chk(self.L.nthip_stream_bloom_query(self.h, C.c_void_p(d_hashes), C.c_uint64(n_kmers), C.c_uint8(m), C.c_void_p(d_filter),
+                                             C.c_uint64(n_bits), C.c_void_p(d_flags), C.byref(found)))
+        return found.value
 
     def stream_count_insert_ptr(self, d_hashes, n_values, d_counters, n_counters):
         _chk(self.L.nthip_stream_count_insert(self.h, C.c_void_p(d_hashes), C.c_uint64(n_values), C.c_void_p(d_counters),

@@ -400,6 +400,26 @@ static __global__ __launch_bounds__(256) void count_query_kernel(const uint64_t*
 }
 
 
+// Bloom membership of every k-mer of a hash stream (m values per k-mer, as nthip_kmer_hash writes them): out[i] = 1 when all
+// m bits of k-mer i are set, else 0; *found += the number of ones
+static __global__ __launch_bounds__(256) void stream_bloom_flags_kernel(const uint64_t* __restrict__ hashes, uint64_t n_kmers, uint32_t m,
+                                                                        const uint32_t* __restrict__ bloom, uint64_t n_bits, uint64_t magic,
+                                                                        uint8_t* __restrict__ out, unsigned long long* __restrict__ found)
+{
+  uint32_t mine = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_kmers; i += (uint64_t)gridDim.x * blockDim.x) {
+    bool hit = true;
+    for (uint32_t j = 0; j < m; ++j) {
+      const uint64_t p = mod_invariant(hashes[i * m + j], n_bits, magic);
+      hit = hit && ((bloom[p >> 5] >> ((uint32_t)p & 31u)) & 1u);
+    }
+    out[i] = hit ? 1 : 0;
+    mine += hit ? 1u : 0u;
+  }
+  for (int d = 32; d > 0; d >>= 1) mine += (uint32_t)__shfl_xor((int)mine, d, 64);
+  if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(found, (unsigned long long)mine);
+}
+
 // Bloom membership of the k-mers of a hash stream, per READ (reads of any lengths: the stream's read r is k-mers
 // roff[r] ... roff[r + 1], m values each): hits[r] = number of its k-mers whose m bits are all set.  One wave per read
 // at a time; the loads of the filter are what it waits for (four k-mers per lane in flight).

@@ -418,6 +418,29 @@ int check_sketch(const void* d_counters, uint64_t n_counters)
 }
 } // namespace
 
+extern "C" int nthip_stream_bloom_query(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_kmers, uint8_t m, const uint8_t* d_filter,
+                                        uint64_t n_bits, uint8_t* d_flags, uint64_t* found)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  if (!d_filter || n_bits == 0) return fail(NTHIP_ERR_ARG, "filter is NULL / n_bits is 0");
+  if ((uintptr_t)d_filter & 3u) return fail(NTHIP_ERR_ARG, "filter must be 4-byte aligned");
+  if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
+  if (n_kmers && (!d_hashes || !d_flags)) return fail(NTHIP_ERR_ARG, "hashes / flags is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  if (found) *found = 0;
+  if (n_kmers == 0) return NTHIP_OK;
+  HIPCHK(hipMemsetAsync(c->d_small + 24, 0, 8, c->stream));
+  prof_begin(c, "stream_bloom_flags_kernel");
+  hipLaunchKernelGGL(stream_bloom_flags_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, d_hashes, n_kmers, (uint32_t)m,
+                     (const uint32_t*)d_filter, n_bits, bloom_magic_of(n_bits), d_flags, (unsigned long long*)(c->d_small + 24));
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_small + 24, c->d_small + 24, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (found) memcpy(found, c->h_small + 24, 8);
+  return NTHIP_OK;
+}
+
 extern "C" int nthip_stream_count_insert(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, uint8_t* d_counters,
                                          uint64_t n_counters)
 {

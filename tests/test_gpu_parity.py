@@ -1495,6 +1495,16 @@ def test_consumers_take_reads_given_by_offsets(ctx, oracle, n, lmax, k, m, n_bit
         hits, total, found = ctx.bloom_query(b, k, m, 0, n, d_f, n_bits, offsets=offs)
     assert total == hb["total"] and found == int(want_hits.sum())
     assert (hits == want_hits).all()
+    # the same question per k-mer on the stream (nthip_stream_bloom_query)
+    hs = np.ascontiguousarray(hb["hashes"]).ravel()
+    if hs.size:
+        d_hs, d_fl = ctx.malloc(hs.nbytes), ctx.malloc(hb["total"] + 16)
+        ctx.h2d(d_hs, hs)
+        assert ctx.stream_bloom_query_ptr(d_hs, hb["total"], m, d_f, n_bits, d_fl) == int(present.sum())
+        fl = np.zeros(hb["total"], np.uint8)
+        ctx.d2h(fl, d_fl)
+        assert (fl == present.astype(np.uint8)).all()
+        ctx.free(d_hs); ctx.free(d_fl)
     # counting sketch
     n_counters = 1 << 18
     d_c = ctx.malloc(n_counters)
