@@ -1860,6 +1860,38 @@ def test_fastx_file_stream_vs_oracle(ctx, oracle, tmp_path, fmt, chunk, final_ne
     assert (np.concatenate(got_h) == want["hashes"].ravel()).all()
 
 
+def test_fastx_file_batches_into_the_stream_consumers(ctx, oracle, tmp_path):
+    """a FASTQ file end to end into a Bloom filter and a counting sketch: the stream consumers called on every batch from
+    inside the driver's callback, with the driver's own context -- filter and counters == those of the
+    oracle's stream over the parsed reads"""
+    rng = np.random.default_rng(321)
+    buf, seqs = _make_fastx(rng, 5000, 4, lo=20, hi=300)
+    path = tmp_path / "reads.fq"
+    path.write_bytes(buf)
+    k, m, n_bits, n_counters = 31, 2, 3_000_017, 1 << 18
+    data, offs = concat_reads(seqs)
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    d_f, nbytes = ctx.bloom_new(n_bits)
+    d_c = ctx.malloc(n_counters)
+    ctx.memset(d_c, 0, n_counters)
+
+    def on_batch(b):
+        if b.n_kmers:
+            ctx.stream_bloom_insert_ptr(b.hashes, b.n_kmers * m, d_f, n_bits)
+            ctx.stream_count_insert_ptr(b.hashes, b.n_kmers * m, d_c, n_counters)
+
+    st = ctx.fastx_kmer_hash_file(path, 4, k, m, chunk_bytes=1 << 17, on_batch=on_batch)
+    assert st.kmers == want["total"] and st.batches > 2
+    got = np.zeros(nbytes, np.uint8)
+    ctx.d2h(got, d_f)
+    assert (got == _bloom_expected(want["hashes"], n_bits)).all()
+    tally = np.bincount((np.ascontiguousarray(want["hashes"]).ravel() % np.uint64(n_counters)).astype(np.int64), minlength=n_counters)
+    cnt = np.zeros(n_counters, np.uint8)
+    ctx.d2h(cnt, d_c)
+    assert (cnt == np.minimum(tally, 255).astype(np.uint8)).all()
+    ctx.free(d_f); ctx.free(d_c)
+
+
 @pytest.mark.parametrize("fmt,crlf,chunk,final_newline,devices", [
     (4, False, 1 << 16, True, [0, 0, 0]), (4, True, 70_000, False, [0, 0]), (2, False, 1 << 16, True, [0, 0, 0, 0]),
     (4, False, 1 << 22, True, [0, 0, 0]), (4, False, 1 << 16, True, None)])
