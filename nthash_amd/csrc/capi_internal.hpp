@@ -136,6 +136,7 @@ struct nthip_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
   const char* last_kernel = "";
+  bool pos_listed_only = false; // (internal, nthip_kmer_minimizers) NTHIP_OUT_READ_SLOTS on fixed-length reads: positions of the redone reads only
   bool async_pending = false; // NTHIP_ASYNC launches since the last nthip_ctx_take_dirty: d_small[0] accumulates
   nthip_tune tune;
   // blocks per CU of (kernel, dynamic LDS) pairs already configured

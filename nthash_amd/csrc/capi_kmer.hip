@@ -308,7 +308,7 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
                            (uint64_t)nwin);
         HIPCHK(hipGetLastError());
       }
-      if (st.pos) { // get_pos() of a read of bases only: the window index
+      if (st.pos && !(fslots && c->pos_listed_only)) { // get_pos() of a read of bases only: the window index
         hipLaunchKernelGGL(fill_window_pos_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, st.pos, rd->n_reads, nwin,
                            (const uint64_t*)nullptr, (const uint64_t*)nullptr);
         HIPCHK(hipGetLastError());

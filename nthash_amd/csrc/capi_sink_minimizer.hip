@@ -271,7 +271,9 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
         } else {
           out.counts = d_counts;
           out.pos = d_pos;
+          c->pos_listed_only = true; // (a read that fills its slot has its k-mers at their window indices: the kernel knows)
           rc = nthip_kmer_hash(c, &part, k16, 1, &out, &n_kmers, NTHIP_OUT_READ_SLOTS);
+          c->pos_listed_only = false;
           if (rc == NTHIP_OK) slots = settled = true;
           else if (rc != NTHIP_ERR_UNSUPPORTED) return rc;
           out.counts = nullptr;

@@ -341,26 +341,50 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
     // sparse: the k-mers (hash, position) of read r + 1 are in flight; s_* / c_*: first k-mer (relative to the chunk's)
     // and number of k-mers of read r (cur) / r + 1 (nxt)
     uint32_t pp0 = 0, pp1 = 0, s_cur = 0, c_cur = 0, s_nxt = 0, c_nxt = 0;
-    auto geom = [&](const uint32_t rr, uint32_t& st, uint32_t& cn) { // read rr of the chunk
-      const uint64_t g = r0 + rr;
-      if (g >= a.n_reads) {
-        st = 0;
-        cn = 0;
-      } else if (a.counts != nullptr) {
-        st = rr * a.nwin;
-        cn = (uint32_t)a.counts[g];
-      } else {
-        const uint64_t b = a.roff[g], e = g + 1u < a.n_reads ? a.roff[g + 1u] : a.n_kmers;
-        st = (uint32_t)(b - kb);
-        cn = (uint32_t)(e - b);
+    // the geometry of 64 consecutive reads of the chunk at a time, a read per lane (a scalar value that comes through a
+    // vector load is a wait for everything in flight: once per 64 reads instead of once per read), handed out by readlane
+    uint32_t g_st = 0, g_cn = 0, g_len = 0, g_blk = ~0u, l_blk = ~0u;
+    auto geom = [&](const uint32_t rr, uint32_t& st, uint32_t& cn) { // read rr of the chunk: first k-mer (relative), k-mers
+      const uint32_t blk = rr >> 6;
+      if (blk != g_blk) { // (wave-uniform)
+        const uint32_t rl = blk * 64u + lane;
+        const uint64_t g = r0 + rl;
+        g_st = 0;
+        g_cn = 0;
+        if (g < a.n_reads) {
+          if (a.counts != nullptr) {
+            g_st = rl * a.nwin;
+            g_cn = (uint32_t)a.counts[g];
+          } else {
+            const uint64_t b = a.roff[g], e = g + 1u < a.n_reads ? a.roff[g + 1u] : a.n_kmers;
+            g_st = (uint32_t)(b - kb);
+            g_cn = (uint32_t)(e - b);
+          }
+        }
+        g_blk = blk;
       }
+      st = (uint32_t)__builtin_amdgcn_readlane((int)g_st, (int)(rr & 63u));
+      cn = (uint32_t)__builtin_amdgcn_readlane((int)g_cn, (int)(rr & 63u));
     };
+    auto read_len = [&](const uint32_t rr) -> uint32_t { // bases of read rr of the chunk (reads given by offsets)
+      const uint32_t blk = rr >> 6;
+      if (blk != l_blk) {
+        const uint64_t g = r0 + blk * 64u + lane;
+        uint64_t l = 0;
+        if (g < a.n_reads) l = a.offsets[g + 1u] - a.offsets[g];
+        g_len = l < 0xFFFFFFFFull ? (uint32_t)l : 0xFFFFFFFFu;
+        l_blk = blk;
+      }
+      return (uint32_t)__builtin_amdgcn_readlane((int)g_len, (int)(rr & 63u));
+    };
+    // (read-slots form: a read that fills its slot -- counts[r] == nwin, no non-base -- has its k-mers at their window
+    //  indices; its positions are neither stored nor read, and it needs no layout through LDS)
     auto load_sparse = [&](const uint32_t i0, const uint32_t cn) {
       const uint32_t i1 = i0 + cn;
       if (cn != 0u) { // (wave-uniform)
         const uint32_t e0 = i0 + lane < i1 ? i0 + lane : i1 - 1u, e1 = i0 + 64u + lane < i1 ? i0 + 64u + lane : i1 - 1u;
         pf0 = hc[e0];
-        pp0 = pc[e0];
+        pp0 = pc[e0]; // (of a read that fills its slot: not written, not used -- loaded all the same: no branch among the loads)
         if constexpr (!ONE) {
           pf1 = hc[e1];
           pp1 = pc[e1];
@@ -384,8 +408,8 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
       if constexpr (SPARSE) {
         const uint32_t cnt = c_cur; // k-mers of the read (<= its windows)
         if (a.offsets != nullptr) {         // this read's windows
-          const uint64_t l = a.offsets[r0 + r + 1u] - a.offsets[r0 + r];
-          nwin = l >= a.k ? (uint32_t)(l - a.k + 1u) : 0u;
+          const uint32_t l = read_len(r);
+          nwin = l >= a.k ? l - a.k + 1u : 0u;
           w = a.w < nwin ? a.w : nwin;
           n_starts = nwin - w + 1u;
           J = 0;
@@ -394,7 +418,8 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
           v0 = lane < n_starts;
           v1 = lane + 64u < n_starts;
         }
-        if (cnt != 0u) {
+        const bool full = a.counts != nullptr && cnt == a.nwin;
+        if (cnt != 0u && !full) {
           A[lane] = ~0ull;
           if constexpr (!ONE) A[lane + 64u] = ~0ull;
           wave_sync();
@@ -403,7 +428,8 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
             if (lane + 64u < cnt) A[pp1] = pf1;
           wave_sync();
         }
-        const uint64_t x0 = cnt != 0u ? A[lane] : ~0ull, x1 = !ONE && cnt != 0u ? A[lane + 64u] : ~0ull;
+        const uint64_t x0 = full ? pf0 : cnt != 0u ? A[lane] : ~0ull;
+        const uint64_t x1 = ONE ? ~0ull : full ? pf1 : cnt != 0u ? A[lane + 64u] : ~0ull;
         h0l = (uint32_t)x0; h0h = (uint32_t)(x0 >> 32); h1l = (uint32_t)x1; h1h = (uint32_t)(x1 >> 32);
         s_cur = s_nxt;
         c_cur = c_nxt;
@@ -565,19 +591,41 @@ static __global__ __launch_bounds__(256) void minimizer_regn_kernel(const Minimi
     uint64_t pf[NS];
     uint32_t pp[NS];
     uint32_t s_cur = 0, c_cur = 0, s_nxt = 0, c_nxt = 0;
-    auto geom = [&](const uint32_t rr, uint32_t& st, uint32_t& cn) {
-      const uint64_t g = r0 + rr;
-      if (g >= a.n_reads) {
-        st = 0;
-        cn = 0;
-      } else if (a.counts != nullptr) {
-        st = rr * a.nwin;
-        cn = (uint32_t)a.counts[g];
-      } else {
-        const uint64_t b = a.roff[g], e = g + 1u < a.n_reads ? a.roff[g + 1u] : a.n_kmers;
-        st = (uint32_t)(b - kb);
-        cn = (uint32_t)(e - b);
+    // the geometry of 64 consecutive reads of the chunk at a time, a read per lane (a scalar value that comes through a
+    // vector load is a wait for everything in flight: once per 64 reads instead of once per read), handed out by readlane
+    uint32_t g_st = 0, g_cn = 0, g_len = 0, g_blk = ~0u, l_blk = ~0u;
+    auto geom = [&](const uint32_t rr, uint32_t& st, uint32_t& cn) { // read rr of the chunk: first k-mer (relative), k-mers
+      const uint32_t blk = rr >> 6;
+      if (blk != g_blk) { // (wave-uniform)
+        const uint32_t rl = blk * 64u + lane;
+        const uint64_t g = r0 + rl;
+        g_st = 0;
+        g_cn = 0;
+        if (g < a.n_reads) {
+          if (a.counts != nullptr) {
+            g_st = rl * a.nwin;
+            g_cn = (uint32_t)a.counts[g];
+          } else {
+            const uint64_t b = a.roff[g], e = g + 1u < a.n_reads ? a.roff[g + 1u] : a.n_kmers;
+            g_st = (uint32_t)(b - kb);
+            g_cn = (uint32_t)(e - b);
+          }
+        }
+        g_blk = blk;
       }
+      st = (uint32_t)__builtin_amdgcn_readlane((int)g_st, (int)(rr & 63u));
+      cn = (uint32_t)__builtin_amdgcn_readlane((int)g_cn, (int)(rr & 63u));
+    };
+    auto read_len = [&](const uint32_t rr) -> uint32_t { // bases of read rr of the chunk (reads given by offsets)
+      const uint32_t blk = rr >> 6;
+      if (blk != l_blk) {
+        const uint64_t g = r0 + blk * 64u + lane;
+        uint64_t l = 0;
+        if (g < a.n_reads) l = a.offsets[g + 1u] - a.offsets[g];
+        g_len = l < 0xFFFFFFFFull ? (uint32_t)l : 0xFFFFFFFFu;
+        l_blk = blk;
+      }
+      return (uint32_t)__builtin_amdgcn_readlane((int)g_len, (int)(rr & 63u));
     };
     auto load_read = [&](const uint32_t i0, const uint32_t cn) { // the read's k-mers (dense: its windows), a lane past the last one loads it again
       if (cn != 0u) {
@@ -585,7 +633,7 @@ static __global__ __launch_bounds__(256) void minimizer_regn_kernel(const Minimi
         for (uint32_t s_ = 0; s_ < NS; ++s_) {
           const uint32_t e = i0 + (s_ * 64u + lane < cn ? s_ * 64u + lane : cn - 1u);
           pf[s_] = hc[e];
-          if constexpr (SPARSE) pp[s_] = pc[e];
+          if constexpr (SPARSE) pp[s_] = pc[e]; // (of a read that fills its slot: not written, not used)
         }
       }
     };
@@ -609,15 +657,16 @@ static __global__ __launch_bounds__(256) void minimizer_regn_kernel(const Minimi
       const uint32_t cnt = c_cur;
       if constexpr (SPARSE) {
         if (a.offsets != nullptr) {
-          const uint64_t l = a.offsets[r0 + r + 1u] - a.offsets[r0 + r];
-          nwin = l >= a.k ? (uint32_t)(l - a.k + 1u) : 0u;
+          const uint32_t l = read_len(r);
+          nwin = l >= a.k ? l - a.k + 1u : 0u;
           w = a.w < nwin ? a.w : nwin;
           n_starts = nwin - w + 1u;
           J = 0;
           while ((2u << J) <= w) ++J;
           q = w - (1u << J);
         }
-        if (cnt != 0u) {
+        const bool full = a.counts != nullptr && cnt == a.nwin;
+        if (cnt != 0u && !full) {
 #pragma unroll
           for (uint32_t s_ = 0; s_ < NS; ++s_) A[s_ * 64u + lane] = ~0ull;
           wave_sync();
@@ -628,7 +677,7 @@ static __global__ __launch_bounds__(256) void minimizer_regn_kernel(const Minimi
         }
 #pragma unroll
         for (uint32_t s_ = 0; s_ < NS; ++s_) {
-          const uint64_t x = cnt != 0u ? A[s_ * 64u + lane] : ~0ull;
+          const uint64_t x = full ? pf[s_] : cnt != 0u ? A[s_ * 64u + lane] : ~0ull;
           hl[s_] = (uint32_t)x;
           hh[s_] = (uint32_t)(x >> 32);
         }
