@@ -418,7 +418,7 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
           v0 = lane < n_starts;
           v1 = lane + 64u < n_starts;
         }
-        const bool full = a.counts != nullptr && cnt == a.nwin;
+        const bool full = cnt == nwin && cnt != 0u; // every window of the read is there: the k-mers stand at their window indices
         if (cnt != 0u && !full) {
           A[lane] = ~0ull;
           if constexpr (!ONE) A[lane + 64u] = ~0ull;
@@ -665,7 +665,7 @@ static __global__ __launch_bounds__(256) void minimizer_regn_kernel(const Minimi
           while ((2u << J) <= w) ++J;
           q = w - (1u << J);
         }
-        const bool full = a.counts != nullptr && cnt == a.nwin;
+        const bool full = cnt == nwin && cnt != 0u; // every window of the read is there: the k-mers stand at their window indices
         if (cnt != 0u && !full) {
 #pragma unroll
           for (uint32_t s_ = 0; s_ < NS; ++s_) A[s_ * 64u + lane] = ~0ull;
