@@ -471,6 +471,7 @@ class Workload:
 def consumers(torch, ctx, dev, n_reads=20_000_000):
     """What the reference's callers do with hashes(), on the device: whole-call rates on 20 M x 150 bp
     (k = 31), each with a cheap exact or necessary check.  Not part of `value`; N = 1 only."""
+    import numpy as np
     L, k = 150, 31
     nwin = L - k + 1
     kmers = n_reads * nwin
@@ -538,7 +539,14 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
         out["minimizers_w10"] = {"value": kmers / t_m, "ms": t_m * 1e3, "minimizers": totm, "density": dens,
                                  "check": "density within 10 % of 2 / (w + 1); offsets ascending, last == total",
                                  "ok": bool(mono and abs(dens - 2 / (w + 1)) < 0.1 * 2 / (w + 1))}
-        for p in (d_h, d_p, d_o):
+        # the same reads given by offsets (what a FASTQ batch looks like to the consumer): the same minimizers
+        d_of = ctx.malloc((n_reads + 1) * 8)
+        owned.append(d_of)
+        ctx.h2d(d_of, np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L))
+        t_mo, totmo = best(lambda: ctx.minimizers_ptr(d_in, n_reads, 0, 0, k, w, d_h, d_p, d_o, cap, offsets=d_of))
+        out["minimizers_w10_offsets"] = {"value": kmers / t_mo, "ms": t_mo * 1e3, "minimizers": totmo,
+                                         "check": "as many minimizers as the fixed-length call", "ok": bool(totmo == totm)}
+        for p in (d_h, d_p, d_o, d_of):
             ctx.free(p)
             owned.remove(p)
         # per-read MinHash, 4 hashes per k-mer (fused: no stream is written)

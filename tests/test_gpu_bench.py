@@ -131,6 +131,6 @@ def test_bench_consumers_section():
     """bench.py's `consumers` object (Bloom insert / query, counting sketch, minimizers, MinHash on device-resident reads),
     at a tenth of its size: every check it carries holds"""
     res = run_bench("--consumers-reads", "2000000")["consumers"]
-    for key in ("bloom_insert_fresh_4GiB", "count_insert_fresh_1Gi_counters", "minimizers_w10", "minhash_m4"):
+    for key in ("bloom_insert_fresh_4GiB", "count_insert_fresh_1Gi_counters", "minimizers_w10", "minimizers_w10_offsets", "minhash_m4"):
         assert res[key]["ok"] is True and res[key]["value"] > 0, (key, res[key])
     assert res["bloom_query_4GiB"]["value"] > 0
