@@ -286,6 +286,13 @@ int nthip_kmer_hash_spans(nthip_ctx* ctx, const char* d_buf, uint64_t buf_bytes,
                           const uint64_t* d_ends, uint64_t n_reads, uint16_t k, uint8_t m,
                           const nthip_out* out, uint64_t* total, uint32_t flags);
 
+/* nthip_kmer_minimizers for reads given as spans of one device buffer (the sequence lines of a raw FASTQ chunk, as
+ * nthip_fastx_index finds them): the same picks, in the order of the spans.  Device pointers throughout; one round. */
+int nthip_kmer_minimizers_spans(nthip_ctx* ctx, const char* d_buf, uint64_t buf_bytes, const uint64_t* d_starts,
+                                const uint64_t* d_ends, uint64_t n_reads, uint16_t k, uint32_t w,
+                                uint64_t* d_min_hashes, uint32_t* d_min_pos, uint64_t* d_min_offsets, uint64_t capacity,
+                                uint64_t* total);
+
 /* nthip_seed_hash over spans: as nthip_seed_hash (the reference's position state machine, App. B Q3) */
 int nthip_seed_hash_spans(nthip_ctx* ctx, const char* d_buf, uint64_t buf_bytes, const uint64_t* d_starts,
                           const uint64_t* d_ends, uint64_t n_reads, const nthip_seeds* seeds, uint8_t m2,

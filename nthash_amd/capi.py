@@ -44,7 +44,7 @@ SYMBOLS = [
     "nthip_multi_seeds_create", "nthip_multi_seeds_destroy", "nthip_multi_seed_hash",
     "nthip_packed_size", "nthip_pack_reads", "nthip_multi_fastx_kmer_hash_file", "nthip_host_alloc", "nthip_host_free",
     "nthip_kmer_count_insert", "nthip_stream_count_insert", "nthip_stream_count_query", "nthip_kmer_minimizers",
-    "nthip_stream_bloom_query",
+    "nthip_stream_bloom_query", "nthip_kmer_minimizers_spans",
 ]
 
 
@@ -126,6 +126,7 @@ def load():
     L.nthip_stream_bloom_query.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp, C.POINTER(u64)]
     L.nthip_stream_count_query.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp]
     L.nthip_kmer_minimizers.argtypes = [vp, C.POINTER(Reads), C.c_uint16, u32, vp, vp, vp, u64, C.POINTER(u64), u32]
+    L.nthip_kmer_minimizers_spans.argtypes = [vp, vp, u64, vp, vp, u64, C.c_uint16, u32, vp, vp, vp, u64, C.POINTER(u64)]
     L.nthip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.nthip_host_free.argtypes = [vp]
     L.nthip_kmer_hash_spans.argtypes = [vp, vp, u64, vp, vp, u64, C.c_uint16, C.c_uint8, C.POINTER(Out),
@@ -389,6 +390,19 @@ class Context:
         total = C.c_uint64(0)
         rc = self.L.nthip_kmer_minimizers(self.h, C.byref(rd), k, w, C.c_void_p(d_hashes), C.c_void_p(d_pos) if d_pos else None,
                                           C.c_void_p(d_offsets), C.c_uint64(capacity), C.byref(total), flags)
+        if rc != NTHIP_OK:
+            err = NtHipError(rc, self.L.nthip_last_error().decode(errors="replace"))
+            err.total = total.value
+            raise err
+        return total.value
+
+    def minimizers_spans_ptr(self, d_buf, buf_bytes, d_starts, d_ends, n_reads, k, w, d_hashes, d_pos, d_offsets, capacity):
+        """minimizers of reads given as spans of a device buffer; -> number of minimizers"""
+        total = C.c_uint64(0)
+        rc = self.L.nthip_kmer_minimizers_spans(self.h, C.c_void_p(d_buf), C.c_uint64(buf_bytes), C.c_void_p(d_starts), C.c_void_p(d_ends),
+                                                C.c_uint64(n_reads), C.c_uint16(k), C.c_uint32(w), C.c_void_p(d_hashes),
+                                                C.c_void_p(d_pos) if d_pos else None, C.c_void_p(d_offsets), C.c_uint64(capacity),
+                                                C.byref(total))
         if rc != NTHIP_OK:
             err = NtHipError(rc, self.L.nthip_last_error().decode(errors="replace"))
             err.total = total.value

@@ -11,7 +11,7 @@ namespace {
 
 // one round of reads of at most MZ_REG_POS windows through minimizer_reg_kernel + minimizer_gather_kernel
 // d_slot_counts: the read-slots form (read r's k-mers at r * nwin); else d_roff; both NULL: every read emits every one of its nwin windows (positions = indices); d_lpre / d_ctot / d_coff: n_reads u64 each
-int minimizers_reg_round(nthip_ctx* c, uint64_t* d_h, uint32_t* d_pos, const uint64_t* d_roff, const uint64_t* d_slot_counts, uint64_t n_kmers, const uint64_t* d_offsets,
+int minimizers_reg_round(nthip_ctx* c, uint64_t* d_h, uint32_t* d_pos, const uint64_t* d_roff, const uint64_t* d_slot_counts, uint64_t n_kmers, const uint64_t* d_offsets, const uint64_t* d_ends,
                          uint32_t k, uint64_t nr, uint32_t nwin, uint32_t w, uint64_t* d_lpre, uint64_t* d_ctot, uint64_t* d_coff,
                          uint64_t* d_sums, uint64_t* d_tot, uint64_t base, uint64_t capacity, uint64_t* d_min_hashes,
                          uint32_t* d_min_pos, uint64_t* d_min_offsets, uint64_t* round_total)
@@ -33,6 +33,7 @@ int minimizers_reg_round(nthip_ctx* c, uint64_t* d_h, uint32_t* d_pos, const uin
   da.counts = d_slot_counts;
   da.n_kmers = n_kmers;
   da.offsets = d_offsets;
+  da.ends = d_ends;
   da.k = k;
   da.lpre = d_lpre;
   da.ctot = d_ctot;
@@ -62,27 +63,16 @@ int minimizers_reg_round(nthip_ctx* c, uint64_t* d_h, uint32_t* d_pos, const uin
   return NTHIP_OK;
 }
 
-// reads of any lengths (offsets): ONE round -- the emitted stream of the whole batch (at most one k-mer per base) in the
-// context's scratch; the kernels take every read's window count from its length
-int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint32_t w, uint64_t* d_min_hashes, uint32_t* d_min_pos,
-                          uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out, uint32_t flags)
+// reads of any lengths, device-resident -- read r = [d_starts[r], d_ends ? d_ends[r] : d_starts[r + 1]) of d_seqs --: ONE
+// round, the emitted stream of the whole batch (at most one k-mer per byte of the buffer) in the context's scratch; the
+// kernels take every read's window count from its length
+int minimizers_of_spans(nthip_ctx* c, const uint8_t* d_seqs, uint64_t total_bytes, const uint64_t* d_starts, const uint64_t* d_ends,
+                        uint64_t n, uint64_t max_len, uint16_t k16, uint32_t w, uint64_t* d_min_hashes, uint32_t* d_min_pos,
+                        uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out)
 {
   const uint32_t k = k16;
-  const uint64_t n = rd->n_reads;
-  if (n == 0) {
-    HIPCHK(hipMemsetAsync(d_min_offsets, 0, sizeof(uint64_t), c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return NTHIP_OK;
-  }
-  uint64_t total_bytes = 0;
-  NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
-  Staged st;
-  NTCHK(stage_inputs(c, rd, flags & NTHIP_HOST_INPUT, total_bytes, st));
-  OffsetsSurvey sv;
-  NTCHK(offsets_survey_device(c, st.offsets, n, total_bytes, &sv));
-  if (sv.bad) return fail(NTHIP_ERR_ARG, "offsets are not non-decreasing or reach outside the read buffer");
-  const uint64_t max_nwin64 = sv.max_len >= k ? sv.max_len - k + 1 : 0;
-  if (max_nwin64 > 0xFFFFFFFFull) return fail(NTHIP_ERR_UNSUPPORTED, "a read of %llu bases: window positions are 32 bits wide", (unsigned long long)sv.max_len);
+  const uint64_t max_nwin64 = max_len >= k ? max_len - k + 1 : 0;
+  if (max_nwin64 > 0xFFFFFFFFull) return fail(NTHIP_ERR_UNSUPPORTED, "a read of %llu bases: window positions are 32 bits wide", (unsigned long long)max_len);
   const uint32_t max_nwin = (uint32_t)max_nwin64;
   if (max_nwin == 0) { // no read has a window
     HIPCHK(hipMemsetAsync(d_min_offsets, 0, (n + 1) * sizeof(uint64_t), c->stream));
@@ -117,11 +107,6 @@ int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uin
   uint64_t* d_ooff = (uint64_t*)p; p += b_rd;
   uint64_t* d_sums = (uint64_t*)p; p += b_sums;
   uint64_t* d_tot = (uint64_t*)p;
-  nthip_reads dr;
-  memset(&dr, 0, sizeof dr);
-  dr.seqs = (const char*)st.seqs;
-  dr.offsets = st.offsets;
-  dr.n_reads = n;
   nthip_out out;
   memset(&out, 0, sizeof out);
   out.hashes = d_h;
@@ -129,11 +114,20 @@ int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uin
   out.counts = d_counts;
   out.pos = d_pos;
   uint64_t n_kmers = 0;
-  NTCHK(nthip_kmer_hash(c, &dr, k16, 1, &out, &n_kmers, 0));
+  if (d_ends) {
+    NTCHK(nthip_kmer_hash_spans(c, (const char*)d_seqs, total_bytes, d_starts, d_ends, n, k16, 1, &out, &n_kmers, 0));
+  } else {
+    nthip_reads dr;
+    memset(&dr, 0, sizeof dr);
+    dr.seqs = (const char*)d_seqs;
+    dr.offsets = d_starts;
+    dr.n_reads = n;
+    NTCHK(nthip_kmer_hash(c, &dr, k16, 1, &out, &n_kmers, 0));
+  }
   NTCHK(device_exclusive_scan(c, d_counts, d_roff, n, d_sums, d_tot));
   if (max_nwin <= MZ_REGN_POS && !c->tune.mz_table) { // short reads (a FASTQ batch): the tables in registers
     uint64_t total = 0;
-    NTCHK(minimizers_reg_round(c, d_h, d_pos, d_roff, nullptr, n_kmers, st.offsets, k, n, max_nwin, w, d_picked, d_counts, d_ooff, d_sums,
+    NTCHK(minimizers_reg_round(c, d_h, d_pos, d_roff, nullptr, n_kmers, d_starts, d_ends, k, n, max_nwin, w, d_picked, d_counts, d_ooff, d_sums,
                                d_tot + 1, 0, capacity, d_min_hashes, d_min_pos, d_min_offsets, &total));
     HIPCHK(hipMemcpyAsync(d_min_offsets + n, &total, sizeof total, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -152,7 +146,8 @@ int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uin
   a.n_kmers = n_kmers;
   a.nwin = max_nwin;
   a.w = w;
-  a.offsets = st.offsets;
+  a.offsets = d_starts;
+  a.ends = d_ends;
   a.k = k;
   a.masks = d_masks;
   a.chunks = chunks;
@@ -183,6 +178,27 @@ int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uin
     return fail(NTHIP_ERR_CAPACITY, "output capacity %llu minimizers < %llu needed", (unsigned long long)capacity,
                 (unsigned long long)total);
   return NTHIP_OK;
+}
+
+// reads given by offsets (host or device): staged, surveyed, then as spans whose ends are the next starts
+int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint32_t w, uint64_t* d_min_hashes, uint32_t* d_min_pos,
+                          uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out, uint32_t flags)
+{
+  const uint64_t n = rd->n_reads;
+  if (n == 0) {
+    HIPCHK(hipMemsetAsync(d_min_offsets, 0, sizeof(uint64_t), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTHIP_OK;
+  }
+  uint64_t total_bytes = 0;
+  NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
+  Staged st;
+  NTCHK(stage_inputs(c, rd, flags & NTHIP_HOST_INPUT, total_bytes, st));
+  OffsetsSurvey sv;
+  NTCHK(offsets_survey_device(c, st.offsets, n, total_bytes, &sv));
+  if (sv.bad) return fail(NTHIP_ERR_ARG, "offsets are not non-decreasing or reach outside the read buffer");
+  return minimizers_of_spans(c, st.seqs, total_bytes, st.offsets, nullptr, n, sv.max_len, k16, w, d_min_hashes, d_min_pos, d_min_offsets,
+                             capacity, total_out);
 }
 
 } // namespace
@@ -298,7 +314,7 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
       // short reads: the table in registers, the picks compacted in place chunk by chunk, then gathered
       uint64_t round_total = 0;
       // (read-slots form: the counts are an input, the chunks' totals go where the compact form's read offsets would be)
-      NTCHK(minimizers_reg_round(c, d_h, d_pos, dense || slots ? nullptr : d_roff, slots ? d_counts : nullptr, n_kmers, nullptr, k, nr, nwin,
+      NTCHK(minimizers_reg_round(c, d_h, d_pos, dense || slots ? nullptr : d_roff, slots ? d_counts : nullptr, n_kmers, nullptr, nullptr, k, nr, nwin,
                                  w, d_picked, slots ? d_roff : d_counts, d_ooff, d_sums, d_tot + 1, base, capacity, d_min_hashes,
                                  d_min_pos, d_min_offsets + r0, &round_total));
       if (base + round_total > capacity) overflow = true;
@@ -352,4 +368,28 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
     return fail(NTHIP_ERR_CAPACITY, "output capacity %llu minimizers < %llu needed", (unsigned long long)capacity,
                 (unsigned long long)base);
   return NTHIP_OK;
+}
+
+extern "C" int nthip_kmer_minimizers_spans(nthip_ctx* c, const char* d_buf, uint64_t buf_bytes, const uint64_t* d_starts,
+                                           const uint64_t* d_ends, uint64_t n_reads, uint16_t k, uint32_t w, uint64_t* d_min_hashes,
+                                           uint32_t* d_min_pos, uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
+  if (k < 3) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 is undefined in the reference (src/kmer.cpp:47)");
+  if (w == 0) return fail(NTHIP_ERR_ARG, "w must be greater than 0");
+  if (!d_min_offsets || (capacity && !d_min_hashes)) return fail(NTHIP_ERR_ARG, "min_offsets / min_hashes is NULL");
+  if (n_reads && (!d_buf || !d_starts || !d_ends)) return fail(NTHIP_ERR_ARG, "buf / starts / ends is NULL");
+  if (c->async_pending) return fail(NTHIP_ERR_ARG, "NTHIP_ASYNC batches are pending: call nthip_ctx_take_dirty first");
+  HIPCHK(hipSetDevice(c->device));
+  if (total_out) *total_out = 0;
+  if (n_reads == 0) {
+    HIPCHK(hipMemsetAsync(d_min_offsets, 0, sizeof(uint64_t), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTHIP_OK;
+  }
+  uint64_t max_len = 0;
+  NTCHK(check_offsets_device(c, d_starts, d_ends, n_reads, buf_bytes, false, &max_len));
+  return minimizers_of_spans(c, (const uint8_t*)d_buf, buf_bytes, d_starts, d_ends, n_reads, max_len, k, w, d_min_hashes, d_min_pos,
+                             d_min_offsets, capacity, total_out);
 }

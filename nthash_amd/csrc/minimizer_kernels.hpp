@@ -36,6 +36,7 @@ struct MinimizerArgs {
   uint32_t nwin;          // window positions of a read (fixed-length reads: len - k + 1; with offsets: of the longest read)
   uint32_t w;
   const uint64_t* offsets; // reads of any lengths (read r = [offsets[r], offsets[r + 1])): the window positions come from here; else NULL
+  const uint64_t* ends;    // with offsets: read r = [offsets[r], ends[r]) (spans of a raw buffer); NULL: offsets[r + 1]
   uint32_t k, pad1;
   uint64_t* masks;        // [n_reads * chunks] bit l of word (r, c): the k-mer at window position 64 c + l of read r is a minimizer
   uint32_t chunks;        // ceil(nwin / 64)
@@ -86,7 +87,7 @@ static __global__ __launch_bounds__(64 * MZ_WAVES) void minimizer_flag_kernel(co
   for (uint64_t r = wave; r < a.n_reads; r += n_waves) {
     uint32_t nwin = a.nwin;
     if (!DENSE && a.offsets != nullptr) { // reads of any lengths
-      const uint64_t l = a.offsets[r + 1] - a.offsets[r];
+      const uint64_t l = (a.ends != nullptr ? a.ends[r] : a.offsets[r + 1]) - a.offsets[r];
       nwin = l >= a.k ? (l - a.k + 1u < 0xFFFFFFFFull ? (uint32_t)(l - a.k + 1u) : 0xFFFFFFFFu) : 0u;
     }
     if (nwin == 0u) { // (shorter than k: no k-mer, nothing picked)
@@ -259,6 +260,7 @@ struct MinimizerDenseArgs {
   const uint64_t* counts;  // the read-slots form (fixed-length reads): read r's counts[r] k-mers stand at r * nwin; else NULL
   uint64_t n_kmers;
   const uint64_t* offsets; // reads of any lengths: read r = [offsets[r], offsets[r + 1]); NULL: fixed-length reads
+  const uint64_t* ends;    // with offsets: read r = [offsets[r], ends[r]) (spans of a raw buffer); NULL: offsets[r + 1]
   uint32_t k, pad1;
   uint64_t* lpre;      // [n_reads] picks of the chunk's reads before read r
   uint64_t* ctot;      // [n_chunks] picks of the chunk
@@ -371,7 +373,7 @@ static __global__ __launch_bounds__(256) void minimizer_reg_kernel(const Minimiz
       if (blk != l_blk) {
         const uint64_t g = r0 + blk * 64u + lane;
         uint64_t l = 0;
-        if (g < a.n_reads) l = a.offsets[g + 1u] - a.offsets[g];
+        if (g < a.n_reads) l = (a.ends != nullptr ? a.ends[g] : a.offsets[g + 1u]) - a.offsets[g];
         g_len = l < 0xFFFFFFFFull ? (uint32_t)l : 0xFFFFFFFFu;
         l_blk = blk;
       }
@@ -621,7 +623,7 @@ static __global__ __launch_bounds__(256) void minimizer_regn_kernel(const Minimi
       if (blk != l_blk) {
         const uint64_t g = r0 + blk * 64u + lane;
         uint64_t l = 0;
-        if (g < a.n_reads) l = a.offsets[g + 1u] - a.offsets[g];
+        if (g < a.n_reads) l = (a.ends != nullptr ? a.ends[g] : a.offsets[g + 1u]) - a.offsets[g];
         g_len = l < 0xFFFFFFFFull ? (uint32_t)l : 0xFFFFFFFFu;
         l_blk = blk;
       }

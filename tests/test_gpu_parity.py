@@ -1860,6 +1860,31 @@ def test_fastx_file_stream_vs_oracle(ctx, oracle, tmp_path, fmt, chunk, final_ne
     assert (np.concatenate(got_h) == want["hashes"].ravel()).all()
 
 
+@pytest.mark.parametrize("n,lo,hi,k,w", [(3000, 20, 150, 31, 10), (1500, 30, 280, 25, 19), (400, 100, 900, 31, 12)])
+def test_minimizers_of_spans_of_a_raw_fastq_buffer(ctx, oracle, n, lo, hi, k, w):
+    """nthip_kmer_minimizers_spans on the sequence lines of a raw FASTQ buffer (indexed on the device) == nthip_kmer_minimizers
+    on the parsed reads given by offsets (itself tested against the brute force): register tables (at most 256 windows) and
+    LDS tables"""
+    rng = np.random.default_rng(n + hi)
+    buf, seqs = _make_fastx(rng, n, 4, lo=lo, hi=hi)
+    data, offs = concat_reads(seqs)
+    want = ctx.minimizers(data, k, w, 0, n, offsets=offs)
+    raw = np.frombuffer(buf, dtype=np.uint8)
+    d_buf, d_s, d_e = ctx.malloc(raw.size + 16), ctx.malloc(n * 8 + 8), ctx.malloc(n * 8 + 8)
+    ctx.h2d(d_buf, raw)
+    n_rec, _cons, bad = ctx.fastx_index_ptr(d_buf, raw.size, 4, d_s, d_e, n)
+    assert n_rec == n and not bad
+    cap = max(int(data.size), 1)
+    d_h, d_p, d_o = ctx.malloc(cap * 8), ctx.malloc(cap * 4), ctx.malloc((n + 1) * 8)
+    total = ctx.minimizers_spans_ptr(d_buf, raw.size, d_s, d_e, n, k, w, d_h, d_p, d_o, cap)
+    assert total == want["total"]
+    o, h, p = np.zeros(n + 1, np.uint64), np.zeros(total, np.uint64), np.zeros(total, np.uint32)
+    ctx.d2h(o, d_o); ctx.d2h(h, d_h); ctx.d2h(p, d_p)
+    assert (o == want["offsets"]).all() and (h == want["hashes"]).all() and (p == want["pos"]).all()
+    for d in (d_buf, d_s, d_e, d_h, d_p, d_o):
+        ctx.free(d)
+
+
 def test_fastx_file_batches_into_the_stream_consumers(ctx, oracle, tmp_path):
     """a FASTQ file end to end into a Bloom filter and a counting sketch: the stream consumers called on every batch from
     inside the driver's callback, with the driver's own context -- filter and counters == those of the
