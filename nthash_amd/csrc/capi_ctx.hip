@@ -271,6 +271,9 @@ void load_tuning(nthip_tune& t)
   t.no_any_k_runs = is_one("NTHIP_TUNE_NO_ANY_K_RUNS");
   t.no_fh = is_one("NTHIP_TUNE_NO_FH");
   t.mz_table = is_one("NTHIP_TUNE_MZ_TABLE");
+  t.mz_fused = num("NTHIP_TUNE_MZ_FUSED", 1, 2);
+  t.mz_c = num("NTHIP_TUNE_MZ_C", 2, 16);
+  t.mz_waves = num("NTHIP_TUNE_MZ_WAVES", 1, 16);
   t.reads_run_len = num("NTHIP_TUNE_READS_RUN_LEN", 2, 16);
   t.reads_per_tile = num("NTHIP_TUNE_READS_PER_TILE", 1, 64);
   t.reads_waves = num("NTHIP_TUNE_READS_WAVES", 1, 16);

@@ -83,6 +83,8 @@ struct nthip_tune {
   bool no_seed_wave = false; // NTHIP_TUNE_NO_SEED_WAVE (set)
   bool no_seed_wtile = false; // NTHIP_TUNE_NO_SEED_WTILE=1: the block-tile dense seed kernel instead of the wave-tile one
   bool mz_table = false;      // NTHIP_TUNE_MZ_TABLE=1: minimizers of clean short reads through the LDS tables too (A/B)
+  uint32_t mz_fused = 0;      // NTHIP_TUNE_MZ_FUSED=2: never the one-pass minimizer kernel (minimizer_fused_kernel.hpp; A/B, tests)
+  uint32_t mz_c = 0, mz_waves = 0; // NTHIP_TUNE_MZ_C / _MZ_WAVES: its run length and waves per block (0: planned)
   bool no_fh = false;         // NTHIP_TUNE_NO_FH=1: full position tables for k = 49 ... 64 (A/B)
   bool no_any_k_runs = false; // NTHIP_TUNE_NO_ANY_K_RUNS=1: only the k = 31 / run length 15, 30 instantiations of kmer_runs_kernel
   bool no_seed_align = false; // NTHIP_TUNE_NO_SEED_ALIGN=1: seed_rtile_kernel's groups end anywhere (A/B)

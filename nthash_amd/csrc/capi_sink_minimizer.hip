@@ -1,6 +1,8 @@
 // capi_sink_minimizer.hip -- per-read (w, k)-minimizers: nthip_kmer_minimizers
 // Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
 #include "capi_internal.hpp"
+#include "minimizer_fused_kernel.hpp"
+#include "minimizer_w_kernel.hpp"
 #include "minimizer_kernels.hpp"
 #include "util_kernels.hpp"
 
@@ -8,6 +10,251 @@ using namespace ntamd;
 using namespace ntamd::host;
 
 namespace {
+
+// ---- the one-pass kernel (minimizer_fused_kernel.hpp): fixed-length reads lying back to back, k within the position
+// tables, w <= the read's windows.  The run length C is the block of the sliding minimum: C <= w.
+struct MzfPlan {
+  uint32_t C = 0, rpr = 0, R = 0, m0 = 0, r = 0, extra = 0, waves = 0, bits_dwords = 0, pitch_h = 0, pitch_b = 0, per_wave_dwords = 0,
+           nw = 0;
+  size_t lds = 0;
+};
+bool minimizer_fused_plan(const nthip_ctx* c, uint32_t len, uint32_t k, uint32_t w, MzfPlan* p)
+{
+  if (len < k || k > KMER_TABLE_K_MAX || w < 2 || w > 128) return false;
+  const uint32_t nwin = len - k + 1;
+  if (nwin < w) return false; // (a read with fewer windows than w is one window: the round-3 kernels)
+  const uint32_t nw = kmer_nw(k);
+  double best = 0;
+  uint32_t best_c = 0;
+  for (uint32_t C = 2; C <= 16 && C <= w; ++C) {
+    const uint32_t rpr = (nwin + C - 1) / C, m0 = (w - 1) / C;
+    if (rpr > 64 || m0 + 1 > MZF_MAX_MM) continue;
+    if (c->tune.mz_c && C != c->tune.mz_c) continue;
+    // lane-instructions per read: a first window, C - 1 rolls, the two sweeps; idle lanes of a tile of whole reads; an
+    // even row pitch costs the tile writes bank conflicts, which the padding to an odd one removes
+    const uint32_t R = 64 / rpr;
+    const double per_block = 60.0 + 25.0 * (C - 1) + (m0 ? 38.0 : 30.0) * C + (m0 ? 12.0 * m0 : 0.0);
+    const double cost = per_block * rpr * 64.0 / (R * rpr);
+    if (best_c == 0 || cost < best) {
+      best = cost;
+      best_c = C;
+    }
+  }
+  if (best_c == 0) return false;
+  const uint32_t C = best_c;
+  p->C = C;
+  p->nw = nw;
+  p->rpr = (nwin + C - 1) / C;
+  p->R = 64 / p->rpr;
+  p->m0 = (w - 1) / C;
+  p->r = (w - 1) % C;
+  p->extra = p->rpr * C - nwin;
+  p->pitch_h = C | 1u;
+  p->pitch_b = 4u * (((C + 3u) / 4u) | 1u);
+  p->bits_dwords = ((15u + p->R * len + p->extra + 15u) >> 4) + nw + 8u;
+  p->per_wave_dwords = 2u * MZF_ROWS * p->pitch_h + 3u * MZF_FULL + (MZF_ROWS * p->pitch_b) / 4u + (64u * p->pitch_b) / 4u + p->bits_dwords;
+  p->per_wave_dwords = (p->per_wave_dwords + 3u) & ~3u;
+  const size_t tables = (size_t)4 * nw * 256 * 16 + 256;
+  const size_t cap = lds_cap_of(c);
+  if (cap < tables + (size_t)p->per_wave_dwords * 4 * 2) return false;
+  uint32_t waves = (uint32_t)((cap - tables) / ((size_t)p->per_wave_dwords * 4));
+  if (waves > (uint32_t)MZF_MAX_THREADS / 64) waves = MZF_MAX_THREADS / 64;
+  if (c->tune.mz_waves && c->tune.mz_waves < waves) waves = c->tune.mz_waves;
+  p->waves = waves;
+  p->lds = tables + (size_t)waves * p->per_wave_dwords * 4;
+  return true;
+}
+
+// *handled = false (and nothing written that the caller relies on) when the shape is outside the kernel or a read of the
+// batch holds a non-base
+int minimizers_fused(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t len, uint32_t k, uint32_t w, uint64_t* d_min_hashes,
+                     uint32_t* d_min_pos, uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out, bool* handled)
+{
+  *handled = false;
+  MzfPlan p;
+  if (!minimizer_fused_plan(c, len, k, w, &p)) return NTHIP_OK;
+  const uint64_t n_tiles = (n + p.R - 1) / p.R;
+  if (n_tiles >= 0x7FFFFFFFull) return NTHIP_OK;
+  NTCHK(ensure_scratch(c, n_tiles + 8));
+  // scratch: [0] total, [1] abort (u32) | dirty (u32), [2 ...) the tiles' look-back words
+  HIPCHK(hipMemsetAsync(c->d_scratch, 0, (n_tiles + 2) * sizeof(uint64_t), c->stream));
+  MinimizerFusedArgs a;
+  memset(&a, 0, sizeof a);
+  a.seqs = d_seqs;
+  NTCHK(get_kmer_tab(c, k, &a.init_tab));
+  a.total = c->d_scratch;
+  a.abort = (uint32_t*)(c->d_scratch + 1);
+  a.dirty = a.abort + 1;
+  a.status = (unsigned long long*)(c->d_scratch + 2);
+  a.out_hashes = d_min_hashes;
+  a.out_pos = d_min_pos;
+  a.out_offsets = d_min_offsets;
+  a.capacity = capacity;
+  a.n_reads = n;
+  a.total_bytes = n * len;
+  a.n_tiles = (uint32_t)n_tiles;
+  a.len = len;
+  a.k = k;
+  a.w = w;
+  a.nwin = len - k + 1;
+  a.nwv = a.nwin - w + 1;
+  a.C = p.C;
+  a.rpr = p.rpr;
+  a.inv_rpr = 65536u / p.rpr + 1u;
+  a.R = p.R;
+  a.m0 = p.m0;
+  a.r = p.r;
+  a.extra = p.extra;
+  a.waves = p.waves;
+  a.bits_dwords = p.bits_dwords;
+  a.pitch_h = p.pitch_h;
+  a.pitch_b = p.pitch_b;
+  a.per_wave_dwords = p.per_wave_dwords;
+  KmerFixedArgs consts;
+  memset(&consts, 0, sizeof consts);
+  fill_kmer_consts(k, 1, consts);
+  memcpy(a.tab, consts.tab, sizeof a.tab);
+  auto launch = [&](auto kernel) -> int {
+    int per_cu = 1;
+    NTCHK(blocks_per_cu(c, kernel, (int)p.waves * 64, p.lds, &per_cu));
+    uint64_t grid = (uint64_t)c->n_cu * per_cu;
+    const uint64_t need = (n_tiles + p.waves - 1) / p.waves;
+    if (grid > need) grid = need;
+    prof_begin(c, "minimizer_fused_kernel");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(p.waves * 64), p.lds, c->stream, a);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    return NTHIP_OK;
+  };
+  const bool mid = p.m0 != 0;
+  switch (p.nw * 2 + (mid ? 1 : 0)) {
+    case 2: NTCHK(launch(minimizer_fused_kernel<1, false>)); break;
+    case 3: NTCHK(launch(minimizer_fused_kernel<1, true>)); break;
+    case 4: NTCHK(launch(minimizer_fused_kernel<2, false>)); break;
+    case 5: NTCHK(launch(minimizer_fused_kernel<2, true>)); break;
+    case 6: NTCHK(launch(minimizer_fused_kernel<3, false>)); break;
+    case 7: NTCHK(launch(minimizer_fused_kernel<3, true>)); break;
+    case 8: NTCHK(launch(minimizer_fused_kernel<4, false>)); break;
+    default: NTCHK(launch(minimizer_fused_kernel<4, true>)); break;
+  }
+  HIPCHK(hipMemcpyAsync(c->h_small + 32, c->d_scratch, 16, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t total = 0;
+  uint32_t td[2];
+  memcpy(&total, c->h_small + 32, 8);
+  memcpy(td, c->h_small + 40, 8);
+  if (td[1] != 0 || td[0] != 0) return NTHIP_OK; // a non-base somewhere (or the grid was not resident): the caller takes the N-aware path
+  *handled = true;
+  if (total_out) *total_out = total;
+  if (total > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu minimizers < %llu needed", (unsigned long long)capacity,
+                (unsigned long long)total);
+  return NTHIP_OK;
+}
+
+// ---- the record form (minimizer_w_kernel.hpp): run length = w (4 ... 16), k <= 32 ----
+template <int C>
+int launch_minimizer_w(nthip_ctx* c, const MinimizerWArgs& a0, size_t lds_fixed, uint64_t n_tiles)
+{
+  MinimizerWArgs a = a0;
+  auto kernel = minimizer_w_kernel<C>;
+  const size_t lds = lds_fixed + (size_t)a.waves * a.per_wave_dwords * 4;
+  int per_cu = 1;
+  NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, lds, &per_cu));
+  uint64_t grid = (uint64_t)c->n_cu * per_cu; // every block resident: the look-back waits for blocks of the same round
+  const uint64_t need = (n_tiles + a.waves - 1) / a.waves;
+  if (grid > need) grid = need;
+  a.n_rounds = (uint32_t)((n_tiles + grid * a.waves - 1) / (grid * a.waves));
+  const uint64_t n_status = (uint64_t)a.n_rounds * grid;
+  NTCHK(ensure_scratch(c, n_status + 8));
+  // scratch: [0] total, [1] abort (u32) | dirty (u32), [2 ...) the block-rounds' look-back words
+  HIPCHK(hipMemsetAsync(c->d_scratch, 0, (n_status + 2) * sizeof(uint64_t), c->stream));
+  a.total = c->d_scratch;
+  a.abort = (uint32_t*)(c->d_scratch + 1);
+  a.dirty = a.abort + 1;
+  a.status = (unsigned long long*)(c->d_scratch + 2);
+  prof_begin(c, "minimizer_w_kernel");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), lds, c->stream, a);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+// *handled = false when the shape is outside the kernel or a read of the batch holds a non-base
+int minimizers_w(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t len, uint32_t k, uint32_t w, uint64_t* d_min_hashes,
+                 uint32_t* d_min_pos, uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out, bool* handled)
+{
+  *handled = false;
+  if (len < k || k > 32 || k > KMER_TABLE_K_MAX || w < 4 || w > 16) return NTHIP_OK;
+  if (c->tune.mz_c && c->tune.mz_c != w) return NTHIP_OK; // (a forced run length: the any-run-length form)
+  const uint32_t nwin = len - k + 1;
+  if (nwin < w) return NTHIP_OK;
+  const uint32_t C = w, rpr = (nwin + C - 1) / C;
+  if (rpr > 64) return NTHIP_OK;
+  MinimizerWArgs a;
+  memset(&a, 0, sizeof a);
+  a.R = 64 / rpr;
+  const uint64_t n_tiles = (n + a.R - 1) / a.R;
+  if (n_tiles >= 0x7FFFFFFFull) return NTHIP_OK;
+  a.seqs = d_seqs;
+  NTCHK(get_kmer_tab(c, k, &a.init_tab));
+  a.src_tabs = kmer_ntab(k);
+  a.out_hashes = d_min_hashes;
+  a.out_pos = d_min_pos;
+  a.out_offsets = d_min_offsets;
+  a.capacity = capacity;
+  a.n_reads = n;
+  a.total_bytes = n * len;
+  a.n_tiles = (uint32_t)n_tiles;
+  a.len = len;
+  a.k = k;
+  a.nwin = nwin;
+  a.nwv = nwin - w + 1;
+  a.rpr = rpr;
+  a.inv_rpr = 65536u / rpr + 1u;
+  a.extra = rpr * C - nwin;
+  a.bits_dwords = ((15u + a.R * len + a.extra + 15u) >> 4) + 2u + 8u;
+  // the stash parks one tile's picks: three times the expected 2 / (w + 1) of the tile's windows, at least 256; a tile with
+  // more writes them itself, a round late
+  const uint32_t max_picks = a.R * a.nwv;
+  uint32_t cap = 6u * a.R * nwin / (w + 1u);
+  cap = cap < 256u ? 256u : cap;
+  cap = cap > max_picks ? max_picks : cap;
+  a.stash_cap = (cap + 1u) & ~1u;
+  a.per_wave_dwords = 2u * a.stash_cap + a.stash_cap / 2u + a.bits_dwords;
+  a.per_wave_dwords = (a.per_wave_dwords + 1u) & ~1u;
+  const size_t fixed = (size_t)8 * 256 * 16 + 256 + MZW_CTRL_DWORDS * 4;
+  const size_t cap_lds = lds_cap_of(c);
+  if (cap_lds < fixed + (size_t)a.per_wave_dwords * 4 * 2) return NTHIP_OK;
+  uint32_t waves = (uint32_t)((cap_lds - fixed) / ((size_t)a.per_wave_dwords * 4));
+  if (waves > mzw_max_waves((int)C)) waves = mzw_max_waves((int)C);
+  if (c->tune.mz_waves && c->tune.mz_waves < waves) waves = c->tune.mz_waves;
+  a.waves = waves;
+  KmerFixedArgs consts;
+  memset(&consts, 0, sizeof consts);
+  fill_kmer_consts(k, 1, consts);
+  memcpy(a.tab, consts.tab, sizeof a.tab);
+  switch (C) {
+#define MZW_CASE(CC) case CC: NTCHK(launch_minimizer_w<CC>(c, a, fixed, n_tiles)); break;
+    MZW_CASE(4) MZW_CASE(5) MZW_CASE(6) MZW_CASE(7) MZW_CASE(8) MZW_CASE(9) MZW_CASE(10) MZW_CASE(11) MZW_CASE(12)
+    MZW_CASE(13) MZW_CASE(14) MZW_CASE(15) MZW_CASE(16)
+#undef MZW_CASE
+    default: return NTHIP_OK;
+  }
+  HIPCHK(hipMemcpyAsync(c->h_small + 32, c->d_scratch, 16, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t total = 0;
+  uint32_t td[2];
+  memcpy(&total, c->h_small + 32, 8);
+  memcpy(td, c->h_small + 40, 8);
+  if (td[1] != 0 || td[0] != 0) return NTHIP_OK; // a non-base somewhere (or the grid was not resident): the caller goes on
+  *handled = true;
+  if (total_out) *total_out = total;
+  if (total > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu minimizers < %llu needed", (unsigned long long)capacity,
+                (unsigned long long)total);
+  return NTHIP_OK;
+}
 
 // one round of reads of at most MZ_REG_POS windows through minimizer_reg_kernel + minimizer_gather_kernel
 // d_slot_counts: the read-slots form (read r's k-mers at r * nwin); else d_roff; both NULL: every read emits every one of its nwin windows (positions = indices); d_lpre / d_ctot / d_coff: n_reads u64 each
@@ -226,6 +473,18 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
     return NTHIP_OK;
   }
   const uint32_t nwin = len - k + 1;
+  if (!(flags & NTHIP_HOST_INPUT) && stride == len && c->tune.mz_fused != 2) {
+    // one pass over the bases, nothing of the hash stream in HBM; a batch with a non-base comes back unhandled
+    bool handled = false;
+    if (c->tune.mz_fused != 1) { // (1: the any-run-length form on every shape it takes)
+      const int rcw = minimizers_w(c, (const uint8_t*)rd->seqs, n, len, k, w, d_min_hashes, d_min_pos, d_min_offsets, capacity, total_out,
+                                   &handled);
+      if (rcw != NTHIP_OK || handled) return rcw;
+    }
+    const int rc = minimizers_fused(c, (const uint8_t*)rd->seqs, n, len, k, w, d_min_hashes, d_min_pos, d_min_offsets, capacity, total_out,
+                                    &handled);
+    if (rc != NTHIP_OK || handled) return rc;
+  }
   // rounds of reads: the emitted stream of a round (hash 8, position 4 -- only written for a round that has a read with a
   // non-base --, flag 1 byte per k-mer; three 8-byte values per read) in the context's consumer scratch
   size_t free_b = 0, total_b = 0;

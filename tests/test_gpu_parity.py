@@ -1275,6 +1275,87 @@ def test_minimizers_of_clean_short_reads(oracle, n, L, k, w, table):
     ctx.close()
 
 
+@pytest.mark.parametrize("n,L,k,w,C", [
+    (3000, 150, 31, 10, 0), (3000, 150, 31, 10, 8), (3000, 150, 31, 10, 7), (3000, 150, 31, 10, 5), (3000, 150, 31, 10, 2),
+    (2000, 150, 31, 2, 0), (2000, 150, 31, 3, 0), (2000, 150, 31, 5, 0), (2000, 150, 31, 16, 0), (2000, 150, 31, 17, 0),
+    (2000, 150, 31, 19, 0), (2000, 150, 31, 19, 9), (2000, 150, 31, 33, 0), (2000, 150, 31, 50, 0), (2000, 150, 31, 50, 8),
+    (2000, 150, 31, 64, 16), (1000, 150, 31, 120, 0), (1000, 150, 31, 119, 0), (1000, 150, 31, 100, 15),
+    (3000, 151, 31, 10, 0), (3000, 101, 21, 7, 0), (3000, 100, 64, 12, 0), (3000, 96, 48, 9, 0), (3000, 76, 15, 11, 0),
+    (2000, 250, 31, 10, 0), (2000, 250, 31, 25, 0), (1000, 1054, 31, 16, 16), (500, 600, 17, 40, 0), (5000, 40, 31, 10, 0),
+    (5000, 36, 21, 7, 0), (3000, 150, 31, 128, 0),
+    (3000, 150, 31, 4, 0), (3000, 150, 31, 6, 0), (3000, 150, 31, 7, 0), (3000, 150, 31, 8, 0), (3000, 150, 31, 9, 0),
+    (3000, 150, 31, 11, 0), (3000, 150, 31, 12, 0), (3000, 150, 31, 13, 0), (3000, 150, 31, 14, 0), (3000, 150, 31, 15, 0),
+    (3000, 100, 21, 10, 0), (3000, 250, 31, 14, 0), (3000, 45, 31, 15, 0), (3000, 46, 31, 15, 0), (3000, 40, 16, 5, 0),
+    (3000, 61, 12, 10, 0), (2000, 1055, 32, 16, 0),
+    (200000, 150, 31, 10, 0), (300000, 100, 25, 5, 0),         # many rounds of tiles: the look-back over the block-rounds
+])
+def test_minimizers_fused_one_pass(oracle, n, L, k, w, C):
+    """minimizer_fused_kernel (round 4): device-resident clean fixed-length reads are hashed and their minimizers picked in
+    ONE kernel -- no hash stream in HBM.  Against the vectorised brute force over the oracle's stream (first argmin of every
+    window of w), for run lengths (= blocks of the sliding minimum) chosen by the plan and forced (NTHIP_TUNE_MZ_C),
+    w from 2 to 128 (with and without whole blocks between a window's ends), k across the table widths, reads of one
+    repeated base / short periods (ties: the leftmost), too small a capacity, and the round-3 kernels on the same batch
+    (NTHIP_TUNE_MZ_FUSED=2).  A batch with a non-base comes back through the N-aware path with the same answers."""
+    import os
+    import nthash_amd
+    from numpy.lib.stride_tricks import sliding_window_view
+    if C:
+        os.environ["NTHIP_TUNE_MZ_C"] = str(C)
+    try:
+        ctx = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_MZ_C", None)
+    os.environ["NTHIP_TUNE_MZ_FUSED"] = "2"
+    try:
+        old = nthash_amd.Context(0)
+        os.environ["NTHIP_TUNE_MZ_FUSED"] = "1"     # the any-run-length form where the record form (run length = w) would run
+        gen = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_MZ_FUSED", None)
+    data = oracle.synth_reads(5, n, L, 17 + k + w).copy()
+    data[2 * L: 3 * L] = ord("A")
+    data[3 * L: 4 * L] = np.frombuffer(b"AC" * L, dtype=np.uint8)[:L]
+    data[5 * L: 6 * L] = np.frombuffer(b"ACG" * L, dtype=np.uint8)[:L]
+    data[(n - 1) * L:] = ord("t")                               # the batch's last read too
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    nwin = L - k + 1
+    hs = oracle.kmer_batch(data, offs, k, 1, want_pos=False)["hashes"].ravel().reshape(n, nwin)
+    weff = min(w, nwin)
+    arg = sliding_window_view(hs, weff, axis=1).argmin(axis=2) + np.arange(nwin - weff + 1)[None, :]
+    pick = np.zeros((n, nwin), dtype=bool)
+    np.put_along_axis(pick, arg, True, axis=1)
+    exp_off = np.concatenate([[0], np.cumsum(pick.sum(axis=1))]).astype(np.uint64)
+    rr, pp = np.nonzero(pick)
+    exp_pos, exp_h = pp.astype(np.uint32), hs[rr, pp]
+    ctx.set_profiling(True)
+    got = ctx.minimizers(data, k, w, L, n, device_input=True)
+    if w <= 100 and w <= nwin:    # (w beyond 7 blocks of 16 windows, or beyond the read: the round-3 kernels)
+        record_form = C in (0, w) and 4 <= w <= 16 and k <= 32 and -(-nwin // w) <= 64
+        assert ctx.last_kernel_ms()[1] == ("minimizer_w_kernel" if record_form else "minimizer_fused_kernel")
+    assert got["total"] == len(exp_pos)
+    assert (got["offsets"] == exp_off).all()
+    assert (got["pos"] == exp_pos).all()
+    assert (got["hashes"] == exp_h).all()
+    if n <= 5000:
+        for other in (old, gen):
+            ref = other.minimizers(data, k, w, L, n, device_input=True)
+            assert ref["total"] == got["total"] and (ref["offsets"] == got["offsets"]).all()
+            assert (ref["pos"] == got["pos"]).all() and (ref["hashes"] == got["hashes"]).all()
+        with pytest.raises(nthash_amd.NtHipError) as ei:        # too small a capacity: the need is reported, nothing past it written
+            ctx.minimizers(data, k, w, L, n, capacity=got["total"] - 1, device_input=True)
+        assert ei.value.code == nthash_amd.capi.NTHIP_ERR_CAPACITY and ei.value.total == got["total"]
+        # a non-base: the one-pass kernel reports it, the N-aware path answers
+        dirty = data.copy()
+        dirty[7 * L + L // 2] = ord("N")
+        a = ctx.minimizers(dirty, k, w, L, n, device_input=True)
+        b = old.minimizers(dirty, k, w, L, n, device_input=True)
+        assert a["total"] == b["total"] and (a["offsets"] == b["offsets"]).all()
+        assert (a["pos"] == b["pos"]).all() and (a["hashes"] == b["hashes"]).all()
+    ctx.close()
+    old.close()
+    gen.close()
+
+
 @pytest.mark.parametrize("n,lmax,k,w,dirty", [
     (400, 300, 31, 10, True), (300, 180, 21, 300, False),     # w beyond every read: one minimizer per read
     (60, 3000, 31, 19, True),                                  # reads on both sides of the 1024-window limit of the wave tables

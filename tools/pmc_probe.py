@@ -23,6 +23,7 @@ else:
 L, k, m, seeds = SHAPE[cfg] if cfg in SHAPE else {"c2": (150, 31, 1, None), "c3": (150, 31, 4, None), "c4": (250, 31, 3, SEEDS),
                   "mh": (150, 31, 1, None), "gen": (150, 31, 1, None),      # mh: fused MinHash; gen: general kernel
                   "rag": (150, 31, 1, None),                                # rag: variable-length reads (100..150 bp)
+                  "mz": (150, 31, 1, None),                                 # mz: (w, k)-minimizers, w = $MZ_W (10), one pass
                   "na": (150, 31, 1, None)}[cfg]                            # na: fixed-length batch with N's (N-aware pass)
 if cfg == "gen":
     os.environ["NTHIP_TUNE_NO_SPECIAL"] = "1"
@@ -55,6 +56,9 @@ for _ in range(3):
         ctx.kmer_hash_ptr(d_in, d_offs, n, 0, 0, k, m, d_out, n * nwin)
     elif cfg == "mh":
         ctx.minhash_ptr(d_in, n, L, 0, k, m, d_out)
+    elif cfg == "mz":
+        cap = n * nwin // 2
+        ctx.minimizers_ptr(d_in, n, L, 0, k, int(os.environ.get("MZ_W", "10")), d_out, d_out + cap * 8, d_out + cap * 12, cap)
     elif sd is None:
         ctx.kmer_hash_ptr(d_in, 0, n, L, 0, k, m, d_out, n * nwin)
     else:

@@ -11,7 +11,7 @@ acc = defaultdict(list)
 for f in sorted(glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True)):
     for row in csv.DictReader(open(f)):
         name = row.get("Kernel_Name", "")
-        short = "copy" if "copy_kernel" in name else "ragged_hash" if "kmer_ragged_kernel<2" in name else \
+        short = "mz_fused" if "minimizer_fused" in name else "mz_w" if "minimizer_w_kernel" in name else "copy" if "copy_kernel" in name else "ragged_hash" if "kmer_ragged_kernel<2" in name else \
             "ragged_count" if "kmer_ragged_kernel<1" in name else "reads_hash" if "kmer_reads_kernel<2" in name else \
             "reads_mark" if "kmer_reads_kernel<1" in name else "reads_dirty" if "kmer_dirty_reads" in name else "kmer_runs_gen" if "kmer_runs_gen" in name else \
             "kmer_runs" if "kmer_runs" in name else "kmer_fixed" if "kmer_fixed" in name else \
