@@ -480,6 +480,7 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
     owned = [d_in]
     try:
         ctx.synth_reads_ptr(d_in, 0, n_reads, L, 42)
+        ctx.set_profiling(True)   # (HIP events around the kernel of record of every call: `roofline.kernel_ms` below)
 
         def best(f, reps=3):
             ts = []
@@ -489,6 +490,20 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
                 r = f()
                 ts.append(time.perf_counter() - t0)
             return min(ts), r
+
+        def roof(alg_bytes, call_s, what, note=None):
+            """a consumer's roofline: algorithmic bytes = the bases it must read (L / nwin B per k-mer) + what it must write;
+            `frac` over the whole call (every kernel of it), `kernel` / `kernel_ms` = the call's kernel of record"""
+            try:
+                kms, kname = ctx.last_kernel_ms()
+            except Exception:  # noqa: BLE001
+                kms, kname = None, None
+            r = {"bound": "hbm", "bytes": what, "algorithmic_bytes": alg_bytes, "achieved": alg_bytes / call_s / 1e9, "peak": HBM_PEAK_GBPS,
+                 "unit": "GB/s", "frac": alg_bytes / call_s / 1e9 / HBM_PEAK_GBPS, "kernel": kname, "kernel_ms": kms, "traffic": None}
+            if note:
+                r["note"] = note
+            return r
+        in_bytes = n_reads * L
         # Bloom filter: a fresh 4 GiB filter per repetition, one hash per k-mer; every inserted k-mer must then be found
         n_bits = 1 << 35
         d_f = ctx.malloc(n_bits // 8)
@@ -501,9 +516,16 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
             return time.perf_counter() - t0, tot
         t_ins, tot = min(ins() for _ in range(3))
         t_q, (tq, found) = best(lambda: ctx.bloom_query_ptr(d_in, n_reads, L, 0, k, 1, d_f, n_bits))
+        out["bloom_query_4GiB"] = {"value": tq / t_q, "ms": t_q * 1e3,
+                                   "roofline": roof(in_bytes + 8 * n_reads, t_q, "bases in + 8 B per read (hits)",
+                                                    "random-load bound: one 4-byte filter load per k-mer from a 4 GiB table")}
+        ctx.memset(d_f, 0, n_bits // 8)
+        ctx.bloom_insert_ptr(d_in, n_reads, L, 0, k, 1, d_f, n_bits)   # (the kernel of record of an insert, for the line below)
         out["bloom_insert_fresh_4GiB"] = {"value": tot / t_ins, "ms": t_ins * 1e3, "check": "every inserted k-mer is found",
-                                          "ok": bool(tot == kmers and tq == kmers and found == kmers)}
-        out["bloom_query_4GiB"] = {"value": tq / t_q, "ms": t_q * 1e3}
+                                          "ok": bool(tot == kmers and tq == kmers and found == kmers),
+                                          "roofline": roof(in_bytes + 2 * (n_bits // 8), t_ins, "bases in + the filter read and written once",
+                                                           "binned insert: hash to a stream, histogram, two partition levels, apply -- "
+                                                           "40 B of list traffic per value (DESIGN 4.8); the kernel named is the last of them")}
         ctx.free(d_f)
         owned.remove(d_f)
         # counting sketch: 1 Gi one-byte counters, fresh; no counter saturates here, so the bytes add up to the k-mers
@@ -523,7 +545,9 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
         del view
         out["count_insert_fresh_1Gi_counters"] = {"value": totc / t_c, "ms": t_c * 1e3,
                                                   "check": "sum of the counters == k-mers inserted (largest counter %d)" % top,
-                                                  "ok": bool(totc == kmers and (s_bytes == kmers or top == 255))}
+                                                  "ok": bool(totc == kmers and (s_bytes == kmers or top == 255)),
+                                                  "roofline": roof(in_bytes + 2 * n_cnt, t_c, "bases in + the counters read and written once",
+                                                                   "on the binned insert's lists (DESIGN 4.8)")}
         ctx.free(d_c)
         owned.remove(d_c)
         # (w, k)-minimizers, w = 10: density close to 2 / (w + 1) on random reads, offsets ascending
@@ -538,14 +562,20 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
         dens = totm / kmers
         out["minimizers_w10"] = {"value": kmers / t_m, "ms": t_m * 1e3, "minimizers": totm, "density": dens,
                                  "check": "density within 10 % of 2 / (w + 1); offsets ascending, last == total",
-                                 "ok": bool(mono and abs(dens - 2 / (w + 1)) < 0.1 * 2 / (w + 1))}
+                                 "ok": bool(mono and abs(dens - 2 / (w + 1)) < 0.1 * 2 / (w + 1)),
+                                 "roofline": roof(in_bytes + 12 * totm + 8 * (n_reads + 1), t_m,
+                                                  "bases in + 12 B per minimizer (hash, position) + 8 B per read (offsets)",
+                                                  "one kernel, no hash stream in HBM; instruction-bound (~60 VALU per k-mer: hashing 35, "
+                                                  "record masks 12, staging + placing the rest)")}
         # the same reads given by offsets (what a FASTQ batch looks like to the consumer): the same minimizers
         d_of = ctx.malloc((n_reads + 1) * 8)
         owned.append(d_of)
         ctx.h2d(d_of, np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L))
         t_mo, totmo = best(lambda: ctx.minimizers_ptr(d_in, n_reads, 0, 0, k, w, d_h, d_p, d_o, cap, offsets=d_of))
         out["minimizers_w10_offsets"] = {"value": kmers / t_mo, "ms": t_mo * 1e3, "minimizers": totmo,
-                                         "check": "as many minimizers as the fixed-length call", "ok": bool(totmo == totm)}
+                                         "check": "as many minimizers as the fixed-length call", "ok": bool(totmo == totm),
+                                         "roofline": roof(in_bytes + 12 * totmo + 16 * (n_reads + 1), t_mo,
+                                                          "bases + offsets in, 12 B per minimizer + 8 B per read out")}
         for p in (d_h, d_p, d_o, d_of):
             ctx.free(p)
             owned.remove(p)
@@ -553,7 +583,9 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
         d_s = ctx.malloc(n_reads * 4 * 8)
         owned.append(d_s)
         t_s, tots = best(lambda: ctx.minhash_ptr(d_in, n_reads, L, 0, k, 4, d_s))
-        out["minhash_m4"] = {"value": tots / t_s, "ms": t_s * 1e3, "ok": bool(tots == kmers)}
+        out["minhash_m4"] = {"value": tots / t_s, "ms": t_s * 1e3, "ok": bool(tots == kmers),
+                             "roofline": roof(in_bytes + 32 * n_reads, t_s, "bases in + 4 x 8 B per read (signatures)",
+                                              "one kernel, the hashes stay in registers; instruction-bound")}
     finally:
         torch.cuda.synchronize(dev)
         for p in owned:

@@ -161,17 +161,17 @@ int launch_minimizer_w(nthip_ctx* c, const MinimizerWArgs& a0, size_t lds_fixed,
   const size_t lds = lds_fixed + (size_t)a.waves * a.per_wave_dwords * 4;
   int per_cu = 1;
   NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, lds, &per_cu));
-  uint64_t grid = (uint64_t)c->n_cu * per_cu; // every block resident: the look-back waits for blocks of the same round
+  (void)per_cu;
+  uint64_t grid = (uint64_t)c->n_cu; // one block per CU, every block resident: the look-back needs the blocks of a round to run together
   const uint64_t need = (n_tiles + a.waves - 1) / a.waves;
   if (grid > need) grid = need;
   a.n_rounds = (uint32_t)((n_tiles + grid * a.waves - 1) / (grid * a.waves));
-  const uint64_t n_status = (uint64_t)a.n_rounds * grid;
+  const uint64_t n_status = ((uint64_t)a.n_rounds + 1) * grid;
   NTCHK(ensure_scratch(c, n_status + 8));
-  // scratch: [0] total, [1] abort (u32) | dirty (u32), [2 ...) the block-rounds' look-back words
+  // scratch: [0] total, [1] abort (u32), [2 ...) the block-rounds' look-back words
   HIPCHK(hipMemsetAsync(c->d_scratch, 0, (n_status + 2) * sizeof(uint64_t), c->stream));
   a.total = c->d_scratch;
   a.abort = (uint32_t*)(c->d_scratch + 1);
-  a.dirty = a.abort + 1;
   a.status = (unsigned long long*)(c->d_scratch + 2);
   prof_begin(c, "minimizer_w_kernel");
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), lds, c->stream, a);
@@ -180,7 +180,8 @@ int launch_minimizer_w(nthip_ctx* c, const MinimizerWArgs& a0, size_t lds_fixed,
   return NTHIP_OK;
 }
 
-// *handled = false when the shape is outside the kernel or a read of the batch holds a non-base
+// *handled = false when the shape is outside the kernel (reads with non-bases are its business: a k-mer that holds one is
+// no candidate)
 int minimizers_w(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t len, uint32_t k, uint32_t w, uint64_t* d_min_hashes,
                  uint32_t* d_min_pos, uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out, bool* handled)
 {
@@ -221,7 +222,7 @@ int minimizers_w(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t len, 
   cap = cap < 256u ? 256u : cap;
   cap = cap > max_picks ? max_picks : cap;
   a.stash_cap = (cap + 1u) & ~1u;
-  a.per_wave_dwords = 2u * a.stash_cap + a.stash_cap / 2u + a.bits_dwords;
+  a.per_wave_dwords = 2u * a.stash_cap + a.stash_cap / 2u + a.bits_dwords + (a.bits_dwords + 8u + 1u) / 2u;
   a.per_wave_dwords = (a.per_wave_dwords + 1u) & ~1u;
   const size_t fixed = (size_t)8 * 256 * 16 + 256 + MZW_CTRL_DWORDS * 4;
   const size_t cap_lds = lds_cap_of(c);
@@ -247,7 +248,7 @@ int minimizers_w(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t len, 
   uint32_t td[2];
   memcpy(&total, c->h_small + 32, 8);
   memcpy(td, c->h_small + 40, 8);
-  if (td[1] != 0 || td[0] != 0) return NTHIP_OK; // a non-base somewhere (or the grid was not resident): the caller goes on
+  if (td[0] != 0) return NTHIP_OK; // (the grid was not resident: the caller goes on with the round-3 kernels)
   *handled = true;
   if (total_out) *total_out = total;
   if (total > capacity)
@@ -444,6 +445,13 @@ int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uin
   OffsetsSurvey sv;
   NTCHK(offsets_survey_device(c, st.offsets, n, total_bytes, &sv));
   if (sv.bad) return fail(NTHIP_ERR_ARG, "offsets are not non-decreasing or reach outside the read buffer");
+  if (sv.uniform && sv.len0 >= k16 && sv.len0 <= 0xFFFFFFFFull && c->tune.mz_fused == 0) {
+    // offsets that are one length in disguise (untrimmed reads lying back to back): the one-pass kernel of fixed-length reads
+    bool handled = false;
+    const int rc = minimizers_w(c, st.seqs + sv.off0, n, (uint32_t)sv.len0, k16, w, d_min_hashes, d_min_pos, d_min_offsets, capacity, total_out,
+                                &handled);
+    if (rc != NTHIP_OK || handled) return rc;
+  }
   return minimizers_of_spans(c, st.seqs, total_bytes, st.offsets, nullptr, n, sv.max_len, k16, w, d_min_hashes, d_min_pos, d_min_offsets,
                              capacity, total_out);
 }
@@ -476,14 +484,18 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
   if (!(flags & NTHIP_HOST_INPUT) && stride == len && c->tune.mz_fused != 2) {
     // one pass over the bases, nothing of the hash stream in HBM; a batch with a non-base comes back unhandled
     bool handled = false;
-    if (c->tune.mz_fused != 1) { // (1: the any-run-length form on every shape it takes)
+    if (c->tune.mz_fused != 1) { // the record form: run length = w (4 ... 16), k <= 32
       const int rcw = minimizers_w(c, (const uint8_t*)rd->seqs, n, len, k, w, d_min_hashes, d_min_pos, d_min_offsets, capacity, total_out,
                                    &handled);
       if (rcw != NTHIP_OK || handled) return rcw;
+    } else {
+      // NTHIP_TUNE_MZ_FUSED=1: the any-run-length form (w up to 7 x 16, k within the position tables).  Its look-back is per
+      // tile with the waves waiting, and at 14-20 ms per 20 M reads of 150 bp it is behind the round-3 kernels (12.3 ms):
+      // kept for the shapes' sake and as the cross-check of the record form, not a default
+      const int rc = minimizers_fused(c, (const uint8_t*)rd->seqs, n, len, k, w, d_min_hashes, d_min_pos, d_min_offsets, capacity, total_out,
+                                      &handled);
+      if (rc != NTHIP_OK || handled) return rc;
     }
-    const int rc = minimizers_fused(c, (const uint8_t*)rd->seqs, n, len, k, w, d_min_hashes, d_min_pos, d_min_offsets, capacity, total_out,
-                                    &handled);
-    if (rc != NTHIP_OK || handled) return rc;
   }
   // rounds of reads: the emitted stream of a round (hash 8, position 4 -- only written for a round that has a read with a
   // non-base --, flag 1 byte per k-mer; three 8-byte values per read) in the context's consumer scratch

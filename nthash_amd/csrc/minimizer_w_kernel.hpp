@@ -21,9 +21,12 @@
 //
 // Placing the picks (the CSR output is dense): rounds of tiles, tile = (round * blocks + block) * waves + wave.  The waves
 // of a block add up their tiles' counts through LDS; the wave that arrives last publishes the block's count for the round
-// in a.status, looks back over the earlier block-rounds (256 per hop: one hop reaches the round before, whose inclusive
-// counts are long published), and leaves every wave's offset in LDS.  Nobody waits for it: a tile's picks are parked in a
-// small LDS stash and written -- coalesced -- one round later, when the offsets have been there for a whole tile's time.
+// in a.status.  The look-back over the earlier block-rounds (256 per hop: one hop reaches the round before, whose inclusive
+// counts are published) is done a round LATER by the wave of the block that finishes its next tile first -- every count
+// it needs was published a tile's time ago, and the wave that does it is the one with time to spare -- and leaves every
+// wave's offset in LDS.  Nobody waits for it: a tile's picks are parked in a small LDS stash and written -- coalesced --
+// one round later.  (With the last wave of a round looking back at once the look-back's latency sat on the block's
+// critical path in every round: 7.8 ms against 5.4 ms without any look-back, 20 M x 150 bp, w = 10.)
 // (A look-back per TILE with the waves waiting cost more than the hashing: minimizer_fused_kernel.hpp.)  The bounded-wait
 // rule of that kernel holds here too: a leader that waits 50 ms sets a.abort and the caller takes the round-3 path.
 #pragma once
@@ -36,14 +39,20 @@ namespace ntamd {
 
 // waves per block: 16 while a lane's 4 C + ~60 registers fit 128, else 12
 constexpr uint32_t mzw_max_waves(int C) { return C <= 12 ? 16u : 12u; }
-constexpr uint32_t MZW_CTRL_DWORDS = 4 + 2 * 2 * 16 + 2 * 16; // arrive[2], tag[2], woff[2][16] (u64), agg[2][16]
+#ifndef MZW_ABL_NOLEAD
+#define MZW_ABL_NOLEAD 0 // ablation (wrong placement): the leader does not look back
+#endif
+#ifndef MZW_ABL_NOFLUSH
+#define MZW_ABL_NOFLUSH 0 // ablation: the parked picks are not written
+#endif
+// arrive[2], tag[2], asum_tag[2], claim[2], bsum[2], pad[2], woff[2][16] (u64), agg[2][16], wrel[2][16]
+constexpr uint32_t MZW_CTRL_DWORDS = 12 + 2 * 2 * 16 + 2 * 16 + 2 * 16;
 
 struct MinimizerWArgs {
   const uint8_t* seqs;
   const uint4* init_tab;        // [src_tabs][256] {f.lo, f.hi, r.lo, r.hi}; the kernel pads to 8 tables with zeros
-  uint32_t* dirty;              // set when a non-base is seen
   uint32_t* abort;              // zeroed by the host; set by a leader that waited too long
-  unsigned long long* status;   // [n_rounds * blocks] look-back words of the block-rounds, zeroed by the host
+  unsigned long long* status;   // [(n_rounds + 1) * blocks] look-back words of the block-rounds, zeroed by the host
   uint64_t* out_hashes;
   uint32_t* out_pos;            // may be NULL
   uint64_t* out_offsets;        // [n_reads + 1]
@@ -72,18 +81,23 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
   const uint32_t waves = a.waves;
   const uint64_t seqs_addr = (uint64_t)a.seqs;
 
-  // LDS: first-window tables | pair table | block control | per wave { stash hashes, stash positions, bit stream }
+  // LDS: first-window tables | pair table | block control | per wave { stash hashes, stash positions, bit stream, validity bits }
   uint4* itab = (uint4*)lds_dyn;
   uint4* ptab = itab + ntab * 256u;
   uint32_t* ctrl = (uint32_t*)(ptab + 16);
-  uint32_t* arrive = ctrl;                                   // [2]
-  volatile uint32_t* tag = ctrl + 2;                         // [2]
-  uint64_t* woff = (uint64_t*)(ctrl + 4);                    // [2][16]
-  uint32_t* agg = ctrl + 4 + 64;                             // [2][16]
+  uint32_t* arrive = ctrl;                                   // [2] waves that finished the round's tile
+  volatile uint32_t* tag = ctrl + 2;                         // [2] round + 1 once the round's offsets are in woff
+  volatile uint32_t* asum_tag = ctrl + 4;                    // [2] round + 1 once the block's count of the round is in bsum / wrel
+  uint32_t* claim = ctrl + 6;                                // [2] round + 1 once a wave has taken the round's look-back
+  uint32_t* bsum = ctrl + 8;                                 // [2]
+  uint64_t* woff = (uint64_t*)(ctrl + 12);                   // [2][16]
+  uint32_t* agg = ctrl + 12 + 64;                            // [2][16]
+  uint32_t* wrel = agg + 32;                                 // [2][16]
   uint32_t* wave_base = ctrl + MZW_CTRL_DWORDS + wave * a.per_wave_dwords;
   uint64_t* stash_h = (uint64_t*)wave_base;                  // [stash_cap]
   uint16_t* stash_p = (uint16_t*)(stash_h + a.stash_cap);    // [stash_cap]
-  uint32_t* bits = (uint32_t*)(stash_p + a.stash_cap);       // (stash_cap is even)
+  uint32_t* bits = (uint32_t*)(stash_p + a.stash_cap);       // (stash_cap is even) [bits_dwords]
+  uint16_t* vbits = (uint16_t*)(bits + a.bits_dwords);       // [bits_dwords + 8] validity bits of a slab with a non-base
 
   for (uint32_t i = tid; i < ntab * 256u; i += blockDim.x) itab[i] = i < a.src_tabs * 256u ? a.init_tab[i] : make_uint4(0, 0, 0, 0);
   if (tid < 16)
@@ -100,7 +114,7 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
 
   const uint32_t lr_raw = (lane * a.inv_rpr) >> 16;
   const uint32_t q_raw = lane - lr_raw * rpr;
-  uint32_t bad = 0;
+  uint32_t tbad = 0; // non-bases seen while the current tile's slab was packed
 
   // what is parked from the round before
   bool have_prev = false;
@@ -115,7 +129,7 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
     while (tag[pp] != prev_rd + 1u) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     const uint64_t base = woff[pp * 16u + wave];
-    for (uint32_t i = lane; i < prev_total; i += 64u) {
+    for (uint32_t i = lane; i < prev_total && !MZW_ABL_NOFLUSH; i += 64u) {
       const uint64_t o = base + i;
       if (o < a.capacity) {
         a.out_hashes[o] = stash_h[i];
@@ -126,16 +140,37 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
     have_prev = false;
   };
 
-  // the wave that arrives last at a round: the block's count, the look-back over the block-rounds before, every wave's offset
-  auto lead = [&](uint32_t rd, uint32_t par) {
+  // the wave that arrives LAST at a round: the block's count of the round, published at once (the blocks behind need it)
+  auto sum_round = [&](uint32_t rd, uint32_t par) {
     const uint32_t v = lane < waves ? agg[par * 16u + lane] : 0u;
     const uint32_t incl = wave_incl_add32(v);
     const uint32_t sum = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     const uint64_t br = (uint64_t)rd * gridDim.x + blockIdx.x;
     if (lane == 0)
       __hip_atomic_store(a.status + br, (br == 0 ? MZF_FLAG_P : MZF_FLAG_A) | (unsigned long long)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < waves) wrel[par * 16u + lane] = incl - v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) {
+      bsum[par] = sum;
+      arrive[par] = 0; // (next used two rounds on: a wave gets there only behind this round's offsets)
+      asum_tag[par] = rd + 1u;
+    }
+  };
+  // The look-back of round rd is nobody's critical path: the wave that arrives FIRST at round rd + 1 does it, a whole tile
+  // after every block published its count of round rd and the round before resolved -- one hop, nothing to wait for.  (A
+  // wave whose tile overflows the stash needs its offset in its own round and claims the job early.)
+  auto try_lead = [&](uint32_t rd) {
+    const uint32_t par = rd & 1u;
+    uint32_t before = 0;
+    if (lane == 0) before = __hip_atomic_fetch_max(claim + par, rd + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+    if (before >= rd + 1u) return;
+    while (asum_tag[par] != rd + 1u) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    const uint32_t sum = bsum[par];
+    const uint64_t br = (uint64_t)rd * gridDim.x + blockIdx.x;
     uint64_t excl = 0;
-    if (br != 0) {
+    if (br != 0 && !MZW_ABL_NOLEAD) {
       int64_t look = (int64_t)br - 1 - (int64_t)lane;
       bool done = false, aborted = false;
       while (!done && !aborted) {
@@ -161,8 +196,8 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
           for (uint32_t j = 0; j < 4; ++j)
             if (j < need) missing = missing || (have[j] && s[j] == 0ull);
           if (__ballot(missing) == 0ull) break;
-          __builtin_amdgcn_s_sleep(2);
-          if ((spins & 255u) == 255u) { // (rare: a block is late, or is not running at all)
+          __builtin_amdgcn_s_sleep(8);
+          if ((spins & 63u) == 63u) { // (rare: a block is late, or is not running at all)
             const uint64_t now = __builtin_amdgcn_s_memrealtime(); // 100 MHz
             if (t_wait == 0) t_wait = now;
             const bool late = now - t_wait > 5000000ull; // 50 ms
@@ -193,16 +228,13 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
       if (lane == 0)
         __hip_atomic_store(a.status + br, MZF_FLAG_P | (excl + sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane < waves) woff[par * 16u + lane] = excl + (incl - v);
+    if (lane < waves) woff[par * 16u + lane] = excl + wrel[par * 16u + lane];
     if (rd == a.n_rounds - 1u && blockIdx.x == gridDim.x - 1u && lane == 0) {
       a.out_offsets[a.n_reads] = excl + sum;
       *a.total = excl + sum;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    if (lane == 0) {
-      arrive[par] = 0;
-      tag[par] = rd + 1u;
-    }
+    if (lane == 0) tag[par] = rd + 1u;
   };
 
   // geometry of a tile's slab
@@ -245,8 +277,17 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
           if (qq >= lo_cut && qq < hi_cut) b |= (bx[qq >> 2] >> ((qq & 3) * 8)) & 0xFFu;
       }
     }
-    bad |= b;
+    tbad |= b;
     bits[i] = p;
+  };
+  // a slab that holds a non-base (rare): one validity bit per base, 16 per vector (1 = not a base)
+  auto validity_vec = [&](uint32_t i, const uint4 v) {
+    uint32_t i0, i1, i2, i3;
+    (void)pack4v(v.x, i0);
+    (void)pack4v(v.y, i1);
+    (void)pack4v(v.z, i2);
+    (void)pack4v(v.w, i3);
+    vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
   };
   const uint32_t t_step = gridDim.x * waves;
   uint32_t t = blockIdx.x * waves + wave; // tile of round rd: (rd * blocks + block) * waves + wave (< 2^31 + the grid's waves)
@@ -259,9 +300,9 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
     if (lane + 64u < cur.n_vec) pf1 = *(const uint4*)(a.seqs + cur.byte0 + ((uint64_t)(lane + 64u) << 4));
   }
 
-  for (uint32_t rd = 0; rd < a.n_rounds; ++rd, t += t_step) {
+  for (uint32_t rd = 0; rd <= a.n_rounds; ++rd, t += t_step) { // (round n_rounds: nothing to hash, the round before is placed)
     const uint32_t par = rd & 1u;
-    const bool has = t < a.n_tiles;
+    const bool has = rd < a.n_rounds && t < a.n_tiles;
     uint32_t pick = 0, cnt = 0, incl = 0, tile_total = 0, q = 0, lr = 0;
     uint64_t rf = 0;
     bool live = false;
@@ -273,10 +314,20 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
       const Slab sl = cur;
       rf = sl.rf;
       lds_sync();
+      tbad = 0;
       if (lane < sl.n_vec) pack_vec(sl, lane, pf0);
       if (lane + 64u < sl.n_vec) pack_vec(sl, lane + 64u, pf1);
       for (uint32_t i = 128u + lane; i < sl.n_vec; i += 64u) pack_vec(sl, i, *(const uint4*)(a.seqs + sl.byte0 + ((uint64_t)i << 4)));
       for (uint32_t i = sl.n_vec + lane; i < a.bits_dwords; i += 64u) bits[i] = 0; // the rolls of a last block read ahead
+      // N-aware: a k-mer that holds a non-base is no candidate (NtHash does not emit it: src/kmer.cpp:228-264) -- its hash
+      // becomes the largest value and it is never picked; a tile without a non-base (nearly all) pays one ballot
+      const bool tile_dirty = __ballot(tbad != 0u) != 0ull;
+      if (tile_dirty) {
+        if (lane < sl.n_vec) validity_vec(lane, pf0);
+        if (lane + 64u < sl.n_vec) validity_vec(lane + 64u, pf1);
+        for (uint32_t i = 128u + lane; i < sl.n_vec; i += 64u) validity_vec(i, *(const uint4*)(a.seqs + sl.byte0 + ((uint64_t)i << 4)));
+        for (uint32_t i = sl.n_vec + lane; i < a.bits_dwords + 8u; i += 64u) vbits[i] = 0;
+      }
       if (t + t_step < a.n_tiles) {
         cur = slab_of(t + t_step);
         if (lane < cur.n_vec) pf0 = *(const uint4*)(a.seqs + cur.byte0 + ((uint64_t)lane << 4));
@@ -313,10 +364,7 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
           r_hi = __builtin_amdgcn_bitop3_b32(r_hi, e[jt].w, e[jt + 1].w, 0x96);
         }
       }
-      uint64_t pre[C];
-      uint32_t prbits = 1; // bit (C - 1 - j): column j holds a hash smaller than every one to its left (column 0: always)
       h[0] = canon_pair(f_lo, f_hi, r_lo, r_hi);
-      pre[0] = h[0];
       {
         const uint32_t bi = b0 + k;
         const uint32_t di = bi >> 4, shi = (bi & 15u) << 1;
@@ -348,12 +396,25 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
               r_hi ^= terms[jj].w;
               sror_pair(r_lo, r_hi);
               h[j] = canon_pair(f_lo, f_hi, r_lo, r_hi);
-              const bool lt = h[j] < pre[j - 1]; // strict: the leftmost of equal hashes stays
-              pre[j] = lt ? h[j] : pre[j - 1];
-              prbits = prbits + prbits + (lt ? 1u : 0u);
             }
           }
         }
+      }
+      uint32_t inval = 0; // bit j: the k-mer of column j holds a non-base
+      if (tile_dirty) {
+        lds_sync();
+        inval = windows_with_non_base((const uint32_t*)vbits, b0, k) & ((1u << C) - 1u);
+#pragma unroll
+        for (int j = 0; j < C; ++j) h[j] = ((inval >> j) & 1u) ? ~0ull : h[j];
+      }
+      uint64_t pre[C];
+      uint32_t prbits = 1; // bit (C - 1 - j): column j holds a hash smaller than every one to its left (column 0: always)
+      pre[0] = h[0];
+#pragma unroll
+      for (int j = 1; j < C; ++j) {
+        const bool lt = h[j] < pre[j - 1]; // strict: the leftmost of equal hashes stays
+        pre[j] = lt ? h[j] : pre[j - 1];
+        prbits = prbits + prbits + (lt ? 1u : 0u);
       }
 
       // ---- backward: suffix minima, suffix records, and where the next block's prefix takes over ------------------
@@ -398,7 +459,7 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
         const uint32_t cstop = (uint32_t)__builtin_ctz(SR & ~((1u << (istar - 1u)) - 1u));
         mask_b = SR & ((2u << cstop) - 1u);
       }
-      pick = mask_a | mask_b;
+      pick = (mask_a | mask_b) & ~inval; // (a window whose every k-mer holds a non-base picks nothing)
       cnt = (uint32_t)__builtin_popcount(pick);
       incl = wave_incl_add32(cnt);
       tile_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -414,8 +475,9 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
     old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
     if (old == waves - 1u) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-      lead(rd, par);
+      sum_round(rd, par);
     }
+    if (old == 0u && rd != 0u) try_lead(rd - 1u);
     if (have_prev) flush_prev();
     if (has) {
       // ---- park the tile's picks (hash, position) in the stash, straight from the registers; a tile with more than
@@ -440,6 +502,7 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
         prev_read = rf + lr;
         prev_first = first_block;
       } else {
+        try_lead(rd);
         while (tag[par] != rd + 1u) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         const uint64_t base = woff[par * 16u + wave];
@@ -458,7 +521,6 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
     }
   }
   if (have_prev) flush_prev();
-  if (__ballot(bad != 0u) != 0ull && lane == 0) atomicOr(a.dirty, 1u);
 }
 
 } // namespace ntamd

@@ -1300,11 +1300,13 @@ def test_minimizers_fused_one_pass(oracle, n, L, k, w, C):
     import nthash_amd
     from numpy.lib.stride_tricks import sliding_window_view
     if C:
-        os.environ["NTHIP_TUNE_MZ_C"] = str(C)
+        os.environ["NTHIP_TUNE_MZ_C"] = str(C)           # (a forced run length: of the any-run-length form)
+        os.environ["NTHIP_TUNE_MZ_FUSED"] = "1"
     try:
         ctx = nthash_amd.Context(0)
     finally:
         os.environ.pop("NTHIP_TUNE_MZ_C", None)
+        os.environ.pop("NTHIP_TUNE_MZ_FUSED", None)
     os.environ["NTHIP_TUNE_MZ_FUSED"] = "2"
     try:
         old = nthash_amd.Context(0)
@@ -1329,16 +1331,21 @@ def test_minimizers_fused_one_pass(oracle, n, L, k, w, C):
     exp_pos, exp_h = pp.astype(np.uint32), hs[rr, pp]
     ctx.set_profiling(True)
     got = ctx.minimizers(data, k, w, L, n, device_input=True)
-    if w <= 100 and w <= nwin:    # (w beyond 7 blocks of 16 windows, or beyond the read: the round-3 kernels)
-        record_form = C in (0, w) and 4 <= w <= 16 and k <= 32 and -(-nwin // w) <= 64
-        assert ctx.last_kernel_ms()[1] == ("minimizer_w_kernel" if record_form else "minimizer_fused_kernel")
+    record_form = C == 0 and 4 <= w <= 16 and k <= 32 and w <= nwin and -(-nwin // w) <= 64
+    if record_form:
+        assert ctx.last_kernel_ms()[1] == "minimizer_w_kernel"
+    elif C:
+        assert ctx.last_kernel_ms()[1] == "minimizer_fused_kernel"
     assert got["total"] == len(exp_pos)
     assert (got["offsets"] == exp_off).all()
     assert (got["pos"] == exp_pos).all()
     assert (got["hashes"] == exp_h).all()
     if n <= 5000:
+        gen.set_profiling(True)
         for other in (old, gen):
             ref = other.minimizers(data, k, w, L, n, device_input=True)
+            if other is gen and w <= 100 and w <= nwin:    # (w beyond 7 blocks of 16 windows, or beyond the read: the round-3 kernels)
+                assert gen.last_kernel_ms()[1] == "minimizer_fused_kernel"
             assert ref["total"] == got["total"] and (ref["offsets"] == got["offsets"]).all()
             assert (ref["pos"] == got["pos"]).all() and (ref["hashes"] == got["hashes"]).all()
         with pytest.raises(nthash_amd.NtHipError) as ei:        # too small a capacity: the need is reported, nothing past it written
@@ -1354,6 +1361,31 @@ def test_minimizers_fused_one_pass(oracle, n, L, k, w, C):
     ctx.close()
     old.close()
     gen.close()
+
+
+@pytest.mark.parametrize("w", [4, 10, 16, 21])
+def test_minimizers_one_pass_when_every_window_picks(ctx, oracle, w):
+    """reads of ONE repeated base: all hashes equal, the leftmost wins, so every window picks a new position -- the densest
+    output there is.  In the record form every tile overflows the stash that parks a tile's picks for a round and writes
+    them itself (the wave claims its round's look-back early); mixed with ordinary reads so that both ways meet in one block"""
+    n, L, k = 40000, 150, 31
+    data = oracle.synth_reads(9, n, L, 5).copy().reshape(n, L)
+    data[: n // 2] = ord("A")
+    data[n // 2 + 7:: 50] = ord("c")
+    data = data.ravel()
+    nwin = L - k + 1
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    from numpy.lib.stride_tricks import sliding_window_view
+    hs = oracle.kmer_batch(data, offs, k, 1, want_pos=False)["hashes"].ravel().reshape(n, nwin)
+    arg = sliding_window_view(hs, w, axis=1).argmin(axis=2) + np.arange(nwin - w + 1)[None, :]
+    pick = np.zeros((n, nwin), dtype=bool)
+    np.put_along_axis(pick, arg, True, axis=1)
+    rr, pp = np.nonzero(pick)
+    got = ctx.minimizers(data, k, w, L, n, device_input=True)
+    assert got["total"] == len(pp) and got["total"] >= (n // 2) * (nwin - w + 1)
+    assert (got["offsets"] == np.concatenate([[0], np.cumsum(pick.sum(axis=1))]).astype(np.uint64)).all()
+    assert (got["pos"] == pp.astype(np.uint32)).all()
+    assert (got["hashes"] == hs[rr, pp]).all()
 
 
 @pytest.mark.parametrize("n,lmax,k,w,dirty", [
