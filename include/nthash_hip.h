@@ -396,6 +396,42 @@ int nthip_multi_seed_hash(nthip_multi* multi, const nthip_reads* reads, const nt
 int nthip_multi_fastx_kmer_hash_file(nthip_multi* multi, const char* path, uint32_t format, uint16_t k, uint8_t m,
                                      uint64_t chunk_bytes, nthip_fastx_fn fn, void* user, nthip_fastx_stats* stats);
 
+/* ---- several GPUs, device-resident (round 4; SURVEY.md 5 "distributed", 8e, 8f-1) ----------------------------------
+ * shards[g] (g < the multi's device count): the g-th device's part of the job -- every pointer in it is memory of THAT
+ * device (allocate through the context nthip_multi_ctx returns; host memory with NTHIP_HOST_INPUT); n_reads == 0: nothing
+ * for that device.  One host thread and one context per device, as nthip_multi_kmer_hash.
+ *
+ * nthip_multi_kmer_hash_shards: nthip_kmer_hash on every device at once, outs[g] / totals[g] per device (device memory
+ * unless NTHIP_HOST_OUTPUT): nothing crosses a link.
+ *
+ * Consumers: every device consumes its shard into ITS table (filters[g] / counters[g] / sigs[g], device memory of device
+ * g, all of one size) exactly as the single-device calls do; then the tables are MERGED over peer copies -- a ring
+ * reduce-scatter with the element-wise operator the table needs (OR / saturating add of one-byte counters / minimum of
+ * 64-bit entries; hipMemcpyPeerAsync + a fold kernel, RCCL has no such operators) -- so only RESULTS cross xGMI, never
+ * a hash stream.  Afterwards tables[0] holds the merged table (what ONE device would have built from all the reads,
+ * merged with whatever the tables held before: zero the ones that should contribute nothing); with
+ * NTHIP_MULTI_ALLGATHER every tables[g] does (a ring all-gather: what a sharded query needs next).
+ *   bloom_insert  n_bits a multiple of 128;   count_insert  n_counters a multiple of 16;
+ *   minhash_set   sigs[g]: (m + 1) & ~1 entries of 64 bits; entry i = the minimum of hashes()[i] over EVERY k-mer of every
+ *                 read (the m-permutation MinHash signature of the set; the per-read ones: nthip_kmer_minhash)
+ * *total (optional): k-mers consumed over all devices.  nthip_multi_merge: the merge alone, on tables built elsewhere.
+ * The reference has no counterpart (one object, one thread: include/nthash/nthash.hpp:196-204); the per-device results
+ * are those of the single-device calls, pinned there. */
+#define NTHIP_MULTI_ALLGATHER 0x100u
+#define NTHIP_MERGE_OR 0
+#define NTHIP_MERGE_ADD_SAT_U8 1
+#define NTHIP_MERGE_MIN_U64 2
+int nthip_multi_ctx(nthip_multi* multi, int index, nthip_ctx** ctx);
+int nthip_multi_kmer_hash_shards(nthip_multi* multi, const nthip_reads* shards, uint16_t k, uint8_t m, const nthip_out* outs,
+                                 uint64_t* totals, uint32_t flags);
+int nthip_multi_kmer_bloom_insert(nthip_multi* multi, const nthip_reads* shards, uint16_t k, uint8_t m, uint8_t* const* d_filters,
+                                  uint64_t n_bits, uint64_t* total, uint32_t flags);
+int nthip_multi_kmer_count_insert(nthip_multi* multi, const nthip_reads* shards, uint16_t k, uint8_t m, uint8_t* const* d_counters,
+                                  uint64_t n_counters, uint64_t* total, uint32_t flags);
+int nthip_multi_kmer_minhash_set(nthip_multi* multi, const nthip_reads* shards, uint16_t k, uint8_t m, uint64_t* const* d_sigs,
+                                 uint64_t* total, uint32_t flags);
+int nthip_multi_merge(nthip_multi* multi, void* const* d_tables, uint64_t bytes, int op, uint32_t flags);
+
 /* ---- measurement helpers (device-resident synthetic data, checksums) ---- */
 /* counter-based reads: read r, 32-base word w ->
  * splitmix64(seed + r*W + w), 2 bits per base, "ACGT"[..]; writes

@@ -45,7 +45,11 @@ SYMBOLS = [
     "nthip_packed_size", "nthip_pack_reads", "nthip_multi_fastx_kmer_hash_file", "nthip_host_alloc", "nthip_host_free",
     "nthip_kmer_count_insert", "nthip_stream_count_insert", "nthip_stream_count_query", "nthip_kmer_minimizers",
     "nthip_stream_bloom_query", "nthip_kmer_minimizers_spans",
+    "nthip_multi_ctx", "nthip_multi_kmer_hash_shards", "nthip_multi_kmer_bloom_insert", "nthip_multi_kmer_count_insert",
+    "nthip_multi_kmer_minhash_set", "nthip_multi_merge",
 ]
+NTHIP_MULTI_ALLGATHER = 0x100
+NTHIP_MERGE_OR, NTHIP_MERGE_ADD_SAT_U8, NTHIP_MERGE_MIN_U64 = 0, 1, 2
 
 
 class NtHipError(RuntimeError):
@@ -152,6 +156,12 @@ def load():
     L.nthip_multi_seeds_create.argtypes = [vp, C.POINTER(C.c_char_p), u32, C.c_uint16, C.POINTER(vp), C.POINTER(C.c_int)]
     L.nthip_multi_seeds_destroy.argtypes = [vp]
     L.nthip_multi_seed_hash.argtypes = [vp, vp, vp, C.c_uint8, vp, C.POINTER(u64)]
+    L.nthip_multi_ctx.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.nthip_multi_kmer_hash_shards.argtypes = [vp, vp, C.c_uint16, C.c_uint8, vp, C.POINTER(u64), u32]
+    L.nthip_multi_kmer_bloom_insert.argtypes = [vp, vp, C.c_uint16, C.c_uint8, C.POINTER(vp), u64, C.POINTER(u64), u32]
+    L.nthip_multi_kmer_count_insert.argtypes = [vp, vp, C.c_uint16, C.c_uint8, C.POINTER(vp), u64, C.POINTER(u64), u32]
+    L.nthip_multi_kmer_minhash_set.argtypes = [vp, vp, C.c_uint16, C.c_uint8, C.POINTER(vp), C.POINTER(u64), u32]
+    L.nthip_multi_merge.argtypes = [vp, C.POINTER(vp), u64, C.c_int, u32]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("nthip_version", "nthip_last_error"):
@@ -682,6 +692,54 @@ class Multi:
         n = C.c_int(0)
         _chk(self.L.nthip_multi_device_count(self.h, C.byref(n)))
         return n.value
+
+    # -- device-resident shards, consumers, the merge of their tables over peer copies (round 4) --
+    def ctx(self, index):
+        """the context of the index-th device of the set (owned by the set: do not close it)"""
+        h = C.c_void_p()
+        _chk(self.L.nthip_multi_ctx(self.h, index, C.byref(h)))
+        c = Context.__new__(Context)
+        c.L = self.L
+        c.h = h
+        c.close = lambda: None
+        return c
+
+    def _shards(self, shards):
+        arr = (Reads * len(shards))()
+        for i, (seqs, offsets, n_reads, fixed_len, stride) in enumerate(shards):
+            arr[i] = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
+        return arr
+
+    def _tables(self, ptrs):
+        return (C.c_void_p * len(ptrs))(*[C.c_void_p(p) for p in ptrs])
+
+    def kmer_hash_shards(self, shards, k, m, outs, flags=0):
+        """shards: per device (seqs, offsets, n_reads, fixed_len, stride) with device pointers of that device; outs: per device
+        (d_hashes, capacity).  -> per-device totals"""
+        oa = (Out * len(outs))()
+        for i, (d_h, cap) in enumerate(outs):
+            oa[i] = Out(d_h, cap, None, None, None, None)
+        tots = (C.c_uint64 * len(shards))()
+        _chk(self.L.nthip_multi_kmer_hash_shards(self.h, self._shards(shards), k, m, oa, tots, flags))
+        return list(tots)
+
+    def bloom_insert(self, shards, k, m, d_filters, n_bits, flags=0):
+        total = C.c_uint64(0)
+        _chk(self.L.nthip_multi_kmer_bloom_insert(self.h, self._shards(shards), k, m, self._tables(d_filters), n_bits, C.byref(total), flags))
+        return total.value
+
+    def count_insert(self, shards, k, m, d_counters, n_counters, flags=0):
+        total = C.c_uint64(0)
+        _chk(self.L.nthip_multi_kmer_count_insert(self.h, self._shards(shards), k, m, self._tables(d_counters), n_counters, C.byref(total), flags))
+        return total.value
+
+    def minhash_set(self, shards, k, m, d_sigs, flags=0):
+        total = C.c_uint64(0)
+        _chk(self.L.nthip_multi_kmer_minhash_set(self.h, self._shards(shards), k, m, self._tables(d_sigs), C.byref(total), flags))
+        return total.value
+
+    def merge(self, d_tables, nbytes, op, flags=0):
+        _chk(self.L.nthip_multi_merge(self.h, self._tables(d_tables), nbytes, op, flags))
 
     def fastx_kmer_hash_file(self, path, fmt, k, m, chunk_bytes=0, on_batch=None):
         """stream a FASTQ / single-line FASTA file over the devices; on_batch(FastxBatch) sees every batch once, in file

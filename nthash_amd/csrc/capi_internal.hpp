@@ -17,6 +17,7 @@
 //   capi_fastx.hip         FASTQ / FASTA indexing and the file streaming driver
 //   capi_packed.hip        2-bit packed input: nthip_pack_reads, nthip_kmer_hash with NTHIP_PACKED_INPUT
 //   capi_multi.hip         several devices of one node: shards of a host batch, one thread + context per device
+//   capi_multi_sink.hip    ... device-resident shards, consumers per device, the merge of their tables over peer copies
 // Kernels live in the *_kernel(s).hpp headers; every TU instantiates only the ones it launches.
 // There is no CPU hashing path in any of them.
 #pragma once
@@ -169,6 +170,11 @@ struct nthip_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr};
   } fx;
+};
+
+// several devices of one node (capi_multi.hip, capi_multi_sink.hip): one context per listed device
+struct nthip_multi {
+  std::vector<nthip_ctx*> ctx;
 };
 
 struct nthip_seeds {

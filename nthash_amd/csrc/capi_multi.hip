@@ -15,10 +15,6 @@
 using namespace ntamd;
 using namespace ntamd::host;
 
-struct nthip_multi {
-  std::vector<nthip_ctx*> ctx;
-};
-
 struct nthip_multi_seeds {
   nthip_multi* owner = nullptr;
   std::vector<nthip_seeds*> per_ctx;

@@ -2737,6 +2737,116 @@ def test_windowed_build_of_the_headline_kernel_is_bit_exact():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("devices,allgather", [([0, 0], False), ([0, 0], True), ([0, 0, 0], True), ([0, 0, 0, 0], False),
+                                               ([0, 0, 0, 0, 0], True)])
+def test_multi_device_consumers_merge_over_peer_copies(ctx, oracle, devices, allgather):
+    """nthip_multi_kmer_bloom_insert / _count_insert / _minhash_set (round 4): every device of the set consumes its
+    device-resident shard into its own table, then the tables are merged by the ring reduce-scatter (+ all-gather) over
+    peer copies -- OR, saturating add of one-byte counters, minimum of 64-bit entries.  The box has one GPU, so it is listed
+    2-5 times (peer-to-self copies; separate contexts, threads, tables and staging buffers: the code an 8-GPU node runs).
+    Against ONE device consuming all the reads: bit for bit, what the tables held before included; uneven shards, an empty
+    shard, reads with non-bases; the merge alone on random tables; the device-resident nthip_multi_kmer_hash_shards."""
+    import nthash_amd
+    from nthash_amd import capi
+    G = len(devices)
+    n, L, k, m = 9000, 150, 31, 2
+    nwin = L - k + 1
+    data = oracle.synth_reads(77, n, L, 3).copy()
+    data[5 * L + 40] = ord("N")
+    data[(n - 1) * L + 3] = ord("n")
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    n_bits, n_cnt = 1 << 21, 9008          # (2.1 M values on 9008 counters: some saturate, most do not)
+    rng = np.random.default_rng(4)
+    prior_f = (rng.integers(0, 256, n_bits // 8, dtype=np.uint8) & rng.integers(0, 256, n_bits // 8, dtype=np.uint8)
+               & rng.integers(0, 256, n_bits // 8, dtype=np.uint8))
+    prior_c = rng.integers(0, 3, n_cnt, dtype=np.uint8)
+    # one device, all the reads
+    d_in, d_f, d_c = ctx.malloc(n * L), ctx.malloc(n_bits // 8), ctx.malloc(n_cnt)
+    ctx.h2d(d_in, data)
+    ctx.h2d(d_f, prior_f)
+    ctx.h2d(d_c, prior_c)
+    tot1 = ctx.bloom_insert_ptr(d_in, n, L, 0, k, m, d_f, n_bits)
+    ctx.count_insert_ptr(d_in, n, L, 0, k, m, d_c, n_cnt)
+    one_f, one_c = np.zeros(n_bits // 8, np.uint8), np.zeros(n_cnt, np.uint8)
+    ctx.d2h(one_f, d_f)
+    ctx.d2h(one_c, d_c)
+    assert one_c.max() == 255          # (hot counters saturate: the merge must saturate the same way)
+    for p in (d_in, d_f, d_c):
+        ctx.free(p)
+    one_sig = want["hashes"].reshape(-1, m).min(axis=0)
+    # the set: uneven shards, the second one empty when there are more than two devices
+    cuts = [0] + sorted(int(x) for x in rng.integers(1, n, G - 1)) + [n]
+    if G > 2:
+        cuts[2] = cuts[1]
+    mm = nthash_amd.Multi(devices)
+    assert mm.device_count() == G
+    cs = [mm.ctx(g) for g in range(G)]
+    shards, owned = [], []
+    flt, cnt, sig, outs = [], [], [], []
+    pad_m = (m + 1) & ~1
+    for g in range(G):
+        r0, r1 = cuts[g], cuts[g + 1]
+        d = cs[g].malloc(max((r1 - r0) * L, 16))
+        if r1 > r0:
+            cs[g].h2d(d, data[r0 * L: r1 * L])
+        shards.append((d, 0, r1 - r0, L, 0))
+        f, c_, s_ = cs[g].malloc(n_bits // 8), cs[g].malloc(n_cnt), cs[g].malloc(pad_m * 8)
+        o = cs[g].malloc(max((r1 - r0) * nwin * m * 8, 16))
+        if g == 0:
+            cs[g].h2d(f, prior_f)
+            cs[g].h2d(c_, prior_c)
+        else:
+            cs[g].memset(f, 0, n_bits // 8)
+            cs[g].memset(c_, 0, n_cnt)
+        flt.append(f); cnt.append(c_); sig.append(s_); outs.append((o, (r1 - r0) * nwin))
+        owned += [(g, d), (g, f), (g, c_), (g, s_), (g, o)]
+    flags = capi.NTHIP_MULTI_ALLGATHER if allgather else 0
+    assert mm.bloom_insert(shards, k, m, flt, n_bits, flags) == tot1 == want["total"]
+    assert mm.count_insert(shards, k, m, cnt, n_cnt, flags) == tot1
+    assert mm.minhash_set(shards, k, m, sig, flags) == tot1
+    for g in (range(G) if allgather else [0]):
+        gf, gc, gs = np.zeros(n_bits // 8, np.uint8), np.zeros(n_cnt, np.uint8), np.zeros(pad_m, np.uint64)
+        cs[g].d2h(gf, flt[g]); cs[g].d2h(gc, cnt[g]); cs[g].d2h(gs, sig[g])
+        assert (gf == one_f).all(), g
+        assert (gc == one_c).all(), g
+        assert (gs[:m] == one_sig).all(), g
+    # the device-resident hash call: every device's stream is its shard of the single call's stream
+    tots = mm.kmer_hash_shards(shards, k, m, outs)
+    at = 0
+    for g in range(G):
+        got = np.zeros(tots[g] * m, np.uint64)
+        if tots[g]:
+            cs[g].d2h(got, outs[g][0])
+        assert (got.reshape(-1, m) == want["hashes"].reshape(-1, m)[at: at + tots[g]]).all()
+        at += tots[g]
+    assert at == want["total"]
+    # the merge alone, the three operators on random tables of an awkward size
+    nb = 16 * 1031
+    for op, name in ((capi.NTHIP_MERGE_OR, "or"), (capi.NTHIP_MERGE_ADD_SAT_U8, "add"), (capi.NTHIP_MERGE_MIN_U64, "min")):
+        tabs = [rng.integers(0, 120 if name == "add" else 256, nb, dtype=np.uint8) for _ in range(G)]
+        ptrs = []
+        for g in range(G):
+            p_ = cs[g].malloc(nb)
+            cs[g].h2d(p_, tabs[g])
+            ptrs.append(p_)
+            owned.append((g, p_))
+        mm.merge(ptrs, nb, op, flags)
+        if name == "or":
+            exp = np.bitwise_or.reduce(np.stack(tabs), axis=0)
+        elif name == "add":
+            exp = np.minimum(np.stack(tabs).astype(np.int64).sum(axis=0), 255).astype(np.uint8)
+        else:
+            exp = np.stack([t.view(np.uint64) for t in tabs]).min(axis=0).view(np.uint8)
+        for g in (range(G) if allgather else [0]):
+            got = np.zeros(nb, np.uint8)
+            cs[g].d2h(got, ptrs[g])
+            assert (got == exp).all(), (name, g)
+    for g, p_ in owned:
+        cs[g].free(p_)
+    mm.close()
+
+
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0]])
 def test_multi_device_shards_give_the_single_call_stream(oracle, devices):
     """nthip_multi_*: a host batch cut into one shard of reads per device (here the box's GPU listed several times: one

@@ -121,3 +121,94 @@ def test_two_rank_gloo_shards_real_work():
         e = gold[("c2", rank * 125_000_000, 20_000)]
         assert format(res[0][5][rank], "016x") == e["sum"]
         assert format(res[0][6][rank], "016x") == e["xor"]
+
+
+# ---- the merge of the consumers' tables: the one inter-GPU step (nthash_amd/sharding.py, capi_multi_sink.hip) ----------
+def _tables(op, world, nbytes, seed):
+    rng = np.random.default_rng(seed)
+    hi = 120 if op == "add_sat_u8" else 256       # (sums that saturate and sums that do not)
+    return [rng.integers(0, hi, nbytes, dtype=np.uint8) for _ in range(world)]
+
+
+def _reduce(op, tabs):
+    if op == "or":
+        return np.bitwise_or.reduce(np.stack(tabs), axis=0)
+    if op == "add_sat_u8":
+        return np.minimum(np.stack(tabs).astype(np.int64).sum(axis=0), 255).astype(np.uint8)
+    return np.stack([t.view(np.uint64) for t in tabs]).min(axis=0).view(np.uint8)
+
+
+@pytest.mark.parametrize("op", ["or", "add_sat_u8", "min_u64"])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_ring_merge_schedule_in_one_process(op, world):
+    """the ring's schedule and the three fold operators, ranks as threads exchanging through queues: every rank ends with
+    the element-wise reduction of all tables (all-gather), or with its finished segment (reduce-scatter alone)"""
+    import queue
+    import threading
+
+    import torch
+
+    from nthash_amd import sharding as sh
+    for nbytes in (16 * world, 48, 4096, 16 * 1031):
+        tabs = _tables(op, world, nbytes, 5 * world + nbytes)
+        want = _reduce(op, tabs)
+        for allgather in (True, False):
+            qs = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+            outs = [None] * world
+
+            def run(r):
+                def send(x, dst):
+                    qs[(r, dst)].put(x.clone())
+
+                def recv(x, src):
+                    x.copy_(qs[(src, r)].get(timeout=60))
+                outs[r] = sh.ring_merge(torch.from_numpy(tabs[r].copy()), op, r, world, send, recv, allgather).numpy()
+            th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            seg = sh.ring_segments(nbytes, world)
+            for r in range(world):
+                if allgather:
+                    assert (outs[r] == want).all()
+                else:
+                    i = (r + 1) % world
+                    assert (outs[r][seg[i]:seg[i + 1]] == want[seg[i]:seg[i + 1]]).all()
+
+
+def _merge_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    from nthash_amd import sharding as sh
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    res = {}
+    for op in ("or", "add_sat_u8", "min_u64"):
+        tabs = _tables(op, world, 1 << 16, 99)
+        t = torch.from_numpy(tabs[rank].copy())
+        sh.ring_merge_dist(t, op)
+        res[op] = bool((t.numpy() == _reduce(op, tabs)).all())
+    dist.barrier()
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_merge_of_the_consumers_tables():
+    """world size 2, one process per rank as on the GPUs: filter OR, saturating counter add and signature minimum travel as
+    ring segments over send / recv and are folded locally -- both ranks end with the table one device would have built"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_merge_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(all(r[1].values()) for r in res), res
