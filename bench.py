@@ -93,6 +93,10 @@ def parse():
     ap.add_argument("--no-plain-pass", action="store_true",
                     help="skip the extra pass on plain hipMalloc buffers (roofline.frac_plain_alloc)")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
+    ap.add_argument("--dist-consumer-reads", type=int, default=20_000_000,
+                    help="reads per rank of the `dist_consumer` line (tests: reduced; the filter shrinks with it)")
+    ap.add_argument("--no-dist-consumer", action="store_true",
+                    help="skip the Bloom-insert-and-merge line of the N-GPU runs (`dist_consumer`)")
     ap.add_argument("--consumers-reads", type=int, default=0,
                     help="only the `consumers` object (Bloom / counting sketch / minimizers / MinHash) on this many reads")
     return ap.parse_args()
@@ -593,6 +597,61 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
     return out
 
 
+def dist_consumer_line(torch, dist, ctx, dev, rank, world, share, barrier, n_reads=20_000_000, n_bits=1 << 33):
+    """Bloom insert over the ranks: rank r inserts reads [r * n_reads, (r + 1) * n_reads) of the counter-based set into its own
+    1 GiB filter (device-resident, the single-device call), then the filters are OR-merged over the ring (reduce-scatter +
+    all-gather of nthash_amd/sharding.py on the job's process group) so that every rank holds the filter of ALL reads.
+    Checked: every rank finds every k-mer of its own shard in the merged filter, and all ranks hold the same number of set
+    bits.  `value` = all ranks' k-mers / (slowest insert + slowest merge)."""
+    from nthash_amd.sharding import ring_merge_dist
+    L, k = 150, 31
+    nwin = L - k + 1
+    kmers = n_reads * nwin
+    d_in = ctx.malloc(n_reads * L)
+    try:
+        ctx.synth_reads_ptr(d_in, rank * n_reads, n_reads, L, 42)
+        filt = torch.zeros(n_bits // 8, dtype=torch.uint8, device=dev)
+        barrier()
+        t0 = time.perf_counter()
+        tot = ctx.bloom_insert_ptr(d_in, n_reads, L, 0, k, 1, filt.data_ptr(), n_bits)
+        torch.cuda.synchronize(dev)
+        t_ins = time.perf_counter() - t0
+        barrier()
+        t0 = time.perf_counter()
+        if share:   # (test mode: the ranks share one GPU and talk over gloo, which moves host tensors)
+            host = filt.cpu()
+            ring_merge_dist(host, "or")
+            filt.copy_(host)
+        else:
+            ring_merge_dist(filt, "or")
+        torch.cuda.synchronize(dev)
+        t_merge = time.perf_counter() - t0
+        barrier()
+        tq, found = ctx.bloom_query_ptr(d_in, n_reads, L, 0, k, 1, filt.data_ptr(), n_bits)
+        bits = int(torch.sum(torch.bitwise_count(filt.view(torch.int64)) if hasattr(torch, "bitwise_count") else
+                             filt.to(torch.int64).sum()).item())
+        cpu_dev = "cpu" if share else dev
+        t = torch.tensor([t_ins, t_merge], dtype=torch.float64, device=cpu_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        g = [torch.zeros(2, dtype=torch.float64, device=cpu_dev) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([float(bits), 1.0 if (tot == kmers and tq == kmers and found == kmers) else 0.0],
+                                        dtype=torch.float64, device=cpu_dev))
+        t_ins, t_merge = float(t[0]), float(t[1])
+        moved = 2 * (world - 1) / world * (n_bits // 8)   # bytes every rank sends (and receives) over its ring links
+        return {"what": "Bloom insert, one 1 GiB filter per rank, OR-merged over the ring (reduce-scatter + all-gather)",
+                "reads_per_rank": n_reads, "kmers": kmers * world, "n_bits": n_bits,
+                "value": kmers * world / (t_ins + t_merge), "unit": "kmers/s (all ranks; insert + merge)",
+                "insert_ms": t_ins * 1e3, "merge_ms": t_merge * 1e3,
+                "merge_GBps_per_rank": (moved / t_merge / 1e9) if world > 1 and t_merge > 0 else None,
+                "set_bits": [int(float(q[0])) for q in g],
+                "check": "every rank finds all k-mers of its shard in the merged filter; all ranks hold the same filter population",
+                "ok": bool(all(float(q[1]) == 1.0 for q in g) and len({int(float(q[0])) for q in g}) == 1),
+                "hardware_note": None if world > 1 else "world size 1: the ring has no step to take (the N > 1 path is the gloo / "
+                                                        "peer-to-self tests' until the driver runs it on a node)"}
+    finally:
+        ctx.free(d_in)
+
+
 def measured_peak(torch, ctx, dev):
     """Write-only and copy rates of this box, same process, same clock: the achievable ceilings next to the spec.
     (32 GiB per launch: an 8 GiB fill lasts 1.2 ms and measures 5.6 TB/s on a box whose 24 GiB fill runs at 7.0.)"""
@@ -719,6 +778,16 @@ def main():
             wp.free()
         except Exception as e:
             plain_roof = {"error": str(e)}
+    # the N-GPU consumer line (SURVEY 8e + 8f-1): every rank inserts its shard into its OWN Bloom filter; what crosses xGMI is
+    # the filter, merged by the ring of nthash_amd/sharding.py (RCCL send / recv + a local OR: RCCL has no bitwise reduce)
+    dist_consumer = None
+    if use_dist and not args.no_dist_consumer:
+        try:
+            dcr = args.dist_consumer_reads
+            dist_consumer = dist_consumer_line(torch, dist, ctx, dev, rank, world, share, barrier, dcr,
+                                               1 << 33 if dcr >= 20_000_000 else 1 << 28)
+        except Exception as e:  # noqa: BLE001
+            dist_consumer = {"error": str(e)}
     per_rank = [kmers / my_dt]
     all_ok = ok_local
     checked_full = verify["ok"] is True
@@ -788,6 +857,8 @@ def main():
                                     if use_dist else None,
                      "forced_at_world_1": bool(use_dist and world == 1)},
         }
+        if dist_consumer is not None:
+            res["dist_consumer"] = dist_consumer
     # ---- N = 1 extras: measured ceiling, the other single-GPU configs, the CPU beside it ----------------------
     if world == 1:
         if not args.no_peak:

@@ -62,10 +62,11 @@ def fold(op, mine, theirs):
     return mine
 
 
-def ring_merge(table, op, rank, world, send, recv, allgather=True):
-    """Merge `table` (1-D uint8 torch tensor, the same size on every rank) over the ring.  send(tensor, dst) / recv(tensor,
-    src) move one tensor between neighbours (blocking or not: every step posts its send before it waits for its receive).
-    With allgather every rank ends with the merged table, else only segment (rank + 1) % world of it is final."""
+def ring_merge(table, op, rank, world, exchange, allgather=True):
+    """Merge `table` (1-D uint8 torch tensor, the same size on every rank) over the ring.  exchange(out, dst, inp, src) sends
+    the tensor `out` to rank dst and fills `inp` from rank src (both neighbours, one call per step: a backend that must
+    post the pair together can).  With allgather every rank ends with the merged table, else only segment
+    (rank + 1) % world of it is final."""
     import torch
     if world == 1:
         return table
@@ -74,30 +75,28 @@ def ring_merge(table, op, rank, world, send, recv, allgather=True):
     tmp = torch.empty(max(seg[i + 1] - seg[i] for i in range(world)), dtype=torch.uint8, device=table.device)
     for s, (left, idx) in enumerate(ring_reduce_scatter_steps(rank, world)):
         out_idx = (rank - s) % world                           # what the right neighbour folds in this step
-        pending = send(table[seg[out_idx]:seg[out_idx + 1]], right)
         part = tmp[: seg[idx + 1] - seg[idx]]
-        recv(part, left)
-        if pending is not None:
-            pending.wait()
+        exchange(table[seg[out_idx]:seg[out_idx + 1]], right, part, left)
         fold(op, table[seg[idx]:seg[idx + 1]], part)
     if allgather:
         for s, (left, idx) in enumerate(ring_all_gather_steps(rank, world)):
             out_idx = (rank + 1 - s) % world
-            pending = send(table[seg[out_idx]:seg[out_idx + 1]], right)
-            recv(table[seg[idx]:seg[idx + 1]], left)
-            if pending is not None:
-                pending.wait()
+            exchange(table[seg[out_idx]:seg[out_idx + 1]], right, table[seg[idx]:seg[idx + 1]], left)
     return table
 
 
 def ring_merge_dist(table, op, group=None, allgather=True):
-    """ring_merge over a torch.distributed process group (one process per GPU; "nccl" = RCCL over xGMI, gloo on the CPU)"""
+    """ring_merge over a torch.distributed process group (one process per GPU; "nccl" = RCCL over xGMI, gloo on the CPU):
+    a step's send and receive are posted together (batch_isend_irecv), as RCCL's point-to-point calls ask"""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
 
-    def send(t, dst):
-        return dist.isend(t.contiguous(), dst, group=group)
-
-    def recv(t, src):
-        dist.recv(t, src, group=group)
-    return ring_merge(table, op, rank, world, send, recv, allgather)
+    def exchange(out, dst, inp, src):
+        ops = []
+        if out.numel():
+            ops.append(dist.P2POp(dist.isend, out, dst, group))
+        if inp.numel():
+            ops.append(dist.P2POp(dist.irecv, inp, src, group))
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+    return ring_merge(table, op, rank, world, exchange, allgather)

@@ -33,9 +33,13 @@ def run_bench(*argv, env=None, timeout=900):
 
 def test_bench_two_ranks_self_launch():
     """--gpus 2 without a launcher: two ranks, each its own shard, whole-job value, every rank verified"""
-    res = run_bench("--gpus", "2", "--reads", "2000000", "--steps", "2", "--warmup", "1",
+    res = run_bench("--gpus", "2", "--reads", "2000000", "--steps", "2", "--warmup", "1", "--dist-consumer-reads", "1000000",
                     env={"NTHASH_BENCH_SHARE_GPU": "1"})
     assert res["n_gpus"] == 2
+    # the N-GPU consumer line: a filter per rank, OR-merged over the ring (here: two ranks, gloo), every rank's k-mers found
+    dc = res["dist_consumer"]
+    assert dc["ok"] is True and len(set(dc["set_bits"])) == 1 and dc["set_bits"][0] > 0, dc
+    assert dc["kmers"] == 2 * 1_000_000 * 120 and dc["merge_ms"] > 0 and dc["merge_GBps_per_rank"] > 0
     assert res["scaling"] == "weak"
     assert res["verified_vs_oracle"] is True
     assert len(res["per_rank_kmers_per_s"]) == 2 and all(v > 0 for v in res["per_rank_kmers_per_s"])
@@ -73,8 +77,9 @@ def test_bench_rccl_process_group_at_world_size_one():
     """NTHASH_BENCH_FORCE_DIST=1: the branch an N-GPU run takes -- init_process_group(backend="nccl") = RCCL, barrier,
     all_reduce(MAX) of the step time, all_gather of the per-rank rates and verdicts -- runs on this box's one GPU"""
     res = run_bench("--reads", "2000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-peak",
-                    "--no-secondary", env={"NTHASH_BENCH_FORCE_DIST": "1"})
+                    "--no-secondary", "--dist-consumer-reads", "1000000", env={"NTHASH_BENCH_FORCE_DIST": "1"})
     assert res["n_gpus"] == 1
+    assert res["dist_consumer"]["ok"] is True and res["dist_consumer"]["hardware_note"]
     assert res["dist"]["process_group"] == "nccl (RCCL)" and res["dist"]["forced_at_world_1"] is True
     assert res["verified_vs_oracle"] is True and len(res["per_rank_kmers_per_s"]) == 1
     assert abs(res["per_rank_kmers_per_s"][0] - res["value"]) / res["value"] < 0.2  # (value: max-reduced wall time)
@@ -133,4 +138,7 @@ def test_bench_consumers_section():
     res = run_bench("--consumers-reads", "2000000")["consumers"]
     for key in ("bloom_insert_fresh_4GiB", "count_insert_fresh_1Gi_counters", "minimizers_w10", "minimizers_w10_offsets", "minhash_m4"):
         assert res[key]["ok"] is True and res[key]["value"] > 0, (key, res[key])
+        r = res[key]["roofline"]    # (round 4: every consumer says what it must move and what its kernel of record took)
+        assert r["algorithmic_bytes"] > 0 and 0 < r["frac"] < 1 and r["kernel"] and r["kernel_ms"] > 0, (key, r)
     assert res["bloom_query_4GiB"]["value"] > 0
+    assert res["minimizers_w10"]["roofline"]["kernel"] == "minimizer_w_kernel"

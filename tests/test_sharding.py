@@ -157,12 +157,10 @@ def test_ring_merge_schedule_in_one_process(op, world):
             outs = [None] * world
 
             def run(r):
-                def send(x, dst):
-                    qs[(r, dst)].put(x.clone())
-
-                def recv(x, src):
-                    x.copy_(qs[(src, r)].get(timeout=60))
-                outs[r] = sh.ring_merge(torch.from_numpy(tabs[r].copy()), op, r, world, send, recv, allgather).numpy()
+                def exchange(out, dst, inp, src):
+                    qs[(r, dst)].put(out.clone())
+                    inp.copy_(qs[(src, r)].get(timeout=60))
+                outs[r] = sh.ring_merge(torch.from_numpy(tabs[r].copy()), op, r, world, exchange, allgather).numpy()
             th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
             [t.start() for t in th]
             [t.join() for t in th]
