@@ -204,6 +204,20 @@ int nthip_kmer_extend(nthip_ctx* ctx, const char* kmers, uint64_t n_kmers, uint1
                       uint64_t* self, uint64_t* next, uint64_t* prev, uint32_t flags);
 
 /*
+ * nthip_seed_extend: the same query through spaced seeds -- for each of n windows of k bases (k = the seed set's) the
+ * n_seeds*m2 values of its 4 successors and / or predecessors, i.e. what
+ *     nthash::BlindSeedNtHash h(kmer, seeds, m2, k);          // src/seed.cpp:666-699
+ *     h.roll("ACGT"[b]);  /  h.roll_back("ACGT"[b]);          // src/seed.cpp:701-737
+ * leave in h.hashes(), each from a fresh object.  Layout: next[(i*4 + b)*n_seeds*m2 + s*m2 + j], prev likewise,
+ * self[i*n_seeds*m2 + s*m2 + j] (the window's own values); any of the three may be NULL.  roll_back() reads a seed's
+ * MONOMERS (care runs of one position) from the window it leaves (src/seed.cpp:195-198 reused backwards): reproduced, so
+ * prev is what the reference returns, not the masked formula of the predecessor, whenever a seed has monomers.  Bytes are
+ * not validated (as BlindSeedNtHash): windows must consist of bases.  Seeds of at most 128 bases.
+ */
+int nthip_seed_extend(nthip_ctx* ctx, const char* kmers, uint64_t n_kmers, const nthip_seeds* seeds, uint8_t m2,
+                      uint64_t* self, uint64_t* next, uint64_t* prev, uint32_t flags);
+
+/*
  * Fused consumers of the k-mer hash stream: what ntHash's callers do with
  * hashes() -- Bloom filter insert / membership (the reference points at btllib's Bloom filters,
  * include/nthash/nthash.hpp:14-17,56-57) -- done inside the hashing kernel, so the 8*m bytes per

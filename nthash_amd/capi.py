@@ -46,7 +46,7 @@ SYMBOLS = [
     "nthip_kmer_count_insert", "nthip_stream_count_insert", "nthip_stream_count_query", "nthip_kmer_minimizers",
     "nthip_stream_bloom_query", "nthip_kmer_minimizers_spans",
     "nthip_multi_ctx", "nthip_multi_kmer_hash_shards", "nthip_multi_kmer_bloom_insert", "nthip_multi_kmer_count_insert",
-    "nthip_multi_kmer_minhash_set", "nthip_multi_merge",
+    "nthip_multi_kmer_minhash_set", "nthip_multi_merge", "nthip_seed_extend",
 ]
 NTHIP_MULTI_ALLGATHER = 0x100
 NTHIP_MERGE_OR, NTHIP_MERGE_ADD_SAT_U8, NTHIP_MERGE_MIN_U64 = 0, 1, 2
@@ -120,6 +120,7 @@ def load():
     L.nthip_seed_hash.argtypes = [vp, C.POINTER(Reads), vp, C.c_uint8, C.POINTER(Out),
                                   C.POINTER(u64), u32]
     L.nthip_kmer_extend.argtypes = [vp, vp, u64, C.c_uint16, C.c_uint8, vp, vp, vp, u32]
+    L.nthip_seed_extend.argtypes = [vp, vp, u64, vp, C.c_uint8, vp, vp, vp, u32]
     L.nthip_kmer_bloom_insert.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, u64, C.POINTER(u64), u32]
     L.nthip_kmer_bloom_query.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, u64, vp,
                                          C.POINTER(u64), C.POINTER(u64), u32]
@@ -350,6 +351,32 @@ class Context:
             out["next"] = nx.reshape(n, 4, m)
         if want_prev:
             out["prev"] = pv.reshape(n, 4, m)
+        return out
+
+    def seed_extend(self, kmers, seeds, k, m2, want_self=True, want_next=True, want_prev=True):
+        """host windows (n*k bytes) through the spaced seeds -> dict of self [n, n_seeds*m2], next / prev [n, 4, n_seeds*m2]
+        (base order ACGT; what BlindSeedNtHash::roll / roll_back return from each window)"""
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint8)
+        n = kmers.size // k
+        sd = seeds if isinstance(seeds, Seeds) else Seeds(self, seeds, k)
+        per = sd.n * m2
+        se = np.zeros(n * per, np.uint64) if want_self else None
+        nx = np.zeros(n * 4 * per, np.uint64) if want_next else None
+        pv = np.zeros(n * 4 * per, np.uint64) if want_prev else None
+        p = lambda a: a.ctypes.data if a is not None else None
+        try:
+            _chk(self.L.nthip_seed_extend(self.h, kmers.ctypes.data, n, sd.h, m2, p(se), p(nx), p(pv),
+                                          NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT))
+        finally:
+            if sd is not seeds:
+                sd.close()
+        out = {}
+        if want_self:
+            out["self"] = se.reshape(n, per)
+        if want_next:
+            out["next"] = nx.reshape(n, 4, per)
+        if want_prev:
+            out["prev"] = pv.reshape(n, 4, per)
         return out
 
     # -- fused Bloom-filter consumers (filter: device memory, ceil(n_bits/32)*4 bytes) ---------

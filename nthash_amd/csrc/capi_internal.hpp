@@ -11,6 +11,7 @@
 //   capi_kmer_reads.hip    kmer_reads_kernel (offsets / spans in order, short reads): tiles of whole reads
 //   capi_kmer_ragged.hip   kmer_ragged_kernel (offsets / spans, any lengths)
 //   capi_kmer_general.hip  lane-per-read kernels (correctness paths) and the row-per-read kernel
+//   capi_seed_extend.hip   nthip_seed_extend: the 4 successors / predecessors of n windows through spaced seeds
 //   capi_seed.hip          spaced seeds: dense (seed_wtile / seed_fixed), variable-length (seed_rtile), one wave per read
 //                          (seed_wave), long reads cut into pieces (seed_long_kernels.hpp), lane per read (seed_general)
 //   capi_sink_bloom.hip / capi_sink_minhash.hip   fused consumers
@@ -192,6 +193,12 @@ struct nthip_seeds {
   uint32_t any_groups = 0;
   uint32_t* d_any_mask = nullptr;
   uint4* d_any_acorr = nullptr;
+  // nthip_seed_extend (capi_seed_extend.hip): which positions are covered by an odd number of blocks / are monomers in the
+  // reference's description of every seed (get_blocks, src/seed.cpp:19-66), [n_seeds][k]; the three mask sets of the
+  // kernel -- every contributing position, block positions, monomers -- as [3][n_seeds][any_groups], made on first use
+  std::vector<uint8_t> h_blk_parity, h_is_mono;
+  uint32_t* d_ext_mask = nullptr;
+  uint4* d_ext_acorr = nullptr;
 };
 
 namespace ntamd {

@@ -23,6 +23,7 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
   const uint32_t ntab = k <= 64 ? 4u * ((k + 15) / 16) : (k + 3) / 4, cw = (k + 31) / 32;
   std::vector<uint4> tables((size_t)n_seeds * ntab * 256, make_uint4(0, 0, 0, 0));
   std::vector<uint32_t> care((size_t)n_seeds * cw, 0), blk_start(n_seeds), blk_count(n_seeds), blk_pairs;
+  std::vector<uint8_t> h_blk, h_mono;
   bool asym = false;
   for (uint32_t s = 0; s < n_seeds; ++s) {
     if (!seeds[s]) return fail(NTHIP_ERR_ARG, "seed %u is NULL", s);
@@ -34,6 +35,8 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
     const SeedShape shape = parse_seed_shape(str);
     const std::vector<uint32_t>& pairs = shape.block_pairs;
     const std::vector<uint8_t>& par = shape.care;
+    h_blk.insert(h_blk.end(), shape.blk_parity.begin(), shape.blk_parity.end());
+    h_mono.insert(h_mono.end(), shape.is_mono.begin(), shape.is_mono.end());
     blk_start[s] = (uint32_t)(blk_pairs.size() / 2);
     blk_count[s] = (uint32_t)(pairs.size() / 2);
     blk_pairs.insert(blk_pairs.end(), pairs.begin(), pairs.end());
@@ -72,6 +75,8 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
   sd->ntab = ntab;
   sd->care_words = cw;
   sd->asymmetric = asym;
+  sd->h_blk_parity = h_blk;
+  sd->h_is_mono = h_mono;
   auto up = [&](const void* src, size_t bytes, void** dst) -> int {
     HIPCHK(hipMalloc(dst, bytes));
     HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
@@ -105,6 +110,8 @@ extern "C" int nthip_seeds_destroy(nthip_seeds* sd)
   if (sd->d_blk_pairs) (void)hipFree(sd->d_blk_pairs);
   if (sd->d_any_mask) (void)hipFree(sd->d_any_mask);
   if (sd->d_any_acorr) (void)hipFree(sd->d_any_acorr);
+  if (sd->d_ext_mask) (void)hipFree(sd->d_ext_mask);
+  if (sd->d_ext_acorr) (void)hipFree(sd->d_ext_acorr);
   delete sd;
   return NTHIP_OK;
 }

@@ -384,6 +384,58 @@ void nto_seed_window(const char* win, const char* seed, unsigned k,
   seed_desc_free(&d);
 }
 
+/* BlindSeedNtHash::roll(c) / roll_back(c) from the window `kmer`, for c = A, C, G, T (seed.cpp:701-737 through the NTMSM64
+ * macro, seed.cpp:177-207).  Forward, the macro rolls every block (out = old[b0], in = the window's base at b1) and adds
+ * the monomers from kmer_seq[pos + 1] -- the NEW window: the result is the masked formula of kmer[1..k) + c.  Backward
+ * (ntmsm64l on the deque with c pushed in front) the blocks are those of the new window c + kmer[0..k-1), but the monomers
+ * are read at the same kmer_seq[pos + 1] -- now the OLD window's base at pos (seed.cpp:195-198 reused): reproduced. */
+void nto_seed_extend(const char* kmer, unsigned k, const char* const* seeds, unsigned n_seeds, unsigned m2,
+                     uint64_t* self, uint64_t* next, uint64_t* prev)
+{
+  static const char bases[4] = { 'A', 'C', 'G', 'T' };
+  char* win = (char*)malloc(k + 1);
+  const size_t per = (size_t)n_seeds * m2;
+  for (unsigned s = 0; s < n_seeds; s++) {
+    seed_desc d;
+    seed_desc_make(&d, seeds[s], k);
+    unsigned char* mono = (unsigned char*)calloc(k, 1);
+    for (unsigned i = 0; i < d.nm; i++) mono[d.monos[i]] ^= 1;
+    uint64_t f, r;
+    if (self) {
+      seed_hash_window(&d, kmer, k, &f, &r);
+      nto_extend(f, r, k, m2, self + (size_t)s * m2);
+    }
+    for (unsigned b = 0; b < 4; b++) {
+      if (next) {
+        memcpy(win, kmer + 1, k - 1);
+        win[k - 1] = bases[b];
+        seed_hash_window(&d, win, k, &f, &r);
+        nto_extend(f, r, k, m2, next + b * per + (size_t)s * m2);
+      }
+      if (prev) {
+        win[0] = bases[b];
+        memcpy(win + 1, kmer, k - 1);
+        f = r = 0;
+        for (unsigned p = 0; p < k; p++) {
+          const unsigned blk = d.parity[p] ^ mono[p]; /* covered by an odd number of blocks */
+          if (blk) {
+            f ^= nto_srol_n(nto_seed_fwd((unsigned char)win[p]), k - 1 - p);
+            r ^= nto_srol_n(nto_seed_rc((unsigned char)win[p]), p);
+          }
+          if (mono[p]) {
+            f ^= nto_srol_n(nto_seed_fwd((unsigned char)kmer[p]), k - 1 - p);
+            r ^= nto_srol_n(nto_seed_rc((unsigned char)kmer[p]), p);
+          }
+        }
+        nto_extend(f, r, k, m2, prev + b * per + (size_t)s * m2);
+      }
+    }
+    free(mono);
+    seed_desc_free(&d);
+  }
+  free(win);
+}
+
 /* seed.cpp:146-158: the first-window routine fails on the first NUL byte met
  * while walking seeds -> blocks -> positions in that order. */
 static int seed_first_nul(const seed_desc* ds, unsigned n_seeds, const char* win,

@@ -115,6 +115,8 @@ class Oracle:
         L.nto_get_blocks.argtypes = [C.c_char_p, C.c_uint, _u32p, _u32p, _u32p]
         L.nto_seed_window.restype = None
         L.nto_seed_window.argtypes = [C.c_char_p, C.c_char_p, C.c_uint, _u64p, _u64p]
+        L.nto_seed_extend.restype = None
+        L.nto_seed_extend.argtypes = [C.c_char_p, C.c_uint, C.POINTER(C.c_char_p), C.c_uint, C.c_uint, _u64p, _u64p, _u64p]
         L.nto_splitmix64.restype = C.c_uint64
         L.nto_splitmix64.argtypes = [C.c_uint64]
         L.nto_synth_reads.restype = None
@@ -195,6 +197,16 @@ class Oracle:
     def _seed_batch(self, data, offs, n, sa, k, m2, hashes, pos, counts):
         return self.L.nto_seed_batch(data.ctypes.data, _ptr(offs, _u64p), n, sa.arr, sa.n, k, m2,
                                      _ptr(hashes, _u64p), _ptr(pos, _u32p), _ptr(counts, _u64p))
+
+    def seed_extend(self, kmer, seeds, m2):
+        """BlindSeedNtHash::roll(c) / roll_back(c), c = A, C, G, T, from the window `kmer` (src/seed.cpp:701-737):
+        -> (self [n_seeds * m2], next [4][n_seeds * m2], prev [4][n_seeds * m2])"""
+        kb = kmer.encode("latin-1") if isinstance(kmer, str) else bytes(kmer)
+        sa = _SeedArr(seeds)
+        per = sa.n * m2
+        me, nx, pv = np.zeros(per, np.uint64), np.zeros(4 * per, np.uint64), np.zeros(4 * per, np.uint64)
+        self.L.nto_seed_extend(kb, len(kb), sa.arr, sa.n, m2, _ptr(me, _u64p), _ptr(nx, _u64p), _ptr(pv, _u64p))
+        return me, nx.reshape(4, per), pv.reshape(4, per)
 
     def get_blocks(self, seed):
         k = len(seed)

@@ -229,6 +229,38 @@ def main():
                     "next": [hx(res[1 + b][3]) for b in range(4)],
                     "prev": [hx(res[5 + b][3]) for b in range(4)]})
     json.dump(ext, open(os.path.join(OUT, "extend_cases.json"), "w"), indent=0)
+    # ---- 7. the same query through spaced seeds: BlindSeedNtHash::roll(c) / roll_back(c) per base, each from a fresh object
+    # (src/seed.cpp:701-737).  Seeds with and without monomers (roll_back reads a monomer's base from the window it
+    # leaves, src/seed.cpp:195-198), the don't-care description (get_blocks' second branch), asymmetric seeds, k to 100
+    rng7 = np.random.default_rng(7)
+    sext = []
+
+    def rand_seed(k, kind):
+        if kind == "blocks":       # runs of at least two
+            s, p = "", 0
+            while len(s) < k:
+                run = int(rng7.integers(2, 7))
+                s += ("1" if p % 2 == 0 else "0") * run
+                p += 1
+            s = s[:k]
+            return s if not (s[-1] != s[-2]) else s[:-1] + s[-2]
+        if kind == "dense":        # mostly care: the don't-care description wins
+            a = ["1"] * k
+            for i in rng7.choice(k, max(1, k // 12), replace=False):
+                a[int(i)] = "0"
+            return "".join(a)
+        return "".join("10"[int(x)] for x in rng7.integers(0, 2, k))   # anything: monomers everywhere
+    for i in range(48):
+        k = int(rng7.choice([6, 11, 16, 21, 31, 32, 33, 48, 64, 100]))
+        n_seeds = int(rng7.integers(1, 4))
+        seeds7 = [rand_seed(k, ["blocks", "dense", "any"][(i + j) % 3]) for j in range(n_seeds)]
+        m2 = int(rng7.integers(1, 4))
+        kmer = "".join("ACGTacgtUu"[j] for j in rng7.integers(0, 10, k))
+        base = ref.blindseed_script(kmer, seeds7, m2, k, 0, "")
+        nxt = [hx(ref.blindseed_script(kmer, seeds7, m2, k, 0, "R" + b)[1][3]) for b in "ACGT"]
+        prv = [hx(ref.blindseed_script(kmer, seeds7, m2, k, 0, "B" + b)[1][3]) for b in "ACGT"]
+        sext.append({"kmer": kmer, "k": k, "seeds": seeds7, "m2": m2, "self": hx(base[0][3]), "next": nxt, "prev": prv})
+    json.dump(sext, open(os.path.join(OUT, "seed_extend_cases.json"), "w"), indent=0)
     print("fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

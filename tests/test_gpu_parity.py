@@ -996,6 +996,48 @@ def test_kmer_extend_golden(ctx):
             assert (r["prev"][0, b] == h2i(c["prev"][b])).all(), (c["kmer"], "prev", b)
 
 
+def test_seed_extend_golden(ctx):
+    """nthip_seed_extend against the fixtures recorded from the real BlindSeedNtHash::roll(c) / roll_back(c)
+    (tests/golden/gen_golden.py section 7): seeds with monomers, whose roll_back reads them from the window it leaves,
+    the don't-care description, several seeds, k to 100"""
+    for c in load_golden("seed_extend_cases.json"):
+        kmer = np.frombuffer(c["kmer"].encode("latin-1"), dtype=np.uint8)
+        r = ctx.seed_extend(kmer, c["seeds"], c["k"], c["m2"])
+        assert (r["self"][0] == h2i(c["self"])).all(), (c["kmer"], c["seeds"])
+        for b in range(4):
+            assert (r["next"][0, b] == h2i(c["next"][b])).all(), (c["kmer"], c["seeds"], "next", b)
+            assert (r["prev"][0, b] == h2i(c["prev"][b])).all(), (c["kmer"], c["seeds"], "prev", b)
+
+
+@pytest.mark.parametrize("n,k,n_seeds,m2", [(5000, 31, 2, 3), (3001, 31, 1, 1), (777, 17, 3, 2), (500, 64, 2, 2), (300, 65, 1, 1),
+                                            (200, 100, 2, 2), (64, 6, 1, 1), (1, 48, 2, 1), (100003, 31, 2, 3), (70, 33, 4, 1),
+                                            (1000, 128, 1, 2), (1000, 21, 5, 4)])
+def test_seed_extend_batch_vs_oracle(ctx, oracle, n, k, n_seeds, m2):
+    """a batch of windows against the oracle's nto_seed_extend (pinned to the real reference, tests/test_oracle.py), and
+    the successors against the hash stream: successor b of window i == SeedNtHash of (window[1:] + b)"""
+    rng = np.random.default_rng(k + n_seeds)
+    seeds = ["".join("10"[int(x)] for x in rng.integers(0, 2, k)) for _ in range(n_seeds)]
+    if n_seeds > 1:
+        seeds[1] = "1" * k if k % 2 else "11" + "0" * (k - 4) + "11"
+    kmers = np.frombuffer(b"ACGTacgtUu", dtype=np.uint8)[rng.integers(0, 10, (n, k))]
+    r = ctx.seed_extend(kmers.ravel(), seeds, k, m2)
+    per = n_seeds * m2
+    for i in list(range(min(n, 200))) + [n - 1]:
+        me, nx, pv = oracle.seed_extend(kmers[i].tobytes(), seeds, m2)
+        assert (r["self"][i] == me).all(), i
+        assert (r["next"][i] == nx).all(), i
+        assert (r["prev"][i] == pv).all(), i
+    # every successor through the stream kernels: window[1:] + b as a read of k bases
+    succ = np.empty((n, 4, k), np.uint8)
+    succ[:, :, : k - 1] = kmers[:, None, 1:]
+    succ[:, :, k - 1] = np.frombuffer(b"ACGT", np.uint8)[None, :]
+    offs = np.arange(4 * n + 1, dtype=np.uint64) * k
+    want = oracle.seed_batch(succ.ravel(), offs, seeds, k, m2, want_pos=False)["hashes"]
+    assert (r["next"].reshape(4 * n, per) == want).all()
+    only = ctx.seed_extend(kmers.ravel(), seeds, k, m2, want_self=False, want_next=False)
+    assert (only["prev"] == r["prev"]).all()
+
+
 @pytest.mark.parametrize("n,k,m", [(5000, 31, 3), (3001, 31, 1), (777, 17, 1), (500, 64, 2), (300, 65, 1), (200, 100, 2),
                                    (64, 4, 1), (1, 48, 1), (600033, 31, 1), (70, 33, 1), (4001, 31, 8), (1000, 21, 5), (300000, 25, 2),
                                    (5003, 96, 1), (700, 200, 3), (131, 1000, 2), (70, 2500, 1), (3, 9000, 1)])

@@ -252,3 +252,31 @@ def test_reference_synth_checksum_matches_batch_checksum(oracle, reference):
              else reference.kmer_batch(data, offs, k, m, want_pos=False))
         s, x = reference.checksum(r["hashes"])
         assert reference.synth_checksum(first, n, L, k, m, seeds=seeds, threads=3) == (s, x, int(r["total"]))
+
+
+def test_golden_seed_extend_cases(oracle, reference):
+    """nto_seed_extend -- the 4 successors / predecessors of a window under BlindSeedNtHash::roll(c) / roll_back(c)
+    (src/seed.cpp:701-737) -- against the fixtures recorded from the real reference (tests/golden/gen_golden.py, section 7:
+    seeds with monomers, whose roll_back reads them from the window it leaves; the don't-care description; k to 100), and
+    against the real reference itself on fresh random cases where it is built"""
+    cases = load_golden("seed_extend_cases.json")
+    assert len(cases) >= 40
+    for c in cases:
+        me, nx, pv = oracle.seed_extend(c["kmer"], c["seeds"], c["m2"])
+        assert (me == h2i(c["self"])).all(), c["kmer"]
+        for b in range(4):
+            assert (nx[b] == h2i(c["next"][b])).all(), (c["kmer"], c["seeds"], "next", b)
+            assert (pv[b] == h2i(c["prev"][b])).all(), (c["kmer"], c["seeds"], "prev", b)
+    if reference is None:
+        return
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        k = int(rng.integers(4, 70))
+        seeds = ["".join("10"[int(x)] for x in rng.integers(0, 2, k)) for _ in range(int(rng.integers(1, 4)))]
+        m2 = int(rng.integers(1, 4))
+        kmer = "".join("ACGT"[j] for j in rng.integers(0, 4, k))
+        me, nx, pv = oracle.seed_extend(kmer, seeds, m2)
+        assert (me == reference.blindseed_script(kmer, seeds, m2, k, 0, "")[0][3]).all()
+        for b, ch in enumerate("ACGT"):
+            assert (nx[b] == reference.blindseed_script(kmer, seeds, m2, k, 0, "R" + ch)[1][3]).all()
+            assert (pv[b] == reference.blindseed_script(kmer, seeds, m2, k, 0, "B" + ch)[1][3]).all()
