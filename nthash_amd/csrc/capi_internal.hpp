@@ -267,7 +267,13 @@ int own_alloc(Staged& keep, size_t bytes, void** p);
 // the compact hash stream (m values per k-mer) of a batch given by offsets, hashed in ONE round into memory `keep` owns;
 // d_counts (optional): per-read counts.  NTHIP_ERR_UNSUPPORTED when the stream does not fit the device
 int stream_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m, uint32_t flags, Staged& keep, uint64_t** d_h,
-                      uint64_t** d_counts, uint64_t* n_kmers);
+                      uint64_t** d_counts, uint64_t* n_kmers, uint64_t round_bases = 0);
+// A batch given by offsets, piece by piece (round 4: the consumers took it in ONE round and refused what did not fit): fn(part,
+// r0, bases) for consecutive ranges of reads -- part: the range as a batch of its own (device-resident: the same seqs and
+// offsets + r0; host: rebased), r0: its first read, bases: its bases -- sized so that scratch_per_base bytes of device scratch
+// per base + 48 per read fit the free memory.  One piece when everything fits.
+int offsets_in_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, size_t scratch_per_base,
+                      const std::function<int(const nthip_reads*, uint64_t, uint64_t)>& fn);
 
 // ---- capi_util.hip ------------------------------------------------------------------------------------------
 // exclusive scan of n u64 on the device: out[i] = sum(in[0..i)), *d_total = sum; d_sums: ceil(n/1024) + 16 u64

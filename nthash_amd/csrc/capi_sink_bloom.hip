@@ -1,6 +1,9 @@
 // capi_sink_bloom.hip -- fused consumers of the hash stream: Bloom filter insert / query
 // Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
 #include "capi_internal.hpp"
+
+#include <algorithm>
+
 #include "bloom_binned_kernels.hpp"
 #include "util_kernels.hpp" // (SCAN_TILE)
 
@@ -15,11 +18,59 @@ int ntamd::host::own_alloc(Staged& keep, size_t bytes, void** p)
   return NTHIP_OK;
 }
 
-int ntamd::host::stream_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m, uint32_t flags, Staged& keep, uint64_t** d_h,
-                      uint64_t** d_counts, uint64_t* n_kmers)
+int ntamd::host::offsets_in_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, size_t scratch_per_base,
+                                   const std::function<int(const nthip_reads*, uint64_t, uint64_t)>& fn)
 {
-  uint64_t total_bytes = 0;
-  NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
+  const uint64_t n = rd->n_reads;
+  if (n == 0) return NTHIP_OK;
+  const bool host = (flags & NTHIP_HOST_INPUT) != 0;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
+  uint64_t round_bases = (uint64_t)(free_b / 10 * 8) / (scratch_per_base + (host ? 1 : 0));
+  if (c->tune.bloom_round) round_bases = c->tune.bloom_round; // (tests: several rounds on a small batch)
+  const uint64_t reads_max = std::max<uint64_t>(1, (free_b / 10) / 48);
+  uint64_t first = 0, last = 0;
+  if (host) {
+    first = rd->offsets[0];
+    last = rd->offsets[n];
+  } else {
+    HIPCHK(hipMemcpy(&first, rd->offsets, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&last, rd->offsets + n, 8, hipMemcpyDeviceToHost));
+  }
+  if (last < first) return fail(NTHIP_ERR_ARG, "offsets decrease");
+  if (last - first <= round_bases && n <= reads_max) return fn(rd, 0, last - first);
+  std::vector<uint64_t> ho(n + 1);
+  if (host) memcpy(ho.data(), rd->offsets, (n + 1) * 8);
+  else HIPCHK(hipMemcpy(ho.data(), rd->offsets, (n + 1) * 8, hipMemcpyDeviceToHost));
+  for (uint64_t r = 0; r < n; ++r)
+    if (ho[r + 1] < ho[r]) return fail(NTHIP_ERR_ARG, "offsets decrease at read %llu", (unsigned long long)r);
+  std::vector<uint64_t> rebased;
+  for (uint64_t r0 = 0; r0 < n;) {
+    uint64_t r1 = (uint64_t)(std::upper_bound(ho.begin() + r0, ho.end(), ho[r0] + round_bases) - ho.begin()) - 1;
+    if (r1 <= r0) r1 = r0 + 1; // (a read longer than a round: alone)
+    if (r1 - r0 > reads_max) r1 = r0 + reads_max;
+    if (r1 > n) r1 = n;
+    nthip_reads part = *rd;
+    part.n_reads = r1 - r0;
+    if (host) {
+      rebased.resize(r1 - r0 + 1);
+      for (uint64_t i = 0; i <= r1 - r0; ++i) rebased[i] = ho[r0 + i] - ho[r0];
+      part.seqs = rd->seqs + ho[r0];
+      part.offsets = rebased.data();
+    } else {
+      part.offsets = rd->offsets + r0;
+    }
+    NTCHK(fn(&part, r0, ho[r1] - ho[r0]));
+    r0 = r1;
+  }
+  return NTHIP_OK;
+}
+
+int ntamd::host::stream_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m, uint32_t flags, Staged& keep, uint64_t** d_h,
+                      uint64_t** d_counts, uint64_t* n_kmers, uint64_t round_bases)
+{
+  uint64_t total_bytes = round_bases;
+  if (round_bases == 0) NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
   const uint64_t cap = total_bytes > 0 ? total_bytes : 1;
   const size_t need = (size_t)cap * m * 8 + (d_counts ? (size_t)rd->n_reads * 16 + 4096 : 0);
   size_t free_b = 0, total_b = 0;
@@ -245,29 +296,38 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
   HIPCHK(hipSetDevice(c->device));
   if (total_out) *total_out = 0;
   if (total_hits) *total_hits = 0;
-  if (rd->offsets) { // reads of any lengths: the batch's compact stream, then the stream forms
+  if (rd->offsets) { // reads of any lengths: the compact stream of a round of them, then the stream forms
     if (rd->n_reads == 0) return NTHIP_OK;
-    Staged keep;
-    uint64_t *d_h = nullptr, *d_counts = nullptr, n_kmers = 0;
-    NTCHK(stream_of_offsets(c, rd, k16, m8, flags, keep, &d_h, query ? &d_counts : nullptr, &n_kmers));
-    if (total_out) *total_out = n_kmers;
-    if (!query) return nthip_stream_bloom_insert(c, d_h, n_kmers * m, (uint8_t*)d_filter, n_bits);
-    const bool host = hits && (flags & NTHIP_HOST_OUTPUT);
-    uint64_t* d_hits = hits;
-    if (host) NTCHK(own_alloc(keep, (size_t)rd->n_reads * 8, (void**)&d_hits));
-    uint64_t *d_roff = nullptr, *d_sums = nullptr;
-    NTCHK(own_alloc(keep, (size_t)(rd->n_reads + 1) * 8, (void**)&d_roff));
-    NTCHK(own_alloc(keep, (size_t)(rd->n_reads / SCAN_TILE + 64) * 8, (void**)&d_sums));
-    NTCHK(device_exclusive_scan(c, d_counts, d_roff, rd->n_reads, d_sums, (uint64_t*)(c->d_small + 16)));
-    HIPCHK(hipMemsetAsync(c->d_small + 24, 0, 8, c->stream));
-    const unsigned grid = (unsigned)(c->n_cu * 8);
-    hipLaunchKernelGGL(stream_bloom_query_kernel, dim3(grid), dim3(256), 0, c->stream, d_h, d_roff, rd->n_reads, n_kmers, m, d_filter, n_bits,
-                       bloom_magic_of(n_bits), d_hits, (unsigned long long*)(c->d_small + 24));
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_small + 24, c->d_small + 24, 8, hipMemcpyDeviceToHost, c->stream));
-    if (host) HIPCHK(hipMemcpyAsync(hits, d_hits, rd->n_reads * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (total_hits) memcpy(total_hits, c->h_small + 24, 8);
+    uint64_t sum_kmers = 0, sum_hits = 0;
+    NTCHK(offsets_in_rounds(c, rd, flags, (size_t)8 * m + (query ? 0 : 16), [&](const nthip_reads* part, uint64_t r0, uint64_t bases) -> int {
+      Staged keep;
+      uint64_t *d_h = nullptr, *d_counts = nullptr, n_kmers = 0;
+      NTCHK(stream_of_offsets(c, part, k16, m8, flags, keep, &d_h, query ? &d_counts : nullptr, &n_kmers, bases ? bases : 1));
+      sum_kmers += n_kmers;
+      if (!query) return nthip_stream_bloom_insert(c, d_h, n_kmers * m, (uint8_t*)d_filter, n_bits);
+      const uint64_t nr = part->n_reads;
+      const bool host = hits && (flags & NTHIP_HOST_OUTPUT);
+      uint64_t* d_hits = hits ? hits + r0 : nullptr;
+      if (host) NTCHK(own_alloc(keep, (size_t)nr * 8, (void**)&d_hits));
+      uint64_t *d_roff = nullptr, *d_sums = nullptr;
+      NTCHK(own_alloc(keep, (size_t)(nr + 1) * 8, (void**)&d_roff));
+      NTCHK(own_alloc(keep, (size_t)(nr / SCAN_TILE + 64) * 8, (void**)&d_sums));
+      NTCHK(device_exclusive_scan(c, d_counts, d_roff, nr, d_sums, (uint64_t*)(c->d_small + 16)));
+      HIPCHK(hipMemsetAsync(c->d_small + 24, 0, 8, c->stream));
+      const unsigned grid = (unsigned)(c->n_cu * 8);
+      hipLaunchKernelGGL(stream_bloom_query_kernel, dim3(grid), dim3(256), 0, c->stream, d_h, d_roff, nr, n_kmers, m, d_filter, n_bits,
+                         bloom_magic_of(n_bits), d_hits, (unsigned long long*)(c->d_small + 24));
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(c->h_small + 24, c->d_small + 24, 8, hipMemcpyDeviceToHost, c->stream));
+      if (host) HIPCHK(hipMemcpyAsync(hits + r0, d_hits, nr * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      uint64_t h = 0;
+      memcpy(&h, c->h_small + 24, 8);
+      sum_hits += h;
+      return NTHIP_OK;
+    }));
+    if (total_out) *total_out = sum_kmers;
+    if (total_hits) *total_hits = sum_hits;
     return NTHIP_OK;
   }
   const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
@@ -464,13 +524,18 @@ extern "C" int nthip_kmer_count_insert(nthip_ctx* c, const nthip_reads* rd, uint
   if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
   HIPCHK(hipSetDevice(c->device));
   if (total_out) *total_out = 0;
-  if (rd->offsets) { // reads of any lengths: the batch's compact stream, then the stream form
+  if (rd->offsets) { // reads of any lengths: the compact stream of a round of them, then the stream form
     if (rd->n_reads == 0) return NTHIP_OK;
-    Staged keep;
-    uint64_t *d_h = nullptr, n_kmers = 0;
-    NTCHK(stream_of_offsets(c, rd, k, m, flags, keep, &d_h, nullptr, &n_kmers));
-    if (total_out) *total_out = n_kmers;
-    return nthip_stream_count_insert(c, d_h, n_kmers * m, d_counters, n_counters);
+    uint64_t sum_kmers = 0;
+    NTCHK(offsets_in_rounds(c, rd, flags, (size_t)8 * m + 16, [&](const nthip_reads* part, uint64_t, uint64_t bases) -> int {
+      Staged keep;
+      uint64_t *d_h = nullptr, n_kmers = 0;
+      NTCHK(stream_of_offsets(c, part, k, m, flags, keep, &d_h, nullptr, &n_kmers, bases ? bases : 1));
+      sum_kmers += n_kmers;
+      return nthip_stream_count_insert(c, d_h, n_kmers * m, d_counters, n_counters);
+    }));
+    if (total_out) *total_out = sum_kmers;
+    return NTHIP_OK;
   }
   const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
   if (rd->n_reads == 0 || len < k) return NTHIP_OK;

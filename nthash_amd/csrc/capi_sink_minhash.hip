@@ -23,23 +23,29 @@ int run_kmer_minhash(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t 
   HIPCHK(hipSetDevice(c->device));
   if (total_out) *total_out = 0;
   if (rd->n_reads == 0) return NTHIP_OK;
-  if (rd->offsets) { // reads of any lengths: h[0] of the batch's compact stream in one round, the signatures from the stream
-    Staged keep;
-    uint64_t *d_h = nullptr, *d_counts = nullptr, *d_roff = nullptr, *d_sums = nullptr, n_kmers = 0;
-    NTCHK(stream_of_offsets(c, rd, k16, 1, flags, keep, &d_h, &d_counts, &n_kmers));
-    if (total_out) *total_out = n_kmers;
-    const size_t sb = rd->n_reads * (size_t)m * sizeof(uint64_t);
+  if (rd->offsets) { // reads of any lengths: h[0] of the compact stream of a round of them, the signatures from the stream
+    uint64_t sum_kmers = 0;
     const bool host = (flags & NTHIP_HOST_OUTPUT) != 0;
-    uint64_t* d_sig = sig;
-    if (host) NTCHK(own_alloc(keep, sb, (void**)&d_sig));
-    NTCHK(own_alloc(keep, (size_t)(rd->n_reads + 1) * 8, (void**)&d_roff));
-    NTCHK(own_alloc(keep, (size_t)(rd->n_reads / SCAN_TILE + 64) * 8, (void**)&d_sums));
-    NTCHK(device_exclusive_scan(c, d_counts, d_roff, rd->n_reads, d_sums, (uint64_t*)(c->d_small + 16)));
-    hipLaunchKernelGGL(stream_minhash_kernel, dim3((unsigned)(c->n_cu * 8)), dim3(256), 0, c->stream, d_h, d_roff, rd->n_reads, n_kmers, m,
-                       (uint64_t)k * MULTISEED, d_sig);
-    HIPCHK(hipGetLastError());
-    if (host) HIPCHK(hipMemcpyAsync(sig, d_sig, sb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    NTCHK(offsets_in_rounds(c, rd, flags, 8, [&](const nthip_reads* part, uint64_t r0, uint64_t bases) -> int {
+      Staged keep;
+      const uint64_t nr = part->n_reads;
+      uint64_t *d_h = nullptr, *d_counts = nullptr, *d_roff = nullptr, *d_sums = nullptr, n_kmers = 0;
+      NTCHK(stream_of_offsets(c, part, k16, 1, flags, keep, &d_h, &d_counts, &n_kmers, bases ? bases : 1));
+      sum_kmers += n_kmers;
+      const size_t sb = nr * (size_t)m * sizeof(uint64_t);
+      uint64_t* d_sig = sig + r0 * m;
+      if (host) NTCHK(own_alloc(keep, sb, (void**)&d_sig));
+      NTCHK(own_alloc(keep, (size_t)(nr + 1) * 8, (void**)&d_roff));
+      NTCHK(own_alloc(keep, (size_t)(nr / SCAN_TILE + 64) * 8, (void**)&d_sums));
+      NTCHK(device_exclusive_scan(c, d_counts, d_roff, nr, d_sums, (uint64_t*)(c->d_small + 16)));
+      hipLaunchKernelGGL(stream_minhash_kernel, dim3((unsigned)(c->n_cu * 8)), dim3(256), 0, c->stream, d_h, d_roff, nr, n_kmers, m,
+                         (uint64_t)k * MULTISEED, d_sig);
+      HIPCHK(hipGetLastError());
+      if (host) HIPCHK(hipMemcpyAsync(sig + r0 * m, d_sig, sb, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      return NTHIP_OK;
+    }));
+    if (total_out) *total_out = sum_kmers;
     return NTHIP_OK;
   }
   const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;

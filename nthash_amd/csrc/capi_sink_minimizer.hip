@@ -1,6 +1,9 @@
 // capi_sink_minimizer.hip -- per-read (w, k)-minimizers: nthip_kmer_minimizers
 // Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
 #include "capi_internal.hpp"
+
+#include <algorithm>
+
 #include "minimizer_fused_kernel.hpp"
 #include "minimizer_w_kernel.hpp"
 #include "minimizer_kernels.hpp"
@@ -316,8 +319,11 @@ int minimizers_reg_round(nthip_ctx* c, uint64_t* d_h, uint32_t* d_pos, const uin
 // kernels take every read's window count from its length
 int minimizers_of_spans(nthip_ctx* c, const uint8_t* d_seqs, uint64_t total_bytes, const uint64_t* d_starts, const uint64_t* d_ends,
                         uint64_t n, uint64_t max_len, uint16_t k16, uint32_t w, uint64_t* d_min_hashes, uint32_t* d_min_pos,
-                        uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out)
+                        uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out, uint64_t base = 0, bool last = true,
+                        uint64_t round_bases = 0)
 {
+  // (base: minimizers of the rounds before -- this round's go behind them, its offsets count from there; last: write the
+  // closing offset; round_bases: the bases of this round's reads when it is a piece of a batch -- what sizes the scratch)
   const uint32_t k = k16;
   const uint64_t max_nwin64 = max_len >= k ? max_len - k + 1 : 0;
   if (max_nwin64 > 0xFFFFFFFFull) return fail(NTHIP_ERR_UNSUPPORTED, "a read of %llu bases: window positions are 32 bits wide", (unsigned long long)max_len);
@@ -327,10 +333,15 @@ int minimizers_of_spans(nthip_ctx* c, const uint8_t* d_seqs, uint64_t total_byte
     HIPCHK(hipStreamSynchronize(c->stream));
     return NTHIP_OK;
   }
-  const uint64_t cap_kmers = total_bytes; // (a k-mer starts at a base)
+  const uint64_t cap_kmers = round_bases ? round_bases : total_bytes; // (a k-mer starts at a base)
   const uint32_t chunks = (max_nwin + 63u) / 64u;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  const size_t b_h = al(cap_kmers * 8), b_pos = al(cap_kmers * 4), b_fl = al(n * (size_t)chunks * 8), b_rd = al(n * 8);
+  // the pick masks belong to the LDS-table kernels (reads of more than MZ_REGN_POS windows); with offsets (not spans) a read's
+  // words start at (its first byte >> 6) + its index: total_bytes / 8 + 8 n bytes, whatever the longest read is
+  const bool reg_path = max_nwin <= MZ_REGN_POS && !c->tune.mz_table;
+  const bool by_start = !d_ends;
+  const size_t b_fl = reg_path ? 0 : by_start ? al(((cap_kmers >> 6) + n + 2) * 8) : al(n * (size_t)chunks * 8);
+  const size_t b_h = al(cap_kmers * 8), b_pos = al(cap_kmers * 4), b_rd = al(n * 8);
   const size_t b_sums = al((n / SCAN_TILE + cap_kmers / SCAN_TILE + 64) * 8);
   const size_t need = b_h + b_pos + b_fl + 4 * b_rd + b_sums + 256;
   size_t free_b = 0, total_b = 0;
@@ -376,8 +387,9 @@ int minimizers_of_spans(nthip_ctx* c, const uint8_t* d_seqs, uint64_t total_byte
   if (max_nwin <= MZ_REGN_POS && !c->tune.mz_table) { // short reads (a FASTQ batch): the tables in registers
     uint64_t total = 0;
     NTCHK(minimizers_reg_round(c, d_h, d_pos, d_roff, nullptr, n_kmers, d_starts, d_ends, k, n, max_nwin, w, d_picked, d_counts, d_ooff, d_sums,
-                               d_tot + 1, 0, capacity, d_min_hashes, d_min_pos, d_min_offsets, &total));
-    HIPCHK(hipMemcpyAsync(d_min_offsets + n, &total, sizeof total, hipMemcpyHostToDevice, c->stream));
+                               d_tot + 1, base, capacity, d_min_hashes, d_min_pos, d_min_offsets, &total));
+    total += base;
+    if (last) HIPCHK(hipMemcpyAsync(d_min_offsets + n, &total, sizeof total, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (total_out) *total_out = total;
     if (total > capacity)
@@ -399,15 +411,16 @@ int minimizers_of_spans(nthip_ctx* c, const uint8_t* d_seqs, uint64_t total_byte
   a.k = k;
   a.masks = d_masks;
   a.chunks = chunks;
+  a.mask_by_start = by_start ? 1u : 0u;
   a.picked = d_picked;
   a.out_off = d_ooff;
-  a.base = 0;
+  a.base = base;
   a.capacity = capacity;
   a.out_hashes = d_min_hashes;
   a.out_pos = d_min_pos;
   a.out_offsets = d_min_offsets;
   const unsigned grid = (unsigned)(c->n_cu * 16);
-  if (max_nwin > 256) HIPCHK(hipMemsetAsync(d_masks, 0, n * (size_t)chunks * 8, c->stream)); // (reads that take the walk OR bits in)
+  if (max_nwin > 256) HIPCHK(hipMemsetAsync(d_masks, 0, b_fl, c->stream)); // (reads that take the walk OR bits in)
   prof_begin(c, "minimizer_flag_kernel");
   if (max_nwin <= 256) hipLaunchKernelGGL((minimizer_flag_kernel<false, 256>), dim3(grid * 2), dim3(64 * MZ_WAVES), 0, c->stream, a);
   else hipLaunchKernelGGL((minimizer_flag_kernel<false>), dim3(grid), dim3(64 * MZ_WAVES), 0, c->stream, a);
@@ -419,7 +432,8 @@ int minimizers_of_spans(nthip_ctx* c, const uint8_t* d_seqs, uint64_t total_byte
   HIPCHK(hipStreamSynchronize(c->stream));
   uint64_t total = 0;
   memcpy(&total, c->h_small + 8, 8);
-  HIPCHK(hipMemcpyAsync(d_min_offsets + n, &total, sizeof total, hipMemcpyHostToDevice, c->stream));
+  total += base;
+  if (last) HIPCHK(hipMemcpyAsync(d_min_offsets + n, &total, sizeof total, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (total_out) *total_out = total;
   if (total > capacity)
@@ -452,8 +466,39 @@ int minimizers_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uin
                                 &handled);
     if (rc != NTHIP_OK || handled) return rc;
   }
-  return minimizers_of_spans(c, st.seqs, total_bytes, st.offsets, nullptr, n, sv.max_len, k16, w, d_min_hashes, d_min_pos, d_min_offsets,
-                             capacity, total_out);
+  // rounds of reads whose emitted stream (hash 8 + position 4 bytes per base at most, 40 bytes per read) fits the device
+  // (round 4: one round until then, NTHIP_ERR_UNSUPPORTED beyond it)
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
+  free_b += c->bloom_tmp_bytes;
+  uint64_t round_bases = (uint64_t)(free_b / 10 * 8) / 14;
+  if (c->tune.bloom_round) round_bases = c->tune.bloom_round; // (tests: several rounds on a small batch)
+  if (total_bytes - sv.off0 <= round_bases && n * 40 <= free_b / 10)
+    return minimizers_of_spans(c, st.seqs, total_bytes, st.offsets, nullptr, n, sv.max_len, k16, w, d_min_hashes, d_min_pos, d_min_offsets,
+                               capacity, total_out);
+  std::vector<uint64_t> ho(n + 1);
+  if (flags & NTHIP_HOST_INPUT) memcpy(ho.data(), rd->offsets, (n + 1) * 8);
+  else HIPCHK(hipMemcpy(ho.data(), st.offsets, (n + 1) * 8, hipMemcpyDeviceToHost));
+  const uint64_t reads_max = std::max<uint64_t>(1, (free_b / 10) / 40);
+  uint64_t base = 0;
+  bool overflow = false;
+  for (uint64_t r0 = 0; r0 < n;) {
+    uint64_t r1 = (uint64_t)(std::upper_bound(ho.begin() + r0, ho.end(), ho[r0] + round_bases) - ho.begin()) - 1;
+    if (r1 <= r0) r1 = r0 + 1; // (a read longer than a round: alone)
+    if (r1 - r0 > reads_max) r1 = r0 + reads_max;
+    if (r1 > n) r1 = n;
+    uint64_t tot = 0;
+    const int rc = minimizers_of_spans(c, st.seqs, ho[r1], st.offsets + r0, nullptr, r1 - r0, sv.max_len, k16, w, d_min_hashes, d_min_pos,
+                                       d_min_offsets + r0, capacity, &tot, base, r1 == n, ho[r1] - ho[r0]);
+    if (rc == NTHIP_ERR_CAPACITY) overflow = true;
+    else if (rc != NTHIP_OK) return rc;
+    base = tot;
+    r0 = r1;
+  }
+  if (total_out) *total_out = base;
+  if (overflow)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu minimizers < %llu needed", (unsigned long long)capacity, (unsigned long long)base);
+  return NTHIP_OK;
 }
 
 } // namespace

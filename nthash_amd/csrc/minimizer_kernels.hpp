@@ -40,7 +40,10 @@ struct MinimizerArgs {
   uint32_t k, pad1;
   uint64_t* masks;        // [n_reads * chunks] bit l of word (r, c): the k-mer at window position 64 c + l of read r is a minimizer
   uint32_t chunks;        // ceil(nwin / 64)
-  uint32_t pad0;
+  // reads given by offsets (not spans): read r's mask words start at ((offsets[r] - offsets[0]) >> 6) + r instead of r * chunks -- the
+  // reads lie apart in the buffer, so the rows do too, and the masks take total_bytes / 8 + 8 n bytes whatever the
+  // longest read is (100 k contigs with one of 10 Mbp asked for 125 GB of r * chunks rows)
+  uint32_t mask_by_start;
   uint64_t* picked;       // [n_reads] minimizers of the read
   // second pass
   const uint64_t* out_off; // [n_reads] exclusive scan of picked
@@ -101,7 +104,7 @@ static __global__ __launch_bounds__(64 * MZ_WAVES) void minimizer_flag_kernel(co
     const uint32_t chunks_r = (nwin + 63u) >> 6; // mask words of this read (<= a.chunks)
     const uint64_t i0 = DENSE ? r * nwin : a.roff[r];
     const uint64_t i1 = DENSE ? i0 + nwin : (r + 1 < a.n_reads ? a.roff[r + 1] : a.n_kmers);
-    uint64_t* const mrow = a.masks + r * a.chunks;
+    uint64_t* const mrow = a.masks + (a.mask_by_start ? ((a.offsets[r] - a.offsets[0]) >> 6) + r : r * a.chunks);
     uint32_t n_picked = 0;
     if (nwin <= POSN) {
       // ---- the read by position ----
@@ -214,7 +217,7 @@ static __global__ __launch_bounds__(256) void minimizer_write_kernel(const Minim
     const uint64_t i1 = DENSE ? i0 + a.nwin : (r + 1 < a.n_reads ? a.roff[r + 1] : a.n_kmers);
     uint64_t o = a.base + a.out_off[r];
     if (lane == 0) a.out_offsets[r] = o;
-    const uint64_t* const mrow = a.masks + r * a.chunks;
+    const uint64_t* const mrow = a.masks + (a.mask_by_start ? ((a.offsets[r] - a.offsets[0]) >> 6) + r : r * a.chunks);
     for (uint64_t c0 = i0; c0 < i1; c0 += 64u) {
       const uint64_t i = c0 + lane;
       bool pick = false;

@@ -1598,6 +1598,72 @@ def test_bloom_query_hits_per_read(ctx, oracle, n, L, k, m, n_bits):
     ctx.free(d_f)
 
 
+@pytest.mark.parametrize("n,lmax,k,m,w,round_bases,device_input", [
+    (3000, 250, 31, 2, 10, 20000, True), (3000, 250, 31, 2, 10, 20000, False), (500, 3000, 25, 1, 19, 9000, True),
+    (60, 9000, 31, 3, 5, 4000, False),        # reads longer than a round: each alone
+    (2000, 180, 21, 1, 300, 1000, True),
+])
+def test_consumers_by_offsets_without_a_batch_ceiling(ctx, oracle, n, lmax, k, m, w, round_bases, device_input):
+    """Round 4: the consumers on reads given by offsets took the batch's compact stream in ONE round of device scratch and
+    refused what did not fit (NTHIP_ERR_UNSUPPORTED: split the batch).  Now the batch is cut into rounds of reads whose stream
+    fits (offsets_in_rounds; here NTHIP_TUNE_BLOOM_ROUND makes the rounds tiny -- a batch 20-300 x the bound) and every
+    consumer carries its result across them: the filter and the sketch accumulate, hits and signatures land at their reads,
+    the minimizers' CSR offsets run on.  Bit for bit what one round gives (itself checked against the oracle elsewhere)."""
+    import os
+    import nthash_amd
+    os.environ["NTHIP_TUNE_BLOOM_ROUND"] = str(round_bases)
+    try:
+        small = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_BLOOM_ROUND", None)
+    rng = np.random.default_rng(n + lmax)
+    lens = rng.integers(0, lmax + 1, n).astype(np.uint64)
+    lens[:3] = [0, k - 1, k]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total_b = int(offs[-1])
+    assert total_b > 4 * round_bases
+    a = oracle.synth_reads(5, 1, total_b, 3 + k).copy()
+    a[rng.choice(total_b, max(3, total_b // 900), replace=False)] = ord("N")
+    n_bits, n_cnt = (1 << 22) + 64, 1 << 16
+    res = []
+    for c in (ctx, small):
+        d_f, nbytes = c.bloom_new(n_bits)
+        d_c = c.malloc(n_cnt)
+        c.memset(d_c, 0, n_cnt)
+        if device_input:
+            d_a, d_o, d_hits = c.malloc(total_b + 16), c.malloc(offs.nbytes), c.malloc(n * 8)
+            c.h2d(d_a, a)
+            c.h2d(d_o, offs)
+            t_i = c.bloom_insert_ptr(d_a, n, 0, 0, k, m, d_f, n_bits, offsets=d_o)
+            t_q, found = c.bloom_query_ptr(d_a, n, 0, 0, k, m, d_f, n_bits, hits=d_hits, offsets=d_o)
+            hits = np.zeros(n, np.uint64)
+            c.d2h(hits, d_hits)
+            t_c = c.count_insert_ptr(d_a, n, 0, 0, k, m, d_c, n_cnt, offsets=d_o)
+            for p_ in (d_a, d_o, d_hits):
+                c.free(p_)
+        else:
+            t_i = c.bloom_insert(a, k, m, 0, n, d_f, n_bits, offsets=offs)
+            hits, t_q, found = c.bloom_query(a, k, m, 0, n, d_f, n_bits, offsets=offs)
+            t_c = c.count_insert(a, k, m, 0, n, d_c, n_cnt, offsets=offs)
+        filt, cnt = np.zeros(nbytes, np.uint8), np.zeros(n_cnt, np.uint8)
+        c.d2h(filt, d_f)
+        c.d2h(cnt, d_c)
+        c.free(d_f)
+        c.free(d_c)
+        sig, t_s = c.minhash(a, k, m, 0, n, offsets=offs)
+        mz = c.minimizers(a, k, w, 0, n, offsets=offs, device_input=device_input)
+        res.append(dict(t=(t_i, t_q, found, t_c, t_s, mz["total"]), filt=filt, cnt=cnt, hits=hits, sig=sig, mz=mz))
+    one, many = res
+    want = oracle.kmer_batch(a, offs, k, m, want_pos=False)
+    assert one["t"][0] == want["total"] and one["t"] == many["t"]
+    assert (one["hits"] == want["counts"]).all()        # (every k-mer of the batch is in the filter)
+    for key in ("filt", "cnt", "hits", "sig"):
+        assert (one[key] == many[key]).all(), key
+    for key in ("offsets", "pos", "hashes"):
+        assert (one["mz"][key] == many["mz"][key]).all(), key
+    small.close()
+
+
 @pytest.mark.parametrize("n,lmax,k,m,n_bits,device_input", [
     (1500, 250, 31, 1, 1 << 22, False), (1200, 180, 25, 3, 3_000_017, True), (600, 400, 64, 2, (1 << 23) + 5, False),
     (40, 6000, 31, 2, 1 << 21, True),
