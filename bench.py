@@ -44,10 +44,12 @@ CONFIGS = {
     # name: description, read length, k, hashes per k-mer (m, or m per seed), default reads per GPU
     "c2": dict(desc="NtHash k=31 canonical, 1 hash/k-mer, 100M x 150bp", L=150, k=31, m=1, seeds=None,
                reads=100_000_000),
+    # (launches: the full-size stream does not fit the device -- 384 / 528 GB -- and is made in that many equal launches into
+    #  one buffer, PINNED so that the driver's run and a rocprofv3 run launch the same shapes whatever memory is free)
     "c3": dict(desc="NtHash k=31, m=4 hashes/k-mer (multi-hash), 100M x 150bp", L=150, k=31, m=4,
-               seeds=None, reads=100_000_000),
+               seeds=None, reads=100_000_000, launches=2),
     "c4": dict(desc="SeedNtHash 2 spaced seeds k=31, m=3, 50M x 250bp", L=250, k=31, m=3,
-               seeds=[SEED_A, SEED_B], reads=50_000_000),
+               seeds=[SEED_A, SEED_B], reads=50_000_000, launches=4),
     # the same reads as c2, packed once (2 bits per base + a validity stream: nthip_pack_reads) and hashed from the packed
     # buffer: SURVEY 8(d)'s 8.3125 B per k-mer.  The pack pass is timed apart (pack_ms): it is paid once per batch, not per k
     "c2_packed": dict(desc="NtHash k=31 canonical, 1 hash/k-mer, 100M x 150bp, 2-bit packed input (nthip_pack_reads once)",
@@ -293,9 +295,14 @@ class Workload:
         out_bytes_per_read = self.nwin * self.per * 8
         # (a ring that takes most of the memory cannot be probed -- and need not be: it contains every page set there is)
         budget = int(free_b * 0.85) - n_reads * L
-        chunk = chunk_reads or min(n_reads, max(1, budget // out_bytes_per_read))
+        pinned = 0
+        if not chunk_reads and cfg.get("launches") and n_reads == cfg["reads"]:
+            pinned = -(-n_reads // cfg["launches"])
+            if pinned * out_bytes_per_read > budget:   # (a smaller device: as many launches as it takes)
+                pinned = 0
+        chunk = chunk_reads or pinned or min(n_reads, max(1, budget // out_bytes_per_read))
         chunk = min(chunk, n_reads)
-        if chunk < n_reads and (n_reads % chunk or not chunk_reads):
+        if chunk < n_reads and (n_reads % chunk or not (chunk_reads or pinned)):
             # keep chunks a multiple of the kernels' read tiles -- unless the caller named an exact divisor of the job
             # (equal launches: what a per-kernel profile of one config wants, see tools/profile_round.sh)
             chunk = max(256, chunk // 256 * 256)

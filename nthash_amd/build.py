@@ -28,11 +28,39 @@ FACADE_SO = os.path.join(LIB, "libnthash.so")
 ARCH = "gfx950"
 
 
+# The compiler the kernels' hidden-load sites were written and linted against (nthash_amd/isa_lint.py: nine sites issue the
+# next tile's loads in inline asm and consume them behind a counted s_waitcnt -- what hipcc makes of the code around them
+# is checked on the emitted ISA, and the counted waits' argument at each site assumes this code generator).  Another hipcc
+# may be fine; it has to be looked at before it builds the product: NTHASH_AMD_ALLOW_HIPCC_MISMATCH=1 after doing so.
+EXPECTED_HIPCC = "HIP version: 7.2.26015-fc0010cf6a / AMD clang version 22.0.0git roc-7.2.0 26014"
+_hipcc_seen = {}
+
+
 def _hipcc():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found: nthash_amd needs the ROCm toolchain to build")
+
+
+def hipcc_version(hipcc=None):
+    """'HIP version: X / AMD clang version Y roc-Z N' of the compiler in use (cached)"""
+    hipcc = hipcc or _hipcc()
+    if hipcc not in _hipcc_seen:
+        text = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+        hip = re.search(r"HIP version:\s*(\S+)", text)
+        clang = re.search(r"clang version (\S+) \(\S+ (roc-\S+) (\d+)", text)
+        _hipcc_seen[hipcc] = "HIP version: %s / AMD clang version %s" % (
+            hip.group(1) if hip else "?", " ".join(clang.groups()) if clang else "?")
+    return _hipcc_seen[hipcc]
+
+
+def check_hipcc(hipcc=None):
+    got = hipcc_version(hipcc)
+    if got != EXPECTED_HIPCC and not os.environ.get("NTHASH_AMD_ALLOW_HIPCC_MISMATCH"):
+        raise RuntimeError(f"hipcc is '{got}', the kernels' counted waits and the ISA lint expectations were made with "
+                           f"'{EXPECTED_HIPCC}': review nthash_amd/isa_lint.py's report, then set NTHASH_AMD_ALLOW_HIPCC_MISMATCH=1")
+    return got
 
 
 def _newer(target, sources):
@@ -67,10 +95,13 @@ def _lint_unit(hipcc, unit, objdir, extra, verbose):
            f"-I{os.path.join(ROOT, 'include')}"] + list(extra) + ["-S", "--cuda-device-only", src, "-o", asm]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:   # (the object compiled a moment ago: say what the assembly-only compile has to say)
+        raise RuntimeError(f"{unit}: the ISA-lint compile failed ({' '.join(cmd)}):\n" + r.stderr[-4000:])
     rep = isa_lint.lint_file(asm)
     os.remove(asm)
     rep["unit"] = unit
+    rep["hipcc"] = hipcc_version(hipcc)
     return rep
 
 
@@ -95,7 +126,8 @@ def _compile_unit(hipcc, unit, objdir, extra, force, verbose):
         print(rest, file=sys.stderr)
     if r.returncode != 0:
         raise subprocess.CalledProcessError(r.returncode, cmd)
-    json.dump(kernels, open(obj + ".res.json", "w"), indent=0)
+    with open(obj + ".res.json", "w") as f:
+        json.dump(kernels, f, indent=0)
     # No kernel may spill.  Several of them keep loads in flight behind inline asm that hipcc cannot see (the next
     # tile's slab): a register of such a load that is spilled is saved before the load has landed -- wrong hashes,
     # found on seed_wtile_kernel<8> (k = 64 seeds) in round 2.  Scratch traffic would also break the counted waits.
@@ -106,7 +138,8 @@ def _compile_unit(hipcc, unit, objdir, extra, force, verbose):
                            ", ".join(f"{k_['name']}={k_.get('scratch', 0)}" for k_ in spilling))
     # ... and what the spill check cannot see: a copy or a use of such a register before its counted wait
     rep = _lint_unit(hipcc, unit, objdir, extra, verbose)
-    json.dump(rep, open(lint_json, "w"), indent=0)
+    with open(lint_json, "w") as f:
+        json.dump(rep, f, indent=0)
     if rep["violations"] and not os.environ.get("NTHASH_AMD_ALLOW_LINT_FAIL"):
         os.remove(obj)
         raise RuntimeError(f"{unit}: ISA lint of the hidden-load sites failed ({len(rep['violations'])} violations):\n  " +
@@ -144,6 +177,7 @@ def build_hip(out_so=HIP_SO, objdir=OBJ, extra=(), force=False, verbose=False, o
     os.makedirs(os.path.dirname(out_so), exist_ok=True)
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
+    check_hipcc(hipcc)
     units = hip_units()
     mine = [u for u in units if only_units is None or u[:-4] in only_units]
     jobs = min(len(mine), max(1, (os.cpu_count() or 2)))

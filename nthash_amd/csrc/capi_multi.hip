@@ -257,7 +257,11 @@ extern "C" int nthip_multi_fastx_kmer_hash_file(nthip_multi* mm, const char* pat
     while (begin < file_size) {
       int64_t end = (int64_t)file_size;
       if (begin + chunk_bytes < file_size) {
-        end = fastx_find_record_start(fd, file_size, begin + chunk_bytes, format);
+        // (-2: no boundary could be decided near that place -- a line of a gigabyte --: look one chunk further on rather than
+        // hand the whole rest of the file to one device)
+        uint64_t pos = begin + chunk_bytes;
+        while ((end = fastx_find_record_start(fd, file_size, pos, format)) == -2 && pos + chunk_bytes < file_size) pos += chunk_bytes;
+        if (end == -2) end = (int64_t)file_size;
         if (end < 0) { close(fd); return fail(NTHIP_ERR_ARG, "read error on %s", path); }
       }
       if ((uint64_t)end <= begin) end = (int64_t)file_size; // (cannot happen for pos > begin; never loop)

@@ -16,6 +16,10 @@ namespace {
 
 inline uint64_t packed_codes_bytes(uint64_t n_bases) { return ((n_bases + 63) / 64) * 16 + 16; }   // + one spare vector
 inline uint64_t packed_invalid_bytes(uint64_t n_bases) { return ((n_bases + 127) / 128) * 16 + 16; }
+// The last 8 bytes of the code stream's spare vector say how many bases were packed: the validity stream's place follows
+// from that number, and a hash call that describes other reads (a subset, another stride) would read validity bits from
+// the wrong place without anybody noticing -- now it is refused (NTHIP_ERR_ARG).  NTHIP_PACKED_CLEAN calls never read it.
+constexpr uint64_t PACKED_MAGIC = 0x6e74504bull << 40; // "ntPK" above 40 bits of base count
 
 // one thread per 16 bytes of the batch: a dword of codes ((c >> 1) & 3, as everywhere), 16 validity bits (1 = not a base)
 __global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t* __restrict__ src, uint64_t n_bytes,
@@ -88,6 +92,9 @@ extern "C" int nthip_pack_reads(nthip_ctx* c, const nthip_reads* rd, void* d_pac
   prof_end(c);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_small + 8, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+  const uint64_t stamp = PACKED_MAGIC | (n_bytes & ((1ull << 40) - 1));
+  memcpy(c->h_small + 48, &stamp, 8);
+  HIPCHK(hipMemcpyAsync((uint8_t*)d_packed + packed_codes_bytes(n_bytes) - 8, c->h_small + 48, 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (n_invalid) memcpy(n_invalid, c->h_small + 8, 8);
   return NTHIP_OK;
@@ -183,7 +190,17 @@ int ntamd::host::run_kmer_packed(nthip_ctx* c, const nthip_reads* rd, uint32_t k
     }
     return NTHIP_OK;
   }
-  // batches that hold (or may hold) a non-base: count -> scan -> compact hash pass, validity from the companion stream
+  // batches that hold (or may hold) a non-base: count -> scan -> compact hash pass, validity from the companion stream --
+  // whose place follows from the number of bases that were PACKED: it must be the number this call describes
+  {
+    uint64_t stamp = 0;
+    HIPCHK(hipMemcpyAsync(c->h_small + 48, (const uint8_t*)rd->seqs + packed_codes_bytes(n_bases) - 8, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(&stamp, c->h_small + 48, 8);
+    if (stamp != (PACKED_MAGIC | (n_bases & ((1ull << 40) - 1))))
+      return fail(NTHIP_ERR_ARG, "NTHIP_PACKED_INPUT without NTHIP_PACKED_CLEAN: these reads (%llu bases) are not the batch nthip_pack_reads "
+                  "packed into this buffer -- its validity stream lies elsewhere", (unsigned long long)n_bases);
+  }
   NaPlan na;
   if (!kmer_na_plan(c, len, stride, k, m, st.pos != nullptr, &na))
     return fail(NTHIP_ERR_UNSUPPORTED, "NTHIP_PACKED_INPUT: shape outside the run-split kernels (reads overlapping by more than k - 1 bases)");

@@ -434,9 +434,8 @@ int64_t ntamd::host::fastx_find_record_start(int fd, uint64_t file_size, uint64_
       if (l3 < 0) { undecided = true; break; }
       if (l1 == l3) return (int64_t)(from + ls[li]);
     }
-    if (to_eof && !undecided) return (int64_t)file_size;
-    if (to_eof) return (int64_t)file_size;
-    if (window >= (1ull << 30)) return (int64_t)file_size; // a "record" of a gigabyte: give up on this boundary
+    if (to_eof) return (int64_t)file_size; // (decided or not: no record starts before the end of the file)
+    if (window >= (1ull << 30)) return -2;  // a "record" of a gigabyte: no boundary near pos -- the caller tries further on
   }
 }
 

@@ -2547,6 +2547,14 @@ def test_kmer_packed_input_refusals(ctx, oracle):
         with pytest.raises(nthash_amd.NtHipError) as ei:   # a misaligned buffer is refused, not misread
             ctx.kmer_hash_ptr(d_pk + 4, 0, 10, 100, 0, 31, 1, d_out, 700, flags=nthash_amd.capi.NTHIP_PACKED_INPUT)
         assert ei.value.code == nthash_amd.capi.NTHIP_ERR_ARG
+        # round 4: the validity stream's place follows from the number of bases that were packed; a call that describes
+        # other reads (a subset of them) would take its validity bits from elsewhere -- refused unless it says CLEAN
+        with pytest.raises(nthash_amd.NtHipError) as ei:
+            ctx.kmer_hash_ptr(d_pk, 0, 9, 100, 0, 31, 1, d_out, 700, flags=nthash_amd.capi.NTHIP_PACKED_INPUT)
+        assert ei.value.code == nthash_amd.capi.NTHIP_ERR_ARG and "not the batch" in str(ei.value)
+        clean = nthash_amd.capi.NTHIP_PACKED_INPUT | nthash_amd.capi.NTHIP_PACKED_CLEAN
+        assert ctx.kmer_hash_ptr(d_pk, 0, 9, 100, 0, 31, 1, d_out, 700, flags=clean) == 9 * 70
+        assert ctx.kmer_hash_ptr(d_pk, 0, 10, 100, 0, 31, 1, d_out, 700, flags=nthash_amd.capi.NTHIP_PACKED_INPUT) == 700
         ctx.free(d_offs); ctx.free(d_out)
     finally:
         ctx.free(d_pk)

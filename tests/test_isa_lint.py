@@ -139,3 +139,22 @@ def test_deliberately_broken_unit_is_refused(tmp_path):
     with pytest.raises(RuntimeError, match="ISA lint"):
         nb._compile_unit(hipcc, "capi_kmer_gen.hip", str(tmp_path), ["-DNT_LINT_SELFTEST=1"], True, False)
     assert not os.path.exists(os.path.join(str(tmp_path), "capi_kmer_gen.o"))
+
+
+def test_build_pins_the_compiler(monkeypatch):
+    """round 4: build.py names the hipcc the counted waits and the lint expectations were made with, refuses another one
+    unless told that it has been looked at, and every unit's lint report says which compiler produced the ISA it checked"""
+    import glob
+    import json
+
+    from nthash_amd import build as nb
+    assert nb.hipcc_version() == nb.EXPECTED_HIPCC == nb.check_hipcc()
+    monkeypatch.setattr(nb, "EXPECTED_HIPCC", "HIP version: 0.0 / AMD clang version none")
+    with pytest.raises(RuntimeError, match="review nthash_amd/isa_lint.py"):
+        nb.check_hipcc()
+    monkeypatch.setenv("NTHASH_AMD_ALLOW_HIPCC_MISMATCH", "1")
+    assert nb.check_hipcc() == nb.hipcc_version()
+    reports = glob.glob(os.path.join(nb.OBJ, "capi_*.o.lint.json"))
+    assert len(reports) >= 17
+    stamped = [json.load(open(r)).get("hipcc") for r in reports]
+    assert any(stamped) and all(v in (None, nb.hipcc_version()) for v in stamped)   # (None: a unit built before the stamp existed)
