@@ -58,6 +58,7 @@ struct KmerStream; // device-computed hash stream of one window of a sequence (o
 struct KmerAhead;  // the NEXT window's stream, being computed on the thread's helper while this one is walked
 struct RollTables; // per k: what a byte adds when it enters / leaves a window (host recurrences)
 struct SeedStream;
+struct SeedAhead;  // ... and the same for a SeedNtHash (round 4)
 struct SeedSet;    // parsed seeds: blocks, monomers, masks (host) + device tables
 } // namespace detail
 
@@ -269,6 +270,7 @@ private:
   std::unique_ptr<uint64_t[]> rev_;
   std::unique_ptr<uint64_t[]> hash_arr_;
   std::shared_ptr<detail::SeedStream> stream_;
+  std::shared_ptr<detail::SeedAhead> ahead_;   // the window after stream_, on the thread's helper (not copied)
   size_t cursor_ = 0;
   // views into *stream_ for the inline walk of roll(): positions (relative to sbegin_), hashes, entries
   const uint32_t* sp_ = nullptr;

@@ -387,15 +387,33 @@ struct KmerAhead {
   }
 };
 
+struct SeedStream;
+struct SeedAhead {
+  size_t from = 0;
+  std::future<std::shared_ptr<SeedStream>> fut;
+  std::shared_ptr<std::string> err;
+  ~SeedAhead()
+  {
+    if (fut.valid()) fut.wait(); // the helper reads the caller's sequence: never outlive the object that borrowed it
+  }
+};
+
 struct SeedSet {
   std::vector<std::string> strings;
   std::vector<SeedShape> shapes;
   unsigned k = 0;
+  // the device tables belong to a context, and the helper thread has its own: a second copy for it (round 4 -- until then
+  // a SeedNtHash hashed every window on the user thread: 403 M k-mers/s through roll() against NtHash's 1.16 G)
+  nthip_seeds* dev_helper = nullptr;
+  void* dev_helper_ctx = nullptr;
+  // (copies of one SeedNtHash share this set; walked on different threads they share a slot: one call at a time per slot)
+  std::mutex mu_user, mu_helper;
   nthip_seeds* dev = nullptr;
   void* dev_ctx = nullptr; // the context `dev` lives in
   ~SeedSet()
   {
     if (dev) nthip_seeds_destroy(dev);
+    if (dev_helper) nthip_seeds_destroy(dev_helper);
   }
 };
 
@@ -458,9 +476,16 @@ std::shared_ptr<detail::KmerStream> build_kmer_stream(const char* seq, size_t le
 // position by rolling.  The device call therefore hashes the slice [from, ...) as a sequence of its own -- exactly
 // what the host object does when it (re)initialises at `from` -- and the caller only asks for a window at a position
 // where it is about to init() or has just rolled to: see SeedNtHash::set_window.
+// (err != nullptr: the helper thread's call -- its own context, the seed set's second copy of the device tables, failures
+// reported instead of ending the process)
 std::shared_ptr<detail::SeedStream> build_seed_stream(const char* seq, size_t len, size_t from,
-                                                      detail::SeedSet& seeds, unsigned m2)
+                                                      detail::SeedSet& seeds, unsigned m2, std::string* err = nullptr)
 {
+  auto fail_with = [&](const std::string& msg) -> std::shared_ptr<detail::SeedStream> {
+    if (!err) raise_error("SeedNtHash", msg);
+    *err = msg;
+    return nullptr;
+  };
   auto st = std::make_shared<detail::SeedStream>();
   const unsigned k = seeds.k, ns = (unsigned)seeds.strings.size();
   const size_t n_pos = len - k + 1;
@@ -468,24 +493,27 @@ std::shared_ptr<detail::SeedStream> build_seed_stream(const char* seq, size_t le
   st->w_end = std::min(n_pos, from + window_positions());
   const size_t cap = st->w_end - st->w_begin;
   std::string block_err;
-  if (!st->block.get(cap * ns * m2, cap, &st->hashes.p, &st->pos.p, &block_err)) raise_error("SeedNtHash", block_err);
-  nthip_ctx* ctx = device_ctx("SeedNtHash");
-  if (!seeds.dev || seeds.dev_ctx != ctx) { // (the device tables belong to the thread's context)
-    if (seeds.dev) nthip_seeds_destroy(seeds.dev);
-    seeds.dev = nullptr;
+  if (!st->block.get(cap * ns * m2, cap, &st->hashes.p, &st->pos.p, &block_err)) return fail_with(block_err);
+  nthip_ctx* ctx = device_ctx("SeedNtHash", err);
+  if (!ctx) return nullptr;
+  std::lock_guard<std::mutex> slot(err ? seeds.mu_helper : seeds.mu_user);
+  nthip_seeds*& dev = err ? seeds.dev_helper : seeds.dev;
+  void*& dev_ctx = err ? seeds.dev_helper_ctx : seeds.dev_ctx;
+  if (!dev || dev_ctx != ctx) { // (the device tables belong to the thread's context)
+    if (dev) nthip_seeds_destroy(dev);
+    dev = nullptr;
     std::vector<const char*> ptrs;
     for (const auto& s : seeds.strings) ptrs.push_back(s.c_str());
-    if (nthip_seeds_create(ctx, ptrs.data(), ns, (uint16_t)k, &seeds.dev, nullptr) != NTHIP_OK)
-      raise_error("SeedNtHash", std::string("GPU seed set-up failed: ") + nthip_last_error());
-    seeds.dev_ctx = ctx;
+    if (nthip_seeds_create(ctx, ptrs.data(), ns, (uint16_t)k, &dev, nullptr) != NTHIP_OK)
+      return fail_with(std::string("GPU seed set-up failed: ") + nthip_last_error());
+    dev_ctx = ctx;
   }
   const uint64_t offsets[2] = { 0, (uint64_t)(cap + k - 1) };
   nthip_reads rd = { seq + from, offsets, 1, 0, 0 };
   nthip_out out = { st->hashes.data(), cap, nullptr, st->pos.data(), nullptr, nullptr };
   uint64_t total = 0;
-  if (nthip_seed_hash(ctx, &rd, seeds.dev, (uint8_t)m2, &out, &total, NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT) !=
-      NTHIP_OK)
-    raise_error("SeedNtHash", std::string("GPU hashing failed: ") + nthip_last_error());
+  if (nthip_seed_hash(ctx, &rd, dev, (uint8_t)m2, &out, &total, NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT) != NTHIP_OK)
+    return fail_with(std::string("GPU hashing failed: ") + nthip_last_error());
   st->pos.n = total;
   st->hashes.n = total * ns * m2;
   return st;
@@ -1001,6 +1029,7 @@ SeedNtHash::SeedNtHash(SeedNtHash&& o) noexcept
   , rev_(std::move(o.rev_))
   , hash_arr_(std::move(o.hash_arr_))
   , stream_(std::move(o.stream_))
+  , ahead_(std::move(o.ahead_))
   , cursor_(o.cursor_)
   , sp_(o.sp_)
   , sh_(o.sh_)
@@ -1026,7 +1055,31 @@ void SeedNtHash::set_window(const char* win, bool try_stream)
     // a window of the device stream starts where this walk is (first use: at pos0_): the device then walks the slice
     // the way this object does from here on, and a position its walk does not visit is hashed below
     if (!stream_ || !stream_->covers(p)) {
-      stream_ = build_seed_stream(seq_, len_, stream_ ? p : std::min(p, pos0_), *seeds_, num_hashes_per_seed_);
+      // the window the helper thread has been hashing is the one wanted when the walk arrived where it was expected: a
+      // window is the slice from `from` on hashed as a sequence of its own, on the helper exactly as here
+      const size_t from = stream_ ? p : std::min(p, pos0_);
+      std::shared_ptr<detail::SeedStream> st;
+      if (ahead_) {
+        std::shared_ptr<detail::SeedAhead> a = std::move(ahead_);
+        ahead_.reset();
+        std::shared_ptr<detail::SeedStream> got = a->fut.get();
+        if (!got) raise_error("SeedNtHash", *a->err);
+        if (a->from == from) st = std::move(got);
+      }
+      if (!st) st = build_seed_stream(seq_, len_, from, *seeds_, num_hashes_per_seed_);
+      stream_ = std::move(st);
+      if (prefetch_enabled() && stream_->w_end < len_ - k_ + 1) {
+        auto a = std::make_shared<detail::SeedAhead>();
+        a->from = stream_->w_end;
+        a->err = std::make_shared<std::string>();
+        const char* seq = seq_;
+        const size_t len = len_, nxt = a->from;
+        const unsigned m2 = num_hashes_per_seed_;
+        std::shared_ptr<detail::SeedSet> seeds = seeds_;
+        std::shared_ptr<std::string> err = a->err;
+        a->fut = helper().submit([seq, len, nxt, seeds, m2, err] { return build_seed_stream(seq, len, nxt, *seeds, m2, err.get()); });
+        ahead_ = std::move(a);
+      }
       cursor_ = 0;
       sp_ = stream_->pos.data();
       sh_ = stream_->hashes.data();

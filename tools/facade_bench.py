@@ -53,8 +53,9 @@ with tempfile.TemporaryDirectory() as d:
         print("NTHASH_AMD_PREFETCH=" + pf, flush=True)
         subprocess.run([exe, mb, k, m], env=env)
     if os.environ.get("FACADE_SEEDS") == "1":
-        print("SeedNtHash, 2 seeds x m", flush=True)
-        subprocess.run([exe, str(min(int(mb), 64)), k, m, "seeds"])
+        for pf in ("0", "1"):
+            print("SeedNtHash, 2 seeds x m, NTHASH_AMD_PREFETCH=" + pf, flush=True)
+            subprocess.run([exe, str(min(int(mb), 128)), k, m, "seeds"], env=dict(os.environ, NTHASH_AMD_PREFETCH=pf))
     if os.environ.get("FACADE_TRACE") == "1":
         for pf in ("0", "1"):
             print("trace, NTHASH_AMD_PREFETCH=" + pf, flush=True)
