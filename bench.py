@@ -535,8 +535,9 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
         out["bloom_insert_fresh_4GiB"] = {"value": tot / t_ins, "ms": t_ins * 1e3, "check": "every inserted k-mer is found",
                                           "ok": bool(tot == kmers and tq == kmers and found == kmers),
                                           "roofline": roof(in_bytes + 2 * (n_bits // 8), t_ins, "bases in + the filter read and written once",
-                                                           "binned insert: hash to a stream, histogram, two partition levels, apply -- "
-                                                           "40 B of list traffic per value (DESIGN 4.8); the kernel named is the last of them")}
+                                                           "binned insert without a hash stream (round 4): the reads are hashed twice -- regions "
+                                                           "counted in LDS, first partition level from the registers --, second level, apply: "
+                                                           "16 B of list traffic per value (DESIGN 4.8); the kernel named brackets all of them")}
         ctx.free(d_f)
         owned.remove(d_f)
         # counting sketch: 1 Gi one-byte counters, fresh; no counter saturates here, so the bytes add up to the k-mers
@@ -558,7 +559,7 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
                                                   "check": "sum of the counters == k-mers inserted (largest counter %d)" % top,
                                                   "ok": bool(totc == kmers and (s_bytes == kmers or top == 255)),
                                                   "roofline": roof(in_bytes + 2 * n_cnt, t_c, "bases in + the counters read and written once",
-                                                                   "on the binned insert's lists (DESIGN 4.8)")}
+                                                                   "on the stream-less binned insert's lists (DESIGN 4.8)")}
         ctx.free(d_c)
         owned.remove(d_c)
         # (w, k)-minimizers, w = 10: density close to 2 / (w + 1) on random reads, offsets ascending

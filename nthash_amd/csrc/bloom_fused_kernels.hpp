@@ -1,0 +1,230 @@
+// bloom_fused_kernels.hpp -- the binned Bloom / counting-sketch insert WITHOUT a hash stream (round 4).
+//
+// Until round 3 a round of reads was hashed to a stream (8 B per value written), the stream read by the histogram (8 B)
+// and read again by the first partition level (8 B): 24 of the insert's 40 bytes per value, and the three kernels that
+// move them -- hash 4.7, hist 3.9, part 8.3 ms per 2.4 G values -- more than half of its time.  Hashing is cheaper than
+// that traffic, so here the reads are hashed TWICE and the values never leave the CU:
+//   pass COUNT  every value's region counted in LDS (32-bit counters for every region of the filter, flushed once per
+//               block -- what bloom_hist_kernel did from the stream);
+//   pass PART   every value goes straight from the registers into the first partition level: a tile is the 16 windows a
+//               thread has just rolled x the block's reads, sorted by bucket in LDS and appended run by run at the
+//               buckets' cursors -- bloom_part_kernel<IN64>'s tile, fed by the hash instead of by a load.
+// The second level and the apply kernels are bloom_binned_kernels.hpp's, unchanged: 16 B per value instead of 40.
+//
+// The counters (up to 128 KiB for a filter of 2^35 bits) and the sort buffer leave no room for first-window tables, so
+// the hashing is the table-free form of kmer_fixed_kernel: one read per thread, its first window reached by k rolls from
+// a window of virtual 'A's (f_init / r_init), every step one 16-entry pair-table lookup (next_forward_hash /
+// next_reverse_hash, src/kmer.cpp:84-94,164-174; the first window is what base_forward_hash / base_reverse_hash give,
+// src/kmer.cpp:43-73,123-152, reached by the roll).  len / (len - k + 1) rolls per k-mer: 1.25 for 150 bp reads.
+// A non-base anywhere sets a.dirty (pass COUNT): the caller takes the round through the N-aware stream path instead.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "bloom_binned_kernels.hpp"
+#include "kmer_kernels.hpp"
+
+namespace ntamd {
+
+enum : int { BF_COUNT = 0, BF_PART = 1 };
+
+struct BloomFusedArgs {
+  const uint8_t* seqs;      // fixed-length reads, stride bytes apart
+  uint32_t* dirty;          // set when a non-base is seen
+  uint64_t n_reads;
+  uint32_t len, stride, k, m;
+  uint32_t pad_dwords;      // front pad of the LDS bit stream: ceil(k / 16) + 1 words of virtual 'A'
+  uint32_t n_tiles;         // ceil(n_reads / threads)
+  uint64_t f_init, r_init;  // strand hashes of k virtual 'A's
+  uint64_t tab[16][2];      // [(in << 2) | out] -> {forward term, reverse term}
+  uint64_t mult[KF_MAX_RUNTIME_M];
+  uint64_t n_bits, magic;   // value -> slot: h mod n_bits (filter bits / sketch counters)
+  // pass COUNT
+  uint32_t* counts;         // [n_regions] += values per region
+  uint32_t n_regions, region_shift;
+  // pass PART: the bucket of a slot is slot >> shift, what is written is slot & mask, at the bucket's cursor
+  uint32_t* out;
+  uint32_t* cursor;
+  uint32_t shift, mask, n_buckets;
+};
+
+// THREADS reads per tile; dynamic LDS: bit stream | COUNT: n_regions counters / PART: THREADS * 16 sorted slots
+template <int PASS, uint32_t THREADS>
+__global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  __shared__ __attribute__((aligned(16))) uint4 tab[16];
+  __shared__ uint32_t hist[BB_MAX_BINS], off[BB_MAX_BINS], gbase[BB_MAX_BINS];
+  const uint32_t k = a.k, m = a.m;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // the bit stream of a tile: pad + slab (THREADS reads) + two spare words
+  const uint32_t bits_dwords = a.pad_dwords + (((THREADS - 1u) * a.stride + a.len + 15u + 15u) >> 4) + 2u;
+  uint32_t* const bits = lds_dyn;
+  uint32_t* const area = lds_dyn + ((bits_dwords + 3u) & ~3u); // COUNT: the counters; PART: the sorted tile
+
+  if (tid < 16)
+    tab[tid] = make_uint4((uint32_t)a.tab[tid][0], (uint32_t)(a.tab[tid][0] >> 32), (uint32_t)a.tab[tid][1],
+                          (uint32_t)(a.tab[tid][1] >> 32));
+  for (uint32_t i = tid; i < a.pad_dwords; i += THREADS) bits[i] = 0; // virtual 'A's (code 0)
+  if constexpr (PASS == BF_COUNT)
+    for (uint32_t i = tid; i < a.n_regions; i += THREADS) area[i] = 0;
+
+  const uint32_t kmod = (k - 1u) & 15u;
+  const uint32_t jb = (k - 1u) >> 4;          // the word that holds the first emitting step
+  const uint32_t n_words = (a.len + 15u) >> 4;
+  uint32_t bad = 0;
+
+  for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+    const uint64_t run0 = (uint64_t)t * THREADS;
+    const uint64_t left = a.n_reads - run0;
+    const uint32_t runs_here = left < THREADS ? (uint32_t)left : THREADS;
+    // ---- the slab of ASCII as a 2-bit stream (16-byte vectors aligned in memory; the bytes of a first / last vector that
+    // lie outside the slab are somebody else's: not judged) ----
+    const uint64_t addr0 = (uint64_t)(a.seqs + run0 * a.stride);
+    const uint32_t shift = (uint32_t)(addr0 & 15u);
+    const uint4* vsrc = (const uint4*)(addr0 - shift);
+    const uint32_t slab_bytes = (runs_here - 1u) * a.stride + a.len;
+    const uint32_t n_vec = (shift + slab_bytes + 15u) >> 4;
+    __syncthreads(); // the tile before is consumed; pad / tab / counters are there on the first pass
+    for (uint32_t i = tid; i < n_vec; i += THREADS) {
+      const uint4 v = vsrc[i];
+      uint32_t b = 0;
+      const uint32_t p = pack16(v, b);
+      const int32_t lo_cut = (int32_t)shift - (int32_t)(i << 4);
+      const int32_t hi_cut = (int32_t)(shift + slab_bytes) - (int32_t)(i << 4);
+      if (lo_cut > 0 || hi_cut < 16) {
+        uint32_t bx[4] = {0, 0, 0, 0};
+        (void)pack4(v.x, bx[0]);
+        (void)pack4(v.y, bx[1]);
+        (void)pack4(v.z, bx[2]);
+        (void)pack4(v.w, bx[3]);
+        b = 0;
+        for (int q = 0; q < 16; ++q)
+          if (q >= lo_cut && q < hi_cut) b |= (bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+      }
+      bad |= b;
+      bits[a.pad_dwords + i] = p;
+    }
+    if (tid < 2) bits[a.pad_dwords + n_vec + tid] = 0; // funnels read one word ahead
+    __syncthreads();
+
+    // ---- every thread rolls its read, 16 steps at a time ----
+    const bool live = tid < runs_here;
+    const uint32_t lrun = live ? tid : 0u; // (idle threads of the last tile redo its first read and emit nothing)
+    const uint32_t bl = a.pad_dwords * 16u + shift + lrun * a.stride;
+    const uint32_t in_d = bl >> 4, in_sh = (bl & 15u) << 1;
+    const uint32_t ob = bl - k; // (never negative thanks to the pad)
+    const uint32_t out_d = ob >> 4, out_sh = (ob & 15u) << 1;
+    uint32_t f_lo = (uint32_t)a.f_init, f_hi = (uint32_t)(a.f_init >> 32);
+    uint32_t r_lo = (uint32_t)a.r_init, r_hi = (uint32_t)(a.r_init >> 32);
+    uint32_t in_lo = bits[in_d], out_lo = bits[out_d];
+
+    for (uint32_t j = 0; j < n_words; ++j) {
+      const uint32_t in_hi = bits[in_d + j + 1], out_hi = bits[out_d + j + 1];
+      const uint32_t w_in = funnel(in_hi, in_lo, in_sh);
+      uint32_t w_out = funnel(out_hi, out_lo, out_sh);
+      in_lo = in_hi;
+      out_lo = out_hi;
+      const uint32_t s0 = j << 4;
+      // steps whose outgoing base lies before the read's start see a virtual 'A'
+      if (s0 + 16u <= k) w_out = 0;
+      else if (s0 < k) w_out &= ~0u << ((k - s0) << 1);
+      const uint32_t u = ((w_in & 0x33333333u) << 2) | (w_out & 0x33333333u);
+      const uint32_t v = (w_in & 0xCCCCCCCCu) | ((w_out >> 2) & 0x33333333u);
+      uint4 terms[16];
+#pragma unroll
+      for (uint32_t i = 0; i < 16; ++i) { // (the table terms do not depend on the hash state: all in flight at once)
+        const uint32_t src = (i & 1u) ? v : u;
+        terms[i] = *(const uint4*)((const char*)tab + (((src >> ((i >> 1) * 4u)) & 0xFu) << 4));
+      }
+      // steps [lo, hi) of this word end a window of the read (uniform over the block)
+      const uint32_t lo = j < jb ? 16u : (j == jb ? kmod : 0u);
+      const uint32_t hi = a.len - s0 < 16u ? a.len - s0 : 16u;
+      uint64_t h[16];
+#pragma unroll
+      for (uint32_t i = 0; i < 16; ++i) {
+        srol_pair(f_lo, f_hi);
+        f_lo ^= terms[i].x;
+        f_hi ^= terms[i].y;
+        r_lo ^= terms[i].z;
+        r_hi ^= terms[i].w;
+        sror_pair(r_lo, r_hi);
+        h[i] = canon_pair(f_lo, f_hi, r_lo, r_hi);
+      }
+      if (lo >= hi) continue; // (no window ends in this word: uniform)
+      for (uint32_t jj = 0; jj < m; ++jj) { // the k-mers' m values (extend_hashes, src/internal.hpp:104-118), one set at a time
+        if constexpr (PASS == BF_COUNT) {
+#pragma unroll
+          for (uint32_t i = 0; i < 16; ++i)
+            if (live && i >= lo && i < hi) {
+              const uint64_t val = jj == 0 ? h[i] : mix_hash(h[i], a.mult[jj & (KF_MAX_RUNTIME_M - 1)]);
+              atomicAdd(&area[(uint32_t)(mod_invariant(val, a.n_bits, a.magic) >> a.region_shift)], 1u);
+            }
+        } else {
+          // ---- a tile of the first partition level: THREADS x 16 slots, sorted by bucket, appended at the cursors ----
+          if (tid < BB_MAX_BINS) hist[tid] = 0;
+          __syncthreads();
+          uint32_t val[16], where[16]; // where = bucket << 16 | rank inside the tile's bucket
+#pragma unroll
+          for (uint32_t i = 0; i < 16; ++i) {
+            where[i] = ~0u;
+            val[i] = 0;
+            if (live && i >= lo && i < hi) {
+              const uint64_t hv = jj == 0 ? h[i] : mix_hash(h[i], a.mult[jj & (KF_MAX_RUNTIME_M - 1)]);
+              const uint64_t p = mod_invariant(hv, a.n_bits, a.magic);
+              const uint32_t b = (uint32_t)(p >> a.shift);
+              val[i] = (uint32_t)p & a.mask;
+              where[i] = (b << 16) | atomicAdd(&hist[b], 1u);
+            }
+          }
+          __syncthreads();
+          if (wave == 0) { // exclusive scan of the (at most 256) bucket counts: 4 per lane
+            uint32_t cc[4], s = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+              cc[i] = hist[lane * 4u + i];
+              s += cc[i];
+            }
+            uint32_t incl = s;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+              const uint32_t o = __shfl_up(incl, d, 64);
+              if ((int)lane >= d) incl += o;
+            }
+            uint32_t run = incl - s;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+              off[lane * 4u + i] = run;
+              run += cc[i];
+            }
+          }
+          if (tid < a.n_buckets) {
+            const uint32_t cnt = hist[tid];
+            gbase[tid] = cnt ? atomicAdd(&a.cursor[(size_t)tid * BB_CURSOR_STRIDE], cnt) : 0u;
+          }
+          __syncthreads();
+#pragma unroll
+          for (uint32_t i = 0; i < 16; ++i)
+            if (where[i] != ~0u) area[off[where[i] >> 16] + (where[i] & 0xFFFFu)] = val[i];
+          __syncthreads();
+          for (uint32_t b = wave; b < a.n_buckets; b += THREADS / 64u) {
+            const uint32_t cnt = hist[b], o = off[b];
+            uint32_t* const dst = a.out + gbase[b];
+            for (uint32_t q = lane; q < cnt; q += 64u) dst[q] = area[o + q];
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }
+  if constexpr (PASS == BF_COUNT) {
+    __syncthreads();
+    for (uint32_t i = tid; i < a.n_regions; i += THREADS) {
+      const uint32_t v = area[i];
+      if (v) atomicAdd(&a.counts[i], v);
+    }
+    if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
+  }
+}
+
+} // namespace ntamd

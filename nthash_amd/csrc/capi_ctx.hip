@@ -271,6 +271,7 @@ void load_tuning(nthip_tune& t)
   t.no_any_k_runs = is_one("NTHIP_TUNE_NO_ANY_K_RUNS");
   t.no_fh = is_one("NTHIP_TUNE_NO_FH");
   t.mz_table = is_one("NTHIP_TUNE_MZ_TABLE");
+  t.bloom_fused = num("NTHIP_TUNE_BLOOM_FUSED", 1, 2);
   t.mz_fused = num("NTHIP_TUNE_MZ_FUSED", 1, 2);
   t.mz_c = num("NTHIP_TUNE_MZ_C", 2, 16);
   t.mz_waves = num("NTHIP_TUNE_MZ_WAVES", 1, 16);

@@ -109,6 +109,7 @@ struct nthip_tune {
   // (GB/s; 0: off), NTHIP_TUNE_PF_LEAD_KB = how far ahead per group, NTHIP_TUNE_PF_CHUNK_KB = bytes per burst
   uint32_t pf_gbps = 0, pf_lead_kb = 0, pf_chunk_kb = 0;
   uint32_t bloom_round = 0;  // NTHIP_TUNE_BLOOM_ROUND=<values>: rounds of the binned consumers no longer than this (tests: several rounds on a small batch)
+  uint32_t bloom_fused = 0;  // NTHIP_TUNE_BLOOM_FUSED=1: the stream-less binned insert on every shape it can take, 2: never (A/B, tests)
   uint32_t bloom_binned = 0; // NTHIP_TUNE_BLOOM_BINNED=1: the binned insert whenever the filter allows it, 2: never (A/B, tests)
   uint32_t seed_any = 0;    // NTHIP_TUNE_SEED_ANY=1: dense seed batches on the any-seed form whatever the seed set, 2: none of k <= 128 (A/B, tests)
   uint32_t fw = 0;          // NTHIP_TUNE_FW: first window beyond the position tables -- 1 grouped, 2 prefix scan (0: cost model)

@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include "bloom_binned_kernels.hpp"
+#include "bloom_fused_kernels.hpp"
 #include "util_kernels.hpp" // (SCAN_TILE)
 
 using namespace ntamd;
@@ -169,21 +170,116 @@ uint64_t bloom_round_values(const nthip_ctx* c, uint64_t n_values, bool with_str
   return round;
 }
 
+// ---- the round WITHOUT a hash stream (bloom_fused_kernels.hpp): device-resident fixed-length reads hashed twice ----------
+struct BloomFusedSrc {
+  const uint8_t* seqs = nullptr;
+  uint64_t n_reads = 0;
+  uint32_t len = 0, stride = 0, k = 0, m = 0;
+};
+constexpr uint32_t BF_COUNT_THREADS_BIG = 512; // filters of more than 2^34 slots' regions: 128 KiB of counters leave room for 512 reads
+// LDS of a pass: the tile's bit stream + the counters / the sorted tile (the statics are the kernel's own)
+size_t bloom_fused_lds(const BloomFusedSrc& s, uint32_t threads, uint32_t area_dwords)
+{
+  const uint32_t pad = (s.k + 15u) / 16u + 1u;
+  const uint32_t bits = pad + (((threads - 1u) * s.stride + s.len + 30u) >> 4) + 2u;
+  return ((size_t)((bits + 3u) & ~3u) + area_dwords) * 4;
+}
+bool bloom_fused_ok(const nthip_ctx* c, const BloomFusedSrc& s, uint32_t n_regions)
+{
+  if (c->tune.bloom_fused == 2 || s.m > (uint32_t)KF_MAX_RUNTIME_M || s.len < s.k || s.stride < s.len) return false;
+  if (2u * (s.len - s.k + 1u) < s.len && c->tune.bloom_fused != 1) return false; // (more than two rolls per k-mer: the stream path)
+  const size_t cap = lds_cap_of(c) - 4096; // (tab / hist / off / gbase are static)
+  const uint32_t ct = n_regions > 16384u ? BF_COUNT_THREADS_BIG : 1024u;
+  return bloom_fused_lds(s, ct, n_regions < 128u ? 128u : n_regions) <= cap && bloom_fused_lds(s, 1024u, 1024u * 16u) <= cap;
+}
+void bloom_fused_args(const BloomFusedSrc& s, uint32_t threads, uint64_t n_bits, uint64_t magic, BloomFusedArgs* a)
+{
+  memset(a, 0, sizeof *a);
+  KmerFixedArgs consts;
+  memset(&consts, 0, sizeof consts);
+  fill_kmer_consts(s.k, s.m, consts);
+  a->seqs = s.seqs;
+  a->n_reads = s.n_reads;
+  a->len = s.len;
+  a->stride = s.stride;
+  a->k = s.k;
+  a->m = s.m;
+  a->pad_dwords = (s.k + 15u) / 16u + 1u;
+  a->n_tiles = (uint32_t)((s.n_reads + threads - 1) / threads);
+  a->f_init = consts.f_init;
+  a->r_init = consts.r_init;
+  memcpy(a->tab, consts.tab, sizeof a->tab);
+  memcpy(a->mult, consts.mult, sizeof a->mult);
+  a->n_bits = n_bits;
+  a->magic = magic;
+}
+// pass COUNT: t.counts := values per region; *dirty: a read of the round holds a non-base (the caller takes the stream path)
+int bloom_fused_count(nthip_ctx* c, const BloomFusedSrc& s, uint64_t n_bits, const BloomLists& t, bool counters, bool* dirty)
+{
+  const uint32_t region_shift = counters ? CS_REGION_SHIFT : BB_REGION_SHIFT;
+  const uint32_t n_regions = (uint32_t)((n_bits + (1ull << region_shift) - 1) >> region_shift);
+  HIPCHK(hipMemsetAsync(t.counts, 0, (size_t)n_regions * sizeof(uint32_t), c->stream));
+  HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream));
+  const uint32_t threads = n_regions > 16384u ? BF_COUNT_THREADS_BIG : 1024u;
+  BloomFusedArgs a;
+  bloom_fused_args(s, threads, n_bits, bloom_magic_of(n_bits), &a);
+  a.dirty = (uint32_t*)c->d_small;
+  a.counts = t.counts;
+  a.n_regions = n_regions;
+  a.region_shift = region_shift;
+  const size_t lds = bloom_fused_lds(s, threads, n_regions < 128u ? 128u : n_regions);
+  const unsigned grid = (unsigned)std::min<uint64_t>(a.n_tiles, (uint64_t)c->n_cu);
+  prof_begin(c, counters ? "count fused insert (count, scan, part, apply)" : "bloom fused insert (count, scan, part, apply)");
+  if (threads == 1024u) {
+    NTCHK(set_max_lds(c, bloom_fused_kernel<BF_COUNT, 1024>, lds));
+    hipLaunchKernelGGL((bloom_fused_kernel<BF_COUNT, 1024>), dim3(grid), dim3(1024), lds, c->stream, a);
+  } else {
+    NTCHK(set_max_lds(c, bloom_fused_kernel<BF_COUNT, BF_COUNT_THREADS_BIG>, lds));
+    hipLaunchKernelGGL((bloom_fused_kernel<BF_COUNT, BF_COUNT_THREADS_BIG>), dim3(grid), dim3(BF_COUNT_THREADS_BIG), lds, c->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint32_t d = 0;
+  memcpy(&d, c->h_small, 4);
+  *dirty = d != 0;
+  return NTHIP_OK;
+}
+
 // one round: n <= BB_ROUND_MAX values of a device-resident stream into the filter (launches only, no synchronisation)
+// (fused: the round's values come from the reads themselves -- t.counts already holds pass COUNT's histogram, the first
+// partition level is pass PART)
 int bloom_binned_round(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n, uint32_t* d_filter, uint64_t n_bits,
-                       const BloomLists& t, bool counters = false)
+                       const BloomLists& t, bool counters = false, const BloomFusedSrc* fused = nullptr)
 {
   const uint32_t region_shift = counters ? CS_REGION_SHIFT : BB_REGION_SHIFT, bin_shift = region_shift + 7u;
   const uint32_t n_regions = (uint32_t)((n_bits + (1ull << region_shift) - 1) >> region_shift);
   const uint32_t n_bins = (n_regions + BB_REGIONS_PER_BIN - 1) / BB_REGIONS_PER_BIN;
   const uint64_t magic = bloom_magic_of(n_bits);
   const uint64_t filter_dwords = counters ? (n_bits + 3) / 4 : (n_bits + 31) / 32;
-  HIPCHK(hipMemsetAsync(t.counts, 0, (size_t)n_regions * sizeof(uint32_t), c->stream));
-  const size_t hist_lds = (size_t)(n_regions < 128u ? 128u : n_regions) * sizeof(uint32_t);
-  NTCHK(set_max_lds(c, bloom_hist_kernel, hist_lds));
-  prof_begin(c, counters ? "count binned insert (hist, scan, part, apply)" : "bloom binned insert (hist, scan, part, apply)");
-  hipLaunchKernelGGL(bloom_hist_kernel, dim3(c->n_cu), dim3(1024), hist_lds, c->stream, d_hashes, n, n_bits, magic, n_regions,
-                     t.counts, region_shift);
+  if (!fused) {
+    HIPCHK(hipMemsetAsync(t.counts, 0, (size_t)n_regions * sizeof(uint32_t), c->stream));
+    const size_t hist_lds = (size_t)(n_regions < 128u ? 128u : n_regions) * sizeof(uint32_t);
+    NTCHK(set_max_lds(c, bloom_hist_kernel, hist_lds));
+    prof_begin(c, counters ? "count binned insert (hist, scan, part, apply)" : "bloom binned insert (hist, scan, part, apply)");
+    hipLaunchKernelGGL(bloom_hist_kernel, dim3(c->n_cu), dim3(1024), hist_lds, c->stream, d_hashes, n, n_bits, magic, n_regions,
+                       t.counts, region_shift);
+  }
+  // the first level from the reads (pass PART of bloom_fused_kernels.hpp) instead of from a stream
+  auto fused_level1 = [&](uint32_t* out, uint32_t* cursor, uint32_t shift, uint32_t n_buckets) -> int {
+    BloomFusedArgs fa;
+    bloom_fused_args(*fused, 1024u, n_bits, magic, &fa);
+    fa.out = out;
+    fa.cursor = cursor;
+    fa.shift = shift;
+    fa.mask = (1u << shift) - 1u;
+    fa.n_buckets = n_buckets;
+    const size_t lds = bloom_fused_lds(*fused, 1024u, 1024u * 16u);
+    NTCHK(set_max_lds(c, bloom_fused_kernel<BF_PART, 1024>, lds));
+    hipLaunchKernelGGL((bloom_fused_kernel<BF_PART, 1024>), dim3((unsigned)std::min<uint64_t>(fa.n_tiles, (uint64_t)c->n_cu)), dim3(1024), lds,
+                       c->stream, fa);
+    return NTHIP_OK;
+  };
   hipLaunchKernelGGL(bloom_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)t.counts, n_regions, t.region_base,
                      t.region_cursor, t.bin_cursor);
   auto part_lds = [](uint32_t threads) { return (size_t)threads * BB_PART_ITEMS * (sizeof(uint32_t) + (BB_COPY_SLOT ? 1 : 0)); };
@@ -205,16 +301,20 @@ int bloom_binned_round(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n, uint3
     a.shift = region_shift;
     a.mask = (1u << region_shift) - 1u;
     a.buckets_per_seg = n_regions;
-    hipLaunchKernelGGL((bloom_part_kernel<true, BB_L1_THREADS>), dim3(part_blocks(BB_L1_THREADS)), dim3(BB_L1_THREADS),
-                       part_lds(BB_L1_THREADS), c->stream, a);
+    if (fused) NTCHK(fused_level1(t.list2, t.region_cursor, region_shift, n_regions));
+    else
+      hipLaunchKernelGGL((bloom_part_kernel<true, BB_L1_THREADS>), dim3(part_blocks(BB_L1_THREADS)), dim3(BB_L1_THREADS),
+                         part_lds(BB_L1_THREADS), c->stream, a);
   } else {
     a.out = t.list1;
     a.cursor = t.bin_cursor;
     a.shift = bin_shift;
     a.mask = (1u << bin_shift) - 1u;
     a.buckets_per_seg = n_bins;
-    hipLaunchKernelGGL((bloom_part_kernel<true, BB_L1_THREADS>), dim3(part_blocks(BB_L1_THREADS)), dim3(BB_L1_THREADS),
-                       part_lds(BB_L1_THREADS), c->stream, a);
+    if (fused) NTCHK(fused_level1(t.list1, t.bin_cursor, bin_shift, n_bins));
+    else
+      hipLaunchKernelGGL((bloom_part_kernel<true, BB_L1_THREADS>), dim3(part_blocks(BB_L1_THREADS)), dim3(BB_L1_THREADS),
+                         part_lds(BB_L1_THREADS), c->stream, a);
     a.in = t.list1;
     a.out = t.list2;
     a.cursor = t.region_cursor;
@@ -267,6 +367,20 @@ int run_kmer_bloom_binned(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8
     nthip_reads part = *rd;
     part.seqs = rd->seqs + r0 * stride;
     part.n_reads = nr;
+    // round 4: no hash stream at all when the reads are on the device and hold bases only -- hashed twice, counted in LDS,
+    // partitioned from the registers (bloom_fused_kernels.hpp: 16 B of list traffic per value instead of 40)
+    const BloomFusedSrc src = {(const uint8_t*)part.seqs, nr, len, stride, k, m};
+    const uint32_t n_regions = (uint32_t)((n_bits + (1ull << BB_REGION_SHIFT) - 1) >> BB_REGION_SHIFT);
+    if (!(flags & NTHIP_HOST_INPUT) && bloom_fused_ok(c, src, n_regions)) {
+      bool dirty = false;
+      NTCHK(bloom_fused_count(c, src, n_bits, t, false, &dirty));
+      if (!dirty) {
+        const uint64_t total = nr * (uint64_t)(len - k + 1);
+        NTCHK(bloom_binned_round(c, nullptr, total * m, d_filter, n_bits, t, false, &src));
+        sum += total;
+        continue;
+      }
+    }
     nthip_out out;
     memset(&out, 0, sizeof out);
     out.hashes = t.hashes;
@@ -557,6 +671,20 @@ extern "C" int nthip_kmer_count_insert(nthip_ctx* c, const nthip_reads* rd, uint
     nthip_reads part = *rd;
     part.seqs = rd->seqs + r0 * stride;
     part.n_reads = nr;
+    // (as the Bloom insert: device-resident reads of bases only are hashed twice and never streamed)
+    const BloomFusedSrc src = {(const uint8_t*)part.seqs, nr, len, stride, k, m};
+    const uint32_t n_regions = (uint32_t)((n_counters + (1ull << CS_REGION_SHIFT) - 1) >> CS_REGION_SHIFT);
+    const uint64_t dense = nr * (uint64_t)(len - k + 1);
+    if (!(flags & NTHIP_HOST_INPUT) && stride >= len && bloom_binned_ok(c, d_counters, n_counters, dense * m, true) &&
+        bloom_fused_ok(c, src, n_regions)) {
+      bool dirty = false;
+      NTCHK(bloom_fused_count(c, src, n_counters, t, true, &dirty));
+      if (!dirty) {
+        NTCHK(bloom_binned_round(c, nullptr, dense * m, (uint32_t*)d_counters, n_counters, t, true, &src));
+        sum += dense;
+        continue;
+      }
+    }
     nthip_out out;
     memset(&out, 0, sizeof out);
     out.hashes = t.hashes;
