@@ -109,6 +109,9 @@ __device__ __forceinline__ uint32_t multi_hash_copy_out(const uint64_t* __restri
 #ifndef KRG_LOAD_NT
 #define KRG_LOAD_NT " nt"
 #endif
+#ifndef KRG_XCD_GROUPS
+#define KRG_XCD_GROUPS 0 // experiment of round 4 (tile_range below): no effect, off
+#endif
 constexpr uint32_t KRG_ALIGN_U64 = 128; // the output tile is aligned to 1 KiB of the stream
 constexpr uint32_t KRG_SLACK_U64 = 32;  // N-aware: room below the tile for a first run's recomputed windows (< C <= 31)
 enum : int { SINK_NONE = 0, SINK_BLOOM_INSERT = 1, SINK_BLOOM_QUERY = 2, SINK_MINHASH = 3, SINK_MINHASH1 = 4 };
@@ -323,11 +326,22 @@ __device__ __forceinline__ TileGeo tile_geo(const RunShape& s, uint64_t seqs_add
 }
 // the waves of the grid are split into tile_map groups of consecutive waves; every group owns one
 // contiguous range of tiles and its waves interleave inside it (see kmer_runs_kernel.hpp)
+template <bool XCD = true>
 __device__ __forceinline__ void tile_range(uint32_t tile_map, uint32_t waves, uint32_t wave, uint64_t n_wtiles,
                                            uint64_t& wt, uint64_t& wstride, uint64_t& wt_end)
 {
   const uint64_t n_waves_total = (uint64_t)gridDim.x * waves;
-  const uint64_t gw = (uint64_t)blockIdx.x * waves + wave;
+  // Round 4, -DKRG_XCD_GROUPS=1 (negative result, off): the blocks of a group on ONE XCD.  Block b runs on XCD b % 8
+  // (observed, MI355X_MICROARCH.md) and every XCD has its own L2; a tile that does not start on a line of the stream (every
+  // tile of the N-aware pass behind the first skipped k-mer, every shape whose reads' windows are no multiple of 16) shares
+  // its first and last line with its neighbours -- the next waves of its GROUP.  The idea: on one XCD the two halves of a
+  // line would meet in one L2.  In-process A/B twice over (tools/xcd_ab.sh): N-aware pass 5.89 / 5.85 against 5.79 / 5.90 ms,
+  // 151 / 101 / 250 bp dense within 0.5 % either way -- whatever the partial lines cost, it is not the L2 they go through.
+  uint32_t vb = blockIdx.x;
+#if KRG_XCD_GROUPS
+  if (XCD && (gridDim.x & 7u) == 0u) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#endif
+  const uint64_t gw = (uint64_t)vb * waves + wave;
   uint64_t groups = tile_map ? tile_map : 1u;
   if (groups > n_waves_total) groups = n_waves_total;
   const uint64_t wpg = n_waves_total / groups;
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
 
   uint32_t bad = 0;
   uint64_t wt, wstride, wt_end;
-  tile_range(a.tile_map, a.waves, wave, a.n_wtiles, wt, wstride, wt_end);
+  tile_range<SINK == SINK_NONE>(a.tile_map, a.waves, wave, a.n_wtiles, wt, wstride, wt_end); // (the consumers write no stream)
   uint64_t r_first = (wt * 64u) / rpr;
   uint32_t rem0 = (uint32_t)(wt * 64u - r_first * rpr);
   const uint64_t step_q = (wstride * 64u) / rpr;
