@@ -18,7 +18,7 @@ namespace {
 // tables, w <= the read's windows.  The run length C is the block of the sliding minimum: C <= w.
 struct MzfPlan {
   uint32_t C = 0, rpr = 0, R = 0, m0 = 0, r = 0, extra = 0, waves = 0, bits_dwords = 0, pitch_h = 0, pitch_b = 0, per_wave_dwords = 0,
-           nw = 0;
+           nw = 0, stash_cap = 0, byte_dwords = 0;
   size_t lds = 0;
 };
 bool minimizer_fused_plan(const nthip_ctx* c, uint32_t len, uint32_t k, uint32_t w, MzfPlan* p)
@@ -55,9 +55,17 @@ bool minimizer_fused_plan(const nthip_ctx* c, uint32_t len, uint32_t k, uint32_t
   p->pitch_h = C | 1u;
   p->pitch_b = 4u * (((C + 3u) / 4u) | 1u);
   p->bits_dwords = ((15u + p->R * len + p->extra + 15u) >> 4) + nw + 8u;
-  p->per_wave_dwords = 2u * MZF_ROWS * p->pitch_h + 3u * MZF_FULL + (MZF_ROWS * p->pitch_b) / 4u + (64u * p->pitch_b) / 4u + p->bits_dwords;
+  // the stash parks one tile's picks: three times the expected 2 / (w + 1) of the tile's windows, at least 256
+  const uint32_t max_picks = p->R * (nwin - w + 1u);
+  uint32_t scap = 6u * p->R * nwin / (w + 1u);
+  scap = scap < 256u ? 256u : scap;
+  scap = scap > max_picks ? max_picks : scap;
+  p->stash_cap = (scap + 3u) & ~3u;
+  // (the byte arrays before the stash: (MZF_ROWS + 64) * pitch_b = 129 * 4 * odd bytes -- padded to 8 below)
+  p->byte_dwords = (((MZF_ROWS + 64u) * p->pitch_b + 7u) & ~7u) / 4u;
+  p->per_wave_dwords = 2u * MZF_ROWS * p->pitch_h + 3u * MZF_FULL + p->byte_dwords + 2u * p->stash_cap + p->stash_cap / 2u + p->bits_dwords;
   p->per_wave_dwords = (p->per_wave_dwords + 3u) & ~3u;
-  const size_t tables = (size_t)4 * nw * 256 * 16 + 256;
+  const size_t tables = (size_t)4 * nw * 256 * 16 + 256 + BR_CTRL_DWORDS * 4;
   const size_t cap = lds_cap_of(c);
   if (cap < tables + (size_t)p->per_wave_dwords * 4 * 2) return false;
   uint32_t waves = (uint32_t)((cap - tables) / ((size_t)p->per_wave_dwords * 4));
@@ -78,9 +86,17 @@ int minimizers_fused(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t l
   if (!minimizer_fused_plan(c, len, k, w, &p)) return NTHIP_OK;
   const uint64_t n_tiles = (n + p.R - 1) / p.R;
   if (n_tiles >= 0x7FFFFFFFull) return NTHIP_OK;
-  NTCHK(ensure_scratch(c, n_tiles + 8));
-  // scratch: [0] total, [1] abort (u32) | dirty (u32), [2 ...) the tiles' look-back words
-  HIPCHK(hipMemsetAsync(c->d_scratch, 0, (n_tiles + 2) * sizeof(uint64_t), c->stream));
+  // one block per CU, every block resident: the look-back needs the blocks of a round to run together (block_rounds.hpp)
+  uint64_t grid = (uint64_t)c->n_cu;
+  {
+    const uint64_t need = (n_tiles + p.waves - 1) / p.waves;
+    if (grid > need) grid = need;
+  }
+  const uint32_t n_rounds = (uint32_t)((n_tiles + grid * p.waves - 1) / (grid * p.waves));
+  const uint64_t n_status = ((uint64_t)n_rounds + 1) * grid;
+  NTCHK(ensure_scratch(c, n_status + 8));
+  // scratch: [0] total, [1] abort (u32) | dirty (u32), [2 ...) the block-rounds' look-back words
+  HIPCHK(hipMemsetAsync(c->d_scratch, 0, (n_status + 2) * sizeof(uint64_t), c->stream));
   MinimizerFusedArgs a;
   memset(&a, 0, sizeof a);
   a.seqs = d_seqs;
@@ -96,6 +112,8 @@ int minimizers_fused(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t l
   a.n_reads = n;
   a.total_bytes = n * len;
   a.n_tiles = (uint32_t)n_tiles;
+  a.n_rounds = n_rounds;
+  a.stash_cap = p.stash_cap;
   a.len = len;
   a.k = k;
   a.w = w;
@@ -120,9 +138,7 @@ int minimizers_fused(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t l
   auto launch = [&](auto kernel) -> int {
     int per_cu = 1;
     NTCHK(blocks_per_cu(c, kernel, (int)p.waves * 64, p.lds, &per_cu));
-    uint64_t grid = (uint64_t)c->n_cu * per_cu;
-    const uint64_t need = (n_tiles + p.waves - 1) / p.waves;
-    if (grid > need) grid = need;
+    (void)per_cu;
     prof_begin(c, "minimizer_fused_kernel");
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(p.waves * 64), p.lds, c->stream, a);
     prof_end(c);
@@ -529,18 +545,16 @@ extern "C" int nthip_kmer_minimizers(nthip_ctx* c, const nthip_reads* rd, uint16
   if (!(flags & NTHIP_HOST_INPUT) && stride == len && c->tune.mz_fused != 2) {
     // one pass over the bases, nothing of the hash stream in HBM; a batch with a non-base comes back unhandled
     bool handled = false;
-    if (c->tune.mz_fused != 1) { // the record form: run length = w (4 ... 16), k <= 32
+    if (c->tune.mz_fused != 1) { // the record form: run length = w (4 ... 16), k <= 32; reads with non-bases included
       const int rcw = minimizers_w(c, (const uint8_t*)rd->seqs, n, len, k, w, d_min_hashes, d_min_pos, d_min_offsets, capacity, total_out,
                                    &handled);
       if (rcw != NTHIP_OK || handled) return rcw;
-    } else {
-      // NTHIP_TUNE_MZ_FUSED=1: the any-run-length form (w up to 7 x 16, k within the position tables).  Its look-back is per
-      // tile with the waves waiting, and at 14-20 ms per 20 M reads of 150 bp it is behind the round-3 kernels (12.3 ms):
-      // kept for the shapes' sake and as the cross-check of the record form, not a default
-      const int rc = minimizers_fused(c, (const uint8_t*)rd->seqs, n, len, k, w, d_min_hashes, d_min_pos, d_min_offsets, capacity, total_out,
-                                      &handled);
-      if (rc != NTHIP_OK || handled) return rc;
     }
+    // the any-run-length form (w up to 7 x 16, k within the position tables); a batch with a non-base comes back unhandled
+    // (NTHIP_TUNE_MZ_FUSED=1: this form on every shape it takes -- the cross-check of the record form)
+    const int rc = minimizers_fused(c, (const uint8_t*)rd->seqs, n, len, k, w, d_min_hashes, d_min_pos, d_min_offsets, capacity, total_out,
+                                    &handled);
+    if (rc != NTHIP_OK || handled) return rc;
   }
   // rounds of reads: the emitted stream of a round (hash 8, position 4 -- only written for a round that has a read with a
   // non-base --, flag 1 byte per k-mer; three 8-byte values per read) in the context's consumer scratch

@@ -15,19 +15,16 @@
 //     -- two LDS lookups (the prefix arg-min byte, then its hash) and two 64-bit compares per window, whatever w is;
 //     the middle blocks' minima (w > 2C) are two per-LANE values made once per tile;
 //   * a window picks a new minimizer where its arg-min differs from its left neighbour's; the picks of a tile are counted,
-//     placed by a decoupled look-back over the tiles, and written once: min_hashes, min_pos and min_offsets in their final
-//     places.  Tiles are dealt to the waves of the grid in rounds (tile = round * waves + wave): a tile's predecessors
-//     belong to this round or an earlier one, so they are published by waves that run -- as long as every block of the
-//     grid is resident, which the launcher sizes the grid for.  Should that ever fail (another spinning kernel of another
-//     process on the device), a wave that waits 50 ms raises a.abort, every wave leaves, and the caller repeats the batch
-//     on the round-3 path: the wait is bounded.  (A ticket per tile instead -- one device-scope atomic on one address per
-//     tile -- serialises at ~40 ns: 160 ms for the 4 M tiles of 20 M reads, measured.)
+//     parked in a small LDS stash and placed by the block-round look-back of block_rounds.hpp (one round later, nobody
+//     waits), and written once: min_hashes, min_pos and min_offsets in their final places.  (Until the stash this kernel
+//     looked back per TILE with the waves waiting: 14-20 ms per 20 M reads, of which the hashing and the sweeps were 9.)
 // A tile is R = floor(64 / rpr) WHOLE reads (rpr = ceil(nwin / C) blocks each; the window slots past nwin hold the largest
 // value), so no window crosses a wave.  A non-base anywhere sets a.dirty: the caller repeats the batch on the N-aware path.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
+#include "block_rounds.hpp"
 #include "kmer_runs_gen_kernel.hpp"
 
 namespace ntamd {
@@ -36,12 +33,6 @@ constexpr uint32_t MZF_ROWS = 65;     // 64 lanes + one slack row (what an inval
 constexpr uint32_t MZF_FULL = 72;     // per-block minima: 64 + the furthest middle block
 constexpr uint32_t MZF_MAX_MM = 7;    // rowdelta of a pick code: 3 bits above the 5-bit column
 constexpr int MZF_MAX_THREADS = 768;  // 12 waves per block: 170 registers a lane
-#ifndef MZF_LOOK
-#define MZF_LOOK 4u // predecessors a lane looks at per hop of the look-back
-#endif
-#ifndef MZF_ABL_NOLOOK
-#define MZF_ABL_NOLOOK 0 // ablation (wrong placement): no look-back at all
-#endif
 #ifndef MZF_ABL_NOWRITE
 #define MZF_ABL_NOWRITE 0 // ablation: the picks are not written
 #endif
@@ -53,7 +44,7 @@ struct MinimizerFusedArgs {
   const uint8_t* seqs;
   const uint4* init_tab;        // [4 NW][256] {f.lo, f.hi, r.lo, r.hi}
   uint32_t* dirty;              // set when a non-base is seen
-  unsigned long long* status;   // [n_tiles] look-back words, zeroed by the host
+  unsigned long long* status;   // [(n_rounds + 1) * blocks] look-back words of the block-rounds, zeroed by the host
   uint32_t* abort;              // zeroed by the host; set by a wave that waited too long for a predecessor
   uint64_t* out_hashes;
   uint32_t* out_pos;            // may be NULL
@@ -61,7 +52,7 @@ struct MinimizerFusedArgs {
   uint64_t* total;              // device: the number of picks (also when capacity is smaller)
   uint64_t capacity;
   uint64_t n_reads, total_bytes;
-  uint32_t n_tiles;
+  uint32_t n_tiles, n_rounds, stash_cap;
   uint32_t len, k, w, nwin, nwv; // nwv = nwin - w + 1 window starts
   uint32_t C, rpr, inv_rpr, R;   // run length (block), blocks per read, floor(65536 / rpr) + 1, reads per tile
   uint32_t m0, r;                // (w - 1) div C, (w - 1) mod C
@@ -97,13 +88,16 @@ __global__ __launch_bounds__(MZF_MAX_THREADS) void minimizer_fused_kernel(const 
   // LDS: first-window tables | pair table | per wave { H tile, block minima, prefix arg-min bytes, pick codes, bit stream }
   uint4* itab = (uint4*)lds_dyn;
   uint4* ptab = itab + ntab * 256u;
-  uint32_t* wave_base = (uint32_t*)(ptab + 16) + wave * a.per_wave_dwords;
+  uint32_t* ctrl = (uint32_t*)(ptab + 16); // (block_rounds.hpp)
+  uint32_t* wave_base = ctrl + BR_CTRL_DWORDS + wave * a.per_wave_dwords;
   uint64_t* H = (uint64_t*)wave_base;                       // [MZF_ROWS][pitch_h]
   uint64_t* fullh = H + MZF_ROWS * pitch_h;                 // [MZF_FULL]
   uint32_t* fullc = (uint32_t*)(fullh + MZF_FULL);          // [MZF_FULL]
   uint8_t* pmi = (uint8_t*)(fullc + MZF_FULL);              // [MZF_ROWS][pitch_b]
   uint8_t* pwt = pmi + MZF_ROWS * pitch_b;                  // [64][pitch_b]
-  uint32_t* bits = (uint32_t*)(pwt + 64u * pitch_b);
+  uint64_t* stash_h = (uint64_t*)(pmi + (((MZF_ROWS + 64u) * pitch_b + 7u) & ~7u)); // [stash_cap] a tile's picks, parked for a round
+  uint16_t* stash_p = (uint16_t*)(stash_h + a.stash_cap);   // [stash_cap] (stash_cap is even)
+  uint32_t* bits = (uint32_t*)(stash_p + a.stash_cap);
 
   for (uint32_t i = tid; i < ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
   if (tid < 16)
@@ -116,7 +110,10 @@ __global__ __launch_bounds__(MZF_MAX_THREADS) void minimizer_fused_kernel(const 
     fullh[i] = ~0ull;
     fullc[i] = 0;
   }
+  if (tid < BR_CTRL_DWORDS) ctrl[tid] = 0;
   __syncthreads(); // the only block-wide barrier
+  BlockRounds rounds;
+  rounds.init(ctrl, lane, wave, a.waves, a.n_rounds, a.status, a.abort, a.total, a.out_offsets + a.n_reads);
 
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -131,8 +128,31 @@ __global__ __launch_bounds__(MZF_MAX_THREADS) void minimizer_fused_kernel(const 
   uint32_t bad = 0;
 
   const uint32_t n_waves_total = gridDim.x * a.waves;
-  bool aborted = false;
-  for (uint32_t t = blockIdx.x * a.waves + wave; t < a.n_tiles && !aborted; t += n_waves_total) { // (n_tiles < 2^31)
+  // what is parked from the round before
+  bool have_prev = false;
+  uint32_t prev_rd = 0, prev_total = 0, prev_rel = 0;
+  uint64_t prev_read = 0;
+  bool prev_first = false;
+  auto flush_prev = [&]() {
+    lds_sync();
+    const uint64_t base = rounds.offset_of(prev_rd);
+    for (uint32_t i = lane; i < prev_total && !MZF_ABL_NOWRITE; i += 64u) {
+      const uint64_t o = base + i;
+      if (o < a.capacity) {
+        a.out_hashes[o] = stash_h[i];
+        if (a.out_pos) a.out_pos[o] = stash_p[i];
+      }
+    }
+    if (prev_first) a.out_offsets[prev_read] = base + prev_rel;
+    have_prev = false;
+  };
+  uint32_t t = blockIdx.x * a.waves + wave; // tile of round rd: (rd * blocks + block) * waves + wave (n_tiles < 2^31)
+  for (uint32_t rd = 0; rd <= a.n_rounds; ++rd, t += n_waves_total) { // (round n_rounds: nothing to hash, the round before is placed)
+    if (!(rd < a.n_rounds && t < a.n_tiles)) {
+      rounds.arrive_round(rd, 0u);
+      if (have_prev) flush_prev();
+      continue;
+    }
 
     // ---- stage the tile's slab as a 2-bit stream ----------------------------------------------------------------
     const uint64_t rf = (uint64_t)t * a.R;
@@ -360,101 +380,48 @@ __global__ __launch_bounds__(MZF_MAX_THREADS) void minimizer_fused_kernel(const 
     const uint32_t nv = live && a.nwv > first_w ? (a.nwv - first_w < C ? a.nwv - first_w : C) : 0u;
     uint32_t flags = ((chg & ~1u) | (same0 ? 0u : 1u)) & ((1u << nv) - 1u);
 
-    // ---- phase 3: place the tile's picks (decoupled look-back) and write them -------------------------------------
+    // ---- phase 3: count the tile's picks, arrive, place the tile before, park this one's --------------------------
     const uint32_t cnt = (uint32_t)__builtin_popcount(flags);
     const uint32_t incl = wave_incl_add32(cnt);
     const uint32_t tile_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if (lane == 0)
-      __hip_atomic_store(a.status + t, (t == 0 ? MZF_FLAG_P : MZF_FLAG_A) | (unsigned long long)tile_total, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t tile_excl = 0;
-    if (t != 0 && !MZF_ABL_NOLOOK) {
-      // every lane looks at MZF_LOOK predecessors per hop (lane + 64 j tiles back): the resolved front moves that many
-      // tiles per memory round trip
-      int64_t look = (int64_t)t - 1 - (int64_t)lane;
-      bool done = false;
-      while (!done) {
-        unsigned long long s[MZF_LOOK];
-        bool have[MZF_LOOK];
-#pragma unroll
-        for (uint32_t j = 0; j < MZF_LOOK; ++j) {
-          have[j] = look - 64 * (int64_t)j >= 0;
-          s[j] = 0;
-        }
-        uint64_t t_wait = 0;
-        for (uint32_t spins = 0;; ++spins) {
-          bool missing = false;
-#pragma unroll
-          for (uint32_t j = 0; j < MZF_LOOK; ++j) {
-            if (have[j] && s[j] == 0ull) s[j] = __hip_atomic_load(a.status + (look - 64 * (int64_t)j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          // (only what lies nearer than the nearest inclusive count has to be there)
-          uint32_t need = MZF_LOOK;
-#pragma unroll
-          for (uint32_t j = MZF_LOOK; j-- > 0;)
-            if (__ballot(have[j] && (s[j] & MZF_FLAG_P) != 0ull) != 0ull) need = j + 1u;
-#pragma unroll
-          for (uint32_t j = 0; j < MZF_LOOK; ++j)
-            if (j < need) missing = missing || (have[j] && s[j] == 0ull);
-          if (__ballot(missing) == 0ull) break;
-          __builtin_amdgcn_s_sleep(1);
-          if ((spins & 255u) == 255u) { // (rare: a predecessor's wave is late, or is not running at all)
-            const uint64_t now = __builtin_amdgcn_s_memrealtime(); // 100 MHz
-            if (t_wait == 0) t_wait = now;
-            const bool late = now - t_wait > 5000000ull; // 50 ms
-            if (late && lane == 0) __hip_atomic_store(a.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (late || __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-              aborted = true;
-              break;
-            }
-          }
-        }
-        if (aborted) break;
-#pragma unroll
-        for (uint32_t j = 0; j < MZF_LOOK; ++j) {
-          if (done) break;
-          const uint64_t pmask = __ballot(have[j] && (s[j] & MZF_FLAG_P) != 0ull);
-          // within a row of 64 the nearest predecessor is the lowest lane; one that is still missing lies behind a P
-          const uint64_t zmask = __ballot(have[j] && s[j] == 0ull);
-          uint32_t first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
-          if (zmask && (uint32_t)__builtin_ctzll(zmask) < first_p) { // (cannot happen: `need` covers it)
-            first_p = 64u;
-          }
-          // the tiles nearer than the first one that knows its inclusive count add their own counts
-          const uint32_t mine = have[j] && lane < first_p ? (uint32_t)(s[j] & MZF_VALUE) : 0u;
-          tile_excl += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_add32(mine), 63);
-          if (pmask) {
-            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)s[j], (int)first_p, 64);
-            const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(s[j] >> 32), (int)first_p, 64);
-            tile_excl += (((uint64_t)hi << 32) | lo) & MZF_VALUE;
-            done = true;
-          }
-        }
-        look -= 64 * (int64_t)MZF_LOOK;
-      }
-      if (lane == 0)
-        __hip_atomic_store(a.status + t, MZF_FLAG_P | (tile_excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rounds.arrive_round(rd, tile_total);
+    if (have_prev) flush_prev();
+    const bool park = tile_total <= a.stash_cap;
+    const bool first_block = live && q == 0u;
+    uint64_t base = 0;
+    if (!park) { // (reads of one repeated base: every window a new pick) this round's look-back now, the picks straight out
+      rounds.try_lead(rd);
+      base = rounds.offset_of(rd);
     }
-    if (aborted) break;
-    uint64_t o = tile_excl + (incl - cnt);
-    if (live && q == 0u) a.out_offsets[rf + lr] = o;
-    if (t == a.n_tiles - 1u && lane == 0) {
-      a.out_offsets[a.n_reads] = tile_excl + tile_total;
-      *a.total = tile_excl + tile_total;
-    }
-    while (!MZF_ABL_NOWRITE && __ballot(flags != 0u) != 0ull) {
+    uint32_t o = incl - cnt;
+    lds_sync();
+    while (__ballot(flags != 0u) != 0ull) {
       if (flags != 0u) {
         const uint32_t i = (uint32_t)__builtin_ctz(flags);
         flags &= flags - 1u;
         const uint32_t code = my_pw[i];
-        const uint32_t rd = code >> 5, col = code & 31u;
-        const uint64_t h = H[(lane + rd) * pitch_h + col];
-        if (o < a.capacity) {
-          a.out_hashes[o] = h;
-          if (a.out_pos) a.out_pos[o] = (q + rd) * C + col;
+        const uint32_t rdl = code >> 5, col = code & 31u;
+        const uint64_t h = H[(lane + rdl) * pitch_h + col];
+        const uint32_t pos = (q + rdl) * C + col;
+        if (park) {
+          stash_h[o] = h;
+          stash_p[o] = (uint16_t)pos;
+        } else if (base + o < a.capacity && !MZF_ABL_NOWRITE) {
+          a.out_hashes[base + o] = h;
+          if (a.out_pos) a.out_pos[base + o] = pos;
         }
         ++o;
       }
+    }
+    if (park) {
+      have_prev = true;
+      prev_rd = rd;
+      prev_total = tile_total;
+      prev_rel = incl - cnt;
+      prev_read = rf + lr;
+      prev_first = first_block;
+    } else if (first_block) {
+      a.out_offsets[rf + lr] = base + (incl - cnt);
     }
   }
   if (__ballot(bad != 0u) != 0ull && lane == 0) atomicOr(a.dirty, 1u);

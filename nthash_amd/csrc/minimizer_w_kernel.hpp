@@ -33,20 +33,17 @@
 
 #include <hip/hip_runtime.h>
 
+#include "block_rounds.hpp"
 #include "minimizer_fused_kernel.hpp"
 
 namespace ntamd {
 
 // waves per block: 16 while a lane's 4 C + ~60 registers fit 128, else 12
 constexpr uint32_t mzw_max_waves(int C) { return C <= 12 ? 16u : 12u; }
-#ifndef MZW_ABL_NOLEAD
-#define MZW_ABL_NOLEAD 0 // ablation (wrong placement): the leader does not look back
-#endif
 #ifndef MZW_ABL_NOFLUSH
 #define MZW_ABL_NOFLUSH 0 // ablation: the parked picks are not written
 #endif
-// arrive[2], tag[2], asum_tag[2], claim[2], bsum[2], pad[2], woff[2][16] (u64), agg[2][16], wrel[2][16]
-constexpr uint32_t MZW_CTRL_DWORDS = 12 + 2 * 2 * 16 + 2 * 16 + 2 * 16;
+constexpr uint32_t MZW_CTRL_DWORDS = BR_CTRL_DWORDS;
 
 struct MinimizerWArgs {
   const uint8_t* seqs;
@@ -85,14 +82,8 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
   uint4* itab = (uint4*)lds_dyn;
   uint4* ptab = itab + ntab * 256u;
   uint32_t* ctrl = (uint32_t*)(ptab + 16);
-  uint32_t* arrive = ctrl;                                   // [2] waves that finished the round's tile
-  volatile uint32_t* tag = ctrl + 2;                         // [2] round + 1 once the round's offsets are in woff
-  volatile uint32_t* asum_tag = ctrl + 4;                    // [2] round + 1 once the block's count of the round is in bsum / wrel
-  uint32_t* claim = ctrl + 6;                                // [2] round + 1 once a wave has taken the round's look-back
-  uint32_t* bsum = ctrl + 8;                                 // [2]
-  uint64_t* woff = (uint64_t*)(ctrl + 12);                   // [2][16]
-  uint32_t* agg = ctrl + 12 + 64;                            // [2][16]
-  uint32_t* wrel = agg + 32;                                 // [2][16]
+  BlockRounds rounds; // (block_rounds.hpp: where a tile's picks go, without a pass before and without a wave that waits)
+  rounds.init(ctrl, lane, wave, waves, a.n_rounds, a.status, a.abort, a.total, a.out_offsets + a.n_reads);
   uint32_t* wave_base = ctrl + MZW_CTRL_DWORDS + wave * a.per_wave_dwords;
   uint64_t* stash_h = (uint64_t*)wave_base;                  // [stash_cap]
   uint16_t* stash_p = (uint16_t*)(stash_h + a.stash_cap);    // [stash_cap]
@@ -124,11 +115,8 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
 
   // the picks of the parked tile, and its reads' offsets, to their final places
   auto flush_prev = [&]() {
-    const uint32_t pp = prev_rd & 1u;
     lds_sync(); // (the stash was written lane by lane)
-    while (tag[pp] != prev_rd + 1u) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    const uint64_t base = woff[pp * 16u + wave];
+    const uint64_t base = rounds.offset_of(prev_rd);
     for (uint32_t i = lane; i < prev_total && !MZW_ABL_NOFLUSH; i += 64u) {
       const uint64_t o = base + i;
       if (o < a.capacity) {
@@ -138,103 +126,6 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
     }
     if (prev_first) a.out_offsets[prev_read] = base + prev_rel;
     have_prev = false;
-  };
-
-  // the wave that arrives LAST at a round: the block's count of the round, published at once (the blocks behind need it)
-  auto sum_round = [&](uint32_t rd, uint32_t par) {
-    const uint32_t v = lane < waves ? agg[par * 16u + lane] : 0u;
-    const uint32_t incl = wave_incl_add32(v);
-    const uint32_t sum = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    const uint64_t br = (uint64_t)rd * gridDim.x + blockIdx.x;
-    if (lane == 0)
-      __hip_atomic_store(a.status + br, (br == 0 ? MZF_FLAG_P : MZF_FLAG_A) | (unsigned long long)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (lane < waves) wrel[par * 16u + lane] = incl - v;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    if (lane == 0) {
-      bsum[par] = sum;
-      arrive[par] = 0; // (next used two rounds on: a wave gets there only behind this round's offsets)
-      asum_tag[par] = rd + 1u;
-    }
-  };
-  // The look-back of round rd is nobody's critical path: the wave that arrives FIRST at round rd + 1 does it, a whole tile
-  // after every block published its count of round rd and the round before resolved -- one hop, nothing to wait for.  (A
-  // wave whose tile overflows the stash needs its offset in its own round and claims the job early.)
-  auto try_lead = [&](uint32_t rd) {
-    const uint32_t par = rd & 1u;
-    uint32_t before = 0;
-    if (lane == 0) before = __hip_atomic_fetch_max(claim + par, rd + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
-    if (before >= rd + 1u) return;
-    while (asum_tag[par] != rd + 1u) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    const uint32_t sum = bsum[par];
-    const uint64_t br = (uint64_t)rd * gridDim.x + blockIdx.x;
-    uint64_t excl = 0;
-    if (br != 0 && !MZW_ABL_NOLEAD) {
-      int64_t look = (int64_t)br - 1 - (int64_t)lane;
-      bool done = false, aborted = false;
-      while (!done && !aborted) {
-        unsigned long long s[4];
-        bool have[4];
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-          have[j] = look - 64 * (int64_t)j >= 0;
-          s[j] = 0;
-        }
-        uint64_t t_wait = 0;
-        for (uint32_t spins = 0;; ++spins) {
-#pragma unroll
-          for (uint32_t j = 0; j < 4; ++j)
-            if (have[j] && s[j] == 0ull) s[j] = __hip_atomic_load(a.status + (look - 64 * (int64_t)j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          // (only what lies nearer than the nearest inclusive count has to be there)
-          uint32_t need = 4;
-#pragma unroll
-          for (uint32_t j = 4; j-- > 0;)
-            if (__ballot(have[j] && (s[j] & MZF_FLAG_P) != 0ull) != 0ull) need = j + 1u;
-          bool missing = false;
-#pragma unroll
-          for (uint32_t j = 0; j < 4; ++j)
-            if (j < need) missing = missing || (have[j] && s[j] == 0ull);
-          if (__ballot(missing) == 0ull) break;
-          __builtin_amdgcn_s_sleep(8);
-          if ((spins & 63u) == 63u) { // (rare: a block is late, or is not running at all)
-            const uint64_t now = __builtin_amdgcn_s_memrealtime(); // 100 MHz
-            if (t_wait == 0) t_wait = now;
-            const bool late = now - t_wait > 5000000ull; // 50 ms
-            if (late && lane == 0) __hip_atomic_store(a.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (late || __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-              aborted = true; // (the offsets are garbage from here on; every store stays inside the caller's arrays)
-              break;
-            }
-          }
-        }
-        if (aborted) break;
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-          if (done) break;
-          const uint64_t pmask = __ballot(have[j] && (s[j] & MZF_FLAG_P) != 0ull);
-          const uint32_t first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
-          const uint32_t mine = have[j] && lane < first_p ? (uint32_t)(s[j] & MZF_VALUE) : 0u;
-          excl += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_add32(mine), 63);
-          if (pmask) {
-            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)s[j], (int)first_p, 64);
-            const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(s[j] >> 32), (int)first_p, 64);
-            excl += (((uint64_t)hi << 32) | lo) & MZF_VALUE;
-            done = true;
-          }
-        }
-        look -= 256;
-      }
-      if (lane == 0)
-        __hip_atomic_store(a.status + br, MZF_FLAG_P | (excl + sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (lane < waves) woff[par * 16u + lane] = excl + wrel[par * 16u + lane];
-    if (rd == a.n_rounds - 1u && blockIdx.x == gridDim.x - 1u && lane == 0) {
-      a.out_offsets[a.n_reads] = excl + sum;
-      *a.total = excl + sum;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    if (lane == 0) tag[par] = rd + 1u;
   };
 
   // geometry of a tile's slab
@@ -301,7 +192,6 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
   }
 
   for (uint32_t rd = 0; rd <= a.n_rounds; ++rd, t += t_step) { // (round n_rounds: nothing to hash, the round before is placed)
-    const uint32_t par = rd & 1u;
     const bool has = rd < a.n_rounds && t < a.n_tiles;
     uint32_t pick = 0, cnt = 0, incl = 0, tile_total = 0, q = 0, lr = 0;
     uint64_t rf = 0;
@@ -465,19 +355,8 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
       tile_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
 
-    // ---- arrive: the block's counts of this round ----------------------------------------------------------------
-    uint32_t old = 0;
-    if (lane == 0) {
-      agg[par * 16u + wave] = tile_total;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-      old = __hip_atomic_fetch_add(arrive + par, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
-    if (old == waves - 1u) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-      sum_round(rd, par);
-    }
-    if (old == 0u && rd != 0u) try_lead(rd - 1u);
+    // ---- arrive: the block's counts of this round; the round before is placed by the wave that gets here first -----
+    rounds.arrive_round(rd, tile_total);
     if (have_prev) flush_prev();
     if (has) {
       // ---- park the tile's picks (hash, position) in the stash, straight from the registers; a tile with more than
@@ -502,10 +381,8 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
         prev_read = rf + lr;
         prev_first = first_block;
       } else {
-        try_lead(rd);
-        while (tag[par] != rd + 1u) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-        const uint64_t base = woff[par * 16u + wave];
+        rounds.try_lead(rd);
+        const uint64_t base = rounds.offset_of(rd);
 #pragma unroll
         for (uint32_t c = 0; c < (uint32_t)C; ++c) {
           if (((pick >> c) & 1u) != 0u) {

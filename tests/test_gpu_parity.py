@@ -1376,7 +1376,7 @@ def test_minimizers_fused_one_pass(oracle, n, L, k, w, C):
     record_form = C == 0 and 4 <= w <= 16 and k <= 32 and w <= nwin and -(-nwin // w) <= 64
     if record_form:
         assert ctx.last_kernel_ms()[1] == "minimizer_w_kernel"
-    elif C:
+    elif w <= 100 and w <= nwin:    # (w beyond 7 blocks of 16 windows, or beyond the read: the round-3 kernels)
         assert ctx.last_kernel_ms()[1] == "minimizer_fused_kernel"
     assert got["total"] == len(exp_pos)
     assert (got["offsets"] == exp_off).all()
