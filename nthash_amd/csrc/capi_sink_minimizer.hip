@@ -63,7 +63,8 @@ bool minimizer_fused_plan(const nthip_ctx* c, uint32_t len, uint32_t k, uint32_t
   p->stash_cap = (scap + 3u) & ~3u;
   // (the byte arrays before the stash: (MZF_ROWS + 64) * pitch_b = 129 * 4 * odd bytes -- padded to 8 below)
   p->byte_dwords = (((MZF_ROWS + 64u) * p->pitch_b + 7u) & ~7u) / 4u;
-  p->per_wave_dwords = 2u * MZF_ROWS * p->pitch_h + 3u * MZF_FULL + p->byte_dwords + 2u * p->stash_cap + p->stash_cap / 2u + p->bits_dwords;
+  p->per_wave_dwords = 2u * MZF_ROWS * p->pitch_h + 3u * MZF_FULL + p->byte_dwords + 2u * p->stash_cap + p->stash_cap / 2u + p->bits_dwords +
+                       (p->bits_dwords + 8u + 1u) / 2u;
   p->per_wave_dwords = (p->per_wave_dwords + 3u) & ~3u;
   const size_t tables = (size_t)4 * nw * 256 * 16 + 256 + BR_CTRL_DWORDS * 4;
   const size_t cap = lds_cap_of(c);
@@ -76,8 +77,7 @@ bool minimizer_fused_plan(const nthip_ctx* c, uint32_t len, uint32_t k, uint32_t
   return true;
 }
 
-// *handled = false (and nothing written that the caller relies on) when the shape is outside the kernel or a read of the
-// batch holds a non-base
+// *handled = false (and nothing written that the caller relies on) when the shape is outside the kernel
 int minimizers_fused(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t len, uint32_t k, uint32_t w, uint64_t* d_min_hashes,
                      uint32_t* d_min_pos, uint64_t* d_min_offsets, uint64_t capacity, uint64_t* total_out, bool* handled)
 {
@@ -162,7 +162,7 @@ int minimizers_fused(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t l
   uint32_t td[2];
   memcpy(&total, c->h_small + 32, 8);
   memcpy(td, c->h_small + 40, 8);
-  if (td[1] != 0 || td[0] != 0) return NTHIP_OK; // a non-base somewhere (or the grid was not resident): the caller takes the N-aware path
+  if (td[0] != 0) return NTHIP_OK; // (the grid was not resident: the caller goes on with the round-3 kernels)
   *handled = true;
   if (total_out) *total_out = total;
   if (total > capacity)

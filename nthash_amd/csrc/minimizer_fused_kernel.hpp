@@ -18,8 +18,8 @@
 //     parked in a small LDS stash and placed by the block-round look-back of block_rounds.hpp (one round later, nobody
 //     waits), and written once: min_hashes, min_pos and min_offsets in their final places.  (Until the stash this kernel
 //     looked back per TILE with the waves waiting: 14-20 ms per 20 M reads, of which the hashing and the sweeps were 9.)
-// A tile is R = floor(64 / rpr) WHOLE reads (rpr = ceil(nwin / C) blocks each; the window slots past nwin hold the largest
-// value), so no window crosses a wave.  A non-base anywhere sets a.dirty: the caller repeats the batch on the N-aware path.
+// A tile is R = floor(64 / rpr) WHOLE reads (rpr = ceil(nwin / C) blocks each; the window slots past nwin hash whatever
+// follows and no valid window covers them), so no window crosses a wave.  N-aware: see the staging of a tile.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(MZF_MAX_THREADS) void minimizer_fused_kernel(const 
   uint64_t* stash_h = (uint64_t*)(pmi + (((MZF_ROWS + 64u) * pitch_b + 7u) & ~7u)); // [stash_cap] a tile's picks, parked for a round
   uint16_t* stash_p = (uint16_t*)(stash_h + a.stash_cap);   // [stash_cap] (stash_cap is even)
   uint32_t* bits = (uint32_t*)(stash_p + a.stash_cap);
+  uint16_t* vbits = (uint16_t*)(bits + a.bits_dwords);      // [bits_dwords + 8] validity bits of a slab that holds a non-base
 
   for (uint32_t i = tid; i < ntab * 256u; i += blockDim.x) itab[i] = a.init_tab[i];
   if (tid < 16)
@@ -190,13 +191,31 @@ __global__ __launch_bounds__(MZF_MAX_THREADS) void minimizer_fused_kernel(const 
       bits[i] = p;
     }
     for (uint32_t i = n_vec + lane; i < a.bits_dwords; i += 64u) bits[i] = 0; // the rolls of a last block read ahead
+    // N-aware (round 4, as minimizer_w_kernel.hpp): a k-mer that holds a non-base is no candidate (NtHash does not emit it:
+    // src/kmer.cpp:228-264) -- its hash becomes the largest value, a window of such k-mers only picks nothing.  A tile
+    // without a non-base (nearly all of them) pays one ballot.
+    const bool tile_dirty = __ballot(bad != 0u) != 0ull;
+    bad = 0;
+    if (tile_dirty) {
+      for (uint32_t i = lane; i < n_vec; i += 64u) { // (the slab comes from L2 this time)
+        const uint4 v = *(const uint4*)(a.seqs + byte0 + ((uint64_t)i << 4));
+        uint32_t i0, i1, i2, i3;
+        (void)pack4v(v.x, i0);
+        (void)pack4v(v.y, i1);
+        (void)pack4v(v.z, i2);
+        (void)pack4v(v.w, i3);
+        vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+      }
+      for (uint32_t i = n_vec + lane; i < a.bits_dwords + 8u; i += 64u) vbits[i] = 0;
+    }
     lds_sync();
 
     // ---- phase 1: hash the run, prefix arg-min on the way ---------------------------------------------------------
     const bool live = lr_raw < reads_here;
     const uint32_t lr = live ? lr_raw : 0u, q = live ? q_raw : 0u; // (idle lanes redo the tile's first run)
     const uint32_t b0 = shift + lr * a.len + q * C;
-    const uint32_t n_real = live ? (a.nwin > q * C ? a.nwin - q * C : 0u) : 0u; // window slots of the run that are windows
+    // (window slots past the read's last window hash whatever follows: no valid window ever covers them)
+    const uint32_t inval = tile_dirty ? windows_with_non_base((const uint32_t*)vbits, b0, k) : 0u; // bit j: k-mer j of the run holds a non-base
     uint64_t* const my_row = H + lane * pitch_h;
     uint8_t* const my_pm = pmi + lane * pitch_b;
     uint8_t* const my_pw = pwt + lane * pitch_b;
@@ -228,7 +247,7 @@ __global__ __launch_bounds__(MZF_MAX_THREADS) void minimizer_fused_kernel(const 
     }
     auto emit = [&](uint32_t j) {
       uint64_t h = canon_pair(f_lo, f_hi, r_lo, r_hi);
-      h = j < n_real ? h : ~0ull;
+      h = ((inval >> j) & 1u) ? ~0ull : h;
       my_row[j] = h;
       const bool lt = h < ph; // strict: the leftmost of equal hashes stays
       ph = lt ? h : ph;
@@ -380,6 +399,16 @@ __global__ __launch_bounds__(MZF_MAX_THREADS) void minimizer_fused_kernel(const 
     const uint32_t nv = live && a.nwv > first_w ? (a.nwv - first_w < C ? a.nwv - first_w : C) : 0u;
     uint32_t flags = ((chg & ~1u) | (same0 ? 0u : 1u)) & ((1u << nv) - 1u);
 
+    if (tile_dirty) { // a window whose every k-mer holds a non-base picked one of them: that pick is none
+      lds_sync();
+      uint32_t f = flags;
+      while (f != 0u) {
+        const uint32_t i = (uint32_t)__builtin_ctz(f);
+        f &= f - 1u;
+        const uint32_t code = my_pw[i];
+        if (H[(lane + (code >> 5)) * pitch_h + (code & 31u)] == ~0ull) flags &= ~(1u << i);
+      }
+    }
     // ---- phase 3: count the tile's picks, arrive, place the tile before, park this one's --------------------------
     const uint32_t cnt = (uint32_t)__builtin_popcount(flags);
     const uint32_t incl = wave_incl_add32(cnt);
@@ -424,7 +453,6 @@ __global__ __launch_bounds__(MZF_MAX_THREADS) void minimizer_fused_kernel(const 
       a.out_offsets[rf + lr] = base + (incl - cnt);
     }
   }
-  if (__ballot(bad != 0u) != 0ull && lane == 0) atomicOr(a.dirty, 1u);
 }
 
 } // namespace ntamd
