@@ -285,6 +285,8 @@ void load_tuning(nthip_tune& t)
   t.ph_read = num("NTHIP_TUNE_PH_READ", 1, 10000000);
   t.fw = num("NTHIP_TUNE_FW", 1, 2);
   t.seed_any = num("NTHIP_TUNE_SEED_ANY", 1, 2);
+  t.seed_roll = num("NTHIP_TUNE_SEED_ROLL", 1, 2);
+  t.seed_roll_waves = num("NTHIP_TUNE_SEED_ROLL_WAVES", 2, 8);
   t.bloom_binned = num("NTHIP_TUNE_BLOOM_BINNED", 1, 2);
   t.bloom_round = num("NTHIP_TUNE_BLOOM_ROUND", 1024, 0x7FFFFFFF);
   t.pf_gbps = num("NTHIP_TUNE_PF_GBPS", 1, 100000);

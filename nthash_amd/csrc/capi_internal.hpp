@@ -111,6 +111,8 @@ struct nthip_tune {
   uint32_t bloom_round = 0;  // NTHIP_TUNE_BLOOM_ROUND=<values>: rounds of the binned consumers no longer than this (tests: several rounds on a small batch)
   uint32_t bloom_fused = 0;  // NTHIP_TUNE_BLOOM_FUSED=1: the stream-less binned insert on every shape it can take, 2: never (A/B, tests)
   uint32_t bloom_binned = 0; // NTHIP_TUNE_BLOOM_BINNED=1: the binned insert whenever the filter allows it, 2: never (A/B, tests)
+  uint32_t seed_roll_waves = 0; // NTHIP_TUNE_SEED_ROLL_WAVES=2..8: waves per block of seed_roll_kernel (A/B)
+  uint32_t seed_roll = 0;   // NTHIP_TUNE_SEED_ROLL=1: every dense seed batch the block-rolling kernel takes goes there, 2: none (A/B, tests)
   uint32_t seed_any = 0;    // NTHIP_TUNE_SEED_ANY=1: dense seed batches on the any-seed form whatever the seed set, 2: none of k <= 128 (A/B, tests)
   uint32_t fw = 0;          // NTHIP_TUNE_FW: first window beyond the position tables -- 1 grouped, 2 prefix scan (0: cost model)
 };
@@ -200,6 +202,10 @@ struct nthip_seeds {
   std::vector<uint8_t> h_blk_parity, h_is_mono;
   uint32_t* d_ext_mask = nullptr;
   uint4* d_ext_acorr = nullptr;
+  // rolling run by run (seed_roll_kernel.hpp): every seed as the XOR of its care runs [a, b), each with a 16-entry (in, out)
+  // pair table; roll_terms == 0: more runs than the kernel takes.  roll_in = b, roll_out = a.
+  uint32_t roll_terms = 0, roll_first[65] = {}, roll_in[64] = {}, roll_out[64] = {};
+  uint4* d_roll_tabs = nullptr;
 };
 
 namespace ntamd {

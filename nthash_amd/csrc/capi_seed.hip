@@ -3,6 +3,7 @@
 #include "capi_internal.hpp"
 #include "seed_long_kernels.hpp"
 #include "seed_kernels.hpp"
+#include "seed_roll_kernel.hpp"
 #include "kmer_reads_kernel.hpp" // the mark pass (reads with a non-base) is shared with the k-mer path
 #include "seed_parse.hpp"
 #include "util_kernels.hpp"
@@ -67,6 +68,40 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
       any_mask[(size_t)s * G + g] = mask;
       any_acorr[(size_t)s * G + g] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
     }
+  // block rolling: the care runs of every seed and their pair tables
+  std::vector<uint4> roll_tabs;
+  uint32_t roll_terms = 0, roll_first[SR_MAX_RUNS + 1] = {}, roll_in[SR_MAX_RUNS] = {}, roll_out[SR_MAX_RUNS] = {};
+  if (n_seeds <= 8) {
+    bool ok = true;
+    for (uint32_t s = 0; s < n_seeds && ok; ++s) {
+      auto is_care = [&](uint32_t p) { return ((care[(size_t)s * cw + (p >> 5)] >> (p & 31)) & 1u) != 0; };
+      std::vector<uint32_t> terms; // the care runs as [a, b) pairs (runs alternate, so the description by gaps -- the whole
+      for (uint32_t p = 0; p < k;) { // window XOR its don't-care runs -- never has fewer terms)
+        uint32_t q = p;
+        while (q < k && is_care(q) == is_care(p)) ++q;
+        if (is_care(p)) {
+          terms.push_back(p);
+          terms.push_back(q);
+        }
+        p = q;
+      }
+      if (roll_terms + terms.size() / 2 > SR_MAX_RUNS) { ok = false; break; }
+      for (size_t t = 0; t < terms.size(); t += 2) {
+        const uint32_t a = terms[t], b = terms[t + 1];
+        roll_in[roll_terms] = b;
+        roll_out[roll_terms] = a;
+        for (uint32_t e = 0; e < 16; ++e) {
+          const uint32_t in = e >> 2, out = e & 3u;
+          const uint64_t f = srol_n(seed_of_code(in), k - b) ^ srol_n(seed_of_code(out), k - a);
+          const uint64_t r = srol_n(seed_of_code(in ^ 2u), b) ^ srol_n(seed_of_code(out ^ 2u), a);
+          roll_tabs.push_back(make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32)));
+        }
+        ++roll_terms;
+      }
+      roll_first[s + 1] = roll_terms;
+    }
+    if (!ok) roll_terms = 0;
+  }
   nthip_seeds* sd = new nthip_seeds();
   sd->ctx = c;
   sd->device = c->device;
@@ -83,6 +118,13 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
     return NTHIP_OK;
   };
   int rc = up(tables.data(), tables.size() * sizeof(uint4), (void**)&sd->d_tables);
+  if (rc == NTHIP_OK && roll_terms) {
+    rc = up(roll_tabs.data(), roll_tabs.size() * sizeof(uint4), (void**)&sd->d_roll_tabs);
+    sd->roll_terms = roll_terms;
+    memcpy(sd->roll_first, roll_first, sizeof roll_first);
+    memcpy(sd->roll_in, roll_in, sizeof roll_in);
+    memcpy(sd->roll_out, roll_out, sizeof roll_out);
+  }
   if (rc == NTHIP_OK) rc = up(care.data(), care.size() * 4, (void**)&sd->d_care);
   if (rc == NTHIP_OK) rc = up(blk_start.data(), blk_start.size() * 4, (void**)&sd->d_blk_start);
   if (rc == NTHIP_OK) rc = up(blk_count.data(), blk_count.size() * 4, (void**)&sd->d_blk_count);
@@ -112,6 +154,7 @@ extern "C" int nthip_seeds_destroy(nthip_seeds* sd)
   if (sd->d_any_acorr) (void)hipFree(sd->d_any_acorr);
   if (sd->d_ext_mask) (void)hipFree(sd->d_ext_mask);
   if (sd->d_ext_acorr) (void)hipFree(sd->d_ext_acorr);
+  if (sd->d_roll_tabs) (void)hipFree(sd->d_roll_tabs);
   delete sd;
   return NTHIP_OK;
 }
@@ -793,6 +836,91 @@ int launch_seed_any(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd,
   return NTHIP_OK;
 }
 
+// Seeds rolled run by run (seed_roll_kernel.hpp).  The cost model, per window in units of one run's roll (fitted to
+// tools/seed_roll_sweep.py, profiles/r04_seed_roll_sweep.txt): rolling pays 114 + 6.7 per 16 bases of k once per segment and
+// seed (the any-seed first window, the tile's bases and bookkeeping), 3.3 per seed and window, 1 per run, 5 per hash after a
+// seed's first, and 30 % on top when a window has several values (the stage takes the place of waves); the position-table
+// form pays 1.34 per byte table and seed, the any-seed form 6.2 per 16 bases.  *ran = false: not this kernel's shape, or
+// the direct form is the cheaper one.
+int launch_seed_roll(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, bool* ran)
+{
+  *ran = false;
+  const uint32_t per = f.n_seeds * f.m2;
+  if (!sd->roll_terms || c->tune.seed_roll == 2 || c->tune.seed_any == 1 || per > 8 || f.stride != f.len) return NTHIP_OK;
+  const uint32_t SW = per <= 2 ? 16u : per <= 4 ? 8u : 4u;
+  const uint32_t segs = (f.nwin + SW - 1) / SW, G = sd->any_groups;
+  if (c->tune.seed_roll != 1) {
+    const double sw_eff = (double)f.nwin / segs, extra = per - f.n_seeds;
+    const double roll = (f.n_seeds * ((114.0 + 6.7 * G) / sw_eff + 3.3) + sd->roll_terms + 5.0 * extra) * (per > 1 ? 1.3 : 1.0);
+    const uint32_t tables = f.k <= 64 ? 2 * ((f.k + 7) / 8) : 4 * ((f.k + 15) / 16);
+    const double direct = (f.k <= 128 ? 1.34 * tables : 6.2 * G) * f.n_seeds + 4.5 * extra;
+    if (roll >= direct) return NTHIP_OK;
+  }
+  const uint64_t slab_max = 64ull * SW + (uint64_t)(63u / segs + 2u) * (f.k - 1u) + 16u;
+  const uint64_t n_vec_max = ((slab_max + 15) >> 4) + 1;
+  if (n_vec_max + 2 > SR_VEC_ROUNDS * 64ull) return NTHIP_OK;
+  const uint32_t bits_dwords = (uint32_t)((n_vec_max + 4 + 3) & ~3ull);
+  const uint32_t stage_vals = (64u * SW * per + 16u + 511u) & ~511u;
+  const size_t per_wave = (size_t)stage_vals * 8 + (size_t)bits_dwords * 8;
+  const uint32_t n_grp = f.n_seeds * G;
+  const size_t fixed = (((size_t)SA_TAB_ENTRIES + n_grp + ((n_grp + 3) >> 2) + 15) & ~(size_t)15) * sizeof(uint4) +
+                       (size_t)sd->roll_terms * 256;
+  const size_t cap = lds_cap_of(c);
+  if (fixed + 2 * per_wave > cap) return NTHIP_OK;
+  uint32_t waves = (uint32_t)((cap - fixed) / per_wave);
+  if (waves > SR_MAX_WAVES) waves = SR_MAX_WAVES;
+  if (c->tune.seed_roll_waves && c->tune.seed_roll_waves < waves) waves = c->tune.seed_roll_waves;
+  const uint4* fw = nullptr;
+  NTCHK(get_fw_tab(c, &fw));
+  SeedRollArgs a;
+  memset(&a, 0, sizeof a);
+  a.seqs = f.seqs;
+  a.hashes = f.hashes;
+  a.dirty = f.dirty;
+  a.pair_tabs = sd->d_roll_tabs;
+  a.fw_tabs = fw;
+  a.any_mask = sd->d_any_mask;
+  a.any_acorr = sd->d_any_acorr;
+  a.n_items = f.n_runs * segs;
+  a.n_tiles = (a.n_items + 63) / 64;
+  a.len = f.len;
+  a.k = f.k;
+  a.m2 = f.m2;
+  a.n_seeds = f.n_seeds;
+  a.nwin = f.nwin;
+  a.any_groups = G;
+  a.segs = segs;
+  a.inv_segs = (uint32_t)((1ull << 32) / segs + 1);
+  a.n_runs = sd->roll_terms;
+  a.waves = waves;
+  a.bits_dwords = bits_dwords;
+  a.stage_vals = stage_vals;
+  memcpy(a.seed_first, sd->roll_first, sizeof a.seed_first);
+  memcpy(a.run_end, sd->roll_in, sizeof a.run_end);
+  memcpy(a.run_first, sd->roll_out, sizeof a.run_first);
+  for (uint32_t i = 0; i < (uint32_t)SF_MAX_RUNTIME_M; ++i) a.mult[i] = multiplier(f.k, i);
+  const size_t lds = fixed + per_wave * waves;
+  const uint64_t need = (a.n_tiles + waves - 1) / waves;
+  uint64_t grid = (uint64_t)c->n_cu; // (one block per CU: the tables alone are 64 KiB)
+  if (grid > need) grid = need;
+  a.total_bytes = f.n_runs * (uint64_t)f.len;
+  a.step_reads = (64ull * grid * waves) / segs;
+  a.step_segs = (uint32_t)((64ull * grid * waves) % segs);
+  auto go = [&](auto kernel) -> int {
+    NTCHK(set_max_lds(c, kernel, lds));
+    prof_begin(c, "seed_roll_kernel");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream, a);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    return NTHIP_OK;
+  };
+  if (SW == 16) NTCHK(go(seed_roll_kernel<16>));
+  else if (SW == 8) NTCHK(go(seed_roll_kernel<8>));
+  else NTCHK(go(seed_roll_kernel<4>));
+  *ran = true;
+  return NTHIP_OK;
+}
+
 template <typename K>
 int launch_seed_fixed(nthip_ctx* c, K kernel, const SeedFixedArgs& a, size_t dyn_lds)
 {
@@ -1052,7 +1180,8 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
       // NTHIP_TUNE_SEED_ANY=1 sends every dense batch there, =2 none of k <= 128 (A/B, tests)
       bool wtile_ran = false;
       bool prefer_any = false;
-      if (k > 128 || c->tune.seed_any == 1) NTCHK(launch_seed_any(c, a, sd, &wtile_ran));
+      NTCHK(launch_seed_roll(c, a, sd, &wtile_ran)); // (seeds of few runs: rolled, whatever k)
+      if (!wtile_ran && (k > 128 || c->tune.seed_any == 1)) NTCHK(launch_seed_any(c, a, sd, &wtile_ran));
       if (!wtile_ran && k <= 128)
         NTCHK(launch_seed_wtile(c, a, sd, nh, &wtile_ran, c->tune.seed_any == 2 ? nullptr : &prefer_any));
       if (!wtile_ran && prefer_any) { // (a seed set of several position-table passes)

@@ -343,8 +343,8 @@ __device__ __forceinline__ void sa_load(uint4* tabs, const uint4* fw, const uint
     g_mask[i] = mask[i];
   }
 }
-// canonical hash of the window that starts at stream position (d, sh) under seed s
-__device__ __forceinline__ uint64_t sa_hash(const uint4* tabs, const uint4* g_acorr, const uint32_t* g_mask, const uint32_t* bits,
+// strand hashes {F lo, hi, R lo, hi} of the window that starts at stream position (d, sh) under seed s
+__device__ __forceinline__ uint4 sa_strands(const uint4* tabs, const uint4* g_acorr, const uint32_t* g_mask, const uint32_t* bits,
                                             uint32_t d, uint32_t sh, uint32_t s, uint32_t G, uint32_t k31, uint32_t k33)
 {
   uint4 acc = make_uint4(0, 0, 0, 0);
@@ -365,7 +365,14 @@ __device__ __forceinline__ uint64_t sa_hash(const uint4* tabs, const uint4* g_ac
     acc.x ^= x.x; acc.y ^= x.y; acc.z ^= x.z; acc.w ^= x.w;
   }
   srol_var(acc.x, acc.y, k31, k33);
-  return canon_pair(acc.x, acc.y, acc.z, acc.w);
+  return acc;
+}
+// its canonical hash
+__device__ __forceinline__ uint64_t sa_hash(const uint4* tabs, const uint4* g_acorr, const uint32_t* g_mask, const uint32_t* bits,
+                                            uint32_t d, uint32_t sh, uint32_t s, uint32_t G, uint32_t k31, uint32_t k33)
+{
+  const uint4 st = sa_strands(tabs, g_acorr, g_mask, bits, d, sh, s, G, k31, k33);
+  return canon_pair(st.x, st.y, st.z, st.w);
 }
 
 struct SeedWtileArgs {

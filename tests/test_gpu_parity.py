@@ -2560,6 +2560,82 @@ def test_kmer_packed_input_refusals(ctx, oracle):
         ctx.free(d_pk)
 
 
+def test_seed_rolled_run_by_run_vs_oracle(oracle):
+    """seed_roll_kernel: seeds are rolled the way the reference rolls them (NTMSM64, src/seed.cpp:177-207) -- one base in
+    and one out per care run and window, a lane per segment of 16 / 8 / 4 windows whose first one is hashed directly --
+    instead of ceil(k / 4) lookups per window: long seeds of a few solid
+    blocks, k beyond 128, two seeds, several hashes per seed, monomers, a seed that starts and ends with don't-cares, reads
+    that are not a multiple of 16 long, fewer segments than a tile, reads longer than a tile, six seeds, strided reads
+    (not this kernel's).  Forced with NTHIP_TUNE_SEED_ROLL=1 so that the cost model cannot hide a shape; a batch
+    with an N falls back to the kernels that know the position state machine"""
+    import os
+    import nthash_amd
+    rng = np.random.default_rng(23)
+    os.environ["NTHIP_TUNE_SEED_ROLL"] = "1"
+    try:
+        c = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_SEED_ROLL", None)
+
+    def blocky(k, gaps):  # care everywhere but in the gaps [(start, length)]
+        s = np.ones(k, dtype=bool)
+        for a, n in gaps:
+            s[a:a + n] = False
+        return "".join("1" if b else "0" for b in s)
+
+    cases = [  # (seeds, m2, L, n_reads)
+        ([blocky(128, [(40, 48)])], 1, 250, 700),
+        ([blocky(160, [(30, 20), (110, 20)])], 1, 300, 600),
+        ([blocky(128, [(20, 5), (60, 8), (100, 9)]), blocky(128, [(64, 1)])], 2, 251, 515),
+        ([blocky(64, [(10, 44)])], 3, 150, 1000),
+        ([blocky(31, [(0, 3), (15, 1), (28, 3)])], 1, 100, 300),   # don't-cares at both ends, a gap of one
+        ([blocky(48, [(5, 1), (7, 1), (9, 30), (41, 1), (43, 1)])], 2, 97, 129),  # monomers at 6, 8, 40, 42
+        ([blocky(200, [(50, 100)]), blocky(200, [(10, 180)])], 1, 1000, 70),
+        (["1" * 40], 1, 77, 2000),                                # no gap at all: a k-mer
+        ([blocky(24, [(8, 8)])], 8, 24, 400),                      # one window per read
+        ([blocky(40, [(10, 5)])], 1, 3000, 9),                     # a read is several tiles of segments
+        ([blocky(31, [(3 + i, 2), (20, 4)]) for i in range(6)], 1, 150, 300),  # six seeds: segments of 4 windows
+        ([blocky(64, [(20, 10)]), blocky(64, [(5, 5), (50, 3)]), blocky(64, [(31, 2)])], 1, 200, 257),  # three: 8 windows
+        (["".join("10"[i & 1] for i in range(63)) + "1"], 1, 150, 200),  # 32 monomers
+    ]
+    for seeds, m2, L, n in cases:
+        k = len(seeds[0])
+        data = oracle.synth_reads(29, n, L, k + len(seeds))
+        offs = np.arange(n + 1, dtype=np.uint64) * L
+        want = oracle.seed_batch(data, offs, seeds, k, m2, want_pos=False)
+        c.set_profiling(True)
+        got = c.seed_hash(data, seeds, k, m2, fixed_len=L, n_reads=n)
+        name = c.last_kernel_ms()[1]
+        c.set_profiling(False)
+        assert name == "seed_roll_kernel", (name, k, seeds)
+        assert got["total"] == want["total"] == n * (L - k + 1)
+        assert (got["hashes"] == want["hashes"]).all(), (k, seeds, m2)
+        dirty = data.copy()
+        dirty[rng.choice(n * L, 3, replace=False)] = ord("N")
+        want = oracle.seed_batch(dirty, offs, seeds, k, m2)
+        got = c.seed_hash(dirty, seeds, k, m2, fixed_len=L, n_reads=n, want_pos=True)
+        assert got["total"] == want["total"]
+        for key in ("counts", "pos", "hashes"):
+            assert (got[key] == want[key]).all(), (key, k, seeds)
+    # strided reads (overlapping windows of one long sequence)
+    seeds = [blocky(96, [(32, 32)])]
+    L, stride, n = 200, 50, 333
+    data = oracle.synth_reads(31, 1, stride * (n - 1) + L, 5)
+    rows = np.concatenate([data[i * stride:i * stride + L] for i in range(n)])
+    want = oracle.seed_batch(rows, np.arange(n + 1, dtype=np.uint64) * L, seeds, 96, 2, want_pos=False)
+    got = c.seed_hash(data, seeds, 96, 2, fixed_len=L, n_reads=n, stride=stride)
+    assert (got["hashes"] == want["hashes"]).all()
+    # a seed set outside the kernel (more runs than it takes) is not sent there even when forced
+    many = ["".join("10"[i & 1] for i in range(63)) + "1"] * 3
+    data = oracle.synth_reads(33, 200, 150, 3)
+    want = oracle.seed_batch(data, np.arange(201, dtype=np.uint64) * 150, many, 64, 1, want_pos=False)
+    c.set_profiling(True)
+    got = c.seed_hash(data, many, 64, 1, fixed_len=150, n_reads=200)
+    assert c.last_kernel_ms()[1] != "seed_roll_kernel"
+    c.set_profiling(False)
+    assert (got["hashes"] == want["hashes"]).all()
+
+
 @pytest.mark.parametrize("forced", [False, True])
 def test_seed_any_form_vs_oracle(oracle, forced):
     """seed_wtile_kernel<0>: any seed set of any k in ONE pass from the k-independent tables (care positions as a mask per
@@ -2571,10 +2647,12 @@ def test_seed_any_form_vs_oracle(oracle, forced):
     rng = np.random.default_rng(17 + forced)
     if forced:
         os.environ["NTHIP_TUNE_SEED_ANY"] = "1"
+    os.environ["NTHIP_TUNE_SEED_ROLL"] = "2"  # (seeds beyond 128 bases of up to 64 runs may be rolled: not this test's form)
     try:
         c = nthash_amd.Context(0)
     finally:
         os.environ.pop("NTHIP_TUNE_SEED_ANY", None)
+        os.environ.pop("NTHIP_TUNE_SEED_ROLL", None)
 
     def rand_seed(k, sym=True):
         half = rng.random((k + 1) // 2) < 0.7
