@@ -68,7 +68,8 @@ CONFIGS = {
                            "one-pass read-slots output (NTHIP_OUT_READ_SLOTS)",
                       L=150, lmin=100, k=31, m=1, seeds=None, reads=20_000_000, slots=True, checksum_as="var"),
     # fixed-length reads as a sequencer writes them: config 2's shape with an N in one read of ~1000 (the rule of "var" with
-    # one length).  Compact stream: the optimistic dense pass gives up at the first N, then count -> scan -> hash;
+    # one length).  Compact stream: the optimistic dense pass gives up at the first N, then count -> scan -> hash (the next
+    # batch of the shape starts at the count pass: the context remembers);
     # read slots: ONE dense pass that marks the vectors holding a non-base, the reads they touch redone in their slots
     "c2_dirty": dict(desc="NtHash k=31, 1 hash/k-mer, 20M x 150bp fixed-length reads, an N in 1 read of ~1000 (compact stream)",
                      L=150, lmin=150, k=31, m=1, seeds=None, reads=20_000_000, fixed=True),
@@ -911,8 +912,9 @@ def main():
                         sec[name]["note"] = ("value = whole call (survey of the spans, mark pass, scan, hash pass, reads "
                                              "with an N); kernel / frac = the hash pass alone")
                     if name == "c2_dirty":
-                        sec[name]["note"] = ("value = whole call (the dense pass that gives up at the first N, count pass, scan, "
-                                             "N-aware hash pass); kernel / frac = the hash pass alone")
+                        sec[name]["note"] = ("value = whole call (count pass, scan, N-aware hash pass; the context remembers from "
+                                             "the warm-up batch that this shape had non-bases and skips the dense pass that would "
+                                             "give up at the first N); kernel / frac = the hash pass alone")
                     if name == "c2_dirty_slots":
                         sec[name]["note"] = ("value = whole call (the dense pass marking the vectors with a non-base, the list of "
                                              "the reads they touch, those reads redone in their slots); k-mers counted = slots "

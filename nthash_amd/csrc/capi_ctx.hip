@@ -258,6 +258,8 @@ void load_tuning(nthip_tune& t)
   t.no_dword_tail = is_one("NTHIP_TUNE_NO_DWORD_TAIL");
   t.no_m4 = is_set("NTHIP_TUNE_NO_M4");
   t.no_autotune = is_set("NTHIP_TUNE_NO_AUTOTUNE");
+  t.no_dirty_memory = is_set("NTHIP_TUNE_NO_DIRTY_MEMORY");
+  t.no_na_special = is_set("NTHIP_TUNE_NO_NA_SPECIAL");
   t.no_seed_wave = is_set("NTHIP_TUNE_NO_SEED_WAVE");
   t.no_seed_wtile = is_one("NTHIP_TUNE_NO_SEED_WTILE");
   t.no_seed_rot = is_one("NTHIP_TUNE_NO_SEED_ROT");

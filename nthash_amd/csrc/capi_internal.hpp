@@ -35,6 +35,7 @@
 #include <chrono>
 #include <functional>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -82,6 +83,8 @@ struct nthip_tune {
   bool no_dword_tail = false; // NTHIP_TUNE_NO_DWORD_TAIL=1
   bool no_m4 = false;       // NTHIP_TUNE_NO_M4 (set): runtime-m instantiation for m = 4
   bool no_autotune = false; // NTHIP_TUNE_NO_AUTOTUNE (set)
+  bool no_na_special = false;   // NTHIP_TUNE_NO_NA_SPECIAL (set): batches with non-bases keep the general N-aware kernel for every tile
+  bool no_dirty_memory = false; // NTHIP_TUNE_NO_DIRTY_MEMORY (set): every batch tries the dense pass first
   bool no_seed_wave = false; // NTHIP_TUNE_NO_SEED_WAVE (set)
   bool no_seed_wtile = false; // NTHIP_TUNE_NO_SEED_WTILE=1: the block-tile dense seed kernel instead of the wave-tile one
   bool mz_table = false;      // NTHIP_TUNE_MZ_TABLE=1: minimizers of clean short reads through the LDS tables too (A/B)
@@ -159,6 +162,9 @@ struct nthip_ctx {
   // run length of the general dense kernel per (len, stride, k, m), measured on the first big batch of that shape
   // (the cost model does not see what a longer run costs in waves per CU or LDS conflicts: +-10 % either way)
   std::map<std::array<uint32_t, 4>, uint32_t> run_len_cache;
+  // shapes whose last fixed-length batch held a non-base: the next batch of the shape starts on the N-aware passes (the
+  // dense pass would only find out the same again); a batch that loses no window takes the shape off the list
+  std::set<std::array<uint32_t, 4>> dirty_shapes;
   // staging arena of the NTHIP_HOST_INPUT / NTHIP_HOST_OUTPUT calls: small host-buffer calls (the C++ facade makes
   // one per object) carve their device copies out of it instead of paying five hipMalloc / hipFree pairs each.
   // Grow-only up to STAGE_ARENA_MAX; calls that need more allocate as before.
@@ -375,6 +381,12 @@ int launch_kmer_gen_dense(nthip_ctx* c, const KmerRunsGenArgs& ga, size_t lds, u
 // invalid != nullptr: packed input (st.seqs = the code stream, invalid = its validity stream)
 int run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m, const NaPlan& plan,
                 const KmerFixedArgs& consts, uint64_t capacity, uint64_t* total, const uint16_t* invalid = nullptr);
+// the same contract with the clean tiles on the specialised kernel (kmer_runs_kernel's burst path writing the compact
+// stream at the count pass's offsets), the tiles that lost a window on the N-aware kernel from a list.  ra: the dense
+// launch's arguments for the shape.  *handled = false: not a shape of that path, nothing done
+int run_kmer_na_special(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m, const RunsPlan& plan,
+                        const KmerRunsArgs& ra, bool dt, const KmerFixedArgs& consts, uint64_t capacity, uint64_t* total,
+                        bool* handled);
 // capi_packed.hip: nthip_kmer_hash with NTHIP_PACKED_INPUT (st: the staged outputs)
 int run_kmer_packed(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t m, const nthip_out* out, const Staged& st,
                     uint32_t flags, uint64_t* total);
@@ -447,7 +459,7 @@ int launch_kmer_runs_gen(nthip_ctx* c, K kernel, KmerRunsGenArgs a, size_t dyn_l
 {
   int per_cu = 1;
   NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
-  const uint64_t need = (a.n_wtiles + a.waves - 1) / a.waves;
+  const uint64_t need = ((a.tile_list ? a.n_list : a.n_wtiles) + a.waves - 1) / a.waves;
   uint64_t grid = (uint64_t)c->n_cu * per_cu;
   if (grid > need) grid = need;
   if (a.tile_map == 0xFFFFFFFFu) a.tile_map = (uint32_t)grid;

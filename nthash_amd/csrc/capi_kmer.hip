@@ -108,13 +108,18 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
   // may still fit when the dense stream does not: the counting paths below decide that)
   const bool rows_ok = !rd->offsets && kmer_fixed_eligible(c, len, stride, k, m, &pad, &dyn);
   // (positions do not need the N-aware pass when the batch turns out clean: every window is emitted)
-  const bool want_fast = !rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.fwd && !st.rev &&
-                         !(st.pos && (flags & NTHIP_ASYNC)) &&
-                         len >= k && rd->n_reads * (uint64_t)(len - k + 1) <= out->capacity;
+  bool want_fast = !rd->offsets && !(flags & NTHIP_FORCE_GENERAL) && !st.fwd && !st.rev &&
+                   !(st.pos && (flags & NTHIP_ASYNC)) &&
+                   len >= k && rd->n_reads * (uint64_t)(len - k + 1) <= out->capacity;
   // fixed-length reads that are (or may be) dirty, or whose positions are wanted: N-aware run-split path
   NaPlan na_plan;
   const bool na_ok = !rd->offsets && !(flags & (NTHIP_FORCE_GENERAL | NTHIP_FORCE_ROWS)) &&
                      len >= k && kmer_na_plan(c, len, stride, k, m, st.pos != nullptr, &na_plan);
+  // a shape whose last batch held a non-base: no dense pass that gives up at the first N (0.7 ms of 5.7 for 20 M reads)
+  const std::array<uint32_t, 4> dirty_key = {len, stride, k, m};
+  if (want_fast && na_ok && !c->tune.no_dirty_memory && !(flags & (NTHIP_ASYNC | NTHIP_OUT_READ_SLOTS)) &&
+      c->dirty_shapes.count(dirty_key))
+    want_fast = false;
   if (!rd->offsets && len < k) {
     // every read shorter than k: nothing is emitted
     if (st.counts) {
@@ -371,9 +376,52 @@ extern "C" int nthip_kmer_hash(nthip_ctx* c, const nthip_reads* rd_in, uint16_t 
     if (na_tuned != c->run_len_cache.end() && na_tuned->second != na_plan.g.C &&
         !kmer_na_plan(c, len, stride, k, m, st.pos != nullptr, &na_plan, 0, na_tuned->second))
       return fail(NTHIP_ERR_HIP, "N-aware plan failed for a tuned run length");
-    int rc = run_kmer_na(c, st, rd, k, m, na_plan, consts, out->capacity, &total);
+    // a shape of the specialised kernel: the tiles that lost no window (all but a few) go there, at the compact offsets
+    bool special_done = false;
+    {
+      RunsPlan plan;
+      if (!(flags & NTHIP_FORCE_ROWS) && !c->tune.no_special && m == 1 && !st.pos && !st.fwd && !st.rev &&
+          kmer_runs_plan(c, len, stride, k, m, &plan)) {
+        const bool special31 = k == 31 && (plan.C == 15 || plan.C == 30);
+        const bool any_k = !special31 && !c->tune.no_any_k_runs && plan.rpr <= 128 && !kmer_runs_chunked_compiled() &&
+                           kmer_runs_any_k_compiled(k, m, plan.C);
+        if (special31 || any_k) {
+          KmerRunsArgs ra;
+          memset(&ra, 0, sizeof ra);
+          ra.seqs = st.seqs;
+          if (any_k) NTCHK(get_kmer_tab(c, k, &ra.init_tab));
+          else NTCHK(get_init_tab(c, k, &ra.init_tab));
+          ra.n_reads = rd->n_reads;
+          ra.n_runs = rd->n_reads * plan.rpr;
+          ra.n_wtiles = (ra.n_runs + 63) / 64;
+          ra.len = len;
+          ra.stride = stride;
+          ra.k = k;
+          ra.m = m;
+          ra.nwin = len - k + 1;
+          ra.C = plan.C;
+          ra.rpr = plan.rpr;
+          ra.ntab = any_k ? kmer_ntab(k) : (k + 3) / 4;
+          ra.waves = plan.waves;
+          ra.bits_dwords = plan.bits_dwords;
+          ra.inv_rpr = 65536u / plan.rpr + 1u;
+          ra.dword_tail = plan.dword_tail;
+          ra.ph_tiles = plan.ph_tiles;
+          ra.tile_map = c->tune.has_tile_map ? c->tune.tile_map : 0xFFFFFFFFu;
+          memcpy(ra.tab, consts.tab, sizeof ra.tab);
+          memcpy(ra.mult, consts.mult, sizeof ra.mult);
+          int src = run_kmer_na_special(c, st, rd, k, m, plan, ra, plan.dword_tail != 0, consts, out->capacity, &total,
+                                        &special_done);
+          if (src == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
+          NTCHK(src);
+        }
+      }
+    }
+    int rc = special_done ? NTHIP_OK : run_kmer_na(c, st, rd, k, m, na_plan, consts, out->capacity, &total);
     if (rc == NTHIP_ERR_CAPACITY && total_out) *total_out = total;
     NTCHK(rc);
+    if (total < na_dense) c->dirty_shapes.insert(dirty_key);
+    else c->dirty_shapes.erase(dirty_key);
     done = true;
   }
   if (!done && rd->offsets && !(flags & NTHIP_FORCE_GENERAL)) {

@@ -73,3 +73,89 @@ int ntamd::host::run_kmer_na(nthip_ctx* c, const Staged& st, const nthip_reads* 
   HIPCHK(hipStreamSynchronize(c->stream));
   return NTHIP_OK;
 }
+
+int ntamd::host::run_kmer_na_special(nthip_ctx* c, const Staged& st, const nthip_reads* rd, uint32_t k, uint32_t m,
+                                     const RunsPlan& plan, const KmerRunsArgs& ra0, bool dt, const KmerFixedArgs& consts,
+                                     uint64_t capacity, uint64_t* total, bool* handled)
+{
+  *handled = false;
+  if (m != 1 || plan.ph_tiles != (uint32_t)KR_BURST || st.pos || st.fwd || st.rev || c->tune.no_na_special) return NTHIP_OK;
+  const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
+  NaPlan q; // the count pass and the listed tiles: the general kernel on the SAME tiles (run length, runs per read)
+  if (!kmer_na_plan(c, len, stride, k, m, false, &q, 0, plan.C) || q.g.C != plan.C || q.g.rpr != plan.rpr ||
+      q.g.rpr * q.g.C != len - k + 1)
+    return NTHIP_OK;
+  KmerRunsGenArgs a;
+  fill_gen_args(a, c, st, rd, k, m, q.g, consts);
+  NTCHK(get_kmer_tab(c, k, &a.init_tab));
+  a.counts = st.counts;
+  a.vbits_dwords = q.vbits_dwords;
+  a.ptile_dwords = q.ptile_dwords;
+  a.tile_u64 = q.tile_u64;
+  const uint64_t nt = a.n_wtiles;
+  if (nt != ra0.n_wtiles || plan.lds + (size_t)plan.waves * 128 > lds_cap_of(c) + 512) return NTHIP_OK;
+  const uint64_t nb = (nt + SCAN_TILE - 1) / SCAN_TILE;
+  NTCHK(ensure_scratch(c, 3 * nt + nb + 16));
+  a.tile_counts = c->d_scratch;
+  uint64_t* d_off = c->d_scratch + nt;
+  uint64_t* d_list = c->d_scratch + 2 * nt;
+  uint64_t* d_sums = c->d_scratch + 3 * nt;
+  uint64_t* d_total = (uint64_t*)(c->d_small + 8);
+  unsigned long long* d_nlist = (unsigned long long*)(c->d_small + 32);
+  uint32_t* d_zero = (uint32_t*)(c->d_small + 40); // (the specialised kernel polls a "batch is dirty" word: it stays 0)
+  a.tile_off = d_off;
+  HIPCHK(hipMemsetAsync(c->d_small + 32, 0, 16, c->stream));
+  if (st.counts) HIPCHK(hipMemsetAsync(st.counts, 0, rd->n_reads * sizeof(uint64_t), c->stream));
+  {
+    KmerRunsGenArgs ca = a;
+    ca.waves = 16;
+    while (ca.waves > 1 && (size_t)ca.waves * ca.vbits_dwords * 4 + 64 > 150 * 1024) ca.waves /= 2;
+    const size_t lds = (size_t)ca.waves * ca.vbits_dwords * 4 + 64;
+    int per_cu = 1;
+    NTCHK(blocks_per_cu(c, kmer_runs_count_kernel<false>, (int)ca.waves * 64, lds, &per_cu));
+    const uint64_t need = (ca.n_wtiles + ca.waves - 1) / ca.waves;
+    uint64_t grid = (uint64_t)c->n_cu * per_cu;
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL(kmer_runs_count_kernel<false>, dim3((unsigned)grid), dim3(ca.waves * 64), lds, c->stream, ca);
+    HIPCHK(hipGetLastError());
+  }
+  NTCHK(device_exclusive_scan(c, a.tile_counts, d_off, nt, d_sums, d_total));
+  hipLaunchKernelGGL(list_short_tiles_kernel, dim3((unsigned)(c->n_cu * 4)), dim3(256), 0, c->stream, a.tile_counts, nt, a.n_runs,
+                     plan.C, d_list, d_nlist);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_small + 32, d_nlist, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(total, c->h_small + 8, 8);
+  uint64_t n_list = 0;
+  memcpy(&n_list, c->h_small + 32, 8);
+  *handled = true;
+  if (*total > capacity)
+    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
+                (unsigned long long)capacity, (unsigned long long)*total);
+  // the tiles that lost nothing: the specialised kernel, at the compact offsets
+  KmerRunsArgs ra = ra0;
+  RunsPlan p2 = plan;
+  ra.hashes = st.hashes;
+  ra.dirty = d_zero;
+  ra.vecmap = nullptr;
+  ra.tile_off = d_off;
+  ra.tile_counts = a.tile_counts;
+  ra.tile_u64 = plan.tile_u64 + 16; // (a tile starts anywhere in a 128-byte line of the stream: built that far up)
+  p2.tile_u64 = ra.tile_u64;
+  p2.lds = plan.lds + (size_t)plan.waves * 128;
+  NTCHK(launch_kmer_runs_special(c, ra, p2, dt));
+  if (n_list) { // the others (an N in one read of 1000: under 1 % of the tiles): the N-aware kernel
+    a.counts = nullptr;
+    a.waves = q.waves;
+    a.tile_list = d_list;
+    a.n_list = n_list;
+    const bool prof = c->profiling; // (last_kernel_ms names and times the pass over the bulk of the batch)
+    c->profiling = false;
+    const int rc = launch_kmer_runs_gen_nw<true>(c, a, q.lds, q.g.nw, q.g.dword_tail != 0);
+    c->profiling = prof;
+    NTCHK(rc);
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NTHIP_OK;
+}

@@ -129,6 +129,10 @@ struct KmerRunsGenArgs {
   uint64_t* counts;          // count pass, optional (zeroed by the host): per-read emitted windows
   uint64_t* tile_counts;     // count pass out: valid windows per wave tile
   const uint64_t* tile_off;  // N-aware hash pass in: exclusive scan of tile_counts
+  // N-aware hash pass over SOME tiles (round 4): the n_list tiles listed here, in any order -- the tiles that lost a
+  // window, when kmer_runs_kernel has written all the others of the compact stream.  NULL: every tile
+  const uint64_t* tile_list;
+  uint64_t n_list;
   uint64_t n_reads;
   uint64_t n_runs;       // n_reads * rpr
   uint64_t n_wtiles;     // ceil(n_runs / 64)
@@ -419,10 +423,14 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
   __syncthreads(); // the only block-wide barrier
 
   uint32_t bad = 0;
+  // (listed: wt counts the entries of a.tile_list, the tile itself is tile_at(wt))
+  const bool listed = NA && SINK == SINK_NONE && !PK && a.tile_list != nullptr;
+  auto tile_at = [&](uint64_t i) -> uint64_t { return listed ? a.tile_list[i] : i; };
   uint64_t wt, wstride, wt_end;
-  tile_range<SINK == SINK_NONE>(a.tile_map, a.waves, wave, a.n_wtiles, wt, wstride, wt_end); // (the consumers write no stream)
-  uint64_t r_first = (wt * 64u) / rpr;
-  uint32_t rem0 = (uint32_t)(wt * 64u - r_first * rpr);
+  tile_range<SINK == SINK_NONE>(a.tile_map, a.waves, wave, listed ? a.n_list : a.n_wtiles, wt, wstride, wt_end); // (the consumers write no stream)
+  uint64_t cur_tile = wt < wt_end ? tile_at(wt) : 0u;
+  uint64_t r_first = (cur_tile * 64u) / rpr;
+  uint32_t rem0 = (uint32_t)(cur_tile * 64u - r_first * rpr);
   const uint64_t step_q = (wstride * 64u) / rpr;
   const uint32_t step_r = (uint32_t)(wstride * 64u - step_q * rpr);
 
@@ -548,8 +556,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
   bool test_first = true;              // Bloom insert: look at the bit before the atomic (see below)
   uint32_t probe_wait = 0;
   if (wt < wt_end) {
-    cur = tile_geo(shape, seqs_addr, a.n_runs, a.total_bytes, wt * 64u, r_first, rem0);
-    if constexpr (NA && SINK == SINK_NONE) cur_off = a.tile_off[wt];
+    cur = tile_geo(shape, seqs_addr, a.n_runs, a.total_bytes, cur_tile * 64u, r_first, rem0);
+    if constexpr (NA && SINK == SINK_NONE) cur_off = a.tile_off[cur_tile];
     stage(cur, 0u);
     if constexpr (NA && PK) packed_validity(cur);
     if constexpr (NA) {
@@ -563,16 +571,22 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     const uint32_t my_rem0 = rem0;
     const uint64_t my_rf = r_first;
     // ---- issue the loads of the NEXT tile's slab ---------------------------------
-    r_first += step_q;
-    rem0 += step_r;
-    if (rem0 >= rpr) { rem0 -= rpr; r_first += 1; }
     const uint64_t nwt = wt + wstride;
     const bool have_next = nwt < wt_end;
+    const uint64_t nxt_tile = listed ? (have_next ? a.tile_list[nwt] : cur_tile) : nwt;
+    if (listed) { // (a handful of tiles: a division each)
+      r_first = (nxt_tile * 64u) / rpr;
+      rem0 = (uint32_t)(nxt_tile * 64u - r_first * rpr);
+    } else {
+      r_first += step_q;
+      rem0 += step_r;
+      if (rem0 >= rpr) { rem0 -= rpr; r_first += 1; }
+    }
     TileGeo nxt = cur;
     uint64_t nxt_off = cur_off;
     if (have_next) {
-      nxt = tile_geo(shape, seqs_addr, a.n_runs, a.total_bytes, nwt * 64u, r_first, rem0);
-      if constexpr (NA && SINK == SINK_NONE) nxt_off = a.tile_off[nwt];
+      nxt = tile_geo(shape, seqs_addr, a.n_runs, a.total_bytes, nxt_tile * 64u, r_first, rem0);
+      if constexpr (NA && SINK == SINK_NONE) nxt_off = a.tile_off[nxt_tile];
     }
     v4u pv0, pv1;
     uint32_t pw;
@@ -1047,6 +1061,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
     if (have_next) {
       cur = nxt;
       cur_off = nxt_off;
+      cur_tile = nxt_tile;
       if constexpr (NA) bad = 0;
       if (lane < cur.n_vec) pack_vec(cur, lane, make_uint4(pv0.x, pv0.y, pv0.z, pv0.w));
       if constexpr (DT) {

@@ -82,6 +82,11 @@ struct KmerRunsArgs {
   // a.seqs rounded down to 16) -- set where a vector holds a non-base INSTEAD of flagging the batch dirty: the pass goes on
   // as if the batch were clean, the reads those vectors touch are redone in their slots afterwards.  NULL: the plain pass.
   uint32_t* vecmap;
+  // the COMPACT stream of a batch with non-bases (round 4; burst path, m = 1): tile t's k-mers start at tile_off[t]
+  // (the exclusive scan of the count pass's tile_counts); a tile that lost a window (tile_counts[t] < its windows) is left
+  // out here -- the N-aware kernel writes those few, from a list.  Nothing is judged: the count pass has.  NULL: dense.
+  const uint64_t* tile_off;
+  const uint64_t* tile_counts;
   const uint4* init_tab; // global [ntab][256] {f.lo,f.hi,r.lo,r.hi}, all-care mask
   uint64_t n_reads;
   uint64_t n_runs;       // n_reads * rpr
@@ -93,7 +98,7 @@ struct KmerRunsArgs {
   uint32_t ntab;         // ceil(k/4)
   uint32_t waves;        // waves per block
   uint32_t bits_dwords;  // per-wave bit-stream capacity
-  uint32_t tile_u64;     // per-wave tile capacity (64*C)
+  uint32_t tile_u64;     // per-wave tile capacity (64*C; 16 more for the compact stream: a tile starts anywhere in a line)
   uint32_t inv_rpr;      // floor(65536 / rpr) + 1
   uint32_t dword_tail;   // every slab is <= 1280 bytes: tail staged as one dword per lane
   uint32_t tile_map;     // number of wave groups of the tile -> wave mapping (see the kernel)
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
   constexpr uint32_t NST = NFULL + (REM ? 1u : 0u);        // store instructions of a full tile
 
   // ---- one tile: every lane hashes its run into the wave's LDS tile -----------------------------------
-  auto hash_tile = [&](const uint32_t shift, const uint32_t runs_here, const uint32_t my_rem0) {
+  auto hash_tile = [&](const uint32_t shift, const uint32_t runs_here, const uint32_t my_rem0, const uint32_t tpar = 0u) {
       const bool live = lane < runs_here;
       const uint32_t gl = live ? my_rem0 + lane : my_rem0; // run index relative to r_first's run 0
       const uint32_t lr = (gl * a.inv_rpr) >> 16;           // gl / rpr (gl < 64 + rpr: exact)
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
       const uint32_t b0 = shift + lr * a.stride + q * C;    // first base of the first window
       const uint32_t d0 = b0 >> 4, sh0 = (b0 & 15u) << 1;
 #if KR_ABL_NOHASH
-      (void)d0; (void)sh0;
+      (void)d0; (void)sh0; (void)tpar;
       tile[lane] = (uint64_t)b0; // (keeps the geometry alive)
 #else
       uint32_t w[NW];
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
         }
       }
 #endif
-      uint64_t* my_row = tile + lane * C;
+      uint64_t* my_row = tile + tpar + lane * C; // (compact stream: the tile starts tpar values into a line of the stream)
       my_row[0] = canon_pair(f_lo, f_hi, r_lo, r_hi);
 
       // remaining C-1 windows: roll.  step t (1..C-1): in = base b0+k-1+t, out = base b0+t-1
@@ -409,14 +414,57 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
 
   // ---- copy the tile out: 64*C*m consecutive values of the hash stream; true = a full tile left as exactly
   // NST store instructions (what the counted waits below rely on) ---------------------------------------
-  auto copy_out = [&](const uint64_t g0, const uint32_t runs_here) -> bool {
+  // cmp_off != ~0: the tile's first value in the compact stream (m = 1): the tile was built tpar = cmp_off & 15 slots up
+  auto copy_out = [&](const uint64_t g0, const uint32_t runs_here, const uint64_t cmp_off = ~0ull) -> bool {
     lds_sync();
-      uint64_t* const out0 = a.hashes + g0 * vals_per_run;
+      const bool cmp = cmp_off != ~0ull;
+      const uint32_t tpar = cmp ? (uint32_t)(cmp_off & 15u) : 0u;
+      uint64_t* const out0 = cmp ? a.hashes + (cmp_off - tpar) : a.hashes + g0 * vals_per_run;
       const uint32_t n_vals = runs_here * vals_per_run;
       const uint32_t n_pairs = (n_vals + 1u) >> 1;
       bool counted = false;
       if (m == 1) {
-        if (C_T != 0 && runs_here == 64u) {
+        if (cmp) {
+          // the tile was built tpar slots up, so that piece 0 starts a 128-byte line of the stream: every store instruction
+          // covers whole lines.  Lines that lie inside the tile leave write-through, as the dense tiles do; the two lines it
+          // shares with its neighbours in plain stores (write-through on pieces that do not fill their lines: 4.4 -> 9.1 ms
+          // per 2.4 G k-mers; plain or streaming stores from 16-byte boundaries anywhere: 4.4-4.5).  A full tile still
+          // leaves as at least 8 store instructions (the burst path's wait)
+          const uint32_t span = tpar + n_vals, pieces = (span + 1u) >> 1;
+          const uint32_t line_lo = (tpar + 15u) >> 4, line_hi = span >> 4; // whole lines: [line_lo, line_hi)
+#ifndef KR_CMP_STORE
+#define KR_CMP_STORE 1 // whole lines: 0 plain, 1 streaming (nt), 2 write-through (sc0 sc1)
+#endif
+          auto put_line = [&](const uint32_t pi, const uint4 dv) { // a piece of a whole line
+#if KR_CMP_STORE == 2
+            stream_store16(out0 + 2u * pi, dv);
+#elif KR_CMP_STORE == 1
+            __builtin_nontemporal_store(*(const v4u*)&dv, (v4u*)(out0 + 2u * pi));
+#else
+            *(uint4*)(out0 + 2u * pi) = dv;
+#endif
+          };
+          auto put_edge = [&](const uint32_t pi) { // a piece of a line the tile shares with a neighbour
+            const uint4 dv = *(const uint4*)(tile + 2u * pi);
+            const bool lo_ok = 2u * pi >= tpar && 2u * pi < span, hi_ok = 2u * pi + 1u >= tpar && 2u * pi + 1u < span;
+            if (lo_ok && hi_ok) *(uint4*)(out0 + 2u * pi) = dv;
+            else if (lo_ok) *(uint2*)(out0 + 2u * pi) = make_uint2(dv.x, dv.y);
+            else if (hi_ok) *(uint2*)(out0 + 2u * pi + 1u) = make_uint2(dv.z, dv.w);
+          };
+          // whole lines: groups of four LDS reads, then their stores (the slab registers of the burst path leave no room
+          // for the dense copy-out's eight); a full tile is 60 or 61 whole lines = 8 store instructions
+          const uint32_t p_lo = line_lo << 3, p_hi = line_hi << 3; // their pieces: [p_lo, p_hi)
+          for (uint32_t p0 = p_lo; p0 < p_hi; p0 += 256u) {
+            const uint4* src = (const uint4*)tile + p0 + lane;
+            const uint4 d0 = src[0], d1 = src[64], d2 = src[128], d3 = src[192]; // (past p_hi: the wave's own LDS, not stored)
+            if (p0 + lane < p_hi) put_line(p0 + lane, d0);
+            if (p0 + 64u + lane < p_hi) put_line(p0 + 64u + lane, d1);
+            if (p0 + 128u + lane < p_hi) put_line(p0 + 128u + lane, d2);
+            if (p0 + 192u + lane < p_hi) put_line(p0 + 192u + lane, d3);
+          }
+          if (lane < 8u) { if (line_lo != 0u) put_edge(lane); }                       // the tile's first line
+          else if (lane < 16u) { if (pieces > p_hi) put_edge(p_hi + lane - 8u); }     // and its last
+        } else if (C_T != 0 && runs_here == 64u) {
           // full tile, compile-time shape: LDS reads first, then the stores, in groups of 8
           // (named registers, not an array: hipcc sends a partially predicated
           // uint4 array to scratch, whose traffic would also break the counted wait)
@@ -592,6 +640,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
         return;
       }
       uint32_t* const bits0 = bits;
+      const bool compact = M_T == 1 && a.tile_off != nullptr;
       const uint32_t reads_per_tile = 64u / a.rpr;
       const uint64_t tile_bytes = (uint64_t)reads_per_tile * a.stride;
       const uint64_t base_addr = (uint64_t)a.seqs;
@@ -662,11 +711,16 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
                      "+v"(w4[0]), "+v"(w4[1]), "+v"(w4[2]), "+v"(w4[3]), "+v"(w4[4]), "+v"(w4[5]), "+v"(w4[6]), "+v"(w4[7]), \
                      "+v"(dirty_seen)::"memory")
       static_assert(P == 8u, "the marker above lists 8 slabs");
+      uint64_t nx_cnt = 0, nx_off = 0; // compact stream: count and offset of the tile that comes next
       if (pt < wt_end) {
         issue_piece(pt);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         KR_BURST_MARK();
         pack_piece(pt);
+        if (compact) {
+          nx_cnt = a.tile_counts[pt];
+          nx_off = a.tile_off[pt];
+        }
       }
       while (pt < wt_end) {
         const uint64_t left = wt_end - pt;
@@ -675,6 +729,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
         const bool have_next = npt < wt_end;
         // a non-base in the piece just packed (or anywhere in the batch, as of the last look): the caller redoes the
         // batch on the N-aware path, so stop producing a dense stream nobody will read
+        if (compact) bad = 0; // (the count pass has judged the bytes; a.dirty is a word that stays 0)
         if (__ballot(bad != 0) != 0) {
           if (lane == 0) atomicOr(a.dirty, 1u);
           break;
@@ -688,11 +743,25 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
           const uint64_t runs_left = a.n_runs - g0;
           const uint32_t runs_here = runs_left < 64u ? (uint32_t)runs_left : 64u;
           const uint32_t shift = (uint32_t)((base_addr + t * tile_bytes) & 15u);
+          uint64_t cmp_off = ~0ull;
+          if (compact) {
+            // (the next tile's count and offset are asked for now, a tile ahead: scalar loads whose latency would
+            //  otherwise stand in front of every tile)
+            const uint64_t t_cnt = nx_cnt;
+            cmp_off = nx_off;
+            const uint64_t tn = q + 1u < n_here ? t + 1u : (have_next ? npt : t);
+            nx_cnt = a.tile_counts[tn];
+            nx_off = a.tile_off[tn];
+            if (t_cnt != (uint64_t)runs_here * C) { // a window lost: the N-aware kernel's tile
+              all_full = false;
+              continue;
+            }
+          }
           bits = bits0 + q * a.bits_dwords;
           lds_sync();
-          hash_tile(shift, runs_here, 0u);
+          hash_tile(shift, runs_here, 0u, compact ? (uint32_t)(cmp_off & 15u) : 0u);
           NT_LINT_SELFTEST_TOUCH(dirty_seen);
-          (void)copy_out(g0, runs_here);
+          (void)copy_out(g0, runs_here, cmp_off);
           all_full = all_full && runs_here == 64u;
           lds_sync(); // the tile is free again
         }

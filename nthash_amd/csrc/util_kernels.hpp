@@ -514,4 +514,39 @@ static __global__ __launch_bounds__(256) void check_spans_kernel(const uint64_t*
   if ((threadIdx.x & 63u) == 0 && longest) atomicMax(max_len, (unsigned long long)longest);
 }
 
+// the tiles of the N-aware count pass that lost a window: tile t holds min(64, n_runs - 64 t) runs of C windows when none
+// is lost.  list[0 .. *n_list) in any order (*n_list zeroed by the host).  A block collects its tiles in LDS and takes
+// its place in the list with ONE atomic per 1792 entries (20 000 atomics on one word took 0.19 ms).  256 threads.
+static __global__ __launch_bounds__(256) void list_short_tiles_kernel(const uint64_t* tile_counts, uint64_t n_tiles, uint64_t n_runs,
+                                                                      uint32_t C, uint64_t* list, unsigned long long* n_list)
+{
+  constexpr uint32_t CAP = 2048;
+  __shared__ uint64_t buf[CAP];
+  __shared__ uint32_t n_buf;
+  __shared__ uint64_t base;
+  if (threadIdx.x == 0) n_buf = 0;
+  __syncthreads();
+  auto flush = [&]() { // (block-wide)
+    __syncthreads();
+    const uint32_t n = n_buf;
+    if (threadIdx.x == 0 && n) base = atomicAdd(n_list, (unsigned long long)n);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) list[base + i] = buf[i];
+    __syncthreads();
+    if (threadIdx.x == 0) n_buf = 0;
+    __syncthreads();
+  };
+  for (uint64_t t0 = (uint64_t)blockIdx.x * 256u; t0 < n_tiles; t0 += (uint64_t)gridDim.x * 256u) {
+    const uint64_t t = t0 + threadIdx.x;
+    if (t < n_tiles) {
+      const uint64_t left = n_runs - t * 64u;
+      const uint64_t full = (left < 64u ? left : 64u) * C;
+      if (tile_counts[t] != full) buf[atomicAdd(&n_buf, 1u)] = t;
+    }
+    __syncthreads();
+    if (n_buf + 256u > CAP) flush(); // (uniform: read behind the barrier)
+  }
+  flush();
+}
+
 } // namespace ntamd

@@ -2560,6 +2560,42 @@ def test_kmer_packed_input_refusals(ctx, oracle):
         ctx.free(d_pk)
 
 
+@pytest.mark.parametrize("knob", ["", "NTHIP_TUNE_NO_DIRTY_MEMORY", "NTHIP_TUNE_NO_NA_SPECIAL"])
+def test_fixed_length_batches_with_non_bases_every_way(oracle, knob):
+    """a fixed-length batch with a non-base: the dense pass gives up, the count pass finds every tile's place in the compact
+    stream, the tiles that lost no window go through the specialised kernel at those places (kmer_runs_kernel's compact
+    mode: tiles built where they start in a 128-byte line), the others through the N-aware kernel from a list; the next
+    batch of the shape skips the dense pass (the context remembers), a batch that loses nothing takes the shape back.
+    With either knob off the older paths run.  Shapes of the specialised kernel (150 / 31, run length 15; 151 / 31: 11)
+    and one that is not; N's at a read's first and last base, in neighbouring reads, a read of N's only; batch sizes
+    that end inside a tile and inside a piece of 8 tiles"""
+    import os
+    import nthash_amd
+    if knob:
+        os.environ[knob] = "1"
+    try:
+        c = nthash_amd.Context(0)
+    finally:
+        os.environ.pop(knob, None)
+    rng = np.random.default_rng(41)
+    for n, L, k in ((3000, 150, 31), (70001, 150, 31), (4099, 151, 31), (2000, 100, 25), (5, 150, 31)):
+        clean = oracle.synth_reads(77, n, L, 9)
+        dirty = clean.copy()
+        at = [0, L - 1, 5 * L + 40, 6 * L, (n - 1) * L + L - 1] if n > 10 else [L + 3]
+        at += [int(x) for x in rng.choice(n * L, max(1, n // 400), replace=False)]
+        dirty[at] = ord("N")
+        if n > 100:
+            dirty[50 * L:51 * L] = ord("N")
+        offs = np.arange(n + 1, dtype=np.uint64) * L
+        want = {"clean": oracle.kmer_batch(clean, offs, k, 1, want_pos=False),
+                "dirty": oracle.kmer_batch(dirty, offs, k, 1, want_pos=False)}
+        for which in ("clean", "dirty", "dirty", "clean", "clean", "dirty"):
+            got = c.kmer_hash(clean if which == "clean" else dirty, k, 1, fixed_len=L, n_reads=n)
+            assert got["total"] == want[which]["total"], (which, n, L)
+            assert (got["hashes"][:got["total"]] == want[which]["hashes"][:got["total"]]).all(), (which, n, L)
+            assert (got["counts"] == want[which]["counts"]).all()
+
+
 def test_seed_rolled_run_by_run_vs_oracle(oracle):
     """seed_roll_kernel: seeds are rolled the way the reference rolls them (NTMSM64, src/seed.cpp:177-207) -- one base in
     and one out per care run and window, a lane per segment of 16 / 8 / 4 windows whose first one is hashed directly --

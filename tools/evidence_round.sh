@@ -1,0 +1,27 @@
+#!/bin/bash
+# Everything the round's notes and DESIGN.md cite, made on one GPU box from the tree as it is:
+#   bash tools/evidence_round.sh r04      (then: python tools/collect_profiles.py r04 copies the summaries into profiles/)
+set -u
+TAG=${1:-r04}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+timeout 3000 bash tools/profile_round.sh "$TAG" > "$OUT/profile_round.log" 2>&1
+# consumers, whole calls
+{ for s in clean dirty var; do timeout 300 python tools/minimizer_bench.py 20000000 0 $s; done; } > "$OUT/minimizers.txt" 2>&1
+{ timeout 300 python tools/bloom_bench.py 20000000 1; timeout 300 python tools/bloom_bench.py 20000000 3; timeout 300 python tools/count_bench.py 20000000 1; } > "$OUT/bloom_bench.txt" 2>&1
+timeout 300 python tools/minhash_bench.py > "$OUT/minhash_bench.txt" 2>&1
+# the record-form minimizer kernel under the counters (SQ groups)
+MZ_W=10 PMC_SQ_ONLY=1 timeout 1200 bash tools/run_pmc.sh "$OUT/pmc_mzw" mz 20000000 > "$OUT/pmc_mzw.log" 2>&1
+# spaced seeds: the shapes of the round-3 table, long seeds, seeds of few runs
+timeout 600 python tools/seed_sweep.py > "$OUT/seed_sweep.txt" 2>&1
+SWEEP_SHAPES="250,128,1,1;300,160,1,1;250,96,1,1;250,31,5,1;250,31,8,1;150,48,3,1;150,64,3,1;250,128,1,3" timeout 600 python tools/seed_sweep.py > "$OUT/seed_sweep_long.txt" 2>&1
+timeout 300 python tools/seed_roll_sweep.py > "$OUT/seed_roll_sweep.txt" 2>&1
+timeout 300 python tools/extend_bench.py > "$OUT/extend_bench.txt" 2>&1
+timeout 600 python tools/facade_bench.py > "$OUT/facade_bench.txt" 2>&1
+timeout 600 python tools/shape_sweep.py > "$OUT/shape_sweep.txt" 2>&1
+timeout 2400 python -m pytest tests -q -m gpu > "$OUT/pytest_gpu.txt" 2>&1
+tail -3 "$OUT/pytest_gpu.txt"
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" >> "$OUT/pytest_gpu.txt" 2>&1
+find "$OUT" -name "*.db" -delete; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*_agent_info.csv" -delete
+du -sh "$OUT"
