@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Copy the summaries of a GPU evidence round (tools/evidence_round.sh <tag> -> gpurun_out/<tag>/) into profiles/, tracked.
+
+    python tools/collect_profiles.py r04
+Small text / csv / json files only; traces and databases stay in the scratch directory.
+"""
+import glob, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
+names = {  # scratch name -> tracked name
+    "bench_default.json": f"{tag}_bench_default.json",
+    "minimizers.txt": f"{tag}_minimizers.txt",
+    "bloom_bench.txt": f"{tag}_bloom_bench.txt",
+    "minhash_bench.txt": f"{tag}_minhash_bench.txt",
+    "seed_sweep.txt": f"{tag}_seed_sweep.txt",
+    "seed_sweep_long.txt": f"{tag}_seed_sweep_long.txt",
+    "seed_roll_sweep.txt": f"{tag}_seed_roll_sweep.txt",
+    "extend_bench.txt": f"{tag}_extend_bench.txt",
+    "facade_bench.txt": f"{tag}_facade_bench.txt",
+    "shape_sweep.txt": f"{tag}_shape_sweep.txt",
+    "pytest_gpu.txt": f"{tag}_pytest_gpu.txt",
+    "profile_round.log": f"{tag}_profile_round.log",
+    "pmc_c2/summary.txt": f"{tag}_pmc_c2_summary.txt",
+    "pmc_c4/summary.txt": f"{tag}_pmc_c4_summary.txt",
+    "pmc_rag/summary.txt": f"{tag}_pmc_reads_summary.txt",
+    "pmc_mzw/summary.txt": f"{tag}_pmc_mzw_summary.txt",
+    "bench_consumers_under_rocprof.json": f"{tag}_bench_consumers_under_rocprof.json",
+}
+for f in glob.glob(os.path.join(src, "bench_*_under_rocprof.json")):
+    names[os.path.basename(f)] = f"{tag}_" + os.path.basename(f)
+for f in glob.glob(os.path.join(src, "kernel_stats_*.csv")):
+    names[os.path.basename(f)] = f"{tag}_" + os.path.basename(f)
+for f in glob.glob(os.path.join(src, "minimizer_*_under_rocprof.txt")):
+    names[os.path.basename(f)] = f"{tag}_" + os.path.basename(f)
+n = 0
+for a, b in sorted(names.items()):
+    p = os.path.join(src, a)
+    if os.path.exists(p) and os.path.getsize(p) < (2 << 20):
+        shutil.copyfile(p, os.path.join(dst, b))
+        n += 1
+    else:
+        print("missing or too big:", a)
+print(n, "files copied to profiles/")
