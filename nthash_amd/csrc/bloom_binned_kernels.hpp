@@ -63,6 +63,45 @@ constexpr uint32_t BB_REGION_DWORDS = 1u << (BB_REGION_SHIFT - 5);
 #define BB_CURSOR_STRIDE 32u // dwords between two cursors: one cache line each (tiles of every block hit the same few
 #endif                       // hundred cursors; neighbours in one line serialise in L2 -- profiles/r03_notes.md)
 
+// ---- slots mode (round 4): no histogram at all ------------------------------------------------------------------------
+// The exact lists need every region's count BEFORE the first value moves: a pass over the values (hist, 8 B per value
+// read) or, without a hash stream, a whole extra hashing of the reads (bloom_fused_kernels.hpp pass COUNT: 2.4 of a
+// round's 13.4 ms).  Hash values are uniform, so a bucket's share of a round is known to a few standard deviations
+// without looking: in slots mode every bucket OWNS `cap` = mean + 8 sqrt(mean) + 256 entries (rounded up to 64) of its
+// level's list, its cursor counts from 0, and what does not fit -- a k-mer repeated a million times in real data --
+// goes, as a full 64-bit position, to an overflow list that a test-then-atomic kernel applies after the regions
+// (a bit already set / a counter already at 255 costs a load, not an atomic).  Only when that list overflows too
+// (more than 1/64 of the round) does the round fail: apply and overflow kernels see it in BloomStatus and leave the
+// table untouched, the host redoes the round on the exact lists and keeps to them for that table.
+struct BloomStatus {
+  unsigned long long ovf_n; // values sent to the overflow list (those past ovf_cap were dropped: the round failed)
+  uint32_t dirty;           // the fused pass saw a non-base: the round's lists are garbage
+  uint32_t pad;
+};
+struct BloomSlots {
+  uint64_t cap;             // entries per bucket of the level written (0: exact lists, absolute cursors)
+  uint64_t* ovf;
+  BloomStatus* status;
+  uint64_t ovf_cap;
+};
+__device__ __forceinline__ bool bloom_round_failed(const BloomStatus* st, uint64_t ovf_cap)
+{
+  return st && (__builtin_nontemporal_load(&st->dirty) != 0 || __builtin_nontemporal_load(&st->ovf_n) > ovf_cap);
+}
+// a wave appends the entries [fit, cnt) of a tile's bucket run to the overflow list as full positions
+__device__ __forceinline__ void bloom_overflow_run(const BloomSlots& sl, const uint32_t* run, uint32_t fit, uint32_t cnt, uint64_t bucket_pos,
+                                                   uint32_t lane)
+{
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(&sl.status->ovf_n, (unsigned long long)(cnt - fit));
+  base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+  for (uint32_t q = fit + lane; q < cnt; q += 64u) {
+    const unsigned long long idx = base + (q - fit);
+    if (idx < sl.ovf_cap) sl.ovf[idx] = bucket_pos | run[q];
+  }
+}
+
 // ---- hist: values per region ---------------------------------------------------------------------------------------
 // dynamic LDS: n_regions counters.  counts[r] += ...; every block flushes the counters it touched.
 // (region_shift: log2 of the table slots per region -- 20 for a filter's bits, 15 for a sketch's counters)
@@ -140,6 +179,11 @@ struct BloomPartArgs {
   uint32_t n_regions;
   uint32_t shift, mask;
   uint32_t buckets_per_seg; // IN64: the number of buckets; !IN64: 128 (the last segment may own fewer regions)
+  // slots mode (sl.cap != 0): bucket g = seg * buckets_per_seg + b owns out[g * sl.cap ...), cursor[g] counts from 0;
+  // !IN64: segment s is in[s * cap_in ... + min(seg_fill[s], cap_in))
+  BloomSlots sl;
+  uint64_t cap_in;
+  const uint32_t* seg_fill;
 };
 
 template <bool IN64, uint32_t BB_PART_THREADS>
@@ -162,10 +206,17 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
   } else {
     const uint32_t r0 = seg * a.buckets_per_seg;
     const uint32_t r1 = r0 + a.buckets_per_seg < a.n_regions ? r0 + a.buckets_per_seg : a.n_regions;
-    s0 = a.seg_base[r0];
-    s1 = a.seg_base[r1];
+    if (a.sl.cap) {
+      const uint64_t fill = a.seg_fill[(size_t)seg * BB_CURSOR_STRIDE];
+      s0 = (uint64_t)seg * a.cap_in;
+      s1 = s0 + (fill < a.cap_in ? fill : a.cap_in);
+    } else {
+      s0 = a.seg_base[r0];
+      s1 = a.seg_base[r1];
+    }
     n_buckets = r1 - r0;
   }
+  const uint64_t slots_cap = a.sl.cap;
   uint32_t* const cursor = a.cursor + (size_t)seg * a.buckets_per_seg * BB_CURSOR_STRIDE;
   const uint64_t n_tiles = (s1 - s0 + BB_TILE - 1) / BB_TILE;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -246,11 +297,20 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
     __syncthreads();
     for (uint32_t b = wave; b < n_buckets; b += BB_PART_THREADS / 64u) {
       const uint32_t c = hist[b], o = off[b];
-      uint32_t* const dst = a.out + gbase[b];
 #if BB_ABL == 1 // ablation (WRONG results): everything but the stores
+      uint32_t* const dst = a.out + gbase[b];
       for (uint32_t j = lane; j < c; j += 64u) asm volatile("" ::"v"(sorted[o + j]), "v"(dst));
 #else
-      for (uint32_t j = lane; j < c; j += 64u) dst[j] = sorted[o + j];
+      if (slots_cap == 0) {
+        uint32_t* const dst = a.out + gbase[b];
+        for (uint32_t j = lane; j < c; j += 64u) dst[j] = sorted[o + j];
+      } else if (c) {
+        const uint64_t g = (uint64_t)seg * a.buckets_per_seg + b, at = gbase[b];
+        const uint32_t fit = at >= slots_cap ? 0u : (slots_cap - at < c ? (uint32_t)(slots_cap - at) : c);
+        uint32_t* const dst = a.out + g * slots_cap + at;
+        for (uint32_t j = lane; j < fit; j += 64u) dst[j] = sorted[o + j];
+        if (fit < c) bloom_overflow_run(a.sl, sorted + o, fit, c, g << a.shift, lane);
+      }
 #endif
     }
     __syncthreads();
@@ -260,15 +320,29 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
 
 // ---- apply: a workgroup per region -----------------------------------------------------------------------------------
 // dynamic LDS: 128 KiB.  entries = 20-bit offsets of the region's values.
-static __global__ __launch_bounds__(BB_APPLY_THREADS) void bloom_apply_kernel(const uint32_t* __restrict__ entries,
+// (slots mode, cap != 0: region r's entries are all_entries[r * cap ... + min(fill[r], cap)); a failed round is left alone)
+static __global__ __launch_bounds__(BB_APPLY_THREADS) void bloom_apply_kernel(const uint32_t* __restrict__ all_entries,
                                                                               const uint32_t* __restrict__ region_base,
                                                                               uint32_t n_regions, uint32_t* __restrict__ filter,
-                                                                              uint64_t filter_dwords)
+                                                                              uint64_t filter_dwords, uint64_t cap,
+                                                                              const uint32_t* __restrict__ fill,
+                                                                              const BloomStatus* status, uint64_t ovf_cap)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t bb_lds[];
   uint4* const l4 = (uint4*)bb_lds;
+  if (bloom_round_failed(status, ovf_cap)) return;
   for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
-    const uint32_t e0 = region_base[r], e1 = region_base[r + 1];
+    uint32_t e0, e1;
+    const uint32_t* entries = all_entries;
+    if (cap) {
+      const uint64_t f = fill[(size_t)r * BB_CURSOR_STRIDE];
+      entries += (size_t)r * cap;
+      e0 = 0;
+      e1 = (uint32_t)(f < cap ? f : cap);
+    } else {
+      e0 = region_base[r];
+      e1 = region_base[r + 1];
+    }
     if (e0 == e1) continue; // (uniform over the block)
     for (uint32_t i = threadIdx.x; i < BB_REGION_DWORDS / 4u; i += BB_APPLY_THREADS) l4[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -326,16 +400,29 @@ __device__ __forceinline__ uint32_t sat_add_bytes(uint32_t word, uint32_t a0, ui
   const uint32_t c2 = a2 > 255u || b2 > 255u ? 255u : b2, c3 = a3 > 255u || b3 > 255u ? 255u : b3;
   return c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
 }
-static __global__ __launch_bounds__(BB_APPLY_THREADS) void count_apply_kernel(const uint32_t* __restrict__ entries,
+static __global__ __launch_bounds__(BB_APPLY_THREADS) void count_apply_kernel(const uint32_t* __restrict__ all_entries,
                                                                               const uint32_t* __restrict__ region_base,
                                                                               uint32_t n_regions, uint32_t* __restrict__ sketch,
-                                                                              uint64_t sketch_dwords)
+                                                                              uint64_t sketch_dwords, uint64_t cap,
+                                                                              const uint32_t* __restrict__ fill,
+                                                                              const BloomStatus* status, uint64_t ovf_cap)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t bb_lds[];
   uint4* const l4 = (uint4*)bb_lds;
   constexpr uint32_t SLOTS = 1u << CS_REGION_SHIFT; // counters per region = LDS tallies
+  if (bloom_round_failed(status, ovf_cap)) return;
   for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
-    const uint32_t e0 = region_base[r], e1 = region_base[r + 1];
+    uint32_t e0, e1;
+    const uint32_t* entries = all_entries;
+    if (cap) {
+      const uint64_t f = fill[(size_t)r * BB_CURSOR_STRIDE];
+      entries += (size_t)r * cap;
+      e0 = 0;
+      e1 = (uint32_t)(f < cap ? f : cap);
+    } else {
+      e0 = region_base[r];
+      e1 = region_base[r + 1];
+    }
     if (e0 == e1) continue; // (uniform over the block)
     for (uint32_t i = threadIdx.x; i < SLOTS / 4u; i += BB_APPLY_THREADS) l4[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -364,6 +451,33 @@ static __global__ __launch_bounds__(BB_APPLY_THREADS) void count_apply_kernel(co
       if (t.x | t.y | t.z | t.w) sketch[d0 + i] = sat_add_bytes(sketch[d0 + i], t.x, t.y, t.z, t.w);
     }
     __syncthreads();
+  }
+}
+
+// slots mode: the values that did not fit their bucket, as full positions.  Test, then touch: a heavy hitter's bit is set
+// (its counter saturated) after the first few, the rest cost a load.
+template <bool COUNTERS>
+static __global__ __launch_bounds__(256) void bloom_overflow_apply_kernel(const uint64_t* __restrict__ ovf, const BloomStatus* status,
+                                                                          uint64_t ovf_cap, uint32_t* __restrict__ table)
+{
+  if (bloom_round_failed(status, ovf_cap)) return;
+  const uint64_t n = __builtin_nontemporal_load(&status->ovf_n);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p = ovf[i];
+    if constexpr (COUNTERS) {
+      uint32_t* const w = table + (p >> 2);
+      const uint32_t sh = ((uint32_t)p & 3u) * 8u;
+      uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (((old >> sh) & 0xFFu) != 0xFFu) {
+        const uint32_t seen = atomicCAS(w, old, old + (1u << sh));
+        if (seen == old) break;
+        old = seen;
+      }
+    } else {
+      uint32_t* const w = table + (p >> 5);
+      const uint32_t bit = 1u << ((uint32_t)p & 31u);
+      if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);
+    }
   }
 }
 

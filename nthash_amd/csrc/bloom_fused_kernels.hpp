@@ -9,6 +9,7 @@
 //   pass PART   every value goes straight from the registers into the first partition level: a tile is the 16 windows a
 //               thread has just rolled x the block's reads, sorted by bucket in LDS and appended run by run at the
 //               buckets' cursors -- bloom_part_kernel<IN64>'s tile, fed by the hash instead of by a load.
+// Slots mode (bloom_binned_kernels.hpp) needs no counts: pass PART alone, the reads hashed ONCE.
 // The second level and the apply kernels are bloom_binned_kernels.hpp's, unchanged: 16 B per value instead of 40.
 //
 // The counters (up to 128 KiB for a filter of 2^35 bits) and the sort buffer leave no room for first-window tables, so
@@ -46,6 +47,7 @@ struct BloomFusedArgs {
   uint32_t* out;
   uint32_t* cursor;
   uint32_t shift, mask, n_buckets;
+  BloomSlots sl;            // slots mode (sl.cap != 0; bloom_binned_kernels.hpp): bucket b owns out[b * cap ...), cursors count from 0
 };
 
 // THREADS reads per tile; dynamic LDS: bit stream | COUNT: n_regions counters / PART: THREADS * 16 sorted slots
@@ -207,10 +209,19 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
           for (uint32_t i = 0; i < 16; ++i)
             if (where[i] != ~0u) area[off[where[i] >> 16] + (where[i] & 0xFFFFu)] = val[i];
           __syncthreads();
+          const uint64_t slots_cap = a.sl.cap;
           for (uint32_t b = wave; b < a.n_buckets; b += THREADS / 64u) {
             const uint32_t cnt = hist[b], o = off[b];
-            uint32_t* const dst = a.out + gbase[b];
-            for (uint32_t q = lane; q < cnt; q += 64u) dst[q] = area[o + q];
+            if (slots_cap == 0) {
+              uint32_t* const dst = a.out + gbase[b];
+              for (uint32_t q = lane; q < cnt; q += 64u) dst[q] = area[o + q];
+            } else if (cnt) {
+              const uint64_t at = gbase[b];
+              const uint32_t fit = at >= slots_cap ? 0u : (slots_cap - at < cnt ? (uint32_t)(slots_cap - at) : cnt);
+              uint32_t* const dst = a.out + (uint64_t)b * slots_cap + at;
+              for (uint32_t q = lane; q < fit; q += 64u) dst[q] = area[o + q];
+              if (fit < cnt) bloom_overflow_run(a.sl, area + o, fit, cnt, (uint64_t)b << a.shift, lane);
+            }
           }
           __syncthreads();
         }
@@ -223,8 +234,9 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
       const uint32_t v = area[i];
       if (v) atomicAdd(&a.counts[i], v);
     }
-    if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
   }
+  // (slots mode has no pass COUNT: pass PART reports the non-base itself, apply sees it and leaves the table alone)
+  if (a.dirty && __ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
 }
 
 } // namespace ntamd

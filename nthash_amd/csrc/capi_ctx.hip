@@ -290,6 +290,8 @@ void load_tuning(nthip_tune& t)
   t.seed_roll = num("NTHIP_TUNE_SEED_ROLL", 1, 2);
   t.seed_roll_waves = num("NTHIP_TUNE_SEED_ROLL_WAVES", 2, 8);
   t.bloom_binned = num("NTHIP_TUNE_BLOOM_BINNED", 1, 2);
+  t.bloom_slots = num("NTHIP_TUNE_BLOOM_SLOTS", 1, 2);
+  t.bloom_slot_tight = num("NTHIP_TUNE_BLOOM_SLOT_TIGHT", 1, 2);
   t.bloom_round = num("NTHIP_TUNE_BLOOM_ROUND", 1024, 0x7FFFFFFF);
   t.pf_gbps = num("NTHIP_TUNE_PF_GBPS", 1, 100000);
   t.pf_lead_kb = num("NTHIP_TUNE_PF_LEAD_KB", 1, 1 << 22);

@@ -113,6 +113,8 @@ struct nthip_tune {
   uint32_t pf_gbps = 0, pf_lead_kb = 0, pf_chunk_kb = 0;
   uint32_t bloom_round = 0;  // NTHIP_TUNE_BLOOM_ROUND=<values>: rounds of the binned consumers no longer than this (tests: several rounds on a small batch)
   uint32_t bloom_fused = 0;  // NTHIP_TUNE_BLOOM_FUSED=1: the stream-less binned insert on every shape it can take, 2: never (A/B, tests)
+  uint32_t bloom_slots = 0;  // NTHIP_TUNE_BLOOM_SLOTS=1: slots mode (no histogram) whenever it applies, even after a failed round, 2: never (A/B, tests)
+  uint32_t bloom_slot_tight = 0; // NTHIP_TUNE_BLOOM_SLOT_TIGHT=1: buckets of the mean exactly (the overflow list in use), 2: of half the mean (rounds fail) -- tests
   uint32_t bloom_binned = 0; // NTHIP_TUNE_BLOOM_BINNED=1: the binned insert whenever the filter allows it, 2: never (A/B, tests)
   uint32_t seed_roll_waves = 0; // NTHIP_TUNE_SEED_ROLL_WAVES=2..8: waves per block of seed_roll_kernel (A/B)
   uint32_t seed_roll = 0;   // NTHIP_TUNE_SEED_ROLL=1: every dense seed batch the block-rolling kernel takes goes there, 2: none (A/B, tests)
@@ -142,6 +144,7 @@ struct nthip_ctx {
   // the binned Bloom insert's lists (capi_sink_bloom.hip): grow-only, released by nthip_ctx_trim / nthip_ctx_destroy
   uint8_t* bloom_tmp = nullptr;
   size_t bloom_tmp_bytes = 0;
+  uint32_t bloom_slots_backoff = 0; // calls of the binned consumers that keep to the exact lists (a slots-mode round failed)
   bool profiling = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;

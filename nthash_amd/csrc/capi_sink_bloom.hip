@@ -331,14 +331,228 @@ int bloom_binned_round(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n, uint3
   if (counters) {
     NTCHK(set_max_lds(c, count_apply_kernel, apply_lds));
     hipLaunchKernelGGL(count_apply_kernel, dim3(grid), dim3(BB_APPLY_THREADS), apply_lds, c->stream, entries,
-                       (const uint32_t*)t.region_base, n_regions, d_filter, filter_dwords);
+                       (const uint32_t*)t.region_base, n_regions, d_filter, filter_dwords, (uint64_t)0, (const uint32_t*)nullptr,
+                       (const BloomStatus*)nullptr, (uint64_t)0);
   } else {
     NTCHK(set_max_lds(c, bloom_apply_kernel, apply_lds));
     hipLaunchKernelGGL(bloom_apply_kernel, dim3(grid), dim3(BB_APPLY_THREADS), apply_lds, c->stream, entries,
-                       (const uint32_t*)t.region_base, n_regions, d_filter, filter_dwords);
+                       (const uint32_t*)t.region_base, n_regions, d_filter, filter_dwords, (uint64_t)0, (const uint32_t*)nullptr,
+                       (const BloomStatus*)nullptr, (uint64_t)0);
   }
   prof_end(c);
   HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+// ---- slots mode (bloom_binned_kernels.hpp): no histogram, every bucket owns mean + 8 sigma entries ----------------------
+constexpr uint64_t BB_SLOTS_ROUND_MAX = 0xF0000000ull; // values per round: a bucket's cursor is 32 bits
+constexpr uint32_t BB_SLOTS_BACKOFF = 16;              // calls that keep to the exact lists after a round failed
+
+struct SlotLists {
+  uint32_t *cur1 = nullptr, *cur2 = nullptr; // cursors of the bins / of the regions (filters of one bin: cur2 only)
+  uint32_t *list1 = nullptr, *list2 = nullptr;
+  uint64_t* ovf = nullptr;
+  BloomStatus* status = nullptr;
+  uint64_t cap1 = 0, cap2 = 0, ovf_cap = 0;
+  size_t head_bytes = 0; // status + cursors: zeroed before every round
+};
+// what a bucket of `bucket_slots` of the table's n_slots owns in a round of n values
+uint64_t slot_cap(const nthip_ctx* c, uint64_t n, uint64_t bucket_slots, uint64_t n_slots)
+{
+  const double mean = (double)n * (double)(bucket_slots < n_slots ? bucket_slots : n_slots) / (double)n_slots;
+  double cap = mean + 8.0 * std::sqrt(mean) + 256.0;
+  if (c->tune.bloom_slot_tight == 1) cap = mean;       // (tests: a few values of every bucket take the overflow list)
+  if (c->tune.bloom_slot_tight == 2) cap = mean * 0.5; // (tests: the overflow list overflows, the round fails)
+  return ((uint64_t)cap + 64u) & ~(uint64_t)63u;
+}
+bool bloom_slots_ok(nthip_ctx* c)
+{
+  if (c->tune.bloom_slots == 2) return false;
+  if (c->tune.bloom_slots == 1) return true;
+  if (c->bloom_slots_backoff) {
+    --c->bloom_slots_backoff;
+    return false;
+  }
+  return true;
+}
+// values per round of the slots mode: what the free memory allows (about 8.7 B per value), at most BB_SLOTS_ROUND_MAX
+uint64_t slots_round_values(const nthip_ctx* c, uint64_t n_values)
+{
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+  free_b += c->bloom_tmp_bytes;
+  uint64_t round = (uint64_t)(free_b / 2) / 9;
+  if (round > BB_SLOTS_ROUND_MAX) round = BB_SLOTS_ROUND_MAX;
+  if (round > n_values) round = n_values;
+  if (round < (1u << 20)) round = 1u << 20;
+  if (c->tune.bloom_round) round = c->tune.bloom_round;
+  return round;
+}
+// the lists of a round of n values; 1: the device does not have the memory (the caller keeps to the exact lists' rounds)
+int bloom_slot_lists(nthip_ctx* c, uint64_t n, uint64_t n_slots, bool counters, SlotLists* t)
+{
+  const uint32_t region_shift = counters ? CS_REGION_SHIFT : BB_REGION_SHIFT, bin_shift = region_shift + 7u;
+  const uint32_t n_regions = (uint32_t)((n_slots + (1ull << region_shift) - 1) >> region_shift);
+  const uint32_t n_bins = (n_regions + BB_REGIONS_PER_BIN - 1) / BB_REGIONS_PER_BIN;
+  t->cap1 = n_bins > 1 ? slot_cap(c, n, 1ull << bin_shift, n_slots) : 0;
+  t->cap2 = slot_cap(c, n, 1ull << region_shift, n_slots);
+  t->ovf_cap = n / 64 < 65536 ? 65536 : n / 64;
+  if (c->tune.bloom_slot_tight == 2) t->ovf_cap = 64;
+  const size_t head = (sizeof(BloomStatus) + 255) / 256 * 256 + (size_t)(n_bins + n_regions) * BB_CURSOR_STRIDE * sizeof(uint32_t);
+  const size_t head_al = (head + 255) & ~(size_t)255;
+  const size_t l1 = (size_t)n_bins * t->cap1 * 4, l2 = (size_t)n_regions * t->cap2 * 4;
+  const size_t need = head_al + l1 + l2 + (size_t)t->ovf_cap * 8;
+  if (c->bloom_tmp_bytes < need) {
+    if (c->bloom_tmp) HIPCHK(hipFree(c->bloom_tmp));
+    c->bloom_tmp = nullptr;
+    c->bloom_tmp_bytes = 0;
+    if (hipMalloc((void**)&c->bloom_tmp, need) != hipSuccess) {
+      (void)hipGetLastError();
+      c->bloom_tmp = nullptr;
+      return 1;
+    }
+    c->bloom_tmp_bytes = need;
+  }
+  t->status = (BloomStatus*)c->bloom_tmp;
+  t->cur1 = (uint32_t*)(c->bloom_tmp + (sizeof(BloomStatus) + 255) / 256 * 256);
+  t->cur2 = t->cur1 + (size_t)n_bins * BB_CURSOR_STRIDE;
+  t->head_bytes = head;
+  t->list1 = (uint32_t*)(c->bloom_tmp + head_al);
+  t->list2 = (uint32_t*)(c->bloom_tmp + head_al + l1);
+  t->ovf = (uint64_t*)(c->bloom_tmp + head_al + l1 + l2);
+  return NTHIP_OK;
+}
+
+// One round in slots mode: n values -- of the reads `fused` describes (hashed once, bloom_fused_kernels.hpp pass PART) or
+// of the stream d_hashes -- into the table.  *outcome: 0 done; 1 a read holds a non-base (fused only); 2 the overflow list
+// overflowed; 3 no memory for the lists.  After 1 / 2 / 3 the table is untouched: the caller redoes the round another way.
+int bloom_slots_round(nthip_ctx* c, const BloomFusedSrc* fused, const uint64_t* d_hashes, uint64_t n, uint32_t* d_table, uint64_t n_slots,
+                      bool counters, int* outcome)
+{
+  const uint32_t region_shift = counters ? CS_REGION_SHIFT : BB_REGION_SHIFT, bin_shift = region_shift + 7u;
+  const uint32_t n_regions = (uint32_t)((n_slots + (1ull << region_shift) - 1) >> region_shift);
+  const uint32_t n_bins = (n_regions + BB_REGIONS_PER_BIN - 1) / BB_REGIONS_PER_BIN;
+  const uint64_t magic = bloom_magic_of(n_slots);
+  const uint64_t table_dwords = counters ? (n_slots + 3) / 4 : (n_slots + 31) / 32;
+  SlotLists t;
+  {
+    const int rc = bloom_slot_lists(c, n, n_slots, counters, &t);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      *outcome = 3;
+      return NTHIP_OK;
+    }
+  }
+  HIPCHK(hipMemsetAsync(t.status, 0, t.head_bytes, c->stream));
+  prof_begin(c, fused ? (counters ? "count fused insert, slots (part, part, apply)" : "bloom fused insert, slots (part, part, apply)")
+                      : (counters ? "count binned insert, slots (part, part, apply)" : "bloom binned insert, slots (part, part, apply)"));
+  // level 1: to the bins (to the regions when the table is one bin)
+  const bool one = n_bins == 1;
+  const uint32_t shift1 = one ? region_shift : bin_shift, buckets1 = one ? n_regions : n_bins;
+  uint32_t* const out1 = one ? t.list2 : t.list1;
+  uint32_t* const cur_l1 = one ? t.cur2 : t.cur1;
+  const BloomSlots sl1 = {one ? t.cap2 : t.cap1, t.ovf, t.status, t.ovf_cap};
+  auto part_lds = [](uint32_t threads) { return (size_t)threads * BB_PART_ITEMS * (sizeof(uint32_t) + (BB_COPY_SLOT ? 1 : 0)); };
+  auto part_blocks = [&](uint32_t threads) { return (uint32_t)c->n_cu * (part_lds(threads) > 48 * 1024 ? 2u : 4u); };
+  if (fused) {
+    BloomFusedArgs fa;
+    bloom_fused_args(*fused, 1024u, n_slots, magic, &fa);
+    fa.dirty = &t.status->dirty;
+    fa.out = out1;
+    fa.cursor = cur_l1;
+    fa.shift = shift1;
+    fa.mask = (1u << shift1) - 1u;
+    fa.n_buckets = buckets1;
+    fa.sl = sl1;
+    const size_t lds = bloom_fused_lds(*fused, 1024u, 1024u * 16u);
+    NTCHK(set_max_lds(c, bloom_fused_kernel<BF_PART, 1024>, lds));
+    hipLaunchKernelGGL((bloom_fused_kernel<BF_PART, 1024>), dim3((unsigned)std::min<uint64_t>(fa.n_tiles, (uint64_t)c->n_cu)), dim3(1024), lds,
+                       c->stream, fa);
+  }
+  BloomPartArgs a;
+  memset(&a, 0, sizeof a);
+  a.n = n;
+  a.n_bits = n_slots;
+  a.magic = magic;
+  a.n_regions = n_regions;
+  if (!fused) {
+    a.in = d_hashes;
+    a.out = out1;
+    a.cursor = cur_l1;
+    a.shift = shift1;
+    a.mask = (1u << shift1) - 1u;
+    a.buckets_per_seg = buckets1;
+    a.sl = sl1;
+    NTCHK(set_max_lds(c, bloom_part_kernel<true, BB_L1_THREADS>, part_lds(BB_L1_THREADS)));
+    hipLaunchKernelGGL((bloom_part_kernel<true, BB_L1_THREADS>), dim3(part_blocks(BB_L1_THREADS)), dim3(BB_L1_THREADS),
+                       part_lds(BB_L1_THREADS), c->stream, a);
+  }
+  if (!one) { // level 2: every bin to its regions
+    a.in = t.list1;
+    a.out = t.list2;
+    a.cursor = t.cur2;
+    a.shift = region_shift;
+    a.mask = (1u << region_shift) - 1u;
+    a.buckets_per_seg = BB_REGIONS_PER_BIN;
+    a.sl = {t.cap2, t.ovf, t.status, t.ovf_cap};
+    a.cap_in = t.cap1;
+    a.seg_fill = t.cur1;
+    NTCHK(set_max_lds(c, bloom_part_kernel<false, BB_L2_THREADS>, part_lds(BB_L2_THREADS)));
+    const uint32_t per_bin = part_blocks(BB_L2_THREADS) / n_bins + 1u;
+    hipLaunchKernelGGL((bloom_part_kernel<false, BB_L2_THREADS>), dim3(per_bin, n_bins), dim3(BB_L2_THREADS), part_lds(BB_L2_THREADS),
+                       c->stream, a);
+  }
+  const size_t apply_lds = (size_t)BB_REGION_DWORDS * sizeof(uint32_t);
+  const uint32_t grid = n_regions < (uint32_t)c->n_cu ? n_regions : (uint32_t)c->n_cu;
+  if (counters) {
+    NTCHK(set_max_lds(c, count_apply_kernel, apply_lds));
+    hipLaunchKernelGGL(count_apply_kernel, dim3(grid), dim3(BB_APPLY_THREADS), apply_lds, c->stream, (const uint32_t*)t.list2,
+                       (const uint32_t*)nullptr, n_regions, d_table, table_dwords, t.cap2, (const uint32_t*)t.cur2,
+                       (const BloomStatus*)t.status, t.ovf_cap);
+    hipLaunchKernelGGL(bloom_overflow_apply_kernel<true>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)t.ovf,
+                       (const BloomStatus*)t.status, t.ovf_cap, d_table);
+  } else {
+    NTCHK(set_max_lds(c, bloom_apply_kernel, apply_lds));
+    hipLaunchKernelGGL(bloom_apply_kernel, dim3(grid), dim3(BB_APPLY_THREADS), apply_lds, c->stream, (const uint32_t*)t.list2,
+                       (const uint32_t*)nullptr, n_regions, d_table, table_dwords, t.cap2, (const uint32_t*)t.cur2,
+                       (const BloomStatus*)t.status, t.ovf_cap);
+    hipLaunchKernelGGL(bloom_overflow_apply_kernel<false>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)t.ovf,
+                       (const BloomStatus*)t.status, t.ovf_cap, d_table);
+  }
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_small + 64, t.status, sizeof(BloomStatus), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  BloomStatus st;
+  memcpy(&st, c->h_small + 64, sizeof st);
+  *outcome = st.dirty ? 1 : (st.ovf_n > t.ovf_cap ? 2 : 0);
+  if (*outcome == 2) c->bloom_slots_backoff = BB_SLOTS_BACKOFF;
+  return NTHIP_OK;
+}
+
+// Fixed-length reads on the device through slots-mode rounds: *r0 is advanced past every round that went through, *sum
+// by its k-mers; stops at the first round that did not (a non-base, skewed values, no memory) -- the caller takes the
+// reads from *r0 on through the exact lists / the stream.
+int fused_slots_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t m, uint32_t* d_table, uint64_t n_slots, bool counters,
+                       uint64_t* r0, uint64_t* sum)
+{
+  const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
+  const uint64_t per_read = (uint64_t)(len - k + 1) * m;
+  const uint64_t round = slots_round_values(c, (rd->n_reads - *r0) * per_read);
+  const uint64_t reads_per_round = round / per_read;
+  if (reads_per_round == 0) return NTHIP_OK;
+  while (*r0 < rd->n_reads) {
+    const uint64_t nr = rd->n_reads - *r0 < reads_per_round ? rd->n_reads - *r0 : reads_per_round;
+    const BloomFusedSrc src = {(const uint8_t*)rd->seqs + *r0 * stride, nr, len, stride, k, m};
+    int outcome = 0;
+    NTCHK(bloom_slots_round(c, &src, nullptr, nr * per_read, d_table, n_slots, counters, &outcome));
+    if (outcome) {
+      if (outcome == 1 && c->tune.bloom_slots != 1) c->bloom_slots_backoff = BB_SLOTS_BACKOFF; // (a FASTQ's batches all hold an N)
+      return NTHIP_OK;
+    }
+    *sum += nr * (uint64_t)(len - k + 1);
+    *r0 += nr;
+  }
   return NTHIP_OK;
 }
 
@@ -351,18 +565,28 @@ int run_kmer_bloom_binned(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8
 {
   const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
   const uint64_t per_read = (uint64_t)(len - k + 1) * m;
-  uint64_t round = bloom_round_values(c, rd->n_reads * per_read, true);
-  if (round < per_read) return 1; // (reads of more values than a round: the fused kernel)
+  uint64_t sum = 0, first = 0;
+  const uint32_t n_regions_all = (uint32_t)((n_bits + (1ull << BB_REGION_SHIFT) - 1) >> BB_REGION_SHIFT);
+  // round 4, later: slots mode -- the reads hashed once, no histogram (bloom_binned_kernels.hpp)
+  if (!(flags & NTHIP_HOST_INPUT) && bloom_fused_ok(c, {(const uint8_t*)rd->seqs, rd->n_reads, len, stride, k, m}, n_regions_all) &&
+      bloom_slots_ok(c))
+    NTCHK(fused_slots_rounds(c, rd, k, m, d_filter, n_bits, false, &first, &sum));
+  if (first == rd->n_reads) {
+    if (total_out) *total_out = sum;
+    return NTHIP_OK;
+  }
+  uint64_t round = bloom_round_values(c, (rd->n_reads - first) * per_read, true);
+  if (round < per_read) return first ? fail(NTHIP_ERR_UNSUPPORTED, "reads of more values than a round of the binned insert") : 1; // (1: the fused kernel)
   round = round / per_read * per_read;
   BloomLists t;
   {
     const int rc = bloom_lists(c, &round, true, &t);
-    if (rc) return rc; // (1: no memory for the lists -- the caller takes the fused kernel)
+    if (rc < 0 || (rc && !first)) return rc; // (1: no memory for the lists -- the caller takes the fused kernel)
+    if (rc) return fail(NTHIP_ERR_HIP, "no device memory for the lists of the binned insert");
   }
   const uint64_t reads_per_round = round / per_read;
-  if (reads_per_round == 0) return 1;
-  uint64_t sum = 0;
-  for (uint64_t r0 = 0; r0 < rd->n_reads; r0 += reads_per_round) {
+  if (reads_per_round == 0) return first ? fail(NTHIP_ERR_UNSUPPORTED, "reads too long for the binned insert's rounds") : 1;
+  for (uint64_t r0 = first; r0 < rd->n_reads; r0 += reads_per_round) {
     const uint64_t nr = rd->n_reads - r0 < reads_per_round ? rd->n_reads - r0 : reads_per_round;
     nthip_reads part = *rd;
     part.seqs = rd->seqs + r0 * stride;
@@ -654,7 +878,19 @@ extern "C" int nthip_kmer_count_insert(nthip_ctx* c, const nthip_reads* rd, uint
   const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
   if (rd->n_reads == 0 || len < k) return NTHIP_OK;
   const uint64_t per_read = (uint64_t)(len - k + 1) * m;
-  uint64_t round = bloom_round_values(c, rd->n_reads * per_read, true);
+  uint64_t sum = 0, first = 0;
+  {
+    // slots mode first (bloom_binned_kernels.hpp): the reads hashed once, no histogram
+    const uint32_t n_regions_all = (uint32_t)((n_counters + (1ull << CS_REGION_SHIFT) - 1) >> CS_REGION_SHIFT);
+    if (!(flags & NTHIP_HOST_INPUT) && stride >= len && bloom_binned_ok(c, d_counters, n_counters, rd->n_reads * per_read, true) &&
+        bloom_fused_ok(c, {(const uint8_t*)rd->seqs, rd->n_reads, len, stride, k, m}, n_regions_all) && bloom_slots_ok(c))
+      NTCHK(fused_slots_rounds(c, rd, k, m, (uint32_t*)d_counters, n_counters, true, &first, &sum));
+    if (first == rd->n_reads) {
+      if (total_out) *total_out = sum;
+      return NTHIP_OK;
+    }
+  }
+  uint64_t round = bloom_round_values(c, (rd->n_reads - first) * per_read, true);
   if (round < per_read) round = per_read;
   round = round / per_read * per_read;
   BloomLists t;
@@ -665,8 +901,7 @@ extern "C" int nthip_kmer_count_insert(nthip_ctx* c, const nthip_reads* rd, uint
   }
   const uint64_t reads_per_round = round / per_read;
   if (reads_per_round == 0) return fail(NTHIP_ERR_UNSUPPORTED, "reads too long for the counting sketch's rounds");
-  uint64_t sum = 0;
-  for (uint64_t r0 = 0; r0 < rd->n_reads; r0 += reads_per_round) {
+  for (uint64_t r0 = first; r0 < rd->n_reads; r0 += reads_per_round) {
     const uint64_t nr = rd->n_reads - r0 < reads_per_round ? rd->n_reads - r0 : reads_per_round;
     nthip_reads part = *rd;
     part.seqs = rd->seqs + r0 * stride;

@@ -35,12 +35,14 @@ for shape in clean dirty var; do
   for f in $(find "$OUT/trace_mz_$shape" -name "*kernel_stats.csv"); do cp "$f" "$OUT/kernel_stats_minimizers_$shape.csv"; done
   cat "$OUT/minimizer_${shape}_under_rocprof.txt"; head -6 "$OUT/kernel_stats_minimizers_$shape.csv" 2>/dev/null
 done
+if [ -z "${SKIP_PMC:-}" ]; then
 bash tools/run_pmc.sh "$OUT/pmc_c2" c2 20000000 > "$OUT/pmc_c2.log" 2>&1
 grep -v "^copy" "$OUT/pmc_c2/summary.txt"
 bash tools/run_pmc.sh "$OUT/pmc_c4" c4 8000000 > "$OUT/pmc_c4.log" 2>&1
 grep -v "^copy" "$OUT/pmc_c4/summary.txt"
 PMC_SQ_ONLY=1 bash tools/run_pmc.sh "$OUT/pmc_rag" rag 10000000 > "$OUT/pmc_rag.log" 2>&1
 grep -v "^copy" "$OUT/pmc_rag/summary.txt"
+fi
 # keep only small summaries in the merge-back
 find "$OUT" -name "*.db" -delete; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*_agent_info.csv" -delete
 du -sh "$OUT"
