@@ -1182,6 +1182,85 @@ def test_bloom_binned_insert_matches_oracle_hash_stream(oracle, n, L, k, m, n_bi
     ctx.close()
 
 
+@pytest.mark.parametrize("n,L,k,m,n_bits,n_cnt,dirty,knobs,expect", [
+    (3000, 150, 31, 1, 1 << 22, 1 << 16, False, {}, "slots"),                            # one bin: level 1 straight to the regions
+    (4000, 150, 31, 2, (1 << 28) + 12_345, (1 << 23) + 12_344, False, {}, "slots"),      # 3 bins, the last one partial: both levels
+    (1200, 150, 31, 3, (1 << 33) - 1_234_567, 1 << 26, False, {}, "slots"),              # 64 bins / 16 bins
+    (4000, 150, 31, 2, (1 << 28) + 12_345, (1 << 23) + 12_344, False, {"NTHIP_TUNE_BLOOM_SLOT_TIGHT": "1"}, "slots"),   # the overflow list in use
+    (3000, 150, 31, 1, 1 << 22, 1 << 16, False, {"NTHIP_TUNE_BLOOM_SLOT_TIGHT": "1"}, "slots"),
+    (4000, 150, 31, 2, (1 << 28) + 12_345, (1 << 23) + 12_344, False, {"NTHIP_TUNE_BLOOM_SLOT_TIGHT": "2"}, "fused insert ("),  # the round fails: exact lists
+    (4000, 150, 31, 2, (1 << 28) + 12_345, (1 << 23) + 12_344, False, {"NTHIP_TUNE_BLOOM_SLOTS": "2"}, "fused insert ("),      # never slots
+    (9000, 150, 31, 2, (1 << 28) + 77, 1 << 24, False, {"NTHIP_TUNE_BLOOM_ROUND": "300000"}, "slots"),                         # several rounds
+    (2500, 250, 31, 1, 1 << 30, 1 << 26, True, {}, "binned insert"),                     # reads with non-bases: the round goes through the stream
+    (700, 100, 64, 3, (1 << 20) + 32, 40_000, False, {"NTHIP_TUNE_BLOOM_FUSED": "1"}, "slots"),
+])
+def test_binned_insert_without_a_hash_stream(oracle, n, L, k, m, n_bits, n_cnt, dirty, knobs, expect):
+    """Device-resident fixed-length reads into a Bloom filter / a counting sketch through the lists, with no hash stream:
+    slots mode (every bucket owns mean + 8 sigma entries, the reads hashed once, what does not fit through the overflow list),
+    buckets of exactly the mean (the overflow list really used), of half the mean (the round fails, the table is untouched
+    and the exact lists -- count, scan, part, apply -- redo it), slots mode switched off, several rounds, reads with
+    non-bases.  The table the CPU builds from the oracle's hash stream, on tables that already hold something; low-complexity
+    reads (one value hundreds of times) included."""
+    import os
+    import nthash_amd
+    os.environ["NTHIP_TUNE_BLOOM_BINNED"] = "1"
+    os.environ.update(knobs)
+    try:
+        ctx = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_BLOOM_BINNED", None)
+        for key in knobs:
+            os.environ.pop(key, None)
+    rng = np.random.default_rng(n + L + m)
+    data = oracle.synth_reads(2, n, L, 99 + k).copy()
+    data[: 4 * L] = ord("A")                      # one k-mer ~500 times
+    data[5 * L: 6 * L] = data[4 * L: 5 * L]       # a duplicated read
+    if dirty:
+        bad = rng.choice(n * L, max(3, n * L // 500), replace=False)
+        data[bad] = np.frombuffer(b"NnRY-", dtype=np.uint8)[rng.integers(0, 5, bad.size)]
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    hs = np.ascontiguousarray(want["hashes"]).ravel()
+    d_in = ctx.malloc(n * L)
+    ctx.h2d(d_in, data)
+    # Bloom filter that already holds bits
+    nbytes = (n_bits + 31) // 32 * 4
+    prior = np.zeros(nbytes // 4, np.uint32)
+    prior[::7] = 0x80000001
+    d_f = ctx.malloc(nbytes)
+    ctx.h2d(d_f, prior)
+    ctx.set_profiling(True)
+    total = ctx.bloom_insert_ptr(d_in, n, L, 0, k, m, d_f, n_bits)
+    name = ctx.last_kernel_ms()[1]
+    assert expect in name and name.startswith("bloom"), name
+    assert total == want["total"]
+    pos = (hs % np.uint64(n_bits)).astype(np.int64)
+    exp = prior.copy()
+    np.bitwise_or.at(exp, pos >> 5, (np.uint32(1) << (pos & 31).astype(np.uint32)))
+    got = np.zeros(nbytes // 4, np.uint32)
+    ctx.d2h(got, d_f)
+    assert (got == exp).all(), (int((got != exp).sum()), "words differ")
+    ctx.free(d_f)
+    # counting sketch that already holds counts, some near the top
+    priorc = rng.integers(0, 4, n_cnt, dtype=np.int64)
+    priorc[::5] = 250
+    d_c = ctx.malloc(n_cnt)
+    ctx.h2d(d_c, priorc.astype(np.uint8))
+    total = ctx.count_insert_ptr(d_in, n, L, 0, k, m, d_c, n_cnt)
+    name = ctx.last_kernel_ms()[1]
+    assert expect in name and name.startswith("count"), name
+    assert total == want["total"]
+    tally = np.bincount((hs % np.uint64(n_cnt)).astype(np.int64), minlength=n_cnt).astype(np.int64)
+    expc = np.minimum(255, priorc + tally).astype(np.uint8)
+    gotc = np.zeros(n_cnt, np.uint8)
+    ctx.d2h(gotc, d_c)
+    assert (gotc == expc).all(), (int((gotc != expc).sum()), "counters differ")
+    assert expc.max() == 255
+    ctx.free(d_c)
+    ctx.free(d_in)
+    ctx.close()
+
+
 def _minimizers_brute(pos, hashes, nwin, w):
     """positions picked by the windows of w positions of one read (its emitted k-mers: pos ascending, one hash each)"""
     w = min(w, nwin)
