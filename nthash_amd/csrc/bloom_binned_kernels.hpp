@@ -75,8 +75,7 @@ constexpr uint32_t BB_REGION_DWORDS = 1u << (BB_REGION_SHIFT - 5);
 // table untouched, the host redoes the round on the exact lists and keeps to them for that table.
 struct BloomStatus {
   unsigned long long ovf_n; // values sent to the overflow list (those past ovf_cap were dropped: the round failed)
-  uint32_t dirty;           // the fused pass saw a non-base: the round's lists are garbage
-  uint32_t pad;
+  unsigned long long lost;  // fused pass: windows that hold a non-base (not emitted)
 };
 struct BloomSlots {
   uint64_t cap;             // entries per bucket of the level written (0: exact lists, absolute cursors)
@@ -86,7 +85,7 @@ struct BloomSlots {
 };
 __device__ __forceinline__ bool bloom_round_failed(const BloomStatus* st, uint64_t ovf_cap)
 {
-  return st && (__builtin_nontemporal_load(&st->dirty) != 0 || __builtin_nontemporal_load(&st->ovf_n) > ovf_cap);
+  return st && __builtin_nontemporal_load(&st->ovf_n) > ovf_cap;
 }
 // a wave appends the entries [fit, cnt) of a tile's bucket run to the overflow list as full positions
 __device__ __forceinline__ void bloom_overflow_run(const BloomSlots& sl, const uint32_t* run, uint32_t fit, uint32_t cnt, uint64_t bucket_pos,

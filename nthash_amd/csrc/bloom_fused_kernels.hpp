@@ -17,7 +17,11 @@
 // a window of virtual 'A's (f_init / r_init), every step one 16-entry pair-table lookup (next_forward_hash /
 // next_reverse_hash, src/kmer.cpp:84-94,164-174; the first window is what base_forward_hash / base_reverse_hash give,
 // src/kmer.cpp:43-73,123-152, reached by the roll).  len / (len - k + 1) rolls per k-mer: 1.25 for 150 bp reads.
-// A non-base anywhere sets a.dirty (pass COUNT): the caller takes the round through the N-aware stream path instead.
+// Non-bases (round 4, later): the staging loop marks the READS that hold one (a bit per read of the tile); the thread of
+// such a read -- one in a thousand on real data -- fetches its own bytes again, keeps the number of bases since the last
+// non-base and emits a window only when that reaches k (NtHash::roll, src/kmer.cpp:228-264: windows with a non-base are
+// skipped); the garbage code of a non-base enters and leaves the rolled state identically, so every emitted value is
+// exact.  The windows not emitted are counted in *a.lost (pass PART).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -31,7 +35,7 @@ enum : int { BF_COUNT = 0, BF_PART = 1 };
 
 struct BloomFusedArgs {
   const uint8_t* seqs;      // fixed-length reads, stride bytes apart
-  uint32_t* dirty;          // set when a non-base is seen
+  unsigned long long* lost; // pass PART: += windows that hold a non-base (not emitted)
   uint64_t n_reads;
   uint32_t len, stride, k, m;
   uint32_t pad_dwords;      // front pad of the LDS bit stream: ceil(k / 16) + 1 words of virtual 'A'
@@ -57,6 +61,7 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   __shared__ __attribute__((aligned(16))) uint4 tab[16];
   __shared__ uint32_t hist[BB_MAX_BINS], off[BB_MAX_BINS], gbase[BB_MAX_BINS];
+  __shared__ uint32_t rflag[THREADS / 32u]; // reads of the tile that hold a non-base
   const uint32_t k = a.k, m = a.m;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   // the bit stream of a tile: pad + slab (THREADS reads) + two spare words
@@ -74,7 +79,8 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
   const uint32_t kmod = (k - 1u) & 15u;
   const uint32_t jb = (k - 1u) >> 4;          // the word that holds the first emitting step
   const uint32_t n_words = (a.len + 15u) >> 4;
-  uint32_t bad = 0;
+  const uint32_t nwin = a.len - k + 1u;
+  uint32_t lost = 0;
 
   for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
     const uint64_t run0 = (uint64_t)t * THREADS;
@@ -88,23 +94,27 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
     const uint32_t slab_bytes = (runs_here - 1u) * a.stride + a.len;
     const uint32_t n_vec = (shift + slab_bytes + 15u) >> 4;
     __syncthreads(); // the tile before is consumed; pad / tab / counters are there on the first pass
+    if (tid < THREADS / 32u) rflag[tid] = 0;
+    __syncthreads();
     for (uint32_t i = tid; i < n_vec; i += THREADS) {
       const uint4 v = vsrc[i];
       uint32_t b = 0;
       const uint32_t p = pack16(v, b);
-      const int32_t lo_cut = (int32_t)shift - (int32_t)(i << 4);
-      const int32_t hi_cut = (int32_t)(shift + slab_bytes) - (int32_t)(i << 4);
-      if (lo_cut > 0 || hi_cut < 16) {
+      if (b) { // (rare) whose non-bases?  Bytes outside the slab and between the reads are nobody's
         uint32_t bx[4] = {0, 0, 0, 0};
         (void)pack4(v.x, bx[0]);
         (void)pack4(v.y, bx[1]);
         (void)pack4(v.z, bx[2]);
         (void)pack4(v.w, bx[3]);
-        b = 0;
         for (int q = 0; q < 16; ++q)
-          if (q >= lo_cut && q < hi_cut) b |= (bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+          if ((bx[q >> 2] >> ((q & 3) * 8)) & 0xFFu) {
+            const int32_t at = (int32_t)(i << 4) + q - (int32_t)shift;
+            if (at >= 0 && at < (int32_t)slab_bytes) {
+              const uint32_t r = (uint32_t)at / a.stride;
+              if ((uint32_t)at - r * a.stride < a.len) atomicOr(&rflag[r >> 5], 1u << (r & 31u));
+            }
+          }
       }
-      bad |= b;
       bits[a.pad_dwords + i] = p;
     }
     if (tid < 2) bits[a.pad_dwords + n_vec + tid] = 0; // funnels read one word ahead
@@ -120,6 +130,10 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
     uint32_t f_lo = (uint32_t)a.f_init, f_hi = (uint32_t)(a.f_init >> 32);
     uint32_t r_lo = (uint32_t)a.r_init, r_hi = (uint32_t)(a.r_init >> 32);
     uint32_t in_lo = bits[in_d], out_lo = bits[out_d];
+    const bool dirty_me = live && ((rflag[lrun >> 5] >> (lrun & 31u)) & 1u);
+    const uint8_t* const my_read = a.seqs + (run0 + lrun) * a.stride;
+    uint32_t since = 0;                   // bases since the read's last non-base (dirty_me only)
+    if (dirty_me) lost += nwin;           // (what it does emit is taken off below)
 
     for (uint32_t j = 0; j < n_words; ++j) {
       const uint32_t in_hi = bits[in_d + j + 1], out_hi = bits[out_d + j + 1];
@@ -153,12 +167,26 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
         sror_pair(r_lo, r_hi);
         h[i] = canon_pair(f_lo, f_hi, r_lo, r_hi);
       }
+      // the steps of this word that emit: all of [lo, hi) for a read of bases only
+      uint32_t emask = live ? ((0xFFFFu >> (16u - hi)) & (0xFFFFu << lo)) & 0xFFFFu : 0u;
+      if (dirty_me) {
+        uint32_t ok = 0;
+        const uint32_t here = a.len - s0 < 16u ? a.len - s0 : 16u;
+        for (uint32_t i = 0; i < here; ++i) {
+          uint32_t bb = 0;
+          (void)pack4((uint32_t)my_read[s0 + i] * 0x01010101u, bb);
+          since = bb ? 0u : since + 1u;
+          if (since >= k) ok |= 1u << i;
+        }
+        emask &= ok;
+        if (lo < hi) lost -= (uint32_t)__builtin_popcount(emask);
+      }
       if (lo >= hi) continue; // (no window ends in this word: uniform)
       for (uint32_t jj = 0; jj < m; ++jj) { // the k-mers' m values (extend_hashes, src/internal.hpp:104-118), one set at a time
         if constexpr (PASS == BF_COUNT) {
 #pragma unroll
           for (uint32_t i = 0; i < 16; ++i)
-            if (live && i >= lo && i < hi) {
+            if ((emask >> i) & 1u) {
               const uint64_t val = jj == 0 ? h[i] : mix_hash(h[i], a.mult[jj & (KF_MAX_RUNTIME_M - 1)]);
               atomicAdd(&area[(uint32_t)(mod_invariant(val, a.n_bits, a.magic) >> a.region_shift)], 1u);
             }
@@ -171,7 +199,7 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
           for (uint32_t i = 0; i < 16; ++i) {
             where[i] = ~0u;
             val[i] = 0;
-            if (live && i >= lo && i < hi) {
+            if ((emask >> i) & 1u) {
               const uint64_t hv = jj == 0 ? h[i] : mix_hash(h[i], a.mult[jj & (KF_MAX_RUNTIME_M - 1)]);
               const uint64_t p = mod_invariant(hv, a.n_bits, a.magic);
               const uint32_t b = (uint32_t)(p >> a.shift);
@@ -235,8 +263,12 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
       if (v) atomicAdd(&a.counts[i], v);
     }
   }
-  // (slots mode has no pass COUNT: pass PART reports the non-base itself, apply sees it and leaves the table alone)
-  if (a.dirty && __ballot(bad != 0) != 0 && lane == 0) atomicOr(a.dirty, 1u);
+  if constexpr (PASS == BF_PART) {
+    if (__ballot(lost != 0) != 0) {
+      for (int d = 32; d > 0; d >>= 1) lost += (uint32_t)__shfl_xor((int)lost, d, 64);
+      if (lane == 0 && a.lost) atomicAdd(a.lost, (unsigned long long)lost);
+    }
+  }
 }
 
 } // namespace ntamd

@@ -213,17 +213,15 @@ void bloom_fused_args(const BloomFusedSrc& s, uint32_t threads, uint64_t n_bits,
   a->n_bits = n_bits;
   a->magic = magic;
 }
-// pass COUNT: t.counts := values per region; *dirty: a read of the round holds a non-base (the caller takes the stream path)
-int bloom_fused_count(nthip_ctx* c, const BloomFusedSrc& s, uint64_t n_bits, const BloomLists& t, bool counters, bool* dirty)
+// pass COUNT: t.counts := values per region (launch only)
+int bloom_fused_count(nthip_ctx* c, const BloomFusedSrc& s, uint64_t n_bits, const BloomLists& t, bool counters)
 {
   const uint32_t region_shift = counters ? CS_REGION_SHIFT : BB_REGION_SHIFT;
   const uint32_t n_regions = (uint32_t)((n_bits + (1ull << region_shift) - 1) >> region_shift);
   HIPCHK(hipMemsetAsync(t.counts, 0, (size_t)n_regions * sizeof(uint32_t), c->stream));
-  HIPCHK(hipMemsetAsync(c->d_small, 0, 4, c->stream));
   const uint32_t threads = n_regions > 16384u ? BF_COUNT_THREADS_BIG : 1024u;
   BloomFusedArgs a;
   bloom_fused_args(s, threads, n_bits, bloom_magic_of(n_bits), &a);
-  a.dirty = (uint32_t*)c->d_small;
   a.counts = t.counts;
   a.n_regions = n_regions;
   a.region_shift = region_shift;
@@ -238,11 +236,15 @@ int bloom_fused_count(nthip_ctx* c, const BloomFusedSrc& s, uint64_t n_bits, con
     hipLaunchKernelGGL((bloom_fused_kernel<BF_COUNT, BF_COUNT_THREADS_BIG>), dim3(grid), dim3(BF_COUNT_THREADS_BIG), lds, c->stream, a);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(c->h_small, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
+  return NTHIP_OK;
+}
+// the windows the fused pass PART of the exact lists did not emit: zeroed before the round, read after it (synchronises)
+int bloom_fused_lost_reset(nthip_ctx* c) { HIPCHK(hipMemsetAsync(c->d_small + 48, 0, 8, c->stream)); return NTHIP_OK; }
+int bloom_fused_lost_read(nthip_ctx* c, uint64_t* lost)
+{
+  HIPCHK(hipMemcpyAsync(c->h_small + 48, c->d_small + 48, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  uint32_t d = 0;
-  memcpy(&d, c->h_small, 4);
-  *dirty = d != 0;
+  memcpy(lost, c->h_small + 48, 8);
   return NTHIP_OK;
 }
 
@@ -269,6 +271,7 @@ int bloom_binned_round(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n, uint3
   auto fused_level1 = [&](uint32_t* out, uint32_t* cursor, uint32_t shift, uint32_t n_buckets) -> int {
     BloomFusedArgs fa;
     bloom_fused_args(*fused, 1024u, n_bits, magic, &fa);
+    fa.lost = (unsigned long long*)(c->d_small + 48);
     fa.out = out;
     fa.cursor = cursor;
     fa.shift = shift;
@@ -423,11 +426,12 @@ int bloom_slot_lists(nthip_ctx* c, uint64_t n, uint64_t n_slots, bool counters, 
   return NTHIP_OK;
 }
 
-// One round in slots mode: n values -- of the reads `fused` describes (hashed once, bloom_fused_kernels.hpp pass PART) or
-// of the stream d_hashes -- into the table.  *outcome: 0 done; 1 a read holds a non-base (fused only); 2 the overflow list
-// overflowed; 3 no memory for the lists.  After 1 / 2 / 3 the table is untouched: the caller redoes the round another way.
+// One round in slots mode: n values -- of the reads `fused` describes (hashed once, bloom_fused_kernels.hpp pass PART; n = what
+// they hold when no window is lost, *lost = the windows with a non-base) or of the stream d_hashes -- into the table.
+// *outcome: 0 done; 2 the overflow list overflowed; 3 no memory for the lists.  After 2 / 3 the table is untouched: the
+// caller redoes the round on the exact lists.
 int bloom_slots_round(nthip_ctx* c, const BloomFusedSrc* fused, const uint64_t* d_hashes, uint64_t n, uint32_t* d_table, uint64_t n_slots,
-                      bool counters, int* outcome)
+                      bool counters, int* outcome, uint64_t* lost = nullptr)
 {
   const uint32_t region_shift = counters ? CS_REGION_SHIFT : BB_REGION_SHIFT, bin_shift = region_shift + 7u;
   const uint32_t n_regions = (uint32_t)((n_slots + (1ull << region_shift) - 1) >> region_shift);
@@ -457,7 +461,7 @@ int bloom_slots_round(nthip_ctx* c, const BloomFusedSrc* fused, const uint64_t* 
   if (fused) {
     BloomFusedArgs fa;
     bloom_fused_args(*fused, 1024u, n_slots, magic, &fa);
-    fa.dirty = &t.status->dirty;
+    fa.lost = &t.status->lost;
     fa.out = out1;
     fa.cursor = cur_l1;
     fa.shift = shift1;
@@ -525,14 +529,15 @@ int bloom_slots_round(nthip_ctx* c, const BloomFusedSrc* fused, const uint64_t* 
   HIPCHK(hipStreamSynchronize(c->stream));
   BloomStatus st;
   memcpy(&st, c->h_small + 64, sizeof st);
-  *outcome = st.dirty ? 1 : (st.ovf_n > t.ovf_cap ? 2 : 0);
+  *outcome = st.ovf_n > t.ovf_cap ? 2 : 0;
   if (*outcome == 2) c->bloom_slots_backoff = BB_SLOTS_BACKOFF;
+  if (lost) *lost = st.lost;
   return NTHIP_OK;
 }
 
 // Fixed-length reads on the device through slots-mode rounds: *r0 is advanced past every round that went through, *sum
-// by its k-mers; stops at the first round that did not (a non-base, skewed values, no memory) -- the caller takes the
-// reads from *r0 on through the exact lists / the stream.
+// by its k-mers; stops at the first round that did not (skewed values, no memory) -- the caller takes the reads from *r0 on
+// through the exact lists.
 int fused_slots_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t m, uint32_t* d_table, uint64_t n_slots, bool counters,
                        uint64_t* r0, uint64_t* sum)
 {
@@ -545,13 +550,31 @@ int fused_slots_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t
     const uint64_t nr = rd->n_reads - *r0 < reads_per_round ? rd->n_reads - *r0 : reads_per_round;
     const BloomFusedSrc src = {(const uint8_t*)rd->seqs + *r0 * stride, nr, len, stride, k, m};
     int outcome = 0;
-    NTCHK(bloom_slots_round(c, &src, nullptr, nr * per_read, d_table, n_slots, counters, &outcome));
-    if (outcome) {
-      if (outcome == 1 && c->tune.bloom_slots != 1) c->bloom_slots_backoff = BB_SLOTS_BACKOFF; // (a FASTQ's batches all hold an N)
-      return NTHIP_OK;
-    }
-    *sum += nr * (uint64_t)(len - k + 1);
+    uint64_t lost = 0;
+    NTCHK(bloom_slots_round(c, &src, nullptr, nr * per_read, d_table, n_slots, counters, &outcome, &lost));
+    if (outcome) return NTHIP_OK;
+    *sum += nr * (uint64_t)(len - k + 1) - lost;
     *r0 += nr;
+  }
+  return NTHIP_OK;
+}
+
+// A device-resident hash stream through slots-mode rounds (the stream must not live in the context's list buffer):
+// *done = the values that went through; the caller takes the rest through the exact lists.
+int stream_slots_rounds(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, uint32_t* d_table, uint64_t n_slots, bool counters,
+                        uint64_t* done)
+{
+  *done = 0;
+  const uint8_t* const h0 = (const uint8_t*)d_hashes;
+  if (c->bloom_tmp && h0 < c->bloom_tmp + c->bloom_tmp_bytes && h0 + n_values * 8 > c->bloom_tmp) return NTHIP_OK;
+  if (!bloom_slots_ok(c)) return NTHIP_OK;
+  const uint64_t round = slots_round_values(c, n_values);
+  while (*done < n_values) {
+    const uint64_t nn = n_values - *done < round ? n_values - *done : round;
+    int outcome = 0;
+    NTCHK(bloom_slots_round(c, nullptr, d_hashes + *done, nn, d_table, n_slots, counters, &outcome));
+    if (outcome) break;
+    *done += nn;
   }
   return NTHIP_OK;
 }
@@ -596,14 +619,14 @@ int run_kmer_bloom_binned(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8
     const BloomFusedSrc src = {(const uint8_t*)part.seqs, nr, len, stride, k, m};
     const uint32_t n_regions = (uint32_t)((n_bits + (1ull << BB_REGION_SHIFT) - 1) >> BB_REGION_SHIFT);
     if (!(flags & NTHIP_HOST_INPUT) && bloom_fused_ok(c, src, n_regions)) {
-      bool dirty = false;
-      NTCHK(bloom_fused_count(c, src, n_bits, t, false, &dirty));
-      if (!dirty) {
-        const uint64_t total = nr * (uint64_t)(len - k + 1);
-        NTCHK(bloom_binned_round(c, nullptr, total * m, d_filter, n_bits, t, false, &src));
-        sum += total;
-        continue;
-      }
+      uint64_t lost = 0;
+      NTCHK(bloom_fused_lost_reset(c));
+      NTCHK(bloom_fused_count(c, src, n_bits, t, false));
+      const uint64_t total = nr * (uint64_t)(len - k + 1);
+      NTCHK(bloom_binned_round(c, nullptr, total * m, d_filter, n_bits, t, false, &src));
+      NTCHK(bloom_fused_lost_read(c, &lost));
+      sum += total - lost;
+      continue;
     }
     nthip_out out;
     memset(&out, 0, sizeof out);
@@ -751,6 +774,11 @@ extern "C" int nthip_stream_bloom_insert(nthip_ctx* c, const uint64_t* d_hashes,
   HIPCHK(hipSetDevice(c->device));
   if (n_values == 0) return NTHIP_OK;
   if (bloom_binned_ok(c, d_filter, n_bits, n_values)) {
+    uint64_t done = 0;
+    NTCHK(stream_slots_rounds(c, d_hashes, n_values, (uint32_t*)d_filter, n_bits, false, &done));
+    if (done == n_values) return NTHIP_OK;
+    d_hashes += done;
+    n_values -= done;
     uint64_t round = bloom_round_values(c, n_values, false);
     BloomLists t;
     const int lrc = bloom_lists(c, &round, false, &t);
@@ -784,6 +812,13 @@ int count_insert_stream(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_value
 {
   if (n_values == 0) return NTHIP_OK;
   if (bloom_binned_ok(c, d_counters, n_counters, n_values, true)) {
+    if (!have) {
+      uint64_t done = 0;
+      NTCHK(stream_slots_rounds(c, d_hashes, n_values, d_counters, n_counters, true, &done));
+      if (done == n_values) return NTHIP_OK;
+      d_hashes += done;
+      n_values -= done;
+    }
     BloomLists t;
     uint64_t round = n_values;
     int lrc = 0;
@@ -912,13 +947,13 @@ extern "C" int nthip_kmer_count_insert(nthip_ctx* c, const nthip_reads* rd, uint
     const uint64_t dense = nr * (uint64_t)(len - k + 1);
     if (!(flags & NTHIP_HOST_INPUT) && stride >= len && bloom_binned_ok(c, d_counters, n_counters, dense * m, true) &&
         bloom_fused_ok(c, src, n_regions)) {
-      bool dirty = false;
-      NTCHK(bloom_fused_count(c, src, n_counters, t, true, &dirty));
-      if (!dirty) {
-        NTCHK(bloom_binned_round(c, nullptr, dense * m, (uint32_t*)d_counters, n_counters, t, true, &src));
-        sum += dense;
-        continue;
-      }
+      uint64_t lost = 0;
+      NTCHK(bloom_fused_lost_reset(c));
+      NTCHK(bloom_fused_count(c, src, n_counters, t, true));
+      NTCHK(bloom_binned_round(c, nullptr, dense * m, (uint32_t*)d_counters, n_counters, t, true, &src));
+      NTCHK(bloom_fused_lost_read(c, &lost));
+      sum += dense - lost;
+      continue;
     }
     nthip_out out;
     memset(&out, 0, sizeof out);

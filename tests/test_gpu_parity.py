@@ -1191,7 +1191,9 @@ def test_bloom_binned_insert_matches_oracle_hash_stream(oracle, n, L, k, m, n_bi
     (4000, 150, 31, 2, (1 << 28) + 12_345, (1 << 23) + 12_344, False, {"NTHIP_TUNE_BLOOM_SLOT_TIGHT": "2"}, "fused insert ("),  # the round fails: exact lists
     (4000, 150, 31, 2, (1 << 28) + 12_345, (1 << 23) + 12_344, False, {"NTHIP_TUNE_BLOOM_SLOTS": "2"}, "fused insert ("),      # never slots
     (9000, 150, 31, 2, (1 << 28) + 77, 1 << 24, False, {"NTHIP_TUNE_BLOOM_ROUND": "300000"}, "slots"),                         # several rounds
-    (2500, 250, 31, 1, 1 << 30, 1 << 26, True, {}, "binned insert"),                     # reads with non-bases: the round goes through the stream
+    (2500, 250, 31, 1, 1 << 30, 1 << 26, True, {}, "slots"),                             # reads with non-bases: their threads count the bases since the last one
+    (3000, 150, 31, 4, 4_000_037, 4_000_036, True, {"NTHIP_TUNE_BLOOM_SLOTS": "2"}, "fused insert ("),   # the same on the exact lists (both passes)
+    (3000, 151, 25, 2, 1 << 24, 1 << 20, True, {"NTHIP_TUNE_BLOOM_ROUND": "200000"}, "slots"),
     (700, 100, 64, 3, (1 << 20) + 32, 40_000, False, {"NTHIP_TUNE_BLOOM_FUSED": "1"}, "slots"),
 ])
 def test_binned_insert_without_a_hash_stream(oracle, n, L, k, m, n_bits, n_cnt, dirty, knobs, expect):
@@ -1199,8 +1201,8 @@ def test_binned_insert_without_a_hash_stream(oracle, n, L, k, m, n_bits, n_cnt, 
     slots mode (every bucket owns mean + 8 sigma entries, the reads hashed once, what does not fit through the overflow list),
     buckets of exactly the mean (the overflow list really used), of half the mean (the round fails, the table is untouched
     and the exact lists -- count, scan, part, apply -- redo it), slots mode switched off, several rounds, reads with
-    non-bases.  The table the CPU builds from the oracle's hash stream, on tables that already hold something; low-complexity
-    reads (one value hundreds of times) included."""
+    non-bases (the fused pass skips their windows itself, in both modes).  The table the CPU builds from the oracle's hash
+    stream, on tables that already hold something; low-complexity reads (one value hundreds of times) included."""
     import os
     import nthash_amd
     os.environ["NTHIP_TUNE_BLOOM_BINNED"] = "1"
@@ -1218,6 +1220,10 @@ def test_binned_insert_without_a_hash_stream(oracle, n, L, k, m, n_bits, n_cnt, 
     if dirty:
         bad = rng.choice(n * L, max(3, n * L // 500), replace=False)
         data[bad] = np.frombuffer(b"NnRY-", dtype=np.uint8)[rng.integers(0, 5, bad.size)]
+        data[7 * L] = ord("N")                    # a read's first base, another's last, a read of non-bases, two neighbours
+        data[9 * L - 1] = ord("n")
+        data[10 * L: 11 * L] = ord("N")
+        data[12 * L - 1] = data[12 * L] = ord("-")
     offs = np.arange(n + 1, dtype=np.uint64) * L
     want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
     hs = np.ascontiguousarray(want["hashes"]).ravel()
