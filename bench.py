@@ -536,8 +536,8 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
         out["bloom_insert_fresh_4GiB"] = {"value": tot / t_ins, "ms": t_ins * 1e3, "check": "every inserted k-mer is found",
                                           "ok": bool(tot == kmers and tq == kmers and found == kmers),
                                           "roofline": roof(in_bytes + 2 * (n_bits // 8), t_ins, "bases in + the filter read and written once",
-                                                           "binned insert without a hash stream (round 4): the reads are hashed twice -- regions "
-                                                           "counted in LDS, first partition level from the registers --, second level, apply: "
+                                                           "binned insert without a hash stream or a histogram (round 4, slots mode): the reads are hashed ONCE -- "
+                                                           "first partition level from the registers into buckets of mean + 8 sigma entries --, second level, apply: "
                                                            "16 B of list traffic per value (DESIGN 4.8); the kernel named brackets all of them")}
         ctx.free(d_f)
         owned.remove(d_f)

@@ -2679,6 +2679,16 @@ def test_fixed_length_batches_with_non_bases_every_way(oracle, knob):
             assert got["total"] == want[which]["total"], (which, n, L)
             assert (got["hashes"][:got["total"]] == want[which]["hashes"][:got["total"]]).all(), (which, n, L)
             assert (got["counts"] == want[which]["counts"]).all()
+        if n == 70001:   # device-resident reads that start off a 16-byte boundary
+            for shift in (5, 16):
+                d_in, d_out = c.malloc(n * L + 64), c.malloc(n * (L - k + 1) * 8)
+                c.h2d(d_in + shift, dirty)
+                tot = c.kmer_hash_ptr(d_in + shift, 0, n, L, 0, k, 1, d_out, n * (L - k + 1))
+                assert tot == want["dirty"]["total"]
+                got_h = np.zeros(tot, np.uint64)
+                c.d2h(got_h, d_out)
+                assert (got_h == want["dirty"]["hashes"].ravel()[:tot]).all()
+                c.free(d_in); c.free(d_out)
 
 
 def test_seed_rolled_run_by_run_vs_oracle(oracle):
