@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "bloom_math.hpp"
 
@@ -218,6 +219,22 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
   const uint64_t slots_cap = a.sl.cap;
   uint32_t* const cursor = a.cursor + (size_t)seg * a.buckets_per_seg * BB_CURSOR_STRIDE;
   const uint64_t n_tiles = (s1 - s0 + BB_TILE - 1) / BB_TILE;
+  // The values of the NEXT tile are asked for as soon as this tile's are ranked and arrive while it is scanned, sorted and
+  // copied out (the barriers wait for LDS only): a block used to sit 12 of a tile's 19 us in front of its loads -- the
+  // queueing delay of a memory system that every block had just filled at once (per-phase clocks of one block,
+  // profiles/r04_notes.md 2c).
+  typedef typename std::conditional<IN64, uint64_t, uint32_t>::type in_t;
+  in_t pre[BB_PART_ITEMS];
+  auto fetch = [&](uint64_t tile) {
+    const uint64_t t0 = s0 + tile * BB_TILE;
+#pragma unroll
+    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+      const uint64_t idx = t0 + (uint64_t)j * BB_PART_THREADS + tid;
+      pre[j] = 0;
+      if (idx < s1) pre[j] = __builtin_nontemporal_load((const in_t*)a.in + idx);
+    }
+  };
+  if (blockIdx.x < n_tiles) fetch(blockIdx.x);
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     if (tid < BB_MAX_BINS) hist[tid] = 0;
     __syncthreads();
@@ -230,13 +247,14 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
       val[j] = 0;
       if (idx < s1) {
         uint64_t p;
-        if constexpr (IN64) p = mod_invariant(__builtin_nontemporal_load((const uint64_t*)a.in + idx), a.n_bits, a.magic);
-        else p = __builtin_nontemporal_load((const uint32_t*)a.in + idx);
+        if constexpr (IN64) p = mod_invariant(pre[j], a.n_bits, a.magic);
+        else p = pre[j];
         const uint32_t b = (uint32_t)(p >> a.shift);
         val[j] = (uint32_t)p & a.mask;
         where[j] = (b << 16) | atomicAdd(&hist[b], 1u); // (a tile has 8192 values: the rank fits 16 bits)
       }
     }
+    if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
     __syncthreads();
     if (wave == 0) { // exclusive scan of the (at most 256) bucket counts: 4 per lane
       uint32_t c[4], s = 0;
