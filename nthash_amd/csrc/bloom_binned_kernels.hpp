@@ -41,6 +41,9 @@ constexpr uint32_t BB_MAX_BINS = 256;
 #ifndef BB_ABL
 #define BB_ABL 0
 #endif
+#ifndef BB_TIMING
+#define BB_TIMING 0 // 1: one block of the second level prints the phase times of its tiles (-DBB_TIMING=1 build, tools/ab_build.sh)
+#endif
 #ifndef BB_COPY_SLOT
 #define BB_COPY_SLOT 0
 #endif
@@ -99,6 +102,58 @@ __device__ __forceinline__ void bloom_overflow_run(const BloomSlots& sl, const u
   for (uint32_t q = fit + lane; q < cnt; q += 64u) {
     const unsigned long long idx = base + (q - fit);
     if (idx < sl.ovf_cap) sl.ovf[idx] = bucket_pos | run[q];
+  }
+}
+
+// The copy-out of a sorted tile: wave w takes the buckets w, w + NW, w + 2 NW, ...  A lane holds the count, the place in the
+// tile and the place in the list of ONE of them (three LDS reads per wave instead of three per bucket), the loop takes
+// them back with v_readlane, four buckets at a time -- their first 128 entries read from LDS before the first store is
+// issued.  (One bucket after the other, every LDS read waited for: 4.8 of a tile's 10 us on the second level.)
+// exact lists: gbase = the run's place in `out`; slots mode: relative to bucket (bucket0 + b)'s own cap entries.
+template <uint32_t NW>
+__device__ __forceinline__ void bloom_copy_out(const uint32_t* sorted, const uint32_t* hist, const uint32_t* off, const uint32_t* gbase,
+                                               uint32_t n_buckets, uint32_t wave, uint32_t lane, uint32_t* out, uint64_t bucket0,
+                                               const BloomSlots& sl, uint32_t shift)
+{
+  static_assert(NW >= 4, "at most 64 buckets per wave");
+  const uint32_t myb = wave + lane * NW;
+  uint32_t mc = 0, mo = 0, mg = 0;
+  if (myb < n_buckets) {
+    mc = hist[myb];
+    mo = off[myb];
+    mg = gbase[myb];
+  }
+  const uint32_t n_mine = n_buckets > wave ? (n_buckets - wave + NW - 1u) / NW : 0u;
+  const uint64_t cap = sl.cap;
+  for (uint32_t i0 = 0; i0 < n_mine; i0 += 4u) {
+    uint32_t c[4], o[4], fit[4], v0[4], v1[4];
+    uint32_t* dst[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t i = i0 + u < n_mine ? i0 + u : i0;
+      c[u] = i0 + u < n_mine ? (uint32_t)__builtin_amdgcn_readlane((int)mc, (int)i) : 0u;
+      o[u] = (uint32_t)__builtin_amdgcn_readlane((int)mo, (int)i);
+      const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)mg, (int)i);
+      if (cap == 0) {
+        fit[u] = c[u];
+        dst[u] = out + at;
+      } else {
+        fit[u] = at >= cap ? 0u : (cap - at < c[u] ? (uint32_t)(cap - at) : c[u]);
+        dst[u] = out + (bucket0 + wave + (uint64_t)i * NW) * cap + at;
+      }
+      v0[u] = lane < fit[u] ? sorted[o[u] + lane] : 0u;
+      v1[u] = lane + 64u < fit[u] ? sorted[o[u] + 64u + lane] : 0u;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      if (lane < fit[u]) dst[u][lane] = v0[u];
+      if (lane + 64u < fit[u]) dst[u][lane + 64u] = v1[u];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) { // (rare: a bucket with more than 128 of the tile's values, a bucket that is full)
+      for (uint32_t j = lane + 128u; j < fit[u]; j += 64u) dst[u][j] = sorted[o[u] + j];
+      if (fit[u] < c[u]) bloom_overflow_run(sl, sorted + o[u], fit[u], c[u], (bucket0 + wave + (uint64_t)(i0 + u) * NW) << shift, lane);
+    }
   }
 }
 
@@ -216,7 +271,6 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
     }
     n_buckets = r1 - r0;
   }
-  const uint64_t slots_cap = a.sl.cap;
   uint32_t* const cursor = a.cursor + (size_t)seg * a.buckets_per_seg * BB_CURSOR_STRIDE;
   const uint64_t n_tiles = (s1 - s0 + BB_TILE - 1) / BB_TILE;
   // The values of the NEXT tile are asked for as soon as this tile's are ranked and arrive while it is scanned, sorted and
@@ -236,6 +290,9 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
   };
   if (blockIdx.x < n_tiles) fetch(blockIdx.x);
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#if BB_TIMING
+    const uint64_t tk0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (tid < BB_MAX_BINS) hist[tid] = 0;
     __syncthreads();
     const uint64_t t0 = s0 + tile * BB_TILE;
@@ -256,6 +313,9 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
     }
     if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
     __syncthreads();
+#if BB_TIMING
+    const uint64_t tk1 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (wave == 0) { // exclusive scan of the (at most 256) bucket counts: 4 per lane
       uint32_t c[4], s = 0;
 #pragma unroll
@@ -289,6 +349,9 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
 #endif
     }
     __syncthreads();
+#if BB_TIMING
+    const uint64_t tk2 = __builtin_amdgcn_s_memrealtime();
+#endif
 #if BB_COPY_SLOT
     // copy-out a slot per lane: slot i of the sorted tile goes to its bucket's run (the bucket of a slot: one byte each)
     uint8_t* const sbin = (uint8_t*)(sorted + BB_TILE);
@@ -312,25 +375,26 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
     for (uint32_t j = 0; j < BB_PART_ITEMS; ++j)
       if (where[j] != ~0u) sorted[off[where[j] >> 16] + (where[j] & 0xFFFFu)] = val[j];
     __syncthreads();
+#if BB_TIMING
+    const uint64_t tk3 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if BB_ABL == 1 // ablation (WRONG results): everything but the stores
     for (uint32_t b = wave; b < n_buckets; b += BB_PART_THREADS / 64u) {
       const uint32_t c = hist[b], o = off[b];
-#if BB_ABL == 1 // ablation (WRONG results): everything but the stores
       uint32_t* const dst = a.out + gbase[b];
       for (uint32_t j = lane; j < c; j += 64u) asm volatile("" ::"v"(sorted[o + j]), "v"(dst));
-#else
-      if (slots_cap == 0) {
-        uint32_t* const dst = a.out + gbase[b];
-        for (uint32_t j = lane; j < c; j += 64u) dst[j] = sorted[o + j];
-      } else if (c) {
-        const uint64_t g = (uint64_t)seg * a.buckets_per_seg + b, at = gbase[b];
-        const uint32_t fit = at >= slots_cap ? 0u : (slots_cap - at < c ? (uint32_t)(slots_cap - at) : c);
-        uint32_t* const dst = a.out + g * slots_cap + at;
-        for (uint32_t j = lane; j < fit; j += 64u) dst[j] = sorted[o + j];
-        if (fit < c) bloom_overflow_run(a.sl, sorted + o, fit, c, g << a.shift, lane);
-      }
-#endif
     }
+#else
+    bloom_copy_out<BB_PART_THREADS / 64u>(sorted, hist, off, gbase, n_buckets, wave, lane, a.out, (uint64_t)seg * a.buckets_per_seg, a.sl, a.shift);
+#endif
     __syncthreads();
+#if BB_TIMING
+    if (!IN64 && tid == 0 && blockIdx.x == 2u && blockIdx.y == 3u && tile < 100) {
+      const uint64_t tk4 = __builtin_amdgcn_s_memrealtime();
+      printf("tile %u: wait + rank %u  scan + cursors %u  sort %u  copy-out %u  (10 ns)\n", (unsigned)tile, (unsigned)(tk1 - tk0),
+             (unsigned)(tk2 - tk1), (unsigned)(tk3 - tk2), (unsigned)(tk4 - tk3));
+    }
+#endif
 #endif
   }
 }

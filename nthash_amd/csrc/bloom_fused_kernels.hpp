@@ -237,20 +237,7 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
           for (uint32_t i = 0; i < 16; ++i)
             if (where[i] != ~0u) area[off[where[i] >> 16] + (where[i] & 0xFFFFu)] = val[i];
           __syncthreads();
-          const uint64_t slots_cap = a.sl.cap;
-          for (uint32_t b = wave; b < a.n_buckets; b += THREADS / 64u) {
-            const uint32_t cnt = hist[b], o = off[b];
-            if (slots_cap == 0) {
-              uint32_t* const dst = a.out + gbase[b];
-              for (uint32_t q = lane; q < cnt; q += 64u) dst[q] = area[o + q];
-            } else if (cnt) {
-              const uint64_t at = gbase[b];
-              const uint32_t fit = at >= slots_cap ? 0u : (slots_cap - at < cnt ? (uint32_t)(slots_cap - at) : cnt);
-              uint32_t* const dst = a.out + (uint64_t)b * slots_cap + at;
-              for (uint32_t q = lane; q < fit; q += 64u) dst[q] = area[o + q];
-              if (fit < cnt) bloom_overflow_run(a.sl, area + o, fit, cnt, (uint64_t)b << a.shift, lane);
-            }
-          }
+          bloom_copy_out<THREADS / 64u>(area, hist, off, gbase, a.n_buckets, wave, lane, a.out, 0ull, a.sl, a.shift);
           __syncthreads();
         }
       }
