@@ -62,6 +62,7 @@ constexpr uint32_t BB_PART_ITEMS = BB_PART_ITEMS_N; // values per thread and til
 #define BB_L2_THREADS 512
 #endif
 constexpr uint32_t BB_APPLY_THREADS = 1024;
+constexpr uint32_t BB_APPLY_BATCH = 6; // 16-byte loads of the region's entries a thread has in flight
 constexpr uint32_t BB_REGION_DWORDS = 1u << (BB_REGION_SHIFT - 5);
 #ifndef BB_CURSOR_STRIDE
 #define BB_CURSOR_STRIDE 32u // dwords between two cursors: one cache line each (tiles of every block hit the same few
@@ -435,12 +436,23 @@ static __global__ __launch_bounds__(BB_APPLY_THREADS) void bloom_apply_kernel(co
     if (a1 > a0) {
       const bb_v4u* v = (const bb_v4u*)(entries + a0);
       const uint32_t nv = (a1 - a0) >> 2;
-      for (uint32_t i = threadIdx.x; i < nv; i += BB_APPLY_THREADS) {
-        const bb_v4u q = __builtin_nontemporal_load(v + i);
-        put(q.x);
-        put(q.y);
-        put(q.z);
-        put(q.w);
+      // BB_APPLY_BATCH loads in flight per thread (one block per CU and nobody to wait behind: one load at a time was a
+      // round trip to HBM per 16 bytes -- 18 in a row per region)
+      for (uint32_t i0 = threadIdx.x; i0 < nv; i0 += BB_APPLY_BATCH * BB_APPLY_THREADS) {
+        bb_v4u q[BB_APPLY_BATCH];
+#pragma unroll
+        for (uint32_t u = 0; u < BB_APPLY_BATCH; ++u) {
+          const uint32_t i = i0 + u * BB_APPLY_THREADS;
+          q[u] = __builtin_nontemporal_load(v + (i < nv ? i : i0));
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < BB_APPLY_BATCH; ++u)
+          if (i0 + u * BB_APPLY_THREADS < nv) {
+            put(q[u].x);
+            put(q[u].y);
+            put(q[u].z);
+            put(q[u].w);
+          }
       }
     }
     if (a1 >= a0 && threadIdx.x < e1 - a1) put(entries[a1 + threadIdx.x]);
@@ -450,16 +462,40 @@ static __global__ __launch_bounds__(BB_APPLY_THREADS) void bloom_apply_kernel(co
     const uint64_t left = filter_dwords - d0;
     const uint32_t here = left < BB_REGION_DWORDS ? (uint32_t)left : BB_REGION_DWORDS;
     uint4* const f4 = (uint4*)(filter + d0); // (regions start on 128 KiB of a 16-byte aligned filter -- see the host side)
-    for (uint32_t i = threadIdx.x; i < here / 4u; i += BB_APPLY_THREADS) {
-      const uint4 v = l4[i];
-      if (v.x | v.y | v.z | v.w) {
-        uint4 g = f4[i];
-        g.x |= v.x;
-        g.y |= v.y;
-        g.z |= v.z;
-        g.w |= v.w;
-        f4[i] = g;
+    for (uint32_t i0 = threadIdx.x; i0 < here / 4u; i0 += 4u * BB_APPLY_THREADS) { // (four read-modify-writes in flight)
+      uint4 v[4], g[4];
+      bool every = true;
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + u * BB_APPLY_THREADS;
+        v[u] = i < here / 4u ? l4[i] : make_uint4(0, 0, 0, 0);
+        every = every && (v[u].x | v[u].y | v[u].z | v[u].w) != 0u;
       }
+      if (__ballot(!every) == 0ull) { // every vector of the wave's four rows got a bit (a batch that is dense in the filter):
+#pragma unroll                      // no branch between the loads and the stores, so no wait between the stores either
+        for (uint32_t u = 0; u < 4; ++u) g[u] = f4[i0 + u * BB_APPLY_THREADS];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          g[u].x |= v[u].x;
+          g[u].y |= v[u].y;
+          g[u].z |= v[u].z;
+          g[u].w |= v[u].w;
+          f4[i0 + u * BB_APPLY_THREADS] = g[u];
+        }
+        continue;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u)
+        if (v[u].x | v[u].y | v[u].z | v[u].w) g[u] = f4[i0 + u * BB_APPLY_THREADS];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u)
+        if (v[u].x | v[u].y | v[u].z | v[u].w) {
+          g[u].x |= v[u].x;
+          g[u].y |= v[u].y;
+          g[u].z |= v[u].z;
+          g[u].w |= v[u].w;
+          f4[i0 + u * BB_APPLY_THREADS] = g[u];
+        }
     }
     for (uint32_t i = (here & ~3u) + threadIdx.x; i < here; i += BB_APPLY_THREADS) // (a filter that does not end on 16 bytes)
       if (bb_lds[i]) filter[d0 + i] |= bb_lds[i];
@@ -514,12 +550,23 @@ static __global__ __launch_bounds__(BB_APPLY_THREADS) void count_apply_kernel(co
     if (a1 > a0) {
       const bb_v4u* v = (const bb_v4u*)(entries + a0);
       const uint32_t nv = (a1 - a0) >> 2;
-      for (uint32_t i = threadIdx.x; i < nv; i += BB_APPLY_THREADS) {
-        const bb_v4u q = __builtin_nontemporal_load(v + i);
-        put(q.x);
-        put(q.y);
-        put(q.z);
-        put(q.w);
+      // BB_APPLY_BATCH loads in flight per thread (one block per CU and nobody to wait behind: one load at a time was a
+      // round trip to HBM per 16 bytes -- 18 in a row per region)
+      for (uint32_t i0 = threadIdx.x; i0 < nv; i0 += BB_APPLY_BATCH * BB_APPLY_THREADS) {
+        bb_v4u q[BB_APPLY_BATCH];
+#pragma unroll
+        for (uint32_t u = 0; u < BB_APPLY_BATCH; ++u) {
+          const uint32_t i = i0 + u * BB_APPLY_THREADS;
+          q[u] = __builtin_nontemporal_load(v + (i < nv ? i : i0));
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < BB_APPLY_BATCH; ++u)
+          if (i0 + u * BB_APPLY_THREADS < nv) {
+            put(q[u].x);
+            put(q[u].y);
+            put(q[u].z);
+            put(q[u].w);
+          }
       }
     }
     if (a1 >= a0 && threadIdx.x < e1 - a1) put(entries[a1 + threadIdx.x]);
@@ -527,9 +574,29 @@ static __global__ __launch_bounds__(BB_APPLY_THREADS) void count_apply_kernel(co
     const uint64_t d0 = (uint64_t)r * (SLOTS / 4u); // the region's first dword of the sketch
     const uint64_t left = sketch_dwords - d0;
     const uint32_t here = left < SLOTS / 4u ? (uint32_t)left : SLOTS / 4u;
-    for (uint32_t i = threadIdx.x; i < here; i += BB_APPLY_THREADS) {
-      const uint4 t = l4[i];
-      if (t.x | t.y | t.z | t.w) sketch[d0 + i] = sat_add_bytes(sketch[d0 + i], t.x, t.y, t.z, t.w);
+    for (uint32_t i0 = threadIdx.x; i0 < here; i0 += 4u * BB_APPLY_THREADS) { // (four read-modify-writes in flight)
+      uint4 t[4];
+      uint32_t w[4];
+      bool every = true;
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + u * BB_APPLY_THREADS;
+        t[u] = i < here ? l4[i] : make_uint4(0, 0, 0, 0);
+        every = every && (t[u].x | t[u].y | t[u].z | t[u].w) != 0u;
+      }
+      if (__ballot(!every) == 0ull) { // (every dword of the wave's four rows got a count: no branch, no wait between the stores)
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) w[u] = sketch[d0 + i0 + u * BB_APPLY_THREADS];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) sketch[d0 + i0 + u * BB_APPLY_THREADS] = sat_add_bytes(w[u], t[u].x, t[u].y, t[u].z, t[u].w);
+        continue;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u)
+        if (t[u].x | t[u].y | t[u].z | t[u].w) w[u] = sketch[d0 + i0 + u * BB_APPLY_THREADS];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u)
+        if (t[u].x | t[u].y | t[u].z | t[u].w) sketch[d0 + i0 + u * BB_APPLY_THREADS] = sat_add_bytes(w[u], t[u].x, t[u].y, t[u].z, t[u].w);
     }
     __syncthreads();
   }
