@@ -13,6 +13,7 @@ names = {  # scratch name -> tracked name
     "minimizers.txt": f"{tag}_minimizers.txt",
     "bloom_bench.txt": f"{tag}_bloom_bench.txt",
     "minhash_bench.txt": f"{tag}_minhash_bench.txt",
+    "bloom_one.txt": f"{tag}_bloom_one.txt",
     "seed_sweep.txt": f"{tag}_seed_sweep.txt",
     "seed_sweep_long.txt": f"{tag}_seed_sweep_long.txt",
     "seed_roll_sweep.txt": f"{tag}_seed_roll_sweep.txt",

@@ -10,6 +10,9 @@ timeout 3000 bash tools/profile_round.sh "$TAG" > "$OUT/profile_round.log" 2>&1
 # consumers, whole calls
 { for s in clean dirty var; do timeout 300 python tools/minimizer_bench.py 20000000 0 $s; done; } > "$OUT/minimizers.txt" 2>&1
 { timeout 300 python tools/bloom_bench.py 20000000 1; timeout 300 python tools/bloom_bench.py 20000000 3; timeout 300 python tools/count_bench.py 20000000 1; } > "$OUT/bloom_bench.txt" 2>&1
+{ timeout 300 python tools/bloom_one.py 20000000 0 3; timeout 300 python tools/bloom_one.py 20000000 1 3; } > "$OUT/bloom_one.txt" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bloom_one" -o kt -- python tools/bloom_one.py 20000000 0 3 > /dev/null 2>&1
+for f in $(find "$OUT/trace_bloom_one" -name "*kernel_stats.csv"); do cp "$f" "$OUT/kernel_stats_bloom_one.csv"; done
 timeout 300 python tools/minhash_bench.py > "$OUT/minhash_bench.txt" 2>&1
 # the record-form minimizer kernel under the counters (SQ groups)
 MZ_W=10 PMC_SQ_ONLY=1 timeout 1200 bash tools/run_pmc.sh "$OUT/pmc_mzw" mz 20000000 > "$OUT/pmc_mzw.log" 2>&1
