@@ -317,6 +317,12 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
 #if BB_TIMING
     const uint64_t tk1 = __builtin_amdgcn_s_memrealtime();
 #endif
+    uint32_t my_base = 0;
+    if (tid < n_buckets) {
+      const uint32_t c = hist[tid];
+      // (the answer is wanted by the copy-out only: it travels while the tile is sorted)
+      my_base = c ? atomicAdd(&cursor[(size_t)tid * BB_CURSOR_STRIDE], c) : 0u;
+    }
     if (wave == 0) { // exclusive scan of the (at most 256) bucket counts: 4 per lane
       uint32_t c[4], s = 0;
 #pragma unroll
@@ -337,18 +343,6 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
         run += c[i];
       }
     }
-    if (tid < n_buckets) {
-      const uint32_t c = hist[tid];
-#if BB_ABL == 2 // ablation (WRONG results): no cursor atomics, the tile's runs go out back to back
-      gbase[tid] = (uint32_t)(t0 - s0) + off[tid] + (IN64 ? 0u : (uint32_t)s0);
-      (void)cursor;
-#elif BB_ABL == 3 // ablation (WRONG results): every run starts on a 64-byte piece and is whole pieces long
-      gbase[tid] = c ? (atomicAdd(&cursor[(size_t)tid * BB_CURSOR_STRIDE], c) & ~15u) : 0u;
-      hist[tid] = c & ~15u;
-#else
-      gbase[tid] = c ? atomicAdd(&cursor[(size_t)tid * BB_CURSOR_STRIDE], c) : 0u;
-#endif
-    }
     __syncthreads();
 #if BB_TIMING
     const uint64_t tk2 = __builtin_amdgcn_s_memrealtime();
@@ -363,6 +357,7 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
         sorted[slot] = val[j];
         sbin[slot] = (uint8_t)(where[j] >> 16);
       }
+    if (tid < n_buckets) gbase[tid] = my_base;
     __syncthreads();
     const uint64_t left = s1 - t0;
     const uint32_t n_here = left < BB_TILE ? (uint32_t)left : BB_TILE;
@@ -375,6 +370,7 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
 #pragma unroll
     for (uint32_t j = 0; j < BB_PART_ITEMS; ++j)
       if (where[j] != ~0u) sorted[off[where[j] >> 16] + (where[j] & 0xFFFFu)] = val[j];
+    if (tid < n_buckets) gbase[tid] = my_base;
     __syncthreads();
 #if BB_TIMING
     const uint64_t tk3 = __builtin_amdgcn_s_memrealtime();

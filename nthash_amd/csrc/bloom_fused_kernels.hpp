@@ -208,6 +208,11 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
             }
           }
           __syncthreads();
+          uint32_t my_base = 0; // (the cursor's answer is wanted by the copy-out only: it travels while the tile is sorted)
+          if (tid < a.n_buckets) {
+            const uint32_t cnt = hist[tid];
+            my_base = cnt ? atomicAdd(&a.cursor[(size_t)tid * BB_CURSOR_STRIDE], cnt) : 0u;
+          }
           if (wave == 0) { // exclusive scan of the (at most 256) bucket counts: 4 per lane
             uint32_t cc[4], s = 0;
 #pragma unroll
@@ -228,14 +233,11 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
               run += cc[i];
             }
           }
-          if (tid < a.n_buckets) {
-            const uint32_t cnt = hist[tid];
-            gbase[tid] = cnt ? atomicAdd(&a.cursor[(size_t)tid * BB_CURSOR_STRIDE], cnt) : 0u;
-          }
           __syncthreads();
 #pragma unroll
           for (uint32_t i = 0; i < 16; ++i)
             if (where[i] != ~0u) area[off[where[i] >> 16] + (where[i] & 0xFFFFu)] = val[i];
+          if (tid < a.n_buckets) gbase[tid] = my_base;
           __syncthreads();
           bloom_copy_out<THREADS / 64u>(area, hist, off, gbase, a.n_buckets, wave, lane, a.out, 0ull, a.sl, a.shift);
           __syncthreads();
