@@ -298,18 +298,32 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
     __syncthreads();
     const uint64_t t0 = s0 + tile * BB_TILE;
     uint32_t val[BB_PART_ITEMS], where[BB_PART_ITEMS]; // where = bucket << 16 | rank inside the tile's bucket
+    if (t0 + BB_TILE <= s1) {
+      // a whole tile (all but a segment's last): no branch per value, so the thread's 16 LDS atomics are in flight together
+      // (behind `if (idx < s1)` each one was waited for: an s_waitcnt lgkmcnt(0) per value in the ISA)
 #pragma unroll
-    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
-      const uint64_t idx = t0 + (uint64_t)j * BB_PART_THREADS + tid;
-      where[j] = ~0u;
-      val[j] = 0;
-      if (idx < s1) {
+      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
         uint64_t p;
         if constexpr (IN64) p = mod_invariant(pre[j], a.n_bits, a.magic);
         else p = pre[j];
         const uint32_t b = (uint32_t)(p >> a.shift);
         val[j] = (uint32_t)p & a.mask;
-        where[j] = (b << 16) | atomicAdd(&hist[b], 1u); // (a tile has 8192 values: the rank fits 16 bits)
+        where[j] = (b << 16) | atomicAdd(&hist[b], 1u); // (a tile has at most 16 Ki values: the rank fits 16 bits)
+      }
+    } else {
+#pragma unroll
+      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+        const uint64_t idx = t0 + (uint64_t)j * BB_PART_THREADS + tid;
+        where[j] = ~0u;
+        val[j] = 0;
+        if (idx < s1) {
+          uint64_t p;
+          if constexpr (IN64) p = mod_invariant(pre[j], a.n_bits, a.magic);
+          else p = pre[j];
+          const uint32_t b = (uint32_t)(p >> a.shift);
+          val[j] = (uint32_t)p & a.mask;
+          where[j] = (b << 16) | atomicAdd(&hist[b], 1u);
+        }
       }
     }
     if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
