@@ -16,9 +16,11 @@
 //            that got a bit are read, OR-ed and written back -- plain loads and stores, the region has one owner
 //
 // Every byte moves in whole runs: 8 + (8 + 4) + (4 + 4) + 4 B per value plus one read-modify-write of the touched
-// filter lines per batch.  Exact counts: no capacity guesses, no overflow path, repeated values (low-complexity
-// sequence) only make one region's list longer.  Filters of at most 2^35 bits (32768 regions: the histogram's LDS);
-// larger ones and batches too small to amortise the filter pass keep the atomic kernels.
+// filter lines per batch.  These EXACT lists (round 3) guess no capacity and have no overflow path: repeated values
+// (low-complexity sequence) only make one region's list longer.  Round 4 put SLOTS MODE in front of them (below: no hist,
+// no scan, buckets of mean + 8 sigma entries and an overflow list); the exact lists are what a round falls back to when
+// its values are too skewed for that.  Filters of at most 2^35 bits (32768 regions: the histogram's LDS); larger ones and
+// batches too small to amortise the filter pass keep the atomic kernels.
 #pragma once
 
 #include <hip/hip_runtime.h>
