@@ -290,6 +290,7 @@ void load_tuning(nthip_tune& t)
   t.seed_roll = num("NTHIP_TUNE_SEED_ROLL", 1, 2);
   t.seed_roll_waves = num("NTHIP_TUNE_SEED_ROLL_WAVES", 2, 8);
   t.bloom_binned = num("NTHIP_TUNE_BLOOM_BINNED", 1, 2);
+  t.no_tiles_flag = is_one("NTHIP_TUNE_NO_TILES_FLAG");
   t.bloom_slots = num("NTHIP_TUNE_BLOOM_SLOTS", 1, 2);
   t.bloom_slot_tight = num("NTHIP_TUNE_BLOOM_SLOT_TIGHT", 1, 2);
   t.bloom_round = num("NTHIP_TUNE_BLOOM_ROUND", 1024, 0x7FFFFFFF);

@@ -113,6 +113,7 @@ struct nthip_tune {
   uint32_t pf_gbps = 0, pf_lead_kb = 0, pf_chunk_kb = 0;
   uint32_t bloom_round = 0;  // NTHIP_TUNE_BLOOM_ROUND=<values>: rounds of the binned consumers no longer than this (tests: several rounds on a small batch)
   uint32_t bloom_fused = 0;  // NTHIP_TUNE_BLOOM_FUSED=1: the stream-less binned insert on every shape it can take, 2: never (A/B, tests)
+  bool no_tiles_flag = false; // NTHIP_TUNE_NO_TILES_FLAG=1: the count pass of run_kmer_na_special tile by tile (A/B, tests)
   uint32_t bloom_slots = 0;  // NTHIP_TUNE_BLOOM_SLOTS=1: slots mode (no histogram) whenever it applies, even after a failed round, 2: never (A/B, tests)
   uint32_t bloom_slot_tight = 0; // NTHIP_TUNE_BLOOM_SLOT_TIGHT=1: buckets of the mean exactly (the overflow list in use), 2: of half the mean (rounds fail) -- tests
   uint32_t bloom_binned = 0; // NTHIP_TUNE_BLOOM_BINNED=1: the binned insert whenever the filter allows it, 2: never (A/B, tests)

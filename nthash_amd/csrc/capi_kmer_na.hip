@@ -95,7 +95,7 @@ int ntamd::host::run_kmer_na_special(nthip_ctx* c, const Staged& st, const nthip
   const uint64_t nt = a.n_wtiles;
   if (nt != ra0.n_wtiles || plan.lds + (size_t)plan.waves * 128 > lds_cap_of(c) + 512) return NTHIP_OK;
   const uint64_t nb = (nt + SCAN_TILE - 1) / SCAN_TILE;
-  NTCHK(ensure_scratch(c, 3 * nt + nb + 16));
+  NTCHK(ensure_scratch(c, 3 * nt + nb + 16 + (nt + 63) / 64 + 2)); // (+ a bit per tile: the count pass's flags)
   a.tile_counts = c->d_scratch;
   uint64_t* d_off = c->d_scratch + nt;
   uint64_t* d_list = c->d_scratch + 2 * nt;
@@ -112,11 +112,27 @@ int ntamd::host::run_kmer_na_special(nthip_ctx* c, const Staged& st, const nthip
     while (ca.waves > 1 && (size_t)ca.waves * ca.vbits_dwords * 4 + 64 > 150 * 1024) ca.waves /= 2;
     const size_t lds = (size_t)ca.waves * ca.vbits_dwords * 4 + 64;
     int per_cu = 1;
-    NTCHK(blocks_per_cu(c, kmer_runs_count_kernel<false>, (int)ca.waves * 64, lds, &per_cu));
-    const uint64_t need = (ca.n_wtiles + ca.waves - 1) / ca.waves;
-    uint64_t grid = (uint64_t)c->n_cu * per_cu;
-    if (grid > need) grid = need;
-    hipLaunchKernelGGL(kmer_runs_count_kernel<false>, dim3((unsigned)grid), dim3(ca.waves * 64), lds, c->stream, ca);
+    // tiles of whole reads lying back to back: flag the tiles with a non-base in one sweep over the batch's vectors, count
+    // only those (kmer_runs_gen_kernel.hpp); the flags live behind the scan's sums in the scratch
+    const bool flagged = stride == len && 64u % q.g.rpr == 0u && !c->tune.no_tiles_flag;
+    if (flagged) {
+      uint32_t* const d_flags = (uint32_t*)(c->d_scratch + 3 * nt + nb + 16);
+      const size_t flag_words = (size_t)((nt + 31) / 32) + 1;
+      HIPCHK(hipMemsetAsync(d_flags, 0, flag_words * 4, c->stream));
+      hipLaunchKernelGGL(tiles_flag_kernel, dim3((unsigned)c->n_cu * 8), dim3(256), 0, c->stream, (const uint8_t*)ca.seqs, ca.total_bytes,
+                         (uint32_t)(64u / q.g.rpr) * stride, d_flags);
+      NTCHK(blocks_per_cu(c, tiles_count_flagged_kernel, (int)ca.waves * 64, lds, &per_cu));
+      const uint64_t need = ((ca.n_wtiles + 63) / 64 + ca.waves - 1) / ca.waves;
+      uint64_t grid = (uint64_t)c->n_cu * per_cu;
+      if (grid > need) grid = need;
+      hipLaunchKernelGGL(tiles_count_flagged_kernel, dim3((unsigned)grid), dim3(ca.waves * 64), lds, c->stream, ca, (const uint32_t*)d_flags);
+    } else {
+      NTCHK(blocks_per_cu(c, kmer_runs_count_kernel<false>, (int)ca.waves * 64, lds, &per_cu));
+      const uint64_t need = (ca.n_wtiles + ca.waves - 1) / ca.waves;
+      uint64_t grid = (uint64_t)c->n_cu * per_cu;
+      if (grid > need) grid = need;
+      hipLaunchKernelGGL(kmer_runs_count_kernel<false>, dim3((unsigned)grid), dim3(ca.waves * 64), lds, c->stream, ca);
+    }
     HIPCHK(hipGetLastError());
   }
   NTCHK(device_exclusive_scan(c, a.tile_counts, d_off, nt, d_sums, d_total));

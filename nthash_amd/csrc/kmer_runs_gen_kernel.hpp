@@ -1103,83 +1103,169 @@ static __global__ __launch_bounds__(256) void stream_bloom_insert_kernel(const u
 // hundred bytes of LDS per wave, so the CU runs at full occupancy and the pass
 // streams the reads at close to HBM read rate.  Same geometry and the same window
 // masks as the hash pass.
+// one tile of the count pass: a.tile_counts[wt] = the windows of tile wt without a non-base (and the reads' counts)
+template <bool PK>
+__device__ __forceinline__ void count_one_tile(const KmerRunsGenArgs& a, const RunShape& shape, uint64_t wt, uint16_t* vbits, uint32_t lane)
+{
+  const uint32_t k = a.k, C = a.C, rpr = a.rpr;
+  const uint64_t g0 = wt * 64u;
+  const uint64_t rf = g0 / rpr;
+  const uint32_t rm = (uint32_t)(g0 - rf * rpr);
+  const TileGeo g = tile_geo(shape, PK ? 0ull : (uint64_t)a.seqs, a.n_runs, a.total_bytes, g0, rf, rm);
+  const bool live = lane < g.runs_here;
+  uint32_t lr, w0;
+  bool last_run;
+  run_split(shape, live ? rm + lane : rm, lr, w0, last_run);
+  const uint32_t dup = last_run ? a.last_dup : 0u;
+  const uint32_t run_mask = live ? ((1u << C) - 1u) & ~((1u << dup) - 1u) : 0u;
+  // almost every tile holds bases only: look for a non-base first (no validity bits, no LDS) ...
+  uint32_t any_bad = 0;
+  if constexpr (PK) {
+    for (uint32_t i = lane; i < g.n_vec; i += 64u) any_bad |= a.invalid[(g.byte0 >> 4) + i];
+  } else {
+    for (uint32_t i = lane; i < g.n_vec; i += 64u) {
+      const uint4 v = *(const uint4*)(a.seqs + g.byte0 + ((uint64_t)i << 4));
+      any_bad |= non_base4(v.x) | non_base4(v.y) | non_base4(v.z) | non_base4(v.w);
+    }
+  }
+  uint32_t valid = run_mask;
+  if (__ballot(any_bad != 0u) != 0ull) {
+    // ... and only then build the validity bits (the slab comes from L2 this time) and test every window
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < g.n_vec; i += 64u) {
+      if constexpr (PK) {
+        vbits[i] = a.invalid[(g.byte0 >> 4) + i];
+      } else {
+        const uint4 v = *(const uint4*)(a.seqs + g.byte0 + ((uint64_t)i << 4));
+        uint32_t i0, i1, i2, i3;
+        (void)pack4v(v.x, i0);
+        (void)pack4v(v.y, i1);
+        (void)pack4v(v.z, i2);
+        (void)pack4v(v.w, i3);
+        vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    const uint32_t b0 = g.shift + lr * a.stride + w0 - g.w_first;
+    valid = ~(k <= 64u ? windows_with_non_base((const uint32_t*)vbits, b0, k)
+                       : windows_with_non_base_long((const uint32_t*)vbits, b0, k, C)) & run_mask;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const uint32_t cnt = __builtin_popcount(valid);
+  uint32_t sum = cnt;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+  if (lane == 0) a.tile_counts[wt] = sum;
+  if (a.counts) {
+    if (rpr > 64u) {
+      // long reads: a tile touches at most two of them -- one add each instead of one per lane
+      uint32_t s0 = lr == 0u ? cnt : 0u;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) s0 += __shfl_xor(s0, d, 64);
+      if (lane == 0) {
+        if (s0) atomicAdd((unsigned long long*)&a.counts[rf], (unsigned long long)s0);
+        if (sum - s0) atomicAdd((unsigned long long*)&a.counts[rf + 1u], (unsigned long long)(sum - s0));
+      }
+    } else if (cnt) {
+      atomicAdd((unsigned long long*)&a.counts[rf + lr], (unsigned long long)cnt);
+    }
+  }
+}
+
 template <bool PK = false> // PK: packed input -- the validity stream is read as it is, the bases not at all
 static __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_count_kernel(const KmerRunsGenArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
-  const uint32_t k = a.k, C = a.C, rpr = a.rpr;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const RunShape shape = {C, rpr, a.inv_rpr, a.last_start, a.last_dup, a.stride, a.nwin, k};
+  const RunShape shape = {a.C, a.rpr, a.inv_rpr, a.last_start, a.last_dup, a.stride, a.nwin, a.k};
   uint16_t* vbits = (uint16_t*)(lds_dyn + wave * a.vbits_dwords);
   const uint64_t n_waves_total = (uint64_t)gridDim.x * a.waves;
-  for (uint64_t wt = (uint64_t)blockIdx.x * a.waves + wave; wt < a.n_wtiles; wt += n_waves_total) {
-    const uint64_t g0 = wt * 64u;
-    const uint64_t rf = g0 / rpr;
-    const uint32_t rm = (uint32_t)(g0 - rf * rpr);
-    const TileGeo g = tile_geo(shape, PK ? 0ull : (uint64_t)a.seqs, a.n_runs, a.total_bytes, g0, rf, rm);
-    const bool live = lane < g.runs_here;
-    uint32_t lr, w0;
-    bool last_run;
-    run_split(shape, live ? rm + lane : rm, lr, w0, last_run);
-    const uint32_t dup = last_run ? a.last_dup : 0u;
-    const uint32_t run_mask = live ? ((1u << C) - 1u) & ~((1u << dup) - 1u) : 0u;
-    // almost every tile holds bases only: look for a non-base first (no validity bits, no LDS) ...
-    uint32_t any_bad = 0;
-    if constexpr (PK) {
-      for (uint32_t i = lane; i < g.n_vec; i += 64u) any_bad |= a.invalid[(g.byte0 >> 4) + i];
-    } else {
-      for (uint32_t i = lane; i < g.n_vec; i += 64u) {
-        const uint4 v = *(const uint4*)(a.seqs + g.byte0 + ((uint64_t)i << 4));
-        any_bad |= non_base4(v.x) | non_base4(v.y) | non_base4(v.z) | non_base4(v.w);
+  for (uint64_t wt = (uint64_t)blockIdx.x * a.waves + wave; wt < a.n_wtiles; wt += n_waves_total) count_one_tile<PK>(a, shape, wt, vbits, lane);
+}
+
+// The count pass in two steps, for tiles that are whole reads lying back to back (stride == len, C | windows, runs per
+// read | 64: the shapes of run_kmer_na_special).  Looking at every base of a tile on its own -- a wave, its 1.2 KB, a wait --
+// runs at 3.7 TB/s (0.81 ms per 20 M x 150 bp); a plain grid-stride scan of the batch's 16-byte vectors at 5.1-5.9
+// (tools/bench_micro/scan_rate.hip: 0.51-0.59 ms per 3 GB).  So: tiles_flag_kernel marks the tiles that hold a non-base (a
+// bit per tile; a vector on the border of two tiles marks both), tiles_count_flagged_kernel gives the others their full
+// count and counts the marked ones -- one in a hundred on real data -- exactly (count_one_tile).
+static __global__ __launch_bounds__(256) void tiles_flag_kernel(const uint8_t* __restrict__ seqs, uint64_t total_bytes, uint32_t tile_bytes,
+                                                                uint32_t* __restrict__ flags)
+{
+  const uint64_t base = (uint64_t)seqs;
+  const uint32_t sh = (uint32_t)(base & 15u);
+  const uint4* const v = (const uint4*)(base - sh);
+  const uint64_t n_vec = (sh + total_bytes + 15u) >> 4;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  auto mark = [&](uint64_t at) {
+    const uint64_t t = at / tile_bytes;
+    atomicOr(&flags[t >> 5], 1u << (t & 31u));
+  };
+  constexpr int U = 2;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n_vec; i0 += stride * U) {
+    uint4 x[U];
+    bool inside[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t i = i0 + (uint64_t)u * stride;
+      inside[u] = i < n_vec && (i << 4) >= sh && (i << 4) + 16u <= sh + total_bytes; // (all 16 bytes are the buffer's)
+      x[u] = inside[u] ? v[i] : make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t i = i0 + (uint64_t)u * stride;
+      if (i >= n_vec) continue;
+      if (!inside[u]) { // the buffer's first / last vector: only its own bytes are read
+        for (int q = 0; q < 16; ++q) {
+          const int64_t at = (int64_t)(i << 4) + q - (int64_t)sh;
+          if (at >= 0 && at < (int64_t)total_bytes && non_base4((uint32_t)seqs[at] * 0x01010101u)) mark((uint64_t)at);
+        }
+        continue;
+      }
+      const uint32_t b0 = non_base4(x[u].x), b1 = non_base4(x[u].y), b2 = non_base4(x[u].z), b3 = non_base4(x[u].w);
+      if ((b0 | b1 | b2 | b3) == 0u) continue;
+      // (rare) a vector lies in one tile or on the border of two: its first and its last non-base say which
+      const uint64_t first = (i << 4) - sh;
+      const uint32_t lo = b0 ? 0u : b1 ? 4u : b2 ? 8u : 12u, hi = b3 ? 15u : b2 ? 11u : b1 ? 7u : 3u; // (to four bytes: a tile too many at worst)
+      for (uint64_t t = (first + lo) / tile_bytes; t <= (first + hi) / tile_bytes; ++t) atomicOr(&flags[t >> 5], 1u << (t & 31u));
+    }
+  }
+}
+static __global__ __launch_bounds__(KR_MAX_THREADS) void tiles_count_flagged_kernel(const KmerRunsGenArgs a, const uint32_t* __restrict__ flags)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const RunShape shape = {a.C, a.rpr, a.inv_rpr, a.last_start, a.last_dup, a.stride, a.nwin, a.k};
+  uint16_t* vbits = (uint16_t*)(lds_dyn + wave * a.vbits_dwords);
+  const uint64_t n_waves_total = (uint64_t)gridDim.x * a.waves;
+  const uint32_t reads_per_tile = 64u / a.rpr;
+  const uint64_t n_groups = (a.n_wtiles + 63u) >> 6; // 64 tiles per wave and round: a tile per lane
+  for (uint64_t gi = (uint64_t)blockIdx.x * a.waves + wave; gi < n_groups; gi += n_waves_total) {
+    const uint64_t t = gi * 64u + lane;
+    const bool live = t < a.n_wtiles;
+    const bool marked = live && ((flags[t >> 5] >> (t & 31u)) & 1u);
+    if (live && !marked) {
+      const uint64_t runs_left = a.n_runs - t * 64u;
+      a.tile_counts[t] = (runs_left < 64u ? (uint32_t)runs_left : 64u) * a.C;
+      if (a.counts) {
+        const uint64_t r0 = t * reads_per_tile;
+        for (uint32_t r = 0; r < reads_per_tile; ++r)
+          if ((r0 + r) * a.rpr < a.n_runs) a.counts[r0 + r] = a.nwin;
       }
     }
-    uint32_t valid = run_mask;
-    if (__ballot(any_bad != 0u) != 0ull) {
-      // ... and only then build the validity bits (the slab comes from L2 this time) and test every window
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-      __builtin_amdgcn_wave_barrier();
-      for (uint32_t i = lane; i < g.n_vec; i += 64u) {
-        if constexpr (PK) {
-          vbits[i] = a.invalid[(g.byte0 >> 4) + i];
-        } else {
-          const uint4 v = *(const uint4*)(a.seqs + g.byte0 + ((uint64_t)i << 4));
-          uint32_t i0, i1, i2, i3;
-          (void)pack4v(v.x, i0);
-          (void)pack4v(v.y, i1);
-          (void)pack4v(v.z, i2);
-          (void)pack4v(v.w, i3);
-          vbits[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-      const uint32_t b0 = g.shift + lr * a.stride + w0 - g.w_first;
-      valid = ~(k <= 64u ? windows_with_non_base((const uint32_t*)vbits, b0, k)
-                         : windows_with_non_base_long((const uint32_t*)vbits, b0, k, C)) & run_mask;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-      __builtin_amdgcn_wave_barrier();
-    }
-    const uint32_t cnt = __builtin_popcount(valid);
-    uint32_t sum = cnt;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
-    if (lane == 0) a.tile_counts[wt] = sum;
-    if (a.counts) {
-      if (rpr > 64u) {
-        // long reads: a tile touches at most two of them -- one add each instead of one per lane
-        uint32_t s0 = lr == 0u ? cnt : 0u;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) s0 += __shfl_xor(s0, d, 64);
-        if (lane == 0) {
-          if (s0) atomicAdd((unsigned long long*)&a.counts[rf], (unsigned long long)s0);
-          if (sum - s0) atomicAdd((unsigned long long*)&a.counts[rf + 1u], (unsigned long long)(sum - s0));
-        }
-      } else if (cnt) {
-        atomicAdd((unsigned long long*)&a.counts[rf + lr], (unsigned long long)cnt);
-      }
+    uint64_t todo = __ballot(marked);
+    while (todo) { // (rare) the marked tiles of the 64, one after the other, the whole wave on each
+      const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      count_one_tile<false>(a, shape, gi * 64u + l, vbits, lane);
     }
   }
 }

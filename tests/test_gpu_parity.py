@@ -2645,7 +2645,7 @@ def test_kmer_packed_input_refusals(ctx, oracle):
         ctx.free(d_pk)
 
 
-@pytest.mark.parametrize("knob", ["", "NTHIP_TUNE_NO_DIRTY_MEMORY", "NTHIP_TUNE_NO_NA_SPECIAL"])
+@pytest.mark.parametrize("knob", ["", "NTHIP_TUNE_NO_DIRTY_MEMORY", "NTHIP_TUNE_NO_NA_SPECIAL", "NTHIP_TUNE_NO_TILES_FLAG"])
 def test_fixed_length_batches_with_non_bases_every_way(oracle, knob):
     """a fixed-length batch with a non-base: the dense pass gives up, the count pass finds every tile's place in the compact
     stream, the tiles that lost no window go through the specialised kernel at those places (kmer_runs_kernel's compact
