@@ -424,6 +424,9 @@ int fastx_stream_ranges(nthip_ctx* c, const char* path, uint32_t format, uint16_
                         uint64_t chunk_bytes, const std::vector<FastxRange>& ranges, const FastxDeliver& deliver,
                         nthip_fastx_stats* stats);
 int64_t fastx_find_record_start(int fd, uint64_t file_size, uint64_t pos, uint32_t format);
+// does the file begin with the gzip magic (1f 8b)?  1 / 0, < 0: read error.  Such a file is inflated by one host thread
+// and has no record boundaries to seek to: it feeds ONE device
+int fastx_file_is_gzip(int fd);
 
 // ---- templates every launching TU uses --------------------------------------------------------------------------
 // Dynamic LDS beyond the default needs hipFuncAttributeMaxDynamicSharedMemorySize, and that attribute is ONE value per

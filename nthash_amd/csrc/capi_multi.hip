@@ -253,6 +253,14 @@ extern "C" int nthip_multi_fastx_kmer_hash_file(nthip_multi* mm, const char* pat
     struct stat sb;
     if (fstat(fd, &sb) != 0) { close(fd); return fail(NTHIP_ERR_ARG, "cannot stat %s", path); }
     file_size = (uint64_t)sb.st_size;
+    const int is_gz = file_size ? fastx_file_is_gzip(fd) : 0;
+    if (is_gz < 0) { close(fd); return fail(NTHIP_ERR_ARG, "read error on %s", path); }
+    if (is_gz) {
+      // a deflate stream cannot be cut where records start without inflating it, and one host thread inflates less than
+      // one device hashes: the whole file through the first device's pipeline (same batches, same order, same callback)
+      close(fd);
+      return nthip_fastx_kmer_hash_file(mm->ctx[0], path, format, k, m, chunk_bytes, fn, user, stats);
+    }
     uint64_t begin = 0;
     while (begin < file_size) {
       int64_t end = (int64_t)file_size;

@@ -3,6 +3,7 @@
 // nthip_fastx_kmer_hash_file (reader threads -> pinned buffers -> copy stream -> index + hash).
 #pragma once
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -11,7 +12,9 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <thread>
+#include <vector>
 
 #include "fastx_kernels.hpp"
 
@@ -196,6 +199,96 @@ extern "C" int nthip_fasta_compact(nthip_ctx* c, const char* d_raw, uint64_t n_b
 
 namespace {
 
+
+// ---- gzip input -------------------------------------------------------------------------------------------------------------
+// A file that begins with the gzip magic (1f 8b) is inflated on the host by the system's zlib, loaded at run time
+// (dlopen("libz.so.1"): the library keeps libamdhip64 as its only link-time dependency, and a host without zlib gets
+// NTHIP_ERR_UNSUPPORTED for .gz files, nothing else).  gzread follows concatenated members (bgzip, cat a.gz b.gz).
+// A deflate stream has no place to seek to, so ONE host thread feeds the pinned ring; everything behind it is the plain path.
+struct ZLib {
+  void* (*gzdopen)(int, const char*) = nullptr;
+  int (*gzbuffer)(void*, unsigned) = nullptr;
+  int (*gzread)(void*, void*, unsigned) = nullptr;
+  int (*gzclose)(void*) = nullptr;
+  const char* (*gzerror)(void*, int*) = nullptr;
+  bool ok = false;
+};
+
+inline const ZLib& zlib_api()
+{
+  static const ZLib z = [] {
+    ZLib r;
+    void* h = dlopen("libz.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libz.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return r;
+    r.gzdopen = (void* (*)(int, const char*))dlsym(h, "gzdopen");
+    r.gzbuffer = (int (*)(void*, unsigned))dlsym(h, "gzbuffer");
+    r.gzread = (int (*)(void*, void*, unsigned))dlsym(h, "gzread");
+    r.gzclose = (int (*)(void*))dlsym(h, "gzclose");
+    r.gzerror = (const char* (*)(void*, int*))dlsym(h, "gzerror");
+    r.ok = r.gzdopen && r.gzbuffer && r.gzread && r.gzclose && r.gzerror;
+    return r;
+  }();
+  return z;
+}
+
+// does the file behind fd begin with the gzip magic?  (< 0: read error)
+inline int fd_is_gzip(int fd)
+{
+  uint8_t magic[2] = {0, 0};
+  const ssize_t r = pread(fd, magic, 2, 0);
+  if (r < 0) return -1;
+  return r == 2 && magic[0] == 0x1f && magic[1] == 0x8b ? 1 : 0;
+}
+
+// an inflating reader over a dup of fd (the caller keeps fd); read() fills dst with up to want bytes, fewer only at the
+// end of the stream; < 0: corrupt or truncated input
+struct GzSource {
+  void* gz = nullptr;
+  std::string err;
+  int open_fd(int fd)
+  {
+    const ZLib& z = zlib_api();
+    if (!z.ok) return NTHIP_ERR_UNSUPPORTED;
+    const int d = dup(fd);
+    if (d < 0) return NTHIP_ERR_ARG;
+    if (lseek(d, 0, SEEK_SET) < 0) { ::close(d); return NTHIP_ERR_ARG; }
+    gz = z.gzdopen(d, "rb");
+    if (!gz) { ::close(d); return NTHIP_ERR_ARG; }
+    (void)z.gzbuffer(gz, 1u << 20);
+    return NTHIP_OK;
+  }
+  int64_t read(uint8_t* dst, uint64_t want)
+  {
+    const ZLib& z = zlib_api();
+    uint64_t got = 0;
+    while (got < want) {
+      const unsigned piece = (unsigned)(want - got < (1ull << 30) ? want - got : (1ull << 30));
+      const int r = z.gzread(gz, dst + got, piece);
+      if (r < 0) { note(); return -1; }
+      if (r == 0) break;
+      got += (uint64_t)r;
+    }
+    if (got < want) { // the end of the stream: a file cut short ends here too, and says so (Z_BUF_ERROR)
+      int num = 0;
+      (void)z.gzerror(gz, &num);
+      if (num < 0) { note(); return -1; }
+    }
+    return (int64_t)got;
+  }
+  void note()
+  {
+    int num = 0;
+    const char* msg = zlib_api().gzerror(gz, &num);
+    err = msg && *msg ? msg : "truncated or corrupt gzip stream";
+    if (num == -5 /* Z_BUF_ERROR */) err = "gzip stream ends before its end-of-stream mark (truncated file)";
+  }
+  ~GzSource()
+  {
+    if (gz) (void)zlib_api().gzclose(gz);
+  }
+};
+
 constexpr uint64_t FXS_HEAD = 16ull << 20; // room in front of a chunk for the carried-over tail of the previous one
 
 struct FxReader {
@@ -214,9 +307,53 @@ struct FxReader {
   double read_seconds = 0;
   unsigned n_threads = 0;
   std::thread th;
+  GzSource* gz = nullptr; // gzip input: n_chunks is not known until the stream ends (set, under mu, with the last chunk)
+  std::string err;
+
+  // chunks of the INFLATED stream; one byte is read ahead so that the chunk that ends the stream is known as the last
+  void run_gz()
+  {
+    uint8_t ahead = 0;
+    bool have_ahead = false;
+    for (uint64_t j = 0;; ++j) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || j < next_free; });
+        if (stop) return;
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      uint8_t* dst = pinned[j & 1];
+      uint64_t len = 0;
+      bool ok = true, last = false;
+      if (have_ahead) { dst[0] = ahead; len = 1; have_ahead = false; }
+      const int64_t r = gz->read(dst + len, chunk - len);
+      if (r < 0) ok = false;
+      else {
+        len += (uint64_t)r;
+        if (len < chunk) last = true;
+        else {
+          const int64_t one = gz->read(&ahead, 1);
+          if (one < 0) ok = false;
+          else if (one == 0) last = true;
+          else have_ahead = true;
+        }
+      }
+      read_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        filled[j & 1] = len;
+        if (!ok) { failed = true; err = gz->err; }
+        if (last) n_chunks = len ? j + 1 : j; // (len == 0 only for j == 0: an empty stream)
+        next_ready = j + 1;
+      }
+      cv.notify_all();
+      if (!ok || last) return;
+    }
+  }
 
   void run()
   {
+    if (gz) return run_gz();
     const unsigned n_thr = n_threads ? n_threads : 8u; // (NTHIP_TUNE_READ_THREADS: A/B knob)
     for (uint64_t j = 0; j < n_chunks; ++j) {
       {
@@ -270,10 +407,33 @@ int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, 
   if (fd < 0) return fail(NTHIP_ERR_ARG, "cannot open %s", path);
   struct stat sb;
   if (fstat(fd, &sb) != 0) { close(fd); return fail(NTHIP_ERR_ARG, "cannot stat %s", path); }
-  const uint64_t size = (uint64_t)sb.st_size;
+  uint64_t size = (uint64_t)sb.st_size;
   if (stats) stats->file_bytes = size;
   if (size == 0) { close(fd); return NTHIP_OK; }
   const uint64_t piece = 64ull << 20;
+  // gzip input: the whole file is one batch anyway -- inflated into host memory first (its size is not known before)
+  std::vector<uint8_t> inflated;
+  const int is_gz = fd_is_gzip(fd);
+  if (is_gz < 0) { close(fd); return fail(NTHIP_ERR_ARG, "read error on %s", path); }
+  if (is_gz) {
+    GzSource src;
+    const int zrc = src.open_fd(fd);
+    if (zrc != NTHIP_OK) {
+      close(fd);
+      return fail(zrc, zrc == NTHIP_ERR_UNSUPPORTED ? "%s is gzip-compressed and libz.so.1 could not be loaded" : "cannot open %s as a gzip stream", path);
+    }
+    uint64_t have = 0;
+    for (;;) {
+      inflated.resize(have + piece);
+      const int64_t r = src.read(inflated.data() + have, piece);
+      if (r < 0) { close(fd); return fail(NTHIP_ERR_ARG, "%s: %s", path, src.err.c_str()); }
+      have += (uint64_t)r;
+      if ((uint64_t)r < piece) break;
+    }
+    inflated.resize(have);
+    size = have;
+    if (size == 0) { close(fd); return NTHIP_OK; }
+  }
   uint8_t* pinned[2] = {nullptr, nullptr};
   uint8_t *d_raw = nullptr, *d_seqs = nullptr;
   uint64_t *d_offsets = nullptr, *d_hashes = nullptr, *d_counts = nullptr;
@@ -308,7 +468,8 @@ int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, 
     for (uint64_t off = 0; off < size; off += piece, ++i) {
       const uint64_t len = off + piece <= size ? piece : size - off;
       if (i >= 2) FA_TRY(hipEventSynchronize(ev[i & 1])); // the upload that used this pinned buffer
-      uint64_t done = 0;
+      uint64_t done = is_gz ? len : 0;
+      if (is_gz) memcpy(pinned[i & 1], inflated.data() + off, len);
       while (done < len) {
         const ssize_t r = pread(fd, pinned[i & 1] + done, len - done, (off_t)(off + done));
         if (r <= 0) { rc = fail(NTHIP_ERR_ARG, "read error on %s", path); cleanup(); return rc; }
@@ -385,6 +546,8 @@ int ntamd::host::fastx_stream_ranges(nthip_ctx* c, const char* path, uint32_t fo
 {
   return fastx_stream_file(c, path, format, k, m, seeds, chunk_bytes, nullptr, nullptr, stats, &ranges, &deliver);
 }
+
+int ntamd::host::fastx_file_is_gzip(int fd) { return fd_is_gzip(fd); }
 
 // First record start at or after byte `pos` of a FASTQ / single-line FASTA file (pos > 0), found on the host from the
 // line structure alone: FASTA -- a line that begins with '>'; FASTQ -- a line that begins with '@' whose third line
@@ -482,6 +645,20 @@ int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t 
   rd.file_size = (uint64_t)sb.st_size;
   rd.chunk = chunk_bytes;
   rd.n_chunks = (rd.file_size + chunk_bytes - 1) / chunk_bytes;
+  GzSource gz_src; // (declared before the reader starts: it outlives the reader thread)
+  const int is_gz = rd.file_size ? fd_is_gzip(rd.fd) : 0;
+  if (is_gz < 0) { close(rd.fd); return fail(NTHIP_ERR_ARG, "read error on %s", path); }
+  if (is_gz) {
+    // chunks of the inflated stream, as many as it turns out to hold
+    if (ranges) { close(rd.fd); return fail(NTHIP_ERR_UNSUPPORTED, "%s: byte ranges of a gzip file cannot be read on their own", path); }
+    const int zrc = gz_src.open_fd(rd.fd);
+    if (zrc != NTHIP_OK) {
+      close(rd.fd);
+      return fail(zrc, zrc == NTHIP_ERR_UNSUPPORTED ? "%s is gzip-compressed and libz.so.1 could not be loaded" : "cannot open %s as a gzip stream", path);
+    }
+    rd.gz = &gz_src;
+    rd.n_chunks = ~0ull >> 2;
+  }
   if (ranges) { // record-aligned pieces: whole records, so a piece may be longer than a chunk by up to one record
     rd.ranges = ranges;
     rd.n_chunks = ranges->size();
@@ -598,15 +775,21 @@ int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t 
   };
 
   uint64_t lens[2] = {0, 0};
-  for (uint64_t j = 0; j <= rd.n_chunks && rc == NTHIP_OK; ++j) {
-    if (j < rd.n_chunks) {
-      {
-        std::unique_lock<std::mutex> lk(rd.mu);
-        rd.cv.wait(lk, [&] { return rd.failed || rd.next_ready > j; });
-        if (rd.failed) { rc = fail(NTHIP_ERR_ARG, "read error on %s", path); break; }
+  for (uint64_t j = 0; rc == NTHIP_OK; ++j) {
+    uint64_t n_chunks = 0; // (a gzip stream: known once its last chunk is ready -- published together with it)
+    {
+      std::unique_lock<std::mutex> lk(rd.mu);
+      rd.cv.wait(lk, [&] { return rd.failed || rd.next_ready > j || rd.n_chunks <= j; });
+      if (rd.failed) {
+        rc = rd.err.empty() ? fail(NTHIP_ERR_ARG, "read error on %s", path) : fail(NTHIP_ERR_ARG, "%s: %s", path, rd.err.c_str());
+        break;
       }
+      n_chunks = rd.n_chunks;
+    }
+    if (j > n_chunks) break;
+    if (j < n_chunks) {
       uint64_t len = rd.filled[j & 1];
-      const bool file_end = ranges ? (*ranges)[j].off + (*ranges)[j].len == rd.file_size : j + 1 == rd.n_chunks;
+      const bool file_end = ranges ? (*ranges)[j].off + (*ranges)[j].len == rd.file_size : j + 1 == n_chunks;
       if (file_end && len && rd.pinned[j & 1][len - 1] != '\n') rd.pinned[j & 1][len++] = '\n';
       lens[j & 1] = len;
       // d_raw[j & 1] was last read by piece j-2, processed synchronously two iterations ago
@@ -625,7 +808,7 @@ int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t 
         rd.next_free = j + 2;
       }
       rd.cv.notify_all();
-      rc = process(j - 1, lens[(j - 1) & 1], j == rd.n_chunks);
+      rc = process(j - 1, lens[(j - 1) & 1], j == n_chunks);
     }
   }
 #undef FX_TRY

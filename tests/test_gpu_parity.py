@@ -2400,6 +2400,174 @@ def test_fasta_multiline_file_vs_oracle(ctx, oracle, tmp_path):
         ctx.fastx_kmer_hash_file(tmp_path / "bad.fa", NTHIP_FASTA_MULTILINE, k, m)
 
 
+def _gzip_members(buf, cuts, level=6):
+    """buf as a gzip file of len(cuts) + 1 concatenated members (what bgzip / `cat a.gz b.gz` make)"""
+    import gzip
+    edges = [0] + list(cuts) + [len(buf)]
+    return b"".join(gzip.compress(buf[a:b], compresslevel=level) for a, b in zip(edges[:-1], edges[1:]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,chunk,members,final_newline,use_seeds", [
+    (4, 1 << 16, 1, True, False),        # many chunks of the inflated stream, records across every chunk boundary
+    (4, 100_000, 5, False, False),       # concatenated members cut at arbitrary bytes, no newline at the end
+    (2, 1 << 16, 3, True, False),
+    (4, 1 << 26, 1, True, False),        # the whole stream in one chunk
+    (4, 1 << 16, 2, True, True),         # the spaced-seed stream
+])
+def test_fastx_gzip_file_stream_vs_oracle(ctx, oracle, tmp_path, fmt, chunk, members, final_newline, use_seeds):
+    """a gzip-compressed FASTQ / FASTA file (recognised by its magic, whatever its name) through the same pipeline: hashes,
+    counts, batch order == the oracle on the parsed reads; and == the plain file's own stream, batch for batch"""
+    rng = np.random.default_rng(chunk % 991 + fmt + members)
+    buf, seqs = _make_fastx(rng, 6000, fmt, lo=20, hi=400)
+    if not final_newline:
+        buf = buf[:-1]
+    cuts = sorted(int(x) for x in rng.integers(1, len(buf) - 1, members - 1))
+    gz = _gzip_members(buf, cuts)
+    path = tmp_path / "reads.anything"
+    path.write_bytes(gz)
+    plain = tmp_path / "reads.plain"
+    plain.write_bytes(buf)
+    k, m = 31, 2
+    data, offs = concat_reads(seqs)
+    sd = None
+    if use_seeds:
+        import nthash_amd
+        seeds = ["1010101010101010101010101010101", "1101101101101101011011011011011"]
+        want = oracle.seed_batch(data, offs, seeds, k, m, want_pos=False)
+        sd = nthash_amd.Seeds(ctx, seeds, k)
+        per = len(seeds) * m
+    else:
+        want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+        per = m
+
+    def run(p):
+        got_h, got_c, firsts = [], [], []
+
+        def on_batch(b):
+            h, cnt = np.zeros(b.n_kmers * per, np.uint64), np.zeros(b.n_reads, np.uint64)
+            if h.size:
+                ctx.d2h(h, b.hashes)
+            ctx.d2h(cnt, b.counts)
+            got_h.append(h); got_c.append(cnt); firsts.append(b.first_read)
+
+        st = ctx.fastx_kmer_hash_file(p, fmt, k, m, chunk_bytes=chunk, on_batch=on_batch, seeds=sd)
+        return st, got_h, got_c, firsts
+
+    st, got_h, got_c, firsts = run(path)
+    assert st.reads == len(seqs) and st.kmers == want["total"] and st.file_bytes == len(gz)
+    if chunk < len(buf) // 4:
+        assert st.batches > 4
+    assert firsts == list(np.cumsum([0] + [c.size for c in got_c[:-1]]))
+    assert (np.concatenate(got_c) == want["counts"]).all()
+    assert (np.concatenate(got_h) == want["hashes"].ravel()).all()
+    st2, h2, c2, f2 = run(plain)
+    assert st2.batches == st.batches and f2 == firsts
+    assert all((a == b).all() for a, b in zip(h2, got_h)) and all((a == b).all() for a, b in zip(c2, got_c))
+
+
+@pytest.mark.gpu
+def test_fastx_gzip_chunk_edges_and_errors(ctx, oracle, tmp_path):
+    """the inflated stream an exact multiple of the chunk (the last chunk is known as the last by the byte read ahead), an
+    empty stream, a file cut short, a corrupt member, a gzip magic with nothing behind it"""
+    import gzip
+    import nthash_amd
+    rec = b"@r\nACGTACGTACGTACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n"      # 67 bytes: 30 bases
+    assert len(rec) == 67
+    chunk = 1 << 16
+    recs = []  # 67-byte records and one with a padded header: exactly two chunks
+    total = 0
+    while total + 2 * len(rec) < 2 * chunk:
+        recs.append(rec); total += len(rec)
+    pad = 2 * chunk - total - len(rec)
+    recs.append(b"@r" + b"x" * pad + rec[2:])
+    buf = b"".join(recs)
+    assert len(buf) == 2 * chunk
+    p = tmp_path / "exact.fq.gz"
+    p.write_bytes(gzip.compress(buf))
+    st = ctx.fastx_kmer_hash_file(p, 4, 31, 1, chunk_bytes=chunk)
+    assert st.reads == len(recs) and st.kmers == 0 and st.batches == 2
+    st = ctx.fastx_kmer_hash_file(p, 4, 30, 1, chunk_bytes=chunk)
+    assert st.reads == len(recs) and st.kmers == len(recs)
+    # an empty stream
+    p = tmp_path / "empty.fq.gz"
+    p.write_bytes(gzip.compress(b""))
+    st = ctx.fastx_kmer_hash_file(p, 4, 31, 1)
+    assert st.reads == 0 and st.batches == 0
+    # cut short: inside the deflate data, and inside the trailer
+    whole = gzip.compress(buf)
+    for cut in (len(whole) // 2, len(whole) - 3):
+        p = tmp_path / "short.fq.gz"
+        p.write_bytes(whole[:cut])
+        with pytest.raises(nthash_amd.NtHipError):
+            ctx.fastx_kmer_hash_file(p, 4, 31, 1, chunk_bytes=chunk)
+    # a flipped byte in the deflate data (crc or structure error)
+    bad = bytearray(whole)
+    bad[len(bad) // 2] ^= 0x5A
+    p = tmp_path / "corrupt.fq.gz"
+    p.write_bytes(bytes(bad))
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.fastx_kmer_hash_file(p, 4, 31, 1, chunk_bytes=chunk)
+    p = tmp_path / "magic.fq.gz"
+    p.write_bytes(b"\x1f\x8b")
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.fastx_kmer_hash_file(p, 4, 31, 1)
+    # the context is usable afterwards
+    p = tmp_path / "ok.fq"
+    p.write_bytes(rec)
+    assert ctx.fastx_kmer_hash_file(p, 4, 30, 1).kmers == 1
+
+
+@pytest.mark.gpu
+def test_fastx_gzip_multiline_fasta_and_multi_device(ctx, oracle, tmp_path):
+    """NTHIP_FASTA_MULTILINE from a gzip file (inflated on the host, then the one-batch path), and the multi-device driver
+    on a gzip file: one inflating thread, so the first device's pipeline takes the whole file -- same batches, same order"""
+    import gzip
+    import nthash_amd
+    from nthash_amd.capi import NTHIP_FASTA_MULTILINE
+    rng = np.random.default_rng(78)
+    buf, seqs = _make_multiline_fasta(rng, 40, max_len=60_000)
+    path = tmp_path / "genome.fa.gz"
+    path.write_bytes(_gzip_members(buf[:-1], [len(buf) // 3]))
+    k, m = 31, 2
+    data, offs = concat_reads(seqs)
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    got = {}
+
+    def on_genome(b):
+        h, cnt = np.zeros(b.n_kmers * m, np.uint64), np.zeros(b.n_reads, np.uint64)
+        ctx.d2h(h, b.hashes); ctx.d2h(cnt, b.counts)
+        got["h"], got["c"] = h, cnt
+
+    st = ctx.fastx_kmer_hash_file(path, NTHIP_FASTA_MULTILINE, k, m, on_batch=on_genome)
+    assert st.reads == len(seqs) and st.kmers == want["total"] and st.batches == 1
+    assert (got["c"] == want["counts"]).all() and (got["h"] == want["hashes"].ravel()).all()
+    # multi-device
+    buf, seqs = _make_fastx(rng, 5000, 4, lo=20, hi=300)
+    path = tmp_path / "reads.fq.gz"
+    path.write_bytes(gzip.compress(buf))
+    data, offs = concat_reads(seqs)
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+    got_h, got_c, firsts = [], [], []
+
+    def on_batch(b):
+        h, cnt = np.zeros(b.n_kmers * m, np.uint64), np.zeros(b.n_reads, np.uint64)
+        if h.size:
+            ctx.d2h(h, b.hashes)
+        ctx.d2h(cnt, b.counts)
+        got_h.append(h); got_c.append(cnt); firsts.append(b.first_read)
+
+    mg = nthash_amd.Multi([0, 0, 0])
+    try:
+        st = mg.fastx_kmer_hash_file(path, 4, k, m, chunk_bytes=1 << 17, on_batch=on_batch)
+    finally:
+        mg.close()
+    assert st.reads == len(seqs) and st.kmers == want["total"] and st.batches > 4
+    assert firsts == list(np.cumsum([0] + [c.size for c in got_c[:-1]]))
+    assert (np.concatenate(got_c) == want["counts"]).all()
+    assert (np.concatenate(got_h) == want["hashes"].ravel()).all()
+
+
 def test_fastx_seed_stream_vs_oracle(ctx, oracle, tmp_path):
     """SeedNtHash over a streamed FASTQ (spans + the reference's position state machine on reads with N)"""
     import nthash_amd
