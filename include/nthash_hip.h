@@ -357,7 +357,7 @@ typedef int (*nthip_fastx_fn)(void* user, const nthip_fastx_batch* batch); /* no
 typedef struct nthip_fastx_stats {
   uint64_t file_bytes, reads, kmers, batches;
   double seconds;            /* wall time of the whole call                                        */
-  double read_seconds;       /* time the reader threads spent in pread (overlapped)                */
+  double read_seconds;       /* time the reader threads spent in pread / inflate (overlapped)      */
   double gpu_seconds;        /* index + hash + callback time (overlapped with reads and uploads)   */
 } nthip_fastx_stats;
 /*
@@ -368,6 +368,11 @@ typedef struct nthip_fastx_stats {
  * formats; NTHIP_FASTA_MULTILINE (genomes: few, long sequences) loads the whole file into HBM,
  * compacts it with nthip_fasta_compact and calls `fn` once (raw = the compacted sequences,
  * starts/ends = their offsets).
+ * A file that begins with the gzip magic (1f 8b; any name; concatenated members -- bgzip, cat a.gz b.gz -- included) is
+ * inflated on the host by the system's zlib (libz.so.1, loaded at run time: NTHIP_ERR_UNSUPPORTED if it is absent), by ONE
+ * thread that feeds the same pinned ring with chunks of the INFLATED stream; batches, order and results are those of the
+ * plain file.  stats->file_bytes stays the size on disk; a truncated or corrupt stream is NTHIP_ERR_ARG.  The multi-device
+ * driver gives a gzip file to its first device (a deflate stream cannot be cut at record starts without inflating it).
  */
 int nthip_fastx_kmer_hash_file(nthip_ctx* ctx, const char* path, uint32_t format, uint16_t k, uint8_t m,
                                uint64_t chunk_bytes, nthip_fastx_fn fn, void* user, nthip_fastx_stats* stats);

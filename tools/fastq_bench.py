@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """End-to-end FASTQ file -> k-mer hashes on the device (nthip_fastx_kmer_hash_file).
 
-    python tools/fastq_bench.py [reads] [chunk_MiB] [m]
+    python tools/fastq_bench.py [reads] [chunk_MiB] [m] [seeds|kmers] [gz]
+("gz": the file is also written gzip-compressed -- `gzip -1`, Phred scores drawn from 8 values so that it compresses like a
+sequencer's output, not like a constant -- and streamed through the same call: one inflating host thread feeds the ring)
 Writes a synthetic FASTQ (150 bp reads, 321-byte records) to $TMPDIR, streams it twice (page cache warm),
 prints file GB/s, reads/s, k-mers/s and the stage times the driver reports.
 """
@@ -14,6 +16,7 @@ from nthash_amd.capi import NTHIP_FASTQ
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 chunk = (int(sys.argv[2]) if len(sys.argv) > 2 else 256) << 20
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+use_gz = len(sys.argv) > 5 and sys.argv[5] == "gz"
 use_seeds = len(sys.argv) > 4 and sys.argv[4] == "seeds"   # SeedNtHash, BASELINE config 4 seeds, m hashes per seed
 L, k = 150, 31
 ctx = nthash_amd.Context(0)
@@ -33,6 +36,8 @@ rec[:, 17 + L] = ord("\n")
 rec[:, 18 + L] = ord("+")
 rec[:, 19 + L] = ord("\n")
 rec[:, 20 + L:20 + 2 * L] = ord("I")
+if use_gz:
+    rec[:, 20 + L:20 + 2 * L] = np.frombuffer(b"#,5:AFI?", np.uint8)[np.random.default_rng(1).integers(0, 8, (n, L), dtype=np.uint8)]
 rec[:, 20 + 2 * L] = ord("\n")
 path = os.path.join(tempfile.gettempdir(), "nthash_bench.fq")
 t0 = time.perf_counter()
@@ -45,4 +50,17 @@ for it in range(3):
     print(f"run {it}: {st.seconds*1e3:8.1f} ms  {st.file_bytes/st.seconds/1e9:6.2f} GB/s of file  "
           f"{st.reads/st.seconds/1e6:7.1f} M reads/s  {st.kmers/st.seconds/1e9:6.2f} G k-mers/s  "
           f"(batches {st.batches}, pread {st.read_seconds*1e3:.0f} ms, index+hash {st.gpu_seconds*1e3:.0f} ms)", flush=True)
+if use_gz:
+    import subprocess
+    t0 = time.perf_counter()
+    subprocess.run(["gzip", "-1", "-k", "-f", path], check=True)
+    gz = path + ".gz"
+    print(f"gzip -1: {os.path.getsize(gz)/1e9:.2f} GB in {time.perf_counter()-t0:.1f} s", flush=True)
+    raw_bytes = os.path.getsize(path)
+    for it in range(2):
+        st = ctx.fastx_kmer_hash_file(gz, NTHIP_FASTQ, k, m, chunk_bytes=chunk, seeds=sd)
+        print(f"gz run {it}: {st.seconds*1e3:8.1f} ms  {raw_bytes/st.seconds/1e9:6.2f} GB/s inflated ({st.file_bytes/st.seconds/1e9:5.2f} on disk)  "
+              f"{st.reads/st.seconds/1e6:7.1f} M reads/s  {st.kmers/st.seconds/1e9:6.2f} G k-mers/s  "
+              f"(batches {st.batches}, inflate {st.read_seconds*1e3:.0f} ms, index+hash {st.gpu_seconds*1e3:.0f} ms)", flush=True)
+    os.remove(gz)
 os.remove(path)
