@@ -371,7 +371,9 @@ typedef struct nthip_fastx_stats {
  * A file that begins with the gzip magic (1f 8b; any name; concatenated members -- bgzip, cat a.gz b.gz -- included) is
  * inflated on the host by the system's zlib (libz.so.1, loaded at run time: NTHIP_ERR_UNSUPPORTED if it is absent), by ONE
  * thread that feeds the same pinned ring with chunks of the INFLATED stream; batches, order and results are those of the
- * plain file.  stats->file_bytes stays the size on disk; a truncated or corrupt stream is NTHIP_ERR_ARG.  The multi-device
+ * plain file.  A BGZF file (bgzip: 64 KiB members that carry their sizes) is inflated block-wise by all reader threads
+ * instead (crc32 and sizes checked; NTHIP_TUNE_NO_BGZF=1 in the environment: the one-thread path).  stats->file_bytes stays
+ * the size on disk; a truncated or corrupt stream is NTHIP_ERR_ARG.  The multi-device
  * driver gives a gzip file to its first device (a deflate stream cannot be cut at record starts without inflating it).
  */
 int nthip_fastx_kmer_hash_file(nthip_ctx* ctx, const char* path, uint32_t format, uint16_t k, uint8_t m,

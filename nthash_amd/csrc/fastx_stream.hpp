@@ -211,8 +211,32 @@ struct ZLib {
   int (*gzread)(void*, void*, unsigned) = nullptr;
   int (*gzclose)(void*) = nullptr;
   const char* (*gzerror)(void*, int*) = nullptr;
-  bool ok = false;
+  // block-wise (BGZF) inflate: the stream interface, on zlib's own z_stream layout (stable through zlib 1.x; LP64)
+  const char* (*zlibVersion)() = nullptr;
+  int (*inflateInit2_)(void*, int, const char*, int) = nullptr;
+  int (*inflate)(void*, int) = nullptr;
+  int (*inflateReset)(void*) = nullptr;
+  int (*inflateEnd)(void*) = nullptr;
+  unsigned long (*crc32)(unsigned long, const unsigned char*, unsigned) = nullptr;
+  bool ok = false, ok_raw = false;
 };
+struct NtZStream { // == z_stream of zlib.h
+  const unsigned char* next_in;
+  unsigned avail_in;
+  unsigned long total_in;
+  unsigned char* next_out;
+  unsigned avail_out;
+  unsigned long total_out;
+  const char* msg;
+  void* state;
+  void* zalloc;
+  void* zfree;
+  void* opaque;
+  int data_type;
+  unsigned long adler;
+  unsigned long reserved;
+};
+static_assert(sizeof(NtZStream) == 112, "z_stream layout (LP64)");
 
 inline const ZLib& zlib_api()
 {
@@ -227,6 +251,14 @@ inline const ZLib& zlib_api()
     r.gzclose = (int (*)(void*))dlsym(h, "gzclose");
     r.gzerror = (const char* (*)(void*, int*))dlsym(h, "gzerror");
     r.ok = r.gzdopen && r.gzbuffer && r.gzread && r.gzclose && r.gzerror;
+    r.zlibVersion = (const char* (*)())dlsym(h, "zlibVersion");
+    r.inflateInit2_ = (int (*)(void*, int, const char*, int))dlsym(h, "inflateInit2_");
+    r.inflate = (int (*)(void*, int))dlsym(h, "inflate");
+    r.inflateReset = (int (*)(void*))dlsym(h, "inflateReset");
+    r.inflateEnd = (int (*)(void*))dlsym(h, "inflateEnd");
+    r.crc32 = (unsigned long (*)(unsigned long, const unsigned char*, unsigned))dlsym(h, "crc32");
+    r.ok_raw = r.zlibVersion && r.inflateInit2_ && r.inflate && r.inflateReset && r.inflateEnd && r.crc32 &&
+               r.zlibVersion()[0] == '1';
     return r;
   }();
   return z;
@@ -288,6 +320,67 @@ struct GzSource {
     if (gz) (void)zlib_api().gzclose(gz);
   }
 };
+
+// ---- BGZF (bgzip, samtools/htslib): gzip members of at most 64 KiB, each with its compressed size in an extra field
+// ('B' 'C' 2 BSIZE) and its inflated size in the trailer -- the one kind of gzip file whose pieces can be inflated
+// independently, by as many threads as the host gives.
+constexpr uint32_t BGZF_HEAD = 18, BGZF_TAIL = 8;
+struct BgzfBlock {
+  uint64_t off;      // of the block in the file
+  uint32_t csize;    // whole block: header + deflate data + crc32 + isize
+  uint32_t isize;    // inflated bytes
+  uint64_t out_off;  // where they go in the chunk
+};
+// the block header at `off`: 1 a BGZF block (csize set), 0 something else, < 0 read error / file ends inside it
+inline int bgzf_block_at(int fd, uint64_t file_size, uint64_t off, BgzfBlock* b)
+{
+  uint8_t h[BGZF_HEAD];
+  if (off + BGZF_HEAD + BGZF_TAIL > file_size) return -1;
+  if (pread(fd, h, BGZF_HEAD, (off_t)off) != (ssize_t)BGZF_HEAD) return -1;
+  if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4 || h[10] != 6 || h[11] != 0 || h[12] != 'B' || h[13] != 'C' ||
+      h[14] != 2 || h[15] != 0)
+    return 0;
+  const uint32_t csize = ((uint32_t)h[16] | (uint32_t)h[17] << 8) + 1u;
+  if (csize < BGZF_HEAD + BGZF_TAIL || off + csize > file_size) return -1;
+  uint8_t t[4];
+  if (pread(fd, t, 4, (off_t)(off + csize - 4)) != 4) return -1;
+  b->off = off;
+  b->csize = csize;
+  b->isize = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+  return b->isize <= 65536u ? 1 : -1;
+}
+// blocks [lo, hi) of `bl` into dst (at their out_off); false: a block is corrupt
+inline bool bgzf_inflate_blocks(int fd, const std::vector<BgzfBlock>& bl, size_t lo, size_t hi, uint8_t* dst)
+{
+  const ZLib& z = zlib_api();
+  NtZStream zs;
+  memset(&zs, 0, sizeof zs);
+  if (z.inflateInit2_(&zs, -15, z.zlibVersion(), (int)sizeof zs) != 0) return false;
+  std::vector<uint8_t> in(65536 + 64);
+  bool ok = true;
+  for (size_t i = lo; i < hi && ok; ++i) {
+    const BgzfBlock& b = bl[i];
+    uint64_t done = 0;
+    while (done < b.csize) {
+      const ssize_t r = pread(fd, in.data() + done, b.csize - done, (off_t)(b.off + done));
+      if (r <= 0) { ok = false; break; }
+      done += (uint64_t)r;
+    }
+    if (!ok) break;
+    if (z.inflateReset(&zs) != 0) { ok = false; break; }
+    zs.next_in = in.data() + BGZF_HEAD;
+    zs.avail_in = b.csize - BGZF_HEAD - BGZF_TAIL;
+    zs.next_out = dst + b.out_off;
+    zs.avail_out = b.isize;
+    const int rc = z.inflate(&zs, 4 /* Z_FINISH */);
+    const uint8_t* t = in.data() + b.csize - BGZF_TAIL;
+    const uint32_t crc = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+    ok = rc == 1 /* Z_STREAM_END */ && zs.avail_out == 0 && zs.avail_in == 0 &&
+         (uint32_t)z.crc32(0, dst + b.out_off, b.isize) == crc;
+  }
+  (void)z.inflateEnd(&zs);
+  return ok;
+}
 
 constexpr uint64_t FXS_HEAD = 16ull << 20; // room in front of a chunk for the carried-over tail of the previous one
 
@@ -351,8 +444,68 @@ struct FxReader {
     }
   }
 
+  // BGZF: whole blocks up to `chunk` inflated bytes per chunk, the blocks of a chunk shared out over the reader threads
+  bool bgzf = false;
+  void run_bgzf()
+  {
+    const unsigned n_thr = n_threads ? n_threads : 16u;
+    uint64_t pos = 0;
+    std::vector<BgzfBlock> bl;
+    for (uint64_t j = 0;; ++j) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || j < next_free; });
+        if (stop) return;
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      bl.clear();
+      uint64_t len = 0;
+      bool ok = true;
+      while (pos < file_size) { // (blocks without bytes -- the end-of-file marker -- always fit)
+        BgzfBlock b;
+        const int kind = bgzf_block_at(fd, file_size, pos, &b);
+        if (kind <= 0) {
+          ok = false;
+          err = kind == 0 ? "a member that is not a BGZF block follows BGZF blocks" : "the file ends inside a BGZF block (truncated)";
+          break;
+        }
+        if (len + b.isize > chunk && !bl.empty()) break;
+        b.out_off = len;
+        len += b.isize;
+        pos += b.csize;
+        bl.push_back(b);
+      }
+      const bool last = pos >= file_size;
+      if (ok) {
+        std::atomic<bool> good{true};
+        std::vector<std::thread> ws;
+        const size_t per = (bl.size() + n_thr - 1) / n_thr;
+        for (unsigned t = 0; t < n_thr && per; ++t) {
+          const size_t lo = (size_t)t * per, hi = lo + per < bl.size() ? lo + per : bl.size();
+          if (lo >= hi) break;
+          ws.emplace_back([&, lo, hi] {
+            if (!bgzf_inflate_blocks(fd, bl, lo, hi, pinned[j & 1])) good = false;
+          });
+        }
+        for (auto& w : ws) w.join();
+        if (!good) { ok = false; err = "corrupt BGZF block (inflate / crc32 / size mismatch)"; }
+      }
+      read_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        filled[j & 1] = len;
+        if (!ok) failed = true;
+        if (last) n_chunks = len ? j + 1 : j;
+        next_ready = j + 1;
+      }
+      cv.notify_all();
+      if (!ok || last) return;
+    }
+  }
+
   void run()
   {
+    if (bgzf) return run_bgzf();
     if (gz) return run_gz();
     const unsigned n_thr = n_threads ? n_threads : 8u; // (NTHIP_TUNE_READ_THREADS: A/B knob)
     for (uint64_t j = 0; j < n_chunks; ++j) {
@@ -651,12 +804,19 @@ int fastx_stream_file(nthip_ctx* c, const char* path, uint32_t format, uint16_t 
   if (is_gz) {
     // chunks of the inflated stream, as many as it turns out to hold
     if (ranges) { close(rd.fd); return fail(NTHIP_ERR_UNSUPPORTED, "%s: byte ranges of a gzip file cannot be read on their own", path); }
-    const int zrc = gz_src.open_fd(rd.fd);
-    if (zrc != NTHIP_OK) {
-      close(rd.fd);
-      return fail(zrc, zrc == NTHIP_ERR_UNSUPPORTED ? "%s is gzip-compressed and libz.so.1 could not be loaded" : "cannot open %s as a gzip stream", path);
+    BgzfBlock b0;
+    // (NTHIP_TUNE_NO_BGZF=1, read at every call: the one-thread gzread path on a BGZF file too -- the A/B of tools/fastq_bench.py)
+    const char* no_bgzf = getenv("NTHIP_TUNE_NO_BGZF");
+    if (zlib_api().ok_raw && !(no_bgzf && no_bgzf[0] == '1') && bgzf_block_at(rd.fd, rd.file_size, 0, &b0) == 1) {
+      rd.bgzf = true; // blocks inflated side by side
+    } else {
+      const int zrc = gz_src.open_fd(rd.fd);
+      if (zrc != NTHIP_OK) {
+        close(rd.fd);
+        return fail(zrc, zrc == NTHIP_ERR_UNSUPPORTED ? "%s is gzip-compressed and libz.so.1 could not be loaded" : "cannot open %s as a gzip stream", path);
+      }
+      rd.gz = &gz_src;
     }
-    rd.gz = &gz_src;
     rd.n_chunks = ~0ull >> 2;
   }
   if (ranges) { // record-aligned pieces: whole records, so a piece may be longer than a chunk by up to one record

@@ -2518,6 +2518,104 @@ def test_fastx_gzip_chunk_edges_and_errors(ctx, oracle, tmp_path):
     assert ctx.fastx_kmer_hash_file(p, 4, 30, 1).kmers == 1
 
 
+def _bgzf(buf, block=65280, eof=True, level=6):
+    """buf as a BGZF file (bgzip / htslib): gzip members of `block` inflated bytes with the 'BC' extra field that holds the
+    member's size, and the 28-byte end-of-file marker"""
+    import struct, zlib
+    out = []
+    for a in range(0, len(buf), block):
+        raw = buf[a:a + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        payload = co.compress(raw) + co.flush()
+        bsize = 18 + len(payload) + 8
+        assert bsize <= 65536
+        out.append(struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, bsize - 1) + payload
+                   + struct.pack("<II", zlib.crc32(raw), len(raw)))
+    if eof:
+        out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return b"".join(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,chunk,block,eof,final_newline", [
+    (4, 1 << 16, 65280, True, True),      # bgzip's own block size: one block per chunk
+    (4, 1 << 17, 1000, True, False),      # many small blocks per chunk, no newline at the end of the stream
+    (2, 100_000, 4096, False, True),      # no end-of-file marker
+    (4, 1 << 26, 30_000, True, True),     # the whole file in one chunk
+])
+def test_fastx_bgzf_file_stream_vs_oracle(ctx, oracle, tmp_path, fmt, chunk, block, eof, final_newline):
+    """a BGZF file: its blocks inflated side by side by the reader threads (sizes from the block headers, crc32 checked) ==
+    the oracle on the parsed reads == the same file through the one-thread gzread path (NTHIP_TUNE_NO_BGZF=1)"""
+    import gzip, os
+    rng = np.random.default_rng(chunk % 983 + fmt + block)
+    buf, seqs = _make_fastx(rng, 6000, fmt, lo=20, hi=400)
+    if not final_newline:
+        buf = buf[:-1]
+    bg = _bgzf(buf, block, eof)
+    assert gzip.decompress(bg) == buf                      # (the writer above makes what gzip readers accept)
+    path = tmp_path / "reads.fq.gz"
+    path.write_bytes(bg)
+    k, m = 31, 2
+    data, offs = concat_reads(seqs)
+    want = oracle.kmer_batch(data, offs, k, m, want_pos=False)
+
+    def run():
+        got_h, got_c, firsts = [], [], []
+
+        def on_batch(b):
+            h, cnt = np.zeros(b.n_kmers * m, np.uint64), np.zeros(b.n_reads, np.uint64)
+            if h.size:
+                ctx.d2h(h, b.hashes)
+            ctx.d2h(cnt, b.counts)
+            got_h.append(h); got_c.append(cnt); firsts.append(b.first_read)
+
+        st = ctx.fastx_kmer_hash_file(path, fmt, k, m, chunk_bytes=chunk, on_batch=on_batch)
+        assert firsts == list(np.cumsum([0] + [c.size for c in got_c[:-1]]))
+        return st, np.concatenate(got_h), np.concatenate(got_c)
+
+    st, h, cnt = run()
+    assert st.reads == len(seqs) and st.kmers == want["total"] and st.file_bytes == len(bg)
+    if chunk < len(buf) // 4:
+        assert st.batches > 4
+    assert (cnt == want["counts"]).all() and (h == want["hashes"].ravel()).all()
+    os.environ["NTHIP_TUNE_NO_BGZF"] = "1"
+    try:
+        st1, h1, c1 = run()
+    finally:
+        del os.environ["NTHIP_TUNE_NO_BGZF"]
+    assert st1.reads == st.reads and (h1 == h).all() and (c1 == cnt).all()
+
+
+@pytest.mark.gpu
+def test_fastx_bgzf_errors(ctx, tmp_path):
+    """a block whose data, crc32 or size field was damaged, a file cut inside a block, an ordinary gzip member behind BGZF
+    blocks: NTHIP_ERR_ARG, and the context works afterwards"""
+    import gzip
+    import nthash_amd
+    rng = np.random.default_rng(5)
+    buf, seqs = _make_fastx(rng, 3000, 4, lo=50, hi=200)
+    good = _bgzf(buf, 20_000)
+    first = 18 + int.from_bytes(good[16:18], "little") + 1 - 18      # size of the first block
+    cases = {}
+    b = bytearray(good); b[first // 2] ^= 0x10; cases["data"] = bytes(b)
+    b = bytearray(good); b[first - 8] ^= 0x01; cases["crc"] = bytes(b)
+    b = bytearray(good); b[first - 4] ^= 0x01; cases["isize"] = bytes(b)
+    cases["cut"] = good[:len(good) - 28 - 100]
+    cases["mixed"] = _bgzf(buf[:40_000], 20_000, eof=False) + gzip.compress(buf[40_000:])
+    for name, blob in cases.items():
+        p = tmp_path / (name + ".fq.gz")
+        p.write_bytes(blob)
+        with pytest.raises(nthash_amd.NtHipError):
+            ctx.fastx_kmer_hash_file(p, 4, 31, 1, chunk_bytes=1 << 16)
+    p = tmp_path / "good.fq.gz"
+    p.write_bytes(good)
+    assert ctx.fastx_kmer_hash_file(p, 4, 31, 1, chunk_bytes=1 << 16).reads == len(seqs)
+    # only the end-of-file marker: an empty stream
+    p.write_bytes(_bgzf(b""))
+    st = ctx.fastx_kmer_hash_file(p, 4, 31, 1)
+    assert st.reads == 0 and st.batches == 0
+
+
 @pytest.mark.gpu
 def test_fastx_gzip_multiline_fasta_and_multi_device(ctx, oracle, tmp_path):
     """NTHIP_FASTA_MULTILINE from a gzip file (inflated on the host, then the one-batch path), and the multi-device driver

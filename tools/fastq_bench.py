@@ -63,4 +63,30 @@ if use_gz:
               f"{st.reads/st.seconds/1e6:7.1f} M reads/s  {st.kmers/st.seconds/1e9:6.2f} G k-mers/s  "
               f"(batches {st.batches}, inflate {st.read_seconds*1e3:.0f} ms, index+hash {st.gpu_seconds*1e3:.0f} ms)", flush=True)
     os.remove(gz)
+    # the same bytes as BGZF (bgzip's layout: 65280-byte blocks, level 1 here): blocks inflated by the reader threads
+    import struct, zlib
+    bg = path + ".bgzf.gz"
+    t0 = time.perf_counter()
+    with open(path, "rb") as fi, open(bg, "wb") as fo:
+        while True:
+            raw = fi.read(65280)
+            if not raw:
+                break
+            co = zlib.compressobj(1, zlib.DEFLATED, -15)
+            payload = co.compress(raw) + co.flush()
+            fo.write(struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, 18 + len(payload) + 8 - 1))
+            fo.write(payload)
+            fo.write(struct.pack("<II", zlib.crc32(raw), len(raw)))
+        fo.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    print(f"BGZF: {os.path.getsize(bg)/1e9:.2f} GB in {time.perf_counter()-t0:.1f} s", flush=True)
+    for tag, env in (("bgzf", None), ("bgzf, one thread (NTHIP_TUNE_NO_BGZF=1)", "1")):
+        if env:
+            os.environ["NTHIP_TUNE_NO_BGZF"] = env
+        for it in range(2):
+            st = ctx.fastx_kmer_hash_file(bg, NTHIP_FASTQ, k, m, chunk_bytes=chunk, seeds=sd)
+            print(f"{tag} run {it}: {st.seconds*1e3:8.1f} ms  {raw_bytes/st.seconds/1e9:6.2f} GB/s inflated ({st.file_bytes/st.seconds/1e9:5.2f} on disk)  "
+                  f"{st.reads/st.seconds/1e6:7.1f} M reads/s  {st.kmers/st.seconds/1e9:6.2f} G k-mers/s  "
+                  f"(batches {st.batches}, inflate {st.read_seconds*1e3:.0f} ms, index+hash {st.gpu_seconds*1e3:.0f} ms)", flush=True)
+        os.environ.pop("NTHIP_TUNE_NO_BGZF", None)
+    os.remove(bg)
 os.remove(path)
