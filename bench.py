@@ -530,7 +530,11 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
         t_q, (tq, found) = best(lambda: ctx.bloom_query_ptr(d_in, n_reads, L, 0, k, 1, d_f, n_bits))
         out["bloom_query_4GiB"] = {"value": tq / t_q, "ms": t_q * 1e3,
                                    "roofline": roof(in_bytes + 8 * n_reads, t_q, "bases in + 8 B per read (hits)",
-                                                    "random-load bound: one 4-byte filter load per k-mer from a 4 GiB table")}
+                                                    "random-load bound: one 4-byte filter load per k-mer from a 4 GiB table; every such "
+                                                    "load moves a 128-byte line (line_traffic below: the rate the fabric delivers "
+                                                    "lines at, the same on a 128 MiB filter -- profiles/r04_notes.md 9.2)")}
+        out["bloom_query_4GiB"]["roofline"]["line_traffic"] = {"bytes_per_kmer": 128, "GBps": tq * 128 / t_q / 1e9,
+                                                               "frac_of_peak": tq * 128 / t_q / 1e9 / HBM_PEAK_GBPS}
         ctx.memset(d_f, 0, n_bits // 8)
         ctx.bloom_insert_ptr(d_in, n_reads, L, 0, k, 1, d_f, n_bits)   # (the kernel of record of an insert, for the line below)
         out["bloom_insert_fresh_4GiB"] = {"value": tot / t_ins, "ms": t_ins * 1e3, "check": "every inserted k-mer is found",
