@@ -710,40 +710,8 @@ static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* 
   uint64_t mlen = 0, mpitch = 0, slen = 0;
   uint32_t bad = 0;
   const uint32_t lane = threadIdx.x & 63u;
-  uint64_t r_begin = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
-  if (!tile_sum) {
-    // the survey alone: four grid strides per round, their twelve loads issued before the first is looked at (one read per
-    // lane and round left a wave with 1.5 KB in flight: 0.20 ms per 20 M spans, 1.6 TB/s)
-    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
-    for (; r_begin < n; r_begin += 4 * step) {
-      uint64_t s0[4], e0[4], s1[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint64_t r = r_begin + (uint64_t)j * step + lane;
-        s0[j] = r < n ? starts[r] : 0;
-        e0[j] = r < n ? ends[r] : 0;
-        s1[j] = r + 1 < n ? starts[r + 1] : ~0ull;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint64_t r = r_begin + (uint64_t)j * step + lane;
-        if (r >= n) continue;
-        if (e0[j] < s0[j] || e0[j] > buf_bytes) {
-          bad = 1;
-          continue;
-        }
-        const uint64_t l = e0[j] - s0[j];
-        if (l > mlen) mlen = l;
-        slen += l;
-        if (r + 1 < n) {
-          if (s1[j] < e0[j] && !(allow_overlap && s1[j] >= s0[j] && ends[r + 1] >= e0[j])) bad = 1;
-          else if (s1[j] - s0[j] > mpitch) mpitch = s1[j] - s0[j];
-        }
-      }
-    }
-  }
   // (whole waves iterate together: the segmented scan below needs every lane of a wave in the loop)
-  for (uint64_t r0 = r_begin; r0 < n; r0 += (uint64_t)gridDim.x * blockDim.x) {
+  for (uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); r0 < n; r0 += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t r = r0 + lane;
     uint64_t nwin = 0;
     if (r < n) {
