@@ -248,7 +248,7 @@ def var_reads(first_read, n_reads, len_min, len_max, seed=42):
     return lens, (x >> np.uint64(32)) % np.uint64(997) == 0, (x >> np.uint64(16)) % lens
 
 
-SLOW_FILL_GBPS = 6600.0  # write-only fill of a buffer in the slow placement class: 5.1-6.1 TB/s; the others 6.9-7.2 (r02 notes 11)
+SLOW_FILL_GBPS = float(os.environ.get("NTHASH_BENCH_SLOW_FILL_GBPS", "6600"))  # (the env: to exercise the second round)  # write-only fill of a buffer in the slow placement class: 5.1-6.1 TB/s; the others 6.9-7.2 (r02 notes 11)
 PLACE_CANDIDATES = 3  # nthip_malloc_probed: allocations measured per big buffer (1: plain allocation; --no-placement)
 
 
