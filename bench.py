@@ -38,7 +38,7 @@ SEED_A = "1010101010101010101010101010101"
 SEED_B = "1101101101101101011011011011011"
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 SHARD_READS_MULTI = 125_000_000  # BASELINE config 5: 1 G reads over 8 GPUs
-TRAFFIC_FILE = "profiles/r03_traffic.json"
+TRAFFIC_FILE = "profiles/r04_traffic.json"
 
 CONFIGS = {
     # name: description, read length, k, hashes per k-mer (m, or m per seed), default reads per GPU
