@@ -568,7 +568,44 @@ int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, 
   std::vector<uint8_t> inflated;
   const int is_gz = fd_is_gzip(fd);
   if (is_gz < 0) { close(fd); return fail(NTHIP_ERR_ARG, "read error on %s", path); }
-  if (is_gz) {
+  BgzfBlock b0;
+  const char* no_bgzf = getenv("NTHIP_TUNE_NO_BGZF");
+  if (is_gz && zlib_api().ok_raw && !(no_bgzf && no_bgzf[0] == '1') && bgzf_block_at(fd, size, 0, &b0) == 1) {
+    // BGZF (a bgzipped genome): the sizes are in the block headers -- one walk over them, then every block inflated in
+    // its place by the reader threads
+    std::vector<BgzfBlock> bl;
+    uint64_t pos = 0, have = 0;
+    while (pos < size) {
+      BgzfBlock b;
+      const int kind = bgzf_block_at(fd, size, pos, &b);
+      if (kind <= 0) {
+        close(fd);
+        return fail(NTHIP_ERR_ARG, kind == 0 ? "%s: a member that is not a BGZF block follows BGZF blocks"
+                                             : "%s: the file ends inside a BGZF block (truncated)", path);
+      }
+      b.out_off = have;
+      have += b.isize;
+      pos += b.csize;
+      bl.push_back(b);
+    }
+    inflated.resize(have ? have : 1);
+    const unsigned n_thr = c->tune.read_threads ? c->tune.read_threads : 16u;
+    std::atomic<bool> good{true};
+    std::vector<std::thread> ws;
+    const size_t per = (bl.size() + n_thr - 1) / n_thr;
+    for (unsigned t = 0; t < n_thr && per; ++t) {
+      const size_t lo = (size_t)t * per, hi = lo + per < bl.size() ? lo + per : bl.size();
+      if (lo >= hi) break;
+      ws.emplace_back([&, lo, hi] {
+        if (!bgzf_inflate_blocks(fd, bl, lo, hi, inflated.data())) good = false;
+      });
+    }
+    for (auto& w : ws) w.join();
+    if (!good) { close(fd); return fail(NTHIP_ERR_ARG, "%s: corrupt BGZF block (inflate / crc32 / size mismatch)", path); }
+    inflated.resize(have);
+    size = have;
+    if (size == 0) { close(fd); return NTHIP_OK; }
+  } else if (is_gz) {
     GzSource src;
     const int zrc = src.open_fd(fd);
     if (zrc != NTHIP_OK) {

@@ -2640,6 +2640,17 @@ def test_fastx_gzip_multiline_fasta_and_multi_device(ctx, oracle, tmp_path):
     st = ctx.fastx_kmer_hash_file(path, NTHIP_FASTA_MULTILINE, k, m, on_batch=on_genome)
     assert st.reads == len(seqs) and st.kmers == want["total"] and st.batches == 1
     assert (got["c"] == want["counts"]).all() and (got["h"] == want["hashes"].ravel()).all()
+    # the same genome bgzipped: its blocks inflated side by side before the one-batch path
+    got.clear()
+    path = tmp_path / "genome.bgzf.fa.gz"
+    path.write_bytes(_bgzf(buf[:-1], 30_000))
+    st = ctx.fastx_kmer_hash_file(path, NTHIP_FASTA_MULTILINE, k, m, on_batch=on_genome)
+    assert st.reads == len(seqs) and st.kmers == want["total"] and st.batches == 1
+    assert (got["c"] == want["counts"]).all() and (got["h"] == want["hashes"].ravel()).all()
+    bad = bytearray(_bgzf(buf[:-1], 30_000)); bad[5000] ^= 0x40
+    path.write_bytes(bytes(bad))
+    with pytest.raises(nthash_amd.NtHipError):
+        ctx.fastx_kmer_hash_file(path, NTHIP_FASTA_MULTILINE, k, m)
     # multi-device
     buf, seqs = _make_fastx(rng, 5000, 4, lo=20, hi=300)
     path = tmp_path / "reads.fq.gz"
