@@ -276,13 +276,16 @@ class Workload:
             # every candidate landed in the slow class (one default line in seven, profiles/r04_notes.md): a second round of
             # candidates while this one is HELD -- they cannot be handed the same pages -- if there is room for both
             free_b, _tot = self.torch.cuda.mem_get_info(self.dev)
-            if nbytes + (4 << 30) < free_b:
-                ptr2, gbps2, tried2 = self.ctx.malloc_probed(nbytes, cands)
+            if nbytes + (16 << 30) < free_b:
+                try:
+                    ptr2, gbps2, tried2 = self.ctx.malloc_probed(nbytes, cands)
+                except Exception:  # noqa: BLE001 -- no room after all: the first round's buffer stands
+                    ptr2, gbps2, tried2 = None, None, 0
                 tried += tried2
-                if gbps2 and gbps2 > gbps:
+                if ptr2 and gbps2 and gbps2 > gbps:
                     self.ctx.free(ptr)
                     ptr, gbps = ptr2, gbps2
-                else:
+                elif ptr2:
                     self.ctx.free(ptr2)
         self.placement.append({"buffer": what, "GiB": round(nbytes / 2**30, 2), "fill_GBps": round(gbps, 1) if gbps else None,
                                "candidates_measured": tried})
