@@ -11,6 +11,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -566,6 +567,8 @@ int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, 
   const uint64_t piece = 64ull << 20;
   // gzip input: the whole file is one batch anyway -- inflated into host memory first (its size is not known before)
   std::vector<uint8_t> inflated;
+  std::unique_ptr<uint8_t[]> inflated_raw;
+  const uint8_t* inflated_ptr = nullptr;
   const int is_gz = fd_is_gzip(fd);
   if (is_gz < 0) { close(fd); return fail(NTHIP_ERR_ARG, "read error on %s", path); }
   BgzfBlock b0;
@@ -588,7 +591,9 @@ int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, 
       pos += b.csize;
       bl.push_back(b);
     }
-    inflated.resize(have ? have : 1);
+    // (not a vector: its resize would touch every page from one thread before the first block is inflated)
+    inflated_raw.reset(new uint8_t[have ? have : 1]);
+    inflated_ptr = inflated_raw.get();
     const unsigned n_thr = c->tune.read_threads ? c->tune.read_threads : 16u;
     std::atomic<bool> good{true};
     std::vector<std::thread> ws;
@@ -597,12 +602,11 @@ int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, 
       const size_t lo = (size_t)t * per, hi = lo + per < bl.size() ? lo + per : bl.size();
       if (lo >= hi) break;
       ws.emplace_back([&, lo, hi] {
-        if (!bgzf_inflate_blocks(fd, bl, lo, hi, inflated.data())) good = false;
+        if (!bgzf_inflate_blocks(fd, bl, lo, hi, inflated_raw.get())) good = false;
       });
     }
     for (auto& w : ws) w.join();
     if (!good) { close(fd); return fail(NTHIP_ERR_ARG, "%s: corrupt BGZF block (inflate / crc32 / size mismatch)", path); }
-    inflated.resize(have);
     size = have;
     if (size == 0) { close(fd); return NTHIP_OK; }
   } else if (is_gz) {
@@ -621,6 +625,7 @@ int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, 
       if ((uint64_t)r < piece) break;
     }
     inflated.resize(have);
+    inflated_ptr = inflated.data();
     size = have;
     if (size == 0) { close(fd); return NTHIP_OK; }
   }
@@ -659,7 +664,7 @@ int fasta_multiline_file(nthip_ctx* c, const char* path, uint16_t k, uint8_t m, 
       const uint64_t len = off + piece <= size ? piece : size - off;
       if (i >= 2) FA_TRY(hipEventSynchronize(ev[i & 1])); // the upload that used this pinned buffer
       uint64_t done = is_gz ? len : 0;
-      if (is_gz) memcpy(pinned[i & 1], inflated.data() + off, len);
+      if (is_gz) memcpy(pinned[i & 1], inflated_ptr + off, len);
       while (done < len) {
         const ssize_t r = pread(fd, pinned[i & 1] + done, len - done, (off_t)(off + done));
         if (r <= 0) { rc = fail(NTHIP_ERR_ARG, "read error on %s", path); cleanup(); return rc; }

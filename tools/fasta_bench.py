@@ -35,4 +35,30 @@ for it in range(3):
     st = ctx.fastx_kmer_hash_file(path, NTHIP_FASTA_MULTILINE, 31, 1)
     print(f"run {it}: {st.seconds*1e3:8.1f} ms  {st.file_bytes/st.seconds/1e9:6.2f} GB/s of file  {st.kmers/st.seconds/1e9:6.2f} G k-mers/s"
           f"  (load {st.read_seconds*1e3:.0f} ms, compact+hash {st.gpu_seconds*1e3:.0f} ms, last kernel {ctx.last_kernel_ms()})", flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "gz":
+    # the same genome bgzipped (65280-byte blocks, level 1): blocks inflated by the reader threads, then the one-batch path;
+    # NTHIP_TUNE_NO_BGZF=1: one inflating thread
+    import struct, zlib
+    bg = path + ".gz"
+    t0 = time.perf_counter()
+    with open(path, "rb") as fi, open(bg, "wb") as fo:
+        while True:
+            raw = fi.read(65280)
+            if not raw:
+                break
+            co = zlib.compressobj(1, zlib.DEFLATED, -15)
+            payload = co.compress(raw) + co.flush()
+            fo.write(struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, 18 + len(payload) + 8 - 1))
+            fo.write(payload)
+            fo.write(struct.pack("<II", zlib.crc32(raw), len(raw)))
+        fo.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    print(f"BGZF: {os.path.getsize(bg)/1e9:.2f} GB in {time.perf_counter()-t0:.1f} s", flush=True)
+    for tag, env in (("bgzf", None), ("bgzf, one thread", "1")):
+        if env:
+            os.environ["NTHIP_TUNE_NO_BGZF"] = env
+        for it in range(2):
+            st = ctx.fastx_kmer_hash_file(bg, NTHIP_FASTA_MULTILINE, 31, 1)
+            print(f"{tag} run {it}: {st.seconds*1e3:8.1f} ms  {size/st.seconds/1e9:6.2f} GB/s inflated  {st.kmers/st.seconds/1e9:6.2f} G k-mers/s", flush=True)
+        os.environ.pop("NTHIP_TUNE_NO_BGZF", None)
+    os.remove(bg)
 os.remove(path)
