@@ -22,6 +22,7 @@ names = {  # scratch name -> tracked name
     "shape_sweep.txt": f"{tag}_shape_sweep.txt",
     "pytest_gpu.txt": f"{tag}_pytest_gpu.txt",
     "fastq_gz_bench.txt": f"{tag}_fastq_gz_bench.txt",
+    "fasta_gz_bench.txt": f"{tag}_fasta_gz_bench.txt",
     "profile_round.log": f"{tag}_profile_round.log",
     "pmc_c2/summary.txt": f"{tag}_pmc_c2_summary.txt",
     "pmc_c4/summary.txt": f"{tag}_pmc_c4_summary.txt",

@@ -22,6 +22,8 @@ SWEEP_SHAPES="250,128,1,1;300,160,1,1;250,96,1,1;250,31,5,1;250,31,8,1;150,48,3,
 timeout 300 python tools/seed_roll_sweep.py > "$OUT/seed_roll_sweep.txt" 2>&1
 timeout 300 python tools/extend_bench.py > "$OUT/extend_bench.txt" 2>&1
 timeout 600 python tools/facade_bench.py > "$OUT/facade_bench.txt" 2>&1
+timeout 600 python tools/fastq_bench.py 10000000 256 1 kmers gz > "$OUT/fastq_gz_bench.txt" 2>&1
+timeout 600 python tools/fasta_bench.py 3000 24 gz > "$OUT/fasta_gz_bench.txt" 2>&1
 timeout 600 python tools/shape_sweep.py > "$OUT/shape_sweep.txt" 2>&1
 timeout 2400 python -m pytest tests -q -m gpu > "$OUT/pytest_gpu.txt" 2>&1
 tail -3 "$OUT/pytest_gpu.txt"
