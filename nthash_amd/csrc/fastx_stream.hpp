@@ -1,6 +1,7 @@
 // fastx_stream.hpp -- host side of the FASTQ/FASTA path (included by capi_fastx.hip):
 // nthip_kmer_hash_spans, nthip_fastx_index and the streaming driver
-// nthip_fastx_kmer_hash_file (reader threads -> pinned buffers -> copy stream -> index + hash).
+// nthip_fastx_kmer_hash_file (reader threads -> pinned buffers -> copy stream -> index + hash).  The reader threads pread a
+// plain file; a gzip file is inflated by one of them (gzread), a BGZF file block-wise by all of them (zlib through dlopen).
 #pragma once
 
 #include <dlfcn.h>
