@@ -230,6 +230,8 @@ int nthip_seed_extend(nthip_ctx* ctx, const char* kmers, uint64_t n_kmers, const
  * insert: *total (optional) = k-mers consumed.
  * query : hits[r] (optional; host memory with NTHIP_HOST_OUTPUT) = k-mers of read r whose m bits
  *         are all set; *total = k-mers tested, *total_hits = sum of hits.
+ * A large batch of fixed-length device-resident reads against a filter beyond the caches is not answered load by load (a
+ * 128-byte line per k-mer) but region by region, as the insert goes (the binned query: DESIGN 4.8); same results.
  * Any k >= 3 and m >= 1.  Fixed-length reads (reads->offsets == NULL): fused, any batch size.  Reads of any lengths
  * (reads->offsets: a FASTQ batch): the batch's compact hash stream is produced in ONE round in device scratch and the
  * stream forms consume it -- NTHIP_ERR_UNSUPPORTED when that stream (8 m bytes per base at most) does not fit the
@@ -273,6 +275,15 @@ int nthip_stream_count_insert(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t
                               uint64_t n_counters);
 int nthip_stream_count_query(nthip_ctx* ctx, const uint64_t* d_hashes, uint64_t n_kmers, uint8_t m,
                              const uint8_t* d_counters, uint64_t n_counters, uint8_t* d_estimates);
+/* nthip_kmer_count_query: the sketch's read side on the reads themselves -- no hash stream.  estimates (device memory; host
+ * memory with NTHIP_HOST_OUTPUT): one byte per WINDOW of the batch, read r's windows at slot_off[r] = sum over the reads
+ * before it of max(len - k + 1, 0) (fixed-length reads: r * (len - k + 1)): estimates[slot_off[r] + w] = the smallest of the
+ * m counters of the k-mer NtHash emits at position w of read r (get_pos() == w; src/kmer.cpp:228-264 for what is emitted,
+ * src/internal.hpp:104-118 for hashes()[i]), 0 for a window it skips.  *total (optional) = k-mers NtHash emits.  A large
+ * batch of fixed-length device-resident reads against a large sketch goes region by region (the binned query, as
+ * nthip_kmer_bloom_query); everything else through the compact stream of rounds of reads and nthip_stream_count_query. */
+int nthip_kmer_count_query(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k, uint8_t m, const uint8_t* d_counters,
+                           uint64_t n_counters, uint8_t* estimates, uint64_t* total, uint32_t flags);
 
 /* Per-read (w, k)-minimizers: of every w consecutive window positions of a read, the k-mer NtHash emits there with the
  * smallest canonical hash (hashes()[0]; ties: the leftmost); a k-mer holding a non-base is not a candidate, a window

@@ -46,7 +46,7 @@ SYMBOLS = [
     "nthip_kmer_count_insert", "nthip_stream_count_insert", "nthip_stream_count_query", "nthip_kmer_minimizers",
     "nthip_stream_bloom_query", "nthip_kmer_minimizers_spans",
     "nthip_multi_ctx", "nthip_multi_kmer_hash_shards", "nthip_multi_kmer_bloom_insert", "nthip_multi_kmer_count_insert",
-    "nthip_multi_kmer_minhash_set", "nthip_multi_merge", "nthip_seed_extend",
+    "nthip_multi_kmer_minhash_set", "nthip_multi_merge", "nthip_seed_extend", "nthip_kmer_count_query",
 ]
 NTHIP_MULTI_ALLGATHER = 0x100
 NTHIP_MERGE_OR, NTHIP_MERGE_ADD_SAT_U8, NTHIP_MERGE_MIN_U64 = 0, 1, 2
@@ -130,6 +130,7 @@ def load():
     L.nthip_stream_count_insert.argtypes = [vp, vp, u64, vp, u64]
     L.nthip_stream_bloom_query.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp, C.POINTER(u64)]
     L.nthip_stream_count_query.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp]
+    L.nthip_kmer_count_query.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, u64, vp, C.POINTER(u64), u32]
     L.nthip_kmer_minimizers.argtypes = [vp, C.POINTER(Reads), C.c_uint16, u32, vp, vp, vp, u64, C.POINTER(u64), u32]
     L.nthip_kmer_minimizers_spans.argtypes = [vp, vp, u64, vp, vp, u64, C.c_uint16, u32, vp, vp, vp, u64, C.POINTER(u64)]
     L.nthip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
@@ -493,6 +494,28 @@ class Context:
             offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         return self.count_insert_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, d_counters, n_counters,
                                      flags=NTHIP_HOST_INPUT, offsets=offsets.ctypes.data if offsets is not None else 0)
+
+    def count_query_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_counters, n_counters, estimates, flags=0, offsets=0):
+        """estimates: one byte per window of the batch (read r's at the windows of the reads before it); -> k-mers emitted"""
+        rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
+        total = C.c_uint64(0)
+        _chk(self.L.nthip_kmer_count_query(self.h, C.byref(rd), k, m, C.c_void_p(d_counters), C.c_uint64(n_counters),
+                                           C.c_void_p(estimates), C.byref(total), flags))
+        return total.value
+
+    def count_query(self, data, k, m, fixed_len, n_reads, d_counters, n_counters, stride=0, offsets=None):
+        """host reads -> (estimates per window as a numpy array, k-mers emitted)"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+            n_win = int(np.maximum(lens - k + 1, 0).sum())
+        else:
+            n_win = n_reads * max(fixed_len - k + 1, 0)
+        est = np.zeros(max(n_win, 1), np.uint8)
+        total = self.count_query_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, d_counters, n_counters, est.ctypes.data,
+                                     flags=NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT, offsets=offsets.ctypes.data if offsets is not None else 0)
+        return est[:n_win], total
 
     def stream_bloom_query_ptr(self, d_hashes, n_kmers, m, d_filter, n_bits, d_flags):
         """d_flags[i] = 1 when all m bits of k-mer i are set; -> the number of such k-mers"""

@@ -95,8 +95,9 @@ __device__ __forceinline__ bool bloom_round_failed(const BloomStatus* st, uint64
   return st && __builtin_nontemporal_load(&st->ovf_n) > ovf_cap;
 }
 // a wave appends the entries [fit, cnt) of a tile's bucket run to the overflow list as full positions
-__device__ __forceinline__ void bloom_overflow_run(const BloomSlots& sl, const uint32_t* run, uint32_t fit, uint32_t cnt, uint64_t bucket_pos,
-                                                   uint32_t lane)
+// (returns the run's first index in the overflow list -- the binned QUERY finds its answers there, bloom_query_kernels.hpp)
+__device__ __forceinline__ unsigned long long bloom_overflow_run(const BloomSlots& sl, const uint32_t* run, uint32_t fit, uint32_t cnt,
+                                                                 uint64_t bucket_pos, uint32_t lane)
 {
   unsigned long long base = 0;
   if (lane == 0) base = atomicAdd(&sl.status->ovf_n, (unsigned long long)(cnt - fit));
@@ -106,6 +107,7 @@ __device__ __forceinline__ void bloom_overflow_run(const BloomSlots& sl, const u
     const unsigned long long idx = base + (q - fit);
     if (idx < sl.ovf_cap) sl.ovf[idx] = bucket_pos | run[q];
   }
+  return base;
 }
 
 // The copy-out of a sorted tile: wave w takes the buckets w, w + NW, w + 2 NW, ...  A lane holds the count, the place in the
@@ -113,11 +115,12 @@ __device__ __forceinline__ void bloom_overflow_run(const BloomSlots& sl, const u
 // them back with v_readlane, four buckets at a time -- their first 128 entries read from LDS before the first store is
 // issued.  (One bucket after the other, every LDS read waited for: 4.8 of a tile's 10 us on the second level.)
 // exact lists: gbase = the run's place in `out`; slots mode: relative to bucket (bucket0 + b)'s own cap entries.
-template <uint32_t NW>
+template <uint32_t NW, bool QUERY = false>
 __device__ __forceinline__ void bloom_copy_out(const uint32_t* sorted, const uint32_t* hist, const uint32_t* off, const uint32_t* gbase,
                                                uint32_t n_buckets, uint32_t wave, uint32_t lane, uint32_t* out, uint64_t bucket0,
-                                               const BloomSlots& sl, uint32_t shift)
+                                               const BloomSlots& sl, uint32_t shift, uint32_t* tovf = nullptr)
 {
+  // (tovf, the binned query: tovf[b] = where the tile's overflowing entries of bucket b start in the overflow list)
   static_assert(NW >= 4, "at most 64 buckets per wave");
   const uint32_t myb = wave + lane * NW;
   uint32_t mc = 0, mo = 0, mg = 0;
@@ -155,7 +158,14 @@ __device__ __forceinline__ void bloom_copy_out(const uint32_t* sorted, const uin
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) { // (rare: a bucket with more than 128 of the tile's values, a bucket that is full)
       for (uint32_t j = lane + 128u; j < fit[u]; j += 64u) dst[u][j] = sorted[o[u] + j];
-      if (fit[u] < c[u]) bloom_overflow_run(sl, sorted + o[u], fit[u], c[u], (bucket0 + wave + (uint64_t)(i0 + u) * NW) << shift, lane);
+      if constexpr (QUERY) {
+        if (fit[u] < c[u]) {
+          const unsigned long long ob = bloom_overflow_run(sl, sorted + o[u], fit[u], c[u], (bucket0 + wave + (uint64_t)(i0 + u) * NW) << shift, lane);
+          if (lane == 0) tovf[wave + (i0 + u) * NW] = (uint32_t)(ob < 0xFFFFFFFFull ? ob : 0xFFFFFFFFull);
+        }
+      } else {
+        if (fit[u] < c[u]) (void)bloom_overflow_run(sl, sorted + o[u], fit[u], c[u], (bucket0 + wave + (uint64_t)(i0 + u) * NW) << shift, lane);
+      }
     }
   }
 }
@@ -243,9 +253,21 @@ struct BloomPartArgs {
   uint64_t cap_in;
   const uint32_t* seg_fill;
 };
+// the binned query (QUERY instantiation, slots mode; bloom_query_kernels.hpp): what the way back needs of every tile --
+// q_where[slot of the input list] = bucket << 16 | rank of the entry in its tile's bucket; per tile (segment s, its tile
+// t: row s * q_tiles_per_seg + t) and bucket b, q_tab[row * buckets_per_seg + b] = {entries of the tile, where the run
+// went in the bucket's slots}, q_tovf[...] = where its overflowing entries start in the overflow list (set when any)
+// (a struct of its own: the insert's instantiations keep the argument block -- and the register allocation -- they had)
+struct BloomPartQueryArgs : BloomPartArgs {
+  uint32_t* q_where;
+  uint2* q_tab;
+  uint32_t* q_tovf;
+  uint32_t q_tiles_per_seg;
+};
 
-template <bool IN64, uint32_t BB_PART_THREADS>
-static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(const BloomPartArgs a)
+template <bool IN64, uint32_t BB_PART_THREADS, bool QUERY = false>
+static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(
+    const typename std::conditional<QUERY, BloomPartQueryArgs, BloomPartArgs>::type a)
 {
   constexpr uint32_t BB_TILE = BB_PART_THREADS * BB_PART_ITEMS;
   __shared__ uint32_t hist[BB_MAX_BINS];
@@ -328,16 +350,26 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
         }
       }
     }
+    if constexpr (QUERY) { // the way back: every slot of the input list remembers its place in the tile's sort
+#pragma unroll
+      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+        const uint64_t idx = t0 + (uint64_t)j * BB_PART_THREADS + tid;
+        if (idx < s1) a.q_where[idx] = where[j];
+      }
+    }
     if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
     __syncthreads();
 #if BB_TIMING
     const uint64_t tk1 = __builtin_amdgcn_s_memrealtime();
 #endif
     uint32_t my_base = 0;
+    uint64_t q_row = 0;
+    if constexpr (QUERY) q_row = ((uint64_t)seg * a.q_tiles_per_seg + tile) * a.buckets_per_seg;
     if (tid < n_buckets) {
       const uint32_t c = hist[tid];
       // (the answer is wanted by the copy-out only: it travels while the tile is sorted)
       my_base = c ? atomicAdd(&cursor[(size_t)tid * BB_CURSOR_STRIDE], c) : 0u;
+      if constexpr (QUERY) a.q_tab[q_row + tid] = make_uint2(c, my_base);
     }
     if (wave == 0) { // exclusive scan of the (at most 256) bucket counts: 4 per lane
       uint32_t c[4], s = 0;
@@ -398,7 +430,11 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(cons
       for (uint32_t j = lane; j < c; j += 64u) asm volatile("" ::"v"(sorted[o + j]), "v"(dst));
     }
 #else
-    bloom_copy_out<BB_PART_THREADS / 64u>(sorted, hist, off, gbase, n_buckets, wave, lane, a.out, (uint64_t)seg * a.buckets_per_seg, a.sl, a.shift);
+    if constexpr (QUERY)
+      bloom_copy_out<BB_PART_THREADS / 64u, true>(sorted, hist, off, gbase, n_buckets, wave, lane, a.out, (uint64_t)seg * a.buckets_per_seg, a.sl,
+                                                  a.shift, a.q_tovf + q_row);
+    else
+      bloom_copy_out<BB_PART_THREADS / 64u>(sorted, hist, off, gbase, n_buckets, wave, lane, a.out, (uint64_t)seg * a.buckets_per_seg, a.sl, a.shift);
 #endif
     __syncthreads();
 #if BB_TIMING

@@ -53,10 +53,21 @@ struct BloomFusedArgs {
   uint32_t shift, mask, n_buckets;
   BloomSlots sl;            // slots mode (sl.cap != 0; bloom_binned_kernels.hpp): bucket b owns out[b * cap ...), cursors count from 0
 };
+// the binned QUERY (bloom_query_kernels.hpp; QUERY instantiation of pass PART, slots mode): the way back of every tile.
+// Tile row ts = ((tile * q_steps) + (word - first emitting word)) * m + jj;  q_where[(ts * 16 + i) * THREADS + thread] =
+// bucket << 16 | rank of that window's value in the tile's bucket (~0: nothing emitted), for the steps i that can emit;
+// q_tab[ts * n_buckets + b] = {entries, place of the run in bucket b's slots}; q_tovf[...]: see bloom_copy_out
+// (a struct of its own: the insert's instantiations keep the argument block they had)
+struct BloomFusedQueryArgs : BloomFusedArgs {
+  uint32_t* q_where;
+  uint2* q_tab;
+  uint32_t* q_tovf;
+  uint32_t q_steps;
+};
 
 // THREADS reads per tile; dynamic LDS: bit stream | COUNT: n_regions counters / PART: THREADS * 16 sorted slots
-template <int PASS, uint32_t THREADS>
-__global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedArgs a)
+template <int PASS, uint32_t THREADS, bool QUERY = false>
+__global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename std::conditional<QUERY, BloomFusedQueryArgs, BloomFusedArgs>::type a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   __shared__ __attribute__((aligned(16))) uint4 tab[16];
@@ -207,11 +218,19 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
               where[i] = (b << 16) | atomicAdd(&hist[b], 1u);
             }
           }
+          uint64_t q_ts = 0;
+          if constexpr (QUERY) {
+            q_ts = ((uint64_t)t * a.q_steps + (j - jb)) * m + jj;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; ++i)
+              if (i >= lo && i < hi) a.q_where[(q_ts * 16u + i) * THREADS + tid] = where[i];
+          }
           __syncthreads();
           uint32_t my_base = 0; // (the cursor's answer is wanted by the copy-out only: it travels while the tile is sorted)
           if (tid < a.n_buckets) {
             const uint32_t cnt = hist[tid];
             my_base = cnt ? atomicAdd(&a.cursor[(size_t)tid * BB_CURSOR_STRIDE], cnt) : 0u;
+            if constexpr (QUERY) a.q_tab[q_ts * a.n_buckets + tid] = make_uint2(cnt, my_base);
           }
           if (wave == 0) { // exclusive scan of the (at most 256) bucket counts: 4 per lane
             uint32_t cc[4], s = 0;
@@ -239,7 +258,10 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const BloomFusedAr
             if (where[i] != ~0u) area[off[where[i] >> 16] + (where[i] & 0xFFFFu)] = val[i];
           if (tid < a.n_buckets) gbase[tid] = my_base;
           __syncthreads();
-          bloom_copy_out<THREADS / 64u>(area, hist, off, gbase, a.n_buckets, wave, lane, a.out, 0ull, a.sl, a.shift);
+          if constexpr (QUERY)
+            bloom_copy_out<THREADS / 64u, true>(area, hist, off, gbase, a.n_buckets, wave, lane, a.out, 0ull, a.sl, a.shift,
+                                                a.q_tovf + q_ts * a.n_buckets);
+          else bloom_copy_out<THREADS / 64u>(area, hist, off, gbase, a.n_buckets, wave, lane, a.out, 0ull, a.sl, a.shift);
           __syncthreads();
         }
       }

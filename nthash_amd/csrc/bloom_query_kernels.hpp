@@ -1,0 +1,317 @@
+// bloom_query_kernels.hpp -- the READ side of the binned Bloom filter / counting sketch (round 5).
+//
+// What the reference's callers do with hashes() as often as they insert (include/nthash/nthash.hpp:14-17, 56-57 of the
+// reference: btllib's contains()): test bit `h mod n_bits` of every value.  One dependent 4-byte load per k-mer from a
+// table of gigabytes moves one 128-byte line per k-mer: 49 G k-mers/s at the fabric's line rate, whatever the table is
+// cached in (profiles/r04_notes.md 9.2).  Only locality goes under that, so the query takes the insert's road -- the
+// values brought to the table region by region (bloom_binned_kernels.hpp, slots mode; bloom_fused_kernels.hpp: the first
+// level straight from the hashing registers) -- and then the ANSWERS have to find their way back to the reads:
+//
+//   forward  level 1 (+ level 2): as the insert, and every tile of a level also leaves
+//              where   per value: bucket << 16 | rank inside the tile's bucket      (4 B, written where the value was read)
+//              tab     per tile and bucket: {entries, where the run went in the bucket's slots}
+//   lookup   a workgroup per region: the region's 128 KiB of the table into LDS, then pay[slot] = the answer (a byte: the
+//            bit of a filter, the counter of a sketch) of every entry of the region's list, written next to the list
+//   back     level 2, then level 1: a tile loads the runs it once wrote -- now of answers, one byte each -- back into LDS
+//            in its sorted order (whole runs, coalesced), every value picks its own with `where`; level 2 writes them next
+//            to the bin lists, level 1 -- a thread per read again -- ANDs a k-mer's m answers and sums the read's hits
+//            (sketch: the smallest of the m counters, one byte per window)
+//
+// No atomics on the way back, no 8-byte entries: 20 B of extra traffic per value, all of it in whole runs.  Values that
+// did not fit their bucket's slots (a k-mer repeated a million times) went to the overflow list as full positions; a small
+// kernel looks those up directly and the way back finds them through tovf (bloom_copy_out).  A round whose overflow list
+// overflows is reported to the host, which redoes it with the direct kernel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "bloom_binned_kernels.hpp"
+#include "bloom_fused_kernels.hpp"
+
+namespace ntamd {
+
+enum : int { BQ_BLOOM = 0, BQ_COUNT = 1 };
+constexpr uint32_t BQ_NONE = 0xFFFFFFFFu;     // `where` of a window that emitted nothing
+constexpr uint32_t BQ_COUNT_REGION_SHIFT = 17; // a sketch's region for the query: 2^17 one-byte counters = 128 KiB of LDS
+constexpr uint32_t BQ_LOOKUP_THREADS = 1024;
+constexpr uint32_t BQ_LOOKUP_BATCH = 4;        // 16-byte loads of entries a thread has in flight
+
+template <int KIND>
+__device__ __forceinline__ uint32_t bq_answer_lds(const uint32_t* lds, uint32_t e)
+{
+  if constexpr (KIND == BQ_BLOOM) return (lds[(e >> 5) & (BB_REGION_DWORDS - 1u)] >> (e & 31u)) & 1u;
+  else return ((const uint8_t*)lds)[e & ((1u << BQ_COUNT_REGION_SHIFT) - 1u)];
+}
+
+// ---- lookup: a workgroup per region --------------------------------------------------------------------------------------
+// dynamic LDS: 128 KiB.  Region r's entries: list[r * cap ... + min(fill[r], cap)), offsets inside the region; pay[slot]
+// (one byte per slot of the list, same index) = the answer.  table: 16-byte aligned.
+template <int KIND>
+static __global__ __launch_bounds__(BQ_LOOKUP_THREADS) void bloom_lookup_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ fill,
+                                                                                uint64_t cap, uint32_t n_regions,
+                                                                                const uint32_t* __restrict__ table, uint64_t table_dwords,
+                                                                                uint8_t* __restrict__ pay)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t bq_lds[];
+  uint4* const l4 = (uint4*)bq_lds;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+    const uint64_t f64 = fill[(size_t)r * BB_CURSOR_STRIDE];
+    const uint32_t f = (uint32_t)(f64 < cap ? f64 : cap);
+    if (f == 0) continue; // (uniform over the block)
+    __syncthreads();      // the region before is answered
+    const uint64_t d0 = (uint64_t)r * BB_REGION_DWORDS;
+    const uint64_t left = table_dwords - d0;
+    const uint32_t here = left < BB_REGION_DWORDS ? (uint32_t)left : BB_REGION_DWORDS;
+    const uint4* const t4 = (const uint4*)(table + d0);
+    for (uint32_t i = tid; i < BB_REGION_DWORDS / 4u; i += BQ_LOOKUP_THREADS) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i * 4u + 4u <= here) v = t4[i];
+      else if (i * 4u < here) { // (a table that does not end on 16 bytes)
+        v.x = table[d0 + i * 4u];
+        if (i * 4u + 1u < here) v.y = table[d0 + i * 4u + 1u];
+        if (i * 4u + 2u < here) v.z = table[d0 + i * 4u + 2u];
+      }
+      l4[i] = v;
+    }
+    __syncthreads();
+    const bb_v4u* const e4 = (const bb_v4u*)(list + (size_t)r * cap); // (cap is a multiple of 64: 16-byte aligned, whole vectors)
+    uint32_t* const p4 = (uint32_t*)(pay + (size_t)r * cap);
+    const uint32_t nv = (f + 3u) >> 2;
+    for (uint32_t i0 = tid; i0 < nv; i0 += BQ_LOOKUP_BATCH * BQ_LOOKUP_THREADS) {
+      bb_v4u q[BQ_LOOKUP_BATCH];
+#pragma unroll
+      for (uint32_t u = 0; u < BQ_LOOKUP_BATCH; ++u) {
+        const uint32_t i = i0 + u * BQ_LOOKUP_THREADS;
+        q[u] = __builtin_nontemporal_load(e4 + (i < nv ? i : i0));
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < BQ_LOOKUP_BATCH; ++u) {
+        const uint32_t i = i0 + u * BQ_LOOKUP_THREADS;
+        if (i < nv)
+          p4[i] = bq_answer_lds<KIND>(bq_lds, q[u].x) | (bq_answer_lds<KIND>(bq_lds, q[u].y) << 8) |
+                  (bq_answer_lds<KIND>(bq_lds, q[u].z) << 16) | (bq_answer_lds<KIND>(bq_lds, q[u].w) << 24);
+      }
+    }
+  }
+}
+
+// the values that did not fit their bucket: full positions, answered straight from the table
+template <int KIND>
+static __global__ __launch_bounds__(256) void bloom_ovf_lookup_kernel(const uint64_t* __restrict__ ovf, const BloomStatus* status, uint64_t ovf_cap,
+                                                                      const uint32_t* __restrict__ table, uint8_t* __restrict__ ovf_pay)
+{
+  uint64_t n = __builtin_nontemporal_load(&status->ovf_n);
+  if (n > ovf_cap) n = ovf_cap; // (the round failed: the host redoes it; nothing here is used)
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p = ovf[i];
+    if constexpr (KIND == BQ_BLOOM) ovf_pay[i] = (uint8_t)((table[p >> 5] >> ((uint32_t)p & 31u)) & 1u);
+    else ovf_pay[i] = ((const uint8_t*)table)[p];
+  }
+}
+
+// ---- the way back of one tile ------------------------------------------------------------------------------------------------
+// A tile of a partition level wrote, for every bucket b < n_buckets, a run of tab[b].x entries; the first `fit` of them at
+// slots (bucket0 + b) * cap + tab[b].y ... of the level's list, the rest to the overflow list.  bq_stage_runs loads the
+// answers of those runs (pay: one byte per slot) into `stage` in the tile's sorted order -- stage[off[b] + rank] -- and
+// leaves offfit[b] = off[b] | fit[b] << 16.  Whole block; ends with a barrier.
+template <uint32_t NW>
+__device__ __forceinline__ void bq_stage_runs(const uint2* __restrict__ tab, uint32_t n_buckets, const uint8_t* __restrict__ pay, uint64_t bucket0,
+                                              uint64_t cap, uint8_t* stage, uint32_t* cnt, uint32_t* gat, uint32_t* offfit, uint32_t tid,
+                                              uint32_t lane, uint32_t wave)
+{
+  if (tid < BB_MAX_BINS) {
+    uint2 e = make_uint2(0, 0);
+    if (tid < n_buckets) e = tab[tid];
+    cnt[tid] = e.x;
+    gat[tid] = e.y;
+  }
+  __syncthreads();
+  if (wave == 0) { // the tile's exclusive scan, as the forward pass made it: 4 buckets per lane
+    uint32_t c[4], s = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      c[i] = cnt[lane * 4u + i];
+      s += c[i];
+    }
+    uint32_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if ((int)lane >= d) incl += o;
+    }
+    uint32_t run = incl - s;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      const uint32_t at = gat[lane * 4u + i];
+      const uint32_t fit = at >= cap ? 0u : (cap - at < c[i] ? (uint32_t)(cap - at) : c[i]);
+      offfit[lane * 4u + i] = run | (fit << 16);
+      run += c[i];
+    }
+  }
+  __syncthreads();
+  constexpr uint32_t G = 8; // buckets a wave has in flight (their places are wave-uniform: scalar registers)
+  const uint32_t n_mine = n_buckets > wave ? (n_buckets - wave + NW - 1u) / NW : 0u;
+  for (uint32_t i0 = 0; i0 < n_mine; i0 += G) {
+    uint32_t o[G], fit[G];
+    uint64_t at[G];
+    uint8_t v0[G], v1[G];
+#pragma unroll
+    for (uint32_t u = 0; u < G; ++u) {
+      const uint32_t b = wave + (i0 + u < n_mine ? i0 + u : i0) * NW;
+      const uint32_t of = (uint32_t)__builtin_amdgcn_readfirstlane((int)offfit[b]);
+      const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)gat[b]);
+      o[u] = of & 0xFFFFu;
+      fit[u] = i0 + u < n_mine ? of >> 16 : 0u;
+      at[u] = (bucket0 + b) * cap + g;
+      v0[u] = lane < fit[u] ? pay[at[u] + lane] : (uint8_t)0;
+      v1[u] = lane + 64u < fit[u] ? pay[at[u] + 64u + lane] : (uint8_t)0;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < G; ++u) {
+      if (lane < fit[u]) stage[o[u] + lane] = v0[u];
+      if (lane + 64u < fit[u]) stage[o[u] + 64u + lane] = v1[u];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < G; ++u) // (rare: more than 128 of the tile's values in one bucket)
+      for (uint32_t j = lane + 128u; j < fit[u]; j += 64u) stage[o[u] + j] = pay[at[u] + j];
+  }
+  __syncthreads();
+}
+// the answer of the value that was `w` = bucket << 16 | rank in the tile (after bq_stage_runs)
+__device__ __forceinline__ uint32_t bq_pick(uint32_t w, const uint8_t* stage, const uint32_t* offfit, const uint32_t* __restrict__ tovf,
+                                            const uint8_t* __restrict__ ovf_pay)
+{
+  const uint32_t b = w >> 16, rank = w & 0xFFFFu;
+  const uint32_t of = offfit[b];
+  const uint32_t fit = of >> 16;
+  if (rank < fit) return stage[(of & 0xFFFFu) + rank];
+  return ovf_pay[(uint64_t)tovf[b] + (rank - fit)];
+}
+
+// ---- back, level 2: the answers of the regions' lists to the slots of the bins' lists -------------------------------------
+struct BloomBackArgs {
+  const uint32_t* where;  // level 2: per slot of the bins' lists; level 1: per tile row, step and thread
+  const uint2* tab;
+  const uint32_t* tovf;
+  const uint8_t* pay_in;  // answers next to the list this level WROTE
+  const uint8_t* ovf_pay;
+  const BloomStatus* status; // a round whose overflow list overflowed is left alone (the host redoes it)
+  uint64_t ovf_cap;
+  uint64_t cap;           // slots per bucket of that list
+  // level 2
+  uint8_t* pay_out;       // answers next to the bins' lists (what level 1 reads)
+  const uint32_t* seg_fill;
+  uint64_t cap_in;
+  uint32_t n_regions, buckets_per_seg, tiles_per_seg;
+  // level 1 (a thread per read, the tiles of bloom_fused_kernel)
+  uint64_t n_reads;
+  uint32_t len, k, m, n_tiles, steps, n_buckets;
+  uint64_t* hits;                  // BQ_BLOOM: per read (may be NULL)
+  unsigned long long* total_hits;  // BQ_BLOOM: += the sum
+  uint8_t* estimates;              // BQ_COUNT: [read][window], 0 for a window that emitted nothing
+};
+
+template <uint32_t THREADS>
+static __global__ __launch_bounds__(THREADS) void bloom_back2_kernel(const BloomBackArgs a)
+{
+  constexpr uint32_t TILE = THREADS * BB_PART_ITEMS;
+  __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[TILE];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (bloom_round_failed(a.status, a.ovf_cap)) return;
+  const uint32_t seg = blockIdx.y;
+  const uint32_t r0 = seg * a.buckets_per_seg;
+  const uint32_t r1 = r0 + a.buckets_per_seg < a.n_regions ? r0 + a.buckets_per_seg : a.n_regions;
+  const uint32_t n_buckets = r1 - r0;
+  const uint64_t fill = a.seg_fill[(size_t)seg * BB_CURSOR_STRIDE];
+  const uint64_t s0 = (uint64_t)seg * a.cap_in, s1 = s0 + (fill < a.cap_in ? fill : a.cap_in);
+  const uint64_t n_tiles = (s1 - s0 + TILE - 1) / TILE;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t t0 = s0 + tile * TILE;
+    uint32_t w[BB_PART_ITEMS];
+#pragma unroll
+    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) { // (asked for first: they arrive while the runs are staged)
+      const uint64_t idx = t0 + (uint64_t)j * THREADS + tid;
+      w[j] = idx < s1 ? __builtin_nontemporal_load(a.where + idx) : BQ_NONE;
+    }
+    const uint64_t row = ((uint64_t)seg * a.tiles_per_seg + tile) * a.buckets_per_seg;
+    bq_stage_runs<THREADS / 64u>(a.tab + row, n_buckets, a.pay_in, (uint64_t)r0, a.cap, stage, cnt, gat, offfit, tid, lane, wave);
+#pragma unroll
+    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+      const uint64_t idx = t0 + (uint64_t)j * THREADS + tid;
+      if (w[j] != BQ_NONE) a.pay_out[idx] = (uint8_t)bq_pick(w[j], stage, offfit, a.tovf + row, a.ovf_pay);
+    }
+    __syncthreads(); // (stage / offfit are the next tile's)
+  }
+}
+
+// ---- back, level 1: a thread per read, the tiles of bloom_fused_kernel<BF_PART, THREADS, true> -----------------------------
+template <int KIND, uint32_t THREADS>
+static __global__ __launch_bounds__(THREADS) void bloom_back1_kernel(const BloomBackArgs a)
+{
+  __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[THREADS * 16u];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t k = a.k, m = a.m;
+  const uint32_t kmod = (k - 1u) & 15u, jb = (k - 1u) >> 4;
+  const uint32_t nwin = a.len - k + 1u;
+  if (bloom_round_failed(a.status, a.ovf_cap)) return;
+  unsigned long long mine = 0;
+  for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+    const uint64_t run0 = (uint64_t)t * THREADS;
+    const uint64_t left = a.n_reads - run0;
+    const bool live = tid < left;
+    uint32_t hits = 0;
+    for (uint32_t s = 0; s < a.steps; ++s) {
+      const uint32_t j = jb + s, s0 = j << 4;
+      const uint32_t lo = j == jb ? kmod : 0u;
+      const uint32_t hi = a.len - s0 < 16u ? a.len - s0 : 16u;
+      uint32_t ok = 0, all = 0xFFFFu; // windows of this word that emitted / whose m answers are all 1
+      uint32_t est[16];
+      if constexpr (KIND == BQ_COUNT) {
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i) est[i] = 255u;
+      }
+      for (uint32_t jj = 0; jj < m; ++jj) {
+        const uint64_t ts = ((uint64_t)t * a.steps + s) * m + jj;
+        uint32_t w[16];
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i)
+          w[i] = (i >= lo && i < hi) ? __builtin_nontemporal_load(a.where + (ts * 16u + i) * THREADS + tid) : BQ_NONE;
+        bq_stage_runs<THREADS / 64u>(a.tab + ts * a.n_buckets, a.n_buckets, a.pay_in, 0ull, a.cap, stage, cnt, gat, offfit, tid, lane, wave);
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i)
+          if (w[i] != BQ_NONE) {
+            const uint32_t p = bq_pick(w[i], stage, offfit, a.tovf + ts * a.n_buckets, a.ovf_pay);
+            ok |= 1u << i;
+            if constexpr (KIND == BQ_BLOOM) {
+              if (!p) all &= ~(1u << i);
+            } else {
+              est[i] = p < est[i] ? p : est[i];
+            }
+          }
+        __syncthreads(); // (stage / offfit are the next row's)
+      }
+      if constexpr (KIND == BQ_BLOOM) hits += (uint32_t)__builtin_popcount(ok & all);
+      else if (live && a.estimates) {
+        uint8_t* const dst = a.estimates + (run0 + tid) * nwin;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i)
+          if (i >= lo && i < hi) dst[s0 + i - (k - 1u)] = (uint8_t)(((ok >> i) & 1u) ? est[i] : 0u);
+      }
+    }
+    if constexpr (KIND == BQ_BLOOM) {
+      if (live) {
+        if (a.hits) a.hits[run0 + tid] = hits;
+        mine += hits;
+      }
+    }
+  }
+  if constexpr (KIND == BQ_BLOOM) {
+    for (int d = 32; d > 0; d >>= 1) mine += (unsigned long long)__shfl_xor((long long)mine, d, 64);
+    if (lane == 0 && mine && a.total_hits) atomicAdd(a.total_hits, mine);
+  }
+}
+
+} // namespace ntamd

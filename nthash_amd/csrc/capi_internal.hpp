@@ -117,6 +117,7 @@ struct nthip_tune {
   uint32_t bloom_slots = 0;  // NTHIP_TUNE_BLOOM_SLOTS=1: slots mode (no histogram) whenever it applies, even after a failed round, 2: never (A/B, tests)
   uint32_t bloom_slot_tight = 0; // NTHIP_TUNE_BLOOM_SLOT_TIGHT=1: buckets of the mean exactly (the overflow list in use), 2: of half the mean (rounds fail) -- tests
   uint32_t bloom_binned = 0; // NTHIP_TUNE_BLOOM_BINNED=1: the binned insert whenever the filter allows it, 2: never (A/B, tests)
+  uint32_t bloom_query = 0;  // NTHIP_TUNE_BLOOM_QUERY=1: the binned query (bloom_query_kernels.hpp) on every batch it can take, 2: never (A/B, tests)
   uint32_t seed_roll_waves = 0; // NTHIP_TUNE_SEED_ROLL_WAVES=2..8: waves per block of seed_roll_kernel (A/B)
   uint32_t seed_roll = 0;   // NTHIP_TUNE_SEED_ROLL=1: every dense seed batch the block-rolling kernel takes goes there, 2: none (A/B, tests)
   uint32_t seed_any = 0;    // NTHIP_TUNE_SEED_ANY=1: dense seed batches on the any-seed form whatever the seed set, 2: none of k <= 128 (A/B, tests)
@@ -291,6 +292,15 @@ int stream_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m
 // per base + 48 per read fit the free memory.  One piece when everything fits.
 int offsets_in_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, size_t scratch_per_base,
                       const std::function<int(const nthip_reads*, uint64_t, uint64_t)>& fn);
+
+// ---- capi_sink_query.hip: the binned read side of the Bloom filter / counting sketch (bloom_query_kernels.hpp) ----
+// Fixed-length device-resident reads [*first, n_reads) against the table (kind: BQ_BLOOM bits / BQ_COUNT one-byte counters),
+// round by round while the rounds go through: *first is advanced past them, *kmers by the k-mers they emit, *hits_sum by
+// their hits (BQ_BLOOM; d_hits[r], optional, per read -- device memory) or d_est[r * windows + w] written (BQ_COUNT).
+// Stops early -- *first < n_reads, not an error -- when the shape, the table or the memory is not the binned query's, or a
+// round's overflow list overflowed (skewed values): the caller takes the rest through its direct kernels.
+int bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t m, const uint32_t* d_table, uint64_t n_slots, int kind,
+                       uint64_t* d_hits, uint8_t* d_est, uint64_t* first, uint64_t* kmers, uint64_t* hits_sum);
 
 // ---- capi_util.hip ------------------------------------------------------------------------------------------
 // exclusive scan of n u64 on the device: out[i] = sum(in[0..i)), *d_total = sum; d_sums: ceil(n/1024) + 16 u64

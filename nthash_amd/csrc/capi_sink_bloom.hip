@@ -6,6 +6,8 @@
 
 #include "bloom_binned_kernels.hpp"
 #include "bloom_fused_kernels.hpp"
+#include "bloom_host.hpp"
+#include "bloom_query_kernels.hpp" // (BQ_BLOOM)
 #include "util_kernels.hpp" // (SCAN_TILE)
 
 using namespace ntamd;
@@ -91,11 +93,6 @@ int ntamd::host::stream_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t
 
 namespace {
 
-uint64_t bloom_magic_of(uint64_t n_bits)
-{
-  return (n_bits & (n_bits - 1)) == 0 ? 0ull : ~0ull / n_bits;
-}
-
 // ---- the binned insert (bloom_binned_kernels.hpp) -------------------------------------------------------------------
 constexpr uint64_t BB_ROUND_MAX = 1ull << 31; // values per round: the lists are indexed with 32 bits
 
@@ -171,48 +168,6 @@ uint64_t bloom_round_values(const nthip_ctx* c, uint64_t n_values, bool with_str
 }
 
 // ---- the round WITHOUT a hash stream (bloom_fused_kernels.hpp): device-resident fixed-length reads hashed twice ----------
-struct BloomFusedSrc {
-  const uint8_t* seqs = nullptr;
-  uint64_t n_reads = 0;
-  uint32_t len = 0, stride = 0, k = 0, m = 0;
-};
-constexpr uint32_t BF_COUNT_THREADS_BIG = 512; // filters of more than 2^34 slots' regions: 128 KiB of counters leave room for 512 reads
-// LDS of a pass: the tile's bit stream + the counters / the sorted tile (the statics are the kernel's own)
-size_t bloom_fused_lds(const BloomFusedSrc& s, uint32_t threads, uint32_t area_dwords)
-{
-  const uint32_t pad = (s.k + 15u) / 16u + 1u;
-  const uint32_t bits = pad + (((threads - 1u) * s.stride + s.len + 30u) >> 4) + 2u;
-  return ((size_t)((bits + 3u) & ~3u) + area_dwords) * 4;
-}
-bool bloom_fused_ok(const nthip_ctx* c, const BloomFusedSrc& s, uint32_t n_regions)
-{
-  if (c->tune.bloom_fused == 2 || s.m > (uint32_t)KF_MAX_RUNTIME_M || s.len < s.k || s.stride < s.len) return false;
-  if (2u * (s.len - s.k + 1u) < s.len && c->tune.bloom_fused != 1) return false; // (more than two rolls per k-mer: the stream path)
-  const size_t cap = lds_cap_of(c) - 4096; // (tab / hist / off / gbase are static)
-  const uint32_t ct = n_regions > 16384u ? BF_COUNT_THREADS_BIG : 1024u;
-  return bloom_fused_lds(s, ct, n_regions < 128u ? 128u : n_regions) <= cap && bloom_fused_lds(s, 1024u, 1024u * 16u) <= cap;
-}
-void bloom_fused_args(const BloomFusedSrc& s, uint32_t threads, uint64_t n_bits, uint64_t magic, BloomFusedArgs* a)
-{
-  memset(a, 0, sizeof *a);
-  KmerFixedArgs consts;
-  memset(&consts, 0, sizeof consts);
-  fill_kmer_consts(s.k, s.m, consts);
-  a->seqs = s.seqs;
-  a->n_reads = s.n_reads;
-  a->len = s.len;
-  a->stride = s.stride;
-  a->k = s.k;
-  a->m = s.m;
-  a->pad_dwords = (s.k + 15u) / 16u + 1u;
-  a->n_tiles = (uint32_t)((s.n_reads + threads - 1) / threads);
-  a->f_init = consts.f_init;
-  a->r_init = consts.r_init;
-  memcpy(a->tab, consts.tab, sizeof a->tab);
-  memcpy(a->mult, consts.mult, sizeof a->mult);
-  a->n_bits = n_bits;
-  a->magic = magic;
-}
 // pass COUNT: t.counts := values per region (launch only)
 int bloom_fused_count(nthip_ctx* c, const BloomFusedSrc& s, uint64_t n_bits, const BloomLists& t, bool counters)
 {
@@ -365,15 +320,6 @@ struct SlotLists {
   uint64_t cap1 = 0, cap2 = 0, ovf_cap = 0;
   size_t head_bytes = 0; // status + cursors: zeroed before every round
 };
-// what a bucket of `bucket_slots` of the table's n_slots owns in a round of n values
-uint64_t slot_cap(const nthip_ctx* c, uint64_t n, uint64_t bucket_slots, uint64_t n_slots)
-{
-  const double mean = (double)n * (double)(bucket_slots < n_slots ? bucket_slots : n_slots) / (double)n_slots;
-  double cap = mean + 8.0 * std::sqrt(mean) + 256.0;
-  if (c->tune.bloom_slot_tight == 1) cap = mean;       // (tests: a few values of every bucket take the overflow list)
-  if (c->tune.bloom_slot_tight == 2) cap = mean * 0.5; // (tests: the overflow list overflows, the round fails)
-  return ((uint64_t)cap + 64u) & ~(uint64_t)63u;
-}
 bool bloom_slots_ok(nthip_ctx* c)
 {
   if (c->tune.bloom_slots == 2) return false;
@@ -719,24 +665,41 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
     const int rc = run_kmer_bloom_binned(c, rd, k16, m8, d_filter, n_bits, total_out, flags);
     if (rc != 1) return rc; // (1: the lists do not fit the device right now)
   }
-  NaPlan plan;
-  if (!kmer_na_plan(c, len, stride, k, m, /*want_pos (the k-mer's read)*/ query, &plan))
-    return fail(NTHIP_ERR_UNSUPPORTED, "shape outside the fused consumer kernels (k <= 64, m <= 8, stride >= windows)");
-  uint64_t total_bytes = 0;
-  NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
-  Staged st;
-  NTCHK(stage_inputs(c, rd, flags, total_bytes, st));
+  // round 5: the query of a large batch against a large filter goes region by region as the insert does, the answers
+  // finding their way back to the reads (bloom_query_kernels.hpp); what that does not take -- small batches, filters that
+  // sit in the caches, host input, a round of skewed values -- keeps the kernel below, one filter load per k-mer
+  uint64_t first = 0, q_kmers = 0, q_hits = 0;
   uint64_t* d_hits = hits;
+  Staged st;
   if (host_hits) {
     HIPCHK(hipMalloc((void**)&d_hits, rd->n_reads * sizeof(uint64_t)));
     st.owned.push_back(d_hits);
   }
-  if (query && d_hits) HIPCHK(hipMemsetAsync(d_hits, 0, rd->n_reads * sizeof(uint64_t), c->stream));
+  if (query && !(flags & NTHIP_HOST_INPUT)) {
+    NTCHK(bloom_query_binned(c, rd, k, m, d_filter, n_bits, BQ_BLOOM, d_hits, nullptr, &first, &q_kmers, &q_hits));
+    if (first == rd->n_reads) {
+      if (host_hits) HIPCHK(hipMemcpyAsync(hits, d_hits, rd->n_reads * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (total_out) *total_out = q_kmers;
+      if (total_hits) *total_hits = q_hits;
+      return NTHIP_OK;
+    }
+  }
+  nthip_reads part = *rd;
+  part.seqs = rd->seqs + first * stride;
+  part.n_reads = rd->n_reads - first;
+  NaPlan plan;
+  if (!kmer_na_plan(c, len, stride, k, m, /*want_pos (the k-mer's read)*/ query, &plan))
+    return fail(NTHIP_ERR_UNSUPPORTED, "shape outside the fused consumer kernels (k <= 64, m <= 8, stride >= windows)");
+  uint64_t total_bytes = 0;
+  NTCHK(reads_total_bytes(c, &part, flags, &total_bytes));
+  NTCHK(stage_inputs(c, &part, flags, total_bytes, st));
+  if (query && d_hits) HIPCHK(hipMemsetAsync(d_hits + first, 0, part.n_reads * sizeof(uint64_t), c->stream));
   KmerFixedArgs consts;
   memset(&consts, 0, sizeof consts);
   fill_kmer_consts(k, m, consts);
   KmerRunsGenArgs a;
-  fill_gen_args(a, c, st, rd, k, m, plan.g, consts);
+  fill_gen_args(a, c, st, &part, k, m, plan.g, consts);
   NTCHK(get_kmer_tab(c, k, &a.init_tab));
   a.hashes = nullptr;
   a.vbits_dwords = plan.vbits_dwords;
@@ -746,7 +709,7 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
   a.bloom = d_filter;
   a.n_bits = n_bits;
   a.bloom_magic = bloom_magic_of(n_bits);
-  a.hits = query ? d_hits : nullptr;
+  a.hits = query && d_hits ? d_hits + first : nullptr;
   a.sink_totals = (uint64_t*)(c->d_small + 16);
   HIPCHK(hipMemsetAsync(c->d_small + 16, 0, 16, c->stream));
   if (query) NTCHK((launch_kmer_runs_gen_nw<true, SINK_BLOOM_QUERY>(c, a, plan.lds, plan.g.nw, plan.g.dword_tail != 0)));
@@ -756,8 +719,8 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
   HIPCHK(hipStreamSynchronize(c->stream));
   uint64_t tot[2];
   memcpy(tot, c->h_small + 16, 16);
-  if (total_out) *total_out = tot[0];
-  if (total_hits) *total_hits = tot[1];
+  if (total_out) *total_out = tot[0] + q_kmers;
+  if (total_hits) *total_hits = tot[1] + q_hits;
   return NTHIP_OK;
 }
 

@@ -1,0 +1,420 @@
+// capi_sink_query.hip -- the binned read side of the Bloom filter / counting sketch (bloom_query_kernels.hpp), and
+// nthip_kmer_count_query
+// Part of libnthash_hip.so (include/nthash_hip.h); see capi_internal.hpp for the file map.
+#include "capi_internal.hpp"
+
+#include <algorithm>
+
+#include "bloom_host.hpp"
+#include "bloom_query_kernels.hpp"
+#include "util_kernels.hpp" // (SCAN_TILE)
+
+using namespace ntamd;
+using namespace ntamd::host;
+
+namespace {
+
+constexpr uint64_t BQ_ROUND_MAX = 1ull << 31; // values per round (every list position and overflow index fits 32 bits with room to spare)
+constexpr uint32_t BQ_L2_THREADS = BB_L2_THREADS, BQ_L2_TILE = BQ_L2_THREADS * BB_PART_ITEMS;
+
+struct QueryGeo {
+  uint32_t region_shift = 0, bin_shift = 0, n_regions = 0, n_bins = 0;
+  bool one = false; // a table of one bin: level 1 goes straight to the regions
+};
+bool query_geo(uint64_t n_slots, int kind, QueryGeo* g)
+{
+  g->region_shift = kind == BQ_BLOOM ? BB_REGION_SHIFT : BQ_COUNT_REGION_SHIFT;
+  g->bin_shift = g->region_shift + 7u;
+  const uint64_t nr = (n_slots + (1ull << g->region_shift) - 1) >> g->region_shift;
+  if (nr > BB_MAX_REGIONS) return false;
+  g->n_regions = (uint32_t)nr;
+  g->n_bins = (g->n_regions + BB_REGIONS_PER_BIN - 1) / BB_REGIONS_PER_BIN;
+  g->one = g->n_bins == 1;
+  return true;
+}
+
+struct QueryScratch {
+  BloomStatus* status = nullptr;
+  unsigned long long* total_hits = nullptr;
+  uint32_t *cur1 = nullptr, *cur2 = nullptr, *list1 = nullptr, *list2 = nullptr;
+  uint64_t* ovf = nullptr;
+  uint32_t *where1 = nullptr, *where2 = nullptr, *tovf1 = nullptr, *tovf2 = nullptr;
+  uint2 *tab1 = nullptr, *tab2 = nullptr;
+  uint8_t *pay1 = nullptr, *pay2 = nullptr, *ovf_pay = nullptr;
+  uint64_t cap1 = 0, cap2 = 0, ovf_cap = 0;
+  uint32_t tiles_per_seg = 0;
+  size_t head_bytes = 0;
+};
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// the scratch of a round of nr reads (n values) carved out of the context's list buffer; *need (always) = its size;
+// returns false when the buffer is smaller (nothing carved)
+bool query_scratch(nthip_ctx* c, const QueryGeo& g, uint64_t nr, uint64_t n, uint64_t n_slots, uint32_t steps, uint32_t m, QueryScratch* q,
+                   size_t* need)
+{
+  q->cap1 = g.one ? 0 : slot_cap(c, n, 1ull << g.bin_shift, n_slots);
+  q->cap2 = slot_cap(c, n, 1ull << g.region_shift, n_slots);
+  q->ovf_cap = n / 64 < 65536 ? 65536 : n / 64;
+  if (c->tune.bloom_slot_tight == 2) q->ovf_cap = 64;
+  q->tiles_per_seg = (uint32_t)((q->cap1 + BQ_L2_TILE - 1) / BQ_L2_TILE);
+  const uint64_t n_tiles1 = (nr + 1023) / 1024;
+  const uint64_t rows1 = n_tiles1 * steps * m;
+  const uint32_t buckets1 = g.one ? g.n_regions : g.n_bins;
+  const uint64_t rows2 = g.one ? 0 : (uint64_t)g.n_bins * q->tiles_per_seg;
+  const size_t slots1 = (size_t)g.n_bins * q->cap1, slots2 = (size_t)g.n_regions * q->cap2;
+  const size_t head = 256 + (size_t)(g.n_bins + g.n_regions) * BB_CURSOR_STRIDE * sizeof(uint32_t);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = off;
+    off += al256(bytes);
+    return at;
+  };
+  const size_t o_head = take(head), o_l1 = take(slots1 * 4), o_l2 = take(slots2 * 4), o_ovf = take((size_t)q->ovf_cap * 8);
+  const size_t o_w1 = take((size_t)rows1 * 16 * 1024 * 4), o_w2 = take(slots1 * 4);
+  const size_t o_t1 = take((size_t)rows1 * buckets1 * 8), o_v1 = take((size_t)rows1 * buckets1 * 4);
+  const size_t o_t2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 8), o_v2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 4);
+  const size_t o_p1 = take(slots1), o_p2 = take(slots2), o_po = take((size_t)q->ovf_cap);
+  *need = off;
+  if (c->bloom_tmp_bytes < off) return false;
+  uint8_t* const b = c->bloom_tmp;
+  q->status = (BloomStatus*)(b + o_head);
+  q->total_hits = (unsigned long long*)(b + o_head + 128);
+  q->cur1 = (uint32_t*)(b + o_head + 256);
+  q->cur2 = q->cur1 + (size_t)g.n_bins * BB_CURSOR_STRIDE;
+  q->head_bytes = head;
+  q->list1 = (uint32_t*)(b + o_l1);
+  q->list2 = (uint32_t*)(b + o_l2);
+  q->ovf = (uint64_t*)(b + o_ovf);
+  q->where1 = (uint32_t*)(b + o_w1);
+  q->where2 = (uint32_t*)(b + o_w2);
+  q->tab1 = (uint2*)(b + o_t1);
+  q->tovf1 = (uint32_t*)(b + o_v1);
+  q->tab2 = (uint2*)(b + o_t2);
+  q->tovf2 = (uint32_t*)(b + o_v2);
+  q->pay1 = b + o_p1;
+  q->pay2 = b + o_p2;
+  q->ovf_pay = b + o_po;
+  return true;
+}
+
+template <int KIND>
+int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const BloomFusedSrc& src, const uint32_t* d_table, uint64_t n_slots,
+                uint32_t steps, uint64_t* d_hits, uint8_t* d_est, bool* failed, uint64_t* lost, uint64_t* hits)
+{
+  const uint64_t magic = bloom_magic_of(n_slots);
+  const uint64_t table_dwords = KIND == BQ_BLOOM ? (n_slots + 31) / 32 : (n_slots + 3) / 4;
+  const uint32_t shift1 = g.one ? g.region_shift : g.bin_shift, buckets1 = g.one ? g.n_regions : g.n_bins;
+  const uint64_t capL1 = g.one ? q.cap2 : q.cap1;
+  HIPCHK(hipMemsetAsync(q.status, 0, q.head_bytes, c->stream));
+  prof_begin(c, KIND == BQ_BLOOM ? "bloom binned query (part, part, lookup, back, back)" : "count binned query (part, part, lookup, back, back)");
+  // ---- forward, level 1: from the reads (bloom_fused_kernels.hpp pass PART, QUERY) ----
+  BloomFusedQueryArgs fa;
+  bloom_fused_args(src, 1024u, n_slots, magic, &fa);
+  fa.lost = &q.status->lost;
+  fa.out = g.one ? q.list2 : q.list1;
+  fa.cursor = g.one ? q.cur2 : q.cur1;
+  fa.shift = shift1;
+  fa.mask = (1u << shift1) - 1u;
+  fa.n_buckets = buckets1;
+  fa.sl = {capL1, q.ovf, q.status, q.ovf_cap};
+  fa.q_where = q.where1;
+  fa.q_tab = q.tab1;
+  fa.q_tovf = q.tovf1;
+  fa.q_steps = steps;
+  {
+    const size_t lds = bloom_fused_lds(src, 1024u, 1024u * 16u);
+    NTCHK(set_max_lds(c, bloom_fused_kernel<BF_PART, 1024, true>, lds));
+    hipLaunchKernelGGL((bloom_fused_kernel<BF_PART, 1024, true>), dim3((unsigned)std::min<uint64_t>(fa.n_tiles, (uint64_t)c->n_cu)), dim3(1024), lds,
+                       c->stream, fa);
+  }
+  // ---- forward, level 2: every bin to its regions ----
+  uint32_t per_bin = 1;
+  if (!g.one) {
+    BloomPartQueryArgs a;
+    memset((void*)&a, 0, sizeof a);
+    a.n_bits = n_slots;
+    a.magic = magic;
+    a.n_regions = g.n_regions;
+    a.in = q.list1;
+    a.out = q.list2;
+    a.cursor = q.cur2;
+    a.shift = g.region_shift;
+    a.mask = (1u << g.region_shift) - 1u;
+    a.buckets_per_seg = BB_REGIONS_PER_BIN;
+    a.sl = {q.cap2, q.ovf, q.status, q.ovf_cap};
+    a.cap_in = q.cap1;
+    a.seg_fill = q.cur1;
+    a.q_where = q.where2;
+    a.q_tab = q.tab2;
+    a.q_tovf = q.tovf2;
+    a.q_tiles_per_seg = q.tiles_per_seg;
+    const size_t lds = (size_t)BQ_L2_TILE * sizeof(uint32_t);
+    int l2_per_cu = 1;
+    NTCHK(blocks_per_cu(c, bloom_part_kernel<false, BQ_L2_THREADS, true>, (int)BQ_L2_THREADS, lds, &l2_per_cu));
+    const uint32_t l2_grid = 2u * (uint32_t)c->n_cu * (uint32_t)l2_per_cu;
+    per_bin = l2_grid / g.n_bins ? l2_grid / g.n_bins : 1u;
+    hipLaunchKernelGGL((bloom_part_kernel<false, BQ_L2_THREADS, true>), dim3(per_bin, g.n_bins), dim3(BQ_L2_THREADS), lds, c->stream, a);
+  }
+  // ---- lookup: region by region, and the overflow list ----
+  {
+    const size_t lds = (size_t)BB_REGION_DWORDS * sizeof(uint32_t);
+    NTCHK(set_max_lds(c, bloom_lookup_kernel<KIND>, lds));
+    const uint32_t grid = g.n_regions < (uint32_t)c->n_cu ? g.n_regions : (uint32_t)c->n_cu;
+    hipLaunchKernelGGL(bloom_lookup_kernel<KIND>, dim3(grid), dim3(BQ_LOOKUP_THREADS), lds, c->stream, (const uint32_t*)q.list2,
+                       (const uint32_t*)q.cur2, q.cap2, g.n_regions, d_table, table_dwords, q.pay2);
+    hipLaunchKernelGGL(bloom_ovf_lookup_kernel<KIND>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)q.ovf, (const BloomStatus*)q.status,
+                       q.ovf_cap, d_table, q.ovf_pay);
+  }
+  // ---- back ----
+  BloomBackArgs b;
+  memset(&b, 0, sizeof b);
+  b.ovf_pay = q.ovf_pay;
+  b.status = q.status;
+  b.ovf_cap = q.ovf_cap;
+  if (!g.one) {
+    b.where = q.where2;
+    b.tab = q.tab2;
+    b.tovf = q.tovf2;
+    b.pay_in = q.pay2;
+    b.cap = q.cap2;
+    b.pay_out = q.pay1;
+    b.seg_fill = q.cur1;
+    b.cap_in = q.cap1;
+    b.n_regions = g.n_regions;
+    b.buckets_per_seg = BB_REGIONS_PER_BIN;
+    b.tiles_per_seg = q.tiles_per_seg;
+    int per_cu = 1;
+    NTCHK(blocks_per_cu(c, bloom_back2_kernel<BQ_L2_THREADS>, (int)BQ_L2_THREADS, 0, &per_cu));
+    const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
+    const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
+    hipLaunchKernelGGL(bloom_back2_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
+  }
+  b.where = q.where1;
+  b.tab = q.tab1;
+  b.tovf = q.tovf1;
+  b.pay_in = g.one ? q.pay2 : q.pay1;
+  b.cap = capL1;
+  b.n_reads = src.n_reads;
+  b.len = src.len;
+  b.k = src.k;
+  b.m = src.m;
+  b.n_tiles = fa.n_tiles;
+  b.steps = steps;
+  b.n_buckets = buckets1;
+  b.hits = d_hits;
+  b.total_hits = q.total_hits;
+  b.estimates = d_est;
+  {
+    int per_cu = 1;
+    NTCHK(blocks_per_cu(c, bloom_back1_kernel<KIND, 1024>, 1024, 0, &per_cu));
+    const uint64_t grid = std::min<uint64_t>(fa.n_tiles, (uint64_t)c->n_cu * (uint64_t)per_cu);
+    hipLaunchKernelGGL((bloom_back1_kernel<KIND, 1024>), dim3((unsigned)grid), dim3(1024), 0, c->stream, b);
+  }
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_small + 64, q.status, 136, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  BloomStatus st;
+  memcpy(&st, c->h_small + 64, sizeof st);
+  *failed = st.ovf_n > q.ovf_cap;
+  *lost = st.lost;
+  memcpy(hits, c->h_small + 64 + 128, 8);
+  return NTHIP_OK;
+}
+
+// ---- nthip_kmer_count_query on the direct road: the compact stream of a round, the stream query, the estimates to their windows ----
+static __global__ __launch_bounds__(256) void window_counts_kernel(const uint64_t* __restrict__ offsets, uint64_t n_reads, uint32_t k,
+                                                                   uint64_t* __restrict__ wins)
+{
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t len = offsets[r + 1] - offsets[r];
+    wins[r] = len >= k ? len - k + 1 : 0;
+  }
+}
+// a wave per read: the estimates of its emitted k-mers (compact, at roff[r]) go to est[slot[r] + pos]
+static __global__ __launch_bounds__(256) void place_estimates_kernel(const uint8_t* __restrict__ compact, const uint32_t* __restrict__ pos,
+                                                                     const uint64_t* __restrict__ roff, uint64_t n_kmers, const uint64_t* __restrict__ slot,
+                                                                     uint64_t fixed_wins, uint64_t n_reads, uint8_t* __restrict__ est)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t r = wave; r < n_reads; r += n_waves) {
+    const uint64_t i0 = roff[r], i1 = r + 1 < n_reads ? roff[r + 1] : n_kmers;
+    const uint64_t s = slot ? slot[r] : r * fixed_wins;
+    for (uint64_t i = i0 + lane; i < i1; i += 64u) est[s + pos[i]] = compact[i];
+  }
+}
+
+} // namespace
+
+int ntamd::host::bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t m, const uint32_t* d_table, uint64_t n_slots, int kind,
+                                    uint64_t* d_hits, uint8_t* d_est, uint64_t* first, uint64_t* kmers, uint64_t* hits_sum)
+{
+  if (c->tune.bloom_query == 2 || rd->offsets || *first >= rd->n_reads) return NTHIP_OK;
+  const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
+  if (len < k || stride < len || ((uintptr_t)d_table & 15u)) return NTHIP_OK;
+  QueryGeo g;
+  if (!query_geo(n_slots, kind, &g)) return NTHIP_OK;
+  if (c->lds_max < (size_t)BB_REGION_DWORDS * 4 + 1024) return NTHIP_OK;
+  const BloomFusedSrc shape = {(const uint8_t*)rd->seqs, rd->n_reads, len, stride, k, m};
+  if (!bloom_fused_ok(c, shape, 128u)) return NTHIP_OK;
+  const uint32_t nwin = len - k + 1u;
+  const uint64_t per_read = (uint64_t)nwin * m;
+  const uint64_t left_values = (rd->n_reads - *first) * per_read;
+  const uint64_t table_bytes = kind == BQ_BLOOM ? (n_slots + 7) / 8 : n_slots;
+  // worth it?  The direct kernels pay a 128-byte line per value (~20 ps) unless the table sits in the L2s (~8 ps); the lists
+  // ~11 ps per value, and a pass over the table (0.2 ps per byte)
+  if (c->tune.bloom_query != 1 && (left_values < (1ull << 24) || table_bytes < (32ull << 20) || left_values < table_bytes / 32)) return NTHIP_OK;
+  const uint32_t steps = ((len + 15u) >> 4) - ((k - 1u) >> 4);
+  // reads per round: what the free memory allows (~21 B per value + the tiles' tables)
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+  free_b += c->bloom_tmp_bytes;
+  uint64_t round = (uint64_t)(free_b / 10 * 8) / 26;
+  if (round > BQ_ROUND_MAX) round = BQ_ROUND_MAX;
+  if (c->tune.bloom_round) round = c->tune.bloom_round;
+  uint64_t reads_per_round = round / per_read;
+  if (reads_per_round == 0) return NTHIP_OK;
+  if (reads_per_round > rd->n_reads - *first) reads_per_round = rd->n_reads - *first;
+  QueryScratch q;
+  for (;;) { // the scratch of the largest round
+    size_t need = 0;
+    if (query_scratch(c, g, reads_per_round, reads_per_round * per_read, n_slots, steps, m, &q, &need)) break;
+    if (c->bloom_tmp) HIPCHK(hipFree(c->bloom_tmp));
+    c->bloom_tmp = nullptr;
+    c->bloom_tmp_bytes = 0;
+    if (hipMalloc((void**)&c->bloom_tmp, need) == hipSuccess) {
+      c->bloom_tmp_bytes = need;
+      continue;
+    }
+    (void)hipGetLastError();
+    c->bloom_tmp = nullptr;
+    if (reads_per_round * per_read <= (1u << 22)) return NTHIP_OK; // (no memory for the lists: the direct kernels)
+    reads_per_round /= 2;
+  }
+  while (*first < rd->n_reads) {
+    const uint64_t nr = std::min<uint64_t>(rd->n_reads - *first, reads_per_round);
+    size_t need = 0;
+    if (!query_scratch(c, g, nr, nr * per_read, n_slots, steps, m, &q, &need)) return NTHIP_OK; // (cannot happen: a smaller round needs less)
+    const BloomFusedSrc src = {(const uint8_t*)rd->seqs + *first * stride, nr, len, stride, k, m};
+    bool failed = false;
+    uint64_t lost = 0, hits = 0;
+    uint64_t* const dh = d_hits ? d_hits + *first : nullptr;
+    uint8_t* const de = d_est ? d_est + *first * nwin : nullptr;
+    if (kind == BQ_BLOOM) NTCHK((query_round<BQ_BLOOM>(c, g, q, src, d_table, n_slots, steps, dh, de, &failed, &lost, &hits)));
+    else NTCHK((query_round<BQ_COUNT>(c, g, q, src, d_table, n_slots, steps, dh, de, &failed, &lost, &hits)));
+    if (failed) return NTHIP_OK; // (skewed values: the caller's direct kernels take it from here)
+    *first += nr;
+    *kmers += nr * (uint64_t)nwin - lost;
+    *hits_sum += hits;
+  }
+  return NTHIP_OK;
+}
+
+// ---- nthip_kmer_count_query ---------------------------------------------------------------------------------------------------
+extern "C" int nthip_kmer_count_query(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8, const uint8_t* d_counters, uint64_t n_counters,
+                                      uint8_t* estimates, uint64_t* total, uint32_t flags)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  NTCHK(check_reads(rd));
+  const uint32_t k = k16, m = m8;
+  if (!d_counters || n_counters == 0) return fail(NTHIP_ERR_ARG, "sketch is NULL / n_counters is 0");
+  if ((uintptr_t)d_counters & 3u) return fail(NTHIP_ERR_ARG, "sketch must be 4-byte aligned");
+  if (n_counters & 3u) return fail(NTHIP_ERR_ARG, "n_counters must be a multiple of 4");
+  if (k == 0) return fail(NTHIP_ERR_ARG, "k must be greater than 0");
+  if (k < 3) return fail(NTHIP_ERR_UNSUPPORTED, "k < 3 is undefined in the reference (src/kmer.cpp:47)");
+  if (m == 0) return fail(NTHIP_ERR_UNSUPPORTED, "num_hashes must be >= 1");
+  if (rd->n_reads && !estimates) return fail(NTHIP_ERR_ARG, "estimates is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  if (total) *total = 0;
+  if (rd->n_reads == 0) return NTHIP_OK;
+  const bool host_in = (flags & NTHIP_HOST_INPUT) != 0, host_out = (flags & NTHIP_HOST_OUTPUT) != 0;
+  Staged keep;
+  uint64_t sum_kmers = 0;
+  // the slot of read r: the windows of the reads before it
+  uint64_t n_slots_out = 0;
+  uint64_t* d_slot = nullptr; // (offsets only)
+  const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
+  const uint64_t fixed_wins = (!rd->offsets && len >= k) ? len - k + 1 : 0;
+  const uint64_t* d_offsets = rd->offsets;
+  if (rd->offsets) {
+    if (host_in) {
+      uint64_t* p = nullptr;
+      NTCHK(own_alloc(keep, (size_t)(rd->n_reads + 1) * 8, (void**)&p));
+      HIPCHK(hipMemcpyAsync(p, rd->offsets, (size_t)(rd->n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+      d_offsets = p;
+    }
+    uint64_t* d_sums = nullptr;
+    NTCHK(own_alloc(keep, (size_t)(rd->n_reads + 1) * 8, (void**)&d_slot));
+    NTCHK(own_alloc(keep, (size_t)(rd->n_reads / SCAN_TILE + 64) * 8, (void**)&d_sums));
+    hipLaunchKernelGGL(window_counts_kernel, dim3(c->n_cu * 4), dim3(256), 0, c->stream, d_offsets, rd->n_reads, k, d_slot);
+    HIPCHK(hipGetLastError());
+    NTCHK(device_exclusive_scan(c, d_slot, d_slot, rd->n_reads, d_sums, (uint64_t*)(c->d_small + 16)));
+    HIPCHK(hipMemcpyAsync(c->h_small + 16, c->d_small + 16, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(&n_slots_out, c->h_small + 16, 8);
+  } else {
+    n_slots_out = rd->n_reads * fixed_wins;
+  }
+  if (n_slots_out == 0) return NTHIP_OK;
+  uint8_t* d_est = estimates;
+  if (host_out) NTCHK(own_alloc(keep, (size_t)n_slots_out, (void**)&d_est));
+  uint64_t first = 0, hits_dummy = 0;
+  if (!rd->offsets && !host_in)
+    NTCHK(bloom_query_binned(c, rd, k, m, (const uint32_t*)d_counters, n_counters, BQ_COUNT, nullptr, d_est, &first, &sum_kmers, &hits_dummy));
+  if (first < rd->n_reads) {
+    // the direct road for what is left: rounds of reads hashed to their compact stream (positions and counts with it), the
+    // stream query, every estimate to its window; windows that emit nothing stay 0
+    const uint64_t done_slots = rd->offsets ? 0 : first * fixed_wins;
+    HIPCHK(hipMemsetAsync(d_est + done_slots, 0, (size_t)(n_slots_out - done_slots), c->stream));
+    auto one_round = [&](const nthip_reads* part, uint64_t r0, uint64_t bases) -> int {
+      Staged rk;
+      const uint64_t cap = bases ? bases : 1;
+      uint64_t *d_h = nullptr, *d_counts = nullptr, *d_roff = nullptr, *d_sums = nullptr, n_kmers = 0;
+      uint32_t* d_pos = nullptr;
+      uint8_t* d_cmp = nullptr;
+      NTCHK(own_alloc(rk, (size_t)cap * m * 8, (void**)&d_h));
+      NTCHK(own_alloc(rk, (size_t)cap * 4, (void**)&d_pos));
+      NTCHK(own_alloc(rk, (size_t)cap, (void**)&d_cmp));
+      NTCHK(own_alloc(rk, (size_t)(part->n_reads + 1) * 8, (void**)&d_counts));
+      NTCHK(own_alloc(rk, (size_t)(part->n_reads + 1) * 8, (void**)&d_roff));
+      NTCHK(own_alloc(rk, (size_t)(part->n_reads / SCAN_TILE + 64) * 8, (void**)&d_sums));
+      nthip_out out;
+      memset(&out, 0, sizeof out);
+      out.hashes = d_h;
+      out.capacity = cap;
+      out.counts = d_counts;
+      out.pos = d_pos;
+      NTCHK(nthip_kmer_hash(c, part, k16, m8, &out, &n_kmers, flags & NTHIP_HOST_INPUT));
+      sum_kmers += n_kmers;
+      if (n_kmers == 0) return NTHIP_OK;
+      NTCHK(nthip_stream_count_query(c, d_h, n_kmers, m8, d_counters, n_counters, d_cmp));
+      NTCHK(device_exclusive_scan(c, d_counts, d_roff, part->n_reads, d_sums, (uint64_t*)(c->d_small + 16)));
+      hipLaunchKernelGGL(place_estimates_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, (const uint8_t*)d_cmp, (const uint32_t*)d_pos,
+                         (const uint64_t*)d_roff, n_kmers, d_slot ? (const uint64_t*)(d_slot + r0) : (const uint64_t*)nullptr, fixed_wins,
+                         part->n_reads, d_slot ? d_est : d_est + r0 * fixed_wins);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(c->stream));
+      return NTHIP_OK;
+    };
+    if (rd->offsets) {
+      NTCHK(offsets_in_rounds(c, rd, flags, (size_t)8 * m + 8, one_round));
+    } else {
+      // fixed-length reads: rounds of reads whose stream fits a fifth of the free memory
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
+      uint64_t reads_per_round = std::max<uint64_t>(1, (uint64_t)(free_b / 5) / ((uint64_t)fixed_wins * (8 * m + 5) + 32 + (host_in ? stride : 0)));
+      if (c->tune.bloom_round) reads_per_round = std::max<uint64_t>(1, c->tune.bloom_round / (fixed_wins * m));
+      for (uint64_t r0 = first; r0 < rd->n_reads; r0 += reads_per_round) {
+        nthip_reads part = *rd;
+        part.seqs = rd->seqs + r0 * stride;
+        part.n_reads = std::min<uint64_t>(reads_per_round, rd->n_reads - r0);
+        NTCHK(one_round(&part, r0, part.n_reads * fixed_wins));
+      }
+    }
+  }
+  if (host_out) HIPCHK(hipMemcpyAsync(estimates, d_est, (size_t)n_slots_out, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (total) *total = sum_kmers;
+  return NTHIP_OK;
+}

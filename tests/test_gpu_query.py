@@ -1,0 +1,261 @@
+"""Round 5: the binned read side of the Bloom filter / counting sketch (nthash_amd/csrc/bloom_query_kernels.hpp,
+capi_sink_query.hip) and nthip_kmer_count_query -- every road against the oracle's hash stream
+(reference emission rule src/kmer.cpp:228-264, hashes()[i] src/internal.hpp:104-118)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx_with(env):
+    import nthash_amd
+    for k_, v in env.items():
+        os.environ[k_] = str(v)
+    try:
+        return nthash_amd.Context(0)
+    finally:
+        for k_ in env:
+            os.environ.pop(k_, None)
+
+
+def _bloom_expected(hashes, n_bits):
+    """filter bytes after setting bit (h mod n_bits) of every hash: bit p = bit p & 7 of byte p >> 3 (filters of gigabits:
+    no array of one byte per bit)"""
+    nbytes = (n_bits + 31) // 32 * 4
+    pos = hashes.ravel() % np.uint64(n_bits)
+    filt = np.zeros(nbytes, np.uint8)
+    np.bitwise_or.at(filt, (pos >> np.uint64(3)).astype(np.int64), (np.uint8(1) << (pos & np.uint64(7)).astype(np.uint8)))
+    return filt
+
+
+def _present(filt, hashes, n_bits, m):
+    pos = hashes % np.uint64(n_bits)
+    bit = (filt[(pos >> np.uint64(3)).astype(np.int64)] >> (pos & np.uint64(7)).astype(np.uint8)) & 1
+    return bit.reshape(-1, m).all(axis=1)
+
+
+def _dirty(rng, reads, n, L, every=700):
+    bad = rng.choice(n * L, max(3, n * L // every), replace=False)
+    reads[bad] = np.frombuffer(b"NnRY-", dtype=np.uint8)[rng.integers(0, 5, bad.size)]
+
+
+def _query_device(ctx, reads, n, L, k, m, d_f, n_bits, stride=0):
+    """device-resident reads, device hits -> (hits, total, found, kernel of record)"""
+    d_in = ctx.malloc(reads.size + 16)
+    ctx.h2d(d_in, reads)
+    d_hits = ctx.malloc(max(8, n * 8))
+    ctx.memset(d_hits, 0xEE, max(8, n * 8))          # (every read's count must be WRITTEN, not added to)
+    ctx.set_profiling(True)
+    total, found = ctx.bloom_query_ptr(d_in, n, L, stride, k, m, d_f, n_bits, hits=d_hits)
+    name = ctx.last_kernel_ms()[1]
+    ctx.set_profiling(False)
+    hits = np.zeros(n, np.uint64)
+    ctx.d2h(hits, d_hits)
+    ctx.free(d_in)
+    ctx.free(d_hits)
+    return hits, total, found, name
+
+
+@pytest.mark.parametrize("n,L,k,m,n_bits,tight,round_values", [
+    (5000, 150, 31, 1, 1 << 22, 0, 0),                   # one bin: level 1 straight to the regions
+    (5000, 150, 31, 1, (1 << 28) + 4_000_037 * 32, 0, 0),  # 3 bins, a partial last region, not a power of two
+    (3000, 150, 31, 3, 1 << 29, 0, 0),                   # m = 3: a k-mer hits when all three answers are 1
+    (2500, 101, 25, 2, 3_000_000_128, 0, 0),             # 23 bins, invariant modulo
+    (1100, 250, 64, 1, 1 << 30, 0, 0),                   # k = 64, 8 bins, a last tile that is not full
+    (4000, 150, 31, 2, 1 << 28, 1, 0),                   # buckets of the mean exactly: the overflow list answers
+    (4000, 150, 31, 1, 1 << 28, 2, 0),                   # ... of half the mean and a list of 64: the round fails -> direct kernel
+    (6000, 150, 31, 1, 1 << 29, 0, 150_000),             # several rounds of reads
+    (300, 48, 21, 1, 1 << 28, 0, 0), (1, 150, 31, 1, 1 << 28, 0, 0),
+])
+def test_bloom_binned_query_hits_per_read(oracle, n, L, k, m, n_bits, tight, round_values):
+    """insert batch A, query batch B (half of A's reads + new ones, with non-bases) on the binned road
+    (NTHIP_TUNE_BLOOM_QUERY=1): hits per read, k-mers tested and found == what the oracle's hashes and the expected filter
+    say; and == the direct kernel's (NTHIP_TUNE_BLOOM_QUERY=2) answers"""
+    env = {"NTHIP_TUNE_BLOOM_QUERY": 1}
+    if tight:
+        env["NTHIP_TUNE_BLOOM_SLOT_TIGHT"] = tight
+    if round_values:
+        env["NTHIP_TUNE_BLOOM_ROUND"] = round_values
+    ctx = _ctx_with(env)
+    direct = _ctx_with({"NTHIP_TUNE_BLOOM_QUERY": 2})
+    rng = np.random.default_rng(11 * n + L + m)
+    a_reads = oracle.synth_reads(0, n, L, 5)
+    b_reads = oracle.synth_reads(n // 2, n, L, 5).copy()
+    b_reads[: 3 * L] = ord("C")                            # a k-mer many times over (and absent from the filter)
+    if n > 10:
+        _dirty(rng, b_reads, n, L)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    ha = oracle.kmer_batch(a_reads, offs, k, m, want_pos=False)
+    filt = _bloom_expected(ha["hashes"], n_bits)
+    d_f, nbytes = ctx.bloom_new(n_bits)
+    ctx.h2d(d_f, filt)
+    hb = oracle.kmer_batch(b_reads, offs, k, m, want_pos=False)
+    present = _present(filt, hb["hashes"], n_bits, m)
+    read_of = np.repeat(np.arange(n), hb["counts"].astype(np.int64))
+    want_hits = np.bincount(read_of[present], minlength=n).astype(np.uint64)
+    hits, total, found, name = _query_device(ctx, b_reads, n, L, k, m, d_f, n_bits)
+    if tight == 2:
+        assert name == "kmer_runs_gen_kernel(bloom query)", name     # the failed round was redone
+    else:
+        assert name.startswith("bloom binned query"), name
+    assert total == hb["total"]
+    assert (hits == want_hits).all(), int((hits != want_hits).sum())
+    assert found == int(want_hits.sum())
+    hits2, total2, found2, name2 = _query_device(direct, b_reads, n, L, k, m, d_f, n_bits)
+    assert name2 == "kmer_runs_gen_kernel(bloom query)"
+    assert total2 == total and found2 == found and (hits2 == hits).all()
+    # host buffers on the same context: the direct road (the binned one is for device-resident reads), same answers
+    hits3, total3, found3 = ctx.bloom_query(b_reads, k, m, L, n, d_f, n_bits)
+    assert total3 == total and found3 == found and (hits3 == hits).all()
+    ctx.free(d_f)
+    ctx.close()
+    direct.close()
+
+
+def test_bloom_binned_query_padded_rows_and_default_choice(ctx, oracle):
+    """stride > length (one read per line of a text file) on the binned road; and the default context keeps a small batch
+    on the direct kernel"""
+    n, L, k, m, n_bits, stride = 3000, 100, 31, 2, 1 << 28, 101
+    forced = _ctx_with({"NTHIP_TUNE_BLOOM_QUERY": 1})
+    rows = np.full(n * stride, ord("\n"), np.uint8)
+    reads = oracle.synth_reads(3, n, L, 9)
+    rows.reshape(n, stride)[:, :L] = reads.reshape(n, L)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    h = oracle.kmer_batch(reads, offs, k, m, want_pos=False)
+    filt = _bloom_expected(h["hashes"][: h["hashes"].shape[0] // 2], n_bits)     # the first half of the k-mers
+    d_f, _ = forced.bloom_new(n_bits)
+    forced.h2d(d_f, filt)
+    present = _present(filt, h["hashes"], n_bits, m)
+    want = present.reshape(n, L - k + 1).sum(axis=1).astype(np.uint64)
+    hits, total, found, name = _query_device(forced, rows, n, L, k, m, d_f, n_bits, stride=stride)
+    assert name.startswith("bloom binned query"), name
+    assert total == h["total"] and found == int(want.sum()) and (hits == want).all()
+    d_f2, _ = ctx.bloom_new(n_bits)
+    ctx.h2d(d_f2, filt)
+    hits2, total2, found2, name2 = _query_device(ctx, rows, n, L, k, m, d_f2, n_bits, stride=stride)
+    assert name2 == "kmer_runs_gen_kernel(bloom query)", name2
+    assert total2 == total and found2 == found and (hits2 == hits).all()
+    ctx.free(d_f2)
+    forced.free(d_f)
+    forced.close()
+
+
+@pytest.mark.parametrize("n,L,k,m,n_counters,binned,tight,dirty", [
+    (4000, 150, 31, 1, 1 << 20, True, 0, False),          # 8 regions, one bin
+    (4000, 150, 31, 3, (1 << 25) + 40_000, True, 0, True),  # 3 bins, a partial last region, reads with non-bases
+    (3000, 150, 31, 2, 1 << 26, True, 1, True),           # the overflow list answers
+    (3000, 150, 31, 2, 1 << 26, True, 2, False),          # the round fails: the stream road takes over
+    (2000, 101, 25, 2, 999_984, False, 0, True),          # the stream road from the start
+    (600, 40, 31, 1, 1 << 16, False, 0, False),
+])
+def test_kmer_count_query_matches_stream_query_on_the_oracle_stream(oracle, n, L, k, m, n_counters, binned, tight, dirty):
+    """nthip_kmer_count_query (fixed-length device-resident reads; binned or by rounds of the compact stream) == the
+    smallest of each emitted k-mer's m counters at its window (== what nthip_stream_count_query answers on the ORACLE's
+    stream), 0 for the windows NtHash skips"""
+    env = {"NTHIP_TUNE_BLOOM_QUERY": 1 if binned else 2}
+    if tight:
+        env["NTHIP_TUNE_BLOOM_SLOT_TIGHT"] = tight
+    ctx = _ctx_with(env)
+    rng = np.random.default_rng(5 * n + L + m)
+    reads = oracle.synth_reads(1, n, L, 21).copy()
+    reads[: 2 * L] = ord("G")
+    if dirty:
+        _dirty(rng, reads, n, L, every=400)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    h = oracle.kmer_batch(reads, offs, k, m, want_pos=True)
+    sketch = rng.integers(0, 256, n_counters, dtype=np.int64).astype(np.uint8)
+    sketch[::7] = 0
+    d_c = ctx.malloc(n_counters)
+    ctx.h2d(d_c, sketch)
+    hs = np.ascontiguousarray(h["hashes"]).reshape(-1, m)
+    n_kmers = hs.shape[0]
+    # the stream query on the oracle's stream
+    d_h, d_e = ctx.malloc(max(8, hs.size * 8)), ctx.malloc(max(4, n_kmers))
+    ctx.h2d(d_h, hs.ravel())
+    ctx.stream_count_query_ptr(d_h, n_kmers, m, d_c, n_counters, d_e)
+    est_stream = np.zeros(n_kmers, np.uint8)
+    ctx.d2h(est_stream, d_e)
+    assert (est_stream == sketch[(hs % np.uint64(n_counters)).astype(np.int64)].min(axis=1)).all()
+    nwin = L - k + 1
+    want = np.zeros(n * nwin, np.uint8)
+    read_of = np.repeat(np.arange(n), h["counts"].astype(np.int64))
+    want[read_of * nwin + h["pos"].astype(np.int64)] = est_stream
+    # device-resident reads, device estimates
+    d_in, d_out = ctx.malloc(reads.size + 16), ctx.malloc(n * nwin)
+    ctx.h2d(d_in, reads)
+    ctx.memset(d_out, 0xEE, n * nwin)
+    ctx.set_profiling(True)
+    total = ctx.count_query_ptr(d_in, n, L, 0, k, m, d_c, n_counters, d_out)
+    name = ctx.last_kernel_ms()[1]
+    ctx.set_profiling(False)
+    got = np.zeros(n * nwin, np.uint8)
+    ctx.d2h(got, d_out)
+    if binned and tight != 2:
+        assert name.startswith("count binned query"), name
+    else:
+        assert not name.startswith("count binned query"), name
+    assert total == h["total"]
+    assert (got == want).all(), int((got != want).sum())
+    # host buffers: the stream road, same answers
+    got2, total2 = ctx.count_query(reads, k, m, L, n, d_c, n_counters)
+    assert total2 == total and (got2 == want).all()
+    for p in (d_in, d_out, d_h, d_e, d_c):
+        ctx.free(p)
+    ctx.close()
+
+
+def test_kmer_count_query_reads_by_offsets(ctx, oracle):
+    """reads of any lengths: read r's windows at the sum of the windows of the reads before it"""
+    n, k, m, n_counters = 700, 25, 2, 1 << 18
+    rng = np.random.default_rng(99)
+    lens = rng.integers(0, 400, n).astype(np.uint64)
+    lens[:3] = [0, k - 1, k]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total_b = int(offs[-1])
+    reads = oracle.synth_reads(4, 1, total_b, 3).copy()
+    reads[rng.choice(total_b, total_b // 300, replace=False)] = ord("N")
+    h = oracle.kmer_batch(reads, offs, k, m, want_pos=True)
+    sketch = rng.integers(0, 256, n_counters, dtype=np.int64).astype(np.uint8)
+    d_c = ctx.malloc(n_counters)
+    ctx.h2d(d_c, sketch)
+    wins = np.maximum(lens.astype(np.int64) - k + 1, 0)
+    slot = np.concatenate([[0], np.cumsum(wins)])
+    hs = np.ascontiguousarray(h["hashes"]).reshape(-1, m)
+    est = sketch[(hs % np.uint64(n_counters)).astype(np.int64)].min(axis=1)
+    want = np.zeros(int(slot[-1]), np.uint8)
+    read_of = np.repeat(np.arange(n), h["counts"].astype(np.int64))
+    want[slot[read_of] + h["pos"].astype(np.int64)] = est
+    got, total = ctx.count_query(reads, k, m, 0, n, d_c, n_counters, offsets=offs)
+    assert total == h["total"]
+    assert (got == want).all(), int((got != want).sum())
+    # device-resident batch
+    d_in, d_o, d_out = ctx.malloc(total_b + 16), ctx.malloc(offs.nbytes), ctx.malloc(max(4, want.size))
+    ctx.h2d(d_in, reads)
+    ctx.h2d(d_o, offs)
+    total2 = ctx.count_query_ptr(d_in, n, 0, 0, k, m, d_c, n_counters, d_out, offsets=d_o)
+    got2 = np.zeros(want.size, np.uint8)
+    ctx.d2h(got2, d_out)
+    assert total2 == total and (got2 == want).all()
+    for p in (d_in, d_o, d_out, d_c):
+        ctx.free(p)
+
+
+def test_kmer_count_query_argument_errors(ctx):
+    import nthash_amd
+    d_c, d_e = ctx.malloc(1024), ctx.malloc(4096)
+    data = np.frombuffer(b"ACGT" * 50, dtype=np.uint8)
+    d_in = ctx.malloc(256)
+    ctx.h2d(d_in, data)
+    for bad in (lambda: ctx.count_query_ptr(d_in, 1, 200, 0, 31, 1, 0, 1024, d_e),         # NULL sketch
+                lambda: ctx.count_query_ptr(d_in, 1, 200, 0, 31, 1, d_c + 1, 1024, d_e),   # unaligned
+                lambda: ctx.count_query_ptr(d_in, 1, 200, 0, 31, 1, d_c, 1022, d_e),       # not a multiple of 4
+                lambda: ctx.count_query_ptr(d_in, 1, 200, 0, 31, 1, d_c, 1024, 0),         # NULL estimates
+                lambda: ctx.count_query_ptr(d_in, 1, 200, 0, 0, 1, d_c, 1024, d_e),
+                lambda: ctx.count_query_ptr(d_in, 1, 200, 0, 31, 0, d_c, 1024, d_e)):
+        with pytest.raises(nthash_amd.NtHipError):
+            bad()
+    assert ctx.count_query_ptr(d_in, 10, 20, 0, 31, 1, d_c, 1024, d_e) == 0      # reads shorter than k: nothing to estimate
+    for p in (d_c, d_e, d_in):
+        ctx.free(p)
