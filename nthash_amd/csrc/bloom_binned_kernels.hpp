@@ -117,11 +117,12 @@ __device__ __forceinline__ unsigned long long bloom_overflow_run(const BloomSlot
 // exact lists: gbase = the run's place in `out`; slots mode: relative to bucket (bucket0 + b)'s own cap entries.
 template <uint32_t NW, bool QUERY = false>
 __device__ __forceinline__ void bloom_copy_out(const uint32_t* sorted, const uint32_t* hist, const uint32_t* off, const uint32_t* gbase,
-                                               uint32_t n_buckets, uint32_t wave, uint32_t lane, uint32_t* out, uint64_t bucket0,
+                                               uint32_t n_buckets, uint32_t wave_v, uint32_t lane, uint32_t* out, uint64_t bucket0,
                                                const BloomSlots& sl, uint32_t shift, uint32_t* tovf = nullptr)
 {
   // (tovf, the binned query: tovf[b] = where the tile's overflowing entries of bucket b start in the overflow list)
   static_assert(NW >= 4, "at most 64 buckets per wave");
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_v); // (uniform, and known to be: scalar address arithmetic)
   const uint32_t myb = wave + lane * NW;
   uint32_t mc = 0, mo = 0, mg = 0;
   if (myb < n_buckets) {
@@ -168,6 +169,96 @@ __device__ __forceinline__ void bloom_copy_out(const uint32_t* sorted, const uin
       }
     }
   }
+}
+
+// ---- pieces mode (round 5): whole lines into block-private pieces ------------------------------------------------------
+// What the appended runs cost is what HBM makes of them (tools/bench_micro/runs_append.hip, 8 GiB of runs of 48..80 entries
+// to 256 lists): behind a cursor every block shares -- every run starts where another CU's ended, two of its three lines
+// are written in part -- 4.0-4.8 ms; every block appending to its OWN piece of every list, whole 128-byte lines only:
+// 2.1 ms while writing a quarter more bytes.  So in pieces mode bucket b's list is not one run of slots but one PIECE per
+// writing block ((piece0 + b * piece_step) * cap entries into `out`), the block keeps the entries of a bucket that do not
+// fill a line (fewer than 32) in LDS until the next tile brings the rest (`left`, `lcnt`), and its cursor is its own count
+// (no global atomic, no round trip per tile): everything that reaches memory is a whole aligned line behind the block's
+// last one.  An entry's place in its piece is still `count before the tile + rank in the tile`: the binned query's way back
+// (bloom_query_kernels.hpp) does not care when it was written.  Entries past the piece's cap go to the overflow list as
+// before.  The last lines of the pieces are written when the block is done (bloom_flush_lines).
+// Sixteen lanes per bucket, four buckets per instruction: what a bucket's run needs -- its counts, its place, the 64-bit
+// address -- is vector arithmetic done once per four buckets.  (One bucket per wave at a time with everything about it in
+// scalar registers -- the shape of bloom_copy_out -- took 6-9 of a tile's 11-14 us WITHOUT its stores: a CU issues one scalar
+// instruction per cycle for all its waves, and 256 bucket runs of ~100 instructions each are 25 K cycles.)
+template <uint32_t NW, bool QUERY = false>
+__device__ __forceinline__ void bloom_copy_out_lines(const uint32_t* sorted, const uint32_t* hist, const uint32_t* off, const uint32_t* gbase,
+                                                     uint32_t* left, uint32_t* lcnt, uint32_t n_buckets, uint32_t wave_v, uint32_t lane,
+                                                     uint32_t* out, uint64_t piece0, uint64_t piece_step, uint64_t bucket0, const BloomSlots& sl,
+                                                     uint32_t shift, uint32_t* tovf = nullptr)
+{
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_v);
+  const uint32_t cap = (uint32_t)sl.cap; // (a multiple of 32)
+  const uint32_t g = lane >> 4, l = lane & 15u;
+  const uint32_t n_mine = n_buckets > wave ? (n_buckets - wave + NW - 1u) / NW : 0u;
+  for (uint32_t i0 = 0; i0 < n_mine; i0 += 4u) {
+    const bool mine = i0 + g < n_mine;
+    const uint32_t b = wave + (mine ? i0 + g : i0) * NW;
+    const uint32_t c = mine ? hist[b] : 0u, o = off[b], at = gbase[b], L = mine ? lcnt[b] : 0u;
+    const uint32_t fit = at >= cap ? 0u : (cap - at < c ? cap - at : c); // what the piece still takes of the tile's run
+    const uint32_t tot = L + fit, n = tot & ~31u, rem = tot - n;          // the whole lines that can go; what waits
+    uint32_t* const dst = out + ((piece0 + (uint64_t)b * piece_step) * cap + ((at < cap ? at : cap) - L));
+    uint32_t* const lb = left + b * 32u;
+    const uint32_t* const sb = sorted + o - L; // the waiting entries, then the run: entry q is lb[q] (q < L) or sb[q]
+    {
+      // the first 64 entries of the four buckets: read, then written
+      const uint32_t q0 = l, q1 = l + 16u, q2 = l + 32u, q3 = l + 48u;
+      const uint32_t v0 = q0 < n ? (q0 < L ? lb[q0] : sb[q0]) : 0u;
+      const uint32_t v1 = q1 < n ? (q1 < L ? lb[q1] : sb[q1]) : 0u;
+      const uint32_t v2 = q2 < n ? sb[q2] : 0u;
+      const uint32_t v3 = q3 < n ? sb[q3] : 0u;
+      if (q0 < n) dst[q0] = v0;
+      if (q1 < n) dst[q1] = v1;
+      if (q2 < n) dst[q2] = v2;
+      if (q3 < n) dst[q3] = v3;
+    }
+    for (uint32_t q = l + 64u; __ballot(q < n) != 0ull; q += 32u) { // (longer runs: 32 entries of each at a time)
+      const uint32_t v0 = q < n ? sb[q] : 0u;
+      const uint32_t v1 = q + 16u < n ? sb[q + 16u] : 0u;
+      if (q < n) dst[q] = v0;
+      if (q + 16u < n) dst[q + 16u] = v1;
+    }
+    // what does not fill a line waits in LDS for the next tile: behind the old ones when no line went, else the tail
+    if (n) {
+      if (l < rem) lb[l] = sb[n + l];
+      if (l + 16u < rem) lb[l + 16u] = sb[n + l + 16u];
+    } else {
+      if (l < fit) lb[L + l] = sb[L + l];
+      if (l + 16u < fit) lb[L + l + 16u] = sb[L + l + 16u];
+    }
+    if (mine && l == 0) lcnt[b] = rem;
+    if (__ballot(fit < c) != 0ull) { // (rare) the entries past a piece's cap: the overflow list, a bucket at a time
+      for (uint32_t gg = 0; gg < 4u; ++gg) {
+        const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)(gg * 16u)), ff = (uint32_t)__builtin_amdgcn_readlane((int)fit, (int)(gg * 16u));
+        const uint32_t oo = (uint32_t)__builtin_amdgcn_readlane((int)o, (int)(gg * 16u)), bb = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)(gg * 16u));
+        if (ff < cc) {
+          const unsigned long long ob = bloom_overflow_run(sl, sorted + oo, ff, cc, (bucket0 + bb) << shift, lane);
+          if constexpr (QUERY) {
+            if (lane == 0) tovf[bb] = (uint32_t)(ob < 0xFFFFFFFFull ? ob : 0xFFFFFFFFull);
+          }
+        }
+      }
+    }
+  }
+}
+// the block is done: the lines its pieces end with (in part), and how many entries every piece got (fill[b]; may be past the cap)
+template <uint32_t NW>
+__device__ __forceinline__ void bloom_flush_lines(const uint32_t* left, const uint32_t* lcnt, const uint32_t* pcur, uint32_t n_buckets, uint32_t wave,
+                                                  uint32_t lane, uint32_t tid, uint32_t* out, uint64_t piece0, uint64_t piece_step, uint64_t cap,
+                                                  uint32_t* fill)
+{
+  wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+  for (uint32_t b = wave; b < n_buckets; b += NW) {
+    const uint32_t L = lcnt[b];
+    const uint64_t cur = pcur[b] < cap ? pcur[b] : cap;
+    if (lane < L) out[(piece0 + (uint64_t)b * piece_step) * cap + (cur - L) + lane] = left[b * 32u + lane];
+  }
+  if (tid < n_buckets) fill[tid] = pcur[tid];
 }
 
 // ---- hist: values per region ---------------------------------------------------------------------------------------
@@ -448,6 +539,164 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(
   }
 }
 
+// ---- part, pieces mode: the second level between two lists of pieces -----------------------------------------------------
+// Segment s (a bin) of the level before is n_pieces_in pieces -- piece p at in[(s * n_pieces_in + p) * cap_in ...), its
+// entries min(fill_in[p * in_buckets + s], cap_in) -- and block x of the segment's gridDim.x blocks takes the pieces x, x +
+// gridDim.x, ... tile by tile; bucket b of the segment (region s * buckets_per_seg + b) gets a piece per block:
+// out[((s * buckets_per_seg + b) * gridDim.x + x) * sl.cap ...), fill_out[(s * gridDim.x + x) * buckets_per_seg + b] entries.
+struct BloomPartPiecesArgs {
+  const uint32_t* in;
+  uint32_t* out;
+  const uint32_t* fill_in;
+  uint32_t* fill_out;
+  uint64_t cap_in;
+  uint32_t n_pieces_in, in_buckets;
+  uint32_t n_regions, shift, mask, buckets_per_seg;
+  BloomSlots sl; // cap: entries per piece written
+  // the binned query: q_where per slot of `in`; tile row ((s * n_pieces_in + p) * q_tiles_per_piece + tile of the piece)
+  uint32_t* q_where;
+  uint2* q_tab;
+  uint32_t* q_tovf;
+  uint32_t q_tiles_per_piece;
+};
+
+template <uint32_t BB_PART_THREADS, bool QUERY = false>
+static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_pieces_kernel(const BloomPartPiecesArgs a)
+{
+  constexpr uint32_t BB_TILE = BB_PART_THREADS * BB_PART_ITEMS;
+  __shared__ uint32_t hist[BB_MAX_BINS];
+  __shared__ uint32_t off[BB_MAX_BINS];
+  __shared__ uint32_t gbase[BB_MAX_BINS];
+  __shared__ uint32_t lcnt[BB_MAX_BINS], pcur[BB_MAX_BINS];
+  extern __shared__ __attribute__((aligned(16))) uint32_t bb_lds[];
+  uint32_t* const sorted = bb_lds;       // BB_TILE entries
+  uint32_t* const left = bb_lds + BB_TILE; // [bucket][32]
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t seg = blockIdx.y, gx = gridDim.x;
+  const uint32_t r0 = seg * a.buckets_per_seg;
+  const uint32_t r1 = r0 + a.buckets_per_seg < a.n_regions ? r0 + a.buckets_per_seg : a.n_regions;
+  const uint32_t n_buckets = r1 - r0;
+  if (tid < BB_MAX_BINS) {
+    lcnt[tid] = 0;
+    pcur[tid] = 0;
+  }
+  auto count_of = [&](uint32_t p) -> uint32_t { // (uniform)
+    if (p >= a.n_pieces_in) return 0u;
+    const uint64_t f = a.fill_in[(size_t)p * a.in_buckets + seg];
+    return (uint32_t)(f < a.cap_in ? f : a.cap_in);
+  };
+  // the tile at hand: piece p, its tile kk; cnt = the piece's entries; cnt_next = those of piece p + gx (asked for a piece ahead)
+  uint32_t p = blockIdx.x, kk = 0, cnt = count_of(p), cnt_next = count_of(p + gx);
+  while (p < a.n_pieces_in && cnt == 0) {
+    p += gx;
+    cnt = cnt_next;
+    cnt_next = count_of(p + gx);
+  }
+  uint32_t pre[BB_PART_ITEMS];
+  auto fetch = [&](uint32_t pp, uint32_t k2, uint32_t c2) {
+    const uint64_t base = ((uint64_t)seg * a.n_pieces_in + pp) * a.cap_in;
+    const uint32_t t0 = k2 * BB_TILE;
+#pragma unroll
+    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+      const uint32_t idx = t0 + j * BB_PART_THREADS + tid;
+      pre[j] = 0;
+      if (idx < c2) pre[j] = __builtin_nontemporal_load(a.in + base + idx);
+    }
+  };
+  if (p < a.n_pieces_in) fetch(p, 0, cnt);
+  while (p < a.n_pieces_in) {
+    if (tid < BB_MAX_BINS) hist[tid] = 0;
+    __syncthreads();
+    const uint64_t base = ((uint64_t)seg * a.n_pieces_in + p) * a.cap_in;
+    const uint32_t t0 = kk * BB_TILE;
+    uint32_t val[BB_PART_ITEMS], where[BB_PART_ITEMS]; // where = bucket << 16 | rank inside the tile's bucket
+    if (t0 + BB_TILE <= cnt) {
+#pragma unroll
+      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+        const uint32_t b = pre[j] >> a.shift;
+        val[j] = pre[j] & a.mask;
+        where[j] = (b << 16) | atomicAdd(&hist[b], 1u);
+      }
+    } else {
+#pragma unroll
+      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+        const uint32_t idx = t0 + j * BB_PART_THREADS + tid;
+        where[j] = ~0u;
+        val[j] = 0;
+        if (idx < cnt) {
+          const uint32_t b = pre[j] >> a.shift;
+          val[j] = pre[j] & a.mask;
+          where[j] = (b << 16) | atomicAdd(&hist[b], 1u);
+        }
+      }
+    }
+    if constexpr (QUERY) {
+#pragma unroll
+      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+        const uint32_t idx = t0 + j * BB_PART_THREADS + tid;
+        if (idx < cnt) a.q_where[base + idx] = where[j];
+      }
+    }
+    // the next tile: of this piece, or the first of the block's next piece that holds anything
+    uint32_t np = p, nk = kk + 1u, ncnt = cnt;
+    if (nk * BB_TILE >= cnt) {
+      nk = 0;
+      do {
+        np += gx;
+        ncnt = cnt_next;
+        cnt_next = count_of(np + gx);
+      } while (np < a.n_pieces_in && ncnt == 0);
+    }
+    if (np < a.n_pieces_in) fetch(np, nk, ncnt);
+    __syncthreads();
+    uint32_t my_base = 0;
+    uint64_t q_row = 0;
+    if constexpr (QUERY) q_row = (((uint64_t)seg * a.n_pieces_in + p) * a.q_tiles_per_piece + kk) * a.buckets_per_seg;
+    if (tid < n_buckets) {
+      const uint32_t c = hist[tid];
+      my_base = pcur[tid];
+      pcur[tid] = my_base + c;
+      gbase[tid] = my_base;
+      if constexpr (QUERY) a.q_tab[q_row + tid] = make_uint2(c, my_base);
+    }
+    if (wave == 0) { // exclusive scan of the (at most 256) bucket counts: 4 per lane
+      uint32_t c[4], s = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) {
+        c[i] = hist[lane * 4u + i];
+        s += c[i];
+      }
+      uint32_t incl = s;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += o;
+      }
+      uint32_t run = incl - s;
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) {
+        off[lane * 4u + i] = run;
+        run += c[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j)
+      if (where[j] != ~0u) sorted[off[where[j] >> 16] + (where[j] & 0xFFFFu)] = val[j];
+    __syncthreads();
+    bloom_copy_out_lines<BB_PART_THREADS / 64u, QUERY>(sorted, hist, off, gbase, left, lcnt, n_buckets, wave, lane, a.out,
+                                                       (uint64_t)r0 * gx + blockIdx.x, (uint64_t)gx, (uint64_t)r0, a.sl, a.shift,
+                                                       QUERY ? a.q_tovf + q_row : nullptr);
+    __syncthreads();
+    p = np;
+    kk = nk;
+    cnt = ncnt;
+  }
+  __syncthreads();
+  bloom_flush_lines<BB_PART_THREADS / 64u>(left, lcnt, pcur, n_buckets, wave, lane, tid, a.out, (uint64_t)r0 * gx + blockIdx.x, (uint64_t)gx, a.sl.cap,
+                                           a.fill_out + ((size_t)seg * gx + blockIdx.x) * a.buckets_per_seg);
+}
+
 // ---- apply: a workgroup per region -----------------------------------------------------------------------------------
 // dynamic LDS: 128 KiB.  entries = 20-bit offsets of the region's values.
 // (slots mode, cap != 0: region r's entries are all_entries[r * cap ... + min(fill[r], cap)); a failed round is left alone)
@@ -456,15 +705,26 @@ static __global__ __launch_bounds__(BB_APPLY_THREADS) void bloom_apply_kernel(co
                                                                               uint32_t n_regions, uint32_t* __restrict__ filter,
                                                                               uint64_t filter_dwords, uint64_t cap,
                                                                               const uint32_t* __restrict__ fill,
-                                                                              const BloomStatus* status, uint64_t ovf_cap)
+                                                                              const BloomStatus* status, uint64_t ovf_cap,
+                                                                              uint32_t n_pieces = 0, uint32_t bps = 0)
 {
+  // (pieces mode, n_pieces != 0: region r is n_pieces pieces of cap entries -- piece x at (r * n_pieces + x) * cap, its entries
+  // fill[((r / bps) * n_pieces + x) * bps + r % bps] -- see bloom_part_pieces_kernel)
   extern __shared__ __attribute__((aligned(16))) uint32_t bb_lds[];
   uint4* const l4 = (uint4*)bb_lds;
   if (bloom_round_failed(status, ovf_cap)) return;
   for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+   const uint32_t n_runs = n_pieces ? n_pieces : 1u;
+   bool zeroed = false;
+   for (uint32_t x = 0; x < n_runs; ++x) {
     uint32_t e0, e1;
     const uint32_t* entries = all_entries;
-    if (cap) {
+    if (n_pieces) {
+      const uint64_t f = fill[((size_t)(r / bps) * n_pieces + x) * bps + r % bps];
+      entries += ((size_t)r * n_pieces + x) * cap;
+      e0 = 0;
+      e1 = (uint32_t)(f < cap ? f : cap);
+    } else if (cap) {
       const uint64_t f = fill[(size_t)r * BB_CURSOR_STRIDE];
       entries += (size_t)r * cap;
       e0 = 0;
@@ -474,8 +734,11 @@ static __global__ __launch_bounds__(BB_APPLY_THREADS) void bloom_apply_kernel(co
       e1 = region_base[r + 1];
     }
     if (e0 == e1) continue; // (uniform over the block)
-    for (uint32_t i = threadIdx.x; i < BB_REGION_DWORDS / 4u; i += BB_APPLY_THREADS) l4[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    if (!zeroed) {
+      for (uint32_t i = threadIdx.x; i < BB_REGION_DWORDS / 4u; i += BB_APPLY_THREADS) l4[i] = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+      zeroed = true;
+    }
     // entries: vectors of 4 where aligned, singles at the two ends
     const uint32_t up = (e0 + 3u) & ~3u;
     const uint32_t a0 = up < e1 ? up : e1, a1 = e1 & ~3u;
@@ -504,6 +767,8 @@ static __global__ __launch_bounds__(BB_APPLY_THREADS) void bloom_apply_kernel(co
       }
     }
     if (a1 >= a0 && threadIdx.x < e1 - a1) put(entries[a1 + threadIdx.x]);
+   }
+   if (!zeroed) continue; // (nothing for this region: uniform)
     __syncthreads();
     // the filter lines that got a bit
     const uint64_t d0 = (uint64_t)r * BB_REGION_DWORDS;
@@ -570,16 +835,25 @@ static __global__ __launch_bounds__(BB_APPLY_THREADS) void count_apply_kernel(co
                                                                               uint32_t n_regions, uint32_t* __restrict__ sketch,
                                                                               uint64_t sketch_dwords, uint64_t cap,
                                                                               const uint32_t* __restrict__ fill,
-                                                                              const BloomStatus* status, uint64_t ovf_cap)
+                                                                              const BloomStatus* status, uint64_t ovf_cap,
+                                                                              uint32_t n_pieces = 0, uint32_t bps = 0)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t bb_lds[];
   uint4* const l4 = (uint4*)bb_lds;
   constexpr uint32_t SLOTS = 1u << CS_REGION_SHIFT; // counters per region = LDS tallies
   if (bloom_round_failed(status, ovf_cap)) return;
   for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+   const uint32_t n_runs = n_pieces ? n_pieces : 1u; // (pieces mode: as bloom_apply_kernel)
+   bool zeroed = false;
+   for (uint32_t x = 0; x < n_runs; ++x) {
     uint32_t e0, e1;
     const uint32_t* entries = all_entries;
-    if (cap) {
+    if (n_pieces) {
+      const uint64_t f = fill[((size_t)(r / bps) * n_pieces + x) * bps + r % bps];
+      entries += ((size_t)r * n_pieces + x) * cap;
+      e0 = 0;
+      e1 = (uint32_t)(f < cap ? f : cap);
+    } else if (cap) {
       const uint64_t f = fill[(size_t)r * BB_CURSOR_STRIDE];
       entries += (size_t)r * cap;
       e0 = 0;
@@ -589,8 +863,11 @@ static __global__ __launch_bounds__(BB_APPLY_THREADS) void count_apply_kernel(co
       e1 = region_base[r + 1];
     }
     if (e0 == e1) continue; // (uniform over the block)
-    for (uint32_t i = threadIdx.x; i < SLOTS / 4u; i += BB_APPLY_THREADS) l4[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    if (!zeroed) {
+      for (uint32_t i = threadIdx.x; i < SLOTS / 4u; i += BB_APPLY_THREADS) l4[i] = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+      zeroed = true;
+    }
     const uint32_t up = (e0 + 3u) & ~3u;
     const uint32_t a0 = up < e1 ? up : e1, a1 = e1 & ~3u;
     auto put = [&](uint32_t e) { atomicAdd(&bb_lds[e], 1u); };
@@ -618,6 +895,8 @@ static __global__ __launch_bounds__(BB_APPLY_THREADS) void count_apply_kernel(co
       }
     }
     if (a1 >= a0 && threadIdx.x < e1 - a1) put(entries[a1 + threadIdx.x]);
+   }
+   if (!zeroed) continue; // (nothing for this region: uniform)
     __syncthreads();
     const uint64_t d0 = (uint64_t)r * (SLOTS / 4u); // the region's first dword of the sketch
     const uint64_t left = sketch_dwords - d0;

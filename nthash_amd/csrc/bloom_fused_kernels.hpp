@@ -32,6 +32,12 @@
 namespace ntamd {
 
 enum : int { BF_COUNT = 0, BF_PART = 1 };
+#ifndef BF_TIMING
+#define BF_TIMING 0 // 1: one block prints the phase times of its first tiles (tools/ab_build.sh)
+#endif
+#ifndef BF_ABL
+#define BF_ABL 0 // ablations of pass PART (WRONG results; tools/ab_build.sh): 1 hashing only, 2 + ranking, 3 + scan and sort (no copy-out)
+#endif
 
 struct BloomFusedArgs {
   const uint8_t* seqs;      // fixed-length reads, stride bytes apart
@@ -65,9 +71,20 @@ struct BloomFusedQueryArgs : BloomFusedArgs {
   uint32_t q_steps;
 };
 
+// pieces mode (bloom_binned_kernels.hpp, bloom_copy_out_lines): bucket b's entries of block x go to piece (b * gridDim.x + x)
+// of `out` (sl.cap entries each), whole lines only; p_fill[x * n_buckets + b] = how many it got.  No cursors.
+struct BloomFusedPiecesArgs : BloomFusedQueryArgs {
+  uint32_t* p_fill;
+};
+template <bool QUERY, bool PIECES>
+struct BloomFusedArgsOf {
+  typedef typename std::conditional<PIECES, BloomFusedPiecesArgs, typename std::conditional<QUERY, BloomFusedQueryArgs, BloomFusedArgs>::type>::type type;
+};
+
 // THREADS reads per tile; dynamic LDS: bit stream | COUNT: n_regions counters / PART: THREADS * 16 sorted slots
-template <int PASS, uint32_t THREADS, bool QUERY = false>
-__global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename std::conditional<QUERY, BloomFusedQueryArgs, BloomFusedArgs>::type a)
+// (PIECES: + 256 x 32 entries that wait for their line, + 2 x 256 counters)
+template <int PASS, uint32_t THREADS, bool QUERY = false, bool PIECES = false>
+__global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename BloomFusedArgsOf<QUERY, PIECES>::type a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   __shared__ __attribute__((aligned(16))) uint4 tab[16];
@@ -79,6 +96,15 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename std
   const uint32_t bits_dwords = a.pad_dwords + (((THREADS - 1u) * a.stride + a.len + 15u + 15u) >> 4) + 2u;
   uint32_t* const bits = lds_dyn;
   uint32_t* const area = lds_dyn + ((bits_dwords + 3u) & ~3u); // COUNT: the counters; PART: the sorted tile
+  uint32_t* const lwait = area + THREADS * 16u;                 // PIECES: [bucket][32] entries waiting for their line,
+  uint32_t* const lcnt = lwait + BB_MAX_BINS * 32u;              //   how many of them,
+  uint32_t* const pcur = lcnt + BB_MAX_BINS;                    //   entries of the block's piece of every bucket so far
+  if constexpr (PIECES) {
+    if (tid < BB_MAX_BINS) {
+      lcnt[tid] = 0;
+      pcur[tid] = 0;
+    }
+  }
 
   if (tid < 16)
     tab[tid] = make_uint4((uint32_t)a.tab[tid][0], (uint32_t)(a.tab[tid][0] >> 32), (uint32_t)a.tab[tid][1],
@@ -147,6 +173,9 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename std
     if (dirty_me) lost += nwin;           // (what it does emit is taken off below)
 
     for (uint32_t j = 0; j < n_words; ++j) {
+#if BF_TIMING
+      const uint64_t tk0 = __builtin_amdgcn_s_memrealtime();
+#endif
       const uint32_t in_hi = bits[in_d + j + 1], out_hi = bits[out_d + j + 1];
       const uint32_t w_in = funnel(in_hi, in_lo, in_sh);
       uint32_t w_out = funnel(out_hi, out_lo, out_sh);
@@ -203,8 +232,17 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename std
             }
         } else {
           // ---- a tile of the first partition level: THREADS x 16 slots, sorted by bucket, appended at the cursors ----
+#if BF_ABL == 1
+#pragma unroll
+          for (uint32_t i = 0; i < 16; ++i)
+            if ((emask >> i) & 1u) lost += (uint32_t)h[i] == 0x12345u;
+          continue;
+#endif
           if (tid < BB_MAX_BINS) hist[tid] = 0;
           __syncthreads();
+#if BF_TIMING
+          const uint64_t tk1 = __builtin_amdgcn_s_memrealtime();
+#endif
           uint32_t val[16], where[16]; // where = bucket << 16 | rank inside the tile's bucket
 #pragma unroll
           for (uint32_t i = 0; i < 16; ++i) {
@@ -226,10 +264,23 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename std
               if (i >= lo && i < hi) a.q_where[(q_ts * 16u + i) * THREADS + tid] = where[i];
           }
           __syncthreads();
+#if BF_TIMING
+          const uint64_t tk2 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if BF_ABL == 2
+#pragma unroll
+          for (uint32_t i = 0; i < 16; ++i) lost += where[i] == 0x12345u && val[i] == 77u;
+          continue;
+#endif
           uint32_t my_base = 0; // (the cursor's answer is wanted by the copy-out only: it travels while the tile is sorted)
           if (tid < a.n_buckets) {
             const uint32_t cnt = hist[tid];
-            my_base = cnt ? atomicAdd(&a.cursor[(size_t)tid * BB_CURSOR_STRIDE], cnt) : 0u;
+            if constexpr (PIECES) {
+              my_base = pcur[tid];
+              pcur[tid] = my_base + cnt;
+            } else {
+              my_base = cnt ? atomicAdd(&a.cursor[(size_t)tid * BB_CURSOR_STRIDE], cnt) : 0u;
+            }
             if constexpr (QUERY) a.q_tab[q_ts * a.n_buckets + tid] = make_uint2(cnt, my_base);
           }
           if (wave == 0) { // exclusive scan of the (at most 256) bucket counts: 4 per lane
@@ -253,16 +304,31 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename std
             }
           }
           __syncthreads();
+#if BF_TIMING
+          const uint64_t tk3 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
           for (uint32_t i = 0; i < 16; ++i)
             if (where[i] != ~0u) area[off[where[i] >> 16] + (where[i] & 0xFFFFu)] = val[i];
           if (tid < a.n_buckets) gbase[tid] = my_base;
           __syncthreads();
-          if constexpr (QUERY)
+#if BF_TIMING
+          const uint64_t tk4 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if BF_ABL == 3
+          continue;
+#endif
+          if constexpr (PIECES)
+            bloom_copy_out_lines<THREADS / 64u, QUERY>(area, hist, off, gbase, lwait, lcnt, a.n_buckets, wave, lane, a.out, (uint64_t)blockIdx.x,
+                                                       (uint64_t)gridDim.x, 0ull, a.sl, a.shift, QUERY ? a.q_tovf + q_ts * a.n_buckets : nullptr);
+          else if constexpr (QUERY)
             bloom_copy_out<THREADS / 64u, true>(area, hist, off, gbase, a.n_buckets, wave, lane, a.out, 0ull, a.sl, a.shift,
                                                 a.q_tovf + q_ts * a.n_buckets);
           else bloom_copy_out<THREADS / 64u>(area, hist, off, gbase, a.n_buckets, wave, lane, a.out, 0ull, a.sl, a.shift);
           __syncthreads();
+#if BF_TIMING
+          if (tid == 0 && blockIdx.x == 3u && t < gridDim.x * 3u) { const uint64_t tk5 = __builtin_amdgcn_s_memrealtime(); printf("tile %u word %u: hash %u  rank %u  scan %u  sort %u  copy-out %u (10 ns)\n", t, j, (unsigned)(tk1 - tk0), (unsigned)(tk2 - tk1), (unsigned)(tk3 - tk2), (unsigned)(tk4 - tk3), (unsigned)(tk5 - tk4)); }
+#endif
         }
       }
     }
@@ -273,6 +339,11 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename std
       const uint32_t v = area[i];
       if (v) atomicAdd(&a.counts[i], v);
     }
+  }
+  if constexpr (PIECES) {
+    __syncthreads();
+    bloom_flush_lines<THREADS / 64u>(lwait, lcnt, pcur, a.n_buckets, wave, lane, tid, a.out, (uint64_t)blockIdx.x, (uint64_t)gridDim.x, a.sl.cap,
+                                     a.p_fill + (size_t)blockIdx.x * a.n_buckets);
   }
   if constexpr (PASS == BF_PART) {
     if (__ballot(lost != 0) != 0) {

@@ -69,5 +69,38 @@ inline uint64_t slot_cap(const nthip_ctx* c, uint64_t n, uint64_t bucket_slots, 
   return ((uint64_t)cap + 64u) & ~(uint64_t)63u;
 }
 
+
+// ---- pieces mode (bloom_binned_kernels.hpp): the lists of a two-level round as block-private pieces ----------------------
+constexpr uint32_t BB_PIECES_LDS_DWORDS = BB_MAX_BINS * 32u + 2u * BB_MAX_BINS; // level 1: the waiting entries + two counters per bucket
+struct PiecesGeo {
+  uint32_t g1 = 0, gx = 0;     // blocks of level 1 (a piece of every bin each); blocks per bin of level 2 (a piece of every region each)
+  uint64_t cap1 = 0, cap2 = 0; // entries per piece
+};
+inline uint64_t piece_cap(const nthip_ctx* c, double mean)
+{
+  double cap = mean + 8.0 * std::sqrt(mean) + 256.0;
+  if (c->tune.bloom_slot_tight == 1) cap = mean;       // (tests: the overflow list in use)
+  if (c->tune.bloom_slot_tight == 2) cap = mean * 0.5; // (tests: the overflow list overflows, the round fails)
+  return ((uint64_t)cap + 64u) & ~(uint64_t)63u;
+}
+// n_reads fixed-length reads of values_per_read values each into a table of n_slots slots, regions of 2^region_shift, bins of
+// 128 regions; gx = blocks per bin the second level is launched with
+inline void pieces_geo(const nthip_ctx* c, uint64_t n_reads, uint64_t values_per_read, uint64_t n_slots, uint32_t region_shift, uint32_t gx,
+                       PiecesGeo* g)
+{
+  const uint64_t n_tiles = (n_reads + 1023) / 1024;
+  g->g1 = (uint32_t)(n_tiles < (uint64_t)c->n_cu ? n_tiles : (uint64_t)c->n_cu);
+  if (g->g1 == 0) g->g1 = 1;
+  g->gx = gx;
+  const uint64_t tiles_per_block = (n_tiles + g->g1 - 1) / g->g1;
+  const double per_block = (double)tiles_per_block * 1024.0 * (double)values_per_read; // what a level-1 block may see
+  const double bin_slots = (double)(1ull << (region_shift + 7u)), region_slots = (double)(1ull << region_shift);
+  const double share1 = bin_slots < (double)n_slots ? bin_slots / (double)n_slots : 1.0;
+  const double share2 = region_slots < (double)n_slots ? region_slots / (double)n_slots : 1.0;
+  g->cap1 = piece_cap(c, per_block * share1);
+  const uint32_t pieces_per_block = (g->g1 + gx - 1) / gx; // of a bin, per level-2 block
+  g->cap2 = piece_cap(c, (double)pieces_per_block * per_block * share2);
+}
+
 } // namespace host
 } // namespace ntamd

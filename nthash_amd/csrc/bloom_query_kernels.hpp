@@ -50,47 +50,57 @@ template <int KIND>
 static __global__ __launch_bounds__(BQ_LOOKUP_THREADS) void bloom_lookup_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ fill,
                                                                                 uint64_t cap, uint32_t n_regions,
                                                                                 const uint32_t* __restrict__ table, uint64_t table_dwords,
-                                                                                uint8_t* __restrict__ pay)
+                                                                                uint8_t* __restrict__ pay, uint32_t n_pieces, uint32_t bps)
 {
+  // (pieces mode, n_pieces != 0: region r is n_pieces pieces -- piece x at slot (r * n_pieces + x) * cap, its entries
+  // fill[((r / bps) * n_pieces + x) * bps + r % bps]; bloom_part_pieces_kernel)
   extern __shared__ __attribute__((aligned(16))) uint32_t bq_lds[];
   uint4* const l4 = (uint4*)bq_lds;
   const uint32_t tid = threadIdx.x;
+  const uint32_t n_runs = n_pieces ? n_pieces : 1u;
   for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
-    const uint64_t f64 = fill[(size_t)r * BB_CURSOR_STRIDE];
-    const uint32_t f = (uint32_t)(f64 < cap ? f64 : cap);
-    if (f == 0) continue; // (uniform over the block)
-    __syncthreads();      // the region before is answered
-    const uint64_t d0 = (uint64_t)r * BB_REGION_DWORDS;
-    const uint64_t left = table_dwords - d0;
-    const uint32_t here = left < BB_REGION_DWORDS ? (uint32_t)left : BB_REGION_DWORDS;
-    const uint4* const t4 = (const uint4*)(table + d0);
-    for (uint32_t i = tid; i < BB_REGION_DWORDS / 4u; i += BQ_LOOKUP_THREADS) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (i * 4u + 4u <= here) v = t4[i];
-      else if (i * 4u < here) { // (a table that does not end on 16 bytes)
-        v.x = table[d0 + i * 4u];
-        if (i * 4u + 1u < here) v.y = table[d0 + i * 4u + 1u];
-        if (i * 4u + 2u < here) v.z = table[d0 + i * 4u + 2u];
+    bool loaded = false;
+    for (uint32_t x = 0; x < n_runs; ++x) {
+      const uint64_t f64 = n_pieces ? fill[((size_t)(r / bps) * n_pieces + x) * bps + r % bps] : fill[(size_t)r * BB_CURSOR_STRIDE];
+      const uint32_t f = (uint32_t)(f64 < cap ? f64 : cap);
+      if (f == 0) continue; // (uniform over the block)
+      if (!loaded) {
+        __syncthreads(); // the region before is answered
+        const uint64_t d0 = (uint64_t)r * BB_REGION_DWORDS;
+        const uint64_t left = table_dwords - d0;
+        const uint32_t here = left < BB_REGION_DWORDS ? (uint32_t)left : BB_REGION_DWORDS;
+        const uint4* const t4 = (const uint4*)(table + d0);
+        for (uint32_t i = tid; i < BB_REGION_DWORDS / 4u; i += BQ_LOOKUP_THREADS) {
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (i * 4u + 4u <= here) v = t4[i];
+          else if (i * 4u < here) { // (a table that does not end on 16 bytes)
+            v.x = table[d0 + i * 4u];
+            if (i * 4u + 1u < here) v.y = table[d0 + i * 4u + 1u];
+            if (i * 4u + 2u < here) v.z = table[d0 + i * 4u + 2u];
+          }
+          l4[i] = v;
+        }
+        __syncthreads();
+        loaded = true;
       }
-      l4[i] = v;
-    }
-    __syncthreads();
-    const bb_v4u* const e4 = (const bb_v4u*)(list + (size_t)r * cap); // (cap is a multiple of 64: 16-byte aligned, whole vectors)
-    uint32_t* const p4 = (uint32_t*)(pay + (size_t)r * cap);
-    const uint32_t nv = (f + 3u) >> 2;
-    for (uint32_t i0 = tid; i0 < nv; i0 += BQ_LOOKUP_BATCH * BQ_LOOKUP_THREADS) {
-      bb_v4u q[BQ_LOOKUP_BATCH];
+      const size_t slot0 = ((size_t)r * n_runs + x) * cap; // (cap is a multiple of 64: 16-byte aligned, whole vectors)
+      const bb_v4u* const e4 = (const bb_v4u*)(list + slot0);
+      uint32_t* const p4 = (uint32_t*)(pay + slot0);
+      const uint32_t nv = (f + 3u) >> 2;
+      for (uint32_t i0 = tid; i0 < nv; i0 += BQ_LOOKUP_BATCH * BQ_LOOKUP_THREADS) {
+        bb_v4u q[BQ_LOOKUP_BATCH];
 #pragma unroll
-      for (uint32_t u = 0; u < BQ_LOOKUP_BATCH; ++u) {
-        const uint32_t i = i0 + u * BQ_LOOKUP_THREADS;
-        q[u] = __builtin_nontemporal_load(e4 + (i < nv ? i : i0));
-      }
+        for (uint32_t u = 0; u < BQ_LOOKUP_BATCH; ++u) {
+          const uint32_t i = i0 + u * BQ_LOOKUP_THREADS;
+          q[u] = __builtin_nontemporal_load(e4 + (i < nv ? i : i0));
+        }
 #pragma unroll
-      for (uint32_t u = 0; u < BQ_LOOKUP_BATCH; ++u) {
-        const uint32_t i = i0 + u * BQ_LOOKUP_THREADS;
-        if (i < nv)
-          p4[i] = bq_answer_lds<KIND>(bq_lds, q[u].x) | (bq_answer_lds<KIND>(bq_lds, q[u].y) << 8) |
-                  (bq_answer_lds<KIND>(bq_lds, q[u].z) << 16) | (bq_answer_lds<KIND>(bq_lds, q[u].w) << 24);
+        for (uint32_t u = 0; u < BQ_LOOKUP_BATCH; ++u) {
+          const uint32_t i = i0 + u * BQ_LOOKUP_THREADS;
+          if (i < nv)
+            p4[i] = bq_answer_lds<KIND>(bq_lds, q[u].x) | (bq_answer_lds<KIND>(bq_lds, q[u].y) << 8) |
+                    (bq_answer_lds<KIND>(bq_lds, q[u].z) << 16) | (bq_answer_lds<KIND>(bq_lds, q[u].w) << 24);
+        }
       }
     }
   }
@@ -112,14 +122,16 @@ static __global__ __launch_bounds__(256) void bloom_ovf_lookup_kernel(const uint
 
 // ---- the way back of one tile ------------------------------------------------------------------------------------------------
 // A tile of a partition level wrote, for every bucket b < n_buckets, a run of tab[b].x entries; the first `fit` of them at
-// slots (bucket0 + b) * cap + tab[b].y ... of the level's list, the rest to the overflow list.  bq_stage_runs loads the
+// slots (piece0 + b * piece_step) * cap + tab[b].y ... of the level's list (slots mode: piece0 = the first bucket, step 1;
+// pieces mode: the writing block's piece of every bucket), the rest to the overflow list.  bq_stage_runs loads the
 // answers of those runs (pay: one byte per slot) into `stage` in the tile's sorted order -- stage[off[b] + rank] -- and
 // leaves offfit[b] = off[b] | fit[b] << 16.  Whole block; ends with a barrier.
 template <uint32_t NW>
-__device__ __forceinline__ void bq_stage_runs(const uint2* __restrict__ tab, uint32_t n_buckets, const uint8_t* __restrict__ pay, uint64_t bucket0,
-                                              uint64_t cap, uint8_t* stage, uint32_t* cnt, uint32_t* gat, uint32_t* offfit, uint32_t tid,
-                                              uint32_t lane, uint32_t wave)
+__device__ __forceinline__ void bq_stage_runs(const uint2* __restrict__ tab, uint32_t n_buckets, const uint8_t* __restrict__ pay, uint64_t piece0,
+                                              uint64_t piece_step, uint64_t cap, uint8_t* stage, uint32_t* cnt, uint32_t* gat, uint32_t* offfit, uint32_t tid,
+                                              uint32_t lane, uint32_t wave_v)
 {
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_v); // (uniform, and known to be: scalar address arithmetic)
   if (tid < BB_MAX_BINS) {
     uint2 e = make_uint2(0, 0);
     if (tid < n_buckets) e = tab[tid];
@@ -163,7 +175,7 @@ __device__ __forceinline__ void bq_stage_runs(const uint2* __restrict__ tab, uin
       const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)gat[b]);
       o[u] = of & 0xFFFFu;
       fit[u] = i0 + u < n_mine ? of >> 16 : 0u;
-      at[u] = (bucket0 + b) * cap + g;
+      at[u] = (piece0 + (uint64_t)b * piece_step) * cap + g;
       v0[u] = lane < fit[u] ? pay[at[u] + lane] : (uint8_t)0;
       v1[u] = lane + 64u < fit[u] ? pay[at[u] + 64u + lane] : (uint8_t)0;
     }
@@ -204,6 +216,10 @@ struct BloomBackArgs {
   const uint32_t* seg_fill;
   uint64_t cap_in;
   uint32_t n_regions, buckets_per_seg, tiles_per_seg;
+  // pieces mode (bloom_part_pieces_kernel): level 2 read n_pieces_in pieces per segment (fill_in, in_buckets as there) with gx
+  // blocks per segment, tiles_per_seg = tile rows per PIECE; level 1 ran with g1 blocks (0: slots mode)
+  const uint32_t* fill_in;
+  uint32_t n_pieces_in, in_buckets, gx, g1;
   // level 1 (a thread per read, the tiles of bloom_fused_kernel)
   uint64_t n_reads;
   uint32_t len, k, m, n_tiles, steps, n_buckets;
@@ -236,13 +252,51 @@ static __global__ __launch_bounds__(THREADS) void bloom_back2_kernel(const Bloom
       w[j] = idx < s1 ? __builtin_nontemporal_load(a.where + idx) : BQ_NONE;
     }
     const uint64_t row = ((uint64_t)seg * a.tiles_per_seg + tile) * a.buckets_per_seg;
-    bq_stage_runs<THREADS / 64u>(a.tab + row, n_buckets, a.pay_in, (uint64_t)r0, a.cap, stage, cnt, gat, offfit, tid, lane, wave);
+    bq_stage_runs<THREADS / 64u>(a.tab + row, n_buckets, a.pay_in, (uint64_t)r0, 1ull, a.cap, stage, cnt, gat, offfit, tid, lane, wave);
 #pragma unroll
     for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
       const uint64_t idx = t0 + (uint64_t)j * THREADS + tid;
       if (w[j] != BQ_NONE) a.pay_out[idx] = (uint8_t)bq_pick(w[j], stage, offfit, a.tovf + row, a.ovf_pay);
     }
     __syncthreads(); // (stage / offfit are the next tile's)
+  }
+}
+
+// back, level 2, pieces mode: the tiles of bloom_part_pieces_kernel (piece p of segment s was sorted by block p % gx of the segment)
+template <uint32_t THREADS>
+static __global__ __launch_bounds__(THREADS) void bloom_back2_pieces_kernel(const BloomBackArgs a)
+{
+  constexpr uint32_t TILE = THREADS * BB_PART_ITEMS;
+  __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[TILE];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (bloom_round_failed(a.status, a.ovf_cap)) return;
+  const uint32_t seg = blockIdx.y;
+  const uint32_t r0 = seg * a.buckets_per_seg;
+  const uint32_t r1 = r0 + a.buckets_per_seg < a.n_regions ? r0 + a.buckets_per_seg : a.n_regions;
+  const uint32_t n_buckets = r1 - r0;
+  for (uint32_t p = blockIdx.x; p < a.n_pieces_in; p += gridDim.x) {
+    const uint64_t f = a.fill_in[(size_t)p * a.in_buckets + seg];
+    const uint32_t n_here = (uint32_t)(f < a.cap_in ? f : a.cap_in);
+    const uint64_t base = ((uint64_t)seg * a.n_pieces_in + p) * a.cap_in;
+    const uint64_t piece0 = (uint64_t)r0 * a.gx + p % a.gx;
+    for (uint32_t kk = 0; kk * TILE < n_here; ++kk) {
+      const uint32_t t0 = kk * TILE;
+      uint32_t w[BB_PART_ITEMS];
+#pragma unroll
+      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+        const uint32_t idx = t0 + j * THREADS + tid;
+        w[j] = idx < n_here ? __builtin_nontemporal_load(a.where + base + idx) : BQ_NONE;
+      }
+      const uint64_t row = (((uint64_t)seg * a.n_pieces_in + p) * a.tiles_per_seg + kk) * a.buckets_per_seg;
+      bq_stage_runs<THREADS / 64u>(a.tab + row, n_buckets, a.pay_in, piece0, (uint64_t)a.gx, a.cap, stage, cnt, gat, offfit, tid, lane, wave);
+#pragma unroll
+      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+        const uint32_t idx = t0 + j * THREADS + tid;
+        if (w[j] != BQ_NONE) a.pay_out[base + idx] = (uint8_t)bq_pick(w[j], stage, offfit, a.tovf + row, a.ovf_pay);
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -279,7 +333,8 @@ static __global__ __launch_bounds__(THREADS) void bloom_back1_kernel(const Bloom
 #pragma unroll
         for (uint32_t i = 0; i < 16; ++i)
           w[i] = (i >= lo && i < hi) ? __builtin_nontemporal_load(a.where + (ts * 16u + i) * THREADS + tid) : BQ_NONE;
-        bq_stage_runs<THREADS / 64u>(a.tab + ts * a.n_buckets, a.n_buckets, a.pay_in, 0ull, a.cap, stage, cnt, gat, offfit, tid, lane, wave);
+        bq_stage_runs<THREADS / 64u>(a.tab + ts * a.n_buckets, a.n_buckets, a.pay_in, a.g1 ? (uint64_t)(t % a.g1) : 0ull, a.g1 ? (uint64_t)a.g1 : 1ull,
+                                     a.cap, stage, cnt, gat, offfit, tid, lane, wave);
 #pragma unroll
         for (uint32_t i = 0; i < 16; ++i)
           if (w[i] != BQ_NONE) {

@@ -493,6 +493,119 @@ int bloom_slots_round(nthip_ctx* c, const BloomFusedSrc* fused, const uint64_t* 
   return NTHIP_OK;
 }
 
+// ---- pieces mode (bloom_binned_kernels.hpp): a two-level round of device-resident fixed-length reads, the lists as
+// block-private pieces written in whole lines -- no cursors, no atomics.  *outcome as bloom_slots_round, and 4: not a shape /
+// table of this mode (nothing done)
+int bloom_pieces_round(nthip_ctx* c, const BloomFusedSrc& src, uint32_t* d_table, uint64_t n_slots, bool counters, int* outcome, uint64_t* lost)
+{
+  const uint32_t region_shift = counters ? CS_REGION_SHIFT : BB_REGION_SHIFT, bin_shift = region_shift + 7u;
+  const uint32_t n_regions = (uint32_t)((n_slots + (1ull << region_shift) - 1) >> region_shift);
+  const uint32_t n_bins = (n_regions + BB_REGIONS_PER_BIN - 1) / BB_REGIONS_PER_BIN;
+  *outcome = 4;
+  if (n_bins < 2 || c->tune.bloom_pieces == 2) return NTHIP_OK;
+  const size_t lds1 = bloom_fused_lds(src, 1024u, 1024u * 16u + BB_PIECES_LDS_DWORDS);
+  if (lds1 > lds_cap_of(c) - 4096) return NTHIP_OK;
+  const uint64_t magic = bloom_magic_of(n_slots);
+  const uint64_t table_dwords = counters ? (n_slots + 3) / 4 : (n_slots + 31) / 32;
+  const uint32_t nwin = src.len - src.k + 1u;
+  const uint64_t n = src.n_reads * (uint64_t)nwin * src.m;
+  constexpr uint32_t L2_TILE = BB_L2_THREADS * BB_PART_ITEMS;
+  const size_t lds2 = ((size_t)L2_TILE + (size_t)BB_REGIONS_PER_BIN * 32u) * sizeof(uint32_t);
+  int l2_per_cu = 1;
+  NTCHK(blocks_per_cu(c, bloom_part_pieces_kernel<BB_L2_THREADS, false>, (int)BB_L2_THREADS, lds2, &l2_per_cu));
+  const uint32_t l2_grid = 2u * (uint32_t)c->n_cu * (uint32_t)l2_per_cu;
+  const uint32_t gx = l2_grid / n_bins ? l2_grid / n_bins : 1u;
+  PiecesGeo g;
+  pieces_geo(c, src.n_reads, (uint64_t)nwin * src.m, n_slots, region_shift, gx, &g);
+  const uint64_t ovf_cap = c->tune.bloom_slot_tight == 2 ? 64 : (n / 64 < 65536 ? 65536 : n / 64);
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t o_fill1 = 256, o_fill2 = o_fill1 + al((size_t)g.g1 * n_bins * 4), o_l1 = o_fill2 + al((size_t)n_bins * gx * BB_REGIONS_PER_BIN * 4);
+  const size_t o_l2 = o_l1 + al((size_t)n_bins * g.g1 * g.cap1 * 4), o_ovf = o_l2 + al((size_t)n_regions * gx * g.cap2 * 4);
+  const size_t need = o_ovf + al((size_t)ovf_cap * 8);
+  if (c->bloom_tmp_bytes < need) {
+    if (c->bloom_tmp) HIPCHK(hipFree(c->bloom_tmp));
+    c->bloom_tmp = nullptr;
+    c->bloom_tmp_bytes = 0;
+    if (hipMalloc((void**)&c->bloom_tmp, need) != hipSuccess) {
+      (void)hipGetLastError();
+      c->bloom_tmp = nullptr;
+      *outcome = 3;
+      return NTHIP_OK;
+    }
+    c->bloom_tmp_bytes = need;
+  }
+  BloomStatus* const status = (BloomStatus*)c->bloom_tmp;
+  uint32_t* const fill1 = (uint32_t*)(c->bloom_tmp + o_fill1);
+  uint32_t* const fill2 = (uint32_t*)(c->bloom_tmp + o_fill2);
+  uint32_t* const list1 = (uint32_t*)(c->bloom_tmp + o_l1);
+  uint32_t* const list2 = (uint32_t*)(c->bloom_tmp + o_l2);
+  uint64_t* const ovf = (uint64_t*)(c->bloom_tmp + o_ovf);
+  HIPCHK(hipMemsetAsync(status, 0, 256, c->stream));
+  prof_begin(c, counters ? "count fused insert, pieces (part, part, apply)" : "bloom fused insert, pieces (part, part, apply)");
+  {
+    BloomFusedPiecesArgs fa;
+    bloom_fused_args(src, 1024u, n_slots, magic, &fa);
+    fa.lost = &status->lost;
+    fa.out = list1;
+    fa.cursor = nullptr;
+    fa.shift = bin_shift;
+    fa.mask = (1u << bin_shift) - 1u;
+    fa.n_buckets = n_bins;
+    fa.sl = {g.cap1, ovf, status, ovf_cap};
+    fa.q_where = nullptr;
+    fa.q_tab = nullptr;
+    fa.q_tovf = nullptr;
+    fa.q_steps = 0;
+    fa.p_fill = fill1;
+    NTCHK(set_max_lds(c, bloom_fused_kernel<BF_PART, 1024, false, true>, lds1));
+    hipLaunchKernelGGL((bloom_fused_kernel<BF_PART, 1024, false, true>), dim3(g.g1), dim3(1024), lds1, c->stream, fa);
+  }
+  {
+    BloomPartPiecesArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = list1;
+    a.out = list2;
+    a.fill_in = fill1;
+    a.fill_out = fill2;
+    a.cap_in = g.cap1;
+    a.n_pieces_in = g.g1;
+    a.in_buckets = n_bins;
+    a.n_regions = n_regions;
+    a.shift = region_shift;
+    a.mask = (1u << region_shift) - 1u;
+    a.buckets_per_seg = BB_REGIONS_PER_BIN;
+    a.sl = {g.cap2, ovf, status, ovf_cap};
+    hipLaunchKernelGGL((bloom_part_pieces_kernel<BB_L2_THREADS, false>), dim3(gx, n_bins), dim3(BB_L2_THREADS), lds2, c->stream, a);
+  }
+  const size_t apply_lds = (size_t)BB_REGION_DWORDS * sizeof(uint32_t);
+  const uint32_t grid = n_regions < (uint32_t)c->n_cu ? n_regions : (uint32_t)c->n_cu;
+  if (counters) {
+    NTCHK(set_max_lds(c, count_apply_kernel, apply_lds));
+    hipLaunchKernelGGL(count_apply_kernel, dim3(grid), dim3(BB_APPLY_THREADS), apply_lds, c->stream, (const uint32_t*)list2, (const uint32_t*)nullptr,
+                       n_regions, d_table, table_dwords, g.cap2, (const uint32_t*)fill2, (const BloomStatus*)status, ovf_cap, gx,
+                       (uint32_t)BB_REGIONS_PER_BIN);
+    hipLaunchKernelGGL(bloom_overflow_apply_kernel<true>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)ovf, (const BloomStatus*)status,
+                       ovf_cap, d_table);
+  } else {
+    NTCHK(set_max_lds(c, bloom_apply_kernel, apply_lds));
+    hipLaunchKernelGGL(bloom_apply_kernel, dim3(grid), dim3(BB_APPLY_THREADS), apply_lds, c->stream, (const uint32_t*)list2, (const uint32_t*)nullptr,
+                       n_regions, d_table, table_dwords, g.cap2, (const uint32_t*)fill2, (const BloomStatus*)status, ovf_cap, gx,
+                       (uint32_t)BB_REGIONS_PER_BIN);
+    hipLaunchKernelGGL(bloom_overflow_apply_kernel<false>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)ovf, (const BloomStatus*)status,
+                       ovf_cap, d_table);
+  }
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_small + 64, status, sizeof(BloomStatus), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  BloomStatus st;
+  memcpy(&st, c->h_small + 64, sizeof st);
+  *outcome = st.ovf_n > ovf_cap ? 2 : 0;
+  if (*outcome == 2) c->bloom_slots_backoff = BB_SLOTS_BACKOFF;
+  *lost = st.lost;
+  return NTHIP_OK;
+}
+
 // Fixed-length reads on the device through slots-mode rounds: *r0 is advanced past every round that went through, *sum
 // by its k-mers; stops at the first round that did not (skewed values, no memory) -- the caller takes the reads from *r0 on
 // through the exact lists.
@@ -509,7 +622,8 @@ int fused_slots_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t
     const BloomFusedSrc src = {(const uint8_t*)rd->seqs + *r0 * stride, nr, len, stride, k, m};
     int outcome = 0;
     uint64_t lost = 0;
-    NTCHK(bloom_slots_round(c, &src, nullptr, nr * per_read, d_table, n_slots, counters, &outcome, &lost));
+    NTCHK(bloom_pieces_round(c, src, d_table, n_slots, counters, &outcome, &lost)); // (round 5: two-level tables)
+    if (outcome == 4) NTCHK(bloom_slots_round(c, &src, nullptr, nr * per_read, d_table, n_slots, counters, &outcome, &lost));
     if (outcome) return NTHIP_OK;
     *sum += nr * (uint64_t)(len - k + 1) - lost;
     *r0 += nr;

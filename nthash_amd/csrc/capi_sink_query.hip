@@ -42,27 +42,61 @@ struct QueryScratch {
   uint2 *tab1 = nullptr, *tab2 = nullptr;
   uint8_t *pay1 = nullptr, *pay2 = nullptr, *ovf_pay = nullptr;
   uint64_t cap1 = 0, cap2 = 0, ovf_cap = 0;
-  uint32_t tiles_per_seg = 0;
+  uint32_t tiles_per_seg = 0; // slots mode: tile rows per bin; pieces mode: per piece
   size_t head_bytes = 0;
+  // pieces mode (two-level tables; bloom_binned_kernels.hpp): cur1 / cur2 are the fill arrays of the pieces
+  bool pieces = false;
+  PiecesGeo pg;
 };
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // the scratch of a round of nr reads (n values) carved out of the context's list buffer; *need (always) = its size;
 // returns false when the buffer is smaller (nothing carved)
-bool query_scratch(nthip_ctx* c, const QueryGeo& g, uint64_t nr, uint64_t n, uint64_t n_slots, uint32_t steps, uint32_t m, QueryScratch* q,
-                   size_t* need)
+// pieces mode? (a two-level table, the level-1 tile + its waiting lines fit the LDS); *gx = blocks per bin of level 2
+bool query_pieces_ok(nthip_ctx* c, const QueryGeo& g, const BloomFusedSrc& shape, uint32_t* gx)
 {
-  q->cap1 = g.one ? 0 : slot_cap(c, n, 1ull << g.bin_shift, n_slots);
-  q->cap2 = slot_cap(c, n, 1ull << g.region_shift, n_slots);
+  if (g.one || c->tune.bloom_pieces == 2) return false;
+  if (bloom_fused_lds(shape, 1024u, 1024u * 16u + BB_PIECES_LDS_DWORDS) > lds_cap_of(c) - 4096) return false;
+  const size_t lds2 = ((size_t)BQ_L2_TILE + (size_t)BB_REGIONS_PER_BIN * 32u) * sizeof(uint32_t);
+  int per_cu = 1;
+  if (blocks_per_cu(c, bloom_part_pieces_kernel<BQ_L2_THREADS, true>, (int)BQ_L2_THREADS, lds2, &per_cu) != NTHIP_OK) return false;
+  const uint32_t grid = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
+  *gx = grid / g.n_bins ? grid / g.n_bins : 1u;
+  return true;
+}
+
+bool query_scratch(nthip_ctx* c, const QueryGeo& g, uint64_t nr, uint64_t n, uint64_t n_slots, uint32_t steps, uint32_t m, QueryScratch* q,
+                   size_t* need, bool pieces, uint32_t gx, uint64_t values_per_read)
+{
+  q->pieces = pieces;
+  size_t slots1, slots2, fills1, fills2;
+  uint64_t rows2;
+  if (pieces) {
+    pieces_geo(c, nr, values_per_read, n_slots, g.region_shift, gx, &q->pg);
+    q->cap1 = q->pg.cap1;
+    q->cap2 = q->pg.cap2;
+    q->tiles_per_seg = (uint32_t)((q->cap1 + BQ_L2_TILE - 1) / BQ_L2_TILE);
+    slots1 = (size_t)g.n_bins * q->pg.g1 * q->cap1;
+    slots2 = (size_t)g.n_regions * gx * q->cap2;
+    fills1 = (size_t)q->pg.g1 * g.n_bins;
+    fills2 = (size_t)g.n_bins * gx * BB_REGIONS_PER_BIN;
+    rows2 = (uint64_t)g.n_bins * q->pg.g1 * q->tiles_per_seg;
+  } else {
+    q->cap1 = g.one ? 0 : slot_cap(c, n, 1ull << g.bin_shift, n_slots);
+    q->cap2 = slot_cap(c, n, 1ull << g.region_shift, n_slots);
+    q->tiles_per_seg = (uint32_t)((q->cap1 + BQ_L2_TILE - 1) / BQ_L2_TILE);
+    slots1 = (size_t)g.n_bins * q->cap1;
+    slots2 = (size_t)g.n_regions * q->cap2;
+    fills1 = (size_t)g.n_bins * BB_CURSOR_STRIDE;
+    fills2 = (size_t)g.n_regions * BB_CURSOR_STRIDE;
+    rows2 = g.one ? 0 : (uint64_t)g.n_bins * q->tiles_per_seg;
+  }
   q->ovf_cap = n / 64 < 65536 ? 65536 : n / 64;
   if (c->tune.bloom_slot_tight == 2) q->ovf_cap = 64;
-  q->tiles_per_seg = (uint32_t)((q->cap1 + BQ_L2_TILE - 1) / BQ_L2_TILE);
   const uint64_t n_tiles1 = (nr + 1023) / 1024;
   const uint64_t rows1 = n_tiles1 * steps * m;
   const uint32_t buckets1 = g.one ? g.n_regions : g.n_bins;
-  const uint64_t rows2 = g.one ? 0 : (uint64_t)g.n_bins * q->tiles_per_seg;
-  const size_t slots1 = (size_t)g.n_bins * q->cap1, slots2 = (size_t)g.n_regions * q->cap2;
-  const size_t head = 256 + (size_t)(g.n_bins + g.n_regions) * BB_CURSOR_STRIDE * sizeof(uint32_t);
+  const size_t head = 256 + (fills1 + fills2) * sizeof(uint32_t);
   size_t off = 0;
   auto take = [&](size_t bytes) {
     const size_t at = off;
@@ -80,8 +114,8 @@ bool query_scratch(nthip_ctx* c, const QueryGeo& g, uint64_t nr, uint64_t n, uin
   q->status = (BloomStatus*)(b + o_head);
   q->total_hits = (unsigned long long*)(b + o_head + 128);
   q->cur1 = (uint32_t*)(b + o_head + 256);
-  q->cur2 = q->cur1 + (size_t)g.n_bins * BB_CURSOR_STRIDE;
-  q->head_bytes = head;
+  q->cur2 = q->cur1 + fills1;
+  q->head_bytes = pieces ? 256 : head; // (the pieces' fill arrays are written whole by the kernels)
   q->list1 = (uint32_t*)(b + o_l1);
   q->list2 = (uint32_t*)(b + o_l2);
   q->ovf = (uint64_t*)(b + o_ovf);
@@ -108,7 +142,7 @@ int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const Bl
   HIPCHK(hipMemsetAsync(q.status, 0, q.head_bytes, c->stream));
   prof_begin(c, KIND == BQ_BLOOM ? "bloom binned query (part, part, lookup, back, back)" : "count binned query (part, part, lookup, back, back)");
   // ---- forward, level 1: from the reads (bloom_fused_kernels.hpp pass PART, QUERY) ----
-  BloomFusedQueryArgs fa;
+  BloomFusedPiecesArgs fa;
   bloom_fused_args(src, 1024u, n_slots, magic, &fa);
   fa.lost = &q.status->lost;
   fa.out = g.one ? q.list2 : q.list1;
@@ -121,15 +155,43 @@ int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const Bl
   fa.q_tab = q.tab1;
   fa.q_tovf = q.tovf1;
   fa.q_steps = steps;
-  {
+  fa.p_fill = q.cur1;
+  const uint32_t gx = q.pg.gx;
+  if (q.pieces) {
+    const size_t lds = bloom_fused_lds(src, 1024u, 1024u * 16u + BB_PIECES_LDS_DWORDS);
+    NTCHK(set_max_lds(c, bloom_fused_kernel<BF_PART, 1024, true, true>, lds));
+    hipLaunchKernelGGL((bloom_fused_kernel<BF_PART, 1024, true, true>), dim3(q.pg.g1), dim3(1024), lds, c->stream, fa);
+  } else {
+    const BloomFusedQueryArgs& fq = fa;
     const size_t lds = bloom_fused_lds(src, 1024u, 1024u * 16u);
     NTCHK(set_max_lds(c, bloom_fused_kernel<BF_PART, 1024, true>, lds));
     hipLaunchKernelGGL((bloom_fused_kernel<BF_PART, 1024, true>), dim3((unsigned)std::min<uint64_t>(fa.n_tiles, (uint64_t)c->n_cu)), dim3(1024), lds,
-                       c->stream, fa);
+                       c->stream, fq);
   }
   // ---- forward, level 2: every bin to its regions ----
-  uint32_t per_bin = 1;
-  if (!g.one) {
+  if (q.pieces) {
+    BloomPartPiecesArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = q.list1;
+    a.out = q.list2;
+    a.fill_in = q.cur1;
+    a.fill_out = q.cur2;
+    a.cap_in = q.cap1;
+    a.n_pieces_in = q.pg.g1;
+    a.in_buckets = g.n_bins;
+    a.n_regions = g.n_regions;
+    a.shift = g.region_shift;
+    a.mask = (1u << g.region_shift) - 1u;
+    a.buckets_per_seg = BB_REGIONS_PER_BIN;
+    a.sl = {q.cap2, q.ovf, q.status, q.ovf_cap};
+    a.q_where = q.where2;
+    a.q_tab = q.tab2;
+    a.q_tovf = q.tovf2;
+    a.q_tiles_per_piece = q.tiles_per_seg;
+    const size_t lds = ((size_t)BQ_L2_TILE + (size_t)BB_REGIONS_PER_BIN * 32u) * sizeof(uint32_t);
+    NTCHK(set_max_lds(c, bloom_part_pieces_kernel<BQ_L2_THREADS, true>, lds));
+    hipLaunchKernelGGL((bloom_part_pieces_kernel<BQ_L2_THREADS, true>), dim3(gx, g.n_bins), dim3(BQ_L2_THREADS), lds, c->stream, a);
+  } else if (!g.one) {
     BloomPartQueryArgs a;
     memset((void*)&a, 0, sizeof a);
     a.n_bits = n_slots;
@@ -152,7 +214,7 @@ int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const Bl
     int l2_per_cu = 1;
     NTCHK(blocks_per_cu(c, bloom_part_kernel<false, BQ_L2_THREADS, true>, (int)BQ_L2_THREADS, lds, &l2_per_cu));
     const uint32_t l2_grid = 2u * (uint32_t)c->n_cu * (uint32_t)l2_per_cu;
-    per_bin = l2_grid / g.n_bins ? l2_grid / g.n_bins : 1u;
+    const uint32_t per_bin = l2_grid / g.n_bins ? l2_grid / g.n_bins : 1u;
     hipLaunchKernelGGL((bloom_part_kernel<false, BQ_L2_THREADS, true>), dim3(per_bin, g.n_bins), dim3(BQ_L2_THREADS), lds, c->stream, a);
   }
   // ---- lookup: region by region, and the overflow list ----
@@ -161,7 +223,8 @@ int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const Bl
     NTCHK(set_max_lds(c, bloom_lookup_kernel<KIND>, lds));
     const uint32_t grid = g.n_regions < (uint32_t)c->n_cu ? g.n_regions : (uint32_t)c->n_cu;
     hipLaunchKernelGGL(bloom_lookup_kernel<KIND>, dim3(grid), dim3(BQ_LOOKUP_THREADS), lds, c->stream, (const uint32_t*)q.list2,
-                       (const uint32_t*)q.cur2, q.cap2, g.n_regions, d_table, table_dwords, q.pay2);
+                       (const uint32_t*)q.cur2, q.cap2, g.n_regions, d_table, table_dwords, q.pay2, q.pieces ? gx : 0u,
+                       (uint32_t)BB_REGIONS_PER_BIN);
     hipLaunchKernelGGL(bloom_ovf_lookup_kernel<KIND>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)q.ovf, (const BloomStatus*)q.status,
                        q.ovf_cap, d_table, q.ovf_pay);
   }
@@ -183,11 +246,23 @@ int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const Bl
     b.n_regions = g.n_regions;
     b.buckets_per_seg = BB_REGIONS_PER_BIN;
     b.tiles_per_seg = q.tiles_per_seg;
-    int per_cu = 1;
-    NTCHK(blocks_per_cu(c, bloom_back2_kernel<BQ_L2_THREADS>, (int)BQ_L2_THREADS, 0, &per_cu));
-    const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
-    const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
-    hipLaunchKernelGGL(bloom_back2_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
+    if (q.pieces) {
+      b.fill_in = q.cur1;
+      b.n_pieces_in = q.pg.g1;
+      b.in_buckets = g.n_bins;
+      b.gx = gx;
+      int per_cu = 1;
+      NTCHK(blocks_per_cu(c, bloom_back2_pieces_kernel<BQ_L2_THREADS>, (int)BQ_L2_THREADS, 0, &per_cu));
+      const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
+      const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
+      hipLaunchKernelGGL(bloom_back2_pieces_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
+    } else {
+      int per_cu = 1;
+      NTCHK(blocks_per_cu(c, bloom_back2_kernel<BQ_L2_THREADS>, (int)BQ_L2_THREADS, 0, &per_cu));
+      const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
+      const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
+      hipLaunchKernelGGL(bloom_back2_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
+    }
   }
   b.where = q.where1;
   b.tab = q.tab1;
@@ -201,6 +276,7 @@ int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const Bl
   b.n_tiles = fa.n_tiles;
   b.steps = steps;
   b.n_buckets = buckets1;
+  b.g1 = q.pieces ? q.pg.g1 : 0u;
   b.hits = d_hits;
   b.total_hits = q.total_hits;
   b.estimates = d_est;
@@ -277,9 +353,11 @@ int ntamd::host::bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_
   if (reads_per_round == 0) return NTHIP_OK;
   if (reads_per_round > rd->n_reads - *first) reads_per_round = rd->n_reads - *first;
   QueryScratch q;
+  uint32_t gx = 1;
+  const bool pieces = query_pieces_ok(c, g, shape, &gx);
   for (;;) { // the scratch of the largest round
     size_t need = 0;
-    if (query_scratch(c, g, reads_per_round, reads_per_round * per_read, n_slots, steps, m, &q, &need)) break;
+    if (query_scratch(c, g, reads_per_round, reads_per_round * per_read, n_slots, steps, m, &q, &need, pieces, gx, per_read)) break;
     if (c->bloom_tmp) HIPCHK(hipFree(c->bloom_tmp));
     c->bloom_tmp = nullptr;
     c->bloom_tmp_bytes = 0;
@@ -295,7 +373,7 @@ int ntamd::host::bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_
   while (*first < rd->n_reads) {
     const uint64_t nr = std::min<uint64_t>(rd->n_reads - *first, reads_per_round);
     size_t need = 0;
-    if (!query_scratch(c, g, nr, nr * per_read, n_slots, steps, m, &q, &need)) return NTHIP_OK; // (cannot happen: a smaller round needs less)
+    if (!query_scratch(c, g, nr, nr * per_read, n_slots, steps, m, &q, &need, pieces, gx, per_read)) return NTHIP_OK; // (cannot happen: a smaller round needs less)
     const BloomFusedSrc src = {(const uint8_t*)rd->seqs + *first * stride, nr, len, stride, k, m};
     bool failed = false;
     uint64_t lost = 0, hits = 0;
