@@ -162,31 +162,32 @@ __device__ __forceinline__ void bq_stage_runs(const uint2* __restrict__ tab, uin
     }
   }
   __syncthreads();
-  constexpr uint32_t G = 8; // buckets a wave has in flight (their places are wave-uniform: scalar registers)
+  // sixteen lanes per bucket, four buckets per instruction (as bloom_copy_out_lines: what a bucket needs is vector arithmetic
+  // done once per four); the answers come as aligned dwords -- 64 entries of a bucket per load -- and go to LDS byte by byte
+  const uint32_t g = lane >> 4, l = lane & 15u;
   const uint32_t n_mine = n_buckets > wave ? (n_buckets - wave + NW - 1u) / NW : 0u;
-  for (uint32_t i0 = 0; i0 < n_mine; i0 += G) {
-    uint32_t o[G], fit[G];
-    uint64_t at[G];
-    uint8_t v0[G], v1[G];
+  for (uint32_t i0 = 0; i0 < n_mine; i0 += 4u) {
+    const bool mine = i0 + g < n_mine;
+    const uint32_t b = wave + (mine ? i0 + g : i0) * NW;
+    const uint32_t of = offfit[b], at = gat[b];
+    const uint32_t o = of & 0xFFFFu, fit = mine ? of >> 16 : 0u;
+    const uint32_t sh = at & 3u, span = fit + sh; // the run as dwords from the aligned byte before it
+    const uint32_t* const src = (const uint32_t*)(pay + (piece0 + (uint64_t)b * piece_step) * cap + (at - sh));
+    uint8_t* const st = stage + o - sh; // byte e of the span goes to st[e] (sh <= e < span)
+    auto put = [&](uint32_t k, uint32_t w) {
 #pragma unroll
-    for (uint32_t u = 0; u < G; ++u) {
-      const uint32_t b = wave + (i0 + u < n_mine ? i0 + u : i0) * NW;
-      const uint32_t of = (uint32_t)__builtin_amdgcn_readfirstlane((int)offfit[b]);
-      const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)gat[b]);
-      o[u] = of & 0xFFFFu;
-      fit[u] = i0 + u < n_mine ? of >> 16 : 0u;
-      at[u] = (piece0 + (uint64_t)b * piece_step) * cap + g;
-      v0[u] = lane < fit[u] ? pay[at[u] + lane] : (uint8_t)0;
-      v1[u] = lane + 64u < fit[u] ? pay[at[u] + 64u + lane] : (uint8_t)0;
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < G; ++u) {
-      if (lane < fit[u]) stage[o[u] + lane] = v0[u];
-      if (lane + 64u < fit[u]) stage[o[u] + 64u + lane] = v1[u];
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < G; ++u) // (rare: more than 128 of the tile's values in one bucket)
-      for (uint32_t j = lane + 128u; j < fit[u]; j += 64u) stage[o[u] + j] = pay[at[u] + j];
+      for (uint32_t t = 0; t < 4u; ++t) {
+        const uint32_t e = 4u * k + t;
+        if (e >= sh && e < span) st[e] = (uint8_t)(w >> (8u * t));
+      }
+    };
+    const uint32_t k0 = l, k1 = l + 16u;
+    const uint32_t w0 = 4u * k0 < span ? __builtin_nontemporal_load(src + k0) : 0u;
+    const uint32_t w1 = 4u * k1 < span ? __builtin_nontemporal_load(src + k1) : 0u;
+    if (4u * k0 < span) put(k0, w0);
+    if (4u * k1 < span) put(k1, w1);
+    for (uint32_t k = l + 32u; __ballot(4u * k < span) != 0ull; k += 16u) // (rare: more than ~124 of the tile's values in one bucket)
+      if (4u * k < span) put(k, src[k]);
   }
   __syncthreads();
 }

@@ -14,7 +14,7 @@ using namespace ntamd::host;
 
 namespace {
 
-constexpr uint64_t BQ_ROUND_MAX = 1ull << 31; // values per round (every list position and overflow index fits 32 bits with room to spare)
+constexpr uint64_t BQ_ROUND_MAX = 0xC0000000ull; // values per round (list positions are 64-bit; piece counts, overflow indices and tile rows fit 32 bits)
 constexpr uint32_t BQ_L2_THREADS = BB_L2_THREADS, BQ_L2_TILE = BQ_L2_THREADS * BB_PART_ITEMS;
 
 struct QueryGeo {
