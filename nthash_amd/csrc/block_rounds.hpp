@@ -16,9 +16,13 @@
 // What it replaced, measured on the minimizer kernel: a ticket per tile -- one device-scope atomic on one address --
 // serialises at ~40 ns per tile (161 ms for 4 M tiles); a look-back per TILE with the waves waiting cost more than the
 // hashing (every poll is a round trip over the fabric, 3072 waves polling).
-// The look-back needs the blocks of a round to run together: launch one block per CU.  Should that fail (another spinning
-// kernel on the device), a leader that waits 50 ms sets *abort_flag, every later wait ends at once, the offsets are garbage
-// from there on (every store must stay inside the caller's arrays) and the host repeats the call on another path.
+// The look-back needs the blocks of a round to run together: the grid is at most one block per CU and goes out as a
+// COOPERATIVE launch (hipLaunchCooperativeKernel: every block resident, or a launch error the host answers with another
+// path -- round 5; a plain launch only promised that while nothing else held the device).  What is left is time: blocks that
+// get their CUs late because another context's kernel sits there.  A leader that waits 50 ms sets *abort_flag, every later
+// wait ends at once, the offsets are garbage from there on (every store must stay inside the caller's arrays) and the host
+// repeats the call on another path (tests/test_gpu_minimizer_rounds.py forces both: NTHIP_TUNE_MZ_GRID oversizes the grid on
+// a plain launch, NTHIP_TUNE_MZ_TIMEOUT_US shortens the wait).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -61,10 +65,13 @@ struct BlockRounds {
   uint64_t* grand_total;       // global: what everything emits (written by the leader of the last block-round)
   uint64_t* closing_offset;    // global or NULL: the same number once more (the closing entry of a CSR offsets array)
   uint32_t lane, wave, waves, n_rounds;
+  uint64_t timeout_ticks;      // 100 MHz ticks a leader waits for a predecessor before it gives the launch up (5 000 000: 50 ms)
 
   __device__ __forceinline__ void init(uint32_t* ctrl, uint32_t lane_, uint32_t wave_, uint32_t waves_, uint32_t n_rounds_,
-                                       unsigned long long* status_, uint32_t* abort_, uint64_t* total_, uint64_t* closing_)
+                                       unsigned long long* status_, uint32_t* abort_, uint64_t* total_, uint64_t* closing_,
+                                       uint32_t timeout_us = 0)
   {
+    timeout_ticks = timeout_us ? (uint64_t)timeout_us * 100ull : 5000000ull;
     arrive = ctrl;
     tag = ctrl + 2;
     asum_tag = ctrl + 4;
@@ -145,7 +152,7 @@ struct BlockRounds {
           if ((spins & 63u) == 63u) { // (rare: a block is late, or is not running at all)
             const uint64_t now = __builtin_amdgcn_s_memrealtime(); // 100 MHz
             if (t_wait == 0) t_wait = now;
-            const bool late = now - t_wait > 5000000ull; // 50 ms
+            const bool late = now - t_wait > timeout_ticks;
             if (late && lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (late || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
               aborted = true; // (the offsets are garbage from here on)

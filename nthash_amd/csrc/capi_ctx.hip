@@ -276,6 +276,8 @@ void load_tuning(nthip_tune& t)
   t.bloom_fused = num("NTHIP_TUNE_BLOOM_FUSED", 1, 2);
   t.mz_fused = num("NTHIP_TUNE_MZ_FUSED", 1, 2);
   t.mz_c = num("NTHIP_TUNE_MZ_C", 2, 16);
+  t.mz_grid = num("NTHIP_TUNE_MZ_GRID", 1, 1 << 20);
+  t.mz_timeout_us = num("NTHIP_TUNE_MZ_TIMEOUT_US", 1, 100000000);
   t.mz_waves = num("NTHIP_TUNE_MZ_WAVES", 1, 16);
   t.reads_run_len = num("NTHIP_TUNE_READS_RUN_LEN", 2, 16);
   t.reads_per_tile = num("NTHIP_TUNE_READS_PER_TILE", 1, 64);

@@ -89,6 +89,8 @@ struct nthip_tune {
   bool no_seed_wtile = false; // NTHIP_TUNE_NO_SEED_WTILE=1: the block-tile dense seed kernel instead of the wave-tile one
   bool mz_table = false;      // NTHIP_TUNE_MZ_TABLE=1: minimizers of clean short reads through the LDS tables too (A/B)
   uint32_t mz_fused = 0;      // NTHIP_TUNE_MZ_FUSED=2: never the one-pass minimizer kernel (minimizer_fused_kernel.hpp; A/B, tests)
+  uint32_t mz_grid = 0;       // NTHIP_TUNE_MZ_GRID=<blocks>: the one-pass minimizer kernels on a PLAIN launch of that many blocks (tests: more than the device holds)
+  uint32_t mz_timeout_us = 0; // NTHIP_TUNE_MZ_TIMEOUT_US: how long a look-back waits for a predecessor before the launch is given up (tests; 0: 50 ms)
   uint32_t mz_c = 0, mz_waves = 0; // NTHIP_TUNE_MZ_C / _MZ_WAVES: its run length and waves per block (0: planned)
   bool no_fh = false;         // NTHIP_TUNE_NO_FH=1: full position tables for k = 49 ... 64 (A/B)
   bool no_any_k_runs = false; // NTHIP_TUNE_NO_ANY_K_RUNS=1: only the k = 31 / run length 15, 30 instantiations of kmer_runs_kernel
@@ -452,6 +454,28 @@ int set_max_lds(const nthip_ctx* c, K kernel, size_t bytes)
 {
   if (bytes <= 24 * 1024) return NTHIP_OK;
   return raise_max_dynamic_lds(c->device, reinterpret_cast<const void*>(kernel), bytes);
+}
+
+// A grid whose blocks wait for each other (block_rounds.hpp): every block must be resident.  hipLaunchCooperativeKernel
+// promises that or refuses the launch -- *launched = false, no error: the caller takes a path that does not need it.
+template <typename K, typename A>
+int launch_resident(nthip_ctx* c, K kernel, unsigned grid, unsigned threads, size_t dyn_lds, A& args, bool cooperative, bool* launched)
+{
+  *launched = false;
+  if (!cooperative) { // (tests: a plain launch, the grid whatever the knob says)
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), dyn_lds, c->stream, args);
+    HIPCHK(hipGetLastError());
+    *launched = true;
+    return NTHIP_OK;
+  }
+  void* argv[1] = {(void*)&args};
+  const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), dim3(grid), dim3(threads), argv, (unsigned)dyn_lds, c->stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError(); // (too large for the device as it is right now, or no cooperative launches at all: not an error of the call)
+    return NTHIP_OK;
+  }
+  *launched = true;
+  return NTHIP_OK;
 }
 
 // blocks per CU for a persistent-style grid; the LDS opt-in and the occupancy

@@ -87,7 +87,7 @@ int minimizers_fused(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t l
   const uint64_t n_tiles = (n + p.R - 1) / p.R;
   if (n_tiles >= 0x7FFFFFFFull) return NTHIP_OK;
   // one block per CU, every block resident: the look-back needs the blocks of a round to run together (block_rounds.hpp)
-  uint64_t grid = (uint64_t)c->n_cu;
+  uint64_t grid = c->tune.mz_grid ? (uint64_t)c->tune.mz_grid : (uint64_t)c->n_cu;
   {
     const uint64_t need = (n_tiles + p.waves - 1) / p.waves;
     if (grid > need) grid = need;
@@ -103,6 +103,7 @@ int minimizers_fused(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t l
   NTCHK(get_kmer_tab(c, k, &a.init_tab));
   a.total = c->d_scratch;
   a.abort = (uint32_t*)(c->d_scratch + 1);
+  a.timeout_us = c->tune.mz_timeout_us;
   a.dirty = a.abort + 1;
   a.status = (unsigned long long*)(c->d_scratch + 2);
   a.out_hashes = d_min_hashes;
@@ -135,14 +136,14 @@ int minimizers_fused(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t l
   memset(&consts, 0, sizeof consts);
   fill_kmer_consts(k, 1, consts);
   memcpy(a.tab, consts.tab, sizeof a.tab);
+  bool launched = false;
   auto launch = [&](auto kernel) -> int {
     int per_cu = 1;
     NTCHK(blocks_per_cu(c, kernel, (int)p.waves * 64, p.lds, &per_cu));
     (void)per_cu;
     prof_begin(c, "minimizer_fused_kernel");
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(p.waves * 64), p.lds, c->stream, a);
+    NTCHK(launch_resident(c, kernel, (unsigned)grid, p.waves * 64, p.lds, a, c->tune.mz_grid == 0, &launched));
     prof_end(c);
-    HIPCHK(hipGetLastError());
     return NTHIP_OK;
   };
   const bool mid = p.m0 != 0;
@@ -156,6 +157,7 @@ int minimizers_fused(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t l
     case 8: NTCHK(launch(minimizer_fused_kernel<4, false>)); break;
     default: NTCHK(launch(minimizer_fused_kernel<4, true>)); break;
   }
+  if (!launched) return NTHIP_OK; // (the device does not hold the grid right now: the caller goes on with the round-3 kernels)
   HIPCHK(hipMemcpyAsync(c->h_small + 32, c->d_scratch, 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   uint64_t total = 0;
@@ -173,7 +175,7 @@ int minimizers_fused(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t l
 
 // ---- the record form (minimizer_w_kernel.hpp): run length = w (4 ... 16), k <= 32 ----
 template <int C>
-int launch_minimizer_w(nthip_ctx* c, const MinimizerWArgs& a0, size_t lds_fixed, uint64_t n_tiles)
+int launch_minimizer_w(nthip_ctx* c, const MinimizerWArgs& a0, size_t lds_fixed, uint64_t n_tiles, bool* launched)
 {
   MinimizerWArgs a = a0;
   auto kernel = minimizer_w_kernel<C>;
@@ -181,7 +183,7 @@ int launch_minimizer_w(nthip_ctx* c, const MinimizerWArgs& a0, size_t lds_fixed,
   int per_cu = 1;
   NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, lds, &per_cu));
   (void)per_cu;
-  uint64_t grid = (uint64_t)c->n_cu; // one block per CU, every block resident: the look-back needs the blocks of a round to run together
+  uint64_t grid = c->tune.mz_grid ? (uint64_t)c->tune.mz_grid : (uint64_t)c->n_cu; // one block per CU, every block resident: the look-back needs the blocks of a round to run together
   const uint64_t need = (n_tiles + a.waves - 1) / a.waves;
   if (grid > need) grid = need;
   a.n_rounds = (uint32_t)((n_tiles + grid * a.waves - 1) / (grid * a.waves));
@@ -191,11 +193,11 @@ int launch_minimizer_w(nthip_ctx* c, const MinimizerWArgs& a0, size_t lds_fixed,
   HIPCHK(hipMemsetAsync(c->d_scratch, 0, (n_status + 2) * sizeof(uint64_t), c->stream));
   a.total = c->d_scratch;
   a.abort = (uint32_t*)(c->d_scratch + 1);
+  a.timeout_us = c->tune.mz_timeout_us;
   a.status = (unsigned long long*)(c->d_scratch + 2);
   prof_begin(c, "minimizer_w_kernel");
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(a.waves * 64), lds, c->stream, a);
+  NTCHK(launch_resident(c, kernel, (unsigned)grid, a.waves * 64, lds, a, c->tune.mz_grid == 0, launched));
   prof_end(c);
-  HIPCHK(hipGetLastError());
   return NTHIP_OK;
 }
 
@@ -254,13 +256,15 @@ int minimizers_w(nthip_ctx* c, const uint8_t* d_seqs, uint64_t n, uint32_t len, 
   memset(&consts, 0, sizeof consts);
   fill_kmer_consts(k, 1, consts);
   memcpy(a.tab, consts.tab, sizeof a.tab);
+  bool launched = false;
   switch (C) {
-#define MZW_CASE(CC) case CC: NTCHK(launch_minimizer_w<CC>(c, a, fixed, n_tiles)); break;
+#define MZW_CASE(CC) case CC: NTCHK(launch_minimizer_w<CC>(c, a, fixed, n_tiles, &launched)); break;
     MZW_CASE(4) MZW_CASE(5) MZW_CASE(6) MZW_CASE(7) MZW_CASE(8) MZW_CASE(9) MZW_CASE(10) MZW_CASE(11) MZW_CASE(12)
     MZW_CASE(13) MZW_CASE(14) MZW_CASE(15) MZW_CASE(16)
 #undef MZW_CASE
     default: return NTHIP_OK;
   }
+  if (!launched) return NTHIP_OK; // (the device does not hold the grid right now: the caller goes on with the round-3 kernels)
   HIPCHK(hipMemcpyAsync(c->h_small + 32, c->d_scratch, 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   uint64_t total = 0;

@@ -46,6 +46,7 @@ struct MinimizerFusedArgs {
   uint32_t* dirty;              // set when a non-base is seen
   unsigned long long* status;   // [(n_rounds + 1) * blocks] look-back words of the block-rounds, zeroed by the host
   uint32_t* abort;              // zeroed by the host; set by a wave that waited too long for a predecessor
+  uint32_t timeout_us;          // 0: the 50 ms of block_rounds.hpp (tests shorten it)
   uint64_t* out_hashes;
   uint32_t* out_pos;            // may be NULL
   uint64_t* out_offsets;        // [n_reads + 1]
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(MZF_MAX_THREADS) void minimizer_fused_kernel(const 
   if (tid < BR_CTRL_DWORDS) ctrl[tid] = 0;
   __syncthreads(); // the only block-wide barrier
   BlockRounds rounds;
-  rounds.init(ctrl, lane, wave, a.waves, a.n_rounds, a.status, a.abort, a.total, a.out_offsets + a.n_reads);
+  rounds.init(ctrl, lane, wave, a.waves, a.n_rounds, a.status, a.abort, a.total, a.out_offsets + a.n_reads, a.timeout_us);
 
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");

@@ -49,6 +49,7 @@ struct MinimizerWArgs {
   const uint8_t* seqs;
   const uint4* init_tab;        // [src_tabs][256] {f.lo, f.hi, r.lo, r.hi}; the kernel pads to 8 tables with zeros
   uint32_t* abort;              // zeroed by the host; set by a leader that waited too long
+  uint32_t timeout_us;          // 0: the 50 ms of block_rounds.hpp (tests shorten it)
   unsigned long long* status;   // [(n_rounds + 1) * blocks] look-back words of the block-rounds, zeroed by the host
   uint64_t* out_hashes;
   uint32_t* out_pos;            // may be NULL
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
   uint4* ptab = itab + ntab * 256u;
   uint32_t* ctrl = (uint32_t*)(ptab + 16);
   BlockRounds rounds; // (block_rounds.hpp: where a tile's picks go, without a pass before and without a wave that waits)
-  rounds.init(ctrl, lane, wave, waves, a.n_rounds, a.status, a.abort, a.total, a.out_offsets + a.n_reads);
+  rounds.init(ctrl, lane, wave, waves, a.n_rounds, a.status, a.abort, a.total, a.out_offsets + a.n_reads, a.timeout_us);
   uint32_t* wave_base = ctrl + MZW_CTRL_DWORDS + wave * a.per_wave_dwords;
   uint64_t* stash_h = (uint64_t*)wave_base;                  // [stash_cap]
   uint16_t* stash_p = (uint16_t*)(stash_h + a.stash_cap);    // [stash_cap]
