@@ -243,6 +243,19 @@ int nthip_kmer_bloom_query(nthip_ctx* ctx, const nthip_reads* reads, uint16_t k,
                            const uint8_t* d_filter, uint64_t n_bits, uint64_t* hits, uint64_t* total,
                            uint64_t* total_hits, uint32_t flags);
 /*
+ * nthip_seed_bloom_insert / _query: the same filter fed by SPACED SEEDS -- for every window SeedNtHash emits for read r
+ * (nthip_seed_hash: the reference's position state machine on reads with non-bases, src/seed.cpp:493-544) every one of its
+ * n_seeds * m2 hashes (seed-major, include/nthash/nthash.hpp:313-326, 460-479) sets / tests bit  h mod n_bits.  *total =
+ * windows consumed; query: hits[r] = windows of read r whose n_seeds * m2 bits are ALL set (device memory; host memory
+ * with NTHIP_HOST_OUTPUT), *total_hits their sum.  Fixed-length reads in rounds, reads given by offsets in rounds;
+ * NTHIP_HOST_INPUT is honoured.  The seed hashes of a round go through device scratch (48 B per window for two seeds of
+ * three hashes) and the stream forms of the filter: binned insert, per-read query.
+ */
+int nthip_seed_bloom_insert(nthip_ctx* ctx, const nthip_reads* reads, const nthip_seeds* seeds, uint8_t m2, uint8_t* d_filter,
+                            uint64_t n_bits, uint64_t* total, uint32_t flags);
+int nthip_seed_bloom_query(nthip_ctx* ctx, const nthip_reads* reads, const nthip_seeds* seeds, uint8_t m2, const uint8_t* d_filter,
+                           uint64_t n_bits, uint64_t* hits, uint64_t* total, uint64_t* total_hits, uint32_t flags);
+/*
  * nthip_kmer_minhash: per-read MinHash signatures, the other thing callers do with m hashes per k-mer
  * (sketching: one minimum per hash function).  signatures[r*m + i] = the minimum of hashes()[i] over the
  * k-mers NtHash emits for read r (src/kmer.cpp:228-264 for the emission rule, src/internal.hpp:104-118

@@ -46,7 +46,7 @@ SYMBOLS = [
     "nthip_kmer_count_insert", "nthip_stream_count_insert", "nthip_stream_count_query", "nthip_kmer_minimizers",
     "nthip_stream_bloom_query", "nthip_kmer_minimizers_spans",
     "nthip_multi_ctx", "nthip_multi_kmer_hash_shards", "nthip_multi_kmer_bloom_insert", "nthip_multi_kmer_count_insert",
-    "nthip_multi_kmer_minhash_set", "nthip_multi_merge", "nthip_seed_extend", "nthip_kmer_count_query",
+    "nthip_multi_kmer_minhash_set", "nthip_multi_merge", "nthip_seed_extend", "nthip_kmer_count_query", "nthip_seed_bloom_insert", "nthip_seed_bloom_query",
 ]
 NTHIP_MULTI_ALLGATHER = 0x100
 NTHIP_MERGE_OR, NTHIP_MERGE_ADD_SAT_U8, NTHIP_MERGE_MIN_U64 = 0, 1, 2
@@ -130,6 +130,8 @@ def load():
     L.nthip_stream_count_insert.argtypes = [vp, vp, u64, vp, u64]
     L.nthip_stream_bloom_query.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp, C.POINTER(u64)]
     L.nthip_stream_count_query.argtypes = [vp, vp, u64, C.c_uint8, vp, u64, vp]
+    L.nthip_seed_bloom_insert.argtypes = [vp, C.POINTER(Reads), vp, C.c_uint8, vp, u64, C.POINTER(u64), u32]
+    L.nthip_seed_bloom_query.argtypes = [vp, C.POINTER(Reads), vp, C.c_uint8, vp, u64, vp, C.POINTER(u64), C.POINTER(u64), u32]
     L.nthip_kmer_count_query.argtypes = [vp, C.POINTER(Reads), C.c_uint16, C.c_uint8, vp, u64, vp, C.POINTER(u64), u32]
     L.nthip_kmer_minimizers.argtypes = [vp, C.POINTER(Reads), C.c_uint16, u32, vp, vp, vp, u64, C.POINTER(u64), u32]
     L.nthip_kmer_minimizers_spans.argtypes = [vp, vp, u64, vp, vp, u64, C.c_uint16, u32, vp, vp, vp, u64, C.POINTER(u64)]
@@ -494,6 +496,21 @@ class Context:
             offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         return self.count_insert_ptr(data.ctypes.data, n_reads, fixed_len, stride, k, m, d_counters, n_counters,
                                      flags=NTHIP_HOST_INPUT, offsets=offsets.ctypes.data if offsets is not None else 0)
+
+    def seed_bloom_insert_ptr(self, seqs, n_reads, fixed_len, stride, seeds, m2, d_filter, n_bits, flags=0, offsets=0):
+        """every hash of every window SeedNtHash emits into the filter; -> windows consumed"""
+        rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
+        total = C.c_uint64(0)
+        _chk(self.L.nthip_seed_bloom_insert(self.h, C.byref(rd), seeds.h, m2, C.c_void_p(d_filter), C.c_uint64(n_bits), C.byref(total), flags))
+        return total.value
+
+    def seed_bloom_query_ptr(self, seqs, n_reads, fixed_len, stride, seeds, m2, d_filter, n_bits, hits=0, flags=0, offsets=0):
+        """-> (windows tested, windows whose n_seeds * m2 bits are all set); hits: per read"""
+        rd = Reads(seqs, offsets or None, n_reads, fixed_len, stride)
+        total, found = C.c_uint64(0), C.c_uint64(0)
+        _chk(self.L.nthip_seed_bloom_query(self.h, C.byref(rd), seeds.h, m2, C.c_void_p(d_filter), C.c_uint64(n_bits), C.c_void_p(hits or None),
+                                           C.byref(total), C.byref(found), flags))
+        return total.value, found.value
 
     def count_query_ptr(self, seqs, n_reads, fixed_len, stride, k, m, d_counters, n_counters, estimates, flags=0, offsets=0):
         """estimates: one byte per window of the batch (read r's at the windows of the reads before it); -> k-mers emitted"""

@@ -259,3 +259,96 @@ def test_kmer_count_query_argument_errors(ctx):
     assert ctx.count_query_ptr(d_in, 10, 20, 0, 31, 1, d_c, 1024, d_e) == 0      # reads shorter than k: nothing to estimate
     for p in (d_c, d_e, d_in):
         ctx.free(p)
+
+
+# ---- spaced-seed consumers: nthip_seed_bloom_insert / _query -----------------------------------------------------------------
+SEED_A = "1010101010101010101010101010101"       # BASELINE config 4's pair
+SEED_B = "1101101101101101011011011011011"
+SEEDS_K48 = ["110110110110110110110110011011011011011011011011", "101101101101101101101101101101101101101101101101",
+             "111100001111000011110000000011110000111100001111"]
+
+
+@pytest.mark.parametrize("seeds,k,m2,n,L,n_bits,rounds,by_offsets", [
+    ([SEED_A, SEED_B], 31, 3, 3000, 250, (1 << 28) + 12_345_677, False, False),   # config 4's shape; 3 bins: the binned insert's two levels
+    ([SEED_A, SEED_B], 31, 3, 2000, 250, 1 << 22, True, False),                   # several rounds of reads
+    (SEEDS_K48, 48, 2, 1500, 150, 40_000_003, False, False),                      # three seeds of 48
+    (SEEDS_K48, 48, 1, 1200, 0, 1 << 24, False, True),                            # reads of any lengths
+    ([SEED_A], 31, 1, 400, 40, 1 << 20, False, False),
+])
+def test_seed_bloom_insert_and_query_match_oracle_seed_stream(oracle, seeds, k, m2, n, L, n_bits, rounds, by_offsets):
+    """the filter after nthip_seed_bloom_insert == the filter built on the CPU from the oracle's seed_batch stream (every one
+    of the n_seeds * m2 hashes of every window the reference's SeedNtHash emits, src/seed.cpp:493-544 -- reads with
+    non-bases included); nthip_seed_bloom_query's hits per read == the windows whose hashes all hit that filter"""
+    env = {"NTHIP_TUNE_BLOOM_ROUND": 700_000} if rounds else {}
+    ctx = _ctx_with(env)
+    import nthash_amd
+    sd = nthash_amd.Seeds(ctx, seeds, k)
+    per = len(seeds) * m2
+    rng = np.random.default_rng(n + k + m2)
+    if by_offsets:
+        lens = rng.integers(0, 300, n).astype(np.uint64)
+        lens[:3] = [0, k - 1, k]
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    else:
+        offs = np.arange(n + 1, dtype=np.uint64) * L
+    total_b = int(offs[-1])
+    a = oracle.synth_reads(2, 1, total_b, 17 + k).copy()
+    bad = rng.choice(total_b, max(3, total_b // 600), replace=False)
+    a[bad] = np.frombuffer(b"NnRY-", dtype=np.uint8)[rng.integers(0, 5, bad.size)]
+    want = oracle.seed_batch(a, offs, seeds, k, m2, want_pos=False)
+    filt = _bloom_expected(want["hashes"], n_bits)
+    d_f, nbytes = ctx.bloom_new(n_bits)
+    d_in = ctx.malloc(total_b + 16)
+    ctx.h2d(d_in, a)
+    d_o = 0
+    if by_offsets:
+        d_o = ctx.malloc(offs.nbytes)
+        ctx.h2d(d_o, offs)
+    total = ctx.seed_bloom_insert_ptr(d_in, n, 0 if by_offsets else L, 0, sd, m2, d_f, n_bits, offsets=d_o)
+    assert total == want["total"]
+    got = np.zeros(nbytes, np.uint8)
+    ctx.d2h(got, d_f)
+    assert (got == filt).all(), int((got != filt).sum())
+    # query another batch: the second half of the first + new bases, its own non-bases; against a filter with bits missing
+    b = np.concatenate([a[total_b // 2:], oracle.synth_reads(9, 1, total_b // 2 + 1, 99)])[:total_b].copy()
+    b[rng.choice(total_b, max(3, total_b // 500), replace=False)] = ord("N")
+    wb = oracle.seed_batch(b, offs, seeds, k, m2, want_pos=False)
+    present = _present(filt, wb["hashes"], n_bits, per)
+    read_of = np.repeat(np.arange(n), wb["counts"].astype(np.int64))
+    want_hits = np.bincount(read_of[present], minlength=n).astype(np.uint64)
+    ctx.h2d(d_in, b)
+    d_hits = ctx.malloc(n * 8)
+    ctx.memset(d_hits, 0xEE, n * 8)
+    tq, found = ctx.seed_bloom_query_ptr(d_in, n, 0 if by_offsets else L, 0, sd, m2, d_f, n_bits, hits=d_hits, offsets=d_o)
+    hits = np.zeros(n, np.uint64)
+    ctx.d2h(hits, d_hits)
+    assert tq == wb["total"]
+    assert (hits == want_hits).all(), int((hits != want_hits).sum())
+    assert found == int(want_hits.sum())
+    # host buffers
+    from nthash_amd.capi import NTHIP_HOST_INPUT, NTHIP_HOST_OUTPUT
+    hits2 = np.zeros(n, np.uint64)
+    tq2, found2 = ctx.seed_bloom_query_ptr(b.ctypes.data, n, 0 if by_offsets else L, 0, sd, m2, d_f, n_bits, hits=hits2.ctypes.data,
+                                          flags=NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT, offsets=offs.ctypes.data if by_offsets else 0)
+    assert tq2 == tq and found2 == found and (hits2 == hits).all()
+    for p_ in (d_f, d_in, d_hits) + ((d_o,) if d_o else ()):
+        ctx.free(p_)
+    sd.close()
+    ctx.close()
+
+
+def test_seed_bloom_argument_errors(ctx):
+    import nthash_amd
+    sd = nthash_amd.Seeds(ctx, [SEED_A], 31)
+    d_f, _ = ctx.bloom_new(1 << 16)
+    d_in = ctx.malloc(256)
+    for bad in (lambda: ctx.seed_bloom_insert_ptr(d_in, 1, 200, 0, sd, 1, 0, 1 << 16),          # NULL filter
+                lambda: ctx.seed_bloom_insert_ptr(d_in, 1, 200, 0, sd, 1, d_f + 1, 1 << 16),    # unaligned
+                lambda: ctx.seed_bloom_insert_ptr(d_in, 1, 200, 0, sd, 0, d_f, 1 << 16),        # no hash per seed
+                lambda: ctx.seed_bloom_query_ptr(d_in, 1, 200, 0, sd, 1, d_f, 0)):
+        with pytest.raises(nthash_amd.NtHipError):
+            bad()
+    assert ctx.seed_bloom_insert_ptr(d_in, 5, 20, 0, sd, 2, d_f, 1 << 16) == 0                # reads shorter than the seeds
+    ctx.free(d_in)
+    ctx.free(d_f)
+    sd.close()
