@@ -476,6 +476,15 @@ int nthip_multi_kmer_count_insert(nthip_multi* multi, const nthip_reads* shards,
 int nthip_multi_kmer_minhash_set(nthip_multi* multi, const nthip_reads* shards, uint16_t k, uint8_t m, uint64_t* const* d_sigs,
                                  uint64_t* total, uint32_t flags);
 int nthip_multi_merge(nthip_multi* multi, void* const* d_tables, uint64_t bytes, int op, uint32_t flags);
+/* The sharded QUERY the all-gathered tables are for: reads sharded as above, device g asks ITS copy of the table (filters[g]
+ * / counters[g]: what NTHIP_MULTI_ALLGATHER left there, or any table of device g) exactly as nthip_kmer_bloom_query /
+ * nthip_kmer_count_query do; hits[g] (may be NULL, or hold NULLs) / estimates[g]: memory of device g (host memory with
+ * NTHIP_HOST_OUTPUT), laid out as the single-device calls lay them out for shard g.  *total / *total_hits: sums over the
+ * devices.  Nothing crosses a link. */
+int nthip_multi_kmer_bloom_query(nthip_multi* multi, const nthip_reads* shards, uint16_t k, uint8_t m, const uint8_t* const* d_filters,
+                                 uint64_t n_bits, uint64_t* const* hits, uint64_t* total, uint64_t* total_hits, uint32_t flags);
+int nthip_multi_kmer_count_query(nthip_multi* multi, const nthip_reads* shards, uint16_t k, uint8_t m, const uint8_t* const* d_counters,
+                                 uint64_t n_counters, uint8_t* const* estimates, uint64_t* total, uint32_t flags);
 
 /* ---- measurement helpers (device-resident synthetic data, checksums) ---- */
 /* counter-based reads: read r, 32-base word w ->

@@ -47,6 +47,7 @@ SYMBOLS = [
     "nthip_stream_bloom_query", "nthip_kmer_minimizers_spans",
     "nthip_multi_ctx", "nthip_multi_kmer_hash_shards", "nthip_multi_kmer_bloom_insert", "nthip_multi_kmer_count_insert",
     "nthip_multi_kmer_minhash_set", "nthip_multi_merge", "nthip_seed_extend", "nthip_kmer_count_query", "nthip_seed_bloom_insert", "nthip_seed_bloom_query",
+    "nthip_multi_kmer_bloom_query", "nthip_multi_kmer_count_query",
 ]
 NTHIP_MULTI_ALLGATHER = 0x100
 NTHIP_MERGE_OR, NTHIP_MERGE_ADD_SAT_U8, NTHIP_MERGE_MIN_U64 = 0, 1, 2
@@ -166,6 +167,8 @@ def load():
     L.nthip_multi_kmer_count_insert.argtypes = [vp, vp, C.c_uint16, C.c_uint8, C.POINTER(vp), u64, C.POINTER(u64), u32]
     L.nthip_multi_kmer_minhash_set.argtypes = [vp, vp, C.c_uint16, C.c_uint8, C.POINTER(vp), C.POINTER(u64), u32]
     L.nthip_multi_merge.argtypes = [vp, C.POINTER(vp), u64, C.c_int, u32]
+    L.nthip_multi_kmer_bloom_query.argtypes = [vp, vp, C.c_uint16, C.c_uint8, C.POINTER(vp), u64, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), u32]
+    L.nthip_multi_kmer_count_query.argtypes = [vp, vp, C.c_uint16, C.c_uint8, C.POINTER(vp), u64, C.POINTER(vp), C.POINTER(u64), u32]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("nthip_version", "nthip_last_error"):
@@ -807,6 +810,21 @@ class Multi:
 
     def merge(self, d_tables, nbytes, op, flags=0):
         _chk(self.L.nthip_multi_merge(self.h, self._tables(d_tables), nbytes, op, flags))
+
+    def bloom_query(self, shards, k, m, d_filters, n_bits, d_hits=None, flags=0):
+        """every device asks its copy of the filter about its shard; d_hits: per device, a pointer (memory of that device) or 0.
+        -> (k-mers tested, k-mers found) over all devices"""
+        total, found = C.c_uint64(0), C.c_uint64(0)
+        hits = self._tables(d_hits) if d_hits is not None else None
+        _chk(self.L.nthip_multi_kmer_bloom_query(self.h, self._shards(shards), k, m, self._tables(d_filters), n_bits, hits,
+                                                 C.byref(total), C.byref(found), flags))
+        return total.value, found.value
+
+    def count_query(self, shards, k, m, d_counters, n_counters, d_estimates, flags=0):
+        total = C.c_uint64(0)
+        _chk(self.L.nthip_multi_kmer_count_query(self.h, self._shards(shards), k, m, self._tables(d_counters), n_counters,
+                                                 self._tables(d_estimates), C.byref(total), flags))
+        return total.value
 
     def fastx_kmer_hash_file(self, path, fmt, k, m, chunk_bytes=0, on_batch=None):
         """stream a FASTQ / single-line FASTA file over the devices; on_batch(FastxBatch) sees every batch once, in file

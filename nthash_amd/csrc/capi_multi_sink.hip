@@ -305,3 +305,49 @@ extern "C" int nthip_multi_kmer_minhash_set(nthip_multi* m, const nthip_reads* s
     return rc;
   });
 }
+
+// ---- the sharded QUERY that the all-gathered tables are for (round 5) ---------------------------------------------------------
+// Reads sharded as for the insert, every device asks ITS copy of the table (nthip_multi_kmer_bloom_insert / _count_insert
+// with NTHIP_MULTI_ALLGATHER left the merged table on every device); the answers stay where the reads are: hits[g] /
+// estimates[g] are memory of device g (host memory with NTHIP_HOST_OUTPUT).  Nothing crosses a link.
+extern "C" int nthip_multi_kmer_bloom_query(nthip_multi* m, const nthip_reads* shards, uint16_t k, uint8_t mh, const uint8_t* const* d_filters,
+                                            uint64_t n_bits, uint64_t* const* hits, uint64_t* total, uint64_t* total_hits, uint32_t flags)
+{
+  NTCHK(check_multi_tables(m, (const void* const*)d_filters, "filters"));
+  if (!shards) return fail(NTHIP_ERR_ARG, "shards is NULL");
+  const size_t G = m->ctx.size();
+  std::vector<uint64_t> tot(G, 0), found(G, 0);
+  const int rc = on_every_device(m, [&](size_t g) -> int {
+    if (shards[g].n_reads == 0) return NTHIP_OK;
+    return nthip_kmer_bloom_query(m->ctx[g], &shards[g], k, mh, d_filters[g], n_bits, hits ? hits[g] : nullptr, &tot[g], &found[g],
+                                  flags & (NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT));
+  });
+  if (total) {
+    *total = 0;
+    for (uint64_t t : tot) *total += t;
+  }
+  if (total_hits) {
+    *total_hits = 0;
+    for (uint64_t t : found) *total_hits += t;
+  }
+  return rc;
+}
+
+extern "C" int nthip_multi_kmer_count_query(nthip_multi* m, const nthip_reads* shards, uint16_t k, uint8_t mh, const uint8_t* const* d_counters,
+                                            uint64_t n_counters, uint8_t* const* estimates, uint64_t* total, uint32_t flags)
+{
+  NTCHK(check_multi_tables(m, (const void* const*)d_counters, "counters"));
+  if (!shards || !estimates) return fail(NTHIP_ERR_ARG, "shards / estimates is NULL");
+  const size_t G = m->ctx.size();
+  std::vector<uint64_t> tot(G, 0);
+  const int rc = on_every_device(m, [&](size_t g) -> int {
+    if (shards[g].n_reads == 0) return NTHIP_OK;
+    return nthip_kmer_count_query(m->ctx[g], &shards[g], k, mh, d_counters[g], n_counters, estimates[g], &tot[g],
+                                  flags & (NTHIP_HOST_INPUT | NTHIP_HOST_OUTPUT));
+  });
+  if (total) {
+    *total = 0;
+    for (uint64_t t : tot) *total += t;
+  }
+  return rc;
+}

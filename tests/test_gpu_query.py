@@ -352,3 +352,79 @@ def test_seed_bloom_argument_errors(ctx):
     ctx.free(d_in)
     ctx.free(d_f)
     sd.close()
+
+
+# ---- the sharded query over all-gathered tables ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0, 0]])
+def test_multi_device_query_of_all_gathered_tables(ctx, oracle, devices):
+    """nthip_multi_kmer_bloom_insert / _count_insert with NTHIP_MULTI_ALLGATHER leave the merged table on every device;
+    nthip_multi_kmer_bloom_query / _count_query then shard a SECOND batch over the devices, every device asks its own copy,
+    the answers stay with the reads.  The box has one GPU, so it is listed 2-5 times (separate contexts, threads, tables: the
+    code an 8-GPU node runs).  Against one device asking one table about all the reads; uneven shards, an empty one."""
+    import nthash_amd
+    from nthash_amd import capi
+    G = len(devices)
+    n, L, k, m = 8000, 150, 31, 2
+    nwin = L - k + 1
+    a = oracle.synth_reads(5, n, L, 31)
+    b = oracle.synth_reads(5 + n // 2, n, L, 31).copy()          # half of A's reads, half new ones
+    rng = np.random.default_rng(8)
+    _dirty(rng, b, n, L, every=900)
+    n_bits, n_cnt = 1 << 22, 1 << 16
+    # one device: insert A, ask about B
+    d_a, d_b = ctx.malloc(n * L), ctx.malloc(n * L)
+    ctx.h2d(d_a, a)
+    ctx.h2d(d_b, b)
+    d_f, _ = ctx.bloom_new(n_bits)
+    d_c = ctx.malloc(n_cnt)
+    ctx.memset(d_c, 0, n_cnt)
+    ctx.bloom_insert_ptr(d_a, n, L, 0, k, m, d_f, n_bits)
+    ctx.count_insert_ptr(d_a, n, L, 0, k, m, d_c, n_cnt)
+    d_h, d_e = ctx.malloc(n * 8), ctx.malloc(n * nwin)
+    tot1, found1 = ctx.bloom_query_ptr(d_b, n, L, 0, k, m, d_f, n_bits, hits=d_h)
+    totc1 = ctx.count_query_ptr(d_b, n, L, 0, k, m, d_c, n_cnt, d_e)
+    hits1, est1 = np.zeros(n, np.uint64), np.zeros(n * nwin, np.uint8)
+    ctx.d2h(hits1, d_h)
+    ctx.d2h(est1, d_e)
+    for p_ in (d_a, d_b, d_f, d_c, d_h, d_e):
+        ctx.free(p_)
+    # the set
+    cuts = [0] + sorted(int(x) for x in rng.integers(1, n, G - 1)) + [n]
+    if G > 2:
+        cuts[2] = cuts[1]
+    mm = nthash_amd.Multi(devices)
+    cs = [mm.ctx(g) for g in range(G)]
+    sh_a, sh_b, flt, cnt, hit, est, owned = [], [], [], [], [], [], []
+    for g in range(G):
+        r0, r1 = cuts[g], cuts[g + 1]
+        da, db = cs[g].malloc(max((r1 - r0) * L, 16)), cs[g].malloc(max((r1 - r0) * L, 16))
+        if r1 > r0:
+            cs[g].h2d(da, a[r0 * L: r1 * L])
+            cs[g].h2d(db, b[r0 * L: r1 * L])
+        sh_a.append((da, 0, r1 - r0, L, 0))
+        sh_b.append((db, 0, r1 - r0, L, 0))
+        f, c_ = cs[g].malloc(n_bits // 8), cs[g].malloc(n_cnt)
+        cs[g].memset(f, 0, n_bits // 8)
+        cs[g].memset(c_, 0, n_cnt)
+        h_, e_ = cs[g].malloc(max((r1 - r0) * 8, 16)), cs[g].malloc(max((r1 - r0) * nwin, 16))
+        flt.append(f); cnt.append(c_); hit.append(h_); est.append(e_)
+        owned += [(g, da), (g, db), (g, f), (g, c_), (g, h_), (g, e_)]
+    mm.bloom_insert(sh_a, k, m, flt, n_bits, capi.NTHIP_MULTI_ALLGATHER)
+    mm.count_insert(sh_a, k, m, cnt, n_cnt, capi.NTHIP_MULTI_ALLGATHER)
+    tot, found = mm.bloom_query(sh_b, k, m, flt, n_bits, hit)
+    assert tot == tot1 and found == found1
+    totc = mm.count_query(sh_b, k, m, cnt, n_cnt, est)
+    assert totc == totc1
+    for g in range(G):
+        r0, r1 = cuts[g], cuts[g + 1]
+        if r1 == r0:
+            continue
+        hg, eg = np.zeros(r1 - r0, np.uint64), np.zeros((r1 - r0) * nwin, np.uint8)
+        cs[g].d2h(hg, hit[g])
+        cs[g].d2h(eg, est[g])
+        assert (hg == hits1[r0:r1]).all(), g
+        assert (eg == est1[r0 * nwin: r1 * nwin]).all(), g
+    assert mm.bloom_query(sh_b, k, m, flt, n_bits) == (tot1, found1)          # no per-read hits asked for
+    for g, p_ in owned:
+        cs[g].free(p_)
+    mm.close()
