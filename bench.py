@@ -187,8 +187,7 @@ def cpu_baseline(cfg, sample_reads):
             out["openmp"] = {"value": nk2 / sec2, "unit": "kmers/s", "cores": used,
                              "speedup_vs_1_thread": (nk2 / sec2) / out["value"],
                              "sample": f"{n_mt} reads x {reps} passes, {nk2} k-mers in {sec2:.2f}s",
-                             "note": "OpenMP parallel-for over reads added by the harness; threads = CPUs the "
-                                     "cgroup quota grants (cpu.max) out of the usable ones"}
+                             "note": "OpenMP parallel-for over reads added by the harness; threads = cgroup cpu.max"}
         return out
     impl = ref if ref is not None else Oracle()
     data = impl.synth_reads(0, sample_reads, L, 42)
@@ -543,22 +542,40 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
             tot = ctx.bloom_insert_ptr(d_in, n_reads, L, 0, k, 1, d_f, n_bits)
             return time.perf_counter() - t0, tot
         t_ins, tot = min(ins() for _ in range(3))
-        t_q, (tq, found) = best(lambda: ctx.bloom_query_ptr(d_in, n_reads, L, 0, k, 1, d_f, n_bits))
-        out["bloom_query_4GiB"] = {"value": tq / t_q, "ms": t_q * 1e3,
-                                   "roofline": roof(in_bytes + 8 * n_reads, t_q, "bases in + 8 B per read (hits)",
-                                                    "random-load bound: one 4-byte filter load per k-mer from a 4 GiB table; every such "
-                                                    "load moves a 128-byte line (line_traffic below: the rate the fabric delivers "
-                                                    "lines at, the same on a 128 MiB filter -- profiles/r04_notes.md 9.2)")}
-        out["bloom_query_4GiB"]["roofline"]["line_traffic"] = {"bytes_per_kmer": 128, "GBps": tq * 128 / t_q / 1e9,
-                                                               "frac_of_peak": tq * 128 / t_q / 1e9 / HBM_PEAK_GBPS}
+        d_hits = ctx.malloc(n_reads * 8)
+        owned.append(d_hits)
+        t_q, (tq, found) = best(lambda: ctx.bloom_query_ptr(d_in, n_reads, L, 0, k, 1, d_f, n_bits, hits=d_hits))
+        hits_sum = int(torch.as_tensor(_DevView(d_hits, n_reads, "<i8"), device=dev).sum().item())
+        # the binned query: what it moves per k-mer through its lists, both ways (bytes: DESIGN "bench line legend")
+        list_bytes = 40
+        out["bloom_query_4GiB"] = {"value": tq / t_q, "ms": t_q * 1e3, "check": "hits per read add up to the k-mers found; every inserted k-mer is found",
+                                   "ok": bool(hits_sum == found == kmers),
+                                   "roofline": roof(in_bytes + 8 * n_reads + n_bits // 8, t_q, "bases in + 8 B per read (hits) + the filter read once")}
+        out["bloom_query_4GiB"]["roofline"]["list_traffic"] = {"bytes_per_kmer": list_bytes, "GBps": tq * list_bytes / t_q / 1e9,
+                                                               "frac_of_peak": tq * list_bytes / t_q / 1e9 / HBM_PEAK_GBPS}
+        try:   # the kernel it replaced, same filter, same process: one filter load per k-mer, a 128-byte line each
+            os.environ["NTHIP_TUNE_BLOOM_QUERY"] = "2"
+            import nthash_amd
+            direct = nthash_amd.Context(torch.cuda.current_device())
+            os.environ.pop("NTHIP_TUNE_BLOOM_QUERY", None)
+            t_d, (tqd, foundd) = best(lambda: direct.bloom_query_ptr(d_in, n_reads, L, 0, k, 1, d_f, n_bits), reps=2)
+            direct.close()
+            out["bloom_query_4GiB"]["direct_kernel"] = {"value": tqd / t_d, "ms": t_d * 1e3, "same_answer": bool(foundd == found),
+                                                        "line_traffic_GBps": tqd * 128 / t_d / 1e9}
+        except Exception as e:  # noqa: BLE001
+            out["bloom_query_4GiB"]["direct_kernel"] = {"error": str(e)}
+        finally:
+            os.environ.pop("NTHIP_TUNE_BLOOM_QUERY", None)
+        t_q3, (tq3, found3) = best(lambda: ctx.bloom_query_ptr(d_in, n_reads, L, 0, k, 3, d_f, n_bits), reps=2)
+        out["bloom_query_4GiB_m3"] = {"value": tq3 / t_q3, "ms": t_q3 * 1e3, "x_m1": t_q3 / t_q, "found": found3,
+                                      "roofline": roof(in_bytes + 8 * n_reads + n_bits // 8, t_q3, "as m = 1")}
+        ctx.free(d_hits)
+        owned.remove(d_hits)
         ctx.memset(d_f, 0, n_bits // 8)
         ctx.bloom_insert_ptr(d_in, n_reads, L, 0, k, 1, d_f, n_bits)   # (the kernel of record of an insert, for the line below)
         out["bloom_insert_fresh_4GiB"] = {"value": tot / t_ins, "ms": t_ins * 1e3, "check": "every inserted k-mer is found",
                                           "ok": bool(tot == kmers and tq == kmers and found == kmers),
-                                          "roofline": roof(in_bytes + 2 * (n_bits // 8), t_ins, "bases in + the filter read and written once",
-                                                           "binned insert without a hash stream or a histogram (round 4, slots mode): the reads are hashed ONCE -- "
-                                                           "first partition level from the registers into buckets of mean + 8 sigma entries --, second level, apply: "
-                                                           "16 B of list traffic per value (DESIGN 4.8); the kernel named brackets all of them")}
+                                          "roofline": roof(in_bytes + 2 * (n_bits // 8), t_ins, "bases in + the filter read and written once")}
         ctx.free(d_f)
         owned.remove(d_f)
         # counting sketch: 1 Gi one-byte counters, fresh; no counter saturates here, so the bytes add up to the k-mers
@@ -579,10 +596,45 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
         out["count_insert_fresh_1Gi_counters"] = {"value": totc / t_c, "ms": t_c * 1e3,
                                                   "check": "sum of the counters == k-mers inserted (largest counter %d)" % top,
                                                   "ok": bool(totc == kmers and (s_bytes == kmers or top == 255)),
-                                                  "roofline": roof(in_bytes + 2 * n_cnt, t_c, "bases in + the counters read and written once",
-                                                                   "on the stream-less binned insert's lists (DESIGN 4.8)")}
+                                                  "roofline": roof(in_bytes + 2 * n_cnt, t_c, "bases in + the counters read and written once")}
+        # the sketch's read side on the reads: an estimate per window (binned, as the filter's query)
+        d_e = ctx.malloc(n_reads * nwin)
+        owned.append(d_e)
+        t_cq, totq = best(lambda: ctx.count_query_ptr(d_in, n_reads, L, 0, k, 1, d_c, n_cnt, d_e))
+        ev = torch.as_tensor(_DevView(d_e, n_reads * nwin, "|u1"), device=dev)
+        e_min = int(ev.min().item())
+        del ev
+        out["count_query_1Gi_counters"] = {"value": totq / t_cq, "ms": t_cq * 1e3, "check": "every inserted k-mer's estimate is at least 1",
+                                           "ok": bool(totq == kmers and e_min >= 1),
+                                           "roofline": roof(in_bytes + n_reads * nwin + n_cnt, t_cq, "bases in + 1 B per window out + the counters read once")}
+        ctx.free(d_e)
+        owned.remove(d_e)
         ctx.free(d_c)
         owned.remove(d_c)
+        # spaced seeds into a filter: BASELINE config 4's seed pair, 3 hashes per seed, 250 bp reads (a tenth of config 4's batch)
+        import nthash_amd as _na
+        n4, L4 = 5_000_000, 250
+        d_in4 = ctx.malloc(n4 * L4)
+        owned.append(d_in4)
+        ctx.synth_reads_ptr(d_in4, 0, n4, L4, 42)
+        sd = _na.Seeds(ctx, [SEED_A, SEED_B], 31)
+        n_bits4 = 1 << 35
+        d_f4 = ctx.malloc(n_bits4 // 8)
+        owned.append(d_f4)
+        ctx.memset(d_f4, 0, n_bits4 // 8)
+        t0 = time.perf_counter()
+        tot4 = ctx.seed_bloom_insert_ptr(d_in4, n4, L4, 0, sd, 3, d_f4, n_bits4)
+        t_s4 = time.perf_counter() - t0
+        t_sq, (tq4, found4) = best(lambda: ctx.seed_bloom_query_ptr(d_in4, n4, L4, 0, sd, 3, d_f4, n_bits4), reps=2)
+        win4 = n4 * (L4 - 31 + 1)
+        out["seed_bloom_insert_c4_seeds"] = {"value": tot4 / t_s4, "ms": t_s4 * 1e3, "unit": "windows/s (6 hashes each)", "values_per_s": 6 * tot4 / t_s4,
+                                             "check": "every window is consumed and found again", "ok": bool(tot4 == win4 and tq4 == win4 and found4 == win4),
+                                             "query": {"value": tq4 / t_sq, "ms": t_sq * 1e3},
+                                             "roofline": roof(n4 * L4 + 2 * (n_bits4 // 8), t_s4, "bases in + the filter read and written once")}
+        sd.close()
+        for p in (d_in4, d_f4):
+            ctx.free(p)
+            owned.remove(p)
         # (w, k)-minimizers, w = 10: density close to 2 / (w + 1) on random reads, offsets ascending
         w = 10
         cap = n_reads * (2 * nwin // (w + 1) + 4)
@@ -597,9 +649,7 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
                                  "check": "density within 10 % of 2 / (w + 1); offsets ascending, last == total",
                                  "ok": bool(mono and abs(dens - 2 / (w + 1)) < 0.1 * 2 / (w + 1)),
                                  "roofline": roof(in_bytes + 12 * totm + 8 * (n_reads + 1), t_m,
-                                                  "bases in + 12 B per minimizer (hash, position) + 8 B per read (offsets)",
-                                                  "one kernel, no hash stream in HBM; instruction-bound (~60 VALU per k-mer: hashing 35, "
-                                                  "record masks 12, staging + placing the rest)")}
+                                                  "bases in + 12 B per minimizer (hash, position) + 8 B per read (offsets)")}
         # the same reads given by offsets (what a FASTQ batch looks like to the consumer): the same minimizers
         d_of = ctx.malloc((n_reads + 1) * 8)
         owned.append(d_of)
@@ -617,8 +667,7 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
         owned.append(d_s)
         t_s, tots = best(lambda: ctx.minhash_ptr(d_in, n_reads, L, 0, k, 4, d_s))
         out["minhash_m4"] = {"value": tots / t_s, "ms": t_s * 1e3, "ok": bool(tots == kmers),
-                             "roofline": roof(in_bytes + 32 * n_reads, t_s, "bases in + 4 x 8 B per read (signatures)",
-                                              "one kernel, the hashes stay in registers; instruction-bound")}
+                             "roofline": roof(in_bytes + 32 * n_reads, t_s, "bases in + 4 x 8 B per read (signatures)")}
     finally:
         torch.cuda.synchronize(dev)
         for p in owned:
@@ -657,8 +706,7 @@ def dist_consumer_line(torch, dist, ctx, dev, rank, world, share, barrier, n_rea
         t_merge = time.perf_counter() - t0
         barrier()
         tq, found = ctx.bloom_query_ptr(d_in, n_reads, L, 0, k, 1, filt.data_ptr(), n_bits)
-        bits = int(torch.sum(torch.bitwise_count(filt.view(torch.int64)) if hasattr(torch, "bitwise_count") else
-                             filt.to(torch.int64).sum()).item())
+        bits = _popcount_u8(torch, filt)
         cpu_dev = "cpu" if share else dev
         t = torch.tensor([t_ins, t_merge], dtype=torch.float64, device=cpu_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -679,6 +727,16 @@ def dist_consumer_line(torch, dist, ctx, dev, rank, world, share, barrier, n_rea
                                                         "peer-to-self tests' until the driver runs it on a node)"}
     finally:
         ctx.free(d_in)
+
+
+def _popcount_u8(torch, t, chunk=1 << 28):
+    """set bits of a uint8 tensor: a 256-entry table, a quarter GiB at a time (torch has no popcount; summing the BYTES,
+    as this line once did, is a checksum and needs 8 x the filter as int64 -- ADVICE r04)"""
+    lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=t.device)
+    total = 0
+    for i in range(0, t.numel(), chunk):
+        total += int(lut[t[i:i + chunk].to(torch.int64)].sum().item())
+    return total
 
 
 def measured_peak(torch, ctx, dev):
@@ -836,9 +894,7 @@ def main():
         total_kmers = kmers * world
         if plain_roof is not None:
             roof["frac_plain_alloc"] = plain_roof.get("frac")
-            roof["plain_alloc"] = ({"achieved": plain_roof["achieved"], "kernel_avg_ms": plain_roof["kernel_avg_ms"],
-                                    "how": "the same workload on one plain hipMalloc per buffer (no placement probe), "
-                                           "1 warm-up + 3 steps after the timed region, HIP-event kernel time"}
+            roof["plain_alloc"] = ({"achieved": plain_roof["achieved"], "kernel_avg_ms": plain_roof["kernel_avg_ms"]}
                                    if "frac" in plain_roof else plain_roof)
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 gfx950 correction +
         # WRITE_SIZE, separate rocprofv3 --pmc runs of the same kernel); counters cannot be read inside this process
@@ -846,8 +902,7 @@ def main():
             tj = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
             if args.config in tj:
                 roof["traffic"] = tj[args.config]["bytes_per_kmer_measured"] * roof["kmers_per_launch"]
-                roof["traffic_source"] = TRAFFIC_FILE + " (offline rocprofv3 --pmc passes of this kernel, scaled by " \
-                                                        "k-mers per launch; not measured in this run)"
+                roof["traffic_source"] = TRAFFIC_FILE + " (offline --pmc passes, scaled)"
         except Exception:
             roof["traffic"] = None
         workload = cfg["desc"]
@@ -872,10 +927,7 @@ def main():
             "config": {"workload": workload, "reads_per_gpu": n_reads, "read_len": L, "k": k,
                        "hashes_per_kmer": wl.per, "launches_per_step": wl.n_chunks, "input": "ASCII, device-resident",
                        "parallelism": "reads sharded by rank, no data-path collective",
-                       "placement": {"allocator": "nthip_malloc_probed: up to %d allocations per buffer (two more under 48 GiB) measured with the "
-                                                  "library's write-only fill, the fastest kept; a buffer whose best candidate fills under 6.6 TB/s gets one more "
-                                                  "such round while it is held (rank 0's buffers shown)"
-                                                  % PLACE_CANDIDATES if PLACE_CANDIDATES > 1 else "plain hipMalloc",
+                       "placement": {"allocator": ("nthip_malloc_probed, %d candidates" % PLACE_CANDIDATES) if PLACE_CANDIDATES > 1 else "plain hipMalloc",
                                      "buffers": placement}},
             "roofline": roof,
             "verify": verify,
@@ -925,21 +977,6 @@ def main():
                                  "placement_fill_GBps": [b["fill_GBps"] for b in w2.placement]}
                     if w2.pack:
                         sec[name]["pack"] = w2.pack
-                    if name == "var_slots":
-                        sec[name]["note"] = ("value = whole call (survey of the spans, tile sums + scan, the one pass over the bases, "
-                                             "reads with an N redone in their slots); k-mers counted = slots (every window); "
-                                             "kernel / frac = the pass alone")
-                    if name == "var":
-                        sec[name]["note"] = ("value = whole call (survey of the spans, mark pass, scan, hash pass, reads "
-                                             "with an N); kernel / frac = the hash pass alone")
-                    if name == "c2_dirty":
-                        sec[name]["note"] = ("value = whole call (count pass, scan, N-aware hash pass; the context remembers from "
-                                             "the warm-up batch that this shape had non-bases and skips the dense pass that would "
-                                             "give up at the first N); kernel / frac = the hash pass alone")
-                    if name == "c2_dirty_slots":
-                        sec[name]["note"] = ("value = whole call (the dense pass marking the vectors with a non-base, the list of "
-                                             "the reads they touch, those reads redone in their slots); k-mers counted = slots "
-                                             "(every window); kernel / frac = the dense pass alone")
                     w2.free()
                 except Exception as e:
                     sec[name] = {"error": str(e)}
@@ -957,6 +994,29 @@ def main():
             except Exception as e:
                 res["cpu_baseline"] = {"value": None, "error": str(e)}
     if rank == 0:
+        # what the driver keeps of a line is its LAST 2000 characters: the numbers of every part of the bench once more, short, at
+        # the very end (G k-mers/s, roofline fraction; the words of every entry: DESIGN.md "bench line legend")
+        def g(v):
+            return None if v is None else round(v / 1e9, 1)
+
+        def f3(v):
+            return None if v is None else round(v, 3)
+        summ = {"c2": [g(res["value"]), f3(res["roofline"].get("frac")), f3(res["roofline"].get("frac_plain_alloc"))]}
+        if isinstance(res.get("secondary"), dict):
+            summ["sec"] = {n_: ([g(v.get("value")), f3(v.get("frac"))] if "error" not in v else "error") for n_, v in res["secondary"].items()}
+        if isinstance(res.get("consumers"), dict) and "error" not in res["consumers"]:
+            summ["cons"] = {n_: [g(v.get("value")), f3(v.get("roofline", {}).get("frac")), v.get("ok")]
+                            for n_, v in res["consumers"].items() if isinstance(v, dict)}
+            q = res["consumers"].get("bloom_query_4GiB", {})
+            summ["query"] = {"binned_G": g(q.get("value")), "direct_G": g(q.get("direct_kernel", {}).get("value")),
+                             "list_traffic_GBps": f3(q.get("roofline", {}).get("list_traffic", {}).get("GBps")),
+                             "m3_x_m1": f3(res["consumers"].get("bloom_query_4GiB_m3", {}).get("x_m1"))}
+        if isinstance(res.get("cpu_baseline"), dict):
+            cb = res["cpu_baseline"]
+            summ["cpu"] = {"kind": cb.get("kind"), "one_core_M": None if cb.get("value") is None else round(cb["value"] / 1e6, 1),
+                           "openmp_M": None if not cb.get("openmp") else round(cb["openmp"]["value"] / 1e6, 1),
+                           "threads": None if not cb.get("openmp") else cb["openmp"].get("cores")}
+        res["summary"] = summ
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

@@ -3,6 +3,8 @@
 #include "capi_internal.hpp"
 #include "seed_extend_kernel.hpp"
 
+#include <mutex>
+
 using namespace ntamd;
 using namespace ntamd::host;
 
@@ -11,9 +13,13 @@ namespace {
 // the kernel's three mask sets of a seed set, once per nthip_seeds: per 16-base group a 2-bit-per-base mask and what the
 // masked-out positions contribute when they read as code 0 (first_window.hpp: position u of a word contributes
 // sror^{u+1}(S[c]) / srol^{u}(S[~c]); the same correction nthip_seeds_create makes for the any-seed form)
+// (made on first use, under a lock: two host threads with their own contexts may share one seed set -- ADVICE r04; both
+// pointers are published only when both tables are on the device)
+std::mutex g_ext_mu;
 int ext_masks(nthip_seeds* sd)
 {
-  if (sd->d_ext_mask) return NTHIP_OK;
+  std::lock_guard<std::mutex> lk(g_ext_mu);
+  if (sd->d_ext_mask && sd->d_ext_acorr) return NTHIP_OK;
   const uint32_t k = sd->k, S = sd->n_seeds, G = sd->any_groups;
   std::vector<uint32_t> mask((size_t)3 * S * G, 0);
   std::vector<uint4> acorr((size_t)3 * S * G, make_uint4(0, 0, 0, 0));
@@ -39,10 +45,18 @@ int ext_masks(nthip_seeds* sd)
         mask[((size_t)t * S + s) * G + g] = m;
         acorr[((size_t)t * S + s) * G + g] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
       }
-  HIPCHK(hipMalloc((void**)&sd->d_ext_mask, mask.size() * 4));
-  HIPCHK(hipMemcpy(sd->d_ext_mask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc((void**)&sd->d_ext_acorr, acorr.size() * sizeof(uint4)));
-  HIPCHK(hipMemcpy(sd->d_ext_acorr, acorr.data(), acorr.size() * sizeof(uint4), hipMemcpyHostToDevice));
+  uint32_t* d_mask = nullptr;
+  uint4* d_acorr = nullptr;
+  HIPCHK(hipMalloc((void**)&d_mask, mask.size() * 4));
+  if (hipMemcpy(d_mask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc((void**)&d_acorr, acorr.size() * sizeof(uint4)) != hipSuccess ||
+      hipMemcpy(d_acorr, acorr.data(), acorr.size() * sizeof(uint4), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(d_mask);
+    if (d_acorr) (void)hipFree(d_acorr);
+    return fail(NTHIP_ERR_HIP, "the mask tables of nthip_seed_extend could not be put on the device");
+  }
+  sd->d_ext_acorr = d_acorr;
+  sd->d_ext_mask = d_mask;
   return NTHIP_OK;
 }
 

@@ -671,16 +671,17 @@ int run_kmer_bloom_binned(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8
     return NTHIP_OK;
   }
   uint64_t round = bloom_round_values(c, (rd->n_reads - first) * per_read, true);
-  if (round < per_read) return first ? fail(NTHIP_ERR_UNSUPPORTED, "reads of more values than a round of the binned insert") : 1; // (1: the fused kernel)
+  // (1: the caller takes the fused / atomic kernel for the WHOLE batch -- also when some rounds have gone through already:
+  // setting a bit twice is setting it once, so a call that only ran short of memory half way finishes there -- ADVICE r04)
+  if (round < per_read) return 1;
   round = round / per_read * per_read;
   BloomLists t;
   {
     const int rc = bloom_lists(c, &round, true, &t);
-    if (rc < 0 || (rc && !first)) return rc; // (1: no memory for the lists -- the caller takes the fused kernel)
-    if (rc) return fail(NTHIP_ERR_HIP, "no device memory for the lists of the binned insert");
+    if (rc) return rc; // (1: no memory for the lists -- the caller takes the fused kernel)
   }
   const uint64_t reads_per_round = round / per_read;
-  if (reads_per_round == 0) return first ? fail(NTHIP_ERR_UNSUPPORTED, "reads too long for the binned insert's rounds") : 1;
+  if (reads_per_round == 0) return 1;
   for (uint64_t r0 = first; r0 < rd->n_reads; r0 += reads_per_round) {
     const uint64_t nr = rd->n_reads - r0 < reads_per_round ? rd->n_reads - r0 : reads_per_round;
     nthip_reads part = *rd;

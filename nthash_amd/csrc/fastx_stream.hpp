@@ -332,18 +332,31 @@ struct BgzfBlock {
   uint32_t csize;    // whole block: header + deflate data + crc32 + isize
   uint32_t isize;    // inflated bytes
   uint64_t out_off;  // where they go in the chunk
+  uint32_t head;     // bytes in front of the deflate data: 12 + XLEN (18 when 'BC' is the only extra subfield)
 };
 // the block header at `off`: 1 a BGZF block (csize set), 0 something else, < 0 read error / file ends inside it
 inline int bgzf_block_at(int fd, uint64_t file_size, uint64_t off, BgzfBlock* b)
 {
-  uint8_t h[BGZF_HEAD];
+  // (the extra field may hold other subfields next to 'BC' -- RFC 1952 2.3.1.1; a block-0 probe that only knew XLEN == 6
+  // chose the BGZF path for files whose later blocks then failed in the middle of the stream: ADVICE r04)
+  uint8_t h[12 + 256];
   if (off + BGZF_HEAD + BGZF_TAIL > file_size) return -1;
-  if (pread(fd, h, BGZF_HEAD, (off_t)off) != (ssize_t)BGZF_HEAD) return -1;
-  if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4 || h[10] != 6 || h[11] != 0 || h[12] != 'B' || h[13] != 'C' ||
-      h[14] != 2 || h[15] != 0)
-    return 0;
-  const uint32_t csize = ((uint32_t)h[16] | (uint32_t)h[17] << 8) + 1u;
-  if (csize < BGZF_HEAD + BGZF_TAIL || off + csize > file_size) return -1;
+  if (pread(fd, h, 12, (off_t)off) != 12) return -1;
+  if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 4) == 0 || (h[3] & ~4) != 0) return 0; // (FEXTRA alone, as bgzip writes)
+  const uint32_t xlen = (uint32_t)h[10] | (uint32_t)h[11] << 8;
+  if (xlen < 6 || xlen > 256 || off + 12 + xlen + BGZF_TAIL > file_size) return 0;
+  if (pread(fd, h + 12, xlen, (off_t)(off + 12)) != (ssize_t)xlen) return -1;
+  uint32_t csize = 0;
+  for (uint32_t p = 0; p + 4 <= xlen;) {
+    const uint8_t* f = h + 12 + p;
+    const uint32_t flen = (uint32_t)f[2] | (uint32_t)f[3] << 8;
+    if (p + 4 + flen > xlen) return 0;
+    if (f[0] == 'B' && f[1] == 'C' && flen == 2) csize = ((uint32_t)f[4] | (uint32_t)f[5] << 8) + 1u;
+    p += 4 + flen;
+  }
+  if (csize == 0) return 0;
+  b->head = 12 + xlen;
+  if (csize < b->head + BGZF_TAIL || off + csize > file_size) return -1;
   uint8_t t[4];
   if (pread(fd, t, 4, (off_t)(off + csize - 4)) != 4) return -1;
   b->off = off;
@@ -370,8 +383,8 @@ inline bool bgzf_inflate_blocks(int fd, const std::vector<BgzfBlock>& bl, size_t
     }
     if (!ok) break;
     if (z.inflateReset(&zs) != 0) { ok = false; break; }
-    zs.next_in = in.data() + BGZF_HEAD;
-    zs.avail_in = b.csize - BGZF_HEAD - BGZF_TAIL;
+    zs.next_in = in.data() + b.head;
+    zs.avail_in = b.csize - b.head - BGZF_TAIL;
     zs.next_out = dst + b.out_off;
     zs.avail_out = b.isize;
     const int rc = z.inflate(&zs, 4 /* Z_FINISH */);

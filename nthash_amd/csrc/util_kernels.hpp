@@ -544,7 +544,9 @@ static __global__ __launch_bounds__(256) void list_short_tiles_kernel(const uint
       if (tile_counts[t] != full) buf[atomicAdd(&n_buf, 1u)] = t;
     }
     __syncthreads();
-    if (n_buf + 256u > CAP) flush(); // (uniform: read behind the barrier)
+    const bool full = n_buf + 256u > CAP; // every thread reads the count behind ONE barrier ...
+    __syncthreads();                      // ... and nobody adds to it before all have: the decision is the block's (ADVICE r04:
+    if (full) flush();                    // a fast wave of the next iteration could push a slow one's reading over the limit)
   }
   flush();
 }

@@ -91,12 +91,15 @@ def ring_merge_dist(table, op, group=None, allgather=True):
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
 
+    def peer(r):   # P2POp wants GLOBAL ranks; ring_merge counts inside the group
+        return dist.get_global_rank(group, r) if group is not None else r
+
     def exchange(out, dst, inp, src):
         ops = []
         if out.numel():
-            ops.append(dist.P2POp(dist.isend, out, dst, group))
+            ops.append(dist.P2POp(dist.isend, out, peer(dst), group))
         if inp.numel():
-            ops.append(dist.P2POp(dist.irecv, inp, src, group))
+            ops.append(dist.P2POp(dist.irecv, inp, peer(src), group))
         for req in (dist.batch_isend_irecv(ops) if ops else []):
             req.wait()
     return ring_merge(table, op, rank, world, exchange, allgather)

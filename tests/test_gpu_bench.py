@@ -136,9 +136,13 @@ def test_bench_consumers_section():
     """bench.py's `consumers` object (Bloom insert / query, counting sketch, minimizers, MinHash on device-resident reads),
     at a tenth of its size: every check it carries holds"""
     res = run_bench("--consumers-reads", "2000000")["consumers"]
-    for key in ("bloom_insert_fresh_4GiB", "count_insert_fresh_1Gi_counters", "minimizers_w10", "minimizers_w10_offsets", "minhash_m4"):
+    for key in ("bloom_insert_fresh_4GiB", "count_insert_fresh_1Gi_counters", "minimizers_w10", "minimizers_w10_offsets", "minhash_m4",
+                "bloom_query_4GiB", "count_query_1Gi_counters", "seed_bloom_insert_c4_seeds"):
         assert res[key]["ok"] is True and res[key]["value"] > 0, (key, res[key])
         r = res[key]["roofline"]    # (round 4: every consumer says what it must move and what its kernel of record took)
         assert r["algorithmic_bytes"] > 0 and 0 < r["frac"] < 1 and r["kernel"] and r["kernel_ms"] > 0, (key, r)
-    assert res["bloom_query_4GiB"]["value"] > 0
+    q = res["bloom_query_4GiB"]     # (round 5: the binned query, the kernel it replaced beside it, what it moves through its lists)
+    assert q["roofline"]["kernel"].startswith("bloom binned query") and q["roofline"]["list_traffic"]["GBps"] > 0
+    assert q["direct_kernel"]["same_answer"] is True and q["direct_kernel"]["value"] > 0
+    assert res["bloom_query_4GiB_m3"]["value"] > 0 and res["seed_bloom_insert_c4_seeds"]["query"]["value"] > 0
     assert res["minimizers_w10"]["roofline"]["kernel"] == "minimizer_w_kernel"
