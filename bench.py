@@ -92,7 +92,9 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the c3 / c4 / ref lines at N = 1")
     ap.add_argument("--no-peak", action="store_true", help="skip the measured fill / copy ceiling")
     ap.add_argument("--no-placement", action="store_true",
-                    help="plain allocations instead of the library's placement-aware allocator (nthip_malloc_probed)")
+                    help="(the default since round 5) one allocation per buffer through nthip_malloc: no candidates measured")
+    ap.add_argument("--placement", type=int, default=1,
+                    help="candidates nthip_malloc_probed measures per big buffer (1, the default since round 5: one plain allocation)")
     ap.add_argument("--no-plain-pass", action="store_true",
                     help="skip the extra pass on plain hipMalloc buffers (roofline.frac_plain_alloc)")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
@@ -248,7 +250,7 @@ def var_reads(first_read, n_reads, len_min, len_max, seed=42):
 
 
 SLOW_FILL_GBPS = float(os.environ.get("NTHASH_BENCH_SLOW_FILL_GBPS", "6600"))  # (the env: to exercise the second round)  # write-only fill of a buffer in the slow placement class: 5.1-6.1 TB/s; the others 6.9-7.2 (r02 notes 11)
-PLACE_CANDIDATES = 3  # nthip_malloc_probed: allocations measured per big buffer (1: plain allocation; --no-placement)
+PLACE_CANDIDATES = 1  # allocations nthip_malloc_probed measures per big buffer (--placement N); 1: one plain allocation per buffer
 
 
 class _DevView:
@@ -761,8 +763,7 @@ def measured_peak(torch, ctx, dev):
 def main():
     args = parse()
     global PLACE_CANDIDATES
-    if args.no_placement:
-        PLACE_CANDIDATES = 1
+    PLACE_CANDIDATES = 1 if args.no_placement else max(1, args.placement)
     if args.consumers_reads:  # (tests: the consumers object alone, at a reduced size)
         import torch
         import nthash_amd
@@ -927,7 +928,8 @@ def main():
             "config": {"workload": workload, "reads_per_gpu": n_reads, "read_len": L, "k": k,
                        "hashes_per_kmer": wl.per, "launches_per_step": wl.n_chunks, "input": "ASCII, device-resident",
                        "parallelism": "reads sharded by rank, no data-path collective",
-                       "placement": {"allocator": ("nthip_malloc_probed, %d candidates" % PLACE_CANDIDATES) if PLACE_CANDIDATES > 1 else "plain hipMalloc",
+                       "placement": {"allocator": ("nthip_malloc_probed, %d candidates" % PLACE_CANDIDATES) if PLACE_CANDIDATES > 1
+                                     else "nthip_malloc (hipMalloc), one allocation per buffer",
                                      "buffers": placement}},
             "roofline": roof,
             "verify": verify,

@@ -264,7 +264,8 @@ void load_tuning(nthip_tune& t)
   t.no_seed_wtile = is_one("NTHIP_TUNE_NO_SEED_WTILE");
   t.no_seed_rot = is_one("NTHIP_TUNE_NO_SEED_ROT");
   t.seed_pass = num("NTHIP_TUNE_SEED_PASS", 1, 255);
-  t.no_scattered = is_one("NTHIP_TUNE_NO_SCATTERED");
+  t.no_scattered = !is_one("NTHIP_TUNE_SCATTERED"); // (round 5: mapped-from-pieces candidates only on request -- capi_util.hip says why)
+  t.malloc_pieces = num("NTHIP_TUNE_MALLOC_PIECES", 1, 4096);
   t.no_seed_long = is_one("NTHIP_TUNE_NO_SEED_LONG");
   t.no_seed_w6 = is_one("NTHIP_TUNE_NO_SEED_W6");
   t.no_kmer_reads = is_one("NTHIP_TUNE_NO_KMER_READS");
@@ -452,8 +453,7 @@ extern "C" int nthip_malloc(nthip_ctx* c, size_t bytes, void** p)
 {
   if (!c || !p) return fail(NTHIP_ERR_ARG, "ctx/dptr is NULL");
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipMalloc(p, bytes ? bytes : 16));
-  return NTHIP_OK;
+  return default_alloc(c, bytes, p);
 }
 extern "C" int nthip_free(nthip_ctx* c, void* p)
 {

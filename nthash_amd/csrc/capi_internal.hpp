@@ -100,7 +100,8 @@ struct nthip_tune {
   uint32_t reads_run_len = 0, reads_per_tile = 0, reads_waves = 0; // NTHIP_TUNE_READS_RUN_LEN / _PER_TILE / _WAVES (kmer_reads_kernel)
   bool no_seed_w6 = false;    // NTHIP_TUNE_NO_SEED_W6=1: seed_wtile_kernel with 4 waves where 6 would fit (A/B)
   bool no_seed_long = false;  // NTHIP_TUNE_NO_SEED_LONG=1: long reads of SeedNtHash stay on one wave per read
-  bool no_scattered = false;  // NTHIP_TUNE_NO_SCATTERED=1: nthip_malloc_probed tries plain hipMalloc candidates only
+  bool no_scattered = true;   // unless NTHIP_TUNE_SCATTERED=1: nthip_malloc_probed tries plain hipMalloc candidates only (round 5: see capi_util.hip)
+  uint32_t malloc_pieces = 0; // NTHIP_TUNE_MALLOC_PIECES=<MiB>: nthip_malloc maps buffers of 1 GiB and more from physical pieces of that size (1: plain hipMalloc always; unset: the default policy)
   uint32_t seed_pass = 0;     // NTHIP_TUNE_SEED_PASS=n: seed_wtile_kernel hashes n seeds per pass (A/B; 0: planned)
   bool no_seed_rot = false;   // NTHIP_TUNE_NO_SEED_ROT=1: the plain [table][entry] layout of the byte tables in LDS
   // phased headline kernel (kmer_runs_kernel.hpp): tiles per wave and period, period / read window in 10 ns ticks
@@ -233,6 +234,8 @@ void fastx_buffers_release(nthip_ctx* c); // the file driver's pinned / device b
 // capi_util.hip: a buffer of `bytes` mapped from physical pieces of `piece` bytes (see nthip_malloc_probed); false + *out =
 // nullptr when the virtual-memory API refuses; scattered_free() returns false for a pointer it does not own
 bool scattered_alloc(nthip_ctx* c, size_t bytes, size_t piece, void** out);
+// what nthip_malloc does: big buffers mapped from small physical pieces (the fast class of profiles/r02_notes.md 26), else hipMalloc
+int default_alloc(nthip_ctx* c, size_t bytes, void** out);
 bool scattered_free(nthip_ctx* c, void* p);
 
 inline void prof_begin(nthip_ctx* c, const char* name)

@@ -263,6 +263,25 @@ extern "C" int nthip_fill_bench(nthip_ctx* c, void* d_dst, size_t bytes, int rep
 // not change it (profiles/r02_notes.md 11).  For a long-lived buffer -- the hash stream of a pipeline -- it pays to
 // look: up to `candidates` allocations are made (as many at a time as the free memory holds), each is filled once or
 // twice with the write-only yardstick, the fastest is kept and the others are freed.  The buffer's content is garbage.
+// Where the physical pages of a big buffer lie decides which of two classes its streaming kernels run in (one big physical
+// block spreads over the memory channels worse than many small ones: profiles/r02_notes.md 26).  Mapping big buffers from 8 MiB
+// pieces made the headline line tight on one box (0.732-0.735 in 5 of 5 fresh processes, plain hipMalloc 0.704-0.732) -- and
+// was NOT made the default: buffers mapped, released and mapped again through HIP's virtual-memory API came back with
+// foreign bytes in them (tools/vmm_reuse_check.py: 125 M synthetic reads, on their second mapping ~3 000 of them held
+// non-bases; one cycle in four on one box, none on the next; plain hipMalloc never).  A wrong hash costs more than 3 %
+// of bandwidth: pieces only on request (NTHIP_TUNE_MALLOC_PIECES, NTHIP_TUNE_SCATTERED=1 for nthip_malloc_probed).
+constexpr size_t DEFAULT_PIECES_MIN = (size_t)1 << 30; // buffers from this size on are mapped from pieces
+#ifndef NTHIP_DEFAULT_PIECE_MIB
+#define NTHIP_DEFAULT_PIECE_MIB 0 // plain hipMalloc unless NTHIP_TUNE_MALLOC_PIECES says otherwise (see below: why not pieces)
+#endif
+int ntamd::host::default_alloc(nthip_ctx* c, size_t bytes, void** out)
+{
+  const uint32_t mib = c->tune.malloc_pieces ? c->tune.malloc_pieces : (uint32_t)NTHIP_DEFAULT_PIECE_MIB;
+  if (mib >= 2 && bytes >= DEFAULT_PIECES_MIN && !c->tune.no_scattered && scattered_alloc(c, bytes, (size_t)mib << 20, out)) return NTHIP_OK;
+  HIPCHK(hipMalloc(out, bytes ? bytes : 16));
+  return NTHIP_OK;
+}
+
 extern "C" int nthip_malloc_probed(nthip_ctx* c, size_t bytes, int candidates, void** out, double* gbps, int* tried)
 {
   if (!c || !out) return fail(NTHIP_ERR_ARG, "ctx/dptr is NULL");
@@ -270,8 +289,8 @@ extern "C" int nthip_malloc_probed(nthip_ctx* c, size_t bytes, int candidates, v
   *out = nullptr;
   if (gbps) *gbps = 0;
   if (tried) *tried = 0;
-  if (bytes < (size_t)(64u << 20) || candidates <= 1) { // nothing to measure on a small buffer
-    HIPCHK(hipMalloc(out, bytes ? bytes : 16));
+  if (bytes < (size_t)(64u << 20) || candidates <= 1) { // nothing to measure on a small buffer / one candidate: what nthip_malloc gives
+    NTCHK(default_alloc(c, bytes, out));
     if (tried) *tried = 1;
     return NTHIP_OK;
   }
@@ -359,10 +378,29 @@ bool ntamd::host::scattered_alloc(nthip_ctx* c, size_t bytes, size_t piece, void
     rec.pieces.emplace_back(h, sz);
   }
   if (ok) {
-    hipMemAccessDesc acc = {};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    ok = hipMemSetAccess(va, total, &acc, 1) == hipSuccess;
+    // readable and writable from this device, and from every device that can reach it over xGMI: the tables of the
+    // multi-device consumers travel by hipMemcpyPeerAsync (capi_multi_sink.hip), which a mapping for one device would refuse
+    std::vector<hipMemAccessDesc> acc;
+    hipMemAccessDesc own = {};
+    own.location = prop.location;
+    own.flags = hipMemAccessFlagsProtReadWrite;
+    acc.push_back(own);
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
+    for (int d = 0; d < n_dev; ++d) {
+      int can = 0;
+      if (d != c->device && hipDeviceCanAccessPeer(&can, d, c->device) == hipSuccess && can) {
+        hipMemAccessDesc peer = own;
+        peer.location.id = d;
+        acc.push_back(peer);
+      }
+    }
+    (void)hipGetLastError();
+    ok = hipMemSetAccess(va, total, acc.data(), acc.size()) == hipSuccess;
+    if (!ok && acc.size() > 1) { // (peers refused: this device alone, as before)
+      (void)hipGetLastError();
+      ok = hipMemSetAccess(va, total, &own, 1) == hipSuccess;
+    }
   }
   if (!ok) {
     (void)hipGetLastError();
