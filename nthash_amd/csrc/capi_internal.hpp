@@ -504,7 +504,7 @@ int launch_kmer_runs_gen(nthip_ctx* c, K kernel, KmerRunsGenArgs a, size_t dyn_l
 {
   int per_cu = 1;
   NTCHK(blocks_per_cu(c, kernel, (int)a.waves * 64, dyn_lds, &per_cu));
-  const uint64_t need = ((a.tile_list ? a.n_list : a.n_wtiles) + a.waves - 1) / a.waves;
+  const uint64_t need = ((a.tile_list && !a.n_list_dev ? a.n_list : a.n_wtiles) + a.waves - 1) / a.waves;
   uint64_t grid = (uint64_t)c->n_cu * per_cu;
   if (grid > need) grid = need;
   if (a.tile_map == 0xFFFFFFFFu) a.tile_map = (uint32_t)grid;

@@ -141,14 +141,20 @@ int ntamd::host::run_kmer_na_special(nthip_ctx* c, const Staged& st, const nthip
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(c->h_small + 32, d_nlist, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  memcpy(total, c->h_small + 8, 8);
-  uint64_t n_list = 0;
-  memcpy(&n_list, c->h_small + 32, 8);
   *handled = true;
-  if (*total > capacity)
-    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
-                (unsigned long long)capacity, (unsigned long long)*total);
+  // Round 5: when the caller's capacity holds every window of the batch nothing can overflow, and the two passes below go out
+  // WITHOUT the host waiting for the counts (the listed pass reads its number of tiles on the device): one wait per call
+  // instead of two, the kernels back to back.  Else: wait, check, as before.
+  const bool no_wait = capacity >= rd->n_reads * (uint64_t)(len - k + 1);
+  uint64_t n_list = 0;
+  if (!no_wait) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(total, c->h_small + 8, 8);
+    memcpy(&n_list, c->h_small + 32, 8);
+    if (*total > capacity)
+      return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed",
+                  (unsigned long long)capacity, (unsigned long long)*total);
+  }
   // the tiles that lost nothing: the specialised kernel, at the compact offsets
   KmerRunsArgs ra = ra0;
   RunsPlan p2 = plan;
@@ -161,11 +167,12 @@ int ntamd::host::run_kmer_na_special(nthip_ctx* c, const Staged& st, const nthip
   p2.tile_u64 = ra.tile_u64;
   p2.lds = plan.lds + (size_t)plan.waves * 128;
   NTCHK(launch_kmer_runs_special(c, ra, p2, dt));
-  if (n_list) { // the others (an N in one read of 1000: under 1 % of the tiles): the N-aware kernel
+  if (no_wait || n_list) { // the others (an N in one read of 1000: under 1 % of the tiles): the N-aware kernel
     a.counts = nullptr;
     a.waves = q.waves;
     a.tile_list = d_list;
     a.n_list = n_list;
+    a.n_list_dev = no_wait ? d_nlist : nullptr;
     const bool prof = c->profiling; // (last_kernel_ms names and times the pass over the bulk of the batch)
     c->profiling = false;
     const int rc = launch_kmer_runs_gen_nw<true>(c, a, q.lds, q.g.nw, q.g.dword_tail != 0);
@@ -173,5 +180,6 @@ int ntamd::host::run_kmer_na_special(nthip_ctx* c, const Staged& st, const nthip
     NTCHK(rc);
   }
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (no_wait) memcpy(total, c->h_small + 8, 8);
   return NTHIP_OK;
 }

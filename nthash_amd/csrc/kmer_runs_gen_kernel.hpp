@@ -133,6 +133,7 @@ struct KmerRunsGenArgs {
   // window, when kmer_runs_kernel has written all the others of the compact stream.  NULL: every tile
   const uint64_t* tile_list;
   uint64_t n_list;
+  const unsigned long long* n_list_dev; // != NULL: the number of listed tiles is read HERE (the host launched without waiting for it)
   uint64_t n_reads;
   uint64_t n_runs;       // n_reads * rpr
   uint64_t n_wtiles;     // ceil(n_runs / 64)
@@ -427,7 +428,8 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
   const bool listed = NA && SINK == SINK_NONE && !PK && a.tile_list != nullptr;
   auto tile_at = [&](uint64_t i) -> uint64_t { return listed ? a.tile_list[i] : i; };
   uint64_t wt, wstride, wt_end;
-  tile_range<SINK == SINK_NONE>(a.tile_map, a.waves, wave, listed ? a.n_list : a.n_wtiles, wt, wstride, wt_end); // (the consumers write no stream)
+  const uint64_t n_listed = listed ? (a.n_list_dev ? (uint64_t)*a.n_list_dev : a.n_list) : 0;
+  tile_range<SINK == SINK_NONE>(a.tile_map, a.waves, wave, listed ? n_listed : a.n_wtiles, wt, wstride, wt_end); // (the consumers write no stream)
   uint64_t cur_tile = wt < wt_end ? tile_at(wt) : 0u;
   uint64_t r_first = (cur_tile * 64u) / rpr;
   uint32_t rem0 = (uint32_t)(cur_tile * 64u - r_first * rpr);

@@ -1195,6 +1195,9 @@ def test_bloom_binned_insert_matches_oracle_hash_stream(oracle, n, L, k, m, n_bi
     (3000, 150, 31, 4, 4_000_037, 4_000_036, True, {"NTHIP_TUNE_BLOOM_SLOTS": "2"}, "fused insert ("),   # the same on the exact lists (both passes)
     (3000, 151, 25, 2, 1 << 24, 1 << 20, True, {"NTHIP_TUNE_BLOOM_ROUND": "200000"}, "slots"),
     (700, 100, 64, 3, (1 << 20) + 32, 40_000, False, {"NTHIP_TUNE_BLOOM_FUSED": "1"}, "slots"),
+    (4000, 150, 31, 2, (1 << 28) + 12_345, (1 << 23) + 12_344, True, {"NTHIP_TUNE_BLOOM_PIECES": "2"}, "slots ("),   # round 5: two levels behind shared cursors (not pieces)
+    (5000, 150, 31, 1, (1 << 30) + 64, 1 << 27, True, {}, "pieces"),                    # round 5: block-private pieces, whole lines; reads with non-bases
+    (5000, 150, 31, 3, (1 << 29) - 8_000_000, 1 << 25, False, {"NTHIP_TUNE_BLOOM_SLOT_TIGHT": "1"}, "pieces"),   # ... the overflow list in use
 ])
 def test_binned_insert_without_a_hash_stream(oracle, n, L, k, m, n_bits, n_cnt, dirty, knobs, expect):
     """Device-resident fixed-length reads into a Bloom filter / a counting sketch through the lists, with no hash stream:
@@ -1238,7 +1241,8 @@ def test_binned_insert_without_a_hash_stream(oracle, n, L, k, m, n_bits, n_cnt, 
     ctx.set_profiling(True)
     total = ctx.bloom_insert_ptr(d_in, n, L, 0, k, m, d_f, n_bits)
     name = ctx.last_kernel_ms()[1]
-    assert expect in name and name.startswith("bloom"), name
+    # (round 5: a slots-mode round of a two-level table runs on block-private pieces -- "slots" rows accept either label)
+    assert (expect in name or (expect == "slots" and "pieces" in name)) and name.startswith("bloom"), name
     assert total == want["total"]
     pos = (hs % np.uint64(n_bits)).astype(np.int64)
     exp = prior.copy()
@@ -1254,7 +1258,8 @@ def test_binned_insert_without_a_hash_stream(oracle, n, L, k, m, n_bits, n_cnt, 
     ctx.h2d(d_c, priorc.astype(np.uint8))
     total = ctx.count_insert_ptr(d_in, n, L, 0, k, m, d_c, n_cnt)
     name = ctx.last_kernel_ms()[1]
-    assert expect in name and name.startswith("count"), name
+    okc = expect in name or (expect in ("slots", "pieces", "slots (") and ("pieces" in name or "slots" in name))
+    assert okc and name.startswith("count"), name
     assert total == want["total"]
     tally = np.bincount((hs % np.uint64(n_cnt)).astype(np.int64), minlength=n_cnt).astype(np.int64)
     expc = np.minimum(255, priorc + tally).astype(np.uint8)
