@@ -44,8 +44,8 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   // ---- shape of the batch: longest read, largest distance between starts, order ----
   unsigned long long* d_res = (unsigned long long*)(c->d_small + 96); // [0] max length [1] max pitch [2] out of order
   unsigned long long* d_ndirty = (unsigned long long*)(c->d_small + 128);
-  HIPCHK(hipMemsetAsync(c->d_small + 96, 0, 48, c->stream));
-  uint64_t res[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemsetAsync(c->d_small + 96, 0, 56, c->stream)); // (+ the sum of the windows at 144)
+  uint64_t res[5] = {0, 0, 0, 0, 0}; // max length, max pitch, out of order, sum of lengths, sum of windows
   // NTHIP_OUT_READ_SLOTS: the survey also sums the windows of every tile, for the usual tile of 32 reads (decided below:
   // a batch whose slabs would not fit gets fewer reads per tile and its sums from a pass of their own)
   const uint32_t R_guess = c->tune.reads_per_tile ? (c->tune.reads_per_tile > 64 ? 64 : c->tune.reads_per_tile) : 32;
@@ -54,6 +54,7 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
     res[0] = shape->max_len;
     res[1] = shape->max_pitch;
     res[3] = shape->sum_len;
+    res[4] = shape->sum_len; // (an upper bound: a window starts at a base)
   } else {
     uint64_t blocks = (n + 255) / 256;
     if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
@@ -64,11 +65,12 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
       HIPCHK(hipMemsetAsync(d_guess, 0, nt_guess * sizeof(uint64_t), c->stream));
     }
     hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n, total_bytes, d_res,
-                       0u, R_guess, k, d_guess);
+                       0u, R_guess, k, d_guess, (unsigned long long*)(c->d_small + 144));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_small + 96, d_res, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_small + 96, d_res, 56, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     memcpy(res, c->h_small + 96, 32);
+    memcpy(&res[4], c->h_small + 144, 8);
   }
   const uint64_t max_len = res[0], max_pitch = res[1] > res[0] ? res[1] : res[0];
   if (res[2] || max_len > RD_MAX_LEN) return NTHIP_OK; // long reads: kmer_ragged_kernel spreads them over tiles
@@ -262,11 +264,16 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   HIPCHK(hipGetLastError());
   NTCHK(device_exclusive_scan(c, d_tsum, d_toff, n_tiles, d_sums, d_total));
   HIPCHK(hipMemcpyAsync(c->h_small + 8, d_total, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  memcpy(total, c->h_small + 8, 8);
-  if (*total > capacity)
-    return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed", (unsigned long long)capacity,
-                (unsigned long long)*total);
+  // (round 5) a capacity that holds every window of every read cannot overflow: the hash pass goes out behind the scan without
+  // the host waiting for the count -- one wait fewer per call, the kernels back to back
+  const bool no_wait = capacity >= res[4];
+  if (!no_wait) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(total, c->h_small + 8, 8);
+    if (*total > capacity)
+      return fail(NTHIP_ERR_CAPACITY, "output capacity %llu k-mers < %llu needed", (unsigned long long)capacity,
+                  (unsigned long long)*total);
+  }
   // ---- hash: the clean reads, then the listed ones into the holes they left ----
   NTCHK(launch(RD_MODE_HASH, a, lds));
   for (uint32_t sel = 1; sel <= 2; ++sel) { // strand hashes: the hash pass again with another value selected
@@ -283,6 +290,7 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
   hipLaunchKernelGGL(kmer_dirty_reads_kernel<false>, dim3(dblocks), dim3(256), 0, c->stream, da);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (no_wait) memcpy(total, c->h_small + 8, 8);
   return NTHIP_OK;
 }
 

@@ -703,11 +703,12 @@ static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* 
                                                                 const uint64_t* __restrict__ ends, uint64_t n,
                                                                 uint64_t buf_bytes, unsigned long long* __restrict__ res,
                                                                 uint32_t allow_overlap = 0, uint32_t R = 0, uint32_t k = 0,
-                                                                unsigned long long* __restrict__ tile_sum = nullptr)
+                                                                unsigned long long* __restrict__ tile_sum = nullptr,
+                                                                unsigned long long* __restrict__ win_sum = nullptr)
 {
   // allow_overlap: consecutive reads may share bytes as long as starts and ends both go up (the pieces of a long read
   // overlap by k - 1: seed_rtile_kernel only needs a tile's reads inside one slab that ends with the last read)
-  uint64_t mlen = 0, mpitch = 0, slen = 0;
+  uint64_t mlen = 0, mpitch = 0, slen = 0, wsum = 0;
   uint32_t bad = 0;
   const uint32_t lane = threadIdx.x & 63u;
   // (whole waves iterate together: the segmented scan below needs every lane of a wave in the loop)
@@ -722,6 +723,7 @@ static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* 
         if (e0 - s0 > mlen) mlen = e0 - s0;
         slen += e0 - s0;
         nwin = e0 - s0 >= k ? e0 - s0 - k + 1u : 0u;
+        wsum += nwin;
         if (r + 1 < n) {
           const uint64_t s1 = starts[r + 1];
           if (s1 < e0 && !(allow_overlap && s1 >= s0 && ends[r + 1] >= e0)) bad = 1; // not in order, or overlapping
@@ -758,16 +760,28 @@ static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* 
                         (uint32_t)__shfl_down((int)(uint32_t)mpitch, d, 64);
     const uint64_t os = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(slen >> 32), d, 64) << 32) |
                         (uint32_t)__shfl_down((int)(uint32_t)slen, d, 64);
+    const uint64_t ow = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(wsum >> 32), d, 64) << 32) |
+                        (uint32_t)__shfl_down((int)(uint32_t)wsum, d, 64);
     if (ol > mlen) mlen = ol;
     if (op > mpitch) mpitch = op;
     slen += os;
+    wsum += ow;
   }
-  __shared__ unsigned long long block_sum; // total length of the reads: one atomic per block
-  if (threadIdx.x == 0) block_sum = 0;
+  __shared__ unsigned long long block_sum, block_win; // total length / windows (k given) of the reads: one atomic per block
+  if (threadIdx.x == 0) {
+    block_sum = 0;
+    block_win = 0;
+  }
   __syncthreads();
-  if ((threadIdx.x & 63u) == 0) atomicAdd(&block_sum, (unsigned long long)slen);
+  if ((threadIdx.x & 63u) == 0) {
+    atomicAdd(&block_sum, (unsigned long long)slen);
+    atomicAdd(&block_win, (unsigned long long)wsum);
+  }
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&res[3], block_sum);
+  if (threadIdx.x == 0) {
+    atomicAdd(&res[3], block_sum);
+    if (win_sum) atomicAdd(win_sum, block_win); // (every window of every read: what the batch emits when no read holds a non-base)
+  }
   // (thousands of waves hammering one address serialise in L2: look first, the maximum is reached early)
   if ((threadIdx.x & 63u) == 0) {
     if (mlen > __atomic_load_n(&res[0], __ATOMIC_RELAXED)) atomicMax(&res[0], (unsigned long long)mlen);
