@@ -14,6 +14,9 @@ names = {  # scratch name -> tracked name
     "bloom_bench.txt": f"{tag}_bloom_bench.txt",
     "minhash_bench.txt": f"{tag}_minhash_bench.txt",
     "bloom_one.txt": f"{tag}_bloom_one.txt",
+    "query_bench.txt": f"{tag}_query_bench.txt",
+    "default_line_spread.txt": f"{tag}_default_line_spread_evidence_box.txt",
+    "vmm_reuse_check.txt": f"{tag}_vmm_reuse_check.txt",
     "seed_sweep.txt": f"{tag}_seed_sweep.txt",
     "seed_sweep_long.txt": f"{tag}_seed_sweep_long.txt",
     "seed_roll_sweep.txt": f"{tag}_seed_roll_sweep.txt",

@@ -14,6 +14,13 @@ timeout 3000 bash tools/profile_round.sh "$TAG" > "$OUT/profile_round.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bloom_one" -o kt -- python tools/bloom_one.py 20000000 0 3 > /dev/null 2>&1
 for f in $(find "$OUT/trace_bloom_one" -name "*kernel_stats.csv"); do cp "$f" "$OUT/kernel_stats_bloom_one.csv"; done
 timeout 300 python tools/minhash_bench.py > "$OUT/minhash_bench.txt" 2>&1
+# round 5: the binned read side of the filter / the sketch against the direct kernels, and its kernels under rocprofv3
+timeout 600 python tools/query_bench.py 20000000 1,3 35 30 > "$OUT/query_bench.txt" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_query" -o kt -- python tools/query_bench.py 20000000 1 35 0 > /dev/null 2>&1
+for f in $(find "$OUT/trace_query" -name "*kernel_stats.csv"); do cp "$f" "$OUT/kernel_stats_query_bench.csv"; done
+# round 5: fresh-process default lines (one plain allocation per buffer), and what buffers mapped from physical pieces do on reuse
+timeout 900 bash tools/placement_spread.sh 6 "$OUT/default_line_spread.txt" default > /dev/null 2>&1
+timeout 300 python tools/vmm_reuse_check.py 8 4 > "$OUT/vmm_reuse_check.txt" 2>&1
 # the record-form minimizer kernel under the counters (SQ groups)
 MZ_W=10 PMC_SQ_ONLY=1 timeout 1200 bash tools/run_pmc.sh "$OUT/pmc_mzw" mz 20000000 > "$OUT/pmc_mzw.log" 2>&1
 # spaced seeds: the shapes of the round-3 table, long seeds, seeds of few runs
