@@ -171,6 +171,58 @@ __device__ __forceinline__ void bloom_copy_out(const uint32_t* sorted, const uin
   }
 }
 
+// bloom_copy_out for tiles of MANY buckets (runs of ~64 entries): sixteen lanes per bucket, four buckets per instruction -- what a
+// bucket needs is vector arithmetic done once per four (round 5: one bucket per wave at a time spends ~100 mostly scalar
+// instructions per run, and a CU issues one scalar instruction per cycle for all its waves; see bloom_copy_out_lines).
+// The same runs to the same places as bloom_copy_out.
+template <uint32_t NW, bool QUERY = false>
+__device__ __forceinline__ void bloom_copy_out_groups(const uint32_t* sorted, const uint32_t* hist, const uint32_t* off, const uint32_t* gbase,
+                                                      uint32_t n_buckets, uint32_t wave_v, uint32_t lane, uint32_t* out, uint64_t bucket0,
+                                                      const BloomSlots& sl, uint32_t shift, uint32_t* tovf = nullptr)
+{
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_v);
+  const uint64_t cap = sl.cap;
+  const uint32_t g = lane >> 4, l = lane & 15u;
+  const uint32_t n_mine = n_buckets > wave ? (n_buckets - wave + NW - 1u) / NW : 0u;
+  for (uint32_t i0 = 0; i0 < n_mine; i0 += 4u) {
+    const bool mine = i0 + g < n_mine;
+    const uint32_t b = wave + (mine ? i0 + g : i0) * NW;
+    const uint32_t c = mine ? hist[b] : 0u, o = off[b], at = gbase[b];
+    uint32_t fit = c;
+    uint32_t* dst = out + at; // exact lists: the run's place in `out`
+    if (cap != 0) {           // slots mode: relative to the bucket's own cap entries
+      fit = at >= cap ? 0u : (cap - at < c ? (uint32_t)(cap - at) : c);
+      dst = out + (bucket0 + b) * cap + at;
+    }
+    const uint32_t* const sb = sorted + o;
+    {
+      const uint32_t q0 = l, q1 = l + 16u, q2 = l + 32u, q3 = l + 48u;
+      const uint32_t v0 = q0 < fit ? sb[q0] : 0u, v1 = q1 < fit ? sb[q1] : 0u, v2 = q2 < fit ? sb[q2] : 0u, v3 = q3 < fit ? sb[q3] : 0u;
+      if (q0 < fit) dst[q0] = v0;
+      if (q1 < fit) dst[q1] = v1;
+      if (q2 < fit) dst[q2] = v2;
+      if (q3 < fit) dst[q3] = v3;
+    }
+    for (uint32_t q = l + 64u; __ballot(q < fit) != 0ull; q += 32u) {
+      const uint32_t v0 = q < fit ? sb[q] : 0u, v1 = q + 16u < fit ? sb[q + 16u] : 0u;
+      if (q < fit) dst[q] = v0;
+      if (q + 16u < fit) dst[q + 16u] = v1;
+    }
+    if (__ballot(fit < c) != 0ull) { // (rare) a bucket that is full: the overflow list, a bucket at a time
+      for (uint32_t gg = 0; gg < 4u; ++gg) {
+        const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)(gg * 16u)), ff = (uint32_t)__builtin_amdgcn_readlane((int)fit, (int)(gg * 16u));
+        const uint32_t oo = (uint32_t)__builtin_amdgcn_readlane((int)o, (int)(gg * 16u)), bb = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)(gg * 16u));
+        if (ff < cc) {
+          const unsigned long long ob = bloom_overflow_run(sl, sorted + oo, ff, cc, (bucket0 + bb) << shift, lane);
+          if constexpr (QUERY) {
+            if (lane == 0) tovf[bb] = (uint32_t)(ob < 0xFFFFFFFFull ? ob : 0xFFFFFFFFull);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---- pieces mode (round 5): whole lines into block-private pieces ------------------------------------------------------
 // What the appended runs cost is what HBM makes of them (tools/bench_micro/runs_append.hip, 8 GiB of runs of 48..80 entries
 // to 256 lists): behind a cursor every block shares -- every run starts where another CU's ended, two of its three lines
@@ -521,7 +573,14 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(
       for (uint32_t j = lane; j < c; j += 64u) asm volatile("" ::"v"(sorted[o + j]), "v"(dst));
     }
 #else
-    if constexpr (QUERY)
+    if (n_buckets * 192u >= BB_TILE) { // runs of at most ~192 entries on average: four buckets per instruction
+      if constexpr (QUERY)
+        bloom_copy_out_groups<BB_PART_THREADS / 64u, true>(sorted, hist, off, gbase, n_buckets, wave, lane, a.out, (uint64_t)seg * a.buckets_per_seg,
+                                                           a.sl, a.shift, a.q_tovf + q_row);
+      else
+        bloom_copy_out_groups<BB_PART_THREADS / 64u>(sorted, hist, off, gbase, n_buckets, wave, lane, a.out, (uint64_t)seg * a.buckets_per_seg, a.sl,
+                                                     a.shift);
+    } else if constexpr (QUERY)
       bloom_copy_out<BB_PART_THREADS / 64u, true>(sorted, hist, off, gbase, n_buckets, wave, lane, a.out, (uint64_t)seg * a.buckets_per_seg, a.sl,
                                                   a.shift, a.q_tovf + q_row);
     else

@@ -69,6 +69,11 @@ struct BloomFusedQueryArgs : BloomFusedArgs {
   uint2* q_tab;
   uint32_t* q_tovf;
   uint32_t q_steps;
+  // a pass over SOME of a k-mer's hashes (the query of m > 1 asks the later ones only for the k-mers whose earlier ones hit):
+  // the pass's values are hashes()[q_jj0 ... q_jj0 + m) (m: the pass's count); q_surv (may be NULL: every window) holds, per
+  // tile, emitting word and thread, the 16 windows of the word that are still in the race
+  uint32_t q_jj0;
+  const uint16_t* q_surv;
 };
 
 // pieces mode (bloom_binned_kernels.hpp, bloom_copy_out_lines): bucket b's entries of block x go to piece (b * gridDim.x + x)
@@ -222,6 +227,11 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename Blo
         if (lo < hi) lost -= (uint32_t)__builtin_popcount(emask);
       }
       if (lo >= hi) continue; // (no window ends in this word: uniform)
+      uint32_t jj0 = 0;
+      if constexpr (QUERY) {
+        jj0 = a.q_jj0;
+        if (a.q_surv) emask &= a.q_surv[((uint64_t)t * a.q_steps + (j - jb)) * THREADS + tid]; // (behind the `lost` count: that is pass 0's)
+      }
       for (uint32_t jj = 0; jj < m; ++jj) { // the k-mers' m values (extend_hashes, src/internal.hpp:104-118), one set at a time
         if constexpr (PASS == BF_COUNT) {
 #pragma unroll
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename Blo
             where[i] = ~0u;
             val[i] = 0;
             if ((emask >> i) & 1u) {
-              const uint64_t hv = jj == 0 ? h[i] : mix_hash(h[i], a.mult[jj & (KF_MAX_RUNTIME_M - 1)]);
+              const uint64_t hv = jj + jj0 == 0 ? h[i] : mix_hash(h[i], a.mult[(jj + jj0) & (KF_MAX_RUNTIME_M - 1)]);
               const uint64_t p = mod_invariant(hv, a.n_bits, a.magic);
               const uint32_t b = (uint32_t)(p >> a.shift);
               val[i] = (uint32_t)p & a.mask;

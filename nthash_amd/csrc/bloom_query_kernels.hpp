@@ -224,6 +224,8 @@ struct BloomBackArgs {
   // level 1 (a thread per read, the tiles of bloom_fused_kernel)
   uint64_t n_reads;
   uint32_t len, k, m, n_tiles, steps, n_buckets;
+  const uint16_t* surv_in;         // BQ_BLOOM, a pass over some of the hashes: the windows still in the race (NULL: all) ...
+  uint16_t* surv_out;              // ... and those that still are after it (NULL: the last pass -- the hits are summed)
   uint64_t* hits;                  // BQ_BLOOM: per read (may be NULL)
   unsigned long long* total_hits;  // BQ_BLOOM: += the sum
   uint8_t* estimates;              // BQ_COUNT: [read][window], 0 for a window that emitted nothing
@@ -349,7 +351,11 @@ static __global__ __launch_bounds__(THREADS) void bloom_back1_kernel(const Bloom
           }
         __syncthreads(); // (stage / offfit are the next row's)
       }
-      if constexpr (KIND == BQ_BLOOM) hits += (uint32_t)__builtin_popcount(ok & all);
+      if constexpr (KIND == BQ_BLOOM) {
+        // (a later pass emitted the survivors only: `ok` is inside surv_in already)
+        if (a.surv_out) a.surv_out[((uint64_t)t * a.steps + s) * THREADS + tid] = (uint16_t)(ok & all);
+        hits += (uint32_t)__builtin_popcount(ok & all); // (a pass that is not the last: the k-mers still in the race)
+      }
       else if (live && a.estimates) {
         uint8_t* const dst = a.estimates + (run0 + tid) * nwin;
 #pragma unroll
@@ -359,7 +365,7 @@ static __global__ __launch_bounds__(THREADS) void bloom_back1_kernel(const Bloom
     }
     if constexpr (KIND == BQ_BLOOM) {
       if (live) {
-        if (a.hits) a.hits[run0 + tid] = hits;
+        if (a.hits && !a.surv_out) a.hits[run0 + tid] = hits;
         mine += hits;
       }
     }

@@ -298,6 +298,7 @@ void load_tuning(nthip_tune& t)
   t.bloom_slot_tight = num("NTHIP_TUNE_BLOOM_SLOT_TIGHT", 1, 2);
   t.bloom_round = num("NTHIP_TUNE_BLOOM_ROUND", 1024, 0x7FFFFFFF);
   t.bloom_query = num("NTHIP_TUNE_BLOOM_QUERY", 1, 2);
+  t.bloom_query_passes = num("NTHIP_TUNE_BLOOM_QUERY_PASSES", 1, 2);
   t.bloom_pieces = num("NTHIP_TUNE_BLOOM_PIECES", 1, 2);
   t.pf_gbps = num("NTHIP_TUNE_PF_GBPS", 1, 100000);
   t.pf_lead_kb = num("NTHIP_TUNE_PF_LEAD_KB", 1, 1 << 22);

@@ -121,6 +121,7 @@ struct nthip_tune {
   uint32_t bloom_slot_tight = 0; // NTHIP_TUNE_BLOOM_SLOT_TIGHT=1: buckets of the mean exactly (the overflow list in use), 2: of half the mean (rounds fail) -- tests
   uint32_t bloom_binned = 0; // NTHIP_TUNE_BLOOM_BINNED=1: the binned insert whenever the filter allows it, 2: never (A/B, tests)
   uint32_t bloom_pieces = 0; // NTHIP_TUNE_BLOOM_PIECES=2: the two-level binned rounds on slots behind shared cursors, not on block-private pieces (A/B, tests)
+  uint32_t bloom_query_passes = 0; // NTHIP_TUNE_BLOOM_QUERY_PASSES=1: the binned query of m > 1 one hash per pass whatever survives, 2: all m in one pass (A/B, tests)
   uint32_t bloom_query = 0;  // NTHIP_TUNE_BLOOM_QUERY=1: the binned query (bloom_query_kernels.hpp) on every batch it can take, 2: never (A/B, tests)
   uint32_t seed_roll_waves = 0; // NTHIP_TUNE_SEED_ROLL_WAVES=2..8: waves per block of seed_roll_kernel (A/B)
   uint32_t seed_roll = 0;   // NTHIP_TUNE_SEED_ROLL=1: every dense seed batch the block-rolling kernel takes goes there, 2: none (A/B, tests)

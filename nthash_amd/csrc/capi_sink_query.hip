@@ -41,6 +41,7 @@ struct QueryScratch {
   uint32_t *where1 = nullptr, *where2 = nullptr, *tovf1 = nullptr, *tovf2 = nullptr;
   uint2 *tab1 = nullptr, *tab2 = nullptr;
   uint8_t *pay1 = nullptr, *pay2 = nullptr, *ovf_pay = nullptr;
+  uint16_t* surv = nullptr; // m > 1 in passes: per tile, emitting word and thread, the windows whose hashes so far all hit
   uint64_t cap1 = 0, cap2 = 0, ovf_cap = 0;
   uint32_t tiles_per_seg = 0; // slots mode: tile rows per bin; pieces mode: per piece
   size_t head_bytes = 0;
@@ -108,6 +109,7 @@ bool query_scratch(nthip_ctx* c, const QueryGeo& g, uint64_t nr, uint64_t n, uin
   const size_t o_t1 = take((size_t)rows1 * buckets1 * 8), o_v1 = take((size_t)rows1 * buckets1 * 4);
   const size_t o_t2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 8), o_v2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 4);
   const size_t o_p1 = take(slots1), o_p2 = take(slots2), o_po = take((size_t)q->ovf_cap);
+  const size_t o_sv = take((size_t)n_tiles1 * steps * 1024 * 2);
   *need = off;
   if (c->bloom_tmp_bytes < off) return false;
   uint8_t* const b = c->bloom_tmp;
@@ -128,13 +130,16 @@ bool query_scratch(nthip_ctx* c, const QueryGeo& g, uint64_t nr, uint64_t n, uin
   q->pay1 = b + o_p1;
   q->pay2 = b + o_p2;
   q->ovf_pay = b + o_po;
+  q->surv = (uint16_t*)(b + o_sv);
   return true;
 }
 
 template <int KIND>
 int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const BloomFusedSrc& src, const uint32_t* d_table, uint64_t n_slots,
-                uint32_t steps, uint64_t* d_hits, uint8_t* d_est, bool* failed, uint64_t* lost, uint64_t* hits)
+                uint32_t steps, uint64_t* d_hits, uint8_t* d_est, bool* failed, uint64_t* lost, uint64_t* hits, uint32_t jj0 = 0,
+                const uint16_t* surv_in = nullptr, uint16_t* surv_out = nullptr)
 {
+  // (src.m: the hashes of THIS pass, hashes()[jj0 ... jj0 + src.m); surv_in / surv_out: see BloomFusedQueryArgs / BloomBackArgs)
   const uint64_t magic = bloom_magic_of(n_slots);
   const uint64_t table_dwords = KIND == BQ_BLOOM ? (n_slots + 31) / 32 : (n_slots + 3) / 4;
   const uint32_t shift1 = g.one ? g.region_shift : g.bin_shift, buckets1 = g.one ? g.n_regions : g.n_bins;
@@ -155,6 +160,8 @@ int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const Bl
   fa.q_tab = q.tab1;
   fa.q_tovf = q.tovf1;
   fa.q_steps = steps;
+  fa.q_jj0 = jj0;
+  fa.q_surv = surv_in;
   fa.p_fill = q.cur1;
   const uint32_t gx = q.pg.gx;
   if (q.pieces) {
@@ -277,6 +284,8 @@ int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const Bl
   b.steps = steps;
   b.n_buckets = buckets1;
   b.g1 = q.pieces ? q.pg.g1 : 0u;
+  b.surv_in = surv_in;
+  b.surv_out = surv_out;
   b.hits = d_hits;
   b.total_hits = q.total_hits;
   b.estimates = d_est;
@@ -335,8 +344,13 @@ int ntamd::host::bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_
   const BloomFusedSrc shape = {(const uint8_t*)rd->seqs, rd->n_reads, len, stride, k, m};
   if (!bloom_fused_ok(c, shape, 128u)) return NTHIP_OK;
   const uint32_t nwin = len - k + 1u;
-  const uint64_t per_read = (uint64_t)nwin * m;
-  const uint64_t left_values = (rd->n_reads - *first) * per_read;
+  // m > 1 against a filter: the later hashes are asked only for the k-mers whose earlier ones hit (a k-mer that is not in the
+  // filter is out after one lookup, not m) -- pass 0 takes hashes()[0] of every k-mer and leaves the survivors' windows,
+  // the second pass the other m - 1 hashes of the survivors.  m_s: the most hashes a pass takes.
+  const bool passes = kind == BQ_BLOOM && m > 1 && c->tune.bloom_query_passes != 2;
+  const uint32_t m_s = passes ? (m - 1u > 1u ? m - 1u : 1u) : m;
+  const uint64_t per_read = (uint64_t)nwin * m_s;
+  const uint64_t left_values = (rd->n_reads - *first) * (uint64_t)nwin * m;
   const uint64_t table_bytes = kind == BQ_BLOOM ? (n_slots + 7) / 8 : n_slots;
   // worth it?  The direct kernels pay a 128-byte line per value (~20 ps) unless the table sits in the L2s (~8 ps); the lists
   // ~11 ps per value, and a pass over the table (0.2 ps per byte)
@@ -357,7 +371,7 @@ int ntamd::host::bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_
   const bool pieces = query_pieces_ok(c, g, shape, &gx);
   for (;;) { // the scratch of the largest round
     size_t need = 0;
-    if (query_scratch(c, g, reads_per_round, reads_per_round * per_read, n_slots, steps, m, &q, &need, pieces, gx, per_read)) break;
+    if (query_scratch(c, g, reads_per_round, reads_per_round * per_read, n_slots, steps, m_s, &q, &need, pieces, gx, per_read)) break;
     if (c->bloom_tmp) HIPCHK(hipFree(c->bloom_tmp));
     c->bloom_tmp = nullptr;
     c->bloom_tmp_bytes = 0;
@@ -373,14 +387,35 @@ int ntamd::host::bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_
   while (*first < rd->n_reads) {
     const uint64_t nr = std::min<uint64_t>(rd->n_reads - *first, reads_per_round);
     size_t need = 0;
-    if (!query_scratch(c, g, nr, nr * per_read, n_slots, steps, m, &q, &need, pieces, gx, per_read)) return NTHIP_OK; // (cannot happen: a smaller round needs less)
-    const BloomFusedSrc src = {(const uint8_t*)rd->seqs + *first * stride, nr, len, stride, k, m};
+    if (!query_scratch(c, g, nr, nr * per_read, n_slots, steps, m_s, &q, &need, pieces, gx, per_read)) return NTHIP_OK; // (cannot happen: a smaller round needs less)
+    BloomFusedSrc src = {(const uint8_t*)rd->seqs + *first * stride, nr, len, stride, k, m};
     bool failed = false;
     uint64_t lost = 0, hits = 0;
     uint64_t* const dh = d_hits ? d_hits + *first : nullptr;
     uint8_t* const de = d_est ? d_est + *first * nwin : nullptr;
-    if (kind == BQ_BLOOM) NTCHK((query_round<BQ_BLOOM>(c, g, q, src, d_table, n_slots, steps, dh, de, &failed, &lost, &hits)));
-    else NTCHK((query_round<BQ_COUNT>(c, g, q, src, d_table, n_slots, steps, dh, de, &failed, &lost, &hits)));
+    if (kind != BQ_BLOOM) {
+      NTCHK((query_round<BQ_COUNT>(c, g, q, src, d_table, n_slots, steps, dh, de, &failed, &lost, &hits)));
+    } else if (!passes) {
+      NTCHK((query_round<BQ_BLOOM>(c, g, q, src, d_table, n_slots, steps, dh, de, &failed, &lost, &hits)));
+    } else {
+      uint64_t lost_p = 0, alive = 0;
+      src.m = 1;
+      NTCHK((query_round<BQ_BLOOM>(c, g, q, src, d_table, n_slots, steps, nullptr, nullptr, &failed, &lost, &alive, 0u, nullptr, q.surv)));
+      const uint64_t emitted = nr * (uint64_t)nwin - lost;
+      // the rest in ONE more pass (a pass has fixed costs -- the reads are hashed, every window's place is written and read
+      // back -- that a pass per hash pays m - 1 times: 4 GiB filter, m = 3, half the k-mers in it: 71 ms one by one, ~55 ms
+      // so, 74 ms with all three in one pass)
+      (void)emitted;
+      const bool at_once = c->tune.bloom_query_passes != 1;
+      for (uint32_t jj0 = 1; jj0 < m && !failed;) {
+        const uint32_t mp = at_once ? m - jj0 : 1u;
+        const bool last = jj0 + mp == m;
+        src.m = mp;
+        NTCHK((query_round<BQ_BLOOM>(c, g, q, src, d_table, n_slots, steps, last ? dh : nullptr, nullptr, &failed, &lost_p, last ? &hits : &alive, jj0,
+                                     q.surv, last ? nullptr : q.surv)));
+        jj0 += mp;
+      }
+    }
     if (failed) return NTHIP_OK; // (skewed values: the caller's direct kernels take it from here)
     *first += nr;
     *kmers += nr * (uint64_t)nwin - lost;

@@ -1,5 +1,5 @@
-run() { python bench.py --config var --no-cpu-baseline --no-peak --no-secondary --steps 10 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', round(d['value']/1e9,1), round(d['ms_per_step'],3), round(d['roofline']['frac'],3), d['roofline']['kernel_avg_ms'])"; }
-run default
-for c in 7 11 13 15; do NTHIP_TUNE_READS_RUN_LEN=$c run "C=$c"; done
-for r in 16 24 48 64; do NTHIP_TUNE_READS_PER_TILE=$r run "R=$r"; done
-for w in 8 12; do NTHIP_TUNE_READS_WAVES=$w run "W=$w"; done
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_query.py -x -q -k "bloom or count or sketch or consumers or seed_bloom or query" 2>&1 | tail -4
+timeout 300 python tools/query_bench.py 20000000 1,3 35 0 2>&1 | grep -v rocprof
+NTHIP_TUNE_BLOOM_QUERY_PASSES=1 timeout 300 python tools/query_bench.py 20000000 3 35 0 2>&1 | grep "binned"
+NTHIP_TUNE_BLOOM_QUERY_PASSES=2 timeout 300 python tools/query_bench.py 20000000 3 35 0 2>&1 | grep "binned"
+timeout 200 python bench.py --consumers-reads 20000000 2>/dev/null | python tools/show_consumers.py /dev/stdin 2>/dev/null | head -20
