@@ -229,6 +229,8 @@ struct BloomBackArgs {
   uint64_t* hits;                  // BQ_BLOOM: per read (may be NULL)
   unsigned long long* total_hits;  // BQ_BLOOM: += the sum
   uint8_t* estimates;              // BQ_COUNT: [read][window], 0 for a window that emitted nothing
+  uint32_t est_lds;                // BQ_COUNT: != 0: a tile's estimates (THREADS x windows bytes) are collected in dynamic LDS and go out
+                                   // in whole vectors (16 bytes per thread and word at a stride of `windows` bytes: 17.9 ms of the call's 36)
 };
 
 template <uint32_t THREADS>
@@ -309,6 +311,7 @@ static __global__ __launch_bounds__(THREADS) void bloom_back1_kernel(const Bloom
 {
   __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS];
   __shared__ __attribute__((aligned(16))) uint8_t stage[THREADS * 16u];
+  extern __shared__ __attribute__((aligned(16))) uint8_t bq_est_tile[]; // BQ_COUNT with est_lds: [thread][window]
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t k = a.k, m = a.m;
   const uint32_t kmod = (k - 1u) & 15u, jb = (k - 1u) >> 4;
@@ -357,10 +360,29 @@ static __global__ __launch_bounds__(THREADS) void bloom_back1_kernel(const Bloom
         hits += (uint32_t)__builtin_popcount(ok & all); // (a pass that is not the last: the k-mers still in the race)
       }
       else if (live && a.estimates) {
-        uint8_t* const dst = a.estimates + (run0 + tid) * nwin;
+        uint8_t* const dst = a.est_lds ? bq_est_tile + (size_t)tid * nwin : a.estimates + (run0 + tid) * nwin;
 #pragma unroll
         for (uint32_t i = 0; i < 16; ++i)
           if (i >= lo && i < hi) dst[s0 + i - (k - 1u)] = (uint8_t)(((ok >> i) & 1u) ? est[i] : 0u);
+      }
+    }
+    if constexpr (KIND == BQ_COUNT) {
+      if (a.est_lds && a.estimates) { // the tile's estimates: one contiguous piece of the output, in whole vectors where they are aligned
+        __syncthreads();
+        const uint32_t n_here = (uint32_t)((left < THREADS ? left : THREADS) * nwin);
+        uint8_t* const out = a.estimates + run0 * nwin;
+        const uint32_t head = (uint32_t)((16u - ((uintptr_t)out & 15u)) & 15u) < n_here ? (uint32_t)((16u - ((uintptr_t)out & 15u)) & 15u) : n_here;
+        if (tid < head) out[tid] = bq_est_tile[tid];
+        const uint32_t nv = (n_here - head) >> 4;
+        for (uint32_t i = tid; i < nv; i += THREADS) { // (LDS side: head is not a multiple of 16 in general -- bytes, four dwords at a time)
+          const uint8_t* const sp = bq_est_tile + head + (size_t)i * 16u;
+          uint4 v;
+          __builtin_memcpy(&v, sp, 16);
+          *(uint4*)(out + head + (size_t)i * 16u) = v;
+        }
+        const uint32_t done = head + nv * 16u;
+        if (tid < n_here - done) out[done + tid] = bq_est_tile[done + tid];
+        __syncthreads();
       }
     }
     if constexpr (KIND == BQ_BLOOM) {

@@ -290,10 +290,17 @@ int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const Bl
   b.total_hits = q.total_hits;
   b.estimates = d_est;
   {
+    // (the sketch: a tile's estimates collected in LDS when 1024 x windows bytes fit beside the stage)
+    size_t lds1 = 0;
+    if (KIND == BQ_COUNT && d_est) {
+      const size_t want = (((size_t)1024 * (src.len - src.k + 1u)) + 255) & ~(size_t)255;
+      if (want + 24 * 1024 <= lds_cap_of(c)) lds1 = want;
+    }
+    b.est_lds = lds1 ? 1u : 0u;
     int per_cu = 1;
-    NTCHK(blocks_per_cu(c, bloom_back1_kernel<KIND, 1024>, 1024, 0, &per_cu));
+    NTCHK(blocks_per_cu(c, bloom_back1_kernel<KIND, 1024>, 1024, lds1, &per_cu));
     const uint64_t grid = std::min<uint64_t>(fa.n_tiles, (uint64_t)c->n_cu * (uint64_t)per_cu);
-    hipLaunchKernelGGL((bloom_back1_kernel<KIND, 1024>), dim3((unsigned)grid), dim3(1024), 0, c->stream, b);
+    hipLaunchKernelGGL((bloom_back1_kernel<KIND, 1024>), dim3((unsigned)grid), dim3(1024), lds1, c->stream, b);
   }
   prof_end(c);
   HIPCHK(hipGetLastError());
