@@ -398,4 +398,82 @@ static __global__ __launch_bounds__(THREADS) void bloom_back1_kernel(const Bloom
   }
 }
 
+// ---- the binned query of a hash STREAM (reads of any lengths, spaced seeds, nthip_stream_*_query) -------------------------------
+// Level 1 is bloom_part_kernel<true, THREADS, true> on the stream (tiles of THREADS x 16 values, `where` per value, `tab` per
+// tile); the way back of its tiles gives one answer byte per VALUE, next to the stream: ans[i].
+template <uint32_t THREADS>
+static __global__ __launch_bounds__(THREADS) void bloom_back1_stream_kernel(const BloomBackArgs a, uint64_t n_values, uint8_t* __restrict__ ans)
+{
+  constexpr uint32_t TILE = THREADS * BB_PART_ITEMS;
+  __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[TILE];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (bloom_round_failed(a.status, a.ovf_cap)) return;
+  const uint64_t n_tiles = (n_values + TILE - 1) / TILE;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t t0 = tile * TILE;
+    uint32_t w[BB_PART_ITEMS];
+#pragma unroll
+    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+      const uint64_t idx = t0 + (uint64_t)j * THREADS + tid;
+      w[j] = idx < n_values ? __builtin_nontemporal_load(a.where + idx) : BQ_NONE;
+    }
+    const uint64_t row = tile * a.n_buckets;
+    bq_stage_runs<THREADS / 64u>(a.tab + row, a.n_buckets, a.pay_in, 0ull, 1ull, a.cap, stage, cnt, gat, offfit, tid, lane, wave);
+#pragma unroll
+    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+      const uint64_t idx = t0 + (uint64_t)j * THREADS + tid;
+      if (w[j] != BQ_NONE) ans[idx] = (uint8_t)bq_pick(w[j], stage, offfit, a.tovf + row, a.ovf_pay);
+    }
+    __syncthreads();
+  }
+}
+
+// a k-mer's m answers (consecutive in the stream) to ONE byte: filter: 1 when all are set (*found += the ones); sketch: the smallest
+// (out may be ans when m == 1)
+template <int KIND>
+static __global__ __launch_bounds__(256) void answers_per_kmer_kernel(const uint8_t* ans, uint64_t n_kmers, uint32_t m,
+                                                                      uint8_t* out, unsigned long long* __restrict__ found)
+{
+  uint32_t mine = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_kmers; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t v = KIND == BQ_BLOOM ? 1u : 255u;
+    for (uint32_t j = 0; j < m; ++j) {
+      const uint32_t x = ans[i * m + j];
+      v = KIND == BQ_BLOOM ? (v & (x != 0u ? 1u : 0u)) : (x < v ? x : v);
+    }
+    out[i] = (uint8_t)v;
+    mine += KIND == BQ_BLOOM ? v : 0u;
+  }
+  if constexpr (KIND == BQ_BLOOM) {
+    for (int d = 32; d > 0; d >>= 1) mine += (uint32_t)__shfl_xor((int)mine, d, 64);
+    if ((threadIdx.x & 63u) == 0 && mine && found) atomicAdd(found, (unsigned long long)mine);
+  }
+}
+
+// hits per READ from the answers of its k-mers' values (read r: k-mers roff[r] ... roff[r + 1], m values each): a wave per read
+static __global__ __launch_bounds__(256) void answers_per_read_kernel(const uint8_t* __restrict__ ans, const uint64_t* __restrict__ roff,
+                                                                      uint64_t n_reads, uint64_t n_kmers, uint32_t m, uint64_t* __restrict__ hits,
+                                                                      unsigned long long* __restrict__ total_hits)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  uint64_t mine = 0;
+  for (uint64_t r = wave; r < n_reads; r += n_waves) {
+    const uint64_t i0 = roff[r], i1 = r + 1 < n_reads ? roff[r + 1] : n_kmers;
+    uint32_t found = 0;
+    for (uint64_t i = i0 + lane; i < i1; i += 64u) {
+      uint32_t v = 1u;
+      for (uint32_t j = 0; j < m; ++j) v &= ans[i * m + j] != 0u ? 1u : 0u;
+      found += v;
+    }
+    for (int d = 32; d > 0; d >>= 1) found += (uint32_t)__shfl_xor((int)found, d, 64);
+    if (lane == 0) {
+      if (hits) hits[r] = found;
+      mine += found;
+    }
+  }
+  if (lane == 0 && mine) atomicAdd(total_hits, (unsigned long long)mine);
+}
+
 } // namespace ntamd

@@ -309,6 +309,21 @@ int offsets_in_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, size_
 int bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t m, const uint32_t* d_table, uint64_t n_slots, int kind,
                        uint64_t* d_hits, uint8_t* d_est, uint64_t* first, uint64_t* kmers, uint64_t* hits_sum);
 
+// The binned query of a hash STREAM (device memory, not inside the context's list buffer): d_ans[i] = the answer of value i
+// (filter: its bit; sketch: its counter), region by region as above (slots mode: level 1 is the stream's partition).
+// *done = false (nothing written): not a table / a stream for it, or skewed values -- the caller keeps its direct kernel.
+int stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, const uint32_t* d_table, uint64_t n_slots, int kind,
+                        uint8_t* d_ans, bool* done);
+// the answers of a stream's values, k-mer by k-mer (m consecutive values each): filter: flags[i] = all set, *found their number;
+// sketch: out[i] = the smallest.  hits per read (roff: first k-mer of every read): answers_hits_per_read.  Launches only.
+int answers_per_kmer(nthip_ctx* c, const uint8_t* d_ans, uint64_t n_kmers, uint32_t m, int kind, uint8_t* d_out, unsigned long long* d_found);
+// hits per read of a stream of k-mers' values against a filter: stream_query_binned + answers_hits_per_read when that applies,
+// stream_bloom_query_kernel (a filter line per value) otherwise.  *d_total += the hits.  Launches, and waits when it held scratch.
+int stream_hits_per_read(nthip_ctx* c, const uint64_t* d_h, const uint64_t* d_roff, uint64_t n_reads, uint64_t n_kmers, uint32_t m,
+                         const uint32_t* d_filter, uint64_t n_bits, uint64_t* d_hits, unsigned long long* d_total, const char* direct_label);
+int answers_hits_per_read(nthip_ctx* c, const uint8_t* d_ans, const uint64_t* d_roff, uint64_t n_reads, uint64_t n_kmers, uint32_t m,
+                          uint64_t* d_hits, unsigned long long* d_total_hits);
+
 // ---- capi_util.hip ------------------------------------------------------------------------------------------
 // exclusive scan of n u64 on the device: out[i] = sum(in[0..i)), *d_total = sum; d_sums: ceil(n/1024) + 16 u64
 // (in-place is allowed: d_out == d_in)

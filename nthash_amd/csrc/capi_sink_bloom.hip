@@ -748,10 +748,8 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
       NTCHK(own_alloc(keep, (size_t)(nr / SCAN_TILE + 64) * 8, (void**)&d_sums));
       NTCHK(device_exclusive_scan(c, d_counts, d_roff, nr, d_sums, (uint64_t*)(c->d_small + 16)));
       HIPCHK(hipMemsetAsync(c->d_small + 24, 0, 8, c->stream));
-      const unsigned grid = (unsigned)(c->n_cu * 8);
-      hipLaunchKernelGGL(stream_bloom_query_kernel, dim3(grid), dim3(256), 0, c->stream, d_h, d_roff, nr, n_kmers, m, d_filter, n_bits,
-                         bloom_magic_of(n_bits), d_hits, (unsigned long long*)(c->d_small + 24));
-      HIPCHK(hipGetLastError());
+      NTCHK(stream_hits_per_read(c, d_h, d_roff, nr, n_kmers, m, d_filter, n_bits, d_hits, (unsigned long long*)(c->d_small + 24),
+                                 "stream_bloom_query_kernel"));
       HIPCHK(hipMemcpyAsync(c->h_small + 24, c->d_small + 24, 8, hipMemcpyDeviceToHost, c->stream));
       if (host) HIPCHK(hipMemcpyAsync(hits + r0, d_hits, nr * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
@@ -953,6 +951,31 @@ extern "C" int nthip_stream_bloom_query(nthip_ctx* c, const uint64_t* d_hashes, 
   if (found) *found = 0;
   if (n_kmers == 0) return NTHIP_OK;
   HIPCHK(hipMemsetAsync(c->d_small + 24, 0, 8, c->stream));
+  { // a large stream against a large filter: region by region (capi_sink_query.hip); m == 1: the answers ARE the flags
+    const uint64_t n_values = n_kmers * m;
+    bool done = false;
+    uint8_t* d_ans = d_flags;
+    if (m > 1 && (c->tune.bloom_query == 2 || (c->tune.bloom_query != 1 && n_values < (1ull << 24)) || hipMalloc((void**)&d_ans, n_values) != hipSuccess)) {
+      (void)hipGetLastError();
+      d_ans = nullptr;
+    }
+    if (d_ans) {
+      int rc = stream_query_binned(c, d_hashes, n_values, (const uint32_t*)d_filter, n_bits, 0, d_ans, &done);
+      if (rc == NTHIP_OK && done) {
+        prof_begin(c, "answers_per_kmer_kernel");
+        rc = answers_per_kmer(c, d_ans, n_kmers, m, 0, d_flags, (unsigned long long*)(c->d_small + 24));
+        prof_end(c);
+      }
+      if (rc == NTHIP_OK && done) HIPCHK(hipMemcpyAsync(c->h_small + 24, c->d_small + 24, 8, hipMemcpyDeviceToHost, c->stream));
+      (void)hipStreamSynchronize(c->stream);
+      if (d_ans != d_flags) (void)hipFree(d_ans);
+      NTCHK(rc);
+      if (done) {
+        if (found) memcpy(found, c->h_small + 24, 8);
+        return NTHIP_OK;
+      }
+    }
+  }
   prof_begin(c, "stream_bloom_flags_kernel");
   hipLaunchKernelGGL(stream_bloom_flags_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, d_hashes, n_kmers, (uint32_t)m,
                      (const uint32_t*)d_filter, n_bits, bloom_magic_of(n_bits), d_flags, (unsigned long long*)(c->d_small + 24));
@@ -1068,6 +1091,27 @@ extern "C" int nthip_stream_count_query(nthip_ctx* c, const uint64_t* d_hashes, 
   if (n_kmers && (!d_hashes || !d_estimates)) return fail(NTHIP_ERR_ARG, "hashes / estimates is NULL");
   HIPCHK(hipSetDevice(c->device));
   if (n_kmers == 0) return NTHIP_OK;
+  { // a large stream against a large sketch: region by region; m == 1: the answers ARE the estimates
+    const uint64_t n_values = n_kmers * m;
+    bool done = false;
+    uint8_t* d_ans = d_estimates;
+    if (m > 1 && (c->tune.bloom_query == 2 || (c->tune.bloom_query != 1 && n_values < (1ull << 24)) || hipMalloc((void**)&d_ans, n_values) != hipSuccess)) {
+      (void)hipGetLastError();
+      d_ans = nullptr;
+    }
+    if (d_ans) {
+      int rc = stream_query_binned(c, d_hashes, n_values, (const uint32_t*)d_counters, n_counters, 1, d_ans, &done);
+      if (rc == NTHIP_OK && done && m > 1) {
+        prof_begin(c, "answers_per_kmer_kernel");
+        rc = answers_per_kmer(c, d_ans, n_kmers, m, 1, d_estimates, nullptr);
+        prof_end(c);
+      }
+      (void)hipStreamSynchronize(c->stream);
+      if (d_ans != d_estimates) (void)hipFree(d_ans);
+      NTCHK(rc);
+      if (done) return NTHIP_OK;
+    }
+  }
   prof_begin(c, "count_query_kernel");
   hipLaunchKernelGGL(count_query_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, d_hashes, n_kmers, (uint32_t)m, d_counters,
                      n_counters, bloom_magic_of(n_counters), d_estimates);

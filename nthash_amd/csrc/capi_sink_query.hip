@@ -431,6 +431,276 @@ int ntamd::host::bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_
   return NTHIP_OK;
 }
 
+// ---- the binned query of a hash stream ---------------------------------------------------------------------------------------------
+int ntamd::host::answers_per_kmer(nthip_ctx* c, const uint8_t* d_ans, uint64_t n_kmers, uint32_t m, int kind, uint8_t* d_out,
+                                  unsigned long long* d_found)
+{
+  if (n_kmers == 0) return NTHIP_OK;
+  const unsigned grid = (unsigned)std::min<uint64_t>((n_kmers + 255) / 256, (uint64_t)c->n_cu * 16);
+  if (kind == BQ_BLOOM) hipLaunchKernelGGL(answers_per_kmer_kernel<BQ_BLOOM>, dim3(grid), dim3(256), 0, c->stream, d_ans, n_kmers, m, d_out, d_found);
+  else hipLaunchKernelGGL(answers_per_kmer_kernel<BQ_COUNT>, dim3(grid), dim3(256), 0, c->stream, d_ans, n_kmers, m, d_out, d_found);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+int ntamd::host::answers_hits_per_read(nthip_ctx* c, const uint8_t* d_ans, const uint64_t* d_roff, uint64_t n_reads, uint64_t n_kmers, uint32_t m,
+                                       uint64_t* d_hits, unsigned long long* d_total_hits)
+{
+  if (n_reads == 0) return NTHIP_OK;
+  hipLaunchKernelGGL(answers_per_read_kernel, dim3((unsigned)(c->n_cu * 8)), dim3(256), 0, c->stream, d_ans, d_roff, n_reads, n_kmers, m, d_hits,
+                     d_total_hits);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
+int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, const uint32_t* d_table, uint64_t n_slots, int kind,
+                                     uint8_t* d_ans, bool* done)
+{
+  *done = false;
+  if (c->tune.bloom_query == 2 || n_values == 0 || ((uintptr_t)d_table & 15u)) return NTHIP_OK;
+  QueryGeo g;
+  if (!query_geo(n_slots, kind, &g)) return NTHIP_OK;
+  if (c->lds_max < (size_t)BB_REGION_DWORDS * 4 + 1024) return NTHIP_OK;
+  const uint64_t table_bytes = kind == BQ_BLOOM ? (n_slots + 7) / 8 : n_slots;
+  if (c->tune.bloom_query != 1 && (n_values < (1ull << 24) || table_bytes < (32ull << 20) || n_values < table_bytes / 32)) return NTHIP_OK;
+  {
+    const uint8_t* const h0 = (const uint8_t*)d_hashes; // (the stream must not live in the buffer the lists are carved from)
+    if (c->bloom_tmp && h0 < c->bloom_tmp + c->bloom_tmp_bytes && h0 + n_values * 8 > c->bloom_tmp) return NTHIP_OK;
+  }
+#ifndef SQ_L1_THREADS
+#define SQ_L1_THREADS 512 // (1024 threads with the query's records: 28 B of scratch; 512 held to 128 VGPRs: 20 B)
+#endif
+  constexpr uint32_t L1_THREADS = SQ_L1_THREADS, L1_TILE = L1_THREADS * BB_PART_ITEMS;
+  const uint64_t magic = bloom_magic_of(n_slots);
+  const uint64_t table_dwords = kind == BQ_BLOOM ? (n_slots + 31) / 32 : (n_slots + 3) / 4;
+  const uint32_t shift1 = g.one ? g.region_shift : g.bin_shift, buckets1 = g.one ? g.n_regions : g.n_bins;
+  // values per round: ~19 B of scratch per value
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+  free_b += c->bloom_tmp_bytes;
+  uint64_t round = (uint64_t)(free_b / 10 * 8) / 22;
+  if (round > BQ_ROUND_MAX) round = BQ_ROUND_MAX;
+  if (c->tune.bloom_round) round = c->tune.bloom_round;
+  if (round > n_values) round = n_values;
+  if (round < (1u << 16)) round = 1u << 16;
+  struct S {
+    BloomStatus* status;
+    uint32_t *cur1, *cur2, *list1, *list2, *where1, *where2, *tovf1, *tovf2;
+    uint64_t* ovf;
+    uint2 *tab1, *tab2;
+    uint8_t *pay1, *pay2, *ovf_pay;
+    uint64_t cap1, cap2, ovf_cap;
+    uint32_t tiles_per_seg;
+    size_t head;
+  } q;
+  auto carve = [&](uint64_t n, size_t* need) -> bool {
+    q.cap1 = g.one ? 0 : slot_cap(c, n, 1ull << g.bin_shift, n_slots);
+    q.cap2 = slot_cap(c, n, 1ull << g.region_shift, n_slots);
+    q.ovf_cap = n / 64 < 65536 ? 65536 : n / 64;
+    if (c->tune.bloom_slot_tight == 2) q.ovf_cap = 64;
+    q.tiles_per_seg = (uint32_t)((q.cap1 + BQ_L2_TILE - 1) / BQ_L2_TILE);
+    const uint64_t tiles1 = (n + L1_TILE - 1) / L1_TILE, rows2 = g.one ? 0 : (uint64_t)g.n_bins * q.tiles_per_seg;
+    const size_t slots1 = (size_t)g.n_bins * q.cap1, slots2 = (size_t)g.n_regions * q.cap2;
+    q.head = 256 + (size_t)(g.n_bins + g.n_regions) * BB_CURSOR_STRIDE * sizeof(uint32_t);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+      const size_t at = off;
+      off += al256(bytes);
+      return at;
+    };
+    const size_t o_head = take(q.head), o_l1 = take(slots1 * 4), o_l2 = take(slots2 * 4), o_ovf = take((size_t)q.ovf_cap * 8);
+    const size_t o_w1 = take((size_t)n * 4), o_w2 = take(slots1 * 4);
+    const size_t o_t1 = take((size_t)tiles1 * buckets1 * 8), o_v1 = take((size_t)tiles1 * buckets1 * 4);
+    const size_t o_t2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 8), o_v2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 4);
+    const size_t o_p1 = take(slots1), o_p2 = take(slots2), o_po = take((size_t)q.ovf_cap);
+    *need = off;
+    if (c->bloom_tmp_bytes < off) return false;
+    uint8_t* const b = c->bloom_tmp;
+    q.status = (BloomStatus*)(b + o_head);
+    q.cur1 = (uint32_t*)(b + o_head + 256);
+    q.cur2 = q.cur1 + (size_t)g.n_bins * BB_CURSOR_STRIDE;
+    q.list1 = (uint32_t*)(b + o_l1);
+    q.list2 = (uint32_t*)(b + o_l2);
+    q.ovf = (uint64_t*)(b + o_ovf);
+    q.where1 = (uint32_t*)(b + o_w1);
+    q.where2 = (uint32_t*)(b + o_w2);
+    q.tab1 = (uint2*)(b + o_t1);
+    q.tovf1 = (uint32_t*)(b + o_v1);
+    q.tab2 = (uint2*)(b + o_t2);
+    q.tovf2 = (uint32_t*)(b + o_v2);
+    q.pay1 = b + o_p1;
+    q.pay2 = b + o_p2;
+    q.ovf_pay = b + o_po;
+    return true;
+  };
+  for (;;) {
+    size_t need = 0;
+    if (carve(round, &need)) break;
+    if (c->bloom_tmp) HIPCHK(hipFree(c->bloom_tmp));
+    c->bloom_tmp = nullptr;
+    c->bloom_tmp_bytes = 0;
+    if (hipMalloc((void**)&c->bloom_tmp, need) == hipSuccess) {
+      c->bloom_tmp_bytes = need;
+      continue;
+    }
+    (void)hipGetLastError();
+    c->bloom_tmp = nullptr;
+    if (round <= (1u << 22)) return NTHIP_OK;
+    round /= 2;
+  }
+  for (uint64_t v0 = 0; v0 < n_values; v0 += round) {
+    const uint64_t n = std::min<uint64_t>(round, n_values - v0);
+    size_t need = 0;
+    if (!carve(n, &need)) return fail(NTHIP_ERR_HIP, "the lists of a smaller round do not fit the buffer of a larger one");
+    const uint64_t capL1 = g.one ? q.cap2 : q.cap1;
+    HIPCHK(hipMemsetAsync(q.status, 0, q.head, c->stream));
+    prof_begin(c, kind == BQ_BLOOM ? "bloom binned stream query (part, part, lookup, back, back)" : "count binned stream query (part, part, lookup, back, back)");
+    { // forward, level 1: the stream's values
+      BloomPartQueryArgs a;
+      memset((void*)&a, 0, sizeof a);
+      a.in = d_hashes + v0;
+      a.n = n;
+      a.n_bits = n_slots;
+      a.magic = magic;
+      a.n_regions = g.n_regions;
+      a.out = g.one ? q.list2 : q.list1;
+      a.cursor = g.one ? q.cur2 : q.cur1;
+      a.shift = shift1;
+      a.mask = (1u << shift1) - 1u;
+      a.buckets_per_seg = buckets1;
+      a.sl = {capL1, q.ovf, q.status, q.ovf_cap};
+      a.q_where = q.where1;
+      a.q_tab = q.tab1;
+      a.q_tovf = q.tovf1;
+      a.q_tiles_per_seg = (uint32_t)((n + L1_TILE - 1) / L1_TILE);
+      const size_t lds = (size_t)L1_TILE * sizeof(uint32_t);
+      NTCHK(set_max_lds(c, bloom_part_kernel<true, L1_THREADS, true>, lds));
+      hipLaunchKernelGGL((bloom_part_kernel<true, L1_THREADS, true>), dim3((unsigned)c->n_cu * (2048u / L1_THREADS)), dim3(L1_THREADS), lds, c->stream, a);
+    }
+    if (!g.one) { // level 2
+      BloomPartQueryArgs a;
+      memset((void*)&a, 0, sizeof a);
+      a.n_bits = n_slots;
+      a.magic = magic;
+      a.n_regions = g.n_regions;
+      a.in = q.list1;
+      a.out = q.list2;
+      a.cursor = q.cur2;
+      a.shift = g.region_shift;
+      a.mask = (1u << g.region_shift) - 1u;
+      a.buckets_per_seg = BB_REGIONS_PER_BIN;
+      a.sl = {q.cap2, q.ovf, q.status, q.ovf_cap};
+      a.cap_in = q.cap1;
+      a.seg_fill = q.cur1;
+      a.q_where = q.where2;
+      a.q_tab = q.tab2;
+      a.q_tovf = q.tovf2;
+      a.q_tiles_per_seg = q.tiles_per_seg;
+      const size_t lds = (size_t)BQ_L2_TILE * sizeof(uint32_t);
+      int per_cu = 1;
+      NTCHK(blocks_per_cu(c, bloom_part_kernel<false, BQ_L2_THREADS, true>, (int)BQ_L2_THREADS, lds, &per_cu));
+      const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
+      const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
+      hipLaunchKernelGGL((bloom_part_kernel<false, BQ_L2_THREADS, true>), dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), lds, c->stream, a);
+    }
+    { // lookup
+      const size_t lds = (size_t)BB_REGION_DWORDS * sizeof(uint32_t);
+      const uint32_t grid = g.n_regions < (uint32_t)c->n_cu ? g.n_regions : (uint32_t)c->n_cu;
+      if (kind == BQ_BLOOM) {
+        NTCHK(set_max_lds(c, bloom_lookup_kernel<BQ_BLOOM>, lds));
+        hipLaunchKernelGGL(bloom_lookup_kernel<BQ_BLOOM>, dim3(grid), dim3(BQ_LOOKUP_THREADS), lds, c->stream, (const uint32_t*)q.list2,
+                           (const uint32_t*)q.cur2, q.cap2, g.n_regions, d_table, table_dwords, q.pay2, 0u, (uint32_t)BB_REGIONS_PER_BIN);
+        hipLaunchKernelGGL(bloom_ovf_lookup_kernel<BQ_BLOOM>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)q.ovf,
+                           (const BloomStatus*)q.status, q.ovf_cap, d_table, q.ovf_pay);
+      } else {
+        NTCHK(set_max_lds(c, bloom_lookup_kernel<BQ_COUNT>, lds));
+        hipLaunchKernelGGL(bloom_lookup_kernel<BQ_COUNT>, dim3(grid), dim3(BQ_LOOKUP_THREADS), lds, c->stream, (const uint32_t*)q.list2,
+                           (const uint32_t*)q.cur2, q.cap2, g.n_regions, d_table, table_dwords, q.pay2, 0u, (uint32_t)BB_REGIONS_PER_BIN);
+        hipLaunchKernelGGL(bloom_ovf_lookup_kernel<BQ_COUNT>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)q.ovf,
+                           (const BloomStatus*)q.status, q.ovf_cap, d_table, q.ovf_pay);
+      }
+    }
+    BloomBackArgs b;
+    memset(&b, 0, sizeof b);
+    b.ovf_pay = q.ovf_pay;
+    b.status = q.status;
+    b.ovf_cap = q.ovf_cap;
+    if (!g.one) {
+      b.where = q.where2;
+      b.tab = q.tab2;
+      b.tovf = q.tovf2;
+      b.pay_in = q.pay2;
+      b.cap = q.cap2;
+      b.pay_out = q.pay1;
+      b.seg_fill = q.cur1;
+      b.cap_in = q.cap1;
+      b.n_regions = g.n_regions;
+      b.buckets_per_seg = BB_REGIONS_PER_BIN;
+      b.tiles_per_seg = q.tiles_per_seg;
+      int per_cu = 1;
+      NTCHK(blocks_per_cu(c, bloom_back2_kernel<BQ_L2_THREADS>, (int)BQ_L2_THREADS, 0, &per_cu));
+      const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
+      const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
+      hipLaunchKernelGGL(bloom_back2_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
+    }
+    b.where = q.where1;
+    b.tab = q.tab1;
+    b.tovf = q.tovf1;
+    b.pay_in = g.one ? q.pay2 : q.pay1;
+    b.cap = capL1;
+    b.n_buckets = buckets1;
+    {
+      int per_cu = 1;
+      NTCHK(blocks_per_cu(c, bloom_back1_stream_kernel<L1_THREADS>, (int)L1_THREADS, 0, &per_cu));
+      const uint64_t tiles = (n + L1_TILE - 1) / L1_TILE;
+      const uint64_t grid = std::min<uint64_t>(tiles, (uint64_t)c->n_cu * (uint64_t)per_cu);
+      hipLaunchKernelGGL(bloom_back1_stream_kernel<L1_THREADS>, dim3((unsigned)grid), dim3(L1_THREADS), 0, c->stream, b, n, d_ans + v0);
+    }
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_small + 64, q.status, sizeof(BloomStatus), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    BloomStatus st;
+    memcpy(&st, c->h_small + 64, sizeof st);
+    if (st.ovf_n > q.ovf_cap) return NTHIP_OK; // (skewed values: *done stays false, the caller's direct kernel answers everything)
+  }
+  *done = true;
+  return NTHIP_OK;
+}
+
+int ntamd::host::stream_hits_per_read(nthip_ctx* c, const uint64_t* d_h, const uint64_t* d_roff, uint64_t n_reads, uint64_t n_kmers, uint32_t m,
+                                      const uint32_t* d_filter, uint64_t n_bits, uint64_t* d_hits, unsigned long long* d_total,
+                                      const char* direct_label)
+{
+  if (n_reads == 0) return NTHIP_OK;
+  const uint64_t n_values = n_kmers * m;
+  bool done = false;
+  uint8_t* d_ans = nullptr;
+  if (c->tune.bloom_query != 2 && (c->tune.bloom_query == 1 || n_values >= (1ull << 24)) && hipMalloc((void**)&d_ans, n_values) != hipSuccess) {
+    (void)hipGetLastError();
+    d_ans = nullptr;
+  }
+  if (d_ans) {
+    const int rc = stream_query_binned(c, d_h, n_values, d_filter, n_bits, BQ_BLOOM, d_ans, &done);
+    if (rc == NTHIP_OK && done) {
+      prof_begin(c, "answers_per_read_kernel");
+      const int rc2 = answers_hits_per_read(c, d_ans, d_roff, n_reads, n_kmers, m, d_hits, d_total);
+      prof_end(c);
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipFree(d_ans);
+      return rc2;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_ans);
+    NTCHK(rc);
+  }
+  prof_begin(c, direct_label);
+  hipLaunchKernelGGL(stream_bloom_query_kernel, dim3((unsigned)(c->n_cu * 8)), dim3(256), 0, c->stream, d_h, d_roff, n_reads, n_kmers, m, d_filter,
+                     n_bits, bloom_magic_of(n_bits), d_hits, d_total);
+  prof_end(c);
+  HIPCHK(hipGetLastError());
+  return NTHIP_OK;
+}
+
 // ---- nthip_kmer_count_query ---------------------------------------------------------------------------------------------------
 extern "C" int nthip_kmer_count_query(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8, const uint8_t* d_counters, uint64_t n_counters,
                                       uint8_t* estimates, uint64_t* total, uint32_t flags)

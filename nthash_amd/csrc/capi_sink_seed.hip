@@ -57,11 +57,8 @@ int run_seed_bloom(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, u
     NTCHK(own_alloc(keep, (size_t)(nr / SCAN_TILE + 64) * 8, (void**)&d_sums));
     NTCHK(device_exclusive_scan(c, d_counts, d_roff, nr, d_sums, (uint64_t*)(c->d_small + 16)));
     HIPCHK(hipMemsetAsync(c->d_small + 24, 0, 8, c->stream));
-    prof_begin(c, "stream_bloom_query_kernel (spaced seeds)");
-    hipLaunchKernelGGL(stream_bloom_query_kernel, dim3((unsigned)(c->n_cu * 8)), dim3(256), 0, c->stream, (const uint64_t*)d_h, (const uint64_t*)d_roff, nr,
-                       n_windows, per, (const uint32_t*)d_filter, n_bits, bloom_magic_of(n_bits), d_hits, (unsigned long long*)(c->d_small + 24));
-    prof_end(c);
-    HIPCHK(hipGetLastError());
+    NTCHK(stream_hits_per_read(c, d_h, d_roff, nr, n_windows, per, (const uint32_t*)d_filter, n_bits, d_hits, (unsigned long long*)(c->d_small + 24),
+                               "stream_bloom_query_kernel (spaced seeds)"));
     HIPCHK(hipMemcpyAsync(c->h_small + 24, c->d_small + 24, 8, hipMemcpyDeviceToHost, c->stream));
     if (host_hits) HIPCHK(hipMemcpyAsync(hits + r0, d_hits, nr * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
