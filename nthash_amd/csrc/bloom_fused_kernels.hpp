@@ -204,12 +204,7 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename Blo
       uint64_t h[16];
 #pragma unroll
       for (uint32_t i = 0; i < 16; ++i) {
-        srol_pair(f_lo, f_hi);
-        f_lo ^= terms[i].x;
-        f_hi ^= terms[i].y;
-        r_lo ^= terms[i].z;
-        r_hi ^= terms[i].w;
-        sror_pair(r_lo, r_hi);
+        roll_step(f_lo, f_hi, r_lo, r_hi, terms[i]);
         h[i] = canon_pair(f_lo, f_hi, r_lo, r_hi);
       }
       // the steps of this word that emit: all of [lo, hi) for a read of bases only

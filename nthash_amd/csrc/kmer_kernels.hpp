@@ -121,10 +121,66 @@ __device__ __forceinline__ void stream_store16(void* p, const uint4 v)
 //   sror: the inverse
 __device__ __forceinline__ void sror_pair(uint32_t& lo, uint32_t& hi)
 {
-  const uint32_t nlo = __builtin_amdgcn_alignbit(hi, lo, 1); // bits 32..1 -> 31..0
-  const uint32_t x = (hi << 30) | (lo & 1u);                 // bit 33 -> bit 63, bit 0 -> bit 32
-  hi = ((hi >> 1) & 0x7FFFFFFEu) | (x & 0x80000001u);
+  const uint32_t nlo = __builtin_amdgcn_alignbit(hi, lo, 1);     // bits 32..1 -> 31..0
+  const uint32_t t = __builtin_amdgcn_alignbit(hi >> 1, hi, 1);  // bits 63..34 -> 62..33, bit 33 -> bit 63 (and bit 32, replaced:)
+  hi = (t & ~1u) | (lo & 1u);                                    // bit 0 -> bit 32
   lo = nlo;
+}
+
+// One step of the roll (next_forward_hash / next_reverse_hash, src/kmer.cpp:84-94, 164-174) on the register pairs, with the
+// pair-table term {f.lo, f.hi, r.lo, r.hi} of the bases that enter and leave:
+//     f = srol(f) ^ term.f          r = sror(r ^ term.r)
+// Round 5: written out.  From the C++ above hipcc made 19-20 instructions of a step (it spreads the XORs over v_bitop3 and
+// then computes both the folded and the unfolded form of the rotated halves); the split rotates are 5 and 4 instructions
+//     srol: lo' = (hi & 1) | lo << 1;  hi' = bfi(2, hi >> 30, alignbit(hi, lo, 31))          (bit 63 -> 33, bit 32 -> 0)
+//     sror: lo' = alignbit(hi, lo, 1); hi' = bfi(1, lo, alignbit(hi >> 1, hi, 1))            (bit 33 -> 63, bit 0 -> 32)
+// and a step is 7 + 6 (+ 2 for the canonical sum): the kernels that are bound by their instruction stream (reads of any
+// lengths, minimizers, MinHash, the fused Bloom level, k > 32) get that back.  Two statements: the strands are independent.
+#ifndef NT_ROLL_ASM
+#define NT_ROLL_ASM 1
+#endif
+// (ASM = false: the instantiations that sit at 128 registers with the compiler's form and would spill with this one)
+template <bool ASM = true>
+__device__ __forceinline__ void roll_step(uint32_t& f_lo, uint32_t& f_hi, uint32_t& r_lo, uint32_t& r_hi, const uint4 term)
+{
+#if NT_ROLL_ASM
+  if constexpr (!ASM) {
+    srol_pair(f_lo, f_hi);
+    f_lo ^= term.x;
+    f_hi ^= term.y;
+    r_lo ^= term.z;
+    r_hi ^= term.w;
+    sror_pair(r_lo, r_hi);
+    return;
+  }
+  // (in place where the old value is not needed again: the kernels around this are at their register limit)
+  uint32_t t0, t1, nr_lo;
+  asm("v_lshrrev_b32 %2, 30, %1\n\t"
+      "v_alignbit_b32 %3, %1, %0, 31\n\t"
+      "v_lshlrev_b32 %0, 1, %0\n\t"
+      "v_and_or_b32 %0, %1, 1, %0\n\t"
+      "v_bfi_b32 %1, 2, %2, %3\n\t"
+      "v_xor_b32 %0, %0, %4\n\t"
+      "v_xor_b32 %1, %1, %5"
+      : "+v"(f_lo), "+v"(f_hi), "=&v"(t0), "=&v"(t1)
+      : "v"(term.x), "v"(term.y));
+  asm("v_xor_b32 %3, %4, %5\n\t"
+      "v_xor_b32 %1, %1, %6\n\t"
+      "v_lshrrev_b32 %2, 1, %1\n\t"
+      "v_alignbit_b32 %0, %1, %3, 1\n\t"
+      "v_alignbit_b32 %2, %2, %1, 1\n\t"
+      "v_bfi_b32 %1, 1, %3, %2"
+      : "=&v"(nr_lo), "+v"(r_hi), "=&v"(t0), "=&v"(t1)
+      : "v"(r_lo), "v"(term.z), "v"(term.w));
+  r_lo = nr_lo;
+#else
+  srol_pair(f_lo, f_hi);
+  f_lo ^= term.x;
+  f_hi ^= term.y;
+  r_lo ^= term.z;
+  r_hi ^= term.w;
+  sror_pair(r_lo, r_hi);
+#endif
 }
 
 // Tiles -> waves for the kernels whose waves own whole tiles: the blocks of the grid are split into `groups` groups of
@@ -344,12 +400,7 @@ __global__ __launch_bounds__(KF_THREADS) void kmer_fixed_kernel(const KmerFixedA
         return *(const uint4*)((const char*)tab + off);
       };
       auto roll = [&](const uint4 term) {
-        srol_pair(f_lo, f_hi);
-        f_lo ^= term.x;
-        f_hi ^= term.y;
-        r_lo ^= term.z;
-        r_hi ^= term.w;
-        sror_pair(r_lo, r_hi);
+        roll_step(f_lo, f_hi, r_lo, r_hi, term);
       };
       if constexpr (MODE == W_CHECKED) {
         const uint32_t steps = (a.len - s0) < 16u ? (a.len - s0) : 16u;

@@ -419,12 +419,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_ragged_kernel(const KmerR
           return *(const uint4*)((const char*)ptab + toff);
         };
         auto roll = [&](const uint4 term) {
-          srol_pair(f_lo, f_hi);
-          f_lo ^= term.x;
-          f_hi ^= term.y;
-          r_lo ^= term.z;
-          r_hi ^= term.w;
-          sror_pair(r_lo, r_hi);
+          roll_step(f_lo, f_hi, r_lo, r_hi, term);
         };
         // table terms do not depend on the hash state: fetch a batch ahead of the dependent chain
         auto batch = [&](uint32_t i0, auto n_tag) {

@@ -413,12 +413,7 @@ void kmer_reads_kernel(const KmerReadsArgs a)
             return make_uint4(e.x, e.y, e.z, e.w);
           };
           auto roll = [&](const uint4 term) {
-            srol_pair(f_lo, f_hi);
-            f_lo ^= term.x;
-            f_hi ^= term.y;
-            r_lo ^= term.z;
-            r_hi ^= term.w;
-            sror_pair(r_lo, r_hi);
+            roll_step<!(MODE == RD_MODE_HASH && NW >= 4)>(f_lo, f_hi, r_lo, r_hi, term);
           };
           auto batch = [&](uint32_t i0, auto n_tag) {
             constexpr uint32_t N = decltype(n_tag)::value;
@@ -447,14 +442,18 @@ void kmer_reads_kernel(const KmerReadsArgs a)
           }
         }
       };
-      if (act) {
+#ifndef RD_ABL
+#define RD_ABL 0 // measurement builds (WRONG results): 1: nothing is stored, 2: nothing is hashed, 3: neither
+#endif
+      if (act && !(RD_ABL & 2)) {
         if (short_reads) hash_run(std::true_type{});
         else hash_run(std::false_type{});
       }
       lds_sync();
       // ---- copy-out: the tile was built shifted by tpar = o0 mod 16: every 16-byte piece is aligned, a wave
       // instruction covers whole 128-byte lines of the stream ----
-      if (m == 1) {
+      if (RD_ABL & 1) {
+      } else if (m == 1) {
         const uint32_t sp = tpar + span;
         const uint32_t pieces = (sp + 1u) >> 1;
         uint64_t* const base = a.hashes + (o0 - tpar);

@@ -825,12 +825,7 @@ __global__ __launch_bounds__(KR_MAX_THREADS) void kmer_runs_gen_kernel(const Kme
           return *(const uint4*)((const char*)ptab + off);
         };
         auto roll = [&](const uint4 term) {
-          srol_pair(f_lo, f_hi);
-          f_lo ^= term.x;
-          f_hi ^= term.y;
-          r_lo ^= term.z;
-          r_hi ^= term.w;
-          sror_pair(r_lo, r_hi);
+          roll_step<!(NA && SINK == SINK_NONE && NW >= 3)>(f_lo, f_hi, r_lo, r_hi, term);
         };
         // table terms do not depend on the hash state: fetch a batch of them ahead of the
         // dependent chain so that their LDS latencies overlap

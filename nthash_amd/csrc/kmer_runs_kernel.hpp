@@ -349,12 +349,7 @@ __global__ __launch_bounds__(M_T == 1 ? KR_M1_THREADS : KR_MAX_THREADS) void kme
           return *(const uint4*)((const char*)ptab + off);
         };
         auto roll = [&](const uint4 term) {
-          srol_pair(f_lo, f_hi);
-          f_lo ^= term.x;
-          f_hi ^= term.y;
-          r_lo ^= term.z;
-          r_hi ^= term.w;
-          sror_pair(r_lo, r_hi);
+          roll_step(f_lo, f_hi, r_lo, r_hi, term);
         };
         constexpr uint32_t NS = decltype(n_tag)::value; // 0 = runtime count
         if constexpr (NS != 0) {

@@ -270,12 +270,7 @@ __global__ __launch_bounds__(MZF_MAX_THREADS) void minimizer_fused_kernel(const 
         return *(const uint4*)((const char*)ptab + off);
       };
       auto roll = [&](const uint4 term) {
-        srol_pair(f_lo, f_hi);
-        f_lo ^= term.x;
-        f_hi ^= term.y;
-        r_lo ^= term.z;
-        r_hi ^= term.w;
-        sror_pair(r_lo, r_hi);
+        roll_step(f_lo, f_hi, r_lo, r_hi, term);
       };
       auto batch = [&](uint32_t i0, auto n_tag) {
         constexpr uint32_t N = decltype(n_tag)::value;

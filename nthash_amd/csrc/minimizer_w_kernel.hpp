@@ -280,12 +280,7 @@ __global__ __launch_bounds__(64 * mzw_max_waves(C)) void minimizer_w_kernel(cons
           for (uint32_t jj = 0; jj < 8u; ++jj) {
             const uint32_t j = j0 + jj;
             if (j < (uint32_t)C) {
-              srol_pair(f_lo, f_hi);
-              f_lo ^= terms[jj].x;
-              f_hi ^= terms[jj].y;
-              r_lo ^= terms[jj].z;
-              r_hi ^= terms[jj].w;
-              sror_pair(r_lo, r_hi);
+              roll_step(f_lo, f_hi, r_lo, r_hi, terms[jj]);
               h[j] = canon_pair(f_lo, f_hi, r_lo, r_hi);
             }
           }

@@ -237,12 +237,7 @@ __global__ __launch_bounds__(SR_MAX_WAVES * 64) void seed_roll_kernel(const Seed
       }
 #pragma unroll
       for (int i = 0; i < SW - 1; ++i) {
-        srol_pair(st.x, st.y);
-        st.x ^= tacc[i].x;
-        st.y ^= tacc[i].y;
-        st.z ^= tacc[i].z;
-        st.w ^= tacc[i].w;
-        sror_pair(st.z, st.w);
+        roll_step(st.x, st.y, st.z, st.w, tacc[i]);
         emit((uint32_t)i + 1u, st.x, st.y, st.z, st.w);
       }
       const uint32_t vs = v0 + s * m2;
