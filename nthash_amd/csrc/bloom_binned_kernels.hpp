@@ -756,6 +756,132 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_pieces_kern
                                            a.fill_out + ((size_t)seg * gx + blockIdx.x) * a.buckets_per_seg);
 }
 
+// ---- part, pieces mode, level 1 of a hash STREAM ------------------------------------------------------------------------
+// Block x of the gridDim.x blocks takes the tiles x, x + gridDim.x, ... of the stream (BB_PART_THREADS * 16 values each) and
+// owns piece x of every bucket (a bin of a two-level table): out[(b * gridDim.x + x) * sl.cap ...), fill_out[x * n_buckets + b]
+// entries -- what bloom_part_pieces_kernel reads as n_pieces_in = gridDim.x, in_buckets = n_buckets.  What
+// bloom_fused_kernel<..., PIECES> is to the reads (bloom_fused_kernels.hpp), for values that are in memory already (spaced-seed
+// hashes, the compact stream of reads given by offsets, a caller's own stream).  dynamic LDS: the tile + 32 waiting entries
+// per bucket.  QUERY: q_where per value, q_tab / q_tovf rows per tile (tile t: row t), as bloom_part_kernel.
+struct BloomPartStreamPiecesArgs {
+  const uint64_t* in;
+  uint64_t n, n_bits, magic;
+  uint32_t* out;
+  uint32_t* fill_out;
+  uint32_t shift, mask, n_buckets;
+  BloomSlots sl; // cap: entries per piece
+  uint32_t* q_where;
+  uint2* q_tab;
+  uint32_t* q_tovf;
+};
+
+template <uint32_t BB_PART_THREADS, bool QUERY = false>
+static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_stream_pieces_kernel(const BloomPartStreamPiecesArgs a)
+{
+  constexpr uint32_t BB_TILE = BB_PART_THREADS * BB_PART_ITEMS;
+  __shared__ uint32_t hist[BB_MAX_BINS];
+  __shared__ uint32_t off[BB_MAX_BINS];
+  __shared__ uint32_t gbase[BB_MAX_BINS];
+  __shared__ uint32_t lcnt[BB_MAX_BINS], pcur[BB_MAX_BINS];
+  extern __shared__ __attribute__((aligned(16))) uint32_t bb_lds[];
+  uint32_t* const sorted = bb_lds;         // BB_TILE entries
+  uint32_t* const left = bb_lds + BB_TILE; // [bucket][32]
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n_buckets = a.n_buckets;
+  if (tid < BB_MAX_BINS) {
+    lcnt[tid] = 0;
+    pcur[tid] = 0;
+  }
+  const uint64_t n_tiles = (a.n + BB_TILE - 1) / BB_TILE;
+  uint64_t pre[BB_PART_ITEMS];
+  auto fetch = [&](uint64_t tile) {
+    const uint64_t t0 = tile * BB_TILE;
+#pragma unroll
+    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+      const uint64_t idx = t0 + (uint64_t)j * BB_PART_THREADS + tid;
+      pre[j] = 0;
+      if (idx < a.n) pre[j] = __builtin_nontemporal_load(a.in + idx);
+    }
+  };
+  if (blockIdx.x < n_tiles) fetch(blockIdx.x);
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    if (tid < BB_MAX_BINS) hist[tid] = 0;
+    __syncthreads();
+    const uint64_t t0 = tile * BB_TILE;
+    uint32_t val[BB_PART_ITEMS], where[BB_PART_ITEMS]; // where = bucket << 16 | rank inside the tile's bucket
+    if (t0 + BB_TILE <= a.n) {
+#pragma unroll
+      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+        const uint64_t p = mod_invariant(pre[j], a.n_bits, a.magic);
+        const uint32_t b = (uint32_t)(p >> a.shift);
+        val[j] = (uint32_t)p & a.mask;
+        where[j] = (b << 16) | atomicAdd(&hist[b], 1u);
+      }
+    } else {
+#pragma unroll
+      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+        const uint64_t idx = t0 + (uint64_t)j * BB_PART_THREADS + tid;
+        where[j] = ~0u;
+        val[j] = 0;
+        if (idx < a.n) {
+          const uint64_t p = mod_invariant(pre[j], a.n_bits, a.magic);
+          const uint32_t b = (uint32_t)(p >> a.shift);
+          val[j] = (uint32_t)p & a.mask;
+          where[j] = (b << 16) | atomicAdd(&hist[b], 1u);
+        }
+      }
+    }
+    if constexpr (QUERY) {
+#pragma unroll
+      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+        const uint64_t idx = t0 + (uint64_t)j * BB_PART_THREADS + tid;
+        if (idx < a.n) a.q_where[idx] = where[j];
+      }
+    }
+    if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+    __syncthreads();
+    const uint64_t q_row = tile * n_buckets;
+    if (tid < n_buckets) {
+      const uint32_t c = hist[tid];
+      const uint32_t my_base = pcur[tid];
+      pcur[tid] = my_base + c;
+      gbase[tid] = my_base;
+      if constexpr (QUERY) a.q_tab[q_row + tid] = make_uint2(c, my_base);
+    }
+    if (wave == 0) { // exclusive scan of the (at most 256) bucket counts: 4 per lane
+      uint32_t c[4], s = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) {
+        c[i] = hist[lane * 4u + i];
+        s += c[i];
+      }
+      uint32_t incl = s;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += o;
+      }
+      uint32_t run = incl - s;
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) {
+        off[lane * 4u + i] = run;
+        run += c[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j)
+      if (where[j] != ~0u) sorted[off[where[j] >> 16] + (where[j] & 0xFFFFu)] = val[j];
+    __syncthreads();
+    bloom_copy_out_lines<BB_PART_THREADS / 64u, QUERY>(sorted, hist, off, gbase, left, lcnt, n_buckets, wave, lane, a.out, (uint64_t)blockIdx.x,
+                                                       (uint64_t)gridDim.x, 0ull, a.sl, a.shift, QUERY ? a.q_tovf + q_row : nullptr);
+    __syncthreads();
+  }
+  __syncthreads();
+  bloom_flush_lines<BB_PART_THREADS / 64u>(left, lcnt, pcur, n_buckets, wave, lane, tid, a.out, (uint64_t)blockIdx.x, (uint64_t)gridDim.x, a.sl.cap,
+                                           a.fill_out + (size_t)blockIdx.x * n_buckets);
+}
+
 // ---- apply: a workgroup per region -----------------------------------------------------------------------------------
 // dynamic LDS: 128 KiB.  entries = 20-bit offsets of the region's values.
 // (slots mode, cap != 0: region r's entries are all_entries[r * cap ... + min(fill[r], cap)); a failed round is left alone)

@@ -419,7 +419,9 @@ static __global__ __launch_bounds__(THREADS) void bloom_back1_stream_kernel(cons
       w[j] = idx < n_values ? __builtin_nontemporal_load(a.where + idx) : BQ_NONE;
     }
     const uint64_t row = tile * a.n_buckets;
-    bq_stage_runs<THREADS / 64u>(a.tab + row, a.n_buckets, a.pay_in, 0ull, 1ull, a.cap, stage, cnt, gat, offfit, tid, lane, wave);
+    // (pieces mode, g1 blocks at level 1: the tile was written by block tile % g1 into ITS piece of every bucket)
+    bq_stage_runs<THREADS / 64u>(a.tab + row, a.n_buckets, a.pay_in, a.g1 ? tile % a.g1 : 0ull, a.g1 ? (uint64_t)a.g1 : 1ull, a.cap, stage, cnt, gat,
+                                 offfit, tid, lane, wave);
 #pragma unroll
     for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
       const uint64_t idx = t0 + (uint64_t)j * THREADS + tid;

@@ -496,19 +496,23 @@ int bloom_slots_round(nthip_ctx* c, const BloomFusedSrc* fused, const uint64_t* 
 // ---- pieces mode (bloom_binned_kernels.hpp): a two-level round of device-resident fixed-length reads, the lists as
 // block-private pieces written in whole lines -- no cursors, no atomics.  *outcome as bloom_slots_round, and 4: not a shape /
 // table of this mode (nothing done)
-int bloom_pieces_round(nthip_ctx* c, const BloomFusedSrc& src, uint32_t* d_table, uint64_t n_slots, bool counters, int* outcome, uint64_t* lost)
+// (stream != NULL: the n_stream values of a hash stream instead of reads -- level 1 is bloom_part_stream_pieces_kernel)
+int bloom_pieces_round(nthip_ctx* c, const BloomFusedSrc* srcp, const uint64_t* stream, uint64_t n_stream, uint32_t* d_table, uint64_t n_slots,
+                       bool counters, int* outcome, uint64_t* lost)
 {
+  constexpr uint32_t S1_THREADS = 1024, S1_TILE = S1_THREADS * BB_PART_ITEMS;
+  const BloomFusedSrc src = srcp ? *srcp : BloomFusedSrc{};
   const uint32_t region_shift = counters ? CS_REGION_SHIFT : BB_REGION_SHIFT, bin_shift = region_shift + 7u;
   const uint32_t n_regions = (uint32_t)((n_slots + (1ull << region_shift) - 1) >> region_shift);
   const uint32_t n_bins = (n_regions + BB_REGIONS_PER_BIN - 1) / BB_REGIONS_PER_BIN;
   *outcome = 4;
   if (n_bins < 2 || c->tune.bloom_pieces == 2) return NTHIP_OK;
-  const size_t lds1 = bloom_fused_lds(src, 1024u, 1024u * 16u + BB_PIECES_LDS_DWORDS);
+  const size_t lds1 = stream ? ((size_t)S1_TILE + (size_t)BB_MAX_BINS * 32u) * sizeof(uint32_t) : bloom_fused_lds(src, 1024u, 1024u * 16u + BB_PIECES_LDS_DWORDS);
   if (lds1 > lds_cap_of(c) - 4096) return NTHIP_OK;
   const uint64_t magic = bloom_magic_of(n_slots);
   const uint64_t table_dwords = counters ? (n_slots + 3) / 4 : (n_slots + 31) / 32;
-  const uint32_t nwin = src.len - src.k + 1u;
-  const uint64_t n = src.n_reads * (uint64_t)nwin * src.m;
+  const uint32_t nwin = stream ? 0u : src.len - src.k + 1u;
+  const uint64_t n = stream ? n_stream : src.n_reads * (uint64_t)nwin * src.m;
   constexpr uint32_t L2_TILE = BB_L2_THREADS * BB_PART_ITEMS;
   const size_t lds2 = ((size_t)L2_TILE + (size_t)BB_REGIONS_PER_BIN * 32u) * sizeof(uint32_t);
   int l2_per_cu = 1;
@@ -516,7 +520,19 @@ int bloom_pieces_round(nthip_ctx* c, const BloomFusedSrc& src, uint32_t* d_table
   const uint32_t l2_grid = 2u * (uint32_t)c->n_cu * (uint32_t)l2_per_cu;
   const uint32_t gx = l2_grid / n_bins ? l2_grid / n_bins : 1u;
   PiecesGeo g;
-  pieces_geo(c, src.n_reads, (uint64_t)nwin * src.m, n_slots, region_shift, gx, &g);
+  if (stream) { // a block of level 1 takes every g1-th tile of the stream
+    int per1 = 1;
+    NTCHK(blocks_per_cu(c, bloom_part_stream_pieces_kernel<S1_THREADS, false>, (int)S1_THREADS, lds1, &per1));
+    const uint64_t tiles1 = (n + S1_TILE - 1) / S1_TILE;
+    g.g1 = (uint32_t)std::min<uint64_t>(tiles1 ? tiles1 : 1, (uint64_t)c->n_cu * (uint64_t)per1);
+    g.gx = gx;
+    const double per_block = (double)((tiles1 + g.g1 - 1) / g.g1) * (double)S1_TILE;
+    const double bin_slots = (double)(1ull << bin_shift), region_slots = (double)(1ull << region_shift);
+    g.cap1 = piece_cap(c, per_block * (bin_slots < (double)n_slots ? bin_slots / (double)n_slots : 1.0));
+    g.cap2 = piece_cap(c, (double)((g.g1 + gx - 1) / gx) * per_block * (region_slots < (double)n_slots ? region_slots / (double)n_slots : 1.0));
+  } else {
+    pieces_geo(c, src.n_reads, (uint64_t)nwin * src.m, n_slots, region_shift, gx, &g);
+  }
   const uint64_t ovf_cap = c->tune.bloom_slot_tight == 2 ? 64 : (n / 64 < 65536 ? 65536 : n / 64);
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t o_fill1 = 256, o_fill2 = o_fill1 + al((size_t)g.g1 * n_bins * 4), o_l1 = o_fill2 + al((size_t)n_bins * gx * BB_REGIONS_PER_BIN * 4);
@@ -541,8 +557,24 @@ int bloom_pieces_round(nthip_ctx* c, const BloomFusedSrc& src, uint32_t* d_table
   uint32_t* const list2 = (uint32_t*)(c->bloom_tmp + o_l2);
   uint64_t* const ovf = (uint64_t*)(c->bloom_tmp + o_ovf);
   HIPCHK(hipMemsetAsync(status, 0, 256, c->stream));
-  prof_begin(c, counters ? "count fused insert, pieces (part, part, apply)" : "bloom fused insert, pieces (part, part, apply)");
-  {
+  prof_begin(c, stream ? (counters ? "count binned insert, pieces (part, part, apply)" : "bloom binned insert, pieces (part, part, apply)")
+                       : (counters ? "count fused insert, pieces (part, part, apply)" : "bloom fused insert, pieces (part, part, apply)"));
+  if (stream) {
+    BloomPartStreamPiecesArgs a;
+    memset((void*)&a, 0, sizeof a);
+    a.in = stream;
+    a.n = n;
+    a.n_bits = n_slots;
+    a.magic = magic;
+    a.out = list1;
+    a.fill_out = fill1;
+    a.shift = bin_shift;
+    a.mask = (1u << bin_shift) - 1u;
+    a.n_buckets = n_bins;
+    a.sl = {g.cap1, ovf, status, ovf_cap};
+    NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<S1_THREADS, false>, lds1));
+    hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<S1_THREADS, false>), dim3(g.g1), dim3(S1_THREADS), lds1, c->stream, a);
+  } else {
     BloomFusedPiecesArgs fa;
     bloom_fused_args(src, 1024u, n_slots, magic, &fa);
     fa.lost = &status->lost;
@@ -602,7 +634,7 @@ int bloom_pieces_round(nthip_ctx* c, const BloomFusedSrc& src, uint32_t* d_table
   memcpy(&st, c->h_small + 64, sizeof st);
   *outcome = st.ovf_n > ovf_cap ? 2 : 0;
   if (*outcome == 2) c->bloom_slots_backoff = BB_SLOTS_BACKOFF;
-  *lost = st.lost;
+  if (lost) *lost = st.lost;
   return NTHIP_OK;
 }
 
@@ -622,7 +654,7 @@ int fused_slots_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t
     const BloomFusedSrc src = {(const uint8_t*)rd->seqs + *r0 * stride, nr, len, stride, k, m};
     int outcome = 0;
     uint64_t lost = 0;
-    NTCHK(bloom_pieces_round(c, src, d_table, n_slots, counters, &outcome, &lost)); // (round 5: two-level tables)
+    NTCHK(bloom_pieces_round(c, &src, nullptr, 0, d_table, n_slots, counters, &outcome, &lost)); // (round 5: two-level tables)
     if (outcome == 4) NTCHK(bloom_slots_round(c, &src, nullptr, nr * per_read, d_table, n_slots, counters, &outcome, &lost));
     if (outcome) return NTHIP_OK;
     *sum += nr * (uint64_t)(len - k + 1) - lost;
@@ -643,8 +675,9 @@ int stream_slots_rounds(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_value
   const uint64_t round = slots_round_values(c, n_values);
   while (*done < n_values) {
     const uint64_t nn = n_values - *done < round ? n_values - *done : round;
-    int outcome = 0;
-    NTCHK(bloom_slots_round(c, nullptr, d_hashes + *done, nn, d_table, n_slots, counters, &outcome));
+    int outcome = 4;
+    NTCHK(bloom_pieces_round(c, nullptr, d_hashes + *done, nn, d_table, n_slots, counters, &outcome, nullptr)); // (round 5: two-level tables)
+    if (outcome == 4) NTCHK(bloom_slots_round(c, nullptr, d_hashes + *done, nn, d_table, n_slots, counters, &outcome));
     if (outcome) break;
     *done += nn;
   }

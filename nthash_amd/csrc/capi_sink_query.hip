@@ -452,6 +452,12 @@ int ntamd::host::answers_hits_per_read(nthip_ctx* c, const uint8_t* d_ans, const
   return NTHIP_OK;
 }
 
+#ifndef SQ_L1_THREADS
+#define SQ_L1_THREADS 512 // slots mode (1024 threads with the query's records: 28 B of scratch; 512 held to 128 VGPRs: 20 B)
+#endif
+#ifndef SQ_PIECES_THREADS
+#define SQ_PIECES_THREADS 1024 // pieces mode
+#endif
 int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, const uint32_t* d_table, uint64_t n_slots, int kind,
                                      uint8_t* d_ans, bool* done)
 {
@@ -466,18 +472,33 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
     const uint8_t* const h0 = (const uint8_t*)d_hashes; // (the stream must not live in the buffer the lists are carved from)
     if (c->bloom_tmp && h0 < c->bloom_tmp + c->bloom_tmp_bytes && h0 + n_values * 8 > c->bloom_tmp) return NTHIP_OK;
   }
-#ifndef SQ_L1_THREADS
-#define SQ_L1_THREADS 512 // (1024 threads with the query's records: 28 B of scratch; 512 held to 128 VGPRs: 20 B)
-#endif
   constexpr uint32_t L1_THREADS = SQ_L1_THREADS, L1_TILE = L1_THREADS * BB_PART_ITEMS;
+  constexpr uint32_t P1_THREADS = SQ_PIECES_THREADS, P1_TILE = P1_THREADS * BB_PART_ITEMS;
   const uint64_t magic = bloom_magic_of(n_slots);
   const uint64_t table_dwords = kind == BQ_BLOOM ? (n_slots + 31) / 32 : (n_slots + 3) / 4;
   const uint32_t shift1 = g.one ? g.region_shift : g.bin_shift, buckets1 = g.one ? g.n_regions : g.n_bins;
-  // values per round: ~19 B of scratch per value
+  // pieces mode (a two-level table): block-private pieces at both levels, whole lines only (bloom_binned_kernels.hpp)
+  bool pieces = !g.one && c->tune.bloom_pieces != 2;
+  const size_t p1_lds = ((size_t)P1_TILE + (size_t)BB_MAX_BINS * 32u) * sizeof(uint32_t);
+  const size_t p2_lds = ((size_t)BQ_L2_TILE + (size_t)BB_REGIONS_PER_BIN * 32u) * sizeof(uint32_t);
+  uint32_t g1_max = 1, gx = 1;
+  if (pieces) {
+    int per1 = 1, per2 = 1;
+    if (p1_lds + 4096 > lds_cap_of(c) || blocks_per_cu(c, bloom_part_stream_pieces_kernel<P1_THREADS, true>, (int)P1_THREADS, p1_lds, &per1) != NTHIP_OK ||
+        blocks_per_cu(c, bloom_part_pieces_kernel<BQ_L2_THREADS, true>, (int)BQ_L2_THREADS, p2_lds, &per2) != NTHIP_OK) {
+      (void)hipGetLastError();
+      pieces = false;
+    } else {
+      g1_max = (uint32_t)c->n_cu * (uint32_t)per1;
+      const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per2;
+      gx = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
+    }
+  }
+  // values per round: ~22 B of scratch per value
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
   free_b += c->bloom_tmp_bytes;
-  uint64_t round = (uint64_t)(free_b / 10 * 8) / 22;
+  uint64_t round = (uint64_t)(free_b / 10 * 8) / 24;
   if (round > BQ_ROUND_MAX) round = BQ_ROUND_MAX;
   if (c->tune.bloom_round) round = c->tune.bloom_round;
   if (round > n_values) round = n_values;
@@ -489,18 +510,41 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
     uint2 *tab1, *tab2;
     uint8_t *pay1, *pay2, *ovf_pay;
     uint64_t cap1, cap2, ovf_cap;
-    uint32_t tiles_per_seg;
-    size_t head;
+    uint32_t tiles_per_seg, g1;
+    size_t head, clear;
   } q;
   auto carve = [&](uint64_t n, size_t* need) -> bool {
-    q.cap1 = g.one ? 0 : slot_cap(c, n, 1ull << g.bin_shift, n_slots);
-    q.cap2 = slot_cap(c, n, 1ull << g.region_shift, n_slots);
+    size_t slots1, slots2, fills1, fills2;
+    uint64_t tiles1, rows2;
+    if (pieces) {
+      tiles1 = (n + P1_TILE - 1) / P1_TILE;
+      q.g1 = (uint32_t)std::min<uint64_t>(tiles1, g1_max);
+      const double per_block = (double)((tiles1 + q.g1 - 1) / q.g1) * (double)P1_TILE; // what a level-1 block may see
+      const double bin_slots = (double)(1ull << g.bin_shift), region_slots = (double)(1ull << g.region_shift);
+      q.cap1 = piece_cap(c, per_block * (bin_slots < (double)n_slots ? bin_slots / (double)n_slots : 1.0));
+      q.cap2 = piece_cap(c, (double)((q.g1 + gx - 1) / gx) * per_block * (region_slots < (double)n_slots ? region_slots / (double)n_slots : 1.0));
+      q.tiles_per_seg = (uint32_t)((q.cap1 + BQ_L2_TILE - 1) / BQ_L2_TILE); // (tile rows per PIECE)
+      slots1 = (size_t)g.n_bins * q.g1 * q.cap1;
+      slots2 = (size_t)g.n_regions * gx * q.cap2;
+      fills1 = (size_t)q.g1 * g.n_bins;
+      fills2 = (size_t)g.n_bins * gx * BB_REGIONS_PER_BIN;
+      rows2 = (uint64_t)g.n_bins * q.g1 * q.tiles_per_seg;
+    } else {
+      tiles1 = (n + L1_TILE - 1) / L1_TILE;
+      q.g1 = 0;
+      q.cap1 = g.one ? 0 : slot_cap(c, n, 1ull << g.bin_shift, n_slots);
+      q.cap2 = slot_cap(c, n, 1ull << g.region_shift, n_slots);
+      q.tiles_per_seg = (uint32_t)((q.cap1 + BQ_L2_TILE - 1) / BQ_L2_TILE);
+      slots1 = (size_t)g.n_bins * q.cap1;
+      slots2 = (size_t)g.n_regions * q.cap2;
+      fills1 = (size_t)g.n_bins * BB_CURSOR_STRIDE;
+      fills2 = (size_t)g.n_regions * BB_CURSOR_STRIDE;
+      rows2 = g.one ? 0 : (uint64_t)g.n_bins * q.tiles_per_seg;
+    }
     q.ovf_cap = n / 64 < 65536 ? 65536 : n / 64;
     if (c->tune.bloom_slot_tight == 2) q.ovf_cap = 64;
-    q.tiles_per_seg = (uint32_t)((q.cap1 + BQ_L2_TILE - 1) / BQ_L2_TILE);
-    const uint64_t tiles1 = (n + L1_TILE - 1) / L1_TILE, rows2 = g.one ? 0 : (uint64_t)g.n_bins * q.tiles_per_seg;
-    const size_t slots1 = (size_t)g.n_bins * q.cap1, slots2 = (size_t)g.n_regions * q.cap2;
-    q.head = 256 + (size_t)(g.n_bins + g.n_regions) * BB_CURSOR_STRIDE * sizeof(uint32_t);
+    q.head = 256 + (fills1 + fills2) * sizeof(uint32_t);
+    q.clear = pieces ? 256 : q.head; // (the pieces' fill arrays are written whole by the kernels)
     size_t off = 0;
     auto take = [&](size_t bytes) {
       const size_t at = off;
@@ -517,7 +561,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
     uint8_t* const b = c->bloom_tmp;
     q.status = (BloomStatus*)(b + o_head);
     q.cur1 = (uint32_t*)(b + o_head + 256);
-    q.cur2 = q.cur1 + (size_t)g.n_bins * BB_CURSOR_STRIDE;
+    q.cur2 = q.cur1 + fills1;
     q.list1 = (uint32_t*)(b + o_l1);
     q.list2 = (uint32_t*)(b + o_l2);
     q.ovf = (uint64_t*)(b + o_ovf);
@@ -552,69 +596,110 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
     size_t need = 0;
     if (!carve(n, &need)) return fail(NTHIP_ERR_HIP, "the lists of a smaller round do not fit the buffer of a larger one");
     const uint64_t capL1 = g.one ? q.cap2 : q.cap1;
-    HIPCHK(hipMemsetAsync(q.status, 0, q.head, c->stream));
+    HIPCHK(hipMemsetAsync(q.status, 0, q.clear, c->stream));
     prof_begin(c, kind == BQ_BLOOM ? "bloom binned stream query (part, part, lookup, back, back)" : "count binned stream query (part, part, lookup, back, back)");
-    { // forward, level 1: the stream's values
-      BloomPartQueryArgs a;
+    if (pieces) { // forward, level 1: the stream's values into the blocks' pieces of the bins
+      BloomPartStreamPiecesArgs a;
       memset((void*)&a, 0, sizeof a);
       a.in = d_hashes + v0;
       a.n = n;
       a.n_bits = n_slots;
       a.magic = magic;
-      a.n_regions = g.n_regions;
-      a.out = g.one ? q.list2 : q.list1;
-      a.cursor = g.one ? q.cur2 : q.cur1;
-      a.shift = shift1;
-      a.mask = (1u << shift1) - 1u;
-      a.buckets_per_seg = buckets1;
-      a.sl = {capL1, q.ovf, q.status, q.ovf_cap};
+      a.out = q.list1;
+      a.fill_out = q.cur1;
+      a.shift = g.bin_shift;
+      a.mask = (1u << g.bin_shift) - 1u;
+      a.n_buckets = g.n_bins;
+      a.sl = {q.cap1, q.ovf, q.status, q.ovf_cap};
       a.q_where = q.where1;
       a.q_tab = q.tab1;
       a.q_tovf = q.tovf1;
-      a.q_tiles_per_seg = (uint32_t)((n + L1_TILE - 1) / L1_TILE);
-      const size_t lds = (size_t)L1_TILE * sizeof(uint32_t);
-      NTCHK(set_max_lds(c, bloom_part_kernel<true, L1_THREADS, true>, lds));
-      hipLaunchKernelGGL((bloom_part_kernel<true, L1_THREADS, true>), dim3((unsigned)c->n_cu * (2048u / L1_THREADS)), dim3(L1_THREADS), lds, c->stream, a);
-    }
-    if (!g.one) { // level 2
-      BloomPartQueryArgs a;
-      memset((void*)&a, 0, sizeof a);
-      a.n_bits = n_slots;
-      a.magic = magic;
-      a.n_regions = g.n_regions;
-      a.in = q.list1;
-      a.out = q.list2;
-      a.cursor = q.cur2;
-      a.shift = g.region_shift;
-      a.mask = (1u << g.region_shift) - 1u;
-      a.buckets_per_seg = BB_REGIONS_PER_BIN;
-      a.sl = {q.cap2, q.ovf, q.status, q.ovf_cap};
-      a.cap_in = q.cap1;
-      a.seg_fill = q.cur1;
-      a.q_where = q.where2;
-      a.q_tab = q.tab2;
-      a.q_tovf = q.tovf2;
-      a.q_tiles_per_seg = q.tiles_per_seg;
-      const size_t lds = (size_t)BQ_L2_TILE * sizeof(uint32_t);
-      int per_cu = 1;
-      NTCHK(blocks_per_cu(c, bloom_part_kernel<false, BQ_L2_THREADS, true>, (int)BQ_L2_THREADS, lds, &per_cu));
-      const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
-      const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
-      hipLaunchKernelGGL((bloom_part_kernel<false, BQ_L2_THREADS, true>), dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), lds, c->stream, a);
+      NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<P1_THREADS, true>, p1_lds));
+      hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<P1_THREADS, true>), dim3(q.g1), dim3(P1_THREADS), p1_lds, c->stream, a);
+      BloomPartPiecesArgs a2; // level 2: every bin's pieces to the blocks' pieces of its regions
+      memset(&a2, 0, sizeof a2);
+      a2.in = q.list1;
+      a2.out = q.list2;
+      a2.fill_in = q.cur1;
+      a2.fill_out = q.cur2;
+      a2.cap_in = q.cap1;
+      a2.n_pieces_in = q.g1;
+      a2.in_buckets = g.n_bins;
+      a2.n_regions = g.n_regions;
+      a2.shift = g.region_shift;
+      a2.mask = (1u << g.region_shift) - 1u;
+      a2.buckets_per_seg = BB_REGIONS_PER_BIN;
+      a2.sl = {q.cap2, q.ovf, q.status, q.ovf_cap};
+      a2.q_where = q.where2;
+      a2.q_tab = q.tab2;
+      a2.q_tovf = q.tovf2;
+      a2.q_tiles_per_piece = q.tiles_per_seg;
+      NTCHK(set_max_lds(c, bloom_part_pieces_kernel<BQ_L2_THREADS, true>, p2_lds));
+      hipLaunchKernelGGL((bloom_part_pieces_kernel<BQ_L2_THREADS, true>), dim3(gx, g.n_bins), dim3(BQ_L2_THREADS), p2_lds, c->stream, a2);
+    } else {
+      { // forward, level 1: the stream's values behind shared cursors
+        BloomPartQueryArgs a;
+        memset((void*)&a, 0, sizeof a);
+        a.in = d_hashes + v0;
+        a.n = n;
+        a.n_bits = n_slots;
+        a.magic = magic;
+        a.n_regions = g.n_regions;
+        a.out = g.one ? q.list2 : q.list1;
+        a.cursor = g.one ? q.cur2 : q.cur1;
+        a.shift = shift1;
+        a.mask = (1u << shift1) - 1u;
+        a.buckets_per_seg = buckets1;
+        a.sl = {capL1, q.ovf, q.status, q.ovf_cap};
+        a.q_where = q.where1;
+        a.q_tab = q.tab1;
+        a.q_tovf = q.tovf1;
+        a.q_tiles_per_seg = (uint32_t)((n + L1_TILE - 1) / L1_TILE);
+        const size_t lds = (size_t)L1_TILE * sizeof(uint32_t);
+        NTCHK(set_max_lds(c, bloom_part_kernel<true, L1_THREADS, true>, lds));
+        hipLaunchKernelGGL((bloom_part_kernel<true, L1_THREADS, true>), dim3((unsigned)c->n_cu * (2048u / L1_THREADS)), dim3(L1_THREADS), lds, c->stream, a);
+      }
+      if (!g.one) { // level 2
+        BloomPartQueryArgs a;
+        memset((void*)&a, 0, sizeof a);
+        a.n_bits = n_slots;
+        a.magic = magic;
+        a.n_regions = g.n_regions;
+        a.in = q.list1;
+        a.out = q.list2;
+        a.cursor = q.cur2;
+        a.shift = g.region_shift;
+        a.mask = (1u << g.region_shift) - 1u;
+        a.buckets_per_seg = BB_REGIONS_PER_BIN;
+        a.sl = {q.cap2, q.ovf, q.status, q.ovf_cap};
+        a.cap_in = q.cap1;
+        a.seg_fill = q.cur1;
+        a.q_where = q.where2;
+        a.q_tab = q.tab2;
+        a.q_tovf = q.tovf2;
+        a.q_tiles_per_seg = q.tiles_per_seg;
+        const size_t lds = (size_t)BQ_L2_TILE * sizeof(uint32_t);
+        int per_cu = 1;
+        NTCHK(blocks_per_cu(c, bloom_part_kernel<false, BQ_L2_THREADS, true>, (int)BQ_L2_THREADS, lds, &per_cu));
+        const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
+        const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
+        hipLaunchKernelGGL((bloom_part_kernel<false, BQ_L2_THREADS, true>), dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), lds, c->stream, a);
+      }
     }
     { // lookup
       const size_t lds = (size_t)BB_REGION_DWORDS * sizeof(uint32_t);
       const uint32_t grid = g.n_regions < (uint32_t)c->n_cu ? g.n_regions : (uint32_t)c->n_cu;
+      const uint32_t np = pieces ? gx : 0u;
       if (kind == BQ_BLOOM) {
         NTCHK(set_max_lds(c, bloom_lookup_kernel<BQ_BLOOM>, lds));
         hipLaunchKernelGGL(bloom_lookup_kernel<BQ_BLOOM>, dim3(grid), dim3(BQ_LOOKUP_THREADS), lds, c->stream, (const uint32_t*)q.list2,
-                           (const uint32_t*)q.cur2, q.cap2, g.n_regions, d_table, table_dwords, q.pay2, 0u, (uint32_t)BB_REGIONS_PER_BIN);
+                           (const uint32_t*)q.cur2, q.cap2, g.n_regions, d_table, table_dwords, q.pay2, np, (uint32_t)BB_REGIONS_PER_BIN);
         hipLaunchKernelGGL(bloom_ovf_lookup_kernel<BQ_BLOOM>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)q.ovf,
                            (const BloomStatus*)q.status, q.ovf_cap, d_table, q.ovf_pay);
       } else {
         NTCHK(set_max_lds(c, bloom_lookup_kernel<BQ_COUNT>, lds));
         hipLaunchKernelGGL(bloom_lookup_kernel<BQ_COUNT>, dim3(grid), dim3(BQ_LOOKUP_THREADS), lds, c->stream, (const uint32_t*)q.list2,
-                           (const uint32_t*)q.cur2, q.cap2, g.n_regions, d_table, table_dwords, q.pay2, 0u, (uint32_t)BB_REGIONS_PER_BIN);
+                           (const uint32_t*)q.cur2, q.cap2, g.n_regions, d_table, table_dwords, q.pay2, np, (uint32_t)BB_REGIONS_PER_BIN);
         hipLaunchKernelGGL(bloom_ovf_lookup_kernel<BQ_COUNT>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)q.ovf,
                            (const BloomStatus*)q.status, q.ovf_cap, d_table, q.ovf_pay);
       }
@@ -637,10 +722,19 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
       b.buckets_per_seg = BB_REGIONS_PER_BIN;
       b.tiles_per_seg = q.tiles_per_seg;
       int per_cu = 1;
-      NTCHK(blocks_per_cu(c, bloom_back2_kernel<BQ_L2_THREADS>, (int)BQ_L2_THREADS, 0, &per_cu));
+      if (pieces) {
+        b.fill_in = q.cur1;
+        b.n_pieces_in = q.g1;
+        b.in_buckets = g.n_bins;
+        b.gx = gx;
+        NTCHK(blocks_per_cu(c, bloom_back2_pieces_kernel<BQ_L2_THREADS>, (int)BQ_L2_THREADS, 0, &per_cu));
+      } else {
+        NTCHK(blocks_per_cu(c, bloom_back2_kernel<BQ_L2_THREADS>, (int)BQ_L2_THREADS, 0, &per_cu));
+      }
       const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
       const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
-      hipLaunchKernelGGL(bloom_back2_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
+      if (pieces) hipLaunchKernelGGL(bloom_back2_pieces_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
+      else hipLaunchKernelGGL(bloom_back2_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
     }
     b.where = q.where1;
     b.tab = q.tab1;
@@ -648,12 +742,20 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
     b.pay_in = g.one ? q.pay2 : q.pay1;
     b.cap = capL1;
     b.n_buckets = buckets1;
+    b.g1 = q.g1;
     {
       int per_cu = 1;
-      NTCHK(blocks_per_cu(c, bloom_back1_stream_kernel<L1_THREADS>, (int)L1_THREADS, 0, &per_cu));
-      const uint64_t tiles = (n + L1_TILE - 1) / L1_TILE;
-      const uint64_t grid = std::min<uint64_t>(tiles, (uint64_t)c->n_cu * (uint64_t)per_cu);
-      hipLaunchKernelGGL(bloom_back1_stream_kernel<L1_THREADS>, dim3((unsigned)grid), dim3(L1_THREADS), 0, c->stream, b, n, d_ans + v0);
+      if (pieces) {
+        NTCHK(blocks_per_cu(c, bloom_back1_stream_kernel<P1_THREADS>, (int)P1_THREADS, 0, &per_cu));
+        const uint64_t tiles = (n + P1_TILE - 1) / P1_TILE;
+        const uint64_t grid = std::min<uint64_t>(tiles, (uint64_t)c->n_cu * (uint64_t)per_cu);
+        hipLaunchKernelGGL(bloom_back1_stream_kernel<P1_THREADS>, dim3((unsigned)grid), dim3(P1_THREADS), 0, c->stream, b, n, d_ans + v0);
+      } else {
+        NTCHK(blocks_per_cu(c, bloom_back1_stream_kernel<L1_THREADS>, (int)L1_THREADS, 0, &per_cu));
+        const uint64_t tiles = (n + L1_TILE - 1) / L1_TILE;
+        const uint64_t grid = std::min<uint64_t>(tiles, (uint64_t)c->n_cu * (uint64_t)per_cu);
+        hipLaunchKernelGGL(bloom_back1_stream_kernel<L1_THREADS>, dim3((unsigned)grid), dim3(L1_THREADS), 0, c->stream, b, n, d_ans + v0);
+      }
     }
     prof_end(c);
     HIPCHK(hipGetLastError());

@@ -44,7 +44,10 @@ def _last_name(ctx):
 
 @pytest.mark.parametrize("n,L,k,m,n_bits,env,binned", [
     (6000, 150, 31, 1, (1 << 22) + 77, {}, True),                                   # 5 regions, one bin: level 1 goes to the regions
-    (6000, 150, 31, 3, (1 << 28) + 12_345_677, {}, True),                           # 3 bins: two levels; m = 3: answers -> flags
+    (6000, 150, 31, 3, (1 << 28) + 12_345_677, {}, True),                           # 3 bins: two levels, pieces; m = 3: answers -> flags
+    (6000, 150, 31, 3, (1 << 28) + 12_345_677, {"NTHIP_TUNE_BLOOM_PIECES": 2}, True),  # ... behind shared cursors
+    (6000, 150, 31, 1, (1 << 30) + 5, {"NTHIP_TUNE_BLOOM_SLOT_TIGHT": 1, "NTHIP_TUNE_BLOOM_PIECES": 2}, True),
+    (40000, 150, 31, 1, (1 << 33) + 12_345, {}, True),                              # 65 bins, 4.7 M values: pieces of every bin per block
     (6000, 150, 31, 2, 1 << 29, {"NTHIP_TUNE_BLOOM_SLOT_TIGHT": 1}, True),          # buckets of the mean: the overflow list on the way out and back
     (6000, 150, 31, 2, 1 << 24, {"NTHIP_TUNE_BLOOM_ROUND": 200_000}, True),         # several rounds of values
     (6000, 150, 31, 2, 1 << 29, {"NTHIP_TUNE_BLOOM_SLOT_TIGHT": 2}, False),         # the overflow list overflows: the direct kernel answers
@@ -92,7 +95,8 @@ def test_stream_bloom_query_binned_flags(oracle, n, L, k, m, n_bits, env, binned
 
 @pytest.mark.parametrize("n,L,k,m,n_counters,env", [
     (6000, 150, 31, 1, (1 << 19) + 4, {}),                                # 5 regions of 2^17 counters
-    (6000, 150, 31, 3, (1 << 25) + 40, {}),                               # 3 bins
+    (6000, 150, 31, 3, (1 << 25) + 40, {}),                               # 3 bins: pieces
+    (6000, 150, 31, 3, (1 << 25) + 40, {"NTHIP_TUNE_BLOOM_PIECES": 2}),   # ... shared cursors
     (6000, 150, 31, 2, 1 << 26, {"NTHIP_TUNE_BLOOM_SLOT_TIGHT": 1}),
     (6000, 150, 31, 4, 1 << 22, {"NTHIP_TUNE_BLOOM_ROUND": 300_000}),
 ])
@@ -179,7 +183,8 @@ def test_bloom_query_of_reads_by_offsets_through_the_regions(oracle, m, n_bits, 
     ctx.close()
 
 
-@pytest.mark.parametrize("by_offsets,env", [(False, {}), (True, {}), (False, {"NTHIP_TUNE_BLOOM_ROUND": 400_000})])
+@pytest.mark.parametrize("by_offsets,env", [(False, {}), (True, {}), (False, {"NTHIP_TUNE_BLOOM_ROUND": 400_000}),
+                                            (False, {"NTHIP_TUNE_BLOOM_PIECES": 2}), (True, {"NTHIP_TUNE_BLOOM_SLOT_TIGHT": 1, "NTHIP_TUNE_BLOOM_PIECES": 2})])
 def test_seed_bloom_query_through_the_regions(oracle, by_offsets, env):
     """nthip_seed_bloom_query with the answers of the seeds' hashes coming through the regions: hits per read == the windows
     whose n_seeds * m2 hashes (oracle's seed_batch stream) all hit a filter built on the CPU"""
