@@ -38,7 +38,7 @@ SEED_A = "1010101010101010101010101010101"
 SEED_B = "1101101101101101011011011011011"
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 SHARD_READS_MULTI = 125_000_000  # BASELINE config 5: 1 G reads over 8 GPUs
-TRAFFIC_FILE = "profiles/r04_traffic.json"
+TRAFFIC_FILE = "profiles/r05_traffic.json"
 
 CONFIGS = {
     # name: description, read length, k, hashes per k-mer (m, or m per seed), default reads per GPU
@@ -631,7 +631,8 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
         win4 = n4 * (L4 - 31 + 1)
         out["seed_bloom_insert_c4_seeds"] = {"value": tot4 / t_s4, "ms": t_s4 * 1e3, "unit": "windows/s (6 hashes each)", "values_per_s": 6 * tot4 / t_s4,
                                              "check": "every window is consumed and found again", "ok": bool(tot4 == win4 and tq4 == win4 and found4 == win4),
-                                             "query": {"value": tq4 / t_sq, "ms": t_sq * 1e3},
+                                             "query": {"value": tq4 / t_sq, "ms": t_sq * 1e3, "values_per_s": 6 * tq4 / t_sq,
+                                                       "how": "the seeds' hashes through the regions of the filter (stream_query_binned)"},
                                              "roofline": roof(n4 * L4 + 2 * (n_bits4 // 8), t_s4, "bases in + the filter read and written once")}
         sd.close()
         for p in (d_in4, d_f4):
@@ -1012,7 +1013,8 @@ def main():
             q = res["consumers"].get("bloom_query_4GiB", {})
             summ["query"] = {"binned_G": g(q.get("value")), "direct_G": g(q.get("direct_kernel", {}).get("value")),
                              "list_traffic_GBps": f3(q.get("roofline", {}).get("list_traffic", {}).get("GBps")),
-                             "m3_x_m1": f3(res["consumers"].get("bloom_query_4GiB_m3", {}).get("x_m1"))}
+                             "m3_x_m1": f3(res["consumers"].get("bloom_query_4GiB_m3", {}).get("x_m1")),
+                             "seed_query_G": g(res["consumers"].get("seed_bloom_insert_c4_seeds", {}).get("query", {}).get("value"))}
         if isinstance(res.get("cpu_baseline"), dict):
             cb = res["cpu_baseline"]
             summ["cpu"] = {"kind": cb.get("kind"), "one_core_M": None if cb.get("value") is None else round(cb["value"] / 1e6, 1),

@@ -23,6 +23,11 @@ names = {  # scratch name -> tracked name
     "extend_bench.txt": f"{tag}_extend_bench.txt",
     "facade_bench.txt": f"{tag}_facade_bench.txt",
     "shape_sweep.txt": f"{tag}_shape_sweep.txt",
+    "shape_sweep_long_k.txt": f"{tag}_shape_sweep_long_k.txt",
+    "stream_query_bench.txt": f"{tag}_stream_query_bench.txt",
+    "seed_insert_one.txt": f"{tag}_seed_insert_one.txt",
+    "kernel_stats_seed_insert.csv": f"{tag}_kernel_stats_seed_insert.csv",
+    "reads_kernel_ablation.txt": f"{tag}_reads_kernel_ablation.txt",
     "pytest_gpu.txt": f"{tag}_pytest_gpu.txt",
     "fastq_gz_bench.txt": f"{tag}_fastq_gz_bench.txt",
     "fasta_gz_bench.txt": f"{tag}_fasta_gz_bench.txt",

@@ -32,6 +32,12 @@ timeout 600 python tools/facade_bench.py > "$OUT/facade_bench.txt" 2>&1
 timeout 600 python tools/fastq_bench.py 10000000 256 1 kmers gz > "$OUT/fastq_gz_bench.txt" 2>&1
 timeout 600 python tools/fasta_bench.py 3000 24 gz > "$OUT/fasta_gz_bench.txt" 2>&1
 timeout 600 python tools/shape_sweep.py > "$OUT/shape_sweep.txt" 2>&1
+SWEEP_SHAPES="150,65,1;150,100,1;250,200,1;1000,500,1;150,80,2;300,128,1;10000,200,1;400,255,1;100,64,3;100,64,1;150,64,1" timeout 600 python tools/shape_sweep.py > "$OUT/shape_sweep_long_k.txt" 2>&1
+# round 5: hash STREAMS through the regions (stream / offsets / spaced-seed query, seed insert), and the reads kernel without its stores / its hashing
+timeout 600 python tools/stream_query_bench.py > "$OUT/stream_query_bench.txt" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_seed_insert" -o kt -- python tools/seed_insert_one.py > "$OUT/seed_insert_one.txt" 2>&1
+for f in $(find "$OUT/trace_seed_insert" -name "*kernel_stats.csv"); do cp "$f" "$OUT/kernel_stats_seed_insert.csv"; done
+if [ -f nthash_amd/lib/ab/libnthash_hip_rabl1.so ]; then timeout 300 python tools/ab_ragged.py rabl1,rabl2,rabl3 20000000 12 > "$OUT/reads_kernel_ablation.txt" 2>&1; fi
 timeout 2400 python -m pytest tests -q -m gpu > "$OUT/pytest_gpu.txt" 2>&1
 tail -3 "$OUT/pytest_gpu.txt"
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" >> "$OUT/pytest_gpu.txt" 2>&1
