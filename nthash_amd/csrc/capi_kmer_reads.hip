@@ -56,15 +56,15 @@ int ntamd::host::run_kmer_reads(nthip_ctx* c, const Staged& st, const uint64_t* 
     res[3] = shape->sum_len;
     res[4] = shape->sum_len; // (an upper bound: a window starts at a base)
   } else {
-    uint64_t blocks = (n + 255) / 256;
-    if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
+    uint64_t blocks = (n + READS_PREP_THREADS - 1) / READS_PREP_THREADS;
+    if (blocks > (uint64_t)c->n_cu * 2) blocks = (uint64_t)c->n_cu * 2;
     if (slots) {
       const uint64_t nt_guess = (n + R_guess - 1) / R_guess;
       NTCHK(ensure_scratch2(c, nt_guess + 16));
       d_guess = (unsigned long long*)c->d_scratch2;
       HIPCHK(hipMemsetAsync(d_guess, 0, nt_guess * sizeof(uint64_t), c->stream));
     }
-    hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n, total_bytes, d_res,
+    hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(READS_PREP_THREADS), 0, c->stream, d_starts, d_ends, n, total_bytes, d_res,
                        0u, R_guess, k, d_guess, (unsigned long long*)(c->d_small + 144));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_small + 96, d_res, 56, hipMemcpyDeviceToHost, c->stream));

@@ -244,9 +244,9 @@ int run_seed_reads(nthip_ctx* c, const Staged& st, const uint64_t* d_starts, con
   unsigned long long* d_ndirty = (unsigned long long*)(c->d_small + 128);
   HIPCHK(hipMemsetAsync(c->d_small + 96, 0, 48, c->stream));
   {
-    uint64_t blocks = (n + 255) / 256;
-    if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
-    hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_starts, d_ends, n, ~0ull, d_res, 1u);
+    uint64_t blocks = (n + READS_PREP_THREADS - 1) / READS_PREP_THREADS;
+    if (blocks > (uint64_t)c->n_cu * 2) blocks = (uint64_t)c->n_cu * 2;
+    hipLaunchKernelGGL(reads_prep_kernel, dim3((unsigned)blocks), dim3(READS_PREP_THREADS), 0, c->stream, d_starts, d_ends, n, ~0ull, d_res, 1u);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemcpyAsync(c->h_small + 96, d_res, 24, hipMemcpyDeviceToHost, c->stream));

@@ -698,7 +698,10 @@ static __global__ __launch_bounds__(256) void reads_tile_windows_kernel(const ui
 // max length, max distance between consecutive starts, order, total length: what the host needs to size the tiles
 // tile_sum != nullptr (NTHIP_OUT_READ_SLOTS): also the windows of every tile of R reads -- (len - k + 1 where len >= k),
 // summed per tile with a wave-level segmented scan and at most a few atomics per wave (tile_sum zeroed by the host)
-static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* __restrict__ starts,
+// (launched with READS_PREP_THREADS threads and at most two blocks per CU: the sums and maxima end in same-address atomics, ~40 ns
+// each one after the other -- 2048 blocks of 256 spent 0.16 of the kernel's 0.2 ms there)
+constexpr uint32_t READS_PREP_THREADS = 1024;
+static __global__ __launch_bounds__(READS_PREP_THREADS) void reads_prep_kernel(const uint64_t* __restrict__ starts,
                                                                 const uint64_t* __restrict__ ends, uint64_t n,
                                                                 uint64_t buf_bytes, unsigned long long* __restrict__ res,
                                                                 uint32_t allow_overlap = 0, uint32_t R = 0, uint32_t k = 0,
@@ -711,11 +714,35 @@ static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* 
   uint32_t bad = 0;
   const uint32_t lane = threadIdx.x & 63u;
   // (whole waves iterate together: the segmented scan below needs every lane of a wave in the loop)
-  for (uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); r0 < n; r0 += (uint64_t)gridDim.x * blockDim.x) {
+  // Round 5: the spans of the NEXT 64 reads are asked for before this wave's are looked at, and a read's successor comes from
+  // the neighbouring lane (lane 63 loads it): one iteration's loads in flight per wave and four load instructions per read
+  // made 0.19 ms of 320 MB of spans (1.7 TB/s).
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+  uint64_t s_nx = 0, e_nx = 0, s_tl = 0, e_tl = 0; // this lane's read of the iteration; lane 63: the read behind the wave's
+  auto fetch = [&](uint64_t base) {
+    const uint64_t r = base + lane;
+    s_nx = r < n ? starts[r] : 0;
+    e_nx = r < n ? ends[r] : 0;
+    if (lane == 63u && r + 1 < n) {
+      s_tl = starts[r + 1];
+      e_tl = ends[r + 1];
+    }
+  };
+  if (r0 < n) fetch(r0);
+  for (; r0 < n; r0 += stride) {
     const uint64_t r = r0 + lane;
+    const uint64_t s0 = s_nx, e0 = e_nx, st = s_tl, et = e_tl;
+    if (r0 + stride < n) fetch(r0 + stride);
+    // the read behind this lane's: the next lane's, or what lane 63 loaded
+    uint64_t s1 = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(s0 >> 32), 1, 64) << 32) | (uint32_t)__shfl_down((int)(uint32_t)s0, 1, 64);
+    uint64_t e1 = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(e0 >> 32), 1, 64) << 32) | (uint32_t)__shfl_down((int)(uint32_t)e0, 1, 64);
+    if (lane == 63u) {
+      s1 = st;
+      e1 = et;
+    }
     uint64_t nwin = 0;
     if (r < n) {
-      const uint64_t s0 = starts[r], e0 = ends[r];
       if (e0 < s0 || e0 > buf_bytes) {
         bad = 1; // (also what check_spans_kernel looks for)
       } else {
@@ -724,8 +751,7 @@ static __global__ __launch_bounds__(256) void reads_prep_kernel(const uint64_t* 
         nwin = e0 - s0 >= k ? e0 - s0 - k + 1u : 0u;
         wsum += nwin;
         if (r + 1 < n) {
-          const uint64_t s1 = starts[r + 1];
-          if (s1 < e0 && !(allow_overlap && s1 >= s0 && ends[r + 1] >= e0)) bad = 1; // not in order, or overlapping
+          if (s1 < e0 && !(allow_overlap && s1 >= s0 && e1 >= e0)) bad = 1; // not in order, or overlapping
           else if (s1 - s0 > mpitch) mpitch = s1 - s0;
         }
       }
