@@ -229,14 +229,33 @@ void kmer_reads_kernel(const KmerReadsArgs a)
         (void)pack4v(x.w, i3);
         ((uint16_t*)bits)[i] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
       };
+      // (round 5) a slab without any non-base -- all but a few per cent of the tiles of real reads, none of a FASTQ chunk's, whose
+      // header and quality lines lie between the spans -- needs no bits: the validity masks of the vectors in registers are
+      // OR-ed over the wave first, and only a slab that has one is staged and looked at read by read
+      uint16_t vm[RD_PF_ROUNDS ? RD_PF_ROUNDS : 1];
+      uint32_t vany = 0;
 #pragma unroll
       for (uint32_t rd = 0; rd < RD_PF_ROUNDS; ++rd) {
         const uint32_t i = rd * 64u + lane;
-        if (i < n_vec) mark_vec(i, pv[rd]);
+        uint32_t i0, i1, i2, i3;
+        (void)pack4v(pv[rd].x, i0);
+        (void)pack4v(pv[rd].y, i1);
+        (void)pack4v(pv[rd].z, i2);
+        (void)pack4v(pv[rd].w, i3);
+        vm[rd] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+        if (i < n_vec) vany |= vm[rd];
       }
-      for (uint32_t i = RD_PF_ROUNDS * 64u + lane; i < n_vec; i += 64u) mark_vec(i, *(const uint4*)(vbase + ((uint64_t)i << 4)));
-      if (lane < 4u) ((uint16_t*)bits)[n_vec + lane] = 0;
-      lds_sync();
+      const bool clean_slab = n_vec <= RD_PF_ROUNDS * 64u && __ballot(vany != 0u) == 0ull;
+      if (!clean_slab) {
+#pragma unroll
+        for (uint32_t rd = 0; rd < RD_PF_ROUNDS; ++rd) {
+          const uint32_t i = rd * 64u + lane;
+          if (i < n_vec) ((uint16_t*)bits)[i] = vm[rd];
+        }
+        for (uint32_t i = RD_PF_ROUNDS * 64u + lane; i < n_vec; i += 64u) mark_vec(i, *(const uint4*)(vbase + ((uint64_t)i << 4)));
+        if (lane < 4u) ((uint16_t*)bits)[n_vec + lane] = 0;
+        lds_sync();
+      }
       // ---- the next tile's slab and the spans of the tile after it: in flight during the rest of this tile ----
       if (have_next) {
         m_cur = m_nxt;
@@ -246,7 +265,7 @@ void kmer_reads_kernel(const KmerReadsArgs a)
       }
       // ---- any non-base inside [sb_j, sb_j + len_j) ? ----
       uint32_t any = 0;
-      if (len_j) {
+      if (len_j && !clean_slab) {
         const uint32_t b_end = sb_j + (uint32_t)len_j; // one past the last byte
         const uint32_t w_lo = sb_j >> 5, w_hi = (b_end - 1u) >> 5;
         for (uint32_t w = w_lo; w <= w_hi; ++w) {
@@ -264,7 +283,7 @@ void kmer_reads_kernel(const KmerReadsArgs a)
       }
       const uint32_t tsum = wave_incl_scan32(dirty || !has ? 0u : nwin_raw);
       if (lane == 63u) a.tile_sum[t] = tsum;
-      lds_sync(); // the bit stream is free again
+      if (!clean_slab) lds_sync(); // the bit stream is free again
       continue;
     }
 
