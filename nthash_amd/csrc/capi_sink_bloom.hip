@@ -766,7 +766,7 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
   if (rd->offsets) { // reads of any lengths: the compact stream of a round of them, then the stream forms
     if (rd->n_reads == 0) return NTHIP_OK;
     uint64_t sum_kmers = 0, sum_hits = 0;
-    NTCHK(offsets_in_rounds(c, rd, flags, (size_t)8 * m + (query ? 0 : 16), [&](const nthip_reads* part, uint64_t r0, uint64_t bases) -> int {
+    NTCHK(offsets_in_rounds(c, rd, flags, (size_t)8 * m + (query ? (size_t)26 * m : 16), [&](const nthip_reads* part, uint64_t r0, uint64_t bases) -> int {
       Staged keep;
       uint64_t *d_h = nullptr, *d_counts = nullptr, n_kmers = 0;
       NTCHK(stream_of_offsets(c, part, k16, m8, flags, keep, &d_h, query ? &d_counts : nullptr, &n_kmers, bases ? bases : 1));

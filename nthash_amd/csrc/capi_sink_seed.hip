@@ -68,7 +68,7 @@ int run_seed_bloom(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, u
     return NTHIP_OK;
   };
   if (rd->offsets) {
-    NTCHK(offsets_in_rounds(c, rd, flags, (size_t)8 * per + (query ? 0 : 16), one_round));
+    NTCHK(offsets_in_rounds(c, rd, flags, (size_t)8 * per + (query ? (size_t)26 * per : 16), one_round));
   } else {
     const uint32_t len = rd->fixed_len, stride = rd->stride ? rd->stride : len;
     if (len < k) {
@@ -84,8 +84,10 @@ int run_seed_bloom(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, u
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
     free_b += c->bloom_tmp_bytes;
-    const uint64_t per_read = nwin * per * (query ? 8 : 24) + 48 + ((flags & NTHIP_HOST_INPUT) ? stride : 0);
-    uint64_t reads_per_round = std::max<uint64_t>(1, (uint64_t)(free_b / 3) / per_read);
+    // (the query through the regions: 8 B of hash + 1 B of answer + ~24 B of lists and records per value -- a round whose hashes
+    //  alone took a third of the memory left the lists no room, and the call fell back to a filter line per value)
+    const uint64_t per_read = nwin * per * (query ? 34 : 24) + 48 + ((flags & NTHIP_HOST_INPUT) ? stride : 0);
+    uint64_t reads_per_round = std::max<uint64_t>(1, (uint64_t)(query ? free_b / 10 * 7 : free_b / 3) / per_read);
     if (c->tune.bloom_round) reads_per_round = std::max<uint64_t>(1, c->tune.bloom_round / (nwin * per));
     for (uint64_t r0 = 0; r0 < rd->n_reads; r0 += reads_per_round) {
       nthip_reads part = *rd;
