@@ -134,47 +134,16 @@ bool query_scratch(nthip_ctx* c, const QueryGeo& g, uint64_t nr, uint64_t n, uin
   return true;
 }
 
+// ---- what the rounds of both entry points (reads: query_round; hash streams: stream_query_binned) share: level 2 forward, the
+// lookup region by region, level 2 back -- and *b ready for the caller's level-1 back kernel (where1 / tab1 / tovf1, the answers
+// next to the list level 1 wrote, g1).  q.pieces: block-private pieces at both levels (q.pg.g1 blocks at level 1, q.pg.gx per bin
+// at level 2), else shared cursors.  Launches only.
 template <int KIND>
-int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const BloomFusedSrc& src, const uint32_t* d_table, uint64_t n_slots,
-                uint32_t steps, uint64_t* d_hits, uint8_t* d_est, bool* failed, uint64_t* lost, uint64_t* hits, uint32_t jj0 = 0,
-                const uint16_t* surv_in = nullptr, uint16_t* surv_out = nullptr)
+int query_middle(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const uint32_t* d_table, uint64_t n_slots, BloomBackArgs* bp)
 {
-  // (src.m: the hashes of THIS pass, hashes()[jj0 ... jj0 + src.m); surv_in / surv_out: see BloomFusedQueryArgs / BloomBackArgs)
   const uint64_t magic = bloom_magic_of(n_slots);
   const uint64_t table_dwords = KIND == BQ_BLOOM ? (n_slots + 31) / 32 : (n_slots + 3) / 4;
-  const uint32_t shift1 = g.one ? g.region_shift : g.bin_shift, buckets1 = g.one ? g.n_regions : g.n_bins;
-  const uint64_t capL1 = g.one ? q.cap2 : q.cap1;
-  HIPCHK(hipMemsetAsync(q.status, 0, q.head_bytes, c->stream));
-  prof_begin(c, KIND == BQ_BLOOM ? "bloom binned query (part, part, lookup, back, back)" : "count binned query (part, part, lookup, back, back)");
-  // ---- forward, level 1: from the reads (bloom_fused_kernels.hpp pass PART, QUERY) ----
-  BloomFusedPiecesArgs fa;
-  bloom_fused_args(src, 1024u, n_slots, magic, &fa);
-  fa.lost = &q.status->lost;
-  fa.out = g.one ? q.list2 : q.list1;
-  fa.cursor = g.one ? q.cur2 : q.cur1;
-  fa.shift = shift1;
-  fa.mask = (1u << shift1) - 1u;
-  fa.n_buckets = buckets1;
-  fa.sl = {capL1, q.ovf, q.status, q.ovf_cap};
-  fa.q_where = q.where1;
-  fa.q_tab = q.tab1;
-  fa.q_tovf = q.tovf1;
-  fa.q_steps = steps;
-  fa.q_jj0 = jj0;
-  fa.q_surv = surv_in;
-  fa.p_fill = q.cur1;
   const uint32_t gx = q.pg.gx;
-  if (q.pieces) {
-    const size_t lds = bloom_fused_lds(src, 1024u, 1024u * 16u + BB_PIECES_LDS_DWORDS);
-    NTCHK(set_max_lds(c, bloom_fused_kernel<BF_PART, 1024, true, true>, lds));
-    hipLaunchKernelGGL((bloom_fused_kernel<BF_PART, 1024, true, true>), dim3(q.pg.g1), dim3(1024), lds, c->stream, fa);
-  } else {
-    const BloomFusedQueryArgs& fq = fa;
-    const size_t lds = bloom_fused_lds(src, 1024u, 1024u * 16u);
-    NTCHK(set_max_lds(c, bloom_fused_kernel<BF_PART, 1024, true>, lds));
-    hipLaunchKernelGGL((bloom_fused_kernel<BF_PART, 1024, true>), dim3((unsigned)std::min<uint64_t>(fa.n_tiles, (uint64_t)c->n_cu)), dim3(1024), lds,
-                       c->stream, fq);
-  }
   // ---- forward, level 2: every bin to its regions ----
   if (q.pieces) {
     BloomPartPiecesArgs a;
@@ -235,8 +204,8 @@ int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const Bl
     hipLaunchKernelGGL(bloom_ovf_lookup_kernel<KIND>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)q.ovf, (const BloomStatus*)q.status,
                        q.ovf_cap, d_table, q.ovf_pay);
   }
-  // ---- back ----
-  BloomBackArgs b;
+  // ---- back, level 2 ----
+  BloomBackArgs& b = *bp;
   memset(&b, 0, sizeof b);
   b.ovf_pay = q.ovf_pay;
   b.status = q.status;
@@ -253,37 +222,80 @@ int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const Bl
     b.n_regions = g.n_regions;
     b.buckets_per_seg = BB_REGIONS_PER_BIN;
     b.tiles_per_seg = q.tiles_per_seg;
+    int per_cu = 1;
     if (q.pieces) {
       b.fill_in = q.cur1;
       b.n_pieces_in = q.pg.g1;
       b.in_buckets = g.n_bins;
       b.gx = gx;
-      int per_cu = 1;
       NTCHK(blocks_per_cu(c, bloom_back2_pieces_kernel<BQ_L2_THREADS>, (int)BQ_L2_THREADS, 0, &per_cu));
-      const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
-      const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
-      hipLaunchKernelGGL(bloom_back2_pieces_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
     } else {
-      int per_cu = 1;
       NTCHK(blocks_per_cu(c, bloom_back2_kernel<BQ_L2_THREADS>, (int)BQ_L2_THREADS, 0, &per_cu));
-      const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
-      const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
-      hipLaunchKernelGGL(bloom_back2_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
     }
+    const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
+    const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
+    if (q.pieces) hipLaunchKernelGGL(bloom_back2_pieces_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
+    else hipLaunchKernelGGL(bloom_back2_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
   }
+  // ---- what level 1's way back reads ----
   b.where = q.where1;
   b.tab = q.tab1;
   b.tovf = q.tovf1;
   b.pay_in = g.one ? q.pay2 : q.pay1;
-  b.cap = capL1;
+  b.cap = g.one ? q.cap2 : q.cap1;
+  b.n_buckets = g.one ? g.n_regions : g.n_bins;
+  b.g1 = q.pieces ? q.pg.g1 : 0u;
+  return NTHIP_OK;
+}
+
+template <int KIND>
+int query_round(nthip_ctx* c, const QueryGeo& g, const QueryScratch& q, const BloomFusedSrc& src, const uint32_t* d_table, uint64_t n_slots,
+                uint32_t steps, uint64_t* d_hits, uint8_t* d_est, bool* failed, uint64_t* lost, uint64_t* hits, uint32_t jj0 = 0,
+                const uint16_t* surv_in = nullptr, uint16_t* surv_out = nullptr)
+{
+  // (src.m: the hashes of THIS pass, hashes()[jj0 ... jj0 + src.m); surv_in / surv_out: see BloomFusedQueryArgs / BloomBackArgs)
+  const uint64_t magic = bloom_magic_of(n_slots);
+  const uint32_t shift1 = g.one ? g.region_shift : g.bin_shift, buckets1 = g.one ? g.n_regions : g.n_bins;
+  const uint64_t capL1 = g.one ? q.cap2 : q.cap1;
+  HIPCHK(hipMemsetAsync(q.status, 0, q.head_bytes, c->stream));
+  prof_begin(c, KIND == BQ_BLOOM ? "bloom binned query (part, part, lookup, back, back)" : "count binned query (part, part, lookup, back, back)");
+  // ---- forward, level 1: from the reads (bloom_fused_kernels.hpp pass PART, QUERY) ----
+  BloomFusedPiecesArgs fa;
+  bloom_fused_args(src, 1024u, n_slots, magic, &fa);
+  fa.lost = &q.status->lost;
+  fa.out = g.one ? q.list2 : q.list1;
+  fa.cursor = g.one ? q.cur2 : q.cur1;
+  fa.shift = shift1;
+  fa.mask = (1u << shift1) - 1u;
+  fa.n_buckets = buckets1;
+  fa.sl = {capL1, q.ovf, q.status, q.ovf_cap};
+  fa.q_where = q.where1;
+  fa.q_tab = q.tab1;
+  fa.q_tovf = q.tovf1;
+  fa.q_steps = steps;
+  fa.q_jj0 = jj0;
+  fa.q_surv = surv_in;
+  fa.p_fill = q.cur1;
+  if (q.pieces) {
+    const size_t lds = bloom_fused_lds(src, 1024u, 1024u * 16u + BB_PIECES_LDS_DWORDS);
+    NTCHK(set_max_lds(c, bloom_fused_kernel<BF_PART, 1024, true, true>, lds));
+    hipLaunchKernelGGL((bloom_fused_kernel<BF_PART, 1024, true, true>), dim3(q.pg.g1), dim3(1024), lds, c->stream, fa);
+  } else {
+    const BloomFusedQueryArgs& fq = fa;
+    const size_t lds = bloom_fused_lds(src, 1024u, 1024u * 16u);
+    NTCHK(set_max_lds(c, bloom_fused_kernel<BF_PART, 1024, true>, lds));
+    hipLaunchKernelGGL((bloom_fused_kernel<BF_PART, 1024, true>), dim3((unsigned)std::min<uint64_t>(fa.n_tiles, (uint64_t)c->n_cu)), dim3(1024), lds,
+                       c->stream, fq);
+  }
+  // ---- level 2 forward, lookup, level 2 back ----
+  BloomBackArgs b;
+  NTCHK(query_middle<KIND>(c, g, q, d_table, n_slots, &b));
   b.n_reads = src.n_reads;
   b.len = src.len;
   b.k = src.k;
   b.m = src.m;
   b.n_tiles = fa.n_tiles;
   b.steps = steps;
-  b.n_buckets = buckets1;
-  b.g1 = q.pieces ? q.pg.g1 : 0u;
   b.surv_in = surv_in;
   b.surv_out = surv_out;
   b.hits = d_hits;
@@ -475,7 +487,6 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
   constexpr uint32_t L1_THREADS = SQ_L1_THREADS, L1_TILE = L1_THREADS * BB_PART_ITEMS;
   constexpr uint32_t P1_THREADS = SQ_PIECES_THREADS, P1_TILE = P1_THREADS * BB_PART_ITEMS;
   const uint64_t magic = bloom_magic_of(n_slots);
-  const uint64_t table_dwords = kind == BQ_BLOOM ? (n_slots + 31) / 32 : (n_slots + 3) / 4;
   const uint32_t shift1 = g.one ? g.region_shift : g.bin_shift, buckets1 = g.one ? g.n_regions : g.n_bins;
   // pieces mode (a two-level table): block-private pieces at both levels, whole lines only (bloom_binned_kernels.hpp)
   bool pieces = !g.one && c->tune.bloom_pieces != 2;
@@ -503,35 +514,28 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
   if (c->tune.bloom_round) round = c->tune.bloom_round;
   if (round > n_values) round = n_values;
   if (round < (1u << 16)) round = 1u << 16;
-  struct S {
-    BloomStatus* status;
-    uint32_t *cur1, *cur2, *list1, *list2, *where1, *where2, *tovf1, *tovf2;
-    uint64_t* ovf;
-    uint2 *tab1, *tab2;
-    uint8_t *pay1, *pay2, *ovf_pay;
-    uint64_t cap1, cap2, ovf_cap;
-    uint32_t tiles_per_seg, g1;
-    size_t head, clear;
-  } q;
+  QueryScratch q;
   auto carve = [&](uint64_t n, size_t* need) -> bool {
     size_t slots1, slots2, fills1, fills2;
     uint64_t tiles1, rows2;
     if (pieces) {
       tiles1 = (n + P1_TILE - 1) / P1_TILE;
-      q.g1 = (uint32_t)std::min<uint64_t>(tiles1, g1_max);
-      const double per_block = (double)((tiles1 + q.g1 - 1) / q.g1) * (double)P1_TILE; // what a level-1 block may see
+      q.pg.g1 = (uint32_t)std::min<uint64_t>(tiles1, g1_max);
+      q.pg.gx = gx;
+      const double per_block = (double)((tiles1 + q.pg.g1 - 1) / q.pg.g1) * (double)P1_TILE; // what a level-1 block may see
       const double bin_slots = (double)(1ull << g.bin_shift), region_slots = (double)(1ull << g.region_shift);
       q.cap1 = piece_cap(c, per_block * (bin_slots < (double)n_slots ? bin_slots / (double)n_slots : 1.0));
-      q.cap2 = piece_cap(c, (double)((q.g1 + gx - 1) / gx) * per_block * (region_slots < (double)n_slots ? region_slots / (double)n_slots : 1.0));
+      q.cap2 = piece_cap(c, (double)((q.pg.g1 + gx - 1) / gx) * per_block * (region_slots < (double)n_slots ? region_slots / (double)n_slots : 1.0));
       q.tiles_per_seg = (uint32_t)((q.cap1 + BQ_L2_TILE - 1) / BQ_L2_TILE); // (tile rows per PIECE)
-      slots1 = (size_t)g.n_bins * q.g1 * q.cap1;
+      slots1 = (size_t)g.n_bins * q.pg.g1 * q.cap1;
       slots2 = (size_t)g.n_regions * gx * q.cap2;
-      fills1 = (size_t)q.g1 * g.n_bins;
+      fills1 = (size_t)q.pg.g1 * g.n_bins;
       fills2 = (size_t)g.n_bins * gx * BB_REGIONS_PER_BIN;
-      rows2 = (uint64_t)g.n_bins * q.g1 * q.tiles_per_seg;
+      rows2 = (uint64_t)g.n_bins * q.pg.g1 * q.tiles_per_seg;
     } else {
       tiles1 = (n + L1_TILE - 1) / L1_TILE;
-      q.g1 = 0;
+      q.pg.g1 = 0;
+      q.pg.gx = 0;
       q.cap1 = g.one ? 0 : slot_cap(c, n, 1ull << g.bin_shift, n_slots);
       q.cap2 = slot_cap(c, n, 1ull << g.region_shift, n_slots);
       q.tiles_per_seg = (uint32_t)((q.cap1 + BQ_L2_TILE - 1) / BQ_L2_TILE);
@@ -543,15 +547,16 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
     }
     q.ovf_cap = n / 64 < 65536 ? 65536 : n / 64;
     if (c->tune.bloom_slot_tight == 2) q.ovf_cap = 64;
-    q.head = 256 + (fills1 + fills2) * sizeof(uint32_t);
-    q.clear = pieces ? 256 : q.head; // (the pieces' fill arrays are written whole by the kernels)
+    q.pieces = pieces;
+    const size_t head = 256 + (fills1 + fills2) * sizeof(uint32_t);
+    q.head_bytes = pieces ? 256 : head; // (the pieces' fill arrays are written whole by the kernels)
     size_t off = 0;
     auto take = [&](size_t bytes) {
       const size_t at = off;
       off += al256(bytes);
       return at;
     };
-    const size_t o_head = take(q.head), o_l1 = take(slots1 * 4), o_l2 = take(slots2 * 4), o_ovf = take((size_t)q.ovf_cap * 8);
+    const size_t o_head = take(head), o_l1 = take(slots1 * 4), o_l2 = take(slots2 * 4), o_ovf = take((size_t)q.ovf_cap * 8);
     const size_t o_w1 = take((size_t)n * 4), o_w2 = take(slots1 * 4);
     const size_t o_t1 = take((size_t)tiles1 * buckets1 * 8), o_v1 = take((size_t)tiles1 * buckets1 * 4);
     const size_t o_t2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 8), o_v2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 4);
@@ -596,7 +601,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
     size_t need = 0;
     if (!carve(n, &need)) return fail(NTHIP_ERR_HIP, "the lists of a smaller round do not fit the buffer of a larger one");
     const uint64_t capL1 = g.one ? q.cap2 : q.cap1;
-    HIPCHK(hipMemsetAsync(q.status, 0, q.clear, c->stream));
+    HIPCHK(hipMemsetAsync(q.status, 0, q.head_bytes, c->stream));
     prof_begin(c, kind == BQ_BLOOM ? "bloom binned stream query (part, part, lookup, back, back)" : "count binned stream query (part, part, lookup, back, back)");
     if (pieces) { // forward, level 1: the stream's values into the blocks' pieces of the bins
       BloomPartStreamPiecesArgs a;
@@ -615,27 +620,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
       a.q_tab = q.tab1;
       a.q_tovf = q.tovf1;
       NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<P1_THREADS, true>, p1_lds));
-      hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<P1_THREADS, true>), dim3(q.g1), dim3(P1_THREADS), p1_lds, c->stream, a);
-      BloomPartPiecesArgs a2; // level 2: every bin's pieces to the blocks' pieces of its regions
-      memset(&a2, 0, sizeof a2);
-      a2.in = q.list1;
-      a2.out = q.list2;
-      a2.fill_in = q.cur1;
-      a2.fill_out = q.cur2;
-      a2.cap_in = q.cap1;
-      a2.n_pieces_in = q.g1;
-      a2.in_buckets = g.n_bins;
-      a2.n_regions = g.n_regions;
-      a2.shift = g.region_shift;
-      a2.mask = (1u << g.region_shift) - 1u;
-      a2.buckets_per_seg = BB_REGIONS_PER_BIN;
-      a2.sl = {q.cap2, q.ovf, q.status, q.ovf_cap};
-      a2.q_where = q.where2;
-      a2.q_tab = q.tab2;
-      a2.q_tovf = q.tovf2;
-      a2.q_tiles_per_piece = q.tiles_per_seg;
-      NTCHK(set_max_lds(c, bloom_part_pieces_kernel<BQ_L2_THREADS, true>, p2_lds));
-      hipLaunchKernelGGL((bloom_part_pieces_kernel<BQ_L2_THREADS, true>), dim3(gx, g.n_bins), dim3(BQ_L2_THREADS), p2_lds, c->stream, a2);
+      hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<P1_THREADS, true>), dim3(q.pg.g1), dim3(P1_THREADS), p1_lds, c->stream, a);
     } else {
       { // forward, level 1: the stream's values behind shared cursors
         BloomPartQueryArgs a;
@@ -659,90 +644,11 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
         NTCHK(set_max_lds(c, bloom_part_kernel<true, L1_THREADS, true>, lds));
         hipLaunchKernelGGL((bloom_part_kernel<true, L1_THREADS, true>), dim3((unsigned)c->n_cu * (2048u / L1_THREADS)), dim3(L1_THREADS), lds, c->stream, a);
       }
-      if (!g.one) { // level 2
-        BloomPartQueryArgs a;
-        memset((void*)&a, 0, sizeof a);
-        a.n_bits = n_slots;
-        a.magic = magic;
-        a.n_regions = g.n_regions;
-        a.in = q.list1;
-        a.out = q.list2;
-        a.cursor = q.cur2;
-        a.shift = g.region_shift;
-        a.mask = (1u << g.region_shift) - 1u;
-        a.buckets_per_seg = BB_REGIONS_PER_BIN;
-        a.sl = {q.cap2, q.ovf, q.status, q.ovf_cap};
-        a.cap_in = q.cap1;
-        a.seg_fill = q.cur1;
-        a.q_where = q.where2;
-        a.q_tab = q.tab2;
-        a.q_tovf = q.tovf2;
-        a.q_tiles_per_seg = q.tiles_per_seg;
-        const size_t lds = (size_t)BQ_L2_TILE * sizeof(uint32_t);
-        int per_cu = 1;
-        NTCHK(blocks_per_cu(c, bloom_part_kernel<false, BQ_L2_THREADS, true>, (int)BQ_L2_THREADS, lds, &per_cu));
-        const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
-        const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
-        hipLaunchKernelGGL((bloom_part_kernel<false, BQ_L2_THREADS, true>), dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), lds, c->stream, a);
-      }
     }
-    { // lookup
-      const size_t lds = (size_t)BB_REGION_DWORDS * sizeof(uint32_t);
-      const uint32_t grid = g.n_regions < (uint32_t)c->n_cu ? g.n_regions : (uint32_t)c->n_cu;
-      const uint32_t np = pieces ? gx : 0u;
-      if (kind == BQ_BLOOM) {
-        NTCHK(set_max_lds(c, bloom_lookup_kernel<BQ_BLOOM>, lds));
-        hipLaunchKernelGGL(bloom_lookup_kernel<BQ_BLOOM>, dim3(grid), dim3(BQ_LOOKUP_THREADS), lds, c->stream, (const uint32_t*)q.list2,
-                           (const uint32_t*)q.cur2, q.cap2, g.n_regions, d_table, table_dwords, q.pay2, np, (uint32_t)BB_REGIONS_PER_BIN);
-        hipLaunchKernelGGL(bloom_ovf_lookup_kernel<BQ_BLOOM>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)q.ovf,
-                           (const BloomStatus*)q.status, q.ovf_cap, d_table, q.ovf_pay);
-      } else {
-        NTCHK(set_max_lds(c, bloom_lookup_kernel<BQ_COUNT>, lds));
-        hipLaunchKernelGGL(bloom_lookup_kernel<BQ_COUNT>, dim3(grid), dim3(BQ_LOOKUP_THREADS), lds, c->stream, (const uint32_t*)q.list2,
-                           (const uint32_t*)q.cur2, q.cap2, g.n_regions, d_table, table_dwords, q.pay2, np, (uint32_t)BB_REGIONS_PER_BIN);
-        hipLaunchKernelGGL(bloom_ovf_lookup_kernel<BQ_COUNT>, dim3(c->n_cu), dim3(256), 0, c->stream, (const uint64_t*)q.ovf,
-                           (const BloomStatus*)q.status, q.ovf_cap, d_table, q.ovf_pay);
-      }
-    }
+    // level 2 forward, lookup, level 2 back (what the reads' rounds do); then every value's answer
     BloomBackArgs b;
-    memset(&b, 0, sizeof b);
-    b.ovf_pay = q.ovf_pay;
-    b.status = q.status;
-    b.ovf_cap = q.ovf_cap;
-    if (!g.one) {
-      b.where = q.where2;
-      b.tab = q.tab2;
-      b.tovf = q.tovf2;
-      b.pay_in = q.pay2;
-      b.cap = q.cap2;
-      b.pay_out = q.pay1;
-      b.seg_fill = q.cur1;
-      b.cap_in = q.cap1;
-      b.n_regions = g.n_regions;
-      b.buckets_per_seg = BB_REGIONS_PER_BIN;
-      b.tiles_per_seg = q.tiles_per_seg;
-      int per_cu = 1;
-      if (pieces) {
-        b.fill_in = q.cur1;
-        b.n_pieces_in = q.g1;
-        b.in_buckets = g.n_bins;
-        b.gx = gx;
-        NTCHK(blocks_per_cu(c, bloom_back2_pieces_kernel<BQ_L2_THREADS>, (int)BQ_L2_THREADS, 0, &per_cu));
-      } else {
-        NTCHK(blocks_per_cu(c, bloom_back2_kernel<BQ_L2_THREADS>, (int)BQ_L2_THREADS, 0, &per_cu));
-      }
-      const uint32_t grid2 = 2u * (uint32_t)c->n_cu * (uint32_t)per_cu;
-      const uint32_t pb = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
-      if (pieces) hipLaunchKernelGGL(bloom_back2_pieces_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
-      else hipLaunchKernelGGL(bloom_back2_kernel<BQ_L2_THREADS>, dim3(pb, g.n_bins), dim3(BQ_L2_THREADS), 0, c->stream, b);
-    }
-    b.where = q.where1;
-    b.tab = q.tab1;
-    b.tovf = q.tovf1;
-    b.pay_in = g.one ? q.pay2 : q.pay1;
-    b.cap = capL1;
-    b.n_buckets = buckets1;
-    b.g1 = q.g1;
+    if (kind == BQ_BLOOM) NTCHK(query_middle<BQ_BLOOM>(c, g, q, d_table, n_slots, &b));
+    else NTCHK(query_middle<BQ_COUNT>(c, g, q, d_table, n_slots, &b));
     {
       int per_cu = 1;
       if (pieces) {
