@@ -397,12 +397,12 @@ struct BloomPartArgs {
   const uint32_t* seg_fill;
 };
 // the binned query (QUERY instantiation, slots mode; bloom_query_kernels.hpp): what the way back needs of every tile --
-// q_where[slot of the input list] = bucket << 16 | rank of the entry in its tile's bucket; per tile (segment s, its tile
+// q_where[slot of the input list] = the entry's place in its tile's SORTED order (16 bits: a tile has at most 16 Ki entries); per tile (segment s, its tile
 // t: row s * q_tiles_per_seg + t) and bucket b, q_tab[row * buckets_per_seg + b] = {entries of the tile, where the run
 // went in the bucket's slots}, q_tovf[...] = where its overflowing entries start in the overflow list (set when any)
 // (a struct of its own: the insert's instantiations keep the argument block -- and the register allocation -- they had)
 struct BloomPartQueryArgs : BloomPartArgs {
-  uint32_t* q_where;
+  uint16_t* q_where;
   uint2* q_tab;
   uint32_t* q_tovf;
   uint32_t q_tiles_per_seg;
@@ -493,13 +493,6 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(
         }
       }
     }
-    if constexpr (QUERY) { // the way back: every slot of the input list remembers its place in the tile's sort
-#pragma unroll
-      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
-        const uint64_t idx = t0 + (uint64_t)j * BB_PART_THREADS + tid;
-        if (idx < s1) a.q_where[idx] = where[j];
-      }
-    }
     if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
     __syncthreads();
 #if BB_TIMING
@@ -547,6 +540,7 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(
         const uint32_t slot = off[where[j] >> 16] + (where[j] & 0xFFFFu);
         sorted[slot] = val[j];
         sbin[slot] = (uint8_t)(where[j] >> 16);
+        if constexpr (QUERY) a.q_where[t0 + (uint64_t)j * BB_PART_THREADS + tid] = (uint16_t)slot;
       }
     if (tid < n_buckets) gbase[tid] = my_base;
     __syncthreads();
@@ -560,7 +554,12 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_kernel(
 #else
 #pragma unroll
     for (uint32_t j = 0; j < BB_PART_ITEMS; ++j)
-      if (where[j] != ~0u) sorted[off[where[j] >> 16] + (where[j] & 0xFFFFu)] = val[j];
+      if (where[j] != ~0u) {
+        const uint32_t slot = off[where[j] >> 16] + (where[j] & 0xFFFFu);
+        sorted[slot] = val[j];
+        // the way back: every slot of the input list remembers its place in the tile's sorted order
+        if constexpr (QUERY) a.q_where[t0 + (uint64_t)j * BB_PART_THREADS + tid] = (uint16_t)slot;
+      }
     if (tid < n_buckets) gbase[tid] = my_base;
     __syncthreads();
 #if BB_TIMING
@@ -613,7 +612,7 @@ struct BloomPartPiecesArgs {
   uint32_t n_regions, shift, mask, buckets_per_seg;
   BloomSlots sl; // cap: entries per piece written
   // the binned query: q_where per slot of `in`; tile row ((s * n_pieces_in + p) * q_tiles_per_piece + tile of the piece)
-  uint32_t* q_where;
+  uint16_t* q_where;
   uint2* q_tab;
   uint32_t* q_tovf;
   uint32_t q_tiles_per_piece;
@@ -689,13 +688,6 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_pieces_kern
         }
       }
     }
-    if constexpr (QUERY) {
-#pragma unroll
-      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
-        const uint32_t idx = t0 + j * BB_PART_THREADS + tid;
-        if (idx < cnt) a.q_where[base + idx] = where[j];
-      }
-    }
     // the next tile: of this piece, or the first of the block's next piece that holds anything
     uint32_t np = p, nk = kk + 1u, ncnt = cnt;
     if (nk * BB_TILE >= cnt) {
@@ -741,7 +733,11 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_pieces_kern
     __syncthreads();
 #pragma unroll
     for (uint32_t j = 0; j < BB_PART_ITEMS; ++j)
-      if (where[j] != ~0u) sorted[off[where[j] >> 16] + (where[j] & 0xFFFFu)] = val[j];
+      if (where[j] != ~0u) {
+        const uint32_t slot = off[where[j] >> 16] + (where[j] & 0xFFFFu);
+        sorted[slot] = val[j];
+        if constexpr (QUERY) a.q_where[base + t0 + j * BB_PART_THREADS + tid] = (uint16_t)slot;
+      }
     __syncthreads();
     bloom_copy_out_lines<BB_PART_THREADS / 64u, QUERY>(sorted, hist, off, gbase, left, lcnt, n_buckets, wave, lane, a.out,
                                                        (uint64_t)r0 * gx + blockIdx.x, (uint64_t)gx, (uint64_t)r0, a.sl, a.shift,
@@ -770,7 +766,7 @@ struct BloomPartStreamPiecesArgs {
   uint32_t* fill_out;
   uint32_t shift, mask, n_buckets;
   BloomSlots sl; // cap: entries per piece
-  uint32_t* q_where;
+  uint16_t* q_where;
   uint2* q_tab;
   uint32_t* q_tovf;
 };
@@ -831,13 +827,6 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_stream_piec
         }
       }
     }
-    if constexpr (QUERY) {
-#pragma unroll
-      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
-        const uint64_t idx = t0 + (uint64_t)j * BB_PART_THREADS + tid;
-        if (idx < a.n) a.q_where[idx] = where[j];
-      }
-    }
     if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
     __syncthreads();
     const uint64_t q_row = tile * n_buckets;
@@ -871,7 +860,11 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_stream_piec
     __syncthreads();
 #pragma unroll
     for (uint32_t j = 0; j < BB_PART_ITEMS; ++j)
-      if (where[j] != ~0u) sorted[off[where[j] >> 16] + (where[j] & 0xFFFFu)] = val[j];
+      if (where[j] != ~0u) {
+        const uint32_t slot = off[where[j] >> 16] + (where[j] & 0xFFFFu);
+        sorted[slot] = val[j];
+        if constexpr (QUERY) a.q_where[t0 + (uint64_t)j * BB_PART_THREADS + tid] = (uint16_t)slot;
+      }
     __syncthreads();
     bloom_copy_out_lines<BB_PART_THREADS / 64u, QUERY>(sorted, hist, off, gbase, left, lcnt, n_buckets, wave, lane, a.out, (uint64_t)blockIdx.x,
                                                        (uint64_t)gridDim.x, 0ull, a.sl, a.shift, QUERY ? a.q_tovf + q_row : nullptr);

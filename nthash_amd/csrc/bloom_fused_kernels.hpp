@@ -61,11 +61,11 @@ struct BloomFusedArgs {
 };
 // the binned QUERY (bloom_query_kernels.hpp; QUERY instantiation of pass PART, slots mode): the way back of every tile.
 // Tile row ts = ((tile * q_steps) + (word - first emitting word)) * m + jj;  q_where[(ts * 16 + i) * THREADS + thread] =
-// bucket << 16 | rank of that window's value in the tile's bucket (~0: nothing emitted), for the steps i that can emit;
+// the place of that window's value in the tile's sorted order (0xFFFF: nothing emitted), for the steps i that can emit;
 // q_tab[ts * n_buckets + b] = {entries, place of the run in bucket b's slots}; q_tovf[...]: see bloom_copy_out
 // (a struct of its own: the insert's instantiations keep the argument block they had)
 struct BloomFusedQueryArgs : BloomFusedArgs {
-  uint32_t* q_where;
+  uint16_t* q_where;
   uint2* q_tab;
   uint32_t* q_tovf;
   uint32_t q_steps;
@@ -262,12 +262,7 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename Blo
             }
           }
           uint64_t q_ts = 0;
-          if constexpr (QUERY) {
-            q_ts = ((uint64_t)t * a.q_steps + (j - jb)) * m + jj;
-#pragma unroll
-            for (uint32_t i = 0; i < 16; ++i)
-              if (i >= lo && i < hi) a.q_where[(q_ts * 16u + i) * THREADS + tid] = where[i];
-          }
+          if constexpr (QUERY) q_ts = ((uint64_t)t * a.q_steps + (j - jb)) * m + jj;
           __syncthreads();
 #if BF_TIMING
           const uint64_t tk2 = __builtin_amdgcn_s_memrealtime();
@@ -313,8 +308,16 @@ __global__ __launch_bounds__(THREADS) void bloom_fused_kernel(const typename Blo
           const uint64_t tk3 = __builtin_amdgcn_s_memrealtime();
 #endif
 #pragma unroll
-          for (uint32_t i = 0; i < 16; ++i)
-            if (where[i] != ~0u) area[off[where[i] >> 16] + (where[i] & 0xFFFFu)] = val[i];
+          for (uint32_t i = 0; i < 16; ++i) {
+            uint32_t slot = 0xFFFFu;
+            if (where[i] != ~0u) {
+              slot = off[where[i] >> 16] + (where[i] & 0xFFFFu);
+              area[slot] = val[i];
+            }
+            if constexpr (QUERY) {
+              if (i >= lo && i < hi) a.q_where[(q_ts * 16u + i) * THREADS + tid] = (uint16_t)slot;
+            }
+          }
           if (tid < a.n_buckets) gbase[tid] = my_base;
           __syncthreads();
 #if BF_TIMING

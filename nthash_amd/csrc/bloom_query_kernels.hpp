@@ -31,7 +31,7 @@
 namespace ntamd {
 
 enum : int { BQ_BLOOM = 0, BQ_COUNT = 1 };
-constexpr uint32_t BQ_NONE = 0xFFFFFFFFu;     // `where` of a window that emitted nothing
+constexpr uint32_t BQ_NONE = 0xFFFFu;         // `where` of a window that emitted nothing (a place in a tile's sorted order is < 16 Ki)
 constexpr uint32_t BQ_COUNT_REGION_SHIFT = 17; // a sketch's region for the query: 2^17 one-byte counters = 128 KiB of LDS
 constexpr uint32_t BQ_LOOKUP_THREADS = 1024;
 constexpr uint32_t BQ_LOOKUP_BATCH = 4;        // 16-byte loads of entries a thread has in flight
@@ -126,6 +126,7 @@ static __global__ __launch_bounds__(256) void bloom_ovf_lookup_kernel(const uint
 // pieces mode: the writing block's piece of every bucket), the rest to the overflow list.  bq_stage_runs loads the
 // answers of those runs (pay: one byte per slot) into `stage` in the tile's sorted order -- stage[off[b] + rank] -- and
 // leaves offfit[b] = off[b] | fit[b] << 16.  Whole block; ends with a barrier.
+// (offfit has BB_MAX_BINS + 1 words: the last one is set when a run of the tile did not fit its bucket -- bq_pick's slow road)
 template <uint32_t NW>
 __device__ __forceinline__ void bq_stage_runs(const uint2* __restrict__ tab, uint32_t n_buckets, const uint8_t* __restrict__ pay, uint64_t piece0,
                                               uint64_t piece_step, uint64_t cap, uint8_t* stage, uint32_t* cnt, uint32_t* gat, uint32_t* offfit, uint32_t tid,
@@ -138,6 +139,7 @@ __device__ __forceinline__ void bq_stage_runs(const uint2* __restrict__ tab, uin
     cnt[tid] = e.x;
     gat[tid] = e.y;
   }
+  if (tid == 0) offfit[BB_MAX_BINS] = 0;
   __syncthreads();
   if (wave == 0) { // the tile's exclusive scan, as the forward pass made it: 4 buckets per lane
     uint32_t c[4], s = 0;
@@ -158,6 +160,7 @@ __device__ __forceinline__ void bq_stage_runs(const uint2* __restrict__ tab, uin
       const uint32_t at = gat[lane * 4u + i];
       const uint32_t fit = at >= cap ? 0u : (cap - at < c[i] ? (uint32_t)(cap - at) : c[i]);
       offfit[lane * 4u + i] = run | (fit << 16);
+      if (fit < c[i]) offfit[BB_MAX_BINS] = 1u; // (rare: part of the run is in the overflow list)
       run += c[i];
     }
   }
@@ -191,20 +194,28 @@ __device__ __forceinline__ void bq_stage_runs(const uint2* __restrict__ tab, uin
   }
   __syncthreads();
 }
-// the answer of the value that was `w` = bucket << 16 | rank in the tile (after bq_stage_runs)
+// the answer of the value at place `w` of the tile's sorted order (after bq_stage_runs): the stage holds the tile's answers in
+// that order.  Only a tile with a run that did not fit its bucket asks which bucket the place belongs to (the last one whose
+// offset is <= w: empty buckets share their successor's offset) and, past the bucket's fit, goes to the overflow list.
 __device__ __forceinline__ uint32_t bq_pick(uint32_t w, const uint8_t* stage, const uint32_t* offfit, const uint32_t* __restrict__ tovf,
                                             const uint8_t* __restrict__ ovf_pay)
 {
-  const uint32_t b = w >> 16, rank = w & 0xFFFFu;
-  const uint32_t of = offfit[b];
-  const uint32_t fit = of >> 16;
-  if (rank < fit) return stage[(of & 0xFFFFu) + rank];
-  return ovf_pay[(uint64_t)tovf[b] + (rank - fit)];
+  if (offfit[BB_MAX_BINS] == 0u) return stage[w];
+  uint32_t lo = 0, hi = BB_MAX_BINS;
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((offfit[mid] & 0xFFFFu) <= w) lo = mid;
+    else hi = mid;
+  }
+  const uint32_t of = offfit[lo];
+  const uint32_t rank = w - (of & 0xFFFFu), fit = of >> 16;
+  if (rank < fit) return stage[w];
+  return ovf_pay[(uint64_t)tovf[lo] + (rank - fit)];
 }
 
 // ---- back, level 2: the answers of the regions' lists to the slots of the bins' lists -------------------------------------
 struct BloomBackArgs {
-  const uint32_t* where;  // level 2: per slot of the bins' lists; level 1: per tile row, step and thread
+  const uint16_t* where;  // level 2: per slot of the bins' lists; level 1: per tile row, step and thread (places in the tiles' sorted order)
   const uint2* tab;
   const uint32_t* tovf;
   const uint8_t* pay_in;  // answers next to the list this level WROTE
@@ -237,7 +248,7 @@ template <uint32_t THREADS>
 static __global__ __launch_bounds__(THREADS) void bloom_back2_kernel(const BloomBackArgs a)
 {
   constexpr uint32_t TILE = THREADS * BB_PART_ITEMS;
-  __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS];
+  __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS + 1];
   __shared__ __attribute__((aligned(16))) uint8_t stage[TILE];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (bloom_round_failed(a.status, a.ovf_cap)) return;
@@ -254,7 +265,7 @@ static __global__ __launch_bounds__(THREADS) void bloom_back2_kernel(const Bloom
 #pragma unroll
     for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) { // (asked for first: they arrive while the runs are staged)
       const uint64_t idx = t0 + (uint64_t)j * THREADS + tid;
-      w[j] = idx < s1 ? __builtin_nontemporal_load(a.where + idx) : BQ_NONE;
+      w[j] = idx < s1 ? (uint32_t)__builtin_nontemporal_load(a.where + idx) : BQ_NONE;
     }
     const uint64_t row = ((uint64_t)seg * a.tiles_per_seg + tile) * a.buckets_per_seg;
     bq_stage_runs<THREADS / 64u>(a.tab + row, n_buckets, a.pay_in, (uint64_t)r0, 1ull, a.cap, stage, cnt, gat, offfit, tid, lane, wave);
@@ -272,7 +283,7 @@ template <uint32_t THREADS>
 static __global__ __launch_bounds__(THREADS) void bloom_back2_pieces_kernel(const BloomBackArgs a)
 {
   constexpr uint32_t TILE = THREADS * BB_PART_ITEMS;
-  __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS];
+  __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS + 1];
   __shared__ __attribute__((aligned(16))) uint8_t stage[TILE];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (bloom_round_failed(a.status, a.ovf_cap)) return;
@@ -291,7 +302,7 @@ static __global__ __launch_bounds__(THREADS) void bloom_back2_pieces_kernel(cons
 #pragma unroll
       for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
         const uint32_t idx = t0 + j * THREADS + tid;
-        w[j] = idx < n_here ? __builtin_nontemporal_load(a.where + base + idx) : BQ_NONE;
+        w[j] = idx < n_here ? (uint32_t)__builtin_nontemporal_load(a.where + base + idx) : BQ_NONE;
       }
       const uint64_t row = (((uint64_t)seg * a.n_pieces_in + p) * a.tiles_per_seg + kk) * a.buckets_per_seg;
       bq_stage_runs<THREADS / 64u>(a.tab + row, n_buckets, a.pay_in, piece0, (uint64_t)a.gx, a.cap, stage, cnt, gat, offfit, tid, lane, wave);
@@ -309,7 +320,7 @@ static __global__ __launch_bounds__(THREADS) void bloom_back2_pieces_kernel(cons
 template <int KIND, uint32_t THREADS>
 static __global__ __launch_bounds__(THREADS) void bloom_back1_kernel(const BloomBackArgs a)
 {
-  __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS];
+  __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS + 1];
   __shared__ __attribute__((aligned(16))) uint8_t stage[THREADS * 16u];
   extern __shared__ __attribute__((aligned(16))) uint8_t bq_est_tile[]; // BQ_COUNT with est_lds: [thread][window]
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -338,7 +349,7 @@ static __global__ __launch_bounds__(THREADS) void bloom_back1_kernel(const Bloom
         uint32_t w[16];
 #pragma unroll
         for (uint32_t i = 0; i < 16; ++i)
-          w[i] = (i >= lo && i < hi) ? __builtin_nontemporal_load(a.where + (ts * 16u + i) * THREADS + tid) : BQ_NONE;
+          w[i] = (i >= lo && i < hi) ? (uint32_t)__builtin_nontemporal_load(a.where + (ts * 16u + i) * THREADS + tid) : BQ_NONE;
         bq_stage_runs<THREADS / 64u>(a.tab + ts * a.n_buckets, a.n_buckets, a.pay_in, a.g1 ? (uint64_t)(t % a.g1) : 0ull, a.g1 ? (uint64_t)a.g1 : 1ull,
                                      a.cap, stage, cnt, gat, offfit, tid, lane, wave);
 #pragma unroll
@@ -405,7 +416,7 @@ template <uint32_t THREADS>
 static __global__ __launch_bounds__(THREADS) void bloom_back1_stream_kernel(const BloomBackArgs a, uint64_t n_values, uint8_t* __restrict__ ans)
 {
   constexpr uint32_t TILE = THREADS * BB_PART_ITEMS;
-  __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS];
+  __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS + 1];
   __shared__ __attribute__((aligned(16))) uint8_t stage[TILE];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (bloom_round_failed(a.status, a.ovf_cap)) return;
@@ -416,7 +427,7 @@ static __global__ __launch_bounds__(THREADS) void bloom_back1_stream_kernel(cons
 #pragma unroll
     for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
       const uint64_t idx = t0 + (uint64_t)j * THREADS + tid;
-      w[j] = idx < n_values ? __builtin_nontemporal_load(a.where + idx) : BQ_NONE;
+      w[j] = idx < n_values ? (uint32_t)__builtin_nontemporal_load(a.where + idx) : BQ_NONE;
     }
     const uint64_t row = tile * a.n_buckets;
     // (pieces mode, g1 blocks at level 1: the tile was written by block tile % g1 into ITS piece of every bucket)

@@ -38,7 +38,8 @@ struct QueryScratch {
   unsigned long long* total_hits = nullptr;
   uint32_t *cur1 = nullptr, *cur2 = nullptr, *list1 = nullptr, *list2 = nullptr;
   uint64_t* ovf = nullptr;
-  uint32_t *where1 = nullptr, *where2 = nullptr, *tovf1 = nullptr, *tovf2 = nullptr;
+  uint16_t *where1 = nullptr, *where2 = nullptr; // places in the tiles' sorted order (2 B per value and level)
+  uint32_t *tovf1 = nullptr, *tovf2 = nullptr;
   uint2 *tab1 = nullptr, *tab2 = nullptr;
   uint8_t *pay1 = nullptr, *pay2 = nullptr, *ovf_pay = nullptr;
   uint16_t* surv = nullptr; // m > 1 in passes: per tile, emitting word and thread, the windows whose hashes so far all hit
@@ -105,7 +106,7 @@ bool query_scratch(nthip_ctx* c, const QueryGeo& g, uint64_t nr, uint64_t n, uin
     return at;
   };
   const size_t o_head = take(head), o_l1 = take(slots1 * 4), o_l2 = take(slots2 * 4), o_ovf = take((size_t)q->ovf_cap * 8);
-  const size_t o_w1 = take((size_t)rows1 * 16 * 1024 * 4), o_w2 = take(slots1 * 4);
+  const size_t o_w1 = take((size_t)rows1 * 16 * 1024 * 2), o_w2 = take(slots1 * 2);
   const size_t o_t1 = take((size_t)rows1 * buckets1 * 8), o_v1 = take((size_t)rows1 * buckets1 * 4);
   const size_t o_t2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 8), o_v2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 4);
   const size_t o_p1 = take(slots1), o_p2 = take(slots2), o_po = take((size_t)q->ovf_cap);
@@ -121,8 +122,8 @@ bool query_scratch(nthip_ctx* c, const QueryGeo& g, uint64_t nr, uint64_t n, uin
   q->list1 = (uint32_t*)(b + o_l1);
   q->list2 = (uint32_t*)(b + o_l2);
   q->ovf = (uint64_t*)(b + o_ovf);
-  q->where1 = (uint32_t*)(b + o_w1);
-  q->where2 = (uint32_t*)(b + o_w2);
+  q->where1 = (uint16_t*)(b + o_w1);
+  q->where2 = (uint16_t*)(b + o_w2);
   q->tab1 = (uint2*)(b + o_t1);
   q->tovf1 = (uint32_t*)(b + o_v1);
   q->tab2 = (uint2*)(b + o_t2);
@@ -557,7 +558,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
       return at;
     };
     const size_t o_head = take(head), o_l1 = take(slots1 * 4), o_l2 = take(slots2 * 4), o_ovf = take((size_t)q.ovf_cap * 8);
-    const size_t o_w1 = take((size_t)n * 4), o_w2 = take(slots1 * 4);
+    const size_t o_w1 = take((size_t)n * 2), o_w2 = take(slots1 * 2);
     const size_t o_t1 = take((size_t)tiles1 * buckets1 * 8), o_v1 = take((size_t)tiles1 * buckets1 * 4);
     const size_t o_t2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 8), o_v2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 4);
     const size_t o_p1 = take(slots1), o_p2 = take(slots2), o_po = take((size_t)q.ovf_cap);
@@ -570,8 +571,8 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
     q.list1 = (uint32_t*)(b + o_l1);
     q.list2 = (uint32_t*)(b + o_l2);
     q.ovf = (uint64_t*)(b + o_ovf);
-    q.where1 = (uint32_t*)(b + o_w1);
-    q.where2 = (uint32_t*)(b + o_w2);
+    q.where1 = (uint16_t*)(b + o_w1);
+    q.where2 = (uint16_t*)(b + o_w2);
     q.tab1 = (uint2*)(b + o_t1);
     q.tovf1 = (uint32_t*)(b + o_v1);
     q.tab2 = (uint2*)(b + o_t2);
