@@ -549,7 +549,7 @@ def consumers(torch, ctx, dev, n_reads=20_000_000):
         t_q, (tq, found) = best(lambda: ctx.bloom_query_ptr(d_in, n_reads, L, 0, k, 1, d_f, n_bits, hits=d_hits))
         hits_sum = int(torch.as_tensor(_DevView(d_hits, n_reads, "<i8"), device=dev).sum().item())
         # the binned query: what it moves per k-mer through its lists, both ways (bytes: DESIGN "bench line legend")
-        list_bytes = 40
+        list_bytes = 32   # 4+2 | 4+4+2 | 4+1 | 2+1+1 | 2+1 (entries, 16-bit places, answer bytes through the five kernels)
         out["bloom_query_4GiB"] = {"value": tq / t_q, "ms": t_q * 1e3, "check": "hits per read add up to the k-mers found; every inserted k-mer is found",
                                    "ok": bool(hits_sum == found == kmers),
                                    "roofline": roof(in_bytes + 8 * n_reads + n_bits // 8, t_q, "bases in + 8 B per read (hits) + the filter read once")}
