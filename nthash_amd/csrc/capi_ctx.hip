@@ -266,6 +266,7 @@ void load_tuning(nthip_tune& t)
   t.seed_pass = num("NTHIP_TUNE_SEED_PASS", 1, 255);
   t.no_scattered = !is_one("NTHIP_TUNE_SCATTERED"); // (round 5: mapped-from-pieces candidates only on request -- capi_util.hip says why)
   t.malloc_pieces = num("NTHIP_TUNE_MALLOC_PIECES", 1, 4096);
+  t.malloc_probe = num("NTHIP_TUNE_MALLOC_PROBE", 1, 8);
   t.no_seed_long = is_one("NTHIP_TUNE_NO_SEED_LONG");
   t.no_seed_w6 = is_one("NTHIP_TUNE_NO_SEED_W6");
   t.no_kmer_reads = is_one("NTHIP_TUNE_NO_KMER_READS");
@@ -368,6 +369,8 @@ extern "C" int nthip_ctx_destroy(nthip_ctx* c)
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->d_scratch2) (void)hipFree(c->d_scratch2);
   if (c->bloom_tmp) (void)hipFree(c->bloom_tmp);
+  for (int i = 0; i < 2; ++i)
+    if (c->kept[i]) (void)hipFree(c->kept[i]);
   for (auto& kv : c->init_tabs) (void)hipFree(kv.second);
   while (!c->scattered.empty()) (void)scattered_free(c, c->scattered.begin()->first);
   fastx_buffers_release(c);
@@ -397,6 +400,11 @@ extern "C" int nthip_ctx_trim(nthip_ctx* c)
   if (c->bloom_tmp) (void)hipFree(c->bloom_tmp);
   c->bloom_tmp = nullptr;
   c->bloom_tmp_bytes = 0;
+  for (int i = 0; i < 2; ++i) {
+    if (c->kept[i]) (void)hipFree(c->kept[i]);
+    c->kept[i] = nullptr;
+    c->kept_bytes[i] = 0;
+  }
   return NTHIP_OK;
 }
 
@@ -454,6 +462,15 @@ extern "C" int nthip_malloc(nthip_ctx* c, size_t bytes, void** p)
 {
   if (!c || !p) return fail(NTHIP_ERR_ARG, "ctx/dptr is NULL");
   HIPCHK(hipSetDevice(c->device));
+  // Which pages hipMalloc hands out puts a big buffer into one of two classes -- five 15 GB allocations of one process: the
+  // compact-stream pass of 20 M reads 4.14-4.21 ms into three of them, 4.68-4.70 into the other two, every time
+  // (tools/var_alloc_spread.py) -- and a fill kernel tells them apart (2.16-2.44 against 2.67-2.68 ms).
+  // NTHIP_TUNE_MALLOC_PROBE=<n> makes a buffer of 1 GiB and more the fastest of n plain allocations (held together, two fills
+  // each, the others given back: nthip_malloc_probed).  NOT the default: the memory given back is not free at once -- a process
+  // that releases tens of GB and allocates again waits for the driver, 2-6 s per 50 GB (tools/probe_cost.py, profiles/r05_notes.md
+  // §12) -- so a caller who wants the fast class asks for it once, at start-up.  (Mapping from physical pieces: default_alloc.)
+  const uint32_t probe = c->tune.malloc_probe ? c->tune.malloc_probe : 1u;
+  if (probe > 1 && bytes >= ((size_t)1 << 30) && c->tune.malloc_pieces < 2) return nthip_malloc_probed(c, bytes, (int)probe, p, nullptr, nullptr);
   return default_alloc(c, bytes, p);
 }
 extern "C" int nthip_free(nthip_ctx* c, void* p)

@@ -101,6 +101,7 @@ struct nthip_tune {
   bool no_seed_w6 = false;    // NTHIP_TUNE_NO_SEED_W6=1: seed_wtile_kernel with 4 waves where 6 would fit (A/B)
   bool no_seed_long = false;  // NTHIP_TUNE_NO_SEED_LONG=1: long reads of SeedNtHash stay on one wave per read
   bool no_scattered = true;   // unless NTHIP_TUNE_SCATTERED=1: nthip_malloc_probed tries plain hipMalloc candidates only (round 5: see capi_util.hip)
+  uint32_t malloc_probe = 0;  // NTHIP_TUNE_MALLOC_PROBE=<n>: plain allocations nthip_malloc measures for a buffer of 1 GiB and more, the fastest kept (1: none; unset: 3)
   uint32_t malloc_pieces = 0; // NTHIP_TUNE_MALLOC_PIECES=<MiB>: nthip_malloc maps buffers of 1 GiB and more from physical pieces of that size (1: plain hipMalloc always; unset: the default policy)
   uint32_t seed_pass = 0;     // NTHIP_TUNE_SEED_PASS=n: seed_wtile_kernel hashes n seeds per pass (A/B; 0: planned)
   bool no_seed_rot = false;   // NTHIP_TUNE_NO_SEED_ROT=1: the plain [table][entry] layout of the byte tables in LDS
@@ -151,6 +152,11 @@ struct nthip_ctx {
   // the binned Bloom insert's lists (capi_sink_bloom.hip): grow-only, released by nthip_ctx_trim / nthip_ctx_destroy
   uint8_t* bloom_tmp = nullptr;
   size_t bloom_tmp_bytes = 0;
+  // the big buffers the consumers' rounds used to allocate and free per call -- [0] the hash stream of a round (reads by offsets,
+  // spaced seeds), [1] the answers of a stream query: grow-only, released by nthip_ctx_trim / nthip_ctx_destroy.  (Round 5: a
+  // process that frees tens of GB and allocates again waits for the driver -- seconds: kept_alloc, capi_util.hip)
+  void* kept[2] = {nullptr, nullptr};
+  size_t kept_bytes[2] = {0, 0};
   uint32_t bloom_slots_backoff = 0; // calls of the binned consumers that keep to the exact lists (a slots-mode round failed)
   bool profiling = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -289,6 +295,12 @@ inline size_t lds_cap_of(const nthip_ctx* c) { return (c->lds_max < 160 * 1024 ?
 // ---- capi_sink_bloom.hip: consumers on reads of any lengths ----
 // device memory that `keep` frees (not the staging arena, which starts over in every staged call)
 int own_alloc(Staged& keep, size_t bytes, void** p);
+// *p = the context's kept buffer `slot` (KEPT_STREAM / KEPT_ANSWERS), at least `bytes` long; grown (freed and allocated anew: its
+// contents are gone) when smaller.  NTHIP_ERR_HIP when the device does not have the memory (the slot is empty then).
+enum : int { KEPT_STREAM = 0, KEPT_ANSWERS = 1 };
+int kept_alloc(nthip_ctx* c, int slot, size_t bytes, void** p);
+// what the context holds and a consumer's round may count as free memory: its lists and its kept buffers are reused, not added to
+inline size_t reusable_bytes(const nthip_ctx* c) { return c->bloom_tmp_bytes + c->kept_bytes[0] + c->kept_bytes[1]; }
 // the compact hash stream (m values per k-mer) of a batch given by offsets, hashed in ONE round into memory `keep` owns;
 // d_counts (optional): per-read counts.  NTHIP_ERR_UNSUPPORTED when the stream does not fit the device
 int stream_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t k, uint8_t m, uint32_t flags, Staged& keep, uint64_t** d_h,

@@ -21,6 +21,30 @@ int ntamd::host::own_alloc(Staged& keep, size_t bytes, void** p)
   return NTHIP_OK;
 }
 
+// The hash stream of a round and the answers of a stream query were hipMalloc'ed and freed per call: 53 GB + 6.6 GB for config 4's
+// seed pair on 5 M reads.  Memory given back is not free at once -- the next allocation of that size waits for the driver: every
+// second or third call of nthip_seed_bloom_query took 3.5-6.5 s instead of 83 ms (tools/seed_query_loop.py).  The context keeps
+// them (grow-only; nthip_ctx_trim gives them back).
+int ntamd::host::kept_alloc(nthip_ctx* c, int slot, size_t bytes, void** p)
+{
+  *p = nullptr;
+  if (bytes == 0) bytes = 16;
+  if (c->kept_bytes[slot] < bytes) {
+    if (c->kept[slot]) HIPCHK(hipFree(c->kept[slot]));
+    c->kept[slot] = nullptr;
+    c->kept_bytes[slot] = 0;
+    const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    if (hipMalloc(&c->kept[slot], want) != hipSuccess) {
+      (void)hipGetLastError();
+      c->kept[slot] = nullptr;
+      return fail(NTHIP_ERR_HIP, "no device memory for %zu MB of a round's hash stream / answers", want >> 20);
+    }
+    c->kept_bytes[slot] = want;
+  }
+  *p = c->kept[slot];
+  return NTHIP_OK;
+}
+
 int ntamd::host::offsets_in_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, size_t scratch_per_base,
                                    const std::function<int(const nthip_reads*, uint64_t, uint64_t)>& fn)
 {
@@ -29,6 +53,7 @@ int ntamd::host::offsets_in_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t
   const bool host = (flags & NTHIP_HOST_INPUT) != 0;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
+  free_b += reusable_bytes(c); // (the context's lists and kept buffers are reused by the round, not added to)
   uint64_t round_bases = (uint64_t)(free_b / 10 * 8) / (scratch_per_base + (host ? 1 : 0));
   if (c->tune.bloom_round) round_bases = c->tune.bloom_round; // (tests: several rounds on a small batch)
   const uint64_t reads_max = std::max<uint64_t>(1, (free_b / 10) / 48);
@@ -78,10 +103,11 @@ int ntamd::host::stream_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t
   const size_t need = (size_t)cap * m * 8 + (d_counts ? (size_t)rd->n_reads * 16 + 4096 : 0);
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  free_b += c->kept_bytes[KEPT_STREAM];
   if (need > free_b / 10 * 9)
     return fail(NTHIP_ERR_UNSUPPORTED, "reads given by offsets: the batch's hash stream (%llu MB) does not fit the device in one round; split the batch",
                 (unsigned long long)(need >> 20));
-  NTCHK(own_alloc(keep, (size_t)cap * m * 8, (void**)d_h));
+  NTCHK(kept_alloc(c, KEPT_STREAM, (size_t)cap * m * 8, (void**)d_h));
   if (d_counts) NTCHK(own_alloc(keep, (size_t)(rd->n_reads + 1) * 8, (void**)d_counts));
   nthip_out out;
   memset(&out, 0, sizeof out);
@@ -988,8 +1014,7 @@ extern "C" int nthip_stream_bloom_query(nthip_ctx* c, const uint64_t* d_hashes, 
     const uint64_t n_values = n_kmers * m;
     bool done = false;
     uint8_t* d_ans = d_flags;
-    if (m > 1 && (c->tune.bloom_query == 2 || (c->tune.bloom_query != 1 && n_values < (1ull << 24)) || hipMalloc((void**)&d_ans, n_values) != hipSuccess)) {
-      (void)hipGetLastError();
+    if (m > 1 && (c->tune.bloom_query == 2 || (c->tune.bloom_query != 1 && n_values < (1ull << 24)) || kept_alloc(c, KEPT_ANSWERS, n_values, (void**)&d_ans) != NTHIP_OK)) {
       d_ans = nullptr;
     }
     if (d_ans) {
@@ -1001,7 +1026,6 @@ extern "C" int nthip_stream_bloom_query(nthip_ctx* c, const uint64_t* d_hashes, 
       }
       if (rc == NTHIP_OK && done) HIPCHK(hipMemcpyAsync(c->h_small + 24, c->d_small + 24, 8, hipMemcpyDeviceToHost, c->stream));
       (void)hipStreamSynchronize(c->stream);
-      if (d_ans != d_flags) (void)hipFree(d_ans);
       NTCHK(rc);
       if (done) {
         if (found) memcpy(found, c->h_small + 24, 8);
@@ -1128,8 +1152,7 @@ extern "C" int nthip_stream_count_query(nthip_ctx* c, const uint64_t* d_hashes, 
     const uint64_t n_values = n_kmers * m;
     bool done = false;
     uint8_t* d_ans = d_estimates;
-    if (m > 1 && (c->tune.bloom_query == 2 || (c->tune.bloom_query != 1 && n_values < (1ull << 24)) || hipMalloc((void**)&d_ans, n_values) != hipSuccess)) {
-      (void)hipGetLastError();
+    if (m > 1 && (c->tune.bloom_query == 2 || (c->tune.bloom_query != 1 && n_values < (1ull << 24)) || kept_alloc(c, KEPT_ANSWERS, n_values, (void**)&d_ans) != NTHIP_OK)) {
       d_ans = nullptr;
     }
     if (d_ans) {
@@ -1140,7 +1163,6 @@ extern "C" int nthip_stream_count_query(nthip_ctx* c, const uint64_t* d_hashes, 
         prof_end(c);
       }
       (void)hipStreamSynchronize(c->stream);
-      if (d_ans != d_estimates) (void)hipFree(d_ans);
       NTCHK(rc);
       if (done) return NTHIP_OK;
     }

@@ -684,23 +684,17 @@ int ntamd::host::stream_hits_per_read(nthip_ctx* c, const uint64_t* d_h, const u
   const uint64_t n_values = n_kmers * m;
   bool done = false;
   uint8_t* d_ans = nullptr;
-  if (c->tune.bloom_query != 2 && (c->tune.bloom_query == 1 || n_values >= (1ull << 24)) && hipMalloc((void**)&d_ans, n_values) != hipSuccess) {
-    (void)hipGetLastError();
+  if (c->tune.bloom_query != 2 && (c->tune.bloom_query == 1 || n_values >= (1ull << 24)) &&
+      kept_alloc(c, KEPT_ANSWERS, n_values, (void**)&d_ans) != NTHIP_OK)
     d_ans = nullptr;
-  }
   if (d_ans) {
-    const int rc = stream_query_binned(c, d_h, n_values, d_filter, n_bits, BQ_BLOOM, d_ans, &done);
-    if (rc == NTHIP_OK && done) {
+    NTCHK(stream_query_binned(c, d_h, n_values, d_filter, n_bits, BQ_BLOOM, d_ans, &done));
+    if (done) {
       prof_begin(c, "answers_per_read_kernel");
       const int rc2 = answers_hits_per_read(c, d_ans, d_roff, n_reads, n_kmers, m, d_hits, d_total);
       prof_end(c);
-      (void)hipStreamSynchronize(c->stream);
-      (void)hipFree(d_ans);
       return rc2;
     }
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(d_ans);
-    NTCHK(rc);
   }
   prof_begin(c, direct_label);
   hipLaunchKernelGGL(stream_bloom_query_kernel, dim3((unsigned)(c->n_cu * 8)), dim3(256), 0, c->stream, d_h, d_roff, n_reads, n_kmers, m, d_filter,

@@ -40,7 +40,7 @@ int run_seed_bloom(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, u
     const uint64_t cap = bases ? bases : 1;
     const uint64_t nr = part->n_reads;
     uint64_t *d_h = nullptr, *d_counts = nullptr, n_windows = 0;
-    NTCHK(own_alloc(keep, (size_t)cap * per * 8, (void**)&d_h));
+    NTCHK(kept_alloc(c, KEPT_STREAM, (size_t)cap * per * 8, (void**)&d_h));
     if (query) NTCHK(own_alloc(keep, (size_t)(nr + 1) * 8, (void**)&d_counts));
     nthip_out out;
     memset(&out, 0, sizeof out);
@@ -83,7 +83,7 @@ int run_seed_bloom(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, u
     // rounds of reads whose seed hashes (+ the lists of the binned insert: 16 B per value) fit a third of the free memory
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
-    free_b += c->bloom_tmp_bytes;
+    free_b += reusable_bytes(c);
     // (the query through the regions: 8 B of hash + 1 B of answer + ~24 B of lists and records per value -- a round whose hashes
     //  alone took a third of the memory left the lists no room, and the call fell back to a filter line per value)
     const uint64_t per_read = nwin * per * (query ? 34 : 24) + 48 + ((flags & NTHIP_HOST_INPUT) ? stride : 0);
