@@ -26,6 +26,7 @@ names = {  # scratch name -> tracked name
     "shape_sweep_long_k.txt": f"{tag}_shape_sweep_long_k.txt",
     "stream_query_bench.txt": f"{tag}_stream_query_bench.txt",
     "stress_stream_query.txt": f"{tag}_stress_stream_query.txt",
+    "alloc_effects.txt": f"{tag}_alloc_effects.txt",
     "kernel_stats_seed_insert.csv": f"{tag}_kernel_stats_seed_insert.csv",
     "reads_kernel_ablation.txt": f"{tag}_reads_kernel_ablation.txt",
     "pytest_gpu.txt": f"{tag}_pytest_gpu.txt",

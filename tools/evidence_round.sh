@@ -36,6 +36,7 @@ SWEEP_SHAPES="150,65,1;150,100,1;250,200,1;1000,500,1;150,80,2;300,128,1;10000,2
 # round 5: hash STREAMS through the regions (stream / offsets / spaced-seed query, seed insert), and the reads kernel without its stores / its hashing
 timeout 600 python tools/stream_query_bench.py > "$OUT/stream_query_bench.txt" 2>&1
 timeout 900 python tools/stress_stream_query.py 60 1 > "$OUT/stress_stream_query.txt" 2>&1
+{ timeout 300 python tools/seed_query_loop.py; timeout 300 python tools/var_alloc_spread.py; timeout 300 python tools/probe_cost.py; } > "$OUT/alloc_effects.txt" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_seed_insert" -o kt -- python tools/seed_insert_one.py > "$OUT/seed_insert_one.txt" 2>&1
 for f in $(find "$OUT/trace_seed_insert" -name "*kernel_stats.csv"); do cp "$f" "$OUT/kernel_stats_seed_insert.csv"; done
 if [ -f nthash_amd/lib/ab/libnthash_hip_rabl1.so ]; then timeout 300 python tools/ab_ragged.py rabl1,rabl2,rabl3 20000000 12 > "$OUT/reads_kernel_ablation.txt" 2>&1; fi
