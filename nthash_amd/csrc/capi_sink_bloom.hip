@@ -357,13 +357,13 @@ bool bloom_slots_ok(nthip_ctx* c)
   return true;
 }
 // values per round of the slots mode: what the free memory allows (about 8.7 B per value), at most BB_SLOTS_ROUND_MAX
-uint64_t slots_round_values(const nthip_ctx* c, uint64_t n_values)
+uint64_t slots_round_values(const nthip_ctx* c, uint64_t n_values, uint64_t round_max = BB_SLOTS_ROUND_MAX)
 {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
   free_b += c->bloom_tmp_bytes;
   uint64_t round = (uint64_t)(free_b / 2) / 9;
-  if (round > BB_SLOTS_ROUND_MAX) round = BB_SLOTS_ROUND_MAX;
+  if (round > round_max) round = round_max;
   if (round > n_values) round = n_values;
   if (round < (1u << 20)) round = 1u << 20;
   if (c->tune.bloom_round) round = c->tune.bloom_round;
@@ -699,11 +699,17 @@ int stream_slots_rounds(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_value
   if (c->bloom_tmp && h0 < c->bloom_tmp + c->bloom_tmp_bytes && h0 + n_values * 8 > c->bloom_tmp) return NTHIP_OK;
   if (!bloom_slots_ok(c)) return NTHIP_OK;
   const uint64_t round = slots_round_values(c, n_values);
+  // pieces mode counts per piece (32 bits each) and places in 64 bits: its rounds are as long as the memory allows (at most 2^33
+  // values) -- every round less is one read-modify-write of the whole table less (config 4's seed pair on 5 M reads: 6.6 G values)
+  const uint64_t round_p = slots_round_values(c, n_values, 1ull << 33);
   while (*done < n_values) {
-    const uint64_t nn = n_values - *done < round ? n_values - *done : round;
+    uint64_t nn = n_values - *done < round_p ? n_values - *done : round_p;
     int outcome = 4;
     NTCHK(bloom_pieces_round(c, nullptr, d_hashes + *done, nn, d_table, n_slots, counters, &outcome, nullptr)); // (round 5: two-level tables)
-    if (outcome == 4) NTCHK(bloom_slots_round(c, nullptr, d_hashes + *done, nn, d_table, n_slots, counters, &outcome));
+    if (outcome == 4) {
+      nn = n_values - *done < round ? n_values - *done : round;
+      NTCHK(bloom_slots_round(c, nullptr, d_hashes + *done, nn, d_table, n_slots, counters, &outcome));
+    }
     if (outcome) break;
     *done += nn;
   }

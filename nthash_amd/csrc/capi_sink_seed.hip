@@ -86,8 +86,9 @@ int run_seed_bloom(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, u
     free_b += reusable_bytes(c);
     // (the query through the regions: 8 B of hash + 1 B of answer + ~24 B of lists and records per value -- a round whose hashes
     //  alone took a third of the memory left the lists no room, and the call fell back to a filter line per value)
-    const uint64_t per_read = nwin * per * (query ? 34 : 24) + 48 + ((flags & NTHIP_HOST_INPUT) ? stride : 0);
-    uint64_t reads_per_round = std::max<uint64_t>(1, (uint64_t)(query ? free_b / 10 * 7 : free_b / 3) / per_read);
+    // (the insert: 8 B of hash + ~9 B of lists per value)
+    const uint64_t per_read = nwin * per * (query ? 34 : 20) + 48 + ((flags & NTHIP_HOST_INPUT) ? stride : 0);
+    uint64_t reads_per_round = std::max<uint64_t>(1, (uint64_t)(free_b / 10 * 7) / per_read);
     if (c->tune.bloom_round) reads_per_round = std::max<uint64_t>(1, c->tune.bloom_round / (nwin * per));
     for (uint64_t r0 = 0; r0 < rd->n_reads; r0 += reads_per_round) {
       nthip_reads part = *rd;
