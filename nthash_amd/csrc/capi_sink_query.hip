@@ -14,6 +14,7 @@ using namespace ntamd::host;
 
 namespace {
 
+constexpr uint64_t BQ_PIECES_ROUND_MAX = 1ull << 33; // pieces mode: counts per piece (32 bits each), every place in 64 bits -- as long as the memory allows
 constexpr uint64_t BQ_ROUND_MAX = 0xC0000000ull; // values per round (list positions are 64-bit; piece counts, overflow indices and tile rows fit 32 bits)
 constexpr uint32_t BQ_L2_THREADS = BB_L2_THREADS, BQ_L2_TILE = BQ_L2_THREADS * BB_PART_ITEMS;
 
@@ -380,15 +381,16 @@ int ntamd::host::bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
   free_b += c->bloom_tmp_bytes;
+  QueryScratch q;
+  uint32_t gx = 1;
+  const bool pieces = query_pieces_ok(c, g, shape, &gx);
   uint64_t round = (uint64_t)(free_b / 10 * 8) / 26;
-  if (round > BQ_ROUND_MAX) round = BQ_ROUND_MAX;
+  const uint64_t round_max = pieces ? BQ_PIECES_ROUND_MAX : BQ_ROUND_MAX;
+  if (round > round_max) round = round_max;
   if (c->tune.bloom_round) round = c->tune.bloom_round;
   uint64_t reads_per_round = round / per_read;
   if (reads_per_round == 0) return NTHIP_OK;
   if (reads_per_round > rd->n_reads - *first) reads_per_round = rd->n_reads - *first;
-  QueryScratch q;
-  uint32_t gx = 1;
-  const bool pieces = query_pieces_ok(c, g, shape, &gx);
   for (;;) { // the scratch of the largest round
     size_t need = 0;
     if (query_scratch(c, g, reads_per_round, reads_per_round * per_read, n_slots, steps, m_s, &q, &need, pieces, gx, per_read)) break;
@@ -511,7 +513,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
   free_b += c->bloom_tmp_bytes;
   uint64_t round = (uint64_t)(free_b / 10 * 8) / 24;
-  if (round > BQ_ROUND_MAX) round = BQ_ROUND_MAX;
+  if (round > (pieces ? BQ_PIECES_ROUND_MAX : BQ_ROUND_MAX)) round = pieces ? BQ_PIECES_ROUND_MAX : BQ_ROUND_MAX;
   if (c->tune.bloom_round) round = c->tune.bloom_round;
   if (round > n_values) round = n_values;
   if (round < (1u << 16)) round = 1u << 16;
