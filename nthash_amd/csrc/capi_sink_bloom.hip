@@ -21,30 +21,6 @@ int ntamd::host::own_alloc(Staged& keep, size_t bytes, void** p)
   return NTHIP_OK;
 }
 
-// The hash stream of a round and the answers of a stream query were hipMalloc'ed and freed per call: 53 GB + 6.6 GB for config 4's
-// seed pair on 5 M reads.  Memory given back is not free at once -- the next allocation of that size waits for the driver: every
-// second or third call of nthip_seed_bloom_query took 3.5-6.5 s instead of 83 ms (tools/seed_query_loop.py).  The context keeps
-// them (grow-only; nthip_ctx_trim gives them back).
-int ntamd::host::kept_alloc(nthip_ctx* c, int slot, size_t bytes, void** p)
-{
-  *p = nullptr;
-  if (bytes == 0) bytes = 16;
-  if (c->kept_bytes[slot] < bytes) {
-    if (c->kept[slot]) HIPCHK(hipFree(c->kept[slot]));
-    c->kept[slot] = nullptr;
-    c->kept_bytes[slot] = 0;
-    const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-    if (hipMalloc(&c->kept[slot], want) != hipSuccess) {
-      (void)hipGetLastError();
-      c->kept[slot] = nullptr;
-      return fail(NTHIP_ERR_HIP, "no device memory for %zu MB of a round's hash stream / answers", want >> 20);
-    }
-    c->kept_bytes[slot] = want;
-  }
-  *p = c->kept[slot];
-  return NTHIP_OK;
-}
-
 int ntamd::host::offsets_in_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t flags, size_t scratch_per_base,
                                    const std::function<int(const nthip_reads*, uint64_t, uint64_t)>& fn)
 {

@@ -274,6 +274,30 @@ constexpr size_t DEFAULT_PIECES_MIN = (size_t)1 << 30; // buffers from this size
 #ifndef NTHIP_DEFAULT_PIECE_MIB
 #define NTHIP_DEFAULT_PIECE_MIB 0 // plain hipMalloc unless NTHIP_TUNE_MALLOC_PIECES says otherwise (see below: why not pieces)
 #endif
+// The hash stream of a round and the answers of a stream query were hipMalloc'ed and freed per call: 53 GB + 6.6 GB for config 4's
+// seed pair on 5 M reads.  Memory given back is not free at once -- the next allocation of that size waits for the driver: every
+// second or third call of nthip_seed_bloom_query took 3.5-6.5 s instead of 83 ms (tools/seed_query_loop.py).  The context keeps
+// them (grow-only; nthip_ctx_trim gives them back).
+int ntamd::host::kept_alloc(nthip_ctx* c, int slot, size_t bytes, void** p)
+{
+  *p = nullptr;
+  if (bytes == 0) bytes = 16;
+  if (c->kept_bytes[slot] < bytes) {
+    if (c->kept[slot]) HIPCHK(hipFree(c->kept[slot]));
+    c->kept[slot] = nullptr;
+    c->kept_bytes[slot] = 0;
+    const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    if (hipMalloc(&c->kept[slot], want) != hipSuccess) {
+      (void)hipGetLastError();
+      c->kept[slot] = nullptr;
+      return fail(NTHIP_ERR_HIP, "no device memory for %zu MB of a round's hash stream / answers", want >> 20);
+    }
+    c->kept_bytes[slot] = want;
+  }
+  *p = c->kept[slot];
+  return NTHIP_OK;
+}
+
 int ntamd::host::default_alloc(nthip_ctx* c, size_t bytes, void** out)
 {
   const uint32_t mib = c->tune.malloc_pieces ? c->tune.malloc_pieces : (uint32_t)NTHIP_DEFAULT_PIECE_MIB;
