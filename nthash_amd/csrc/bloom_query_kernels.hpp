@@ -475,10 +475,19 @@ static __global__ __launch_bounds__(256) void answers_per_read_kernel(const uint
   for (uint64_t r = wave; r < n_reads; r += n_waves) {
     const uint64_t i0 = roff[r], i1 = r + 1 < n_reads ? roff[r + 1] : n_kmers;
     uint32_t found = 0;
-    for (uint64_t i = i0 + lane; i < i1; i += 64u) {
-      uint32_t v = 1u;
-      for (uint32_t j = 0; j < m; ++j) v &= ans[i * m + j] != 0u ? 1u : 0u;
-      found += v;
+    if (m <= 8u) { // the k-mer's m answer bytes (0 / 1) in ONE unaligned 8-byte load (the array has 8 bytes of slack behind it)
+      const uint64_t want = m == 8u ? 0x0101010101010101ull : (0x0101010101010101ull & ((1ull << (8u * m)) - 1ull));
+      for (uint64_t i = i0 + lane; i < i1; i += 64u) {
+        uint64_t v;
+        __builtin_memcpy(&v, ans + i * m, 8);
+        found += (v & want) == want ? 1u : 0u;
+      }
+    } else {
+      for (uint64_t i = i0 + lane; i < i1; i += 64u) {
+        uint32_t v = 1u;
+        for (uint32_t j = 0; j < m; ++j) v &= ans[i * m + j] != 0u ? 1u : 0u;
+        found += v;
+      }
     }
     for (int d = 32; d > 0; d >>= 1) found += (uint32_t)__shfl_xor((int)found, d, 64);
     if (lane == 0) {

@@ -687,7 +687,7 @@ int ntamd::host::stream_hits_per_read(nthip_ctx* c, const uint64_t* d_h, const u
   bool done = false;
   uint8_t* d_ans = nullptr;
   if (c->tune.bloom_query != 2 && (c->tune.bloom_query == 1 || n_values >= (1ull << 24)) &&
-      kept_alloc(c, KEPT_ANSWERS, n_values, (void**)&d_ans) != NTHIP_OK)
+      kept_alloc(c, KEPT_ANSWERS, n_values + 8, (void**)&d_ans) != NTHIP_OK) // (+ 8: answers_per_read_kernel loads 8 bytes at a k-mer's first)
     d_ans = nullptr;
   if (d_ans) {
     NTCHK(stream_query_binned(c, d_h, n_values, d_filter, n_bits, BQ_BLOOM, d_ans, &done));
