@@ -451,9 +451,18 @@ static __global__ __launch_bounds__(256) void answers_per_kmer_kernel(const uint
   uint32_t mine = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_kmers; i += (uint64_t)gridDim.x * blockDim.x) {
     uint32_t v = KIND == BQ_BLOOM ? 1u : 255u;
-    for (uint32_t j = 0; j < m; ++j) {
-      const uint32_t x = ans[i * m + j];
-      v = KIND == BQ_BLOOM ? (v & (x != 0u ? 1u : 0u)) : (x < v ? x : v);
+    if (m <= 8u && out != ans) { // the m answer bytes in one unaligned 8-byte load (m > 1: `ans` is scratch with 8 bytes of slack behind it)
+      uint64_t w;
+      __builtin_memcpy(&w, ans + i * m, 8);
+      for (uint32_t j = 0; j < m; ++j) {
+        const uint32_t x = (uint32_t)(w >> (8u * j)) & 0xFFu;
+        v = KIND == BQ_BLOOM ? (v & (x != 0u ? 1u : 0u)) : (x < v ? x : v);
+      }
+    } else {
+      for (uint32_t j = 0; j < m; ++j) {
+        const uint32_t x = ans[i * m + j];
+        v = KIND == BQ_BLOOM ? (v & (x != 0u ? 1u : 0u)) : (x < v ? x : v);
+      }
     }
     out[i] = (uint8_t)v;
     mine += KIND == BQ_BLOOM ? v : 0u;

@@ -996,7 +996,7 @@ extern "C" int nthip_stream_bloom_query(nthip_ctx* c, const uint64_t* d_hashes, 
     const uint64_t n_values = n_kmers * m;
     bool done = false;
     uint8_t* d_ans = d_flags;
-    if (m > 1 && (c->tune.bloom_query == 2 || (c->tune.bloom_query != 1 && n_values < (1ull << 24)) || kept_alloc(c, KEPT_ANSWERS, n_values, (void**)&d_ans) != NTHIP_OK)) {
+    if (m > 1 && (c->tune.bloom_query == 2 || (c->tune.bloom_query != 1 && n_values < (1ull << 24)) || kept_alloc(c, KEPT_ANSWERS, n_values + 8, (void**)&d_ans) != NTHIP_OK)) {
       d_ans = nullptr;
     }
     if (d_ans) {
@@ -1134,7 +1134,7 @@ extern "C" int nthip_stream_count_query(nthip_ctx* c, const uint64_t* d_hashes, 
     const uint64_t n_values = n_kmers * m;
     bool done = false;
     uint8_t* d_ans = d_estimates;
-    if (m > 1 && (c->tune.bloom_query == 2 || (c->tune.bloom_query != 1 && n_values < (1ull << 24)) || kept_alloc(c, KEPT_ANSWERS, n_values, (void**)&d_ans) != NTHIP_OK)) {
+    if (m > 1 && (c->tune.bloom_query == 2 || (c->tune.bloom_query != 1 && n_values < (1ull << 24)) || kept_alloc(c, KEPT_ANSWERS, n_values + 8, (void**)&d_ans) != NTHIP_OK)) {
       d_ans = nullptr;
     }
     if (d_ans) {
