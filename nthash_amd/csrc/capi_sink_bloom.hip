@@ -651,13 +651,19 @@ int fused_slots_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t
   const uint64_t round = slots_round_values(c, (rd->n_reads - *r0) * per_read);
   const uint64_t reads_per_round = round / per_read;
   if (reads_per_round == 0) return NTHIP_OK;
+  // (pieces mode: rounds as long as the memory allows -- every round less is a read-modify-write of the whole table less)
+  const uint64_t reads_per_round_p = std::max<uint64_t>(reads_per_round, slots_round_values(c, (rd->n_reads - *r0) * per_read, 1ull << 33) / per_read);
   while (*r0 < rd->n_reads) {
-    const uint64_t nr = rd->n_reads - *r0 < reads_per_round ? rd->n_reads - *r0 : reads_per_round;
-    const BloomFusedSrc src = {(const uint8_t*)rd->seqs + *r0 * stride, nr, len, stride, k, m};
+    uint64_t nr = rd->n_reads - *r0 < reads_per_round_p ? rd->n_reads - *r0 : reads_per_round_p;
+    BloomFusedSrc src = {(const uint8_t*)rd->seqs + *r0 * stride, nr, len, stride, k, m};
     int outcome = 0;
     uint64_t lost = 0;
     NTCHK(bloom_pieces_round(c, &src, nullptr, 0, d_table, n_slots, counters, &outcome, &lost)); // (round 5: two-level tables)
-    if (outcome == 4) NTCHK(bloom_slots_round(c, &src, nullptr, nr * per_read, d_table, n_slots, counters, &outcome, &lost));
+    if (outcome == 4) {
+      nr = rd->n_reads - *r0 < reads_per_round ? rd->n_reads - *r0 : reads_per_round;
+      src.n_reads = nr;
+      NTCHK(bloom_slots_round(c, &src, nullptr, nr * per_read, d_table, n_slots, counters, &outcome, &lost));
+    }
     if (outcome) return NTHIP_OK;
     *sum += nr * (uint64_t)(len - k + 1) - lost;
     *r0 += nr;
