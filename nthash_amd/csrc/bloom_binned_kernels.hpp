@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "bloom_math.hpp"
+#include "nt_math.hpp" // (mix_hash: the values of a stream that holds hashes()[0] only)
 
 namespace ntamd {
 
@@ -769,19 +770,26 @@ struct BloomPartStreamPiecesArgs {
   uint16_t* q_where;
   uint2* q_tab;
   uint32_t* q_tovf;
+  uint64_t kmul; // M > 1: k * MULTISEED
 };
 
-template <uint32_t BB_PART_THREADS, bool QUERY = false>
+// M > 1: the stream holds ONE value per M -- hashes()[0] of a k-mer / of a seed's window -- and the kernel makes the other M - 1
+// itself (extend_hashes, src/internal.hpp:104-118: h[j] = mix(h[0] * (j ^ k * MULTISEED))): a.n counts the INPUTS, a thread takes
+// 16 / M of them per tile, value v of the full stream is h[v % M] of input v / M (q_where is indexed by v).  The stream that is
+// written and read back shrinks M-fold: config 4's seed pair with 3 hashes per seed moves 17.6 GB each way instead of 53.
+template <uint32_t BB_PART_THREADS, bool QUERY = false, uint32_t M = 1>
 static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_stream_pieces_kernel(const BloomPartStreamPiecesArgs a)
 {
-  constexpr uint32_t BB_TILE = BB_PART_THREADS * BB_PART_ITEMS;
+  constexpr uint32_t IN = BB_PART_ITEMS / M;            // inputs per thread and tile
+  constexpr uint32_t BB_TILE = BB_PART_THREADS * IN;    // inputs per tile (M == 1: BB_PART_THREADS * 16)
+  constexpr uint32_t BB_SORTED = BB_PART_THREADS * BB_PART_ITEMS; // room of the sorted tile (its values: BB_TILE * M)
   __shared__ uint32_t hist[BB_MAX_BINS];
   __shared__ uint32_t off[BB_MAX_BINS];
   __shared__ uint32_t gbase[BB_MAX_BINS];
   __shared__ uint32_t lcnt[BB_MAX_BINS], pcur[BB_MAX_BINS];
   extern __shared__ __attribute__((aligned(16))) uint32_t bb_lds[];
-  uint32_t* const sorted = bb_lds;         // BB_TILE entries
-  uint32_t* const left = bb_lds + BB_TILE; // [bucket][32]
+  uint32_t* const sorted = bb_lds;           // BB_SORTED entries
+  uint32_t* const left = bb_lds + BB_SORTED; // [bucket][32]
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t n_buckets = a.n_buckets;
   if (tid < BB_MAX_BINS) {
@@ -789,11 +797,11 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_stream_piec
     pcur[tid] = 0;
   }
   const uint64_t n_tiles = (a.n + BB_TILE - 1) / BB_TILE;
-  uint64_t pre[BB_PART_ITEMS];
+  uint64_t pre[IN];
   auto fetch = [&](uint64_t tile) {
     const uint64_t t0 = tile * BB_TILE;
 #pragma unroll
-    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
+    for (uint32_t j = 0; j < IN; ++j) {
       const uint64_t idx = t0 + (uint64_t)j * BB_PART_THREADS + tid;
       pre[j] = 0;
       if (idx < a.n) pre[j] = __builtin_nontemporal_load(a.in + idx);
@@ -805,25 +813,23 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_stream_piec
     __syncthreads();
     const uint64_t t0 = tile * BB_TILE;
     uint32_t val[BB_PART_ITEMS], where[BB_PART_ITEMS]; // where = bucket << 16 | rank inside the tile's bucket
-    if (t0 + BB_TILE <= a.n) {
+    const bool whole = t0 + BB_TILE <= a.n; // (no test per value then: the thread's rank atomics are in flight together)
 #pragma unroll
-      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
-        const uint64_t p = mod_invariant(pre[j], a.n_bits, a.magic);
-        const uint32_t b = (uint32_t)(p >> a.shift);
-        val[j] = (uint32_t)p & a.mask;
-        where[j] = (b << 16) | atomicAdd(&hist[b], 1u);
-      }
-    } else {
+    for (uint32_t q = 0; q < BB_PART_ITEMS; ++q) {
+      where[q] = ~0u;
+      val[q] = 0;
+    }
 #pragma unroll
-      for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
-        const uint64_t idx = t0 + (uint64_t)j * BB_PART_THREADS + tid;
-        where[j] = ~0u;
-        val[j] = 0;
-        if (idx < a.n) {
-          const uint64_t p = mod_invariant(pre[j], a.n_bits, a.magic);
+    for (uint32_t u = 0; u < IN; ++u) {
+      const uint64_t idx = t0 + (uint64_t)u * BB_PART_THREADS + tid;
+      if (whole || idx < a.n) {
+#pragma unroll
+        for (uint32_t j = 0; j < M; ++j) {
+          const uint64_t h = j == 0 ? pre[u] : mix_hash(pre[u], (uint64_t)j ^ a.kmul);
+          const uint64_t p = mod_invariant(h, a.n_bits, a.magic);
           const uint32_t b = (uint32_t)(p >> a.shift);
-          val[j] = (uint32_t)p & a.mask;
-          where[j] = (b << 16) | atomicAdd(&hist[b], 1u);
+          val[u * M + j] = (uint32_t)p & a.mask;
+          where[u * M + j] = (b << 16) | atomicAdd(&hist[b], 1u);
         }
       }
     }
@@ -859,12 +865,14 @@ static __global__ __launch_bounds__(BB_PART_THREADS) void bloom_part_stream_piec
     }
     __syncthreads();
 #pragma unroll
-    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j)
-      if (where[j] != ~0u) {
-        const uint32_t slot = off[where[j] >> 16] + (where[j] & 0xFFFFu);
-        sorted[slot] = val[j];
-        if constexpr (QUERY) a.q_where[t0 + (uint64_t)j * BB_PART_THREADS + tid] = (uint16_t)slot;
-      }
+    for (uint32_t u = 0; u < IN; ++u)
+#pragma unroll
+      for (uint32_t j = 0; j < M; ++j)
+        if (where[u * M + j] != ~0u) {
+          const uint32_t slot = off[where[u * M + j] >> 16] + (where[u * M + j] & 0xFFFFu);
+          sorted[slot] = val[u * M + j];
+          if constexpr (QUERY) a.q_where[(t0 + (uint64_t)u * BB_PART_THREADS + tid) * M + j] = (uint16_t)slot;
+        }
     __syncthreads();
     bloom_copy_out_lines<BB_PART_THREADS / 64u, QUERY>(sorted, hist, off, gbase, left, lcnt, n_buckets, wave, lane, a.out, (uint64_t)blockIdx.x,
                                                        (uint64_t)gridDim.x, 0ull, a.sl, a.shift, QUERY ? a.q_tovf + q_row : nullptr);

@@ -412,32 +412,37 @@ static __global__ __launch_bounds__(THREADS) void bloom_back1_kernel(const Bloom
 // ---- the binned query of a hash STREAM (reads of any lengths, spaced seeds, nthip_stream_*_query) -------------------------------
 // Level 1 is bloom_part_kernel<true, THREADS, true> on the stream (tiles of THREADS x 16 values, `where` per value, `tab` per
 // tile); the way back of its tiles gives one answer byte per VALUE, next to the stream: ans[i].
-template <uint32_t THREADS>
-static __global__ __launch_bounds__(THREADS) void bloom_back1_stream_kernel(const BloomBackArgs a, uint64_t n_values, uint8_t* __restrict__ ans)
+template <uint32_t THREADS, uint32_t M = 1>
+static __global__ __launch_bounds__(THREADS) void bloom_back1_stream_kernel(const BloomBackArgs a, uint64_t n_inputs, uint8_t* __restrict__ ans)
 {
-  constexpr uint32_t TILE = THREADS * BB_PART_ITEMS;
+  // (M > 1: the tiles of bloom_part_stream_pieces_kernel<.., M> -- 16 / M inputs per thread, value v = input * M + j)
+  constexpr uint32_t IN = BB_PART_ITEMS / M, TILE = THREADS * IN;
   __shared__ uint32_t cnt[BB_MAX_BINS], gat[BB_MAX_BINS], offfit[BB_MAX_BINS + 1];
-  __shared__ __attribute__((aligned(16))) uint8_t stage[TILE];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[THREADS * BB_PART_ITEMS];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (bloom_round_failed(a.status, a.ovf_cap)) return;
-  const uint64_t n_tiles = (n_values + TILE - 1) / TILE;
+  const uint64_t n_tiles = (n_inputs + TILE - 1) / TILE;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t t0 = tile * TILE;
     uint32_t w[BB_PART_ITEMS];
 #pragma unroll
-    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
-      const uint64_t idx = t0 + (uint64_t)j * THREADS + tid;
-      w[j] = idx < n_values ? (uint32_t)__builtin_nontemporal_load(a.where + idx) : BQ_NONE;
-    }
+    for (uint32_t u = 0; u < IN; ++u)
+#pragma unroll
+      for (uint32_t j = 0; j < M; ++j) {
+        const uint64_t idx = t0 + (uint64_t)u * THREADS + tid;
+        w[u * M + j] = idx < n_inputs ? (uint32_t)__builtin_nontemporal_load(a.where + idx * M + j) : BQ_NONE;
+      }
     const uint64_t row = tile * a.n_buckets;
     // (pieces mode, g1 blocks at level 1: the tile was written by block tile % g1 into ITS piece of every bucket)
     bq_stage_runs<THREADS / 64u>(a.tab + row, a.n_buckets, a.pay_in, a.g1 ? tile % a.g1 : 0ull, a.g1 ? (uint64_t)a.g1 : 1ull, a.cap, stage, cnt, gat,
                                  offfit, tid, lane, wave);
 #pragma unroll
-    for (uint32_t j = 0; j < BB_PART_ITEMS; ++j) {
-      const uint64_t idx = t0 + (uint64_t)j * THREADS + tid;
-      if (w[j] != BQ_NONE) ans[idx] = (uint8_t)bq_pick(w[j], stage, offfit, a.tovf + row, a.ovf_pay);
-    }
+    for (uint32_t u = 0; u < IN; ++u)
+#pragma unroll
+      for (uint32_t j = 0; j < M; ++j) {
+        const uint64_t idx = t0 + (uint64_t)u * THREADS + tid;
+        if (w[u * M + j] != BQ_NONE) ans[idx * M + j] = (uint8_t)bq_pick(w[u * M + j], stage, offfit, a.tovf + row, a.ovf_pay);
+      }
     __syncthreads();
   }
 }

@@ -333,6 +333,11 @@ int answers_per_kmer(nthip_ctx* c, const uint8_t* d_ans, uint64_t n_kmers, uint3
 // stream_bloom_query_kernel (a filter line per value) otherwise.  *d_total += the hits.  Launches, and waits when it held scratch.
 int stream_hits_per_read(nthip_ctx* c, const uint64_t* d_h, const uint64_t* d_roff, uint64_t n_reads, uint64_t n_kmers, uint32_t m,
                          const uint32_t* d_filter, uint64_t n_bits, uint64_t* d_hits, unsigned long long* d_total, const char* direct_label);
+// the stream insert / the binned stream query of a stream that holds hashes()[0] only: level 1 makes the other expand_m - 1 values of
+// every input (bloom_part_stream_pieces_kernel<.., M>; expand_m 2 ... 4, kmul = k * MULTISEED).  *done = false: the caller hashes
+// the full stream and takes the usual road.
+int stream_bloom_insert_expand(nthip_ctx* c, const uint64_t* d_h0, uint64_t n_inputs, uint32_t expand_m, uint64_t kmul, uint32_t* d_filter,
+                               uint64_t n_bits, bool* done);
 int answers_hits_per_read(nthip_ctx* c, const uint8_t* d_ans, const uint64_t* d_roff, uint64_t n_reads, uint64_t n_kmers, uint32_t m,
                           uint64_t* d_hits, unsigned long long* d_total_hits);
 

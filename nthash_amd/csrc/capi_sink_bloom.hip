@@ -499,8 +499,10 @@ int bloom_slots_round(nthip_ctx* c, const BloomFusedSrc* fused, const uint64_t* 
 // block-private pieces written in whole lines -- no cursors, no atomics.  *outcome as bloom_slots_round, and 4: not a shape /
 // table of this mode (nothing done)
 // (stream != NULL: the n_stream values of a hash stream instead of reads -- level 1 is bloom_part_stream_pieces_kernel)
+// (expand_m = 2 ... 4: the stream holds hashes()[0] only and level 1 makes the other expand_m - 1 values of every input -- kmul =
+//  k * MULTISEED, n_stream counts the INPUTS; other expand_m: outcome 4)
 int bloom_pieces_round(nthip_ctx* c, const BloomFusedSrc* srcp, const uint64_t* stream, uint64_t n_stream, uint32_t* d_table, uint64_t n_slots,
-                       bool counters, int* outcome, uint64_t* lost)
+                       bool counters, int* outcome, uint64_t* lost, uint32_t expand_m = 1, uint64_t kmul = 0)
 {
   constexpr uint32_t S1_THREADS = 1024, S1_TILE = S1_THREADS * BB_PART_ITEMS;
   const BloomFusedSrc src = srcp ? *srcp : BloomFusedSrc{};
@@ -509,12 +511,13 @@ int bloom_pieces_round(nthip_ctx* c, const BloomFusedSrc* srcp, const uint64_t* 
   const uint32_t n_bins = (n_regions + BB_REGIONS_PER_BIN - 1) / BB_REGIONS_PER_BIN;
   *outcome = 4;
   if (n_bins < 2 || c->tune.bloom_pieces == 2) return NTHIP_OK;
+  if (expand_m < 1 || expand_m > 4 || (expand_m > 1 && !stream)) return NTHIP_OK;
   const size_t lds1 = stream ? ((size_t)S1_TILE + (size_t)BB_MAX_BINS * 32u) * sizeof(uint32_t) : bloom_fused_lds(src, 1024u, 1024u * 16u + BB_PIECES_LDS_DWORDS);
   if (lds1 > lds_cap_of(c) - 4096) return NTHIP_OK;
   const uint64_t magic = bloom_magic_of(n_slots);
   const uint64_t table_dwords = counters ? (n_slots + 3) / 4 : (n_slots + 31) / 32;
   const uint32_t nwin = stream ? 0u : src.len - src.k + 1u;
-  const uint64_t n = stream ? n_stream : src.n_reads * (uint64_t)nwin * src.m;
+  const uint64_t n = stream ? n_stream * expand_m : src.n_reads * (uint64_t)nwin * src.m; // values
   constexpr uint32_t L2_TILE = BB_L2_THREADS * BB_PART_ITEMS;
   const size_t lds2 = ((size_t)L2_TILE + (size_t)BB_REGIONS_PER_BIN * 32u) * sizeof(uint32_t);
   int l2_per_cu = 1;
@@ -525,10 +528,11 @@ int bloom_pieces_round(nthip_ctx* c, const BloomFusedSrc* srcp, const uint64_t* 
   if (stream) { // a block of level 1 takes every g1-th tile of the stream
     int per1 = 1;
     NTCHK(blocks_per_cu(c, bloom_part_stream_pieces_kernel<S1_THREADS, false>, (int)S1_THREADS, lds1, &per1));
-    const uint64_t tiles1 = (n + S1_TILE - 1) / S1_TILE;
+    const uint64_t tile_in = (uint64_t)S1_THREADS * (BB_PART_ITEMS / expand_m); // inputs per tile
+    const uint64_t tiles1 = (n_stream + tile_in - 1) / tile_in;
     g.g1 = (uint32_t)std::min<uint64_t>(tiles1 ? tiles1 : 1, (uint64_t)c->n_cu * (uint64_t)per1);
     g.gx = gx;
-    const double per_block = (double)((tiles1 + g.g1 - 1) / g.g1) * (double)S1_TILE;
+    const double per_block = (double)((tiles1 + g.g1 - 1) / g.g1) * (double)(tile_in * expand_m);
     const double bin_slots = (double)(1ull << bin_shift), region_slots = (double)(1ull << region_shift);
     g.cap1 = piece_cap(c, per_block * (bin_slots < (double)n_slots ? bin_slots / (double)n_slots : 1.0));
     g.cap2 = piece_cap(c, (double)((g.g1 + gx - 1) / gx) * per_block * (region_slots < (double)n_slots ? region_slots / (double)n_slots : 1.0));
@@ -565,7 +569,8 @@ int bloom_pieces_round(nthip_ctx* c, const BloomFusedSrc* srcp, const uint64_t* 
     BloomPartStreamPiecesArgs a;
     memset((void*)&a, 0, sizeof a);
     a.in = stream;
-    a.n = n;
+    a.n = n_stream;
+    a.kmul = kmul;
     a.n_bits = n_slots;
     a.magic = magic;
     a.out = list1;
@@ -574,8 +579,23 @@ int bloom_pieces_round(nthip_ctx* c, const BloomFusedSrc* srcp, const uint64_t* 
     a.mask = (1u << bin_shift) - 1u;
     a.n_buckets = n_bins;
     a.sl = {g.cap1, ovf, status, ovf_cap};
-    NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<S1_THREADS, false>, lds1));
-    hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<S1_THREADS, false>), dim3(g.g1), dim3(S1_THREADS), lds1, c->stream, a);
+    switch (expand_m) {
+      case 2:
+        NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<S1_THREADS, false, 2>, lds1));
+        hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<S1_THREADS, false, 2>), dim3(g.g1), dim3(S1_THREADS), lds1, c->stream, a);
+        break;
+      case 3:
+        NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<S1_THREADS, false, 3>, lds1));
+        hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<S1_THREADS, false, 3>), dim3(g.g1), dim3(S1_THREADS), lds1, c->stream, a);
+        break;
+      case 4:
+        NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<S1_THREADS, false, 4>, lds1));
+        hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<S1_THREADS, false, 4>), dim3(g.g1), dim3(S1_THREADS), lds1, c->stream, a);
+        break;
+      default:
+        NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<S1_THREADS, false>, lds1));
+        hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<S1_THREADS, false>), dim3(g.g1), dim3(S1_THREADS), lds1, c->stream, a);
+    }
   } else {
     BloomFusedPiecesArgs fa;
     bloom_fused_args(src, 1024u, n_slots, magic, &fa);
@@ -673,8 +693,10 @@ int fused_slots_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t
 
 // A device-resident hash stream through slots-mode rounds (the stream must not live in the context's list buffer):
 // *done = the values that went through; the caller takes the rest through the exact lists.
+// (expand_m > 1: d_hashes holds hashes()[0] of n_values INPUTS, level 1 makes the other values -- pieces mode only: *done stays
+//  short of n_values when the table / the device is not for it, and the caller hashes the full stream)
 int stream_slots_rounds(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, uint32_t* d_table, uint64_t n_slots, bool counters,
-                        uint64_t* done)
+                        uint64_t* done, uint32_t expand_m = 1, uint64_t kmul = 0)
 {
   *done = 0;
   const uint8_t* const h0 = (const uint8_t*)d_hashes;
@@ -683,11 +705,12 @@ int stream_slots_rounds(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_value
   const uint64_t round = slots_round_values(c, n_values);
   // pieces mode counts per piece (32 bits each) and places in 64 bits: its rounds are as long as the memory allows (at most 2^33
   // values) -- every round less is one read-modify-write of the whole table less (config 4's seed pair on 5 M reads: 6.6 G values)
-  const uint64_t round_p = slots_round_values(c, n_values, 1ull << 33);
+  const uint64_t round_p = slots_round_values(c, n_values * expand_m, 1ull << 33) / expand_m;
   while (*done < n_values) {
     uint64_t nn = n_values - *done < round_p ? n_values - *done : round_p;
     int outcome = 4;
-    NTCHK(bloom_pieces_round(c, nullptr, d_hashes + *done, nn, d_table, n_slots, counters, &outcome, nullptr)); // (round 5: two-level tables)
+    NTCHK(bloom_pieces_round(c, nullptr, d_hashes + *done, nn, d_table, n_slots, counters, &outcome, nullptr, expand_m, kmul)); // (round 5: two-level tables)
+    if (outcome == 4 && expand_m > 1) break;
     if (outcome == 4) {
       nn = n_values - *done < round ? n_values - *done : round;
       NTCHK(bloom_slots_round(c, nullptr, d_hashes + *done, nn, d_table, n_slots, counters, &outcome));
@@ -897,6 +920,22 @@ extern "C" int nthip_kmer_bloom_query(nthip_ctx* c, const nthip_reads* rd, uint1
                                       uint64_t* total_hits, uint32_t flags)
 {
   return run_kmer_bloom(c, rd, k, m, (uint32_t*)d_filter, n_bits, hits, total, total_hits, flags, true);
+}
+
+// The stream insert for a stream that holds hashes()[0] only (n_inputs of them; the filter gets expand_m values of each: level 1
+// makes the others).  *done = false (filter untouched or touched in part -- setting a bit twice is harmless): not a table / a
+// device for it, the caller hashes the full stream and takes nthip_stream_bloom_insert.  Waits for the stream.
+int ntamd::host::stream_bloom_insert_expand(nthip_ctx* c, const uint64_t* d_h0, uint64_t n_inputs, uint32_t expand_m, uint64_t kmul, uint32_t* d_filter,
+                                            uint64_t n_bits, bool* done)
+{
+  *done = false;
+  if (expand_m < 2 || expand_m > 4 || n_inputs == 0) return NTHIP_OK;
+  if (!bloom_binned_ok(c, d_filter, n_bits, n_inputs * expand_m)) return NTHIP_OK;
+  uint64_t got = 0;
+  NTCHK(stream_slots_rounds(c, d_h0, n_inputs, d_filter, n_bits, false, &got, expand_m, kmul));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *done = got == n_inputs;
+  return NTHIP_OK;
 }
 
 extern "C" int nthip_stream_bloom_insert(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, uint8_t* d_filter,

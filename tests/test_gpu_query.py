@@ -274,12 +274,16 @@ SEEDS_K48 = ["110110110110110110110110011011011011011011011011", "10110110110110
     (SEEDS_K48, 48, 2, 1500, 150, 40_000_003, False, False),                      # three seeds of 48
     (SEEDS_K48, 48, 1, 1200, 0, 1 << 24, False, True),                            # reads of any lengths
     ([SEED_A], 31, 1, 400, 40, 1 << 20, False, False),
+    # the insert from hashes()[0] alone, the first partition level making the other m2 - 1 values (forced through the lists)
+    ([SEED_A, SEED_B], 31, 3, 3000, 250, (1 << 28) + 12_345_677, "binned", False),
+    ([SEED_A, SEED_B], 31, 2, 2500, 250, (1 << 29) + 5, "binned", False),
+    (SEEDS_K48, 48, 4, 1500, 150, (1 << 28) + 77, "binned", True),
 ])
 def test_seed_bloom_insert_and_query_match_oracle_seed_stream(oracle, seeds, k, m2, n, L, n_bits, rounds, by_offsets):
     """the filter after nthip_seed_bloom_insert == the filter built on the CPU from the oracle's seed_batch stream (every one
     of the n_seeds * m2 hashes of every window the reference's SeedNtHash emits, src/seed.cpp:493-544 -- reads with
     non-bases included); nthip_seed_bloom_query's hits per read == the windows whose hashes all hit that filter"""
-    env = {"NTHIP_TUNE_BLOOM_ROUND": 700_000} if rounds else {}
+    env = {"NTHIP_TUNE_BLOOM_BINNED": 1} if rounds == "binned" else {"NTHIP_TUNE_BLOOM_ROUND": 700_000} if rounds else {}
     ctx = _ctx_with(env)
     import nthash_amd
     sd = nthash_amd.Seeds(ctx, seeds, k)
