@@ -324,15 +324,18 @@ int bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t
 // The binned query of a hash STREAM (device memory, not inside the context's list buffer): d_ans[i] = the answer of value i
 // (filter: its bit; sketch: its counter), region by region as above (slots mode: level 1 is the stream's partition).
 // *done = false (nothing written): not a table / a stream for it, or skewed values -- the caller keeps its direct kernel.
+// (expand_m = 2 ... 4: d_hashes holds hashes()[0] of n_values INPUTS and level 1 makes the other values of each -- d_ans[input *
+//  expand_m + j], kmul = k * MULTISEED; two-level tables in pieces mode only, *done = false otherwise)
 int stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, const uint32_t* d_table, uint64_t n_slots, int kind,
-                        uint8_t* d_ans, bool* done);
+                        uint8_t* d_ans, bool* done, uint32_t expand_m = 1, uint64_t kmul = 0);
 // the answers of a stream's values, k-mer by k-mer (m consecutive values each): filter: flags[i] = all set, *found their number;
 // sketch: out[i] = the smallest.  hits per read (roff: first k-mer of every read): answers_hits_per_read.  Launches only.
 int answers_per_kmer(nthip_ctx* c, const uint8_t* d_ans, uint64_t n_kmers, uint32_t m, int kind, uint8_t* d_out, unsigned long long* d_found);
 // hits per read of a stream of k-mers' values against a filter: stream_query_binned + answers_hits_per_read when that applies,
 // stream_bloom_query_kernel (a filter line per value) otherwise.  *d_total += the hits.  Launches, and waits when it held scratch.
 int stream_hits_per_read(nthip_ctx* c, const uint64_t* d_h, const uint64_t* d_roff, uint64_t n_reads, uint64_t n_kmers, uint32_t m,
-                         const uint32_t* d_filter, uint64_t n_bits, uint64_t* d_hits, unsigned long long* d_total, const char* direct_label);
+                         const uint32_t* d_filter, uint64_t n_bits, uint64_t* d_hits, unsigned long long* d_total, const char* direct_label,
+                         uint32_t expand_m = 1, uint64_t kmul = 0, bool* expanded = nullptr);
 // the stream insert / the binned stream query of a stream that holds hashes()[0] only: level 1 makes the other expand_m - 1 values of
 // every input (bloom_part_stream_pieces_kernel<.., M>; expand_m 2 ... 4, kmul = k * MULTISEED).  *done = false: the caller hashes
 // the full stream and takes the usual road.

@@ -473,10 +473,14 @@ int ntamd::host::answers_hits_per_read(nthip_ctx* c, const uint8_t* d_ans, const
 #ifndef SQ_PIECES_THREADS
 #define SQ_PIECES_THREADS 1024 // pieces mode
 #endif
-int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, const uint32_t* d_table, uint64_t n_slots, int kind,
-                                     uint8_t* d_ans, bool* done)
+int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_in, const uint32_t* d_table, uint64_t n_slots, int kind,
+                                     uint8_t* d_ans, bool* done, uint32_t M, uint64_t kmul)
 {
+  // (M = 2 ... 4: the stream holds hashes()[0] of n_in inputs, level 1 makes the other M - 1 values of each -- pieces mode only;
+  //  d_ans[input * M + j]; n_values below: what is looked up)
   *done = false;
+  if (M < 1 || M > 4) return NTHIP_OK;
+  const uint64_t n_values = n_in * M;
   if (c->tune.bloom_query == 2 || n_values == 0 || ((uintptr_t)d_table & 15u)) return NTHIP_OK;
   QueryGeo g;
   if (!query_geo(n_slots, kind, &g)) return NTHIP_OK;
@@ -485,15 +489,16 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
   if (c->tune.bloom_query != 1 && (n_values < (1ull << 24) || table_bytes < (32ull << 20) || n_values < table_bytes / 32)) return NTHIP_OK;
   {
     const uint8_t* const h0 = (const uint8_t*)d_hashes; // (the stream must not live in the buffer the lists are carved from)
-    if (c->bloom_tmp && h0 < c->bloom_tmp + c->bloom_tmp_bytes && h0 + n_values * 8 > c->bloom_tmp) return NTHIP_OK;
+    if (c->bloom_tmp && h0 < c->bloom_tmp + c->bloom_tmp_bytes && h0 + n_in * 8 > c->bloom_tmp) return NTHIP_OK;
   }
   constexpr uint32_t L1_THREADS = SQ_L1_THREADS, L1_TILE = L1_THREADS * BB_PART_ITEMS;
-  constexpr uint32_t P1_THREADS = SQ_PIECES_THREADS, P1_TILE = P1_THREADS * BB_PART_ITEMS;
+  constexpr uint32_t P1_THREADS = SQ_PIECES_THREADS, P1_SORTED = P1_THREADS * BB_PART_ITEMS;
+  const uint64_t P1_TILE = (uint64_t)P1_THREADS * (BB_PART_ITEMS / M); // inputs per tile of the pieces level
   const uint64_t magic = bloom_magic_of(n_slots);
   const uint32_t shift1 = g.one ? g.region_shift : g.bin_shift, buckets1 = g.one ? g.n_regions : g.n_bins;
   // pieces mode (a two-level table): block-private pieces at both levels, whole lines only (bloom_binned_kernels.hpp)
   bool pieces = !g.one && c->tune.bloom_pieces != 2;
-  const size_t p1_lds = ((size_t)P1_TILE + (size_t)BB_MAX_BINS * 32u) * sizeof(uint32_t);
+  const size_t p1_lds = ((size_t)P1_SORTED + (size_t)BB_MAX_BINS * 32u) * sizeof(uint32_t);
   const size_t p2_lds = ((size_t)BQ_L2_TILE + (size_t)BB_REGIONS_PER_BIN * 32u) * sizeof(uint32_t);
   uint32_t g1_max = 1, gx = 1;
   if (pieces) {
@@ -508,6 +513,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
       gx = grid2 / g.n_bins ? grid2 / g.n_bins : 1u;
     }
   }
+  if (M > 1 && !pieces) return NTHIP_OK;
   // values per round: ~22 B of scratch per value
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
@@ -517,6 +523,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
   if (c->tune.bloom_round) round = c->tune.bloom_round;
   if (round > n_values) round = n_values;
   if (round < (1u << 16)) round = 1u << 16;
+  round = (round + M - 1) / M; // inputs per round from here on
   QueryScratch q;
   auto carve = [&](uint64_t n, size_t* need) -> bool {
     size_t slots1, slots2, fills1, fills2;
@@ -525,7 +532,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
       tiles1 = (n + P1_TILE - 1) / P1_TILE;
       q.pg.g1 = (uint32_t)std::min<uint64_t>(tiles1, g1_max);
       q.pg.gx = gx;
-      const double per_block = (double)((tiles1 + q.pg.g1 - 1) / q.pg.g1) * (double)P1_TILE; // what a level-1 block may see
+      const double per_block = (double)((tiles1 + q.pg.g1 - 1) / q.pg.g1) * (double)(P1_TILE * M); // the values a level-1 block may see
       const double bin_slots = (double)(1ull << g.bin_shift), region_slots = (double)(1ull << g.region_shift);
       q.cap1 = piece_cap(c, per_block * (bin_slots < (double)n_slots ? bin_slots / (double)n_slots : 1.0));
       q.cap2 = piece_cap(c, (double)((q.pg.g1 + gx - 1) / gx) * per_block * (region_slots < (double)n_slots ? region_slots / (double)n_slots : 1.0));
@@ -539,7 +546,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
       tiles1 = (n + L1_TILE - 1) / L1_TILE;
       q.pg.g1 = 0;
       q.pg.gx = 0;
-      q.cap1 = g.one ? 0 : slot_cap(c, n, 1ull << g.bin_shift, n_slots);
+      q.cap1 = g.one ? 0 : slot_cap(c, n, 1ull << g.bin_shift, n_slots); // (M == 1 here)
       q.cap2 = slot_cap(c, n, 1ull << g.region_shift, n_slots);
       q.tiles_per_seg = (uint32_t)((q.cap1 + BQ_L2_TILE - 1) / BQ_L2_TILE);
       slots1 = (size_t)g.n_bins * q.cap1;
@@ -548,7 +555,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
       fills2 = (size_t)g.n_regions * BB_CURSOR_STRIDE;
       rows2 = g.one ? 0 : (uint64_t)g.n_bins * q.tiles_per_seg;
     }
-    q.ovf_cap = n / 64 < 65536 ? 65536 : n / 64;
+    q.ovf_cap = n * M / 64 < 65536 ? 65536 : n * M / 64;
     if (c->tune.bloom_slot_tight == 2) q.ovf_cap = 64;
     q.pieces = pieces;
     const size_t head = 256 + (fills1 + fills2) * sizeof(uint32_t);
@@ -560,7 +567,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
       return at;
     };
     const size_t o_head = take(head), o_l1 = take(slots1 * 4), o_l2 = take(slots2 * 4), o_ovf = take((size_t)q.ovf_cap * 8);
-    const size_t o_w1 = take((size_t)n * 2), o_w2 = take(slots1 * 2);
+    const size_t o_w1 = take((size_t)n * M * 2), o_w2 = take(slots1 * 2);
     const size_t o_t1 = take((size_t)tiles1 * buckets1 * 8), o_v1 = take((size_t)tiles1 * buckets1 * 4);
     const size_t o_t2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 8), o_v2 = take((size_t)rows2 * BB_REGIONS_PER_BIN * 4);
     const size_t o_p1 = take(slots1), o_p2 = take(slots2), o_po = take((size_t)q.ovf_cap);
@@ -599,8 +606,8 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
     if (round <= (1u << 22)) return NTHIP_OK;
     round /= 2;
   }
-  for (uint64_t v0 = 0; v0 < n_values; v0 += round) {
-    const uint64_t n = std::min<uint64_t>(round, n_values - v0);
+  for (uint64_t v0 = 0; v0 < n_in; v0 += round) {
+    const uint64_t n = std::min<uint64_t>(round, n_in - v0);
     size_t need = 0;
     if (!carve(n, &need)) return fail(NTHIP_ERR_HIP, "the lists of a smaller round do not fit the buffer of a larger one");
     const uint64_t capL1 = g.one ? q.cap2 : q.cap1;
@@ -611,6 +618,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
       memset((void*)&a, 0, sizeof a);
       a.in = d_hashes + v0;
       a.n = n;
+      a.kmul = kmul;
       a.n_bits = n_slots;
       a.magic = magic;
       a.out = q.list1;
@@ -622,8 +630,23 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
       a.q_where = q.where1;
       a.q_tab = q.tab1;
       a.q_tovf = q.tovf1;
-      NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<P1_THREADS, true>, p1_lds));
-      hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<P1_THREADS, true>), dim3(q.pg.g1), dim3(P1_THREADS), p1_lds, c->stream, a);
+      switch (M) {
+        case 2:
+          NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<P1_THREADS, true, 2>, p1_lds));
+          hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<P1_THREADS, true, 2>), dim3(q.pg.g1), dim3(P1_THREADS), p1_lds, c->stream, a);
+          break;
+        case 3:
+          NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<P1_THREADS, true, 3>, p1_lds));
+          hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<P1_THREADS, true, 3>), dim3(q.pg.g1), dim3(P1_THREADS), p1_lds, c->stream, a);
+          break;
+        case 4:
+          NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<P1_THREADS, true, 4>, p1_lds));
+          hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<P1_THREADS, true, 4>), dim3(q.pg.g1), dim3(P1_THREADS), p1_lds, c->stream, a);
+          break;
+        default:
+          NTCHK(set_max_lds(c, bloom_part_stream_pieces_kernel<P1_THREADS, true>, p1_lds));
+          hipLaunchKernelGGL((bloom_part_stream_pieces_kernel<P1_THREADS, true>), dim3(q.pg.g1), dim3(P1_THREADS), p1_lds, c->stream, a);
+      }
     } else {
       { // forward, level 1: the stream's values behind shared cursors
         BloomPartQueryArgs a;
@@ -657,8 +680,14 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
       if (pieces) {
         NTCHK(blocks_per_cu(c, bloom_back1_stream_kernel<P1_THREADS>, (int)P1_THREADS, 0, &per_cu));
         const uint64_t tiles = (n + P1_TILE - 1) / P1_TILE;
-        const uint64_t grid = std::min<uint64_t>(tiles, (uint64_t)c->n_cu * (uint64_t)per_cu);
-        hipLaunchKernelGGL(bloom_back1_stream_kernel<P1_THREADS>, dim3((unsigned)grid), dim3(P1_THREADS), 0, c->stream, b, n, d_ans + v0);
+        const unsigned grid = (unsigned)std::min<uint64_t>(tiles, (uint64_t)c->n_cu * (uint64_t)per_cu);
+        uint8_t* const ans = d_ans + v0 * M;
+        switch (M) {
+          case 2: hipLaunchKernelGGL((bloom_back1_stream_kernel<P1_THREADS, 2>), dim3(grid), dim3(P1_THREADS), 0, c->stream, b, n, ans); break;
+          case 3: hipLaunchKernelGGL((bloom_back1_stream_kernel<P1_THREADS, 3>), dim3(grid), dim3(P1_THREADS), 0, c->stream, b, n, ans); break;
+          case 4: hipLaunchKernelGGL((bloom_back1_stream_kernel<P1_THREADS, 4>), dim3(grid), dim3(P1_THREADS), 0, c->stream, b, n, ans); break;
+          default: hipLaunchKernelGGL(bloom_back1_stream_kernel<P1_THREADS>, dim3(grid), dim3(P1_THREADS), 0, c->stream, b, n, ans);
+        }
       } else {
         NTCHK(blocks_per_cu(c, bloom_back1_stream_kernel<L1_THREADS>, (int)L1_THREADS, 0, &per_cu));
         const uint64_t tiles = (n + L1_TILE - 1) / L1_TILE;
@@ -680,9 +709,15 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
 
 int ntamd::host::stream_hits_per_read(nthip_ctx* c, const uint64_t* d_h, const uint64_t* d_roff, uint64_t n_reads, uint64_t n_kmers, uint32_t m,
                                       const uint32_t* d_filter, uint64_t n_bits, uint64_t* d_hits, unsigned long long* d_total,
-                                      const char* direct_label)
+                                      const char* direct_label, uint32_t expand_m, uint64_t kmul, bool* expanded)
 {
-  if (n_reads == 0) return NTHIP_OK;
+  // (expand_m > 1: d_h holds hashes()[0] only -- m / expand_m values per k-mer -- and the binned road makes the others; *expanded
+  //  = false, nothing launched, when that road is not taken: the caller hashes the full stream and calls again)
+  if (expanded) *expanded = false;
+  if (n_reads == 0) {
+    if (expanded) *expanded = true;
+    return NTHIP_OK;
+  }
   const uint64_t n_values = n_kmers * m;
   bool done = false;
   uint8_t* d_ans = nullptr;
@@ -690,14 +725,16 @@ int ntamd::host::stream_hits_per_read(nthip_ctx* c, const uint64_t* d_h, const u
       kept_alloc(c, KEPT_ANSWERS, n_values + 8, (void**)&d_ans) != NTHIP_OK) // (+ 8: answers_per_read_kernel loads 8 bytes at a k-mer's first)
     d_ans = nullptr;
   if (d_ans) {
-    NTCHK(stream_query_binned(c, d_h, n_values, d_filter, n_bits, BQ_BLOOM, d_ans, &done));
+    NTCHK(stream_query_binned(c, d_h, n_values / expand_m, d_filter, n_bits, BQ_BLOOM, d_ans, &done, expand_m, kmul));
     if (done) {
       prof_begin(c, "answers_per_read_kernel");
       const int rc2 = answers_hits_per_read(c, d_ans, d_roff, n_reads, n_kmers, m, d_hits, d_total);
       prof_end(c);
+      if (expanded) *expanded = true;
       return rc2;
     }
   }
+  if (expand_m > 1) return NTHIP_OK;
   prof_begin(c, direct_label);
   hipLaunchKernelGGL(stream_bloom_query_kernel, dim3((unsigned)(c->n_cu * 8)), dim3(256), 0, c->stream, d_h, d_roff, n_reads, n_kmers, m, d_filter,
                      n_bits, bloom_magic_of(n_bits), d_hits, d_total);

@@ -59,12 +59,15 @@ int run_seed_bloom(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, u
       } // (else: the full stream, below -- a bit set twice is set)
     }
     if (query) NTCHK(own_alloc(keep, (size_t)(nr + 1) * 8, (void**)&d_counts));
+    // (the query of a two-level filter likewise: hashes()[0] of every seed, the other m2 - 1 values made on the way to the regions)
+    const bool q_expand = query && m2 >= 2 && m2 <= 4 && n_bits > (1ull << 27) && c->tune.bloom_pieces != 2 && c->tune.bloom_query != 2 &&
+                          (c->tune.bloom_query == 1 || (cap * per >= (1ull << 24) && (n_bits >> 3) >= (32ull << 20) && cap * per >= (n_bits >> 3) / 32));
     nthip_out out;
     memset(&out, 0, sizeof out);
     out.hashes = d_h;
     out.capacity = cap;
     out.counts = d_counts;
-    NTCHK(nthip_seed_hash(c, part, sd, m28, &out, &n_windows, flags & NTHIP_HOST_INPUT));
+    NTCHK(nthip_seed_hash(c, part, sd, q_expand ? (uint8_t)1 : m28, &out, &n_windows, flags & NTHIP_HOST_INPUT));
     sum_windows += n_windows;
     if (!query) return n_windows ? nthip_stream_bloom_insert(c, d_h, n_windows * per, (uint8_t*)d_filter, n_bits) : NTHIP_OK;
     uint64_t* d_hits = hits ? hits + r0 : nullptr;
@@ -74,8 +77,19 @@ int run_seed_bloom(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, u
     NTCHK(own_alloc(keep, (size_t)(nr / SCAN_TILE + 64) * 8, (void**)&d_sums));
     NTCHK(device_exclusive_scan(c, d_counts, d_roff, nr, d_sums, (uint64_t*)(c->d_small + 16)));
     HIPCHK(hipMemsetAsync(c->d_small + 24, 0, 8, c->stream));
-    NTCHK(stream_hits_per_read(c, d_h, d_roff, nr, n_windows, per, (const uint32_t*)d_filter, n_bits, d_hits, (unsigned long long*)(c->d_small + 24),
-                               "stream_bloom_query_kernel (spaced seeds)"));
+    bool expanded = false;
+    if (q_expand)
+      NTCHK(stream_hits_per_read(c, d_h, d_roff, nr, n_windows, per, (const uint32_t*)d_filter, n_bits, d_hits, (unsigned long long*)(c->d_small + 24),
+                                 "stream_bloom_query_kernel (spaced seeds)", m2, (uint64_t)k * MULTISEED, &expanded));
+    if (!expanded) {
+      if (q_expand) { // (the road was not taken after all -- skewed values, no memory: the full stream)
+        uint64_t again = 0;
+        out.counts = nullptr;
+        NTCHK(nthip_seed_hash(c, part, sd, m28, &out, &again, flags & NTHIP_HOST_INPUT));
+      }
+      NTCHK(stream_hits_per_read(c, d_h, d_roff, nr, n_windows, per, (const uint32_t*)d_filter, n_bits, d_hits, (unsigned long long*)(c->d_small + 24),
+                                 "stream_bloom_query_kernel (spaced seeds)"));
+    }
     HIPCHK(hipMemcpyAsync(c->h_small + 24, c->d_small + 24, 8, hipMemcpyDeviceToHost, c->stream));
     if (host_hits) HIPCHK(hipMemcpyAsync(hits + r0, d_hits, nr * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
