@@ -806,9 +806,22 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
     NTCHK(offsets_in_rounds(c, rd, flags, (size_t)8 * m + (query ? (size_t)26 * m : 16), [&](const nthip_reads* part, uint64_t r0, uint64_t bases) -> int {
       Staged keep;
       uint64_t *d_h = nullptr, *d_counts = nullptr, n_kmers = 0;
-      NTCHK(stream_of_offsets(c, part, k16, m8, flags, keep, &d_h, query ? &d_counts : nullptr, &n_kmers, bases ? bases : 1));
+      // several hashes per k-mer into / against a two-level filter: the round's stream holds hashes()[0] only, the first partition
+      // level makes the others (stream_bloom_insert_expand / stream_hits_per_read: an m times shorter stream written and read back)
+      const bool expand = m >= 2 && m <= 4 && n_bits > (1ull << 27) && c->tune.bloom_pieces != 2 &&
+                          (query ? c->tune.bloom_query != 2 : c->tune.bloom_binned != 2);
+      NTCHK(stream_of_offsets(c, part, k16, expand ? (uint8_t)1 : m8, flags, keep, &d_h, query ? &d_counts : nullptr, &n_kmers, bases ? bases : 1));
       sum_kmers += n_kmers;
-      if (!query) return nthip_stream_bloom_insert(c, d_h, n_kmers * m, (uint8_t*)d_filter, n_bits);
+      if (!query) {
+        bool done = false;
+        if (expand && n_kmers) NTCHK(stream_bloom_insert_expand(c, d_h, n_kmers, m, (uint64_t)k * MULTISEED, d_filter, n_bits, &done));
+        if (done || n_kmers == 0) return NTHIP_OK;
+        if (expand) { // (not a batch / a device for it: the full stream)
+          uint64_t again = 0;
+          NTCHK(stream_of_offsets(c, part, k16, m8, flags, keep, &d_h, nullptr, &again, bases ? bases : 1));
+        }
+        return nthip_stream_bloom_insert(c, d_h, n_kmers * m, (uint8_t*)d_filter, n_bits);
+      }
       const uint64_t nr = part->n_reads;
       const bool host = hits && (flags & NTHIP_HOST_OUTPUT);
       uint64_t* d_hits = hits ? hits + r0 : nullptr;
@@ -818,8 +831,18 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
       NTCHK(own_alloc(keep, (size_t)(nr / SCAN_TILE + 64) * 8, (void**)&d_sums));
       NTCHK(device_exclusive_scan(c, d_counts, d_roff, nr, d_sums, (uint64_t*)(c->d_small + 16)));
       HIPCHK(hipMemsetAsync(c->d_small + 24, 0, 8, c->stream));
-      NTCHK(stream_hits_per_read(c, d_h, d_roff, nr, n_kmers, m, d_filter, n_bits, d_hits, (unsigned long long*)(c->d_small + 24),
-                                 "stream_bloom_query_kernel"));
+      bool expanded = false;
+      if (expand)
+        NTCHK(stream_hits_per_read(c, d_h, d_roff, nr, n_kmers, m, d_filter, n_bits, d_hits, (unsigned long long*)(c->d_small + 24),
+                                   "stream_bloom_query_kernel", m, (uint64_t)k * MULTISEED, &expanded));
+      if (!expanded) {
+        if (expand) {
+          uint64_t again = 0;
+          NTCHK(stream_of_offsets(c, part, k16, m8, flags, keep, &d_h, nullptr, &again, bases ? bases : 1));
+        }
+        NTCHK(stream_hits_per_read(c, d_h, d_roff, nr, n_kmers, m, d_filter, n_bits, d_hits, (unsigned long long*)(c->d_small + 24),
+                                   "stream_bloom_query_kernel"));
+      }
       HIPCHK(hipMemcpyAsync(c->h_small + 24, c->d_small + 24, 8, hipMemcpyDeviceToHost, c->stream));
       if (host) HIPCHK(hipMemcpyAsync(hits + r0, d_hits, nr * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));

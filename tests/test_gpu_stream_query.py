@@ -272,3 +272,43 @@ def test_stream_query_default_choice_and_full_size(ctx):
             ctx.free(p_)
     ctx.free(d_in)
     direct.close()
+
+
+@pytest.mark.parametrize("m,n_bits", [(3, (1 << 28) + 12_345), (2, (1 << 29) + 7), (4, (1 << 28) + 1)])
+def test_bloom_insert_of_reads_by_offsets_from_first_hashes(oracle, m, n_bits):
+    """nthip_kmer_bloom_insert of reads of any lengths into a two-level filter: the round's stream holds hashes()[0] only and the
+    first partition level makes the other m - 1 values (extend_hashes, src/internal.hpp:104-118) -- the filter is the one built on
+    the CPU from the oracle's full stream; and the query of the same reads finds every k-mer"""
+    ctx = _ctx_with({"NTHIP_TUNE_BLOOM_BINNED": 1, "NTHIP_TUNE_BLOOM_QUERY": 1})
+    n, k = 4000, 27
+    rng = np.random.default_rng(m)
+    lens = rng.integers(0, 300, n).astype(np.uint64)
+    lens[:3] = [0, k - 1, k]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    tb = int(offs[-1])
+    a = oracle.synth_reads(6, 1, tb, 31).copy()
+    a[rng.choice(tb, tb // 400, replace=False)] = ord("N")
+    want = oracle.kmer_batch(a, offs, k, m, want_pos=False)
+    filt = _filter_of(want["hashes"], n_bits)
+    d_f, nbytes = ctx.bloom_new(n_bits)
+    d_in = ctx.malloc(tb + 16)
+    ctx.h2d(d_in, a)
+    d_o = ctx.malloc(offs.nbytes)
+    ctx.h2d(d_o, offs)
+    ctx.set_profiling(True)
+    total = ctx.bloom_insert_ptr(d_in, n, 0, 0, k, m, d_f, n_bits, offsets=d_o)
+    name = _last_name(ctx)
+    ctx.set_profiling(False)
+    assert "pieces" in name, name
+    assert total == want["total"]
+    got = np.zeros(nbytes, np.uint8)
+    ctx.d2h(got, d_f)
+    assert (got == filt).all(), int((got != filt).sum())
+    d_hits = ctx.malloc(n * 8)
+    tq, found = ctx.bloom_query_ptr(d_in, n, 0, 0, k, m, d_f, n_bits, hits=d_hits, offsets=d_o)
+    hits = np.zeros(n, np.uint64)
+    ctx.d2h(hits, d_hits)
+    assert tq == total and found == total and (hits == want["counts"]).all()
+    for p_ in (d_f, d_in, d_o, d_hits):
+        ctx.free(p_)
+    ctx.close()
