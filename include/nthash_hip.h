@@ -179,6 +179,15 @@ int nthip_seeds_create(nthip_ctx* ctx, const char* const* seeds, uint32_t n_seed
                        nthip_seeds** out, int* asymmetric);
 int nthip_seeds_destroy(nthip_seeds* seeds);
 /*
+ * The kernel specialisation cache: for large dense batches nthip_seed_hash compiles a kernel for the
+ * very seed set and read length at run time (hiprtc; a second or two once per seed set and shape, kept in
+ * $NTHIP_JIT_CACHE / $XDG_CACHE_HOME/nthash_amd / ~/.cache/nthash_amd afterwards; NTHIP_SEED_JIT=0: never, =1: for every
+ * batch the kernel takes).  Without hiprtc the precompiled kernels hash the batch: same stream.
+ * nthip_seed_jit_source: the text that is compiled for `seeds` on reads of `len` bases (*out is malloc'ed: free() it;
+ * NTHIP_ERR_UNSUPPORTED: a shape without a specialised kernel).  Needs no device.
+ */
+int nthip_seed_jit_source(const char* const* seeds, uint32_t n_seeds, uint16_t k, uint32_t len, uint8_t m2, char** out);
+/*
  * nthip_seed_hash: for every read r, what
  *     nthash::SeedNtHash h(seq_r, len_r, seeds, m2, k); // src/seed.cpp:449-471
  *     while (h.roll()) emit(h.hashes()[0..n_seeds*m2)); // src/seed.cpp:518-544

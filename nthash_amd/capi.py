@@ -36,7 +36,7 @@ SYMBOLS = [
     "nthip_ctx_destroy", "nthip_ctx_set_stream", "nthip_ctx_synchronize", "nthip_ctx_take_dirty",
     "nthip_ctx_set_profiling", "nthip_last_kernel_ms", "nthip_malloc", "nthip_free",
     "nthip_ctx_trim", "nthip_memcpy_h2d", "nthip_memcpy_d2h", "nthip_memset", "nthip_kmer_hash", "nthip_seeds_create",
-    "nthip_seeds_destroy", "nthip_seed_hash", "nthip_kmer_extend", "nthip_kmer_bloom_insert",
+    "nthip_seeds_destroy", "nthip_seed_jit_source", "nthip_seed_hash", "nthip_kmer_extend", "nthip_kmer_bloom_insert",
     "nthip_kmer_bloom_query", "nthip_kmer_minhash", "nthip_stream_bloom_insert", "nthip_kmer_hash_spans", "nthip_fastx_index",
     "nthip_fastx_kmer_hash_file", "nthip_fastx_seed_hash_file", "nthip_seed_hash_spans", "nthip_fasta_compact", "nthip_synth_reads", "nthip_checksum",
     "nthip_copy_bench", "nthip_fill_bench", "nthip_malloc_probed", "nthip_ctx_reload_tuning",
@@ -118,6 +118,7 @@ def load():
     L.nthip_seeds_create.argtypes = [vp, C.POINTER(C.c_char_p), u32, C.c_uint16, C.POINTER(vp),
                                      C.POINTER(C.c_int)]
     L.nthip_seeds_destroy.argtypes = [vp]
+    L.nthip_seed_jit_source.argtypes = [C.POINTER(C.c_char_p), u32, C.c_uint16, u32, C.c_uint8, C.POINTER(vp)]
     L.nthip_seed_hash.argtypes = [vp, C.POINTER(Reads), vp, C.c_uint8, C.POINTER(Out),
                                   C.POINTER(u64), u32]
     L.nthip_kmer_extend.argtypes = [vp, vp, u64, C.c_uint16, C.c_uint8, vp, vp, vp, u32]

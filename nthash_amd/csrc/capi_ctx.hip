@@ -230,9 +230,8 @@ int check_reads(const nthip_reads* rd)
 extern "C" const char* nthip_version(void) { return "nthash_amd 0.3 (gfx950; ntHash_v2 bit-exact)"; }
 extern "C" const char* nthip_last_error(void) { return g_err.c_str(); }
 
-namespace {
 // the A/B knobs of the measurement tools; production runs have none of them set
-void load_tuning(nthip_tune& t)
+void ntamd::host::load_tuning(nthip_tune& t)
 {
   t = nthip_tune();
   auto num = [](const char* name, uint32_t lo, uint32_t hi) -> uint32_t {
@@ -292,6 +291,13 @@ void load_tuning(nthip_tune& t)
   t.fw = num("NTHIP_TUNE_FW", 1, 2);
   t.seed_any = num("NTHIP_TUNE_SEED_ANY", 1, 2);
   t.seed_roll = num("NTHIP_TUNE_SEED_ROLL", 1, 2);
+  t.seed_px = num("NTHIP_TUNE_SEED_PX", 1, 2);
+  t.seed_ps = num("NTHIP_TUNE_SEED_PS", 1, 2);
+  if (const char* v = getenv("NTHIP_SEED_JIT")) t.seed_jit = v[0] == '0' ? 2u : v[0] == '1' ? 1u : 0u; // (2: never)
+  t.seed_ps_lanes = num("NTHIP_TUNE_SEED_PS_LANES", 16, 64);
+  t.seed_px_array = num("NTHIP_TUNE_SEED_PX_ARRAY", 1, 300);
+  t.seed_px_reads = num("NTHIP_TUNE_SEED_PX_READS", 1, 64);
+  t.seed_px_waves = num("NTHIP_TUNE_SEED_PX_WAVES", 1, 8);
   t.seed_roll_waves = num("NTHIP_TUNE_SEED_ROLL_WAVES", 2, 8);
   t.bloom_binned = num("NTHIP_TUNE_BLOOM_BINNED", 1, 2);
   t.no_tiles_flag = is_one("NTHIP_TUNE_NO_TILES_FLAG");
@@ -307,6 +313,7 @@ void load_tuning(nthip_tune& t)
   const uint32_t tk = num("NTHIP_TUNE_TABLE_K_MAX", 16, 64);
   ntamd::host::g_kmer_table_k_max = tk ? tk : (uint32_t)KMER_TABLE_K_MAX_N;
 }
+namespace {
 } // namespace
 
 extern "C" int nthip_ctx_reload_tuning(nthip_ctx* c)

@@ -43,6 +43,7 @@
 #include "kmer_runs_kernel.hpp"
 #include "kmer_runs_gen_kernel.hpp"
 #include "nt_math.hpp"
+#include "seed_px_plan.hpp"
 
 namespace ntamd {
 namespace host {
@@ -126,6 +127,13 @@ struct nthip_tune {
   uint32_t bloom_query = 0;  // NTHIP_TUNE_BLOOM_QUERY=1: the binned query (bloom_query_kernels.hpp) on every batch it can take, 2: never (A/B, tests)
   uint32_t seed_roll_waves = 0; // NTHIP_TUNE_SEED_ROLL_WAVES=2..8: waves per block of seed_roll_kernel (A/B)
   uint32_t seed_roll = 0;   // NTHIP_TUNE_SEED_ROLL=1: every dense seed batch the block-rolling kernel takes goes there, 2: none (A/B, tests)
+  uint32_t seed_px = 0;     // NTHIP_TUNE_SEED_PX=1: every dense seed batch seed_px_kernel takes goes there, 2: none (A/B, tests)
+  uint32_t seed_px_array = 0; // NTHIP_TUNE_SEED_PX_ARRAY=1 + f: px_make_plan's force_array = f (tests: every array form against the oracle)
+  uint32_t seed_px_reads = 0; // NTHIP_TUNE_SEED_PX_READS=R: reads per tile of seed_px_kernel (A/B; 0: planned)
+  uint32_t seed_jit = 0;    // NTHIP_SEED_JIT=0: no kernel is compiled at run time, 1: for every batch the specialised kernel takes (unset: large batches)
+  uint32_t seed_ps = 0;     // NTHIP_TUNE_SEED_PS=1: every dense seed batch seed_ps_kernel takes goes there, 2: none (A/B, tests)
+  uint32_t seed_ps_lanes = 0; // NTHIP_TUNE_SEED_PS_LANES=16 / 32 / 64: window lanes per read of seed_ps_kernel (A/B; 0: planned)
+  uint32_t seed_px_waves = 0; // NTHIP_TUNE_SEED_PX_WAVES=1..8: waves per block of seed_px_kernel (A/B; 0: planned)
   uint32_t seed_any = 0;    // NTHIP_TUNE_SEED_ANY=1: dense seed batches on the any-seed form whatever the seed set, 2: none of k <= 128 (A/B, tests)
   uint32_t fw = 0;          // NTHIP_TUNE_FW: first window beyond the position tables -- 1 grouped, 2 prefix scan (0: cost model)
 };
@@ -228,12 +236,38 @@ struct nthip_seeds {
   // pair table; roll_terms == 0: more runs than the kernel takes.  roll_in = b, roll_out = a.
   uint32_t roll_terms = 0, roll_first[65] = {}, roll_in[64] = {}, roll_out[64] = {};
   uint4* d_roll_tabs = nullptr;
+  // sparse sums over scanned arrays (seed_px_plan.hpp / seed_px_kernel.hpp): the care positions of every seed, and the plan
+  // made for the last read shape asked for (a plan weighs the arrays' cost per position against the reads per window)
+  std::vector<std::vector<uint8_t>> h_care;
+  mutable ntamd::PxPlan px_plan;
+  mutable uint32_t px_plan_len = 0;
+  mutable int px_plan_force = -2;
+  // seed_ps_kernel.hpp: the same reads as byte offsets per step of a segment, on the device, for the last geometry asked for
+  // capi_seed_jit.hip: the kernels compiled for this seed set at run time, source key -> {hipModule_t, hipFunction_t}
+  mutable std::map<std::string, std::pair<void*, void*>> jit;
+  mutable std::set<std::string> jit_failed;
+  mutable uint32_t* d_ps_off = nullptr;
+  mutable uint64_t ps_key = 0;
+  mutable ntamd::PxPlan ps_plan;
+  mutable uint32_t ps_plan_len = 0;
+  mutable int ps_plan_force = -2;
 };
 
 namespace ntamd {
 namespace host {
 
+// ---- capi_seed_jit.hip: the kernel specialisation cache --------------------------------------------------------
+struct SeedJitShape { // what seed_psj_kernel.inc is compiled for
+  uint32_t len = 0, k = 0, nwin = 0, m2 = 0, n_seeds = 0, W = 0, nb_log = 0, lpr_log = 0, n_arrays = 0, segs_b = 0, waves = 0;
+  std::vector<uint32_t> term_arr, term_e, seed_first;
+};
+std::string seed_psj_source(const SeedJitShape& g);
+void* seed_psj_get(nthip_ctx* c, const nthip_seeds* sd, const SeedJitShape& g, std::string* why); // hipFunction_t or nullptr
+void seed_jit_release(const nthip_seeds* sd);
+bool seed_jit_shape(nthip_ctx* c, const nthip_seeds* sd, uint32_t len, uint32_t m2, SeedJitShape* out); // capi_seed.hip
+
 // ---- capi_ctx.hip -------------------------------------------------------------------------------------------
+void load_tuning(nthip_tune& t);
 int ensure_scratch(nthip_ctx* c, size_t elems);
 int ensure_scratch2(nthip_ctx* c, size_t elems);
 int ensure_args(nthip_ctx* c, size_t bytes);

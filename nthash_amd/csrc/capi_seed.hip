@@ -4,6 +4,8 @@
 #include "seed_long_kernels.hpp"
 #include "seed_kernels.hpp"
 #include "seed_roll_kernel.hpp"
+#include "seed_px_kernel.hpp"
+#include "seed_ps_kernel.hpp"
 #include "kmer_reads_kernel.hpp" // the mark pass (reads with a non-base) is shared with the k-mer path
 #include "seed_parse.hpp"
 #include "util_kernels.hpp"
@@ -112,6 +114,11 @@ extern "C" int nthip_seeds_create(nthip_ctx* c, const char* const* seeds, uint32
   sd->asymmetric = asym;
   sd->h_blk_parity = h_blk;
   sd->h_is_mono = h_mono;
+  sd->h_care.resize(n_seeds);
+  for (uint32_t s = 0; s < n_seeds; ++s) {
+    sd->h_care[s].resize(k);
+    for (uint32_t p = 0; p < k; ++p) sd->h_care[s][p] = (uint8_t)((care[(size_t)s * cw + (p >> 5)] >> (p & 31)) & 1u);
+  }
   auto up = [&](const void* src, size_t bytes, void** dst) -> int {
     HIPCHK(hipMalloc(dst, bytes));
     HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
@@ -155,6 +162,8 @@ extern "C" int nthip_seeds_destroy(nthip_seeds* sd)
   if (sd->d_ext_mask) (void)hipFree(sd->d_ext_mask);
   if (sd->d_ext_acorr) (void)hipFree(sd->d_ext_acorr);
   if (sd->d_roll_tabs) (void)hipFree(sd->d_roll_tabs);
+  if (sd->d_ps_off) (void)hipFree(sd->d_ps_off);
+  seed_jit_release(sd);
   delete sd;
   return NTHIP_OK;
 }
@@ -921,6 +930,339 @@ int launch_seed_roll(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd
   return NTHIP_OK;
 }
 
+// seed_ps_kernel (seed_ps_kernel.hpp): the seeds as sparse sums over the prefix XOR (and the terms) of a read, a lane per
+// segment of W positions / windows; compiled for the very seed set and read shape at run time when the batch is worth it
+// (capi_seed_jit.hip).  The geometry and the reads of a shape:
+struct PsGeo {
+  uint32_t W = 0, nb_log = 0, lpr_log = 0, segs_b = 0, n_arrays = 0, waves = 0;
+  size_t wave_bytes = 0, fixed = 0;
+  double cost = 0;
+  std::vector<uint32_t> first;                      // seed s reads [first[s], first[s + 1])
+  std::vector<std::pair<uint32_t, uint32_t>> reads; // (array: 0 prefix, 1 terms; e)
+};
+bool ps_geometry(nthip_ctx* c, const nthip_seeds* sd, uint32_t len, uint32_t m2, PsGeo* out)
+{
+  const uint32_t k = sd->k;
+  if (len < k || sd->h_care.empty() || sd->n_seeds > PX_MAX_SEEDS || m2 == 0 || m2 > (uint32_t)SF_MAX_RUNTIME_M) return false;
+  const uint32_t nwin = len - k + 1, n_seeds = sd->n_seeds, per = n_seeds * m2;
+  int force = c->tune.seed_px_array ? (int)c->tune.seed_px_array - 1 : -1;
+  if (force > 2) return false; // (a stride form: seed_px_kernel's)
+  if (sd->ps_plan_len != len || sd->ps_plan_force != force) {
+    sd->ps_plan = px_make_plan(sd->h_care, k, (double)len / nwin, force, /*allow_strides=*/false);
+    sd->ps_plan_len = len;
+    sd->ps_plan_force = force;
+  }
+  const PxPlan& plan = sd->ps_plan;
+  if (!plan.ok) return false;
+  // the kernel's arrays: the prefix first, the terms second
+  const bool has_raw = std::find(plan.arrays.begin(), plan.arrays.end(), PxArray{0, 0}) != plan.arrays.end();
+  const uint32_t n_arrays = has_raw ? 2u : 1u;
+  const size_t cap = lds_cap_of(c);
+  PsGeo best;
+  bool found = false;
+  for (uint32_t lpr_log = 4; lpr_log <= 6; ++lpr_log) {
+    if (c->tune.seed_ps_lanes && c->tune.seed_ps_lanes != (1u << lpr_log)) continue;
+    const uint32_t lpr = 1u << lpr_log, W = (nwin + lpr - 1) / lpr;
+    if (W == 0 || W > PS_MAX_W) continue;
+    const uint32_t segs_b = (len + 1 + W - 1) / W;
+    uint32_t nb_log = 4;
+    while ((1u << nb_log) < segs_b) ++nb_log;
+    if (nb_log > 6) continue;
+    const uint32_t rpw = 64u >> lpr_log, epr = W << nb_log;
+    if ((uint64_t)rpw * len + 16 > PX_VEC_ROUNDS * 1024ull - 64) continue;
+    const uint32_t codes_dw = ((rpw * len + 16u + 15u) >> 4) + 4u;
+    PsGeo g;
+    g.W = W; g.nb_log = nb_log; g.lpr_log = lpr_log; g.segs_b = segs_b; g.n_arrays = n_arrays;
+    g.wave_bytes = (size_t)n_arrays * rpw * epr * 16 + ((codes_dw * 4 + 15) & ~15u);
+    g.fixed = (size_t)4 * epr * 16;
+    if (g.fixed + g.wave_bytes > cap) continue;
+    // wave instructions per window: the build's two passes per round, W steps of the seeds' reads and rotations
+    const uint32_t rounds = (rpw + (64u >> nb_log) - 1) / (64u >> nb_log);
+    const double step = 12.0 + 38.0 * n_seeds + 3.2 * plan.n_terms() + 6.0 * (per - n_seeds);
+    g.cost = (rounds * (20.0 * W + 45.0) + W * step + 60.0) / ((double)rpw * nwin);
+    const size_t waves_fit = (cap - g.fixed) / g.wave_bytes;
+    if (waves_fit < 8) g.cost *= 1.0 + 0.08 * (8 - waves_fit); // (few waves: the phases of a tile are not hidden)
+    if (!found || g.cost < best.cost) { best = g; found = true; }
+  }
+  if (!found) return false;
+  uint32_t waves = (uint32_t)((cap - best.fixed) / best.wave_bytes);
+  if (waves > PS_MAX_WAVES) waves = PS_MAX_WAVES;
+  if (c->tune.seed_px_waves && c->tune.seed_px_waves < waves) waves = c->tune.seed_px_waves;
+  if (waves == 0) return false;
+  best.waves = waves;
+  best.first.assign(n_seeds + 1, 0);
+  for (uint32_t s = 0; s < n_seeds; ++s) {
+    for (uint32_t i = plan.seed_first[s]; i < plan.seed_first[s + 1]; ++i) {
+      const PxArray& y = plan.arrays[plan.terms[i].arr];
+      best.reads.push_back({y.d1 == 1u ? 0u : 1u, plan.terms[i].e});
+    }
+    best.first[s + 1] = (uint32_t)best.reads.size();
+  }
+  *out = best;
+  return true;
+}
+} // namespace
+bool ntamd::host::seed_jit_shape(nthip_ctx* c, const nthip_seeds* sd, uint32_t len, uint32_t m2, SeedJitShape* out)
+{
+  PsGeo g;
+  if (!ps_geometry(c, sd, len, m2, &g)) return false;
+  if ((uint64_t)g.W * g.reads.size() > 2048) return false; // (straight-line code: reads x steps)
+  SeedJitShape j;
+  j.len = len; j.k = sd->k; j.nwin = len - sd->k + 1; j.m2 = m2; j.n_seeds = sd->n_seeds; j.W = g.W; j.nb_log = g.nb_log;
+  j.lpr_log = g.lpr_log; j.n_arrays = g.n_arrays; j.segs_b = g.segs_b; j.waves = g.waves;
+  for (auto& r : g.reads) {
+    j.term_arr.push_back(r.first);
+    j.term_e.push_back(r.second);
+  }
+  j.seed_first = g.first;
+  *out = j;
+  return true;
+}
+namespace {
+// *ran = false: not this kernel's shape (reads of more than ~2000 bases or 64 segments, more than 8 hashes per seed, a gap
+// between the reads), or another form is cheaper.
+int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, bool* ran)
+{
+  *ran = false;
+  if (c->tune.seed_ps == 2 || c->tune.seed_px == 1 || c->tune.seed_any == 1 || c->tune.seed_roll == 1 || f.stride != f.len || f.n_runs == 0)
+    return NTHIP_OK;
+  PsGeo best;
+  if (!ps_geometry(c, sd, f.len, f.m2, &best)) return NTHIP_OK;
+  const uint32_t per = f.n_seeds * f.m2;
+  const uint32_t W = best.W, NB = 1u << best.nb_log, rpw = 64u >> best.lpr_log, epr = W << best.nb_log, waves = best.waves;
+  const uint32_t n_terms = (uint32_t)best.reads.size();
+  // compiled for the shape when the batch pays for it (a compile is a second or two once per seed set and read shape, then
+  // the disk cache): straight-line code, every read an immediate offset
+  const bool jit_wanted = c->tune.seed_jit != 2 && (c->tune.seed_jit == 1 || f.n_runs * (uint64_t)f.nwin >= (1ull << 24)) &&
+                          (uint64_t)W * n_terms <= 2048;
+  if (c->tune.seed_ps != 1) { // against the other dense forms: picoseconds per window (fitted on tools/seed_sweep.py, seed_roll_sweep.py)
+    const double ps = best.cost * (jit_wanted ? 0.9 : 1.7) + 0.5;
+    const uint32_t tables = f.k <= 64 ? 2 * ((f.k + 7) / 8) : 4 * ((f.k + 15) / 16);
+    const double direct = ((f.k <= 128 ? 1.34 * tables : 6.2 * sd->any_groups) * f.n_seeds + 4.5 * (per - f.n_seeds)) * 0.205;
+    if (ps >= direct) return NTHIP_OK;
+  }
+  const uint64_t n_tiles = (f.n_runs + rpw - 1) / rpw, need = (n_tiles + waves - 1) / waves;
+  if (jit_wanted) {
+    SeedJitShape j;
+    std::string why;
+    if (seed_jit_shape(c, sd, f.len, f.m2, &j)) {
+      HIPCHK(hipSetDevice(c->device));
+      hipFunction_t fn = (hipFunction_t)seed_psj_get(c, sd, j, &why);
+      if (fn) {
+        const size_t lds = best.fixed + best.wave_bytes * waves;
+        uint64_t per_cu = lds ? lds_cap_of(c) / lds : 1;
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu * waves > 32) per_cu = 32 / waves ? 32 / waves : 1;
+        uint64_t grid = (uint64_t)c->n_cu * per_cu;
+        if (grid > need) grid = need;
+        const uint8_t* seqs = f.seqs;
+        uint64_t* hashes = f.hashes;
+        uint32_t* dirty = f.dirty;
+        uint64_t n_reads = f.n_runs, nt = n_tiles, total_bytes = f.n_runs * (uint64_t)f.len;
+        void* args[] = {&seqs, &hashes, &dirty, &n_reads, &nt, &total_bytes};
+        prof_begin(c, "seed_psj_kernel");
+        const hipError_t e = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, waves * 64, 1, 1, 0, c->stream, args, nullptr);
+        prof_end(c);
+        if (e == hipSuccess) {
+          *ran = true;
+          return NTHIP_OK;
+        }
+        (void)hipGetLastError(); // (a launch the device refuses: the precompiled kernel below)
+      } else if (c->tune.seed_jit == 1 && getenv("NTHIP_JIT_VERBOSE")) {
+        fprintf(stderr, "nthash_amd: no specialised seed kernel (%s)\n", why.c_str());
+      }
+    }
+  }
+  // the reads, per step of a segment: term t at step i is entry ((i + e) % W) * NB + (i + e) / W of its array
+  const uint32_t arr_bytes = rpw * epr * 16u;
+  const int force = c->tune.seed_px_array ? (int)c->tune.seed_px_array - 1 : -1;
+  const uint64_t key = ((uint64_t)f.len << 40) ^ ((uint64_t)W << 32) ^ ((uint64_t)best.nb_log << 24) ^ ((uint64_t)best.lpr_log << 16) ^
+                       ((uint64_t)(force + 2) << 8) ^ best.n_arrays;
+  if (!sd->d_ps_off || sd->ps_key != key) {
+    std::vector<uint32_t> off((size_t)W * n_terms + 4, 0);
+    for (uint32_t i = 0; i < W; ++i)
+      for (uint32_t t = 0; t < n_terms; ++t) {
+        const uint32_t j = i + best.reads[t].second;
+        off[(size_t)i * n_terms + t] = best.reads[t].first * arr_bytes + ((j % W) * NB + j / W) * 16u;
+      }
+    HIPCHK(hipSetDevice(c->device));
+    if (sd->d_ps_off) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      (void)hipFree(sd->d_ps_off);
+      sd->d_ps_off = nullptr;
+    }
+    HIPCHK(hipMalloc((void**)&sd->d_ps_off, off.size() * 4));
+    HIPCHK(hipMemcpy(sd->d_ps_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    sd->ps_key = key;
+  }
+  SeedPsArgs a;
+  memset(&a, 0, sizeof a);
+  a.seqs = f.seqs;
+  a.hashes = f.hashes;
+  a.dirty = f.dirty;
+  a.step_off = sd->d_ps_off;
+  a.n_reads = f.n_runs;
+  a.n_tiles = n_tiles;
+  a.total_bytes = f.n_runs * (uint64_t)f.len;
+  a.len = f.len;
+  a.k = f.k;
+  a.m2 = f.m2;
+  a.n_seeds = f.n_seeds;
+  a.nwin = f.nwin;
+  a.W = W;
+  a.nb_log = best.nb_log;
+  a.lpr_log = best.lpr_log;
+  a.n_arrays = best.n_arrays;
+  a.n_terms = n_terms;
+  a.waves = waves;
+  a.segs_b = best.segs_b;
+  a.k31 = (f.k - 1u) % 31u;
+  a.k33 = (f.k - 1u) % 33u;
+  for (uint32_t s = 0; s <= f.n_seeds; ++s) a.seed_first[s] = best.first[s];
+  for (uint32_t i = 0; i < (uint32_t)SF_MAX_RUNTIME_M; ++i) a.mult[i] = multiplier(f.k, i);
+  const size_t lds = best.fixed + best.wave_bytes * waves;
+  const int perc = per <= 2 ? (int)per : 0;
+  auto go = [&](auto kernel) -> int {
+    int per_cu = 1;
+    NTCHK(blocks_per_cu(c, kernel, (int)waves * 64, lds, &per_cu));
+    uint64_t grid = (uint64_t)c->n_cu * per_cu;
+    if (grid > need) grid = need;
+    prof_begin(c, "seed_ps_kernel");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream, a);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    return NTHIP_OK;
+  };
+  if (perc == 1) NTCHK(go(seed_ps_kernel<1>));
+  else if (perc == 2) NTCHK(go(seed_ps_kernel<2>));
+  else NTCHK(go(seed_ps_kernel<0>));
+  *ran = true;
+  return NTHIP_OK;
+}
+
+// seed_px_kernel (seed_px_plan.hpp): the seeds as sparse sums over scanned term arrays.  *ran = false: not this kernel's
+// shape (reads of more than its slab, more than 8 hashes per seed, a gap between the reads), or another form is cheaper.
+int launch_seed_px(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, bool* ran)
+{
+  *ran = false;
+  if (c->tune.seed_px == 2 || c->tune.seed_any == 1 || c->tune.seed_roll == 1 || f.stride != f.len || f.m2 > (uint32_t)SF_MAX_RUNTIME_M ||
+      sd->h_care.empty() || f.n_seeds > PX_MAX_SEEDS || f.n_runs == 0)
+    return NTHIP_OK;
+  const int force = c->tune.seed_px_array ? (int)c->tune.seed_px_array - 1 : -1;
+  if (sd->px_plan_len != f.len || sd->px_plan_force != force) {
+    sd->px_plan = px_make_plan(sd->h_care, f.k, (double)f.len / f.nwin, force);
+    sd->px_plan_len = f.len;
+    sd->px_plan_force = force;
+  }
+  const PxPlan& plan = sd->px_plan;
+  if (!plan.ok) return NTHIP_OK;
+  const uint32_t per = f.n_seeds * f.m2, n_arrays = (uint32_t)plan.arrays.size();
+  const int perc = per <= 2 ? (int)per : 0;
+  // reads per tile: a wave's arrays, stage and codes in a 16th of the CU's LDS where a read allows it (two waves per SIMD
+  // hide nothing: a tile is a chain of short phases), then the count nearby that leaves the fewest idle lanes in a
+  // tile's last group of 64 windows
+  const size_t cap = lds_cap_of(c);
+  const uint32_t stage_vals = perc ? 0u : (64u * per + 31u + 127u) & ~127u;
+  auto entries_of = [&](uint32_t R) { return (15u + R * f.len + plan.reach + 1u + 127u) & ~127u; };
+  auto wave_bytes_of = [&](uint32_t R) {
+    const uint32_t ne = entries_of(R);
+    return (size_t)n_arrays * ne * 16 + (size_t)stage_vals * 8 + ((ne >> 4) + 4) * 4;
+  };
+  const size_t target = (cap - 256) / 16;
+  uint32_t R_max = 0;
+  for (uint32_t R = 1; R <= 64; ++R) {
+    if (15ull + (uint64_t)R * f.len > PX_VEC_ROUNDS * 1024ull || entries_of(R) > 2048u) break;
+    if (wave_bytes_of(R) > (R == 1 ? cap - 256 : target)) break;
+    R_max = R;
+  }
+  if (R_max == 0) return NTHIP_OK;
+  uint32_t R = R_max;
+  if (c->tune.seed_px_reads) R = c->tune.seed_px_reads < R_max ? c->tune.seed_px_reads : R_max;
+  else {
+    double best = -1;
+    for (uint32_t r = R_max; r >= 1 && r + 3 >= R_max; --r) {
+      const uint32_t w = r * f.nwin, groups = (w + 63u) / 64u;
+      const double fill = (double)w / (groups * 64.0) - 0.01 * (R_max - r); // (a smaller tile: more of the per-tile work)
+      if (fill > best) {
+        best = fill;
+        R = r;
+      }
+    }
+  }
+  if (c->tune.seed_px != 1) { // the cost model against the other dense forms: picoseconds per window (tools/seed_px_fit.py)
+    const double pos_per_win = (double)f.len / f.nwin;
+    double arr = 0;
+    for (const PxArray& y : plan.arrays) arr += (y.d1 == 1 ? 1.4 : 1.0) + (y.d1 > 1 ? 2.0 : 0.0) + (y.d2 > 1 ? 2.0 : 0.0);
+    const double px = 0.45 * pos_per_win * arr + 0.085 * plan.n_terms() + 0.55 * f.n_seeds + 0.25 * (per - f.n_seeds) + 0.6;
+    const uint32_t tables = f.k <= 64 ? 2 * ((f.k + 7) / 8) : 4 * ((f.k + 15) / 16);
+    const double direct = ((f.k <= 128 ? 1.34 * tables : 6.2 * sd->any_groups) * f.n_seeds + 4.5 * (per - f.n_seeds)) * 0.205;
+    if (px >= direct) return NTHIP_OK;
+  }
+  const size_t per_wave = wave_bytes_of(R);
+  uint32_t waves = (uint32_t)((cap - 256) / per_wave);
+  if (waves > PX_MAX_WAVES) waves = PX_MAX_WAVES;
+  if (c->tune.seed_px_waves && c->tune.seed_px_waves < waves) waves = c->tune.seed_px_waves;
+  if (waves == 0) return NTHIP_OK;
+  SeedPxArgs a;
+  memset(&a, 0, sizeof a);
+  a.seqs = f.seqs;
+  a.hashes = f.hashes;
+  a.dirty = f.dirty;
+  a.n_reads = f.n_runs;
+  a.n_tiles = (f.n_runs + R - 1) / R;
+  a.total_bytes = f.n_runs * (uint64_t)f.len;
+  a.len = f.len;
+  a.k = f.k;
+  a.m2 = f.m2;
+  a.n_seeds = f.n_seeds;
+  a.nwin = f.nwin;
+  a.inv_nwin = (uint32_t)((1ull << 32) / f.nwin + 1);
+  a.R = R;
+  a.n_entries = entries_of(R);
+  a.n_arrays = n_arrays;
+  a.waves = waves;
+  a.stage_vals = stage_vals;
+  uint32_t g = per, h = 16;
+  while (h) { const uint32_t t = g % h; g = h; h = t; }
+  a.align_win = 16u / g;
+  a.reach = plan.reach + 1u;
+  a.k31 = (f.k - 1u) % 31u;
+  a.k33 = (f.k - 1u) % 33u;
+  // the kernel's order: the arrays that start from the prefix XOR first
+  uint32_t slot_of[PX_MAX_ARRAYS] = {}, n_slot = 0;
+  for (int pre = 1; pre >= 0; --pre)
+    for (uint32_t y = 0; y < n_arrays; ++y)
+      if ((plan.arrays[y].d1 == 1u) == (pre == 1)) {
+        slot_of[y] = n_slot;
+        a.arr_d[n_slot] = pre ? plan.arrays[y].d2 : plan.arrays[y].d1;
+        if (!pre && plan.arrays[y].d2) return NTHIP_OK; // (two strides on the terms: not a form the planner makes)
+        ++n_slot;
+        if (pre) ++a.n_pre;
+      }
+  for (uint32_t s = 0; s <= f.n_seeds; ++s) a.seed_first[s] = plan.seed_first[s];
+  for (uint32_t i = 0; i < plan.n_terms(); ++i)
+    a.term_off[i] = slot_of[plan.terms[i].arr] * a.n_entries * 16u + (uint32_t)plan.terms[i].e * 16u;
+  for (uint32_t i = 0; i < (uint32_t)SF_MAX_RUNTIME_M; ++i) a.mult[i] = multiplier(f.k, i);
+  const size_t lds = 256 + per_wave * waves;
+  auto go = [&](auto kernel) -> int {
+    int per_cu = 1;
+    NTCHK(blocks_per_cu(c, kernel, (int)waves * 64, lds, &per_cu));
+    const uint64_t need = (a.n_tiles + waves - 1) / waves;
+    uint64_t grid = (uint64_t)c->n_cu * per_cu;
+    if (grid > need) grid = need;
+    prof_begin(c, "seed_px_kernel");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(waves * 64), lds, c->stream, a);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    return NTHIP_OK;
+  };
+  if (perc == 1) NTCHK(go(seed_px_kernel<1>));
+  else if (perc == 2) NTCHK(go(seed_px_kernel<2>));
+  else NTCHK(go(seed_px_kernel<0>));
+  *ran = true;
+  return NTHIP_OK;
+}
+
 template <typename K>
 int launch_seed_fixed(nthip_ctx* c, K kernel, const SeedFixedArgs& a, size_t dyn_lds)
 {
@@ -1180,7 +1522,9 @@ extern "C" int nthip_seed_hash(nthip_ctx* c, const nthip_reads* rd_in, const nth
       // NTHIP_TUNE_SEED_ANY=1 sends every dense batch there, =2 none of k <= 128 (A/B, tests)
       bool wtile_ran = false;
       bool prefer_any = false;
-      NTCHK(launch_seed_roll(c, a, sd, &wtile_ran)); // (seeds of few runs: rolled, whatever k)
+      NTCHK(launch_seed_ps(c, a, sd, &wtile_ran)); // (sparse sums over the prefix XOR of a read: the cost follows the seed)
+      if (!wtile_ran) NTCHK(launch_seed_px(c, a, sd, &wtile_ran)); // (... over stride scans; longer reads)
+      if (!wtile_ran) NTCHK(launch_seed_roll(c, a, sd, &wtile_ran)); // (seeds of few runs: rolled, whatever k)
       if (!wtile_ran && (k > 128 || c->tune.seed_any == 1)) NTCHK(launch_seed_any(c, a, sd, &wtile_ran));
       if (!wtile_ran && k <= 128)
         NTCHK(launch_seed_wtile(c, a, sd, nh, &wtile_ran, c->tune.seed_any == 2 ? nullptr : &prefer_any));

@@ -2,8 +2,9 @@
 """Seeds of few runs: the run-by-run rolling kernel (seed_roll_kernel.hpp) against the masked direct forms, kernel time.
 
     python tools/seed_roll_sweep.py [out.json]
-Every shape is hashed by a context with NTHIP_TUNE_SEED_ROLL=1 (rolled whenever the kernel takes the seed set), one with
-=2 (never) and one without the knob (the cost model's choice).  Prints G k-mers/s and the fraction of the 8 TB/s roofline
+Every shape is hashed by a context with NTHIP_TUNE_SEED_PX=1 (sparse sums over scanned arrays, seed_px_kernel.hpp), one with
+NTHIP_TUNE_SEED_ROLL=1 (rolled whenever the kernel takes the seed set), one with both =2 (neither) and one without a knob
+(the cost model's choice).  Prints G k-mers/s and the fraction of the 8 TB/s roofline
 (input bytes + 8 * seeds * m bytes per k-mer).
 """
 import json, os, statistics, sys
@@ -51,18 +52,20 @@ SHAPES = [  # (L, seeds, m per seed)
 OUT_BUDGET = int(os.environ.get("SWEEP_GIB", "8")) << 30
 
 
-def make_ctx(knob):
-    if knob:
-        os.environ["NTHIP_TUNE_SEED_ROLL"] = knob
+def make_ctx(**env):
+    for key, v in env.items():
+        os.environ[key] = v
     try:
         c = nthash_amd.Context(0)
     finally:
-        os.environ.pop("NTHIP_TUNE_SEED_ROLL", None)
+        for key in env:
+            os.environ.pop(key, None)
     c.set_profiling(True)
     return c
 
 
-ctxs = {"rolled": make_ctx("1"), "direct": make_ctx("2"), "default": make_ctx("")}
+ctxs = {"px": make_ctx(NTHIP_TUNE_SEED_PX="1"), "rolled": make_ctx(NTHIP_TUNE_SEED_ROLL="1"),
+        "direct": make_ctx(NTHIP_TUNE_SEED_ROLL="2", NTHIP_TUNE_SEED_PX="2"), "default": make_ctx()}
 rows = []
 for (L, seeds, m2) in SHAPES:
     k, ns = len(seeds[0]), len(seeds)
@@ -87,6 +90,6 @@ for (L, seeds, m2) in SHAPES:
     c0.free(d_in); c0.free(d_out)
     rows.append(row)
     print(f"L={L:4d} k={k:3d} seeds={ns} m={m2} runs={runs:2d}  " + "  ".join(
-        f"{t}: {row[t]['gkmer_s']:6.1f} G ({row[t]['frac']:.2f}) {row[t]['kernel'][:24]}" for t in ctxs), flush=True)
+        f"{t}: {row[t]['gkmer_s']:6.1f} G ({row[t]['frac']:.2f}) {row[t]['kernel'][5:14]}" for t in ctxs), flush=True)
 if len(sys.argv) > 1:
     json.dump(rows, open(sys.argv[1], "w"), indent=1)
