@@ -243,9 +243,6 @@ struct nthip_seeds {
   mutable uint32_t px_plan_len = 0;
   mutable int px_plan_force = -2;
   // seed_ps_kernel.hpp: the same reads as byte offsets per step of a segment, on the device, for the last geometry asked for
-  // capi_seed_jit.hip: the kernels compiled for this seed set at run time, source key -> {hipModule_t, hipFunction_t}
-  mutable std::map<std::string, std::pair<void*, void*>> jit;
-  mutable std::set<std::string> jit_failed;
   mutable uint32_t* d_ps_off = nullptr;
   mutable uint64_t ps_key = 0;
   mutable ntamd::PxPlan ps_plan;

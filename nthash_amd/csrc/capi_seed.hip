@@ -940,7 +940,8 @@ struct PsGeo {
   std::vector<uint32_t> first;                      // seed s reads [first[s], first[s + 1])
   std::vector<std::pair<uint32_t, uint32_t>> reads; // (array: 0 prefix, 1 terms; e)
 };
-bool ps_geometry(nthip_ctx* c, const nthip_seeds* sd, uint32_t len, uint32_t m2, PsGeo* out)
+// (jit: the specialised kernel, which stages a tile's values in LDS -- seed_psj_kernel.inc: STAGE_U64)
+bool ps_geometry(nthip_ctx* c, const nthip_seeds* sd, uint32_t len, uint32_t m2, bool jit, PsGeo* out)
 {
   const uint32_t k = sd->k;
   if (len < k || sd->h_care.empty() || sd->n_seeds > PX_MAX_SEEDS || m2 == 0 || m2 > (uint32_t)SF_MAX_RUNTIME_M) return false;
@@ -974,6 +975,10 @@ bool ps_geometry(nthip_ctx* c, const nthip_seeds* sd, uint32_t len, uint32_t m2,
     PsGeo g;
     g.W = W; g.nb_log = nb_log; g.lpr_log = lpr_log; g.segs_b = segs_b; g.n_arrays = n_arrays;
     g.wave_bytes = (size_t)n_arrays * rpw * epr * 16 + ((codes_dw * 4 + 15) & ~15u);
+    if (jit) {
+      const uint32_t nv = rpw * nwin * per;
+      g.wave_bytes += (((size_t)nv + 16 + ((nv + 16) >> 3) + 2 + 1) / 2) * 16;
+    }
     g.fixed = (size_t)4 * epr * 16;
     if (g.fixed + g.wave_bytes > cap) continue;
     // wave instructions per window: the build's two passes per round, W steps of the seeds' reads and rotations
@@ -981,7 +986,7 @@ bool ps_geometry(nthip_ctx* c, const nthip_seeds* sd, uint32_t len, uint32_t m2,
     const double step = 12.0 + 38.0 * n_seeds + 3.2 * plan.n_terms() + 6.0 * (per - n_seeds);
     g.cost = (rounds * (20.0 * W + 45.0) + W * step + 60.0) / ((double)rpw * nwin);
     const size_t waves_fit = (cap - g.fixed) / g.wave_bytes;
-    if (waves_fit < 8) g.cost *= 1.0 + 0.08 * (8 - waves_fit); // (few waves: the phases of a tile are not hidden)
+    if (waves_fit < 12) g.cost *= 1.0 + 0.06 * (12 - waves_fit); // (few waves: the phases of a tile are not hidden)
     if (!found || g.cost < best.cost) { best = g; found = true; }
   }
   if (!found) return false;
@@ -1005,11 +1010,12 @@ bool ps_geometry(nthip_ctx* c, const nthip_seeds* sd, uint32_t len, uint32_t m2,
 bool ntamd::host::seed_jit_shape(nthip_ctx* c, const nthip_seeds* sd, uint32_t len, uint32_t m2, SeedJitShape* out)
 {
   PsGeo g;
-  if (!ps_geometry(c, sd, len, m2, &g)) return false;
+  if (!ps_geometry(c, sd, len, m2, true, &g)) return false;
   if ((uint64_t)g.W * g.reads.size() > 2048) return false; // (straight-line code: reads x steps)
   SeedJitShape j;
   j.len = len; j.k = sd->k; j.nwin = len - sd->k + 1; j.m2 = m2; j.n_seeds = sd->n_seeds; j.W = g.W; j.nb_log = g.nb_log;
-  j.lpr_log = g.lpr_log; j.n_arrays = g.n_arrays; j.segs_b = g.segs_b; j.waves = g.waves;
+  j.lpr_log = g.lpr_log; j.n_arrays = g.n_arrays; j.segs_b = g.segs_b;
+  j.waves = g.waves;
   for (auto& r : g.reads) {
     j.term_arr.push_back(r.first);
     j.term_e.push_back(r.second);
@@ -1027,7 +1033,7 @@ int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, 
   if (c->tune.seed_ps == 2 || c->tune.seed_px == 1 || c->tune.seed_any == 1 || c->tune.seed_roll == 1 || f.stride != f.len || f.n_runs == 0)
     return NTHIP_OK;
   PsGeo best;
-  if (!ps_geometry(c, sd, f.len, f.m2, &best)) return NTHIP_OK;
+  if (!ps_geometry(c, sd, f.len, f.m2, false, &best)) return NTHIP_OK;
   const uint32_t per = f.n_seeds * f.m2;
   const uint32_t W = best.W, NB = 1u << best.nb_log, rpw = 64u >> best.lpr_log, epr = W << best.nb_log, waves = best.waves;
   const uint32_t n_terms = (uint32_t)best.reads.size();
@@ -1035,11 +1041,29 @@ int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, 
   // the disk cache): straight-line code, every read an immediate offset
   const bool jit_wanted = c->tune.seed_jit != 2 && (c->tune.seed_jit == 1 || f.n_runs * (uint64_t)f.nwin >= (1ull << 24)) &&
                           (uint64_t)W * n_terms <= 2048;
-  if (c->tune.seed_ps != 1) { // against the other dense forms: picoseconds per window (fitted on tools/seed_sweep.py, seed_roll_sweep.py)
-    const double ps = best.cost * (jit_wanted ? 0.9 : 1.7) + 0.5;
-    const uint32_t tables = f.k <= 64 ? 2 * ((f.k + 7) / 8) : 4 * ((f.k + 15) / 16);
-    const double direct = ((f.k <= 128 ? 1.34 * tables : 6.2 * sd->any_groups) * f.n_seeds + 4.5 * (per - f.n_seeds)) * 0.205;
-    if (ps >= direct) return NTHIP_OK;
+  if (c->tune.seed_ps != 1) {
+    // Against the other dense forms, picoseconds per window, fitted on tools/seed_sweep.py and seed_roll_sweep.py
+    // (profiles/r06_seed_sweep*.txt, r06_seed_roll_sweep.txt).  The precompiled segment kernel is behind them on every
+    // shape measured (its reads cost an address and a scalar load each): it hashes only when asked for.
+    if (!jit_wanted) return NTHIP_OK;
+    const double pos_per_win = (double)f.len / f.nwin, extra = per - f.n_seeds;
+    double psj = 0.9 * pos_per_win + 1.9 * f.n_seeds + 0.08 * n_terms + 1.5 * extra;
+    const double hbm = (8.0 * per + pos_per_win) / 5.5; // (bytes per window at 5.5 TB/s)
+    if (psj < hbm) psj = hbm;
+    double direct;
+    if (f.k <= 32) {
+      static const double few[5] = {0, 2.8, 4.15, 6.7, 8.5}; // (the rotated-slot tables: one to four seeds)
+      direct = (f.n_seeds <= 4 ? few[f.n_seeds] : 4.3 * f.n_seeds) + 1.4 * extra;
+    } else {
+      const size_t tab_bytes = (size_t)f.n_seeds * ((f.k + 7) / 8) * 2 * 4096; // (8 KiB of byte tables per 8 bases and seed)
+      direct = 0.36 * ((f.k + 3) / 4) * f.n_seeds * (tab_bytes > 120 * 1024 ? 1.25 : 1.0) + 0.8 * extra;
+      if (f.k > 128) direct = 1.0 * ((f.k + 15) / 16) * f.n_seeds + 0.8 * extra; // (the any-seed form)
+    }
+    uint32_t runs = 0;
+    for (const auto& care : sd->h_care)
+      for (uint32_t p = 0; p < f.k; ++p) runs += care[p] && (p == 0 || !care[p - 1]);
+    const double roll = per <= 8 && runs <= SR_MAX_RUNS ? f.n_seeds * (3.0 + 0.004 * f.k) + 0.27 * runs + 3.0 * extra : 1e9;
+    if (psj >= 0.97 * (direct < roll ? direct : roll)) return NTHIP_OK;
   }
   const uint64_t n_tiles = (f.n_runs + rpw - 1) / rpw, need = (n_tiles + waves - 1) / waves;
   if (jit_wanted) {
@@ -1047,21 +1071,32 @@ int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, 
     std::string why;
     if (seed_jit_shape(c, sd, f.len, f.m2, &j)) {
       HIPCHK(hipSetDevice(c->device));
+      if (j.waves > 12 && j.waves < 16) j.waves = 12; // (13-15 waves are four on one SIMD: 128 registers, as for 16)
       hipFunction_t fn = (hipFunction_t)seed_psj_get(c, sd, j, &why);
+      // a kernel that spills at this block size gets the registers of a smaller one
+      while (!fn && why.find("spills") != std::string::npos && j.waves > 4) {
+        j.waves = j.waves > 12 ? 12 : j.waves > 8 ? 8 : 4;
+        why.clear();
+        fn = (hipFunction_t)seed_psj_get(c, sd, j, &why);
+      }
       if (fn) {
-        const size_t lds = best.fixed + best.wave_bytes * waves;
-        uint64_t per_cu = lds ? lds_cap_of(c) / lds : 1;
+        const uint32_t jw = j.waves, jrpw = 64u >> j.lpr_log; // (the specialised kernel's own tiles: its geometry counts the stage)
+        const uint64_t n_tiles_j = (f.n_runs + jrpw - 1) / jrpw;
+        int lds_static = 0;
+        (void)hipFuncGetAttribute(&lds_static, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, fn);
+        uint64_t per_cu = lds_static > 0 ? lds_cap_of(c) / (size_t)lds_static : 1;
         if (per_cu < 1) per_cu = 1;
-        if (per_cu * waves > 32) per_cu = 32 / waves ? 32 / waves : 1;
+        if (per_cu * jw > 32) per_cu = 32 / jw ? 32 / jw : 1;
         uint64_t grid = (uint64_t)c->n_cu * per_cu;
-        if (grid > need) grid = need;
+        const uint64_t need_j = (n_tiles_j + jw - 1) / jw;
+        if (grid > need_j) grid = need_j;
         const uint8_t* seqs = f.seqs;
         uint64_t* hashes = f.hashes;
         uint32_t* dirty = f.dirty;
-        uint64_t n_reads = f.n_runs, nt = n_tiles, total_bytes = f.n_runs * (uint64_t)f.len;
+        uint64_t n_reads = f.n_runs, nt = n_tiles_j, total_bytes = f.n_runs * (uint64_t)f.len;
         void* args[] = {&seqs, &hashes, &dirty, &n_reads, &nt, &total_bytes};
         prof_begin(c, "seed_psj_kernel");
-        const hipError_t e = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, waves * 64, 1, 1, 0, c->stream, args, nullptr);
+        const hipError_t e = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, jw * 64, 1, 1, 0, c->stream, args, nullptr);
         prof_end(c);
         if (e == hipSuccess) {
           *ran = true;
@@ -1145,7 +1180,10 @@ int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, 
 int launch_seed_px(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, bool* ran)
 {
   *ran = false;
-  if (c->tune.seed_px == 2 || c->tune.seed_any == 1 || c->tune.seed_roll == 1 || f.stride != f.len || f.m2 > (uint32_t)SF_MAX_RUNTIME_M ||
+  // (only when asked for: two positions per lane and step with a wave-wide scan -- ~85 instructions per position -- leave it
+  //  behind the other dense forms on every shape of tools/seed_sweep.py / seed_roll_sweep.py; it is the form that takes the
+  //  stride-d scans of the plan and reads of up to ~2000 bases, kept bit-exact by tests/test_gpu_seed_px.py)
+  if (c->tune.seed_px != 1 || c->tune.seed_any == 1 || c->tune.seed_roll == 1 || f.stride != f.len || f.m2 > (uint32_t)SF_MAX_RUNTIME_M ||
       sd->h_care.empty() || f.n_seeds > PX_MAX_SEEDS || f.n_runs == 0)
     return NTHIP_OK;
   const int force = c->tune.seed_px_array ? (int)c->tune.seed_px_array - 1 : -1;

@@ -166,46 +166,53 @@ std::string ntamd::host::seed_psj_source(const SeedJitShape& g)
   return o.str();
 }
 
-// the specialised kernel of a shape: from the seed set's cache, the disk, or the compiler.  nullptr (and *why): not available
+// The specialised kernel of a shape: from the process's registry, the disk, or the compiler.  nullptr (and *why): not
+// available.  A code object is loaded ONCE per process and device and stays loaded: seed sets of the same strings share it
+// (loading and unloading the same image again and again -- a seed set per call, several contexts -- ended in memory faults
+// of the launched kernels on ROCm 7.2; the registry is bounded by the distinct seed sets and read shapes a process meets).
+namespace {
+struct Loaded {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  std::vector<char> image; // (the runtime may load from the image lazily: it lives as long as the module)
+};
+std::map<std::string, Loaded> g_loaded;
+std::set<std::string> g_failed;
+std::mutex g_loaded_mu;
+} // namespace
 void* ntamd::host::seed_psj_get(nthip_ctx* c, const nthip_seeds* sd, const SeedJitShape& g, std::string* why)
 {
+  (void)sd;
   const std::string src = seed_psj_source(g);
   char key[48];
   snprintf(key, sizeof key, "%016llx_%zu_%d", (unsigned long long)fnv1a(src), src.size(), c->device);
-  auto it = sd->jit.find(key);
-  if (it != sd->jit.end()) return it->second.second;
-  if (sd->jit_failed.count(key)) {
-    *why = "compile failed before";
+  std::lock_guard<std::mutex> lk(g_loaded_mu);
+  auto it = g_loaded.find(key);
+  if (it != g_loaded.end()) return (void*)it->second.fn;
+  if (g_failed.count(key)) {
+    *why = "the specialised kernel spills registers / did not compile (earlier in this process)";
     return nullptr;
   }
-  std::vector<char> code;
-  hipModule_t mod = nullptr;
-  hipFunction_t fn = nullptr;
-  if (!compile_source(src, &code, why) || hipModuleLoadData(&mod, code.data()) != hipSuccess ||
-      hipModuleGetFunction(&fn, mod, "psj") != hipSuccess) {
+  Loaded& L = g_loaded[key];
+  if (!compile_source(src, &L.image, why) || hipModuleLoadData(&L.mod, L.image.data()) != hipSuccess ||
+      hipModuleGetFunction(&L.fn, L.mod, "psj") != hipSuccess) {
     if (why->empty()) *why = "hipModuleLoadData / hipModuleGetFunction failed";
     (void)hipGetLastError();
-    if (mod) (void)hipModuleUnload(mod);
-    sd->jit_failed.insert(key);
+    g_loaded.erase(key);
+    g_failed.insert(key);
     return nullptr;
   }
   int scratch = 0; // (a kernel that spills is slower than the precompiled one it replaces)
-  if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn) == hipSuccess && scratch > 0) {
+  if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, L.fn) == hipSuccess && scratch > 0) {
     *why = "the specialised kernel spills registers";
-    (void)hipModuleUnload(mod);
-    sd->jit_failed.insert(key);
+    L.fn = nullptr; // (stays loaded, never launched)
+    g_failed.insert(key);
     return nullptr;
   }
-  sd->jit[key] = {(void*)mod, (void*)fn};
-  return (void*)fn;
+  return (void*)L.fn;
 }
 
-void ntamd::host::seed_jit_release(const nthip_seeds* sd)
-{
-  for (auto& kv : sd->jit)
-    if (kv.second.first) (void)hipModuleUnload((hipModule_t)kv.second.first);
-  sd->jit.clear();
-}
+void ntamd::host::seed_jit_release(const nthip_seeds* sd) { (void)sd; }
 
 // The source text that is compiled for a seed set on reads of `len` bases (malloc'ed: free() it) -- no device needed: what
 // tests/test_seed_jit_source.py compiles with hipcc and what a user may want to look at.

@@ -64,8 +64,10 @@ def make_ctx(**env):
     return c
 
 
-ctxs = {"px": make_ctx(NTHIP_TUNE_SEED_PX="1"), "rolled": make_ctx(NTHIP_TUNE_SEED_ROLL="1"),
-        "direct": make_ctx(NTHIP_TUNE_SEED_ROLL="2", NTHIP_TUNE_SEED_PX="2"), "default": make_ctx()}
+ctxs = {"ps": make_ctx(NTHIP_TUNE_SEED_PS="1"), "px": make_ctx(NTHIP_TUNE_SEED_PX="1"), "rolled": make_ctx(NTHIP_TUNE_SEED_ROLL="1"),
+        "direct": make_ctx(NTHIP_TUNE_SEED_ROLL="2", NTHIP_TUNE_SEED_PX="2", NTHIP_TUNE_SEED_PS="2"), "default": make_ctx()}
+if os.environ.get("SWEEP_ONLY"):
+    ctxs = {t: c for t, c in ctxs.items() if t in os.environ["SWEEP_ONLY"].split(",") or t == "default"}
 rows = []
 for (L, seeds, m2) in SHAPES:
     k, ns = len(seeds[0]), len(seeds)
