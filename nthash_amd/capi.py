@@ -35,7 +35,7 @@ SYMBOLS = [
     "nthip_version", "nthip_last_error", "nthip_device_count", "nthip_ctx_create",
     "nthip_ctx_destroy", "nthip_ctx_set_stream", "nthip_ctx_synchronize", "nthip_ctx_take_dirty",
     "nthip_ctx_set_profiling", "nthip_last_kernel_ms", "nthip_malloc", "nthip_free",
-    "nthip_ctx_trim", "nthip_memcpy_h2d", "nthip_memcpy_d2h", "nthip_memset", "nthip_kmer_hash", "nthip_seeds_create",
+    "nthip_ctx_trim", "nthip_ctx_set_scratch_limit", "nthip_ctx_scratch_info", "nthip_memcpy_h2d", "nthip_memcpy_d2h", "nthip_memset", "nthip_kmer_hash", "nthip_seeds_create",
     "nthip_seeds_destroy", "nthip_seed_jit_source", "nthip_seed_hash", "nthip_kmer_extend", "nthip_kmer_bloom_insert",
     "nthip_kmer_bloom_query", "nthip_kmer_minhash", "nthip_stream_bloom_insert", "nthip_kmer_hash_spans", "nthip_fastx_index",
     "nthip_fastx_kmer_hash_file", "nthip_fastx_seed_hash_file", "nthip_seed_hash_spans", "nthip_fasta_compact", "nthip_synth_reads", "nthip_checksum",
@@ -103,6 +103,8 @@ def load():
     L.nthip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.nthip_ctx_destroy.argtypes = [vp]
     L.nthip_ctx_trim.argtypes = [vp]
+    L.nthip_ctx_set_scratch_limit.argtypes = [vp, C.c_size_t]
+    L.nthip_ctx_scratch_info.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.nthip_ctx_set_stream.argtypes = [vp, vp]
     L.nthip_ctx_synchronize.argtypes = [vp]
     L.nthip_ctx_take_dirty.argtypes = [vp, C.POINTER(C.c_int)]
@@ -405,6 +407,16 @@ class Context:
     def trim(self):
         """release the buffers the context caches between calls (streaming driver, scan scratch)"""
         _chk(self.L.nthip_ctx_trim(self.h))
+
+    def set_scratch_limit(self, nbytes):
+        """bound what the consumers' rounds plan with and the context keeps between calls (0: the default, a quarter of the device)"""
+        _chk(self.L.nthip_ctx_set_scratch_limit(self.h, nbytes))
+
+    def scratch_info(self):
+        """-> (bytes the context holds now, the limit in force)"""
+        kept, lim = C.c_size_t(0), C.c_size_t(0)
+        _chk(self.L.nthip_ctx_scratch_info(self.h, C.byref(kept), C.byref(lim)))
+        return kept.value, lim.value
 
     def minhash_ptr(self, seqs, n_reads, fixed_len, stride, k, m, sig, flags=0, offsets=0):
         """per-read MinHash signatures into sig[n_reads * m]; -> k-mers consumed"""

@@ -263,8 +263,6 @@ void ntamd::host::load_tuning(nthip_tune& t)
   t.no_seed_wtile = is_one("NTHIP_TUNE_NO_SEED_WTILE");
   t.no_seed_rot = is_one("NTHIP_TUNE_NO_SEED_ROT");
   t.seed_pass = num("NTHIP_TUNE_SEED_PASS", 1, 255);
-  t.no_scattered = !is_one("NTHIP_TUNE_SCATTERED"); // (round 5: mapped-from-pieces candidates only on request -- capi_util.hip says why)
-  t.malloc_pieces = num("NTHIP_TUNE_MALLOC_PIECES", 1, 4096);
   t.malloc_probe = num("NTHIP_TUNE_MALLOC_PROBE", 1, 8);
   t.no_seed_long = is_one("NTHIP_TUNE_NO_SEED_LONG");
   t.no_seed_w6 = is_one("NTHIP_TUNE_NO_SEED_W6");
@@ -379,7 +377,6 @@ extern "C" int nthip_ctx_destroy(nthip_ctx* c)
   for (int i = 0; i < 2; ++i)
     if (c->kept[i]) (void)hipFree(c->kept[i]);
   for (auto& kv : c->init_tabs) (void)hipFree(kv.second);
-  while (!c->scattered.empty()) (void)scattered_free(c, c->scattered.begin()->first);
   fastx_buffers_release(c);
   if (c->stage_buf) (void)hipFree(c->stage_buf);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -477,14 +474,13 @@ extern "C" int nthip_malloc(nthip_ctx* c, size_t bytes, void** p)
   // that releases tens of GB and allocates again waits for the driver, 2-6 s per 50 GB (tools/probe_cost.py, profiles/r05_notes.md
   // §12) -- so a caller who wants the fast class asks for it once, at start-up.  (Mapping from physical pieces: default_alloc.)
   const uint32_t probe = c->tune.malloc_probe ? c->tune.malloc_probe : 1u;
-  if (probe > 1 && bytes >= ((size_t)1 << 30) && c->tune.malloc_pieces < 2) return nthip_malloc_probed(c, bytes, (int)probe, p, nullptr, nullptr);
+  if (probe > 1 && bytes >= ((size_t)1 << 30)) return nthip_malloc_probed(c, bytes, (int)probe, p, nullptr, nullptr);
   return default_alloc(c, bytes, p);
 }
 extern "C" int nthip_free(nthip_ctx* c, void* p)
 {
   if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
   HIPCHK(hipSetDevice(c->device));
-  if (scattered_free(c, p)) return NTHIP_OK;
   HIPCHK(hipFree(p));
   return NTHIP_OK;
 }

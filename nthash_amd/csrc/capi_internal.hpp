@@ -101,9 +101,7 @@ struct nthip_tune {
   uint32_t reads_run_len = 0, reads_per_tile = 0, reads_waves = 0; // NTHIP_TUNE_READS_RUN_LEN / _PER_TILE / _WAVES (kmer_reads_kernel)
   bool no_seed_w6 = false;    // NTHIP_TUNE_NO_SEED_W6=1: seed_wtile_kernel with 4 waves where 6 would fit (A/B)
   bool no_seed_long = false;  // NTHIP_TUNE_NO_SEED_LONG=1: long reads of SeedNtHash stay on one wave per read
-  bool no_scattered = true;   // unless NTHIP_TUNE_SCATTERED=1: nthip_malloc_probed tries plain hipMalloc candidates only (round 5: see capi_util.hip)
-  uint32_t malloc_probe = 0;  // NTHIP_TUNE_MALLOC_PROBE=<n>: plain allocations nthip_malloc measures for a buffer of 1 GiB and more, the fastest kept (1: none; unset: 3)
-  uint32_t malloc_pieces = 0; // NTHIP_TUNE_MALLOC_PIECES=<MiB>: nthip_malloc maps buffers of 1 GiB and more from physical pieces of that size (1: plain hipMalloc always; unset: the default policy)
+  uint32_t malloc_probe = 0;  // NTHIP_TUNE_MALLOC_PROBE=<n>: plain allocations nthip_malloc measures for a buffer of 1 GiB and more, the fastest kept (1 or unset: none -- one plain allocation)
   uint32_t seed_pass = 0;     // NTHIP_TUNE_SEED_PASS=n: seed_wtile_kernel hashes n seeds per pass (A/B; 0: planned)
   bool no_seed_rot = false;   // NTHIP_TUNE_NO_SEED_ROT=1: the plain [table][entry] layout of the byte tables in LDS
   // phased headline kernel (kmer_runs_kernel.hpp): tiles per wave and period, period / read window in 10 ns ticks
@@ -177,12 +175,9 @@ struct nthip_ctx {
   std::map<std::pair<const void*, size_t>, int> occ_cache;
   // all-care byte tables for the first window of a run, per k (device memory)
   std::map<uint32_t, uint4*> init_tabs;
-  // buffers nthip_malloc_probed mapped from many small physical pieces (capi_util.hip): base -> pieces, for nthip_free
-  struct ScatteredAlloc {
-    size_t bytes = 0;
-    std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> pieces;
-  };
-  std::map<void*, ScatteredAlloc> scattered;
+  // what the consumers' rounds may hold in device scratch -- the kept buffers above, the lists of the binned consumers, the
+  // temporaries of a round (nthip_ctx_set_scratch_limit; 0: a quarter of the device's memory); rounds are sized to fit
+  size_t scratch_limit = 0, device_mem = 0;
   // run length of the general dense kernel per (len, stride, k, m), measured on the first big batch of that shape
   // (the cost model does not see what a longer run costs in waves per CU or LDS conflicts: +-10 % either way)
   std::map<std::array<uint32_t, 4>, uint32_t> run_len_cache;
@@ -269,12 +264,13 @@ int ensure_scratch(nthip_ctx* c, size_t elems);
 int ensure_scratch2(nthip_ctx* c, size_t elems);
 int ensure_args(nthip_ctx* c, size_t bytes);
 void fastx_buffers_release(nthip_ctx* c); // the file driver's pinned / device buffers
-// capi_util.hip: a buffer of `bytes` mapped from physical pieces of `piece` bytes (see nthip_malloc_probed); false + *out =
-// nullptr when the virtual-memory API refuses; scattered_free() returns false for a pointer it does not own
-bool scattered_alloc(nthip_ctx* c, size_t bytes, size_t piece, void** out);
-// what nthip_malloc does: big buffers mapped from small physical pieces (the fast class of profiles/r02_notes.md 26), else hipMalloc
+// capi_util.hip: what nthip_malloc does -- hipMalloc
 int default_alloc(nthip_ctx* c, size_t bytes, void** out);
-bool scattered_free(nthip_ctx* c, void* p);
+// the context's scratch limit in bytes (its default: a quarter of the device's memory)
+size_t scratch_limit_of(nthip_ctx* c);
+// the memory a consumer's round may plan with: what is free now + `reusable` (what the context already holds and the round
+// reuses), capped by the scratch limit
+size_t round_memory(nthip_ctx* c, size_t reusable, size_t fallback_free);
 
 inline void prof_begin(nthip_ctx* c, const char* name)
 {
@@ -370,6 +366,7 @@ int stream_hits_per_read(nthip_ctx* c, const uint64_t* d_h, const uint64_t* d_ro
 // the stream insert / the binned stream query of a stream that holds hashes()[0] only: level 1 makes the other expand_m - 1 values of
 // every input (bloom_part_stream_pieces_kernel<.., M>; expand_m 2 ... 4, kmul = k * MULTISEED).  *done = false: the caller hashes
 // the full stream and takes the usual road.
+bool bloom_binned_applies(const nthip_ctx* c, const void* d_filter, uint64_t n_bits, uint64_t n_values); // (the binned insert takes such a batch)
 int stream_bloom_insert_expand(nthip_ctx* c, const uint64_t* d_h0, uint64_t n_inputs, uint32_t expand_m, uint64_t kmul, uint32_t* d_filter,
                                uint64_t n_bits, bool* done);
 int answers_hits_per_read(nthip_ctx* c, const uint8_t* d_ans, const uint64_t* d_roff, uint64_t n_reads, uint64_t n_kmers, uint32_t m,

@@ -27,9 +27,8 @@ int ntamd::host::offsets_in_rounds(nthip_ctx* c, const nthip_reads* rd, uint32_t
   const uint64_t n = rd->n_reads;
   if (n == 0) return NTHIP_OK;
   const bool host = (flags & NTHIP_HOST_INPUT) != 0;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
-  free_b += reusable_bytes(c); // (the context's lists and kept buffers are reused by the round, not added to)
+  // (the context's lists and kept buffers are reused by the round, not added to; the context's scratch limit caps the sum)
+  const size_t free_b = round_memory(c, reusable_bytes(c), (size_t)4 << 30);
   uint64_t round_bases = (uint64_t)(free_b / 10 * 8) / (scratch_per_base + (host ? 1 : 0));
   if (c->tune.bloom_round) round_bases = c->tune.bloom_round; // (tests: several rounds on a small batch)
   const uint64_t reads_max = std::max<uint64_t>(1, (free_b / 10) / 48);
@@ -77,9 +76,7 @@ int ntamd::host::stream_of_offsets(nthip_ctx* c, const nthip_reads* rd, uint16_t
   if (round_bases == 0) NTCHK(reads_total_bytes(c, rd, flags, &total_bytes));
   const uint64_t cap = total_bytes > 0 ? total_bytes : 1;
   const size_t need = (size_t)cap * m * 8 + (d_counts ? (size_t)rd->n_reads * 16 + 4096 : 0);
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-  free_b += c->kept_bytes[KEPT_STREAM];
+  const size_t free_b = round_memory(c, c->kept_bytes[KEPT_STREAM], 0);
   if (need > free_b / 10 * 9)
     return fail(NTHIP_ERR_UNSUPPORTED, "reads given by offsets: the batch's hash stream (%llu MB) does not fit the device in one round; split the batch",
                 (unsigned long long)(need >> 20));
@@ -157,9 +154,7 @@ int bloom_lists(nthip_ctx* c, uint64_t* round, bool with_stream, BloomLists* t)
 // values per round: what the free memory allows (16 B per value with the hash stream, 8 without), at most BB_ROUND_MAX
 uint64_t bloom_round_values(const nthip_ctx* c, uint64_t n_values, bool with_stream)
 {
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
-  free_b += c->bloom_tmp_bytes; // (what the context already holds is ours to reuse)
+  const size_t free_b = round_memory(const_cast<nthip_ctx*>(c), c->bloom_tmp_bytes, (size_t)8 << 30); // (what the context already holds is ours to reuse)
   const uint64_t per = with_stream ? 16 : 8;
   uint64_t round = (uint64_t)(free_b / 2) / per;
   if (round > BB_ROUND_MAX) round = BB_ROUND_MAX;
@@ -335,9 +330,7 @@ bool bloom_slots_ok(nthip_ctx* c)
 // values per round of the slots mode: what the free memory allows (about 8.7 B per value), at most BB_SLOTS_ROUND_MAX
 uint64_t slots_round_values(const nthip_ctx* c, uint64_t n_values, uint64_t round_max = BB_SLOTS_ROUND_MAX)
 {
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
-  free_b += c->bloom_tmp_bytes;
+  const size_t free_b = round_memory(const_cast<nthip_ctx*>(c), c->bloom_tmp_bytes, (size_t)8 << 30);
   uint64_t round = (uint64_t)(free_b / 2) / 9;
   if (round > round_max) round = round_max;
   if (round > n_values) round = n_values;
@@ -808,8 +801,13 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
       uint64_t *d_h = nullptr, *d_counts = nullptr, n_kmers = 0;
       // several hashes per k-mer into / against a two-level filter: the round's stream holds hashes()[0] only, the first partition
       // level makes the others (stream_bloom_insert_expand / stream_hits_per_read: an m times shorter stream written and read back)
+      // (only when the road that consumes such a stream will take the batch -- the same predicates as stream_bloom_insert_expand /
+      //  stream_query_binned: a batch they decline would be hashed with one hash per k-mer, then again in full)
+      const uint64_t est_values = (bases ? bases : 1) * (uint64_t)m;
       const bool expand = m >= 2 && m <= 4 && n_bits > (1ull << 27) && c->tune.bloom_pieces != 2 &&
-                          (query ? c->tune.bloom_query != 2 : c->tune.bloom_binned != 2);
+                          (query ? c->tune.bloom_query != 2 && (c->tune.bloom_query == 1 || (est_values >= (1ull << 24) && (n_bits >> 3) >= (32ull << 20) &&
+                                                                                             est_values >= (n_bits >> 3) / 32))
+                                 : bloom_binned_ok(c, d_filter, n_bits, est_values));
       NTCHK(stream_of_offsets(c, part, k16, expand ? (uint8_t)1 : m8, flags, keep, &d_h, query ? &d_counts : nullptr, &n_kmers, bases ? bases : 1));
       sum_kmers += n_kmers;
       if (!query) {
@@ -948,6 +946,10 @@ extern "C" int nthip_kmer_bloom_query(nthip_ctx* c, const nthip_reads* rd, uint1
 // The stream insert for a stream that holds hashes()[0] only (n_inputs of them; the filter gets expand_m values of each: level 1
 // makes the others).  *done = false (filter untouched or touched in part -- setting a bit twice is harmless): not a table / a
 // device for it, the caller hashes the full stream and takes nthip_stream_bloom_insert.  Waits for the stream.
+bool ntamd::host::bloom_binned_applies(const nthip_ctx* c, const void* d_filter, uint64_t n_bits, uint64_t n_values)
+{
+  return bloom_binned_ok(c, d_filter, n_bits, n_values);
+}
 int ntamd::host::stream_bloom_insert_expand(nthip_ctx* c, const uint64_t* d_h0, uint64_t n_inputs, uint32_t expand_m, uint64_t kmul, uint32_t* d_filter,
                                             uint64_t n_bits, bool* done)
 {

@@ -378,9 +378,7 @@ int ntamd::host::bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_
   if (c->tune.bloom_query != 1 && (left_values < (1ull << 24) || table_bytes < (32ull << 20) || left_values < table_bytes / 32)) return NTHIP_OK;
   const uint32_t steps = ((len + 15u) >> 4) - ((k - 1u) >> 4);
   // reads per round: what the free memory allows (~21 B per value + the tiles' tables)
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
-  free_b += c->bloom_tmp_bytes;
+  const size_t free_b = round_memory(c, c->bloom_tmp_bytes, (size_t)8 << 30);
   QueryScratch q;
   uint32_t gx = 1;
   const bool pieces = query_pieces_ok(c, g, shape, &gx);
@@ -515,9 +513,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
   }
   if (M > 1 && !pieces) return NTHIP_OK;
   // values per round: ~22 B of scratch per value
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
-  free_b += c->bloom_tmp_bytes;
+  const size_t free_b = round_memory(c, c->bloom_tmp_bytes, (size_t)8 << 30);
   uint64_t round = (uint64_t)(free_b / 10 * 8) / 24;
   if (round > (pieces ? BQ_PIECES_ROUND_MAX : BQ_ROUND_MAX)) round = pieces ? BQ_PIECES_ROUND_MAX : BQ_ROUND_MAX;
   if (c->tune.bloom_round) round = c->tune.bloom_round;
@@ -609,7 +605,7 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
   for (uint64_t v0 = 0; v0 < n_in; v0 += round) {
     const uint64_t n = std::min<uint64_t>(round, n_in - v0);
     size_t need = 0;
-    if (!carve(n, &need)) return fail(NTHIP_ERR_HIP, "the lists of a smaller round do not fit the buffer of a larger one");
+    if (!carve(n, &need)) return NTHIP_OK; // (a sizing slip: *done stays false, the caller's direct kernel answers everything)
     const uint64_t capL1 = g.one ? q.cap2 : q.cap1;
     HIPCHK(hipMemsetAsync(q.status, 0, q.head_bytes, c->stream));
     prof_begin(c, kind == BQ_BLOOM ? "bloom binned stream query (part, part, lookup, back, back)" : "count binned stream query (part, part, lookup, back, back)");
@@ -833,8 +829,7 @@ extern "C" int nthip_kmer_count_query(nthip_ctx* c, const nthip_reads* rd, uint1
       NTCHK(offsets_in_rounds(c, rd, flags, (size_t)8 * m + 8, one_round));
     } else {
       // fixed-length reads: rounds of reads whose stream fits a fifth of the free memory
-      size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
+      const size_t free_b = round_memory(c, reusable_bytes(c), (size_t)4 << 30);
       uint64_t reads_per_round = std::max<uint64_t>(1, (uint64_t)(free_b / 5) / ((uint64_t)fixed_wins * (8 * m + 5) + 32 + (host_in ? stride : 0)));
       if (c->tune.bloom_round) reads_per_round = std::max<uint64_t>(1, c->tune.bloom_round / (fixed_wins * m));
       for (uint64_t r0 = first; r0 < rd->n_reads; r0 += reads_per_round) {

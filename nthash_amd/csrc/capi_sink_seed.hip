@@ -44,7 +44,8 @@ int run_seed_bloom(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, u
     // The insert into a two-level filter asks the seed kernel for hashes()[0] of every seed only and lets the first partition level
     // make the other m2 - 1 (extend_hashes is a multiply and a shift of hashes()[0]): the stream written and read back is m2 times
     // shorter -- 17.6 GB each way instead of 53 for config 4's pair with 3 hashes per seed on 5 M reads.
-    if (!query && m2 >= 2 && m2 <= 4 && n_bits > (1ull << 27) && c->tune.bloom_pieces != 2 && c->tune.bloom_binned != 2) {
+    // (only when the binned insert will take the batch: one it declines would be hashed with one hash per seed, then in full)
+    if (!query && m2 >= 2 && m2 <= 4 && n_bits > (1ull << 27) && c->tune.bloom_pieces != 2 && bloom_binned_applies(c, d_filter, n_bits, cap * per)) {
       nthip_out o1;
       memset(&o1, 0, sizeof o1);
       o1.hashes = d_h;
@@ -112,9 +113,7 @@ int run_seed_bloom(nthip_ctx* c, const nthip_reads* rd, const nthip_seeds* sd, u
     }
     const uint64_t nwin = len - k + 1;
     // rounds of reads whose seed hashes (+ the lists of the binned insert: 16 B per value) fit a third of the free memory
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
-    free_b += reusable_bytes(c);
+    const size_t free_b = round_memory(c, reusable_bytes(c), (size_t)4 << 30);
     // (the query through the regions: 8 B of hash + 1 B of answer + ~24 B of lists and records per value -- a round whose hashes
     //  alone took a third of the memory left the lists no room, and the call fell back to a filter line per value)
     // (the insert: 8 B of hash + ~9 B of lists per value)

@@ -263,25 +263,64 @@ extern "C" int nthip_fill_bench(nthip_ctx* c, void* d_dst, size_t bytes, int rep
 // not change it (profiles/r02_notes.md 11).  For a long-lived buffer -- the hash stream of a pipeline -- it pays to
 // look: up to `candidates` allocations are made (as many at a time as the free memory holds), each is filled once or
 // twice with the write-only yardstick, the fastest is kept and the others are freed.  The buffer's content is garbage.
-// Where the physical pages of a big buffer lie decides which of two classes its streaming kernels run in (one big physical
-// block spreads over the memory channels worse than many small ones: profiles/r02_notes.md 26).  Mapping big buffers from 8 MiB
-// pieces made the headline line tight on one box (0.732-0.735 in 5 of 5 fresh processes, plain hipMalloc 0.704-0.732) -- and
-// was NOT made the default: buffers mapped, released and mapped again through HIP's virtual-memory API came back with
-// foreign bytes in them (tools/vmm_reuse_check.py: 125 M synthetic reads, on their second mapping ~3 000 of them held
-// non-bases; one cycle in four on one box, none on the next; plain hipMalloc never).  A wrong hash costs more than 3 %
-// of bandwidth: pieces only on request (NTHIP_TUNE_MALLOC_PIECES, NTHIP_TUNE_SCATTERED=1 for nthip_malloc_probed).
-constexpr size_t DEFAULT_PIECES_MIN = (size_t)1 << 30; // buffers from this size on are mapped from pieces
-#ifndef NTHIP_DEFAULT_PIECE_MIB
-#define NTHIP_DEFAULT_PIECE_MIB 0 // plain hipMalloc unless NTHIP_TUNE_MALLOC_PIECES says otherwise (see below: why not pieces)
-#endif
+// (Round 5 mapped big buffers from small physical pieces through HIP's virtual-memory API -- one big physical block spreads over
+// the memory channels worse than many small ones -- and found buffers mapped, released and mapped again coming back with foreign
+// bytes in them (profiles/r05_vmm_reuse_check.txt).  A wrong hash costs more than 3 % of bandwidth: round 6 removed that code
+// and its knobs; every buffer of this library is a plain hipMalloc.)
 // The hash stream of a round and the answers of a stream query were hipMalloc'ed and freed per call: 53 GB + 6.6 GB for config 4's
 // seed pair on 5 M reads.  Memory given back is not free at once -- the next allocation of that size waits for the driver: every
 // second or third call of nthip_seed_bloom_query took 3.5-6.5 s instead of 83 ms (tools/seed_query_loop.py).  The context keeps
 // them (grow-only; nthip_ctx_trim gives them back).
+size_t ntamd::host::scratch_limit_of(nthip_ctx* c)
+{
+  if (c->scratch_limit) return c->scratch_limit;
+  if (!c->device_mem) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+      (void)hipGetLastError();
+      total_b = (size_t)64 << 30;
+    }
+    c->device_mem = total_b;
+  }
+  return c->device_mem / 4;
+}
+size_t ntamd::host::round_memory(nthip_ctx* c, size_t reusable, size_t fallback_free)
+{
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    free_b = fallback_free;
+  }
+  free_b += reusable;
+  const size_t lim = scratch_limit_of(c);
+  return free_b < lim ? free_b : lim;
+}
+extern "C" int nthip_ctx_set_scratch_limit(nthip_ctx* c, size_t bytes)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  if (bytes != 0 && bytes < ((size_t)256 << 20)) return fail(NTHIP_ERR_ARG, "a scratch limit under 256 MiB leaves the consumers' rounds no room");
+  HIPCHK(hipSetDevice(c->device));
+  c->scratch_limit = bytes;
+  // what is held over the new limit goes back now (the next round makes what it needs)
+  if (reusable_bytes(c) > scratch_limit_of(c)) return nthip_ctx_trim(c);
+  return NTHIP_OK;
+}
+extern "C" int nthip_ctx_scratch_info(nthip_ctx* c, size_t* kept_bytes, size_t* limit_bytes)
+{
+  if (!c) return fail(NTHIP_ERR_ARG, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  if (kept_bytes) *kept_bytes = reusable_bytes(c);
+  if (limit_bytes) *limit_bytes = scratch_limit_of(c);
+  return NTHIP_OK;
+}
+
 int ntamd::host::kept_alloc(nthip_ctx* c, int slot, size_t bytes, void** p)
 {
   *p = nullptr;
   if (bytes == 0) bytes = 16;
+  if (bytes > scratch_limit_of(c)) // (the rounds of the consumers are sized under the limit: a caller that is not asks for too much)
+    return fail(NTHIP_ERR_HIP, "%zu MB of a round's hash stream / answers are over the context's scratch limit (%zu MB: nthip_ctx_set_scratch_limit)",
+                bytes >> 20, scratch_limit_of(c) >> 20);
   if (c->kept_bytes[slot] < bytes) {
     if (c->kept[slot]) HIPCHK(hipFree(c->kept[slot]));
     c->kept[slot] = nullptr;
@@ -300,8 +339,7 @@ int ntamd::host::kept_alloc(nthip_ctx* c, int slot, size_t bytes, void** p)
 
 int ntamd::host::default_alloc(nthip_ctx* c, size_t bytes, void** out)
 {
-  const uint32_t mib = c->tune.malloc_pieces ? c->tune.malloc_pieces : (uint32_t)NTHIP_DEFAULT_PIECE_MIB;
-  if (mib >= 2 && bytes >= DEFAULT_PIECES_MIN && !c->tune.no_scattered && scattered_alloc(c, bytes, (size_t)mib << 20, out)) return NTHIP_OK;
+  (void)c;
   HIPCHK(hipMalloc(out, bytes ? bytes : 16));
   return NTHIP_OK;
 }
@@ -322,7 +360,7 @@ extern "C" int nthip_malloc_probed(nthip_ctx* c, size_t bytes, int candidates, v
   float best_ms = 1e30f;
   std::vector<void*> held; // candidates are kept until the end so that the next one gets other pages
   auto give_back = [&](void* p) {
-    if (p && !scattered_free(c, p)) (void)hipFree(p);
+    if (p) (void)hipFree(p);
   };
   int n = 0;
   for (; n < candidates; ++n) {
@@ -337,16 +375,11 @@ extern "C" int nthip_malloc_probed(nthip_ctx* c, size_t bytes, int candidates, v
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
       if (free_b < bytes + ((size_t)2 << 30)) break;
     }
-    // the first candidate is a plain hipMalloc; the others are mapped from 32 / 8 MiB physical pieces: one big physical
-    // allocation is the usual way into the slow class (tools/bench_micro/vmm_alloc.hip: 32 GiB from hipMalloc 5.05-5.16
-    // TB/s in 15 of 15 allocations on one box, from pieces of 2-64 MiB 5.99-6.33 in 8 of 8)
     void* p = nullptr;
-    if (n == 0 || c->tune.no_scattered || !scattered_alloc(c, bytes, (size_t)(n & 1 ? 32 : 8) << 20, &p)) {
-      if (hipMalloc(&p, bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        if (n == 0) return fail(NTHIP_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
-        break;
-      }
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      if (n == 0) return fail(NTHIP_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
+      break;
     }
     held.push_back(p);
     float ms = 0;
@@ -366,94 +399,3 @@ extern "C" int nthip_malloc_probed(nthip_ctx* c, size_t bytes, int candidates, v
   return NTHIP_OK;
 }
 
-// A buffer whose virtual range is mapped from many small physical allocations (HIP's virtual-memory API).
-bool ntamd::host::scattered_alloc(nthip_ctx* c, size_t bytes, size_t piece, void** out)
-{
-  *out = nullptr;
-  hipMemAllocationProp prop = {};
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = c->device;
-  size_t gran = 0;
-  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) {
-    (void)hipGetLastError();
-    return false;
-  }
-  const size_t unit = gran > ((size_t)2 << 20) ? gran : ((size_t)2 << 20);
-  const size_t total = (bytes + unit - 1) / unit * unit;
-  piece = (piece + unit - 1) / unit * unit;
-  void* va = nullptr;
-  if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
-  }
-  nthip_ctx::ScatteredAlloc rec;
-  rec.bytes = total;
-  bool ok = true;
-  for (size_t off = 0; off < total && ok; off += piece) {
-    const size_t sz = total - off < piece ? total - off : piece;
-    hipMemGenericAllocationHandle_t h;
-    if (hipMemCreate(&h, sz, &prop, 0) != hipSuccess) { ok = false; break; }
-    if (hipMemMap((char*)va + off, sz, 0, h, 0) != hipSuccess) {
-      (void)hipMemRelease(h);
-      ok = false;
-      break;
-    }
-    rec.pieces.emplace_back(h, sz);
-  }
-  if (ok) {
-    // readable and writable from this device, and from every device that can reach it over xGMI: the tables of the
-    // multi-device consumers travel by hipMemcpyPeerAsync (capi_multi_sink.hip), which a mapping for one device would refuse
-    std::vector<hipMemAccessDesc> acc;
-    hipMemAccessDesc own = {};
-    own.location = prop.location;
-    own.flags = hipMemAccessFlagsProtReadWrite;
-    acc.push_back(own);
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
-    for (int d = 0; d < n_dev; ++d) {
-      int can = 0;
-      if (d != c->device && hipDeviceCanAccessPeer(&can, d, c->device) == hipSuccess && can) {
-        hipMemAccessDesc peer = own;
-        peer.location.id = d;
-        acc.push_back(peer);
-      }
-    }
-    (void)hipGetLastError();
-    ok = hipMemSetAccess(va, total, acc.data(), acc.size()) == hipSuccess;
-    if (!ok && acc.size() > 1) { // (peers refused: this device alone, as before)
-      (void)hipGetLastError();
-      ok = hipMemSetAccess(va, total, &own, 1) == hipSuccess;
-    }
-  }
-  if (!ok) {
-    (void)hipGetLastError();
-    size_t off = 0;
-    for (auto& pc : rec.pieces) {
-      (void)hipMemUnmap((char*)va + off, pc.second);
-      (void)hipMemRelease(pc.first);
-      off += pc.second;
-    }
-    (void)hipMemAddressFree(va, total);
-    return false;
-  }
-  c->scattered[va] = std::move(rec);
-  *out = va;
-  return true;
-}
-
-bool ntamd::host::scattered_free(nthip_ctx* c, void* p)
-{
-  auto it = c->scattered.find(p);
-  if (it == c->scattered.end()) return false;
-  (void)hipDeviceSynchronize();
-  size_t off = 0;
-  for (auto& pc : it->second.pieces) {
-    (void)hipMemUnmap((char*)p + off, pc.second);
-    (void)hipMemRelease(pc.first);
-    off += pc.second;
-  }
-  (void)hipMemAddressFree(p, it->second.bytes);
-  c->scattered.erase(it);
-  return true;
-}

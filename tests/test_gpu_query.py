@@ -432,3 +432,67 @@ def test_multi_device_query_of_all_gathered_tables(ctx, oracle, devices):
     for g, p_ in owned:
         cs[g].free(p_)
     mm.close()
+
+
+@pytest.mark.gpu
+def test_scratch_limit_bounds_the_kept_buffers_same_filter():
+    """nthip_ctx_set_scratch_limit: config 4's seed pair x 3 hashes on 1.5 M x 250 bp (2 G values: 40 GB of
+    stream and lists when a round may take what is free) under a 1 GiB limit -- the rounds shrink to fit, the context never
+    holds more than the limit, and the filter is the unlimited context's, word for word (as is the filter of rounds cut by
+    NTHIP_TUNE_BLOOM_ROUND: tools/seed_insert_rounds_check.py's check); the same for the k-mer insert and the queries' hits"""
+    import os
+    import nthash_amd
+    seeds = ["1010101010101010101010101010101", "1101101101101101011011011011011"]
+    n, L, k, n_bits = 1_500_000, 250, 31, 1 << 33
+    os.environ["NTHIP_TUNE_BLOOM_ROUND"] = str(300_000_000)
+    try:
+        c_rounds = nthash_amd.Context(0)
+    finally:
+        os.environ.pop("NTHIP_TUNE_BLOOM_ROUND", None)
+    c_free, c_lim = nthash_amd.Context(0), nthash_amd.Context(0)
+    lim = 1 << 30
+    c_lim.set_scratch_limit(lim)
+    assert c_lim.scratch_info()[1] == lim and c_free.scratch_info()[1] > (16 << 30)
+    d_in = c_free.malloc(n * L)
+    c_free.synth_reads_ptr(d_in, 0, n, L, 42)
+    sums, hits = [], []
+    for c in (c_free, c_lim, c_rounds):
+        sd = nthash_amd.Seeds(c, seeds, k)
+        d_f = c.malloc(n_bits // 8)
+        c.memset(d_f, 0, n_bits // 8)
+        tot = c.seed_bloom_insert_ptr(d_in, n, L, 0, sd, 3, d_f, n_bits)
+        assert tot == n * (L - k + 1)
+        kept, _ = c.scratch_info()
+        if c is c_lim:
+            assert kept <= lim, (kept, lim)
+        sums.append(c.checksum_ptr(d_f, n_bits // 64))
+        d_h = c.malloc(n * 8)
+        tq, found = c.seed_bloom_query_ptr(d_in, n, L, 0, sd, 3, d_f, n_bits, hits=d_h)
+        assert tq == found == tot
+        if c is c_lim:
+            assert c.scratch_info()[0] <= lim
+        hs = np.zeros(n, np.uint64)
+        c.d2h(hs, d_h)
+        hits.append(hs)
+        # the k-mer consumers under the same limit
+        c.memset(d_f, 0, n_bits // 8)
+        tk = c.bloom_insert_ptr(d_in, n, L, 0, k, 3, d_f, n_bits)
+        assert tk == n * (L - k + 1)
+        sums.append(c.checksum_ptr(d_f, n_bits // 64))
+        if c is c_lim:
+            assert c.scratch_info()[0] <= lim
+        c.free(d_f); c.free(d_h); sd.close()
+    assert sums[0:2] == sums[2:4] == sums[4:6], sums
+    assert (hits[0] == hits[1]).all() and (hits[0] == hits[2]).all() and (hits[0] == L - k + 1).all()
+    # a new limit under what is held releases it at once; 0 restores the default
+    kept_free = c_free.scratch_info()[0]
+    assert kept_free > lim
+    c_free.set_scratch_limit(lim)
+    assert c_free.scratch_info()[0] <= lim
+    c_free.set_scratch_limit(0)
+    assert c_free.scratch_info()[1] > (16 << 30)
+    with pytest.raises(nthash_amd.NtHipError):
+        c_free.set_scratch_limit(1 << 20)
+    c_free.free(d_in)
+    for c in (c_free, c_lim, c_rounds):
+        c.close()
