@@ -115,7 +115,7 @@ int nthip_ctx_trim(nthip_ctx* ctx);
 /* The consumers (Bloom / counting-sketch / spaced-seed insert and query) work in rounds whose device scratch -- the hash
  * stream of a round, its lists, its answers -- the context KEEPS between calls (allocating tens of GB anew costs seconds).
  * nthip_ctx_set_scratch_limit bounds what a round may plan with and the context may keep: rounds shrink to fit, what is
- * held over a new limit is released at once.  bytes = 0 restores the default, a quarter of the device's memory; limits
+ * held over a new limit is released at once.  bytes = 0 restores the default, half of the device's memory; limits
  * under 256 MiB are refused.  nthip_ctx_scratch_info reports what the context holds now and the limit in force. */
 int nthip_ctx_set_scratch_limit(nthip_ctx* ctx, size_t bytes);
 int nthip_ctx_scratch_info(nthip_ctx* ctx, size_t* kept_bytes, size_t* limit_bytes);

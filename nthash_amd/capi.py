@@ -409,7 +409,7 @@ class Context:
         _chk(self.L.nthip_ctx_trim(self.h))
 
     def set_scratch_limit(self, nbytes):
-        """bound what the consumers' rounds plan with and the context keeps between calls (0: the default, a quarter of the device)"""
+        """bound what the consumers' rounds plan with and the context keeps between calls (0: the default, half of the device)"""
         _chk(self.L.nthip_ctx_set_scratch_limit(self.h, nbytes))
 
     def scratch_info(self):

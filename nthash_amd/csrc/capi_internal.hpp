@@ -176,7 +176,7 @@ struct nthip_ctx {
   // all-care byte tables for the first window of a run, per k (device memory)
   std::map<uint32_t, uint4*> init_tabs;
   // what the consumers' rounds may hold in device scratch -- the kept buffers above, the lists of the binned consumers, the
-  // temporaries of a round (nthip_ctx_set_scratch_limit; 0: a quarter of the device's memory); rounds are sized to fit
+  // temporaries of a round (nthip_ctx_set_scratch_limit; 0: half of the device's memory); rounds are sized to fit
   size_t scratch_limit = 0, device_mem = 0;
   // run length of the general dense kernel per (len, stride, k, m), measured on the first big batch of that shape
   // (the cost model does not see what a longer run costs in waves per CU or LDS conflicts: +-10 % either way)
@@ -266,7 +266,7 @@ int ensure_args(nthip_ctx* c, size_t bytes);
 void fastx_buffers_release(nthip_ctx* c); // the file driver's pinned / device buffers
 // capi_util.hip: what nthip_malloc does -- hipMalloc
 int default_alloc(nthip_ctx* c, size_t bytes, void** out);
-// the context's scratch limit in bytes (its default: a quarter of the device's memory)
+// the context's scratch limit in bytes (its default: half of the device's memory)
 size_t scratch_limit_of(nthip_ctx* c);
 // the memory a consumer's round may plan with: what is free now + `reusable` (what the context already holds and the round
 // reuses), capped by the scratch limit

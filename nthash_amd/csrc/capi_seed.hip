@@ -975,9 +975,11 @@ bool ps_geometry(nthip_ctx* c, const nthip_seeds* sd, uint32_t len, uint32_t m2,
     PsGeo g;
     g.W = W; g.nb_log = nb_log; g.lpr_log = lpr_log; g.segs_b = segs_b; g.n_arrays = n_arrays;
     g.wave_bytes = (size_t)n_arrays * rpw * epr * 16 + ((codes_dw * 4 + 15) & ~15u);
-    if (jit) {
+    if (jit) { // (the stage takes the place of the arrays)
       const uint32_t nv = rpw * nwin * per;
-      g.wave_bytes += (((size_t)nv + 16 + ((nv + 16) >> 3) + 2 + 1) / 2) * 16;
+      const size_t stage = (((size_t)nv + 16 + ((nv + 16) >> 3) + 2 + 1) / 2) * 16, arrays = (size_t)n_arrays * rpw * epr * 16;
+      if (stage > arrays) g.wave_bytes += stage - arrays;
+      if ((uint64_t)W * per > 64) continue; // (a segment's values wait in registers)
     }
     g.fixed = (size_t)4 * epr * 16;
     if (g.fixed + g.wave_bytes > cap) continue;

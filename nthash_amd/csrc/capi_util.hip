@@ -282,7 +282,7 @@ size_t ntamd::host::scratch_limit_of(nthip_ctx* c)
     }
     c->device_mem = total_b;
   }
-  return c->device_mem / 4;
+  return c->device_mem / 2;
 }
 size_t ntamd::host::round_memory(nthip_ctx* c, size_t reusable, size_t fallback_free)
 {
