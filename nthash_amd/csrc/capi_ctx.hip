@@ -241,51 +241,27 @@ void ntamd::host::load_tuning(nthip_tune& t)
     return x >= (long)lo && x <= (long)hi ? (uint32_t)x : 0u;
   };
   auto is_one = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
+  // (round 6: 29 knobs of concluded experiments -- wave counts, the phased / prefetching experiments of the headline kernel,
+  //  tile maps, per-kernel on/off switches nobody measures any more -- are no longer read from the environment: their
+  //  fields keep the defaults the measurements settled on.  DESIGN.md "tuning knobs" lists what is left and who sets it.)
   auto is_set = [](const char* name) { return getenv(name) != nullptr; };
   t.run_len = num("NTHIP_TUNE_RUN_LEN", 1, 64);
   t.run_max = num("NTHIP_TUNE_RUN_MAX", 1, 31);
   t.waves = num("NTHIP_TUNE_WAVES", 1, 16);
-  t.na_waves = num("NTHIP_TUNE_NA_WAVES", 1, 16);
-  t.seed_rpt = num("NTHIP_TUNE_SEED_RPT", 1, 256);
-  t.seed_waves = num("NTHIP_TUNE_SEED_WAVES", 4, 16);
-  t.read_threads = num("NTHIP_TUNE_READ_THREADS", 1, 64);
-  if (const char* v = getenv("NTHIP_TUNE_TILE_MAP")) {
-    t.has_tile_map = true;
-    t.tile_map = (uint32_t)atoi(v);
-  }
   t.no_special = is_one("NTHIP_TUNE_NO_SPECIAL");
-  t.no_dword_tail = is_one("NTHIP_TUNE_NO_DWORD_TAIL");
-  t.no_m4 = is_set("NTHIP_TUNE_NO_M4");
   t.no_autotune = is_set("NTHIP_TUNE_NO_AUTOTUNE");
   t.no_dirty_memory = is_set("NTHIP_TUNE_NO_DIRTY_MEMORY");
   t.no_na_special = is_set("NTHIP_TUNE_NO_NA_SPECIAL");
   t.no_seed_wave = is_set("NTHIP_TUNE_NO_SEED_WAVE");
-  t.no_seed_wtile = is_one("NTHIP_TUNE_NO_SEED_WTILE");
   t.no_seed_rot = is_one("NTHIP_TUNE_NO_SEED_ROT");
   t.seed_pass = num("NTHIP_TUNE_SEED_PASS", 1, 255);
   t.malloc_probe = num("NTHIP_TUNE_MALLOC_PROBE", 1, 8);
   t.no_seed_long = is_one("NTHIP_TUNE_NO_SEED_LONG");
-  t.no_seed_w6 = is_one("NTHIP_TUNE_NO_SEED_W6");
   t.no_kmer_reads = is_one("NTHIP_TUNE_NO_KMER_READS");
-  t.no_seed_reads = is_one("NTHIP_TUNE_NO_SEED_READS");
-  t.no_seed_align = is_one("NTHIP_TUNE_NO_SEED_ALIGN");
-  t.no_any_k_runs = is_one("NTHIP_TUNE_NO_ANY_K_RUNS");
-  t.no_fh = is_one("NTHIP_TUNE_NO_FH");
-  t.mz_table = is_one("NTHIP_TUNE_MZ_TABLE");
   t.bloom_fused = num("NTHIP_TUNE_BLOOM_FUSED", 1, 2);
   t.mz_fused = num("NTHIP_TUNE_MZ_FUSED", 1, 2);
-  t.mz_c = num("NTHIP_TUNE_MZ_C", 2, 16);
   t.mz_grid = num("NTHIP_TUNE_MZ_GRID", 1, 1 << 20);
   t.mz_timeout_us = num("NTHIP_TUNE_MZ_TIMEOUT_US", 1, 100000000);
-  t.mz_waves = num("NTHIP_TUNE_MZ_WAVES", 1, 16);
-  t.reads_run_len = num("NTHIP_TUNE_READS_RUN_LEN", 2, 16);
-  t.reads_per_tile = num("NTHIP_TUNE_READS_PER_TILE", 1, 64);
-  t.reads_waves = num("NTHIP_TUNE_READS_WAVES", 1, 16);
-  t.no_phases = is_one("NTHIP_TUNE_NO_PHASES");
-  t.no_pacing = is_one("NTHIP_TUNE_NO_PACING");
-  t.ph_tiles = num("NTHIP_TUNE_PH_TILES", 1, 64);
-  t.ph_period = num("NTHIP_TUNE_PH_PERIOD", 1, 10000000);
-  t.ph_read = num("NTHIP_TUNE_PH_READ", 1, 10000000);
   t.fw = num("NTHIP_TUNE_FW", 1, 2);
   t.seed_any = num("NTHIP_TUNE_SEED_ANY", 1, 2);
   t.seed_roll = num("NTHIP_TUNE_SEED_ROLL", 1, 2);
@@ -296,18 +272,13 @@ void ntamd::host::load_tuning(nthip_tune& t)
   t.seed_px_array = num("NTHIP_TUNE_SEED_PX_ARRAY", 1, 300);
   t.seed_px_reads = num("NTHIP_TUNE_SEED_PX_READS", 1, 64);
   t.seed_px_waves = num("NTHIP_TUNE_SEED_PX_WAVES", 1, 8);
-  t.seed_roll_waves = num("NTHIP_TUNE_SEED_ROLL_WAVES", 2, 8);
   t.bloom_binned = num("NTHIP_TUNE_BLOOM_BINNED", 1, 2);
   t.no_tiles_flag = is_one("NTHIP_TUNE_NO_TILES_FLAG");
   t.bloom_slots = num("NTHIP_TUNE_BLOOM_SLOTS", 1, 2);
   t.bloom_slot_tight = num("NTHIP_TUNE_BLOOM_SLOT_TIGHT", 1, 2);
   t.bloom_round = num("NTHIP_TUNE_BLOOM_ROUND", 1024, 0x7FFFFFFF);
   t.bloom_query = num("NTHIP_TUNE_BLOOM_QUERY", 1, 2);
-  t.bloom_query_passes = num("NTHIP_TUNE_BLOOM_QUERY_PASSES", 1, 2);
   t.bloom_pieces = num("NTHIP_TUNE_BLOOM_PIECES", 1, 2);
-  t.pf_gbps = num("NTHIP_TUNE_PF_GBPS", 1, 100000);
-  t.pf_lead_kb = num("NTHIP_TUNE_PF_LEAD_KB", 1, 1 << 22);
-  t.pf_chunk_kb = num("NTHIP_TUNE_PF_CHUNK_KB", 1, 1 << 20);
   const uint32_t tk = num("NTHIP_TUNE_TABLE_K_MAX", 16, 64);
   ntamd::host::g_kmer_table_k_max = tk ? tk : (uint32_t)KMER_TABLE_K_MAX_N;
 }

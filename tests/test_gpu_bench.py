@@ -49,6 +49,23 @@ def test_bench_two_ranks_self_launch():
     assert res["roofline"]["frac"] > 0 and res["roofline"]["kernel"] == "kmer_runs_kernel"
 
 
+def test_bench_two_ranks_at_a_real_shards_size():
+    """--gpus 2 with 60 M reads per rank: the two ranks' buffers -- 2 x (9 GB of reads + 57.6 GB of
+    hashes) -- fill most of one GPU's HBM the way a 125 M-read shard fills a GPU of its own, so that the first real
+    multi-GPU run cannot die on a size-dependent path (64-bit offsets, one launch per step, the verify pass, the consumer
+    line); the ranks share this box's one GPU over gloo"""
+    n = 60_000_000
+    res = run_bench("--gpus", "2", "--reads", str(n), "--steps", "2", "--warmup", "1", "--dist-consumer-reads", "4000000",
+                    env={"NTHASH_BENCH_SHARE_GPU": "1"}, timeout=1500)
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak"
+    assert res["verified_vs_oracle"] is True   # (spot compare with the oracle on every rank; no committed checksum of 60 M-read shards)
+    assert res["config"]["reads_per_gpu"] == n and res["config"]["launches_per_step"] == 1
+    assert len(res["per_rank_kmers_per_s"]) == 2 and all(v > 1e10 for v in res["per_rank_kmers_per_s"])
+    kmers = 2 * 2 * n * 120
+    assert abs(res["value"] - kmers / (res["ms_per_step"] * 2 * 1e-3)) / res["value"] < 1e-6
+    assert res["dist_consumer"]["ok"] is True
+
+
 def test_bench_refuses_more_gpus_than_visible():
     import torch
     have = torch.cuda.device_count()

@@ -6,7 +6,7 @@ Small text / csv / json files only; traces and databases stay in the scratch dir
 """
 import glob, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 names = {  # scratch name -> tracked name
     "bench_default.json": f"{tag}_bench_default.json",
@@ -16,7 +16,11 @@ names = {  # scratch name -> tracked name
     "bloom_one.txt": f"{tag}_bloom_one.txt",
     "query_bench.txt": f"{tag}_query_bench.txt",
     "default_line_spread.txt": f"{tag}_default_line_spread_evidence_box.txt",
-    "vmm_reuse_check.txt": f"{tag}_vmm_reuse_check.txt",
+    "pmc_seed_rnd6.txt": f"{tag}_pmc_seed_rnd6_summary.txt",
+    "pmc_seed_k128.txt": f"{tag}_pmc_seed_k128_summary.txt",
+    "pmc_seed_static.txt": f"{tag}_pmc_seed_static_summary.txt",
+    "pmc_ref/summary.txt": f"{tag}_pmc_ref_summary.txt",
+    "pmc_k200/summary.txt": f"{tag}_pmc_k200_summary.txt",
     "seed_sweep.txt": f"{tag}_seed_sweep.txt",
     "seed_sweep_long.txt": f"{tag}_seed_sweep_long.txt",
     "seed_roll_sweep.txt": f"{tag}_seed_roll_sweep.txt",
