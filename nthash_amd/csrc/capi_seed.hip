@@ -977,11 +977,12 @@ bool ps_geometry(nthip_ctx* c, const nthip_seeds* sd, uint32_t len, uint32_t m2,
     g.wave_bytes = (size_t)n_arrays * rpw * epr * 16 + ((codes_dw * 4 + 15) & ~15u);
     if (jit) { // (the stage takes the place of the arrays)
       const uint32_t nv = rpw * nwin * per;
-      const size_t stage = (((size_t)nv + 16 + ((nv + 16) >> 3) + 2 + 1) / 2) * 16, arrays = (size_t)n_arrays * rpw * epr * 16;
+      const uint32_t seg_vals = W * per; // (seed_psj_kernel.inc: STAGE_U64 -- a slot of padding per segment's worth of values)
+      const size_t stage = (((size_t)nv + ((seg_vals & 1u) ? 0 : nv / seg_vals + 1) + 2 + 1) / 2) * 16, arrays = (size_t)n_arrays * rpw * epr * 16;
       if (stage > arrays) g.wave_bytes += stage - arrays;
       if ((uint64_t)W * per > 64) continue; // (a segment's values wait in registers)
     }
-    g.fixed = (size_t)4 * epr * 16;
+    g.fixed = (size_t)4 * epr * 16 + (64 + (k + W) / W) * 16; // (+ room behind the last wave for the reads of its idle lanes)
     if (g.fixed + g.wave_bytes > cap) continue;
     // wave instructions per window: the build's two passes per round, W steps of the seeds' reads and rotations
     const uint32_t rounds = (rpw + (64u >> nb_log) - 1) / (64u >> nb_log);

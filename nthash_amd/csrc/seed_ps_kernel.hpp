@@ -223,8 +223,10 @@ __global__ __launch_bounds__(PS_MAX_WAVES * 64) void seed_ps_kernel(const SeedPs
     {
       const bool lane_in = rl < T.n_r;
       const uint32_t steps = lane_in ? n_steps_w : 0u;
-      // (a lane without a window reads where segment 0 of read 0 does: its values are dropped, its addresses are real)
-      const char* const ent = arrays + (steps ? (rl * epr + sw) * 16u : 0u);
+      // (a lane without a window reads what its place implies all the same -- its values are dropped; sent to one address
+      //  instead, the idle lanes shared a bank with a busy lane of their 16-lane group: 16 % of the LDS cycles.  Their reads
+      //  may end up to 64 + k / W entries behind the wave's arrays: the launch leaves that room behind the last wave)
+      const char* const ent = arrays + (rl * epr + sw) * 16u;
       uint64_t* out = a.hashes + ((T.read0 + rl) * nwin + win0) * per;
       uint32_t p31 = p31_0, p33 = p33_0;
       // (the constant address space: scalar loads whatever the kernel has stored before)

@@ -28,8 +28,8 @@ SWEEP_SHAPES="250,128,1,1;300,160,1,1;250,96,1,1;250,31,5,1;250,31,8,1;150,48,3,
 timeout 600 python tools/seed_roll_sweep.py > "$OUT/seed_roll_sweep.txt" 2>&1
 # round 6: the specialised seed kernel (hiprtc) under the counters -- LDS bank conflicts of the segment layout -- and the
 # reference's benchmark shape / a long k of the k-mer path (what limits them)
-timeout 600 bash tools/pmc_any.sh "$OUT/pmc_seed_rnd6" seed_ps python tools/px_probe.py 250 31 rnd6 1 4000000 > "$OUT/pmc_seed_rnd6.txt" 2>&1
-timeout 600 bash tools/pmc_any.sh "$OUT/pmc_seed_k128" seed_ps python tools/px_probe.py 250 128 rnd1 1 4000000 > "$OUT/pmc_seed_k128.txt" 2>&1
+timeout 600 bash tools/pmc_any.sh "$OUT/pmc_seed_rnd6" psj python tools/px_probe.py 250 31 rnd6 1 4000000 > "$OUT/pmc_seed_rnd6.txt" 2>&1
+timeout 600 bash tools/pmc_any.sh "$OUT/pmc_seed_k128" psj python tools/px_probe.py 250 128 rnd1 1 4000000 > "$OUT/pmc_seed_k128.txt" 2>&1
 NTHIP_SEED_JIT=0 timeout 600 bash tools/pmc_any.sh "$OUT/pmc_seed_static" seed_ps python tools/px_probe.py 250 128 3 1 4000000 > "$OUT/pmc_seed_static.txt" 2>&1
 PMC_SQ_ONLY=1 timeout 900 bash tools/run_pmc.sh "$OUT/pmc_ref" shape:100,64,3 20000000 > "$OUT/pmc_ref.log" 2>&1
 PMC_SQ_ONLY=1 timeout 900 bash tools/run_pmc.sh "$OUT/pmc_k200" shape:250,200,1 10000000 > "$OUT/pmc_k200.log" 2>&1
