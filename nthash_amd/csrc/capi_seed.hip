@@ -1050,7 +1050,14 @@ int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, 
     // shape measured (its reads cost an address and a scalar load each): it hashes only when asked for.
     if (!jit_wanted) return NTHIP_OK;
     const double pos_per_win = (double)f.len / f.nwin, extra = per - f.n_seeds;
-    double psj = 0.9 * pos_per_win + 1.9 * f.n_seeds + 0.08 * n_terms + 1.5 * extra;
+    // (the specialised kernel: a tile's fixed work, a seed's rotations, 0.11 per read of 16 bytes, the build per position, 1.5 per
+    //  further hash -- over the fraction of its window lanes that have a window)
+    double fill = 1.0;
+    {
+      PsGeo gj;
+      if (ps_geometry(c, sd, f.len, f.m2, true, &gj)) fill = (double)f.nwin / ((double)(1u << gj.lpr_log) * gj.W);
+    }
+    double psj = (1.9 + 1.4 * f.n_seeds + 0.11 * n_terms + 0.25 * pos_per_win + 1.5 * extra) / fill;
     const double hbm = (8.0 * per + pos_per_win) / 5.5; // (bytes per window at 5.5 TB/s)
     if (psj < hbm) psj = hbm;
     double direct;
