@@ -187,7 +187,8 @@ int nthip_seeds_create(nthip_ctx* ctx, const char* const* seeds, uint32_t n_seed
 int nthip_seeds_destroy(nthip_seeds* seeds);
 /*
  * The kernel specialisation cache: for large dense batches nthip_seed_hash compiles a kernel for the
- * very seed set and read length at run time (hiprtc; a second or two once per seed set and shape, kept in
+ * very seed set and read length at run time (hiprtc, on a thread of its own: until the code object is there the precompiled
+ * kernels hash; a second or two once per seed set and shape, kept in
  * $NTHIP_JIT_CACHE / $XDG_CACHE_HOME/nthash_amd / ~/.cache/nthash_amd afterwards; NTHIP_SEED_JIT=0: never, =1: for every
  * batch the kernel takes).  Without hiprtc the precompiled kernels hash the batch: same stream.
  * nthip_seed_jit_source: the text that is compiled for `seeds` on reads of `len` bases (*out is malloc'ed: free() it;

@@ -128,7 +128,7 @@ struct nthip_tune {
   uint32_t seed_px = 0;     // NTHIP_TUNE_SEED_PX=1: every dense seed batch seed_px_kernel takes goes there, 2: none (A/B, tests)
   uint32_t seed_px_array = 0; // NTHIP_TUNE_SEED_PX_ARRAY=1 + f: px_make_plan's force_array = f (tests: every array form against the oracle)
   uint32_t seed_px_reads = 0; // NTHIP_TUNE_SEED_PX_READS=R: reads per tile of seed_px_kernel (A/B; 0: planned)
-  uint32_t seed_jit = 0;    // NTHIP_SEED_JIT=0: no kernel is compiled at run time, 1: for every batch the specialised kernel takes (unset: large batches)
+  uint32_t seed_jit = 0;    // NTHIP_SEED_JIT=0: no kernel is compiled at run time (2 here), 1: for every batch the specialised kernel takes, compiled on the spot; unset: large batches, compiled on a thread of its own while the precompiled kernels go on hashing
   uint32_t seed_ps = 0;     // NTHIP_TUNE_SEED_PS=1: every dense seed batch seed_ps_kernel takes goes there, 2: none (A/B, tests)
   uint32_t seed_ps_lanes = 0; // NTHIP_TUNE_SEED_PS_LANES=16 / 32 / 64: window lanes per read of seed_ps_kernel (A/B; 0: planned)
   uint32_t seed_px_waves = 0; // NTHIP_TUNE_SEED_PX_WAVES=1..8: waves per block of seed_px_kernel (A/B; 0: planned)
@@ -254,7 +254,7 @@ struct SeedJitShape { // what seed_psj_kernel.inc is compiled for
   std::vector<uint32_t> term_arr, term_e, seed_first;
 };
 std::string seed_psj_source(const SeedJitShape& g);
-void* seed_psj_get(nthip_ctx* c, const nthip_seeds* sd, const SeedJitShape& g, std::string* why); // hipFunction_t or nullptr
+void* seed_psj_get(nthip_ctx* c, const nthip_seeds* sd, const SeedJitShape& g, bool wait, std::string* why); // hipFunction_t or nullptr
 void seed_jit_release(const nthip_seeds* sd);
 bool seed_jit_shape(nthip_ctx* c, const nthip_seeds* sd, uint32_t len, uint32_t m2, SeedJitShape* out); // capi_seed.hip
 

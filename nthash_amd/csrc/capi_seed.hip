@@ -1040,9 +1040,10 @@ int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, 
   const uint32_t per = f.n_seeds * f.m2;
   const uint32_t W = best.W, NB = 1u << best.nb_log, rpw = 64u >> best.lpr_log, epr = W << best.nb_log, waves = best.waves;
   const uint32_t n_terms = (uint32_t)best.reads.size();
-  // compiled for the shape when the batch pays for it (a compile is a second or two once per seed set and read shape, then
-  // the disk cache): straight-line code, every read an immediate offset
-  const bool jit_wanted = c->tune.seed_jit != 2 && (c->tune.seed_jit == 1 || f.n_runs * (uint64_t)f.nwin >= (1ull << 24)) &&
+  // compiled for the shape (a second or two once per seed set and read shape, then the disk cache -- on a thread of its own
+  // unless NTHIP_SEED_JIT=1: until the code object is there the other forms hash): straight-line code, every read an
+  // immediate offset
+  const bool jit_wanted = c->tune.seed_jit != 2 && (c->tune.seed_jit == 1 || f.n_runs * (uint64_t)f.nwin >= (1ull << 22)) &&
                           (uint64_t)W * n_terms <= 2048;
   if (c->tune.seed_ps != 1) {
     // Against the other dense forms, picoseconds per window, fitted on tools/seed_sweep.py and seed_roll_sweep.py
@@ -1082,12 +1083,13 @@ int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, 
     if (seed_jit_shape(c, sd, f.len, f.m2, &j)) {
       HIPCHK(hipSetDevice(c->device));
       if (j.waves > 12 && j.waves < 16) j.waves = 12; // (13-15 waves are four on one SIMD: 128 registers, as for 16)
-      hipFunction_t fn = (hipFunction_t)seed_psj_get(c, sd, j, &why);
+      const bool wait = c->tune.seed_jit == 1;
+      hipFunction_t fn = (hipFunction_t)seed_psj_get(c, sd, j, wait, &why);
       // a kernel that spills at this block size gets the registers of a smaller one
       while (!fn && why.find("spills") != std::string::npos && j.waves > 4) {
         j.waves = j.waves > 12 ? 12 : j.waves > 8 ? 8 : 4;
         why.clear();
-        fn = (hipFunction_t)seed_psj_get(c, sd, j, &why);
+        fn = (hipFunction_t)seed_psj_get(c, sd, j, wait, &why);
       }
       if (fn) {
         const uint32_t jw = j.waves, jrpw = 64u >> j.lpr_log; // (the specialised kernel's own tiles: its geometry counts the stage)
@@ -1118,6 +1120,8 @@ int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, 
       }
     }
   }
+  // (no specialised kernel, or not yet -- it is being compiled on a thread of its own: the other dense forms hash this batch)
+  if (c->tune.seed_ps != 1) return NTHIP_OK;
   // the reads, per step of a segment: term t at step i is entry ((i + e) % W) * NB + (i + e) / W of its array
   const uint32_t arr_bytes = rpw * epr * 16u;
   const int force = c->tune.seed_px_array ? (int)c->tune.seed_px_array - 1 : -1;

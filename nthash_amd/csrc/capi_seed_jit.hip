@@ -13,6 +13,7 @@
 
 #include <fstream>
 #include <mutex>
+#include <thread>
 #include <sstream>
 
 using namespace ntamd;
@@ -167,49 +168,106 @@ std::string ntamd::host::seed_psj_source(const SeedJitShape& g)
 }
 
 // The specialised kernel of a shape: from the process's registry, the disk, or the compiler.  nullptr (and *why): not
-// available.  A code object is loaded ONCE per process and device and stays loaded: seed sets of the same strings share it
-// (loading and unloading the same image again and again -- a seed set per call, several contexts -- ended in memory faults
+// available (yet).  A code object is loaded ONCE per process and device and stays loaded: seed sets of the same strings share
+// it (loading and unloading the same image again and again -- a seed set per call, several contexts -- ended in memory faults
 // of the launched kernels on ROCm 7.2; the registry is bounded by the distinct seed sets and read shapes a process meets).
+// wait == false: a compile that has to be made runs on a thread of its own and THIS call returns nullptr -- the caller's
+// precompiled kernels hash the batch; a later call finds the code object and loads it.  A second or two of compiler are
+// then never on anybody's clock.  wait == true (NTHIP_SEED_JIT=1): compile here and now.
 namespace {
 struct Loaded {
+  enum State { COMPILING, COMPILED, READY, FAILED } state = COMPILING;
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   std::vector<char> image; // (the runtime may load from the image lazily: it lives as long as the module)
+  std::string why;
 };
-std::map<std::string, Loaded> g_loaded;
-std::set<std::string> g_failed;
-std::mutex g_loaded_mu;
-} // namespace
-void* ntamd::host::seed_psj_get(nthip_ctx* c, const nthip_seeds* sd, const SeedJitShape& g, std::string* why)
+// (never destroyed: a compile thread may outlive main())
+std::map<std::string, Loaded>& registry() { static auto* r = new std::map<std::string, Loaded>(); return *r; }
+std::mutex& registry_mu() { static auto* m = new std::mutex(); return *m; }
+
+// COMPILED -> READY / FAILED, on the caller's thread (its device is current)
+void load_module(Loaded& L)
 {
-  (void)sd;
-  const std::string src = seed_psj_source(g);
-  char key[48];
-  snprintf(key, sizeof key, "%016llx_%zu_%d", (unsigned long long)fnv1a(src), src.size(), c->device);
-  std::lock_guard<std::mutex> lk(g_loaded_mu);
-  auto it = g_loaded.find(key);
-  if (it != g_loaded.end()) return (void*)it->second.fn;
-  if (g_failed.count(key)) {
-    *why = "the specialised kernel spills registers / did not compile (earlier in this process)";
-    return nullptr;
-  }
-  Loaded& L = g_loaded[key];
-  if (!compile_source(src, &L.image, why) || hipModuleLoadData(&L.mod, L.image.data()) != hipSuccess ||
-      hipModuleGetFunction(&L.fn, L.mod, "psj") != hipSuccess) {
-    if (why->empty()) *why = "hipModuleLoadData / hipModuleGetFunction failed";
+  if (hipModuleLoadData(&L.mod, L.image.data()) != hipSuccess || hipModuleGetFunction(&L.fn, L.mod, "psj") != hipSuccess) {
     (void)hipGetLastError();
-    g_loaded.erase(key);
-    g_failed.insert(key);
-    return nullptr;
+    L.why = "hipModuleLoadData / hipModuleGetFunction failed";
+    L.state = Loaded::FAILED;
+    return;
   }
   int scratch = 0; // (a kernel that spills is slower than the precompiled one it replaces)
   if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, L.fn) == hipSuccess && scratch > 0) {
-    *why = "the specialised kernel spills registers";
+    L.why = "the specialised kernel spills registers";
     L.fn = nullptr; // (stays loaded, never launched)
-    g_failed.insert(key);
-    return nullptr;
+    L.state = Loaded::FAILED;
+    return;
   }
-  return (void*)L.fn;
+  L.state = Loaded::READY;
+}
+} // namespace
+void* ntamd::host::seed_psj_get(nthip_ctx* c, const nthip_seeds* sd, const SeedJitShape& g, bool wait, std::string* why)
+{
+  (void)sd;
+  const std::string src = seed_psj_source(g);
+  char keybuf[48];
+  snprintf(keybuf, sizeof keybuf, "%016llx_%zu_%d", (unsigned long long)fnv1a(src), src.size(), c->device);
+  const std::string key = keybuf;
+  std::unique_lock<std::mutex> lk(registry_mu());
+  auto& reg = registry();
+  auto it = reg.find(key);
+  if (it == reg.end()) {
+    Loaded& L = reg[key]; // (COMPILING)
+    if (wait) {
+      lk.unlock();
+      std::vector<char> image;
+      std::string w;
+      const bool ok = compile_source(src, &image, &w);
+      lk.lock();
+      Loaded& M = reg[key];
+      if (ok) {
+        M.image.swap(image);
+        M.state = Loaded::COMPILED;
+      } else {
+        M.why = w;
+        M.state = Loaded::FAILED;
+      }
+    } else {
+      (void)L;
+      std::thread([src, key]() {
+        std::vector<char> image;
+        std::string w;
+        const bool ok = compile_source(src, &image, &w);
+        std::lock_guard<std::mutex> g2(registry_mu());
+        Loaded& M = registry()[key];
+        if (ok) {
+          M.image.swap(image);
+          M.state = Loaded::COMPILED;
+        } else {
+          M.why = w;
+          M.state = Loaded::FAILED;
+        }
+      }).detach();
+      *why = "being compiled";
+      return nullptr;
+    }
+    it = reg.find(key);
+  }
+  Loaded& L = it->second;
+  if (L.state == Loaded::COMPILING) {
+    if (!wait) {
+      *why = "being compiled";
+      return nullptr;
+    }
+    while (L.state == Loaded::COMPILING) { // (another thread's compile: wait for it)
+      lk.unlock();
+      std::this_thread::sleep_for(std::chrono::milliseconds(5));
+      lk.lock();
+    }
+  }
+  if (L.state == Loaded::COMPILED) load_module(L);
+  if (L.state == Loaded::READY) return (void*)L.fn;
+  *why = L.why.empty() ? "no specialised kernel" : L.why;
+  return nullptr;
 }
 
 void ntamd::host::seed_jit_release(const nthip_seeds* sd) { (void)sd; }

@@ -262,3 +262,39 @@ def test_seed_jit_specialised_kernel_vs_oracle(oracle, form, tmp_path):
                 os.environ.pop(k_, None)
         if form == "planned":   # (the other forms meet shapes the process has loaded already: nothing new on the disk)
             assert len(list(tmp_path.glob("psj_*.hsaco"))) >= 6
+
+
+def test_seed_jit_compiles_in_the_background(oracle, tmp_path):
+    """the default (NTHIP_SEED_JIT unset): the first batch of a seed set the specialised kernel would take starts its compile
+    on a thread of its own and is hashed by the precompiled kernels; some batch later the code object is there and the
+    specialised kernel takes over -- the stream is the oracle's before, while and after"""
+    import time
+    import nthash_amd
+    os.environ["NTHIP_JIT_CACHE"] = str(tmp_path)
+    os.environ.pop("NTHIP_SEED_JIT", None)
+    try:
+        c = nthash_amd.Context(0)
+        rng = np.random.default_rng(77)
+        seeds = []
+        for _ in range(6):   # six seeds of 31 x 1 hash: a shape the specialised kernel wins
+            half = rng.random(16) < 0.7
+            s = np.concatenate([half, half[:15][::-1]])
+            s[0] = s[-1] = True
+            seeds.append("".join("1" if b else "0" for b in s))
+        n, L, k = 20000, 250, 31
+        data = oracle.synth_reads(5, n, L, 11)
+        want = oracle.seed_batch(data, np.arange(n + 1, dtype=np.uint64) * L, seeds, k, 1, want_pos=False)["hashes"]
+        c.set_profiling(True)
+        names, t0 = [], time.time()
+        while time.time() - t0 < 120:
+            got = c.seed_hash(data, seeds, k, 1, fixed_len=L, n_reads=n)
+            names.append(c.last_kernel_ms()[1])
+            assert (got["hashes"] == want).all(), names[-1]
+            if names[-1] == "seed_psj_kernel":
+                break
+            time.sleep(0.2)
+        assert names[0] != "seed_psj_kernel" and names[-1] == "seed_psj_kernel", names
+        assert len(list(tmp_path.glob("psj_*.hsaco"))) == 1
+        c.close()
+    finally:
+        os.environ.pop("NTHIP_JIT_CACHE", None)

@@ -6,6 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+os.environ.setdefault("NTHIP_SEED_JIT", "1")  # steady state: compile on the spot (a job meets its kernel after the first batches)
 import nthash_amd
 
 L, k, spec, m2 = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
