@@ -238,6 +238,9 @@ struct nthip_seeds {
   mutable uint32_t px_plan_len = 0;
   mutable int px_plan_force = -2;
   // seed_ps_kernel.hpp: the same reads as byte offsets per step of a segment, on the device, for the last geometry asked for
+  // the specialised kernels this seed set has met, (len, m2, waves, device) -> hipFunction_t: the registry of capi_seed_jit.hip is
+  // keyed by the source TEXT, which a call should not have to write out again
+  mutable std::map<uint64_t, std::pair<void*, uint32_t>> psj_ready; // (+ the waves per block it was compiled for)
   mutable uint32_t* d_ps_off = nullptr;
   mutable uint64_t ps_key = 0;
   mutable ntamd::PxPlan ps_plan;

@@ -1084,7 +1084,12 @@ int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, 
       HIPCHK(hipSetDevice(c->device));
       if (j.waves > 12 && j.waves < 16) j.waves = 12; // (13-15 waves are four on one SIMD: 128 registers, as for 16)
       const bool wait = c->tune.seed_jit == 1;
-      hipFunction_t fn = (hipFunction_t)seed_psj_get(c, sd, j, wait, &why);
+      const int force_j = c->tune.seed_px_array ? (int)c->tune.seed_px_array : 0;
+      const uint64_t fn_key = ((uint64_t)f.len << 32) ^ ((uint64_t)f.m2 << 24) ^ ((uint64_t)c->device << 16) ^ ((uint64_t)force_j << 8) ^
+                              (c->tune.seed_ps_lanes | (c->tune.seed_px_waves << 4));
+      auto known = sd->psj_ready.find(fn_key);
+      if (known != sd->psj_ready.end()) j.waves = known->second.second;
+      hipFunction_t fn = known != sd->psj_ready.end() ? (hipFunction_t)known->second.first : (hipFunction_t)seed_psj_get(c, sd, j, wait, &why);
       // a kernel that spills at this block size gets the registers of a smaller one
       while (!fn && why.find("spills") != std::string::npos && j.waves > 4) {
         j.waves = j.waves > 12 ? 12 : j.waves > 8 ? 8 : 4;
@@ -1092,6 +1097,7 @@ int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, 
         fn = (hipFunction_t)seed_psj_get(c, sd, j, wait, &why);
       }
       if (fn) {
+        sd->psj_ready[fn_key] = {(void*)fn, j.waves};
         const uint32_t jw = j.waves, jrpw = 64u >> j.lpr_log; // (the specialised kernel's own tiles: its geometry counts the stage)
         const uint64_t n_tiles_j = (f.n_runs + jrpw - 1) / jrpw;
         int lds_static = 0;
