@@ -1052,13 +1052,14 @@ int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, 
     if (!jit_wanted) return NTHIP_OK;
     const double pos_per_win = (double)f.len / f.nwin, extra = per - f.n_seeds;
     // (the specialised kernel: a tile's fixed work, a seed's rotations, 0.11 per read of 16 bytes, the build per position, 1.5 per
-    //  further hash -- over the fraction of its window lanes that have a window)
+    //  further hash -- over the root of the fraction of its window lanes that have a window: idle lanes cost, but less than
+    //  their share)
     double fill = 1.0;
     {
       PsGeo gj;
       if (ps_geometry(c, sd, f.len, f.m2, true, &gj)) fill = (double)f.nwin / ((double)(1u << gj.lpr_log) * gj.W);
     }
-    double psj = (1.9 + 1.4 * f.n_seeds + 0.11 * n_terms + 0.25 * pos_per_win + 1.5 * extra) / fill;
+    double psj = (1.9 + 1.4 * f.n_seeds + 0.11 * n_terms + 0.25 * pos_per_win + 1.5 * extra) / sqrt(fill);
     const double hbm = (8.0 * per + pos_per_win) / 5.5; // (bytes per window at 5.5 TB/s)
     if (psj < hbm) psj = hbm;
     double direct;
@@ -1074,6 +1075,10 @@ int launch_seed_ps(nthip_ctx* c, const SeedFixedArgs& f, const nthip_seeds* sd, 
     for (const auto& care : sd->h_care)
       for (uint32_t p = 0; p < f.k; ++p) runs += care[p] && (p == 0 || !care[p - 1]);
     const double roll = per <= 8 && runs <= SR_MAX_RUNS ? f.n_seeds * (3.0 + 0.004 * f.k) + 0.27 * runs + 3.0 * extra : 1e9;
+    static const bool verbose = getenv("NTHIP_JIT_VERBOSE") != nullptr;
+    if (verbose)
+      fprintf(stderr, "nthash_amd: seed forms, ps per window: specialised %.2f (fill %.2f, %u reads), tables %.2f, roll %.2f (%u runs)\n", psj, fill,
+              n_terms, direct, roll, runs);
     if (psj >= 0.97 * (direct < roll ? direct : roll)) return NTHIP_OK;
   }
   const uint64_t n_tiles = (f.n_runs + rpw - 1) / rpw, need = (n_tiles + waves - 1) / waves;
