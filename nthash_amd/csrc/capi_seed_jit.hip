@@ -13,6 +13,7 @@
 
 #include <fstream>
 #include <mutex>
+#include <atomic>
 #include <thread>
 #include <sstream>
 
@@ -87,19 +88,30 @@ std::string cache_dir()
   return dir;
 }
 
-// source text -> code object for gfx950 (from the disk cache when the same text was compiled before)
-bool compile_source(const std::string& src, std::vector<char>* code, std::string* why)
+std::string cache_path(const std::string& src)
 {
   char tag[64];
   snprintf(tag, sizeof tag, "psj_%016llx_%zu.hsaco", (unsigned long long)fnv1a(src), src.size());
-  const std::string dir = cache_dir(), path = dir.empty() ? "" : dir + "/" + tag;
-  if (!path.empty()) {
-    std::ifstream in(path, std::ios::binary);
-    if (in) {
-      code->assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
-      if (code->size() > 64) return true;
-    }
-  }
+  const std::string dir = cache_dir();
+  return dir.empty() ? "" : dir + "/" + tag;
+}
+
+// the code object of a source text that was compiled before (the disk cache): milliseconds, on the caller's thread
+bool cached_code(const std::string& src, std::vector<char>* code)
+{
+  const std::string path = cache_path(src);
+  if (path.empty()) return false;
+  std::ifstream in(path, std::ios::binary);
+  if (!in) return false;
+  code->assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
+  return code->size() > 64;
+}
+
+// source text -> code object for gfx950 (from the disk cache when the same text was compiled before)
+bool compile_source(const std::string& src, std::vector<char>* code, std::string* why)
+{
+  if (cached_code(src, code)) return true;
+  const std::string path = cache_path(src);
   if (!rtc_ready()) {
     *why = "libhiprtc.so not found";
     return false;
@@ -186,6 +198,23 @@ struct Loaded {
 std::map<std::string, Loaded>& registry() { static auto* r = new std::map<std::string, Loaded>(); return *r; }
 std::mutex& registry_mu() { static auto* m = new std::mutex(); return *m; }
 
+// A process that ends while a compile thread is inside the compiler would pull the compiler's own statics from under it:
+// exit() waits for the compiles in flight (a second or two; bounded).  Registered AFTER libhiprtc.so is loaded, so it runs
+// BEFORE that library's destructors.
+std::atomic<int> g_compiles_in_flight{0};
+void wait_for_compiles()
+{
+  for (int i = 0; i < 6000 && g_compiles_in_flight.load() > 0; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+}
+void arm_exit_wait()
+{
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)rtc_ready();
+    atexit(wait_for_compiles);
+  });
+}
+
 // COMPILED -> READY / FAILED, on the caller's thread (its device is current)
 void load_module(Loaded& L)
 {
@@ -217,11 +246,14 @@ void* ntamd::host::seed_psj_get(nthip_ctx* c, const nthip_seeds* sd, const SeedJ
   auto it = reg.find(key);
   if (it == reg.end()) {
     Loaded& L = reg[key]; // (COMPILING)
-    if (wait) {
+    std::vector<char> known;
+    if (wait || cached_code(src, &known)) { // (a code object on the disk is read here and now, whatever `wait` says)
       lk.unlock();
       std::vector<char> image;
       std::string w;
-      const bool ok = compile_source(src, &image, &w);
+      bool ok = !known.empty();
+      if (ok) image.swap(known);
+      else ok = compile_source(src, &image, &w);
       lk.lock();
       Loaded& M = reg[key];
       if (ok) {
@@ -233,19 +265,24 @@ void* ntamd::host::seed_psj_get(nthip_ctx* c, const nthip_seeds* sd, const SeedJ
       }
     } else {
       (void)L;
+      arm_exit_wait();
+      g_compiles_in_flight.fetch_add(1);
       std::thread([src, key]() {
         std::vector<char> image;
         std::string w;
         const bool ok = compile_source(src, &image, &w);
-        std::lock_guard<std::mutex> g2(registry_mu());
-        Loaded& M = registry()[key];
-        if (ok) {
-          M.image.swap(image);
-          M.state = Loaded::COMPILED;
-        } else {
-          M.why = w;
-          M.state = Loaded::FAILED;
+        {
+          std::lock_guard<std::mutex> g2(registry_mu());
+          Loaded& M = registry()[key];
+          if (ok) {
+            M.image.swap(image);
+            M.state = Loaded::COMPILED;
+          } else {
+            M.why = w;
+            M.state = Loaded::FAILED;
+          }
         }
+        g_compiles_in_flight.fetch_sub(1);
       }).detach();
       *why = "being compiled";
       return nullptr;

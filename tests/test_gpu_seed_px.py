@@ -298,3 +298,44 @@ def test_seed_jit_compiles_in_the_background(oracle, tmp_path):
         c.close()
     finally:
         os.environ.pop("NTHIP_JIT_CACHE", None)
+
+
+_EXIT_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import nthash_amd
+c = nthash_amd.Context(0)
+seeds = {seeds!r}
+n, L, k = 20000, 250, 31
+data = np.frombuffer(np.random.default_rng(3).choice(np.frombuffer(b"ACGT", dtype=np.uint8), n * L).tobytes(), dtype=np.uint8)
+c.set_profiling(True)
+c.seed_hash(data, seeds, k, 1, fixed_len=L, n_reads=n)
+print("KERNEL", c.last_kernel_ms()[1])
+"""
+
+
+def test_seed_jit_process_that_ends_mid_compile_and_the_next_one(tmp_path):
+    """a process that ends while its compile thread is inside the compiler waits for it at exit (no crash, the code object on
+    the disk); the NEXT process finds the code object and hashes its FIRST batch with the specialised kernel"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(78)
+    seeds = []
+    for _ in range(6):
+        half = rng.random(16) < 0.7
+        s = np.concatenate([half, half[:15][::-1]])
+        s[0] = s[-1] = True
+        seeds.append("".join("1" if b else "0" for b in s))
+    env = dict(os.environ)
+    env["NTHIP_JIT_CACHE"] = str(tmp_path)
+    env.pop("NTHIP_SEED_JIT", None)
+    script = _EXIT_SCRIPT.format(root=root, seeds=seeds)
+    first = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert first.returncode == 0, first.stderr[-2000:]
+    assert "KERNEL" in first.stdout and "seed_psj_kernel" not in first.stdout, first.stdout
+    assert len(list(tmp_path.glob("psj_*.hsaco"))) == 1
+    second = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert second.returncode == 0, second.stderr[-2000:]
+    assert "KERNEL seed_psj_kernel" in second.stdout, second.stdout
