@@ -497,7 +497,10 @@ int bloom_slots_round(nthip_ctx* c, const BloomFusedSrc* fused, const uint64_t* 
 int bloom_pieces_round(nthip_ctx* c, const BloomFusedSrc* srcp, const uint64_t* stream, uint64_t n_stream, uint32_t* d_table, uint64_t n_slots,
                        bool counters, int* outcome, uint64_t* lost, uint32_t expand_m = 1, uint64_t kmul = 0)
 {
-  constexpr uint32_t S1_THREADS = 1024, S1_TILE = S1_THREADS * BB_PART_ITEMS;
+#ifndef BB_S1_THREADS
+#define BB_S1_THREADS 1024
+#endif
+  constexpr uint32_t S1_THREADS = BB_S1_THREADS, S1_TILE = S1_THREADS * BB_PART_ITEMS;
   const BloomFusedSrc src = srcp ? *srcp : BloomFusedSrc{};
   const uint32_t region_shift = counters ? CS_REGION_SHIFT : BB_REGION_SHIFT, bin_shift = region_shift + 7u;
   const uint32_t n_regions = (uint32_t)((n_slots + (1ull << region_shift) - 1) >> region_shift);
