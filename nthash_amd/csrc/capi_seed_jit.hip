@@ -82,8 +82,11 @@ std::string cache_dir()
   std::string dir;
   if (d) dir = d;
   else if (const char* x = getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/nthash_amd";
-  else if (const char* h = getenv("HOME")) dir = std::string(h) + "/.cache/nthash_amd";
-  else return "";
+  else if (const char* h = getenv("HOME")) {
+    dir = std::string(h) + "/.cache";
+    (void)mkdir(dir.c_str(), 0755); // (a fresh account has no ~/.cache yet)
+    dir += "/nthash_amd";
+  } else return "";
   (void)mkdir(dir.c_str(), 0755);
   return dir;
 }
