@@ -19,6 +19,7 @@ names = {  # scratch name -> tracked name
     "pmc_seed_rnd6.txt": f"{tag}_pmc_seed_rnd6_summary.txt",
     "pmc_seed_k128.txt": f"{tag}_pmc_seed_k128_summary.txt",
     "pmc_seed_static.txt": f"{tag}_pmc_seed_static_summary.txt",
+    "pmc_seed_insert.txt": f"{tag}_pmc_seed_insert_summary.txt",
     "pmc_ref/summary.txt": f"{tag}_pmc_ref_summary.txt",
     "pmc_k200/summary.txt": f"{tag}_pmc_k200_summary.txt",
     "seed_sweep.txt": f"{tag}_seed_sweep.txt",

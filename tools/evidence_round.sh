@@ -32,6 +32,7 @@ timeout 600 bash tools/pmc_any.sh "$OUT/pmc_seed_rnd6" psj python tools/px_probe
 timeout 600 bash tools/pmc_any.sh "$OUT/pmc_seed_k128" psj python tools/px_probe.py 250 128 rnd1 1 4000000 > "$OUT/pmc_seed_k128.txt" 2>&1
 NTHIP_SEED_JIT=0 timeout 600 bash tools/pmc_any.sh "$OUT/pmc_seed_static" seed_ps python tools/px_probe.py 250 128 3 1 4000000 > "$OUT/pmc_seed_static.txt" 2>&1
 PMC_SQ_ONLY=1 timeout 900 bash tools/run_pmc.sh "$OUT/pmc_ref" shape:100,64,3 20000000 > "$OUT/pmc_ref.log" 2>&1
+timeout 600 bash tools/pmc_any.sh "$OUT/pmc_seed_insert" bloom_ python tools/seed_insert_one.py > /dev/null 2>&1; python tools/pmc_levels_summary.py "$OUT/pmc_seed_insert" > "$OUT/pmc_seed_insert.txt" 2>&1
 PMC_SQ_ONLY=1 timeout 900 bash tools/run_pmc.sh "$OUT/pmc_k200" shape:250,200,1 10000000 > "$OUT/pmc_k200.log" 2>&1
 timeout 300 python tools/extend_bench.py > "$OUT/extend_bench.txt" 2>&1
 timeout 600 python tools/facade_bench.py > "$OUT/facade_bench.txt" 2>&1
