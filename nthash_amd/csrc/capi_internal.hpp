@@ -358,6 +358,8 @@ int bloom_query_binned(nthip_ctx* c, const nthip_reads* rd, uint32_t k, uint32_t
 //  expand_m + j], kmul = k * MULTISEED; two-level tables in pieces mode only, *done = false otherwise)
 int stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_values, const uint32_t* d_table, uint64_t n_slots, int kind,
                         uint8_t* d_ans, bool* done, uint32_t expand_m = 1, uint64_t kmul = 0);
+// (its tests that need only the shapes -- table kind 0 filter / 1 sketch, alignment, sizes: asked before the kept answers are taken)
+bool stream_query_applies(const nthip_ctx* c, const void* d_table, uint64_t n_slots, int kind, uint64_t n_values);
 // the answers of a stream's values, k-mer by k-mer (m consecutive values each): filter: flags[i] = all set, *found their number;
 // sketch: out[i] = the smallest.  hits per read (roff: first k-mer of every read): answers_hits_per_read.  Launches only.
 int answers_per_kmer(nthip_ctx* c, const uint8_t* d_ans, uint64_t n_kmers, uint32_t m, int kind, uint8_t* d_out, unsigned long long* d_found);

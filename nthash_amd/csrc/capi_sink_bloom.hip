@@ -882,6 +882,11 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
     HIPCHK(hipMalloc((void**)&d_hits, rd->n_reads * sizeof(uint64_t)));
     st.owned.push_back(d_hits);
   }
+  NaPlan plan;
+  const bool plan_ok = kmer_na_plan(c, len, stride, k, m, /*want_pos (the k-mer's read)*/ query, &plan);
+  // (a shape the direct kernels below do not take is refused BEFORE the binned query writes anything: it may stop early --
+  //  skewed values, memory -- and would leave the rest of the reads without a kernel, the hits half written)
+  if (query && !plan_ok) return fail(NTHIP_ERR_UNSUPPORTED, "shape outside the fused consumer kernels (k <= 64, m <= 8, stride >= windows)");
   if (query && !(flags & NTHIP_HOST_INPUT)) {
     NTCHK(bloom_query_binned(c, rd, k, m, d_filter, n_bits, BQ_BLOOM, d_hits, nullptr, &first, &q_kmers, &q_hits));
     if (first == rd->n_reads) {
@@ -895,9 +900,7 @@ int run_kmer_bloom(nthip_ctx* c, const nthip_reads* rd, uint16_t k16, uint8_t m8
   nthip_reads part = *rd;
   part.seqs = rd->seqs + first * stride;
   part.n_reads = rd->n_reads - first;
-  NaPlan plan;
-  if (!kmer_na_plan(c, len, stride, k, m, /*want_pos (the k-mer's read)*/ query, &plan))
-    return fail(NTHIP_ERR_UNSUPPORTED, "shape outside the fused consumer kernels (k <= 64, m <= 8, stride >= windows)");
+  if (!plan_ok) return fail(NTHIP_ERR_UNSUPPORTED, "shape outside the fused consumer kernels (k <= 64, m <= 8, stride >= windows)");
   uint64_t total_bytes = 0;
   NTCHK(reads_total_bytes(c, &part, flags, &total_bytes));
   NTCHK(stage_inputs(c, &part, flags, total_bytes, st));
@@ -1069,7 +1072,7 @@ extern "C" int nthip_stream_bloom_query(nthip_ctx* c, const uint64_t* d_hashes, 
     const uint64_t n_values = n_kmers * m;
     bool done = false;
     uint8_t* d_ans = d_flags;
-    if (m > 1 && (c->tune.bloom_query == 2 || (c->tune.bloom_query != 1 && n_values < (1ull << 24)) || kept_alloc(c, KEPT_ANSWERS, n_values + 8, (void**)&d_ans) != NTHIP_OK)) {
+    if (!stream_query_applies(c, d_filter, n_bits, 0, n_values) || (m > 1 && kept_alloc(c, KEPT_ANSWERS, n_values + 8, (void**)&d_ans) != NTHIP_OK)) {
       d_ans = nullptr;
     }
     if (d_ans) {
@@ -1207,7 +1210,7 @@ extern "C" int nthip_stream_count_query(nthip_ctx* c, const uint64_t* d_hashes, 
     const uint64_t n_values = n_kmers * m;
     bool done = false;
     uint8_t* d_ans = d_estimates;
-    if (m > 1 && (c->tune.bloom_query == 2 || (c->tune.bloom_query != 1 && n_values < (1ull << 24)) || kept_alloc(c, KEPT_ANSWERS, n_values + 8, (void**)&d_ans) != NTHIP_OK)) {
+    if (!stream_query_applies(c, d_counters, n_counters, 1, n_values) || (m > 1 && kept_alloc(c, KEPT_ANSWERS, n_values + 8, (void**)&d_ans) != NTHIP_OK)) {
       d_ans = nullptr;
     }
     if (d_ans) {

@@ -471,6 +471,18 @@ int ntamd::host::answers_hits_per_read(nthip_ctx* c, const uint8_t* d_ans, const
 #ifndef SQ_PIECES_THREADS
 #define SQ_PIECES_THREADS 1024 // pieces mode
 #endif
+// the tests of stream_query_binned that need nothing but the shapes: a caller asks BEFORE it takes the kept answers buffer (a
+// grow-only buffer of a byte per value has no business in a context whose batches the binned road then declines)
+bool ntamd::host::stream_query_applies(const nthip_ctx* c, const void* d_table, uint64_t n_slots, int kind, uint64_t n_values)
+{
+  if (c->tune.bloom_query == 2 || n_values == 0 || ((uintptr_t)d_table & 15u)) return false;
+  QueryGeo g;
+  if (!query_geo(n_slots, kind, &g)) return false;
+  if (c->lds_max < (size_t)BB_REGION_DWORDS * 4 + 1024) return false;
+  const uint64_t table_bytes = kind == BQ_BLOOM ? (n_slots + 7) / 8 : n_slots;
+  return c->tune.bloom_query == 1 || !(n_values < (1ull << 24) || table_bytes < (32ull << 20) || n_values < table_bytes / 32);
+}
+
 int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uint64_t n_in, const uint32_t* d_table, uint64_t n_slots, int kind,
                                      uint8_t* d_ans, bool* done, uint32_t M, uint64_t kmul)
 {
@@ -479,12 +491,9 @@ int ntamd::host::stream_query_binned(nthip_ctx* c, const uint64_t* d_hashes, uin
   *done = false;
   if (M < 1 || M > 4) return NTHIP_OK;
   const uint64_t n_values = n_in * M;
-  if (c->tune.bloom_query == 2 || n_values == 0 || ((uintptr_t)d_table & 15u)) return NTHIP_OK;
+  if (!stream_query_applies(c, d_table, n_slots, kind, n_values)) return NTHIP_OK;
   QueryGeo g;
   if (!query_geo(n_slots, kind, &g)) return NTHIP_OK;
-  if (c->lds_max < (size_t)BB_REGION_DWORDS * 4 + 1024) return NTHIP_OK;
-  const uint64_t table_bytes = kind == BQ_BLOOM ? (n_slots + 7) / 8 : n_slots;
-  if (c->tune.bloom_query != 1 && (n_values < (1ull << 24) || table_bytes < (32ull << 20) || n_values < table_bytes / 32)) return NTHIP_OK;
   {
     const uint8_t* const h0 = (const uint8_t*)d_hashes; // (the stream must not live in the buffer the lists are carved from)
     if (c->bloom_tmp && h0 < c->bloom_tmp + c->bloom_tmp_bytes && h0 + n_in * 8 > c->bloom_tmp) return NTHIP_OK;
@@ -717,7 +726,7 @@ int ntamd::host::stream_hits_per_read(nthip_ctx* c, const uint64_t* d_h, const u
   const uint64_t n_values = n_kmers * m;
   bool done = false;
   uint8_t* d_ans = nullptr;
-  if (c->tune.bloom_query != 2 && (c->tune.bloom_query == 1 || n_values >= (1ull << 24)) &&
+  if (stream_query_applies(c, d_filter, n_bits, BQ_BLOOM, n_values) &&
       kept_alloc(c, KEPT_ANSWERS, n_values + 8, (void**)&d_ans) != NTHIP_OK) // (+ 8: answers_per_read_kernel loads 8 bytes at a k-mer's first)
     d_ans = nullptr;
   if (d_ans) {
