@@ -339,3 +339,27 @@ def test_seed_jit_process_that_ends_mid_compile_and_the_next_one(tmp_path):
     second = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
     assert second.returncode == 0, second.stderr[-2000:]
     assert "KERNEL seed_psj_kernel" in second.stdout, second.stdout
+
+
+@pytest.mark.parametrize("cache", ["unwritable", "off"])
+def test_seed_jit_without_a_disk_cache(oracle, cache):
+    """a cache directory that cannot be made (or NTHIP_JIT_CACHE= : none wanted) costs the next process a compile, nothing else:
+    the specialised kernel is compiled, loaded and hashes the oracle's stream"""
+    import nthash_amd
+    os.environ["NTHIP_JIT_CACHE"] = "/proc/nthash_amd_no_such_dir/cache" if cache == "unwritable" else ""
+    os.environ["NTHIP_SEED_JIT"] = "1"
+    os.environ["NTHIP_TUNE_SEED_PS"] = "1"
+    try:
+        c = nthash_amd.Context(0)
+        seeds = [blocky(40, [(9, 6), (22, 9)] if cache == "unwritable" else [(5, 8), (19, 12)])]   # (shapes no other test compiles)
+        n, L, k = 3000, 173, 40
+        data = oracle.synth_reads(43, n, L, 9)
+        want = oracle.seed_batch(data, np.arange(n + 1, dtype=np.uint64) * L, seeds, k, 2, want_pos=False)
+        c.set_profiling(True)
+        got = c.seed_hash(data, seeds, k, 2, fixed_len=L, n_reads=n)
+        assert c.last_kernel_ms()[1] == "seed_psj_kernel"
+        assert (got["hashes"] == want["hashes"]).all()
+        c.close()
+    finally:
+        for k_ in ("NTHIP_JIT_CACHE", "NTHIP_SEED_JIT", "NTHIP_TUNE_SEED_PS"):
+            os.environ.pop(k_, None)
