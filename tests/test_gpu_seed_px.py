@@ -363,3 +363,58 @@ def test_seed_jit_without_a_disk_cache(oracle, cache):
     finally:
         for k_ in ("NTHIP_JIT_CACHE", "NTHIP_SEED_JIT", "NTHIP_TUNE_SEED_PS"):
             os.environ.pop(k_, None)
+
+
+def test_seed_jit_threads_and_contexts(oracle, tmp_path):
+    """four threads, a context each, two seed sets between them, background compiles (the default): the registry hands every
+    thread the same code object once it is there -- the streams are the oracle's before and after, in every thread"""
+    import threading
+    import time
+    import nthash_amd
+    os.environ["NTHIP_JIT_CACHE"] = str(tmp_path)
+    os.environ.pop("NTHIP_SEED_JIT", None)
+    rng = np.random.default_rng(79)
+    sets = []
+    for _ in range(2):
+        seeds = []
+        for _ in range(5):
+            half = rng.random(16) < 0.7
+            s = np.concatenate([half, half[:15][::-1]])
+            s[0] = s[-1] = True
+            seeds.append("".join("1" if b else "0" for b in s))
+        sets.append(seeds)
+    n, L, k = 20000, 250, 31
+    data = oracle.synth_reads(6, n, L, 12)
+    wants = [oracle.seed_batch(data, np.arange(n + 1, dtype=np.uint64) * L, s, k, 1, want_pos=False)["hashes"] for s in sets]
+    errors, finals = [], [None] * 4
+
+    def work(i):
+        try:
+            c = nthash_amd.Context(0)
+            c.set_profiling(True)
+            t0 = time.time()
+            while time.time() - t0 < 120:
+                got = c.seed_hash(data, sets[i % 2], k, 1, fixed_len=L, n_reads=n)
+                name = c.last_kernel_ms()[1]
+                if not (got["hashes"] == wants[i % 2]).all():
+                    errors.append((i, name))
+                    break
+                finals[i] = name
+                if name == "seed_psj_kernel":
+                    break
+                time.sleep(0.05)
+            c.close()
+        except Exception as e:  # noqa: BLE001 (reported below, in the test's thread)
+            errors.append((i, repr(e)))
+
+    try:
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert finals == ["seed_psj_kernel"] * 4, finals
+        assert len(list(tmp_path.glob("psj_*.hsaco"))) == 2
+    finally:
+        os.environ.pop("NTHIP_JIT_CACHE", None)
