@@ -418,3 +418,14 @@ def test_seed_jit_threads_and_contexts(oracle, tmp_path):
         assert len(list(tmp_path.glob("psj_*.hsaco"))) == 2
     finally:
         os.environ.pop("NTHIP_JIT_CACHE", None)
+
+
+def test_seed_jit_random_shapes():
+    """tools/stress_seed_jit.py: 60 clean fixed-length batches of random read length, k, seed sets and hashes per seed through the
+    specialised (or, where no code object can be made, the precompiled) segment kernel against the lane-per-read kernel"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_seed_jit.py"), "60", "17"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "0 mismatches" in r.stdout and "seed_psj_kernel" in r.stdout, r.stdout[-500:]
